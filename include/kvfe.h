@@ -1,0 +1,384 @@
+/*
+ * kvfe.h — C ABI of libkvfe: an MI355X-native (gfx950 / HIP) stereo visual
+ * front-end that drops in behind Kimera-VIO's
+ *   StereoVisionImuFrontend / FeatureDetector / Tracker / StereoMatcher /
+ *   UndistorterRectifier / StereoCamera
+ * C++ classes.  Kimera-VIO has no FFI layer of its own; the boundary is its
+ * concrete class API.  Every entry point below names the reference method it
+ * replaces (paths relative to the Kimera-VIO tree).  INTEGRATION.md shows the
+ * reference-side adapter a maintainer would add; include/kvfe_adapter.hpp is
+ * that adapter written against plain structs.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++/torch types; all functions return
+ *    kvfe_status (0 = ok, <0 = error), never throw, never abort.
+ *  - images: 8-bit gray, row-major, `stride` in bytes.
+ *  - keypoints: interleaved float32 (x, y) pairs == cv::Point2f.
+ *  - per-point status bytes use the values of VIO::KeypointStatus
+ *    (include/kimera-vio/common/vio_types.h:38-44).
+ *  - a kvfe_ctx is single-threaded (one HIP stream); distinct contexts are
+ *    independent and may live on different threads / GPUs.
+ */
+#ifndef KVFE_H_
+#define KVFE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVFE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* status / enums                                                            */
+/* ------------------------------------------------------------------------- */
+typedef int32_t kvfe_status;
+enum {
+  KVFE_OK = 0,
+  KVFE_ERR_INVALID_ARG = -1,   /* reference: CHECK_* abort                    */
+  KVFE_ERR_UNSUPPORTED = -2,   /* reference: LOG(FATAL) "not implemented"     */
+  KVFE_ERR_NO_DEVICE = -3,     /* no gfx950 device / HIP runtime error        */
+  KVFE_ERR_HIP = -4,
+  KVFE_ERR_CAPACITY = -5,      /* a device-side list overflowed its capacity  */
+  KVFE_ERR_NOT_READY = -6
+};
+
+/* VIO::KeypointStatus, include/kimera-vio/common/vio_types.h:38-44 */
+enum {
+  KVFE_KP_VALID = 0,
+  KVFE_KP_NO_LEFT_RECT = 1,
+  KVFE_KP_NO_RIGHT_RECT = 2,
+  KVFE_KP_NO_DEPTH = 3,
+  KVFE_KP_FAILED_ARUN = 4
+};
+
+/* VIO::AnmsAlgorithmType (feature-detector/NonMaximumSuppression.h) */
+enum {
+  KVFE_ANMS_TOPN = 0,
+  KVFE_ANMS_BROWN = 1,
+  KVFE_ANMS_SDC = 2,
+  KVFE_ANMS_KDTREE = 3,
+  KVFE_ANMS_RANGETREE = 4,
+  KVFE_ANMS_SSC = 5,
+  KVFE_ANMS_BINNING = 6
+};
+
+/* VIO::FeatureDetectorType */
+enum { KVFE_DET_FAST = 0, KVFE_DET_ORB = 1, KVFE_DET_AGAST = 2, KVFE_DET_GFTT = 3 };
+
+/* VIO::OpticalFlowPredictorType */
+enum { KVFE_FLOW_NO_PREDICTION = 0, KVFE_FLOW_ROTATIONAL = 1 };
+
+/* VIO::DistortionModel (only RADTAN and NONE are implemented on device) */
+enum { KVFE_DIST_NONE = 0, KVFE_DIST_RADTAN = 1, KVFE_DIST_EQUIDISTANT = 2 };
+
+/* how cv::sortIdx's all-equal-keys permutation is reproduced before ANMS
+ * (src/frontend/feature-detector/NonMaximumSuppression.cpp:50-60): the
+ * reference truncates the GFTT responses to int (all 0) and calls
+ * cv::sortIdx(DESCENDING) = std::sort with an always-false comparator followed
+ * by a reversal.  LIBSTDCXX reproduces libstdc++'s introsort permutation
+ * (what the reference binary really does); STABLE keeps quality order. */
+enum { KVFE_SORTIDX_LIBSTDCXX = 0, KVFE_SORTIDX_STABLE = 1 };
+
+#define KVFE_MAX_BINS 256
+#define KVFE_MAX_DIST_COEFFS 8
+
+/* ------------------------------------------------------------------------- */
+/* parameter structs (PODs mirroring the reference's param classes)          */
+/* ------------------------------------------------------------------------- */
+
+/* VIO::CameraParams (include/kimera-vio/frontend/CameraParams.h) */
+typedef struct kvfe_camera_params {
+  int32_t width, height;                     /* image_size_                  */
+  double intrinsics[4];                      /* fu, fv, cu, cv               */
+  int32_t distortion_model;                  /* KVFE_DIST_*                  */
+  int32_t n_distortion;                      /* >= 4 for radtan              */
+  double distortion[KVFE_MAX_DIST_COEFFS];   /* k1 k2 p1 p2 [k3 k4 k5 k6]    */
+  double body_pose_cam[16];                  /* T_BS, row-major 4x4          */
+} kvfe_camera_params;
+
+/* VIO::FeatureDetectorParams + SubPixelCornerFinderParams
+ * (include/kimera-vio/frontend/feature-detector/FeatureDetectorParams.h:25-106) */
+typedef struct kvfe_detector_params {
+  int32_t feature_detector_type;             /* only KVFE_DET_GFTT           */
+  int32_t max_features_per_frame;            /* maxFeaturesPerFrame          */
+  int32_t enable_subpixel_corner_refinement;
+  int32_t subpix_window_size;                /* window_size (half window)    */
+  int32_t subpix_zero_zone;                  /* zero_zone                    */
+  int32_t subpix_max_iters;                  /* max_iters                    */
+  double subpix_epsilon;                     /* epsilon_error                */
+  int32_t enable_non_max_suppression;
+  int32_t non_max_suppression_type;          /* KVFE_ANMS_*                  */
+  int32_t min_distance;                      /* min_distance (GFTT + mask r) */
+  int32_t max_nr_keypoints_before_anms;
+  int32_t nr_horizontal_bins, nr_vertical_bins;
+  uint8_t binning_mask[KVFE_MAX_BINS];       /* row-major [vbin][hbin], 0/1  */
+  double quality_level;
+  int32_t block_size;
+  int32_t use_harris_detector;
+  double k;
+  int32_t sortidx_policy;                    /* KVFE_SORTIDX_*               */
+  int32_t reserved0;
+} kvfe_detector_params;
+
+/* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85);
+ * RANSAC members are carried for completeness but geometric outlier rejection
+ * is outside this library. */
+typedef struct kvfe_tracker_params {
+  int32_t klt_win_size;
+  int32_t klt_max_iter;
+  int32_t klt_max_level;
+  int32_t max_feature_track_age;             /* maxFeatureAge                */
+  double klt_eps;
+  int32_t optical_flow_predictor_type;       /* KVFE_FLOW_*                  */
+  int32_t reserved0;
+  double disparity_threshold;                /* disparityThreshold           */
+} kvfe_tracker_params;
+
+/* VIO::StereoMatchingParams (include/kimera-vio/frontend/StereoMatchingParams.h:24-60) */
+typedef struct kvfe_stereo_params {
+  double tolerance_template_matching;
+  int32_t templ_cols, templ_rows, stripe_extra_rows;
+  int32_t subpixel_refinement;
+  double min_point_dist, max_point_dist;
+} kvfe_stereo_params;
+
+/* VIO::FrontendParams (include/kimera-vio/frontend/VisionImuFrontendParams.h:25-76) */
+typedef struct kvfe_frontend_params {
+  kvfe_detector_params detector;
+  kvfe_tracker_params tracker;
+  kvfe_stereo_params stereo;
+  double min_intra_keyframe_time_ns;
+  double max_intra_keyframe_time_ns;
+  int64_t min_number_features;
+  double max_disparity_since_lkf;
+  int32_t use_stereo_tracking;
+  int32_t use_ransac;                        /* must be 0 (f1 is "next")     */
+} kvfe_frontend_params;
+
+typedef struct kvfe_config {
+  kvfe_camera_params left, right;
+  kvfe_frontend_params params;
+  int32_t batch;                 /* number of independent stereo streams     */
+  int32_t device;                /* HIP device ordinal                       */
+  void* hip_stream;              /* optional hipStream_t owned by the caller */
+  int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
+  int32_t reserved0;
+} kvfe_config;
+
+typedef struct kvfe_ctx kvfe_ctx;
+
+/* rectification constants computed at creation
+ * (StereoCamera::computeRectificationParameters, src/frontend/StereoCamera.cpp:292-379) */
+typedef struct kvfe_rectification {
+  double R1[9], R2[9], P1[12], P2[12], Q[16];
+  int32_t roi1[4], roi2[4];
+  double baseline;               /* 1 / Q(3,2), StereoCamera.cpp:70-72       */
+} kvfe_rectification;
+
+/* ------------------------------------------------------------------------- */
+/* lifecycle                                                                 */
+/* ------------------------------------------------------------------------- */
+KVFE_API const char* kvfe_version(void);
+KVFE_API const char* kvfe_status_string(kvfe_status s);
+KVFE_API const char* kvfe_last_error(const kvfe_ctx* ctx);
+
+/* fills *p with the class defaults of FeatureDetectorParams / TrackerParams /
+ * StereoMatchingParams / FrontendParams (header defaults, not the YAML ones). */
+KVFE_API void kvfe_default_frontend_params(kvfe_frontend_params* p);
+
+/* StereoCamera::StereoCamera + UndistorterRectifier ctor x2 + FeatureDetector
+ * ctor + Tracker ctor (src/frontend/StereoCamera.cpp:34-94,
+ * UndistorterRectifier.cpp:26-31, FeatureDetector.cpp:18-89, Tracker.cpp:54-86).
+ * Fails with KVFE_ERR_NO_DEVICE when no gfx950 device is usable: there is no
+ * CPU fallback. */
+KVFE_API kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out);
+KVFE_API void kvfe_destroy(kvfe_ctx* ctx);
+
+/* host-only part of creation (no device needed): stereoRectify + maps.
+ * Used by the CPU-side tests of the host logic. */
+KVFE_API kvfe_status kvfe_compute_rectification(const kvfe_camera_params* left,
+                                                const kvfe_camera_params* right,
+                                                kvfe_rectification* out);
+/* UndistorterRectifier::initUndistortRectifyMaps (UndistorterRectifier.cpp:230-292).
+ * cam: 0 = left, 1 = right; map_x/map_y: width*height float32 each. */
+KVFE_API kvfe_status kvfe_compute_undistort_rectify_maps(
+    const kvfe_camera_params* cam, const double R[9], const double P[12],
+    float* map_x, float* map_y);
+
+KVFE_API kvfe_status kvfe_get_rectification(const kvfe_ctx* ctx,
+                                            kvfe_rectification* out);
+
+/* ------------------------------------------------------------------------- */
+/* component level: host buffers in, host buffers out (one stream)           */
+/* ------------------------------------------------------------------------- */
+
+/* UndistorterRectifier::undistortRectifyImage (UndistorterRectifier.cpp:115-128)
+ * == cv::remap(INTER_LINEAR, BORDER_REPLICATE).  cam: 0 left, 1 right. */
+KVFE_API kvfe_status kvfe_undistort_rectify_image(kvfe_ctx* ctx, int32_t cam,
+                                                  const uint8_t* src, size_t src_stride,
+                                                  uint8_t* dst, size_t dst_stride);
+
+/* UndistorterRectifier::UndistortRectifyKeypoints (UndistorterRectifier.cpp:33-68)
+ * == cv::undistortPoints(K, D, R?, P?) of camera `cam`.
+ * use_R/use_P select the rectifier's own R/P (R1,P1 or R2,P2). */
+KVFE_API kvfe_status kvfe_undistort_rectify_keypoints(kvfe_ctx* ctx, int32_t cam,
+                                                      const float* xy, int32_t n,
+                                                      int32_t use_R, int32_t use_P,
+                                                      float* out_xy);
+
+/* UndistorterRectifier::GetBearingVector (UndistorterRectifier.cpp:73-113),
+ * batched: out_versors is n x 3 float64, unit norm. */
+KVFE_API kvfe_status kvfe_get_bearing_vectors(kvfe_ctx* ctx, int32_t cam,
+                                              const float* xy, int32_t n,
+                                              double* out_versors);
+
+/* FeatureDetector::rawFeatureDetection (FeatureDetector.cpp:165-172)
+ * == cv::GFTTDetector::detect(img, kps, mask); mask may be NULL (all 255).
+ * Returns integer-valued corners in quality-descending order. */
+KVFE_API kvfe_status kvfe_raw_feature_detection(kvfe_ctx* ctx,
+                                                const uint8_t* img, size_t stride,
+                                                const uint8_t* mask, size_t mask_stride,
+                                                float* out_xy, int32_t capacity,
+                                                int32_t* out_n);
+
+/* private FeatureDetector::featureDetection(const Frame&, need_n_corners)
+ * (FeatureDetector.cpp:174-299): mask discs around the tracked keypoints,
+ * GFTT, ANMS, cornerSubPix.  tracked_xy: keypoints with landmark != -1. */
+KVFE_API kvfe_status kvfe_feature_detection(kvfe_ctx* ctx,
+                                            const uint8_t* img, size_t stride,
+                                            const float* tracked_xy, int32_t n_tracked,
+                                            int32_t need_n_corners,
+                                            float* out_xy, int32_t capacity,
+                                            int32_t* out_n);
+
+/* cv::cornerSubPix as called at FeatureDetector.cpp:288-292 /
+ * StereoMatcher.cpp:404-413; xy is refined in place. */
+KVFE_API kvfe_status kvfe_corner_subpix(kvfe_ctx* ctx,
+                                        const uint8_t* img, size_t stride,
+                                        float* xy, int32_t n,
+                                        int32_t half_win, int32_t zero_zone,
+                                        int32_t max_iters, double eps);
+
+/* cv::calcOpticalFlowPyrLK as called at Tracker.cpp:137-146
+ * (OPTFLOW_USE_INITIAL_FLOW, minEigThreshold 1e-4); cur_xy holds the initial
+ * guess on entry and the tracked positions on return. */
+KVFE_API kvfe_status kvfe_calc_optical_flow_pyr_lk(kvfe_ctx* ctx,
+                                                   const uint8_t* prev_img,
+                                                   const uint8_t* cur_img, size_t stride,
+                                                   const float* prev_xy, float* cur_xy,
+                                                   int32_t n, uint8_t* status,
+                                                   float* err);
+
+/* OpticalFlowPredictor::predictSparseFlow
+ * (optical-flow/OpticalFlowPredictor.cpp:27-33,70-126); ref_R_cur row-major. */
+KVFE_API kvfe_status kvfe_predict_sparse_flow(kvfe_ctx* ctx, const float* prev_xy,
+                                              int32_t n, const double ref_R_cur[9],
+                                              float* out_xy);
+
+/* StereoMatcher::getRightKeypointsRectified (StereoMatcher.cpp:196-281):
+ * rectified images in, integer right matches out; score = min_val after
+ * cv::normalize (always 0 for found matches, -1 for rejected placement). */
+KVFE_API kvfe_status kvfe_get_right_keypoints_rectified(
+    kvfe_ctx* ctx, const uint8_t* left_rect, const uint8_t* right_rect, size_t stride,
+    const float* left_rect_xy, const uint8_t* left_status, int32_t n,
+    float* right_rect_xy, uint8_t* right_status, double* score);
+
+/* StereoMatcher::sparseStereoReconstruction(StereoFrame*)
+ * (StereoMatcher.cpp:123-175) for one stereo pair given the raw images and the
+ * left keypoints.  All outputs have length n; any may be NULL. */
+typedef struct kvfe_stereo_output {
+  float* left_rect_xy;        /* left_keypoints_rectified_ (.second)          */
+  uint8_t* left_status;       /* left_keypoints_rectified_ (.first)           */
+  float* right_rect_xy;       /* right_keypoints_rectified_ (.second)         */
+  uint8_t* right_status;      /* right_keypoints_rectified_ (.first)          */
+  double* depth;              /* keypoints_depth_                             */
+  float* right_xy;            /* right_frame_.keypoints_ (distorted px)       */
+  double* keypoints_3d;       /* keypoints_3d_, n x 3                         */
+  uint8_t* left_rect_img;     /* optional W*H rectified left image            */
+  uint8_t* right_rect_img;    /* optional W*H rectified right image           */
+} kvfe_stereo_output;
+
+KVFE_API kvfe_status kvfe_sparse_stereo_reconstruction(
+    kvfe_ctx* ctx, const uint8_t* left_img, const uint8_t* right_img, size_t stride,
+    const float* left_xy, int32_t n, kvfe_stereo_output* out);
+
+/* ------------------------------------------------------------------------- */
+/* front-end level: `batch` independent streams, lock-step, device resident  */
+/* ------------------------------------------------------------------------- */
+
+/* per-stream, per-frame input: what StereoVisionImuFrontend::nominalSpinStereo
+ * hands to processStereoFrame (StereoVisionImuFrontend.cpp:102-240). */
+typedef struct kvfe_frame_input {
+  int64_t timestamp_ns;
+  double keyframe_R_cur_frame[9];   /* camLrectLkf_R_camLrectK_imu, row-major */
+  int32_t force_keyframe;           /* Frame::isKeyframe_ set by the user     */
+  int32_t reserved0;
+} kvfe_frame_input;
+
+/* StereoVisionImuFrontend::processFirstStereoFrame / processStereoFrame for
+ * all streams of the context (StereoVisionImuFrontend.cpp:245-481) with
+ * useRANSAC = 0.  left/right: `batch` images back to back (image s at
+ * base + s*image_stride_bytes).  The *_host variant copies from host memory;
+ * the *_device variant takes device pointers that must stay valid until the
+ * next step of this context has completed.  Both only enqueue work. */
+KVFE_API kvfe_status kvfe_frontend_step_host(kvfe_ctx* ctx, const uint8_t* left,
+                                             const uint8_t* right, size_t row_stride,
+                                             size_t image_stride,
+                                             const kvfe_frame_input* inputs);
+KVFE_API kvfe_status kvfe_frontend_step_device(kvfe_ctx* ctx, const void* left_dev,
+                                               const void* right_dev, size_t row_stride,
+                                               size_t image_stride,
+                                               const kvfe_frame_input* inputs);
+KVFE_API kvfe_status kvfe_frontend_reset(kvfe_ctx* ctx);
+KVFE_API kvfe_status kvfe_synchronize(kvfe_ctx* ctx);
+
+/* StereoFrontendOutput (StereoVisionImuFrontend-definitions.h:25-91) reduced to
+ * the arrays the hot path produces.  Caller allocates `capacity` entries per
+ * array (NULL arrays are skipped); synchronises the context. */
+typedef struct kvfe_frame_output {
+  int32_t capacity;
+  int32_t n_keypoints;          /* left_frame_.keypoints_.size()             */
+  int32_t is_keyframe;
+  int32_t n_tracked;            /* keypoints carried over by featureTracking */
+  int32_t n_detected;           /* keypoints appended by featureDetection    */
+  int32_t n_measurements;       /* getSmartStereoMeasurements entries        */
+  int64_t frame_id;
+  int64_t* landmarks;           /* left_frame_.landmarks_                    */
+  int32_t* landmarks_age;
+  float* keypoints;             /* left_frame_.keypoints_                    */
+  double* versors;              /* left_frame_.versors_, n x 3               */
+  float* left_rect_xy;
+  uint8_t* left_status;
+  float* right_rect_xy;
+  uint8_t* right_status;
+  double* depth;
+  float* right_xy;
+  double* keypoints_3d;
+  int64_t* meas_landmark;       /* StereoMeasurement.first                   */
+  double* meas_uL_uR_v;         /* StereoPoint2 (uL, uR or NaN, v), n x 3    */
+} kvfe_frame_output;
+
+KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,
+                                              kvfe_frame_output* out);
+
+/* ------------------------------------------------------------------------- */
+/* measurement hooks (bench.py): HIP-event timing on the context's stream    */
+/* ------------------------------------------------------------------------- */
+#define KVFE_N_STAGES 16
+typedef struct kvfe_stage_times {
+  int32_t n_stages;
+  int32_t n_samples;
+  const char* name[KVFE_N_STAGES];
+  double ms_total[KVFE_N_STAGES];      /* summed over samples                 */
+  double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch        */
+} kvfe_stage_times;
+KVFE_API kvfe_status kvfe_profile_enable(kvfe_ctx* ctx, int32_t on);
+KVFE_API kvfe_status kvfe_profile_read(kvfe_ctx* ctx, kvfe_stage_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVFE_H_ */

@@ -1,0 +1,145 @@
+"""ctypes mirror of include/kvfe.h (POD structs + enums).  Keep in lock-step with the header."""
+import ctypes as C
+
+KVFE_MAX_BINS = 256
+KVFE_MAX_DIST_COEFFS = 8
+KVFE_N_STAGES = 16
+
+# status
+KVFE_OK = 0
+KVFE_ERR_INVALID_ARG = -1
+KVFE_ERR_UNSUPPORTED = -2
+KVFE_ERR_NO_DEVICE = -3
+KVFE_ERR_HIP = -4
+KVFE_ERR_CAPACITY = -5
+KVFE_ERR_NOT_READY = -6
+
+# VIO::KeypointStatus
+KP_VALID, KP_NO_LEFT_RECT, KP_NO_RIGHT_RECT, KP_NO_DEPTH, KP_FAILED_ARUN = range(5)
+# VIO::AnmsAlgorithmType
+ANMS_TOPN, ANMS_BROWN, ANMS_SDC, ANMS_KDTREE, ANMS_RANGETREE, ANMS_SSC, ANMS_BINNING = range(7)
+DET_FAST, DET_ORB, DET_AGAST, DET_GFTT = range(4)
+FLOW_NO_PREDICTION, FLOW_ROTATIONAL = range(2)
+DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = range(3)
+SORTIDX_LIBSTDCXX, SORTIDX_STABLE = range(2)
+
+
+class CameraParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("intrinsics", C.c_double * 4),
+        ("distortion_model", C.c_int32), ("n_distortion", C.c_int32),
+        ("distortion", C.c_double * KVFE_MAX_DIST_COEFFS),
+        ("body_pose_cam", C.c_double * 16),
+    ]
+
+
+class DetectorParams(C.Structure):
+    _fields_ = [
+        ("feature_detector_type", C.c_int32),
+        ("max_features_per_frame", C.c_int32),
+        ("enable_subpixel_corner_refinement", C.c_int32),
+        ("subpix_window_size", C.c_int32),
+        ("subpix_zero_zone", C.c_int32),
+        ("subpix_max_iters", C.c_int32),
+        ("subpix_epsilon", C.c_double),
+        ("enable_non_max_suppression", C.c_int32),
+        ("non_max_suppression_type", C.c_int32),
+        ("min_distance", C.c_int32),
+        ("max_nr_keypoints_before_anms", C.c_int32),
+        ("nr_horizontal_bins", C.c_int32), ("nr_vertical_bins", C.c_int32),
+        ("binning_mask", C.c_uint8 * KVFE_MAX_BINS),
+        ("quality_level", C.c_double),
+        ("block_size", C.c_int32),
+        ("use_harris_detector", C.c_int32),
+        ("k", C.c_double),
+        ("sortidx_policy", C.c_int32),
+        ("reserved0", C.c_int32),
+    ]
+
+
+class TrackerParams(C.Structure):
+    _fields_ = [
+        ("klt_win_size", C.c_int32), ("klt_max_iter", C.c_int32),
+        ("klt_max_level", C.c_int32), ("max_feature_track_age", C.c_int32),
+        ("klt_eps", C.c_double),
+        ("optical_flow_predictor_type", C.c_int32), ("reserved0", C.c_int32),
+        ("disparity_threshold", C.c_double),
+    ]
+
+
+class StereoParams(C.Structure):
+    _fields_ = [
+        ("tolerance_template_matching", C.c_double),
+        ("templ_cols", C.c_int32), ("templ_rows", C.c_int32),
+        ("stripe_extra_rows", C.c_int32), ("subpixel_refinement", C.c_int32),
+        ("min_point_dist", C.c_double), ("max_point_dist", C.c_double),
+    ]
+
+
+class FrontendParams(C.Structure):
+    _fields_ = [
+        ("detector", DetectorParams), ("tracker", TrackerParams), ("stereo", StereoParams),
+        ("min_intra_keyframe_time_ns", C.c_double),
+        ("max_intra_keyframe_time_ns", C.c_double),
+        ("min_number_features", C.c_int64),
+        ("max_disparity_since_lkf", C.c_double),
+        ("use_stereo_tracking", C.c_int32), ("use_ransac", C.c_int32),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("left", CameraParams), ("right", CameraParams), ("params", FrontendParams),
+        ("batch", C.c_int32), ("device", C.c_int32),
+        ("hip_stream", C.c_void_p),
+        ("candidate_capacity", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class Rectification(C.Structure):
+    _fields_ = [
+        ("R1", C.c_double * 9), ("R2", C.c_double * 9),
+        ("P1", C.c_double * 12), ("P2", C.c_double * 12), ("Q", C.c_double * 16),
+        ("roi1", C.c_int32 * 4), ("roi2", C.c_int32 * 4),
+        ("baseline", C.c_double),
+    ]
+
+
+class StereoOutput(C.Structure):
+    _fields_ = [
+        ("left_rect_xy", C.c_void_p), ("left_status", C.c_void_p),
+        ("right_rect_xy", C.c_void_p), ("right_status", C.c_void_p),
+        ("depth", C.c_void_p), ("right_xy", C.c_void_p), ("keypoints_3d", C.c_void_p),
+        ("left_rect_img", C.c_void_p), ("right_rect_img", C.c_void_p),
+    ]
+
+
+class FrameInput(C.Structure):
+    _fields_ = [
+        ("timestamp_ns", C.c_int64),
+        ("keyframe_R_cur_frame", C.c_double * 9),
+        ("force_keyframe", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class FrameOutput(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int32), ("n_keypoints", C.c_int32), ("is_keyframe", C.c_int32),
+        ("n_tracked", C.c_int32), ("n_detected", C.c_int32), ("n_measurements", C.c_int32),
+        ("frame_id", C.c_int64),
+        ("landmarks", C.c_void_p), ("landmarks_age", C.c_void_p), ("keypoints", C.c_void_p),
+        ("versors", C.c_void_p), ("left_rect_xy", C.c_void_p), ("left_status", C.c_void_p),
+        ("right_rect_xy", C.c_void_p), ("right_status", C.c_void_p), ("depth", C.c_void_p),
+        ("right_xy", C.c_void_p), ("keypoints_3d", C.c_void_p),
+        ("meas_landmark", C.c_void_p), ("meas_uL_uR_v", C.c_void_p),
+    ]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [
+        ("n_stages", C.c_int32), ("n_samples", C.c_int32),
+        ("name", C.c_char_p * KVFE_N_STAGES),
+        ("ms_total", C.c_double * KVFE_N_STAGES),
+        ("alg_bytes", C.c_double * KVFE_N_STAGES),
+    ]

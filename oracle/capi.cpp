@@ -1,0 +1,303 @@
+// TEST INFRASTRUCTURE — C entry points of the CPU oracle for ctypes
+// (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).  Never linked into
+// or called from the product library.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "kimera.hpp"
+#include "ocv.hpp"
+
+using kimera::StatusKeypoint;
+using ocv::Point2f;
+
+#define KVO_API extern "C" __attribute__((visibility("default")))
+
+KVO_API const char* kvo_version() { return "kvfe-oracle 0.1 (OpenCV-4.2 restatement; test infrastructure)"; }
+
+namespace ocv { extern int g_stereo_rectify_variant; }
+KVO_API void kvo_set_stereo_rectify_variant(int v) { ocv::g_stereo_rectify_variant = v; }
+
+// ---- calib ---------------------------------------------------------------
+KVO_API int kvo_compute_rectification(const kvfe_camera_params* l, const kvfe_camera_params* r,
+                                      kvfe_rectification* out) {
+  kimera::StereoCamera cam;
+  cam.init(*l, *r);
+  *out = cam.rect;
+  return 0;
+}
+
+struct kvo_camera {
+  kimera::StereoCamera cam;
+};
+
+KVO_API kvo_camera* kvo_camera_create(const kvfe_camera_params* l, const kvfe_camera_params* r) {
+  kvo_camera* c = new kvo_camera;
+  c->cam.init(*l, *r);
+  return c;
+}
+KVO_API void kvo_camera_destroy(kvo_camera* c) { delete c; }
+KVO_API void kvo_camera_get_rectification(const kvo_camera* c, kvfe_rectification* out) {
+  *out = c->cam.rect;
+}
+KVO_API void kvo_camera_get_maps(const kvo_camera* c, int cam, float* mx, float* my) {
+  std::memcpy(mx, c->cam.map_x[cam].data(), c->cam.map_x[cam].size() * sizeof(float));
+  std::memcpy(my, c->cam.map_y[cam].data(), c->cam.map_y[cam].size() * sizeof(float));
+}
+KVO_API void kvo_camera_rectify_image(const kvo_camera* c, int cam, const uint8_t* src,
+                                      size_t stride, uint8_t* dst) {
+  c->cam.undistortRectifyImage(cam, src, stride, dst);
+}
+KVO_API void kvo_camera_undistort_keypoints(const kvo_camera* c, int cam, const float* xy, int n,
+                                            int useR, int useP, float* out) {
+  c->cam.undistortRectifyKeypoints(cam, (const Point2f*)xy, n, useR != 0, useP != 0,
+                                   (Point2f*)out);
+}
+KVO_API void kvo_camera_bearing_vectors(const kvo_camera* c, int cam, const float* xy, int n,
+                                        double* out) {
+  for (int i = 0; i < n; i++) c->cam.getBearingVector(cam, Point2f{xy[2 * i], xy[2 * i + 1]}, out + 3 * i);
+}
+KVO_API void kvo_camera_undistort_rectify_left(const kvo_camera* c, const float* xy, int n,
+                                               float* out_xy, uint8_t* out_status) {
+  std::vector<Point2f> kps((const Point2f*)xy, (const Point2f*)xy + n);
+  std::vector<StatusKeypoint> out;
+  c->cam.undistortRectifyLeftKeypoints(kps, out);
+  for (int i = 0; i < n; i++) {
+    out_xy[2 * i] = out[i].kp.x;
+    out_xy[2 * i + 1] = out[i].kp.y;
+    out_status[i] = out[i].status;
+  }
+}
+
+// ---- imgproc ---------------------------------------------------------------
+KVO_API void kvo_remap(const uint8_t* src, int w, int h, size_t stride, const float* mx,
+                       const float* my, uint8_t* dst) {
+  ocv::remap_linear_replicate(src, w, h, stride, dst, w, h, w, mx, my);
+}
+KVO_API void kvo_corner_min_eigen_val(const uint8_t* img, int w, int h, size_t stride, int block,
+                                      float* eig) {
+  ocv::cornerMinEigenVal(img, w, h, stride, block, eig);
+}
+KVO_API int kvo_good_features_to_track(const uint8_t* img, int w, int h, size_t stride,
+                                       const uint8_t* mask, size_t mask_stride, int maxCorners,
+                                       double quality, double minDist, int block, float* out_xy,
+                                       float* out_quality, int capacity) {
+  std::vector<Point2f> c;
+  std::vector<float> q;
+  ocv::goodFeaturesToTrack(img, w, h, stride, mask, mask_stride, maxCorners, quality, minDist,
+                           block, c, &q);
+  int n = std::min((int)c.size(), capacity);
+  for (int i = 0; i < n; i++) {
+    out_xy[2 * i] = c[i].x;
+    out_xy[2 * i + 1] = c[i].y;
+    if (out_quality) out_quality[i] = q[i];
+  }
+  return (int)c.size();
+}
+KVO_API void kvo_draw_detection_mask(int w, int h, const float* xy, int n, int radius,
+                                     uint8_t* mask) {
+  std::memset(mask, 255, (size_t)w * h);
+  for (int i = 0; i < n; i++)
+    ocv::circle_filled(mask, w, h, w, ocv::cvRoundf(xy[2 * i]), ocv::cvRoundf(xy[2 * i + 1]), radius, 0);
+}
+KVO_API void kvo_corner_subpix(const uint8_t* img, int w, int h, size_t stride, float* xy, int n,
+                               int win, int zero_zone, int max_iters, double eps) {
+  ocv::cornerSubPix(img, w, h, stride, (Point2f*)xy, n, win, zero_zone, max_iters, eps);
+}
+KVO_API void kvo_pyr_down(const uint8_t* src, int w, int h, size_t stride, uint8_t* dst) {
+  ocv::pyrDown(src, w, h, stride, dst, (w + 1) / 2, (h + 1) / 2, (w + 1) / 2);
+}
+KVO_API int kvo_calc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h,
+                                         size_t stride, const float* prev_xy, float* next_xy,
+                                         int n, uint8_t* status, float* err, int win,
+                                         int maxLevel, int maxIter, double eps,
+                                         int use_initial_flow, double minEigThreshold) {
+  return ocv::calcOpticalFlowPyrLK(prev, next, w, h, stride, (const Point2f*)prev_xy,
+                                   (Point2f*)next_xy, n, status, err, win, maxLevel, maxIter, eps,
+                                   use_initial_flow != 0, minEigThreshold);
+}
+
+// ---- reference-owned logic ---------------------------------------------------
+KVO_API void kvo_sortidx_permutation(int n, int policy, int* idx) {
+  std::vector<int> v;
+  kimera::sortidx_descending_equal_keys(n, policy, v);
+  std::memcpy(idx, v.data(), sizeof(int) * n);
+}
+// what the reference binary does: std::sort with an always-false comparator + reverse
+KVO_API void kvo_sortidx_permutation_stdsort(int n, int* idx) {
+  std::vector<int> keys(n, 0);
+  for (int i = 0; i < n; i++) idx[i] = i;
+  const int* k = keys.data();
+  std::sort(idx, idx + n, [k](int a, int b) { return k[a] < k[b]; });
+  for (int j = 0; j < n / 2; j++) std::swap(idx[j], idx[n - 1 - j]);
+}
+
+KVO_API int kvo_suppress_non_max(const float* xy, int n, int numRet, int cols, int rows,
+                                 const kvfe_detector_params* p, float* out_xy, int capacity) {
+  std::vector<Point2f> in((const Point2f*)xy, (const Point2f*)xy + n), out;
+  if (!kimera::suppressNonMax(in, numRet, cols, rows, *p, out)) return -2;
+  int m = std::min((int)out.size(), capacity);
+  std::memcpy(out_xy, out.data(), sizeof(Point2f) * m);
+  return (int)out.size();
+}
+
+KVO_API int kvo_feature_detection(const uint8_t* img, int w, int h, size_t stride,
+                                  const float* tracked_xy, int n_tracked, int need,
+                                  const kvfe_detector_params* p, float* out_xy, int capacity,
+                                  float* raw_xy, int raw_capacity, int* raw_n) {
+  std::vector<Point2f> tracked((const Point2f*)tracked_xy, (const Point2f*)tracked_xy + n_tracked);
+  std::vector<Point2f> corners, raw;
+  if (!kimera::featureDetection(img, w, h, stride, tracked, need, *p, corners, &raw)) return -2;
+  int m = std::min((int)corners.size(), capacity);
+  std::memcpy(out_xy, corners.data(), sizeof(Point2f) * m);
+  if (raw_xy) {
+    int r = std::min((int)raw.size(), raw_capacity);
+    std::memcpy(raw_xy, raw.data(), sizeof(Point2f) * r);
+  }
+  if (raw_n) *raw_n = (int)raw.size();
+  return (int)corners.size();
+}
+
+KVO_API void kvo_predict_sparse_flow(int type, const kvfe_camera_params* cam, const float* prev,
+                                     int n, const double* R, float* next) {
+  double K[9];
+  kimera::camera_matrix(*cam, K);
+  kimera::predictSparseFlow(type, K, cam->width, cam->height, (const Point2f*)prev, n, R,
+                            (Point2f*)next);
+}
+
+KVO_API void kvo_get_right_keypoints_rectified(const uint8_t* left_rect, const uint8_t* right_rect,
+                                               int w, int h, size_t stride, const float* left_xy,
+                                               const uint8_t* left_status, int n, double fx,
+                                               double baseline, const kvfe_stereo_params* p,
+                                               float* right_xy, uint8_t* right_status,
+                                               double* score) {
+  std::vector<StatusKeypoint> left(n), right;
+  for (int i = 0; i < n; i++) left[i] = {left_status[i], {left_xy[2 * i], left_xy[2 * i + 1]}};
+  std::vector<double> sc;
+  kimera::getRightKeypointsRectified(left_rect, right_rect, w, h, stride, left, fx, baseline, *p,
+                                     right, &sc);
+  for (int i = 0; i < n; i++) {
+    right_xy[2 * i] = right[i].kp.x;
+    right_xy[2 * i + 1] = right[i].kp.y;
+    right_status[i] = right[i].status;
+    if (score) score[i] = sc[i];
+  }
+}
+
+KVO_API void kvo_sparse_stereo_reconstruction(const kvo_camera* c, const kvfe_stereo_params* p,
+                                              const uint8_t* left, const uint8_t* right,
+                                              size_t stride, const float* left_xy, int n,
+                                              kvfe_stereo_output* out) {
+  const int w = c->cam.w, h = c->cam.h;
+  kimera::StereoFrame sf;
+  sf.left.w = w;
+  sf.left.h = h;
+  sf.left.img.resize((size_t)w * h);
+  sf.right_img.resize((size_t)w * h);
+  for (int y = 0; y < h; y++) {
+    std::memcpy(&sf.left.img[(size_t)y * w], left + y * stride, w);
+    std::memcpy(&sf.right_img[(size_t)y * w], right + y * stride, w);
+  }
+  sf.left.keypoints.assign((const Point2f*)left_xy, (const Point2f*)left_xy + n);
+  sf.left.versors.resize((size_t)n * 3);
+  for (int i = 0; i < n; i++) c->cam.getBearingVector(0, sf.left.keypoints[i], &sf.left.versors[3 * i]);
+  kimera::sparseStereoReconstruction(c->cam, *p, sf);
+  for (int i = 0; i < n; i++) {
+    if (out->left_rect_xy) {
+      out->left_rect_xy[2 * i] = sf.left_kp_rect[i].kp.x;
+      out->left_rect_xy[2 * i + 1] = sf.left_kp_rect[i].kp.y;
+    }
+    if (out->left_status) out->left_status[i] = sf.left_kp_rect[i].status;
+    if (out->right_rect_xy) {
+      out->right_rect_xy[2 * i] = sf.right_kp_rect[i].kp.x;
+      out->right_rect_xy[2 * i + 1] = sf.right_kp_rect[i].kp.y;
+    }
+    if (out->right_status) out->right_status[i] = sf.right_kp_rect[i].status;
+    if (out->depth) out->depth[i] = sf.depth[i];
+    if (out->right_xy) {
+      out->right_xy[2 * i] = sf.right_kp[i].x;
+      out->right_xy[2 * i + 1] = sf.right_kp[i].y;
+    }
+    if (out->keypoints_3d)
+      for (int k = 0; k < 3; k++) out->keypoints_3d[3 * i + k] = sf.kp3d[3 * i + k];
+  }
+  if (out->left_rect_img) std::memcpy(out->left_rect_img, sf.left_rect.data(), (size_t)w * h);
+  if (out->right_rect_img) std::memcpy(out->right_rect_img, sf.right_rect.data(), (size_t)w * h);
+}
+
+// ---- front-end ---------------------------------------------------------------
+struct kvo_frontend {
+  kimera::Frontend fe;
+};
+KVO_API kvo_frontend* kvo_frontend_create(const kvfe_camera_params* l, const kvfe_camera_params* r,
+                                          const kvfe_frontend_params* p) {
+  kvo_frontend* f = new kvo_frontend;
+  f->fe.init(*l, *r, *p);
+  return f;
+}
+KVO_API void kvo_frontend_destroy(kvo_frontend* f) { delete f; }
+KVO_API void kvo_frontend_process(kvo_frontend* f, const uint8_t* left, const uint8_t* right,
+                                  size_t stride, const kvfe_frame_input* in) {
+  f->fe.process(left, right, stride, *in);
+}
+KVO_API int kvo_frontend_get_output(kvo_frontend* f, kvfe_frame_output* out) {
+  const kimera::StereoFrame& sf = f->fe.current();
+  const int n = (int)sf.left.keypoints.size();
+  out->n_keypoints = n;
+  out->is_keyframe = f->fe.last_is_keyframe ? 1 : 0;
+  out->n_tracked = sf.n_tracked;
+  out->n_detected = sf.n_detected;
+  out->n_measurements = (int)f->fe.meas_lmk.size();
+  out->frame_id = sf.left.id;
+  const int m = std::min(n, out->capacity);
+  const bool has_stereo = (int)sf.left_kp_rect.size() == n;
+  for (int i = 0; i < m; i++) {
+    if (out->landmarks) out->landmarks[i] = sf.left.landmarks[i];
+    if (out->landmarks_age) out->landmarks_age[i] = sf.left.landmarks_age[i];
+    if (out->keypoints) {
+      out->keypoints[2 * i] = sf.left.keypoints[i].x;
+      out->keypoints[2 * i + 1] = sf.left.keypoints[i].y;
+    }
+    if (out->versors)
+      for (int k = 0; k < 3; k++) out->versors[3 * i + k] = sf.left.versors[3 * i + k];
+    if (!has_stereo) continue;
+    if (out->left_rect_xy) {
+      out->left_rect_xy[2 * i] = sf.left_kp_rect[i].kp.x;
+      out->left_rect_xy[2 * i + 1] = sf.left_kp_rect[i].kp.y;
+    }
+    if (out->left_status) out->left_status[i] = sf.left_kp_rect[i].status;
+    if (out->right_rect_xy) {
+      out->right_rect_xy[2 * i] = sf.right_kp_rect[i].kp.x;
+      out->right_rect_xy[2 * i + 1] = sf.right_kp_rect[i].kp.y;
+    }
+    if (out->right_status) out->right_status[i] = sf.right_kp_rect[i].status;
+    if (out->depth) out->depth[i] = sf.depth[i];
+    if (out->right_xy) {
+      out->right_xy[2 * i] = sf.right_kp[i].x;
+      out->right_xy[2 * i + 1] = sf.right_kp[i].y;
+    }
+    if (out->keypoints_3d)
+      for (int k = 0; k < 3; k++) out->keypoints_3d[3 * i + k] = sf.kp3d[3 * i + k];
+  }
+  const int mm = std::min(out->n_measurements, out->capacity);
+  for (int i = 0; i < mm; i++) {
+    if (out->meas_landmark) out->meas_landmark[i] = f->fe.meas_lmk[i];
+    if (out->meas_uL_uR_v)
+      for (int k = 0; k < 3; k++) out->meas_uL_uR_v[3 * i + k] = f->fe.meas_uLuRv[3 * i + k];
+  }
+  return has_stereo ? 1 : 0;
+}
+
+// Timed replay for bench.py's cpu_baseline leg: runs `n_frames` stereo pairs of
+// one stream through the oracle front-end and returns the elapsed seconds.
+KVO_API double kvo_frontend_time_sequence(kvo_frontend* f, const uint8_t* left,
+                                          const uint8_t* right, int w, int h, int n_frames,
+                                          const kvfe_frame_input* inputs) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_frames; i++)
+    f->fe.process(left + (size_t)i * w * h, right + (size_t)i * w * h, w, inputs[i]);
+  auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(t1 - t0).count();
+}

@@ -1,0 +1,769 @@
+// TEST INFRASTRUCTURE — see kimera.hpp.  Restatement of the reference-owned
+// front-end logic; file:line citations are relative to /root/reference.
+#include "kimera.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+
+namespace kimera {
+
+void camera_matrix(const kvfe_camera_params& c, double K[9]) {
+  // CameraParams::convertIntrinsicsVectorToMatrix (src/frontend/CameraParams.cpp)
+  const double k[9] = {c.intrinsics[0], 0, c.intrinsics[2], 0, c.intrinsics[1],
+                       c.intrinsics[3], 0, 0, 1};
+  std::memcpy(K, k, sizeof(k));
+}
+
+static void mat3_mul(const double A[9], const double B[9], double C[9]) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j];
+      t[i * 3 + j] = s;
+    }
+  std::memcpy(C, t, sizeof(t));
+}
+
+// --------------------------------------------------------------------------
+// StereoCamera::StereoCamera / computeRectificationParameters
+// (src/frontend/StereoCamera.cpp:34-94,292-379)
+// --------------------------------------------------------------------------
+void StereoCamera::init(const kvfe_camera_params& l, const kvfe_camera_params& r) {
+  left = l;
+  right = r;
+  w = l.width;
+  h = l.height;
+  camera_matrix(l, K1);
+  camera_matrix(r, K2);
+  // camL_Pose_camR = body_Pose_camL.between(body_Pose_camR)  (StereoCamera.cpp:311-312)
+  const double* TL = l.body_pose_cam;
+  const double* TR = r.body_pose_cam;
+  double RL[9], RR[9], tL[3], tR[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      RL[i * 3 + j] = TL[i * 4 + j];
+      RR[i * 3 + j] = TR[i * 4 + j];
+    }
+    tL[i] = TL[i * 4 + 3];
+    tR[i] = TR[i * 4 + 3];
+  }
+  double RLt[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RLt[i * 3 + j] = RL[j * 3 + i];
+  double Rrel[9], trel[3], d[3] = {tR[0] - tL[0], tR[1] - tL[1], tR[2] - tL[2]};
+  mat3_mul(RLt, RR, Rrel);
+  for (int i = 0; i < 3; i++) trel[i] = RLt[i * 3] * d[0] + RLt[i * 3 + 1] * d[1] + RLt[i * 3 + 2] * d[2];
+  // OpenCV convention is the inverse pose (StereoCamera.cpp:314-319)
+  double Rinv[9], tinv[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Rinv[i * 3 + j] = Rrel[j * 3 + i];
+  for (int i = 0; i < 3; i++)
+    tinv[i] = -(Rinv[i * 3] * trel[0] + Rinv[i * 3 + 1] * trel[1] + Rinv[i * 3 + 2] * trel[2]);
+
+  ocv::stereoRectify(K1, l.distortion, l.n_distortion, K2, r.distortion, r.n_distortion, w, h,
+                     Rinv, tinv, /*alpha=*/0, /*zero_disparity=*/true, rect.R1, rect.R2, rect.P1,
+                     rect.P2, rect.Q, rect.roi1, rect.roi2);
+  rect.baseline = 1.0 / rect.Q[3 * 4 + 2];  // StereoCamera.cpp:70-72
+  for (int c = 0; c < 2; c++) {
+    map_x[c].resize((size_t)w * h);
+    map_y[c].resize((size_t)w * h);
+    const kvfe_camera_params& cp = c == 0 ? l : r;
+    ocv::initUndistortRectifyMap(c == 0 ? K1 : K2, cp.distortion, cp.n_distortion,
+                                 c == 0 ? rect.R1 : rect.R2, c == 0 ? rect.P1 : rect.P2, w, h,
+                                 map_x[c].data(), map_y[c].data());
+  }
+}
+
+void StereoCamera::undistortRectifyImage(int cam, const uint8_t* src, size_t stride,
+                                         uint8_t* dst) const {
+  ocv::remap_linear_replicate(src, w, h, stride, dst, w, h, w, map_x[cam].data(),
+                              map_y[cam].data());
+}
+
+void StereoCamera::undistortRectifyKeypoints(int cam, const Point2f* in, int n, bool useR,
+                                             bool useP, Point2f* out) const {
+  const kvfe_camera_params& cp = cam == 0 ? left : right;
+  ocv::undistortPoints(in, out, n, cam == 0 ? K1 : K2, cp.distortion, cp.n_distortion,
+                       useR ? (cam == 0 ? rect.R1 : rect.R2) : nullptr,
+                       useP ? (cam == 0 ? rect.P1 : rect.P2) : nullptr);
+}
+
+void StereoCamera::getBearingVector(int cam, Point2f kp, double versor[3]) const {
+  Point2f u;
+  undistortRectifyKeypoints(cam, &kp, 1, true, false, &u);
+  double x = u.x, y = u.y, z = 1.0;
+  double n = std::sqrt(x * x + (y * y + z * z));  // Eigen Vector3d::normalized()
+  versor[0] = x / n;
+  versor[1] = y / n;
+  versor[2] = z / n;
+}
+
+static bool cropToSize(Point2f* px, int w, int h) {  // UtilsOpenCV.cpp:215-235
+  bool cropped = false;
+  float max_width = (float)(w - 1);
+  if (px->x > max_width) {
+    px->x = max_width;
+    cropped = true;
+  } else if (px->x < 0.0f) {
+    px->x = 0.0f;
+    cropped = true;
+  }
+  float max_height = (float)(h - 1);
+  if (px->y > max_height) {
+    px->y = max_height;
+    cropped = true;
+  } else if (px->y < 0.0f) {
+    px->y = 0.0f;
+    cropped = true;
+  }
+  return cropped;
+}
+
+void StereoCamera::undistortRectifyLeftKeypoints(const std::vector<Point2f>& kps,
+                                                 std::vector<StatusKeypoint>& out) const {
+  std::vector<Point2f> und(kps.size());
+  undistortRectifyKeypoints(0, kps.data(), (int)kps.size(), true, true, und.data());
+  out.clear();
+  out.reserve(kps.size());
+  const float pixel_tol = 2.0f;
+  for (size_t i = 0; i < und.size(); i++) {
+    Point2f distorted_kp = kps[i];
+    Point2f undistorted_kp = und[i];
+    bool cropped = cropToSize(&undistorted_kp, w, h);
+    int ry = (int)std::round(undistorted_kp.y), rx = (int)std::round(undistorted_kp.x);
+    float ex = map_x[0][(size_t)ry * w + rx];
+    float ey = map_y[0][(size_t)ry * w + rx];
+    if (cropped) {
+      out.push_back({KVFE_KP_NO_LEFT_RECT, undistorted_kp});
+    } else if (std::fabs(distorted_kp.x - ex) > pixel_tol ||
+               std::fabs(distorted_kp.y - ey) > pixel_tol) {
+      out.push_back({KVFE_KP_NO_LEFT_RECT, undistorted_kp});
+    } else {
+      out.push_back({KVFE_KP_VALID, undistorted_kp});
+    }
+  }
+}
+
+void StereoCamera::distortUnrectifyRightKeypoints(const std::vector<StatusKeypoint>& rectk,
+                                                  std::vector<Point2f>& out) const {
+  out.clear();
+  out.reserve(rectk.size());
+  for (const StatusKeypoint& sk : rectk) {
+    if (sk.status == KVFE_KP_VALID) {
+      int ry = (int)std::round(sk.kp.y), rx = (int)std::round(sk.kp.x);
+      out.push_back({map_x[1][(size_t)ry * w + rx], map_y[1][(size_t)ry * w + rx]});
+    } else {
+      out.push_back({0.0f, 0.0f});
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// cv::sortIdx on all-equal keys (NonMaximumSuppression.cpp:50-60)
+// libstdc++ std::sort = introsort(threshold 16, median-of-3 moved to first,
+// unguarded partition) + final insertion sort; comparator is always false.
+// --------------------------------------------------------------------------
+static void introsort_loop_equal(int* first, int* last) {
+  while (last - first > 16) {
+    int* mid = first + (last - first) / 2;
+    // __move_median_to_first(first, first+1, mid, last-1): all comparisons false
+    std::swap(*first, *mid);
+    // __unguarded_partition(first+1, last, pivot=first)
+    int* lo = first + 1;
+    int* hi = last;
+    for (;;) {
+      --hi;
+      if (!(lo < hi)) break;
+      std::swap(*lo, *hi);
+      ++lo;
+    }
+    int* cut = lo;
+    introsort_loop_equal(cut, last);
+    last = cut;
+  }
+}
+
+void sortidx_descending_equal_keys(int n, int policy, std::vector<int>& idx) {
+  idx.resize(n);
+  for (int i = 0; i < n; i++) idx[i] = i;
+  if (policy == KVFE_SORTIDX_STABLE || n == 0) return;
+  introsort_loop_equal(idx.data(), idx.data() + n);  // final insertion sort: no-op
+  for (int j = 0; j < n / 2; j++) std::swap(idx[j], idx[n - 1 - j]);  // SORT_DESCENDING
+}
+
+// --------------------------------------------------------------------------
+// ANMS (NonMaximumSuppression.cpp:33-169, anms/anms.cpp:37-49)
+// --------------------------------------------------------------------------
+bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int cols, int rows,
+                    const kvfe_detector_params& p, std::vector<Point2f>& out) {
+  out.clear();
+  if (keyPoints.empty()) return true;  // "No keypoints for non-max suppression..."
+  std::vector<int> Indx;
+  sortidx_descending_equal_keys((int)keyPoints.size(), p.sortidx_policy, Indx);
+  std::vector<Point2f> keyPointsSorted(keyPoints.size());
+  for (size_t i = 0; i < keyPoints.size(); i++) keyPointsSorted[i] = keyPoints[Indx[i]];
+
+  switch (p.non_max_suppression_type) {
+    case KVFE_ANMS_TOPN: {  // anms::TopN on the UNSORTED keypoints (NonMaximumSuppression.cpp:67)
+      if ((size_t)numRetPoints > keyPoints.size()) {
+        out = keyPoints;
+        return true;
+      }
+      for (int i = 0; i < numRetPoints; i++) out.push_back(keyPoints[i]);
+      return true;
+    }
+    case KVFE_ANMS_BINNING: {  // NonMaximumSuppression.cpp:125-169
+      if ((size_t)numRetPoints > keyPointsSorted.size()) {
+        out = keyPointsSorted;
+        return true;
+      }
+      const int hb = p.nr_horizontal_bins, vb = p.nr_vertical_bins;
+      float binRowSize = float(rows) / float(vb);
+      float binColSize = float(cols) / float(hb);
+      double masksum = 0;
+      for (int i = 0; i < hb * vb; i++) masksum += p.binning_mask[i];
+      float nrActiveBins = (float)masksum;
+      const int numRetPointsPerBin = (int)std::round(float(numRetPoints) / float(nrActiveBins));
+      std::vector<double> nrKptsInBin((size_t)hb * vb, 0.0);
+      for (size_t i = 0; i < keyPointsSorted.size(); i++) {
+        const size_t binRowInd = (size_t)(keyPointsSorted[i].y / binRowSize);
+        const size_t binColInd = (size_t)(keyPointsSorted[i].x / binColSize);
+        if (binRowInd >= (size_t)vb || binColInd >= (size_t)hb) continue;  // (Eigen OOB in ref)
+        if (p.binning_mask[binRowInd * hb + binColInd] == 1 &&
+            nrKptsInBin[binRowInd * hb + binColInd] < numRetPointsPerBin) {
+          out.push_back(keyPointsSorted[i]);
+          nrKptsInBin[binRowInd * hb + binColInd] += 1;
+        }
+      }
+      return true;
+    }
+    case KVFE_ANMS_RANGETREE: {  // anms::RangeTree (anms/anms.cpp:254-335), tolerance 0.1
+      const std::vector<Point2f>& kp = keyPointsSorted;
+      const float tolerance = 0.1f;
+      int exp1 = rows + cols + 2 * numRetPoints;
+      long long exp2 = ((long long)4 * cols + (long long)4 * numRetPoints +
+                        (long long)4 * rows * numRetPoints + (long long)rows * rows +
+                        (long long)cols * cols - (long long)2 * rows * cols +
+                        (long long)4 * rows * cols * numRetPoints);
+      double exp3 = std::sqrt((double)exp2);
+      double exp4 = numRetPoints - 1;
+      double sol1 = -std::round((exp1 + exp3) / exp4);
+      double sol2 = -std::round((exp1 - exp3) / exp4);
+      int high = (int)((sol1 > sol2) ? sol1 : sol2);
+      int low = (int)std::floor(std::sqrt((double)kp.size() / numRetPoints));
+      // rangetree<u16,u16>: coordinates truncated to u16, inclusive square query
+      std::vector<uint16_t> px(kp.size()), py(kp.size());
+      for (size_t i = 0; i < kp.size(); i++) {
+        px[i] = (uint16_t)kp[i].x;
+        py[i] = (uint16_t)kp[i].y;
+      }
+      bool complete = false;
+      unsigned int K = numRetPoints;
+      unsigned int Kmin = (unsigned int)std::round(K - (K * tolerance));
+      unsigned int Kmax = (unsigned int)std::round(K + (K * tolerance));
+      std::vector<int> ResultVec, result;
+      int width, prevwidth = -1;
+      while (!complete) {
+        std::vector<bool> Included(kp.size(), true);
+        width = low + (high - low) / 2;
+        if (width == prevwidth || low > high) {
+          ResultVec = result;
+          break;
+        }
+        result.clear();
+        for (unsigned int i = 0; i < kp.size(); ++i) {
+          if (Included[i]) {
+            Included[i] = false;
+            result.push_back(i);
+            int minx = (int)(kp[i].x - width), maxx = (int)(kp[i].x + width);
+            int miny = (int)(kp[i].y - width), maxy = (int)(kp[i].y + width);
+            if (minx < 0) minx = 0;
+            if (miny < 0) miny = 0;
+            uint16_t x0 = (uint16_t)minx, x1 = (uint16_t)maxx, y0 = (uint16_t)miny, y1 = (uint16_t)maxy;
+            if (x1 < x0) std::swap(x0, x1);
+            if (y1 < y0) std::swap(y0, y1);
+            for (size_t j = 0; j < kp.size(); j++)
+              if (Included[j] && px[j] >= x0 && px[j] <= x1 && py[j] >= y0 && py[j] <= y1)
+                Included[j] = false;
+          }
+        }
+        if (result.size() >= Kmin && result.size() <= Kmax) {
+          ResultVec = result;
+          complete = true;
+        } else if (result.size() < Kmin)
+          high = width - 1;
+        else
+          low = width + 1;
+        prevwidth = width;
+      }
+      for (int r : ResultVec) out.push_back(kp[r]);
+      return true;
+    }
+    default:
+      return false;
+  }
+}
+
+// --------------------------------------------------------------------------
+// FeatureDetector::featureDetection(const Frame&, need) (FeatureDetector.cpp:174-299)
+// --------------------------------------------------------------------------
+bool featureDetection(const uint8_t* img, int w, int h, size_t stride,
+                      const std::vector<Point2f>& tracked, int need_n_corners,
+                      const kvfe_detector_params& p, std::vector<Point2f>& new_corners,
+                      std::vector<Point2f>* raw_gftt) {
+  std::vector<uint8_t> mask((size_t)w * h, 255);
+  for (const Point2f& kp : tracked)
+    ocv::circle_filled(mask.data(), w, h, w, ocv::cvRoundf(kp.x), ocv::cvRoundf(kp.y),
+                       p.min_distance, 0);
+  std::vector<Point2f> keypoints;
+  ocv::goodFeaturesToTrack(img, w, h, stride, mask.data(), w, p.max_nr_keypoints_before_anms,
+                           p.quality_level, (double)p.min_distance, p.block_size, keypoints);
+  if (raw_gftt) *raw_gftt = keypoints;
+  std::vector<Point2f> max_keypoints = keypoints;
+  if (p.enable_non_max_suppression) {
+    if (!suppressNonMax(keypoints, need_n_corners, w, h, p, max_keypoints)) return false;
+  }
+  new_corners = max_keypoints;
+  if (!new_corners.empty() && p.enable_subpixel_corner_refinement) {
+    ocv::cornerSubPix(img, w, h, stride, new_corners.data(), (int)new_corners.size(),
+                      p.subpix_window_size, p.subpix_zero_zone, p.subpix_max_iters,
+                      p.subpix_epsilon);
+  }
+  return true;
+}
+
+// --------------------------------------------------------------------------
+// OpticalFlowPredictor (optical-flow/OpticalFlowPredictor.cpp:27-33,70-126)
+// --------------------------------------------------------------------------
+static double quaternion_w(const double m[9]) {  // Eigen::Quaterniond(Matrix3d).w()
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    return 0.5 * t;
+  }
+  int i = 0;
+  if (m[4] > m[0]) i = 1;
+  if (m[8] > m[i * 4]) i = 2;
+  int j = (i + 1) % 3, k = (j + 1) % 3;
+  t = std::sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
+  t = 0.5 / t;
+  return (m[k * 3 + j] - m[j * 3 + k]) * t;
+}
+
+static void matx33f_mul(const float a[9], const float b[9], float c[9]) {
+  float t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float s = 0;
+      for (int k = 0; k < 3; k++) s += a[i * 3 + k] * b[k * 3 + j];
+      t[i * 3 + j] = s;
+    }
+  std::memcpy(c, t, sizeof(t));
+}
+
+static void matx33f_inv(const float a[9], float b[9]) {  // Matx_FastInvOp<float,3,3>
+  auto A = [&](int r, int c) { return a[r * 3 + c]; };
+  float d = A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) -
+            A(0, 1) * (A(1, 0) * A(2, 2) - A(2, 0) * A(1, 2)) +
+            A(0, 2) * (A(1, 0) * A(2, 1) - A(2, 0) * A(1, 1));
+  d = 1 / d;
+  b[0] = (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) * d;
+  b[1] = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) * d;
+  b[2] = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) * d;
+  b[3] = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) * d;
+  b[4] = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) * d;
+  b[5] = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) * d;
+  b[6] = (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0)) * d;
+  b[7] = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) * d;
+  b[8] = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) * d;
+}
+
+void predictSparseFlow(int type, const double K[9], int w, int h, const Point2f* prev, int n,
+                       const double R_in[9], Point2f* next) {
+  if (type == KVFE_FLOW_NO_PREDICTION) {
+    for (int i = 0; i < n; i++) next[i] = prev[i];
+    return;
+  }
+  static constexpr double kSmallRotationTol = 1e-4;
+  if (std::abs(1.0 - std::abs(quaternion_w(R_in))) < kSmallRotationTol) {
+    for (int i = 0; i < n; i++) next[i] = prev[i];
+    return;
+  }
+  float Kf[9], Kinv[9], Rt[9], KR[9], H[9];
+  for (int i = 0; i < 9; i++) Kf[i] = (float)K[i];
+  matx33f_inv(Kf, Kinv);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Rt[i * 3 + j] = (float)R_in[j * 3 + i];
+  matx33f_mul(Kf, Rt, KR);
+  matx33f_mul(KR, Kinv, H);
+  for (int i = 0; i < n; i++) {
+    const Point2f prev_kpt = prev[i];
+    const float p1[3] = {prev_kpt.x, prev_kpt.y, 1.0f};
+    float p2[3];
+    for (int r = 0; r < 3; r++) {
+      float s = 0;
+      for (int k = 0; k < 3; k++) s += H[r * 3 + k] * p1[k];
+      p2[r] = s;
+    }
+    Point2f new_kpt;
+    if (p2[2] > 0.0f)
+      new_kpt = {p2[0] / p2[2], p2[1] / p2[2]};
+    else
+      new_kpt = prev_kpt;
+    // cv::Rect2f(0,0,w,h).contains(new_kpt)
+    if (0.0f <= new_kpt.x && new_kpt.x < (float)w && 0.0f <= new_kpt.y && new_kpt.y < (float)h)
+      next[i] = new_kpt;
+    else
+      next[i] = prev_kpt;
+  }
+}
+
+// --------------------------------------------------------------------------
+// StereoMatcher (StereoMatcher.cpp:196-483)
+// --------------------------------------------------------------------------
+static void searchRightKeypointEpipolar(const uint8_t* left_rect, Point2f left_kp,
+                                        const uint8_t* right_rect, int w, int h, size_t stride,
+                                        int stripe_cols, int stripe_rows,
+                                        const kvfe_stereo_params& p, StatusKeypoint* out,
+                                        double* score) {
+  int rounded_x = (int)std::round(left_kp.x);
+  int rounded_y = (int)std::round(left_kp.y);
+  int temp_corner_y = rounded_y - (p.templ_rows - 1) / 2;
+  if (temp_corner_y < 0 || temp_corner_y + p.templ_rows > h - 1) {
+    *score = -1.0;
+    *out = {KVFE_KP_NO_RIGHT_RECT, {0.0f, 0.0f}};
+    return;
+  }
+  int offset_temp = 0;
+  int temp_corner_x = rounded_x - (p.templ_cols - 1) / 2;
+  if (temp_corner_x < 0) {
+    offset_temp = temp_corner_x;
+    temp_corner_x = 0;
+  }
+  if (temp_corner_x + p.templ_cols > w - 1) {
+    offset_temp = (temp_corner_x + p.templ_cols) - (w - 1);
+    temp_corner_x -= offset_temp;
+  }
+  int stripe_corner_y = rounded_y - (stripe_rows - 1) / 2;
+  if (stripe_corner_y < 0 || stripe_corner_y + stripe_rows > h - 1) {
+    *score = -1.0;
+    *out = {KVFE_KP_NO_RIGHT_RECT, {0.0f, 0.0f}};
+    return;
+  }
+  int offset_stripe = 0;
+  int stripe_corner_x = rounded_x + (p.templ_cols - 1) / 2 - stripe_cols;
+  if (stripe_corner_x + stripe_cols > w - 1) {
+    offset_stripe = (stripe_corner_x + stripe_cols) - (w - 1);
+    stripe_corner_x -= offset_stripe;
+  }
+  if (stripe_corner_x < 0) stripe_corner_x = 0;
+
+  std::vector<int64_t> result;
+  ocv::matchTemplateSqdiff(right_rect + (size_t)stripe_corner_y * stride + stripe_corner_x,
+                           stripe_cols, stripe_rows, stride,
+                           left_rect + (size_t)temp_corner_y * stride + temp_corner_x,
+                           p.templ_cols, p.templ_rows, stride, result);
+  const int rw = stripe_cols - p.templ_cols + 1, rh = stripe_rows - p.templ_rows + 1;
+  // normalize(0,1,MINMAX) + minMaxLoc: first minimum in row-major order; the
+  // normalised minimum is 0 (also for a flat result).
+  int64_t best = std::numeric_limits<int64_t>::max();
+  int bx = 0, by = 0;
+  for (int y = 0; y < rh; y++)
+    for (int x = 0; x < rw; x++)
+      if (result[(size_t)y * rw + x] < best) {
+        best = result[(size_t)y * rw + x];
+        bx = x;
+        by = y;
+      }
+  double min_val = 0.0;
+  int mx = bx + stripe_corner_x + (p.templ_cols - 1) / 2 + offset_temp;
+  int my = by + stripe_corner_y + (p.templ_rows - 1) / 2;
+  Point2f match_px = {(float)mx, (float)my};
+  if (p.subpixel_refinement) {  // StereoMatcher.cpp:404-413
+    ocv::cornerSubPix(right_rect, w, h, stride, &match_px, 1, 10, -1, 40, 0.001);
+  }
+  *score = min_val;
+  if (min_val < p.tolerance_template_matching)
+    *out = {KVFE_KP_VALID, match_px};
+  else
+    *out = {KVFE_KP_NO_RIGHT_RECT, match_px};
+}
+
+void getRightKeypointsRectified(const uint8_t* left_rect, const uint8_t* right_rect, int w, int h,
+                                size_t stride, const std::vector<StatusKeypoint>& left,
+                                double fx, double baseline, const kvfe_stereo_params& p,
+                                std::vector<StatusKeypoint>& right, std::vector<double>* scores) {
+  right.clear();
+  right.reserve(left.size());
+  if (scores) scores->clear();
+  int stripe_rows = p.templ_rows + p.stripe_extra_rows;
+  int stripe_cols = (int)std::round(fx * baseline / p.min_point_dist) + p.templ_cols + 4;
+  if (stripe_cols % 2 != 1) stripe_cols += 1;
+  if (stripe_cols > w) stripe_cols = w;
+  for (const StatusKeypoint& lk : left) {
+    if (lk.status != KVFE_KP_VALID) {
+      right.push_back({lk.status, {0.0f, 0.0f}});
+      if (scores) scores->push_back(-1.0);
+      continue;
+    }
+    StatusKeypoint cand;
+    double score;
+    searchRightKeypointEpipolar(left_rect, lk.kp, right_rect, w, h, stride, stripe_cols,
+                                stripe_rows, p, &cand, &score);
+    right.push_back(cand);
+    if (scores) scores->push_back(score);
+  }
+}
+
+void getDepthFromRectifiedMatches(std::vector<StatusKeypoint>& left,
+                                  std::vector<StatusKeypoint>& right, double fx, double baseline,
+                                  const kvfe_stereo_params& p, std::vector<double>& depths) {
+  depths.clear();
+  double fx_b = fx * baseline;
+  for (size_t i = 0; i < left.size(); i++) {
+    if (left[i].status == KVFE_KP_VALID && right[i].status == KVFE_KP_VALID) {
+      double disparity = left[i].kp.x - right[i].kp.x;
+      if (disparity >= 0.0) {
+        double depth = fx_b / disparity;
+        if (depth < p.min_point_dist || depth > p.max_point_dist) {
+          right[i].status = KVFE_KP_NO_DEPTH;
+          depths.push_back(0.0);
+        } else
+          depths.push_back(depth);
+      } else {
+        right[i].status = KVFE_KP_NO_DEPTH;
+        depths.push_back(0.0);
+      }
+    } else {
+      if (left[i].status != KVFE_KP_VALID && right[i].status != left[i].status)
+        right[i].status = left[i].status;
+      depths.push_back(0.0);
+    }
+  }
+}
+
+void sparseStereoReconstruction(const StereoCamera& cam, const kvfe_stereo_params& p,
+                                StereoFrame& sf) {
+  const int w = cam.w, h = cam.h;
+  sf.left_rect.resize((size_t)w * h);
+  sf.right_rect.resize((size_t)w * h);
+  cam.undistortRectifyImage(0, sf.left.img.data(), w, sf.left_rect.data());
+  cam.undistortRectifyImage(1, sf.right_img.data(), w, sf.right_rect.data());
+  cam.undistortRectifyLeftKeypoints(sf.left.keypoints, sf.left_kp_rect);
+  getRightKeypointsRectified(sf.left_rect.data(), sf.right_rect.data(), w, h, w, sf.left_kp_rect,
+                             cam.fx(), cam.baseline(), p, sf.right_kp_rect, nullptr);
+  getDepthFromRectifiedMatches(sf.left_kp_rect, sf.right_kp_rect, cam.fx(), cam.baseline(), p,
+                               sf.depth);
+  cam.distortUnrectifyRightKeypoints(sf.right_kp_rect, sf.right_kp);
+  sf.kp3d.assign(sf.right_kp_rect.size() * 3, 0.0);
+  for (size_t i = 0; i < sf.right_kp_rect.size(); i++) {
+    if (sf.right_kp_rect[i].status == KVFE_KP_VALID) {
+      const double* v = &sf.left.versors[i * 3];
+      for (int c = 0; c < 3; c++) sf.kp3d[i * 3 + c] = v[c] * sf.depth[i] / v[2];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// Frontend
+// --------------------------------------------------------------------------
+void Frontend::init(const kvfe_camera_params& l, const kvfe_camera_params& r,
+                    const kvfe_frontend_params& fp) {
+  cam.init(l, r);
+  p = fp;
+  lmk_id = 0;
+  frame_count = 0;
+  initialized = false;
+}
+
+// FeatureDetector::featureDetection(Frame*, R) (FeatureDetector.cpp:94-163)
+void Frontend::featureDetectionFrame(Frame& f, int* n_detected) {
+  int n_existing = 0;
+  std::vector<Point2f> tracked;
+  for (size_t i = 0; i < f.landmarks.size(); ++i) {
+    if (f.landmarks[i] != -1) {
+      ++n_existing;
+      tracked.push_back(f.keypoints[i]);
+    }
+    f.landmarks_age[i]++;
+  }
+  int need = std::max(p.detector.max_features_per_frame - n_existing, 0);
+  std::vector<Point2f> corners;
+  featureDetection(f.img.data(), f.w, f.h, f.w, tracked, need, p.detector, corners);
+  for (const Point2f& c : corners) {
+    f.landmarks.push_back(lmk_id);
+    f.landmarks_age.push_back(1);
+    f.keypoints.push_back(c);
+    double v[3];
+    cam.getBearingVector(0, c, v);
+    f.versors.insert(f.versors.end(), v, v + 3);
+    ++lmk_id;
+  }
+  if (n_detected) *n_detected = (int)corners.size();
+}
+
+// Tracker::featureTracking (Tracker.cpp:92-211)
+void Frontend::featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]) {
+  std::vector<Point2f> px_ref;
+  std::vector<size_t> idx_valid;
+  for (size_t i = 0; i < ref.keypoints.size(); ++i)
+    if (ref.landmarks[i] != -1) {
+      px_ref.push_back(ref.keypoints[i]);
+      idx_valid.push_back(i);
+    }
+  std::vector<Point2f> px_cur(px_ref.size());
+  // predictor built from the ORIGINAL left K and image size (Tracker.cpp:65-69)
+  predictSparseFlow(p.tracker.optical_flow_predictor_type, cam.K1, cam.w, cam.h, px_ref.data(),
+                    (int)px_ref.size(), ref_R_cur, px_cur.data());
+  std::vector<uint8_t> status(px_ref.size());
+  std::vector<float> error(px_ref.size());
+  ocv::calcOpticalFlowPyrLK(ref.img.data(), cur.img.data(), cam.w, cam.h, cam.w, px_ref.data(),
+                            px_cur.data(), (int)px_ref.size(), status.data(), error.data(),
+                            p.tracker.klt_win_size, p.tracker.klt_max_level,
+                            p.tracker.klt_max_iter, p.tracker.klt_eps, true, 1e-4);
+  for (size_t i = 0; i < idx_valid.size(); ++i) {
+    const size_t idx = idx_valid[i];
+    const int32_t lmk_age = ref.landmarks_age[idx];
+    const int64_t id = ref.landmarks[idx];
+    if (!status[i] || lmk_age > p.tracker.max_feature_track_age) {
+      ref.landmarks[idx] = -1;
+      continue;
+    }
+    cur.landmarks.push_back(id);
+    cur.landmarks_age.push_back(lmk_age);
+    cur.keypoints.push_back(px_cur[i]);
+    double v[3];
+    cam.getBearingVector(0, px_cur[i], v);
+    cur.versors.insert(cur.versors.end(), v, v + 3);
+  }
+}
+
+// VisionImuFrontend::shouldBeKeyframe (VisionImuFrontend.cpp:175-232) with
+// Tracker::findMatchingKeypoints / computeMedianDisparity (Tracker.cpp:919-1018);
+// kfTrackingStatus_mono_ is never LOW_DISPARITY when useRANSAC = 0.
+bool Frontend::shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) const {
+  const int64_t kf_diff_ns = frame.timestamp - frame_lkf.timestamp;
+  size_t nr_valid_features = 0;
+  for (int64_t l : frame.landmarks)
+    if (l != -1) nr_valid_features++;
+  const bool min_time_elapsed = (double)kf_diff_ns >= p.min_intra_keyframe_time_ns;
+  const bool max_time_elapsed = (double)kf_diff_ns >= p.max_intra_keyframe_time_ns;
+  const bool nr_features_low = nr_valid_features <= (size_t)p.min_number_features;
+
+  std::map<int64_t, size_t> ref_map;
+  for (size_t i = 0; i < frame_lkf.landmarks.size(); ++i)
+    if (frame_lkf.landmarks[i] != -1) ref_map[frame_lkf.landmarks[i]] = i;
+  std::vector<double> disparity_sq;
+  for (size_t i = 0; i < frame.landmarks.size(); ++i) {
+    if (frame.landmarks[i] == -1) continue;
+    auto it = ref_map.find(frame.landmarks[i]);
+    if (it == ref_map.end()) continue;
+    float dx = frame.keypoints[i].x - frame_lkf.keypoints[it->second].x;
+    float dy = frame.keypoints[i].y - frame_lkf.keypoints[it->second].y;
+    double px_dist = dx * dx + dy * dy;
+    disparity_sq.push_back(px_dist);
+  }
+  double disparity = 0.0;
+  if (!disparity_sq.empty()) {
+    const size_t center = disparity_sq.size() / 2;
+    std::nth_element(disparity_sq.begin(), disparity_sq.begin() + center, disparity_sq.end());
+    disparity = std::sqrt(disparity_sq[center]);
+  }
+  const bool is_disparity_low = disparity < p.tracker.disparity_threshold;
+  const bool disparity_low_first_time = is_disparity_low;  // status != LOW_DISPARITY
+  const bool enough_disparity = !is_disparity_low;
+  const bool max_disparity_reached = disparity > p.max_disparity_since_lkf;
+  const bool disparity_flipped = ((enough_disparity || disparity_low_first_time) && min_time_elapsed);
+  return max_time_elapsed || max_disparity_reached || disparity_flipped || nr_features_low ||
+         frame.isKeyframe;
+}
+
+// getSmartStereoMeasurements (StereoVisionImuFrontend.cpp:485-531)
+void Frontend::getSmartStereoMeasurements(const StereoFrame& sf) {
+  meas_lmk.clear();
+  meas_uLuRv.clear();
+  for (size_t i = 0; i < sf.left.landmarks.size(); ++i) {
+    if (sf.left.landmarks[i] == -1) continue;
+    double uL = sf.left_kp_rect[i].kp.x, v = sf.left_kp_rect[i].kp.y;
+    double uR = std::numeric_limits<double>::quiet_NaN();
+    if (p.use_stereo_tracking && sf.right_kp_rect[i].status == KVFE_KP_VALID)
+      uR = sf.right_kp_rect[i].kp.x;
+    meas_lmk.push_back(sf.left.landmarks[i]);
+    meas_uLuRv.push_back(uL);
+    meas_uLuRv.push_back(uR);
+    meas_uLuRv.push_back(v);
+  }
+}
+
+void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
+                       const kvfe_frame_input& in) {
+  const int w = cam.w, h = cam.h;
+  k = StereoFrame();
+  k.left.id = frame_count;
+  k.left.timestamp = in.timestamp_ns;
+  k.left.isKeyframe = in.force_keyframe != 0;
+  k.left.w = w;
+  k.left.h = h;
+  k.left.img.resize((size_t)w * h);
+  k.right_img.resize((size_t)w * h);
+  for (int y = 0; y < h; y++) {
+    std::memcpy(&k.left.img[(size_t)y * w], left + (size_t)y * stride, w);
+    std::memcpy(&k.right_img[(size_t)y * w], right + (size_t)y * stride, w);
+  }
+  meas_lmk.clear();
+  meas_uLuRv.clear();
+
+  if (!initialized) {  // processFirstStereoFrame (StereoVisionImuFrontend.cpp:245-276)
+    k.left.isKeyframe = true;
+    featureDetectionFrame(k.left, &k.n_detected);
+    if (!k.left.keypoints.empty()) sparseStereoReconstruction(cam, p.stereo, k);
+    km1 = k;
+    lkf = k;
+    km1_is_lkf = true;
+    ++frame_count;
+    initialized = true;
+    last_is_keyframe = true;
+    for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+
+  // processStereoFrame (StereoVisionImuFrontend.cpp:283-481), useRANSAC = 0
+  double RrefT[9], ref_R_cur[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RrefT[i * 3 + j] = keyframe_R_ref_frame[j * 3 + i];
+  mat3_mul(RrefT, in.keyframe_R_cur_frame, ref_R_cur);
+  featureTracking(km1.left, k.left, ref_R_cur);
+  if (km1_is_lkf) lkf.left.landmarks = km1.left.landmarks;  // same object in the reference
+  k.n_tracked = (int)k.left.keypoints.size();
+
+  if (k.left.keypoints.empty()) {  // :313-323
+    featureDetectionFrame(k.left, &k.n_detected);
+    km1 = k;
+    km1_is_lkf = false;
+    ++frame_count;
+    last_is_keyframe = false;
+    return;
+  }
+  const bool new_keyframe = shouldBeKeyframe(k.left, lkf.left);
+  if (new_keyframe) {
+    k.left.isKeyframe = true;
+    featureDetectionFrame(k.left, &k.n_detected);
+    sparseStereoReconstruction(cam, p.stereo, k);
+    lkf = k;
+    getSmartStereoMeasurements(k);
+    for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    k.left.isKeyframe = false;
+    std::memcpy(keyframe_R_ref_frame, in.keyframe_R_cur_frame, sizeof(keyframe_R_ref_frame));
+  }
+  last_is_keyframe = new_keyframe;
+  km1 = k;
+  km1_is_lkf = new_keyframe;
+  ++frame_count;
+}
+
+}  // namespace kimera

@@ -1,0 +1,140 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+// CPU restatement of the reference-owned logic of Kimera-VIO's stereo front-end
+// (the parts that live in /root/reference, as opposed to OpenCV): every function
+// cites the reference file:line it follows.  Built on oracle/ocv.hpp.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../include/kvfe.h"  // POD parameter structs only (no product code is linked)
+#include "ocv.hpp"
+
+namespace kimera {
+
+using ocv::Point2f;
+
+struct StatusKeypoint {
+  uint8_t status;
+  Point2f kp;
+};
+
+// StereoCamera + UndistorterRectifier x2 (src/frontend/StereoCamera.cpp:34-94,
+// src/frontend/UndistorterRectifier.cpp:26-31,230-292)
+struct StereoCamera {
+  kvfe_camera_params left, right;
+  double K1[9], K2[9];
+  kvfe_rectification rect;
+  std::vector<float> map_x[2], map_y[2];
+  int w, h;
+  void init(const kvfe_camera_params& l, const kvfe_camera_params& r);
+  double fx() const { return rect.P1[0]; }
+  double baseline() const { return rect.baseline; }
+  // UndistorterRectifier::undistortRectifyImage (UndistorterRectifier.cpp:115-128)
+  void undistortRectifyImage(int cam, const uint8_t* src, size_t stride, uint8_t* dst) const;
+  // UndistorterRectifier::UndistortRectifyKeypoints (UndistorterRectifier.cpp:33-68)
+  void undistortRectifyKeypoints(int cam, const Point2f* in, int n, bool useR, bool useP,
+                                 Point2f* out) const;
+  // UndistorterRectifier::GetBearingVector (UndistorterRectifier.cpp:73-113)
+  void getBearingVector(int cam, Point2f kp, double versor[3]) const;
+  // StereoCamera::undistortRectifyLeftKeypoints (StereoCamera.cpp:236-260) =
+  // undistortRectifyKeypoints + checkUndistortedRectifiedLeftKeypoints
+  // (UndistorterRectifier.cpp:138-211, pixel_tol = 2.0f)
+  void undistortRectifyLeftKeypoints(const std::vector<Point2f>& kps,
+                                     std::vector<StatusKeypoint>& out) const;
+  // UndistorterRectifier::distortUnrectifyKeypoints (UndistorterRectifier.cpp:213-228)
+  void distortUnrectifyRightKeypoints(const std::vector<StatusKeypoint>& rect,
+                                      std::vector<Point2f>& out) const;
+};
+
+void camera_matrix(const kvfe_camera_params& c, double K[9]);
+
+// cv::sortIdx(all-equal int keys, SORT_DESCENDING) permutation
+// (NonMaximumSuppression.cpp:50-60): libstdc++ introsort with an always-false
+// comparator, then reversed.  policy: KVFE_SORTIDX_*.
+void sortidx_descending_equal_keys(int n, int policy, std::vector<int>& idx);
+
+// AdaptiveNonMaximumSuppression::suppressNonMax (NonMaximumSuppression.cpp:33-122)
+// for TopN and Binning (the types the shipped YAMLs and the reference tests use).
+// Returns false for the other ANMS types.
+bool suppressNonMax(const std::vector<Point2f>& keypoints, int numRetPoints, int cols, int rows,
+                    const kvfe_detector_params& p, std::vector<Point2f>& out);
+
+// private FeatureDetector::featureDetection(const Frame&, need) (FeatureDetector.cpp:174-299)
+bool featureDetection(const uint8_t* img, int w, int h, size_t stride,
+                      const std::vector<Point2f>& tracked, int need_n_corners,
+                      const kvfe_detector_params& p, std::vector<Point2f>& new_corners,
+                      std::vector<Point2f>* raw_gftt = nullptr);
+
+// OpticalFlowPredictor::predictSparseFlow (OpticalFlowPredictor.cpp:27-33,70-126)
+void predictSparseFlow(int type, const double K[9], int w, int h, const Point2f* prev, int n,
+                       const double ref_R_cur[9], Point2f* next);
+
+// StereoMatcher::getRightKeypointsRectified + searchRightKeypointEpipolar
+// (StereoMatcher.cpp:196-423)
+void getRightKeypointsRectified(const uint8_t* left_rect, const uint8_t* right_rect, int w, int h,
+                                size_t stride, const std::vector<StatusKeypoint>& left,
+                                double fx, double baseline, const kvfe_stereo_params& p,
+                                std::vector<StatusKeypoint>& right, std::vector<double>* scores);
+
+// StereoMatcher::getDepthFromRectifiedMatches (StereoMatcher.cpp:425-483)
+void getDepthFromRectifiedMatches(std::vector<StatusKeypoint>& left,
+                                  std::vector<StatusKeypoint>& right, double fx, double baseline,
+                                  const kvfe_stereo_params& p, std::vector<double>& depth);
+
+struct Frame {
+  int64_t id = 0, timestamp = 0;
+  bool isKeyframe = false;
+  int w = 0, h = 0;
+  std::vector<uint8_t> img;
+  std::vector<Point2f> keypoints;
+  std::vector<int64_t> landmarks;
+  std::vector<int32_t> landmarks_age;
+  std::vector<double> versors;  // n x 3
+};
+
+struct StereoFrame {
+  Frame left;
+  std::vector<uint8_t> right_img, left_rect, right_rect;
+  std::vector<StatusKeypoint> left_kp_rect, right_kp_rect;
+  std::vector<double> depth;
+  std::vector<Point2f> right_kp;
+  std::vector<double> kp3d;
+  int n_tracked = 0, n_detected = 0;
+};
+
+// StereoMatcher::sparseStereoReconstruction(StereoFrame*) (StereoMatcher.cpp:123-175)
+void sparseStereoReconstruction(const StereoCamera& cam, const kvfe_stereo_params& p,
+                                StereoFrame& sf);
+
+// StereoVisionImuFrontend (processFirstStereoFrame / processStereoFrame with
+// useRANSAC = 0; src/frontend/StereoVisionImuFrontend.cpp:245-531) +
+// VisionImuFrontend::shouldBeKeyframe (VisionImuFrontend.cpp:175-232) +
+// Tracker::featureTracking (Tracker.cpp:92-211) +
+// FeatureDetector::featureDetection(Frame*, R) (FeatureDetector.cpp:94-163).
+struct Frontend {
+  StereoCamera cam;
+  kvfe_frontend_params p;
+  int64_t lmk_id = 0;  // FeatureDetector.cpp:141 (static counter, here per stream)
+  int64_t frame_count = 0;
+  bool initialized = false;
+  StereoFrame km1, lkf, k;
+  bool km1_is_lkf = false;
+  double keyframe_R_ref_frame[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::vector<int64_t> meas_lmk;
+  std::vector<double> meas_uLuRv;
+  bool last_is_keyframe = false;
+
+  void init(const kvfe_camera_params& l, const kvfe_camera_params& r,
+            const kvfe_frontend_params& fp);
+  void process(const uint8_t* left, const uint8_t* right, size_t stride,
+               const kvfe_frame_input& in);
+  const StereoFrame& current() const { return km1; }
+
+ private:
+  void featureDetectionFrame(Frame& f, int* n_detected);
+  void featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]);
+  bool shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) const;
+  void getSmartStereoMeasurements(const StereoFrame& sf);
+};
+
+}  // namespace kimera

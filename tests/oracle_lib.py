@@ -1,0 +1,371 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle_kvfe.so) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+The library is (re)built with `make -C oracle` when missing or stale.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from kimera_vio_amd import _abi as abi
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_ORACLE_DIR, "liboracle_kvfe.so")
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+
+
+def build_oracle(force: bool = False) -> str:
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR)
+            if f.endswith((".cpp", ".hpp"))] + [os.path.join(_ROOT, "include", "kvfe.h")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _ORACLE_DIR, "-B", "liboracle_kvfe.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        so = build_oracle()
+        L = C.CDLL(so)
+    except (OSError, subprocess.CalledProcessError):
+        so = build_oracle(force=True)
+        L = C.CDLL(so)
+    L.kvo_version.restype = C.c_char_p
+    L.kvo_camera_create.restype = C.c_void_p
+    L.kvo_camera_create.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams)]
+    L.kvo_camera_destroy.argtypes = [C.c_void_p]
+    L.kvo_camera_get_rectification.argtypes = [C.c_void_p, C.POINTER(abi.Rectification)]
+    L.kvo_camera_get_maps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.kvo_camera_rectify_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.kvo_camera_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_int, C.c_void_p]
+    L.kvo_camera_bearing_vectors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.kvo_camera_undistort_rectify_left.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                    C.c_void_p]
+    L.kvo_remap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                            C.c_void_p]
+    L.kvo_corner_min_eigen_val.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                           C.c_void_p]
+    L.kvo_good_features_to_track.restype = C.c_int
+    L.kvo_good_features_to_track.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                             C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int]
+    L.kvo_draw_detection_mask.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.kvo_corner_subpix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_double]
+    L.kvo_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+    L.kvo_calc_optical_flow_pyr_lk.restype = C.c_int
+    L.kvo_calc_optical_flow_pyr_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                               C.c_int, C.c_double]
+    L.kvo_sortidx_permutation.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.kvo_sortidx_permutation_stdsort.argtypes = [C.c_int, C.c_void_p]
+    L.kvo_suppress_non_max.restype = C.c_int
+    L.kvo_suppress_non_max.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(abi.DetectorParams), C.c_void_p, C.c_int]
+    L.kvo_feature_detection.restype = C.c_int
+    L.kvo_feature_detection.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                        C.c_int, C.POINTER(abi.DetectorParams), C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.kvo_predict_sparse_flow.argtypes = [C.c_int, C.POINTER(abi.CameraParams), C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p]
+    L.kvo_get_right_keypoints_rectified.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_double, C.c_double,
+                                                    C.POINTER(abi.StereoParams), C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]
+    L.kvo_sparse_stereo_reconstruction.argtypes = [C.c_void_p, C.POINTER(abi.StereoParams),
+                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                   C.c_int, C.POINTER(abi.StereoOutput)]
+    L.kvo_frontend_create.restype = C.c_void_p
+    L.kvo_frontend_create.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams),
+                                      C.POINTER(abi.FrontendParams)]
+    L.kvo_frontend_destroy.argtypes = [C.c_void_p]
+    L.kvo_frontend_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.POINTER(abi.FrameInput)]
+    L.kvo_frontend_get_output.restype = C.c_int
+    L.kvo_frontend_get_output.argtypes = [C.c_void_p, C.POINTER(abi.FrameOutput)]
+    L.kvo_frontend_time_sequence.restype = C.c_double
+    L.kvo_frontend_time_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _img(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+# --------------------------------------------------------------------------- imgproc
+def good_features_to_track(img, max_corners, quality, min_dist, block=3, mask=None):
+    img = _img(img)
+    h, w = img.shape
+    cap = max(max_corners, 1) if max_corners > 0 else w * h
+    xy = np.zeros((cap, 2), np.float32)
+    q = np.zeros(cap, np.float32)
+    if mask is not None:
+        mask = _img(mask)
+    n = lib().kvo_good_features_to_track(_p(img), w, h, w, _p(mask) if mask is not None else None,
+                                         w, max_corners, quality, float(min_dist), block, _p(xy),
+                                         _p(q), cap)
+    n = min(n, cap)
+    return xy[:n].copy(), q[:n].copy()
+
+
+def corner_min_eigen_val(img, block=3):
+    img = _img(img)
+    h, w = img.shape
+    eig = np.zeros((h, w), np.float32)
+    lib().kvo_corner_min_eigen_val(_p(img), w, h, w, block, _p(eig))
+    return eig
+
+
+def draw_detection_mask(w, h, xy, radius):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    mask = np.zeros((h, w), np.uint8)
+    lib().kvo_draw_detection_mask(w, h, _p(xy), len(xy), radius, _p(mask))
+    return mask
+
+
+def corner_subpix(img, xy, win=10, zero_zone=-1, max_iters=40, eps=0.001):
+    img = _img(img)
+    h, w = img.shape
+    out = np.ascontiguousarray(xy, np.float32).reshape(-1, 2).copy()
+    lib().kvo_corner_subpix(_p(img), w, h, w, _p(out), len(out), win, zero_zone, max_iters, eps)
+    return out
+
+
+def pyr_down(img):
+    img = _img(img)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().kvo_pyr_down(_p(img), w, h, w, _p(out))
+    return out
+
+
+def remap(img, map_x, map_y):
+    img = _img(img)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    mx = np.ascontiguousarray(map_x, np.float32)
+    my = np.ascontiguousarray(map_y, np.float32)
+    lib().kvo_remap(_p(img), w, h, w, _p(mx), _p(my), _p(out))
+    return out
+
+
+def calc_optical_flow_pyr_lk(prev, nxt, prev_xy, init_xy, win=24, max_level=4, max_iter=30, eps=0.1,
+                             use_initial_flow=True, min_eig=1e-4):
+    prev, nxt = _img(prev), _img(nxt)
+    h, w = prev.shape
+    pxy = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+    nxy = np.ascontiguousarray(init_xy, np.float32).reshape(-1, 2).copy()
+    n = len(pxy)
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    lvl = lib().kvo_calc_optical_flow_pyr_lk(_p(prev), _p(nxt), w, h, w, _p(pxy), _p(nxy), n,
+                                             _p(status), _p(err), win, max_level, max_iter, eps,
+                                             1 if use_initial_flow else 0, min_eig)
+    return nxy, status, err, lvl
+
+
+# --------------------------------------------------------------------------- reference logic
+def sortidx_permutation(n, policy=abi.SORTIDX_LIBSTDCXX):
+    idx = np.zeros(n, np.int32)
+    lib().kvo_sortidx_permutation(n, policy, _p(idx))
+    return idx
+
+
+def sortidx_permutation_stdsort(n):
+    idx = np.zeros(n, np.int32)
+    lib().kvo_sortidx_permutation_stdsort(n, _p(idx))
+    return idx
+
+
+def feature_detection(img, tracked_xy, need, det: abi.DetectorParams):
+    img = _img(img)
+    h, w = img.shape
+    tr = np.ascontiguousarray(tracked_xy, np.float32).reshape(-1, 2)
+    cap = det.max_nr_keypoints_before_anms + 16
+    out = np.zeros((cap, 2), np.float32)
+    raw = np.zeros((cap, 2), np.float32)
+    raw_n = C.c_int(0)
+    n = lib().kvo_feature_detection(_p(img), w, h, w, _p(tr), len(tr), need, C.byref(det), _p(out),
+                                    cap, _p(raw), cap, C.byref(raw_n))
+    if n < 0:
+        raise RuntimeError("oracle: unsupported ANMS type")
+    return out[:n].copy(), raw[:raw_n.value].copy()
+
+
+def predict_sparse_flow(ptype, cam: abi.CameraParams, prev_xy, R):
+    p = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(p)
+    Rm = np.ascontiguousarray(R, np.float64).reshape(9)
+    lib().kvo_predict_sparse_flow(ptype, C.byref(cam), _p(p), len(p), _p(Rm), _p(out))
+    return out
+
+
+class Camera:
+    """kimera::StereoCamera of the oracle."""
+
+    def __init__(self, left: abi.CameraParams, right: abi.CameraParams):
+        self.left, self.right = left, right
+        self.w, self.h = left.width, left.height
+        self._h = lib().kvo_camera_create(C.byref(left), C.byref(right))
+        self.rect = abi.Rectification()
+        lib().kvo_camera_get_rectification(self._h, C.byref(self.rect))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kvo_camera_destroy(self._h)
+            self._h = None
+
+    def maps(self, cam):
+        mx = np.zeros((self.h, self.w), np.float32)
+        my = np.zeros((self.h, self.w), np.float32)
+        lib().kvo_camera_get_maps(self._h, cam, _p(mx), _p(my))
+        return mx, my
+
+    def rectify_image(self, cam, img):
+        img = _img(img)
+        out = np.zeros_like(img)
+        lib().kvo_camera_rectify_image(self._h, cam, _p(img), img.shape[1], _p(out))
+        return out
+
+    def undistort_keypoints(self, cam, xy, use_R=True, use_P=True):
+        p = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros_like(p)
+        lib().kvo_camera_undistort_keypoints(self._h, cam, _p(p), len(p), int(use_R), int(use_P), _p(out))
+        return out
+
+    def bearing_vectors(self, cam, xy):
+        p = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros((len(p), 3), np.float64)
+        lib().kvo_camera_bearing_vectors(self._h, cam, _p(p), len(p), _p(out))
+        return out
+
+    def undistort_rectify_left(self, xy):
+        p = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros_like(p)
+        st = np.zeros(len(p), np.uint8)
+        lib().kvo_camera_undistort_rectify_left(self._h, _p(p), len(p), _p(out), _p(st))
+        return out, st
+
+    def get_right_keypoints_rectified(self, left_rect, right_rect, left_xy, left_status,
+                                      sp: abi.StereoParams):
+        left_rect, right_rect = _img(left_rect), _img(right_rect)
+        h, w = left_rect.shape
+        p = np.ascontiguousarray(left_xy, np.float32).reshape(-1, 2)
+        st = np.ascontiguousarray(left_status, np.uint8)
+        n = len(p)
+        rxy = np.zeros((n, 2), np.float32)
+        rst = np.zeros(n, np.uint8)
+        score = np.zeros(n, np.float64)
+        lib().kvo_get_right_keypoints_rectified(_p(left_rect), _p(right_rect), w, h, w, _p(p), _p(st),
+                                                n, self.rect.P1[0], self.rect.baseline, C.byref(sp),
+                                                _p(rxy), _p(rst), _p(score))
+        return rxy, rst, score
+
+    def sparse_stereo(self, left, right, left_xy, sp: abi.StereoParams, want_images=False):
+        left, right = _img(left), _img(right)
+        h, w = left.shape
+        p = np.ascontiguousarray(left_xy, np.float32).reshape(-1, 2)
+        n = len(p)
+        res = dict(left_rect_xy=np.zeros((n, 2), np.float32), left_status=np.zeros(n, np.uint8),
+                   right_rect_xy=np.zeros((n, 2), np.float32), right_status=np.zeros(n, np.uint8),
+                   depth=np.zeros(n, np.float64), right_xy=np.zeros((n, 2), np.float32),
+                   keypoints_3d=np.zeros((n, 3), np.float64))
+        if want_images:
+            res["left_rect_img"] = np.zeros((h, w), np.uint8)
+            res["right_rect_img"] = np.zeros((h, w), np.uint8)
+        so = abi.StereoOutput()
+        for k, v in res.items():
+            setattr(so, k, v.ctypes.data)
+        lib().kvo_sparse_stereo_reconstruction(self._h, C.byref(sp), _p(left), _p(right), w, _p(p), n,
+                                               C.byref(so))
+        return res
+
+
+def alloc_frame_output(cap: int):
+    """numpy-backed kvfe_frame_output."""
+    arrs = dict(landmarks=np.zeros(cap, np.int64), landmarks_age=np.zeros(cap, np.int32),
+                keypoints=np.zeros((cap, 2), np.float32), versors=np.zeros((cap, 3), np.float64),
+                left_rect_xy=np.zeros((cap, 2), np.float32), left_status=np.zeros(cap, np.uint8),
+                right_rect_xy=np.zeros((cap, 2), np.float32), right_status=np.zeros(cap, np.uint8),
+                depth=np.zeros(cap, np.float64), right_xy=np.zeros((cap, 2), np.float32),
+                keypoints_3d=np.zeros((cap, 3), np.float64), meas_landmark=np.zeros(cap, np.int64),
+                meas_uL_uR_v=np.zeros((cap, 3), np.float64))
+    out = abi.FrameOutput()
+    out.capacity = cap
+    for k, v in arrs.items():
+        setattr(out, k, v.ctypes.data)
+    return out, arrs
+
+
+def frame_output_to_dict(out: abi.FrameOutput, arrs: dict) -> dict:
+    n = min(out.n_keypoints, out.capacity)
+    m = min(out.n_measurements, out.capacity)
+    d = dict(n_keypoints=out.n_keypoints, is_keyframe=out.is_keyframe, n_tracked=out.n_tracked,
+             n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id)
+    for k, v in arrs.items():
+        d[k] = v[:m].copy() if k.startswith("meas_") else v[:n].copy()
+    return d
+
+
+class Frontend:
+    """kimera::Frontend of the oracle (StereoVisionImuFrontend, useRANSAC = 0)."""
+
+    def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams):
+        self.params = params
+        self.w, self.h = left.width, left.height
+        self._h = lib().kvo_frontend_create(C.byref(left), C.byref(right), C.byref(params))
+        self.cap = params.detector.max_features_per_frame + params.detector.max_nr_keypoints_before_anms + 64
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kvo_frontend_destroy(self._h)
+            self._h = None
+
+    def process(self, left, right, timestamp_ns, R=None, force_keyframe=False) -> dict:
+        left, right = _img(left), _img(right)
+        fi = abi.FrameInput()
+        fi.timestamp_ns = int(timestamp_ns)
+        Rm = np.eye(3) if R is None else np.asarray(R, np.float64).reshape(3, 3)
+        for i in range(9):
+            fi.keyframe_R_cur_frame[i] = float(Rm.reshape(9)[i])
+        fi.force_keyframe = int(force_keyframe)
+        lib().kvo_frontend_process(self._h, _p(left), _p(right), left.shape[1], C.byref(fi))
+        out, arrs = alloc_frame_output(self.cap)
+        has_stereo = lib().kvo_frontend_get_output(self._h, C.byref(out))
+        d = frame_output_to_dict(out, arrs)
+        d["has_stereo"] = bool(has_stereo)
+        return d
+
+    def time_sequence(self, lefts, rights, inputs) -> float:
+        lefts = np.ascontiguousarray(lefts, np.uint8)
+        rights = np.ascontiguousarray(rights, np.uint8)
+        n = lefts.shape[0]
+        arr = (abi.FrameInput * n)(*inputs)
+        return lib().kvo_frontend_time_sequence(self._h, _p(lefts), _p(rights), self.w, self.h, n, arr)
