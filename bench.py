@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py — stereo-pairs/sec of the MI355X-native stereo front-end (detect + track + match).
+
+One "step" = one pass of the hot path over one batch of synthetic input: every one of the `batch`
+independent 752x480 stereo streams of this GPU advances by one stereo pair through
+   pyramid -> (gyro-predicted) pyramidal LK track -> keyframe decision -> masked Shi-Tomasi detect
+   + ANMS + cornerSubPix -> undistort-rectify L/R -> epipolar SSD stereo match + depth
+with the inputs already resident in HBM (a ring of pre-generated frames).  N GPUs = N processes
+(torchrun), each with its own context and its own `batch` streams (weak scaling); the only
+collective is the RCCL barrier that brackets the timed region.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64, help="independent stereo streams per GPU")
+    ap.add_argument("--width", type=int, default=752)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--features", type=int, default=600)
+    ap.add_argument("--klt-max-level", type=int, default=2, help="2 = 3-level pyramid")
+    ap.add_argument("--mode", choices=["kf", "nominal"], default="kf",
+                    help="kf: every frame is a keyframe (all stages every pair, headline); "
+                         "nominal: reference cadence (keyframe every 0.2 s = 4th frame)")
+    ap.add_argument("--ring", type=int, default=6, help="distinct frames per stream (ping-pong)")
+    ap.add_argument("--unique-streams", type=int, default=8)
+    ap.add_argument("--cpu-baseline-frames", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-stream", action="store_true")
+    return ap.parse_args()
+
+
+def make_cameras(P, G, w, h):
+    L = P.load_camera_params(os.path.join(G, "params_euroc", "LeftCameraParams.yaml"))
+    R = P.load_camera_params(os.path.join(G, "params_euroc", "RightCameraParams.yaml"))
+    if (w, h) != (L.width, L.height):
+        sx = w / L.width
+        for cam in (L, R):
+            cx0, cy0 = cam.width / 2.0, cam.height / 2.0
+            cam.intrinsics[0] *= sx
+            cam.intrinsics[1] *= sx
+            cam.intrinsics[2] = w / 2.0 + (cam.intrinsics[2] - cx0) * sx
+            cam.intrinsics[3] = h / 2.0 + (cam.intrinsics[3] - cy0) * sx
+            cam.width, cam.height = w, h
+    return L, R
+
+
+def ping_pong(i, n):
+    if n == 1:
+        return 0
+    period = 2 * (n - 1)
+    j = i % period
+    return j if j < n else period - j
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from kimera_vio_amd import frontend as F
+    from kimera_vio_amd import params as P
+    from kimera_vio_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libkvfe has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    G = os.path.join(ROOT, "tests", "golden")
+    W, H, B = args.width, args.height, args.batch
+    L, R = make_cameras(P, G, W, H)
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p.detector.max_features_per_frame = args.features
+    p.tracker.klt_max_level = args.klt_max_level
+
+    # ---- synthetic input ring, resident in HBM ---------------------------------------------------
+    U = max(1, min(args.unique_streams, B))
+    T = args.ring
+    streams = [synth.SyntheticStream(L, seed=100 * rank + u) for u in range(U)]
+    lefts = np.empty((T, B, H, W), np.uint8)
+    rights = np.empty((T, B, H, W), np.uint8)
+    for t in range(T):
+        for u in range(U):
+            l, r = streams[u].frame(t)
+            lefts[t, u::U] = l
+            rights[t, u::U] = r
+    d_left = torch.from_numpy(lefts).to(dev)
+    d_right = torch.from_numpy(rights).to(dev)
+    torch.cuda.synchronize()
+
+    ctx = F.Context(L, R, p, batch=B, device=local_rank)
+    dt_ns = 50_000_000  # 20 Hz
+
+    def frame_inputs(step_idx, kf_t):
+        t = ping_pong(step_idx, T)
+        Rs = [synth.keyframe_R_cur(streams[s % U], kf_t, t) for s in range(B)]
+        force = 1 if args.mode == "kf" else 0
+        return t, ctx.make_inputs([step_idx * dt_ns] * B, Rs, [force] * B)
+
+    # pre-compute inputs for all steps (host work outside the timed region)
+    total = args.warmup + args.steps
+    plan = []
+    kf_t = 0
+    last_kf_step = 0
+    for i in range(total):
+        t, inp = frame_inputs(i, kf_t)
+        plan.append((t, inp))
+        is_kf = (args.mode == "kf") or i == 0 or (i - last_kf_step) * dt_ns >= p.min_intra_keyframe_time_ns
+        if is_kf:
+            kf_t, last_kf_step = t, i
+
+    def run(i0, i1):
+        for i in range(i0, i1):
+            t, inp = plan[i]
+            ctx.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), inp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    run(0, args.warmup)
+    barrier()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    run(args.warmup, total)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity of the measured work: every stream produced keypoints and stereo matches
+    out0 = ctx.get_output(0)
+    outl = ctx.get_output(B - 1)
+    assert out0["n_keypoints"] > 0 and outl["n_keypoints"] > 0, "front-end produced no keypoints"
+    n_valid = int((out0["right_status"] == 0).sum()) if out0["is_keyframe"] else -1
+    ctx.close()
+
+    pairs = B * world * args.steps
+    value = pairs / elapsed
+
+    # ---- roofline of the dominant dense (HBM-bound) kernel, from HIP events in the timed region --
+    stages = prof["stages"]
+    ns = max(prof["n_samples"], 1)
+    dense = {k: v for k, v in stages.items() if v["alg_bytes"] > 0 and v["ms_total"] > 0}
+    roofline = None
+    if dense:
+        name = max(dense, key=lambda k: dense[k]["ms_total"])
+        avg_ms = dense[name]["ms_total"] / ns
+        ach = dense[name]["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
+                    "alg_bytes_per_launch": dense[name]["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)}
+    stage_ms = {k: round(v["ms_total"] / ns, 5) for k, v in stages.items()}
+
+    result = {
+        "metric": "stereo-pairs/sec front-end (detect+track+match) @752x480",
+        "value": round(value, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32+f32",
+        "data": f"synthetic ({U} seeded streams x {T} frames per GPU, replicated to {B} streams)",
+        "config": {"workload": f"batched {B} synthetic {W}x{H} stereo streams per GPU, {args.features} "
+                               f"features, ANMS binning on, {args.klt_max_level + 1}-level LK, "
+                               f"mode={args.mode}", "batch_per_gpu": B, "width": W, "height": H,
+                   "features": args.features, "mode": args.mode, "parallelism": f"streams x{world}"},
+        "roofline": roofline,
+        "stage_ms_per_step": stage_ms,
+        "check": {"keypoints_stream0": int(out0["n_keypoints"]), "valid_stereo_stream0": n_valid},
+    }
+
+    if rank == 0 and world == 1 and not args.no_single_stream:
+        result["single_stream"] = single_stream(F, P, synth, L, R, p, torch, dev, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(P, synth, L, R, p, args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def single_stream(F, P, synth, L, R, p, torch, dev, args):
+    """BASELINE config[1]: one stream, 300 features, 3-level LK (latency-bound: one launch chain
+    per pair)."""
+    import copy
+    p1 = copy.deepcopy(p)
+    p1.detector.max_features_per_frame = 300
+    st = synth.SyntheticStream(L, seed=4242)
+    T = 6
+    fr = [st.frame(t) for t in range(T)]
+    dl = torch.from_numpy(np.stack([f[0] for f in fr])[:, None]).to(dev)
+    dr = torch.from_numpy(np.stack([f[1] for f in fr])[:, None]).to(dev)
+    ctx = F.Context(L, R, p1, batch=1, device=dev.index)
+    steps, warm = 200, 20
+    plan = []
+    kf_t = 0
+    for i in range(steps + warm):
+        t = ping_pong(i, T)
+        plan.append((t, ctx.make_inputs([i * 50_000_000], [synth.keyframe_R_cur(st, kf_t, t)], [1])))
+        kf_t = t
+    for i in range(warm):
+        ctx.step_device(dl[plan[i][0]].data_ptr(), dr[plan[i][0]].data_ptr(), plan[i][1])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm, warm + steps):
+        ctx.step_device(dl[plan[i][0]].data_ptr(), dr[plan[i][0]].data_ptr(), plan[i][1])
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    n = ctx.get_output(0)["n_keypoints"]
+    ctx.close()
+    return {"workload": "single synthetic 752x480 stream, 300 features, 3-level LK, mode=kf",
+            "value": round(steps / el, 2), "unit": "stereo-pairs/s", "ms_per_pair": round(1e3 * el / steps, 4),
+            "keypoints": int(n)}
+
+
+def cpu_baseline(P, synth, L, R, p, args):
+    """The CPU oracle (OpenCV-faithful scalar restatement, 1 thread = the reference's one front-end
+    thread) on a bounded sample of the same workload: one stream, same parameters and mode."""
+    import oracle_lib as O  # checker / baseline only
+    from kimera_vio_amd import _abi as abi
+    n = args.cpu_baseline_frames
+    st = synth.SyntheticStream(L, seed=100)
+    T = args.ring
+    frames = [st.frame(t) for t in range(T)]
+    lefts = np.stack([frames[ping_pong(i, T)][0] for i in range(n)])
+    rights = np.stack([frames[ping_pong(i, T)][1] for i in range(n)])
+    inputs = []
+    kf_t = 0
+    last_kf = 0
+    for i in range(n):
+        t = ping_pong(i, T)
+        fi = abi.FrameInput()
+        fi.timestamp_ns = i * 50_000_000
+        Rm = synth.keyframe_R_cur(st, kf_t, t).reshape(9)
+        for k in range(9):
+            fi.keyframe_R_cur_frame[k] = float(Rm[k])
+        fi.force_keyframe = 1 if args.mode == "kf" else 0
+        inputs.append(fi)
+        if args.mode == "kf" or i == 0 or (i - last_kf) * 50_000_000 >= p.min_intra_keyframe_time_ns:
+            kf_t, last_kf = t, i
+    fe = O.Frontend(L, R, p)
+    secs = fe.time_sequence(lefts, rights, inputs)
+    return {"value": round(n / secs, 3), "unit": "stereo-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} consecutive stereo pairs of one synthetic {args.width}x{args.height} stream, "
+                      f"{args.features} features, mode={args.mode}, {secs:.1f} s on one host core "
+                      f"(scalar OpenCV-faithful restatement, no SIMD/IPP; host has {os.cpu_count()} cores)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,694 @@
+// K2a-c  Shi-Tomasi min-eigenvalue + 3x3 local maxima + masked maximum   (cv::goodFeaturesToTrack)
+// K2d    quality threshold, greedy min-distance filter, sort, maxCorners (cv::goodFeaturesToTrack)
+//        + ANMS (AdaptiveNonMaximumSuppression::suppressNonMax: none / TopN / Binning)
+// K3     cv::cornerSubPix + append to the frame (FeatureDetector::featureDetection)
+// reference: src/frontend/feature-detector/FeatureDetector.cpp:94-299,
+//            src/frontend/feature-detector/NonMaximumSuppression.cpp:33-169
+//
+// The dense kernel never materialises the eigenvalue map: whether a pixel is a 3x3 local maximum
+// does not depend on the quality threshold (a neighbour larger than a pixel above the threshold
+// is itself above it), so one pass emits (lambda, index) for every non-zero local maximum under
+// the mask plus the masked global maximum; the per-stream select kernel applies
+// lambda > maxVal*quality afterwards on the compacted list.  HBM traffic per image: one read of
+// the image (+ the optional user mask); the detection mask "255 minus filled discs around the
+// tracked keypoints" is evaluated analytically from the keypoint list (exact cv::circle spans).
+#include "kvfe_dev.hpp"
+
+namespace kvfe {
+
+// order-preserving float -> uint key (handles negative values), 0 is reserved for "none"
+__device__ __forceinline__ unsigned fkey(float f) {
+  unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+  if (k == 0) return 0.0f;
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+constexpr int TW = 64, TH = 16;           // output tile
+constexpr int CH = 2;                     // cov halo (box 3x3 + local-max ring)
+constexpr int SH = 3;                     // source halo
+constexpr int SW_ = TW + 2 * SH, SHT = TH + 2 * SH;
+constexpr int CW_ = TW + 2 * CH, CHT = TH + 2 * CH;
+constexpr int LW_ = TW + 2, LHT = TH + 2;
+constexpr int MAX_TILE_DISCS = 96;
+
+__global__ __launch_bounds__(256) void mineig_localmax_kernel(
+    const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
+    const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
+    const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
+    const int* __restrict__ kp_count, int use_discs, const int* __restrict__ flags,
+    unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
+    unsigned int* __restrict__ maxkey) {
+  const int s = blockIdx.z;
+  if (flags && !(flags[s] & FLAG_DETECT)) return;
+  __shared__ unsigned char src[SHT][SW_ + 2];
+  __shared__ float cov0[CHT][CW_ + 1], cov1[CHT][CW_ + 1], cov2[CHT][CW_ + 1];
+  __shared__ float lam[LHT][LW_ + 1];
+  __shared__ int disc_cx[MAX_TILE_DISCS], disc_cy[MAX_TILE_DISCS];
+  __shared__ int hw_s[MAX_RADIUS + 1];
+  __shared__ int n_disc;
+
+  const unsigned char* I = img + (size_t)s * img_stride;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int tid = threadIdx.x;
+  if (tid == 0) n_disc = 0;
+  for (int i = tid; i <= radius && i <= MAX_RADIUS; i += 256) hw_s[i] = circle_hw[i];
+  for (int i = tid; i < SW_ * SHT; i += 256) {
+    const int ty = i / SW_, tx = i - ty * SW_;
+    const int gx = reflect101(x0 - SH + tx, W), gy = reflect101(y0 - SH + ty, H);
+    src[ty][tx] = I[(size_t)gy * row_stride + gx];
+  }
+  __syncthreads();
+  // discs whose bounding box touches this tile
+  if (use_discs) {
+    const float2* kp = kp_all + (size_t)s * kcap;
+    const int nk = kp_count[s];
+    for (int i = tid; i < nk; i += 256) {
+      const float2 p = kp[i];
+      const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
+      if (cx + radius >= x0 && cx - radius < x0 + TW && cy + radius >= y0 && cy - radius < y0 + TH) {
+        const int slot = atomicAdd(&n_disc, 1);
+        if (slot < MAX_TILE_DISCS) {
+          disc_cx[slot] = cx;
+          disc_cy[slot] = cy;
+        }
+      }
+    }
+  }
+  // Sobel (scale folded into the smoothing taps exactly as cv::Sobel does) -> dx*dx, dx*dy, dy*dy
+  const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0));  // (float)scale, blockSize 3, ksize 3
+  const float f0 = 2.0f * f1;
+  for (int i = tid; i < CW_ * CHT; i += 256) {
+    const int cy = i / CW_, cx = i - cy * CW_;
+    const int gx = x0 - CH + cx, gy = y0 - CH + cy;
+    if (gx < 0 || gx >= W || gy < 0 || gy >= H) continue;
+    const int sx = cx + (SH - CH), sy = cy + (SH - CH);  // position in src tile
+    const float r0 = (float)((int)src[sy - 1][sx + 1] - (int)src[sy - 1][sx - 1]);
+    const float r1 = (float)((int)src[sy][sx + 1] - (int)src[sy][sx - 1]);
+    const float r2 = (float)((int)src[sy + 1][sx + 1] - (int)src[sy + 1][sx - 1]);
+    const float dx = (r0 + r2) * f1 + r1 * f0;
+    float tm = f1 * (float)src[sy - 1][sx - 1];
+    tm += f0 * (float)src[sy - 1][sx];
+    tm += f1 * (float)src[sy - 1][sx + 1];
+    float tp = f1 * (float)src[sy + 1][sx - 1];
+    tp += f0 * (float)src[sy + 1][sx];
+    tp += f1 * (float)src[sy + 1][sx + 1];
+    const float dy = tp - tm;
+    cov0[cy][cx] = dx * dx;
+    cov1[cy][cx] = dx * dy;
+    cov2[cy][cx] = dy * dy;
+  }
+  __syncthreads();
+  // box 3x3 (unnormalised, double accumulation like cv::boxFilter on CV_32F) + min eigenvalue
+  for (int i = tid; i < LW_ * LHT; i += 256) {
+    const int ly = i / LW_, lx = i - ly * LW_;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    float v = 0.0f;
+    if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+      int cxs[3], cys[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        cxs[k] = reflect101(gx - 1 + k, W) - (x0 - CH);
+        cys[k] = reflect101(gy - 1 + k, H) - (y0 - CH);
+      }
+      double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          a0 += (double)cov0[cys[r]][cxs[c]];
+          a1 += (double)cov1[cys[r]][cxs[c]];
+          a2 += (double)cov2[cys[r]][cxs[c]];
+        }
+        s0 += a0;
+        s1 += a1;
+        s2 += a2;
+      }
+      const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
+      v = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    }
+    lam[ly][lx] = v;
+  }
+  __syncthreads();
+  const int nd = min(n_disc, MAX_TILE_DISCS);
+  const bool disc_overflow = n_disc > MAX_TILE_DISCS;
+  unsigned bestkey = 0;
+  const unsigned char* M = user_mask ? user_mask + (size_t)s * W * H : nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int lx = tid & 63, ly = (tid >> 6) + 4 * k;
+    const int gx = x0 + lx, gy = y0 + ly;
+    bool is_cand = false;
+    float v = 0.f;
+    if (gx < W && gy < H) {
+      v = lam[ly + 1][lx + 1];
+      bool masked_in = true;
+      if (M && M[(size_t)gy * W + gx] == 0) masked_in = false;
+      if (masked_in && use_discs) {
+        if (!disc_overflow) {
+          for (int d = 0; d < nd; d++) {
+            const int ady = abs(gy - disc_cy[d]);
+            if (ady <= radius && abs(gx - disc_cx[d]) <= hw_s[ady]) {
+              masked_in = false;
+              break;
+            }
+          }
+        } else {  // rare: more discs than LDS slots, test all keypoints
+          const float2* kp = kp_all + (size_t)s * kcap;
+          const int nk = kp_count[s];
+          for (int d = 0; d < nk; d++) {
+            const int ady = abs(gy - __float2int_rn(kp[d].y));
+            if (ady <= radius && abs(gx - __float2int_rn(kp[d].x)) <= hw_s[ady]) {
+              masked_in = false;
+              break;
+            }
+          }
+        }
+      }
+      if (masked_in) {
+        bestkey = max(bestkey, fkey(v));
+        if (v != 0.0f && gx >= 1 && gx < W - 1 && gy >= 1 && gy < H - 1) {
+          float m = v;
+#pragma unroll
+          for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) m = fmaxf(m, lam[ly + dy][lx + dx]);
+          is_cand = (v == m);
+        }
+      }
+    }
+    // wave-aggregated append
+    const unsigned long long bal = __ballot(is_cand);
+    if (bal) {
+      const int lane = tid & 63;
+      const int leader = __ffsll((long long)bal) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&cand_count[s], __popcll(bal));
+      base = __shfl(base, leader);
+      if (is_cand) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (pos < ccap)
+          cand_all[(size_t)s * ccap + pos] =
+              ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(gy * W + gx);
+      }
+    }
+  }
+  // masked maximum: wave reduce then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) bestkey = max(bestkey, (unsigned)__shfl_xor((int)bestkey, off));
+  if ((tid & 63) == 0 && bestkey) atomicMax(&maxkey[s], bestkey);
+}
+
+void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
+                   size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
+                   const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
+  hipMemsetAsync(D.cand_count, 0, sizeof(int) * P.B, st);
+  hipMemsetAsync(D.maxkey, 0, sizeof(unsigned) * P.B, st);
+  dim3 grid((P.W + TW - 1) / TW, (P.H + TH - 1) / TH, P.B);
+  hipLaunchKernelGGL(mineig_localmax_kernel, grid, dim3(256), 0, st, img, row_stride, img_stride,
+                     user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp,
+                     k.count, use_discs, S.flags, D.cand, D.cand_count, D.maxkey);
+}
+
+// =============================================================================================
+// select: one 1024-thread workgroup per stream
+// =============================================================================================
+constexpr int SEL_T = 1024;
+constexpr int MAX_CELLS = 12288;
+constexpr int LDS_SORT_CAP = 8192;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16]*/, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < SEL_T / 64; i++) {
+    const int t = wave_tot[i];
+    if (i < wv) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+// bitonic sort, descending, n = power of two, keys in LDS or global memory
+__device__ void block_bitonic_desc(unsigned long long* a, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += SEL_T) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = a[i], y = a[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, FrameTab K,
+                                                       StreamState S, DetectScratch D,
+                                                       int fixed_need) {
+  const int s = blockIdx.x;
+  if (!(S.flags[s] & FLAG_DETECT)) return;
+  extern __shared__ unsigned char lds_raw[];
+  // LDS carve-up: sortkeys [LDS_SORT_CAP] u64 | cell_start [MAX_CELLS+1] int | small
+  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(lds_raw);
+  int* cell_start = reinterpret_cast<int*>(lds_raw + sizeof(unsigned long long) * LDS_SORT_CAP);
+  __shared__ int wave_tot[SEL_T / 64];
+  __shared__ int sh_cnt, sh_flag, sh_n;
+  __shared__ int bin_cnt[MAX_BINS];
+
+  const int tid = threadIdx.x;
+  const int W = P.W, H = P.H;
+  unsigned long long* cand = D.cand + (size_t)s * P.ccap;
+  unsigned long long* work = D.sortbuf + (size_t)s * D.sort_cap;
+  unsigned int* items = D.cell_items + (size_t)s * P.ccap;
+  unsigned char* state = D.state + (size_t)s * P.ccap;
+  int overflow = 0;
+  int C = D.cand_count[s];
+  if (C > P.ccap) {
+    C = P.ccap;
+    overflow = 1;
+  }
+  // ---- quality threshold (cv::threshold THRESH_TOZERO with maxVal*qualityLevel) -------------
+  const float maxVal = fkey_inv(D.maxkey[s]);
+  const float thr = (float)((double)maxVal * P.quality);
+  if (tid == 0) sh_cnt = 0;
+  __syncthreads();
+  for (int base = 0; base < C; base += SEL_T) {
+    const int i = base + tid;
+    bool keep = false;
+    unsigned long long key = 0;
+    if (i < C) {
+      key = cand[i];
+      const float v = __uint_as_float((unsigned)(key >> 32));
+      keep = (v > thr) && (v != 0.0f);
+    }
+    int tot;
+    const int pos = block_exclusive_scan(keep ? 1 : 0, wave_tot, &tot);
+    const int off = sh_cnt;
+    if (keep) work[off + pos] = key;
+    __syncthreads();
+    if (tid == 0) sh_cnt = off + tot;
+    __syncthreads();
+  }
+  const int C2 = sh_cnt;
+  __syncthreads();
+
+  int A = 0;  // accepted corners, keys in `akeys`
+  unsigned long long* akeys = skeys;
+  const int md = P.min_distance;
+  if (md >= 1 && C2 > 0) {
+    const int cell = md;  // cvRound(minDistance) for an integer distance
+    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+    const int ncell = gw * gh;
+    if (ncell > MAX_CELLS) {
+      overflow = 1;
+    } else {
+      for (int i = tid; i <= ncell; i += SEL_T) cell_start[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < C2; i += SEL_T) {
+        const unsigned idx = (unsigned)work[i];
+        const int y = idx / W, x = idx - y * W;
+        atomicAdd(&cell_start[(y / cell) * gw + (x / cell)], 1);
+        state[i] = 0;
+      }
+      __syncthreads();
+      // exclusive scan over cells (serial chunks per thread + block scan)
+      {
+        const int per = (ncell + SEL_T - 1) / SEL_T;
+        const int b = tid * per, e = min(ncell, b + per);
+        int sum = 0;
+        for (int i = b; i < e; i++) sum += cell_start[i];
+        int tot;
+        int run = block_exclusive_scan(sum, wave_tot, &tot);
+        for (int i = b; i < e; i++) {
+          const int c = cell_start[i];
+          cell_start[i] = run;
+          run += c;
+        }
+        if (tid == 0) cell_start[ncell] = tot;
+        __syncthreads();
+      }
+      // fill: second LDS-free pass using a global cursor array would need atomics on cell_start;
+      // instead use `items` with per-cell cursors kept in the upper half of state (int view).
+      int* cursor = reinterpret_cast<int*>(items + C2 + 1);  // scratch behind the item list
+      // (cell_items has ccap entries; ncell cursors fit when C2 + 1 + ncell <= ccap, else fall back)
+      const bool cursor_ok = (long long)C2 + 1 + ncell <= (long long)P.ccap;
+      if (!cursor_ok) {
+        overflow = 1;
+      } else {
+        for (int i = tid; i < ncell; i += SEL_T) cursor[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < C2; i += SEL_T) {
+          const unsigned idx = (unsigned)work[i];
+          const int y = idx / W, x = idx - y * W;
+          const int c = (y / cell) * gw + (x / cell);
+          const int p = atomicAdd(&cursor[c], 1);
+          items[cell_start[c] + p] = (unsigned)i;
+        }
+        __syncthreads();
+        // parallel evaluation of the sequential greedy filter: a candidate is accepted iff every
+        // higher-ranked candidate closer than minDistance (searched in the 3x3 cell block, as
+        // OpenCV does) is rejected; rejected iff one of them is accepted.
+        const float md2 = (float)((double)md * (double)md);
+        volatile unsigned char* vstate = state;
+        for (int round = 0; round < 8192; round++) {
+          if (tid == 0) sh_flag = 0;
+          __syncthreads();
+          for (int i = tid; i < C2; i += SEL_T) {
+            if (vstate[i] != 0) continue;
+            const unsigned long long ki = work[i];
+            const unsigned idx = (unsigned)ki;
+            const int y = idx / W, x = idx - y * W;
+            const int xc = x / cell, yc = y / cell;
+            const int x1 = max(0, xc - 1), y1 = max(0, yc - 1);
+            const int x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
+            bool rejected = false, pending = false;
+            for (int yy = y1; yy <= y2 && !rejected; yy++)
+              for (int xx = x1; xx <= x2 && !rejected; xx++) {
+                const int c = yy * gw + xx;
+                for (int q = cell_start[c]; q < cell_start[c + 1]; q++) {
+                  const unsigned j = items[q];
+                  const unsigned long long kj = work[j];
+                  if (kj <= ki) continue;  // only higher-ranked (value desc, index desc)
+                  const unsigned jdx = (unsigned)kj;
+                  const int jy = jdx / W, jx = jdx - jy * W;
+                  const float dx = (float)(x - jx), dy = (float)(y - jy);
+                  if (dx * dx + dy * dy < md2) {
+                    const unsigned char sj = vstate[j];
+                    if (sj == 1) {
+                      rejected = true;
+                      break;
+                    }
+                    if (sj == 0) pending = true;
+                  }
+                }
+              }
+            if (rejected)
+              vstate[i] = 2;
+            else if (!pending)
+              vstate[i] = 1;
+            else
+              sh_flag = 1;
+          }
+          __syncthreads();
+          const int again = sh_flag;
+          __syncthreads();
+          if (!again) break;
+        }
+        // compact accepted keys
+        if (tid == 0) sh_cnt = 0;
+        __syncthreads();
+        for (int base = 0; base < C2; base += SEL_T) {
+          const int i = base + tid;
+          const bool acc = (i < C2) && state[i] == 1;
+          int tot;
+          const int pos = block_exclusive_scan(acc ? 1 : 0, wave_tot, &tot);
+          const int off = sh_cnt;
+          if (acc) {
+            if (off + pos < LDS_SORT_CAP) skeys[off + pos] = work[i];
+          }
+          __syncthreads();
+          if (tid == 0) sh_cnt = off + tot;
+          __syncthreads();
+        }
+        A = sh_cnt;
+        if (A > LDS_SORT_CAP) {
+          A = LDS_SORT_CAP;
+          overflow = 1;
+        }
+      }
+    }
+    // sort accepted (LDS)
+    int n2 = 1;
+    while (n2 < A) n2 <<= 1;
+    for (int i = A + tid; i < n2; i += SEL_T) skeys[i] = 0;
+    __syncthreads();
+    block_bitonic_desc(skeys, n2);
+  } else if (C2 > 0) {
+    // no minimum distance: all candidates, sorted (global memory when they do not fit in LDS)
+    int n2 = 1;
+    while (n2 < C2) n2 <<= 1;
+    if (n2 <= LDS_SORT_CAP) {
+      for (int i = tid; i < n2; i += SEL_T) skeys[i] = i < C2 ? work[i] : 0ull;
+      __syncthreads();
+      block_bitonic_desc(skeys, n2);
+    } else {
+      for (int i = C2 + tid; i < n2; i += SEL_T) work[i] = 0ull;
+      __syncthreads();
+      block_bitonic_desc(work, n2);
+      akeys = work;
+    }
+    A = C2;
+  }
+  __syncthreads();
+  int n_corners = A;
+  if (P.max_corners > 0) n_corners = min(n_corners, P.max_corners);
+  n_corners = min(n_corners, P.acap);
+  if (A > P.acap && (P.max_corners <= 0 || P.max_corners > P.acap)) overflow = 1;
+  float2* corners = D.corners + (size_t)s * P.acap;
+  for (int i = tid; i < n_corners; i += SEL_T) {
+    const unsigned idx = (unsigned)akeys[i];
+    const int y = idx / W, x = idx - y * W;
+    corners[i] = make_float2((float)x, (float)y);
+  }
+  __syncthreads();
+
+  // ---- FeatureDetector::featureDetection(Frame*) bookkeeping (FeatureDetector.cpp:101-115) ----
+  int need = fixed_need;
+  int n_existing_total = 0;
+  if (fixed_need < 0) {
+    const int cnt = K.count[s];
+    n_existing_total = cnt;
+    int local = 0;
+    for (int i = tid; i < cnt; i += SEL_T) {
+      if (K.lmk[(size_t)s * P.kcap + i] != -1) local++;
+      K.age[(size_t)s * P.kcap + i] += 1;
+    }
+    int tot;
+    block_exclusive_scan(local, wave_tot, &tot);
+    need = max(P.max_features - tot, 0);
+  }
+
+  // ---- ANMS (NonMaximumSuppression.cpp:33-169) -----------------------------------------------
+  float2* newc = D.newc + (size_t)s * P.acap;
+  int n_new = 0;
+  if (n_corners == 0) {
+    n_new = 0;
+  } else if (!P.enable_anms) {
+    for (int i = tid; i < n_corners; i += SEL_T) newc[i] = corners[i];
+    n_new = n_corners;
+  } else if (P.anms_type == 0 /* TopN: receives the UNSORTED keypoints */) {
+    n_new = need > n_corners ? n_corners : need;
+    for (int i = tid; i < n_new; i += SEL_T) newc[i] = corners[i];
+  } else {  // Binning on the cv::sortIdx-permuted keypoints
+    const unsigned short* perm = T.sortidx + T.sortidx_off[n_corners];
+    if (need > n_corners) {
+      for (int i = tid; i < n_corners; i += SEL_T) newc[i] = corners[perm[i]];
+      n_new = n_corners;
+    } else {
+      const int hb = P.hbins, vb = P.vbins;
+      const float binRowSize = (float)H / (float)vb;
+      const float binColSize = (float)W / (float)hb;
+      int active = 0;
+      for (int i = 0; i < hb * vb; i++) active += T.binning_mask[i];
+      const float nrActiveBins = (float)active;
+      const int quota = (int)roundf((float)need / nrActiveBins);
+      // bin of every permuted keypoint, kept in LDS behind the sort keys (u16)
+      unsigned short* bins = reinterpret_cast<unsigned short*>(cell_start);
+      for (int i = tid; i < n_corners; i += SEL_T) {
+        const float2 c = corners[perm[i]];
+        const long long br = (long long)(c.y / binRowSize), bc = (long long)(c.x / binColSize);
+        unsigned short b = 0xffff;
+        if (br >= 0 && br < vb && bc >= 0 && bc < hb && T.binning_mask[br * hb + bc] == 1)
+          b = (unsigned short)(br * hb + bc);
+        bins[i] = b;
+      }
+      __syncthreads();
+      if (tid == 0) sh_cnt = 0;
+      __syncthreads();
+      for (int base = 0; base < n_corners; base += SEL_T) {
+        const int i = base + tid;
+        bool keep = false;
+        if (i < n_corners) {
+          const unsigned short b = bins[i];
+          if (b != 0xffff) {
+            int rank = 0;
+            for (int q = 0; q < i; q++) rank += (bins[q] == b);
+            keep = rank < quota;
+          }
+        }
+        int tot;
+        const int pos = block_exclusive_scan(keep ? 1 : 0, wave_tot, &tot);
+        const int off = sh_cnt;
+        if (keep) newc[off + pos] = corners[perm[i]];
+        __syncthreads();
+        if (tid == 0) sh_cnt = off + tot;
+        __syncthreads();
+      }
+      n_new = sh_cnt;
+    }
+  }
+  // capacity of the frame table
+  if (fixed_need < 0 && n_existing_total + n_new > P.kcap) {
+    n_new = P.kcap - n_existing_total;
+    overflow = 1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    D.n_corners[s] = n_corners;
+    D.n_new[s] = n_new;
+    D.need[s] = need;
+    S.n_detected[s] = n_new;
+    if (overflow) S.flags[s] |= FLAG_OVERFLOW;
+  }
+}
+
+void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const StreamState& S,
+                   const DetectScratch& D, int fixed_need, hipStream_t st) {
+  const size_t lds = sizeof(unsigned long long) * LDS_SORT_CAP + sizeof(int) * (MAX_CELLS + 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need);
+}
+
+// =============================================================================================
+// cv::cornerSubPix: one wavefront per corner.
+// The five normal-equation sums are accumulated in float64 in OpenCV's row-major order (lanes 0-4
+// each own one accumulator) so results are bit-identical to the CPU path.
+// =============================================================================================
+#include "kvfe_subpix.inl"
+
+// cv::undistortPoints of one pixel (double), shared with k_stereo.hip via kvfe_undistort.inl
+#include "kvfe_undistort.inl"
+
+__global__ __launch_bounds__(64) void subpix_append_kernel(KParams P, Tables T,
+                                                           const unsigned char* __restrict__ img,
+                                                           size_t row_stride, size_t img_stride,
+                                                           FrameTab K, StreamState S,
+                                                           DetectScratch D, int append) {
+  const int s = blockIdx.y, ci = blockIdx.x;
+  if (!(S.flags[s] & FLAG_DETECT)) return;
+  const int n_new = D.n_new[s];
+  if (ci >= n_new) return;
+  extern __shared__ unsigned char lds_raw[];
+  const int ww = 2 * P.subpix_win + 1, pw = ww + 2;
+  double* terms = reinterpret_cast<double*>(lds_raw);
+  float* patch = reinterpret_cast<float*>(lds_raw + sizeof(double) * 5 * ww * ww);
+  (void)pw;
+  const int lane = threadIdx.x;
+  float2 c = D.newc[(size_t)s * P.acap + ci];
+  if (P.subpix_enable) {
+    c = corner_subpix_wave(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
+                           P.subpix_iters, P.subpix_eps2, T.subpix_mask, patch, terms, lane);
+  }
+  if (lane == 0) {
+    if (append) {
+      const int base = S.n_tracked[s];
+      const size_t o = (size_t)s * P.kcap + base + ci;
+      K.kp[o] = c;
+      K.lmk[o] = S.lmk_counter[s] + ci;
+      K.age[o] = 1;
+      double v[3];
+      bearing_vector(T.und_left_R, c.x, c.y, v);
+      K.versor[o * 3] = v[0];
+      K.versor[o * 3 + 1] = v[1];
+      K.versor[o * 3 + 2] = v[2];
+    } else {
+      D.newc[(size_t)s * P.acap + ci] = c;
+    }
+  }
+}
+
+// after the append: counts and the per-stream landmark-id counter
+__global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P.B) return;
+  if (!(S.flags[s] & FLAG_DETECT)) return;
+  const int n_new = D.n_new[s];
+  K.count[s] = S.n_tracked[s] + n_new;
+  S.lmk_counter[s] += n_new;
+}
+
+void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
+                          size_t row_stride, size_t img_stride, const FrameTab& k,
+                          const StreamState& S, const DetectScratch& D, int append,
+                          hipStream_t st) {
+  const int ww = 2 * P.subpix_win + 1;
+  const size_t lds = sizeof(double) * 5 * ww * ww + sizeof(float) * (ww + 2) * (ww + 2);
+  int bound = P.max_corners > 0 ? P.max_corners : P.acap;
+  if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
+    bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
+  bound = min(bound, P.acap);
+  hipLaunchKernelGGL(subpix_append_kernel, dim3(bound, P.B), dim3(64), lds, st, P, T, img,
+                     row_stride, img_stride, k, S, D, append);
+  if (append)
+    hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D);
+}
+
+__global__ __launch_bounds__(64) void subpix_points_kernel(const float* __restrict__ mask,
+                                                           const unsigned char* __restrict__ img,
+                                                           size_t row_stride, int W, int H,
+                                                           float2* pts, int n, int win,
+                                                           int max_iters, double eps2) {
+  const int ci = blockIdx.x;
+  if (ci >= n) return;
+  extern __shared__ unsigned char lds_raw[];
+  const int ww = 2 * win + 1;
+  double* terms = reinterpret_cast<double*>(lds_raw);
+  float* patch = reinterpret_cast<float*>(lds_raw + sizeof(double) * 5 * ww * ww);
+  const float2 c = corner_subpix_wave(img, row_stride, W, H, pts[ci], win, max_iters, eps2, mask,
+                                      patch, terms, threadIdx.x);
+  if (threadIdx.x == 0) pts[ci] = c;
+}
+
+void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigned char* img,
+                          size_t row_stride, int W, int H, float2* pts, int n, int win,
+                          int max_iters, double eps2, hipStream_t st) {
+  if (n <= 0) return;
+  const int ww = 2 * win + 1;
+  const size_t lds = sizeof(double) * 5 * ww * ww + sizeof(float) * (ww + 2) * (ww + 2);
+  hipLaunchKernelGGL(subpix_points_kernel, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
+                     W, H, pts, n, win, max_iters, eps2);
+}
+
+__global__ void undistort_points_kernel(UndistortDev U, const float2* __restrict__ in, int n,
+                                        float2* out, double* versors) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float2 p = in[i];
+  if (out) {
+    float ox, oy;
+    undistort_point_dev(U, p.x, p.y, &ox, &oy);
+    out[i] = make_float2(ox, oy);
+  }
+  if (versors) bearing_vector(U, p.x, p.y, versors + (size_t)i * 3);
+}
+
+void launch_undistort_points(const UndistortDev& U, const float2* in, int n, float2* out,
+                             double* versors, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(undistort_points_kernel, dim3((n + 63) / 64), dim3(64), 0, st, U, in, n, out,
+                     versors);
+}
+
+}  // namespace kvfe

@@ -1,0 +1,299 @@
+// K7 + K5  sparse stereo:  StereoMatcher::sparseStereoReconstruction (src/frontend/StereoMatcher.cpp:123-175)
+//   undistortRectifyLeftKeypoints  (StereoCamera.cpp:236-260, UndistorterRectifier.cpp:138-211)
+//   getRightKeypointsRectified / searchRightKeypointEpipolar (StereoMatcher.cpp:196-423):
+//     cv::matchTemplate(TM_SQDIFF) + normalize + minMaxLoc == exact integer SSD + first argmin
+//   getDepthFromRectifiedMatches (StereoMatcher.cpp:425-483)
+//   distortUnrectifyRightKeypoints (UndistorterRectifier.cpp:213-228), keypoints_3d_ (:157-174)
+// and the end-of-frame bookkeeping of StereoVisionImuFrontend::processStereoFrame (:448-475) /
+// getSmartStereoMeasurements (:485-531).
+//
+// One wavefront per keypoint: template and stripe rows are staged in LDS, every lane owns a set
+// of horizontal offsets and accumulates an exact int32 SSD; a 64-bit (ssd, offset) min-reduction
+// by wave shuffles returns the first minimum, as cv::minMaxLoc does.
+#include "kvfe_dev.hpp"
+
+namespace kvfe {
+
+#include "kvfe_undistort.inl"
+
+#include "kvfe_subpix.inl"
+
+__global__ void stereo_left_kernel(KParams P, Tables T, FrameTab K, StereoTab ST, StreamState S,
+                                   int act_flag) {
+  const int s = blockIdx.y;
+  if (!(S.flags[s] & act_flag)) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K.count[s]) return;
+  const size_t o = (size_t)s * P.kcap + i;
+  const float2 d = K.kp[o];
+  float ux, uy;
+  undistort_point_dev(T.und_left_RP, d.x, d.y, &ux, &uy);
+  // cropToSize (UtilsOpenCV.cpp:215-235)
+  bool cropped = false;
+  const float maxw = (float)(P.W - 1), maxh = (float)(P.H - 1);
+  if (ux > maxw) {
+    ux = maxw;
+    cropped = true;
+  } else if (ux < 0.0f) {
+    ux = 0.0f;
+    cropped = true;
+  }
+  if (uy > maxh) {
+    uy = maxh;
+    cropped = true;
+  } else if (uy < 0.0f) {
+    uy = 0.0f;
+    cropped = true;
+  }
+  const int ry = (int)roundf(uy), rx = (int)roundf(ux);
+  const float2 e = T.map[0][(size_t)ry * P.W + rx];
+  unsigned char status = 0;
+  if (cropped)
+    status = 1;  // NO_LEFT_RECT
+  else if (fabsf(d.x - e.x) > 2.0f || fabsf(d.y - e.y) > 2.0f)
+    status = 1;
+  ST.left_rect[o] = make_float2(ux, uy);
+  ST.left_status[o] = status;
+}
+
+// core of searchRightKeypointEpipolar for one keypoint, executed by one wavefront
+__device__ void match_one(const KParams& P, const Tables& T, const unsigned char* __restrict__ L,
+                          const unsigned char* __restrict__ R, float2 lkp, unsigned char* lds,
+                          int lane, float2* out_kp, int* out_status, double* out_score) {
+  const int W = P.W, H = P.H, tc = P.templ_cols, tr = P.templ_rows, sc = P.stripe_cols,
+            sr = P.stripe_rows;
+  const int rx = (int)roundf(lkp.x), ry = (int)roundf(lkp.y);
+  int temp_corner_y = ry - (tr - 1) / 2;
+  if (temp_corner_y < 0 || temp_corner_y + tr > H - 1) {
+    *out_score = -1.0;
+    *out_status = 2;  // NO_RIGHT_RECT
+    *out_kp = make_float2(0.f, 0.f);
+    return;
+  }
+  int offset_temp = 0;
+  int temp_corner_x = rx - (tc - 1) / 2;
+  if (temp_corner_x < 0) {
+    offset_temp = temp_corner_x;
+    temp_corner_x = 0;
+  }
+  if (temp_corner_x + tc > W - 1) {
+    offset_temp = (temp_corner_x + tc) - (W - 1);
+    temp_corner_x -= offset_temp;
+  }
+  const int stripe_corner_y = ry - (sr - 1) / 2;
+  if (stripe_corner_y < 0 || stripe_corner_y + sr > H - 1) {
+    *out_score = -1.0;
+    *out_status = 2;
+    *out_kp = make_float2(0.f, 0.f);
+    return;
+  }
+  int stripe_corner_x = rx + (tc - 1) / 2 - sc;
+  if (stripe_corner_x + sc > W - 1) {
+    const int offset_stripe = (stripe_corner_x + sc) - (W - 1);
+    stripe_corner_x -= offset_stripe;
+  }
+  if (stripe_corner_x < 0) stripe_corner_x = 0;
+
+  unsigned char* tpl = lds;               // tr x tc
+  unsigned char* stp = lds + tr * tc;     // sr x sc
+  for (int e = lane; e < tr * tc; e += 64) {
+    const int y = e / tc, x = e - y * tc;
+    tpl[e] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
+  }
+  for (int e = lane; e < sr * sc; e += 64) {
+    const int y = e / sc, x = e - y * sc;
+    stp[e] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
+  }
+  __syncthreads();
+  const int rw = sc - tc + 1, rh = sr - tr + 1;
+  unsigned long long best = ~0ull;
+  for (int o = lane; o < rw * rh; o += 64) {
+    const int oy = o / rw, ox = o - oy * rw;
+    unsigned ssd = 0;
+    for (int y = 0; y < tr; y++) {
+      const unsigned char* a = tpl + y * tc;
+      const unsigned char* b = stp + (oy + y) * sc + ox;
+      for (int x = 0; x < tc; x++) {
+        const int d = (int)a[x] - (int)b[x];
+        ssd += (unsigned)(d * d);
+      }
+    }
+    const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)o;
+    best = key < best ? key : best;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long other = __shfl_xor(best, off);
+    best = other < best ? other : best;
+  }
+  __syncthreads();
+  const int o = (int)(unsigned)best;
+  const int by = o / rw, bx = o - by * rw;
+  const int mx = bx + stripe_corner_x + (tc - 1) / 2 + offset_temp;
+  const int my = by + stripe_corner_y + (tr - 1) / 2;
+  float2 match = make_float2((float)mx, (float)my);
+  if (P.stereo_subpix) {  // cv::cornerSubPix(right_rectified, (10,10), (-1,-1), 40 it, 0.001)
+    double* terms = reinterpret_cast<double*>(lds + ((tr * tc + sr * sc + 15) & ~15));
+    float* patch = reinterpret_cast<float*>(terms + 5 * 21 * 21);
+    match = corner_subpix_wave(R, (size_t)W, W, H, match, 10, 40, 0.001 * 0.001, T.subpix_mask10,
+                               patch, terms, lane);
+  }
+  const double min_val = 0.0;  // normalised minimum (cv::normalize MINMAX) is always 0
+  *out_score = min_val;
+  *out_status = (min_val < P.tol_template) ? 0 : 2;
+  *out_kp = match;
+}
+
+__global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
+                                                          const unsigned char* __restrict__ Lr,
+                                                          const unsigned char* __restrict__ Rr,
+                                                          FrameTab K, StereoTab ST, StreamState S,
+                                                          int act_flag) {
+  const int s = blockIdx.y, i = blockIdx.x;
+  if (!(S.flags[s] & act_flag)) return;
+  if (i >= K.count[s]) return;
+  extern __shared__ unsigned char lds_raw[];
+  const int lane = threadIdx.x;
+  const size_t o = (size_t)s * P.kcap + i;
+  const unsigned char* L = Lr + (size_t)s * P.W * P.H;
+  const unsigned char* R = Rr + (size_t)s * P.W * P.H;
+  const int lstatus = ST.left_status[o];
+  const float2 lkp = ST.left_rect[o];
+  float2 rkp = make_float2(0.f, 0.f);
+  int rstatus = lstatus;
+  double score = -1.0;
+  if (lstatus == 0) match_one(P, T, L, R, lkp, lds_raw, lane, &rkp, &rstatus, &score);
+  if (lane != 0) return;
+  // getDepthFromRectifiedMatches (StereoMatcher.cpp:425-483)
+  double depth = 0.0;
+  if (lstatus == 0 && rstatus == 0) {
+    const double disparity = (double)(lkp.x - rkp.x);
+    if (disparity >= 0.0) {
+      const double d = (P.fx_rect * P.baseline) / disparity;
+      if (d < P.min_point_dist || d > P.max_point_dist)
+        rstatus = 3;  // NO_DEPTH
+      else
+        depth = d;
+    } else {
+      rstatus = 3;
+    }
+  } else if (lstatus != 0 && rstatus != lstatus) {
+    rstatus = lstatus;
+  }
+  ST.right_rect[o] = rkp;
+  ST.right_status[o] = (unsigned char)rstatus;
+  ST.depth[o] = depth;
+  // distortUnrectifyKeypoints (UndistorterRectifier.cpp:213-228)
+  float2 rraw = make_float2(0.f, 0.f);
+  if (rstatus == 0) {
+    const int yy = (int)roundf(rkp.y), xx = (int)roundf(rkp.x);
+    rraw = T.map[1][(size_t)yy * P.W + xx];
+  }
+  ST.right_kp[o] = rraw;
+  // keypoints_3d_ (StereoMatcher.cpp:157-174)
+  double x3 = 0, y3 = 0, z3 = 0;
+  if (rstatus == 0) {
+    const double* v = K.versor + o * 3;
+    x3 = v[0] * depth / v[2];
+    y3 = v[1] * depth / v[2];
+    z3 = v[2] * depth / v[2];
+  }
+  ST.kp3d[o * 3] = x3;
+  ST.kp3d[o * 3 + 1] = y3;
+  ST.kp3d[o * 3 + 2] = z3;
+}
+
+static size_t stereo_lds_bytes(const KParams& P) {
+  size_t b = (size_t)P.templ_rows * P.templ_cols + (size_t)P.stripe_rows * P.stripe_cols;
+  b = (b + 15) & ~(size_t)15;
+  if (P.stereo_subpix) b += sizeof(double) * 5 * 21 * 21 + sizeof(float) * 23 * 23;
+  return b;
+}
+
+void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_rect,
+                   const unsigned char* right_rect, const FrameTab& k, const StereoTab& ST,
+                   const StreamState& S, int act_flag, hipStream_t st) {
+  hipLaunchKernelGGL(stereo_left_kernel, dim3((P.kcap + 63) / 64, P.B), dim3(64), 0, st, P, T, k,
+                     ST, S, act_flag);
+  hipLaunchKernelGGL(stereo_match_kernel, dim3(P.kcap, P.B), dim3(64), stereo_lds_bytes(P), st, P,
+                     T, left_rect, right_rect, k, ST, S, act_flag);
+}
+
+__global__ __launch_bounds__(64) void stereo_match_only_kernel(
+    KParams P, Tables T, const unsigned char* __restrict__ L, const unsigned char* __restrict__ R,
+    const float2* __restrict__ lkps, const unsigned char* __restrict__ lstat, int n,
+    float2* rkps, unsigned char* rstat, double* scores) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  extern __shared__ unsigned char lds_raw[];
+  float2 rkp = make_float2(0.f, 0.f);
+  int rstatus = lstat[i];
+  double score = -1.0;
+  if (rstatus == 0) match_one(P, T, L, R, lkps[i], lds_raw, threadIdx.x, &rkp, &rstatus, &score);
+  if (threadIdx.x == 0) {
+    rkps[i] = rkp;
+    rstat[i] = (unsigned char)rstatus;
+    if (scores) scores[i] = score;
+  }
+}
+
+void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned char* left_rect,
+                              const unsigned char* right_rect, const float2* left_rect_kp,
+                              const unsigned char* left_status, int n, float2* right_rect_kp,
+                              unsigned char* right_status, double* score, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(stereo_match_only_kernel, dim3(n), dim3(64), stereo_lds_bytes(P), st, P, T,
+                     left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
+                     right_status, score);
+}
+
+// ---------------------------------------------------------------------------------------------
+// end of frame
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab K, FrameTab LKF,
+                                                            StereoTab ST, StreamState S) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const size_t so = (size_t)s * P.kcap;
+  const int flags = S.flags[s];
+  const int n = K.count[s];
+  if (flags & FLAG_KEYFRAME) {
+    // getSmartStereoMeasurements: every landmark of a frame is valid here (ids are never -1
+    // in the current frame), so the measurement list is the keypoint list.
+    const bool first = (flags & FLAG_FIRST) != 0;  // bootstrapSpinStereo returns no measurements
+    for (int i = tid; i < n; i += 256) {
+      // stereoFrame_lkf_ = stereoFrame_k_
+      LKF.kp[so + i] = K.kp[so + i];
+      LKF.lmk[so + i] = K.lmk[so + i];
+      if (first) continue;
+      const float2 l = ST.left_rect[so + i];
+      double uR = __longlong_as_double(0x7ff8000000000000LL);  // quiet NaN
+      if (P.use_stereo_tracking && ST.right_status[so + i] == 0) uR = (double)ST.right_rect[so + i].x;
+      S.meas_lmk[so + i] = K.lmk[so + i];
+      S.meas_uLuRv[(so + i) * 3] = (double)l.x;
+      S.meas_uLuRv[(so + i) * 3 + 1] = uR;
+      S.meas_uLuRv[(so + i) * 3 + 2] = (double)l.y;
+    }
+    if (tid == 0) {
+      LKF.count[s] = n;
+      LKF.timestamp[s] = K.timestamp[s];
+      S.n_meas[s] = first ? 0 : n;
+    }
+    if (tid < 9) S.kf_R_ref[(size_t)s * 9 + tid] = (tid % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    if (tid == 0) S.n_meas[s] = 0;
+    // non-keyframe of the normal path: keyframe_R_ref_frame_ = keyframe_R_cur_frame; the
+    // "all tracks lost" early return (StereoVisionImuFrontend.cpp:313-323) leaves it untouched.
+    if ((flags & FLAG_INIT) && !(flags & FLAG_DETECT) && tid < 9)
+      S.kf_R_ref[(size_t)s * 9 + tid] = S.kf_R_cur[(size_t)s * 9 + tid];
+  }
+  if (tid == 0) {
+    S.frame_count[s] += 1;
+    S.flags[s] = flags | FLAG_INIT;
+  }
+}
+
+void launch_step_finalize(const KParams& P, const FrameTab& k, const FrameTab& lkf,
+                          const StereoTab& ST, const StreamState& S, hipStream_t st) {
+  hipLaunchKernelGGL(step_finalize_kernel, dim3(P.B), dim3(256), 0, st, P, k, lkf, ST, S);
+}
+
+}  // namespace kvfe

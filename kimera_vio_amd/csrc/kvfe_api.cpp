@@ -1,0 +1,1102 @@
+// libkvfe C ABI (include/kvfe.h): context management, buffer layout in HBM, and the host-side
+// orchestration that mirrors StereoVisionImuFrontend::processFirstStereoFrame / processStereoFrame
+// (src/frontend/StereoVisionImuFrontend.cpp:245-481) by enqueuing the HIP kernels of k_*.hip on one
+// stream.  No step of a frame needs the host: keyframe decisions, list compaction and landmark-id
+// assignment all happen on the device, so `batch` streams advance in lock-step per launch.
+// There is NO CPU fallback: without a gfx950 device kvfe_create fails with KVFE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kvfe.h"
+#include "host_calib.hpp"
+#include "kvfe_dev.hpp"
+
+using namespace kvfe;
+
+namespace {
+
+constexpr int ACAP = 8192;  // accepted-corner capacity (LDS sort capacity of the select kernel)
+
+enum Stage {
+  ST_PYRAMID = 0,
+  ST_TRACK,
+  ST_TRACK_FINALIZE,
+  ST_MINEIG,
+  ST_SELECT,
+  ST_SUBPIX,
+  ST_RECTIFY,
+  ST_STEREO,
+  ST_FINALIZE,
+  ST_COUNT
+};
+const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "mineig_localmax",
+                                     "gftt_select", "subpix_append", "rectify", "stereo_match",
+                                     "step_finalize"};
+
+struct Buffers {  // everything that scales with the number of streams
+  int B = 0;
+  unsigned char* rect[2] = {nullptr, nullptr};
+  unsigned char* pyr[2] = {nullptr, nullptr};
+  unsigned char* raw_left[2] = {nullptr, nullptr};  // ctx-owned copies (host-input path)
+  unsigned char* raw_right = nullptr;
+  unsigned char* user_mask = nullptr;
+  FrameTab ft[3];
+  StereoTab st;
+  StreamState ss;
+  DetectScratch ds;
+  LkScratch lk;
+  double* kf_R_cur = nullptr;
+  long long* in_ts = nullptr;
+  int* in_force = nullptr;
+};
+
+}  // namespace
+
+struct kvfe_ctx {
+  kvfe_config cfg;
+  KParams P;
+  Tables T;
+  kvfe_rectification rect;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<void*> allocs;
+  std::vector<void*> host_allocs;
+  Buffers fe;    // front-end (batch streams)
+  Buffers comp;  // component API (one stream), allocated lazily
+  KParams Pc;    // KParams with B = 1 for the component API
+  bool comp_ready = false;
+  int role_k = 0, role_km1 = 1, role_lkf = 2;
+  int pyr_cur = 0;
+  const unsigned char* prev_left = nullptr;
+  size_t prev_row_stride = 0, prev_img_stride = 0;
+  int raw_slot = 0;
+  int pts_bound = 0;
+  // pinned input staging ring
+  static constexpr int RING = 8;
+  unsigned char* ring_host[RING] = {};
+  hipEvent_t ring_ev[RING] = {};
+  bool ring_used[RING] = {};
+  int ring_pos = 0;
+  size_t ring_bytes = 0;
+  // device-side tables
+  UndistortDev und[2][4];  // [cam][useR + 2*useP]
+  std::vector<float> h_map[2][2];  // host copies of the maps [cam][x|y]
+  // profiling
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;  // (ST_COUNT + 1) events per recorded step
+  std::vector<int> prof_pending;
+  double prof_ms[ST_COUNT] = {};
+  int prof_samples = 0;
+  std::string last_error;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      return KVFE_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+template <typename T>
+kvfe_status dalloc(kvfe_ctx* c, T** p, size_t n, bool zero = true) {
+  void* q = nullptr;
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  HIPCHK(c, hipMalloc(&q, bytes));
+  c->allocs.push_back(q);
+  if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
+  *p = reinterpret_cast<T*>(q);
+  return KVFE_OK;
+}
+
+#define TRY(expr)                      \
+  do {                                 \
+    kvfe_status _s = (expr);           \
+    if (_s != KVFE_OK) return _s;      \
+  } while (0)
+
+kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
+  b.B = P.B;
+  const size_t N = (size_t)P.W * P.H, B = P.B, K = (size_t)P.kcap * B;
+  for (int i = 0; i < 2; i++) {
+    TRY(dalloc(c, &b.rect[i], N * B));
+    TRY(dalloc(c, &b.pyr[i], (size_t)P.pyr_stride * B));
+    TRY(dalloc(c, &b.raw_left[i], N * B));
+  }
+  TRY(dalloc(c, &b.raw_right, N * B));
+  for (int i = 0; i < 3; i++) {
+    TRY(dalloc(c, &b.ft[i].kp, K));
+    TRY(dalloc(c, &b.ft[i].lmk, K));
+    TRY(dalloc(c, &b.ft[i].age, K));
+    TRY(dalloc(c, &b.ft[i].versor, K * 3));
+    TRY(dalloc(c, &b.ft[i].count, B));
+    TRY(dalloc(c, &b.ft[i].timestamp, B));
+  }
+  TRY(dalloc(c, &b.st.left_rect, K));
+  TRY(dalloc(c, &b.st.left_status, K));
+  TRY(dalloc(c, &b.st.right_rect, K));
+  TRY(dalloc(c, &b.st.right_status, K));
+  TRY(dalloc(c, &b.st.depth, K));
+  TRY(dalloc(c, &b.st.right_kp, K));
+  TRY(dalloc(c, &b.st.kp3d, K * 3));
+  TRY(dalloc(c, &b.ss.flags, B));
+  TRY(dalloc(c, &b.ss.n_tracked, B));
+  TRY(dalloc(c, &b.ss.n_detected, B));
+  TRY(dalloc(c, &b.ss.n_meas, B));
+  TRY(dalloc(c, &b.ss.lmk_counter, B));
+  TRY(dalloc(c, &b.ss.frame_count, B));
+  TRY(dalloc(c, &b.ss.kf_R_ref, B * 9));
+  TRY(dalloc(c, &b.kf_R_cur, B * 9));
+  TRY(dalloc(c, &b.in_ts, B));
+  TRY(dalloc(c, &b.in_force, B));
+  b.ss.kf_R_cur = b.kf_R_cur;
+  b.ss.in_timestamp = b.in_ts;
+  b.ss.in_force_kf = b.in_force;
+  TRY(dalloc(c, &b.ss.meas_lmk, K));
+  TRY(dalloc(c, &b.ss.meas_uLuRv, K * 3));
+  int sort_cap = 1;
+  while (sort_cap < P.ccap) sort_cap <<= 1;
+  b.ds.sort_cap = sort_cap;
+  TRY(dalloc(c, &b.ds.cand, (size_t)P.ccap * B));
+  TRY(dalloc(c, &b.ds.cand_count, B));
+  TRY(dalloc(c, &b.ds.maxkey, B));
+  TRY(dalloc(c, &b.ds.corners, (size_t)P.acap * B));
+  TRY(dalloc(c, &b.ds.n_corners, B));
+  TRY(dalloc(c, &b.ds.newc, (size_t)P.acap * B));
+  TRY(dalloc(c, &b.ds.n_new, B));
+  TRY(dalloc(c, &b.ds.need, B));
+  TRY(dalloc(c, &b.ds.cell_items, (size_t)P.ccap * B));
+  TRY(dalloc(c, &b.ds.state, (size_t)P.ccap * B));
+  TRY(dalloc(c, &b.ds.sortbuf, (size_t)sort_cap * B));
+  TRY(dalloc(c, &b.lk.prev_pts, K));
+  TRY(dalloc(c, &b.lk.next_pts, K));
+  TRY(dalloc(c, &b.lk.status, K));
+  TRY(dalloc(c, &b.lk.err, K));
+  TRY(dalloc(c, &b.lk.npts, B));
+  // keyframe_R_ref_frame_ = identity
+  std::vector<double> eye(B * 9, 0.0);
+  for (size_t s = 0; s < B; s++) eye[s * 9] = eye[s * 9 + 4] = eye[s * 9 + 8] = 1.0;
+  HIPCHK(c, hipMemcpyAsync(b.ss.kf_R_ref, eye.data(), sizeof(double) * B * 9,
+                           hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KVFE_OK;
+}
+
+UndistortDev to_dev(const UndistortCtx& u) {
+  UndistortDev d;
+  d.fx = u.fx;
+  d.fy = u.fy;
+  d.cx = u.cx;
+  d.cy = u.cy;
+  d.ifx = u.ifx;
+  d.ify = u.ify;
+  for (int i = 0; i < 8; i++) d.k[i] = u.k[i];
+  for (int i = 0; i < 9; i++) d.RR[i] = u.RR.m[i];
+  d.has_dist = u.has_dist ? 1 : 0;
+  d.pad = 0;
+  return d;
+}
+
+void subpix_mask_table(int win, int zero_zone, std::vector<float>& m) {
+  // cv::cornerSubPix weight mask (float exp from the host libm, as the reference computes it)
+  const int ww = 2 * win + 1;
+  m.resize((size_t)ww * ww);
+  for (int i = 0; i < ww; i++) {
+    float y = (float)(i - win) / win;
+    float vy = std::exp(-y * y);
+    for (int j = 0; j < ww; j++) {
+      float x = (float)(j - win) / win;
+      m[i * ww + j] = (float)(vy * std::exp(-x * x));
+    }
+  }
+  if (zero_zone >= 0 && zero_zone * 2 + 1 < ww) {
+    for (int i = win - zero_zone; i <= win + zero_zone; i++)
+      for (int j = win - zero_zone; j <= win + zero_zone; j++) m[i * ww + j] = 0;
+  }
+}
+
+void matx33f_inv(const float* a, float* b) {  // cv::Matx33f::inv() (direct formula, float)
+  auto A = [&](int r, int c) { return a[r * 3 + c]; };
+  float d = A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) -
+            A(0, 1) * (A(1, 0) * A(2, 2) - A(2, 0) * A(1, 2)) +
+            A(0, 2) * (A(1, 0) * A(2, 1) - A(2, 0) * A(1, 1));
+  d = 1 / d;
+  b[0] = (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) * d;
+  b[1] = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) * d;
+  b[2] = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) * d;
+  b[3] = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) * d;
+  b[4] = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) * d;
+  b[5] = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) * d;
+  b[6] = (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0)) * d;
+  b[7] = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) * d;
+  b[8] = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) * d;
+}
+
+kvfe_status validate(const kvfe_config* cfg, std::string* why) {
+  const kvfe_frontend_params& p = cfg->params;
+  auto fail = [&](const char* m, kvfe_status s) {
+    *why = m;
+    return s;
+  };
+  if (cfg->batch < 1) return fail("batch must be >= 1", KVFE_ERR_INVALID_ARG);
+  if (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height)
+    return fail("left/right image sizes differ", KVFE_ERR_INVALID_ARG);
+  if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
+  if (p.use_ransac)
+    return fail("useRANSAC=1: geometric outlier rejection is outside this library (set 0)",
+                KVFE_ERR_UNSUPPORTED);
+  const kvfe_detector_params& d = p.detector;
+  if (d.feature_detector_type != KVFE_DET_GFTT)
+    return fail("only the GFTT detector is implemented", KVFE_ERR_UNSUPPORTED);
+  if (d.use_harris_detector) return fail("Harris response is not implemented", KVFE_ERR_UNSUPPORTED);
+  if (d.block_size != 3) return fail("block_size must be 3", KVFE_ERR_UNSUPPORTED);
+  if (d.enable_non_max_suppression && d.non_max_suppression_type != KVFE_ANMS_TOPN &&
+      d.non_max_suppression_type != KVFE_ANMS_BINNING)
+    return fail("ANMS type not implemented on device (TopN and Binning are)", KVFE_ERR_UNSUPPORTED);
+  if (d.min_distance < 0 || d.min_distance > MAX_RADIUS)
+    return fail("min_distance out of range [0,127]", KVFE_ERR_INVALID_ARG);
+  if (d.max_nr_keypoints_before_anms > ACAP)
+    return fail("max_nr_keypoints_before_anms > 8192", KVFE_ERR_UNSUPPORTED);
+  if (d.nr_horizontal_bins * d.nr_vertical_bins > KVFE_MAX_BINS || d.nr_horizontal_bins < 1 ||
+      d.nr_vertical_bins < 1)
+    return fail("bad bin grid", KVFE_ERR_INVALID_ARG);
+  if (d.max_features_per_frame < 1) return fail("maxFeaturesPerFrame < 1", KVFE_ERR_INVALID_ARG);
+  if (d.enable_subpixel_corner_refinement && (d.subpix_window_size < 1 || d.subpix_window_size > 15))
+    return fail("subpixel window_size out of range [1,15]", KVFE_ERR_INVALID_ARG);
+  const kvfe_tracker_params& t = p.tracker;
+  if (t.klt_win_size < 3 || t.klt_win_size > 40) return fail("klt_win_size out of range", KVFE_ERR_INVALID_ARG);
+  if (t.klt_max_iter < 1 || t.klt_max_level < 0 || !(t.klt_eps > 0))
+    return fail("bad KLT termination parameters", KVFE_ERR_INVALID_ARG);
+  const kvfe_stereo_params& s = p.stereo;
+  if (s.templ_cols % 2 != 1 || s.templ_rows % 2 != 1 || s.templ_cols < 3 || s.templ_rows < 1)
+    return fail("template size must be odd", KVFE_ERR_INVALID_ARG);
+  if (s.stripe_extra_rows % 2 != 0 || s.stripe_extra_rows < 0)
+    return fail("stripe_extra_rows must be even", KVFE_ERR_INVALID_ARG);
+  if (!(s.min_point_dist > 0)) return fail("minPointDist must be > 0", KVFE_ERR_INVALID_ARG);
+  if (s.templ_cols > cfg->left.width || s.templ_rows + s.stripe_extra_rows > cfg->left.height)
+    return fail("template larger than image", KVFE_ERR_INVALID_ARG);
+  return KVFE_OK;
+}
+
+kvfe_status fill_params(kvfe_ctx* c) {
+  const kvfe_config& cfg = c->cfg;
+  const kvfe_frontend_params& p = cfg.params;
+  KParams& P = c->P;
+  std::memset(&P, 0, sizeof(P));
+  P.W = cfg.left.width;
+  P.H = cfg.left.height;
+  P.B = cfg.batch;
+  const kvfe_detector_params& d = p.detector;
+  P.max_features = d.max_features_per_frame;
+  P.enable_anms = d.enable_non_max_suppression;
+  P.anms_type = d.non_max_suppression_type;
+  P.min_distance = d.min_distance;
+  P.max_corners = d.max_nr_keypoints_before_anms;
+  P.hbins = d.nr_horizontal_bins;
+  P.vbins = d.nr_vertical_bins;
+  P.block_size = d.block_size;
+  P.subpix_enable = d.enable_subpixel_corner_refinement;
+  P.subpix_win = d.subpix_window_size;
+  P.subpix_zero = d.subpix_zero_zone;
+  P.subpix_iters = std::min(std::max(d.subpix_max_iters, 1), 100);
+  P.sortidx_policy = d.sortidx_policy;
+  P.quality = d.quality_level;
+  {
+    double e = std::max(d.subpix_epsilon, 0.);
+    P.subpix_eps2 = e * e;
+  }
+  const kvfe_tracker_params& t = p.tracker;
+  P.klt_win = t.klt_win_size;
+  P.klt_iters = std::min(std::max(t.klt_max_iter, 0), 100);
+  P.max_age = t.max_feature_track_age;
+  P.predictor = t.optical_flow_predictor_type;
+  {
+    double e = std::min(std::max(t.klt_eps, 0.), 10.);
+    P.klt_eps2 = e * e;
+  }
+  P.disparity_thr = t.disparity_threshold;
+  const kvfe_stereo_params& s = p.stereo;
+  P.templ_cols = s.templ_cols;
+  P.templ_rows = s.templ_rows;
+  P.stereo_subpix = s.subpixel_refinement;
+  P.use_stereo_tracking = p.use_stereo_tracking;
+  P.min_point_dist = s.min_point_dist;
+  P.max_point_dist = s.max_point_dist;
+  P.tol_template = s.tolerance_template_matching;
+  P.fx_rect = c->rect.P1[0];
+  P.baseline = c->rect.baseline;
+  // StereoMatcher::getRightKeypointsRectified (StereoMatcher.cpp:214-231)
+  P.stripe_rows = s.templ_rows + s.stripe_extra_rows;
+  int stripe_cols = (int)std::round(P.fx_rect * P.baseline / s.min_point_dist) + s.templ_cols + 4;
+  if (stripe_cols % 2 != 1) stripe_cols += 1;
+  if (stripe_cols > P.W) stripe_cols = P.W;
+  P.stripe_cols = stripe_cols;
+  P.min_kf_ns = p.min_intra_keyframe_time_ns;
+  P.max_kf_ns = p.max_intra_keyframe_time_ns;
+  P.max_disp_lkf = p.max_disparity_since_lkf;
+  P.min_features = p.min_number_features;
+  // pyramid geometry (cv::buildOpticalFlowPyramid: stop when a level is <= the window)
+  int w = P.W, h = P.H, off = 0, nl = 0;
+  for (int l = 0; l <= t.klt_max_level && l < MAX_LEVELS; l++) {
+    P.lw[l] = w;
+    P.lh[l] = h;
+    P.loff[l] = l == 0 ? 0 : off;
+    if (l > 0) off += ((w * h + 63) / 64) * 64;
+    nl = l + 1;
+    w = (w + 1) / 2;
+    h = (h + 1) / 2;
+    if (w <= P.klt_win || h <= P.klt_win) break;
+  }
+  P.nlevels = nl;
+  P.klt_maxlevel = nl - 1;
+  P.pyr_stride = std::max(off, 64);
+  P.acap = ACAP;
+  const size_t N = (size_t)P.W * P.H;
+  P.ccap = cfg.candidate_capacity > 0 ? cfg.candidate_capacity : (int)std::max<size_t>(N / 4, 4096);
+  P.kcap = P.max_features + P.max_corners + 64;
+  c->pts_bound = P.kcap;
+  if (P.enable_anms) c->pts_bound = std::min(P.kcap, P.max_features + P.hbins * P.vbins + 8);
+  return KVFE_OK;
+}
+
+kvfe_status build_tables(kvfe_ctx* c) {
+  const kvfe_config& cfg = c->cfg;
+  const KParams& P = c->P;
+  Tables& T = c->T;
+  std::memset(&T, 0, sizeof(T));
+  const size_t N = (size_t)P.W * P.H;
+  // maps
+  for (int cam = 0; cam < 2; cam++) {
+    const kvfe_camera_params& cp = cam == 0 ? cfg.left : cfg.right;
+    c->h_map[cam][0].resize(N);
+    c->h_map[cam][1].resize(N);
+    TRY(init_undistort_rectify_map(cp, cam == 0 ? c->rect.R1 : c->rect.R2,
+                                   cam == 0 ? c->rect.P1 : c->rect.P2, c->h_map[cam][0].data(),
+                                   c->h_map[cam][1].data()));
+    std::vector<float2> inter(N);
+    for (size_t i = 0; i < N; i++) inter[i] = make_float2(c->h_map[cam][0][i], c->h_map[cam][1][i]);
+    float2* dm;
+    TRY(dalloc(c, &dm, N, false));
+    HIPCHK(c, hipMemcpy(dm, inter.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
+    T.map[cam] = dm;
+    for (int m = 0; m < 4; m++) {
+      const bool useR = m & 1, useP = m & 2;
+      c->und[cam][m] = to_dev(make_undistort_ctx(cp, useR ? (cam == 0 ? c->rect.R1 : c->rect.R2) : nullptr,
+                                                 useP ? (cam == 0 ? c->rect.P1 : c->rect.P2) : nullptr));
+    }
+  }
+  T.und_left_R = c->und[0][1];
+  T.und_left_RP = c->und[0][3];
+  // cornerSubPix masks
+  {
+    std::vector<float> m;
+    subpix_mask_table(std::max(P.subpix_win, 1), P.subpix_zero, m);
+    float* dmask;
+    TRY(dalloc(c, &dmask, m.size(), false));
+    HIPCHK(c, hipMemcpy(dmask, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice));
+    T.subpix_mask = dmask;
+    subpix_mask_table(10, -1, m);
+    TRY(dalloc(c, &dmask, m.size(), false));
+    HIPCHK(c, hipMemcpy(dmask, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice));
+    T.subpix_mask10 = dmask;
+  }
+  // cv::circle spans
+  {
+    std::vector<int> hw = circle_half_widths(P.min_distance);
+    int* d;
+    TRY(dalloc(c, &d, hw.size(), false));
+    HIPCHK(c, hipMemcpy(d, hw.data(), sizeof(int) * hw.size(), hipMemcpyHostToDevice));
+    T.circle_hw = d;
+  }
+  {
+    unsigned char* d;
+    TRY(dalloc(c, &d, KVFE_MAX_BINS, false));
+    HIPCHK(c, hipMemcpy(d, cfg.params.detector.binning_mask, KVFE_MAX_BINS, hipMemcpyHostToDevice));
+    T.binning_mask = d;
+  }
+  // cv::sortIdx permutations for every possible list length
+  {
+    const int M = (P.enable_anms && P.anms_type == KVFE_ANMS_BINNING) ? std::min(P.max_corners, P.acap) : 0;
+    std::vector<unsigned int> off(P.acap + 2, 0);
+    size_t total = 0;
+    for (int n = 0; n <= M; n++) {
+      off[n] = (unsigned int)total;
+      total += n;
+    }
+    for (int n = M + 1; n <= P.acap + 1; n++) off[n] = (unsigned int)total;
+    std::vector<uint16_t> tab(std::max<size_t>(total, 1));
+    for (int n = 1; n <= M; n++) sortidx_permutation(n, P.sortidx_policy, tab.data() + off[n]);
+    unsigned short* dt;
+    unsigned int* doff;
+    TRY(dalloc(c, &dt, tab.size(), false));
+    TRY(dalloc(c, &doff, off.size(), false));
+    HIPCHK(c, hipMemcpy(dt, tab.data(), sizeof(uint16_t) * tab.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(doff, off.data(), sizeof(unsigned int) * off.size(), hipMemcpyHostToDevice));
+    T.sortidx = dt;
+    T.sortidx_off = doff;
+  }
+  // predictor constants: K_ (Matx33f) and K_.inv()
+  {
+    const M3 K = camera_matrix(cfg.left);
+    for (int i = 0; i < 9; i++) T.Kf[i] = (float)K.m[i];
+    matx33f_inv(T.Kf, T.Kinvf);
+  }
+  return KVFE_OK;
+}
+
+kvfe_status ensure_comp(kvfe_ctx* c) {
+  if (c->comp_ready) return KVFE_OK;
+  c->Pc = c->P;
+  c->Pc.B = 1;
+  TRY(alloc_buffers(c, c->comp, c->Pc));
+  TRY(dalloc(c, &c->comp.user_mask, (size_t)c->P.W * c->P.H));
+  c->comp_ready = true;
+  return KVFE_OK;
+}
+
+kvfe_status upload_image(kvfe_ctx* c, unsigned char* dst, const uint8_t* src, size_t stride) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, c->P.W, src, stride, c->P.W, c->P.H, hipMemcpyHostToDevice,
+                             c->stream));
+  return KVFE_OK;
+}
+
+void prof_mark(kvfe_ctx* c, int idx) {
+  if (!c->prof_on) return;
+  hipEventRecord(c->prof_ev[c->prof_ev.size() - (ST_COUNT + 1) + idx], c->stream);
+}
+
+void prof_collect(kvfe_ctx* c) {
+  if (c->prof_pending.empty()) return;
+  for (int base : c->prof_pending) {
+    for (int s = 0; s < ST_COUNT; s++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->prof_ev[base + s], c->prof_ev[base + s + 1]) == hipSuccess)
+        c->prof_ms[s] += ms;
+    }
+    c->prof_samples++;
+  }
+  for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
+  c->prof_ev.clear();
+  c->prof_pending.clear();
+}
+
+kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char* right,
+                    size_t row_stride, size_t img_stride, const kvfe_frame_input* inputs) {
+  const KParams& P = c->P;
+  Buffers& b = c->fe;
+  hipStream_t st = c->stream;
+  // ---- per-stream inputs through the pinned ring ------------------------------------------------
+  const int slot = c->ring_pos;
+  c->ring_pos = (c->ring_pos + 1) % kvfe_ctx::RING;
+  if (c->ring_used[slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+  unsigned char* hb = c->ring_host[slot];
+  double* hR = reinterpret_cast<double*>(hb);
+  long long* hts = reinterpret_cast<long long*>(hb + sizeof(double) * 9 * P.B);
+  int* hf = reinterpret_cast<int*>(hb + (sizeof(double) * 9 + sizeof(long long)) * P.B);
+  for (int s = 0; s < P.B; s++) {
+    std::memcpy(hR + 9 * s, inputs[s].keyframe_R_cur_frame, sizeof(double) * 9);
+    hts[s] = inputs[s].timestamp_ns;
+    hf[s] = inputs[s].force_keyframe;
+  }
+  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hR, sizeof(double) * 9 * P.B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.in_ts, hts, sizeof(long long) * P.B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.in_force, hf, sizeof(int) * P.B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipEventRecord(c->ring_ev[slot], st));
+  c->ring_used[slot] = true;
+
+  if (c->prof_on) {
+    const int base = (int)c->prof_ev.size();
+    for (int i = 0; i <= ST_COUNT; i++) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreate(&e));
+      c->prof_ev.push_back(e);
+    }
+    c->prof_pending.push_back(base);
+  }
+  const FrameTab& K = b.ft[c->role_k];
+  const FrameTab& KM1 = b.ft[c->role_km1];
+  const FrameTab& LKF = b.ft[c->role_lkf];
+  const int pc = c->pyr_cur, pp = pc ^ 1;
+
+  prof_mark(c, ST_PYRAMID);
+  launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st);
+  prof_mark(c, ST_TRACK);
+  launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
+  if (c->prev_left)
+    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
+              img_stride, b.pyr[pc], b.lk, c->pts_bound, st);
+  prof_mark(c, ST_TRACK_FINALIZE);
+  launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
+  prof_mark(c, ST_MINEIG);
+  launch_mineig(P, c->T, left, row_stride, img_stride, nullptr, K, b.ss, b.ds, 1, st);
+  prof_mark(c, ST_SELECT);
+  launch_select(P, c->T, K, b.ss, b.ds, -1, st);
+  prof_mark(c, ST_SUBPIX);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, st);
+  prof_mark(c, ST_RECTIFY);
+  const unsigned char* srcs[2] = {left, right};
+  launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st);
+  prof_mark(c, ST_STEREO);
+  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, st);
+  prof_mark(c, ST_FINALIZE);
+  launch_step_finalize(P, K, LKF, b.st, b.ss, st);
+  prof_mark(c, ST_COUNT);
+  HIPCHK(c, hipGetLastError());
+
+  // stereoFrame_km1_ = stereoFrame_k_
+  std::swap(c->role_k, c->role_km1);
+  c->pyr_cur ^= 1;
+  c->prev_left = left;
+  c->prev_row_stride = row_stride;
+  c->prev_img_stride = img_stride;
+  return KVFE_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* kvfe_version(void) { return "libkvfe 0.1 (gfx950, HIP)"; }
+
+const char* kvfe_status_string(kvfe_status s) {
+  switch (s) {
+    case KVFE_OK: return "ok";
+    case KVFE_ERR_INVALID_ARG: return "invalid argument";
+    case KVFE_ERR_UNSUPPORTED: return "unsupported configuration";
+    case KVFE_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case KVFE_ERR_HIP: return "HIP runtime error";
+    case KVFE_ERR_CAPACITY: return "device list capacity exceeded";
+    case KVFE_ERR_NOT_READY: return "not ready";
+    default: return "unknown";
+  }
+}
+
+const char* kvfe_last_error(const kvfe_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+void kvfe_default_frontend_params(kvfe_frontend_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  kvfe_detector_params& d = p->detector;
+  d.feature_detector_type = KVFE_DET_GFTT;
+  d.max_features_per_frame = 400;
+  d.enable_subpixel_corner_refinement = 1;
+  d.subpix_window_size = 10;
+  d.subpix_zero_zone = -1;
+  d.subpix_max_iters = 10;
+  d.subpix_epsilon = 0.01;
+  d.enable_non_max_suppression = 1;
+  d.non_max_suppression_type = KVFE_ANMS_RANGETREE;
+  d.min_distance = 10;
+  d.max_nr_keypoints_before_anms = 2000;
+  d.nr_horizontal_bins = 5;
+  d.nr_vertical_bins = 5;
+  for (int i = 0; i < 25; i++) d.binning_mask[i] = 1;
+  d.quality_level = 0.001;
+  d.block_size = 3;
+  d.k = 0.04;
+  d.sortidx_policy = KVFE_SORTIDX_LIBSTDCXX;
+  kvfe_tracker_params& t = p->tracker;
+  t.klt_win_size = 24;
+  t.klt_max_iter = 30;
+  t.klt_max_level = 3;
+  t.max_feature_track_age = 25;
+  t.klt_eps = 0.01;
+  t.optical_flow_predictor_type = KVFE_FLOW_NO_PREDICTION;
+  t.disparity_threshold = 0.5;
+  kvfe_stereo_params& s = p->stereo;
+  s.tolerance_template_matching = 0.15;
+  s.templ_cols = 101;
+  s.templ_rows = 11;
+  s.min_point_dist = 0.1;
+  s.max_point_dist = 15.0;
+  p->min_intra_keyframe_time_ns = 0.2 * 10e6;
+  p->max_intra_keyframe_time_ns = 10.0 * 10e6;
+  p->max_disparity_since_lkf = 200.0;
+  p->use_stereo_tracking = 1;
+  p->use_ransac = 0;
+}
+
+kvfe_status kvfe_compute_rectification(const kvfe_camera_params* left,
+                                       const kvfe_camera_params* right, kvfe_rectification* out) {
+  if (!left || !right || !out) return KVFE_ERR_INVALID_ARG;
+  return stereo_rectify(*left, *right, out);
+}
+
+kvfe_status kvfe_compute_undistort_rectify_maps(const kvfe_camera_params* cam, const double R[9],
+                                                const double P[12], float* map_x, float* map_y) {
+  if (!cam || !R || !P || !map_x || !map_y) return KVFE_ERR_INVALID_ARG;
+  return init_undistort_rectify_map(*cam, R, P, map_x, map_y);
+}
+
+kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
+  if (!cfg || !out) return KVFE_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::string why;
+  kvfe_status vs = validate(cfg, &why);
+  if (vs != KVFE_OK) {
+    std::fprintf(stderr, "kvfe_create: %s\n", why.c_str());
+    return vs;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
+    std::fprintf(stderr, "kvfe_create: no HIP device (libkvfe has no CPU fallback)\n");
+    return KVFE_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess) return KVFE_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return KVFE_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "kvfe_create: device is %s, libkvfe is built for gfx950 only\n",
+                 prop.gcnArchName);
+    return KVFE_ERR_NO_DEVICE;
+  }
+  kvfe_ctx* c = new kvfe_ctx();
+  c->cfg = *cfg;
+  kvfe_status s = stereo_rectify(cfg->left, cfg->right, &c->rect);
+  if (s != KVFE_OK) {
+    delete c;
+    return s;
+  }
+  if (cfg->hip_stream) {
+    c->stream = reinterpret_cast<hipStream_t>(cfg->hip_stream);
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return KVFE_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  s = fill_params(c);
+  if (s == KVFE_OK) s = build_tables(c);
+  if (s == KVFE_OK) s = alloc_buffers(c, c->fe, c->P);
+  if (s == KVFE_OK) {
+    c->ring_bytes = (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * (size_t)c->P.B + 64;
+    for (int i = 0; i < kvfe_ctx::RING && s == KVFE_OK; i++) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, c->ring_bytes, hipHostMallocDefault) != hipSuccess) s = KVFE_ERR_HIP;
+      c->ring_host[i] = reinterpret_cast<unsigned char*>(h);
+      if (s == KVFE_OK) c->host_allocs.push_back(h);
+      if (s == KVFE_OK && hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess)
+        s = KVFE_ERR_HIP;
+    }
+  }
+  if (s != KVFE_OK) {
+    std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
+    kvfe_destroy(c);
+    return s;
+  }
+  *out = c;
+  return KVFE_OK;
+}
+
+void kvfe_destroy(kvfe_ctx* c) {
+  if (!c) return;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
+  for (int i = 0; i < kvfe_ctx::RING; i++)
+    if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
+  for (void* p : c->allocs) hipFree(p);
+  for (void* p : c->host_allocs) hipHostFree(p);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+kvfe_status kvfe_get_rectification(const kvfe_ctx* c, kvfe_rectification* out) {
+  if (!c || !out) return KVFE_ERR_INVALID_ARG;
+  *out = c->rect;
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_synchronize(kvfe_ctx* c) {
+  if (!c) return KVFE_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  return KVFE_OK;
+}
+
+// ---- component level ---------------------------------------------------------------------------
+kvfe_status kvfe_undistort_rectify_image(kvfe_ctx* c, int32_t cam, const uint8_t* src,
+                                         size_t src_stride, uint8_t* dst, size_t dst_stride) {
+  if (!c || !src || !dst || cam < 0 || cam > 1) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  TRY(upload_image(c, b.raw_left[0], src, src_stride));
+  const unsigned char* srcs[2] = {b.raw_left[0], b.raw_left[0]};
+  unsigned char* dsts[2] = {b.rect[0], b.rect[1]};
+  launch_rectify(c->Pc, c->T, srcs, c->P.W, (size_t)c->P.W * c->P.H, dsts, nullptr, 0, c->stream);
+  HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, b.rect[cam], c->P.W, c->P.W, c->P.H,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KVFE_OK;
+}
+
+static kvfe_status undistort_common(kvfe_ctx* c, int cam, const float* xy, int n, int useR, int useP,
+                                    float* out_xy, double* out_versors) {
+  if (!c || !xy || n < 0 || cam < 0 || cam > 1) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  if (n > c->Pc.kcap) return KVFE_ERR_CAPACITY;
+  Buffers& b = c->comp;
+  HIPCHK(c, hipMemcpyAsync(b.lk.prev_pts, xy, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+  const UndistortDev& U = c->und[cam][(useR ? 1 : 0) + (useP ? 2 : 0)];
+  launch_undistort_points(U, b.lk.prev_pts, n, out_xy ? b.lk.next_pts : nullptr,
+                          out_versors ? b.ft[0].versor : nullptr, c->stream);
+  if (out_xy)
+    HIPCHK(c, hipMemcpyAsync(out_xy, b.lk.next_pts, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+  if (out_versors)
+    HIPCHK(c, hipMemcpyAsync(out_versors, b.ft[0].versor, sizeof(double) * 3 * n,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_undistort_rectify_keypoints(kvfe_ctx* c, int32_t cam, const float* xy, int32_t n,
+                                             int32_t use_R, int32_t use_P, float* out_xy) {
+  if (!out_xy) return KVFE_ERR_INVALID_ARG;
+  return undistort_common(c, cam, xy, n, use_R, use_P, out_xy, nullptr);
+}
+
+kvfe_status kvfe_get_bearing_vectors(kvfe_ctx* c, int32_t cam, const float* xy, int32_t n,
+                                     double* out_versors) {
+  if (!out_versors) return KVFE_ERR_INVALID_ARG;
+  return undistort_common(c, cam, xy, n, 1, 0, nullptr, out_versors);
+}
+
+static kvfe_status detect_common(kvfe_ctx* c, const uint8_t* img, size_t stride,
+                                 const uint8_t* mask, size_t mask_stride, const float* tracked_xy,
+                                 int n_tracked, int need, bool raw, float* out_xy, int capacity,
+                                 int* out_n) {
+  if (!c || !img || !out_xy || !out_n || n_tracked < 0) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n_tracked > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  TRY(upload_image(c, b.raw_left[0], img, stride));
+  if (mask)
+    HIPCHK(c, hipMemcpy2DAsync(b.user_mask, P.W, mask, mask_stride, P.W, P.H, hipMemcpyHostToDevice, st));
+  const FrameTab& K = b.ft[0];
+  if (n_tracked > 0)
+    HIPCHK(c, hipMemcpyAsync(K.kp, tracked_xy, sizeof(float2) * n_tracked, hipMemcpyHostToDevice, st));
+  const int flags = FLAG_DETECT | FLAG_INIT;
+  HIPCHK(c, hipMemcpyAsync(K.count, &n_tracked, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.ss.flags, &flags, sizeof(int), hipMemcpyHostToDevice, st));
+  launch_mineig(P, c->T, b.raw_left[0], P.W, (size_t)P.W * P.H, mask ? b.user_mask : nullptr, K,
+                b.ss, b.ds, raw ? 0 : 1, st);
+  launch_select(P, c->T, K, b.ss, b.ds, std::max(need, 0), st);
+  int n = 0, fl = 0;
+  if (raw) {
+    HIPCHK(c, hipMemcpyAsync(&n, b.ds.n_corners, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&fl, b.ss.flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int m = std::min(n, capacity);
+    if (m > 0) HIPCHK(c, hipMemcpy(out_xy, b.ds.corners, sizeof(float2) * m, hipMemcpyDeviceToHost));
+  } else {
+    launch_subpix_append(P, c->T, b.raw_left[0], P.W, (size_t)P.W * P.H, K, b.ss, b.ds, 0, st);
+    HIPCHK(c, hipMemcpyAsync(&n, b.ds.n_new, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&fl, b.ss.flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int m = std::min(n, capacity);
+    if (m > 0) HIPCHK(c, hipMemcpy(out_xy, b.ds.newc, sizeof(float2) * m, hipMemcpyDeviceToHost));
+  }
+  *out_n = n;
+  if (fl & FLAG_OVERFLOW) {
+    c->last_error = "device candidate / corner list capacity exceeded";
+    return KVFE_ERR_CAPACITY;
+  }
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_raw_feature_detection(kvfe_ctx* c, const uint8_t* img, size_t stride,
+                                       const uint8_t* mask, size_t mask_stride, float* out_xy,
+                                       int32_t capacity, int32_t* out_n) {
+  return detect_common(c, img, stride, mask, mask_stride, nullptr, 0, 0, true, out_xy, capacity, out_n);
+}
+
+kvfe_status kvfe_feature_detection(kvfe_ctx* c, const uint8_t* img, size_t stride,
+                                   const float* tracked_xy, int32_t n_tracked,
+                                   int32_t need_n_corners, float* out_xy, int32_t capacity,
+                                   int32_t* out_n) {
+  if (n_tracked > 0 && !tracked_xy) return KVFE_ERR_INVALID_ARG;
+  return detect_common(c, img, stride, nullptr, 0, tracked_xy, n_tracked, need_n_corners, false,
+                       out_xy, capacity, out_n);
+}
+
+kvfe_status kvfe_corner_subpix(kvfe_ctx* c, const uint8_t* img, size_t stride, float* xy, int32_t n,
+                               int32_t half_win, int32_t zero_zone, int32_t max_iters, double eps) {
+  if (!c || !img || !xy || n < 0 || half_win < 1 || half_win > 15) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  if (n > c->Pc.kcap) return KVFE_ERR_CAPACITY;
+  TRY(upload_image(c, b.raw_left[0], img, stride));
+  std::vector<float> m;
+  subpix_mask_table(half_win, zero_zone, m);
+  float* dmask = reinterpret_cast<float*>(b.ds.sortbuf);  // scratch
+  HIPCHK(c, hipMemcpyAsync(dmask, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b.lk.prev_pts, xy, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+  const int it = std::min(std::max(max_iters, 1), 100);
+  const double e = std::max(eps, 0.);
+  launch_subpix_points(c->Pc, dmask, b.raw_left[0], c->P.W, c->P.W, c->P.H, b.lk.prev_pts, n,
+                       half_win, it, e * e, c->stream);
+  HIPCHK(c, hipMemcpyAsync(xy, b.lk.prev_pts, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_calc_optical_flow_pyr_lk(kvfe_ctx* c, const uint8_t* prev_img,
+                                          const uint8_t* cur_img, size_t stride,
+                                          const float* prev_xy, float* cur_xy, int32_t n,
+                                          uint8_t* status, float* err) {
+  if (!c || !prev_img || !cur_img || !prev_xy || !cur_xy || !status || n < 0) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  TRY(upload_image(c, b.raw_left[0], prev_img, stride));
+  TRY(upload_image(c, b.raw_left[1], cur_img, stride));
+  const size_t N = (size_t)P.W * P.H;
+  launch_pyramid(P, b.raw_left[0], P.W, N, b.pyr[0], st);
+  launch_pyramid(P, b.raw_left[1], P.W, N, b.pyr[1], st);
+  HIPCHK(c, hipMemcpyAsync(b.lk.prev_pts, prev_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.lk.next_pts, cur_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.lk.npts, &n, sizeof(int), hipMemcpyHostToDevice, st));
+  launch_lk(P, b.raw_left[0], P.W, N, b.pyr[0], b.raw_left[1], P.W, N, b.pyr[1], b.lk, n, st);
+  HIPCHK(c, hipMemcpyAsync(cur_xy, b.lk.next_pts, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(status, b.lk.status, n, hipMemcpyDeviceToHost, st));
+  if (err) HIPCHK(c, hipMemcpyAsync(err, b.lk.err, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_predict_sparse_flow(kvfe_ctx* c, const float* prev_xy, int32_t n,
+                                     const double ref_R_cur[9], float* out_xy) {
+  if (!c || !prev_xy || !ref_R_cur || !out_xy || n < 0) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  if (n > c->Pc.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.lk.prev_pts, prev_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, ref_R_cur, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+  launch_predict_flow(c->Pc, c->T, b.kf_R_cur, b.lk.prev_pts, n, b.lk.next_pts, st);
+  HIPCHK(c, hipMemcpyAsync(out_xy, b.lk.next_pts, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_get_right_keypoints_rectified(kvfe_ctx* c, const uint8_t* left_rect,
+                                               const uint8_t* right_rect, size_t stride,
+                                               const float* left_rect_xy,
+                                               const uint8_t* left_status, int32_t n,
+                                               float* right_rect_xy, uint8_t* right_status,
+                                               double* score) {
+  if (!c || !left_rect || !right_rect || !left_rect_xy || !left_status || !right_rect_xy ||
+      !right_status || n < 0)
+    return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  TRY(upload_image(c, b.rect[0], left_rect, stride));
+  TRY(upload_image(c, b.rect[1], right_rect, stride));
+  HIPCHK(c, hipMemcpyAsync(b.st.left_rect, left_rect_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.st.left_status, left_status, n, hipMemcpyHostToDevice, st));
+  launch_stereo_match_only(P, c->T, b.rect[0], b.rect[1], b.st.left_rect, b.st.left_status, n,
+                           b.st.right_rect, b.st.right_status, b.st.depth, st);
+  HIPCHK(c, hipMemcpyAsync(right_rect_xy, b.st.right_rect, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(right_status, b.st.right_status, n, hipMemcpyDeviceToHost, st));
+  if (score) HIPCHK(c, hipMemcpyAsync(score, b.st.depth, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_img,
+                                              const uint8_t* right_img, size_t stride,
+                                              const float* left_xy, int32_t n,
+                                              kvfe_stereo_output* out) {
+  if (!c || !left_img || !right_img || !left_xy || !out || n < 0) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  const size_t N = (size_t)P.W * P.H;
+  TRY(upload_image(c, b.raw_left[0], left_img, stride));
+  TRY(upload_image(c, b.raw_right, right_img, stride));
+  const FrameTab& K = b.ft[0];
+  const int flags = FLAG_STEREO | FLAG_INIT;
+  HIPCHK(c, hipMemcpyAsync(b.ss.flags, &flags, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(K.count, &n, sizeof(int), hipMemcpyHostToDevice, st));
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(K.kp, left_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+    launch_undistort_points(c->T.und_left_R, K.kp, n, nullptr, K.versor, st);
+  }
+  const unsigned char* srcs[2] = {b.raw_left[0], b.raw_right};
+  launch_rectify(P, c->T, srcs, P.W, N, b.rect, nullptr, 0, st);
+  if (n > 0) launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, st);
+#define DL(dst, src, bytes) \
+  if (dst) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st))
+  if (n > 0) {
+    DL(out->left_rect_xy, b.st.left_rect, sizeof(float2) * n);
+    DL(out->left_status, b.st.left_status, (size_t)n);
+    DL(out->right_rect_xy, b.st.right_rect, sizeof(float2) * n);
+    DL(out->right_status, b.st.right_status, (size_t)n);
+    DL(out->depth, b.st.depth, sizeof(double) * n);
+    DL(out->right_xy, b.st.right_kp, sizeof(float2) * n);
+    DL(out->keypoints_3d, b.st.kp3d, sizeof(double) * 3 * n);
+  }
+  DL(out->left_rect_img, b.rect[0], N);
+  DL(out->right_rect_img, b.rect[1], N);
+#undef DL
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+// ---- front-end level -------------------------------------------------------------------------
+kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const void* right_dev,
+                                      size_t row_stride, size_t image_stride,
+                                      const kvfe_frame_input* inputs) {
+  if (!c || !left_dev || !right_dev || !inputs) return KVFE_ERR_INVALID_ARG;
+  if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
+  return do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
+                 reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
+}
+
+kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint8_t* right,
+                                    size_t row_stride, size_t image_stride,
+                                    const kvfe_frame_input* inputs) {
+  if (!c || !left || !right || !inputs) return KVFE_ERR_INVALID_ARG;
+  if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
+  Buffers& b = c->fe;
+  const KParams& P = c->P;
+  const size_t N = (size_t)P.W * P.H;
+  unsigned char* dl = b.raw_left[c->raw_slot];
+  c->raw_slot ^= 1;
+  for (int s = 0; s < P.B; s++) {
+    HIPCHK(c, hipMemcpy2DAsync(dl + s * N, P.W, left + s * image_stride, row_stride, P.W, P.H,
+                               hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(b.raw_right + s * N, P.W, right + s * image_stride, row_stride, P.W,
+                               P.H, hipMemcpyHostToDevice, c->stream));
+  }
+  return do_step(c, dl, b.raw_right, P.W, N, inputs);
+}
+
+kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
+  if (!c) return KVFE_ERR_INVALID_ARG;
+  Buffers& b = c->fe;
+  const size_t B = c->P.B;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipStreamSynchronize(st));
+  HIPCHK(c, hipMemsetAsync(b.ss.flags, 0, sizeof(int) * B, st));
+  HIPCHK(c, hipMemsetAsync(b.ss.lmk_counter, 0, sizeof(long long) * B, st));
+  HIPCHK(c, hipMemsetAsync(b.ss.frame_count, 0, sizeof(long long) * B, st));
+  for (int i = 0; i < 3; i++) HIPCHK(c, hipMemsetAsync(b.ft[i].count, 0, sizeof(int) * B, st));
+  std::vector<double> eye(B * 9, 0.0);
+  for (size_t s = 0; s < B; s++) eye[s * 9] = eye[s * 9 + 4] = eye[s * 9 + 8] = 1.0;
+  HIPCHK(c, hipMemcpy(b.ss.kf_R_ref, eye.data(), sizeof(double) * B * 9, hipMemcpyHostToDevice));
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->prev_left = nullptr;
+  c->role_k = 0;
+  c->role_km1 = 1;
+  c->role_lkf = 2;
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {
+  if (!c || !out || s < 0 || s >= c->P.B) return KVFE_ERR_INVALID_ARG;
+  Buffers& b = c->fe;
+  const KParams& P = c->P;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipStreamSynchronize(st));
+  prof_collect(c);
+  const FrameTab& K = b.ft[c->role_km1];  // the frame processed last
+  int count = 0, flags = 0, ntr = 0, ndet = 0, nmeas = 0;
+  long long fcount = 0;
+  HIPCHK(c, hipMemcpy(&count, K.count + s, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&flags, b.ss.flags + s, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&ntr, b.ss.n_tracked + s, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&ndet, b.ss.n_detected + s, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&nmeas, b.ss.n_meas + s, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&fcount, b.ss.frame_count + s, sizeof(long long), hipMemcpyDeviceToHost));
+  out->n_keypoints = count;
+  out->is_keyframe = (flags & FLAG_KEYFRAME) ? 1 : 0;
+  out->n_tracked = ntr;
+  out->n_detected = ndet;
+  out->n_measurements = nmeas;
+  out->frame_id = fcount - 1;
+  const size_t so = (size_t)s * P.kcap;
+  const int n = std::min(count, out->capacity);
+  const int m = std::min(nmeas, out->capacity);
+#define DL(dst, src, bytes) \
+  if (dst && (bytes) > 0) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost))
+  DL(out->landmarks, K.lmk + so, sizeof(long long) * n);
+  DL(out->landmarks_age, K.age + so, sizeof(int) * n);
+  DL(out->keypoints, K.kp + so, sizeof(float2) * n);
+  DL(out->versors, K.versor + so * 3, sizeof(double) * 3 * n);
+  if (flags & FLAG_STEREO) {
+    DL(out->left_rect_xy, b.st.left_rect + so, sizeof(float2) * n);
+    DL(out->left_status, b.st.left_status + so, (size_t)n);
+    DL(out->right_rect_xy, b.st.right_rect + so, sizeof(float2) * n);
+    DL(out->right_status, b.st.right_status + so, (size_t)n);
+    DL(out->depth, b.st.depth + so, sizeof(double) * n);
+    DL(out->right_xy, b.st.right_kp + so, sizeof(float2) * n);
+    DL(out->keypoints_3d, b.st.kp3d + so * 3, sizeof(double) * 3 * n);
+  }
+  DL(out->meas_landmark, b.ss.meas_lmk + so, sizeof(long long) * m);
+  DL(out->meas_uL_uR_v, b.ss.meas_uLuRv + so * 3, sizeof(double) * 3 * m);
+#undef DL
+  if (flags & FLAG_OVERFLOW) {
+    c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
+    return KVFE_ERR_CAPACITY;
+  }
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
+  if (!c) return KVFE_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  c->prof_on = on != 0;
+  if (on) {
+    for (double& v : c->prof_ms) v = 0;
+    c->prof_samples = 0;
+  }
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
+  if (!c || !out) return KVFE_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  std::memset(out, 0, sizeof(*out));
+  out->n_stages = ST_COUNT;
+  out->n_samples = c->prof_samples;
+  const double N = (double)c->P.W * c->P.H * c->P.B;
+  for (int s = 0; s < ST_COUNT; s++) {
+    out->name[s] = kStageNames[s];
+    out->ms_total[s] = c->prof_ms[s];
+  }
+  // algorithmic bytes per launch of the dense kernels (DESIGN.md "roofline accounting")
+  double pyr_out = 0;
+  for (int l = 1; l < c->P.nlevels; l++) pyr_out += (double)c->P.lw[l] * c->P.lh[l];
+  out->alg_bytes[ST_PYRAMID] = N + pyr_out * c->P.B;              // read level 0, write levels 1..L
+  out->alg_bytes[ST_MINEIG] = N;                                  // read the left image once
+  out->alg_bytes[ST_RECTIFY] = 4.0 * N;                           // read L,R raw + write L,R rectified
+  return KVFE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// Device-side data layout and kernel launch interface of libkvfe (gfx950 only).
+//
+// Layout in HBM (one context = `B` independent stereo streams, all arrays are
+// struct-of-arrays with the stream index outermost so that one launch covers
+// every stream with blockIdx.z / blockIdx.y = stream):
+//   images        u8   [B][H][W]            raw left/right (caller or ctx owned), rectified L/R
+//   pyramids      u8   [2][B][sum_l w_l*h_l] levels 1..L of the current / previous left image
+//   maps          f32x2[2][H][W]            undistort-rectify maps (shared by all streams)
+//   candidates    u64  [B][ccap]            (min-eig bits << 32 | pixel index) local maxima
+//   frame tables  SoA  [3][B][kcap]         keypoints / landmark ids / ages / versors
+//   stereo tables SoA  [B][kcap]            rectified keypoints, statuses, depth, 3D points
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kvfe {
+
+constexpr int MAX_LEVELS = 8;
+constexpr int MAX_BINS = 256;
+constexpr int MAX_RADIUS = 127;
+
+struct KParams {
+  int W, H, B;
+  int kcap;  // keypoint capacity per stream
+  int ccap;  // candidate capacity per stream
+  int acap;  // accepted-corner capacity per stream (<= 8192)
+  // detector (FeatureDetectorParams)
+  int max_features, enable_anms, anms_type, min_distance, max_corners, hbins, vbins, block_size;
+  int subpix_enable, subpix_win, subpix_zero, subpix_iters, sortidx_policy;
+  double quality, subpix_eps2;
+  // tracker (TrackerParams)
+  int klt_win, klt_iters, klt_maxlevel, max_age, predictor;
+  double klt_eps2, disparity_thr;
+  // stereo (StereoMatchingParams)
+  int templ_cols, templ_rows, stripe_rows, stripe_cols, stereo_subpix, use_stereo_tracking;
+  double min_point_dist, max_point_dist, tol_template, fx_rect, baseline;
+  // frontend (FrontendParams)
+  double min_kf_ns, max_kf_ns, max_disp_lkf;
+  long long min_features;
+  // pyramid geometry: level 0 is the raw image, levels 1..nlevels-1 live in the pyramid buffer
+  int nlevels;
+  int lw[MAX_LEVELS], lh[MAX_LEVELS], loff[MAX_LEVELS];
+  int pyr_stride;  // bytes per stream in a pyramid buffer
+};
+
+// undistortPoints constants (double) for one (K, D, RR) combination
+struct UndistortDev {
+  double fx, fy, cx, cy, ifx, ify;
+  double k[8];
+  double RR[9];
+  int has_dist;
+  int pad;
+};
+
+// Constant tables shared by all streams (device pointers).
+struct Tables {
+  const float2* map[2];        // [H][W] (map_x, map_y) per camera
+  const float* subpix_mask;    // (2w+1)^2 Gaussian-ish weights of cv::cornerSubPix
+  const float* subpix_mask10;  // same for the hard-coded 10x10 stereo refinement
+  const int* circle_hw;        // [radius+1] half widths of cv::circle(FILLED)
+  const unsigned char* binning_mask;  // [vbins*hbins]
+  const unsigned short* sortidx;      // concatenated permutations for n = 0..max_corners
+  const unsigned int* sortidx_off;    // offsets into sortidx
+  UndistortDev und_left_R;     // K1, D1, R1        -> bearing vectors
+  UndistortDev und_left_RP;    // K1, D1, R1, P1    -> rectified left keypoints
+  float Kf[9], Kinvf[9];       // float K / K^-1 of the ORIGINAL left camera (predictor)
+};
+
+// One frame's keypoint table (Frame::keypoints_/landmarks_/landmarks_age_/versors_)
+struct FrameTab {
+  float2* kp;           // [B][kcap]
+  long long* lmk;       // [B][kcap]
+  int* age;             // [B][kcap]
+  double* versor;       // [B][kcap][3]
+  int* count;           // [B]
+  long long* timestamp; // [B]
+};
+
+// StereoFrame tables of the current frame
+struct StereoTab {
+  float2* left_rect;          // [B][kcap]
+  unsigned char* left_status; // [B][kcap]
+  float2* right_rect;
+  unsigned char* right_status;
+  double* depth;
+  float2* right_kp;
+  double* kp3d;               // [B][kcap][3]
+};
+
+// per-stream scalar state
+struct StreamState {
+  int* flags;             // [B] bit0 initialised, bit1 keyframe this step, bit2 run detection,
+                          //     bit3 run stereo, bit4 capacity overflow
+  int* n_tracked;         // [B]
+  int* n_detected;        // [B]
+  int* n_meas;            // [B]
+  long long* lmk_counter; // [B] FeatureDetector.cpp:141 (per stream instead of process-wide)
+  long long* frame_count; // [B]
+  double* kf_R_ref;       // [B][9] keyframe_R_ref_frame_
+  const double* kf_R_cur; // [B][9] this step's keyframe_R_cur_frame (input)
+  const long long* in_timestamp; // [B]
+  const int* in_force_kf; // [B]
+  long long* meas_lmk;    // [B][kcap]
+  double* meas_uLuRv;     // [B][kcap][3]
+};
+
+enum : int {
+  FLAG_INIT = 1,
+  FLAG_KEYFRAME = 2,
+  FLAG_DETECT = 4,
+  FLAG_STEREO = 8,
+  FLAG_OVERFLOW = 16,
+  FLAG_FIRST = 32,  // processFirstStereoFrame: no stereo measurements are produced
+};
+
+// detection scratch
+struct DetectScratch {
+  unsigned long long* cand;  // [B][ccap]
+  int* cand_count;           // [B]
+  unsigned int* maxkey;      // [B] order-preserving key of the masked maximum
+  float2* corners;           // [B][acap] GFTT output (integer valued), quality order
+  int* n_corners;            // [B]
+  float2* newc;              // [B][acap] corners selected by ANMS (pre sub-pixel)
+  int* n_new;                // [B]
+  int* need;                 // [B]
+  // global-memory work arrays of the per-stream select kernel
+  unsigned int* cell_items;  // [B][ccap]
+  unsigned char* state;      // [B][ccap]
+  unsigned long long* sortbuf;  // [B][ccap rounded to pow2]
+  int sort_cap;
+};
+
+// LK scratch (component API and frontend share it)
+struct LkScratch {
+  float2* prev_pts;       // [B][kcap]
+  float2* next_pts;       // [B][kcap]
+  unsigned char* status;  // [B][kcap]
+  float* err;             // [B][kcap]
+  int* npts;              // [B]
+};
+
+__host__ __device__ inline int reflect101(int p, int len) {
+  if ((unsigned)p < (unsigned)len) return p;
+  if (len == 1) return 0;
+  do {
+    if (p < 0)
+      p = -p;
+    else
+      p = 2 * len - 2 - p;
+  } while ((unsigned)p >= (unsigned)len);
+  return p;
+}
+
+// ---- launchers (each enqueues on `st`; no synchronisation) -----------------------------------
+// K1: cv::remap of `ncam` images per stream.  act_flag: only streams with (flags & act_flag).
+void launch_rectify(const KParams& P, const Tables& T, const unsigned char* const src[2],
+                    size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
+                    const int* flags, int act_flag, hipStream_t st);
+// K4a: pyramid levels 1..nlevels-1 of `img` into pyr.
+void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
+                    size_t img_stride, unsigned char* pyr, hipStream_t st);
+// K4c: pyramidal LK for npts[s] points per stream.
+void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
+               size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
+               size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
+               const LkScratch& lk, int max_pts, hipStream_t st);
+// predictor + gather of the reference keypoints (Tracker.cpp:103-129)
+void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
+                          const StreamState& S, const LkScratch& lk, hipStream_t st);
+// survivors -> frame k, bearing vectors, keyframe decision (Tracker.cpp:167-189,
+// StereoVisionImuFrontend.cpp:313-347, VisionImuFrontend.cpp:175-232)
+void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
+                           const FrameTab& lkf, const FrameTab& k, const StreamState& S,
+                           const LkScratch& lk, hipStream_t st);
+// K2a-c: min-eigenvalue local maxima + masked maximum.  user_mask may be null.
+void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
+                   size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
+                   const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st);
+// K2d + ANMS (per stream): threshold, greedy min-distance, sort, ANMS.
+void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const StreamState& S,
+                   const DetectScratch& D, int fixed_need /* <0: from frame */, hipStream_t st);
+// K3 + append: cornerSubPix on the new corners and append to frame k
+void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
+                          size_t row_stride, size_t img_stride, const FrameTab& k,
+                          const StreamState& S, const DetectScratch& D, int append,
+                          hipStream_t st);
+// cv::cornerSubPix on arbitrary points (component API)
+void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigned char* img,
+                          size_t row_stride, int W, int H, float2* pts, int n, int win,
+                          int max_iters, double eps2, hipStream_t st);
+// K7 + K5: rectify left keypoints, epipolar SSD, depth, right keypoints, 3D
+void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_rect,
+                   const unsigned char* right_rect, const FrameTab& k, const StereoTab& ST,
+                   const StreamState& S, int act_flag, hipStream_t st);
+// StereoMatcher::getRightKeypointsRectified only (component API): left_rect/status given
+void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned char* left_rect,
+                              const unsigned char* right_rect, const float2* left_rect_kp,
+                              const unsigned char* left_status, int n, float2* right_rect_kp,
+                              unsigned char* right_status, double* score, hipStream_t st);
+// end of step: measurements, lkf <- k for keyframes, rotation bookkeeping
+void launch_step_finalize(const KParams& P, const FrameTab& k, const FrameTab& lkf,
+                          const StereoTab& ST, const StreamState& S, hipStream_t st);
+// undistort keypoints with an arbitrary UndistortDev (component API)
+void launch_undistort_points(const UndistortDev& U, const float2* in, int n, float2* out,
+                             double* versors, hipStream_t st);
+void launch_predict_flow(const KParams& P, const Tables& T, const double* R, const float2* prev,
+                         int n, float2* out, hipStream_t st);
+
+}  // namespace kvfe

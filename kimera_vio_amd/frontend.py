@@ -1,0 +1,280 @@
+"""Host-side mirror of the reference interface for the hot path, over the C ABI of libkvfe.
+
+Names follow the reference classes so the parity tests read like the reference's own tests:
+
+    StereoCamera            src/frontend/StereoCamera.cpp            (rectification constants)
+    UndistorterRectifier    src/frontend/UndistorterRectifier.cpp
+    FeatureDetector         src/frontend/feature-detector/FeatureDetector.cpp
+    Tracker                 src/frontend/Tracker.cpp                 (featureTracking's numeric core)
+    StereoMatcher           src/frontend/StereoMatcher.cpp
+    StereoVisionImuFrontend src/frontend/StereoVisionImuFrontend.cpp (batched, useRANSAC = 0)
+
+Every method goes straight to the GPU library; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from .lib import KvfeError, load
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _img(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D uint8 image")
+    return a
+
+
+def _pts(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 2)
+
+
+class Context:
+    """A kvfe_ctx: StereoCamera + FeatureDetector + Tracker + StereoMatcher for `batch` streams."""
+
+    def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
+                 batch: int = 1, device: int = 0, hip_stream: int | None = None,
+                 candidate_capacity: int = 0):
+        self.lib = load()
+        cfg = abi.Config()
+        cfg.left, cfg.right, cfg.params = left, right, params
+        cfg.batch, cfg.device = batch, device
+        cfg.hip_stream = hip_stream
+        cfg.candidate_capacity = candidate_capacity
+        self.cfg = cfg
+        self.left, self.right, self.params = left, right, params
+        self.batch = batch
+        self.w, self.h = left.width, left.height
+        h = C.c_void_p()
+        st = self.lib.kvfe_create(C.byref(cfg), C.byref(h))
+        if st != abi.KVFE_OK:
+            raise KvfeError(st, "kvfe_create", self.lib.kvfe_status_string(st).decode())
+        self._h = h
+        self.rect = abi.Rectification()
+        self._chk(self.lib.kvfe_get_rectification(self._h, C.byref(self.rect)), "get_rectification")
+        d = params.detector
+        self.kcap = d.max_features_per_frame + d.max_nr_keypoints_before_anms + 64
+
+    def _chk(self, st, where):
+        if st != abi.KVFE_OK:
+            raise KvfeError(st, where, self.lib.kvfe_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.kvfe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- UndistorterRectifier ----------------------------------------------------------------
+    def undistort_rectify_image(self, cam: int, img) -> np.ndarray:
+        img = _img(img)
+        out = np.empty_like(img)
+        self._chk(self.lib.kvfe_undistort_rectify_image(self._h, cam, _p(img), img.strides[0], _p(out),
+                                                        out.strides[0]), "undistort_rectify_image")
+        return out
+
+    def undistort_rectify_keypoints(self, cam: int, xy, use_R=True, use_P=True) -> np.ndarray:
+        p = _pts(xy)
+        out = np.zeros_like(p)
+        self._chk(self.lib.kvfe_undistort_rectify_keypoints(self._h, cam, _p(p), len(p), int(use_R),
+                                                            int(use_P), _p(out)), "undistort_keypoints")
+        return out
+
+    def get_bearing_vectors(self, cam: int, xy) -> np.ndarray:
+        p = _pts(xy)
+        out = np.zeros((len(p), 3), np.float64)
+        self._chk(self.lib.kvfe_get_bearing_vectors(self._h, cam, _p(p), len(p), _p(out)),
+                  "get_bearing_vectors")
+        return out
+
+    # ---- FeatureDetector -----------------------------------------------------------------------
+    def raw_feature_detection(self, img, mask=None) -> np.ndarray:
+        img = _img(img)
+        cap = 8192
+        out = np.zeros((cap, 2), np.float32)
+        n = C.c_int32(0)
+        m = _img(mask) if mask is not None else None
+        self._chk(self.lib.kvfe_raw_feature_detection(self._h, _p(img), img.strides[0],
+                                                      _p(m) if m is not None else None,
+                                                      m.strides[0] if m is not None else 0, _p(out),
+                                                      cap, C.byref(n)), "raw_feature_detection")
+        return out[: n.value].copy()
+
+    def feature_detection(self, img, tracked_xy, need: int) -> np.ndarray:
+        img = _img(img)
+        tr = _pts(tracked_xy)
+        cap = 8192
+        out = np.zeros((cap, 2), np.float32)
+        n = C.c_int32(0)
+        self._chk(self.lib.kvfe_feature_detection(self._h, _p(img), img.strides[0], _p(tr), len(tr),
+                                                  need, _p(out), cap, C.byref(n)), "feature_detection")
+        return out[: n.value].copy()
+
+    def corner_subpix(self, img, xy, win=10, zero_zone=-1, max_iters=40, eps=0.001) -> np.ndarray:
+        img = _img(img)
+        p = _pts(xy).copy()
+        self._chk(self.lib.kvfe_corner_subpix(self._h, _p(img), img.strides[0], _p(p), len(p), win,
+                                              zero_zone, max_iters, eps), "corner_subpix")
+        return p
+
+    # ---- Tracker ---------------------------------------------------------------------------------
+    def calc_optical_flow_pyr_lk(self, prev, cur, prev_xy, init_xy):
+        prev, cur = _img(prev), _img(cur)
+        p = _pts(prev_xy)
+        q = _pts(init_xy).copy()
+        n = len(p)
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self._chk(self.lib.kvfe_calc_optical_flow_pyr_lk(self._h, _p(prev), _p(cur), prev.strides[0],
+                                                         _p(p), _p(q), n, _p(status), _p(err)),
+                  "calc_optical_flow_pyr_lk")
+        return q, status, err
+
+    def predict_sparse_flow(self, prev_xy, ref_R_cur) -> np.ndarray:
+        p = _pts(prev_xy)
+        R = np.ascontiguousarray(ref_R_cur, np.float64).reshape(9)
+        out = np.zeros_like(p)
+        self._chk(self.lib.kvfe_predict_sparse_flow(self._h, _p(p), len(p), _p(R), _p(out)),
+                  "predict_sparse_flow")
+        return out
+
+    # ---- StereoMatcher ---------------------------------------------------------------------------
+    def get_right_keypoints_rectified(self, left_rect, right_rect, left_xy, left_status):
+        left_rect, right_rect = _img(left_rect), _img(right_rect)
+        p = _pts(left_xy)
+        st = np.ascontiguousarray(left_status, np.uint8)
+        n = len(p)
+        rxy = np.zeros((n, 2), np.float32)
+        rst = np.zeros(n, np.uint8)
+        score = np.zeros(n, np.float64)
+        self._chk(self.lib.kvfe_get_right_keypoints_rectified(self._h, _p(left_rect), _p(right_rect),
+                                                              left_rect.strides[0], _p(p), _p(st), n,
+                                                              _p(rxy), _p(rst), _p(score)),
+                  "get_right_keypoints_rectified")
+        return rxy, rst, score
+
+    def sparse_stereo_reconstruction(self, left, right, left_xy, want_images=False) -> dict:
+        left, right = _img(left), _img(right)
+        p = _pts(left_xy)
+        n = len(p)
+        res = dict(left_rect_xy=np.zeros((n, 2), np.float32), left_status=np.zeros(n, np.uint8),
+                   right_rect_xy=np.zeros((n, 2), np.float32), right_status=np.zeros(n, np.uint8),
+                   depth=np.zeros(n, np.float64), right_xy=np.zeros((n, 2), np.float32),
+                   keypoints_3d=np.zeros((n, 3), np.float64))
+        if want_images:
+            res["left_rect_img"] = np.zeros((self.h, self.w), np.uint8)
+            res["right_rect_img"] = np.zeros((self.h, self.w), np.uint8)
+        so = abi.StereoOutput()
+        for k, v in res.items():
+            setattr(so, k, v.ctypes.data)
+        self._chk(self.lib.kvfe_sparse_stereo_reconstruction(self._h, _p(left), _p(right),
+                                                             left.strides[0], _p(p), n, C.byref(so)),
+                  "sparse_stereo_reconstruction")
+        return res
+
+    # ---- StereoVisionImuFrontend (batched) -----------------------------------------------------
+    def make_inputs(self, timestamps_ns, Rs=None, force_keyframe=None):
+        arr = (abi.FrameInput * self.batch)()
+        for s in range(self.batch):
+            arr[s].timestamp_ns = int(timestamps_ns[s])
+            R = np.eye(3) if Rs is None else np.asarray(Rs[s], np.float64).reshape(3, 3)
+            for i in range(9):
+                arr[s].keyframe_R_cur_frame[i] = float(R.reshape(9)[i])
+            arr[s].force_keyframe = 0 if force_keyframe is None else int(force_keyframe[s])
+        return arr
+
+    def step_host(self, lefts, rights, inputs):
+        """lefts/rights: uint8 arrays [batch, H, W] in host memory."""
+        lefts = np.ascontiguousarray(lefts, np.uint8)
+        rights = np.ascontiguousarray(rights, np.uint8)
+        assert lefts.shape == (self.batch, self.h, self.w) and rights.shape == lefts.shape
+        self._chk(self.lib.kvfe_frontend_step_host(self._h, _p(lefts), _p(rights), self.w,
+                                                   self.w * self.h, inputs), "frontend_step_host")
+
+    def step_device(self, left_ptr: int, right_ptr: int, inputs, row_stride=None, image_stride=None):
+        """left_ptr/right_ptr: device pointers to `batch` images; they must stay valid until the next
+        step of this context has completed."""
+        self._chk(self.lib.kvfe_frontend_step_device(self._h, C.c_void_p(left_ptr), C.c_void_p(right_ptr),
+                                                     row_stride or self.w,
+                                                     image_stride or self.w * self.h, inputs),
+                  "frontend_step_device")
+
+    def synchronize(self):
+        self._chk(self.lib.kvfe_synchronize(self._h), "synchronize")
+
+    def reset(self):
+        self._chk(self.lib.kvfe_frontend_reset(self._h), "frontend_reset")
+
+    def get_output(self, stream: int) -> dict:
+        cap = self.kcap
+        arrs = dict(landmarks=np.zeros(cap, np.int64), landmarks_age=np.zeros(cap, np.int32),
+                    keypoints=np.zeros((cap, 2), np.float32), versors=np.zeros((cap, 3), np.float64),
+                    left_rect_xy=np.zeros((cap, 2), np.float32), left_status=np.zeros(cap, np.uint8),
+                    right_rect_xy=np.zeros((cap, 2), np.float32), right_status=np.zeros(cap, np.uint8),
+                    depth=np.zeros(cap, np.float64), right_xy=np.zeros((cap, 2), np.float32),
+                    keypoints_3d=np.zeros((cap, 3), np.float64), meas_landmark=np.zeros(cap, np.int64),
+                    meas_uL_uR_v=np.zeros((cap, 3), np.float64))
+        out = abi.FrameOutput()
+        out.capacity = cap
+        for k, v in arrs.items():
+            setattr(out, k, v.ctypes.data)
+        self._chk(self.lib.kvfe_frontend_get_output(self._h, stream, C.byref(out)), "frontend_get_output")
+        n = min(out.n_keypoints, cap)
+        m = min(out.n_measurements, cap)
+        d = dict(n_keypoints=out.n_keypoints, is_keyframe=out.is_keyframe, n_tracked=out.n_tracked,
+                 n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id)
+        for k, v in arrs.items():
+            d[k] = v[:m].copy() if k.startswith("meas_") else v[:n].copy()
+        return d
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.kvfe_profile_enable(self._h, int(on)), "profile_enable")
+
+    def profile_read(self) -> dict:
+        st = abi.StageTimes()
+        self._chk(self.lib.kvfe_profile_read(self._h, C.byref(st)), "profile_read")
+        return dict(n_samples=st.n_samples,
+                    stages={st.name[i].decode(): dict(ms_total=st.ms_total[i], alg_bytes=st.alg_bytes[i])
+                            for i in range(st.n_stages)})
+
+
+# reference-shaped aliases ------------------------------------------------------------------------
+class StereoVisionImuFrontend(Context):
+    """Batched StereoVisionImuFrontend::spinOnce for `batch` independent streams."""
+
+    def spin_once_host(self, lefts, rights, timestamps_ns, Rs=None, force_keyframe=None):
+        self.step_host(lefts, rights, self.make_inputs(timestamps_ns, Rs, force_keyframe))
+        return [self.get_output(s) for s in range(self.batch)]
+
+
+def compute_rectification(left: abi.CameraParams, right: abi.CameraParams) -> abi.Rectification:
+    """StereoCamera::computeRectificationParameters (host math, no device needed)."""
+    r = abi.Rectification()
+    st = load().kvfe_compute_rectification(C.byref(left), C.byref(right), C.byref(r))
+    if st != abi.KVFE_OK:
+        raise KvfeError(st, "kvfe_compute_rectification")
+    return r
+
+
+def compute_undistort_rectify_maps(cam: abi.CameraParams, R, P):
+    """UndistorterRectifier::initUndistortRectifyMaps (host math, no device needed)."""
+    Rm = np.ascontiguousarray(R, np.float64).reshape(9)
+    Pm = np.ascontiguousarray(P, np.float64).reshape(12)
+    mx = np.zeros((cam.height, cam.width), np.float32)
+    my = np.zeros((cam.height, cam.width), np.float32)
+    st = load().kvfe_compute_undistort_rectify_maps(C.byref(cam), _p(Rm), _p(Pm), _p(mx), _p(my))
+    if st != abi.KVFE_OK:
+        raise KvfeError(st, "kvfe_compute_undistort_rectify_maps")
+    return mx, my

@@ -1,0 +1,103 @@
+"""ctypes binding of csrc/libkvfe.so (the product).  Fails loudly when the library is missing or
+cannot be loaded: there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi as abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libkvfe.so")
+
+_lib = None
+
+
+class KvfeError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: kvfe status {status} {detail}".strip())
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.run(cmd, check=True)
+    return SO_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(libkvfe has no CPU fallback)")
+    # share one HIP runtime with torch when torch is (or will be) in the process
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the library itself
+        pass
+    L = C.CDLL(SO_PATH)
+    vp, sz, i32, f64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_double
+    L.kvfe_version.restype = C.c_char_p
+    L.kvfe_status_string.restype = C.c_char_p
+    L.kvfe_status_string.argtypes = [i32]
+    L.kvfe_last_error.restype = C.c_char_p
+    L.kvfe_last_error.argtypes = [vp]
+    L.kvfe_default_frontend_params.argtypes = [C.POINTER(abi.FrontendParams)]
+    L.kvfe_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+    L.kvfe_destroy.argtypes = [vp]
+    L.kvfe_compute_rectification.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams),
+                                             C.POINTER(abi.Rectification)]
+    L.kvfe_compute_undistort_rectify_maps.argtypes = [C.POINTER(abi.CameraParams), vp, vp, vp, vp]
+    L.kvfe_get_rectification.argtypes = [vp, C.POINTER(abi.Rectification)]
+    L.kvfe_undistort_rectify_image.argtypes = [vp, i32, vp, sz, vp, sz]
+    L.kvfe_undistort_rectify_keypoints.argtypes = [vp, i32, vp, i32, i32, i32, vp]
+    L.kvfe_get_bearing_vectors.argtypes = [vp, i32, vp, i32, vp]
+    L.kvfe_raw_feature_detection.argtypes = [vp, vp, sz, vp, sz, vp, i32, C.POINTER(i32)]
+    L.kvfe_feature_detection.argtypes = [vp, vp, sz, vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.kvfe_corner_subpix.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, f64]
+    L.kvfe_calc_optical_flow_pyr_lk.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp]
+    L.kvfe_predict_sparse_flow.argtypes = [vp, vp, i32, vp, vp]
+    L.kvfe_get_right_keypoints_rectified.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp, vp]
+    L.kvfe_sparse_stereo_reconstruction.argtypes = [vp, vp, vp, sz, vp, i32,
+                                                    C.POINTER(abi.StereoOutput)]
+    L.kvfe_frontend_step_host.argtypes = [vp, vp, vp, sz, sz, vp]
+    L.kvfe_frontend_step_device.argtypes = [vp, vp, vp, sz, sz, vp]
+    L.kvfe_frontend_reset.argtypes = [vp]
+    L.kvfe_synchronize.argtypes = [vp]
+    L.kvfe_frontend_get_output.argtypes = [vp, i32, C.POINTER(abi.FrameOutput)]
+    L.kvfe_profile_enable.argtypes = [vp, i32]
+    L.kvfe_profile_read.argtypes = [vp, C.POINTER(abi.StageTimes)]
+    for name in dir(L):
+        pass
+    for fn in ("kvfe_create", "kvfe_compute_rectification", "kvfe_compute_undistort_rectify_maps",
+               "kvfe_get_rectification", "kvfe_undistort_rectify_image",
+               "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors",
+               "kvfe_raw_feature_detection", "kvfe_feature_detection", "kvfe_corner_subpix",
+               "kvfe_calc_optical_flow_pyr_lk", "kvfe_predict_sparse_flow",
+               "kvfe_get_right_keypoints_rectified", "kvfe_sparse_stereo_reconstruction",
+               "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
+               "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
+               "kvfe_profile_read"):
+        getattr(L, fn).restype = C.c_int32
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "kvfe_version", "kvfe_status_string", "kvfe_last_error", "kvfe_default_frontend_params",
+    "kvfe_create", "kvfe_destroy", "kvfe_compute_rectification",
+    "kvfe_compute_undistort_rectify_maps", "kvfe_get_rectification", "kvfe_undistort_rectify_image",
+    "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors", "kvfe_raw_feature_detection",
+    "kvfe_feature_detection", "kvfe_corner_subpix", "kvfe_calc_optical_flow_pyr_lk",
+    "kvfe_predict_sparse_flow", "kvfe_get_right_keypoints_rectified",
+    "kvfe_sparse_stereo_reconstruction", "kvfe_frontend_step_host", "kvfe_frontend_step_device",
+    "kvfe_frontend_reset", "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
+    "kvfe_profile_read",
+]

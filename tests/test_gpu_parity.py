@@ -1,0 +1,436 @@
+"""GPU parity tests: the HIP path (through the C ABI of libkvfe.so) against the CPU oracle on the
+same inputs.  Integer / index / status outputs must be bit-exact; float outputs are produced by
+the same IEEE operations in the same order on both sides, so they are asserted bit-exact too
+(tolerance 0) except where a tolerance is written explicitly in the test.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib as O
+from kimera_vio_amd import _abi as abi
+from kimera_vio_amd import frontend as F
+from kimera_vio_amd import params as P
+from kimera_vio_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gray(name):
+    return np.array(Image.open(os.path.join(G, name)).convert("L"))
+
+
+def euroc_cams():
+    return (P.load_camera_params(os.path.join(G, "sensorLeft.yaml")),
+            P.load_camera_params(os.path.join(G, "sensorRight.yaml")))
+
+
+def euroc_params(**det):
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    for k, v in det.items():
+        setattr(p.detector, k, v)
+    return p
+
+
+@pytest.fixture(scope="module")
+def seq():
+    z = np.load(os.path.join(G, "micro_euroc_f10_18.npz"))
+    return dict(lefts=z["lefts"], rights=z["rights"], ts=z["timestamps"], body_R=z["body_R"])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    L, R = euroc_cams()
+    c = F.Context(L, R, euroc_params())
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ocam():
+    L, R = euroc_cams()
+    return O.Camera(L, R)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_native_library_is_loaded():
+    from kimera_vio_amd import lib
+    assert os.path.exists(lib.SO_PATH)
+    assert lib.load().kvfe_version().decode().startswith("libkvfe")
+
+
+def test_rectify_bit_exact(ctx, ocam, seq):
+    """K1 vs cv::remap restatement: every pixel identical, both cameras."""
+    for cam, img in ((0, gray("left_img_0.png")), (1, gray("right_img_0.png")),
+                     (0, seq["lefts"][3]), (1, seq["rights"][3])):
+        got = ctx.undistort_rectify_image(cam, img)
+        exp = ocam.rectify_image(cam, img)
+        assert np.array_equal(got, exp)
+    rng = np.random.RandomState(0)
+    noise = rng.randint(0, 256, size=(480, 752)).astype(np.uint8)
+    assert np.array_equal(ctx.undistort_rectify_image(0, noise), ocam.rectify_image(0, noise))
+
+
+def test_undistort_keypoints_and_versors_bit_exact(ctx, ocam):
+    rng = np.random.RandomState(1)
+    pts = np.stack([rng.uniform(-5, 757, 500), rng.uniform(-5, 485, 500)], 1).astype(np.float32)
+    for cam in (0, 1):
+        for useR, useP in ((1, 1), (1, 0), (0, 0)):
+            got = ctx.undistort_rectify_keypoints(cam, pts, useR, useP)
+            exp = ocam.undistort_keypoints(cam, pts, useR, useP)
+            assert np.array_equal(got, exp)
+        assert np.array_equal(ctx.get_bearing_vectors(cam, pts), ocam.bearing_vectors(cam, pts))
+
+
+def test_predict_sparse_flow_bit_exact(ctx):
+    L, _ = euroc_cams()
+    rng = np.random.RandomState(2)
+    pts = np.stack([rng.uniform(0, 752, 300), rng.uniform(0, 480, 300)], 1).astype(np.float32)
+    for ang in (0.0, 1e-6, 0.002, 0.02, 0.3):
+        R = synth.rot_from_axis_angle([0.3, -0.8, 0.5], ang)
+        got = ctx.predict_sparse_flow(pts, R)
+        exp = O.predict_sparse_flow(abi.FLOW_ROTATIONAL, L, pts, R)
+        assert np.array_equal(got, exp)
+
+
+def test_raw_gftt_bit_exact_and_kat_393():
+    """K2: cv::GFTTDetector::detect restatement; includes the reference KAT (393 corners,
+    tests/testFeatureDetector.cpp:25-50)."""
+    img = gray("left_fisheye_img_0.png")
+    L, R = euroc_cams()
+    d = P.load_detector_params(os.path.join(G, "ForFeatureDetector", "frontendParams-noNMS.yaml"))
+    p = euroc_params()
+    p.detector = d
+    c = F.Context(L, R, p)
+    try:
+        got = c.raw_feature_detection(img)
+        exp, _ = O.good_features_to_track(img, d.max_nr_keypoints_before_anms, d.quality_level,
+                                          d.min_distance, 3)
+        assert len(got) == 393
+        assert np.array_equal(got, exp)
+        rng = np.random.RandomState(3)
+        mask = (rng.uniform(size=img.shape) > 0.3).astype(np.uint8) * 255
+        mask[100:200, 300:500] = 0
+        got = c.raw_feature_detection(img, mask)
+        exp, _ = O.good_features_to_track(img, d.max_nr_keypoints_before_anms, d.quality_level,
+                                          d.min_distance, 3, mask=mask)
+        assert np.array_equal(got, exp)
+        blank = np.full(img.shape, 200, np.uint8)
+        assert len(c.raw_feature_detection(blank)) == 0
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("yaml_name,overrides,expected", [
+    ("frontendParams-noNMS.yaml", {}, 393),
+    ("frontendParams-noNMS.yaml", {"quality_level": 1e-10}, 400),
+    ("frontendParams-NMS-TopN.yaml", {}, 300),
+    ("frontendParams-NMS-Binning.yaml", {}, 20),
+    ("frontendParams-NMS-Binning.yaml", {"max_features_per_frame": 200, "quality_level": 1e-10,
+                                         "enable_subpixel_corner_refinement": 0}, 200),
+    ("frontendParams-NMS-Binning2.yaml", {"quality_level": 1e-10,
+                                          "enable_subpixel_corner_refinement": 0}, 140),
+    ("frontendParams-NMS-Binning.yaml", {"sortidx_policy": abi.SORTIDX_STABLE}, 20),
+])
+def test_feature_detection_kats_and_parity(yaml_name, overrides, expected):
+    """FeatureDetector::featureDetection on the reference's own KAT configurations
+    (tests/testFeatureDetector.cpp): counts match the reference, every keypoint matches the oracle."""
+    img = gray("left_fisheye_img_0.png")
+    L, R = euroc_cams()
+    d = P.load_detector_params(os.path.join(G, "ForFeatureDetector", yaml_name))
+    for k, v in overrides.items():
+        setattr(d, k, v)
+    p = euroc_params()
+    p.detector = d
+    c = F.Context(L, R, p)
+    try:
+        none = np.zeros((0, 2), np.float32)
+        got = c.feature_detection(img, none, d.max_features_per_frame)
+        exp, _ = O.feature_detection(img, none, d.max_features_per_frame, d)
+        assert len(got) == expected
+        assert np.array_equal(got, exp)
+    finally:
+        c.close()
+
+
+def test_feature_detection_with_tracked_mask(ctx, seq):
+    """mask = 255 minus cv::circle discs around tracked keypoints (FeatureDetector.cpp:185-203)."""
+    img = seq["lefts"][0]
+    d = ctx.params.detector
+    first, _ = O.feature_detection(img, np.zeros((0, 2), np.float32), 300, d)
+    tracked = first[::2] + np.float32(0.37)  # non-integer centres exercise cvRound
+    need = 300 - len(tracked)
+    got = ctx.feature_detection(img, tracked, need)
+    exp, _ = O.feature_detection(img, tracked, need, d)
+    assert len(got) > 0
+    assert np.array_equal(got, exp)
+    # keypoints at the image border exercise the clipped discs
+    border = np.array([[0.2, 0.4], [751.4, 479.2], [3.5, 470.5], [748.5, 2.5]], np.float32)
+    got = ctx.feature_detection(img, border, 120)
+    exp, _ = O.feature_detection(img, border, 120, d)
+    assert np.array_equal(got, exp)
+
+
+def test_corner_subpix_bit_exact(ctx, seq):
+    img = seq["lefts"][1]
+    pts, _ = O.good_features_to_track(img, 400, 0.001, 10, 3)
+    edge = np.array([[2.0, 3.0], [749.0, 477.0], [5.0, 240.0], [375.0, 4.0], [11.5, 11.5]], np.float32)
+    pts = np.concatenate([pts, edge])
+    got = ctx.corner_subpix(img, pts, 10, -1, 40, 0.001)
+    exp = O.corner_subpix(img, pts, 10, -1, 40, 0.001)
+    assert np.array_equal(got, exp)
+    got = ctx.corner_subpix(img, pts[:50], 5, 1, 10, 0.01)
+    exp = O.corner_subpix(img, pts[:50], 5, 1, 10, 0.01)
+    assert np.array_equal(got, exp)
+
+
+def test_lk_bit_exact(ctx, seq):
+    """K4: cv::calcOpticalFlowPyrLK restatement (SSE2 accumulation order): positions, status and
+    error identical."""
+    t = ctx.params.tracker
+    for a, b in ((0, 1), (2, 5), (0, 8)):
+        prev, cur = seq["lefts"][a], seq["lefts"][b]
+        pts, _ = O.good_features_to_track(prev, 300, 0.001, 20, 3)
+        pts = O.corner_subpix(prev, pts)
+        extra = np.array([[1.0, 1.0], [750.5, 478.5], [10.0, 470.0], [745.0, 8.0], [376.0, 240.0]], np.float32)
+        pts = np.concatenate([pts, extra])
+        init = pts + np.float32(0.75)
+        got, gst, gerr = ctx.calc_optical_flow_pyr_lk(prev, cur, pts, init)
+        exp, est, eerr, lvl = O.calc_optical_flow_pyr_lk(prev, cur, pts, init, t.klt_win_size,
+                                                         t.klt_max_level, t.klt_max_iter, t.klt_eps)
+        assert lvl == 4
+        assert np.array_equal(gst, est)
+        assert np.array_equal(got, exp)
+        assert np.array_equal(gerr, eerr)
+        assert est.sum() > 100
+
+
+def test_stereo_match_849_of_900_and_parity(ocam):
+    """tests/testStereoMatcher.cpp:272-388 on the GPU path (default StereoMatchingParams)."""
+    L, R = euroc_cams()
+    p = euroc_params()
+    p.stereo = P.default_frontend_params().stereo
+    left = gray("left_img_0.png")
+    kps, _ = O.good_features_to_track(left, 100, 0.01, 10, 3)
+    rows, cols = left.shape
+    count_valid = total = 0
+    # the reference test passes fx = 458.654; build a context whose rectified fx is what the
+    # matcher sees is not possible through the API, so compare against the oracle at the context's
+    # own fx and count validity with the reference's rule.
+    c = F.Context(L, R, p)
+    try:
+        for offset in (-20, -10, -5):
+            right = np.zeros_like(left)
+            right[:, : cols + offset] = left[:, -offset:]
+            acc = np.zeros((0, 2), np.float32)
+            for t in range(2):
+                add = kps if t == 0 else np.round(kps)
+                acc = np.concatenate([acc, add.astype(np.float32)])
+                st = np.zeros(len(acc), np.uint8)
+                rxy, rst, sc = c.get_right_keypoints_rectified(left, right, acc, st)
+                exy, est, esc = ocam.get_right_keypoints_rectified(left, right, acc, st, p.stereo)
+                assert np.array_equal(rxy, exy) and np.array_equal(rst, est) and np.array_equal(sc, esc)
+                for i in range(len(acc)):
+                    total += 1
+                    y_left = float(acc[i, 1])
+                    x_exp = float(acc[i, 0]) + offset
+                    if y_left <= 7 or y_left + 7 >= rows:
+                        assert rst[i] == abi.KP_NO_RIGHT_RECT
+                    elif x_exp >= 50 and x_exp + 50 < cols:
+                        assert rst[i] == abi.KP_VALID
+                        assert abs(x_exp - float(rxy[i, 0])) < 0.5
+                        assert abs(float(acc[i, 1]) - float(rxy[i, 1])) < 0.5
+                        count_valid += 1
+    finally:
+        c.close()
+    assert total == 900 and count_valid == 849
+
+
+@pytest.mark.parametrize("subpix", [0, 1])
+def test_sparse_stereo_bit_exact(ocam, subpix):
+    L, R = euroc_cams()
+    p = euroc_params()
+    p.stereo.subpixel_refinement = subpix
+    left, right = gray("left_img_0.png"), gray("right_img_0.png")
+    kps, _ = O.good_features_to_track(left, 300, 0.001, 10, 3)
+    kps = np.concatenate([O.corner_subpix(left, kps),
+                          np.array([[3.0, 3.0], [748.0, 476.0], [400.0, 2.0], [-4.0, 100.0]], np.float32)])
+    c = F.Context(L, R, p)
+    try:
+        got = c.sparse_stereo_reconstruction(left, right, kps, want_images=True)
+        exp = ocam.sparse_stereo(left, right, kps, p.stereo, want_images=True)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), k
+        assert (got["right_status"] == abi.KP_VALID).sum() > 100
+    finally:
+        c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+def _kf_rotations(body_R, cam: O.Camera):
+    """camLrect_R_body used by nominalSpinStereo (StereoVisionImuFrontend.cpp:143-150)."""
+    TL = np.array(cam.left.body_pose_cam).reshape(4, 4)
+    R1 = np.array(cam.rect.R1).reshape(3, 3)
+    body_R_cam = TL[:3, :3] @ R1.T
+    return [body_R_cam.T @ R @ body_R_cam for R in body_R]
+
+
+def _run_sequence(oracle_fe, gpu_ctx, seq, stream_of=lambda s, i: i, force_kf=False, n=None):
+    """drives oracle and GPU front-ends in lock-step and asserts identical outputs per frame"""
+    B = gpu_ctx.batch
+    n = n or len(seq["ts"])
+    kf_index = [0] * B
+    camR = seq["camR"]
+    kinds = []
+    for i in range(n):
+        idx = [stream_of(s, i) for s in range(B)]
+        Rs = [camR[kf_index[s]].T @ camR[idx[s]] for s in range(B)]
+        ts = [int(seq["ts"][i]) for _ in range(B)]
+        lefts = np.stack([seq["lefts"][j] for j in idx])
+        rights = np.stack([seq["rights"][j] for j in idx])
+        inputs = gpu_ctx.make_inputs(ts, Rs, [int(force_kf)] * B)
+        gpu_ctx.step_host(lefts, rights, inputs)
+        for s in range(B):
+            exp = oracle_fe[s].process(lefts[s], rights[s], ts[s], Rs[s], force_kf)
+            got = gpu_ctx.get_output(s)
+            for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected", "n_measurements", "frame_id"):
+                assert got[k] == exp[k], (i, s, k, got[k], exp[k])
+            keys = ["landmarks", "landmarks_age", "keypoints", "versors"]
+            if exp["has_stereo"] and exp["is_keyframe"]:
+                keys += ["left_rect_xy", "left_status", "right_rect_xy", "right_status", "depth",
+                         "right_xy", "keypoints_3d", "meas_landmark"]
+            for k in keys:
+                assert np.array_equal(got[k], exp[k]), (i, s, k)
+            if exp["is_keyframe"]:
+                assert np.array_equal(got["meas_uL_uR_v"], exp["meas_uL_uR_v"], equal_nan=True), (i, s)
+                kf_index[s] = idx[s]
+            kinds.append((i, s, exp["is_keyframe"], exp["n_tracked"], exp["n_detected"]))
+    return kinds
+
+
+def test_frontend_sequence_single_stream(seq, ocam):
+    """C2: one EuRoC stream through processFirstStereoFrame / processStereoFrame (useRANSAC = 0);
+    landmark ids, ages, keypoints, versors, stereo statuses, depths and measurements identical to
+    the oracle on every frame; keyframes every 0.2 s as in the reference."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = euroc_params()
+    fe = [O.Frontend(L, R, p)]
+    c = F.Context(L, R, p, batch=1)
+    try:
+        kinds = _run_sequence(fe, c, seq)
+    finally:
+        c.close()
+    kfs = [k[2] for k in kinds]
+    assert kfs == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    assert all(k[3] > 100 for k in kinds[1:])
+
+
+def test_frontend_sequence_batched_streams(seq, ocam):
+    """C3-style: 4 independent streams in one context (different frame offsets / directions), each
+    with its own landmark-id counter starting at 0, all identical to per-stream oracles."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = euroc_params(max_features_per_frame=200)
+    B = 4
+    fe = [O.Frontend(L, R, p) for _ in range(B)]
+    c = F.Context(L, R, p, batch=B)
+
+    def stream_of(s, i):
+        return [i, 8 - i, min(i + 2, 8), (3 * i) % 9][s]
+
+    try:
+        _run_sequence(fe, c, seq, stream_of=stream_of, n=7)
+    finally:
+        c.close()
+
+
+def test_frontend_force_keyframe_every_frame(seq, ocam):
+    """KF-every-frame mode used by the benchmark (Frame::isKeyframe_ forced by the caller)."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = euroc_params()
+    fe = [O.Frontend(L, R, p)]
+    c = F.Context(L, R, p, batch=1)
+    try:
+        kinds = _run_sequence(fe, c, seq, force_kf=True, n=5)
+    finally:
+        c.close()
+    assert all(k[2] == 1 for k in kinds)
+
+
+def test_frontend_lost_tracks_redetects(ocam):
+    """StereoVisionImuFrontend.cpp:313-323: when LK loses every point the frame re-detects and is
+    not a keyframe (tests/testStereoVisionImuFrontend.cpp testLostFeatureTrack)."""
+    L, R = euroc_cams()
+    p = euroc_params()
+    rng = np.random.RandomState(5)
+    a = gray("left_img_0.png")
+    b = gray("right_img_0.png")
+    flat = np.full_like(a, 127)
+    fe = O.Frontend(L, R, p)
+    c = F.Context(L, R, p, batch=1)
+    try:
+        frames = [(a, b), (flat, flat), (a, b), (a, b)]
+        for i, (l, r) in enumerate(frames):
+            ts = 1000 + i * 50_000_000
+            c.step_host(l[None], r[None], c.make_inputs([ts]))
+            exp = fe.process(l, r, ts)
+            got = c.get_output(0)
+            for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected"):
+                assert got[k] == exp[k], (i, k, got[k], exp[k])
+            for k in ("landmarks", "landmarks_age", "keypoints"):
+                assert np.array_equal(got[k], exp[k]), (i, k)
+        assert exp["n_keypoints"] > 0
+    finally:
+        c.close()
+
+
+def test_synthetic_1280x720_properties_and_parity():
+    """C5-sized synthetic frames (1280x720, 1000 features, 4-level LK): parity with the oracle on
+    a short run plus size-independent properties (ids unique and increasing, ages, statuses)."""
+    L, R = euroc_cams()
+    for cam in (L, R):
+        cam.width, cam.height = 1280, 720
+        cam.intrinsics[0] *= 1280 / 752.0
+        cam.intrinsics[1] *= 1280 / 752.0
+        cam.intrinsics[2] = 640.0 + (cam.intrinsics[2] - 376.0)
+        cam.intrinsics[3] = 360.0 + (cam.intrinsics[3] - 240.0)
+    p = euroc_params(max_features_per_frame=1000)
+    p.tracker.klt_max_level = 3
+    st = synth.SyntheticStream(L, seed=7)
+    fe = O.Frontend(L, R, p)
+    c = F.Context(L, R, p, batch=1)
+    try:
+        kf = 0
+        seen = set()
+        for t in range(4):
+            l, r = st.frame(t)
+            Rk = synth.keyframe_R_cur(st, kf, t)
+            ts = t * 50_000_000
+            c.step_host(l[None], r[None], c.make_inputs([ts], [Rk], [1]))
+            exp = fe.process(l, r, ts, Rk, True)
+            got = c.get_output(0)
+            assert got["n_keypoints"] == exp["n_keypoints"] > 500
+            for k in ("landmarks", "landmarks_age", "keypoints", "left_status", "right_status",
+                      "right_rect_xy", "depth"):
+                assert np.array_equal(got[k], exp[k]), (t, k)
+            ids = got["landmarks"]
+            assert len(set(ids.tolist())) == len(ids)
+            new = ids[got["n_tracked"]:]
+            assert np.all(np.diff(new) == 1) if len(new) > 1 else True
+            assert not (set(new.tolist()) & seen)
+            seen |= set(ids.tolist())
+            assert np.all(got["landmarks_age"][got["n_tracked"]:] == 1)
+            kf = t
+    finally:
+        c.close()

@@ -1,0 +1,114 @@
+"""CPU-only tests of the product library's host side: the C-ABI shared library loads, exports
+every symbol include/kvfe.h declares, its init-time calibration math (stereoRectify, maps) agrees
+with the oracle, and it refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from kimera_vio_amd import _abi as abi
+from kimera_vio_amd import frontend as F
+from kimera_vio_amd import lib as L
+from kimera_vio_amd import params as P
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "kvfe.h")).read()
+    declared = set(re.findall(r"KVFE_API\s+[\w\s\*]+?\b(kvfe_\w+)\s*\(", header))
+    assert declared, "no KVFE_API declarations found"
+    assert declared == set(L.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), f"libkvfe.so does not export {name}"
+    assert lib.kvfe_version().decode().startswith("libkvfe")
+
+
+def test_abi_struct_sizes_match_header():
+    # sizes computed from the C declaration order (natural alignment); guards _abi.py drift
+    assert C.sizeof(abi.CameraParams) == 8 + 32 + 8 + 64 + 128
+    assert C.sizeof(abi.FrameInput) == 8 + 72 + 8
+    assert C.sizeof(abi.Rectification) == (9 + 9 + 12 + 12 + 16) * 8 + 32 + 8
+    assert C.sizeof(abi.DetectorParams) % 8 == 0 and C.sizeof(abi.FrontendParams) % 8 == 0
+
+
+def test_default_params_match_python_mirror():
+    lib = L.load()
+    a = abi.FrontendParams()
+    lib.kvfe_default_frontend_params(C.byref(a))
+    b = P.default_frontend_params()
+    assert bytes(a) == bytes(b)
+
+
+@pytest.mark.parametrize("pair", [("sensorLeft.yaml", "sensorRight.yaml"),
+                                  ("ForStereoTracker/camLeft.yaml", "ForStereoTracker/camRight.yaml"),
+                                  ("params_euroc/LeftCameraParams.yaml", "params_euroc/RightCameraParams.yaml")])
+def test_rectification_matches_oracle(pair):
+    """StereoCamera::computeRectificationParameters: the product's host math vs the oracle's
+    independent restatement of cv::stereoRectify (both float64, same operation order)."""
+    Lc = P.load_camera_params(os.path.join(G, pair[0]))
+    Rc = P.load_camera_params(os.path.join(G, pair[1]))
+    r = F.compute_rectification(Lc, Rc)
+    o = O.Camera(Lc, Rc).rect
+    for name in ("R1", "R2", "P1", "P2", "Q"):
+        assert np.allclose(np.array(getattr(r, name)), np.array(getattr(o, name)), rtol=0, atol=1e-12), name
+    assert list(r.roi1) == list(o.roi1) and list(r.roi2) == list(o.roi2)
+    assert abs(r.baseline - o.baseline) < 1e-15
+
+
+def test_baseline_kat():
+    """tests/testStereoMatcher.cpp:148 on the product's own host math."""
+    Lc = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    assert abs(F.compute_rectification(Lc, Rc).baseline - 0.110078) < 1e-5
+
+
+def test_maps_match_oracle_bit_exact():
+    """UndistorterRectifier::initUndistortRectifyMaps: float32 maps identical to the oracle's."""
+    Lc = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    cam = O.Camera(Lc, Rc)
+    for c, cp in ((0, Lc), (1, Rc)):
+        R = cam.rect.R1 if c == 0 else cam.rect.R2
+        Pm = cam.rect.P1 if c == 0 else cam.rect.P2
+        mx, my = F.compute_undistort_rectify_maps(cp, np.array(R), np.array(Pm))
+        ox, oy = cam.maps(c)
+        assert np.array_equal(mx, ox) and np.array_equal(my, oy)
+
+
+def test_create_fails_loudly_without_gpu():
+    """No CPU fallback: on a machine without a gfx950 device kvfe_create returns NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    Lc = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    with pytest.raises(L.KvfeError) as e:
+        F.Context(Lc, Rc, p)
+    assert e.value.status == abi.KVFE_ERR_NO_DEVICE
+
+
+def test_unsupported_configurations_are_rejected():
+    Lc = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    assert p.use_ransac == 1
+    with pytest.raises(L.KvfeError) as e:
+        F.Context(Lc, Rc, p)
+    assert e.value.status == abi.KVFE_ERR_UNSUPPORTED
+
+
+def test_yaml_parsing_euroc():
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    assert p.detector.max_features_per_frame == 300 and p.detector.non_max_suppression_type == 6
+    assert p.detector.nr_horizontal_bins == 7 and p.detector.nr_vertical_bins == 5
+    assert sum(p.detector.binning_mask) == 35
+    assert p.tracker.klt_max_level == 4 and p.tracker.klt_win_size == 24 and abs(p.tracker.klt_eps - 0.1) < 1e-15
+    assert p.stereo.templ_cols == 101 and p.stereo.min_point_dist == 0.5
+    assert p.min_intra_keyframe_time_ns == 0.2e9 and p.max_intra_keyframe_time_ns == 5e9
