@@ -32,7 +32,6 @@ constexpr int SH = 3;                     // source halo
 constexpr int SW_ = TW + 2 * SH, SHT = TH + 2 * SH;
 constexpr int CW_ = TW + 2 * CH, CHT = TH + 2 * CH;
 constexpr int LW_ = TW + 2, LHT = TH + 2;
-constexpr int MAX_TILE_DISCS = 96;
 
 __global__ __launch_bounds__(256) void mineig_localmax_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
@@ -44,36 +43,53 @@ __global__ __launch_bounds__(256) void mineig_localmax_kernel(
   const int s = blockIdx.z;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
   __shared__ unsigned char src[SHT][SW_ + 2];
-  __shared__ float cov0[CHT][CW_ + 1], cov1[CHT][CW_ + 1], cov2[CHT][CW_ + 1];
+  __shared__ float covs[3][CHT][CW_ + 1];  // dx*dx, dx*dy, dy*dy
+  float(*cov0)[CW_ + 1] = covs[0];
+  float(*cov1)[CW_ + 1] = covs[1];
+  float(*cov2)[CW_ + 1] = covs[2];
   __shared__ float lam[LHT][LW_ + 1];
-  __shared__ int disc_cx[MAX_TILE_DISCS], disc_cy[MAX_TILE_DISCS];
+  __shared__ unsigned long long rowmask[TH];  // bit x set: pixel (x0+x, y0+row) is masked OUT
   __shared__ int hw_s[MAX_RADIUS + 1];
-  __shared__ int n_disc;
+  __shared__ int blk_n, blk_base;
+  __shared__ unsigned blk_key;
 
   const unsigned char* I = img + (size_t)s * img_stride;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tid = threadIdx.x;
-  if (tid == 0) n_disc = 0;
+  if (tid < TH) rowmask[tid] = 0ull;
   for (int i = tid; i <= radius && i <= MAX_RADIUS; i += 256) hw_s[i] = circle_hw[i];
-  for (int i = tid; i < SW_ * SHT; i += 256) {
-    const int ty = i / SW_, tx = i - ty * SW_;
-    const int gx = reflect101(x0 - SH + tx, W), gy = reflect101(y0 - SH + ty, H);
-    src[ty][tx] = I[(size_t)gy * row_stride + gx];
+  // tile (with its source halo) entirely inside the image: no border reflection anywhere
+  const bool interior = x0 - SH >= 0 && y0 - SH >= 0 && x0 + TW + SH <= W && y0 + TH + SH <= H;
+  if (interior) {
+    for (int i = tid; i < SW_ * SHT; i += 256) {
+      const int ty = i / SW_, tx = i - ty * SW_;
+      src[ty][tx] = I[(size_t)(y0 - SH + ty) * row_stride + (x0 - SH + tx)];
+    }
+  } else {
+    for (int i = tid; i < SW_ * SHT; i += 256) {
+      const int ty = i / SW_, tx = i - ty * SW_;
+      const int gx = reflect101(x0 - SH + tx, W), gy = reflect101(y0 - SH + ty, H);
+      src[ty][tx] = I[(size_t)gy * row_stride + gx];
+    }
   }
   __syncthreads();
-  // discs whose bounding box touches this tile
+  // detection mask: rasterise the cv::circle discs that touch this tile into 16 row bitmasks
   if (use_discs) {
     const float2* kp = kp_all + (size_t)s * kcap;
     const int nk = kp_count[s];
     for (int i = tid; i < nk; i += 256) {
       const float2 p = kp[i];
       const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
-      if (cx + radius >= x0 && cx - radius < x0 + TW && cy + radius >= y0 && cy - radius < y0 + TH) {
-        const int slot = atomicAdd(&n_disc, 1);
-        if (slot < MAX_TILE_DISCS) {
-          disc_cx[slot] = cx;
-          disc_cy[slot] = cy;
-        }
+      if (cx + radius < x0 || cx - radius >= x0 + TW || cy + radius < y0 || cy - radius >= y0 + TH)
+        continue;
+      const int r0 = max(cy - radius, y0), r1 = min(cy + radius, y0 + TH - 1);
+      for (int gy = r0; gy <= r1; gy++) {
+        const int hw = hw_s[abs(gy - cy)];
+        const int xa = max(cx - hw, x0) - x0, xb = min(cx + hw, x0 + TW - 1) - x0;
+        if (xa > xb) continue;
+        const unsigned long long bits =
+            (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
+        atomicOr(&rowmask[gy - y0], bits);
       }
     }
   }
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(256) void mineig_localmax_kernel(
   for (int i = tid; i < CW_ * CHT; i += 256) {
     const int cy = i / CW_, cx = i - cy * CW_;
     const int gx = x0 - CH + cx, gy = y0 - CH + cy;
-    if (gx < 0 || gx >= W || gy < 0 || gy >= H) continue;
+    if (!interior && (gx < 0 || gx >= W || gy < 0 || gy >= H)) continue;
     const int sx = cx + (SH - CH), sy = cy + (SH - CH);  // position in src tile
     const float r0 = (float)((int)src[sy - 1][sx + 1] - (int)src[sy - 1][sx - 1]);
     const float r1 = (float)((int)src[sy][sx + 1] - (int)src[sy][sx - 1]);
@@ -101,42 +117,98 @@ __global__ __launch_bounds__(256) void mineig_localmax_kernel(
     cov2[cy][cx] = dy * dy;
   }
   __syncthreads();
-  // box 3x3 (unnormalised, double accumulation like cv::boxFilter on CV_32F) + min eigenvalue
-  for (int i = tid; i < LW_ * LHT; i += 256) {
-    const int ly = i / LW_, lx = i - ly * LW_;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    float v = 0.0f;
-    if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
-      int cxs[3], cys[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        cxs[k] = reflect101(gx - 1 + k, W) - (x0 - CH);
-        cys[k] = reflect101(gy - 1 + k, H) - (y0 - CH);
+  // box 3x3 (unnormalised, double accumulation like cv::boxFilter on CV_32F), separable: a thread
+  // walks a 6-row segment of one lambda column keeping the horizontal sums of the last three cov
+  // rows in registers (row sums first, then the column sum: the order cv::boxFilter uses).
+  {
+    constexpr int SEG = 6;  // LHT = 18 = 3 segments
+    const int lx = tid % LW_, seg = tid / LW_;
+    if (seg < LHT / SEG) {
+      const int gx = x0 - 1 + lx;
+      const bool col_ok = interior || (gx >= 0 && gx < W);
+      int c0 = lx, c1 = lx + 1, c2 = lx + 2;  // cov columns of gx-1, gx, gx+1
+      if (!interior && col_ok) {
+        c0 = reflect101(gx - 1, W) - (x0 - CH);
+        c2 = reflect101(gx + 1, W) - (x0 - CH);
       }
-      double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
+      double h0[3], h1[3], h2[3];  // horizontal sums of cov rows gy-1, gy, gy+1 (rolling)
+      auto hsum = [&](int cr, double& o0, double& o1, double& o2) {
         double a0 = 0, a1 = 0, a2 = 0;
+        a0 += (double)cov0[cr][c0];
+        a0 += (double)cov0[cr][c1];
+        a0 += (double)cov0[cr][c2];
+        a1 += (double)cov1[cr][c0];
+        a1 += (double)cov1[cr][c1];
+        a1 += (double)cov1[cr][c2];
+        a2 += (double)cov2[cr][c0];
+        a2 += (double)cov2[cr][c1];
+        a2 += (double)cov2[cr][c2];
+        o0 = a0;
+        o1 = a1;
+        o2 = a2;
+      };
+      const int ly0 = seg * SEG;
+      if (interior) {
+        hsum(ly0, h0[0], h1[0], h2[0]);
+        hsum(ly0 + 1, h0[1], h1[1], h2[1]);
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          a0 += (double)cov0[cys[r]][cxs[c]];
-          a1 += (double)cov1[cys[r]][cxs[c]];
-          a2 += (double)cov2[cys[r]][cxs[c]];
+        for (int r = 0; r < SEG; r++) {
+          const int ly = ly0 + r;
+          hsum(ly + 2, h0[(r + 2) % 3], h1[(r + 2) % 3], h2[(r + 2) % 3]);
+          double s0 = 0, s1 = 0, s2 = 0;
+          s0 += h0[r % 3];
+          s0 += h0[(r + 1) % 3];
+          s0 += h0[(r + 2) % 3];
+          s1 += h1[r % 3];
+          s1 += h1[(r + 1) % 3];
+          s1 += h1[(r + 2) % 3];
+          s2 += h2[r % 3];
+          s2 += h2[(r + 1) % 3];
+          s2 += h2[(r + 2) % 3];
+          const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
+          lam[ly][lx] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
         }
-        s0 += a0;
-        s1 += a1;
-        s2 += a2;
+      } else {
+        for (int r = 0; r < SEG; r++) {
+          const int ly = ly0 + r, gy = y0 - 1 + ly;
+          float v = 0.0f;
+          if (col_ok && gy >= 0 && gy < H) {
+            const int r0 = reflect101(gy - 1, H) - (y0 - CH), r1 = gy - (y0 - CH),
+                      r2 = reflect101(gy + 1, H) - (y0 - CH);
+            hsum(r0, h0[0], h1[0], h2[0]);
+            hsum(r1, h0[1], h1[1], h2[1]);
+            hsum(r2, h0[2], h1[2], h2[2]);
+            double s0 = 0, s1 = 0, s2 = 0;
+            s0 += h0[0];
+            s0 += h0[1];
+            s0 += h0[2];
+            s1 += h1[0];
+            s1 += h1[1];
+            s1 += h1[2];
+            s2 += h2[0];
+            s2 += h2[1];
+            s2 += h2[2];
+            const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
+            v = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+          }
+          lam[ly][lx] = v;
+        }
       }
-      const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
-      v = (a + c) - sqrtf((a - c) * (a - c) + b * b);
     }
-    lam[ly][lx] = v;
   }
   __syncthreads();
-  const int nd = min(n_disc, MAX_TILE_DISCS);
-  const bool disc_overflow = n_disc > MAX_TILE_DISCS;
   unsigned bestkey = 0;
   const unsigned char* M = user_mask ? user_mask + (size_t)s * W * H : nullptr;
+  // candidates are first collected per block in LDS (reusing the cov0 array), then appended to
+  // the stream's list with ONE global atomic per block.
+  unsigned long long* lcand = reinterpret_cast<unsigned long long*>(&covs[0][0][0]);
+  constexpr int LCAP = (int)(sizeof(covs) / sizeof(unsigned long long));
+  static_assert(LCAP >= TW * TH, "every pixel of a tile may be a candidate");
+  if (tid == 0) {
+    blk_n = 0;
+    blk_key = 0;
+  }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int lx = tid & 63, ly = (tid >> 6) + 4 * k;
@@ -145,29 +217,8 @@ __global__ __launch_bounds__(256) void mineig_localmax_kernel(
     float v = 0.f;
     if (gx < W && gy < H) {
       v = lam[ly + 1][lx + 1];
-      bool masked_in = true;
+      bool masked_in = !((rowmask[ly] >> lx) & 1ull);
       if (M && M[(size_t)gy * W + gx] == 0) masked_in = false;
-      if (masked_in && use_discs) {
-        if (!disc_overflow) {
-          for (int d = 0; d < nd; d++) {
-            const int ady = abs(gy - disc_cy[d]);
-            if (ady <= radius && abs(gx - disc_cx[d]) <= hw_s[ady]) {
-              masked_in = false;
-              break;
-            }
-          }
-        } else {  // rare: more discs than LDS slots, test all keypoints
-          const float2* kp = kp_all + (size_t)s * kcap;
-          const int nk = kp_count[s];
-          for (int d = 0; d < nk; d++) {
-            const int ady = abs(gy - __float2int_rn(kp[d].y));
-            if (ady <= radius && abs(gx - __float2int_rn(kp[d].x)) <= hw_s[ady]) {
-              masked_in = false;
-              break;
-            }
-          }
-        }
-      }
       if (masked_in) {
         bestkey = max(bestkey, fkey(v));
         if (v != 0.0f && gx >= 1 && gx < W - 1 && gy >= 1 && gy < H - 1) {
@@ -180,25 +231,35 @@ __global__ __launch_bounds__(256) void mineig_localmax_kernel(
         }
       }
     }
-    // wave-aggregated append
     const unsigned long long bal = __ballot(is_cand);
     if (bal) {
       const int lane = tid & 63;
       const int leader = __ffsll((long long)bal) - 1;
       int base = 0;
-      if (lane == leader) base = atomicAdd(&cand_count[s], __popcll(bal));
+      if (lane == leader) base = atomicAdd(&blk_n, __popcll(bal));
       base = __shfl(base, leader);
       if (is_cand) {
         const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (pos < ccap)
-          cand_all[(size_t)s * ccap + pos] =
-              ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(gy * W + gx);
+        if (pos < LCAP)
+          lcand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(gy * W + gx);
       }
     }
   }
-  // masked maximum: wave reduce then one atomic per wave
   for (int off = 32; off > 0; off >>= 1) bestkey = max(bestkey, (unsigned)__shfl_xor((int)bestkey, off));
-  if ((tid & 63) == 0 && bestkey) atomicMax(&maxkey[s], bestkey);
+  if ((tid & 63) == 0 && bestkey) atomicMax(&blk_key, bestkey);
+  __syncthreads();
+  const int nloc = min(blk_n, LCAP);
+  if (tid == 0) {
+    blk_base = nloc > 0 ? atomicAdd(&cand_count[s], nloc) : 0;
+    // masked maximum: one global atomic per block, skipped when it cannot raise the maximum
+    if (blk_key && blk_key > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(&maxkey[s], blk_key);
+  }
+  __syncthreads();
+  for (int i = tid; i < nloc; i += 256) {
+    const int pos = blk_base + i;
+    if (pos < ccap) cand_all[(size_t)s * ccap + pos] = lcand[i];
+  }
 }
 
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,

@@ -94,30 +94,59 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   }
   if (stripe_corner_x < 0) stripe_corner_x = 0;
 
-  unsigned char* tpl = lds;               // tr x tc
-  unsigned char* stp = lds + tr * tc;     // sr x sc
+  // LDS layout: template rows padded to a multiple of 4 bytes (zero filled), stripe rows padded
+  // to a multiple of 4 bytes plus two slack dwords, both dword-addressable.
+  const int tcw = (tc + 3) >> 2;            // template dwords per row
+  const int scw = ((sc + 3) >> 2) + 2;      // stripe dwords per row
+  unsigned* tplw = reinterpret_cast<unsigned*>(lds);
+  unsigned* stpw = tplw + tr * tcw;
+  unsigned char* tpl = reinterpret_cast<unsigned char*>(tplw);
+  unsigned char* stp = reinterpret_cast<unsigned char*>(stpw);
+  for (int e = lane; e < tr * tcw; e += 64) tplw[e] = 0u;
+  for (int e = lane; e < sr * scw; e += 64) stpw[e] = 0u;
+  __syncthreads();
   for (int e = lane; e < tr * tc; e += 64) {
     const int y = e / tc, x = e - y * tc;
-    tpl[e] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
+    tpl[y * tcw * 4 + x] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
   }
   for (int e = lane; e < sr * sc; e += 64) {
     const int y = e / sc, x = e - y * sc;
-    stp[e] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
+    stp[y * scw * 4 + x] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
   }
   __syncthreads();
+  // SSD(o) = sum T^2 + sum S_o^2 - 2 sum T*S_o with packed u8 dot products (exact in int32:
+  // 101*11*255^2 < 2^27).  A lane owns offsets o = lane + 64 j; the unaligned stripe dword is
+  // rebuilt from two aligned LDS dwords with v_alignbyte.
+  unsigned t2 = 0;
+  for (int e = lane; e < tr * tcw; e += 64) t2 = __builtin_amdgcn_udot4(tplw[e], tplw[e], t2, false);
+  for (int off = 32; off > 0; off >>= 1) t2 += (unsigned)__shfl_xor((int)t2, off);
   const int rw = sc - tc + 1, rh = sr - tr + 1;
+  const int rem = tc & 3;
+  const unsigned lastmask = rem == 0 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
   unsigned long long best = ~0ull;
   for (int o = lane; o < rw * rh; o += 64) {
     const int oy = o / rw, ox = o - oy * rw;
-    unsigned ssd = 0;
+    const int q0 = ox >> 2, sh = ox & 3;
+    unsigned ss = 0, ts = 0;
     for (int y = 0; y < tr; y++) {
-      const unsigned char* a = tpl + y * tc;
-      const unsigned char* b = stp + (oy + y) * sc + ox;
-      for (int x = 0; x < tc; x++) {
-        const int d = (int)a[x] - (int)b[x];
-        ssd += (unsigned)(d * d);
+      const unsigned* trow = tplw + y * tcw;
+      const unsigned* srow = stpw + (oy + y) * scw + q0;
+      unsigned lo = srow[0];
+      for (int k = 0; k < tcw - 1; k++) {
+        const unsigned hi = srow[k + 1];
+        const unsigned sv = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        ts = __builtin_amdgcn_udot4(trow[k], sv, ts, false);
+        ss = __builtin_amdgcn_udot4(sv, sv, ss, false);
+        lo = hi;
+      }
+      {
+        const unsigned hi = srow[tcw];
+        const unsigned sv = __builtin_amdgcn_alignbyte(hi, lo, sh) & lastmask;
+        ts = __builtin_amdgcn_udot4(trow[tcw - 1], sv, ts, false);
+        ss = __builtin_amdgcn_udot4(sv, sv, ss, false);
       }
     }
+    const unsigned ssd = t2 + ss - 2u * ts;
     const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)o;
     best = key < best ? key : best;
   }
@@ -132,7 +161,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int my = by + stripe_corner_y + (tr - 1) / 2;
   float2 match = make_float2((float)mx, (float)my);
   if (P.stereo_subpix) {  // cv::cornerSubPix(right_rectified, (10,10), (-1,-1), 40 it, 0.001)
-    double* terms = reinterpret_cast<double*>(lds + ((tr * tc + sr * sc + 15) & ~15));
+    double* terms = reinterpret_cast<double*>(lds + ((4 * (tr * tcw + sr * scw) + 15) & ~15));
     float* patch = reinterpret_cast<float*>(terms + 5 * 21 * 21);
     match = corner_subpix_wave(R, (size_t)W, W, H, match, 10, 40, 0.001 * 0.001, T.subpix_mask10,
                                patch, terms, lane);
@@ -203,7 +232,8 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
 }
 
 static size_t stereo_lds_bytes(const KParams& P) {
-  size_t b = (size_t)P.templ_rows * P.templ_cols + (size_t)P.stripe_rows * P.stripe_cols;
+  const size_t tcw = (P.templ_cols + 3) / 4, scw = (P.stripe_cols + 3) / 4 + 2;
+  size_t b = 4 * ((size_t)P.templ_rows * tcw + (size_t)P.stripe_rows * scw);
   b = (b + 15) & ~(size_t)15;
   if (P.stereo_subpix) b += sizeof(double) * 5 * 21 * 21 + sizeof(float) * 23 * 23;
   return b;
@@ -211,10 +241,11 @@ static size_t stereo_lds_bytes(const KParams& P) {
 
 void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_rect,
                    const unsigned char* right_rect, const FrameTab& k, const StereoTab& ST,
-                   const StreamState& S, int act_flag, hipStream_t st) {
-  hipLaunchKernelGGL(stereo_left_kernel, dim3((P.kcap + 63) / 64, P.B), dim3(64), 0, st, P, T, k,
+                   const StreamState& S, int act_flag, int max_kp, hipStream_t st) {
+  const int nb = max_kp > 0 ? (max_kp < P.kcap ? max_kp : P.kcap) : P.kcap;
+  hipLaunchKernelGGL(stereo_left_kernel, dim3((nb + 63) / 64, P.B), dim3(64), 0, st, P, T, k,
                      ST, S, act_flag);
-  hipLaunchKernelGGL(stereo_match_kernel, dim3(P.kcap, P.B), dim3(64), stereo_lds_bytes(P), st, P,
+  hipLaunchKernelGGL(stereo_match_kernel, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st, P,
                      T, left_rect, right_rect, k, ST, S, act_flag);
 }
 

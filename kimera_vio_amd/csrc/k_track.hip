@@ -51,6 +51,9 @@ __device__ __forceinline__ void lk_weights(float a, float b, int* w00, int* w01,
   *w11 = (1 << W_BITS) - *w00 - *w01 - *w10;
 }
 
+// NPX > 0: window pixels per lane held in registers (win*win <= 64*NPX), current-frame window
+// staged in LDS, exact-sum fast path for the b vector.  NPX == 0: generic fallback.
+template <int NPX>
 __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* prev_img,
                                                 size_t prev_row_stride, size_t prev_img_stride,
                                                 const unsigned char* prev_pyr,
@@ -70,7 +73,21 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
   int* prod1 = reinterpret_cast<int*>(dpy + wp * wp + ((wp * wp + 3 * w2) & 1));
   int* prod2 = prod1 + w2;
   unsigned char* patch = reinterpret_cast<unsigned char*>(prod2 + w2);  // (win+3)^2
+  constexpr int JM = 3;                 // margin of the staged current-frame window
+  const int JS = win + 1 + 2 * JM;      // staged window side
+  unsigned char* jwin = patch + ((ws * ws + 3) & ~3);  // JS^2
   __shared__ float chain[16];
+  // per-lane window pixels (fixed for the whole kernel)
+  constexpr int NP = NPX > 0 ? NPX : 1;
+  int pxy[NP];
+  if (NPX > 0) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const int e = lane + 64 * k;
+      const int y = e / win, x = e - y * win;
+      pxy[k] = e < w2 ? (y * 64 + x) : -1;  // packed (y, x), x < 64
+    }
+  }
 
   const unsigned char* pimg = prev_img + (size_t)s * prev_img_stride;
   const unsigned char* cimg = cur_img + (size_t)s * cur_img_stride;
@@ -198,6 +215,31 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
     nextPt.x -= halfWin;
     nextPt.y -= halfWin;
     float2 prevDelta = make_float2(0.f, 0.f);
+    // register copies of the template / derivative window and LDS staging of the J window
+    int ri[NP], rgx[NP], rgy[NP];
+    int jx0 = 0, jy0 = 0;
+    bool jvalid = false;
+    if (NPX > 0) {
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int e = lane + 64 * k;
+        const bool ok = pxy[k] >= 0;
+        ri[k] = ok ? (int)Iwin[e] : 0;
+        rgx[k] = ok ? (int)dIx[e] : 0;
+        rgy[k] = ok ? (int)dIy[e] : 0;
+      }
+    }
+    auto stage_j = [&](int inx, int iny) {
+      jx0 = inx - JM;
+      jy0 = iny - JM;
+      __syncthreads();
+      for (int e = lane; e < JS * JS; e += 64) {
+        const int yy = e / JS, xx = e - yy * JS;
+        jwin[e] = (unsigned char)at101(LJ, jx0 + xx, jy0 + yy);
+      }
+      __syncthreads();
+      jvalid = true;
+    };
     for (int j = 0; j < P.klt_iters; j++) {
       const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
       if (inx < -win || inx >= LJ.w || iny < -win || iny >= LJ.h) {
@@ -207,45 +249,116 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
       a = nextPt.x - inx;
       b = nextPt.y - iny;
       lk_weights(a, b, &iw00, &iw01, &iw10, &iw11);
-      for (int e = lane; e < w2; e += 64) {
-        const int y = e / win, x = e - y * win;
-        const int gx = inx + x, gy = iny + y;
-        const int y0 = reflect101(gy, LJ.h), y1 = reflect101(gy + 1, LJ.h);
-        const int x0 = reflect101(gx, LJ.w), x1 = reflect101(gx + 1, LJ.w);
-        const unsigned char* r0 = LJ.p + (size_t)y0 * LJ.stride;
-        const unsigned char* r1 = LJ.p + (size_t)y1 * LJ.stride;
-        const int t = (r0[x0] * iw00 + r0[x1] * iw01 + r1[x0] * iw10 + r1[x1] * iw11 +
-                       (1 << (W_BITS1 - 5 - 1))) >> (W_BITS1 - 5);
-        const int diff = t - (int)Iwin[e];
-        prod1[e] = diff * (int)dIx[e];
-        prod2[e] = diff * (int)dIy[e];
-      }
-      __syncthreads();
-      {
-        const int n8 = win / 8, tail0 = n8 * 8;
-        float acc = 0.f;
-        if (lane < 8) {
-          const int g = lane >> 1;
-          const int* pr = (lane & 1) ? prod2 : prod1;
-          for (int y = 0; y < win; y++) {
-            const int* r = pr + y * win;
-            for (int c = 0; c < n8; c++) acc = acc + (float)(r[8 * c + g] + r[8 * c + g + 4]);
-          }
-        } else if (lane < 10) {
-          const int* pr = (lane & 1) ? prod2 : prod1;
-          for (int y = 0; y < win; y++)
-            for (int x = tail0; x < win; x++) acc += (float)pr[y * win + x];
+      float ib1, ib2;
+      if (NPX > 0) {
+        if (!jvalid || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + JS || iny + win + 1 > jy0 + JS)
+          stage_j(inx, iny);
+        const int ob = (iny - jy0) * JS + (inx - jx0);
+        int p1[NP], p2[NP];
+        int s1 = 0, s2 = 0;
+        unsigned a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+          const int yx = pxy[k] < 0 ? 0 : pxy[k];
+          const unsigned char* r0 = jwin + ob + (yx >> 6) * JS + (yx & 63);
+          const int t = (r0[0] * iw00 + r0[1] * iw01 + r0[JS] * iw10 + r0[JS + 1] * iw11 +
+                         (1 << (W_BITS1 - 5 - 1))) >> (W_BITS1 - 5);
+          const int diff = pxy[k] < 0 ? 0 : t - ri[k];
+          p1[k] = diff * rgx[k];
+          p2[k] = diff * rgy[k];
+          s1 += p1[k];
+          s2 += p2[k];
+          a1 += (unsigned)abs(p1[k]);
+          a2 += (unsigned)abs(p2[k]);
         }
-        if (lane < 10) chain[lane] = acc;
+        // exactness test: if sum|terms| < 2^24 every partial sum of every SSE lane chain is an
+        // integer below 2^24, so the float chains equal the exact integer sum in any order.
+        unsigned am = max(a1, a2);
+        am = min(am, 1u << 25);
+        for (int off = 32; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off);
+          s2 += __shfl_xor(s2, off);
+          am += (unsigned)__shfl_xor((int)am, off);
+        }
+        if (am < (1u << 24)) {
+          ib1 = (float)s1;
+          ib2 = (float)s2;
+        } else {
+#pragma unroll
+          for (int k = 0; k < NP; k++) {
+            const int e = lane + 64 * k;
+            if (pxy[k] >= 0) {
+              prod1[e] = p1[k];
+              prod2[e] = p2[k];
+            }
+          }
+          __syncthreads();
+          const int n8 = win / 8, tail0 = n8 * 8;
+          float acc = 0.f;
+          if (lane < 8) {
+            const int g = lane >> 1;
+            const int* pr = (lane & 1) ? prod2 : prod1;
+            for (int y = 0; y < win; y++) {
+              const int* r = pr + y * win;
+              for (int c = 0; c < n8; c++) acc = acc + (float)(r[8 * c + g] + r[8 * c + g + 4]);
+            }
+          } else if (lane < 10) {
+            const int* pr = (lane & 1) ? prod2 : prod1;
+            for (int y = 0; y < win; y++)
+              for (int x = tail0; x < win; x++) acc += (float)pr[y * win + x];
+          }
+          if (lane < 10) chain[lane] = acc;
+          __syncthreads();
+          const float bb0 = chain[0] + chain[4], bb1 = chain[1] + chain[5],
+                      bb2 = chain[2] + chain[6], bb3 = chain[3] + chain[7];
+          ib1 = chain[8];
+          ib2 = chain[9];
+          ib1 += bb0 + bb2;
+          ib2 += bb1 + bb3;
+          __syncthreads();
+        }
+      } else {
+        for (int e = lane; e < w2; e += 64) {
+          const int y = e / win, x = e - y * win;
+          const int gx = inx + x, gy = iny + y;
+          const int y0 = reflect101(gy, LJ.h), y1 = reflect101(gy + 1, LJ.h);
+          const int x0 = reflect101(gx, LJ.w), x1 = reflect101(gx + 1, LJ.w);
+          const unsigned char* r0 = LJ.p + (size_t)y0 * LJ.stride;
+          const unsigned char* r1 = LJ.p + (size_t)y1 * LJ.stride;
+          const int t = (r0[x0] * iw00 + r0[x1] * iw01 + r1[x0] * iw10 + r1[x1] * iw11 +
+                         (1 << (W_BITS1 - 5 - 1))) >> (W_BITS1 - 5);
+          const int diff = t - (int)Iwin[e];
+          prod1[e] = diff * (int)dIx[e];
+          prod2[e] = diff * (int)dIy[e];
+        }
+        __syncthreads();
+        {
+          const int n8 = win / 8, tail0 = n8 * 8;
+          float acc = 0.f;
+          if (lane < 8) {
+            const int g = lane >> 1;
+            const int* pr = (lane & 1) ? prod2 : prod1;
+            for (int y = 0; y < win; y++) {
+              const int* r = pr + y * win;
+              for (int c = 0; c < n8; c++) acc = acc + (float)(r[8 * c + g] + r[8 * c + g + 4]);
+            }
+          } else if (lane < 10) {
+            const int* pr = (lane & 1) ? prod2 : prod1;
+            for (int y = 0; y < win; y++)
+              for (int x = tail0; x < win; x++) acc += (float)pr[y * win + x];
+          }
+          if (lane < 10) chain[lane] = acc;
+        }
+        __syncthreads();
+        // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]
+        const float bb0 = chain[0] + chain[4], bb1 = chain[1] + chain[5], bb2 = chain[2] + chain[6],
+                    bb3 = chain[3] + chain[7];
+        ib1 = chain[8];
+        ib2 = chain[9];
+        ib1 += bb0 + bb2;
+        ib2 += bb1 + bb3;
+        __syncthreads();
       }
-      __syncthreads();
-      // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]
-      const float bb0 = chain[0] + chain[4], bb1 = chain[1] + chain[5], bb2 = chain[2] + chain[6],
-                  bb3 = chain[3] + chain[7];
-      float ib1 = chain[8], ib2 = chain[9];
-      ib1 += bb0 + bb2;
-      ib2 += bb1 + bb3;
-      __syncthreads();
       const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
       const float2 delta =
           make_float2((float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D));
@@ -300,7 +413,8 @@ static size_t lk_lds_bytes(int win) {
   const int w2 = win * win, wp = win + 1, ws = win + 3;
   size_t shorts = (size_t)3 * w2 + 2 * wp * wp;
   shorts += shorts & 1;
-  return shorts * 2 + sizeof(int) * 2 * w2 + (size_t)ws * ws + 16;
+  const int js = win + 1 + 2 * 3;
+  return shorts * 2 + sizeof(int) * 2 * w2 + (((size_t)ws * ws + 3) & ~(size_t)3) + (size_t)js * js + 16;
 }
 
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
@@ -308,9 +422,14 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
                const LkScratch& lk, int max_pts, hipStream_t st) {
   if (max_pts <= 0) return;
-  hipLaunchKernelGGL(lk_kernel, dim3(max_pts, P.B), dim3(64), lk_lds_bytes(P.klt_win), st, P,
-                     prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img, cur_row_stride,
-                     cur_img_stride, cur_pyr, lk);
+  if (P.klt_win * P.klt_win <= 64 * 9 && P.klt_win <= 60)
+    hipLaunchKernelGGL(lk_kernel<9>, dim3(max_pts, P.B), dim3(64), lk_lds_bytes(P.klt_win), st, P,
+                       prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
+                       cur_row_stride, cur_img_stride, cur_pyr, lk);
+  else
+    hipLaunchKernelGGL(lk_kernel<0>, dim3(max_pts, P.B), dim3(64), lk_lds_bytes(P.klt_win), st, P,
+                       prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
+                       cur_row_stride, cur_img_stride, cur_pyr, lk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -462,8 +581,8 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
   long long* lkf_ids = reinterpret_cast<long long*>(lds_raw);        // [kcap]
   float* disp = reinterpret_cast<float*>(lkf_ids + P.kcap);          // [kcap]
   __shared__ int wave_tot[TF_T / 64];
-  __shared__ int sh_cnt, sh_m;
-  __shared__ float sh_med;
+  __shared__ int sh_cnt, sh_m, sh_digit, sh_rank;
+  __shared__ int hist[256];
   const size_t so = (size_t)s * P.kcap;
   const long long ts = S.in_timestamp[s];
 
@@ -517,15 +636,27 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
     return;
   }
   // ---- shouldBeKeyframe (VisionImuFrontend.cpp:175-232) ----------------------------------------
+  // findMatchingKeypoints: landmark ids of a frame are strictly increasing (tracked ids keep their
+  // order, new ids are larger than every earlier id), so the std::map lookup is a binary search.
   const int nl = LKF.count[s];
   for (int i = tid; i < nl; i += TF_T) lkf_ids[i] = LKF.lmk[so + i];
   if (tid == 0) sh_m = 0;
   __syncthreads();
   for (int i = tid; i < nk; i += TF_T) {
     const long long id = K.lmk[so + i];
-    int j = -1;
-    for (int q = 0; q < nl; q++)
-      if (lkf_ids[q] == id) j = q;  // std::map keeps the LAST index inserted for an id
+    int lo = 0, hi = nl - 1, j = -1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const long long v = lkf_ids[mid];
+      if (v == id) {
+        j = mid;
+        break;
+      }
+      if (v < id)
+        lo = mid + 1;
+      else
+        hi = mid - 1;
+    }
     if (j >= 0) {
       const float2 c = K.kp[so + i], r = LKF.kp[so + j];
       const float dx = c.x - r.x, dy = c.y - r.y;
@@ -537,19 +668,54 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
   const int m = sh_m;
   double disparity = 0.0;
   if (m > 0) {
-    const int center = m / 2;
-    for (int i = tid; i < m; i += TF_T) {
-      const float v = disp[i];
-      int less = 0, leq = 0;
-      for (int q = 0; q < m; q++) {
-        const float u = disp[q];
-        less += (u < v);
-        leq += (u <= v);
+    // std::nth_element(center = m/2): radix select on the (non-negative) float bit patterns
+    unsigned* keys = reinterpret_cast<unsigned*>(disp);
+    unsigned prefix = 0;
+    int kth = m / 2;
+    for (int pass = 3; pass >= 0; pass--) {
+      const int shift = 8 * pass;
+      for (int i = tid; i < 256; i += TF_T) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < m; i += TF_T) {
+        const unsigned key = keys[i];
+        if (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+          atomicAdd(&hist[(key >> shift) & 255u], 1);
       }
-      if (less <= center && center < leq) sh_med = v;  // all writers hold the same value
+      __syncthreads();
+      if (tid < 64) {
+        const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2],
+                  c3 = hist[4 * tid + 3];
+        const int tot = c0 + c1 + c2 + c3;
+        int inc = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_up(inc, off);
+          if (tid >= off) inc += t;
+        }
+        const int before = inc - tot;
+        if (kth >= before && kth < inc) {  // exactly one lane
+          int r = kth - before, d;
+          if (r < c0)
+            d = 0;
+          else if (r < c0 + c1) {
+            d = 1;
+            r -= c0;
+          } else if (r < c0 + c1 + c2) {
+            d = 2;
+            r -= c0 + c1;
+          } else {
+            d = 3;
+            r -= c0 + c1 + c2;
+          }
+          sh_digit = 4 * tid + d;
+          sh_rank = r;
+        }
+      }
+      __syncthreads();
+      prefix |= (unsigned)sh_digit << shift;
+      kth = sh_rank;
+      __syncthreads();
     }
-    __syncthreads();
-    disparity = sqrt((double)sh_med);
+    disparity = sqrt((double)__uint_as_float(prefix));
   }
   if (tid == 0) {
     const long long kf_diff_ns = ts - LKF.timestamp[s];

@@ -546,7 +546,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   const unsigned char* srcs[2] = {left, right};
   launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st);
   prof_mark(c, ST_STEREO);
-  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, st);
+  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, st);
   prof_mark(c, ST_FINALIZE);
   launch_step_finalize(P, K, LKF, b.st, b.ss, st);
   prof_mark(c, ST_COUNT);
@@ -947,7 +947,7 @@ kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_i
   }
   const unsigned char* srcs[2] = {b.raw_left[0], b.raw_right};
   launch_rectify(P, c->T, srcs, P.W, N, b.rect, nullptr, 0, st);
-  if (n > 0) launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, st);
+  if (n > 0) launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, n, st);
 #define DL(dst, src, bytes) \
   if (dst) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st))
   if (n > 0) {
