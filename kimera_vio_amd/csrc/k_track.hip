@@ -51,15 +51,20 @@ __device__ __forceinline__ void lk_weights(float a, float b, int* w00, int* w01,
   *w11 = (1 << W_BITS) - *w00 - *w01 - *w10;
 }
 
-// NPX > 0: window pixels per lane held in registers (win*win <= 64*NPX), current-frame window
-// staged in LDS, exact-sum fast path for the b vector.  NPX == 0: generic fallback.
-template <int NPX>
-__global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* prev_img,
-                                                size_t prev_row_stride, size_t prev_img_stride,
-                                                const unsigned char* prev_pyr,
-                                                const unsigned char* cur_img,
-                                                size_t cur_row_stride, size_t cur_img_stride,
-                                                const unsigned char* cur_pyr, LkScratch lk) {
+// ---------------------------------------------------------------------------------------------
+// Generic kernel (any window size): template / derivative windows and the per-iteration
+// products go through LDS, the SSE-lane float chains are walked by lanes 0-14.  Used only when
+// the systolic kernel below does not cover the window size.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lk_kernel_generic(KParams P, const unsigned char* prev_img,
+                                                        size_t prev_row_stride,
+                                                        size_t prev_img_stride,
+                                                        const unsigned char* prev_pyr,
+                                                        const unsigned char* cur_img,
+                                                        size_t cur_row_stride,
+                                                        size_t cur_img_stride,
+                                                        const unsigned char* cur_pyr,
+                                                        LkScratch lk) {
   const int s = blockIdx.y, pt = blockIdx.x;
   if (pt >= lk.npts[s]) return;
   const int lane = threadIdx.x;
@@ -73,21 +78,7 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
   int* prod1 = reinterpret_cast<int*>(dpy + wp * wp + ((wp * wp + 3 * w2) & 1));
   int* prod2 = prod1 + w2;
   unsigned char* patch = reinterpret_cast<unsigned char*>(prod2 + w2);  // (win+3)^2
-  constexpr int JM = 3;                 // margin of the staged current-frame window
-  const int JS = win + 1 + 2 * JM;      // staged window side
-  unsigned char* jwin = patch + ((ws * ws + 3) & ~3);  // JS^2
   __shared__ float chain[16];
-  // per-lane window pixels (fixed for the whole kernel)
-  constexpr int NP = NPX > 0 ? NPX : 1;
-  int pxy[NP];
-  if (NPX > 0) {
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-      const int e = lane + 64 * k;
-      const int y = e / win, x = e - y * win;
-      pxy[k] = e < w2 ? (y * 64 + x) : -1;  // packed (y, x), x < 64
-    }
-  }
 
   const unsigned char* pimg = prev_img + (size_t)s * prev_img_stride;
   const unsigned char* cimg = cur_img + (size_t)s * cur_img_stride;
@@ -215,31 +206,6 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
     nextPt.x -= halfWin;
     nextPt.y -= halfWin;
     float2 prevDelta = make_float2(0.f, 0.f);
-    // register copies of the template / derivative window and LDS staging of the J window
-    int ri[NP], rgx[NP], rgy[NP];
-    int jx0 = 0, jy0 = 0;
-    bool jvalid = false;
-    if (NPX > 0) {
-#pragma unroll
-      for (int k = 0; k < NP; k++) {
-        const int e = lane + 64 * k;
-        const bool ok = pxy[k] >= 0;
-        ri[k] = ok ? (int)Iwin[e] : 0;
-        rgx[k] = ok ? (int)dIx[e] : 0;
-        rgy[k] = ok ? (int)dIy[e] : 0;
-      }
-    }
-    auto stage_j = [&](int inx, int iny) {
-      jx0 = inx - JM;
-      jy0 = iny - JM;
-      __syncthreads();
-      for (int e = lane; e < JS * JS; e += 64) {
-        const int yy = e / JS, xx = e - yy * JS;
-        jwin[e] = (unsigned char)at101(LJ, jx0 + xx, jy0 + yy);
-      }
-      __syncthreads();
-      jvalid = true;
-    };
     for (int j = 0; j < P.klt_iters; j++) {
       const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
       if (inx < -win || inx >= LJ.w || iny < -win || iny >= LJ.h) {
@@ -250,115 +216,46 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
       b = nextPt.y - iny;
       lk_weights(a, b, &iw00, &iw01, &iw10, &iw11);
       float ib1, ib2;
-      if (NPX > 0) {
-        if (!jvalid || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + JS || iny + win + 1 > jy0 + JS)
-          stage_j(inx, iny);
-        const int ob = (iny - jy0) * JS + (inx - jx0);
-        int p1[NP], p2[NP];
-        int s1 = 0, s2 = 0;
-        unsigned a1 = 0, a2 = 0;
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-          const int yx = pxy[k] < 0 ? 0 : pxy[k];
-          const unsigned char* r0 = jwin + ob + (yx >> 6) * JS + (yx & 63);
-          const int t = (r0[0] * iw00 + r0[1] * iw01 + r0[JS] * iw10 + r0[JS + 1] * iw11 +
-                         (1 << (W_BITS1 - 5 - 1))) >> (W_BITS1 - 5);
-          const int diff = pxy[k] < 0 ? 0 : t - ri[k];
-          p1[k] = diff * rgx[k];
-          p2[k] = diff * rgy[k];
-          s1 += p1[k];
-          s2 += p2[k];
-          a1 += (unsigned)abs(p1[k]);
-          a2 += (unsigned)abs(p2[k]);
-        }
-        // exactness test: if sum|terms| < 2^24 every partial sum of every SSE lane chain is an
-        // integer below 2^24, so the float chains equal the exact integer sum in any order.
-        unsigned am = max(a1, a2);
-        am = min(am, 1u << 25);
-        for (int off = 32; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off);
-          s2 += __shfl_xor(s2, off);
-          am += (unsigned)__shfl_xor((int)am, off);
-        }
-        if (am < (1u << 24)) {
-          ib1 = (float)s1;
-          ib2 = (float)s2;
-        } else {
-#pragma unroll
-          for (int k = 0; k < NP; k++) {
-            const int e = lane + 64 * k;
-            if (pxy[k] >= 0) {
-              prod1[e] = p1[k];
-              prod2[e] = p2[k];
-            }
-          }
-          __syncthreads();
-          const int n8 = win / 8, tail0 = n8 * 8;
-          float acc = 0.f;
-          if (lane < 8) {
-            const int g = lane >> 1;
-            const int* pr = (lane & 1) ? prod2 : prod1;
-            for (int y = 0; y < win; y++) {
-              const int* r = pr + y * win;
-              for (int c = 0; c < n8; c++) acc = acc + (float)(r[8 * c + g] + r[8 * c + g + 4]);
-            }
-          } else if (lane < 10) {
-            const int* pr = (lane & 1) ? prod2 : prod1;
-            for (int y = 0; y < win; y++)
-              for (int x = tail0; x < win; x++) acc += (float)pr[y * win + x];
-          }
-          if (lane < 10) chain[lane] = acc;
-          __syncthreads();
-          const float bb0 = chain[0] + chain[4], bb1 = chain[1] + chain[5],
-                      bb2 = chain[2] + chain[6], bb3 = chain[3] + chain[7];
-          ib1 = chain[8];
-          ib2 = chain[9];
-          ib1 += bb0 + bb2;
-          ib2 += bb1 + bb3;
-          __syncthreads();
-        }
-      } else {
-        for (int e = lane; e < w2; e += 64) {
-          const int y = e / win, x = e - y * win;
-          const int gx = inx + x, gy = iny + y;
-          const int y0 = reflect101(gy, LJ.h), y1 = reflect101(gy + 1, LJ.h);
-          const int x0 = reflect101(gx, LJ.w), x1 = reflect101(gx + 1, LJ.w);
-          const unsigned char* r0 = LJ.p + (size_t)y0 * LJ.stride;
-          const unsigned char* r1 = LJ.p + (size_t)y1 * LJ.stride;
-          const int t = (r0[x0] * iw00 + r0[x1] * iw01 + r1[x0] * iw10 + r1[x1] * iw11 +
-                         (1 << (W_BITS1 - 5 - 1))) >> (W_BITS1 - 5);
-          const int diff = t - (int)Iwin[e];
-          prod1[e] = diff * (int)dIx[e];
-          prod2[e] = diff * (int)dIy[e];
-        }
-        __syncthreads();
-        {
-          const int n8 = win / 8, tail0 = n8 * 8;
-          float acc = 0.f;
-          if (lane < 8) {
-            const int g = lane >> 1;
-            const int* pr = (lane & 1) ? prod2 : prod1;
-            for (int y = 0; y < win; y++) {
-              const int* r = pr + y * win;
-              for (int c = 0; c < n8; c++) acc = acc + (float)(r[8 * c + g] + r[8 * c + g + 4]);
-            }
-          } else if (lane < 10) {
-            const int* pr = (lane & 1) ? prod2 : prod1;
-            for (int y = 0; y < win; y++)
-              for (int x = tail0; x < win; x++) acc += (float)pr[y * win + x];
-          }
-          if (lane < 10) chain[lane] = acc;
-        }
-        __syncthreads();
-        // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]
-        const float bb0 = chain[0] + chain[4], bb1 = chain[1] + chain[5], bb2 = chain[2] + chain[6],
-                    bb3 = chain[3] + chain[7];
-        ib1 = chain[8];
-        ib2 = chain[9];
-        ib1 += bb0 + bb2;
-        ib2 += bb1 + bb3;
-        __syncthreads();
+      for (int e = lane; e < w2; e += 64) {
+        const int y = e / win, x = e - y * win;
+        const int gx = inx + x, gy = iny + y;
+        const int y0 = reflect101(gy, LJ.h), y1 = reflect101(gy + 1, LJ.h);
+        const int x0 = reflect101(gx, LJ.w), x1 = reflect101(gx + 1, LJ.w);
+        const unsigned char* r0 = LJ.p + (size_t)y0 * LJ.stride;
+        const unsigned char* r1 = LJ.p + (size_t)y1 * LJ.stride;
+        const int t = (r0[x0] * iw00 + r0[x1] * iw01 + r1[x0] * iw10 + r1[x1] * iw11 +
+                       (1 << (W_BITS1 - 5 - 1))) >> (W_BITS1 - 5);
+        const int diff = t - (int)Iwin[e];
+        prod1[e] = diff * (int)dIx[e];
+        prod2[e] = diff * (int)dIy[e];
       }
+      __syncthreads();
+      {
+        const int n8 = win / 8, tail0 = n8 * 8;
+        float acc = 0.f;
+        if (lane < 8) {
+          const int g = lane >> 1;
+          const int* pr = (lane & 1) ? prod2 : prod1;
+          for (int y = 0; y < win; y++) {
+            const int* r = pr + y * win;
+            for (int c = 0; c < n8; c++) acc = acc + (float)(r[8 * c + g] + r[8 * c + g + 4]);
+          }
+        } else if (lane < 10) {
+          const int* pr = (lane & 1) ? prod2 : prod1;
+          for (int y = 0; y < win; y++)
+            for (int x = tail0; x < win; x++) acc += (float)pr[y * win + x];
+        }
+        if (lane < 10) chain[lane] = acc;
+      }
+      __syncthreads();
+      // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]
+      const float bb0 = chain[0] + chain[4], bb1 = chain[1] + chain[5], bb2 = chain[2] + chain[6],
+                  bb3 = chain[3] + chain[7];
+      ib1 = chain[8];
+      ib2 = chain[9];
+      ib1 += bb0 + bb2;
+      ib2 += bb1 + bb3;
+      __syncthreads();
       const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
       const float2 delta =
           make_float2((float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D));
@@ -409,12 +306,362 @@ __global__ __launch_bounds__(64) void lk_kernel(KParams P, const unsigned char* 
   }
 }
 
-static size_t lk_lds_bytes(int win) {
+static size_t lk_generic_lds_bytes(int win) {
   const int w2 = win * win, wp = win + 1, ws = win + 3;
   size_t shorts = (size_t)3 * w2 + 2 * wp * wp;
   shorts += shorts & 1;
-  const int js = win + 1 + 2 * 3;
-  return shorts * 2 + sizeof(int) * 2 * w2 + (((size_t)ws * ws + 3) & ~(size_t)3) + (size_t)js * js + 16;
+  return shorts * 2 + sizeof(int) * 2 * w2 + (((size_t)ws * ws + 3) & ~(size_t)3) + 16;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Systolic kernel, WIN in {16, 24, 32} (WIN % 8 == 0): one wavefront per point, no LDS in the
+// accumulation chains.
+//
+// Lane map: g = lane >> 4 (one DPP row of 16 lanes per SSE lane class x & 3), q = lane & 15;
+// lanes with q < WIN/2 own window rows {2q, 2q+1} and columns {g + 4m, m < WIN/4}: their template,
+// gradient and product values never leave registers.  OpenCV's four-lane SSE accumulators are
+// strictly sequential float chains over (row, chunk); a chain is therefore a systolic pipeline
+// along the DPP row: in stage t every lane adds its own terms to the carry it received (lane t
+// holds the true partial sum at stage t) and hands the result to lane q+1 with row_shr:1.  The
+// two b components (and A11/A12) ride in one v_pk_add_f32.  The bilinear samples are
+// v_dot2_i32_i16 on (pixel, pixel+1) pairs staged once per level in LDS.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dpp_row_shr1(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int dot2_i16(int a, int b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
+}
+__device__ __forceinline__ int pack_lo16(int lo, int hi) {  // (lo & 0xffff) | (hi << 16)
+  return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u);
+}
+__device__ __forceinline__ int pack_hi16(int lo, int hi) {  // (lo >> 16) | (hi & 0xffff0000)
+  return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u);
+}
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int sat16(int v) { return max(-32768, min(32767, v)); }
+
+template <int WIN>
+struct LkSys {
+  static constexpr int NC = WIN / 4;        // columns per lane
+  static constexpr int NQ = WIN / 2;        // active lanes per DPP row
+  static constexpr int NPX = 2 * NC;        // pixels per lane
+  static constexpr int NST = NC;            // b-chain steps per lane (2 rows x NC/2 chunks)
+  static constexpr int WS = WIN + 3;        // previous-level byte patch side
+  static constexpr int WP = WIN + 1;        // derivative patch side
+  static constexpr int JM = 3;              // margin of the staged current-level window
+  static constexpr int JS = WIN + 1 + 2 * JM;   // staged rows; JS-1 pair columns
+  static constexpr int JSTR = ((JS - 1 - 1 + 15) / 16) * 16 + 1;  // == 1 (mod 16): conflict free
+  static constexpr int PATCH_B = (WS * WS + 3) & ~3;
+  static constexpr int DXY_W = WP * WP;
+  static constexpr int LDS_BYTES = PATCH_B + 4 * DXY_W + 4 * JS * JSTR;
+};
+
+template <int WIN>
+__global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned char* prev_img,
+                                                    size_t prev_row_stride,
+                                                    size_t prev_img_stride,
+                                                    const unsigned char* prev_pyr,
+                                                    const unsigned char* cur_img,
+                                                    size_t cur_row_stride, size_t cur_img_stride,
+                                                    const unsigned char* cur_pyr, LkScratch lk) {
+  using C = LkSys<WIN>;
+  constexpr int NC = C::NC, NQ = C::NQ, NPX = C::NPX, NST = C::NST, WS = C::WS, WP = C::WP,
+                JM = C::JM, JS = C::JS, JSTR = C::JSTR;
+  const int s = blockIdx.y, pt = blockIdx.x;
+  if (pt >= lk.npts[s]) return;
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, q = lane & 15;
+  const bool active = q < NQ;
+  const int qa = active ? q : 0;  // idle lanes shadow lane q = 0 (their results are never read)
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
+  unsigned char* patch = lds;                                            // WS x WS bytes
+  int* dxy = reinterpret_cast<int*>(lds + C::PATCH_B);                   // WP x WP (dx | dy << 16)
+  int* jp = dxy + C::DXY_W;                                              // JS x JSTR pixel pairs
+
+  const unsigned char* pimg = prev_img + (size_t)s * prev_img_stride;
+  const unsigned char* cimg = cur_img + (size_t)s * cur_img_stride;
+  const unsigned char* ppyr = prev_pyr + (size_t)s * P.pyr_stride;
+  const unsigned char* cpyr = cur_pyr + (size_t)s * P.pyr_stride;
+
+  const size_t po = (size_t)s * P.kcap + pt;
+  const float2 prevPt0 = lk.prev_pts[po];
+  float2 nextOut = lk.next_pts[po];  // initial flow
+  int status = 1;
+  float errOut = 0.f;
+  const int maxLevel = P.nlevels - 1;
+  const float FLT_SCALE = 1.f / (1 << 20);
+  const float halfWin = (WIN - 1) * 0.5f;
+  const int klt_iters = P.klt_iters;
+  const double klt_eps2 = P.klt_eps2;
+  // window offset of this lane's first pixel (row 2q, column g)
+  const int y0w = 2 * qa, x0w = g;
+
+  for (int level = maxLevel; level >= 0; level--) {
+    const LevelImg LI = level_img(P, pimg, prev_row_stride, ppyr, level);
+    const LevelImg LJ = level_img(P, cimg, cur_row_stride, cpyr, level);
+    const float lscale = (float)(1. / (1 << level));
+    float2 prevPt = make_float2(prevPt0.x * lscale, prevPt0.y * lscale);
+    float2 nextPt;
+    if (level == maxLevel)
+      nextPt = make_float2(nextOut.x * lscale, nextOut.y * lscale);
+    else
+      nextPt = make_float2(nextOut.x * 2.f, nextOut.y * 2.f);
+    nextOut = nextPt;
+
+    prevPt.x -= halfWin;
+    prevPt.y -= halfWin;
+    const int ipx = (int)floorf(prevPt.x), ipy = (int)floorf(prevPt.y);
+    if (ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h) {
+      if (level == 0) {
+        status = 0;
+        errOut = 0.f;
+      }
+      continue;
+    }
+    float a = prevPt.x - ipx, b = prevPt.y - ipy;
+    int iw00, iw01, iw10, iw11;
+    lk_weights(a, b, &iw00, &iw01, &iw10, &iw11);
+    int wq0 = pack_lo16(iw00, iw01), wq1 = pack_lo16(iw10, iw11);
+
+    __syncthreads();  // previous level's readers of patch / dxy / jp are done
+    // stage the (WIN+3)^2 neighbourhood of the previous level (REFLECT_101 padded image)
+    {
+      const bool interior = ipx - 1 >= 0 && ipy - 1 >= 0 && ipx - 1 + WS <= LI.w && ipy - 1 + WS <= LI.h;
+      if (interior) {
+        const unsigned char* base = LI.p + (size_t)(ipy - 1) * LI.stride + (ipx - 1);
+        for (int e = lane; e < WS * WS; e += 64) {
+          const int py = e / WS, px = e - py * WS;
+          patch[e] = base[(size_t)py * LI.stride + px];
+        }
+      } else {
+        for (int e = lane; e < WS * WS; e += 64) {
+          const int py = e / WS, px = e - py * WS;
+          patch[e] = (unsigned char)at101(LI, ipx - 1 + px, ipy - 1 + py);
+        }
+      }
+    }
+    __syncthreads();
+    // Scharr derivative at the (WIN+1)^2 positions; zero outside the image (BORDER_CONSTANT)
+    for (int e = lane; e < WP * WP; e += 64) {
+      const int y = e / WP, x = e - y * WP;
+      const int gx = ipx + x, gy = ipy + y;
+      int vx = 0, vy = 0;
+      if (gx >= 0 && gx < LI.w && gy >= 0 && gy < LI.h) {
+        const unsigned char* r0 = patch + y * WS + x;  // row gy-1, col gx-1
+        const unsigned char* r1 = r0 + WS;
+        const unsigned char* r2 = r1 + WS;
+        const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
+        const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
+        vx = t0p - t0m;
+        vy = (t1p + t1m) * 3 + t1c * 10;
+      }
+      dxy[e] = pack_lo16(vx, vy);
+    }
+    __syncthreads();
+    // bilinear template and derivative window of this lane's pixels -> registers
+    int rI[NPX], rgxy[NPX];  // rgxy = (Ix & 0xffff) | (Iy << 16)
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int m = 0; m < NC; m++) {
+        const int k = r * NC + m;
+        const int y = y0w + r, x = x0w + 4 * m;
+        const unsigned char* s0 = patch + (y + 1) * WS + (x + 1);
+        const int p0 = (int)s0[0] | ((int)s0[1] << 16), p1 = (int)s0[WS] | ((int)s0[WS + 1] << 16);
+        const int ival = dot2_i16(p0, wq0, dot2_i16(p1, wq1, 1 << 8)) >> 9;
+        const int* d = dxy + y * WP + x;
+        const int d00 = d[0], d01 = d[1], d10 = d[WP], d11 = d[WP + 1];
+        const int ixval =
+            dot2_i16(pack_lo16(d00, d01), wq0, dot2_i16(pack_lo16(d10, d11), wq1, 1 << 13)) >> 14;
+        const int iyval =
+            dot2_i16(pack_hi16(d00, d01), wq0, dot2_i16(pack_hi16(d10, d11), wq1, 1 << 13)) >> 14;
+        rI[k] = active ? sat16(ival) : 0;
+        rgxy[k] = active ? pack_lo16(sat16(ixval), sat16(iyval)) : 0;
+      }
+    // A11/A12/A22 chains (SSE lane l = g; order: row, then column chunk)
+    float A11, A12, A22;
+    {
+      v2f pa[NPX];
+      float pc[NPX];
+#pragma unroll
+      for (int k = 0; k < NPX; k++) {
+        const float fx = (float)(short)(rgxy[k] & 0xffff), fy = (float)(rgxy[k] >> 16);
+        pa[k] = v2f{fx * fx, fx * fy};
+        pc[k] = fy * fy;
+      }
+      float c11 = 0.f, c12 = 0.f, c22 = 0.f;
+      v2f t = {0.f, 0.f};
+      float t22 = 0.f;
+#pragma unroll
+      for (int st = 0; st < NQ; st++) {
+        t = v2f{c11, c12};
+        t22 = c22;
+#pragma unroll
+        for (int k = 0; k < NPX; k++) {
+          t = t + pa[k];
+          t22 = t22 + pc[k];
+        }
+        c11 = dpp_row_shr1(t.x);
+        c12 = dpp_row_shr1(t.y);
+        c22 = dpp_row_shr1(t22);
+      }
+      constexpr int L0 = NQ - 1, L1 = 16 + NQ - 1, L2 = 32 + NQ - 1, L3 = 48 + NQ - 1;
+      float iA11 = 0.f, iA12 = 0.f, iA22 = 0.f;
+      iA11 += lane_f(t.x, L0) + lane_f(t.x, L1) + lane_f(t.x, L2) + lane_f(t.x, L3);
+      iA12 += lane_f(t.y, L0) + lane_f(t.y, L1) + lane_f(t.y, L2) + lane_f(t.y, L3);
+      iA22 += lane_f(t22, L0) + lane_f(t22, L1) + lane_f(t22, L2) + lane_f(t22, L3);
+      A11 = iA11 * FLT_SCALE;
+      A12 = iA12 * FLT_SCALE;
+      A22 = iA22 * FLT_SCALE;
+    }
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                         (float)(2 * WIN * WIN);
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    D = 1.f / D;
+
+    nextPt.x -= halfWin;
+    nextPt.y -= halfWin;
+    float2 prevDelta = make_float2(0.f, 0.f);
+    int jx0 = 0, jy0 = 0;
+    bool jvalid = false;
+    // (re)stage the current-level window as (pixel, pixel+1) pairs around (inx, iny)
+    auto stage_j = [&](int inx, int iny) {
+      jx0 = inx - JM;
+      jy0 = iny - JM;
+      __syncthreads();
+      const bool interior = jx0 >= 0 && jy0 >= 0 && jx0 + JS <= LJ.w && jy0 + JS <= LJ.h;
+      if (interior) {
+        const unsigned char* base = LJ.p + (size_t)jy0 * LJ.stride + jx0;
+        for (int e = lane; e < JS * (JS - 1); e += 64) {
+          const int yy = e / (JS - 1), xx = e - yy * (JS - 1);
+          const unsigned char* r = base + (size_t)yy * LJ.stride + xx;
+          jp[yy * JSTR + xx] = (int)r[0] | ((int)r[1] << 16);
+        }
+      } else {
+        for (int e = lane; e < JS * (JS - 1); e += 64) {
+          const int yy = e / (JS - 1), xx = e - yy * (JS - 1);
+          jp[yy * JSTR + xx] =
+              at101(LJ, jx0 + xx, jy0 + yy) | (at101(LJ, jx0 + xx + 1, jy0 + yy) << 16);
+        }
+      }
+      __syncthreads();
+      jvalid = true;
+    };
+    for (int j = 0; j < klt_iters; j++) {
+      const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
+      if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+        if (level == 0) status = 0;
+        break;
+      }
+      a = nextPt.x - inx;
+      b = nextPt.y - iny;
+      lk_weights(a, b, &iw00, &iw01, &iw10, &iw11);
+      wq0 = pack_lo16(iw00, iw01);
+      wq1 = pack_lo16(iw10, iw11);
+      if (!jvalid || inx < jx0 || iny < jy0 || inx + WIN + 1 > jx0 + JS || iny + WIN + 1 > jy0 + JS)
+        stage_j(inx, iny);
+      const int* jb = jp + (iny - jy0 + y0w) * JSTR + (inx - jx0 + x0w);
+      int diff[NPX];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+          const int k = r * NC + m;
+          const int t = dot2_i16(jb[r * JSTR + 4 * m], wq0,
+                                 dot2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, 1 << 8)) >> 9;
+          diff[k] = t - rI[k];
+        }
+      // chain terms: madd pairs (x, x+4) of one row chunk, converted to float
+      v2f term[NST];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < NC / 2; c++) {
+          const int k0 = r * NC + 2 * c, k1 = k0 + 1;
+          const int dd = pack_lo16(diff[k0], diff[k1]);
+          const int m1 = dot2_i16(dd, pack_lo16(rgxy[k0], rgxy[k1]), 0);
+          const int m2 = dot2_i16(dd, pack_hi16(rgxy[k0], rgxy[k1]), 0);
+          term[r * (NC / 2) + c] = v2f{(float)m1, (float)m2};
+        }
+      float cb1 = 0.f, cb2 = 0.f;
+      v2f t = {0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < NQ; st++) {
+        t = v2f{cb1, cb2};
+#pragma unroll
+        for (int i = 0; i < NST; i++) t = t + term[i];
+        cb1 = dpp_row_shr1(t.x);
+        cb2 = dpp_row_shr1(t.y);
+      }
+      constexpr int L0 = NQ - 1, L1 = 16 + NQ - 1, L2 = 32 + NQ - 1, L3 = 48 + NQ - 1;
+      // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]
+      const float bb0 = lane_f(t.x, L0) + lane_f(t.x, L2), bb1 = lane_f(t.y, L0) + lane_f(t.y, L2);
+      const float bb2 = lane_f(t.x, L1) + lane_f(t.x, L3), bb3 = lane_f(t.y, L1) + lane_f(t.y, L3);
+      float ib1 = 0.f, ib2 = 0.f;
+      ib1 += bb0 + bb2;
+      ib2 += bb1 + bb3;
+      const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+      const float2 delta =
+          make_float2((float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D));
+      nextPt.x += delta.x;
+      nextPt.y += delta.y;
+      nextOut = make_float2(nextPt.x + halfWin, nextPt.y + halfWin);
+      if ((double)delta.x * (double)delta.x + (double)delta.y * (double)delta.y <= klt_eps2) break;
+      if (j > 0 && fabs((double)(delta.x + prevDelta.x)) < 0.01 &&
+          fabs((double)(delta.y + prevDelta.y)) < 0.01) {
+        nextOut.x -= delta.x * 0.5f;
+        nextOut.y -= delta.y * 0.5f;
+        break;
+      }
+      prevDelta = delta;
+    }
+
+    if (status && level == 0) {
+      const float2 np = make_float2(nextOut.x - halfWin, nextOut.y - halfWin);
+      const int inx = (int)floorf(np.x), iny = (int)floorf(np.y);
+      if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+        status = 0;
+        continue;
+      }
+      const float aa = np.x - inx, bb = np.y - iny;
+      lk_weights(aa, bb, &iw00, &iw01, &iw10, &iw11);
+      wq0 = pack_lo16(iw00, iw01);
+      wq1 = pack_lo16(iw10, iw11);
+      if (!jvalid || inx < jx0 || iny < jy0 || inx + WIN + 1 > jx0 + JS || iny + WIN + 1 > jy0 + JS)
+        stage_j(inx, iny);
+      const int* jb = jp + (iny - jy0 + y0w) * JSTR + (inx - jx0 + x0w);
+      // errval is a float sum of integers < 2^24: exact in any order
+      int esum = 0;
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+          const int k = r * NC + m;
+          const int t = dot2_i16(jb[r * JSTR + 4 * m], wq0,
+                                 dot2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, 1 << 8)) >> 9;
+          esum += active ? abs(t - rI[k]) : 0;
+        }
+      for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
+      errOut = (float)esum * 1.f / (float)(32 * WIN * WIN);
+    }
+  }
+  if (lane == 0) {
+    lk.next_pts[po] = nextOut;
+    lk.status[po] = (unsigned char)status;
+    lk.err[po] = errOut;
+  }
 }
 
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
@@ -422,14 +669,21 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
                const LkScratch& lk, int max_pts, hipStream_t st) {
   if (max_pts <= 0) return;
-  if (P.klt_win * P.klt_win <= 64 * 9 && P.klt_win <= 60)
-    hipLaunchKernelGGL(lk_kernel<9>, dim3(max_pts, P.B), dim3(64), lk_lds_bytes(P.klt_win), st, P,
-                       prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
-                       cur_row_stride, cur_img_stride, cur_pyr, lk);
-  else
-    hipLaunchKernelGGL(lk_kernel<0>, dim3(max_pts, P.B), dim3(64), lk_lds_bytes(P.klt_win), st, P,
-                       prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
-                       cur_row_stride, cur_img_stride, cur_pyr, lk);
+  const dim3 grid(max_pts, P.B), block(64);
+#define KVFE_LK_SYS(WINSZ)                                                                      \
+  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, grid, block, 0, st, P, prev_img, prev_row_stride,    \
+                     prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,        \
+                     cur_pyr, lk)
+  switch (P.klt_win) {
+    case 16: KVFE_LK_SYS(16); break;
+    case 24: KVFE_LK_SYS(24); break;
+    case 32: KVFE_LK_SYS(32); break;
+    default:
+      hipLaunchKernelGGL(lk_kernel_generic, grid, block, lk_generic_lds_bytes(P.klt_win), st, P,
+                         prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
+                         cur_row_stride, cur_img_stride, cur_pyr, lk);
+  }
+#undef KVFE_LK_SYS
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -211,6 +211,34 @@ def test_lk_bit_exact(ctx, seq):
         assert est.sum() > 100
 
 
+@pytest.mark.parametrize("win,max_level,max_iter,eps", [(16, 2, 30, 0.1), (32, 3, 10, 0.01),
+                                                        (21, 2, 30, 0.1), (9, 1, 5, 0.03),
+                                                        (24, 0, 30, 0.001)])
+def test_lk_other_windows_bit_exact(seq, win, max_level, max_iter, eps):
+    """The systolic kernel covers windows 16/24/32, every other size takes the generic kernel;
+    both must reproduce the oracle exactly, also for large initial errors and border points."""
+    L, R = euroc_cams()
+    p = euroc_params()
+    p.tracker.klt_win_size, p.tracker.klt_max_level = win, max_level
+    p.tracker.klt_max_iter, p.tracker.klt_eps = max_iter, eps
+    c = F.Context(L, R, p)
+    try:
+        prev, cur = seq["lefts"][1], seq["lefts"][4]
+        pts, _ = O.good_features_to_track(prev, 200, 0.001, 15, 3)
+        rng = np.random.default_rng(win)
+        extra = np.stack([rng.uniform(-3, 755, 60), rng.uniform(-3, 483, 60)], 1).astype(np.float32)
+        pts = np.concatenate([pts, extra])
+        init = pts + rng.uniform(-6, 6, pts.shape).astype(np.float32)
+        got, gst, gerr = c.calc_optical_flow_pyr_lk(prev, cur, pts, init)
+        exp, est, eerr, _ = O.calc_optical_flow_pyr_lk(prev, cur, pts, init, win, max_level, max_iter, eps)
+        assert np.array_equal(gst, est)
+        assert np.array_equal(got, exp)
+        assert np.array_equal(gerr, eerr)
+        assert est.sum() > 50
+    finally:
+        c.close()
+
+
 def test_stereo_match_849_of_900_and_parity(ocam):
     """tests/testStereoMatcher.cpp:272-388 on the GPU path (default StereoMatchingParams)."""
     L, R = euroc_cams()
