@@ -39,8 +39,12 @@ def parse():
                          "nominal: reference cadence (keyframe every 0.2 s = 4th frame)")
     ap.add_argument("--ring", type=int, default=6, help="distinct frames per stream (ping-pong)")
     ap.add_argument("--unique-streams", type=int, default=8)
-    ap.add_argument("--cpu-baseline-frames", type=int, default=60)
+    ap.add_argument("--groups", type=int, default=0,
+                    help="stream groups per context (0 = library default for the batch size)")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true",
+                    help="do not record per-stage HIP events in the timed region (no roofline object)")
     ap.add_argument("--no-single-stream", action="store_true")
     return ap.parse_args()
 
@@ -75,11 +79,9 @@ def main():
 
     from kimera_vio_amd import frontend as F
     from kimera_vio_amd import params as P
-    from kimera_vio_amd import synth
+    from kimera_vio_amd import sharding, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = sharding.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libkvfe has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -109,7 +111,7 @@ def main():
     d_right = torch.from_numpy(rights).to(dev)
     torch.cuda.synchronize()
 
-    ctx = F.Context(L, R, p, batch=B, device=local_rank)
+    ctx = F.Context(L, R, p, batch=B, device=local_rank, stream_groups=args.groups)
     dt_ns = 50_000_000  # 20 Hz
 
     def frame_inputs(step_idx, kf_t):
@@ -136,39 +138,54 @@ def main():
             ctx.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), inp)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        sharding.barrier(dist, world)  # RCCL: lock-step only, no data-path collective
         ctx.synchronize()
         torch.cuda.synchronize()
 
     run(0, args.warmup)
     barrier()
-    ctx.profile_enable(True)
+    if not args.no_stage_events:
+        ctx.profile_enable(True)
     t0 = time.perf_counter()
     run(args.warmup, total)
+    t_enq = time.perf_counter()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, pairs = sharding.reduce_timing(dist, world, elapsed, B * args.steps, device=dev)
 
     # sanity of the measured work: every stream produced keypoints and stereo matches
     out0 = ctx.get_output(0)
     outl = ctx.get_output(B - 1)
     assert out0["n_keypoints"] > 0 and outl["n_keypoints"] > 0, "front-end produced no keypoints"
     n_valid = int((out0["right_status"] == 0).sum()) if out0["is_keyframe"] else -1
+
+    # PCIe-inclusive rate (host buffers handed over at the boundary): reported, never `value`
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_single_stream:
+        hl = np.ascontiguousarray(lefts[:2])
+        hr = np.ascontiguousarray(rights[:2])
+        ctx.reset()
+        n_h = 6
+        for i in range(2):
+            ctx.step_host(hl[i % 2], hr[i % 2], plan[i][1])
+        ctx.synchronize()
+        th = time.perf_counter()
+        for i in range(2, 2 + n_h):
+            ctx.step_host(hl[i % 2], hr[i % 2], plan[i][1])
+        ctx.synchronize()
+        pcie = {"value": round(B * n_h / (time.perf_counter() - th), 2), "unit": "stereo-pairs/s",
+                "note": "kvfe_frontend_step_host from pageable host memory, H2D copies inside the timed region"}
     ctx.close()
 
-    pairs = B * world * args.steps
     value = pairs / elapsed
 
     # ---- roofline of the dominant dense (HBM-bound) kernel, from HIP events in the timed region --
     stages = prof["stages"]
-    ns = max(prof["n_samples"], 1)
+    ns = max(prof["n_samples"], 1)          # launches recorded per stage (all stream groups)
+    groups = max(prof["n_groups"], 1)       # launches per step
     dense = {k: v for k, v in stages.items() if v["alg_bytes"] > 0 and v["ms_total"] > 0}
     roofline = None
     if dense:
@@ -178,7 +195,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
                     "alg_bytes_per_launch": dense[name]["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)}
-    stage_ms = {k: round(v["ms_total"] / ns, 5) for k, v in stages.items()}
+    # per step: the launches of all stream groups added up (they overlap on the GPU, so the sum
+    # exceeds ms_per_step when groups > 1)
+    stage_ms = {k: round(v["ms_total"] / ns * groups, 5) for k, v in stages.items()}
 
     result = {
         "metric": "stereo-pairs/sec front-end (detect+track+match) @752x480",
@@ -189,9 +208,12 @@ def main():
         "config": {"workload": f"batched {B} synthetic {W}x{H} stereo streams per GPU, {args.features} "
                                f"features, ANMS binning on, {args.klt_max_level + 1}-level LK, "
                                f"mode={args.mode}", "batch_per_gpu": B, "width": W, "height": H,
-                   "features": args.features, "mode": args.mode, "parallelism": f"streams x{world}"},
+                   "features": args.features, "mode": args.mode, "stream_groups": groups,
+                   "parallelism": f"streams x{world}"},
         "roofline": roofline,
-        "stage_ms_per_step": stage_ms,
+        "stage_ms_per_step_summed_over_groups": stage_ms,
+        "pcie_inclusive": pcie,
+        "host_enqueue_ms_per_step": round(1e3 * (t_enq - t0) / args.steps, 4),
         "check": {"keypoints_stream0": int(out0["n_keypoints"]), "valid_stereo_stream0": n_valid},
     }
 

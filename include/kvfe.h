@@ -165,7 +165,10 @@ typedef struct kvfe_config {
   int32_t device;                /* HIP device ordinal                       */
   void* hip_stream;              /* optional hipStream_t owned by the caller */
   int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
-  int32_t reserved0;
+  int32_t stream_groups;         /* 0 = automatic.  The batch is split into this many
+                                    groups of streams, each on its own HIP stream, so
+                                    that latency-bound and throughput-bound kernels of
+                                    different groups overlap (always 1 with hip_stream) */
 } kvfe_config;
 
 typedef struct kvfe_ctx kvfe_ctx;
@@ -370,10 +373,12 @@ KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,
 #define KVFE_N_STAGES 16
 typedef struct kvfe_stage_times {
   int32_t n_stages;
-  int32_t n_samples;
+  int32_t n_samples;                   /* launches recorded per stage (all groups)  */
+  int32_t n_groups;                    /* stream groups (launches per step)         */
+  int32_t reserved0;
   const char* name[KVFE_N_STAGES];
   double ms_total[KVFE_N_STAGES];      /* summed over samples                 */
-  double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch        */
+  double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch (mean) */
 } kvfe_stage_times;
 KVFE_API kvfe_status kvfe_profile_enable(kvfe_ctx* ctx, int32_t on);
 KVFE_API kvfe_status kvfe_profile_read(kvfe_ctx* ctx, kvfe_stage_times* out);

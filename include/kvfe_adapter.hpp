@@ -1,0 +1,281 @@
+// kvfe_adapter.hpp — header-only C++ adapter over the C ABI of libkvfe (kvfe.h) that carries the
+// class and method names of Kimera-VIO's stereo front-end, written against plain structs so that
+// it compiles without OpenCV / GTSAM.  INTEGRATION.md shows how a Kimera-VIO maintainer maps
+// cv::Mat / cv::Point2f / gtsam::Rot3 / StatusKeypointsCV onto these (they are layout compatible:
+// KeypointCV == cv::Point2f == {float x, y}; StatusKeypointCV == {KeypointStatus, KeypointCV}).
+//
+// Reference interfaces mirrored (paths relative to the Kimera-VIO tree):
+//   UndistorterRectifier   include/kimera-vio/frontend/UndistorterRectifier.h:51-114
+//   StereoCamera           include/kimera-vio/frontend/StereoCamera.h:203-233
+//   FeatureDetector        include/kimera-vio/frontend/feature-detector/FeatureDetector.h:39-49
+//   Tracker                include/kimera-vio/frontend/Tracker.h:70-74
+//   StereoMatcher          include/kimera-vio/frontend/StereoMatcher.h:49-92
+//   StereoVisionImuFrontend include/kimera-vio/frontend/StereoVisionImuFrontend.h (spinOnce path)
+// Error behaviour: the reference CHECK-aborts on contract violations; the adapter throws
+// kvfe::Error carrying the kvfe_status and kvfe_last_error() text instead (never UB, never a
+// silent CPU fallback — there is none).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kvfe.h"
+
+namespace kvfe {
+
+struct Error : std::runtime_error {
+  kvfe_status status;
+  Error(kvfe_status s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+// KeypointCV / StatusKeypointCV / KeypointStatus (include/kimera-vio/common/vio_types.h:38-66)
+struct KeypointCV {
+  float x, y;
+};
+enum class KeypointStatus : uint8_t {
+  VALID = KVFE_KP_VALID,
+  NO_LEFT_RECT = KVFE_KP_NO_LEFT_RECT,
+  NO_RIGHT_RECT = KVFE_KP_NO_RIGHT_RECT,
+  NO_DEPTH = KVFE_KP_NO_DEPTH,
+  FAILED_ARUN = KVFE_KP_FAILED_ARUN
+};
+using KeypointsCV = std::vector<KeypointCV>;
+using StatusKeypointCV = std::pair<KeypointStatus, KeypointCV>;
+using StatusKeypointsCV = std::vector<StatusKeypointCV>;
+
+// 8-bit gray image view (cv::Mat CV_8UC1: data, rows, cols, step)
+struct ImageView {
+  const uint8_t* data;
+  int rows, cols;
+  size_t step;
+};
+
+// Owns a kvfe_ctx: StereoCamera + the four front-end classes share it, as the reference's
+// StereoVisionImuFrontend owns its StereoCamera::ConstPtr, Tracker, FeatureDetector and
+// StereoMatcher.
+class Context {
+ public:
+  Context(const kvfe_camera_params& left, const kvfe_camera_params& right,
+          const kvfe_frontend_params& params, int batch = 1, int device = 0) {
+    std::memset(&cfg_, 0, sizeof(cfg_));
+    cfg_.left = left;
+    cfg_.right = right;
+    cfg_.params = params;
+    cfg_.batch = batch;
+    cfg_.device = device;
+    kvfe_ctx* c = nullptr;
+    const kvfe_status s = kvfe_create(&cfg_, &c);
+    if (s != KVFE_OK) throw Error(s, std::string("kvfe_create: ") + kvfe_status_string(s));
+    ctx_.reset(c, kvfe_destroy);
+  }
+  kvfe_ctx* get() const { return ctx_.get(); }
+  const kvfe_config& config() const { return cfg_; }
+  void check(kvfe_status s, const char* where) const {
+    if (s != KVFE_OK)
+      throw Error(s, std::string(where) + ": " + kvfe_status_string(s) + " (" +
+                         kvfe_last_error(ctx_.get()) + ")");
+  }
+
+ private:
+  kvfe_config cfg_;
+  std::shared_ptr<kvfe_ctx> ctx_;
+};
+
+// UndistorterRectifier (src/frontend/UndistorterRectifier.cpp); cam: 0 = left, 1 = right
+class UndistorterRectifier {
+ public:
+  UndistorterRectifier(Context ctx, int cam) : c_(std::move(ctx)), cam_(cam) {}
+  // undistortRectifyImage (UndistorterRectifier.cpp:115-128); dst: cols*rows bytes, tightly packed
+  void undistortRectifyImage(const ImageView& img, uint8_t* dst) const {
+    c_.check(kvfe_undistort_rectify_image(c_.get(), cam_, img.data, img.step, dst, (size_t)img.cols),
+             "undistortRectifyImage");
+  }
+  // undistortRectifyKeypoints (UndistorterRectifier.cpp:130-136)
+  void undistortRectifyKeypoints(const KeypointsCV& kps, KeypointsCV* out) const {
+    out->resize(kps.size());
+    c_.check(kvfe_undistort_rectify_keypoints(c_.get(), cam_, &kps.data()->x, (int32_t)kps.size(), 1, 1,
+                                              &out->data()->x),
+             "undistortRectifyKeypoints");
+  }
+  // GetBearingVector (UndistorterRectifier.cpp:73-113), batched: n x 3 doubles
+  void getBearingVectors(const KeypointsCV& kps, std::vector<double>* versors) const {
+    versors->resize(kps.size() * 3);
+    c_.check(kvfe_get_bearing_vectors(c_.get(), cam_, &kps.data()->x, (int32_t)kps.size(), versors->data()),
+             "GetBearingVector");
+  }
+
+ private:
+  Context c_;
+  int cam_;
+};
+
+// StereoCamera (src/frontend/StereoCamera.cpp:34-94,236-379)
+class StereoCamera {
+ public:
+  explicit StereoCamera(Context ctx) : c_(std::move(ctx)) {
+    c_.check(kvfe_get_rectification(c_.get(), &rect_), "computeRectificationParameters");
+  }
+  double getBaseline() const { return rect_.baseline; }
+  const double* getR1() const { return rect_.R1; }
+  const double* getR2() const { return rect_.R2; }
+  const double* getP1() const { return rect_.P1; }
+  const double* getP2() const { return rect_.P2; }
+  const double* getQ() const { return rect_.Q; }
+  const Context& context() const { return c_; }
+
+ private:
+  Context c_;
+  kvfe_rectification rect_;
+};
+
+// FeatureDetector (src/frontend/feature-detector/FeatureDetector.cpp)
+class FeatureDetector {
+ public:
+  explicit FeatureDetector(Context ctx) : c_(std::move(ctx)) {}
+  // rawFeatureDetection (FeatureDetector.cpp:165-172); mask may be null
+  KeypointsCV rawFeatureDetection(const ImageView& img, const ImageView* mask = nullptr) const {
+    KeypointsCV out(8192);
+    int32_t n = 0;
+    c_.check(kvfe_raw_feature_detection(c_.get(), img.data, img.step, mask ? mask->data : nullptr,
+                                        mask ? mask->step : 0, &out.data()->x, (int32_t)out.size(), &n),
+             "rawFeatureDetection");
+    out.resize(n);
+    return out;
+  }
+  // private featureDetection(const Frame&, need_n_corners) (FeatureDetector.cpp:174-299):
+  // `tracked` = keypoints of the frame whose landmark id is not -1
+  KeypointsCV featureDetection(const ImageView& img, const KeypointsCV& tracked, int need_n_corners) const {
+    KeypointsCV out(8192);
+    int32_t n = 0;
+    c_.check(kvfe_feature_detection(c_.get(), img.data, img.step, &tracked.data()->x,
+                                    (int32_t)tracked.size(), need_n_corners, &out.data()->x,
+                                    (int32_t)out.size(), &n),
+             "featureDetection");
+    out.resize(n);
+    return out;
+  }
+
+ private:
+  Context c_;
+};
+
+// Tracker::featureTracking core (src/frontend/Tracker.cpp:92-211): prediction + pyramidal LK
+class Tracker {
+ public:
+  explicit Tracker(Context ctx) : c_(std::move(ctx)) {}
+  // px_ref: valid reference keypoints; ref_R_cur row-major 3x3 (gtsam::Rot3::matrix()).
+  // Returns px_cur, status (1 = tracked) and error, as cv::calcOpticalFlowPyrLK does.
+  void featureTracking(const ImageView& ref_img, const ImageView& cur_img, const KeypointsCV& px_ref,
+                       const double ref_R_cur[9], KeypointsCV* px_cur, std::vector<uint8_t>* status,
+                       std::vector<float>* error) const {
+    const int32_t n = (int32_t)px_ref.size();
+    px_cur->resize(n);
+    status->resize(n);
+    error->resize(n);
+    c_.check(kvfe_predict_sparse_flow(c_.get(), &px_ref.data()->x, n, ref_R_cur, &px_cur->data()->x),
+             "predictSparseFlow");
+    c_.check(kvfe_calc_optical_flow_pyr_lk(c_.get(), ref_img.data, cur_img.data, ref_img.step,
+                                           &px_ref.data()->x, &px_cur->data()->x, n, status->data(),
+                                           error->data()),
+             "calcOpticalFlowPyrLK");
+  }
+
+ private:
+  Context c_;
+};
+
+// StereoMatcher (src/frontend/StereoMatcher.cpp:123-483)
+class StereoMatcher {
+ public:
+  explicit StereoMatcher(Context ctx) : c_(std::move(ctx)) {}
+  struct SparseResult {
+    StatusKeypointsCV left_keypoints_rectified, right_keypoints_rectified;
+    std::vector<double> keypoints_depth;     // n
+    KeypointsCV right_keypoints;             // distorted right pixels
+    std::vector<double> keypoints_3d;        // n x 3
+  };
+  // sparseStereoReconstruction(StereoFrame*) (StereoMatcher.cpp:123-175)
+  SparseResult sparseStereoReconstruction(const ImageView& left, const ImageView& right,
+                                          const KeypointsCV& left_keypoints) const {
+    const int32_t n = (int32_t)left_keypoints.size();
+    std::vector<KeypointCV> lr(n), rr(n);
+    std::vector<uint8_t> ls(n), rs(n);
+    SparseResult r;
+    r.keypoints_depth.resize(n);
+    r.right_keypoints.resize(n);
+    r.keypoints_3d.resize((size_t)n * 3);
+    kvfe_stereo_output o;
+    std::memset(&o, 0, sizeof(o));
+    o.left_rect_xy = &lr.data()->x;
+    o.left_status = ls.data();
+    o.right_rect_xy = &rr.data()->x;
+    o.right_status = rs.data();
+    o.depth = r.keypoints_depth.data();
+    o.right_xy = &r.right_keypoints.data()->x;
+    o.keypoints_3d = r.keypoints_3d.data();
+    c_.check(kvfe_sparse_stereo_reconstruction(c_.get(), left.data, right.data, left.step,
+                                               &left_keypoints.data()->x, n, &o),
+             "sparseStereoReconstruction");
+    r.left_keypoints_rectified.resize(n);
+    r.right_keypoints_rectified.resize(n);
+    for (int32_t i = 0; i < n; i++) {
+      r.left_keypoints_rectified[i] = {static_cast<KeypointStatus>(ls[i]), lr[i]};
+      r.right_keypoints_rectified[i] = {static_cast<KeypointStatus>(rs[i]), rr[i]};
+    }
+    return r;
+  }
+  // getRightKeypointsRectified (StereoMatcher.cpp:196-281) on already rectified images
+  void getRightKeypointsRectified(const ImageView& left_rectified, const ImageView& right_rectified,
+                                  const StatusKeypointsCV& left_keypoints_rectified,
+                                  StatusKeypointsCV* right_keypoints_rectified) const {
+    const int32_t n = (int32_t)left_keypoints_rectified.size();
+    std::vector<KeypointCV> l(n), r(n);
+    std::vector<uint8_t> ls(n), rs(n);
+    for (int32_t i = 0; i < n; i++) {
+      ls[i] = static_cast<uint8_t>(left_keypoints_rectified[i].first);
+      l[i] = left_keypoints_rectified[i].second;
+    }
+    c_.check(kvfe_get_right_keypoints_rectified(c_.get(), left_rectified.data, right_rectified.data,
+                                                left_rectified.step, &l.data()->x, ls.data(), n,
+                                                &r.data()->x, rs.data(), nullptr),
+             "getRightKeypointsRectified");
+    right_keypoints_rectified->resize(n);
+    for (int32_t i = 0; i < n; i++)
+      (*right_keypoints_rectified)[i] = {static_cast<KeypointStatus>(rs[i]), r[i]};
+  }
+
+ private:
+  Context c_;
+};
+
+// StereoVisionImuFrontend::spinOnce visual path (StereoVisionImuFrontend.cpp:102-481) for
+// `batch` independent streams.  IMU preintegration stays on the host: the caller passes
+// keyframe_R_cur_frame (camLrectLkf_R_camLrectK_imu) per stream.
+class StereoVisionImuFrontend {
+ public:
+  explicit StereoVisionImuFrontend(Context ctx) : c_(std::move(ctx)) {}
+  // images: `batch` images back to back (host memory)
+  void spinOnce(const uint8_t* left, const uint8_t* right, size_t row_stride, size_t image_stride,
+                const kvfe_frame_input* inputs) {
+    c_.check(kvfe_frontend_step_host(c_.get(), left, right, row_stride, image_stride, inputs), "spinOnce");
+  }
+  // same with device pointers (batched many-sequence mode, inputs already in HBM)
+  void spinOnceDevice(const void* left_dev, const void* right_dev, size_t row_stride,
+                      size_t image_stride, const kvfe_frame_input* inputs) {
+    c_.check(kvfe_frontend_step_device(c_.get(), left_dev, right_dev, row_stride, image_stride, inputs),
+             "spinOnceDevice");
+  }
+  // StereoFrontendOutput of one stream; arrays sized by out->capacity
+  void getOutput(int stream, kvfe_frame_output* out) {
+    c_.check(kvfe_frontend_get_output(c_.get(), stream, out), "getOutput");
+  }
+  void reset() { c_.check(kvfe_frontend_reset(c_.get()), "reset"); }
+
+ private:
+  Context c_;
+};
+
+}  // namespace kvfe

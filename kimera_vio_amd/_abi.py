@@ -93,7 +93,7 @@ class Config(C.Structure):
         ("left", CameraParams), ("right", CameraParams), ("params", FrontendParams),
         ("batch", C.c_int32), ("device", C.c_int32),
         ("hip_stream", C.c_void_p),
-        ("candidate_capacity", C.c_int32), ("reserved0", C.c_int32),
+        ("candidate_capacity", C.c_int32), ("stream_groups", C.c_int32),
     ]
 
 
@@ -139,6 +139,7 @@ class FrameOutput(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [
         ("n_stages", C.c_int32), ("n_samples", C.c_int32),
+        ("n_groups", C.c_int32), ("reserved0", C.c_int32),
         ("name", C.c_char_p * KVFE_N_STAGES),
         ("ms_total", C.c_double * KVFE_N_STAGES),
         ("alg_bytes", C.c_double * KVFE_N_STAGES),

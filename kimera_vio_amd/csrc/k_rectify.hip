@@ -12,67 +12,135 @@ namespace kvfe {
 
 __device__ __forceinline__ int clipi(int x, int b) { return x >= 0 ? (x < b ? x : b - 1) : 0; }
 
-// one output pixel of cv::remap: 1/32-px fixed-point coordinates, 15-bit weights
-__device__ __forceinline__ unsigned remap_px(const unsigned char* __restrict__ src, int W, int H,
-                                             size_t stride, float mx, float my) {
-  int sxf = __float2int_rn(mx * 32.0f);
-  int syf = __float2int_rn(my * 32.0f);
+// cv::remap taps of one output pixel: 1/32-px fixed-point coordinates, 15-bit weights, the four
+// source offsets already clamped (BORDER_REPLICATE).  Depends only on the map, not on the image:
+// a block computes the taps once and applies them to SPB streams.
+struct RemapTap {
+  int o00, o01, o10, o11;   // byte offsets into the source image
+  int w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ RemapTap remap_tap(int W, int H, int stride, float mx, float my) {
+  const int sxf = __float2int_rn(mx * 32.0f);
+  const int syf = __float2int_rn(my * 32.0f);
   const int ax = sxf & 31, ay = syf & 31;
   int sx = sxf >> 5, sy = syf >> 5;
   sx = max(-32768, min(32767, sx));  // saturate_cast<short>
   sy = max(-32768, min(32767, sy));
-  int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32,
-      w11 = ax * ay * 32;
+  RemapTap t;
+  t.w00 = (32 - ax) * (32 - ay) * 32;
+  t.w01 = ax * (32 - ay) * 32;
+  t.w10 = (32 - ax) * ay * 32;
+  t.w11 = ax * ay * 32;
   if ((ax | ay) == 0) {  // table entry (0,0) after saturation and fix-up: {32767,0,0,1}
-    w00 = 32767;
-    w11 = 1;
+    t.w00 = 32767;
+    t.w11 = 1;
   }
-  int v0, v1, v2, v3;
-  if ((unsigned)sx < (unsigned)max(W - 1, 0) && (unsigned)sy < (unsigned)max(H - 1, 0)) {
-    const unsigned char* S = src + (size_t)sy * stride + sx;
-    v0 = S[0];
-    v1 = S[1];
-    v2 = S[stride];
-    v3 = S[stride + 1];
-  } else {
-    const int sx0 = clipi(sx, W), sx1 = clipi(sx + 1, W);
-    const int sy0 = clipi(sy, H), sy1 = clipi(sy + 1, H);
-    v0 = src[(size_t)sy0 * stride + sx0];
-    v1 = src[(size_t)sy0 * stride + sx1];
-    v2 = src[(size_t)sy1 * stride + sx0];
-    v3 = src[(size_t)sy1 * stride + sx1];
-  }
-  int r = (v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + (1 << 14)) >> 15;
-  return (unsigned)max(0, min(255, r));
+  const int sx0 = clipi(sx, W), sx1 = clipi(sx + 1, W);
+  const int sy0 = clipi(sy, H) * stride, sy1 = clipi(sy + 1, H) * stride;
+  t.o00 = sy0 + sx0;
+  t.o01 = sy0 + sx1;
+  t.o10 = sy1 + sx0;
+  t.o11 = sy1 + sx1;
+  return t;
 }
+
+__device__ __forceinline__ unsigned remap_apply(const unsigned char* __restrict__ src, const RemapTap& t) {
+  const int r = ((int)src[t.o00] * t.w00 + (int)src[t.o01] * t.w01 + (int)src[t.o10] * t.w10 +
+                 (int)src[t.o11] * t.w11 + (1 << 14)) >> 15;
+  // the four weights sum to 2^15, so 0 <= r <= 255 without the saturate_cast of the reference.
+  // (Deliberately no min/max here: hipcc 7.2 fuses "ashr, clamp, pack" into v_ashr_pk_u8_i32,
+  // which leaves the upper half of its destination unwritten -> corrupted third pixel.)
+  return (unsigned)r & 0xffu;
+}
+
+constexpr int RECT_SPB = 8;  // streams per block: the map is read once per RECT_SPB images
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void rectify_kernel(
     const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1,
     size_t src_row_stride, size_t src_img_stride, unsigned char* __restrict__ dst0,
     unsigned char* __restrict__ dst1, const float2* __restrict__ map0,
-    const float2* __restrict__ map1, int W, int H, const int* __restrict__ flags, int act_flag) {
-  const int s = blockIdx.z, cam = blockIdx.y;
-  if (flags && !(flags[s] & act_flag)) return;
-  const unsigned char* src = (cam == 0 ? src0 : src1) + (size_t)s * src_img_stride;
-  unsigned char* dst = (cam == 0 ? dst0 : dst1) + (size_t)s * W * H;
+    const float2* __restrict__ map1, int W, int H, int B, const int* __restrict__ flags,
+    int act_flag) {
+  const int cam = blockIdx.y, s_begin = blockIdx.z * RECT_SPB;
+  const int s_end = min(B, s_begin + RECT_SPB);
+  const unsigned char* src = cam == 0 ? src0 : src1;
+  unsigned char* dst = cam == 0 ? dst0 : dst1;
   const float2* map = cam == 0 ? map0 : map1;
   const int N = W * H;
+  const int stride = (int)src_row_stride;
   if (VEC4) {
     const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= N) return;
     const float4 m01 = *reinterpret_cast<const float4*>(map + i);
     const float4 m23 = *reinterpret_cast<const float4*>(map + i + 2);
-    unsigned p0 = remap_px(src, W, H, src_row_stride, m01.x, m01.y);
-    unsigned p1 = remap_px(src, W, H, src_row_stride, m01.z, m01.w);
-    unsigned p2 = remap_px(src, W, H, src_row_stride, m23.x, m23.y);
-    unsigned p3 = remap_px(src, W, H, src_row_stride, m23.z, m23.w);
-    *reinterpret_cast<unsigned*>(dst + i) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    const RemapTap t0 = remap_tap(W, H, stride, m01.x, m01.y);
+    const RemapTap t1 = remap_tap(W, H, stride, m01.z, m01.w);
+    const RemapTap t2 = remap_tap(W, H, stride, m23.x, m23.y);
+    const RemapTap t3 = remap_tap(W, H, stride, m23.z, m23.w);
+    // A rectification map is locally smooth: the 16 taps of four neighbouring output pixels
+    // normally lie in two source rows within 8 bytes.  Then two unaligned 8-byte loads per image
+    // replace 16 byte gathers; bytes are picked with v_perm_b32 and blended with v_dot2_i32_i16.
+    const int r0 = t0.o00 - (t0.o00 % stride), r1 = t0.o10 - (t0.o10 % stride);
+    const int xmin = min(min(t0.o00, t1.o00), min(t2.o00, t3.o00)) - r0;
+    auto in_rows = [&](const RemapTap& t) {
+      const int x0 = t.o00 - r0, x1 = t.o01 - r0;
+      return t.o10 - r1 == x0 && t.o11 - r1 == x1 && x0 >= xmin && x0 < xmin + 8 && x1 >= xmin &&
+             x1 < xmin + 8 && x0 < stride && x1 < stride;
+    };
+    const bool fast = in_rows(t0) && in_rows(t1) && in_rows(t2) && in_rows(t3) &&
+                      (long long)r1 + xmin + 8 <= (long long)stride * H &&
+                      (long long)r0 + xmin + 8 <= (long long)stride * H;
+    if (fast) {
+      auto sel_of = [&](const RemapTap& t) {  // (byte x0) | 0 << 8 | (byte x1) << 16 | 0 << 24
+        const unsigned b0 = (unsigned)(t.o00 - r0 - xmin), b1 = (unsigned)(t.o01 - r0 - xmin);
+        return b0 | (0x0cu << 8) | (b1 << 16) | (0x0cu << 24);
+      };
+      typedef short v2s_ __attribute__((ext_vector_type(2)));
+      auto pk = [](int lo, int hi) { return (lo & 0xffff) | (hi << 16); };
+      const unsigned e0 = sel_of(t0), e1 = sel_of(t1), e2 = sel_of(t2), e3 = sel_of(t3);
+      const int a0 = pk(t0.w00, t0.w01), b0 = pk(t0.w10, t0.w11), a1 = pk(t1.w00, t1.w01),
+                b1 = pk(t1.w10, t1.w11), a2 = pk(t2.w00, t2.w01), b2 = pk(t2.w10, t2.w11),
+                a3 = pk(t3.w00, t3.w01), b3 = pk(t3.w10, t3.w11);
+      const int off0 = r0 + xmin, off1 = r1 + xmin;
+      auto blend = [&](uint2 u, uint2 v, unsigned sel, int wa, int wb) {
+        const unsigned p = __builtin_amdgcn_perm(u.y, u.x, sel), q = __builtin_amdgcn_perm(v.y, v.x, sel);
+        const int r = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s_, p), __builtin_bit_cast(v2s_, wa),
+                                             __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s_, q),
+                                                                    __builtin_bit_cast(v2s_, wb),
+                                                                    1 << 14, false),
+                                             false) >> 15;
+        return (unsigned)r & 0xffu;  // weights sum to 2^15: already within 0..255 (see remap_apply)
+      };
+      for (int s = s_begin; s < s_end; s++) {
+        if (flags && !(flags[s] & act_flag)) continue;
+        const unsigned char* S = src + (size_t)s * src_img_stride;
+        uint2 u, v;
+        __builtin_memcpy(&u, S + off0, 8);
+        __builtin_memcpy(&v, S + off1, 8);
+        const unsigned p0 = blend(u, v, e0, a0, b0), p1 = blend(u, v, e1, a1, b1),
+                       p2 = blend(u, v, e2, a2, b2), p3 = blend(u, v, e3, a3, b3);
+        *reinterpret_cast<unsigned*>(dst + (size_t)s * N + i) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+      }
+    } else {
+      for (int s = s_begin; s < s_end; s++) {
+        if (flags && !(flags[s] & act_flag)) continue;
+        const unsigned char* S = src + (size_t)s * src_img_stride;
+        const unsigned p0 = remap_apply(S, t0), p1 = remap_apply(S, t1), p2 = remap_apply(S, t2),
+                       p3 = remap_apply(S, t3);
+        *reinterpret_cast<unsigned*>(dst + (size_t)s * N + i) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+      }
+    }
   } else {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float2 m = map[i];
-    dst[i] = (unsigned char)remap_px(src, W, H, src_row_stride, m.x, m.y);
+    const RemapTap t = remap_tap(W, H, stride, m.x, m.y);
+    for (int s = s_begin; s < s_end; s++) {
+      if (flags && !(flags[s] & act_flag)) continue;
+      dst[(size_t)s * N + i] = (unsigned char)remap_apply(src + (size_t)s * src_img_stride, t);
+    }
   }
 }
 
@@ -80,16 +148,17 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
                     size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
                     const int* flags, int act_flag, hipStream_t st) {
   const int N = P.W * P.H;
+  const int gz = (P.B + RECT_SPB - 1) / RECT_SPB;
   if (N % 4 == 0) {
-    dim3 grid((N / 4 + 255) / 256, 2, P.B);
+    dim3 grid((N / 4 + 255) / 256, 2, gz);
     hipLaunchKernelGGL(rectify_kernel<true>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
-                       P.H, flags, act_flag);
+                       P.H, P.B, flags, act_flag);
   } else {
-    dim3 grid((N + 255) / 256, 2, P.B);
+    dim3 grid((N + 255) / 256, 2, gz);
     hipLaunchKernelGGL(rectify_kernel<false>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
-                       P.H, flags, act_flag);
+                       P.H, P.B, flags, act_flag);
   }
 }
 

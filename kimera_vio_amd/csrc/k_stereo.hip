@@ -56,6 +56,28 @@ __global__ void stereo_left_kernel(KParams P, Tables T, FrameTab K, StereoTab ST
   ST.left_status[o] = status;
 }
 
+// LDS geometry of match_one (dwords), shared by the kernel and the launcher
+struct StereoGeom {
+  int tcw, MC, TSW, SSW, P2N;
+  size_t match_bytes;
+};
+__host__ __device__ inline StereoGeom stereo_geom(const KParams& P) {
+  StereoGeom g;
+  g.tcw = (P.templ_cols + 3) >> 2;              // template dwords per row
+  g.MC = (g.tcw + 3 + 3) >> 2;                  // 16-byte stripe chunks walked per row
+  g.TSW = 4 * (g.MC + 1);                       // [4 zeros | template | zeros]
+  const int rw = P.stripe_cols - P.templ_cols + 1;
+  const int NJ = (3 + rw + 15) >> 4;
+  int ssw = 4 * NJ + 4 * g.MC + 4;              // furthest chunk any task reads
+  const int ndw = (3 + P.stripe_cols + 3) >> 2;
+  if (ssw < ndw + 4) ssw = (ndw + 4 + 3) & ~3;
+  g.SSW = ssw;
+  g.P2N = 4 * ndw + 4;
+  size_t b = 4 * ((size_t)P.templ_rows * g.TSW + (size_t)P.stripe_rows * g.SSW + (size_t)g.P2N);
+  g.match_bytes = (b + 15) & ~(size_t)15;
+  return g;
+}
+
 // core of searchRightKeypointEpipolar for one keypoint, executed by one wavefront
 __device__ void match_one(const KParams& P, const Tables& T, const unsigned char* __restrict__ L,
                           const unsigned char* __restrict__ R, float2 lkp, unsigned char* lds,
@@ -94,61 +116,158 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   }
   if (stripe_corner_x < 0) stripe_corner_x = 0;
 
-  // LDS layout: template rows padded to a multiple of 4 bytes (zero filled), stripe rows padded
-  // to a multiple of 4 bytes plus two slack dwords, both dword-addressable.
-  const int tcw = (tc + 3) >> 2;            // template dwords per row
-  const int scw = ((sc + 3) >> 2) + 2;      // stripe dwords per row
+  // ---- LDS layout (dwords) -----------------------------------------------------------------------
+  //   template : tr rows x TSW, row = [4 zero dwords | tcw template dwords | zeros]; the last
+  //              template dword is zero padded, so padding contributes nothing to sum(T*S)
+  //   stripe   : sr rows x SSW, staged from the dword-aligned position left of the stripe
+  //              (LDS byte u <-> stripe offset u - sh0), zero filled beyond the loaded dwords
+  //   P2       : exclusive prefix sums of the per-column sum of squares over the tr stripe rows
+  // SSD(o) = sum T^2 + sum S_o^2 - 2 sum T*S_o, exact in uint32 (101*11*255^2 < 2^27).
+  // sum S_o^2 comes from P2; sum T*S_o from v_dot4_u32_u8: a lane owns FOUR consecutive dword
+  // offsets of one byte phase r = lane & 3 (task (J, r): LDS bytes u = 16 J + 4 a + r, a < 4),
+  // walks the stripe in 16-byte chunks (one ds_read_b128 + 4 v_alignbyte for the phase) and reuses
+  // each chunk for the four offsets against a sliding window of template dwords: 16 dot4 per
+  // 2 LDS reads.
+  const StereoGeom G = stereo_geom(P);
+  const int tcw = G.tcw, MC = G.MC, TSW = G.TSW, SSW = G.SSW;
   unsigned* tplw = reinterpret_cast<unsigned*>(lds);
-  unsigned* stpw = tplw + tr * tcw;
-  unsigned char* tpl = reinterpret_cast<unsigned char*>(tplw);
-  unsigned char* stp = reinterpret_cast<unsigned char*>(stpw);
-  for (int e = lane; e < tr * tcw; e += 64) tplw[e] = 0u;
-  for (int e = lane; e < sr * scw; e += 64) stpw[e] = 0u;
+  unsigned* stpw = tplw + tr * TSW;
+  unsigned* P2 = stpw + sr * SSW;
+  const uint4* tpl4 = reinterpret_cast<const uint4*>(lds);   // rows are whole uint4s (TSW, SSW % 4 == 0)
+  const uint4* stp4 = tpl4 + tr * (TSW >> 2);
+  const int TSW4 = TSW >> 2, SSW4 = SSW >> 2;
+  unsigned char* tplb = reinterpret_cast<unsigned char*>(tplw);
+  const bool dword_rows = (W & 3) == 0 && ((size_t)R & 3) == 0;
+  const int sh0 = dword_rows ? (stripe_corner_x & 3) : 0;
+  const int x_al = stripe_corner_x - sh0;
+  const int ncol = sh0 + sc;                 // staged stripe bytes per row that hold image data
+  const int ndw = (ncol + 3) >> 2;
+  for (int e = lane; e < tr * TSW; e += 64) tplw[e] = 0u;
+  for (int e = lane; e < sr * SSW; e += 64) stpw[e] = 0u;
   __syncthreads();
   for (int e = lane; e < tr * tc; e += 64) {
     const int y = e / tc, x = e - y * tc;
-    tpl[y * tcw * 4 + x] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
+    tplb[(y * TSW + 4) * 4 + x] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
   }
-  for (int e = lane; e < sr * sc; e += 64) {
-    const int y = e / sc, x = e - y * sc;
-    stp[y * scw * 4 + x] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
+  if (dword_rows) {
+    for (int e = lane; e < sr * ndw; e += 64) {
+      const int y = e / ndw, q = e - y * ndw;
+      stpw[y * SSW + q] =
+          *reinterpret_cast<const unsigned*>(R + (size_t)(stripe_corner_y + y) * W + x_al + 4 * q);
+    }
+  } else {
+    unsigned char* stpb = reinterpret_cast<unsigned char*>(stpw);
+    for (int e = lane; e < sr * sc; e += 64) {
+      const int y = e / sc, x = e - y * sc;
+      stpb[y * SSW * 4 + x] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
+    }
   }
   __syncthreads();
-  // SSD(o) = sum T^2 + sum S_o^2 - 2 sum T*S_o with packed u8 dot products (exact in int32:
-  // 101*11*255^2 < 2^27).  A lane owns offsets o = lane + 64 j; the unaligned stripe dword is
-  // rebuilt from two aligned LDS dwords with v_alignbyte.
   unsigned t2 = 0;
-  for (int e = lane; e < tr * tcw; e += 64) t2 = __builtin_amdgcn_udot4(tplw[e], tplw[e], t2, false);
+  for (int e = lane; e < tr * TSW; e += 64) t2 = __builtin_amdgcn_udot4(tplw[e], tplw[e], t2, false);
   for (int off = 32; off > 0; off >>= 1) t2 += (unsigned)__shfl_xor((int)t2, off);
   const int rw = sc - tc + 1, rh = sr - tr + 1;
-  const int rem = tc & 3;
-  const unsigned lastmask = rem == 0 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+  const int NJ = (sh0 + rw + 15) >> 4;        // tasks: (J, r), J < NJ, r < 4
+  const int r = lane & 3;
+  const int cpl = ((ndw + 63) >> 6);          // stripe dwords per lane for the column sums
   unsigned long long best = ~0ull;
-  for (int o = lane; o < rw * rh; o += 64) {
-    const int oy = o / rw, ox = o - oy * rw;
-    const int q0 = ox >> 2, sh = ox & 3;
-    unsigned ss = 0, ts = 0;
-    for (int y = 0; y < tr; y++) {
-      const unsigned* trow = tplw + y * tcw;
-      const unsigned* srow = stpw + (oy + y) * scw + q0;
-      unsigned lo = srow[0];
-      for (int k = 0; k < tcw - 1; k++) {
-        const unsigned hi = srow[k + 1];
-        const unsigned sv = __builtin_amdgcn_alignbyte(hi, lo, sh);
-        ts = __builtin_amdgcn_udot4(trow[k], sv, ts, false);
-        ss = __builtin_amdgcn_udot4(sv, sv, ss, false);
-        lo = hi;
+  for (int oy = 0; oy < rh; oy++) {
+    // ---- P2: exclusive prefix of the column sums of squares over rows oy .. oy+tr-1 -----------
+    {
+      unsigned run = 0;
+      const int q0 = lane * cpl;
+      // first pass: lane total
+      for (int q = q0; q < min(q0 + cpl, ndw); q++)
+        for (int y = 0; y < tr; y++) {
+          const unsigned v = stpw[(oy + y) * SSW + q];
+          run = __builtin_amdgcn_udot4(v, v, run, false);
+        }
+      unsigned inc = run;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += t;
       }
-      {
-        const unsigned hi = srow[tcw];
-        const unsigned sv = __builtin_amdgcn_alignbyte(hi, lo, sh) & lastmask;
-        ts = __builtin_amdgcn_udot4(trow[tcw - 1], sv, ts, false);
-        ss = __builtin_amdgcn_udot4(sv, sv, ss, false);
+      unsigned base = inc - run;  // exclusive prefix of this lane's first column
+      __syncthreads();
+      for (int q = q0; q < min(q0 + cpl, ndw); q++) {
+        unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int y = 0; y < tr; y++) {
+          const unsigned v = stpw[(oy + y) * SSW + q];
+          const unsigned b0 = v & 0xffu, b1 = (v >> 8) & 0xffu, b2 = (v >> 16) & 0xffu, b3 = v >> 24;
+          c0 += b0 * b0;
+          c1 += b1 * b1;
+          c2 += b2 * b2;
+          c3 += b3 * b3;
+        }
+        P2[4 * q] = base;
+        P2[4 * q + 1] = base + c0;
+        P2[4 * q + 2] = base + c0 + c1;
+        P2[4 * q + 3] = base + c0 + c1 + c2;
+        base += c0 + c1 + c2 + c3;
+      }
+      if (lane == 63) P2[4 * ndw] = inc;  // total (lane 63 ends the last segment or is empty)
+      __syncthreads();
+    }
+    for (int task = lane; task < NJ * 4; task += 64) {
+      const int J = task >> 2;
+      unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+      // one 16-byte stripe chunk against the template window {tp = dwords 4m-4..4m-1, tq = 4m..4m+3}
+#define KVFE_SSD_CHUNK(tp, tq, raw, nxt)                                        \
+  {                                                                             \
+    const unsigned s0 = __builtin_amdgcn_alignbyte(raw.y, raw.x, r);            \
+    const unsigned s1 = __builtin_amdgcn_alignbyte(raw.z, raw.y, r);            \
+    const unsigned s2 = __builtin_amdgcn_alignbyte(raw.w, raw.z, r);            \
+    const unsigned s3 = __builtin_amdgcn_alignbyte(nxt.x, raw.w, r);            \
+    acc0 = __builtin_amdgcn_udot4(tq.x, s0, acc0, false);                       \
+    acc1 = __builtin_amdgcn_udot4(tp.w, s0, acc1, false);                       \
+    acc2 = __builtin_amdgcn_udot4(tp.z, s0, acc2, false);                       \
+    acc3 = __builtin_amdgcn_udot4(tp.y, s0, acc3, false);                       \
+    acc0 = __builtin_amdgcn_udot4(tq.y, s1, acc0, false);                       \
+    acc1 = __builtin_amdgcn_udot4(tq.x, s1, acc1, false);                       \
+    acc2 = __builtin_amdgcn_udot4(tp.w, s1, acc2, false);                       \
+    acc3 = __builtin_amdgcn_udot4(tp.z, s1, acc3, false);                       \
+    acc0 = __builtin_amdgcn_udot4(tq.z, s2, acc0, false);                       \
+    acc1 = __builtin_amdgcn_udot4(tq.y, s2, acc1, false);                       \
+    acc2 = __builtin_amdgcn_udot4(tq.x, s2, acc2, false);                       \
+    acc3 = __builtin_amdgcn_udot4(tp.w, s2, acc3, false);                       \
+    acc0 = __builtin_amdgcn_udot4(tq.w, s3, acc0, false);                       \
+    acc1 = __builtin_amdgcn_udot4(tq.z, s3, acc1, false);                       \
+    acc2 = __builtin_amdgcn_udot4(tq.y, s3, acc2, false);                       \
+    acc3 = __builtin_amdgcn_udot4(tq.x, s3, acc3, false);                       \
+  }
+      for (int y = 0; y < tr; y++) {
+        const uint4* trow = tpl4 + y * TSW4;
+        const uint4* srow = stp4 + (oy + y) * SSW4 + J;
+        uint4 ta = trow[0];  // zeros (template dwords -4 .. -1)
+        uint4 ra = srow[0];
+        int m = 0;
+        for (; m + 2 <= MC; m += 2) {  // two chunks per trip: the register windows swap roles
+          const uint4 tb = trow[m + 1], rb = srow[m + 1];
+          KVFE_SSD_CHUNK(ta, tb, ra, rb)
+          ta = trow[m + 2];
+          ra = srow[m + 2];
+          KVFE_SSD_CHUNK(tb, ta, rb, ra)
+        }
+        if (m < MC) {
+          const uint4 tb = trow[m + 1], rb = srow[m + 1];
+          KVFE_SSD_CHUNK(ta, tb, ra, rb)
+        }
+      }
+#undef KVFE_SSD_CHUNK
+      const unsigned ts[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const int u = 16 * J + 4 * a + r;
+        const int ox = u - sh0;
+        if (ox >= 0 && ox < rw) {
+          const unsigned ss = P2[u + tc] - P2[u];
+          const unsigned ssd = t2 + ss - 2u * ts[a];
+          const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)(oy * rw + ox);
+          best = key < best ? key : best;
+        }
       }
     }
-    const unsigned ssd = t2 + ss - 2u * ts;
-    const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)o;
-    best = key < best ? key : best;
+    __syncthreads();
   }
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned long long other = __shfl_xor(best, off);
@@ -161,7 +280,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int my = by + stripe_corner_y + (tr - 1) / 2;
   float2 match = make_float2((float)mx, (float)my);
   if (P.stereo_subpix) {  // cv::cornerSubPix(right_rectified, (10,10), (-1,-1), 40 it, 0.001)
-    double* terms = reinterpret_cast<double*>(lds + ((4 * (tr * tcw + sr * scw) + 15) & ~15));
+    double* terms = reinterpret_cast<double*>(lds + G.match_bytes);
     float* patch = reinterpret_cast<float*>(terms + 5 * 21 * 21);
     match = corner_subpix_wave(R, (size_t)W, W, H, match, 10, 40, 0.001 * 0.001, T.subpix_mask10,
                                patch, terms, lane);
@@ -180,7 +299,7 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
   const int s = blockIdx.y, i = blockIdx.x;
   if (!(S.flags[s] & act_flag)) return;
   if (i >= K.count[s]) return;
-  extern __shared__ unsigned char lds_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x;
   const size_t o = (size_t)s * P.kcap + i;
   const unsigned char* L = Lr + (size_t)s * P.W * P.H;
@@ -232,9 +351,7 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
 }
 
 static size_t stereo_lds_bytes(const KParams& P) {
-  const size_t tcw = (P.templ_cols + 3) / 4, scw = (P.stripe_cols + 3) / 4 + 2;
-  size_t b = 4 * ((size_t)P.templ_rows * tcw + (size_t)P.stripe_rows * scw);
-  b = (b + 15) & ~(size_t)15;
+  size_t b = stereo_geom(P).match_bytes;
   if (P.stereo_subpix) b += sizeof(double) * 5 * 21 * 21 + sizeof(float) * 23 * 23;
   return b;
 }
@@ -255,7 +372,7 @@ __global__ __launch_bounds__(64) void stereo_match_only_kernel(
     float2* rkps, unsigned char* rstat, double* scores) {
   const int i = blockIdx.x;
   if (i >= n) return;
-  extern __shared__ unsigned char lds_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float2 rkp = make_float2(0.f, 0.f);
   int rstatus = lstat[i];
   double score = -1.0;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,6 +23,7 @@ using namespace kvfe;
 namespace {
 
 constexpr int ACAP = 8192;  // accepted-corner capacity (LDS sort capacity of the select kernel)
+constexpr int MIN_GROUP_STREAMS = 8;  // automatic stream groups hold at least this many streams
 
 enum Stage {
   ST_PYRAMID = 0,
@@ -78,7 +80,7 @@ struct kvfe_ctx {
   int raw_slot = 0;
   int pts_bound = 0;
   // pinned input staging ring
-  static constexpr int RING = 8;
+  static constexpr int RING = 64;
   unsigned char* ring_host[RING] = {};
   hipEvent_t ring_ev[RING] = {};
   bool ring_used[RING] = {};
@@ -94,6 +96,16 @@ struct kvfe_ctx {
   double prof_ms[ST_COUNT] = {};
   int prof_samples = 0;
   std::string last_error;
+  // stream groups: a context with batch >= 2*MIN_GROUP_STREAMS splits its streams into `groups`
+  // child contexts (own HIP stream, own buffers, shared constant tables).  The children free-run;
+  // the only coupling is the token below that staggers their phases so that the latency-bound
+  // kernels of one group (select, cornerSubPix tails) overlap the throughput-bound kernels (LK,
+  // min-eig, SSD) of the others.
+  std::vector<kvfe_ctx*> children;
+  kvfe_ctx* parent = nullptr;
+  int s0 = 0;                       // first stream of this child in the parent's batch
+  hipEvent_t ev_tracked = nullptr;  // recorded after this group's track_finalize launch
+  bool ev_tracked_valid = false;
 };
 
 namespace {
@@ -536,6 +548,10 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
               img_stride, b.pyr[pc], b.lk, c->pts_bound, st);
   prof_mark(c, ST_TRACK_FINALIZE);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
+  if (c->ev_tracked) {
+    HIPCHK(c, hipEventRecord(c->ev_tracked, st));
+    c->ev_tracked_valid = true;
+  }
   prof_mark(c, ST_MINEIG);
   launch_mineig(P, c->T, left, row_stride, img_stride, nullptr, K, b.ss, b.ds, 1, st);
   prof_mark(c, ST_SELECT);
@@ -558,6 +574,30 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   c->prev_left = left;
   c->prev_row_stride = row_stride;
   c->prev_img_stride = img_stride;
+  return KVFE_OK;
+}
+
+// all groups of a parent context: group g starts its step once group g-1 (cyclically: the last
+// group's previous step) has issued its tracking stage
+kvfe_status step_groups(kvfe_ctx* c, const unsigned char* left, const unsigned char* right,
+                        size_t row_stride, size_t img_stride, const kvfe_frame_input* inputs,
+                        bool host_input) {
+  const int G = (int)c->children.size();
+  for (int g = 0; g < G; g++) {
+    kvfe_ctx* ch = c->children[g];
+    kvfe_ctx* pred = c->children[(g + G - 1) % G];
+    static const bool no_token = std::getenv("KVFE_NO_TOKEN") != nullptr;
+    if (G > 1 && !no_token && pred->ev_tracked_valid) HIPCHK(c, hipStreamWaitEvent(ch->stream, pred->ev_tracked, 0));
+    const unsigned char* l = left + (size_t)ch->s0 * img_stride;
+    const unsigned char* r = right + (size_t)ch->s0 * img_stride;
+    kvfe_status s = host_input
+                        ? kvfe_frontend_step_host(ch, l, r, row_stride, img_stride, inputs + ch->s0)
+                        : do_step(ch, l, r, row_stride, img_stride, inputs + ch->s0);
+    if (s != KVFE_OK) {
+      c->last_error = ch->last_error;
+      return s;
+    }
+  }
   return KVFE_OK;
 }
 
@@ -637,6 +677,64 @@ kvfe_status kvfe_compute_undistort_rectify_maps(const kvfe_camera_params* cam, c
   return init_undistort_rectify_map(*cam, R, P, map_x, map_y);
 }
 
+static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, int batch,
+                              bool alloc_frontend, kvfe_ctx** out) {
+  kvfe_ctx* c = new kvfe_ctx();
+  c->cfg = *cfg;
+  c->cfg.batch = batch;
+  c->parent = parent;
+  c->s0 = s0;
+  kvfe_status s = KVFE_OK;
+  if (parent)
+    c->rect = parent->rect;
+  else
+    s = stereo_rectify(cfg->left, cfg->right, &c->rect);
+  if (s != KVFE_OK) {
+    delete c;
+    return s;
+  }
+  if (cfg->hip_stream && !parent) {
+    c->stream = reinterpret_cast<hipStream_t>(cfg->hip_stream);
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return KVFE_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  s = fill_params(c);
+  if (s == KVFE_OK) {
+    if (parent) {  // constant tables are shared with (and owned by) the parent
+      c->T = parent->T;
+      std::memcpy(c->und, parent->und, sizeof(c->und));
+    } else {
+      s = build_tables(c);
+    }
+  }
+  if (s == KVFE_OK && alloc_frontend) s = alloc_buffers(c, c->fe, c->P);
+  if (s == KVFE_OK && alloc_frontend) {
+    c->ring_bytes = (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * (size_t)c->P.B + 64;
+    for (int i = 0; i < kvfe_ctx::RING && s == KVFE_OK; i++) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, c->ring_bytes, hipHostMallocDefault) != hipSuccess) s = KVFE_ERR_HIP;
+      c->ring_host[i] = reinterpret_cast<unsigned char*>(h);
+      if (s == KVFE_OK) c->host_allocs.push_back(h);
+      if (s == KVFE_OK && hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess)
+        s = KVFE_ERR_HIP;
+    }
+  }
+  if (s == KVFE_OK && parent &&
+      hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess)
+    s = KVFE_ERR_HIP;
+  if (s != KVFE_OK) {
+    std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
+    kvfe_destroy(c);
+    return s;
+  }
+  *out = c;
+  return KVFE_OK;
+}
+
 kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
   if (!cfg || !out) return KVFE_ERR_INVALID_ARG;
   *out = nullptr;
@@ -659,40 +757,31 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
                  prop.gcnArchName);
     return KVFE_ERR_NO_DEVICE;
   }
-  kvfe_ctx* c = new kvfe_ctx();
-  c->cfg = *cfg;
-  kvfe_status s = stereo_rectify(cfg->left, cfg->right, &c->rect);
-  if (s != KVFE_OK) {
-    delete c;
-    return s;
-  }
-  if (cfg->hip_stream) {
-    c->stream = reinterpret_cast<hipStream_t>(cfg->hip_stream);
-  } else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-      delete c;
-      return KVFE_ERR_HIP;
+  // number of stream groups: explicit, or by batch size (a caller-owned stream keeps one group so
+  // that all work stays ordered on that stream)
+  int groups = cfg->stream_groups;
+  if (groups < 0) return KVFE_ERR_INVALID_ARG;
+  if (cfg->hip_stream) groups = 1;
+  if (groups == 0) groups = cfg->batch >= 4 * MIN_GROUP_STREAMS ? 4 : (cfg->batch >= 2 * MIN_GROUP_STREAMS ? 2 : 1);
+  groups = std::max(1, std::min(groups, cfg->batch));
+  kvfe_ctx* c = nullptr;
+  kvfe_status s = create_one(cfg, nullptr, 0, cfg->batch, groups == 1, &c);
+  if (s != KVFE_OK) return s;
+  if (groups > 1) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // shared tables are complete
+    const int base = cfg->batch / groups, rem = cfg->batch % groups;
+    int s0 = 0;
+    for (int g = 0; g < groups && s == KVFE_OK; g++) {
+      const int bg = base + (g < rem ? 1 : 0);
+      kvfe_ctx* ch = nullptr;
+      s = create_one(cfg, c, s0, bg, true, &ch);
+      if (s == KVFE_OK) c->children.push_back(ch);
+      s0 += bg;
     }
-    c->own_stream = true;
-  }
-  s = fill_params(c);
-  if (s == KVFE_OK) s = build_tables(c);
-  if (s == KVFE_OK) s = alloc_buffers(c, c->fe, c->P);
-  if (s == KVFE_OK) {
-    c->ring_bytes = (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * (size_t)c->P.B + 64;
-    for (int i = 0; i < kvfe_ctx::RING && s == KVFE_OK; i++) {
-      void* h = nullptr;
-      if (hipHostMalloc(&h, c->ring_bytes, hipHostMallocDefault) != hipSuccess) s = KVFE_ERR_HIP;
-      c->ring_host[i] = reinterpret_cast<unsigned char*>(h);
-      if (s == KVFE_OK) c->host_allocs.push_back(h);
-      if (s == KVFE_OK && hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess)
-        s = KVFE_ERR_HIP;
+    if (s != KVFE_OK) {
+      kvfe_destroy(c);
+      return s;
     }
-  }
-  if (s != KVFE_OK) {
-    std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
-    kvfe_destroy(c);
-    return s;
   }
   *out = c;
   return KVFE_OK;
@@ -700,10 +789,13 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
 
 void kvfe_destroy(kvfe_ctx* c) {
   if (!c) return;
+  for (kvfe_ctx* ch : c->children) kvfe_destroy(ch);
+  c->children.clear();
   if (c->stream) hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   for (int i = 0; i < kvfe_ctx::RING; i++)
     if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
+  if (c->ev_tracked) hipEventDestroy(c->ev_tracked);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->host_allocs) hipHostFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -718,6 +810,7 @@ kvfe_status kvfe_get_rectification(const kvfe_ctx* c, kvfe_rectification* out) {
 
 kvfe_status kvfe_synchronize(kvfe_ctx* c) {
   if (!c) return KVFE_ERR_INVALID_ARG;
+  for (kvfe_ctx* ch : c->children) TRY(kvfe_synchronize(ch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   return KVFE_OK;
@@ -972,6 +1065,10 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
                                       const kvfe_frame_input* inputs) {
   if (!c || !left_dev || !right_dev || !inputs) return KVFE_ERR_INVALID_ARG;
   if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
+  if (!c->children.empty())
+    return step_groups(c, reinterpret_cast<const unsigned char*>(left_dev),
+                       reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride,
+                       inputs, false);
   return do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
                  reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
 }
@@ -981,6 +1078,7 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
                                     const kvfe_frame_input* inputs) {
   if (!c || !left || !right || !inputs) return KVFE_ERR_INVALID_ARG;
   if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
+  if (!c->children.empty()) return step_groups(c, left, right, row_stride, image_stride, inputs, true);
   Buffers& b = c->fe;
   const KParams& P = c->P;
   const size_t N = (size_t)P.W * P.H;
@@ -997,6 +1095,13 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
 
 kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   if (!c) return KVFE_ERR_INVALID_ARG;
+  if (!c->children.empty()) {
+    for (kvfe_ctx* ch : c->children) {
+      TRY(kvfe_frontend_reset(ch));
+      ch->ev_tracked_valid = false;
+    }
+    return KVFE_OK;
+  }
   Buffers& b = c->fe;
   const size_t B = c->P.B;
   hipStream_t st = c->stream;
@@ -1018,6 +1123,12 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
 
 kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {
   if (!c || !out || s < 0 || s >= c->P.B) return KVFE_ERR_INVALID_ARG;
+  for (kvfe_ctx* ch : c->children)
+    if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
+      const kvfe_status r = kvfe_frontend_get_output(ch, s - ch->s0, out);
+      if (r != KVFE_OK) c->last_error = ch->last_error;
+      return r;
+    }
   Buffers& b = c->fe;
   const KParams& P = c->P;
   hipStream_t st = c->stream;
@@ -1068,6 +1179,7 @@ kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* 
 
 kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
   if (!c) return KVFE_ERR_INVALID_ARG;
+  for (kvfe_ctx* ch : c->children) TRY(kvfe_profile_enable(ch, on));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   c->prof_on = on != 0;
@@ -1080,10 +1192,28 @@ kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
 
 kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
   if (!c || !out) return KVFE_ERR_INVALID_ARG;
+  if (!c->children.empty()) {  // launches of all groups: summed durations, mean bytes per launch
+    std::memset(out, 0, sizeof(*out));
+    out->n_stages = ST_COUNT;
+    out->n_groups = (int)c->children.size();
+    for (kvfe_ctx* ch : c->children) {
+      kvfe_stage_times t;
+      TRY(kvfe_profile_read(ch, &t));
+      out->n_samples += t.n_samples;
+      for (int s = 0; s < ST_COUNT; s++) {
+        out->name[s] = t.name[s];
+        out->ms_total[s] += t.ms_total[s];
+        out->alg_bytes[s] += t.alg_bytes[s] * t.n_samples;
+      }
+    }
+    for (int s = 0; s < ST_COUNT; s++) out->alg_bytes[s] /= std::max(out->n_samples, 1);
+    return KVFE_OK;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   std::memset(out, 0, sizeof(*out));
   out->n_stages = ST_COUNT;
+  out->n_groups = 1;
   out->n_samples = c->prof_samples;
   const double N = (double)c->P.W * c->P.H * c->P.B;
   for (int s = 0; s < ST_COUNT; s++) {

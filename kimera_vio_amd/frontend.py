@@ -41,13 +41,14 @@ class Context:
 
     def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
                  batch: int = 1, device: int = 0, hip_stream: int | None = None,
-                 candidate_capacity: int = 0):
+                 candidate_capacity: int = 0, stream_groups: int = 0):
         self.lib = load()
         cfg = abi.Config()
         cfg.left, cfg.right, cfg.params = left, right, params
         cfg.batch, cfg.device = batch, device
         cfg.hip_stream = hip_stream
         cfg.candidate_capacity = candidate_capacity
+        cfg.stream_groups = stream_groups
         self.cfg = cfg
         self.left, self.right, self.params = left, right, params
         self.batch = batch
@@ -245,7 +246,7 @@ class Context:
     def profile_read(self) -> dict:
         st = abi.StageTimes()
         self._chk(self.lib.kvfe_profile_read(self._h, C.byref(st)), "profile_read")
-        return dict(n_samples=st.n_samples,
+        return dict(n_samples=st.n_samples, n_groups=st.n_groups,
                     stages={st.name[i].decode(): dict(ms_total=st.ms_total[i], alg_bytes=st.alg_bytes[i])
                             for i in range(st.n_stages)})
 

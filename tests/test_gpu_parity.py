@@ -361,19 +361,20 @@ def test_frontend_sequence_single_stream(seq, ocam):
     assert all(k[3] > 100 for k in kinds[1:])
 
 
-def test_frontend_sequence_batched_streams(seq, ocam):
-    """C3-style: 4 independent streams in one context (different frame offsets / directions), each
-    with its own landmark-id counter starting at 0, all identical to per-stream oracles."""
+@pytest.mark.parametrize("B,groups", [(4, 1), (4, 2), (5, 3)])
+def test_frontend_sequence_batched_streams(seq, ocam, B, groups):
+    """C3-style: independent streams in one context (different frame offsets / directions), each
+    with its own landmark-id counter starting at 0, all identical to per-stream oracles -- with the
+    batch on one HIP stream and split into stream groups (uneven split included)."""
     seq = dict(seq)
     seq["camR"] = _kf_rotations(seq["body_R"], ocam)
     L, R = euroc_cams()
     p = euroc_params(max_features_per_frame=200)
-    B = 4
     fe = [O.Frontend(L, R, p) for _ in range(B)]
-    c = F.Context(L, R, p, batch=B)
+    c = F.Context(L, R, p, batch=B, stream_groups=groups)
 
     def stream_of(s, i):
-        return [i, 8 - i, min(i + 2, 8), (3 * i) % 9][s]
+        return [i, 8 - i, min(i + 2, 8), (3 * i) % 9, (5 * i + 1) % 9][s]
 
     try:
         _run_sequence(fe, c, seq, stream_of=stream_of, n=7)

@@ -1,0 +1,106 @@
+"""N>1 path on CPU: two `gloo` ranks shard independent streams (no data-path collective), run the
+front-end restatement (oracle, as the stand-in for the device path) on their own streams, and
+reduce timing/unit counts exactly as bench.py does.  Checks: shards are disjoint and cover all
+streams; a stream's output does not depend on the rank that processed it; MAX/SUM reduction."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_streams(stream_ids, n_frames=3):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    import oracle_lib as O
+    from kimera_vio_amd import params as P
+    L = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    R = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p.detector.max_features_per_frame = 100
+    z = np.load(os.path.join(G, "micro_euroc_f10_18.npz"))
+    out = {}
+    for s in stream_ids:
+        fe = O.Frontend(L, R, p)
+        sig = []
+        for i in range(n_frames):
+            j = (s + i) % len(z["lefts"])  # every stream starts at a different frame
+            o = fe.process(z["lefts"][j], z["rights"][j], int(z["timestamps"][0]) + i * 50_000_000)
+            sig.append((o["n_keypoints"], float(np.asarray(o["keypoints"], np.float64).sum()),
+                        int(np.asarray(o["landmarks"]).sum())))
+        out[s] = sig
+    return out
+
+
+def _worker(rank, world, port, n_streams, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch.distributed as dist
+    from kimera_vio_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r, _, w = sharding.env_rank()
+        mine = sharding.shard_streams(n_streams, w, r)
+        sharding.barrier(dist, w)
+        t0 = time.perf_counter()
+        res = _run_streams(mine)
+        sharding.barrier(dist, w)
+        el = time.perf_counter() - t0
+        units = sum(len(v) for v in res.values())
+        el_max, units_sum = sharding.reduce_timing(dist, w, el, units)
+        q.put((rank, mine, res, el, el_max, units_sum))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_streams_partition():
+    sys.path.insert(0, ROOT)
+    from kimera_vio_amd import sharding
+    for n, w in ((8, 8), (64, 8), (5, 2), (3, 4), (1, 1)):
+        shards = [sharding.shard_streams(n, w, r) for r in range(w)]
+        flat = sorted(s for sh in shards for s in sh)
+        assert flat == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_streams(4, 2, 2)
+
+
+def test_two_gloo_ranks_shard_streams_and_reduce_timing():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, n_streams = 2, 4
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda g: g[0])
+    all_streams = sorted(s for g in got for s in g[1])
+    assert all_streams == list(range(n_streams))
+    assert got[0][4] == got[1][4] == max(got[0][3], got[1][3])        # MAX over ranks
+    assert got[0][5] == got[1][5] == n_streams * 3                    # SUM of stereo pairs
+    # a stream's result is independent of where it ran
+    single = _run_streams(range(n_streams))
+    for g in got:
+        for s, sig in g[2].items():
+            assert sig == single[s]
