@@ -26,14 +26,40 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-constexpr int TW = 64, TH = 16;           // output tile
-constexpr int CH = 2;                     // cov halo (box 3x3 + local-max ring)
-constexpr int SH = 3;                     // source halo
-constexpr int SW_ = TW + 2 * SH, SHT = TH + 2 * SH;
-constexpr int CW_ = TW + 2 * CH, CHT = TH + 2 * CH;
-constexpr int LW_ = TW + 2, LHT = TH + 2;
+// ---------------------------------------------------------------------------------------------
+// One wavefront streams down a strip of 58 output columns x ME_ROWS rows (64 lanes = 58 columns
+// + 3 halo columns each side).  Nothing but the detection mask and the candidate buffer touches
+// LDS: horizontal neighbours come from DPP wave shifts, vertical neighbours from three rotating
+// register rows.  Per source row r the pipeline emits
+//   pixel row r  ->  Sobel partials dh(r), sm(r)           (horizontal difference / smoothing)
+//   cov row  r-1 ->  dx*dx, dx*dy, dy*dy and their horizontal 3-sums h(r-1) in float64
+//   box row  r-2 ->  lambda(r-2) and its horizontal 3-max hm(r-2)
+//   row      r-3 ->  3x3 local-maximum test, candidates appended to an LDS list
+// with BORDER_REFLECT_101 applied exactly where cv::Sobel / cv::boxFilter apply it.
+// The float operations and their order are those of cv::cornerMinEigenVal (see oracle).
+// ---------------------------------------------------------------------------------------------
+constexpr int ME_HALO = 3;
+constexpr int ME_COLS = 64 - 2 * ME_HALO;  // 58 output columns per wave
+constexpr int ME_ROWS = 48;                // output rows per wave
+constexpr int ME_LCAP = 1024;              // LDS candidate buffer (flushed when nearly full)
 
-__global__ __launch_bounds__(256) void mineig_localmax_kernel(
+__device__ __forceinline__ float dpp_from_left(float v) {   // lane i <- lane i-1
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_right(float v) {  // lane i <- lane i+1
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+struct MeRow {          // per-lane values of one image row at the different pipeline stages
+  float dh, sm;         // Sobel partials of the pixel row
+  double h0, h1, h2;    // horizontal 3-sums of dx*dx, dx*dy, dy*dy
+  float hm, lam;        // horizontal 3-max of lambda, lambda
+};
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(64) void mineig_localmax_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
     const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
     const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
@@ -42,224 +68,177 @@ __global__ __launch_bounds__(256) void mineig_localmax_kernel(
     unsigned int* __restrict__ maxkey) {
   const int s = blockIdx.z;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
-  __shared__ unsigned char src[SHT][SW_ + 2];
-  __shared__ float covs[3][CHT][CW_ + 1];  // dx*dx, dx*dy, dy*dy
-  float(*cov0)[CW_ + 1] = covs[0];
-  float(*cov1)[CW_ + 1] = covs[1];
-  float(*cov2)[CW_ + 1] = covs[2];
-  __shared__ float lam[LHT][LW_ + 1];
-  __shared__ unsigned long long rowmask[TH];  // bit x set: pixel (x0+x, y0+row) is masked OUT
+  __shared__ unsigned long long rowmask[ME_ROWS];  // bit l set: lane l's column is masked OUT
+  __shared__ unsigned long long lcand[ME_LCAP];
   __shared__ int hw_s[MAX_RADIUS + 1];
-  __shared__ int blk_n, blk_base;
-  __shared__ unsigned blk_key;
 
   const unsigned char* I = img + (size_t)s * img_stride;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int tid = threadIdx.x;
-  if (tid < TH) rowmask[tid] = 0ull;
-  for (int i = tid; i <= radius && i <= MAX_RADIUS; i += 256) hw_s[i] = circle_hw[i];
-  // tile (with its source halo) entirely inside the image: no border reflection anywhere
-  const bool interior = x0 - SH >= 0 && y0 - SH >= 0 && x0 + TW + SH <= W && y0 + TH + SH <= H;
-  if (interior) {
-    for (int i = tid; i < SW_ * SHT; i += 256) {
-      const int ty = i / SW_, tx = i - ty * SW_;
-      src[ty][tx] = I[(size_t)(y0 - SH + ty) * row_stride + (x0 - SH + tx)];
-    }
-  } else {
-    for (int i = tid; i < SW_ * SHT; i += 256) {
-      const int ty = i / SW_, tx = i - ty * SW_;
-      const int gx = reflect101(x0 - SH + tx, W), gy = reflect101(y0 - SH + ty, H);
-      src[ty][tx] = I[(size_t)gy * row_stride + gx];
-    }
-  }
+  const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
+  const int lane = threadIdx.x;
+  const int xs = blockIdx.x * ME_COLS, ys = blockIdx.y * ME_ROWS;
+  const int ye = min(ys + ME_ROWS, H);
+  const int x0 = xs - ME_HALO;          // column of lane 0
+  const int gx = x0 + lane;
+  const int cxr = reflect101(gx, W);    // source column (BORDER_REFLECT_101)
+  const bool col_in = gx >= 0 && gx < W;
+  const bool out_col = lane >= ME_HALO && lane < 64 - ME_HALO && gx < W;
+  const bool at_left = gx == 0, at_right = gx == W - 1;
+
+  if (lane < ME_ROWS) rowmask[lane] = 0ull;
+  for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
   __syncthreads();
-  // detection mask: rasterise the cv::circle discs that touch this tile into 16 row bitmasks
+  // detection mask: rasterise the cv::circle discs that touch this strip into row bit-masks
   if (use_discs) {
     const float2* kp = kp_all + (size_t)s * kcap;
     const int nk = kp_count[s];
-    for (int i = tid; i < nk; i += 256) {
+    for (int i = lane; i < nk; i += 64) {
       const float2 p = kp[i];
       const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
-      if (cx + radius < x0 || cx - radius >= x0 + TW || cy + radius < y0 || cy - radius >= y0 + TH)
+      if (cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye)
         continue;
-      const int r0 = max(cy - radius, y0), r1 = min(cy + radius, y0 + TH - 1);
+      const int r0 = max(cy - radius, ys), r1 = min(cy + radius, ye - 1);
       for (int gy = r0; gy <= r1; gy++) {
         const int hw = hw_s[abs(gy - cy)];
-        const int xa = max(cx - hw, x0) - x0, xb = min(cx + hw, x0 + TW - 1) - x0;
+        const int xa = max(cx - hw, x0) - x0, xb = min(cx + hw, x0 + 63) - x0;
         if (xa > xb) continue;
         const unsigned long long bits =
             (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
-        atomicOr(&rowmask[gy - y0], bits);
+        atomicOr(&rowmask[gy - ys], bits);
       }
     }
   }
-  // Sobel (scale folded into the smoothing taps exactly as cv::Sobel does) -> dx*dx, dx*dy, dy*dy
+  __syncthreads();
+
   const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0));  // (float)scale, blockSize 3, ksize 3
   const float f0 = 2.0f * f1;
-  for (int i = tid; i < CW_ * CHT; i += 256) {
-    const int cy = i / CW_, cx = i - cy * CW_;
-    const int gx = x0 - CH + cx, gy = y0 - CH + cy;
-    if (!interior && (gx < 0 || gx >= W || gy < 0 || gy >= H)) continue;
-    const int sx = cx + (SH - CH), sy = cy + (SH - CH);  // position in src tile
-    const float r0 = (float)((int)src[sy - 1][sx + 1] - (int)src[sy - 1][sx - 1]);
-    const float r1 = (float)((int)src[sy][sx + 1] - (int)src[sy][sx - 1]);
-    const float r2 = (float)((int)src[sy + 1][sx + 1] - (int)src[sy + 1][sx - 1]);
-    const float dx = (r0 + r2) * f1 + r1 * f0;
-    float tm = f1 * (float)src[sy - 1][sx - 1];
-    tm += f0 * (float)src[sy - 1][sx];
-    tm += f1 * (float)src[sy - 1][sx + 1];
-    float tp = f1 * (float)src[sy + 1][sx - 1];
-    tp += f0 * (float)src[sy + 1][sx];
-    tp += f1 * (float)src[sy + 1][sx + 1];
-    const float dy = tp - tm;
-    cov0[cy][cx] = dx * dx;
-    cov1[cy][cx] = dx * dy;
-    cov2[cy][cx] = dy * dy;
-  }
-  __syncthreads();
-  // box 3x3 (unnormalised, double accumulation like cv::boxFilter on CV_32F), separable: a thread
-  // walks a 6-row segment of one lambda column keeping the horizontal sums of the last three cov
-  // rows in registers (row sums first, then the column sum: the order cv::boxFilter uses).
-  {
-    constexpr int SEG = 6;  // LHT = 18 = 3 segments
-    const int lx = tid % LW_, seg = tid / LW_;
-    if (seg < LHT / SEG) {
-      const int gx = x0 - 1 + lx;
-      const bool col_ok = interior || (gx >= 0 && gx < W);
-      int c0 = lx, c1 = lx + 1, c2 = lx + 2;  // cov columns of gx-1, gx, gx+1
-      if (!interior && col_ok) {
-        c0 = reflect101(gx - 1, W) - (x0 - CH);
-        c2 = reflect101(gx + 1, W) - (x0 - CH);
+  // rows: hm rows b0..b1, cov/h rows c0..c1, pixel rows c0-1..c1+1 (reflected outside the image)
+  const int b0 = max(ys - 1, 0), b1 = min(ye, H - 1);
+  const int c0 = max(b0 - 1, 0), c1 = min(b1 + 1, H - 1);
+  const int r_first = c0 - 1, r_last = min(ye + 2, H + 1);
+  const int lm0 = max(ys, 1), lm1 = min(ye - 1, H - 2);
+
+  float bestv = -__builtin_inff();  // masked maximum of lambda (no pixel has lambda = -inf)
+  int n_loc = 0;                    // wave-uniform
+  auto flush = [&]() {
+    int base = 0;
+    if (lane == 0 && n_loc > 0) base = atomicAdd(&cand_count[s], n_loc);
+    base = __shfl(base, 0);
+    for (int i = lane; i < n_loc; i += 64) {
+      const int pos = base + i;
+      if (pos < ccap) cand_all[(size_t)s * ccap + pos] = lcand[i];
+    }
+    n_loc = 0;
+  };
+
+  // source column of this lane; rows are addressed with 32-bit offsets (an image is < 2 GiB)
+  const unsigned char* colp = I + cxr;
+  const unsigned stride_u = (unsigned)row_stride;
+  const unsigned char* mcol = HAS_MASK ? M + min(max(gx, 0), W - 1) : nullptr;
+  unsigned p_next = colp[(unsigned)reflect101(r_first, H) * stride_u];  // raw byte: converted at use
+  const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
+
+  // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  Only wave-uniform
+  // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
+  auto step = [&](int r, MeRow& X, MeRow& Y, MeRow& Z) {
+    // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
+    if (r <= H) {
+      const float p = (float)p_next;
+      if (r + 1 <= H) p_next = colp[(unsigned)reflect101(r + 1, H) * stride_u];
+      const float pl = dpp_from_left(p), pr = dpp_from_right(p);
+      X.dh = pr - pl;
+      float t = f1 * pl;
+      t += f0 * p;
+      t += f1 * pr;
+      X.sm = t;
+    }
+    // ---- cov row c = r-1 -> horizontal float64 sums --------------------------------------------
+    const int c = r - 1;
+    if (c >= c0 && c <= c1) {
+      const float dx = (Z.dh + X.dh) * f1 + Y.dh * f0;
+      const float dy = X.sm - Z.sm;
+      const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
+      const float lxx = dpp_from_left(cxx), rxx = dpp_from_right(cxx);
+      const float lxy = dpp_from_left(cxy), rxy = dpp_from_right(cxy);
+      const float lyy = dpp_from_left(cyy), ryy = dpp_from_right(cyy);
+      // BORDER_REFLECT_101 of cv::boxFilter: column -1 is column 1, column W is column W-2
+      float axx = lxx, bxx = rxx, axy = lxy, bxy = rxy, ayy = lyy, byy = ryy;
+      if (edge_strip) {
+        axx = at_left ? rxx : lxx, bxx = at_right ? lxx : rxx;
+        axy = at_left ? rxy : lxy, bxy = at_right ? lxy : rxy;
+        ayy = at_left ? ryy : lyy, byy = at_right ? lyy : ryy;
       }
-      double h0[3], h1[3], h2[3];  // horizontal sums of cov rows gy-1, gy, gy+1 (rolling)
-      auto hsum = [&](int cr, double& o0, double& o1, double& o2) {
-        double a0 = 0, a1 = 0, a2 = 0;
-        a0 += (double)cov0[cr][c0];
-        a0 += (double)cov0[cr][c1];
-        a0 += (double)cov0[cr][c2];
-        a1 += (double)cov1[cr][c0];
-        a1 += (double)cov1[cr][c1];
-        a1 += (double)cov1[cr][c2];
-        a2 += (double)cov2[cr][c0];
-        a2 += (double)cov2[cr][c1];
-        a2 += (double)cov2[cr][c2];
-        o0 = a0;
-        o1 = a1;
-        o2 = a2;
-      };
-      const int ly0 = seg * SEG;
-      if (interior) {
-        hsum(ly0, h0[0], h1[0], h2[0]);
-        hsum(ly0 + 1, h0[1], h1[1], h2[1]);
-#pragma unroll
-        for (int r = 0; r < SEG; r++) {
-          const int ly = ly0 + r;
-          hsum(ly + 2, h0[(r + 2) % 3], h1[(r + 2) % 3], h2[(r + 2) % 3]);
-          double s0 = 0, s1 = 0, s2 = 0;
-          s0 += h0[r % 3];
-          s0 += h0[(r + 1) % 3];
-          s0 += h0[(r + 2) % 3];
-          s1 += h1[r % 3];
-          s1 += h1[(r + 1) % 3];
-          s1 += h1[(r + 2) % 3];
-          s2 += h2[r % 3];
-          s2 += h2[(r + 1) % 3];
-          s2 += h2[(r + 2) % 3];
-          const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
-          lam[ly][lx] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-        }
-      } else {
-        for (int r = 0; r < SEG; r++) {
-          const int ly = ly0 + r, gy = y0 - 1 + ly;
-          float v = 0.0f;
-          if (col_ok && gy >= 0 && gy < H) {
-            const int r0 = reflect101(gy - 1, H) - (y0 - CH), r1 = gy - (y0 - CH),
-                      r2 = reflect101(gy + 1, H) - (y0 - CH);
-            hsum(r0, h0[0], h1[0], h2[0]);
-            hsum(r1, h0[1], h1[1], h2[1]);
-            hsum(r2, h0[2], h1[2], h2[2]);
-            double s0 = 0, s1 = 0, s2 = 0;
-            s0 += h0[0];
-            s0 += h0[1];
-            s0 += h0[2];
-            s1 += h1[0];
-            s1 += h1[1];
-            s1 += h1[2];
-            s2 += h2[0];
-            s2 += h2[1];
-            s2 += h2[2];
-            const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
-            v = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-          }
-          lam[ly][lx] = v;
-        }
+      // cv::boxFilter accumulates 0 + a + b + c in float64; "0 +" is dropped: it is exact for the
+      // non-negative dx*dx / dy*dy sums and can only change the sign of a zero dx*dy sum, which
+      // enters lambda squared.
+      Y.h0 = ((double)axx + (double)cxx) + (double)bxx;
+      Y.h1 = ((double)axy + (double)cxy) + (double)bxy;
+      Y.h2 = ((double)ayy + (double)cyy) + (double)byy;
+    }
+    // ---- box row b = r-2 -> lambda, horizontal max; masked maximum ------------------------------
+    const int b = r - 2;
+    if (b >= b0 && b <= b1) {
+      // rows b-1, b, b+1 = slots X, Z, Y; BORDER_REFLECT_101 at the image border: row -1 is row 1
+      // (slot Y), row H is row H-2 (slot X) -- wave-uniform branches taken once per strip
+      if (b == 0) {
+        X.h0 = Y.h0;
+        X.h1 = Y.h1;
+        X.h2 = Y.h2;
+      }
+      if (b == H - 1) {
+        Y.h0 = X.h0;
+        Y.h1 = X.h1;
+        Y.h2 = X.h2;
+      }
+      const double s0 = (X.h0 + Z.h0) + Y.h0, s1 = (X.h1 + Z.h1) + Y.h1, s2 = (X.h2 + Z.h2) + Y.h2;
+      const float fa = (float)s0 * 0.5f, fb = (float)s1, fc = (float)s2 * 0.5f;
+      const float lam = (fa + fc) - sqrtf((fa - fc) * (fa - fc) + fb * fb);
+      Z.lam = lam;
+      Z.hm = fmaxf(fmaxf(dpp_from_left(lam), lam), dpp_from_right(lam));
+      if (b >= ys && b < ye) {
+        bool masked_in = out_col & !((rowmask[b - ys] >> lane) & 1ull);
+        if (HAS_MASK) masked_in &= mcol[(unsigned)(b * W)] != 0;
+        bestv = masked_in ? fmaxf(bestv, lam) : bestv;
       }
     }
-  }
-  __syncthreads();
-  unsigned bestkey = 0;
-  const unsigned char* M = user_mask ? user_mask + (size_t)s * W * H : nullptr;
-  // candidates are first collected per block in LDS (reusing the cov0 array), then appended to
-  // the stream's list with ONE global atomic per block.
-  unsigned long long* lcand = reinterpret_cast<unsigned long long*>(&covs[0][0][0]);
-  constexpr int LCAP = (int)(sizeof(covs) / sizeof(unsigned long long));
-  static_assert(LCAP >= TW * TH, "every pixel of a tile may be a candidate");
-  if (tid == 0) {
-    blk_n = 0;
-    blk_key = 0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int lx = tid & 63, ly = (tid >> 6) + 4 * k;
-    const int gx = x0 + lx, gy = y0 + ly;
-    bool is_cand = false;
-    float v = 0.f;
-    if (gx < W && gy < H) {
-      v = lam[ly + 1][lx + 1];
-      bool masked_in = !((rowmask[ly] >> lx) & 1ull);
-      if (M && M[(size_t)gy * W + gx] == 0) masked_in = false;
-      if (masked_in) {
-        bestkey = max(bestkey, fkey(v));
-        if (v != 0.0f && gx >= 1 && gx < W - 1 && gy >= 1 && gy < H - 1) {
-          float m = v;
-#pragma unroll
-          for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 3; dx++) m = fmaxf(m, lam[ly + dy][lx + dx]);
-          is_cand = (v == m);
+    // ---- row m = r-3: 3x3 local maximum (rows m-1, m, m+1 = slots Y, X, Z) ----------------------
+    const int m = r - 3;
+    if (m >= lm0 && m <= lm1) {
+      const float v = X.lam;
+      bool is_cand = out_col & (gx >= 1) & (gx < W - 1) & (v != 0.0f) &
+                     !((rowmask[m - ys] >> lane) & 1ull) & (v == fmaxf(fmaxf(Y.hm, X.hm), Z.hm));
+      if (HAS_MASK) is_cand &= mcol[(unsigned)(m * W)] != 0;
+      const unsigned long long bal = __ballot(is_cand);
+      if (bal) {
+        if (is_cand) {
+          const int pos = n_loc + __popcll(bal & ((1ull << lane) - 1ull));
+          lcand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(m * W + gx);
+        }
+        n_loc += __popcll(bal);
+        if (n_loc > ME_LCAP - 64) {
+          __syncthreads();
+          flush();
+          __syncthreads();
         }
       }
     }
-    const unsigned long long bal = __ballot(is_cand);
-    if (bal) {
-      const int lane = tid & 63;
-      const int leader = __ffsll((long long)bal) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&blk_n, __popcll(bal));
-      base = __shfl(base, leader);
-      if (is_cand) {
-        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (pos < LCAP)
-          lcand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(gy * W + gx);
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) bestkey = max(bestkey, (unsigned)__shfl_xor((int)bestkey, off));
-  if ((tid & 63) == 0 && bestkey) atomicMax(&blk_key, bestkey);
-  __syncthreads();
-  const int nloc = min(blk_n, LCAP);
-  if (tid == 0) {
-    blk_base = nloc > 0 ? atomicAdd(&cand_count[s], nloc) : 0;
-    // masked maximum: one global atomic per block, skipped when it cannot raise the maximum
-    if (blk_key && blk_key > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(&maxkey[s], blk_key);
+  };
+
+  MeRow S0, S1, S2;
+  S0 = S1 = S2 = MeRow{0.f, 0.f, 0., 0., 0., 0.f, 0.f};
+  // slots rotate with the row index: slot(r) = (r - r_first) % 3
+  for (int r = r_first; r <= r_last; r += 3) {
+    step(r, S0, S2, S1);
+    if (r + 1 <= r_last) step(r + 1, S1, S0, S2);
+    if (r + 2 <= r_last) step(r + 2, S2, S1, S0);
   }
   __syncthreads();
-  for (int i = tid; i < nloc; i += 256) {
-    const int pos = blk_base + i;
-    if (pos < ccap) cand_all[(size_t)s * ccap + pos] = lcand[i];
-  }
+  flush();
+  for (int off = 32; off > 0; off >>= 1) bestv = fmaxf(bestv, __shfl_xor(bestv, off));
+  const unsigned bestkey = bestv == -__builtin_inff() ? 0u : fkey(bestv);
+  // masked maximum: one global atomic per wave, skipped when it cannot raise the maximum
+  if (lane == 0 && bestkey &&
+      bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&maxkey[s], bestkey);
 }
 
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
@@ -267,10 +246,17 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
   hipMemsetAsync(D.cand_count, 0, sizeof(int) * P.B, st);
   hipMemsetAsync(D.maxkey, 0, sizeof(unsigned) * P.B, st);
-  dim3 grid((P.W + TW - 1) / TW, (P.H + TH - 1) / TH, P.B);
-  hipLaunchKernelGGL(mineig_localmax_kernel, grid, dim3(256), 0, st, img, row_stride, img_stride,
-                     user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp,
-                     k.count, use_discs, S.flags, D.cand, D.cand_count, D.maxkey);
+  dim3 grid((P.W + ME_COLS - 1) / ME_COLS, (P.H + ME_ROWS - 1) / ME_ROWS, P.B);
+  if (user_mask)
+    hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
+                       img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
+                       T.circle_hw, k.kp, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                       D.maxkey);
+  else
+    hipLaunchKernelGGL(mineig_localmax_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
+                       img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
+                       T.circle_hw, k.kp, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                       D.maxkey);
 }
 
 // =============================================================================================
