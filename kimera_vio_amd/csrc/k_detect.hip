@@ -14,6 +14,8 @@
 // tracked keypoints" is evaluated analytically from the keypoint list (exact cv::circle spans).
 #include "kvfe_dev.hpp"
 
+#include <utility>
+
 namespace kvfe {
 
 // order-preserving float -> uint key (handles negative values), 0 is reserved for "none"
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
                                                        int fixed_need) {
   const int s = blockIdx.x;
   if (!(S.flags[s] & FLAG_DETECT)) return;
-  extern __shared__ unsigned char lds_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // LDS carve-up: sortkeys [LDS_SORT_CAP] u64 | cell_start [MAX_CELLS+1] int | small
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(lds_raw);
   int* cell_start = reinterpret_cast<int*>(lds_raw + sizeof(unsigned long long) * LDS_SORT_CAP);
@@ -637,16 +639,12 @@ __global__ __launch_bounds__(64) void subpix_append_kernel(KParams P, Tables T,
   if (!(S.flags[s] & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
   if (ci >= n_new) return;
-  extern __shared__ unsigned char lds_raw[];
-  const int ww = 2 * P.subpix_win + 1, pw = ww + 2;
-  double* terms = reinterpret_cast<double*>(lds_raw);
-  float* patch = reinterpret_cast<float*>(lds_raw + sizeof(double) * 5 * ww * ww);
-  (void)pw;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x;
   float2 c = D.newc[(size_t)s * P.acap + ci];
   if (P.subpix_enable) {
     c = corner_subpix_wave(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
-                           P.subpix_iters, P.subpix_eps2, T.subpix_mask, patch, terms, lane);
+                           P.subpix_iters, P.subpix_eps2, T.subpix_mask, lds_raw, lane);
   }
   if (lane == 0) {
     if (append) {
@@ -680,8 +678,7 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
                           hipStream_t st) {
-  const int ww = 2 * P.subpix_win + 1;
-  const size_t lds = sizeof(double) * 5 * ww * ww + sizeof(float) * (ww + 2) * (ww + 2);
+  const size_t lds = subpix_geom(P.subpix_win).bytes;
   int bound = P.max_corners > 0 ? P.max_corners : P.acap;
   if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
     bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
@@ -699,12 +696,9 @@ __global__ __launch_bounds__(64) void subpix_points_kernel(const float* __restri
                                                            int max_iters, double eps2) {
   const int ci = blockIdx.x;
   if (ci >= n) return;
-  extern __shared__ unsigned char lds_raw[];
-  const int ww = 2 * win + 1;
-  double* terms = reinterpret_cast<double*>(lds_raw);
-  float* patch = reinterpret_cast<float*>(lds_raw + sizeof(double) * 5 * ww * ww);
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const float2 c = corner_subpix_wave(img, row_stride, W, H, pts[ci], win, max_iters, eps2, mask,
-                                      patch, terms, threadIdx.x);
+                                      lds_raw, threadIdx.x);
   if (threadIdx.x == 0) pts[ci] = c;
 }
 
@@ -712,8 +706,7 @@ void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigne
                           size_t row_stride, int W, int H, float2* pts, int n, int win,
                           int max_iters, double eps2, hipStream_t st) {
   if (n <= 0) return;
-  const int ww = 2 * win + 1;
-  const size_t lds = sizeof(double) * 5 * ww * ww + sizeof(float) * (ww + 2) * (ww + 2);
+  const size_t lds = subpix_geom(win).bytes;
   hipLaunchKernelGGL(subpix_points_kernel, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
                      W, H, pts, n, win, max_iters, eps2);
 }

@@ -12,18 +12,39 @@
 // by wave shuffles returns the first minimum, as cv::minMaxLoc does.
 #include "kvfe_dev.hpp"
 
+#include <utility>
+
 namespace kvfe {
 
 #include "kvfe_undistort.inl"
 
 #include "kvfe_subpix.inl"
 
+// keypoint range of a stereo launch: all keypoints of the frame, only the tracked ones (known as
+// soon as tracking is done, so their matching overlaps corner refinement on another HIP stream),
+// or only the newly detected ones
+enum : int { STEREO_ALL = 0, STEREO_TRACKED = 1, STEREO_NEW = 2 };
+__device__ __forceinline__ bool stereo_range(const FrameTab& K, const StreamState& S, int s, int mode,
+                                             int idx, int* i) {
+  const int nt = S.n_tracked[s];
+  if (mode == STEREO_TRACKED) {
+    *i = idx;
+    return idx < nt;
+  }
+  if (mode == STEREO_NEW) {
+    *i = nt + idx;
+    return *i < K.count[s];
+  }
+  *i = idx;
+  return idx < K.count[s];
+}
+
 __global__ void stereo_left_kernel(KParams P, Tables T, FrameTab K, StereoTab ST, StreamState S,
-                                   int act_flag) {
+                                   int act_flag, int mode) {
   const int s = blockIdx.y;
   if (!(S.flags[s] & act_flag)) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K.count[s]) return;
+  int i;
+  if (!stereo_range(K, S, s, mode, blockIdx.x * blockDim.x + threadIdx.x, &i)) return;
   const size_t o = (size_t)s * P.kcap + i;
   const float2 d = K.kp[o];
   float ux, uy;
@@ -79,6 +100,10 @@ __host__ __device__ inline StereoGeom stereo_geom(const KParams& P) {
 }
 
 // core of searchRightKeypointEpipolar for one keypoint, executed by one wavefront
+// SUBPIX = StereoMatchingParams::subpixel_refinement_ (off in every shipped parameter set): the
+// refinement code is compiled only into the <true> instantiation so that the common kernel keeps a
+// small register footprint.
+template <bool SUBPIX>
 __device__ void match_one(const KParams& P, const Tables& T, const unsigned char* __restrict__ L,
                           const unsigned char* __restrict__ R, float2 lkp, unsigned char* lds,
                           int lane, float2* out_kp, int* out_status, double* out_score) {
@@ -279,11 +304,9 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int mx = bx + stripe_corner_x + (tc - 1) / 2 + offset_temp;
   const int my = by + stripe_corner_y + (tr - 1) / 2;
   float2 match = make_float2((float)mx, (float)my);
-  if (P.stereo_subpix) {  // cv::cornerSubPix(right_rectified, (10,10), (-1,-1), 40 it, 0.001)
-    double* terms = reinterpret_cast<double*>(lds + G.match_bytes);
-    float* patch = reinterpret_cast<float*>(terms + 5 * 21 * 21);
+  if (SUBPIX) {  // cv::cornerSubPix(right_rectified, (10,10), (-1,-1), 40 it, 0.001)
     match = corner_subpix_wave(R, (size_t)W, W, H, match, 10, 40, 0.001 * 0.001, T.subpix_mask10,
-                               patch, terms, lane);
+                               lds + G.match_bytes, lane);
   }
   const double min_val = 0.0;  // normalised minimum (cv::normalize MINMAX) is always 0
   *out_score = min_val;
@@ -291,14 +314,16 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   *out_kp = match;
 }
 
+template <bool SUBPIX>
 __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
                                                           const unsigned char* __restrict__ Lr,
                                                           const unsigned char* __restrict__ Rr,
                                                           FrameTab K, StereoTab ST, StreamState S,
-                                                          int act_flag) {
-  const int s = blockIdx.y, i = blockIdx.x;
+                                                          int act_flag, int mode) {
+  const int s = blockIdx.y;
   if (!(S.flags[s] & act_flag)) return;
-  if (i >= K.count[s]) return;
+  int i;
+  if (!stereo_range(K, S, s, mode, blockIdx.x, &i)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x;
   const size_t o = (size_t)s * P.kcap + i;
@@ -309,7 +334,7 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
   float2 rkp = make_float2(0.f, 0.f);
   int rstatus = lstatus;
   double score = -1.0;
-  if (lstatus == 0) match_one(P, T, L, R, lkp, lds_raw, lane, &rkp, &rstatus, &score);
+  if (lstatus == 0) match_one<SUBPIX>(P, T, L, R, lkp, lds_raw, lane, &rkp, &rstatus, &score);
   if (lane != 0) return;
   // getDepthFromRectifiedMatches (StereoMatcher.cpp:425-483)
   double depth = 0.0;
@@ -352,20 +377,25 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
 
 static size_t stereo_lds_bytes(const KParams& P) {
   size_t b = stereo_geom(P).match_bytes;
-  if (P.stereo_subpix) b += sizeof(double) * 5 * 21 * 21 + sizeof(float) * 23 * 23;
+  if (P.stereo_subpix) b += subpix_geom(10).bytes;
   return b;
 }
 
 void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_rect,
                    const unsigned char* right_rect, const FrameTab& k, const StereoTab& ST,
-                   const StreamState& S, int act_flag, int max_kp, hipStream_t st) {
+                   const StreamState& S, int act_flag, int max_kp, int mode, hipStream_t st) {
   const int nb = max_kp > 0 ? (max_kp < P.kcap ? max_kp : P.kcap) : P.kcap;
   hipLaunchKernelGGL(stereo_left_kernel, dim3((nb + 63) / 64, P.B), dim3(64), 0, st, P, T, k,
-                     ST, S, act_flag);
-  hipLaunchKernelGGL(stereo_match_kernel, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st, P,
-                     T, left_rect, right_rect, k, ST, S, act_flag);
+                     ST, S, act_flag, mode);
+  if (P.stereo_subpix)
+    hipLaunchKernelGGL(stereo_match_kernel<true>, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st,
+                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode);
+  else
+    hipLaunchKernelGGL(stereo_match_kernel<false>, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st,
+                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode);
 }
 
+template <bool SUBPIX>
 __global__ __launch_bounds__(64) void stereo_match_only_kernel(
     KParams P, Tables T, const unsigned char* __restrict__ L, const unsigned char* __restrict__ R,
     const float2* __restrict__ lkps, const unsigned char* __restrict__ lstat, int n,
@@ -376,7 +406,8 @@ __global__ __launch_bounds__(64) void stereo_match_only_kernel(
   float2 rkp = make_float2(0.f, 0.f);
   int rstatus = lstat[i];
   double score = -1.0;
-  if (rstatus == 0) match_one(P, T, L, R, lkps[i], lds_raw, threadIdx.x, &rkp, &rstatus, &score);
+  if (rstatus == 0)
+    match_one<SUBPIX>(P, T, L, R, lkps[i], lds_raw, threadIdx.x, &rkp, &rstatus, &score);
   if (threadIdx.x == 0) {
     rkps[i] = rkp;
     rstat[i] = (unsigned char)rstatus;
@@ -389,9 +420,14 @@ void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned 
                               const unsigned char* left_status, int n, float2* right_rect_kp,
                               unsigned char* right_status, double* score, hipStream_t st) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(stereo_match_only_kernel, dim3(n), dim3(64), stereo_lds_bytes(P), st, P, T,
-                     left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
-                     right_status, score);
+  if (P.stereo_subpix)
+    hipLaunchKernelGGL(stereo_match_only_kernel<true>, dim3(n), dim3(64), stereo_lds_bytes(P), st, P,
+                       T, left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
+                       right_status, score);
+  else
+    hipLaunchKernelGGL(stereo_match_only_kernel<false>, dim3(n), dim3(64), stereo_lds_bytes(P), st, P,
+                       T, left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
+                       right_status, score);
 }
 
 // ---------------------------------------------------------------------------------------------

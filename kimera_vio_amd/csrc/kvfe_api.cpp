@@ -34,12 +34,13 @@ enum Stage {
   ST_SUBPIX,
   ST_RECTIFY,
   ST_STEREO,
+  ST_STEREO_NEW,
   ST_FINALIZE,
   ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "mineig_localmax",
                                      "gftt_select", "subpix_append", "rectify", "stereo_match",
-                                     "step_finalize"};
+                                     "stereo_match_new", "step_finalize"};
 
 struct Buffers {  // everything that scales with the number of streams
   int B = 0;
@@ -91,7 +92,11 @@ struct kvfe_ctx {
   std::vector<float> h_map[2][2];  // host copies of the maps [cam][x|y]
   // profiling
   bool prof_on = false;
-  std::vector<hipEvent_t> prof_ev;  // (ST_COUNT + 1) events per recorded step
+  std::vector<hipEvent_t> prof_ev;  // 2 * ST_COUNT (begin, end) events per recorded step
+  // corner refinement runs on a side stream, concurrently with rectification and the stereo
+  // matching of the tracked keypoints (its result is only needed by the newly detected ones)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
   int prof_samples = 0;
@@ -481,9 +486,13 @@ kvfe_status upload_image(kvfe_ctx* c, unsigned char* dst, const uint8_t* src, si
   return KVFE_OK;
 }
 
-void prof_mark(kvfe_ctx* c, int idx) {
+void prof_begin(kvfe_ctx* c, int stage, hipStream_t st) {
   if (!c->prof_on) return;
-  hipEventRecord(c->prof_ev[c->prof_ev.size() - (ST_COUNT + 1) + idx], c->stream);
+  hipEventRecord(c->prof_ev[c->prof_ev.size() - 2 * ST_COUNT + 2 * stage], st);
+}
+void prof_end(kvfe_ctx* c, int stage, hipStream_t st) {
+  if (!c->prof_on) return;
+  hipEventRecord(c->prof_ev[c->prof_ev.size() - 2 * ST_COUNT + 2 * stage + 1], st);
 }
 
 void prof_collect(kvfe_ctx* c) {
@@ -491,7 +500,7 @@ void prof_collect(kvfe_ctx* c) {
   for (int base : c->prof_pending) {
     for (int s = 0; s < ST_COUNT; s++) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->prof_ev[base + s], c->prof_ev[base + s + 1]) == hipSuccess)
+      if (hipEventElapsedTime(&ms, c->prof_ev[base + 2 * s], c->prof_ev[base + 2 * s + 1]) == hipSuccess)
         c->prof_ms[s] += ms;
     }
     c->prof_samples++;
@@ -527,7 +536,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
 
   if (c->prof_on) {
     const int base = (int)c->prof_ev.size();
-    for (int i = 0; i <= ST_COUNT; i++) {
+    for (int i = 0; i < 2 * ST_COUNT; i++) {
       hipEvent_t e;
       HIPCHK(c, hipEventCreate(&e));
       c->prof_ev.push_back(e);
@@ -538,34 +547,54 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   const FrameTab& KM1 = b.ft[c->role_km1];
   const FrameTab& LKF = b.ft[c->role_lkf];
   const int pc = c->pyr_cur, pp = pc ^ 1;
+  hipStream_t sd = c->side ? c->side : st;
 
-  prof_mark(c, ST_PYRAMID);
+  prof_begin(c, ST_PYRAMID, st);
   launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st);
-  prof_mark(c, ST_TRACK);
+  prof_end(c, ST_PYRAMID, st);
+  prof_begin(c, ST_TRACK, st);
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
   if (c->prev_left)
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
               img_stride, b.pyr[pc], b.lk, c->pts_bound, st);
-  prof_mark(c, ST_TRACK_FINALIZE);
+  prof_end(c, ST_TRACK, st);
+  prof_begin(c, ST_TRACK_FINALIZE, st);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
+  prof_end(c, ST_TRACK_FINALIZE, st);
   if (c->ev_tracked) {
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
     c->ev_tracked_valid = true;
   }
-  prof_mark(c, ST_MINEIG);
+  prof_begin(c, ST_MINEIG, st);
   launch_mineig(P, c->T, left, row_stride, img_stride, nullptr, K, b.ss, b.ds, 1, st);
-  prof_mark(c, ST_SELECT);
+  prof_end(c, ST_MINEIG, st);
+  prof_begin(c, ST_SELECT, st);
   launch_select(P, c->T, K, b.ss, b.ds, -1, st);
-  prof_mark(c, ST_SUBPIX);
-  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, st);
-  prof_mark(c, ST_RECTIFY);
+  prof_end(c, ST_SELECT, st);
+  // fork: cornerSubPix + append of the new corners (side stream) || rectify + stereo matching of
+  // the tracked keypoints (main stream); join before the new keypoints are matched
+  if (c->side) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
+  }
+  prof_begin(c, ST_SUBPIX, sd);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, sd);
+  prof_end(c, ST_SUBPIX, sd);
+  if (c->side) HIPCHK(c, hipEventRecord(c->ev_join, sd));
+  prof_begin(c, ST_RECTIFY, st);
   const unsigned char* srcs[2] = {left, right};
   launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st);
-  prof_mark(c, ST_STEREO);
-  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, st);
-  prof_mark(c, ST_FINALIZE);
+  prof_end(c, ST_RECTIFY, st);
+  prof_begin(c, ST_STEREO, st);
+  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, st);
+  prof_end(c, ST_STEREO, st);
+  if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  prof_begin(c, ST_STEREO_NEW, st);
+  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, st);
+  prof_end(c, ST_STEREO_NEW, st);
+  prof_begin(c, ST_FINALIZE, st);
   launch_step_finalize(P, K, LKF, b.st, b.ss, st);
-  prof_mark(c, ST_COUNT);
+  prof_end(c, ST_FINALIZE, st);
   HIPCHK(c, hipGetLastError());
 
   // stereoFrame_km1_ = stereoFrame_k_
@@ -726,6 +755,13 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
   if (s == KVFE_OK && parent &&
       hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess)
     s = KVFE_ERR_HIP;
+  static const bool no_side = std::getenv("KVFE_NO_SIDE_STREAM") != nullptr;
+  if (s == KVFE_OK && alloc_frontend && !no_side) {
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+      s = KVFE_ERR_HIP;
+  }
   if (s != KVFE_OK) {
     std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
     kvfe_destroy(c);
@@ -796,6 +832,12 @@ void kvfe_destroy(kvfe_ctx* c) {
   for (int i = 0; i < kvfe_ctx::RING; i++)
     if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
   if (c->ev_tracked) hipEventDestroy(c->ev_tracked);
+  if (c->side) {
+    hipStreamSynchronize(c->side);
+    hipStreamDestroy(c->side);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->host_allocs) hipHostFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1040,7 +1082,7 @@ kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_i
   }
   const unsigned char* srcs[2] = {b.raw_left[0], b.raw_right};
   launch_rectify(P, c->T, srcs, P.W, N, b.rect, nullptr, 0, st);
-  if (n > 0) launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, n, st);
+  if (n > 0) launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, n, 0, st);
 #define DL(dst, src, bytes) \
   if (dst) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st))
   if (n > 0) {

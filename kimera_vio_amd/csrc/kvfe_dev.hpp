@@ -191,7 +191,8 @@ void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigne
 // K7 + K5: rectify left keypoints, epipolar SSD, depth, right keypoints, 3D
 void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_rect,
                    const unsigned char* right_rect, const FrameTab& k, const StereoTab& ST,
-                   const StreamState& S, int act_flag, int max_kp, hipStream_t st);
+                   const StreamState& S, int act_flag, int max_kp, int mode /* 0 all, 1 tracked,
+                   2 newly detected */, hipStream_t st);
 // StereoMatcher::getRightKeypointsRectified only (component API): left_rect/status given
 void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned char* left_rect,
                               const unsigned char* right_rect, const float2* left_rect_kp,

@@ -82,38 +82,210 @@ static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, 
   }
 }
 
+// LDS carve-up of corner_subpix_wave (bytes), shared by the kernels and their launchers
+struct SubpixGeom {
+  int ww, pw, nt, ntp, rs;
+  size_t terms_off, patch_off, stage_off, bytes;
+};
+__host__ __device__ inline SubpixGeom subpix_geom(int win) {
+  SubpixGeom g;
+  g.ww = 2 * win + 1;
+  g.pw = g.ww + 2;
+  g.nt = g.ww * g.ww;
+  g.ntp = (g.nt + 31) & ~31;          // chains are walked in batches of 32, zero padded
+  g.rs = g.pw + 1 + 2 * 6;            // staged source side: bilinear footprint + 6 px margin
+  g.terms_off = 0;
+  g.patch_off = sizeof(double) * 5 * (size_t)g.ntp;
+  g.stage_off = g.patch_off + sizeof(float) * (size_t)g.pw * g.pw;
+  g.bytes = (g.stage_off + (size_t)g.rs * g.rs + 15) & ~(size_t)15;
+  return g;
+}
+
+// interior branch of cv::getRectSubPix reading the source from the LDS stage (row stride rs);
+// eij[t] = (i << 8) | j of this lane's patch entries e = lane + 64 t (fixed per corner)
+template <int MAXP>
+static __device__ __forceinline__ void rect_subpix_from_stage(const unsigned char* stage, int rs,
+                                                              int dx0, int dy0, float ccx, float ccy,
+                                                              int ipx, int ipy, int n,
+                                                              const int (&eij)[MAXP], float* dst,
+                                                              int lane) {
+  float a = ccx - ipx;
+  const float b = ccy - ipy;
+  a = fmaxf(a, 0.0001f);
+  const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+  const double sc = (1. - a) / a;
+  const unsigned char* S = stage + dy0 * rs + dx0;
+#pragma unroll
+  for (int t = 0; t < MAXP; t++) {
+    const int e = lane + 64 * t;
+    if (e < n * n) {
+      const int i = eij[t] >> 8, j = eij[t] & 255;
+      const unsigned char* R = S + i * rs;
+      // j == 0: prev = (1-a) * (b1*R[0] + b2*R[rs]); else prev = (float)((a12*R[j] + a22*R[j+rs]) * sc)
+      const float r0 = (float)R[j], r1 = (float)R[j + rs];
+      const float first = (1 - a) * (b1 * r0 + b2 * r1);
+      const float tp = a12 * r0 + a22 * r1;
+      const float prev = j == 0 ? first : (float)(tp * sc);
+      const float tt = a12 * R[j + 1] + a22 * R[j + 1 + rs];
+      dst[e] = prev + tt;
+    }
+  }
+}
+
 // refines one corner; all 64 lanes of the wave call it with identical arguments.
-// LDS: patch (2w+3)^2 floats, terms 5*(2w+1)^2 doubles.
-static __device__ float2 corner_subpix_wave(const unsigned char* __restrict__ img, size_t step, int W,
-                                     int H, float2 cT, int win, int max_iters, double eps2,
-                                     const float* __restrict__ mask, float* patch, double* terms,
-                                     int lane) {
-  const int ww = 2 * win + 1, pw = ww + 2, nt = ww * ww;
+// LDS (subpix_geom): terms 5 x ntp float64 | patch (2w+3)^2 float | stage rs^2 bytes.
+// Latency matters here (40 strictly sequential iterations for a corner that does not converge):
+// the u8 neighbourhood is staged in LDS once and re-used while the corner stays inside it, the
+// Gaussian mask weights and window coordinates live in registers, and the five float64 chains
+// are walked by lanes 0-4 with the LDS reads of the next batch in flight.
+// Sequential float64 sum of NV2 double2 values in LDS, in index order (one chain per lane).
+// A dependent v_add_f64 issues every ~6 cycles once its operand is in a register, but an LDS read
+// takes ~100 cycles; hipcc keeps only three reads ahead of the adds.  Here 15 ds_read_b128 stay in
+// flight (the lgkmcnt limit) in a 16-slot register ring; the waits are explicit, tied to the slot
+// register so that the consuming add cannot be scheduled above its wait.
+typedef double kvfe_d2 __attribute__((ext_vector_type(2)));
+template <int IDX>
+static __device__ __forceinline__ void lds_chain_read(kvfe_d2 (&ring)[16], unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[IDX % 16]) : "v"(addr), "n"(IDX * 16));
+}
+template <int NV2, int I>
+static __device__ __forceinline__ void lds_chain_step(kvfe_d2 (&ring)[16], unsigned addr, double& acc) {
+  constexpr int kAhead = NV2 - 1 - I < 14 ? NV2 - 1 - I : 14;  // reads issued after read I
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[I % 16]) : "n"(kAhead));
+  acc += ring[I % 16].x;
+  acc += ring[I % 16].y;
+  if constexpr (I + 15 < NV2) lds_chain_read<I + 15>(ring, addr);
+}
+template <int NV2, int... Is>
+static __device__ __forceinline__ void lds_chain_prologue(kvfe_d2 (&ring)[16], unsigned addr,
+                                                          std::integer_sequence<int, Is...>) {
+  (lds_chain_read<Is>(ring, addr), ...);
+}
+template <int NV2, int... Is>
+static __device__ __forceinline__ void lds_chain_body(kvfe_d2 (&ring)[16], unsigned addr, double& acc,
+                                                      std::integer_sequence<int, Is...>) {
+  (lds_chain_step<NV2, Is>(ring, addr, acc), ...);
+}
+template <int NV2>
+static __device__ __forceinline__ double lds_chain_sum(const double* base_lds) {
+  static_assert(NV2 >= 16, "ring deeper than the chain");
+  const unsigned addr = (unsigned)(size_t)base_lds;  // LDS byte address (low 32 bits of the pointer)
+  kvfe_d2 ring[16];
+  lds_chain_prologue<NV2>(ring, addr, std::make_integer_sequence<int, 15>{});
+  double acc = 0;
+  lds_chain_body<NV2>(ring, addr, acc, std::make_integer_sequence<int, NV2>{});
+  return acc;
+}
+
+// WIN > 0: window half size fixed at compile time (all loops unroll, divisions fold); WIN == 0:
+// any half size up to 15 at run time.
+template <int WIN>
+static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ img, size_t step, int W,
+                                       int H, float2 cT, int win_rt, int max_iters, double eps2,
+                                       const float* __restrict__ mask, unsigned char* lds, int lane) {
+  const int win = WIN > 0 ? WIN : win_rt;
+  const SubpixGeom G = subpix_geom(win);
+  const int ww = G.ww, pw = G.pw, nt = G.nt, ntp = G.ntp, rs = G.rs;
+  constexpr int MAXT = WIN > 0 ? ((2 * WIN + 1) * (2 * WIN + 1) + 63) / 64 : 16;
+  constexpr int MAXP = WIN > 0 ? ((2 * WIN + 3) * (2 * WIN + 3) + 63) / 64 : 18;
+  double* terms = reinterpret_cast<double*>(lds + G.terms_off);
+  float* patch = reinterpret_cast<float*>(lds + G.patch_off);
+  unsigned char* stage = lds + G.stage_off;
+  // per-lane term slots k = lane + 64 t: mask weight and window coordinates (fixed per corner)
+  float mk[MAXT];
+  int pij[MAXT];            // (i << 8) | j
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) {
+    const int k = lane + 64 * t;
+    mk[t] = 0.f;
+    pij[t] = 0;
+    if (k < nt) {
+      const int i = k / ww, j = k - i * ww;
+      mk[t] = mask[k];
+      pij[t] = (i << 8) | j;
+    }
+  }
+  int eij[MAXP];            // patch entries e = lane + 64 t of the (2w+3)^2 window
+#pragma unroll
+  for (int t = 0; t < MAXP; t++) {
+    const int e = lane + 64 * t;
+    const int i = e / pw;
+    eij[t] = (i << 8) | (e - i * pw);
+  }
+  for (int k = nt + lane; k < ntp; k += 64)
+    for (int q = 0; q < 5; q++) terms[q * ntp + k] = 0.0;
+  int sx0 = 0, sy0 = 0;
+  bool staged = false;
   float2 cI = cT;
   int iter = 0;
   double err = 0;
   do {
-    rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane);
-    __syncthreads();
-    for (int k = lane; k < nt; k += 64) {
-      const int i = k / ww, j = k - i * ww;
-      const float* sp = patch + (i + 1) * pw + (j + 1);
-      const double m = (double)mask[k];
-      const double tgx = (double)(sp[1] - sp[-1]);
-      const double tgy = (double)(sp[pw] - sp[-pw]);
-      const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-      const double px = (double)(j - win), py = (double)(i - win);
-      terms[k] = gxx;
-      terms[nt + k] = gxy;
-      terms[2 * nt + k] = gyy;
-      terms[3 * nt + k] = gxx * px + gxy * py;
-      terms[4 * nt + k] = gxy * px + gyy * py;
+    {
+      const float ccx = cI.x - (pw - 1) * 0.5f, ccy = cI.y - (pw - 1) * 0.5f;
+      const int ipx = cv_floorf(ccx), ipy = cv_floorf(ccy);
+      const bool interior = 0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H;
+      bool use_stage = false;
+      if (interior) {
+        // footprint: columns ipx .. ipx+pw, rows ipy .. ipy+pw
+        if (!staged || ipx < sx0 || ipy < sy0 || ipx + pw >= sx0 + rs || ipy + pw >= sy0 + rs) {
+          const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
+          if (nx0 >= 0 && ny0 >= 0) {
+            __syncthreads();
+            for (int e = lane; e < rs * rs; e += 64) {
+              const int y = e / rs, x = e - y * rs;
+              stage[e] = img[(size_t)(ny0 + y) * step + nx0 + x];
+            }
+            __syncthreads();
+            sx0 = nx0;
+            sy0 = ny0;
+            staged = true;
+          } else {
+            staged = false;
+          }
+        }
+        use_stage = staged && ipx >= sx0 && ipy >= sy0 && ipx + pw < sx0 + rs && ipy + pw < sy0 + rs;
+      }
+      if (use_stage)
+        rect_subpix_from_stage<MAXP>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
+      else
+        rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane);
     }
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+      const int k = lane + 64 * t;
+      if (k < nt) {
+        const int i = pij[t] >> 8, j = pij[t] & 255;
+        const float* sp = patch + (i + 1) * pw + (j + 1);
+        const double m = (double)mk[t];
+        const double tgx = (double)(sp[1] - sp[-1]);
+        const double tgy = (double)(sp[pw] - sp[-pw]);
+        const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+        const double px = (double)(j - win), py = (double)(i - win);
+        terms[k] = gxx;
+        terms[ntp + k] = gxy;
+        terms[2 * ntp + k] = gyy;
+        terms[3 * ntp + k] = gxx * px + gxy * py;
+        terms[4 * ntp + k] = gxy * px + gyy * py;
+      }
+    }
+    __syncthreads();
+    // the five sequential float64 chains (lanes 0-4): a dependent v_add_f64 issues every ~6 cycles
+    // as long as its operand has landed, so the loop only has to keep LDS reads ahead of the adds
     double acc = 0;
     if (lane < 5) {
-      const double* t = terms + lane * nt;
-      for (int k = 0; k < nt; k++) acc += t[k];
+      const double2* t2 = reinterpret_cast<const double2*>(terms + lane * ntp);
+      if (WIN > 0) {
+        constexpr int NTP = (((2 * WIN + 1) * (2 * WIN + 1) + 31) & ~31);
+        acc = lds_chain_sum<(WIN > 0 ? NTP / 2 : 16)>(terms + lane * ntp);
+      } else {
+#pragma unroll 16
+        for (int k2 = 0; k2 < ntp / 2; k2++) {
+          const double2 v = t2[k2];
+          acc += v.x;
+          acc += v.y;
+        }
+      }
     }
     const double a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2), bb1 = __shfl(acc, 3),
                  bb2 = __shfl(acc, 4);
@@ -132,3 +304,11 @@ static __device__ float2 corner_subpix_wave(const unsigned char* __restrict__ im
   return cI;
 }
 
+// the reference uses half size 10 everywhere (FeatureDetector.cpp:288-292, StereoMatcher.cpp:406-411)
+static __device__ float2 corner_subpix_wave(const unsigned char* __restrict__ img, size_t step, int W,
+                                     int H, float2 cT, int win, int max_iters, double eps2,
+                                     const float* __restrict__ mask, unsigned char* lds, int lane) {
+  if (win == 10)
+    return corner_subpix_wave_t<10>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
+  return corner_subpix_wave_t<0>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
+}
