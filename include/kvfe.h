@@ -165,10 +165,11 @@ typedef struct kvfe_config {
   int32_t device;                /* HIP device ordinal                       */
   void* hip_stream;              /* optional hipStream_t owned by the caller */
   int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
-  int32_t stream_groups;         /* 0 = automatic.  The batch is split into this many
+  int32_t stream_groups;         /* 0 = default (1).  The batch is split into this many
                                     groups of streams, each on its own HIP stream, so
                                     that latency-bound and throughput-bound kernels of
-                                    different groups overlap (always 1 with hip_stream) */
+                                    different groups can overlap (always 1 with
+                                    hip_stream).  Measured on MI355X: 1 is fastest    */
 } kvfe_config;
 
 typedef struct kvfe_ctx kvfe_ctx;

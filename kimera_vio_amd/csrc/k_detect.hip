@@ -246,8 +246,7 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
-  hipMemsetAsync(D.cand_count, 0, sizeof(int) * P.B, st);
-  hipMemsetAsync(D.maxkey, 0, sizeof(unsigned) * P.B, st);
+  // D.cand_count / D.maxkey are zero here: allocated zeroed, re-zeroed by every select_kernel
   dim3 grid((P.W + ME_COLS - 1) / ME_COLS, (P.H + ME_ROWS - 1) / ME_ROWS, P.B);
   if (user_mask)
     hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
@@ -338,6 +337,12 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   const float thr = (float)((double)maxVal * P.quality);
   if (tid == 0) sh_cnt = 0;
   __syncthreads();
+  // every thread has read the counters: leave them zeroed for the next mineig launch of this
+  // stream (invariant: cand_count / maxkey are zero between a select and the next mineig)
+  if (tid == 0) {
+    D.cand_count[s] = 0;
+    D.maxkey[s] = 0u;
+  }
   for (int base = 0; base < C; base += SEL_T) {
     const int i = base + tid;
     bool keep = false;
@@ -630,6 +635,7 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
 // cv::undistortPoints of one pixel (double), shared with k_stereo.hip via kvfe_undistort.inl
 #include "kvfe_undistort.inl"
 
+template <int WIN>
 __global__ __launch_bounds__(64) void subpix_append_kernel(KParams P, Tables T,
                                                            const unsigned char* __restrict__ img,
                                                            size_t row_stride, size_t img_stride,
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(64) void subpix_append_kernel(KParams P, Tables T,
   const int lane = threadIdx.x;
   float2 c = D.newc[(size_t)s * P.acap + ci];
   if (P.subpix_enable) {
-    c = corner_subpix_wave(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
+    c = corner_subpix_wave<WIN>(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
                            P.subpix_iters, P.subpix_eps2, T.subpix_mask, lds_raw, lane);
   }
   if (lane == 0) {
@@ -683,12 +689,17 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
     bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
   bound = min(bound, P.acap);
-  hipLaunchKernelGGL(subpix_append_kernel, dim3(bound, P.B), dim3(64), lds, st, P, T, img,
-                     row_stride, img_stride, k, S, D, append);
+  if (P.subpix_win == 10)
+    hipLaunchKernelGGL(subpix_append_kernel<10>, dim3(bound, P.B), dim3(64), lds, st, P, T, img,
+                       row_stride, img_stride, k, S, D, append);
+  else
+    hipLaunchKernelGGL(subpix_append_kernel<0>, dim3(bound, P.B), dim3(64), lds, st, P, T, img,
+                       row_stride, img_stride, k, S, D, append);
   if (append)
     hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D);
 }
 
+template <int WIN>
 __global__ __launch_bounds__(64) void subpix_points_kernel(const float* __restrict__ mask,
                                                            const unsigned char* __restrict__ img,
                                                            size_t row_stride, int W, int H,
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(64) void subpix_points_kernel(const float* __restri
   const int ci = blockIdx.x;
   if (ci >= n) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const float2 c = corner_subpix_wave(img, row_stride, W, H, pts[ci], win, max_iters, eps2, mask,
+  const float2 c = corner_subpix_wave<WIN>(img, row_stride, W, H, pts[ci], win, max_iters, eps2, mask,
                                       lds_raw, threadIdx.x);
   if (threadIdx.x == 0) pts[ci] = c;
 }
@@ -707,8 +718,12 @@ void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigne
                           int max_iters, double eps2, hipStream_t st) {
   if (n <= 0) return;
   const size_t lds = subpix_geom(win).bytes;
-  hipLaunchKernelGGL(subpix_points_kernel, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
-                     W, H, pts, n, win, max_iters, eps2);
+  if (win == 10)
+    hipLaunchKernelGGL(subpix_points_kernel<10>, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
+                       W, H, pts, n, win, max_iters, eps2);
+  else
+    hipLaunchKernelGGL(subpix_points_kernel<0>, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
+                       W, H, pts, n, win, max_iters, eps2);
 }
 
 __global__ void undistort_points_kernel(UndistortDev U, const float2* __restrict__ in, int n,

@@ -8,6 +8,8 @@
 // so a wave touches ~2-3 source rows).  Integer arithmetic only => bit-exact vs the CPU path.
 #include "kvfe_dev.hpp"
 
+#include <cstdlib>
+
 namespace kvfe {
 
 __device__ __forceinline__ int clipi(int x, int b) { return x >= 0 ? (x < b ? x : b - 1) : 0; }
@@ -62,8 +64,43 @@ __global__ __launch_bounds__(256) void rectify_kernel(
     size_t src_row_stride, size_t src_img_stride, unsigned char* __restrict__ dst0,
     unsigned char* __restrict__ dst1, const float2* __restrict__ map0,
     const float2* __restrict__ map1, int W, int H, int B, const int* __restrict__ flags,
-    int act_flag) {
-  const int cam = blockIdx.y, s_begin = blockIdx.z * RECT_SPB;
+    int act_flag, int n_tiles, int gz, int mode) {
+  // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (each with its
+  // own L2), so linear block id L runs on XCD L & 7.  XCD k owns the k-th horizontal band of the
+  // image for ALL streams and both cameras, and walks it tile-major / stream-group-minor: a map
+  // tile comes from HBM once (the other stream groups hit it in this XCD's L2) and the source rows
+  // shared by vertically adjacent tiles are fetched by one L2 only.  (Placement is a speed
+  // assumption, never a correctness one.)
+  const int L = blockIdx.x;
+  int tile, cam, s_begin;
+  if (mode == 3) {  // 3-D grid (tile, camera, stream group)
+    tile = blockIdx.x;
+    cam = blockIdx.y;
+    s_begin = blockIdx.z * RECT_SPB;
+  } else if (mode == 0) {  // plain: tile fastest, then camera, then stream group (XCD-oblivious)
+    const int bt8 = 8 * ((n_tiles + 7) >> 3);
+    tile = L % bt8;
+    const int rem = L / bt8;
+    cam = rem & 1;
+    s_begin = (rem >> 1) * RECT_SPB;
+    if (tile >= n_tiles) return;
+  } else {
+    const int xcd = L & 7, j = L >> 3;
+    const int band0 = (xcd * n_tiles) >> 3, band1 = ((xcd + 1) * n_tiles) >> 3;
+    const int band_tiles = (n_tiles + 7) >> 3;
+    int rem;
+    if (mode == 1) {  // tile-major, stream-group-minor
+      const int per_tile = 2 * gz;
+      tile = band0 + j / per_tile;
+      rem = j % per_tile;
+    } else {          // stream-group-major, tile-minor
+      tile = band0 + j % band_tiles;
+      rem = j / band_tiles;
+    }
+    if (tile >= band1) return;
+    cam = rem / gz;
+    s_begin = (rem - cam * gz) * RECT_SPB;
+  }
   const int s_end = min(B, s_begin + RECT_SPB);
   const unsigned char* src = cam == 0 ? src0 : src1;
   unsigned char* dst = cam == 0 ? dst0 : dst1;
@@ -71,7 +108,7 @@ __global__ __launch_bounds__(256) void rectify_kernel(
   const int N = W * H;
   const int stride = (int)src_row_stride;
   if (VEC4) {
-    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int i = (tile * 256 + threadIdx.x) * 4;
     if (i >= N) return;
     const float4 m01 = *reinterpret_cast<const float4*>(map + i);
     const float4 m23 = *reinterpret_cast<const float4*>(map + i + 2);
@@ -113,14 +150,22 @@ __global__ __launch_bounds__(256) void rectify_kernel(
                                              false) >> 15;
         return (unsigned)r & 0xffu;  // weights sum to 2^15: already within 0..255 (see remap_apply)
       };
-      for (int s = s_begin; s < s_end; s++) {
-        if (flags && !(flags[s] & act_flag)) continue;
-        const unsigned char* S = src + (size_t)s * src_img_stride;
-        uint2 u, v;
-        __builtin_memcpy(&u, S + off0, 8);
-        __builtin_memcpy(&v, S + off1, 8);
-        const unsigned p0 = blend(u, v, e0, a0, b0), p1 = blend(u, v, e1, a1, b1),
-                       p2 = blend(u, v, e2, a2, b2), p3 = blend(u, v, e3, a3, b3);
+      // all RECT_SPB streams' source words are requested before the first one is used (the loop
+      // is otherwise one exposed memory latency per stream); out-of-range streams re-read the
+      // last one and are not stored
+      uint2 u[RECT_SPB], v[RECT_SPB];
+#pragma unroll
+      for (int k = 0; k < RECT_SPB; k++) {
+        const unsigned char* S = src + (size_t)min(s_begin + k, B - 1) * src_img_stride;
+        __builtin_memcpy(&u[k], S + off0, 8);
+        __builtin_memcpy(&v[k], S + off1, 8);
+      }
+#pragma unroll
+      for (int k = 0; k < RECT_SPB; k++) {
+        const int s = s_begin + k;
+        if (s >= s_end || (flags && !(flags[s] & act_flag))) continue;
+        const unsigned p0 = blend(u[k], v[k], e0, a0, b0), p1 = blend(u[k], v[k], e1, a1, b1),
+                       p2 = blend(u[k], v[k], e2, a2, b2), p3 = blend(u[k], v[k], e3, a3, b3);
         *reinterpret_cast<unsigned*>(dst + (size_t)s * N + i) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
       }
     } else {
@@ -133,7 +178,7 @@ __global__ __launch_bounds__(256) void rectify_kernel(
       }
     }
   } else {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = tile * 256 + threadIdx.x;
     if (i >= N) return;
     const float2 m = map[i];
     const RemapTap t = remap_tap(W, H, stride, m.x, m.y);
@@ -149,17 +194,21 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
                     const int* flags, int act_flag, hipStream_t st) {
   const int N = P.W * P.H;
   const int gz = (P.B + RECT_SPB - 1) / RECT_SPB;
-  if (N % 4 == 0) {
-    dim3 grid((N / 4 + 255) / 256, 2, gz);
+  const bool vec4 = N % 4 == 0;
+  const int n_tiles = vec4 ? (N / 4 + 255) / 256 : (N + 255) / 256;
+  // 1-D grid: 8 XCDs x (tiles of the largest band) x 2 cameras x stream groups (see the kernel)
+  const int band_tiles = (n_tiles + 7) / 8;
+  dim3 grid(8 * band_tiles * 2 * gz);
+  static const int mode = std::getenv("KVFE_RECT_MODE") ? std::atoi(std::getenv("KVFE_RECT_MODE")) : 3;
+  if (mode == 3) grid = dim3(n_tiles, 2, gz);
+  if (vec4)
     hipLaunchKernelGGL(rectify_kernel<true>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
-                       P.H, P.B, flags, act_flag);
-  } else {
-    dim3 grid((N + 255) / 256, 2, gz);
+                       P.H, P.B, flags, act_flag, n_tiles, gz, mode);
+  else
     hipLaunchKernelGGL(rectify_kernel<false>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
-                       P.H, P.B, flags, act_flag);
-  }
+                       P.H, P.B, flags, act_flag, n_tiles, gz, mode);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -305,7 +305,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int my = by + stripe_corner_y + (tr - 1) / 2;
   float2 match = make_float2((float)mx, (float)my);
   if (SUBPIX) {  // cv::cornerSubPix(right_rectified, (10,10), (-1,-1), 40 it, 0.001)
-    match = corner_subpix_wave(R, (size_t)W, W, H, match, 10, 40, 0.001 * 0.001, T.subpix_mask10,
+    match = corner_subpix_wave<10>(R, (size_t)W, W, H, match, 10, 40, 0.001 * 0.001, T.subpix_mask10,
                                lds + G.match_bytes, lane);
   }
   const double min_val = 0.0;  // normalised minimum (cv::normalize MINMAX) is always 0

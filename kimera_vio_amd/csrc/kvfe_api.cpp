@@ -172,9 +172,14 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.ss.lmk_counter, B));
   TRY(dalloc(c, &b.ss.frame_count, B));
   TRY(dalloc(c, &b.ss.kf_R_ref, B * 9));
-  TRY(dalloc(c, &b.kf_R_cur, B * 9));
-  TRY(dalloc(c, &b.in_ts, B));
-  TRY(dalloc(c, &b.in_force, B));
+  {  // per-step inputs live in one block so that a step needs a single H2D copy:
+     // [B][9] f64 keyframe_R_cur_frame | [B] i64 timestamp | [B] i32 force_keyframe
+    unsigned char* blk;
+    TRY(dalloc(c, &blk, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * B));
+    b.kf_R_cur = reinterpret_cast<double*>(blk);
+    b.in_ts = reinterpret_cast<long long*>(blk + sizeof(double) * 9 * B);
+    b.in_force = reinterpret_cast<int*>(blk + (sizeof(double) * 9 + sizeof(long long)) * B);
+  }
   b.ss.kf_R_cur = b.kf_R_cur;
   b.ss.in_timestamp = b.in_ts;
   b.ss.in_force_kf = b.in_force;
@@ -528,9 +533,8 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     hts[s] = inputs[s].timestamp_ns;
     hf[s] = inputs[s].force_keyframe;
   }
-  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hR, sizeof(double) * 9 * P.B, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(b.in_ts, hts, sizeof(long long) * P.B, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(b.in_force, hf, sizeof(int) * P.B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B,
+                           hipMemcpyHostToDevice, st));
   HIPCHK(c, hipEventRecord(c->ring_ev[slot], st));
   c->ring_used[slot] = true;
 
@@ -798,7 +802,9 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
   int groups = cfg->stream_groups;
   if (groups < 0) return KVFE_ERR_INVALID_ARG;
   if (cfg->hip_stream) groups = 1;
-  if (groups == 0) groups = cfg->batch >= 4 * MIN_GROUP_STREAMS ? 4 : (cfg->batch >= 2 * MIN_GROUP_STREAMS ? 2 : 1);
+  // measured on MI355X (profiles/r1_groups_sweep.md): with the current kernels one group is fastest at
+  // every batch size (the latency-bound kernels do not shrink with the group), so 0 means 1
+  if (groups == 0) groups = 1;
   groups = std::max(1, std::min(groups, cfg->batch));
   kvfe_ctx* c = nullptr;
   kvfe_status s = create_one(cfg, nullptr, 0, cfg->batch, groups == 1, &c);

@@ -84,7 +84,7 @@ static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, 
 
 // LDS carve-up of corner_subpix_wave (bytes), shared by the kernels and their launchers
 struct SubpixGeom {
-  int ww, pw, nt, ntp, rs;
+  int ww, pw, nt, ntp, ts, rs;
   size_t terms_off, patch_off, stage_off, bytes;
 };
 __host__ __device__ inline SubpixGeom subpix_geom(int win) {
@@ -93,9 +93,11 @@ __host__ __device__ inline SubpixGeom subpix_geom(int win) {
   g.pw = g.ww + 2;
   g.nt = g.ww * g.ww;
   g.ntp = (g.nt + 31) & ~31;          // chains are walked in batches of 32, zero padded
+  g.ts = g.ntp + 2;                   // chain stride (float64s): +16 B so that the five chain
+                                      // lanes read five different groups of four LDS banks
   g.rs = g.pw + 1 + 2 * 6;            // staged source side: bilinear footprint + 6 px margin
   g.terms_off = 0;
-  g.patch_off = sizeof(double) * 5 * (size_t)g.ntp;
+  g.patch_off = sizeof(double) * 5 * (size_t)g.ts;
   g.stage_off = g.patch_off + sizeof(float) * (size_t)g.pw * g.pw;
   g.bytes = (g.stage_off + (size_t)g.rs * g.rs + 15) & ~(size_t)15;
   return g;
@@ -185,7 +187,7 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
                                        const float* __restrict__ mask, unsigned char* lds, int lane) {
   const int win = WIN > 0 ? WIN : win_rt;
   const SubpixGeom G = subpix_geom(win);
-  const int ww = G.ww, pw = G.pw, nt = G.nt, ntp = G.ntp, rs = G.rs;
+  const int ww = G.ww, pw = G.pw, nt = G.nt, ntp = G.ntp, ts = G.ts, rs = G.rs;
   constexpr int MAXT = WIN > 0 ? ((2 * WIN + 1) * (2 * WIN + 1) + 63) / 64 : 16;
   constexpr int MAXP = WIN > 0 ? ((2 * WIN + 3) * (2 * WIN + 3) + 63) / 64 : 18;
   double* terms = reinterpret_cast<double*>(lds + G.terms_off);
@@ -213,7 +215,7 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
     eij[t] = (i << 8) | (e - i * pw);
   }
   for (int k = nt + lane; k < ntp; k += 64)
-    for (int q = 0; q < 5; q++) terms[q * ntp + k] = 0.0;
+    for (int q = 0; q < 5; q++) terms[q * ts + k] = 0.0;
   int sx0 = 0, sy0 = 0;
   bool staged = false;
   float2 cI = cT;
@@ -263,10 +265,10 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
         const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
         const double px = (double)(j - win), py = (double)(i - win);
         terms[k] = gxx;
-        terms[ntp + k] = gxy;
-        terms[2 * ntp + k] = gyy;
-        terms[3 * ntp + k] = gxx * px + gxy * py;
-        terms[4 * ntp + k] = gxy * px + gyy * py;
+        terms[ts + k] = gxy;
+        terms[2 * ts + k] = gyy;
+        terms[3 * ts + k] = gxx * px + gxy * py;
+        terms[4 * ts + k] = gxy * px + gyy * py;
       }
     }
     __syncthreads();
@@ -274,10 +276,10 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
     // as long as its operand has landed, so the loop only has to keep LDS reads ahead of the adds
     double acc = 0;
     if (lane < 5) {
-      const double2* t2 = reinterpret_cast<const double2*>(terms + lane * ntp);
+      const double2* t2 = reinterpret_cast<const double2*>(terms + lane * ts);
       if (WIN > 0) {
         constexpr int NTP = (((2 * WIN + 1) * (2 * WIN + 1) + 31) & ~31);
-        acc = lds_chain_sum<(WIN > 0 ? NTP / 2 : 16)>(terms + lane * ntp);
+        acc = lds_chain_sum<(WIN > 0 ? NTP / 2 : 16)>(terms + lane * ts);
       } else {
 #pragma unroll 16
         for (int k2 = 0; k2 < ntp / 2; k2++) {
@@ -304,11 +306,15 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
   return cI;
 }
 
-// the reference uses half size 10 everywhere (FeatureDetector.cpp:288-292, StereoMatcher.cpp:406-411)
-static __device__ float2 corner_subpix_wave(const unsigned char* __restrict__ img, size_t step, int W,
-                                     int H, float2 cT, int win, int max_iters, double eps2,
-                                     const float* __restrict__ mask, unsigned char* lds, int lane) {
-  if (win == 10)
-    return corner_subpix_wave_t<10>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
-  return corner_subpix_wave_t<0>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
+// The reference uses half size 10 everywhere (FeatureDetector.cpp:288-292,
+// StereoMatcher.cpp:406-411): kernels are instantiated for WIN = 10 (everything unrolled, window
+// coordinates and mask weights register resident) and WIN = 0 (any half size at run time), and the
+// launcher picks one, so the hot instantiation does not pay the registers of the generic one.
+template <int WIN>
+static __device__ __forceinline__ float2 corner_subpix_wave(const unsigned char* __restrict__ img,
+                                                            size_t step, int W, int H, float2 cT,
+                                                            int win, int max_iters, double eps2,
+                                                            const float* __restrict__ mask,
+                                                            unsigned char* lds, int lane) {
+  return corner_subpix_wave_t<WIN>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
 }
