@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--mode", choices=["kf", "nominal"], default="kf",
                     help="kf: every frame is a keyframe (all stages every pair, headline); "
                          "nominal: reference cadence (keyframe every 0.2 s = 4th frame)")
+    ap.add_argument("--ransac", type=int, default=1, choices=[0, 1],
+                    help="useRANSAC of params/Euroc/FrontendParams.yaml (1 = as shipped: 2-point mono + "
+                         "1-point stereo geometric outlier rejection on every keyframe)")
     ap.add_argument("--ring", type=int, default=6, help="distinct frames per stream (ping-pong)")
     ap.add_argument("--unique-streams", type=int, default=8)
     ap.add_argument("--groups", type=int, default=0,
@@ -92,14 +95,15 @@ def main():
     G = os.path.join(ROOT, "tests", "golden")
     W, H, B = args.width, args.height, args.batch
     L, R = make_cameras(P, G, W, H)
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=args.ransac)
     p.detector.max_features_per_frame = args.features
     p.tracker.klt_max_level = args.klt_max_level
 
     # ---- synthetic input ring, resident in HBM ---------------------------------------------------
     U = max(1, min(args.unique_streams, B))
     T = args.ring
-    streams = [synth.SyntheticStream(L, seed=100 * rank + u) for u in range(U)]
+    R1 = np.array(F.compute_rectification(L, R).R1).reshape(3, 3)
+    streams = [synth.RigStream(L, R, seed=100 * rank + u, rect_R1=R1) for u in range(U)]
     lefts = np.empty((T, B, H, W), np.uint8)
     rights = np.empty((T, B, H, W), np.uint8)
     for t in range(T):
@@ -116,7 +120,7 @@ def main():
 
     def frame_inputs(step_idx, kf_t):
         t = ping_pong(step_idx, T)
-        Rs = [synth.keyframe_R_cur(streams[s % U], kf_t, t) for s in range(B)]
+        Rs = [synth.rig_keyframe_R_cur(streams[s % U], kf_t, t) for s in range(B)]
         force = 1 if args.mode == "kf" else 0
         return t, ctx.make_inputs([step_idx * dt_ns] * B, Rs, [force] * B)
 
@@ -204,11 +208,13 @@ def main():
         "value": round(value, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32+f32",
-        "data": f"synthetic ({U} seeded streams x {T} frames per GPU, replicated to {B} streams)",
+        "data": f"synthetic ({U} seeded streams x {T} frames per GPU rendered through the calibrated stereo rig, "
+                f"replicated to {B} streams)",
         "config": {"workload": f"batched {B} synthetic {W}x{H} stereo streams per GPU, {args.features} "
                                f"features, ANMS binning on, {args.klt_max_level + 1}-level LK, "
-                               f"mode={args.mode}", "batch_per_gpu": B, "width": W, "height": H,
-                   "features": args.features, "mode": args.mode, "stream_groups": groups,
+                               f"useRANSAC={args.ransac}, mode={args.mode}", "batch_per_gpu": B, "width": W, "height": H,
+                   "features": args.features, "mode": args.mode, "use_ransac": args.ransac,
+                   "stream_groups": groups,
                    "parallelism": f"streams x{world}"},
         "roofline": roofline,
         "stage_ms_per_step_summed_over_groups": stage_ms,
@@ -233,7 +239,7 @@ def single_stream(F, P, synth, L, R, p, torch, dev, args):
     import copy
     p1 = copy.deepcopy(p)
     p1.detector.max_features_per_frame = 300
-    st = synth.SyntheticStream(L, seed=4242)
+    st = synth.RigStream(L, R, seed=4242, rect_R1=np.array(F.compute_rectification(L, R).R1).reshape(3, 3))
     T = 6
     fr = [st.frame(t) for t in range(T)]
     dl = torch.from_numpy(np.stack([f[0] for f in fr])[:, None]).to(dev)
@@ -244,7 +250,7 @@ def single_stream(F, P, synth, L, R, p, torch, dev, args):
     kf_t = 0
     for i in range(steps + warm):
         t = ping_pong(i, T)
-        plan.append((t, ctx.make_inputs([i * 50_000_000], [synth.keyframe_R_cur(st, kf_t, t)], [1])))
+        plan.append((t, ctx.make_inputs([i * 50_000_000], [synth.rig_keyframe_R_cur(st, kf_t, t)], [1])))
         kf_t = t
     for i in range(warm):
         ctx.step_device(dl[plan[i][0]].data_ptr(), dr[plan[i][0]].data_ptr(), plan[i][1])
@@ -267,7 +273,8 @@ def cpu_baseline(P, synth, L, R, p, args):
     import oracle_lib as O  # checker / baseline only
     from kimera_vio_amd import _abi as abi
     n = args.cpu_baseline_frames
-    st = synth.SyntheticStream(L, seed=100)
+    from kimera_vio_amd import frontend as F
+    st = synth.RigStream(L, R, seed=100, rect_R1=np.array(F.compute_rectification(L, R).R1).reshape(3, 3))
     T = args.ring
     frames = [st.frame(t) for t in range(T)]
     lefts = np.stack([frames[ping_pong(i, T)][0] for i in range(n)])
@@ -279,7 +286,7 @@ def cpu_baseline(P, synth, L, R, p, args):
         t = ping_pong(i, T)
         fi = abi.FrameInput()
         fi.timestamp_ns = i * 50_000_000
-        Rm = synth.keyframe_R_cur(st, kf_t, t).reshape(9)
+        Rm = synth.rig_keyframe_R_cur(st, kf_t, t).reshape(9)
         for k in range(9):
             fi.keyframe_R_cur_frame[k] = float(Rm[k])
         fi.force_keyframe = 1 if args.mode == "kf" else 0

@@ -54,6 +54,21 @@ enum {
   KVFE_KP_FAILED_ARUN = 4
 };
 
+/* VIO::TrackingStatus, include/kimera-vio/frontend/Tracker-definitions.h:126-132 */
+enum {
+  KVFE_TRACKING_VALID = 0,
+  KVFE_TRACKING_LOW_DISPARITY = 1,
+  KVFE_TRACKING_FEW_MATCHES = 2,
+  KVFE_TRACKING_INVALID = 3,
+  KVFE_TRACKING_DISABLED = 4
+};
+
+/* std::uniform_int_distribution<int>(0, INT_MAX) over std::mt19937, as drawn by
+ * opengv::sac::SampleConsensusProblem::rnd(), is implementation defined.
+ * PRE11: libstdc++ <= 10 (GCC 9.4 of the reference's Ubuntu 20.04 image) redraws
+ * while the 32-bit output is >= 2^31; V11: libstdc++ >= 11 returns output >> 1. */
+enum { KVFE_RNG_LIBSTDCXX_PRE11 = 0, KVFE_RNG_LIBSTDCXX_11 = 1 };
+
 /* VIO::AnmsAlgorithmType (feature-detector/NonMaximumSuppression.h) */
 enum {
   KVFE_ANMS_TOPN = 0,
@@ -123,9 +138,12 @@ typedef struct kvfe_detector_params {
   int32_t reserved0;
 } kvfe_detector_params;
 
-/* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85);
- * RANSAC members are carried for completeness but geometric outlier rejection
- * is outside this library. */
+/* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85).
+ * Geometric outlier rejection (FrontendParams::useRANSAC_) is implemented for the
+ * IMU-aided problems every shipped Euroc-style parameter set selects:
+ * ransac_use_2point_mono (opengv TranslationOnlySacProblem) and
+ * ransac_use_1point_stereo (the reference's own voting scheme).  The 5-point /
+ * 3-point / PnP problems and ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
 typedef struct kvfe_tracker_params {
   int32_t klt_win_size;
   int32_t klt_max_iter;
@@ -135,6 +153,17 @@ typedef struct kvfe_tracker_params {
   int32_t optical_flow_predictor_type;       /* KVFE_FLOW_*                  */
   int32_t reserved0;
   double disparity_threshold;                /* disparityThreshold           */
+  int32_t min_nr_mono_inliers;               /* minNrMonoInliers             */
+  int32_t min_nr_stereo_inliers;             /* minNrStereoInliers           */
+  double ransac_threshold_mono;              /* 1 - cos on bearing vectors   */
+  double ransac_threshold_stereo;            /* Mahalanobis (float32 test)   */
+  int32_t ransac_max_iterations;
+  int32_t ransac_randomize;                  /* must be 0 (fixed seed 12345) */
+  double ransac_probability;
+  int32_t ransac_use_1point_stereo;
+  int32_t ransac_use_2point_mono;
+  int32_t ransac_rng_policy;                 /* KVFE_RNG_*                   */
+  int32_t reserved1;
 } kvfe_tracker_params;
 
 /* VIO::StereoMatchingParams (include/kimera-vio/frontend/StereoMatchingParams.h:24-60) */
@@ -155,7 +184,7 @@ typedef struct kvfe_frontend_params {
   int64_t min_number_features;
   double max_disparity_since_lkf;
   int32_t use_stereo_tracking;
-  int32_t use_ransac;                        /* must be 0 (f1 is "next")     */
+  int32_t use_ransac;                        /* useRANSAC                    */
 } kvfe_frontend_params;
 
 typedef struct kvfe_config {
@@ -309,6 +338,35 @@ KVFE_API kvfe_status kvfe_sparse_stereo_reconstruction(
     kvfe_ctx* ctx, const uint8_t* left_img, const uint8_t* right_img, size_t stride,
     const float* left_xy, int32_t n, kvfe_stereo_output* out);
 
+/* Tracker::geometricOutlierRejection2d2d(ref_bearings, cur_bearings, matches,
+ * inliers, cam_lkf_Pose_cam_kf) with ransac_use_2point_mono (Tracker.cpp:213-318):
+ * opengv RANSAC over TranslationOnlySacProblem with the rotation given.
+ * f_ref / f_cur: n matched bearing vectors (n x 3 float64).  Outputs: tracking
+ * status (VALID / FEW_MATCHES / INVALID), pose 3x4 [R | t], inlier indices into
+ * the match list (ascending, capacity n), RANSAC iterations. */
+typedef struct kvfe_ransac_output {
+  int32_t status;            /* KVFE_TRACKING_*                              */
+  int32_t n_inliers;
+  int32_t iterations;
+  int32_t reserved0;
+  double pose[12];           /* row-major 3x4 [R | t]                        */
+  double info[9];            /* stereo only: information matrix of t         */
+} kvfe_ransac_output;
+
+KVFE_API kvfe_status kvfe_outlier_rejection_2d2d_given_rotation(
+    kvfe_ctx* ctx, const double* f_ref, const double* f_cur, int32_t n,
+    const double R_ref_cur[9], int32_t* inliers, kvfe_ransac_output* out);
+
+/* Tracker::geometricOutlierRejection3d3dGivenRotation (Tracker.cpp:382-632) +
+ * Tracker::getPoint3AndCovariance (:772-818): the 1-point voting scheme on n
+ * stereo matches.  Per match and per frame (ref = last keyframe, cur): rectified
+ * left pixel (x, y), rectified right pixel x, 3-D point (keypoints_3d_). */
+KVFE_API kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
+    kvfe_ctx* ctx, const float* ref_left_rect_xy, const float* ref_right_rect_x,
+    const double* ref_points_3d, const float* cur_left_rect_xy,
+    const float* cur_right_rect_x, const double* cur_points_3d, int32_t n,
+    const double R_ref_cur[9], int32_t* inliers, kvfe_ransac_output* out);
+
 /* ------------------------------------------------------------------------- */
 /* front-end level: `batch` independent streams, lock-step, device resident  */
 /* ------------------------------------------------------------------------- */
@@ -323,8 +381,9 @@ typedef struct kvfe_frame_input {
 } kvfe_frame_input;
 
 /* StereoVisionImuFrontend::processFirstStereoFrame / processStereoFrame for
- * all streams of the context (StereoVisionImuFrontend.cpp:245-481) with
- * useRANSAC = 0.  left/right: `batch` images back to back (image s at
+ * all streams of the context (StereoVisionImuFrontend.cpp:245-481), including
+ * the geometric outlier rejection of keyframes when useRANSAC = 1
+ * (VisionImuFrontend.cpp:90-144).  left/right: `batch` images back to back (image s at
  * base + s*image_stride_bytes).  The *_host variant copies from host memory;
  * the *_device variant takes device pointers that must stay valid until the
  * next step of this context has completed.  Both only enqueue work. */
@@ -363,6 +422,16 @@ typedef struct kvfe_frame_output {
   double* keypoints_3d;
   int64_t* meas_landmark;       /* StereoMeasurement.first                   */
   double* meas_uL_uR_v;         /* StereoPoint2 (uL, uR or NaN, v), n x 3    */
+  /* TrackerStatusSummary (Tracker-definitions.h:135-183) of this frame, valid on
+   * keyframes; poses are row-major 3x4 [R | t] of lkf_T_k                     */
+  int32_t tracking_status_mono;    /* kfTrackingStatus_mono_,   KVFE_TRACKING_* */
+  int32_t tracking_status_stereo;  /* kfTrackingStatus_stereo_                  */
+  double lkf_T_k_mono[12];
+  double lkf_T_k_stereo[12];
+  double info_mat_stereo_translation[9];   /* infoMatStereoTranslation_         */
+  /* DebugTrackerInfo (Tracker-definitions.h:78-124) */
+  int32_t nr_mono_putatives, nr_mono_inliers, mono_ransac_iters;
+  int32_t nr_stereo_putatives, nr_stereo_inliers, reserved0;
 } kvfe_frame_output;
 
 KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,

@@ -22,6 +22,8 @@ DET_FAST, DET_ORB, DET_AGAST, DET_GFTT = range(4)
 FLOW_NO_PREDICTION, FLOW_ROTATIONAL = range(2)
 DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = range(3)
 SORTIDX_LIBSTDCXX, SORTIDX_STABLE = range(2)
+TRACKING_VALID, TRACKING_LOW_DISPARITY, TRACKING_FEW_MATCHES, TRACKING_INVALID, TRACKING_DISABLED = range(5)
+RNG_LIBSTDCXX_PRE11, RNG_LIBSTDCXX_11 = range(2)
 
 
 class CameraParams(C.Structure):
@@ -65,6 +67,12 @@ class TrackerParams(C.Structure):
         ("klt_eps", C.c_double),
         ("optical_flow_predictor_type", C.c_int32), ("reserved0", C.c_int32),
         ("disparity_threshold", C.c_double),
+        ("min_nr_mono_inliers", C.c_int32), ("min_nr_stereo_inliers", C.c_int32),
+        ("ransac_threshold_mono", C.c_double), ("ransac_threshold_stereo", C.c_double),
+        ("ransac_max_iterations", C.c_int32), ("ransac_randomize", C.c_int32),
+        ("ransac_probability", C.c_double),
+        ("ransac_use_1point_stereo", C.c_int32), ("ransac_use_2point_mono", C.c_int32),
+        ("ransac_rng_policy", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -133,6 +141,19 @@ class FrameOutput(C.Structure):
         ("right_rect_xy", C.c_void_p), ("right_status", C.c_void_p), ("depth", C.c_void_p),
         ("right_xy", C.c_void_p), ("keypoints_3d", C.c_void_p),
         ("meas_landmark", C.c_void_p), ("meas_uL_uR_v", C.c_void_p),
+        ("tracking_status_mono", C.c_int32), ("tracking_status_stereo", C.c_int32),
+        ("lkf_T_k_mono", C.c_double * 12), ("lkf_T_k_stereo", C.c_double * 12),
+        ("info_mat_stereo_translation", C.c_double * 9),
+        ("nr_mono_putatives", C.c_int32), ("nr_mono_inliers", C.c_int32),
+        ("mono_ransac_iters", C.c_int32), ("nr_stereo_putatives", C.c_int32),
+        ("nr_stereo_inliers", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class RansacOutput(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("n_inliers", C.c_int32), ("iterations", C.c_int32),
+        ("reserved0", C.c_int32), ("pose", C.c_double * 12), ("info", C.c_double * 9),
     ]
 
 

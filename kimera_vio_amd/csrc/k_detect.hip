@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
     const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
     const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
-    const int* __restrict__ kp_count, int use_discs, const int* __restrict__ flags,
+    const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
+    const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
     unsigned int* __restrict__ maxkey) {
   const int s = blockIdx.z;
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
   if (use_discs) {
     const float2* kp = kp_all + (size_t)s * kcap;
     const int nk = kp_count[s];
+    const long long* lmk = lmk_all + (size_t)s * kcap;
     for (int i = lane; i < nk; i += 64) {
+      if (lmk[i] == -1) continue;  // only keypoints with a landmark mask (FeatureDetector.cpp:191)
       const float2 p = kp[i];
       const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
       if (cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye)
@@ -251,12 +254,12 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
   if (user_mask)
     hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                        img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
-                       T.circle_hw, k.kp, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                       T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
                        D.maxkey);
   else
     hipLaunchKernelGGL(mineig_localmax_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
                        img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
-                       T.circle_hw, k.kp, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                       T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
                        D.maxkey);
 }
 
@@ -266,6 +269,7 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
 constexpr int SEL_T = 1024;
 constexpr int MAX_CELLS = 12288;
 constexpr int LDS_SORT_CAP = 8192;
+constexpr int GREEDY_CELLS = 3072;  // 16-byte accepted-corner slots of the in-order greedy filter (LDS)
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16]*/, int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -366,7 +370,105 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   int A = 0;  // accepted corners, keys in `akeys`
   unsigned long long* akeys = skeys;
   const int md = P.min_distance;
-  if (md >= 1 && C2 > 0) {
+  bool sorted_accepted = false;
+  if (md >= 1 && C2 > 0 && C2 <= LDS_SORT_CAP &&
+      ((W + md - 1) / md) * ((H + md - 1) / md) <= GREEDY_CELLS && W < 65536 && H < 65536) {
+    // ---- cv::goodFeaturesToTrack's greedy minimum-distance filter, in its own (sequential) order ----
+    // 1. all candidates sorted by (value, index) descending in LDS;
+    // 2. one wavefront walks them 64 at a time: every lane tests its candidate against the grid of
+    //    already accepted corners (3x3 cells of side minDistance, at most four accepted corners per
+    //    cell), then the survivors of the batch are resolved in rank order with ballots -- the
+    //    lowest surviving lane is accepted and knocks out the later lanes closer than minDistance.
+    // The accepted list comes out in quality order (= the function's output order) and stops at
+    // maxCorners exactly where the reference loop breaks.
+    const int cell = md;
+    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+    const int ncell = gw * gh;
+    unsigned* grid = reinterpret_cast<unsigned*>(cell_start);  // [ncell][4] packed (x | y << 16)
+    if (C2 <= 2048 && C2 <= (int)((MAX_CELLS + 1) * sizeof(int) / sizeof(unsigned long long))) {
+      // rank sort: keys are distinct, rank = number of larger keys
+      unsigned long long* tmp = reinterpret_cast<unsigned long long*>(cell_start);
+      for (int i = tid; i < C2; i += SEL_T) tmp[i] = work[i];
+      __syncthreads();
+      for (int i = tid; i < C2; i += SEL_T) {
+        const unsigned long long k = tmp[i];
+        int rank = 0;
+        for (int q = 0; q < C2; q++) rank += tmp[q] > k ? 1 : 0;
+        skeys[rank] = k;
+      }
+      __syncthreads();
+    } else {
+      int n2 = 1;
+      while (n2 < C2) n2 <<= 1;
+      for (int i = tid; i < n2; i += SEL_T) skeys[i] = i < C2 ? work[i] : 0ull;
+      __syncthreads();
+      block_bitonic_desc(skeys, n2);
+    }
+    for (int i = tid; i < ncell * 4; i += SEL_T) grid[i] = 0xffffffffu;
+    if (tid == 0) sh_flag = 0;
+    __syncthreads();
+    if (tid < 64) {
+      const int lane = tid;
+      const float md2 = (float)((double)md * (double)md);
+      int acc = 0;
+      bool done = false;
+      for (int base = 0; base < C2 && !done; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < C2;
+        const unsigned long long key = valid ? skeys[i] : 0ull;
+        const unsigned idx = (unsigned)key;
+        const int y = idx / W, x = idx - y * W;
+        bool ok = valid;
+        if (ok) {
+          const int xc = x / cell, yc = y / cell;
+          const int x1 = max(0, xc - 1), y1 = max(0, yc - 1);
+          const int x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
+          for (int yy = y1; yy <= y2 && ok; yy++)
+            for (int xx = x1; xx <= x2 && ok; xx++) {
+              const unsigned* g = grid + (yy * gw + xx) * 4;
+              for (int q = 0; q < 4; q++) {
+                const unsigned v = g[q];
+                if (v == 0xffffffffu) break;
+                const float dx = (float)(x - (int)(v & 0xffffu)), dy = (float)(y - (int)(v >> 16));
+                if (dx * dx + dy * dy < md2) {
+                  ok = false;
+                  break;
+                }
+              }
+            }
+        }
+        unsigned long long mask = __ballot(ok);
+        while (mask) {
+          const int l = __ffsll((long long)mask) - 1;  // highest-ranked survivor of the batch
+          const int lx = __shfl(x, l), ly = __shfl(y, l);
+          const unsigned long long lkey = __shfl(key, l);
+          if (lane == 0) {
+            skeys[acc] = lkey;  // in place: acc <= base, the batch itself is in registers
+            unsigned* g = grid + ((ly / cell) * gw + (lx / cell)) * 4;
+            int q = 0;
+            while (q < 4 && g[q] != 0xffffffffu) q++;
+            if (q < 4)
+              g[q] = (unsigned)lx | ((unsigned)ly << 16);
+            else
+              sh_flag = 2;  // cannot happen: five corners >= minDistance apart in one cell
+          }
+          acc++;
+          if (P.max_corners > 0 && acc == P.max_corners) {
+            done = true;
+            break;
+          }
+          const float dx = (float)(x - lx), dy = (float)(y - ly);
+          const bool near = ok && (dx * dx + dy * dy < md2);
+          mask &= ~__ballot(near);
+        }
+      }
+      if (lane == 0) sh_cnt = acc;
+    }
+    __syncthreads();
+    A = sh_cnt;
+    if (sh_flag == 2) overflow = 1;
+    sorted_accepted = true;
+  } else if (md >= 1 && C2 > 0) {
     const int cell = md;  // cvRound(minDistance) for an integer distance
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
     const int ncell = gw * gh;
@@ -494,7 +596,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     for (int i = A + tid; i < n2; i += SEL_T) skeys[i] = 0;
     __syncthreads();
     block_bitonic_desc(skeys, n2);
-  } else if (C2 > 0) {
+  } else if (C2 > 0 && !sorted_accepted) {
     // no minimum distance: all candidates, sorted (global memory when they do not fit in LDS)
     int n2 = 1;
     while (n2 < C2) n2 <<= 1;

@@ -1,0 +1,903 @@
+// Geometric outlier rejection of keyframes (FrontendParams::useRANSAC_), device resident so that a
+// keyframe still needs no host round trip:
+//   VisionImuFrontend::outlierRejectionMono / outlierRejectionStereo  src/frontend/VisionImuFrontend.cpp:90-144
+//   Tracker::geometricOutlierRejection2d2d (rotation given)           src/frontend/Tracker.cpp:213-378
+//     = opengv::sac::Ransac<TranslationOnlySacProblem> (2-point), Tracker::runRansac, Tracker.h:247-296
+//   Tracker::geometricOutlierRejection3d3dGivenRotation (1-point voting, the reference's own scheme)
+//                                                                      src/frontend/Tracker.cpp:382-661
+//   Tracker::getPoint3AndCovariance                                    src/frontend/Tracker.cpp:772-818
+//   Tracker::findMatchingKeypoints / findMatchingStereoKeypoints / computeMedianDisparity / removeOutliers*
+//                                                                      src/frontend/Tracker.cpp:856-1018
+//
+// One 256-thread workgroup per stream.  RANSAC iterations are sequential (adaptive stopping), the
+// scoring of every hypothesis is parallel over the matches; the O(n^2) float32 Mahalanobis voting is
+// parallel over rows.  All float64 / float32 expressions are evaluated in the order of the CPU path
+// (oracle/opengv_re.cpp, oracle/kimera_ransac.cpp), no FMA contraction.  The random numbers of
+// opengv's sampler (std::mt19937 seeded with 12345 through uniform_int_distribution) are a fixed
+// stream, generated once on the host (Tables::ransac_rnd).
+#include "kvfe_dev.hpp"
+
+#include <climits>
+
+namespace kvfe {
+
+constexpr int RS_T = 256;
+
+__device__ __forceinline__ double rs_dot3(const double* a, const double* b) {
+  return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+__device__ __forceinline__ void rs_cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void rs_matvec3(const double* R, const double* v, double* o) {
+  for (int r = 0; r < 3; r++) o[r] = (R[r * 3] * v[0] + R[r * 3 + 1] * v[1]) + R[r * 3 + 2] * v[2];
+}
+
+// gtsam::Rot3::equals(Rot3(), 1e-9) (fpEqual without the relative test)
+__device__ bool rs_rot_is_identity(const double* R) {
+  for (int i = 0; i < 9; i++) {
+    const double a = R[i], b = (i % 4 == 0) ? 1.0 : 0.0;
+    if (isnan(a)) return false;
+    if (isinf(a)) return false;
+    if (a == b) continue;
+    if (!(fabs(a - b) <= 1e-9)) return false;
+  }
+  return true;
+}
+
+// exclusive scan of one int per thread over the 256-thread block; *total = block sum
+__device__ __forceinline__ int rs_scan(int v, int* wave_tot /*[4]*/, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < RS_T / 64; i++) {
+    const int t = wave_tot[i];
+    if (i < wv) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+__device__ __forceinline__ int rs_block_sum(int v, int* wave_tot) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  __syncthreads();
+  return tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tracker::findMatchingKeypoints (+ findMatchingStereoKeypoints when ST/LST are given): matches
+// (index in lkf, index in k) in the order of k's keypoints.  Valid landmark ids of a frame are
+// strictly increasing, so the std::map lookup is a binary search over the compacted valid ids.
+// LDS: ids [kcap] i64 | idx [kcap] i32.
+// ---------------------------------------------------------------------------------------------
+__device__ int rs_build_matches(const KParams& P, const FrameTab& K, const FrameTab& LKF,
+                                const unsigned char* k_rstat, const unsigned char* l_rstat, int s,
+                                long long* ids, int* idx, int* wave_tot, int2* matches) {
+  const int tid = threadIdx.x;
+  const size_t so = (size_t)s * P.kcap;
+  const int nl = LKF.count[s], nk = K.count[s];
+  __shared__ int sh_off;
+  if (tid == 0) sh_off = 0;
+  __syncthreads();
+  for (int base = 0; base < nl; base += RS_T) {
+    const int j = base + tid;
+    long long id = -1;
+    if (j < nl) id = LKF.lmk[so + j];
+    int tot;
+    const int pos = rs_scan(id != -1 ? 1 : 0, wave_tot, &tot);
+    const int off = sh_off;
+    if (id != -1) {
+      ids[off + pos] = id;
+      idx[off + pos] = j;
+    }
+    __syncthreads();
+    if (tid == 0) sh_off = off + tot;
+    __syncthreads();
+  }
+  const int nv = sh_off;
+  __syncthreads();
+  if (tid == 0) sh_off = 0;
+  __syncthreads();
+  for (int base = 0; base < nk; base += RS_T) {
+    const int i = base + tid;
+    int j = -1;
+    if (i < nk) {
+      const long long id = K.lmk[so + i];
+      if (id != -1) {
+        int lo = 0, hi = nv - 1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const long long v = ids[mid];
+          if (v == id) {
+            j = idx[mid];
+            break;
+          }
+          if (v < id)
+            lo = mid + 1;
+          else
+            hi = mid - 1;
+        }
+      }
+      if (j >= 0 && k_rstat && !(l_rstat[so + j] == 0 && k_rstat[so + i] == 0)) j = -1;
+    }
+    int tot;
+    const int pos = rs_scan(j >= 0 ? 1 : 0, wave_tot, &tot);
+    const int off = sh_off;
+    if (j >= 0) matches[off + pos] = make_int2(j, i);
+    __syncthreads();
+    if (tid == 0) sh_off = off + tot;
+    __syncthreads();
+  }
+  const int n = sh_off;
+  __syncthreads();
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// opengv TranslationOnlySacProblem
+// ---------------------------------------------------------------------------------------------
+struct RsModel {
+  double R[9], t[3], inv[12];  // model [R | t] and the inverse solution [R^T | -R^T t]
+};
+
+// relative_pose::twopt(adapter, unrotate = true, i0, i1)
+__device__ void rs_twopt(const double* f1, const double* f2, const double* R12, int i0, int i1,
+                         RsModel* M) {
+  double a1[3], b1[3], fa[3], fb[3], a2[3], b2[3];
+  for (int c = 0; c < 3; c++) {
+    a1[c] = f1[3 * (size_t)i0 + c];
+    b1[c] = f1[3 * (size_t)i1 + c];
+    fa[c] = f2[3 * (size_t)i0 + c];
+    fb[c] = f2[3 * (size_t)i1 + c];
+  }
+  rs_matvec3(R12, fa, a2);
+  rs_matvec3(R12, fb, b2);
+  double n1[3], n2[3], t[3];
+  rs_cross3(a1, a2, n1);
+  rs_cross3(b1, b2, n2);
+  rs_cross3(n1, n2, t);
+  const double nrm = sqrt(rs_dot3(t, t));
+  for (int i = 0; i < 3; i++) t[i] = t[i] / nrm;
+  const double flow[3] = {a1[0] - a2[0], a1[1] - a2[1], a1[2] - a2[2]};
+  if (rs_dot3(flow, t) < 0)
+    for (int i = 0; i < 3; i++) t[i] = -t[i];
+  for (int i = 0; i < 9; i++) M->R[i] = R12[i];
+  for (int i = 0; i < 3; i++) M->t[i] = t[i];
+  double Rt[9], it[3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) Rt[r * 3 + c] = R12[c * 3 + r];
+  rs_matvec3(Rt, t, it);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) M->inv[r * 4 + c] = Rt[r * 3 + c];
+    M->inv[r * 4 + 3] = -it[r];
+  }
+}
+
+// getSelectedDistancesToModel for one correspondence: triangulate2, reproject, 1 - cos in both views
+__device__ double rs_distance(const RsModel& M, const double* a, const double* b) {
+  double bu[3];
+  rs_matvec3(M.R, b, bu);
+  const double b0 = rs_dot3(M.t, a), b1 = rs_dot3(M.t, bu);
+  const double A00 = rs_dot3(a, a), A10 = rs_dot3(a, bu), A01 = -A10, A11 = -rs_dot3(bu, bu);
+  const double det = A00 * A11 - A10 * A01;
+  const double invdet = 1.0 / det;
+  const double i00 = A11 * invdet, i10 = -A10 * invdet, i01 = -A01 * invdet, i11 = A00 * invdet;
+  const double l0 = i00 * b0 + i01 * b1, l1 = i10 * b0 + i11 * b1;
+  double p[3];
+  for (int c = 0; c < 3; c++) {
+    const double xm = l0 * a[c];
+    const double xn = M.t[c] + l1 * bu[c];
+    p[c] = (xm + xn) / 2;
+  }
+  double r1[3], r2[3];
+  const double n1 = sqrt(rs_dot3(p, p));
+  for (int c = 0; c < 3; c++) r1[c] = p[c] / n1;
+  for (int r = 0; r < 3; r++)
+    r2[r] = ((M.inv[r * 4] * p[0] + M.inv[r * 4 + 1] * p[1]) + M.inv[r * 4 + 2] * p[2]) + M.inv[r * 4 + 3] * 1.0;
+  const double n2 = sqrt(rs_dot3(r2, r2));
+  for (int c = 0; c < 3; c++) r2[c] = r2[c] / n2;
+  const double e1 = 1.0 - rs_dot3(a, r1);
+  const double e2 = 1.0 - rs_dot3(b, r2);
+  return e1 + e2;
+}
+
+struct Rs2d2dResult {
+  int status, n_inliers, iterations;
+  double pose[12];
+};
+
+// opengv::sac::Ransac<TranslationOnlySacProblem>::computeModel + the checks of Tracker::runRansac and
+// Tracker::geometricOutlierRejection2d2d.  Every thread of the block calls it with the same
+// arguments and gets the same result; `inliers` receives the ascending inlier indices.
+// LDS: shuffled [n] int.
+__device__ Rs2d2dResult rs_ransac_2d2d(const KParams& P, const Tables& T, const double* f1,
+                                       const double* f2, int n, const double* R12, int* shuffled,
+                                       int* wave_tot, int* inliers) {
+  const int tid = threadIdx.x;
+  __shared__ int sh_sel[2];
+  __shared__ int sh_cnt;
+  Rs2d2dResult res;
+  res.status = TRK_INVALID;
+  res.n_inliers = 0;
+  res.iterations = 0;
+  for (int i = 0; i < 12; i++) res.pose[i] = (i % 5 == 0) ? 1.0 : 0.0;  // Pose3()
+  for (int i = tid; i < n; i += RS_T) shuffled[i] = i;
+  __syncthreads();
+  int iterations = 0, best = -INT_MAX, draw = 0;
+  double k = 1.0;
+  bool have_model = false;
+  RsModel Mbest;
+  if (n >= 2) {
+    while ((double)iterations < k) {
+      if (tid == 0) {  // SampleConsensusProblem::drawIndexSample (the shuffle persists across iterations)
+        for (int i = 0; i < 2; ++i) {
+          const int r = T.ransac_rnd[min(draw + i, T.n_ransac_rnd - 1)];
+          const int j = i + (int)((unsigned)r % (unsigned)(n - i));
+          const int tmp = shuffled[i];
+          shuffled[i] = shuffled[j];
+          shuffled[j] = tmp;
+        }
+        sh_sel[0] = shuffled[0];
+        sh_sel[1] = shuffled[1];
+      }
+      draw += 2;
+      __syncthreads();
+      RsModel M;
+      rs_twopt(f1, f2, R12, sh_sel[0], sh_sel[1], &M);
+      int cnt = 0;
+      for (int i = tid; i < n; i += RS_T) {
+        double a[3], b[3];
+        for (int c = 0; c < 3; c++) {
+          a[c] = f1[3 * (size_t)i + c];
+          b[c] = f2[3 * (size_t)i + c];
+        }
+        if (rs_distance(M, a, b) < P.ransac_thr_mono) cnt++;
+      }
+      cnt = rs_block_sum(cnt, wave_tot);
+      if (cnt > best) {
+        best = cnt;
+        Mbest = M;
+        have_model = true;
+        const double w = (double)best / (double)n;
+        double p_no_outliers = 1.0 - pow(w, 2.0);
+        p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
+        p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
+        k = log(1.0 - P.ransac_probability) / log(p_no_outliers);
+      }
+      ++iterations;
+      if (iterations > P.ransac_max_iters) break;
+    }
+  } else {
+    iterations = INT_MAX;  // getSamples: not enough correspondences
+  }
+  res.iterations = iterations;
+  if (!have_model) return res;
+  // selectWithinDistance
+  if (tid == 0) sh_cnt = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += RS_T) {
+    const int i = base + tid;
+    bool in = false;
+    if (i < n) {
+      double a[3], b[3];
+      for (int c = 0; c < 3; c++) {
+        a[c] = f1[3 * (size_t)i + c];
+        b[c] = f2[3 * (size_t)i + c];
+      }
+      in = rs_distance(Mbest, a, b) < P.ransac_thr_mono;
+    }
+    int tot;
+    const int pos = rs_scan(in ? 1 : 0, wave_tot, &tot);
+    const int off = sh_cnt;
+    if (in) inliers[off + pos] = i;
+    __syncthreads();
+    if (tid == 0) sh_cnt = off + tot;
+    __syncthreads();
+  }
+  const int n_in = sh_cnt;
+  __syncthreads();
+  if (iterations >= P.ransac_max_iters && n_in == 0) return res;  // Tracker.h:270-273
+  res.n_inliers = n_in;
+  res.status = n_in < P.min_mono_inliers ? TRK_FEW_MATCHES : TRK_VALID;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) res.pose[r * 4 + c] = Mbest.R[r * 3 + c];
+    res.pose[r * 4 + 3] = Mbest.t[r];
+  }
+  return res;
+}
+
+// k-th smallest (0-based) of m non-negative floats in LDS = the value std::nth_element leaves at
+// position k: 4 x 8-bit radix select on the bit patterns (order preserving for non-negative floats)
+__device__ float rs_kth(const float* v, int m, int kth, int* hist /*[256]*/, int* sh2 /*[2]*/) {
+  const unsigned* keys = reinterpret_cast<const unsigned*>(v);
+  const int tid = threadIdx.x;
+  unsigned prefix = 0;
+  for (int pass = 3; pass >= 0; pass--) {
+    const int shift = 8 * pass;
+    for (int i = tid; i < 256; i += RS_T) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += RS_T) {
+      const unsigned key = keys[i];
+      if (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+      const int tot = c0 + c1 + c2 + c3;
+      int inc = tot;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (tid >= off) inc += t;
+      }
+      const int before = inc - tot;
+      if (kth >= before && kth < inc) {  // exactly one lane
+        int r = kth - before, d;
+        if (r < c0)
+          d = 0;
+        else if (r < c0 + c1) {
+          d = 1;
+          r -= c0;
+        } else if (r < c0 + c1 + c2) {
+          d = 2;
+          r -= c0 + c1;
+        } else {
+          d = 3;
+          r -= c0 + c1 + c2;
+        }
+        sh2[0] = 4 * tid + d;
+        sh2[1] = r;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)sh2[0] << shift;
+    kth = sh2[1];
+    __syncthreads();
+  }
+  return __uint_as_float(prefix);
+}
+
+// LDS carve-up shared by the two front-end kernels
+struct RsLds {
+  long long* ids;  // [kcap]
+  int* idx;        // [kcap]
+  int* work;       // [kcap] shuffled indices / inlier flags
+  float* disp;     // [kcap]
+};
+__host__ __device__ inline size_t rs_lds_bytes(int kcap) {
+  return (size_t)kcap * (sizeof(long long) + 3 * sizeof(int)) + 16;
+}
+__device__ __forceinline__ RsLds rs_carve(unsigned char* raw, int kcap) {
+  RsLds L;
+  L.ids = reinterpret_cast<long long*>(raw);
+  L.idx = reinterpret_cast<int*>(L.ids + kcap);
+  L.work = L.idx + kcap;
+  L.disp = reinterpret_cast<float*>(L.work + kcap);
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VisionImuFrontend::outlierRejectionMono for the keyframes of this step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, FrameTab K,
+                                                           FrameTab LKF, StreamState S,
+                                                           RansacScratch RS) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int flags = S.flags[s];
+  // tracker_status_summary_ only changes on keyframes of the nominal path
+  if (!(flags & FLAG_KEYFRAME) || (flags & FLAG_FIRST)) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot[RS_T / 64];
+  __shared__ int hist[256];
+  __shared__ int sh2[2];
+  const RsLds L = rs_carve(lds_raw, P.kcap);
+  const size_t so = (size_t)s * P.kcap;
+  int* st = S.trk_status + 2 * (size_t)s;
+  if (!P.use_ransac) {  // StereoVisionImuFrontend.cpp:400-404
+    if (tid == 0) st[0] = st[1] = TRK_DISABLED;
+    return;
+  }
+  if (tid == 0) st[0] = st[1] = TRK_INVALID;  // :353-354
+  const double* R = S.kf_R_cur + (size_t)s * 9;
+  const bool imu_ok = !rs_rot_is_identity(R);
+  if (!(P.ransac_2pt_mono && imu_ok)) return;  // 5-point problem: not implemented, status stays INVALID
+  int2* matches = RS.matches + so;
+  const int n = rs_build_matches(P, K, LKF, nullptr, nullptr, s, L.ids, L.idx, wave_tot, matches);
+  if (n == 0) return;
+  double* f1 = RS.f_ref + so * 3;
+  double* f2 = RS.f_cur + so * 3;
+  for (int m = tid; m < n; m += RS_T) {
+    const int2 mm = matches[m];
+    for (int c = 0; c < 3; c++) {
+      f1[3 * (size_t)m + c] = LKF.versor[(so + mm.x) * 3 + c];
+      f2[3 * (size_t)m + c] = K.versor[(so + mm.y) * 3 + c];
+    }
+  }
+  __syncthreads();
+  double Rl[9];
+  for (int i = 0; i < 9; i++) Rl[i] = R[i];
+  int* inliers = RS.inliers + so;
+  Rs2d2dResult res = rs_ransac_2d2d(P, T, f1, f2, n, Rl, L.work, wave_tot, inliers);
+  int status = res.status;
+  if (status != TRK_FEW_MATCHES) {  // removeOutliersMono: landmarks of the outliers -> -1 in frame k
+    for (int m = tid; m < n; m += RS_T) L.work[m] = 0;
+    __syncthreads();
+    for (int q = tid; q < res.n_inliers; q += RS_T) L.work[inliers[q]] = 1;
+    __syncthreads();
+    for (int m = tid; m < n; m += RS_T)
+      if (!L.work[m]) K.lmk[so + matches[m].y] = -1;
+  }
+  if (status == TRK_VALID) {  // computeMedianDisparity over the inlier matches (Tracker.cpp:361-373)
+    const int m = res.n_inliers;
+    for (int q = tid; q < m; q += RS_T) {
+      const int2 mm = matches[inliers[q]];
+      const float2 c = K.kp[so + mm.y], r = LKF.kp[so + mm.x];
+      const float dx = c.x - r.x, dy = c.y - r.y;
+      L.disp[q] = dx * dx + dy * dy;
+    }
+    __syncthreads();
+    if (m > 0) {
+      const double disparity = sqrt((double)rs_kth(L.disp, m, m / 2, hist, sh2));
+      if (disparity < P.disparity_thr) status = TRK_LOW_DISPARITY;
+    }
+  }
+  if (tid == 0) {
+    st[0] = status;
+    if (res.status != TRK_INVALID) {
+      int* cn = S.trk_counts + 6 * (size_t)s;
+      cn[0] = n;
+      cn[1] = res.n_inliers;
+      cn[2] = 0;  // monoRansacIters_ is not accessible in the reference either (Tracker.cpp:297-298)
+    }
+    if (status == TRK_VALID) {
+      double* pose = S.trk_pose + 24 * (size_t)s;
+      for (int i = 0; i < 12; i++) pose[i] = res.pose[i];
+    }
+  }
+}
+
+void launch_mono_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
+                        const StreamState& S, const RansacScratch& RS, hipStream_t st) {
+  hipLaunchKernelGGL(mono_ransac_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k,
+                     lkf, S, RS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1-point voting
+// ---------------------------------------------------------------------------------------------
+// gtsam::StereoCamera(Pose3(), K).backproject2 Jacobian + Tracker::getPoint3AndCovariance
+__device__ void rs_point3_cov(const KParams& P, double uL, double uR, double v, const double* p3,
+                              const double* Rmat, double* point, double* cov) {
+  const double disparity = uL - uR;
+  const double local_z = P.baseline * P.fx_rect / disparity;
+  const double lx = local_z * (uL - P.cx_rect) / P.fx_rect, ly = local_z * (v - P.cy_rect) / P.fy_rect;
+  const double z_partial_uR = local_z / disparity;
+  const double x_partial_uR = lx / disparity;
+  const double y_partial_uR = ly / disparity;
+  double J[9] = {-x_partial_uR + local_z / P.fx_rect, x_partial_uR, 0,
+                 -y_partial_uR,                       y_partial_uR, local_z / P.fy_rect,
+                 -z_partial_uR,                       z_partial_uR, 0};
+  for (int i = 0; i < 3; i++) point[i] = p3[i];
+  if (Rmat) {
+    double q[3], RJ[9];
+    rs_matvec3(Rmat, p3, q);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+        RJ[r * 3 + c] = (Rmat[r * 3] * J[c] + Rmat[r * 3 + 1] * J[3 + c]) + Rmat[r * 3 + 2] * J[6 + c];
+    for (int i = 0; i < 3; i++) point[i] = q[i];
+    for (int i = 0; i < 9; i++) J[i] = RJ[i];
+  }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++)
+      cov[r * 3 + c] = (J[r * 3] * J[c * 3] + J[r * 3 + 1] * J[c * 3 + 1]) + J[r * 3 + 2] * J[c * 3 + 2];
+}
+
+// Eigen::Matrix3d::inverse() (cofactor formula of Eigen/src/LU/InverseImpl.h)
+__device__ void rs_inverse3(const double* m, double* r) {
+#define M_(i, j) m[(i) * 3 + (j)]
+#define COF_(i, j) \
+  (M_(((i) + 1) % 3, ((j) + 1) % 3) * M_(((i) + 2) % 3, ((j) + 2) % 3) - M_(((i) + 1) % 3, ((j) + 2) % 3) * M_(((i) + 2) % 3, ((j) + 1) % 3))
+  const double c00 = COF_(0, 0), c10 = COF_(1, 0), c20 = COF_(2, 0);
+  const double det = (c00 * M_(0, 0) + c10 * M_(1, 0)) + c20 * M_(2, 0);
+  const double invdet = 1.0 / det;
+  r[3] = COF_(0, 1) * invdet;
+  r[4] = COF_(1, 1) * invdet;
+  r[6] = COF_(0, 2) * invdet;
+  r[5] = COF_(2, 1) * invdet;
+  r[7] = COF_(1, 2) * invdet;
+  r[8] = COF_(2, 2) * invdet;
+  r[0] = c00 * invdet;
+  r[1] = c10 * invdet;
+  r[2] = c20 * invdet;
+#undef COF_
+#undef M_
+}
+
+// the float32 Mahalanobis test of the voting loop, literally (Tracker.cpp:499-523); a = row i, b = row j
+__device__ __forceinline__ float rs_mahalanobis(const float* a, const float* b) {
+  float v[3], O[9];
+  for (int k = 0; k < 3; k++) v[k] = a[k] - b[k];
+  for (int k = 0; k < 9; k++) O[k] = a[3 + k] + b[3 + k];
+#define O_(r, c) O[(r) * 3 + (c)]
+  const float dinv = 1 / (O_(0, 0) * (O_(1, 1) * O_(2, 2) - O_(1, 2) * O_(2, 1)) -
+                          O_(1, 0) * (O_(0, 1) * O_(2, 2) - O_(0, 2) * O_(2, 1)) +
+                          O_(2, 0) * (O_(0, 1) * O_(1, 2) - O_(1, 1) * O_(0, 2)));
+  const float d =
+      dinv * v[0] *
+          (v[0] * (O_(1, 1) * O_(2, 2) - O_(1, 2) * O_(2, 1)) -
+           v[1] * (O_(0, 1) * O_(2, 2) - O_(0, 2) * O_(2, 1)) +
+           v[2] * (O_(0, 1) * O_(1, 2) - O_(1, 1) * O_(0, 2))) +
+      dinv * v[1] *
+          (O_(0, 0) * (v[1] * O_(2, 2) - O_(1, 2) * v[2]) -
+           O_(1, 0) * (v[0] * O_(2, 2) - O_(0, 2) * v[2]) +
+           O_(2, 0) * (v[0] * O_(1, 2) - v[1] * O_(0, 2))) +
+      dinv * v[2] *
+          (O_(0, 0) * (O_(1, 1) * v[2] - v[1] * O_(2, 1)) -
+           O_(1, 0) * (O_(0, 1) * v[2] - v[0] * O_(2, 1)) +
+           O_(2, 0) * (O_(0, 1) * v[1] - O_(1, 1) * v[0]));
+#undef O_
+  return d;
+}
+
+struct Rs3d3dResult {
+  int status, n_inliers;
+  double t[3], info[9];
+};
+
+// The voting runs as three launches so that the O(n^2) coherence tests of all streams spread over
+// the whole GPU instead of one workgroup per stream:
+//   prepare : matches, float64 relative translations / covariances and their float32 copies
+//   tiles   : one wavefront per 64 x 64 tile (i-block, j-block >= i-block) of the pair matrix
+//   finish  : first largest coherent set, its members, information-weighted translation
+// relv / relc: [n][3] / [n][9] float64, votef: [n][12] float32, cnt: [n] coherent-set sizes.
+template <typename GetMatch>
+__device__ void rs_vote_prepare(const KParams& P, int n, const double* R, GetMatch get, double* relv,
+                                double* relc, float* votef, int* cnt) {
+  for (int m = threadIdx.x; m < n; m += RS_T) {
+    double rl[3], rp[3], cl[3], cp[3];  // (uL, uR, v), 3-D point of ref / cur
+    get(m, rl, rp, cl, cp);
+    double f_ref[3], cov_ref[9], R_f_cur[3], cov_R_cur[9];
+    rs_point3_cov(P, rl[0], rl[1], rl[2], rp, nullptr, f_ref, cov_ref);
+    rs_point3_cov(P, cl[0], cl[1], cl[2], cp, R, R_f_cur, cov_R_cur);
+    for (int k = 0; k < 3; k++) {
+      const double v = f_ref[k] - R_f_cur[k];
+      relv[3 * (size_t)m + k] = v;
+      votef[12 * (size_t)m + k] = (float)v;
+    }
+    for (int k = 0; k < 9; k++) {
+      const double c = cov_R_cur[k] + cov_ref[k];
+      relc[9 * (size_t)m + k] = c;
+      votef[12 * (size_t)m + 3 + k] = (float)c;
+    }
+    cnt[m] = 1;  // a vector is coherent with itself
+  }
+}
+
+// one wavefront: rows ib*64.., columns jb*64.. (jb >= ib); lane = row, the column is uniform
+__device__ void rs_vote_tile(const KParams& P, int n, int tile, const float* __restrict__ votef,
+                             int* cnt) {
+  // tile -> (ib, jb) of the upper triangle, row-major
+  const int nb = (n + 63) >> 6;
+  int ib = 0, rem = tile;
+  while (ib < nb && rem >= nb - ib) {
+    rem -= nb - ib;
+    ib++;
+  }
+  if (ib >= nb) return;
+  const int jb = ib + rem;
+  const int lane = threadIdx.x;
+  const int i = ib * 64 + lane;
+  const bool row = i < n;
+  float a[12];
+  for (int k = 0; k < 12; k++) a[k] = row ? votef[12 * (size_t)i + k] : 0.f;
+  const float thr = P.ransac_thr_stereo;
+  const int j0 = jb * 64, j1 = min(n, j0 + 64);
+  int mine = 0;
+  for (int j = j0; j < j1; j++) {
+    float b[12];
+    for (int k = 0; k < 12; k++) b[k] = votef[12 * (size_t)j + k];  // uniform address
+    const bool coh = row && j > i && rs_mahalanobis(a, b) < thr;
+    const unsigned long long m = __ballot(coh);
+    if (m) {
+      if (coh) mine++;
+      if (lane == 0) atomicAdd(&cnt[j], __popcll(m));
+    }
+  }
+  if (mine) atomicAdd(&cnt[i], mine);
+}
+
+__device__ Rs3d3dResult rs_vote_finish(const KParams& P, int n, const double* relv, const double* relc,
+                                       const float* votef, double* acc, const int* cnt, int* wave_tot,
+                                       int* inliers) {
+  const int tid = threadIdx.x;
+  __shared__ int sh_best, sh_cnt;
+  __shared__ double sh_sum[12];
+  __shared__ unsigned long long sh_key[RS_T / 64];
+  Rs3d3dResult res;
+  res.status = TRK_INVALID;
+  res.n_inliers = 0;
+  for (int i = 0; i < 3; i++) res.t[i] = 0;
+  for (int i = 0; i < 9; i++) res.info[i] = 0;
+  const float thr = P.ransac_thr_stereo;
+  // first index with the largest coherent set
+  int best_c = 0, best_i = INT_MAX;
+  for (int i = tid; i < n; i += RS_T) {
+    const int c = cnt[i];
+    if (c > best_c) {  // ascending i per thread: strict > keeps the first
+      best_c = c;
+      best_i = i;
+    }
+  }
+  unsigned long long key = ((unsigned long long)(unsigned)best_c << 32) | (unsigned)(INT_MAX - best_i);
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off);
+    key = o > key ? o : key;
+  }
+  if ((tid & 63) == 0) sh_key[tid >> 6] = key;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long k2 = sh_key[0];
+    for (int w = 1; w < RS_T / 64; w++) k2 = sh_key[w] > k2 ? sh_key[w] : k2;
+    sh_best = (int)(k2 >> 32) >= 2 ? INT_MAX - (int)(unsigned)(k2 & 0xffffffffu) : -1;
+    sh_cnt = 0;
+  }
+  __syncthreads();
+  const int best = sh_best;
+  if (n == 0 || best < 0) return res;  // maxCoherentSetSize < 2
+  // members of the winning coherent set, ascending (= the sorted inlier list)
+  {
+    float a[12];
+    for (int k = 0; k < 12; k++) a[k] = votef[12 * (size_t)best + k];
+    for (int base = 0; base < n; base += RS_T) {
+      const int j = base + tid;
+      bool in = false;
+      if (j < n) {
+        if (j == best) {
+          in = true;
+        } else {
+          float b[12];
+          for (int k = 0; k < 12; k++) b[k] = votef[12 * (size_t)j + k];
+          in = (j > best ? rs_mahalanobis(a, b) : rs_mahalanobis(b, a)) < thr;
+        }
+      }
+      int tot;
+      const int pos = rs_scan(in ? 1 : 0, wave_tot, &tot);
+      const int off = sh_cnt;
+      if (in) inliers[off + pos] = j;
+      __syncthreads();
+      if (tid == 0) sh_cnt = off + tot;
+      __syncthreads();
+    }
+  }
+  const int n_in = sh_cnt;
+  __syncthreads();
+  res.n_inliers = n_in;
+  res.status = n_in < P.min_stereo_inliers ? TRK_FEW_MATCHES : TRK_VALID;
+  // t = (sum_i info_i)^-1 sum_i info_i v_i, summed in inlier order (Tracker.cpp:584-592): the terms
+  // are computed in parallel, staged in LDS component-major, and twelve lanes walk one chain each
+  constexpr int CH = 256;  // inliers per LDS chunk
+  __shared__ double sh_terms[12][CH + 1];
+  double sum = 0.0;
+  for (int base = 0; base < n_in; base += CH) {
+    const int q = base + tid;
+    if (q < n_in) {
+      const int id = inliers[q];
+      double info[9], iv[3];
+      rs_inverse3(relc + 9 * (size_t)id, info);
+      rs_matvec3(info, relv + 3 * (size_t)id, iv);
+      for (int k = 0; k < 3; k++) sh_terms[k][tid] = iv[k];
+      for (int k = 0; k < 9; k++) sh_terms[3 + k][tid] = info[k];
+    }
+    __syncthreads();
+    if (tid < 12) {
+      const int m = min(CH, n_in - base);
+      for (int q2 = 0; q2 < m; q2++) sum = sum + sh_terms[tid][q2];
+    }
+    __syncthreads();
+  }
+  if (tid < 12) sh_sum[tid] = sum;
+  __syncthreads();
+  double total[9], inv_total[9], tsum[3];
+  for (int k = 0; k < 3; k++) tsum[k] = sh_sum[k];
+  for (int k = 0; k < 9; k++) total[k] = sh_sum[3 + k];
+  rs_inverse3(total, inv_total);
+  rs_matvec3(inv_total, tsum, res.t);
+  for (int k = 0; k < 9; k++) res.info[k] = total[k];
+  __syncthreads();
+  return res;
+}
+
+// ---- front-end: the three launches over all streams ------------------------------------------------
+__global__ __launch_bounds__(RS_T) void stereo_ransac_prepare_kernel(KParams P, Tables T, FrameTab K,
+                                                                     FrameTab LKF, StereoTab ST,
+                                                                     StereoTab LST, StreamState S,
+                                                                     RansacScratch RS) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int flags = S.flags[s];
+  if (tid == 0) RS.n_matches[s] = -1;
+  if (!(flags & FLAG_KEYFRAME) || (flags & FLAG_FIRST) || !P.use_ransac) return;
+  if (!P.use_stereo_tracking) return;  // status stays INVALID (StereoVisionImuFrontend.cpp:380-385)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot[RS_T / 64];
+  const RsLds L = rs_carve(lds_raw, P.kcap);
+  const size_t so = (size_t)s * P.kcap;
+  const double* R = S.kf_R_cur + (size_t)s * 9;
+  const bool imu_ok = !rs_rot_is_identity(R);
+  if (!(P.ransac_1pt_stereo && imu_ok)) {  // 3-point problem: not implemented; zero information
+    if (tid < 9) S.trk_info[9 * (size_t)s + tid] = 0.0;
+    return;
+  }
+  int2* matches = RS.matches + so;
+  const int n = rs_build_matches(P, K, LKF, ST.right_status, LST.right_status, s, L.ids, L.idx,
+                                 wave_tot, matches);
+  double Rl[9];
+  for (int i = 0; i < 9; i++) Rl[i] = R[i];
+  auto get = [&](int m, double* rl, double* rp, double* cl, double* cp) {
+    const int2 mm = matches[m];
+    const float2 a = LST.left_rect[so + mm.x], b = ST.left_rect[so + mm.y];
+    rl[0] = (double)a.x;
+    rl[1] = (double)LST.right_rect[so + mm.x].x;
+    rl[2] = (double)a.y;
+    cl[0] = (double)b.x;
+    cl[1] = (double)ST.right_rect[so + mm.y].x;
+    cl[2] = (double)b.y;
+    for (int c = 0; c < 3; c++) {
+      rp[c] = LST.kp3d[(so + mm.x) * 3 + c];
+      cp[c] = ST.kp3d[(so + mm.y) * 3 + c];
+    }
+  };
+  rs_vote_prepare(P, n, Rl, get, RS.f_ref + so * 3, RS.relc + so * 9, RS.votef + so * 12, RS.cnt + so);
+  if (tid == 0) RS.n_matches[s] = n;
+}
+
+__global__ __launch_bounds__(64) void stereo_ransac_tile_kernel(KParams P, RansacScratch RS) {
+  const int s = blockIdx.y;
+  const int n = RS.n_matches[s];
+  if (n <= 1) return;
+  const size_t so = (size_t)s * P.kcap;
+  rs_vote_tile(P, n, blockIdx.x, RS.votef + so * 12, RS.cnt + so);
+}
+
+__global__ __launch_bounds__(RS_T) void stereo_ransac_finish_kernel(KParams P, StreamState S,
+                                                                    RansacScratch RS) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int n = RS.n_matches[s];
+  if (n < 0) return;
+  __shared__ int wave_tot[RS_T / 64];
+  const size_t so = (size_t)s * P.kcap;
+  Rs3d3dResult res = rs_vote_finish(P, n, RS.f_ref + so * 3, RS.relc + so * 9, RS.votef + so * 12,
+                                    RS.acc + so * 12, RS.cnt + so, wave_tot, RS.inliers + so);
+  if (tid == 0) {
+    S.trk_status[2 * (size_t)s + 1] = res.status;
+    if (res.status != TRK_INVALID) {
+      int* cn = S.trk_counts + 6 * (size_t)s;
+      cn[3] = n;
+      cn[4] = res.n_inliers;
+    }
+    if (res.status == TRK_VALID) {
+      const double* R = S.kf_R_cur + (size_t)s * 9;
+      double* pose = S.trk_pose + 24 * (size_t)s + 12;
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) pose[r * 4 + c] = R[r * 3 + c];
+        pose[r * 4 + 3] = res.t[r];
+      }
+    }
+  }
+  if (tid < 9) S.trk_info[9 * (size_t)s + tid] = res.info[tid];
+}
+
+static int rs_n_tiles(int max_matches) {
+  const int nb = (max_matches + 63) / 64;
+  return nb * (nb + 1) / 2;
+}
+
+void launch_stereo_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
+                          const StereoTab& ST, const StereoTab& LST, const StreamState& S,
+                          const RansacScratch& RS, int max_matches, hipStream_t st) {
+  hipLaunchKernelGGL(stereo_ransac_prepare_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T,
+                     k, lkf, ST, LST, S, RS);
+  hipLaunchKernelGGL(stereo_ransac_tile_kernel, dim3(rs_n_tiles(max_matches), P.B), dim3(64), 0, st, P, RS);
+  hipLaunchKernelGGL(stereo_ransac_finish_kernel, dim3(P.B), dim3(RS_T), 0, st, P, S, RS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// component API: the two problems on caller-supplied matches
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_T) void ransac_2d2d_points_kernel(KParams P, Tables T,
+                                                                  const double* f_ref,
+                                                                  const double* f_cur, int n,
+                                                                  const double* R, RansacScratch RS,
+                                                                  int* out_status, double* out_pose,
+                                                                  int* out_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot[RS_T / 64];
+  const RsLds L = rs_carve(lds_raw, P.kcap);
+  double Rl[9];
+  for (int i = 0; i < 9; i++) Rl[i] = R[i];
+  Rs2d2dResult res = rs_ransac_2d2d(P, T, f_ref, f_cur, n, Rl, L.work, wave_tot, RS.inliers);
+  if (threadIdx.x == 0) {
+    out_status[0] = res.status;
+    out_counts[0] = n;
+    out_counts[1] = res.n_inliers;
+    out_counts[2] = res.iterations;
+    for (int i = 0; i < 12; i++) out_pose[i] = res.pose[i];
+    RS.n_inliers[0] = res.n_inliers;
+  }
+}
+
+void launch_ransac_2d2d_points(const KParams& P, const Tables& T, const double* f_ref,
+                               const double* f_cur, int n, const double* R, const RansacScratch& RS,
+                               int* out_status, double* out_pose, int* out_counts, hipStream_t st) {
+  hipLaunchKernelGGL(ransac_2d2d_points_kernel, dim3(1), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T,
+                     f_ref, f_cur, n, R, RS, out_status, out_pose, out_counts);
+}
+
+__global__ __launch_bounds__(RS_T) void ransac_3d3d_prepare_kernel(
+    KParams P, const float* ref_left, const float* ref_right_x, const double* ref_p3,
+    const float* cur_left, const float* cur_right_x, const double* cur_p3, int n, const double* R,
+    RansacScratch RS) {
+  double Rl[9];
+  for (int i = 0; i < 9; i++) Rl[i] = R[i];
+  auto get = [&](int m, double* rl, double* rp, double* cl, double* cp) {
+    rl[0] = (double)ref_left[2 * m];
+    rl[1] = (double)ref_right_x[m];
+    rl[2] = (double)ref_left[2 * m + 1];
+    cl[0] = (double)cur_left[2 * m];
+    cl[1] = (double)cur_right_x[m];
+    cl[2] = (double)cur_left[2 * m + 1];
+    for (int c = 0; c < 3; c++) {
+      rp[c] = ref_p3[3 * (size_t)m + c];
+      cp[c] = cur_p3[3 * (size_t)m + c];
+    }
+  };
+  rs_vote_prepare(P, n, Rl, get, RS.f_ref, RS.relc, RS.votef, RS.cnt);
+  if (threadIdx.x == 0) RS.n_matches[0] = n;
+}
+
+__global__ __launch_bounds__(RS_T) void ransac_3d3d_finish_kernel(KParams P, int n, const double* R,
+                                                                  RansacScratch RS, int* out_status,
+                                                                  double* out_pose, double* out_info,
+                                                                  int* out_counts) {
+  __shared__ int wave_tot[RS_T / 64];
+  Rs3d3dResult res = rs_vote_finish(P, n, RS.f_ref, RS.relc, RS.votef, RS.acc, RS.cnt, wave_tot, RS.inliers);
+  if (threadIdx.x == 0) {
+    out_status[0] = res.status;
+    out_counts[0] = n;
+    out_counts[1] = res.n_inliers;
+    out_counts[2] = 1;
+    RS.n_inliers[0] = res.n_inliers;
+    for (int i = 0; i < 12; i++) out_pose[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    if (res.status != TRK_INVALID)
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) out_pose[r * 4 + c] = R[r * 3 + c];
+        out_pose[r * 4 + 3] = res.t[r];
+      }
+    for (int i = 0; i < 9; i++) out_info[i] = res.info[i];
+  }
+}
+
+void launch_ransac_3d3d_points(const KParams& P, const Tables& T, const float* ref_left,
+                               const float* ref_right_x, const double* ref_p3, const float* cur_left,
+                               const float* cur_right_x, const double* cur_p3, int n, const double* R,
+                               const RansacScratch& RS, int* out_status, double* out_pose,
+                               double* out_info, int* out_counts, hipStream_t st) {
+  hipLaunchKernelGGL(ransac_3d3d_prepare_kernel, dim3(1), dim3(RS_T), 0, st, P, ref_left, ref_right_x,
+                     ref_p3, cur_left, cur_right_x, cur_p3, n, R, RS);
+  if (n > 1)
+    hipLaunchKernelGGL(stereo_ransac_tile_kernel, dim3(rs_n_tiles(n), 1), dim3(64), 0, st, P, RS);
+  hipLaunchKernelGGL(ransac_3d3d_finish_kernel, dim3(1), dim3(RS_T), 0, st, P, n, R, RS, out_status,
+                     out_pose, out_info, out_counts);
+}
+
+}  // namespace kvfe

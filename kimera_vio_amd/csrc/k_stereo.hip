@@ -434,32 +434,73 @@ void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned 
 // end of frame
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab K, FrameTab LKF,
-                                                            StereoTab ST, StreamState S) {
+                                                            StereoTab ST, StereoTab LST,
+                                                            StreamState S) {
   const int s = blockIdx.x, tid = threadIdx.x;
   const size_t so = (size_t)s * P.kcap;
   const int flags = S.flags[s];
   const int n = K.count[s];
+  __shared__ int wave_tot[4];
+  __shared__ int sh_off;
   if (flags & FLAG_KEYFRAME) {
-    // getSmartStereoMeasurements: every landmark of a frame is valid here (ids are never -1
-    // in the current frame), so the measurement list is the keypoint list.
     const bool first = (flags & FLAG_FIRST) != 0;  // bootstrapSpinStereo returns no measurements
-    for (int i = tid; i < n; i += 256) {
-      // stereoFrame_lkf_ = stereoFrame_k_
-      LKF.kp[so + i] = K.kp[so + i];
-      LKF.lmk[so + i] = K.lmk[so + i];
-      if (first) continue;
-      const float2 l = ST.left_rect[so + i];
-      double uR = __longlong_as_double(0x7ff8000000000000LL);  // quiet NaN
-      if (P.use_stereo_tracking && ST.right_status[so + i] == 0) uR = (double)ST.right_rect[so + i].x;
-      S.meas_lmk[so + i] = K.lmk[so + i];
-      S.meas_uLuRv[(so + i) * 3] = (double)l.x;
-      S.meas_uLuRv[(so + i) * 3 + 1] = uR;
-      S.meas_uLuRv[(so + i) * 3 + 2] = (double)l.y;
+    if (tid == 0) sh_off = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+      const int i = base + tid;
+      const bool in = i < n;
+      long long lmk = -1;
+      if (in) {
+        // stereoFrame_lkf_ = stereoFrame_k_ (what the next keyframe decision and the next
+        // geometric outlier rejection read of it)
+        lmk = K.lmk[so + i];
+        LKF.kp[so + i] = K.kp[so + i];
+        LKF.lmk[so + i] = lmk;
+        if (P.use_ransac) {
+          for (int c = 0; c < 3; c++) {
+            LKF.versor[(so + i) * 3 + c] = K.versor[(so + i) * 3 + c];
+            LST.kp3d[(so + i) * 3 + c] = ST.kp3d[(so + i) * 3 + c];
+          }
+          LST.left_rect[so + i] = ST.left_rect[so + i];
+          LST.right_rect[so + i] = ST.right_rect[so + i];
+          LST.right_status[so + i] = ST.right_status[so + i];
+        }
+      }
+      // getSmartStereoMeasurements (StereoVisionImuFrontend.cpp:485-531): landmarks that geometric
+      // outlier rejection set to -1 carry no measurement, the others keep their order
+      const bool meas = in && !first && lmk != -1;
+      const int lane = tid & 63, wv = tid >> 6;
+      int inc = meas ? 1 : 0;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+      }
+      if (lane == 63) wave_tot[wv] = inc;
+      __syncthreads();
+      int wbase = 0, tot = 0;
+      for (int w = 0; w < 4; w++) {
+        if (w < wv) wbase += wave_tot[w];
+        tot += wave_tot[w];
+      }
+      const int off0 = sh_off;
+      if (meas) {
+        const size_t o = so + off0 + wbase + inc - 1;
+        const float2 l = ST.left_rect[so + i];
+        double uR = __longlong_as_double(0x7ff8000000000000LL);  // quiet NaN
+        if (P.use_stereo_tracking && ST.right_status[so + i] == 0) uR = (double)ST.right_rect[so + i].x;
+        S.meas_lmk[o] = lmk;
+        S.meas_uLuRv[o * 3] = (double)l.x;
+        S.meas_uLuRv[o * 3 + 1] = uR;
+        S.meas_uLuRv[o * 3 + 2] = (double)l.y;
+      }
+      __syncthreads();
+      if (tid == 0) sh_off = off0 + tot;
+      __syncthreads();
     }
     if (tid == 0) {
       LKF.count[s] = n;
       LKF.timestamp[s] = K.timestamp[s];
-      S.n_meas[s] = first ? 0 : n;
+      S.n_meas[s] = sh_off;
     }
     if (tid < 9) S.kf_R_ref[(size_t)s * 9 + tid] = (tid % 4 == 0) ? 1.0 : 0.0;
   } else {
@@ -476,8 +517,9 @@ __global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab 
 }
 
 void launch_step_finalize(const KParams& P, const FrameTab& k, const FrameTab& lkf,
-                          const StereoTab& ST, const StreamState& S, hipStream_t st) {
-  hipLaunchKernelGGL(step_finalize_kernel, dim3(P.B), dim3(256), 0, st, P, k, lkf, ST, S);
+                          const StereoTab& ST, const StereoTab& LST, const StreamState& S,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(step_finalize_kernel, dim3(P.B), dim3(256), 0, st, P, k, lkf, ST, LST, S);
 }
 
 }  // namespace kvfe

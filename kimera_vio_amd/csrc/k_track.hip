@@ -767,13 +767,43 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
     for (int i = 0; i < 9; i++) Hs[i] = H[i];
   }
   __syncthreads();
+  // Tracker.cpp:103-112: only keypoints with a valid landmark are tracked (geometric outlier
+  // rejection leaves landmark -1 entries in a keyframe); src_idx maps point -> index in frame k-1
   const int n = KM1.count[s];
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float2 p = KM1.kp[(size_t)s * P.kcap + i];
-    lk.prev_pts[(size_t)s * P.kcap + i] = p;
-    lk.next_pts[(size_t)s * P.kcap + i] = use_h ? predict_point(Hs, p, P.W, P.H) : p;
+  const size_t so = (size_t)s * P.kcap;
+  __shared__ int wave_tot[4];
+  __shared__ int sh_off;
+  if (threadIdx.x == 0) sh_off = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + threadIdx.x;
+    const bool valid = i < n && KM1.lmk[so + i] != -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = valid ? 1 : 0;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int w = 0; w < 4; w++) {
+      if (w < wv) wbase += wave_tot[w];
+      tot += wave_tot[w];
+    }
+    const int off0 = sh_off;
+    if (valid) {
+      const int o = off0 + wbase + inc - 1;
+      const float2 p = KM1.kp[so + i];
+      lk.prev_pts[so + o] = p;
+      lk.next_pts[so + o] = use_h ? predict_point(Hs, p, P.W, P.H) : p;
+      lk.src_idx[so + o] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh_off = off0 + tot;
+    __syncthreads();
   }
-  if (threadIdx.x == 0) lk.npts[s] = n;
+  if (threadIdx.x == 0) lk.npts[s] = sh_off;
 }
 
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
@@ -857,7 +887,8 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
   for (int base = 0; base < n; base += TF_T) {
     const int i = base + tid;
     bool keep = false;
-    if (i < n) keep = lk.status[so + i] && !(KM1.age[so + i] > P.max_age);
+    const int src = i < n ? lk.src_idx[so + i] : 0;
+    if (i < n) keep = lk.status[so + i] && !(KM1.age[so + src] > P.max_age);
     int tot;
     const int pos = block_scan256(keep ? 1 : 0, wave_tot, &tot);
     const int off = sh_cnt;
@@ -865,8 +896,8 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
       const size_t o = so + off + pos;
       const float2 p = lk.next_pts[so + i];
       K.kp[o] = p;
-      K.lmk[o] = KM1.lmk[so + i];
-      K.age[o] = KM1.age[so + i];
+      K.lmk[o] = KM1.lmk[so + src];
+      K.age[o] = KM1.age[so + src];
       double v[3];
       bearing_vector(T.und_left_R, p.x, p.y, v);
       K.versor[o * 3] = v[0];
@@ -892,8 +923,28 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
   // ---- shouldBeKeyframe (VisionImuFrontend.cpp:175-232) ----------------------------------------
   // findMatchingKeypoints: landmark ids of a frame are strictly increasing (tracked ids keep their
   // order, new ids are larger than every earlier id), so the std::map lookup is a binary search.
-  const int nl = LKF.count[s];
-  for (int i = tid; i < nl; i += TF_T) lkf_ids[i] = LKF.lmk[so + i];
+  // (the last keyframe may hold landmark -1 entries left by its outlier rejection: they are
+  // squeezed out of the search list, lkf_pos keeps the position of each remaining id)
+  int* lkf_pos = reinterpret_cast<int*>(disp + P.kcap);
+  const int nl_all = LKF.count[s];
+  if (tid == 0) sh_cnt = 0;
+  __syncthreads();
+  for (int base = 0; base < nl_all; base += TF_T) {
+    const int j = base + tid;
+    long long id = -1;
+    if (j < nl_all) id = LKF.lmk[so + j];
+    int tot;
+    const int pos = block_scan256(id != -1 ? 1 : 0, wave_tot, &tot);
+    const int off = sh_cnt;
+    if (id != -1) {
+      lkf_ids[off + pos] = id;
+      lkf_pos[off + pos] = j;
+    }
+    __syncthreads();
+    if (tid == 0) sh_cnt = off + tot;
+    __syncthreads();
+  }
+  const int nl = sh_cnt;
   if (tid == 0) sh_m = 0;
   __syncthreads();
   for (int i = tid; i < nk; i += TF_T) {
@@ -903,7 +954,7 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
       const int mid = (lo + hi) >> 1;
       const long long v = lkf_ids[mid];
       if (v == id) {
-        j = mid;
+        j = lkf_pos[mid];
         break;
       }
       if (v < id)
@@ -977,7 +1028,9 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
     const bool max_time_elapsed = (double)kf_diff_ns >= P.max_kf_ns;
     const bool nr_features_low = (long long)nk <= P.min_features;
     const bool is_disparity_low = disparity < P.disparity_thr;
-    const bool disparity_low_first_time = is_disparity_low;  // status is never LOW_DISPARITY w/o RANSAC
+    // kfTrackingStatus_mono_ of the last keyframe (LOW_DISPARITY only arises with useRANSAC)
+    const bool disparity_low_first_time =
+        is_disparity_low && !(S.trk_status[2 * (size_t)s] == TRK_LOW_DISPARITY);
     const bool enough_disparity = !is_disparity_low;
     const bool max_disparity_reached = disparity > P.max_disp_lkf;
     const bool disparity_flipped = (enough_disparity || disparity_low_first_time) && min_time_elapsed;
@@ -996,7 +1049,7 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
 void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
                            const FrameTab& lkf, const FrameTab& k, const StreamState& S,
                            const LkScratch& lk, hipStream_t st) {
-  const size_t lds = (sizeof(long long) + sizeof(float)) * (size_t)P.kcap;
+  const size_t lds = (sizeof(long long) + sizeof(float) + sizeof(int)) * (size_t)P.kcap;
   hipLaunchKernelGGL(track_finalize_kernel, dim3(P.B), dim3(TF_T), lds, st, P, T, km1, lkf, k, S,
                      lk);
 }

@@ -36,11 +36,14 @@ enum Stage {
   ST_STEREO,
   ST_STEREO_NEW,
   ST_FINALIZE,
+  ST_RANSAC_MONO,
+  ST_RANSAC_STEREO,
   ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "mineig_localmax",
                                      "gftt_select", "subpix_append", "rectify", "stereo_match",
-                                     "stereo_match_new", "step_finalize"};
+                                     "stereo_match_new", "step_finalize", "ransac_mono",
+                                     "ransac_stereo"};
 
 struct Buffers {  // everything that scales with the number of streams
   int B = 0;
@@ -51,6 +54,8 @@ struct Buffers {  // everything that scales with the number of streams
   unsigned char* user_mask = nullptr;
   FrameTab ft[3];
   StereoTab st;
+  StereoTab lst;  // stereo tables of the last keyframe (geometric outlier rejection reads them)
+  RansacScratch rs;
   StreamState ss;
   DetectScratch ds;
   LkScratch lk;
@@ -141,6 +146,20 @@ kvfe_status dalloc(kvfe_ctx* c, T** p, size_t n, bool zero = true) {
     if (_s != KVFE_OK) return _s;      \
   } while (0)
 
+// TrackerStatusSummary(): both statuses INVALID, identity poses, zero information
+kvfe_status reset_tracker_status(kvfe_ctx* c, Buffers& b) {
+  const size_t B = b.B;
+  std::vector<int> st(B * 2, TRK_INVALID);
+  std::vector<double> pose(B * 24, 0.0);
+  for (size_t i = 0; i < B * 2; i++) pose[i * 12] = pose[i * 12 + 5] = pose[i * 12 + 10] = 1.0;
+  HIPCHK(c, hipMemcpyAsync(b.ss.trk_status, st.data(), sizeof(int) * st.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b.ss.trk_pose, pose.data(), sizeof(double) * pose.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(b.ss.trk_info, 0, sizeof(double) * 9 * B, c->stream));
+  HIPCHK(c, hipMemsetAsync(b.ss.trk_counts, 0, sizeof(int) * 6 * B, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+  return KVFE_OK;
+}
+
 kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   b.B = P.B;
   const size_t N = (size_t)P.W * P.H, B = P.B, K = (size_t)P.kcap * B;
@@ -165,6 +184,25 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.st.depth, K));
   TRY(dalloc(c, &b.st.right_kp, K));
   TRY(dalloc(c, &b.st.kp3d, K * 3));
+  std::memset(&b.lst, 0, sizeof(b.lst));
+  TRY(dalloc(c, &b.lst.left_rect, K));
+  TRY(dalloc(c, &b.lst.right_rect, K));
+  TRY(dalloc(c, &b.lst.right_status, K));
+  TRY(dalloc(c, &b.lst.kp3d, K * 3));
+  TRY(dalloc(c, &b.rs.matches, K));
+  TRY(dalloc(c, &b.rs.f_ref, K * 3));
+  TRY(dalloc(c, &b.rs.f_cur, K * 3));
+  TRY(dalloc(c, &b.rs.relc, K * 9));
+  TRY(dalloc(c, &b.rs.votef, K * 12));
+  TRY(dalloc(c, &b.rs.acc, K * 12));
+  TRY(dalloc(c, &b.rs.inliers, K));
+  TRY(dalloc(c, &b.rs.n_inliers, B));
+  TRY(dalloc(c, &b.rs.cnt, K));
+  TRY(dalloc(c, &b.rs.n_matches, B));
+  TRY(dalloc(c, &b.ss.trk_status, B * 2));
+  TRY(dalloc(c, &b.ss.trk_pose, B * 24));
+  TRY(dalloc(c, &b.ss.trk_info, B * 9));
+  TRY(dalloc(c, &b.ss.trk_counts, B * 6));
   TRY(dalloc(c, &b.ss.flags, B));
   TRY(dalloc(c, &b.ss.n_tracked, B));
   TRY(dalloc(c, &b.ss.n_detected, B));
@@ -204,6 +242,8 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
+  TRY(dalloc(c, &b.lk.src_idx, K));
+  TRY(reset_tracker_status(c, b));
   // keyframe_R_ref_frame_ = identity
   std::vector<double> eye(B * 9, 0.0);
   for (size_t s = 0; s < B; s++) eye[s * 9] = eye[s * 9 + 4] = eye[s * 9 + 8] = 1.0;
@@ -246,6 +286,39 @@ void subpix_mask_table(int win, int zero_zone, std::vector<float>& m) {
   }
 }
 
+// std::mt19937 (ISO C++ [rand.eng.mers]) + libstdc++'s uniform_int_distribution<int>(0, INT_MAX):
+// KVFE_RNG_LIBSTDCXX_PRE11 redraws while the output is >= 2^31, KVFE_RNG_LIBSTDCXX_11 shifts it right
+void ransac_rnd_stream(int policy, int n, int* out) {
+  uint32_t mt[624];
+  mt[0] = 12345u;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int idx = 624;
+  auto next = [&]() {
+    if (idx >= 624) {
+      for (int k = 0; k < 624; k++) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  };
+  for (int i = 0; i < n; i++) {
+    uint32_t r = next();
+    if (policy == KVFE_RNG_LIBSTDCXX_11) {
+      out[i] = (int)(r >> 1);
+    } else {
+      while (r >= 0x80000000u) r = next();
+      out[i] = (int)r;
+    }
+  }
+}
+
 void matx33f_inv(const float* a, float* b) {  // cv::Matx33f::inv() (direct formula, float)
   auto A = [&](int r, int c) { return a[r * 3 + c]; };
   float d = A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) -
@@ -273,9 +346,23 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
   if (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height)
     return fail("left/right image sizes differ", KVFE_ERR_INVALID_ARG);
   if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
-  if (p.use_ransac)
-    return fail("useRANSAC=1: geometric outlier rejection is outside this library (set 0)",
-                KVFE_ERR_UNSUPPORTED);
+  if (p.use_ransac) {
+    const kvfe_tracker_params& tr = p.tracker;
+    if (tr.ransac_randomize)
+      return fail("ransac_randomize=1 (time-seeded sampling) is not reproducible: set 0", KVFE_ERR_UNSUPPORTED);
+    if (!tr.ransac_use_2point_mono)
+      return fail("ransac_use_2point_mono=0 selects the 5-point problem, which is not implemented",
+                  KVFE_ERR_UNSUPPORTED);
+    if (p.use_stereo_tracking && !tr.ransac_use_1point_stereo)
+      return fail("ransac_use_1point_stereo=0 selects the 3-point problem, which is not implemented",
+                  KVFE_ERR_UNSUPPORTED);
+    if (tr.ransac_max_iterations < 1 || tr.ransac_max_iterations > 1000)
+      return fail("ransac_max_iterations out of range [1,1000]", KVFE_ERR_INVALID_ARG);
+    if (!(tr.ransac_probability > 0.0 && tr.ransac_probability < 1.0))
+      return fail("ransac_probability must be in (0,1)", KVFE_ERR_INVALID_ARG);
+    if (tr.ransac_rng_policy != KVFE_RNG_LIBSTDCXX_PRE11 && tr.ransac_rng_policy != KVFE_RNG_LIBSTDCXX_11)
+      return fail("bad ransac_rng_policy", KVFE_ERR_INVALID_ARG);
+  }
   const kvfe_detector_params& d = p.detector;
   if (d.feature_detector_type != KVFE_DET_GFTT)
     return fail("only the GFTT detector is implemented", KVFE_ERR_UNSUPPORTED);
@@ -366,6 +453,19 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.max_kf_ns = p.max_intra_keyframe_time_ns;
   P.max_disp_lkf = p.max_disparity_since_lkf;
   P.min_features = p.min_number_features;
+  P.use_ransac = p.use_ransac ? 1 : 0;
+  P.ransac_2pt_mono = t.ransac_use_2point_mono ? 1 : 0;
+  P.ransac_1pt_stereo = t.ransac_use_1point_stereo ? 1 : 0;
+  P.ransac_max_iters = t.ransac_max_iterations;
+  P.min_mono_inliers = t.min_nr_mono_inliers;
+  P.min_stereo_inliers = t.min_nr_stereo_inliers;
+  P.ransac_thr_mono = t.ransac_threshold_mono;
+  P.ransac_probability = t.ransac_probability;
+  P.ransac_thr_stereo = (float)t.ransac_threshold_stereo;
+  // gtsam::Cal3_S2Stereo(P1) of StereoCamera.cpp:75-83
+  P.fy_rect = c->rect.P1[5];
+  P.cx_rect = c->rect.P1[2];
+  P.cy_rect = c->rect.P1[6];
   // pyramid geometry (cv::buildOpticalFlowPyramid: stop when a level is <= the window)
   int w = P.W, h = P.H, off = 0, nl = 0;
   for (int l = 0; l <= t.klt_max_level && l < MAX_LEVELS; l++) {
@@ -465,6 +565,18 @@ kvfe_status build_tables(kvfe_ctx* c) {
     HIPCHK(c, hipMemcpy(doff, off.data(), sizeof(unsigned int) * off.size(), hipMemcpyHostToDevice));
     T.sortidx = dt;
     T.sortidx_off = doff;
+  }
+  // opengv::sac::SampleConsensusProblem::rnd(): std::mt19937 seeded with 12345 (randomSeed = false)
+  // drawn through std::uniform_int_distribution<int>(0, INT_MAX) -- a fixed stream
+  {
+    const int n = 4096;
+    std::vector<int> r(n);
+    ransac_rnd_stream(cfg.params.tracker.ransac_rng_policy, n, r.data());
+    int* d;
+    TRY(dalloc(c, &d, n, false));
+    HIPCHK(c, hipMemcpy(d, r.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    T.ransac_rnd = d;
+    T.n_ransac_rnd = n;
   }
   // predictor constants: K_ (Matx33f) and K_.inv()
   {
@@ -569,6 +681,11 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
     c->ev_tracked_valid = true;
   }
+  // keyframes: mono geometric outlier rejection before detection (it frees landmarks, so more
+  // corners are extracted, StereoVisionImuFrontend.cpp:349-363,413-417)
+  prof_begin(c, ST_RANSAC_MONO, st);
+  launch_mono_ransac(P, c->T, K, LKF, b.ss, b.rs, st);
+  prof_end(c, ST_RANSAC_MONO, st);
   prof_begin(c, ST_MINEIG, st);
   launch_mineig(P, c->T, left, row_stride, img_stride, nullptr, K, b.ss, b.ds, 1, st);
   prof_end(c, ST_MINEIG, st);
@@ -592,12 +709,16 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_STEREO, st);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, st);
   prof_end(c, ST_STEREO, st);
+  // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387)
+  prof_begin(c, ST_RANSAC_STEREO, st);
+  if (P.use_ransac) launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st);
+  prof_end(c, ST_RANSAC_STEREO, st);
   if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   prof_begin(c, ST_STEREO_NEW, st);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, st);
   prof_end(c, ST_STEREO_NEW, st);
   prof_begin(c, ST_FINALIZE, st);
-  launch_step_finalize(P, K, LKF, b.st, b.ss, st);
+  launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, st);
   prof_end(c, ST_FINALIZE, st);
   HIPCHK(c, hipGetLastError());
 
@@ -685,6 +806,16 @@ void kvfe_default_frontend_params(kvfe_frontend_params* p) {
   t.klt_eps = 0.01;
   t.optical_flow_predictor_type = KVFE_FLOW_NO_PREDICTION;
   t.disparity_threshold = 0.5;
+  t.min_nr_mono_inliers = 10;
+  t.min_nr_stereo_inliers = 5;
+  t.ransac_threshold_mono = 1.0e-6;
+  t.ransac_threshold_stereo = 1.0;
+  t.ransac_max_iterations = 100;
+  t.ransac_randomize = 1;  // class default (VisionImuTrackerParams.h:64); every shipped YAML sets 0
+  t.ransac_probability = 0.995;
+  t.ransac_use_1point_stereo = 1;
+  t.ransac_use_2point_mono = 1;
+  t.ransac_rng_policy = KVFE_RNG_LIBSTDCXX_PRE11;
   kvfe_stereo_params& s = p->stereo;
   s.tolerance_template_matching = 0.15;
   s.templ_cols = 101;
@@ -695,7 +826,7 @@ void kvfe_default_frontend_params(kvfe_frontend_params* p) {
   p->max_intra_keyframe_time_ns = 10.0 * 10e6;
   p->max_disparity_since_lkf = 200.0;
   p->use_stereo_tracking = 1;
-  p->use_ransac = 0;
+  p->use_ransac = 1;  // VisionImuFrontendParams.h:56
 }
 
 kvfe_status kvfe_compute_rectification(const kvfe_camera_params* left,
@@ -1107,6 +1238,79 @@ kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_i
   return KVFE_OK;
 }
 
+static kvfe_status ransac_download(kvfe_ctx* c, Buffers& b, int32_t* inliers, kvfe_ransac_output* out,
+                                   bool with_info) {
+  hipStream_t st = c->stream;
+  int status = 0, cnt[6] = {0};
+  HIPCHK(c, hipMemcpyAsync(&status, b.ss.trk_status, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(cnt, b.ss.trk_counts, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(out->pose, b.ss.trk_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, st));
+  if (with_info)
+    HIPCHK(c, hipMemcpyAsync(out->info, b.ss.trk_info, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+  else
+    std::memset(out->info, 0, sizeof(out->info));
+  HIPCHK(c, hipStreamSynchronize(st));
+  out->status = status;
+  out->n_inliers = status == KVFE_TRACKING_INVALID ? 0 : cnt[1];
+  out->iterations = cnt[2];
+  out->reserved0 = 0;
+  if (inliers && out->n_inliers > 0)
+    HIPCHK(c, hipMemcpy(inliers, b.rs.inliers, sizeof(int) * out->n_inliers, hipMemcpyDeviceToHost));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_outlier_rejection_2d2d_given_rotation(kvfe_ctx* c, const double* f_ref,
+                                                       const double* f_cur, int32_t n,
+                                                       const double R_ref_cur[9], int32_t* inliers,
+                                                       kvfe_ransac_output* out) {
+  // CHECK_GT(f_ref.size(), 0) (Tracker.cpp:243)
+  if (!c || !f_ref || !f_cur || !R_ref_cur || !out || n <= 0) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.rs.f_ref, f_ref, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.rs.f_cur, f_cur, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, R_ref_cur, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+  launch_ransac_2d2d_points(P, c->T, b.rs.f_ref, b.rs.f_cur, n, b.kf_R_cur, b.rs, b.ss.trk_status,
+                            b.ss.trk_pose, b.ss.trk_counts, st);
+  return ransac_download(c, b, inliers, out, false);
+}
+
+kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
+    kvfe_ctx* c, const float* ref_left_rect_xy, const float* ref_right_rect_x,
+    const double* ref_points_3d, const float* cur_left_rect_xy, const float* cur_right_rect_x,
+    const double* cur_points_3d, int32_t n, const double R_ref_cur[9], int32_t* inliers,
+    kvfe_ransac_output* out) {
+  if (!c || !R_ref_cur || !out || n < 0) return KVFE_ERR_INVALID_ARG;
+  if (n > 0 && (!ref_left_rect_xy || !ref_right_rect_x || !ref_points_3d || !cur_left_rect_xy ||
+                !cur_right_rect_x || !cur_points_3d))
+    return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  float* d_ref_left = reinterpret_cast<float*>(b.lk.prev_pts);
+  float* d_cur_left = reinterpret_cast<float*>(b.lk.next_pts);
+  float* d_ref_rx = b.lk.err;
+  float* d_cur_rx = reinterpret_cast<float*>(b.st.depth);
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(d_ref_left, ref_left_rect_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_cur_left, cur_left_rect_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_ref_rx, ref_right_rect_x, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_cur_rx, cur_right_rect_x, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(b.lst.kp3d, ref_points_3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(b.st.kp3d, cur_points_3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, R_ref_cur, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+  launch_ransac_3d3d_points(P, c->T, d_ref_left, d_ref_rx, b.lst.kp3d, d_cur_left, d_cur_rx, b.st.kp3d,
+                            n, b.kf_R_cur, b.rs, b.ss.trk_status, b.ss.trk_pose, b.ss.trk_info,
+                            b.ss.trk_counts, st);
+  return ransac_download(c, b, inliers, out, true);
+}
+
 // ---- front-end level -------------------------------------------------------------------------
 kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const void* right_dev,
                                       size_t row_stride, size_t image_stride,
@@ -1158,6 +1362,7 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   HIPCHK(c, hipMemsetAsync(b.ss.lmk_counter, 0, sizeof(long long) * B, st));
   HIPCHK(c, hipMemsetAsync(b.ss.frame_count, 0, sizeof(long long) * B, st));
   for (int i = 0; i < 3; i++) HIPCHK(c, hipMemsetAsync(b.ft[i].count, 0, sizeof(int) * B, st));
+  TRY(reset_tracker_status(c, b));
   std::vector<double> eye(B * 9, 0.0);
   for (size_t s = 0; s < B; s++) eye[s * 9] = eye[s * 9 + 4] = eye[s * 9 + 8] = 1.0;
   HIPCHK(c, hipMemcpy(b.ss.kf_R_ref, eye.data(), sizeof(double) * B * 9, hipMemcpyHostToDevice));
@@ -1197,6 +1402,22 @@ kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* 
   out->n_detected = ndet;
   out->n_measurements = nmeas;
   out->frame_id = fcount - 1;
+  {
+    int stt[2], cnt[6];
+    HIPCHK(c, hipMemcpy(stt, b.ss.trk_status + 2 * (size_t)s, sizeof(stt), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cnt, b.ss.trk_counts + 6 * (size_t)s, sizeof(cnt), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->lkf_T_k_mono, b.ss.trk_pose + 24 * (size_t)s, sizeof(double) * 12, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->lkf_T_k_stereo, b.ss.trk_pose + 24 * (size_t)s + 12, sizeof(double) * 12, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->info_mat_stereo_translation, b.ss.trk_info + 9 * (size_t)s, sizeof(double) * 9, hipMemcpyDeviceToHost));
+    out->tracking_status_mono = stt[0];
+    out->tracking_status_stereo = stt[1];
+    out->nr_mono_putatives = cnt[0];
+    out->nr_mono_inliers = cnt[1];
+    out->mono_ransac_iters = cnt[2];
+    out->nr_stereo_putatives = cnt[3];
+    out->nr_stereo_inliers = cnt[4];
+    out->reserved0 = 0;
+  }
   const size_t so = (size_t)s * P.kcap;
   const int n = std::min(count, out->capacity);
   const int m = std::min(nmeas, out->capacity);

@@ -37,6 +37,12 @@ struct KParams {
   // frontend (FrontendParams)
   double min_kf_ns, max_kf_ns, max_disp_lkf;
   long long min_features;
+  // geometric outlier rejection (FrontendParams::useRANSAC_, TrackerParams ransac_*)
+  int use_ransac, ransac_2pt_mono, ransac_1pt_stereo, ransac_max_iters;
+  int min_mono_inliers, min_stereo_inliers;
+  double ransac_thr_mono, ransac_probability;
+  float ransac_thr_stereo;
+  double fy_rect, cx_rect, cy_rect;  // gtsam::Cal3_S2Stereo of the rectified pair (with fx_rect, baseline)
   // pyramid geometry: level 0 is the raw image, levels 1..nlevels-1 live in the pyramid buffer
   int nlevels;
   int lw[MAX_LEVELS], lh[MAX_LEVELS], loff[MAX_LEVELS];
@@ -61,6 +67,8 @@ struct Tables {
   const unsigned char* binning_mask;  // [vbins*hbins]
   const unsigned short* sortidx;      // concatenated permutations for n = 0..max_corners
   const unsigned int* sortidx_off;    // offsets into sortidx
+  const int* ransac_rnd;       // SampleConsensusProblem::rnd() stream for seed 12345 (host generated)
+  int n_ransac_rnd;
   UndistortDev und_left_R;     // K1, D1, R1        -> bearing vectors
   UndistortDev und_left_RP;    // K1, D1, R1, P1    -> rectified left keypoints
   float Kf[9], Kinvf[9];       // float K / K^-1 of the ORIGINAL left camera (predictor)
@@ -102,6 +110,28 @@ struct StreamState {
   const int* in_force_kf; // [B]
   long long* meas_lmk;    // [B][kcap]
   double* meas_uLuRv;     // [B][kcap][3]
+  // TrackerStatusSummary / DebugTrackerInfo of the last keyframe (Tracker-definitions.h:78-183)
+  int* trk_status;        // [B][2]  kfTrackingStatus_mono_, kfTrackingStatus_stereo_
+  double* trk_pose;       // [B][2][12] lkf_T_k_mono_, lkf_T_k_stereo_ (row-major 3x4)
+  double* trk_info;       // [B][9]  infoMatStereoTranslation_
+  int* trk_counts;        // [B][6]  mono putatives, inliers, iterations; stereo putatives, inliers; -
+};
+
+// VIO::TrackingStatus
+enum : int { TRK_VALID = 0, TRK_LOW_DISPARITY = 1, TRK_FEW_MATCHES = 2, TRK_INVALID = 3, TRK_DISABLED = 4 };
+
+// scratch of the geometric outlier rejection kernels
+struct RansacScratch {
+  int2* matches;          // [B][kcap] (index in lkf, index in k)
+  double* f_ref;          // [B][kcap][3] gathered bearing vectors / stereo work values
+  double* f_cur;          // [B][kcap][3]
+  double* relc;           // [B][kcap][9] float64 covariances of the relative translations
+  float* votef;           // [B][kcap][12] float32 relative translations + covariances (voting)
+  double* acc;            // [B][kcap][12] float64 information-weighted terms of the inliers
+  int* inliers;           // [B][kcap]
+  int* n_inliers;         // [B]
+  int* cnt;               // [B][kcap] coherent-set sizes of the voting
+  int* n_matches;         // [B] stereo matches entering the voting (-1: voting skipped)
 };
 
 enum : int {
@@ -137,6 +167,8 @@ struct LkScratch {
   unsigned char* status;  // [B][kcap]
   float* err;             // [B][kcap]
   int* npts;              // [B]
+  int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
+                          //           not tracked, Tracker.cpp:103-112)
 };
 
 __host__ __device__ inline int reflect101(int p, int len) {
@@ -198,9 +230,28 @@ void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned 
                               const unsigned char* right_rect, const float2* left_rect_kp,
                               const unsigned char* left_status, int n, float2* right_rect_kp,
                               unsigned char* right_status, double* score, hipStream_t st);
-// end of step: measurements, lkf <- k for keyframes, rotation bookkeeping
+// end of step: measurements, lkf <- k for keyframes (incl. the stereo tables the next keyframe's
+// outlier rejection reads), rotation bookkeeping
 void launch_step_finalize(const KParams& P, const FrameTab& k, const FrameTab& lkf,
-                          const StereoTab& ST, const StreamState& S, hipStream_t st);
+                          const StereoTab& ST, const StereoTab& LST, const StreamState& S,
+                          hipStream_t st);
+// VisionImuFrontend::outlierRejectionMono on keyframes (2-point RANSAC, rotation given):
+// landmarks of the outliers are set to -1 in frame k, status / pose -> S.trk_*
+void launch_mono_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
+                        const StreamState& S, const RansacScratch& RS, hipStream_t st);
+// VisionImuFrontend::outlierRejectionStereo on keyframes (1-point voting)
+void launch_stereo_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
+                          const StereoTab& ST, const StereoTab& LST, const StreamState& S,
+                          const RansacScratch& RS, int max_matches, hipStream_t st);
+// component API: the two problems on caller-supplied matches (one stream)
+void launch_ransac_2d2d_points(const KParams& P, const Tables& T, const double* f_ref,
+                               const double* f_cur, int n, const double* R, const RansacScratch& RS,
+                               int* out_status, double* out_pose, int* out_counts, hipStream_t st);
+void launch_ransac_3d3d_points(const KParams& P, const Tables& T, const float* ref_left,
+                               const float* ref_right_x, const double* ref_p3, const float* cur_left,
+                               const float* cur_right_x, const double* cur_p3, int n, const double* R,
+                               const RansacScratch& RS, int* out_status, double* out_pose,
+                               double* out_info, int* out_counts, hipStream_t st);
 // undistort keypoints with an arbitrary UndistortDev (component API)
 void launch_undistort_points(const UndistortDev& U, const float2* in, int n, float2* out,
                              double* versors, hipStream_t st);

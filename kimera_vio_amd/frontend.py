@@ -7,7 +7,8 @@ Names follow the reference classes so the parity tests read like the reference's
     FeatureDetector         src/frontend/feature-detector/FeatureDetector.cpp
     Tracker                 src/frontend/Tracker.cpp                 (featureTracking's numeric core)
     StereoMatcher           src/frontend/StereoMatcher.cpp
-    StereoVisionImuFrontend src/frontend/StereoVisionImuFrontend.cpp (batched, useRANSAC = 0)
+    StereoVisionImuFrontend src/frontend/StereoVisionImuFrontend.cpp (batched; useRANSAC with the
+                            2-point mono / 1-point stereo problems)
 
 Every method goes straight to the GPU library; nothing here computes on the CPU.
 """
@@ -185,6 +186,42 @@ class Context:
                   "sparse_stereo_reconstruction")
         return res
 
+    # ---- Tracker: geometric outlier rejection ----------------------------------------------------
+    @staticmethod
+    def _ransac_result(out, inl):
+        return dict(status=out.status, n_inliers=out.n_inliers, iterations=out.iterations,
+                    pose=np.array(out.pose, np.float64).reshape(3, 4),
+                    info=np.array(out.info, np.float64).reshape(3, 3), inliers=inl[: out.n_inliers].copy())
+
+    def outlier_rejection_2d2d_given_rotation(self, f_ref, f_cur, R) -> dict:
+        """Tracker::geometricOutlierRejection2d2d with the rotation given (2-point RANSAC)."""
+        a = np.ascontiguousarray(f_ref, np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(f_cur, np.float64).reshape(-1, 3)
+        Rm = np.ascontiguousarray(R, np.float64).reshape(9)
+        inl = np.zeros(max(len(a), 1), np.int32)
+        out = abi.RansacOutput()
+        self._chk(self.lib.kvfe_outlier_rejection_2d2d_given_rotation(self._h, _p(a), _p(b), len(a), _p(Rm),
+                                                                      _p(inl), C.byref(out)),
+                  "outlier_rejection_2d2d_given_rotation")
+        return self._ransac_result(out, inl)
+
+    def outlier_rejection_3d3d_given_rotation(self, ref_left_xy, ref_right_x, ref_p3, cur_left_xy,
+                                              cur_right_x, cur_p3, R) -> dict:
+        """Tracker::geometricOutlierRejection3d3dGivenRotation (1-point voting)."""
+        rl, cl = _pts(ref_left_xy), _pts(cur_left_xy)
+        rr = np.ascontiguousarray(ref_right_x, np.float32).reshape(-1)
+        cr = np.ascontiguousarray(cur_right_x, np.float32).reshape(-1)
+        rp = np.ascontiguousarray(ref_p3, np.float64).reshape(-1, 3)
+        cp = np.ascontiguousarray(cur_p3, np.float64).reshape(-1, 3)
+        Rm = np.ascontiguousarray(R, np.float64).reshape(9)
+        n = len(rl)
+        inl = np.zeros(max(n, 1), np.int32)
+        out = abi.RansacOutput()
+        self._chk(self.lib.kvfe_outlier_rejection_3d3d_given_rotation(
+            self._h, _p(rl), _p(rr), _p(rp), _p(cl), _p(cr), _p(cp), n, _p(Rm), _p(inl), C.byref(out)),
+            "outlier_rejection_3d3d_given_rotation")
+        return self._ransac_result(out, inl)
+
     # ---- StereoVisionImuFrontend (batched) -----------------------------------------------------
     def make_inputs(self, timestamps_ns, Rs=None, force_keyframe=None):
         arr = (abi.FrameInput * self.batch)()
@@ -235,7 +272,14 @@ class Context:
         n = min(out.n_keypoints, cap)
         m = min(out.n_measurements, cap)
         d = dict(n_keypoints=out.n_keypoints, is_keyframe=out.is_keyframe, n_tracked=out.n_tracked,
-                 n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id)
+                 n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id,
+                 tracking_status_mono=out.tracking_status_mono,
+                 tracking_status_stereo=out.tracking_status_stereo,
+                 lkf_T_k_mono=np.array(out.lkf_T_k_mono, np.float64).reshape(3, 4),
+                 lkf_T_k_stereo=np.array(out.lkf_T_k_stereo, np.float64).reshape(3, 4),
+                 info_mat_stereo_translation=np.array(out.info_mat_stereo_translation, np.float64).reshape(3, 3),
+                 nr_mono_putatives=out.nr_mono_putatives, nr_mono_inliers=out.nr_mono_inliers,
+                 nr_stereo_putatives=out.nr_stereo_putatives, nr_stereo_inliers=out.nr_stereo_inliers)
         for k, v in arrs.items():
             d[k] = v[:m].copy() if k.startswith("meas_") else v[:n].copy()
         return d

@@ -67,6 +67,10 @@ def load() -> C.CDLL:
     L.kvfe_get_right_keypoints_rectified.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp, vp]
     L.kvfe_sparse_stereo_reconstruction.argtypes = [vp, vp, vp, sz, vp, i32,
                                                     C.POINTER(abi.StereoOutput)]
+    L.kvfe_outlier_rejection_2d2d_given_rotation.argtypes = [vp, vp, vp, i32, vp, vp,
+                                                             C.POINTER(abi.RansacOutput)]
+    L.kvfe_outlier_rejection_3d3d_given_rotation.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
+                                                             C.POINTER(abi.RansacOutput)]
     L.kvfe_frontend_step_host.argtypes = [vp, vp, vp, sz, sz, vp]
     L.kvfe_frontend_step_device.argtypes = [vp, vp, vp, sz, sz, vp]
     L.kvfe_frontend_reset.argtypes = [vp]
@@ -82,7 +86,8 @@ def load() -> C.CDLL:
                "kvfe_raw_feature_detection", "kvfe_feature_detection", "kvfe_corner_subpix",
                "kvfe_calc_optical_flow_pyr_lk", "kvfe_predict_sparse_flow",
                "kvfe_get_right_keypoints_rectified", "kvfe_sparse_stereo_reconstruction",
-               "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
+               "kvfe_outlier_rejection_2d2d_given_rotation",
+               "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
                "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
                "kvfe_profile_read"):
         getattr(L, fn).restype = C.c_int32
@@ -97,7 +102,8 @@ EXPORTED_SYMBOLS = [
     "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors", "kvfe_raw_feature_detection",
     "kvfe_feature_detection", "kvfe_corner_subpix", "kvfe_calc_optical_flow_pyr_lk",
     "kvfe_predict_sparse_flow", "kvfe_get_right_keypoints_rectified",
-    "kvfe_sparse_stereo_reconstruction", "kvfe_frontend_step_host", "kvfe_frontend_step_device",
+    "kvfe_sparse_stereo_reconstruction", "kvfe_outlier_rejection_2d2d_given_rotation",
+    "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_frontend_step_host", "kvfe_frontend_step_device",
     "kvfe_frontend_reset", "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
     "kvfe_profile_read",
 ]

@@ -59,6 +59,16 @@ def default_frontend_params() -> abi.FrontendParams:
     t.klt_eps = 0.01
     t.optical_flow_predictor_type = abi.FLOW_NO_PREDICTION
     t.disparity_threshold = 0.5
+    t.min_nr_mono_inliers = 10
+    t.min_nr_stereo_inliers = 5
+    t.ransac_threshold_mono = 1.0e-6
+    t.ransac_threshold_stereo = 1.0
+    t.ransac_max_iterations = 100
+    t.ransac_randomize = 1          # class default (VisionImuTrackerParams.h:64); every YAML sets 0
+    t.ransac_probability = 0.995
+    t.ransac_use_1point_stereo = 1
+    t.ransac_use_2point_mono = 1
+    t.ransac_rng_policy = abi.RNG_LIBSTDCXX_PRE11
     s = p.stereo
     s.tolerance_template_matching = 0.15
     s.templ_cols = 101
@@ -72,7 +82,7 @@ def default_frontend_params() -> abi.FrontendParams:
     p.min_number_features = 0
     p.max_disparity_since_lkf = 200.0
     p.use_stereo_tracking = 1
-    p.use_ransac = 0  # geometric outlier rejection is outside this library
+    p.use_ransac = 1  # VisionImuFrontendParams.h:60
     return p
 
 
@@ -114,8 +124,8 @@ def load_detector_params(path: str, into: abi.DetectorParams | None = None) -> a
 
 
 def load_frontend_params(path: str, use_ransac: int | None = 0) -> abi.FrontendParams:
-    """FrontendParams::parseYAML.  ``use_ransac=None`` keeps the YAML's value (the library
-    then refuses to create a context unless it is 0)."""
+    """FrontendParams::parseYAML.  ``use_ransac=None`` keeps the YAML's value; the default 0
+    switches geometric outlier rejection off (tests of the tracking / detection / stereo path)."""
     y = _read_yaml(path)
     p = default_frontend_params()
     load_detector_params(path, p.detector)
@@ -127,6 +137,15 @@ def load_frontend_params(path: str, use_ransac: int | None = 0) -> abi.FrontendP
     t.max_feature_track_age = int(y["maxFeatureAge"])
     t.disparity_threshold = float(y["disparityThreshold"])
     t.optical_flow_predictor_type = int(y["optical_flow_predictor_type"])
+    t.min_nr_mono_inliers = int(y["minNrMonoInliers"])
+    t.min_nr_stereo_inliers = int(y["minNrStereoInliers"])
+    t.ransac_threshold_mono = float(y["ransac_threshold_mono"])
+    t.ransac_threshold_stereo = float(y["ransac_threshold_stereo"])
+    t.ransac_max_iterations = int(y["ransac_max_iterations"])
+    t.ransac_probability = float(y["ransac_probability"])
+    t.ransac_randomize = int(y["ransac_randomize"])
+    t.ransac_use_1point_stereo = int(y["ransac_use_1point_stereo"])
+    t.ransac_use_2point_mono = int(y["ransac_use_2point_mono"])
     s = p.stereo
     s.tolerance_template_matching = float(y["toleranceTemplateMatching"])
     s.templ_cols = int(y["templ_cols"])

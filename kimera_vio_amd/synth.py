@@ -111,3 +111,101 @@ def keyframe_R_cur(stream: SyntheticStream, t_kf: int, t_cur: int) -> np.ndarray
     """keyframe_R_cur_frame for the predictor: rotation taking current-frame vectors to the keyframe
     (consistent with frame(): p_cur ~ K R_cur^T R_kf K^-1 p_kf)."""
     return stream.rotation(t_kf).T @ stream.rotation(t_cur)
+
+
+# ---------------------------------------------------------------------------------------------
+# physically consistent rig: both cameras of the calibrated pair look at one textured plane
+# ---------------------------------------------------------------------------------------------
+def _undistort_normalized(xd, yd, k1, k2, p1, p2, iters=25):
+    """inverse radial-tangential model on normalized coordinates (fixed-point iteration)"""
+    x, y = xd.copy(), yd.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (xd - dx) * icdist
+        y = (yd - dy) * icdist
+    return x, y
+
+
+def _pixel_rays(cam: abi.CameraParams) -> np.ndarray:
+    """unit ray of every pixel in the camera frame, [H, W, 3] float64 (distortion inverted)"""
+    fx, fy, cx, cy = (cam.intrinsics[i] for i in range(4))
+    yy, xx = np.mgrid[0:cam.height, 0:cam.width].astype(np.float64)
+    xd, yd = (xx - cx) / fx, (yy - cy) / fy
+    if cam.distortion_model == abi.DIST_RADTAN:
+        k1, k2, p1, p2 = (cam.distortion[i] for i in range(4))
+        xd, yd = _undistort_normalized(xd, yd, k1, k2, p1, p2)
+    r = np.stack([xd, yd, np.ones_like(xd)], -1)
+    return r / np.linalg.norm(r, axis=-1, keepdims=True)
+
+
+class RigStream:
+    """One stereo stream rendered through the calibrated camera pair (intrinsics, radial-tangential
+    distortion and extrinsics of both kvfe_camera_params): a textured plane at 1.5-3 m, slightly
+    tilted, seen from a rig that translates a few centimetres and rotates a fraction of a degree per
+    frame.  Bearing vectors of tracked points therefore satisfy the epipolar geometry of
+    (rotation(t), position(t)) and stereo disparities follow from the plane depth, so the geometric
+    outlier rejection of keyframes sees a consistent scene (SURVEY.md §8d asks for the forward
+    distortion model; a shift-only right view would not rectify consistently).
+
+    frame(t) -> (left u8, right u8).  keyframe_R_cur(stream, t_kf, t_cur) applies as for
+    SyntheticStream; `rect_R1` (3x3, from kvfe_compute_rectification) expresses it in the rectified
+    left frame, which is the frame of the front-end's bearing vectors."""
+
+    def __init__(self, left: abi.CameraParams, right: abi.CameraParams, seed: int, rect_R1=None,
+                 max_step_deg: float = 0.3, max_step_m: float = 0.04):
+        self.w, self.h = left.width, left.height
+        self.tex = base_texture(self.w, self.h, seed)
+        self.rays = [_pixel_rays(left), _pixel_rays(right)]
+        TL = np.array(left.body_pose_cam, np.float64).reshape(4, 4)
+        TR = np.array(right.body_pose_cam, np.float64).reshape(4, 4)
+        T_lr = np.linalg.inv(TL) @ TR            # pose of the right camera in the left camera frame
+        self.R_lr, self.t_lr = T_lr[:3, :3], T_lr[:3, 3]
+        self.R1 = np.eye(3) if rect_R1 is None else np.asarray(rect_R1, np.float64).reshape(3, 3)
+        rng = np.random.RandomState(3000 + seed)
+        self.axis = rng.normal(size=3)
+        self.axis[2] *= 0.3
+        self.step = np.deg2rad(rng.uniform(0.3, 1.0) * max_step_deg)
+        v = rng.normal(size=3)
+        v[2] *= 0.5
+        self.vel = v / np.linalg.norm(v) * rng.uniform(0.4, 1.0) * max_step_m
+        n = np.array([rng.uniform(-0.25, 0.25), rng.uniform(-0.25, 0.25), 1.0])
+        self.n = n / np.linalg.norm(n)
+        self.d0 = rng.uniform(1.5, 3.0) * self.n[2]          # plane n.X = d0; optical axis hits it at z = d0/n_z
+        self.X0 = np.array([0.0, 0.0, self.d0 / self.n[2]])
+        e1 = np.cross([0.0, 1.0, 0.0], self.n)
+        self.e1 = e1 / np.linalg.norm(e1)
+        self.e2 = np.cross(self.n, self.e1)
+        self.f = left.intrinsics[0]
+        self.c0 = (left.intrinsics[2], left.intrinsics[3])
+
+    def rotation(self, t: int) -> np.ndarray:
+        return rot_from_axis_angle(self.axis, self.step * t)
+
+    def position(self, t: int) -> np.ndarray:
+        return self.vel * t
+
+    def _render(self, cam: int, t: int) -> np.ndarray:
+        R = self.rotation(t)
+        o = self.position(t)
+        if cam == 1:
+            o = o + R @ self.t_lr
+            R = R @ self.R_lr
+        d = self.rays[cam] @ R.T                                  # world ray of every pixel
+        lam = (self.d0 - self.n @ o) / (d @ self.n)
+        X = o + lam[..., None] * d - self.X0
+        s = self.f / self.X0[2]                                   # texture px per metre on the plane
+        u = (X @ self.e1) * s + self.c0[0] + 96
+        v = (X @ self.e2) * s + self.c0[1] + 96
+        img = _sample_bilinear(self.tex, u.astype(np.float32), v.astype(np.float32))
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    def frame(self, t: int):
+        return self._render(0, t), self._render(1, t)
+
+
+def rig_keyframe_R_cur(stream: RigStream, t_kf: int, t_cur: int) -> np.ndarray:
+    """keyframe_R_cur_frame in the rectified left frame (camLrectLkf_R_camLrectK)."""
+    return stream.R1 @ stream.rotation(t_kf).T @ stream.rotation(t_cur) @ stream.R1.T

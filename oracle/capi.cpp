@@ -227,6 +227,77 @@ KVO_API void kvo_sparse_stereo_reconstruction(const kvo_camera* c, const kvfe_st
   if (out->right_rect_img) std::memcpy(out->right_rect_img, sf.right_rect.data(), (size_t)w * h);
 }
 
+// ---- geometric outlier rejection -------------------------------------------------
+static void fill_ransac_out(const kimera::RansacOut& r, int32_t* inliers, kvfe_ransac_output* out) {
+  out->status = r.status;
+  out->n_inliers = (int)r.inliers.size();
+  out->iterations = r.iterations;
+  out->reserved0 = 0;
+  std::memcpy(out->pose, r.pose, sizeof(out->pose));
+  std::memcpy(out->info, r.info, sizeof(out->info));
+  if (inliers)
+    for (size_t i = 0; i < r.inliers.size(); i++) inliers[i] = r.inliers[i];
+}
+KVO_API void kvo_outlier_rejection_2d2d_given_rotation(const double* f_ref, const double* f_cur,
+                                                       int n, const double* R,
+                                                       const kvfe_tracker_params* tp,
+                                                       int32_t* inliers, kvfe_ransac_output* out) {
+  fill_ransac_out(kimera::outlierRejection2d2dGivenRot(f_ref, f_cur, n, R, *tp), inliers, out);
+}
+KVO_API void kvo_outlier_rejection_3d3d_given_rotation(
+    const kvo_camera* c, const float* ref_left_xy, const float* ref_right_x, const double* ref_p3,
+    const float* cur_left_xy, const float* cur_right_x, const double* cur_p3, int n,
+    const double* R, const kvfe_tracker_params* tp, int32_t* inliers, kvfe_ransac_output* out) {
+  kimera::StereoCalib K;
+  K.fx = c->cam.rect.P1[0];
+  K.fy = c->cam.rect.P1[5];
+  K.s = c->cam.rect.P1[1];
+  K.cx = c->cam.rect.P1[2];
+  K.cy = c->cam.rect.P1[6];
+  K.b = c->cam.rect.baseline;
+  fill_ransac_out(kimera::outlierRejection3d3dGivenRot(ref_left_xy, ref_right_x, ref_p3, cur_left_xy,
+                                                       cur_right_x, cur_p3, n, K, R, *tp),
+                  inliers, out);
+}
+KVO_API void kvo_get_point3_and_covariance(const kvo_camera* c, double uL, double uR, double v,
+                                           const double* p3, const double* Rmat, double* point,
+                                           double* cov) {
+  kimera::StereoCalib K;
+  K.fx = c->cam.rect.P1[0];
+  K.fy = c->cam.rect.P1[5];
+  K.s = c->cam.rect.P1[1];
+  K.cx = c->cam.rect.P1[2];
+  K.cy = c->cam.rect.P1[6];
+  K.b = c->cam.rect.baseline;
+  kimera::getPoint3AndCovariance(K, uL, uR, v, p3, Rmat, point, cov);
+}
+// opengv::sac::Ransac<PointCloudSacProblem> (3-point Arun), for the reference's 3d3d KAT
+#include "opengv_re.hpp"
+KVO_API int kvo_ransac_point_cloud(const double* p1, const double* p2, int n, double threshold,
+                                   int max_iterations, double probability, int rng_policy,
+                                   int32_t* inliers, double* pose, int* iterations) {
+  opengv_re::RansacResult r = opengv_re::ransac_point_cloud(p1, p2, n, threshold, max_iterations,
+                                                            probability, rng_policy);
+  if (iterations) *iterations = r.iterations;
+  if (!r.success) return -1;
+  std::memcpy(pose, r.coeff, sizeof(double) * 12);
+  for (size_t i = 0; i < r.inliers.size(); i++) inliers[i] = r.inliers[i];
+  return (int)r.inliers.size();
+}
+KVO_API void kvo_mt19937_draws(int policy, int n, int32_t* out) {  // SampleConsensusProblem::rnd()
+  opengv_re::Mt19937 e;
+  e.seed(12345u);
+  for (int i = 0; i < n; i++) {
+    uint32_t r = e.next();
+    if (policy == opengv_re::RNG_LIBSTDCXX_11) {
+      out[i] = (int32_t)(r >> 1);
+    } else {
+      while (r >= 0x80000000u) r = e.next();
+      out[i] = (int32_t)r;
+    }
+  }
+}
+
 // ---- front-end ---------------------------------------------------------------
 struct kvo_frontend {
   kimera::Frontend fe;
@@ -251,6 +322,20 @@ KVO_API int kvo_frontend_get_output(kvo_frontend* f, kvfe_frame_output* out) {
   out->n_detected = sf.n_detected;
   out->n_measurements = (int)f->fe.meas_lmk.size();
   out->frame_id = sf.left.id;
+  {
+    const kimera::TrackerStatusSummary& T = f->fe.tracker_status;
+    out->tracking_status_mono = T.mono;
+    out->tracking_status_stereo = T.stereo;
+    std::memcpy(out->lkf_T_k_mono, T.lkf_T_k_mono, sizeof(out->lkf_T_k_mono));
+    std::memcpy(out->lkf_T_k_stereo, T.lkf_T_k_stereo, sizeof(out->lkf_T_k_stereo));
+    std::memcpy(out->info_mat_stereo_translation, T.info, sizeof(T.info));
+    out->nr_mono_putatives = T.nr_mono_putatives;
+    out->nr_mono_inliers = T.nr_mono_inliers;
+    out->mono_ransac_iters = T.mono_iters;
+    out->nr_stereo_putatives = T.nr_stereo_putatives;
+    out->nr_stereo_inliers = T.nr_stereo_inliers;
+    out->reserved0 = 0;
+  }
   const int m = std::min(n, out->capacity);
   const bool has_stereo = (int)sf.left_kp_rect.size() == n;
   for (int i = 0; i < m; i++) {

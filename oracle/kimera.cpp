@@ -578,6 +578,7 @@ void Frontend::init(const kvfe_camera_params& l, const kvfe_camera_params& r,
   lmk_id = 0;
   frame_count = 0;
   initialized = false;
+  tracker_status = TrackerStatusSummary();
 }
 
 // FeatureDetector::featureDetection(Frame*, R) (FeatureDetector.cpp:94-163)
@@ -644,7 +645,7 @@ void Frontend::featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]
 
 // VisionImuFrontend::shouldBeKeyframe (VisionImuFrontend.cpp:175-232) with
 // Tracker::findMatchingKeypoints / computeMedianDisparity (Tracker.cpp:919-1018);
-// kfTrackingStatus_mono_ is never LOW_DISPARITY when useRANSAC = 0.
+// kfTrackingStatus_mono_ (of the last keyframe) can only be LOW_DISPARITY when useRANSAC = 1.
 bool Frontend::shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) const {
   const int64_t kf_diff_ns = frame.timestamp - frame_lkf.timestamp;
   size_t nr_valid_features = 0;
@@ -674,7 +675,8 @@ bool Frontend::shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) cons
     disparity = std::sqrt(disparity_sq[center]);
   }
   const bool is_disparity_low = disparity < p.tracker.disparity_threshold;
-  const bool disparity_low_first_time = is_disparity_low;  // status != LOW_DISPARITY
+  const bool disparity_low_first_time =
+      is_disparity_low && !(tracker_status.mono == KVFE_TRACKING_LOW_DISPARITY);
   const bool enough_disparity = !is_disparity_low;
   const bool max_disparity_reached = disparity > p.max_disparity_since_lkf;
   const bool disparity_flipped = ((enough_disparity || disparity_low_first_time) && min_time_elapsed);
@@ -750,6 +752,21 @@ void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
   }
   const bool new_keyframe = shouldBeKeyframe(k.left, lkf.left);
   if (new_keyframe) {
+    // StereoVisionImuFrontend.cpp:349-412
+    tracker_status.mono = KVFE_TRACKING_INVALID;
+    tracker_status.stereo = KVFE_TRACKING_INVALID;
+    if (p.use_ransac) {
+      outlierRejectionMono(in.keyframe_R_cur_frame, lkf.left, k.left);
+      sparseStereoReconstruction(cam, p.stereo, k);
+      if (p.use_stereo_tracking) {
+        outlierRejectionStereo(in.keyframe_R_cur_frame, lkf, k);
+      } else {
+        tracker_status.stereo = KVFE_TRACKING_INVALID;
+      }
+    } else {
+      tracker_status.mono = KVFE_TRACKING_DISABLED;
+      tracker_status.stereo = KVFE_TRACKING_DISABLED;
+    }
     k.left.isKeyframe = true;
     featureDetectionFrame(k.left, &k.n_detected);
     sparseStereoReconstruction(cam, p.stereo, k);

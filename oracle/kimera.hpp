@@ -102,12 +102,61 @@ struct StereoFrame {
   int n_tracked = 0, n_detected = 0;
 };
 
+// ---- geometric outlier rejection (Tracker.cpp:213-1018) ------------------------------------------
+typedef std::pair<size_t, size_t> KeypointMatch;  // (index in ref frame, index in cur frame)
+
+// TrackerStatusSummary + DebugTrackerInfo (Tracker-definitions.h:78-183); poses 3x4 [R | t]
+struct TrackerStatusSummary {
+  int mono = KVFE_TRACKING_INVALID, stereo = KVFE_TRACKING_INVALID;
+  double lkf_T_k_mono[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  double lkf_T_k_stereo[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  double info[9] = {0};
+  int nr_mono_putatives = 0, nr_mono_inliers = 0, mono_iters = 0;
+  int nr_stereo_putatives = 0, nr_stereo_inliers = 0;
+};
+
+// Tracker::findMatchingKeypoints (Tracker.cpp:919-946)
+void findMatchingKeypoints(const Frame& ref, const Frame& cur, std::vector<KeypointMatch>& out);
+// Tracker::findMatchingStereoKeypoints (Tracker.cpp:948-989)
+void findMatchingStereoKeypoints(const StereoFrame& ref, const StereoFrame& cur,
+                                 const std::vector<KeypointMatch>& mono,
+                                 std::vector<KeypointMatch>& out);
+// Tracker::computeMedianDisparity (Tracker.cpp:991-1018)
+bool computeMedianDisparity(const std::vector<Point2f>& ref, const std::vector<Point2f>& cur,
+                            const std::vector<KeypointMatch>& matches, double* median);
+
+struct RansacOut {
+  int status = KVFE_TRACKING_INVALID;
+  double pose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  double info[9] = {0};
+  std::vector<int> inliers;
+  int iterations = 0;
+};
+// Tracker::geometricOutlierRejection2d2d(bearings, ..., cam_lkf_Pose_cam_kf) with
+// ransac_use_2point_mono_ (Tracker.cpp:213-318) over n already gathered matches
+RansacOut outlierRejection2d2dGivenRot(const double* f_ref, const double* f_cur, int n,
+                                       const double R[9], const kvfe_tracker_params& tp);
+// gtsam::Cal3_S2Stereo of the rectified pair (StereoCamera.cpp:75-83)
+struct StereoCalib {
+  double fx, fy, s, cx, cy, b;
+};
+// Tracker::getPoint3AndCovariance (Tracker.cpp:772-818), stereo_point_covariance = I
+void getPoint3AndCovariance(const StereoCalib& K, double uL, double uR, double v, const double p3[3],
+                            const double* Rmat /* may be null */, double point[3], double cov[9]);
+// Tracker::geometricOutlierRejection3d3dGivenRotation (Tracker.cpp:382-632) over n stereo matches
+RansacOut outlierRejection3d3dGivenRot(const float* ref_left_xy, const float* ref_right_x,
+                                       const double* ref_p3, const float* cur_left_xy,
+                                       const float* cur_right_x, const double* cur_p3, int n,
+                                       const StereoCalib& K, const double R[9],
+                                       const kvfe_tracker_params& tp);
+
 // StereoMatcher::sparseStereoReconstruction(StereoFrame*) (StereoMatcher.cpp:123-175)
 void sparseStereoReconstruction(const StereoCamera& cam, const kvfe_stereo_params& p,
                                 StereoFrame& sf);
 
-// StereoVisionImuFrontend (processFirstStereoFrame / processStereoFrame with
-// useRANSAC = 0; src/frontend/StereoVisionImuFrontend.cpp:245-531) +
+// StereoVisionImuFrontend (processFirstStereoFrame / processStereoFrame incl. the useRANSAC
+// branch for the 2-point mono / 1-point stereo problems;
+// src/frontend/StereoVisionImuFrontend.cpp:245-531) +
 // VisionImuFrontend::shouldBeKeyframe (VisionImuFrontend.cpp:175-232) +
 // Tracker::featureTracking (Tracker.cpp:92-211) +
 // FeatureDetector::featureDetection(Frame*, R) (FeatureDetector.cpp:94-163).
@@ -123,6 +172,7 @@ struct Frontend {
   std::vector<int64_t> meas_lmk;
   std::vector<double> meas_uLuRv;
   bool last_is_keyframe = false;
+  TrackerStatusSummary tracker_status;  // tracker_status_summary_ (persists between keyframes)
 
   void init(const kvfe_camera_params& l, const kvfe_camera_params& r,
             const kvfe_frontend_params& fp);
@@ -135,6 +185,12 @@ struct Frontend {
   void featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]);
   bool shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) const;
   void getSmartStereoMeasurements(const StereoFrame& sf);
+  // VisionImuFrontend::outlierRejectionMono / outlierRejectionStereo (VisionImuFrontend.cpp:90-144)
+  void outlierRejectionMono(const double R[9], Frame& lkf_left, Frame& k_left);
+  void outlierRejectionStereo(const double R[9], StereoFrame& lkf_sf, StereoFrame& k_sf);
 };
+
+// gtsam::Rot3::equals(Rot3(), 1e-9) as used for `given_rot` (VisionImuFrontend.cpp:97,125)
+bool rot_equals_identity(const double R[9], double tol);
 
 }  // namespace kimera

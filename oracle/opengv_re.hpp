@@ -1,0 +1,57 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+// CPU restatement of the parts of OpenGV that Kimera-VIO's geometric outlier rejection calls
+// (Tracker::runRansac, include/kimera-vio/frontend/Tracker.h:247-296, with the problem types of
+// include/kimera-vio/frontend/Tracker-definitions.h:43-61).
+//
+// OpenGV is an un-vendored third-party dependency of the reference (fork marcusabate/opengv,
+// no version pin: Dockerfile_20_04:55); its sources are not in /root/reference.  What is restated
+// here is its published algorithm:
+//   opengv::sac::Ransac<P>::computeModel           (opengv/sac/implementation/Ransac.hpp)
+//   opengv::sac::SampleConsensusProblem<M>         (getSamples / drawIndexSample / rnd,
+//                                                   opengv/sac/implementation/SampleConsensusProblem.hpp)
+//   sac_problems::relative_pose::TranslationOnlySacProblem  (2-point, rotation known)
+//   relative_pose::twopt, triangulation::triangulate2
+//   sac_problems::point_cloud::PointCloudSacProblem + point_cloud::threept_arun (3-point Arun)
+// PARITY UNPINNED at the bit level (no OpenGV build is reachable here).  It is anchored on the
+// reference's own known-answer tests for these call sites (tests/testTracker.cpp:704-1186: every
+// synthetic inlier kept, every synthetic outlier rejected, translation recovered) — see
+// tests/test_oracle_kat.py.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace opengv_re {
+
+// std::uniform_int_distribution<int>(0, INT_MAX) over std::mt19937 is implementation defined:
+//   RNG_LIBSTDCXX_PRE11: libstdc++ <= 10 (GCC 9.4 of the reference's Ubuntu 20.04 image):
+//                        "downscaling" = redraw while the 32-bit output is >= 2^31
+//   RNG_LIBSTDCXX_11   : libstdc++ >= 11 (Lemire's method) = 32-bit output >> 1, never redraws
+enum { RNG_LIBSTDCXX_PRE11 = 0, RNG_LIBSTDCXX_11 = 1 };
+
+struct Mt19937 {  // std::mt19937 (ISO C++ [rand.eng.mers], bit-exact by definition)
+  uint32_t mt[624];
+  int idx;
+  void seed(uint32_t s);
+  uint32_t next();
+};
+
+struct RansacResult {
+  bool success = false;       // Ransac::computeModel() return value
+  int iterations = 0;         // Ransac::iterations_
+  std::vector<int> model;     // Ransac::model_ (sample of the best model)
+  double coeff[12] = {0};     // Ransac::model_coefficients_ (3x4 [R|t], row-major)
+  std::vector<int> inliers;   // Ransac::inliers_
+};
+
+// opengv::sac::Ransac<TranslationOnlySacProblem>::computeModel with
+// TranslationOnlySacProblem(adapter(f1, f2) + setR12(R12), randomSeed = false)
+// f1, f2: n x 3 bearing vectors (reference / current frame)
+RansacResult ransac_translation_only(const double* f1, const double* f2, int n, const double R12[9],
+                                     double threshold, int max_iterations, double probability,
+                                     int rng_policy);
+
+// opengv::sac::Ransac<PointCloudSacProblem>::computeModel (3-point Arun), p1, p2: n x 3 points
+RansacResult ransac_point_cloud(const double* p1, const double* p2, int n, double threshold,
+                                int max_iterations, double probability, int rng_policy);
+
+}  // namespace opengv_re

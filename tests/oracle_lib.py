@@ -94,6 +94,18 @@ def lib() -> C.CDLL:
     L.kvo_sparse_stereo_reconstruction.argtypes = [C.c_void_p, C.POINTER(abi.StereoParams),
                                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                                    C.c_int, C.POINTER(abi.StereoOutput)]
+    vp = C.c_void_p
+    L.kvo_outlier_rejection_2d2d_given_rotation.argtypes = [vp, vp, C.c_int, vp,
+                                                            C.POINTER(abi.TrackerParams), vp,
+                                                            C.POINTER(abi.RansacOutput)]
+    L.kvo_outlier_rejection_3d3d_given_rotation.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
+                                                            C.POINTER(abi.TrackerParams), vp,
+                                                            C.POINTER(abi.RansacOutput)]
+    L.kvo_get_point3_and_covariance.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp]
+    L.kvo_ransac_point_cloud.restype = C.c_int
+    L.kvo_ransac_point_cloud.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
+                                         vp, vp, C.POINTER(C.c_int)]
+    L.kvo_mt19937_draws.argtypes = [C.c_int, C.c_int, vp]
     L.kvo_frontend_create.restype = C.c_void_p
     L.kvo_frontend_create.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams),
                                       C.POINTER(abi.FrontendParams)]
@@ -308,6 +320,70 @@ class Camera:
         return res
 
 
+# --------------------------------------------------------------------------- outlier rejection
+def _ransac_result(out, inl):
+    return dict(status=out.status, n_inliers=out.n_inliers, iterations=out.iterations,
+                pose=np.array(out.pose, np.float64).reshape(3, 4),
+                info=np.array(out.info, np.float64).reshape(3, 3), inliers=inl[: out.n_inliers].copy())
+
+
+def outlier_rejection_2d2d_given_rotation(f_ref, f_cur, R, tp: abi.TrackerParams) -> dict:
+    a = np.ascontiguousarray(f_ref, np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(f_cur, np.float64).reshape(-1, 3)
+    Rm = np.ascontiguousarray(R, np.float64).reshape(9)
+    inl = np.zeros(max(len(a), 1), np.int32)
+    out = abi.RansacOutput()
+    lib().kvo_outlier_rejection_2d2d_given_rotation(_p(a), _p(b), len(a), _p(Rm), C.byref(tp), _p(inl),
+                                                    C.byref(out))
+    return _ransac_result(out, inl)
+
+
+def outlier_rejection_3d3d_given_rotation(cam: "Camera", ref_left_xy, ref_right_x, ref_p3, cur_left_xy,
+                                          cur_right_x, cur_p3, R, tp: abi.TrackerParams) -> dict:
+    rl = np.ascontiguousarray(ref_left_xy, np.float32).reshape(-1, 2)
+    cl = np.ascontiguousarray(cur_left_xy, np.float32).reshape(-1, 2)
+    rr = np.ascontiguousarray(ref_right_x, np.float32).reshape(-1)
+    cr = np.ascontiguousarray(cur_right_x, np.float32).reshape(-1)
+    rp = np.ascontiguousarray(ref_p3, np.float64).reshape(-1, 3)
+    cp = np.ascontiguousarray(cur_p3, np.float64).reshape(-1, 3)
+    Rm = np.ascontiguousarray(R, np.float64).reshape(9)
+    n = len(rl)
+    inl = np.zeros(max(n, 1), np.int32)
+    out = abi.RansacOutput()
+    lib().kvo_outlier_rejection_3d3d_given_rotation(cam._h, _p(rl), _p(rr), _p(rp), _p(cl), _p(cr), _p(cp),
+                                                    n, _p(Rm), C.byref(tp), _p(inl), C.byref(out))
+    return _ransac_result(out, inl)
+
+
+def get_point3_and_covariance(cam: "Camera", uL, uR, v, p3, Rmat=None):
+    p3 = np.ascontiguousarray(p3, np.float64).reshape(3)
+    Rm = None if Rmat is None else np.ascontiguousarray(Rmat, np.float64).reshape(9)
+    point = np.zeros(3)
+    cov = np.zeros(9)
+    lib().kvo_get_point3_and_covariance(cam._h, float(uL), float(uR), float(v), _p(p3),
+                                        _p(Rm) if Rm is not None else None, _p(point), _p(cov))
+    return point, cov.reshape(3, 3)
+
+
+def ransac_point_cloud(p1, p2, threshold, max_iterations, probability, rng_policy=0):
+    a = np.ascontiguousarray(p1, np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(p2, np.float64).reshape(-1, 3)
+    inl = np.zeros(max(len(a), 1), np.int32)
+    pose = np.zeros(12)
+    it = C.c_int(0)
+    n = lib().kvo_ransac_point_cloud(_p(a), _p(b), len(a), threshold, max_iterations, probability,
+                                     rng_policy, _p(inl), _p(pose), C.byref(it))
+    if n < 0:
+        return None
+    return dict(inliers=inl[:n].copy(), pose=pose.reshape(3, 4), iterations=it.value)
+
+
+def mt19937_draws(policy: int, n: int) -> np.ndarray:
+    out = np.zeros(n, np.int32)
+    lib().kvo_mt19937_draws(policy, n, _p(out))
+    return out
+
+
 def alloc_frame_output(cap: int):
     """numpy-backed kvfe_frame_output."""
     arrs = dict(landmarks=np.zeros(cap, np.int64), landmarks_age=np.zeros(cap, np.int32),
@@ -328,14 +404,21 @@ def frame_output_to_dict(out: abi.FrameOutput, arrs: dict) -> dict:
     n = min(out.n_keypoints, out.capacity)
     m = min(out.n_measurements, out.capacity)
     d = dict(n_keypoints=out.n_keypoints, is_keyframe=out.is_keyframe, n_tracked=out.n_tracked,
-             n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id)
+             n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id,
+             tracking_status_mono=out.tracking_status_mono,
+             tracking_status_stereo=out.tracking_status_stereo,
+             lkf_T_k_mono=np.array(out.lkf_T_k_mono, np.float64).reshape(3, 4),
+             lkf_T_k_stereo=np.array(out.lkf_T_k_stereo, np.float64).reshape(3, 4),
+             info_mat_stereo_translation=np.array(out.info_mat_stereo_translation, np.float64).reshape(3, 3),
+             nr_mono_putatives=out.nr_mono_putatives, nr_mono_inliers=out.nr_mono_inliers,
+             nr_stereo_putatives=out.nr_stereo_putatives, nr_stereo_inliers=out.nr_stereo_inliers)
     for k, v in arrs.items():
         d[k] = v[:m].copy() if k.startswith("meas_") else v[:n].copy()
     return d
 
 
 class Frontend:
-    """kimera::Frontend of the oracle (StereoVisionImuFrontend, useRANSAC = 0)."""
+    """kimera::Frontend of the oracle (StereoVisionImuFrontend incl. the useRANSAC branch)."""
 
     def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams):
         self.params = params

@@ -338,6 +338,12 @@ def _run_sequence(oracle_fe, gpu_ctx, seq, stream_of=lambda s, i: i, force_kf=Fa
             if exp["is_keyframe"]:
                 assert np.array_equal(got["meas_uL_uR_v"], exp["meas_uL_uR_v"], equal_nan=True), (i, s)
                 kf_index[s] = idx[s]
+            # TrackerStatusSummary / DebugTrackerInfo (geometric outlier rejection)
+            for k in ("tracking_status_mono", "tracking_status_stereo", "nr_mono_putatives",
+                      "nr_mono_inliers", "nr_stereo_putatives", "nr_stereo_inliers"):
+                assert got[k] == exp[k], (i, s, k, got[k], exp[k])
+            for k in ("lkf_T_k_mono", "lkf_T_k_stereo", "info_mat_stereo_translation"):
+                assert np.array_equal(got[k], exp[k]), (i, s, k, got[k], exp[k])
             kinds.append((i, s, exp["is_keyframe"], exp["n_tracked"], exp["n_detected"]))
     return kinds
 
@@ -463,3 +469,116 @@ def test_synthetic_1280x720_properties_and_parity():
             kf = t
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# geometric outlier rejection (FrontendParams::useRANSAC_)
+# ---------------------------------------------------------------------------------------------
+import test_oracle_ransac as TR  # scene generators shared with the oracle's known-answer tests
+
+
+@pytest.fixture(scope="module")
+def rctx():
+    L, R = euroc_cams()
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    assert p.use_ransac == 1 and p.tracker.ransac_use_2point_mono == 1 and p.tracker.ransac_use_1point_stereo == 1
+    c = F.Context(L, R, p)
+    yield c
+    c.close()
+
+
+def _same_ransac(got, exp):
+    assert got["status"] == exp["status"]
+    assert list(got["inliers"]) == list(exp["inliers"])
+    assert got["iterations"] == exp["iterations"]
+    assert np.array_equal(got["pose"], exp["pose"]), (got["pose"], exp["pose"])
+    assert np.array_equal(got["info"], exp["info"])
+
+
+@pytest.mark.parametrize("planar,n_in,n_out,seed", [(False, 80, 0, 1), (False, 80, 20, 2), (True, 80, 20, 3),
+                                                    (False, 300, 250, 4), (False, 6, 0, 5), (False, 1, 0, 6)])
+def test_outlier_rejection_2d2d_given_rotation(rctx, ocam, planar, n_in, n_out, seed):
+    """2-point RANSAC (opengv TranslationOnlySacProblem): same sample stream, same hypotheses, same
+    inlier sets, iteration count and pose as the CPU path; scenes of tests/testTracker.cpp:804-895."""
+    rng = np.random.default_rng(seed)
+    R = TR.expmap([0.02, -0.01, 0.03]) if seed % 2 else np.eye(3)
+    T = np.array([1.0, 0.0, 0.0]) if seed % 2 == 0 else np.array([0.3, 0.1, -0.05])
+    f_ref, f_cur = TR.mono_scene(ocam, rng, R, T, planar, n_in, n_out)
+    exp = O.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, R, rctx.params.tracker)
+    got = rctx.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, R)
+    _same_ransac(got, exp)
+    if n_in >= 10:  # (a random outlier pair can lie on an epipolar line: allow a few extra inliers)
+        assert exp["status"] == abi.TRACKING_VALID
+        assert set(range(n_in)) <= set(exp["inliers"]) and len(exp["inliers"]) <= n_in + 3
+
+
+@pytest.mark.parametrize("case,planar,n_in,n_out,noise", [(0, False, 3, 0, 0.0), (1, False, 40, 0, 0.0),
+                                                          (2, False, 80, 40, 0.0), (3, True, 80, 40, 0.01),
+                                                          (4, False, 500, 100, 0.0), (5, False, 1, 0, 0.0),
+                                                          (6, False, 0, 0, 0.0)])
+def test_outlier_rejection_3d3d_given_rotation(rctx, ocam, case, planar, n_in, n_out, noise):
+    """1-point voting: float32 Mahalanobis coherence, first largest coherent set, float64 information-
+    weighted translation summed in inlier order; scenes of tests/testTracker.cpp:1042-1185."""
+    rng = np.random.default_rng(300 + case)
+    R = TR.expmap([0.1, 0.1, 0.1])
+    T = np.array([ocam.rect.baseline, 0.0, 0.0])
+    rl, rr, p_ref, cl, cr, p_cur = TR.stereo_scene(ocam, rng, R, T, planar, n_in, n_out, noise)
+    exp = O.outlier_rejection_3d3d_given_rotation(ocam, rl, rr, p_ref, cl, cr, p_cur, R, rctx.params.tracker)
+    got = rctx.outlier_rejection_3d3d_given_rotation(rl, rr, p_ref, cl, cr, p_cur, R)
+    exp["iterations"] = got["iterations"] = 1
+    _same_ransac(got, exp)
+    if n_in >= 5:
+        assert exp["status"] == abi.TRACKING_VALID and list(exp["inliers"]) == list(range(n_in))
+
+
+def _euroc_ransac_params(**det):
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    for k, v in det.items():
+        setattr(p.detector, k, v)
+    return p
+
+
+def test_frontend_sequence_with_outlier_rejection(seq, ocam):
+    """The shipped params/Euroc/FrontendParams.yaml as it is (useRANSAC: 1, 2-point mono + 1-point
+    stereo): landmarks rejected by the mono RANSAC become -1 and are re-detected, measurements skip
+    them, TrackerStatusSummary (statuses, lkf_T_k, information matrix) identical to the oracle."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params()
+    fe = [O.Frontend(L, R, p)]
+    c = F.Context(L, R, p, batch=1)
+    try:
+        kinds = _run_sequence(fe, c, seq)
+        last = c.get_output(0)
+    finally:
+        c.close()
+    # the clip is almost static: the keyframe at 0.2 s is LOW_DISPARITY, which (VisionImuFrontend.cpp:
+    # 194-197) suppresses the "disparity low for the first time" keyframe at 0.4 s
+    assert [k[2] for k in kinds] == [1, 0, 0, 0, 1, 0, 0, 0, 0]
+    assert last["tracking_status_mono"] == abi.TRACKING_LOW_DISPARITY
+    assert last["tracking_status_stereo"] == abi.TRACKING_VALID
+    assert last["nr_mono_putatives"] > 250 and last["nr_mono_inliers"] > 30 and last["nr_stereo_inliers"] > 10
+
+
+def test_frontend_outlier_rejection_batched_and_forced_keyframes(seq, ocam):
+    """Outlier rejection on every frame (forced keyframes) for 3 streams with different frame orders:
+    exercises landmark -1 entries in frames k-1 / lkf (tracking gather, keyframe matching)."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=200)
+    p.tracker.ransac_threshold_mono = 2e-7   # tight: real outliers on most keyframes
+    B = 3
+    fe = [O.Frontend(L, R, p) for _ in range(B)]
+    c = F.Context(L, R, p, batch=B)
+
+    def stream_of(s, i):
+        return [i, 8 - i, (2 * i) % 9][s]
+
+    try:
+        _run_sequence(fe, c, seq, stream_of=stream_of, force_kf=True, n=8)
+        outs = [c.get_output(s) for s in range(B)]
+    finally:
+        c.close()
+    assert any((o["landmarks"] == -1).any() for o in outs)
