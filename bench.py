@@ -186,22 +186,53 @@ def main():
 
     value = pairs / elapsed
 
-    # ---- roofline of the dominant dense (HBM-bound) kernel, from HIP events in the timed region --
+    # ---- roofline, from HIP events recorded on the context's own stream inside the timed region ----
+    # Every dense (image-sized) kernel is priced against the HBM roofline with its ALGORITHMIC bytes
+    # per launch; `roofline` is the dominant dense kernel by time, `roofline_kernels`
+    # lists all of them.  `traffic` = HBM-side bytes per launch from the rocprofv3 PMC passes of the
+    # same command (profiles/pmc_traffic_latest.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    # correction of MI355X_MICROARCH.md for wide coalesced reads -> an upper bound), null when the
+    # committed counters were taken on another workload.
     stages = prof["stages"]
     ns = max(prof["n_samples"], 1)          # launches recorded per stage (all stream groups)
     groups = max(prof["n_groups"], 1)       # launches per step
+    pmc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+            pmc = json.load(f)
+    except OSError:
+        pass
+    pmc_ok = pmc is not None and (B, W, H, args.features, groups) == (64, 752, 480, 600, 1)
+    pmc_names = {"pyramid": ("pyrdown_kernel", 2), "mineig_localmax": ("mineig_localmax_kernel<false>", 1),
+                 "rectify": ("rectify_kernel<true>", 1)}
+
+    def traffic_of(stage):
+        if not pmc_ok or stage not in pmc_names:
+            return None
+        k, launches = pmc_names[stage]
+        if k not in pmc:
+            return None
+        return round((2.0 * pmc[k]["fetch_kb"] + pmc[k]["write_kb"]) * 1024.0 * launches)
+
     dense = {k: v for k, v in stages.items() if v["alg_bytes"] > 0 and v["ms_total"] > 0}
-    roofline = None
-    if dense:
-        name = max(dense, key=lambda k: dense[k]["ms_total"])
-        avg_ms = dense[name]["ms_total"] / ns
-        ach = dense[name]["alg_bytes"] / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
-                    "alg_bytes_per_launch": dense[name]["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)}
+    kernels = []
+    for name, v in dense.items():
+        avg_ms = v["ms_total"] / ns
+        ach = v["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+        kernels.append({"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic_of(name),
+                        "alg_bytes_per_launch": v["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)})
+    kernels.sort(key=lambda r: -r["avg_launch_ms"])
+    roofline = dict(kernels[0]) if kernels else None
     # per step: the launches of all stream groups added up (they overlap on the GPU, so the sum
     # exceeds ms_per_step when groups > 1)
     stage_ms = {k: round(v["ms_total"] / ns * groups, 5) for k, v in stages.items()}
+    # the sparse (per-keypoint) kernels are VALU-issue / latency bound, not HBM bound: their share of
+    # the step and the end-to-end algorithmic traffic are reported for context
+    n_px = float(W) * H
+    alg_pair = 7.33 * n_px  # SURVEY.md §8d, lambda recomputed instead of materialised
+    e2e = {"alg_bytes_per_pair": round(alg_pair), "achieved_GBps": round(alg_pair * (pairs / elapsed) / 1e9, 2),
+           "frac_of_hbm_peak": round(alg_pair * (pairs / elapsed) / 8e12, 5)}
 
     result = {
         "metric": "stereo-pairs/sec front-end (detect+track+match) @752x480",
@@ -217,6 +248,8 @@ def main():
                    "stream_groups": groups,
                    "parallelism": f"streams x{world}"},
         "roofline": roofline,
+        "roofline_kernels": kernels,
+        "end_to_end_traffic": e2e,
         "stage_ms_per_step_summed_over_groups": stage_ms,
         "pcie_inclusive": pcie,
         "host_enqueue_ms_per_step": round(1e3 * (t_enq - t0) / args.steps, 4),

@@ -162,7 +162,8 @@ class FeatureDetector {
   Context c_;
 };
 
-// Tracker::featureTracking core (src/frontend/Tracker.cpp:92-211): prediction + pyramidal LK
+// Tracker (src/frontend/Tracker.cpp): featureTracking core (:92-211: prediction + pyramidal LK) and the
+// IMU-aided geometric outlier rejection (:213-661)
 class Tracker {
  public:
   explicit Tracker(Context ctx) : c_(std::move(ctx)) {}
@@ -181,6 +182,54 @@ class Tracker {
                                            &px_ref.data()->x, &px_cur->data()->x, n, status->data(),
                                            error->data()),
              "calcOpticalFlowPyrLK");
+  }
+
+  // TrackingStatusPose (Tracker-definitions.h:126-133) with the pose as row-major 3x4 [R | t]
+  struct TrackingStatusPose {
+    int status = KVFE_TRACKING_INVALID;  // VIO::TrackingStatus
+    double pose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // stereo: infoMatStereoTranslation_
+  };
+  // geometricOutlierRejection2d2d(ref_bearings, cur_bearings, matches, inliers, cam_lkf_Pose_cam_kf)
+  // with ransac_use_2point_mono_ (Tracker.cpp:213-318); f_ref / f_cur: the matched bearing vectors
+  // (n x 3), R: cam_lkf_Pose_cam_kf.rotation().matrix() row-major
+  TrackingStatusPose geometricOutlierRejection2d2d(const std::vector<double>& f_ref,
+                                                   const std::vector<double>& f_cur, const double R[9],
+                                                   std::vector<int>* inliers) const {
+    const int32_t n = (int32_t)(f_ref.size() / 3);
+    std::vector<int32_t> inl((size_t)(n > 0 ? n : 1));
+    kvfe_ransac_output o;
+    c_.check(kvfe_outlier_rejection_2d2d_given_rotation(c_.get(), f_ref.data(), f_cur.data(), n, R,
+                                                        inl.data(), &o),
+             "geometricOutlierRejection2d2d");
+    inliers->assign(inl.begin(), inl.begin() + o.n_inliers);
+    TrackingStatusPose r;
+    r.status = o.status;
+    std::memcpy(r.pose, o.pose, sizeof(r.pose));
+    return r;
+  }
+  // geometricOutlierRejection3d3dGivenRotation (Tracker.cpp:382-632) on the stereo matches: per match
+  // the rectified left pixel, the rectified right x and keypoints_3d_ of the reference (last
+  // keyframe) and current frame
+  TrackingStatusPose geometricOutlierRejection3d3dGivenRotation(
+      const KeypointsCV& ref_left_rect, const std::vector<float>& ref_right_x,
+      const std::vector<double>& ref_points_3d, const KeypointsCV& cur_left_rect,
+      const std::vector<float>& cur_right_x, const std::vector<double>& cur_points_3d, const double R[9],
+      std::vector<int>* inliers) const {
+    const int32_t n = (int32_t)ref_left_rect.size();
+    std::vector<int32_t> inl((size_t)(n > 0 ? n : 1));
+    kvfe_ransac_output o;
+    c_.check(kvfe_outlier_rejection_3d3d_given_rotation(
+                 c_.get(), n ? &ref_left_rect.data()->x : nullptr, ref_right_x.data(), ref_points_3d.data(),
+                 n ? &cur_left_rect.data()->x : nullptr, cur_right_x.data(), cur_points_3d.data(), n, R,
+                 inl.data(), &o),
+             "geometricOutlierRejection3d3dGivenRotation");
+    inliers->assign(inl.begin(), inl.begin() + o.n_inliers);
+    TrackingStatusPose r;
+    r.status = o.status;
+    std::memcpy(r.pose, o.pose, sizeof(r.pose));
+    std::memcpy(r.info, o.info, sizeof(r.info));
+    return r;
   }
 
  private:

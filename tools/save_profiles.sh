@@ -14,3 +14,5 @@ cp gpurun_out/gpu_tests.log profiles/${T}_gpu_tests.log
   echo "SQ pass 2:"; echo;
   python tools/rocpd_pmc.py gpurun_out/prof_sq2/s2_results.db; } > profiles/${T}_pmc.md
 ls -la profiles/${T}_*
+python tools/rocpd_traffic.py gpurun_out/prof_fetch/f_results.db gpurun_out/prof_write/w_results.db > profiles/${T}_pmc_traffic.json
+cp profiles/${T}_pmc_traffic.json profiles/pmc_traffic_latest.json
