@@ -166,22 +166,40 @@ def main():
     assert out0["n_keypoints"] > 0 and outl["n_keypoints"] > 0, "front-end produced no keypoints"
     n_valid = int((out0["right_status"] == 0).sum()) if out0["is_keyframe"] else -1
 
-    # PCIe-inclusive rate (host buffers handed over at the boundary): reported, never `value`
+    # PCIe-inclusive rates (host buffers handed over at the boundary): reported, never `value`.
+    #  staged : the data provider writes into the context's pinned slots, the upload runs on a copy
+    #           stream and overlaps the previous step (kvfe_frontend_step_staged)
+    #  pageable: kvfe_frontend_step_host from ordinary host memory, copies on the compute stream
     pcie = None
     if rank == 0 and world == 1 and not args.no_single_stream:
-        hl = np.ascontiguousarray(lefts[:2])
-        hr = np.ascontiguousarray(rights[:2])
+        hl = np.ascontiguousarray(lefts[:3])
+        hr = np.ascontiguousarray(rights[:3])
         ctx.reset()
-        n_h = 6
+        n_h = 12
+        for sl in range(3):  # "decoded" frames sit in the pinned slots before the clock starts
+            a, b = ctx.staging_buffers(sl)
+            a[:] = hl[sl]
+            b[:] = hr[sl]
+        for i in range(3):
+            ctx.step_staged(i % 3, plan[i][1])
+        ctx.synchronize()
+        th = time.perf_counter()
+        for i in range(3, 3 + n_h):
+            ctx.step_staged(i % 3, plan[i][1])
+        ctx.synchronize()
+        staged = B * n_h / (time.perf_counter() - th)
+        ctx.reset()
         for i in range(2):
             ctx.step_host(hl[i % 2], hr[i % 2], plan[i][1])
         ctx.synchronize()
         th = time.perf_counter()
-        for i in range(2, 2 + n_h):
+        for i in range(2, 8):
             ctx.step_host(hl[i % 2], hr[i % 2], plan[i][1])
         ctx.synchronize()
-        pcie = {"value": round(B * n_h / (time.perf_counter() - th), 2), "unit": "stereo-pairs/s",
-                "note": "kvfe_frontend_step_host from pageable host memory, H2D copies inside the timed region"}
+        pcie = {"value": round(staged, 2), "unit": "stereo-pairs/s",
+                "note": "kvfe_frontend_step_staged: pinned staging slots, H2D upload of every frame inside the "
+                        "timed region on a copy stream overlapping the previous step",
+                "pageable_value": round(B * 6 / (time.perf_counter() - th), 2)}
     ctx.close()
 
     value = pairs / elapsed

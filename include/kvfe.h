@@ -172,6 +172,9 @@ typedef struct kvfe_stereo_params {
   int32_t templ_cols, templ_rows, stripe_extra_rows;
   int32_t subpixel_refinement;
   double min_point_dist, max_point_dist;
+  int32_t equalize_image;                    /* equalizeImage: cv::equalizeHist on both
+                                                input images (UtilsOpenCV.cpp:398-401) */
+  int32_t reserved0;
 } kvfe_stereo_params;
 
 /* VIO::FrontendParams (include/kimera-vio/frontend/VisionImuFrontendParams.h:25-76) */
@@ -267,6 +270,11 @@ KVFE_API kvfe_status kvfe_undistort_rectify_keypoints(kvfe_ctx* ctx, int32_t cam
 KVFE_API kvfe_status kvfe_get_bearing_vectors(kvfe_ctx* ctx, int32_t cam,
                                               const float* xy, int32_t n,
                                               double* out_versors);
+
+/* cv::equalizeHist as applied by UtilsOpenCV::ReadAndConvertToGrayScale(img, equalize = true)
+ * (src/utils/UtilsOpenCV.cpp:390-403; data provider side). */
+KVFE_API kvfe_status kvfe_equalize_hist(kvfe_ctx* ctx, const uint8_t* src, size_t src_stride,
+                                        uint8_t* dst, size_t dst_stride);
 
 /* FeatureDetector::rawFeatureDetection (FeatureDetector.cpp:165-172)
  * == cv::GFTTDetector::detect(img, kps, mask); mask may be NULL (all 255).
@@ -394,6 +402,18 @@ KVFE_API kvfe_status kvfe_frontend_step_host(kvfe_ctx* ctx, const uint8_t* left,
 KVFE_API kvfe_status kvfe_frontend_step_device(kvfe_ctx* ctx, const void* left_dev,
                                                const void* right_dev, size_t row_stride,
                                                size_t image_stride,
+                                               const kvfe_frame_input* inputs);
+/* Staged input (the hand-off the data provider feeds, EurocDataProvider.cpp:146-195
+ * / StereoDataProviderModule.cpp:35-91).  The context owns KVFE_STAGING_SLOTS pinned host slots of
+ * `batch` left + `batch` right images (tightly packed, width*height bytes each); the data provider
+ * decodes straight into a slot and calls kvfe_frontend_step_staged, which uploads the slot on a copy
+ * stream (overlapping the previous step's kernels) and enqueues the step.  A slot may be refilled
+ * once kvfe_frontend_staging_wait(slot) returns (its upload has completed). */
+#define KVFE_STAGING_SLOTS 3
+KVFE_API kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* ctx, int32_t slot, uint8_t** left,
+                                                  uint8_t** right);
+KVFE_API kvfe_status kvfe_frontend_staging_wait(kvfe_ctx* ctx, int32_t slot);
+KVFE_API kvfe_status kvfe_frontend_step_staged(kvfe_ctx* ctx, int32_t slot,
                                                const kvfe_frame_input* inputs);
 KVFE_API kvfe_status kvfe_frontend_reset(kvfe_ctx* ctx);
 KVFE_API kvfe_status kvfe_synchronize(kvfe_ctx* ctx);

@@ -82,6 +82,7 @@ class StereoParams(C.Structure):
         ("templ_cols", C.c_int32), ("templ_rows", C.c_int32),
         ("stripe_extra_rows", C.c_int32), ("subpixel_refinement", C.c_int32),
         ("min_point_dist", C.c_double), ("max_point_dist", C.c_double),
+        ("equalize_image", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

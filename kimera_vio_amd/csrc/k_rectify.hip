@@ -266,4 +266,80 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cv::equalizeHist (reference: UtilsOpenCV::ReadAndConvertToGrayScale, src/utils/UtilsOpenCV.cpp:398-401)
+// pass 1: 256-bin histogram per image (LDS histogram per block, one global atomic per occupied bin)
+// pass 2: LUT = saturate_cast<uchar>(cumulative count above the first occupied bin * scale) rebuilt
+//         by every block from the 1 KB histogram, applied to 16 pixels per lane
+// ---------------------------------------------------------------------------------------------
+constexpr int EQ_T = 256;
+constexpr int EQ_PX = EQ_T * 16 * 4;  // pixels per block
+
+__global__ __launch_bounds__(EQ_T) void equalize_count_kernel(const unsigned char* __restrict__ src,
+                                                              size_t row_stride, size_t img_stride,
+                                                              int W, int H, int* __restrict__ hist) {
+  __shared__ int lh[256];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  lh[tid] = 0;
+  __syncthreads();
+  const unsigned char* S = src + (size_t)s * img_stride;
+  const int N = W * H;
+  const int p0 = blockIdx.x * EQ_PX;
+  for (int p = p0 + tid * 4; p < min(N, p0 + EQ_PX); p += EQ_T * 4) {
+    // 4 consecutive pixels (a row may have any stride; W % 4 == 0 is not assumed)
+    for (int k = 0; k < 4 && p + k < N; k++) {
+      const int y = (p + k) / W, x = (p + k) - y * W;
+      atomicAdd(&lh[S[(size_t)y * row_stride + x]], 1);
+    }
+  }
+  __syncthreads();
+  const int c = lh[tid];
+  if (c) atomicAdd(&hist[s * 256 + tid], c);
+}
+
+__global__ __launch_bounds__(EQ_T) void equalize_apply_kernel(const unsigned char* __restrict__ src,
+                                                              size_t row_stride, size_t img_stride,
+                                                              int W, int H,
+                                                              const int* __restrict__ hist,
+                                                              unsigned char* __restrict__ dst) {
+  __shared__ int lh[256];
+  __shared__ unsigned char lut[256];
+  __shared__ int sh_first;
+  const int s = blockIdx.y, tid = threadIdx.x;
+  lh[tid] = hist[s * 256 + tid];
+  if (tid == 0) sh_first = 256;
+  __syncthreads();
+  if (lh[tid]) atomicMin(&sh_first, tid);
+  __syncthreads();
+  const int first = sh_first, total = W * H;
+  if (lh[first] == total) {
+    lut[tid] = (unsigned char)first;  // dst.setTo(i)
+  } else {
+    const float scale = (256 - 1.f) / (float)(total - lh[first]);
+    int sum = 0;
+    for (int i = first + 1; i <= tid; i++) sum += lh[i];
+    const int v = __float2int_rn((float)sum * scale);
+    lut[tid] = tid <= first ? 0 : (unsigned char)min(max(v, 0), 255);
+  }
+  __syncthreads();
+  const unsigned char* S = src + (size_t)s * img_stride;
+  unsigned char* D = dst + (size_t)s * total;
+  const int p0 = blockIdx.x * EQ_PX;
+  for (int p = p0 + tid * 4; p < min(total, p0 + EQ_PX); p += EQ_T * 4)
+    for (int k = 0; k < 4 && p + k < total; k++) {
+      const int y = (p + k) / W, x = (p + k) - y * W;
+      D[p + k] = lut[S[(size_t)y * row_stride + x]];
+    }
+}
+
+void launch_equalize_hist(int W, int H, int B, const unsigned char* src, size_t src_row_stride,
+                          size_t src_img_stride, unsigned char* dst, int* hist, hipStream_t st) {
+  hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)B, st);
+  const dim3 grid((W * H + EQ_PX - 1) / EQ_PX, B);
+  hipLaunchKernelGGL(equalize_count_kernel, grid, dim3(EQ_T), 0, st, src, src_row_stride, src_img_stride,
+                     W, H, hist);
+  hipLaunchKernelGGL(equalize_apply_kernel, grid, dim3(EQ_T), 0, st, src, src_row_stride, src_img_stride,
+                     W, H, hist, dst);
+}
+
 }  // namespace kvfe

@@ -49,8 +49,14 @@ struct Buffers {  // everything that scales with the number of streams
   int B = 0;
   unsigned char* rect[2] = {nullptr, nullptr};
   unsigned char* pyr[2] = {nullptr, nullptr};
-  unsigned char* raw_left[2] = {nullptr, nullptr};  // ctx-owned copies (host-input path)
-  unsigned char* raw_right = nullptr;
+  // ctx-owned image slots (host-input / staged / equalised paths): a left image is read by two
+  // consecutive steps (LK re-reads frame k-1), a right image by one -> three / two slots let the
+  // upload of frame k+1 overlap the kernels of frame k
+  unsigned char* raw_left[3] = {nullptr, nullptr, nullptr};
+  unsigned char* raw_right2[2] = {nullptr, nullptr};
+  unsigned char*& raw_right = raw_right2[0];
+  unsigned char* eq_in[2] = {nullptr, nullptr};  // staged upload target when equalizeImage is on
+  int* eq_hist = nullptr;                        // [2][B][256]
   unsigned char* user_mask = nullptr;
   FrameTab ft[3];
   StereoTab st;
@@ -84,6 +90,15 @@ struct kvfe_ctx {
   const unsigned char* prev_left = nullptr;
   size_t prev_row_stride = 0, prev_img_stride = 0;
   int raw_slot = 0;
+  long long img_step = 0;  // steps that went through the ctx-owned image slots
+  // staged input (kvfe_frontend_step_staged)
+  unsigned char* stage_host[KVFE_STAGING_SLOTS] = {};
+  hipEvent_t stage_copied[KVFE_STAGING_SLOTS] = {};
+  bool stage_pending[KVFE_STAGING_SLOTS] = {};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t step_done[4] = {};
+  bool step_done_valid[4] = {};
+  bool last_step_staged = false;
   int pts_bound = 0;
   // pinned input staging ring
   static constexpr int RING = 64;
@@ -167,8 +182,10 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
     TRY(dalloc(c, &b.rect[i], N * B));
     TRY(dalloc(c, &b.pyr[i], (size_t)P.pyr_stride * B));
     TRY(dalloc(c, &b.raw_left[i], N * B));
+    TRY(dalloc(c, &b.raw_right2[i], N * B));
   }
-  TRY(dalloc(c, &b.raw_right, N * B));
+  TRY(dalloc(c, &b.raw_left[2], N * B));
+  TRY(dalloc(c, &b.eq_hist, 2 * 256 * B));
   for (int i = 0; i < 3; i++) {
     TRY(dalloc(c, &b.ft[i].kp, K));
     TRY(dalloc(c, &b.ft[i].lmk, K));
@@ -822,6 +839,7 @@ void kvfe_default_frontend_params(kvfe_frontend_params* p) {
   s.templ_rows = 11;
   s.min_point_dist = 0.1;
   s.max_point_dist = 15.0;
+  s.equalize_image = 0;
   p->min_intra_keyframe_time_ns = 0.2 * 10e6;
   p->max_intra_keyframe_time_ns = 10.0 * 10e6;
   p->max_disparity_since_lkf = 200.0;
@@ -973,6 +991,14 @@ void kvfe_destroy(kvfe_ctx* c) {
     hipStreamSynchronize(c->side);
     hipStreamDestroy(c->side);
   }
+  if (c->copy_stream) {
+    hipStreamSynchronize(c->copy_stream);
+    hipStreamDestroy(c->copy_stream);
+  }
+  for (int i = 0; i < KVFE_STAGING_SLOTS; i++)
+    if (c->stage_copied[i]) hipEventDestroy(c->stage_copied[i]);
+  for (int i = 0; i < 4; i++)
+    if (c->step_done[i]) hipEventDestroy(c->step_done[i]);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   for (void* p : c->allocs) hipFree(p);
@@ -1007,6 +1033,20 @@ kvfe_status kvfe_undistort_rectify_image(kvfe_ctx* c, int32_t cam, const uint8_t
   launch_rectify(c->Pc, c->T, srcs, c->P.W, (size_t)c->P.W * c->P.H, dsts, nullptr, 0, c->stream);
   HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, b.rect[cam], c->P.W, c->P.W, c->P.H,
                              hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_equalize_hist(kvfe_ctx* c, const uint8_t* src, size_t src_stride, uint8_t* dst,
+                               size_t dst_stride) {
+  if (!c || !src || !dst) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  TRY(upload_image(c, b.raw_left[0], src, src_stride));
+  launch_equalize_hist(c->P.W, c->P.H, 1, b.raw_left[0], c->P.W, (size_t)c->P.W * c->P.H, b.raw_left[1],
+                       b.eq_hist, c->stream);
+  HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, b.raw_left[1], c->P.W, c->P.W, c->P.H, hipMemcpyDeviceToHost,
+                             c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return KVFE_OK;
 }
@@ -1321,6 +1361,21 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
     return step_groups(c, reinterpret_cast<const unsigned char*>(left_dev),
                        reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride,
                        inputs, false);
+  if (c->cfg.params.stereo.equalize_image) {  // equalised copies live in the ctx-owned slots
+    Buffers& b = c->fe;
+    const KParams& P = c->P;
+    const size_t N = (size_t)P.W * P.H;
+    unsigned char* dl = b.raw_left[c->img_step % 3];
+    unsigned char* dr = b.raw_right2[c->img_step % 2];
+    launch_equalize_hist(P.W, P.H, P.B, reinterpret_cast<const unsigned char*>(left_dev), row_stride,
+                         image_stride, dl, b.eq_hist, c->stream);
+    launch_equalize_hist(P.W, P.H, P.B, reinterpret_cast<const unsigned char*>(right_dev), row_stride,
+                         image_stride, dr, b.eq_hist + 256 * P.B, c->stream);
+    c->img_step++;
+    c->last_step_staged = false;
+    return do_step(c, dl, dr, P.W, N, inputs);
+  }
+  c->last_step_staged = false;
   return do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
                  reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
 }
@@ -1334,15 +1389,107 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   Buffers& b = c->fe;
   const KParams& P = c->P;
   const size_t N = (size_t)P.W * P.H;
-  unsigned char* dl = b.raw_left[c->raw_slot];
-  c->raw_slot ^= 1;
-  for (int s = 0; s < P.B; s++) {
-    HIPCHK(c, hipMemcpy2DAsync(dl + s * N, P.W, left + s * image_stride, row_stride, P.W, P.H,
-                               hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(b.raw_right + s * N, P.W, right + s * image_stride, row_stride, P.W,
-                               P.H, hipMemcpyHostToDevice, c->stream));
+  const bool eq = c->cfg.params.stereo.equalize_image != 0;
+  unsigned char* dl = b.raw_left[c->img_step % 3];
+  unsigned char* dr = b.raw_right2[c->img_step % 2];
+  unsigned char* ul = eq ? b.rect[0] : dl;  // (rectified buffers are free until rectification runs)
+  unsigned char* ur = eq ? b.rect[1] : dr;
+  if (row_stride == (size_t)P.W && image_stride == N) {  // tightly packed batch: one copy per side
+    HIPCHK(c, hipMemcpyAsync(ul, left, N * P.B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ur, right, N * P.B, hipMemcpyHostToDevice, c->stream));
+  } else {
+    for (int s = 0; s < P.B; s++) {
+      HIPCHK(c, hipMemcpy2DAsync(ul + s * N, P.W, left + s * image_stride, row_stride, P.W, P.H,
+                                 hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpy2DAsync(ur + s * N, P.W, right + s * image_stride, row_stride, P.W, P.H,
+                                 hipMemcpyHostToDevice, c->stream));
+    }
   }
-  return do_step(c, dl, b.raw_right, P.W, N, inputs);
+  if (eq) {
+    launch_equalize_hist(P.W, P.H, P.B, ul, P.W, N, dl, b.eq_hist, c->stream);
+    launch_equalize_hist(P.W, P.H, P.B, ur, P.W, N, dr, b.eq_hist + 256 * P.B, c->stream);
+  }
+  c->img_step++;
+  c->last_step_staged = false;
+  return do_step(c, dl, dr, P.W, N, inputs);
+}
+
+// ---- staged input -----------------------------------------------------------------
+static kvfe_status ensure_staging(kvfe_ctx* c) {
+  if (c->copy_stream) return KVFE_OK;
+  const size_t bytes = 2 * (size_t)c->P.W * c->P.H * c->P.B;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < KVFE_STAGING_SLOTS; i++) {
+    void* h = nullptr;
+    HIPCHK(c, hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    c->host_allocs.push_back(h);
+    c->stage_host[i] = reinterpret_cast<unsigned char*>(h);
+    HIPCHK(c, hipEventCreateWithFlags(&c->stage_copied[i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
+  if (c->cfg.params.stereo.equalize_image)
+    for (int i = 0; i < 2; i++) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* c, int32_t slot, uint8_t** left, uint8_t** right) {
+  if (!c || !left || !right || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
+  if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;  // staged input drives one stream group
+  TRY(ensure_staging(c));
+  *left = c->stage_host[slot];
+  *right = c->stage_host[slot] + (size_t)c->P.W * c->P.H * c->P.B;
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_frontend_staging_wait(kvfe_ctx* c, int32_t slot) {
+  if (!c || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
+  if (c->stage_pending[slot]) {
+    HIPCHK(c, hipEventSynchronize(c->stage_copied[slot]));
+    c->stage_pending[slot] = false;
+  }
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_frame_input* inputs) {
+  if (!c || !inputs || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
+  if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;
+  TRY(ensure_staging(c));
+  Buffers& b = c->fe;
+  const KParams& P = c->P;
+  const size_t N = (size_t)P.W * P.H, NB = N * P.B;
+  const bool eq = c->cfg.params.stereo.equalize_image != 0;
+  const long long n = c->img_step;
+  unsigned char* dl = b.raw_left[n % 3];
+  unsigned char* dr = b.raw_right2[n % 2];
+  // the upload may start as soon as the last readers of its target are done: left slot n%3 was
+  // frame n-3 (read by steps n-3 and n-2), right slot n%2 was frame n-2; the equalise inputs are
+  // free once step n-1 has consumed them -> wait for step n-2 (n-1 with equalisation)
+  const long long dep = eq ? n - 1 : n - 2;
+  if (n > 0 && !c->last_step_staged) {
+    // the previous step went through another entry point: order the upload after everything enqueued
+    HIPCHK(c, hipEventRecord(c->step_done[(n - 1) % 4], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->step_done[(n - 1) % 4], 0));
+    c->step_done_valid[(n - 1) % 4] = true;
+  } else if (dep >= 0 && c->step_done_valid[dep % 4]) {
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->step_done[dep % 4], 0));
+  }
+  unsigned char* ul = eq ? b.eq_in[0] : dl;
+  unsigned char* ur = eq ? b.eq_in[1] : dr;
+  HIPCHK(c, hipMemcpyAsync(ul, c->stage_host[slot], NB, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(c, hipMemcpyAsync(ur, c->stage_host[slot] + NB, NB, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(c, hipEventRecord(c->stage_copied[slot], c->copy_stream));
+  c->stage_pending[slot] = true;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->stage_copied[slot], 0));
+  if (eq) {
+    launch_equalize_hist(P.W, P.H, P.B, ul, P.W, N, dl, b.eq_hist, c->stream);
+    launch_equalize_hist(P.W, P.H, P.B, ur, P.W, N, dr, b.eq_hist + 256 * P.B, c->stream);
+  }
+  c->img_step++;
+  TRY(do_step(c, dl, dr, P.W, N, inputs));
+  HIPCHK(c, hipEventRecord(c->step_done[n % 4], c->stream));
+  c->step_done_valid[n % 4] = true;
+  c->last_step_staged = true;
+  return KVFE_OK;
 }
 
 kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
@@ -1368,6 +1515,8 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   HIPCHK(c, hipMemcpy(b.ss.kf_R_ref, eye.data(), sizeof(double) * B * 9, hipMemcpyHostToDevice));
   HIPCHK(c, hipStreamSynchronize(st));
   c->prev_left = nullptr;
+  c->img_step = 0;
+  for (int i = 0; i < 4; i++) c->step_done_valid[i] = false;
   c->role_k = 0;
   c->role_km1 = 1;
   c->role_lkf = 2;

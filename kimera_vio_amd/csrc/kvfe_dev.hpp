@@ -188,6 +188,9 @@ __host__ __device__ inline int reflect101(int p, int len) {
 void launch_rectify(const KParams& P, const Tables& T, const unsigned char* const src[2],
                     size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
                     const int* flags, int act_flag, hipStream_t st);
+// cv::equalizeHist of B images: dst[s] = lut_s(src[s]); hist: [B][256] int scratch (zeroed here)
+void launch_equalize_hist(int W, int H, int B, const unsigned char* src, size_t src_row_stride,
+                          size_t src_img_stride, unsigned char* dst, int* hist, hipStream_t st);
 // K4a: pyramid levels 1..nlevels-1 of `img` into pyr.
 void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
                     size_t img_stride, unsigned char* pyr, hipStream_t st);

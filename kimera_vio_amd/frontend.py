@@ -101,6 +101,14 @@ class Context:
                   "get_bearing_vectors")
         return out
 
+    def equalize_hist(self, img) -> np.ndarray:
+        """cv::equalizeHist as UtilsOpenCV::ReadAndConvertToGrayScale(img, equalize=True) applies it."""
+        img = _img(img)
+        out = np.empty_like(img)
+        self._chk(self.lib.kvfe_equalize_hist(self._h, _p(img), img.strides[0], _p(out), out.strides[0]),
+                  "equalize_hist")
+        return out
+
     # ---- FeatureDetector -----------------------------------------------------------------------
     def raw_feature_detection(self, img, mask=None) -> np.ndarray:
         img = _img(img)
@@ -248,6 +256,24 @@ class Context:
                                                      row_stride or self.w,
                                                      image_stride or self.w * self.h, inputs),
                   "frontend_step_device")
+
+    def staging_buffers(self, slot: int):
+        """numpy views [batch, H, W] of the pinned left / right staging slot `slot`."""
+        pl, pr = C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.kvfe_frontend_staging_buffer(self._h, slot, C.byref(pl), C.byref(pr)),
+                  "frontend_staging_buffer")
+        n = self.batch * self.h * self.w
+        shape = (self.batch, self.h, self.w)
+        left = np.ctypeslib.as_array((C.c_uint8 * n).from_address(pl.value)).reshape(shape)
+        right = np.ctypeslib.as_array((C.c_uint8 * n).from_address(pr.value)).reshape(shape)
+        return left, right
+
+    def staging_wait(self, slot: int):
+        self._chk(self.lib.kvfe_frontend_staging_wait(self._h, slot), "frontend_staging_wait")
+
+    def step_staged(self, slot: int, inputs):
+        """upload staging slot `slot` on the copy stream (overlapping the previous step) and step."""
+        self._chk(self.lib.kvfe_frontend_step_staged(self._h, slot, inputs), "frontend_step_staged")
 
     def synchronize(self):
         self._chk(self.lib.kvfe_synchronize(self._h), "synchronize")

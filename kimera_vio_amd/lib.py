@@ -71,6 +71,10 @@ def load() -> C.CDLL:
                                                              C.POINTER(abi.RansacOutput)]
     L.kvfe_outlier_rejection_3d3d_given_rotation.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
                                                              C.POINTER(abi.RansacOutput)]
+    L.kvfe_equalize_hist.argtypes = [vp, vp, sz, vp, sz]
+    L.kvfe_frontend_staging_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.kvfe_frontend_staging_wait.argtypes = [vp, i32]
+    L.kvfe_frontend_step_staged.argtypes = [vp, i32, vp]
     L.kvfe_frontend_step_host.argtypes = [vp, vp, vp, sz, sz, vp]
     L.kvfe_frontend_step_device.argtypes = [vp, vp, vp, sz, sz, vp]
     L.kvfe_frontend_reset.argtypes = [vp]
@@ -87,7 +91,9 @@ def load() -> C.CDLL:
                "kvfe_calc_optical_flow_pyr_lk", "kvfe_predict_sparse_flow",
                "kvfe_get_right_keypoints_rectified", "kvfe_sparse_stereo_reconstruction",
                "kvfe_outlier_rejection_2d2d_given_rotation",
-               "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
+               "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_equalize_hist",
+               "kvfe_frontend_staging_buffer", "kvfe_frontend_staging_wait", "kvfe_frontend_step_staged",
+               "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
                "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
                "kvfe_profile_read"):
         getattr(L, fn).restype = C.c_int32
@@ -103,7 +109,9 @@ EXPORTED_SYMBOLS = [
     "kvfe_feature_detection", "kvfe_corner_subpix", "kvfe_calc_optical_flow_pyr_lk",
     "kvfe_predict_sparse_flow", "kvfe_get_right_keypoints_rectified",
     "kvfe_sparse_stereo_reconstruction", "kvfe_outlier_rejection_2d2d_given_rotation",
-    "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_frontend_step_host", "kvfe_frontend_step_device",
+    "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_equalize_hist", "kvfe_frontend_staging_buffer",
+    "kvfe_frontend_staging_wait", "kvfe_frontend_step_staged", "kvfe_frontend_step_host",
+    "kvfe_frontend_step_device",
     "kvfe_frontend_reset", "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
     "kvfe_profile_read",
 ]

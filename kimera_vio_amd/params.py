@@ -75,6 +75,7 @@ def default_frontend_params() -> abi.FrontendParams:
     s.templ_rows = 11
     s.stripe_extra_rows = 0
     s.subpixel_refinement = 0
+    s.equalize_image = 0
     s.min_point_dist = 0.1
     s.max_point_dist = 15.0
     p.min_intra_keyframe_time_ns = 0.2 * 10e6   # sic: VisionImuFrontendParams.h:48
@@ -154,6 +155,7 @@ def load_frontend_params(path: str, use_ransac: int | None = 0) -> abi.FrontendP
     s.min_point_dist = float(y["minPointDist"])
     s.max_point_dist = float(y["maxPointDist"])
     s.subpixel_refinement = int(y["subpixelRefinementStereo"])
+    s.equalize_image = int(y["equalizeImage"])
     p.min_intra_keyframe_time_ns = float(y.get("min_intra_keyframe_time", y.get("intra_keyframe_time", 0.2))) * 1e9
     p.max_intra_keyframe_time_ns = float(y.get("max_intra_keyframe_time", 5.0)) * 1e9
     p.min_number_features = int(y["minNumberFeatures"])

@@ -105,6 +105,9 @@ KVO_API void kvo_corner_subpix(const uint8_t* img, int w, int h, size_t stride, 
                                int win, int zero_zone, int max_iters, double eps) {
   ocv::cornerSubPix(img, w, h, stride, (Point2f*)xy, n, win, zero_zone, max_iters, eps);
 }
+KVO_API void kvo_equalize_hist(const uint8_t* src, int w, int h, size_t stride, uint8_t* dst) {
+  ocv::equalizeHist(src, w, h, stride, dst, w);
+}
 KVO_API void kvo_pyr_down(const uint8_t* src, int w, int h, size_t stride, uint8_t* dst) {
   ocv::pyrDown(src, w, h, stride, dst, (w + 1) / 2, (h + 1) / 2, (w + 1) / 2);
 }

@@ -716,6 +716,10 @@ void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
     std::memcpy(&k.left.img[(size_t)y * w], left + (size_t)y * stride, w);
     std::memcpy(&k.right_img[(size_t)y * w], right + (size_t)y * stride, w);
   }
+  if (p.stereo.equalize_image) {  // UtilsOpenCV::ReadAndConvertToGrayScale(name, equalize) on both views
+    ocv::equalizeHist(k.left.img.data(), w, h, w, k.left.img.data(), w);
+    ocv::equalizeHist(k.right_img.data(), w, h, w, k.right_img.data(), w);
+  }
   meas_lmk.clear();
   meas_uLuRv.clear();
 

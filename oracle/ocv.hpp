@@ -119,6 +119,9 @@ void circle_filled(uint8_t* img, int w, int h, size_t stride, int cx, int cy, in
 void cornerSubPix(const uint8_t* img, int w, int h, size_t stride, Point2f* corners, int n,
                   int win, int zero_zone, int max_iters, double eps);
 
+// cv::equalizeHist(src u8, dst) (reference call: UtilsOpenCV.cpp:398-401, equalizeImage: 1)
+void equalizeHist(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+
 // cv::pyrDown(src u8, dst, Size((w+1)/2,(h+1)/2), BORDER_DEFAULT).
 void pyrDown(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,
              size_t dstride);

@@ -414,6 +414,30 @@ void cornerSubPix(const uint8_t* img, int w, int h, size_t stride, Point2f* corn
 }
 
 // ---------------------------------------------------------------------------
+// cv::equalizeHist (imgproc/src/histogram.cpp): 256-bin histogram, LUT = saturate_cast<uchar>(
+// cumulative count above the first occupied bin * (255.f / (total - hist[first]))), float arithmetic
+void equalizeHist(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride) {
+  int hist[256] = {0}, lut[256] = {0};
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) hist[src[(size_t)y * sstride + x]]++;
+  int i = 0;
+  while (!hist[i]) ++i;
+  const int total = w * h;
+  if (hist[i] == total) {
+    for (int y = 0; y < h; y++) std::memset(dst + (size_t)y * dstride, i, w);
+    return;
+  }
+  const float scale = (256 - 1.f) / (total - hist[i]);
+  int sum = 0;
+  for (lut[i++] = 0; i < 256; ++i) {
+    sum += hist[i];
+    int v = cvRoundf(sum * scale);
+    lut[i] = v < 0 ? 0 : (v > 255 ? 255 : v);
+  }
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) dst[(size_t)y * dstride + x] = (uint8_t)lut[src[(size_t)y * sstride + x]];
+}
+
 // cv::pyrDown (u8, 5x5 [1 4 6 4 1]/16, REFLECT_101, (sum+128)>>8)
 // ---------------------------------------------------------------------------
 void pyrDown(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,

@@ -70,6 +70,7 @@ def lib() -> C.CDLL:
     L.kvo_corner_subpix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_double]
     L.kvo_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+    L.kvo_equalize_hist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
     L.kvo_calc_optical_flow_pyr_lk.restype = C.c_int
     L.kvo_calc_optical_flow_pyr_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -145,6 +146,14 @@ def good_features_to_track(img, max_corners, quality, min_dist, block=3, mask=No
                                          _p(q), cap)
     n = min(n, cap)
     return xy[:n].copy(), q[:n].copy()
+
+
+def equalize_hist(img):
+    img = _img(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().kvo_equalize_hist(_p(img), w, h, w, _p(out))
+    return out
 
 
 def corner_min_eigen_val(img, block=3):

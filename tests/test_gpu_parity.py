@@ -582,3 +582,56 @@ def test_frontend_outlier_rejection_batched_and_forced_keyframes(seq, ocam):
     finally:
         c.close()
     assert any((o["landmarks"] == -1).any() for o in outs)
+
+
+# ---------------------------------------------------------------------------------------------
+# input side: equalizeHist and the staged (pinned, copy-stream) hand-off
+# ---------------------------------------------------------------------------------------------
+def test_equalize_hist_bit_exact(ctx):
+    for name in ("left_img_0.png", "right_img_0.png", "left_fisheye_img_0.png"):
+        img = gray(name)
+        assert np.array_equal(ctx.equalize_hist(img), O.equalize_hist(img)), name
+    const = np.full((480, 752), 200, np.uint8)
+    assert np.array_equal(ctx.equalize_hist(const), const)
+
+
+@pytest.mark.parametrize("equalize", [0, 1])
+def test_frontend_staged_input_matches_host_input(seq, ocam, equalize):
+    """kvfe_frontend_step_staged (pinned slots, upload on the copy stream overlapping the previous
+    step) == kvfe_frontend_step_host == oracle, with and without equalizeImage, 2 streams."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=150)
+    p.stereo.equalize_image = equalize
+    B = 2
+    fe = [O.Frontend(L, R, p) for _ in range(B)]
+    c = F.Context(L, R, p, batch=B)
+    try:
+        kf = [0] * B
+        for i in range(9):
+            idx = [i, 8 - i]
+            Rs = [seq["camR"][kf[s]].T @ seq["camR"][idx[s]] for s in range(B)]
+            ts = [int(seq["ts"][i])] * B
+            slot = i % 3
+            c.staging_wait(slot)
+            sl, sr = c.staging_buffers(slot)
+            for s in range(B):
+                sl[s] = seq["lefts"][idx[s]]
+                sr[s] = seq["rights"][idx[s]]
+            c.step_staged(slot, c.make_inputs(ts, Rs, [0] * B))   # enqueue only: the next slot is
+            if i + 1 < 9:                                           # filled while this step runs
+                c.staging_wait((i + 1) % 3)
+            for s in range(B):
+                exp = fe[s].process(seq["lefts"][idx[s]], seq["rights"][idx[s]], ts[s], Rs[s], False)
+                got = c.get_output(s)
+                for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected", "n_measurements",
+                          "tracking_status_mono", "tracking_status_stereo"):
+                    assert got[k] == exp[k], (i, s, k)
+                for k in ("landmarks", "keypoints", "versors"):
+                    assert np.array_equal(got[k], exp[k]), (i, s, k)
+                if exp["is_keyframe"]:
+                    assert np.array_equal(got["meas_uL_uR_v"], exp["meas_uL_uR_v"], equal_nan=True)
+                    kf[s] = idx[s]
+    finally:
+        c.close()

@@ -336,3 +336,25 @@ def test_process_first_frame_synthetic_pair():
     v = out["versors"]
     v_exp = v * (depth_gt[idx] / v[:, 2])[:, None]
     assert np.max(np.linalg.norm(v_exp - out["keypoints_3d"], axis=1)) < 5.0
+
+
+def test_equalize_hist_properties():
+    """cv::equalizeHist (UtilsOpenCV.cpp:398-401, equalizeImage: 1).  The reference holds no golden
+    image for it (parity unpinned); the restatement is checked on the properties the algorithm
+    defines: monotone LUT starting at 0 for the first occupied bin, 255 for the last occupied bin,
+    the LUT formula itself in float32, and the constant-image special case."""
+    img = np.array(Image.open(os.path.join(G, "left_img_0.png")).convert("L"))
+    out = O.equalize_hist(img)
+    hist = np.bincount(img.ravel(), minlength=256)
+    first = int(np.nonzero(hist)[0][0])
+    last = int(np.nonzero(hist)[0][-1])
+    scale = np.float32(255.0) / np.float32(img.size - hist[first])
+    csum = np.cumsum(hist) - hist[:first + 1].sum()
+    lut = np.zeros(256, np.int64)
+    for i in range(first + 1, 256):
+        lut[i] = int(np.clip(np.rint(np.float32(csum[i]) * scale), 0, 255))
+    assert np.array_equal(out, lut[img].astype(np.uint8))
+    assert out[img == first].max() == 0 and out[img == last].min() == 255
+    assert np.all(np.diff(lut[first:last + 1]) >= 0)
+    const = np.full((48, 64), 77, np.uint8)
+    assert np.array_equal(O.equalize_hist(const), const)

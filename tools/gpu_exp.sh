@@ -1,5 +1,5 @@
-timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-for r in 1; do echo "== ransac $r"; python bench.py --ransac $r --no-cpu-baseline | python -c "
+timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py --no-cpu-baseline | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms_per_step_summed_over_groups'], d['check'], d['single_stream'])"
-done
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['pcie_inclusive'], d['roofline_kernels'], d['end_to_end_traffic'])"
