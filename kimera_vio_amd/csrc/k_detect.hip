@@ -652,6 +652,134 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   } else if (P.anms_type == 0 /* TopN: receives the UNSORTED keypoints */) {
     n_new = need > n_corners ? n_corners : need;
     for (int i = tid; i < n_new; i += SEL_T) newc[i] = corners[i];
+  } else if (P.anms_type >= 2 && P.anms_type <= 5) {
+    // ---- anms::Sdc / KdTree / RangeTree / Ssc (anms/anms.cpp:83-436) on the permuted keypoints -----
+    // Binary search on the suppression radius; every probe is the greedy sweep "keep a keypoint
+    // unless an already kept one covers it", run by one wave 64 candidates at a time (test against
+    // the kept list, then resolve the batch in order with ballots).  The spatial indices of the
+    // reference only accelerate the covering relation, which is evaluated directly:
+    //   SDC (2)       cells of side c = 0.25 r / sqrt 2 : sqrt(dr^2 + dc^2) <= r / c
+    //   KdTree (3)    dx^2 + dy^2 < r^2 on integer pixels
+    //   RangeTree (4) |dx| <= w and |dy| <= w
+    //   SSC (5)       cells of side c = (double)(w / 2) : |dr|, |dc| <= floor(w / c)
+    // The sweep that defines the result is replayed once at the end to write the corners out.
+    const unsigned short* perm = T.sortidx + T.sortidx_off[n_corners];
+    int* pxy = reinterpret_cast<int*>(cell_start);          // [n] x | y << 16 of the permuted keypoints
+    int* sel = pxy + n_corners;                              // [n] kept keypoints (pixel or cell coords)
+    const int n = n_corners;
+    const int type = P.anms_type;
+    for (int i = tid; i < n; i += SEL_T) {
+      const float2 c = corners[perm[i]];
+      pxy[i] = (int)c.x | ((int)c.y << 16);
+    }
+    if (tid == 0) sh_flag = 0;
+    __syncthreads();
+    if (tid < 64 && need >= 2 && 3 * n <= MAX_CELLS + 1) {
+      const int lane = tid;
+      int low, high;
+      if (type == 2) {
+        low = 1;
+        high = W;
+      } else {
+        const int exp1 = H + W + 2 * need;
+        const long long exp2 = ((long long)4 * W + (long long)4 * need + (long long)4 * H * need +
+                                (long long)H * H + (long long)W * W - (long long)2 * H * W +
+                                (long long)4 * H * W * need);
+        const double exp3 = sqrt((double)exp2);
+        const double exp4 = need - 1;
+        const double sol1 = -round((exp1 + exp3) / exp4);
+        const double sol2 = -round((exp1 - exp3) / exp4);
+        high = (int)((sol1 > sol2) ? sol1 : sol2);
+        low = (int)floor(sqrt((double)n / need));
+      }
+      const float Kf = (float)(unsigned)need;
+      const unsigned Kmin = (unsigned)roundf(Kf - (Kf * 0.1f));
+      const unsigned Kmax = (unsigned)roundf(Kf + (Kf * 0.1f));
+      // one greedy sweep for radius r; write != nullptr: the kept keypoints go to newc
+      auto sweep = [&](int r, bool write) -> int {
+        double c = 0.0, reach = 0.0;
+        if (type == 2) {
+          c = 0.25 * r / sqrt(2.0);
+          reach = ((double)r) / c;
+        } else if (type == 5) {
+          c = (double)(r / 2);
+          reach = floor(r / c);
+        }
+        const int ireach = (int)reach;
+        const int r2 = r * r;
+        int nsel = 0;
+        for (int base = 0; base < n; base += 64) {
+          const int i = base + lane;
+          const bool valid = i < n;
+          const int v = valid ? pxy[i] : 0;
+          int a = v & 0xffff, b = v >> 16;  // pixel (x, y) ...
+          if (type == 2 || type == 5) {     // ... or cell (col, row)
+            a = (int)floor((float)(v & 0xffff) / c);
+            b = (int)floor((float)(v >> 16) / c);
+          }
+          auto covers = [&](int sa, int sb) -> bool {
+            const int da = a - sa, db = b - sb;
+            if (type == 2) return sqrt((double)(db * db + da * da)) <= reach;
+            if (type == 3) return da * da + db * db < r2;
+            if (type == 4) return abs(da) <= r && abs(db) <= r;
+            return abs(db) <= ireach && abs(da) <= ireach;
+          };
+          bool ok = valid;
+          for (int q = 0; q < nsel && __ballot(ok); q++) {
+            const int sv = sel[2 * q], sw = sel[2 * q + 1];
+            if (ok && covers(sv, sw)) ok = false;
+          }
+          unsigned long long mask = __ballot(ok);
+          while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            const int la = __shfl(a, l), lb = __shfl(b, l);
+            if (lane == 0) {
+              sel[2 * nsel] = la;
+              sel[2 * nsel + 1] = lb;
+              if (write) newc[nsel] = corners[perm[base + l]];
+            }
+            nsel++;
+            const bool near = ok && covers(la, lb);
+            mask &= ~__ballot(near);
+            mask &= ~(1ull << l);
+          }
+        }
+        return nsel;
+      };
+      bool complete = false;
+      int r = 0, prev = -1, r_result = -1, cnt_result = 0;
+      int last_r = -1, last_cnt = 0;  // the previous sweep (what `result` holds in the reference)
+      while (!complete) {
+        r = low + (high - low) / 2;
+        if (r == prev || low > high || (type == 5 && r / 2 == 0)) {  // (SSC: c = 0, see the oracle)
+          r_result = last_r;
+          cnt_result = last_cnt;
+          break;
+        }
+        const int cnt = sweep(r, false);
+        last_r = r;
+        last_cnt = cnt;
+        if ((unsigned)cnt >= Kmin && (unsigned)cnt <= Kmax) {
+          r_result = r;
+          cnt_result = cnt;
+          complete = true;
+        } else if ((unsigned)cnt < Kmin) {
+          high = r - 1;
+        } else {
+          low = r + 1;
+        }
+        if (type != 2) prev = r;  // Sdc never updates prevradius
+      }
+      int nn = 0;
+      if (r_result >= 0 && cnt_result > 0) nn = sweep(r_result, true);
+      if (lane == 0) sh_cnt = nn;
+    } else if (tid == 0) {
+      sh_cnt = 0;
+      if (need >= 2) sh_flag = 3;  // keypoint list does not fit the LDS work area
+    }
+    __syncthreads();
+    n_new = sh_cnt;
+    if (sh_flag == 3) overflow = 1;
   } else {  // Binning on the cv::sortIdx-permuted keypoints
     const unsigned short* perm = T.sortidx + T.sortidx_off[n_corners];
     if (need > n_corners) {

@@ -385,9 +385,12 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     return fail("only the GFTT detector is implemented", KVFE_ERR_UNSUPPORTED);
   if (d.use_harris_detector) return fail("Harris response is not implemented", KVFE_ERR_UNSUPPORTED);
   if (d.block_size != 3) return fail("block_size must be 3", KVFE_ERR_UNSUPPORTED);
-  if (d.enable_non_max_suppression && d.non_max_suppression_type != KVFE_ANMS_TOPN &&
-      d.non_max_suppression_type != KVFE_ANMS_BINNING)
-    return fail("ANMS type not implemented on device (TopN and Binning are)", KVFE_ERR_UNSUPPORTED);
+  if (d.enable_non_max_suppression && d.non_max_suppression_type == KVFE_ANMS_BROWN)
+    return fail("BrownANMS is not implemented (its output order rests on an unstable std::sort)",
+                KVFE_ERR_UNSUPPORTED);
+  if (d.enable_non_max_suppression &&
+      (d.non_max_suppression_type < KVFE_ANMS_TOPN || d.non_max_suppression_type > KVFE_ANMS_BINNING))
+    return fail("unknown non_max_suppression_type", KVFE_ERR_INVALID_ARG);
   if (d.min_distance < 0 || d.min_distance > MAX_RADIUS)
     return fail("min_distance out of range [0,127]", KVFE_ERR_INVALID_ARG);
   if (d.max_nr_keypoints_before_anms > ACAP)
@@ -503,7 +506,10 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.ccap = cfg.candidate_capacity > 0 ? cfg.candidate_capacity : (int)std::max<size_t>(N / 4, 4096);
   P.kcap = P.max_features + P.max_corners + 64;
   c->pts_bound = P.kcap;
-  if (P.enable_anms) c->pts_bound = std::min(P.kcap, P.max_features + P.hbins * P.vbins + 8);
+  // (TopN / Binning never return more than need (+ one per bin); the radius-search variants can
+  // return any number of corners when their binary search fails, so only kcap bounds them)
+  if (P.enable_anms && (P.anms_type == KVFE_ANMS_TOPN || P.anms_type == KVFE_ANMS_BINNING))
+    c->pts_bound = std::min(P.kcap, P.max_features + P.hbins * P.vbins + 8);
   return KVFE_OK;
 }
 
@@ -564,7 +570,8 @@ kvfe_status build_tables(kvfe_ctx* c) {
   }
   // cv::sortIdx permutations for every possible list length
   {
-    const int M = (P.enable_anms && P.anms_type == KVFE_ANMS_BINNING) ? std::min(P.max_corners, P.acap) : 0;
+    // (every type but TopN / BrownANMS receives the cv::sortIdx-permuted keypoints)
+    const int M = (P.enable_anms && P.anms_type >= KVFE_ANMS_SDC) ? std::min(P.max_corners, P.acap) : 0;
     std::vector<unsigned int> off(P.acap + 2, 0);
     size_t total = 0;
     for (int n = 0; n <= M; n++) {

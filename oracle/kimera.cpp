@@ -198,6 +198,116 @@ void sortidx_descending_equal_keys(int n, int policy, std::vector<int>& idx) {
 // --------------------------------------------------------------------------
 // ANMS (NonMaximumSuppression.cpp:33-169, anms/anms.cpp:37-49)
 // --------------------------------------------------------------------------
+// anms::Sdc / KdTree / RangeTree / Ssc (src/frontend/feature-detector/anms/anms.cpp:83-436,
+// Bailo et al.): binary search on the suppression radius / width until the greedy sweep keeps
+// between K(1-tol) and K(1+tol) keypoints, tol = 0.1f (FeatureDetector.cpp:226).  The spatial index
+// of each variant (grid of covered cells, nanoflann k-d tree, u16 range tree) only answers "which
+// later keypoints does an accepted keypoint exclude"; that relation is restated directly:
+//   SDC       cells of side c = 0.25 r / sqrt(2): sqrt(drow^2 + dcol^2) <= r / c     (anms.cpp:83-162)
+//   KdTree    integer pixels, nanoflann radiusSearch(r*r): dx^2 + dy^2 <  r^2         (:164-252)
+//   RangeTree u16 pixels, inclusive square [x-w, x+w] x [y-w, y+w]                    (:254-335)
+//   SSC       cells of side c = (double)(w / 2) (integer division): |drow|,|dcol| <= floor(w / c) (:337-436)
+// Keypoints are integer valued here (GFTT corners before cornerSubPix), so the float -> int / u16
+// conversions of the reference are exact.  SSC with w < 2 divides by c = 0 in the reference (the
+// process dies on the vector allocation that follows); here the search stops and returns the
+// previous sweep.
+static void anmsBinarySearch(const std::vector<Point2f>& kp, int numRetPoints, int cols, int rows,
+                             int type, std::vector<Point2f>& out) {
+  const float tolerance = 0.1f;
+  const int n = (int)kp.size();
+  int low, high;
+  if (type == KVFE_ANMS_SDC) {
+    low = 1;
+    high = cols;
+  } else {
+    int exp1 = rows + cols + 2 * numRetPoints;
+    long long exp2 = ((long long)4 * cols + (long long)4 * numRetPoints +
+                      (long long)4 * rows * numRetPoints + (long long)rows * rows +
+                      (long long)cols * cols - (long long)2 * rows * cols +
+                      (long long)4 * rows * cols * numRetPoints);
+    double exp3 = std::sqrt((double)exp2);
+    double exp4 = numRetPoints - 1;
+    double sol1 = -std::round((exp1 + exp3) / exp4);
+    double sol2 = -std::round((exp1 - exp3) / exp4);
+    high = (int)((sol1 > sol2) ? sol1 : sol2);
+    low = (int)std::floor(std::sqrt((double)kp.size() / numRetPoints));
+  }
+  std::vector<int> xi(n), yi(n);
+  for (int i = 0; i < n; i++) {
+    xi[i] = (int)kp[i].x;
+    yi[i] = (int)kp[i].y;
+  }
+  bool complete = false;
+  unsigned int K = numRetPoints;
+  unsigned int Kmin = (unsigned int)std::round(K - (K * tolerance));
+  unsigned int Kmax = (unsigned int)std::round(K + (K * tolerance));
+  std::vector<int> ResultVec, result;
+  int r, prev = -1;
+  std::vector<int> row(n), col(n);
+  while (!complete) {
+    std::vector<bool> Included(n, true);
+    r = low + (high - low) / 2;
+    if (r == prev || low > high) {
+      ResultVec = result;
+      break;
+    }
+    double c = 0, reach = 0;
+    if (type == KVFE_ANMS_SDC) {
+      c = 0.25 * r / std::sqrt(2);
+      reach = ((double)r) / c;
+    } else if (type == KVFE_ANMS_SSC) {
+      c = r / 2;  // integer division, as in the reference
+      if (c == 0) {
+        ResultVec = result;
+        break;
+      }
+      reach = std::floor(r / c);
+    }
+    if (type == KVFE_ANMS_SDC || type == KVFE_ANMS_SSC)
+      for (int i = 0; i < n; i++) {
+        row[i] = (int)std::floor(kp[i].y / c);
+        col[i] = (int)std::floor(kp[i].x / c);
+      }
+    result.clear();
+    for (int i = 0; i < n; ++i) {
+      if (!Included[i]) continue;
+      Included[i] = false;
+      result.push_back(i);
+      for (int j = i + 1; j < n; j++) {
+        if (!Included[j]) continue;
+        bool covered;
+        switch (type) {
+          case KVFE_ANMS_SDC: {
+            const int dr = row[j] - row[i], dc = col[j] - col[i];
+            covered = std::sqrt((double)(dr * dr + dc * dc)) <= reach;
+          } break;
+          case KVFE_ANMS_KDTREE: {
+            const int dx = xi[j] - xi[i], dy = yi[j] - yi[i];
+            covered = dx * dx + dy * dy < r * r;
+          } break;
+          case KVFE_ANMS_RANGETREE:
+            covered = std::abs(xi[j] - xi[i]) <= r && std::abs(yi[j] - yi[i]) <= r;
+            break;
+          default: {  // SSC
+            const int dr = row[j] - row[i], dc = col[j] - col[i];
+            covered = std::abs(dr) <= (int)reach && std::abs(dc) <= (int)reach;
+          }
+        }
+        if (covered) Included[j] = false;
+      }
+    }
+    if (result.size() >= Kmin && result.size() <= Kmax) {
+      ResultVec = result;
+      complete = true;
+    } else if (result.size() < Kmin)
+      high = r - 1;
+    else
+      low = r + 1;
+    if (type != KVFE_ANMS_SDC) prev = r;  // Sdc never updates prevradius (anms.cpp:83-162)
+  }
+  for (int i : ResultVec) out.push_back(kp[i]);
+}
+
 bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int cols, int rows,
                     const kvfe_detector_params& p, std::vector<Point2f>& out) {
   out.clear();
@@ -241,68 +351,12 @@ bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int
       }
       return true;
     }
-    case KVFE_ANMS_RANGETREE: {  // anms::RangeTree (anms/anms.cpp:254-335), tolerance 0.1
-      const std::vector<Point2f>& kp = keyPointsSorted;
-      const float tolerance = 0.1f;
-      int exp1 = rows + cols + 2 * numRetPoints;
-      long long exp2 = ((long long)4 * cols + (long long)4 * numRetPoints +
-                        (long long)4 * rows * numRetPoints + (long long)rows * rows +
-                        (long long)cols * cols - (long long)2 * rows * cols +
-                        (long long)4 * rows * cols * numRetPoints);
-      double exp3 = std::sqrt((double)exp2);
-      double exp4 = numRetPoints - 1;
-      double sol1 = -std::round((exp1 + exp3) / exp4);
-      double sol2 = -std::round((exp1 - exp3) / exp4);
-      int high = (int)((sol1 > sol2) ? sol1 : sol2);
-      int low = (int)std::floor(std::sqrt((double)kp.size() / numRetPoints));
-      // rangetree<u16,u16>: coordinates truncated to u16, inclusive square query
-      std::vector<uint16_t> px(kp.size()), py(kp.size());
-      for (size_t i = 0; i < kp.size(); i++) {
-        px[i] = (uint16_t)kp[i].x;
-        py[i] = (uint16_t)kp[i].y;
-      }
-      bool complete = false;
-      unsigned int K = numRetPoints;
-      unsigned int Kmin = (unsigned int)std::round(K - (K * tolerance));
-      unsigned int Kmax = (unsigned int)std::round(K + (K * tolerance));
-      std::vector<int> ResultVec, result;
-      int width, prevwidth = -1;
-      while (!complete) {
-        std::vector<bool> Included(kp.size(), true);
-        width = low + (high - low) / 2;
-        if (width == prevwidth || low > high) {
-          ResultVec = result;
-          break;
-        }
-        result.clear();
-        for (unsigned int i = 0; i < kp.size(); ++i) {
-          if (Included[i]) {
-            Included[i] = false;
-            result.push_back(i);
-            int minx = (int)(kp[i].x - width), maxx = (int)(kp[i].x + width);
-            int miny = (int)(kp[i].y - width), maxy = (int)(kp[i].y + width);
-            if (minx < 0) minx = 0;
-            if (miny < 0) miny = 0;
-            uint16_t x0 = (uint16_t)minx, x1 = (uint16_t)maxx, y0 = (uint16_t)miny, y1 = (uint16_t)maxy;
-            if (x1 < x0) std::swap(x0, x1);
-            if (y1 < y0) std::swap(y0, y1);
-            for (size_t j = 0; j < kp.size(); j++)
-              if (Included[j] && px[j] >= x0 && px[j] <= x1 && py[j] >= y0 && py[j] <= y1)
-                Included[j] = false;
-          }
-        }
-        if (result.size() >= Kmin && result.size() <= Kmax) {
-          ResultVec = result;
-          complete = true;
-        } else if (result.size() < Kmin)
-          high = width - 1;
-        else
-          low = width + 1;
-        prevwidth = width;
-      }
-      for (int r : ResultVec) out.push_back(kp[r]);
+    case KVFE_ANMS_SDC:
+    case KVFE_ANMS_KDTREE:
+    case KVFE_ANMS_RANGETREE:
+    case KVFE_ANMS_SSC:
+      anmsBinarySearch(keyPointsSorted, numRetPoints, cols, rows, p.non_max_suppression_type, out);
       return true;
-    }
     default:
       return false;
   }

@@ -225,6 +225,17 @@ def sortidx_permutation_stdsort(n):
     return idx
 
 
+def suppress_non_max(xy, num_ret, cols, rows, det: abi.DetectorParams):
+    """AdaptiveNonMaximumSuppression::suppressNonMax on GFTT-ordered keypoints."""
+    pts = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    cap = len(pts) + 16
+    out = np.zeros((cap, 2), np.float32)
+    n = lib().kvo_suppress_non_max(_p(pts), len(pts), num_ret, cols, rows, C.byref(det), _p(out), cap)
+    if n < 0:
+        raise ValueError("ANMS type not restated")
+    return out[:n].copy()
+
+
 def feature_detection(img, tracked_xy, need, det: abi.DetectorParams):
     img = _img(img)
     h, w = img.shape

@@ -635,3 +635,49 @@ def test_frontend_staged_input_matches_host_input(seq, ocam, equalize):
                     kf[s] = idx[s]
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# ANMS: the radius-search variants of anms/anms.cpp (RangeTree is the class default)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("anms_type", [abi.ANMS_SDC, abi.ANMS_KDTREE, abi.ANMS_RANGETREE, abi.ANMS_SSC])
+def test_feature_detection_anms_variants(anms_type, seq):
+    """featureDetection with non_max_suppression_type 2..5: the binary search on the suppression radius
+    and every greedy sweep equal the CPU path (same corners, same order, then cornerSubPix), with and
+    without tracked keypoints, for several `need`; need < 2 returns nothing (closed form divides by 0)."""
+    L, R = euroc_cams()
+    p = euroc_params()
+    p.detector.non_max_suppression_type = anms_type
+    c = F.Context(L, R, p)
+    try:
+        none = np.zeros((0, 2), np.float32)
+        for img in (gray("left_fisheye_img_0.png"), seq["lefts"][2]):
+            for need in (300, 120, 40, 1500):
+                got = c.feature_detection(img, none, need)
+                exp, _ = O.feature_detection(img, none, need, p.detector)
+                assert np.array_equal(got, exp), (anms_type, need, len(got), len(exp))
+            assert len(exp) > 0
+            first = exp
+            tracked = first[::3]
+            got = c.feature_detection(img, tracked, 200)
+            exp, _ = O.feature_detection(img, tracked, 200, p.detector)
+            assert len(exp) > 20 and np.array_equal(got, exp)
+        if anms_type != abi.ANMS_SDC:
+            assert len(c.feature_detection(img, none, 1)) == 0
+    finally:
+        c.close()
+
+
+def test_frontend_sequence_class_default_anms(seq, ocam):
+    """FeatureDetectorParams' class default is RangeTree (FeatureDetectorParams.h): the front-end with
+    it, outlier rejection on, identical to the oracle over the clip."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(non_max_suppression_type=abi.ANMS_RANGETREE, max_features_per_frame=250)
+    fe = [O.Frontend(L, R, p)]
+    c = F.Context(L, R, p, batch=1)
+    try:
+        _run_sequence(fe, c, seq, force_kf=True, n=6)
+    finally:
+        c.close()

@@ -358,3 +358,76 @@ def test_equalize_hist_properties():
     assert np.all(np.diff(lut[first:last + 1]) >= 0)
     const = np.full((48, 64), 77, np.uint8)
     assert np.array_equal(O.equalize_hist(const), const)
+
+
+def _anms_reference_python(kps, need, cols, rows, kind):
+    """independent restatement of the Bailo et al. binary search (anms/anms.cpp) for the two variants
+    whose covering relation is a plain pixel predicate"""
+    n = len(kps)
+    x = kps[:, 0].astype(int)
+    y = kps[:, 1].astype(int)
+    exp1 = rows + cols + 2 * need
+    exp2 = 4 * cols + 4 * need + 4 * rows * need + rows * rows + cols * cols - 2 * rows * cols + 4 * rows * cols * need
+    exp3 = np.sqrt(float(exp2))
+    exp4 = need - 1
+    rnd = lambda v: np.floor(abs(v) + 0.5) * np.sign(v)
+    high = int(max(-rnd((exp1 + exp3) / exp4), -rnd((exp1 - exp3) / exp4)))
+    low = int(np.floor(np.sqrt(n / need)))
+    kmin = int(rnd(np.float32(need) - np.float32(need) * np.float32(0.1)))
+    kmax = int(rnd(np.float32(need) + np.float32(need) * np.float32(0.1)))
+    result, prev = [], -1
+    while True:
+        r = low + int((high - low) / 2)
+        if r == prev or low > high:
+            return result
+        inc = np.ones(n, bool)
+        res = []
+        for i in range(n):
+            if not inc[i]:
+                continue
+            res.append(i)
+            dx, dy = x - x[i], y - y[i]
+            cov = (dx * dx + dy * dy < r * r) if kind == "kdtree" else ((abs(dx) <= r) & (abs(dy) <= r))
+            inc &= ~cov
+            inc[i] = False
+        result = res
+        if kmin <= len(res) <= kmax:
+            return result
+        if len(res) < kmin:
+            high = r - 1
+        else:
+            low = r + 1
+        prev = r
+
+
+@pytest.mark.parametrize("anms_type,name", [(2, "sdc"), (3, "kdtree"), (4, "rangetree"), (5, "ssc")])
+def test_anms_radius_search_variants(anms_type, name):
+    """anms::Sdc / KdTree / RangeTree / Ssc (anms/anms.cpp:83-436): no golden numbers in the reference
+    (its detector tests use TopN and Binning), so: the output is an order-preserving subset of the
+    sortIdx-permuted input, its size lands in [K(1-tol), K(1+tol)] on a well-populated image, the kept
+    corners respect the spacing the variant implies, and KdTree / RangeTree equal an independent
+    Python restatement."""
+    img = np.array(Image.open(os.path.join(G, "left_fisheye_img_0.png")).convert("L"))
+    h, w = img.shape
+    kps, _ = O.good_features_to_track(img, 2000, 0.001, 10, 3)
+    p = P.default_frontend_params().detector
+    p.non_max_suppression_type = anms_type
+    perm = O.sortidx_permutation(len(kps), p.sortidx_policy)
+    sorted_kps = kps[perm]
+    for need in (100, 300):
+        out = O.suppress_non_max(kps, need, w, h, p)
+        kmin, kmax = round(need * 0.9), round(need * 1.1)
+        assert kmin <= len(out) <= kmax, (name, need, len(out))
+        # order-preserving subset of the permuted input
+        pos = {tuple(k): i for i, k in enumerate(sorted_kps.tolist())}
+        idx = [pos[tuple(k)] for k in out.tolist()]
+        assert idx == sorted(idx) and len(set(idx)) == len(idx)
+        d = out[:, None, :] - out[None, :, :]
+        cheb = np.abs(d).max(-1) + np.eye(len(out)) * 1e9
+        assert cheb.min() >= 1
+        if name in ("kdtree", "rangetree"):
+            exp = _anms_reference_python(sorted_kps, need, w, h, name)
+            assert idx == exp, (name, need)
+    # numRetPoints < 2: exp4 = 0 in the reference's closed form (UB there) -> nothing is returned
+    if name != "sdc":
+        assert len(O.suppress_non_max(kps, 1, w, h, p)) == 0

@@ -1,5 +1,1 @@
-timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py --no-cpu-baseline | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['pcie_inclusive'], d['roofline_kernels'], d['end_to_end_traffic'])"
+timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -25
