@@ -69,6 +69,9 @@ enum {
  * while the 32-bit output is >= 2^31; V11: libstdc++ >= 11 returns output >> 1. */
 enum { KVFE_RNG_LIBSTDCXX_PRE11 = 0, KVFE_RNG_LIBSTDCXX_11 = 1 };
 
+/* VIO::FrontendType (stereo: StereoVisionImuFrontend, mono: MonoVisionImuFrontend) */
+enum { KVFE_FRONTEND_STEREO = 0, KVFE_FRONTEND_MONO = 1 };
+
 /* VIO::AnmsAlgorithmType (feature-detector/NonMaximumSuppression.h) */
 enum {
   KVFE_ANMS_TOPN = 0,
@@ -197,6 +200,9 @@ typedef struct kvfe_config {
   int32_t device;                /* HIP device ordinal                       */
   void* hip_stream;              /* optional hipStream_t owned by the caller */
   int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
+  int32_t frontend_type;         /* KVFE_FRONTEND_*: stereo (default) or the monocular front-end
+                                    (MonoVisionImuFrontend.cpp: `left` only, `right` ignored)   */
+  int32_t reserved0;
   int32_t stream_groups;         /* 0 = default (1).  The batch is split into this many
                                     groups of streams, each on its own HIP stream, so
                                     that latency-bound and throughput-bound kernels of

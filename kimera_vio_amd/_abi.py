@@ -24,6 +24,7 @@ DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = range(3)
 SORTIDX_LIBSTDCXX, SORTIDX_STABLE = range(2)
 TRACKING_VALID, TRACKING_LOW_DISPARITY, TRACKING_FEW_MATCHES, TRACKING_INVALID, TRACKING_DISABLED = range(5)
 RNG_LIBSTDCXX_PRE11, RNG_LIBSTDCXX_11 = range(2)
+FRONTEND_STEREO, FRONTEND_MONO = range(2)
 
 
 class CameraParams(C.Structure):
@@ -102,7 +103,8 @@ class Config(C.Structure):
         ("left", CameraParams), ("right", CameraParams), ("params", FrontendParams),
         ("batch", C.c_int32), ("device", C.c_int32),
         ("hip_stream", C.c_void_p),
-        ("candidate_capacity", C.c_int32), ("stream_groups", C.c_int32),
+        ("candidate_capacity", C.c_int32), ("frontend_type", C.c_int32), ("reserved0", C.c_int32),
+        ("stream_groups", C.c_int32),
     ]
 
 

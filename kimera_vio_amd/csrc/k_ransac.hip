@@ -395,7 +395,15 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
                                                            RansacScratch RS) {
   const int s = blockIdx.x, tid = threadIdx.x;
   const int flags = S.flags[s];
-  // tracker_status_summary_ only changes on keyframes of the nominal path
+  if (P.mono && (flags & FLAG_INIT) && !(flags & FLAG_KEYFRAME)) {
+    // MonoVisionImuFrontend::processFrame resets both statuses on every frame (:264-265)
+    if (tid == 0) {
+      S.trk_status[2 * (size_t)s] = TRK_INVALID;
+      S.trk_status[2 * (size_t)s + 1] = TRK_DISABLED;
+    }
+    return;
+  }
+  // stereo: tracker_status_summary_ only changes on keyframes of the nominal path
   if (!(flags & FLAG_KEYFRAME) || (flags & FLAG_FIRST)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int wave_tot[RS_T / 64];
@@ -408,7 +416,10 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
     if (tid == 0) st[0] = st[1] = TRK_DISABLED;
     return;
   }
-  if (tid == 0) st[0] = st[1] = TRK_INVALID;  // :353-354
+  if (tid == 0) {
+    st[0] = TRK_INVALID;                               // :353-354
+    st[1] = P.mono ? TRK_DISABLED : TRK_INVALID;
+  }
   const double* R = S.kf_R_cur + (size_t)s * 9;
   const bool imu_ok = !rs_rot_is_identity(R);
   if (!(P.ransac_2pt_mono && imu_ok)) return;  // 5-point problem: not implemented, status stays INVALID

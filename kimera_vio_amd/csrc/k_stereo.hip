@@ -395,6 +395,13 @@ void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_
                        P, T, left_rect, right_rect, k, ST, S, act_flag, mode);
 }
 
+void launch_undistort_left(const KParams& P, const Tables& T, const FrameTab& k, const StereoTab& ST,
+                           const StreamState& S, int act_flag, int max_kp, hipStream_t st) {
+  const int nb = max_kp > 0 ? (max_kp < P.kcap ? max_kp : P.kcap) : P.kcap;
+  hipLaunchKernelGGL(stereo_left_kernel, dim3((nb + 63) / 64, P.B), dim3(64), 0, st, P, T, k, ST, S,
+                     act_flag, STEREO_ALL);
+}
+
 template <bool SUBPIX>
 __global__ __launch_bounds__(64) void stereo_match_only_kernel(
     KParams P, Tables T, const unsigned char* __restrict__ L, const unsigned char* __restrict__ R,

@@ -910,7 +910,8 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
   }
   const int nk = sh_cnt;
   __syncthreads();
-  if (nk == 0) {  // StereoVisionImuFrontend.cpp:313-323: re-detect and move on
+  if (nk == 0 && !P.mono) {  // StereoVisionImuFrontend.cpp:313-323: re-detect and move on (the mono
+                             // front-end has no such early return, MonoVisionImuFrontend.cpp:248-262)
     if (tid == 0) {
       K.count[s] = 0;
       K.timestamp[s] = ts;
@@ -1029,8 +1030,9 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
     const bool nr_features_low = (long long)nk <= P.min_features;
     const bool is_disparity_low = disparity < P.disparity_thr;
     // kfTrackingStatus_mono_ of the last keyframe (LOW_DISPARITY only arises with useRANSAC)
+    // (MonoVisionImuFrontend::processFrame resets the status to INVALID before this test, :264-265)
     const bool disparity_low_first_time =
-        is_disparity_low && !(S.trk_status[2 * (size_t)s] == TRK_LOW_DISPARITY);
+        is_disparity_low && (P.mono || !(S.trk_status[2 * (size_t)s] == TRK_LOW_DISPARITY));
     const bool enough_disparity = !is_disparity_low;
     const bool max_disparity_reached = disparity > P.max_disp_lkf;
     const bool disparity_flipped = (enough_disparity || disparity_low_first_time) && min_time_elapsed;

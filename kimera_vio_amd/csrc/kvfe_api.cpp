@@ -360,7 +360,10 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     return s;
   };
   if (cfg->batch < 1) return fail("batch must be >= 1", KVFE_ERR_INVALID_ARG);
-  if (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height)
+  if (cfg->frontend_type != KVFE_FRONTEND_STEREO && cfg->frontend_type != KVFE_FRONTEND_MONO)
+    return fail("unknown frontend_type", KVFE_ERR_INVALID_ARG);
+  const bool mono = cfg->frontend_type == KVFE_FRONTEND_MONO;
+  if (!mono && (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height))
     return fail("left/right image sizes differ", KVFE_ERR_INVALID_ARG);
   if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
   if (p.use_ransac) {
@@ -370,7 +373,7 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     if (!tr.ransac_use_2point_mono)
       return fail("ransac_use_2point_mono=0 selects the 5-point problem, which is not implemented",
                   KVFE_ERR_UNSUPPORTED);
-    if (p.use_stereo_tracking && !tr.ransac_use_1point_stereo)
+    if (!mono && p.use_stereo_tracking && !tr.ransac_use_1point_stereo)
       return fail("ransac_use_1point_stereo=0 selects the 3-point problem, which is not implemented",
                   KVFE_ERR_UNSUPPORTED);
     if (tr.ransac_max_iterations < 1 || tr.ransac_max_iterations > 1000)
@@ -473,6 +476,8 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.max_kf_ns = p.max_intra_keyframe_time_ns;
   P.max_disp_lkf = p.max_disparity_since_lkf;
   P.min_features = p.min_number_features;
+  P.mono = cfg.frontend_type == KVFE_FRONTEND_MONO ? 1 : 0;
+  if (P.mono) P.use_stereo_tracking = 0;  // mono measurements carry uR = NaN
   P.use_ransac = p.use_ransac ? 1 : 0;
   P.ransac_2pt_mono = t.ransac_use_2point_mono ? 1 : 0;
   P.ransac_1pt_stereo = t.ransac_use_1point_stereo ? 1 : 0;
@@ -716,6 +721,27 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SELECT, st);
   launch_select(P, c->T, K, b.ss, b.ds, -1, st);
   prof_end(c, ST_SELECT, st);
+  if (P.mono) {
+    // MonoVisionImuFrontend::processFrame (:288-318): refine + append the new corners, undistort all
+    // keypoints (Camera::undistortKeypoints), measurements
+    prof_begin(c, ST_SUBPIX, st);
+    launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, st);
+    prof_end(c, ST_SUBPIX, st);
+    prof_begin(c, ST_STEREO, st);
+    // (tracked entries, incl. those RANSAC just invalidated, + new corners: at most twice the bound of either)
+    launch_undistort_left(P, c->T, K, b.st, b.ss, FLAG_STEREO, std::min(P.kcap, 2 * c->pts_bound), st);
+    prof_end(c, ST_STEREO, st);
+    prof_begin(c, ST_FINALIZE, st);
+    launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, st);
+    prof_end(c, ST_FINALIZE, st);
+    HIPCHK(c, hipGetLastError());
+    std::swap(c->role_k, c->role_km1);
+    c->pyr_cur ^= 1;
+    c->prev_left = left;
+    c->prev_row_stride = row_stride;
+    c->prev_img_stride = img_stride;
+    return KVFE_OK;
+  }
   // fork: cornerSubPix + append of the new corners (side stream) || rectify + stereo matching of
   // the tracked keypoints (main stream); join before the new keypoints are matched
   if (c->side) {
@@ -874,10 +900,20 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
   c->parent = parent;
   c->s0 = s0;
   kvfe_status s = KVFE_OK;
-  if (parent)
+  if (parent) {
     c->rect = parent->rect;
-  else
+  } else if (cfg->frontend_type == KVFE_FRONTEND_MONO) {
+    // Camera::Camera (src/frontend/Camera.cpp:29-49): no rectification, R = I and P = K
+    std::memset(&c->rect, 0, sizeof(c->rect));
+    const M3 K = camera_matrix(cfg->left);
+    for (int i = 0; i < 3; i++) {
+      c->rect.R1[i * 4] = c->rect.R2[i * 4] = 1.0;
+      for (int j = 0; j < 3; j++) c->rect.P1[i * 4 + j] = c->rect.P2[i * 4 + j] = K.m[i * 3 + j];
+    }
+    c->cfg.right = cfg->left;
+  } else {
     s = stereo_rectify(cfg->left, cfg->right, &c->rect);
+  }
   if (s != KVFE_OK) {
     delete c;
     return s;
@@ -1362,7 +1398,11 @@ kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
 kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const void* right_dev,
                                       size_t row_stride, size_t image_stride,
                                       const kvfe_frame_input* inputs) {
-  if (!c || !left_dev || !right_dev || !inputs) return KVFE_ERR_INVALID_ARG;
+  if (!c || !left_dev || !inputs) return KVFE_ERR_INVALID_ARG;
+  if (!right_dev) {
+    if (!c->P.mono) return KVFE_ERR_INVALID_ARG;
+    right_dev = left_dev;  // the mono front-end never reads it
+  }
   if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty())
     return step_groups(c, reinterpret_cast<const unsigned char*>(left_dev),
@@ -1390,7 +1430,11 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
 kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint8_t* right,
                                     size_t row_stride, size_t image_stride,
                                     const kvfe_frame_input* inputs) {
-  if (!c || !left || !right || !inputs) return KVFE_ERR_INVALID_ARG;
+  if (!c || !left || !inputs) return KVFE_ERR_INVALID_ARG;
+  if (!right) {
+    if (!c->P.mono) return KVFE_ERR_INVALID_ARG;
+    right = left;
+  }
   if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) return step_groups(c, left, right, row_stride, image_stride, inputs, true);
   Buffers& b = c->fe;

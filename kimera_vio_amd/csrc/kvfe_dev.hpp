@@ -38,6 +38,7 @@ struct KParams {
   double min_kf_ns, max_kf_ns, max_disp_lkf;
   long long min_features;
   // geometric outlier rejection (FrontendParams::useRANSAC_, TrackerParams ransac_*)
+  int mono;  // MonoVisionImuFrontend: no right camera, keypoints undistorted with R = I, P = K
   int use_ransac, ransac_2pt_mono, ransac_1pt_stereo, ransac_max_iters;
   int min_mono_inliers, min_stereo_inliers;
   double ransac_thr_mono, ransac_probability;
@@ -223,6 +224,9 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
 void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigned char* img,
                           size_t row_stride, int W, int H, float2* pts, int n, int win,
                           int max_iters, double eps2, hipStream_t st);
+// mono front-end: Camera::undistortKeypoints (Camera.cpp:110-133) = the left-keypoint half of K7
+void launch_undistort_left(const KParams& P, const Tables& T, const FrameTab& k, const StereoTab& ST,
+                           const StreamState& S, int act_flag, int max_kp, hipStream_t st);
 // K7 + K5: rectify left keypoints, epipolar SSD, depth, right keypoints, 3D
 void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_rect,
                    const unsigned char* right_rect, const FrameTab& k, const StereoTab& ST,

@@ -42,7 +42,7 @@ class Context:
 
     def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
                  batch: int = 1, device: int = 0, hip_stream: int | None = None,
-                 candidate_capacity: int = 0, stream_groups: int = 0):
+                 candidate_capacity: int = 0, stream_groups: int = 0, frontend_type: int = 0):
         self.lib = load()
         cfg = abi.Config()
         cfg.left, cfg.right, cfg.params = left, right, params
@@ -50,6 +50,7 @@ class Context:
         cfg.hip_stream = hip_stream
         cfg.candidate_capacity = candidate_capacity
         cfg.stream_groups = stream_groups
+        cfg.frontend_type = frontend_type
         self.cfg = cfg
         self.left, self.right, self.params = left, right, params
         self.batch = batch
@@ -242,12 +243,14 @@ class Context:
         return arr
 
     def step_host(self, lefts, rights, inputs):
-        """lefts/rights: uint8 arrays [batch, H, W] in host memory."""
+        """lefts/rights: uint8 arrays [batch, H, W] in host memory (rights = None for the mono front-end)."""
         lefts = np.ascontiguousarray(lefts, np.uint8)
-        rights = np.ascontiguousarray(rights, np.uint8)
-        assert lefts.shape == (self.batch, self.h, self.w) and rights.shape == lefts.shape
-        self._chk(self.lib.kvfe_frontend_step_host(self._h, _p(lefts), _p(rights), self.w,
-                                                   self.w * self.h, inputs), "frontend_step_host")
+        assert lefts.shape == (self.batch, self.h, self.w)
+        if rights is not None:
+            rights = np.ascontiguousarray(rights, np.uint8)
+            assert rights.shape == lefts.shape
+        self._chk(self.lib.kvfe_frontend_step_host(self._h, _p(lefts), _p(rights) if rights is not None else None,
+                                                   self.w, self.w * self.h, inputs), "frontend_step_host")
 
     def step_device(self, left_ptr: int, right_ptr: int, inputs, row_stride=None, image_stride=None):
         """left_ptr/right_ptr: device pointers to `batch` images; they must stay valid until the next

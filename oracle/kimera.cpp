@@ -78,6 +78,25 @@ void StereoCamera::init(const kvfe_camera_params& l, const kvfe_camera_params& r
   }
 }
 
+void StereoCamera::initMono(const kvfe_camera_params& c) {
+  left = right = c;
+  w = c.width;
+  h = c.height;
+  camera_matrix(c, K1);
+  camera_matrix(c, K2);
+  std::memset(&rect, 0, sizeof(rect));
+  for (int i = 0; i < 3; i++) {
+    rect.R1[i * 4] = rect.R2[i * 4] = 1.0;
+    for (int j = 0; j < 3; j++) rect.P1[i * 4 + j] = rect.P2[i * 4 + j] = K1[i * 3 + j];
+  }
+  for (int cam = 0; cam < 2; cam++) {
+    map_x[cam].resize((size_t)w * h);
+    map_y[cam].resize((size_t)w * h);
+    ocv::initUndistortRectifyMap(K1, c.distortion, c.n_distortion, rect.R1, rect.P1, w, h,
+                                 map_x[cam].data(), map_y[cam].data());
+  }
+}
+
 void StereoCamera::undistortRectifyImage(int cam, const uint8_t* src, size_t stride,
                                          uint8_t* dst) const {
   ocv::remap_linear_replicate(src, w, h, stride, dst, w, h, w, map_x[cam].data(),
@@ -626,8 +645,12 @@ void sparseStereoReconstruction(const StereoCamera& cam, const kvfe_stereo_param
 // Frontend
 // --------------------------------------------------------------------------
 void Frontend::init(const kvfe_camera_params& l, const kvfe_camera_params& r,
-                    const kvfe_frontend_params& fp) {
-  cam.init(l, r);
+                    const kvfe_frontend_params& fp, bool mono_frontend) {
+  mono = mono_frontend;
+  if (mono)
+    cam.initMono(l);
+  else
+    cam.init(l, r);
   p = fp;
   lmk_id = 0;
   frame_count = 0;
@@ -776,6 +799,10 @@ void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
   }
   meas_lmk.clear();
   meas_uLuRv.clear();
+  if (mono) {
+    processMono(in);
+    return;
+  }
 
   if (!initialized) {  // processFirstStereoFrame (StereoVisionImuFrontend.cpp:245-276)
     k.left.isKeyframe = true;
@@ -830,6 +857,66 @@ void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
     sparseStereoReconstruction(cam, p.stereo, k);
     lkf = k;
     getSmartStereoMeasurements(k);
+    for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    k.left.isKeyframe = false;
+    std::memcpy(keyframe_R_ref_frame, in.keyframe_R_cur_frame, sizeof(keyframe_R_ref_frame));
+  }
+  last_is_keyframe = new_keyframe;
+  km1 = k;
+  km1_is_lkf = new_keyframe;
+  ++frame_count;
+}
+
+// MonoVisionImuFrontend::processFirstFrame / processFrame (src/frontend/MonoVisionImuFrontend.cpp:
+// 196-335) + getSmartMonoMeasurements (:340-369); `k` already holds the new image
+void Frontend::processMono(const kvfe_frame_input& in) {
+  auto undistortKeypoints = [&]() {  // Camera::undistortKeypoints (Camera.cpp:110-133)
+    cam.undistortRectifyLeftKeypoints(k.left.keypoints, k.left_kp_rect);
+    k.right_kp_rect.assign(k.left_kp_rect.size(), StatusKeypoint{0, {0.f, 0.f}});
+    k.depth.assign(k.left_kp_rect.size(), 0.0);
+    k.right_kp.assign(k.left_kp_rect.size(), Point2f{0.f, 0.f});
+    k.kp3d.assign(k.left_kp_rect.size() * 3, 0.0);
+  };
+  if (!initialized) {
+    k.left.isKeyframe = true;
+    featureDetectionFrame(k.left, &k.n_detected);
+    undistortKeypoints();
+    km1 = k;
+    lkf = k;
+    km1_is_lkf = true;
+    ++frame_count;
+    initialized = true;
+    last_is_keyframe = true;
+    for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  double RrefT[9], ref_R_cur[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RrefT[i * 3 + j] = keyframe_R_ref_frame[j * 3 + i];
+  mat3_mul(RrefT, in.keyframe_R_cur_frame, ref_R_cur);
+  featureTracking(km1.left, k.left, ref_R_cur);
+  if (km1_is_lkf) lkf.left.landmarks = km1.left.landmarks;
+  k.n_tracked = (int)k.left.keypoints.size();
+  tracker_status.mono = KVFE_TRACKING_INVALID;
+  tracker_status.stereo = KVFE_TRACKING_DISABLED;
+  const bool new_keyframe = shouldBeKeyframe(k.left, lkf.left);
+  if (new_keyframe) {
+    if (p.use_ransac)
+      outlierRejectionMono(in.keyframe_R_cur_frame, lkf.left, k.left);
+    else
+      tracker_status.mono = KVFE_TRACKING_DISABLED;
+    k.left.isKeyframe = true;
+    featureDetectionFrame(k.left, &k.n_detected);
+    undistortKeypoints();
+    lkf = k;
+    for (size_t i = 0; i < k.left.landmarks.size(); ++i) {  // getSmartMonoMeasurements
+      if (k.left.landmarks[i] == -1) continue;
+      meas_lmk.push_back(k.left.landmarks[i]);
+      meas_uLuRv.push_back((double)k.left_kp_rect[i].kp.x);
+      meas_uLuRv.push_back(std::numeric_limits<double>::quiet_NaN());
+      meas_uLuRv.push_back((double)k.left_kp_rect[i].kp.y);
+    }
     for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
   } else {
     k.left.isKeyframe = false;

@@ -27,6 +27,8 @@ struct StereoCamera {
   std::vector<float> map_x[2], map_y[2];
   int w, h;
   void init(const kvfe_camera_params& l, const kvfe_camera_params& r);
+  // VIO::Camera (src/frontend/Camera.cpp:29-49): one camera, undistorter with R = I and P = K
+  void initMono(const kvfe_camera_params& c);
   double fx() const { return rect.P1[0]; }
   double baseline() const { return rect.baseline; }
   // UndistorterRectifier::undistortRectifyImage (UndistorterRectifier.cpp:115-128)
@@ -174,8 +176,9 @@ struct Frontend {
   bool last_is_keyframe = false;
   TrackerStatusSummary tracker_status;  // tracker_status_summary_ (persists between keyframes)
 
+  bool mono = false;  // MonoVisionImuFrontend (src/frontend/MonoVisionImuFrontend.cpp:196-335)
   void init(const kvfe_camera_params& l, const kvfe_camera_params& r,
-            const kvfe_frontend_params& fp);
+            const kvfe_frontend_params& fp, bool mono_frontend = false);
   void process(const uint8_t* left, const uint8_t* right, size_t stride,
                const kvfe_frame_input& in);
   const StereoFrame& current() const { return km1; }
@@ -188,6 +191,7 @@ struct Frontend {
   // VisionImuFrontend::outlierRejectionMono / outlierRejectionStereo (VisionImuFrontend.cpp:90-144)
   void outlierRejectionMono(const double R[9], Frame& lkf_left, Frame& k_left);
   void outlierRejectionStereo(const double R[9], StereoFrame& lkf_sf, StereoFrame& k_sf);
+  void processMono(const kvfe_frame_input& in);
 };
 
 // gtsam::Rot3::equals(Rot3(), 1e-9) as used for `given_rot` (VisionImuFrontend.cpp:97,125)

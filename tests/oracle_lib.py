@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
     L.kvo_frontend_create.restype = C.c_void_p
     L.kvo_frontend_create.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams),
                                       C.POINTER(abi.FrontendParams)]
+    L.kvo_frontend_create_mono.restype = C.c_void_p
+    L.kvo_frontend_create_mono.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.FrontendParams)]
     L.kvo_frontend_destroy.argtypes = [C.c_void_p]
     L.kvo_frontend_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.POINTER(abi.FrameInput)]
@@ -440,10 +442,14 @@ def frame_output_to_dict(out: abi.FrameOutput, arrs: dict) -> dict:
 class Frontend:
     """kimera::Frontend of the oracle (StereoVisionImuFrontend incl. the useRANSAC branch)."""
 
-    def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams):
+    def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
+                 mono: bool = False):
         self.params = params
         self.w, self.h = left.width, left.height
-        self._h = lib().kvo_frontend_create(C.byref(left), C.byref(right), C.byref(params))
+        if mono:  # MonoVisionImuFrontend: `right` is ignored
+            self._h = lib().kvo_frontend_create_mono(C.byref(left), C.byref(params))
+        else:
+            self._h = lib().kvo_frontend_create(C.byref(left), C.byref(right), C.byref(params))
         self.cap = params.detector.max_features_per_frame + params.detector.max_nr_keypoints_before_anms + 64
 
     def __del__(self):

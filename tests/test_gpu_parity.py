@@ -681,3 +681,47 @@ def test_frontend_sequence_class_default_anms(seq, ocam):
         _run_sequence(fe, c, seq, force_kf=True, n=6)
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# monocular front-end (MonoVisionImuFrontend): the same kernels without the right camera
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_ransac,force_kf", [(1, False), (1, True), (0, False)])
+def test_mono_frontend_sequence(seq, use_ransac, force_kf):
+    """MonoVisionImuFrontend::processFirstFrame / processFrame: tracking, keyframe decision, 2-point
+    RANSAC, detection, Camera::undistortKeypoints (R = I, P = K) and the mono measurements
+    (uL, NaN, v) identical to the oracle; bearing vectors are in the unrectified camera frame."""
+    L, _ = euroc_cams()
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=use_ransac)
+    p.detector.max_features_per_frame = 200
+    TL = np.array(L.body_pose_cam).reshape(4, 4)
+    camR = [TL[:3, :3].T @ Rb @ TL[:3, :3] for Rb in seq["body_R"]]  # rotations of the (unrectified) camera
+    fe = O.Frontend(L, L, p, mono=True)
+    c = F.Context(L, L, p, batch=1, frontend_type=abi.FRONTEND_MONO)
+    try:
+        kf = 0
+        n_kf = 0
+        for i in range(9):
+            Rk = camR[kf].T @ camR[i]
+            ts = int(seq["ts"][i])
+            c.step_host(seq["lefts"][i][None], None, c.make_inputs([ts], [Rk], [int(force_kf)]))
+            exp = fe.process(seq["lefts"][i], seq["lefts"][i], ts, Rk, force_kf)
+            got = c.get_output(0)
+            for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected", "n_measurements",
+                      "tracking_status_mono", "tracking_status_stereo", "nr_mono_putatives", "nr_mono_inliers"):
+                assert got[k] == exp[k], (i, k, got[k], exp[k])
+            for k in ("landmarks", "landmarks_age", "keypoints", "versors"):
+                assert np.array_equal(got[k], exp[k]), (i, k)
+            assert np.array_equal(got["lkf_T_k_mono"], exp["lkf_T_k_mono"])
+            if exp["is_keyframe"]:
+                assert np.array_equal(got["left_rect_xy"], exp["left_rect_xy"])
+                assert np.array_equal(got["left_status"], exp["left_status"])
+                assert np.array_equal(got["meas_landmark"], exp["meas_landmark"])
+                assert np.array_equal(got["meas_uL_uR_v"], exp["meas_uL_uR_v"], equal_nan=True)
+                assert np.isnan(got["meas_uL_uR_v"][:, 1]).all() or len(got["meas_uL_uR_v"]) == 0
+                kf = i
+                n_kf += 1
+            assert got["tracking_status_stereo"] == (abi.TRACKING_DISABLED if i > 0 else abi.TRACKING_INVALID)
+        assert n_kf >= 2
+    finally:
+        c.close()
