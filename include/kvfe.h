@@ -89,7 +89,8 @@ enum { KVFE_DET_FAST = 0, KVFE_DET_ORB = 1, KVFE_DET_AGAST = 2, KVFE_DET_GFTT = 
 /* VIO::OpticalFlowPredictorType */
 enum { KVFE_FLOW_NO_PREDICTION = 0, KVFE_FLOW_ROTATIONAL = 1 };
 
-/* VIO::DistortionModel (only RADTAN and NONE are implemented on device) */
+/* VIO::DistortionModel (RADTAN = cv::undistortPoints family, EQUIDISTANT = cv::fisheye family;
+ * the omni model of Camera.cpp is not implemented) */
 enum { KVFE_DIST_NONE = 0, KVFE_DIST_RADTAN = 1, KVFE_DIST_EQUIDISTANT = 2 };
 
 /* how cv::sortIdx's all-equal-keys permutation is reproduced before ANMS

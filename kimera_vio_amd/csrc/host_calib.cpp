@@ -103,7 +103,9 @@ UndistortCtx make_undistort_ctx(const kvfe_camera_params& cam, const double* R, 
   u.ifx = 1. / u.fx;
   u.ify = 1. / u.fy;
   for (int i = 0; i < 8; i++) u.k[i] = i < cam.n_distortion ? cam.distortion[i] : 0.0;
-  u.has_dist = cam.distortion_model == KVFE_DIST_RADTAN && cam.n_distortion > 0;
+  u.has_dist = (cam.distortion_model == KVFE_DIST_RADTAN && cam.n_distortion > 0) ? 1
+               : cam.distortion_model == KVFE_DIST_EQUIDISTANT                      ? 2
+                                                                                    : 0;
   M3 RR = M3::eye();
   if (R) std::memcpy(RR.m, R, sizeof(RR.m));
   if (P) {
@@ -114,13 +116,49 @@ UndistortCtx make_undistort_ctx(const kvfe_camera_params& cam, const double* R, 
   return u;
 }
 
+// cv::fisheye::undistortPoints (calib3d/src/fisheye.cpp, OpenCV 4.2) for one pixel
+static void fisheye_undistort_point(const UndistortCtx& u, float x_in, float y_in, float* x_out,
+                                    float* y_out) {
+  const double* k = u.k;
+  const double pw0 = ((double)x_in - u.cx) / u.fx, pw1 = ((double)y_in - u.cy) / u.fy;
+  double scale = 1.0;
+  double theta_d = std::sqrt(pw0 * pw0 + pw1 * pw1);
+  theta_d = std::min(std::max(-3.14159265358979323846 / 2., theta_d), 3.14159265358979323846 / 2.);
+  if (theta_d > 1e-8) {
+    double theta = theta_d;
+    const double EPS = 1e-8;
+    for (int j = 0; j < 10; j++) {
+      const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2,
+                   theta8 = theta6 * theta2;
+      const double k0_theta2 = k[0] * theta2, k1_theta4 = k[1] * theta4, k2_theta6 = k[2] * theta6,
+                   k3_theta8 = k[3] * theta8;
+      const double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                               (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+      theta = theta - theta_fix;
+      if (std::fabs(theta_fix) < EPS) break;
+    }
+    scale = std::tan(theta) / theta_d;
+  }
+  const double pu0 = pw0 * scale, pu1 = pw1 * scale;
+  const M3& RR = u.RR;
+  const double pr0 = RR(0, 0) * pu0 + RR(0, 1) * pu1 + RR(0, 2) * 1.0;
+  const double pr1 = RR(1, 0) * pu0 + RR(1, 1) * pu1 + RR(1, 2) * 1.0;
+  const double pr2 = RR(2, 0) * pu0 + RR(2, 1) * pu1 + RR(2, 2) * 1.0;
+  *x_out = (float)(pr0 / pr2);
+  *y_out = (float)(pr1 / pr2);
+}
+
 void undistort_point(const UndistortCtx& u, float x_in, float y_in, float* x_out, float* y_out) {
+  if (u.has_dist == 2) {
+    fisheye_undistort_point(u, x_in, y_in, x_out, y_out);
+    return;
+  }
   const double* k = u.k;  // k1 k2 p1 p2 k3 k4 k5 k6
   double x = x_in, y = y_in;
   const double px = x, py = y;
   x = (x - u.cx) * u.ifx;
   y = (y - u.cy) * u.ify;
-  if (u.has_dist) {
+  if (u.has_dist == 1) {
     const double x0 = x, y0 = y;
     for (int j = 0; j < 5; j++) {
       const double r2 = x * x + y * y;
@@ -197,12 +235,123 @@ void clip_roi(int r[4], int W, int H) {
 
 }  // namespace
 
+namespace {
+
+// cv::fisheye::estimateNewCameraMatrixForUndistortRectify(K, D, size, R, P, balance = 0,
+// new_size = (), fov_scale = 1) (calib3d/src/fisheye.cpp)
+M3 fisheye_estimate_new_camera_matrix(const kvfe_camera_params& cam, const M3& K, const M3& R) {
+  const int w = cam.width, h = cam.height;
+  const UndistortCtx u = make_undistort_ctx(cam, R.m, nullptr);
+  // the four edge mid-points, undistorted in float64 (the function works on a CV_64FC2 array)
+  const double pts[4][2] = {{(double)(w / 2), 0.0}, {(double)w, (double)(h / 2)}, {(double)(w / 2), (double)h},
+                            {0.0, (double)(h / 2)}};
+  double q[4][2];
+  for (int i = 0; i < 4; i++) {
+    // float64 path of fisheye::undistortPoints: same arithmetic as fisheye_undistort_point without
+    // the float rounding of the input / output
+    const double* k = u.k;
+    const double pw0 = (pts[i][0] - u.cx) / u.fx, pw1 = (pts[i][1] - u.cy) / u.fy;
+    double scale = 1.0;
+    double theta_d = std::sqrt(pw0 * pw0 + pw1 * pw1);
+    theta_d = std::min(std::max(-3.14159265358979323846 / 2., theta_d), 3.14159265358979323846 / 2.);
+    if (theta_d > 1e-8) {
+      double theta = theta_d;
+      for (int j = 0; j < 10; j++) {
+        const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+        const double a = k[0] * t2, b = k[1] * t4, c = k[2] * t6, d = k[3] * t8;
+        const double fix = (theta * (1 + a + b + c + d) - theta_d) / (1 + 3 * a + 5 * b + 7 * c + 9 * d);
+        theta = theta - fix;
+        if (std::fabs(fix) < 1e-8) break;
+      }
+      scale = std::tan(theta) / theta_d;
+    }
+    const double pu0 = pw0 * scale, pu1 = pw1 * scale;
+    const double pr0 = u.RR(0, 0) * pu0 + u.RR(0, 1) * pu1 + u.RR(0, 2);
+    const double pr1 = u.RR(1, 0) * pu0 + u.RR(1, 1) * pu1 + u.RR(1, 2);
+    const double pr2 = u.RR(2, 0) * pu0 + u.RR(2, 1) * pu1 + u.RR(2, 2);
+    q[i][0] = pr0 / pr2;
+    q[i][1] = pr1 / pr2;
+  }
+  double cn[2] = {(q[0][0] + q[1][0] + q[2][0] + q[3][0]) / 4.0, (q[0][1] + q[1][1] + q[2][1] + q[3][1]) / 4.0};
+  const double aspect_ratio = K(0, 0) / K(1, 1);
+  cn[0] *= aspect_ratio;  // sic: "convert to identity ratio" scales cn[0] and the points' y
+  for (int i = 0; i < 4; i++) q[i][1] *= aspect_ratio;
+  double minx = DBL_MAX, miny = DBL_MAX, maxx = -DBL_MAX, maxy = -DBL_MAX;
+  for (int i = 0; i < 4; i++) {
+    miny = std::min(miny, q[i][1]);
+    maxy = std::max(maxy, q[i][1]);
+    minx = std::min(minx, q[i][0]);
+    maxx = std::max(maxx, q[i][0]);
+  }
+  const double f1 = w * 0.5 / (cn[0] - minx), f2 = w * 0.5 / (maxx - cn[0]);
+  const double f3 = h * 0.5 * aspect_ratio / (cn[1] - miny), f4 = h * 0.5 * aspect_ratio / (maxy - cn[1]);
+  const double fmin = std::min(f1, std::min(f2, std::min(f3, f4)));
+  const double fmax = std::max(f1, std::max(f2, std::max(f3, f4)));
+  const double balance = 0.0;
+  double f = balance * fmin + (1.0 - balance) * fmax;
+  f *= 1.0;  // fov_scale = 1
+  double new_f[2] = {f, f};
+  double new_c[2] = {-cn[0] * f + w * 0.5, -cn[1] * f + (h * aspect_ratio) * 0.5};
+  new_f[1] /= aspect_ratio;
+  new_c[1] /= aspect_ratio;
+  return M3{{new_f[0], 0, new_c[0], 0, new_f[1], new_c[1], 0, 0, 1}};
+}
+
+// cv::fisheye::stereoRectify(K1, D1, K2, D2, size, R, T, R1, R2, P1, P2, Q, CALIB_ZERO_DISPARITY)
+// (StereoCamera.cpp:350-366; balance 0, fov_scale 1, newImageSize = imageSize)
+kvfe_status fisheye_stereo_rectify(const kvfe_camera_params& L, const kvfe_camera_params& Rc, const M3& K1,
+                                   const M3& K2, const M3& Rcv, const V3& Tcv, kvfe_rectification* out) {
+  V3 rvec = rodrigues_inv(Rcv);  // Affine3d(rmat).rvec()
+  for (double& v : rvec.v) v *= -0.5;
+  const M3 r_r = rodrigues(rvec);
+  const V3 t = mul(r_r, Tcv);
+  const V3 uu{{t.v[0] > 0 ? 1.0 : -1.0, 0, 0}};
+  V3 ww{{t.v[1] * uu.v[2] - t.v[2] * uu.v[1], t.v[2] * uu.v[0] - t.v[0] * uu.v[2],
+         t.v[0] * uu.v[1] - t.v[1] * uu.v[0]}};
+  const double nw = std::sqrt(ww.v[0] * ww.v[0] + ww.v[1] * ww.v[1] + ww.v[2] * ww.v[2]);
+  const double nt = std::sqrt(t.v[0] * t.v[0] + t.v[1] * t.v[1] + t.v[2] * t.v[2]);
+  if (nw > 0.0) {
+    const double sc = std::acos(std::fabs(t.v[0]) / nt) / nw;
+    for (double& v : ww.v) v *= sc;
+  }
+  const M3 wr = rodrigues(ww);
+  const M3 ri1 = mul(wr, r_r.t());
+  const M3 ri2 = mul(wr, r_r);
+  const V3 tnew = mul(ri2, Tcv);
+  const M3 newK1 = fisheye_estimate_new_camera_matrix(L, K1, ri1);
+  const M3 newK2 = fisheye_estimate_new_camera_matrix(Rc, K2, ri2);
+  const double fc_new = std::min(newK1(1, 1), newK2(1, 1));
+  double cc0[2] = {newK1(0, 2), newK1(1, 2)}, cc1[2] = {newK2(0, 2), newK2(1, 2)};
+  // CALIB_ZERO_DISPARITY: both principal points become their average
+  for (int i = 0; i < 2; i++) cc0[i] = cc1[i] = (cc0[i] + cc1[i]) * 0.5;
+  std::memset(out, 0, sizeof(*out));
+  std::memcpy(out->R1, ri1.m, sizeof(out->R1));
+  std::memcpy(out->R2, ri2.m, sizeof(out->R2));
+  const double P1[12] = {fc_new, 0, cc0[0], 0, 0, fc_new, cc0[1], 0, 0, 0, 1, 0};
+  const double P2[12] = {fc_new, 0, cc1[0], tnew.v[0] * fc_new, 0, fc_new, cc1[1], 0, 0, 0, 1, 0};
+  std::memcpy(out->P1, P1, sizeof(P1));
+  std::memcpy(out->P2, P2, sizeof(P2));
+  const double Q[16] = {1, 0, 0, -cc0[0], 0, 1, 0, -cc0[1], 0, 0, 0, fc_new,
+                        0, 0, -1. / tnew.v[0], (cc0[0] - cc1[0]) / tnew.v[0]};
+  std::memcpy(out->Q, Q, sizeof(Q));
+  // (cv::fisheye::stereoRectify reports no valid-pixel ROIs)
+  if (out->Q[14] == 0.0) return KVFE_ERR_INVALID_ARG;
+  out->baseline = 1.0 / out->Q[14];
+  if (!(out->baseline > 0.0)) return KVFE_ERR_INVALID_ARG;
+  return KVFE_OK;
+}
+
+}  // namespace
+
 kvfe_status stereo_rectify(const kvfe_camera_params& L, const kvfe_camera_params& Rc,
                            kvfe_rectification* out) {
   if (L.width != Rc.width || L.height != Rc.height || L.width <= 0 || L.height <= 0)
     return KVFE_ERR_INVALID_ARG;
-  if (L.distortion_model == KVFE_DIST_EQUIDISTANT || Rc.distortion_model == KVFE_DIST_EQUIDISTANT)
-    return KVFE_ERR_UNSUPPORTED;  // cv::fisheye::stereoRectify path is not implemented
+  // StereoCamera::computeRectificationParameters switches on the LEFT camera's model
+  // (StereoCamera.cpp:324-378); a mixed pair is not a configuration the reference can express
+  if ((L.distortion_model == KVFE_DIST_EQUIDISTANT) != (Rc.distortion_model == KVFE_DIST_EQUIDISTANT))
+    return KVFE_ERR_UNSUPPORTED;
+  const bool fisheye = L.distortion_model == KVFE_DIST_EQUIDISTANT;
   const double nx = L.width, ny = L.height;
   const M3 K1 = camera_matrix(L), K2 = camera_matrix(Rc);
 
@@ -223,6 +372,8 @@ kvfe_status stereo_rectify(const kvfe_camera_params& L, const kvfe_camera_params
   const M3 Rcv = Rrel.t();
   V3 Tcv = mul(Rcv, trel);
   for (double& v : Tcv.v) v = -v;
+
+  if (fisheye) return fisheye_stereo_rectify(L, Rc, K1, K2, Rcv, Tcv, out);
 
   // Bouguet: split the rotation, align the baseline with the x (or y) axis.
   V3 om = rodrigues_inv(Rcv);
@@ -345,7 +496,38 @@ kvfe_status stereo_rectify(const kvfe_camera_params& L, const kvfe_camera_params
 
 kvfe_status init_undistort_rectify_map(const kvfe_camera_params& cam, const double R[9],
                                        const double P[12], float* map_x, float* map_y) {
-  if (cam.distortion_model == KVFE_DIST_EQUIDISTANT) return KVFE_ERR_UNSUPPORTED;
+  if (cam.distortion_model == KVFE_DIST_EQUIDISTANT) {
+    // cv::fisheye::initUndistortRectifyMap (calib3d/src/fisheye.cpp); the reference's inverse is
+    // cv::invert(DECOMP_SVD), here the closed-form 3x3 inverse (agrees to rounding)
+    M3 Rm;
+    std::memcpy(Rm.m, R, sizeof(Rm.m));
+    const M3 PP{{P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]}};
+    const M3 iR = inv3(mul(PP, Rm));
+    const double* kk = cam.distortion;
+    const double f0 = cam.intrinsics[0], f1 = cam.intrinsics[1], c0 = cam.intrinsics[2], c1 = cam.intrinsics[3];
+    for (int i = 0; i < cam.height; ++i) {
+      float* m1f = map_x + (size_t)i * cam.width;
+      float* m2f = map_y + (size_t)i * cam.width;
+      double _x = i * iR(0, 1) + iR(0, 2), _y = i * iR(1, 1) + iR(1, 2), _w = i * iR(2, 1) + iR(2, 2);
+      for (int j = 0; j < cam.width; ++j) {
+        const double x = _x / _w, y = _y / _w;
+        const double r = std::sqrt(x * x + y * y);
+        const double theta = std::atan(r);
+        const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2,
+                     theta8 = theta4 * theta4;
+        const double theta_d = theta * (1 + kk[0] * theta2 + kk[1] * theta4 + kk[2] * theta6 + kk[3] * theta8);
+        const double scale = (r == 0) ? 1.0 : theta_d / r;
+        const double u = f0 * x * scale + c0;
+        const double v = f1 * y * scale + c1;
+        m1f[j] = (float)u;
+        m2f[j] = (float)v;
+        _x += iR(0, 0);
+        _y += iR(1, 0);
+        _w += iR(2, 0);
+      }
+    }
+    return KVFE_OK;
+  }
   double k[8];
   for (int i = 0; i < 8; i++)
     k[i] = (cam.distortion_model == KVFE_DIST_RADTAN && i < cam.n_distortion) ? cam.distortion[i] : 0;

@@ -40,12 +40,14 @@ V3 rodrigues_inv(const M3& R);
 
 M3 camera_matrix(const kvfe_camera_params& c);
 
-// radial-tangential undistortion of one pixel: K^-1, 5 fixed-point iterations,
-// then RR = (P[:, :3] *) R applied.  float in / float out like cv::undistortPoints.
+// undistortion of one pixel, float in / float out:
+//   has_dist 1 (radial-tangential, cv::undistortPoints): K^-1, 5 fixed-point iterations
+//   has_dist 2 (equidistant, cv::fisheye::undistortPoints): K^-1, Newton iterations on theta, tan
+// then RR = (P[:, :3] *) R applied.
 struct UndistortCtx {
   double fx, fy, cx, cy, ifx, ify;
   double k[8];
-  bool has_dist;
+  int has_dist;  // 0 none, 1 radtan, 2 equidistant
   M3 RR;
 };
 UndistortCtx make_undistort_ctx(const kvfe_camera_params& cam, const double* R /*9|null*/,

@@ -280,7 +280,7 @@ UndistortDev to_dev(const UndistortCtx& u) {
   d.ify = u.ify;
   for (int i = 0; i < 8; i++) d.k[i] = u.k[i];
   for (int i = 0; i < 9; i++) d.RR[i] = u.RR.m[i];
-  d.has_dist = u.has_dist ? 1 : 0;
+  d.has_dist = u.has_dist;
   d.pad = 0;
   return d;
 }

@@ -55,7 +55,7 @@ struct UndistortDev {
   double fx, fy, cx, cy, ifx, ify;
   double k[8];
   double RR[9];
-  int has_dist;
+  int has_dist;  // 0 none, 1 radial-tangential, 2 equidistant (cv::fisheye)
   int pad;
 };
 

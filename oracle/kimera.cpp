@@ -64,17 +64,29 @@ void StereoCamera::init(const kvfe_camera_params& l, const kvfe_camera_params& r
   for (int i = 0; i < 3; i++)
     tinv[i] = -(Rinv[i * 3] * trel[0] + Rinv[i * 3 + 1] * trel[1] + Rinv[i * 3 + 2] * trel[2]);
 
-  ocv::stereoRectify(K1, l.distortion, l.n_distortion, K2, r.distortion, r.n_distortion, w, h,
-                     Rinv, tinv, /*alpha=*/0, /*zero_disparity=*/true, rect.R1, rect.R2, rect.P1,
-                     rect.P2, rect.Q, rect.roi1, rect.roi2);
+  const bool fisheye = l.distortion_model == KVFE_DIST_EQUIDISTANT;  // StereoCamera.cpp:324-366
+  if (fisheye) {
+    std::memset(&rect, 0, sizeof(rect));
+    ocv::fisheye::stereoRectify(K1, l.distortion, K2, r.distortion, w, h, Rinv, tinv, rect.R1, rect.R2,
+                                rect.P1, rect.P2, rect.Q);
+  } else {
+    ocv::stereoRectify(K1, l.distortion, l.n_distortion, K2, r.distortion, r.n_distortion, w, h,
+                       Rinv, tinv, /*alpha=*/0, /*zero_disparity=*/true, rect.R1, rect.R2, rect.P1,
+                       rect.P2, rect.Q, rect.roi1, rect.roi2);
+  }
   rect.baseline = 1.0 / rect.Q[3 * 4 + 2];  // StereoCamera.cpp:70-72
   for (int c = 0; c < 2; c++) {
     map_x[c].resize((size_t)w * h);
     map_y[c].resize((size_t)w * h);
     const kvfe_camera_params& cp = c == 0 ? l : r;
-    ocv::initUndistortRectifyMap(c == 0 ? K1 : K2, cp.distortion, cp.n_distortion,
-                                 c == 0 ? rect.R1 : rect.R2, c == 0 ? rect.P1 : rect.P2, w, h,
-                                 map_x[c].data(), map_y[c].data());
+    if (fisheye)
+      ocv::fisheye::initUndistortRectifyMap(c == 0 ? K1 : K2, cp.distortion, c == 0 ? rect.R1 : rect.R2,
+                                            c == 0 ? rect.P1 : rect.P2, w, h, map_x[c].data(),
+                                            map_y[c].data());
+    else
+      ocv::initUndistortRectifyMap(c == 0 ? K1 : K2, cp.distortion, cp.n_distortion,
+                                   c == 0 ? rect.R1 : rect.R2, c == 0 ? rect.P1 : rect.P2, w, h,
+                                   map_x[c].data(), map_y[c].data());
   }
 }
 
@@ -92,8 +104,12 @@ void StereoCamera::initMono(const kvfe_camera_params& c) {
   for (int cam = 0; cam < 2; cam++) {
     map_x[cam].resize((size_t)w * h);
     map_y[cam].resize((size_t)w * h);
-    ocv::initUndistortRectifyMap(K1, c.distortion, c.n_distortion, rect.R1, rect.P1, w, h,
-                                 map_x[cam].data(), map_y[cam].data());
+    if (c.distortion_model == KVFE_DIST_EQUIDISTANT)
+      ocv::fisheye::initUndistortRectifyMap(K1, c.distortion, rect.R1, rect.P1, w, h, map_x[cam].data(),
+                                            map_y[cam].data());
+    else
+      ocv::initUndistortRectifyMap(K1, c.distortion, c.n_distortion, rect.R1, rect.P1, w, h,
+                                   map_x[cam].data(), map_y[cam].data());
   }
 }
 
@@ -106,7 +122,14 @@ void StereoCamera::undistortRectifyImage(int cam, const uint8_t* src, size_t str
 void StereoCamera::undistortRectifyKeypoints(int cam, const Point2f* in, int n, bool useR,
                                              bool useP, Point2f* out) const {
   const kvfe_camera_params& cp = cam == 0 ? left : right;
-  ocv::undistortPoints(in, out, n, cam == 0 ? K1 : K2, cp.distortion, cp.n_distortion,
+  if (cp.distortion_model == KVFE_DIST_EQUIDISTANT) {  // UndistorterRectifier.cpp:49-57
+    ocv::fisheye::undistortPoints(in, out, n, cam == 0 ? K1 : K2, cp.distortion,
+                                  useR ? (cam == 0 ? rect.R1 : rect.R2) : nullptr,
+                                  useP ? (cam == 0 ? rect.P1 : rect.P2) : nullptr);
+    return;
+  }
+  ocv::undistortPoints(in, out, n, cam == 0 ? K1 : K2, cp.distortion,
+                       cp.distortion_model == KVFE_DIST_RADTAN ? cp.n_distortion : 0,
                        useR ? (cam == 0 ? rect.R1 : rect.R2) : nullptr,
                        useP ? (cam == 0 ? rect.P1 : rect.P2) : nullptr);
 }

@@ -83,6 +83,24 @@ void stereoRectify(const double K1[9], const double* D1, int nD1, const double K
                    double R2[9], double P1[12], double P2[12], double Q[16], int roi1[4],
                    int roi2[4]);
 
+// cv::fisheye (calib3d/src/fisheye.cpp, OpenCV 4.2): the equidistant model the reference selects for
+// distortion_model: equidistant (UndistorterRectifier.cpp:49-57,260-272, StereoCamera.cpp:350-366).
+// D: 4 coefficients.  The reference's own tests of this model are DISABLED_ (tests/
+// testUndistortRectifier.cpp:222-330): parity unpinned.
+namespace fisheye {
+void undistortPoints(const Point2f* src, Point2f* dst, int n, const double K[9], const double D[4],
+                     const double* R /*9|null*/, const double* P /*12|null*/);
+void undistortPointsD(const double* src_xy, double* dst_xy, int n, const double K[9], const double D[4],
+                      const double* R);  // CV_64FC2 input (estimateNewCameraMatrixForUndistortRectify)
+void estimateNewCameraMatrixForUndistortRectify(const double K[9], const double D[4], int w, int h,
+                                                const double R[9], double newK[9]);
+void stereoRectify(const double K1[9], const double D1[4], const double K2[9], const double D2[4], int w,
+                   int h, const double R[9], const double T[3], double R1[9], double R2[9],
+                   double P1[12], double P2[12], double Q[16]);  // CALIB_ZERO_DISPARITY, balance 0
+void initUndistortRectifyMap(const double K[9], const double D[4], const double R[9], const double P[12],
+                             int w, int h, float* map_x, float* map_y);
+}  // namespace fisheye
+
 // cv::initUndistortRectifyMap(K, D, R, P, size, CV_32FC1, map1, map2).
 // Reference: UndistorterRectifier.cpp:248-258.
 void initUndistortRectifyMap(const double K[9], const double* D, int nD, const double R[9],

@@ -11,6 +11,9 @@
 
 namespace ocv {
 
+static const double CV_PI_ = 3.1415926535897932384626433832795;
+
+
 static void matmul3(const double A[9], const double B[9], double C[9]) {
   double t[9];
   for (int i = 0; i < 3; i++)
@@ -410,5 +413,171 @@ void initUndistortRectifyMap(const double K[9], const double* D, int nD, const d
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// cv::fisheye (equidistant model)
+// ---------------------------------------------------------------------------
+namespace fisheye {
+
+static void undistort_one(double px, double py, const double K[9], const double D[4], const double RR[9],
+                          double* ox, double* oy) {
+  const double f0 = K[0], f1 = K[4], c0 = K[2], c1 = K[5];
+  const double pw0 = (px - c0) / f0, pw1 = (py - c1) / f1;
+  double scale = 1.0;
+  double theta_d = std::sqrt(pw0 * pw0 + pw1 * pw1);
+  theta_d = std::min(std::max(-CV_PI_ / 2., theta_d), CV_PI_ / 2.);
+  if (theta_d > 1e-8) {
+    double theta = theta_d;
+    const double EPS = 1e-8;
+    for (int j = 0; j < 10; j++) {
+      double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
+      double k0_theta2 = D[0] * theta2, k1_theta4 = D[1] * theta4, k2_theta6 = D[2] * theta6,
+             k3_theta8 = D[3] * theta8;
+      double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                         (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+      theta = theta - theta_fix;
+      if (std::fabs(theta_fix) < EPS) break;
+    }
+    scale = std::tan(theta) / theta_d;
+  }
+  const double pu0 = pw0 * scale, pu1 = pw1 * scale;
+  const double pr0 = RR[0] * pu0 + RR[1] * pu1 + RR[2] * 1.0;
+  const double pr1 = RR[3] * pu0 + RR[4] * pu1 + RR[5] * 1.0;
+  const double pr2 = RR[6] * pu0 + RR[7] * pu1 + RR[8] * 1.0;
+  *ox = pr0 / pr2;
+  *oy = pr1 / pr2;
+}
+
+static void make_RR(const double* R, const double* P, double RR[9]) {
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::memcpy(RR, R ? R : I, sizeof(I));
+  if (P) {
+    double PP[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    matmul3(PP, RR, RR);
+  }
+}
+
+void undistortPoints(const Point2f* src, Point2f* dst, int n, const double K[9], const double D[4],
+                     const double* R, const double* P) {
+  double RR[9];
+  make_RR(R, P, RR);
+  for (int i = 0; i < n; i++) {
+    double x, y;
+    undistort_one((double)src[i].x, (double)src[i].y, K, D, RR, &x, &y);
+    dst[i].x = (float)x;
+    dst[i].y = (float)y;
+  }
+}
+
+void undistortPointsD(const double* src, double* dst, int n, const double K[9], const double D[4],
+                      const double* R) {
+  double RR[9];
+  make_RR(R, nullptr, RR);
+  for (int i = 0; i < n; i++) undistort_one(src[2 * i], src[2 * i + 1], K, D, RR, &dst[2 * i], &dst[2 * i + 1]);
+}
+
+void estimateNewCameraMatrixForUndistortRectify(const double K[9], const double D[4], int w, int h,
+                                                const double R[9], double newK[9]) {
+  double pts[8] = {(double)(w / 2), 0, (double)w, (double)(h / 2), (double)(w / 2), (double)h, 0, (double)(h / 2)};
+  undistortPointsD(pts, pts, 4, K, D, R);
+  double cn[2] = {(pts[0] + pts[2] + pts[4] + pts[6]) / 4.0, (pts[1] + pts[3] + pts[5] + pts[7]) / 4.0};
+  const double aspect_ratio = K[0] / K[4];
+  cn[0] *= aspect_ratio;  // sic
+  for (int i = 0; i < 4; i++) pts[2 * i + 1] *= aspect_ratio;
+  double minx = DBL_MAX, miny = DBL_MAX, maxx = -DBL_MAX, maxy = -DBL_MAX;
+  for (int i = 0; i < 4; i++) {
+    miny = std::min(miny, pts[2 * i + 1]);
+    maxy = std::max(maxy, pts[2 * i + 1]);
+    minx = std::min(minx, pts[2 * i]);
+    maxx = std::max(maxx, pts[2 * i]);
+  }
+  double f1 = w * 0.5 / (cn[0] - minx);
+  double f2 = w * 0.5 / (maxx - cn[0]);
+  double f3 = h * 0.5 * aspect_ratio / (cn[1] - miny);
+  double f4 = h * 0.5 * aspect_ratio / (maxy - cn[1]);
+  double fmin = std::min(f1, std::min(f2, std::min(f3, f4)));
+  double fmax = std::max(f1, std::max(f2, std::max(f3, f4)));
+  const double balance = 0.0, fov_scale = 1.0;
+  double f = balance * fmin + (1.0 - balance) * fmax;
+  f *= fov_scale > 0 ? 1.0 / fov_scale : 1.0;
+  double new_f[2] = {f, f};
+  double new_c[2] = {-cn[0] * f + w * 0.5, -cn[1] * f + (h * aspect_ratio) * 0.5};
+  new_f[1] /= aspect_ratio;
+  new_c[1] /= aspect_ratio;
+  const double out[9] = {new_f[0], 0, new_c[0], 0, new_f[1], new_c[1], 0, 0, 1};
+  std::memcpy(newK, out, sizeof(out));
+}
+
+void stereoRectify(const double K1[9], const double D1[4], const double K2[9], const double D2[4], int w,
+                   int h, const double R[9], const double T[3], double R1[9], double R2[9],
+                   double P1[12], double P2[12], double Q[16]) {
+  double rvec[3];
+  rodrigues_mat_to_vec(R, rvec);  // Affine3d(rmat).rvec() (its SVD re-orthogonalisation is omitted)
+  for (double& v : rvec) v *= -0.5;
+  double r_r[9];
+  rodrigues_vec_to_mat(rvec, r_r);
+  double t[3];
+  for (int i = 0; i < 3; i++) t[i] = r_r[i * 3] * T[0] + r_r[i * 3 + 1] * T[1] + r_r[i * 3 + 2] * T[2];
+  const double uu[3] = {t[0] > 0 ? 1.0 : -1.0, 0, 0};
+  double ww[3] = {t[1] * uu[2] - t[2] * uu[1], t[2] * uu[0] - t[0] * uu[2], t[0] * uu[1] - t[1] * uu[0]};
+  const double nw = std::sqrt(ww[0] * ww[0] + ww[1] * ww[1] + ww[2] * ww[2]);
+  const double nt = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+  if (nw > 0.0) {
+    const double sc = std::acos(std::fabs(t[0]) / nt) / nw;
+    for (double& v : ww) v *= sc;
+  }
+  double wr[9], r_rt[9];
+  rodrigues_vec_to_mat(ww, wr);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r_rt[i * 3 + j] = r_r[j * 3 + i];
+  matmul3(wr, r_rt, R1);
+  matmul3(wr, r_r, R2);
+  double tnew[3];
+  for (int i = 0; i < 3; i++) tnew[i] = R2[i * 3] * T[0] + R2[i * 3 + 1] * T[1] + R2[i * 3 + 2] * T[2];
+  double newK1[9], newK2[9];
+  estimateNewCameraMatrixForUndistortRectify(K1, D1, w, h, R1, newK1);
+  estimateNewCameraMatrixForUndistortRectify(K2, D2, w, h, R2, newK2);
+  const double fc_new = std::min(newK1[4], newK2[4]);
+  double cc0[2] = {newK1[2], newK1[5]}, cc1[2] = {newK2[2], newK2[5]};
+  for (int i = 0; i < 2; i++) cc0[i] = cc1[i] = (cc0[i] + cc1[i]) * 0.5;  // CALIB_ZERO_DISPARITY
+  const double p1[12] = {fc_new, 0, cc0[0], 0, 0, fc_new, cc0[1], 0, 0, 0, 1, 0};
+  const double p2[12] = {fc_new, 0, cc1[0], tnew[0] * fc_new, 0, fc_new, cc1[1], 0, 0, 0, 1, 0};
+  const double q[16] = {1, 0, 0, -cc0[0], 0, 1, 0, -cc0[1], 0, 0, 0, fc_new,
+                        0, 0, -1. / tnew[0], (cc0[0] - cc1[0]) / tnew[0]};
+  std::memcpy(P1, p1, sizeof(p1));
+  std::memcpy(P2, p2, sizeof(p2));
+  std::memcpy(Q, q, sizeof(q));
+}
+
+void initUndistortRectifyMap(const double K[9], const double D[4], const double R[9], const double P[12],
+                             int w, int h, float* map_x, float* map_y) {
+  const double f0 = K[0], f1 = K[4], c0 = K[2], c1 = K[5];
+  double PP[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+  double PR[9], iR[9];
+  matmul3(PP, R, PR);
+  invert3(PR, iR);  // cv::invert(DECOMP_SVD) in the reference; closed form here
+  for (int i = 0; i < h; ++i) {
+    float* m1f = map_x + (size_t)i * w;
+    float* m2f = map_y + (size_t)i * w;
+    double _x = i * iR[1] + iR[2], _y = i * iR[4] + iR[5], _w = i * iR[7] + iR[8];
+    for (int j = 0; j < w; ++j) {
+      double x = _x / _w, y = _y / _w;
+      double r = std::sqrt(x * x + y * y);
+      double theta = std::atan(r);
+      double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      double theta_d = theta * (1 + D[0] * theta2 + D[1] * theta4 + D[2] * theta6 + D[3] * theta8);
+      double scale = (r == 0) ? 1.0 : theta_d / r;
+      double u = f0 * x * scale + c0;
+      double v = f1 * y * scale + c1;
+      m1f[j] = (float)u;
+      m2f[j] = (float)v;
+      _x += iR[0];
+      _y += iR[3];
+      _w += iR[6];
+    }
+  }
+}
+
+}  // namespace fisheye
 
 }  // namespace ocv

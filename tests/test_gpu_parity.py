@@ -725,3 +725,69 @@ def test_mono_frontend_sequence(seq, use_ransac, force_kf):
         assert n_kf >= 2
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# equidistant distortion model (cv::fisheye; params/RealSenseIR, tests/data/ForStereoFrame/*_fisheye.yaml)
+# ---------------------------------------------------------------------------------------------
+def _fisheye_cams():
+    return (P.load_camera_params(os.path.join(G, "left_sensor_fisheye.yaml")),
+            P.load_camera_params(os.path.join(G, "right_sensor_fisheye.yaml")))
+
+
+def test_fisheye_rectify_and_keypoints(seq):
+    """distortion_model: equidistant.  Rectified images bit-exact (the maps are host float64 math on both
+    sides); undistorted keypoints / bearing vectors go through tan() on the device, whose last bit may
+    differ from glibc's: tolerance 1e-4 px / 1e-7 (north_star allows 0.5 px)."""
+    L, R = _fisheye_cams()
+    cam = O.Camera(L, R)
+    c = F.Context(L, R, euroc_params())
+    try:
+        for camid, img in ((0, gray("left_fisheye_img_0.png")), (1, seq["rights"][0])):
+            assert np.array_equal(c.undistort_rectify_image(camid, img), cam.rectify_image(camid, img))
+        rng = np.random.default_rng(3)
+        px = np.stack([rng.uniform(0, 751, 500), rng.uniform(0, 479, 500)], 1).astype(np.float32)
+        for useR, useP in ((True, True), (False, False), (True, False)):
+            got = c.undistort_rectify_keypoints(0, px, useR, useP)
+            exp = cam.undistort_keypoints(0, px, useR, useP)
+            assert np.allclose(got, exp, rtol=0, atol=1e-4), (useR, useP, np.abs(got - exp).max())
+        assert np.allclose(c.get_bearing_vectors(0, px), cam.bearing_vectors(0, px), rtol=0, atol=1e-7)
+    finally:
+        c.close()
+
+
+def test_fisheye_frontend_sequence(seq):
+    """the whole front-end on an equidistant pair (outlier rejection on): discrete outputs identical,
+    float outputs that depend on tan() within 1e-4 px / 1e-6 relative."""
+    L, R = _fisheye_cams()
+    cam = O.Camera(L, R)
+    p = _euroc_ransac_params(max_features_per_frame=200)
+    TL = np.array(L.body_pose_cam).reshape(4, 4)
+    body_R_cam = TL[:3, :3] @ np.array(cam.rect.R1).reshape(3, 3).T
+    camR = [body_R_cam.T @ Rb @ body_R_cam for Rb in seq["body_R"]]
+    fe = O.Frontend(L, R, p)
+    c = F.Context(L, R, p, batch=1)
+    try:
+        kf = 0
+        for i in range(6):
+            Rk = camR[kf].T @ camR[i]
+            ts = int(seq["ts"][i])
+            c.step_host(seq["lefts"][i][None], seq["rights"][i][None], c.make_inputs([ts], [Rk], [1]))
+            exp = fe.process(seq["lefts"][i], seq["rights"][i], ts, Rk, True)
+            got = c.get_output(0)
+            for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected", "n_measurements",
+                      "tracking_status_mono", "tracking_status_stereo", "nr_mono_putatives",
+                      "nr_mono_inliers", "nr_stereo_putatives", "nr_stereo_inliers"):
+                assert got[k] == exp[k], (i, k, got[k], exp[k])
+            for k in ("landmarks", "landmarks_age", "keypoints", "left_status", "right_status", "meas_landmark"):
+                assert np.array_equal(got[k], exp[k]), (i, k)
+            assert np.allclose(got["versors"], exp["versors"], rtol=0, atol=1e-7)
+            assert np.allclose(got["left_rect_xy"], exp["left_rect_xy"], rtol=0, atol=1e-4)
+            assert np.allclose(got["right_rect_xy"], exp["right_rect_xy"], rtol=0, atol=1e-4)
+            assert np.allclose(got["depth"], exp["depth"], rtol=1e-5, atol=0)
+            assert np.allclose(got["keypoints_3d"], exp["keypoints_3d"], rtol=1e-5, atol=1e-9)
+            assert np.allclose(got["lkf_T_k_stereo"], exp["lkf_T_k_stereo"], rtol=1e-5, atol=1e-7)
+            kf = i
+        assert (got["right_status"] == abi.KP_VALID).sum() > 20
+    finally:
+        c.close()
