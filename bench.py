@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true",
                     help="do not record per-stage HIP events in the timed region (no roofline object)")
+    ap.add_argument("--stage-event-stride", type=int, default=4,
+                    help="every N-th timed step records per-stage HIP events (roofline / stage breakdown)")
     ap.add_argument("--no-single-stream", action="store_true")
     return ap.parse_args()
 
@@ -149,7 +151,7 @@ def main():
     run(0, args.warmup)
     barrier()
     if not args.no_stage_events:
-        ctx.profile_enable(True)
+        ctx.profile_enable(args.stage_event_stride)
     t0 = time.perf_counter()
     run(args.warmup, total)
     t_enq = time.perf_counter()

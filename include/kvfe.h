@@ -477,6 +477,8 @@ typedef struct kvfe_stage_times {
   double ms_total[KVFE_N_STAGES];      /* summed over samples                 */
   double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch (mean) */
 } kvfe_stage_times;
+/* on = 0: off; on = N > 0: every N-th step records a begin/end HIP event pair per stage on the
+ * stream the stage runs on (recording every step costs ~10 % at 64 streams: 24 extra stream ops) */
 KVFE_API kvfe_status kvfe_profile_enable(kvfe_ctx* ctx, int32_t on);
 KVFE_API kvfe_status kvfe_profile_read(kvfe_ctx* ctx, kvfe_stage_times* out);
 

@@ -84,10 +84,12 @@ __device__ __forceinline__ int rs_block_sum(int v, int* wave_tot) {
 // ---------------------------------------------------------------------------------------------
 __device__ int rs_build_matches(const KParams& P, const FrameTab& K, const FrameTab& LKF,
                                 const unsigned char* k_rstat, const unsigned char* l_rstat, int s,
-                                long long* ids, int* idx, int* wave_tot, int2* matches) {
+                                int n_tracked, long long* ids, int* idx, int* wave_tot, int2* matches) {
   const int tid = threadIdx.x;
   const size_t so = (size_t)s * P.kcap;
-  const int nl = LKF.count[s], nk = K.count[s];
+  // only the tracked part of frame k: both rejections run before / concurrently with the detection
+  // that appends new entries behind it (and whose landmark ids cannot match the last keyframe anyway)
+  const int nl = LKF.count[s], nk = n_tracked;
   __shared__ int sh_off;
   if (tid == 0) sh_off = 0;
   __syncthreads();
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
   const bool imu_ok = !rs_rot_is_identity(R);
   if (!(P.ransac_2pt_mono && imu_ok)) return;  // 5-point problem: not implemented, status stays INVALID
   int2* matches = RS.matches + so;
-  const int n = rs_build_matches(P, K, LKF, nullptr, nullptr, s, L.ids, L.idx, wave_tot, matches);
+  const int n = rs_build_matches(P, K, LKF, nullptr, nullptr, s, S.n_tracked[s], L.ids, L.idx, wave_tot, matches);
   if (n == 0) return;
   double* f1 = RS.f_ref + so * 3;
   double* f2 = RS.f_cur + so * 3;
@@ -750,8 +752,8 @@ __global__ __launch_bounds__(RS_T) void stereo_ransac_prepare_kernel(KParams P, 
     return;
   }
   int2* matches = RS.matches + so;
-  const int n = rs_build_matches(P, K, LKF, ST.right_status, LST.right_status, s, L.ids, L.idx,
-                                 wave_tot, matches);
+  const int n = rs_build_matches(P, K, LKF, ST.right_status, LST.right_status, s, S.n_tracked[s],
+                                 L.ids, L.idx, wave_tot, matches);
   double Rl[9];
   for (int i = 0; i < 9; i++) Rl[i] = R[i];
   auto get = [&](int m, double* rl, double* rp, double* cl, double* cp) {

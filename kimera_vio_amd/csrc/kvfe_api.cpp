@@ -111,12 +111,14 @@ struct kvfe_ctx {
   UndistortDev und[2][4];  // [cam][useR + 2*useP]
   std::vector<float> h_map[2][2];  // host copies of the maps [cam][x|y]
   // profiling
-  bool prof_on = false;
+  bool prof_on = false;      // this step records stage events
+  int prof_stride = 0;       // 0 = profiling off; N = every N-th step records
+  long long prof_step = 0;
   std::vector<hipEvent_t> prof_ev;  // 2 * ST_COUNT (begin, end) events per recorded step
   // corner refinement runs on a side stream, concurrently with rectification and the stereo
   // matching of the tracked keypoints (its result is only needed by the newly detected ones)
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
   int prof_samples = 0;
@@ -674,11 +676,35 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     hts[s] = inputs[s].timestamp_ns;
     hf[s] = inputs[s].force_keyframe;
   }
-  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B,
-                           hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipEventRecord(c->ring_ev[slot], st));
-  c->ring_used[slot] = true;
+  // The kernels read this step's inputs straight from the pinned, device-mapped ring slot (a few
+  // hundred bytes over PCIe, once per per-stream block): no H2D copy and none of the two launch
+  // gaps around it.  The slot is released by the event recorded after the step's last kernel.
+  static const bool copy_inputs = std::getenv("KVFE_COPY_INPUTS") != nullptr;
+  if (copy_inputs) {
+    HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B,
+                             hipMemcpyHostToDevice, st));
+    b.ss.kf_R_cur = b.kf_R_cur;
+    b.ss.in_timestamp = b.in_ts;
+    b.ss.in_force_kf = b.in_force;
+  } else {
+    void* dp = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&dp, hb, 0));
+    unsigned char* d = reinterpret_cast<unsigned char*>(dp);
+    b.ss.kf_R_cur = reinterpret_cast<const double*>(d);
+    b.ss.in_timestamp = reinterpret_cast<const long long*>(d + sizeof(double) * 9 * P.B);
+    b.ss.in_force_kf = reinterpret_cast<const int*>(d + (sizeof(double) * 9 + sizeof(long long)) * P.B);
+  }
+  struct SlotRelease {  // records the slot's event when do_step returns (all kernels enqueued)
+    kvfe_ctx* c;
+    int slot;
+    hipStream_t st;
+    ~SlotRelease() {
+      hipEventRecord(c->ring_ev[slot], st);
+      c->ring_used[slot] = true;
+    }
+  } slot_release{c, slot, st};
 
+  c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
   if (c->prof_on) {
     const int base = (int)c->prof_ev.size();
     for (int i = 0; i < 2 * ST_COUNT; i++) {
@@ -742,8 +768,12 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     c->prev_img_stride = img_stride;
     return KVFE_OK;
   }
-  // fork: cornerSubPix + append of the new corners (side stream) || rectify + stereo matching of
-  // the tracked keypoints (main stream); join before the new keypoints are matched
+  // fork: cornerSubPix + append of the new corners (side stream: few waves, latency bound) ||
+  // rectify + stereo matching + stereo outlier rejection of the tracked keypoints (main stream:
+  // throughput bound); join before the new keypoints are matched.  (Measured alternative: moving the
+  // rectify / stereo chain to the side stream right after track_finalize is 10 % slower -- its
+  // workgroups delay the one-block-per-stream kernels of the detection chain; stream priorities
+  // do not change that.)
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
@@ -955,7 +985,8 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
   if (s == KVFE_OK && alloc_frontend && !no_side) {
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_mono, hipEventDisableTiming) != hipSuccess)
       s = KVFE_ERR_HIP;
   }
   if (s != KVFE_OK) {
@@ -1044,6 +1075,7 @@ void kvfe_destroy(kvfe_ctx* c) {
     if (c->step_done[i]) hipEventDestroy(c->step_done[i]);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->ev_mono) hipEventDestroy(c->ev_mono);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->host_allocs) hipHostFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1651,7 +1683,9 @@ kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
   for (kvfe_ctx* ch : c->children) TRY(kvfe_profile_enable(ch, on));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
-  c->prof_on = on != 0;
+  c->prof_stride = on > 0 ? on : 0;  // on = N: every N-th step records its stage events
+  c->prof_step = 0;
+  c->prof_on = false;
   if (on) {
     for (double& v : c->prof_ms) v = 0;
     c->prof_samples = 0;

@@ -313,7 +313,8 @@ class Context:
             d[k] = v[:m].copy() if k.startswith("meas_") else v[:n].copy()
         return d
 
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=1):
+        """on = N: every N-th step records per-stage HIP events (0 / False: off)."""
         self._chk(self.lib.kvfe_profile_enable(self._h, int(on)), "profile_enable")
 
     def profile_read(self) -> dict:
