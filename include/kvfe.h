@@ -283,6 +283,69 @@ KVFE_API kvfe_status kvfe_get_bearing_vectors(kvfe_ctx* ctx, int32_t cam,
 KVFE_API kvfe_status kvfe_equalize_hist(kvfe_ctx* ctx, const uint8_t* src, size_t src_stride,
                                         uint8_t* dst, size_t dst_stride);
 
+/* ---- dense stereo -------------------------------- */
+/* DenseStereoParams (include/kimera-vio/frontend/StereoMatchingParams.h:39-58).  The reference
+ * never parses these from YAML (StereoMatcher.cpp:30 default-constructs them), so
+ * kvfe_dense_stereo_params_default() is what denseStereoReconstruction runs with. */
+typedef struct kvfe_dense_stereo_params {
+  int32_t use_sgbm;               /* use_sgbm_ = true                                  */
+  int32_t post_filter_disparity;  /* post_filter_disparity_ = false (a no-op upstream) */
+  int32_t median_blur_disparity;  /* median_blur_disparity_ = false: cv::medianBlur(5) */
+  int32_t pre_filter_cap;         /* 31 */
+  int32_t sad_window_size;        /* 11 */
+  int32_t min_disparity;          /* 1  */
+  int32_t num_disparities;        /* 64 */
+  int32_t uniqueness_ratio;       /* 0  */
+  int32_t speckle_range;          /* 3  */
+  int32_t speckle_window_size;    /* 500 */
+  int32_t texture_threshold;      /* 0 (BM) */
+  int32_t pre_filter_type;        /* cv::StereoBM::PREFILTER_XSOBEL = 1 (BM) */
+  int32_t pre_filter_size;        /* 9 (BM, unused by XSOBEL) */
+  int32_t p1;                     /* 120 */
+  int32_t p2;                     /* 240 */
+  int32_t disp_12_max_diff;       /* -1 */
+  int32_t use_mode_hh;            /* use_mode_HH_ = true: cv::StereoSGBM::MODE_HH */
+  int32_t reserved0;
+} kvfe_dense_stereo_params;
+KVFE_API void kvfe_dense_stereo_params_default(kvfe_dense_stereo_params* p);
+
+/* StereoMatcher::denseStereoReconstruction(left_img_rectified, right_img_rectified, disparity_img)
+ * (StereoMatcher.cpp:32-121), batched over n_pairs independent rectified pairs of the context's
+ * image size: cv::StereoSGBM::compute (MODE_HH; BT pixel cost, 8-path aggregation, uniqueness,
+ * sub-pixel fit, left-right check, 3x3 median, cv::filterSpeckles) and the optional 5x5 median.
+ * disparity: n_pairs images of int16 with 4 fractional bits, (min_disparity - 1) * 16 where
+ * invalid — the CV_16S matrix cv::StereoSGBM::compute leaves in *disparity_img (compute()
+ * re-creates the CV_32F matrix the caller passed as CV_16S; callers divide by 16:
+ * tests/testStereoCamera.cpp:296-300).  KVFE_ERR_UNSUPPORTED: use_sgbm = 0 (cv::StereoBM),
+ * use_mode_hh = 0 (MODE_SGBM), num_disparities > 64 or not a multiple of 16, cost ranges that
+ * leave 16 bits (sad_window_size^2 * 125 + 2 * p2 > 16383). */
+KVFE_API kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* ctx,
+                                                      const kvfe_dense_stereo_params* params,
+                                                      int32_t n_pairs,
+                                                      const uint8_t* const* left_rect,
+                                                      const uint8_t* const* right_rect,
+                                                      size_t stride,
+                                                      int16_t* const* disparity,
+                                                      size_t disparity_stride_elems);
+
+/* measurement hook: summed HIP-event time of the kernel sequences of the
+ * kvfe_dense_stereo_reconstruction calls since the last read (copies excluded), and the
+ * number of pairs they processed; both counters are reset. */
+KVFE_API kvfe_status kvfe_dense_profile_read(kvfe_ctx* ctx, double* kernel_ms, int64_t* pairs);
+
+/* test hook: cost volumes [H][width1][D] int16 of the first pair of the last
+ * kvfe_dense_stereo_reconstruction call: which = 2: C(p,d) of computeDisparitySGBM (with its +P2
+ * bias); 0 / 1: the sums of the four path costs of pass 1 / pass 2 (uint16). */
+KVFE_API kvfe_status kvfe_dense_debug_volume(kvfe_ctx* ctx, int32_t which, int16_t* out,
+                                             size_t elems);
+
+/* StereoCamera::backProjectDisparityTo3D (StereoCamera.cpp:176-196) ==
+ * cv::reprojectImageTo3D(disparity CV_32F, depth CV_32FC3, Q, handleMissingValues = true):
+ * disparity is the float image (int16 / 16), xyz is h x w x 3 float; pixels at the minimum
+ * disparity of the image get z = 10000.  Q is the context's rectification Q. */
+KVFE_API kvfe_status kvfe_backproject_disparity_to_3d(kvfe_ctx* ctx, const float* disparity,
+                                                      size_t stride_elems, float* xyz);
+
 /* FeatureDetector::rawFeatureDetection (FeatureDetector.cpp:165-172)
  * == cv::GFTTDetector::detect(img, kps, mask); mask may be NULL (all 255).
  * Returns integer-valued corners in quality-descending order. */

@@ -87,6 +87,30 @@ class StereoParams(C.Structure):
     ]
 
 
+class DenseStereoParams(C.Structure):
+    """kvfe_dense_stereo_params (DenseStereoParams, StereoMatchingParams.h:39-58)"""
+    _fields_ = [
+        ("use_sgbm", C.c_int32), ("post_filter_disparity", C.c_int32),
+        ("median_blur_disparity", C.c_int32), ("pre_filter_cap", C.c_int32),
+        ("sad_window_size", C.c_int32), ("min_disparity", C.c_int32),
+        ("num_disparities", C.c_int32), ("uniqueness_ratio", C.c_int32),
+        ("speckle_range", C.c_int32), ("speckle_window_size", C.c_int32),
+        ("texture_threshold", C.c_int32), ("pre_filter_type", C.c_int32),
+        ("pre_filter_size", C.c_int32), ("p1", C.c_int32), ("p2", C.c_int32),
+        ("disp_12_max_diff", C.c_int32), ("use_mode_hh", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+def dense_stereo_params_default() -> "DenseStereoParams":
+    """the values the reference runs with (it never parses them from YAML)"""
+    return DenseStereoParams(use_sgbm=1, post_filter_disparity=0, median_blur_disparity=0,
+                             pre_filter_cap=31, sad_window_size=11, min_disparity=1,
+                             num_disparities=64, uniqueness_ratio=0, speckle_range=3,
+                             speckle_window_size=500, texture_threshold=0, pre_filter_type=1,
+                             pre_filter_size=9, p1=120, p2=240, disp_12_max_diff=-1, use_mode_hh=1,
+                             reserved0=0)
+
+
 class FrontendParams(C.Structure):
     _fields_ = [
         ("detector", DetectorParams), ("tracker", TrackerParams), ("stereo", StereoParams),

@@ -1,0 +1,555 @@
+// Dense stereo correspondence for gfx950: cv::StereoSGBM (MODE_HH) as reached through
+// StereoMatcher::denseStereoReconstruction (reference: src/frontend/StereoMatcher.cpp:32-121,
+// DenseStereoParams include/kimera-vio/frontend/StereoMatchingParams.h:39-58), bit-exact against
+// oracle/ocv_stereo.cpp (integer arithmetic throughout).
+//
+// Data layout in HBM, per rectified pair (W x H, D disparities, width1 = W - minX1 columns that
+// can be matched):
+//   rec    u8x8 [2][H][W]          per pixel of the left / right image: Sobel-x response through the
+//                                  clip table and raw intensity, each with the min / max over the
+//                                  half-pixel neighbourhood (Birchfield-Tomasi)
+//   vol0-2 i16  [H][width1][D]     cost volumes, disparity innermost so that one wave (lane = d) reads
+//                                  one 128-byte line per pixel: pixel cost -> row sums -> C(p,d);
+//                                  the first two are then reused for the two 4-path sums
+//   disp   i16  [2][H][W], labels i32 [2][H][W]
+// Kernels (all HBM / latency bound; no contraction, so no MFMA):
+//   dense_prefilter   1 thread / pixel
+//   dense_bt_cost     wave = one pixel, lane = disparity
+//   dense_hsum/vsum   sliding window sums along x then y (2 lines read per line written)
+//   dense_aggregate   one wave per scan-line path (8 directions), lane = disparity; neighbours d-1 / d+1
+//                     through DPP wave shifts, min_k L_r through DPP + readlane; the running path cost
+//                     stays in a register, the 4-path sums are accumulated in place (u16)
+//   dense_select      block = image row: winner-take-all, uniqueness, sub-pixel fit, the right-view
+//                     disparity buffer as 64-bit LDS atomic-min keys, left-right check
+//   dense_median3/5, speckle filter as connected-component labelling (row runs + union-find)
+#include "kvfe_dev.hpp"
+
+namespace kvfe {
+
+namespace {
+
+constexpr int DISP_SHIFT = 4;
+constexpr int DISP_SCALE = 16;
+constexpr int MAXC = 32767;
+
+__device__ __forceinline__ int dpp_wave_shr1(int v, int fill) {   // lane i <- lane i-1, lane 0 <- fill
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_wave_shl1(int v, int fill) {   // lane i <- lane i+1, lane 63 <- fill
+  return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);
+}
+// minimum over the 64 lanes, returned uniformly
+__device__ __forceinline__ int wave_min(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+// ---- calcPixelCostBT, first half: per-pixel records -------------------------------------------
+// (stereosgbm.cpp calcPixelCostBT: prow1/prow2 rows and the v0/v1, u0/u1 half-pixel bounds)
+__global__ __launch_bounds__(256) void dense_prefilter_kernel(DenseParams P, const uint8_t* __restrict__ left,
+                                                              const uint8_t* __restrict__ right,
+                                                              uint2* __restrict__ rec) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z & 1, pair = blockIdx.z >> 1;
+  if (x >= P.W) return;
+  const size_t plane = (size_t)P.W * P.H;
+  const uint8_t* src = (img ? right : left) + pair * plane;
+  const uint8_t* r1 = src + (size_t)y * P.W;
+  const uint8_t* rn = y > 0 ? r1 - P.W : r1;
+  const uint8_t* rs = y < P.H - 1 ? r1 + P.W : r1;
+  const int ft = P.ftzero;
+  auto chan = [&](int xx, int& p0, int& p1) {
+    if (xx <= 0 || xx >= P.W - 1) {   // first / last column of both channels: tab[0]
+      p0 = p1 = ft;
+      return;
+    }
+    const int g = (r1[xx + 1] - r1[xx - 1]) * 2 + rn[xx + 1] - rn[xx - 1] + rs[xx + 1] - rs[xx - 1];
+    p0 = min(max(g, -ft), ft) + ft;
+    p1 = r1[xx];
+  };
+  int a0, a1, b0, b1, c0, c1;
+  chan(x, a0, a1);
+  chan(x - 1, b0, b1);
+  chan(x + 1, c0, c1);
+  const int l0 = x > 0 ? (a0 + b0) / 2 : a0, h0 = x < P.W - 1 ? (a0 + c0) / 2 : a0;
+  const int l1 = x > 0 ? (a1 + b1) / 2 : a1, h1 = x < P.W - 1 ? (a1 + c1) / 2 : a1;
+  const int lo0 = min(min(l0, h0), a0), hi0 = max(max(l0, h0), a0);
+  const int lo1 = min(min(l1, h1), a1), hi1 = max(max(l1, h1), a1);
+  uint2 o;
+  o.x = (unsigned)a0 | ((unsigned)lo0 << 8) | ((unsigned)hi0 << 16) | ((unsigned)a1 << 24);
+  o.y = (unsigned)lo1 | ((unsigned)hi1 << 8);
+  rec[((size_t)blockIdx.z * P.H + y) * P.W + x] = o;
+}
+
+// ---- calcPixelCostBT, second half: cost(x, d), wave = pixel, lane = d -----------------------------
+constexpr int BT_XPB = 64;   // columns per block (16 per wave)
+__global__ __launch_bounds__(256) void dense_bt_cost_kernel(DenseParams P, const uint2* __restrict__ rec,
+                                                            short* __restrict__ pix) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int y = blockIdx.y, pair = blockIdx.z;
+  const int xb = blockIdx.x * BT_XPB + wv * (BT_XPB / 4);
+  const uint2* recL = rec + ((size_t)(pair * 2) * P.H + y) * P.W;
+  const uint2* recR = rec + ((size_t)(pair * 2 + 1) * P.H + y) * P.W;
+  short* out = pix + (((size_t)pair * P.H + y) * P.width1) * P.D;
+  const bool act = lane < P.D;
+  for (int i = 0; i < BT_XPB / 4; i++) {
+    const int x = xb + i;
+    if (x >= P.width1) break;
+    const int xa = x + P.minX1;
+    const uint2 L = recL[xa];
+    const int xr = xa - (lane + P.minD);
+    const uint2 R = recR[act ? xr : xa];
+    const int u = L.x & 255, u0 = (L.x >> 8) & 255, u1 = (L.x >> 16) & 255;
+    const int v = R.x & 255, v0 = (R.x >> 8) & 255, v1 = (R.x >> 16) & 255;
+    const int c0 = max(max(0, u - v1), v0 - u), c1 = max(max(0, v - u1), u0 - v);
+    const int ur = L.x >> 24, ur0 = L.y & 255, ur1 = (L.y >> 8) & 255;
+    const int vr = R.x >> 24, vr0 = R.y & 255, vr1 = (R.y >> 8) & 255;
+    const int e0 = max(max(0, ur - vr1), vr0 - ur), e1 = max(max(0, vr - ur1), ur0 - vr);
+    if (act) out[(size_t)x * P.D + lane] = (short)(min(c0, c1) + (min(e0, e1) >> 2));
+  }
+}
+
+// ---- window sums (computeDisparitySGBM: hsumAdd / C recurrences, written as clamped box sums) ---------
+// hs(y,x,d) = sum_{i=-SW2..SW2} pix(y, clamp(x+i, 0, width1-1), d)
+constexpr int HS_CHUNK = 32;
+__global__ __launch_bounds__(256) void dense_hsum_kernel(DenseParams P, const short* __restrict__ pix,
+                                                         short* __restrict__ hs) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int y = blockIdx.y, pair = blockIdx.z;
+  const int x0 = (blockIdx.x * 4 + wv) * HS_CHUNK;
+  if (x0 >= P.width1 || lane >= P.D) return;
+  const size_t row = ((size_t)pair * P.H + y) * P.width1;
+  const short* in = pix + row * P.D + lane;
+  short* out = hs + row * P.D + lane;
+  const int w1 = P.width1 - 1;
+  int s = 0;
+  for (int i = -P.SW2; i <= P.SW2; i++) s += in[(size_t)min(max(x0 + i, 0), w1) * P.D];
+  out[(size_t)x0 * P.D] = (short)s;
+  const int xe = min(x0 + HS_CHUNK, P.width1);
+  for (int x = x0 + 1; x < xe; x++) {
+    s += in[(size_t)min(x + P.SW2, w1) * P.D] - in[(size_t)max(x - P.SW2 - 1, 0) * P.D];
+    out[(size_t)x * P.D] = (short)s;
+  }
+}
+
+// C(y,x,d) = P2 + sum_{k=-SH2..SH2} hs(clamp(y+k, 0, H-1), x, d); OpenCV's recurrence leaves C at its
+// initial value P2 in column 0 of every row but the first, and in the last SH2 rows (y + SH2 >= H)
+constexpr int VS_CHUNK = 32;
+__global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const short* __restrict__ hs,
+                                                         short* __restrict__ Cv) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int x = blockIdx.x * 4 + wv, pair = blockIdx.z;
+  const int y0 = blockIdx.y * VS_CHUNK;
+  if (x >= P.width1 || lane >= P.D) return;
+  const size_t rs = (size_t)P.width1 * P.D;
+  const short* in = hs + (size_t)pair * P.H * rs + (size_t)x * P.D + lane;
+  short* out = Cv + (size_t)pair * P.H * rs + (size_t)x * P.D + lane;
+  const int h1 = P.H - 1, SH2 = P.SW2;
+  const int ye = min(y0 + VS_CHUNK, P.H);
+  int s = 0;
+  bool have = false;
+  for (int y = y0; y < ye; y++) {
+    const bool plain = y > 0 && (x == 0 || y + SH2 >= P.H);
+    if (plain) {
+      out[(size_t)y * rs] = (short)P.P2;
+      have = false;
+      continue;
+    }
+    if (!have) {
+      s = 0;
+      for (int k = -SH2; k <= SH2; k++) s += in[(size_t)min(max(y + k, 0), h1) * rs];
+      have = true;
+    } else {
+      s += in[(size_t)min(y + SH2, h1) * rs] - in[(size_t)max(y - SH2 - 1, 0) * rs];
+    }
+    out[(size_t)y * rs] = (short)(P.P2 + s);
+  }
+}
+
+// ---- path aggregation ---------------------------------------------------------------------------
+// L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, min_k L_r(p-r,k)+P2) - (min_k L_r(p-r,k)+P2)
+// along one scan line; outside the volume L_r = 0 for every d (the zeroed borders of OpenCV's Lr / minLr
+// buffers), L_r(., -1) = L_r(., D) = SHRT_MAX.  SX,SY = direction of travel (p - r is the previous pixel).
+template <int SX, int SY, bool FIRST>
+__global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, const short* __restrict__ Cv,
+                                                              unsigned short* __restrict__ sum) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int path = blockIdx.x * 4 + wv, pair = blockIdx.y;
+  const int W1 = P.width1, H = P.H;
+  int x, y, len;
+  if (SY == 0) {
+    if (path >= H) return;
+    y = path;
+    x = SX > 0 ? 0 : W1 - 1;
+    len = W1;
+  } else if (SX == 0) {
+    if (path >= W1) return;
+    x = path;
+    y = SY > 0 ? 0 : H - 1;
+    len = H;
+  } else {
+    if (path >= W1 + H - 1) return;
+    if (path < W1) {
+      x = path;
+      y = SY > 0 ? 0 : H - 1;
+    } else {
+      const int j = path - W1;
+      x = SX > 0 ? 0 : W1 - 1;
+      y = SY > 0 ? j + 1 : H - 2 - j;
+    }
+    const int nx = SX > 0 ? W1 - x : x + 1, ny = SY > 0 ? H - y : y + 1;
+    len = min(nx, ny);
+  }
+  const bool act = lane < P.D;
+  const size_t base = (size_t)pair * H * W1 * P.D + ((size_t)y * W1 + x) * P.D + lane;
+  const long step = ((long)SY * W1 + SX) * P.D;
+  const short* cp = Cv + base;
+  unsigned short* sp = sum + base;
+  int Lp = act ? 0 : MAXC;   // lanes >= D stand for d = D, D+1, ...: never below SHRT_MAX
+  int minp = 0;
+  const int P1 = P.P1, P2 = P.P2;
+  // software pipeline: the loads of the next pixels do not depend on the recurrence
+  constexpr int PF = 4;
+  int cbuf[PF];
+  int sbuf[PF];
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    cbuf[i] = (i < len && act) ? cp[(long)i * step] : 0;
+    if (!FIRST) sbuf[i] = (i < len && act) ? sp[(long)i * step] : 0;
+  }
+  for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const int t = t0 + i;
+      if (t >= len) break;
+      const int c = cbuf[i];
+      const int sprev = FIRST ? 0 : sbuf[i];
+      const int tn = t + PF;
+      if (tn < len && act) {
+        cbuf[i] = cp[(long)tn * step];
+        if (!FIRST) sbuf[i] = sp[(long)tn * step];
+      }
+      const int delta = minp + P2;
+      const int lm = dpp_wave_shr1(Lp, MAXC), lq = dpp_wave_shl1(Lp, MAXC);
+      const int m = min(min(Lp, delta), min(lm, lq) + P1);
+      const int L = c + m - delta;
+      Lp = act ? L : MAXC;
+      minp = wave_min(Lp);
+      if (act) sp[(long)t * step] = (unsigned short)(sprev + L);
+    }
+  }
+}
+
+// ---- disparity selection (computeDisparitySGBM, pass == npasses block) ---------------------------------
+constexpr int SEL_MAXW = 2048;
+__global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const unsigned short* __restrict__ sumA,
+                                                           const unsigned short* __restrict__ sumB,
+                                                           short* __restrict__ disp) {
+  __shared__ unsigned long long d2key[SEL_MAXW];
+  __shared__ short d1[SEL_MAXW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int y = blockIdx.x, pair = blockIdx.y;
+  const int W = P.W, W1 = P.width1, D = P.D;
+  const short INVALID = (short)P.invalid_scaled;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    d2key[x] = ~0ull;
+    d1[x] = INVALID;
+  }
+  __syncthreads();
+  const size_t row = (((size_t)pair * P.H + y) * W1) * D;
+  const bool act = lane < D;
+  for (int x = W1 - 1 - wv; x >= 0; x -= 4) {
+    int S = 0x7fffffff;
+    if (act) {
+      const int a = sumA[row + (size_t)x * D + lane], b = sumB[row + (size_t)x * D + lane];
+      S = min(MAXC, min(MAXC, a) + b);   // saturate_cast<short> after each pass
+    }
+    const int minS = wave_min(S);
+    if (minS >= MAXC) continue;   // bestDisp = -1: the pixel keeps INVALID_DISP_SCALED
+    const unsigned long long eq = __ballot(act && S == minS);
+    const int best = __ffsll((long long)eq) - 1;
+    const int Sv = act ? S : MAXC;
+    const bool viol = act && (Sv * (100 - P.uniq) < minS * 100) && abs(best - lane) > 1;
+    if (__ballot(viol)) continue;
+    const int Sm = __shfl(S, max(best - 1, 0)), Sq = __shfl(S, min(best + 1, 63));
+    if (lane == 0) {
+      const int x2 = x + P.minX1 - best - P.minD;
+      // scanning x downwards, a strictly smaller cost replaces: lowest cost, then largest x
+      atomicMin(&d2key[x2], ((unsigned long long)minS << 32) | ((unsigned long long)(0xFFFF - x) << 16) |
+                                (unsigned long long)best);
+      int d;
+      if (0 < best && best < D - 1) {
+        const int denom2 = max(Sm + Sq - 2 * minS, 1);
+        d = best * DISP_SCALE + ((Sm - Sq) * DISP_SCALE + denom2) / (denom2 * 2);
+      } else
+        d = best * DISP_SCALE;
+      d1[x + P.minX1] = (short)(d + P.minD * DISP_SCALE);
+    }
+  }
+  __syncthreads();
+  short* out = disp + ((size_t)pair * P.H + y) * W;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    int dv = d1[x];
+    if (x >= P.minX1 && x < P.minX1 + W1 && dv != INVALID) {
+      const int _d = dv >> DISP_SHIFT, d_ = (dv + DISP_SCALE - 1) >> DISP_SHIFT;
+      const int _x = x - _d, x_ = x - d_;
+      auto disp2 = [&](int xx) {
+        const unsigned long long k = d2key[xx];
+        return k == ~0ull ? P.minD - 1 : (int)(k & 0xFFFF) + P.minD;
+      };
+      bool bad = false;
+      if (0 <= _x && _x < W && 0 <= x_ && x_ < W) {
+        const int a = disp2(_x), b = disp2(x_);
+        bad = a >= P.minD && abs(a - _d) > P.disp12 && b >= P.minD && abs(b - d_) > P.disp12;
+      }
+      if (bad) dv = INVALID;
+    }
+    out[x] = (short)dv;
+  }
+}
+
+// ---- cv::medianBlur on CV_16S (replicated borders) -----------------------------------------------
+__device__ __forceinline__ void cswap(int& a, int& b) {
+  const int t = min(a, b);
+  b = max(a, b);
+  a = t;
+}
+__global__ __launch_bounds__(256) void dense_median3_kernel(int W, int H, const short* __restrict__ src,
+                                                            short* __restrict__ dst) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const short* s = src + (size_t)blockIdx.z * W * H;
+  int v[9];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int yy = min(max(y + j - 1, 0), H - 1);
+#pragma unroll
+    for (int i = 0; i < 3; i++) v[j * 3 + i] = s[(size_t)yy * W + min(max(x + i - 1, 0), W - 1)];
+  }
+  // 19-exchange median-of-9 network
+  cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+  cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+  cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+  cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+  cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+  cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+  cswap(v[4], v[2]);
+  dst[(size_t)blockIdx.z * W * H + (size_t)y * W + x] = (short)v[4];
+}
+__global__ __launch_bounds__(256) void dense_median5_kernel(int W, int H, const short* __restrict__ src,
+                                                            short* __restrict__ dst) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const short* s = src + (size_t)blockIdx.z * W * H;
+  int v[25];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const int yy = min(max(y + j - 2, 0), H - 1);
+#pragma unroll
+    for (int i = 0; i < 5; i++) v[j * 5 + i] = s[(size_t)yy * W + min(max(x + i - 2, 0), W - 1)];
+  }
+  // partial selection: 13 rounds of "move the minimum of the remaining elements to the front"
+#pragma unroll
+  for (int k = 0; k < 13; k++)
+#pragma unroll
+    for (int i = 24; i > k; i--) cswap(v[i - 1], v[i]);
+  dst[(size_t)blockIdx.z * W * H + (size_t)y * W + x] = (short)v[12];
+}
+
+// ---- cv::filterSpeckles as connected-component labelling ------------------------------------------------
+// A pixel is removed iff its 4-connected component (edges between valid neighbours whose values differ by
+// at most maxDiff) has at most maxSpeckleSize pixels — the flood fill's result does not depend on scan order.
+// Step 1: block = row: every pixel gets the index of the first pixel of its horizontal run.
+__global__ __launch_bounds__(256) void speckle_rows_kernel(int W, int H, int newVal, int maxDiff,
+                                                           const short* __restrict__ disp, int* __restrict__ label,
+                                                           int* __restrict__ count) {
+  __shared__ int start[SEL_MAXW];
+  __shared__ int wave_tot[4];
+  const int y = blockIdx.x;
+  const size_t img = (size_t)blockIdx.y * W * H;
+  const short* d = disp + img + (size_t)y * W;
+  const int per = (W + 255) / 256;
+  const int x0 = min((int)threadIdx.x * per, W), x1 = min(x0 + per, W);
+  // start[x] = running maximum of (x if a run starts at x else -1): inclusive prefix max over the row
+  int run = -1;
+  for (int x = x0; x < x1; x++) {
+    const int v = d[x];
+    const bool valid = v != newVal;
+    const bool joins = valid && x > 0 && d[x - 1] != newVal && abs(v - d[x - 1]) <= maxDiff;
+    if (valid && !joins) run = x;
+    start[x] = run;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = run;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc = max(inc, o);
+  }
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int pre = __shfl_up(inc, 1);
+  if (lane == 0) pre = -1;
+  for (int k = 0; k < wv; k++) pre = max(pre, wave_tot[k]);
+  for (int x = x0; x < x1; x++) start[x] = max(start[x], pre);
+  __syncthreads();
+  for (int x = threadIdx.x; x < W; x += 256) {
+    const size_t i = img + (size_t)y * W + x;
+    label[i] = d[x] != newVal ? y * W + start[x] : -1;
+    count[i] = 0;
+  }
+}
+__device__ __forceinline__ int cc_find(const int* L, int i) {
+  int p;
+  while ((p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != i) i = p;
+  return i;
+}
+__device__ void cc_union(int* L, int a, int b) {
+  for (;;) {
+    a = cc_find(L, a);
+    b = cc_find(L, b);
+    if (a == b) return;
+    if (a < b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }
+    const int old = atomicMin(&L[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+// Step 2: vertical links (only where a run changes on either row, or at the first column of a run pair)
+__global__ __launch_bounds__(256) void speckle_merge_kernel(int W, int H, int newVal, int maxDiff,
+                                                            const short* __restrict__ disp, int* __restrict__ label) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W || y >= H - 1) return;
+  const size_t img = (size_t)blockIdx.z * W * H;
+  const short* d = disp + img;
+  int* L = label + img;
+  const int i = y * W + x;
+  const int v = d[i], u = d[i + W];
+  if (v == newVal || u == newVal || abs(v - u) > maxDiff) return;
+  // skip links already implied by the left neighbour's link (same runs above and below, and linked)
+  if (x > 0) {
+    const int vl = d[i - 1], ul = d[i + W - 1];
+    if (vl != newVal && ul != newVal && abs(vl - ul) <= maxDiff && abs(v - vl) <= maxDiff && abs(u - ul) <= maxDiff)
+      return;
+  }
+  cc_union(L, i, i + W);
+}
+__global__ __launch_bounds__(256) void speckle_count_kernel(int W, int H, int* __restrict__ label,
+                                                            int* __restrict__ count) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const size_t img = (size_t)blockIdx.z * W * H;
+  int* L = label + img;
+  const int i = y * W + x;
+  if (L[i] < 0) return;
+  const int r = cc_find(L, i);
+  L[i] = r;
+  atomicAdd(&count[img + r], 1);
+}
+__global__ __launch_bounds__(256) void speckle_apply_kernel(int W, int H, int newVal, int maxSize,
+                                                            const int* __restrict__ label, const int* __restrict__ count,
+                                                            short* __restrict__ disp) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const size_t img = (size_t)blockIdx.z * W * H;
+  const size_t i = img + (size_t)y * W + x;
+  const int r = label[i];
+  if (r >= 0 && count[img + r] <= maxSize) disp[i] = (short)newVal;
+}
+
+// cv::reprojectImageTo3D(CV_32F -> CV_32FC3, handleMissingValues = true)
+__global__ __launch_bounds__(256) void dense_min_kernel(int n, const float* __restrict__ disp, unsigned* __restrict__ out) {
+  // order-preserving map float -> unsigned, atomicMin
+  float m = 3.402823466e+38f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fminf(m, disp[i]);
+  for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned b = __float_as_uint(m);
+    atomicMin(out, (b & 0x80000000u) ? ~b : (b | 0x80000000u));
+  }
+}
+__global__ __launch_bounds__(256) void dense_reproject_kernel(int W, int H, const float* __restrict__ disp,
+                                                              const unsigned* __restrict__ minkey, ReprojectQ Q,
+                                                              float* __restrict__ xyz) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const unsigned k = *minkey;
+  const double minDisparity = (double)__uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+  const double d = disp[(size_t)y * W + x];
+  const double v[4] = {(double)x, (double)y, d, 1.0};
+  double hom[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) s += Q.q[i * 4 + j] * v[j];
+    hom[i] = s;
+  }
+  const double ialpha = 1. / hom[3];
+  float* o = xyz + ((size_t)y * W + x) * 3;
+  o[0] = (float)((double)(float)hom[0] * ialpha);
+  o[1] = (float)((double)(float)hom[1] * ialpha);
+  o[2] = fabs(d - minDisparity) <= 1.192092896e-07 ? 10000.f : (float)((double)(float)hom[2] * ialpha);
+}
+
+}  // namespace
+
+size_t dense_volume_elems(const DenseParams& P) { return (size_t)P.H * P.width1 * P.D; }
+
+void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st) {
+  const dim3 blk(256);
+  dense_prefilter_kernel<<<dim3((P.W + 255) / 256, P.H, 2 * n), blk, 0, st>>>(P, B.left, B.right, B.rec);
+  dense_bt_cost_kernel<<<dim3((P.width1 + BT_XPB - 1) / BT_XPB, P.H, n), blk, 0, st>>>(P, B.rec, B.vol[0]);
+  dense_hsum_kernel<<<dim3((P.width1 + 4 * HS_CHUNK - 1) / (4 * HS_CHUNK), P.H, n), blk, 0, st>>>(P, B.vol[0],
+                                                                                                 B.vol[1]);
+  dense_vsum_kernel<<<dim3((P.width1 + 3) / 4, (P.H + VS_CHUNK - 1) / VS_CHUNK, n), blk, 0, st>>>(P, B.vol[1],
+                                                                                                 B.vol[2]);
+  const short* Cv = B.vol[2];
+  unsigned short* sA = (unsigned short*)B.vol[0];
+  unsigned short* sB = (unsigned short*)B.vol[1];
+  const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
+  // pass 1 of computeDisparitySGBM: previous pixel at (x-1,y), (x-1,y-1), (x,y-1), (x+1,y-1)
+  dense_aggregate_kernel<1, 0, true><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
+  dense_aggregate_kernel<1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  dense_aggregate_kernel<0, 1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
+  dense_aggregate_kernel<-1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  // pass 2: previous pixel at (x+1,y), (x-1,y+1), (x,y+1), (x+1,y+1)
+  dense_aggregate_kernel<-1, 0, true><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sB);
+  dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sB);
+  dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sB);
+  dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sB);
+  dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, sB, B.disp[0]);
+  const dim3 gpx((P.W + 255) / 256, P.H, n);
+  dense_median3_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.disp[0], B.disp[1]);
+  short* cur = B.disp[1];
+  short* other = B.disp[0];
+  if (P.speckle_win > 0) {
+    speckle_rows_kernel<<<dim3(P.H, n), blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_diff, cur, B.label,
+                                                      B.count);
+    speckle_merge_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_diff, cur, B.label);
+    speckle_count_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.label, B.count);
+    speckle_apply_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_win, B.label, B.count, cur);
+  }
+  if (P.median5) {
+    dense_median5_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, cur, other);
+    cur = other;
+  }
+  if (cur != B.disp[0])
+    (void)hipMemcpyAsync(B.disp[0], cur, sizeof(short) * (size_t)P.W * P.H * n, hipMemcpyDeviceToDevice, st);
+}
+
+void launch_reproject_to_3d(int W, int H, const float* disp, const ReprojectQ& Q, unsigned* minkey, float* xyz,
+                            hipStream_t st) {
+  (void)hipMemsetAsync(minkey, 0xff, sizeof(unsigned), st);
+  dense_min_kernel<<<dim3(64), dim3(256), 0, st>>>(W * H, disp, minkey);
+  dense_reproject_kernel<<<dim3((W + 255) / 256, H), dim3(256), 0, st>>>(W, H, disp, minkey, Q, xyz);
+}
+
+}  // namespace kvfe

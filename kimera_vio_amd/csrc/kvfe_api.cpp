@@ -123,6 +123,15 @@ struct kvfe_ctx {
   double prof_ms[ST_COUNT] = {};
   int prof_samples = 0;
   std::string last_error;
+  // dense stereo (allocated on first use, re-allocated when the volume geometry changes)
+  DenseBuffers dense;
+  std::vector<void*> dense_allocs;
+  float* dense_dispf = nullptr;   // reprojectImageTo3D input / output staging
+  float* dense_xyz = nullptr;
+  unsigned* dense_minkey = nullptr;
+  hipEvent_t dense_ev[2] = {};
+  double dense_ms = 0;            // kernel time of kvfe_dense_stereo_reconstruction calls (HIP events)
+  long long dense_pairs = 0;
   // stream groups: a context with batch >= 2*MIN_GROUP_STREAMS splits its streams into `groups`
   // child contexts (own HIP stream, own buffers, shared constant tables).  The children free-run;
   // the only coupling is the token below that staggers their phases so that the latency-bound
@@ -1077,6 +1086,9 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mono) hipEventDestroy(c->ev_mono);
   for (void* p : c->allocs) hipFree(p);
+  for (void* p : c->dense_allocs) hipFree(p);
+  for (int i = 0; i < 2; i++)
+    if (c->dense_ev[i]) hipEventDestroy(c->dense_ev[i]);
   for (void* p : c->host_allocs) hipHostFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -1675,6 +1687,192 @@ kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* 
     c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
     return KVFE_ERR_CAPACITY;
   }
+  return KVFE_OK;
+}
+
+// ---- dense stereo --------------------------------------------------------
+void kvfe_dense_stereo_params_default(kvfe_dense_stereo_params* p) {
+  if (!p) return;
+  // DenseStereoParams member initialisers, StereoMatchingParams.h:40-58
+  *p = kvfe_dense_stereo_params{};
+  p->use_sgbm = 1;
+  p->pre_filter_cap = 31;
+  p->sad_window_size = 11;
+  p->min_disparity = 1;
+  p->num_disparities = 64;
+  p->uniqueness_ratio = 0;
+  p->speckle_range = 3;
+  p->speckle_window_size = 500;
+  p->texture_threshold = 0;
+  p->pre_filter_type = 1;   // cv::StereoBM::PREFILTER_XSOBEL
+  p->pre_filter_size = 9;
+  p->p1 = 120;
+  p->p2 = 240;
+  p->disp_12_max_diff = -1;
+  p->use_mode_hh = 1;
+}
+
+// cv::StereoSGBM's own defaulting of its parameters (stereosgbm.cpp computeDisparitySGBM prologue)
+static kvfe_status dense_params(kvfe_ctx* c, const kvfe_dense_stereo_params& dp, DenseParams* out) {
+  auto unsupported = [&](const char* why) {
+    c->last_error = std::string("dense stereo: ") + why;
+    return KVFE_ERR_UNSUPPORTED;
+  };
+  if (!dp.use_sgbm) return unsupported("use_sgbm = 0 (cv::StereoBM) is not implemented on the device");
+  if (!dp.use_mode_hh) return unsupported("use_mode_HH = 0 (cv::StereoSGBM::MODE_SGBM) is not implemented on the device");
+  if (dp.num_disparities <= 0 || dp.num_disparities % 16 != 0) return KVFE_ERR_INVALID_ARG;
+  if (dp.num_disparities > 64) return unsupported("num_disparities > 64");
+  DenseParams P{};
+  P.W = c->P.W;
+  P.H = c->P.H;
+  if (P.W > 2048) return unsupported("image width > 2048");
+  P.minD = dp.min_disparity;
+  P.D = dp.num_disparities;
+  const int maxD = P.minD + P.D;
+  P.minX1 = std::max(maxD, 0);
+  const int maxX1 = P.W + std::min(P.minD, 0);
+  P.width1 = maxX1 - P.minX1;
+  if (P.minD < 0) return unsupported("min_disparity < 0");
+  const int bs = dp.sad_window_size > 0 ? dp.sad_window_size : 5;
+  P.SW2 = bs / 2;
+  P.ftzero = std::max(dp.pre_filter_cap, 15) | 1;
+  P.uniq = dp.uniqueness_ratio >= 0 ? dp.uniqueness_ratio : 10;
+  P.disp12 = dp.disp_12_max_diff > 0 ? dp.disp_12_max_diff : 1;
+  P.P1 = dp.p1 > 0 ? dp.p1 : 2;
+  P.P2 = std::max(dp.p2 > 0 ? dp.p2 : 5, P.P1 + 1);
+  P.invalid_scaled = (P.minD - 1) * 16;
+  P.speckle_win = dp.speckle_window_size;
+  P.speckle_diff = 16 * dp.speckle_range;
+  P.median5 = dp.median_blur_disparity ? 1 : 0;
+  // 16-bit cost arithmetic: one path cost <= window * (2*ftzero + 63) + 2*P2, four of them per u16 sum
+  const long long win = (long long)(2 * P.SW2 + 1) * (2 * P.SW2 + 1);
+  if (win * (2 * P.ftzero + 63) + 2LL * P.P2 > 16383)
+    return unsupported("sad_window_size / p2 leave the 16-bit cost range (OpenCV's CostType is short)");
+  *out = P;
+  return KVFE_OK;
+}
+
+static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
+  DenseBuffers& b = c->dense;
+  const size_t ve = P.width1 > 0 ? dense_volume_elems(P) : 1;
+  if (b.cap_pairs >= pairs && b.vol_elems == ve) return KVFE_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (void* p : c->dense_allocs) hipFree(p);
+  c->dense_allocs.clear();
+  b = DenseBuffers{};
+  auto al = [&](void** p, size_t bytes) -> kvfe_status {
+    HIPCHK(c, hipMalloc(p, std::max<size_t>(bytes, 16)));
+    c->dense_allocs.push_back(*p);
+    return KVFE_OK;
+  };
+  const size_t px = (size_t)P.W * P.H;
+  TRY(al((void**)&b.left, px * pairs));
+  TRY(al((void**)&b.right, px * pairs));
+  TRY(al((void**)&b.rec, sizeof(uint2) * px * 2 * pairs));
+  for (int i = 0; i < 3; i++) TRY(al((void**)&b.vol[i], sizeof(short) * ve * pairs));
+  for (int i = 0; i < 2; i++) TRY(al((void**)&b.disp[i], sizeof(short) * px * pairs));
+  TRY(al((void**)&b.label, sizeof(int) * px * pairs));
+  TRY(al((void**)&b.count, sizeof(int) * px * pairs));
+  TRY(al((void**)&c->dense_dispf, sizeof(float) * px));
+  TRY(al((void**)&c->dense_xyz, sizeof(float) * 3 * px));
+  TRY(al((void**)&c->dense_minkey, 16));
+  b.cap_pairs = pairs;
+  b.vol_elems = ve;
+  for (int i = 0; i < 2; i++)
+    if (!c->dense_ev[i]) HIPCHK(c, hipEventCreate(&c->dense_ev[i]));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stereo_params* params,
+                                             int32_t n_pairs, const uint8_t* const* left_rect,
+                                             const uint8_t* const* right_rect, size_t stride,
+                                             int16_t* const* disparity, size_t dstride) {
+  if (!c || !params || n_pairs < 0 || (n_pairs > 0 && (!left_rect || !right_rect || !disparity)))
+    return KVFE_ERR_INVALID_ARG;
+  DenseParams P;
+  TRY(dense_params(c, *params, &P));
+  if (stride < (size_t)P.W || dstride < (size_t)P.W) return KVFE_ERR_INVALID_ARG;
+  for (int i = 0; i < n_pairs; i++)
+    if (!left_rect[i] || !right_rect[i] || !disparity[i]) return KVFE_ERR_INVALID_ARG;
+  if (n_pairs == 0) return KVFE_OK;
+  if (P.width1 <= 0) {   // computeDisparitySGBM: minX1 >= maxX1 -> all INVALID_DISP_SCALED (the 3x3 median and
+                         // the speckle filter leave a constant image unchanged)
+    for (int i = 0; i < n_pairs; i++)
+      for (int y = 0; y < P.H; y++)
+        for (int x = 0; x < P.W; x++) disparity[i][(size_t)y * dstride + x] = (int16_t)P.invalid_scaled;
+    return KVFE_OK;
+  }
+  static const int env_chunk = [] {
+    const char* e = getenv("KVFE_DENSE_BATCH");
+    return e ? std::max(1, atoi(e)) : 8;
+  }();
+  const int chunk = std::min<int>(env_chunk, n_pairs);
+  TRY(dense_ensure(c, P, chunk));
+  DenseBuffers& b = c->dense;
+  const size_t px = (size_t)P.W * P.H;
+  for (int i0 = 0; i0 < n_pairs; i0 += chunk) {
+    const int n = std::min(chunk, n_pairs - i0);
+    for (int i = 0; i < n; i++) {
+      HIPCHK(c, hipMemcpy2DAsync(b.left + px * i, P.W, left_rect[i0 + i], stride, P.W, P.H, hipMemcpyHostToDevice,
+                                 c->stream));
+      HIPCHK(c, hipMemcpy2DAsync(b.right + px * i, P.W, right_rect[i0 + i], stride, P.W, P.H,
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->dense_ev[0], c->stream));
+    launch_dense_sgbm(P, b, n, c->stream);
+    HIPCHK(c, hipEventRecord(c->dense_ev[1], c->stream));
+    HIPCHK(c, hipGetLastError());
+    for (int i = 0; i < n; i++)
+      HIPCHK(c, hipMemcpy2DAsync(disparity[i0 + i], dstride * sizeof(int16_t), b.disp[0] + px * i,
+                                 P.W * sizeof(int16_t), P.W * sizeof(int16_t), P.H, hipMemcpyDeviceToHost,
+                                 c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->dense_ev[0], c->dense_ev[1]) == hipSuccess) {
+      c->dense_ms += ms;
+      c->dense_pairs += n;
+    }
+  }
+  return KVFE_OK;
+}
+
+// debug / test hook: the cost volumes of the FIRST pair of the last kvfe_dense_stereo_reconstruction
+// call, [H][width1][D] int16: which = 0 summed path costs of pass 1, 1 of pass 2 (u16), 2 = C(p,d)
+kvfe_status kvfe_dense_debug_volume(kvfe_ctx* c, int32_t which, int16_t* out, size_t elems) {
+  if (!c || !out || which < 0 || which > 2 || !c->dense.vol[which] || elems > c->dense.vol_elems)
+    return KVFE_ERR_INVALID_ARG;
+  HIPCHK(c, hipMemcpy(out, c->dense.vol[which], elems * sizeof(int16_t), hipMemcpyDeviceToHost));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_dense_profile_read(kvfe_ctx* c, double* kernel_ms, int64_t* pairs) {
+  if (!c) return KVFE_ERR_INVALID_ARG;
+  if (kernel_ms) *kernel_ms = c->dense_ms;
+  if (pairs) *pairs = c->dense_pairs;
+  c->dense_ms = 0;
+  c->dense_pairs = 0;
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_backproject_disparity_to_3d(kvfe_ctx* c, const float* disparity, size_t stride, float* xyz) {
+  if (!c || !disparity || !xyz || stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
+  // StereoCamera::backProjectDisparityTo3D CHECKs Q(3,2) != 0 and Q(3,3) == 0 (StereoCamera.cpp:188-190)
+  if (c->rect.Q[14] == 0.0 || c->rect.Q[15] != 0.0) return KVFE_ERR_INVALID_ARG;
+  DenseParams P{};
+  P.W = c->P.W;
+  P.H = c->P.H;
+  P.D = 16;
+  P.width1 = 1;
+  if (!c->dense_dispf) TRY(dense_ensure(c, P, 1));
+  ReprojectQ Q;
+  for (int i = 0; i < 16; i++) Q.q[i] = c->rect.Q[i];
+  HIPCHK(c, hipMemcpy2DAsync(c->dense_dispf, P.W * sizeof(float), disparity, stride * sizeof(float),
+                             P.W * sizeof(float), P.H, hipMemcpyHostToDevice, c->stream));
+  launch_reproject_to_3d(P.W, P.H, c->dense_dispf, Q, c->dense_minkey, c->dense_xyz, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(xyz, c->dense_xyz, sizeof(float) * 3 * (size_t)P.W * P.H, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return KVFE_OK;
 }
 

@@ -50,6 +50,35 @@ struct KParams {
   int pyr_stride;  // bytes per stream in a pyramid buffer
 };
 
+// dense stereo (k_dense.hip): cv::StereoSGBM MODE_HH parameters after OpenCV's own defaulting
+struct DenseParams {
+  int W, H;
+  int minD, D;           // minDisparity, numDisparities (<= 64: one wave lane per disparity)
+  int minX1, width1;     // first matchable column, number of matchable columns
+  int SW2;               // blockSize / 2
+  int P1, P2, ftzero, uniq, disp12;
+  int invalid_scaled;    // (minDisparity - 1) * 16
+  int speckle_win, speckle_diff;   // filterSpeckles maxSpeckleSize, maxDiff (16 * speckleRange)
+  int median5;           // DenseStereoParams::median_blur_disparity_
+};
+struct DenseBuffers {
+  uint8_t *left = nullptr, *right = nullptr;   // [n][H][W] rectified images
+  uint2* rec = nullptr;                        // [2n][H][W] Birchfield-Tomasi pixel records
+  short* vol[3] = {};                          // [n][H][width1][D]
+  short* disp[2] = {};                         // [n][H][W]
+  int *label = nullptr, *count = nullptr;      // [n][H][W]
+  int cap_pairs = 0;
+  size_t vol_elems = 0;                        // elements per pair in vol[]
+};
+struct ReprojectQ {
+  double q[16];
+};
+size_t dense_volume_elems(const DenseParams& P);
+// inputs in B.left / B.right, result in B.disp[0]
+void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st);
+void launch_reproject_to_3d(int W, int H, const float* disp, const ReprojectQ& Q, unsigned* minkey, float* xyz,
+                            hipStream_t st);
+
 // undistortPoints constants (double) for one (K, D, RR) combination
 struct UndistortDev {
   double fx, fy, cx, cy, ifx, ify;

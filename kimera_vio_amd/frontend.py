@@ -110,6 +110,42 @@ class Context:
                   "equalize_hist")
         return out
 
+    # ---- StereoMatcher::denseStereoReconstruction / StereoCamera::backProjectDisparityTo3D ---------
+    def dense_stereo_reconstruction(self, left_rect, right_rect, params: abi.DenseStereoParams = None):
+        """StereoMatcher::denseStereoReconstruction (StereoMatcher.cpp:32-121) on one rectified pair or
+        a list of pairs -> int16 disparity (x16; (min_disparity - 1) * 16 where invalid), same shape"""
+        single = not isinstance(left_rect, (list, tuple))
+        lefts = [_img(a) for a in ([left_rect] if single else left_rect)]
+        rights = [_img(a) for a in ([right_rect] if single else right_rect)]
+        dp = params if params is not None else abi.dense_stereo_params_default()
+        n = len(lefts)
+        outs = [np.empty(a.shape, np.int16) for a in lefts]
+        lp = (C.c_void_p * n)(*[a.ctypes.data for a in lefts])
+        rp = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
+        op = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+        w = lefts[0].shape[1]
+        self._chk(self.lib.kvfe_dense_stereo_reconstruction(self._h, C.byref(dp), n, lp, rp, w, op, w),
+                  "dense_stereo_reconstruction")
+        return outs[0] if single else outs
+
+    def dense_debug_volume(self, which: int, shape) -> np.ndarray:
+        out = np.empty(shape, np.int16)
+        self._chk(self.lib.kvfe_dense_debug_volume(self._h, which, _p(out), out.size), "dense_debug_volume")
+        return out
+
+    def dense_profile_read(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._chk(self.lib.kvfe_dense_profile_read(self._h, C.byref(ms), C.byref(n)), "dense_profile_read")
+        return ms.value, n.value
+
+    def backproject_disparity_to_3d(self, disparity_f32) -> np.ndarray:
+        """StereoCamera::backProjectDisparityTo3D: float disparity (int16 / 16) -> [h, w, 3] float32"""
+        d = np.ascontiguousarray(disparity_f32, np.float32)
+        out = np.empty(d.shape + (3,), np.float32)
+        self._chk(self.lib.kvfe_backproject_disparity_to_3d(self._h, _p(d), d.shape[1], _p(out)),
+                  "backproject_disparity_to_3d")
+        return out
+
     # ---- FeatureDetector -----------------------------------------------------------------------
     def raw_feature_detection(self, img, mask=None) -> np.ndarray:
         img = _img(img)

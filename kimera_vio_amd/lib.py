@@ -72,6 +72,13 @@ def load() -> C.CDLL:
     L.kvfe_outlier_rejection_3d3d_given_rotation.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
                                                              C.POINTER(abi.RansacOutput)]
     L.kvfe_equalize_hist.argtypes = [vp, vp, sz, vp, sz]
+    L.kvfe_dense_stereo_params_default.argtypes = [C.POINTER(abi.DenseStereoParams)]
+    L.kvfe_dense_stereo_params_default.restype = None
+    L.kvfe_dense_stereo_reconstruction.argtypes = [vp, C.POINTER(abi.DenseStereoParams), i32, vp, vp, sz,
+                                                   vp, sz]
+    L.kvfe_dense_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.kvfe_backproject_disparity_to_3d.argtypes = [vp, vp, sz, vp]
+    L.kvfe_dense_debug_volume.argtypes = [vp, i32, vp, sz]
     L.kvfe_frontend_staging_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.kvfe_frontend_staging_wait.argtypes = [vp, i32]
     L.kvfe_frontend_step_staged.argtypes = [vp, i32, vp]
@@ -95,7 +102,8 @@ def load() -> C.CDLL:
                "kvfe_frontend_staging_buffer", "kvfe_frontend_staging_wait", "kvfe_frontend_step_staged",
                "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
                "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
-               "kvfe_profile_read"):
+               "kvfe_profile_read", "kvfe_dense_stereo_reconstruction", "kvfe_dense_profile_read",
+               "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume"):
         getattr(L, fn).restype = C.c_int32
     _lib = L
     return L
@@ -113,5 +121,6 @@ EXPORTED_SYMBOLS = [
     "kvfe_frontend_staging_wait", "kvfe_frontend_step_staged", "kvfe_frontend_step_host",
     "kvfe_frontend_step_device",
     "kvfe_frontend_reset", "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
-    "kvfe_profile_read",
+    "kvfe_profile_read", "kvfe_dense_stereo_params_default", "kvfe_dense_stereo_reconstruction",
+    "kvfe_dense_profile_read", "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume",
 ]

@@ -121,6 +121,48 @@ KVO_API int kvo_calc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* nex
                                    use_initial_flow != 0, minEigThreshold);
 }
 
+// ---- dense stereo (parity unpinned) --------------------------------------------
+namespace ocv { extern short* g_sgbm_debug_C; extern short* g_sgbm_debug_S; }
+// params: minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap,
+// uniquenessRatio, speckleWindowSize, speckleRange, mode (0 SGBM, 1 HH)
+KVO_API void kvo_stereo_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                             const int* params, short* disp, short* debug_C, short* debug_S) {
+  ocv::StereoSGBMParams p{params[0], params[1], params[2], params[3], params[4], params[5],
+                          params[6], params[7], params[8], params[9], params[10]};
+  ocv::g_sgbm_debug_C = debug_C;
+  ocv::g_sgbm_debug_S = debug_S;
+  ocv::stereoSGBM_compute(left, right, w, h, stride, p, disp, w);
+  ocv::g_sgbm_debug_C = ocv::g_sgbm_debug_S = nullptr;
+}
+// params: preFilterCap, blockSize, minDisparity, numDisparities, textureThreshold, uniquenessRatio,
+// speckleRange, speckleWindowSize, roi1[4], roi2[4]
+KVO_API void kvo_stereo_bm(const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                           const int* params, short* disp) {
+  ocv::StereoBMParams p;
+  p.preFilterCap = params[0]; p.blockSize = params[1]; p.minDisparity = params[2];
+  p.numDisparities = params[3]; p.textureThreshold = params[4]; p.uniquenessRatio = params[5];
+  p.speckleRange = params[6]; p.speckleWindowSize = params[7];
+  for (int i = 0; i < 4; i++) { p.roi1[i] = params[8 + i]; p.roi2[i] = params[12 + i]; }
+  ocv::stereoBM_compute(left, right, w, h, stride, p, disp, w);
+}
+KVO_API void kvo_median_blur_16s(const short* src, int w, int h, short* dst, int ksize) {
+  ocv::medianBlur16s(src, w, h, w, dst, w, ksize);
+}
+KVO_API void kvo_filter_speckles_16s(short* img, int w, int h, int newVal, int maxSpeckleSize, int maxDiff) {
+  ocv::filterSpeckles16s(img, w, h, w, newVal, maxSpeckleSize, maxDiff);
+}
+KVO_API void kvo_reproject_image_to_3d(const float* disparity, int w, int h, const double* Q,
+                                       int handle_missing, float* xyz) {
+  ocv::reprojectImageTo3D(disparity, w, h, w, Q, handle_missing != 0, xyz);
+}
+// StereoMatcher::denseStereoReconstruction (StereoMatcher.cpp:32-121) on rectified images
+KVO_API void kvo_dense_stereo_reconstruction(const kvfe_dense_stereo_params* dp, const int* roi1,
+                                             const int* roi2, const uint8_t* left_rect,
+                                             const uint8_t* right_rect, int w, int h, size_t stride,
+                                             short* disp) {
+  kimera::denseStereoReconstruction(*dp, roi1, roi2, left_rect, right_rect, w, h, stride, disp);
+}
+
 // ---- reference-owned logic ---------------------------------------------------
 KVO_API void kvo_sortidx_permutation(int n, int policy, int* idx) {
   std::vector<int> v;

@@ -951,4 +951,34 @@ void Frontend::processMono(const kvfe_frame_input& in) {
   ++frame_count;
 }
 
+// StereoMatcher::denseStereoReconstruction (StereoMatcher.cpp:32-121)
+void denseStereoReconstruction(const kvfe_dense_stereo_params& dp, const int roi1[4], const int roi2[4],
+                               const uint8_t* left_rect, const uint8_t* right_rect, int w, int h,
+                               size_t stride, short* disp) {
+  if (dp.use_sgbm) {   // :47-65
+    ocv::StereoSGBMParams p{dp.min_disparity, dp.num_disparities, dp.sad_window_size, dp.p1, dp.p2,
+                            dp.disp_12_max_diff, dp.pre_filter_cap, dp.uniqueness_ratio,
+                            dp.speckle_window_size, dp.speckle_range,
+                            dp.use_mode_hh ? ocv::STEREO_SGBM_MODE_HH : ocv::STEREO_SGBM_MODE_SGBM};
+    ocv::stereoSGBM_compute(left_rect, right_rect, w, h, stride, p, disp, w);
+  } else {             // :66-90 (cv::StereoBM::create(numDisparities, blockSize) + setters)
+    ocv::StereoBMParams p;
+    p.preFilterCap = dp.pre_filter_cap;
+    p.blockSize = dp.sad_window_size;
+    p.minDisparity = dp.min_disparity;
+    p.numDisparities = dp.num_disparities;
+    p.textureThreshold = dp.texture_threshold;
+    p.uniquenessRatio = dp.uniqueness_ratio;
+    p.speckleRange = dp.speckle_range;
+    p.speckleWindowSize = dp.speckle_window_size;
+    const bool have = roi1 && roi2 && roi1[2] > 0 && roi1[3] > 0 && roi2[2] > 0 && roi2[3] > 0;   // :81-86
+    for (int i = 0; i < 4; i++) {
+      p.roi1[i] = have ? roi1[i] : 0;
+      p.roi2[i] = have ? roi2[i] : 0;
+    }
+    ocv::stereoBM_compute(left_rect, right_rect, w, h, stride, p, disp, w);
+  }
+  if (dp.median_blur_disparity) ocv::medianBlur16s(disp, w, h, w, disp, w, 5);   // :104-107
+}
+
 }  // namespace kimera

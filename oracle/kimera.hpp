@@ -162,6 +162,12 @@ void sparseStereoReconstruction(const StereoCamera& cam, const kvfe_stereo_param
 // VisionImuFrontend::shouldBeKeyframe (VisionImuFrontend.cpp:175-232) +
 // Tracker::featureTracking (Tracker.cpp:92-211) +
 // FeatureDetector::featureDetection(Frame*, R) (FeatureDetector.cpp:94-163).
+// StereoMatcher::denseStereoReconstruction (StereoMatcher.cpp:32-121) on rectified images; roi1/roi2:
+// StereoCamera::getROI1/2 (x, y, w, h), used by the StereoBM branch only.  disp: CV_16S, stride w.
+void denseStereoReconstruction(const kvfe_dense_stereo_params& dp, const int roi1[4], const int roi2[4],
+                               const uint8_t* left_rect, const uint8_t* right_rect, int w, int h,
+                               size_t stride, short* disp);
+
 struct Frontend {
   StereoCamera cam;
   kvfe_frontend_params p;

@@ -151,6 +151,30 @@ void matchTemplateSqdiff(const uint8_t* img, int iw, int ih, size_t istride,
                          const uint8_t* templ, int tw, int th, size_t tstride,
                          std::vector<int64_t>& result);
 
+// ---- calib3d: dense stereo (ocv_stereo.cpp) -----------------------------------
+// Reference: StereoMatcher.cpp:32-121 (DenseStereoParams, StereoMatchingParams.h:39-58).  PARITY
+// UNPINNED (no numeric test in the reference).
+enum { STEREO_SGBM_MODE_SGBM = 0, STEREO_SGBM_MODE_HH = 1 };
+struct StereoSGBMParams {
+  int minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+      speckleWindowSize, speckleRange, mode;
+};
+struct StereoBMParams {   // PREFILTER_XSOBEL, CV_16S output, disp12MaxDiff < 0
+  int preFilterCap, blockSize, minDisparity, numDisparities, textureThreshold, uniquenessRatio,
+      speckleRange, speckleWindowSize;
+  int roi1[4], roi2[4];   // x, y, width, height (all zero: whole image)
+};
+// cv::StereoSGBM::compute -> CV_16S disparity with 4 fractional bits ((minDisparity-1)*16 = invalid)
+void stereoSGBM_compute(const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                        const StereoSGBMParams& p, short* disp, size_t dstride);
+// cv::StereoBM::compute -> CV_16S
+void stereoBM_compute(const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                      const StereoBMParams& p, short* disp, size_t dstride);
+void medianBlur16s(const short* src, int w, int h, size_t sstride, short* dst, size_t dstride, int ksize);
+void filterSpeckles16s(short* img, int w, int h, size_t step, int newVal, int maxSpeckleSize, int maxDiff);
+void reprojectImageTo3D(const float* disparity, int w, int h, size_t dstride, const double Q[16],
+                        bool handleMissingValues, float* xyz);
+
 // ---- video ------------------------------------------------------------------
 // cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err,
 // Size(win,win), maxLevel, TermCriteria(COUNT+EPS, maxIter, eps),

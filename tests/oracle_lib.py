@@ -134,6 +134,77 @@ def _img(a) -> np.ndarray:
     return a
 
 
+# --------------------------------------------------------------------------- dense stereo
+def _sgbm_params(dp: abi.DenseStereoParams):
+    return np.array([dp.min_disparity, dp.num_disparities, dp.sad_window_size, dp.p1, dp.p2,
+                     dp.disp_12_max_diff, dp.pre_filter_cap, dp.uniqueness_ratio,
+                     dp.speckle_window_size, dp.speckle_range, 1 if dp.use_mode_hh else 0], np.int32)
+
+
+def stereo_sgbm(left, right, dp: abi.DenseStereoParams, debug=False):
+    """cv::StereoSGBM::compute -> int16 disparity (x16); debug=True also returns (C, S) volumes of
+    computeDisparitySGBM [h, width1, D] (MODE_HH only)"""
+    left, right = _img(left), _img(right)
+    h, w = left.shape
+    disp = np.empty((h, w), np.int16)
+    Cv = Sv = None
+    if debug:
+        maxD = dp.min_disparity + dp.num_disparities
+        w1 = (w + min(dp.min_disparity, 0)) - max(maxD, 0)
+        Cv = np.zeros((h, w1, dp.num_disparities), np.int16)
+        Sv = np.zeros_like(Cv)
+    pr = _sgbm_params(dp)
+    lib().kvo_stereo_sgbm(_p(left), _p(right), w, h, C.c_size_t(w), _p(pr), _p(disp),
+                          _p(Cv) if debug else None, _p(Sv) if debug else None)
+    return (disp, Cv, Sv) if debug else disp
+
+
+def stereo_bm(left, right, dp: abi.DenseStereoParams, roi1=(0, 0, 0, 0), roi2=(0, 0, 0, 0)):
+    left, right = _img(left), _img(right)
+    h, w = left.shape
+    disp = np.empty((h, w), np.int16)
+    pr = np.array([dp.pre_filter_cap, dp.sad_window_size, dp.min_disparity, dp.num_disparities,
+                   dp.texture_threshold, dp.uniqueness_ratio, dp.speckle_range,
+                   dp.speckle_window_size, *roi1, *roi2], np.int32)
+    lib().kvo_stereo_bm(_p(left), _p(right), w, h, C.c_size_t(w), _p(pr), _p(disp))
+    return disp
+
+
+def median_blur_16s(img, ksize):
+    img = np.ascontiguousarray(img, np.int16)
+    out = np.empty_like(img)
+    lib().kvo_median_blur_16s(_p(img), img.shape[1], img.shape[0], _p(out), ksize)
+    return out
+
+
+def filter_speckles_16s(img, new_val, max_speckle_size, max_diff):
+    out = np.ascontiguousarray(img, np.int16).copy()
+    lib().kvo_filter_speckles_16s(_p(out), out.shape[1], out.shape[0], int(new_val),
+                                  int(max_speckle_size), int(max_diff))
+    return out
+
+
+def reproject_image_to_3d(disp_f32, Q, handle_missing=True):
+    d = np.ascontiguousarray(disp_f32, np.float32)
+    Q = np.ascontiguousarray(Q, np.float64).reshape(16)
+    out = np.empty(d.shape + (3,), np.float32)
+    lib().kvo_reproject_image_to_3d(_p(d), d.shape[1], d.shape[0], _p(Q), 1 if handle_missing else 0,
+                                    _p(out))
+    return out
+
+
+def dense_stereo_reconstruction(left_rect, right_rect, dp: abi.DenseStereoParams, roi1=None, roi2=None):
+    """StereoMatcher::denseStereoReconstruction on rectified images -> int16 disparity (x16)"""
+    left, right = _img(left_rect), _img(right_rect)
+    h, w = left.shape
+    disp = np.empty((h, w), np.int16)
+    r1 = np.array(roi1 if roi1 is not None else (0, 0, 0, 0), np.int32)
+    r2 = np.array(roi2 if roi2 is not None else (0, 0, 0, 0), np.int32)
+    lib().kvo_dense_stereo_reconstruction(C.byref(dp), _p(r1), _p(r2), _p(left), _p(right), w, h,
+                                          C.c_size_t(w), _p(disp))
+    return disp
+
+
 # --------------------------------------------------------------------------- imgproc
 def good_features_to_track(img, max_corners, quality, min_dist, block=3, mask=None):
     img = _img(img)

@@ -791,3 +791,102 @@ def test_fisheye_frontend_sequence(seq):
         assert (got["right_status"] == abi.KP_VALID).sum() > 20
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# dense stereo: cv::StereoSGBM MODE_HH + medianBlur + filterSpeckles
+# ---------------------------------------------------------------------------------------------
+def _dense_pairs(ctx, ocam, seq):
+    pairs = [(ocam.rectify_image(0, gray("left_img_0.png")), ocam.rectify_image(1, gray("right_img_0.png")))]
+    for i in (2, 6):
+        pairs.append((ocam.rectify_image(0, seq["lefts"][i]), ocam.rectify_image(1, seq["rights"][i])))
+    return pairs
+
+
+def test_dense_stereo_default_params_bit_exact(ctx, ocam, seq):
+    """StereoMatcher::denseStereoReconstruction with the reference's DenseStereoParams (SGBM MODE_HH,
+    block 11, 64 disparities from 1, P1/P2 120/240, speckle 500/3) on rectified EuRoC pairs: every
+    int16 disparity identical to the oracle; batched call == single calls."""
+    dp = abi.dense_stereo_params_default()
+    pairs = _dense_pairs(ctx, ocam, seq)
+    exp = [O.dense_stereo_reconstruction(l, r, dp) for l, r in pairs]
+    got = ctx.dense_stereo_reconstruction([p[0] for p in pairs], [p[1] for p in pairs], dp)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e), (np.count_nonzero(g != e), g.shape)
+    single = ctx.dense_stereo_reconstruction(pairs[1][0], pairs[1][1], dp)
+    assert np.array_equal(single, exp[1])
+    valid = exp[0] != (dp.min_disparity - 1) * 16
+    assert valid.mean() > 0.3        # the scene is matchable: not a trivially empty comparison
+    assert exp[0][valid].min() >= dp.min_disparity * 16
+    assert exp[0][valid].max() <= (dp.min_disparity + dp.num_disparities - 1) * 16
+
+
+@pytest.mark.parametrize("kw", [
+    dict(num_disparities=32, sad_window_size=5, p1=40, p2=160),
+    dict(num_disparities=48, min_disparity=0, sad_window_size=7, uniqueness_ratio=10),
+    dict(num_disparities=16, min_disparity=4, sad_window_size=3, disp_12_max_diff=2, speckle_window_size=0),
+    dict(sad_window_size=9, uniqueness_ratio=5, speckle_window_size=100, speckle_range=1,
+         median_blur_disparity=1, pre_filter_cap=63),
+])
+def test_dense_stereo_parameter_variants_bit_exact(ctx, ocam, seq, kw):
+    dp = abi.dense_stereo_params_default()
+    for k, v in kw.items():
+        setattr(dp, k, v)
+    l, r = _dense_pairs(ctx, ocam, seq)[0]
+    exp = O.dense_stereo_reconstruction(l, r, dp)
+    got = ctx.dense_stereo_reconstruction(l, r, dp)
+    assert np.array_equal(got, exp), (kw, np.count_nonzero(got != exp))
+
+
+def test_dense_stereo_synthetic_shift_and_noise(ctx):
+    """known disparity: right(x) = left(x + d) -> most valid pixels within 1 px of d, and bit-exact
+    against the oracle also on pure noise (worst case for ties / saturation of the summed costs)."""
+    dp = abi.dense_stereo_params_default()
+    h, w = 480, 752
+    tex = synth.base_texture(w, h, 5)
+    base = np.clip(np.rint(tex[96:96 + h, 40:40 + w + 64]), 0, 255).astype(np.uint8)
+    left = np.ascontiguousarray(base[:, :w])
+    d = 23
+    right = np.ascontiguousarray(base[:, d:d + w])
+    exp = O.dense_stereo_reconstruction(left, right, dp)
+    got = ctx.dense_stereo_reconstruction(left, right, dp)
+    assert np.array_equal(got, exp)
+    valid = got != (dp.min_disparity - 1) * 16
+    assert valid.mean() > 0.5
+    assert np.mean(np.abs(got[valid] / 16.0 - d) <= 1.0) > 0.95
+    rng = np.random.RandomState(3)
+    nl = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    nr = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    assert np.array_equal(ctx.dense_stereo_reconstruction(nl, nr, dp), O.dense_stereo_reconstruction(nl, nr, dp))
+    flat = np.full((h, w), 77, np.uint8)
+    assert np.array_equal(ctx.dense_stereo_reconstruction(flat, flat, dp),
+                          O.dense_stereo_reconstruction(flat, flat, dp))
+
+
+def test_dense_stereo_unsupported_configurations(ctx):
+    l = np.zeros((480, 752), np.uint8)
+    for kw in (dict(use_sgbm=0), dict(use_mode_hh=0), dict(num_disparities=128), dict(sad_window_size=21)):
+        dp = abi.dense_stereo_params_default()
+        for k, v in kw.items():
+            setattr(dp, k, v)
+        with pytest.raises(F.KvfeError) as e:
+            ctx.dense_stereo_reconstruction(l, l, dp)
+        assert e.value.status == abi.KVFE_ERR_UNSUPPORTED, kw
+
+
+def test_backproject_disparity_to_3d_bit_exact(ctx, ocam, seq):
+    """StereoCamera::backProjectDisparityTo3D == cv::reprojectImageTo3D(handleMissingValues=true)"""
+    dp = abi.dense_stereo_params_default()
+    l, r = _dense_pairs(ctx, ocam, seq)[0]
+    disp = ctx.dense_stereo_reconstruction(l, r, dp).astype(np.float32) / 16.0
+    Q = np.array(ctx.rect.Q, np.float64).reshape(4, 4)
+    exp = O.reproject_image_to_3d(disp, Q, True)
+    got = ctx.backproject_disparity_to_3d(disp)
+    assert np.array_equal(got, exp)
+    # tests/testStereoCamera.cpp:264-362: points reproject onto the pixels that generated them
+    valid = (disp > 0) & (got[..., 2] < 5.0)
+    fx, cx, cy = Q[2, 3], -Q[0, 3], -Q[1, 3]
+    v, u = np.nonzero(valid)
+    p = got[v, u]
+    assert np.allclose(fx * p[:, 0] / p[:, 2] + cx, u, atol=1e-2)
+    assert np.allclose(fx * p[:, 1] / p[:, 2] + cy, v, atol=1e-2)
