@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void dense_hsum_kernel(DenseParams P, const sh
   for (int i = -P.SW2; i <= P.SW2; i++) s += in[(size_t)min(max(x0 + i, 0), w1) * P.D];
   out[(size_t)x0 * P.D] = (short)s;
   const int xe = min(x0 + HS_CHUNK, P.width1);
+#pragma unroll 8
   for (int x = x0 + 1; x < xe; x++) {
     s += in[(size_t)min(x + P.SW2, w1) * P.D] - in[(size_t)max(x - P.SW2 - 1, 0) * P.D];
     out[(size_t)x * P.D] = (short)s;
@@ -150,23 +151,14 @@ __global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const sh
   short* out = Cv + (size_t)pair * P.H * rs + (size_t)x * P.D + lane;
   const int h1 = P.H - 1, SH2 = P.SW2;
   const int ye = min(y0 + VS_CHUNK, P.H);
+  // the clamped window sum slides for every row; rows OpenCV leaves at P2 just do not use it
   int s = 0;
-  bool have = false;
-  for (int y = y0; y < ye; y++) {
-    const bool plain = y > 0 && (x == 0 || y + SH2 >= P.H);
-    if (plain) {
-      out[(size_t)y * rs] = (short)P.P2;
-      have = false;
-      continue;
-    }
-    if (!have) {
-      s = 0;
-      for (int k = -SH2; k <= SH2; k++) s += in[(size_t)min(max(y + k, 0), h1) * rs];
-      have = true;
-    } else {
-      s += in[(size_t)min(y + SH2, h1) * rs] - in[(size_t)max(y - SH2 - 1, 0) * rs];
-    }
-    out[(size_t)y * rs] = (short)(P.P2 + s);
+  for (int k = -SH2; k <= SH2; k++) s += in[(size_t)min(max(y0 + k, 0), h1) * rs];
+  out[(size_t)y0 * rs] = (short)((y0 > 0 && (x == 0 || y0 + SH2 >= P.H)) ? P.P2 : P.P2 + s);
+#pragma unroll 8
+  for (int y = y0 + 1; y < ye; y++) {
+    s += in[(size_t)min(y + SH2, h1) * rs] - in[(size_t)max(y - SH2 - 1, 0) * rs];
+    out[(size_t)y * rs] = (short)((x == 0 || y + SH2 >= P.H) ? P.P2 : P.P2 + s);
   }
 }
 
@@ -174,6 +166,10 @@ __global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const sh
 // L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, min_k L_r(p-r,k)+P2) - (min_k L_r(p-r,k)+P2)
 // along one scan line; outside the volume L_r = 0 for every d (the zeroed borders of OpenCV's Lr / minLr
 // buffers), L_r(., -1) = L_r(., D) = SHRT_MAX.  SX,SY = direction of travel (p - r is the previous pixel).
+// The four path costs of a pass are added into one u16 volume with saturation at 65535.  OpenCV keeps
+// S = saturate_cast<short>(S + L0 + L1 + L2 + L3) per pass; every L_r >= 0 (C >= P2 and the min term is
+// >= min_k L_r - delta = -P2), so saturate(saturate(A) + B) == min(32767, A + B) and the order in which the
+// eight directions are accumulated does not matter.
 template <int SX, int SY, bool FIRST>
 __global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, const short* __restrict__ Cv,
                                                               unsigned short* __restrict__ sum) {
@@ -205,7 +201,9 @@ __global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, con
     len = min(nx, ny);
   }
   const bool act = lane < P.D;
-  const size_t base = (size_t)pair * H * W1 * P.D + ((size_t)y * W1 + x) * P.D + lane;
+  // lanes >= D load lane D-1's element (no divergent branch around the loads: a load under a lane
+  // predicate makes the compiler wait for it at the end of the branch, which serialises the prefetch)
+  const size_t base = (size_t)pair * H * W1 * P.D + ((size_t)y * W1 + x) * P.D + min(lane, P.D - 1);
   const long step = ((long)SY * W1 + SX) * P.D;
   const short* cp = Cv + base;
   unsigned short* sp = sum + base;
@@ -213,41 +211,41 @@ __global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, con
   int minp = 0;
   const int P1 = P.P1, P2 = P.P2;
   // software pipeline: the loads of the next pixels do not depend on the recurrence
-  constexpr int PF = 4;
+  constexpr int PF = 8;
   int cbuf[PF];
   int sbuf[PF];
+  const int last = len - 1;
 #pragma unroll
   for (int i = 0; i < PF; i++) {
-    cbuf[i] = (i < len && act) ? cp[(long)i * step] : 0;
-    if (!FIRST) sbuf[i] = (i < len && act) ? sp[(long)i * step] : 0;
+    cbuf[i] = cp[(long)min(i, last) * step];
+    if (!FIRST) sbuf[i] = sp[(long)min(i, last) * step];
   }
   for (int t0 = 0; t0 < len; t0 += PF) {
 #pragma unroll
     for (int i = 0; i < PF; i++) {
-      const int t = t0 + i;
-      if (t >= len) break;
+      const int t = min(t0 + i, last);   // the tail repeats the last pixel (same value stored again)
+      const bool live = t0 + i <= last;
       const int c = cbuf[i];
       const int sprev = FIRST ? 0 : sbuf[i];
-      const int tn = t + PF;
-      if (tn < len && act) {
-        cbuf[i] = cp[(long)tn * step];
-        if (!FIRST) sbuf[i] = sp[(long)tn * step];
-      }
+      const long tn = (long)min(t0 + i + PF, last) * step;
+      cbuf[i] = cp[tn];
+      if (!FIRST) sbuf[i] = sp[tn];
       const int delta = minp + P2;
       const int lm = dpp_wave_shr1(Lp, MAXC), lq = dpp_wave_shl1(Lp, MAXC);
       const int m = min(min(Lp, delta), min(lm, lq) + P1);
       const int L = c + m - delta;
-      Lp = act ? L : MAXC;
-      minp = wave_min(Lp);
-      if (act) sp[(long)t * step] = (unsigned short)(sprev + L);
+      if (live) {   // wave-uniform
+        Lp = act ? L : MAXC;
+        minp = wave_min(Lp);
+        if (act) sp[(long)t * step] = (unsigned short)min(sprev + L, 65535);
+      }
     }
   }
 }
 
 // ---- disparity selection (computeDisparitySGBM, pass == npasses block) ---------------------------------
 constexpr int SEL_MAXW = 2048;
-__global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const unsigned short* __restrict__ sumA,
-                                                           const unsigned short* __restrict__ sumB,
+__global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const unsigned short* __restrict__ sum,
                                                            short* __restrict__ disp) {
   __shared__ unsigned long long d2key[SEL_MAXW];
   __shared__ short d1[SEL_MAXW];
@@ -262,32 +260,47 @@ __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const 
   __syncthreads();
   const size_t row = (((size_t)pair * P.H + y) * W1) * D;
   const bool act = lane < D;
-  for (int x = W1 - 1 - wv; x >= 0; x -= 4) {
-    int S = 0x7fffffff;
-    if (act) {
-      const int a = sumA[row + (size_t)x * D + lane], b = sumB[row + (size_t)x * D + lane];
-      S = min(MAXC, min(MAXC, a) + b);   // saturate_cast<short> after each pass
-    }
-    const int minS = wave_min(S);
-    if (minS >= MAXC) continue;   // bestDisp = -1: the pixel keeps INVALID_DISP_SCALED
-    const unsigned long long eq = __ballot(act && S == minS);
-    const int best = __ffsll((long long)eq) - 1;
-    const int Sv = act ? S : MAXC;
-    const bool viol = act && (Sv * (100 - P.uniq) < minS * 100) && abs(best - lane) > 1;
-    if (__ballot(viol)) continue;
-    const int Sm = __shfl(S, max(best - 1, 0)), Sq = __shfl(S, min(best + 1, 63));
-    if (lane == 0) {
-      const int x2 = x + P.minX1 - best - P.minD;
-      // scanning x downwards, a strictly smaller cost replaces: lowest cost, then largest x
-      atomicMin(&d2key[x2], ((unsigned long long)minS << 32) | ((unsigned long long)(0xFFFF - x) << 16) |
-                                (unsigned long long)best);
-      int d;
-      if (0 < best && best < D - 1) {
-        const int denom2 = max(Sm + Sq - 2 * minS, 1);
-        d = best * DISP_SCALE + ((Sm - Sq) * DISP_SCALE + denom2) / (denom2 * 2);
-      } else
-        d = best * DISP_SCALE;
-      d1[x + P.minX1] = (short)(d + P.minD * DISP_SCALE);
+  const unsigned short* srow = sum + row + min(lane, D - 1);
+  constexpr int UN = 8;   // columns per batch; the next batch is loaded before this one is processed
+  int nxt[UN];
+  {
+    const int xb = W1 - 1 - wv * UN;
+#pragma unroll
+    for (int u = 0; u < UN; u++) nxt[u] = srow[(size_t)max(xb - u, 0) * D];
+  }
+  for (int xb = W1 - 1 - wv * UN; xb >= 0; xb -= 4 * UN) {
+    int Sv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) Sv[u] = nxt[u];
+    const int xn = xb - 4 * UN;
+#pragma unroll
+    for (int u = 0; u < UN; u++) nxt[u] = srow[(size_t)max(xn - u, 0) * D];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int x = xb - u;
+      if (x < 0) break;
+      const int S = act ? min(MAXC, Sv[u]) : 0x7fffffff;   // saturate_cast<short>
+      const int minS = wave_min(S);
+      if (minS >= MAXC) continue;   // bestDisp = -1: the pixel keeps INVALID_DISP_SCALED
+      const unsigned long long eq = __ballot(act && S == minS);
+      const int best = __ffsll((long long)eq) - 1;
+      const int Sc = act ? S : MAXC;
+      const bool viol = act && (Sc * (100 - P.uniq) < minS * 100) && abs(best - lane) > 1;
+      if (__ballot(viol)) continue;
+      const int Sm = __shfl(S, max(best - 1, 0)), Sq = __shfl(S, min(best + 1, 63));
+      if (lane == 0) {
+        const int x2 = x + P.minX1 - best - P.minD;
+        // scanning x downwards, a strictly smaller cost replaces: lowest cost, then largest x
+        atomicMin(&d2key[x2], ((unsigned long long)minS << 32) | ((unsigned long long)(0xFFFF - x) << 16) |
+                                  (unsigned long long)best);
+        int d;
+        if (0 < best && best < D - 1) {
+          const int denom2 = max(Sm + Sq - 2 * minS, 1);
+          d = best * DISP_SCALE + ((Sm - Sq) * DISP_SCALE + denom2) / (denom2 * 2);
+        } else
+          d = best * DISP_SCALE;
+        d1[x + P.minX1] = (short)(d + P.minD * DISP_SCALE);
+      }
     }
   }
   __syncthreads();
@@ -299,7 +312,9 @@ __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const 
       const int _x = x - _d, x_ = x - d_;
       auto disp2 = [&](int xx) {
         const unsigned long long k = d2key[xx];
-        return k == ~0ull ? P.minD - 1 : (int)(k & 0xFFFF) + P.minD;
+        // untouched entries hold INVALID_DISP_SCALED like OpenCV's disp2ptr (so for minDisparity >= 2
+        // they pass the ">= minD" test below, as they do upstream)
+        return k == ~0ull ? P.invalid_scaled : (int)(k & 0xFFFF) + P.minD;
       };
       bool bad = false;
       if (0 <= _x && _x < W && 0 <= x_ && x_ < W) {
@@ -366,8 +381,9 @@ __global__ __launch_bounds__(256) void dense_median5_kernel(int W, int H, const 
 // Step 1: block = row: every pixel gets the index of the first pixel of its horizontal run.
 __global__ __launch_bounds__(256) void speckle_rows_kernel(int W, int H, int newVal, int maxDiff,
                                                            const short* __restrict__ disp, int* __restrict__ label,
-                                                           int* __restrict__ count) {
+                                                           int* __restrict__ count, int* __restrict__ runlen) {
   __shared__ int start[SEL_MAXW];
+  __shared__ int rl[SEL_MAXW];
   __shared__ int wave_tot[4];
   const int y = blockIdx.x;
   const size_t img = (size_t)blockIdx.y * W * H;
@@ -394,12 +410,19 @@ __global__ __launch_bounds__(256) void speckle_rows_kernel(int W, int H, int new
   int pre = __shfl_up(inc, 1);
   if (lane == 0) pre = -1;
   for (int k = 0; k < wv; k++) pre = max(pre, wave_tot[k]);
-  for (int x = x0; x < x1; x++) start[x] = max(start[x], pre);
+  for (int x = x0; x < x1; x++) {
+    start[x] = max(start[x], pre);
+    rl[x] = 0;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < W; x += 256)
+    if (d[x] != newVal) atomicAdd(&rl[start[x]], 1);
   __syncthreads();
   for (int x = threadIdx.x; x < W; x += 256) {
     const size_t i = img + (size_t)y * W + x;
     label[i] = d[x] != newVal ? y * W + start[x] : -1;
     count[i] = 0;
+    runlen[i] = rl[x];   // pixels of the run, at its first pixel; 0 elsewhere
   }
 }
 __device__ __forceinline__ int cc_find(const int* L, int i) {
@@ -441,17 +464,16 @@ __global__ __launch_bounds__(256) void speckle_merge_kernel(int W, int H, int ne
   }
   cc_union(L, i, i + W);
 }
-__global__ __launch_bounds__(256) void speckle_count_kernel(int W, int H, int* __restrict__ label,
-                                                            int* __restrict__ count) {
+// Step 3: component sizes, one atomic per horizontal run
+__global__ __launch_bounds__(256) void speckle_count_kernel(int W, int H, const int* __restrict__ label,
+                                                            const int* __restrict__ runlen, int* __restrict__ count) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
   const size_t img = (size_t)blockIdx.z * W * H;
-  int* L = label + img;
   const int i = y * W + x;
-  if (L[i] < 0) return;
-  const int r = cc_find(L, i);
-  L[i] = r;
-  atomicAdd(&count[img + r], 1);
+  const int n = runlen[img + i];
+  if (n == 0) return;
+  atomicAdd(&count[img + cc_find(label + img, i)], n);
 }
 __global__ __launch_bounds__(256) void speckle_apply_kernel(int W, int H, int newVal, int maxSize,
                                                             const int* __restrict__ label, const int* __restrict__ count,
@@ -461,7 +483,7 @@ __global__ __launch_bounds__(256) void speckle_apply_kernel(int W, int H, int ne
   const size_t img = (size_t)blockIdx.z * W * H;
   const size_t i = img + (size_t)y * W + x;
   const int r = label[i];
-  if (r >= 0 && count[img + r] <= maxSize) disp[i] = (short)newVal;
+  if (r >= 0 && count[img + cc_find(label + img, r)] <= maxSize) disp[i] = (short)newVal;
 }
 
 // cv::reprojectImageTo3D(CV_32F -> CV_32FC3, handleMissingValues = true)
@@ -513,7 +535,6 @@ void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipSt
                                                                                                  B.vol[2]);
   const short* Cv = B.vol[2];
   unsigned short* sA = (unsigned short*)B.vol[0];
-  unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
   // pass 1 of computeDisparitySGBM: previous pixel at (x-1,y), (x-1,y-1), (x,y-1), (x+1,y-1)
   dense_aggregate_kernel<1, 0, true><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
@@ -521,20 +542,20 @@ void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipSt
   dense_aggregate_kernel<0, 1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
   dense_aggregate_kernel<-1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
   // pass 2: previous pixel at (x+1,y), (x-1,y+1), (x,y+1), (x+1,y+1)
-  dense_aggregate_kernel<-1, 0, true><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sB);
-  dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sB);
-  dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sB);
-  dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sB);
-  dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, sB, B.disp[0]);
+  dense_aggregate_kernel<-1, 0, false><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
+  dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
+  dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, B.disp[0]);
   const dim3 gpx((P.W + 255) / 256, P.H, n);
   dense_median3_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.disp[0], B.disp[1]);
   short* cur = B.disp[1];
   short* other = B.disp[0];
   if (P.speckle_win > 0) {
     speckle_rows_kernel<<<dim3(P.H, n), blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_diff, cur, B.label,
-                                                      B.count);
+                                                      B.count, B.runlen);
     speckle_merge_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_diff, cur, B.label);
-    speckle_count_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.label, B.count);
+    speckle_count_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.label, B.runlen, B.count);
     speckle_apply_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_win, B.label, B.count, cur);
   }
   if (P.median5) {

@@ -1773,6 +1773,7 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   for (int i = 0; i < 2; i++) TRY(al((void**)&b.disp[i], sizeof(short) * px * pairs));
   TRY(al((void**)&b.label, sizeof(int) * px * pairs));
   TRY(al((void**)&b.count, sizeof(int) * px * pairs));
+  TRY(al((void**)&b.runlen, sizeof(int) * px * pairs));
   TRY(al((void**)&c->dense_dispf, sizeof(float) * px));
   TRY(al((void**)&c->dense_xyz, sizeof(float) * 3 * px));
   TRY(al((void**)&c->dense_minkey, 16));
@@ -1837,7 +1838,7 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
 }
 
 // debug / test hook: the cost volumes of the FIRST pair of the last kvfe_dense_stereo_reconstruction
-// call, [H][width1][D] int16: which = 0 summed path costs of pass 1, 1 of pass 2 (u16), 2 = C(p,d)
+// call, [H][width1][D] int16: which = 0 sum of the eight path costs (u16, saturated at 65535), 2 = C(p,d)
 kvfe_status kvfe_dense_debug_volume(kvfe_ctx* c, int32_t which, int16_t* out, size_t elems) {
   if (!c || !out || which < 0 || which > 2 || !c->dense.vol[which] || elems > c->dense.vol_elems)
     return KVFE_ERR_INVALID_ARG;

@@ -66,7 +66,7 @@ struct DenseBuffers {
   uint2* rec = nullptr;                        // [2n][H][W] Birchfield-Tomasi pixel records
   short* vol[3] = {};                          // [n][H][width1][D]
   short* disp[2] = {};                         // [n][H][W]
-  int *label = nullptr, *count = nullptr;      // [n][H][W]
+  int *label = nullptr, *count = nullptr, *runlen = nullptr;   // [n][H][W]
   int cap_pairs = 0;
   size_t vol_elems = 0;                        // elements per pair in vol[]
 };

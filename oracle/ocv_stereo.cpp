@@ -593,8 +593,11 @@ void stereoBM_compute(const uint8_t* left0, const uint8_t* right0, int width, in
 
 // cv::reprojectImageTo3D(disparity CV_32F, _3dImage CV_32FC3, Q, handleMissingValues, CV_32F)
 // (calib3d/src/calibration.cpp).  Reference: StereoCamera.cpp:193-194.
-void reprojectImageTo3D(const float* disparity, int w, int h, size_t dstride, const double Q[16],
-                        bool handleMissingValues, float* xyz /* h*w*3 */) {
+// (optimize("O2"): g++ 11 -O3 drops the double -> float -> double round trip of the Vec3d -> Vec3f
+// conversion below when it vectorises the loop, which changes results by one float ulp)
+__attribute__((optimize("O2"))) void reprojectImageTo3D(const float* disparity, int w, int h, size_t dstride,
+                                                        const double Q[16], bool handleMissingValues,
+                                                        float* xyz /* h*w*3 */) {
   const float bigZ = 10000.f;
   double minDisparity = 3.402823466e+38;   // FLT_MAX
   if (handleMissingValues) {

@@ -13,7 +13,7 @@ def main():
                      "sgpr_count, scratch_size from kernels order by start").fetchall()
     agg = {}
     for name, s, e, gx, gy, gz, wx, lds, vg, sg, scr in rows:
-        short = name.split("(")[0].replace("void ", "").replace("kvfe::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("kvfe::", "")
         a = agg.setdefault(short, dict(n=0, tot=0, mn=1e18, mx=0, grid=(gx, gy, gz), wg=wx, lds=lds, vgpr=vg,
                                        sgpr=sg, scratch=scr))
         d = e - s
