@@ -245,10 +245,15 @@ __global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, con
 
 // ---- disparity selection (computeDisparitySGBM, pass == npasses block) ---------------------------------
 constexpr int SEL_MAXW = 2048;
+// Block = one image row.  Each wave takes tiles of 64 columns: it reads the tile with lane = disparity
+// (one 128-byte line per column), transposes it through LDS, and then works with lane = column, so that the
+// minimum search, the uniqueness test, the parabola fit and the integer division run on 64 pixels at once.
+constexpr int SEL_PITCH = 66;   // halfwords per disparity row of the transposed tile (bank-conflict padding)
 __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const unsigned short* __restrict__ sum,
                                                            short* __restrict__ disp) {
   __shared__ unsigned long long d2key[SEL_MAXW];
   __shared__ short d1[SEL_MAXW];
+  __shared__ unsigned short tile[4][64 * SEL_PITCH];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int y = blockIdx.x, pair = blockIdx.y;
   const int W = P.W, W1 = P.width1, D = P.D;
@@ -259,49 +264,54 @@ __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const 
   }
   __syncthreads();
   const size_t row = (((size_t)pair * P.H + y) * W1) * D;
-  const bool act = lane < D;
   const unsigned short* srow = sum + row + min(lane, D - 1);
-  constexpr int UN = 8;   // columns per batch; the next batch is loaded before this one is processed
-  int nxt[UN];
-  {
-    const int xb = W1 - 1 - wv * UN;
-#pragma unroll
-    for (int u = 0; u < UN; u++) nxt[u] = srow[(size_t)max(xb - u, 0) * D];
-  }
-  for (int xb = W1 - 1 - wv * UN; xb >= 0; xb -= 4 * UN) {
-    int Sv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; u++) Sv[u] = nxt[u];
-    const int xn = xb - 4 * UN;
-#pragma unroll
-    for (int u = 0; u < UN; u++) nxt[u] = srow[(size_t)max(xn - u, 0) * D];
-#pragma unroll
-    for (int u = 0; u < UN; u++) {
-      const int x = xb - u;
-      if (x < 0) break;
-      const int S = act ? min(MAXC, Sv[u]) : 0x7fffffff;   // saturate_cast<short>
-      const int minS = wave_min(S);
-      if (minS >= MAXC) continue;   // bestDisp = -1: the pixel keeps INVALID_DISP_SCALED
-      const unsigned long long eq = __ballot(act && S == minS);
-      const int best = __ffsll((long long)eq) - 1;
-      const int Sc = act ? S : MAXC;
-      const bool viol = act && (Sc * (100 - P.uniq) < minS * 100) && abs(best - lane) > 1;
-      if (__ballot(viol)) continue;
-      const int Sm = __shfl(S, max(best - 1, 0)), Sq = __shfl(S, min(best + 1, 63));
-      if (lane == 0) {
-        const int x2 = x + P.minX1 - best - P.minD;
-        // scanning x downwards, a strictly smaller cost replaces: lowest cost, then largest x
-        atomicMin(&d2key[x2], ((unsigned long long)minS << 32) | ((unsigned long long)(0xFFFF - x) << 16) |
-                                  (unsigned long long)best);
-        int d;
-        if (0 < best && best < D - 1) {
-          const int denom2 = max(Sm + Sq - 2 * minS, 1);
-          d = best * DISP_SCALE + ((Sm - Sq) * DISP_SCALE + denom2) / (denom2 * 2);
-        } else
-          d = best * DISP_SCALE;
-        d1[x + P.minX1] = (short)(d + P.minD * DISP_SCALE);
+  unsigned short* T = tile[wv];
+  const int ntiles = (W1 + 63) / 64;
+  for (int tl = wv; tl < ntiles; tl += 4) {
+    const int x0 = tl * 64;
+    // lane = disparity: column j of the tile -> T[lane][j]
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) {
+      const unsigned short v = srow[(size_t)min(x0 + j, W1 - 1) * D];
+      T[lane * SEL_PITCH + j] = v;
+    }
+    // (one wave owns the tile: the LDS writes above are complete before the reads below are issued in order)
+    __builtin_amdgcn_wave_barrier();
+    const int x = x0 + lane;
+    // lane = column
+    int minS = MAXC, best = -1;
+    for (int d = 0; d < D; d++) {
+      const int S = min(MAXC, (int)T[d * SEL_PITCH + lane]);   // saturate_cast<short>
+      if (S < minS) {
+        minS = S;
+        best = d;
       }
     }
+    bool ok = x < W1 && best >= 0;   // best = -1: every S saturated, the pixel keeps INVALID_DISP_SCALED
+    if (P.uniq > 0 || true) {
+      bool viol = false;
+      for (int d = 0; d < D; d++) {
+        const int S = min(MAXC, (int)T[d * SEL_PITCH + lane]);
+        viol |= (S * (100 - P.uniq) < minS * 100) && abs(best - d) > 1;
+      }
+      ok = ok && !viol;
+    }
+    if (ok) {
+      const int x2 = x + P.minX1 - best - P.minD;
+      // scanning x downwards, a strictly smaller cost replaces: lowest cost, then largest x
+      atomicMin(&d2key[x2], ((unsigned long long)minS << 32) | ((unsigned long long)(0xFFFF - x) << 16) |
+                                (unsigned long long)best);
+      int d;
+      if (0 < best && best < D - 1) {
+        const int Sm = min(MAXC, (int)T[(best - 1) * SEL_PITCH + lane]);
+        const int Sq = min(MAXC, (int)T[(best + 1) * SEL_PITCH + lane]);
+        const int denom2 = max(Sm + Sq - 2 * minS, 1);
+        d = best * DISP_SCALE + ((Sm - Sq) * DISP_SCALE + denom2) / (denom2 * 2);
+      } else
+        d = best * DISP_SCALE;
+      d1[x + P.minX1] = (short)(d + P.minD * DISP_SCALE);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   short* out = disp + ((size_t)pair * P.H + y) * W;
