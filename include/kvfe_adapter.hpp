@@ -125,6 +125,12 @@ class StereoCamera {
   const double* getP2() const { return rect_.P2; }
   const double* getQ() const { return rect_.Q; }
   const Context& context() const { return c_; }
+  // backProjectDisparityTo3D(disparity_img CV_32F, depth CV_32FC3) (StereoCamera.cpp:176-196):
+  // disparity: h x w float (CV_16S / 16), depth: h x w x 3 float
+  void backProjectDisparityTo3D(const float* disparity, size_t stride_elems, float* depth) const {
+    c_.check(kvfe_backproject_disparity_to_3d(c_.get(), disparity, stride_elems, depth),
+             "backProjectDisparityTo3D");
+  }
 
  private:
   Context c_;
@@ -276,6 +282,24 @@ class StereoMatcher {
     }
     return r;
   }
+  // denseStereoReconstruction(left_img_rectified, right_img_rectified, disparity_img)
+  // (StereoMatcher.cpp:32-121).  disparity: h x w int16 with 4 fractional bits — the CV_16S matrix
+  // cv::StereoSGBM::compute leaves in *disparity_img; dense_stereo_params_ defaults to the reference's
+  // member initialisers (StereoMatchingParams.h:39-58).
+  void denseStereoReconstruction(const ImageView& left_img_rectified, const ImageView& right_img_rectified,
+                                 int16_t* disparity, size_t disparity_stride_elems) const {
+    kvfe_dense_stereo_params p = dense_stereo_params_;
+    const uint8_t* l = left_img_rectified.data;
+    const uint8_t* r = right_img_rectified.data;
+    c_.check(kvfe_dense_stereo_reconstruction(c_.get(), &p, 1, &l, &r, left_img_rectified.step, &disparity,
+                                              disparity_stride_elems),
+             "denseStereoReconstruction");
+  }
+  kvfe_dense_stereo_params dense_stereo_params_ = [] {
+    kvfe_dense_stereo_params p;
+    kvfe_dense_stereo_params_default(&p);
+    return p;
+  }();
   // getRightKeypointsRectified (StereoMatcher.cpp:196-281) on already rectified images
   void getRightKeypointsRectified(const ImageView& left_rectified, const ImageView& right_rectified,
                                   const StatusKeypointsCV& left_keypoints_rectified,
