@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--stage-event-stride", type=int, default=4,
                     help="every N-th timed step records per-stage HIP events (roofline / stage breakdown)")
     ap.add_argument("--no-single-stream", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-stereo (SGBM) leg")
     return ap.parse_args()
 
 
@@ -278,6 +279,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_single_stream:
         result["single_stream"] = single_stream(F, P, synth, L, R, p, torch, dev, args)
+    if rank == 0 and world == 1 and not args.no_dense:
+        result["dense_stereo"] = dense_stereo(F, P, synth, L, R, p, dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(P, synth, L, R, p, args)
     if rank == 0:
@@ -318,6 +321,39 @@ def single_stream(F, P, synth, L, R, p, torch, dev, args):
     return {"workload": "single synthetic 752x480 stream, 300 features, 3-level LK, mode=kf",
             "value": round(steps / el, 2), "unit": "stereo-pairs/s", "ms_per_pair": round(1e3 * el / steps, 4),
             "keypoints": int(n)}
+
+
+def dense_stereo(F, P, synth, L, R, p, dev, args):
+    """SURVEY.md §8 a29 / BASELINE config[4] "dense stereo row": StereoMatcher::denseStereoReconstruction
+    (cv::StereoSGBM MODE_HH with the reference's DenseStereoParams) on 8 rectified pairs per call.
+    Time = HIP events around the kernel sequence inside libkvfe (the component call takes host
+    buffers; its H2D / D2H copies are outside the events)."""
+    from kimera_vio_amd import _abi as abi
+    ctx = F.Context(L, R, p, batch=1, device=dev.index)
+    n = 8
+    st = [synth.RigStream(L, R, seed=900 + i) for i in range(2)]
+    pairs = []
+    for i in range(n):
+        l, r = st[i % 2].frame(i // 2)
+        pairs.append((ctx.undistort_rectify_image(0, l), ctx.undistort_rectify_image(1, r)))
+    dp = abi.dense_stereo_params_default()
+    lefts, rights = [a for a, _ in pairs], [b for _, b in pairs]
+    ctx.dense_stereo_reconstruction(lefts, rights, dp)
+    ctx.dense_profile_read()
+    reps = 5
+    for _ in range(reps):
+        disp = ctx.dense_stereo_reconstruction(lefts, rights, dp)
+    ms, cnt = ctx.dense_profile_read()
+    ctx.close()
+    W, H, D = args.width, args.height, dp.num_disparities
+    w1 = W - (dp.min_disparity + D)
+    vol = H * w1 * D * 2.0                      # one int16 cost volume
+    agg_bytes = 8 * vol + vol + 7 * 2 * vol     # 8 reads of C, one sum write, seven sum read-modify-writes
+    valid = float(np.mean(disp[0] != (dp.min_disparity - 1) * 16))
+    return {"workload": f"cv::StereoSGBM MODE_HH, block {dp.sad_window_size}, {D} disparities, {W}x{H}, "
+                        f"{n} rectified pairs per call",
+            "value": round(cnt / (ms * 1e-3), 2), "unit": "stereo-pairs/s", "ms_per_pair": round(ms / cnt, 4),
+            "alg_bytes_per_pair_aggregation": round(agg_bytes), "valid_fraction_pair0": round(valid, 3)}
 
 
 def cpu_baseline(P, synth, L, R, p, args):

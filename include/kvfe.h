@@ -311,13 +311,14 @@ KVFE_API void kvfe_dense_stereo_params_default(kvfe_dense_stereo_params* p);
 
 /* StereoMatcher::denseStereoReconstruction(left_img_rectified, right_img_rectified, disparity_img)
  * (StereoMatcher.cpp:32-121), batched over n_pairs independent rectified pairs of the context's
- * image size: cv::StereoSGBM::compute (MODE_HH; BT pixel cost, 8-path aggregation, uniqueness,
- * sub-pixel fit, left-right check, 3x3 median, cv::filterSpeckles) and the optional 5x5 median.
+ * image size: cv::StereoSGBM::compute (MODE_HH, or MODE_SGBM with use_mode_hh = 0; BT pixel cost,
+ * 8- / 5-path aggregation, uniqueness, sub-pixel fit, left-right check, 3x3 median,
+ * cv::filterSpeckles) and the optional 5x5 median.
  * disparity: n_pairs images of int16 with 4 fractional bits, (min_disparity - 1) * 16 where
  * invalid — the CV_16S matrix cv::StereoSGBM::compute leaves in *disparity_img (compute()
  * re-creates the CV_32F matrix the caller passed as CV_16S; callers divide by 16:
  * tests/testStereoCamera.cpp:296-300).  KVFE_ERR_UNSUPPORTED: use_sgbm = 0 (cv::StereoBM),
- * use_mode_hh = 0 (MODE_SGBM), num_disparities > 64 or not a multiple of 16, cost ranges that
+ * num_disparities > 64, min_disparity < 0, cost ranges that
  * leave 16 bits (sad_window_size^2 * 125 + 2 * p2 > 16383). */
 KVFE_API kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* ctx,
                                                       const kvfe_dense_stereo_params* params,

@@ -151,14 +151,29 @@ __global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const sh
   short* out = Cv + (size_t)pair * P.H * rs + (size_t)x * P.D + lane;
   const int h1 = P.H - 1, SH2 = P.SW2;
   const int ye = min(y0 + VS_CHUNK, P.H);
-  // the clamped window sum slides for every row; rows OpenCV leaves at P2 just do not use it
-  int s = 0;
-  for (int k = -SH2; k <= SH2; k++) s += in[(size_t)min(max(y0 + k, 0), h1) * rs];
-  out[(size_t)y0 * rs] = (short)((y0 > 0 && (x == 0 || y0 + SH2 >= P.H)) ? P.P2 : P.P2 + s);
+  // the clamped window sum slides for every row; the rows / column OpenCV's recurrence does not touch just
+  // do not use it.  MODE_HH keeps C for every row, untouched entries hold the initial P2; MODE_SGBM reuses
+  // one row buffer, so untouched entries repeat what the row above held: column 0 keeps the first row's
+  // value and the last SH2 rows repeat row H-1-SH2.
+  const int ylast = max(P.H - 1 - SH2, 0);   // last row whose C is computed (y + SH2 < H), row 0 always is
+  auto window = [&](int yc) {
+    int t = 0;
+    for (int k = -SH2; k <= SH2; k++) t += in[(size_t)min(max(yc + k, 0), h1) * rs];
+    return t;
+  };
+  int s = window(y0);
+  int frozen = 0;
+  if (!P.full_dp) frozen = x == 0 ? window(0) : window(ylast);
+  auto value = [&](int y, int cur) {
+    const bool untouched = y > 0 && (x == 0 || y + SH2 >= P.H);
+    if (!untouched) return P.P2 + cur;
+    return P.full_dp ? P.P2 : P.P2 + frozen;
+  };
+  out[(size_t)y0 * rs] = (short)value(y0, s);
 #pragma unroll 8
   for (int y = y0 + 1; y < ye; y++) {
     s += in[(size_t)min(y + SH2, h1) * rs] - in[(size_t)max(y - SH2 - 1, 0) * rs];
-    out[(size_t)y * rs] = (short)((x == 0 || y + SH2 >= P.H) ? P.P2 : P.P2 + s);
+    out[(size_t)y * rs] = (short)value(y, s);
   }
 }
 
@@ -551,11 +566,14 @@ void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipSt
   dense_aggregate_kernel<1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
   dense_aggregate_kernel<0, 1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
   dense_aggregate_kernel<-1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
-  // pass 2: previous pixel at (x+1,y), (x-1,y+1), (x,y+1), (x+1,y+1)
+  // MODE_SGBM: the fifth direction, previous pixel at (x+1,y); MODE_HH pass 2: (x+1,y), (x-1,y+1), (x,y+1),
+  // (x+1,y+1)
   dense_aggregate_kernel<-1, 0, false><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
-  dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
-  dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
-  dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  if (P.full_dp) {
+    dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+    dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
+    dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  }
   dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, B.disp[0]);
   const dim3 gpx((P.W + 255) / 256, P.H, n);
   dense_median3_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.disp[0], B.disp[1]);

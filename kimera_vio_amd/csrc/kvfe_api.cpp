@@ -1719,7 +1719,6 @@ static kvfe_status dense_params(kvfe_ctx* c, const kvfe_dense_stereo_params& dp,
     return KVFE_ERR_UNSUPPORTED;
   };
   if (!dp.use_sgbm) return unsupported("use_sgbm = 0 (cv::StereoBM) is not implemented on the device");
-  if (!dp.use_mode_hh) return unsupported("use_mode_HH = 0 (cv::StereoSGBM::MODE_SGBM) is not implemented on the device");
   if (dp.num_disparities <= 0 || dp.num_disparities % 16 != 0) return KVFE_ERR_INVALID_ARG;
   if (dp.num_disparities > 64) return unsupported("num_disparities > 64");
   DenseParams P{};
@@ -1744,6 +1743,7 @@ static kvfe_status dense_params(kvfe_ctx* c, const kvfe_dense_stereo_params& dp,
   P.speckle_win = dp.speckle_window_size;
   P.speckle_diff = 16 * dp.speckle_range;
   P.median5 = dp.median_blur_disparity ? 1 : 0;
+  P.full_dp = dp.use_mode_hh ? 1 : 0;
   // 16-bit cost arithmetic: one path cost <= window * (2*ftzero + 63) + 2*P2, four of them per u16 sum
   const long long win = (long long)(2 * P.SW2 + 1) * (2 * P.SW2 + 1);
   if (win * (2 * P.ftzero + 63) + 2LL * P.P2 > 16383)

@@ -60,6 +60,7 @@ struct DenseParams {
   int invalid_scaled;    // (minDisparity - 1) * 16
   int speckle_win, speckle_diff;   // filterSpeckles maxSpeckleSize, maxDiff (16 * speckleRange)
   int median5;           // DenseStereoParams::median_blur_disparity_
+  int full_dp;           // 1: cv::StereoSGBM::MODE_HH (8 directions), 0: MODE_SGBM (5 directions)
 };
 struct DenseBuffers {
   uint8_t *left = nullptr, *right = nullptr;   // [n][H][W] rectified images

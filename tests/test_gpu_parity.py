@@ -827,6 +827,8 @@ def test_dense_stereo_default_params_bit_exact(ctx, ocam, seq):
     dict(num_disparities=16, min_disparity=4, sad_window_size=3, disp_12_max_diff=2, speckle_window_size=0),
     dict(sad_window_size=9, uniqueness_ratio=5, speckle_window_size=100, speckle_range=1,
          median_blur_disparity=1, pre_filter_cap=63),
+    dict(use_mode_hh=0),                                                      # cv::StereoSGBM::MODE_SGBM
+    dict(use_mode_hh=0, num_disparities=32, min_disparity=3, sad_window_size=5, uniqueness_ratio=15),
 ])
 def test_dense_stereo_parameter_variants_bit_exact(ctx, ocam, seq, kw):
     dp = abi.dense_stereo_params_default()
@@ -865,7 +867,7 @@ def test_dense_stereo_synthetic_shift_and_noise(ctx):
 
 def test_dense_stereo_unsupported_configurations(ctx):
     l = np.zeros((480, 752), np.uint8)
-    for kw in (dict(use_sgbm=0), dict(use_mode_hh=0), dict(num_disparities=128), dict(sad_window_size=21)):
+    for kw in (dict(use_sgbm=0), dict(num_disparities=128), dict(sad_window_size=21)):
         dp = abi.dense_stereo_params_default()
         for k, v in kw.items():
             setattr(dp, k, v)
