@@ -143,11 +143,11 @@ typedef struct kvfe_detector_params {
 } kvfe_detector_params;
 
 /* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85).
- * Geometric outlier rejection (FrontendParams::useRANSAC_) is implemented for the
- * IMU-aided problems every shipped Euroc-style parameter set selects:
- * ransac_use_2point_mono (opengv TranslationOnlySacProblem) and
- * ransac_use_1point_stereo (the reference's own voting scheme).  The 5-point /
- * 3-point / PnP problems and ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
+ * Geometric outlier rejection (FrontendParams::useRANSAC_) is implemented for
+ * ransac_use_2point_mono (opengv TranslationOnlySacProblem), ransac_use_1point_stereo (the
+ * reference's own voting scheme) and the 3-point Arun problem the stereo branch falls back to
+ * (ransac_use_1point_stereo = 0, or a keyframe without gyro rotation).  The 5-point mono and
+ * PnP problems and ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
 typedef struct kvfe_tracker_params {
   int32_t klt_win_size;
   int32_t klt_max_iter;
@@ -446,6 +446,17 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
     const double* ref_points_3d, const float* cur_left_rect_xy,
     const float* cur_right_rect_x, const double* cur_points_3d, int32_t n,
     const double R_ref_cur[9], int32_t* inliers, kvfe_ransac_output* out);
+
+/* Tracker::geometricOutlierRejection3d3d(ref_keypoints_3d, cur_keypoints_3d, matches, inliers)
+ * (Tracker.cpp:667-742): opengv 3-point Arun RANSAC (PointCloudSacProblem, fixed seed) over n
+ * matched 3-D points (n x 3 float64 each, already gathered by match); the front-end takes this
+ * branch when ransac_use_1point_stereo is off or the keyframe has no gyro rotation
+ * (VisionImuFrontend.cpp:127-142).  pose = lkf_T_k (points_ref = R points_cur + t); info is zero.
+ * The 3x3 SVD is a Jacobi iteration, not Eigen's: poses agree with the reference to rounding,
+ * inlier decisions are pinned by the scenes of tests/testTracker.cpp:1004-1186. */
+KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* ref_points_3d,
+                                                 const double* cur_points_3d, int32_t n,
+                                                 int32_t* inliers, kvfe_ransac_output* out);
 
 /* ------------------------------------------------------------------------- */
 /* front-end level: `batch` independent streams, lock-step, device resident  */

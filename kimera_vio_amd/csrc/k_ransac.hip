@@ -731,6 +731,250 @@ __device__ Rs3d3dResult rs_vote_finish(const KParams& P, int n, const double* re
   return res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// opengv PointCloudSacProblem: 3-point Arun (Tracker::geometricOutlierRejection3d3d, Tracker.cpp:667-742)
+// ---------------------------------------------------------------------------------------------
+// one-sided Jacobi SVD of a 3x3 matrix; operation for operation the oracle's svd3 (oracle/opengv_re.cpp)
+__device__ void rs_svd3(const double* H, double* U, double* S, double* V) {
+  double A[9];
+  for (int i = 0; i < 9; i++) {
+    A[i] = H[i];
+    V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < 3; r++) {
+          alpha += A[r * 3 + p] * A[r * 3 + p];
+          beta += A[r * 3 + q] * A[r * 3 + q];
+          gamma += A[r * 3 + p] * A[r * 3 + q];
+        }
+        off = fmax(off, fabs(gamma) / sqrt(fmax(alpha * beta, 1e-300)));
+        if (fabs(gamma) <= 1e-300) continue;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+        for (int r = 0; r < 3; r++) {
+          const double ap = A[r * 3 + p], aq = A[r * 3 + q];
+          A[r * 3 + p] = c * ap - sn * aq;
+          A[r * 3 + q] = sn * ap + c * aq;
+          const double vp = V[r * 3 + p], vq = V[r * 3 + q];
+          V[r * 3 + p] = c * vp - sn * vq;
+          V[r * 3 + q] = sn * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  for (int c = 0; c < 3; c++) S[c] = sqrt(A[c] * A[c] + A[3 + c] * A[3 + c] + A[6 + c] * A[6 + c]);
+  int order[3] = {0, 1, 2};
+  for (int i = 1; i < 3; i++)
+    for (int j = i; j > 0 && S[order[j]] > S[order[j - 1]]; j--) {
+      const int t = order[j];
+      order[j] = order[j - 1];
+      order[j - 1] = t;
+    }
+  double A2[9], V2[9], S2[3];
+  for (int c = 0; c < 3; c++) {
+    S2[c] = S[order[c]];
+    for (int r = 0; r < 3; r++) {
+      A2[r * 3 + c] = A[r * 3 + order[c]];
+      V2[r * 3 + c] = V[r * 3 + order[c]];
+    }
+  }
+  for (int i = 0; i < 9; i++) V[i] = V2[i];
+  for (int i = 0; i < 3; i++) S[i] = S2[i];
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) U[r * 3 + c] = S[c] > 1e-300 ? A2[r * 3 + c] / S[c] : 0.0;
+  if (S[2] <= 1e-12 * fmax(S[0], 1e-300)) {
+    const double u0[3] = {U[0], U[3], U[6]}, u1[3] = {U[1], U[4], U[7]};
+    double u2[3];
+    rs_cross3(u0, u1, u2);
+    const double n = sqrt(rs_dot3(u2, u2));
+    if (n > 0)
+      for (int r = 0; r < 3; r++) U[r * 3 + 2] = u2[r] / n;
+  }
+}
+
+// point_cloud::threept_arun over three correspondences -> model [R | t] (3x4 row-major): p1 = R p2 + t
+__device__ void rs_arun3(const double* p1, const double* p2, const int* sel, double* model) {
+  double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++)
+    for (int c = 0; c < 3; c++) {
+      c1[c] += p1[3 * (size_t)sel[k] + c];
+      c2[c] += p2[3 * (size_t)sel[k] + c];
+    }
+  for (int c = 0; c < 3; c++) {
+    c1[c] = c1[c] / 3.0;
+    c2[c] = c2[c] / 3.0;
+  }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 3; k++) {
+    double f[3], fp[3];
+    for (int c = 0; c < 3; c++) {
+      f[c] = p1[3 * (size_t)sel[k] + c] - c1[c];
+      fp[c] = p2[3 * (size_t)sel[k] + c] - c2[c];
+    }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) H[r * 3 + c] += fp[r] * f[c];
+  }
+  double U[9], S[3], V[9], R[9];
+  rs_svd3(H, U, S, V);
+  auto mulVUt = [&](const double* Vm) {
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+        R[r * 3 + c] = (Vm[r * 3] * U[c * 3] + Vm[r * 3 + 1] * U[c * 3 + 1]) + Vm[r * 3 + 2] * U[c * 3 + 2];
+  };
+  mulVUt(V);
+  const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+                     R[2] * (R[3] * R[7] - R[4] * R[6]);
+  if (det < 0) {
+    double Vp[9];
+    for (int i = 0; i < 9; i++) Vp[i] = V[i];
+    for (int r = 0; r < 3; r++) Vp[r * 3 + 2] = -Vp[r * 3 + 2];
+    mulVUt(Vp);
+  }
+  double Rc2[3];
+  rs_matvec3(R, c2, Rc2);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) model[r * 4 + c] = R[r * 3 + c];
+    model[r * 4 + 3] = c1[r] - Rc2[r];
+  }
+}
+__device__ __forceinline__ double rs_arun_distance(const double* model, const double* a, const double* b) {
+  const double R[9] = {model[0], model[1], model[2], model[4], model[5], model[6], model[8], model[9], model[10]};
+  double q[3], d[3];
+  rs_matvec3(R, b, q);
+  for (int c = 0; c < 3; c++) d[c] = a[c] - (q[c] + model[c * 4 + 3]);
+  return sqrt(rs_dot3(d, d));
+}
+
+// opengv::sac::Ransac<PointCloudSacProblem>::computeModel + the checks of Tracker::runRansac and
+// Tracker::geometricOutlierRejection3d3d; same calling convention as rs_ransac_2d2d
+__device__ Rs2d2dResult rs_ransac_arun(const KParams& P, const Tables& T, const double* p1, const double* p2,
+                                       int n, int* shuffled, int* wave_tot, int* inliers) {
+  const int tid = threadIdx.x;
+  __shared__ int sh_sel3[3];
+  __shared__ int sh_cnt3;
+  __shared__ double sh_model[12];
+  Rs2d2dResult res;
+  res.status = TRK_INVALID;
+  res.n_inliers = 0;
+  res.iterations = 0;
+  for (int i = 0; i < 12; i++) res.pose[i] = (i % 5 == 0) ? 1.0 : 0.0;  // Pose3()
+  for (int i = tid; i < n; i += RS_T) shuffled[i] = i;
+  __syncthreads();
+  int iterations = 0, best = -INT_MAX, draw = 0;
+  double k = 1.0;
+  bool have_model = false;
+  double Mbest[12];
+  if (n >= 3) {
+    while ((double)iterations < k) {
+      if (tid == 0) {  // drawIndexSample, then threept_arun on the sample
+        for (int i = 0; i < 3; ++i) {
+          const int r = T.ransac_rnd[min(draw + i, T.n_ransac_rnd - 1)];
+          const int j = i + (int)((unsigned)r % (unsigned)(n - i));
+          const int tmp = shuffled[i];
+          shuffled[i] = shuffled[j];
+          shuffled[j] = tmp;
+        }
+        for (int i = 0; i < 3; i++) sh_sel3[i] = shuffled[i];
+        double m[12];
+        rs_arun3(p1, p2, sh_sel3, m);
+        for (int i = 0; i < 12; i++) sh_model[i] = m[i];
+      }
+      draw += 3;
+      __syncthreads();
+      double M[12];
+      for (int i = 0; i < 12; i++) M[i] = sh_model[i];
+      int cnt = 0;
+      for (int i = tid; i < n; i += RS_T)
+        if (rs_arun_distance(M, p1 + 3 * (size_t)i, p2 + 3 * (size_t)i) < P.ransac_thr_stereo_d) cnt++;
+      cnt = rs_block_sum(cnt, wave_tot);
+      if (cnt > best) {
+        best = cnt;
+        for (int i = 0; i < 12; i++) Mbest[i] = M[i];
+        have_model = true;
+        const double w = (double)best / (double)n;
+        double p_no_outliers = 1.0 - pow(w, 3.0);
+        p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
+        p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
+        k = log(1.0 - P.ransac_probability) / log(p_no_outliers);
+      }
+      ++iterations;
+      if (iterations > P.ransac_max_iters) break;
+    }
+  } else {
+    iterations = INT_MAX;  // getSamples: not enough correspondences
+  }
+  res.iterations = iterations;
+  if (!have_model) return res;
+  if (tid == 0) sh_cnt3 = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += RS_T) {   // selectWithinDistance
+    const int i = base + tid;
+    const bool in = i < n && rs_arun_distance(Mbest, p1 + 3 * (size_t)min(i, n - 1), p2 + 3 * (size_t)min(i, n - 1)) <
+                                 P.ransac_thr_stereo_d;
+    int tot;
+    const int pos = rs_scan(in ? 1 : 0, wave_tot, &tot);
+    const int off = sh_cnt3;
+    if (in) inliers[off + pos] = i;
+    __syncthreads();
+    if (tid == 0) sh_cnt3 = off + tot;
+    __syncthreads();
+  }
+  const int n_in = sh_cnt3;
+  __syncthreads();
+  if (iterations >= P.ransac_max_iters && n_in == 0) return res;  // Tracker.h:270-273
+  res.n_inliers = n_in;
+  res.status = n_in < P.min_stereo_inliers ? TRK_FEW_MATCHES : TRK_VALID;
+  for (int i = 0; i < 12; i++) res.pose[i] = Mbest[i];
+  return res;
+}
+
+// outlierRejectionStereo, 3-point branch (VisionImuFrontend.cpp:137-142): streams whose keyframe has no
+// usable gyro rotation, or every stream when ransac_use_1point_stereo is off
+__global__ __launch_bounds__(RS_T) void stereo_arun_kernel(KParams P, Tables T, FrameTab K, FrameTab LKF,
+                                                           StereoTab ST, StereoTab LST, StreamState S,
+                                                           RansacScratch RS) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int flags = S.flags[s];
+  if (!(flags & FLAG_KEYFRAME) || (flags & FLAG_FIRST) || !P.use_ransac || !P.use_stereo_tracking) return;
+  const double* R = S.kf_R_cur + (size_t)s * 9;
+  if (P.ransac_1pt_stereo && !rs_rot_is_identity(R)) return;   // handled by the 1-point voting
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot[RS_T / 64];
+  const RsLds L = rs_carve(lds_raw, P.kcap);
+  const size_t so = (size_t)s * P.kcap;
+  int2* matches = RS.matches + so;
+  const int n = rs_build_matches(P, K, LKF, ST.right_status, LST.right_status, s, S.n_tracked[s], L.ids, L.idx,
+                                 wave_tot, matches);
+  double* p1 = RS.f_ref + so * 3;
+  double* p2 = RS.f_cur + so * 3;
+  for (int m = tid; m < n; m += RS_T) {
+    const int2 mm = matches[m];
+    for (int c = 0; c < 3; c++) {
+      p1[3 * (size_t)m + c] = LST.kp3d[(so + mm.x) * 3 + c];
+      p2[3 * (size_t)m + c] = ST.kp3d[(so + mm.y) * 3 + c];
+    }
+  }
+  __syncthreads();
+  const Rs2d2dResult res = rs_ransac_arun(P, T, p1, p2, n, L.work, wave_tot, RS.inliers + so);
+  if (tid == 0) {
+    S.trk_status[2 * (size_t)s + 1] = res.status;
+    if (res.status != TRK_INVALID) {
+      int* cn = S.trk_counts + 6 * (size_t)s;
+      cn[3] = n;
+      cn[4] = res.n_inliers;
+    }
+    if (res.status == TRK_VALID) {
+      double* pose = S.trk_pose + 24 * (size_t)s + 12;
+      for (int i = 0; i < 12; i++) pose[i] = res.pose[i];
+    }
+  }
+}
+
 // ---- front-end: the three launches over all streams ------------------------------------------------
 __global__ __launch_bounds__(RS_T) void stereo_ransac_prepare_kernel(KParams P, Tables T, FrameTab K,
                                                                      FrameTab LKF, StereoTab ST,
@@ -747,7 +991,7 @@ __global__ __launch_bounds__(RS_T) void stereo_ransac_prepare_kernel(KParams P, 
   const size_t so = (size_t)s * P.kcap;
   const double* R = S.kf_R_cur + (size_t)s * 9;
   const bool imu_ok = !rs_rot_is_identity(R);
-  if (!(P.ransac_1pt_stereo && imu_ok)) {  // 3-point problem: not implemented; zero information
+  if (!(P.ransac_1pt_stereo && imu_ok)) {  // 3-point problem (stereo_arun_kernel); zero information
     if (tid < 9) S.trk_info[9 * (size_t)s + tid] = 0.0;
     return;
   }
@@ -822,6 +1066,8 @@ void launch_stereo_ransac(const KParams& P, const Tables& T, const FrameTab& k, 
                      k, lkf, ST, LST, S, RS);
   hipLaunchKernelGGL(stereo_ransac_tile_kernel, dim3(rs_n_tiles(max_matches), P.B), dim3(64), 0, st, P, RS);
   hipLaunchKernelGGL(stereo_ransac_finish_kernel, dim3(P.B), dim3(RS_T), 0, st, P, S, RS);
+  hipLaunchKernelGGL(stereo_arun_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k, lkf, ST, LST,
+                     S, RS);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -911,6 +1157,29 @@ void launch_ransac_3d3d_points(const KParams& P, const Tables& T, const float* r
     hipLaunchKernelGGL(stereo_ransac_tile_kernel, dim3(rs_n_tiles(n), 1), dim3(64), 0, st, P, RS);
   hipLaunchKernelGGL(ransac_3d3d_finish_kernel, dim3(1), dim3(RS_T), 0, st, P, n, R, RS, out_status,
                      out_pose, out_info, out_counts);
+}
+
+// Tracker::geometricOutlierRejection3d3d on caller-supplied matched points (one problem)
+__global__ __launch_bounds__(RS_T) void ransac_3d3d_arun_points_kernel(KParams P, Tables T, const double* p1,
+                                                                       const double* p2, int n, RansacScratch RS,
+                                                                       int* out_status, double* out_pose,
+                                                                       int* out_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot[RS_T / 64];
+  const RsLds L = rs_carve(lds_raw, P.kcap);
+  const Rs2d2dResult res = rs_ransac_arun(P, T, p1, p2, n, L.work, wave_tot, RS.inliers);
+  if (threadIdx.x == 0) {
+    out_status[0] = res.status;
+    out_counts[0] = res.n_inliers;
+    out_counts[1] = res.iterations;
+    for (int i = 0; i < 12; i++) out_pose[i] = res.pose[i];
+  }
+}
+void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const double* p1, const double* p2, int n,
+                                    const RansacScratch& RS, int* out_status, double* out_pose, int* out_counts,
+                                    hipStream_t st) {
+  hipLaunchKernelGGL(ransac_3d3d_arun_points_kernel, dim3(1), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, p1, p2,
+                     n, RS, out_status, out_pose, out_counts);
 }
 
 }  // namespace kvfe

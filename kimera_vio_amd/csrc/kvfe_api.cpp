@@ -384,9 +384,6 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     if (!tr.ransac_use_2point_mono)
       return fail("ransac_use_2point_mono=0 selects the 5-point problem, which is not implemented",
                   KVFE_ERR_UNSUPPORTED);
-    if (!mono && p.use_stereo_tracking && !tr.ransac_use_1point_stereo)
-      return fail("ransac_use_1point_stereo=0 selects the 3-point problem, which is not implemented",
-                  KVFE_ERR_UNSUPPORTED);
     if (tr.ransac_max_iterations < 1 || tr.ransac_max_iterations > 1000)
       return fail("ransac_max_iterations out of range [1,1000]", KVFE_ERR_INVALID_ARG);
     if (!(tr.ransac_probability > 0.0 && tr.ransac_probability < 1.0))
@@ -498,6 +495,7 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.ransac_thr_mono = t.ransac_threshold_mono;
   P.ransac_probability = t.ransac_probability;
   P.ransac_thr_stereo = (float)t.ransac_threshold_stereo;
+  P.ransac_thr_stereo_d = t.ransac_threshold_stereo;
   // gtsam::Cal3_S2Stereo(P1) of StereoCamera.cpp:75-83
   P.fy_rect = c->rect.P1[5];
   P.cx_rect = c->rect.P1[2];
@@ -1436,6 +1434,23 @@ kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
                             n, b.kf_R_cur, b.rs, b.ss.trk_status, b.ss.trk_pose, b.ss.trk_info,
                             b.ss.trk_counts, st);
   return ransac_download(c, b, inliers, out, true);
+}
+
+kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* c, const double* ref_points_3d, const double* cur_points_3d,
+                                        int32_t n, int32_t* inliers, kvfe_ransac_output* out) {
+  if (!c || !out || n < 0 || (n > 0 && (!ref_points_3d || !cur_points_3d))) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(b.rs.f_ref, ref_points_3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(b.rs.f_cur, cur_points_3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  }
+  launch_ransac_3d3d_arun_points(P, c->T, b.rs.f_ref, b.rs.f_cur, n, b.rs, b.ss.trk_status, b.ss.trk_pose,
+                                 b.ss.trk_counts + 1, st);
+  return ransac_download(c, b, inliers, out, false);
 }
 
 // ---- front-end level -------------------------------------------------------------------------

@@ -42,7 +42,8 @@ struct KParams {
   int use_ransac, ransac_2pt_mono, ransac_1pt_stereo, ransac_max_iters;
   int min_mono_inliers, min_stereo_inliers;
   double ransac_thr_mono, ransac_probability;
-  float ransac_thr_stereo;
+  float ransac_thr_stereo;      // 1-point voting (float32 Mahalanobis test)
+  double ransac_thr_stereo_d;   // 3-point Arun RANSAC (point distance)
   double fy_rect, cx_rect, cy_rect;  // gtsam::Cal3_S2Stereo of the rectified pair (with fx_rect, baseline)
   // pyramid geometry: level 0 is the raw image, levels 1..nlevels-1 live in the pyramid buffer
   int nlevels;
@@ -289,6 +290,9 @@ void launch_ransac_3d3d_points(const KParams& P, const Tables& T, const float* r
                                const float* cur_right_x, const double* cur_p3, int n, const double* R,
                                const RansacScratch& RS, int* out_status, double* out_pose,
                                double* out_info, int* out_counts, hipStream_t st);
+void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const double* p1, const double* p2, int n,
+                                    const RansacScratch& RS, int* out_status, double* out_pose, int* out_counts,
+                                    hipStream_t st);
 // undistort keypoints with an arbitrary UndistortDev (component API)
 void launch_undistort_points(const UndistortDev& U, const float2* in, int n, float2* out,
                              double* versors, hipStream_t st);

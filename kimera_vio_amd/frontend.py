@@ -267,6 +267,17 @@ class Context:
             "outlier_rejection_3d3d_given_rotation")
         return self._ransac_result(out, inl)
 
+    def outlier_rejection_3d3d(self, ref_p3, cur_p3) -> dict:
+        """Tracker::geometricOutlierRejection3d3d (3-point Arun RANSAC) on matched 3-D points."""
+        rp = np.ascontiguousarray(ref_p3, np.float64).reshape(-1, 3)
+        cp = np.ascontiguousarray(cur_p3, np.float64).reshape(-1, 3)
+        n = len(rp)
+        inl = np.zeros(max(n, 1), np.int32)
+        out = abi.RansacOutput()
+        self._chk(self.lib.kvfe_outlier_rejection_3d3d(self._h, _p(rp), _p(cp), n, _p(inl), C.byref(out)),
+                  "outlier_rejection_3d3d")
+        return self._ransac_result(out, inl)
+
     # ---- StereoVisionImuFrontend (batched) -----------------------------------------------------
     def make_inputs(self, timestamps_ns, Rs=None, force_keyframe=None):
         arr = (abi.FrameInput * self.batch)()

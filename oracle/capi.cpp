@@ -304,6 +304,11 @@ KVO_API void kvo_outlier_rejection_3d3d_given_rotation(
                                                        cur_right_x, cur_p3, n, K, R, *tp),
                   inliers, out);
 }
+KVO_API void kvo_outlier_rejection_3d3d(const double* ref_p3, const double* cur_p3, int n,
+                                        const kvfe_tracker_params* tp, int32_t* inliers,
+                                        kvfe_ransac_output* out) {
+  fill_ransac_out(kimera::outlierRejection3d3d(ref_p3, cur_p3, n, *tp), inliers, out);
+}
 KVO_API void kvo_get_point3_and_covariance(const kvo_camera* c, double uL, double uR, double v,
                                            const double* p3, const double* Rmat, double* point,
                                            double* cov) {

@@ -106,6 +106,28 @@ RansacOut outlierRejection2d2dGivenRot(const double* f_ref, const double* f_cur,
   return o;
 }
 
+// Tracker::geometricOutlierRejection3d3d (Tracker.cpp:667-742) -> runRansac<Problem3d3d>
+// (Tracker.h:247-296; optimize_3d3d_pose_from_inliers_ = false)
+RansacOut outlierRejection3d3d(const double* ref_p3, const double* cur_p3, int n,
+                               const kvfe_tracker_params& tp) {
+  RansacOut o;
+  opengv_re::RansacResult r = opengv_re::ransac_point_cloud(
+      ref_p3, cur_p3, n, tp.ransac_threshold_stereo, tp.ransac_max_iterations, tp.ransac_probability,
+      tp.ransac_rng_policy);
+  bool success = r.success;
+  o.iterations = r.iterations;
+  if (success && r.iterations >= tp.ransac_max_iterations && r.inliers.empty()) success = false;
+  if (!success) {
+    o.status = KVFE_TRACKING_INVALID;
+    return o;
+  }
+  o.inliers = r.inliers;
+  std::memcpy(o.pose, r.coeff, sizeof(o.pose));
+  o.status = KVFE_TRACKING_VALID;
+  if ((int)o.inliers.size() < tp.min_nr_stereo_inliers) o.status = KVFE_TRACKING_FEW_MATCHES;
+  return o;
+}
+
 // gtsam::StereoCamera(Pose3(), K).backproject2(z, boost::none, H2) (gtsam 4.2
 // geometry/StereoCamera.cpp) and Tracker::getPoint3AndCovariance (Tracker.cpp:772-818)
 void getPoint3AndCovariance(const StereoCalib& K, double uL, double uR, double v, const double p3[3],
@@ -322,9 +344,36 @@ void Frontend::outlierRejectionStereo(const double R[9], StereoFrame& ref, Stere
   TrackerStatusSummary& S = tracker_status;
   const bool imu_ok = !rot_equals_identity(R, 1e-9);
   if (!(p.tracker.ransac_use_1point_stereo && imu_ok)) {
-    // the 3-point (Arun) front-end path is not wired: INVALID, zero information (documented gap)
-    S.stereo = KVFE_TRACKING_INVALID;
+    // 3-point RANSAC: Tracker::geometricOutlierRejection3d3d(frame_lkf, frame_k) (Tracker.cpp:744-769),
+    // translation information zero (VisionImuFrontend.cpp:140-142)
+    std::vector<KeypointMatch> mono3, m3;
+    findMatchingKeypoints(ref.left, cur.left, mono3);
+    findMatchingStereoKeypoints(ref, cur, mono3, m3);
+    const int n3 = (int)m3.size();
+    std::vector<double> rp3(3 * (size_t)n3), cp3(3 * (size_t)n3);
+    for (int m = 0; m < n3; m++)
+      for (int c = 0; c < 3; c++) {
+        rp3[3 * m + c] = ref.kp3d[3 * m3[m].first + c];
+        cp3[3 * m + c] = cur.kp3d[3 * m3[m].second + c];
+      }
+    RansacOut res3 = outlierRejection3d3d(rp3.data(), cp3.data(), n3, p.tracker);
+    if (res3.status != KVFE_TRACKING_INVALID) {
+      S.nr_stereo_putatives = n3;
+      S.nr_stereo_inliers = (int)res3.inliers.size();
+      std::vector<int> outliers3;   // removeOutliersStereo (Tracker.cpp:763-767)
+      findOutliers(m3.size(), res3.inliers, outliers3);
+      for (int out : outliers3) {
+        const size_t a = m3[out].first, b = m3[out].second;
+        ref.right_kp_rect[a].status = KVFE_KP_FAILED_ARUN;
+        ref.depth[a] = 0.0;
+        cur.right_kp_rect[b].status = KVFE_KP_FAILED_ARUN;
+        cur.depth[b] = 0.0;
+        for (int c = 0; c < 3; c++) ref.kp3d[3 * a + c] = cur.kp3d[3 * b + c] = 0.0;
+      }
+    }
+    S.stereo = res3.status;
     std::memset(S.info, 0, sizeof(S.info));
+    if (res3.status == KVFE_TRACKING_VALID) std::memcpy(S.lkf_T_k_stereo, res3.pose, sizeof(res3.pose));
     return;
   }
   std::vector<KeypointMatch> mono, matches;

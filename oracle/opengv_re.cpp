@@ -252,7 +252,8 @@ void svd3(const double H[9], double U[9], double S[3], double V[9]) {
   for (int c = 0; c < 3; c++) S[c] = std::sqrt(A[c] * A[c] + A[3 + c] * A[3 + c] + A[6 + c] * A[6 + c]);
   // sort singular values descending (Eigen's convention)
   int order[3] = {0, 1, 2};
-  std::sort(order, order + 3, [&](int a, int b) { return S[a] > S[b]; });
+  for (int i = 1; i < 3; i++)   // stable insertion sort (the device kernel does the same)
+    for (int j = i; j > 0 && S[order[j]] > S[order[j - 1]]; j--) std::swap(order[j], order[j - 1]);
   double A2[9], V2[9], S2[3];
   for (int c = 0; c < 3; c++) {
     S2[c] = S[order[c]];

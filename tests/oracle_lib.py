@@ -448,6 +448,17 @@ def outlier_rejection_3d3d_given_rotation(cam: "Camera", ref_left_xy, ref_right_
     return _ransac_result(out, inl)
 
 
+def outlier_rejection_3d3d(ref_p3, cur_p3, tp: abi.TrackerParams) -> dict:
+    """Tracker::geometricOutlierRejection3d3d (3-point Arun RANSAC) on matched 3-D points"""
+    rp = np.ascontiguousarray(ref_p3, np.float64).reshape(-1, 3)
+    cp = np.ascontiguousarray(cur_p3, np.float64).reshape(-1, 3)
+    n = len(rp)
+    inl = np.zeros(max(n, 1), np.int32)
+    out = abi.RansacOutput()
+    lib().kvo_outlier_rejection_3d3d(_p(rp), _p(cp), n, C.byref(tp), _p(inl), C.byref(out))
+    return _ransac_result(out, inl)
+
+
 def get_point3_and_covariance(cam: "Camera", uL, uR, v, p3, Rmat=None):
     p3 = np.ascontiguousarray(p3, np.float64).reshape(3)
     Rm = None if Rmat is None else np.ascontiguousarray(Rmat, np.float64).reshape(9)

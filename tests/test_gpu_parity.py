@@ -531,6 +531,60 @@ def test_outlier_rejection_3d3d_given_rotation(rctx, ocam, case, planar, n_in, n
         assert exp["status"] == abi.TRACKING_VALID and list(exp["inliers"]) == list(range(n_in))
 
 
+@pytest.mark.parametrize("case,n_in,n_out,noise", [(0, 3, 0, 0.0), (1, 40, 0, 0.0), (2, 80, 40, 0.0),
+                                                   (3, 400, 300, 0.002), (4, 2, 0, 0.0), (5, 0, 0, 0.0)])
+def test_outlier_rejection_3d3d_arun(ocam, case, n_in, n_out, noise):
+    """3-point Arun RANSAC (opengv PointCloudSacProblem, Tracker.cpp:667-742): same sample stream, the same
+    Jacobi SVD operation for operation on both sides -> identical hypotheses, inlier sets, iteration counts
+    and poses; scenes of tests/testTracker.cpp:898-1039."""
+    L, R_ = euroc_cams()
+    p = _euroc_ransac_params()
+    p.tracker.ransac_use_1point_stereo = 0
+    p.tracker.ransac_threshold_stereo = 1e-3 if noise == 0 else 0.05
+    c = F.Context(L, R_, p)
+    try:
+        rng = np.random.default_rng(400 + case)
+        R = TR.expmap([0.1, 0.1, 0.1])
+        T = np.array([ocam.rect.baseline, 0.0, 0.0])
+        _, _, p_ref, _, _, p_cur = TR.stereo_scene(ocam, rng, R, T, False, n_in, n_out, noise)
+        exp = O.outlier_rejection_3d3d(p_ref, p_cur, p.tracker)
+        got = c.outlier_rejection_3d3d(p_ref, p_cur)
+        _same_ransac(got, exp)
+        if n_in >= 3 and noise == 0:
+            assert exp["status"] in (abi.TRACKING_VALID, abi.TRACKING_FEW_MATCHES)
+            assert list(exp["inliers"]) == list(range(n_in))
+            assert np.allclose(exp["pose"][:, :3], R, atol=1e-6) and np.allclose(exp["pose"][:, 3], T, atol=1e-6)
+        if n_in < 3:
+            assert exp["status"] == abi.TRACKING_INVALID
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("one_point", [0, 1])
+def test_frontend_sequence_three_point_stereo(seq, ocam, one_point):
+    """outlierRejectionStereo's 3-point branch (VisionImuFrontend.cpp:137-142): with
+    ransac_use_1point_stereo: 0 (params/D455, KinectAzure) on every keyframe, and with the shipped Euroc
+    setting on keyframes whose gyro rotation is exactly identity (streams alternate here)."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    if one_point:
+        seq["camR"] = [np.eye(3) for _ in seq["camR"]]   # no usable rotation: mono INVALID, stereo Arun
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=200)
+    p.tracker.ransac_use_1point_stereo = one_point
+    fe = [O.Frontend(L, R, p) for _ in range(2)]
+    c = F.Context(L, R, p, batch=2)
+    try:
+        _run_sequence(fe, c, seq, stream_of=lambda s, i: i if s == 0 else 8 - i, force_kf=True, n=6)
+        last = [c.get_output(s) for s in range(2)]
+    finally:
+        c.close()
+    for o in last:
+        assert o["tracking_status_stereo"] in (abi.TRACKING_VALID, abi.TRACKING_FEW_MATCHES)
+        assert np.all(o["info_mat_stereo_translation"] == 0)
+        assert o["nr_stereo_putatives"] > 20 and o["nr_stereo_inliers"] > 10
+
+
 def _euroc_ransac_params(**det):
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
     for k, v in det.items():

@@ -100,7 +100,6 @@ def test_unsupported_configurations_are_rejected():
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
     assert p.use_ransac == 1 and p.tracker.ransac_use_2point_mono == 1 and p.tracker.ransac_randomize == 0
     for field, value in (("ransac_use_2point_mono", 0),    # 5-point (Nister) problem
-                         ("ransac_use_1point_stereo", 0),  # 3-point (Arun) problem
                          ("ransac_randomize", 1)):         # time-seeded sampling
         q = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
         setattr(q.tracker, field, value)
