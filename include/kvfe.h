@@ -317,8 +317,10 @@ KVFE_API void kvfe_dense_stereo_params_default(kvfe_dense_stereo_params* p);
  * disparity: n_pairs images of int16 with 4 fractional bits, (min_disparity - 1) * 16 where
  * invalid — the CV_16S matrix cv::StereoSGBM::compute leaves in *disparity_img (compute()
  * re-creates the CV_32F matrix the caller passed as CV_16S; callers divide by 16:
- * tests/testStereoCamera.cpp:296-300).  KVFE_ERR_UNSUPPORTED: use_sgbm = 0 (cv::StereoBM),
- * num_disparities > 64, min_disparity < 0, cost ranges that
+ * tests/testStereoCamera.cpp:296-300).  use_sgbm = 0 runs cv::StereoBM (PREFILTER_XSOBEL; ROI1/ROI2
+ * = the context's rectification ROIs, StereoMatcher.cpp:81-86).  KVFE_ERR_UNSUPPORTED:
+ * num_disparities > 64, SGBM with min_disparity < 0, BM's normalized-response prefilter or
+ * disp_12_max_diff >= 0, cost ranges that
  * leave 16 bits (sad_window_size^2 * 125 + 2 * p2 > 16383). */
 KVFE_API kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* ctx,
                                                       const kvfe_dense_stereo_params* params,

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const sh
   int frozen = 0;
   if (!P.full_dp) frozen = x == 0 ? window(0) : window(ylast);
   auto value = [&](int y, int cur) {
+    if (P.bm) return cur;   // cv::StereoBM: plain window sum of the row SADs (rows clamped to the image)
     const bool untouched = y > 0 && (x == 0 || y + SH2 >= P.H);
     if (!untouched) return P.P2 + cur;
     return P.full_dp ? P.P2 : P.P2 + frozen;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const 
       }
     }
     bool ok = x < W1 && best >= 0;   // best = -1: every S saturated, the pixel keeps INVALID_DISP_SCALED
-    if (P.uniq > 0 || true) {
+    {   // uniqueness: any other disparity (|d - best| > 1) whose cost is within the ratio invalidates
       bool viol = false;
       for (int d = 0; d < D; d++) {
         const int S = min(MAXC, (int)T[d * SEL_PITCH + lane]);
@@ -349,6 +350,124 @@ __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const 
       if (bad) dv = INVALID;
     }
     out[x] = (short)dv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::StereoBM (stereobm.cpp, PREFILTER_XSOBEL, CV_16S): use_sgbm_ = false (StereoMatcher.cpp:66-90)
+// ---------------------------------------------------------------------------------------------
+// prefilterXSobel: rows reflect-101, first / last column and (odd H) the last row hold ftzero
+__global__ __launch_bounds__(256) void bm_prefilter_kernel(DenseParams P, const uint8_t* __restrict__ left,
+                                                           const uint8_t* __restrict__ right,
+                                                           uint8_t* __restrict__ pre) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z & 1, pair = blockIdx.z >> 1;
+  if (x >= P.W) return;
+  const size_t plane = (size_t)P.W * P.H;
+  const uint8_t* src = (img ? right : left) + pair * plane;
+  const int ft = P.ftzero;
+  int v = ft;   // tab[0 + OFS]
+  const bool last_odd_row = (P.H & 1) && y == P.H - 1;
+  if (x > 0 && x < P.W - 1 && !last_odd_row) {
+    const int ym = y > 0 ? y - 1 : (P.H > 1 ? 1 : 0), yp = y < P.H - 1 ? y + 1 : (P.H > 1 ? P.H - 2 : 0);
+    const uint8_t *r0 = src + (size_t)ym * P.W, *r1 = src + (size_t)y * P.W, *r2 = src + (size_t)yp * P.W;
+    const int g = (r0[x + 1] - r0[x - 1]) + (r1[x + 1] - r1[x - 1]) * 2 + (r2[x + 1] - r2[x - 1]);
+    v = g < -ft ? 0 : g > ft ? ft * 2 : g + ft;
+  }
+  pre[((size_t)blockIdx.z * P.H + y) * P.W + x] = (uint8_t)v;
+}
+
+// hsad(y, x, d) = sum over the window columns c = x-wsz2 .. x+wsz2 of |L'(y, clampL(c)) - R'(y, rbase(c) + d)|
+// with findStereoCorrespondenceBM's own column clamps (left pixel clamped, right BASE clamped); d indexes
+// disparity ndisp - 1 - d + mindisp.  wave = pixel, lane = d.
+__global__ __launch_bounds__(256) void bm_hsad_kernel(DenseParams P, const uint8_t* __restrict__ pre,
+                                                      short* __restrict__ hs) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int y = blockIdx.y, pair = blockIdx.z;
+  const uint8_t* L = pre + ((size_t)(pair * 2) * P.H + y) * P.W;
+  const uint8_t* R = pre + ((size_t)(pair * 2 + 1) * P.H + y) * P.W;
+  short* out = hs + (((size_t)pair * P.H + y) * P.width1) * P.D;
+  const int lofs = P.minX1, rofs = P.bm_rofs, wsz2 = P.SW2, nd = P.D;
+  const int dl = min(lane, nd - 1);
+  for (int i = 0; i < BT_XPB / 4; i++) {
+    const int x = blockIdx.x * BT_XPB + wv * (BT_XPB / 4) + i;
+    if (x >= P.width1) break;
+    int s = 0;
+    for (int c = x - wsz2; c <= x + wsz2; c++) {
+      const int lv = L[lofs + min(max(c, -lofs), P.W - 1 - lofs)];
+      const int rv = R[rofs + min(max(c, -rofs), P.W - nd - rofs) + dl];
+      s += abs(lv - rv);
+    }
+    if (lane < nd) out[(size_t)x * nd + lane] = (short)s;
+  }
+}
+
+// texture sum of findStereoCorrespondenceBM: sum over the window of |L'(clamped) - ftzero|
+__global__ __launch_bounds__(256) void bm_texture_kernel(DenseParams P, const uint8_t* __restrict__ pre,
+                                                         int* __restrict__ tex) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, pair = blockIdx.z;
+  if (x >= P.width1) return;
+  const uint8_t* L = pre + ((size_t)(pair * 2) * P.H) * P.W;
+  int s = 0;
+  for (int k = -P.SW2; k <= P.SW2; k++) {
+    const uint8_t* row = L + (size_t)min(max(y + k, 0), P.H - 1) * P.W;
+    for (int c = x - P.SW2; c <= x + P.SW2; c++)
+      s += abs((int)row[P.minX1 + min(max(c, -P.minX1), P.W - 1 - P.minX1)] - P.ftzero);
+  }
+  tex[((size_t)pair * P.H + y) * P.W + x] = s;
+}
+
+// minimum SAD, texture / uniqueness tests, sub-pixel fit (the tail of findStereoCorrespondenceBM's y loop),
+// FILTERED outside the valid-disparity rectangle (FindStereoCorrespInvoker).  Same tile transposition as
+// dense_select_kernel: lane = d while loading, lane = column while deciding.
+__global__ __launch_bounds__(256) void bm_select_kernel(DenseParams P, const short* __restrict__ sad,
+                                                        const int* __restrict__ tex, short* __restrict__ disp) {
+  __shared__ unsigned short tile[4][64 * SEL_PITCH];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int y = blockIdx.x, pair = blockIdx.y;
+  const int W = P.W, W1 = P.width1, D = P.D;
+  const short FILTERED = (short)P.invalid_scaled;
+  short* out = disp + ((size_t)pair * P.H + y) * W;
+  for (int x = threadIdx.x; x < W; x += 256) out[x] = FILTERED;
+  if (y < P.bm_roi[1] || y >= P.bm_roi[1] + P.bm_roi[3]) return;
+  __syncthreads();
+  const size_t row = (((size_t)pair * P.H + y) * W1) * D;
+  const short* srow = sad + row + min(lane, D - 1);
+  unsigned short* T = tile[wv];
+  const int ntiles = (W1 + 63) / 64;
+  for (int tl = wv; tl < ntiles; tl += 4) {
+    const int x0 = tl * 64;
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) T[lane * SEL_PITCH + j] = (unsigned short)srow[(size_t)min(x0 + j, W1 - 1) * D];
+    __builtin_amdgcn_wave_barrier();
+    const int x = x0 + lane;
+    int minsad = 0x7fffffff, mind = -1;
+    for (int d = 0; d < D; d++) {
+      const int v = T[d * SEL_PITCH + lane];
+      if (v < minsad) {
+        minsad = v;
+        mind = d;
+      }
+    }
+    const int xo = P.minX1 + x;   // output column
+    bool ok = x < W1 && xo >= P.bm_roi[0] && xo < P.bm_roi[0] + P.bm_roi[2];
+    if (ok && P.bm_texture > 0) ok = tex[((size_t)pair * P.H + y) * W + x] >= P.bm_texture;
+    if (ok && P.uniq > 0) {
+      const int thresh = minsad + (minsad * P.uniq / 100);
+      bool viol = false;
+      for (int d = 0; d < D; d++) {
+        const int v = T[d * SEL_PITCH + lane];
+        viol |= (d < mind - 1 || d > mind + 1) && v <= thresh;
+      }
+      ok = !viol;
+    }
+    if (ok) {
+      // sad[-1] = sad[1]; sad[ndisp] = sad[ndisp-2]
+      const int ip = mind + 1 < D ? mind + 1 : D - 2, in = mind - 1 >= 0 ? mind - 1 : 1;
+      const int p = T[ip * SEL_PITCH + lane], n = T[in * SEL_PITCH + lane];
+      const int dd = p + n - 2 * minsad + abs(p - n);
+      out[xo] = (short)(((D - mind - 1 + P.minD) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -592,6 +711,33 @@ void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipSt
   }
   if (cur != B.disp[0])
     (void)hipMemcpyAsync(B.disp[0], cur, sizeof(short) * (size_t)P.W * P.H * n, hipMemcpyDeviceToDevice, st);
+}
+
+// cv::StereoBM::compute: inputs in B.left / B.right, result in B.disp[0].  Reuses the SGBM buffers: the
+// pre-filtered images live in B.rec, hsad in vol[0], the window SADs in vol[1], the texture sums in B.count.
+void launch_dense_bm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st) {
+  const dim3 blk(256);
+  uint8_t* pre = reinterpret_cast<uint8_t*>(B.rec);
+  bm_prefilter_kernel<<<dim3((P.W + 255) / 256, P.H, 2 * n), blk, 0, st>>>(P, B.left, B.right, pre);
+  bm_hsad_kernel<<<dim3((P.width1 + BT_XPB - 1) / BT_XPB, P.H, n), blk, 0, st>>>(P, pre, B.vol[0]);
+  dense_vsum_kernel<<<dim3((P.width1 + 3) / 4, (P.H + VS_CHUNK - 1) / VS_CHUNK, n), blk, 0, st>>>(P, B.vol[0],
+                                                                                                 B.vol[1]);
+  if (P.bm_texture > 0)
+    bm_texture_kernel<<<dim3((P.width1 + 255) / 256, P.H, n), blk, 0, st>>>(P, pre, B.count);
+  bm_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, B.vol[1], B.count, B.disp[0]);
+  const dim3 gpx((P.W + 255) / 256, P.H, n);
+  short* cur = B.disp[0];
+  if (P.speckle_win > 0) {
+    speckle_rows_kernel<<<dim3(P.H, n), blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_diff, cur, B.label,
+                                                      B.count, B.runlen);
+    speckle_merge_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_diff, cur, B.label);
+    speckle_count_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.label, B.runlen, B.count);
+    speckle_apply_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, P.invalid_scaled, P.speckle_win, B.label, B.count, cur);
+  }
+  if (P.median5) {
+    dense_median5_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, cur, B.disp[1]);
+    (void)hipMemcpyAsync(B.disp[0], B.disp[1], sizeof(short) * (size_t)P.W * P.H * n, hipMemcpyDeviceToDevice, st);
+  }
 }
 
 void launch_reproject_to_3d(int W, int H, const float* disp, const ReprojectQ& Q, unsigned* minkey, float* xyz,

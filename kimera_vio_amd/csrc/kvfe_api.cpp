@@ -1733,7 +1733,6 @@ static kvfe_status dense_params(kvfe_ctx* c, const kvfe_dense_stereo_params& dp,
     c->last_error = std::string("dense stereo: ") + why;
     return KVFE_ERR_UNSUPPORTED;
   };
-  if (!dp.use_sgbm) return unsupported("use_sgbm = 0 (cv::StereoBM) is not implemented on the device");
   if (dp.num_disparities <= 0 || dp.num_disparities % 16 != 0) return KVFE_ERR_INVALID_ARG;
   if (dp.num_disparities > 64) return unsupported("num_disparities > 64");
   DenseParams P{};
@@ -1742,6 +1741,53 @@ static kvfe_status dense_params(kvfe_ctx* c, const kvfe_dense_stereo_params& dp,
   if (P.W > 2048) return unsupported("image width > 2048");
   P.minD = dp.min_disparity;
   P.D = dp.num_disparities;
+  if (!dp.use_sgbm) {   // cv::StereoBM::create(numDisparities, blockSize) + setters (StereoMatcher.cpp:66-90)
+    // argument checks of StereoBMImpl::compute
+    if (dp.pre_filter_type != 0 && dp.pre_filter_type != 1) return KVFE_ERR_INVALID_ARG;
+    if (dp.pre_filter_type != 1) return unsupported("StereoBM PREFILTER_NORMALIZED_RESPONSE");
+    if (dp.pre_filter_cap < 1 || dp.pre_filter_cap > 63) return KVFE_ERR_INVALID_ARG;
+    const int wsz = dp.sad_window_size;
+    if (wsz < 5 || wsz > 255 || wsz % 2 == 0 || wsz >= std::min(P.W, P.H)) return KVFE_ERR_INVALID_ARG;
+    if (dp.texture_threshold < 0 || dp.uniqueness_ratio < 0) return KVFE_ERR_INVALID_ARG;
+    if (dp.disp_12_max_diff >= 0) return unsupported("StereoBM disp12MaxDiff >= 0 (validateDisparity)");
+    if ((long long)wsz * wsz * 2 * dp.pre_filter_cap > 32767) return unsupported("StereoBM window SAD above 16 bits");
+    P.bm = 1;
+    P.full_dp = 1;
+    P.minX1 = std::max(P.D - 1 + P.minD, 0);            // lofs
+    P.bm_rofs = -std::min(P.D - 1 + P.minD, 0);         // rofs
+    P.width1 = P.W - P.bm_rofs - P.D + 1;
+    if (P.minX1 >= P.W || P.bm_rofs >= P.W || P.width1 < 1) P.width1 = 0;   // everything FILTERED
+    P.SW2 = wsz / 2;
+    P.ftzero = dp.pre_filter_cap;
+    P.uniq = dp.uniqueness_ratio;
+    P.bm_texture = dp.texture_threshold;
+    P.invalid_scaled = (P.minD - 1) * 16;
+    P.speckle_win = dp.speckle_range >= 0 ? dp.speckle_window_size : 0;
+    P.speckle_diff = dp.speckle_range;                  // (cv::StereoBM passes the range unscaled)
+    P.median5 = dp.median_blur_disparity ? 1 : 0;
+    // cv::getValidDisparityROI(roi1, roi2, minDisparity, numDisparities, blockSize) with the ROIs of the
+    // rectification when both are non-empty (StereoMatcher.cpp:81-86), else the whole image
+    const int32_t* r1 = c->rect.roi1;
+    const int32_t* r2 = c->rect.roi2;
+    const bool have = r1[2] > 0 && r1[3] > 0 && r2[2] > 0 && r2[3] > 0;
+    const int a[4] = {have ? r1[0] : 0, have ? r1[1] : 0, have ? r1[2] : P.W, have ? r1[3] : P.H};
+    const int b[4] = {have ? r2[0] : 0, have ? r2[1] : 0, have ? r2[2] : P.W, have ? r2[3] : P.H};
+    const int maxD1 = P.minD + P.D - 1;
+    const int xmin = std::max(a[0], b[0] + maxD1) + P.SW2, xmax = std::min(a[0] + a[2], b[0] + b[2] - P.minD) - P.SW2;
+    const int ymin = std::max(a[1], b[1]) + P.SW2, ymax = std::min(a[1] + a[3], b[1] + b[3]) - P.SW2;
+    int roi[4] = {xmin, ymin, xmax - xmin, ymax - ymin};
+    if (roi[2] <= 0 || roi[3] <= 0) roi[0] = roi[1] = roi[2] = roi[3] = 0;
+    // intersect with the image
+    const int x0 = std::max(roi[0], 0), y0 = std::max(roi[1], 0);
+    const int x1 = std::min(roi[0] + roi[2], P.W), y1 = std::min(roi[1] + roi[3], P.H);
+    P.bm_roi[0] = x0;
+    P.bm_roi[1] = y0;
+    P.bm_roi[2] = std::max(x1 - x0, 0);
+    P.bm_roi[3] = std::max(y1 - y0, 0);
+    if (P.bm_roi[2] == 0 || P.bm_roi[3] == 0) P.bm_roi[2] = P.bm_roi[3] = 0;
+    *out = P;
+    return KVFE_OK;
+  }
   const int maxD = P.minD + P.D;
   P.minX1 = std::max(maxD, 0);
   const int maxX1 = P.W + std::min(P.minD, 0);
@@ -1835,7 +1881,10 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
                                  hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->dense_ev[0], c->stream));
-    launch_dense_sgbm(P, b, n, c->stream);
+    if (P.bm)
+      launch_dense_bm(P, b, n, c->stream);
+    else
+      launch_dense_sgbm(P, b, n, c->stream);
     HIPCHK(c, hipEventRecord(c->dense_ev[1], c->stream));
     HIPCHK(c, hipGetLastError());
     for (int i = 0; i < n; i++)

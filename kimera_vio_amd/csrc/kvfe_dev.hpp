@@ -62,6 +62,11 @@ struct DenseParams {
   int speckle_win, speckle_diff;   // filterSpeckles maxSpeckleSize, maxDiff (16 * speckleRange)
   int median5;           // DenseStereoParams::median_blur_disparity_
   int full_dp;           // 1: cv::StereoSGBM::MODE_HH (8 directions), 0: MODE_SGBM (5 directions)
+  // cv::StereoBM (use_sgbm_ = false): minX1 = lofs, width1 = width - rofs - ndisp + 1, SW2 = SADWindowSize / 2,
+  // ftzero = preFilterCap, uniq = uniquenessRatio, invalid_scaled = FILTERED, speckle_diff = speckleRange
+  int bm;                // 1: block matching
+  int bm_rofs, bm_texture;
+  int bm_roi[4];         // valid-disparity rectangle (x, y, w, h); rows / columns outside are FILTERED
 };
 struct DenseBuffers {
   uint8_t *left = nullptr, *right = nullptr;   // [n][H][W] rectified images
@@ -78,6 +83,7 @@ struct ReprojectQ {
 size_t dense_volume_elems(const DenseParams& P);
 // inputs in B.left / B.right, result in B.disp[0]
 void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st);
+void launch_dense_bm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st);
 void launch_reproject_to_3d(int W, int H, const float* disp, const ReprojectQ& Q, unsigned* minkey, float* xyz,
                             hipStream_t st);
 

@@ -523,7 +523,7 @@ void findStereoCorrespondenceBM(const uint8_t* left, const uint8_t* right, int w
       }
       tsum += htext[y + wsz2] - htext[y - wsz2 - 1];
       if (tsum < textureThreshold) {
-        dptr[y * dstep] = FILTERED;
+        if (lofs + x < width) dptr[y * dstep] = FILTERED;
         continue;
       }
       if (uniquenessRatio > 0) {
@@ -532,7 +532,7 @@ void findStereoCorrespondenceBM(const uint8_t* left, const uint8_t* right, int w
         for (d = 0; d < ndisp; d++)
           if ((d < mind - 1 || d > mind + 1) && sad[d] <= thresh) break;
         if (d < ndisp) {
-          dptr[y * dstep] = FILTERED;
+          if (lofs + x < width) dptr[y * dstep] = FILTERED;
           continue;
         }
       }
@@ -540,6 +540,11 @@ void findStereoCorrespondenceBM(const uint8_t* left, const uint8_t* right, int w
       sad[ndisp] = sad[ndisp - 2];
       const int p = sad[mind + 1], n = sad[mind - 1];
       const int dd = p + n - 2 * sad[mind] + std::abs(p - n);
+      // With minDisparity > 0 OpenCV's x loop runs minDisparity columns past the end of the row (lofs + width1
+      // = width + minDisparity): the writes land in the first columns of the next row, which the invoker
+      // overwrites with FILTERED afterwards (roi.x > maxD) — except below the last row of the band, where
+      // they are a stray write.  The restatement drops those out-of-row writes.
+      if (lofs + x >= width) continue;
       dptr[y * dstep] = (short)(((ndisp - mind - 1 + mindisp) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
     }
   }

@@ -894,6 +894,30 @@ def test_dense_stereo_parameter_variants_bit_exact(ctx, ocam, seq, kw):
     assert np.array_equal(got, exp), (kw, np.count_nonzero(got != exp))
 
 
+@pytest.mark.parametrize("kw", [
+    dict(),                                                                    # reference defaults, use_sgbm_ = false
+    dict(uniqueness_ratio=15, texture_threshold=10, speckle_window_size=100, speckle_range=4),
+    dict(num_disparities=32, min_disparity=0, sad_window_size=21, pre_filter_cap=20, median_blur_disparity=1),
+    dict(num_disparities=16, min_disparity=5, sad_window_size=5, speckle_window_size=0),
+])
+def test_dense_stereo_block_matching_bit_exact(ctx, ocam, seq, kw):
+    """use_sgbm_ = false: cv::StereoBM (XSOBEL prefilter, SAD block matching inside the valid-disparity
+    rectangle of the rectification's ROIs, texture / uniqueness tests, sub-pixel fit, filterSpeckles with the
+    unscaled range) — every int16 identical to the oracle, on two pairs in one call."""
+    dp = abi.dense_stereo_params_default()
+    dp.use_sgbm = 0
+    for k, v in kw.items():
+        setattr(dp, k, v)
+    pairs = _dense_pairs(ctx, ocam, seq)[:2]
+    roi1, roi2 = list(ctx.rect.roi1), list(ctx.rect.roi2)
+    exp = [O.dense_stereo_reconstruction(l, r, dp, roi1, roi2) for l, r in pairs]
+    got = ctx.dense_stereo_reconstruction([p[0] for p in pairs], [p[1] for p in pairs], dp)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e), (kw, np.count_nonzero(g != e))
+    inv = (dp.min_disparity - 1) * 16
+    assert (exp[0] != inv).mean() > 0.05
+
+
 def test_dense_stereo_synthetic_shift_and_noise(ctx):
     """known disparity: right(x) = left(x + d) -> most valid pixels within 1 px of d, and bit-exact
     against the oracle also on pure noise (worst case for ties / saturation of the summed costs)."""
@@ -921,7 +945,8 @@ def test_dense_stereo_synthetic_shift_and_noise(ctx):
 
 def test_dense_stereo_unsupported_configurations(ctx):
     l = np.zeros((480, 752), np.uint8)
-    for kw in (dict(use_sgbm=0), dict(num_disparities=128), dict(sad_window_size=21)):
+    for kw in (dict(num_disparities=128), dict(sad_window_size=21), dict(use_sgbm=0, pre_filter_type=0),
+               dict(use_sgbm=0, disp_12_max_diff=1)):
         dp = abi.dense_stereo_params_default()
         for k, v in kw.items():
             setattr(dp, k, v)
