@@ -69,8 +69,11 @@ enum {
  * while the 32-bit output is >= 2^31; V11: libstdc++ >= 11 returns output >> 1. */
 enum { KVFE_RNG_LIBSTDCXX_PRE11 = 0, KVFE_RNG_LIBSTDCXX_11 = 1 };
 
-/* VIO::FrontendType (stereo: StereoVisionImuFrontend, mono: MonoVisionImuFrontend) */
-enum { KVFE_FRONTEND_STEREO = 0, KVFE_FRONTEND_MONO = 1 };
+/* VIO::FrontendType (stereo: StereoVisionImuFrontend, mono: MonoVisionImuFrontend, rgbd:
+ * RgbdVisionImuFrontend) */
+enum { KVFE_FRONTEND_STEREO = 0, KVFE_FRONTEND_MONO = 1, KVFE_FRONTEND_RGBD = 2 };
+/* cv::Mat type of the depth image of the RGBD front-end (DepthFrame.cpp:30) */
+enum { KVFE_DEPTH_U16 = 0 /* CV_16UC1 */, KVFE_DEPTH_F32 = 1 /* CV_32FC1 */ };
 
 /* VIO::AnmsAlgorithmType (feature-detector/NonMaximumSuppression.h) */
 enum {
@@ -194,6 +197,18 @@ typedef struct kvfe_frontend_params {
   int32_t use_ransac;                        /* useRANSAC                    */
 } kvfe_frontend_params;
 
+/* CameraParams::DepthParams (include/kimera-vio/frontend/CameraParams.h:131-155), RGBD front-end only.
+ * is_registered must be 1 (an unregistered depth image goes through cv::rgbd::registerDepth in the
+ * reference, DepthFrame.cpp:97-110: not implemented). */
+typedef struct kvfe_depth_params {
+  float virtual_baseline;        /* 1e-2: baseline of the hallucinated right camera          */
+  float depth_to_meters;         /* 1.0                                                      */
+  float min_depth;               /* 0.0                                                      */
+  float max_depth;               /* 10.0                                                     */
+  int32_t is_registered;         /* 1                                                        */
+  int32_t depth_type;            /* KVFE_DEPTH_U16 | KVFE_DEPTH_F32                          */
+} kvfe_depth_params;
+
 typedef struct kvfe_config {
   kvfe_camera_params left, right;
   kvfe_frontend_params params;
@@ -201,9 +216,13 @@ typedef struct kvfe_config {
   int32_t device;                /* HIP device ordinal                       */
   void* hip_stream;              /* optional hipStream_t owned by the caller */
   int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
-  int32_t frontend_type;         /* KVFE_FRONTEND_*: stereo (default) or the monocular front-end
-                                    (MonoVisionImuFrontend.cpp: `left` only, `right` ignored)   */
+  int32_t frontend_type;         /* KVFE_FRONTEND_*: stereo (default), the monocular front-end
+                                    (MonoVisionImuFrontend.cpp: `left` only, `right` ignored) or
+                                    the RGBD front-end (RgbdVisionImuFrontend.cpp: `left` is the
+                                    colour camera; the `right` images of the step calls are the
+                                    depth images, see kvfe_frontend_step_host)                   */
   int32_t reserved0;
+  kvfe_depth_params depth;       /* RGBD front-end only                                          */
   int32_t stream_groups;         /* 0 = default (1).  The batch is split into this many
                                     groups of streams, each on its own HIP stream, so
                                     that latency-bound and throughput-bound kernels of
@@ -479,7 +498,11 @@ typedef struct kvfe_frame_input {
  * (VisionImuFrontend.cpp:90-144).  left/right: `batch` images back to back (image s at
  * base + s*image_stride_bytes).  The *_host variant copies from host memory;
  * the *_device variant takes device pointers that must stay valid until the
- * next step of this context has completed.  Both only enqueue work. */
+ * next step of this context has completed.  Both only enqueue work.
+ * RGBD front-end (RgbdVisionImuFrontend::processFirstFrame / processFrame,
+ * RgbdVisionImuFrontend.cpp:184-368): `right` holds the depth images (uint16 or float per
+ * kvfe_depth_params::depth_type) with the same geometry in ELEMENTS: row s starts at
+ * base + (s*image_stride_bytes + y*row_stride_bytes) * sizeof(depth element). */
 KVFE_API kvfe_status kvfe_frontend_step_host(kvfe_ctx* ctx, const uint8_t* left,
                                              const uint8_t* right, size_t row_stride,
                                              size_t image_stride,

@@ -367,4 +367,26 @@ class StereoVisionImuFrontend {
   Context c_;
 };
 
+// RgbdVisionImuFrontend::spinOnce visual path (RgbdVisionImuFrontend.cpp:184-431) for `batch` independent
+// streams: create the context with kvfe_config.frontend_type = KVFE_FRONTEND_RGBD and kvfe_config.depth =
+// CameraParams::DepthParams.  `depth` are the registered depth images (uint16 or float per depth_type) with
+// the geometry of the intensity images in elements.
+class RgbdVisionImuFrontend {
+ public:
+  explicit RgbdVisionImuFrontend(Context ctx) : c_(std::move(ctx)) {}
+  void spinOnce(const uint8_t* intensity, const void* depth, size_t row_stride, size_t image_stride,
+                const kvfe_frame_input* inputs) {
+    c_.check(kvfe_frontend_step_host(c_.get(), intensity, static_cast<const uint8_t*>(depth), row_stride,
+                                     image_stride, inputs),
+             "spinOnce");
+  }
+  void getOutput(int stream, kvfe_frame_output* out) {
+    c_.check(kvfe_frontend_get_output(c_.get(), stream, out), "getOutput");
+  }
+  void reset() { c_.check(kvfe_frontend_reset(c_.get()), "reset"); }
+
+ private:
+  Context c_;
+};
+
 }  // namespace kvfe

@@ -24,7 +24,8 @@ DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = range(3)
 SORTIDX_LIBSTDCXX, SORTIDX_STABLE = range(2)
 TRACKING_VALID, TRACKING_LOW_DISPARITY, TRACKING_FEW_MATCHES, TRACKING_INVALID, TRACKING_DISABLED = range(5)
 RNG_LIBSTDCXX_PRE11, RNG_LIBSTDCXX_11 = range(2)
-FRONTEND_STEREO, FRONTEND_MONO = range(2)
+FRONTEND_STEREO, FRONTEND_MONO, FRONTEND_RGBD = range(3)
+DEPTH_U16, DEPTH_F32 = range(2)
 
 
 class CameraParams(C.Structure):
@@ -122,12 +123,26 @@ class FrontendParams(C.Structure):
     ]
 
 
+class DepthParams(C.Structure):
+    """kvfe_depth_params (CameraParams::DepthParams, CameraParams.h:131-155)"""
+    _fields_ = [
+        ("virtual_baseline", C.c_float), ("depth_to_meters", C.c_float), ("min_depth", C.c_float),
+        ("max_depth", C.c_float), ("is_registered", C.c_int32), ("depth_type", C.c_int32),
+    ]
+
+
+def depth_params_default(depth_type: int = 0) -> "DepthParams":
+    return DepthParams(virtual_baseline=1.0e-2, depth_to_meters=1.0, min_depth=0.0, max_depth=10.0,
+                       is_registered=1, depth_type=depth_type)
+
+
 class Config(C.Structure):
     _fields_ = [
         ("left", CameraParams), ("right", CameraParams), ("params", FrontendParams),
         ("batch", C.c_int32), ("device", C.c_int32),
         ("hip_stream", C.c_void_p),
         ("candidate_capacity", C.c_int32), ("frontend_type", C.c_int32), ("reserved0", C.c_int32),
+        ("depth", DepthParams),
         ("stream_groups", C.c_int32),
     ]
 

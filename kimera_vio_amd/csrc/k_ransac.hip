@@ -401,7 +401,8 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
     // MonoVisionImuFrontend::processFrame resets both statuses on every frame (:264-265)
     if (tid == 0) {
       S.trk_status[2 * (size_t)s] = TRK_INVALID;
-      S.trk_status[2 * (size_t)s + 1] = TRK_DISABLED;
+      // (RgbdVisionImuFrontend::processFrame resets both to INVALID, RgbdVisionImuFrontend.cpp:269-270)
+      S.trk_status[2 * (size_t)s + 1] = P.rgbd ? TRK_INVALID : TRK_DISABLED;
     }
     return;
   }
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
   }
   if (tid == 0) {
     st[0] = TRK_INVALID;                               // :353-354
-    st[1] = P.mono ? TRK_DISABLED : TRK_INVALID;
+    st[1] = (P.mono && !P.rgbd) ? TRK_DISABLED : TRK_INVALID;
   }
   const double* R = S.kf_R_cur + (size_t)s * 9;
   const bool imu_ok = !rs_rot_is_identity(R);

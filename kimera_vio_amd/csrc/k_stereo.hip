@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab 
         const size_t o = so + off0 + wbase + inc - 1;
         const float2 l = ST.left_rect[so + i];
         double uR = __longlong_as_double(0x7ff8000000000000LL);  // quiet NaN
-        if (P.use_stereo_tracking && ST.right_status[so + i] == 0) uR = (double)ST.right_rect[so + i].x;
+        if (P.meas_right && ST.right_status[so + i] == 0) uR = (double)ST.right_rect[so + i].x;
         S.meas_lmk[o] = lmk;
         S.meas_uLuRv[o * 3] = (double)l.x;
         S.meas_uLuRv[o * 3 + 1] = uR;
@@ -521,6 +521,84 @@ __global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab 
     S.frame_count[s] += 1;
     S.flags[s] = flags | FLAG_INIT;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RgbdVisionImuFrontend: the right view is hallucinated from the registered depth image
+// ---------------------------------------------------------------------------------------------
+// DepthFrame::getDetectionMask (DepthFrame.cpp:76-96): cv::inRange(depth, min, max) -> 255 / 0
+__global__ __launch_bounds__(256) void depth_mask_kernel(KParams P, const void* __restrict__ depth,
+                                                         size_t row_stride, size_t img_stride, StreamState S,
+                                                         int act_flag, unsigned char* __restrict__ mask) {
+  const int s = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (!(S.flags[s] & act_flag) || x >= P.W) return;
+  const size_t e = (size_t)s * img_stride + (size_t)y * row_stride + x;
+  bool in;
+  if (P.depth_f32) {
+    const float v = static_cast<const float*>(depth)[e];
+    in = P.mask_lo_f <= v && v <= P.mask_hi_f;
+  } else {
+    const int v = static_cast<const unsigned short*>(depth)[e];
+    in = P.mask_lo_u <= v && v <= P.mask_hi_u;
+  }
+  mask[((size_t)s * P.H + y) * P.W + x] = in ? 255 : 0;
+}
+void launch_depth_mask(const KParams& P, const void* depth, size_t row_stride, size_t img_stride,
+                       const StreamState& S, int act_flag, unsigned char* mask, hipStream_t st) {
+  hipLaunchKernelGGL(depth_mask_kernel, dim3((P.W + 255) / 256, P.H, P.B), dim3(256), 0, st, P, depth, row_stride,
+                     img_stride, S, act_flag, mask);
+}
+
+// RgbdFrame::fillStereoFrame (RgbdFrame.cpp:48-115) with DepthFrame::getDepthAtPoint (DepthFrame.cpp:40-74) and
+// RgbdCamera::distortKeypoints (UndistorterRectifier.cpp:213-228), one thread per keypoint
+__global__ void rgbd_fill_kernel(KParams P, Tables T, const void* __restrict__ depth, size_t row_stride,
+                                 size_t img_stride, FrameTab K, StereoTab ST, StreamState S, int act_flag) {
+  const int s = blockIdx.y;
+  if (!(S.flags[s] & act_flag)) return;
+  int i;
+  if (!stereo_range(K, S, s, STEREO_ALL, blockIdx.x * blockDim.x + threadIdx.x, &i)) return;
+  const size_t o = (size_t)s * P.kcap + i;
+  const int lstat = ST.left_status[o];
+  float2 rr = make_float2(0.f, 0.f), rk = make_float2(0.f, 0.f);
+  int rstat = lstat;
+  double dep = 0.0, p3[3] = {0.0, 0.0, 0.0};
+  if (lstat == 0) {
+    const float2 pt = K.kp[o], l = ST.left_rect[o];
+    const int x = (int)pt.x, y = (int)pt.y;
+    float d = __int_as_float(0x7fc00000);   // quiet NaN
+    if (!(x < 0 || x >= P.W || y < 0 || y >= P.H)) {
+      const size_t e = (size_t)s * img_stride + (size_t)y * row_stride + x;
+      d = P.depth_f32 ? static_cast<const float*>(depth)[e] : (float)static_cast<const unsigned short*>(depth)[e];
+      d *= P.depth_to_m;
+      if (d < P.depth_min) d = __int_as_float(0x7fc00000);
+    }
+    rstat = 3;   // NO_DEPTH
+    if (isfinite(d)) {
+      const float disparity = (float)(P.depth_fx_b / (double)d);
+      const float uR = l.x - disparity;
+      if (!(uR < 0.0f)) {
+        rstat = 0;
+        rr = make_float2(uR, l.y);
+        dep = (double)d;
+        const double v2 = K.versor[o * 3 + 2];
+        for (int c = 0; c < 3; c++) p3[c] = K.versor[o * 3 + c] * (double)d / v2;
+        const int ry = (int)roundf(rr.y), rx = (int)roundf(rr.x);
+        rk = T.map[0][(size_t)ry * P.W + rx];
+      }
+    }
+  }
+  ST.right_rect[o] = rr;
+  ST.right_status[o] = (unsigned char)rstat;
+  ST.depth[o] = dep;
+  ST.right_kp[o] = rk;
+  for (int c = 0; c < 3; c++) ST.kp3d[o * 3 + c] = p3[c];
+}
+void launch_rgbd_fill(const KParams& P, const Tables& T, const void* depth, size_t row_stride, size_t img_stride,
+                      const FrameTab& k, const StereoTab& ST, const StreamState& S, int act_flag, int max_kp,
+                      hipStream_t st) {
+  const int nb = max_kp > 0 ? (max_kp < P.kcap ? max_kp : P.kcap) : P.kcap;
+  hipLaunchKernelGGL(rgbd_fill_kernel, dim3((nb + 63) / 64, P.B), dim3(64), 0, st, P, T, depth, row_stride,
+                     img_stride, k, ST, S, act_flag);
 }
 
 void launch_step_finalize(const KParams& P, const FrameTab& k, const FrameTab& lkf,

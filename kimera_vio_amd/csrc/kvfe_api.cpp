@@ -58,6 +58,8 @@ struct Buffers {  // everything that scales with the number of streams
   unsigned char* eq_in[2] = {nullptr, nullptr};  // staged upload target when equalizeImage is on
   int* eq_hist = nullptr;                        // [2][B][256]
   unsigned char* user_mask = nullptr;
+  unsigned char* depth_slot[2] = {nullptr, nullptr};  // RGBD: ctx-owned depth images of the host-input path
+  unsigned char* depth_mask = nullptr;                 // RGBD: DepthFrame::getDetectionMask, [B][H][W]
   FrameTab ft[3];
   StereoTab st;
   StereoTab lst;  // stereo tables of the last keyframe (geometric outlier rejection reads them)
@@ -197,6 +199,11 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   }
   TRY(dalloc(c, &b.raw_left[2], N * B));
   TRY(dalloc(c, &b.eq_hist, 2 * 256 * B));
+  if (P.rgbd) {
+    const size_t bpp = P.depth_f32 ? 4 : 2;
+    for (int i = 0; i < 2; i++) TRY(dalloc(c, &b.depth_slot[i], N * B * bpp));
+    TRY(dalloc(c, &b.depth_mask, N * B));
+  }
   for (int i = 0; i < 3; i++) {
     TRY(dalloc(c, &b.ft[i].kp, K));
     TRY(dalloc(c, &b.ft[i].lmk, K));
@@ -371,9 +378,23 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     return s;
   };
   if (cfg->batch < 1) return fail("batch must be >= 1", KVFE_ERR_INVALID_ARG);
-  if (cfg->frontend_type != KVFE_FRONTEND_STEREO && cfg->frontend_type != KVFE_FRONTEND_MONO)
+  if (cfg->frontend_type != KVFE_FRONTEND_STEREO && cfg->frontend_type != KVFE_FRONTEND_MONO &&
+      cfg->frontend_type != KVFE_FRONTEND_RGBD)
     return fail("unknown frontend_type", KVFE_ERR_INVALID_ARG);
-  const bool mono = cfg->frontend_type == KVFE_FRONTEND_MONO;
+  const bool rgbd = cfg->frontend_type == KVFE_FRONTEND_RGBD;
+  const bool mono = cfg->frontend_type == KVFE_FRONTEND_MONO || rgbd;   // one camera, R = I, P = K
+  if (rgbd) {
+    const kvfe_depth_params& d = cfg->depth;
+    if (d.depth_type != KVFE_DEPTH_U16 && d.depth_type != KVFE_DEPTH_F32)
+      return fail("bad depth_type", KVFE_ERR_INVALID_ARG);
+    if (!(d.virtual_baseline > 0.f)) return fail("virtual_baseline must be positive", KVFE_ERR_INVALID_ARG);  // CameraParams.cpp:344
+    if (!(d.depth_to_meters > 0.f)) return fail("depth_to_meters must be positive", KVFE_ERR_INVALID_ARG);
+    if (!d.is_registered)
+      return fail("unregistered depth images need cv::rgbd::registerDepth, which is not implemented",
+                  KVFE_ERR_UNSUPPORTED);
+    if (p.stereo.equalize_image) return fail("equalize_image with the RGBD front-end", KVFE_ERR_UNSUPPORTED);
+    if (cfg->stream_groups > 1) return fail("stream_groups > 1 with the RGBD front-end", KVFE_ERR_UNSUPPORTED);
+  }
   if (!mono && (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height))
     return fail("left/right image sizes differ", KVFE_ERR_INVALID_ARG);
   if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
@@ -484,8 +505,22 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.max_kf_ns = p.max_intra_keyframe_time_ns;
   P.max_disp_lkf = p.max_disparity_since_lkf;
   P.min_features = p.min_number_features;
-  P.mono = cfg.frontend_type == KVFE_FRONTEND_MONO ? 1 : 0;
-  if (P.mono) P.use_stereo_tracking = 0;  // mono measurements carry uR = NaN
+  P.rgbd = cfg.frontend_type == KVFE_FRONTEND_RGBD ? 1 : 0;
+  P.mono = (cfg.frontend_type == KVFE_FRONTEND_MONO || P.rgbd) ? 1 : 0;
+  if (P.mono && !P.rgbd) P.use_stereo_tracking = 0;  // mono measurements carry uR = NaN
+  P.meas_right = P.rgbd ? 1 : P.use_stereo_tracking;  // RgbdVisionImuFrontend::fillSmartStereoMeasurements keeps uR
+  if (P.rgbd) {
+    const kvfe_depth_params& d = cfg.depth;
+    P.depth_f32 = d.depth_type == KVFE_DEPTH_F32 ? 1 : 0;
+    P.depth_to_m = d.depth_to_meters;
+    P.depth_min = d.min_depth;
+    P.mask_lo_f = d.min_depth * 1.0f / d.depth_to_meters;   // DepthFrame.cpp:77-78
+    P.mask_hi_f = d.max_depth * 1.0f / d.depth_to_meters;
+    P.mask_lo_u = (int)static_cast<uint16_t>(P.mask_lo_f);
+    P.mask_hi_u = (int)static_cast<uint16_t>(P.mask_hi_f);
+    P.depth_fx_b = cfg.left.intrinsics[0] * d.virtual_baseline;   // RgbdFrame.cpp:65
+    P.baseline = (double)d.virtual_baseline;                      // RgbdCamera::getFakeStereoCalib
+  }
   P.use_ransac = p.use_ransac ? 1 : 0;
   P.ransac_2pt_mono = t.ransac_use_2point_mono ? 1 : 0;
   P.ransac_1pt_stereo = t.ransac_use_1point_stereo ? 1 : 0;
@@ -749,7 +784,9 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   launch_mono_ransac(P, c->T, K, LKF, b.ss, b.rs, st);
   prof_end(c, ST_RANSAC_MONO, st);
   prof_begin(c, ST_MINEIG, st);
-  launch_mineig(P, c->T, left, row_stride, img_stride, nullptr, K, b.ss, b.ds, 1, st);
+  if (P.rgbd)  // left_frame->detection_mask_ = depth_img_.getDetectionMask(...) (RgbdVisionImuFrontend.cpp:200,357)
+    launch_depth_mask(P, right, row_stride, img_stride, b.ss, FLAG_DETECT, b.depth_mask, st);
+  launch_mineig(P, c->T, left, row_stride, img_stride, P.rgbd ? b.depth_mask : nullptr, K, b.ss, b.ds, 1, st);
   prof_end(c, ST_MINEIG, st);
   prof_begin(c, ST_SELECT, st);
   launch_select(P, c->T, K, b.ss, b.ds, -1, st);
@@ -763,7 +800,18 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     prof_begin(c, ST_STEREO, st);
     // (tracked entries, incl. those RANSAC just invalidated, + new corners: at most twice the bound of either)
     launch_undistort_left(P, c->T, K, b.st, b.ss, FLAG_STEREO, std::min(P.kcap, 2 * c->pts_bound), st);
+    if (P.rgbd)  // RgbdFrame::fillStereoFrame: hallucinated right keypoints, depths and 3-D points from the depth image
+      launch_rgbd_fill(P, c->T, right, row_stride, img_stride, K, b.st, b.ss, FLAG_STEREO,
+                       std::min(P.kcap, 2 * c->pts_bound), st);
     prof_end(c, ST_STEREO, st);
+    if (P.rgbd && P.use_ransac) {
+      // outlierRejectionStereo with the fake stereo camera (RgbdVisionImuFrontend.cpp:312-327).  The reference runs
+      // it before detection on the tracked keypoints; their table entries are the same after the second
+      // fillStereoFrame, and it does not touch landmarks, so running it here gives the same result
+      prof_begin(c, ST_RANSAC_STEREO, st);
+      launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st);
+      prof_end(c, ST_RANSAC_STEREO, st);
+    }
     prof_begin(c, ST_FINALIZE, st);
     launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, st);
     prof_end(c, ST_FINALIZE, st);
@@ -939,7 +987,7 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
   kvfe_status s = KVFE_OK;
   if (parent) {
     c->rect = parent->rect;
-  } else if (cfg->frontend_type == KVFE_FRONTEND_MONO) {
+  } else if (cfg->frontend_type == KVFE_FRONTEND_MONO || cfg->frontend_type == KVFE_FRONTEND_RGBD) {
     // Camera::Camera (src/frontend/Camera.cpp:29-49): no rectification, R = I and P = K
     std::memset(&c->rect, 0, sizeof(c->rect));
     const M3 K = camera_matrix(cfg->left);
@@ -948,6 +996,7 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
       for (int j = 0; j < 3; j++) c->rect.P1[i * 4 + j] = c->rect.P2[i * 4 + j] = K.m[i * 3 + j];
     }
     c->cfg.right = cfg->left;
+    if (cfg->frontend_type == KVFE_FRONTEND_RGBD) c->rect.baseline = (double)cfg->depth.virtual_baseline;
   } else {
     s = stereo_rectify(cfg->left, cfg->right, &c->rect);
   }
@@ -1459,7 +1508,7 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
                                       const kvfe_frame_input* inputs) {
   if (!c || !left_dev || !inputs) return KVFE_ERR_INVALID_ARG;
   if (!right_dev) {
-    if (!c->P.mono) return KVFE_ERR_INVALID_ARG;
+    if (!c->P.mono || c->P.rgbd) return KVFE_ERR_INVALID_ARG;
     right_dev = left_dev;  // the mono front-end never reads it
   }
   if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
@@ -1491,7 +1540,7 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
                                     const kvfe_frame_input* inputs) {
   if (!c || !left || !inputs) return KVFE_ERR_INVALID_ARG;
   if (!right) {
-    if (!c->P.mono) return KVFE_ERR_INVALID_ARG;
+    if (!c->P.mono || c->P.rgbd) return KVFE_ERR_INVALID_ARG;
     right = left;
   }
   if (row_stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
@@ -1499,6 +1548,20 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   Buffers& b = c->fe;
   const KParams& P = c->P;
   const size_t N = (size_t)P.W * P.H;
+  if (P.rgbd) {   // left: colour / intensity image; right: depth image with the same geometry in elements
+    const size_t bpp = P.depth_f32 ? 4 : 2;
+    unsigned char* dl = b.raw_left[c->img_step % 3];
+    unsigned char* dd = b.depth_slot[c->img_step % 2];
+    for (int s = 0; s < P.B; s++) {
+      HIPCHK(c, hipMemcpy2DAsync(dl + s * N, P.W, left + s * image_stride, row_stride, P.W, P.H,
+                                 hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpy2DAsync(dd + s * N * bpp, P.W * bpp, right + s * image_stride * bpp, row_stride * bpp,
+                                 P.W * bpp, P.H, hipMemcpyHostToDevice, c->stream));
+    }
+    c->img_step++;
+    c->last_step_staged = false;
+    return do_step(c, dl, dd, P.W, N, inputs);
+  }
   const bool eq = c->cfg.params.stereo.equalize_image != 0;
   unsigned char* dl = b.raw_left[c->img_step % 3];
   unsigned char* dr = b.raw_right2[c->img_step % 2];
@@ -1545,6 +1608,7 @@ static kvfe_status ensure_staging(kvfe_ctx* c) {
 kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* c, int32_t slot, uint8_t** left, uint8_t** right) {
   if (!c || !left || !right || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;  // staged input drives one stream group
+  if (c->P.rgbd) return KVFE_ERR_UNSUPPORTED;             // (depth images: use the host / device step)
   TRY(ensure_staging(c));
   *left = c->stage_host[slot];
   *right = c->stage_host[slot] + (size_t)c->P.W * c->P.H * c->P.B;

@@ -45,6 +45,13 @@ struct KParams {
   float ransac_thr_stereo;      // 1-point voting (float32 Mahalanobis test)
   double ransac_thr_stereo_d;   // 3-point Arun RANSAC (point distance)
   double fy_rect, cx_rect, cy_rect;  // gtsam::Cal3_S2Stereo of the rectified pair (with fx_rect, baseline)
+  // RgbdVisionImuFrontend (frontend_type RGBD; `mono` is set too: one camera, R = I, P = K)
+  int rgbd, depth_f32;               // depth image element type: uint16 (0) or float (1)
+  int meas_right;                    // measurements carry uR of VALID right keypoints (stereo: use_stereo_tracking)
+  float depth_to_m, depth_min;       // DepthParams::depth_to_meters_, min_depth_
+  float mask_lo_f, mask_hi_f;        // DepthFrame::getDetectionMask bounds (float / uint16 images)
+  int mask_lo_u, mask_hi_u;
+  double depth_fx_b;                 // intrinsics[0] * virtual_baseline (RgbdFrame.cpp:65)
   // pyramid geometry: level 0 is the raw image, levels 1..nlevels-1 live in the pyramid buffer
   int nlevels;
   int lw[MAX_LEVELS], lh[MAX_LEVELS], loff[MAX_LEVELS];
@@ -276,6 +283,13 @@ void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned 
                               unsigned char* right_status, double* score, hipStream_t st);
 // end of step: measurements, lkf <- k for keyframes (incl. the stereo tables the next keyframe's
 // outlier rejection reads), rotation bookkeeping
+// RgbdVisionImuFrontend: DepthFrame::getDetectionMask for the streams flagged `act_flag`, and
+// RgbdFrame::fillStereoFrame for all keypoints of those streams (depth: row_stride / img_stride in elements)
+void launch_depth_mask(const KParams& P, const void* depth, size_t row_stride, size_t img_stride,
+                       const StreamState& S, int act_flag, unsigned char* mask, hipStream_t st);
+void launch_rgbd_fill(const KParams& P, const Tables& T, const void* depth, size_t row_stride, size_t img_stride,
+                      const FrameTab& k, const StereoTab& ST, const StreamState& S, int act_flag, int max_kp,
+                      hipStream_t st);
 void launch_step_finalize(const KParams& P, const FrameTab& k, const FrameTab& lkf,
                           const StereoTab& ST, const StereoTab& LST, const StreamState& S,
                           hipStream_t st);

@@ -42,7 +42,8 @@ class Context:
 
     def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
                  batch: int = 1, device: int = 0, hip_stream: int | None = None,
-                 candidate_capacity: int = 0, stream_groups: int = 0, frontend_type: int = 0):
+                 candidate_capacity: int = 0, stream_groups: int = 0, frontend_type: int = 0,
+                 depth: "abi.DepthParams | None" = None):
         self.lib = load()
         cfg = abi.Config()
         cfg.left, cfg.right, cfg.params = left, right, params
@@ -51,6 +52,9 @@ class Context:
         cfg.candidate_capacity = candidate_capacity
         cfg.stream_groups = stream_groups
         cfg.frontend_type = frontend_type
+        if depth is not None:   # RgbdVisionImuFrontend: CameraParams::DepthParams of `left`
+            cfg.depth = depth
+        self.depth_params = depth
         self.cfg = cfg
         self.left, self.right, self.params = left, right, params
         self.batch = batch
@@ -290,9 +294,17 @@ class Context:
         return arr
 
     def step_host(self, lefts, rights, inputs):
-        """lefts/rights: uint8 arrays [batch, H, W] in host memory (rights = None for the mono front-end)."""
+        """lefts/rights: uint8 arrays [batch, H, W] in host memory (rights = None for the mono front-end;
+        the RGBD front-end takes the depth images, uint16 or float32 per DepthParams.depth_type)."""
         lefts = np.ascontiguousarray(lefts, np.uint8)
         assert lefts.shape == (self.batch, self.h, self.w)
+        if self.cfg.frontend_type == abi.FRONTEND_RGBD:
+            dt = np.float32 if self.depth_params.depth_type == abi.DEPTH_F32 else np.uint16
+            depths = np.ascontiguousarray(rights, dt)
+            assert depths.shape == lefts.shape
+            self._chk(self.lib.kvfe_frontend_step_host(self._h, _p(lefts), _p(depths), self.w, self.w * self.h,
+                                                       inputs), "frontend_step_host")
+            return
         if rights is not None:
             rights = np.ascontiguousarray(rights, np.uint8)
             assert rights.shape == lefts.shape

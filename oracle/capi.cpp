@@ -364,6 +364,12 @@ KVO_API kvo_frontend* kvo_frontend_create_mono(const kvfe_camera_params* cam,
   f->fe.init(*cam, *cam, *p, true);
   return f;
 }
+KVO_API kvo_frontend* kvo_frontend_create_rgbd(const kvfe_camera_params* cam, const kvfe_frontend_params* p,
+                                               const kvfe_depth_params* dp) {
+  kvo_frontend* f = new kvo_frontend;
+  f->fe.initRgbd(*cam, *p, *dp);
+  return f;
+}
 KVO_API void kvo_frontend_destroy(kvo_frontend* f) { delete f; }
 KVO_API void kvo_frontend_process(kvo_frontend* f, const uint8_t* left, const uint8_t* right,
                                   size_t stride, const kvfe_frame_input* in) {

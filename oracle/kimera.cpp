@@ -410,8 +410,9 @@ bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int
 bool featureDetection(const uint8_t* img, int w, int h, size_t stride,
                       const std::vector<Point2f>& tracked, int need_n_corners,
                       const kvfe_detector_params& p, std::vector<Point2f>& new_corners,
-                      std::vector<Point2f>* raw_gftt) {
-  std::vector<uint8_t> mask((size_t)w * h, 255);
+                      std::vector<Point2f>* raw_gftt, const uint8_t* detection_mask) {
+  std::vector<uint8_t> mask((size_t)w * h, 255);   // FeatureDetector.cpp:186-190
+  if (detection_mask) std::memcpy(mask.data(), detection_mask, mask.size());
   for (const Point2f& kp : tracked)
     ocv::circle_filled(mask.data(), w, h, w, ocv::cvRoundf(kp.x), ocv::cvRoundf(kp.y),
                        p.min_distance, 0);
@@ -682,7 +683,7 @@ void Frontend::init(const kvfe_camera_params& l, const kvfe_camera_params& r,
 }
 
 // FeatureDetector::featureDetection(Frame*, R) (FeatureDetector.cpp:94-163)
-void Frontend::featureDetectionFrame(Frame& f, int* n_detected) {
+void Frontend::featureDetectionFrame(Frame& f, int* n_detected, const uint8_t* detection_mask) {
   int n_existing = 0;
   std::vector<Point2f> tracked;
   for (size_t i = 0; i < f.landmarks.size(); ++i) {
@@ -694,7 +695,7 @@ void Frontend::featureDetectionFrame(Frame& f, int* n_detected) {
   }
   int need = std::max(p.detector.max_features_per_frame - n_existing, 0);
   std::vector<Point2f> corners;
-  featureDetection(f.img.data(), f.w, f.h, f.w, tracked, need, p.detector, corners);
+  featureDetection(f.img.data(), f.w, f.h, f.w, tracked, need, p.detector, corners, nullptr, detection_mask);
   for (const Point2f& c : corners) {
     f.landmarks.push_back(lmk_id);
     f.landmarks_age.push_back(1);
@@ -814,14 +815,18 @@ void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
   k.right_img.resize((size_t)w * h);
   for (int y = 0; y < h; y++) {
     std::memcpy(&k.left.img[(size_t)y * w], left + (size_t)y * stride, w);
-    std::memcpy(&k.right_img[(size_t)y * w], right + (size_t)y * stride, w);
+    if (!rgbd) std::memcpy(&k.right_img[(size_t)y * w], right + (size_t)y * stride, w);
   }
-  if (p.stereo.equalize_image) {  // UtilsOpenCV::ReadAndConvertToGrayScale(name, equalize) on both views
+  if (p.stereo.equalize_image && !rgbd) {  // UtilsOpenCV::ReadAndConvertToGrayScale(name, equalize) on both views
     ocv::equalizeHist(k.left.img.data(), w, h, w, k.left.img.data(), w);
     ocv::equalizeHist(k.right_img.data(), w, h, w, k.right_img.data(), w);
   }
   meas_lmk.clear();
   meas_uLuRv.clear();
+  if (rgbd) {
+    processRgbd(in, right, stride);
+    return;
+  }
   if (mono) {
     processMono(in);
     return;
@@ -940,6 +945,168 @@ void Frontend::processMono(const kvfe_frame_input& in) {
       meas_uLuRv.push_back(std::numeric_limits<double>::quiet_NaN());
       meas_uLuRv.push_back((double)k.left_kp_rect[i].kp.y);
     }
+    for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    k.left.isKeyframe = false;
+    std::memcpy(keyframe_R_ref_frame, in.keyframe_R_cur_frame, sizeof(keyframe_R_ref_frame));
+  }
+  last_is_keyframe = new_keyframe;
+  km1 = k;
+  km1_is_lkf = new_keyframe;
+  ++frame_count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RgbdVisionImuFrontend (src/frontend/RgbdVisionImuFrontend.cpp:184-431)
+// ---------------------------------------------------------------------------------------------
+void Frontend::initRgbd(const kvfe_camera_params& c, const kvfe_frontend_params& fp,
+                        const kvfe_depth_params& dp) {
+  init(c, c, fp, true);   // RgbdCamera is a Camera: undistortion with R = I, P = K like the mono front-end
+  rgbd = true;
+  depth_params = dp;
+  // RgbdCamera::getFakeStereoCalib (RgbdCamera.cpp:92-100): Cal3_S2Stereo(fx, fy, skew, px, py, virtual baseline)
+  cam.rect.baseline = (double)dp.virtual_baseline;
+}
+
+// DepthFrame::getDetectionMask (DepthFrame.cpp:76-96): cv::inRange(depth, min, max)
+void Frontend::depthDetectionMask(const void* depth, size_t stride, std::vector<uint8_t>& mask) const {
+  const int w = cam.w, h = cam.h;
+  mask.assign((size_t)w * h, 0);
+  const float mn = depth_params.min_depth * 1.0f / depth_params.depth_to_meters;
+  const float mx = depth_params.max_depth * 1.0f / depth_params.depth_to_meters;
+  if (depth_params.depth_type == KVFE_DEPTH_F32) {
+    const float* d = static_cast<const float*>(depth);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        const float v = d[(size_t)y * stride + x];
+        mask[(size_t)y * w + x] = (mn <= v && v <= mx) ? 255 : 0;
+      }
+  } else {
+    const uint16_t lo = static_cast<uint16_t>(mn), hi = static_cast<uint16_t>(mx);
+    const uint16_t* d = static_cast<const uint16_t*>(depth);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        const uint16_t v = d[(size_t)y * stride + x];
+        mask[(size_t)y * w + x] = (lo <= v && v <= hi) ? 255 : 0;
+      }
+  }
+}
+
+// RgbdFrame::fillStereoFrame (RgbdFrame.cpp:48-115) + DepthFrame::getDepthAtPoint (DepthFrame.cpp:40-74)
+void Frontend::fillStereoFrame(StereoFrame& sf, const void* depth, size_t stride) const {
+  const int w = cam.w, h = cam.h;
+  const size_t n = sf.left_kp_rect.size();
+  const double fx_b = cam.left.intrinsics[0] * depth_params.virtual_baseline;
+  sf.right_kp_rect.assign(n, StatusKeypoint{0, {0.f, 0.f}});
+  sf.depth.assign(n, 0.0);
+  sf.kp3d.assign(n * 3, 0.0);
+  sf.right_kp.assign(n, Point2f{0.f, 0.f});
+  for (size_t i = 0; i < n; ++i) {
+    const StatusKeypoint& lk = sf.left_kp_rect[i];
+    if (lk.status != KVFE_KP_VALID) {
+      sf.right_kp_rect[i].status = lk.status;
+      continue;
+    }
+    const Point2f pt = sf.left.keypoints[i];
+    const int x = static_cast<int>(pt.x), y = static_cast<int>(pt.y);
+    float d = std::numeric_limits<float>::quiet_NaN();
+    if (!(x < 0 || x >= w || y < 0 || y >= h)) {
+      if (depth_params.depth_type == KVFE_DEPTH_F32)
+        d = static_cast<const float*>(depth)[(size_t)y * stride + x];
+      else
+        d = static_cast<const uint16_t*>(depth)[(size_t)y * stride + x];
+      d *= depth_params.depth_to_meters;
+      if (d < depth_params.min_depth) d = std::numeric_limits<float>::quiet_NaN();
+    }
+    if (!std::isfinite(d)) {
+      sf.right_kp_rect[i].status = KVFE_KP_NO_DEPTH;
+      continue;
+    }
+    const float disparity = (float)(fx_b / d);
+    const float uR = lk.kp.x - disparity;
+    if (uR < 0.0f) {
+      sf.right_kp_rect[i].status = KVFE_KP_NO_DEPTH;
+      continue;
+    }
+    sf.right_kp_rect[i] = StatusKeypoint{KVFE_KP_VALID, {uR, lk.kp.y}};
+    sf.depth[i] = d;
+    const double* v = &sf.left.versors[3 * i];
+    for (int c = 0; c < 3; c++) sf.kp3d[3 * i + c] = v[c] * (double)d / v[2];
+  }
+  // RgbdCamera::distortKeypoints -> UndistorterRectifier::distortUnrectifyKeypoints (:213-228)
+  for (size_t i = 0; i < n; ++i) {
+    if (sf.right_kp_rect[i].status != KVFE_KP_VALID) continue;
+    const Point2f px = sf.right_kp_rect[i].kp;
+    const int ry = (int)std::round(px.y), rx = (int)std::round(px.x);
+    sf.right_kp[i] = Point2f{cam.map_x[0][(size_t)ry * w + rx], cam.map_y[0][(size_t)ry * w + rx]};
+  }
+}
+
+void Frontend::processRgbd(const kvfe_frame_input& in, const void* depth, size_t stride) {
+  std::vector<uint8_t> mask;
+  auto undistortKeypoints = [&]() {  // Camera::undistortKeypoints (Camera.cpp:110-133)
+    cam.undistortRectifyLeftKeypoints(k.left.keypoints, k.left_kp_rect);
+  };
+  if (!initialized) {   // processFirstFrame (:184-217)
+    k.left.isKeyframe = true;
+    depthDetectionMask(depth, stride, mask);
+    featureDetectionFrame(k.left, &k.n_detected, mask.data());
+    undistortKeypoints();
+    fillStereoFrame(k, depth, stride);
+    km1 = k;
+    lkf = k;
+    km1_is_lkf = true;
+    ++frame_count;
+    initialized = true;
+    last_is_keyframe = true;
+    for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  // processFrame (:236-298)
+  double RrefT[9], ref_R_cur[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RrefT[i * 3 + j] = keyframe_R_ref_frame[j * 3 + i];
+  mat3_mul(RrefT, in.keyframe_R_cur_frame, ref_R_cur);
+  featureTracking(km1.left, k.left, ref_R_cur);
+  if (km1_is_lkf) lkf.left.landmarks = km1.left.landmarks;
+  k.n_tracked = (int)k.left.keypoints.size();
+  undistortKeypoints();
+  // the stereo tables of a non-keyframe stay those of the constructor (RgbdFrame::getStereoFrame): empty
+  k.right_kp_rect.assign(k.left_kp_rect.size(), StatusKeypoint{0, {0.f, 0.f}});
+  k.depth.assign(k.left_kp_rect.size(), 0.0);
+  k.right_kp.assign(k.left_kp_rect.size(), Point2f{0.f, 0.f});
+  k.kp3d.assign(k.left_kp_rect.size() * 3, 0.0);
+  tracker_status.mono = KVFE_TRACKING_INVALID;
+  tracker_status.stereo = KVFE_TRACKING_INVALID;
+  const bool new_keyframe = shouldBeKeyframe(k.left, lkf.left);
+  if (new_keyframe) {   // handleKeyframe (:300-368)
+    if (p.use_ransac) {
+      outlierRejectionMono(in.keyframe_R_cur_frame, lkf.left, k.left);
+      fillStereoFrame(k, depth, stride);
+      if (p.use_stereo_tracking)
+        outlierRejectionStereo(in.keyframe_R_cur_frame, lkf, k);
+      else
+        tracker_status.stereo = KVFE_TRACKING_INVALID;
+    } else {
+      tracker_status.mono = KVFE_TRACKING_DISABLED;
+      tracker_status.stereo = KVFE_TRACKING_DISABLED;
+    }
+    k.left.isKeyframe = true;
+    depthDetectionMask(depth, stride, mask);
+    featureDetectionFrame(k.left, &k.n_detected, mask.data());
+    undistortKeypoints();
+    fillStereoFrame(k, depth, stride);
+    // fillSmartStereoMeasurements (:370-399)
+    for (size_t i = 0; i < k.left.landmarks.size(); ++i) {
+      if (k.left.landmarks[i] == -1) continue;
+      meas_lmk.push_back(k.left.landmarks[i]);
+      meas_uLuRv.push_back((double)k.left_kp_rect[i].kp.x);
+      meas_uLuRv.push_back(k.right_kp_rect[i].status == KVFE_KP_VALID
+                               ? (double)k.right_kp_rect[i].kp.x
+                               : std::numeric_limits<double>::quiet_NaN());
+      meas_uLuRv.push_back((double)k.left_kp_rect[i].kp.y);
+    }
+    lkf = k;
     for (int i = 0; i < 9; i++) keyframe_R_ref_frame[i] = (i % 4 == 0) ? 1.0 : 0.0;
   } else {
     k.left.isKeyframe = false;

@@ -65,7 +65,8 @@ bool suppressNonMax(const std::vector<Point2f>& keypoints, int numRetPoints, int
 bool featureDetection(const uint8_t* img, int w, int h, size_t stride,
                       const std::vector<Point2f>& tracked, int need_n_corners,
                       const kvfe_detector_params& p, std::vector<Point2f>& new_corners,
-                      std::vector<Point2f>* raw_gftt = nullptr);
+                      std::vector<Point2f>* raw_gftt = nullptr,
+                      const uint8_t* detection_mask = nullptr /* Frame::detection_mask_, w*h */);
 
 // OpticalFlowPredictor::predictSparseFlow (OpticalFlowPredictor.cpp:27-33,70-126)
 void predictSparseFlow(int type, const double K[9], int w, int h, const Point2f* prev, int n,
@@ -187,14 +188,19 @@ struct Frontend {
   TrackerStatusSummary tracker_status;  // tracker_status_summary_ (persists between keyframes)
 
   bool mono = false;  // MonoVisionImuFrontend (src/frontend/MonoVisionImuFrontend.cpp:196-335)
+  bool rgbd = false;  // RgbdVisionImuFrontend (src/frontend/RgbdVisionImuFrontend.cpp:184-368)
+  kvfe_depth_params depth_params{};
   void init(const kvfe_camera_params& l, const kvfe_camera_params& r,
             const kvfe_frontend_params& fp, bool mono_frontend = false);
+  void initRgbd(const kvfe_camera_params& cam, const kvfe_frontend_params& fp, const kvfe_depth_params& dp);
+  // stereo / mono: right = right image (ignored by mono); rgbd: right = depth image (uint16 or float, `stride`
+  // elements per row)
   void process(const uint8_t* left, const uint8_t* right, size_t stride,
                const kvfe_frame_input& in);
   const StereoFrame& current() const { return km1; }
 
  private:
-  void featureDetectionFrame(Frame& f, int* n_detected);
+  void featureDetectionFrame(Frame& f, int* n_detected, const uint8_t* detection_mask = nullptr);
   void featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]);
   bool shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) const;
   void getSmartStereoMeasurements(const StereoFrame& sf);
@@ -202,6 +208,9 @@ struct Frontend {
   void outlierRejectionMono(const double R[9], Frame& lkf_left, Frame& k_left);
   void outlierRejectionStereo(const double R[9], StereoFrame& lkf_sf, StereoFrame& k_sf);
   void processMono(const kvfe_frame_input& in);
+  void processRgbd(const kvfe_frame_input& in, const void* depth, size_t depth_stride);
+  void fillStereoFrame(StereoFrame& sf, const void* depth, size_t depth_stride) const;
+  void depthDetectionMask(const void* depth, size_t depth_stride, std::vector<uint8_t>& mask) const;
 };
 
 // gtsam::Rot3::equals(Rot3(), 1e-9) as used for `given_rot` (VisionImuFrontend.cpp:97,125)

@@ -112,6 +112,9 @@ def lib() -> C.CDLL:
                                       C.POINTER(abi.FrontendParams)]
     L.kvo_frontend_create_mono.restype = C.c_void_p
     L.kvo_frontend_create_mono.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.FrontendParams)]
+    L.kvo_frontend_create_rgbd.restype = C.c_void_p
+    L.kvo_frontend_create_rgbd.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.FrontendParams),
+                                           C.POINTER(abi.DepthParams)]
     L.kvo_frontend_destroy.argtypes = [C.c_void_p]
     L.kvo_frontend_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.POINTER(abi.FrameInput)]
@@ -525,10 +528,13 @@ class Frontend:
     """kimera::Frontend of the oracle (StereoVisionImuFrontend incl. the useRANSAC branch)."""
 
     def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
-                 mono: bool = False):
+                 mono: bool = False, depth: "abi.DepthParams | None" = None):
         self.params = params
         self.w, self.h = left.width, left.height
-        if mono:  # MonoVisionImuFrontend: `right` is ignored
+        self.depth = depth
+        if depth is not None:  # RgbdVisionImuFrontend: process(left, depth image, ...)
+            self._h = lib().kvo_frontend_create_rgbd(C.byref(left), C.byref(params), C.byref(depth))
+        elif mono:  # MonoVisionImuFrontend: `right` is ignored
             self._h = lib().kvo_frontend_create_mono(C.byref(left), C.byref(params))
         else:
             self._h = lib().kvo_frontend_create(C.byref(left), C.byref(right), C.byref(params))
@@ -540,7 +546,11 @@ class Frontend:
             self._h = None
 
     def process(self, left, right, timestamp_ns, R=None, force_keyframe=False) -> dict:
-        left, right = _img(left), _img(right)
+        left = _img(left)
+        if self.depth is not None:
+            right = np.ascontiguousarray(right, np.float32 if self.depth.depth_type == abi.DEPTH_F32 else np.uint16)
+        else:
+            right = _img(right)
         fi = abi.FrameInput()
         fi.timestamp_ns = int(timestamp_ns)
         Rm = np.eye(3) if R is None else np.asarray(R, np.float64).reshape(3, 3)

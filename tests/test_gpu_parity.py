@@ -782,6 +782,105 @@ def test_mono_frontend_sequence(seq, use_ransac, force_kf):
 
 
 # ---------------------------------------------------------------------------------------------
+# RgbdVisionImuFrontend: depth image instead of a right camera
+# ---------------------------------------------------------------------------------------------
+def _synthetic_depth(h, w, t, depth_type, seed=0):
+    """smooth scene depth 1.2-6 m that drifts with the frame index, with holes (0 / NaN), a band beyond
+    max_depth and a band below min_depth; uint16 millimetres or float32 metres"""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    d = 3.5 + 2.2 * np.sin(xx / 97.0 + 0.05 * t) * np.cos(yy / 71.0) + 0.002 * yy
+    d[60:90, 100:260] = 14.0            # beyond max_depth 10 m: masked out of detection, still a valid depth
+    d[300:330, 400:520] = 0.05          # below min_depth
+    holes = rng.randint(0, 100, (h, w)) < 4
+    if depth_type == abi.DEPTH_F32:
+        d = d.astype(np.float32)
+        d[holes] = np.nan
+        d[200:205, 600:640] = np.inf
+        return d
+    d = np.clip(np.rint(d * 1000.0), 0, 65535).astype(np.uint16)
+    d[holes] = 0
+    return d
+
+
+@pytest.mark.parametrize("depth_type,use_ransac,one_point", [(abi.DEPTH_U16, 1, 1), (abi.DEPTH_F32, 1, 0),
+                                                              (abi.DEPTH_U16, 0, 1)])
+def test_rgbd_frontend_sequence(seq, depth_type, use_ransac, one_point):
+    """RgbdVisionImuFrontend::processFirstFrame / processFrame / handleKeyframe: detection under the
+    depth-range mask, tracking, undistortion with R = I / P = K, RgbdFrame::fillStereoFrame (hallucinated
+    right keypoints, depths, 3-D points, distorted right pixels), mono + stereo outlier rejection with the
+    fake stereo camera, fillSmartStereoMeasurements — all identical to the oracle, two streams."""
+    L, _ = euroc_cams()
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=use_ransac)
+    p.detector.max_features_per_frame = 200
+    p.tracker.ransac_use_1point_stereo = one_point
+    p.tracker.ransac_threshold_stereo = 0.5
+    dp = abi.depth_params_default(depth_type)
+    dp.virtual_baseline = 0.05
+    dp.min_depth = 0.3
+    if depth_type == abi.DEPTH_U16:
+        dp.depth_to_meters = 0.001
+    TL = np.array(L.body_pose_cam).reshape(4, 4)
+    camR = [TL[:3, :3].T @ Rb @ TL[:3, :3] for Rb in seq["body_R"]]
+    B = 2
+    fe = [O.Frontend(L, L, p, depth=dp) for _ in range(B)]
+    c = F.Context(L, L, p, batch=B, frontend_type=abi.FRONTEND_RGBD, depth=dp)
+    h, w = seq["lefts"][0].shape
+    try:
+        kf = [0] * B
+        n_kf = 0
+        for i in range(9):
+            idx = [i, 8 - i]
+            Rs = [camR[kf[s]].T @ camR[idx[s]] for s in range(B)]
+            ts = [int(seq["ts"][i])] * B
+            lefts = np.stack([seq["lefts"][j] for j in idx])
+            depths = np.stack([_synthetic_depth(h, w, j, depth_type, seed=j) for j in idx])
+            c.step_host(lefts, depths, c.make_inputs(ts, Rs, [0] * B))
+            for s in range(B):
+                exp = fe[s].process(lefts[s], depths[s], ts[s], Rs[s], False)
+                got = c.get_output(s)
+                for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected", "n_measurements",
+                          "tracking_status_mono", "tracking_status_stereo", "nr_mono_putatives", "nr_mono_inliers",
+                          "nr_stereo_putatives", "nr_stereo_inliers"):
+                    assert got[k] == exp[k], (i, s, k, got[k], exp[k])
+                for k in ("landmarks", "landmarks_age", "keypoints", "versors", "lkf_T_k_mono", "lkf_T_k_stereo",
+                          "info_mat_stereo_translation"):
+                    assert np.array_equal(got[k], exp[k]), (i, s, k)
+                if exp["is_keyframe"]:
+                    for k in ("left_rect_xy", "left_status", "right_rect_xy", "right_status", "depth", "right_xy",
+                              "keypoints_3d", "meas_landmark"):
+                        assert np.array_equal(got[k], exp[k]), (i, s, k)
+                    assert np.array_equal(got["meas_uL_uR_v"], exp["meas_uL_uR_v"], equal_nan=True)
+                    kf[s] = idx[s]
+                    n_kf += 1
+                    if i == 8:
+                        st = exp["right_status"]
+                        assert (st == 0).sum() > 50 and (st == 3).sum() > 0     # VALID and NO_DEPTH both occur
+                        m = exp["meas_uL_uR_v"]
+                        assert np.isnan(m[:, 1]).any() and (~np.isnan(m[:, 1])).any()
+                if not use_ransac and exp["is_keyframe"] and i > 0:
+                    assert got["tracking_status_mono"] == got["tracking_status_stereo"] == abi.TRACKING_DISABLED
+        assert n_kf >= 4
+    finally:
+        c.close()
+
+
+def test_rgbd_unsupported_configurations():
+    L, _ = euroc_cams()
+    p = euroc_params()
+    dp = abi.depth_params_default()
+    dp.is_registered = 0            # needs cv::rgbd::registerDepth
+    with pytest.raises(F.KvfeError) as e:
+        F.Context(L, L, p, frontend_type=abi.FRONTEND_RGBD, depth=dp)
+    assert e.value.status == abi.KVFE_ERR_UNSUPPORTED
+    dp = abi.depth_params_default()
+    dp.virtual_baseline = 0.0       # CHECK_GT(virtual_baseline_, 0.0) (CameraParams.cpp:344)
+    with pytest.raises(F.KvfeError) as e:
+        F.Context(L, L, p, frontend_type=abi.FRONTEND_RGBD, depth=dp)
+    assert e.value.status == abi.KVFE_ERR_INVALID_ARG
+
+
+# ---------------------------------------------------------------------------------------------
 # equidistant distortion model (cv::fisheye; params/RealSenseIR, tests/data/ForStereoFrame/*_fisheye.yaml)
 # ---------------------------------------------------------------------------------------------
 def _fisheye_cams():
