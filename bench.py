@@ -348,12 +348,32 @@ def dense_stereo(F, P, synth, L, R, p, dev, args):
     W, H, D = args.width, args.height, dp.num_disparities
     w1 = W - (dp.min_disparity + D)
     vol = H * w1 * D * 2.0                      # one int16 cost volume
-    agg_bytes = 8 * vol + vol + 7 * 2 * vol     # 8 reads of C, one sum write, seven sum read-modify-writes
+    npx = float(W) * H
+    # algorithmic bytes per pair: pixel records, cost -> row sums -> C (write + read each), eight
+    # path sweeps (C read, one sum write, seven sum read-modify-writes), selection, the small disparity passes
+    agg_bytes = 8 * vol + vol + 7 * 2 * vol
+    alg = (2 * npx + 16 * npx) + (16 * npx + vol) + 2 * vol + 2 * vol + agg_bytes + (vol + 2 * npx) + 24 * npx
+    traffic = None
+    try:   # HBM-side bytes of the same kernels from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+            pmc = json.load(f)
+        tb = sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 for k, v in pmc.items()
+                 if k.startswith(("dense_", "speckle_")))
+        if tb > 0 and (W, H) == (752, 480):
+            traffic = round(tb / n)
+    except OSError:
+        pass
+    ach = alg / (ms / cnt * 1e-3) / 1e9
     valid = float(np.mean(disp[0] != (dp.min_disparity - 1) * 16))
     return {"workload": f"cv::StereoSGBM MODE_HH, block {dp.sad_window_size}, {D} disparities, {W}x{H}, "
                         f"{n} rectified pairs per call",
             "value": round(cnt / (ms * 1e-3), 2), "unit": "stereo-pairs/s", "ms_per_pair": round(ms / cnt, 4),
-            "alg_bytes_per_pair_aggregation": round(agg_bytes), "valid_fraction_pair0": round(valid, 3)}
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                         "alg_bytes_per_pair": round(alg), "alg_bytes_per_pair_aggregation": round(agg_bytes),
+                         "note": "whole kernel sequence of one pair (HIP events inside libkvfe); traffic = PMC bytes "
+                                 "per pair of the dense_* / speckle_* kernels"},
+            "valid_fraction_pair0": round(valid, 3)}
 
 
 def cpu_baseline(P, synth, L, R, p, args):

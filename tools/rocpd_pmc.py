@@ -13,7 +13,7 @@ def main():
         q = ("select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection "
              "group by 1, 2")
         for k, cn, n, v, d in c.execute(q):
-            short = k.split("(")[0].replace("void ", "").replace("kvfe::", "")
+            short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("kvfe::", "")
             a = agg.setdefault(short, {})
             a[cn] = v / n
             a["_n"] = n

@@ -14,7 +14,7 @@ def main():
     rows = rows[first:first + count]
     t0 = rows[0][1]
     for name, s, e, q, st in rows:
-        short = name.split("(")[0].replace("void ", "").replace("kvfe::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("kvfe::", "")
         print(f"{(s - t0) / 1e3:10.1f} us  +{(e - s) / 1e3:8.1f} us  q{q} s{st}  {short}")
 
 

@@ -13,7 +13,7 @@ def per_kernel(db, counter):
                      "order by start", (counter,)).fetchall()
     agg = {}
     for name, v, _ in rows:
-        short = name.split("(")[0].replace("void ", "").replace("kvfe::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("kvfe::", "")
         agg.setdefault(short, []).append(v)
     out = {}
     for k, vals in agg.items():
