@@ -404,10 +404,41 @@ def cpu_baseline(P, synth, L, R, p, args):
             kf_t, last_kf = t, i
     fe = O.Frontend(L, R, p)
     secs = fe.time_sequence(lefts, rights, inputs)
-    return {"value": round(n / secs, 3), "unit": "stereo-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{n} consecutive stereo pairs of one synthetic {args.width}x{args.height} stream, "
-                      f"{args.features} features, mode={args.mode}, {secs:.1f} s on one host core "
-                      f"(scalar OpenCV-faithful restatement, no SIMD/IPP; host has {os.cpu_count()} cores)"}
+    out = {"value": round(n / secs, 3), "unit": "stereo-pairs/s", "cores": 1, "kind": "port",
+           "sample": f"{n} consecutive stereo pairs of one synthetic {args.width}x{args.height} stream, "
+                     f"{args.features} features, mode={args.mode}, {secs:.1f} s on one host core "
+                     f"(scalar OpenCV-faithful restatement, no SIMD/IPP; host has {os.cpu_count()} cores)"}
+    # independent streams on the host's cores (one single-threaded front-end per core, the
+    # many-sequence mode on the CPU), bounded to a few seconds
+    try:
+        import multiprocessing as mp
+        C_ = max(1, min(os.cpu_count() or 1, 64))
+        m = max(20, min(n, 80))
+        ctx = mp.get_context("fork")
+        with ctx.Pool(C_, initializer=_cpu_worker_init, initargs=(L, R, p, lefts[:m], rights[:m], inputs[:m])) as pool:
+            pool.map(_cpu_worker_run, range(C_))            # warm: library load, first-touch
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker_run, range(C_))
+            wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(C_ * m / wall, 2), "unit": "stereo-pairs/s", "cores": C_,
+                            "sample": f"{C_} processes x {m} pairs of the same stream, {wall:.1f} s wall"}
+    except Exception as e:  # the single-core figure above is the contract; this one is informative
+        out["all_cores"] = {"error": repr(e)}
+    return out
+
+
+_CPU_W = {}
+
+
+def _cpu_worker_init(L, R, p, lefts, rights, inputs):
+    import oracle_lib as O
+    _CPU_W.update(L=L, R=R, p=p, lefts=lefts, rights=rights, inputs=inputs, O=O)
+
+
+def _cpu_worker_run(_):
+    w = _CPU_W
+    fe = w["O"].Frontend(w["L"], w["R"], w["p"])
+    return fe.time_sequence(w["lefts"], w["rights"], w["inputs"])
 
 
 if __name__ == "__main__":
