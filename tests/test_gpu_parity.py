@@ -1071,3 +1071,31 @@ def test_backproject_disparity_to_3d_bit_exact(ctx, ocam, seq):
     p = got[v, u]
     assert np.allclose(fx * p[:, 0] / p[:, 2] + cx, u, atol=1e-2)
     assert np.allclose(fx * p[:, 1] / p[:, 2] + cy, v, atol=1e-2)
+
+
+@pytest.mark.parametrize("w,h", [(323, 241), (1280, 720)])
+def test_dense_stereo_other_image_sizes(w, h):
+    """odd sizes (tiles / chunks not multiples of 64 / 32) and BASELINE's C5 size: SGBM MODE_HH, MODE_SGBM and
+    StereoBM identical to the oracle on a synthetic pair with a known shift"""
+    import bench
+    L, R = bench.make_cameras(P, G, w, h)
+    c = F.Context(L, R, euroc_params())
+    try:
+        tex = synth.base_texture(w + 80, h, 11)
+        base = np.clip(np.rint(tex[96:96 + h, 60:60 + w + 70]), 0, 255).astype(np.uint8)
+        left, right = np.ascontiguousarray(base[:, :w]), np.ascontiguousarray(base[:, 13:13 + w])
+        roi1, roi2 = list(c.rect.roi1), list(c.rect.roi2)
+        for kw in (dict(), dict(use_mode_hh=0), dict(use_sgbm=0)):
+            if (w, h) == (1280, 720) and kw:
+                continue   # (the oracle takes ~1 s per SGBM call at this size: the default configuration only)
+            dp = abi.dense_stereo_params_default()
+            for k, v in kw.items():
+                setattr(dp, k, v)
+            exp = O.dense_stereo_reconstruction(left, right, dp, roi1, roi2)
+            got = c.dense_stereo_reconstruction(left, right, dp)
+            assert np.array_equal(got, exp), (w, h, kw, np.count_nonzero(got != exp))
+            valid = got != (dp.min_disparity - 1) * 16
+            if dp.use_sgbm:
+                assert valid.mean() > 0.4 and np.mean(np.abs(got[valid] / 16.0 - 13) <= 1.0) > 0.9
+    finally:
+        c.close()
