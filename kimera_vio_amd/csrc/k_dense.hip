@@ -186,11 +186,14 @@ __global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const sh
 // S = saturate_cast<short>(S + L0 + L1 + L2 + L3) per pass; every L_r >= 0 (C >= P2 and the min term is
 // >= min_k L_r - delta = -P2), so saturate(saturate(A) + B) == min(32767, A + B) and the order in which the
 // eight directions are accumulated does not matter.
-template <int SX, int SY, bool FIRST>
-__global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, const short* __restrict__ Cv,
-                                                              unsigned short* __restrict__ sum) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int path = blockIdx.x * 4 + wv, pair = blockIdx.y;
+// MODE: 0 = this sweep writes the sum, 1 = read-modify-write (sweeps launched one after the other),
+// 2 = packed 32-bit atomic adds of two u16 sums (all sweeps of a pair in one launch, see below)
+enum { AGG_WRITE = 0, AGG_RMW = 1, AGG_ATOMIC = 2 };
+template <int SX, int SY, int MODE>
+__device__ __forceinline__ void dense_aggregate_path(const DenseParams& P, const short* __restrict__ Cv,
+                                                     unsigned short* __restrict__ sum, int path, int pair) {
+  const int lane = threadIdx.x & 63;
+  constexpr bool FIRST = MODE != AGG_RMW;   // no read of the running sum
   const int W1 = P.width1, H = P.H;
   int x, y, len;
   if (SY == 0) {
@@ -253,9 +256,42 @@ __global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, con
       if (live) {   // wave-uniform
         Lp = act ? L : MAXC;
         minp = wave_min(Lp);
-        if (act) sp[(long)t * step] = (unsigned short)min(sprev + L, 65535);
+        if (MODE == AGG_ATOMIC) {
+          // even lanes add (L_d | L_{d+1} << 16): four sweeps share a volume, 4 * 16383 < 65536, so no carry
+          const int hi = dpp_wave_shl1(act ? L : 0, 0);
+          if (act && !(lane & 1))
+            atomicAdd(reinterpret_cast<unsigned*>(sp + (long)t * step), (unsigned)L | ((unsigned)hi << 16));
+        } else if (act) {
+          sp[(long)t * step] = (unsigned short)min(sprev + L, 65535);
+        }
       }
     }
+  }
+}
+
+template <int SX, int SY, bool FIRST>
+__global__ __launch_bounds__(256) void dense_aggregate_kernel(DenseParams P, const short* __restrict__ Cv,
+                                                              unsigned short* __restrict__ sum) {
+  dense_aggregate_path<SX, SY, FIRST ? AGG_WRITE : AGG_RMW>(P, Cv, sum, blockIdx.x * 4 + (threadIdx.x >> 6),
+                                                            blockIdx.y);
+}
+
+// Up to three pairs: a sweep has only 480-1170 scan lines per pair, so a launch per direction is latency bound
+// (0.09-0.13 ms each).  Here all directions of a pair run in ONE launch (blockIdx.y = direction) and add into
+// two zeroed volumes with packed atomics: directions 0-3 into sumA, 4-7 into sumB (S = min(32767, A + B)).
+__global__ __launch_bounds__(256) void dense_aggregate_all_kernel(DenseParams P, const short* __restrict__ Cv,
+                                                                  unsigned short* __restrict__ sumA,
+                                                                  unsigned short* __restrict__ sumB) {
+  const int path = blockIdx.x * 4 + (threadIdx.x >> 6), pair = blockIdx.z;
+  switch (blockIdx.y) {
+    case 0: dense_aggregate_path<1, 0, AGG_ATOMIC>(P, Cv, sumA, path, pair); break;
+    case 1: dense_aggregate_path<1, 1, AGG_ATOMIC>(P, Cv, sumA, path, pair); break;
+    case 2: dense_aggregate_path<0, 1, AGG_ATOMIC>(P, Cv, sumA, path, pair); break;
+    case 3: dense_aggregate_path<-1, 1, AGG_ATOMIC>(P, Cv, sumA, path, pair); break;
+    case 4: dense_aggregate_path<-1, 0, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
+    case 5: dense_aggregate_path<1, -1, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
+    case 6: dense_aggregate_path<0, -1, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
+    default: dense_aggregate_path<-1, -1, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
   }
 }
 
@@ -266,6 +302,7 @@ constexpr int SEL_MAXW = 2048;
 // minimum search, the uniqueness test, the parabola fit and the integer division run on 64 pixels at once.
 constexpr int SEL_PITCH = 66;   // halfwords per disparity row of the transposed tile (bank-conflict padding)
 __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const unsigned short* __restrict__ sum,
+                                                           const unsigned short* __restrict__ sum2,
                                                            short* __restrict__ disp) {
   __shared__ unsigned long long d2key[SEL_MAXW];
   __shared__ short d1[SEL_MAXW];
@@ -281,15 +318,21 @@ __global__ __launch_bounds__(256) void dense_select_kernel(DenseParams P, const 
   __syncthreads();
   const size_t row = (((size_t)pair * P.H + y) * W1) * D;
   const unsigned short* srow = sum + row + min(lane, D - 1);
+  const unsigned short* srow2 = sum2 ? sum2 + row + min(lane, D - 1) : nullptr;
   unsigned short* T = tile[wv];
   const int ntiles = (W1 + 63) / 64;
   for (int tl = wv; tl < ntiles; tl += 4) {
     const int x0 = tl * 64;
     // lane = disparity: column j of the tile -> T[lane][j]
+    if (srow2) {   // two partial sums (single-launch aggregation): each < 65536, their sum saturates here
 #pragma unroll 16
-    for (int j = 0; j < 64; j++) {
-      const unsigned short v = srow[(size_t)min(x0 + j, W1 - 1) * D];
-      T[lane * SEL_PITCH + j] = v;
+      for (int j = 0; j < 64; j++) {
+        const size_t o = (size_t)min(x0 + j, W1 - 1) * D;
+        T[lane * SEL_PITCH + j] = (unsigned short)min((int)srow[o] + (int)srow2[o], 65535);
+      }
+    } else {
+#pragma unroll 16
+      for (int j = 0; j < 64; j++) T[lane * SEL_PITCH + j] = srow[(size_t)min(x0 + j, W1 - 1) * D];
     }
     // (one wave owns the tile: the LDS writes above are complete before the reads below are issued in order)
     __builtin_amdgcn_wave_barrier();
@@ -679,21 +722,31 @@ void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipSt
                                                                                                  B.vol[2]);
   const short* Cv = B.vol[2];
   unsigned short* sA = (unsigned short*)B.vol[0];
+  unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
-  // pass 1 of computeDisparitySGBM: previous pixel at (x-1,y), (x-1,y-1), (x,y-1), (x+1,y-1)
-  dense_aggregate_kernel<1, 0, true><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
-  dense_aggregate_kernel<1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
-  dense_aggregate_kernel<0, 1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
-  dense_aggregate_kernel<-1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
-  // MODE_SGBM: the fifth direction, previous pixel at (x+1,y); MODE_HH pass 2: (x+1,y), (x-1,y+1), (x,y+1),
-  // (x+1,y+1)
-  dense_aggregate_kernel<-1, 0, false><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
-  if (P.full_dp) {
-    dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
-    dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
-    dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+  if (n <= 3 && P.full_dp) {
+    // few pairs: every direction of a pair in one launch, packed atomic adds into two zeroed volumes
+    const size_t bytes = sizeof(short) * dense_volume_elems(P) * n;
+    (void)hipMemsetAsync(sA, 0, bytes, st);
+    (void)hipMemsetAsync(sB, 0, bytes, st);
+    dense_aggregate_all_kernel<<<dim3(nd, 8, n), blk, 0, st>>>(P, Cv, sA, sB);
+    dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, sB, B.disp[0]);
+  } else {
+    // pass 1 of computeDisparitySGBM: previous pixel at (x-1,y), (x-1,y-1), (x,y-1), (x+1,y-1)
+    dense_aggregate_kernel<1, 0, true><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
+    dense_aggregate_kernel<1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+    dense_aggregate_kernel<0, 1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
+    dense_aggregate_kernel<-1, 1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+    // MODE_SGBM: the fifth direction, previous pixel at (x+1,y); MODE_HH pass 2: (x+1,y), (x-1,y+1), (x,y+1),
+    // (x+1,y+1)
+    dense_aggregate_kernel<-1, 0, false><<<dim3(nh, n), blk, 0, st>>>(P, Cv, sA);
+    if (P.full_dp) {
+      dense_aggregate_kernel<1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+      dense_aggregate_kernel<0, -1, false><<<dim3(nw, n), blk, 0, st>>>(P, Cv, sA);
+      dense_aggregate_kernel<-1, -1, false><<<dim3(nd, n), blk, 0, st>>>(P, Cv, sA);
+    }
+    dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, nullptr, B.disp[0]);
   }
-  dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, B.disp[0]);
   const dim3 gpx((P.W + 255) / 256, P.H, n);
   dense_median3_kernel<<<gpx, blk, 0, st>>>(P.W, P.H, B.disp[0], B.disp[1]);
   short* cur = B.disp[1];
