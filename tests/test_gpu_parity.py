@@ -1099,3 +1099,77 @@ def test_dense_stereo_other_image_sizes(w, h):
                 assert valid.mean() > 0.4 and np.mean(np.abs(got[valid] / 16.0 - 13) <= 1.0) > 0.9
     finally:
         c.close()
+
+
+def test_frontend_device_input_path_matches_oracle(seq, ocam):
+    """kvfe_frontend_step_device (inputs already in HBM: the path bench.py times) gives the same per-frame
+    outputs as the oracle: stereo with the shipped Euroc parameters on two streams with a padded row stride,
+    and the RGBD front-end with a device-resident uint16 depth image."""
+    import torch
+    dev = torch.device("cuda", 0)
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=200)
+    B, h, w = 2, 480, 752
+    pitch = w + 16
+    fe = [O.Frontend(L, R, p) for _ in range(B)]
+    c = F.Context(L, R, p, batch=B)
+    keep = []   # device buffers must outlive the next step
+    try:
+        kf = [0] * B
+        for i in range(7):
+            idx = [i, 8 - i]
+            Rs = [seq["camR"][kf[s]].T @ seq["camR"][idx[s]] for s in range(B)]
+            ts = [int(seq["ts"][i])] * B
+            hl = np.zeros((B, h, pitch), np.uint8)
+            hr = np.zeros((B, h, pitch), np.uint8)
+            for s in range(B):
+                hl[s, :, :w] = seq["lefts"][idx[s]]
+                hr[s, :, :w] = seq["rights"][idx[s]]
+            dl, dr = torch.from_numpy(hl).to(dev), torch.from_numpy(hr).to(dev)
+            keep = keep[-2:] + [(dl, dr)]
+            c.step_device(dl.data_ptr(), dr.data_ptr(), c.make_inputs(ts, Rs, [0] * B), row_stride=pitch,
+                          image_stride=h * pitch)
+            for s in range(B):
+                exp = fe[s].process(seq["lefts"][idx[s]], seq["rights"][idx[s]], ts[s], Rs[s], False)
+                got = c.get_output(s)
+                for k in ("n_keypoints", "is_keyframe", "n_tracked", "n_detected", "n_measurements",
+                          "tracking_status_mono", "tracking_status_stereo"):
+                    assert got[k] == exp[k], (i, s, k)
+                for k in ("landmarks", "keypoints", "versors", "lkf_T_k_stereo"):
+                    assert np.array_equal(got[k], exp[k]), (i, s, k)
+                if exp["is_keyframe"]:
+                    for k in ("right_rect_xy", "right_status", "depth", "keypoints_3d", "meas_landmark"):
+                        assert np.array_equal(got[k], exp[k]), (i, s, k)
+                    kf[s] = idx[s]
+    finally:
+        c.close()
+    # RGBD: intensity + uint16 depth on the device
+    dp = abi.depth_params_default(abi.DEPTH_U16)
+    dp.virtual_baseline, dp.min_depth, dp.depth_to_meters = 0.05, 0.3, 0.001
+    TL = np.array(L.body_pose_cam).reshape(4, 4)
+    camR = [TL[:3, :3].T @ Rb @ TL[:3, :3] for Rb in seq["body_R"]]
+    fe = O.Frontend(L, L, p, depth=dp)
+    c = F.Context(L, L, p, batch=1, frontend_type=abi.FRONTEND_RGBD, depth=dp)
+    try:
+        kf0 = 0
+        for i in range(6):
+            depth = _synthetic_depth(h, w, i, abi.DEPTH_U16, seed=i)
+            dl = torch.from_numpy(np.ascontiguousarray(seq["lefts"][i])[None]).to(dev)
+            dd = torch.from_numpy(depth.view(np.int16)[None].copy()).to(dev)
+            keep = keep[-2:] + [(dl, dd)]
+            Rk = camR[kf0].T @ camR[i]
+            ts = int(seq["ts"][i])
+            c.step_device(dl.data_ptr(), dd.data_ptr(), c.make_inputs([ts], [Rk], [0]))
+            exp = fe.process(seq["lefts"][i], depth, ts, Rk, False)
+            got = c.get_output(0)
+            for k in ("n_keypoints", "is_keyframe", "n_measurements", "tracking_status_stereo"):
+                assert got[k] == exp[k], (i, k)
+            assert np.array_equal(got["keypoints"], exp["keypoints"])
+            if exp["is_keyframe"]:
+                for k in ("right_rect_xy", "right_status", "depth", "keypoints_3d"):
+                    assert np.array_equal(got[k], exp[k]), (i, k)
+                kf0 = i
+    finally:
+        c.close()
