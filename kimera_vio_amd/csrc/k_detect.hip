@@ -469,7 +469,11 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     if (sh_flag == 2) overflow = 1;
     sorted_accepted = true;
   } else if (md >= 1 && C2 > 0) {
-    const int cell = md;  // cvRound(minDistance) for an integer distance
+    // grid of cells of side >= minDistance (cvRound(minDistance) for an integer distance): the 3x3 block
+    // around a candidate holds every corner closer than minDistance.  For a small distance on a large
+    // image the side grows until the grid fits the LDS work area (the grid only accelerates the search).
+    int cell = md;
+    while ((long long)((W + cell - 1) / cell) * ((H + cell - 1) / cell) > MAX_CELLS) cell++;
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
     const int ncell = gw * gh;
     if (ncell > MAX_CELLS) {
@@ -674,7 +678,11 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     }
     if (tid == 0) sh_flag = 0;
     __syncthreads();
-    if (tid < 64 && need >= 2 && 3 * n <= MAX_CELLS + 1) {
+    // numRetPoints < 2: KdTree / RangeTree / Ssc divide by (numRetPoints - 1) resp. by numRetPoints and convert
+    // the infinite result to int (undefined upstream): no new corners, like the oracle.  Sdc has no such term
+    // and runs for 0 and 1 as well.
+    const bool search = need >= 2 || type == 2;
+    if (tid < 64 && search && 3 * n <= MAX_CELLS + 1) {
       const int lane = tid;
       int low, high;
       if (type == 2) {
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
       if (lane == 0) sh_cnt = nn;
     } else if (tid == 0) {
       sh_cnt = 0;
-      if (need >= 2) sh_flag = 3;  // keypoint list does not fit the LDS work area
+      if (search) sh_flag = 3;  // keypoint list does not fit the LDS work area
     }
     __syncthreads();
     n_new = sh_cnt;

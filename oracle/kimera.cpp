@@ -397,6 +397,11 @@ bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int
     case KVFE_ANMS_KDTREE:
     case KVFE_ANMS_RANGETREE:
     case KVFE_ANMS_SSC:
+      // numRetPoints < 2 (the frame already holds maxFeaturesPerFrame - 1 or more keypoints): KdTree, RangeTree
+      // and Ssc divide by numRetPoints - 1 / numRetPoints and convert an infinite double to int (anms.cpp:
+      // 175-189 and the like) -- undefined behaviour upstream; defined here as "no new corners".  Sdc has no
+      // such term and is restated for every numRetPoints.
+      if (numRetPoints < 2 && p.non_max_suppression_type != KVFE_ANMS_SDC) return true;
       anmsBinarySearch(keyPointsSorted, numRetPoints, cols, rows, p.non_max_suppression_type, out);
       return true;
     default:

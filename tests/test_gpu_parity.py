@@ -716,10 +716,39 @@ def test_feature_detection_anms_variants(anms_type, seq):
             got = c.feature_detection(img, tracked, 200)
             exp, _ = O.feature_detection(img, tracked, 200, p.detector)
             assert len(exp) > 20 and np.array_equal(got, exp)
-        if anms_type != abi.ANMS_SDC:
-            assert len(c.feature_detection(img, none, 1)) == 0
+        # numRetPoints 0 / 1 (the frame already holds maxFeaturesPerFrame keypoints): Sdc is defined upstream and
+        # still returns a corner or two; KdTree / RangeTree / Ssc divide by zero there -> no new corners on
+        # both sides (found by tools/fuzz_frontend.py)
+        for need in (0, 1, 2, 3):
+            got = c.feature_detection(img, none, need)
+            exp, _ = O.feature_detection(img, none, need, p.detector)
+            assert np.array_equal(got, exp), (anms_type, need, len(got), len(exp))
+            if anms_type != abi.ANMS_SDC and need < 2:
+                assert len(got) == 0
+        if anms_type == abi.ANMS_SDC:
+            assert len(c.feature_detection(img, none, 0)) >= 1
     finally:
         c.close()
+
+
+def test_feature_detection_small_min_distance(seq):
+    """min_distance 5 on 752x480: more grid cells of side minDistance than the LDS work area holds; the
+    acceleration grid then uses larger cells (found by tools/fuzz_frontend.py)"""
+    L, R = euroc_cams()
+    for anms in (abi.ANMS_RANGETREE, abi.ANMS_BINNING):
+        p = euroc_params(min_distance=5, quality_level=0.001, non_max_suppression_type=anms,
+                         max_features_per_frame=200)
+        c = F.Context(L, R, p)
+        try:
+            none = np.zeros((0, 2), np.float32)
+            img = seq["lefts"][4]
+            got = c.feature_detection(img, none, 200)
+            exp, _ = O.feature_detection(img, none, 200, p.detector)
+            assert len(exp) > 100 and np.array_equal(got, exp)
+            raw = c.raw_feature_detection(img)
+            assert len(raw) == p.detector.max_nr_keypoints_before_anms   # dense texture: the cap is hit
+        finally:
+            c.close()
 
 
 def test_frontend_sequence_class_default_anms(seq, ocam):
