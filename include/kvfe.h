@@ -147,10 +147,11 @@ typedef struct kvfe_detector_params {
 
 /* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85).
  * Geometric outlier rejection (FrontendParams::useRANSAC_) is implemented for
- * ransac_use_2point_mono (opengv TranslationOnlySacProblem), ransac_use_1point_stereo (the
- * reference's own voting scheme) and the 3-point Arun problem the stereo branch falls back to
- * (ransac_use_1point_stereo = 0, or a keyframe without gyro rotation).  The 5-point mono and
- * PnP problems and ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
+ * ransac_use_2point_mono (opengv TranslationOnlySacProblem), its 5-point alternative
+ * (ransac_use_2point_mono = 0: CentralRelativePoseSacProblem, NISTER), ransac_use_1point_stereo
+ * (the reference's own voting scheme) and the 3-point Arun problem the stereo branch falls back
+ * to (ransac_use_1point_stereo = 0, or a keyframe without gyro rotation).  PnP tracking, the other
+ * 2d2d algorithms and ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
 typedef struct kvfe_tracker_params {
   int32_t klt_win_size;
   int32_t klt_max_iter;
@@ -170,7 +171,9 @@ typedef struct kvfe_tracker_params {
   int32_t ransac_use_1point_stereo;
   int32_t ransac_use_2point_mono;
   int32_t ransac_rng_policy;                 /* KVFE_RNG_*                   */
-  int32_t reserved1;
+  int32_t pose_2d2d_algorithm;               /* 2d2d_algorithm (opengv CentralRelativePoseSacProblem::
+                                                Algorithm): 1 = NISTER in every shipped YAML; the only
+                                                one implemented for ransac_use_2point_mono = 0        */
 } kvfe_tracker_params;
 
 /* VIO::StereoMatchingParams (include/kimera-vio/frontend/StereoMatchingParams.h:24-60) */
@@ -457,6 +460,16 @@ typedef struct kvfe_ransac_output {
 KVFE_API kvfe_status kvfe_outlier_rejection_2d2d_given_rotation(
     kvfe_ctx* ctx, const double* f_ref, const double* f_cur, int32_t n,
     const double R_ref_cur[9], int32_t* inliers, kvfe_ransac_output* out);
+
+/* Tracker::geometricOutlierRejection2d2d without a rotation prior (Tracker.cpp:262-275): opengv
+ * CentralRelativePoseSacProblem, NISTER (5 + 3 points per sample), the problem of
+ * ransac_use_2point_mono = 0 (params/D455).  pose = lkf_T_k with a translation of arbitrary norm
+ * (the norm follows the scale of the essential matrix: it carries no information upstream either).
+ * The polynomial solver is not OpenGV's: poses agree with the reference to rounding, inlier
+ * decisions are pinned by the scenes of tests/testTracker.cpp:704-802. */
+KVFE_API kvfe_status kvfe_outlier_rejection_2d2d(kvfe_ctx* ctx, const double* f_ref,
+                                                 const double* f_cur, int32_t n,
+                                                 int32_t* inliers, kvfe_ransac_output* out);
 
 /* Tracker::geometricOutlierRejection3d3dGivenRotation (Tracker.cpp:382-632) +
  * Tracker::getPoint3AndCovariance (:772-818): the 1-point voting scheme on n

@@ -74,7 +74,7 @@ class TrackerParams(C.Structure):
         ("ransac_max_iterations", C.c_int32), ("ransac_randomize", C.c_int32),
         ("ransac_probability", C.c_double),
         ("ransac_use_1point_stereo", C.c_int32), ("ransac_use_2point_mono", C.c_int32),
-        ("ransac_rng_policy", C.c_int32), ("reserved1", C.c_int32),
+        ("ransac_rng_policy", C.c_int32), ("pose_2d2d_algorithm", C.c_int32),
     ]
 
 

@@ -220,6 +220,9 @@ struct Rs2d2dResult {
   double pose[12];
 };
 
+__device__ Rs2d2dResult rs_ransac_nister(const KParams& P, const Tables& T, const double* f1, const double* f2,
+                                         int n, int* shuffled, int* wave_tot, int* inliers);   // 5-point, below
+
 // opengv::sac::Ransac<TranslationOnlySacProblem>::computeModel + the checks of Tracker::runRansac and
 // Tracker::geometricOutlierRejection2d2d.  Every thread of the block calls it with the same
 // arguments and gets the same result; `inliers` receives the ascending inlier indices.
@@ -392,6 +395,10 @@ __device__ __forceinline__ RsLds rs_carve(unsigned char* raw, int kcap) {
 // ---------------------------------------------------------------------------------------------
 // VisionImuFrontend::outlierRejectionMono for the keyframes of this step
 // ---------------------------------------------------------------------------------------------
+// NISTER: the 5-point problem (ransac_use_2point_mono = 0) -- its own instantiation, so that the registers and
+// the scratch memory of the polynomial solver do not weigh on the 2-point kernel every shipped Euroc-style
+// configuration runs
+template <bool NISTER>
 __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, FrameTab K,
                                                            FrameTab LKF, StreamState S,
                                                            RansacScratch RS) {
@@ -424,8 +431,8 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
     st[1] = (P.mono && !P.rgbd) ? TRK_DISABLED : TRK_INVALID;
   }
   const double* R = S.kf_R_cur + (size_t)s * 9;
-  const bool imu_ok = !rs_rot_is_identity(R);
-  if (!(P.ransac_2pt_mono && imu_ok)) return;  // 5-point problem: not implemented, status stays INVALID
+  // Tracker::geometricOutlierRejection2d2d branches on the parameter only (Tracker.cpp:247-275): the 2-point
+  // problem also runs for a keyframe without gyro rotation (R = I then, VisionImuFrontend.cpp:108-111)
   int2* matches = RS.matches + so;
   const int n = rs_build_matches(P, K, LKF, nullptr, nullptr, s, S.n_tracked[s], L.ids, L.idx, wave_tot, matches);
   if (n == 0) return;
@@ -442,7 +449,11 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
   double Rl[9];
   for (int i = 0; i < 9; i++) Rl[i] = R[i];
   int* inliers = RS.inliers + so;
-  Rs2d2dResult res = rs_ransac_2d2d(P, T, f1, f2, n, Rl, L.work, wave_tot, inliers);
+  Rs2d2dResult res;
+  if (NISTER)
+    res = rs_ransac_nister(P, T, f1, f2, n, L.work, wave_tot, inliers);
+  else
+    res = rs_ransac_2d2d(P, T, f1, f2, n, Rl, L.work, wave_tot, inliers);
   int status = res.status;
   if (status != TRK_FEW_MATCHES) {  // removeOutliersMono: landmarks of the outliers -> -1 in frame k
     for (int m = tid; m < n; m += RS_T) L.work[m] = 0;
@@ -483,8 +494,12 @@ __global__ __launch_bounds__(RS_T) void mono_ransac_kernel(KParams P, Tables T, 
 
 void launch_mono_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
                         const StreamState& S, const RansacScratch& RS, hipStream_t st) {
-  hipLaunchKernelGGL(mono_ransac_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k,
-                     lkf, S, RS);
+  if (P.ransac_2pt_mono)
+    hipLaunchKernelGGL(mono_ransac_kernel<false>, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k, lkf,
+                       S, RS);
+  else
+    hipLaunchKernelGGL(mono_ransac_kernel<true>, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k, lkf,
+                       S, RS);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -976,6 +991,556 @@ __global__ __launch_bounds__(RS_T) void stereo_arun_kernel(KParams P, Tables T, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// opengv CentralRelativePoseSacProblem(NISTER): the 5-point problem of ransac_use_2point_mono = 0
+// (Tracker.cpp:262-275).  The solver is, operation for operation, the oracle's (oracle/opengv_re.cpp: Jacobi null
+// space, the ten cubic constraints, Gauss-Jordan in Nister's monomial order, det B(z) of degree 10, Sturm
+// bracketing + bisection); the four decompositions of every essential matrix are scored on the 5 + 3 sample
+// points like CentralRelativePoseSacProblem::computeModelCoefficients.  One thread solves one hypothesis; a
+// batch of hypotheses is solved in parallel and replayed in order (the sample stream does not depend on results).
+// ---------------------------------------------------------------------------------------------
+__constant__ signed char NP_IDX[4][4][4] = {{{0, 3, 9, 19}, {2, 8, 18, -1}, {7, 17, -1, -1}, {16, -1, -1, -1}},
+                                            {{1, 6, 15, -1}, {5, 14, -1, -1}, {13, -1, -1, -1}, {-1, -1, -1, -1}},
+                                            {{4, 12, -1, -1}, {11, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}},
+                                            {{10, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}}};
+__constant__ signed char NP_MONO[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1},
+                                           {0, 2, 0}, {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2},
+                                           {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+struct NPoly3 {
+  double c[20];
+};
+__device__ NPoly3 np3_zero() {
+  NPoly3 r;
+  for (int i = 0; i < 20; i++) r.c[i] = 0.0;
+  return r;
+}
+__device__ NPoly3 np3_lin(double x, double y, double z, double w) {
+  NPoly3 r = np3_zero();
+  r.c[NP_IDX[1][0][0]] = x;
+  r.c[NP_IDX[0][1][0]] = y;
+  r.c[NP_IDX[0][0][1]] = z;
+  r.c[NP_IDX[0][0][0]] = w;
+  return r;
+}
+__device__ NPoly3 np3_add(const NPoly3& a, const NPoly3& b, double sb = 1.0) {
+  NPoly3 r;
+  for (int i = 0; i < 20; i++) r.c[i] = a.c[i] + sb * b.c[i];
+  return r;
+}
+__device__ NPoly3 np3_mul(const NPoly3& a, const NPoly3& b) {
+  NPoly3 r = np3_zero();
+  for (int i1 = 0; i1 <= 3; i1++)
+    for (int j1 = 0; i1 + j1 <= 3; j1++)
+      for (int k1 = 0; i1 + j1 + k1 <= 3; k1++) {
+        const double ca = a.c[NP_IDX[i1][j1][k1]];
+        if (ca == 0.0) continue;
+        for (int i2 = 0; i1 + j1 + k1 + i2 <= 3; i2++)
+          for (int j2 = 0; i1 + j1 + k1 + i2 + j2 <= 3; j2++)
+            for (int k2 = 0; i1 + j1 + k1 + i2 + j2 + k2 <= 3; k2++)
+              r.c[NP_IDX[i1 + i2][j1 + j2][k1 + k2]] += ca * b.c[NP_IDX[i2][j2][k2]];
+      }
+  return r;
+}
+__device__ void np_jacobi_eig9(double* A /* 81, destroyed */, double* V, double* w) {
+  const int n = 9;
+  for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; k++) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - sn * akq;
+          A[k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - sn * aqk;
+          A[q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - sn * vkq;
+          V[k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  int order[9];
+  for (int i = 0; i < n; i++) order[i] = i;
+  for (int i = 1; i < n; i++)
+    for (int j = i; j > 0 && A[order[j] * n + order[j]] < A[order[j - 1] * n + order[j - 1]]; j--) {
+      const int t = order[j];
+      order[j] = order[j - 1];
+      order[j - 1] = t;
+    }
+  double V2[81];
+  for (int c = 0; c < n; c++) {
+    w[c] = A[order[c] * n + order[c]];
+    for (int r = 0; r < n; r++) V2[r * n + c] = V[r * n + order[c]];
+  }
+  for (int i = 0; i < 81; i++) V[i] = V2[i];
+}
+struct NPoly1 {
+  double c[12];
+  int deg;
+};
+__device__ NPoly1 np1_make(int deg) {
+  NPoly1 r;
+  for (int i = 0; i < 12; i++) r.c[i] = 0.0;
+  r.deg = deg;
+  return r;
+}
+__device__ NPoly1 np1_mul(const NPoly1& a, const NPoly1& b) {
+  NPoly1 r = np1_make(a.deg + b.deg);
+  for (int i = 0; i <= a.deg; i++)
+    for (int j = 0; j <= b.deg; j++) r.c[i + j] += a.c[i] * b.c[j];
+  return r;
+}
+__device__ NPoly1 np1_sub(const NPoly1& a, const NPoly1& b) {
+  NPoly1 r = np1_make(max(a.deg, b.deg));
+  for (int i = 0; i <= a.deg; i++) r.c[i] += a.c[i];
+  for (int i = 0; i <= b.deg; i++) r.c[i] -= b.c[i];
+  return r;
+}
+__device__ double np1_eval(const NPoly1& a, double z) {
+  double v = 0;
+  for (int i = a.deg; i >= 0; i--) v = v * z + a.c[i];
+  return v;
+}
+__device__ int np1_real_roots(NPoly1 p, double* roots) {
+  {
+    double m = 0;
+    for (int i = 0; i <= p.deg; i++) m = fmax(m, fabs(p.c[i]));
+    while (p.deg > 0 && fabs(p.c[p.deg]) <= 1e-14 * m) p.deg--;
+  }
+  if (p.deg < 1) return 0;
+  NPoly1 chain[12];
+  int nc = 0;
+  chain[nc++] = p;
+  NPoly1 d = np1_make(p.deg - 1);
+  for (int i = 1; i <= p.deg; i++) d.c[i - 1] = i * p.c[i];
+  chain[nc++] = d;
+  while (chain[nc - 1].deg > 0 && nc < 12) {
+    NPoly1 a = chain[nc - 2];
+    const NPoly1& b = chain[nc - 1];
+    for (int i = a.deg; i >= b.deg; i--) {
+      const double f = a.c[i] / b.c[b.deg];
+      for (int j = 0; j <= b.deg; j++) a.c[i - b.deg + j] -= f * b.c[j];
+      a.c[i] = 0.0;
+    }
+    a.deg = max(b.deg - 1, 0);
+    double m = 0;
+    for (int i = 0; i <= a.deg; i++) m = fmax(m, fabs(a.c[i]));
+    if (m == 0) break;
+    for (int i = 0; i <= a.deg; i++) a.c[i] = -a.c[i] / m;
+    while (a.deg > 0 && fabs(a.c[a.deg]) <= 1e-13) a.deg--;
+    chain[nc++] = a;
+  }
+  auto changes = [&](double z) {
+    int n = 0, prev = 0;
+    for (int i = 0; i < nc; i++) {
+      const double v = np1_eval(chain[i], z);
+      const int sgn = v > 0 ? 1 : v < 0 ? -1 : 0;
+      if (sgn != 0) {
+        if (prev != 0 && sgn != prev) n++;
+        prev = sgn;
+      }
+    }
+    return n;
+  };
+  double bound = 0;
+  for (int i = 0; i < p.deg; i++) bound = fmax(bound, fabs(p.c[i] / p.c[p.deg]));
+  bound += 1.0;
+  int nroots = 0;
+  double sa[64], sb[64];
+  int sna[64], snb[64];
+  int sp = 0;
+  sa[0] = -bound;
+  sb[0] = bound;
+  sna[0] = changes(-bound);
+  snb[0] = changes(bound);
+  sp = 1;
+  while (sp > 0 && nroots < 10) {
+    --sp;
+    const double ia = sa[sp], ib = sb[sp];
+    const int na = sna[sp], nb = snb[sp];
+    const int cnt = na - nb;
+    if (cnt <= 0) continue;
+    const double mid = 0.5 * (ia + ib);
+    if (cnt == 1 || ib - ia < 1e-13 * fmax(1.0, fabs(mid))) {
+      double a = ia, b = ib;
+      double fa = np1_eval(p, a);
+      for (int it = 0; it < 200 && b - a > 1e-16 * fmax(1.0, fabs(a) + fabs(b)); it++) {
+        const double m = 0.5 * (a + b);
+        if (m <= a || m >= b) break;
+        const double fm = np1_eval(p, m);
+        if (cnt == 1 && ((fa < 0) != (fm < 0))) {
+          b = m;
+        } else if (cnt == 1) {
+          a = m;
+          fa = fm;
+        } else
+          break;
+      }
+      roots[nroots++] = 0.5 * (a + b);
+      continue;
+    }
+    const int nm = changes(mid);
+    if (sp + 2 <= 64) {
+      sa[sp] = mid;
+      sb[sp] = ib;
+      sna[sp] = nm;
+      snb[sp] = nb;
+      sp++;
+      sa[sp] = ia;
+      sb[sp] = mid;
+      sna[sp] = na;
+      snb[sp] = nm;
+      sp++;
+    }
+  }
+  for (int i = 1; i < nroots; i++)   // ascending (std::sort in the oracle; the values are distinct)
+    for (int j = i; j > 0 && roots[j] < roots[j - 1]; j--) {
+      const double t = roots[j];
+      roots[j] = roots[j - 1];
+      roots[j - 1] = t;
+    }
+  return nroots;
+}
+// relative_pose::fivept_nister: essential matrices (row-major, f1^T E f2 = 0), up to 10
+__device__ int np_fivept(const double* f1, const double* f2, const int* idx5, double (*E_out)[9]) {
+  double QtQ[81], V[81], w[9];
+  {
+    double Q[5][9];
+    for (int i = 0; i < 5; i++) {
+      const double* f = f1 + 3 * (size_t)idx5[i];
+      const double* fp = f2 + 3 * (size_t)idx5[i];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Q[i][3 * r + c] = f[c] * fp[r];
+    }
+    for (int a = 0; a < 9; a++)
+      for (int b = 0; b < 9; b++) {
+        double sacc = 0;
+        for (int i = 0; i < 5; i++) sacc += Q[i][a] * Q[i][b];
+        QtQ[a * 9 + b] = sacc;
+      }
+  }
+  np_jacobi_eig9(QtQ, V, w);
+  double N[4][9];
+  for (int k = 0; k < 4; k++)
+    for (int a = 0; a < 9; a++) N[k][a] = V[a * 9 + k];
+  double M[10][20];
+  {
+    NPoly3 E[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+        E[r][c] = np3_lin(N[0][3 * r + c], N[1][3 * r + c], N[2][3 * r + c], N[3][3 * r + c]);
+    NPoly3 cons;
+    auto put = [&](int row, const NPoly3& q) {
+      for (int c = 0; c < 20; c++) M[row][c] = q.c[NP_IDX[NP_MONO[c][0]][NP_MONO[c][1]][NP_MONO[c][2]]];
+    };
+    {
+      const NPoly3 m0 = np3_add(np3_mul(E[1][1], E[2][2]), np3_mul(E[1][2], E[2][1]), -1.0);
+      const NPoly3 m1 = np3_add(np3_mul(E[1][0], E[2][2]), np3_mul(E[1][2], E[2][0]), -1.0);
+      const NPoly3 m2 = np3_add(np3_mul(E[1][0], E[2][1]), np3_mul(E[1][1], E[2][0]), -1.0);
+      cons = np3_add(np3_add(np3_mul(E[0][0], m0), np3_mul(E[0][1], m1), -1.0), np3_mul(E[0][2], m2));
+      put(0, cons);
+    }
+    NPoly3 EEt[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        EEt[r][c] = np3_zero();
+        for (int k = 0; k < 3; k++) EEt[r][c] = np3_add(EEt[r][c], np3_mul(E[r][k], E[c][k]));
+      }
+    const NPoly3 tr = np3_add(np3_add(EEt[0][0], EEt[1][1]), EEt[2][2]);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        NPoly3 acc = np3_zero();
+        for (int k = 0; k < 3; k++) acc = np3_add(acc, np3_mul(EEt[r][k], E[k][c]));
+        cons = np3_add(np3_add(acc, acc), np3_mul(tr, E[r][c]), -1.0);
+        put(1 + 3 * r + c, cons);
+      }
+  }
+  for (int col = 0; col < 10; col++) {
+    int piv = col;
+    for (int r = col + 1; r < 10; r++)
+      if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+    if (fabs(M[piv][col]) < 1e-300) return 0;
+    if (piv != col)
+      for (int c = 0; c < 20; c++) {
+        const double t = M[piv][c];
+        M[piv][c] = M[col][c];
+        M[col][c] = t;
+      }
+    const double inv = 1.0 / M[col][col];
+    for (int c = 0; c < 20; c++) M[col][c] *= inv;
+    for (int r = 0; r < 10; r++) {
+      if (r == col) continue;
+      const double f = M[r][col];
+      if (f == 0.0) continue;
+      for (int c = 0; c < 20; c++) M[r][c] -= f * M[col][c];
+    }
+  }
+  NPoly1 B[3][3];
+  for (int q = 0; q < 3; q++) {
+    const double* e = M[4 + 2 * q] + 10;
+    const double* f = M[5 + 2 * q] + 10;
+    for (int v = 0; v < 2; v++) {
+      NPoly1 b = np1_make(3);
+      b.c[0] = e[3 * v + 2];
+      b.c[1] = e[3 * v + 1] - f[3 * v + 2];
+      b.c[2] = e[3 * v] - f[3 * v + 1];
+      b.c[3] = -f[3 * v];
+      B[q][v] = b;
+    }
+    NPoly1 b = np1_make(4);
+    b.c[0] = e[9];
+    b.c[1] = e[8] - f[9];
+    b.c[2] = e[7] - f[8];
+    b.c[3] = e[6] - f[7];
+    b.c[4] = -f[6];
+    B[q][2] = b;
+  }
+  NPoly1 one = np1_make(0);
+  one.c[0] = 1.0;
+  const NPoly1 det = np1_sub(
+      np1_sub(np1_mul(B[0][0], np1_sub(np1_mul(B[1][1], B[2][2]), np1_mul(B[1][2], B[2][1]))),
+              np1_mul(B[0][1], np1_sub(np1_mul(B[1][0], B[2][2]), np1_mul(B[1][2], B[2][0])))),
+      np1_mul(np1_mul(B[0][2], np1_sub(np1_mul(B[1][1], B[2][0]), np1_mul(B[1][0], B[2][1]))), one));
+  double roots[10];
+  const int nr = np1_real_roots(det, roots);
+  int ne = 0;
+  for (int k = 0; k < nr; k++) {
+    const double z = roots[k];
+    double b[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) b[r][c] = np1_eval(B[r][c], z);
+    double bestdet = 0;
+    int r0 = 0, r1 = 1;
+    const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int pi = 0; pi < 3; pi++) {
+      const double dd = b[pairs[pi][0]][0] * b[pairs[pi][1]][1] - b[pairs[pi][0]][1] * b[pairs[pi][1]][0];
+      if (fabs(dd) > fabs(bestdet)) {
+        bestdet = dd;
+        r0 = pairs[pi][0];
+        r1 = pairs[pi][1];
+      }
+    }
+    if (bestdet == 0) continue;
+    const double x = (-b[r0][2] * b[r1][1] + b[r1][2] * b[r0][1]) / bestdet;
+    const double y = (-b[r0][0] * b[r1][2] + b[r1][0] * b[r0][2]) / bestdet;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        const int a = i + 3 * j;
+        E_out[ne][3 * i + j] = ((x * N[0][a] + y * N[1][a]) + z * N[2][a]) + N[3][a];
+      }
+    ne++;
+  }
+  return ne;
+}
+__device__ void np_set_model(const double* R, const double* t, RsModel* M) {
+  for (int i = 0; i < 9; i++) M->R[i] = R[i];
+  for (int i = 0; i < 3; i++) M->t[i] = t[i];
+  double Rt[9], it[3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) Rt[r * 3 + c] = R[c * 3 + r];
+  rs_matvec3(Rt, t, it);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) M->inv[r * 4 + c] = Rt[r * 3 + c];
+    M->inv[r * 4 + 3] = -it[r];
+  }
+}
+// the four [R | t] of an essential matrix (CentralRelativePoseSacProblem.cpp, NISTER case); j selects one
+__device__ void np_decompose(const double* E, int j, RsModel* M) {
+  double U[9], S[3], V[9];
+  rs_svd3(E, U, S, V);
+  const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+  const double* Wm = (j & 1) ? Wt : W;
+  double UW[9], R[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) UW[r * 3 + c] = (U[r * 3] * Wm[c] + U[r * 3 + 1] * Wm[3 + c]) + U[r * 3 + 2] * Wm[6 + c];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++)
+      R[r * 3 + c] = (UW[r * 3] * V[c * 3] + UW[r * 3 + 1] * V[c * 3 + 1]) + UW[r * 3 + 2] * V[c * 3 + 2];
+  const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+                     R[2] * (R[3] * R[7] - R[4] * R[6]);
+  if (det < 0)
+    for (int i = 0; i < 9; i++) R[i] = -R[i];
+  const double scale = S[0], sg = (j & 2) ? -1.0 : 1.0;
+  const double t[3] = {sg * (scale * U[2]), sg * (scale * U[5]), sg * (scale * U[8])};
+  np_set_model(R, t, M);
+}
+// CentralRelativePoseSacProblem::computeModelCoefficients(NISTER) for one sample of 5 + 3 indices
+__device__ bool np_model(const double* f1, const double* f2, const int* s8, RsModel* out) {
+  double Es[10][9];
+  const int ne = np_fivept(f1, f2, s8, Es);
+  double bestQuality = 1000000.0;
+  int best_i = -1, best_j = -1;
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j < 4; j++) {
+      RsModel M;
+      np_decompose(Es[i], j, &M);
+      double quality = 0.0;
+      for (int k = 0; k < 8; k++) {
+        double a[3], b[3];
+        for (int c = 0; c < 3; c++) {
+          a[c] = f1[3 * (size_t)s8[k] + c];
+          b[c] = f2[3 * (size_t)s8[k] + c];
+        }
+        quality += rs_distance(M, a, b);
+      }
+      if (quality < bestQuality) {
+        bestQuality = quality;
+        best_i = i;
+        best_j = j;
+      }
+    }
+  if (best_i == -1) return false;
+  np_decompose(Es[best_i], best_j, out);
+  return true;
+}
+
+constexpr int NP_BATCH = 64;   // hypotheses solved in parallel per round
+// opengv::sac::Ransac<CentralRelativePoseSacProblem>::computeModel + the checks of Tracker::runRansac and
+// Tracker::geometricOutlierRejection2d2d; calling convention of rs_ransac_2d2d
+__device__ Rs2d2dResult rs_ransac_nister(const KParams& P, const Tables& T, const double* f1, const double* f2,
+                                         int n, int* shuffled, int* wave_tot, int* inliers) {
+  const int tid = threadIdx.x;
+  __shared__ int sh_sel8[NP_BATCH][8];
+  __shared__ int sh_okm[NP_BATCH];
+  __shared__ int sh_cntm[NP_BATCH];
+  __shared__ RsModel sh_models[NP_BATCH];
+  __shared__ int sh_state[4];   // 0: stop flag, 1: best hypothesis slot of this round (-1 none), 2: n inliers, 3: spare
+  __shared__ RsModel sh_best;
+  Rs2d2dResult res;
+  res.status = TRK_INVALID;
+  res.n_inliers = 0;
+  res.iterations = 0;
+  for (int i = 0; i < 12; i++) res.pose[i] = (i % 5 == 0) ? 1.0 : 0.0;  // Pose3()
+  for (int i = tid; i < n; i += RS_T) shuffled[i] = i;
+  __syncthreads();
+  // replay state (identical in every thread: all read the same shared results)
+  int iterations = 0, best = -INT_MAX, draw = 0;
+  unsigned skipped = 0;
+  const unsigned max_skip = (unsigned)P.ransac_max_iters * 10u;
+  double k = 1.0;
+  bool have_model = false, done = false;
+  if (n < 8) {
+    iterations = INT_MAX;  // getSamples: not enough correspondences
+    done = true;
+  }
+  while (!done) {
+    if (tid == 0) {   // drawIndexSample for the next NP_BATCH hypotheses (the shuffle persists)
+      for (int h = 0; h < NP_BATCH; h++) {
+        for (int i = 0; i < 8; ++i) {
+          const int r = T.ransac_rnd[min(draw + 8 * h + i, T.n_ransac_rnd - 1)];
+          const int j = i + (int)((unsigned)r % (unsigned)(n - i));
+          const int tmp = shuffled[i];
+          shuffled[i] = shuffled[j];
+          shuffled[j] = tmp;
+        }
+        for (int i = 0; i < 8; i++) sh_sel8[h][i] = shuffled[i];
+      }
+    }
+    draw += 8 * NP_BATCH;
+    __syncthreads();
+    if (tid < NP_BATCH) {
+      RsModel M;
+      const bool ok = np_model(f1, f2, sh_sel8[tid], &M);
+      sh_okm[tid] = ok ? 1 : 0;
+      sh_models[tid] = M;
+      sh_cntm[tid] = 0;
+    }
+    __syncthreads();
+    // countWithinDistance of every hypothesis of the round: (hypothesis, match) pairs over the block
+    for (int h = 0; h < NP_BATCH; h++) {
+      if (!sh_okm[h]) continue;
+      const RsModel M = sh_models[h];
+      int cnt = 0;
+      for (int i = tid; i < n; i += RS_T) {
+        double a[3], b[3];
+        for (int c = 0; c < 3; c++) {
+          a[c] = f1[3 * (size_t)i + c];
+          b[c] = f2[3 * (size_t)i + c];
+        }
+        if (rs_distance(M, a, b) < P.ransac_thr_mono) cnt++;
+      }
+      cnt = rs_block_sum(cnt, wave_tot);
+      if (tid == 0) sh_cntm[h] = cnt;
+    }
+    __syncthreads();
+    // replay the sequential loop of Ransac::computeModel over the round
+    for (int h = 0; h < NP_BATCH && !done; h++) {
+      if (!((double)iterations < k && skipped < max_skip)) {
+        done = true;
+        break;
+      }
+      if (!sh_okm[h]) {
+        ++skipped;
+        continue;
+      }
+      const int cnt = sh_cntm[h];
+      if (cnt > best) {
+        best = cnt;
+        have_model = true;
+        if (tid == 0) sh_best = sh_models[h];
+        const double w = (double)best / (double)n;
+        double p_no_outliers = 1.0 - pow(w, 8.0);
+        p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
+        p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
+        k = log(1.0 - P.ransac_probability) / log(p_no_outliers);
+      }
+      ++iterations;
+      if (iterations > P.ransac_max_iters) done = true;
+    }
+    if (!((double)iterations < k && skipped < max_skip)) done = true;
+    __syncthreads();
+  }
+  res.iterations = iterations;
+  if (!have_model) return res;
+  __syncthreads();
+  const RsModel Mbest = sh_best;
+  if (tid == 0) sh_state[2] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += RS_T) {   // selectWithinDistance
+    const int i = base + tid;
+    bool in = false;
+    if (i < n) {
+      double a[3], b[3];
+      for (int c = 0; c < 3; c++) {
+        a[c] = f1[3 * (size_t)i + c];
+        b[c] = f2[3 * (size_t)i + c];
+      }
+      in = rs_distance(Mbest, a, b) < P.ransac_thr_mono;
+    }
+    int tot;
+    const int pos = rs_scan(in ? 1 : 0, wave_tot, &tot);
+    const int off = sh_state[2];
+    if (in) inliers[off + pos] = i;
+    __syncthreads();
+    if (tid == 0) sh_state[2] = off + tot;
+    __syncthreads();
+  }
+  const int n_in = sh_state[2];
+  __syncthreads();
+  if (iterations >= P.ransac_max_iters && n_in == 0) return res;  // Tracker.h:270-273
+  res.n_inliers = n_in;
+  res.status = n_in < P.min_mono_inliers ? TRK_FEW_MATCHES : TRK_VALID;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) res.pose[r * 4 + c] = Mbest.R[r * 3 + c];
+    res.pose[r * 4 + 3] = Mbest.t[r];
+  }
+  return res;
+}
+
 // ---- front-end: the three launches over all streams ------------------------------------------------
 __global__ __launch_bounds__(RS_T) void stereo_ransac_prepare_kernel(KParams P, Tables T, FrameTab K,
                                                                      FrameTab LKF, StereoTab ST,
@@ -1101,6 +1666,31 @@ void launch_ransac_2d2d_points(const KParams& P, const Tables& T, const double* 
                                int* out_status, double* out_pose, int* out_counts, hipStream_t st) {
   hipLaunchKernelGGL(ransac_2d2d_points_kernel, dim3(1), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T,
                      f_ref, f_cur, n, R, RS, out_status, out_pose, out_counts);
+}
+
+// Tracker::geometricOutlierRejection2d2d without rotation prior (5-point Nister) on caller-supplied matches
+__global__ __launch_bounds__(RS_T) void ransac_2d2d_nister_points_kernel(KParams P, Tables T, const double* f_ref,
+                                                                         const double* f_cur, int n,
+                                                                         RansacScratch RS, int* out_status,
+                                                                         double* out_pose, int* out_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot[RS_T / 64];
+  const RsLds L = rs_carve(lds_raw, P.kcap);
+  Rs2d2dResult res = rs_ransac_nister(P, T, f_ref, f_cur, n, L.work, wave_tot, RS.inliers);
+  if (threadIdx.x == 0) {
+    out_status[0] = res.status;
+    out_counts[0] = n;
+    out_counts[1] = res.n_inliers;
+    out_counts[2] = res.iterations;
+    for (int i = 0; i < 12; i++) out_pose[i] = res.pose[i];
+    RS.n_inliers[0] = res.n_inliers;
+  }
+}
+void launch_ransac_2d2d_nister_points(const KParams& P, const Tables& T, const double* f_ref, const double* f_cur,
+                                      int n, const RansacScratch& RS, int* out_status, double* out_pose,
+                                      int* out_counts, hipStream_t st) {
+  hipLaunchKernelGGL(ransac_2d2d_nister_points_kernel, dim3(1), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, f_ref,
+                     f_cur, n, RS, out_status, out_pose, out_counts);
 }
 
 __global__ __launch_bounds__(RS_T) void ransac_3d3d_prepare_kernel(

@@ -402,8 +402,8 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     const kvfe_tracker_params& tr = p.tracker;
     if (tr.ransac_randomize)
       return fail("ransac_randomize=1 (time-seeded sampling) is not reproducible: set 0", KVFE_ERR_UNSUPPORTED);
-    if (!tr.ransac_use_2point_mono)
-      return fail("ransac_use_2point_mono=0 selects the 5-point problem, which is not implemented",
+    if (!tr.ransac_use_2point_mono && tr.pose_2d2d_algorithm != 1)
+      return fail("2d2d_algorithm: only NISTER (1) is implemented for ransac_use_2point_mono=0",
                   KVFE_ERR_UNSUPPORTED);
     if (tr.ransac_max_iterations < 1 || tr.ransac_max_iterations > 1000)
       return fail("ransac_max_iterations out of range [1,1000]", KVFE_ERR_INVALID_ARG);
@@ -642,7 +642,7 @@ kvfe_status build_tables(kvfe_ctx* c) {
   // opengv::sac::SampleConsensusProblem::rnd(): std::mt19937 seeded with 12345 (randomSeed = false)
   // drawn through std::uniform_int_distribution<int>(0, INT_MAX) -- a fixed stream
   {
-    const int n = 4096;
+    const int n = 16384;   // 8 draws per 5-point hypothesis: 2048 hypotheses
     std::vector<int> r(n);
     ransac_rnd_stream(cfg.params.tracker.ransac_rng_policy, n, r.data());
     int* d;
@@ -951,6 +951,7 @@ void kvfe_default_frontend_params(kvfe_frontend_params* p) {
   t.ransac_use_1point_stereo = 1;
   t.ransac_use_2point_mono = 1;
   t.ransac_rng_policy = KVFE_RNG_LIBSTDCXX_PRE11;
+  t.pose_2d2d_algorithm = 1;  // Pose2d2dAlgorithm::NISTER (VisionImuTrackerParams.h:68)
   kvfe_stereo_params& s = p->stereo;
   s.tolerance_template_matching = 0.15;
   s.templ_cols = 101;
@@ -1483,6 +1484,22 @@ kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
                             n, b.kf_R_cur, b.rs, b.ss.trk_status, b.ss.trk_pose, b.ss.trk_info,
                             b.ss.trk_counts, st);
   return ransac_download(c, b, inliers, out, true);
+}
+
+kvfe_status kvfe_outlier_rejection_2d2d(kvfe_ctx* c, const double* f_ref, const double* f_cur, int32_t n,
+                                        int32_t* inliers, kvfe_ransac_output* out) {
+  // CHECK_GT(f_ref.size(), 0) (Tracker.cpp:243)
+  if (!c || !f_ref || !f_cur || !out || n <= 0) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.rs.f_ref, f_ref, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.rs.f_cur, f_cur, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  launch_ransac_2d2d_nister_points(P, c->T, b.rs.f_ref, b.rs.f_cur, n, b.rs, b.ss.trk_status, b.ss.trk_pose,
+                                   b.ss.trk_counts, st);
+  return ransac_download(c, b, inliers, out, false);
 }
 
 kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* c, const double* ref_points_3d, const double* cur_points_3d,

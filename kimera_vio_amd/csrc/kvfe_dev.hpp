@@ -310,6 +310,9 @@ void launch_ransac_3d3d_points(const KParams& P, const Tables& T, const float* r
                                const float* cur_right_x, const double* cur_p3, int n, const double* R,
                                const RansacScratch& RS, int* out_status, double* out_pose,
                                double* out_info, int* out_counts, hipStream_t st);
+void launch_ransac_2d2d_nister_points(const KParams& P, const Tables& T, const double* f_ref, const double* f_cur,
+                                      int n, const RansacScratch& RS, int* out_status, double* out_pose,
+                                      int* out_counts, hipStream_t st);
 void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const double* p1, const double* p2, int n,
                                     const RansacScratch& RS, int* out_status, double* out_pose, int* out_counts,
                                     hipStream_t st);

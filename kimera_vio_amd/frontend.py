@@ -271,6 +271,17 @@ class Context:
             "outlier_rejection_3d3d_given_rotation")
         return self._ransac_result(out, inl)
 
+    def outlier_rejection_2d2d(self, f_ref, f_cur) -> dict:
+        """Tracker::geometricOutlierRejection2d2d without rotation prior (5-point Nister RANSAC)."""
+        a = np.ascontiguousarray(f_ref, np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(f_cur, np.float64).reshape(-1, 3)
+        n = len(a)
+        inl = np.zeros(max(n, 1), np.int32)
+        out = abi.RansacOutput()
+        self._chk(self.lib.kvfe_outlier_rejection_2d2d(self._h, _p(a), _p(b), n, _p(inl), C.byref(out)),
+                  "outlier_rejection_2d2d")
+        return self._ransac_result(out, inl)
+
     def outlier_rejection_3d3d(self, ref_p3, cur_p3) -> dict:
         """Tracker::geometricOutlierRejection3d3d (3-point Arun RANSAC) on matched 3-D points."""
         rp = np.ascontiguousarray(ref_p3, np.float64).reshape(-1, 3)

@@ -72,6 +72,7 @@ def load() -> C.CDLL:
     L.kvfe_outlier_rejection_3d3d_given_rotation.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp,
                                                              C.POINTER(abi.RansacOutput)]
     L.kvfe_outlier_rejection_3d3d.argtypes = [vp, vp, vp, i32, vp, C.POINTER(abi.RansacOutput)]
+    L.kvfe_outlier_rejection_2d2d.argtypes = [vp, vp, vp, i32, vp, C.POINTER(abi.RansacOutput)]
     L.kvfe_equalize_hist.argtypes = [vp, vp, sz, vp, sz]
     L.kvfe_dense_stereo_params_default.argtypes = [C.POINTER(abi.DenseStereoParams)]
     L.kvfe_dense_stereo_params_default.restype = None
@@ -104,7 +105,8 @@ def load() -> C.CDLL:
                "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
                "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
                "kvfe_profile_read", "kvfe_dense_stereo_reconstruction", "kvfe_dense_profile_read",
-               "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume", "kvfe_outlier_rejection_3d3d"):
+               "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume", "kvfe_outlier_rejection_3d3d",
+               "kvfe_outlier_rejection_2d2d"):
         getattr(L, fn).restype = C.c_int32
     _lib = L
     return L
@@ -124,5 +126,5 @@ EXPORTED_SYMBOLS = [
     "kvfe_frontend_reset", "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
     "kvfe_profile_read", "kvfe_dense_stereo_params_default", "kvfe_dense_stereo_reconstruction",
     "kvfe_dense_profile_read", "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume",
-    "kvfe_outlier_rejection_3d3d",
+    "kvfe_outlier_rejection_3d3d", "kvfe_outlier_rejection_2d2d",
 ]

@@ -69,6 +69,7 @@ def default_frontend_params() -> abi.FrontendParams:
     t.ransac_use_1point_stereo = 1
     t.ransac_use_2point_mono = 1
     t.ransac_rng_policy = abi.RNG_LIBSTDCXX_PRE11
+    t.pose_2d2d_algorithm = 1  # Pose2d2dAlgorithm::NISTER (VisionImuTrackerParams.h:68)
     s = p.stereo
     s.tolerance_template_matching = 0.15
     s.templ_cols = 101
@@ -147,6 +148,8 @@ def load_frontend_params(path: str, use_ransac: int | None = 0) -> abi.FrontendP
     t.ransac_randomize = int(y["ransac_randomize"])
     t.ransac_use_1point_stereo = int(y["ransac_use_1point_stereo"])
     t.ransac_use_2point_mono = int(y["ransac_use_2point_mono"])
+    if "2d2d_algorithm" in y:
+        t.pose_2d2d_algorithm = int(y["2d2d_algorithm"])
     s = p.stereo
     s.tolerance_template_matching = float(y["toleranceTemplateMatching"])
     s.templ_cols = int(y["templ_cols"])

@@ -8,6 +8,7 @@
 
 #include "kimera.hpp"
 #include "ocv.hpp"
+#include "opengv_re.hpp"
 
 using kimera::StatusKeypoint;
 using ocv::Point2f;
@@ -303,6 +304,14 @@ KVO_API void kvo_outlier_rejection_3d3d_given_rotation(
   fill_ransac_out(kimera::outlierRejection3d3dGivenRot(ref_left_xy, ref_right_x, ref_p3, cur_left_xy,
                                                        cur_right_x, cur_p3, n, K, R, *tp),
                   inliers, out);
+}
+KVO_API int kvo_fivept_nister(const double* f1, const double* f2, const int* idx5, double* E_out) {
+  return opengv_re::fivept_nister_essentials(f1, f2, idx5, E_out);
+}
+KVO_API void kvo_outlier_rejection_2d2d(const double* f_ref, const double* f_cur, int n,
+                                        const kvfe_tracker_params* tp, int32_t* inliers,
+                                        kvfe_ransac_output* out) {
+  fill_ransac_out(kimera::outlierRejection2d2d(f_ref, f_cur, n, *tp), inliers, out);
 }
 KVO_API void kvo_outlier_rejection_3d3d(const double* ref_p3, const double* cur_p3, int n,
                                         const kvfe_tracker_params* tp, int32_t* inliers,

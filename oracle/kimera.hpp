@@ -139,6 +139,9 @@ struct RansacOut {
 // ransac_use_2point_mono_ (Tracker.cpp:213-318) over n already gathered matches
 RansacOut outlierRejection2d2dGivenRot(const double* f_ref, const double* f_cur, int n,
                                        const double R[9], const kvfe_tracker_params& tp);
+// Tracker::geometricOutlierRejection2d2d without a rotation prior (ransac_use_2point_mono_ = false or no gyro
+// rotation): 5-point Nister RANSAC (Tracker.cpp:213-318, Problem2d2d::NISTER) over n gathered matches
+RansacOut outlierRejection2d2d(const double* f_ref, const double* f_cur, int n, const kvfe_tracker_params& tp);
 // Tracker::geometricOutlierRejection3d3d(ref_keypoints_3d, cur_keypoints_3d, matches, inliers)
 // (Tracker.cpp:667-742): 3-point Arun RANSAC over n already gathered matches
 RansacOut outlierRejection3d3d(const double* ref_p3, const double* cur_p3, int n,

@@ -106,6 +106,26 @@ RansacOut outlierRejection2d2dGivenRot(const double* f_ref, const double* f_cur,
   return o;
 }
 
+// Tracker::geometricOutlierRejection2d2d, 5-point branch (Tracker.cpp:262-275) -> runRansac<Problem2d2d(NISTER)>
+RansacOut outlierRejection2d2d(const double* f_ref, const double* f_cur, int n, const kvfe_tracker_params& tp) {
+  RansacOut o;
+  opengv_re::RansacResult r = opengv_re::ransac_central_relative_pose_nister(
+      f_ref, f_cur, n, tp.ransac_threshold_mono, tp.ransac_max_iterations, tp.ransac_probability,
+      tp.ransac_rng_policy);
+  bool success = r.success;
+  o.iterations = r.iterations;
+  if (success && r.iterations >= tp.ransac_max_iterations && r.inliers.empty()) success = false;
+  if (!success) {
+    o.status = KVFE_TRACKING_INVALID;
+    return o;
+  }
+  o.inliers = r.inliers;
+  std::memcpy(o.pose, r.coeff, sizeof(o.pose));
+  o.status = KVFE_TRACKING_VALID;
+  if ((int)o.inliers.size() < tp.min_nr_mono_inliers) o.status = KVFE_TRACKING_FEW_MATCHES;
+  return o;
+}
+
 // Tracker::geometricOutlierRejection3d3d (Tracker.cpp:667-742) -> runRansac<Problem3d3d>
 // (Tracker.h:247-296; optimize_3d3d_pose_from_inliers_ = false)
 RansacOut outlierRejection3d3d(const double* ref_p3, const double* cur_p3, int n,
@@ -297,11 +317,6 @@ void Frontend::outlierRejectionMono(const double R[9], Frame& ref, Frame& cur) {
   RansacOut result;
   std::vector<KeypointMatch> matches;
   findMatchingKeypoints(ref, cur, matches);
-  if (!(p.tracker.ransac_use_2point_mono && imu_ok)) {
-    // the 5-point (Nister) problem is not restated: INVALID, nothing removed (documented gap)
-    S.mono = KVFE_TRACKING_INVALID;
-    return;
-  }
   if (matches.empty()) {
     S.mono = KVFE_TRACKING_INVALID;
     return;
@@ -312,7 +327,14 @@ void Frontend::outlierRejectionMono(const double R[9], Frame& ref, Frame& cur) {
       f_ref[3 * m + c] = ref.versors[3 * matches[m].first + c];
       f_cur[3 * m + c] = cur.versors[3 * matches[m].second + c];
     }
-  result = outlierRejection2d2dGivenRot(f_ref.data(), f_cur.data(), (int)matches.size(), R, p.tracker);
+  // Tracker::geometricOutlierRejection2d2d(bearings, ...) branches on the PARAMETER only (Tracker.cpp:247-275):
+  // with ransac_use_2point_mono the 2-point problem runs even without gyro rotation (outlierRejectionMono then
+  // passes Pose3(), i.e. R = I, VisionImuFrontend.cpp:108-111); without it the 5-point problem (2d2d_algorithm).
+  (void)imu_ok;
+  if (p.tracker.ransac_use_2point_mono)
+    result = outlierRejection2d2dGivenRot(f_ref.data(), f_cur.data(), (int)matches.size(), R, p.tracker);
+  else
+    result = outlierRejection2d2d(f_ref.data(), f_cur.data(), (int)matches.size(), p.tracker);
   if (result.status != KVFE_TRACKING_INVALID) {  // debug info is filled on RANSAC success only
     S.nr_mono_putatives = (int)matches.size();
     S.nr_mono_inliers = (int)result.inliers.size();

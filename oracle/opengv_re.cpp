@@ -341,6 +341,438 @@ struct PointCloud : Problem {
   }
 };
 
+// ---- CentralRelativePoseSacProblem(NISTER): 5-point problem ---------------------------------------
+// relative_pose::fivept_nister (Nister, "An efficient solution to the five-point relative pose problem",
+// PAMI 2004): null space of the 5 epipolar constraints, the ten cubic constraints on E = xA + yB + zC + D,
+// Gauss-Jordan elimination in Nister's monomial order, the 3x3 polynomial matrix B(z), its determinant (degree
+// 10), real roots by Sturm sequences.  OpenGV's own arithmetic (Eigen::JacobiSVD for the null space, its
+// expansion of the determinant) is not reproduced: the essential matrices are the same up to rounding and up
+// to the scale that the choice of null-space basis fixes (the translation norm of the model follows that scale
+// in OpenGV too, i.e. it carries no information).  PARITY UNPINNED at the bit level; inlier decisions pinned by
+// the scenes of tests/testTracker.cpp:704-802.
+struct Poly3 {   // polynomial of total degree <= 3 in (x, y, z), coefficient c[idx(i,j,k)] of x^i y^j z^k
+  double c[20];
+};
+static int p3_idx(int i, int j, int k) {
+  static int table[4][4][4];
+  static bool init = false;
+  if (!init) {
+    int n = 0;
+    for (int d = 0; d <= 3; d++)
+      for (int a = d; a >= 0; a--)
+        for (int b = d - a; b >= 0; b--) table[a][b][d - a - b] = n++;
+    init = true;
+  }
+  return table[i][j][k];
+}
+static Poly3 p3_zero() {
+  Poly3 r;
+  for (double& v : r.c) v = 0.0;
+  return r;
+}
+static Poly3 p3_lin(double x, double y, double z, double w) {
+  Poly3 r = p3_zero();
+  r.c[p3_idx(1, 0, 0)] = x;
+  r.c[p3_idx(0, 1, 0)] = y;
+  r.c[p3_idx(0, 0, 1)] = z;
+  r.c[p3_idx(0, 0, 0)] = w;
+  return r;
+}
+static Poly3 p3_add(const Poly3& a, const Poly3& b, double sb = 1.0) {
+  Poly3 r;
+  for (int i = 0; i < 20; i++) r.c[i] = a.c[i] + sb * b.c[i];
+  return r;
+}
+static Poly3 p3_mul(const Poly3& a, const Poly3& b) {   // terms above degree 3 do not occur in the uses below
+  Poly3 r = p3_zero();
+  for (int i1 = 0; i1 <= 3; i1++)
+    for (int j1 = 0; i1 + j1 <= 3; j1++)
+      for (int k1 = 0; i1 + j1 + k1 <= 3; k1++) {
+        const double ca = a.c[p3_idx(i1, j1, k1)];
+        if (ca == 0.0) continue;
+        for (int i2 = 0; i1 + j1 + k1 + i2 <= 3; i2++)
+          for (int j2 = 0; i1 + j1 + k1 + i2 + j2 <= 3; j2++)
+            for (int k2 = 0; i1 + j1 + k1 + i2 + j2 + k2 <= 3; k2++)
+              r.c[p3_idx(i1 + i2, j1 + j2, k1 + k2)] += ca * b.c[p3_idx(i2, j2, k2)];
+      }
+  return r;
+}
+
+// symmetric Jacobi eigen-decomposition (n <= 9), eigenvalues ascending, eigenvectors in the columns of V
+static void jacobi_eig(int n, double* A /* n*n, destroyed */, double* V, double* w) {
+  for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; k++) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - sn * akq;
+          A[k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - sn * aqk;
+          A[q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - sn * vkq;
+          V[k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  int order[9];
+  for (int i = 0; i < n; i++) order[i] = i;
+  for (int i = 1; i < n; i++)
+    for (int j = i; j > 0 && A[order[j] * n + order[j]] < A[order[j - 1] * n + order[j - 1]]; j--)
+      std::swap(order[j], order[j - 1]);
+  double V2[81];
+  for (int c = 0; c < n; c++) {
+    w[c] = A[order[c] * n + order[c]];
+    for (int r = 0; r < n; r++) V2[r * n + c] = V[r * n + order[c]];
+  }
+  std::memcpy(V, V2, sizeof(double) * n * n);
+}
+
+// univariate polynomials, coefficient c[k] of z^k
+struct Poly1 {
+  double c[12];
+  int deg;
+};
+static Poly1 p1_make(int deg) {
+  Poly1 r;
+  for (double& v : r.c) v = 0.0;
+  r.deg = deg;
+  return r;
+}
+static Poly1 p1_mul(const Poly1& a, const Poly1& b) {
+  Poly1 r = p1_make(a.deg + b.deg);
+  for (int i = 0; i <= a.deg; i++)
+    for (int j = 0; j <= b.deg; j++) r.c[i + j] += a.c[i] * b.c[j];
+  return r;
+}
+static Poly1 p1_sub(const Poly1& a, const Poly1& b) {
+  Poly1 r = p1_make(std::max(a.deg, b.deg));
+  for (int i = 0; i <= a.deg; i++) r.c[i] += a.c[i];
+  for (int i = 0; i <= b.deg; i++) r.c[i] -= b.c[i];
+  return r;
+}
+static double p1_eval(const Poly1& a, double z) {
+  double v = 0;
+  for (int i = a.deg; i >= 0; i--) v = v * z + a.c[i];
+  return v;
+}
+static void p1_trim(Poly1& a) {
+  double m = 0;
+  for (int i = 0; i <= a.deg; i++) m = std::max(m, std::fabs(a.c[i]));
+  while (a.deg > 0 && std::fabs(a.c[a.deg]) <= 1e-14 * m) a.deg--;
+}
+// real roots by a Sturm chain (remainders rescaled by positive factors) + bisection
+static int p1_real_roots(Poly1 p, double* roots /* up to 10 */) {
+  p1_trim(p);
+  if (p.deg < 1) return 0;
+  Poly1 chain[12];
+  int nc = 0;
+  chain[nc++] = p;
+  Poly1 d = p1_make(p.deg - 1);
+  for (int i = 1; i <= p.deg; i++) d.c[i - 1] = i * p.c[i];
+  chain[nc++] = d;
+  while (chain[nc - 1].deg > 0 && nc < 12) {
+    Poly1 a = chain[nc - 2];
+    const Poly1& b = chain[nc - 1];
+    for (int i = a.deg; i >= b.deg; i--) {   // a <- a mod b
+      const double f = a.c[i] / b.c[b.deg];
+      for (int j = 0; j <= b.deg; j++) a.c[i - b.deg + j] -= f * b.c[j];
+      a.c[i] = 0.0;
+    }
+    a.deg = std::max(b.deg - 1, 0);
+    double m = 0;
+    for (int i = 0; i <= a.deg; i++) m = std::max(m, std::fabs(a.c[i]));
+    if (m == 0) break;
+    for (int i = 0; i <= a.deg; i++) a.c[i] = -a.c[i] / m;
+    while (a.deg > 0 && std::fabs(a.c[a.deg]) <= 1e-13) a.deg--;
+    chain[nc++] = a;
+  }
+  auto changes = [&](double z) {
+    int n = 0, prev = 0;
+    for (int i = 0; i < nc; i++) {
+      const double v = p1_eval(chain[i], z);
+      const int sgn = v > 0 ? 1 : v < 0 ? -1 : 0;
+      if (sgn != 0) {
+        if (prev != 0 && sgn != prev) n++;
+        prev = sgn;
+      }
+    }
+    return n;
+  };
+  double bound = 0;
+  for (int i = 0; i < p.deg; i++) bound = std::max(bound, std::fabs(p.c[i] / p.c[p.deg]));
+  bound += 1.0;
+  int nroots = 0;
+  struct Iv {
+    double a, b;
+    int na, nb;
+  };
+  Iv stack[64];
+  int sp = 0;
+  stack[sp++] = Iv{-bound, bound, changes(-bound), changes(bound)};
+  while (sp > 0 && nroots < 10) {
+    const Iv iv = stack[--sp];
+    const int cnt = iv.na - iv.nb;
+    if (cnt <= 0) continue;
+    const double mid = 0.5 * (iv.a + iv.b);
+    if (cnt == 1 || iv.b - iv.a < 1e-13 * std::max(1.0, std::fabs(mid))) {
+      double a = iv.a, b = iv.b;
+      double fa = p1_eval(p, a);
+      for (int it = 0; it < 200 && b - a > 1e-16 * std::max(1.0, std::fabs(a) + std::fabs(b)); it++) {
+        const double m = 0.5 * (a + b);
+        if (m <= a || m >= b) break;
+        const double fm = p1_eval(p, m);
+        if (cnt == 1 && ((fa < 0) != (fm < 0))) {
+          b = m;
+        } else if (cnt == 1) {
+          a = m;
+          fa = fm;
+        } else
+          break;
+      }
+      roots[nroots++] = 0.5 * (a + b);
+      continue;
+    }
+    const int nm = changes(mid);
+    if (sp + 2 <= 64) {
+      stack[sp++] = Iv{mid, iv.b, nm, iv.nb};
+      stack[sp++] = Iv{iv.a, mid, iv.na, nm};
+    }
+  }
+  std::sort(roots, roots + nroots);
+  return nroots;
+}
+
+// relative_pose::fivept_nister(adapter, indices): essential matrices E (row-major 3x3, f1^T E f2 = 0), up to 10
+static int fivept_nister(const double* f1, const double* f2, const int* idx5, double E_out[][9]) {
+  double Q[5][9];
+  for (int i = 0; i < 5; i++) {
+    const double* f = f1 + 3 * idx5[i];
+    const double* fp = f2 + 3 * idx5[i];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Q[i][3 * r + c] = f[c] * fp[r];
+  }
+  double QtQ[81], V[81], w[9];
+  for (int a = 0; a < 9; a++)
+    for (int b = 0; b < 9; b++) {
+      double sacc = 0;
+      for (int i = 0; i < 5; i++) sacc += Q[i][a] * Q[i][b];
+      QtQ[a * 9 + b] = sacc;
+    }
+  jacobi_eig(9, QtQ, V, w);
+  // E = x A + y B + z C + D with the four null vectors (smallest eigenvalues)
+  double N[4][9];
+  for (int k = 0; k < 4; k++)
+    for (int a = 0; a < 9; a++) N[k][a] = V[a * 9 + k];
+  Poly3 E[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) E[r][c] = p3_lin(N[0][3 * r + c], N[1][3 * r + c], N[2][3 * r + c], N[3][3 * r + c]);
+  Poly3 cons[10];
+  // det(E)
+  {
+    const Poly3 m0 = p3_add(p3_mul(E[1][1], E[2][2]), p3_mul(E[1][2], E[2][1]), -1.0);
+    const Poly3 m1 = p3_add(p3_mul(E[1][0], E[2][2]), p3_mul(E[1][2], E[2][0]), -1.0);
+    const Poly3 m2 = p3_add(p3_mul(E[1][0], E[2][1]), p3_mul(E[1][1], E[2][0]), -1.0);
+    cons[0] = p3_add(p3_add(p3_mul(E[0][0], m0), p3_mul(E[0][1], m1), -1.0), p3_mul(E[0][2], m2));
+  }
+  // 2 E E^T E - trace(E E^T) E
+  {
+    Poly3 EEt[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        EEt[r][c] = p3_zero();
+        for (int k = 0; k < 3; k++) EEt[r][c] = p3_add(EEt[r][c], p3_mul(E[r][k], E[c][k]));
+      }
+    const Poly3 tr = p3_add(p3_add(EEt[0][0], EEt[1][1]), EEt[2][2]);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        Poly3 acc = p3_zero();
+        for (int k = 0; k < 3; k++) acc = p3_add(acc, p3_mul(EEt[r][k], E[k][c]));
+        cons[1 + 3 * r + c] = p3_add(p3_add(acc, acc), p3_mul(tr, E[r][c]), -1.0);
+      }
+  }
+  // Nister's monomial order: x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1
+  static const int mono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1},
+                                  {0, 2, 0}, {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2},
+                                  {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+  double M[10][20];
+  for (int r = 0; r < 10; r++)
+    for (int c = 0; c < 20; c++) M[r][c] = cons[r].c[p3_idx(mono[c][0], mono[c][1], mono[c][2])];
+  // Gauss-Jordan with partial pivoting on the first ten columns
+  for (int col = 0; col < 10; col++) {
+    int piv = col;
+    for (int r = col + 1; r < 10; r++)
+      if (std::fabs(M[r][col]) > std::fabs(M[piv][col])) piv = r;
+    if (std::fabs(M[piv][col]) < 1e-300) return 0;
+    if (piv != col)
+      for (int c = 0; c < 20; c++) std::swap(M[piv][c], M[col][c]);
+    const double inv = 1.0 / M[col][col];
+    for (int c = 0; c < 20; c++) M[col][c] *= inv;
+    for (int r = 0; r < 10; r++) {
+      if (r == col) continue;
+      const double f = M[r][col];
+      if (f == 0.0) continue;
+      for (int c = 0; c < 20; c++) M[r][c] -= f * M[col][c];
+    }
+  }
+  // rows <k> = <e> - z<f>, <l> = <g> - z<h>, <m> = <i> - z<j>: B(z) [x y 1]^T = 0
+  Poly1 B[3][3];
+  for (int q = 0; q < 3; q++) {
+    const double* e = M[4 + 2 * q] + 10;
+    const double* f = M[5 + 2 * q] + 10;
+    for (int v = 0; v < 2; v++) {   // x and y columns: degree 3
+      Poly1 b = p1_make(3);
+      b.c[0] = e[3 * v + 2];
+      b.c[1] = e[3 * v + 1] - f[3 * v + 2];
+      b.c[2] = e[3 * v] - f[3 * v + 1];
+      b.c[3] = -f[3 * v];
+      B[q][v] = b;
+    }
+    Poly1 b = p1_make(4);
+    b.c[0] = e[9];
+    b.c[1] = e[8] - f[9];
+    b.c[2] = e[7] - f[8];
+    b.c[3] = e[6] - f[7];
+    b.c[4] = -f[6];
+    B[q][2] = b;
+  }
+  const Poly1 det = p1_sub(
+      p1_sub(p1_mul(B[0][0], p1_sub(p1_mul(B[1][1], B[2][2]), p1_mul(B[1][2], B[2][1]))),
+             p1_mul(B[0][1], p1_sub(p1_mul(B[1][0], B[2][2]), p1_mul(B[1][2], B[2][0])))),
+      p1_mul(p1_mul(B[0][2], p1_sub(p1_mul(B[1][1], B[2][0]), p1_mul(B[1][0], B[2][1]))), [] {
+        Poly1 one = p1_make(0);
+        one.c[0] = 1.0;
+        return one;
+      }()));
+  double roots[10];
+  const int nr = p1_real_roots(det, roots);
+  int ne = 0;
+  for (int k = 0; k < nr; k++) {
+    const double z = roots[k];
+    double b[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) b[r][c] = p1_eval(B[r][c], z);
+    // [x y]: the best conditioned pair of rows
+    double bestdet = 0;
+    int r0 = 0, r1 = 1;
+    static const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (const auto& pr : pairs) {
+      const double dd = b[pr[0]][0] * b[pr[1]][1] - b[pr[0]][1] * b[pr[1]][0];
+      if (std::fabs(dd) > std::fabs(bestdet)) {
+        bestdet = dd;
+        r0 = pr[0];
+        r1 = pr[1];
+      }
+    }
+    if (bestdet == 0) continue;
+    const double x = (-b[r0][2] * b[r1][1] + b[r1][2] * b[r0][1]) / bestdet;
+    const double y = (-b[r0][0] * b[r1][2] + b[r1][0] * b[r0][2]) / bestdet;
+    // the 9-vector is column-major in OpenGV (Eigen): E(i, j) = e[i + 3 j], i.e. f1^T E f2 = 0, E = [t12]x R12
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        const int a = i + 3 * j;
+        E_out[ne][3 * i + j] = ((x * N[0][a] + y * N[1][a]) + z * N[2][a]) + N[3][a];
+      }
+    ne++;
+  }
+  return ne;
+}
+
+struct CentralRelativePose : Problem {   // CentralRelativePoseSacProblem(adapter, NISTER)
+  const double *f1, *f2;
+  int n;
+  int sampleSize() const override { return 5 + 3; }
+  int size() const override { return n; }
+  static void inverse_tf(const double* T, double* inv) {
+    double Rt[9], t[3] = {T[3], T[7], T[11]}, it[3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Rt[r * 3 + c] = T[c * 4 + r];
+    matvec3(Rt, t, it);
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) inv[r * 4 + c] = Rt[r * 3 + c];
+      inv[r * 4 + 3] = -it[r];
+    }
+  }
+  // the four [R | t] decompositions of an essential matrix (CentralRelativePoseSacProblem.cpp, NISTER case)
+  static void decompose(const double* E, double T[4][12]) {
+    double U[9], S[3], V[9];
+    svd3(E, U, S, V);
+    const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    auto uwvt = [&](const double* Wm, double* R) {
+      double UW[9];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) UW[r * 3 + c] = (U[r * 3] * Wm[c] + U[r * 3 + 1] * Wm[3 + c]) + U[r * 3 + 2] * Wm[6 + c];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) R[r * 3 + c] = (UW[r * 3] * V[c * 3] + UW[r * 3 + 1] * V[c * 3 + 1]) + UW[r * 3 + 2] * V[c * 3 + 2];
+      if (det3(R) < 0)
+        for (int i = 0; i < 9; i++) R[i] = -R[i];
+    };
+    double Ra[9], Rb[9];
+    uwvt(W, Ra);
+    uwvt(Wt, Rb);
+    const double scale = S[0];
+    const double ta[3] = {scale * U[2], scale * U[5], scale * U[8]};
+    const double* Rs[4] = {Ra, Rb, Ra, Rb};
+    const double sg[4] = {1, 1, -1, -1};
+    for (int j = 0; j < 4; j++)
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T[j][r * 4 + c] = Rs[j][r * 3 + c];
+        T[j][r * 4 + 3] = sg[j] * ta[r];
+      }
+  }
+  double reproj(const double* T, const double* inv, int i) const {   // same terms as TranslationOnly::distance
+    TranslationOnly tmp;
+    tmp.f1 = f1;
+    tmp.f2 = f2;
+    tmp.R12 = nullptr;
+    tmp.n = n;
+    return tmp.distance(T, inv, i);
+  }
+  bool computeModelCoefficients(const std::vector<int>& s, double* model) const override {
+    double Es[10][9];
+    const int ne = fivept_nister(f1, f2, s.data(), Es);
+    double bestQuality = 1000000.0;
+    int best_i = -1, best_j = -1;
+    for (int i = 0; i < ne; i++) {
+      double T[4][12];
+      decompose(Es[i], T);
+      for (int j = 0; j < 4; j++) {
+        double inv[12];
+        inverse_tf(T[j], inv);
+        double quality = 0.0;
+        for (int k = 0; k < sampleSize(); k++) quality += reproj(T[j], inv, s[k]);
+        if (quality < bestQuality) {
+          bestQuality = quality;
+          best_i = i;
+          best_j = j;
+        }
+      }
+    }
+    if (best_i == -1) return false;
+    double T[4][12];
+    decompose(Es[best_i], T);
+    std::memcpy(model, T[best_j], sizeof(double) * 12);
+    return true;
+  }
+  void prepare(const double* model, double* aux) const override { inverse_tf(model, aux); }
+  double distance(const double* model, const double* aux, int i) const override { return reproj(model, aux, i); }
+};
+
 }  // namespace
 
 RansacResult ransac_translation_only(const double* f1, const double* f2, int n, const double R12[9],
@@ -361,6 +793,22 @@ RansacResult ransac_point_cloud(const double* p1, const double* p2, int n, doubl
   p.p2 = p2;
   p.n = n;
   return run_ransac(p, threshold, max_iterations, probability, rng_policy);
+}
+
+RansacResult ransac_central_relative_pose_nister(const double* f1, const double* f2, int n, double threshold,
+                                                 int max_iterations, double probability, int rng_policy) {
+  CentralRelativePose p;
+  p.f1 = f1;
+  p.f2 = f2;
+  p.n = n;
+  return run_ransac(p, threshold, max_iterations, probability, rng_policy);
+}
+
+int fivept_nister_essentials(const double* f1, const double* f2, const int* idx5, double* E_out /* 10 x 9 */) {
+  double Es[10][9];
+  const int n = fivept_nister(f1, f2, idx5, Es);
+  std::memcpy(E_out, Es, sizeof(double) * 9 * n);
+  return n;
 }
 
 }  // namespace opengv_re

@@ -54,4 +54,11 @@ RansacResult ransac_translation_only(const double* f1, const double* f2, int n, 
 RansacResult ransac_point_cloud(const double* p1, const double* p2, int n, double threshold,
                                 int max_iterations, double probability, int rng_policy);
 
+// opengv::sac::Ransac<CentralRelativePoseSacProblem(NISTER)>::computeModel: 5-point problem, sample size 5 + 3
+RansacResult ransac_central_relative_pose_nister(const double* f1, const double* f2, int n, double threshold,
+                                                 int max_iterations, double probability, int rng_policy);
+
+// relative_pose::fivept_nister on five correspondences (test hook): up to 10 essential matrices, row-major
+int fivept_nister_essentials(const double* f1, const double* f2, const int* idx5, double* E_out);
+
 }  // namespace opengv_re

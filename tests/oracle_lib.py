@@ -451,6 +451,17 @@ def outlier_rejection_3d3d_given_rotation(cam: "Camera", ref_left_xy, ref_right_
     return _ransac_result(out, inl)
 
 
+def outlier_rejection_2d2d(f_ref, f_cur, tp: abi.TrackerParams) -> dict:
+    """Tracker::geometricOutlierRejection2d2d without rotation prior (5-point Nister RANSAC)"""
+    a = np.ascontiguousarray(f_ref, np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(f_cur, np.float64).reshape(-1, 3)
+    n = len(a)
+    inl = np.zeros(max(n, 1), np.int32)
+    out = abi.RansacOutput()
+    lib().kvo_outlier_rejection_2d2d(_p(a), _p(b), n, C.byref(tp), _p(inl), C.byref(out))
+    return _ransac_result(out, inl)
+
+
 def outlier_rejection_3d3d(ref_p3, cur_p3, tp: abi.TrackerParams) -> dict:
     """Tracker::geometricOutlierRejection3d3d (3-point Arun RANSAC) on matched 3-D points"""
     rp = np.ascontiguousarray(ref_p3, np.float64).reshape(-1, 3)

@@ -560,6 +560,60 @@ def test_outlier_rejection_3d3d_arun(ocam, case, n_in, n_out, noise):
         c.close()
 
 
+@pytest.mark.parametrize("planar,n_in,n_out,seed", [(False, 82, 0, 1), (False, 80, 40, 2), (True, 80, 40, 3),
+                                                    (False, 300, 200, 4), (False, 8, 0, 5), (False, 7, 0, 6)])
+def test_outlier_rejection_2d2d_five_point(ocam, planar, n_in, n_out, seed):
+    """5-point Nister RANSAC (opengv CentralRelativePoseSacProblem, ransac_use_2point_mono: 0): the device
+    solves 64 hypotheses per round in parallel and replays them in order; same sample stream, same solver
+    operation for operation -> identical inlier sets, iteration counts and poses as the CPU path; scenes of
+    tests/testTracker.cpp:704-802."""
+    L, R_ = euroc_cams()
+    p = _euroc_ransac_params()
+    p.tracker.ransac_use_2point_mono = 0
+    p.tracker.ransac_max_iterations = 1000
+    c = F.Context(L, R_, p)
+    try:
+        rng = np.random.default_rng(500 + seed)
+        R = TR.expmap([0.01, 0.01, 0.01])
+        T = np.array([1.0, 0.0, 0.0])
+        f_ref, f_cur = TR.mono_scene(ocam, rng, R, T, planar, n_in, n_out)
+        exp = O.outlier_rejection_2d2d(f_ref, f_cur, p.tracker)
+        got = c.outlier_rejection_2d2d(f_ref, f_cur)
+        _same_ransac(got, exp)
+        if n_in >= 80:
+            assert exp["status"] == abi.TRACKING_VALID
+            assert set(range(n_in)) <= set(exp["inliers"]) and len(exp["inliers"]) <= n_in + 3
+            assert np.allclose(exp["pose"][:, :3], R, atol=1e-8)
+        if n_in < 8:
+            assert exp["status"] == abi.TRACKING_INVALID   # fewer matches than the 5 + 3 sample
+    finally:
+        c.close()
+
+
+def test_frontend_sequence_d455_style_ransac(seq, ocam):
+    """params/D455/FrontendParams.yaml selects ransac_use_2point_mono: 0 and ransac_use_1point_stereo: 0 (5-point
+    mono + 3-point stereo): keyframe outlier rejection through both, two streams, identical to the oracle."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=200)
+    p.tracker.ransac_use_2point_mono = 0
+    p.tracker.ransac_use_1point_stereo = 0
+    p.tracker.ransac_max_iterations = 500          # D455 values
+    p.tracker.ransac_threshold_stereo = 0.8
+    p.tracker.ransac_probability = 0.995
+    fe = [O.Frontend(L, R, p) for _ in range(2)]
+    c = F.Context(L, R, p, batch=2)
+    try:
+        _run_sequence(fe, c, seq, stream_of=lambda s, i: i if s == 0 else 8 - i, force_kf=True, n=6)
+        last = [c.get_output(s) for s in range(2)]
+    finally:
+        c.close()
+    for o in last:
+        assert o["tracking_status_mono"] in (abi.TRACKING_VALID, abi.TRACKING_LOW_DISPARITY, abi.TRACKING_FEW_MATCHES)
+        assert o["nr_mono_putatives"] > 50
+
+
 @pytest.mark.parametrize("one_point", [0, 1])
 def test_frontend_sequence_three_point_stereo(seq, ocam, one_point):
     """outlierRejectionStereo's 3-point branch (VisionImuFrontend.cpp:137-142): with

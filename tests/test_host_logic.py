@@ -99,13 +99,20 @@ def test_unsupported_configurations_are_rejected():
     Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
     assert p.use_ransac == 1 and p.tracker.ransac_use_2point_mono == 1 and p.tracker.ransac_randomize == 0
-    for field, value in (("ransac_use_2point_mono", 0),    # 5-point (Nister) problem
-                         ("ransac_randomize", 1)):         # time-seeded sampling
+    for field, value in (("ransac_randomize", 1),):        # time-seeded sampling
         q = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
         setattr(q.tracker, field, value)
         with pytest.raises(L.KvfeError) as e:
             F.Context(Lc, Rc, q)
         assert e.value.status == abi.KVFE_ERR_UNSUPPORTED, field
+    # the 5-point problem is implemented for 2d2d_algorithm: 1 (NISTER, every shipped YAML) only
+    q = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    assert q.tracker.pose_2d2d_algorithm == 1
+    q.tracker.ransac_use_2point_mono = 0
+    q.tracker.pose_2d2d_algorithm = 0   # STEWENIUS
+    with pytest.raises(L.KvfeError) as e:
+        F.Context(Lc, Rc, q)
+    assert e.value.status == abi.KVFE_ERR_UNSUPPORTED
 
 
 def test_yaml_parsing_euroc():

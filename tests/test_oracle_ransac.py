@@ -230,6 +230,57 @@ def test_3d3d_arun_ransac(cam, case, n_in, n_out):
     assert np.allclose(r["pose"][:, :3], R, atol=1e-6) and np.allclose(r["pose"][:, 3], T, atol=1e-6)
 
 
+@pytest.mark.parametrize("planar,n_in,n_out", [(False, 82, 0), (False, 80, 40), (True, 80, 40)])
+def test_2d2d_five_point_nister(cam, planar, n_in, n_out):
+    """testTracker.cpp:704-802 (ransac_use_2point_mono_ = false, 1000 iterations): opengv
+    CentralRelativePoseSacProblem(NISTER) keeps every synthetic inlier and rejects every outlier; rotation and
+    translation direction recovered (the translation norm is the scale of the essential matrix: arbitrary)."""
+    rng = np.random.default_rng(5 + n_out + int(planar))
+    R, T = expmap([0.01, 0.01, 0.01]), np.array([1.0, 0.0, 0.0])
+    f_ref, f_cur = mono_scene(cam, rng, R, T, planar, n_in, n_out)
+    r = O.outlier_rejection_2d2d(f_ref, f_cur, tracker_params(ransac_max_iterations=1000, ransac_use_2point_mono=0))
+    assert r["status"] == abi.TRACKING_VALID
+    assert list(r["inliers"]) == list(range(n_in))
+    assert np.allclose(r["pose"][:, :3], R, atol=1e-9)
+    t = r["pose"][:, 3]
+    assert abs(abs(t @ T) / np.linalg.norm(t) - 1) < 1e-9
+    if n_out == 0:
+        assert r["iterations"] == 1
+
+
+def test_five_point_solver_returns_the_true_essential_matrix():
+    """relative_pose::fivept_nister on five exact correspondences: every returned E satisfies the epipolar
+    constraints, det E = 0 and 2 E E^T E - tr(E E^T) E = 0, and one of them is [t]x R of the scene."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        R = expmap(rng.normal(0, 0.2, 3))
+        T = rng.normal(0, 1, 3)
+        P3 = np.stack([rng.uniform(-2, 2, 5), rng.uniform(-2, 2, 5), rng.uniform(3, 8, 5)], 1)
+        f1 = np.ascontiguousarray(P3 / np.linalg.norm(P3, axis=1, keepdims=True))
+        pc = (R.T @ (P3 - T).T).T
+        f2 = np.ascontiguousarray(pc / np.linalg.norm(pc, axis=1, keepdims=True))
+        idx = np.arange(5, dtype=np.int32)
+        E = np.zeros((10, 9))
+        L = O.lib()
+        L.kvo_fivept_nister.argtypes = [C.c_void_p] * 4
+        n = L.kvo_fivept_nister(f1.ctypes.data, f2.ctypes.data, idx.ctypes.data, E.ctypes.data)
+        assert 1 <= n <= 10
+        skew = np.array([[0, -T[2], T[1]], [T[2], 0, -T[0]], [-T[1], T[0], 0]])
+        Et = skew @ R
+        Et /= np.linalg.norm(Et)
+        best = 1.0
+        for k in range(n):
+            Ek = E[k].reshape(3, 3)
+            sc = np.linalg.norm(Ek)
+            assert max(abs(f1[i] @ Ek @ f2[i]) for i in range(5)) < 1e-10 * sc
+            assert abs(np.linalg.det(Ek)) < 1e-6 * sc ** 3
+            assert np.abs(2 * Ek @ Ek.T @ Ek - np.trace(Ek @ Ek.T) * Ek).max() < 1e-6 * sc ** 3
+            En = Ek / sc
+            best = min(best, np.abs(En - Et).max(), np.abs(En + Et).max())
+        assert best < 1e-7, (trial, best)
+
+
 def test_sampler_stream_matches_std_mt19937():
     """SampleConsensusProblem::rnd(): std::mt19937(12345) through uniform_int_distribution<int>(0, INT_MAX);
     numpy's legacy seeding is the same init_genrand, so its raw stream is the reference stream."""
