@@ -237,6 +237,22 @@ class Tracker {
     std::memcpy(r.info, o.info, sizeof(r.info));
     return r;
   }
+  // geometricOutlierRejection2d2d without rotation prior (Tracker.cpp:262-275): 5-point Nister RANSAC
+  TrackingStatusPose geometricOutlierRejection2d2d(const std::vector<double>& f_ref,
+                                                   const std::vector<double>& f_cur,
+                                                   std::vector<int>* inliers) const {
+    const int32_t n = (int32_t)(f_ref.size() / 3);
+    std::vector<int32_t> inl((size_t)(n > 0 ? n : 1));
+    kvfe_ransac_output o;
+    c_.check(kvfe_outlier_rejection_2d2d(c_.get(), f_ref.data(), f_cur.data(), n, inl.data(), &o),
+             "geometricOutlierRejection2d2d");
+    inliers->assign(inl.begin(), inl.begin() + o.n_inliers);
+    TrackingStatusPose r;
+    r.status = o.status;
+    std::memcpy(r.pose, o.pose, sizeof(r.pose));
+    std::memset(r.info, 0, sizeof(r.info));
+    return r;
+  }
   // geometricOutlierRejection3d3d (Tracker.cpp:667-742): 3-point Arun RANSAC on the matched keypoints_3d_
   TrackingStatusPose geometricOutlierRejection3d3d(const std::vector<double>& ref_points_3d,
                                                    const std::vector<double>& cur_points_3d,

@@ -591,17 +591,16 @@ def test_outlier_rejection_2d2d_five_point(ocam, planar, n_in, n_out, seed):
 
 
 def test_frontend_sequence_d455_style_ransac(seq, ocam):
-    """params/D455/FrontendParams.yaml selects ransac_use_2point_mono: 0 and ransac_use_1point_stereo: 0 (5-point
-    mono + 3-point stereo): keyframe outlier rejection through both, two streams, identical to the oracle."""
+    """The shipped params/D455/FrontendParams.yaml as it is (ransac_use_2point_mono: 0, ransac_use_1point_stereo:
+    0, 500 iterations, no optical-flow predictor) on the EuRoC camera pair: keyframe outlier rejection through
+    the 5-point and the 3-point problems, two streams, identical to the oracle."""
     seq = dict(seq)
     seq["camR"] = _kf_rotations(seq["body_R"], ocam)
     L, R = euroc_cams()
-    p = _euroc_ransac_params(max_features_per_frame=200)
-    p.tracker.ransac_use_2point_mono = 0
-    p.tracker.ransac_use_1point_stereo = 0
-    p.tracker.ransac_max_iterations = 500          # D455 values
-    p.tracker.ransac_threshold_stereo = 0.8
-    p.tracker.ransac_probability = 0.995
+    p = P.load_frontend_params(os.path.join(G, "params_d455", "FrontendParams.yaml"), use_ransac=None)
+    assert p.use_ransac == 1 and p.tracker.ransac_use_2point_mono == 0 and p.tracker.ransac_use_1point_stereo == 0
+    assert p.tracker.ransac_max_iterations == 500 and p.tracker.pose_2d2d_algorithm == 1
+    p.detector.max_features_per_frame = 200
     fe = [O.Frontend(L, R, p) for _ in range(2)]
     c = F.Context(L, R, p, batch=2)
     try:
