@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--ransac", type=int, default=1, choices=[0, 1],
                     help="useRANSAC of params/Euroc/FrontendParams.yaml (1 = as shipped: 2-point mono + "
                          "1-point stereo geometric outlier rejection on every keyframe)")
+    ap.add_argument("--mono-2point", type=int, default=1, choices=[0, 1],
+                    help="ransac_use_2point_mono (0: the 5-point problem of params/D455)")
+    ap.add_argument("--stereo-1point", type=int, default=1, choices=[0, 1],
+                    help="ransac_use_1point_stereo (0: the 3-point Arun problem of params/D455)")
     ap.add_argument("--ring", type=int, default=6, help="distinct frames per stream (ping-pong)")
     ap.add_argument("--unique-streams", type=int, default=8)
     ap.add_argument("--groups", type=int, default=0,
@@ -101,6 +105,8 @@ def main():
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=args.ransac)
     p.detector.max_features_per_frame = args.features
     p.tracker.klt_max_level = args.klt_max_level
+    p.tracker.ransac_use_2point_mono = args.mono_2point
+    p.tracker.ransac_use_1point_stereo = args.stereo_1point
 
     # ---- synthetic input ring, resident in HBM ---------------------------------------------------
     U = max(1, min(args.unique_streams, B))
