@@ -999,155 +999,161 @@ __global__ __launch_bounds__(RS_T) void stereo_arun_kernel(KParams P, Tables T, 
 // points like CentralRelativePoseSacProblem::computeModelCoefficients.  One thread solves one hypothesis; a
 // batch of hypotheses is solved in parallel and replayed in order (the sample stream does not depend on results).
 // ---------------------------------------------------------------------------------------------
-__constant__ signed char NP_IDX[4][4][4] = {{{0, 3, 9, 19}, {2, 8, 18, -1}, {7, 17, -1, -1}, {16, -1, -1, -1}},
-                                            {{1, 6, 15, -1}, {5, 14, -1, -1}, {13, -1, -1, -1}, {-1, -1, -1, -1}},
-                                            {{4, 12, -1, -1}, {11, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}},
-                                            {{10, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}}};
-__constant__ signed char NP_MONO[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1},
-                                           {0, 2, 0}, {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2},
-                                           {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
-struct NPoly3 {
-  double c[20];
+// per-hypothesis work area in LDS (dynamic indexing of private arrays would go to scratch memory)
+struct NpSlot {
+  double Q[5][9];
+  double N[4][9];
+  double M[10][20];
+  double chain[12][12];   // Sturm chain, coefficient k of z^k
+  int cdeg[12];
+  int pad[4];
 };
-__device__ NPoly3 np3_zero() {
-  NPoly3 r;
-  for (int i = 0; i < 20; i++) r.c[i] = 0.0;
-  return r;
+// linear x linear -> quadratic [x2 y2 z2 xy xz yz x y z 1]
+__device__ __forceinline__ void np_lin_mul(const double* a, const double* b, double* q) {
+  q[0] = a[0] * b[0];
+  q[1] = a[1] * b[1];
+  q[2] = a[2] * b[2];
+  q[3] = a[0] * b[1] + a[1] * b[0];
+  q[4] = a[0] * b[2] + a[2] * b[0];
+  q[5] = a[1] * b[2] + a[2] * b[1];
+  q[6] = a[0] * b[3] + a[3] * b[0];
+  q[7] = a[1] * b[3] + a[3] * b[1];
+  q[8] = a[2] * b[3] + a[3] * b[2];
+  q[9] = a[3] * b[3];
 }
-__device__ NPoly3 np3_lin(double x, double y, double z, double w) {
-  NPoly3 r = np3_zero();
-  r.c[NP_IDX[1][0][0]] = x;
-  r.c[NP_IDX[0][1][0]] = y;
-  r.c[NP_IDX[0][0][1]] = z;
-  r.c[NP_IDX[0][0][0]] = w;
-  return r;
+// quadratic x linear -> cubic in Nister's monomial order, out += sign * product
+__device__ __forceinline__ void np_quadlin_acc(const double* q, const double* l, double sign, double* out) {
+  out[0] += sign * (q[0] * l[0]);
+  out[1] += sign * (q[1] * l[1]);
+  out[2] += sign * (q[0] * l[1] + q[3] * l[0]);
+  out[3] += sign * (q[1] * l[0] + q[3] * l[1]);
+  out[4] += sign * (q[0] * l[2] + q[4] * l[0]);
+  out[5] += sign * (q[0] * l[3] + q[6] * l[0]);
+  out[6] += sign * (q[1] * l[2] + q[5] * l[1]);
+  out[7] += sign * (q[1] * l[3] + q[7] * l[1]);
+  out[8] += sign * ((q[3] * l[2] + q[4] * l[1]) + q[5] * l[0]);
+  out[9] += sign * ((q[3] * l[3] + q[6] * l[1]) + q[7] * l[0]);
+  out[10] += sign * (q[2] * l[0] + q[4] * l[2]);
+  out[11] += sign * ((q[4] * l[3] + q[6] * l[2]) + q[8] * l[0]);
+  out[12] += sign * (q[6] * l[3] + q[9] * l[0]);
+  out[13] += sign * (q[2] * l[1] + q[5] * l[2]);
+  out[14] += sign * ((q[5] * l[3] + q[7] * l[2]) + q[8] * l[1]);
+  out[15] += sign * (q[7] * l[3] + q[9] * l[1]);
+  out[16] += sign * (q[2] * l[2]);
+  out[17] += sign * (q[2] * l[3] + q[8] * l[2]);
+  out[18] += sign * (q[8] * l[3] + q[9] * l[2]);
+  out[19] += sign * (q[9] * l[3]);
 }
-__device__ NPoly3 np3_add(const NPoly3& a, const NPoly3& b, double sb = 1.0) {
-  NPoly3 r;
-  for (int i = 0; i < 20; i++) r.c[i] = a.c[i] + sb * b.c[i];
-  return r;
-}
-__device__ NPoly3 np3_mul(const NPoly3& a, const NPoly3& b) {
-  NPoly3 r = np3_zero();
-  for (int i1 = 0; i1 <= 3; i1++)
-    for (int j1 = 0; i1 + j1 <= 3; j1++)
-      for (int k1 = 0; i1 + j1 + k1 <= 3; k1++) {
-        const double ca = a.c[NP_IDX[i1][j1][k1]];
-        if (ca == 0.0) continue;
-        for (int i2 = 0; i1 + j1 + k1 + i2 <= 3; i2++)
-          for (int j2 = 0; i1 + j1 + k1 + i2 + j2 <= 3; j2++)
-            for (int k2 = 0; i1 + j1 + k1 + i2 + j2 + k2 <= 3; k2++)
-              r.c[NP_IDX[i1 + i2][j1 + j2][k1 + k2]] += ca * b.c[NP_IDX[i2][j2][k2]];
-      }
-  return r;
-}
-__device__ void np_jacobi_eig9(double* A /* 81, destroyed */, double* V, double* w) {
-  const int n = 9;
-  for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
-    for (int p = 0; p < n; p++)
-      for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
-    if (off < 1e-300) break;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
-        const double apq = A[p * n + q];
-        if (fabs(apq) < 1e-300) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-        for (int k = 0; k < n; k++) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - sn * akq;
-          A[k * n + q] = sn * akp + c * akq;
-        }
-        for (int k = 0; k < n; k++) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - sn * aqk;
-          A[q * n + k] = sn * apk + c * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - sn * vkq;
-          V[k * n + q] = sn * vkp + c * vkq;
+// four orthonormal null vectors of W.Q (5 x 9): Gauss-Jordan with complete pivoting, Gram-Schmidt
+__device__ bool np_nullspace(NpSlot& W) {
+  int pc[5];
+  unsigned used = 0;
+  for (int s = 0; s < 5; s++) {
+    int br = s, bc = -1;
+    double bv = -1.0;
+    for (int r = s; r < 5; r++)
+      for (int c = 0; c < 9; c++) {
+        if (used & (1u << c)) continue;
+        const double v = fabs(W.Q[r][c]);
+        if (v > bv) {
+          bv = v;
+          br = r;
+          bc = c;
         }
       }
-  }
-  int order[9];
-  for (int i = 0; i < n; i++) order[i] = i;
-  for (int i = 1; i < n; i++)
-    for (int j = i; j > 0 && A[order[j] * n + order[j]] < A[order[j - 1] * n + order[j - 1]]; j--) {
-      const int t = order[j];
-      order[j] = order[j - 1];
-      order[j - 1] = t;
+    if (!(bv > 1e-300)) return false;
+    if (br != s)
+      for (int c = 0; c < 9; c++) {
+        const double t = W.Q[br][c];
+        W.Q[br][c] = W.Q[s][c];
+        W.Q[s][c] = t;
+      }
+    used |= 1u << bc;
+    pc[s] = bc;
+    const double inv = 1.0 / W.Q[s][bc];
+    for (int c = 0; c < 9; c++) W.Q[s][c] *= inv;
+    for (int r = 0; r < 5; r++) {
+      if (r == s) continue;
+      const double f = W.Q[r][bc];
+      if (f == 0.0) continue;
+      for (int c = 0; c < 9; c++) W.Q[r][c] -= f * W.Q[s][c];
     }
-  double V2[81];
-  for (int c = 0; c < n; c++) {
-    w[c] = A[order[c] * n + order[c]];
-    for (int r = 0; r < n; r++) V2[r * n + c] = V[r * n + order[c]];
   }
-  for (int i = 0; i < 81; i++) V[i] = V2[i];
+  int j = 0;
+  for (int fc = 0; fc < 9; fc++) {
+    if (used & (1u << fc)) continue;
+    for (int c = 0; c < 9; c++) W.N[j][c] = 0.0;
+    W.N[j][fc] = 1.0;
+    for (int s = 0; s < 5; s++) W.N[j][pc[s]] = -W.Q[s][fc];
+    j++;
+  }
+  for (int a = 0; a < 4; a++) {
+    for (int b = 0; b < a; b++) {
+      double d = 0;
+      for (int c = 0; c < 9; c++) d += W.N[a][c] * W.N[b][c];
+      for (int c = 0; c < 9; c++) W.N[a][c] -= d * W.N[b][c];
+    }
+    double nn = 0;
+    for (int c = 0; c < 9; c++) nn += W.N[a][c] * W.N[a][c];
+    nn = sqrt(nn);
+    if (!(nn > 1e-300)) return false;
+    for (int c = 0; c < 9; c++) W.N[a][c] = W.N[a][c] / nn;
+  }
+  return true;
 }
-struct NPoly1 {
-  double c[12];
-  int deg;
-};
-__device__ NPoly1 np1_make(int deg) {
-  NPoly1 r;
-  for (int i = 0; i < 12; i++) r.c[i] = 0.0;
-  r.deg = deg;
-  return r;
+// r[i + j] += a[i] * b[j], i ascending then j ascending (Poly1 multiplication of the oracle), fixed degrees
+template <int DA, int DB>
+__device__ __forceinline__ void np_conv(const double* a, const double* b, double* r) {
+#pragma unroll
+  for (int i = 0; i <= DA + DB; i++) r[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i <= DA; i++)
+#pragma unroll
+    for (int j = 0; j <= DB; j++) r[i + j] += a[i] * b[j];
 }
-__device__ NPoly1 np1_mul(const NPoly1& a, const NPoly1& b) {
-  NPoly1 r = np1_make(a.deg + b.deg);
-  for (int i = 0; i <= a.deg; i++)
-    for (int j = 0; j <= b.deg; j++) r.c[i + j] += a.c[i] * b.c[j];
-  return r;
-}
-__device__ NPoly1 np1_sub(const NPoly1& a, const NPoly1& b) {
-  NPoly1 r = np1_make(max(a.deg, b.deg));
-  for (int i = 0; i <= a.deg; i++) r.c[i] += a.c[i];
-  for (int i = 0; i <= b.deg; i++) r.c[i] -= b.c[i];
-  return r;
-}
-__device__ double np1_eval(const NPoly1& a, double z) {
+__device__ double np_chain_eval(const NpSlot& W, int k, double z) {
   double v = 0;
-  for (int i = a.deg; i >= 0; i--) v = v * z + a.c[i];
+  for (int i = W.cdeg[k]; i >= 0; i--) v = v * z + W.chain[k][i];
   return v;
 }
-__device__ int np1_real_roots(NPoly1 p, double* roots) {
+// real roots of the polynomial in W.chain[0] (degree W.cdeg[0]) by a Sturm chain + bisection
+__device__ int np_real_roots(NpSlot& W, double* roots) {
   {
+    int deg = W.cdeg[0];
     double m = 0;
-    for (int i = 0; i <= p.deg; i++) m = fmax(m, fabs(p.c[i]));
-    while (p.deg > 0 && fabs(p.c[p.deg]) <= 1e-14 * m) p.deg--;
+    for (int i = 0; i <= deg; i++) m = fmax(m, fabs(W.chain[0][i]));
+    while (deg > 0 && fabs(W.chain[0][deg]) <= 1e-14 * m) deg--;
+    W.cdeg[0] = deg;
   }
-  if (p.deg < 1) return 0;
-  NPoly1 chain[12];
-  int nc = 0;
-  chain[nc++] = p;
-  NPoly1 d = np1_make(p.deg - 1);
-  for (int i = 1; i <= p.deg; i++) d.c[i - 1] = i * p.c[i];
-  chain[nc++] = d;
-  while (chain[nc - 1].deg > 0 && nc < 12) {
-    NPoly1 a = chain[nc - 2];
-    const NPoly1& b = chain[nc - 1];
-    for (int i = a.deg; i >= b.deg; i--) {
-      const double f = a.c[i] / b.c[b.deg];
-      for (int j = 0; j <= b.deg; j++) a.c[i - b.deg + j] -= f * b.c[j];
-      a.c[i] = 0.0;
+  const int pdeg = W.cdeg[0];
+  if (pdeg < 1) return 0;
+  int nc = 1;
+  for (int i = 1; i <= pdeg; i++) W.chain[1][i - 1] = i * W.chain[0][i];
+  W.cdeg[1] = pdeg - 1;
+  nc = 2;
+  while (W.cdeg[nc - 1] > 0 && nc < 12) {
+    const int da = W.cdeg[nc - 2], db = W.cdeg[nc - 1];
+    double* a = W.chain[nc];   // remainder built in place in the next slot
+    for (int i = 0; i <= da; i++) a[i] = W.chain[nc - 2][i];
+    const double* b = W.chain[nc - 1];
+    for (int i = da; i >= db; i--) {
+      const double f = a[i] / b[db];
+      for (int j = 0; j <= db; j++) a[i - db + j] -= f * b[j];
+      a[i] = 0.0;
     }
-    a.deg = max(b.deg - 1, 0);
+    int deg = max(db - 1, 0);
     double m = 0;
-    for (int i = 0; i <= a.deg; i++) m = fmax(m, fabs(a.c[i]));
+    for (int i = 0; i <= deg; i++) m = fmax(m, fabs(a[i]));
     if (m == 0) break;
-    for (int i = 0; i <= a.deg; i++) a.c[i] = -a.c[i] / m;
-    while (a.deg > 0 && fabs(a.c[a.deg]) <= 1e-13) a.deg--;
-    chain[nc++] = a;
+    for (int i = 0; i <= deg; i++) a[i] = -a[i] / m;
+    while (deg > 0 && fabs(a[deg]) <= 1e-13) deg--;
+    W.cdeg[nc] = deg;
+    nc++;
   }
   auto changes = [&](double z) {
     int n = 0, prev = 0;
     for (int i = 0; i < nc; i++) {
-      const double v = np1_eval(chain[i], z);
+      const double v = np_chain_eval(W, i, z);
       const int sgn = v > 0 ? 1 : v < 0 ? -1 : 0;
       if (sgn != 0) {
         if (prev != 0 && sgn != prev) n++;
@@ -1157,17 +1163,17 @@ __device__ int np1_real_roots(NPoly1 p, double* roots) {
     return n;
   };
   double bound = 0;
-  for (int i = 0; i < p.deg; i++) bound = fmax(bound, fabs(p.c[i] / p.c[p.deg]));
+  for (int i = 0; i < pdeg; i++) bound = fmax(bound, fabs(W.chain[0][i] / W.chain[0][pdeg]));
   bound += 1.0;
   int nroots = 0;
+  // interval stack: reuse the unused rows of Q / N / M?  a small private stack is fine (depth <= 64)
   double sa[64], sb[64];
   int sna[64], snb[64];
-  int sp = 0;
   sa[0] = -bound;
   sb[0] = bound;
   sna[0] = changes(-bound);
   snb[0] = changes(bound);
-  sp = 1;
+  int sp = 1;
   while (sp > 0 && nroots < 10) {
     --sp;
     const double ia = sa[sp], ib = sb[sp];
@@ -1177,11 +1183,11 @@ __device__ int np1_real_roots(NPoly1 p, double* roots) {
     const double mid = 0.5 * (ia + ib);
     if (cnt == 1 || ib - ia < 1e-13 * fmax(1.0, fabs(mid))) {
       double a = ia, b = ib;
-      double fa = np1_eval(p, a);
+      double fa = np_chain_eval(W, 0, a);
       for (int it = 0; it < 200 && b - a > 1e-16 * fmax(1.0, fabs(a) + fabs(b)); it++) {
         const double m = 0.5 * (a + b);
         if (m <= a || m >= b) break;
-        const double fm = np1_eval(p, m);
+        const double fm = np_chain_eval(W, 0, m);
         if (cnt == 1 && ((fa < 0) != (fm < 0))) {
           b = m;
         } else if (cnt == 1) {
@@ -1215,137 +1221,6 @@ __device__ int np1_real_roots(NPoly1 p, double* roots) {
     }
   return nroots;
 }
-// relative_pose::fivept_nister: essential matrices (row-major, f1^T E f2 = 0), up to 10
-__device__ int np_fivept(const double* f1, const double* f2, const int* idx5, double (*E_out)[9]) {
-  double QtQ[81], V[81], w[9];
-  {
-    double Q[5][9];
-    for (int i = 0; i < 5; i++) {
-      const double* f = f1 + 3 * (size_t)idx5[i];
-      const double* fp = f2 + 3 * (size_t)idx5[i];
-      for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) Q[i][3 * r + c] = f[c] * fp[r];
-    }
-    for (int a = 0; a < 9; a++)
-      for (int b = 0; b < 9; b++) {
-        double sacc = 0;
-        for (int i = 0; i < 5; i++) sacc += Q[i][a] * Q[i][b];
-        QtQ[a * 9 + b] = sacc;
-      }
-  }
-  np_jacobi_eig9(QtQ, V, w);
-  double N[4][9];
-  for (int k = 0; k < 4; k++)
-    for (int a = 0; a < 9; a++) N[k][a] = V[a * 9 + k];
-  double M[10][20];
-  {
-    NPoly3 E[3][3];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++)
-        E[r][c] = np3_lin(N[0][3 * r + c], N[1][3 * r + c], N[2][3 * r + c], N[3][3 * r + c]);
-    NPoly3 cons;
-    auto put = [&](int row, const NPoly3& q) {
-      for (int c = 0; c < 20; c++) M[row][c] = q.c[NP_IDX[NP_MONO[c][0]][NP_MONO[c][1]][NP_MONO[c][2]]];
-    };
-    {
-      const NPoly3 m0 = np3_add(np3_mul(E[1][1], E[2][2]), np3_mul(E[1][2], E[2][1]), -1.0);
-      const NPoly3 m1 = np3_add(np3_mul(E[1][0], E[2][2]), np3_mul(E[1][2], E[2][0]), -1.0);
-      const NPoly3 m2 = np3_add(np3_mul(E[1][0], E[2][1]), np3_mul(E[1][1], E[2][0]), -1.0);
-      cons = np3_add(np3_add(np3_mul(E[0][0], m0), np3_mul(E[0][1], m1), -1.0), np3_mul(E[0][2], m2));
-      put(0, cons);
-    }
-    NPoly3 EEt[3][3];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) {
-        EEt[r][c] = np3_zero();
-        for (int k = 0; k < 3; k++) EEt[r][c] = np3_add(EEt[r][c], np3_mul(E[r][k], E[c][k]));
-      }
-    const NPoly3 tr = np3_add(np3_add(EEt[0][0], EEt[1][1]), EEt[2][2]);
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) {
-        NPoly3 acc = np3_zero();
-        for (int k = 0; k < 3; k++) acc = np3_add(acc, np3_mul(EEt[r][k], E[k][c]));
-        cons = np3_add(np3_add(acc, acc), np3_mul(tr, E[r][c]), -1.0);
-        put(1 + 3 * r + c, cons);
-      }
-  }
-  for (int col = 0; col < 10; col++) {
-    int piv = col;
-    for (int r = col + 1; r < 10; r++)
-      if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
-    if (fabs(M[piv][col]) < 1e-300) return 0;
-    if (piv != col)
-      for (int c = 0; c < 20; c++) {
-        const double t = M[piv][c];
-        M[piv][c] = M[col][c];
-        M[col][c] = t;
-      }
-    const double inv = 1.0 / M[col][col];
-    for (int c = 0; c < 20; c++) M[col][c] *= inv;
-    for (int r = 0; r < 10; r++) {
-      if (r == col) continue;
-      const double f = M[r][col];
-      if (f == 0.0) continue;
-      for (int c = 0; c < 20; c++) M[r][c] -= f * M[col][c];
-    }
-  }
-  NPoly1 B[3][3];
-  for (int q = 0; q < 3; q++) {
-    const double* e = M[4 + 2 * q] + 10;
-    const double* f = M[5 + 2 * q] + 10;
-    for (int v = 0; v < 2; v++) {
-      NPoly1 b = np1_make(3);
-      b.c[0] = e[3 * v + 2];
-      b.c[1] = e[3 * v + 1] - f[3 * v + 2];
-      b.c[2] = e[3 * v] - f[3 * v + 1];
-      b.c[3] = -f[3 * v];
-      B[q][v] = b;
-    }
-    NPoly1 b = np1_make(4);
-    b.c[0] = e[9];
-    b.c[1] = e[8] - f[9];
-    b.c[2] = e[7] - f[8];
-    b.c[3] = e[6] - f[7];
-    b.c[4] = -f[6];
-    B[q][2] = b;
-  }
-  NPoly1 one = np1_make(0);
-  one.c[0] = 1.0;
-  const NPoly1 det = np1_sub(
-      np1_sub(np1_mul(B[0][0], np1_sub(np1_mul(B[1][1], B[2][2]), np1_mul(B[1][2], B[2][1]))),
-              np1_mul(B[0][1], np1_sub(np1_mul(B[1][0], B[2][2]), np1_mul(B[1][2], B[2][0])))),
-      np1_mul(np1_mul(B[0][2], np1_sub(np1_mul(B[1][1], B[2][0]), np1_mul(B[1][0], B[2][1]))), one));
-  double roots[10];
-  const int nr = np1_real_roots(det, roots);
-  int ne = 0;
-  for (int k = 0; k < nr; k++) {
-    const double z = roots[k];
-    double b[3][3];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) b[r][c] = np1_eval(B[r][c], z);
-    double bestdet = 0;
-    int r0 = 0, r1 = 1;
-    const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-    for (int pi = 0; pi < 3; pi++) {
-      const double dd = b[pairs[pi][0]][0] * b[pairs[pi][1]][1] - b[pairs[pi][0]][1] * b[pairs[pi][1]][0];
-      if (fabs(dd) > fabs(bestdet)) {
-        bestdet = dd;
-        r0 = pairs[pi][0];
-        r1 = pairs[pi][1];
-      }
-    }
-    if (bestdet == 0) continue;
-    const double x = (-b[r0][2] * b[r1][1] + b[r1][2] * b[r0][1]) / bestdet;
-    const double y = (-b[r0][0] * b[r1][2] + b[r1][0] * b[r0][2]) / bestdet;
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        const int a = i + 3 * j;
-        E_out[ne][3 * i + j] = ((x * N[0][a] + y * N[1][a]) + z * N[2][a]) + N[3][a];
-      }
-    ne++;
-  }
-  return ne;
-}
 __device__ void np_set_model(const double* R, const double* t, RsModel* M) {
   for (int i = 0; i < 9; i++) M->R[i] = R[i];
   for (int i = 0; i < 3; i++) M->t[i] = t[i];
@@ -1378,37 +1253,223 @@ __device__ void np_decompose(const double* E, int j, RsModel* M) {
   const double t[3] = {sg * (scale * U[2]), sg * (scale * U[5]), sg * (scale * U[8])};
   np_set_model(R, t, M);
 }
-// CentralRelativePoseSacProblem::computeModelCoefficients(NISTER) for one sample of 5 + 3 indices
-__device__ bool np_model(const double* f1, const double* f2, const int* s8, RsModel* out) {
-  double Es[10][9];
-  const int ne = np_fivept(f1, f2, s8, Es);
+// CentralRelativePoseSacProblem::computeModelCoefficients(NISTER) for one sample of 5 + 3 indices:
+// relative_pose::fivept_nister on the first five, then every decomposition of every essential matrix scored on
+// all eight (the lowest summed reprojection error wins, first one on ties)
+__device__ bool np_model(const double* f1, const double* f2, const int* s8, NpSlot& W, RsModel* out) {
+  for (int i = 0; i < 5; i++) {
+    const double* f = f1 + 3 * (size_t)s8[i];
+    const double* fp = f2 + 3 * (size_t)s8[i];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) W.Q[i][3 * r + c] = f[c] * fp[r];
+  }
+  if (!np_nullspace(W)) return false;
+  {
+    double El[3][3][4];   // entry (r, c) of E = x A + y B + z C + D as a linear polynomial
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) El[r][c][k] = W.N[k][3 * r + c];
+    double row[20];
+    {   // det(E)
+      double m0[10], m1[10], m2[10], ta[10], tb[10];
+      np_lin_mul(El[1][1], El[2][2], ta);
+      np_lin_mul(El[1][2], El[2][1], tb);
+#pragma unroll
+      for (int i = 0; i < 10; i++) m0[i] = ta[i] - tb[i];
+      np_lin_mul(El[1][0], El[2][2], ta);
+      np_lin_mul(El[1][2], El[2][0], tb);
+#pragma unroll
+      for (int i = 0; i < 10; i++) m1[i] = ta[i] - tb[i];
+      np_lin_mul(El[1][0], El[2][1], ta);
+      np_lin_mul(El[1][1], El[2][0], tb);
+#pragma unroll
+      for (int i = 0; i < 10; i++) m2[i] = ta[i] - tb[i];
+#pragma unroll
+      for (int i = 0; i < 20; i++) row[i] = 0.0;
+      np_quadlin_acc(m0, El[0][0], 1.0, row);
+      np_quadlin_acc(m1, El[0][1], -1.0, row);
+      np_quadlin_acc(m2, El[0][2], 1.0, row);
+#pragma unroll
+      for (int i = 0; i < 20; i++) W.M[0][i] = row[i];
+    }
+    // 2 E E^T E - trace(E E^T) E, row by row of E E^T (recomputed: same operations, same values)
+    auto eet = [&](int r, int c, double* q) {
+      double t[10];
+      np_lin_mul(El[r][0], El[c][0], q);
+      np_lin_mul(El[r][1], El[c][1], t);
+#pragma unroll
+      for (int i = 0; i < 10; i++) q[i] += t[i];
+      np_lin_mul(El[r][2], El[c][2], t);
+#pragma unroll
+      for (int i = 0; i < 10; i++) q[i] += t[i];
+    };
+    double tr[10];
+    {
+      double d0[10], d1[10], d2[10];
+      eet(0, 0, d0);
+      eet(1, 1, d1);
+      eet(2, 2, d2);
+#pragma unroll
+      for (int i = 0; i < 10; i++) tr[i] = (d0[i] + d1[i]) + d2[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double e0[10], e1[10], e2[10];
+      eet(r, 0, e0);
+      eet(r, 1, e1);
+      eet(r, 2, e2);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int i = 0; i < 20; i++) row[i] = 0.0;
+        np_quadlin_acc(e0, El[0][c], 2.0, row);
+        np_quadlin_acc(e1, El[1][c], 2.0, row);
+        np_quadlin_acc(e2, El[2][c], 2.0, row);
+        np_quadlin_acc(tr, El[r][c], -1.0, row);
+#pragma unroll
+        for (int i = 0; i < 20; i++) W.M[1 + 3 * r + c][i] = row[i];
+      }
+    }
+  }
+  // Gauss-Jordan with partial pivoting on the first ten columns
+  for (int col = 0; col < 10; col++) {
+    int piv = col;
+    for (int r = col + 1; r < 10; r++)
+      if (fabs(W.M[r][col]) > fabs(W.M[piv][col])) piv = r;
+    if (fabs(W.M[piv][col]) < 1e-300) return false;
+    if (piv != col)
+      for (int c = 0; c < 20; c++) {
+        const double t = W.M[piv][c];
+        W.M[piv][c] = W.M[col][c];
+        W.M[col][c] = t;
+      }
+    const double inv = 1.0 / W.M[col][col];
+    for (int c = 0; c < 20; c++) W.M[col][c] *= inv;
+    for (int r = 0; r < 10; r++) {
+      if (r == col) continue;
+      const double f = W.M[r][col];
+      if (f == 0.0) continue;
+      for (int c = 0; c < 20; c++) W.M[r][c] -= f * W.M[col][c];
+    }
+  }
+  // rows <k> = <e> - z<f>, <l> = <g> - z<h>, <m> = <i> - z<j>: B(z) [x y 1]^T = 0
+  double Bx[3][4], By[3][4], Bc[3][5];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const double* e = W.M[4 + 2 * q] + 10;
+    const double* f = W.M[5 + 2 * q] + 10;
+    Bx[q][0] = e[2];
+    Bx[q][1] = e[1] - f[2];
+    Bx[q][2] = e[0] - f[1];
+    Bx[q][3] = -f[0];
+    By[q][0] = e[5];
+    By[q][1] = e[4] - f[5];
+    By[q][2] = e[3] - f[4];
+    By[q][3] = -f[3];
+    Bc[q][0] = e[9];
+    Bc[q][1] = e[8] - f[9];
+    Bc[q][2] = e[7] - f[8];
+    Bc[q][3] = e[6] - f[7];
+    Bc[q][4] = -f[6];
+  }
+  {   // det B(z) = B00 (B11 B22 - B12 B21) - B01 (B10 B22 - B12 B20) + B02 (B10 B21 - B11 B20)
+    double t1[8], t2[8], d7[8], T0[11], T1[11], T2[11], x6a[7], x6b[7], d6[7];
+    np_conv<3, 4>(By[1], Bc[2], t1);
+    np_conv<4, 3>(Bc[1], By[2], t2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d7[i] = (0.0 + t1[i]) - t2[i];
+    np_conv<3, 7>(Bx[0], d7, T0);
+    np_conv<3, 4>(Bx[1], Bc[2], t1);
+    np_conv<4, 3>(Bc[1], Bx[2], t2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d7[i] = (0.0 + t1[i]) - t2[i];
+    np_conv<3, 7>(By[0], d7, T1);
+    np_conv<3, 3>(By[1], Bx[2], x6a);
+    np_conv<3, 3>(Bx[1], By[2], x6b);
+#pragma unroll
+    for (int i = 0; i < 7; i++) d6[i] = (0.0 + x6a[i]) - x6b[i];
+    np_conv<4, 6>(Bc[0], d6, T2);
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      const double inner = (0.0 + T0[i]) - T1[i];
+      const double t2one = 0.0 + T2[i] * 1.0;
+      W.chain[0][i] = (0.0 + inner) - t2one;
+    }
+    W.cdeg[0] = 10;
+  }
+  double roots[10];
+  const int nr = np_real_roots(W, roots);
   double bestQuality = 1000000.0;
-  int best_i = -1, best_j = -1;
-  for (int i = 0; i < ne; i++)
+  bool found = false;
+  for (int k = 0; k < nr; k++) {
+    const double z = roots[k];
+    double b[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double v = 0;
+#pragma unroll
+      for (int i = 3; i >= 0; i--) v = v * z + Bx[r][i];
+      b[r][0] = v;
+      v = 0;
+#pragma unroll
+      for (int i = 3; i >= 0; i--) v = v * z + By[r][i];
+      b[r][1] = v;
+      v = 0;
+#pragma unroll
+      for (int i = 4; i >= 0; i--) v = v * z + Bc[r][i];
+      b[r][2] = v;
+    }
+    double bestdet = 0;
+    int r0 = 0, r1 = 1;
+#pragma unroll
+    for (int pi = 0; pi < 3; pi++) {
+      const int pa = pi == 2 ? 1 : 0, pb = pi == 0 ? 1 : 2;
+      const double dd = b[pa][0] * b[pb][1] - b[pa][1] * b[pb][0];
+      if (fabs(dd) > fabs(bestdet)) {
+        bestdet = dd;
+        r0 = pa;
+        r1 = pb;
+      }
+    }
+    if (bestdet == 0) continue;
+    const double b00 = r0 == 0 ? b[0][0] : b[1][0], b01 = r0 == 0 ? b[0][1] : b[1][1], b02 = r0 == 0 ? b[0][2] : b[1][2];
+    const double b10 = r1 == 1 ? b[1][0] : b[2][0], b11 = r1 == 1 ? b[1][1] : b[2][1], b12 = r1 == 1 ? b[1][2] : b[2][2];
+    const double x = (-b02 * b11 + b12 * b01) / bestdet;
+    const double y = (-b00 * b12 + b10 * b02) / bestdet;
+    double E[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int a = i + 3 * j;
+        E[3 * i + j] = ((x * W.N[0][a] + y * W.N[1][a]) + z * W.N[2][a]) + W.N[3][a];
+      }
     for (int j = 0; j < 4; j++) {
       RsModel M;
-      np_decompose(Es[i], j, &M);
+      np_decompose(E, j, &M);
       double quality = 0.0;
-      for (int k = 0; k < 8; k++) {
-        double a[3], b[3];
+      for (int q = 0; q < 8; q++) {
+        double a[3], bb[3];
         for (int c = 0; c < 3; c++) {
-          a[c] = f1[3 * (size_t)s8[k] + c];
-          b[c] = f2[3 * (size_t)s8[k] + c];
+          a[c] = f1[3 * (size_t)s8[q] + c];
+          bb[c] = f2[3 * (size_t)s8[q] + c];
         }
-        quality += rs_distance(M, a, b);
+        quality += rs_distance(M, a, bb);
       }
       if (quality < bestQuality) {
         bestQuality = quality;
-        best_i = i;
-        best_j = j;
+        *out = M;
+        found = true;
       }
     }
-  if (best_i == -1) return false;
-  np_decompose(Es[best_i], best_j, out);
-  return true;
+  }
+  return found;
 }
 
-constexpr int NP_BATCH = 64;   // hypotheses solved in parallel per round
+constexpr int NP_BATCH = 16;   // hypotheses solved in parallel per round (one LDS work area each)
 // opengv::sac::Ransac<CentralRelativePoseSacProblem>::computeModel + the checks of Tracker::runRansac and
 // Tracker::geometricOutlierRejection2d2d; calling convention of rs_ransac_2d2d
 __device__ Rs2d2dResult rs_ransac_nister(const KParams& P, const Tables& T, const double* f1, const double* f2,
@@ -1418,6 +1479,7 @@ __device__ Rs2d2dResult rs_ransac_nister(const KParams& P, const Tables& T, cons
   __shared__ int sh_okm[NP_BATCH];
   __shared__ int sh_cntm[NP_BATCH];
   __shared__ RsModel sh_models[NP_BATCH];
+  __shared__ NpSlot sh_slots[NP_BATCH];
   __shared__ int sh_state[4];   // 0: stop flag, 1: best hypothesis slot of this round (-1 none), 2: n inliers, 3: spare
   __shared__ RsModel sh_best;
   Rs2d2dResult res;
@@ -1454,7 +1516,7 @@ __device__ Rs2d2dResult rs_ransac_nister(const KParams& P, const Tables& T, cons
     __syncthreads();
     if (tid < NP_BATCH) {
       RsModel M;
-      const bool ok = np_model(f1, f2, sh_sel8[tid], &M);
+      const bool ok = np_model(f1, f2, sh_sel8[tid], sh_slots[tid], &M);
       sh_okm[tid] = ok ? 1 : 0;
       sh_models[tid] = M;
       sh_cntm[tid] = 0;

@@ -350,97 +350,97 @@ struct PointCloud : Problem {
 // to the scale that the choice of null-space basis fixes (the translation norm of the model follows that scale
 // in OpenGV too, i.e. it carries no information).  PARITY UNPINNED at the bit level; inlier decisions pinned by
 // the scenes of tests/testTracker.cpp:704-802.
-struct Poly3 {   // polynomial of total degree <= 3 in (x, y, z), coefficient c[idx(i,j,k)] of x^i y^j z^k
-  double c[20];
-};
-static int p3_idx(int i, int j, int k) {
-  static int table[4][4][4];
-  static bool init = false;
-  if (!init) {
-    int n = 0;
-    for (int d = 0; d <= 3; d++)
-      for (int a = d; a >= 0; a--)
-        for (int b = d - a; b >= 0; b--) table[a][b][d - a - b] = n++;
-    init = true;
-  }
-  return table[i][j][k];
+// linear polynomial (x, y, z, 1 coefficients) times linear -> quadratic [x2 y2 z2 xy xz yz x y z 1]
+static inline void lin_mul(const double* a, const double* b, double* q) {
+  q[0] = a[0] * b[0];
+  q[1] = a[1] * b[1];
+  q[2] = a[2] * b[2];
+  q[3] = a[0] * b[1] + a[1] * b[0];
+  q[4] = a[0] * b[2] + a[2] * b[0];
+  q[5] = a[1] * b[2] + a[2] * b[1];
+  q[6] = a[0] * b[3] + a[3] * b[0];
+  q[7] = a[1] * b[3] + a[3] * b[1];
+  q[8] = a[2] * b[3] + a[3] * b[2];
+  q[9] = a[3] * b[3];
 }
-static Poly3 p3_zero() {
-  Poly3 r;
-  for (double& v : r.c) v = 0.0;
-  return r;
-}
-static Poly3 p3_lin(double x, double y, double z, double w) {
-  Poly3 r = p3_zero();
-  r.c[p3_idx(1, 0, 0)] = x;
-  r.c[p3_idx(0, 1, 0)] = y;
-  r.c[p3_idx(0, 0, 1)] = z;
-  r.c[p3_idx(0, 0, 0)] = w;
-  return r;
-}
-static Poly3 p3_add(const Poly3& a, const Poly3& b, double sb = 1.0) {
-  Poly3 r;
-  for (int i = 0; i < 20; i++) r.c[i] = a.c[i] + sb * b.c[i];
-  return r;
-}
-static Poly3 p3_mul(const Poly3& a, const Poly3& b) {   // terms above degree 3 do not occur in the uses below
-  Poly3 r = p3_zero();
-  for (int i1 = 0; i1 <= 3; i1++)
-    for (int j1 = 0; i1 + j1 <= 3; j1++)
-      for (int k1 = 0; i1 + j1 + k1 <= 3; k1++) {
-        const double ca = a.c[p3_idx(i1, j1, k1)];
-        if (ca == 0.0) continue;
-        for (int i2 = 0; i1 + j1 + k1 + i2 <= 3; i2++)
-          for (int j2 = 0; i1 + j1 + k1 + i2 + j2 <= 3; j2++)
-            for (int k2 = 0; i1 + j1 + k1 + i2 + j2 + k2 <= 3; k2++)
-              r.c[p3_idx(i1 + i2, j1 + j2, k1 + k2)] += ca * b.c[p3_idx(i2, j2, k2)];
-      }
-  return r;
+// quadratic times linear -> cubic in Nister's monomial order
+// [x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1]; out += sign * product
+static inline void quadlin_acc(const double* q, const double* l, double sign, double* out) {
+  out[0] += sign * (q[0] * l[0]);
+  out[1] += sign * (q[1] * l[1]);
+  out[2] += sign * (q[0] * l[1] + q[3] * l[0]);
+  out[3] += sign * (q[1] * l[0] + q[3] * l[1]);
+  out[4] += sign * (q[0] * l[2] + q[4] * l[0]);
+  out[5] += sign * (q[0] * l[3] + q[6] * l[0]);
+  out[6] += sign * (q[1] * l[2] + q[5] * l[1]);
+  out[7] += sign * (q[1] * l[3] + q[7] * l[1]);
+  out[8] += sign * ((q[3] * l[2] + q[4] * l[1]) + q[5] * l[0]);
+  out[9] += sign * ((q[3] * l[3] + q[6] * l[1]) + q[7] * l[0]);
+  out[10] += sign * (q[2] * l[0] + q[4] * l[2]);
+  out[11] += sign * ((q[4] * l[3] + q[6] * l[2]) + q[8] * l[0]);
+  out[12] += sign * (q[6] * l[3] + q[9] * l[0]);
+  out[13] += sign * (q[2] * l[1] + q[5] * l[2]);
+  out[14] += sign * ((q[5] * l[3] + q[7] * l[2]) + q[8] * l[1]);
+  out[15] += sign * (q[7] * l[3] + q[9] * l[1]);
+  out[16] += sign * (q[2] * l[2]);
+  out[17] += sign * (q[2] * l[3] + q[8] * l[2]);
+  out[18] += sign * (q[8] * l[3] + q[9] * l[2]);
+  out[19] += sign * (q[9] * l[3]);
 }
 
-// symmetric Jacobi eigen-decomposition (n <= 9), eigenvalues ascending, eigenvectors in the columns of V
-static void jacobi_eig(int n, double* A /* n*n, destroyed */, double* V, double* w) {
-  for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
-    for (int p = 0; p < n; p++)
-      for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
-    if (off < 1e-300) break;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
-        const double apq = A[p * n + q];
-        if (std::fabs(apq) < 1e-300) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-        for (int k = 0; k < n; k++) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - sn * akq;
-          A[k * n + q] = sn * akp + c * akq;
-        }
-        for (int k = 0; k < n; k++) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - sn * aqk;
-          A[q * n + k] = sn * apk + c * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - sn * vkq;
-          V[k * n + q] = sn * vkp + c * vkq;
+// four orthonormal null vectors of the 5 x 9 system Q: Gauss-Jordan with complete pivoting, the free columns in
+// ascending order, modified Gram-Schmidt
+static bool nullspace_5x9(double Q[5][9], double N[4][9]) {
+  int pc[5];
+  bool used[9] = {false, false, false, false, false, false, false, false, false};
+  for (int s = 0; s < 5; s++) {
+    int br = s, bc = -1;
+    double bv = -1.0;
+    for (int r = s; r < 5; r++)
+      for (int c = 0; c < 9; c++) {
+        if (used[c]) continue;
+        const double v = std::fabs(Q[r][c]);
+        if (v > bv) {
+          bv = v;
+          br = r;
+          bc = c;
         }
       }
+    if (!(bv > 1e-300)) return false;
+    if (br != s)
+      for (int c = 0; c < 9; c++) std::swap(Q[br][c], Q[s][c]);
+    used[bc] = true;
+    pc[s] = bc;
+    const double inv = 1.0 / Q[s][bc];
+    for (int c = 0; c < 9; c++) Q[s][c] *= inv;
+    for (int r = 0; r < 5; r++) {
+      if (r == s) continue;
+      const double f = Q[r][bc];
+      if (f == 0.0) continue;
+      for (int c = 0; c < 9; c++) Q[r][c] -= f * Q[s][c];
+    }
   }
-  int order[9];
-  for (int i = 0; i < n; i++) order[i] = i;
-  for (int i = 1; i < n; i++)
-    for (int j = i; j > 0 && A[order[j] * n + order[j]] < A[order[j - 1] * n + order[j - 1]]; j--)
-      std::swap(order[j], order[j - 1]);
-  double V2[81];
-  for (int c = 0; c < n; c++) {
-    w[c] = A[order[c] * n + order[c]];
-    for (int r = 0; r < n; r++) V2[r * n + c] = V[r * n + order[c]];
+  int j = 0;
+  for (int fc = 0; fc < 9; fc++) {
+    if (used[fc]) continue;
+    for (int c = 0; c < 9; c++) N[j][c] = 0.0;
+    N[j][fc] = 1.0;
+    for (int s = 0; s < 5; s++) N[j][pc[s]] = -Q[s][fc];
+    j++;
   }
-  std::memcpy(V, V2, sizeof(double) * n * n);
+  for (int a = 0; a < 4; a++) {
+    for (int b = 0; b < a; b++) {
+      double d = 0;
+      for (int c = 0; c < 9; c++) d += N[a][c] * N[b][c];
+      for (int c = 0; c < 9; c++) N[a][c] -= d * N[b][c];
+    }
+    double nn = 0;
+    for (int c = 0; c < 9; c++) nn += N[a][c] * N[a][c];
+    nn = std::sqrt(nn);
+    if (!(nn > 1e-300)) return false;
+    for (int c = 0; c < 9; c++) N[a][c] = N[a][c] / nn;
+  }
+  return true;
 }
 
 // univariate polynomials, coefficient c[k] of z^k
@@ -567,52 +567,49 @@ static int fivept_nister(const double* f1, const double* f2, const int* idx5, do
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) Q[i][3 * r + c] = f[c] * fp[r];
   }
-  double QtQ[81], V[81], w[9];
-  for (int a = 0; a < 9; a++)
-    for (int b = 0; b < 9; b++) {
-      double sacc = 0;
-      for (int i = 0; i < 5; i++) sacc += Q[i][a] * Q[i][b];
-      QtQ[a * 9 + b] = sacc;
-    }
-  jacobi_eig(9, QtQ, V, w);
-  // E = x A + y B + z C + D with the four null vectors (smallest eigenvalues)
+  // E = x A + y B + z C + D with four orthonormal null vectors
   double N[4][9];
-  for (int k = 0; k < 4; k++)
-    for (int a = 0; a < 9; a++) N[k][a] = V[a * 9 + k];
-  Poly3 E[3][3];
+  if (!nullspace_5x9(Q, N)) return 0;
+  double El[3][3][4];   // entry (r, c) as a linear polynomial
   for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) E[r][c] = p3_lin(N[0][3 * r + c], N[1][3 * r + c], N[2][3 * r + c], N[3][3 * r + c]);
-  Poly3 cons[10];
-  // det(E)
-  {
-    const Poly3 m0 = p3_add(p3_mul(E[1][1], E[2][2]), p3_mul(E[1][2], E[2][1]), -1.0);
-    const Poly3 m1 = p3_add(p3_mul(E[1][0], E[2][2]), p3_mul(E[1][2], E[2][0]), -1.0);
-    const Poly3 m2 = p3_add(p3_mul(E[1][0], E[2][1]), p3_mul(E[1][1], E[2][0]), -1.0);
-    cons[0] = p3_add(p3_add(p3_mul(E[0][0], m0), p3_mul(E[0][1], m1), -1.0), p3_mul(E[0][2], m2));
-  }
-  // 2 E E^T E - trace(E E^T) E
-  {
-    Poly3 EEt[3][3];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) {
-        EEt[r][c] = p3_zero();
-        for (int k = 0; k < 3; k++) EEt[r][c] = p3_add(EEt[r][c], p3_mul(E[r][k], E[c][k]));
-      }
-    const Poly3 tr = p3_add(p3_add(EEt[0][0], EEt[1][1]), EEt[2][2]);
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) {
-        Poly3 acc = p3_zero();
-        for (int k = 0; k < 3; k++) acc = p3_add(acc, p3_mul(EEt[r][k], E[k][c]));
-        cons[1 + 3 * r + c] = p3_add(p3_add(acc, acc), p3_mul(tr, E[r][c]), -1.0);
-      }
-  }
-  // Nister's monomial order: x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1
-  static const int mono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1},
-                                  {0, 2, 0}, {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2},
-                                  {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+    for (int c = 0; c < 3; c++)
+      for (int k = 0; k < 4; k++) El[r][c][k] = N[k][3 * r + c];
   double M[10][20];
   for (int r = 0; r < 10; r++)
-    for (int c = 0; c < 20; c++) M[r][c] = cons[r].c[p3_idx(mono[c][0], mono[c][1], mono[c][2])];
+    for (int c = 0; c < 20; c++) M[r][c] = 0.0;
+  {   // det(E)
+    double m0[10], m1[10], m2[10], ta[10], tb[10];
+    lin_mul(El[1][1], El[2][2], ta);
+    lin_mul(El[1][2], El[2][1], tb);
+    for (int i = 0; i < 10; i++) m0[i] = ta[i] - tb[i];
+    lin_mul(El[1][0], El[2][2], ta);
+    lin_mul(El[1][2], El[2][0], tb);
+    for (int i = 0; i < 10; i++) m1[i] = ta[i] - tb[i];
+    lin_mul(El[1][0], El[2][1], ta);
+    lin_mul(El[1][1], El[2][0], tb);
+    for (int i = 0; i < 10; i++) m2[i] = ta[i] - tb[i];
+    quadlin_acc(m0, El[0][0], 1.0, M[0]);
+    quadlin_acc(m1, El[0][1], -1.0, M[0]);
+    quadlin_acc(m2, El[0][2], 1.0, M[0]);
+  }
+  {   // 2 E E^T E - trace(E E^T) E
+    double EEt[3][3][10], tr[10], t[10];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        lin_mul(El[r][0], El[c][0], EEt[r][c]);
+        lin_mul(El[r][1], El[c][1], t);
+        for (int i = 0; i < 10; i++) EEt[r][c][i] += t[i];
+        lin_mul(El[r][2], El[c][2], t);
+        for (int i = 0; i < 10; i++) EEt[r][c][i] += t[i];
+      }
+    for (int i = 0; i < 10; i++) tr[i] = (EEt[0][0][i] + EEt[1][1][i]) + EEt[2][2][i];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double* row = M[1 + 3 * r + c];
+        for (int k = 0; k < 3; k++) quadlin_acc(EEt[r][k], El[k][c], 2.0, row);
+        quadlin_acc(tr, El[r][c], -1.0, row);
+      }
+  }
   // Gauss-Jordan with partial pivoting on the first ten columns
   for (int col = 0; col < 10; col++) {
     int piv = col;
