@@ -1005,8 +1005,12 @@ struct NpSlot {
   double N[4][9];
   double M[10][20];
   double chain[12][12];   // Sturm chain, coefficient k of z^k
+  double leaf_a[10], leaf_b[10];   // isolating intervals in the order the interval stack yields them
+  double roots[10];
+  double qual[10];        // best summed reprojection error over the decompositions of root k
   int cdeg[12];
-  int pad[4];
+  int leaf_cnt[10];
+  int nleaf, ok;
 };
 // linear x linear -> quadratic [x2 y2 z2 xy xz yz x y z 1]
 __device__ __forceinline__ void np_lin_mul(const double* a, const double* b, double* q) {
@@ -1111,13 +1115,47 @@ __device__ __forceinline__ void np_conv(const double* a, const double* b, double
 #pragma unroll
     for (int j = 0; j <= DB; j++) r[i + j] += a[i] * b[j];
 }
-__device__ double np_chain_eval(const NpSlot& W, int k, double z) {
+// Horner on a register copy of one chain polynomial: the steps above its degree are skipped by selects, so the
+// operations are those of the plain loop from `deg` down to 0 without an LDS round trip inside the dependent chain
+__device__ __forceinline__ double np_horner11(const double (&c)[11], int deg, double z) {
   double v = 0;
-  for (int i = W.cdeg[k]; i >= 0; i--) v = v * z + W.chain[k][i];
+#pragma unroll
+  for (int i = 10; i >= 0; i--) {
+    const double t = v * z + c[i];
+    v = i <= deg ? t : v;
+  }
   return v;
 }
-// real roots of the polynomial in W.chain[0] (degree W.cdeg[0]) by a Sturm chain + bisection
-__device__ int np_real_roots(NpSlot& W, double* roots) {
+// sign changes of the Sturm chain at z: all polynomials advance together (chain k has degree <= 10 - k), which
+// gives the scheduler nc independent Horner chains instead of one LDS-latency-bound chain after the other
+__device__ int np_sturm_changes(const NpSlot& W, const int (&degs)[11], double z) {
+  double v[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) v[k] = 0;
+#pragma unroll
+  for (int i = 10; i >= 0; i--) {
+#pragma unroll
+    for (int k = 0; k <= 10 - i; k++) {
+      const double t = v[k] * z + W.chain[k][i];
+      v[k] = i <= degs[k] ? t : v[k];
+    }
+  }
+  int n = 0, prev = 0;
+#pragma unroll
+  for (int k = 0; k < 11; k++) {
+    const int sgn = v[k] > 0 ? 1 : v[k] < 0 ? -1 : 0;
+    if (sgn != 0) {
+      if (prev != 0 && sgn != prev) n++;
+      prev = sgn;
+    }
+  }
+  return n;
+}
+// Real roots of the polynomial in W.chain[0] (degree W.cdeg[0]), step 1: Sturm chain + interval subdivision.
+// Every interval the stack loop of the oracle would refine is recorded (in that order) instead of refined on the
+// spot: the bisections are independent of the subdivision and of each other, so they run one per lane afterwards.
+__device__ void np_isolate(NpSlot& W) {
+  W.nleaf = 0;
   {
     int deg = W.cdeg[0];
     double m = 0;
@@ -1126,7 +1164,7 @@ __device__ int np_real_roots(NpSlot& W, double* roots) {
     W.cdeg[0] = deg;
   }
   const int pdeg = W.cdeg[0];
-  if (pdeg < 1) return 0;
+  if (pdeg < 1) return;
   int nc = 1;
   for (int i = 1; i <= pdeg; i++) W.chain[1][i - 1] = i * W.chain[0][i];
   W.cdeg[1] = pdeg - 1;
@@ -1150,29 +1188,23 @@ __device__ int np_real_roots(NpSlot& W, double* roots) {
     W.cdeg[nc] = deg;
     nc++;
   }
-  auto changes = [&](double z) {
-    int n = 0, prev = 0;
-    for (int i = 0; i < nc; i++) {
-      const double v = np_chain_eval(W, i, z);
-      const int sgn = v > 0 ? 1 : v < 0 ? -1 : 0;
-      if (sgn != 0) {
-        if (prev != 0 && sgn != prev) n++;
-        prev = sgn;
-      }
-    }
-    return n;
-  };
+  // chain k of the nc built has degree cdeg[k] <= 10 - k; the others never contribute (degree -1 -> value 0)
+  int degs[11];
+#pragma unroll
+  for (int kk = 0; kk < 11; kk++) degs[kk] = kk < nc ? W.cdeg[kk] : -1;
   double bound = 0;
   for (int i = 0; i < pdeg; i++) bound = fmax(bound, fabs(W.chain[0][i] / W.chain[0][pdeg]));
   bound += 1.0;
   int nroots = 0;
-  // interval stack: reuse the unused rows of Q / N / M?  a small private stack is fine (depth <= 64)
-  double sa[64], sb[64];
-  int sna[64], snb[64];
+  // interval stack (depth <= 64) in the constraint-matrix area of the slot, which is dead by now
+  double* sa = &W.M[0][0];
+  double* sb = sa + 64;
+  int* sna = reinterpret_cast<int*>(sb + 64);
+  int* snb = sna + 64;
   sa[0] = -bound;
   sb[0] = bound;
-  sna[0] = changes(-bound);
-  snb[0] = changes(bound);
+  sna[0] = np_sturm_changes(W, degs, -bound);
+  snb[0] = np_sturm_changes(W, degs, bound);
   int sp = 1;
   while (sp > 0 && nroots < 10) {
     --sp;
@@ -1182,24 +1214,13 @@ __device__ int np_real_roots(NpSlot& W, double* roots) {
     if (cnt <= 0) continue;
     const double mid = 0.5 * (ia + ib);
     if (cnt == 1 || ib - ia < 1e-13 * fmax(1.0, fabs(mid))) {
-      double a = ia, b = ib;
-      double fa = np_chain_eval(W, 0, a);
-      for (int it = 0; it < 200 && b - a > 1e-16 * fmax(1.0, fabs(a) + fabs(b)); it++) {
-        const double m = 0.5 * (a + b);
-        if (m <= a || m >= b) break;
-        const double fm = np_chain_eval(W, 0, m);
-        if (cnt == 1 && ((fa < 0) != (fm < 0))) {
-          b = m;
-        } else if (cnt == 1) {
-          a = m;
-          fa = fm;
-        } else
-          break;
-      }
-      roots[nroots++] = 0.5 * (a + b);
+      W.leaf_a[nroots] = ia;
+      W.leaf_b[nroots] = ib;
+      W.leaf_cnt[nroots] = cnt;
+      nroots++;
       continue;
     }
-    const int nm = changes(mid);
+    const int nm = np_sturm_changes(W, degs, mid);
     if (sp + 2 <= 64) {
       sa[sp] = mid;
       sb[sp] = ib;
@@ -1213,13 +1234,39 @@ __device__ int np_real_roots(NpSlot& W, double* roots) {
       sp++;
     }
   }
-  for (int i = 1; i < nroots; i++)   // ascending (std::sort in the oracle; the values are distinct)
-    for (int j = i; j > 0 && roots[j] < roots[j - 1]; j--) {
-      const double t = roots[j];
-      roots[j] = roots[j - 1];
-      roots[j - 1] = t;
+  W.nleaf = nroots;
+}
+// step 2: bisection of isolating interval r (a cluster the chain cannot split further yields its midpoint)
+__device__ double np_bisect_leaf(const NpSlot& W, int r) {
+  double c0[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) c0[i] = W.chain[0][i];
+  const int pdeg = W.cdeg[0], cnt = W.leaf_cnt[r];
+  double a = W.leaf_a[r], b = W.leaf_b[r];
+  double fa = np_horner11(c0, pdeg, a);
+  for (int it = 0; it < 200 && b - a > 1e-16 * fmax(1.0, fabs(a) + fabs(b)); it++) {
+    const double m = 0.5 * (a + b);
+    if (m <= a || m >= b) break;
+    const double fm = np_horner11(c0, pdeg, m);
+    if (cnt == 1 && ((fa < 0) != (fm < 0))) {
+      b = m;
+    } else if (cnt == 1) {
+      a = m;
+      fa = fm;
+    } else
+      break;
+  }
+  return 0.5 * (a + b);
+}
+// step 3: ascending order (std::sort in the oracle; the values are distinct)
+__device__ void np_sort_roots(NpSlot& W) {
+  const int n = W.nleaf;
+  for (int i = 1; i < n; i++)
+    for (int j = i; j > 0 && W.roots[j] < W.roots[j - 1]; j--) {
+      const double t = W.roots[j];
+      W.roots[j] = W.roots[j - 1];
+      W.roots[j - 1] = t;
     }
-  return nroots;
 }
 __device__ void np_set_model(const double* R, const double* t, RsModel* M) {
   for (int i = 0; i < 9; i++) M->R[i] = R[i];
@@ -1233,10 +1280,9 @@ __device__ void np_set_model(const double* R, const double* t, RsModel* M) {
     M->inv[r * 4 + 3] = -it[r];
   }
 }
-// the four [R | t] of an essential matrix (CentralRelativePoseSacProblem.cpp, NISTER case); j selects one
-__device__ void np_decompose(const double* E, int j, RsModel* M) {
-  double U[9], S[3], V[9];
-  rs_svd3(E, U, S, V);
+// the four [R | t] of an essential matrix (CentralRelativePoseSacProblem.cpp, NISTER case) from its SVD; j
+// selects one
+__device__ void np_decompose(const double* U, const double* S, const double* V, int j, RsModel* M) {
   const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
   const double* Wm = (j & 1) ? Wt : W;
   double UW[9], R[9];
@@ -1255,8 +1301,16 @@ __device__ void np_decompose(const double* E, int j, RsModel* M) {
 }
 // CentralRelativePoseSacProblem::computeModelCoefficients(NISTER) for one sample of 5 + 3 indices:
 // relative_pose::fivept_nister on the first five, then every decomposition of every essential matrix scored on
-// all eight (the lowest summed reprojection error wins, first one on ties)
-__device__ bool np_model(const double* f1, const double* f2, const int* s8, NpSlot& W, RsModel* out) {
+// all eight (the lowest summed reprojection error wins, first one on ties).  The block solves NP_BATCH samples
+// at a time in stages that change the work distribution but not one operation of the sequential algorithm:
+//   A  one lane per sample     null space of the epipolar constraints, the 10 x 20 constraint matrix
+//   B  16 lanes per sample     Gauss-Jordan elimination, two columns per lane
+//   C  one lane per sample     B(z), its determinant, Sturm chain, root isolation
+//   D  one lane per root       bisection
+//   E  one lane per root       essential matrix, SVD, the four decompositions scored on the eight points
+//   F  one lane per root       the winner (lowest error, first on ties) publishes its model
+// stage A
+__device__ bool np_stage_a(const double* f1, const double* f2, const int* s8, NpSlot& W) {
   for (int i = 0; i < 5; i++) {
     const double* f = f1 + 3 * (size_t)s8[i];
     const double* fp = f2 + 3 * (size_t)s8[i];
@@ -1334,27 +1388,62 @@ __device__ bool np_model(const double* f1, const double* f2, const int* s8, NpSl
       }
     }
   }
-  // Gauss-Jordan with partial pivoting on the first ten columns
+  return true;
+}
+// stage B: Gauss-Jordan with partial pivoting on the first ten columns; lane l of the 16 of a sample owns columns
+// l and l + 16.  Every element sees the operations of the sequential elimination in the same order; the barriers
+// separate the reads of a pivot column from the updates of its owner.  Called by all threads of the block.
+__device__ void np_stage_b(NpSlot& W, int l) {
+  bool ok = W.ok != 0;
+  const int c0 = l, c1 = l + 16;
+  const bool has1 = c1 < 20;
   for (int col = 0; col < 10; col++) {
     int piv = col;
-    for (int r = col + 1; r < 10; r++)
-      if (fabs(W.M[r][col]) > fabs(W.M[piv][col])) piv = r;
-    if (fabs(W.M[piv][col]) < 1e-300) return false;
-    if (piv != col)
-      for (int c = 0; c < 20; c++) {
-        const double t = W.M[piv][c];
-        W.M[piv][c] = W.M[col][c];
-        W.M[col][c] = t;
-      }
-    const double inv = 1.0 / W.M[col][col];
-    for (int c = 0; c < 20; c++) W.M[col][c] *= inv;
-    for (int r = 0; r < 10; r++) {
-      if (r == col) continue;
-      const double f = W.M[r][col];
-      if (f == 0.0) continue;
-      for (int c = 0; c < 20; c++) W.M[r][c] -= f * W.M[col][c];
+    if (ok) {
+      for (int r = col + 1; r < 10; r++)
+        if (fabs(W.M[r][col]) > fabs(W.M[piv][col])) piv = r;
+      if (fabs(W.M[piv][col]) < 1e-300) ok = false;
     }
+    __syncthreads();
+    if (ok && piv != col) {
+      double t = W.M[piv][c0];
+      W.M[piv][c0] = W.M[col][c0];
+      W.M[col][c0] = t;
+      if (has1) {
+        t = W.M[piv][c1];
+        W.M[piv][c1] = W.M[col][c1];
+        W.M[col][c1] = t;
+      }
+    }
+    __syncthreads();
+    double inv = 0;
+    if (ok) inv = 1.0 / W.M[col][col];
+    __syncthreads();
+    if (ok) {
+      W.M[col][c0] *= inv;
+      if (has1) W.M[col][c1] *= inv;
+    }
+    __syncthreads();
+    double f[10];
+#pragma unroll
+    for (int r = 0; r < 10; r++) f[r] = ok ? W.M[r][col] : 0.0;
+    __syncthreads();
+    if (ok) {
+      const double p0 = W.M[col][c0], p1 = has1 ? W.M[col][c1] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 10; r++) {
+        if (r == col || f[r] == 0.0) continue;
+        W.M[r][c0] -= f[r] * p0;
+        if (has1) W.M[r][c1] -= f[r] * p1;
+      }
+    }
+    __syncthreads();
   }
+  if (l == 0 && !ok) W.ok = 0;
+  __syncthreads();
+}
+// stage C
+__device__ void np_stage_c(NpSlot& W) {
   // rows <k> = <e> - z<f>, <l> = <g> - z<h>, <m> = <i> - z<j>: B(z) [x y 1]^T = 0
   double Bx[3][4], By[3][4], Bc[3][5];
 #pragma unroll
@@ -1400,73 +1489,86 @@ __device__ bool np_model(const double* f1, const double* f2, const int* s8, NpSl
     }
     W.cdeg[0] = 10;
   }
-  double roots[10];
-  const int nr = np_real_roots(W, roots);
-  double bestQuality = 1000000.0;
-  bool found = false;
-  for (int k = 0; k < nr; k++) {
-    const double z = roots[k];
-    double b[3][3];
+  // B(z) stays in the (dead) epipolar-constraint area for stage E
+  double* Bs = &W.Q[0][0];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-      double v = 0;
+  for (int q = 0; q < 3; q++) {
 #pragma unroll
-      for (int i = 3; i >= 0; i--) v = v * z + Bx[r][i];
-      b[r][0] = v;
-      v = 0;
-#pragma unroll
-      for (int i = 3; i >= 0; i--) v = v * z + By[r][i];
-      b[r][1] = v;
-      v = 0;
-#pragma unroll
-      for (int i = 4; i >= 0; i--) v = v * z + Bc[r][i];
-      b[r][2] = v;
+    for (int i = 0; i < 4; i++) {
+      Bs[13 * q + i] = Bx[q][i];
+      Bs[13 * q + 4 + i] = By[q][i];
     }
-    double bestdet = 0;
-    int r0 = 0, r1 = 1;
 #pragma unroll
-    for (int pi = 0; pi < 3; pi++) {
-      const int pa = pi == 2 ? 1 : 0, pb = pi == 0 ? 1 : 2;
-      const double dd = b[pa][0] * b[pb][1] - b[pa][1] * b[pb][0];
-      if (fabs(dd) > fabs(bestdet)) {
-        bestdet = dd;
-        r0 = pa;
-        r1 = pb;
-      }
-    }
-    if (bestdet == 0) continue;
-    const double b00 = r0 == 0 ? b[0][0] : b[1][0], b01 = r0 == 0 ? b[0][1] : b[1][1], b02 = r0 == 0 ? b[0][2] : b[1][2];
-    const double b10 = r1 == 1 ? b[1][0] : b[2][0], b11 = r1 == 1 ? b[1][1] : b[2][1], b12 = r1 == 1 ? b[1][2] : b[2][2];
-    const double x = (-b02 * b11 + b12 * b01) / bestdet;
-    const double y = (-b00 * b12 + b10 * b02) / bestdet;
-    double E[9];
+    for (int i = 0; i < 5; i++) Bs[13 * q + 8 + i] = Bc[q][i];
+  }
+  np_isolate(W);
+}
+// stage E: root k of the sample -> best of its four decompositions (returns its summed error, 1e6 when none)
+__device__ double np_stage_e(const double* f1, const double* f2, const int* s8, const NpSlot& W, int k, RsModel* out) {
+  const double z = W.roots[k];
+  const double* Bs = &W.Q[0][0];
+  double b[3][3];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+  for (int r = 0; r < 3; r++) {
+    double v = 0;
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int a = i + 3 * j;
-        E[3 * i + j] = ((x * W.N[0][a] + y * W.N[1][a]) + z * W.N[2][a]) + W.N[3][a];
-      }
-    for (int j = 0; j < 4; j++) {
-      RsModel M;
-      np_decompose(E, j, &M);
-      double quality = 0.0;
-      for (int q = 0; q < 8; q++) {
-        double a[3], bb[3];
-        for (int c = 0; c < 3; c++) {
-          a[c] = f1[3 * (size_t)s8[q] + c];
-          bb[c] = f2[3 * (size_t)s8[q] + c];
-        }
-        quality += rs_distance(M, a, bb);
-      }
-      if (quality < bestQuality) {
-        bestQuality = quality;
-        *out = M;
-        found = true;
-      }
+    for (int i = 3; i >= 0; i--) v = v * z + Bs[13 * r + i];
+    b[r][0] = v;
+    v = 0;
+#pragma unroll
+    for (int i = 3; i >= 0; i--) v = v * z + Bs[13 * r + 4 + i];
+    b[r][1] = v;
+    v = 0;
+#pragma unroll
+    for (int i = 4; i >= 0; i--) v = v * z + Bs[13 * r + 8 + i];
+    b[r][2] = v;
+  }
+  double bestdet = 0;
+  int r0 = 0, r1 = 1;
+#pragma unroll
+  for (int pi = 0; pi < 3; pi++) {
+    const int pa = pi == 2 ? 1 : 0, pb = pi == 0 ? 1 : 2;
+    const double dd = b[pa][0] * b[pb][1] - b[pa][1] * b[pb][0];
+    if (fabs(dd) > fabs(bestdet)) {
+      bestdet = dd;
+      r0 = pa;
+      r1 = pb;
     }
   }
-  return found;
+  double bestQuality = 1000000.0;
+  if (bestdet == 0) return bestQuality;
+  const double b00 = r0 == 0 ? b[0][0] : b[1][0], b01 = r0 == 0 ? b[0][1] : b[1][1], b02 = r0 == 0 ? b[0][2] : b[1][2];
+  const double b10 = r1 == 1 ? b[1][0] : b[2][0], b11 = r1 == 1 ? b[1][1] : b[2][1], b12 = r1 == 1 ? b[1][2] : b[2][2];
+  const double x = (-b02 * b11 + b12 * b01) / bestdet;
+  const double y = (-b00 * b12 + b10 * b02) / bestdet;
+  double E[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int a = i + 3 * j;
+      E[3 * i + j] = ((x * W.N[0][a] + y * W.N[1][a]) + z * W.N[2][a]) + W.N[3][a];
+    }
+  double U[9], S[3], V[9];
+  rs_svd3(E, U, S, V);
+  for (int j = 0; j < 4; j++) {
+    RsModel M;
+    np_decompose(U, S, V, j, &M);
+    double quality = 0.0;
+    for (int q = 0; q < 8; q++) {
+      double a[3], bb[3];
+      for (int c = 0; c < 3; c++) {
+        a[c] = f1[3 * (size_t)s8[q] + c];
+        bb[c] = f2[3 * (size_t)s8[q] + c];
+      }
+      quality += rs_distance(M, a, bb);
+    }
+    if (quality < bestQuality) {
+      bestQuality = quality;
+      *out = M;
+    }
+  }
+  return bestQuality;
 }
 
 constexpr int NP_BATCH = 16;   // hypotheses solved in parallel per round (one LDS work area each)
@@ -1514,12 +1616,41 @@ __device__ Rs2d2dResult rs_ransac_nister(const KParams& P, const Tables& T, cons
     }
     draw += 8 * NP_BATCH;
     __syncthreads();
-    if (tid < NP_BATCH) {
+    {
+      static_assert(NP_BATCH * 16 == RS_T, "16 lanes per sample");
+      const int h = tid >> 4, l = tid & 15;
+      NpSlot& W = sh_slots[h];
+      if (l == 0) {
+        W.ok = np_stage_a(f1, f2, sh_sel8[h], W) ? 1 : 0;
+        W.nleaf = 0;
+        sh_okm[h] = 0;
+        sh_cntm[h] = 0;
+      }
+      __syncthreads();
+      np_stage_b(W, l);
+      if (l == 0 && W.ok) np_stage_c(W);
+      __syncthreads();
+      const int nr = W.nleaf;
+      if (l < nr) W.roots[l] = np_bisect_leaf(W, l);   // stage D
+      __syncthreads();
+      if (l == 0) np_sort_roots(W);
+      __syncthreads();
       RsModel M;
-      const bool ok = np_model(f1, f2, sh_sel8[tid], sh_slots[tid], &M);
-      sh_okm[tid] = ok ? 1 : 0;
-      sh_models[tid] = M;
-      sh_cntm[tid] = 0;
+      double q = 1000000.0;
+      if (l < nr) q = np_stage_e(f1, f2, sh_sel8[h], W, l, &M);
+      if (l < 10) W.qual[l] = q;
+      __syncthreads();
+      if (l < nr && q < 1000000.0) {   // stage F
+        bool win = true;
+        for (int k = 0; k < nr; k++) {
+          const double qk = W.qual[k];
+          if (k < l ? qk <= q : k > l ? qk < q : false) win = false;
+        }
+        if (win) {
+          sh_models[h] = M;
+          sh_okm[h] = 1;
+        }
+      }
     }
     __syncthreads();
     // countWithinDistance of every hypothesis of the round: (hypothesis, match) pairs over the block
