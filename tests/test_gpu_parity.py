@@ -564,8 +564,8 @@ def test_outlier_rejection_3d3d_arun(ocam, case, n_in, n_out, noise):
                                                     (False, 300, 200, 4), (False, 8, 0, 5), (False, 7, 0, 6)])
 def test_outlier_rejection_2d2d_five_point(ocam, planar, n_in, n_out, seed):
     """5-point Nister RANSAC (opengv CentralRelativePoseSacProblem, ransac_use_2point_mono: 0): the device
-    solves 64 hypotheses per round in parallel and replays them in order; same sample stream, same solver
-    operation for operation -> identical inlier sets, iteration counts and poses as the CPU path; scenes of
+    solves 16 hypotheses per round in block-cooperative stages and replays them in order; same sample stream,
+    same solver operation for operation -> identical inlier sets, iteration counts and poses as the CPU path; scenes of
     tests/testTracker.cpp:704-802."""
     L, R_ = euroc_cams()
     p = _euroc_ransac_params()

@@ -33,10 +33,12 @@ for ci in range(n_cfg):
     s.templ_rows = int(rng.choice([5, 11]))
     s.subpixel_refinement = int(rng.randint(0, 2))
     p.tracker.ransac_use_1point_stereo = int(rng.randint(0, 2))
+    p.tracker.ransac_use_2point_mono = int(rng.randint(0, 2))
     desc = dict(w=w, h=h, feats=d.max_features_per_frame, md=d.min_distance, q=d.quality_level,
                 anms=d.non_max_suppression_type, subpix=d.enable_subpixel_corner_refinement, win=t.klt_win_size,
                 lvl=t.klt_max_level, it=t.klt_max_iter, age=t.max_feature_track_age, tc=s.templ_cols, tr=s.templ_rows,
-                ssub=s.subpixel_refinement, ransac=p.use_ransac, one=p.tracker.ransac_use_1point_stereo)
+                ssub=s.subpixel_refinement, ransac=p.use_ransac, one=p.tracker.ransac_use_1point_stereo,
+                two=p.tracker.ransac_use_2point_mono)
     stream_seed = int(rng.randint(0, 1000))
     forces = [bool(rng.randint(0, 2)) for _ in range(5)]
     R1 = np.array(F.compute_rectification(L, R).R1).reshape(3, 3)
