@@ -10,9 +10,9 @@ cp gpurun_out/gpu_tests.log profiles/${T}_gpu_tests.log
 { echo "# rocprofv3 --pmc (separate passes; kernels serialised), same command.  FETCH_SIZE / WRITE_SIZE in KB per launch"; echo;
   python tools/rocpd_pmc.py gpurun_out/prof_fetch/f_results.db gpurun_out/prof_write/w_results.db; echo;
   echo "SQ pass 1 (SQ_* cycle counters are in quad-cycles summed over all SIMDs/XCDs):"; echo;
-  python tools/rocpd_pmc.py gpurun_out/prof_sq/s_results.db; echo;
+  python tools/rocpd_pmc.py gpurun_out/prof_sq/s_results.db 2>/dev/null || echo "(not collected in this run)"; echo;
   echo "SQ pass 2:"; echo;
-  python tools/rocpd_pmc.py gpurun_out/prof_sq2/s2_results.db; } > profiles/${T}_pmc.md
+  python tools/rocpd_pmc.py gpurun_out/prof_sq2/s2_results.db 2>/dev/null || echo "(not collected in this run)"; } > profiles/${T}_pmc.md
 ls -la profiles/${T}_*
 python tools/rocpd_traffic.py gpurun_out/prof_fetch/f_results.db gpurun_out/prof_write/w_results.db > profiles/${T}_pmc_traffic.json
 cp profiles/${T}_pmc_traffic.json profiles/pmc_traffic_latest.json
