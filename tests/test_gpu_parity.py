@@ -1255,3 +1255,130 @@ def test_frontend_device_input_path_matches_oracle(seq, ocam):
                 kf0 = i
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the C++ side of the drop-in boundary: a plain g++ host program over include/kvfe_adapter.hpp
+# ---------------------------------------------------------------------------------------------
+def _read_records(path):
+    recs = []
+    with open(path, "rb") as f:
+        buf = f.read()
+    o = 0
+    while o < len(buf):
+        tag = buf[o:o + 16].split(b"\0")[0].decode()
+        nb = int(np.frombuffer(buf, np.int64, 1, o + 16)[0])
+        recs.append((tag, buf[o + 24:o + 24 + nb]))
+        o += 24 + nb
+    return recs
+
+
+def test_cpp_adapter_program_matches_oracle(seq, ocam, tmp_path):
+    """tests/cpp/adapter_sequence.cpp uses libkvfe only through the reference's class and method names
+    (kvfe_adapter.hpp: StereoCamera, UndistorterRectifier, FeatureDetector, Tracker, StereoMatcher,
+    StereoVisionImuFrontend::spinOnce), compiled by g++ without HIP.  Component calls equal the ctypes
+    path and the oracle; the six-frame front-end sequence (shipped Euroc parameters, useRANSAC: 1) equals
+    the oracle front-end frame by frame, bit for bit; a contract violation surfaces as kvfe::Error."""
+    import ctypes
+    import subprocess
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    exe = os.path.join(cpp, "adapter_sequence")
+    subprocess.run(["make", "-C", cpp], check=True, capture_output=True)
+    L, R = euroc_cams()
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    assert p.use_ransac == 1
+    cfg = abi.Config()
+    cfg.left, cfg.right, cfg.params, cfg.batch, cfg.device = L, R, p, 1, 0
+    n = 6
+    camR = _kf_rotations(seq["body_R"], ocam)
+    fe = O.Frontend(L, R, p)
+    H, W = seq["lefts"][0].shape
+    exp_frames, inputs = [], []
+    kf = 0
+    c = F.Context(L, R, p, batch=1)
+    try:
+        for i in range(n):
+            Rk = camR[kf].T @ camR[i]
+            inputs.append(c.make_inputs([int(seq["ts"][i])], [Rk], [0])[0])
+            e = fe.process(seq["lefts"][i], seq["rights"][i], int(seq["ts"][i]), Rk, False)
+            exp_frames.append(e)
+            if e["is_keyframe"]:
+                kf = i
+        with open(tmp_path / "in.bin", "wb") as f:
+            f.write(bytes(cfg))
+            f.write(np.array([n, W, H], np.int32).tobytes())
+            for i in range(n):
+                f.write(bytes(inputs[i]))
+                f.write(np.ascontiguousarray(seq["lefts"][i]).tobytes())
+                f.write(np.ascontiguousarray(seq["rights"][i]).tobytes())
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        recs = _read_records(tmp_path / "out.bin")
+        one = {t: b for t, b in recs if not t.startswith("f_")}
+
+        # StereoCamera / UndistorterRectifier
+        assert abs(np.frombuffer(one["baseline"], np.float64)[0] - 0.110078) < 1e-5  # testStereoMatcher.cpp:148
+        assert np.array_equal(np.frombuffer(one["P1"], np.float64), np.array(ocam.rect.P1))
+        assert np.array_equal(np.frombuffer(one["left_rect"], np.uint8).reshape(H, W),
+                              ocam.rectify_image(0, seq["lefts"][0]))
+        # FeatureDetector::featureDetection on an empty frame = GFTT + ANMS + cornerSubPix
+        corners = np.frombuffer(one["corners"], np.float32).reshape(-1, 2)
+        assert np.array_equal(corners, c.feature_detection(seq["lefts"][0], np.zeros((0, 2), np.float32),
+                                                           p.detector.max_features_per_frame))
+        assert len(corners) > 200
+        assert np.array_equal(np.frombuffer(one["versors"], np.float64).reshape(-1, 3),
+                              c.get_bearing_vectors(0, corners))
+        # Tracker::featureTracking = predictor + calcOpticalFlowPyrLK against the oracle
+        t = p.tracker
+        Rk1 = np.array(inputs[1].keyframe_R_cur_frame).reshape(3, 3)
+        init = c.predict_sparse_flow(corners, Rk1)
+        exp, est, eerr, _ = O.calc_optical_flow_pyr_lk(seq["lefts"][0], seq["lefts"][1], corners, init,
+                                                       t.klt_win_size, t.klt_max_level, t.klt_max_iter, t.klt_eps)
+        assert np.array_equal(np.frombuffer(one["lk_px"], np.float32).reshape(-1, 2), exp)
+        assert np.array_equal(np.frombuffer(one["lk_status"], np.uint8), est)
+        assert np.array_equal(np.frombuffer(one["lk_err"], np.float32), eerr)
+        # StereoMatcher::sparseStereoReconstruction
+        sr = c.sparse_stereo_reconstruction(seq["lefts"][0], seq["rights"][0], corners)
+        for tag, key, dt in (("st_lstat", "left_status", np.uint8), ("st_rstat", "right_status", np.uint8),
+                             ("st_lrect", "left_rect_xy", np.float32), ("st_rrect", "right_rect_xy", np.float32),
+                             ("st_depth", "depth", np.float64), ("st_3d", "keypoints_3d", np.float64)):
+            assert np.array_equal(np.frombuffer(one[tag], dt), np.asarray(sr[key]).reshape(-1)), tag
+        assert (np.frombuffer(one["st_rstat"], np.uint8) == 0).sum() > 100
+        assert np.frombuffer(one["err_status"], np.int32)[0] == abi.KVFE_ERR_INVALID_ARG
+    finally:
+        c.close()
+
+    # StereoVisionImuFrontend::spinOnce, frame by frame against the oracle front-end
+    frames, cur = [], None
+    for tag, b in recs:
+        if tag == "f_head":
+            cur = {}
+            frames.append(cur)
+        if tag.startswith("f_"):
+            cur[tag] = b
+    assert len(frames) == n
+    for i, (g, e) in enumerate(zip(frames, exp_frames)):
+        head = np.frombuffer(g["f_head"], np.int32)
+        assert list(head) == [e["n_keypoints"], e["is_keyframe"], e["n_tracked"], e["n_detected"],
+                              e["n_measurements"], e["frame_id"]], (i, head)
+        assert np.array_equal(np.frombuffer(g["f_lmk"], np.int64), e["landmarks"]), i
+        assert np.array_equal(np.frombuffer(g["f_age"], np.int32), e["landmarks_age"]), i
+        assert np.array_equal(np.frombuffer(g["f_kp"], np.float32).reshape(-1, 2), e["keypoints"]), i
+        assert np.array_equal(np.frombuffer(g["f_versors"], np.float64).reshape(-1, 3), e["versors"]), i
+        if e["is_keyframe"]:
+            assert np.array_equal(np.frombuffer(g["f_lrect"], np.float32).reshape(-1, 2), e["left_rect_xy"]), i
+            assert np.array_equal(np.frombuffer(g["f_lstat"], np.uint8), e["left_status"]), i
+            assert np.array_equal(np.frombuffer(g["f_rrect"], np.float32).reshape(-1, 2), e["right_rect_xy"]), i
+            assert np.array_equal(np.frombuffer(g["f_rstat"], np.uint8), e["right_status"]), i
+            assert np.array_equal(np.frombuffer(g["f_depth"], np.float64), e["depth"]), i
+            assert np.array_equal(np.frombuffer(g["f_3d"], np.float64).reshape(-1, 3), e["keypoints_3d"]), i
+            assert np.array_equal(np.frombuffer(g["f_mlmk"], np.int64), e["meas_landmark"]), i
+            assert np.array_equal(np.frombuffer(g["f_meas"], np.float64).reshape(-1, 3), e["meas_uL_uR_v"],
+                                  equal_nan=True), i
+        trk = np.frombuffer(g["f_trk"], np.int32)
+        assert list(trk) == [e[k] for k in ("tracking_status_mono", "tracking_status_stereo", "nr_mono_putatives",
+                                            "nr_mono_inliers", "nr_stereo_putatives", "nr_stereo_inliers")], (i, trk)
+        assert np.array_equal(np.frombuffer(g["f_Tmono"], np.float64).reshape(3, 4), e["lkf_T_k_mono"]), i
+        assert np.array_equal(np.frombuffer(g["f_Tstereo"], np.float64).reshape(3, 4), e["lkf_T_k_stereo"]), i
+    assert [e["is_keyframe"] for e in exp_frames] == [1, 0, 0, 0, 1, 0]
