@@ -54,6 +54,26 @@ __device__ __forceinline__ float dpp_from_right(float v) {  // lane i <- lane i+
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
+// Correctly rounded sqrtf for 0 <= x < 2^96 (every lambda discriminant: sums of squares of scaled
+// 8-bit gradients).  v_sqrt_f32 is good to 1 ulp; the two FMA residuals pick the neighbour exactly as
+// the compiler's own IEEE expansion does.  The input is always scaled by 2^32 (exact; the expansion
+// scales only below 2^-96 to keep the residuals normal) and zero needs no special case: its
+// "neighbour below" is a NaN pattern whose residual compares false, its neighbour above leaves +0.
+__device__ __forceinline__ float sqrt_rn_small(float x) {
+  const float xs = x * 4294967296.0f;
+  float s = __builtin_amdgcn_sqrtf(xs);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float ed = __builtin_fmaf(-sd, s, xs), eu = __builtin_fmaf(-su, s, xs);
+  s = ed <= 0.f ? sd : s;
+  s = eu > 0.f ? su : s;
+  return s * 1.52587890625e-05f;
+}
+__device__ __forceinline__ float vmaxf(float a, float b) {  // v_max_f32 without canonicalising moves
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 struct MeRow {          // per-lane values of one image row at the different pipeline stages
   float dh, sm;         // Sobel partials of the pixel row
   double h0, h1, h2;    // horizontal 3-sums of dx*dx, dx*dy, dy*dy
@@ -144,7 +164,9 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
 
   // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  Only wave-uniform
   // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
+  bool in_b = false;  // lane's pixel of box row b passes the detection mask (carried to stage m)
   auto step = [&](int r, MeRow& X, MeRow& Y, MeRow& Z) {
+    const bool in_m = in_b;  // row m = r-3 was the box row of the previous step
     // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
     if (r <= H) {
       const float p = (float)p_next;
@@ -185,33 +207,36 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
       // rows b-1, b, b+1 = slots X, Z, Y; BORDER_REFLECT_101 at the image border: row -1 is row 1
       // (slot Y), row H is row H-2 (slot X) -- wave-uniform branches taken once per strip
       if (b == 0) {
+        asm volatile("");  // keep the once-per-strip border copies out of the row loop's selects
         X.h0 = Y.h0;
         X.h1 = Y.h1;
         X.h2 = Y.h2;
       }
       if (b == H - 1) {
+        asm volatile("");
         Y.h0 = X.h0;
         Y.h1 = X.h1;
         Y.h2 = X.h2;
       }
       const double s0 = (X.h0 + Z.h0) + Y.h0, s1 = (X.h1 + Z.h1) + Y.h1, s2 = (X.h2 + Z.h2) + Y.h2;
       const float fa = (float)s0 * 0.5f, fb = (float)s1, fc = (float)s2 * 0.5f;
-      const float lam = (fa + fc) - sqrtf((fa - fc) * (fa - fc) + fb * fb);
+      const float lam = (fa + fc) - sqrt_rn_small((fa - fc) * (fa - fc) + fb * fb);
       Z.lam = lam;
       Z.hm = fmaxf(fmaxf(dpp_from_left(lam), lam), dpp_from_right(lam));
       if (b >= ys && b < ye) {
-        bool masked_in = out_col & !((rowmask[b - ys] >> lane) & 1ull);
+        // the row's bit mask is wave-uniform: one LDS read, then it IS the lane predicate
+        bool masked_in = out_col & !__builtin_amdgcn_inverse_ballot_w64(rowmask[b - ys]);
         if (HAS_MASK) masked_in &= mcol[(unsigned)(b * W)] != 0;
-        bestv = masked_in ? fmaxf(bestv, lam) : bestv;
+        in_b = masked_in;
+        bestv = vmaxf(bestv, masked_in ? lam : -__builtin_inff());
       }
     }
     // ---- row m = r-3: 3x3 local maximum (rows m-1, m, m+1 = slots Y, X, Z) ----------------------
     const int m = r - 3;
     if (m >= lm0 && m <= lm1) {
       const float v = X.lam;
-      bool is_cand = out_col & (gx >= 1) & (gx < W - 1) & (v != 0.0f) &
-                     !((rowmask[m - ys] >> lane) & 1ull) & (v == fmaxf(fmaxf(Y.hm, X.hm), Z.hm));
-      if (HAS_MASK) is_cand &= mcol[(unsigned)(m * W)] != 0;
+      const bool is_cand = in_m & (gx >= 1) & (gx < W - 1) & (v != 0.0f) &
+                           (v == fmaxf(fmaxf(Y.hm, X.hm), Z.hm));
       const unsigned long long bal = __ballot(is_cand);
       if (bal) {
         if (is_cand) {
