@@ -159,18 +159,39 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
   const unsigned char* colp = I + cxr;
   const unsigned stride_u = (unsigned)row_stride;
   const unsigned char* mcol = HAS_MASK ? M + min(max(gx, 0), W - 1) : nullptr;
-  unsigned p_next = colp[(unsigned)reflect101(r_first, H) * stride_u];  // raw byte: converted at use
+  // three source rows in flight per lane (one per rotating slot): a row is a fresh 64-byte line for
+  // every wave, so one row of look-ahead (~one pipeline step) does not cover an HBM miss
+  // The loads are issued and awaited by hand (vmcnt counts in issue order, so "at most two
+  // outstanding" means this slot's load has landed): the compiler's own waits drain the queue at every
+  // branch join of the step and would shorten the look-ahead to one row again.
+  auto row_of = [&](int r) {  // BORDER_REFLECT_101 for r in [-1, H], clamped for the unused row H+1
+    int rr = r < 0 ? -r : r;
+    rr = rr >= H ? 2 * H - 2 - rr : rr;
+    return (unsigned)min(max(rr, 0), H - 1);
+  };
+  auto issue_row = [&](unsigned& dst, int r) {
+    const unsigned char* a = colp + row_of(r) * stride_u;
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(a) : "memory");
+  };
+  unsigned pq0, pq1, pq2;  // raw bytes: converted at use
+  issue_row(pq0, r_first);
+  issue_row(pq1, r_first + 1);
+  issue_row(pq2, r_first + 2);
   const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
 
   // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  Only wave-uniform
   // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
   bool in_b = false;  // lane's pixel of box row b passes the detection mask (carried to stage m)
-  auto step = [&](int r, MeRow& X, MeRow& Y, MeRow& Z) {
+  auto step = [&](int r, MeRow& X, MeRow& Y, MeRow& Z, unsigned& p_next) {
     const bool in_m = in_b;  // row m = r-3 was the box row of the previous step
     // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
-    if (r <= H) {
+    // (unconditional, one load and one use per step with the row index clamped: the compiler can then
+    // wait for exactly this slot's load, vmcnt(2), instead of draining all three at a branch join;
+    // the clamped extra row H+1 is never consumed by a cov row)
+    {
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(p_next));
       const float p = (float)p_next;
-      if (r + 1 <= H) p_next = colp[(unsigned)reflect101(r + 1, H) * stride_u];
+      issue_row(p_next, r + 3);
       const float pl = dpp_from_left(p), pr = dpp_from_right(p);
       X.dh = pr - pl;
       float t = f1 * pl;
@@ -257,9 +278,9 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
   S0 = S1 = S2 = MeRow{0.f, 0.f, 0., 0., 0., 0.f, 0.f};
   // slots rotate with the row index: slot(r) = (r - r_first) % 3
   for (int r = r_first; r <= r_last; r += 3) {
-    step(r, S0, S2, S1);
-    if (r + 1 <= r_last) step(r + 1, S1, S0, S2);
-    if (r + 2 <= r_last) step(r + 2, S2, S1, S0);
+    step(r, S0, S2, S1, pq0);
+    if (r + 1 <= r_last) step(r + 1, S1, S0, S2, pq1);
+    if (r + 2 <= r_last) step(r + 2, S2, S1, S0, pq2);
   }
   __syncthreads();
   flush();
