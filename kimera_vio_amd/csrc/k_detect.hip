@@ -42,8 +42,8 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
 // ---------------------------------------------------------------------------------------------
 constexpr int ME_HALO = 3;
 constexpr int ME_COLS = 64 - 2 * ME_HALO;  // 58 output columns per wave
-constexpr int ME_ROWS = 48;                // output rows per wave
-constexpr int ME_LCAP = 1024;              // LDS candidate buffer (flushed when nearly full)
+constexpr int ME_ROWS = 64;                // most output rows per wave (rows per strip is a launch parameter)
+constexpr int ME_LCAP = 256;               // LDS candidate buffer (flushed when nearly full); small = 8 waves per SIMD
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i <- lane i-1
   return __builtin_bit_cast(
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
     const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
     const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey) {
+    unsigned int* __restrict__ maxkey, int strip_rows) {
   const int s = blockIdx.z;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
   __shared__ unsigned long long rowmask[ME_ROWS];  // bit l set: lane l's column is masked OUT
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
   const unsigned char* I = img + (size_t)s * img_stride;
   const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
   const int lane = threadIdx.x;
-  const int xs = blockIdx.x * ME_COLS, ys = blockIdx.y * ME_ROWS;
-  const int ye = min(ys + ME_ROWS, H);
+  const int xs = blockIdx.x * ME_COLS, ys = blockIdx.y * strip_rows;
+  const int ye = min(ys + strip_rows, H);
   const int x0 = xs - ME_HALO;          // column of lane 0
   const int gx = x0 + lane;
   const int cxr = reflect101(gx, W);    // source column (BORDER_REFLECT_101)
@@ -296,17 +296,38 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
   // D.cand_count / D.maxkey are zero here: allocated zeroed, re-zeroed by every select_kernel
-  dim3 grid((P.W + ME_COLS - 1) / ME_COLS, (P.H + ME_ROWS - 1) / ME_ROWS, P.B);
+  // Rows per strip: every strip pays 5 pipeline rows of overlap, so strips should be long, but the
+  // launch should also fit the chip's wave slots in ONE round (8 waves per SIMD: 38 VGPRs, 2.5 KB of
+  // LDS) -- 64 streams of 752x480 at 48 rows are 8320 waves for 8192 slots, and the 128 left over run
+  // after everything else.  Few streams want short strips instead (more waves than SIMDs).
+  static int slots = 0;
+  if (!slots) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                ? prop.multiProcessorCount * 4 * 8 : 8192;
+  }
+  const int nx = (P.W + ME_COLS - 1) / ME_COLS;
+  int strip_rows = 16;
+  double best = 1e30;
+  for (int rws = 16; rws <= ME_ROWS; rws += 4) {
+    const int ns = (P.H + rws - 1) / rws;
+    const double fill = (double)nx * ns * P.B / slots;
+    // time ~ rounds x rows per wave; below a quarter of the slots a wave runs at its own latency
+    const double cost = (fill > 1.0 ? ceil(fill) : fmax(fill, 0.25)) * (min(rws, P.H) + 5);
+    if (cost <= best) best = cost, strip_rows = rws;
+  }
+  dim3 grid(nx, (P.H + strip_rows - 1) / strip_rows, P.B);
   if (user_mask)
     hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                        img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
                        T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                       D.maxkey);
+                       D.maxkey, strip_rows);
   else
     hipLaunchKernelGGL(mineig_localmax_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
                        img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
                        T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                       D.maxkey);
+                       D.maxkey, strip_rows);
 }
 
 // =============================================================================================
