@@ -63,8 +63,17 @@ for ci in range(n_cfg):
             f_cur /= np.linalg.norm(f_cur, axis=1, keepdims=True)
         if len(f_ref):   # geometricOutlierRejection2d2d CHECKs for a non-empty match set (Tracker.cpp:243)
             same("5-point", c.outlier_rejection_2d2d(f_ref, f_cur), O.outlier_rejection_2d2d(f_ref, f_cur, t), desc)
-        same("2-point", c.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, Rm),
-             O.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, Rm, t), desc)
+            same("2-point", c.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, Rm),
+                 O.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, Rm, t), desc)
+        else:            # ... for both solvers: the CHECK abort is KVFE_ERR_INVALID_ARG at the C boundary
+            for call in (lambda: c.outlier_rejection_2d2d(f_ref, f_cur),
+                         lambda: c.outlier_rejection_2d2d_given_rotation(f_ref, f_cur, Rm)):
+                try:
+                    call()
+                    bad += 1
+                    print("MISMATCH empty match set accepted", desc)
+                except F.KvfeError as e:
+                    assert e.status == -1, e
         Ts = np.array([ocam.rect.baseline, 0.0, 0.0]) * float(rng.choice([1.0, 3.0]))
         rl, rr, p_ref, cl, cr, p_cur = TR.stereo_scene(ocam, srng, Rm, Ts, planar, n_in, n_out,
                                                        float(rng.choice([0.0, 0.002])))
