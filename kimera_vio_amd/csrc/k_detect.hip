@@ -358,8 +358,73 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16]*
   return base + inc - v;
 }
 
+// Bitonic sort, descending, n = EPT * 1024 keys with EPT in registers per thread (element i lives in
+// thread i % 1024, slot i / 1024).  Of the log2(n)(log2(n)+1)/2 compare-exchange steps only those with
+// partner distance 64 <= j < 1024 cross wavefronts (through `a` and a barrier: 22 of 91 for n = 8192);
+// j >= 1024 stays inside the thread, j < 64 inside the wavefront (shuffles).  Equal keys only occur
+// as zero padding, so max/min exchanges are exact.
+template <int EPT>
+__device__ void block_bitonic_desc_reg(unsigned long long* a) {
+  const int tid = threadIdx.x;
+  unsigned long long v[EPT];
+#pragma unroll
+  for (int m = 0; m < EPT; m++) v[m] = a[tid + m * SEL_T];
+  constexpr int n = EPT * SEL_T;
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= SEL_T) {
+        const int jm = j / SEL_T;
+#pragma unroll
+        for (int JM = 1; JM < EPT; JM <<= 1) {
+          if (jm != JM) continue;
+#pragma unroll
+          for (int m = 0; m < EPT; m++) {
+            if ((m & JM) == 0) {
+              const bool desc = (((m * SEL_T) & k) == 0);
+              const unsigned long long x = v[m], y = v[m | JM];
+              const unsigned long long hi = x > y ? x : y, lo = x > y ? y : x;
+              v[m] = desc ? hi : lo;
+              v[m | JM] = desc ? lo : hi;
+            }
+          }
+        }
+      } else if (j >= 64) {
+        __syncthreads();  // the previous exchange's readers are done
+#pragma unroll
+        for (int m = 0; m < EPT; m++) a[tid + m * SEL_T] = v[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < EPT; m++) {
+          const int i = tid + m * SEL_T;
+          const unsigned long long o = a[i ^ j];
+          const bool keepmax = ((i & j) == 0) == ((i & k) == 0);
+          const unsigned long long hi = v[m] > o ? v[m] : o, lo = v[m] > o ? o : v[m];
+          v[m] = keepmax ? hi : lo;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < EPT; m++) {
+          const int i = tid + m * SEL_T;
+          const unsigned long long o = __shfl_xor(v[m], j);
+          const bool keepmax = ((i & j) == 0) == ((i & k) == 0);
+          const unsigned long long hi = v[m] > o ? v[m] : o, lo = v[m] > o ? o : v[m];
+          v[m] = keepmax ? hi : lo;
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < EPT; m++) a[tid + m * SEL_T] = v[m];
+  __syncthreads();
+}
+
 // bitonic sort, descending, n = power of two, keys in LDS or global memory
 __device__ void block_bitonic_desc(unsigned long long* a, int n) {
+  if (n == SEL_T) return block_bitonic_desc_reg<1>(a);
+  if (n == 2 * SEL_T) return block_bitonic_desc_reg<2>(a);
+  if (n == 4 * SEL_T) return block_bitonic_desc_reg<4>(a);
+  if (n == 8 * SEL_T) return block_bitonic_desc_reg<8>(a);
   for (int k = 2; k <= n; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = threadIdx.x; i < n; i += SEL_T) {
@@ -486,36 +551,45 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
         const unsigned idx = (unsigned)key;
         const int y = idx / W, x = idx - y * W;
         bool ok = valid;
-        if (ok) {
-          const int xc = x / cell, yc = y / cell;
-          const int x1 = max(0, xc - 1), y1 = max(0, yc - 1);
-          const int x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
-          for (int yy = y1; yy <= y2 && ok; yy++)
-            for (int xx = x1; xx <= x2 && ok; xx++) {
-              const unsigned* g = grid + (yy * gw + xx) * 4;
+        const int xc = x / cell, yc = y / cell;
+        const int mycell = yc * gw + xc;
+        int myslot = 0;  // accepted corners already in this candidate's own cell
+        {
+          // 3x3 cells, one 16-byte LDS read each and no early exit: nine independent reads in flight
+          // instead of up to 36 dependent ones (border cells are clamped = tested twice, harmless)
+          const uint4* g4 = reinterpret_cast<const uint4*>(grid);
+          bool clear = true;
+#pragma unroll
+          for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+              const int cy = min(max(yc + dy, 0), gh - 1), cx = min(max(xc + dx, 0), gw - 1);
+              const uint4 g = g4[cy * gw + cx];
+              const unsigned e[4] = {g.x, g.y, g.z, g.w};
+              int cnt = 0;
+#pragma unroll
               for (int q = 0; q < 4; q++) {
-                const unsigned v = g[q];
-                if (v == 0xffffffffu) break;
-                const float dx = (float)(x - (int)(v & 0xffffu)), dy = (float)(y - (int)(v >> 16));
-                if (dx * dx + dy * dy < md2) {
-                  ok = false;
-                  break;
-                }
+                const bool used = e[q] != 0xffffffffu;
+                const float fx = (float)(x - (int)(e[q] & 0xffffu)), fy = (float)(y - (int)(e[q] >> 16));
+                clear &= !(used && (fx * fx + fy * fy < md2));
+                cnt += used ? 1 : 0;
               }
+              if (dy == 0 && dx == 0) myslot = cnt;  // slots fill in order
             }
+          ok = valid && clear;
         }
+        // The batch is resolved in rank order without a round trip through LDS: the accepted lane
+        // writes its own key and grid slot (fire and forget), everybody else only needs its position
+        // (readlane) -- later lanes of the same cell count it into their slot index.
         unsigned long long mask = __ballot(ok);
         while (mask) {
           const int l = __ffsll((long long)mask) - 1;  // highest-ranked survivor of the batch
-          const int lx = __shfl(x, l), ly = __shfl(y, l);
-          const unsigned long long lkey = __shfl(key, l);
-          if (lane == 0) {
-            skeys[acc] = lkey;  // in place: acc <= base, the batch itself is in registers
-            unsigned* g = grid + ((ly / cell) * gw + (lx / cell)) * 4;
-            int q = 0;
-            while (q < 4 && g[q] != 0xffffffffu) q++;
-            if (q < 4)
-              g[q] = (unsigned)lx | ((unsigned)ly << 16);
+          const int lx = __builtin_amdgcn_readlane(x, l), ly = __builtin_amdgcn_readlane(y, l);
+          const int lcell = __builtin_amdgcn_readlane(mycell, l);
+          if (lane == l) {
+            skeys[acc] = key;  // in place: acc <= base, the batch itself is in registers
+            if (myslot < 4)
+              grid[mycell * 4 + myslot] = (unsigned)x | ((unsigned)y << 16);
             else
               sh_flag = 2;  // cannot happen: five corners >= minDistance apart in one cell
           }
@@ -527,6 +601,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
           const float dx = (float)(x - lx), dy = (float)(y - ly);
           const bool near = ok && (dx * dx + dy * dy < md2);
           mask &= ~__ballot(near);
+          myslot += mycell == lcell ? 1 : 0;
         }
       }
       if (lane == 0) sh_cnt = acc;
