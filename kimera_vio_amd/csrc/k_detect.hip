@@ -517,8 +517,9 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
     const int ncell = gw * gh;
     unsigned* grid = reinterpret_cast<unsigned*>(cell_start);  // [ncell][4] packed (x | y << 16)
-    if (C2 <= 2048 && C2 <= (int)((MAX_CELLS + 1) * sizeof(int) / sizeof(unsigned long long))) {
-      // rank sort: keys are distinct, rank = number of larger keys
+    if (C2 <= 512) {
+      // rank sort: keys are distinct, rank = number of larger keys (O(n^2): only for short lists --
+      // 2048 keys cost 80 us this way, 10 us with the register-resident bitonic network below)
       unsigned long long* tmp = reinterpret_cast<unsigned long long*>(cell_start);
       for (int i = tid; i < C2; i += SEL_T) tmp[i] = work[i];
       __syncthreads();
