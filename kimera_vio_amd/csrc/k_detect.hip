@@ -398,8 +398,7 @@ __device__ void block_bitonic_desc_reg(unsigned long long* a) {
           const int i = tid + m * SEL_T;
           const unsigned long long o = a[i ^ j];
           const bool keepmax = ((i & j) == 0) == ((i & k) == 0);
-          const unsigned long long hi = v[m] > o ? v[m] : o, lo = v[m] > o ? o : v[m];
-          v[m] = keepmax ? hi : lo;
+          v[m] = ((o > v[m]) == keepmax) ? o : v[m];  // equal keys (zero padding): either copy
         }
       } else {
 #pragma unroll
@@ -407,8 +406,7 @@ __device__ void block_bitonic_desc_reg(unsigned long long* a) {
           const int i = tid + m * SEL_T;
           const unsigned long long o = __shfl_xor(v[m], j);
           const bool keepmax = ((i & j) == 0) == ((i & k) == 0);
-          const unsigned long long hi = v[m] > o ? v[m] : o, lo = v[m] > o ? o : v[m];
-          v[m] = keepmax ? hi : lo;
+          v[m] = ((o > v[m]) == keepmax) ? o : v[m];  // equal keys (zero padding): either copy
         }
       }
     }
