@@ -332,6 +332,47 @@ KVO_API void kvo_get_point3_and_covariance(const kvo_camera* c, double uL, doubl
 }
 // opengv::sac::Ransac<PointCloudSacProblem> (3-point Arun), for the reference's 3d3d KAT
 #include "opengv_re.hpp"
+// Tracker::findMatchingKeypoints / findMatchingStereoKeypoints / computeMedianDisparity and the voting
+// loop's Mahalanobis distance on their own (pinned by tests/testTracker.cpp:1320-1533)
+KVO_API int kvo_find_matching_keypoints(const int64_t* ref_lmk, int n_ref, const int64_t* cur_lmk, int n_cur,
+                                        const uint8_t* ref_right_status, const uint8_t* cur_right_status,
+                                        int32_t* out_pairs) {
+  kimera::StereoFrame ref, cur;
+  ref.left.landmarks.assign(ref_lmk, ref_lmk + n_ref);
+  cur.left.landmarks.assign(cur_lmk, cur_lmk + n_cur);
+  std::vector<kimera::KeypointMatch> m, ms;
+  kimera::findMatchingKeypoints(ref.left, cur.left, m);
+  if (ref_right_status && cur_right_status) {  // stereo variant: both right keypoints VALID
+    ref.right_kp_rect.resize(n_ref);
+    cur.right_kp_rect.resize(n_cur);
+    for (int i = 0; i < n_ref; i++) ref.right_kp_rect[i].status = ref_right_status[i];
+    for (int i = 0; i < n_cur; i++) cur.right_kp_rect[i].status = cur_right_status[i];
+    kimera::findMatchingStereoKeypoints(ref, cur, m, ms);
+    m.swap(ms);
+  }
+  for (size_t i = 0; i < m.size(); i++) {
+    out_pairs[2 * i] = (int32_t)m[i].first;
+    out_pairs[2 * i + 1] = (int32_t)m[i].second;
+  }
+  return (int)m.size();
+}
+KVO_API int kvo_compute_median_disparity(const float* ref_xy, const float* cur_xy, const int32_t* pairs, int n,
+                                         double* median) {
+  int hi = 0;
+  for (int i = 0; i < 2 * n; i++) hi = std::max(hi, pairs[i] + 1);
+  std::vector<Point2f> r(hi), c(hi);
+  for (int i = 0; i < hi; i++) {
+    r[i] = Point2f{ref_xy[2 * i], ref_xy[2 * i + 1]};
+    c[i] = Point2f{cur_xy[2 * i], cur_xy[2 * i + 1]};
+  }
+  std::vector<kimera::KeypointMatch> m(n);
+  for (int i = 0; i < n; i++) m[i] = std::make_pair((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]);
+  return kimera::computeMedianDisparity(r, c, m, median) ? 1 : 0;
+}
+KVO_API float kvo_mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj) {
+  return kimera::mahalanobis_f(vi, Ci, vj, Cj);
+}
+
 KVO_API int kvo_ransac_point_cloud(const double* p1, const double* p2, int n, double threshold,
                                    int max_iterations, double probability, int rng_policy,
                                    int32_t* inliers, double* pose, int* iterations) {

@@ -124,6 +124,8 @@ void findMatchingKeypoints(const Frame& ref, const Frame& cur, std::vector<Keypo
 void findMatchingStereoKeypoints(const StereoFrame& ref, const StereoFrame& cur,
                                  const std::vector<KeypointMatch>& mono,
                                  std::vector<KeypointMatch>& out);
+// the float32 Mahalanobis distance of the 1-point voting loop (Tracker.cpp:499-523): (vi - vj)^T (Ci + Cj)^-1 (vi - vj)
+float mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj);
 // Tracker::computeMedianDisparity (Tracker.cpp:991-1018)
 bool computeMedianDisparity(const std::vector<Point2f>& ref, const std::vector<Point2f>& cur,
                             const std::vector<KeypointMatch>& matches, double* median);

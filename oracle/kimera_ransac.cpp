@@ -201,7 +201,7 @@ static void eigen_inverse3(const double* m, double* r) {
 }
 
 // the float32 Mahalanobis test of the voting loop, literally (Tracker.cpp:499-523)
-static inline float mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj) {
+float mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj) {
   float v[3], O[9];
   for (int k = 0; k < 3; k++) v[k] = vi[k] - vj[k];
   for (int k = 0; k < 9; k++) O[k] = Ci[k] + Cj[k];

@@ -581,3 +581,38 @@ class Frontend:
         n = lefts.shape[0]
         arr = (abi.FrameInput * n)(*inputs)
         return lib().kvo_frontend_time_sequence(self._h, _p(lefts), _p(rights), self.w, self.h, n, arr)
+
+
+# ---- Tracker helper functions on their own (tests/test_oracle_ransac.py KATs) ---------------------------
+def find_matching_keypoints(ref_lmk, cur_lmk, ref_right_status=None, cur_right_status=None):
+    """Tracker::findMatchingKeypoints, or findMatchingStereoKeypoints when the right statuses are given."""
+    r = np.ascontiguousarray(ref_lmk, np.int64)
+    c = np.ascontiguousarray(cur_lmk, np.int64)
+    out = np.zeros((max(len(r), len(c), 1), 2), np.int32)
+    L = lib()
+    L.kvo_find_matching_keypoints.restype = C.c_int
+    rs = cs = None
+    if ref_right_status is not None:
+        rs = np.ascontiguousarray(ref_right_status, np.uint8)
+        cs = np.ascontiguousarray(cur_right_status, np.uint8)
+    n = L.kvo_find_matching_keypoints(_p(r), len(r), _p(c), len(c), _p(rs) if rs is not None else None,
+                                      _p(cs) if cs is not None else None, _p(out))
+    return out[:n].copy()
+
+
+def compute_median_disparity(ref_xy, cur_xy, pairs):
+    r = np.ascontiguousarray(ref_xy, np.float32).reshape(-1, 2)
+    c = np.ascontiguousarray(cur_xy, np.float32).reshape(-1, 2)
+    m = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    med = C.c_double(0)
+    L = lib()
+    L.kvo_compute_median_disparity.restype = C.c_int
+    ok = L.kvo_compute_median_disparity(_p(r), _p(c), _p(m), len(m), C.byref(med))
+    return bool(ok), med.value
+
+
+def mahalanobis_f(vi, Ci, vj, Cj) -> float:
+    L = lib()
+    L.kvo_mahalanobis_f.restype = C.c_float
+    a = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in (vi, Ci, vj, Cj)]
+    return float(L.kvo_mahalanobis_f(*[_p(x) for x in a]))

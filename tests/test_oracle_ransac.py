@@ -292,3 +292,79 @@ def test_sampler_stream_matches_std_mt19937():
     assert np.array_equal(O.mt19937_draws(abi.RNG_LIBSTDCXX_11, 4000), (raw >> 1).astype(np.int32))
     acc = raw[raw < 2 ** 31].astype(np.int32)
     assert np.array_equal(O.mt19937_draws(abi.RNG_LIBSTDCXX_PRE11, 1500), acc[:1500])
+
+
+# ---------------------------------------------------------------------------------------------
+# Tracker helper functions on their own (tests/testTracker.cpp:1320-1533)
+# ---------------------------------------------------------------------------------------------
+def _landmark_frames(rng, with_status):
+    """the synthetic landmark lists of FindMatchingKeypoints / FindMatchingStereoKeypoints
+    (testTracker.cpp:1327-1366, :1386-1451): 100 common ids 3i, 90 only in ref (3i+1), 80 only in cur
+    (3i+2), 70 invalid (-1) in both, shuffled."""
+    ref = [3 * i for i in range(100)] + [3 * i + 1 for i in range(90)] + [-1] * 70
+    cur = [3 * i for i in range(100)] + [3 * i + 2 for i in range(80)] + [-1] * 70
+    ref, cur = np.array(ref, np.int64), np.array(cur, np.int64)
+    rng.shuffle(ref)
+    rng.shuffle(cur)
+    if not with_status:
+        return ref, cur, None, None
+    VALID, NO_RIGHT_RECT = 0, 2   # KeypointStatus (vio_types.h:38-44)
+    rs = np.where(ref % 6 == 0, VALID, NO_RIGHT_RECT).astype(np.uint8)
+    cs = np.where(cur % 6 == 0, VALID, NO_RIGHT_RECT).astype(np.uint8)
+    return ref, cur, rs, cs
+
+
+def test_find_matching_keypoints():
+    """TestTracker.FindMatchingKeypoints (:1320-1383): exactly the 100 common landmarks, each once,
+    matched index to index."""
+    ref, cur, _, _ = _landmark_frames(np.random.default_rng(7), False)
+    m = O.find_matching_keypoints(ref, cur)
+    assert len(m) == 100
+    assert np.array_equal(ref[m[:, 0]], cur[m[:, 1]])
+    assert len(set(ref[m[:, 0]].tolist())) == 100 and (ref[m[:, 0]] != -1).all()
+    # order: the current frame's keypoint order (Tracker.cpp:934-945 walks cur.landmarks_)
+    assert np.all(np.diff(m[:, 1]) > 0)
+
+
+def test_find_matching_stereo_keypoints():
+    """TestTracker.FindMatchingStereoKeypoints (:1386-1474): of the 100 common landmarks only those with
+    a VALID right keypoint in both frames (ids divisible by 6) survive: (100 + 1) / 2 = 50."""
+    ref, cur, rs, cs = _landmark_frames(np.random.default_rng(8), True)
+    m = O.find_matching_keypoints(ref, cur, rs, cs)
+    assert len(m) == (100 + 1) // 2
+    assert np.array_equal(ref[m[:, 0]], cur[m[:, 1]])
+    assert (ref[m[:, 0]] % 6 == 0).all()
+    assert len(set(ref[m[:, 0]].tolist())) == len(m)
+
+
+def test_mahalanobis_distance_three_ways():
+    """TestTracker.MahalanobisDistance (:1477-1533): the hand-expanded float32 formula the voting loop uses
+    (Tracker.cpp:499-523) against an LLT solve and against v' O^-1 v, 1000 random cases, tolerance 1e-2."""
+    rng = np.random.default_rng(9)
+    for _ in range(1000):
+        mm = rng.uniform(-1, 1, (3, 5))
+        Om = (mm @ mm.T).astype(np.float32)
+        v = rng.uniform(-1, 1, 3).astype(np.float32)
+        d3 = O.mahalanobis_f(v, Om, np.zeros(3, np.float32), np.zeros(9, np.float32))
+        d1 = float(v.astype(np.float64) @ np.linalg.solve(Om.astype(np.float64), v.astype(np.float64)))
+        d2 = float(v @ np.linalg.inv(Om) @ v)
+        scale = max(1.0, abs(d1))  # the reference's absolute 1e-2 on O(1) values; relative for ill-conditioned draws
+        assert abs(d3 - d1) < 1e-2 * scale, (d3, d1)
+        assert abs(d3 - d2) < 1e-2 * scale, (d3, d2)
+
+
+def test_compute_median_disparity():
+    """Tracker::computeMedianDisparity (Tracker.cpp:991-1018; exercised by testDisparityCheck,
+    testStereoVisionImuFrontend.cpp:674-926): pixel distance of the matched keypoints, std::nth_element
+    median at index n / 2, sqrt of it; false and 0 for an empty match set."""
+    rng = np.random.default_rng(10)
+    ref = rng.uniform(0, 700, (50, 2)).astype(np.float32)
+    shift = rng.uniform(-30, 30, (50, 2)).astype(np.float32)
+    cur = ref + shift
+    pairs = np.stack([np.arange(50), np.arange(50)], 1).astype(np.int32)[rng.permutation(50)[:31]]
+    ok, med = O.compute_median_disparity(ref, cur, pairs)
+    d = cur[pairs[:, 1]] - ref[pairs[:, 0]]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)   # float products, widened
+    assert ok and med == np.sqrt(np.sort(d2)[len(d2) // 2])
+    ok, med = O.compute_median_disparity(ref, cur, np.zeros((0, 2), np.int32))
+    assert not ok and med == 0.0
