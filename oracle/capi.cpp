@@ -369,6 +369,26 @@ KVO_API int kvo_compute_median_disparity(const float* ref_xy, const float* cur_x
   for (int i = 0; i < n; i++) m[i] = std::make_pair((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]);
   return kimera::computeMedianDisparity(r, c, m, median) ? 1 : 0;
 }
+KVO_API int kvo_get_smart_stereo_measurements(const int64_t* lmk, const float* left_rect_xy,
+                                              const uint8_t* right_status, const float* right_rect_xy, int n,
+                                              int use_stereo_tracking, int64_t* out_lmk, double* out_uLuRv) {
+  kimera::StereoFrame sf;
+  sf.left.landmarks.assign(lmk, lmk + n);
+  sf.left_kp_rect.resize(n);
+  sf.right_kp_rect.resize(n);
+  for (int i = 0; i < n; i++) {
+    sf.left_kp_rect[i].status = KVFE_KP_VALID;
+    sf.left_kp_rect[i].kp = Point2f{left_rect_xy[2 * i], left_rect_xy[2 * i + 1]};
+    sf.right_kp_rect[i].status = right_status[i];
+    sf.right_kp_rect[i].kp = Point2f{right_rect_xy[2 * i], right_rect_xy[2 * i + 1]};
+  }
+  std::vector<int64_t> ml;
+  std::vector<double> mv;
+  kimera::smartStereoMeasurements(sf, use_stereo_tracking != 0, ml, mv);
+  std::copy(ml.begin(), ml.end(), out_lmk);
+  std::copy(mv.begin(), mv.end(), out_uLuRv);
+  return (int)ml.size();
+}
 KVO_API float kvo_mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj) {
   return kimera::mahalanobis_f(vi, Ci, vj, Cj);
 }

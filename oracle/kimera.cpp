@@ -791,20 +791,24 @@ bool Frontend::shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) cons
 }
 
 // getSmartStereoMeasurements (StereoVisionImuFrontend.cpp:485-531)
-void Frontend::getSmartStereoMeasurements(const StereoFrame& sf) {
+void smartStereoMeasurements(const StereoFrame& sf, bool use_stereo_tracking, std::vector<int64_t>& meas_lmk,
+                             std::vector<double>& meas_uLuRv) {
   meas_lmk.clear();
   meas_uLuRv.clear();
   for (size_t i = 0; i < sf.left.landmarks.size(); ++i) {
     if (sf.left.landmarks[i] == -1) continue;
     double uL = sf.left_kp_rect[i].kp.x, v = sf.left_kp_rect[i].kp.y;
     double uR = std::numeric_limits<double>::quiet_NaN();
-    if (p.use_stereo_tracking && sf.right_kp_rect[i].status == KVFE_KP_VALID)
+    if (use_stereo_tracking && sf.right_kp_rect[i].status == KVFE_KP_VALID)
       uR = sf.right_kp_rect[i].kp.x;
     meas_lmk.push_back(sf.left.landmarks[i]);
     meas_uLuRv.push_back(uL);
     meas_uLuRv.push_back(uR);
     meas_uLuRv.push_back(v);
   }
+}
+void Frontend::getSmartStereoMeasurements(const StereoFrame& sf) {
+  smartStereoMeasurements(sf, p.use_stereo_tracking != 0, meas_lmk, meas_uLuRv);
 }
 
 void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,

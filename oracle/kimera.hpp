@@ -218,6 +218,11 @@ struct Frontend {
   void depthDetectionMask(const void* depth, size_t depth_stride, std::vector<uint8_t>& mask) const;
 };
 
+// StereoVisionImuFrontend::getSmartStereoMeasurements (StereoVisionImuFrontend.cpp:485-531): (landmark id,
+// uL, uR or NaN, v) of every keypoint with a landmark
+void smartStereoMeasurements(const StereoFrame& sf, bool use_stereo_tracking, std::vector<int64_t>& meas_lmk,
+                             std::vector<double>& meas_uLuRv);
+
 // gtsam::Rot3::equals(Rot3(), 1e-9) as used for `given_rot` (VisionImuFrontend.cpp:97,125)
 bool rot_equals_identity(const double R[9], double tol);
 

@@ -616,3 +616,16 @@ def mahalanobis_f(vi, Ci, vj, Cj) -> float:
     L.kvo_mahalanobis_f.restype = C.c_float
     a = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in (vi, Ci, vj, Cj)]
     return float(L.kvo_mahalanobis_f(*[_p(x) for x in a]))
+
+
+def get_smart_stereo_measurements(lmk, left_rect_xy, right_status, right_rect_xy, use_stereo_tracking=True):
+    l = np.ascontiguousarray(lmk, np.int64)
+    lx = np.ascontiguousarray(left_rect_xy, np.float32).reshape(-1, 2)
+    rs = np.ascontiguousarray(right_status, np.uint8)
+    rx = np.ascontiguousarray(right_rect_xy, np.float32).reshape(-1, 2)
+    ol, om = np.zeros(len(l), np.int64), np.zeros((len(l), 3), np.float64)
+    L = lib()
+    L.kvo_get_smart_stereo_measurements.restype = C.c_int
+    n = L.kvo_get_smart_stereo_measurements(_p(l), _p(lx), _p(rs), _p(rx), len(l), int(use_stereo_tracking),
+                                            _p(ol), _p(om))
+    return ol[:n].copy(), om[:n].copy()

@@ -494,3 +494,30 @@ def test_fisheye_rectification_and_undistortion():
     assert abs(prod.baseline - rect.baseline) < 1e-14
     pmx, pmy = F.compute_undistort_rectify_maps(L, prod.R1, prod.P1)
     assert np.abs(pmx - mx).max() < 1e-3 and np.abs(pmy - my).max() < 1e-3
+
+
+def test_get_smart_stereo_measurements():
+    """StereoVisionImuFrontendFixture.getSmartStereoMeasurements (tests/testStereoVisionImuFrontend.cpp:360-452):
+    12 valid keypoints, 12 without a right match, 12 without a landmark -> 24 measurements (landmark i = i),
+    uL / v from the rectified left keypoint, uR from the right one or NaN, no landmark twice."""
+    rng = np.random.RandomState(5)
+    n_valid = n_missing = n_invalid = 12
+    n = n_valid + n_missing + n_invalid
+    uL = rng.randint(0, 800, n).astype(np.float32)
+    uR = uL + rng.randint(-40, 40, n).astype(np.float32)
+    v = rng.randint(0, 600, n).astype(np.float32)
+    lmk = np.array(list(range(n_valid + n_missing)) + [-1] * n_invalid, np.int64)
+    VALID, NO_RIGHT_RECT = 0, 2
+    rstat = np.array([VALID] * n_valid + [NO_RIGHT_RECT] * n_missing + [VALID] * n_invalid, np.uint8)
+    ml, mv = O.get_smart_stereo_measurements(lmk, np.stack([uL, v], 1), rstat, np.stack([uR, v], 1))
+    assert len(ml) == n_valid + n_missing
+    assert len(set(ml.tolist())) == len(ml)
+    for lid, (muL, muR, mvv) in zip(ml, mv):
+        assert muL == uL[lid] and mvv == v[lid]
+        if rstat[lid] == VALID:
+            assert muR == uR[lid]
+        else:
+            assert np.isnan(muR)
+    # use_stereo_tracking off (StereoVisionImuFrontend.cpp:509): every uR is NaN
+    _, mono = O.get_smart_stereo_measurements(lmk, np.stack([uL, v], 1), rstat, np.stack([uR, v], 1), False)
+    assert np.isnan(mono[:, 1]).all()
