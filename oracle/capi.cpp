@@ -389,6 +389,26 @@ KVO_API int kvo_get_smart_stereo_measurements(const int64_t* lmk, const float* l
   std::copy(mv.begin(), mv.end(), out_uLuRv);
   return (int)ml.size();
 }
+// StereoMatcher::getDepthFromRectifiedMatches on its own (pinned by tests/testStereoMatcher.cpp:394-502);
+// statuses are updated in place as the reference does (NO_DEPTH)
+KVO_API void kvo_get_depth_from_rectified_matches(const kvo_camera* c, const kvfe_stereo_params* p, int n,
+                                                  const float* left_xy, uint8_t* left_status,
+                                                  const float* right_xy, uint8_t* right_status, double* depth) {
+  std::vector<StatusKeypoint> l(n), r(n);
+  for (int i = 0; i < n; i++) {
+    l[i].status = left_status[i];
+    l[i].kp = Point2f{left_xy[2 * i], left_xy[2 * i + 1]};
+    r[i].status = right_status[i];
+    r[i].kp = Point2f{right_xy[2 * i], right_xy[2 * i + 1]};
+  }
+  std::vector<double> d;
+  kimera::getDepthFromRectifiedMatches(l, r, c->cam.fx(), c->cam.baseline(), *p, d);
+  for (int i = 0; i < n; i++) {
+    depth[i] = d[i];
+    left_status[i] = l[i].status;
+    right_status[i] = r[i].status;
+  }
+}
 KVO_API float kvo_mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj) {
   return kimera::mahalanobis_f(vi, Ci, vj, Cj);
 }

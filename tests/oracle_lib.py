@@ -629,3 +629,15 @@ def get_smart_stereo_measurements(lmk, left_rect_xy, right_status, right_rect_xy
     n = L.kvo_get_smart_stereo_measurements(_p(l), _p(lx), _p(rs), _p(rx), len(l), int(use_stereo_tracking),
                                             _p(ol), _p(om))
     return ol[:n].copy(), om[:n].copy()
+
+
+def get_depth_from_rectified_matches(cam: "Camera", sp: abi.StereoParams, left_xy, left_status, right_xy,
+                                     right_status):
+    """StereoMatcher::getDepthFromRectifiedMatches; returns (depth, left_status, right_status)."""
+    lx = np.ascontiguousarray(left_xy, np.float32).reshape(-1, 2)
+    rx = np.ascontiguousarray(right_xy, np.float32).reshape(-1, 2)
+    ls = np.array(left_status, np.uint8)
+    rs = np.array(right_status, np.uint8)
+    d = np.zeros(len(lx), np.float64)
+    lib().kvo_get_depth_from_rectified_matches(C.c_void_p(cam._h), C.byref(sp), len(lx), _p(lx), _p(ls), _p(rx), _p(rs), _p(d))
+    return d, ls, rs

@@ -521,3 +521,45 @@ def test_get_smart_stereo_measurements():
     # use_stereo_tracking off (StereoVisionImuFrontend.cpp:509): every uR is NaN
     _, mono = O.get_smart_stereo_measurements(lmk, np.stack([uL, v], 1), rstat, np.stack([uR, v], 1), False)
     assert np.isnan(mono[:, 1]).all()
+
+
+def test_get_depth_from_rectified_matches(euroc_cam):
+    """StereoMatcherFixture.getDepthFromRectifiedMatches (tests/testStereoMatcher.cpp:394-502): 3-D points at
+    11 depth-to-baseline ratios x 9 image positions projected with P1 / P2; depth = fx b / disparity within 1e-3,
+    0 outside [min_point_dist, max_point_dist] of the default StereoMatchingParams (0.1, 15), 0 for every
+    keypoint pair that is not VALID / VALID and for a negative disparity."""
+    cam = euroc_cam
+    P1 = np.array(cam.rect.P1).reshape(3, 4)
+    P2 = np.array(cam.rect.P2).reshape(3, 4)
+    b = cam.rect.baseline
+    sp = abi.StereoParams()
+    sp.min_point_dist, sp.max_point_dist = 0.1, 15.0       # StereoMatchingParams.h:50-52
+    lxy, rxy, expd = [], [], []
+    for ratio in (0.5, 1.0, 2.0, 3.0, 5.0, 10.0, 15.0, 20.0, 30.0, 50.0, 100.0):
+        for x2d in (-0.2, 0, 0.2):
+            for y2d in (-0.2, 0, 0.2):
+                depth = ratio * b
+                X = np.array([x2d * depth, y2d * depth, depth, 1.0])
+                pl, pr = P1 @ X, P2 @ X
+                lxy.append(pl[:2] / pl[2])
+                rxy.append(pr[:2] / pr[2])
+                expd.append(depth)
+    VALID, NO_LEFT_RECT, NO_RIGHT_RECT, NO_DEPTH, FAILED_ARUN = range(5)
+    n = len(expd)
+    ls, rs = [VALID] * n, [VALID] * n
+    for l_s, r_s, lx in ((VALID, NO_RIGHT_RECT, 1.0), (NO_LEFT_RECT, VALID, 1.0), (NO_DEPTH, FAILED_ARUN, 1.0),
+                         (NO_DEPTH, FAILED_ARUN, 3.0)):           # the last one: negative disparity
+        lxy.append(np.array([lx, 2.0]))
+        rxy.append(np.array([1.0, 2.0]))
+        ls.append(l_s)
+        rs.append(r_s)
+        expd.append(0.0)
+    d, _, _ = O.get_depth_from_rectified_matches(cam, sp, np.array(lxy), ls, np.array(rxy), rs)
+    checked = 0
+    for got, exp in zip(d, expd):
+        if exp < sp.min_point_dist or exp > sp.max_point_dist:
+            assert abs(got) < 1e-3
+        else:
+            assert abs(got - exp) < 1e-3, (got, exp)
+            checked += 1
+    assert checked >= 9 * 9   # ratios 1 .. 100 of a 0.11 m baseline lie inside (0.1, 15) m
