@@ -123,3 +123,15 @@ def test_yaml_parsing_euroc():
     assert p.tracker.klt_max_level == 4 and p.tracker.klt_win_size == 24 and abs(p.tracker.klt_eps - 0.1) < 1e-15
     assert p.stereo.templ_cols == 101 and p.stereo.min_point_dist == 0.5
     assert p.min_intra_keyframe_time_ns == 0.2e9 and p.max_intra_keyframe_time_ns == 5e9
+
+
+def test_cpp_adapter_program_builds_with_plain_gxx():
+    """tests/cpp/adapter_sequence.cpp (the reference-shaped C++ host program over include/kvfe_adapter.hpp)
+    compiles with g++ alone and links libkvfe.so; without arguments it prints its usage and exits 2.  The GPU
+    suite runs it against the oracle."""
+    import subprocess
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    r = subprocess.run(["make", "-C", cpp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([os.path.join(cpp, "adapter_sequence")], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
