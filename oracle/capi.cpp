@@ -409,6 +409,13 @@ KVO_API void kvo_get_depth_from_rectified_matches(const kvo_camera* c, const kvf
     right_status[i] = r[i].status;
   }
 }
+KVO_API int kvo_crop_to_size(float* xy, int w, int h, int round_first) {
+  Point2f p{xy[0], xy[1]};
+  const bool c = round_first ? kimera::roundAndCropToSize(&p, w, h) : kimera::cropToSize(&p, w, h);
+  xy[0] = p.x;
+  xy[1] = p.y;
+  return c ? 1 : 0;
+}
 KVO_API float kvo_mahalanobis_f(const float* vi, const float* Ci, const float* vj, const float* Cj) {
   return kimera::mahalanobis_f(vi, Ci, vj, Cj);
 }

@@ -144,7 +144,7 @@ void StereoCamera::getBearingVector(int cam, Point2f kp, double versor[3]) const
   versor[2] = z / n;
 }
 
-static bool cropToSize(Point2f* px, int w, int h) {  // UtilsOpenCV.cpp:215-235
+bool cropToSize(Point2f* px, int w, int h) {  // UtilsOpenCV.cpp:215-235
   bool cropped = false;
   float max_width = (float)(w - 1);
   if (px->x > max_width) {
@@ -163,6 +163,12 @@ static bool cropToSize(Point2f* px, int w, int h) {  // UtilsOpenCV.cpp:215-235
     cropped = true;
   }
   return cropped;
+}
+
+bool roundAndCropToSize(Point2f* px, int w, int h) {  // UtilsOpenCV.cpp:242-247
+  px->x = std::round(px->x);
+  px->y = std::round(px->y);
+  return cropToSize(px, w, h);
 }
 
 void StereoCamera::undistortRectifyLeftKeypoints(const std::vector<Point2f>& kps,

@@ -218,6 +218,10 @@ struct Frontend {
   void depthDetectionMask(const void* depth, size_t depth_stride, std::vector<uint8_t>& mask) const;
 };
 
+// UtilsOpenCV::cropToSize / roundAndCropToSize (UtilsOpenCV.cpp:215-247): clamp to [0, w-1] x [0, h-1], true if moved
+bool cropToSize(Point2f* px, int w, int h);
+bool roundAndCropToSize(Point2f* px, int w, int h);
+
 // StereoVisionImuFrontend::getSmartStereoMeasurements (StereoVisionImuFrontend.cpp:485-531): (landmark id,
 // uL, uR or NaN, v) of every keypoint with a landmark
 void smartStereoMeasurements(const StereoFrame& sf, bool use_stereo_tracking, std::vector<int64_t>& meas_lmk,

@@ -641,3 +641,12 @@ def get_depth_from_rectified_matches(cam: "Camera", sp: abi.StereoParams, left_x
     d = np.zeros(len(lx), np.float64)
     lib().kvo_get_depth_from_rectified_matches(C.c_void_p(cam._h), C.byref(sp), len(lx), _p(lx), _p(ls), _p(rx), _p(rs), _p(d))
     return d, ls, rs
+
+
+def crop_to_size(px, w, h, round_first=False):
+    """UtilsOpenCV::cropToSize / roundAndCropToSize; returns ((x, y), cropped)."""
+    p = np.array(px, np.float32)
+    L = lib()
+    L.kvo_crop_to_size.restype = C.c_int
+    c = L.kvo_crop_to_size(_p(p), int(w), int(h), int(round_first))
+    return (float(p[0]), float(p[1])), bool(c)

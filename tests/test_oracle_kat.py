@@ -563,3 +563,24 @@ def test_get_depth_from_rectified_matches(euroc_cam):
             assert abs(got - exp) < 1e-3, (got, exp)
             checked += 1
     assert checked >= 9 * 9   # ratios 1 .. 100 of a 0.11 m baseline lie inside (0.1, 15) m
+
+
+@pytest.mark.parametrize("px,rnd,expected,cropped", [
+    ((700, 300), False, (700, 300), False),          # CropToSizeInside (tests/testUtilsOpenCV.cpp:280-288)
+    ((799, 599), False, (799, 599), False),          # CropToSizeBoundary (:291-317)
+    ((800, 600), False, (799, 599), True),
+    ((0, 0), False, (0, 0), False),
+    ((-1, -1), False, (0, 0), True),
+    ((1000, 700), False, (799, 599), True),          # CropToSize (:320-349)
+    ((-100, -200), False, (0, 0), True),
+    ((700.3, 399.5), True, (700, 400), False),
+    ((699.50001, 300.499), True, (700, 300), False),
+    ((799.5, 599.5), True, (799, 599), True),        # RoundAndCropToSizeBoundary (:352-366)
+    ((-0.499, -0.499), True, (0, 0), False),
+    ((1000.4, 700.4), True, (799, 599), True),       # RoundAndCropToSizeOutside (:369-383)
+    ((-1000, -800), True, (0, 0), True),
+])
+def test_crop_to_size(px, rnd, expected, cropped):
+    """UtilsOpenCV::cropToSize / roundAndCropToSize in an 800 x 600 frame, every case of the reference's tests."""
+    got, c = O.crop_to_size(px, 800, 600, rnd)
+    assert got == (float(expected[0]), float(expected[1])) and c == cropped
