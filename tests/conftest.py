@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): compile libkvfe.so for gfx950 once
+    (hipcc cross-compiles without a GPU; ~30 s) so that the suite does not depend on build() having run first.
+    Building is not a fallback: without the library every product call still fails loudly."""
+    so = os.path.join(ROOT, "kimera_vio_amd", "csrc", "libkvfe.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.dirname(so), "-j8"], check=True, capture_output=True)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return GOLDEN
