@@ -2,18 +2,28 @@
 """bench.py — stereo-pairs/sec of the MI355X-native stereo front-end (detect + track + match).
 
 One "step" = one pass of the hot path over one batch of synthetic input: every one of the `batch`
-independent 752x480 stereo streams of this GPU advances by one stereo pair through
-   pyramid -> (gyro-predicted) pyramidal LK track -> keyframe decision -> masked Shi-Tomasi detect
-   + ANMS + cornerSubPix -> undistort-rectify L/R -> epipolar SSD stereo match + depth
+independent stereo streams of this GPU advances by one stereo pair through
+   pyramid -> (gyro-predicted) pyramidal LK track -> keyframe decision -> geometric outlier rejection
+   -> masked Shi-Tomasi detect + ANMS + cornerSubPix -> undistort-rectify L/R -> epipolar SSD stereo
+   match + depth -> smart stereo measurements
 with the inputs already resident in HBM (a ring of pre-generated frames).  N GPUs = N processes
-(torchrun), each with its own context and its own `batch` streams (weak scaling); the only
-collective is the RCCL barrier that brackets the timed region.
+(torch.distributed.run), each with its own context and its own streams; the only collective is the
+RCCL barrier that brackets the timed region.  `python bench.py --gpus N` without a torchrun
+environment re-executes itself under `python -m torch.distributed.run --nproc-per-node N`.
 
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline accounting.
+The workloads are built by kimera_vio_amd/workloads.py — the same call the parity tests
+(tests/test_gpu_bench_configs.py) use, so what is timed here is compared with the oracle there.
+
+Prints ONE JSON line (rank 0): `value` = BASELINE configs[2] (64 x 752x480, 600 features, every frame
+a keyframe) unless --config says otherwise; the other BASELINE configurations ride along as legs
+(`nominal`, `single_stream` = configs[1], `c5` = configs[4] incl. its dense-stereo row) at N = 1.
+See DESIGN.md "Measurement" for the roofline accounting.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -23,31 +33,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+ALL_LEGS = ("nominal", "single_stream", "c5", "dense", "dense_c5", "pcie", "cpu")
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=64, help="independent stereo streams per GPU")
-    ap.add_argument("--width", type=int, default=752)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--features", type=int, default=600)
-    ap.add_argument("--klt-max-level", type=int, default=2, help="2 = 3-level pyramid")
+    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
+                    help="which BASELINE config `value` is measured on: c3 = configs[2] (headline), c4 = configs[3] "
+                         "(8 EuRoC sequences sharded over the GPUs, one stream per sequence, strong scaling), "
+                         "c5 = configs[4]")
+    ap.add_argument("--batch", type=int, default=None, help="independent stereo streams per GPU (config default)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--features", type=int, default=None)
+    ap.add_argument("--klt-max-level", type=int, default=None, help="2 = 3-level pyramid")
     ap.add_argument("--mode", choices=["kf", "nominal"], default="kf",
                     help="kf: every frame is a keyframe (all stages every pair, headline); "
                          "nominal: reference cadence (keyframe every 0.2 s = 4th frame)")
     ap.add_argument("--ransac", type=int, default=1, choices=[0, 1],
-                    help="useRANSAC of params/Euroc/FrontendParams.yaml (1 = as shipped: 2-point mono + "
-                         "1-point stereo geometric outlier rejection on every keyframe)")
+                    help="useRANSAC of params/Euroc/FrontendParams.yaml (1 = as shipped)")
     ap.add_argument("--mono-2point", type=int, default=1, choices=[0, 1],
                     help="ransac_use_2point_mono (0: the 5-point problem of params/D455)")
     ap.add_argument("--stereo-1point", type=int, default=1, choices=[0, 1],
                     help="ransac_use_1point_stereo (0: the 3-point Arun problem of params/D455)")
-    ap.add_argument("--ring", type=int, default=6, help="distinct frames per stream (ping-pong)")
-    ap.add_argument("--unique-streams", type=int, default=8)
+    ap.add_argument("--ring", type=int, default=None, help="distinct frames per stream (ping-pong)")
+    ap.add_argument("--unique-streams", type=int, default=None)
     ap.add_argument("--groups", type=int, default=0,
                     help="stream groups per context (0 = library default for the batch size)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region of exactly --steps steps is run this many times; `value` is the median")
+    ap.add_argument("--legs", default="all",
+                    help="comma list of the extra N=1 legs to run: " + ",".join(ALL_LEGS) + " | all | none")
     ap.add_argument("--cpu-baseline-frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true",
@@ -55,95 +75,89 @@ def parse():
     ap.add_argument("--stage-event-stride", type=int, default=4,
                     help="every N-th timed step records per-stage HIP events (roofline / stage breakdown)")
     ap.add_argument("--no-single-stream", action="store_true")
-    ap.add_argument("--no-dense", action="store_true", help="skip the dense-stereo (SGBM) leg")
-    return ap.parse_args()
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-stereo (SGBM) legs")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only (tests/test_multi_rank.py, no GPU): become --gpus ranks, build each "
+                         "rank's workload shard, barrier + timing reduction over gloo, print the shard map; "
+                         "nothing is computed or timed and no `value` is printed")
+    a = ap.parse_args()
+    legs = set(ALL_LEGS) if a.legs == "all" else set(x for x in a.legs.split(",") if x and x != "none")
+    unknown = legs - set(ALL_LEGS)
+    if unknown:
+        ap.error(f"unknown legs {sorted(unknown)}")
+    if a.no_cpu_baseline:
+        legs.discard("cpu")
+    if a.no_single_stream:
+        legs -= {"single_stream", "pcie"}
+    if a.no_dense:
+        legs -= {"dense", "dense_c5"}
+    a.legs = legs
+    return a
 
 
-def make_cameras(P, G, w, h):
-    L = P.load_camera_params(os.path.join(G, "params_euroc", "LeftCameraParams.yaml"))
-    R = P.load_camera_params(os.path.join(G, "params_euroc", "RightCameraParams.yaml"))
-    if (w, h) != (L.width, L.height):
-        sx = w / L.width
-        for cam in (L, R):
-            cx0, cy0 = cam.width / 2.0, cam.height / 2.0
-            cam.intrinsics[0] *= sx
-            cam.intrinsics[1] *= sx
-            cam.intrinsics[2] = w / 2.0 + (cam.intrinsics[2] - cx0) * sx
-            cam.intrinsics[3] = h / 2.0 + (cam.intrinsics[3] - cy0) * sx
-            cam.width, cam.height = w, h
-    return L, R
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def ping_pong(i, n):
-    if n == 1:
-        return 0
-    period = 2 * (n - 1)
-    j = i % period
-    return j if j < n else period - j
+def maybe_reexec_distributed(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become N ranks, one process per GPU."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+def load_pmc():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
-    from kimera_vio_amd import frontend as F
-    from kimera_vio_amd import params as P
-    from kimera_vio_amd import sharding, synth
 
-    rank, local_rank, world = sharding.env_rank()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libkvfe has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+# kernel behind every dense (image-sized) stage: (rocprof kernel name, launches per step)
+PMC_NAMES = {"pyramid": ("pyrdown", 2), "mineig_localmax": ("mineig_localmax_kernel", 1),
+             "rectify": ("rectify_kernel", 1)}
 
-    G = os.path.join(ROOT, "tests", "golden")
-    W, H, B = args.width, args.height, args.batch
-    L, R = make_cameras(P, G, W, H)
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=args.ransac)
-    p.detector.max_features_per_frame = args.features
-    p.tracker.klt_max_level = args.klt_max_level
-    p.tracker.ransac_use_2point_mono = args.mono_2point
-    p.tracker.ransac_use_1point_stereo = args.stereo_1point
 
-    # ---- synthetic input ring, resident in HBM ---------------------------------------------------
-    U = max(1, min(args.unique_streams, B))
-    T = args.ring
-    R1 = np.array(F.compute_rectification(L, R).R1).reshape(3, 3)
-    streams = [synth.RigStream(L, R, seed=100 * rank + u, rect_R1=R1) for u in range(U)]
-    lefts = np.empty((T, B, H, W), np.uint8)
-    rights = np.empty((T, B, H, W), np.uint8)
-    for t in range(T):
-        for u in range(U):
-            l, r = streams[u].frame(t)
-            lefts[t, u::U] = l
-            rights[t, u::U] = r
+def pmc_traffic(pmc_leg, stage):
+    """HBM-side bytes per step of the stage's kernel(s) from the committed rocprofv3 PMC passes of the same
+    leg alone (tools/rocpd_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes; per launch shape, the
+    shapes of one step added up — the pyramid is one launch per level).  2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads
+    — an upper bound for kernels that also issue narrow loads.  None when no counters are committed for
+    this leg."""
+    if not pmc_leg or stage not in PMC_NAMES:
+        return None
+    prefix, launches = PMC_NAMES[stage]
+    tot, hit = 0.0, False
+    for k, v in pmc_leg.items():
+        if k.startswith(prefix):
+            tot += (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0
+            hit = True
+    if not hit:
+        return None
+    return round(tot)
+
+
+def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, repeats, groups, stage_stride,
+                     pmc_leg=None):
+    """times `repeats` regions of exactly `steps` steps of the workload on this rank's GPU; returns the
+    result dict of the leg (rank-reduced: MAX time over ranks, SUM of pairs)."""
+    B, W, H = wl.batch, wl.width, wl.height
+    lefts, rights = wl.replicated()
     d_left = torch.from_numpy(lefts).to(dev)
     d_right = torch.from_numpy(rights).to(dev)
     torch.cuda.synchronize()
-
-    ctx = F.Context(L, R, p, batch=B, device=local_rank, stream_groups=args.groups)
-    dt_ns = 50_000_000  # 20 Hz
-
-    def frame_inputs(step_idx, kf_t):
-        t = ping_pong(step_idx, T)
-        Rs = [synth.rig_keyframe_R_cur(streams[s % U], kf_t, t) for s in range(B)]
-        force = 1 if args.mode == "kf" else 0
-        return t, ctx.make_inputs([step_idx * dt_ns] * B, Rs, [force] * B)
-
-    # pre-compute inputs for all steps (host work outside the timed region)
-    total = args.warmup + args.steps
-    plan = []
-    kf_t = 0
-    last_kf_step = 0
-    for i in range(total):
-        t, inp = frame_inputs(i, kf_t)
-        plan.append((t, inp))
-        is_kf = (args.mode == "kf") or i == 0 or (i - last_kf_step) * dt_ns >= p.min_intra_keyframe_time_ns
-        if is_kf:
-            kf_t, last_kf_step = t, i
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=B, device=dev.index, stream_groups=groups)
+    total = warmup + repeats * steps
+    plan = [(st[0], wl.batch_inputs(ctx, st)) for st in wl.plan(total)]   # host work outside the timed region
 
     def run(i0, i1):
         for i in range(i0, i1):
@@ -155,203 +169,267 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    run(0, args.warmup)
+    run(0, warmup)
     barrier()
-    if not args.no_stage_events:
-        ctx.profile_enable(args.stage_event_stride)
-    t0 = time.perf_counter()
-    run(args.warmup, total)
-    t_enq = time.perf_counter()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    prof = ctx.profile_read()
+    if stage_stride:
+        ctx.profile_enable(stage_stride)
+    times, enq = [], []
+    new_corners, kf_steps = 0, 0
+    for r in range(repeats):
+        i0 = warmup + r * steps
+        barrier()
+        t0 = time.perf_counter()
+        run(i0, i0 + steps)
+        t_enq = time.perf_counter()
+        barrier()
+        t1 = time.perf_counter()
+        el, pairs = sharding.reduce_timing(dist, world, t1 - t0, B * steps, device=dev)
+        times.append(el)
+        enq.append(t_enq - t0)
+        o = ctx.get_output(0)             # outside the timed region: detection-side work per keyframe
+        if o["is_keyframe"]:
+            new_corners += o["n_detected"]
+            kf_steps += 1
+    prof = ctx.profile_read() if stage_stride else None
     ctx.profile_enable(False)
-    elapsed, pairs = sharding.reduce_timing(dist, world, elapsed, B * args.steps, device=dev)
-
-    # sanity of the measured work: every stream produced keypoints and stereo matches
-    out0 = ctx.get_output(0)
-    outl = ctx.get_output(B - 1)
+    out0, outl = ctx.get_output(0), ctx.get_output(B - 1)
     assert out0["n_keypoints"] > 0 and outl["n_keypoints"] > 0, "front-end produced no keypoints"
-    n_valid = int((out0["right_status"] == 0).sum()) if out0["is_keyframe"] else -1
-
-    # PCIe-inclusive rates (host buffers handed over at the boundary): reported, never `value`.
-    #  staged : the data provider writes into the context's pinned slots, the upload runs on a copy
-    #           stream and overlaps the previous step (kvfe_frontend_step_staged)
-    #  pageable: kvfe_frontend_step_host from ordinary host memory, copies on the compute stream
-    pcie = None
-    if rank == 0 and world == 1 and not args.no_single_stream:
-        hl = np.ascontiguousarray(lefts[:3])
-        hr = np.ascontiguousarray(rights[:3])
-        ctx.reset()
-        n_h = 12
-        for sl in range(3):  # "decoded" frames sit in the pinned slots before the clock starts
-            a, b = ctx.staging_buffers(sl)
-            a[:] = hl[sl]
-            b[:] = hr[sl]
-        for i in range(3):
-            ctx.step_staged(i % 3, plan[i][1])
-        ctx.synchronize()
-        th = time.perf_counter()
-        for i in range(3, 3 + n_h):
-            ctx.step_staged(i % 3, plan[i][1])
-        ctx.synchronize()
-        staged = B * n_h / (time.perf_counter() - th)
-        ctx.reset()
-        for i in range(2):
-            ctx.step_host(hl[i % 2], hr[i % 2], plan[i][1])
-        ctx.synchronize()
-        th = time.perf_counter()
-        for i in range(2, 8):
-            ctx.step_host(hl[i % 2], hr[i % 2], plan[i][1])
-        ctx.synchronize()
-        pcie = {"value": round(staged, 2), "unit": "stereo-pairs/s",
-                "note": "kvfe_frontend_step_staged: pinned staging slots, H2D upload of every frame inside the "
-                        "timed region on a copy stream overlapping the previous step",
-                "pageable_value": round(B * 6 / (time.perf_counter() - th), 2)}
     ctx.close()
+    del d_left, d_right
 
-    value = pairs / elapsed
-
-    # ---- roofline, from HIP events recorded on the context's own stream inside the timed region ----
-    # Every dense (image-sized) kernel is priced against the HBM roofline with its ALGORITHMIC bytes
-    # per launch; `roofline` is the dominant dense kernel by time, `roofline_kernels`
-    # lists all of them.  `traffic` = HBM-side bytes per launch from the rocprofv3 PMC passes of the
-    # same command (profiles/pmc_traffic_latest.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
-    # correction of MI355X_MICROARCH.md for wide coalesced reads -> an upper bound), null when the
-    # committed counters were taken on another workload.
-    stages = prof["stages"]
-    ns = max(prof["n_samples"], 1)          # launches recorded per stage (all stream groups)
-    groups = max(prof["n_groups"], 1)       # launches per step
-    pmc = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
-            pmc = json.load(f)
-    except OSError:
-        pass
-    pmc_ok = pmc is not None and (B, W, H, args.features, groups) == (64, 752, 480, 600, 1)
-    pmc_names = {"pyramid": ("pyrdown_kernel", 2), "mineig_localmax": ("mineig_localmax_kernel<false>", 1),
-                 "rectify": ("rectify_kernel<true>", 1)}
-
-    def traffic_of(stage):
-        if not pmc_ok or stage not in pmc_names:
-            return None
-        k, launches = pmc_names[stage]
-        if k not in pmc:
-            return None
-        return round((2.0 * pmc[k]["fetch_kb"] + pmc[k]["write_kb"]) * 1024.0 * launches)
-
-    dense = {k: v for k, v in stages.items() if v["alg_bytes"] > 0 and v["ms_total"] > 0}
-    kernels = []
-    for name, v in dense.items():
-        avg_ms = v["ms_total"] / ns
-        ach = v["alg_bytes"] / (avg_ms * 1e-3) / 1e9
-        kernels.append({"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic_of(name),
-                        "alg_bytes_per_launch": v["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)})
-    kernels.sort(key=lambda r: -r["avg_launch_ms"])
-    roofline = dict(kernels[0]) if kernels else None
-    # per step: the launches of all stream groups added up (they overlap on the GPU, so the sum
-    # exceeds ms_per_step when groups > 1)
-    stage_ms = {k: round(v["ms_total"] / ns * groups, 5) for k, v in stages.items()}
-    # the sparse (per-keypoint) kernels are VALU-issue / latency bound, not HBM bound: their share of
-    # the step and the end-to-end algorithmic traffic are reported for context
+    med = statistics.median(times)
+    res = {"value": round(pairs / med, 2), "unit": "stereo-pairs/s", "ms_per_step": round(1e3 * med / steps, 4),
+           "repeats": {"n": repeats, "steps_each": steps,
+                       "values": [round(pairs / t, 2) for t in times],
+                       "best": round(pairs / min(times), 2), "median": round(pairs / med, 2)},
+           "host_enqueue_ms_per_step": round(1e3 * statistics.median(enq) / steps, 4),
+           "check": {"keypoints_stream0": int(out0["n_keypoints"]), "tracked_stream0": int(out0["n_tracked"]),
+                     "new_corners_per_keyframe_stream0": (round(new_corners / kf_steps, 1) if kf_steps else None),
+                     "valid_stereo_stream0": int((out0["right_status"] == 0).sum()) if out0["is_keyframe"] else -1}}
     n_px = float(W) * H
-    alg_pair = 7.33 * n_px  # SURVEY.md §8d, lambda recomputed instead of materialised
-    e2e = {"alg_bytes_per_pair": round(alg_pair), "achieved_GBps": round(alg_pair * (pairs / elapsed) / 1e9, 2),
-           "frac_of_hbm_peak": round(alg_pair * (pairs / elapsed) / 8e12, 5)}
+    rate = pairs / med
+    res["end_to_end_traffic"] = {
+        "note": "SURVEY.md 8d algorithmic bytes per pair x pairs/s vs the 8 TB/s HBM peak; 7.33 N = lambda "
+                "recomputed (this design), 14.33 N = materialised fp32 lambda map",
+        "alg_bytes_per_pair_7p33N": round(7.33 * n_px), "achieved_GBps_7p33N": round(7.33 * n_px * rate / 1e9, 2),
+        "frac_of_hbm_peak_7p33N": round(7.33 * n_px * rate / 8e12, 5),
+        "alg_bytes_per_pair_14p33N": round(14.33 * n_px), "achieved_GBps_14p33N": round(14.33 * n_px * rate / 1e9, 2),
+        "frac_of_hbm_peak_14p33N": round(14.33 * n_px * rate / 8e12, 5)}
+    if prof:
+        stages = prof["stages"]
+        ns = max(prof["n_samples"], 1)          # launches recorded per stage (all stream groups)
+        g = max(prof["n_groups"], 1)            # launches per step
+        kernels = []
+        for name, v in stages.items():
+            if v["alg_bytes"] > 0 and v["ms_total"] > 0:
+                avg_ms = v["ms_total"] / ns
+                ach = v["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+                kernels.append({"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                                "traffic": pmc_traffic(pmc_leg, name),
+                                "alg_bytes_per_launch": v["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)})
+        kernels.sort(key=lambda r: -r["avg_launch_ms"])
+        res["roofline"] = dict(kernels[0]) if kernels else None
+        res["roofline_kernels"] = kernels
+        res["stage_ms_per_step_summed_over_groups"] = {k: round(v["ms_total"] / ns * g, 5) for k, v in stages.items()}
+        res["stream_groups"] = g
+    return res
 
+
+def main():
+    args = parse()
+    maybe_reexec_distributed(args)
+    import torch
+    import torch.distributed as dist
+
+    from kimera_vio_amd import frontend as F
+    from kimera_vio_amd import sharding
+    from kimera_vio_amd import workloads as WL
+
+    rank, local_rank, world = sharding.env_rank()
+    if args.dry_run:
+        return dry_run(args, dist, sharding, WL, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libkvfe has no CPU fallback")
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    pmc = load_pmc()
+
+    kw = dict(use_ransac=args.ransac, mono_2point=args.mono_2point, stereo_1point=args.stereo_1point,
+              batch=args.batch, features=args.features, klt_max_level=args.klt_max_level,
+              unique=args.unique_streams, ring=args.ring, width=args.width, height=args.height)
+    scaling = "weak"
+    if args.config == "c4":
+        # configs[3]: 8 EuRoC sequences, sequence q on rank q mod world (one per GPU at 8 GPUs); no collective
+        seqs = sharding.shard_streams(8, world, rank)
+        wl = WL.build("c4", mode=args.mode, rank=rank, sequences=seqs, **kw)
+        scaling = "strong"
+    else:
+        wl = WL.build(args.config, mode=args.mode, rank=rank, **kw)
+    stride = 0 if args.no_stage_events else args.stage_event_stride
+    overridden = any(v is not None for v in (args.batch, args.features, args.klt_max_level, args.width, args.height))
+    pmc_leg = None if (overridden or args.groups > 1) else pmc.get(f"{args.config}_{args.mode}")
+    main_leg = run_frontend_leg(torch, F, dist, sharding, wl, dev, world, args.steps, args.warmup, args.repeats,
+                                args.groups, stride, pmc_leg)
+    p = wl.params
+    B, W, H = wl.batch, wl.width, wl.height
+    src = (f"{wl.unique} seeded streams x {wl.ring} frames per GPU rendered through the calibrated stereo rig "
+           f"(synth.RigStream), replicated to {B} streams, ring walked ping-pong" if wl.source == "rig" else
+           f"{wl.unique} window(s) of {wl.ring} MicroEuroc frames per GPU (tests/golden/micro_euroc_f10_18.npz), "
+           f"walked ping-pong")
     result = {
-        "metric": "stereo-pairs/sec front-end (detect+track+match) @752x480",
-        "value": round(value, 2), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32+f32",
-        "data": f"synthetic ({U} seeded streams x {T} frames per GPU rendered through the calibrated stereo rig, "
-                f"replicated to {B} streams)",
-        "config": {"workload": f"batched {B} synthetic {W}x{H} stereo streams per GPU, {args.features} "
-                               f"features, ANMS binning on, {args.klt_max_level + 1}-level LK, "
-                               f"useRANSAC={args.ransac}, mode={args.mode}", "batch_per_gpu": B, "width": W, "height": H,
-                   "features": args.features, "mode": args.mode, "use_ransac": args.ransac,
-                   "stream_groups": groups,
+        "metric": f"stereo-pairs/sec front-end (detect+track+match) @{W}x{H}",
+        "value": main_leg["value"], "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"],
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/int32+f32",
+        "data": f"synthetic ({src})",
+        "config": {"workload": f"BASELINE {args.config}: batched {B} {W}x{H} stereo streams per GPU, "
+                               f"{p.detector.max_features_per_frame} features, ANMS binning on, "
+                               f"{p.tracker.klt_max_level + 1}-level LK, useRANSAC={p.use_ransac}, mode={args.mode}",
+                   "batch_per_gpu": B, "width": W, "height": H, "features": p.detector.max_features_per_frame,
+                   "mode": args.mode, "use_ransac": p.use_ransac, "stream_groups": main_leg.get("stream_groups", 1),
                    "parallelism": f"streams x{world}"},
-        "roofline": roofline,
-        "roofline_kernels": kernels,
-        "end_to_end_traffic": e2e,
-        "stage_ms_per_step_summed_over_groups": stage_ms,
-        "pcie_inclusive": pcie,
-        "host_enqueue_ms_per_step": round(1e3 * (t_enq - t0) / args.steps, 4),
-        "check": {"keypoints_stream0": int(out0["n_keypoints"]), "valid_stereo_stream0": n_valid},
+        "value_is": f"median of {args.repeats} timed regions of exactly {args.steps} steps each",
     }
+    for k in ("repeats", "roofline", "roofline_kernels", "end_to_end_traffic",
+              "stage_ms_per_step_summed_over_groups", "host_enqueue_ms_per_step", "check"):
+        if k in main_leg:
+            result[k] = main_leg[k]
 
-    if rank == 0 and world == 1 and not args.no_single_stream:
-        result["single_stream"] = single_stream(F, P, synth, L, R, p, torch, dev, args)
-    if rank == 0 and world == 1 and not args.no_dense:
-        result["dense_stereo"] = dense_stereo(F, P, synth, L, R, p, dev, args)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(P, synth, L, R, p, args)
+    solo = rank == 0 and world == 1
+    if solo and args.config == "c3" and args.mode == "kf" and "nominal" in args.legs:
+        import dataclasses
+        leg = run_frontend_leg(torch, F, dist, sharding, dataclasses.replace(wl, mode="nominal"), dev, 1, args.steps,
+                               args.warmup, args.repeats, args.groups, stride, pmc.get("c3_nominal"))
+        leg["workload"] = ("same streams, reference cadence: track every frame, detect + rectify + match only on "
+                           "keyframes (every min_intra_keyframe_time = 0.2 s = 4th frame)")
+        result["nominal"] = leg
+    if solo and "single_stream" in args.legs:
+        w2 = WL.build("c2", mode="kf", use_ransac=args.ransac)
+        leg = run_frontend_leg(torch, F, dist, sharding, w2, dev, 1, 200, 20, args.repeats, 0, 0)
+        leg["workload"] = ("BASELINE configs[1]: single EuRoC 752x480 stream (MicroEuroc frames), 300 features, "
+                           "3-level LK, mode=kf; latency-bound: one launch chain per pair")
+        leg["ms_per_pair"] = leg["ms_per_step"]
+        result["single_stream"] = leg
+    if solo and "c5" in args.legs and args.config != "c5":
+        w5 = WL.build("c5", mode="kf", use_ransac=args.ransac)
+        leg = run_frontend_leg(torch, F, dist, sharding, w5, dev, 1, max(8, args.steps // 2), args.warmup, args.repeats,
+                               0, stride, pmc.get("c5_kf"))
+        leg["workload"] = (f"BASELINE configs[4]: batched {w5.batch} {w5.width}x{w5.height} streams ({w5.unique} "
+                           f"unique), 1000 features, 4-level LK, useRANSAC={args.ransac}, mode=kf")
+        result["c5"] = leg
+    if solo and "dense" in args.legs:
+        result["dense_stereo"] = dense_stereo(F, WL, 752, 480, dev, pmc.get("dense"))
+    if solo and "dense_c5" in args.legs:
+        result["dense_stereo_c5"] = dense_stereo(F, WL, 1280, 720, dev, pmc.get("dense_c5"))
+    if solo and "pcie" in args.legs and args.config == "c3":
+        result["pcie_inclusive"] = pcie_inclusive(F, wl)
+    if solo and "cpu" in args.legs:
+        result["cpu_baseline"] = cpu_baseline(wl, args)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 
 
-def single_stream(F, P, synth, L, R, p, torch, dev, args):
-    """BASELINE config[1]: one stream, 300 features, 3-level LK (latency-bound: one launch chain
-    per pair)."""
-    import copy
-    p1 = copy.deepcopy(p)
-    p1.detector.max_features_per_frame = 300
-    st = synth.RigStream(L, R, seed=4242, rect_R1=np.array(F.compute_rectification(L, R).R1).reshape(3, 3))
-    T = 6
-    fr = [st.frame(t) for t in range(T)]
-    dl = torch.from_numpy(np.stack([f[0] for f in fr])[:, None]).to(dev)
-    dr = torch.from_numpy(np.stack([f[1] for f in fr])[:, None]).to(dev)
-    ctx = F.Context(L, R, p1, batch=1, device=dev.index)
-    steps, warm = 200, 20
-    plan = []
-    kf_t = 0
-    for i in range(steps + warm):
-        t = ping_pong(i, T)
-        plan.append((t, ctx.make_inputs([i * 50_000_000], [synth.rig_keyframe_R_cur(st, kf_t, t)], [1])))
-        kf_t = t
-    for i in range(warm):
-        ctx.step_device(dl[plan[i][0]].data_ptr(), dr[plan[i][0]].data_ptr(), plan[i][1])
+def dry_run(args, dist, sharding, WL, rank, world):
+    """--dry-run: the N-rank launch path without a GPU (gloo).  No front-end call is made."""
+    import torch
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        dist.init_process_group("gloo")
+    if args.config == "c4":
+        seqs = sharding.shard_streams(8, world, rank)
+        wl = WL.build("c4", mode=args.mode, rank=rank, sequences=seqs, rect_R1=np.eye(3))
+    else:
+        seqs = None
+        wl = WL.build(args.config, mode=args.mode, rank=rank, batch=args.batch or 2, unique=2, ring=2, width=64,
+                      height=48, rect_R1=np.eye(3))
+    sharding.barrier(dist, world)
+    el, pairs = sharding.reduce_timing(dist, world, 1.0 + rank, wl.batch * args.steps)
+    mine = {"rank": rank, "batch": wl.batch, "sequences": seqs, "first_pixel_sum": int(wl.lefts[0].sum())}
+    gathered = [None] * world
+    if world > 1:
+        dist.all_gather_object(gathered, mine)
+    else:
+        gathered = [mine]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed_max": el, "pairs_sum": pairs,
+                          "scaling": "strong" if args.config == "c4" else "weak", "ranks": gathered}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def pcie_inclusive(F, wl):
+    """PCIe-inclusive rates (host buffers handed over at the boundary): reported, never `value`.
+      staged  : the data provider writes into the context's pinned slots, the upload runs on a copy stream and
+                overlaps the previous step (kvfe_frontend_step_staged)
+      pageable: kvfe_frontend_step_host from ordinary host memory, copies on the compute stream"""
+    B = wl.batch
+    lefts, rights = wl.replicated()
+    hl = np.ascontiguousarray(lefts[:3])
+    hr = np.ascontiguousarray(rights[:3])
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=B)
+    plan = [wl.batch_inputs(ctx, st) for st in wl.plan(20)]
+    n_h = 12
+    for sl in range(3):  # "decoded" frames sit in the pinned slots before the clock starts
+        a, b = ctx.staging_buffers(sl)
+        a[:] = hl[sl]
+        b[:] = hr[sl]
+    for i in range(3):
+        ctx.step_staged(i % 3, plan[i])
     ctx.synchronize()
-    t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        ctx.step_device(dl[plan[i][0]].data_ptr(), dr[plan[i][0]].data_ptr(), plan[i][1])
+    th = time.perf_counter()
+    for i in range(3, 3 + n_h):
+        ctx.step_staged(i % 3, plan[i])
     ctx.synchronize()
-    el = time.perf_counter() - t0
-    n = ctx.get_output(0)["n_keypoints"]
+    staged = B * n_h / (time.perf_counter() - th)
+    ctx.reset()
+    for i in range(2):
+        ctx.step_host(hl[i % 2], hr[i % 2], plan[i])
+    ctx.synchronize()
+    th = time.perf_counter()
+    for i in range(2, 8):
+        ctx.step_host(hl[i % 2], hr[i % 2], plan[i])
+    ctx.synchronize()
+    pageable = B * 6 / (time.perf_counter() - th)
     ctx.close()
-    return {"workload": "single synthetic 752x480 stream, 300 features, 3-level LK, mode=kf",
-            "value": round(steps / el, 2), "unit": "stereo-pairs/s", "ms_per_pair": round(1e3 * el / steps, 4),
-            "keypoints": int(n)}
+    return {"value": round(staged, 2), "unit": "stereo-pairs/s",
+            "note": "kvfe_frontend_step_staged: pinned staging slots, H2D upload of every frame inside the "
+                    "timed region on a copy stream overlapping the previous step",
+            "pageable_value": round(pageable, 2)}
 
 
-def dense_stereo(F, P, synth, L, R, p, dev, args):
+def dense_stereo(F, WL, W, H, dev, pmc_leg):
     """SURVEY.md §8 a29 / BASELINE config[4] "dense stereo row": StereoMatcher::denseStereoReconstruction
     (cv::StereoSGBM MODE_HH with the reference's DenseStereoParams) on 8 rectified pairs per call.
     Time = HIP events around the kernel sequence inside libkvfe (the component call takes host
     buffers; its H2D / D2H copies are outside the events)."""
     from kimera_vio_amd import _abi as abi
-    ctx = F.Context(L, R, p, batch=1, device=dev.index)
     n = 8
-    st = [synth.RigStream(L, R, seed=900 + i) for i in range(2)]
+    wl = WL.build("c5", batch=2, unique=2, ring=n // 2, width=W, height=H, seed_base=900)
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=1, device=dev.index)
     pairs = []
     for i in range(n):
-        l, r = st[i % 2].frame(i // 2)
+        l, r = wl.lefts[i // 2, i % 2], wl.rights[i // 2, i % 2]
         pairs.append((ctx.undistort_rectify_image(0, l), ctx.undistort_rectify_image(1, r)))
     dp = abi.dense_stereo_params_default()
     lefts, rights = [a for a, _ in pairs], [b for _, b in pairs]
     ctx.dense_stereo_reconstruction(lefts, rights, dp)
     ctx.dense_profile_read()
-    reps = 5
-    for _ in range(reps):
+    vals = []
+    for _ in range(5):
         disp = ctx.dense_stereo_reconstruction(lefts, rights, dp)
-    ms, cnt = ctx.dense_profile_read()
+        ms, cnt = ctx.dense_profile_read()
+        vals.append(ms / cnt)
     ctx.close()
-    W, H, D = args.width, args.height, dp.num_disparities
+    ms_pair = statistics.median(vals)
+    D = dp.num_disparities
     w1 = W - (dp.min_disparity + D)
     vol = H * w1 * D * 2.0                      # one int16 cost volume
     npx = float(W) * H
@@ -360,74 +438,67 @@ def dense_stereo(F, P, synth, L, R, p, dev, args):
     agg_bytes = 8 * vol + vol + 7 * 2 * vol
     alg = (2 * npx + 16 * npx) + (16 * npx + vol) + 2 * vol + 2 * vol + agg_bytes + (vol + 2 * npx) + 24 * npx
     traffic = None
-    try:   # HBM-side bytes of the same kernels from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
-            pmc = json.load(f)
-        tb = sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 for k, v in pmc.items()
+    if pmc_leg:   # HBM-side bytes of the same kernels from the committed rocprofv3 PMC passes
+        tb = sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 for k, v in pmc_leg.items()
                  if k.startswith(("dense_", "speckle_")))
-        if tb > 0 and (W, H) == (752, 480):
-            traffic = round(tb / n)
-    except OSError:
-        pass
-    ach = alg / (ms / cnt * 1e-3) / 1e9
+        traffic = round(tb / n) if tb > 0 else None
+    ach = alg / (ms_pair * 1e-3) / 1e9
     valid = float(np.mean(disp[0] != (dp.min_disparity - 1) * 16))
     return {"workload": f"cv::StereoSGBM MODE_HH, block {dp.sad_window_size}, {D} disparities, {W}x{H}, "
                         f"{n} rectified pairs per call",
-            "value": round(cnt / (ms * 1e-3), 2), "unit": "stereo-pairs/s", "ms_per_pair": round(ms / cnt, 4),
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "value": round(1e3 / ms_pair, 2), "unit": "stereo-pairs/s", "ms_per_pair": round(ms_pair, 4),
+            "ms_per_pair_min": round(min(vals), 4),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "alg_bytes_per_pair": round(alg), "alg_bytes_per_pair_aggregation": round(agg_bytes),
                          "note": "whole kernel sequence of one pair (HIP events inside libkvfe); traffic = PMC bytes "
                                  "per pair of the dense_* / speckle_* kernels"},
             "valid_fraction_pair0": round(valid, 3)}
 
 
-def cpu_baseline(P, synth, L, R, p, args):
+def cpu_baseline(wl, args):
     """The CPU oracle (OpenCV-faithful scalar restatement, 1 thread = the reference's one front-end
-    thread) on a bounded sample of the same workload: one stream, same parameters and mode."""
+    thread, Pipeline.cpp:331) on a bounded sample of the same workload: one stream, same parameters and mode."""
     import oracle_lib as O  # checker / baseline only
     from kimera_vio_amd import _abi as abi
     n = args.cpu_baseline_frames
-    from kimera_vio_amd import frontend as F
-    st = synth.RigStream(L, R, seed=100, rect_R1=np.array(F.compute_rectification(L, R).R1).reshape(3, 3))
-    T = args.ring
-    frames = [st.frame(t) for t in range(T)]
-    lefts = np.stack([frames[ping_pong(i, T)][0] for i in range(n)])
-    rights = np.stack([frames[ping_pong(i, T)][1] for i in range(n)])
+    plan = wl.plan(n)
+    lefts = np.stack([wl.lefts[st[0], 0] for st in plan])
+    rights = np.stack([wl.rights[st[0], 0] for st in plan])
     inputs = []
-    kf_t = 0
-    last_kf = 0
-    for i in range(n):
-        t = ping_pong(i, T)
+    for (t, ts, Rs, force) in plan:
         fi = abi.FrameInput()
-        fi.timestamp_ns = i * 50_000_000
-        Rm = synth.rig_keyframe_R_cur(st, kf_t, t).reshape(9)
+        fi.timestamp_ns = ts
+        Rm = np.asarray(Rs[0], np.float64).reshape(9)
         for k in range(9):
             fi.keyframe_R_cur_frame[k] = float(Rm[k])
-        fi.force_keyframe = 1 if args.mode == "kf" else 0
+        fi.force_keyframe = force
         inputs.append(fi)
-        if args.mode == "kf" or i == 0 or (i - last_kf) * 50_000_000 >= p.min_intra_keyframe_time_ns:
-            kf_t, last_kf = t, i
-    fe = O.Frontend(L, R, p)
+    fe = O.Frontend(wl.left, wl.right, wl.params)
     secs = fe.time_sequence(lefts, rights, inputs)
+    p = wl.params
     out = {"value": round(n / secs, 3), "unit": "stereo-pairs/s", "cores": 1, "kind": "port",
-           "sample": f"{n} consecutive stereo pairs of one synthetic {args.width}x{args.height} stream, "
-                     f"{args.features} features, mode={args.mode}, {secs:.1f} s on one host core "
+           "sample": f"{n} consecutive stereo pairs of one {wl.width}x{wl.height} stream of the `value` workload, "
+                     f"{p.detector.max_features_per_frame} features, mode={wl.mode}, {secs:.1f} s on one host core "
                      f"(scalar OpenCV-faithful restatement, no SIMD/IPP; host has {os.cpu_count()} cores)"}
     # SURVEY.md 8d (ii): independent streams on the host's cores (one single-threaded front-end per core, the
-    # many-sequence mode on the CPU), bounded to a few seconds
+    # many-sequence mode on the CPU), bounded to a few seconds; best of 3
     try:
         import multiprocessing as mp
         C_ = max(1, min(os.cpu_count() or 1, 64))
-        m = max(20, min(n, 80))
-        ctx = mp.get_context("fork")
-        with ctx.Pool(C_, initializer=_cpu_worker_init, initargs=(L, R, p, lefts[:m], rights[:m], inputs[:m])) as pool:
+        m = max(20, min(n, 60))
+        mctx = mp.get_context("fork")
+        with mctx.Pool(C_, initializer=_cpu_worker_init,
+                       initargs=(wl.left, wl.right, p, lefts[:m], rights[:m], inputs[:m])) as pool:
             pool.map(_cpu_worker_run, range(C_))            # warm: library load, first-touch
-            t0 = time.perf_counter()
-            pool.map(_cpu_worker_run, range(C_))
-            wall = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(C_ * m / wall, 2), "unit": "stereo-pairs/s", "cores": C_,
-                            "sample": f"{C_} processes x {m} pairs of the same stream, {wall:.1f} s wall"}
+            walls = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pool.map(_cpu_worker_run, range(C_))
+                walls.append(time.perf_counter() - t0)
+        out["all_cores"] = {"value": round(C_ * m / min(walls), 2), "unit": "stereo-pairs/s", "cores": C_,
+                            "sample": f"{C_} processes x {m} pairs of the same stream, best of 3 "
+                                      f"({min(walls):.1f} s wall; all: {[round(w, 1) for w in walls]})"}
     except Exception as e:  # the single-core figure above is the contract; this one is informative
         out["all_cores"] = {"error": repr(e)}
     return out

@@ -12,6 +12,7 @@
 // lambda > maxVal*quality afterwards on the compacted list.  HBM traffic per image: one read of
 // the image (+ the optional user mask); the detection mask "255 minus filled discs around the
 // tracked keypoints" is evaluated analytically from the keypoint list (exact cv::circle spans).
+#include <mutex>
 #include "kvfe_dev.hpp"
 
 #include <utility>
@@ -995,11 +996,19 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
 void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const StreamState& S,
                    const DetectScratch& D, int fixed_need, hipStream_t st) {
   const size_t lds = sizeof(unsigned long long) * LDS_SORT_CAP + sizeof(int) * (MAX_CELLS + 1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: apply it once on every device a
+  // context of this process launches on (contexts may live on different GPUs / threads, kvfe.h)
+  static std::mutex mu;
+  static unsigned long long done_mask[4] = {0, 0, 0, 0};   // 256 devices
+  int dev = 0;
+  hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 256 && !((done_mask[dev >> 6] >> (dev & 63)) & 1ull)) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done_mask[dev >> 6] |= 1ull << (dev & 63);
+    }
   }
   hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need);
 }

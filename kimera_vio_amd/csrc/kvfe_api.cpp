@@ -157,6 +157,23 @@ namespace {
     }                                                                                      \
   } while (0)
 
+// Every public entry point runs on the context's device whatever the calling thread's current device is
+// (distinct contexts may live on different GPUs / threads, kvfe.h), and leaves the caller's device as it was.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const kvfe_ctx* c) {
+    if (c) enter(c->cfg.device);
+  }
+  explicit DeviceGuard(int device) { enter(device); }
+  void enter(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) hipSetDevice(prev);
+  }
+};
+
 template <typename T>
 kvfe_status dalloc(kvfe_ctx* c, T** p, size_t n, bool zero = true) {
   void* q = nullptr;
@@ -425,6 +442,8 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     return fail("unknown non_max_suppression_type", KVFE_ERR_INVALID_ARG);
   if (d.min_distance < 0 || d.min_distance > MAX_RADIUS)
     return fail("min_distance out of range [0,127]", KVFE_ERR_INVALID_ARG);
+  if (d.max_nr_keypoints_before_anms < 0)
+    return fail("max_nr_keypoints_before_anms < 0", KVFE_ERR_INVALID_ARG);
   if (d.max_nr_keypoints_before_anms > ACAP)
     return fail("max_nr_keypoints_before_anms > 8192", KVFE_ERR_UNSUPPORTED);
   if (d.nr_horizontal_bins * d.nr_vertical_bins > KVFE_MAX_BINS || d.nr_horizontal_bins < 1 ||
@@ -879,9 +898,11 @@ kvfe_status step_groups(kvfe_ctx* c, const unsigned char* left, const unsigned c
     if (G > 1 && !no_token && pred->ev_tracked_valid) HIPCHK(c, hipStreamWaitEvent(ch->stream, pred->ev_tracked, 0));
     const unsigned char* l = left + (size_t)ch->s0 * img_stride;
     const unsigned char* r = right + (size_t)ch->s0 * img_stride;
+    // through the child's own entry point, so that whatever the entry point does before do_step (uploads,
+    // cv::equalizeHist into the ctx-owned slots when equalizeImage is on) also happens per group
     kvfe_status s = host_input
                         ? kvfe_frontend_step_host(ch, l, r, row_stride, img_stride, inputs + ch->s0)
-                        : do_step(ch, l, r, row_stride, img_stride, inputs + ch->s0);
+                        : kvfe_frontend_step_device(ch, l, r, row_stride, img_stride, inputs + ch->s0);
     if (s != KVFE_OK) {
       c->last_error = ch->last_error;
       return s;
@@ -1069,7 +1090,9 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
     std::fprintf(stderr, "kvfe_create: no HIP device (libkvfe has no CPU fallback)\n");
     return KVFE_ERR_NO_DEVICE;
   }
-  if (hipSetDevice(cfg->device) != hipSuccess) return KVFE_ERR_NO_DEVICE;
+  DeviceGuard _dev(cfg->device);   // the caller's current device is restored on return
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) return KVFE_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return KVFE_ERR_NO_DEVICE;
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -1090,7 +1113,10 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
   kvfe_status s = create_one(cfg, nullptr, 0, cfg->batch, groups == 1, &c);
   if (s != KVFE_OK) return s;
   if (groups > 1) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // shared tables are complete
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {  // shared tables are complete
+      kvfe_destroy(c);
+      return KVFE_ERR_HIP;
+    }
     const int base = cfg->batch / groups, rem = cfg->batch % groups;
     int s0 = 0;
     for (int g = 0; g < groups && s == KVFE_OK; g++) {
@@ -1110,6 +1136,7 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
 }
 
 void kvfe_destroy(kvfe_ctx* c) {
+  DeviceGuard _dev(c);
   if (!c) return;
   for (kvfe_ctx* ch : c->children) kvfe_destroy(ch);
   c->children.clear();
@@ -1143,12 +1170,14 @@ void kvfe_destroy(kvfe_ctx* c) {
 }
 
 kvfe_status kvfe_get_rectification(const kvfe_ctx* c, kvfe_rectification* out) {
+  DeviceGuard _dev(c);
   if (!c || !out) return KVFE_ERR_INVALID_ARG;
   *out = c->rect;
   return KVFE_OK;
 }
 
 kvfe_status kvfe_synchronize(kvfe_ctx* c) {
+  DeviceGuard _dev(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children) TRY(kvfe_synchronize(ch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1159,6 +1188,7 @@ kvfe_status kvfe_synchronize(kvfe_ctx* c) {
 // ---- component level ---------------------------------------------------------------------------
 kvfe_status kvfe_undistort_rectify_image(kvfe_ctx* c, int32_t cam, const uint8_t* src,
                                          size_t src_stride, uint8_t* dst, size_t dst_stride) {
+  DeviceGuard _dev(c);
   if (!c || !src || !dst || cam < 0 || cam > 1) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
   Buffers& b = c->comp;
@@ -1174,6 +1204,7 @@ kvfe_status kvfe_undistort_rectify_image(kvfe_ctx* c, int32_t cam, const uint8_t
 
 kvfe_status kvfe_equalize_hist(kvfe_ctx* c, const uint8_t* src, size_t src_stride, uint8_t* dst,
                                size_t dst_stride) {
+  DeviceGuard _dev(c);
   if (!c || !src || !dst) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
   Buffers& b = c->comp;
@@ -1188,6 +1219,7 @@ kvfe_status kvfe_equalize_hist(kvfe_ctx* c, const uint8_t* src, size_t src_strid
 
 static kvfe_status undistort_common(kvfe_ctx* c, int cam, const float* xy, int n, int useR, int useP,
                                     float* out_xy, double* out_versors) {
+  DeviceGuard _dev(c);
   if (!c || !xy || n < 0 || cam < 0 || cam > 1) return KVFE_ERR_INVALID_ARG;
   if (n == 0) return KVFE_OK;
   TRY(ensure_comp(c));
@@ -1208,12 +1240,14 @@ static kvfe_status undistort_common(kvfe_ctx* c, int cam, const float* xy, int n
 
 kvfe_status kvfe_undistort_rectify_keypoints(kvfe_ctx* c, int32_t cam, const float* xy, int32_t n,
                                              int32_t use_R, int32_t use_P, float* out_xy) {
+  DeviceGuard _dev(c);
   if (!out_xy) return KVFE_ERR_INVALID_ARG;
   return undistort_common(c, cam, xy, n, use_R, use_P, out_xy, nullptr);
 }
 
 kvfe_status kvfe_get_bearing_vectors(kvfe_ctx* c, int32_t cam, const float* xy, int32_t n,
                                      double* out_versors) {
+  DeviceGuard _dev(c);
   if (!out_versors) return KVFE_ERR_INVALID_ARG;
   return undistort_common(c, cam, xy, n, 1, 0, nullptr, out_versors);
 }
@@ -1222,6 +1256,7 @@ static kvfe_status detect_common(kvfe_ctx* c, const uint8_t* img, size_t stride,
                                  const uint8_t* mask, size_t mask_stride, const float* tracked_xy,
                                  int n_tracked, int need, bool raw, float* out_xy, int capacity,
                                  int* out_n) {
+  DeviceGuard _dev(c);
   if (!c || !img || !out_xy || !out_n || n_tracked < 0) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
   Buffers& b = c->comp;
@@ -1266,6 +1301,7 @@ static kvfe_status detect_common(kvfe_ctx* c, const uint8_t* img, size_t stride,
 kvfe_status kvfe_raw_feature_detection(kvfe_ctx* c, const uint8_t* img, size_t stride,
                                        const uint8_t* mask, size_t mask_stride, float* out_xy,
                                        int32_t capacity, int32_t* out_n) {
+  DeviceGuard _dev(c);
   return detect_common(c, img, stride, mask, mask_stride, nullptr, 0, 0, true, out_xy, capacity, out_n);
 }
 
@@ -1273,6 +1309,7 @@ kvfe_status kvfe_feature_detection(kvfe_ctx* c, const uint8_t* img, size_t strid
                                    const float* tracked_xy, int32_t n_tracked,
                                    int32_t need_n_corners, float* out_xy, int32_t capacity,
                                    int32_t* out_n) {
+  DeviceGuard _dev(c);
   if (n_tracked > 0 && !tracked_xy) return KVFE_ERR_INVALID_ARG;
   return detect_common(c, img, stride, nullptr, 0, tracked_xy, n_tracked, need_n_corners, false,
                        out_xy, capacity, out_n);
@@ -1280,6 +1317,7 @@ kvfe_status kvfe_feature_detection(kvfe_ctx* c, const uint8_t* img, size_t strid
 
 kvfe_status kvfe_corner_subpix(kvfe_ctx* c, const uint8_t* img, size_t stride, float* xy, int32_t n,
                                int32_t half_win, int32_t zero_zone, int32_t max_iters, double eps) {
+  DeviceGuard _dev(c);
   if (!c || !img || !xy || n < 0 || half_win < 1 || half_win > 15) return KVFE_ERR_INVALID_ARG;
   if (n == 0) return KVFE_OK;
   TRY(ensure_comp(c));
@@ -1304,6 +1342,7 @@ kvfe_status kvfe_calc_optical_flow_pyr_lk(kvfe_ctx* c, const uint8_t* prev_img,
                                           const uint8_t* cur_img, size_t stride,
                                           const float* prev_xy, float* cur_xy, int32_t n,
                                           uint8_t* status, float* err) {
+  DeviceGuard _dev(c);
   if (!c || !prev_img || !cur_img || !prev_xy || !cur_xy || !status || n < 0) return KVFE_ERR_INVALID_ARG;
   if (n == 0) return KVFE_OK;
   TRY(ensure_comp(c));
@@ -1329,6 +1368,7 @@ kvfe_status kvfe_calc_optical_flow_pyr_lk(kvfe_ctx* c, const uint8_t* prev_img,
 
 kvfe_status kvfe_predict_sparse_flow(kvfe_ctx* c, const float* prev_xy, int32_t n,
                                      const double ref_R_cur[9], float* out_xy) {
+  DeviceGuard _dev(c);
   if (!c || !prev_xy || !ref_R_cur || !out_xy || n < 0) return KVFE_ERR_INVALID_ARG;
   if (n == 0) return KVFE_OK;
   TRY(ensure_comp(c));
@@ -1349,6 +1389,7 @@ kvfe_status kvfe_get_right_keypoints_rectified(kvfe_ctx* c, const uint8_t* left_
                                                const uint8_t* left_status, int32_t n,
                                                float* right_rect_xy, uint8_t* right_status,
                                                double* score) {
+  DeviceGuard _dev(c);
   if (!c || !left_rect || !right_rect || !left_rect_xy || !left_status || !right_rect_xy ||
       !right_status || n < 0)
     return KVFE_ERR_INVALID_ARG;
@@ -1375,6 +1416,7 @@ kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_i
                                               const uint8_t* right_img, size_t stride,
                                               const float* left_xy, int32_t n,
                                               kvfe_stereo_output* out) {
+  DeviceGuard _dev(c);
   if (!c || !left_img || !right_img || !left_xy || !out || n < 0) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
   Buffers& b = c->comp;
@@ -1415,6 +1457,7 @@ kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_i
 
 static kvfe_status ransac_download(kvfe_ctx* c, Buffers& b, int32_t* inliers, kvfe_ransac_output* out,
                                    bool with_info) {
+  DeviceGuard _dev(c);
   hipStream_t st = c->stream;
   int status = 0, cnt[6] = {0};
   HIPCHK(c, hipMemcpyAsync(&status, b.ss.trk_status, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1438,6 +1481,7 @@ kvfe_status kvfe_outlier_rejection_2d2d_given_rotation(kvfe_ctx* c, const double
                                                        const double* f_cur, int32_t n,
                                                        const double R_ref_cur[9], int32_t* inliers,
                                                        kvfe_ransac_output* out) {
+  DeviceGuard _dev(c);
   // CHECK_GT(f_ref.size(), 0) (Tracker.cpp:243)
   if (!c || !f_ref || !f_cur || !R_ref_cur || !out || n <= 0) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
@@ -1458,6 +1502,7 @@ kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
     const double* ref_points_3d, const float* cur_left_rect_xy, const float* cur_right_rect_x,
     const double* cur_points_3d, int32_t n, const double R_ref_cur[9], int32_t* inliers,
     kvfe_ransac_output* out) {
+  DeviceGuard _dev(c);
   if (!c || !R_ref_cur || !out || n < 0) return KVFE_ERR_INVALID_ARG;
   if (n > 0 && (!ref_left_rect_xy || !ref_right_rect_x || !ref_points_3d || !cur_left_rect_xy ||
                 !cur_right_rect_x || !cur_points_3d))
@@ -1488,6 +1533,7 @@ kvfe_status kvfe_outlier_rejection_3d3d_given_rotation(
 
 kvfe_status kvfe_outlier_rejection_2d2d(kvfe_ctx* c, const double* f_ref, const double* f_cur, int32_t n,
                                         int32_t* inliers, kvfe_ransac_output* out) {
+  DeviceGuard _dev(c);
   // CHECK_GT(f_ref.size(), 0) (Tracker.cpp:243)
   if (!c || !f_ref || !f_cur || !out || n <= 0) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
@@ -1504,6 +1550,7 @@ kvfe_status kvfe_outlier_rejection_2d2d(kvfe_ctx* c, const double* f_ref, const 
 
 kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* c, const double* ref_points_3d, const double* cur_points_3d,
                                         int32_t n, int32_t* inliers, kvfe_ransac_output* out) {
+  DeviceGuard _dev(c);
   if (!c || !out || n < 0 || (n > 0 && (!ref_points_3d || !cur_points_3d))) return KVFE_ERR_INVALID_ARG;
   TRY(ensure_comp(c));
   Buffers& b = c->comp;
@@ -1523,6 +1570,7 @@ kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* c, const double* ref_points_3d
 kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const void* right_dev,
                                       size_t row_stride, size_t image_stride,
                                       const kvfe_frame_input* inputs) {
+  DeviceGuard _dev(c);
   if (!c || !left_dev || !inputs) return KVFE_ERR_INVALID_ARG;
   if (!right_dev) {
     if (!c->P.mono || c->P.rgbd) return KVFE_ERR_INVALID_ARG;
@@ -1555,6 +1603,7 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
 kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint8_t* right,
                                     size_t row_stride, size_t image_stride,
                                     const kvfe_frame_input* inputs) {
+  DeviceGuard _dev(c);
   if (!c || !left || !inputs) return KVFE_ERR_INVALID_ARG;
   if (!right) {
     if (!c->P.mono || c->P.rgbd) return KVFE_ERR_INVALID_ARG;
@@ -1606,6 +1655,7 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
 
 // ---- staged input -----------------------------------------------------------------
 static kvfe_status ensure_staging(kvfe_ctx* c) {
+  DeviceGuard _dev(c);
   if (c->copy_stream) return KVFE_OK;
   const size_t bytes = 2 * (size_t)c->P.W * c->P.H * c->P.B;
   HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -1623,6 +1673,7 @@ static kvfe_status ensure_staging(kvfe_ctx* c) {
 }
 
 kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* c, int32_t slot, uint8_t** left, uint8_t** right) {
+  DeviceGuard _dev(c);
   if (!c || !left || !right || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;  // staged input drives one stream group
   if (c->P.rgbd) return KVFE_ERR_UNSUPPORTED;             // (depth images: use the host / device step)
@@ -1633,6 +1684,7 @@ kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* c, int32_t slot, uint8_t** le
 }
 
 kvfe_status kvfe_frontend_staging_wait(kvfe_ctx* c, int32_t slot) {
+  DeviceGuard _dev(c);
   if (!c || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
   if (c->stage_pending[slot]) {
     HIPCHK(c, hipEventSynchronize(c->stage_copied[slot]));
@@ -1642,6 +1694,7 @@ kvfe_status kvfe_frontend_staging_wait(kvfe_ctx* c, int32_t slot) {
 }
 
 kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_frame_input* inputs) {
+  DeviceGuard _dev(c);
   if (!c || !inputs || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;
   TRY(ensure_staging(c));
@@ -1684,6 +1737,7 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
 }
 
 kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
+  DeviceGuard _dev(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) {
     for (kvfe_ctx* ch : c->children) {
@@ -1707,6 +1761,8 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(st));
   c->prev_left = nullptr;
   c->img_step = 0;
+  c->pyr_cur = 0;
+  c->last_step_staged = false;
   for (int i = 0; i < 4; i++) c->step_done_valid[i] = false;
   c->role_k = 0;
   c->role_km1 = 1;
@@ -1715,7 +1771,8 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
 }
 
 kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {
-  if (!c || !out || s < 0 || s >= c->P.B) return KVFE_ERR_INVALID_ARG;
+  DeviceGuard _dev(c);
+  if (!c || !out || s < 0 || s >= c->P.B || out->capacity < 0) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children)
     if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
       const kvfe_status r = kvfe_frontend_get_output(ch, s - ch->s0, out);
@@ -1895,6 +1952,7 @@ static kvfe_status dense_params(kvfe_ctx* c, const kvfe_dense_stereo_params& dp,
 }
 
 static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
+  DeviceGuard _dev(c);
   DenseBuffers& b = c->dense;
   const size_t ve = P.width1 > 0 ? dense_volume_elems(P) : 1;
   if (b.cap_pairs >= pairs && b.vol_elems == ve) return KVFE_OK;
@@ -1930,6 +1988,7 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
                                              int32_t n_pairs, const uint8_t* const* left_rect,
                                              const uint8_t* const* right_rect, size_t stride,
                                              int16_t* const* disparity, size_t dstride) {
+  DeviceGuard _dev(c);
   if (!c || !params || n_pairs < 0 || (n_pairs > 0 && (!left_rect || !right_rect || !disparity)))
     return KVFE_ERR_INVALID_ARG;
   DenseParams P;
@@ -1985,6 +2044,7 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
 // debug / test hook: the cost volumes of the FIRST pair of the last kvfe_dense_stereo_reconstruction
 // call, [H][width1][D] int16: which = 0 sum of the eight path costs (u16, saturated at 65535), 2 = C(p,d)
 kvfe_status kvfe_dense_debug_volume(kvfe_ctx* c, int32_t which, int16_t* out, size_t elems) {
+  DeviceGuard _dev(c);
   if (!c || !out || which < 0 || which > 2 || !c->dense.vol[which] || elems > c->dense.vol_elems)
     return KVFE_ERR_INVALID_ARG;
   HIPCHK(c, hipMemcpy(out, c->dense.vol[which], elems * sizeof(int16_t), hipMemcpyDeviceToHost));
@@ -1992,6 +2052,7 @@ kvfe_status kvfe_dense_debug_volume(kvfe_ctx* c, int32_t which, int16_t* out, si
 }
 
 kvfe_status kvfe_dense_profile_read(kvfe_ctx* c, double* kernel_ms, int64_t* pairs) {
+  DeviceGuard _dev(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   if (kernel_ms) *kernel_ms = c->dense_ms;
   if (pairs) *pairs = c->dense_pairs;
@@ -2001,6 +2062,7 @@ kvfe_status kvfe_dense_profile_read(kvfe_ctx* c, double* kernel_ms, int64_t* pai
 }
 
 kvfe_status kvfe_backproject_disparity_to_3d(kvfe_ctx* c, const float* disparity, size_t stride, float* xyz) {
+  DeviceGuard _dev(c);
   if (!c || !disparity || !xyz || stride < (size_t)c->P.W) return KVFE_ERR_INVALID_ARG;
   // StereoCamera::backProjectDisparityTo3D CHECKs Q(3,2) != 0 and Q(3,3) == 0 (StereoCamera.cpp:188-190)
   if (c->rect.Q[14] == 0.0 || c->rect.Q[15] != 0.0) return KVFE_ERR_INVALID_ARG;
@@ -2023,6 +2085,7 @@ kvfe_status kvfe_backproject_disparity_to_3d(kvfe_ctx* c, const float* disparity
 }
 
 kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
+  DeviceGuard _dev(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children) TRY(kvfe_profile_enable(ch, on));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2038,6 +2101,7 @@ kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
 }
 
 kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
+  DeviceGuard _dev(c);
   if (!c || !out) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) {  // launches of all groups: summed durations, mean bytes per launch
     std::memset(out, 0, sizeof(*out));

@@ -91,8 +91,6 @@ def load() -> C.CDLL:
     L.kvfe_frontend_get_output.argtypes = [vp, i32, C.POINTER(abi.FrameOutput)]
     L.kvfe_profile_enable.argtypes = [vp, i32]
     L.kvfe_profile_read.argtypes = [vp, C.POINTER(abi.StageTimes)]
-    for name in dir(L):
-        pass
     for fn in ("kvfe_create", "kvfe_compute_rectification", "kvfe_compute_undistort_rectify_maps",
                "kvfe_get_rectification", "kvfe_undistort_rectify_image",
                "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors",

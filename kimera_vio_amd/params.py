@@ -125,9 +125,10 @@ def load_detector_params(path: str, into: abi.DetectorParams | None = None) -> a
     return d
 
 
-def load_frontend_params(path: str, use_ransac: int | None = 0) -> abi.FrontendParams:
-    """FrontendParams::parseYAML.  ``use_ransac=None`` keeps the YAML's value; the default 0
-    switches geometric outlier rejection off (tests of the tracking / detection / stereo path)."""
+def load_frontend_params(path: str, use_ransac: int | None = None) -> abi.FrontendParams:
+    """FrontendParams::parseYAML.  ``use_ransac=None`` (default) keeps the YAML's useRANSAC as the
+    reference does; tests of the tracking / detection / stereo path alone pass 0 explicitly.
+    Like YamlParser::getYamlParam (YamlParser.h:41-47) every key the reference reads is required."""
     y = _read_yaml(path)
     p = default_frontend_params()
     load_detector_params(path, p.detector)
@@ -159,12 +160,19 @@ def load_frontend_params(path: str, use_ransac: int | None = 0) -> abi.FrontendP
     s.max_point_dist = float(y["maxPointDist"])
     s.subpixel_refinement = int(y["subpixelRefinementStereo"])
     s.equalize_image = int(y["equalizeImage"])
-    p.min_intra_keyframe_time_ns = float(y.get("min_intra_keyframe_time", y.get("intra_keyframe_time", 0.2))) * 1e9
-    p.max_intra_keyframe_time_ns = float(y.get("max_intra_keyframe_time", 5.0)) * 1e9
+    p.min_intra_keyframe_time_ns = float(y["min_intra_keyframe_time"]) * 1e9
+    p.max_intra_keyframe_time_ns = float(y["max_intra_keyframe_time"]) * 1e9
     p.min_number_features = int(y["minNumberFeatures"])
     p.use_stereo_tracking = int(y["useStereoTracking"])
-    p.max_disparity_since_lkf = float(y.get("max_disparity_since_lkf", 200.0))
+    p.max_disparity_since_lkf = float(y["max_disparity_since_lkf"])
     p.use_ransac = int(y["useRANSAC"]) if use_ransac is None else int(use_ransac)
+    # use_2d2d_tracking / use_3d3d_tracking are parsed by the reference (VisionImuFrontendParams.cpp:104-105)
+    # and read nowhere in src/; use_pnp_tracking gates Tracker::pnp on keyframes
+    # (StereoVisionImuFrontend.cpp:389), which needs the back-end's landmark map: not on this path.
+    int(y["use_2d2d_tracking"]), int(y["use_3d3d_tracking"])
+    if int(y["use_pnp_tracking"]) and p.use_ransac:
+        raise NotImplementedError("use_pnp_tracking: 1 (Tracker::pnp, Tracker.cpp:1064) is not implemented by "
+                                  "libkvfe (KVFE_ERR_UNSUPPORTED); set it to 0 or useRANSAC to 0")
     return p
 
 

@@ -1,0 +1,142 @@
+"""Parity ON WHAT IS BENCHMARKED: every BASELINE.json configuration that `bench.py` times is built here
+through the same `kimera_vio_amd.workloads.build()` call (same cameras, parameters, rendered frames,
+rotation plan, replication of the unique streams over the batch, device-resident input ring and
+`kvfe_frontend_step_device` entry point) and every step of it is compared field by field, tolerance 0,
+with the CPU oracle (`StereoVisionImuFrontend::processStereoFrame` restatement,
+/root/reference/src/frontend/StereoVisionImuFrontend.cpp:283-481).
+
+    C2  single EuRoC stream (MicroEuroc frames), 300 features, 3-level LK      kf + nominal cadence
+    C3  64 streams (8 unique RigStream seeds replicated), 600 features, 3-level LK, useRANSAC 1,
+        ring of 6 frames walked ping-pong incl. the turn-around              kf + nominal cadence
+    C5  1280x720, 1000 features, 4-level LK, batched                          kf + nominal cadence
+    C5 dense row: cv::StereoSGBM MODE_HH on rectified 1280x720 pairs (component call)
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from kimera_vio_amd import _abi as abi
+from kimera_vio_amd import frontend as F
+from kimera_vio_amd import workloads as WL
+from parity_util import assert_step_equal
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _build(config, mode, **kw):
+    """frames are rendered once per configuration; the two cadences share them"""
+    import dataclasses
+    key = (config, tuple(sorted(kw.items())))
+    if key not in _CACHE:
+        _CACHE[key] = WL.build(config, mode="kf", **kw)
+    return dataclasses.replace(_CACHE[key], mode=mode)
+
+
+def _run_workload(wl, n_steps, check_streams, replicas_equal_at_end=True):
+    """drives the GPU context exactly like bench.py's timed loop and the per-unique-stream oracles in
+    lock-step; returns [(step, is_keyframe, n_tracked, n_detected)] of unique stream 0"""
+    import torch
+    dev = torch.device("cuda", 0)
+    lefts, rights = wl.replicated()
+    d_left = torch.from_numpy(lefts).to(dev)
+    d_right = torch.from_numpy(rights).to(dev)
+    torch.cuda.synchronize()
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=wl.batch)
+    fes = [O.Frontend(wl.left, wl.right, wl.params) for _ in range(wl.unique)]
+    kinds = []
+    try:
+        for i, step in enumerate(wl.plan(n_steps)):
+            t, ts, Rs, force = step
+            ctx.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), wl.batch_inputs(ctx, step))
+            exp = [fes[u].process(wl.lefts[t, u], wl.rights[t, u], ts, Rs[u], bool(force))
+                   for u in range(wl.unique)]
+            for s in check_streams:
+                assert_step_equal(ctx.get_output(s), exp[wl.unique_of(s)], (wl.name, wl.mode, "step", i, "stream", s))
+            kinds.append((i, exp[0]["is_keyframe"], exp[0]["n_tracked"], exp[0]["n_detected"]))
+        if replicas_equal_at_end and wl.batch > wl.unique:
+            # size-independent property over the WHOLE batch: replica s is bit-identical to stream s mod U
+            ref = [ctx.get_output(u) for u in range(wl.unique)]
+            for s in range(wl.unique, wl.batch):
+                got = ctx.get_output(s)
+                for k in ("n_keypoints", "n_measurements", "is_keyframe"):
+                    assert got[k] == ref[wl.unique_of(s)][k], (s, k)
+                for k in ("keypoints", "landmarks", "depth", "meas_uL_uR_v"):
+                    assert np.array_equal(got[k], ref[wl.unique_of(s)][k], equal_nan=True), (s, k)
+    finally:
+        ctx.close()
+    return kinds
+
+
+@pytest.mark.parametrize("mode", ["kf", "nominal"])
+def test_c3_headline_64_streams_600_features(mode):
+    """BASELINE configs[2], the workload of bench.py's `value`: all 8 unique streams + replica 63 on every
+    step of 12 (the 6-frame ring is walked 0..5 and back: the turn-around re-tracks into frames seen before)."""
+    wl = _build("c3", mode)
+    assert (wl.batch, wl.unique, wl.ring, wl.width, wl.height) == (64, 8, 6, 752, 480)
+    assert wl.params.detector.max_features_per_frame == 600 and wl.params.tracker.klt_max_level == 2
+    assert wl.params.use_ransac == 1 and wl.params.detector.non_max_suppression_type == abi.ANMS_BINNING
+    kinds = _run_workload(wl, 12, list(range(8)) + [63])
+    if mode == "kf":
+        assert all(k[1] == 1 for k in kinds)
+        assert all(k[2] > 400 for k in kinds[1:]), kinds        # the headline really tracks ~600 points
+    else:
+        assert [k[1] for k in kinds[:9]] == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+
+
+@pytest.mark.parametrize("mode", ["kf", "nominal"])
+def test_c2_single_euroc_stream_300_features_3_level_lk(mode):
+    """BASELINE configs[1] as stated: EuRoC frames (MicroEuroc 10..18), 300 features, klt_max_level 2, shipped
+    Euroc parameters with useRANSAC 1; 14 steps = the ring forwards and most of the way back."""
+    wl = _build("c2", mode)
+    assert (wl.batch, wl.ring) == (1, 9) and wl.params.detector.max_features_per_frame == 300
+    assert wl.params.tracker.klt_max_level == 2
+    kinds = _run_workload(wl, 14, [0])
+    assert all(k[2] > 100 for k in kinds[1:])
+
+
+@pytest.mark.parametrize("mode", ["kf", "nominal"])
+def test_c5_1280x720_1000_features_4_level_lk_batched(mode):
+    """BASELINE configs[4] shape (bench.py's `c5` leg runs it with batch 32 = 4 unique streams x 8): here batch 8
+    = 4 unique streams x 2, every unique stream and one replica compared on 8 steps."""
+    wl = _build("c5", mode, batch=8)
+    assert (wl.width, wl.height, wl.unique) == (1280, 720, 4)
+    assert wl.params.detector.max_features_per_frame == 1000 and wl.params.tracker.klt_max_level == 3
+    kinds = _run_workload(wl, 8, [0, 1, 2, 3, 7])
+    assert all(k[2] > 600 for k in kinds[1:]), kinds
+
+
+def test_c5_dense_stereo_row_1280x720():
+    """the "dense stereo row" of configs[4]: StereoMatcher::denseStereoReconstruction (StereoMatcher.cpp:32-121,
+    cv::StereoSGBM MODE_HH with the reference's DenseStereoParams) on rectified 1280x720 pairs, bit-exact;
+    bench.py's `dense_stereo_c5` leg times this call."""
+    wl = WL.build("c5", batch=2, unique=2, ring=1)
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=1)
+    ocam = O.Camera(wl.left, wl.right)
+    try:
+        dp = abi.dense_stereo_params_default()
+        pairs = []
+        for u in range(2):
+            lr = ctx.undistort_rectify_image(0, wl.lefts[0, u])
+            rr = ctx.undistort_rectify_image(1, wl.rights[0, u])
+            assert np.array_equal(lr, ocam.rectify_image(0, wl.lefts[0, u]))
+            pairs.append((lr, rr))
+        got = ctx.dense_stereo_reconstruction([a for a, _ in pairs], [b for _, b in pairs], dp)
+        for u in range(2):
+            exp = O.dense_stereo_reconstruction(pairs[u][0], pairs[u][1], dp)
+            assert np.array_equal(got[u], exp)
+            assert np.mean(exp != (dp.min_disparity - 1) * 16) > 0.5      # a real disparity map, not all invalid
+    finally:
+        ctx.close()
+
+
+def test_c4_rank_windows_are_distinct_sequences():
+    """configs[3]: 8 sequences, one per GPU, batch 1 — rank r replays its own window of MicroEuroc; rank 3's
+    window on this GPU matches its oracle (the 8-GPU launch itself is the driver's)."""
+    wl = WL.build("c4", mode="nominal", rank=3)
+    wl0 = WL.build("c4", mode="nominal", rank=0)
+    assert not np.array_equal(wl.lefts[0], wl0.lefts[0])
+    _run_workload(wl, 9, [0])

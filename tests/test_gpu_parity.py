@@ -32,7 +32,7 @@ def euroc_cams():
 
 
 def euroc_params(**det):
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
     for k, v in det.items():
         setattr(p.detector, k, v)
     return p
@@ -742,6 +742,55 @@ def test_frontend_staged_input_matches_host_input(seq, ocam, equalize):
                     kf[s] = idx[s]
     finally:
         c.close()
+
+
+def test_frontend_stream_groups_equalize_device_input(seq, ocam):
+    """ADVICE r1: stream_groups > 1 + equalizeImage + kvfe_frontend_step_device used to skip cv::equalizeHist
+    (the group path called do_step directly).  3 streams in 2 groups, device-resident raw images, every frame
+    equal to the oracle (which equalises, UtilsOpenCV.cpp:398-401)."""
+    import torch
+    from parity_util import assert_step_equal
+    dev = torch.device("cuda", 0)
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=150)
+    p.stereo.equalize_image = 1
+    B = 3
+    fe = [O.Frontend(L, R, p) for _ in range(B)]
+    c = F.Context(L, R, p, batch=B, stream_groups=2)
+    keep = []
+    try:
+        kf = [0] * B
+        for i in range(6):
+            idx = [i, 8 - i, (2 * i) % 9]
+            Rs = [seq["camR"][kf[s]].T @ seq["camR"][idx[s]] for s in range(B)]
+            ts = [int(seq["ts"][i])] * B
+            dl = torch.from_numpy(np.stack([seq["lefts"][j] for j in idx])).to(dev)
+            dr = torch.from_numpy(np.stack([seq["rights"][j] for j in idx])).to(dev)
+            keep = keep[-2:] + [(dl, dr)]
+            c.step_device(dl.data_ptr(), dr.data_ptr(), c.make_inputs(ts, Rs, [0] * B))
+            for s in range(B):
+                exp = fe[s].process(seq["lefts"][idx[s]], seq["rights"][idx[s]], ts[s], Rs[s], False)
+                assert_step_equal(c.get_output(s), exp, (i, s))
+                if exp["is_keyframe"]:
+                    kf[s] = idx[s]
+    finally:
+        c.close()
+
+
+def test_c_abi_argument_validation(ctx):
+    """the C ABI never aborts: negative capacities / sizes are KVFE_ERR_INVALID_ARG"""
+    import ctypes as C
+    from kimera_vio_amd.lib import KvfeError
+    out = abi.FrameOutput()
+    out.capacity = -1
+    assert ctx.lib.kvfe_frontend_get_output(ctx._h, 0, C.byref(out)) == abi.KVFE_ERR_INVALID_ARG
+    L, R = euroc_cams()
+    p = euroc_params(max_nr_keypoints_before_anms=-5)
+    with pytest.raises(KvfeError) as e:
+        F.Context(L, R, p)
+    assert e.value.status == abi.KVFE_ERR_INVALID_ARG
 
 
 # ---------------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ def test_create_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     Lc = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
     Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
     with pytest.raises(L.KvfeError) as e:
         F.Context(Lc, Rc, p)
     assert e.value.status == abi.KVFE_ERR_NO_DEVICE
@@ -116,7 +116,7 @@ def test_unsupported_configurations_are_rejected():
 
 
 def test_yaml_parsing_euroc():
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
     assert p.detector.max_features_per_frame == 300 and p.detector.non_max_suppression_type == 6
     assert p.detector.nr_horizontal_bins == 7 and p.detector.nr_vertical_bins == 5
     assert sum(p.detector.binning_mask) == 35

@@ -29,7 +29,7 @@ def _run_streams(stream_ids, n_frames=3):
     from kimera_vio_amd import params as P
     L = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
     R = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
     p.detector.max_features_per_frame = 100
     z = np.load(os.path.join(G, "micro_euroc_f10_18.npz"))
     out = {}
@@ -104,3 +104,23 @@ def test_two_gloo_ranks_shard_streams_and_reduce_timing():
     for g in got:
         for s, sig in g[2].items():
             assert sig == single[s]
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` without a torchrun environment re-executes itself under
+    `python -m torch.distributed.run --nproc-per-node 2` (the flag used to be ignored) and, with
+    --config c4, shards BASELINE configs[3]'s 8 sequences over the ranks (sequence q on rank q mod world).
+    --dry-run = launch plumbing over gloo only: no GPU, nothing computed."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                           "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4",
+                        "--steps", "5", "--dry-run"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert [x["sequences"] for x in d["ranks"]] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert d["pairs_sum"] == 8 * 5 and d["elapsed_max"] == 2.0          # SUM of units, MAX of rank times
+    assert d["ranks"][0]["first_pixel_sum"] != d["ranks"][1]["first_pixel_sum"]   # different sequences

@@ -6,7 +6,7 @@ import oracle_lib as O
 from kimera_vio_amd import _abi as abi, frontend as F, params as P
 G = "/root/repo/tests/golden"
 L = P.load_camera_params(os.path.join(G, "sensorLeft.yaml")); R = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
-p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
 oc = O.Camera(L, R)
 l = oc.rectify_image(0, np.array(Image.open(os.path.join(G, "left_img_0.png")).convert("L")))
 r = oc.rectify_image(1, np.array(Image.open(os.path.join(G, "right_img_0.png")).convert("L")))

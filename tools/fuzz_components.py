@@ -7,8 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
-import bench
-from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth
+from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
 G = os.path.join(ROOT, "tests", "golden")
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -29,8 +28,8 @@ def check(name, a, b, desc):
 for ci in range(n_cfg):
     w = int(rng.choice([96, 160, 256, 320, 377, 480, 752]))
     h = int(rng.choice([80, 120, 192, 241, 360, 480]))
-    L, R = bench.make_cameras(P, G, w, h)
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+    L, R = workloads.make_cameras(w, h)
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
     p.tracker.klt_win_size = int(rng.choice([9, 15, 16, 21, 24, 32]))
     p.tracker.klt_max_level = int(rng.choice([0, 1, 2, 4]))
     p.tracker.klt_max_iter = int(rng.choice([5, 30]))

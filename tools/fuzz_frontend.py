@@ -6,8 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
-import bench
-from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth
+from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
 G = os.path.join(ROOT, "tests", "golden")
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -17,7 +16,7 @@ bad = 0
 for ci in range(n_cfg):
     w = int(rng.choice([256, 320, 376, 480, 640, 752]))
     h = int(rng.choice([192, 240, 288, 360, 480]))
-    L, R = bench.make_cameras(P, G, w, h)
+    L, R = workloads.make_cameras(w, h)
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=int(rng.randint(0, 2)))
     d, t, s = p.detector, p.tracker, p.stereo
     d.max_features_per_frame = int(rng.choice([40, 100, 200, 400]))

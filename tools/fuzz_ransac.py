@@ -8,15 +8,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
-import bench
 import test_oracle_ransac as TR
-from kimera_vio_amd import frontend as F, params as P
+from kimera_vio_amd import frontend as F, params as P, workloads
 
 G = os.path.join(ROOT, "tests", "golden")
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed0)
-L, R_ = bench.make_cameras(P, G, 752, 480)
+L, R_ = workloads.make_cameras(752, 480)
 ocam = O.Camera(L, R_)
 bad = 0
 

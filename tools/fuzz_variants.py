@@ -6,8 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
-import bench
-from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth
+from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
 G = os.path.join(ROOT, "tests", "golden")
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -34,7 +33,7 @@ for ci in range(n_cfg):
     w = int(rng.choice([320, 376, 480, 752]))
     h = int(rng.choice([240, 288, 480]))
     B = int(rng.choice([1, 2, 3]))
-    L, R = bench.make_cameras(P, G, w, h)
+    L, R = workloads.make_cameras(w, h)
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=int(rng.randint(0, 2)))
     p.detector.max_features_per_frame = int(rng.choice([60, 150, 300]))
     p.detector.non_max_suppression_type = int(rng.choice([0, 4, 6]))
@@ -113,7 +112,7 @@ for ci in range(n_cfg):
     bad += 0 if ok else 1
 
 # dense stereo parameters
-c = F.Context(*bench.make_cameras(P, G, 376, 240), P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml")))
+c = F.Context(*workloads.make_cameras(376, 240), P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0))
 dbad = 0
 for ci in range(n_cfg):
     dp = abi.dense_stereo_params_default()

@@ -8,7 +8,7 @@ from kimera_vio_amd import frontend as F, params as P, synth
 G = os.path.join(ROOT, "tests", "golden")
 L = P.load_camera_params(os.path.join(G, "params_euroc", "LeftCameraParams.yaml"))
 R = P.load_camera_params(os.path.join(G, "params_euroc", "RightCameraParams.yaml"))
-p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"))
+p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
 img = synth.RigStream(L, R, seed=1).frame(0)[0]
 c = F.Context(L, R, p)
 rng = np.random.default_rng(0)
