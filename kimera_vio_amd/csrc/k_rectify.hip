@@ -8,6 +8,7 @@
 // so a wave touches ~2-3 source rows).  Integer arithmetic only => bit-exact vs the CPU path.
 #include "kvfe_dev.hpp"
 
+#include <cstdint>
 #include <cstdlib>
 
 namespace kvfe {
@@ -189,10 +190,277 @@ __global__ __launch_bounds__(256) void rectify_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiled cv::remap: one block = one 128 x 16 output tile of one camera for SPB streams.
+//   phase A  the block reads its 16 KB map tile once (32 B per lane and row, coalesced), turns every
+//            pixel into (clamped source position, four 15-bit weights) -- BORDER_REPLICATE is folded
+//            into the weights: a tap that clamps onto its neighbour hands its weight over, so every
+//            pixel reads the 2x2 block at its clamped position -- and reduces the bounding box of
+//            the source positions over the block;
+//   phase B  the bounding box (16-byte aligned in x; <= 160 B x 32 rows for the EuRoC / D455 maps,
+//            whose rows drift ~7 px per 128 columns) of each of the SPB streams is copied into LDS
+//            with global_load_lds_dwordx4 (LDS-DMA: 1 KiB per wave instruction, no VGPR round trip,
+//            every byte of a source row segment requested exactly once per block);
+//   phase C  16 ds_read_u8 + 8 v_dot2_u32_u16 per lane and stream blend 8 pixels; two coalesced dword
+//            stores per lane (a wave writes 2 x 128 B row segments per store instruction).
+// The taps are computed once per block and reused for all SPB streams (registers: 3 per pixel).
+// Blocks whose box does not fit (exotic maps) take the gather path of the same kernel, so any map
+// is handled; images whose rows are not 16-byte aligned use rectify_kernel above.
+// ---------------------------------------------------------------------------------------------
+constexpr int RT_W = 128, RT_H = 16;
+constexpr int RT_CPR = 10;                       // 16-byte chunks per staged source row
+constexpr int RT_PITCH = RT_CPR * 16;
+constexpr int RT_ROWS = 32;                      // staged source rows per stream
+constexpr int RT_PATCH = RT_PITCH * (RT_ROWS + 1) + 16;  // folded taps read one row / byte further (weight 0)
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+typedef __attribute__((address_space(1))) const unsigned char glb_cu8_t;
+typedef unsigned short v2u16_ __attribute__((ext_vector_type(2)));
+
+struct RTap {
+  int cx, cy;          // clamped source position of the 2x2 block
+  unsigned w0, w1;     // w00 | w01 << 16, w10 | w11 << 16 (after folding; each <= 32768)
+};
+
+__device__ __forceinline__ RTap rtap(int W, int H, float mx, float my) {
+  const int sxf = __float2int_rn(mx * 32.0f);
+  const int syf = __float2int_rn(my * 32.0f);
+  const int ax = sxf & 31, ay = syf & 31;
+  int sx = sxf >> 5, sy = syf >> 5;
+  sx = max(-32768, min(32767, sx));  // saturate_cast<short>
+  sy = max(-32768, min(32767, sy));
+  int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+  if ((ax | ay) == 0) {  // table entry (0,0) after saturation and fix-up: {32767,0,0,1}
+    w00 = 32767;
+    w11 = 1;
+  }
+  const int sx0 = clipi(sx, W), sx1 = clipi(sx + 1, W), sy0 = clipi(sy, H), sy1 = clipi(sy + 1, H);
+  if (sx1 == sx0) {  // both columns clamp onto the same source column
+    w00 += w01;
+    w10 += w11;
+    w01 = w11 = 0;
+  }
+  if (sy1 == sy0) {
+    w00 += w10;
+    w01 += w11;
+    w10 = w11 = 0;
+  }
+  RTap t;
+  t.cx = sx0;
+  t.cy = sy0;
+  t.w0 = (unsigned)w00 | ((unsigned)w01 << 16);
+  t.w1 = (unsigned)w10 | ((unsigned)w11 << 16);
+  return t;
+}
+
+__device__ __forceinline__ unsigned rblend(unsigned p00, unsigned p01, unsigned p10, unsigned p11, unsigned w0,
+                                           unsigned w1) {
+  const unsigned p = p00 | (p01 << 16), q = p10 | (p11 << 16);
+  const unsigned r = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_, p), __builtin_bit_cast(v2u16_, w0),
+                                            __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16_, q),
+                                                                   __builtin_bit_cast(v2u16_, w1), 1u << 14, false),
+                                            false);
+  return r >> 15;   // the weights sum to 2^15: 0 <= r <= 255
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+  return v;
+}
+
+template <int SPB>
+__global__ __launch_bounds__(256) void rectify_tile_kernel(
+    const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1, size_t src_row_stride,
+    size_t src_img_stride, unsigned char* __restrict__ dst0, unsigned char* __restrict__ dst1,
+    const float2* __restrict__ map0, const float2* __restrict__ map1, int W, int H, int B,
+    const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  int* bounds = reinterpret_cast<int*>(sm + (size_t)SPB * RT_PATCH);   // [4 waves][4]
+  int tx, ty, cam, s_begin;
+  if (mode == 0) {  // 3-D grid (tile, camera, stream group)
+    tx = blockIdx.x % tiles_x;
+    ty = blockIdx.x / tiles_x;
+    cam = blockIdx.y;
+    s_begin = blockIdx.z * SPB;
+  } else {
+    // XCD-banded 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (block L runs on XCD L & 7, a speed
+    // assumption only): XCD k owns the k-th band of tile rows of both cameras for ALL streams and walks it
+    // tile-major / stream-group-minor, so a map tile comes from HBM once (the other stream groups hit it in this
+    // XCD's L2) and the source rows shared by neighbouring tiles are fetched by one L2 only.
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int r0 = (xcd * tiles_y) >> 3, r1 = ((xcd + 1) * tiles_y) >> 3;
+    const int nb = (r1 - r0) * tiles_x;
+    const int g = j % gz, t = j / gz;
+    if (t >= 2 * nb) return;
+    cam = t / nb;
+    const int tt = t - cam * nb;
+    ty = r0 + tt / tiles_x;
+    tx = tt % tiles_x;
+    s_begin = g * SPB;
+  }
+  const unsigned char* src = cam == 0 ? src0 : src1;
+  unsigned char* dst = cam == 0 ? dst0 : dst1;
+  const float2* map = cam == 0 ? map0 : map1;
+  const int N = W * H;
+  const int stride = (int)src_row_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = tid & 31, ly = tid >> 5;
+  const int x = tx * RT_W + lx * 4;
+  const int y0 = ty * RT_H + ly;
+  // ---- phase A: taps of this lane's 2 x 4 pixels ----------------------------------------------------------
+  RTap tp[8];
+  int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
+  bool okr[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int y = y0 + 8 * r;
+    okr[r] = x < W && y < H;
+    if (okr[r]) {
+      const int i = y * W + x;
+      const float4 m01 = *reinterpret_cast<const float4*>(map + i);
+      const float4 m23 = *reinterpret_cast<const float4*>(map + i + 2);
+      tp[4 * r + 0] = rtap(W, H, m01.x, m01.y);
+      tp[4 * r + 1] = rtap(W, H, m01.z, m01.w);
+      tp[4 * r + 2] = rtap(W, H, m23.x, m23.y);
+      tp[4 * r + 3] = rtap(W, H, m23.z, m23.w);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        mnx = min(mnx, tp[4 * r + q].cx);
+        mxx = max(mxx, tp[4 * r + q].cx);
+        mny = min(mny, tp[4 * r + q].cy);
+        mxy = max(mxy, tp[4 * r + q].cy);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) tp[4 * r + q] = RTap{0, 0, 0u, 0u};
+    }
+  }
+  mnx = wave_min(mnx);
+  mxx = wave_max(mxx);
+  mny = wave_min(mny);
+  mxy = wave_max(mxy);
+  if (lane == 0) {
+    bounds[wave * 4 + 0] = mnx;
+    bounds[wave * 4 + 1] = mxx;
+    bounds[wave * 4 + 2] = mny;
+    bounds[wave * 4 + 3] = mxy;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    mnx = min(mnx, bounds[w * 4 + 0]);
+    mxx = max(mxx, bounds[w * 4 + 1]);
+    mny = min(mny, bounds[w * 4 + 2]);
+    mxy = max(mxy, bounds[w * 4 + 3]);
+  }
+  const int x_lo = mnx & ~15, y_lo = mny;
+  const int ncx = ((min(mxx + 1, W - 1) - x_lo) >> 4) + 1;   // 16-byte chunks per row that hold needed bytes
+  const int ph = min(mxy + 1, H - 1) - y_lo + 1;             // rows that hold needed bytes
+  const bool staged = mxx >= 0 && ncx <= RT_CPR && ph <= RT_ROWS;
+  // stream activity (block-uniform)
+  unsigned act = 0;
+#pragma unroll
+  for (int k = 0; k < SPB; k++) {
+    const int s = s_begin + k;
+    if (s < B && (!flags || (flags[s] & act_flag))) act |= 1u << k;
+  }
+  if (!act) return;
+  if (staged) {
+    // ---- phase B: LDS-DMA of the source boxes ------------------------------------------------------------
+    const int n = ph * RT_CPR;
+#pragma unroll
+    for (int k = 0; k < SPB; k++) {
+      if (!((act >> k) & 1u)) continue;
+      const unsigned char* S = src + (size_t)(s_begin + k) * src_img_stride + (size_t)y_lo * stride + x_lo;
+      unsigned char* pk = sm + k * RT_PATCH;
+      for (int c0 = wave * 64; c0 < n; c0 += 256) {
+        const int c = c0 + lane;
+        const int row = c / RT_CPR, ch = c - row * RT_CPR;
+        if (c < n && ch < ncx)
+          __builtin_amdgcn_global_load_lds((glb_cu8_t*)(S + (size_t)row * stride + ch * 16), (lds_u8_t*)(pk + c0 * 16),
+                                           16, 0, 0);
+      }
+    }
+    __syncthreads();   // (hipcc drains vmcnt before the barrier: the boxes have landed)
+    // ---- phase C ----------------------------------------------------------------------------------------
+    unsigned ad[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) ad[q] = (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
+#pragma unroll
+    for (int k = 0; k < SPB; k++) {
+      if (!((act >> k) & 1u)) continue;
+      const unsigned char* pk = sm + k * RT_PATCH;
+      unsigned char* D = dst + (size_t)(s_begin + k) * N;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (!okr[r]) continue;
+        unsigned px[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const unsigned char* a = pk + ad[4 * r + q];
+          px[q] = rblend(a[0], a[1], a[RT_PITCH], a[RT_PITCH + 1], tp[4 * r + q].w0, tp[4 * r + q].w1);
+        }
+        *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+      }
+    }
+  } else {
+    // gather path: the box of this tile does not fit the LDS stage
+#pragma unroll 1
+    for (int k = 0; k < SPB; k++) {
+      if (!((act >> k) & 1u)) continue;
+      const unsigned char* S = src + (size_t)(s_begin + k) * src_img_stride;
+      unsigned char* D = dst + (size_t)(s_begin + k) * N;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (!okr[r]) continue;
+        unsigned px[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const RTap& t = tp[4 * r + q];
+          const int xa = t.cx, xb = min(t.cx + 1, W - 1);
+          const size_t ra = (size_t)t.cy * stride, rb = (size_t)min(t.cy + 1, H - 1) * stride;
+          px[q] = rblend(S[ra + xa], S[ra + xb], S[rb + xa], S[rb + xb], t.w0, t.w1);
+        }
+        *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+      }
+    }
+  }
+}
+
 void launch_rectify(const KParams& P, const Tables& T, const unsigned char* const src[2],
                     size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
                     const int* flags, int act_flag, hipStream_t st) {
   const int N = P.W * P.H;
+  // KVFE_RECT_IMPL: 0 = per-lane gathers (rectify_kernel), 1 = LDS-staged tiles (default where the source rows are
+  // 16-byte aligned); KVFE_RECT_TILE_MODE: 0 = 3-D grid, 1 = XCD-banded; KVFE_RECT_SPB: streams per block (4 | 8)
+  static const int impl = std::getenv("KVFE_RECT_IMPL") ? std::atoi(std::getenv("KVFE_RECT_IMPL")) : 1;
+  static const int tmode = std::getenv("KVFE_RECT_TILE_MODE") ? std::atoi(std::getenv("KVFE_RECT_TILE_MODE")) : 0;
+  static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 8;
+  const bool aligned = P.W % 4 == 0 && src_row_stride % 16 == 0 && src_img_stride % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(src[0]) % 16 == 0 && reinterpret_cast<uintptr_t>(src[1]) % 16 == 0;
+  if (impl == 1 && aligned) {
+    const int tiles_x = (P.W + RT_W - 1) / RT_W, tiles_y = (P.H + RT_H - 1) / RT_H;
+    const int S = (spb == 4 || P.B <= 4) ? 4 : 8;
+    const int gz = (P.B + S - 1) / S;
+    dim3 grid(tiles_x * tiles_y, 2, gz);
+    if (tmode == 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
+    const size_t lds = (size_t)S * RT_PATCH + 64;
+    if (S == 4)
+      hipLaunchKernelGGL(rectify_tile_kernel<4>, grid, dim3(256), lds, st, src[0], src[1], src_row_stride,
+                         src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, tiles_x,
+                         tiles_y, gz, tmode);
+    else
+      hipLaunchKernelGGL(rectify_tile_kernel<8>, grid, dim3(256), lds, st, src[0], src[1], src_row_stride,
+                         src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, tiles_x,
+                         tiles_y, gz, tmode);
+    return;
+  }
   const int gz = (P.B + RECT_SPB - 1) / RECT_SPB;
   const bool vec4 = N % 4 == 0;
   const int n_tiles = vec4 ? (N / 4 + 255) / 256 : (N + 255) / 256;

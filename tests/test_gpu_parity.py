@@ -1208,8 +1208,8 @@ def test_backproject_disparity_to_3d_bit_exact(ctx, ocam, seq):
 def test_dense_stereo_other_image_sizes(w, h):
     """odd sizes (tiles / chunks not multiples of 64 / 32) and BASELINE's C5 size: SGBM MODE_HH, MODE_SGBM and
     StereoBM identical to the oracle on a synthetic pair with a known shift"""
-    import bench
-    L, R = bench.make_cameras(P, G, w, h)
+    from kimera_vio_amd import workloads
+    L, R = workloads.make_cameras(w, h)
     c = F.Context(L, R, euroc_params())
     try:
         tex = synth.base_texture(w + 80, h, 11)
