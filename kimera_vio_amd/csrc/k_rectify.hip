@@ -274,20 +274,21 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-template <int SPB>
-__global__ __launch_bounds__(256) void rectify_tile_kernel(
+template <int SPB, int NSUB, int MINW>
+__global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1, size_t src_row_stride,
     size_t src_img_stride, unsigned char* __restrict__ dst0, unsigned char* __restrict__ dst1,
     const float2* __restrict__ map0, const float2* __restrict__ map1, int W, int H, int B,
     const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  int* bounds = reinterpret_cast<int*>(sm + (size_t)SPB * RT_PATCH);   // [4 waves][4]
+  constexpr int NBUF = NSUB > 1 ? 2 : 1;   // LDS boxes: SPB streams x NBUF buffers
+  int* bounds = reinterpret_cast<int*>(sm + (size_t)SPB * NBUF * RT_PATCH);   // [4 waves][4]
   int tx, ty, cam, s_begin;
-  if (mode == 0) {  // 3-D grid (tile, camera, stream group)
+  if ((mode & 1) == 0) {  // 3-D grid (tile, camera, stream group)
     tx = blockIdx.x % tiles_x;
     ty = blockIdx.x / tiles_x;
     cam = blockIdx.y;
-    s_begin = blockIdx.z * SPB;
+    s_begin = blockIdx.z * (SPB * NSUB);
   } else {
     // XCD-banded 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (block L runs on XCD L & 7, a speed
     // assumption only): XCD k owns the k-th band of tile rows of both cameras for ALL streams and walks it
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void rectify_tile_kernel(
     const int tt = t - cam * nb;
     ty = r0 + tt / tiles_x;
     tx = tt % tiles_x;
-    s_begin = g * SPB;
+    s_begin = g * (SPB * NSUB);
   }
   const unsigned char* src = cam == 0 ? src0 : src1;
   unsigned char* dst = cam == 0 ? dst0 : dst1;
@@ -362,72 +363,90 @@ __global__ __launch_bounds__(256) void rectify_tile_kernel(
   const int x_lo = mnx & ~15, y_lo = mny;
   const int ncx = ((min(mxx + 1, W - 1) - x_lo) >> 4) + 1;   // 16-byte chunks per row that hold needed bytes
   const int ph = min(mxy + 1, H - 1) - y_lo + 1;             // rows that hold needed bytes
-  const bool staged = mxx >= 0 && ncx <= RT_CPR && ph <= RT_ROWS;
-  // stream activity (block-uniform)
+  const bool staged = mxx >= 0 && ncx <= RT_CPR && ph <= RT_ROWS && !(mode & 2);   // mode bit 1: force the gather path (tests)
+  // stream activity (block-uniform), one bit per stream of the block
   unsigned act = 0;
 #pragma unroll
-  for (int k = 0; k < SPB; k++) {
+  for (int k = 0; k < SPB * NSUB; k++) {
     const int s = s_begin + k;
     if (s < B && (!flags || (flags[s] & act_flag))) act |= 1u << k;
   }
   if (!act) return;
   if (staged) {
-    // ---- phase B: LDS-DMA of the source boxes ------------------------------------------------------------
+    // ---- phase B: LDS-DMA of the source boxes, phase C: blend; software pipeline over sub-chunks of SPB streams:
+    //      the boxes of sub-chunk j+1 are in flight while sub-chunk j is blended (two LDS buffers) ----------------
     const int n = ph * RT_CPR;
+    // this lane's (at most two) 16-byte chunks of a box: offsets are the same for every stream
+    int goff[2];
+    bool gok[2];
 #pragma unroll
-    for (int k = 0; k < SPB; k++) {
-      if (!((act >> k) & 1u)) continue;
-      const unsigned char* S = src + (size_t)(s_begin + k) * src_img_stride + (size_t)y_lo * stride + x_lo;
-      unsigned char* pk = sm + k * RT_PATCH;
-      for (int c0 = wave * 64; c0 < n; c0 += 256) {
-        const int c = c0 + lane;
-        const int row = c / RT_CPR, ch = c - row * RT_CPR;
-        if (c < n && ch < ncx)
-          __builtin_amdgcn_global_load_lds((glb_cu8_t*)(S + (size_t)row * stride + ch * 16), (lds_u8_t*)(pk + c0 * 16),
-                                           16, 0, 0);
-      }
+    for (int it = 0; it < 2; it++) {
+      const int c = wave * 64 + it * 256 + lane;
+      const int row = c / RT_CPR, ch = c - row * RT_CPR;
+      gok[it] = c < n && ch < ncx;
+      goff[it] = row * stride + ch * 16;
     }
-    __syncthreads();   // (hipcc drains vmcnt before the barrier: the boxes have landed)
-    // ---- phase C ----------------------------------------------------------------------------------------
+    const unsigned char* Sbase = src + (size_t)y_lo * stride + x_lo;
+    auto issue = [&](int j) {
+      unsigned char* pb = sm + (j & (NBUF - 1)) * (SPB * RT_PATCH);
+#pragma unroll
+      for (int k = 0; k < SPB; k++) {
+        if (!((act >> (j * SPB + k)) & 1u)) continue;
+        const unsigned char* S = Sbase + (size_t)(s_begin + j * SPB + k) * src_img_stride;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+          if (wave * 64 + it * 256 < n && gok[it])
+            __builtin_amdgcn_global_load_lds((glb_cu8_t*)(S + goff[it]),
+                                             (lds_u8_t*)(pb + k * RT_PATCH + (wave * 64 + it * 256) * 16), 16, 0, 0);
+        }
+      }
+    };
     unsigned ad[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) ad[q] = (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
+    issue(0);
 #pragma unroll
-    for (int k = 0; k < SPB; k++) {
-      if (!((act >> k) & 1u)) continue;
-      const unsigned char* pk = sm + k * RT_PATCH;
-      unsigned char* D = dst + (size_t)(s_begin + k) * N;
+    for (int j = 0; j < NSUB; j++) {
+      if (!(act >> (j * SPB))) break;   // no active stream in this or any later sub-chunk (block-uniform)
+      __syncthreads();   // hipcc drains vmcnt before the barrier: sub-chunk j has landed; everybody is done with j-1
+      if (j + 1 < NSUB) issue(j + 1);
+      const unsigned char* pb = sm + (j & (NBUF - 1)) * (SPB * RT_PATCH);
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        if (!okr[r]) continue;
-        unsigned px[4];
+      for (int k = 0; k < SPB; k++) {
+        if (!((act >> (j * SPB + k)) & 1u)) continue;
+        const unsigned char* pk = pb + k * RT_PATCH;
+        unsigned char* D = dst + (size_t)(s_begin + j * SPB + k) * N;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const unsigned char* a = pk + ad[4 * r + q];
-          px[q] = rblend(a[0], a[1], a[RT_PITCH], a[RT_PITCH + 1], tp[4 * r + q].w0, tp[4 * r + q].w1);
+        for (int r = 0; r < 2; r++) {
+          if (!okr[r]) continue;
+          unsigned px[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned char* a = pk + ad[4 * r + q];
+            px[q] = rblend(a[0], a[1], a[RT_PITCH], a[RT_PITCH + 1], tp[4 * r + q].w0, tp[4 * r + q].w1);
+          }
+          *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
         }
-        *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
       }
     }
   } else {
-    // gather path: the box of this tile does not fit the LDS stage
+    // gather path: the box of this tile does not fit the LDS stage (exotic maps only, so it is written for
+    // few registers, not for speed: the taps are recomputed pixel by pixel from the map)
 #pragma unroll 1
-    for (int k = 0; k < SPB; k++) {
+    for (int k = 0; k < SPB * NSUB; k++) {
       if (!((act >> k) & 1u)) continue;
       const unsigned char* S = src + (size_t)(s_begin + k) * src_img_stride;
       unsigned char* D = dst + (size_t)(s_begin + k) * N;
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        if (!okr[r]) continue;
-        unsigned px[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const RTap& t = tp[4 * r + q];
-          const int xa = t.cx, xb = min(t.cx + 1, W - 1);
-          const size_t ra = (size_t)t.cy * stride, rb = (size_t)min(t.cy + 1, H - 1) * stride;
-          px[q] = rblend(S[ra + xa], S[ra + xb], S[rb + xa], S[rb + xb], t.w0, t.w1);
-        }
-        *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+#pragma unroll 1
+      for (int e = 0; e < 8; e++) {
+        const int y = y0 + 8 * (e >> 2);
+        if (x >= W || y >= H) continue;
+        const int i = y * W + x + (e & 3);
+        const float2 m = map[i];
+        const RTap t = rtap(W, H, m.x, m.y);
+        const int xa = t.cx, xb = min(t.cx + 1, W - 1);
+        const size_t ra = (size_t)t.cy * stride, rb = (size_t)min(t.cy + 1, H - 1) * stride;
+        D[i] = (unsigned char)rblend(S[ra + xa], S[ra + xb], S[rb + xa], S[rb + xb], t.w0, t.w1);
       }
     }
   }
@@ -440,25 +459,34 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
   // KVFE_RECT_IMPL: 0 = per-lane gathers (rectify_kernel), 1 = LDS-staged tiles (default where the source rows are
   // 16-byte aligned); KVFE_RECT_TILE_MODE: 0 = 3-D grid, 1 = XCD-banded; KVFE_RECT_SPB: streams per block (4 | 8)
   static const int impl = std::getenv("KVFE_RECT_IMPL") ? std::atoi(std::getenv("KVFE_RECT_IMPL")) : 1;
-  static const int tmode = std::getenv("KVFE_RECT_TILE_MODE") ? std::atoi(std::getenv("KVFE_RECT_TILE_MODE")) : 0;
-  static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 8;
+  static const int tmode = (std::getenv("KVFE_RECT_TILE_MODE") ? std::atoi(std::getenv("KVFE_RECT_TILE_MODE")) & 1 : 0) |
+                           (std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0);
+  static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 4;
+  static const int nsub = std::getenv("KVFE_RECT_NSUB") ? std::atoi(std::getenv("KVFE_RECT_NSUB")) : 4;
   const bool aligned = P.W % 4 == 0 && src_row_stride % 16 == 0 && src_img_stride % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(src[0]) % 16 == 0 && reinterpret_cast<uintptr_t>(src[1]) % 16 == 0;
   if (impl == 1 && aligned) {
     const int tiles_x = (P.W + RT_W - 1) / RT_W, tiles_y = (P.H + RT_H - 1) / RT_H;
-    const int S = (spb == 4 || P.B <= 4) ? 4 : 8;
-    const int gz = (P.B + S - 1) / S;
+    // streams per block = SPB (streams per LDS buffer) x NSUB (pipelined sub-chunks; taps computed once for all)
+    int S = spb == 2 ? 2 : 4, NS = nsub == 1 ? 1 : (nsub == 2 ? 2 : 4);
+    if (P.B <= S) NS = 1;
+    else if (P.B <= 2 * S && NS > 2) NS = 2;
+    const int per_block = S * NS;
+    const int gz = (P.B + per_block - 1) / per_block;
     dim3 grid(tiles_x * tiles_y, 2, gz);
-    if (tmode == 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
-    const size_t lds = (size_t)S * RT_PATCH + 64;
-    if (S == 4)
-      hipLaunchKernelGGL(rectify_tile_kernel<4>, grid, dim3(256), lds, st, src[0], src[1], src_row_stride,
-                         src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, tiles_x,
-                         tiles_y, gz, tmode);
-    else
-      hipLaunchKernelGGL(rectify_tile_kernel<8>, grid, dim3(256), lds, st, src[0], src[1], src_row_stride,
-                         src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, tiles_x,
-                         tiles_y, gz, tmode);
+    if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
+    const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * RT_PATCH + 64;
+#define KVFE_RT_LAUNCH(SPB_, NSUB_, MINW_)                                                                        \
+  hipLaunchKernelGGL((rectify_tile_kernel<SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],            \
+                     src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, \
+                     tiles_x, tiles_y, gz, tmode)
+    if (S == 2 && NS == 1) KVFE_RT_LAUNCH(2, 1, 8);
+    else if (S == 2 && NS == 2) KVFE_RT_LAUNCH(2, 2, 7);
+    else if (S == 2) KVFE_RT_LAUNCH(2, 4, 7);
+    else if (NS == 1) KVFE_RT_LAUNCH(4, 1, 7);
+    else if (NS == 2) KVFE_RT_LAUNCH(4, 2, 3);
+    else KVFE_RT_LAUNCH(4, 4, 3);
+#undef KVFE_RT_LAUNCH
     return;
   }
   const int gz = (P.B + RECT_SPB - 1) / RECT_SPB;

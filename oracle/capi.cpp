@@ -445,6 +445,43 @@ KVO_API void kvo_mt19937_draws(int policy, int n, int32_t* out) {  // SampleCons
   }
 }
 
+// ---- RGBD components on their own (pinned by tests/testRgbdFrame.cpp:85-165, tests/testDepthFrame.cpp:56-171) ----
+KVO_API void kvo_depth_detection_mask(const kvfe_depth_params* dp, const void* depth, int w, int h, size_t stride,
+                                      uint8_t* mask) {
+  std::vector<uint8_t> m;
+  kimera::depthDetectionMask(*dp, depth, w, h, stride, m);
+  std::memcpy(mask, m.data(), m.size());
+}
+KVO_API float kvo_depth_at_point(const kvfe_depth_params* dp, const void* depth, int w, int h, size_t stride, float x,
+                                 float y) {
+  return kimera::depthAtPoint(*dp, depth, w, h, stride, kimera::Point2f{x, y});
+}
+// RgbdFrame::fillStereoFrame with caller-provided left keypoints / rectified keypoints / statuses / versors
+KVO_API void kvo_rgbd_fill_stereo_frame(const kvfe_camera_params* cam, const kvfe_frontend_params* p,
+                                        const kvfe_depth_params* dp, const void* depth, int dw, int dh, size_t stride,
+                                        int n, const float* left_xy, const float* left_rect_xy,
+                                        const uint8_t* left_status, const double* versors, uint8_t* right_status,
+                                        float* right_rect_xy, double* depths, double* kp3d, float* right_xy) {
+  kimera::Frontend fe;
+  fe.initRgbd(*cam, *p, *dp);
+  kimera::StereoFrame sf;
+  for (int i = 0; i < n; i++) {
+    sf.left.keypoints.push_back(kimera::Point2f{left_xy[2 * i], left_xy[2 * i + 1]});
+    sf.left_kp_rect.push_back(kimera::StatusKeypoint{left_status[i], {left_rect_xy[2 * i], left_rect_xy[2 * i + 1]}});
+    for (int c = 0; c < 3; c++) sf.left.versors.push_back(versors[3 * i + c]);
+  }
+  fe.fillStereoFrame(sf, depth, stride, dw, dh);
+  for (int i = 0; i < n; i++) {
+    right_status[i] = (uint8_t)sf.right_kp_rect[i].status;
+    right_rect_xy[2 * i] = sf.right_kp_rect[i].kp.x;
+    right_rect_xy[2 * i + 1] = sf.right_kp_rect[i].kp.y;
+    depths[i] = sf.depth[i];
+    for (int c = 0; c < 3; c++) kp3d[3 * i + c] = sf.kp3d[3 * i + c];
+    right_xy[2 * i] = sf.right_kp[i].x;
+    right_xy[2 * i + 1] = sf.right_kp[i].y;
+  }
+}
+
 // ---- front-end ---------------------------------------------------------------
 struct kvo_frontend {
   kimera::Frontend fe;

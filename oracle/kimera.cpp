@@ -984,12 +984,12 @@ void Frontend::initRgbd(const kvfe_camera_params& c, const kvfe_frontend_params&
 }
 
 // DepthFrame::getDetectionMask (DepthFrame.cpp:76-96): cv::inRange(depth, min, max)
-void Frontend::depthDetectionMask(const void* depth, size_t stride, std::vector<uint8_t>& mask) const {
-  const int w = cam.w, h = cam.h;
+void depthDetectionMask(const kvfe_depth_params& dp, const void* depth, int w, int h, size_t stride,
+                        std::vector<uint8_t>& mask) {
   mask.assign((size_t)w * h, 0);
-  const float mn = depth_params.min_depth * 1.0f / depth_params.depth_to_meters;
-  const float mx = depth_params.max_depth * 1.0f / depth_params.depth_to_meters;
-  if (depth_params.depth_type == KVFE_DEPTH_F32) {
+  const float mn = dp.min_depth * 1.0f / dp.depth_to_meters;
+  const float mx = dp.max_depth * 1.0f / dp.depth_to_meters;
+  if (dp.depth_type == KVFE_DEPTH_F32) {
     const float* d = static_cast<const float*>(depth);
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
@@ -1006,10 +1006,29 @@ void Frontend::depthDetectionMask(const void* depth, size_t stride, std::vector<
       }
   }
 }
+void Frontend::depthDetectionMask(const void* depth, size_t stride, std::vector<uint8_t>& mask) const {
+  kimera::depthDetectionMask(depth_params, depth, cam.w, cam.h, stride, mask);
+}
+
+// DepthFrame::getDepthAtPoint (DepthFrame.cpp:40-74); (w, h) = size of the depth image
+float depthAtPoint(const kvfe_depth_params& dp, const void* depth, int w, int h, size_t stride, Point2f pt) {
+  const int x = static_cast<int>(pt.x), y = static_cast<int>(pt.y);
+  float d = std::numeric_limits<float>::quiet_NaN();
+  if (x < 0 || x >= w || y < 0 || y >= h) return d;
+  if (dp.depth_type == KVFE_DEPTH_F32)
+    d = static_cast<const float*>(depth)[(size_t)y * stride + x];
+  else
+    d = static_cast<const uint16_t*>(depth)[(size_t)y * stride + x];
+  d *= dp.depth_to_meters;
+  if (d < dp.min_depth) return std::numeric_limits<float>::quiet_NaN();
+  return d;
+}
 
 // RgbdFrame::fillStereoFrame (RgbdFrame.cpp:48-115) + DepthFrame::getDepthAtPoint (DepthFrame.cpp:40-74)
-void Frontend::fillStereoFrame(StereoFrame& sf, const void* depth, size_t stride) const {
-  const int w = cam.w, h = cam.h;
+void Frontend::fillStereoFrame(StereoFrame& sf, const void* depth, size_t stride, int dw, int dh) const {
+  const int w = cam.w;
+  if (dw <= 0) dw = cam.w;
+  if (dh <= 0) dh = cam.h;
   const size_t n = sf.left_kp_rect.size();
   const double fx_b = cam.left.intrinsics[0] * depth_params.virtual_baseline;
   sf.right_kp_rect.assign(n, StatusKeypoint{0, {0.f, 0.f}});
@@ -1022,17 +1041,7 @@ void Frontend::fillStereoFrame(StereoFrame& sf, const void* depth, size_t stride
       sf.right_kp_rect[i].status = lk.status;
       continue;
     }
-    const Point2f pt = sf.left.keypoints[i];
-    const int x = static_cast<int>(pt.x), y = static_cast<int>(pt.y);
-    float d = std::numeric_limits<float>::quiet_NaN();
-    if (!(x < 0 || x >= w || y < 0 || y >= h)) {
-      if (depth_params.depth_type == KVFE_DEPTH_F32)
-        d = static_cast<const float*>(depth)[(size_t)y * stride + x];
-      else
-        d = static_cast<const uint16_t*>(depth)[(size_t)y * stride + x];
-      d *= depth_params.depth_to_meters;
-      if (d < depth_params.min_depth) d = std::numeric_limits<float>::quiet_NaN();
-    }
+    const float d = depthAtPoint(depth_params, depth, dw, dh, stride, sf.left.keypoints[i]);
     if (!std::isfinite(d)) {
       sf.right_kp_rect[i].status = KVFE_KP_NO_DEPTH;
       continue;

@@ -178,6 +178,12 @@ void denseStereoReconstruction(const kvfe_dense_stereo_params& dp, const int roi
                                const uint8_t* left_rect, const uint8_t* right_rect, int w, int h,
                                size_t stride, short* disp);
 
+// DepthFrame::getDetectionMask (DepthFrame.cpp:76-96) / DepthFrame::getDepthAtPoint (DepthFrame.cpp:40-74) on a depth
+// image of (w, h) elements, uint16 or float per kvfe_depth_params::depth_type
+void depthDetectionMask(const kvfe_depth_params& dp, const void* depth, int w, int h, size_t stride,
+                        std::vector<uint8_t>& mask);
+float depthAtPoint(const kvfe_depth_params& dp, const void* depth, int w, int h, size_t stride, Point2f pt);
+
 struct Frontend {
   StereoCamera cam;
   kvfe_frontend_params p;
@@ -204,6 +210,10 @@ struct Frontend {
                const kvfe_frame_input& in);
   const StereoFrame& current() const { return km1; }
 
+ // RgbdFrame::fillStereoFrame (public so that the reference's component KAT can drive it, capi.cpp);
+  // (dw, dh) = size of the depth image; <= 0: the camera resolution
+  void fillStereoFrame(StereoFrame& sf, const void* depth, size_t depth_stride, int dw = 0, int dh = 0) const;
+
  private:
   void featureDetectionFrame(Frame& f, int* n_detected, const uint8_t* detection_mask = nullptr);
   void featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]);
@@ -214,7 +224,6 @@ struct Frontend {
   void outlierRejectionStereo(const double R[9], StereoFrame& lkf_sf, StereoFrame& k_sf);
   void processMono(const kvfe_frame_input& in);
   void processRgbd(const kvfe_frame_input& in, const void* depth, size_t depth_stride);
-  void fillStereoFrame(StereoFrame& sf, const void* depth, size_t depth_stride) const;
   void depthDetectionMask(const void* depth, size_t depth_stride, std::vector<uint8_t>& mask) const;
 };
 

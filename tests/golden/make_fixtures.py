@@ -51,5 +51,60 @@ def main():
     print("wrote", OUT, os.path.getsize(OUT) / 1e6, "MB")
 
 
+def bgr2gray_opencv(rgb: np.ndarray) -> np.ndarray:
+    """cv::cvtColor(COLOR_BGR2GRAY) on 8-bit data: fixed point, 14 fractional bits, coefficients
+    R 4899, G 9617, B 1868 (0.299, 0.587, 0.114), rounded -- what UtilsOpenCV::ReadAndConvertToGrayScale
+    (src/utils/UtilsOpenCV.cpp:390-403) applies to a 3-channel file.  (PIL's convert("L") uses other constants.)"""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+REF = "/root/reference/tests/data"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def fisheye_golden():
+    """tests/testUndistortRectifier.cpp:270-347 (DISABLED_undistortFisheyeStereoFrame): the reference's own
+    real-OpenCV rectified fisheye pair.  The PNG is RGB with R = G = B; stored as one grey channel."""
+    import shutil
+    shutil.copy(os.path.join(REF, "ForStereoFrame", "right_fisheye_img_0.png"), HERE)
+    sb = np.array(Image.open(os.path.join(REF, "ForStereoFrame", "sidebyside_ref_img_0.png")))
+    assert sb.ndim == 3 and np.array_equal(sb[..., 0], sb[..., 1]) and np.array_equal(sb[..., 0], sb[..., 2])
+    Image.fromarray(sb[..., 0]).save(os.path.join(HERE, "sidebyside_ref_img_0_gray.png"), optimize=True)
+
+
+def stereo_tracker_frames():
+    """tests/testStereoVisionImuFrontend.cpp:674-926 (testDisparityCheck): the three JPEG stereo pairs it replays,
+    decoded here (PIL / libjpeg-turbo, the decoder family OpenCV's imread uses) and converted to grey with OpenCV's
+    BGR2GRAY arithmetic; the camera YAMLs of that test."""
+    import shutil
+    d = os.path.join(REF, "ForStereoTracker")
+    out = {}
+    for side in ("left", "right"):
+        out[side] = np.stack([bgr2gray_opencv(np.array(Image.open(os.path.join(d, f"{side}_frame{n:04d}.jpg")).convert("RGB")))
+                              for n in (0, 1, 8)])
+    np.savez_compressed(os.path.join(HERE, "ForStereoTracker", "frames_0_1_8.npz"), lefts=out["left"],
+                        rights=out["right"], frame_numbers=np.array([0, 1, 8]))
+    for f in ("camLeftEuroc.yaml", "camRightEuroc.yaml"):
+        shutil.copy(os.path.join(d, f), os.path.join(HERE, "ForStereoTracker"))
+
+
+def rgbd_frames():
+    """tests/testDepthFrame.cpp / tests/testRgbdFrame.cpp data: two colour images (grey via BGR2GRAY) and their
+    float32 depth images (metres), the camera YAML with the depth block."""
+    import shutil
+    d = os.path.join(REF, "ForRgbd")
+    os.makedirs(os.path.join(HERE, "ForRgbd"), exist_ok=True)
+    lefts = np.stack([bgr2gray_opencv(np.array(Image.open(os.path.join(d, f"left_img_{i}.png")).convert("RGB")))
+                      for i in (0, 1)])
+    depths = np.stack([np.array(Image.open(os.path.join(d, f"depth_img_{i}.tiff"))) for i in (0, 1)])
+    assert depths.dtype == np.float32
+    np.savez_compressed(os.path.join(HERE, "ForRgbd", "rgbd_0_1.npz"), lefts=lefts, depths=depths)
+    shutil.copy(os.path.join(d, "sensorLeft.yaml"), os.path.join(HERE, "ForRgbd"))
+
+
 if __name__ == "__main__":
     main()
+    fisheye_golden()
+    stereo_tracker_frames()
+    rgbd_frames()

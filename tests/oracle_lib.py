@@ -123,6 +123,12 @@ def lib() -> C.CDLL:
     L.kvo_frontend_time_sequence.restype = C.c_double
     L.kvo_frontend_time_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                              C.c_int, C.c_void_p]
+    L.kvo_depth_detection_mask.argtypes = [C.POINTER(abi.DepthParams), vp, C.c_int, C.c_int, C.c_size_t, vp]
+    L.kvo_depth_at_point.restype = C.c_float
+    L.kvo_depth_at_point.argtypes = [C.POINTER(abi.DepthParams), vp, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float]
+    L.kvo_rgbd_fill_stereo_frame.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.FrontendParams),
+                                             C.POINTER(abi.DepthParams), vp, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -650,3 +656,43 @@ def crop_to_size(px, w, h, round_first=False):
     L.kvo_crop_to_size.restype = C.c_int
     c = L.kvo_crop_to_size(_p(p), int(w), int(h), int(round_first))
     return (float(p[0]), float(p[1])), bool(c)
+
+
+# ---- RGBD components on their own (tests/test_oracle_kat.py: tests/testRgbdFrame.cpp, tests/testDepthFrame.cpp) ----
+def _depth_array(depth, dp: abi.DepthParams):
+    return np.ascontiguousarray(depth, np.float32 if dp.depth_type == abi.DEPTH_F32 else np.uint16)
+
+
+def depth_detection_mask(depth, dp: abi.DepthParams) -> np.ndarray:
+    """DepthFrame::getDetectionMask (DepthFrame.cpp:76-96)"""
+    d = _depth_array(depth, dp)
+    h, w = d.shape
+    mask = np.zeros((h, w), np.uint8)
+    lib().kvo_depth_detection_mask(C.byref(dp), _p(d), w, h, w, _p(mask))
+    return mask
+
+
+def depth_at_point(depth, dp: abi.DepthParams, x: float, y: float) -> float:
+    """DepthFrame::getDepthAtPoint (DepthFrame.cpp:40-74)"""
+    d = _depth_array(depth, dp)
+    h, w = d.shape
+    return float(lib().kvo_depth_at_point(C.byref(dp), _p(d), w, h, w, float(x), float(y)))
+
+
+def rgbd_fill_stereo_frame(cam: abi.CameraParams, params: abi.FrontendParams, dp: abi.DepthParams, depth,
+                           left_xy, left_rect_xy, left_status, versors) -> dict:
+    """RgbdFrame::fillStereoFrame (RgbdFrame.cpp:48-115)"""
+    d = _depth_array(depth, dp)
+    h, w = d.shape
+    lx = np.ascontiguousarray(left_xy, np.float32).reshape(-1, 2)
+    n = len(lx)
+    lr = np.ascontiguousarray(left_rect_xy, np.float32).reshape(-1, 2)
+    ls = np.ascontiguousarray(left_status, np.uint8)
+    v = np.ascontiguousarray(versors, np.float64).reshape(-1, 3)
+    out = dict(right_status=np.zeros(n, np.uint8), right_rect_xy=np.zeros((n, 2), np.float32),
+               depth=np.zeros(n, np.float64), keypoints_3d=np.zeros((n, 3), np.float64),
+               right_xy=np.zeros((n, 2), np.float32))
+    lib().kvo_rgbd_fill_stereo_frame(C.byref(cam), C.byref(params), C.byref(dp), _p(d), w, h, w, n, _p(lx), _p(lr),
+                                     _p(ls), _p(v), _p(out["right_status"]), _p(out["right_rect_xy"]),
+                                     _p(out["depth"]), _p(out["keypoints_3d"]), _p(out["right_xy"]))
+    return out
