@@ -461,7 +461,7 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
   static const int impl = std::getenv("KVFE_RECT_IMPL") ? std::atoi(std::getenv("KVFE_RECT_IMPL")) : 1;
   static const int tmode = (std::getenv("KVFE_RECT_TILE_MODE") ? std::atoi(std::getenv("KVFE_RECT_TILE_MODE")) & 1 : 0) |
                            (std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0);
-  static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 4;
+  static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 2;
   static const int nsub = std::getenv("KVFE_RECT_NSUB") ? std::atoi(std::getenv("KVFE_RECT_NSUB")) : 4;
   const bool aligned = P.W % 4 == 0 && src_row_stride % 16 == 0 && src_img_stride % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(src[0]) % 16 == 0 && reinterpret_cast<uintptr_t>(src[1]) % 16 == 0;
