@@ -207,11 +207,13 @@ __global__ __launch_bounds__(256) void rectify_kernel(
 // Blocks whose box does not fit (exotic maps) take the gather path of the same kernel, so any map
 // is handled; images whose rows are not 16-byte aligned use rectify_kernel above.
 // ---------------------------------------------------------------------------------------------
-constexpr int RT_W = 128, RT_H = 16;
-constexpr int RT_CPR = 10;                       // 16-byte chunks per staged source row
-constexpr int RT_PITCH = RT_CPR * 16;
-constexpr int RT_ROWS = 32;                      // staged source rows per stream
-constexpr int RT_PATCH = RT_PITCH * (RT_ROWS + 1) + 16;  // folded taps read one row / byte further (weight 0)
+constexpr int RT_W = 128;                        // tile width; the tile height TH (16 | 32) is a template parameter
+constexpr int RT_CPR = 16;                       // 16-byte chunk slots per staged source row: the row pitch of 256 B
+constexpr int RT_PITCH = RT_CPR * 16;            //   = 64 banks keeps the 32 lanes of a row group on 32 different banks
+                                                 //   however the map drifts across source rows (a 160-B pitch cost
+                                                 //   2.2 bank-conflict cycles per LDS cycle)
+constexpr int rt_rows(int th) { return th + 16; }          // staged source rows per stream
+constexpr int rt_patch(int th) { return RT_PITCH * (rt_rows(th) + 1) + 16; }  // folded taps read one row / byte further
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
 typedef __attribute__((address_space(1))) const unsigned char glb_cu8_t;
@@ -274,7 +276,7 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-template <int SPB, int NSUB, int MINW>
+template <int TH, int SPB, int NSUB, int MINW>
 __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1, size_t src_row_stride,
     size_t src_img_stride, unsigned char* __restrict__ dst0, unsigned char* __restrict__ dst1,
@@ -282,6 +284,9 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int NBUF = NSUB > 1 ? 2 : 1;   // LDS boxes: SPB streams x NBUF buffers
+  constexpr int NR = TH / 8;               // tile rows per lane
+  constexpr int RT_ROWS = rt_rows(TH), RT_PATCH = rt_patch(TH);
+  constexpr int NIT = (RT_ROWS * RT_CPR + 255) / 256;   // DMA wave-instructions per lane and box
   int* bounds = reinterpret_cast<int*>(sm + (size_t)SPB * NBUF * RT_PATCH);   // [4 waves][4]
   int tx, ty, cam, s_begin;
   if ((mode & 1) == 0) {  // 3-D grid (tile, camera, stream group)
@@ -313,13 +318,13 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = tid & 31, ly = tid >> 5;
   const int x = tx * RT_W + lx * 4;
-  const int y0 = ty * RT_H + ly;
-  // ---- phase A: taps of this lane's 2 x 4 pixels ----------------------------------------------------------
-  RTap tp[8];
+  const int y0 = ty * TH + ly;
+  // ---- phase A: taps of this lane's NR x 4 pixels ----------------------------------------------------------
+  RTap tp[4 * NR];
   int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
-  bool okr[2];
+  bool okr[NR];
 #pragma unroll
-  for (int r = 0; r < 2; r++) {
+  for (int r = 0; r < NR; r++) {
     const int y = y0 + 8 * r;
     okr[r] = x < W && y < H;
     if (okr[r]) {
@@ -376,11 +381,11 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     // ---- phase B: LDS-DMA of the source boxes, phase C: blend; software pipeline over sub-chunks of SPB streams:
     //      the boxes of sub-chunk j+1 are in flight while sub-chunk j is blended (two LDS buffers) ----------------
     const int n = ph * RT_CPR;
-    // this lane's (at most two) 16-byte chunks of a box: offsets are the same for every stream
-    int goff[2];
-    bool gok[2];
+    // this lane's (at most NIT) 16-byte chunks of a box: offsets are the same for every stream
+    int goff[NIT];
+    bool gok[NIT];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < NIT; it++) {
       const int c = wave * 64 + it * 256 + lane;
       const int row = c / RT_CPR, ch = c - row * RT_CPR;
       gok[it] = c < n && ch < ncx;
@@ -394,16 +399,16 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
         if (!((act >> (j * SPB + k)) & 1u)) continue;
         const unsigned char* S = Sbase + (size_t)(s_begin + j * SPB + k) * src_img_stride;
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
+        for (int it = 0; it < NIT; it++) {
           if (wave * 64 + it * 256 < n && gok[it])
             __builtin_amdgcn_global_load_lds((glb_cu8_t*)(S + goff[it]),
                                              (lds_u8_t*)(pb + k * RT_PATCH + (wave * 64 + it * 256) * 16), 16, 0, 0);
         }
       }
     };
-    unsigned ad[8];
+    unsigned ad[4 * NR];
 #pragma unroll
-    for (int q = 0; q < 8; q++) ad[q] = (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
+    for (int q = 0; q < 4 * NR; q++) ad[q] = (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
     issue(0);
 #pragma unroll
     for (int j = 0; j < NSUB; j++) {
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
         const unsigned char* pk = pb + k * RT_PATCH;
         unsigned char* D = dst + (size_t)(s_begin + j * SPB + k) * N;
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
+        for (int r = 0; r < NR; r++) {
           if (!okr[r]) continue;
           unsigned px[4];
 #pragma unroll
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
       const unsigned char* S = src + (size_t)(s_begin + k) * src_img_stride;
       unsigned char* D = dst + (size_t)(s_begin + k) * N;
 #pragma unroll 1
-      for (int e = 0; e < 8; e++) {
+      for (int e = 0; e < 4 * NR; e++) {
         const int y = y0 + 8 * (e >> 2);
         if (x >= W || y >= H) continue;
         const int i = y * W + x + (e & 3);
@@ -463,29 +468,37 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
                            (std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0);
   static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 2;
   static const int nsub = std::getenv("KVFE_RECT_NSUB") ? std::atoi(std::getenv("KVFE_RECT_NSUB")) : 4;
+  static const int th = std::getenv("KVFE_RECT_TH") ? std::atoi(std::getenv("KVFE_RECT_TH")) : 16;
   const bool aligned = P.W % 4 == 0 && src_row_stride % 16 == 0 && src_img_stride % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(src[0]) % 16 == 0 && reinterpret_cast<uintptr_t>(src[1]) % 16 == 0;
   if (impl == 1 && aligned) {
-    const int tiles_x = (P.W + RT_W - 1) / RT_W, tiles_y = (P.H + RT_H - 1) / RT_H;
+    const int TH = th == 16 ? 16 : 32;
+    const int tiles_x = (P.W + RT_W - 1) / RT_W, tiles_y = (P.H + TH - 1) / TH;
     // streams per block = SPB (streams per LDS buffer) x NSUB (pipelined sub-chunks; taps computed once for all)
-    int S = spb == 2 ? 2 : 4, NS = nsub == 1 ? 1 : (nsub == 2 ? 2 : 4);
+    int S = spb == 1 ? 1 : 2, NS = nsub == 1 ? 1 : (nsub == 2 ? 2 : 4);
     if (P.B <= S) NS = 1;
     else if (P.B <= 2 * S && NS > 2) NS = 2;
     const int per_block = S * NS;
     const int gz = (P.B + per_block - 1) / per_block;
     dim3 grid(tiles_x * tiles_y, 2, gz);
     if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
-    const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * RT_PATCH + 64;
-#define KVFE_RT_LAUNCH(SPB_, NSUB_, MINW_)                                                                        \
-  hipLaunchKernelGGL((rectify_tile_kernel<SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],            \
+    const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * rt_patch(TH) + 64;
+#define KVFE_RT_LAUNCH(TH_, SPB_, NSUB_, MINW_)                                                                     \
+  hipLaunchKernelGGL((rectify_tile_kernel<TH_, SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],        \
                      src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, \
                      tiles_x, tiles_y, gz, tmode)
-    if (S == 2 && NS == 1) KVFE_RT_LAUNCH(2, 1, 8);
-    else if (S == 2 && NS == 2) KVFE_RT_LAUNCH(2, 2, 7);
-    else if (S == 2) KVFE_RT_LAUNCH(2, 4, 7);
-    else if (NS == 1) KVFE_RT_LAUNCH(4, 1, 7);
-    else if (NS == 2) KVFE_RT_LAUNCH(4, 2, 3);
-    else KVFE_RT_LAUNCH(4, 4, 3);
+#define KVFE_RT_DISPATCH(TH_, W1_, W2_)                 \
+  do {                                                  \
+    if (S == 1 && NS == 1) KVFE_RT_LAUNCH(TH_, 1, 1, W1_);      \
+    else if (S == 1 && NS == 2) KVFE_RT_LAUNCH(TH_, 1, 2, W1_); \
+    else if (S == 1) KVFE_RT_LAUNCH(TH_, 1, 4, W1_);            \
+    else if (NS == 1) KVFE_RT_LAUNCH(TH_, 2, 1, W1_);           \
+    else if (NS == 2) KVFE_RT_LAUNCH(TH_, 2, 2, W2_);           \
+    else KVFE_RT_LAUNCH(TH_, 2, 4, W2_);                        \
+  } while (0)
+    if (TH == 16) KVFE_RT_DISPATCH(16, 7, 4);
+    else KVFE_RT_DISPATCH(32, 4, 3);
+#undef KVFE_RT_DISPATCH
 #undef KVFE_RT_LAUNCH
     return;
   }
