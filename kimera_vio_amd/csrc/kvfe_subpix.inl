@@ -4,6 +4,14 @@
 // OpenCV's row-major order (lanes 0-4 each own one accumulator) => bit-identical to the CPU path.
 __device__ __forceinline__ int cv_floorf(float v) { return (int)floorf(v); }
 
+// phase stamps for tools/ubench/subpix_phases.hip (cycle counter deltas per phase of an iteration); no-ops in the
+// library build
+#ifdef KVFE_SUBPIX_PROF
+#define KVFE_SP_T(i) do { const unsigned long long _t = __builtin_readcyclecounter(); kvfe_sp_acc[i] += _t - kvfe_sp_last; kvfe_sp_last = _t; } while (0)
+#else
+#define KVFE_SP_T(i) do { } while (0)
+#endif
+
 // cv::getRectSubPix(u8 -> f32) of a (n x n) window centred at c, into LDS `dst` (row stride n)
 static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, size_t step, int W, int H,
                                   float cx, float cy, int n, float* dst, int lane) {
@@ -221,7 +229,11 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
   float2 cI = cT;
   int iter = 0;
   double err = 0;
+#ifdef KVFE_SUBPIX_PROF
+  unsigned long long kvfe_sp_acc[6] = {0, 0, 0, 0, 0, 0}, kvfe_sp_last = __builtin_readcyclecounter();
+#endif
   do {
+    KVFE_SP_T(5);
     {
       const float ccx = cI.x - (pw - 1) * 0.5f, ccy = cI.y - (pw - 1) * 0.5f;
       const int ipx = cv_floorf(ccx), ipy = cv_floorf(ccy);
@@ -253,6 +265,7 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
         rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane);
     }
     __syncthreads();
+    KVFE_SP_T(0);
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
       const int k = lane + 64 * t;
@@ -272,6 +285,7 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
       }
     }
     __syncthreads();
+    KVFE_SP_T(1);
     // the five sequential float64 chains (lanes 0-4): a dependent v_add_f64 issues every ~6 cycles
     // as long as its operand has landed, so the loop only has to keep LDS reads ahead of the adds
     double acc = 0;
@@ -289,9 +303,11 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
         }
       }
     }
+    KVFE_SP_T(2);
     const double a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2), bb1 = __shfl(acc, 3),
                  bb2 = __shfl(acc, 4);
     __syncthreads();
+    KVFE_SP_T(3);
     const double det = a * c - b * b;
     if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
     const double scale = 1.0 / det;
@@ -301,7 +317,13 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
     err = (double)((cI2.x - cI.x) * (cI2.x - cI.x) + (cI2.y - cI.y) * (cI2.y - cI.y));
     cI = cI2;
     if (cI.x < 0 || cI.x >= W || cI.y < 0 || cI.y >= H) break;
+    KVFE_SP_T(4);
   } while (++iter < max_iters && err > eps2);
+#ifdef KVFE_SUBPIX_PROF
+  if (lane == 0 && kvfe_sp_out)
+    for (int i = 0; i < 6; i++) kvfe_sp_out[i] = kvfe_sp_acc[i];
+  if (lane == 0 && kvfe_sp_out) kvfe_sp_out[6] = (unsigned long long)iter;
+#endif
   if (fabsf(cI.x - cT.x) > win || fabsf(cI.y - cT.y) > win) cI = cT;
   return cI;
 }
