@@ -12,6 +12,7 @@
 // lambda > maxVal*quality afterwards on the compacted list.  HBM traffic per image: one read of
 // the image (+ the optional user mask); the detection mask "255 minus filled discs around the
 // tracked keypoints" is evaluated analytically from the keypoint list (exact cv::circle spans).
+#include <cstdlib>
 #include <mutex>
 #include "kvfe_dev.hpp"
 
@@ -1023,8 +1024,8 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
 // cv::undistortPoints of one pixel (double), shared with k_stereo.hip via kvfe_undistort.inl
 #include "kvfe_undistort.inl"
 
-template <int WIN>
-__global__ __launch_bounds__(64) void subpix_append_kernel(KParams P, Tables T,
+template <int WIN, int NW>
+__global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Tables T,
                                                            const unsigned char* __restrict__ img,
                                                            size_t row_stride, size_t img_stride,
                                                            FrameTab K, StreamState S,
@@ -1037,8 +1038,8 @@ __global__ __launch_bounds__(64) void subpix_append_kernel(KParams P, Tables T,
   const int lane = threadIdx.x;
   float2 c = D.newc[(size_t)s * P.acap + ci];
   if (P.subpix_enable) {
-    c = corner_subpix_wave<WIN>(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
-                           P.subpix_iters, P.subpix_eps2, T.subpix_mask, lds_raw, lane);
+    c = corner_subpix_wave<WIN, NW>(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
+                               P.subpix_iters, P.subpix_eps2, T.subpix_mask, lds_raw, lane);
   }
   if (lane == 0) {
     if (append) {
@@ -1077,18 +1078,23 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
     bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
   bound = min(bound, P.acap);
-  if (P.subpix_win == 10)
-    hipLaunchKernelGGL(subpix_append_kernel<10>, dim3(bound, P.B), dim3(64), lds, st, P, T, img,
+  // KVFE_SUBPIX_WAVES=1: one wave per corner (LDS-ring chains); default 2 (DPP broadcast chains, kvfe_subpix.inl)
+  static const int nw = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 2;
+  if (P.subpix_win == 10 && nw == 2)
+    hipLaunchKernelGGL((subpix_append_kernel<10, 2>), dim3(bound, P.B), dim3(128), lds, st, P, T, img,
+                       row_stride, img_stride, k, S, D, append);
+  else if (P.subpix_win == 10)
+    hipLaunchKernelGGL((subpix_append_kernel<10, 1>), dim3(bound, P.B), dim3(64), lds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append);
   else
-    hipLaunchKernelGGL(subpix_append_kernel<0>, dim3(bound, P.B), dim3(64), lds, st, P, T, img,
+    hipLaunchKernelGGL((subpix_append_kernel<0, 1>), dim3(bound, P.B), dim3(64), lds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append);
   if (append)
     hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D);
 }
 
-template <int WIN>
-__global__ __launch_bounds__(64) void subpix_points_kernel(const float* __restrict__ mask,
+template <int WIN, int NW>
+__global__ __launch_bounds__(64 * NW) void subpix_points_kernel(const float* __restrict__ mask,
                                                            const unsigned char* __restrict__ img,
                                                            size_t row_stride, int W, int H,
                                                            float2* pts, int n, int win,
@@ -1096,8 +1102,8 @@ __global__ __launch_bounds__(64) void subpix_points_kernel(const float* __restri
   const int ci = blockIdx.x;
   if (ci >= n) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const float2 c = corner_subpix_wave<WIN>(img, row_stride, W, H, pts[ci], win, max_iters, eps2, mask,
-                                      lds_raw, threadIdx.x);
+  const float2 c = corner_subpix_wave<WIN, NW>(img, row_stride, W, H, pts[ci], win, max_iters, eps2, mask,
+                                          lds_raw, threadIdx.x);
   if (threadIdx.x == 0) pts[ci] = c;
 }
 
@@ -1106,11 +1112,15 @@ void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigne
                           int max_iters, double eps2, hipStream_t st) {
   if (n <= 0) return;
   const size_t lds = subpix_geom(win).bytes;
-  if (win == 10)
-    hipLaunchKernelGGL(subpix_points_kernel<10>, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
+  static const int nw = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 2;
+  if (win == 10 && nw == 2)
+    hipLaunchKernelGGL((subpix_points_kernel<10, 2>), dim3(n), dim3(128), lds, st, mask_tab, img, row_stride,
+                       W, H, pts, n, win, max_iters, eps2);
+  else if (win == 10)
+    hipLaunchKernelGGL((subpix_points_kernel<10, 1>), dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
                        W, H, pts, n, win, max_iters, eps2);
   else
-    hipLaunchKernelGGL(subpix_points_kernel<0>, dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
+    hipLaunchKernelGGL((subpix_points_kernel<0, 1>), dim3(n), dim3(64), lds, st, mask_tab, img, row_stride,
                        W, H, pts, n, win, max_iters, eps2);
 }
 

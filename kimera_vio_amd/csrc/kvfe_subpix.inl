@@ -14,7 +14,7 @@ __device__ __forceinline__ int cv_floorf(float v) { return (int)floorf(v); }
 
 // cv::getRectSubPix(u8 -> f32) of a (n x n) window centred at c, into LDS `dst` (row stride n)
 static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, size_t step, int W, int H,
-                                  float cx, float cy, int n, float* dst, int lane) {
+                                  float cx, float cy, int n, float* dst, int lane, int nthr = 64) {
   const float ccx = cx - (n - 1) * 0.5f, ccy = cy - (n - 1) * 0.5f;
   const int ipx = cv_floorf(ccx), ipy = cv_floorf(ccy);
   if (0 <= ipx && ipx + n < W && 0 <= ipy && ipy + n < H) {
@@ -24,7 +24,7 @@ static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, 
     const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
     const double sc = (1. - a) / a;
     const unsigned char* S = img + (size_t)ipy * step + ipx;
-    for (int e = lane; e < n * n; e += 64) {
+    for (int e = lane; e < n * n; e += nthr) {
       const int i = e / n, j = e - i * n;
       const unsigned char* R = S + (size_t)i * step;
       float prev;
@@ -62,7 +62,7 @@ static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, 
       if (rh < 0) rh = 0;
     }
     const int row0 = ipy >= 0 ? ipy : 0;
-    for (int e = lane; e < n * n; e += 64) {
+    for (int e = lane; e < n * n; e += nthr) {
       const int i = e / n, j = e - i * n;
       // running source row after i window rows: advances once per row with r.y <= row < r.height
       int adv = min(i, rh) - min(i, ry);
@@ -93,7 +93,7 @@ static __device__ void rect_subpix_8u32f(const unsigned char* __restrict__ img, 
 // LDS carve-up of corner_subpix_wave (bytes), shared by the kernels and their launchers
 struct SubpixGeom {
   int ww, pw, nt, ntp, ts, rs;
-  size_t terms_off, patch_off, stage_off, bytes;
+  size_t terms_off, patch_off, stage_off, res_off, bytes;
 };
 __host__ __device__ inline SubpixGeom subpix_geom(int win) {
   SubpixGeom g;
@@ -107,13 +107,14 @@ __host__ __device__ inline SubpixGeom subpix_geom(int win) {
   g.terms_off = 0;
   g.patch_off = sizeof(double) * 5 * (size_t)g.ts;
   g.stage_off = g.patch_off + sizeof(float) * (size_t)g.pw * g.pw;
-  g.bytes = (g.stage_off + (size_t)g.rs * g.rs + 15) & ~(size_t)15;
+  g.res_off = (g.stage_off + (size_t)g.rs * g.rs + 15) & ~(size_t)15;   // five float64 sums (two-wave variant)
+  g.bytes = g.res_off + 64;
   return g;
 }
 
 // interior branch of cv::getRectSubPix reading the source from the LDS stage (row stride rs);
 // eij[t] = (i << 8) | j of this lane's patch entries e = lane + 64 t (fixed per corner)
-template <int MAXP>
+template <int MAXP, int NTHR = 64>
 static __device__ __forceinline__ void rect_subpix_from_stage(const unsigned char* stage, int rs,
                                                               int dx0, int dy0, float ccx, float ccy,
                                                               int ipx, int ipy, int n,
@@ -127,7 +128,7 @@ static __device__ __forceinline__ void rect_subpix_from_stage(const unsigned cha
   const unsigned char* S = stage + dy0 * rs + dx0;
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
-    const int e = lane + 64 * t;
+    const int e = lane + NTHR * t;
     if (e < n * n) {
       const int i = eij[t] >> 8, j = eij[t] & 255;
       const unsigned char* R = S + i * rs;
@@ -187,17 +188,78 @@ static __device__ __forceinline__ double lds_chain_sum(const double* base_lds) {
   return acc;
 }
 
+// Two-wave variant of the chains (WIN = 10: 448 zero-padded terms per chain).  A lone wave issues one instruction
+// per ~5 cycles whatever its type (tools/ubench/subpix_phases.hip: the LDS-ring walk above costs 6.2-7.2 k cycles
+// per iteration, 2 instructions per add), and a dependent v_add_f64 has 6.1 cycles of latency, so the floor is one
+// instruction per add.  gfx950 has it: v_fmac_f64 is a VOP2 instruction and DP-ALU DPP supports row_newbcast, so
+//     v_fmac_f64_dpp acc, T[m], 1.0 row_newbcast:p          acc = fma(T[m] of lane p of this row, 1.0, acc)
+// adds, in every lane of a DPP row, the term held by lane p: fma(t, 1, acc) is the correctly rounded acc + t, i.e.
+// bit-identical to v_add_f64.  Lane p of row r holds terms 28 p .. 28 p + 27 of chain r in registers (14
+// ds_read_b128), the 448 adds of a chain are 448 instructions with no LDS traffic and no waits, four chains ride in
+// the four DPP rows of wave 0 and the fifth in wave 1 on another SIMD.
+// One asm statement per source lane p: 28 dependent v_fmac_f64_dpp (hipcc pads every asm statement with an s_nop,
+// which is an issue slot of the lone wave: one statement per add would double the chain).  Operands: %0 acc, %1 1.0,
+// %2..%29 the 28 terms -- 30 operands, the most an asm statement takes.
+#define KVFE_FM1(P_, I_) "v_fmac_f64_dpp %0, %" #I_ ", %1 row_newbcast:" #P_ " row_mask:0xf bank_mask:0xf\n\t"
+#define KVFE_FM28(P_)                                                                                                 \
+  KVFE_FM1(P_, 2) KVFE_FM1(P_, 3) KVFE_FM1(P_, 4) KVFE_FM1(P_, 5) KVFE_FM1(P_, 6) KVFE_FM1(P_, 7) KVFE_FM1(P_, 8)         \
+  KVFE_FM1(P_, 9) KVFE_FM1(P_, 10) KVFE_FM1(P_, 11) KVFE_FM1(P_, 12) KVFE_FM1(P_, 13) KVFE_FM1(P_, 14) KVFE_FM1(P_, 15)   \
+  KVFE_FM1(P_, 16) KVFE_FM1(P_, 17) KVFE_FM1(P_, 18) KVFE_FM1(P_, 19) KVFE_FM1(P_, 20) KVFE_FM1(P_, 21) KVFE_FM1(P_, 22) \
+  KVFE_FM1(P_, 23) KVFE_FM1(P_, 24) KVFE_FM1(P_, 25) KVFE_FM1(P_, 26) KVFE_FM1(P_, 27) KVFE_FM1(P_, 28) KVFE_FM1(P_, 29)
+#define KVFE_CHAIN_LANE(P_)                                                                                           \
+  asm volatile(KVFE_FM28(P_)                                                                                          \
+               : "+v"(acc)                                                                                            \
+               : "v"(one), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6]), "v"(T[7]),     \
+                 "v"(T[8]), "v"(T[9]), "v"(T[10]), "v"(T[11]), "v"(T[12]), "v"(T[13]), "v"(T[14]), "v"(T[15]),        \
+                 "v"(T[16]), "v"(T[17]), "v"(T[18]), "v"(T[19]), "v"(T[20]), "v"(T[21]), "v"(T[22]), "v"(T[23]),      \
+                 "v"(T[24]), "v"(T[25]), "v"(T[26]), "v"(T[27]))
+// chain_base: this lane's 28 consecutive terms (16-byte aligned LDS address)
+static __device__ __forceinline__ double dpp_chain_sum448(const double* chain_base) {
+  const kvfe_d2* src = reinterpret_cast<const kvfe_d2*>(chain_base);
+  double T[28];
+#pragma unroll
+  for (int m = 0; m < 14; m++) {
+    const kvfe_d2 v = src[m];
+    T[2 * m] = v.x;
+    T[2 * m + 1] = v.y;
+  }
+  double one = 1.0, acc = 0.0;
+  // the terms come from LDS loads (no VALU write feeds a DPP read); `one` and `acc` are not DPP operands
+  asm volatile("s_nop 1" : "+v"(one), "+v"(acc));
+  KVFE_CHAIN_LANE(0);
+  KVFE_CHAIN_LANE(1);
+  KVFE_CHAIN_LANE(2);
+  KVFE_CHAIN_LANE(3);
+  KVFE_CHAIN_LANE(4);
+  KVFE_CHAIN_LANE(5);
+  KVFE_CHAIN_LANE(6);
+  KVFE_CHAIN_LANE(7);
+  KVFE_CHAIN_LANE(8);
+  KVFE_CHAIN_LANE(9);
+  KVFE_CHAIN_LANE(10);
+  KVFE_CHAIN_LANE(11);
+  KVFE_CHAIN_LANE(12);
+  KVFE_CHAIN_LANE(13);
+  KVFE_CHAIN_LANE(14);
+  KVFE_CHAIN_LANE(15);
+  return acc;
+}
+
 // WIN > 0: window half size fixed at compile time (all loops unroll, divisions fold); WIN == 0:
 // any half size up to 15 at run time.
-template <int WIN>
+// NW = number of wavefronts working on the corner (block of 64 NW threads, `lane` = thread index in the block):
+// 1, or 2 for WIN = 10 (patch and term work split between the waves, chains by dpp_chain_sum448).
+template <int WIN, int NW = 1>
 static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ img, size_t step, int W,
                                        int H, float2 cT, int win_rt, int max_iters, double eps2,
                                        const float* __restrict__ mask, unsigned char* lds, int lane) {
+  static_assert(NW == 1 || (NW == 2 && WIN == 10), "the two-wave variant is written for half size 10");
+  constexpr int NTHR = 64 * NW;
   const int win = WIN > 0 ? WIN : win_rt;
   const SubpixGeom G = subpix_geom(win);
   const int ww = G.ww, pw = G.pw, nt = G.nt, ntp = G.ntp, ts = G.ts, rs = G.rs;
-  constexpr int MAXT = WIN > 0 ? ((2 * WIN + 1) * (2 * WIN + 1) + 63) / 64 : 16;
-  constexpr int MAXP = WIN > 0 ? ((2 * WIN + 3) * (2 * WIN + 3) + 63) / 64 : 18;
+  constexpr int MAXT = WIN > 0 ? ((2 * WIN + 1) * (2 * WIN + 1) + NTHR - 1) / NTHR : 16;
+  constexpr int MAXP = WIN > 0 ? ((2 * WIN + 3) * (2 * WIN + 3) + NTHR - 1) / NTHR : 18;
   double* terms = reinterpret_cast<double*>(lds + G.terms_off);
   float* patch = reinterpret_cast<float*>(lds + G.patch_off);
   unsigned char* stage = lds + G.stage_off;
@@ -206,7 +268,7 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
   int pij[MAXT];            // (i << 8) | j
 #pragma unroll
   for (int t = 0; t < MAXT; t++) {
-    const int k = lane + 64 * t;
+    const int k = lane + NTHR * t;
     mk[t] = 0.f;
     pij[t] = 0;
     if (k < nt) {
@@ -218,11 +280,11 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
   int eij[MAXP];            // patch entries e = lane + 64 t of the (2w+3)^2 window
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
-    const int e = lane + 64 * t;
+    const int e = lane + NTHR * t;
     const int i = e / pw;
     eij[t] = (i << 8) | (e - i * pw);
   }
-  for (int k = nt + lane; k < ntp; k += 64)
+  for (int k = nt + lane; k < ntp; k += NTHR)
     for (int q = 0; q < 5; q++) terms[q * ts + k] = 0.0;
   int sx0 = 0, sy0 = 0;
   bool staged = false;
@@ -245,7 +307,7 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
           const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
           if (nx0 >= 0 && ny0 >= 0) {
             __syncthreads();
-            for (int e = lane; e < rs * rs; e += 64) {
+            for (int e = lane; e < rs * rs; e += NTHR) {
               const int y = e / rs, x = e - y * rs;
               stage[e] = img[(size_t)(ny0 + y) * step + nx0 + x];
             }
@@ -260,15 +322,15 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
         use_stage = staged && ipx >= sx0 && ipy >= sy0 && ipx + pw < sx0 + rs && ipy + pw < sy0 + rs;
       }
       if (use_stage)
-        rect_subpix_from_stage<MAXP>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
+        rect_subpix_from_stage<MAXP, NTHR>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
       else
-        rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane);
+        rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane, NTHR);
     }
     __syncthreads();
     KVFE_SP_T(0);
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
-      const int k = lane + 64 * t;
+      const int k = lane + NTHR * t;
       if (k < nt) {
         const int i = pij[t] >> 8, j = pij[t] & 255;
         const float* sp = patch + (i + 1) * pw + (j + 1);
@@ -288,25 +350,44 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
     KVFE_SP_T(1);
     // the five sequential float64 chains (lanes 0-4): a dependent v_add_f64 issues every ~6 cycles
     // as long as its operand has landed, so the loop only has to keep LDS reads ahead of the adds
-    double acc = 0;
-    if (lane < 5) {
-      const double2* t2 = reinterpret_cast<const double2*>(terms + lane * ts);
-      if (WIN > 0) {
-        constexpr int NTP = (((2 * WIN + 1) * (2 * WIN + 1) + 31) & ~31);
-        acc = lds_chain_sum<(WIN > 0 ? NTP / 2 : 16)>(terms + lane * ts);
-      } else {
+    double a, b, c, bb1, bb2;
+    if constexpr (NW == 2) {
+      // wave 0: DPP row r walks chain r (a, b, c, bb1); wave 1: chain 4 (bb2) -- see dpp_chain_sum448
+      double* res = reinterpret_cast<double*>(lds + G.res_off);
+      const int wv = lane >> 6, l = lane & 63, q = wv == 0 ? (l >> 4) : 4;
+      const double acc = dpp_chain_sum448(terms + q * ts + 28 * (l & 15));
+      KVFE_SP_T(2);
+      if ((l & 15) == 0 && (wv == 0 || l == 0)) res[q] = acc;
+      __syncthreads();
+      a = res[0];
+      b = res[1];
+      c = res[2];
+      bb1 = res[3];
+      bb2 = res[4];
+    } else {
+      double acc = 0;
+      if (lane < 5) {
+        const double2* t2 = reinterpret_cast<const double2*>(terms + lane * ts);
+        if (WIN > 0) {
+          constexpr int NTP = (((2 * WIN + 1) * (2 * WIN + 1) + 31) & ~31);
+          acc = lds_chain_sum<(WIN > 0 ? NTP / 2 : 16)>(terms + lane * ts);
+        } else {
 #pragma unroll 16
-        for (int k2 = 0; k2 < ntp / 2; k2++) {
-          const double2 v = t2[k2];
-          acc += v.x;
-          acc += v.y;
+          for (int k2 = 0; k2 < ntp / 2; k2++) {
+            const double2 v = t2[k2];
+            acc += v.x;
+            acc += v.y;
+          }
         }
       }
+      KVFE_SP_T(2);
+      a = __shfl(acc, 0);
+      b = __shfl(acc, 1);
+      c = __shfl(acc, 2);
+      bb1 = __shfl(acc, 3);
+      bb2 = __shfl(acc, 4);
+      __syncthreads();
     }
-    KVFE_SP_T(2);
-    const double a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2), bb1 = __shfl(acc, 3),
-                 bb2 = __shfl(acc, 4);
-    __syncthreads();
     KVFE_SP_T(3);
     const double det = a * c - b * b;
     if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
@@ -332,11 +413,11 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
 // StereoMatcher.cpp:406-411): kernels are instantiated for WIN = 10 (everything unrolled, window
 // coordinates and mask weights register resident) and WIN = 0 (any half size at run time), and the
 // launcher picks one, so the hot instantiation does not pay the registers of the generic one.
-template <int WIN>
+template <int WIN, int NW = 1>
 static __device__ __forceinline__ float2 corner_subpix_wave(const unsigned char* __restrict__ img,
                                                             size_t step, int W, int H, float2 cT,
                                                             int win, int max_iters, double eps2,
                                                             const float* __restrict__ mask,
                                                             unsigned char* lds, int lane) {
-  return corner_subpix_wave_t<WIN>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
+  return corner_subpix_wave_t<WIN, NW>(img, step, W, H, cT, win, max_iters, eps2, mask, lds, lane);
 }

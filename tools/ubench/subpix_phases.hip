@@ -10,13 +10,13 @@
 __device__ unsigned long long* kvfe_sp_out = nullptr;
 namespace kvfe {
 #include "kvfe_subpix.inl"
-template <int WIN>
-__global__ __launch_bounds__(64) void k(const float* mask, const unsigned char* img, size_t step, int W, int H, float2* pts,
+template <int WIN, int NW>
+__global__ __launch_bounds__(64 * NW) void k(const float* mask, const unsigned char* img, size_t step, int W, int H, float2* pts,
                                         int iters, unsigned long long* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   if (blockIdx.x == 0) kvfe_sp_out = out;   // (one writer; the ubench launches one block per measurement)
   __syncthreads();
-  const float2 c = corner_subpix_wave<WIN>(img, step, W, H, pts[blockIdx.x], 10, iters, 0.0, mask, lds_raw, threadIdx.x);
+  const float2 c = corner_subpix_wave<WIN, NW>(img, step, W, H, pts[blockIdx.x], 10, iters, 0.0, mask, lds_raw, threadIdx.x);
   if (threadIdx.x == 0) pts[blockIdx.x] = c;
 }
 }  // namespace kvfe
@@ -37,6 +37,7 @@ int main() {
   hipMemcpy(dimg, img.data(), W * H, hipMemcpyHostToDevice);
   hipMemcpy(dmask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice);
   const size_t lds = kvfe::subpix_geom(win).bytes;
+  for (int nw : {1, 2})
   for (int nblk : {1, 256, 1024}) {
     for (int rep = 0; rep < 2; rep++) {
       std::vector<float2> pts(1024);
@@ -45,14 +46,17 @@ int main() {
       hipMemset(dout, 0, 64);
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       hipEventRecord(e0);
-      hipLaunchKernelGGL(kvfe::k<10>, dim3(nblk), dim3(64), lds, 0, dmask, dimg, (size_t)W, W, H, dpts, 40, dout);
+      if (nw == 1)
+        hipLaunchKernelGGL((kvfe::k<10, 1>), dim3(nblk), dim3(64), lds, 0, dmask, dimg, (size_t)W, W, H, dpts, 40, dout);
+      else
+        hipLaunchKernelGGL((kvfe::k<10, 2>), dim3(nblk), dim3(128), lds, 0, dmask, dimg, (size_t)W, W, H, dpts, 40, dout);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       unsigned long long h[8]; hipMemcpy(h, dout, 64, hipMemcpyDeviceToHost);
       const double it = (double)h[6];
       if (rep == 1)
-        printf("blocks %4d: kernel %.1f us, %g iterations; cycles per iteration: patch %.0f | terms %.0f | chains %.0f | bcast+barrier %.0f | solve %.0f | loop %.0f | total %.0f\n",
-               nblk, ms * 1e3, it, h[0] / it, h[1] / it, h[2] / it, h[3] / it, h[4] / it, h[5] / it,
+        printf("waves/corner %d, blocks %4d: kernel %.1f us, %g iterations; cycles per iteration: patch %.0f | terms %.0f | chains %.0f | bcast+barrier %.0f | solve %.0f | loop %.0f | total %.0f\n",
+               nw, nblk, ms * 1e3, it, h[0] / it, h[1] / it, h[2] / it, h[3] / it, h[4] / it, h[5] / it,
                (h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / it);
     }
   }
