@@ -1072,9 +1072,10 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
   hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, grid, block, 0, st, P, prev_img, prev_row_stride,    \
                      prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,        \
                      cur_pyr, lk)
-  // KVFE_LK_PTS=1: one point per wave for every window size (lk_kernel_sys); default: two points per wave for the
-  // reference's window of 24 (lk_kernel_sys2)
-  static const int lk_pts = std::getenv("KVFE_LK_PTS") ? std::atoi(std::getenv("KVFE_LK_PTS")) : 2;
+  // KVFE_LK_PTS=2: two points per wave for the reference's window of 24 (lk_kernel_sys2: bit-exact, 18 % fewer VALU
+  // instructions, but 0.65 ms against 0.56 ms per 64-stream step -- three waves per SIMD do not hide its LDS latency
+  // and the two points' windows collide on LDS banks, profiles/r2_lk2_pmc.md); default: one point per wave
+  static const int lk_pts = std::getenv("KVFE_LK_PTS") ? std::atoi(std::getenv("KVFE_LK_PTS")) : 1;
   switch (P.klt_win) {
     case 16: KVFE_LK_SYS(16); break;
     case 24:

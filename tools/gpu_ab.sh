@@ -5,14 +5,14 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 IFS='|' read -ra TV <<< "${TEST_VARIANTS:-}"
 for v in "${TV[@]}"; do
-  ( IFS=';'; for kv in $v; do [ -n "$kv" ] && export "$kv"; done
+  ( IFS=';'; for kv in $v; do [ -n "$kv" ] && export "$kv"; done; IFS=$' \t\n'
     L=gpurun_out/ab_tests_$(echo "$v" | tr ';=/' '___').log
     timeout 1200 python -m pytest tests -m gpu -x -q ${TEST_ARGS:-} > $L 2>&1
     echo "TESTS [$v] rc=$? $(tail -1 $L)" )
 done
 IFS='|' read -ra BV <<< "${VARIANTS:-}"
 for v in "${BV[@]}"; do
-  ( IFS=';'; for kv in $v; do [ -n "$kv" ] && export "$kv"; done
+  ( IFS=';'; for kv in $v; do [ -n "$kv" ] && export "$kv"; done; IFS=$' \t\n'
     timeout 600 python bench.py --legs ${LEGS:-none} --repeats ${REPEATS:-2} --steps 20 --warmup 5 --stage-event-stride 1 ${BENCH_ARGS:-} > gpurun_out/ab_bench.json 2> gpurun_out/ab_bench.err
     python - "$v" <<'PY'
 import json, sys
