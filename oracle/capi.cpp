@@ -445,6 +445,88 @@ KVO_API void kvo_mt19937_draws(int policy, int n, int32_t* out) {  // SampleCons
   }
 }
 
+// ---- UndistorterRectifier / StereoCamera keypoint methods on their own (SURVEY.md 8b component calls) ----
+KVO_API void kvo_camera_check_undistorted_rectified(const kvo_camera* c, int cam, const float* dist_xy,
+                                                    const float* und_xy, int n, float pixel_tol, float* out_xy,
+                                                    uint8_t* out_status) {
+  std::vector<Point2f> d((const Point2f*)dist_xy, (const Point2f*)dist_xy + n);
+  std::vector<Point2f> u((const Point2f*)und_xy, (const Point2f*)und_xy + n);
+  std::vector<StatusKeypoint> out;
+  c->cam.checkUndistortedRectifiedKeypoints(cam, d, u, pixel_tol, out);
+  for (int i = 0; i < n; i++) {
+    out_xy[2 * i] = out[i].kp.x;
+    out_xy[2 * i + 1] = out[i].kp.y;
+    out_status[i] = out[i].status;
+  }
+}
+KVO_API void kvo_camera_distort_unrectify(const kvo_camera* c, int cam, const float* rect_xy, const uint8_t* status,
+                                          int n, float* out_xy) {
+  std::vector<StatusKeypoint> r(n);
+  for (int i = 0; i < n; i++) r[i] = StatusKeypoint{status[i], {rect_xy[2 * i], rect_xy[2 * i + 1]}};
+  std::vector<Point2f> out;
+  c->cam.distortUnrectifyKeypoints(cam, r, out);
+  for (int i = 0; i < n; i++) {
+    out_xy[2 * i] = out[i].x;
+    out_xy[2 * i + 1] = out[i].y;
+  }
+}
+
+// ---- FeatureDetector::featureDetection(Frame*, R) and Tracker::featureTracking as component calls ----
+static void frame_in(kimera::Frame& f, const uint8_t* img, int w, int h, size_t stride, int n, const float* kps,
+                     const int64_t* lmk, const int32_t* age, const double* versors) {
+  f.w = w;
+  f.h = h;
+  f.img.resize((size_t)w * h);
+  for (int y = 0; y < h; y++) std::memcpy(&f.img[(size_t)y * w], img + (size_t)y * stride, w);
+  for (int i = 0; i < n; i++) {
+    f.keypoints.push_back(Point2f{kps[2 * i], kps[2 * i + 1]});
+    f.landmarks.push_back(lmk[i]);
+    f.landmarks_age.push_back(age[i]);
+    for (int c = 0; c < 3; c++) f.versors.push_back(versors ? versors[3 * i + c] : 0.0);
+  }
+}
+static int frame_out(const kimera::Frame& f, int capacity, float* kps, int64_t* lmk, int32_t* age, double* versors) {
+  const int n = (int)f.keypoints.size(), m = std::min(n, capacity);
+  for (int i = 0; i < m; i++) {
+    kps[2 * i] = f.keypoints[i].x;
+    kps[2 * i + 1] = f.keypoints[i].y;
+    lmk[i] = f.landmarks[i];
+    age[i] = f.landmarks_age[i];
+    for (int c = 0; c < 3; c++) versors[3 * i + c] = f.versors[3 * i + c];
+  }
+  return n;
+}
+// returns the new keypoint count; *lmk_counter is FeatureDetector.cpp:141's function-static landmark id
+KVO_API int kvo_feature_detection_frame(const kvfe_camera_params* l, const kvfe_camera_params* r,
+                                        const kvfe_frontend_params* p, int mono, const uint8_t* img, size_t stride,
+                                        int capacity, int n, float* kps, int64_t* lmk, int32_t* age, double* versors,
+                                        int64_t* lmk_counter) {
+  kimera::Frontend fe;
+  fe.init(*l, *r, *p, mono != 0);
+  fe.lmk_id = *lmk_counter;
+  kimera::Frame f;
+  frame_in(f, img, l->width, l->height, stride, n, kps, lmk, age, versors);
+  fe.featureDetectionFrame(f, nullptr);
+  *lmk_counter = fe.lmk_id;
+  return frame_out(f, capacity, kps, lmk, age, versors);
+}
+// ref landmarks are updated in place (-1 where the track was lost or too old); returns the size of cur
+KVO_API int kvo_feature_tracking_frame(const kvfe_camera_params* l, const kvfe_camera_params* r,
+                                       const kvfe_frontend_params* p, int mono, const uint8_t* ref_img,
+                                       const uint8_t* cur_img, size_t stride, int n_ref, const float* ref_kps,
+                                       int64_t* ref_lmk, const int32_t* ref_age, const double ref_R_cur[9],
+                                       int capacity, float* cur_kps, int64_t* cur_lmk, int32_t* cur_age,
+                                       double* cur_versors) {
+  kimera::Frontend fe;
+  fe.init(*l, *r, *p, mono != 0);
+  kimera::Frame ref, cur;
+  frame_in(ref, ref_img, l->width, l->height, stride, n_ref, ref_kps, ref_lmk, ref_age, nullptr);
+  frame_in(cur, cur_img, l->width, l->height, stride, 0, nullptr, nullptr, nullptr, nullptr);
+  fe.featureTracking(ref, cur, ref_R_cur);
+  for (int i = 0; i < n_ref; i++) ref_lmk[i] = ref.landmarks[i];
+  return frame_out(cur, capacity, cur_kps, cur_lmk, cur_age, cur_versors);
+}
+
 // ---- RGBD components on their own (pinned by tests/testRgbdFrame.cpp:85-165, tests/testDepthFrame.cpp:56-171) ----
 KVO_API void kvo_depth_detection_mask(const kvfe_depth_params* dp, const void* depth, int w, int h, size_t stride,
                                       uint8_t* mask) {

@@ -171,20 +171,19 @@ bool roundAndCropToSize(Point2f* px, int w, int h) {  // UtilsOpenCV.cpp:242-247
   return cropToSize(px, w, h);
 }
 
-void StereoCamera::undistortRectifyLeftKeypoints(const std::vector<Point2f>& kps,
-                                                 std::vector<StatusKeypoint>& out) const {
-  std::vector<Point2f> und(kps.size());
-  undistortRectifyKeypoints(0, kps.data(), (int)kps.size(), true, true, und.data());
+// UndistorterRectifier::checkUndistortedRectifiedLeftKeypoints (UndistorterRectifier.cpp:138-211) of camera `cam`
+void StereoCamera::checkUndistortedRectifiedKeypoints(int cam, const std::vector<Point2f>& kps,
+                                                      const std::vector<Point2f>& und, float pixel_tol,
+                                                      std::vector<StatusKeypoint>& out) const {
   out.clear();
   out.reserve(kps.size());
-  const float pixel_tol = 2.0f;
   for (size_t i = 0; i < und.size(); i++) {
     Point2f distorted_kp = kps[i];
     Point2f undistorted_kp = und[i];
     bool cropped = cropToSize(&undistorted_kp, w, h);
     int ry = (int)std::round(undistorted_kp.y), rx = (int)std::round(undistorted_kp.x);
-    float ex = map_x[0][(size_t)ry * w + rx];
-    float ey = map_y[0][(size_t)ry * w + rx];
+    float ex = map_x[cam][(size_t)ry * w + rx];
+    float ey = map_y[cam][(size_t)ry * w + rx];
     if (cropped) {
       out.push_back({KVFE_KP_NO_LEFT_RECT, undistorted_kp});
     } else if (std::fabs(distorted_kp.x - ex) > pixel_tol ||
@@ -196,18 +195,31 @@ void StereoCamera::undistortRectifyLeftKeypoints(const std::vector<Point2f>& kps
   }
 }
 
-void StereoCamera::distortUnrectifyRightKeypoints(const std::vector<StatusKeypoint>& rectk,
-                                                  std::vector<Point2f>& out) const {
+void StereoCamera::undistortRectifyLeftKeypoints(const std::vector<Point2f>& kps,
+                                                 std::vector<StatusKeypoint>& out) const {
+  std::vector<Point2f> und(kps.size());
+  undistortRectifyKeypoints(0, kps.data(), (int)kps.size(), true, true, und.data());
+  checkUndistortedRectifiedKeypoints(0, kps, und, 2.0f, out);
+}
+
+// UndistorterRectifier::distortUnrectifyKeypoints (UndistorterRectifier.cpp:213-228) of camera `cam`
+void StereoCamera::distortUnrectifyKeypoints(int cam, const std::vector<StatusKeypoint>& rectk,
+                                             std::vector<Point2f>& out) const {
   out.clear();
   out.reserve(rectk.size());
   for (const StatusKeypoint& sk : rectk) {
     if (sk.status == KVFE_KP_VALID) {
       int ry = (int)std::round(sk.kp.y), rx = (int)std::round(sk.kp.x);
-      out.push_back({map_x[1][(size_t)ry * w + rx], map_y[1][(size_t)ry * w + rx]});
+      out.push_back({map_x[cam][(size_t)ry * w + rx], map_y[cam][(size_t)ry * w + rx]});
     } else {
       out.push_back({0.0f, 0.0f});
     }
   }
+}
+
+void StereoCamera::distortUnrectifyRightKeypoints(const std::vector<StatusKeypoint>& rectk,
+                                                  std::vector<Point2f>& out) const {
+  distortUnrectifyKeypoints(1, rectk, out);
 }
 
 // --------------------------------------------------------------------------

@@ -46,6 +46,11 @@ struct StereoCamera {
   // UndistorterRectifier::distortUnrectifyKeypoints (UndistorterRectifier.cpp:213-228)
   void distortUnrectifyRightKeypoints(const std::vector<StatusKeypoint>& rect,
                                       std::vector<Point2f>& out) const;
+  // the two UndistorterRectifier methods on their own, for either camera's rectifier
+  void checkUndistortedRectifiedKeypoints(int cam, const std::vector<Point2f>& distorted,
+                                          const std::vector<Point2f>& undistorted, float pixel_tol,
+                                          std::vector<StatusKeypoint>& out) const;
+  void distortUnrectifyKeypoints(int cam, const std::vector<StatusKeypoint>& rect, std::vector<Point2f>& out) const;
 };
 
 void camera_matrix(const kvfe_camera_params& c, double K[9]);
@@ -213,10 +218,11 @@ struct Frontend {
  // RgbdFrame::fillStereoFrame (public so that the reference's component KAT can drive it, capi.cpp);
   // (dw, dh) = size of the depth image; <= 0: the camera resolution
   void fillStereoFrame(StereoFrame& sf, const void* depth, size_t depth_stride, int dw = 0, int dh = 0) const;
-
- private:
+  // FeatureDetector::featureDetection(Frame*, R) / Tracker::featureTracking as component calls (capi.cpp)
   void featureDetectionFrame(Frame& f, int* n_detected, const uint8_t* detection_mask = nullptr);
   void featureTracking(Frame& ref, Frame& cur, const double ref_R_cur[9]);
+
+ private:
   bool shouldBeKeyframe(const Frame& frame, const Frame& frame_lkf) const;
   void getSmartStereoMeasurements(const StereoFrame& sf);
   // VisionImuFrontend::outlierRejectionMono / outlierRejectionStereo (VisionImuFrontend.cpp:90-144)
