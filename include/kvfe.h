@@ -492,6 +492,76 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* re
                                                  const double* cur_points_3d, int32_t n,
                                                  int32_t* inliers, kvfe_ransac_output* out);
 
+/* ---- UndistorterRectifier / StereoCamera / StereoMatcher keypoint methods on their own -------- */
+/* (the front-end step runs them fused; these are the reference's public methods as component calls) */
+
+/* UndistorterRectifier::checkUndistortedRectifiedLeftKeypoints(distorted_kps, undistorted_kps, status_kps,
+ * pixel_tol = 2.0f) (UndistorterRectifier.h:96-100, UndistorterRectifier.cpp:138-211) of camera `cam`'s
+ * rectifier: crop the rectified keypoint to the image, look the map up at the rounded position, VALID if
+ * it lands within pixel_tol of the distorted keypoint, else NO_LEFT_RECT; out_xy = the cropped keypoint. */
+KVFE_API kvfe_status kvfe_check_undistorted_rectified_left_keypoints(
+    kvfe_ctx* ctx, int32_t cam, const float* distorted_xy, const float* undistorted_xy, int32_t n,
+    float pixel_tol, float* out_xy, uint8_t* out_status);
+
+/* UndistorterRectifier::distortUnrectifyKeypoints (UndistorterRectifier.h:108-110, .cpp:213-228) of camera
+ * `cam`: (map_x, map_y) at the rounded rectified pixel for VALID keypoints, (0, 0) otherwise.  A VALID keypoint
+ * whose rounded position lies outside the image is KVFE_ERR_INVALID_ARG (cv::Mat::at out of range upstream). */
+KVFE_API kvfe_status kvfe_distort_unrectify_keypoints(kvfe_ctx* ctx, int32_t cam, const float* rect_xy,
+                                                      const uint8_t* status, int32_t n, float* out_xy);
+
+/* StereoCamera::undistortRectifyLeftKeypoints (StereoCamera.h:203-213, StereoCamera.cpp:236-260):
+ * undistortRectifyKeypoints (K1, D1, R1, P1) + checkUndistortedRectifiedLeftKeypoints. */
+KVFE_API kvfe_status kvfe_undistort_rectify_left_keypoints(kvfe_ctx* ctx, const float* xy, int32_t n,
+                                                           float* out_xy, uint8_t* out_status);
+
+/* StereoCamera::distortUnrectifyRightKeypoints (StereoCamera.h:215-223, StereoCamera.cpp:262-267). */
+KVFE_API kvfe_status kvfe_distort_unrectify_right_keypoints(kvfe_ctx* ctx, const float* rect_xy,
+                                                            const uint8_t* status, int32_t n, float* out_xy);
+
+/* StereoCamera::undistortRectifyStereoFrame (StereoCamera.h:225-233, StereoCamera.cpp:269-290): both images
+ * through their rectifiers (StereoFrame::setRectifiedImages receives left_rect / right_rect). */
+KVFE_API kvfe_status kvfe_undistort_rectify_stereo_frame(kvfe_ctx* ctx, const uint8_t* left, const uint8_t* right,
+                                                         size_t src_stride, uint8_t* left_rect,
+                                                         uint8_t* right_rect, size_t dst_stride);
+
+/* StereoMatcher::getDepthFromRectifiedMatches(left_keypoints_rectified, right_keypoints_rectified,
+ * keypoints_depth) (StereoMatcher.h:85-92, StereoMatcher.cpp:425-483): depth = fx b / (uL - uR) for VALID pairs;
+ * right_status is updated in place as upstream (NO_DEPTH for a negative disparity or a depth outside
+ * [minPointDist, maxPointDist]; the left status where the left keypoint is invalid), depth 0 where invalid. */
+KVFE_API kvfe_status kvfe_get_depth_from_rectified_matches(kvfe_ctx* ctx, const float* left_rect_xy,
+                                                           const uint8_t* left_status, const float* right_rect_xy,
+                                                           uint8_t* right_status, int32_t n, double* depth);
+
+/* VIO::Frame as far as the hot path touches it (include/kimera-vio/frontend/Frame.h:160-186): parallel arrays of
+ * n_keypoints entries in caller-owned storage of `capacity` entries (scores_ is not carried: the reference
+ * never sets it, FeatureDetector.cpp:147 "NOT IMPLEMENTED"). */
+typedef struct kvfe_frame {
+  int32_t capacity;
+  int32_t n_keypoints;
+  float* keypoints;            /* keypoints_      n x 2 */
+  int64_t* landmarks;          /* landmarks_      -1 = no landmark */
+  int32_t* landmarks_age;      /* landmarks_age_ */
+  double* versors;             /* versors_        n x 3 (input may be NULL for a reference frame) */
+} kvfe_frame;
+
+/* void FeatureDetector::featureDetection(Frame* cur_frame, std::optional<cv::Mat> R)
+ * (FeatureDetector.h:39-41, FeatureDetector.cpp:94-163): ages of all entries + 1, need = maxFeaturesPerFrame -
+ * #landmarks != -1, masked GFTT + ANMS + cornerSubPix, then the new corners are appended with landmark ids
+ * *landmark_counter, +1, ... (the function-static `lmk_id` of FeatureDetector.cpp:141, owned by the caller
+ * here), age 1 and their bearing vectors (GetBearingVector with the context's R: R1 for a stereo context,
+ * none for a mono one).  KVFE_ERR_CAPACITY if the frame does not hold the result. */
+KVFE_API kvfe_status kvfe_feature_detection_frame(kvfe_ctx* ctx, const uint8_t* img, size_t stride,
+                                                  kvfe_frame* frame, int64_t* landmark_counter);
+
+/* void Tracker::featureTracking(Frame* ref_frame, Frame* cur_frame, const gtsam::Rot3& ref_R_cur,
+ * const FeatureDetectorParams&, std::optional<cv::Mat> R) (Tracker.h:70-74, Tracker.cpp:92-211): the reference
+ * keypoints with a landmark are predicted (OpticalFlowPredictor) and tracked (calcOpticalFlowPyrLK); survivors
+ * not older than maxFeatureAge are pushed to cur_frame (ids, ages, keypoints, bearing vectors), the others
+ * get ref_frame->landmarks[i] = -1.  cur_frame must be empty on entry (the reference CHECKs it). */
+KVFE_API kvfe_status kvfe_feature_tracking_frame(kvfe_ctx* ctx, const uint8_t* ref_img, const uint8_t* cur_img,
+                                                 size_t stride, kvfe_frame* ref_frame, kvfe_frame* cur_frame,
+                                                 const double ref_R_cur[9]);
+
 /* ------------------------------------------------------------------------- */
 /* front-end level: `batch` independent streams, lock-step, device resident  */
 /* ------------------------------------------------------------------------- */

@@ -53,6 +53,43 @@ struct ImageView {
   size_t step;
 };
 
+// VIO::Frame as far as the hot path touches it (include/kimera-vio/frontend/Frame.h:160-186): img_ and the
+// parallel arrays keypoints_ / landmarks_ / landmarks_age_ / versors_ (scores_ is never set upstream)
+struct Frame {
+  ImageView img_{nullptr, 0, 0, 0};
+  KeypointsCV keypoints_;
+  std::vector<int64_t> landmarks_;
+  std::vector<int32_t> landmarks_age_;
+  std::vector<double> versors_;  // n x 3
+};
+
+namespace detail {
+// kvfe_frame view of a Frame whose vectors have been resized to `capacity`
+inline kvfe_frame frame_view(Frame* f, int n, int capacity) {
+  f->keypoints_.resize(capacity);
+  f->landmarks_.resize(capacity);
+  f->landmarks_age_.resize(capacity);
+  f->versors_.resize((size_t)capacity * 3);
+  kvfe_frame v;
+  v.capacity = capacity;
+  v.n_keypoints = n;
+  v.keypoints = &f->keypoints_.data()->x;
+  v.landmarks = f->landmarks_.data();
+  v.landmarks_age = f->landmarks_age_.data();
+  v.versors = f->versors_.data();
+  return v;
+}
+inline void frame_shrink(Frame* f, int n) {
+  f->keypoints_.resize(n);
+  f->landmarks_.resize(n);
+  f->landmarks_age_.resize(n);
+  f->versors_.resize((size_t)n * 3);
+}
+inline int frame_capacity(const kvfe_config& cfg) {
+  return cfg.params.detector.max_features_per_frame + cfg.params.detector.max_nr_keypoints_before_anms + 64;
+}
+}  // namespace detail
+
 // Owns a kvfe_ctx: StereoCamera + the four front-end classes share it, as the reference's
 // StereoVisionImuFrontend owns its StereoCamera::ConstPtr, Tracker, FeatureDetector and
 // StereoMatcher.
@@ -66,6 +103,13 @@ class Context {
     cfg_.params = params;
     cfg_.batch = batch;
     cfg_.device = device;
+    kvfe_ctx* c = nullptr;
+    const kvfe_status s = kvfe_create(&cfg_, &c);
+    if (s != KVFE_OK) throw Error(s, std::string("kvfe_create: ") + kvfe_status_string(s));
+    ctx_.reset(c, kvfe_destroy);
+  }
+  // any kvfe_config (frontend_type KVFE_FRONTEND_MONO / _RGBD, stream groups, a caller-owned HIP stream ...)
+  explicit Context(const kvfe_config& cfg) : cfg_(cfg) {
     kvfe_ctx* c = nullptr;
     const kvfe_status s = kvfe_create(&cfg_, &c);
     if (s != KVFE_OK) throw Error(s, std::string("kvfe_create: ") + kvfe_status_string(s));
@@ -106,6 +150,38 @@ class UndistorterRectifier {
     c_.check(kvfe_get_bearing_vectors(c_.get(), cam_, &kps.data()->x, (int32_t)kps.size(), versors->data()),
              "GetBearingVector");
   }
+  // checkUndistortedRectifiedLeftKeypoints(distorted_kps, undistorted_kps, status_kps, pixel_tol = 2.0f)
+  // (UndistorterRectifier.h:96-100, UndistorterRectifier.cpp:138-211)
+  void checkUndistortedRectifiedLeftKeypoints(const KeypointsCV& distorted_kps, const KeypointsCV& undistorted_kps,
+                                              StatusKeypointsCV* status_kps, const float& pixel_tol = 2.0f) const {
+    if (distorted_kps.size() != undistorted_kps.size())   // CHECK_EQ upstream
+      throw Error(KVFE_ERR_INVALID_ARG, "checkUndistortedRectifiedLeftKeypoints: size mismatch");
+    const int32_t n = (int32_t)distorted_kps.size();
+    KeypointsCV out(n);
+    std::vector<uint8_t> st(n);
+    c_.check(kvfe_check_undistorted_rectified_left_keypoints(c_.get(), cam_, n ? &distorted_kps.data()->x : nullptr,
+                                                             n ? &undistorted_kps.data()->x : nullptr, n, pixel_tol,
+                                                             n ? &out.data()->x : reinterpret_cast<float*>(&out),
+                                                             n ? st.data() : reinterpret_cast<uint8_t*>(&st)),
+             "checkUndistortedRectifiedLeftKeypoints");
+    status_kps->resize(n);
+    for (int32_t i = 0; i < n; i++) (*status_kps)[i] = {static_cast<KeypointStatus>(st[i]), out[i]};
+  }
+  // distortUnrectifyKeypoints(keypoints_rectified, keypoints_unrectified) (UndistorterRectifier.cpp:213-228)
+  void distortUnrectifyKeypoints(const StatusKeypointsCV& keypoints_rectified, KeypointsCV* keypoints_unrectified) const {
+    const int32_t n = (int32_t)keypoints_rectified.size();
+    KeypointsCV r(n);
+    std::vector<uint8_t> st(n);
+    for (int32_t i = 0; i < n; i++) {
+      st[i] = static_cast<uint8_t>(keypoints_rectified[i].first);
+      r[i] = keypoints_rectified[i].second;
+    }
+    keypoints_unrectified->assign(n, KeypointCV{0.f, 0.f});
+    if (n == 0) return;
+    c_.check(kvfe_distort_unrectify_keypoints(c_.get(), cam_, &r.data()->x, st.data(), n,
+                                              &keypoints_unrectified->data()->x),
+             "distortUnrectifyKeypoints");
+  }
 
  private:
   Context c_;
@@ -125,6 +201,29 @@ class StereoCamera {
   const double* getP2() const { return rect_.P2; }
   const double* getQ() const { return rect_.Q; }
   const Context& context() const { return c_; }
+  // undistortRectifyLeftKeypoints(keypoints, status_keypoints_rectified) (StereoCamera.h:203-213, .cpp:236-260)
+  void undistortRectifyLeftKeypoints(const KeypointsCV& keypoints, StatusKeypointsCV* status_keypoints_rectified) const {
+    const int32_t n = (int32_t)keypoints.size();
+    KeypointsCV out(n);
+    std::vector<uint8_t> st(n);
+    status_keypoints_rectified->resize(n);
+    if (n == 0) return;
+    c_.check(kvfe_undistort_rectify_left_keypoints(c_.get(), &keypoints.data()->x, n, &out.data()->x, st.data()),
+             "undistortRectifyLeftKeypoints");
+    for (int32_t i = 0; i < n; i++) (*status_keypoints_rectified)[i] = {static_cast<KeypointStatus>(st[i]), out[i]};
+  }
+  // distortUnrectifyRightKeypoints(status_keypoints_rectified, keypoints) (StereoCamera.h:215-223, .cpp:262-267)
+  void distortUnrectifyRightKeypoints(const StatusKeypointsCV& status_keypoints_rectified, KeypointsCV* keypoints) const {
+    UndistorterRectifier(c_, 1).distortUnrectifyKeypoints(status_keypoints_rectified, keypoints);
+  }
+  // undistortRectifyStereoFrame(StereoFrame*) (StereoCamera.h:225-233, .cpp:269-290): the two rectified images
+  // (StereoFrame::setRectifiedImages), tightly packed cols*rows bytes each
+  void undistortRectifyStereoFrame(const ImageView& left_img, const ImageView& right_img, uint8_t* left_img_rectified,
+                                   uint8_t* right_img_rectified) const {
+    c_.check(kvfe_undistort_rectify_stereo_frame(c_.get(), left_img.data, right_img.data, left_img.step,
+                                                 left_img_rectified, right_img_rectified, (size_t)left_img.cols),
+             "undistortRectifyStereoFrame");
+  }
   // backProjectDisparityTo3D(disparity_img CV_32F, depth CV_32FC3) (StereoCamera.cpp:176-196):
   // disparity: h x w float (CV_16S / 16), depth: h x w x 3 float
   void backProjectDisparityTo3D(const float* disparity, size_t stride_elems, float* depth) const {
@@ -150,6 +249,23 @@ class FeatureDetector {
              "rawFeatureDetection");
     out.resize(n);
     return out;
+  }
+  // void featureDetection(Frame* cur_frame, std::optional<cv::Mat> R) (FeatureDetector.h:39-41,
+  // FeatureDetector.cpp:94-163).  R is the context's (R1 for a stereo context, none for a mono one).  New landmarks
+  // take their ids from landmarkCounter(): the reference keeps a function-static `lmk_id` (FeatureDetector.cpp:141)
+  // shared by every FeatureDetector of the process, and so does this adapter.
+  static int64_t& landmarkCounter() {
+    static int64_t lmk_id = 0;
+    return lmk_id;
+  }
+  void featureDetection(Frame* cur_frame) const {
+    const int cap = detail::frame_capacity(c_.config());
+    const int n = (int)cur_frame->landmarks_.size();
+    kvfe_frame v = detail::frame_view(cur_frame, n, cap);
+    const kvfe_status s = kvfe_feature_detection_frame(c_.get(), cur_frame->img_.data, cur_frame->img_.step, &v,
+                                                       &landmarkCounter());
+    detail::frame_shrink(cur_frame, s == KVFE_OK ? v.n_keypoints : n);
+    c_.check(s, "featureDetection");
   }
   // private featureDetection(const Frame&, need_n_corners) (FeatureDetector.cpp:174-299):
   // `tracked` = keypoints of the frame whose landmark id is not -1
@@ -188,6 +304,24 @@ class Tracker {
                                            &px_ref.data()->x, &px_cur->data()->x, n, status->data(),
                                            error->data()),
              "calcOpticalFlowPyrLK");
+  }
+
+  // void featureTracking(Frame* ref_frame, Frame* cur_frame, const gtsam::Rot3& ref_R_cur,
+  //                      const FeatureDetectorParams&, std::optional<cv::Mat> R) (Tracker.h:70-74, Tracker.cpp:92-211)
+  // incl. the survivor bookkeeping: ids / ages / keypoints / versors pushed to cur_frame, ref_frame->landmarks_[i] = -1
+  // for lost or too old tracks.  ref_R_cur: gtsam::Rot3::matrix() row-major; R: the context's (see FeatureDetector).
+  void featureTracking(Frame* ref_frame, Frame* cur_frame, const double ref_R_cur[9]) const {
+    if (!cur_frame->keypoints_.empty() || !cur_frame->landmarks_.empty())   // CHECK(cur_frame->keypoints_.empty())
+      throw Error(KVFE_ERR_INVALID_ARG, "featureTracking: cur_frame must be empty");
+    const int cap = detail::frame_capacity(c_.config());
+    const int n = (int)ref_frame->landmarks_.size();
+    kvfe_frame r = detail::frame_view(ref_frame, n, n > 0 ? n : 1);
+    kvfe_frame k = detail::frame_view(cur_frame, 0, cap);
+    const kvfe_status s = kvfe_feature_tracking_frame(c_.get(), ref_frame->img_.data, cur_frame->img_.data,
+                                                      ref_frame->img_.step, &r, &k, ref_R_cur);
+    detail::frame_shrink(ref_frame, n);
+    detail::frame_shrink(cur_frame, s == KVFE_OK ? k.n_keypoints : 0);
+    c_.check(s, "featureTracking");
   }
 
   // TrackingStatusPose (Tracker-definitions.h:126-133) with the pose as row-major 3x4 [R | t]
@@ -314,6 +448,29 @@ class StereoMatcher {
     }
     return r;
   }
+  // getDepthFromRectifiedMatches(left_keypoints_rectified, right_keypoints_rectified, keypoints_depth)
+  // (StereoMatcher.h:85-92, StereoMatcher.cpp:425-483); right statuses are updated in place as upstream
+  void getDepthFromRectifiedMatches(StatusKeypointsCV& left_keypoints_rectified,
+                                    StatusKeypointsCV& right_keypoints_rectified,
+                                    std::vector<double>* keypoints_depth) const {
+    if (left_keypoints_rectified.size() != right_keypoints_rectified.size())   // CHECK_EQ upstream
+      throw Error(KVFE_ERR_INVALID_ARG, "getDepthFromRectifiedMatches: size mismatch");
+    const int32_t n = (int32_t)left_keypoints_rectified.size();
+    KeypointsCV l(n), r(n);
+    std::vector<uint8_t> ls(n), rs(n);
+    for (int32_t i = 0; i < n; i++) {
+      ls[i] = static_cast<uint8_t>(left_keypoints_rectified[i].first);
+      l[i] = left_keypoints_rectified[i].second;
+      rs[i] = static_cast<uint8_t>(right_keypoints_rectified[i].first);
+      r[i] = right_keypoints_rectified[i].second;
+    }
+    keypoints_depth->assign(n, 0.0);
+    if (n == 0) return;
+    c_.check(kvfe_get_depth_from_rectified_matches(c_.get(), &l.data()->x, ls.data(), &r.data()->x, rs.data(), n,
+                                                   keypoints_depth->data()),
+             "getDepthFromRectifiedMatches");
+    for (int32_t i = 0; i < n; i++) right_keypoints_rectified[i].first = static_cast<KeypointStatus>(rs[i]);
+  }
   // denseStereoReconstruction(left_img_rectified, right_img_rectified, disparity_img)
   // (StereoMatcher.cpp:32-121).  disparity: h x w int16 with 4 fractional bits — the CV_16S matrix
   // cv::StereoSGBM::compute leaves in *disparity_img; dense_stereo_params_ defaults to the reference's
@@ -374,6 +531,39 @@ class StereoVisionImuFrontend {
              "spinOnceDevice");
   }
   // StereoFrontendOutput of one stream; arrays sized by out->capacity
+  void getOutput(int stream, kvfe_frame_output* out) {
+    c_.check(kvfe_frontend_get_output(c_.get(), stream, out), "getOutput");
+  }
+  void reset() { c_.check(kvfe_frontend_reset(c_.get()), "reset"); }
+
+ private:
+  Context c_;
+};
+
+// MonoVisionImuFrontend::spinOnce visual path (src/frontend/MonoVisionImuFrontend.cpp:196-369) for `batch`
+// independent streams: create the context with kvfe_config.frontend_type = KVFE_FRONTEND_MONO (one camera: R = I,
+// P = K; measurements are (u, NaN, v), getSmartMonoMeasurements :340-369).
+class MonoVisionImuFrontend {
+ public:
+  explicit MonoVisionImuFrontend(Context ctx) : c_(std::move(ctx)) {
+    if (c_.config().frontend_type != KVFE_FRONTEND_MONO)
+      throw Error(KVFE_ERR_INVALID_ARG, "MonoVisionImuFrontend needs a KVFE_FRONTEND_MONO context");
+  }
+  static kvfe_config config(const kvfe_camera_params& cam, const kvfe_frontend_params& params, int batch = 1,
+                            int device = 0) {
+    kvfe_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.left = cam;
+    cfg.right = cam;
+    cfg.params = params;
+    cfg.batch = batch;
+    cfg.device = device;
+    cfg.frontend_type = KVFE_FRONTEND_MONO;
+    return cfg;
+  }
+  void spinOnce(const uint8_t* img, size_t row_stride, size_t image_stride, const kvfe_frame_input* inputs) {
+    c_.check(kvfe_frontend_step_host(c_.get(), img, nullptr, row_stride, image_stride, inputs), "spinOnce");
+  }
   void getOutput(int stream, kvfe_frame_output* out) {
     c_.check(kvfe_frontend_get_output(c_.get(), stream, out), "getOutput");
   }

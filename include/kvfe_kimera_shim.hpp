@@ -1,0 +1,225 @@
+// kvfe_kimera_shim.hpp — the thin layer a Kimera-VIO build puts between its own types and kvfe_adapter.hpp, so that
+// the call sites in src/frontend keep the reference's exact signatures:
+//
+//   void FeatureDetector::featureDetection(Frame* cur_frame, std::optional<cv::Mat> R)       FeatureDetector.h:39-41
+//   std::vector<cv::KeyPoint> rawFeatureDetection(const cv::Mat& img, const cv::Mat& mask)    FeatureDetector.h:46-49
+//   void Tracker::featureTracking(Frame* ref_frame, Frame* cur_frame, const gtsam::Rot3& ref_R_cur,
+//                                 const FeatureDetectorParams&, std::optional<cv::Mat> R)     Tracker.h:70-74
+//   void UndistorterRectifier::undistortRectifyImage(const cv::Mat& img, cv::Mat* out) const  UndistorterRectifier.h:76-78
+//   void StereoMatcher::getDepthFromRectifiedMatches(StatusKeypointsCV&, StatusKeypointsCV&, Depths*) const
+//                                                                                             StereoMatcher.h:85-92
+//   void StereoCamera::undistortRectifyStereoFrame(StereoFrame*) const                        StereoCamera.h:225-233
+//
+// It needs <opencv2/core.hpp> (cv::Mat, cv::Point2f, cv::KeyPoint) and <gtsam/geometry/Rot3.h>; the Kimera types
+// (VIO::Frame, VIO::StereoFrame, VIO::FeatureDetectorParams) are template parameters, so this header does not
+// include Kimera's.  Layout facts used: cv::Point2f == {float x, y} == kvfe::KeypointCV; VIO::KeypointStatus has the
+// values of kvfe::KeypointStatus (vio_types.h:38-44); LandmarkId = long (vio_types.h:55); landmarks_age_ is
+// std::vector<size_t>; versors_ is std::vector<gtsam::Vector3> (vio_types.h:67-69).
+//
+// This container has neither OpenCV nor GTSAM: tests/cpp/shim_check.cpp compiles this header against minimal
+// stand-ins (tests/cpp/stubs/) and runs it; INTEGRATION.md shows the two-line change at each reference call site.
+#pragma once
+#include <optional>
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include <gtsam/geometry/Rot3.h>
+#include <opencv2/core.hpp>
+
+#include "kvfe_adapter.hpp"
+
+namespace kvfe {
+namespace shim {
+
+inline ImageView view(const cv::Mat& m) {
+  if (m.empty() || m.type() != CV_8UC1) throw Error(KVFE_ERR_INVALID_ARG, "expected a non-empty CV_8UC1 image");
+  return ImageView{m.data, m.rows, m.cols, (size_t)m.step};
+}
+inline void rot_to_array(const gtsam::Rot3& R, double out[9]) {
+  const auto M = R.matrix();
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) out[3 * i + j] = M(i, j);
+}
+
+// VIO::Frame <-> kvfe::Frame (copies of the small per-keypoint arrays; the image is a view)
+template <class VioFrame>
+Frame to_frame(const VioFrame& f) {
+  Frame o;
+  o.img_ = view(f.img_);
+  const size_t n = f.landmarks_.size();
+  o.keypoints_.resize(n);
+  o.landmarks_.resize(n);
+  o.landmarks_age_.resize(n);
+  o.versors_.resize(3 * n);
+  for (size_t i = 0; i < n; i++) {
+    o.keypoints_[i] = KeypointCV{f.keypoints_[i].x, f.keypoints_[i].y};
+    o.landmarks_[i] = (int64_t)f.landmarks_[i];
+    o.landmarks_age_[i] = (int32_t)f.landmarks_age_[i];
+    if (i < f.versors_.size())
+      for (int c = 0; c < 3; c++) o.versors_[3 * i + c] = f.versors_[i](c);
+  }
+  return o;
+}
+template <class VioFrame>
+void from_frame(const Frame& o, VioFrame* f) {
+  const size_t n = o.landmarks_.size();
+  f->keypoints_.resize(n);
+  f->landmarks_.resize(n);
+  f->landmarks_age_.resize(n);
+  f->scores_.resize(n, 0.0);   // "NOT IMPLEMENTED" upstream (FeatureDetector.cpp:147)
+  f->versors_.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    f->keypoints_[i].x = o.keypoints_[i].x;
+    f->keypoints_[i].y = o.keypoints_[i].y;
+    f->landmarks_[i] = (decltype(f->landmarks_[i] + 0))o.landmarks_[i];
+    f->landmarks_age_[i] = (size_t)o.landmarks_age_[i];
+    for (int c = 0; c < 3; c++) f->versors_[i](c) = o.versors_[3 * i + c];
+  }
+}
+template <class StatusKps>
+StatusKeypointsCV to_status(const StatusKps& v) {
+  StatusKeypointsCV o(v.size());
+  for (size_t i = 0; i < v.size(); i++)
+    o[i] = {static_cast<KeypointStatus>(static_cast<uint8_t>(v[i].first)), KeypointCV{v[i].second.x, v[i].second.y}};
+  return o;
+}
+template <class StatusKps>
+void from_status(const StatusKeypointsCV& o, StatusKps* v) {
+  v->resize(o.size());
+  for (size_t i = 0; i < o.size(); i++) {
+    (*v)[i].first = static_cast<decltype((*v)[i].first)>(static_cast<uint8_t>(o[i].first));
+    (*v)[i].second.x = o[i].second.x;
+    (*v)[i].second.y = o[i].second.y;
+  }
+}
+
+// ---- the reference's classes with the reference's signatures -------------------------------------------------
+class FeatureDetector {
+ public:
+  explicit FeatureDetector(Context ctx) : impl_(std::move(ctx)) {}
+  // FeatureDetector.h:39-41.  R is accepted for signature compatibility: the context was created from the same
+  // StereoCamera, so its R1 is the matrix the reference passes (StereoVisionImuFrontend.cpp:258,418).
+  template <class VioFrame>
+  void featureDetection(VioFrame* cur_frame, std::optional<cv::Mat> /*R*/ = std::nullopt) {
+    Frame f = to_frame(*cur_frame);
+    impl_.featureDetection(&f);
+    from_frame(f, cur_frame);
+  }
+  // FeatureDetector.h:46-49
+  std::vector<cv::KeyPoint> rawFeatureDetection(const cv::Mat& img, const cv::Mat& mask = cv::Mat()) {
+    const ImageView iv = view(img);
+    ImageView mv{nullptr, 0, 0, 0};
+    if (!mask.empty()) mv = view(mask);
+    const KeypointsCV k = impl_.rawFeatureDetection(iv, mask.empty() ? nullptr : &mv);
+    std::vector<cv::KeyPoint> out;
+    out.reserve(k.size());
+    for (const KeypointCV& p : k) out.emplace_back(cv::Point2f(p.x, p.y), 3.0f /* blockSize */);
+    return out;
+  }
+
+ private:
+  kvfe::FeatureDetector impl_;
+};
+
+class Tracker {
+ public:
+  explicit Tracker(Context ctx) : impl_(std::move(ctx)) {}
+  // Tracker.h:70-74
+  template <class VioFrame, class FeatureDetectorParamsT>
+  void featureTracking(VioFrame* ref_frame, VioFrame* cur_frame, const gtsam::Rot3& ref_R_cur,
+                       const FeatureDetectorParamsT& /*feature_detector_params*/,
+                       std::optional<cv::Mat> /*R*/ = std::nullopt) {
+    Frame r = to_frame(*ref_frame), c = to_frame(*cur_frame);
+    double R9[9];
+    rot_to_array(ref_R_cur, R9);
+    impl_.featureTracking(&r, &c, R9);
+    for (size_t i = 0; i < r.landmarks_.size(); i++)   // only the landmark ids of the reference frame change
+      ref_frame->landmarks_[i] = (decltype(ref_frame->landmarks_[i] + 0))r.landmarks_[i];
+    from_frame(c, cur_frame);
+  }
+
+ private:
+  kvfe::Tracker impl_;
+};
+
+class UndistorterRectifier {
+ public:
+  UndistorterRectifier(Context ctx, int cam) : impl_(std::move(ctx), cam) {}
+  // UndistorterRectifier.h:76-78
+  void undistortRectifyImage(const cv::Mat& img, cv::Mat* undistorted_img) const {
+    undistorted_img->create(img.rows, img.cols, CV_8UC1);
+    impl_.undistortRectifyImage(view(img), undistorted_img->data);
+  }
+  // UndistorterRectifier.h:96-100 / 108-110
+  template <class Kps, class StatusKps>
+  void checkUndistortedRectifiedLeftKeypoints(const Kps& distorted_kps, const Kps& undistorted_kps, StatusKps* status_kps,
+                                              const float& pixel_tol = 2.0f) const {
+    KeypointsCV d(distorted_kps.size()), u(undistorted_kps.size());
+    for (size_t i = 0; i < d.size(); i++) d[i] = KeypointCV{distorted_kps[i].x, distorted_kps[i].y};
+    for (size_t i = 0; i < u.size(); i++) u[i] = KeypointCV{undistorted_kps[i].x, undistorted_kps[i].y};
+    StatusKeypointsCV out;
+    impl_.checkUndistortedRectifiedLeftKeypoints(d, u, &out, pixel_tol);
+    from_status(out, status_kps);
+  }
+  template <class StatusKps, class Kps>
+  void distortUnrectifyKeypoints(const StatusKps& keypoints_rectified, Kps* keypoints_unrectified) const {
+    KeypointsCV out;
+    impl_.distortUnrectifyKeypoints(to_status(keypoints_rectified), &out);
+    keypoints_unrectified->resize(out.size());
+    for (size_t i = 0; i < out.size(); i++) {
+      (*keypoints_unrectified)[i].x = out[i].x;
+      (*keypoints_unrectified)[i].y = out[i].y;
+    }
+  }
+
+ private:
+  kvfe::UndistorterRectifier impl_;
+};
+
+class StereoMatcher {
+ public:
+  explicit StereoMatcher(Context ctx) : impl_(std::move(ctx)) {}
+  // StereoMatcher.h:85-92
+  template <class StatusKps>
+  void getDepthFromRectifiedMatches(StatusKps& left_keypoints_rectified, StatusKps& right_keypoints_rectified,
+                                    std::vector<double>* keypoints_depth) const {
+    StatusKeypointsCV l = to_status(left_keypoints_rectified), r = to_status(right_keypoints_rectified);
+    impl_.getDepthFromRectifiedMatches(l, r, keypoints_depth);
+    from_status(r, &right_keypoints_rectified);
+  }
+  // StereoMatcher.h:62-66 (the overload on rectified images)
+  template <class StatusKps>
+  void getRightKeypointsRectified(const cv::Mat& left_rectified, const cv::Mat& right_rectified,
+                                  const StatusKps& left_keypoints_rectified, StatusKps* right_keypoints_rectified) const {
+    StatusKeypointsCV r;
+    impl_.getRightKeypointsRectified(view(left_rectified), view(right_rectified), to_status(left_keypoints_rectified), &r);
+    from_status(r, right_keypoints_rectified);
+  }
+
+ private:
+  kvfe::StereoMatcher impl_;
+};
+
+class StereoCamera {
+ public:
+  explicit StereoCamera(Context ctx) : impl_(std::move(ctx)) {}
+  // StereoCamera.h:225-233: stereo_frame->setRectifiedImages(left, right)
+  template <class VioStereoFrame>
+  void undistortRectifyStereoFrame(VioStereoFrame* stereo_frame) const {
+    const cv::Mat& l = stereo_frame->left_frame_.img_;
+    const cv::Mat& r = stereo_frame->right_frame_.img_;
+    cv::Mat lr, rr;
+    lr.create(l.rows, l.cols, CV_8UC1);
+    rr.create(r.rows, r.cols, CV_8UC1);
+    impl_.undistortRectifyStereoFrame(view(l), view(r), lr.data, rr.data);
+    stereo_frame->setRectifiedImages(lr, rr);
+  }
+  double getBaseline() const { return impl_.getBaseline(); }
+
+ private:
+  kvfe::StereoCamera impl_;
+};
+
+}  // namespace shim
+}  // namespace kvfe

@@ -136,6 +136,12 @@ def depth_params_default(depth_type: int = 0) -> "DepthParams":
                        is_registered=1, depth_type=depth_type)
 
 
+class Frame(C.Structure):
+    """kvfe_frame (VIO::Frame arrays, Frame.h:160-186)"""
+    _fields_ = [("capacity", C.c_int32), ("n_keypoints", C.c_int32), ("keypoints", C.c_void_p),
+                ("landmarks", C.c_void_p), ("landmarks_age", C.c_void_p), ("versors", C.c_void_p)]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("left", CameraParams), ("right", CameraParams), ("params", FrontendParams),

@@ -5,6 +5,7 @@
 //   StereoMatcher::getDepthFromRectifiedMatches                     src/frontend/StereoMatcher.cpp:425-483
 //   Tracker::featureTracking's `ref_frame->landmarks_[i] = -1`      src/frontend/Tracker.cpp:167-178
 // One lane per keypoint; pure table look-ups and a few float / double operations in the reference's order.
+#include "../../include/kvfe.h"
 #include "kvfe_dev.hpp"
 
 namespace kvfe {
@@ -36,8 +37,8 @@ __global__ void check_undistorted_rectified_kernel(const float2* __restrict__ ma
   }
   const int ry = (int)roundf(uy), rx = (int)roundf(ux);
   const float2 e = map[(size_t)ry * W + rx];
-  unsigned char status = KP_VALID;
-  if (cropped || fabsf(d.x - e.x) > pixel_tol || fabsf(d.y - e.y) > pixel_tol) status = KP_NO_LEFT_RECT;
+  unsigned char status = KVFE_KP_VALID;
+  if (cropped || fabsf(d.x - e.x) > pixel_tol || fabsf(d.y - e.y) > pixel_tol) status = KVFE_KP_NO_LEFT_RECT;
   out_xy[i] = make_float2(ux, uy);
   out_status[i] = status;
 }
@@ -55,7 +56,7 @@ __global__ void distort_unrectify_kernel(const float2* __restrict__ map, int W, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float2 o = make_float2(0.f, 0.f);
-  if (status[i] == KP_VALID) {
+  if (status[i] == KVFE_KP_VALID) {
     const float2 px = rect_xy[i];
     o = map[(size_t)(int)roundf(px.y) * W + (int)roundf(px.x)];
   }
@@ -78,18 +79,18 @@ __global__ void depth_from_matches_kernel(const float2* __restrict__ left_xy, co
   const unsigned char ls = left_status[i];
   unsigned char rs = right_status[i];
   double d = 0.0;
-  if (ls == KP_VALID && rs == KP_VALID) {
+  if (ls == KVFE_KP_VALID && rs == KVFE_KP_VALID) {
     const double disparity = (double)(left_xy[i].x - right_xy[i].x);   // float subtraction, then widened
     if (disparity >= 0.0) {
       const double z = fx_b / disparity;
       if (z < min_dist || z > max_dist)
-        rs = KP_NO_DEPTH;
+        rs = KVFE_KP_NO_DEPTH;
       else
         d = z;
     } else {
-      rs = KP_NO_DEPTH;
+      rs = KVFE_KP_NO_DEPTH;
     }
-  } else if (ls != KP_VALID && rs != ls) {
+  } else if (ls != KVFE_KP_VALID && rs != ls) {
     rs = ls;   // "cannot have a valid right keypoint without a valid left keypoint"
   }
   right_status[i] = rs;

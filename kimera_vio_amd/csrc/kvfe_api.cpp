@@ -1455,6 +1455,236 @@ kvfe_status kvfe_sparse_stereo_reconstruction(kvfe_ctx* c, const uint8_t* left_i
   return KVFE_OK;
 }
 
+// ---- UndistorterRectifier / StereoCamera / StereoMatcher keypoint methods on their own ------------------
+kvfe_status kvfe_check_undistorted_rectified_left_keypoints(kvfe_ctx* c, int32_t cam, const float* distorted_xy,
+                                                            const float* undistorted_xy, int32_t n, float pixel_tol,
+                                                            float* out_xy, uint8_t* out_status) {
+  DeviceGuard _dev(c);
+  if (!c || n < 0 || cam < 0 || cam > 1 || !out_xy || !out_status) return KVFE_ERR_INVALID_ARG;
+  if (n > 0 && (!distorted_xy || !undistorted_xy)) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.lk.prev_pts, distorted_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.lk.next_pts, undistorted_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  launch_check_undistorted_rectified(c->T.map[cam], P.W, P.H, b.lk.prev_pts, b.lk.next_pts, n, pixel_tol,
+                                     b.st.left_rect, b.st.left_status, st);
+  HIPCHK(c, hipMemcpyAsync(out_xy, b.st.left_rect, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(out_status, b.st.left_status, (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_distort_unrectify_keypoints(kvfe_ctx* c, int32_t cam, const float* rect_xy, const uint8_t* status,
+                                             int32_t n, float* out_xy) {
+  DeviceGuard _dev(c);
+  if (!c || n < 0 || cam < 0 || cam > 1 || !out_xy) return KVFE_ERR_INVALID_ARG;
+  if (n > 0 && (!rect_xy || !status)) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  // round(px) indexes the map: a VALID keypoint outside the image is a contract violation in the reference
+  // (cv::Mat::at asserts in debug builds); checked here on the host copy the caller handed over
+  for (int i = 0; i < n; i++)
+    if (status[i] == KVFE_KP_VALID) {
+      const float x = rect_xy[2 * i], y = rect_xy[2 * i + 1];
+      if (!(roundf(x) >= 0.f && roundf(x) <= (float)(P.W - 1) && roundf(y) >= 0.f && roundf(y) <= (float)(P.H - 1)))
+        return KVFE_ERR_INVALID_ARG;
+    }
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.st.right_rect, rect_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.st.right_status, status, (size_t)n, hipMemcpyHostToDevice, st));
+  launch_distort_unrectify(c->T.map[cam], P.W, b.st.right_rect, b.st.right_status, n, b.st.right_kp, st);
+  HIPCHK(c, hipMemcpyAsync(out_xy, b.st.right_kp, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_undistort_rectify_left_keypoints(kvfe_ctx* c, const float* xy, int32_t n, float* out_xy,
+                                                  uint8_t* out_status) {
+  DeviceGuard _dev(c);
+  if (!c || n < 0 || !out_xy || !out_status || (n > 0 && !xy)) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.lk.prev_pts, xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  launch_undistort_points(c->T.und_left_RP, b.lk.prev_pts, n, b.lk.next_pts, nullptr, st);
+  launch_check_undistorted_rectified(c->T.map[0], P.W, P.H, b.lk.prev_pts, b.lk.next_pts, n, 2.0f, b.st.left_rect,
+                                     b.st.left_status, st);
+  HIPCHK(c, hipMemcpyAsync(out_xy, b.st.left_rect, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(out_status, b.st.left_status, (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_distort_unrectify_right_keypoints(kvfe_ctx* c, const float* rect_xy, const uint8_t* status,
+                                                   int32_t n, float* out_xy) {
+  return kvfe_distort_unrectify_keypoints(c, 1, rect_xy, status, n, out_xy);
+}
+
+kvfe_status kvfe_undistort_rectify_stereo_frame(kvfe_ctx* c, const uint8_t* left, const uint8_t* right,
+                                                size_t src_stride, uint8_t* left_rect, uint8_t* right_rect,
+                                                size_t dst_stride) {
+  DeviceGuard _dev(c);
+  if (!c || !left || !right || !left_rect || !right_rect) return KVFE_ERR_INVALID_ARG;
+  if (c->P.mono) return KVFE_ERR_UNSUPPORTED;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (src_stride < (size_t)P.W || dst_stride < (size_t)P.W) return KVFE_ERR_INVALID_ARG;
+  hipStream_t st = c->stream;
+  TRY(upload_image(c, b.raw_left[0], left, src_stride));
+  TRY(upload_image(c, b.raw_right, right, src_stride));
+  const unsigned char* srcs[2] = {b.raw_left[0], b.raw_right};
+  launch_rectify(P, c->T, srcs, P.W, (size_t)P.W * P.H, b.rect, nullptr, 0, st);
+  HIPCHK(c, hipMemcpy2DAsync(left_rect, dst_stride, b.rect[0], P.W, P.W, P.H, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpy2DAsync(right_rect, dst_stride, b.rect[1], P.W, P.W, P.H, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_get_depth_from_rectified_matches(kvfe_ctx* c, const float* left_rect_xy, const uint8_t* left_status,
+                                                  const float* right_rect_xy, uint8_t* right_status, int32_t n,
+                                                  double* depth) {
+  DeviceGuard _dev(c);
+  if (!c || n < 0 || !depth || !right_status) return KVFE_ERR_INVALID_ARG;
+  if (n > 0 && (!left_rect_xy || !left_status || !right_rect_xy)) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.st.left_rect, left_rect_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.st.left_status, left_status, (size_t)n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.st.right_rect, right_rect_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.st.right_status, right_status, (size_t)n, hipMemcpyHostToDevice, st));
+  launch_depth_from_matches(b.st.left_rect, b.st.left_status, b.st.right_rect, b.st.right_status, n,
+                            P.fx_rect * P.baseline, P.min_point_dist, P.max_point_dist, b.st.depth, st);
+  HIPCHK(c, hipMemcpyAsync(right_status, b.st.right_status, (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(depth, b.st.depth, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KVFE_OK;
+}
+
+// ---- Frame-level component calls ---------------------------------------------------------------------------
+static kvfe_status frame_upload(kvfe_ctx* c, const FrameTab& F, const kvfe_frame* f, int n, hipStream_t st) {
+  HIPCHK(c, hipMemcpyAsync(F.count, &n, sizeof(int), hipMemcpyHostToDevice, st));
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(F.kp, f->keypoints, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(F.lmk, f->landmarks, sizeof(long long) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(F.age, f->landmarks_age, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    if (f->versors) HIPCHK(c, hipMemcpyAsync(F.versor, f->versors, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  }
+  return KVFE_OK;
+}
+static kvfe_status frame_download(kvfe_ctx* c, const FrameTab& F, kvfe_frame* f, hipStream_t st) {
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, F.count, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  f->n_keypoints = n;
+  const int m = std::min(n, f->capacity);
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(f->keypoints, F.kp, sizeof(float2) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(f->landmarks, F.lmk, sizeof(long long) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(f->landmarks_age, F.age, sizeof(int) * m, hipMemcpyDeviceToHost, st));
+    if (f->versors) HIPCHK(c, hipMemcpyAsync(f->versors, F.versor, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  return n > f->capacity ? KVFE_ERR_CAPACITY : KVFE_OK;
+}
+static bool frame_args_ok(const kvfe_frame* f, bool need_arrays) {
+  if (!f || f->capacity < 0 || f->n_keypoints < 0 || f->n_keypoints > f->capacity) return false;
+  if ((need_arrays || f->capacity > 0) && (!f->keypoints || !f->landmarks || !f->landmarks_age)) return false;
+  return true;
+}
+
+kvfe_status kvfe_feature_detection_frame(kvfe_ctx* c, const uint8_t* img, size_t stride, kvfe_frame* frame,
+                                         int64_t* landmark_counter) {
+  DeviceGuard _dev(c);
+  if (!c || !img || !landmark_counter || !frame_args_ok(frame, false) || !frame->versors) return KVFE_ERR_INVALID_ARG;
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  const int n = frame->n_keypoints;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  TRY(upload_image(c, b.raw_left[0], img, stride));
+  const FrameTab& K = b.ft[0];
+  TRY(frame_upload(c, K, frame, n, st));
+  const int flags = FLAG_DETECT | FLAG_INIT;
+  const long long counter = *landmark_counter;
+  HIPCHK(c, hipMemcpyAsync(b.ss.flags, &flags, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.ss.n_tracked, &n, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.ss.lmk_counter, &counter, sizeof(long long), hipMemcpyHostToDevice, st));
+  // mask discs around the keypoints with a landmark, GFTT, FeatureDetector.cpp:101-115 bookkeeping (ages, need),
+  // ANMS, cornerSubPix + append with new landmark ids / age 1 / bearing vectors, counters
+  launch_mineig(P, c->T, b.raw_left[0], P.W, (size_t)P.W * P.H, nullptr, K, b.ss, b.ds, 1, st);
+  launch_select(P, c->T, K, b.ss, b.ds, -1, st);
+  launch_subpix_append(P, c->T, b.raw_left[0], P.W, (size_t)P.W * P.H, K, b.ss, b.ds, 1, st);
+  long long counter_out = 0;
+  int fl = 0;
+  HIPCHK(c, hipMemcpyAsync(&counter_out, b.ss.lmk_counter, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(&fl, b.ss.flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  const kvfe_status r = frame_download(c, K, frame, st);
+  *landmark_counter = counter_out;
+  if (fl & FLAG_OVERFLOW) {
+    c->last_error = "device candidate / corner list capacity exceeded";
+    return KVFE_ERR_CAPACITY;
+  }
+  return r;
+}
+
+kvfe_status kvfe_feature_tracking_frame(kvfe_ctx* c, const uint8_t* ref_img, const uint8_t* cur_img, size_t stride,
+                                        kvfe_frame* ref_frame, kvfe_frame* cur_frame, const double ref_R_cur[9]) {
+  DeviceGuard _dev(c);
+  if (!c || !ref_img || !cur_img || !ref_R_cur || !frame_args_ok(ref_frame, false) || !frame_args_ok(cur_frame, false) ||
+      !cur_frame->versors)
+    return KVFE_ERR_INVALID_ARG;
+  if (cur_frame->n_keypoints != 0) return KVFE_ERR_INVALID_ARG;   // CHECK(cur_frame->keypoints_.empty()), Tracker.cpp:150
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  const int n = ref_frame->n_keypoints;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  hipStream_t st = c->stream;
+  const size_t N = (size_t)P.W * P.H;
+  TRY(upload_image(c, b.raw_left[0], ref_img, stride));
+  TRY(upload_image(c, b.raw_left[1], cur_img, stride));
+  launch_pyramid(P, b.raw_left[0], P.W, N, b.pyr[0], st);
+  launch_pyramid(P, b.raw_left[1], P.W, N, b.pyr[1], st);
+  const FrameTab &KM1 = b.ft[1], &K = b.ft[0], &LKF = b.ft[2];
+  TRY(frame_upload(c, KM1, ref_frame, n, st));
+  const int zero = 0, flags = FLAG_INIT;
+  HIPCHK(c, hipMemcpyAsync(K.count, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(LKF.count, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.ss.flags, &flags, sizeof(int), hipMemcpyHostToDevice, st));
+  // ref_frame_R_cur_frame = keyframe_R_ref_frame^-1 * keyframe_R_cur_frame with keyframe_R_ref_frame = I
+  double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  HIPCHK(c, hipMemcpyAsync(b.ss.kf_R_ref, eye, sizeof(eye), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, ref_R_cur, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(b.in_ts, 0, sizeof(long long), st));
+  HIPCHK(c, hipMemsetAsync(b.in_force, 0, sizeof(int), st));
+  b.ss.kf_R_cur = b.kf_R_cur;
+  b.ss.in_timestamp = b.in_ts;
+  b.ss.in_force_kf = b.in_force;
+  launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
+  launch_lk(P, b.raw_left[0], P.W, N, b.pyr[0], b.raw_left[1], P.W, N, b.pyr[1], b.lk, std::max(n, 1), st);
+  launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);   // survivors -> K (ids, ages, keypoints, versors)
+  launch_mark_lost_tracks(P, KM1, b.lk, std::max(n, 1), st);     // ref_frame->landmarks_[i] = -1
+  HIPCHK(c, hipStreamSynchronize(st));   // (eye[] is on this stack frame)
+  if (n > 0) HIPCHK(c, hipMemcpy(ref_frame->landmarks, KM1.lmk, sizeof(long long) * n, hipMemcpyDeviceToHost));
+  return frame_download(c, K, cur_frame, st);
+}
+
 static kvfe_status ransac_download(kvfe_ctx* c, Buffers& b, int32_t* inliers, kvfe_ransac_output* out,
                                    bool with_info) {
   DeviceGuard _dev(c);

@@ -319,6 +319,16 @@ void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const dou
 // undistort keypoints with an arbitrary UndistortDev (component API)
 void launch_undistort_points(const UndistortDev& U, const float2* in, int n, float2* out,
                              double* versors, hipStream_t st);
+// component-level keypoint methods (k_components.hip)
+void launch_check_undistorted_rectified(const float2* map, int W, int H, const float2* distorted,
+                                        const float2* undistorted, int n, float pixel_tol, float2* out_xy,
+                                        unsigned char* out_status, hipStream_t st);
+void launch_distort_unrectify(const float2* map, int W, const float2* rect_xy, const unsigned char* status, int n,
+                              float2* out_xy, hipStream_t st);
+void launch_depth_from_matches(const float2* left_xy, const unsigned char* left_status, const float2* right_xy,
+                               unsigned char* right_status, int n, double fx_b, double min_dist, double max_dist,
+                               double* depth, hipStream_t st);
+void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScratch& lk, int max_pts, hipStream_t st);
 void launch_predict_flow(const KParams& P, const Tables& T, const double* R, const float2* prev,
                          int n, float2* out, hipStream_t st);
 

@@ -293,6 +293,106 @@ class Context:
                   "outlier_rejection_3d3d")
         return self._ransac_result(out, inl)
 
+    # ---- UndistorterRectifier / StereoCamera / StereoMatcher keypoint methods on their own -------
+    def check_undistorted_rectified_left_keypoints(self, cam: int, distorted_xy, undistorted_xy, pixel_tol=2.0):
+        d, u = _pts(distorted_xy), _pts(undistorted_xy)
+        assert len(d) == len(u)
+        out, st = np.zeros_like(d), np.zeros(len(d), np.uint8)
+        self._chk(self.lib.kvfe_check_undistorted_rectified_left_keypoints(
+            self._h, cam, _p(d), _p(u), len(d), float(pixel_tol), _p(out), _p(st)), "check_undistorted_rectified")
+        return out, st
+
+    def distort_unrectify_keypoints(self, cam: int, rect_xy, status) -> np.ndarray:
+        r = _pts(rect_xy)
+        st = np.ascontiguousarray(status, np.uint8)
+        out = np.zeros_like(r)
+        self._chk(self.lib.kvfe_distort_unrectify_keypoints(self._h, cam, _p(r), _p(st), len(r), _p(out)),
+                  "distort_unrectify_keypoints")
+        return out
+
+    def undistort_rectify_left_keypoints(self, xy):
+        k = _pts(xy)
+        out, st = np.zeros_like(k), np.zeros(len(k), np.uint8)
+        self._chk(self.lib.kvfe_undistort_rectify_left_keypoints(self._h, _p(k), len(k), _p(out), _p(st)),
+                  "undistort_rectify_left_keypoints")
+        return out, st
+
+    def distort_unrectify_right_keypoints(self, rect_xy, status) -> np.ndarray:
+        r = _pts(rect_xy)
+        st = np.ascontiguousarray(status, np.uint8)
+        out = np.zeros_like(r)
+        self._chk(self.lib.kvfe_distort_unrectify_right_keypoints(self._h, _p(r), _p(st), len(r), _p(out)),
+                  "distort_unrectify_right_keypoints")
+        return out
+
+    def undistort_rectify_stereo_frame(self, left, right):
+        l, r = _img(left), _img(right)
+        lo, ro = np.empty_like(l), np.empty_like(r)
+        self._chk(self.lib.kvfe_undistort_rectify_stereo_frame(self._h, _p(l), _p(r), l.shape[1], _p(lo), _p(ro),
+                                                               l.shape[1]), "undistort_rectify_stereo_frame")
+        return lo, ro
+
+    def get_depth_from_rectified_matches(self, left_xy, left_status, right_xy, right_status):
+        l, r = _pts(left_xy), _pts(right_xy)
+        ls = np.ascontiguousarray(left_status, np.uint8)
+        rs = np.ascontiguousarray(right_status, np.uint8).copy()
+        depth = np.zeros(len(l), np.float64)
+        self._chk(self.lib.kvfe_get_depth_from_rectified_matches(self._h, _p(l), _p(ls), _p(r), _p(rs), len(l),
+                                                                 _p(depth)), "get_depth_from_rectified_matches")
+        return depth, rs
+
+    # ---- Frame-level FeatureDetector / Tracker calls ------------------------------------------------
+    @staticmethod
+    def _frame_struct(cap, n, kps, lmk, age, ver):
+        f = abi.Frame()
+        f.capacity, f.n_keypoints = cap, n
+        f.keypoints, f.landmarks, f.landmarks_age, f.versors = (kps.ctypes.data, lmk.ctypes.data, age.ctypes.data,
+                                                                ver.ctypes.data)
+        return f
+
+    def _frame_arrays(self, frame: dict | None, cap: int):
+        kps = np.zeros((cap, 2), np.float32)
+        lmk = np.zeros(cap, np.int64)
+        age = np.zeros(cap, np.int32)
+        ver = np.zeros((cap, 3), np.float64)
+        n = 0
+        if frame is not None:
+            n = len(frame["landmarks"])
+            kps[:n] = _pts(frame["keypoints"])
+            lmk[:n] = frame["landmarks"]
+            age[:n] = frame["landmarks_age"]
+            if "versors" in frame and frame["versors"] is not None:
+                ver[:n] = np.asarray(frame["versors"], np.float64).reshape(-1, 3)
+        return n, kps, lmk, age, ver
+
+    @staticmethod
+    def _frame_dict(f, kps, lmk, age, ver) -> dict:
+        n = f.n_keypoints
+        return dict(keypoints=kps[:n].copy(), landmarks=lmk[:n].copy(), landmarks_age=age[:n].copy(),
+                    versors=ver[:n].copy())
+
+    def feature_detection_frame(self, img, frame: dict | None, landmark_counter: int = 0):
+        """FeatureDetector::featureDetection(Frame*, R): returns (frame dict, new landmark counter)"""
+        img = _img(img)
+        n, kps, lmk, age, ver = self._frame_arrays(frame, self.kcap)
+        f = self._frame_struct(self.kcap, n, kps, lmk, age, ver)
+        ctr = C.c_int64(int(landmark_counter))
+        self._chk(self.lib.kvfe_feature_detection_frame(self._h, _p(img), img.shape[1], C.byref(f), C.byref(ctr)),
+                  "feature_detection_frame")
+        return self._frame_dict(f, kps, lmk, age, ver), int(ctr.value)
+
+    def feature_tracking_frame(self, ref_img, cur_img, ref_frame: dict, ref_R_cur=None):
+        """Tracker::featureTracking: returns (ref landmarks after the call, cur frame dict)"""
+        a, b = _img(ref_img), _img(cur_img)
+        n, kps, lmk, age, ver = self._frame_arrays(ref_frame, self.kcap)
+        fr = self._frame_struct(self.kcap, n, kps, lmk, age, ver)
+        _, ck, cl, ca, cv = self._frame_arrays(None, self.kcap)
+        fc = self._frame_struct(self.kcap, 0, ck, cl, ca, cv)
+        R = np.ascontiguousarray(np.eye(3) if ref_R_cur is None else ref_R_cur, np.float64).reshape(9)
+        self._chk(self.lib.kvfe_feature_tracking_frame(self._h, _p(a), _p(b), a.shape[1], C.byref(fr), C.byref(fc),
+                                                       _p(R)), "feature_tracking_frame")
+        return lmk[:n].copy(), self._frame_dict(fc, ck, cl, ca, cv)
+
     # ---- StereoVisionImuFrontend (batched) -----------------------------------------------------
     def make_inputs(self, timestamps_ns, Rs=None, force_keyframe=None):
         arr = (abi.FrameInput * self.batch)()

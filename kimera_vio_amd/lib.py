@@ -91,6 +91,17 @@ def load() -> C.CDLL:
     L.kvfe_frontend_get_output.argtypes = [vp, i32, C.POINTER(abi.FrameOutput)]
     L.kvfe_profile_enable.argtypes = [vp, i32]
     L.kvfe_profile_read.argtypes = [vp, C.POINTER(abi.StageTimes)]
+    f32 = C.c_float
+    L.kvfe_check_undistorted_rectified_left_keypoints.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp]
+    L.kvfe_distort_unrectify_keypoints.argtypes = [vp, i32, vp, vp, i32, vp]
+    L.kvfe_undistort_rectify_left_keypoints.argtypes = [vp, vp, i32, vp, vp]
+    L.kvfe_distort_unrectify_right_keypoints.argtypes = [vp, vp, vp, i32, vp]
+    L.kvfe_undistort_rectify_stereo_frame.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+    L.kvfe_get_depth_from_rectified_matches.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.kvfe_feature_detection_frame.argtypes = [vp, vp, sz, C.POINTER(abi.Frame), C.POINTER(C.c_int64)]
+    L.kvfe_feature_tracking_frame.argtypes = [vp, vp, vp, sz, C.POINTER(abi.Frame), C.POINTER(abi.Frame), vp]
+    for fn in NEW_R2_SYMBOLS:
+        getattr(L, fn).restype = C.c_int32
     for fn in ("kvfe_create", "kvfe_compute_rectification", "kvfe_compute_undistort_rectify_maps",
                "kvfe_get_rectification", "kvfe_undistort_rectify_image",
                "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors",
@@ -110,7 +121,14 @@ def load() -> C.CDLL:
     return L
 
 
-EXPORTED_SYMBOLS = [
+NEW_R2_SYMBOLS = [
+    "kvfe_check_undistorted_rectified_left_keypoints", "kvfe_distort_unrectify_keypoints",
+    "kvfe_undistort_rectify_left_keypoints", "kvfe_distort_unrectify_right_keypoints",
+    "kvfe_undistort_rectify_stereo_frame", "kvfe_get_depth_from_rectified_matches",
+    "kvfe_feature_detection_frame", "kvfe_feature_tracking_frame",
+]
+
+EXPORTED_SYMBOLS = NEW_R2_SYMBOLS + [
     "kvfe_version", "kvfe_status_string", "kvfe_last_error", "kvfe_default_frontend_params",
     "kvfe_create", "kvfe_destroy", "kvfe_compute_rectification",
     "kvfe_compute_undistort_rectify_maps", "kvfe_get_rectification", "kvfe_undistort_rectify_image",

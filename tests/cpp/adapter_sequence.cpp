@@ -9,6 +9,7 @@
 //   adapter_sequence <in.bin> <out.bin>
 // in.bin : kvfe_config | int32 n_frames, W, H | n_frames x { kvfe_frame_input, left[W*H], right[W*H] }
 // out.bin: a flat sequence of records { char tag[16]; int64 nbytes; payload }
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -113,6 +114,93 @@ int main(int argc, char** argv) {
       w.vec("st_rrect", rr);
       w.vec("st_depth", sr.keypoints_depth);
       w.vec("st_3d", sr.keypoints_3d);
+    }
+
+    // ---- the remaining public keypoint / frame methods (round 2), each called once ---------------
+    {
+      auto put_status = [&](const char* tag_st, const char* tag_xy, const kvfe::StatusKeypointsCV& v) {
+        std::vector<uint8_t> st;
+        kvfe::KeypointsCV xy;
+        for (const auto& k : v) {
+          st.push_back((uint8_t)k.first);
+          xy.push_back(k.second);
+        }
+        w.vec(tag_st, st);
+        w.vec(tag_xy, xy);
+      };
+      // StereoCamera::undistortRectifyLeftKeypoints
+      kvfe::StatusKeypointsCV left_rect_kps;
+      stereo_camera.undistortRectifyLeftKeypoints(corners, &left_rect_kps);
+      put_status("r2_url_st", "r2_url_xy", left_rect_kps);
+      // UndistorterRectifier::undistortRectifyKeypoints + checkUndistortedRectifiedLeftKeypoints (tolerance 0.5)
+      kvfe::KeypointsCV und;
+      left_rectifier.undistortRectifyKeypoints(corners, &und);
+      kvfe::StatusKeypointsCV checked;
+      left_rectifier.checkUndistortedRectifiedLeftKeypoints(corners, und, &checked, 0.5f);
+      put_status("r2_chk_st", "r2_chk_xy", checked);
+      // StereoCamera::undistortRectifyStereoFrame
+      std::vector<uint8_t> lrect(N), rrect(N);
+      stereo_camera.undistortRectifyStereoFrame(view(lefts[0]), view(rights[0]), lrect.data(), rrect.data());
+      w.vec("r2_lrect", lrect);
+      w.vec("r2_rrect", rrect);
+      // StereoMatcher::getRightKeypointsRectified + getDepthFromRectifiedMatches + distortUnrectifyRightKeypoints:
+      // the steps of sparseStereoReconstruction one by one
+      kvfe::StatusKeypointsCV right_rect_kps;
+      stereo_matcher.getRightKeypointsRectified(view(lrect), view(rrect), left_rect_kps, &right_rect_kps);
+      std::vector<double> depths;
+      stereo_matcher.getDepthFromRectifiedMatches(left_rect_kps, right_rect_kps, &depths);
+      put_status("r2_dep_st", "r2_dep_xy", right_rect_kps);
+      w.vec("r2_depth", depths);
+      kvfe::KeypointsCV right_kps;
+      stereo_camera.distortUnrectifyRightKeypoints(right_rect_kps, &right_kps);
+      w.vec("r2_rkps", right_kps);
+      // FeatureDetector::featureDetection(Frame*) -> Tracker::featureTracking(Frame*, Frame*, R) -> featureDetection
+      auto put_frame = [&](const std::string& pre, const kvfe::Frame& f) {
+        w.vec((pre + "_kp").c_str(), f.keypoints_);
+        w.vec((pre + "_lmk").c_str(), f.landmarks_);
+        w.vec((pre + "_age").c_str(), f.landmarks_age_);
+        w.vec((pre + "_ver").c_str(), f.versors_);
+      };
+      kvfe::FeatureDetector::landmarkCounter() = 0;
+      kvfe::Frame f0, f1;
+      f0.img_ = view(lefts[0]);
+      feature_detector.featureDetection(&f0);
+      put_frame("r2_f0", f0);
+      if (n_frames > 1) {
+        kvfe::Tracker tracker2(ctx);
+        f1.img_ = view(lefts[1]);
+        tracker2.featureTracking(&f0, &f1, inputs[1].keyframe_R_cur_frame);
+        w.vec("r2_ref_lmk", f0.landmarks_);
+        put_frame("r2_f1t", f1);
+        feature_detector.featureDetection(&f1);
+        put_frame("r2_f1d", f1);
+        w.val("r2_counter", kvfe::FeatureDetector::landmarkCounter());
+      }
+    }
+
+    // ---- MonoVisionImuFrontend::spinOnce on the left images (its own context) ----------------------------
+    {
+      kvfe::MonoVisionImuFrontend mono(kvfe::Context(kvfe::MonoVisionImuFrontend::config(cfg.left, cfg.params, 1, cfg.device)));
+      const int cap = 4096;
+      std::vector<int64_t> landmarks(cap), meas_lmk(cap);
+      std::vector<float> kp(2 * cap);
+      std::vector<double> meas(3 * cap);
+      for (int i = 0; i < std::min(n_frames, 3); i++) {
+        mono.spinOnce(lefts[i].data(), (size_t)W, N, &inputs[i]);
+        kvfe_frame_output o;
+        std::memset(&o, 0, sizeof(o));
+        o.capacity = cap;
+        o.landmarks = landmarks.data();
+        o.keypoints = kp.data();
+        o.meas_landmark = meas_lmk.data();
+        o.meas_uL_uR_v = meas.data();
+        mono.getOutput(0, &o);
+        const int32_t head[4] = {o.n_keypoints, o.is_keyframe, o.n_tracked, o.n_measurements};
+        w.put("m_head", head, sizeof(head));
+        w.put("m_lmk", landmarks.data(), (size_t)o.n_keypoints * 8);
+        w.put("m_kp", kp.data(), (size_t)o.n_keypoints * 8);
+        w.put("m_meas", meas.data(), (size_t)o.n_measurements * 24);
+      }
     }
 
     // ---- StereoVisionImuFrontend::spinOnce over the sequence -----------------------------------

@@ -1,0 +1,144 @@
+// shim_check: compiles include/kvfe_kimera_shim.hpp against the stand-in OpenCV / GTSAM headers of tests/cpp/stubs
+// and drives the reference-signature methods on Kimera-shaped Frame / StereoFrame structs (same member names and
+// types as include/kimera-vio/frontend/Frame.h:160-186, StereoFrame.h:137-171).  Input / output format as
+// adapter_sequence.cpp; tests/test_gpu_parity.py compares the records with the oracle.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kvfe_kimera_shim.hpp"
+
+namespace VIO {   // Kimera-shaped types (only what the hot path touches)
+using LandmarkId = long int;
+enum class KeypointStatus { VALID, NO_LEFT_RECT, NO_RIGHT_RECT, NO_DEPTH, FAILED_ARUN };
+using KeypointCV = cv::Point2f;
+using KeypointsCV = std::vector<KeypointCV>;
+using StatusKeypointCV = std::pair<KeypointStatus, KeypointCV>;
+using StatusKeypointsCV = std::vector<StatusKeypointCV>;
+struct FeatureDetectorParams {};
+struct Frame {
+  cv::Mat img_;
+  KeypointsCV keypoints_;
+  std::vector<double> scores_;
+  std::vector<LandmarkId> landmarks_;
+  std::vector<size_t> landmarks_age_;
+  std::vector<gtsam::Vector3> versors_;
+};
+struct StereoFrame {
+  Frame left_frame_, right_frame_;
+  cv::Mat left_img_rectified_, right_img_rectified_;
+  void setRectifiedImages(const cv::Mat& l, const cv::Mat& r) {
+    left_img_rectified_ = l;
+    right_img_rectified_ = r;
+  }
+};
+}  // namespace VIO
+
+namespace {
+struct Writer {
+  FILE* f;
+  void put(const char* tag, const void* p, size_t n) {
+    char t[16] = {0};
+    std::snprintf(t, sizeof(t), "%s", tag);
+    const int64_t nb = (int64_t)n;
+    std::fwrite(t, 1, 16, f);
+    std::fwrite(&nb, sizeof(nb), 1, f);
+    if (n) std::fwrite(p, 1, n, f);
+  }
+};
+void put_frame(Writer& w, const std::string& pre, const VIO::Frame& f) {
+  std::vector<float> kp;
+  std::vector<int64_t> lmk;
+  std::vector<int32_t> age;
+  std::vector<double> ver;
+  for (size_t i = 0; i < f.landmarks_.size(); i++) {
+    kp.push_back(f.keypoints_[i].x);
+    kp.push_back(f.keypoints_[i].y);
+    lmk.push_back(f.landmarks_[i]);
+    age.push_back((int32_t)f.landmarks_age_[i]);
+    for (int c = 0; c < 3; c++) ver.push_back(f.versors_[i](c));
+  }
+  w.put((pre + "_kp").c_str(), kp.data(), kp.size() * 4);
+  w.put((pre + "_lmk").c_str(), lmk.data(), lmk.size() * 8);
+  w.put((pre + "_age").c_str(), age.data(), age.size() * 4);
+  w.put((pre + "_ver").c_str(), ver.data(), ver.size() * 8);
+}
+bool read_exact(FILE* f, void* p, size_t n) { return std::fread(p, 1, n, f) == n; }
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc != 3) return 2;
+  FILE* fi = std::fopen(argv[1], "rb");
+  FILE* fo = std::fopen(argv[2], "wb");
+  if (!fi || !fo) return 2;
+  kvfe_config cfg;
+  int32_t hdr[3];
+  if (!read_exact(fi, &cfg, sizeof(cfg)) || !read_exact(fi, hdr, sizeof(hdr))) return 2;
+  const int n_frames = hdr[0], W = hdr[1], H = hdr[2];
+  const size_t N = (size_t)W * H;
+  if (n_frames < 2) return 2;
+  std::vector<kvfe_frame_input> inputs(n_frames);
+  std::vector<std::vector<uint8_t>> lefts(n_frames), rights(n_frames);
+  for (int i = 0; i < n_frames; i++) {
+    lefts[i].resize(N);
+    rights[i].resize(N);
+    if (!read_exact(fi, &inputs[i], sizeof(kvfe_frame_input)) || !read_exact(fi, lefts[i].data(), N) ||
+        !read_exact(fi, rights[i].data(), N))
+      return 2;
+  }
+  std::fclose(fi);
+  Writer w{fo};
+  try {
+    kvfe::Context ctx(cfg.left, cfg.right, cfg.params, 1, cfg.device);
+    kvfe::shim::FeatureDetector feature_detector(ctx);
+    kvfe::shim::Tracker tracker(ctx);
+    kvfe::shim::StereoCamera stereo_camera(ctx);
+    kvfe::shim::StereoMatcher stereo_matcher(ctx);
+    kvfe::FeatureDetector::landmarkCounter() = 0;
+
+    VIO::Frame ref, cur;
+    ref.img_ = cv::Mat(H, W, CV_8UC1, lefts[0].data(), (size_t)W);
+    cur.img_ = cv::Mat(H, W, CV_8UC1, lefts[1].data(), (size_t)W);
+    feature_detector.featureDetection(&ref, std::nullopt);                       // FeatureDetector.h:39-41
+    put_frame(w, "s_f0", ref);
+    gtsam::Matrix3 M;
+    for (int i = 0; i < 9; i++) M.m[i] = inputs[1].keyframe_R_cur_frame[i];
+    tracker.featureTracking(&ref, &cur, gtsam::Rot3(M), VIO::FeatureDetectorParams(), std::nullopt);   // Tracker.h:70-74
+    put_frame(w, "s_ref", ref);
+    put_frame(w, "s_f1", cur);
+    const std::vector<cv::KeyPoint> raw = feature_detector.rawFeatureDetection(ref.img_);
+    std::vector<float> rawxy;
+    for (const auto& k : raw) {
+      rawxy.push_back(k.pt.x);
+      rawxy.push_back(k.pt.y);
+    }
+    w.put("s_raw", rawxy.data(), rawxy.size() * 4);
+
+    VIO::StereoFrame sf;
+    sf.left_frame_.img_ = ref.img_;
+    sf.right_frame_.img_ = cv::Mat(H, W, CV_8UC1, rights[0].data(), (size_t)W);
+    stereo_camera.undistortRectifyStereoFrame(&sf);                               // StereoCamera.h:225-233
+    w.put("s_lrect", sf.left_img_rectified_.data, N);
+    w.put("s_rrect", sf.right_img_rectified_.data, N);
+
+    VIO::StatusKeypointsCV left{{VIO::KeypointStatus::VALID, {400.f, 200.f}},
+                                {VIO::KeypointStatus::VALID, {300.f, 100.f}},
+                                {VIO::KeypointStatus::NO_LEFT_RECT, {10.f, 10.f}}};
+    VIO::StatusKeypointsCV right{{VIO::KeypointStatus::VALID, {380.f, 200.f}},
+                                 {VIO::KeypointStatus::VALID, {310.f, 100.f}},
+                                 {VIO::KeypointStatus::VALID, {5.f, 10.f}}};
+    std::vector<double> depths;
+    stereo_matcher.getDepthFromRectifiedMatches(left, right, &depths);            // StereoMatcher.h:85-92
+    std::vector<uint8_t> rs;
+    for (const auto& k : right) rs.push_back((uint8_t)k.first);
+    w.put("s_depth", depths.data(), depths.size() * 8);
+    w.put("s_rstat", rs.data(), rs.size());
+  } catch (const kvfe::Error& e) {
+    std::fprintf(stderr, "kvfe::Error %d: %s\n", (int)e.status, e.what());
+    std::fclose(fo);
+    return 1;
+  }
+  std::fclose(fo);
+  return 0;
+}

@@ -1,0 +1,21 @@
+// Minimal stand-in for <gtsam/geometry/Rot3.h> (gtsam::Rot3::matrix(), gtsam::Vector3 with operator()):
+// TEST INFRASTRUCTURE for tests/cpp/shim_check.cpp, not part of the product.
+#pragma once
+namespace gtsam {
+struct Matrix3 {
+  double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double operator()(int i, int j) const { return m[3 * i + j]; }
+  double& operator()(int i, int j) { return m[3 * i + j]; }
+};
+struct Vector3 {
+  double v[3] = {0, 0, 0};
+  double operator()(int i) const { return v[i]; }
+  double& operator()(int i) { return v[i]; }
+};
+struct Rot3 {
+  Matrix3 R;
+  Rot3() = default;
+  explicit Rot3(const Matrix3& M) : R(M) {}
+  Matrix3 matrix() const { return R; }
+};
+}  // namespace gtsam

@@ -123,6 +123,16 @@ def lib() -> C.CDLL:
     L.kvo_frontend_time_sequence.restype = C.c_double
     L.kvo_frontend_time_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                              C.c_int, C.c_void_p]
+    L.kvo_camera_check_undistorted_rectified.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_float, vp, vp]
+    L.kvo_camera_distort_unrectify.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
+    L.kvo_feature_detection_frame.restype = C.c_int
+    L.kvo_feature_detection_frame.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams),
+                                              C.POINTER(abi.FrontendParams), C.c_int, vp, C.c_size_t, C.c_int, C.c_int,
+                                              vp, vp, vp, vp, C.POINTER(C.c_int64)]
+    L.kvo_feature_tracking_frame.restype = C.c_int
+    L.kvo_feature_tracking_frame.argtypes = [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraParams),
+                                             C.POINTER(abi.FrontendParams), C.c_int, vp, vp, C.c_size_t, C.c_int, vp,
+                                             vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.kvo_depth_detection_mask.argtypes = [C.POINTER(abi.DepthParams), vp, C.c_int, C.c_int, C.c_size_t, vp]
     L.kvo_depth_at_point.restype = C.c_float
     L.kvo_depth_at_point.argtypes = [C.POINTER(abi.DepthParams), vp, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float]
@@ -696,3 +706,60 @@ def rgbd_fill_stereo_frame(cam: abi.CameraParams, params: abi.FrontendParams, dp
                                      _p(ls), _p(v), _p(out["right_status"]), _p(out["right_rect_xy"]),
                                      _p(out["depth"]), _p(out["keypoints_3d"]), _p(out["right_xy"]))
     return out
+
+
+# ---- component calls of round 2 (UndistorterRectifier / StereoCamera methods, frame-level detect / track) ----
+def check_undistorted_rectified(cam: "Camera", c: int, distorted_xy, undistorted_xy, pixel_tol=2.0):
+    d = np.ascontiguousarray(distorted_xy, np.float32).reshape(-1, 2)
+    u = np.ascontiguousarray(undistorted_xy, np.float32).reshape(-1, 2)
+    out, st = np.zeros_like(d), np.zeros(len(d), np.uint8)
+    lib().kvo_camera_check_undistorted_rectified(cam._h, c, _p(d), _p(u), len(d), float(pixel_tol), _p(out), _p(st))
+    return out, st
+
+
+def distort_unrectify(cam: "Camera", c: int, rect_xy, status):
+    r = np.ascontiguousarray(rect_xy, np.float32).reshape(-1, 2)
+    st = np.ascontiguousarray(status, np.uint8)
+    out = np.zeros_like(r)
+    lib().kvo_camera_distort_unrectify(cam._h, c, _p(r), _p(st), len(r), _p(out))
+    return out
+
+
+def _frame_arrays(frame, cap):
+    kps = np.zeros((cap, 2), np.float32)
+    lmk = np.zeros(cap, np.int64)
+    age = np.zeros(cap, np.int32)
+    ver = np.zeros((cap, 3), np.float64)
+    n = 0
+    if frame is not None:
+        n = len(frame["landmarks"])
+        kps[:n] = np.asarray(frame["keypoints"], np.float32).reshape(-1, 2)
+        lmk[:n] = frame["landmarks"]
+        age[:n] = frame["landmarks_age"]
+        if frame.get("versors") is not None:
+            ver[:n] = np.asarray(frame["versors"], np.float64).reshape(-1, 3)
+    return n, kps, lmk, age, ver
+
+
+def feature_detection_frame(left, right, params, img, frame, landmark_counter=0, mono=False, cap=4096):
+    """FeatureDetector::featureDetection(Frame*, R) -> (frame dict, new landmark counter)"""
+    img = _img(img)
+    n, kps, lmk, age, ver = _frame_arrays(frame, cap)
+    ctr = C.c_int64(int(landmark_counter))
+    m = lib().kvo_feature_detection_frame(C.byref(left), C.byref(right), C.byref(params), int(mono), _p(img),
+                                          img.shape[1], cap, n, _p(kps), _p(lmk), _p(age), _p(ver), C.byref(ctr))
+    return dict(keypoints=kps[:m].copy(), landmarks=lmk[:m].copy(), landmarks_age=age[:m].copy(),
+                versors=ver[:m].copy()), int(ctr.value)
+
+
+def feature_tracking_frame(left, right, params, ref_img, cur_img, ref_frame, ref_R_cur=None, mono=False, cap=4096):
+    """Tracker::featureTracking -> (ref landmarks after the call, cur frame dict)"""
+    a, b = _img(ref_img), _img(cur_img)
+    n, kps, lmk, age, _ = _frame_arrays(ref_frame, cap)
+    _, ck, cl, ca, cv = _frame_arrays(None, cap)
+    R = np.ascontiguousarray(np.eye(3) if ref_R_cur is None else ref_R_cur, np.float64).reshape(9)
+    m = lib().kvo_feature_tracking_frame(C.byref(left), C.byref(right), C.byref(params), int(mono), _p(a), _p(b),
+                                         a.shape[1], n, _p(kps), _p(lmk), _p(age), _p(R), cap, _p(ck), _p(cl), _p(ca),
+                                         _p(cv))
+    return lmk[:n].copy(), dict(keypoints=ck[:m].copy(), landmarks=cl[:m].copy(), landmarks_age=ca[:m].copy(),
+                                versors=cv[:m].copy())

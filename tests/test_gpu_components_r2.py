@@ -1,0 +1,229 @@
+"""Component-level exports added in round 2 (VERDICT r1 "boundary holes"): every public method of
+UndistorterRectifier / StereoCamera / StereoMatcher / FeatureDetector / Tracker that the front-end step only ran
+fused now has its own C entry point; each is compared here with the oracle on the same inputs (tolerance 0), the
+frame-level calls also against the fused front-end step itself."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from kimera_vio_amd import _abi as abi
+from kimera_vio_amd import frontend as F
+from kimera_vio_amd import params as P
+from test_gpu_parity import G, _kf_rotations, euroc_cams, euroc_params, gray  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def seq():
+    z = np.load(os.path.join(G, "micro_euroc_f10_18.npz"))
+    return dict(lefts=z["lefts"], rights=z["rights"], ts=z["timestamps"], body_R=z["body_R"])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    L, R = euroc_cams()
+    c = F.Context(L, R, euroc_params())
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ocam():
+    L, R = euroc_cams()
+    return O.Camera(L, R)
+
+
+def _grid_and_random(n=400, seed=4):
+    rng = np.random.RandomState(seed)
+    pts = np.stack([rng.uniform(-8, 760, n), rng.uniform(-8, 488, n)], 1).astype(np.float32)
+    pts[:30] = np.rint(pts[:30])
+    return pts
+
+
+def test_check_undistorted_rectified_left_keypoints(ctx, ocam):
+    """UndistorterRectifier::checkUndistortedRectifiedLeftKeypoints (UndistorterRectifier.cpp:138-211), both
+    rectifiers, default and custom tolerance"""
+    d = _grid_and_random()
+    for cam in (0, 1):
+        u = ocam.undistort_keypoints(cam, d, True, True)
+        u[::7] += 5.0       # some that remap far from their source: NO_LEFT_RECT
+        for tol in (2.0, 0.25):
+            gx, gs = ctx.check_undistorted_rectified_left_keypoints(cam, d, u, tol)
+            ex, es = O.check_undistorted_rectified(ocam, cam, d, u, tol)
+            assert np.array_equal(gs, es) and np.array_equal(gx, ex)
+            assert 0 < (es == abi.KP_VALID).sum() < len(es)
+
+
+def test_undistort_rectify_left_keypoints(ctx, ocam):
+    """StereoCamera::undistortRectifyLeftKeypoints (StereoCamera.cpp:236-260)"""
+    d = _grid_and_random(seed=5)
+    gx, gs = ctx.undistort_rectify_left_keypoints(d)
+    ex, es = ocam.undistort_rectify_left(d)
+    assert np.array_equal(gs, es) and np.array_equal(gx, ex)
+
+
+def test_distort_unrectify_keypoints(ctx, ocam):
+    """UndistorterRectifier::distortUnrectifyKeypoints on the grid of tests/testUndistortRectifier.cpp:152-221
+    (8 x 10, alternating VALID / NO_RIGHT_RECT) for both cameras, and StereoCamera::distortUnrectifyRightKeypoints"""
+    pts, st = [], []
+    for r in range(8):
+        for c in range(10):
+            pts.append((752 // 9 * c, 480 // 7 * r))
+            st.append(abi.KP_NO_RIGHT_RECT if (r + c) % 2 == 0 else abi.KP_VALID)
+    pts, st = np.array(pts, np.float32), np.array(st, np.uint8)
+    for cam in (0, 1):
+        got = ctx.distort_unrectify_keypoints(cam, pts, st)
+        assert np.array_equal(got, O.distort_unrectify(ocam, cam, pts, st))
+        assert np.all(got[st != abi.KP_VALID] == 0)
+    assert np.array_equal(ctx.distort_unrectify_right_keypoints(pts, st), O.distort_unrectify(ocam, 1, pts, st))
+    from kimera_vio_amd.lib import KvfeError
+    with pytest.raises(KvfeError) as e:      # a VALID keypoint outside the image is a contract violation
+        ctx.distort_unrectify_keypoints(0, np.array([[800.0, 10.0]], np.float32), np.array([0], np.uint8))
+    assert e.value.status == abi.KVFE_ERR_INVALID_ARG
+
+
+def test_undistort_rectify_stereo_frame(ctx, ocam, seq):
+    """StereoCamera::undistortRectifyStereoFrame (StereoCamera.cpp:269-290)"""
+    lr, rr = ctx.undistort_rectify_stereo_frame(seq["lefts"][2], seq["rights"][2])
+    assert np.array_equal(lr, ocam.rectify_image(0, seq["lefts"][2]))
+    assert np.array_equal(rr, ocam.rectify_image(1, seq["rights"][2]))
+
+
+def test_get_depth_from_rectified_matches(ctx, ocam):
+    """StereoMatcher::getDepthFromRectifiedMatches (StereoMatcher.cpp:425-483): valid pairs, negative disparities,
+    depths outside [minPointDist, maxPointDist], invalid left / right statuses"""
+    rng = np.random.RandomState(6)
+    n = 300
+    lx = np.stack([rng.uniform(0, 751, n), rng.uniform(0, 479, n)], 1).astype(np.float32)
+    rx = lx.copy()
+    rx[:, 0] -= rng.uniform(-3, 120, n).astype(np.float32)      # some negative disparities, some tiny (far) ones
+    ls = (rng.randint(0, 8, n) == 0).astype(np.uint8) * abi.KP_NO_LEFT_RECT
+    rs = np.where(rng.randint(0, 6, n) == 0, abi.KP_NO_RIGHT_RECT, abi.KP_VALID).astype(np.uint8)
+    p = euroc_params()
+    gd, grs = ctx.get_depth_from_rectified_matches(lx, ls, rx, rs)
+    ed, els, ers = O.get_depth_from_rectified_matches(ocam, p.stereo, lx, ls.copy(), rx, rs.copy())
+    assert np.array_equal(gd, ed) and np.array_equal(grs, ers)
+    assert (ers == abi.KP_NO_DEPTH).sum() > 10 and (gd > 0).sum() > 50
+
+
+def _frame_eq(a, b):
+    for k in ("landmarks", "landmarks_age", "keypoints", "versors"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_feature_detection_frame_and_tracking_frame(seq, ocam):
+    """FeatureDetector::featureDetection(Frame*, R) and Tracker::featureTracking as component calls, chained the
+    way processStereoFrame chains them (detect on frame 0, track 0->1, detect on 1 with the survivors masked,
+    track 1->2), against the oracle's methods AND against the fused front-end step of the same library."""
+    L, R = euroc_cams()
+    p = euroc_params(max_features_per_frame=250)
+    c = F.Context(L, R, p)
+    fe_ctx = F.Context(L, R, p, batch=1)      # the fused path, for cross-checking
+    camR = _kf_rotations(seq["body_R"], ocam)
+    try:
+        # frame 0: empty frame -> detection
+        g0, gctr = c.feature_detection_frame(seq["lefts"][0], None, 0)
+        e0, ectr = O.feature_detection_frame(L, R, p, seq["lefts"][0], None, 0)
+        _frame_eq(g0, e0)
+        assert gctr == ectr == len(e0["landmarks"]) > 100
+        assert list(e0["landmarks"]) == list(range(len(e0["landmarks"]))) and np.all(e0["landmarks_age"] == 1)
+        fe_ctx.step_host(seq["lefts"][0][None], seq["rights"][0][None], fe_ctx.make_inputs([int(seq["ts"][0])]))
+        f0 = fe_ctx.get_output(0)
+        _frame_eq(g0, f0)
+        # track 0 -> 1 with the gyro rotation
+        R01 = camR[0].T @ camR[1]
+        gref, g1 = c.feature_tracking_frame(seq["lefts"][0], seq["lefts"][1], g0, R01)
+        eref, e1 = O.feature_tracking_frame(L, R, p, seq["lefts"][0], seq["lefts"][1], e0, R01)
+        assert np.array_equal(gref, eref)
+        _frame_eq(g1, e1)
+        lost = int((eref == -1).sum())
+        assert len(e1["landmarks"]) == len(e0["landmarks"]) - lost and len(e1["landmarks"]) > 80
+        fe_ctx.step_host(seq["lefts"][1][None], seq["rights"][1][None],
+                         fe_ctx.make_inputs([int(seq["ts"][1])], [R01], [0]))
+        f1 = fe_ctx.get_output(0)
+        assert not f1["is_keyframe"]
+        _frame_eq(g1, f1)
+        # age limit: everything older than maxFeatureAge is dropped and marked in the reference frame
+        old = dict(g0)
+        old["landmarks_age"] = g0["landmarks_age"].copy()
+        old["landmarks_age"][::3] = p.tracker.max_feature_track_age + 1
+        gref2, g1b = c.feature_tracking_frame(seq["lefts"][0], seq["lefts"][1], old, R01)
+        eref2, e1b = O.feature_tracking_frame(L, R, p, seq["lefts"][0], seq["lefts"][1], old, R01)
+        assert np.array_equal(gref2, eref2) and np.all(eref2[::3] == -1)
+        _frame_eq(g1b, e1b)
+        # detection on frame 1 with survivors (some landmarks invalidated: they do not mask)
+        g1["landmarks"][5:25] = -1
+        e1["landmarks"][5:25] = -1
+        g1d, gctr2 = c.feature_detection_frame(seq["lefts"][1], g1, gctr)
+        e1d, ectr2 = O.feature_detection_frame(L, R, p, seq["lefts"][1], e1, ectr)
+        _frame_eq(g1d, e1d)
+        assert gctr2 == ectr2 > gctr
+        n1 = len(e1["landmarks"])
+        assert np.all(e1d["landmarks_age"][:n1] == e1["landmarks_age"] + 1)       # every existing entry aged
+        assert np.all(e1d["landmarks"][n1:] == np.arange(ectr, ectr2))            # new ids continue the counter
+        # empty reference frame: nothing to track, nothing aborts
+        gref3, g3 = c.feature_tracking_frame(seq["lefts"][1], seq["lefts"][2], None, np.eye(3))
+        assert len(gref3) == 0 and len(g3["landmarks"]) == 0
+    finally:
+        c.close()
+        fe_ctx.close()
+
+
+def test_kimera_shim_reference_signatures(seq, ocam, tmp_path):
+    """include/kvfe_kimera_shim.hpp — FeatureDetector::featureDetection(Frame*, optional<cv::Mat>),
+    Tracker::featureTracking(Frame*, Frame*, const gtsam::Rot3&, const FeatureDetectorParams&, optional<cv::Mat>),
+    StereoCamera::undistortRectifyStereoFrame(StereoFrame*), StereoMatcher::getDepthFromRectifiedMatches(StatusKeypointsCV&,
+    StatusKeypointsCV&, Depths*), rawFeatureDetection(const cv::Mat&, const cv::Mat&) — compiled against stand-in
+    OpenCV / GTSAM headers (tests/cpp/stubs) by tests/cpp/shim_check.cpp on Kimera-shaped Frame / StereoFrame
+    structs; every record equals the oracle."""
+    import subprocess
+    from test_gpu_parity import _read_records
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.run(["make", "-C", cpp, "shim_check"], check=True, capture_output=True)
+    L, R = euroc_cams()
+    p = euroc_params(max_features_per_frame=200)
+    cfg = abi.Config()
+    cfg.left, cfg.right, cfg.params, cfg.batch, cfg.device = L, R, p, 1, 0
+    camR = _kf_rotations(seq["body_R"], ocam)
+    R01 = camR[0].T @ camR[1]
+    H, W = seq["lefts"][0].shape
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(bytes(cfg))
+        f.write(np.array([2, W, H], np.int32).tobytes())
+        for i in range(2):
+            fi = abi.FrameInput()
+            fi.timestamp_ns = int(seq["ts"][i])
+            for k in range(9):
+                fi.keyframe_R_cur_frame[k] = float((R01 if i else np.eye(3)).reshape(9)[k])
+            f.write(bytes(fi))
+            f.write(np.ascontiguousarray(seq["lefts"][i]).tobytes())
+            f.write(np.ascontiguousarray(seq["rights"][i]).tobytes())
+    r = subprocess.run([os.path.join(cpp, "shim_check"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    one = dict(_read_records(tmp_path / "out.bin"))
+
+    def frame_of(pre):
+        return dict(keypoints=np.frombuffer(one[pre + "_kp"], np.float32).reshape(-1, 2),
+                    landmarks=np.frombuffer(one[pre + "_lmk"], np.int64),
+                    landmarks_age=np.frombuffer(one[pre + "_age"], np.int32),
+                    versors=np.frombuffer(one[pre + "_ver"], np.float64).reshape(-1, 3))
+    e0, ctr = O.feature_detection_frame(L, R, p, seq["lefts"][0], None, 0)
+    _frame_eq(frame_of("s_f0"), e0)
+    eref, e1 = O.feature_tracking_frame(L, R, p, seq["lefts"][0], seq["lefts"][1], e0, R01)
+    assert np.array_equal(frame_of("s_ref")["landmarks"], eref)
+    _frame_eq(frame_of("s_f1"), e1)
+    d = p.detector
+    raw, _ = O.good_features_to_track(seq["lefts"][0], d.max_nr_keypoints_before_anms, d.quality_level, d.min_distance, 3)
+    assert np.array_equal(np.frombuffer(one["s_raw"], np.float32).reshape(-1, 2), raw)
+    assert np.array_equal(np.frombuffer(one["s_lrect"], np.uint8).reshape(H, W), ocam.rectify_image(0, seq["lefts"][0]))
+    assert np.array_equal(np.frombuffer(one["s_rrect"], np.uint8).reshape(H, W), ocam.rectify_image(1, seq["rights"][0]))
+    lx = np.array([[400, 200], [300, 100], [10, 10]], np.float32)
+    rx = np.array([[380, 200], [310, 100], [5, 10]], np.float32)
+    ed, _, ers = O.get_depth_from_rectified_matches(ocam, p.stereo, lx, np.array([0, 0, 1], np.uint8), rx,
+                                                    np.array([0, 0, 0], np.uint8))
+    assert np.array_equal(np.frombuffer(one["s_depth"], np.float64), ed)
+    assert list(np.frombuffer(one["s_rstat"], np.uint8)) == list(ers) == [abi.KP_VALID, abi.KP_NO_DEPTH, abi.KP_NO_LEFT_RECT]

@@ -1398,6 +1398,58 @@ def test_cpp_adapter_program_matches_oracle(seq, ocam, tmp_path):
     finally:
         c.close()
 
+    # ---- round-2 methods called by the program -------------------------------------------------------------
+    f32 = lambda tag: np.frombuffer(one[tag], np.float32).reshape(-1, 2)   # noqa: E731
+    u8 = lambda tag: np.frombuffer(one[tag], np.uint8)                     # noqa: E731
+    exy, est = ocam.undistort_rectify_left(corners)
+    assert np.array_equal(u8("r2_url_st"), est) and np.array_equal(f32("r2_url_xy"), exy)
+    cxy, cst = O.check_undistorted_rectified(ocam, 0, corners, ocam.undistort_keypoints(0, corners, True, True), 0.5)
+    assert np.array_equal(u8("r2_chk_st"), cst) and np.array_equal(f32("r2_chk_xy"), cxy)
+    lrect, rrect = ocam.rectify_image(0, seq["lefts"][0]), ocam.rectify_image(1, seq["rights"][0])
+    assert np.array_equal(u8("r2_lrect").reshape(H, W), lrect) and np.array_equal(u8("r2_rrect").reshape(H, W), rrect)
+    esr = ocam.sparse_stereo(seq["lefts"][0], seq["rights"][0], corners, p.stereo)
+    assert np.array_equal(u8("r2_dep_st"), esr["right_status"]) and np.array_equal(f32("r2_dep_xy"), esr["right_rect_xy"])
+    assert np.array_equal(np.frombuffer(one["r2_depth"], np.float64), esr["depth"])
+    assert np.array_equal(f32("r2_rkps"), esr["right_xy"])
+
+    def frame_of(pre):
+        return dict(keypoints=f32(pre + "_kp"), landmarks=np.frombuffer(one[pre + "_lmk"], np.int64),
+                    landmarks_age=np.frombuffer(one[pre + "_age"], np.int32),
+                    versors=np.frombuffer(one[pre + "_ver"], np.float64).reshape(-1, 3))
+
+    def same_frame(a, b):
+        for k in ("keypoints", "landmarks", "landmarks_age", "versors"):
+            assert np.array_equal(a[k], b[k]), k
+    e0, ectr = O.feature_detection_frame(L, R, p, seq["lefts"][0], None, 0)
+    same_frame(frame_of("r2_f0"), e0)
+    Rk1 = np.array(inputs[1].keyframe_R_cur_frame).reshape(3, 3)
+    eref, e1 = O.feature_tracking_frame(L, R, p, seq["lefts"][0], seq["lefts"][1], e0, Rk1)
+    assert np.array_equal(np.frombuffer(one["r2_ref_lmk"], np.int64), eref)
+    same_frame(frame_of("r2_f1t"), e1)
+    e1d, ectr2 = O.feature_detection_frame(L, R, p, seq["lefts"][1], e1, ectr)
+    same_frame(frame_of("r2_f1d"), e1d)
+    assert np.frombuffer(one["r2_counter"], np.int64)[0] == ectr2
+    # MonoVisionImuFrontend through the adapter
+    mfe = O.Frontend(L, L, p, mono=True)
+    mono_frames, curm = [], None
+    for tag, b in recs:
+        if tag == "m_head":
+            curm = {}
+            mono_frames.append(curm)
+        if tag.startswith("m_"):
+            curm[tag] = b
+    assert len(mono_frames) == 3
+    for i, g in enumerate(mono_frames):
+        Rm = np.array(inputs[i].keyframe_R_cur_frame).reshape(3, 3)
+        e = mfe.process(seq["lefts"][i], seq["lefts"][i], int(seq["ts"][i]), Rm, False)
+        assert list(np.frombuffer(g["m_head"], np.int32)) == [e["n_keypoints"], e["is_keyframe"], e["n_tracked"],
+                                                              e["n_measurements"]], i
+        assert np.array_equal(np.frombuffer(g["m_lmk"], np.int64), e["landmarks"]), i
+        assert np.array_equal(np.frombuffer(g["m_kp"], np.float32).reshape(-1, 2), e["keypoints"]), i
+        if e["is_keyframe"]:
+            assert np.array_equal(np.frombuffer(g["m_meas"], np.float64).reshape(-1, 3), e["meas_uL_uR_v"],
+                                  equal_nan=True), i
+
     # StereoVisionImuFrontend::spinOnce, frame by frame against the oracle front-end
     frames, cur = [], None
     for tag, b in recs:
