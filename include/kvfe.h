@@ -132,7 +132,7 @@ typedef struct kvfe_detector_params {
   int32_t subpix_max_iters;                  /* max_iters                    */
   double subpix_epsilon;                     /* epsilon_error                */
   int32_t enable_non_max_suppression;
-  int32_t non_max_suppression_type;          /* KVFE_ANMS_* (all but BROWN)  */
+  int32_t non_max_suppression_type;          /* KVFE_ANMS_*                  */
   int32_t min_distance;                      /* min_distance (GFTT + mask r) */
   int32_t max_nr_keypoints_before_anms;
   int32_t nr_horizontal_bins, nr_vertical_bins;

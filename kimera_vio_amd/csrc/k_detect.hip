@@ -443,6 +443,19 @@ __device__ void block_bitonic_desc(unsigned long long* a, int n) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// anms::BrownANMS (anms/anms.cpp:51-81) orders its (radius, index) pairs with
+//     std::sort(results.begin(), results.end(), sort_pred())        sort_pred: left.first > right.first
+// Radii between integer pixel positions tie all the time and std::sort is not stable, so WHICH of the tied
+// keypoints make the cut is decided by libstdc++'s introsort (bits/stl_algo.h: __introsort_loop with the
+// median-of-three moved to the front, __unguarded_partition, depth limit 2 lg n with a heap-sort fallback, then
+// __final_insertion_sort; threshold 16).  That algorithm is restated here step for step on the device; the oracle
+// calls the real std::sort of the host's libstdc++, and the parity tests compare the two.
+// ---------------------------------------------------------------------------------------------
+#define KVFE_HD __device__
+#include "kvfe_stdsort.inl"
+#undef KVFE_HD
+
 __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, FrameTab K,
                                                        StreamState S, DetectScratch D,
                                                        int fixed_need) {
@@ -799,6 +812,33 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   } else if (P.anms_type == 0 /* TopN: receives the UNSORTED keypoints */) {
     n_new = need > n_corners ? n_corners : need;
     for (int i = tid; i < n_new; i += SEL_T) newc[i] = corners[i];
+  } else if (P.anms_type == 1 /* BrownANMS: receives the UNSORTED keypoints (NonMaximumSuppression.cpp:74) */) {
+    if (need > n_corners) {
+      for (int i = tid; i < n_corners; i += SEL_T) newc[i] = corners[i];
+      n_new = n_corners;
+    } else {
+      // radius of keypoint i = distance to the nearest keypoint that precedes it (float, as upstream)
+      BrownRI* res = reinterpret_cast<BrownRI*>(skeys);          // [n_corners <= LDS_SORT_CAP]
+      int* stack = cell_start;                                    // introsort ranges
+      __syncthreads();
+      for (int i = tid; i < n_corners; i += SEL_T) {
+        float minDist = 3.402823466e+38f;  // FLT_MAX
+        const float2 ci = corners[i];
+        for (int j = 0; j < i; j++) {
+          const float2 cj = corners[j];
+          const float exp1 = cj.x - ci.x, exp2 = cj.y - ci.y;
+          const float curDist = sqrtf(exp1 * exp1 + exp2 * exp2);
+          minDist = fminf(curDist, minDist);
+        }
+        res[i].r = minDist;
+        res[i].i = i;
+      }
+      __syncthreads();
+      if (tid == 0) brown_std_sort(res, n_corners, stack);
+      __syncthreads();
+      n_new = need;
+      for (int i = tid; i < n_new; i += SEL_T) newc[i] = corners[res[i].i];
+    }
   } else if (P.anms_type >= 2 && P.anms_type <= 5) {
     // ---- anms::Sdc / KdTree / RangeTree / Ssc (anms/anms.cpp:83-436) on the permuted keypoints -----
     // Binary search on the suppression radius; every probe is the greedy sweep "keep a keypoint

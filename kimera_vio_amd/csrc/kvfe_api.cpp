@@ -434,9 +434,6 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     return fail("only the GFTT detector is implemented", KVFE_ERR_UNSUPPORTED);
   if (d.use_harris_detector) return fail("Harris response is not implemented", KVFE_ERR_UNSUPPORTED);
   if (d.block_size != 3) return fail("block_size must be 3", KVFE_ERR_UNSUPPORTED);
-  if (d.enable_non_max_suppression && d.non_max_suppression_type == KVFE_ANMS_BROWN)
-    return fail("BrownANMS is not implemented (its output order rests on an unstable std::sort)",
-                KVFE_ERR_UNSUPPORTED);
   if (d.enable_non_max_suppression &&
       (d.non_max_suppression_type < KVFE_ANMS_TOPN || d.non_max_suppression_type > KVFE_ANMS_BINNING))
     return fail("unknown non_max_suppression_type", KVFE_ERR_INVALID_ARG);

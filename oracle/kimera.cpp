@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE — see kimera.hpp.  Restatement of the reference-owned
 // front-end logic; file:line citations are relative to /root/reference.
 #include "kimera.hpp"
+#include <cfloat>
 
 #include <algorithm>
 #include <cmath>
@@ -384,6 +385,29 @@ bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int
         return true;
       }
       for (int i = 0; i < numRetPoints; i++) out.push_back(keyPoints[i]);
+      return true;
+    }
+    case KVFE_ANMS_BROWN: {  // anms::BrownANMS on the UNSORTED keypoints (anms.cpp:51-81, NonMaximumSuppression.cpp:74)
+      if ((size_t)numRetPoints > keyPoints.size()) {
+        out = keyPoints;
+        return true;
+      }
+      std::vector<std::pair<float, int>> results;
+      results.push_back(std::make_pair(FLT_MAX, 0));
+      for (unsigned int i = 1; i < keyPoints.size(); ++i) {
+        float minDist = FLT_MAX;
+        for (unsigned int j = 0; j < i; ++j) {
+          float exp1 = (keyPoints[j].x - keyPoints[i].x);
+          float exp2 = (keyPoints[j].y - keyPoints[i].y);
+          float curDist = std::sqrt(exp1 * exp1 + exp2 * exp2);
+          minDist = std::min(curDist, minDist);
+        }
+        results.push_back(std::make_pair(minDist, (int)i));
+      }
+      // the REAL std::sort of the host's libstdc++ (the reference's tie order is whatever this does)
+      std::sort(results.begin(), results.end(),
+                [](const std::pair<float, int>& left, const std::pair<float, int>& right) { return left.first > right.first; });
+      for (int i = 0; i < numRetPoints; ++i) out.push_back(keyPoints[results[i].second]);
       return true;
     }
     case KVFE_ANMS_BINNING: {  // NonMaximumSuppression.cpp:125-169

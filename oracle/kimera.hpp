@@ -61,8 +61,8 @@ void camera_matrix(const kvfe_camera_params& c, double K[9]);
 void sortidx_descending_equal_keys(int n, int policy, std::vector<int>& idx);
 
 // AdaptiveNonMaximumSuppression::suppressNonMax (NonMaximumSuppression.cpp:33-122)
-// for TopN, Binning (the types the shipped YAMLs and the reference tests use) and the radius-search
-// variants Sdc / KdTree / RangeTree / Ssc (anms/anms.cpp).  Returns false for BrownANMS.
+// for TopN, Binning (the types the shipped YAMLs and the reference tests use), BrownANMS and the
+// radius-search variants Sdc / KdTree / RangeTree / Ssc (anms/anms.cpp).
 bool suppressNonMax(const std::vector<Point2f>& keypoints, int numRetPoints, int cols, int rows,
                     const kvfe_detector_params& p, std::vector<Point2f>& out);
 

@@ -796,10 +796,11 @@ def test_c_abi_argument_validation(ctx):
 # ---------------------------------------------------------------------------------------------
 # ANMS: the radius-search variants of anms/anms.cpp (RangeTree is the class default)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("anms_type", [abi.ANMS_SDC, abi.ANMS_KDTREE, abi.ANMS_RANGETREE, abi.ANMS_SSC])
+@pytest.mark.parametrize("anms_type", [abi.ANMS_BROWN, abi.ANMS_SDC, abi.ANMS_KDTREE, abi.ANMS_RANGETREE, abi.ANMS_SSC])
 def test_feature_detection_anms_variants(anms_type, seq):
-    """featureDetection with non_max_suppression_type 2..5: the binary search on the suppression radius
-    and every greedy sweep equal the CPU path (same corners, same order, then cornerSubPix), with and
+    """featureDetection with non_max_suppression_type 1..5.  BrownANMS (1): the radii and the libstdc++ std::sort
+    order over their many ties (kvfe_stdsort.inl on the device, the real std::sort in the oracle).  2..5: the
+    binary search on the suppression radius and every greedy sweep equal the CPU path (same corners, same order, then cornerSubPix), with and
     without tracked keypoints, for several `need`; need < 2 returns nothing (closed form divides by 0)."""
     L, R = euroc_cams()
     p = euroc_params()
@@ -825,7 +826,7 @@ def test_feature_detection_anms_variants(anms_type, seq):
             got = c.feature_detection(img, none, need)
             exp, _ = O.feature_detection(img, none, need, p.detector)
             assert np.array_equal(got, exp), (anms_type, need, len(got), len(exp))
-            if anms_type != abi.ANMS_SDC and need < 2:
+            if anms_type not in (abi.ANMS_SDC, abi.ANMS_BROWN) and need < 2:
                 assert len(got) == 0
         if anms_type == abi.ANMS_SDC:
             assert len(c.feature_detection(img, none, 0)) >= 1

@@ -135,3 +135,15 @@ def test_cpp_adapter_program_builds_with_plain_gxx():
     assert r.returncode == 0, r.stderr
     r = subprocess.run([os.path.join(cpp, "adapter_sequence")], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_device_std_sort_restatement_equals_libstdcxx():
+    """kimera_vio_amd/csrc/kvfe_stdsort.inl -- the introsort the select kernel runs for BrownANMS -- compiled for
+    the host and compared with the real std::sort (comparator of anms/anms.h sort_pred) on tie-heavy inputs up
+    to 8192 elements, heap-sort fallback included: same permutation."""
+    import subprocess
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    r = subprocess.run(["make", "-C", cpp, "stdsort_check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([os.path.join(cpp, "stdsort_check"), "1200"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr

@@ -433,6 +433,45 @@ def test_anms_radius_search_variants(anms_type, name):
         assert len(O.suppress_non_max(kps, 1, w, h, p)) == 0
 
 
+def test_anms_brown():
+    """anms::BrownANMS (anms/anms.cpp:51-81; no golden numbers upstream): keypoint i gets the distance to the nearest
+    keypoint BEFORE it in the (unsorted) input, the pairs are std::sort-ed by radius descending and the first
+    numRetPoints are returned.  Checked against a numpy restatement of the radii: the output radii are non-increasing,
+    start with keypoint 0 (FLT_MAX), every returned radius >= every dropped one, and where radii are distinct the
+    order is forced.  numRetPoints > size returns the input unchanged."""
+    img = np.array(Image.open(os.path.join(G, "left_fisheye_img_0.png")).convert("L"))
+    h, w = img.shape
+    kps, _ = O.good_features_to_track(img, 1200, 0.001, 10, 3)
+    p = P.default_frontend_params().detector
+    p.non_max_suppression_type = 1
+    n = len(kps)
+    assert n > 600
+    d = kps[:, None, :].astype(np.float32) - kps[None, :, :].astype(np.float32)
+    dist = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(np.float32)).astype(np.float32)
+    radius = np.full(n, np.finfo(np.float32).max, np.float32)
+    for i in range(1, n):
+        radius[i] = dist[i, :i].min()
+    pos = {tuple(k): i for i, k in enumerate(kps.tolist())}
+    for need in (1, 50, 300, n):
+        out = O.suppress_non_max(kps, need, w, h, p)
+        assert len(out) == need
+        idx = [pos[tuple(k)] for k in out.tolist()]
+        assert len(set(idx)) == need and idx[0] == 0
+        r = radius[idx]
+        assert np.all(r[:-1] >= r[1:])
+        rest = np.setdiff1d(np.arange(n), idx)
+        if len(rest):
+            assert r[-1] >= radius[rest].max()
+        uniq, counts = np.unique(radius, return_counts=True)
+        single = set(uniq[counts == 1].tolist())
+        order = np.argsort(-radius, kind="stable")
+        for k in range(need):
+            if float(radius[order[k]]) in single:
+                assert idx[k] == order[k]
+    assert np.array_equal(O.suppress_non_max(kps, n + 1, w, h, p), kps)
+    assert len(O.suppress_non_max(kps, 0, w, h, p)) == 0
+
+
 # --------------------------------------------------------------------------- equidistant (cv::fisheye)
 def _fisheye_cams():
     return (P.load_camera_params(os.path.join(G, "left_sensor_fisheye.yaml")),

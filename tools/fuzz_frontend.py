@@ -22,7 +22,7 @@ for ci in range(n_cfg):
     d.max_features_per_frame = int(rng.choice([40, 100, 200, 400]))
     d.min_distance = int(rng.choice([5, 10, 20]))
     d.quality_level = float(rng.choice([0.001, 0.01, 0.05]))
-    d.non_max_suppression_type = int(rng.choice([0, 2, 3, 4, 5, 6]))
+    d.non_max_suppression_type = int(rng.choice([0, 1, 2, 3, 4, 5, 6]))
     d.enable_subpixel_corner_refinement = int(rng.randint(0, 2))
     t.klt_win_size = int(rng.choice([16, 24, 32, 21, 15]))
     t.klt_max_level = int(rng.choice([1, 2, 3, 4]))
