@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c3",
                     help="which BASELINE config `value` is measured on: c3 = configs[2] (headline), c4 = configs[3] "
                          "(8 EuRoC sequences sharded over the GPUs, one stream per sequence, strong scaling), "
                          "c5 = configs[4]")

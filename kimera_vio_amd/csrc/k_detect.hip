@@ -12,6 +12,8 @@
 // lambda > maxVal*quality afterwards on the compacted list.  HBM traffic per image: one read of
 // the image (+ the optional user mask); the detection mask "255 minus filled discs around the
 // tracked keypoints" is evaluated analytically from the keypoint list (exact cv::circle spans).
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include "kvfe_dev.hpp"
@@ -339,6 +341,28 @@ constexpr int SEL_T = 1024;
 constexpr int MAX_CELLS = 12288;
 constexpr int LDS_SORT_CAP = 8192;
 constexpr int GREEDY_CELLS = 3072;  // 16-byte accepted-corner slots of the in-order greedy filter (LDS)
+constexpr int SEL_LDS_BASE = (int)(sizeof(unsigned long long) * LDS_SORT_CAP + sizeof(int) * (MAX_CELLS + 1));
+constexpr int SEL_LDS_MAX = 160 * 1024 - 2048;  // dynamic LDS ceiling (statics of the kernel stay below 2 KB)
+// "blocked" bitmap of the in-order minimum-distance filter: one bit per pixel, rows of `rw` 64-bit words (odd, so
+// that the rows of a disc land in different banks, and with at least one spare word at the end of a row so that a
+// span may always be written as two words); it sits behind the packed (x | y << 16) candidate list
+__host__ __device__ inline int sel_bitmap_row_words(int W) { return (((W + 63) >> 6) + 1) | 1; }  // >= 1 pad word
+__host__ __device__ inline long long sel_bitmap_lds_bytes(int W, int H) {
+  return (long long)sizeof(unsigned) * LDS_SORT_CAP + (long long)H * sel_bitmap_row_words(W) * 8;
+}
+// LDS layout when the bitmap fits (every image up to about 1280x720):
+//   [0, 32 K)        xy      u32 [8192]  candidates in rank order, packed x | y << 16 (accepted ones in place)
+//   [32 K, 96 K)     skeys   u64 [8192]  candidate keys as compacted (unordered)          } the bitmap overlays these
+//   [96 K, 112 K)    hist    int [4096]  radix-rank sort: keys per bin / cursors           } once the ranks are known
+//   [112 K, 128 K)   start   int [4096]  first rank of each bin                            }
+//   [128 K, 144 K)   tmpidx  u16 [8192]  key positions grouped by bin                      }
+// the other paths of the kernel use skeys and, behind it, cell_start [MAX_CELLS + 1] as before (ends at 147 460).
+constexpr int SEL_XY_BYTES = (int)sizeof(unsigned) * LDS_SORT_CAP;
+constexpr int SEL_RADIX_BINS = 4096;
+constexpr int SEL_LDS_BITMAP_MIN = SEL_XY_BYTES + SEL_LDS_BASE + 12;  // 147 472
+__host__ __device__ inline bool sel_use_bitmap(int W, int H, int md) {
+  return md >= 1 && md <= 127 && W < 65536 && H < 65536 && sel_bitmap_lds_bytes(W, H) <= SEL_LDS_MAX;
+}
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16]*/, int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -455,16 +479,28 @@ __device__ void block_bitonic_desc(unsigned long long* a, int n) {
 #define KVFE_HD __device__
 #include "kvfe_stdsort.inl"
 #undef KVFE_HD
+#include "kvfe_blocksort.inl"
+
+// KVFE_SELECT_PROF=1 (debugging aid): phase time stamps of stream 0's block, summed on the host and printed at exit
+__device__ unsigned long long kvfe_select_stamps[16];
+#define SEL_STAMP(i)                                                                        \
+  do {                                                                                      \
+    if (prof && s == 0 && threadIdx.x == 0) kvfe_select_stamps[i] = __builtin_readcyclecounter(); \
+  } while (0)
 
 __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, FrameTab K,
                                                        StreamState S, DetectScratch D,
-                                                       int fixed_need) {
+                                                       int fixed_need, int prof) {
   const int s = blockIdx.x;
   if (!(S.flags[s] & FLAG_DETECT)) return;
+  SEL_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  // LDS carve-up: sortkeys [LDS_SORT_CAP] u64 | cell_start [MAX_CELLS+1] int | small
-  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(lds_raw);
-  int* cell_start = reinterpret_cast<int*>(lds_raw + sizeof(unsigned long long) * LDS_SORT_CAP);
+  // LDS carve-up: [xy u32 [LDS_SORT_CAP] when the blocked-pixel bitmap fits |] sortkeys [LDS_SORT_CAP] u64 |
+  // cell_start [MAX_CELLS+1] int | small
+  const bool bitmap_cfg = sel_use_bitmap(P.W, P.H, P.min_distance);
+  unsigned char* lds_keys = lds_raw + (bitmap_cfg ? SEL_XY_BYTES : 0);
+  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(lds_keys);
+  int* cell_start = reinterpret_cast<int*>(lds_keys + sizeof(unsigned long long) * LDS_SORT_CAP);
   __shared__ int wave_tot[SEL_T / 64];
   __shared__ int sh_cnt, sh_flag, sh_n;
   __shared__ int bin_cnt[MAX_BINS];
@@ -492,6 +528,8 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     D.cand_count[s] = 0;
     D.maxkey[s] = 0u;
   }
+  // (the order of the survivors is irrelevant: keys are distinct and everything downstream ranks by key, so the
+  // list is appended wave by wave with one LDS atomic per wave instead of block scans and barriers)
   for (int base = 0; base < C; base += SEL_T) {
     const int i = base + tid;
     bool keep = false;
@@ -501,22 +539,267 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
       const float v = __uint_as_float((unsigned)(key >> 32));
       keep = (v > thr) && (v != 0.0f);
     }
-    int tot;
-    const int pos = block_exclusive_scan(keep ? 1 : 0, wave_tot, &tot);
-    const int off = sh_cnt;
-    if (keep) work[off + pos] = key;
-    __syncthreads();
-    if (tid == 0) sh_cnt = off + tot;
-    __syncthreads();
+    const unsigned long long km = __ballot(keep);
+    if (km) {
+      const int lane = tid & 63;
+      int wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&sh_cnt, __popcll(km));
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
+      if (keep) {
+        const int pos = wbase + __popcll(km & ((1ull << lane) - 1ull));
+        work[pos] = key;
+        if (pos < LDS_SORT_CAP) skeys[pos] = key;
+      }
+    }
   }
+  __syncthreads();
   const int C2 = sh_cnt;
   __syncthreads();
+  SEL_STAMP(1);
+  if (prof && s == 0 && tid == 0) {
+    kvfe_select_stamps[10] = C;
+    kvfe_select_stamps[11] = C2;
+  }
 
   int A = 0;  // accepted corners, keys in `akeys`
   unsigned long long* akeys = skeys;
   const int md = P.min_distance;
-  bool sorted_accepted = false;
-  if (md >= 1 && C2 > 0 && C2 <= LDS_SORT_CAP &&
+  bool sorted_accepted = false, corners_written = false;
+  if (bitmap_cfg && C2 > 0 && C2 <= LDS_SORT_CAP) {
+    // ---- cv::goodFeaturesToTrack's greedy minimum-distance filter, in its own (sequential) order ----
+    // 1. the candidates are RANKED by (value, index) descending: radix-rank sort -- histogram over the top bits of the
+    //    value, prefix sum, grouping by bin, then every key counts the larger keys of its own bin (two or three on real
+    //    images); a bin with more than 64 keys (flat synthetic patterns) falls back to the block-wide bitonic sort;
+    // 2. blocked-pixel bitmap: accepting a corner marks the open disc of radius minDistance around it, a candidate is
+    //    tested with ONE bit lookup (the reference's 3x3-cell search evaluates exactly this predicate: dx^2 + dy^2 <
+    //    minDistance^2 against every accepted corner).  One wavefront walks the ranked list 64 at a time; survivors of a
+    //    batch are resolved in rank order with ballots.  The sequential wave spends its time on the ~n_corners
+    //    acceptances, not on the C2 candidates, and stops at maxCorners exactly where the reference loop breaks.
+    unsigned* xy = reinterpret_cast<unsigned*>(lds_raw);  // candidates in rank order; accepted ones in place
+    unsigned long long* bm = reinterpret_cast<unsigned long long*>(lds_raw + SEL_XY_BYTES);
+    const int rw = sel_bitmap_row_words(W);
+    auto pack_xy = [&](unsigned long long key) -> unsigned {
+      const unsigned idx = (unsigned)key;
+      const unsigned y = idx / (unsigned)W;
+      return (idx - y * (unsigned)W) | (y << 16);
+    };
+    if (C2 <= 256) {
+      // short list: rank = number of larger keys
+      for (int i = tid; i < C2; i += SEL_T) {
+        const unsigned long long k = skeys[i];
+        int rank = 0;
+        for (int q = 0; q < C2; q++) rank += skeys[q] > k ? 1 : 0;
+        xy[rank] = pack_xy(k);
+      }
+    } else {
+      int* hist = cell_start;                        // [SEL_RADIX_BINS]
+      int* start = hist + SEL_RADIX_BINS;            // [SEL_RADIX_BINS]
+      unsigned short* tmpidx = reinterpret_cast<unsigned short*>(start + SEL_RADIX_BINS);  // [LDS_SORT_CAP]
+      // bin = monotone non-increasing function of the key: the value's float bits relative to the threshold's,
+      // scaled so that [threshold, maximum] spans the bins; bin 0 holds the largest values
+      const unsigned lo_bits = __float_as_uint(fmaxf(thr, 0.0f));
+      const unsigned hi_bits = max(__float_as_uint(maxVal), lo_bits + 1u);
+      int shift = 0;
+      while (((hi_bits - lo_bits) >> shift) >= (unsigned)SEL_RADIX_BINS) shift++;
+      auto bin_of = [&](unsigned long long key) -> int {
+        const unsigned vb = (unsigned)(key >> 32);
+        const unsigned d = vb > lo_bits ? vb - lo_bits : 0u;
+        return max(SEL_RADIX_BINS - 1 - (int)min(d >> shift, (unsigned)(SEL_RADIX_BINS - 1)), 0);
+      };
+      for (int i = tid; i < SEL_RADIX_BINS; i += SEL_T) hist[i] = 0;
+      if (tid == 0) sh_flag = 0;
+      __syncthreads();
+      for (int i = tid; i < C2; i += SEL_T) atomicAdd(&hist[bin_of(skeys[i])], 1);
+      __syncthreads();
+      {
+        constexpr int PER = SEL_RADIX_BINS / SEL_T;
+        int c[PER], sum = 0;
+        bool big = false;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          c[q] = hist[tid * PER + q];
+          sum += c[q];
+          big |= c[q] > 64;
+        }
+        if (big) sh_flag = 1;
+        int run = block_exclusive_scan(sum, wave_tot, nullptr);
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          start[tid * PER + q] = run;
+          hist[tid * PER + q] = run;  // becomes the bin's cursor
+          run += c[q];
+        }
+      }
+      __syncthreads();
+      if (sh_flag == 0) {
+        for (int i = tid; i < C2; i += SEL_T) {
+          const int pos = atomicAdd(&hist[bin_of(skeys[i])], 1);
+          tmpidx[pos] = (unsigned short)i;
+        }
+        __syncthreads();
+        for (int p0 = tid; p0 < C2; p0 += SEL_T) {
+          const unsigned long long k = skeys[tmpidx[p0]];
+          const int b = bin_of(k);
+          const int b0 = start[b], b1 = hist[b];  // the cursor ended at the bin's end
+          int rank = b0;
+          for (int q = b0; q < b1; q++) rank += skeys[tmpidx[q]] > k ? 1 : 0;
+          xy[rank] = pack_xy(k);
+        }
+      } else {
+        // many equal or nearly equal values: block-wide bitonic sort of the zero-padded list
+        constexpr int EPT = LDS_SORT_CAP / SEL_T;
+        unsigned long long v[EPT];
+#pragma unroll
+        for (int m = 0; m < EPT; m++) {
+          const int i = tid + m * SEL_T;
+          v[m] = i < C2 ? skeys[i] : 0ull;
+        }
+        __syncthreads();
+        blocksort::sort_desc_blocked<EPT>(v, skeys);
+#pragma unroll
+        for (int m = 0; m < EPT; m++) {
+          const int r = EPT * tid + m;
+          if (r < C2) xy[r] = pack_xy(v[m]);
+        }
+      }
+    }
+    __syncthreads();
+    SEL_STAMP(6);
+    for (int i = tid; i < H * rw; i += SEL_T) bm[i] = 0ull;
+    __syncthreads();
+    SEL_STAMP(2);
+    if (tid < 64) {
+      const int lane = tid;
+      const int md2i = md * md;
+      // half width of the disc on the row lane + 64 p of its 2 md - 1 rows: largest h with h^2 + dy^2 < md^2
+      int hw[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int dy = lane + 64 * p - (md - 1);
+        int h = -1;
+        if (dy < md) {
+          const int t = md2i - dy * dy;  // > 0
+          h = (int)sqrtf((float)t);
+          while (h * h >= t) h--;
+          while ((h + 1) * (h + 1) < t) h++;
+        }
+        hw[p] = h;
+      }
+      int acc = 0;
+      bool done = false;
+      if (md <= 32) {
+        // one pass of rows (2 md - 1 <= 63) and a span of at most 63 bits = two words, all straight-line: the wave
+        // runs alone, every instruction and above all every taken branch of the per-acceptance path costs latency
+        const int h = hw[0];
+        const int row0 = lane - (md - 1);
+        unsigned vn = lane < C2 ? xy[lane] : 0u;
+        unsigned long long t_test = 0, t_res = 0, t_prev = prof ? __builtin_readcyclecounter() : 0;
+        for (int base = 0; base < C2 && !done; base += 64) {
+          const unsigned v = vn;
+          const bool valid = base + lane < C2;
+          const int nb = base + 64 + lane;
+          vn = nb < C2 ? xy[nb] : 0u;  // next batch's candidates: their LDS latency hides behind this batch
+          const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
+          const unsigned long long wbits = bm[y * rw + (x >> 6)];
+          const bool ok = valid && !((wbits >> (x & 63)) & 1ull);
+          unsigned long long mask = __ballot(ok);
+          if (prof) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_test += t - t_prev;
+            t_prev = t;
+          }
+          while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            const int lx = __builtin_amdgcn_readlane(x, l), ly = __builtin_amdgcn_readlane(y, l);
+            if (lane == l) xy[acc] = v;
+            acc++;
+            if (P.max_corners > 0 && acc == P.max_corners) {
+              done = true;
+              break;
+            }
+            const int yy = ly + row0;
+            if (h >= 0 && (unsigned)yy < (unsigned)H) {
+              const int x0 = max(lx - h, 0), x1 = min(lx + h, W - 1);
+              const int sh = x0 & 63;
+              const unsigned long long span = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 63 ones
+              unsigned long long* pw = &bm[yy * rw + (x0 >> 6)];
+              __hip_atomic_fetch_or(pw, span << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_or(pw + 1, (span >> 1) >> (63 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const int dx = x - lx, dy = y - ly;
+            const bool near = ok && (dx * dx + dy * dy < md2i);
+            mask &= ~__ballot(near);
+          }
+          __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the next batch's lookups follow the marks (LDS is in order)
+          if (prof) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_res += t - t_prev;
+            t_prev = t;
+          }
+        }
+        if (prof && s == 0 && lane == 0) {
+          kvfe_select_stamps[8] = t_test;
+          kvfe_select_stamps[9] = t_res;
+        }
+      } else {
+      for (int base = 0; base < C2 && !done; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < C2;
+        const unsigned v = valid ? xy[i] : 0u;
+        const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
+        const unsigned long long wbits = bm[y * rw + (x >> 6)];
+        const bool ok = valid && !((wbits >> (x & 63)) & 1ull);
+        unsigned long long mask = __ballot(ok);
+        while (mask) {
+          const int l = __ffsll((long long)mask) - 1;  // highest-ranked survivor of the batch
+          const int lx = __builtin_amdgcn_readlane(x, l), ly = __builtin_amdgcn_readlane(y, l);
+          if (lane == l) xy[acc] = v;  // in place: acc <= base + l, the batch itself is in registers
+          acc++;
+          if (P.max_corners > 0 && acc == P.max_corners) {
+            done = true;
+            break;
+          }
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            if (64 * p < 2 * md - 1) {  // wave-uniform
+              const int yy = ly - (md - 1) + lane + 64 * p;
+              const int h = hw[p];
+              if (h >= 0 && yy >= 0 && yy < H) {
+                const int x0 = max(lx - h, 0), x1 = min(lx + h, W - 1);
+                const int w0 = x0 >> 6, w1 = x1 >> 6;
+                for (int w = w0; w <= w1; w++) {
+                  const int lo = w == w0 ? (x0 & 63) : 0, hi = w == w1 ? (x1 & 63) : 63;
+                  const unsigned long long bits = (~0ull >> (63 - hi)) & (~0ull << lo);
+                  __hip_atomic_fetch_or(&bm[yy * rw + w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              }
+            }
+          }
+          const int dx = x - lx, dy = y - ly;
+          const bool near = ok && (dx * dx + dy * dy < md2i);
+          mask &= ~__ballot(near);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the next batch's lookups follow the marks (LDS is in order)
+      }
+      }
+      if (lane == 0) sh_cnt = acc;
+    }
+    __syncthreads();
+    A = sh_cnt;
+    // corners are written from the packed list (the u64 key area is gone)
+    {
+      int nc = A;
+      if (P.max_corners > 0) nc = min(nc, P.max_corners);
+      nc = min(nc, P.acap);
+      float2* cw = D.corners + (size_t)s * P.acap;
+      for (int i = tid; i < nc; i += SEL_T) {
+        const unsigned v = xy[i];
+        cw[i] = make_float2((float)(v & 0xffffu), (float)(v >> 16));
+      }
+    }
+    corners_written = true;
+    sorted_accepted = true;
+  } else if (md >= 1 && C2 > 0 && C2 <= LDS_SORT_CAP &&
       ((W + md - 1) / md) * ((H + md - 1) / md) <= GREEDY_CELLS && W < 65536 && H < 65536) {
     // ---- cv::goodFeaturesToTrack's greedy minimum-distance filter, in its own (sequential) order ----
     // 1. all candidates sorted by (value, index) descending in LDS;
@@ -534,7 +817,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
       // rank sort: keys are distinct, rank = number of larger keys (O(n^2): only for short lists --
       // 2048 keys cost 80 us this way, 10 us with the register-resident bitonic network below)
       unsigned long long* tmp = reinterpret_cast<unsigned long long*>(cell_start);
-      for (int i = tid; i < C2; i += SEL_T) tmp[i] = work[i];
+      for (int i = tid; i < C2; i += SEL_T) tmp[i] = skeys[i];
       __syncthreads();
       for (int i = tid; i < C2; i += SEL_T) {
         const unsigned long long k = tmp[i];
@@ -546,13 +829,16 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     } else {
       int n2 = 1;
       while (n2 < C2) n2 <<= 1;
-      for (int i = tid; i < n2; i += SEL_T) skeys[i] = i < C2 ? work[i] : 0ull;
+      for (int i = C2 + tid; i < n2; i += SEL_T) skeys[i] = 0ull;  // (the keys are in skeys since the compaction)
       __syncthreads();
       block_bitonic_desc(skeys, n2);
     }
+    SEL_STAMP(6);
+    {
     for (int i = tid; i < ncell * 4; i += SEL_T) grid[i] = 0xffffffffu;
     if (tid == 0) sh_flag = 0;
     __syncthreads();
+    SEL_STAMP(2);
     if (tid < 64) {
       const int lane = tid;
       const float md2 = (float)((double)md * (double)md);
@@ -624,6 +910,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     A = sh_cnt;
     if (sh_flag == 2) overflow = 1;
     sorted_accepted = true;
+    }
   } else if (md >= 1 && C2 > 0) {
     // grid of cells of side >= minDistance (cvRound(minDistance) for an integer distance): the 3x3 block
     // around a candidate holds every corner closer than minDistance.  For a small distance on a large
@@ -681,6 +968,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
         // parallel evaluation of the sequential greedy filter: a candidate is accepted iff every
         // higher-ranked candidate closer than minDistance (searched in the 3x3 cell block, as
         // OpenCV does) is rejected; rejected iff one of them is accepted.
+        SEL_STAMP(2);
         const float md2 = (float)((double)md * (double)md);
         volatile unsigned char* vstate = state;
         for (int round = 0; round < 8192; round++) {
@@ -773,12 +1061,13 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     A = C2;
   }
   __syncthreads();
+  SEL_STAMP(3);
   int n_corners = A;
   if (P.max_corners > 0) n_corners = min(n_corners, P.max_corners);
   n_corners = min(n_corners, P.acap);
   if (A > P.acap && (P.max_corners <= 0 || P.max_corners > P.acap)) overflow = 1;
   float2* corners = D.corners + (size_t)s * P.acap;
-  for (int i = tid; i < n_corners; i += SEL_T) {
+  for (int i = tid; i < n_corners && !corners_written; i += SEL_T) {
     const unsigned idx = (unsigned)akeys[i];
     const int y = idx / W, x = idx - y * W;
     corners[i] = make_float2((float)x, (float)y);
@@ -801,6 +1090,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     need = max(P.max_features - tot, 0);
   }
 
+  SEL_STAMP(4);
   // ---- ANMS (NonMaximumSuppression.cpp:33-169) -----------------------------------------------
   float2* newc = D.newc + (size_t)s * P.acap;
   int n_new = 0;
@@ -1025,6 +1315,11 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     overflow = 1;
   }
   __syncthreads();
+  SEL_STAMP(5);
+  if (prof && s == 0 && tid == 0) {
+    kvfe_select_stamps[12] = n_corners;
+    kvfe_select_stamps[13] = n_new;
+  }
   if (tid == 0) {
     D.n_corners[s] = n_corners;
     D.n_new[s] = n_new;
@@ -1036,7 +1331,9 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
 
 void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const StreamState& S,
                    const DetectScratch& D, int fixed_need, hipStream_t st) {
-  const size_t lds = sizeof(unsigned long long) * LDS_SORT_CAP + sizeof(int) * (MAX_CELLS + 1);
+  size_t lds = SEL_LDS_BASE;
+  if (sel_use_bitmap(P.W, P.H, P.min_distance))
+    lds = std::max((size_t)SEL_LDS_BITMAP_MIN, (size_t)sel_bitmap_lds_bytes(P.W, P.H));
   // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: apply it once on every device a
   // context of this process launches on (contexts may live on different GPUs / threads, kvfe.h)
   static std::mutex mu;
@@ -1047,11 +1344,39 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
     std::lock_guard<std::mutex> lk(mu);
     if (dev >= 0 && dev < 256 && !((done_mask[dev >> 6] >> (dev & 63)) & 1ull)) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_MAX);
       done_mask[dev >> 6] |= 1ull << (dev & 63);
     }
   }
-  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need);
+  static const bool prof = std::getenv("KVFE_SELECT_PROF") != nullptr;
+  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need, prof ? 1 : 0);
+  if (prof) {
+    static double acc[16];
+    static long n = 0;
+    static bool reg = false;
+    unsigned long long h[16];
+    hipStreamSynchronize(st);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_select_stamps), sizeof(h));
+    if (h[6] < h[1] || h[2] < h[6] || h[3] < h[2]) return;  // another path ran: the stamps of this one are stale
+    acc[1] += (double)(h[1] - h[0]);   // threshold + compaction
+    acc[2] += (double)(h[6] - h[1]);   // sort
+    acc[6] += (double)(h[2] - h[6]);   // pack + clear
+    acc[3] += (double)(h[3] - h[2]);   // greedy filter
+    acc[4] += (double)(h[4] - h[3]);
+    acc[5] += (double)(h[5] - h[4]);
+    acc[7] += (double)(h[5] - h[0]);
+    acc[8] += (double)h[8];
+    acc[9] += (double)h[9];
+    for (int i = 10; i < 14; i++) acc[i] += (double)h[i];
+    n++;
+    if (!reg) {
+      reg = true;
+      std::atexit([] {
+        std::fprintf(stderr, "KVFE_SELECT_PROF n=%ld cycles: total %.0f (greedy: test %.0f resolve %.0f) threshold+compact %.0f sort %.0f pack+clear %.0f greedy %.0f bookkeeping %.0f anms %.0f | C %.0f C2 %.0f n_corners %.0f n_new %.0f\n",
+                     n, acc[7] / n, acc[8] / n, acc[9] / n, acc[1] / n, acc[2] / n, acc[6] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[10] / n, acc[11] / n, acc[12] / n, acc[13] / n);
+      });
+    }
+  }
 }
 
 // =============================================================================================
