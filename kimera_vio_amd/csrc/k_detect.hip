@@ -692,15 +692,23 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
         // runs alone, every instruction and above all every taken branch of the per-acceptance path costs latency
         const int h = hw[0];
         const int row0 = lane - (md - 1);
-        unsigned vn = lane < C2 ? xy[lane] : 0u;
+        const int rowoff = row0 * rw;  // word offset of this lane's row of the disc relative to the centre row
         unsigned long long t_test = 0, t_res = 0, t_prev = prof ? __builtin_readcyclecounter() : 0;
+        // software pipeline: the candidates of batch b + 2 and the bitmap words of batch b + 1 are fetched while
+        // batch b is resolved; the speculative bitmap word stays valid as long as batch b accepts nothing (the usual
+        // case once the image is covered), otherwise it is read again behind the marks
+        auto word_of = [&](unsigned c) -> const unsigned long long* {
+          return &bm[(int)(c >> 16) * rw + (int)((c & 0xffffu) >> 6)];
+        };
+        unsigned v = lane < C2 ? xy[lane] : 0u;
+        unsigned vn = 64 + lane < C2 ? xy[64 + lane] : 0u;
+        unsigned long long wbits = *word_of(v);
         for (int base = 0; base < C2 && !done; base += 64) {
-          const unsigned v = vn;
+          unsigned long long wn = *word_of(vn);
+          const int nnb = base + 128 + lane;
+          const unsigned vnn = nnb < C2 ? xy[nnb] : 0u;
           const bool valid = base + lane < C2;
-          const int nb = base + 64 + lane;
-          vn = nb < C2 ? xy[nb] : 0u;  // next batch's candidates: their LDS latency hides behind this batch
           const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
-          const unsigned long long wbits = bm[y * rw + (x >> 6)];
           const bool ok = valid && !((wbits >> (x & 63)) & 1ull);
           unsigned long long mask = __ballot(ok);
           if (prof) {
@@ -708,29 +716,35 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
             t_test += t - t_prev;
             t_prev = t;
           }
-          while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            const int lx = __builtin_amdgcn_readlane(x, l), ly = __builtin_amdgcn_readlane(y, l);
-            if (lane == l) xy[acc] = v;
-            acc++;
-            if (P.max_corners > 0 && acc == P.max_corners) {
-              done = true;
-              break;
-            }
-            const int yy = ly + row0;
-            if (h >= 0 && (unsigned)yy < (unsigned)H) {
-              const int x0 = max(lx - h, 0), x1 = min(lx + h, W - 1);
-              const int sh = x0 & 63;
-              const unsigned long long span = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 63 ones
-              unsigned long long* pw = &bm[yy * rw + (x0 >> 6)];
-              __hip_atomic_fetch_or(pw, span << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_or(pw + 1, (span >> 1) >> (63 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            const int dx = x - lx, dy = y - ly;
-            const bool near = ok && (dx * dx + dy * dy < md2i);
-            mask &= ~__ballot(near);
+          if (mask) {
+            do {
+              const int l = __ffsll((long long)mask) - 1;
+              const int lx = __builtin_amdgcn_readlane(x, l), ly = __builtin_amdgcn_readlane(y, l);
+              if (lane == l) xy[acc] = v;  // in place: acc <= base + l, and batches b + 1, b + 2 are in registers
+              acc++;
+              if (P.max_corners > 0 && acc == P.max_corners) {
+                done = true;
+                break;
+              }
+              const int yy = ly + row0;
+              if (h >= 0 && (unsigned)yy < (unsigned)H) {
+                const int x0 = max(lx - h, 0), x1 = min(lx + h, W - 1);
+                const int sh = x0 & 63;
+                const unsigned long long span = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 63 ones
+                unsigned long long* pw = &bm[ly * rw + rowoff + (x0 >> 6)];
+                __hip_atomic_fetch_or(pw, span << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(pw + 1, (span >> 1) >> (63 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+              const int dx = x - lx, dy = y - ly;
+              const bool near = ok && (__mul24(dx, dx) + __mul24(dy, dy) < md2i);
+              mask &= ~__ballot(near);
+            } while (mask);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the lookups below follow the marks (LDS is in order)
+            wn = *static_cast<const volatile unsigned long long*>(word_of(vn));
           }
-          __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the next batch's lookups follow the marks (LDS is in order)
+          v = vn;
+          vn = vnn;
+          wbits = wn;
           if (prof) {
             const unsigned long long t = __builtin_readcyclecounter();
             t_res += t - t_prev;
