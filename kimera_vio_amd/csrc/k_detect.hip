@@ -1457,9 +1457,15 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
     bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
   bound = min(bound, P.acap);
-  // KVFE_SUBPIX_WAVES=1: one wave per corner (LDS-ring chains); default 2 (DPP broadcast chains, kvfe_subpix.inl)
-  static const int nw = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 2;
-  if (P.subpix_win == 10 && nw == 2)
+  // KVFE_SUBPIX_WAVES=1: one wave per corner (LDS-ring chains); default 2 (DPP broadcast chains, kvfe_subpix.inl), and
+  // 4 for a few streams: the patch and term work of an iteration is spread over four SIMDs (5.4 k instead of 6.3 k
+  // cycles per iteration as long as the corners are few; with ~1000 corners in flight two waves are faster)
+  static const int nw_env = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 0;
+  const int nw = nw_env ? nw_env : (P.B <= 4 ? 4 : 2);
+  if (P.subpix_win == 10 && nw == 4)
+    hipLaunchKernelGGL((subpix_append_kernel<10, 4>), dim3(bound, P.B), dim3(256), lds, st, P, T, img,
+                       row_stride, img_stride, k, S, D, append);
+  else if (P.subpix_win == 10 && nw == 2)
     hipLaunchKernelGGL((subpix_append_kernel<10, 2>), dim3(bound, P.B), dim3(128), lds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append);
   else if (P.subpix_win == 10)
@@ -1491,8 +1497,12 @@ void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigne
                           int max_iters, double eps2, hipStream_t st) {
   if (n <= 0) return;
   const size_t lds = subpix_geom(win).bytes;
-  static const int nw = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 2;
-  if (win == 10 && nw == 2)
+  static const int nw_env = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 0;
+  const int nw = nw_env ? nw_env : (n <= 256 ? 4 : 2);
+  if (win == 10 && nw == 4)
+    hipLaunchKernelGGL((subpix_points_kernel<10, 4>), dim3(n), dim3(256), lds, st, mask_tab, img, row_stride,
+                       W, H, pts, n, win, max_iters, eps2);
+  else if (win == 10 && nw == 2)
     hipLaunchKernelGGL((subpix_points_kernel<10, 2>), dim3(n), dim3(128), lds, st, mask_tab, img, row_stride,
                        W, H, pts, n, win, max_iters, eps2);
   else if (win == 10)

@@ -253,7 +253,7 @@ template <int WIN, int NW = 1>
 static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ img, size_t step, int W,
                                        int H, float2 cT, int win_rt, int max_iters, double eps2,
                                        const float* __restrict__ mask, unsigned char* lds, int lane) {
-  static_assert(NW == 1 || (NW == 2 && WIN == 10), "the two-wave variant is written for half size 10");
+  static_assert(NW == 1 || ((NW == 2 || NW == 4) && WIN == 10), "the multi-wave variants are written for half size 10");
   constexpr int NTHR = 64 * NW;
   const int win = WIN > 0 ? WIN : win_rt;
   const SubpixGeom G = subpix_geom(win);
@@ -351,13 +351,16 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
     // the five sequential float64 chains (lanes 0-4): a dependent v_add_f64 issues every ~6 cycles
     // as long as its operand has landed, so the loop only has to keep LDS reads ahead of the adds
     double a, b, c, bb1, bb2;
-    if constexpr (NW == 2) {
-      // wave 0: DPP row r walks chain r (a, b, c, bb1); wave 1: chain 4 (bb2) -- see dpp_chain_sum448
+    if constexpr (NW >= 2) {
+      // wave 0: DPP row r walks chain r (a, b, c, bb1); wave 1: chain 4 (bb2) -- see dpp_chain_sum448; waves 2, 3 of
+      // the four-wave variant only share the patch and term work
       double* res = reinterpret_cast<double*>(lds + G.res_off);
       const int wv = lane >> 6, l = lane & 63, q = wv == 0 ? (l >> 4) : 4;
-      const double acc = dpp_chain_sum448(terms + q * ts + 28 * (l & 15));
+      if (wv < 2) {
+        const double acc = dpp_chain_sum448(terms + q * ts + 28 * (l & 15));
+        if ((l & 15) == 0 && (wv == 0 || l == 0)) res[q] = acc;
+      }
       KVFE_SP_T(2);
-      if ((l & 15) == 0 && (wv == 0 || l == 0)) res[q] = acc;
       __syncthreads();
       a = res[0];
       b = res[1];

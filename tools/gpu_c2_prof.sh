@@ -21,7 +21,7 @@ fs = glob.glob('gpurun_out/c2_kt/**/*kernel_trace.csv', recursive=True)
 rows = list(csv.DictReader(open(fs[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # steady state: last 60 steps worth of dispatches; print one step's timeline
-names = [r['Kernel_Name'].split('(')[0][:40] for r in rows]
+names = [r['Kernel_Name'].replace('void ', '').replace('kvfe::', '').split('(')[0][:40] for r in rows]
 # find indices of pyrdown pairs as step starts
 starts = [i for i, n in enumerate(names) if n.startswith('pyrdown') and (i == 0 or not names[i-1].startswith('pyrdown'))]
 i0, i1 = starts[-20], starts[-19]

@@ -37,7 +37,7 @@ int main() {
   hipMemcpy(dimg, img.data(), W * H, hipMemcpyHostToDevice);
   hipMemcpy(dmask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice);
   const size_t lds = kvfe::subpix_geom(win).bytes;
-  for (int nw : {1, 2})
+  for (int nw : {1, 2, 4})
   for (int nblk : {1, 256, 1024}) {
     for (int rep = 0; rep < 2; rep++) {
       std::vector<float2> pts(1024);
@@ -48,8 +48,10 @@ int main() {
       hipEventRecord(e0);
       if (nw == 1)
         hipLaunchKernelGGL((kvfe::k<10, 1>), dim3(nblk), dim3(64), lds, 0, dmask, dimg, (size_t)W, W, H, dpts, 40, dout);
-      else
+      else if (nw == 2)
         hipLaunchKernelGGL((kvfe::k<10, 2>), dim3(nblk), dim3(128), lds, 0, dmask, dimg, (size_t)W, W, H, dpts, 40, dout);
+      else
+        hipLaunchKernelGGL((kvfe::k<10, 4>), dim3(nblk), dim3(256), lds, 0, dmask, dimg, (size_t)W, W, H, dpts, 40, dout);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       unsigned long long h[8]; hipMemcpy(h, dout, 64, hipMemcpyDeviceToHost);
