@@ -167,24 +167,50 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int x_al = stripe_corner_x - sh0;
   const int ncol = sh0 + sc;                 // staged stripe bytes per row that hold image data
   const int ndw = (ncol + 3) >> 2;
-  for (int e = lane; e < tr * TSW; e += 64) tplw[e] = 0u;
-  for (int e = lane; e < sr * SSW; e += 64) stpw[e] = 0u;
-  __syncthreads();
-  for (int e = lane; e < tr * tc; e += 64) {
-    const int y = e / tc, x = e - y * tc;
-    tplb[(y * TSW + 4) * 4 + x] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
+  {  // zero fill, 16 bytes per store (both areas are whole uint4s and contiguous)
+    uint4* z4 = reinterpret_cast<uint4*>(lds);
+    const int nz = (tr * TSW + sr * SSW) >> 2;
+    for (int e = lane; e < nz; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
   }
-  if (dword_rows) {
-    for (int e = lane; e < sr * ndw; e += 64) {
-      const int y = e / ndw, q = e - y * ndw;
-      stpw[y * SSW + q] =
-          *reinterpret_cast<const unsigned*>(R + (size_t)(stripe_corner_y + y) * W + x_al + 4 * q);
+  __syncthreads();
+  if (dword_rows && ((size_t)L & 3) == 0 && tcw <= 32 && ndw <= 64) {
+    // template: aligned dwords of the left image shifted into place by v_alignbyte (no byte loads, no divisions);
+    // 32 lanes per row, two rows per trip.  The dword behind the last one of a row is inside the image (the template
+    // never touches the last image row), the bytes beyond the template's last column are masked off.
+    const int tsh = temp_corner_x & 3;
+    const unsigned char* Lrow0 = L + (size_t)temp_corner_y * W + (temp_corner_x - tsh);
+    const int q = lane & 31;
+    const int tail = tc & 3;  // valid bytes of the last template dword (0: all four)
+    for (int y = lane >> 5; y < tr; y += 2) {
+      if (q < tcw) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(Lrow0 + (size_t)y * W) + q;
+        const unsigned d0 = src[0], d1 = src[1];
+        unsigned v = __builtin_amdgcn_alignbyte(d1, d0, tsh);
+        if (q == tcw - 1 && tail) v &= (1u << (8 * tail)) - 1u;
+        tplw[y * TSW + 4 + q] = v;
+      }
     }
+    for (int y = 0; y < sr; y++)
+      if (lane < ndw)
+        stpw[y * SSW + lane] =
+            *reinterpret_cast<const unsigned*>(R + (size_t)(stripe_corner_y + y) * W + x_al + 4 * lane);
   } else {
-    unsigned char* stpb = reinterpret_cast<unsigned char*>(stpw);
-    for (int e = lane; e < sr * sc; e += 64) {
-      const int y = e / sc, x = e - y * sc;
-      stpb[y * SSW * 4 + x] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
+    for (int e = lane; e < tr * tc; e += 64) {
+      const int y = e / tc, x = e - y * tc;
+      tplb[(y * TSW + 4) * 4 + x] = L[(size_t)(temp_corner_y + y) * W + temp_corner_x + x];
+    }
+    if (dword_rows) {
+      for (int e = lane; e < sr * ndw; e += 64) {
+        const int y = e / ndw, q = e - y * ndw;
+        stpw[y * SSW + q] =
+            *reinterpret_cast<const unsigned*>(R + (size_t)(stripe_corner_y + y) * W + x_al + 4 * q);
+      }
+    } else {
+      unsigned char* stpb = reinterpret_cast<unsigned char*>(stpw);
+      for (int e = lane; e < sr * sc; e += 64) {
+        const int y = e / sc, x = e - y * sc;
+        stpb[y * SSW * 4 + x] = R[(size_t)(stripe_corner_y + y) * W + stripe_corner_x + x];
+      }
     }
   }
   __syncthreads();
@@ -233,8 +259,18 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
       if (lane == 63) P2[4 * ndw] = inc;  // total (lane 63 ends the last segment or is empty)
       __syncthreads();
     }
-    for (int task = lane; task < NJ * 4; task += 64) {
-      const int J = task >> 2;
+    // With the shipped parameters a stripe has about 100 offsets = 28 tasks for 64 lanes.  The SSD sums are exact
+    // integers, so the template rows of a task are split over 2 (4) lane groups that take the same tasks and are
+    // added up afterwards: 56 of 64 lanes busy instead of 28.
+    const int ntask = NJ * 4;
+    const int nsplit = ntask <= 16 ? 4 : (ntask <= 32 ? 2 : 1);
+    const int gsz = 64 / nsplit;
+    const int split = lane / gsz;
+    const int y_lo = (tr * split) / nsplit, y_hi = (tr * (split + 1)) / nsplit;
+    for (int tbase = 0; tbase < ntask; tbase += gsz) {
+      const int task = tbase + (lane & (gsz - 1));
+      const bool active = task < ntask;
+      const int J = active ? task >> 2 : 0;
       unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
       // one 16-byte stripe chunk against the template window {tp = dwords 4m-4..4m-1, tq = 4m..4m+3}
 #define KVFE_SSD_CHUNK(tp, tq, raw, nxt)                                        \
@@ -260,7 +296,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
     acc2 = __builtin_amdgcn_udot4(tq.y, s3, acc2, false);                       \
     acc3 = __builtin_amdgcn_udot4(tq.x, s3, acc3, false);                       \
   }
-      for (int y = 0; y < tr; y++) {
+      for (int y = y_lo; y < (active ? y_hi : y_lo); y++) {
         const uint4* trow = tpl4 + y * TSW4;
         const uint4* srow = stp4 + (oy + y) * SSW4 + J;
         uint4 ta = trow[0];  // zeros (template dwords -4 .. -1)
@@ -279,12 +315,24 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
         }
       }
 #undef KVFE_SSD_CHUNK
+      if (nsplit >= 2) {  // (wave-uniform) add the row groups: lanes l, l ^ 32 (and l ^ 16) hold the same task
+        acc0 += (unsigned)__shfl_xor((int)acc0, 32);
+        acc1 += (unsigned)__shfl_xor((int)acc1, 32);
+        acc2 += (unsigned)__shfl_xor((int)acc2, 32);
+        acc3 += (unsigned)__shfl_xor((int)acc3, 32);
+        if (nsplit == 4) {
+          acc0 += (unsigned)__shfl_xor((int)acc0, 16);
+          acc1 += (unsigned)__shfl_xor((int)acc1, 16);
+          acc2 += (unsigned)__shfl_xor((int)acc2, 16);
+          acc3 += (unsigned)__shfl_xor((int)acc3, 16);
+        }
+      }
       const unsigned ts[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
       for (int a = 0; a < 4; a++) {
         const int u = 16 * J + 4 * a + r;
         const int ox = u - sh0;
-        if (ox >= 0 && ox < rw) {
+        if (active && ox >= 0 && ox < rw) {
           const unsigned ss = P2[u + tc] - P2[u];
           const unsigned ssd = t2 + ss - 2u * ts[a];
           const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)(oy * rw + ox);
