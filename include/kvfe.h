@@ -492,6 +492,33 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* re
                                                  const double* cur_points_3d, int32_t n,
                                                  int32_t* inliers, kvfe_ransac_output* out);
 
+/* Tracker::pnp(cam_bearing_vectors, F_points, F_Pose_cam_estimate, inliers) (Tracker.cpp:1122-1288) +
+ * VisionImuFrontend::outlierRejectionPnP (VisionImuFrontend.cpp:146-173): 2D-3D RANSAC of the camera pose in the
+ * frame F of the landmarks.  Tracker::pnp(const StereoFrame&, ...) (Tracker.cpp:1064-1120) gathers the
+ * correspondences on the host -- keypoints with a VALID rectified left keypoint whose landmark id is in the map of
+ * optimised landmarks handed over by Tracker::updateMap -- and calls this; the C++ adapter does the same
+ * (kvfe::Tracker::pnp / updateMap in include/kvfe_adapter.hpp).  The step call itself does not run PnP: its result
+ * (kfTracking_status_pnp_, W_T_k_pnp_) does not feed back into the keypoint state (VisionImuFrontend.cpp:163
+ * "TODO remove outliers"), it is reported next to the mono / stereo results.
+ * Implemented: pnp_algorithm 3 (EPNP: opengv AbsolutePoseSacProblem, 6 points per sample, fixed seed), the value
+ * of every shipped parameter set but params/KinectAzure (UPNP); the others return KVFE_ERR_UNSUPPORTED, and so does
+ * optimize_2d3d_pose_from_inliers (off everywhere).  The threshold is 1 - cos(atan(sqrt 2 ransac_threshold_pnp /
+ * f)) with f the mean of the LEFT camera's fx, fy; iterations / probability / sampler come from the tracker
+ * parameters of the context.
+ * out: status = VALID when Tracker::pnp succeeded with more than min_pnp_inliers inliers, else FEW_MATCHES;
+ * reserved0 = Tracker::pnp's return value; pose = F_Pose_cam 3x4 [R | t]; inliers ascending (capacity n).
+ * The dense linear algebra of EPnP is a Jacobi / Householder implementation, not Eigen's: poses agree with the
+ * reference to rounding; the inlier decision is pinned by the scene of tests/testTracker.cpp:1613-1800. */
+typedef struct kvfe_pnp_params {
+  int32_t pnp_algorithm;                     /* Pose3d2dAlgorithm (VisionImuTrackerParams.h): 3 = EPNP */
+  int32_t min_pnp_inliers;
+  double ransac_threshold_pnp;               /* pixels                                                 */
+  int32_t optimize_2d3d_pose_from_inliers;   /* must be 0                                              */
+  int32_t reserved0;
+} kvfe_pnp_params;
+KVFE_API kvfe_status kvfe_pnp(kvfe_ctx* ctx, const kvfe_pnp_params* params, const double* cam_bearing_vectors,
+                              const double* F_points, int32_t n, int32_t* inliers, kvfe_ransac_output* out);
+
 /* ---- UndistorterRectifier / StereoCamera / StereoMatcher keypoint methods on their own -------- */
 /* (the front-end step runs them fused; these are the reference's public methods as component calls) */
 

@@ -205,6 +205,22 @@ class RansacOutput(C.Structure):
     ]
 
 
+class PnpParams(C.Structure):
+    """kvfe_pnp_params (Tracker::pnp, VisionImuTrackerParams.h: pnp_algorithm_, min_pnp_inliers_, ransac_threshold_pnp_)"""
+    _fields_ = [
+        ("pnp_algorithm", C.c_int32), ("min_pnp_inliers", C.c_int32), ("ransac_threshold_pnp", C.c_double),
+        ("optimize_2d3d_pose_from_inliers", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+PNP_KNEIP_P2P, PNP_KNEIP_P3P, PNP_GAO_P3P, PNP_EPNP, PNP_UPNP, PNP_UP3P, PNP_NONLINEAR, PNP_MLPNP = range(8)
+
+
+def pnp_params_default():
+    """VisionImuTrackerParams.h defaults / params/Euroc: EPNP, 20 inliers, 1 px"""
+    return PnpParams(PNP_EPNP, 20, 1.0, 0, 0)
+
+
 class StageTimes(C.Structure):
     _fields_ = [
         ("n_stages", C.c_int32), ("n_samples", C.c_int32),

@@ -305,6 +305,16 @@ KVO_API void kvo_outlier_rejection_3d3d_given_rotation(
                                                        cur_right_x, cur_p3, n, K, R, *tp),
                   inliers, out);
 }
+KVO_API void kvo_pnp(const double* bearings, const double* points, int n, double avg_focal_length,
+                     const kvfe_tracker_params* tp, const kvfe_pnp_params* pp, int32_t* inliers,
+                     kvfe_ransac_output* out) {
+  bool success = false;
+  fill_ransac_out(kimera::pnp(bearings, points, n, avg_focal_length, *tp, *pp, &success), inliers, out);
+  out->reserved0 = success ? 1 : 0;
+}
+KVO_API int kvo_epnp(const double* bearings, const double* points, const int* idx, int n, double* model) {
+  return opengv_re::epnp(bearings, points, idx, n, model);
+}
 KVO_API int kvo_fivept_nister(const double* f1, const double* f2, const int* idx5, double* E_out) {
   return opengv_re::fivept_nister_essentials(f1, f2, idx5, E_out);
 }

@@ -146,6 +146,11 @@ struct RansacOut {
 // ransac_use_2point_mono_ (Tracker.cpp:213-318) over n already gathered matches
 RansacOut outlierRejection2d2dGivenRot(const double* f_ref, const double* f_cur, int n,
                                        const double R[9], const kvfe_tracker_params& tp);
+// Tracker::pnp(bearings, F_points, ...) (Tracker.cpp:1122-1288, EPNP) + the status of
+// VisionImuFrontend::outlierRejectionPnP (VisionImuFrontend.cpp:146-173); *success = Tracker::pnp's return value;
+// avg_focal_length = 0.5 (fx + fy) of the camera the tracker was built with
+RansacOut pnp(const double* bearings, const double* points, int n, double avg_focal_length,
+              const kvfe_tracker_params& tp, const kvfe_pnp_params& pp, bool* success);
 // Tracker::geometricOutlierRejection2d2d without a rotation prior (ransac_use_2point_mono_ = false or no gyro
 // rotation): 5-point Nister RANSAC (Tracker.cpp:213-318, Problem2d2d::NISTER) over n gathered matches
 RansacOut outlierRejection2d2d(const double* f_ref, const double* f_cur, int n, const kvfe_tracker_params& tp);

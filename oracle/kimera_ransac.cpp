@@ -148,6 +148,33 @@ RansacOut outlierRejection3d3d(const double* ref_p3, const double* cur_p3, int n
   return o;
 }
 
+// Tracker::pnp (Tracker.cpp:1122-1288) for pnp_algorithm_ = EPNP -> runRansac<ProblemPnP> (Tracker.h:247-296,
+// optimize_2d3d_pose_from_inliers_ = false), then VisionImuFrontend::outlierRejectionPnP's status
+// (VisionImuFrontend.cpp:146-173)
+RansacOut pnp(const double* bearings, const double* points, int n, double avg_focal_length,
+              const kvfe_tracker_params& tp, const kvfe_pnp_params& pp, bool* success_out) {
+  RansacOut o;
+  bool success = false;
+  if (n == 0) {  // "No 2D-3D correspondences found for 2D-3D RANSAC...": Pose3(), no inliers
+    success = false;
+  } else {
+    const double reprojection_error = pp.ransac_threshold_pnp;
+    const double threshold = 1.0 - std::cos(std::atan(std::sqrt(2.0) * reprojection_error / avg_focal_length));
+    opengv_re::RansacResult r = opengv_re::ransac_absolute_pose_epnp(
+        bearings, points, n, threshold, tp.ransac_max_iterations, tp.ransac_probability, tp.ransac_rng_policy);
+    success = r.success;
+    o.iterations = r.iterations;
+    if (success && r.iterations >= tp.ransac_max_iterations && r.inliers.empty()) success = false;
+    if (success) {
+      o.inliers = r.inliers;
+      std::memcpy(o.pose, r.coeff, sizeof(o.pose));
+    }
+  }
+  if (success_out) *success_out = success;
+  o.status = (success && (int)o.inliers.size() > pp.min_pnp_inliers) ? KVFE_TRACKING_VALID : KVFE_TRACKING_FEW_MATCHES;
+  return o;
+}
+
 // gtsam::StereoCamera(Pose3(), K).backproject2(z, boost::none, H2) (gtsam 4.2
 // geometry/StereoCamera.cpp) and Tracker::getPoint3AndCovariance (Tracker.cpp:772-818)
 void getPoint3AndCovariance(const StereoCalib& K, double uL, double uR, double v, const double p3[3],

@@ -770,7 +770,24 @@ struct CentralRelativePose : Problem {   // CentralRelativePoseSacProblem(adapte
   double distance(const double* model, const double* aux, int i) const override { return reproj(model, aux, i); }
 };
 
+#include "opengv_epnp.inl"
+
 }  // namespace
+
+RansacResult ransac_absolute_pose_epnp(const double* bearings, const double* points, int n, double threshold,
+                                       int max_iterations, double probability, int rng_policy) {
+  AbsolutePoseEpnp p;
+  p.f = bearings;
+  p.p = points;
+  p.n = n;
+  return run_ransac(p, threshold, max_iterations, probability, rng_policy);
+}
+
+int epnp(const double* bearings, const double* points, const int* idx, int n, double model[12]) {
+  if (n < 4) return 0;
+  epnp_transformation(bearings, points, idx, n, model);
+  return 1;
+}
 
 RansacResult ransac_translation_only(const double* f1, const double* f2, int n, const double R12[9],
                                      double threshold, int max_iterations, double probability,

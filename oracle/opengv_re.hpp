@@ -58,6 +58,13 @@ RansacResult ransac_point_cloud(const double* p1, const double* p2, int n, doubl
 RansacResult ransac_central_relative_pose_nister(const double* f1, const double* f2, int n, double threshold,
                                                  int max_iterations, double probability, int rng_policy);
 
+// opengv::sac::Ransac<AbsolutePoseSacProblem(EPNP)>::computeModel (Tracker::pnp, pnp_algorithm 3): sample size 6,
+// bearings: n x 3 camera-frame bearing vectors, points: n x 3 world points; coeff = world_T_camera [R | t]
+RansacResult ransac_absolute_pose_epnp(const double* bearings, const double* points, int n, double threshold,
+                                       int max_iterations, double probability, int rng_policy);
+// absolute_pose::epnp(adapter, indices) on idx[0..n) (test hook), model = world_T_camera 3x4 row-major
+int epnp(const double* bearings, const double* points, const int* idx, int n, double model[12]);
+
 // relative_pose::fivept_nister on five correspondences (test hook): up to 10 essential matrices, row-major
 int fivept_nister_essentials(const double* f1, const double* f2, const int* idx5, double* E_out);
 

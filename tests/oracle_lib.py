@@ -489,6 +489,29 @@ def outlier_rejection_3d3d(ref_p3, cur_p3, tp: abi.TrackerParams) -> dict:
     return _ransac_result(out, inl)
 
 
+def pnp(bearings, points, avg_focal_length, tp: abi.TrackerParams, pp: abi.PnpParams) -> dict:
+    """Tracker::pnp (EPNP RANSAC) + outlierRejectionPnP's status; result["success"] = Tracker::pnp's return value"""
+    f = np.ascontiguousarray(bearings, np.float64).reshape(-1, 3)
+    pw = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    n = len(f)
+    inl = np.zeros(max(n, 1), np.int32)
+    out = abi.RansacOutput()
+    lib().kvo_pnp(_p(f), _p(pw), n, C.c_double(avg_focal_length), C.byref(tp), C.byref(pp), _p(inl), C.byref(out))
+    r = _ransac_result(out, inl)
+    r["success"] = bool(out.reserved0)
+    return r
+
+
+def epnp(bearings, points, idx):
+    """absolute_pose::epnp(adapter, indices): world_T_camera 3x4"""
+    f = np.ascontiguousarray(bearings, np.float64).reshape(-1, 3)
+    pw = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    ix = np.ascontiguousarray(idx, np.int32)
+    model = np.zeros(12)
+    ok = lib().kvo_epnp(_p(f), _p(pw), _p(ix), len(ix), _p(model))
+    return model.reshape(3, 4) if ok else None
+
+
 def get_point3_and_covariance(cam: "Camera", uL, uR, v, p3, Rmat=None):
     p3 = np.ascontiguousarray(p3, np.float64).reshape(3)
     Rm = None if Rmat is None else np.ascontiguousarray(Rmat, np.float64).reshape(9)
