@@ -1,0 +1,562 @@
+// Tracker::pnp (src/frontend/Tracker.cpp:1122-1288) for pnp_algorithm_ = EPNP:
+//   runRansac<ProblemPnP> (Tracker.h:247-296) = opengv::sac::Ransac<AbsolutePoseSacProblem(adapter, EPNP)>::computeModel
+//   sample size 6, model = absolute_pose::epnp(adapter, sample) = world_T_camera, distance = 1 - f . normalize(R^T (p - t))
+// + the status rule of VisionImuFrontend::outlierRejectionPnP (VisionImuFrontend.cpp:146-173).
+//
+// (included at the end of k_ransac.hip: shares its scan / reduction helpers, rs_svd3 and the sampler table)
+//
+// One 256-thread workgroup per problem.  The sample stream does not depend on the results, so EP_BATCH hypotheses are
+// drawn ahead, solved in parallel -- one lane per hypothesis, spread over the four wavefronts, every work array in an
+// LDS slot because a private array with run-time indices would live in scratch memory --, scored by the whole block
+// over all correspondences, and then replayed in order through the adaptive stopping rule of Ransac::computeModel.
+// EPnP itself is, operation for operation, the oracle's (oracle/opengv_epnp.inl): PCA control points, barycentric
+// coordinates, M^T M accumulated row by row, cyclic Jacobi of the 12x12 matrix, L_6x10 / rho, the three beta
+// approximations, five Gauss-Newton steps with the authors' Householder solver, Horn / Arun alignment with rs_svd3,
+// reprojection error, best of N = 1..3.  All float64, no FMA contraction.
+
+constexpr int EP_BATCH = 8;
+constexpr int EP_N = 6;   // AbsolutePoseSacProblem::getSampleSize() for EPNP
+
+struct EpSlot {
+  double a[144];      // M^T M, destroyed by the Jacobi iteration
+  double v[144];      // eigenvectors (columns)
+  double d[12], b[12], z[12];
+  double l[60], rho[6];
+  double pws[3 * EP_N], us[2 * EP_N], alphas[4 * EP_N], pcs[3 * EP_N];
+  double cws[12], ccs[12];
+  double qa[30], qb[6], qx[5], qa1[8], qa2[8];   // qr_solve
+  double c3[9], v3[9], d3[3], b3[3], z3[3];      // 3x3 covariance of the world points
+  double betas[4];
+  double Rs[3][9], ts[3][3], rep[3];
+  int signs[EP_N];
+};
+
+__device__ __forceinline__ double ep_d3(const double* x, const double* y) { return (x[0] * y[0] + x[1] * y[1]) + x[2] * y[2]; }
+
+// cyclic Jacobi for a symmetric n x n matrix; v: columns = eigenvectors, d: eigenvalues, sorted descending
+__device__ void ep_jacobi(double* a, int n, double* v, double* d, double* b, double* z) {
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    b[i] = d[i] = a[i * n + i];
+    z[i] = 0.0;
+  }
+  for (int it = 1; it <= 50; it++) {
+    double sm = 0.0;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) sm += fabs(a[p * n + q]);
+    if (sm == 0.0) break;
+    const double tresh = it < 4 ? 0.2 * sm / (double)(n * n) : 0.0;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double g = 100.0 * fabs(a[p * n + q]);
+        if (it > 4 && fabs(d[p]) + g == fabs(d[p]) && fabs(d[q]) + g == fabs(d[q])) {
+          a[p * n + q] = 0.0;
+        } else if (fabs(a[p * n + q]) > tresh) {
+          double h = d[q] - d[p];
+          double t;
+          if (fabs(h) + g == fabs(h)) {
+            t = a[p * n + q] / h;
+          } else {
+            const double theta = 0.5 * h / a[p * n + q];
+            t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+            if (theta < 0.0) t = -t;
+          }
+          const double c = 1.0 / sqrt(1.0 + t * t);
+          const double s = t * c;
+          const double tau = s / (1.0 + c);
+          h = t * a[p * n + q];
+          z[p] -= h;
+          z[q] += h;
+          d[p] -= h;
+          d[q] += h;
+          a[p * n + q] = 0.0;
+#define KVFE_EP_ROT(m, i1, j1, i2, j2)                         \
+  {                                                            \
+    const double gg = m[(i1) * n + (j1)], hh = m[(i2) * n + (j2)]; \
+    m[(i1) * n + (j1)] = gg - s * (hh + gg * tau);             \
+    m[(i2) * n + (j2)] = hh + s * (gg - hh * tau);             \
+  }
+          for (int j = 0; j < p; j++) KVFE_EP_ROT(a, j, p, j, q)
+          for (int j = p + 1; j < q; j++) KVFE_EP_ROT(a, p, j, j, q)
+          for (int j = q + 1; j < n; j++) KVFE_EP_ROT(a, p, j, q, j)
+          for (int j = 0; j < n; j++) KVFE_EP_ROT(v, j, p, j, q)
+#undef KVFE_EP_ROT
+        }
+      }
+    for (int i = 0; i < n; i++) {
+      b[i] += z[i];
+      d[i] = b[i];
+      z[i] = 0.0;
+    }
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int k = i;
+    double p = d[i];
+    for (int j = i + 1; j < n; j++)
+      if (d[j] > p) {
+        k = j;
+        p = d[j];
+      }
+    if (k != i) {
+      d[k] = d[i];
+      d[i] = p;
+      for (int j = 0; j < n; j++) {
+        const double t = v[j * n + i];
+        v[j * n + i] = v[j * n + k];
+        v[j * n + k] = t;
+      }
+    }
+  }
+}
+
+// Householder least squares of the EPnP reference code; A: nr x nc row-major (destroyed), b: nr (destroyed)
+__device__ bool ep_qr_solve(double* A, double* b, double* X, double* A1, double* A2, int nr, int nc) {
+  for (int k = 0; k < nc; k++) {
+    const int kk = k * nc + k;
+    double eta = fabs(A[kk]);
+    for (int i = k + 1; i < nr; i++) {   // (rows k .. nr-2, as the published code reads them)
+      const double elt = fabs(A[kk + (i - k - 1) * nc]);
+      if (eta < elt) eta = elt;
+    }
+    if (eta == 0) {
+      A1[k] = A2[k] = 0.0;
+      return false;
+    }
+    double sum = 0.0;
+    const double inv_eta = 1. / eta;
+    for (int i = k; i < nr; i++) {
+      const int ik = i * nc + k;
+      A[ik] *= inv_eta;
+      sum += A[ik] * A[ik];
+    }
+    double sigma = sqrt(sum);
+    if (A[kk] < 0) sigma = -sigma;
+    A[kk] += sigma;
+    A1[k] = sigma * A[kk];
+    A2[k] = -eta * sigma;
+    for (int j = k + 1; j < nc; j++) {
+      double sm = 0;
+      for (int i = k; i < nr; i++) sm += A[i * nc + k] * A[i * nc + j];
+      const double tau = sm / A1[k];
+      for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
+    }
+  }
+  for (int j = 0; j < nc; j++) {   // b <- Qt b
+    double tau = 0;
+    for (int i = j; i < nr; i++) tau += A[i * nc + j] * b[i];
+    tau /= A1[j];
+    for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
+  }
+  X[nc - 1] = b[nc - 1] / A2[nc - 1];   // X = R-1 b
+  for (int i = nc - 2; i >= 0; i--) {
+    double sum = 0;
+    for (int j = i + 1; j < nc; j++) sum += A[i * nc + j] * X[j];
+    X[i] = (b[i] - sum) / A2[i];
+  }
+  return true;
+}
+
+__device__ void ep_inv3(const double* m, double* r) {   // Eigen::Matrix3d::inverse() (cofactors)
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = (m[0] * c00 + m[1] * c01) + m[2] * c02;
+  const double id = 1.0 / det;
+  r[0] = c00 * id;
+  r[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+  r[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  r[3] = c01 * id;
+  r[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+  r[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  r[6] = c02 * id;
+  r[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// least squares of L(:, cols) x = rho
+__device__ void ep_solve_subset(EpSlot& W, const int* cols, int nc) {
+  for (int i = 0; i < 6; i++) {
+    for (int c = 0; c < nc; c++) W.qa[i * nc + c] = W.l[10 * i + cols[c]];
+    W.qb[i] = W.rho[i];
+  }
+  if (!ep_qr_solve(W.qa, W.qb, W.qx, W.qa1, W.qa2, 6, nc))
+    for (int c = 0; c < nc; c++) W.qx[c] = 0.0;
+}
+
+__device__ void ep_gauss_newton(EpSlot& W) {
+  double* b = W.betas;
+  for (int k = 0; k < 5; k++) {
+    for (int i = 0; i < 6; i++) {
+      const double* rowL = W.l + i * 10;
+      double* rowA = W.qa + i * 4;
+      rowA[0] = 2 * rowL[0] * b[0] + rowL[1] * b[1] + rowL[3] * b[2] + rowL[6] * b[3];
+      rowA[1] = rowL[1] * b[0] + 2 * rowL[2] * b[1] + rowL[4] * b[2] + rowL[7] * b[3];
+      rowA[2] = rowL[3] * b[0] + rowL[4] * b[1] + 2 * rowL[5] * b[2] + rowL[8] * b[3];
+      rowA[3] = rowL[6] * b[0] + rowL[7] * b[1] + rowL[8] * b[2] + 2 * rowL[9] * b[3];
+      W.qb[i] = W.rho[i] - (rowL[0] * b[0] * b[0] + rowL[1] * b[0] * b[1] + rowL[2] * b[1] * b[1] +
+                            rowL[3] * b[0] * b[2] + rowL[4] * b[1] * b[2] + rowL[5] * b[2] * b[2] +
+                            rowL[6] * b[0] * b[3] + rowL[7] * b[1] * b[3] + rowL[8] * b[2] * b[3] +
+                            rowL[9] * b[3] * b[3]);
+    }
+    if (!ep_qr_solve(W.qa, W.qb, W.qx, W.qa1, W.qa2, 6, 4)) return;
+    for (int i = 0; i < 4; i++) b[i] += W.qx[i];
+  }
+}
+
+// compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t, reprojection_error for the betas of the slot
+__device__ double ep_compute_R_and_t(EpSlot& W, double* R /*[9]*/, double* t /*[3]*/) {
+  constexpr int n = EP_N;
+  for (int i = 0; i < 12; i++) W.ccs[i] = 0.0;
+  for (int i = 0; i < 4; i++) {
+    // row 11 - i of Ut = column 11 - i of v
+    for (int j = 0; j < 4; j++)
+      for (int k = 0; k < 3; k++) W.ccs[3 * j + k] += W.betas[i] * W.v[(3 * j + k) * 12 + (11 - i)];
+  }
+  for (int i = 0; i < n; i++) {
+    const double* al = W.alphas + 4 * i;
+    for (int j = 0; j < 3; j++)
+      W.pcs[3 * i + j] = al[0] * W.ccs[j] + al[1] * W.ccs[3 + j] + al[2] * W.ccs[6 + j] + al[3] * W.ccs[9 + j];
+  }
+  if ((W.pcs[2] < 0.0 && W.signs[0] > 0) || (W.pcs[2] > 0.0 && W.signs[0] < 0)) {
+    for (int i = 0; i < 12; i++) W.ccs[i] = -W.ccs[i];
+    for (int i = 0; i < 3 * n; i++) W.pcs[i] = -W.pcs[i];
+  }
+  double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++) {
+      pc0[j] += W.pcs[3 * i + j];
+      pw0[j] += W.pws[3 * i + j];
+    }
+  for (int j = 0; j < 3; j++) {
+    pc0[j] /= n;
+    pw0[j] /= n;
+  }
+  double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++) {
+      abt[3 * j] += (W.pcs[3 * i + j] - pc0[j]) * (W.pws[3 * i] - pw0[0]);
+      abt[3 * j + 1] += (W.pcs[3 * i + j] - pc0[j]) * (W.pws[3 * i + 1] - pw0[1]);
+      abt[3 * j + 2] += (W.pcs[3 * i + j] - pc0[j]) * (W.pws[3 * i + 2] - pw0[2]);
+    }
+  double U[9], S[3], V[9];
+  rs_svd3(abt, U, S, V);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = ep_d3(U + 3 * i, V + 3 * j);
+  const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] -
+                     R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+  if (det < 0) {
+    R[6] = -R[6];
+    R[7] = -R[7];
+    R[8] = -R[8];
+  }
+  t[0] = pc0[0] - ep_d3(R, pw0);
+  t[1] = pc0[1] - ep_d3(R + 3, pw0);
+  t[2] = pc0[2] - ep_d3(R + 6, pw0);
+  double sum2 = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double* pw = W.pws + 3 * i;
+    const double Xc = ep_d3(R, pw) + t[0];
+    const double Yc = ep_d3(R + 3, pw) + t[1];
+    const double inv_Zc = 1.0 / (ep_d3(R + 6, pw) + t[2]);
+    const double ue = Xc * inv_Zc, ve = Yc * inv_Zc;
+    const double u = W.us[2 * i], v = W.us[2 * i + 1];
+    sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+  }
+  return sum2 / n;
+}
+
+// absolute_pose::epnp over the six correspondences sel[0..6): model = world_T_camera [R^T | -R^T t] (3x4 row-major)
+__device__ void ep_solve(const double* f, const double* p, const int* sel, EpSlot& W, double* model) {
+  constexpr int n = EP_N;
+  for (int i = 0; i < n; i++) {
+    const double* pi = p + 3 * (size_t)sel[i];
+    const double* fi = f + 3 * (size_t)sel[i];
+    W.pws[3 * i] = pi[0];
+    W.pws[3 * i + 1] = pi[1];
+    W.pws[3 * i + 2] = pi[2];
+    W.us[2 * i] = fi[0] / fi[2];
+    W.us[2 * i + 1] = fi[1] / fi[2];
+    W.signs[i] = fi[2] > 0.0 ? 1 : -1;
+  }
+  // choose_control_points
+  W.cws[0] = W.cws[1] = W.cws[2] = 0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++) W.cws[j] += W.pws[3 * i + j];
+  for (int j = 0; j < 3; j++) W.cws[j] /= n;
+  for (int i = 0; i < 9; i++) W.c3[i] = 0.0;
+  for (int i = 0; i < n; i++) {
+    double dlt[3];
+    for (int j = 0; j < 3; j++) dlt[j] = W.pws[3 * i + j] - W.cws[j];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) W.c3[r * 3 + c] += dlt[r] * dlt[c];
+  }
+  ep_jacobi(W.c3, 3, W.v3, W.d3, W.b3, W.z3);
+  for (int i = 1; i < 4; i++) {
+    const double k = sqrt(W.d3[i - 1] / n);
+    for (int j = 0; j < 3; j++) W.cws[3 * i + j] = W.cws[j] + k * W.v3[j * 3 + (i - 1)];
+  }
+  // compute_barycentric_coordinates
+  {
+    double cc[9], ci[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = W.cws[3 * j + i] - W.cws[i];
+    ep_inv3(cc, ci);
+    for (int i = 0; i < n; i++) {
+      const double* pi = W.pws + 3 * i;
+      double* al = W.alphas + 4 * i;
+      for (int j = 0; j < 3; j++)
+        al[1 + j] = ci[3 * j] * (pi[0] - W.cws[0]) + ci[3 * j + 1] * (pi[1] - W.cws[1]) +
+                    ci[3 * j + 2] * (pi[2] - W.cws[2]);
+      al[0] = 1.0 - al[1] - al[2] - al[3];
+    }
+  }
+  // M^T M, row by row
+  for (int i = 0; i < 144; i++) W.a[i] = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double* as = W.alphas + 4 * i;
+    double* m1 = W.qa;        // (the solver's scratch is free here)
+    double* m2 = W.qa + 12;
+    for (int j = 0; j < 4; j++) {
+      m1[3 * j] = as[j];
+      m1[3 * j + 1] = 0.0;
+      m1[3 * j + 2] = as[j] * (0.0 - W.us[2 * i]);
+      m2[3 * j] = 0.0;
+      m2[3 * j + 1] = as[j];
+      m2[3 * j + 2] = as[j] * (0.0 - W.us[2 * i + 1]);
+    }
+    for (int r = 0; r < 12; r++)
+      for (int c = 0; c < 12; c++) {
+        W.a[r * 12 + c] += m1[r] * m1[c];
+        W.a[r * 12 + c] += m2[r] * m2[c];
+      }
+  }
+  ep_jacobi(W.a, 12, W.v, W.d, W.b, W.z);
+  // compute_L_6x10: v[k] = row 11 - k of Ut = column 11 - k of W.v
+  for (int i = 0; i < 6; i++) {
+    // pair (a, b) number i of (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+    const int pa = i < 3 ? 0 : (i < 5 ? 1 : 2);
+    const int pb = i < 3 ? i + 1 : (i < 5 ? i - 1 : 3);
+    double dv[4][3];
+    for (int k = 0; k < 4; k++)
+      for (int c = 0; c < 3; c++)
+        dv[k][c] = W.v[(3 * pa + c) * 12 + (11 - k)] - W.v[(3 * pb + c) * 12 + (11 - k)];
+    double* row = W.l + 10 * i;
+    row[0] = ep_d3(dv[0], dv[0]);
+    row[1] = 2.0 * ep_d3(dv[0], dv[1]);
+    row[2] = ep_d3(dv[1], dv[1]);
+    row[3] = 2.0 * ep_d3(dv[0], dv[2]);
+    row[4] = 2.0 * ep_d3(dv[1], dv[2]);
+    row[5] = ep_d3(dv[2], dv[2]);
+    row[6] = 2.0 * ep_d3(dv[0], dv[3]);
+    row[7] = 2.0 * ep_d3(dv[1], dv[3]);
+    row[8] = 2.0 * ep_d3(dv[2], dv[3]);
+    row[9] = ep_d3(dv[3], dv[3]);
+  }
+  // compute_rho
+  {
+    auto dist2 = [&](int x, int y) {
+      const double* p1 = W.cws + 3 * x;
+      const double* p2 = W.cws + 3 * y;
+      return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
+    };
+    W.rho[0] = dist2(0, 1);
+    W.rho[1] = dist2(0, 2);
+    W.rho[2] = dist2(0, 3);
+    W.rho[3] = dist2(1, 2);
+    W.rho[4] = dist2(1, 3);
+    W.rho[5] = dist2(2, 3);
+  }
+  double* betas = W.betas;
+  // N = 1: [B11 B12 B13 B14]
+  {
+    const int cols[4] = {0, 1, 3, 6};
+    ep_solve_subset(W, cols, 4);
+    const double* b4 = W.qx;
+    if (b4[0] < 0) {
+      betas[0] = sqrt(-b4[0]);
+      betas[1] = -b4[1] / betas[0];
+      betas[2] = -b4[2] / betas[0];
+      betas[3] = -b4[3] / betas[0];
+    } else {
+      betas[0] = sqrt(b4[0]);
+      betas[1] = b4[1] / betas[0];
+      betas[2] = b4[2] / betas[0];
+      betas[3] = b4[3] / betas[0];
+    }
+    ep_gauss_newton(W);
+    W.rep[0] = ep_compute_R_and_t(W, W.Rs[0], W.ts[0]);
+  }
+  // N = 2: [B11 B12 B22]
+  {
+    const int cols[3] = {0, 1, 2};
+    ep_solve_subset(W, cols, 3);
+    const double* b3 = W.qx;
+    if (b3[0] < 0) {
+      betas[0] = sqrt(-b3[0]);
+      betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
+    } else {
+      betas[0] = sqrt(b3[0]);
+      betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+    }
+    if (b3[1] < 0) betas[0] = -betas[0];
+    betas[2] = 0.0;
+    betas[3] = 0.0;
+    ep_gauss_newton(W);
+    W.rep[1] = ep_compute_R_and_t(W, W.Rs[1], W.ts[1]);
+  }
+  // N = 3: [B11 B12 B22 B13 B23]
+  {
+    const int cols[5] = {0, 1, 2, 3, 4};
+    ep_solve_subset(W, cols, 5);
+    const double* b5 = W.qx;
+    if (b5[0] < 0) {
+      betas[0] = sqrt(-b5[0]);
+      betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+    } else {
+      betas[0] = sqrt(b5[0]);
+      betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+    }
+    if (b5[1] < 0) betas[0] = -betas[0];
+    betas[2] = b5[3] / betas[0];
+    betas[3] = 0.0;
+    ep_gauss_newton(W);
+    W.rep[2] = ep_compute_R_and_t(W, W.Rs[2], W.ts[2]);
+  }
+  int N = 0;
+  if (W.rep[1] < W.rep[0]) N = 1;
+  if (W.rep[2] < W.rep[N]) N = 2;
+  const double* R = W.Rs[N];
+  const double* t = W.ts[N];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) model[r * 4 + c] = R[c * 3 + r];   // rotation.transposeInPlace()
+  for (int r = 0; r < 3; r++)                                       // translation = -rotation * translation
+    model[r * 4 + 3] = -((model[r * 4] * t[0] + model[r * 4 + 1] * t[1]) + model[r * 4 + 2] * t[2]);
+}
+
+// AbsolutePoseSacProblem::getSelectedDistancesToModel for one correspondence
+__device__ __forceinline__ double ep_distance(const double* model, const double* bearing, const double* point) {
+  const double dlt[3] = {point[0] - model[3], point[1] - model[7], point[2] - model[11]};
+  double r[3];
+  for (int c = 0; c < 3; c++) r[c] = (model[c] * dlt[0] + model[4 + c] * dlt[1]) + model[8 + c] * dlt[2];
+  const double nrm = sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+  for (int c = 0; c < 3; c++) r[c] = r[c] / nrm;
+  return 1.0 - ((r[0] * bearing[0] + r[1] * bearing[1]) + r[2] * bearing[2]);
+}
+
+// Tracker::pnp over n correspondences (one problem per workgroup).  out_status: outlierRejectionPnP's status;
+// out_counts: [n_inliers, iterations, success]; out_pose 3x4; inliers ascending.
+// LDS (dynamic): shuffled [n] int
+__global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, const double* f, const double* p, int n,
+                                                          double threshold, int min_inliers, int* inliers,
+                                                          int* out_status, double* out_pose, int* out_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  int* shuffled = reinterpret_cast<int*>(lds_raw);
+  __shared__ int wave_tot[RS_T / 64];
+  __shared__ int sh_sel[EP_BATCH][EP_N];
+  __shared__ int sh_cnt[EP_BATCH];
+  __shared__ double sh_models[EP_BATCH][12];
+  __shared__ double sh_best[12];
+  __shared__ EpSlot sh_slots[EP_BATCH];
+  __shared__ int sh_state[2];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += RS_T) shuffled[i] = i;
+  __syncthreads();
+  int iterations = 0, best = -INT_MAX, draw = 0;
+  const unsigned max_skip = (unsigned)P.ransac_max_iters * 10u;
+  unsigned skipped = 0;   // (computeModelCoefficients of EPNP never fails)
+  double k = 1.0;
+  bool have_model = false, done = false;
+  if (n < EP_N) {
+    iterations = INT_MAX;   // getSamples: not enough correspondences -> computeModel returns false
+    done = true;
+  }
+  while (!done) {
+    if (tid == 0) {   // drawIndexSample for the next EP_BATCH hypotheses (the shuffle persists)
+      for (int h = 0; h < EP_BATCH; h++) {
+        for (int i = 0; i < EP_N; ++i) {
+          const int r = T.ransac_rnd[min(draw + EP_N * h + i, T.n_ransac_rnd - 1)];
+          const int j = i + (int)((unsigned)r % (unsigned)(n - i));
+          const int tmp = shuffled[i];
+          shuffled[i] = shuffled[j];
+          shuffled[j] = tmp;
+        }
+        for (int i = 0; i < EP_N; i++) sh_sel[h][i] = shuffled[i];
+      }
+    }
+    draw += EP_N * EP_BATCH;
+    __syncthreads();
+    {
+      static_assert(EP_BATCH * 32 == RS_T, "32 lanes per hypothesis: two solver lanes per wavefront");
+      const int h = tid >> 5;
+      if ((tid & 31) == 0) ep_solve(f, p, sh_sel[h], sh_slots[h], sh_models[h]);
+    }
+    __syncthreads();
+    for (int h = 0; h < EP_BATCH; h++) {   // countWithinDistance
+      double M[12];
+      for (int i = 0; i < 12; i++) M[i] = sh_models[h][i];
+      int cnt = 0;
+      for (int i = tid; i < n; i += RS_T)
+        if (ep_distance(M, f + 3 * (size_t)i, p + 3 * (size_t)i) < threshold) cnt++;
+      cnt = rs_block_sum(cnt, wave_tot);
+      if (tid == 0) sh_cnt[h] = cnt;
+    }
+    __syncthreads();
+    for (int h = 0; h < EP_BATCH && !done; h++) {   // replay of Ransac::computeModel
+      if (!((double)iterations < k && skipped < max_skip)) {
+        done = true;
+        break;
+      }
+      const int cnt = sh_cnt[h];
+      if (cnt > best) {
+        best = cnt;
+        have_model = true;
+        if (tid < 12) sh_best[tid] = sh_models[h][tid];
+        const double w = (double)best / (double)n;
+        double p_no_outliers = 1.0 - pow(w, (double)EP_N);
+        p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
+        p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
+        k = log(1.0 - P.ransac_probability) / log(p_no_outliers);
+      }
+      ++iterations;
+      if (iterations > P.ransac_max_iters) done = true;
+    }
+    if (!((double)iterations < k && skipped < max_skip)) done = true;
+    __syncthreads();
+  }
+  bool success = have_model;
+  int n_in = 0;
+  if (have_model) {
+    __syncthreads();
+    double M[12];
+    for (int i = 0; i < 12; i++) M[i] = sh_best[i];
+    if (tid == 0) sh_state[0] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += RS_T) {   // selectWithinDistance
+      const int i = base + tid;
+      const bool in = i < n && ep_distance(M, f + 3 * (size_t)i, p + 3 * (size_t)i) < threshold;
+      int tot;
+      const int pos = rs_scan(in ? 1 : 0, wave_tot, &tot);
+      const int off = sh_state[0];
+      if (in) inliers[off + pos] = i;
+      __syncthreads();
+      if (tid == 0) sh_state[0] = off + tot;
+      __syncthreads();
+    }
+    n_in = sh_state[0];
+    if (iterations >= P.ransac_max_iters && n_in == 0) {   // Tracker.h:270-273
+      success = false;
+      n_in = 0;
+    }
+  }
+  if (tid == 0) {
+    out_counts[0] = n_in;
+    out_counts[1] = iterations;
+    out_counts[2] = success ? 1 : 0;
+    out_status[0] = (success && n_in > min_inliers) ? TRK_VALID : TRK_FEW_MATCHES;
+    for (int i = 0; i < 12; i++) out_pose[i] = success ? sh_best[i] : ((i % 5 == 0) ? 1.0 : 0.0);
+  }
+}
+
+void launch_pnp(const KParams& P, const Tables& T, const double* f, const double* p, int n, double threshold,
+                int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts, hipStream_t st) {
+  hipLaunchKernelGGL(pnp_ransac_kernel, dim3(1), dim3(RS_T), sizeof(int) * (size_t)(n > 0 ? n : 1), st, P, T, f, p, n,
+                     threshold, min_inliers, inliers, out_status, out_pose, out_counts);
+}

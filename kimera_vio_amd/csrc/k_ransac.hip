@@ -1966,4 +1966,6 @@ void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const dou
                      n, RS, out_status, out_pose, out_counts);
 }
 
+#include "k_pnp.inl"
+
 }  // namespace kvfe

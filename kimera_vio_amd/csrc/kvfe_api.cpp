@@ -1793,6 +1793,50 @@ kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* c, const double* ref_points_3d
   return ransac_download(c, b, inliers, out, false);
 }
 
+// Tracker::pnp (Tracker.cpp:1122-1288) + outlierRejectionPnP's status (VisionImuFrontend.cpp:146-173)
+kvfe_status kvfe_pnp(kvfe_ctx* c, const kvfe_pnp_params* pp, const double* cam_bearing_vectors,
+                     const double* F_points, int32_t n, int32_t* inliers, kvfe_ransac_output* out) {
+  DeviceGuard _dev(c);
+  if (!c || !pp || !out || n < 0 || (n > 0 && (!cam_bearing_vectors || !F_points))) return KVFE_ERR_INVALID_ARG;
+  if (pp->pnp_algorithm != 3) {
+    c->last_error = "pnp_algorithm: only 3 (EPNP) is implemented";
+    return KVFE_ERR_UNSUPPORTED;
+  }
+  if (pp->optimize_2d3d_pose_from_inliers) {
+    c->last_error = "optimize_2d3d_pose_from_inliers is not implemented (off in every shipped parameter set)";
+    return KVFE_ERR_UNSUPPORTED;
+  }
+  TRY(ensure_comp(c));
+  Buffers& b = c->comp;
+  const KParams& P = c->Pc;
+  if (n > P.kcap) return KVFE_ERR_CAPACITY;
+  std::memset(out, 0, sizeof(*out));
+  for (int i = 0; i < 12; i++) out->pose[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  if (n == 0) {  // "No 2D-3D correspondences found for 2D-3D RANSAC..." (Tracker.cpp:1130-1134)
+    out->status = KVFE_TRACKING_FEW_MATCHES;
+    return KVFE_OK;
+  }
+  const double avg_focal_length = 0.5 * (c->cfg.left.intrinsics[0] + c->cfg.left.intrinsics[1]);
+  const double threshold = 1.0 - std::cos(std::atan(std::sqrt(2.0) * pp->ransac_threshold_pnp / avg_focal_length));
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(b.rs.f_ref, cam_bearing_vectors, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(b.rs.f_cur, F_points, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  launch_pnp(P, c->T, b.rs.f_ref, b.rs.f_cur, n, threshold, pp->min_pnp_inliers, b.rs.inliers, b.ss.trk_status,
+             b.ss.trk_pose, b.ss.trk_counts, st);
+  int status = 0, cnt[3] = {0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(&status, b.ss.trk_status, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(cnt, b.ss.trk_counts, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(out->pose, b.ss.trk_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  out->status = status;
+  out->n_inliers = cnt[0];
+  out->iterations = cnt[1];
+  out->reserved0 = cnt[2];
+  if (inliers && out->n_inliers > 0)
+    HIPCHK(c, hipMemcpy(inliers, b.rs.inliers, sizeof(int) * out->n_inliers, hipMemcpyDeviceToHost));
+  return KVFE_OK;
+}
+
 // ---- front-end level -------------------------------------------------------------------------
 kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const void* right_dev,
                                       size_t row_stride, size_t image_stride,

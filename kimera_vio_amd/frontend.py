@@ -293,6 +293,20 @@ class Context:
                   "outlier_rejection_3d3d")
         return self._ransac_result(out, inl)
 
+    def pnp(self, cam_bearing_vectors, F_points, pnp_params: abi.PnpParams = None) -> dict:
+        """Tracker::pnp(bearings, F_points, ...) (Tracker.cpp:1122-1288, EPNP RANSAC) + outlierRejectionPnP's status;
+        result["success"] = Tracker::pnp's return value, pose = F_Pose_cam."""
+        f = np.ascontiguousarray(cam_bearing_vectors, np.float64).reshape(-1, 3)
+        pw = np.ascontiguousarray(F_points, np.float64).reshape(-1, 3)
+        assert len(f) == len(pw)
+        pp = pnp_params if pnp_params is not None else abi.pnp_params_default()
+        inl = np.zeros(max(len(f), 1), np.int32)
+        out = abi.RansacOutput()
+        self._chk(self.lib.kvfe_pnp(self._h, C.byref(pp), _p(f), _p(pw), len(f), _p(inl), C.byref(out)), "pnp")
+        r = self._ransac_result(out, inl)
+        r["success"] = bool(out.reserved0)
+        return r
+
     # ---- UndistorterRectifier / StereoCamera / StereoMatcher keypoint methods on their own -------
     def check_undistorted_rectified_left_keypoints(self, cam: int, distorted_xy, undistorted_xy, pixel_tol=2.0):
         d, u = _pts(distorted_xy), _pts(undistorted_xy)
