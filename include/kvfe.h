@@ -150,8 +150,9 @@ typedef struct kvfe_detector_params {
  * ransac_use_2point_mono (opengv TranslationOnlySacProblem), its 5-point alternative
  * (ransac_use_2point_mono = 0: CentralRelativePoseSacProblem, NISTER), ransac_use_1point_stereo
  * (the reference's own voting scheme) and the 3-point Arun problem the stereo branch falls back
- * to (ransac_use_1point_stereo = 0, or a keyframe without gyro rotation).  PnP tracking, the other
- * 2d2d algorithms and ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
+ * to (ransac_use_1point_stereo = 0, or a keyframe without gyro rotation); PnP tracking (EPNP) is the
+ * separate call kvfe_pnp with its own kvfe_pnp_params.  The other 2d2d algorithms and
+ * ransac_randomize = 1 are KVFE_ERR_UNSUPPORTED. */
 typedef struct kvfe_tracker_params {
   int32_t klt_win_size;
   int32_t klt_max_iter;

@@ -20,6 +20,9 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <array>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "kvfe.h"
@@ -404,8 +407,71 @@ class Tracker {
     return r;
   }
 
+  // ---- PnP tracking (use_pnp_tracking) -----------------------------------------------------------------------------
+  // LandmarksMap (common/vio_types.h): landmark id -> optimised 3-D position in the world frame
+  using LandmarksMap = std::unordered_map<int64_t, std::array<double, 3>>;
+  // void updateMap(const LandmarksMap&) (Tracker.h:82-94): the backend's time horizon, copied under a mutex upstream
+  void updateMap(const LandmarksMap& lmks_map) {
+    std::lock_guard<std::mutex> lock(landmarks_map_mtx_);
+    landmarks_map_ = lmks_map;
+  }
+  // bool pnp(const BearingVectors& cam_bearing_vectors, const Landmarks& F_points, gtsam::Pose3* F_Pose_cam_estimate,
+  //          std::vector<int>* inliers, gtsam::Pose3* F_Pose_cam_prior) (Tracker.cpp:1122-1288); bearings / points
+  // n x 3, pose row-major 3x4 [R | t].  `status` (optional) receives outlierRejectionPnP's TrackingStatus.
+  bool pnp(const std::vector<double>& cam_bearing_vectors, const std::vector<double>& F_points,
+           const kvfe_pnp_params& params, double F_Pose_cam_estimate[12], std::vector<int>* inliers,
+           int* status = nullptr) const {
+    const int32_t n = (int32_t)(F_points.size() / 3);
+    if (cam_bearing_vectors.size() != F_points.size())   // CHECK_EQ(cam_bearing_vectors.size(), F_points.size())
+      throw Error(KVFE_ERR_INVALID_ARG, "pnp: bearing vectors and points differ in number");
+    std::vector<int32_t> inl((size_t)(n > 0 ? n : 1));
+    kvfe_ransac_output o;
+    c_.check(kvfe_pnp(c_.get(), &params, cam_bearing_vectors.data(), F_points.data(), n, inl.data(), &o), "pnp");
+    if (inliers) inliers->assign(inl.begin(), inl.begin() + o.n_inliers);
+    std::memcpy(F_Pose_cam_estimate, o.pose, sizeof(o.pose));
+    if (status) *status = o.status;
+    return o.reserved0 != 0;
+  }
+  // bool pnp(const StereoFrame& cur_stereo_frame, gtsam::Pose3* W_Pose_cam_estimate, std::vector<int>* inliers, ...)
+  // (Tracker.cpp:1064-1120): the 2D-3D correspondences are the keypoints with a VALID rectified left keypoint whose
+  // landmark id is in the map of updateMap.  The frame is passed as the three members the reference reads:
+  // left_keypoints_rectified_[i].first, left_frame_.landmarks_[i], keypoints_3d_[i] (n x 3) -- e.g. left_status /
+  // landmarks / keypoints_3d of kvfe_frame_output.
+  bool pnp(const uint8_t* left_keypoints_rectified_status, const int64_t* landmarks, const double* keypoints_3d,
+           size_t n, const kvfe_pnp_params& params, double W_Pose_cam_estimate[12], std::vector<int>* inliers,
+           int* status = nullptr) const {
+    LandmarksMap copy_W_landmarks_map;
+    {
+      std::lock_guard<std::mutex> lock(landmarks_map_mtx_);
+      copy_W_landmarks_map = landmarks_map_;
+    }
+    std::vector<double> cam_bearing_vectors, W_points;
+    for (size_t i = 0; i < n; i++) {
+      const int64_t lmk_id = landmarks[i];
+      if (left_keypoints_rectified_status[i] == KVFE_KP_VALID && lmk_id != -1) {
+        const auto it = copy_W_landmarks_map.find(lmk_id);
+        if (it != copy_W_landmarks_map.end()) {
+          W_points.insert(W_points.end(), it->second.begin(), it->second.end());
+          cam_bearing_vectors.insert(cam_bearing_vectors.end(), keypoints_3d + 3 * i, keypoints_3d + 3 * i + 3);
+        }
+      }
+    }
+    return pnp(cam_bearing_vectors, W_points, params, W_Pose_cam_estimate, inliers, status);
+  }
+  // VisionImuFrontend::outlierRejectionPnP(frame, &status_pnp) (VisionImuFrontend.cpp:146-173) on the output of a
+  // keyframe step: fills kfTracking_status_pnp_ / W_T_k_pnp_ of the TrackerStatusSummary
+  TrackingStatusPose outlierRejectionPnP(const kvfe_frame_output& frame, const kvfe_pnp_params& params) const {
+    TrackingStatusPose r;
+    std::vector<int> inliers;
+    pnp(frame.left_status, frame.landmarks, frame.keypoints_3d, (size_t)frame.n_keypoints, params, r.pose, &inliers,
+        &r.status);
+    return r;
+  }
+
  private:
   Context c_;
+  mutable std::mutex landmarks_map_mtx_;
+  LandmarksMap landmarks_map_;
 };
 
 // StereoMatcher (src/frontend/StereoMatcher.cpp:123-483)

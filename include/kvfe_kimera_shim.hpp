@@ -139,8 +139,68 @@ class Tracker {
     from_frame(c, cur_frame);
   }
 
+  // tracker_params_.pnp_algorithm_ / min_pnp_inliers_ / ransac_threshold_pnp_ / optimize_2d3d_pose_from_inliers_
+  // (VisionImuTrackerParams.h:72-76); the remaining RANSAC settings are those of the context
+  template <class TrackerParamsT>
+  void setPnpParams(const TrackerParamsT& tp) {
+    pnp_params_.pnp_algorithm = (int32_t)tp.pnp_algorithm_;
+    pnp_params_.min_pnp_inliers = (int32_t)tp.min_pnp_inliers_;
+    pnp_params_.ransac_threshold_pnp = tp.ransac_threshold_pnp_;
+    pnp_params_.optimize_2d3d_pose_from_inliers = tp.optimize_2d3d_pose_from_inliers_ ? 1 : 0;
+  }
+  // Tracker.h:82-94, LandmarksMap = std::unordered_map<LandmarkId, gtsam::Point3>
+  template <class LandmarksMapT>
+  void updateMap(const LandmarksMapT& lmks_map) {
+    kvfe::Tracker::LandmarksMap m;
+    for (const auto& it : lmks_map) m[(int64_t)it.first] = {it.second(0), it.second(1), it.second(2)};
+    impl_.updateMap(m);
+  }
+  // bool pnp(const BearingVectors& cam_bearing_vectors, const Landmarks& F_points, gtsam::Pose3* F_Pose_cam_estimate,
+  //          std::vector<int>* inliers, gtsam::Pose3* F_Pose_cam_prior = nullptr)        (Tracker.h, Tracker.cpp:1122)
+  template <class BearingVectorsT, class LandmarksT, class Pose3T>
+  bool pnp(const BearingVectorsT& cam_bearing_vectors, const LandmarksT& F_points, Pose3T* F_Pose_cam_estimate,
+           std::vector<int>* inliers, Pose3T* /*F_Pose_cam_prior*/ = nullptr) {
+    std::vector<double> f, pw;
+    for (const auto& b : cam_bearing_vectors) f.insert(f.end(), {b(0), b(1), b(2)});
+    for (const auto& q : F_points) pw.insert(pw.end(), {q(0), q(1), q(2)});
+    double T[12];
+    const bool ok = impl_.pnp(f, pw, pnp_params_, T, inliers);
+    *F_Pose_cam_estimate = pose_from_array<Pose3T>(T);
+    return ok;
+  }
+  // bool pnp(const StereoFrame& cur_stereo_frame, gtsam::Pose3* W_Pose_cam_estimate, std::vector<int>* inliers,
+  //          gtsam::Pose3* W_Pose_cam_prior = nullptr)                                  (Tracker.cpp:1064-1120)
+  template <class VioStereoFrame, class Pose3T>
+  bool pnp(const VioStereoFrame& cur_stereo_frame, Pose3T* W_Pose_cam_estimate, std::vector<int>* inliers,
+           Pose3T* /*W_Pose_cam_prior*/ = nullptr) {
+    const size_t n = cur_stereo_frame.left_keypoints_rectified_.size();
+    std::vector<uint8_t> st(n);
+    std::vector<int64_t> ids(n);
+    std::vector<double> p3(3 * n);
+    for (size_t i = 0; i < n; i++) {
+      st[i] = (uint8_t)cur_stereo_frame.left_keypoints_rectified_[i].first;
+      ids[i] = (int64_t)cur_stereo_frame.left_frame_.landmarks_[i];
+      for (int c = 0; c < 3; c++) p3[3 * i + c] = cur_stereo_frame.keypoints_3d_[i](c);
+    }
+    double T[12];
+    const bool ok = impl_.pnp(st.data(), ids.data(), p3.data(), n, pnp_params_, T, inliers);
+    *W_Pose_cam_estimate = pose_from_array<Pose3T>(T);
+    return ok;
+  }
+
  private:
+  template <class Pose3T>
+  static Pose3T pose_from_array(const double T[12]) {
+    gtsam::Matrix3 M;
+    gtsam::Vector3 t;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) M(r, c) = T[4 * r + c];
+      t(r) = T[4 * r + 3];
+    }
+    return Pose3T(gtsam::Rot3(M), t);
+  }
   kvfe::Tracker impl_;
+  kvfe_pnp_params pnp_params_ = {3 /* EPNP */, 20, 1.0, 0, 0};
 };
 
 class UndistorterRectifier {

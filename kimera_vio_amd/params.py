@@ -167,12 +167,16 @@ def load_frontend_params(path: str, use_ransac: int | None = None) -> abi.Fronte
     p.max_disparity_since_lkf = float(y["max_disparity_since_lkf"])
     p.use_ransac = int(y["useRANSAC"]) if use_ransac is None else int(use_ransac)
     # use_2d2d_tracking / use_3d3d_tracking are parsed by the reference (VisionImuFrontendParams.cpp:104-105)
-    # and read nowhere in src/; use_pnp_tracking gates Tracker::pnp on keyframes
-    # (StereoVisionImuFrontend.cpp:389), which needs the back-end's landmark map: not on this path.
+    # and read nowhere in src/.  use_pnp_tracking gates Tracker::pnp on keyframes (StereoVisionImuFrontend.cpp:389);
+    # its result does not feed back into the keypoint state, so it runs next to the step: kvfe_pnp /
+    # Context.pnp with the parameters attached here (p.use_pnp_tracking, p.pnp) and the landmark map of the back-end
+    # (kvfe::Tracker::updateMap / outlierRejectionPnP in include/kvfe_adapter.hpp).  Only EPNP is implemented:
+    # another pnp_algorithm makes that call return KVFE_ERR_UNSUPPORTED, not the step.
     int(y["use_2d2d_tracking"]), int(y["use_3d3d_tracking"])
-    if int(y["use_pnp_tracking"]) and p.use_ransac:
-        raise NotImplementedError("use_pnp_tracking: 1 (Tracker::pnp, Tracker.cpp:1064) is not implemented by "
-                                  "libkvfe (KVFE_ERR_UNSUPPORTED); set it to 0 or useRANSAC to 0")
+    p.use_pnp_tracking = int(y["use_pnp_tracking"])
+    p.pnp = abi.PnpParams(int(y.get("pnp_algorithm", abi.PNP_EPNP)), int(y.get("min_pnp_inliers", 20)),
+                          float(y.get("ransac_threshold_pnp", 1.0)),
+                          int(y.get("optimize_2d3d_pose_from_inliers", 0)), 0)
     return p
 
 

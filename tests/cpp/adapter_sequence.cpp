@@ -211,6 +211,15 @@ int main(int argc, char** argv) {
     std::vector<float> kp(2 * cap), lrect(2 * cap), rrect(2 * cap), rxy(2 * cap);
     std::vector<double> vers(3 * cap), depth(cap), p3d(3 * cap), meas(3 * cap);
     std::vector<uint8_t> lstat(cap), rstat(cap);
+    // PnP tracking next to the step (use_pnp_tracking: StereoVisionImuFrontend.cpp:389-399): the map the backend would
+    // hand over through Tracker::updateMap is played by the 3-D points of frame 0 (world = camera frame of frame 0)
+    kvfe::Tracker pnp_tracker(ctx);
+    kvfe::Tracker::LandmarksMap lmk_map;
+    kvfe_pnp_params pnp_params;
+    std::memset(&pnp_params, 0, sizeof(pnp_params));
+    pnp_params.pnp_algorithm = 3;   // EPNP
+    pnp_params.min_pnp_inliers = 20;
+    pnp_params.ransac_threshold_pnp = 1.0;
     for (int i = 0; i < n_frames; i++) {
       frontend.spinOnce(lefts[i].data(), rights[i].data(), (size_t)W, N, &inputs[i]);
       kvfe_frame_output o;
@@ -251,6 +260,17 @@ int main(int argc, char** argv) {
       w.put("f_trk", trk, sizeof(trk));
       w.put("f_Tmono", o.lkf_T_k_mono, sizeof(o.lkf_T_k_mono));
       w.put("f_Tstereo", o.lkf_T_k_stereo, sizeof(o.lkf_T_k_stereo));
+      if (i == 0) {
+        for (size_t q = 0; q < n; q++)
+          if (rstat[q] == KVFE_KP_VALID && landmarks[q] != -1)
+            lmk_map[landmarks[q]] = {p3d[3 * q], p3d[3 * q + 1], p3d[3 * q + 2]};
+        pnp_tracker.updateMap(lmk_map);
+      } else if (o.is_keyframe) {
+        const kvfe::Tracker::TrackingStatusPose sp = pnp_tracker.outlierRejectionPnP(o, pnp_params);
+        const int32_t ps[2] = {sp.status, (int32_t)lmk_map.size()};
+        w.put("p_status", ps, sizeof(ps));
+        w.put("p_pose", sp.pose, sizeof(sp.pose));
+      }
     }
 
     // ---- error behaviour: a contract violation surfaces as kvfe::Error, never as a crash --------

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cmath>
+#include <unordered_map>
 #include <vector>
 
 #include "kvfe_kimera_shim.hpp"
@@ -25,8 +27,20 @@ struct Frame {
   std::vector<size_t> landmarks_age_;
   std::vector<gtsam::Vector3> versors_;
 };
+enum class Pose3d2dAlgorithm { KneipP2P = 0, KneipP3P = 1, GaoP3P = 2, EPNP = 3, UPNP = 4 };
+struct TrackerParams {   // the PnP members of VisionImuTrackerParams.h:72-76
+  Pose3d2dAlgorithm pnp_algorithm_ = Pose3d2dAlgorithm::EPNP;
+  int min_pnp_inliers_ = 10;
+  double ransac_threshold_pnp_ = 1.0;
+  bool optimize_2d3d_pose_from_inliers_ = false;
+};
+using BearingVectors = std::vector<gtsam::Vector3>;
+using Landmarks = std::vector<gtsam::Point3>;
+using LandmarksMap = std::unordered_map<LandmarkId, gtsam::Point3>;
 struct StereoFrame {
   Frame left_frame_, right_frame_;
+  StatusKeypointsCV left_keypoints_rectified_;
+  BearingVectors keypoints_3d_;
   cv::Mat left_img_rectified_, right_img_rectified_;
   void setRectifiedImages(const cv::Mat& l, const cv::Mat& r) {
     left_img_rectified_ = l;
@@ -114,6 +128,48 @@ int main(int argc, char** argv) {
       rawxy.push_back(k.pt.y);
     }
     w.put("s_raw", rawxy.data(), rawxy.size() * 4);
+
+    {   // Tracker::updateMap + both Tracker::pnp overloads (Tracker.h): a cube of landmarks seen from (I, [0 0 -2])
+      VIO::TrackerParams tp;
+      tracker.setPnpParams(tp);
+      VIO::LandmarksMap map;
+      VIO::StereoFrame pf;
+      VIO::BearingVectors bearings;
+      VIO::Landmarks points;
+      int id = 0;
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++)
+          for (int c = 0; c < 3; c++) {
+            gtsam::Point3 X;
+            X(0) = 0.5 * a - 0.4 + 0.03 * c;
+            X(1) = 0.45 * b - 0.5 + 0.02 * a;
+            X(2) = 0.5 * c + 0.01 * b;
+            gtsam::Vector3 f;
+            const double pc[3] = {X(0), X(1), X(2) + 2.0};
+            const double nrm = std::sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+            for (int k = 0; k < 3; k++) f(k) = pc[k] / nrm;
+            map[id] = X;
+            pf.left_frame_.landmarks_.push_back(id);
+            pf.left_keypoints_rectified_.push_back({VIO::KeypointStatus::VALID, {0.f, 0.f}});
+            pf.keypoints_3d_.push_back(f);
+            bearings.push_back(f);
+            points.push_back(X);
+            id++;
+          }
+      pf.left_frame_.landmarks_[3] = -1;                                           // dropped: no landmark id
+      pf.left_keypoints_rectified_[5].first = VIO::KeypointStatus::NO_LEFT_RECT;   // dropped: not VALID
+      map.erase(7);                                                                // dropped: out of the time horizon
+      tracker.updateMap(map);
+      gtsam::Pose3 T1, T2;
+      std::vector<int> in1, in2;
+      const bool ok1 = tracker.pnp(bearings, points, &T1, &in1);
+      const bool ok2 = tracker.pnp(pf, &T2, &in2);
+      const int32_t head[4] = {ok1, ok2, (int32_t)in1.size(), (int32_t)in2.size()};
+      w.put("s_pnp", head, sizeof(head));
+      double tt[6] = {T1.translation()(0), T1.translation()(1), T1.translation()(2),
+                      T2.translation()(0), T2.translation()(1), T2.translation()(2)};
+      w.put("s_pnp_t", tt, sizeof(tt));
+    }
 
     VIO::StereoFrame sf;
     sf.left_frame_.img_ = ref.img_;

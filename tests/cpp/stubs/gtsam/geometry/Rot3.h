@@ -18,4 +18,13 @@ struct Rot3 {
   explicit Rot3(const Matrix3& M) : R(M) {}
   Matrix3 matrix() const { return R; }
 };
+using Point3 = Vector3;
+struct Pose3 {   // stand-in for <gtsam/geometry/Pose3.h>
+  Rot3 R;
+  Point3 t;
+  Pose3() = default;
+  Pose3(const Rot3& r, const Point3& tt) : R(r), t(tt) {}
+  const Rot3& rotation() const { return R; }
+  const Point3& translation() const { return t; }
+};
 }  // namespace gtsam

@@ -219,6 +219,13 @@ def test_kimera_shim_reference_signatures(seq, ocam, tmp_path):
     d = p.detector
     raw, _ = O.good_features_to_track(seq["lefts"][0], d.max_nr_keypoints_before_anms, d.quality_level, d.min_distance, 3)
     assert np.array_equal(np.frombuffer(one["s_raw"], np.float32).reshape(-1, 2), raw)
+    # Tracker::updateMap + Tracker::pnp(bearings, points, ...) / pnp(StereoFrame, ...): 27 exact correspondences seen
+    # from (I, [0, 0, -2]); the frame overload drops the keypoint without landmark id, the one that is not VALID and
+    # the landmark outside the map
+    head = np.frombuffer(one["s_pnp"], np.int32)
+    assert list(head) == [1, 1, 27, 24], head
+    tt = np.frombuffer(one["s_pnp_t"], np.float64)
+    assert np.allclose(tt[:3], [0, 0, -2], atol=1e-7) and np.allclose(tt[3:], [0, 0, -2], atol=1e-7), tt
     assert np.array_equal(np.frombuffer(one["s_lrect"], np.uint8).reshape(H, W), ocam.rectify_image(0, seq["lefts"][0]))
     assert np.array_equal(np.frombuffer(one["s_rrect"], np.uint8).reshape(H, W), ocam.rectify_image(1, seq["rights"][0]))
     lx = np.array([[400, 200], [300, 100], [10, 10]], np.float32)

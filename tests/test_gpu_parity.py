@@ -1451,6 +1451,26 @@ def test_cpp_adapter_program_matches_oracle(seq, ocam, tmp_path):
             assert np.array_equal(np.frombuffer(g["m_meas"], np.float64).reshape(-1, 3), e["meas_uL_uR_v"],
                                   equal_nan=True), i
 
+    # Tracker::updateMap / pnp / outlierRejectionPnP through the adapter on every keyframe after the first: the map
+    # is frame 0's 3-D points, the correspondences are gathered as Tracker::pnp(const StereoFrame&) does
+    e0f = exp_frames[0]
+    lmk_map = {int(l): e0f["keypoints_3d"][q] for q, l in enumerate(e0f["landmarks"])
+               if e0f["right_status"][q] == abi.KP_VALID and l != -1}
+    pp = abi.pnp_params_default()
+    focal = 0.5 * (L.intrinsics[0] + L.intrinsics[1])
+    pnp_recs = [(t, b) for t, b in recs if t in ("p_status", "p_pose")]
+    kf_after = [e for e in exp_frames[1:] if e["is_keyframe"]]
+    assert len(pnp_recs) == 2 * len(kf_after) and len(kf_after) >= 1
+    for j, e in enumerate(kf_after):
+        sel = [q for q, l in enumerate(e["landmarks"])
+               if e["left_status"][q] == abi.KP_VALID and l != -1 and int(l) in lmk_map]
+        fb = e["keypoints_3d"][sel]
+        pw = np.array([lmk_map[int(e["landmarks"][q])] for q in sel]).reshape(-1, 3)
+        exp_pnp = O.pnp(fb, pw, focal, p.tracker, pp)
+        st = np.frombuffer(pnp_recs[2 * j][1], np.int32)
+        assert st[0] == exp_pnp["status"] and st[1] == len(lmk_map), (j, st, exp_pnp["status"], len(sel))
+        assert np.array_equal(np.frombuffer(pnp_recs[2 * j + 1][1], np.float64).reshape(3, 4), exp_pnp["pose"]), j
+
     # StereoVisionImuFrontend::spinOnce, frame by frame against the oracle front-end
     frames, cur = [], None
     for tag, b in recs:

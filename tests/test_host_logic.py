@@ -125,6 +125,16 @@ def test_yaml_parsing_euroc():
     assert p.min_intra_keyframe_time_ns == 0.2e9 and p.max_intra_keyframe_time_ns == 5e9
 
 
+def test_yaml_pnp_settings():
+    """use_pnp_tracking / pnp_algorithm / min_pnp_inliers / ransac_threshold_pnp (VisionImuFrontendParams.cpp,
+    VisionImuTrackerParams.cpp) are carried next to the C struct for kvfe_pnp; no YAML is rejected for them"""
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    assert p.use_pnp_tracking == 0 and p.pnp.pnp_algorithm == abi.PNP_EPNP
+    assert p.pnp.min_pnp_inliers == 20 and p.pnp.ransac_threshold_pnp == 1.0 and p.pnp.optimize_2d3d_pose_from_inliers == 0
+    d = abi.pnp_params_default()
+    assert (d.pnp_algorithm, d.min_pnp_inliers, d.ransac_threshold_pnp) == (3, 20, 1.0)
+
+
 def test_cpp_adapter_program_builds_with_plain_gxx():
     """tests/cpp/adapter_sequence.cpp (the reference-shaped C++ host program over include/kvfe_adapter.hpp)
     compiles with g++ alone and links libkvfe.so; without arguments it prints its usage and exits 2.  The GPU
