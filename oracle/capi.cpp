@@ -312,6 +312,10 @@ KVO_API void kvo_pnp(const double* bearings, const double* points, int n, double
   fill_ransac_out(kimera::pnp(bearings, points, n, avg_focal_length, *tp, *pp, &success), inliers, out);
   out->reserved0 = success ? 1 : 0;
 }
+KVO_API int kvo_p3p_kneip(const double* bearings, const double* points, const int* idx3, double* sol) {
+  return opengv_re::p3p_kneip_solutions(bearings, points, idx3, sol);
+}
+KVO_API void kvo_quartic_roots(const double* p5, double* roots4) { opengv_re::quartic_roots(p5, roots4); }
 KVO_API int kvo_epnp(const double* bearings, const double* points, const int* idx, int n, double* model) {
   return opengv_re::epnp(bearings, points, idx, n, model);
 }

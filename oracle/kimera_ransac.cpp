@@ -148,7 +148,7 @@ RansacOut outlierRejection3d3d(const double* ref_p3, const double* cur_p3, int n
   return o;
 }
 
-// Tracker::pnp (Tracker.cpp:1122-1288) for pnp_algorithm_ = EPNP -> runRansac<ProblemPnP> (Tracker.h:247-296,
+// Tracker::pnp (Tracker.cpp:1122-1288) for pnp_algorithm_ = EPNP / KneipP3P -> runRansac<ProblemPnP> (Tracker.h:247-296,
 // optimize_2d3d_pose_from_inliers_ = false), then VisionImuFrontend::outlierRejectionPnP's status
 // (VisionImuFrontend.cpp:146-173)
 RansacOut pnp(const double* bearings, const double* points, int n, double avg_focal_length,
@@ -160,8 +160,12 @@ RansacOut pnp(const double* bearings, const double* points, int n, double avg_fo
   } else {
     const double reprojection_error = pp.ransac_threshold_pnp;
     const double threshold = 1.0 - std::cos(std::atan(std::sqrt(2.0) * reprojection_error / avg_focal_length));
-    opengv_re::RansacResult r = opengv_re::ransac_absolute_pose_epnp(
-        bearings, points, n, threshold, tp.ransac_max_iterations, tp.ransac_probability, tp.ransac_rng_policy);
+    opengv_re::RansacResult r =
+        pp.pnp_algorithm == 1   // Pose3d2dAlgorithm::KneipP3P
+            ? opengv_re::ransac_absolute_pose_kneip(bearings, points, n, threshold, tp.ransac_max_iterations,
+                                                    tp.ransac_probability, tp.ransac_rng_policy)
+            : opengv_re::ransac_absolute_pose_epnp(bearings, points, n, threshold, tp.ransac_max_iterations,
+                                                   tp.ransac_probability, tp.ransac_rng_policy);
     success = r.success;
     o.iterations = r.iterations;
     if (success && r.iterations >= tp.ransac_max_iterations && r.inliers.empty()) success = false;

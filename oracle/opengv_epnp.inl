@@ -526,3 +526,259 @@ struct AbsolutePoseEpnp : Problem {
     return 1.0 - ((r[0] * bearing[0] + r[1] * bearing[1]) + r[2] * bearing[2]);
   }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// AbsolutePoseSacProblem(adapter, KNEIP) (pnp_algorithm: 1, params/KinectAzure): sample size 4 = three correspondences
+// for absolute_pose::p3p_kneip (Kneip, Scaramuzza, Siegwart, "A novel parametrization of the perspective-three-point
+// problem for a direct computation of absolute camera position and orientation", CVPR 2011, the authors' published
+// p3p code as carried by OpenGV: intermediate camera and world frames, the quartic in cos(theta), closed-form roots,
+// back-substitution) + a fourth one that picks among the up to four solutions by reprojection.
+// One deliberate difference: OpenGV's math::o4_roots evaluates Ferrari's formulas with std::complex pow / sqrt
+// (libm transcendental functions); here the complex square and cube roots are computed with +, -, *, / and sqrt only
+// (fixed Newton iterations), so that this restatement and the device code agree bit for bit.  Any cube root of R is a
+// valid choice in Ferrari's method, the four roots are the same up to rounding.
+// ---------------------------------------------------------------------------------------------------------------
+struct Cx {
+  double re, im;
+};
+inline Cx cx(double a, double b = 0.0) { return Cx{a, b}; }
+inline Cx cx_add(Cx a, Cx b) { return Cx{a.re + b.re, a.im + b.im}; }
+inline Cx cx_sub(Cx a, Cx b) { return Cx{a.re - b.re, a.im - b.im}; }
+inline Cx cx_mul(Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline Cx cx_scale(Cx a, double s) { return Cx{a.re * s, a.im * s}; }
+inline Cx cx_div(Cx a, Cx b) {
+  const double d = b.re * b.re + b.im * b.im;
+  return Cx{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+inline Cx cx_sqrt(Cx z) {   // principal square root
+  if (z.re == 0.0 && z.im == 0.0) return Cx{0.0, 0.0};
+  const double r = std::sqrt(z.re * z.re + z.im * z.im);
+  const double t = std::sqrt((r + std::fabs(z.re)) / 2.0);
+  if (z.re >= 0.0) return Cx{t, z.im / (2.0 * t)};
+  return Cx{std::fabs(z.im) / (2.0 * t), z.im < 0.0 ? -t : t};
+}
+// real cube root of m > 0: m = g 2^(3k) with g in [1/8, 1): Newton on t^3 = g from t = 1 (monotone from above, stops
+// at the first step that does not decrease), result t 2^k
+inline double cbrt_pos(double m) {
+  int e;
+  const double f = std::frexp(m, &e);   // m = f 2^e, f in [0.5, 1)
+  int k = e / 3;
+  if (3 * k < e) k++;                    // k = ceil(e / 3)
+  const double g = std::ldexp(f, e - 3 * k);
+  double t = 1.0;
+  for (int it = 0; it < 100; it++) {
+    const double tn = t - (t * t * t - g) / (3.0 * t * t);
+    if (tn >= t) break;
+    t = tn;
+  }
+  return std::ldexp(t, k);
+}
+// a cube root of z (the one with argument arg(z) / 3): |z|^(1/3) (cos(phi / 3) + i sin(phi / 3)); cos(phi / 3) is the
+// root in [1/2, 1] of 4 x^3 - 3 x = cos(phi) (Newton from x = 1, monotone), the sign of the sine follows im(z)
+inline Cx cx_cbrt(Cx z) {
+  const double m = std::sqrt(z.re * z.re + z.im * z.im);
+  if (m == 0.0) return Cx{0.0, 0.0};
+  const double c = z.re / m;
+  double x = 1.0;
+  for (int it = 0; it < 100; it++) {
+    const double xn = x - (4.0 * x * x * x - 3.0 * x - c) / (12.0 * x * x - 3.0);
+    if (xn >= x) break;
+    x = xn;
+  }
+  double s2 = 1.0 - x * x;
+  if (s2 < 0.0) s2 = 0.0;
+  const double s = std::sqrt(s2);
+  const double rm = cbrt_pos(m);
+  return Cx{rm * x, z.im < 0.0 ? -(rm * s) : rm * s};
+}
+
+// math::o4_roots: real parts of the four roots of p[0] x^4 + p[1] x^3 + p[2] x^2 + p[3] x + p[4] (Ferrari)
+void o4_roots(const double* p, double* roots) {
+  const double A = p[0], B = p[1], C = p[2], D = p[3], E = p[4];
+  const double A_pw2 = A * A, B_pw2 = B * B, A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B, A_pw4 = A_pw3 * A,
+               B_pw4 = B_pw3 * B;
+  const double alpha = -3 * B_pw2 / (8 * A_pw2) + C / A;
+  const double beta = B_pw3 / (8 * A_pw3) - B * C / (2 * A_pw2) + D / A;
+  const double gamma = -3 * B_pw4 / (256 * A_pw4) + B_pw2 * C / (16 * A_pw3) - B * D / (4 * A_pw2) + E / A;
+  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+  const double P = -alpha_pw2 / 12 - gamma;
+  const double Q = -alpha_pw3 / 108 + alpha * gamma / 3 - beta * beta / 8;
+  const Cx R = cx_add(cx(-Q / 2.0), cx_sqrt(cx(Q * Q / 4.0 + P * P * P / 27.0)));
+  const Cx U = cx_cbrt(R);
+  Cx y;
+  if (U.re == 0) {
+    const double q3 = Q == 0.0 ? 0.0 : (Q > 0 ? cbrt_pos(Q) : -cbrt_pos(-Q));
+    y = cx(-5.0 * alpha / 6.0 - q3);
+  } else {
+    y = cx_add(cx_sub(cx(-5.0 * alpha / 6.0), cx_div(cx(P), cx_scale(U, 3.0))), U);
+  }
+  const Cx w = cx_sqrt(cx_add(cx(alpha), cx_scale(y, 2.0)));
+  const Cx base = cx_add(cx(3.0 * alpha), cx_scale(y, 2.0));
+  const Cx bw = cx_div(cx(2.0 * beta), w);
+  const Cx s1 = cx_sqrt(cx_scale(cx_add(base, bw), -1.0));
+  const Cx s2 = cx_sqrt(cx_scale(cx_sub(base, bw), -1.0));
+  const double sh = -B / (4.0 * A);
+  roots[0] = sh + 0.5 * (w.re + s1.re);
+  roots[1] = sh + 0.5 * (w.re - s1.re);
+  roots[2] = sh + 0.5 * (-w.re + s2.re);
+  roots[3] = sh + 0.5 * (-w.re - s2.re);
+}
+
+inline void x3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline double nrm3(const double* a) { return std::sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); }
+
+// absolute_pose::modules::p3p_kneip_main: up to four world_T_camera solutions [R | C] (3x4 row-major); returns their number
+int p3p_kneip(const double* f, const double* p, const int* idx, double sol[4][12]) {
+  double P1[3], P2[3], P3[3], f1[3], f2[3], f3[3];
+  for (int c = 0; c < 3; c++) {
+    P1[c] = p[3 * idx[0] + c];
+    P2[c] = p[3 * idx[1] + c];
+    P3[c] = p[3 * idx[2] + c];
+    f1[c] = f[3 * idx[0] + c];
+    f2[c] = f[3 * idx[1] + c];
+    f3[c] = f[3 * idx[2] + c];
+  }
+  double temp1[3], temp2[3], cr[3];
+  for (int c = 0; c < 3; c++) {
+    temp1[c] = P2[c] - P1[c];
+    temp2[c] = P3[c] - P1[c];
+  }
+  x3(temp1, temp2, cr);
+  if (nrm3(cr) == 0) return 0;   // collinear world points
+  double T[9];
+  auto frame = [&](const double* a, const double* b) {   // rows e1 = a, e2 = e3 x e1, e3 = a x b normalised
+    double e3[3], e2[3];
+    x3(a, b, e3);
+    const double n = nrm3(e3);
+    for (int c = 0; c < 3; c++) e3[c] = e3[c] / n;
+    x3(e3, a, e2);
+    for (int c = 0; c < 3; c++) {
+      T[c] = a[c];
+      T[3 + c] = e2[c];
+      T[6 + c] = e3[c];
+    }
+  };
+  frame(f1, f2);
+  double f3t[3];
+  for (int r = 0; r < 3; r++) f3t[r] = d3(T + 3 * r, f3);
+  if (f3t[2] > 0) {
+    for (int c = 0; c < 3; c++) {
+      const double t = f1[c];
+      f1[c] = f2[c];
+      f2[c] = t;
+      const double q = P1[c];
+      P1[c] = P2[c];
+      P2[c] = q;
+    }
+    frame(f1, f2);
+    for (int r = 0; r < 3; r++) f3t[r] = d3(T + 3 * r, f3);
+  }
+  double n1[3], n2[3], n3[3], d31[3], N[9];
+  for (int c = 0; c < 3; c++) {
+    n1[c] = P2[c] - P1[c];
+    d31[c] = P3[c] - P1[c];
+  }
+  const double nn1 = nrm3(n1);
+  for (int c = 0; c < 3; c++) n1[c] = n1[c] / nn1;
+  x3(n1, d31, n3);
+  const double nn3 = nrm3(n3);
+  for (int c = 0; c < 3; c++) n3[c] = n3[c] / nn3;
+  x3(n3, n1, n2);
+  for (int c = 0; c < 3; c++) {
+    N[c] = n1[c];
+    N[3 + c] = n2[c];
+    N[6 + c] = n3[c];
+  }
+  double P3n[3];
+  for (int r = 0; r < 3; r++) P3n[r] = d3(N + 3 * r, d31);
+  const double d_12 = nrm3(temp1);
+  const double f_1 = f3t[0] / f3t[2], f_2 = f3t[1] / f3t[2], p_1 = P3n[0], p_2 = P3n[1];
+  const double cos_beta = d3(f1, f2);
+  double b = 1 / (1 - cos_beta * cos_beta) - 1;
+  if (cos_beta < 0)
+    b = -std::sqrt(b);
+  else
+    b = std::sqrt(b);
+  const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2, p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1,
+               p_1_pw4 = p_1_pw3 * p_1, p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2,
+               d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+  double factors[5];
+  factors[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+  factors[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+  factors[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 +
+               f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12 +
+               2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2 +
+               2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+  factors[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b -
+               2 * p_1 * p_2 * d_12_pw2 * b;
+  factors[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 -
+               p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
+               p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+  double roots[4];
+  o4_roots(factors, roots);
+  for (int i = 0; i < 4; i++) {
+    const double cot_alpha =
+        (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
+    const double cos_theta = roots[i];
+    const double sin_theta = std::sqrt(1 - roots[i] * roots[i]);
+    const double sin_alpha = std::sqrt(1 / (cot_alpha * cot_alpha + 1));
+    double cos_alpha = std::sqrt(1 - sin_alpha * sin_alpha);
+    if (cot_alpha < 0) cos_alpha = -cos_alpha;
+    const double k = sin_alpha * b + cos_alpha;
+    const double Cv[3] = {d_12 * cos_alpha * k, cos_theta * d_12 * sin_alpha * k, sin_theta * d_12 * sin_alpha * k};
+    double Cw[3];
+    for (int r = 0; r < 3; r++) Cw[r] = P1[r] + ((N[r] * Cv[0] + N[3 + r] * Cv[1]) + N[6 + r] * Cv[2]);   // P1 + N^T C
+    const double Rm[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta,
+                          sin_alpha,  -cos_alpha * cos_theta, -cos_alpha * sin_theta,
+                          0.0,        -sin_theta,             cos_theta};
+    double NtRt[9];   // N^T R^T
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) NtRt[3 * r + c] = (N[r] * Rm[3 * c] + N[3 + r] * Rm[3 * c + 1]) + N[6 + r] * Rm[3 * c + 2];
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++)
+        sol[i][4 * r + c] = (NtRt[3 * r] * T[c] + NtRt[3 * r + 1] * T[3 + c]) + NtRt[3 * r + 2] * T[6 + c];
+      sol[i][4 * r + 3] = Cw[r];
+    }
+  }
+  return 4;
+}
+
+// AbsolutePoseSacProblem(adapter, KNEIP)
+struct AbsolutePoseKneip : Problem {
+  const double *f, *p;
+  int n;
+  int sampleSize() const override { return 4; }
+  int size() const override { return n; }
+  bool computeModelCoefficients(const std::vector<int>& s, double* model) const override {
+    double sol[4][12];
+    const int ns = p3p_kneip(f, p, s.data(), sol);
+    // the fourth correspondence picks the solution: smallest 1 - f4 . normalize(R^T (p4 - t)) (NaN never wins)
+    double minScore = 1000000.0;
+    int minIndex = -1;
+    AbsolutePoseEpnp scorer;
+    scorer.f = f;
+    scorer.p = p;
+    scorer.n = n;
+    for (int i = 0; i < ns; i++) {
+      const double score = scorer.distance(sol[i], nullptr, s[3]);
+      if (score < minScore) {
+        minScore = score;
+        minIndex = i;
+      }
+    }
+    if (minIndex == -1) return false;
+    std::memcpy(model, sol[minIndex], sizeof(double) * 12);
+    return true;
+  }
+  double distance(const double* model, const double* aux, int i) const override {
+    AbsolutePoseEpnp scorer;
+    scorer.f = f;
+    scorer.p = p;
+    scorer.n = n;
+    return scorer.distance(model, aux, i);
+  }
+};

@@ -783,6 +783,24 @@ RansacResult ransac_absolute_pose_epnp(const double* bearings, const double* poi
   return run_ransac(p, threshold, max_iterations, probability, rng_policy);
 }
 
+RansacResult ransac_absolute_pose_kneip(const double* bearings, const double* points, int n, double threshold,
+                                        int max_iterations, double probability, int rng_policy) {
+  AbsolutePoseKneip p;
+  p.f = bearings;
+  p.p = points;
+  p.n = n;
+  return run_ransac(p, threshold, max_iterations, probability, rng_policy);
+}
+
+int p3p_kneip_solutions(const double* bearings, const double* points, const int* idx3, double* sol /* 4 x 12 */) {
+  double s[4][12];
+  const int n = p3p_kneip(bearings, points, idx3, s);
+  std::memcpy(sol, s, sizeof(double) * 12 * n);
+  return n;
+}
+
+void quartic_roots(const double* p5, double* roots4) { o4_roots(p5, roots4); }
+
 int epnp(const double* bearings, const double* points, const int* idx, int n, double model[12]) {
   if (n < 4) return 0;
   epnp_transformation(bearings, points, idx, n, model);

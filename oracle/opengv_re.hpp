@@ -62,6 +62,13 @@ RansacResult ransac_central_relative_pose_nister(const double* f1, const double*
 // bearings: n x 3 camera-frame bearing vectors, points: n x 3 world points; coeff = world_T_camera [R | t]
 RansacResult ransac_absolute_pose_epnp(const double* bearings, const double* points, int n, double threshold,
                                        int max_iterations, double probability, int rng_policy);
+// opengv::sac::Ransac<AbsolutePoseSacProblem(KNEIP)>::computeModel (pnp_algorithm 1): sample size 4 = Kneip's P3P on
+// three correspondences, the fourth picks among its solutions
+RansacResult ransac_absolute_pose_kneip(const double* bearings, const double* points, int n, double threshold,
+                                        int max_iterations, double probability, int rng_policy);
+// absolute_pose::p3p_kneip on idx3[0..3) (test hook): up to four world_T_camera 3x4 row-major; math::o4_roots
+int p3p_kneip_solutions(const double* bearings, const double* points, const int* idx3, double* sol);
+void quartic_roots(const double* p5, double* roots4);
 // absolute_pose::epnp(adapter, indices) on idx[0..n) (test hook), model = world_T_camera 3x4 row-major
 int epnp(const double* bearings, const double* points, const int* idx, int n, double model[12]);
 

@@ -502,6 +502,22 @@ def pnp(bearings, points, avg_focal_length, tp: abi.TrackerParams, pp: abi.PnpPa
     return r
 
 
+def p3p_kneip(bearings, points, idx3):
+    """absolute_pose::p3p_kneip on three correspondences: up to four world_T_camera 3x4"""
+    f = np.ascontiguousarray(bearings, np.float64).reshape(-1, 3)
+    pw = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    ix = np.ascontiguousarray(idx3, np.int32)
+    sol = np.zeros((4, 12))
+    n = lib().kvo_p3p_kneip(_p(f), _p(pw), _p(ix), _p(sol))
+    return sol[:n].reshape(-1, 3, 4)
+
+
+def quartic_roots(p5):
+    r = np.zeros(4)
+    lib().kvo_quartic_roots(_p(np.ascontiguousarray(p5, np.float64)), _p(r))
+    return r
+
+
 def epnp(bearings, points, idx):
     """absolute_pose::epnp(adapter, indices): world_T_camera 3x4"""
     f = np.ascontiguousarray(bearings, np.float64).reshape(-1, 3)

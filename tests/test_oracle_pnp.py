@@ -117,3 +117,73 @@ def test_pnp_degenerate_inputs():
     pp.min_pnp_inliers = 30                                            # more than the scene holds
     r = O.pnp(f, pw, focal, tp, pp)
     assert r["success"] and r["status"] == abi.TRACKING_FEW_MATCHES and r["n_inliers"] == 22
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pnp_algorithm: 1 (Kneip's P3P, params/KinectAzure)
+# ---------------------------------------------------------------------------------------------------------------
+def test_quartic_roots_closed_form():
+    """math::o4_roots (Ferrari) with the deterministic complex roots: quartics with four real roots, two, none
+    (real parts of the complex pairs), against numpy.roots"""
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        kind = trial % 3
+        if kind == 0:
+            r = np.sort(rng.uniform(-1, 1, 4))
+            coef = np.poly(r) * rng.uniform(0.5, 3.0)
+        elif kind == 1:
+            a, b = rng.uniform(-1, 1, 2)
+            c = complex(rng.uniform(-1, 1), rng.uniform(0.1, 1))
+            coef = np.real(np.poly([a, b, c, np.conj(c)])) * rng.uniform(0.5, 3.0)
+        else:
+            c1 = complex(rng.uniform(-1, 1), rng.uniform(0.1, 1))
+            c2 = complex(rng.uniform(-1, 1), rng.uniform(0.1, 1))
+            coef = np.real(np.poly([c1, np.conj(c1), c2, np.conj(c2)])) * rng.uniform(0.5, 3.0)
+        got = np.sort(O.quartic_roots(coef))
+        exp = np.sort(np.real(np.roots(coef)))
+        assert np.allclose(got, exp, atol=2e-6), (trial, got, exp)
+
+
+def test_p3p_kneip_contains_the_true_pose():
+    """absolute_pose::p3p_kneip on exact correspondences: one of the (up to four) solutions is the true camera pose,
+    and AbsolutePoseSacProblem's fourth point picks it"""
+    rng = np.random.default_rng(8)
+    tp = P.default_frontend_params().tracker
+    tp.ransac_randomize = 0
+    hits = 0
+    for trial in range(60):
+        w = rng.normal(size=3) * 0.5
+        th = np.linalg.norm(w)
+        k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        Rwc = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(size=3)
+        pc = np.stack([rng.uniform(-2, 2, 30), rng.uniform(-1.5, 1.5, 30), rng.uniform(1.5, 8, 30)], 1)
+        pw = (Rwc @ pc.T).T + t
+        f = pc / np.linalg.norm(pc, axis=1, keepdims=True)
+        sols = O.p3p_kneip(f, pw, [0, 1, 2])
+        assert len(sols) == 4
+        err = [np.abs(s[:, :3] - Rwc).max() + np.abs(s[:, 3] - t).max() for s in sols if np.all(np.isfinite(s))]
+        assert min(err) < 1e-6, (trial, err)
+        hits += 1
+        pp = abi.pnp_params_default()
+        pp.pnp_algorithm = abi.PNP_KNEIP_P3P
+        r = O.pnp(f, pw, 458.0, tp, pp)
+        assert r["success"] and r["n_inliers"] == 30
+        assert np.allclose(r["pose"][:, :3], Rwc, atol=1e-6) and np.allclose(r["pose"][:, 3], t, atol=1e-6)
+    assert hits == 60
+
+
+def test_pnp_tracking_reference_scene_kneip():
+    """the PnPTracking scene with pnp_algorithm 1: same assertions (22 inliers of 25, pose within 1e-5)"""
+    f, pw, expected, focal = pnp_scene()
+    tp = P.default_frontend_params().tracker
+    tp.ransac_randomize = 0
+    pp = abi.pnp_params_default()
+    pp.pnp_algorithm = abi.PNP_KNEIP_P3P
+    pp.min_pnp_inliers = 10
+    pp.ransac_threshold_pnp = 0.5
+    r = O.pnp(f, pw, focal, tp, pp)
+    assert r["success"] and r["status"] == abi.TRACKING_VALID and r["n_inliers"] == len(INLIER_LMKS)
+    assert np.all(np.abs(r["pose"][:, 3] - expected[:, 3]) < 1e-5)
+    assert np.all(np.abs(quat(r["pose"][:, :3]) - quat(expected[:, :3])) < 1e-5)

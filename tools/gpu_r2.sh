@@ -22,7 +22,7 @@ cd /tmp
 Q="--steps 10 --warmup 3 --repeats 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -o kt -- python $R/bench.py --steps 20 --warmup 5 --repeats 1 --legs none > $R/gpurun_out/prof_kt.log 2>&1; echo "kt rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt_c5 -o kt -- python $R/bench.py --config c5 --steps 10 --warmup 3 --repeats 1 --legs none > $R/gpurun_out/prof_kt_c5.log 2>&1; echo "kt c5 rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt_c2 -o kt -- python $R/bench.py --steps 2 --warmup 1 --repeats 1 --legs single_stream > $R/gpurun_out/prof_kt_c2.log 2>&1; echo "kt c2 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt_c2 -o kt -- python $R/bench.py --config c2 --steps 200 --warmup 20 --repeats 1 --legs none --no-stage-events > $R/gpurun_out/prof_kt_c2.log 2>&1; echo "kt c2 rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_c3_kf_$C -o p -- python $R/bench.py $Q --legs none > $R/gpurun_out/pmc.log 2>&1; echo "pmc c3 $C rc=$?"
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_c5_kf_$C -o p -- python $R/bench.py --config c5 $Q --legs none > $R/gpurun_out/pmc.log 2>&1; echo "pmc c5 $C rc=$?"
