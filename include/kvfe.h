@@ -502,7 +502,8 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* re
  * (kfTracking_status_pnp_, W_T_k_pnp_) does not feed back into the keypoint state (VisionImuFrontend.cpp:163
  * "TODO remove outliers"), it is reported next to the mono / stereo results.
  * Implemented: pnp_algorithm 3 (EPNP: opengv AbsolutePoseSacProblem, 6 points per sample, fixed seed), the value
- * of every shipped parameter set but params/KinectAzure (UPNP); the others return KVFE_ERR_UNSUPPORTED, and so does
+ * of every shipped parameter set but params/KinectAzure, and that one's pnp_algorithm 1 (KneipP3P: 3 + 1 points per
+ * sample, closed-form quartic); the others return KVFE_ERR_UNSUPPORTED, and so does
  * optimize_2d3d_pose_from_inliers (off everywhere).  The threshold is 1 - cos(atan(sqrt 2 ransac_threshold_pnp /
  * f)) with f the mean of the LEFT camera's fx, fy; iterations / probability / sampler come from the tracker
  * parameters of the context.
@@ -511,7 +512,7 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* re
  * The dense linear algebra of EPnP is a Jacobi / Householder implementation, not Eigen's: poses agree with the
  * reference to rounding; the inlier decision is pinned by the scene of tests/testTracker.cpp:1613-1800. */
 typedef struct kvfe_pnp_params {
-  int32_t pnp_algorithm;                     /* Pose3d2dAlgorithm (VisionImuTrackerParams.h): 3 = EPNP */
+  int32_t pnp_algorithm;                     /* Pose3d2dAlgorithm: 3 = EPNP, 1 = KneipP3P              */
   int32_t min_pnp_inliers;
   double ransac_threshold_pnp;               /* pixels                                                 */
   int32_t optimize_2d3d_pose_from_inliers;   /* must be 0                                              */

@@ -431,6 +431,216 @@ __device__ void ep_solve(const double* f, const double* p, const int* sel, EpSlo
     model[r * 4 + 3] = -((model[r * 4] * t[0] + model[r * 4 + 1] * t[1]) + model[r * 4 + 2] * t[2]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// AbsolutePoseSacProblem(adapter, KNEIP) (pnp_algorithm: 1, params/KinectAzure): Kneip's P3P on three correspondences,
+// the fourth one picks among the up to four solutions.  Operation for operation the oracle's (oracle/opengv_epnp.inl),
+// including its closed-form quartic with complex square / cube roots built from +, -, *, / and sqrt only.
+// ---------------------------------------------------------------------------------------------------------------
+struct KnCx {
+  double re, im;
+};
+__device__ __forceinline__ KnCx kn_cx(double a, double b = 0.0) { return KnCx{a, b}; }
+__device__ __forceinline__ KnCx kn_add(KnCx a, KnCx b) { return KnCx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ KnCx kn_sub(KnCx a, KnCx b) { return KnCx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ KnCx kn_scale(KnCx a, double s) { return KnCx{a.re * s, a.im * s}; }
+__device__ __forceinline__ KnCx kn_div(KnCx a, KnCx b) {
+  const double d = b.re * b.re + b.im * b.im;
+  return KnCx{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+__device__ KnCx kn_sqrt(KnCx z) {
+  if (z.re == 0.0 && z.im == 0.0) return KnCx{0.0, 0.0};
+  const double r = sqrt(z.re * z.re + z.im * z.im);
+  const double t = sqrt((r + fabs(z.re)) / 2.0);
+  if (z.re >= 0.0) return KnCx{t, z.im / (2.0 * t)};
+  return KnCx{fabs(z.im) / (2.0 * t), z.im < 0.0 ? -t : t};
+}
+__device__ double kn_cbrt_pos(double m) {
+  int e;
+  const double f = frexp(m, &e);
+  int k = e / 3;
+  if (3 * k < e) k++;
+  const double g = ldexp(f, e - 3 * k);
+  double t = 1.0;
+  for (int it = 0; it < 100; it++) {
+    const double tn = t - (t * t * t - g) / (3.0 * t * t);
+    if (tn >= t) break;
+    t = tn;
+  }
+  return ldexp(t, k);
+}
+__device__ KnCx kn_cbrt(KnCx z) {
+  const double m = sqrt(z.re * z.re + z.im * z.im);
+  if (m == 0.0) return KnCx{0.0, 0.0};
+  const double c = z.re / m;
+  double x = 1.0;
+  for (int it = 0; it < 100; it++) {
+    const double xn = x - (4.0 * x * x * x - 3.0 * x - c) / (12.0 * x * x - 3.0);
+    if (xn >= x) break;
+    x = xn;
+  }
+  double s2 = 1.0 - x * x;
+  if (s2 < 0.0) s2 = 0.0;
+  const double sn = sqrt(s2);
+  const double rm = kn_cbrt_pos(m);
+  return KnCx{rm * x, z.im < 0.0 ? -(rm * sn) : rm * sn};
+}
+__device__ void kn_o4_roots(const double* p, double* roots) {
+  const double A = p[0], B = p[1], C = p[2], D = p[3], E = p[4];
+  const double A_pw2 = A * A, B_pw2 = B * B, A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B, A_pw4 = A_pw3 * A,
+               B_pw4 = B_pw3 * B;
+  const double alpha = -3 * B_pw2 / (8 * A_pw2) + C / A;
+  const double beta = B_pw3 / (8 * A_pw3) - B * C / (2 * A_pw2) + D / A;
+  const double gamma = -3 * B_pw4 / (256 * A_pw4) + B_pw2 * C / (16 * A_pw3) - B * D / (4 * A_pw2) + E / A;
+  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+  const double P = -alpha_pw2 / 12 - gamma;
+  const double Q = -alpha_pw3 / 108 + alpha * gamma / 3 - beta * beta / 8;
+  const KnCx R = kn_add(kn_cx(-Q / 2.0), kn_sqrt(kn_cx(Q * Q / 4.0 + P * P * P / 27.0)));
+  const KnCx U = kn_cbrt(R);
+  KnCx y;
+  if (U.re == 0) {
+    const double q3 = Q == 0.0 ? 0.0 : (Q > 0 ? kn_cbrt_pos(Q) : -kn_cbrt_pos(-Q));
+    y = kn_cx(-5.0 * alpha / 6.0 - q3);
+  } else {
+    y = kn_add(kn_sub(kn_cx(-5.0 * alpha / 6.0), kn_div(kn_cx(P), kn_scale(U, 3.0))), U);
+  }
+  const KnCx w = kn_sqrt(kn_add(kn_cx(alpha), kn_scale(y, 2.0)));
+  const KnCx base = kn_add(kn_cx(3.0 * alpha), kn_scale(y, 2.0));
+  const KnCx bw = kn_div(kn_cx(2.0 * beta), w);
+  const KnCx s1 = kn_sqrt(kn_scale(kn_add(base, bw), -1.0));
+  const KnCx s2 = kn_sqrt(kn_scale(kn_sub(base, bw), -1.0));
+  const double sh = -B / (4.0 * A);
+  roots[0] = sh + 0.5 * (w.re + s1.re);
+  roots[1] = sh + 0.5 * (w.re - s1.re);
+  roots[2] = sh + 0.5 * (-w.re + s2.re);
+  roots[3] = sh + 0.5 * (-w.re - s2.re);
+}
+__device__ __forceinline__ double kn_nrm3(const double* a) { return sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); }
+__device__ __forceinline__ double ep_distance(const double* model, const double* bearing, const double* point);
+
+// p3p_kneip_main on sel[0..3) + the choice by sel[3]; false when no solution scores (collinear points, NaN)
+__device__ bool kn_solve(const double* f, const double* p, const int* sel, double* model) {
+  double P1[3], P2[3], P3[3], f1[3], f2[3], f3[3];
+  for (int c = 0; c < 3; c++) {
+    P1[c] = p[3 * (size_t)sel[0] + c];
+    P2[c] = p[3 * (size_t)sel[1] + c];
+    P3[c] = p[3 * (size_t)sel[2] + c];
+    f1[c] = f[3 * (size_t)sel[0] + c];
+    f2[c] = f[3 * (size_t)sel[1] + c];
+    f3[c] = f[3 * (size_t)sel[2] + c];
+  }
+  double temp1[3], temp2[3], cr[3];
+  for (int c = 0; c < 3; c++) {
+    temp1[c] = P2[c] - P1[c];
+    temp2[c] = P3[c] - P1[c];
+  }
+  rs_cross3(temp1, temp2, cr);
+  if (kn_nrm3(cr) == 0) return false;
+  double T[9];
+  auto frame = [&](const double* a, const double* b) {
+    double e3[3], e2[3];
+    rs_cross3(a, b, e3);
+    const double n = kn_nrm3(e3);
+    for (int c = 0; c < 3; c++) e3[c] = e3[c] / n;
+    rs_cross3(e3, a, e2);
+    for (int c = 0; c < 3; c++) {
+      T[c] = a[c];
+      T[3 + c] = e2[c];
+      T[6 + c] = e3[c];
+    }
+  };
+  frame(f1, f2);
+  double f3t[3];
+  for (int r = 0; r < 3; r++) f3t[r] = ep_d3(T + 3 * r, f3);
+  if (f3t[2] > 0) {
+    for (int c = 0; c < 3; c++) {
+      const double t = f1[c];
+      f1[c] = f2[c];
+      f2[c] = t;
+      const double q = P1[c];
+      P1[c] = P2[c];
+      P2[c] = q;
+    }
+    frame(f1, f2);
+    for (int r = 0; r < 3; r++) f3t[r] = ep_d3(T + 3 * r, f3);
+  }
+  double n1[3], n2[3], n3[3], d31[3], N[9];
+  for (int c = 0; c < 3; c++) {
+    n1[c] = P2[c] - P1[c];
+    d31[c] = P3[c] - P1[c];
+  }
+  const double nn1 = kn_nrm3(n1);
+  for (int c = 0; c < 3; c++) n1[c] = n1[c] / nn1;
+  rs_cross3(n1, d31, n3);
+  const double nn3 = kn_nrm3(n3);
+  for (int c = 0; c < 3; c++) n3[c] = n3[c] / nn3;
+  rs_cross3(n3, n1, n2);
+  for (int c = 0; c < 3; c++) {
+    N[c] = n1[c];
+    N[3 + c] = n2[c];
+    N[6 + c] = n3[c];
+  }
+  double P3n[3];
+  for (int r = 0; r < 3; r++) P3n[r] = ep_d3(N + 3 * r, d31);
+  const double d_12 = kn_nrm3(temp1);
+  const double f_1 = f3t[0] / f3t[2], f_2 = f3t[1] / f3t[2], p_1 = P3n[0], p_2 = P3n[1];
+  const double cos_beta = ep_d3(f1, f2);
+  double b = 1 / (1 - cos_beta * cos_beta) - 1;
+  if (cos_beta < 0)
+    b = -sqrt(b);
+  else
+    b = sqrt(b);
+  const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2, p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1,
+               p_1_pw4 = p_1_pw3 * p_1, p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2,
+               d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+  double factors[5];
+  factors[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+  factors[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+  factors[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 +
+               f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12 +
+               2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2 +
+               2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+  factors[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b -
+               2 * p_1 * p_2 * d_12_pw2 * b;
+  factors[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 -
+               p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
+               p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+  double roots[4];
+  kn_o4_roots(factors, roots);
+  double minScore = 1000000.0;
+  bool have = false;
+  const double* f4 = f + 3 * (size_t)sel[3];
+  const double* p4 = p + 3 * (size_t)sel[3];
+  for (int i = 0; i < 4; i++) {
+    const double cot_alpha =
+        (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
+    const double cos_theta = roots[i];
+    const double sin_theta = sqrt(1 - roots[i] * roots[i]);
+    const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
+    double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
+    if (cot_alpha < 0) cos_alpha = -cos_alpha;
+    const double k = sin_alpha * b + cos_alpha;
+    const double Cv[3] = {d_12 * cos_alpha * k, cos_theta * d_12 * sin_alpha * k, sin_theta * d_12 * sin_alpha * k};
+    double sol[12];
+    for (int r = 0; r < 3; r++) sol[4 * r + 3] = P1[r] + ((N[r] * Cv[0] + N[3 + r] * Cv[1]) + N[6 + r] * Cv[2]);
+    const double Rm[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta,
+                          sin_alpha,  -cos_alpha * cos_theta, -cos_alpha * sin_theta,
+                          0.0,        -sin_theta,             cos_theta};
+    double NtRt[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) NtRt[3 * r + c] = (N[r] * Rm[3 * c] + N[3 + r] * Rm[3 * c + 1]) + N[6 + r] * Rm[3 * c + 2];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+        sol[4 * r + c] = (NtRt[3 * r] * T[c] + NtRt[3 * r + 1] * T[3 + c]) + NtRt[3 * r + 2] * T[6 + c];
+    const double score = ep_distance(sol, f4, p4);
+    if (score < minScore) {
+      minScore = score;
+      have = true;
+      for (int q = 0; q < 12; q++) model[q] = sol[q];
+    }
+  }
+  return have;
+}
+
 // AbsolutePoseSacProblem::getSelectedDistancesToModel for one correspondence
 __device__ __forceinline__ double ep_distance(const double* model, const double* bearing, const double* point) {
   const double dlt[3] = {point[0] - model[3], point[1] - model[7], point[2] - model[11]};
@@ -444,14 +654,17 @@ __device__ __forceinline__ double ep_distance(const double* model, const double*
 // Tracker::pnp over n correspondences (one problem per workgroup).  out_status: outlierRejectionPnP's status;
 // out_counts: [n_inliers, iterations, success]; out_pose 3x4; inliers ascending.
 // LDS (dynamic): shuffled [n] int
+template <int ALG>   // Pose3d2dAlgorithm: 3 = EPNP (6 points per sample), 1 = KneipP3P (3 + 1)
 __global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, const double* f, const double* p, int n,
                                                           double threshold, int min_inliers, int* inliers,
                                                           int* out_status, double* out_pose, int* out_counts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   int* shuffled = reinterpret_cast<int*>(lds_raw);
+  constexpr int SS = ALG == 3 ? EP_N : 4;   // AbsolutePoseSacProblem::getSampleSize()
   __shared__ int wave_tot[RS_T / 64];
   __shared__ int sh_sel[EP_BATCH][EP_N];
   __shared__ int sh_cnt[EP_BATCH];
+  __shared__ int sh_ok[EP_BATCH];
   __shared__ double sh_models[EP_BATCH][12];
   __shared__ double sh_best[12];
   __shared__ EpSlot sh_slots[EP_BATCH];
@@ -461,35 +674,43 @@ __global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, c
   __syncthreads();
   int iterations = 0, best = -INT_MAX, draw = 0;
   const unsigned max_skip = (unsigned)P.ransac_max_iters * 10u;
-  unsigned skipped = 0;   // (computeModelCoefficients of EPNP never fails)
+  unsigned skipped = 0;   // (computeModelCoefficients of EPNP never fails; P3P does for collinear points)
   double k = 1.0;
   bool have_model = false, done = false;
-  if (n < EP_N) {
+  if (n < SS) {
     iterations = INT_MAX;   // getSamples: not enough correspondences -> computeModel returns false
     done = true;
   }
   while (!done) {
     if (tid == 0) {   // drawIndexSample for the next EP_BATCH hypotheses (the shuffle persists)
       for (int h = 0; h < EP_BATCH; h++) {
-        for (int i = 0; i < EP_N; ++i) {
-          const int r = T.ransac_rnd[min(draw + EP_N * h + i, T.n_ransac_rnd - 1)];
+        for (int i = 0; i < SS; ++i) {
+          const int r = T.ransac_rnd[min(draw + SS * h + i, T.n_ransac_rnd - 1)];
           const int j = i + (int)((unsigned)r % (unsigned)(n - i));
           const int tmp = shuffled[i];
           shuffled[i] = shuffled[j];
           shuffled[j] = tmp;
         }
-        for (int i = 0; i < EP_N; i++) sh_sel[h][i] = shuffled[i];
+        for (int i = 0; i < SS; i++) sh_sel[h][i] = shuffled[i];
       }
     }
-    draw += EP_N * EP_BATCH;
+    draw += SS * EP_BATCH;
     __syncthreads();
     {
       static_assert(EP_BATCH * 32 == RS_T, "32 lanes per hypothesis: two solver lanes per wavefront");
       const int h = tid >> 5;
-      if ((tid & 31) == 0) ep_solve(f, p, sh_sel[h], sh_slots[h], sh_models[h]);
+      if ((tid & 31) == 0) {
+        if (ALG == 3) {
+          ep_solve(f, p, sh_sel[h], sh_slots[h], sh_models[h]);
+          sh_ok[h] = 1;
+        } else {
+          sh_ok[h] = kn_solve(f, p, sh_sel[h], sh_models[h]) ? 1 : 0;
+        }
+      }
     }
     __syncthreads();
     for (int h = 0; h < EP_BATCH; h++) {   // countWithinDistance
+      if (!sh_ok[h]) continue;
       double M[12];
       for (int i = 0; i < 12; i++) M[i] = sh_models[h][i];
       int cnt = 0;
@@ -504,13 +725,17 @@ __global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, c
         done = true;
         break;
       }
+      if (!sh_ok[h]) {
+        ++skipped;
+        continue;
+      }
       const int cnt = sh_cnt[h];
       if (cnt > best) {
         best = cnt;
         have_model = true;
         if (tid < 12) sh_best[tid] = sh_models[h][tid];
         const double w = (double)best / (double)n;
-        double p_no_outliers = 1.0 - pow(w, (double)EP_N);
+        double p_no_outliers = 1.0 - pow(w, (double)SS);
         p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
         p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
         k = log(1.0 - P.ransac_probability) / log(p_no_outliers);
@@ -555,8 +780,14 @@ __global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, c
   }
 }
 
-void launch_pnp(const KParams& P, const Tables& T, const double* f, const double* p, int n, double threshold,
-                int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts, hipStream_t st) {
-  hipLaunchKernelGGL(pnp_ransac_kernel, dim3(1), dim3(RS_T), sizeof(int) * (size_t)(n > 0 ? n : 1), st, P, T, f, p, n,
-                     threshold, min_inliers, inliers, out_status, out_pose, out_counts);
+void launch_pnp(const KParams& P, const Tables& T, int algorithm, const double* f, const double* p, int n,
+                double threshold, int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts,
+                hipStream_t st) {
+  const size_t lds = sizeof(int) * (size_t)(n > 0 ? n : 1);
+  if (algorithm == 1)
+    hipLaunchKernelGGL(pnp_ransac_kernel<1>, dim3(1), dim3(RS_T), lds, st, P, T, f, p, n, threshold, min_inliers,
+                       inliers, out_status, out_pose, out_counts);
+  else
+    hipLaunchKernelGGL(pnp_ransac_kernel<3>, dim3(1), dim3(RS_T), lds, st, P, T, f, p, n, threshold, min_inliers,
+                       inliers, out_status, out_pose, out_counts);
 }

@@ -1798,8 +1798,8 @@ kvfe_status kvfe_pnp(kvfe_ctx* c, const kvfe_pnp_params* pp, const double* cam_b
                      const double* F_points, int32_t n, int32_t* inliers, kvfe_ransac_output* out) {
   DeviceGuard _dev(c);
   if (!c || !pp || !out || n < 0 || (n > 0 && (!cam_bearing_vectors || !F_points))) return KVFE_ERR_INVALID_ARG;
-  if (pp->pnp_algorithm != 3) {
-    c->last_error = "pnp_algorithm: only 3 (EPNP) is implemented";
+  if (pp->pnp_algorithm != 3 && pp->pnp_algorithm != 1) {
+    c->last_error = "pnp_algorithm: only 3 (EPNP) and 1 (KneipP3P) are implemented";
     return KVFE_ERR_UNSUPPORTED;
   }
   if (pp->optimize_2d3d_pose_from_inliers) {
@@ -1821,7 +1821,7 @@ kvfe_status kvfe_pnp(kvfe_ctx* c, const kvfe_pnp_params* pp, const double* cam_b
   hipStream_t st = c->stream;
   HIPCHK(c, hipMemcpyAsync(b.rs.f_ref, cam_bearing_vectors, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(b.rs.f_cur, F_points, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-  launch_pnp(P, c->T, b.rs.f_ref, b.rs.f_cur, n, threshold, pp->min_pnp_inliers, b.rs.inliers, b.ss.trk_status,
+  launch_pnp(P, c->T, pp->pnp_algorithm, b.rs.f_ref, b.rs.f_cur, n, threshold, pp->min_pnp_inliers, b.rs.inliers, b.ss.trk_status,
              b.ss.trk_pose, b.ss.trk_counts, st);
   int status = 0, cnt[3] = {0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(&status, b.ss.trk_status, sizeof(int), hipMemcpyDeviceToHost, st));

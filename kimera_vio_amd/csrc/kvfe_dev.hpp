@@ -314,8 +314,9 @@ void launch_ransac_2d2d_nister_points(const KParams& P, const Tables& T, const d
                                       int n, const RansacScratch& RS, int* out_status, double* out_pose,
                                       int* out_counts, hipStream_t st);
 // Tracker::pnp, EPNP RANSAC over n 2D-3D correspondences (k_pnp.inl): out_counts = [n_inliers, iterations, success]
-void launch_pnp(const KParams& P, const Tables& T, const double* f, const double* p, int n, double threshold,
-                int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts, hipStream_t st);
+void launch_pnp(const KParams& P, const Tables& T, int algorithm, const double* f, const double* p, int n,
+                double threshold, int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts,
+                hipStream_t st);
 void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const double* p1, const double* p2, int n,
                                     const RansacScratch& RS, int* out_status, double* out_pose, int* out_counts,
                                     hipStream_t st);

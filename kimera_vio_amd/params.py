@@ -170,8 +170,8 @@ def load_frontend_params(path: str, use_ransac: int | None = None) -> abi.Fronte
     # and read nowhere in src/.  use_pnp_tracking gates Tracker::pnp on keyframes (StereoVisionImuFrontend.cpp:389);
     # its result does not feed back into the keypoint state, so it runs next to the step: kvfe_pnp /
     # Context.pnp with the parameters attached here (p.use_pnp_tracking, p.pnp) and the landmark map of the back-end
-    # (kvfe::Tracker::updateMap / outlierRejectionPnP in include/kvfe_adapter.hpp).  Only EPNP is implemented:
-    # another pnp_algorithm makes that call return KVFE_ERR_UNSUPPORTED, not the step.
+    # (kvfe::Tracker::updateMap / outlierRejectionPnP in include/kvfe_adapter.hpp).  EPNP and KneipP3P are
+    # implemented: another pnp_algorithm makes that call return KVFE_ERR_UNSUPPORTED, not the step.
     int(y["use_2d2d_tracking"]), int(y["use_3d3d_tracking"])
     p.use_pnp_tracking = int(y["use_pnp_tracking"])
     p.pnp = abi.PnpParams(int(y.get("pnp_algorithm", abi.PNP_EPNP)), int(y.get("min_pnp_inliers", 20)),

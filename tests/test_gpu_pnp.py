@@ -87,6 +87,50 @@ def test_pnp_random_scenes_bit_exact():
             c.close()
 
 
+def test_pnp_kneip_p3p_bit_exact():
+    """pnp_algorithm 1 (KneipP3P, params/KinectAzure): the reference scene and 30 random scenes, field by field and
+    the pose bit-exact (the closed-form quartic uses only +, -, *, / and sqrt on both sides)"""
+    f, pw, expected, focal = pnp_scene()
+    c, p, _ = _ctx()
+    try:
+        pp = abi.pnp_params_default()
+        pp.pnp_algorithm = abi.PNP_KNEIP_P3P
+        pp.min_pnp_inliers = 10
+        pp.ransac_threshold_pnp = 0.5
+        got = c.pnp(f, pw, pp)
+        assert got["success"] and got["n_inliers"] == len(INLIER_LMKS)
+        assert np.all(np.abs(got["pose"][:, 3] - expected[:, 3]) < 1e-5)
+        _same(got, O.pnp(f, pw, focal, p.tracker, pp))
+    finally:
+        c.close()
+    rng = np.random.default_rng(21)
+    for trial in range(30):
+        n = int(rng.integers(8, 300))
+        w = rng.normal(size=3) * 0.3
+        th = np.linalg.norm(w)
+        k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        Rwc = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(size=3)
+        pc = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1.5, 8, n)], 1)
+        pw = (Rwc @ pc.T).T + t
+        noise = rng.normal(size=(n, 2)) * float(rng.choice([0.0, 0.3])) / 458.0
+        fb = np.concatenate([pc[:, :2] / pc[:, 2:3] + noise, np.ones((n, 1))], 1)
+        fb /= np.linalg.norm(fb, axis=1, keepdims=True)
+        bad = rng.random(n) < float(rng.choice([0.0, 0.2, 0.5]))
+        pw[bad] += rng.normal(size=(int(bad.sum()), 3))
+        if trial % 7 == 0:
+            pw[:3] = pw[0] + np.outer([0.0, 1.0, 2.0], [0.1, 0.2, 0.3])   # collinear triples: computeModel fails
+        c, p, focal = _ctx(ransac_rng_policy=int(trial % 2), ransac_max_iterations=int(rng.choice([5, 100])))
+        try:
+            pp = abi.pnp_params_default()
+            pp.pnp_algorithm = abi.PNP_KNEIP_P3P
+            pp.ransac_threshold_pnp = float(rng.choice([0.5, 2.0]))
+            _same(c.pnp(fb, pw, pp), O.pnp(fb, pw, focal, p.tracker, pp))
+        finally:
+            c.close()
+
+
 def test_pnp_degenerate_and_unsupported():
     c, p, focal = _ctx()
     try:
@@ -96,7 +140,7 @@ def test_pnp_degenerate_and_unsupported():
         f, pw, _, _ = pnp_scene()
         _same(c.pnp(f[:5], pw[:5], pp), O.pnp(f[:5], pw[:5], focal, p.tracker, pp))   # below the sample size
         _same(c.pnp(f[:6], pw[:6], pp), O.pnp(f[:6], pw[:6], focal, p.tracker, pp))   # exactly the sample size
-        for alg in (abi.PNP_KNEIP_P2P, abi.PNP_KNEIP_P3P, abi.PNP_GAO_P3P, abi.PNP_UPNP, abi.PNP_UP3P,
+        for alg in (abi.PNP_KNEIP_P2P, abi.PNP_GAO_P3P, abi.PNP_UPNP, abi.PNP_UP3P,
                     abi.PNP_NONLINEAR, abi.PNP_MLPNP):
             pp.pnp_algorithm = alg
             with pytest.raises(F.KvfeError) as e:
