@@ -565,7 +565,77 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   unsigned long long* akeys = skeys;
   const int md = P.min_distance;
   bool sorted_accepted = false, corners_written = false;
-  if (bitmap_cfg && C2 > 0 && C2 <= LDS_SORT_CAP) {
+  // bin of the radix-rank sort = monotone non-increasing function of the key: the value's float bits relative to the
+  // threshold's, scaled so that [threshold, maximum] spans the bins; bin 0 holds the largest values
+  const unsigned lo_bits = __float_as_uint(fmaxf(thr, 0.0f));
+  const unsigned hi_bits = max(__float_as_uint(maxVal), lo_bits + 1u);
+  int shift = 0;
+  while (((hi_bits - lo_bits) >> shift) >= (unsigned)SEL_RADIX_BINS) shift++;
+  auto bin_of = [&](unsigned long long key) -> int {
+    const unsigned vb = (unsigned)(key >> 32);
+    const unsigned d = vb > lo_bits ? vb - lo_bits : 0u;
+    return max(SEL_RADIX_BINS - 1 - (int)min(d >> shift, (unsigned)(SEL_RADIX_BINS - 1)), 0);
+  };
+  // More candidates than the LDS list holds (1280x720 keyframes reach 15 k): TWO passes.  The histogram of all keys
+  // gives the largest prefix of bins with at most LDS_SORT_CAP keys; those are ranked and filtered first -- every key
+  // of a later bin ranks below all of them --, then the remaining keys are tested against the bitmap in parallel and
+  // only the survivors (a few hundred: the image is covered by then) are ranked and walked, continuing the same
+  // accepted list.  NL = keys of the first pass, cut_bin = first bin of the second.
+  int NL = C2, cut_bin = SEL_RADIX_BINS;
+  bool two_pass = false;
+  if (bitmap_cfg && C2 > LDS_SORT_CAP) {
+    int* hist = cell_start;
+    for (int i = tid; i < SEL_RADIX_BINS; i += SEL_T) hist[i] = 0;
+    if (tid == 0) {
+      sh_n = 0;
+      sh_flag = SEL_RADIX_BINS;
+    }
+    __syncthreads();
+    for (int i = tid; i < C2; i += SEL_T) atomicAdd(&hist[bin_of(work[i])], 1);
+    __syncthreads();
+    {
+      constexpr int PER = SEL_RADIX_BINS / SEL_T;
+      int c[PER], sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        c[q] = hist[tid * PER + q];
+        sum += c[q];
+      }
+      int run = block_exclusive_scan(sum, wave_tot, nullptr);
+#pragma unroll
+      for (int q = 0; q < PER; q++) {   // first bin whose end passes the capacity
+        if (run <= LDS_SORT_CAP && run + c[q] > LDS_SORT_CAP) {
+          sh_flag = tid * PER + q;
+          sh_n = run;
+        }
+        run += c[q];
+      }
+    }
+    __syncthreads();
+    cut_bin = sh_flag;
+    NL = sh_n;
+    __syncthreads();
+    if (NL > 0) {   // (NL == 0: more than LDS_SORT_CAP keys in the very first bin -> the generic path below)
+      two_pass = true;
+      if (tid == 0) sh_cnt = 0;
+      __syncthreads();
+      for (int base = 0; base < C2; base += SEL_T) {   // the first pass's keys, unordered, into the LDS list
+        const int i = base + tid;
+        unsigned long long key = 0;
+        const bool keep = i < C2 && bin_of(key = work[i]) < cut_bin;
+        const unsigned long long km = __ballot(keep);
+        if (km) {
+          const int lane = tid & 63;
+          int wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&sh_cnt, __popcll(km));
+          wbase = __builtin_amdgcn_readfirstlane(wbase);
+          if (keep) skeys[wbase + __popcll(km & ((1ull << lane) - 1ull))] = key;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (bitmap_cfg && C2 > 0 && (C2 <= LDS_SORT_CAP || two_pass)) {
     // ---- cv::goodFeaturesToTrack's greedy minimum-distance filter, in its own (sequential) order ----
     // 1. the candidates are RANKED by (value, index) descending: radix-rank sort -- histogram over the top bits of the
     //    value, prefix sum, grouping by bin, then every key counts the larger keys of its own bin (two or three on real
@@ -583,33 +653,22 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
       const unsigned y = idx / (unsigned)W;
       return (idx - y * (unsigned)W) | (y << 16);
     };
-    if (C2 <= 256) {
+    if (NL <= 256) {
       // short list: rank = number of larger keys
-      for (int i = tid; i < C2; i += SEL_T) {
+      for (int i = tid; i < NL; i += SEL_T) {
         const unsigned long long k = skeys[i];
         int rank = 0;
-        for (int q = 0; q < C2; q++) rank += skeys[q] > k ? 1 : 0;
+        for (int q = 0; q < NL; q++) rank += skeys[q] > k ? 1 : 0;
         xy[rank] = pack_xy(k);
       }
     } else {
       int* hist = cell_start;                        // [SEL_RADIX_BINS]
       int* start = hist + SEL_RADIX_BINS;            // [SEL_RADIX_BINS]
       unsigned short* tmpidx = reinterpret_cast<unsigned short*>(start + SEL_RADIX_BINS);  // [LDS_SORT_CAP]
-      // bin = monotone non-increasing function of the key: the value's float bits relative to the threshold's,
-      // scaled so that [threshold, maximum] spans the bins; bin 0 holds the largest values
-      const unsigned lo_bits = __float_as_uint(fmaxf(thr, 0.0f));
-      const unsigned hi_bits = max(__float_as_uint(maxVal), lo_bits + 1u);
-      int shift = 0;
-      while (((hi_bits - lo_bits) >> shift) >= (unsigned)SEL_RADIX_BINS) shift++;
-      auto bin_of = [&](unsigned long long key) -> int {
-        const unsigned vb = (unsigned)(key >> 32);
-        const unsigned d = vb > lo_bits ? vb - lo_bits : 0u;
-        return max(SEL_RADIX_BINS - 1 - (int)min(d >> shift, (unsigned)(SEL_RADIX_BINS - 1)), 0);
-      };
       for (int i = tid; i < SEL_RADIX_BINS; i += SEL_T) hist[i] = 0;
       if (tid == 0) sh_flag = 0;
       __syncthreads();
-      for (int i = tid; i < C2; i += SEL_T) atomicAdd(&hist[bin_of(skeys[i])], 1);
+      for (int i = tid; i < NL; i += SEL_T) atomicAdd(&hist[bin_of(skeys[i])], 1);
       __syncthreads();
       {
         constexpr int PER = SEL_RADIX_BINS / SEL_T;
@@ -632,12 +691,12 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
       }
       __syncthreads();
       if (sh_flag == 0) {
-        for (int i = tid; i < C2; i += SEL_T) {
+        for (int i = tid; i < NL; i += SEL_T) {
           const int pos = atomicAdd(&hist[bin_of(skeys[i])], 1);
           tmpidx[pos] = (unsigned short)i;
         }
         __syncthreads();
-        for (int p0 = tid; p0 < C2; p0 += SEL_T) {
+        for (int p0 = tid; p0 < NL; p0 += SEL_T) {
           const unsigned long long k = skeys[tmpidx[p0]];
           const int b = bin_of(k);
           const int b0 = start[b], b1 = hist[b];  // the cursor ended at the bin's end
@@ -652,14 +711,14 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
 #pragma unroll
         for (int m = 0; m < EPT; m++) {
           const int i = tid + m * SEL_T;
-          v[m] = i < C2 ? skeys[i] : 0ull;
+          v[m] = i < NL ? skeys[i] : 0ull;
         }
         __syncthreads();
         blocksort::sort_desc_blocked<EPT>(v, skeys);
 #pragma unroll
         for (int m = 0; m < EPT; m++) {
           const int r = EPT * tid + m;
-          if (r < C2) xy[r] = pack_xy(v[m]);
+          if (r < NL) xy[r] = pack_xy(v[m]);
         }
       }
     }
@@ -668,6 +727,8 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     for (int i = tid; i < H * rw; i += SEL_T) bm[i] = 0ull;
     __syncthreads();
     SEL_STAMP(2);
+    // the in-order filter over the ranked list positions [lb, le), continuing an accepted list of acc0 entries
+    auto greedy = [&](const int lb, const int le, const int acc0) {
     if (tid < 64) {
       const int lane = tid;
       const int md2i = md * md;
@@ -685,7 +746,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
         }
         hw[p] = h;
       }
-      int acc = 0;
+      int acc = acc0;
       bool done = false;
       if (md <= 32) {
         // one pass of rows (2 md - 1 <= 63) and a span of at most 63 bits = two words, all straight-line: the wave
@@ -700,14 +761,14 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
         auto word_of = [&](unsigned c) -> const unsigned long long* {
           return &bm[(int)(c >> 16) * rw + (int)((c & 0xffffu) >> 6)];
         };
-        unsigned v = lane < C2 ? xy[lane] : 0u;
-        unsigned vn = 64 + lane < C2 ? xy[64 + lane] : 0u;
+        unsigned v = lb + lane < le ? xy[lb + lane] : 0u;
+        unsigned vn = lb + 64 + lane < le ? xy[lb + 64 + lane] : 0u;
         unsigned long long wbits = *word_of(v);
-        for (int base = 0; base < C2 && !done; base += 64) {
+        for (int base = lb; base < le && !done; base += 64) {
           unsigned long long wn = *word_of(vn);
           const int nnb = base + 128 + lane;
-          const unsigned vnn = nnb < C2 ? xy[nnb] : 0u;
-          const bool valid = base + lane < C2;
+          const unsigned vnn = nnb < le ? xy[nnb] : 0u;
+          const bool valid = base + lane < le;
           const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
           const bool ok = valid && !((wbits >> (x & 63)) & 1ull);
           unsigned long long mask = __ballot(ok);
@@ -756,9 +817,9 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
           kvfe_select_stamps[9] = t_res;
         }
       } else {
-      for (int base = 0; base < C2 && !done; base += 64) {
+      for (int base = lb; base < le && !done; base += 64) {
         const int i = base + lane;
-        const bool valid = i < C2;
+        const bool valid = i < le;
         const unsigned v = valid ? xy[i] : 0u;
         const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
         const unsigned long long wbits = bm[y * rw + (x >> 6)];
@@ -796,10 +857,60 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
         __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the next batch's lookups follow the marks (LDS is in order)
       }
       }
-      if (lane == 0) sh_cnt = acc;
+      if (lane == 0) {
+        sh_cnt = acc;
+        sh_flag = done ? 1 : 0;
+      }
     }
     __syncthreads();
+    };
+    greedy(0, NL, 0);
     A = sh_cnt;
+    if (two_pass && !sh_flag) {
+      // second pass: the keys of the bins from cut_bin on that the bitmap has not blocked yet
+      unsigned long long* surv = cand;   // (the raw candidate list is dead since the compaction)
+      const int acc1 = A;
+      __syncthreads();
+      if (tid == 0) sh_n = 0;
+      __syncthreads();
+      for (int base = 0; base < C2; base += SEL_T) {
+        const int i = base + tid;
+        unsigned long long key = 0;
+        bool keep = false;
+        if (i < C2) {
+          key = work[i];
+          if (bin_of(key) >= cut_bin) {
+            const unsigned c = pack_xy(key);
+            const unsigned long long wb = bm[(int)(c >> 16) * rw + (int)((c & 0xffffu) >> 6)];
+            keep = !((wb >> (c & 63u)) & 1ull);
+          }
+        }
+        const unsigned long long km = __ballot(keep);
+        if (km) {
+          const int lane = tid & 63;
+          int wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&sh_n, __popcll(km));
+          wbase = __builtin_amdgcn_readfirstlane(wbase);
+          if (keep) surv[wbase + __popcll(km & ((1ull << lane) - 1ull))] = key;
+        }
+      }
+      __syncthreads();
+      int n2 = sh_n;
+      if (acc1 + n2 > LDS_SORT_CAP) {   // (cannot rank more than the list holds: flagged, not silently dropped)
+        n2 = LDS_SORT_CAP - acc1;
+        overflow = 1;
+      }
+      // rank = number of larger survivors (a few hundred keys, read through L2)
+      for (int i = tid; i < n2; i += SEL_T) {
+        const unsigned long long k = surv[i];
+        int rank = 0;
+        for (int q = 0; q < n2; q++) rank += surv[q] > k ? 1 : 0;
+        xy[acc1 + rank] = pack_xy(k);
+      }
+      __syncthreads();
+      greedy(acc1, acc1 + n2, acc1);
+      A = sh_cnt;
+    }
     // corners are written from the packed list (the u64 key area is gone)
     {
       int nc = A;

@@ -854,6 +854,33 @@ def test_feature_detection_small_min_distance(seq):
             c.close()
 
 
+def test_feature_detection_more_candidates_than_the_lds_list():
+    """band-limited noise at 1280x720 and 752x480: 10-25 k local maxima above the quality threshold, more than the
+    8192 keys the select kernel ranks in LDS -> its two-pass path (top bins first, then the survivors of the bitmap);
+    raw GFTT output (order included), the ANMS selection and the refined corners equal the CPU path.  With
+    min_distance 3 the second pass still accepts corners; with a smooth image the one-pass path runs as control."""
+    from scipy import ndimage as ndi
+    from kimera_vio_amd import workloads as WL
+    rng = np.random.default_rng(77)
+    none = np.zeros((0, 2), np.float32)
+    for (w, h, sigma, md) in ((1280, 720, 1.2, 20), (1280, 720, 1.0, 3), (752, 480, 0.9, 8), (1280, 720, 3.0, 20)):
+        img = ndi.gaussian_filter(rng.normal(size=(h, w)), sigma)
+        img = np.clip(128 + img / img.std() * 45, 0, 255).astype(np.uint8)
+        L, R = WL.make_cameras(w, h)
+        p = euroc_params(min_distance=md, quality_level=0.0005, max_features_per_frame=800)
+        p.detector.max_nr_keypoints_before_anms = 6000
+        c = F.Context(L, R, p)
+        try:
+            raw = c.raw_feature_detection(img)
+            exp_raw, _ = O.good_features_to_track(img, 6000, 0.0005, md, 3)
+            assert len(exp_raw) > 300 and np.array_equal(raw, exp_raw), (w, h, sigma, md, len(raw), len(exp_raw))
+            got = c.feature_detection(img, none, 800)
+            exp, _ = O.feature_detection(img, none, 800, p.detector)
+            assert np.array_equal(got, exp), (w, h, sigma, md)
+        finally:
+            c.close()
+
+
 def test_frontend_sequence_class_default_anms(seq, ocam):
     """FeatureDetectorParams' class default is RangeTree (FeatureDetectorParams.h): the front-end with
     it, outlier rejection on, identical to the oracle over the clip."""
