@@ -124,7 +124,7 @@ def load_pmc():
 
 # kernel behind every dense (image-sized) stage: (rocprof kernel name, launches per step)
 PMC_NAMES = {"pyramid": ("pyrdown", 2), "mineig_localmax": ("mineig_localmax_kernel", 1),
-             "rectify": ("rectify_kernel", 1)}
+             "rectify": ("rectify_", 1)}
 
 
 def pmc_traffic(pmc_leg, stage):
