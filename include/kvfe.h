@@ -609,8 +609,10 @@ typedef struct kvfe_frame_input {
  * the geometric outlier rejection of keyframes when useRANSAC = 1
  * (VisionImuFrontend.cpp:90-144).  left/right: `batch` images back to back (image s at
  * base + s*image_stride_bytes).  The *_host variant copies from host memory;
- * the *_device variant takes device pointers that must stay valid until the
- * next step of this context has completed.  Both only enqueue work.
+ * the *_device variant takes device pointers that are read by THIS step only (they
+ * must stay valid until it has completed -- kvfe_synchronize / kvfe_frontend_get_output --,
+ * as for any asynchronous call; the left image the next step's tracking needs is copied
+ * into the context).  Both only enqueue work.
  * RGBD front-end (RgbdVisionImuFrontend::processFirstFrame / processFrame,
  * RgbdVisionImuFrontend.cpp:184-368): `right` holds the depth images (uint16 or float per
  * kvfe_depth_params::depth_type) with the same geometry in ELEMENTS: row s starts at

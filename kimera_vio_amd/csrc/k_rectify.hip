@@ -528,11 +528,16 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
 constexpr int PT_W = 64, PT_H = 8;
 constexpr int PS_W = 2 * PT_W + 3, PS_H = 2 * PT_H + 3;
 
+// COPY: the block also writes the 128 x 16 source pixels its tile covers into a dense copy of the source level (the
+// context's own level 0 of this frame: next step's LK reads it, so the caller's image pointer is not kept past the step)
+template <bool COPY>
 __global__ __launch_bounds__(256) void pyrdown_kernel(const unsigned char* __restrict__ src,
                                                       size_t src_row_stride,
                                                       size_t src_img_stride, int sw, int sh,
                                                       unsigned char* __restrict__ dst,
-                                                      size_t dst_img_stride, int dw, int dh) {
+                                                      size_t dst_img_stride, int dw, int dh,
+                                                      unsigned char* __restrict__ copy_dst,
+                                                      size_t copy_img_stride) {
   __shared__ unsigned char tile[PS_H][PS_W + 1];
   __shared__ int hrow[PS_H][PT_W];
   const int s = blockIdx.z;
@@ -546,6 +551,22 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const unsigned char* __res
     tile[ty][tx] = S[(size_t)gy * src_row_stride + gx];
   }
   __syncthreads();
+  if (COPY) {
+    unsigned char* C = copy_dst + (size_t)s * copy_img_stride;
+    for (int i = threadIdx.x; i < 2 * PT_H * (2 * PT_W / 4); i += 256) {   // 16 rows x 32 dwords
+      const int ry = i / (2 * PT_W / 4), q = i - ry * (2 * PT_W / 4);
+      const int gy = 2 * oy + ry, gx = 2 * ox + 4 * q;
+      if (gy < sh && gx < sw) {
+        const unsigned char* r = &tile[ry + 2][4 * q + 2];
+        unsigned char* o = C + (size_t)gy * sw + gx;
+        if (gx + 3 < sw && ((sw & 3) == 0)) {
+          *reinterpret_cast<unsigned*>(o) = (unsigned)r[0] | ((unsigned)r[1] << 8) | ((unsigned)r[2] << 16) | ((unsigned)r[3] << 24);
+        } else {
+          for (int k = 0; k < 4 && gx + k < sw; k++) o[k] = r[k];
+        }
+      }
+    }
+  }
   for (int i = threadIdx.x; i < PS_H * PT_W; i += 256) {
     const int ty = i / PT_W, x = i - ty * PT_W;
     const unsigned char* r = &tile[ty][2 * x];
@@ -564,14 +585,23 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const unsigned char* __res
 }
 
 void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
-                    size_t img_stride, unsigned char* pyr, hipStream_t st) {
+                    size_t img_stride, unsigned char* pyr, hipStream_t st, unsigned char* level0_copy) {
+  if (level0_copy && P.nlevels < 2)   // (klt_max_level 0: no level-1 launch to piggyback on)
+    for (int s = 0; s < P.B; s++)
+      (void)hipMemcpy2DAsync(level0_copy + (size_t)s * P.W * P.H, (size_t)P.W, img + (size_t)s * img_stride, row_stride,
+                             (size_t)P.W, (size_t)P.H, hipMemcpyDeviceToDevice, st);
   for (int l = 1; l < P.nlevels; l++) {
     const unsigned char* src = l == 1 ? img : pyr + P.loff[l - 1];
     const size_t srow = l == 1 ? row_stride : (size_t)P.lw[l - 1];
     const size_t simg = l == 1 ? img_stride : (size_t)P.pyr_stride;
     dim3 grid((P.lw[l] + PT_W - 1) / PT_W, (P.lh[l] + PT_H - 1) / PT_H, P.B);
-    hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, st, src, srow, simg, P.lw[l - 1],
-                       P.lh[l - 1], pyr + P.loff[l], (size_t)P.pyr_stride, P.lw[l], P.lh[l]);
+    if (l == 1 && level0_copy)
+      hipLaunchKernelGGL(pyrdown_kernel<true>, grid, dim3(256), 0, st, src, srow, simg, P.lw[l - 1], P.lh[l - 1],
+                         pyr + P.loff[l], (size_t)P.pyr_stride, P.lw[l], P.lh[l], level0_copy,
+                         (size_t)P.W * P.H);
+    else
+      hipLaunchKernelGGL(pyrdown_kernel<false>, grid, dim3(256), 0, st, src, srow, simg, P.lw[l - 1], P.lh[l - 1],
+                         pyr + P.loff[l], (size_t)P.pyr_stride, P.lw[l], P.lh[l], (unsigned char*)nullptr, (size_t)0);
   }
 }
 

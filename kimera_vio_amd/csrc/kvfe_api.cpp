@@ -46,6 +46,7 @@ const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "
                                      "ransac_stereo"};
 
 struct Buffers {  // everything that scales with the number of streams
+  unsigned char* lvl0[2] = {nullptr, nullptr};  // [B][H][W] own copy of the left image per pyramid slot (device-pointer steps)
   int B = 0;
   unsigned char* rect[2] = {nullptr, nullptr};
   unsigned char* pyr[2] = {nullptr, nullptr};
@@ -89,6 +90,7 @@ struct kvfe_ctx {
   bool comp_ready = false;
   int role_k = 0, role_km1 = 1, role_lkf = 2;
   int pyr_cur = 0;
+  bool own_level0 = false;   // this step's left image is copied into fe.lvl0 for the next step's LK
   const unsigned char* prev_left = nullptr;
   size_t prev_row_stride = 0, prev_img_stride = 0;
   int raw_slot = 0;
@@ -779,7 +781,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   hipStream_t sd = c->side ? c->side : st;
 
   prof_begin(c, ST_PYRAMID, st);
-  launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st);
+  launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st, c->own_level0 ? b.lvl0[pc] : nullptr);
   prof_end(c, ST_PYRAMID, st);
   prof_begin(c, ST_TRACK, st);
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
@@ -834,9 +836,9 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipGetLastError());
     std::swap(c->role_k, c->role_km1);
     c->pyr_cur ^= 1;
-    c->prev_left = left;
-    c->prev_row_stride = row_stride;
-    c->prev_img_stride = img_stride;
+    c->prev_left = c->own_level0 ? b.lvl0[pc] : left;
+    c->prev_row_stride = c->own_level0 ? (size_t)P.W : row_stride;
+    c->prev_img_stride = c->own_level0 ? (size_t)P.W * P.H : img_stride;
     return KVFE_OK;
   }
   // fork: cornerSubPix + append of the new corners (side stream: few waves, latency bound) ||
@@ -876,9 +878,9 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // stereoFrame_km1_ = stereoFrame_k_
   std::swap(c->role_k, c->role_km1);
   c->pyr_cur ^= 1;
-  c->prev_left = left;
-  c->prev_row_stride = row_stride;
-  c->prev_img_stride = img_stride;
+  c->prev_left = c->own_level0 ? b.lvl0[pc] : left;
+  c->prev_row_stride = c->own_level0 ? (size_t)P.W : row_stride;
+  c->prev_img_stride = c->own_level0 ? (size_t)P.W * P.H : img_stride;
   return KVFE_OK;
 }
 
@@ -1867,8 +1869,19 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
     return do_step(c, dl, dr, P.W, N, inputs);
   }
   c->last_step_staged = false;
-  return do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
-                 reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
+  // the caller's buffers are only read by THIS step: the left image the next step's LK needs is copied into the
+  // context (by the first pyramid launch, which reads it anyway)
+  {
+    Buffers& b = c->fe;
+    const size_t bytes = (size_t)c->P.W * c->P.H * c->P.B;
+    for (int i = 0; i < 2; i++)
+      if (!b.lvl0[i]) TRY(dalloc(c, &b.lvl0[i], bytes, false));
+  }
+  c->own_level0 = true;
+  const kvfe_status st = do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
+                                 reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
+  c->own_level0 = false;
+  return st;
 }
 
 kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint8_t* right,

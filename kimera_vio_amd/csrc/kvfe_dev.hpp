@@ -238,7 +238,8 @@ void launch_equalize_hist(int W, int H, int B, const unsigned char* src, size_t 
                           size_t src_img_stride, unsigned char* dst, int* hist, hipStream_t st);
 // K4a: pyramid levels 1..nlevels-1 of `img` into pyr.
 void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
-                    size_t img_stride, unsigned char* pyr, hipStream_t st);
+                    size_t img_stride, unsigned char* pyr, hipStream_t st,
+                    unsigned char* level0_copy = nullptr);
 // K4c: pyramidal LK for npts[s] points per stream.
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,

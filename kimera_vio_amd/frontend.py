@@ -437,8 +437,8 @@ class Context:
                                                    self.w, self.w * self.h, inputs), "frontend_step_host")
 
     def step_device(self, left_ptr: int, right_ptr: int, inputs, row_stride=None, image_stride=None):
-        """left_ptr/right_ptr: device pointers to `batch` images; they must stay valid until the next
-        step of this context has completed."""
+        """left_ptr/right_ptr: device pointers to `batch` images, read by this step only (valid until it has
+        completed); no caller pointer is kept past the call."""
         self._chk(self.lib.kvfe_frontend_step_device(self._h, C.c_void_p(left_ptr), C.c_void_p(right_ptr),
                                                      row_stride or self.w,
                                                      image_stride or self.w * self.h, inputs),

@@ -1274,7 +1274,10 @@ def test_frontend_device_input_path_matches_oracle(seq, ocam):
     pitch = w + 16
     fe = [O.Frontend(L, R, p) for _ in range(B)]
     c = F.Context(L, R, p, batch=B)
-    keep = []   # device buffers must outlive the next step
+    # the device buffers are read by their own step only (kvfe.h): ONE pair of buffers is reused for every frame and
+    # scribbled over as soon as the step's output has been fetched (no pointer retained past a call)
+    dl = torch.zeros((B, h, pitch), dtype=torch.uint8, device=dev)
+    dr = torch.zeros((B, h, pitch), dtype=torch.uint8, device=dev)
     try:
         kf = [0] * B
         for i in range(7):
@@ -1286,10 +1289,15 @@ def test_frontend_device_input_path_matches_oracle(seq, ocam):
             for s in range(B):
                 hl[s, :, :w] = seq["lefts"][idx[s]]
                 hr[s, :, :w] = seq["rights"][idx[s]]
-            dl, dr = torch.from_numpy(hl).to(dev), torch.from_numpy(hr).to(dev)
-            keep = keep[-2:] + [(dl, dr)]
+            dl.copy_(torch.from_numpy(hl))
+            dr.copy_(torch.from_numpy(hr))
+            torch.cuda.synchronize()
             c.step_device(dl.data_ptr(), dr.data_ptr(), c.make_inputs(ts, Rs, [0] * B), row_stride=pitch,
                           image_stride=h * pitch)
+            c.synchronize()
+            dl.fill_(0x5a)
+            dr.fill_(0xa5)
+            torch.cuda.synchronize()
             for s in range(B):
                 exp = fe[s].process(seq["lefts"][idx[s]], seq["rights"][idx[s]], ts[s], Rs[s], False)
                 got = c.get_output(s)
@@ -1317,10 +1325,13 @@ def test_frontend_device_input_path_matches_oracle(seq, ocam):
             depth = _synthetic_depth(h, w, i, abi.DEPTH_U16, seed=i)
             dl = torch.from_numpy(np.ascontiguousarray(seq["lefts"][i])[None]).to(dev)
             dd = torch.from_numpy(depth.view(np.int16)[None].copy()).to(dev)
-            keep = keep[-2:] + [(dl, dd)]
             Rk = camR[kf0].T @ camR[i]
             ts = int(seq["ts"][i])
             c.step_device(dl.data_ptr(), dd.data_ptr(), c.make_inputs([ts], [Rk], [0]))
+            c.synchronize()
+            dl.fill_(0x33)     # (the buffers belong to the caller again once the step has completed)
+            dd.fill_(0)
+            torch.cuda.synchronize()
             exp = fe.process(seq["lefts"][i], depth, ts, Rk, False)
             got = c.get_output(0)
             for k in ("n_keypoints", "is_keyframe", "n_measurements", "tracking_status_stereo"):
