@@ -122,6 +122,27 @@ def load_pmc():
         return {}
 
 
+def load_valu():
+    """{kernel: {SQ_INSTS_VALU: wave-instructions per launch, ...}} of the committed SQ pass of the c3 leg
+    (tools/save_profiles_r2.sh -> profiles/pmc_valu_latest.json)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_valu_latest.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def valu_issue(valu, prefix, launch_ms, n_cu, clock_ghz):
+    """what the kernel's own instruction count allows: a wave64 VALU instruction occupies one of the CU's four
+    16-lane SIMDs for 4 cycles, so `insts x 4 / (4 n_cu)` cycles is the floor of a launch; frac = floor / measured"""
+    insts = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in valu.items() if k.startswith(prefix))
+    if not insts or launch_ms <= 0:
+        return None
+    floor_ms = insts * 4.0 / (4.0 * n_cu) / (clock_ghz * 1e6)
+    return {"wave_insts_per_launch": round(insts), "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / launch_ms, 4),
+            "note": "SQ_INSTS_VALU of the committed c3 PMC pass x 4 cycles / (4 SIMDs x CUs) at the peak engine clock"}
+
+
 # kernel behind every dense (image-sized) stage: (rocprof kernel name, launches per step)
 PMC_NAMES = {"pyramid": ("pyrdown", 2), "mineig_localmax": ("mineig_localmax_kernel", 1),
              "rectify": ("rectify_", 1)}
@@ -144,6 +165,9 @@ def pmc_traffic(pmc_leg, stage):
     if not hit:
         return None
     return round(tot)
+
+
+valu_ctx = None   # (per-kernel SQ counters, number of CUs, peak engine clock in GHz), set by main()
 
 
 def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, repeats, groups, stage_stride,
@@ -228,10 +252,20 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
                                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
                                 "traffic": pmc_traffic(pmc_leg, name),
                                 "alg_bytes_per_launch": v["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)})
+                if pmc_leg is not None and valu_ctx and name in PMC_NAMES and B == 64 and W == 752:
+                    vi = valu_issue(valu_ctx[0], PMC_NAMES[name][0], avg_ms / PMC_NAMES[name][1], valu_ctx[1], valu_ctx[2])
+                    if vi:
+                        kernels[-1]["valu_issue"] = vi
         kernels.sort(key=lambda r: -r["avg_launch_ms"])
         res["roofline"] = dict(kernels[0]) if kernels else None
         res["roofline_kernels"] = kernels
         res["stage_ms_per_step_summed_over_groups"] = {k: round(v["ms_total"] / ns * g, 5) for k, v in stages.items()}
+        if pmc_leg is not None and valu_ctx and B == 64 and W == 752 and "lk_track" in stages:
+            lk_ms = stages["lk_track"]["ms_total"] / ns
+            vi = valu_issue(valu_ctx[0], "lk_kernel", lk_ms, valu_ctx[1], valu_ctx[2])
+            if vi:   # the largest kernel of the step is sparse (no HBM roofline): its bound is VALU issue
+                res["largest_kernel"] = {"kernel": "lk_track", "avg_launch_ms": round(lk_ms, 5), "bound": "valu issue",
+                                         "valu_issue": vi}
         res["stream_groups"] = g
     return res
 
@@ -258,6 +292,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     pmc = load_pmc()
+    global valu_ctx
+    props = torch.cuda.get_device_properties(dev)
+    valu_ctx = (load_valu(), int(props.multi_processor_count), float(getattr(props, "clock_rate", 2400000)) / 1e6)
 
     kw = dict(use_ransac=args.ransac, mono_2point=args.mono_2point, stereo_1point=args.stereo_1point,
               batch=args.batch, features=args.features, klt_max_level=args.klt_max_level,

@@ -8,7 +8,7 @@ import sys
 def main():
     agg = {}
     names = []
-    for db in sys.argv[1:]:
+    for db in [a for a in sys.argv[1:] if not a.startswith("--")]:
         c = sqlite3.connect(db)
         q = ("select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection "
              "group by 1, 2")
@@ -20,6 +20,11 @@ def main():
             a.setdefault("_dur_us", d / n / 1e3)
             if cn not in names:
                 names.append(cn)
+    if "--json" in sys.argv:   # {kernel: {counter: mean per launch}} for bench.py (profiles/pmc_valu_latest.json)
+        import json
+        print(json.dumps({k: {n: a[n] for n in names if n in a} for k, a in agg.items() if not k.startswith("__amd")},
+                         indent=1, sort_keys=True))
+        return
     print("| kernel | launches | avg us | " + " | ".join(names) + " |")
     print("|---|---:|---:|" + "---:|" * len(names))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1].get("_dur_us", 0) * kv[1]["_n"]):

@@ -23,5 +23,6 @@ if [ -f gpurun_out/prof_sq/s_results.db ]; then
 { echo "# rocprofv3 --pmc SQ passes, bench.py c3 leg alone (SQ_* cycle counters are quad-cycles summed over all SIMDs/XCDs)"; echo;
   python tools/rocpd_pmc.py gpurun_out/prof_sq/s_results.db; echo;
   python tools/rocpd_pmc.py gpurun_out/prof_sq2/s2_results.db 2>/dev/null || true; } > profiles/${T}_pmc_sq.md
+python tools/rocpd_pmc.py --json gpurun_out/prof_sq/s_results.db > profiles/pmc_valu_latest.json
 fi
 ls -la profiles/${T}_*
