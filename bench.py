@@ -332,7 +332,7 @@ def main():
                    "parallelism": f"streams x{world}"},
         "value_is": f"median of {args.repeats} timed regions of exactly {args.steps} steps each",
     }
-    for k in ("repeats", "roofline", "roofline_kernels", "end_to_end_traffic",
+    for k in ("repeats", "roofline", "roofline_kernels", "largest_kernel", "end_to_end_traffic",
               "stage_ms_per_step_summed_over_groups", "host_enqueue_ms_per_step", "check"):
         if k in main_leg:
             result[k] = main_leg[k]
