@@ -17,6 +17,7 @@
 // stream, generated once on the host (Tables::ransac_rnd).
 #include "kvfe_dev.hpp"
 
+#include <algorithm>
 #include <climits>
 
 namespace kvfe {
@@ -1964,6 +1965,19 @@ void launch_ransac_3d3d_arun_points(const KParams& P, const Tables& T, const dou
                                     hipStream_t st) {
   hipLaunchKernelGGL(ransac_3d3d_arun_points_kernel, dim3(1), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, p1, p2,
                      n, RS, out_status, out_pose, out_counts);
+}
+
+int ransac_max_kcap(bool nister) {
+  int budget = lds_dynamic_budget(reinterpret_cast<const void*>(mono_ransac_kernel<false>));
+  if (nister) budget = std::min(budget, lds_dynamic_budget(reinterpret_cast<const void*>(mono_ransac_kernel<true>)));
+  const void* others[] = {reinterpret_cast<const void*>(stereo_ransac_prepare_kernel),
+                          reinterpret_cast<const void*>(stereo_arun_kernel),
+                          reinterpret_cast<const void*>(ransac_2d2d_points_kernel),
+                          reinterpret_cast<const void*>(ransac_3d3d_arun_points_kernel)};
+  for (const void* k : others) budget = std::min(budget, lds_dynamic_budget(k));
+  if (nister)
+    budget = std::min(budget, lds_dynamic_budget(reinterpret_cast<const void*>(ransac_2d2d_nister_points_kernel)));
+  return (int)((budget - 16) / (sizeof(long long) + 3 * sizeof(int)));
 }
 
 #include "k_pnp.inl"

@@ -1456,6 +1456,11 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
   }
 }
 
+int track_max_kcap() {
+  const int budget = lds_dynamic_budget(reinterpret_cast<const void*>(track_finalize_kernel));
+  return budget / (int)(sizeof(long long) + sizeof(float) + sizeof(int));
+}
+
 void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
                            const FrameTab& lkf, const FrameTab& k, const StreamState& S,
                            const LkScratch& lk, hipStream_t st) {

@@ -572,6 +572,19 @@ kvfe_status fill_params(kvfe_ctx* c) {
   const size_t N = (size_t)P.W * P.H;
   P.ccap = cfg.candidate_capacity > 0 ? cfg.candidate_capacity : (int)std::max<size_t>(N / 4, 4096);
   P.kcap = P.max_features + P.max_corners + 64;
+  {
+    // the per-stream bookkeeping and outlier-rejection kernels keep one frame's keypoint ids / indices in LDS: refuse a
+    // capacity they cannot hold (and raise their dynamic-LDS opt-in limit on this device) instead of failing at launch
+    int limit = track_max_kcap();
+    if (c->cfg.params.use_ransac || true)   // (the component-level RANSAC calls use the same capacity)
+      limit = std::min(limit, ransac_max_kcap(c->cfg.params.tracker.ransac_use_2point_mono == 0));
+    if (P.kcap > limit) {
+      c->last_error = "max_features_per_frame + max_nr_keypoints_before_anms + 64 = " + std::to_string(P.kcap) +
+                      " keypoints per frame exceed the " + std::to_string(limit) +
+                      " the tracking / outlier-rejection kernels hold in LDS";
+      return KVFE_ERR_UNSUPPORTED;
+    }
+  }
   c->pts_bound = P.kcap;
   // (TopN / Binning never return more than need (+ one per bin); the radius-search variants can
   // return any number of corners when their binary search fails, so only kcap bounds them)

@@ -314,6 +314,20 @@ void launch_ransac_3d3d_points(const KParams& P, const Tables& T, const float* r
 void launch_ransac_2d2d_nister_points(const KParams& P, const Tables& T, const double* f_ref, const double* f_cur,
                                       int n, const RansacScratch& RS, int* out_status, double* out_pose,
                                       int* out_counts, hipStream_t st);
+// Dynamic LDS a launch of `kernel` may request on the CURRENT device (gfx950: 160 KB per workgroup minus the kernel's
+// static LDS); raises the kernel's opt-in limit accordingly (above 64 KB a launch fails -- and aborts the HSA queue --
+// without it).  Called at kvfe_create for every kernel whose dynamic LDS scales with the per-frame keypoint capacity.
+inline int lds_dynamic_budget(const void* kernel) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, kernel) != hipSuccess) return 48 * 1024;
+  const int budget = 160 * 1024 - (int)a.sharedSizeBytes - 256;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, budget) != hipSuccess) return 64 * 1024;
+  return budget;
+}
+// largest per-frame keypoint capacity (KParams::kcap) the tracking bookkeeping / the outlier-rejection kernels can hold
+// in LDS on the current device
+int track_max_kcap();
+int ransac_max_kcap(bool nister);
 // Tracker::pnp, EPNP RANSAC over n 2D-3D correspondences (k_pnp.inl): out_counts = [n_inliers, iterations, success]
 void launch_pnp(const KParams& P, const Tables& T, int algorithm, const double* f, const double* p, int n,
                 double threshold, int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts,

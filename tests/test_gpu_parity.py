@@ -881,6 +881,30 @@ def test_feature_detection_more_candidates_than_the_lds_list():
             c.close()
 
 
+def test_large_keypoint_capacity_lds_budget(seq, ocam):
+    """max_nr_keypoints_before_anms 6000: the per-stream bookkeeping / outlier-rejection kernels need 120 KB of dynamic
+    LDS (above the 64 KB a launch gets without the opt-in: found by tools/fuzz_frontend.py as an aborted HSA queue).
+    The sequence still equals the oracle; a capacity no kernel can hold is refused at kvfe_create with
+    KVFE_ERR_UNSUPPORTED (5-point mono RANSAC: its solver slots leave less LDS)."""
+    seq = dict(seq)
+    seq["camR"] = _kf_rotations(seq["body_R"], ocam)
+    L, R = euroc_cams()
+    p = _euroc_ransac_params(max_features_per_frame=300)
+    p.detector.max_nr_keypoints_before_anms = 6000
+    fe = [O.Frontend(L, R, p)]
+    c = F.Context(L, R, p, batch=1)
+    try:
+        _run_sequence(fe, c, seq, force_kf=True, n=4)
+    finally:
+        c.close()
+    q = _euroc_ransac_params(max_features_per_frame=1000)
+    q.detector.max_nr_keypoints_before_anms = 8192
+    q.tracker.ransac_use_2point_mono = 0
+    with pytest.raises(F.KvfeError) as e:
+        F.Context(L, R, q, batch=1)
+    assert e.value.status == abi.KVFE_ERR_UNSUPPORTED
+
+
 def test_frontend_sequence_class_default_anms(seq, ocam):
     """FeatureDetectorParams' class default is RangeTree (FeatureDetectorParams.h): the front-end with
     it, outlier rejection on, identical to the oracle over the clip."""

@@ -20,8 +20,9 @@ for ci in range(n_cfg):
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=int(rng.randint(0, 2)))
     d, t, s = p.detector, p.tracker, p.stereo
     d.max_features_per_frame = int(rng.choice([40, 100, 200, 400]))
-    d.min_distance = int(rng.choice([5, 10, 20]))
-    d.quality_level = float(rng.choice([0.001, 0.01, 0.05]))
+    d.min_distance = int(rng.choice([1, 3, 5, 10, 20, 33, 50]))
+    d.quality_level = float(rng.choice([0.0002, 0.001, 0.01, 0.05]))
+    d.max_nr_keypoints_before_anms = int(rng.choice([150, 2000, 6000]))
     d.non_max_suppression_type = int(rng.choice([0, 1, 2, 3, 4, 5, 6]))
     d.enable_subpixel_corner_refinement = int(rng.randint(0, 2))
     t.klt_win_size = int(rng.choice([16, 24, 32, 21, 15]))
