@@ -1,6 +1,8 @@
-// Tracker::pnp (src/frontend/Tracker.cpp:1122-1288) for pnp_algorithm_ = EPNP:
-//   runRansac<ProblemPnP> (Tracker.h:247-296) = opengv::sac::Ransac<AbsolutePoseSacProblem(adapter, EPNP)>::computeModel
-//   sample size 6, model = absolute_pose::epnp(adapter, sample) = world_T_camera, distance = 1 - f . normalize(R^T (p - t))
+// Tracker::pnp (src/frontend/Tracker.cpp:1122-1288) for pnp_algorithm_ = EPNP (3) and KneipP3P (1):
+//   runRansac<ProblemPnP> (Tracker.h:247-296) = opengv::sac::Ransac<AbsolutePoseSacProblem(adapter, ALG)>::computeModel
+//   EPNP : sample size 6, model = absolute_pose::epnp(adapter, sample)
+//   KNEIP: sample size 4, model = the solution of absolute_pose::p3p_kneip(first three) the fourth one reprojects best
+//   model = world_T_camera, distance = 1 - f . normalize(R^T (p - t))
 // + the status rule of VisionImuFrontend::outlierRejectionPnP (VisionImuFrontend.cpp:146-173).
 //
 // (included at the end of k_ransac.hip: shares its scan / reduction helpers, rs_svd3 and the sampler table)
