@@ -188,6 +188,15 @@ typedef struct kvfe_stereo_params {
   int32_t reserved0;
 } kvfe_stereo_params;
 
+/* the PnP members of VIO::TrackerParams (VisionImuTrackerParams.h:72-76), see kvfe_pnp */
+typedef struct kvfe_pnp_params {
+  int32_t pnp_algorithm;                     /* Pose3d2dAlgorithm: 3 = EPNP, 1 = KneipP3P              */
+  int32_t min_pnp_inliers;
+  double ransac_threshold_pnp;               /* pixels                                                 */
+  int32_t optimize_2d3d_pose_from_inliers;   /* must be 0                                              */
+  int32_t reserved0;
+} kvfe_pnp_params;
+
 /* VIO::FrontendParams (include/kimera-vio/frontend/VisionImuFrontendParams.h:25-76) */
 typedef struct kvfe_frontend_params {
   kvfe_detector_params detector;
@@ -199,6 +208,12 @@ typedef struct kvfe_frontend_params {
   double max_disparity_since_lkf;
   int32_t use_stereo_tracking;
   int32_t use_ransac;                        /* useRANSAC                    */
+  int32_t use_pnp_tracking;                  /* use_pnp_tracking: Tracker::pnp on keyframes against the
+                                                landmark map of kvfe_frontend_update_map
+                                                (StereoVisionImuFrontend.cpp:389-399,
+                                                RgbdVisionImuFrontend.cpp:328-341)            */
+  int32_t reserved1;
+  kvfe_pnp_params pnp;
 } kvfe_frontend_params;
 
 /* CameraParams::DepthParams (include/kimera-vio/frontend/CameraParams.h:131-155), RGBD front-end only.
@@ -225,7 +240,7 @@ typedef struct kvfe_config {
                                     the RGBD front-end (RgbdVisionImuFrontend.cpp: `left` is the
                                     colour camera; the `right` images of the step calls are the
                                     depth images, see kvfe_frontend_step_host)                   */
-  int32_t reserved0;
+  int32_t landmark_map_capacity; /* landmarks per stream kvfe_frontend_update_map can hold (0 = 8192) */
   kvfe_depth_params depth;       /* RGBD front-end only                                          */
   int32_t stream_groups;         /* 0 = default (1).  The batch is split into this many
                                     groups of streams, each on its own HIP stream, so
@@ -511,13 +526,6 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* re
  * reserved0 = Tracker::pnp's return value; pose = F_Pose_cam 3x4 [R | t]; inliers ascending (capacity n).
  * The dense linear algebra of EPnP is a Jacobi / Householder implementation, not Eigen's: poses agree with the
  * reference to rounding; the inlier decision is pinned by the scene of tests/testTracker.cpp:1613-1800. */
-typedef struct kvfe_pnp_params {
-  int32_t pnp_algorithm;                     /* Pose3d2dAlgorithm: 3 = EPNP, 1 = KneipP3P              */
-  int32_t min_pnp_inliers;
-  double ransac_threshold_pnp;               /* pixels                                                 */
-  int32_t optimize_2d3d_pose_from_inliers;   /* must be 0                                              */
-  int32_t reserved0;
-} kvfe_pnp_params;
 KVFE_API kvfe_status kvfe_pnp(kvfe_ctx* ctx, const kvfe_pnp_params* params, const double* cam_bearing_vectors,
                               const double* F_points, int32_t n, int32_t* inliers, kvfe_ransac_output* out);
 
@@ -674,7 +682,18 @@ typedef struct kvfe_frame_output {
   /* DebugTrackerInfo (Tracker-definitions.h:78-124) */
   int32_t nr_mono_putatives, nr_mono_inliers, mono_ransac_iters;
   int32_t nr_stereo_putatives, nr_stereo_inliers, reserved0;
+  /* use_pnp_tracking: kfTracking_status_pnp_ / W_T_k_pnp_ of the last keyframe (INVALID / identity when off) */
+  int32_t tracking_status_pnp;
+  int32_t nr_pnp_inliers;
+  double W_T_k_pnp[12];
 } kvfe_frame_output;
+
+/* Tracker::updateMap (Tracker.h:82-94): the back-end's map of optimised landmarks (id -> world position) of one
+ * stream, replacing the previous one; copied into the context (ids need not be sorted; n <= landmark_map_capacity).
+ * With use_pnp_tracking the step runs Tracker::pnp(stereoFrame_k) on keyframes right after the stereo outlier
+ * rejection (same place as upstream), on the device. */
+KVFE_API kvfe_status kvfe_frontend_update_map(kvfe_ctx* ctx, int32_t stream, const int64_t* landmark_ids,
+                                              const double* xyz, int32_t n);
 
 KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,
                                               kvfe_frame_output* out);

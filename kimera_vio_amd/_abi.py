@@ -112,6 +112,22 @@ def dense_stereo_params_default() -> "DenseStereoParams":
                              reserved0=0)
 
 
+class PnpParams(C.Structure):
+    """kvfe_pnp_params (Tracker::pnp, VisionImuTrackerParams.h: pnp_algorithm_, min_pnp_inliers_, ransac_threshold_pnp_)"""
+    _fields_ = [
+        ("pnp_algorithm", C.c_int32), ("min_pnp_inliers", C.c_int32), ("ransac_threshold_pnp", C.c_double),
+        ("optimize_2d3d_pose_from_inliers", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+PNP_KNEIP_P2P, PNP_KNEIP_P3P, PNP_GAO_P3P, PNP_EPNP, PNP_UPNP, PNP_UP3P, PNP_NONLINEAR, PNP_MLPNP = range(8)
+
+
+def pnp_params_default():
+    """VisionImuTrackerParams.h defaults / params/Euroc: EPNP, 20 inliers, 1 px"""
+    return PnpParams(PNP_EPNP, 20, 1.0, 0, 0)
+
+
 class FrontendParams(C.Structure):
     _fields_ = [
         ("detector", DetectorParams), ("tracker", TrackerParams), ("stereo", StereoParams),
@@ -120,6 +136,7 @@ class FrontendParams(C.Structure):
         ("min_number_features", C.c_int64),
         ("max_disparity_since_lkf", C.c_double),
         ("use_stereo_tracking", C.c_int32), ("use_ransac", C.c_int32),
+        ("use_pnp_tracking", C.c_int32), ("reserved1", C.c_int32), ("pnp", PnpParams),
     ]
 
 
@@ -147,7 +164,7 @@ class Config(C.Structure):
         ("left", CameraParams), ("right", CameraParams), ("params", FrontendParams),
         ("batch", C.c_int32), ("device", C.c_int32),
         ("hip_stream", C.c_void_p),
-        ("candidate_capacity", C.c_int32), ("frontend_type", C.c_int32), ("reserved0", C.c_int32),
+        ("candidate_capacity", C.c_int32), ("frontend_type", C.c_int32), ("landmark_map_capacity", C.c_int32),
         ("depth", DepthParams),
         ("stream_groups", C.c_int32),
     ]
@@ -195,6 +212,7 @@ class FrameOutput(C.Structure):
         ("nr_mono_putatives", C.c_int32), ("nr_mono_inliers", C.c_int32),
         ("mono_ransac_iters", C.c_int32), ("nr_stereo_putatives", C.c_int32),
         ("nr_stereo_inliers", C.c_int32), ("reserved0", C.c_int32),
+        ("tracking_status_pnp", C.c_int32), ("nr_pnp_inliers", C.c_int32), ("W_T_k_pnp", C.c_double * 12),
     ]
 
 
@@ -203,22 +221,6 @@ class RansacOutput(C.Structure):
         ("status", C.c_int32), ("n_inliers", C.c_int32), ("iterations", C.c_int32),
         ("reserved0", C.c_int32), ("pose", C.c_double * 12), ("info", C.c_double * 9),
     ]
-
-
-class PnpParams(C.Structure):
-    """kvfe_pnp_params (Tracker::pnp, VisionImuTrackerParams.h: pnp_algorithm_, min_pnp_inliers_, ransac_threshold_pnp_)"""
-    _fields_ = [
-        ("pnp_algorithm", C.c_int32), ("min_pnp_inliers", C.c_int32), ("ransac_threshold_pnp", C.c_double),
-        ("optimize_2d3d_pose_from_inliers", C.c_int32), ("reserved0", C.c_int32),
-    ]
-
-
-PNP_KNEIP_P2P, PNP_KNEIP_P3P, PNP_GAO_P3P, PNP_EPNP, PNP_UPNP, PNP_UP3P, PNP_NONLINEAR, PNP_MLPNP = range(8)
-
-
-def pnp_params_default():
-    """VisionImuTrackerParams.h defaults / params/Euroc: EPNP, 20 inliers, 1 px"""
-    return PnpParams(PNP_EPNP, 20, 1.0, 0, 0)
 
 
 class StageTimes(C.Structure):

@@ -653,15 +653,12 @@ __device__ __forceinline__ double ep_distance(const double* model, const double*
   return 1.0 - ((r[0] * bearing[0] + r[1] * bearing[1]) + r[2] * bearing[2]);
 }
 
-// Tracker::pnp over n correspondences (one problem per workgroup).  out_status: outlierRejectionPnP's status;
-// out_counts: [n_inliers, iterations, success]; out_pose 3x4; inliers ascending.
-// LDS (dynamic): shuffled [n] int
+// Tracker::pnp over n correspondences, executed by the whole 256-thread workgroup.  out_status: outlierRejectionPnP's
+// status; out_counts: [n_inliers, iterations, success]; out_pose 3x4; inliers ascending.  shuffled: [n] ints of LDS.
 template <int ALG>   // Pose3d2dAlgorithm: 3 = EPNP (6 points per sample), 1 = KneipP3P (3 + 1)
-__global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, const double* f, const double* p, int n,
-                                                          double threshold, int min_inliers, int* inliers,
-                                                          int* out_status, double* out_pose, int* out_counts) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  int* shuffled = reinterpret_cast<int*>(lds_raw);
+__device__ void ep_ransac_block(const KParams& P, const Tables& T, const double* f, const double* p, int n,
+                                double threshold, int min_inliers, int* shuffled, int* inliers, int* out_status,
+                                double* out_pose, int* out_counts) {
   constexpr int SS = ALG == 3 ? EP_N : 4;   // AbsolutePoseSacProblem::getSampleSize()
   __shared__ int wave_tot[RS_T / 64];
   __shared__ int sh_sel[EP_BATCH][EP_N];
@@ -780,6 +777,125 @@ __global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, c
     out_status[0] = (success && n_in > min_inliers) ? TRK_VALID : TRK_FEW_MATCHES;
     for (int i = 0; i < 12; i++) out_pose[i] = success ? sh_best[i] : ((i % 5 == 0) ? 1.0 : 0.0);
   }
+}
+
+template <int ALG>
+__global__ __launch_bounds__(RS_T) void pnp_ransac_kernel(KParams P, Tables T, const double* f, const double* p, int n,
+                                                          double threshold, int min_inliers, int* inliers,
+                                                          int* out_status, double* out_pose, int* out_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  ep_ransac_block<ALG>(P, T, f, p, n, threshold, min_inliers, reinterpret_cast<int*>(lds_raw), inliers, out_status,
+                       out_pose, out_counts);
+}
+
+// VisionImuFrontend::outlierRejectionPnP on the keyframes of the step (StereoVisionImuFrontend.cpp:389-399,
+// RgbdVisionImuFrontend.cpp:328-341): Tracker::pnp(const StereoFrame&) (Tracker.cpp:1064-1120) gathers, in keypoint order,
+// the keypoints with a VALID rectified left keypoint whose landmark id is in the map of Tracker::updateMap (binary
+// search over the sorted ids) -- bearing vector = keypoints_3d_[i] as upstream -- and runs the RANSAC above.
+// One workgroup per stream; LDS: shuffled [kcap] int.
+template <int ALG>
+__global__ __launch_bounds__(RS_T) void pnp_frontend_kernel(KParams P, Tables T, FrameTab K, StereoTab ST, StreamState S,
+                                                            RansacScratch RS) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int flags = S.flags[s];
+  if (!(flags & FLAG_KEYFRAME) || (flags & FLAG_FIRST)) return;
+  if (!P.use_ransac) {   // RgbdVisionImuFrontend.cpp:342-346 sets DISABLED; the stereo front-end leaves the field alone
+    if (P.rgbd && tid == 0) S.pnp_status[s] = TRK_DISABLED;
+    return;
+  }
+  if (!P.use_pnp) return;   // (status INVALID, pose identity: what the fields hold from the start)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int wave_tot_g[RS_T / 64];
+  __shared__ int sh_total;
+  const size_t so = (size_t)s * P.kcap;
+  const int cnt = S.n_tracked[s];   // frame k holds the tracked keypoints only at this point
+  const long long* ids = S.map_ids + (size_t)s * P.map_cap;
+  const double* xyz = S.map_xyz + (size_t)s * P.map_cap * 3;
+  const int nm = S.map_n[s];
+  double* f = RS.f_ref + so * 3;
+  double* p = RS.f_cur + so * 3;
+  // removeOutliersStereo (Tracker.cpp:763-767, 886-917) zeroes keypoints_3d_ of the stereo outliers in frame k before
+  // PnP looks at it; the step never materialises that (the second sparseStereoReconstruction of the keyframe recomputes
+  // every entry), so the outliers are flagged here from the match list and the inlier list of the stereo rejection
+  unsigned char* outl = lds_raw;   // [kcap] flags (the area is re-initialised as `shuffled` afterwards)
+  for (int i = tid; i < cnt; i += RS_T) outl[i] = 0;
+  __syncthreads();
+  if (P.use_stereo_tracking) {
+    const bool voting = P.ransac_1pt_stereo && !rs_rot_is_identity(S.kf_R_cur + (size_t)s * 9);
+    const int st_stereo = S.trk_status[2 * (size_t)s + 1];
+    const int* cn = S.trk_counts + 6 * (size_t)s;
+    int nmat = -1, n_in = 0;
+    if (voting) {   // geometricOutlierRejection3d3dGivenRotation: outliers removed whatever the status
+      nmat = RS.n_matches[s];
+      n_in = st_stereo != TRK_INVALID ? cn[4] : 0;
+    } else if (st_stereo != TRK_INVALID) {   // 3-point problem: only after a successful RANSAC
+      nmat = cn[3];
+      n_in = cn[4];
+    }
+    const int2* matches = RS.matches + so;
+    const int* inl = RS.inliers + so;   // ascending match indices
+    for (int m = tid; m < nmat; m += RS_T) {
+      int lo = 0, hi = n_in;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (inl[mid] < m) lo = mid + 1;
+        else hi = mid;
+      }
+      if (!(lo < n_in && inl[lo] == m)) outl[matches[m].y] = 1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) sh_total = 0;
+  __syncthreads();
+  for (int base = 0; base < cnt; base += RS_T) {
+    const int i = base + tid;
+    int hit = -1;
+    if (i < cnt && ST.left_status[so + i] == 0 /* KeypointStatus::VALID */) {
+      const long long id = K.lmk[so + i];
+      if (id != -1) {
+        int lo = 0, hi = nm;   // first index with ids[idx] >= id
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (ids[mid] < id) lo = mid + 1;
+          else hi = mid;
+        }
+        if (lo < nm && ids[lo] == id) hit = lo;
+      }
+    }
+    int tot;
+    const int pos = rs_scan(hit >= 0 ? 1 : 0, wave_tot_g, &tot);
+    const int off = sh_total;
+    if (hit >= 0) {
+      for (int c = 0; c < 3; c++) {
+        f[3 * (size_t)(off + pos) + c] = outl[i] ? 0.0 : ST.kp3d[(so + i) * 3 + c];
+        p[3 * (size_t)(off + pos) + c] = xyz[3 * (size_t)hit + c];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) sh_total = off + tot;
+    __syncthreads();
+  }
+  const int n = sh_total;
+  __syncthreads();
+  if (n == 0) {   // "No 2D-3D correspondences found for 2D-3D RANSAC...": Pose3(), no inliers, failure
+    if (tid == 0) {
+      S.pnp_status[s] = TRK_FEW_MATCHES;
+      for (int i = 0; i < 3; i++) S.pnp_counts[3 * (size_t)s + i] = 0;
+      for (int i = 0; i < 12; i++) S.pnp_pose[12 * (size_t)s + i] = (i % 5 == 0) ? 1.0 : 0.0;
+    }
+    return;
+  }
+  ep_ransac_block<ALG>(P, T, f, p, n, P.pnp_threshold, P.pnp_min_inliers, reinterpret_cast<int*>(lds_raw),
+                       RS.inliers + so, S.pnp_status + s, S.pnp_pose + 12 * (size_t)s, S.pnp_counts + 3 * (size_t)s);
+}
+
+void launch_pnp_frontend(const KParams& P, const Tables& T, const FrameTab& k, const StereoTab& ST, const StreamState& S,
+                         const RansacScratch& RS, hipStream_t st) {
+  const size_t lds = sizeof(int) * (size_t)P.kcap;
+  if (P.pnp_alg == 1)
+    hipLaunchKernelGGL(pnp_frontend_kernel<1>, dim3(P.B), dim3(RS_T), lds, st, P, T, k, ST, S, RS);
+  else
+    hipLaunchKernelGGL(pnp_frontend_kernel<3>, dim3(P.B), dim3(RS_T), lds, st, P, T, k, ST, S, RS);
 }
 
 void launch_pnp(const KParams& P, const Tables& T, int algorithm, const double* f, const double* p, int n,

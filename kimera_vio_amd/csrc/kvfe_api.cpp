@@ -203,6 +203,9 @@ kvfe_status reset_tracker_status(kvfe_ctx* c, Buffers& b) {
   HIPCHK(c, hipMemcpyAsync(b.ss.trk_pose, pose.data(), sizeof(double) * pose.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b.ss.trk_info, 0, sizeof(double) * 9 * B, c->stream));
   HIPCHK(c, hipMemsetAsync(b.ss.trk_counts, 0, sizeof(int) * 6 * B, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b.ss.pnp_status, st.data(), sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b.ss.pnp_pose, pose.data(), sizeof(double) * 12 * B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(b.ss.pnp_counts, 0, sizeof(int) * 3 * B, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
   return KVFE_OK;
 }
@@ -257,6 +260,12 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.ss.trk_pose, B * 24));
   TRY(dalloc(c, &b.ss.trk_info, B * 9));
   TRY(dalloc(c, &b.ss.trk_counts, B * 6));
+  TRY(dalloc(c, &b.ss.pnp_status, B));
+  TRY(dalloc(c, &b.ss.pnp_counts, B * 3));
+  TRY(dalloc(c, &b.ss.pnp_pose, B * 12));
+  TRY(dalloc(c, &b.ss.map_ids, B * (size_t)P.map_cap));
+  TRY(dalloc(c, &b.ss.map_xyz, B * (size_t)P.map_cap * 3));
+  TRY(dalloc(c, &b.ss.map_n, B));
   TRY(dalloc(c, &b.ss.flags, B));
   TRY(dalloc(c, &b.ss.n_tracked, B));
   TRY(dalloc(c, &b.ss.n_detected, B));
@@ -424,6 +433,13 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
     if (!tr.ransac_use_2point_mono && tr.pose_2d2d_algorithm != 1)
       return fail("2d2d_algorithm: only NISTER (1) is implemented for ransac_use_2point_mono=0",
                   KVFE_ERR_UNSUPPORTED);
+    if (p.use_pnp_tracking && (!mono || rgbd)) {   // (MonoVisionImuFrontend has no PnP stage)
+      if (p.pnp.pnp_algorithm != 3 && p.pnp.pnp_algorithm != 1)
+        return fail("use_pnp_tracking: pnp_algorithm must be 3 (EPNP) or 1 (KneipP3P)", KVFE_ERR_UNSUPPORTED);
+      if (p.pnp.optimize_2d3d_pose_from_inliers)
+        return fail("optimize_2d3d_pose_from_inliers is not implemented", KVFE_ERR_UNSUPPORTED);
+      if (!(p.pnp.ransac_threshold_pnp > 0.0)) return fail("ransac_threshold_pnp must be > 0", KVFE_ERR_INVALID_ARG);
+    }
     if (tr.ransac_max_iterations < 1 || tr.ransac_max_iterations > 1000)
       return fail("ransac_max_iterations out of range [1,1000]", KVFE_ERR_INVALID_ARG);
     if (!(tr.ransac_probability > 0.0 && tr.ransac_probability < 1.0))
@@ -571,6 +587,12 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.acap = ACAP;
   const size_t N = (size_t)P.W * P.H;
   P.ccap = cfg.candidate_capacity > 0 ? cfg.candidate_capacity : (int)std::max<size_t>(N / 4, 4096);
+  P.use_pnp = p.use_pnp_tracking ? 1 : 0;
+  P.pnp_alg = p.pnp.pnp_algorithm;
+  P.pnp_min_inliers = p.pnp.min_pnp_inliers;
+  P.pnp_threshold = 1.0 - std::cos(std::atan(std::sqrt(2.0) * p.pnp.ransac_threshold_pnp /
+                                             (0.5 * (cfg.left.intrinsics[0] + cfg.left.intrinsics[1]))));
+  P.map_cap = cfg.landmark_map_capacity > 0 ? cfg.landmark_map_capacity : 8192;
   P.kcap = P.max_features + P.max_corners + 64;
   {
     // the per-stream bookkeeping and outlier-rejection kernels keep one frame's keypoint ids / indices in LDS: refuse a
@@ -843,6 +865,8 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
       launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st);
       prof_end(c, ST_RANSAC_STEREO, st);
     }
+    if (P.rgbd && (P.use_pnp || !P.use_ransac))   // RgbdVisionImuFrontend.cpp:328-346
+      launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, st);
     prof_begin(c, ST_FINALIZE, st);
     launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, st);
     prof_end(c, ST_FINALIZE, st);
@@ -878,6 +902,8 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387)
   prof_begin(c, ST_RANSAC_STEREO, st);
   if (P.use_ransac) launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st);
+  // outlierRejectionPnP(*stereoFrame_k_) (:389-399): after the stereo rejection, before detection
+  if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, st);
   prof_end(c, ST_RANSAC_STEREO, st);
   if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   prof_begin(c, ST_STEREO_NEW, st);
@@ -997,6 +1023,11 @@ void kvfe_default_frontend_params(kvfe_frontend_params* p) {
   p->max_disparity_since_lkf = 200.0;
   p->use_stereo_tracking = 1;
   p->use_ransac = 1;  // VisionImuFrontendParams.h:56
+  p->use_pnp_tracking = 1;                 // VisionImuFrontendParams.h:59 (every shipped YAML but KinectAzure sets 0)
+  p->pnp.pnp_algorithm = 3;                // Pose3d2dAlgorithm::EPNP (VisionImuTrackerParams.h:75)
+  p->pnp.min_pnp_inliers = 10;             // VisionImuTrackerParams.h:73
+  p->pnp.ransac_threshold_pnp = 1.0;       // :74
+  p->pnp.optimize_2d3d_pose_from_inliers = 0;
 }
 
 kvfe_status kvfe_compute_rectification(const kvfe_camera_params* left,
@@ -2033,6 +2064,47 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
   return KVFE_OK;
 }
 
+kvfe_status kvfe_frontend_update_map(kvfe_ctx* c, int32_t stream, const int64_t* landmark_ids, const double* xyz,
+                                     int32_t n) {
+  DeviceGuard _dev(c);
+  if (!c || stream < 0 || stream >= c->P.B || n < 0 || (n > 0 && (!landmark_ids || !xyz))) return KVFE_ERR_INVALID_ARG;
+  for (kvfe_ctx* ch : c->children)
+    if (stream >= ch->s0 && stream < ch->s0 + ch->P.B)
+      return kvfe_frontend_update_map(ch, stream - ch->s0, landmark_ids, xyz, n);
+  const KParams& P = c->P;
+  if (n > P.map_cap) return KVFE_ERR_CAPACITY;
+  // std::unordered_map semantics: one position per id (the last one given wins), looked up by id -> sorted for the
+  // device's binary search
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return landmark_ids[a] < landmark_ids[b]; });
+  std::vector<long long> ids;
+  std::vector<double> pts;
+  ids.reserve(n);
+  pts.reserve(3 * (size_t)n);
+  for (int k = 0; k < n; k++) {
+    const int i = order[k];
+    if (!ids.empty() && ids.back() == (long long)landmark_ids[i]) {   // duplicate id: keep the later entry
+      for (int q = 0; q < 3; q++) pts[pts.size() - 3 + q] = xyz[3 * (size_t)i + q];
+      continue;
+    }
+    ids.push_back((long long)landmark_ids[i]);
+    for (int q = 0; q < 3; q++) pts.push_back(xyz[3 * (size_t)i + q]);
+  }
+  const int m = (int)ids.size();
+  Buffers& b = c->fe;
+  hipStream_t st = c->stream;
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(b.ss.map_ids + (size_t)stream * P.map_cap, ids.data(), sizeof(long long) * m,
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(b.ss.map_xyz + (size_t)stream * P.map_cap * 3, pts.data(), sizeof(double) * 3 * m,
+                             hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, hipMemcpyAsync(b.ss.map_n + stream, &m, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));   // the host vectors go out of scope
+  return KVFE_OK;
+}
+
 kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   DeviceGuard _dev(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
@@ -2111,6 +2183,12 @@ kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* 
     out->nr_stereo_putatives = cnt[3];
     out->nr_stereo_inliers = cnt[4];
     out->reserved0 = 0;
+    int pst = 0, pcnt[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpy(&pst, b.ss.pnp_status + s, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pcnt, b.ss.pnp_counts + 3 * (size_t)s, sizeof(pcnt), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->W_T_k_pnp, b.ss.pnp_pose + 12 * (size_t)s, sizeof(double) * 12, hipMemcpyDeviceToHost));
+    out->tracking_status_pnp = pst;
+    out->nr_pnp_inliers = pcnt[0];
   }
   const size_t so = (size_t)s * P.kcap;
   const int n = std::min(count, out->capacity);

@@ -40,6 +40,8 @@ struct KParams {
   // geometric outlier rejection (FrontendParams::useRANSAC_, TrackerParams ransac_*)
   int mono;  // MonoVisionImuFrontend: no right camera, keypoints undistorted with R = I, P = K
   int use_ransac, ransac_2pt_mono, ransac_1pt_stereo, ransac_max_iters;
+  int use_pnp, pnp_alg, pnp_min_inliers, map_cap;   // use_pnp_tracking (Tracker::pnp on keyframes), landmark map capacity
+  double pnp_threshold;                              // 1 - cos(atan(sqrt 2 ransac_threshold_pnp / f))
   int min_mono_inliers, min_stereo_inliers;
   double ransac_thr_mono, ransac_probability;
   float ransac_thr_stereo;      // 1-point voting (float32 Mahalanobis test)
@@ -160,6 +162,13 @@ struct StreamState {
   double* trk_pose;       // [B][2][12] lkf_T_k_mono_, lkf_T_k_stereo_ (row-major 3x4)
   double* trk_info;       // [B][9]  infoMatStereoTranslation_
   int* trk_counts;        // [B][6]  mono putatives, inliers, iterations; stereo putatives, inliers; -
+  // use_pnp_tracking: kfTracking_status_pnp_ / W_T_k_pnp_ and the landmark map of Tracker::updateMap
+  int* pnp_status;        // [B]
+  int* pnp_counts;        // [B][3]  inliers, iterations, Tracker::pnp's return value
+  double* pnp_pose;       // [B][12]
+  long long* map_ids;     // [B][map_cap] ascending
+  double* map_xyz;        // [B][map_cap][3]
+  int* map_n;             // [B]
 };
 
 // VIO::TrackingStatus
@@ -329,6 +338,9 @@ inline int lds_dynamic_budget(const void* kernel) {
 int track_max_kcap();
 int ransac_max_kcap(bool nister);
 // Tracker::pnp, EPNP RANSAC over n 2D-3D correspondences (k_pnp.inl): out_counts = [n_inliers, iterations, success]
+// outlierRejectionPnP of the keyframes of this step (frame k after the stereo outlier rejection)
+void launch_pnp_frontend(const KParams& P, const Tables& T, const FrameTab& k, const StereoTab& ST, const StreamState& S,
+                         const RansacScratch& RS, hipStream_t st);
 void launch_pnp(const KParams& P, const Tables& T, int algorithm, const double* f, const double* p, int n,
                 double threshold, int min_inliers, int* inliers, int* out_status, double* out_pose, int* out_counts,
                 hipStream_t st);

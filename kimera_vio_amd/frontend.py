@@ -444,6 +444,13 @@ class Context:
                                                      image_stride or self.w * self.h, inputs),
                   "frontend_step_device")
 
+    def update_map(self, stream: int, landmark_ids, xyz):
+        """Tracker::updateMap for one stream: landmark id -> world position (use_pnp_tracking)."""
+        ids = np.ascontiguousarray(landmark_ids, np.int64).reshape(-1)
+        pts = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        assert len(ids) == len(pts)
+        self._chk(self.lib.kvfe_frontend_update_map(self._h, stream, _p(ids), _p(pts), len(ids)), "frontend_update_map")
+
     def staging_buffers(self, slot: int):
         """numpy views [batch, H, W] of the pinned left / right staging slot `slot`."""
         pl, pr = C.c_void_p(), C.c_void_p()
@@ -488,6 +495,8 @@ class Context:
                  n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id,
                  tracking_status_mono=out.tracking_status_mono,
                  tracking_status_stereo=out.tracking_status_stereo,
+                 tracking_status_pnp=out.tracking_status_pnp, nr_pnp_inliers=out.nr_pnp_inliers,
+                 W_T_k_pnp=np.array(out.W_T_k_pnp, np.float64).reshape(3, 4),
                  lkf_T_k_mono=np.array(out.lkf_T_k_mono, np.float64).reshape(3, 4),
                  lkf_T_k_stereo=np.array(out.lkf_T_k_stereo, np.float64).reshape(3, 4),
                  info_mat_stereo_translation=np.array(out.info_mat_stereo_translation, np.float64).reshape(3, 3),

@@ -73,6 +73,7 @@ def load() -> C.CDLL:
                                                              C.POINTER(abi.RansacOutput)]
     L.kvfe_outlier_rejection_3d3d.argtypes = [vp, vp, vp, i32, vp, C.POINTER(abi.RansacOutput)]
     L.kvfe_pnp.argtypes = [vp, C.POINTER(abi.PnpParams), vp, vp, i32, vp, C.POINTER(abi.RansacOutput)]
+    L.kvfe_frontend_update_map.argtypes = [vp, i32, vp, vp, i32]
     L.kvfe_outlier_rejection_2d2d.argtypes = [vp, vp, vp, i32, vp, C.POINTER(abi.RansacOutput)]
     L.kvfe_equalize_hist.argtypes = [vp, vp, sz, vp, sz]
     L.kvfe_dense_stereo_params_default.argtypes = [C.POINTER(abi.DenseStereoParams)]
@@ -126,7 +127,7 @@ NEW_R2_SYMBOLS = [
     "kvfe_check_undistorted_rectified_left_keypoints", "kvfe_distort_unrectify_keypoints",
     "kvfe_undistort_rectify_left_keypoints", "kvfe_distort_unrectify_right_keypoints",
     "kvfe_undistort_rectify_stereo_frame", "kvfe_get_depth_from_rectified_matches",
-    "kvfe_feature_detection_frame", "kvfe_feature_tracking_frame", "kvfe_pnp",
+    "kvfe_feature_detection_frame", "kvfe_feature_tracking_frame", "kvfe_pnp", "kvfe_frontend_update_map",
 ]
 
 EXPORTED_SYMBOLS = NEW_R2_SYMBOLS + [

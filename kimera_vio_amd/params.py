@@ -70,6 +70,8 @@ def default_frontend_params() -> abi.FrontendParams:
     t.ransac_use_2point_mono = 1
     t.ransac_rng_policy = abi.RNG_LIBSTDCXX_PRE11
     t.pose_2d2d_algorithm = 1  # Pose2d2dAlgorithm::NISTER (VisionImuTrackerParams.h:68)
+    p.use_pnp_tracking = 1     # VisionImuFrontendParams.h:59 (every shipped YAML but KinectAzure sets 0)
+    p.pnp = abi.PnpParams(abi.PNP_EPNP, 10, 1.0, 0, 0)   # VisionImuTrackerParams.h:73-76
     s = p.stereo
     s.tolerance_template_matching = 0.15
     s.templ_cols = 101
@@ -167,11 +169,9 @@ def load_frontend_params(path: str, use_ransac: int | None = None) -> abi.Fronte
     p.max_disparity_since_lkf = float(y["max_disparity_since_lkf"])
     p.use_ransac = int(y["useRANSAC"]) if use_ransac is None else int(use_ransac)
     # use_2d2d_tracking / use_3d3d_tracking are parsed by the reference (VisionImuFrontendParams.cpp:104-105)
-    # and read nowhere in src/.  use_pnp_tracking gates Tracker::pnp on keyframes (StereoVisionImuFrontend.cpp:389);
-    # its result does not feed back into the keypoint state, so it runs next to the step: kvfe_pnp /
-    # Context.pnp with the parameters attached here (p.use_pnp_tracking, p.pnp) and the landmark map of the back-end
-    # (kvfe::Tracker::updateMap / outlierRejectionPnP in include/kvfe_adapter.hpp).  EPNP and KneipP3P are
-    # implemented: another pnp_algorithm makes that call return KVFE_ERR_UNSUPPORTED, not the step.
+    # and read nowhere in src/.  use_pnp_tracking gates Tracker::pnp on keyframes (StereoVisionImuFrontend.cpp:389):
+    # the step runs it on the device against the landmark map of kvfe_frontend_update_map; EPNP and KneipP3P are
+    # implemented, another pnp_algorithm is refused at kvfe_create (KVFE_ERR_UNSUPPORTED).
     int(y["use_2d2d_tracking"]), int(y["use_3d3d_tracking"])
     p.use_pnp_tracking = int(y["use_pnp_tracking"])
     p.pnp = abi.PnpParams(int(y.get("pnp_algorithm", abi.PNP_EPNP)), int(y.get("min_pnp_inliers", 20)),

@@ -605,6 +605,9 @@ KVO_API void kvo_frontend_process(kvo_frontend* f, const uint8_t* left, const ui
                                   size_t stride, const kvfe_frame_input* in) {
   f->fe.process(left, right, stride, *in);
 }
+KVO_API void kvo_frontend_update_map(kvo_frontend* f, const int64_t* ids, const double* xyz, int n) {
+  f->fe.updateMap(ids, xyz, n);
+}
 KVO_API int kvo_frontend_get_output(kvo_frontend* f, kvfe_frame_output* out) {
   const kimera::StereoFrame& sf = f->fe.current();
   const int n = (int)sf.left.keypoints.size();
@@ -627,6 +630,9 @@ KVO_API int kvo_frontend_get_output(kvo_frontend* f, kvfe_frame_output* out) {
     out->nr_stereo_putatives = T.nr_stereo_putatives;
     out->nr_stereo_inliers = T.nr_stereo_inliers;
     out->reserved0 = 0;
+    out->tracking_status_pnp = T.pnp;
+    out->nr_pnp_inliers = T.nr_pnp_inliers;
+    std::memcpy(out->W_T_k_pnp, T.W_T_k_pnp, sizeof(out->W_T_k_pnp));
   }
   const int m = std::min(n, out->capacity);
   const bool has_stereo = (int)sf.left_kp_rect.size() == n;

@@ -927,6 +927,13 @@ void Frontend::process(const uint8_t* left, const uint8_t* right, size_t stride,
       } else {
         tracker_status.stereo = KVFE_TRACKING_INVALID;
       }
+      if (p.use_pnp_tracking) {   // :389-399
+        outlierRejectionPnP(k);
+      } else {
+        tracker_status.pnp = KVFE_TRACKING_INVALID;
+        const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        std::memcpy(tracker_status.W_T_k_pnp, I, sizeof(I));
+      }
     } else {
       tracker_status.mono = KVFE_TRACKING_DISABLED;
       tracker_status.stereo = KVFE_TRACKING_DISABLED;
@@ -1147,9 +1154,17 @@ void Frontend::processRgbd(const kvfe_frame_input& in, const void* depth, size_t
         outlierRejectionStereo(in.keyframe_R_cur_frame, lkf, k);
       else
         tracker_status.stereo = KVFE_TRACKING_INVALID;
+      if (p.use_pnp_tracking) {   // RgbdVisionImuFrontend.cpp:328-334
+        outlierRejectionPnP(k);
+      } else {
+        tracker_status.pnp = KVFE_TRACKING_INVALID;
+        const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        std::memcpy(tracker_status.W_T_k_pnp, I, sizeof(I));
+      }
     } else {
       tracker_status.mono = KVFE_TRACKING_DISABLED;
       tracker_status.stereo = KVFE_TRACKING_DISABLED;
+      tracker_status.pnp = KVFE_TRACKING_DISABLED;   // :345
     }
     k.left.isKeyframe = true;
     depthDetectionMask(depth, stride, mask);

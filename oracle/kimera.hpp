@@ -4,6 +4,8 @@
 // cites the reference file:line it follows.  Built on oracle/ocv.hpp.
 #pragma once
 #include <cstdint>
+#include <array>
+#include <map>
 #include <vector>
 
 #include "../include/kvfe.h"  // POD parameter structs only (no product code is linked)
@@ -121,6 +123,9 @@ struct TrackerStatusSummary {
   double info[9] = {0};
   int nr_mono_putatives = 0, nr_mono_inliers = 0, mono_iters = 0;
   int nr_stereo_putatives = 0, nr_stereo_inliers = 0;
+  int pnp = KVFE_TRACKING_INVALID;   // kfTracking_status_pnp_
+  double W_T_k_pnp[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  int nr_pnp_inliers = 0;
 };
 
 // Tracker::findMatchingKeypoints (Tracker.cpp:919-946)
@@ -219,6 +224,11 @@ struct Frontend {
   void process(const uint8_t* left, const uint8_t* right, size_t stride,
                const kvfe_frame_input& in);
   const StereoFrame& current() const { return km1; }
+  // Tracker::updateMap (Tracker.h:82-94) and VisionImuFrontend::outlierRejectionPnP (VisionImuFrontend.cpp:146-173)
+  // = Tracker::pnp(const StereoFrame&) (Tracker.cpp:1064-1120) on the keyframe
+  std::map<int64_t, std::array<double, 3>> landmarks_map;
+  void updateMap(const int64_t* ids, const double* xyz, int n);
+  void outlierRejectionPnP(const StereoFrame& frame);
 
  // RgbdFrame::fillStereoFrame (public so that the reference's component KAT can drive it, capi.cpp);
   // (dw, dh) = size of the depth image; <= 0: the camera resolution

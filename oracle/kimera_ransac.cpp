@@ -179,6 +179,33 @@ RansacOut pnp(const double* bearings, const double* points, int n, double avg_fo
   return o;
 }
 
+void Frontend::updateMap(const int64_t* ids, const double* xyz, int n) {
+  landmarks_map.clear();
+  for (int i = 0; i < n; i++) landmarks_map[ids[i]] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+}
+
+// VisionImuFrontend::outlierRejectionPnP(frame, &status_pnp) with Tracker::pnp(const StereoFrame&) (Tracker.cpp:1064-1120)
+void Frontend::outlierRejectionPnP(const StereoFrame& frame) {
+  std::vector<double> cam_bearing_vectors, W_points;
+  for (size_t i = 0; i < frame.left_kp_rect.size(); i++) {
+    const int64_t lmk_id = frame.left.landmarks.at(i);
+    if (frame.left_kp_rect[i].status == KVFE_KP_VALID && lmk_id != -1) {
+      const auto it = landmarks_map.find(lmk_id);
+      if (it != landmarks_map.end()) {
+        W_points.insert(W_points.end(), it->second.begin(), it->second.end());
+        cam_bearing_vectors.insert(cam_bearing_vectors.end(), frame.kp3d.begin() + 3 * i, frame.kp3d.begin() + 3 * i + 3);
+      }
+    }
+  }
+  bool success = false;
+  const double focal = 0.5 * (cam.left.intrinsics[0] + cam.left.intrinsics[1]);
+  const RansacOut r = pnp(cam_bearing_vectors.data(), W_points.data(), (int)(W_points.size() / 3), focal, p.tracker,
+                          p.pnp, &success);
+  tracker_status.pnp = r.status;
+  std::memcpy(tracker_status.W_T_k_pnp, r.pose, sizeof(r.pose));
+  tracker_status.nr_pnp_inliers = (int)r.inliers.size();
+}
+
 // gtsam::StereoCamera(Pose3(), K).backproject2(z, boost::none, H2) (gtsam 4.2
 // geometry/StereoCamera.cpp) and Tracker::getPoint3AndCovariance (Tracker.cpp:772-818)
 void getPoint3AndCovariance(const StereoCalib& K, double uL, double uR, double v, const double p3[3],

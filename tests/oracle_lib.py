@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
     L.kvo_frontend_destroy.argtypes = [C.c_void_p]
     L.kvo_frontend_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.POINTER(abi.FrameInput)]
+    L.kvo_frontend_update_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.kvo_frontend_update_map.restype = None
     L.kvo_frontend_get_output.restype = C.c_int
     L.kvo_frontend_get_output.argtypes = [C.c_void_p, C.POINTER(abi.FrameOutput)]
     L.kvo_frontend_time_sequence.restype = C.c_double
@@ -580,6 +582,8 @@ def frame_output_to_dict(out: abi.FrameOutput, arrs: dict) -> dict:
              n_detected=out.n_detected, n_measurements=out.n_measurements, frame_id=out.frame_id,
              tracking_status_mono=out.tracking_status_mono,
              tracking_status_stereo=out.tracking_status_stereo,
+             tracking_status_pnp=out.tracking_status_pnp, nr_pnp_inliers=out.nr_pnp_inliers,
+             W_T_k_pnp=np.array(out.W_T_k_pnp, np.float64).reshape(3, 4),
              lkf_T_k_mono=np.array(out.lkf_T_k_mono, np.float64).reshape(3, 4),
              lkf_T_k_stereo=np.array(out.lkf_T_k_stereo, np.float64).reshape(3, 4),
              info_mat_stereo_translation=np.array(out.info_mat_stereo_translation, np.float64).reshape(3, 3),
@@ -610,6 +614,12 @@ class Frontend:
         if getattr(self, "_h", None):
             lib().kvo_frontend_destroy(self._h)
             self._h = None
+
+    def update_map(self, landmark_ids, xyz):
+        """Tracker::updateMap"""
+        ids = np.ascontiguousarray(landmark_ids, np.int64).reshape(-1)
+        pts = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        lib().kvo_frontend_update_map(self._h, _p(ids), _p(pts), len(ids))
 
     def process(self, left, right, timestamp_ns, R=None, force_keyframe=False) -> dict:
         left = _img(left)

@@ -153,3 +153,124 @@ def test_pnp_degenerate_and_unsupported():
         assert e.value.status == abi.KVFE_ERR_UNSUPPORTED
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# use_pnp_tracking inside the step: Tracker::updateMap + outlierRejectionPnP on keyframes
+# (StereoVisionImuFrontend.cpp:389-399, RgbdVisionImuFrontend.cpp:328-341)
+# ---------------------------------------------------------------------------------------------------------------
+def _seq():
+    z = np.load(os.path.join(G, "micro_euroc_f10_18.npz"))
+    return dict(lefts=z["lefts"], rights=z["rights"], ts=z["timestamps"], body_R=z["body_R"])
+
+
+def _cam_rotations(L, R, body_R):
+    cam = O.Camera(L, R)
+    TL = np.array(L.body_pose_cam).reshape(4, 4)
+    b_R_c = TL[:3, :3] @ np.array(cam.rect.R1).reshape(3, 3).T
+    return [b_R_c.T @ Rb @ b_R_c for Rb in body_R]
+
+
+PNP_KEYS = ("tracking_status_pnp", "nr_pnp_inliers")
+
+
+@pytest.mark.parametrize("alg,streams", [(abi.PNP_EPNP, 1), (abi.PNP_KNEIP_P3P, 2)])
+def test_frontend_step_with_pnp_tracking(alg, streams):
+    """the shipped Euroc parameters with use_pnp_tracking: 1; the back-end's map is played by the 3-D points of the
+    first keyframe (world = its camera frame), handed over after frame 0 and replaced after frame 3 (a map with
+    duplicated and unsorted ids); every later keyframe's kfTracking_status_pnp_ / W_T_k_pnp_ / inlier count equals
+    the oracle front-end's, bit for bit, next to the unchanged rest of the frame."""
+    seq = _seq()
+    L, R = P.load_camera_params(os.path.join(G, "sensorLeft.yaml")), P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+    p.use_pnp_tracking = 1
+    p.pnp.pnp_algorithm = alg
+    p.pnp.min_pnp_inliers = 10
+    camR = _cam_rotations(L, R, seq["body_R"])
+    fe = [O.Frontend(L, R, p) for _ in range(streams)]
+    c = F.Context(L, R, p, batch=streams)
+    valid_seen = 0
+    try:
+        kf = [0] * streams
+        for i in range(8):
+            idx = [i if s == 0 else 8 - i for s in range(streams)]
+            Rs = [camR[kf[s]].T @ camR[idx[s]] for s in range(streams)]
+            ts = [int(seq["ts"][i])] * streams
+            hl = np.stack([seq["lefts"][j] for j in idx])
+            hr = np.stack([seq["rights"][j] for j in idx])
+            c.step_host(hl, hr, c.make_inputs(ts, Rs, [1] * streams))   # every frame a keyframe
+            for s in range(streams):
+                exp = fe[s].process(seq["lefts"][idx[s]], seq["rights"][idx[s]], ts[s], Rs[s], True)
+                got = c.get_output(s)
+                for k in ("n_keypoints", "is_keyframe", "n_tracked", "tracking_status_mono", "tracking_status_stereo") + PNP_KEYS:
+                    assert got[k] == exp[k], (i, s, k, got[k], exp[k])
+                assert np.array_equal(got["W_T_k_pnp"], exp["W_T_k_pnp"]), (i, s)
+                assert np.array_equal(got["landmarks"], exp["landmarks"]) and np.array_equal(got["keypoints"], exp["keypoints"])
+                if i >= 1:
+                    valid_seen += int(got["tracking_status_pnp"] == abi.TRACKING_VALID)
+                if exp["is_keyframe"]:
+                    kf[s] = idx[s]
+                if i in (0, 3):   # Tracker::updateMap from the "back-end"
+                    ok = (exp["right_status"] == abi.KP_VALID) & (exp["landmarks"] != -1)
+                    ids, pts = exp["landmarks"][ok], exp["keypoints_3d"][ok]
+                    if i == 3:   # unsorted, with duplicated ids (the later entry wins, as in std::unordered_map::operator[])
+                        ids = np.concatenate([ids[::-1], ids[:5]])
+                        pts = np.concatenate([pts[::-1], pts[:5] + 0.001])
+                    fe[s].update_map(ids, pts)
+                    c.update_map(s, ids, pts)
+        assert valid_seen >= 2 * streams   # the map really produces poses (not just FEW_MATCHES)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("alg", [abi.PNP_KNEIP_P3P, abi.PNP_EPNP])
+def test_rgbd_frontend_with_pnp_tracking_kinect_azure_style(alg):
+    """params/KinectAzure ships use_pnp_tracking: 1 with pnp_algorithm: 1 (KneipP3P) on the RGBD front-end:
+    RgbdVisionImuFrontend::handleKeyframe's outlierRejectionPnP (:328-341) against the oracle; useRANSAC: 0 reports
+    DISABLED (:342-346).  As upstream, the "bearing vectors" handed to OpenGV are keypoints_3d_ (3-D points, not unit
+    vectors: Tracker.cpp:1100): Kneip's P3P then has no real solution once the depths exceed 1 m (cos beta > 1) and the
+    keyframe reports FEW_MATCHES with no inliers, EPnP (scale free) still recovers a pose -- both reproduced."""
+    from test_gpu_parity import _synthetic_depth
+    seq = _seq()
+    L = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    h, w = seq["lefts"][0].shape
+    TL = np.array(L.body_pose_cam).reshape(4, 4)
+    camR = [TL[:3, :3].T @ Rb @ TL[:3, :3] for Rb in seq["body_R"]]
+    for use_ransac in (1, 0):
+        p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=use_ransac)
+        p.detector.max_features_per_frame = 200
+        p.use_pnp_tracking = 1
+        p.pnp.pnp_algorithm = alg
+        p.pnp.min_pnp_inliers = 20
+        dp = abi.depth_params_default(abi.DEPTH_U16)
+        dp.virtual_baseline, dp.min_depth, dp.depth_to_meters = 0.05, 0.3, 0.001
+        fe = O.Frontend(L, L, p, depth=dp)
+        c = F.Context(L, L, p, batch=1, frontend_type=abi.FRONTEND_RGBD, depth=dp)
+        try:
+            kf0 = 0
+            statuses = []
+            for i in range(6):
+                depth = _synthetic_depth(h, w, i, abi.DEPTH_U16, seed=i)
+                Rk = camR[kf0].T @ camR[i]
+                ts = int(seq["ts"][i])
+                c.step_host(seq["lefts"][i][None], depth[None], c.make_inputs([ts], [Rk], [1]))
+                exp = fe.process(seq["lefts"][i], depth, ts, Rk, True)
+                got = c.get_output(0)
+                for k in ("n_keypoints", "is_keyframe", "tracking_status_stereo") + PNP_KEYS:
+                    assert got[k] == exp[k], (use_ransac, i, k, got[k], exp[k])
+                assert np.array_equal(got["W_T_k_pnp"], exp["W_T_k_pnp"]), (use_ransac, i)
+                statuses.append(got["tracking_status_pnp"])
+                if exp["is_keyframe"]:
+                    kf0 = i
+                if i == 0:
+                    ok = (exp["right_status"] == abi.KP_VALID) & (exp["landmarks"] != -1)
+                    fe.update_map(exp["landmarks"][ok], exp["keypoints_3d"][ok])
+                    c.update_map(0, exp["landmarks"][ok], exp["keypoints_3d"][ok])
+            if use_ransac and alg == abi.PNP_EPNP:
+                assert abi.TRACKING_VALID in statuses[1:]
+            elif use_ransac:
+                assert all(st == abi.TRACKING_FEW_MATCHES for st in statuses[1:])
+            else:
+                assert all(st == abi.TRACKING_DISABLED for st in statuses[1:])
+        finally:
+            c.close()
