@@ -513,9 +513,10 @@ KVFE_API kvfe_status kvfe_outlier_rejection_3d3d(kvfe_ctx* ctx, const double* re
  * frame F of the landmarks.  Tracker::pnp(const StereoFrame&, ...) (Tracker.cpp:1064-1120) gathers the
  * correspondences on the host -- keypoints with a VALID rectified left keypoint whose landmark id is in the map of
  * optimised landmarks handed over by Tracker::updateMap -- and calls this; the C++ adapter does the same
- * (kvfe::Tracker::pnp / updateMap in include/kvfe_adapter.hpp).  The step call itself does not run PnP: its result
+ * (kvfe::Tracker::pnp / updateMap in include/kvfe_adapter.hpp).  With use_pnp_tracking the step runs the same stage on
+ * the device against the map of kvfe_frontend_update_map and reports it in kvfe_frame_output; its result
  * (kfTracking_status_pnp_, W_T_k_pnp_) does not feed back into the keypoint state (VisionImuFrontend.cpp:163
- * "TODO remove outliers"), it is reported next to the mono / stereo results.
+ * "TODO remove outliers").
  * Implemented: pnp_algorithm 3 (EPNP: opengv AbsolutePoseSacProblem, 6 points per sample, fixed seed), the value
  * of every shipped parameter set but params/KinectAzure, and that one's pnp_algorithm 1 (KneipP3P: 3 + 1 points per
  * sample, closed-form quartic); the others return KVFE_ERR_UNSUPPORTED, and so does

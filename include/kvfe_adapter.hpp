@@ -601,6 +601,18 @@ class StereoVisionImuFrontend {
     c_.check(kvfe_frontend_get_output(c_.get(), stream, out), "getOutput");
   }
   void reset() { c_.check(kvfe_frontend_reset(c_.get()), "reset"); }
+  // Tracker::updateMap through the front-end (use_pnp_tracking: the step's outlierRejectionPnP reads this map)
+  void updateMap(int stream, const Tracker::LandmarksMap& lmks_map) {
+    std::vector<int64_t> ids;
+    std::vector<double> xyz;
+    ids.reserve(lmks_map.size());
+    xyz.reserve(3 * lmks_map.size());
+    for (const auto& it : lmks_map) {
+      ids.push_back(it.first);
+      xyz.insert(xyz.end(), it.second.begin(), it.second.end());
+    }
+    c_.check(kvfe_frontend_update_map(c_.get(), stream, ids.data(), xyz.data(), (int32_t)ids.size()), "updateMap");
+  }
 
  private:
   Context c_;
