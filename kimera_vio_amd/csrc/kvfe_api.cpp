@@ -123,6 +123,8 @@ struct kvfe_ctx {
   // matching of the tracked keypoints (its result is only needed by the newly detected ones)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
+  hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // main-stream part of the fork done / tail of the step (side stream) done
+  bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
   int prof_samples = 0;
@@ -175,6 +177,17 @@ struct DeviceGuard {
     if (switched) hipSetDevice(prev);
   }
 };
+
+// The last step's tail runs on the side stream (do_step); every entry point that reads or resets the front-end state
+// through the main stream joins it first, so that "main stream complete" means "step complete" for the caller.
+inline void join_tail(kvfe_ctx* c) {
+  if (c && c->tail_pending && c->stream) {
+    hipStreamWaitEvent(c->stream, c->ev_tail, 0);
+    c->tail_pending = false;
+  }
+  if (c)
+    for (kvfe_ctx* ch : c->children) join_tail(ch);
+}
 
 template <typename T>
 kvfe_status dalloc(kvfe_ctx* c, T** p, size_t n, bool zero = true) {
@@ -789,12 +802,12 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     b.ss.in_timestamp = reinterpret_cast<const long long*>(d + sizeof(double) * 9 * P.B);
     b.ss.in_force_kf = reinterpret_cast<const int*>(d + (sizeof(double) * 9 + sizeof(long long)) * P.B);
   }
-  struct SlotRelease {  // records the slot's event when do_step returns (all kernels enqueued)
-    kvfe_ctx* c;
+  struct SlotRelease {  // records the slot's event when do_step returns (all kernels enqueued), on the stream that
+    kvfe_ctx* c;        // runs the step's last kernels (the side stream when the step forks)
     int slot;
     hipStream_t st;
     ~SlotRelease() {
-      hipEventRecord(c->ring_ev[slot], st);
+      hipEventRecord(c->ring_ev[slot], c->tail_pending && c->side ? c->side : st);
       c->ring_used[slot] = true;
     }
   } slot_release{c, slot, st};
@@ -818,6 +831,12 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_PYRAMID, st);
   launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st, c->own_level0 ? b.lvl0[pc] : nullptr);
   prof_end(c, ST_PYRAMID, st);
+  // the previous step's tail (stereo matching of its new corners + its finalisation, on the side stream) is joined
+  // HERE: this step's pyramid does not depend on it and hides the cross-stream hand-over
+  if (c->tail_pending) {
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
+    c->tail_pending = false;
+  }
   prof_begin(c, ST_TRACK, st);
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
   if (c->prev_left)
@@ -891,7 +910,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SUBPIX, sd);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, sd);
   prof_end(c, ST_SUBPIX, sd);
-  if (c->side) HIPCHK(c, hipEventRecord(c->ev_join, sd));
   prof_begin(c, ST_RECTIFY, st);
   const unsigned char* srcs[2] = {left, right};
   launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st);
@@ -905,13 +923,23 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // outlierRejectionPnP(*stereoFrame_k_) (:389-399): after the stereo rejection, before detection
   if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, st);
   prof_end(c, ST_RANSAC_STEREO, st);
-  if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-  prof_begin(c, ST_STEREO_NEW, st);
-  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, st);
-  prof_end(c, ST_STEREO_NEW, st);
-  prof_begin(c, ST_FINALIZE, st);
-  launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, st);
-  prof_end(c, ST_FINALIZE, st);
+  // the tail -- stereo matching of the new corners, finalisation -- follows the corner refinement on ITS stream (no
+  // cross-stream hand-over on the critical path); the main stream's part of the fork is awaited there, the tail is
+  // joined by the next step after its pyramid (or by kvfe_synchronize / kvfe_frontend_get_output)
+  if (c->side) {
+    HIPCHK(c, hipEventRecord(c->ev_main, st));
+    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_main, 0));
+  }
+  prof_begin(c, ST_STEREO_NEW, sd);
+  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, sd);
+  prof_end(c, ST_STEREO_NEW, sd);
+  prof_begin(c, ST_FINALIZE, sd);
+  launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, sd);
+  prof_end(c, ST_FINALIZE, sd);
+  if (c->side) {
+    HIPCHK(c, hipEventRecord(c->ev_tail, sd));
+    c->tail_pending = true;
+  }
   HIPCHK(c, hipGetLastError());
 
   // stereoFrame_km1_ = stereoFrame_k_
@@ -1107,7 +1135,9 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_mono, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_mono, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess)
       s = KVFE_ERR_HIP;
   }
   if (s != KVFE_OK) {
@@ -1183,6 +1213,7 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (!c) return;
   for (kvfe_ctx* ch : c->children) kvfe_destroy(ch);
   c->children.clear();
+  if (c->side) hipStreamSynchronize(c->side);   // (the last step's tail lives there)
   if (c->stream) hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   for (int i = 0; i < kvfe_ctx::RING; i++)
@@ -1203,6 +1234,8 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mono) hipEventDestroy(c->ev_mono);
+  if (c->ev_main) hipEventDestroy(c->ev_main);
+  if (c->ev_tail) hipEventDestroy(c->ev_tail);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->dense_allocs) hipFree(p);
   for (int i = 0; i < 2; i++)
@@ -1221,6 +1254,7 @@ kvfe_status kvfe_get_rectification(const kvfe_ctx* c, kvfe_rectification* out) {
 
 kvfe_status kvfe_synchronize(kvfe_ctx* c) {
   DeviceGuard _dev(c);
+  join_tail(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children) TRY(kvfe_synchronize(ch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2039,6 +2073,7 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
   const long long dep = eq ? n - 1 : n - 2;
   if (n > 0 && !c->last_step_staged) {
     // the previous step went through another entry point: order the upload after everything enqueued
+    join_tail(c);
     HIPCHK(c, hipEventRecord(c->step_done[(n - 1) % 4], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->step_done[(n - 1) % 4], 0));
     c->step_done_valid[(n - 1) % 4] = true;
@@ -2067,6 +2102,7 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
 kvfe_status kvfe_frontend_update_map(kvfe_ctx* c, int32_t stream, const int64_t* landmark_ids, const double* xyz,
                                      int32_t n) {
   DeviceGuard _dev(c);
+  join_tail(c);
   if (!c || stream < 0 || stream >= c->P.B || n < 0 || (n > 0 && (!landmark_ids || !xyz))) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children)
     if (stream >= ch->s0 && stream < ch->s0 + ch->P.B)
@@ -2107,6 +2143,7 @@ kvfe_status kvfe_frontend_update_map(kvfe_ctx* c, int32_t stream, const int64_t*
 
 kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   DeviceGuard _dev(c);
+  join_tail(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) {
     for (kvfe_ctx* ch : c->children) {
@@ -2141,6 +2178,7 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
 
 kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {
   DeviceGuard _dev(c);
+  join_tail(c);
   if (!c || !out || s < 0 || s >= c->P.B || out->capacity < 0) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children)
     if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
@@ -2461,6 +2499,7 @@ kvfe_status kvfe_backproject_disparity_to_3d(kvfe_ctx* c, const float* disparity
 
 kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
   DeviceGuard _dev(c);
+  join_tail(c);
   if (!c) return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children) TRY(kvfe_profile_enable(ch, on));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2477,6 +2516,7 @@ kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
 
 kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
   DeviceGuard _dev(c);
+  join_tail(c);
   if (!c || !out) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) {  // launches of all groups: summed durations, mean bytes per launch
     std::memset(out, 0, sizeof(*out));
