@@ -253,7 +253,7 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
                                 "traffic": pmc_traffic(pmc_leg, name),
                                 "alg_bytes_per_launch": v["alg_bytes"], "avg_launch_ms": round(avg_ms, 5)})
                 if pmc_leg is not None and valu_ctx and name in PMC_NAMES and B == 64 and W == 752:
-                    vi = valu_issue(valu_ctx[0], PMC_NAMES[name][0], avg_ms / PMC_NAMES[name][1], valu_ctx[1], valu_ctx[2])
+                    vi = valu_issue(valu_ctx[0], PMC_NAMES[name][0], avg_ms, valu_ctx[1], valu_ctx[2])   # (all launches of the stage)
                     if vi:
                         kernels[-1]["valu_issue"] = vi
         kernels.sort(key=lambda r: -r["avg_launch_ms"])
