@@ -13,7 +13,10 @@
 // positions are bit-identical to the reference CPU front-end.
 #include "kvfe_dev.hpp"
 
+#include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace kvfe {
 
@@ -331,6 +334,25 @@ static size_t lk_generic_lds_bytes(int win) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 
+// -DKVFE_LK_PROF (tools/gpu_lk_prof.sh; never in the product build): cycle-counter deltas per phase of
+// lk_kernel_sys, summed over all waves of a launch and printed at exit
+#ifdef KVFE_LK_PROF
+constexpr int LKP_WAVES = 1 << 17, LKP_SLOTS = 12;
+__device__ unsigned long long kvfe_lk_prof[(size_t)LKP_WAVES * LKP_SLOTS];   // one record per wave: no contention
+#define LKP_DECL unsigned long long lkp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lkp_last = __builtin_readcyclecounter(); \
+  const unsigned long long lkp_t0 = __builtin_amdgcn_s_memrealtime(); unsigned lkp_iters = 0, lkp_stages = 0
+#if KVFE_LK_PROF == 2   // start / end of every wave only (the phase stamps cost a few per cent)
+#define LKP(i) do { } while (0)
+#else
+#define LKP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); lkp_acc[i] += t_ - lkp_last; lkp_last = t_; } while (0)
+#endif
+#define LKP_COUNT(v) (v)++
+#else
+#define LKP_DECL do { } while (0)
+#define LKP(i) do { } while (0)
+#define LKP_COUNT(v) do { } while (0)
+#endif
+
 __device__ __forceinline__ float dpp_row_shr1(float v) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
@@ -360,13 +382,31 @@ struct LkSys {
   static constexpr int JM = 3;              // margin of the staged current-level window
   static constexpr int JS = WIN + 1 + 2 * JM;   // staged rows; JS-1 pair columns
   static constexpr int JSTR = ((JS - 1 - 1 + 15) / 16) * 16 + 1;  // == 1 (mod 16): conflict free
-  static constexpr int PATCH_B = (WS * WS + 3) & ~3;
-  static constexpr int DXY_W = WP * WP;
-  static constexpr int LDS_BYTES = PATCH_B + 4 * DXY_W + 4 * JS * JSTR;
+  static constexpr int PSTR = (WS + 3) & ~3;   // byte patch row stride: rows start on a dword
+  static constexpr int NT = (WP + 3) / 4;       // derivative tasks per row (4 outputs each)
+  static constexpr int DSTR = (4 * NT) | 1;     // derivative patch row stride (odd: spread over the banks)
+  static constexpr int NJ = (JS - 1 + 3) / 4;   // pair-staging tasks per row (4 pairs each)
+  static constexpr int PATCH_B = WS * PSTR;
+  static constexpr int DXY_W = WP * DSTR;
+  // the derivative patch is dead once the template registers are filled: the pair window of the iterations aliases it
+  static constexpr int LDS_BYTES = PATCH_B + 4 * (DXY_W > JS * JSTR ? DXY_W : JS * JSTR);
+  static_assert(WP == 4 * (NT - 1) + 1, "last derivative task holds exactly one output");
+  static_assert(JS - 1 == 4 * (NJ - 1) + 2 && 4 * NJ <= JSTR, "last pair task holds exactly two pairs");
 };
 
+typedef int int_u __attribute__((aligned(1)));              // dword at any byte address
+typedef unsigned short ushort_u __attribute__((aligned(1)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2us as_v2us(int v) { return __builtin_bit_cast(v2us, v); }
+__device__ __forceinline__ int as_i32(v2us v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ int perm_b32(int hi, int lo, unsigned sel) {
+  return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, sel);
+}
+
+// six waves per SIMD up to the reference's window of 24 (80 VGPRs without spilling, 4.8 KB of LDS per point); a window
+// of 32 keeps 16 pixels per lane in registers and stays at five
 template <int WIN>
-__global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned char* prev_img,
+__global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams P, const unsigned char* prev_img,
                                                     size_t prev_row_stride,
                                                     size_t prev_img_stride,
                                                     const unsigned char* prev_pyr,
@@ -375,7 +415,8 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
                                                     const unsigned char* cur_pyr, LkScratch lk) {
   using C = LkSys<WIN>;
   constexpr int NC = C::NC, NQ = C::NQ, NPX = C::NPX, NST = C::NST, WS = C::WS, WP = C::WP,
-                JM = C::JM, JS = C::JS, JSTR = C::JSTR;
+                JM = C::JM, JS = C::JS, JSTR = C::JSTR, PSTR = C::PSTR, NT = C::NT, DSTR = C::DSTR,
+                NJ = C::NJ;
   const int s = blockIdx.y, pt = blockIdx.x;
   if (pt >= lk.npts[s]) return;
   const int lane = threadIdx.x;
@@ -386,7 +427,7 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
   __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
   unsigned char* patch = lds;                                            // WS x WS bytes
   int* dxy = reinterpret_cast<int*>(lds + C::PATCH_B);                   // WP x WP (dx | dy << 16)
-  int* jp = dxy + C::DXY_W;                                              // JS x JSTR pixel pairs
+  int* jp = dxy;                                                         // JS x JSTR pixel pairs (over dxy)
 
   const unsigned char* pimg = prev_img + (size_t)s * prev_img_stride;
   const unsigned char* cimg = cur_img + (size_t)s * cur_img_stride;
@@ -405,8 +446,10 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
   const double klt_eps2 = P.klt_eps2;
   // window offset of this lane's first pixel (row 2q, column g)
   const int y0w = 2 * qa, x0w = g;
+  LKP_DECL;
 
   for (int level = maxLevel; level >= 0; level--) {
+    LKP(7);
     const LevelImg LI = level_img(P, pimg, prev_row_stride, ppyr, level);
     const LevelImg LJ = level_img(P, cimg, cur_row_stride, cpyr, level);
     const float lscale = (float)(1. / (1 << level));
@@ -434,40 +477,78 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
     int wq0 = pack_lo16(iw00, iw01), wq1 = pack_lo16(iw10, iw11);
 
     __syncthreads();  // previous level's readers of patch / dxy / jp are done
-    // stage the (WIN+3)^2 neighbourhood of the previous level (REFLECT_101 padded image)
-    {
-      const bool interior = ipx - 1 >= 0 && ipy - 1 >= 0 && ipx - 1 + WS <= LI.w && ipy - 1 + WS <= LI.h;
-      if (interior) {
-        const unsigned char* base = LI.p + (size_t)(ipy - 1) * LI.stride + (ipx - 1);
-        for (int e = lane; e < WS * WS; e += 64) {
-          const int py = e / WS, px = e - py * WS;
-          patch[e] = base[(size_t)py * LI.stride + px];
-        }
-      } else {
-        for (int e = lane; e < WS * WS; e += 64) {
-          const int py = e / WS, px = e - py * WS;
-          patch[e] = (unsigned char)at101(LI, ipx - 1 + px, ipy - 1 + py);
+    LKP(0);
+    // The (WIN+3)^2 byte neighbourhood of the previous level (REFLECT_101 padded image) and the Scharr derivative
+    // at the (WIN+1)^2 window positions (zero outside the image: BORDER_CONSTANT).
+    if (ipx - 1 >= 0 && ipy - 1 >= 0 && ipx - 1 + 4 * NT <= LI.w && ipy - 1 + WS <= LI.h) {
+      // Interior window: one task = four horizontally adjacent derivative positions (x = 4t .. 4t+3 of row y),
+      // read as three rows of 6 bytes straight from the image (dword loads at byte addresses), the vertical
+      // passes of the separable filter in packed 16-bit arithmetic on column pairs; the middle row doubles as the
+      // byte patch of the template gather.  Every sum stays below 2^12 in magnitude: exact.
+      const unsigned char* base = LI.p + (size_t)(ipy - 1) * LI.stride + (ipx - 1);
+#pragma unroll 1
+      for (int it = 0; it < (WP * NT + 63) / 64; it++) {
+        const int e = lane + 64 * it;
+        const int y = e / NT, t = e - y * NT;
+        if (y < WP) {
+          // (the last task of a row holds one output and needs its first three bytes only: its second dword,
+          // which would reach past the window, is a repeat of the first and feeds outputs nobody reads)
+          const unsigned char* r = base + (size_t)y * LI.stride + 4 * t;
+          const int hoff = t < NT - 1 ? 4 : 0;
+          int lo[3], hi[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            lo[k] = *reinterpret_cast<const int_u*>(r + (size_t)k * LI.stride);
+            hi[k] = *reinterpret_cast<const int_u*>(r + (size_t)k * LI.stride + hoff);
+          }
+          *reinterpret_cast<int*>(patch + (y + 1) * PSTR + 4 * t) = lo[1];
+          v2us c01[3], c23[3], c45[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            c01[k] = as_v2us(perm_b32(0, lo[k], 0x0c010c00u));
+            c23[k] = as_v2us(perm_b32(0, lo[k], 0x0c030c02u));
+            c45[k] = as_v2us(perm_b32(0, hi[k], 0x0c010c00u));
+          }
+          const v2us k3 = {3, 3}, k10 = {10, 10};
+          const v2us s01 = (c01[0] + c01[2]) * k3 + c01[1] * k10, s23 = (c23[0] + c23[2]) * k3 + c23[1] * k10,
+                     s45 = (c45[0] + c45[2]) * k3 + c45[1] * k10;
+          const v2us d01 = c01[2] - c01[0], d23 = c23[2] - c23[0], d45 = c45[2] - c45[0];
+          const v2us vx12 = s23 - s01, vx34 = s45 - s23;
+          const v2us m12 = as_v2us(perm_b32(as_i32(d23), as_i32(d01), 0x05040302u));
+          const v2us m34 = as_v2us(perm_b32(as_i32(d45), as_i32(d23), 0x05040302u));
+          const v2us vy12 = (d01 + d23) * k3 + m12 * k10, vy34 = (d23 + d45) * k3 + m34 * k10;
+          int* o = dxy + y * DSTR + 4 * t;
+          o[0] = pack_lo16(as_i32(vx12), as_i32(vy12));
+          o[1] = pack_hi16(as_i32(vx12), as_i32(vy12));
+          o[2] = pack_lo16(as_i32(vx34), as_i32(vy34));
+          o[3] = pack_hi16(as_i32(vx34), as_i32(vy34));
         }
       }
-    }
-    __syncthreads();
-    // Scharr derivative at the (WIN+1)^2 positions; zero outside the image (BORDER_CONSTANT)
-    for (int e = lane; e < WP * WP; e += 64) {
-      const int y = e / WP, x = e - y * WP;
-      const int gx = ipx + x, gy = ipy + y;
-      int vx = 0, vy = 0;
-      if (gx >= 0 && gx < LI.w && gy >= 0 && gy < LI.h) {
-        const unsigned char* r0 = patch + y * WS + x;  // row gy-1, col gx-1
-        const unsigned char* r1 = r0 + WS;
-        const unsigned char* r2 = r1 + WS;
-        const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
-        const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
-        vx = t0p - t0m;
-        vy = (t1p + t1m) * 3 + t1c * 10;
+      __syncthreads();
+    } else {
+      for (int e = lane; e < WS * WS; e += 64) {
+        const int py = e / WS, px = e - py * WS;
+        patch[py * PSTR + px] = (unsigned char)at101(LI, ipx - 1 + px, ipy - 1 + py);
       }
-      dxy[e] = pack_lo16(vx, vy);
+      __syncthreads();
+      for (int e = lane; e < WP * WP; e += 64) {
+        const int y = e / WP, x = e - y * WP;
+        const int gx = ipx + x, gy = ipy + y;
+        int vx = 0, vy = 0;
+        if (gx >= 0 && gx < LI.w && gy >= 0 && gy < LI.h) {
+          const unsigned char* r0 = patch + y * PSTR + x;  // row gy-1, col gx-1
+          const unsigned char* r1 = r0 + PSTR;
+          const unsigned char* r2 = r1 + PSTR;
+          const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
+          const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
+          vx = t0p - t0m;
+          vy = (t1p + t1m) * 3 + t1c * 10;
+        }
+        dxy[y * DSTR + x] = pack_lo16(vx, vy);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    LKP(1);
     // bilinear template and derivative window of this lane's pixels -> registers
     int rI[NPX], rgxy[NPX];  // rgxy = (Ix & 0xffff) | (Iy << 16)
 #pragma unroll
@@ -476,11 +557,12 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
       for (int m = 0; m < NC; m++) {
         const int k = r * NC + m;
         const int y = y0w + r, x = x0w + 4 * m;
-        const unsigned char* s0 = patch + (y + 1) * WS + (x + 1);
-        const int p0 = (int)s0[0] | ((int)s0[1] << 16), p1 = (int)s0[WS] | ((int)s0[WS + 1] << 16);
+        const unsigned char* s0 = patch + (y + 1) * PSTR + (x + 1);
+        const int p0 = perm_b32(0, *reinterpret_cast<const ushort_u*>(s0), 0x0c010c00u);
+        const int p1 = perm_b32(0, *reinterpret_cast<const ushort_u*>(s0 + PSTR), 0x0c010c00u);
         const int ival = dot2_i16(p0, wq0, dot2_i16(p1, wq1, 1 << 8)) >> 9;
-        const int* d = dxy + y * WP + x;
-        const int d00 = d[0], d01 = d[1], d10 = d[WP], d11 = d[WP + 1];
+        const int* d = dxy + y * DSTR + x;
+        const int d00 = d[0], d01 = d[1], d10 = d[DSTR], d11 = d[DSTR + 1];
         const int ixval =
             dot2_i16(pack_lo16(d00, d01), wq0, dot2_i16(pack_lo16(d10, d11), wq1, 1 << 13)) >> 14;
         const int iyval =
@@ -488,6 +570,7 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
         rI[k] = active ? sat16(ival) : 0;
         rgxy[k] = active ? pack_lo16(sat16(ixval), sat16(iyval)) : 0;
       }
+    LKP(2);
     // A11/A12/A22 chains (SSE lane l = g; order: row, then column chunk)
     float A11, A12, A22;
     {
@@ -532,6 +615,7 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
       continue;
     }
     D = 1.f / D;
+    LKP(3);
 
     nextPt.x -= halfWin;
     nextPt.y -= halfWin;
@@ -543,13 +627,26 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
       jx0 = inx - JM;
       jy0 = iny - JM;
       __syncthreads();
-      const bool interior = jx0 >= 0 && jy0 >= 0 && jx0 + JS <= LJ.w && jy0 + JS <= LJ.h;
+      LKP(5);
+      LKP_COUNT(lkp_stages);
+      const bool interior = jx0 >= 0 && jy0 >= 0 && jx0 + 4 * NJ <= LJ.w && jy0 + JS <= LJ.h;
       if (interior) {
+        // one task = four pairs of a row out of five bytes (two dword loads at byte addresses)
         const unsigned char* base = LJ.p + (size_t)jy0 * LJ.stride + jx0;
-        for (int e = lane; e < JS * (JS - 1); e += 64) {
-          const int yy = e / (JS - 1), xx = e - yy * (JS - 1);
-          const unsigned char* r = base + (size_t)yy * LJ.stride + xx;
-          jp[yy * JSTR + xx] = (int)r[0] | ((int)r[1] << 16);
+#pragma unroll 1
+        for (int it = 0; it < (JS * NJ + 63) / 64; it++) {
+          const int e = lane + 64 * it;
+          const int yy = e / NJ, i = e - yy * NJ;
+          if (yy < JS) {
+            const unsigned char* r = base + (size_t)yy * LJ.stride + 4 * i;
+            const int lo = *reinterpret_cast<const int_u*>(r);
+            const int hi = *reinterpret_cast<const int_u*>(r + (i < NJ - 1 ? 4 : 0));  // last task: two pairs, lo only
+            int* o = jp + yy * JSTR + 4 * i;
+            o[0] = perm_b32(hi, lo, 0x0c010c00u);
+            o[1] = perm_b32(hi, lo, 0x0c020c01u);
+            o[2] = perm_b32(hi, lo, 0x0c030c02u);
+            o[3] = perm_b32(hi, lo, 0x0c040c03u);
+          }
         }
       } else {
         for (int e = lane; e < JS * (JS - 1); e += 64) {
@@ -560,8 +657,11 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
       }
       __syncthreads();
       jvalid = true;
+      LKP(4);
     };
     for (int j = 0; j < klt_iters; j++) {
+      LKP(5);
+      LKP_COUNT(lkp_iters);
       const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
       if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
         if (level == 0) status = 0;
@@ -629,6 +729,7 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
       }
       prevDelta = delta;
     }
+    LKP(5);
 
     if (status && level == 0) {
       const float2 np = make_float2(nextOut.x - halfWin, nextOut.y - halfWin);
@@ -657,12 +758,26 @@ __global__ __launch_bounds__(64) void lk_kernel_sys(KParams P, const unsigned ch
         }
       for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
       errOut = (float)esum * 1.f / (float)(32 * WIN * WIN);
+      LKP(6);
     }
   }
   if (lane == 0) {
     lk.next_pts[po] = nextOut;
     lk.status[po] = (unsigned char)status;
     lk.err[po] = errOut;
+#ifdef KVFE_LK_PROF
+    const size_t wid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;   // (dispatch order)
+    if (wid < (size_t)LKP_WAVES) {
+      unsigned long long* o = kvfe_lk_prof + wid * LKP_SLOTS;
+      for (int i = 0; i < 8; i++) o[i] = lkp_acc[i];
+      o[8] = 1ull;
+      o[9] = lkp_iters;
+      o[10] = lkp_stages;
+      o[11] = lkp_t0;                                 // 100 MHz device-wide clock
+      o[7] += 0;
+      o[8] = 1ull | (__builtin_amdgcn_s_memrealtime() - lkp_t0) << 8;   // wave lifetime in 10 ns ticks
+    }
+#endif
   }
 }
 
@@ -1092,6 +1207,100 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                          cur_row_stride, cur_img_stride, cur_pyr, lk);
   }
 #undef KVFE_LK_SYS
+#ifdef KVFE_LK_PROF
+  {
+    static double h[LKP_SLOTS];
+    static std::vector<unsigned long long> buf((size_t)LKP_WAVES * LKP_SLOTS);
+    static double wmax = 0;
+    static bool reg = false;
+    void* dev = nullptr;
+    hipGetSymbolAddress(&dev, HIP_SYMBOL(kvfe_lk_prof));
+    hipStreamSynchronize(st);
+    hipMemcpy(buf.data(), dev, buf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipMemset(dev, 0, buf.size() * sizeof(unsigned long long));
+    static double tl[8], ithist[8];   // timeline of the launch: when 50 / 90 / 99 / 100 % of the waves have ended
+    static long nl = 0;
+    std::vector<double> ends;
+    double t_first = 1e300;
+    for (size_t w = 0; w < (size_t)LKP_WAVES; w++) {
+      const unsigned long long* o = buf.data() + w * LKP_SLOTS;
+      if (!o[8]) continue;
+      double tot = 0;
+      for (int i = 0; i < 8; i++) tot += (double)o[i];
+      if (tot > wmax) wmax = tot;
+      for (int i = 0; i < 11; i++) h[i] += i == 8 ? 1.0 : (double)o[i];
+      if ((double)o[11] < t_first) t_first = (double)o[11];
+      ends.push_back((double)o[11] + (double)(o[8] >> 8));
+      const int it = (int)o[9];
+      ithist[it <= 3 ? 0 : it <= 6 ? 1 : it <= 12 ? 2 : it <= 24 ? 3 : it <= 48 ? 4 : 5] += 1;
+    }
+    if (!ends.empty() && nl == 5) {   // one launch in detail: resident waves and mean lifetime along the launch
+      std::vector<std::pair<double, double>> se;
+      for (size_t w = 0; w < (size_t)LKP_WAVES; w++) {
+        const unsigned long long* o = buf.data() + w * LKP_SLOTS;
+        if (o[8]) se.push_back({(double)o[11] - t_first, (double)(o[8] >> 8)});
+      }
+      double t_end = 0, t_last_start = 0, life_sum = 0;
+      for (auto& e : se) {
+        t_end = std::max(t_end, e.first + e.second);
+        t_last_start = std::max(t_last_start, e.first);
+        life_sum += e.second;
+      }
+      {
+        std::vector<double> lf;
+        for (auto& e : se) lf.push_back(e.second);
+        std::sort(lf.begin(), lf.end());
+        std::fprintf(stderr, "KVFE_LK_PROF one launch: last wave started at %.0f, lifetimes (10 ns): mean %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f; ten longest waves [start, lifetime]:",
+                     t_last_start, life_sum / se.size(), lf[lf.size() / 2], lf[lf.size() * 9 / 10], lf[lf.size() * 99 / 100], lf[lf.size() * 999 / 1000], lf.back());
+        std::vector<std::pair<double, double>> by = se;
+        std::sort(by.begin(), by.end(), [](const std::pair<double, double>& a, const std::pair<double, double>& b) { return a.second > b.second; });
+        for (int k = 0; k < 10 && k < (int)by.size(); k++) std::fprintf(stderr, " [%.0f, %.0f]", by[k].first, by[k].second);
+        std::fprintf(stderr, "\n");
+      }
+      std::fprintf(stderr, "KVFE_LK_PROF one launch, %zu waves, %.0f ticks of 10 ns: [t: resident waves, mean lifetime of the waves started in the slice]",
+                   se.size(), t_end);
+      for (int k = 0; k < 20; k++) {
+        const double t0 = t_end * k / 20, t1 = t_end * (k + 1) / 20, tm = 0.5 * (t0 + t1);
+        int res = 0, ns = 0;
+        double life = 0;
+        for (auto& e : se) {
+          if (e.first <= tm && tm < e.first + e.second) res++;
+          if (e.first >= t0 && e.first < t1) { ns++; life += e.second; }
+        }
+        std::fprintf(stderr, " [%.0f: %d, %d started, %.0f]", tm, res, ns, ns ? life / ns : 0.0);
+      }
+      std::fprintf(stderr, "\n");
+    }
+    if (!ends.empty()) {
+      std::sort(ends.begin(), ends.end());
+      const size_t n = ends.size();
+      tl[0] += ends[n / 2] - t_first;
+      tl[1] += ends[n * 9 / 10] - t_first;
+      tl[2] += ends[n * 99 / 100] - t_first;
+      tl[3] += ends[n - 1] - t_first;
+      tl[4] += ends[n * 999 / 1000] - t_first;
+      nl++;
+    }
+    if (!reg) {
+      reg = true;
+      std::atexit([] {
+        const double n = h[8] ? h[8] : 1.0;
+        std::fprintf(stderr,
+                     "KVFE_LK_PROF waves %.0f  cycles per wave: level-header %.0f  patch+scharr %.0f  gather %.0f  "
+                     "A-chains %.0f  stage_j %.0f  iterations %.0f  err %.0f  between-levels %.0f  (slowest wave %.0f) | "
+                     "iterations %.2f stage_j calls %.2f\n",
+                     h[8], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n, wmax,
+                     h[9] / n, h[10] / n);
+        std::fprintf(stderr,
+                     "KVFE_LK_PROF launch timeline (10 ns ticks after the first wave started): 50 %% of the waves ended by "
+                     "%.0f, 90 %% by %.0f, 99 %% by %.0f, 99.9 %% by %.0f, all by %.0f | iterations per wave (3 levels): <=3 %.3f  <=6 "
+                     "%.3f  <=12 %.3f  <=24 %.3f  <=48 %.3f  more %.3f\n",
+                     tl[0] / nl, tl[1] / nl, tl[2] / nl, tl[4] / nl, tl[3] / nl, ithist[0] / n, ithist[1] / n, ithist[2] / n,
+                     ithist[3] / n, ithist[4] / n, ithist[5] / n);
+      });
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@ from . import _abi as abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libkvfe.so")
+# KVFE_LIB: another build of the same library (A/B timing of kernel variants on one GPU box)
+SO_PATH = os.environ.get("KVFE_LIB") or os.path.join(CSRC, "libkvfe.so")
 
 _lib = None
 
