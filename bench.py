@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALL_LEGS = ("nominal", "single_stream", "c5", "dense", "dense_c5", "pcie", "cpu")
+ALL_LEGS = ("nominal", "single_stream", "c5", "dense", "dense_c5", "pcie", "input", "cpu")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -263,8 +263,11 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
         if pmc_leg is not None and valu_ctx and B == 64 and W == 752 and "lk_track" in stages:
             lk_ms = stages["lk_track"]["ms_total"] / ns
             vi = valu_issue(valu_ctx[0], "lk_kernel", lk_ms, valu_ctx[1], valu_ctx[2])
-            if vi:   # the largest kernel of the step is sparse (no HBM roofline): its bound is VALU issue
-                res["largest_kernel"] = {"kernel": "lk_track", "avg_launch_ms": round(lk_ms, 5), "bound": "valu issue",
+            if vi:   # the largest kernel of the step is sparse (no HBM roofline); its VALU issue floor is reported, but the
+                # launch is NOT bound by it: 26 % fewer instructions left the time unchanged (profiles/r2_v5_lk_analysis.md)
+                res["largest_kernel"] = {"kernel": "lk_track", "avg_launch_ms": round(lk_ms, 5),
+                                         "bound": "per-CU memory-instruction path + tail of non-converging points "
+                                                  "(75-80 waves/us whatever the occupancy; profiles/r2_v5_lk_analysis.md)",
                                          "valu_issue": vi}
         res["stream_groups"] = g
     return res
@@ -365,6 +368,8 @@ def main():
         result["dense_stereo_c5"] = dense_stereo(F, WL, 1280, 720, dev, pmc.get("dense_c5"))
     if solo and "pcie" in args.legs and args.config == "c3":
         result["pcie_inclusive"] = pcie_inclusive(F, wl)
+    if solo and "input" in args.legs:
+        result["input_side"] = input_side()
     if solo and "cpu" in args.legs:
         result["cpu_baseline"] = cpu_baseline(wl, args)
     if rank == 0:
@@ -400,6 +405,40 @@ def dry_run(args, dist, sharding, WL, rank, world):
                           "scaling": "strong" if args.config == "c4" else "weak", "ranks": gathered}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def input_side():
+    """SURVEY 8 f3, host side: PNG -> grey decode rate of the data provider (kvfe_png_decode_gray_batch into one
+    buffer per frame, the role of the pinned staging slots) on the committed 752x480 EuRoC frames, one host thread and
+    all of them, ~1 s each; PIL's decoder on one thread beside it.  Host code: no GPU time, never part of `value`."""
+    import io
+    from kimera_vio_amd import dataprovider as DP
+    files = []
+    for name in ("left_img_0.png", "right_img_0.png"):
+        with open(os.path.join(ROOT, "tests", "golden", name), "rb") as f:
+            files.append(f.read())
+    files = files * 32
+    out = np.empty((len(files), 480, 752), np.uint8)
+    DP.decode_png_gray_batch(files[:2], out[:2], 1)
+    res = {"workload": "64 PNG files per call (32 x tests/golden/{left,right}_img_0.png, 752x480 8-bit grey, "
+                       "362 kB each)", "unit": "frames/s", "host_cores": os.cpu_count()}
+    for key, threads in (("decode_1_thread", 1), ("decode_all_threads", 0)):
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 1.0:
+            DP.decode_png_gray_batch(files, out, threads)
+            n += len(files)
+        res[key] = round(n / (time.perf_counter() - t0), 1)
+    try:
+        from PIL import Image
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.5:
+            np.asarray(Image.open(io.BytesIO(files[n % 2])))
+            n += 1
+        res["pil_1_thread"] = round(n / (time.perf_counter() - t0), 1)
+    except ImportError:
+        res["pil_1_thread"] = None
+    res["stereo_pairs_per_s_all_threads"] = round(res["decode_all_threads"] / 2.0, 1)
+    return res
 
 
 def pcie_inclusive(F, wl):

@@ -700,6 +700,120 @@ KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,
                                               kvfe_frame_output* out);
 
 /* ------------------------------------------------------------------------- */
+/* Input side: what sits between the dataset / sensor and    */
+/* kvfe_frontend_step_*.  Host code (no device work): the data provider runs */
+/* on CPU threads next to the GPU steps, as upstream's does.                  */
+/* ------------------------------------------------------------------------- */
+
+/* UtilsOpenCV::ReadAndConvertToGrayScale without the equalisation (src/utils/UtilsOpenCV.cpp:390-399; the
+ * equalisation is kvfe_equalize_hist / stereo_matching.equalize_image): cv::imread(IMREAD_ANYCOLOR) of PNG data
+ * (8-bit result: 16-bit samples keep their high byte, 1/2/4-bit grey is expanded, alpha dropped, palettes
+ * resolved, Adam7 supported) followed by cv::cvtColor(BGR2GRAY) when the file has colour (15-bit BT.601 weights
+ * 9798 / 19235 / 3735 of OpenCV 4).  EuRoC frames are 8-bit grey PNGs (EurocDataProvider.cpp:172-188).
+ * kvfe_png_info reads the header only.  Errors: KVFE_ERR_INVALID_ARG (not a PNG / corrupt / CRC mismatch /
+ * size mismatch), KVFE_ERR_UNSUPPORTED (a PNG feature outside the list above). */
+KVFE_API kvfe_status kvfe_png_info(const uint8_t* data, size_t size, int32_t* width, int32_t* height,
+                                   int32_t* channels);
+KVFE_API kvfe_status kvfe_png_decode_gray(const uint8_t* data, size_t size, uint8_t* dst, size_t dst_stride,
+                                          int32_t width, int32_t height);
+/* n files by `threads` host threads (<= 0: one per file, at most the hardware concurrency) straight into the
+ * caller's buffers -- typically the pinned staging slot of kvfe_frontend_staging_buffer.  status[i] per file
+ * (may be NULL); returns the first failure. */
+KVFE_API kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t* sizes,
+                                                uint8_t* const* dst, size_t dst_stride, int32_t width,
+                                                int32_t height, int32_t n, int32_t threads,
+                                                kvfe_status* status);
+
+/* utils::ThreadsafeImuBuffer (include/kimera-vio/utils/ThreadsafeImuBuffer.h:46-196, src/utils/
+ * ThreadsafeImuBuffer.cpp:48-234 over ThreadsafeTemporalBuffer-inl.h): a time-ordered map of (acc, gyro)
+ * samples, thread safe.  Query results keep the upstream enum values. */
+enum {
+  KVFE_IMU_DATA_AVAILABLE = 0,            /* kDataAvailable                */
+  KVFE_IMU_DATA_NOT_YET_AVAILABLE = 1,    /* kDataNotYetAvailable          */
+  KVFE_IMU_DATA_NEVER_AVAILABLE = 2,      /* kDataNeverAvailable           */
+  KVFE_IMU_QUEUE_SHUTDOWN = 3,            /* kQueueShutdown                */
+  KVFE_IMU_TOO_FEW_MEASUREMENTS = 4       /* kTooFewMeasurementsAvailable  */
+};
+typedef struct kvfe_imu_buffer kvfe_imu_buffer;
+/* buffer_length_ns <= 0: unbounded (ThreadsafeImuBuffer(-1)) */
+KVFE_API kvfe_imu_buffer* kvfe_imu_buffer_create(int64_t buffer_length_ns);
+KVFE_API void kvfe_imu_buffer_destroy(kvfe_imu_buffer* b);
+/* addMeasurement: acc_gyr = (ax ay az wx wy wz), "Acceleration first!" (EurocDataProvider.cpp:265-267) */
+KVFE_API void kvfe_imu_buffer_add(kvfe_imu_buffer* b, int64_t timestamp_ns, const double acc_gyr[6]);
+KVFE_API int64_t kvfe_imu_buffer_size(const kvfe_imu_buffer* b);
+KVFE_API void kvfe_imu_buffer_shutdown(kvfe_imu_buffer* b);
+/* getImuDataBtwTimestamps / getImuDataInterpolatedUpperBorder / getImuDataInterpolatedBorders.
+ * stamps[capacity], acc_gyr[6 * capacity] (column k = sample k, as ImuAccGyrS); *n = samples written
+ * (0 unless the result is KVFE_IMU_DATA_AVAILABLE).  Returns the query result, or -1 when `capacity` is
+ * too small (*n = the count needed). */
+KVFE_API int32_t kvfe_imu_buffer_between(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to,
+                                         int32_t get_lower_bound, int64_t* stamps, double* acc_gyr,
+                                         int32_t capacity, int32_t* n);
+KVFE_API int32_t kvfe_imu_buffer_interpolated_upper_border(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to,
+                                                           int64_t* stamps, double* acc_gyr,
+                                                           int32_t capacity, int32_t* n);
+KVFE_API int32_t kvfe_imu_buffer_interpolated_borders(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to,
+                                                      int64_t* stamps, double* acc_gyr, int32_t capacity,
+                                                      int32_t* n);
+/* ThreadsafeImuBuffer::linearInterpolate */
+KVFE_API void kvfe_imu_linear_interpolate(int64_t t0, const double y0[6], int64_t t1, const double y1[6],
+                                          int64_t t, double y[6]);
+
+/* StereoDataProviderModule::getInputPacket (src/dataprovider/StereoDataProviderModule.cpp:35-91) over
+ * MonoDataProviderModule::getMonoImuSyncPacket (MonoDataProviderModule.cpp:44-118), DataProviderModule::
+ * getTimeSyncedImuMeasurements (DataProviderModule.cpp:80-181) and SimpleQueueSynchronizer::syncQueue
+ * (pipeline/QueueSynchronizer.h:79-162): left / right frame queues and the IMU buffer in, one
+ * StereoImuSyncPacket out.  Frames are (timestamp, caller tag): the images stay with the caller (e.g. in a
+ * staging slot), the packet says which left / right tags belong together and carries the IMU samples between
+ * the previous packet's frame and this one, borders interpolated.  The decision logic is upstream's; where
+ * upstream blocks on a queue (parallel_run) this returns KVFE_SYNC_EMPTY / KVFE_SYNC_WAIT_* and the caller
+ * calls again after pushing more data. */
+enum {
+  KVFE_SYNC_PACKET = 0,               /* a packet was written                                              */
+  KVFE_SYNC_EMPTY = 1,                /* no left frame queued                                              */
+  KVFE_SYNC_WAIT_IMU = 2,             /* FrameAction::Wait: IMU data up to the frame not there yet; the left
+                                         frame is cached and retried by the next call                      */
+  KVFE_SYNC_DROP_OUT_OF_ORDER = 3,    /* left timestamp <= the last packet's                               */
+  KVFE_SYNC_DROP_NO_IMU = 4,          /* IMU buffer empty                                                  */
+  KVFE_SYNC_DROP_FIRST_FRAME = 5,     /* "Skipping first frame": it only sets the previous-frame timestamp */
+  KVFE_SYNC_DROP_IMU_NEVER = 6,       /* kDataNeverAvailable (the frame becomes the previous frame)        */
+  KVFE_SYNC_DROP_IMU_TOO_FEW = 7,     /* kTooFewMeasurementsAvailable                                      */
+  KVFE_SYNC_DROP_NO_RIGHT = 8,        /* "Missing right frame for left frame": right queue empty or ahead  */
+  KVFE_SYNC_SHUTDOWN = 9
+};
+typedef struct kvfe_stereo_sync kvfe_stereo_sync;
+typedef struct kvfe_sync_packet {
+  int64_t timestamp_ns;
+  int64_t left_tag, right_tag;
+  int32_t n_imu;                      /* samples written to the caller's arrays */
+  int32_t reserved0;
+} kvfe_sync_packet;
+KVFE_API kvfe_stereo_sync* kvfe_stereo_sync_create(int64_t imu_buffer_length_ns);
+KVFE_API void kvfe_stereo_sync_destroy(kvfe_stereo_sync* s);
+KVFE_API void kvfe_stereo_sync_fill_left(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag);
+KVFE_API void kvfe_stereo_sync_fill_right(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag);
+KVFE_API void kvfe_stereo_sync_fill_imu(kvfe_stereo_sync* s, int64_t timestamp_ns, const double acc_gyr[6]);
+/* DataProviderModule::doCoarseImuCameraTemporalSync / setImuTimeShift (DataProviderModule.h:106-119) */
+KVFE_API void kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync(kvfe_stereo_sync* s);
+KVFE_API void kvfe_stereo_sync_set_imu_time_shift(kvfe_stereo_sync* s, double imu_time_shift_s);
+KVFE_API void kvfe_stereo_sync_shutdown(kvfe_stereo_sync* s);
+/* one getInputPacket(): returns KVFE_SYNC_*; imu_stamps[capacity], imu_acc_gyr[6 * capacity] as above
+ * (-1 when capacity is too small: nothing is consumed, packet->n_imu = the count needed) */
+KVFE_API int32_t kvfe_stereo_sync_next(kvfe_stereo_sync* s, kvfe_sync_packet* packet, int64_t* imu_stamps,
+                                       double* imu_acc_gyr, int32_t capacity);
+
+/* EuRoC index files (CameraImageLists::parseCamImgList, DataProviderInterface-definitions.cpp:74-101;
+ * EurocDataProvider::parseImuData, EurocDataProvider.cpp:229-306): the text of mav0/camN/data.csv gives the
+ * frame timestamps (the image is <folder>/data/<timestamp>.png), the text of mav0/imu0/data.csv the IMU
+ * samples, re-ordered acceleration first.  Both skip the header line; *n = rows found; returns
+ * KVFE_ERR_CAPACITY when the arrays are too small (then *n = rows needed), KVFE_ERR_INVALID_ARG on a
+ * malformed row or IMU timestamps that are not increasing. */
+KVFE_API kvfe_status kvfe_euroc_parse_camera_csv(const char* text, size_t size, int64_t* timestamps,
+                                                 int32_t capacity, int32_t* n);
+KVFE_API kvfe_status kvfe_euroc_parse_imu_csv(const char* text, size_t size, int64_t* timestamps,
+                                              double* acc_gyr, int32_t capacity, int32_t* n);
+
+/* ------------------------------------------------------------------------- */
 /* measurement hooks (bench.py): HIP-event timing on the context's stream    */
 /* ------------------------------------------------------------------------- */
 #define KVFE_N_STAGES 16

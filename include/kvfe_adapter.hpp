@@ -11,6 +11,9 @@
 //   Tracker                include/kimera-vio/frontend/Tracker.h:70-74
 //   StereoMatcher          include/kimera-vio/frontend/StereoMatcher.h:49-92
 //   StereoVisionImuFrontend include/kimera-vio/frontend/StereoVisionImuFrontend.h (spinOnce path)
+//   utils::ThreadsafeImuBuffer include/kimera-vio/utils/ThreadsafeImuBuffer.h:46-196                (input side)
+//   StereoDataProviderModule include/kimera-vio/dataprovider/StereoDataProviderModule.h:30-77        (input side)
+//   UtilsOpenCV::ReadAndConvertToGrayScale include/kimera-vio/utils/UtilsOpenCV.h (PNG files)       (input side)
 // Error behaviour: the reference CHECK-aborts on contract violations; the adapter throws
 // kvfe::Error carrying the kvfe_status and kvfe_last_error() text instead (never UB, never a
 // silent CPU fallback — there is none).
@@ -671,6 +674,146 @@ class RgbdVisionImuFrontend {
 
  private:
   Context c_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Input side: what feeds spinOnce.  Host code of the library; see kvfe.h for the semantics.
+// ------------------------------------------------------------------------------------------------------------
+
+// UtilsOpenCV::ReadAndConvertToGrayScale(img_name, equalize = false) for PNG data already in memory: the decoded
+// 8-bit grey image (rows * cols bytes, tightly packed).  Equalisation is the front-end's equalize_image parameter
+// / kvfe_equalize_hist.
+inline std::vector<uint8_t> ReadAndConvertToGrayScale(const uint8_t* png, size_t size, int* rows, int* cols) {
+  int32_t w = 0, h = 0, c = 0;
+  kvfe_status st = kvfe_png_info(png, size, &w, &h, &c);
+  if (st != KVFE_OK) throw Error(st, "ReadAndConvertToGrayScale: not a PNG file this library decodes");
+  std::vector<uint8_t> img((size_t)w * h);
+  st = kvfe_png_decode_gray(png, size, img.data(), (size_t)w, w, h);
+  if (st != KVFE_OK) throw Error(st, "ReadAndConvertToGrayScale: corrupt PNG data");
+  if (rows) *rows = h;
+  if (cols) *cols = w;
+  return img;
+}
+
+// ImuStampS (1 x n int64) / ImuAccGyrS (6 x n, column k = sample k) as plain vectors
+struct ImuMeasurements {
+  std::vector<int64_t> timestamps;
+  std::vector<double> acc_gyr;   // 6 per sample: ax ay az wx wy wz
+  int cols() const { return (int)timestamps.size(); }
+};
+
+namespace utils {
+class ThreadsafeImuBuffer {
+ public:
+  enum class QueryResult {
+    kDataAvailable = KVFE_IMU_DATA_AVAILABLE,
+    kDataNotYetAvailable = KVFE_IMU_DATA_NOT_YET_AVAILABLE,
+    kDataNeverAvailable = KVFE_IMU_DATA_NEVER_AVAILABLE,
+    kQueueShutdown = KVFE_IMU_QUEUE_SHUTDOWN,
+    kTooFewMeasurementsAvailable = KVFE_IMU_TOO_FEW_MEASUREMENTS
+  };
+  explicit ThreadsafeImuBuffer(int64_t buffer_length_ns) : b_(kvfe_imu_buffer_create(buffer_length_ns)) {
+    if (!b_) throw std::bad_alloc();
+  }
+  ~ThreadsafeImuBuffer() { kvfe_imu_buffer_destroy(b_); }
+  ThreadsafeImuBuffer(const ThreadsafeImuBuffer&) = delete;
+  ThreadsafeImuBuffer& operator=(const ThreadsafeImuBuffer&) = delete;
+
+  void addMeasurement(int64_t timestamp_ns, const double acc_gyr[6]) { kvfe_imu_buffer_add(b_, timestamp_ns, acc_gyr); }
+  size_t size() const { return (size_t)kvfe_imu_buffer_size(b_); }
+  void shutdown() { kvfe_imu_buffer_shutdown(b_); }
+  QueryResult getImuDataBtwTimestamps(int64_t from, int64_t to, ImuMeasurements* out, bool get_lower_bound = false) {
+    return query(out, [&](int64_t* t, double* v, int32_t cap, int32_t* n) {
+      return kvfe_imu_buffer_between(b_, from, to, get_lower_bound ? 1 : 0, t, v, cap, n);
+    });
+  }
+  QueryResult getImuDataInterpolatedUpperBorder(int64_t from, int64_t to, ImuMeasurements* out) {
+    return query(out, [&](int64_t* t, double* v, int32_t cap, int32_t* n) {
+      return kvfe_imu_buffer_interpolated_upper_border(b_, from, to, t, v, cap, n);
+    });
+  }
+  QueryResult getImuDataInterpolatedBorders(int64_t from, int64_t to, ImuMeasurements* out) {
+    return query(out, [&](int64_t* t, double* v, int32_t cap, int32_t* n) {
+      return kvfe_imu_buffer_interpolated_borders(b_, from, to, t, v, cap, n);
+    });
+  }
+  static void linearInterpolate(int64_t t0, const double y0[6], int64_t t1, const double y1[6], int64_t t,
+                                double y[6]) {
+    kvfe_imu_linear_interpolate(t0, y0, t1, y1, t, y);
+  }
+
+ private:
+  template <class F>
+  static QueryResult query(ImuMeasurements* out, F f) {
+    int32_t cap = 64, n = 0;
+    for (;;) {
+      out->timestamps.resize(cap);
+      out->acc_gyr.resize((size_t)6 * cap);
+      const int32_t r = f(out->timestamps.data(), out->acc_gyr.data(), cap, &n);
+      if (r == -1) {
+        cap = n;
+        continue;
+      }
+      out->timestamps.resize(n);
+      out->acc_gyr.resize((size_t)6 * n);
+      return static_cast<QueryResult>(r);
+    }
+  }
+  kvfe_imu_buffer* b_;
+};
+}  // namespace utils
+
+// StereoImuSyncPacket (include/kimera-vio/frontend/StereoImuSyncPacket.h:81-107) without the images: the frames
+// are referred to by the tags the caller queued them with
+struct StereoImuSyncPacket {
+  int64_t timestamp = 0;
+  int64_t left_frame_tag = 0, right_frame_tag = 0;
+  ImuMeasurements imu;
+};
+
+// StereoDataProviderModule in sequential mode: fill the queues, getInputPacket() = one spin
+class StereoDataProviderModule {
+ public:
+  explicit StereoDataProviderModule(int64_t imu_buffer_length_ns = -1) : s_(kvfe_stereo_sync_create(imu_buffer_length_ns)) {
+    if (!s_) throw std::bad_alloc();
+  }
+  ~StereoDataProviderModule() { kvfe_stereo_sync_destroy(s_); }
+  StereoDataProviderModule(const StereoDataProviderModule&) = delete;
+  StereoDataProviderModule& operator=(const StereoDataProviderModule&) = delete;
+
+  void fillLeftFrameQueue(int64_t timestamp_ns, int64_t tag) { kvfe_stereo_sync_fill_left(s_, timestamp_ns, tag); }
+  void fillRightFrameQueue(int64_t timestamp_ns, int64_t tag) { kvfe_stereo_sync_fill_right(s_, timestamp_ns, tag); }
+  void fillImuQueue(int64_t timestamp_ns, const double acc_gyr[6]) { kvfe_stereo_sync_fill_imu(s_, timestamp_ns, acc_gyr); }
+  void doCoarseImuCameraTemporalSync() { kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync(s_); }
+  void setImuTimeShift(double imu_time_shift_s) { kvfe_stereo_sync_set_imu_time_shift(s_, imu_time_shift_s); }
+  void shutdown() { kvfe_stereo_sync_shutdown(s_); }
+  // true: *packet written; false: nothing this spin -- lastAction() is the KVFE_SYNC_* reason
+  bool getInputPacket(StereoImuSyncPacket* packet) {
+    int32_t cap = 64;
+    for (;;) {
+      packet->imu.timestamps.resize(cap);
+      packet->imu.acc_gyr.resize((size_t)6 * cap);
+      kvfe_sync_packet pk;
+      const int32_t r = kvfe_stereo_sync_next(s_, &pk, packet->imu.timestamps.data(), packet->imu.acc_gyr.data(), cap);
+      if (r == -1) {
+        cap = pk.n_imu;
+        continue;
+      }
+      last_action_ = r;
+      packet->imu.timestamps.resize(r == KVFE_SYNC_PACKET ? pk.n_imu : 0);
+      packet->imu.acc_gyr.resize(r == KVFE_SYNC_PACKET ? (size_t)6 * pk.n_imu : 0);
+      if (r != KVFE_SYNC_PACKET) return false;
+      packet->timestamp = pk.timestamp_ns;
+      packet->left_frame_tag = pk.left_tag;
+      packet->right_frame_tag = pk.right_tag;
+      return true;
+    }
+  }
+  int lastAction() const { return last_action_; }
+
+ private:
+  kvfe_stereo_sync* s_;
+  int last_action_ = KVFE_SYNC_EMPTY;
 };
 
 }  // namespace kvfe

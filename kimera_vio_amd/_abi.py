@@ -231,3 +231,15 @@ class StageTimes(C.Structure):
         ("ms_total", C.c_double * KVFE_N_STAGES),
         ("alg_bytes", C.c_double * KVFE_N_STAGES),
     ]
+
+
+class SyncPacket(C.Structure):
+    """kvfe_sync_packet (include/kvfe.h, input side)"""
+    _fields_ = [("timestamp_ns", C.c_int64), ("left_tag", C.c_int64), ("right_tag", C.c_int64),
+                ("n_imu", C.c_int32), ("reserved0", C.c_int32)]
+
+
+IMU_DATA_AVAILABLE, IMU_DATA_NOT_YET_AVAILABLE, IMU_DATA_NEVER_AVAILABLE, IMU_QUEUE_SHUTDOWN, \
+    IMU_TOO_FEW_MEASUREMENTS = range(5)
+(SYNC_PACKET, SYNC_EMPTY, SYNC_WAIT_IMU, SYNC_DROP_OUT_OF_ORDER, SYNC_DROP_NO_IMU, SYNC_DROP_FIRST_FRAME,
+ SYNC_DROP_IMU_NEVER, SYNC_DROP_IMU_TOO_FEW, SYNC_DROP_NO_RIGHT, SYNC_SHUTDOWN) = range(10)

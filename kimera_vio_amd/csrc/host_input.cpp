@@ -1,0 +1,729 @@
+// Input side of the front-end, host code behind the C ABI of include/kvfe.h:
+//   * PNG -> 8-bit grey            == UtilsOpenCV::ReadAndConvertToGrayScale (src/utils/UtilsOpenCV.cpp:390-399):
+//                                     cv::imread(IMREAD_ANYCOLOR) [+ cv::cvtColor(BGR2GRAY)] for PNG files
+//   * kvfe_imu_buffer              == utils::ThreadsafeImuBuffer (src/utils/ThreadsafeImuBuffer.cpp:48-234) over
+//                                     utils::ThreadsafeTemporalBuffer (include/kimera-vio/utils/
+//                                     ThreadsafeTemporalBuffer-inl.h)
+//   * kvfe_stereo_sync             == StereoDataProviderModule::getInputPacket (src/dataprovider/
+//                                     StereoDataProviderModule.cpp:35-91), MonoDataProviderModule::
+//                                     getMonoImuSyncPacket (MonoDataProviderModule.cpp:44-118), DataProviderModule::
+//                                     getTimeSyncedImuMeasurements (DataProviderModule.cpp:80-181),
+//                                     SimpleQueueSynchronizer::syncQueue (pipeline/QueueSynchronizer.h:79-162)
+//   * EuRoC index files            == CameraImageLists::parseCamImgList (DataProviderInterface-definitions.cpp:
+//                                     74-101), EurocDataProvider::parseImuData (EurocDataProvider.cpp:229-306)
+// No device work here: the data provider runs on CPU threads beside the GPU steps and writes decoded frames into
+// the pinned staging slots of kvfe_frontend_staging_buffer.  The PNG container is decoded with zlib's inflate (the
+// only codec library in the image); everything around it (chunks, CRCs, filters, Adam7, sample expansion) is here.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/kvfe.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// PNG
+// ------------------------------------------------------------------------------------------------
+struct PngHeader {
+  uint32_t w = 0, h = 0;
+  int depth = 0, color = 0, interlace = 0;
+  int channels() const { return color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : 4; }
+  // channels of the cv::Mat cv::imread(IMREAD_ANYCOLOR) returns (PngDecoder::readHeader + imread_'s type rule)
+  int cv_channels() const { return color == 0 ? 1 : 3; }
+};
+
+inline uint32_t be32(const uint8_t* p) {
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+kvfe_status png_header(const uint8_t* d, size_t n, PngHeader* H) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (!d || n < 8 + 12 + 13 || std::memcmp(d, sig, 8) != 0) return KVFE_ERR_INVALID_ARG;
+  if (be32(d + 8) != 13 || std::memcmp(d + 12, "IHDR", 4) != 0) return KVFE_ERR_INVALID_ARG;
+  const uint8_t* p = d + 16;
+  H->w = be32(p);
+  H->h = be32(p + 4);
+  H->depth = p[8];
+  H->color = p[9];
+  H->interlace = p[12];
+  if (H->w == 0 || H->h == 0 || H->w > (1u << 20) || H->h > (1u << 20)) return KVFE_ERR_INVALID_ARG;
+  if (p[10] != 0 || p[11] != 0 || H->interlace > 1) return KVFE_ERR_INVALID_ARG;
+  const int dp = H->depth;
+  bool ok = false;
+  switch (H->color) {
+    case 0: ok = dp == 1 || dp == 2 || dp == 4 || dp == 8 || dp == 16; break;
+    case 3: ok = dp == 1 || dp == 2 || dp == 4 || dp == 8; break;
+    case 2: case 4: case 6: ok = dp == 8 || dp == 16; break;
+    default: ok = false;
+  }
+  if (!ok) return KVFE_ERR_INVALID_ARG;
+  if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), d + 12, 4 + 13) != be32(d + 29)) return KVFE_ERR_INVALID_ARG;
+  return KVFE_OK;
+}
+
+// undo the scanline filters of one (sub)image in place: rows of 1 + rowbytes bytes.  The first row has no row
+// above (it reads as zeros), the first bpp bytes of a row no byte to the left; Average and Paeth are serial through
+// the byte just written, so their inner loops are kept branch-free (the Paeth predictor as in the PNG specification:
+// the candidate nearest to a + b - c, ties in the order a, b, c).
+kvfe_status unfilter(uint8_t* buf, size_t rows, size_t rowbytes, int bpp) {
+  std::vector<uint8_t> zeros(rowbytes, 0);
+  const uint8_t* prev = zeros.data();
+  const size_t bp = (size_t)bpp;
+  for (size_t y = 0; y < rows; y++) {
+    uint8_t* row = buf + y * (rowbytes + 1);
+    const int ft = row[0];
+    uint8_t* r = row + 1;
+    const size_t head = std::min(bp, rowbytes);
+    switch (ft) {
+      case 0: break;
+      case 1:
+        for (size_t i = bp; i < rowbytes; i++) r[i] = (uint8_t)(r[i] + r[i - bp]);
+        break;
+      case 2:
+        for (size_t i = 0; i < rowbytes; i++) r[i] = (uint8_t)(r[i] + prev[i]);
+        break;
+      case 3:
+        for (size_t i = 0; i < head; i++) r[i] = (uint8_t)(r[i] + (prev[i] >> 1));
+        if (bp == 1) {   // one byte per pixel (the grey frames): the left neighbour rides in a register
+          int a = rowbytes ? r[0] : 0;
+          for (size_t i = 1; i < rowbytes; i++) {
+            a = (r[i] + ((a + (int)prev[i]) >> 1)) & 255;
+            r[i] = (uint8_t)a;
+          }
+        } else {
+          for (size_t i = bp; i < rowbytes; i++) r[i] = (uint8_t)(r[i] + (((int)r[i - bp] + (int)prev[i]) >> 1));
+        }
+        break;
+      case 4:
+        for (size_t i = 0; i < head; i++) r[i] = (uint8_t)(r[i] + prev[i]);   // a = c = 0: the predictor is b
+        if (bp == 1) {
+          int a = rowbytes ? r[0] : 0, c = rowbytes ? prev[0] : 0;
+          for (size_t i = 1; i < rowbytes; i++) {
+            const int b = prev[i];
+            const int pa0 = b - c, pb0 = a - c;             // p - a, p - b with p = a + b - c
+            const int pa = pa0 < 0 ? -pa0 : pa0, pb = pb0 < 0 ? -pb0 : pb0;
+            const int pc0 = pa0 + pb0, pc = pc0 < 0 ? -pc0 : pc0;
+            int pred = pb <= pc ? b : c;
+            pred = (pa <= pb && pa <= pc) ? a : pred;
+            a = (r[i] + pred) & 255;
+            r[i] = (uint8_t)a;
+            c = b;
+          }
+        } else {
+          for (size_t i = bp; i < rowbytes; i++) {
+            const int a = r[i - bp], b = prev[i], c = prev[i - bp];
+            const int pa0 = b - c, pb0 = a - c;
+            const int pa = pa0 < 0 ? -pa0 : pa0, pb = pb0 < 0 ? -pb0 : pb0;
+            const int pc0 = pa0 + pb0, pc = pc0 < 0 ? -pc0 : pc0;
+            int pred = pb <= pc ? b : c;
+            pred = (pa <= pb && pa <= pc) ? a : pred;
+            r[i] = (uint8_t)(r[i] + pred);
+          }
+        }
+        break;
+      default: return KVFE_ERR_INVALID_ARG;
+    }
+    prev = r;
+  }
+  return KVFE_OK;
+}
+
+// sample k (0-based, `depth` bits) of a scanline -> 8 bits: 16-bit samples keep the high byte (png_set_strip_16),
+// 1/2/4-bit grey is expanded (png_set_expand_gray_1_2_4_to_8), palette indices stay indices
+inline int sample8(const uint8_t* r, size_t k, int depth, bool expand) {
+  if (depth == 8) return r[k];
+  if (depth == 16) return r[2 * k];
+  const int per = 8 / depth, shift = (per - 1 - (int)(k % per)) * depth;
+  const int v = (r[k / per] >> shift) & ((1 << depth) - 1);
+  return expand ? v * 255 / ((1 << depth) - 1) : v;
+}
+
+// one decoded pixel -> the 8-bit grey value the reference ends up with
+inline uint8_t to_gray(const PngHeader& H, const uint8_t* r, size_t x, const uint8_t* pal, int npal) {
+  int R, G, B;
+  switch (H.color) {
+    case 0: return (uint8_t)sample8(r, x, H.depth, true);
+    case 4: return (uint8_t)sample8(r, 2 * x, H.depth, false);   // grey replicated to BGR, BGR2GRAY of (v, v, v) = v
+    case 3: {
+      const int idx = sample8(r, x, H.depth, false);
+      if (idx >= npal) {   // libpng: out-of-range index reads as black
+        R = G = B = 0;
+      } else {
+        R = pal[3 * idx];
+        G = pal[3 * idx + 1];
+        B = pal[3 * idx + 2];
+      }
+      break;
+    }
+    default: {   // 2: RGB, 6: RGBA
+      const size_t c = H.color == 2 ? 3 : 4;
+      R = sample8(r, c * x, H.depth, false);
+      G = sample8(r, c * x + 1, H.depth, false);
+      B = sample8(r, c * x + 2, H.depth, false);
+    }
+  }
+  // cv::cvtColor(BGR2GRAY), 8U: CV_DESCALE(b * BY15 + g * GY15 + r * RY15, 15)
+  return (uint8_t)((B * 3735 + G * 19235 + R * 9798 + (1 << 14)) >> 15);
+}
+
+kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stride, int32_t width, int32_t height) {
+  PngHeader H;
+  kvfe_status st = png_header(d, n, &H);
+  if (st != KVFE_OK) return st;
+  if (!dst || (int64_t)H.w != width || (int64_t)H.h != height || dst_stride < (size_t)width) return KVFE_ERR_INVALID_ARG;
+  // chunks
+  std::vector<uint8_t> idat;
+  uint8_t pal[768];
+  int npal = 0;
+  size_t off = 8;
+  bool end = false;
+  while (!end) {
+    if (off + 12 > n) return KVFE_ERR_INVALID_ARG;
+    const uint32_t len = be32(d + off);
+    if ((size_t)len > n - off - 12) return KVFE_ERR_INVALID_ARG;
+    const uint8_t* type = d + off + 4;
+    const uint8_t* body = d + off + 8;
+    const bool critical = !(type[0] & 0x20);
+    const bool crc_ok = (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) == be32(body + len);
+    if (!crc_ok && critical) return KVFE_ERR_INVALID_ARG;   // (libpng only warns for ancillary chunks)
+    if (!std::memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), body, body + len);
+    } else if (!std::memcmp(type, "PLTE", 4)) {
+      if (len % 3 != 0 || len > 768) return KVFE_ERR_INVALID_ARG;
+      std::memcpy(pal, body, len);
+      npal = (int)(len / 3);
+    } else if (!std::memcmp(type, "IEND", 4)) {
+      end = true;
+    } else if (critical && std::memcmp(type, "IHDR", 4) != 0) {
+      return KVFE_ERR_UNSUPPORTED;   // unknown critical chunk
+    }
+    off += 12 + (size_t)len;
+  }
+  if (idat.empty() || (H.color == 3 && npal == 0)) return KVFE_ERR_INVALID_ARG;
+
+  const int bits = H.depth * H.channels();
+  const int bpp = std::max(1, bits / 8);
+  auto rowbytes_of = [&](size_t w) { return (w * (size_t)bits + 7) / 8; };
+  // geometry of the passes (one pass when not interlaced)
+  static const int a7_x0[7] = {0, 4, 0, 2, 0, 1, 0}, a7_y0[7] = {0, 0, 4, 0, 2, 0, 1};
+  static const int a7_dx[7] = {8, 8, 4, 4, 2, 2, 1}, a7_dy[7] = {8, 8, 8, 4, 4, 2, 2};
+  struct Pass { size_t w, h, off; int x0, y0, dx, dy; };
+  std::vector<Pass> passes;
+  size_t total = 0;
+  if (!H.interlace) {
+    passes.push_back({H.w, H.h, 0, 0, 0, 1, 1});
+    total = (size_t)H.h * (rowbytes_of(H.w) + 1);
+  } else {
+    for (int p = 0; p < 7; p++) {
+      const size_t pw = (H.w + a7_dx[p] - 1 - a7_x0[p]) / a7_dx[p], ph = (H.h + a7_dy[p] - 1 - a7_y0[p]) / a7_dy[p];
+      if (pw == 0 || ph == 0) continue;
+      passes.push_back({pw, ph, total, a7_x0[p], a7_y0[p], a7_dx[p], a7_dy[p]});
+      total += ph * (rowbytes_of(pw) + 1);
+    }
+  }
+  std::vector<uint8_t> raw(total);
+  {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) return KVFE_ERR_INVALID_ARG;
+    zs.next_in = idat.data();
+    zs.avail_in = (uInt)idat.size();
+    zs.next_out = raw.data();
+    zs.avail_out = (uInt)raw.size();
+    const int zr = inflate(&zs, Z_FINISH);
+    const bool full = zs.avail_out == 0;
+    inflateEnd(&zs);
+    // (Z_BUF_ERROR with a full output: trailing bytes after the image, which libpng ignores with a warning)
+    if (!(zr == Z_STREAM_END || (zr == Z_BUF_ERROR && full)) || !full) return KVFE_ERR_INVALID_ARG;
+  }
+  for (const Pass& P : passes) {
+    const size_t rb = rowbytes_of(P.w);
+    st = unfilter(raw.data() + P.off, P.h, rb, bpp);
+    if (st != KVFE_OK) return st;
+    for (size_t y = 0; y < P.h; y++) {
+      const uint8_t* r = raw.data() + P.off + y * (rb + 1) + 1;
+      uint8_t* o = dst + (size_t)(P.y0 + y * P.dy) * dst_stride;
+      if (P.dx == 1 && H.color == 0 && H.depth == 8) {
+        std::memcpy(o, r, P.w);   // the EuRoC case
+      } else {
+        for (size_t x = 0; x < P.w; x++) o[P.x0 + x * P.dx] = to_gray(H, r, x, pal, npal);
+      }
+    }
+  }
+  return KVFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IMU buffer
+// ------------------------------------------------------------------------------------------------
+struct AccGyr {
+  double v[6];
+};
+
+}  // namespace
+
+struct kvfe_imu_buffer {
+  mutable std::mutex mu;
+  std::map<int64_t, AccGyr> values;     // ThreadsafeTemporalBuffer::values_
+  int64_t buffer_length_ns = -1;
+  std::atomic<bool> shutdown{false};
+
+  // ThreadsafeImuBuffer::addMeasurement (ThreadsafeImuBuffer-inl.h:52-70: "Enforce strict time-wise ordering", a
+  // sample that is not newer than the newest one is ignored) + ThreadsafeTemporalBuffer::addValue /
+  // removeOutdatedItems
+  void add(int64_t t, const double a[6]) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!values.empty() && t <= values.rbegin()->first) return;
+    AccGyr x;
+    std::memcpy(x.v, a, sizeof(x.v));
+    values.emplace(t, x);
+    if (values.empty() || buffer_length_ns <= 0) return;
+    const int64_t thr = values.rbegin()->first - buffer_length_ns;
+    if (values.begin()->first < thr) values.erase(values.begin(), values.lower_bound(thr));
+  }
+  // isDataAvailableUpToImpl
+  int available(int64_t from, int64_t to) const {
+    if (shutdown) return KVFE_IMU_QUEUE_SHUTDOWN;
+    if (values.empty()) return KVFE_IMU_DATA_NOT_YET_AVAILABLE;
+    if (values.rbegin()->first < to) return KVFE_IMU_DATA_NOT_YET_AVAILABLE;
+    if (from < values.begin()->first) return KVFE_IMU_DATA_NEVER_AVAILABLE;
+    return KVFE_IMU_DATA_AVAILABLE;
+  }
+  // getImuDataBtwTimestamps (lock held by the caller)
+  int between(int64_t from, int64_t to, bool lower, std::vector<int64_t>& ts, std::vector<AccGyr>& vs) const {
+    ts.clear();
+    vs.clear();
+    const int q = available(from, to);
+    if (q != KVFE_IMU_DATA_AVAILABLE) return q;
+    // getValuesBetweenTimes (the 100 % overlap condition holds after `available`)
+    for (auto it = values.lower_bound(from); it != values.end() && it->first < to; ++it) {
+      if (it->first == from && !lower) continue;
+      ts.push_back(it->first);
+      vs.push_back(it->second);
+    }
+    if (ts.empty()) return KVFE_IMU_TOO_FEW_MEASUREMENTS;
+    return q;
+  }
+  // interpolateValueAtTimestamp: getValueAtOrBeforeTime / getValueAtOrAfterTime + linearInterpolate
+  bool interpolate(int64_t t, AccGyr* out) const {
+    auto lb = values.lower_bound(t);
+    std::map<int64_t, AccGyr>::const_iterator pre, post;
+    if (lb != values.end() && lb->first == t) {
+      pre = post = lb;
+    } else {
+      if (values.empty() || lb == values.begin() || lb == values.end()) return false;   // (CHECK upstream)
+      post = lb;
+      pre = std::prev(lb);
+    }
+    kvfe_imu_linear_interpolate(pre->first, pre->second.v, post->first, post->second.v, t, out->v);
+    return true;
+  }
+};
+
+namespace {
+
+int imu_emit(const std::vector<int64_t>& ts, const std::vector<AccGyr>& vs, int64_t* stamps, double* acc_gyr,
+             int32_t capacity, int32_t* n) {
+  if ((int64_t)ts.size() > capacity) {
+    if (n) *n = (int32_t)ts.size();
+    return -1;
+  }
+  for (size_t i = 0; i < ts.size(); i++) {
+    stamps[i] = ts[i];
+    std::memcpy(acc_gyr + 6 * i, vs[i].v, sizeof(double) * 6);
+  }
+  if (n) *n = (int32_t)ts.size();
+  return KVFE_IMU_DATA_AVAILABLE;
+}
+
+int imu_query(kvfe_imu_buffer* b, int mode, int64_t from, int64_t to, bool lower, std::vector<int64_t>& ts,
+              std::vector<AccGyr>& vs) {
+  std::lock_guard<std::mutex> lk(b->mu);
+  int q = b->between(from, to, mode == 1 ? true : (mode == 2 ? false : lower), ts, vs);
+  if (q != KVFE_IMU_DATA_AVAILABLE) {
+    ts.clear();
+    vs.clear();
+    return q;
+  }
+  if (mode == 1) {          // getImuDataInterpolatedUpperBorder
+    AccGyr up;
+    if (!b->interpolate(to, &up)) return KVFE_IMU_DATA_NEVER_AVAILABLE;
+    ts.push_back(to);
+    vs.push_back(up);
+  } else if (mode == 2) {   // getImuDataInterpolatedBorders
+    AccGyr lo, up;
+    if (!b->interpolate(from, &lo) || !b->interpolate(to, &up)) return KVFE_IMU_DATA_NEVER_AVAILABLE;
+    ts.insert(ts.begin(), from);
+    vs.insert(vs.begin(), lo);
+    ts.push_back(to);
+    vs.push_back(up);
+  }
+  return q;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// stereo / IMU synchronisation
+// ------------------------------------------------------------------------------------------------
+struct kvfe_stereo_sync {
+  struct FrameRef {
+    int64_t t, tag;
+  };
+  std::mutex mu;
+  std::deque<FrameRef> left, right;     // left_frame_queue_, right_frame_queue_
+  kvfe_imu_buffer imu;                  // imu_data_.imu_buffer_
+  bool have_cached = false;             // cached_left_frame_
+  FrameRef cached{0, 0};
+  int64_t timestamp_last_frame = 0;     // InvalidTimestamp = 0 (DataProviderModule.h:172)
+  bool do_coarse_sync = false;
+  int64_t imu_timestamp_correction = 0;
+  std::atomic<int64_t> imu_time_shift_ns{0};
+  std::atomic<bool> shutdown{false};
+};
+
+extern "C" {
+
+kvfe_status kvfe_png_info(const uint8_t* data, size_t size, int32_t* width, int32_t* height, int32_t* channels) {
+  PngHeader H;
+  const kvfe_status st = png_header(data, size, &H);
+  if (st != KVFE_OK) return st;
+  if (width) *width = (int32_t)H.w;
+  if (height) *height = (int32_t)H.h;
+  if (channels) *channels = H.cv_channels();
+  return KVFE_OK;
+}
+
+kvfe_status kvfe_png_decode_gray(const uint8_t* data, size_t size, uint8_t* dst, size_t dst_stride, int32_t width,
+                                 int32_t height) {
+  return png_decode(data, size, dst, dst_stride, width, height);
+}
+
+kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t* sizes, uint8_t* const* dst,
+                                       size_t dst_stride, int32_t width, int32_t height, int32_t n, int32_t threads,
+                                       kvfe_status* status) {
+  if (n < 0 || (n > 0 && (!data || !sizes || !dst))) return KVFE_ERR_INVALID_ARG;
+  if (n == 0) return KVFE_OK;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  int nt = threads > 0 ? threads : (int)std::min<unsigned>(hw, (unsigned)n);
+  nt = std::max(1, std::min(nt, n));
+  std::vector<kvfe_status> local((size_t)n, KVFE_OK);
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) return;
+      local[i] = png_decode(data[i], sizes[i], dst[i], dst_stride, width, height);
+    }
+  };
+  if (nt == 1) {
+    work();
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    for (auto& th : pool) th.join();
+  }
+  kvfe_status first = KVFE_OK;
+  for (int i = 0; i < n; i++) {
+    if (status) status[i] = local[i];
+    if (first == KVFE_OK && local[i] != KVFE_OK) first = local[i];
+  }
+  return first;
+}
+
+kvfe_imu_buffer* kvfe_imu_buffer_create(int64_t buffer_length_ns) {
+  kvfe_imu_buffer* b = new (std::nothrow) kvfe_imu_buffer();
+  if (b) b->buffer_length_ns = buffer_length_ns;
+  return b;
+}
+void kvfe_imu_buffer_destroy(kvfe_imu_buffer* b) { delete b; }
+void kvfe_imu_buffer_add(kvfe_imu_buffer* b, int64_t timestamp_ns, const double acc_gyr[6]) {
+  if (b && acc_gyr) b->add(timestamp_ns, acc_gyr);
+}
+int64_t kvfe_imu_buffer_size(const kvfe_imu_buffer* b) {
+  if (!b) return 0;
+  std::lock_guard<std::mutex> lk(b->mu);
+  return (int64_t)b->values.size();
+}
+void kvfe_imu_buffer_shutdown(kvfe_imu_buffer* b) {
+  if (b) b->shutdown = true;
+}
+
+void kvfe_imu_linear_interpolate(int64_t t0, const double y0[6], int64_t t1, const double y1[6], int64_t t,
+                                 double y[6]) {
+  // *y = t0 == t1 ? y0 : y0 + (y1 - y0) * double(t - t0) / double(t1 - t0)   (Eigen: element-wise, left to right)
+  for (int i = 0; i < 6; i++)
+    y[i] = t0 == t1 ? y0[i] : y0[i] + (y1[i] - y0[i]) * static_cast<double>(t - t0) / static_cast<double>(t1 - t0);
+}
+
+static int32_t imu_query_c(kvfe_imu_buffer* b, int mode, int64_t t_from, int64_t t_to, int32_t lower,
+                           int64_t* stamps, double* acc_gyr, int32_t capacity, int32_t* n) {
+  if (n) *n = 0;
+  if (!b || capacity < 0 || (capacity > 0 && (!stamps || !acc_gyr))) return KVFE_IMU_DATA_NEVER_AVAILABLE;
+  std::vector<int64_t> ts;
+  std::vector<AccGyr> vs;
+  const int q = imu_query(b, mode, t_from, t_to, lower != 0, ts, vs);
+  if (q != KVFE_IMU_DATA_AVAILABLE) return q;
+  return imu_emit(ts, vs, stamps, acc_gyr, capacity, n);
+}
+int32_t kvfe_imu_buffer_between(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to, int32_t get_lower_bound,
+                                int64_t* stamps, double* acc_gyr, int32_t capacity, int32_t* n) {
+  return imu_query_c(b, 0, t_from, t_to, get_lower_bound, stamps, acc_gyr, capacity, n);
+}
+int32_t kvfe_imu_buffer_interpolated_upper_border(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to, int64_t* stamps,
+                                                  double* acc_gyr, int32_t capacity, int32_t* n) {
+  return imu_query_c(b, 1, t_from, t_to, 1, stamps, acc_gyr, capacity, n);
+}
+int32_t kvfe_imu_buffer_interpolated_borders(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to, int64_t* stamps,
+                                             double* acc_gyr, int32_t capacity, int32_t* n) {
+  return imu_query_c(b, 2, t_from, t_to, 0, stamps, acc_gyr, capacity, n);
+}
+
+kvfe_stereo_sync* kvfe_stereo_sync_create(int64_t imu_buffer_length_ns) {
+  kvfe_stereo_sync* s = new (std::nothrow) kvfe_stereo_sync();
+  if (s) s->imu.buffer_length_ns = imu_buffer_length_ns;
+  return s;
+}
+void kvfe_stereo_sync_destroy(kvfe_stereo_sync* s) { delete s; }
+void kvfe_stereo_sync_fill_left(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->left.push_back({timestamp_ns, tag});
+}
+void kvfe_stereo_sync_fill_right(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->right.push_back({timestamp_ns, tag});
+}
+void kvfe_stereo_sync_fill_imu(kvfe_stereo_sync* s, int64_t timestamp_ns, const double acc_gyr[6]) {
+  if (s && acc_gyr) s->imu.add(timestamp_ns, acc_gyr);
+}
+void kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync(kvfe_stereo_sync* s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->do_coarse_sync = true;
+}
+void kvfe_stereo_sync_set_imu_time_shift(kvfe_stereo_sync* s, double imu_time_shift_s) {
+  // UtilsNumerical::SecToNsec: nanoseconds of a std::chrono::duration<double>, truncated
+  if (s) s->imu_time_shift_ns = (int64_t)(imu_time_shift_s * 1e9);
+}
+void kvfe_stereo_sync_shutdown(kvfe_stereo_sync* s) {
+  if (!s) return;
+  s->shutdown = true;
+  s->imu.shutdown = true;
+}
+
+int32_t kvfe_stereo_sync_next(kvfe_stereo_sync* s, kvfe_sync_packet* packet, int64_t* imu_stamps,
+                              double* imu_acc_gyr, int32_t capacity) {
+  if (!s || !packet || capacity < 0 || (capacity > 0 && (!imu_stamps || !imu_acc_gyr))) return KVFE_SYNC_SHUTDOWN;
+  std::lock_guard<std::mutex> lk(s->mu);
+  std::memset(packet, 0, sizeof(*packet));
+  if (s->shutdown) return KVFE_SYNC_SHUTDOWN;
+  // ---- getMonoImuSyncPacket(cache_timestamp = false) ----------------------------------------------
+  kvfe_stereo_sync::FrameRef lf;
+  const bool from_cache = s->have_cached;
+  if (from_cache) {
+    lf = s->cached;
+  } else {
+    if (s->left.empty()) return KVFE_SYNC_EMPTY;
+    lf = s->left.front();
+  }
+  auto consume_left = [&]() {
+    if (from_cache)
+      s->have_cached = false;
+    else
+      s->left.pop_front();
+  };
+  if (s->timestamp_last_frame >= lf.t) {
+    consume_left();
+    return KVFE_SYNC_DROP_OUT_OF_ORDER;
+  }
+  // ---- getTimeSyncedImuMeasurements -------------------------------------------------------------
+  if (kvfe_imu_buffer_size(&s->imu) == 0) {
+    consume_left();
+    return KVFE_SYNC_DROP_NO_IMU;
+  }
+  if (s->timestamp_last_frame == 0) {
+    s->timestamp_last_frame = lf.t;
+    consume_left();
+    return KVFE_SYNC_DROP_FIRST_FRAME;
+  }
+  bool coarse = s->do_coarse_sync;
+  int64_t correction = s->imu_timestamp_correction;
+  if (coarse) {
+    std::lock_guard<std::mutex> lki(s->imu.mu);
+    correction = s->imu.values.rbegin()->first - lf.t;   // newest_imu.timestamp_ - timestamp
+  }
+  const int64_t shift = s->imu_time_shift_ns;
+  const int64_t t_last = s->timestamp_last_frame + correction + shift, t_cur = lf.t + correction + shift;
+  std::vector<int64_t> ts;
+  std::vector<AccGyr> vs;
+  const int q = imu_query(&s->imu, 2, t_last, t_cur, false, ts, vs);
+  if (q == KVFE_IMU_DATA_AVAILABLE && (int64_t)ts.size() > capacity) {
+    packet->n_imu = (int32_t)ts.size();
+    return -1;   // nothing consumed, no state changed
+  }
+  if (coarse) {   // (the correction is computed once, on the first frame that reaches this point)
+    s->imu_timestamp_correction = correction;
+    s->do_coarse_sync = false;
+  }
+  switch (q) {
+    case KVFE_IMU_DATA_AVAILABLE: break;
+    case KVFE_IMU_DATA_NOT_YET_AVAILABLE:   // FrameAction::Wait: cached_left_frame_ = the frame
+      if (!from_cache) {
+        s->left.pop_front();
+        s->cached = lf;
+        s->have_cached = true;
+      }
+      return KVFE_SYNC_WAIT_IMU;
+    case KVFE_IMU_QUEUE_SHUTDOWN:
+      s->shutdown = true;
+      consume_left();
+      return KVFE_SYNC_SHUTDOWN;
+    case KVFE_IMU_DATA_NEVER_AVAILABLE:
+      s->timestamp_last_frame = lf.t;
+      consume_left();
+      return KVFE_SYNC_DROP_IMU_NEVER;
+    default:
+      consume_left();
+      return KVFE_SYNC_DROP_IMU_TOO_FEW;
+  }
+  for (int64_t& t : ts) t -= correction + shift;   // "adjust the timestamps for the frontend"
+  consume_left();
+  // ---- syncQueue(timestamp, &right_frame_queue_) ------------------------------------------------
+  bool found = false;
+  kvfe_stereo_sync::FrameRef rf{0, 0};
+  while (!s->right.empty()) {
+    const kvfe_stereo_sync::FrameRef cur = s->right.front();
+    if (cur.t > lf.t) break;          // "Could not retrieve exact timestamp requested": left in the queue
+    s->right.pop_front();
+    if (cur.t == lf.t) {
+      rf = cur;
+      found = true;
+      break;
+    }
+  }
+  if (!found) return KVFE_SYNC_DROP_NO_RIGHT;   // (timestamp_last_frame_ keeps its value)
+  s->timestamp_last_frame = lf.t;
+  packet->timestamp_ns = lf.t;
+  packet->left_tag = lf.tag;
+  packet->right_tag = rf.tag;
+  int32_t n = 0;
+  imu_emit(ts, vs, imu_stamps, imu_acc_gyr, capacity, &n);
+  packet->n_imu = n;
+  return KVFE_SYNC_PACKET;
+}
+
+// ------------------------------------------------------------------------------------------------
+// EuRoC index files
+// ------------------------------------------------------------------------------------------------
+static bool next_line(const char* text, size_t size, size_t* pos, const char** line, size_t* len) {
+  if (*pos >= size) return false;
+  const char* b = text + *pos;
+  const char* e = (const char*)std::memchr(b, '\n', size - *pos);
+  const size_t l = e ? (size_t)(e - b) : size - *pos;
+  *line = b;
+  *len = l;
+  *pos += l + (e ? 1 : 0);
+  return true;
+}
+
+// std::stoll / std::stod of a field: leading whitespace skipped, trailing characters ignored; false = no conversion
+static bool field_ll(const char* b, size_t n, int64_t* v) {
+  char tmp[64];
+  const size_t m = std::min(n, sizeof(tmp) - 1);
+  std::memcpy(tmp, b, m);
+  tmp[m] = 0;
+  char* end = nullptr;
+  errno = 0;
+  const long long x = std::strtoll(tmp, &end, 10);
+  if (end == tmp || errno == ERANGE) return false;
+  *v = (int64_t)x;
+  return true;
+}
+static bool field_d(const char* b, size_t n, double* v) {
+  char tmp[128];
+  const size_t m = std::min(n, sizeof(tmp) - 1);
+  std::memcpy(tmp, b, m);
+  tmp[m] = 0;
+  char* end = nullptr;
+  errno = 0;
+  const double x = std::strtod(tmp, &end);
+  if (end == tmp) return false;
+  *v = x;
+  return true;
+}
+
+kvfe_status kvfe_euroc_parse_camera_csv(const char* text, size_t size, int64_t* timestamps, int32_t capacity,
+                                        int32_t* n) {
+  if (!text || !n || capacity < 0 || (capacity > 0 && !timestamps)) return KVFE_ERR_INVALID_ARG;
+  size_t pos = 0, len = 0;
+  const char* line = nullptr;
+  next_line(text, size, &pos, &line, &len);   // header
+  int64_t count = 0;
+  while (next_line(text, size, &pos, &line, &len)) {
+    const char* c = (const char*)std::memchr(line, ',', len);
+    int64_t t;
+    if (!field_ll(line, c ? (size_t)(c - line) : len, &t)) {
+      if (len == 0 || (len == 1 && line[0] == '\r')) continue;   // (a trailing blank line would throw upstream)
+      return KVFE_ERR_INVALID_ARG;
+    }
+    if (count < capacity) timestamps[count] = t;
+    count++;
+  }
+  *n = (int32_t)count;
+  return count > capacity ? KVFE_ERR_CAPACITY : KVFE_OK;
+}
+
+kvfe_status kvfe_euroc_parse_imu_csv(const char* text, size_t size, int64_t* timestamps, double* acc_gyr,
+                                     int32_t capacity, int32_t* n) {
+  if (!text || !n || capacity < 0 || (capacity > 0 && (!timestamps || !acc_gyr))) return KVFE_ERR_INVALID_ARG;
+  size_t pos = 0, len = 0;
+  const char* line = nullptr;
+  next_line(text, size, &pos, &line, &len);   // header
+  int64_t count = 0, previous = -1;
+  while (next_line(text, size, &pos, &line, &len)) {
+    if (len == 0 || (len == 1 && line[0] == '\r')) continue;
+    int64_t t = 0;
+    double g[6];   // w_x w_y w_z a_x a_y a_z
+    const char* b = line;
+    size_t left = len;
+    for (int i = 0; i < 7; i++) {
+      const char* c = (const char*)std::memchr(b, ',', left);
+      const size_t fl = c ? (size_t)(c - b) : left;
+      if (i == 0 ? !field_ll(b, fl, &t) : !field_d(b, fl, &g[i - 1])) return KVFE_ERR_INVALID_ARG;
+      if (c) {
+        left -= fl + 1;
+        b = c + 1;
+      } else {   // line.substr(npos + 1) == the whole remainder again upstream; a short row is malformed here
+        if (i < 6) return KVFE_ERR_INVALID_ARG;
+        left = 0;
+      }
+    }
+    if (t <= previous) return KVFE_ERR_INVALID_ARG;   // "Euroc IMU data is not in chronological order!"
+    previous = t;
+    if (count < capacity) {
+      timestamps[count] = t;
+      double* o = acc_gyr + 6 * count;   // imu_accgyr << gyr_acc_data.tail(3), gyr_acc_data.head(3)
+      o[0] = g[3]; o[1] = g[4]; o[2] = g[5];
+      o[3] = g[0]; o[4] = g[1]; o[5] = g[2];
+    }
+    count++;
+  }
+  *n = (int32_t)count;
+  return count > capacity ? KVFE_ERR_CAPACITY : KVFE_OK;
+}
+
+}  // extern "C"

@@ -105,6 +105,50 @@ def load() -> C.CDLL:
     L.kvfe_feature_tracking_frame.argtypes = [vp, vp, vp, sz, C.POINTER(abi.Frame), C.POINTER(abi.Frame), vp]
     for fn in NEW_R2_SYMBOLS:
         getattr(L, fn).restype = C.c_int32
+    # input side: host code
+    i64, pi32, pi64, pf64 = C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    L.kvfe_png_info.argtypes = [vp, sz, pi32, pi32, pi32]
+    L.kvfe_png_decode_gray.argtypes = [vp, sz, vp, sz, i32, i32]
+    L.kvfe_png_decode_gray_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), sz, i32, i32, i32, i32,
+                                             pi32]
+    L.kvfe_imu_buffer_create.argtypes = [i64]
+    L.kvfe_imu_buffer_create.restype = vp
+    L.kvfe_imu_buffer_destroy.argtypes = [vp]
+    L.kvfe_imu_buffer_destroy.restype = None
+    L.kvfe_imu_buffer_add.argtypes = [vp, i64, pf64]
+    L.kvfe_imu_buffer_add.restype = None
+    L.kvfe_imu_buffer_size.argtypes = [vp]
+    L.kvfe_imu_buffer_size.restype = i64
+    L.kvfe_imu_buffer_shutdown.argtypes = [vp]
+    L.kvfe_imu_buffer_shutdown.restype = None
+    L.kvfe_imu_buffer_between.argtypes = [vp, i64, i64, i32, pi64, pf64, i32, pi32]
+    L.kvfe_imu_buffer_interpolated_upper_border.argtypes = [vp, i64, i64, pi64, pf64, i32, pi32]
+    L.kvfe_imu_buffer_interpolated_borders.argtypes = [vp, i64, i64, pi64, pf64, i32, pi32]
+    L.kvfe_imu_linear_interpolate.argtypes = [i64, pf64, i64, pf64, i64, pf64]
+    L.kvfe_imu_linear_interpolate.restype = None
+    L.kvfe_stereo_sync_create.argtypes = [i64]
+    L.kvfe_stereo_sync_create.restype = vp
+    L.kvfe_stereo_sync_destroy.argtypes = [vp]
+    L.kvfe_stereo_sync_destroy.restype = None
+    L.kvfe_stereo_sync_fill_left.argtypes = [vp, i64, i64]
+    L.kvfe_stereo_sync_fill_left.restype = None
+    L.kvfe_stereo_sync_fill_right.argtypes = [vp, i64, i64]
+    L.kvfe_stereo_sync_fill_right.restype = None
+    L.kvfe_stereo_sync_fill_imu.argtypes = [vp, i64, pf64]
+    L.kvfe_stereo_sync_fill_imu.restype = None
+    L.kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync.argtypes = [vp]
+    L.kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync.restype = None
+    L.kvfe_stereo_sync_set_imu_time_shift.argtypes = [vp, f64]
+    L.kvfe_stereo_sync_set_imu_time_shift.restype = None
+    L.kvfe_stereo_sync_shutdown.argtypes = [vp]
+    L.kvfe_stereo_sync_shutdown.restype = None
+    L.kvfe_stereo_sync_next.argtypes = [vp, C.POINTER(abi.SyncPacket), pi64, pf64, i32]
+    L.kvfe_euroc_parse_camera_csv.argtypes = [C.c_char_p, sz, pi64, i32, pi32]
+    L.kvfe_euroc_parse_imu_csv.argtypes = [C.c_char_p, sz, pi64, pf64, i32, pi32]
+    for fn in ("kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_imu_buffer_between",
+               "kvfe_imu_buffer_interpolated_upper_border", "kvfe_imu_buffer_interpolated_borders",
+               "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv"):
+        getattr(L, fn).restype = C.c_int32
     for fn in ("kvfe_create", "kvfe_compute_rectification", "kvfe_compute_undistort_rectify_maps",
                "kvfe_get_rectification", "kvfe_undistort_rectify_image",
                "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors",
@@ -131,7 +175,17 @@ NEW_R2_SYMBOLS = [
     "kvfe_feature_detection_frame", "kvfe_feature_tracking_frame", "kvfe_pnp", "kvfe_frontend_update_map",
 ]
 
-EXPORTED_SYMBOLS = NEW_R2_SYMBOLS + [
+INPUT_SIDE_SYMBOLS = [
+    "kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_imu_buffer_create",
+    "kvfe_imu_buffer_destroy", "kvfe_imu_buffer_add", "kvfe_imu_buffer_size", "kvfe_imu_buffer_shutdown",
+    "kvfe_imu_buffer_between", "kvfe_imu_buffer_interpolated_upper_border", "kvfe_imu_buffer_interpolated_borders",
+    "kvfe_imu_linear_interpolate", "kvfe_stereo_sync_create", "kvfe_stereo_sync_destroy",
+    "kvfe_stereo_sync_fill_left", "kvfe_stereo_sync_fill_right", "kvfe_stereo_sync_fill_imu",
+    "kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync", "kvfe_stereo_sync_set_imu_time_shift",
+    "kvfe_stereo_sync_shutdown", "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv",
+]
+
+EXPORTED_SYMBOLS = NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
     "kvfe_version", "kvfe_status_string", "kvfe_last_error", "kvfe_default_frontend_params",
     "kvfe_create", "kvfe_destroy", "kvfe_compute_rectification",
     "kvfe_compute_undistort_rectify_maps", "kvfe_get_rectification", "kvfe_undistort_rectify_image",

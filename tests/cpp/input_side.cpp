@@ -1,0 +1,76 @@
+// Host program over include/kvfe_adapter.hpp only (plain g++, links libkvfe.so): the input-side classes with the
+// reference's names, driven through cases of tests/testStereoProvider.cpp and tests/testThreadsafeImuBuffer.cpp.
+// Prints one line per check; tests/test_host_logic.py compares them with the expected transcript.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+
+#include "kvfe_adapter.hpp"
+
+using kvfe::StereoDataProviderModule;
+using kvfe::StereoImuSyncPacket;
+using Buf = kvfe::utils::ThreadsafeImuBuffer;
+
+static void spin(const char* what, StereoDataProviderModule& m) {
+  StereoImuSyncPacket p;
+  const bool got = m.getInputPacket(&p);
+  std::printf("%s: %s action=%d", what, got ? "packet" : "none", m.lastAction());
+  if (got) {
+    std::printf(" t=%lld tags=%lld,%lld imu=", (long long)p.timestamp, (long long)p.left_frame_tag,
+                (long long)p.right_frame_tag);
+    for (size_t i = 0; i < p.imu.timestamps.size(); i++) std::printf("%s%lld", i ? "," : "", (long long)p.imu.timestamps[i]);
+  }
+  std::printf("\n");
+}
+
+int main(int argc, char** argv) {
+  const double zero[6] = {0, 0, 0, 0, 0, 0};
+  {   // testStereoProvider.cpp:526-560 dropRightFrame
+    StereoDataProviderModule m;
+    int64_t id = 0;
+    auto frame = [&](int64_t t, bool right = true) {
+      m.fillLeftFrameQueue(t, id);
+      if (right) m.fillRightFrameQueue(t, id);
+      id++;
+    };
+    m.fillImuQueue(0, zero);
+    frame(1);
+    spin("first", m);
+    for (int64_t t : {2, 3, 4}) m.fillImuQueue(t, zero);
+    frame(5, false);
+    m.fillImuQueue(6, zero);
+    m.fillImuQueue(7, zero);
+    frame(8);
+    m.fillImuQueue(9, zero);
+    spin("no right", m);
+    spin("valid", m);
+    spin("empty", m);
+  }
+  {   // testThreadsafeImuBuffer.cpp:194-279
+    Buf b(-1);
+    for (int64_t t : {10, 15, 20, 25, 30, 40, 50}) {
+      const double v[6] = {(double)t, (double)t, (double)t, (double)t, (double)t, (double)t};
+      b.addMeasurement(t, v);
+    }
+    kvfe::ImuMeasurements m;
+    const Buf::QueryResult r = b.getImuDataInterpolatedBorders(21, 29, &m);
+    std::printf("borders(21,29): result=%d cols=%d stamps=%lld,%lld,%lld values=%g,%g,%g\n", (int)r, m.cols(),
+                (long long)m.timestamps[0], (long long)m.timestamps[1], (long long)m.timestamps[2], m.acc_gyr[0],
+                m.acc_gyr[6], m.acc_gyr[12]);
+    const Buf::QueryResult r2 = b.getImuDataInterpolatedBorders(40, 51, &m);
+    std::printf("borders(40,51): result=%d cols=%d\n", (int)r2, m.cols());
+    const Buf::QueryResult r3 = b.getImuDataBtwTimestamps(21, 24, &m);
+    std::printf("between(21,24): result=%d cols=%d\n", (int)r3, m.cols());
+  }
+  if (argc > 1) {   // a PNG file: size and a checksum of the decoded grey image
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    int rows = 0, cols = 0;
+    const std::vector<uint8_t> img = kvfe::ReadAndConvertToGrayScale(data.data(), data.size(), &rows, &cols);
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < img.size(); i++) sum += (unsigned long long)img[i] * (i % 251 + 1);
+    std::printf("png: %dx%d checksum=%llu\n", cols, rows, sum);
+  }
+  return 0;
+}

@@ -157,3 +157,30 @@ def test_device_std_sort_restatement_equals_libstdcxx():
     assert r.returncode == 0, r.stderr
     r = subprocess.run([os.path.join(cpp, "stdsort_check"), "1200"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_cpp_adapter_input_side_classes():
+    """tests/cpp/input_side.cpp: the C++ adapter's utils::ThreadsafeImuBuffer / StereoDataProviderModule /
+    ReadAndConvertToGrayScale (include/kvfe_adapter.hpp) through reference cases (testStereoProvider.cpp:526-560
+    dropRightFrame, testThreadsafeImuBuffer.cpp:194-279) and a committed frame; host only, no GPU"""
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    r = subprocess.run(["make", "-C", cpp, "input_side"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    png = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "left_img_0.png")
+    r = subprocess.run([os.path.join(cpp, "input_side"), png], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    a = np.asarray(Image.open(png)).reshape(-1).astype(np.uint64)
+    checksum = int((a * (np.arange(a.size, dtype=np.uint64) % 251 + 1)).sum())
+    assert r.stdout.splitlines() == [
+        "first: none action=5",                                            # KVFE_SYNC_DROP_FIRST_FRAME
+        "no right: none action=8",                                         # KVFE_SYNC_DROP_NO_RIGHT
+        "valid: packet action=0 t=8 tags=2,2 imu=1,2,3,4,6,7,8",
+        "empty: none action=1",
+        "borders(21,29): result=0 cols=3 stamps=21,25,29 values=21,25,29",
+        "borders(40,51): result=1 cols=0",                                 # kDataNotYetAvailable
+        "between(21,24): result=4 cols=0",                                 # kTooFewMeasurementsAvailable
+        f"png: 752x480 checksum={checksum}",
+    ]
