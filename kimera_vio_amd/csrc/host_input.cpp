@@ -234,6 +234,7 @@ kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stri
   }
   std::vector<uint8_t> raw(total);
   {
+    if (idat.size() > 0xffffffffull || raw.size() > 0xffffffffull) return KVFE_ERR_UNSUPPORTED;   // zlib's 32-bit counts
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) return KVFE_ERR_INVALID_ARG;
@@ -405,9 +406,21 @@ kvfe_status kvfe_png_info(const uint8_t* data, size_t size, int32_t* width, int3
   return KVFE_OK;
 }
 
+// the C boundary never throws: an allocation failure inside the decoder is reported, not propagated
+static kvfe_status png_decode_noexcept(const uint8_t* data, size_t size, uint8_t* dst, size_t dst_stride,
+                                       int32_t width, int32_t height) noexcept {
+  try {
+    return png_decode(data, size, dst, dst_stride, width, height);
+  } catch (const std::bad_alloc&) {
+    return KVFE_ERR_CAPACITY;
+  } catch (...) {
+    return KVFE_ERR_INVALID_ARG;
+  }
+}
+
 kvfe_status kvfe_png_decode_gray(const uint8_t* data, size_t size, uint8_t* dst, size_t dst_stride, int32_t width,
                                  int32_t height) {
-  return png_decode(data, size, dst, dst_stride, width, height);
+  return png_decode_noexcept(data, size, dst, dst_stride, width, height);
 }
 
 kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t* sizes, uint8_t* const* dst,
@@ -419,28 +432,35 @@ kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t*
   if (hw == 0) hw = 1;
   int nt = threads > 0 ? threads : (int)std::min<unsigned>(hw, (unsigned)n);
   nt = std::max(1, std::min(nt, n));
-  std::vector<kvfe_status> local((size_t)n, KVFE_OK);
-  std::atomic<int> next{0};
-  auto work = [&]() {
-    for (;;) {
-      const int i = next.fetch_add(1);
-      if (i >= n) return;
-      local[i] = png_decode(data[i], sizes[i], dst[i], dst_stride, width, height);
-    }
-  };
-  if (nt == 1) {
-    work();
-  } else {
+  try {
+    std::vector<kvfe_status> local((size_t)n, KVFE_OK);
+    std::atomic<int> next{0};
+    auto work = [&]() noexcept {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) return;
+        local[i] = png_decode_noexcept(data[i], sizes[i], dst[i], dst_stride, width, height);
+      }
+    };
     std::vector<std::thread> pool;
-    for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    for (int t = 1; t < nt; t++) {   // the calling thread is worker 0; a thread that cannot be started is done without
+      try {
+        pool.emplace_back(work);
+      } catch (const std::exception&) {
+        break;
+      }
+    }
+    work();
     for (auto& th : pool) th.join();
+    kvfe_status first = KVFE_OK;
+    for (int i = 0; i < n; i++) {
+      if (status) status[i] = local[i];
+      if (first == KVFE_OK && local[i] != KVFE_OK) first = local[i];
+    }
+    return first;
+  } catch (const std::bad_alloc&) {
+    return KVFE_ERR_CAPACITY;
   }
-  kvfe_status first = KVFE_OK;
-  for (int i = 0; i < n; i++) {
-    if (status) status[i] = local[i];
-    if (first == KVFE_OK && local[i] != KVFE_OK) first = local[i];
-  }
-  return first;
 }
 
 kvfe_imu_buffer* kvfe_imu_buffer_create(int64_t buffer_length_ns) {
@@ -450,7 +470,11 @@ kvfe_imu_buffer* kvfe_imu_buffer_create(int64_t buffer_length_ns) {
 }
 void kvfe_imu_buffer_destroy(kvfe_imu_buffer* b) { delete b; }
 void kvfe_imu_buffer_add(kvfe_imu_buffer* b, int64_t timestamp_ns, const double acc_gyr[6]) {
-  if (b && acc_gyr) b->add(timestamp_ns, acc_gyr);
+  if (!b || !acc_gyr) return;
+  try {
+    b->add(timestamp_ns, acc_gyr);
+  } catch (const std::bad_alloc&) {   // out of memory: the sample is lost, like one that arrived out of order
+  }
 }
 int64_t kvfe_imu_buffer_size(const kvfe_imu_buffer* b) {
   if (!b) return 0;
@@ -472,11 +496,15 @@ static int32_t imu_query_c(kvfe_imu_buffer* b, int mode, int64_t t_from, int64_t
                            int64_t* stamps, double* acc_gyr, int32_t capacity, int32_t* n) {
   if (n) *n = 0;
   if (!b || capacity < 0 || (capacity > 0 && (!stamps || !acc_gyr))) return KVFE_IMU_DATA_NEVER_AVAILABLE;
-  std::vector<int64_t> ts;
-  std::vector<AccGyr> vs;
-  const int q = imu_query(b, mode, t_from, t_to, lower != 0, ts, vs);
-  if (q != KVFE_IMU_DATA_AVAILABLE) return q;
-  return imu_emit(ts, vs, stamps, acc_gyr, capacity, n);
+  try {
+    std::vector<int64_t> ts;
+    std::vector<AccGyr> vs;
+    const int q = imu_query(b, mode, t_from, t_to, lower != 0, ts, vs);
+    if (q != KVFE_IMU_DATA_AVAILABLE) return q;
+    return imu_emit(ts, vs, stamps, acc_gyr, capacity, n);
+  } catch (const std::bad_alloc&) {
+    return KVFE_IMU_TOO_FEW_MEASUREMENTS;
+  }
 }
 int32_t kvfe_imu_buffer_between(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to, int32_t get_lower_bound,
                                 int64_t* stamps, double* acc_gyr, int32_t capacity, int32_t* n) {
@@ -500,15 +528,21 @@ void kvfe_stereo_sync_destroy(kvfe_stereo_sync* s) { delete s; }
 void kvfe_stereo_sync_fill_left(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(s->mu);
-  s->left.push_back({timestamp_ns, tag});
+  try {
+    s->left.push_back({timestamp_ns, tag});
+  } catch (const std::bad_alloc&) {   // out of memory: the frame is dropped
+  }
 }
 void kvfe_stereo_sync_fill_right(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(s->mu);
-  s->right.push_back({timestamp_ns, tag});
+  try {
+    s->right.push_back({timestamp_ns, tag});
+  } catch (const std::bad_alloc&) {   // out of memory: the frame is dropped
+  }
 }
 void kvfe_stereo_sync_fill_imu(kvfe_stereo_sync* s, int64_t timestamp_ns, const double acc_gyr[6]) {
-  if (s && acc_gyr) s->imu.add(timestamp_ns, acc_gyr);
+  if (s) kvfe_imu_buffer_add(&s->imu, timestamp_ns, acc_gyr);
 }
 void kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync(kvfe_stereo_sync* s) {
   if (!s) return;
@@ -570,7 +604,12 @@ int32_t kvfe_stereo_sync_next(kvfe_stereo_sync* s, kvfe_sync_packet* packet, int
   const int64_t t_last = s->timestamp_last_frame + correction + shift, t_cur = lf.t + correction + shift;
   std::vector<int64_t> ts;
   std::vector<AccGyr> vs;
-  const int q = imu_query(&s->imu, 2, t_last, t_cur, false, ts, vs);
+  int q;
+  try {
+    q = imu_query(&s->imu, 2, t_last, t_cur, false, ts, vs);
+  } catch (const std::bad_alloc&) {
+    return KVFE_SYNC_WAIT_IMU;   // out of memory: nothing consumed, no state changed -- the caller may try again
+  }
   if (q == KVFE_IMU_DATA_AVAILABLE && (int64_t)ts.size() > capacity) {
     packet->n_imu = (int32_t)ts.size();
     return -1;   // nothing consumed, no state changed
