@@ -18,8 +18,11 @@
 // kvfe::Error carrying the kvfe_status and kvfe_last_error() text instead (never UB, never a
 // silent CPU fallback — there is none).
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -814,6 +817,112 @@ class StereoDataProviderModule {
  private:
   kvfe_stereo_sync* s_;
   int last_action_ = KVFE_SYNC_EMPTY;
+};
+
+// EurocDataProvider (include/kimera-vio/dataprovider/EurocDataProvider.h; src/dataprovider/EurocDataProvider.cpp:
+// 108-195 spin / spinOnce, 229-306 parseImuData, 437-482 parseDataset / parseCameraData, 741-751 clipFinalFrame) in
+// sequential mode: parses <dataset_path>/mav0/{cam0,cam1,imu0}/data.csv, spin() sends every IMU sample once and then
+// the frame pairs initial_k .. final_k - 1, decoded to 8-bit grey, through the callbacks.
+class EurocDataProvider {
+ public:
+  using ImuCallback = std::function<void(int64_t timestamp, const double acc_gyr[6])>;
+  using FrameCallback = std::function<void(int64_t k, int64_t timestamp, const uint8_t* img, int rows, int cols)>;
+
+  EurocDataProvider(const std::string& dataset_path, int64_t initial_k, int64_t final_k) : path_(dataset_path) {
+    imu_ = parse_imu(read(path_ + "/mav0/imu0/data.csv"));
+    left_ = parse_cam(read(path_ + "/mav0/cam0/data.csv"));
+    right_ = parse_cam(read(path_ + "/mav0/cam1/data.csv"));
+    initial_k_ = initial_k;
+    final_k_ = std::min<int64_t>(final_k, (int64_t)left_.size());   // clipFinalFrame
+    if (!(final_k_ > initial_k_)) throw Error(KVFE_ERR_INVALID_ARG, "EurocDataProvider: final_k must exceed initial_k");
+    current_k_ = initial_k_;
+  }
+  void registerImuSingleCallback(ImuCallback cb) { imu_cb_ = std::move(cb); }
+  void registerLeftFrameCallback(FrameCallback cb) { left_cb_ = std::move(cb); }
+  void registerRightFrameCallback(FrameCallback cb) { right_cb_ = std::move(cb); }
+  size_t getNumImages() const { return left_.size(); }
+  int64_t timestampAtFrame(int64_t k) const { return left_.at((size_t)k); }
+  bool hasData() const { return current_k_ < final_k_; }
+  std::string getLeftImgName(int64_t k) const { return img_name("cam0", left_, k); }
+  std::string getRightImgName(int64_t k) const { return img_name("cam1", right_, k); }
+
+  bool spinOnce() {
+    if (current_k_ >= final_k_) return false;
+    const int64_t k = current_k_, t = timestampAtFrame(k);
+    std::vector<uint8_t> lf, rf;
+    const std::string ln = getLeftImgName(k), rn = getRightImgName(k);
+    if (!ln.empty() && !rn.empty() && try_read(ln, &lf) && try_read(rn, &rf)) {
+      int r0 = 0, c0 = 0, r1 = 0, c1 = 0;
+      const std::vector<uint8_t> li = ReadAndConvertToGrayScale(lf.data(), lf.size(), &r0, &c0);
+      const std::vector<uint8_t> ri = ReadAndConvertToGrayScale(rf.data(), rf.size(), &r1, &c1);
+      if (left_cb_) left_cb_(k, t, li.data(), r0, c0);
+      if (right_cb_) right_cb_(k, t, ri.data(), r1, c1);
+    }   // else: "Missing left/right stereo pair, proceeding to the next one."
+    current_k_++;
+    return true;
+  }
+  bool spin() {
+    if (!imu_sent_) {
+      if (imu_cb_)
+        for (size_t i = 0; i < imu_.timestamps.size(); i++) imu_cb_(imu_.timestamps[i], &imu_.acc_gyr[6 * i]);
+      imu_sent_ = true;
+    }
+    while (spinOnce()) {
+    }
+    return false;
+  }
+  const ImuMeasurements& imuMeasurements() const { return imu_; }
+
+ private:
+  static bool try_read(const std::string& name, std::vector<uint8_t>* out) {
+    std::FILE* f = std::fopen(name.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out->resize(n > 0 ? (size_t)n : 0);
+    const size_t got = out->empty() ? 0 : std::fread(out->data(), 1, out->size(), f);
+    std::fclose(f);
+    return got == out->size();
+  }
+  static std::vector<uint8_t> read(const std::string& name) {
+    std::vector<uint8_t> d;
+    if (!try_read(name, &d)) throw Error(KVFE_ERR_INVALID_ARG, "EurocDataProvider: cannot open file: " + name);
+    return d;
+  }
+  static std::vector<int64_t> parse_cam(const std::vector<uint8_t>& text) {
+    int32_t n = 0;
+    kvfe_status st = kvfe_euroc_parse_camera_csv(reinterpret_cast<const char*>(text.data()), text.size(), nullptr, 0, &n);
+    if (st != KVFE_OK && st != KVFE_ERR_CAPACITY) throw Error(st, "EurocDataProvider: malformed camera data.csv");
+    std::vector<int64_t> ts((size_t)n);
+    st = kvfe_euroc_parse_camera_csv(reinterpret_cast<const char*>(text.data()), text.size(), ts.data(), n, &n);
+    if (st != KVFE_OK) throw Error(st, "EurocDataProvider: malformed camera data.csv");
+    return ts;
+  }
+  static ImuMeasurements parse_imu(const std::vector<uint8_t>& text) {
+    int32_t n = 0;
+    kvfe_status st =
+        kvfe_euroc_parse_imu_csv(reinterpret_cast<const char*>(text.data()), text.size(), nullptr, nullptr, 0, &n);
+    if (st != KVFE_OK && st != KVFE_ERR_CAPACITY) throw Error(st, "EurocDataProvider: malformed imu data.csv");
+    ImuMeasurements m;
+    m.timestamps.resize((size_t)n);
+    m.acc_gyr.resize((size_t)6 * n);
+    st = kvfe_euroc_parse_imu_csv(reinterpret_cast<const char*>(text.data()), text.size(), m.timestamps.data(),
+                                  m.acc_gyr.data(), n, &n);
+    if (st != KVFE_OK) throw Error(st, "EurocDataProvider: malformed imu data.csv");
+    return m;
+  }
+  std::string img_name(const char* cam, const std::vector<int64_t>& stamps, int64_t k) const {
+    if (k < 0 || (size_t)k >= stamps.size()) return std::string();
+    return path_ + "/mav0/" + cam + "/data/" + std::to_string(stamps[(size_t)k]) + ".png";
+  }
+  std::string path_;
+  ImuMeasurements imu_;
+  std::vector<int64_t> left_, right_;
+  int64_t initial_k_ = 0, final_k_ = 0, current_k_ = 0;
+  bool imu_sent_ = false;
+  ImuCallback imu_cb_;
+  FrameCallback left_cb_, right_cb_;
 };
 
 }  // namespace kvfe

@@ -63,7 +63,35 @@ int main(int argc, char** argv) {
     const Buf::QueryResult r3 = b.getImuDataBtwTimestamps(21, 24, &m);
     std::printf("between(21,24): result=%d cols=%d\n", (int)r3, m.cols());
   }
-  if (argc > 1) {   // a PNG file: size and a checksum of the decoded grey image
+  if (argc > 2) {   // an EuRoC-layout dataset: EurocDataProvider -> StereoDataProviderModule -> packets
+    kvfe::EurocDataProvider prov(argv[2], 0, 1 << 30);
+    StereoDataProviderModule sync;
+    unsigned long long pix = 0;
+    prov.registerImuSingleCallback([&](int64_t t, const double* ag) { sync.fillImuQueue(t, ag); });
+    prov.registerLeftFrameCallback([&](int64_t k, int64_t t, const uint8_t* img, int rows, int cols) {
+      for (int i = 0; i < rows * cols; i++) pix += img[i];
+      sync.fillLeftFrameQueue(t, k);
+    });
+    prov.registerRightFrameCallback([&](int64_t k, int64_t t, const uint8_t* img, int rows, int cols) {
+      for (int i = 0; i < rows * cols; i++) pix += 3ull * img[i];
+      sync.fillRightFrameQueue(t, k);
+    });
+    prov.spin();
+    std::printf("dataset: images=%zu imu=%d pixel_sum=%llu\n", prov.getNumImages(), prov.imuMeasurements().cols(), pix);
+    for (;;) {
+      StereoImuSyncPacket p;
+      const bool got = sync.getInputPacket(&p);
+      if (!got && sync.lastAction() == KVFE_SYNC_EMPTY) break;
+      if (got)
+        std::printf("packet: t=%lld tag=%lld,%lld n_imu=%d first=%lld last=%lld acc0=%.17g\n", (long long)p.timestamp,
+                    (long long)p.left_frame_tag, (long long)p.right_frame_tag, p.imu.cols(), (long long)p.imu.timestamps.front(),
+                    (long long)p.imu.timestamps.back(), p.imu.acc_gyr[0]);
+      else
+        std::printf("dropped: action=%d\n", sync.lastAction());
+      if (!got && sync.lastAction() == KVFE_SYNC_WAIT_IMU) break;   // (upstream would block here until IMU data arrives)
+    }
+  }
+  if (argc > 1 && argv[1][0]) {   // a PNG file: size and a checksum of the decoded grey image
     std::ifstream f(argv[1], std::ios::binary);
     std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     int rows = 0, cols = 0;

@@ -738,3 +738,61 @@ def test_micro_euroc_dataset_of_the_reference():
         inner = imu_t[(imu_t > a) & (imu_t < b)]
         assert p.imu_stamps.tolist() == [a] + inner.tolist() + [b]
         assert np.array_equal(p.imu_accgyrs[:, 1:-1].T, imu[(imu_t > a) & (imu_t < b)][:, [4, 5, 6, 1, 2, 3]])
+
+
+def test_cpp_euroc_data_provider_equals_python(tmp_path):
+    """include/kvfe_adapter.hpp's EurocDataProvider + StereoDataProviderModule (tests/cpp/input_side.cpp) on a dataset
+    written here: the same packets, drops and pixels as the Python mirror"""
+    import subprocess
+    rng = np.random.default_rng(4)
+    t0, n_frames = 2_000_000_000, 7
+    frames = rng.integers(0, 256, (2, n_frames, 20, 28), dtype=np.uint8)
+    stamps = [t0 + k * 50_000_000 for k in range(n_frames)]
+    for c, cam in enumerate(("cam0", "cam1")):
+        d = tmp_path / "mav0" / cam / "data"
+        d.mkdir(parents=True)
+        lines = ["#timestamp [ns],filename"]
+        for k, t in enumerate(stamps):
+            if not (cam == "cam0" and k == 2):
+                PIL.fromarray(frames[c, k]).save(d / f"{t}.png")
+            lines.append(f"{t},{t}.png")
+        (tmp_path / "mav0" / cam / "data.csv").write_text("\n".join(lines) + "\n")
+    (tmp_path / "mav0" / "imu0").mkdir()
+    imu_t = [t0 + 3_000_000 + i * 5_000_000 for i in range(55)]        # the IMU starts after frame 0, ends before frame 6
+    rows = ["#timestamp [ns],w_x,w_y,w_z,a_x,a_y,a_z"] + \
+           [f"{t},{0.01 * i},0.2,-0.3,{1.0 + 0.125 * i},0.5,9.81" for i, t in enumerate(imu_t)]
+    (tmp_path / "mav0" / "imu0" / "data.csv").write_text("\n".join(rows) + "\n")
+
+    prov = dp.EurocDataProvider(str(tmp_path))
+    sync = dp.StereoDataProviderModule(-1)
+    pix = [0]
+
+    def cb(side):
+        def f(k, t, img):
+            pix[0] += int(img.sum()) * (1 if side == 0 else 3)
+            (sync.fillLeftFrameQueue if side == 0 else sync.fillRightFrameQueue)(t, k)
+        return f
+    prov.imu_single_callback = sync.fillImuQueue
+    prov.left_frame_callback, prov.right_frame_callback = cb(0), cb(1)
+    prov.spin()
+    want = [f"dataset: images={n_frames} imu={len(imu_t)} pixel_sum={pix[0]}"]
+    while True:
+        pk = sync.getInputPacket()
+        if pk is None and sync.last_action == abi.SYNC_EMPTY:
+            break
+        if pk is None:
+            want.append(f"dropped: action={sync.last_action}")
+            if sync.last_action == abi.SYNC_WAIT_IMU:      # the last frame waits for IMU data that never comes
+                break
+        else:
+            want.append(f"packet: t={pk.timestamp} tag={pk.left_tag},{pk.right_tag} n_imu={pk.imu_stamps.size} "
+                        f"first={pk.imu_stamps[0]} last={pk.imu_stamps[-1]} acc0={float(pk.imu_accgyrs[0, 0])!r}")
+    assert any(w.startswith("packet") for w in want) and any(w.startswith("dropped") for w in want)
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    r = subprocess.run(["make", "-C", cpp, "input_side"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([os.path.join(cpp, "input_side"), "", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith(("dataset", "packet", "dropped"))]
+    norm = lambda ln: " ".join(f"acc0={float(tok[5:])!r}" if tok.startswith("acc0=") else tok for tok in ln.split())  # noqa: E731
+    assert [norm(g) for g in got] == [norm(w) for w in want]
