@@ -789,6 +789,13 @@ typedef struct kvfe_sync_packet {
   int32_t reserved0;
 } kvfe_sync_packet;
 KVFE_API kvfe_stereo_sync* kvfe_stereo_sync_create(int64_t imu_buffer_length_ns);
+/* The same module for the other two providers: KVFE_SYNC_MODE_MONO = MonoDataProviderModule::getInputPacket
+ * (MonoDataProviderModule.cpp:30-42: no second queue, right_tag = -1); KVFE_SYNC_MODE_RGBD = RgbdDataProviderModule::
+ * getInputPacket (RgbdDataProviderModule.cpp:44-84: the "right" queue holds the depth frames, and the previous-frame
+ * timestamp advances BEFORE the depth frame is looked up -- getMonoImuSyncPacket(cache_timestamp = true) --, so a frame
+ * dropped for a missing depth image still ends the IMU interval).  Default KVFE_SYNC_MODE_STEREO. */
+enum { KVFE_SYNC_MODE_STEREO = 0, KVFE_SYNC_MODE_MONO = 1, KVFE_SYNC_MODE_RGBD = 2 };
+KVFE_API kvfe_status kvfe_stereo_sync_set_mode(kvfe_stereo_sync* s, int32_t mode);
 KVFE_API void kvfe_stereo_sync_destroy(kvfe_stereo_sync* s);
 KVFE_API void kvfe_stereo_sync_fill_left(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag);
 KVFE_API void kvfe_stereo_sync_fill_right(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag);

@@ -777,8 +777,10 @@ struct StereoImuSyncPacket {
 // StereoDataProviderModule in sequential mode: fill the queues, getInputPacket() = one spin
 class StereoDataProviderModule {
  public:
-  explicit StereoDataProviderModule(int64_t imu_buffer_length_ns = -1) : s_(kvfe_stereo_sync_create(imu_buffer_length_ns)) {
+  explicit StereoDataProviderModule(int64_t imu_buffer_length_ns = -1, int mode = KVFE_SYNC_MODE_STEREO)
+      : s_(kvfe_stereo_sync_create(imu_buffer_length_ns)) {
     if (!s_) throw std::bad_alloc();
+    kvfe_stereo_sync_set_mode(s_, mode);
   }
   ~StereoDataProviderModule() { kvfe_stereo_sync_destroy(s_); }
   StereoDataProviderModule(const StereoDataProviderModule&) = delete;
@@ -817,6 +819,20 @@ class StereoDataProviderModule {
  private:
   kvfe_stereo_sync* s_;
   int last_action_ = KVFE_SYNC_EMPTY;
+};
+
+// MonoDataProviderModule (MonoDataProviderModule.cpp:30-118): no second queue, packets carry right_frame_tag = -1
+class MonoDataProviderModule : public StereoDataProviderModule {
+ public:
+  explicit MonoDataProviderModule(int64_t imu_buffer_length_ns = -1)
+      : StereoDataProviderModule(imu_buffer_length_ns, KVFE_SYNC_MODE_MONO) {}
+};
+// RgbdDataProviderModule (RgbdDataProviderModule.cpp:44-84): the second queue holds the depth frames
+class RgbdDataProviderModule : public StereoDataProviderModule {
+ public:
+  explicit RgbdDataProviderModule(int64_t imu_buffer_length_ns = -1)
+      : StereoDataProviderModule(imu_buffer_length_ns, KVFE_SYNC_MODE_RGBD) {}
+  void fillDepthFrameQueue(int64_t timestamp_ns, int64_t tag) { fillRightFrameQueue(timestamp_ns, tag); }
 };
 
 // EurocDataProvider (include/kimera-vio/dataprovider/EurocDataProvider.h; src/dataprovider/EurocDataProvider.cpp:

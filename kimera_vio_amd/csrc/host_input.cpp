@@ -392,6 +392,7 @@ struct kvfe_stereo_sync {
   int64_t imu_timestamp_correction = 0;
   std::atomic<int64_t> imu_time_shift_ns{0};
   std::atomic<bool> shutdown{false};
+  int mode = KVFE_SYNC_MODE_STEREO;
 };
 
 extern "C" {
@@ -525,6 +526,12 @@ kvfe_stereo_sync* kvfe_stereo_sync_create(int64_t imu_buffer_length_ns) {
   return s;
 }
 void kvfe_stereo_sync_destroy(kvfe_stereo_sync* s) { delete s; }
+kvfe_status kvfe_stereo_sync_set_mode(kvfe_stereo_sync* s, int32_t mode) {
+  if (!s || mode < KVFE_SYNC_MODE_STEREO || mode > KVFE_SYNC_MODE_RGBD) return KVFE_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->mode = mode;
+  return KVFE_OK;
+}
 void kvfe_stereo_sync_fill_left(kvfe_stereo_sync* s, int64_t timestamp_ns, int64_t tag) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(s->mu);
@@ -641,10 +648,12 @@ int32_t kvfe_stereo_sync_next(kvfe_stereo_sync* s, kvfe_sync_packet* packet, int
   }
   for (int64_t& t : ts) t -= correction + shift;   // "adjust the timestamps for the frontend"
   consume_left();
-  // ---- syncQueue(timestamp, &right_frame_queue_) ------------------------------------------------
-  bool found = false;
-  kvfe_stereo_sync::FrameRef rf{0, 0};
-  while (!s->right.empty()) {
+  // getMonoImuSyncPacket(cache_timestamp): true for the mono and RGBD providers, false for the stereo one
+  if (s->mode != KVFE_SYNC_MODE_STEREO) s->timestamp_last_frame = lf.t;
+  // ---- syncQueue(timestamp, &right_frame_queue_ / &depth_frame_queue_) --------------------------
+  bool found = s->mode == KVFE_SYNC_MODE_MONO;
+  kvfe_stereo_sync::FrameRef rf{0, -1};
+  while (!found && !s->right.empty()) {
     const kvfe_stereo_sync::FrameRef cur = s->right.front();
     if (cur.t > lf.t) break;          // "Could not retrieve exact timestamp requested": left in the queue
     s->right.pop_front();

@@ -157,11 +157,14 @@ class StereoDataProviderModule:
     """StereoDataProviderModule in sequential mode: fill the queues, call getInputPacket() (spinOnce).
     `last_action` is the KVFE_SYNC_* code of the last call (why a frame was dropped, or that the module waits)."""
 
+    MODE = 0   # KVFE_SYNC_MODE_STEREO
+
     def __init__(self, imu_buffer_length_ns: int = -1):
         self._lib = load()
         self._h = self._lib.kvfe_stereo_sync_create(imu_buffer_length_ns)
         if not self._h:
             raise MemoryError("kvfe_stereo_sync_create")
+        _check(self._lib.kvfe_stereo_sync_set_mode(self._h, self.MODE), "kvfe_stereo_sync_set_mode")
         self.last_action = abi.SYNC_EMPTY
 
     def __del__(self):
@@ -205,6 +208,21 @@ class StereoDataProviderModule:
                 return None
             return StereoImuSyncPacket(pk.timestamp_ns, pk.left_tag, pk.right_tag, stamps[:pk.n_imu].copy(),
                                        vals[:pk.n_imu].T.copy())
+
+
+class MonoDataProviderModule(StereoDataProviderModule):
+    """MonoDataProviderModule (src/dataprovider/MonoDataProviderModule.cpp:30-118): left frames + IMU only; packets
+    carry right_tag = -1"""
+    MODE = 1   # KVFE_SYNC_MODE_MONO
+
+
+class RgbdDataProviderModule(StereoDataProviderModule):
+    """RgbdDataProviderModule (src/dataprovider/RgbdDataProviderModule.cpp:44-84): the second queue holds the depth
+    frames (fillDepthFrameQueue); a frame whose depth image is missing is dropped but still ends the IMU interval"""
+    MODE = 2   # KVFE_SYNC_MODE_RGBD
+
+    def fillDepthFrameQueue(self, timestamp_ns: int, tag: int):
+        self.fillRightFrameQueue(timestamp_ns, tag)
 
 
 # ---------------------------------------------------------------------------------------------------------

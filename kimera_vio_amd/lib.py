@@ -130,6 +130,8 @@ def load() -> C.CDLL:
     L.kvfe_stereo_sync_create.restype = vp
     L.kvfe_stereo_sync_destroy.argtypes = [vp]
     L.kvfe_stereo_sync_destroy.restype = None
+    L.kvfe_stereo_sync_set_mode.argtypes = [vp, i32]
+    L.kvfe_stereo_sync_set_mode.restype = C.c_int32
     L.kvfe_stereo_sync_fill_left.argtypes = [vp, i64, i64]
     L.kvfe_stereo_sync_fill_left.restype = None
     L.kvfe_stereo_sync_fill_right.argtypes = [vp, i64, i64]
@@ -179,7 +181,7 @@ INPUT_SIDE_SYMBOLS = [
     "kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_imu_buffer_create",
     "kvfe_imu_buffer_destroy", "kvfe_imu_buffer_add", "kvfe_imu_buffer_size", "kvfe_imu_buffer_shutdown",
     "kvfe_imu_buffer_between", "kvfe_imu_buffer_interpolated_upper_border", "kvfe_imu_buffer_interpolated_borders",
-    "kvfe_imu_linear_interpolate", "kvfe_stereo_sync_create", "kvfe_stereo_sync_destroy",
+    "kvfe_imu_linear_interpolate", "kvfe_stereo_sync_create", "kvfe_stereo_sync_destroy", "kvfe_stereo_sync_set_mode",
     "kvfe_stereo_sync_fill_left", "kvfe_stereo_sync_fill_right", "kvfe_stereo_sync_fill_imu",
     "kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync", "kvfe_stereo_sync_set_imu_time_shift",
     "kvfe_stereo_sync_shutdown", "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv",

@@ -85,7 +85,8 @@ class StereoProvider:
     (PACKET, EMPTY, WAIT_IMU, DROP_OUT_OF_ORDER, DROP_NO_IMU, DROP_FIRST_FRAME, DROP_IMU_NEVER, DROP_IMU_TOO_FEW,
      DROP_NO_RIGHT, SHUTDOWN) = range(10)
 
-    def __init__(self):
+    def __init__(self, mode=0):        # 0 stereo, 1 mono, 2 RGBD (second queue = depth frames)
+        self.mode = mode
         self.left, self.right = [], []
         self.imu = ImuBuffer(-1)
         self.cached = None
@@ -123,6 +124,10 @@ class StereoProvider:
         if q != K_AVAILABLE:
             return self.DROP_IMU_TOO_FEW, None
         ts = [x - off for x in ts]
+        if self.mode != 0:                 # getMonoImuSyncPacket(cache_timestamp = true)
+            self.last = t
+        if self.mode == 1:
+            return self.PACKET, (t, lf[1], -1, ts, vs)
         rf = None
         while self.right:                  # syncQueue
             cur = self.right[0]

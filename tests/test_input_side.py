@@ -796,3 +796,101 @@ def test_cpp_euroc_data_provider_equals_python(tmp_path):
     got = [ln for ln in r.stdout.splitlines() if ln.startswith(("dataset", "packet", "dropped"))]
     norm = lambda ln: " ".join(f"acc0={float(tok[5:])!r}" if tok.startswith("acc0=") else tok for tok in ln.split())  # noqa: E731
     assert [norm(g) for g in got] == [norm(w) for w in want]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MonoDataProviderModule (tests/testMonoProvider.cpp: the stereo cases without a right queue) and RgbdDataProviderModule
+# ---------------------------------------------------------------------------------------------------------------
+def _mono_script(events):
+    m = dp.MonoDataProviderModule(-1)
+    out, tag = [], 0
+    for kind, t in events:
+        if kind == "i":
+            m.fillImuQueue(t, np.zeros(6))
+        elif kind == "f":
+            m.fillLeftFrameQueue(t, tag)
+            tag += 1
+        else:
+            pk = m.getInputPacket()
+            out.append(None if pk is None else (pk.timestamp, pk.left_tag, pk.right_tag, pk.imu_stamps.tolist()))
+    return out
+
+
+def test_mono_provider_reference_cases():
+    S = ("s", None)
+    # basicSequentialCase (:77-107)
+    assert _mono_script([("i", 10), ("f", 11), S, ("i", 12), ("i", 13), ("i", 14), ("f", 17), ("i", 18), S]) == \
+        [None, (17, 1, -1, [11, 12, 13, 14, 17])]
+    # dropFramesOlderThanImu (:109-142)
+    ev = [("i", 10), ("f", 11), S, ("i", 16)]
+    for t in range(12, 16):
+        ev += [("f", t), S]
+    ev += [("f", 17), ("i", 18), S]
+    assert _mono_script(ev) == [None] * 5 + [(17, 5, -1, [11, 16, 17])]
+    # imageBeforeImuDelayedSpinTest (:206-232)
+    assert _mono_script([("f", 10), ("i", 11), ("f", 12), ("i", 13), ("f", 14), ("i", 15), S, S, S]) == \
+        [None, None, (14, 2, -1, [12, 13, 14])]
+    # monoPipelineInvalidImuSequence (:257-273), testPartialImuSequence (:275-303)
+    assert _mono_script([("i", 10), ("f", 1), S, ("i", 11), ("i", 12), ("i", 13), ("f", 3), S]) == [None, None]
+    assert _mono_script([("i", 0), ("f", 1), S, ("i", 2), ("i", 3), ("i", 4), ("f", 5), S, ("i", 5), S]) == \
+        [None, None, (5, 1, -1, [1, 2, 3, 4, 5])]
+    # testOutOfOrderImuAndImageSequence (:363-393)
+    ev = [("i", 0), ("f", 3), S] + [("i", t) for t in (2, 4, 3, 5, 5, 5)] + [("f", 2), ("i", 5), ("i", 5), ("f", 5), S, S]
+    assert _mono_script(ev) == [None, None, (5, 2, -1, [3, 4, 5])]
+
+
+def test_rgbd_provider_missing_depth_frame_ends_the_imu_interval():
+    """RgbdDataProviderModule.cpp:44-84 caches the frame's timestamp before it looks for the depth frame (the stereo
+    module does not): after a frame without depth image the next packet's IMU data starts at THAT frame"""
+    outs = {}
+    for cls in (dp.StereoDataProviderModule, dp.RgbdDataProviderModule):
+        m = cls(-1)
+        fill2 = m.fillDepthFrameQueue if cls is dp.RgbdDataProviderModule else m.fillRightFrameQueue
+        m.fillImuQueue(0, np.zeros(6))
+        m.fillLeftFrameQueue(1, 0)
+        fill2(1, 0)
+        assert m.getInputPacket() is None
+        for t in (2, 3, 4):
+            m.fillImuQueue(t, np.zeros(6))
+        m.fillLeftFrameQueue(5, 1)                      # no depth / right frame for this one
+        m.fillImuQueue(6, np.zeros(6))
+        m.fillImuQueue(7, np.zeros(6))
+        m.fillLeftFrameQueue(8, 2)
+        fill2(8, 2)
+        m.fillImuQueue(9, np.zeros(6))
+        assert m.getInputPacket() is None and m.last_action == abi.SYNC_DROP_NO_RIGHT
+        outs[cls.__name__] = m.getInputPacket().imu_stamps.tolist()
+    assert outs == {"StereoDataProviderModule": [1, 2, 3, 4, 6, 7, 8], "RgbdDataProviderModule": [5, 6, 7, 8]}
+
+
+def test_mono_and_rgbd_providers_equal_oracle_on_random_traffic():
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        mode = 1 + trial % 2
+        p = (dp.MonoDataProviderModule if mode == 1 else dp.RgbdDataProviderModule)(-1)
+        o = ora.StereoProvider(mode)
+        t_imu, t_cam, tag = 1, 2, 0
+        for _ in range(300):
+            ev = rng.integers(0, 10)
+            if ev < 5:
+                t_imu += int(rng.integers(-1, 4))
+                v = rng.normal(size=6)
+                p.fillImuQueue(t_imu, v)
+                o.imu.add(t_imu, v)
+            elif ev < 8:
+                t_cam = max(1, t_cam + int(rng.integers(-2, 7)))
+                p.fillLeftFrameQueue(t_cam, tag)
+                o.left.append((t_cam, tag))
+                if mode == 2 and rng.integers(0, 8) != 0:
+                    p.fillRightFrameQueue(t_cam, tag)
+                    o.right.append((t_cam, tag))
+                tag += 1
+            else:
+                r = p.getInputPacket()
+                code, pk = o.spin()
+                assert p.last_action == code
+                if pk is None:
+                    assert r is None
+                else:
+                    assert (r.timestamp, r.left_tag, r.right_tag, r.imu_stamps.tolist()) == (pk[0], pk[1], pk[2], pk[3])
+                    assert np.array_equal(r.imu_accgyrs.T, np.asarray(pk[4]))
