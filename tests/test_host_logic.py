@@ -184,3 +184,20 @@ def test_cpp_adapter_input_side_classes():
         "between(21,24): result=4 cols=0",                                 # kTooFewMeasurementsAvailable
         f"png: 752x480 checksum={checksum}",
     ]
+
+
+def test_input_side_under_sanitizers():
+    """tests/cpp/input_fuzz.cpp: host_input.cpp compiled with -fsanitize=address,undefined and fed with damaged PNG
+    files (CRCs repaired so that the damage reaches inflate / unfilter / expansion), 3000 well-formed containers
+    around random scan lines of every colour type / depth / interlacing, mutated index files and random
+    synchroniser traffic with too-small output arrays: no report, no write past the destination, nothing accepted
+    that kvfe_png_info refuses"""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    cpp = os.path.join(here, "cpp")
+    r = subprocess.run(["make", "-C", cpp, "input_fuzz"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([os.path.join(cpp, "input_fuzz"), os.path.join(here, "golden", "left_img_0.png"),
+                        os.path.join(here, "golden", "chessboard.png")], capture_output=True, text=True,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), r.stdout + r.stderr
