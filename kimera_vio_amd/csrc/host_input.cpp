@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cerrno>
 #include <cstdint>
 #include <cstdlib>
@@ -395,6 +396,106 @@ struct kvfe_stereo_sync {
   int mode = KVFE_SYNC_MODE_STEREO;
 };
 
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Worker pool of kvfe_png_decode_gray_batch.  Starting a thread costs 30-50 us, a 752x480 frame decodes in ~1.2 ms:
+// with one thread per file and call the caller spends longer starting 64 threads than any of them works.  The pool
+// is created on first use, grows to the largest thread count asked for (at most the hardware concurrency), lives for
+// the rest of the process (its threads are detached: nothing to join at exit) and serves one batch at a time -- a
+// second caller that finds it busy decodes on threads of its own.
+// ------------------------------------------------------------------------------------------------
+class DecodePool {
+ public:
+  static DecodePool& get() {
+    static DecodePool* p = new DecodePool();   // never destroyed: the workers may outlive static destruction
+    return *p;
+  }
+  // runs fn(i) for i in [0, n) on `threads` threads in total (the caller is one of them); false = pool busy
+  template <class F>
+  bool run(int n, int threads, const F& fn) {
+    std::unique_lock<std::mutex> owner(run_mu_, std::try_to_lock);
+    if (!owner.owns_lock()) return false;
+    struct Ctx { const F* fn; std::atomic<int> next{0}; int n; } ctx;
+    ctx.fn = &fn;
+    ctx.n = n;
+    auto body = [](void* c) noexcept {
+      Ctx* x = static_cast<Ctx*>(c);
+      for (;;) {
+        const int i = x->next.fetch_add(1);
+        if (i >= x->n) return;
+        (*x->fn)(i);
+      }
+    };
+    int helpers = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      grow(threads - 1);
+      helpers = std::min<int>(threads - 1, (int)started_);
+      job_ = body;
+      job_ctx_ = &ctx;
+      want_ = helpers;
+      taken_ = 0;
+      done_ = 0;
+      gen_++;
+    }
+    if (helpers > 0) cv_job_.notify_all();
+    body(&ctx);
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return done_ == taken_ && (taken_ == want_ || ctx.next.load() >= n); });
+    want_ = taken_;   // helpers that have not woken up yet find nothing to take
+    job_ = nullptr;
+    // (a helper that takes the job after this point cannot exist: taking happens under mu_ and checks want_)
+    return true;
+  }
+
+ private:
+  void grow(int helpers) {   // mu_ held
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    const size_t cap = hw > 1 ? hw - 1 : 0;
+    while (started_ < (size_t)std::max(helpers, 0) && started_ < cap) {
+      try {
+        std::thread([this] { worker(); }).detach();
+      } catch (const std::exception&) {
+        break;
+      }
+      started_++;
+    }
+  }
+  void worker() {
+    unsigned long long seen = 0;
+    for (;;) {
+      void (*job)(void*) noexcept = nullptr;
+      void* ctx = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_job_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (!job_ || taken_ >= want_) continue;
+        taken_++;
+        job = job_;
+        ctx = job_ctx_;
+      }
+      job(ctx);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        done_++;
+      }
+      cv_done_.notify_all();
+    }
+  }
+  std::mutex run_mu_, mu_;
+  std::condition_variable cv_job_, cv_done_;
+  void (*job_)(void*) noexcept = nullptr;
+  void* job_ctx_ = nullptr;
+  int want_ = 0, taken_ = 0, done_ = 0;
+  unsigned long long gen_ = 0;
+  size_t started_ = 0;
+};
+
+}  // namespace
+
 extern "C" {
 
 kvfe_status kvfe_png_info(const uint8_t* data, size_t size, int32_t* width, int32_t* height, int32_t* channels) {
@@ -435,24 +536,33 @@ kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t*
   nt = std::max(1, std::min(nt, n));
   try {
     std::vector<kvfe_status> local((size_t)n, KVFE_OK);
-    std::atomic<int> next{0};
-    auto work = [&]() noexcept {
-      for (;;) {
-        const int i = next.fetch_add(1);
-        if (i >= n) return;
-        local[i] = png_decode_noexcept(data[i], sizes[i], dst[i], dst_stride, width, height);
-      }
+    auto one = [&](int i) noexcept {
+      local[i] = png_decode_noexcept(data[i], sizes[i], dst[i], dst_stride, width, height);
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; t++) {   // the calling thread is worker 0; a thread that cannot be started is done without
-      try {
-        pool.emplace_back(work);
-      } catch (const std::exception&) {
-        break;
+    if (nt == 1) {
+      for (int i = 0; i < n; i++) one(i);
+    } else if (!DecodePool::get().run(n, nt, one)) {
+      // the pool serves another caller: threads of this call's own (the calling thread is worker 0; a thread that
+      // cannot be started is done without)
+      std::atomic<int> next{0};
+      auto work = [&]() noexcept {
+        for (;;) {
+          const int i = next.fetch_add(1);
+          if (i >= n) return;
+          one(i);
+        }
+      };
+      std::vector<std::thread> own;
+      for (int t = 1; t < nt; t++) {
+        try {
+          own.emplace_back(work);
+        } catch (const std::exception&) {
+          break;
+        }
       }
+      work();
+      for (auto& th : own) th.join();
     }
-    work();
-    for (auto& th : pool) th.join();
     kvfe_status first = KVFE_OK;
     for (int i = 0; i < n; i++) {
       if (status) status[i] = local[i];

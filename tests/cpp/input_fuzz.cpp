@@ -5,6 +5,8 @@
 // traffic.  Any sanitizer report or crash fails the test (tests/test_host_logic.py).
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +14,7 @@
 #include <iterator>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kvfe.h"
@@ -144,6 +147,39 @@ int main(int argc, char** argv) {
     }
     if (ok < 2000) return 8;   // most of these are valid files
     std::printf("random containers: %ld decoded, %ld refused\n", ok, bad);
+  }
+  // the batch decoder from three caller threads at once (one gets the worker pool, the others find it busy and bring
+  // threads of their own), every result checked
+  {
+    std::ifstream in(argv[1], std::ios::binary);
+    const std::vector<uint8_t> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    int32_t w = 0, h = 0, c = 0;
+    kvfe_png_info(file.data(), file.size(), &w, &h, &c);
+    std::vector<uint8_t> ref((size_t)w * h);
+    if (kvfe_png_decode_gray(file.data(), file.size(), ref.data(), (size_t)w, w, h) != KVFE_OK) return 9;
+    std::atomic<int> failures{0};
+    auto caller = [&](int id) {
+      const int n = 6 + id;
+      std::vector<std::vector<uint8_t>> outs(n, std::vector<uint8_t>((size_t)w * h));
+      std::vector<const uint8_t*> data(n, file.data());
+      std::vector<size_t> sizes(n, file.size());
+      std::vector<uint8_t*> dst(n);
+      for (int rep = 0; rep < 6; rep++) {
+        for (int i = 0; i < n; i++) {
+          std::fill(outs[i].begin(), outs[i].end(), 0);
+          dst[i] = outs[i].data();
+        }
+        if (kvfe_png_decode_gray_batch(data.data(), sizes.data(), dst.data(), (size_t)w, w, h, n, 2 + id, nullptr) != KVFE_OK)
+          failures++;
+        for (int i = 0; i < n; i++)
+          if (outs[i] != ref) failures++;
+      }
+    };
+    std::thread t0(caller, 0), t1(caller, 1), t2(caller, 2);
+    t0.join();
+    t1.join();
+    t2.join();
+    if (failures) return 10;
   }
   // CSV parsers on mutated text
   const std::string imu = "#h\n1,0.1,0.2,0.3,1,2,3\n2,0.1,0.2,0.3,1,2,3\n3,1e-3,-2E2,.5,9.81,0,-0\n";
