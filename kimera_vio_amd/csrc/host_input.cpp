@@ -184,7 +184,15 @@ kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stri
   if (st != KVFE_OK) return st;
   if (!dst || (int64_t)H.w != width || (int64_t)H.h != height || dst_stride < (size_t)width) return KVFE_ERR_INVALID_ARG;
   // chunks
-  std::vector<uint8_t> idat;
+  // Scratch of the calling thread, kept between calls: two fresh 360 kB vectors per frame are two mmap / munmap pairs
+  // and 180 page faults, which serialise the decode threads of a batch in the kernel's address-space lock.  A file
+  // with ONE IDAT chunk (every encoder's output for frames of this size) is inflated from where it lies.
+  thread_local std::vector<uint8_t> idat_joined, raw;
+  std::vector<uint8_t>& idat = idat_joined;
+  idat.clear();
+  const uint8_t* idat_ptr = nullptr;
+  size_t idat_len = 0;
+  int idat_chunks = 0;
   uint8_t pal[768];
   int npal = 0;
   size_t off = 8;
@@ -199,7 +207,15 @@ kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stri
     const bool crc_ok = (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) == be32(body + len);
     if (!crc_ok && critical) return KVFE_ERR_INVALID_ARG;   // (libpng only warns for ancillary chunks)
     if (!std::memcmp(type, "IDAT", 4)) {
-      idat.insert(idat.end(), body, body + len);
+      if (idat_chunks == 0) {
+        idat_ptr = body;
+        idat_len = len;
+      } else {
+        if (idat_chunks == 1) idat.assign(idat_ptr, idat_ptr + idat_len);
+        idat.insert(idat.end(), body, body + len);
+        idat_ptr = nullptr;
+      }
+      idat_chunks++;
     } else if (!std::memcmp(type, "PLTE", 4)) {
       if (len % 3 != 0 || len > 768) return KVFE_ERR_INVALID_ARG;
       std::memcpy(pal, body, len);
@@ -211,7 +227,11 @@ kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stri
     }
     off += 12 + (size_t)len;
   }
-  if (idat.empty() || (H.color == 3 && npal == 0)) return KVFE_ERR_INVALID_ARG;
+  if (idat_chunks > 1) {
+    idat_ptr = idat.data();
+    idat_len = idat.size();
+  }
+  if (idat_chunks == 0 || idat_len == 0 || (H.color == 3 && npal == 0)) return KVFE_ERR_INVALID_ARG;
 
   const int bits = H.depth * H.channels();
   const int bpp = std::max(1, bits / 8);
@@ -233,14 +253,14 @@ kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stri
       total += ph * (rowbytes_of(pw) + 1);
     }
   }
-  std::vector<uint8_t> raw(total);
+  raw.resize(total);
   {
-    if (idat.size() > 0xffffffffull || raw.size() > 0xffffffffull) return KVFE_ERR_UNSUPPORTED;   // zlib's 32-bit counts
+    if (idat_len > 0xffffffffull || raw.size() > 0xffffffffull) return KVFE_ERR_UNSUPPORTED;   // zlib's 32-bit counts
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) return KVFE_ERR_INVALID_ARG;
-    zs.next_in = idat.data();
-    zs.avail_in = (uInt)idat.size();
+    zs.next_in = const_cast<uint8_t*>(idat_ptr);
+    zs.avail_in = (uInt)idat_len;
     zs.next_out = raw.data();
     zs.avail_out = (uInt)raw.size();
     const int zr = inflate(&zs, Z_FINISH);
