@@ -745,7 +745,7 @@ KVFE_API void kvfe_imu_buffer_shutdown(kvfe_imu_buffer* b);
 /* getImuDataBtwTimestamps / getImuDataInterpolatedUpperBorder / getImuDataInterpolatedBorders.
  * stamps[capacity], acc_gyr[6 * capacity] (column k = sample k, as ImuAccGyrS); *n = samples written
  * (0 unless the result is KVFE_IMU_DATA_AVAILABLE).  Returns the query result, or -1 when `capacity` is
- * too small (*n = the count needed). */
+ * too small (*n = the count needed).  t_from >= t_to (a CHECK failure upstream) is KVFE_IMU_DATA_NEVER_AVAILABLE. */
 KVFE_API int32_t kvfe_imu_buffer_between(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to,
                                          int32_t get_lower_bound, int64_t* stamps, double* acc_gyr,
                                          int32_t capacity, int32_t* n);

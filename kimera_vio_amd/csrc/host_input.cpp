@@ -627,6 +627,7 @@ static int32_t imu_query_c(kvfe_imu_buffer* b, int mode, int64_t t_from, int64_t
                            int64_t* stamps, double* acc_gyr, int32_t capacity, int32_t* n) {
   if (n) *n = 0;
   if (!b || capacity < 0 || (capacity > 0 && (!stamps || !acc_gyr))) return KVFE_IMU_DATA_NEVER_AVAILABLE;
+  if (t_from >= t_to) return KVFE_IMU_DATA_NEVER_AVAILABLE;   // (upstream: CHECK_LT(timestamp_ns_from, timestamp_ns_to) aborts)
   try {
     std::vector<int64_t> ts;
     std::vector<AccGyr> vs;

@@ -334,6 +334,8 @@ def test_imu_buffer_ordering_length_shutdown_and_growth():
         big.addMeasurement(t, np.full(6, 0.5 * t))
     q, ts, vs = big.getImuDataInterpolatedBorders(10, 900)
     assert q == B.kDataAvailable and ts.tolist() == list(range(10, 901)) and np.array_equal(vs[3], 0.5 * ts)
+    _expect(big.getImuDataInterpolatedBorders(20, 20), B.kDataNeverAvailable)    # from >= to: CHECK_LT upstream
+    _expect(big.getImuDataBtwTimestamps(30, 20), B.kDataNeverAvailable)
     big.shutdown()
     _expect(big.getImuDataInterpolatedBorders(10, 900), B.kQueueShutdown)
 
