@@ -264,10 +264,12 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
             lk_ms = stages["lk_track"]["ms_total"] / ns
             vi = valu_issue(valu_ctx[0], "lk_kernel", lk_ms, valu_ctx[1], valu_ctx[2])
             if vi:   # the largest kernel of the step is sparse (no HBM roofline); its VALU issue floor is reported, but the
-                # launch is NOT bound by it: 26 % fewer instructions left the time unchanged (profiles/r2_v5_lk_analysis.md)
+                # launch is bound by the issue of ALL its instructions (profiles/r2_v5_lk_analysis.md)
                 res["largest_kernel"] = {"kernel": "lk_track", "avg_launch_ms": round(lk_ms, 5),
-                                         "bound": "per-CU memory-instruction path + tail of non-converging points "
-                                                  "(75-80 waves/us whatever the occupancy; profiles/r2_v5_lk_analysis.md)",
+                                         "bound": "total instruction issue (one instruction of any category per SIMD "
+                                                  "and 4-cycle slot: SQ_ACTIVE_INST_ANY 89 %, 6.9 k instructions per point "
+                                                  "-> 77-80 points/us at any occupancy) + a 10-13 % tail of non-converging "
+                                                  "points; profiles/r2_v5_lk_analysis.md",
                                          "valu_issue": vi}
         res["stream_groups"] = g
     return res
