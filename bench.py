@@ -139,8 +139,16 @@ def valu_issue(valu, prefix, launch_ms, n_cu, clock_ghz):
     if not insts or launch_ms <= 0:
         return None
     floor_ms = insts * 4.0 / (4.0 * n_cu) / (clock_ghz * 1e6)
-    return {"wave_insts_per_launch": round(insts), "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / launch_ms, 4),
-            "note": "SQ_INSTS_VALU of the committed c3 PMC pass x 4 cycles / (4 SIMDs x CUs) at the peak engine clock"}
+    res = {"wave_insts_per_launch": round(insts), "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / launch_ms, 4),
+           "note": "SQ_INSTS_VALU of the committed c3 PMC pass x 4 cycles / (4 SIMDs x CUs) at the peak engine clock"}
+    # all instruction categories: SQ_ACTIVE_INST_ANY (quad-cycles a wave spends issuing anything) against the
+    # SIMD issue slots of the measured launch; ~1 = the SIMDs issue one instruction per 4-cycle slot, the bound the
+    # dense kernels and LK actually run into (profiles/r2_v5_lk_analysis.md); > 1 = categories issued side by side
+    anyq = sum(v.get("SQ_ACTIVE_INST_ANY", 0.0) for k, v in valu.items() if k.startswith(prefix))
+    if anyq:
+        slots = launch_ms * 1e-3 * clock_ghz * 1e9 / 4.0 * (4.0 * n_cu)
+        res["issue_slots_all_categories"] = round(anyq / slots, 4)
+    return res
 
 
 # kernel behind every dense (image-sized) stage: (rocprof kernel name, launches per step)
