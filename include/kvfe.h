@@ -142,7 +142,8 @@ typedef struct kvfe_detector_params {
   int32_t use_harris_detector;
   double k;
   int32_t sortidx_policy;                    /* KVFE_SORTIDX_*               */
-  int32_t reserved0;
+  int32_t fast_thresh;                       /* fast_thresh (FAST / ORB only: parsed and carried, those
+                                                detector types are KVFE_ERR_UNSUPPORTED) */
 } kvfe_detector_params;
 
 /* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85).

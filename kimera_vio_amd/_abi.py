@@ -58,7 +58,7 @@ class DetectorParams(C.Structure):
         ("use_harris_detector", C.c_int32),
         ("k", C.c_double),
         ("sortidx_policy", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("fast_thresh", C.c_int32),
     ]
 
 

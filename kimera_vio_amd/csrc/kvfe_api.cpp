@@ -1020,6 +1020,7 @@ void kvfe_default_frontend_params(kvfe_frontend_params* p) {
   d.block_size = 3;
   d.k = 0.04;
   d.sortidx_policy = KVFE_SORTIDX_LIBSTDCXX;
+  d.fast_thresh = 10;                       // FeatureDetectorParams.h:105
   kvfe_tracker_params& t = p->tracker;
   t.klt_win_size = 24;
   t.klt_max_iter = 30;

@@ -51,6 +51,7 @@ def default_frontend_params() -> abi.FrontendParams:
     d.use_harris_detector = 0
     d.k = 0.04
     d.sortidx_policy = abi.SORTIDX_LIBSTDCXX
+    d.fast_thresh = 10
     t = p.tracker
     t.klt_win_size = 24
     t.klt_max_iter = 30
@@ -124,6 +125,7 @@ def load_detector_params(path: str, into: abi.DetectorParams | None = None) -> a
     d.block_size = int(y["block_size"])
     d.use_harris_detector = int(y["use_harris_detector"])
     d.k = float(y["k"])
+    d.fast_thresh = int(y["fast_thresh"])
     return d
 
 

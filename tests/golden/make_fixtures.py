@@ -52,11 +52,13 @@ def main():
 
 
 def bgr2gray_opencv(rgb: np.ndarray) -> np.ndarray:
-    """cv::cvtColor(COLOR_BGR2GRAY) on 8-bit data: fixed point, 14 fractional bits, coefficients
-    R 4899, G 9617, B 1868 (0.299, 0.587, 0.114), rounded -- what UtilsOpenCV::ReadAndConvertToGrayScale
-    (src/utils/UtilsOpenCV.cpp:390-403) applies to a 3-channel file.  (PIL's convert("L") uses other constants.)"""
+    """cv::cvtColor(COLOR_BGR2GRAY) on 8-bit data: fixed point, 15 fractional bits in OpenCV 4 (RY15 9798, GY15 19235,
+    BY15 3735; OpenCV 3 used 14 bits: 4899 / 9617 / 1868), rounded -- what UtilsOpenCV::ReadAndConvertToGrayScale
+    (src/utils/UtilsOpenCV.cpp:390-403) applies to a 3-channel file and what kvfe_png_decode_gray does.  The JPEG
+    frames converted below carry R = G = B, for which every such weighting returns the value itself.
+    (PIL's convert("L") uses other constants.)"""
     r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
-    return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 REF = "/root/reference/tests/data"
@@ -103,8 +105,16 @@ def rgbd_frames():
     shutil.copy(os.path.join(d, "sensorLeft.yaml"), os.path.join(HERE, "ForRgbd"))
 
 
+def parser_fixtures():
+    """tests/testFeatureDetectorParams.cpp / testVisionImuFrontendParams.cpp: the YAML file both parse"""
+    import shutil
+    os.makedirs(os.path.join(HERE, "ForTracker"), exist_ok=True)
+    shutil.copy(os.path.join(REF, "ForTracker", "trackerParameters.yaml"), os.path.join(HERE, "ForTracker"))
+
+
 if __name__ == "__main__":
     main()
     fisheye_golden()
     stereo_tracker_frames()
     rgbd_frames()
+    parser_fixtures()
