@@ -237,3 +237,21 @@ def test_yaml_loader_reference_param_tests():
         expected[r * 4 + c] = 0
     assert list(d2.binning_mask[:20]) == expected
     assert P.default_frontend_params().detector.fast_thresh == 10      # FeatureDetectorParams.h:105
+
+
+def test_camera_yaml_loader_reference_param_test():
+    """load_camera_params on tests/data/sensor.yaml with the expectations of tests/testCameraParams.cpp:34-95
+    (resolution, intrinsics, body_Pose_cam within gtsam::assert_equal's 1e-9, the four radtan coefficients)"""
+    from kimera_vio_amd import params as P
+    c = P.load_camera_params(os.path.join(G, "sensor.yaml"))
+    assert (c.width, c.height) == (752, 480)
+    assert list(c.intrinsics) == [458.654, 457.296, 367.215, 248.375]
+    assert c.distortion_model == abi.DIST_RADTAN and c.n_distortion == 4
+    assert list(c.distortion)[:4] == [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]
+    T = np.array(c.body_pose_cam).reshape(4, 4)
+    R_expected = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422],
+                           [0.999557249008, 0.0149672133247, 0.025715529948],
+                           [-0.0257744366974, 0.00375618835797, 0.999660727178]])
+    assert np.abs(T[:3, :3] - R_expected).max() < 1e-9
+    assert np.abs(T[:3, 3] - np.array([-0.0216401454975, -0.064676986768, 0.00981073058949])).max() < 1e-9
+    assert T[3].tolist() == [0.0, 0.0, 0.0, 1.0]
