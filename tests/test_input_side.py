@@ -896,3 +896,14 @@ def test_mono_and_rgbd_providers_equal_oracle_on_random_traffic():
                 else:
                     assert (r.timestamp, r.left_tag, r.right_tag, r.imu_stamps.tolist()) == (pk[0], pk[1], pk[2], pk[3])
                     assert np.array_equal(r.imu_accgyrs.T, np.asarray(pk[4]))
+
+
+def test_read_and_convert_to_gray_scale_reference_case():
+    """tests/testUtilsOpenCV.cpp:529-540: ReadAndConvertToGrayScale("chessboard.png") has one channel and equals the
+    pattern of cvCreateChessboard(30, 10, 8) (:77-92: 30-pixel squares, 10 rows x 8 columns, white where the square
+    indices sum to an even number)"""
+    img = dp.ReadAndConvertToGrayScale(os.path.join(GOLDEN, "chessboard.png"))
+    r, c = np.mgrid[0:300, 0:240]
+    expected = np.where(((r // 30) + (c // 30)) % 2 == 0, 255, 0).astype(np.uint8)
+    assert img.shape == (300, 240) and dp.png_info(open(os.path.join(GOLDEN, "chessboard.png"), "rb").read())[2] == 1
+    assert np.array_equal(img, expected)
