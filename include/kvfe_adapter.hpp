@@ -70,6 +70,28 @@ struct Frame {
   std::vector<int64_t> landmarks_;
   std::vector<int32_t> landmarks_age_;
   std::vector<double> versors_;  // n x 3
+
+  // Frame::getNrValidKeypoints / getValidKeypoints / findLmkIdFromPixel (Frame.h:97-139)
+  size_t getNrValidKeypoints() const {
+    size_t count = 0;
+    for (int64_t l : landmarks_) count += l != -1;
+    return count;
+  }
+  KeypointsCV getValidKeypoints() const {
+    KeypointsCV valid;
+    for (size_t i = 0; i < landmarks_.size() && i < keypoints_.size(); i++)
+      if (landmarks_[i] != -1) valid.push_back(keypoints_[i]);
+    return valid;
+  }
+  static int64_t findLmkIdFromPixel(const KeypointCV& px, const KeypointsCV& keypoints,
+                                    const std::vector<int64_t>& landmarks, size_t* idx_in_keypoints = nullptr) {
+    for (size_t i = 0; i < keypoints.size(); i++)
+      if (keypoints[i].x == px.x && keypoints[i].y == px.y) {
+        if (idx_in_keypoints) *idx_in_keypoints = i;
+        return landmarks.at(i);
+      }
+    return -1;
+  }
 };
 
 namespace detail {

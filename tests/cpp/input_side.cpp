@@ -63,6 +63,20 @@ int main(int argc, char** argv) {
     const Buf::QueryResult r3 = b.getImuDataBtwTimestamps(21, 24, &m);
     std::printf("between(21,24): result=%d cols=%d\n", (int)r3, m.cols());
   }
+  {   // tests/testFrame.cpp:82-99 getNrValidKeypoints, :186-200 findLmkIdFromPixel
+    kvfe::Frame f;
+    for (int i = 0; i < 200; i++) {
+      if (i % 5 == 0) f.landmarks_.push_back(-1);
+      f.landmarks_.push_back(i);
+    }
+    f.keypoints_.resize(f.landmarks_.size());
+    for (size_t i = 0; i < f.keypoints_.size(); i++) f.keypoints_[i] = kvfe::KeypointCV{(float)(3 * i) + 0.5f, (float)i};
+    size_t idx = 0;
+    const long long id = kvfe::Frame::findLmkIdFromPixel(f.keypoints_[7], f.keypoints_, f.landmarks_, &idx);
+    std::printf("frame: valid=%zu valid_kps=%zu lmk_of_px7=%lld idx=%zu missing=%lld\n", f.getNrValidKeypoints(),
+                f.getValidKeypoints().size(), id, idx,
+                (long long)kvfe::Frame::findLmkIdFromPixel(kvfe::KeypointCV{-1.f, -1.f}, f.keypoints_, f.landmarks_));
+  }
   if (argc > 2) {   // an EuRoC-layout dataset: EurocDataProvider -> StereoDataProviderModule -> packets
     kvfe::EurocDataProvider prov(argv[2], 0, 1 << 30);
     StereoDataProviderModule sync;

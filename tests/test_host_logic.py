@@ -182,6 +182,7 @@ def test_cpp_adapter_input_side_classes():
         "borders(21,29): result=0 cols=3 stamps=21,25,29 values=21,25,29",
         "borders(40,51): result=1 cols=0",                                 # kDataNotYetAvailable
         "between(21,24): result=4 cols=0",                                 # kTooFewMeasurementsAvailable
+        "frame: valid=200 valid_kps=200 lmk_of_px7=5 idx=7 missing=-1",     # testFrame.cpp:82-99, :186-200
         f"png: 752x480 checksum={checksum}",
     ]
 
