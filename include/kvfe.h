@@ -725,6 +725,17 @@ KVFE_API kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, cons
                                                 int32_t height, int32_t n, int32_t threads,
                                                 kvfe_status* status);
 
+/* The same for JPEG files (the reference's own front-end test frames, tests/data/ForStereoTracker/ *.jpg, are baseline
+ * 4:2:0 JFIF): libjpeg's default decoding pipeline restated in integer arithmetic -- Huffman decoding, the
+ * slow-accurate integer IDCT, fancy chroma upsampling, the fixed-point YCbCr -> RGB tables -- then BGR2GRAY for
+ * three-component files; bit-identical to libjpeg / libjpeg-turbo.  8-bit baseline / extended-sequential Huffman, 1
+ * or 3 components, luma sampling 1x1, 2x1, 2x2, restart intervals; anything else (progressive, arithmetic, CMYK, 12
+ * bit) is KVFE_ERR_UNSUPPORTED.  EXIF orientation is not applied.  channels = components of the file. */
+KVFE_API kvfe_status kvfe_jpeg_info(const uint8_t* data, size_t size, int32_t* width, int32_t* height,
+                                    int32_t* channels);
+KVFE_API kvfe_status kvfe_jpeg_decode_gray(const uint8_t* data, size_t size, uint8_t* dst, size_t dst_stride,
+                                           int32_t width, int32_t height);
+
 /* utils::ThreadsafeImuBuffer (include/kimera-vio/utils/ThreadsafeImuBuffer.h:46-196, src/utils/
  * ThreadsafeImuBuffer.cpp:48-234 over ThreadsafeTemporalBuffer-inl.h): a time-ordered map of (acc, gyro)
  * samples, thread safe.  Query results keep the upstream enum values. */

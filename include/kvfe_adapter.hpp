@@ -705,16 +705,18 @@ class RgbdVisionImuFrontend {
 // Input side: what feeds spinOnce.  Host code of the library; see kvfe.h for the semantics.
 // ------------------------------------------------------------------------------------------------------------
 
-// UtilsOpenCV::ReadAndConvertToGrayScale(img_name, equalize = false) for PNG data already in memory: the decoded
+// UtilsOpenCV::ReadAndConvertToGrayScale(img_name, equalize = false) for PNG / baseline JPEG data in memory: the decoded
 // 8-bit grey image (rows * cols bytes, tightly packed).  Equalisation is the front-end's equalize_image parameter
 // / kvfe_equalize_hist.
 inline std::vector<uint8_t> ReadAndConvertToGrayScale(const uint8_t* png, size_t size, int* rows, int* cols) {
   int32_t w = 0, h = 0, c = 0;
-  kvfe_status st = kvfe_png_info(png, size, &w, &h, &c);
-  if (st != KVFE_OK) throw Error(st, "ReadAndConvertToGrayScale: not a PNG file this library decodes");
+  const bool jpeg = size > 2 && png[0] == 0xFF && png[1] == 0xD8;   // baseline JPEG (kvfe_jpeg_*) or PNG (kvfe_png_*)
+  kvfe_status st = jpeg ? kvfe_jpeg_info(png, size, &w, &h, &c) : kvfe_png_info(png, size, &w, &h, &c);
+  if (st != KVFE_OK) throw Error(st, "ReadAndConvertToGrayScale: not a PNG / baseline JPEG file this library decodes");
   std::vector<uint8_t> img((size_t)w * h);
-  st = kvfe_png_decode_gray(png, size, img.data(), (size_t)w, w, h);
-  if (st != KVFE_OK) throw Error(st, "ReadAndConvertToGrayScale: corrupt PNG data");
+  st = jpeg ? kvfe_jpeg_decode_gray(png, size, img.data(), (size_t)w, w, h)
+            : kvfe_png_decode_gray(png, size, img.data(), (size_t)w, w, h);
+  if (st != KVFE_OK) throw Error(st, "ReadAndConvertToGrayScale: corrupt image data");
   if (rows) *rows = h;
   if (cols) *cols = w;
   return img;

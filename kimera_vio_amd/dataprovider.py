@@ -47,6 +47,25 @@ def decode_png_gray(data: bytes, out: np.ndarray | None = None) -> np.ndarray:
     return out
 
 
+def jpeg_info(data: bytes):
+    """(width, height, components of the file)"""
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(load().kvfe_jpeg_info(data, len(data), C.byref(w), C.byref(h), C.byref(c)), "kvfe_jpeg_info")
+    return w.value, h.value, c.value
+
+
+def decode_jpeg_gray(data: bytes, out: np.ndarray | None = None) -> np.ndarray:
+    """cv::imread(IMREAD_ANYCOLOR) of a baseline JPEG (libjpeg's defaults) + cv::cvtColor(BGR2GRAY) for colour files"""
+    w, h, _ = jpeg_info(data)
+    if out is None:
+        out = np.empty((h, w), np.uint8)
+    if out.shape != (h, w) or out.dtype != np.uint8 or out.strides[1] != 1:
+        raise ValueError("output must be a (height, width) uint8 array with unit column stride")
+    _check(load().kvfe_jpeg_decode_gray(data, len(data), out.ctypes.data_as(C.c_void_p), out.strides[0], w, h),
+           "kvfe_jpeg_decode_gray")
+    return out
+
+
 def decode_png_gray_batch(files: list[bytes], out: np.ndarray, threads: int = 0) -> np.ndarray:
     """n PNG files into out[n, height, width] (e.g. a view of a pinned staging slot) by `threads` host threads"""
     n = len(files)
@@ -65,10 +84,11 @@ def decode_png_gray_batch(files: list[bytes], out: np.ndarray, threads: int = 0)
 
 
 def ReadAndConvertToGrayScale(img_name: str, equalize: bool = False, ctx=None) -> np.ndarray:
-    """UtilsOpenCV::ReadAndConvertToGrayScale for a PNG file; `equalize` needs a front-end context (cv::equalizeHist
+    """UtilsOpenCV::ReadAndConvertToGrayScale for a PNG or baseline JPEG file; `equalize` needs a front-end context (cv::equalizeHist
     runs on the device: kvfe_equalize_hist)"""
     with open(img_name, "rb") as f:
-        img = decode_png_gray(f.read())
+        data = f.read()
+    img = decode_jpeg_gray(data) if data[:2] == b"\xff\xd8" else decode_png_gray(data)
     if equalize:
         if ctx is None:
             raise ValueError("equalize=True needs ctx (kvfe_equalize_hist is a device kernel)")

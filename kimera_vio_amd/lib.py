@@ -109,6 +109,8 @@ def load() -> C.CDLL:
     i64, pi32, pi64, pf64 = C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
     L.kvfe_png_info.argtypes = [vp, sz, pi32, pi32, pi32]
     L.kvfe_png_decode_gray.argtypes = [vp, sz, vp, sz, i32, i32]
+    L.kvfe_jpeg_info.argtypes = [vp, sz, pi32, pi32, pi32]
+    L.kvfe_jpeg_decode_gray.argtypes = [vp, sz, vp, sz, i32, i32]
     L.kvfe_png_decode_gray_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), sz, i32, i32, i32, i32,
                                              pi32]
     L.kvfe_imu_buffer_create.argtypes = [i64]
@@ -147,7 +149,8 @@ def load() -> C.CDLL:
     L.kvfe_stereo_sync_next.argtypes = [vp, C.POINTER(abi.SyncPacket), pi64, pf64, i32]
     L.kvfe_euroc_parse_camera_csv.argtypes = [C.c_char_p, sz, pi64, i32, pi32]
     L.kvfe_euroc_parse_imu_csv.argtypes = [C.c_char_p, sz, pi64, pf64, i32, pi32]
-    for fn in ("kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_imu_buffer_between",
+    for fn in ("kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_jpeg_info",
+               "kvfe_jpeg_decode_gray", "kvfe_imu_buffer_between",
                "kvfe_imu_buffer_interpolated_upper_border", "kvfe_imu_buffer_interpolated_borders",
                "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv"):
         getattr(L, fn).restype = C.c_int32
@@ -178,7 +181,8 @@ NEW_R2_SYMBOLS = [
 ]
 
 INPUT_SIDE_SYMBOLS = [
-    "kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_imu_buffer_create",
+    "kvfe_png_info", "kvfe_png_decode_gray", "kvfe_png_decode_gray_batch", "kvfe_jpeg_info", "kvfe_jpeg_decode_gray",
+    "kvfe_imu_buffer_create",
     "kvfe_imu_buffer_destroy", "kvfe_imu_buffer_add", "kvfe_imu_buffer_size", "kvfe_imu_buffer_shutdown",
     "kvfe_imu_buffer_between", "kvfe_imu_buffer_interpolated_upper_border", "kvfe_imu_buffer_interpolated_borders",
     "kvfe_imu_linear_interpolate", "kvfe_stereo_sync_create", "kvfe_stereo_sync_destroy", "kvfe_stereo_sync_set_mode",

@@ -44,6 +44,25 @@ int main(int argc, char** argv) {
     std::ifstream in(argv[a], std::ios::binary);
     const std::vector<uint8_t> orig((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     int32_t w = 0, h = 0, c = 0;
+    if (orig.size() > 2 && orig[0] == 0xFF && orig[1] == 0xD8) {
+      // a JPEG file: byte damage anywhere (no checksums in the format), truncations, header edits
+      if (kvfe_jpeg_info(orig.data(), orig.size(), &w, &h, &c) != KVFE_OK) return 11;
+      std::vector<uint8_t> out((size_t)w * h + 64, 0xAB);
+      if (kvfe_jpeg_decode_gray(orig.data(), orig.size(), out.data(), (size_t)w, w, h) != KVFE_OK) return 12;
+      for (int it = 0; it < 1500; it++) {
+        std::vector<uint8_t> f = orig;
+        const int kind = it % 4;
+        if (kind == 0) for (int k = 0; k < 1 + (int)(rng() % 6); k++) f[rng() % f.size()] = (uint8_t)rng();
+        else if (kind == 1) f.resize(rng() % f.size());
+        else if (kind == 2) for (int k = 0; k < 1 + (int)(rng() % 3); k++) f[2 + rng() % (f.size() < 700 ? f.size() - 2 : 700)] ^= (uint8_t)(1u << (rng() % 8));
+        else { const size_t at = rng() % (f.size() - 1); f[at] = 0xFF; f[at + 1] = (uint8_t)(0xC0 + rng() % 0x40); }
+        const kvfe_status sd = kvfe_jpeg_decode_gray(f.data(), f.size(), out.data(), (size_t)w, w, h);
+        if (sd == KVFE_OK) decoded++; else refused++;
+        for (size_t k = (size_t)w * h; k < out.size(); k++)
+          if (out[k] != 0xAB) return 13;
+      }
+      continue;
+    }
     if (kvfe_png_info(orig.data(), orig.size(), &w, &h, &c) != KVFE_OK) return 3;
     std::vector<uint8_t> out((size_t)w * h + 64, 0xAB);
     for (int it = 0; it < 300; it++) {
@@ -151,7 +170,7 @@ int main(int argc, char** argv) {
   // the batch decoder from three caller threads at once (one gets the worker pool, the others find it busy and bring
   // threads of their own), every result checked
   {
-    std::ifstream in(argv[1], std::ios::binary);
+    std::ifstream in(argv[1], std::ios::binary);   // (argv[1] is a PNG file)
     const std::vector<uint8_t> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     int32_t w = 0, h = 0, c = 0;
     kvfe_png_info(file.data(), file.size(), &w, &h, &c);

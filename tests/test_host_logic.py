@@ -188,8 +188,9 @@ def test_cpp_adapter_input_side_classes():
 
 
 def test_input_side_under_sanitizers():
-    """tests/cpp/input_fuzz.cpp: host_input.cpp compiled with -fsanitize=address,undefined and fed with damaged PNG
-    files (CRCs repaired so that the damage reaches inflate / unfilter / expansion), 3000 well-formed containers
+    """tests/cpp/input_fuzz.cpp: host_input.cpp and host_jpeg.cpp compiled with -fsanitize=address,undefined and fed
+    with damaged JPEG files (4:2:0, 4:2:2 with restart markers, 4:4:4 with optimised tables; byte damage, truncation,
+    forged markers), damaged PNG files (CRCs repaired so that the damage reaches inflate / unfilter / expansion), 3000 well-formed containers
     around random scan lines of every colour type / depth / interlacing, mutated index files and random
     synchroniser traffic with too-small output arrays: no report, no write past the destination, nothing accepted
     that kvfe_png_info refuses"""
@@ -198,9 +199,22 @@ def test_input_side_under_sanitizers():
     cpp = os.path.join(here, "cpp")
     r = subprocess.run(["make", "-C", cpp, "input_fuzz"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([os.path.join(cpp, "input_fuzz"), os.path.join(here, "golden", "left_img_0.png"),
-                        os.path.join(here, "golden", "chessboard.png")], capture_output=True, text=True,
-                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    import io
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    jpegs = []
+    with tempfile.TemporaryDirectory() as td:
+        for i, (ss, kw) in enumerate([(2, {}), (1, {"restart_marker_blocks": 2}), (0, {"optimize": True})]):
+            a = np.clip(np.kron(rng.integers(0, 256, (12, 16, 3)), np.ones((4, 4, 1))) + rng.normal(0, 5, (48, 64, 3)),
+                        0, 255).astype(np.uint8)
+            path = os.path.join(td, f"f{i}.jpg")
+            Image.fromarray(a[:45, :61]).save(path, "JPEG", quality=85, subsampling=ss, **kw)
+            jpegs.append(path)
+        r = subprocess.run([os.path.join(cpp, "input_fuzz"), os.path.join(here, "golden", "left_img_0.png"),
+                            os.path.join(here, "golden", "chessboard.png")] + jpegs, capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), r.stdout + r.stderr
 
 

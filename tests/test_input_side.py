@@ -907,3 +907,69 @@ def test_read_and_convert_to_gray_scale_reference_case():
     expected = np.where(((r // 30) + (c // 30)) % 2 == 0, 255, 0).astype(np.uint8)
     assert img.shape == (300, 240) and dp.png_info(open(os.path.join(GOLDEN, "chessboard.png"), "rb").read())[2] == 1
     assert np.array_equal(img, expected)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# JPEG (libjpeg's default pipeline restated: Huffman, integer IDCT, fancy upsampling, YCbCr -> RGB) against PIL
+# ---------------------------------------------------------------------------------------------------------------
+def _smooth(rng, h, w, c):
+    a = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2, c)).astype(np.float64)
+    a = np.kron(a, np.ones((4, 4, 1)))[:h, :w] + rng.normal(0, 6, (h, w, c))
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+def test_jpeg_colour_equals_libjpeg(subsampling):
+    """4:4:4 / 4:2:2 / 4:2:0 baseline files of PIL's encoder (standard and optimised Huffman tables, restart intervals,
+    qualities 30-100, sizes that are not MCU multiples down to one pixel): grey == BGR2GRAY of libjpeg's RGB, bit for
+    bit"""
+    rng = np.random.default_rng(100 + subsampling)
+    for (h, w) in [(8, 8), (37, 53), (1, 1), (7, 1), (1, 9), (64, 80), (33, 17), (100, 3), (2, 2), (17, 16)]:
+        for q, kw in [(30, {}), (75, {"optimize": True}), (95, {"restart_marker_blocks": 3}),
+                      (100, {"restart_marker_rows": 1})]:
+            b = io.BytesIO()
+            PIL.fromarray(_smooth(rng, h, w, 3)).save(b, "JPEG", quality=q, subsampling=subsampling, **kw)
+            f = b.getvalue()
+            assert dp.jpeg_info(f) == (w, h, 3)
+            want = cv_gray(np.asarray(PIL.open(io.BytesIO(f)).convert("RGB")))
+            assert np.array_equal(dp.decode_jpeg_gray(f), want), (h, w, q, kw)
+
+
+def test_jpeg_grey_progressive_and_errors():
+    rng = np.random.default_rng(8)
+    for (h, w) in [(8, 8), (37, 53), (1, 1), (40, 200)]:
+        for q in (50, 90):
+            b = io.BytesIO()
+            PIL.fromarray(_smooth(rng, h, w, 1)[..., 0]).save(b, "JPEG", quality=q)
+            f = b.getvalue()
+            assert dp.jpeg_info(f) == (w, h, 1)
+            assert np.array_equal(dp.decode_jpeg_gray(f), np.asarray(PIL.open(io.BytesIO(f))))
+    b = io.BytesIO()
+    PIL.fromarray(_smooth(rng, 32, 32, 3)).save(b, "JPEG", progressive=True)
+    with pytest.raises(KvfeError) as e:
+        dp.decode_jpeg_gray(b.getvalue())
+    assert e.value.status == -2                                   # KVFE_ERR_UNSUPPORTED
+    b = io.BytesIO()
+    PIL.fromarray(_smooth(rng, 24, 24, 3)).save(b, "JPEG", quality=80)
+    good = b.getvalue()
+    for cut in (3, 20, len(good) // 2):                           # truncated inside the headers: refused
+        with pytest.raises(KvfeError):
+            dp.decode_jpeg_gray(good[:cut])
+    out = np.empty((24, 25), np.uint8)                            # a destination of another size: refused
+    assert load().kvfe_jpeg_decode_gray(good, len(good), out.ctypes.data, out.strides[0], 25, 24) == -1
+    tail = dp.decode_jpeg_gray(good[:len(good) - 40] + b"\xff\xd9")   # damaged entropy data decodes to SOMETHING
+    assert tail.shape == (24, 24)
+    with pytest.raises(KvfeError):
+        dp.decode_jpeg_gray(b"\x89PNG not a jpeg")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/data/ForStereoTracker"),
+                    reason="the reference checkout (build container only)")
+def test_jpeg_reference_frames_equal_committed_fixture():
+    """the six JPEG frames of tests/testStereoVisionImuFrontend.cpp:674-926 through ReadAndConvertToGrayScale ==
+    tests/golden/ForStereoTracker/frames_0_1_8.npz (decoded by libjpeg through PIL when the fixture was made)"""
+    z = np.load(os.path.join(GOLDEN, "ForStereoTracker", "frames_0_1_8.npz"))
+    for side, key in (("left", "lefts"), ("right", "rights")):
+        for k, n in enumerate((0, 1, 8)):
+            img = dp.ReadAndConvertToGrayScale(f"/root/reference/tests/data/ForStereoTracker/{side}_frame{n:04d}.jpg")
+            assert np.array_equal(img, z[key][k])
