@@ -94,6 +94,63 @@ struct Frame {
   }
 };
 
+// gtsam::Pose3 as far as the front-end's outputs need it (rotation matrix + translation; compose / inverse /
+// between with gtsam's formulas: R = R1 R2, t = t1 + R1 t2; inverse = (R^T, -R^T t))
+struct Pose3 {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double t[3] = {0, 0, 0};
+  Pose3 compose(const Pose3& o) const {
+    Pose3 r;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) r.R[3 * i + j] = R[3 * i] * o.R[j] + R[3 * i + 1] * o.R[3 + j] + R[3 * i + 2] * o.R[6 + j];
+      r.t[i] = t[i] + (R[3 * i] * o.t[0] + R[3 * i + 1] * o.t[1] + R[3 * i + 2] * o.t[2]);
+    }
+    return r;
+  }
+  Pose3 inverse() const {
+    Pose3 r;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) r.R[3 * i + j] = R[3 * j + i];
+      r.t[i] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+    }
+    return r;
+  }
+  Pose3 between(const Pose3& o) const { return inverse().compose(o); }
+  // row-major 3x4 [R | t] (kvfe_frame_output::lkf_T_k_*) / row-major 4x4 (kvfe_camera_params::body_pose_cam)
+  static Pose3 from3x4(const double* m) {
+    Pose3 r;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) r.R[3 * i + j] = m[4 * i + j];
+      r.t[i] = m[4 * i + 3];
+    }
+    return r;
+  }
+  static Pose3 from4x4(const double* m) { return from3x4(m); }
+};
+
+// StereoCamera::B_Pose_camLrect_ / B_Pose_camRrect_ (src/frontend/StereoCamera.cpp:55-66):
+//   camL_Pose_camLrect = (R1^-1, 0);  B_Pose_camLrect = left.body_Pose_cam . camL_Pose_camLrect
+// and the same with R2 for the right camera -- upstream composes that one with the LEFT camera's body pose as well
+// (StereoCamera.cpp:66), which is reproduced, not corrected.  Host arithmetic: no context needed.
+inline Pose3 bodyPoseCamRect(const double R_rect[9], const kvfe_camera_params& left_cam_params) {
+  Pose3 cam_Pose_camrect;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) cam_Pose_camrect.R[3 * i + j] = R_rect[3 * j + i];   // cvMatToGtsamRot3(R).inverse()
+  return Pose3::from4x4(left_cam_params.body_pose_cam).compose(cam_Pose_camrect);
+}
+// gtsam::Cal3_S2Stereo of the rectified pair (StereoCamera.cpp:73-80: UtilsOpenCV::Cvmat2Cal3_S2(P1) + baseline)
+struct Cal3_S2Stereo {
+  double fx, fy, skew, px, py, baseline;
+};
+inline Cal3_S2Stereo stereoCalib(const kvfe_rectification& r) {
+  return Cal3_S2Stereo{r.P1[0], r.P1[5], r.P1[1], r.P1[2], r.P1[6], r.baseline};
+}
+// StereoVisionImuFrontend::getRelativePoseBodyMono / getRelativePoseBodyStereo (StereoVisionImuFrontend.cpp:699-716):
+// lkfBody_T_kBody = body_Pose_cam . lkf_T_k . body_Pose_cam^-1 with the rectified LEFT camera's body pose
+inline Pose3 relativePoseBody(const Pose3& body_Pose_camLrect, const double lkf_T_k[12]) {
+  return body_Pose_camLrect.compose(Pose3::from3x4(lkf_T_k)).compose(body_Pose_camLrect.inverse());
+}
+
 namespace detail {
 // kvfe_frame view of a Frame whose vectors have been resized to `capacity`
 inline kvfe_frame frame_view(Frame* f, int n, int capacity) {
@@ -231,6 +288,11 @@ class StereoCamera {
   const double* getP1() const { return rect_.P1; }
   const double* getP2() const { return rect_.P2; }
   const double* getQ() const { return rect_.Q; }
+  Cal3_S2Stereo getStereoCalib() const { return stereoCalib(rect_); }
+  // getBodyPoseLeftCamRect / getBodyPoseRightCamRect (StereoCamera.h; the context does not keep the YAML's T_BS, the
+  // caller passes the left camera's parameters it created the context with)
+  Pose3 getBodyPoseLeftCamRect(const kvfe_camera_params& left_cam_params) const { return bodyPoseCamRect(rect_.R1, left_cam_params); }
+  Pose3 getBodyPoseRightCamRect(const kvfe_camera_params& left_cam_params) const { return bodyPoseCamRect(rect_.R2, left_cam_params); }
   const Context& context() const { return c_; }
   // undistortRectifyLeftKeypoints(keypoints, status_keypoints_rectified) (StereoCamera.h:203-213, .cpp:236-260)
   void undistortRectifyLeftKeypoints(const KeypointsCV& keypoints, StatusKeypointsCV* status_keypoints_rectified) const {
@@ -612,6 +674,13 @@ class StereoMatcher {
 // keyframe_R_cur_frame (camLrectLkf_R_camLrectK_imu) per stream.
 class StereoVisionImuFrontend {
  public:
+  // getRelativePoseBodyMono / getRelativePoseBodyStereo (StereoVisionImuFrontend.cpp:699-716) of one stream's output
+  static Pose3 getRelativePoseBodyMono(const kvfe_frame_output& out, const Pose3& body_Pose_camLrect) {
+    return relativePoseBody(body_Pose_camLrect, out.lkf_T_k_mono);
+  }
+  static Pose3 getRelativePoseBodyStereo(const kvfe_frame_output& out, const Pose3& body_Pose_camLrect) {
+    return relativePoseBody(body_Pose_camLrect, out.lkf_T_k_stereo);
+  }
   explicit StereoVisionImuFrontend(Context ctx) : c_(std::move(ctx)) {}
   // images: `batch` images back to back (host memory)
   void spinOnce(const uint8_t* left, const uint8_t* right, size_t row_stride, size_t image_stride,

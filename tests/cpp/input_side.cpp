@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
                 f.getValidKeypoints().size(), id, idx,
                 (long long)kvfe::Frame::findLmkIdFromPixel(kvfe::KeypointCV{-1.f, -1.f}, f.keypoints_, f.landmarks_));
   }
-  if (argc > 2) {   // an EuRoC-layout dataset: EurocDataProvider -> StereoDataProviderModule -> packets
+  if (argc > 2 && argv[2][0]) {   // an EuRoC-layout dataset: EurocDataProvider -> StereoDataProviderModule -> packets
     kvfe::EurocDataProvider prov(argv[2], 0, 1 << 30);
     StereoDataProviderModule sync;
     unsigned long long pix = 0;
@@ -104,6 +104,35 @@ int main(int argc, char** argv) {
         std::printf("dropped: action=%d\n", sync.lastAction());
       if (!got && sync.lastAction() == KVFE_SYNC_WAIT_IMU) break;   // (upstream would block here until IMU data arrives)
     }
+  }
+  if (argc > 3) {   // a text file with the two cameras' parameters: rectified body poses, stereo calibration, relative pose
+    std::ifstream f(argv[3]);
+    kvfe_camera_params cam[2];
+    std::memset(cam, 0, sizeof(cam));
+    for (int c = 0; c < 2; c++) {
+      f >> cam[c].width >> cam[c].height;
+      for (int i = 0; i < 4; i++) f >> cam[c].intrinsics[i];
+      cam[c].distortion_model = KVFE_DIST_RADTAN;
+      cam[c].n_distortion = 4;
+      for (int i = 0; i < 4; i++) f >> cam[c].distortion[i];
+      for (int i = 0; i < 16; i++) f >> cam[c].body_pose_cam[i];
+    }
+    kvfe_rectification r;
+    if (kvfe_compute_rectification(&cam[0], &cam[1], &r) != KVFE_OK) return 3;
+    const kvfe::Pose3 bl = kvfe::bodyPoseCamRect(r.R1, cam[0]), br = kvfe::bodyPoseCamRect(r.R2, cam[0]);
+    const kvfe::Cal3_S2Stereo k = kvfe::stereoCalib(r);
+    const double lkf_T_k[12] = {0.9998, -0.01, 0.015, 0.05, 0.0101, 0.99995, -0.002, -0.02, -0.01498, 0.00215, 0.99989, 0.3};
+    const kvfe::Pose3 rel = kvfe::relativePoseBody(bl, lkf_T_k);
+    auto show = [](const char* name, const kvfe::Pose3& p) {
+      std::printf("%s:", name);
+      for (int i = 0; i < 9; i++) std::printf(" %.17g", p.R[i]);
+      for (int i = 0; i < 3; i++) std::printf(" %.17g", p.t[i]);
+      std::printf("\n");
+    };
+    show("B_Pose_camLrect", bl);
+    show("B_Pose_camRrect", br);
+    show("relative_pose_body", rel);
+    std::printf("stereo_calib: %.17g %.17g %.17g %.17g %.17g %.17g\n", k.fx, k.fy, k.skew, k.px, k.py, k.baseline);
   }
   if (argc > 1 && argv[1][0]) {   // a PNG file: size and a checksum of the decoded grey image
     std::ifstream f(argv[1], std::ios::binary);

@@ -270,3 +270,48 @@ def test_camera_yaml_loader_reference_param_test():
     assert np.abs(T[:3, :3] - R_expected).max() < 1e-9
     assert np.abs(T[:3, 3] - np.array([-0.0216401454975, -0.064676986768, 0.00981073058949])).max() < 1e-9
     assert T[3].tolist() == [0.0, 0.0, 0.0, 1.0]
+
+
+def test_cpp_adapter_rectified_body_poses_and_relative_pose(tmp_path):
+    """include/kvfe_adapter.hpp: StereoCamera::B_Pose_camLrect_ / B_Pose_camRrect_ (StereoCamera.cpp:55-66, the right
+    one composed with the LEFT body pose as upstream), the Cal3_S2Stereo of :73-80 and StereoVisionImuFrontend::
+    getRelativePoseBodyMono / Stereo (StereoVisionImuFrontend.cpp:699-716) against numpy on the EuRoC calibration"""
+    import subprocess
+    Lc = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
+    Rc = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
+    txt = tmp_path / "cams.txt"
+    with open(txt, "w") as f:
+        for c in (Lc, Rc):
+            f.write(f"{c.width} {c.height} " + " ".join(repr(float(x)) for x in list(c.intrinsics)[:4]) + " " +
+                    " ".join(repr(float(x)) for x in list(c.distortion)[:4]) + " " +
+                    " ".join(repr(float(x)) for x in c.body_pose_cam) + "\n")
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    assert subprocess.run(["make", "-C", cpp, "input_side"], capture_output=True, text=True).returncode == 0
+    r = subprocess.run([os.path.join(cpp, "input_side"), "", "", str(txt)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {ln.split(":")[0]: np.array([float(x) for x in ln.split(":")[1].split()]) for ln in r.stdout.splitlines()
+           if ln.startswith(("B_Pose", "relative_pose_body", "stereo_calib"))}
+    rect = F.compute_rectification(Lc, Rc)
+    T = np.array(Lc.body_pose_cam).reshape(4, 4)
+
+    def pose(R1):
+        M = np.eye(4)
+        M[:3, :3] = T[:3, :3] @ np.array(R1).reshape(3, 3).T
+        M[:3, 3] = T[:3, 3]
+        return M
+    for name, R in (("B_Pose_camLrect", rect.R1), ("B_Pose_camRrect", rect.R2)):
+        M = pose(R)
+        assert np.abs(got[name][:9].reshape(3, 3) - M[:3, :3]).max() < 1e-15 and np.array_equal(got[name][9:], M[:3, 3])
+    lkf = np.eye(4)
+    lkf[:3] = np.array([0.9998, -0.01, 0.015, 0.05, 0.0101, 0.99995, -0.002, -0.02, -0.01498, 0.00215, 0.99989,
+                        0.3]).reshape(3, 4)
+    bl = pose(rect.R1)
+    binv = np.eye(4)
+    binv[:3, :3] = bl[:3, :3].T
+    binv[:3, 3] = -bl[:3, :3].T @ bl[:3, 3]
+    rel = bl @ lkf @ binv
+    assert np.abs(got["relative_pose_body"][:9].reshape(3, 3) - rel[:3, :3]).max() < 1e-14
+    assert np.abs(got["relative_pose_body"][9:] - rel[:3, 3]).max() < 1e-14
+    P1 = np.array(rect.P1).reshape(3, 4)
+    assert got["stereo_calib"].tolist() == [P1[0, 0], P1[1, 1], P1[0, 1], P1[0, 2], P1[1, 2], rect.baseline]
+    assert abs(rect.baseline - 0.110078) < 1e-5                      # tests/testStereoMatcher.cpp:148
