@@ -771,6 +771,20 @@ KVFE_API int32_t kvfe_imu_buffer_interpolated_borders(kvfe_imu_buffer* b, int64_
 KVFE_API void kvfe_imu_linear_interpolate(int64_t t0, const double y0[6], int64_t t1, const double y1[6],
                                           int64_t t, double y[6]);
 
+/* The rotation the front-end takes as kvfe_frame_input::keyframe_R_cur_frame, from the gyro samples of the packets:
+ * ImuFrontend::preintegrateImuMeasurements (src/imu-frontend/ImuFrontend.cpp:158-173) as far as the rotation goes --
+ * for i < n - 1: dt = (stamps[i+1] - stamps[i]) / 1e9, deltaRij <- deltaRij . Expmap((gyro_i - gyro_bias) dt), i.e.
+ * gtsam's on-manifold preintegration (GTSAM_TANGENT_PREINTEGRATION=OFF, Dockerfile_20_04:49) with
+ * so3::ExpmapFunctor (I + W for |w|^2 <= eps, else I + sin(t) K + 2 sin^2(t/2) K^2, K = W / t); the last sample only
+ * contributes its time stamp, as upstream.  deltaRij (row-major 3x3) is updated in place: start it at identity at a
+ * keyframe (ImuFrontend::resetIntegrationWithCachedBias), feed every packet since.  KVFE_ERR_INVALID_ARG for n < 2
+ * or a non-positive dt (both CHECKs upstream). */
+KVFE_API kvfe_status kvfe_imu_preintegrate_rotation(const int64_t* stamps, const double* acc_gyr, int32_t n,
+                                                    const double gyro_bias[3], double deltaRij[9]);
+/* camLrectLkf_R_camLrectK_imu = body_R_camLrect^-1 . deltaRij . body_R_camLrect (StereoVisionImuFrontend.cpp:143-150;
+ * body_R_camLrect = rotation of StereoCamera::getBodyPoseLeftCamRect = R_BS . R1^T) */
+KVFE_API void kvfe_keyframe_R_cur_frame(const double body_R_camLrect[9], const double deltaRij[9], double out[9]);
+
 /* StereoDataProviderModule::getInputPacket (src/dataprovider/StereoDataProviderModule.cpp:35-91) over
  * MonoDataProviderModule::getMonoImuSyncPacket (MonoDataProviderModule.cpp:44-118), DataProviderModule::
  * getTimeSyncedImuMeasurements (DataProviderModule.cpp:80-181) and SimpleQueueSynchronizer::syncQueue

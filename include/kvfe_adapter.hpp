@@ -859,6 +859,35 @@ class ThreadsafeImuBuffer {
 };
 }  // namespace utils
 
+// ImuFrontend::preintegrateImuMeasurements as far as the front-end needs it (src/imu-frontend/ImuFrontend.cpp:158-173):
+// the gyro rotation since the last keyframe, advanced by one packet's samples; resetIntegration() at a keyframe
+// (ImuFrontend::resetIntegrationWithCachedBias).  keyframeRcurFrame() is the kvfe_frame_input::keyframe_R_cur_frame of
+// StereoVisionImuFrontend.cpp:143-150.
+class ImuRotationPreintegrator {
+ public:
+  explicit ImuRotationPreintegrator(const double gyro_bias[3] = nullptr) {
+    for (int i = 0; i < 3; i++) bias_[i] = gyro_bias ? gyro_bias[i] : 0.0;
+    resetIntegration();
+  }
+  void resetIntegration() {
+    for (int i = 0; i < 9; i++) deltaRij_[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+  void updateBias(const double gyro_bias[3]) {
+    for (int i = 0; i < 3; i++) bias_[i] = gyro_bias[i];
+  }
+  void preintegrateImuMeasurements(const ImuMeasurements& imu) {
+    const kvfe_status st = kvfe_imu_preintegrate_rotation(imu.timestamps.data(), imu.acc_gyr.data(), imu.cols(), bias_, deltaRij_);
+    if (st != KVFE_OK) throw Error(st, "preintegrateImuMeasurements: fewer than two samples or a non-positive time step");
+  }
+  const double* deltaRij() const { return deltaRij_; }
+  void keyframeRcurFrame(const Pose3& body_Pose_camLrect, double out[9]) const {
+    kvfe_keyframe_R_cur_frame(body_Pose_camLrect.R, deltaRij_, out);
+  }
+
+ private:
+  double bias_[3], deltaRij_[9];
+};
+
 // StereoImuSyncPacket (include/kimera-vio/frontend/StereoImuSyncPacket.h:81-107) without the images: the frames
 // are referred to by the tags the caller queued them with
 struct StereoImuSyncPacket {

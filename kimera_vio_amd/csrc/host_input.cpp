@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cerrno>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -649,6 +650,58 @@ int32_t kvfe_imu_buffer_interpolated_upper_border(kvfe_imu_buffer* b, int64_t t_
 int32_t kvfe_imu_buffer_interpolated_borders(kvfe_imu_buffer* b, int64_t t_from, int64_t t_to, int64_t* stamps,
                                              double* acc_gyr, int32_t capacity, int32_t* n) {
   return imu_query_c(b, 2, t_from, t_to, 0, stamps, acc_gyr, capacity, n);
+}
+
+static inline void mat3_mul(const double* a, const double* b, double* c) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+kvfe_status kvfe_imu_preintegrate_rotation(const int64_t* stamps, const double* acc_gyr, int32_t n,
+                                           const double gyro_bias[3], double deltaRij[9]) {
+  if (!stamps || !acc_gyr || !deltaRij || n < 2) return KVFE_ERR_INVALID_ARG;
+  for (int32_t i = 0; i + 1 < n; i++)
+    if (stamps[i + 1] <= stamps[i]) return KVFE_ERR_INVALID_ARG;   // CHECK_GT(delta_t, 0.0) << "Imu delta is 0!"
+  const double bz[3] = {0, 0, 0};
+  const double* bg = gyro_bias ? gyro_bias : bz;
+  for (int32_t i = 0; i + 1 < n; i++) {
+    const double dt = static_cast<double>(stamps[i + 1] - stamps[i]) / 1e9;       // UtilsNumerical::NsecToSec
+    const double* g = acc_gyr + 6 * (size_t)i + 3;
+    const double w[3] = {(g[0] - bg[0]) * dt, (g[1] - bg[1]) * dt, (g[2] - bg[2]) * dt};
+    // so3::ExpmapFunctor(omega).expmap()
+    const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
+    double E[9];
+    if (theta2 <= 2.220446049250313e-16) {
+      for (int k = 0; k < 9; k++) E[k] = W[k];
+      E[0] += 1.0;
+      E[4] += 1.0;
+      E[8] += 1.0;
+    } else {
+      const double theta = std::sqrt(theta2), sin_theta = std::sin(theta), s2 = std::sin(theta / 2.0);
+      const double one_minus_cos = 2.0 * s2 * s2;
+      double K[9], KK[9];
+      for (int k = 0; k < 9; k++) K[k] = W[k] / theta;
+      mat3_mul(K, K, KK);
+      for (int k = 0; k < 9; k++) E[k] = sin_theta * K[k] + one_minus_cos * KK[k];
+      E[0] += 1.0;
+      E[4] += 1.0;
+      E[8] += 1.0;
+    }
+    double R[9];
+    mat3_mul(deltaRij, E, R);   // deltaXij_.attitude().compose(dR)
+    std::memcpy(deltaRij, R, sizeof(R));
+  }
+  return KVFE_OK;
+}
+
+void kvfe_keyframe_R_cur_frame(const double body_R_camLrect[9], const double deltaRij[9], double out[9]) {
+  if (!body_R_camLrect || !deltaRij || !out) return;
+  double cam_R_body[9], t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) cam_R_body[3 * i + j] = body_R_camLrect[3 * j + i];
+  mat3_mul(cam_R_body, deltaRij, t);        // (cam_Rot_body * pim->deltaRij()) * body_Rot_cam
+  mat3_mul(t, body_R_camLrect, out);
 }
 
 kvfe_stereo_sync* kvfe_stereo_sync_create(int64_t imu_buffer_length_ns) {

@@ -160,6 +160,31 @@ class ThreadsafeImuBuffer:
         return y
 
 
+def preintegrate_rotation(stamps, acc_gyr, gyro_bias=(0.0, 0.0, 0.0), deltaRij=None) -> np.ndarray:
+    """ImuFrontend::preintegrateImuMeasurements, rotation part: deltaRij (3x3, identity when None) advanced by the
+    packet's samples (stamps int64[n], acc_gyr float64[6, n] as the packets carry them)"""
+    t = np.ascontiguousarray(stamps, np.int64)
+    ag = np.ascontiguousarray(np.asarray(acc_gyr, np.float64).T)          # column k = sample k -> 6 per sample
+    R = np.eye(3) if deltaRij is None else np.array(deltaRij, np.float64).reshape(3, 3).copy()
+    b = np.ascontiguousarray(gyro_bias, np.float64).reshape(3)
+    p = C.POINTER(C.c_double)
+    _check(load().kvfe_imu_preintegrate_rotation(t.ctypes.data_as(C.POINTER(C.c_int64)), ag.ctypes.data_as(p), len(t),
+                                                 b.ctypes.data_as(p), R.ctypes.data_as(p)),
+           "kvfe_imu_preintegrate_rotation")
+    return R
+
+
+def keyframe_R_cur_frame(body_R_camLrect, deltaRij) -> np.ndarray:
+    """camLrectLkf_R_camLrectK_imu = cam_R_body . deltaRij . body_R_cam (StereoVisionImuFrontend.cpp:143-150): the
+    kvfe_frame_input::keyframe_R_cur_frame of the current frame"""
+    a = np.ascontiguousarray(body_R_camLrect, np.float64).reshape(3, 3)
+    d = np.ascontiguousarray(deltaRij, np.float64).reshape(3, 3)
+    out = np.empty((3, 3), np.float64)
+    p = C.POINTER(C.c_double)
+    load().kvfe_keyframe_R_cur_frame(a.ctypes.data_as(p), d.ctypes.data_as(p), out.ctypes.data_as(p))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # left / right / IMU synchronisation
 # ---------------------------------------------------------------------------------------------------------

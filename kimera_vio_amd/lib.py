@@ -128,6 +128,10 @@ def load() -> C.CDLL:
     L.kvfe_imu_buffer_interpolated_borders.argtypes = [vp, i64, i64, pi64, pf64, i32, pi32]
     L.kvfe_imu_linear_interpolate.argtypes = [i64, pf64, i64, pf64, i64, pf64]
     L.kvfe_imu_linear_interpolate.restype = None
+    L.kvfe_imu_preintegrate_rotation.argtypes = [pi64, pf64, i32, pf64, pf64]
+    L.kvfe_imu_preintegrate_rotation.restype = C.c_int32
+    L.kvfe_keyframe_R_cur_frame.argtypes = [pf64, pf64, pf64]
+    L.kvfe_keyframe_R_cur_frame.restype = None
     L.kvfe_stereo_sync_create.argtypes = [i64]
     L.kvfe_stereo_sync_create.restype = vp
     L.kvfe_stereo_sync_destroy.argtypes = [vp]
@@ -185,7 +189,8 @@ INPUT_SIDE_SYMBOLS = [
     "kvfe_imu_buffer_create",
     "kvfe_imu_buffer_destroy", "kvfe_imu_buffer_add", "kvfe_imu_buffer_size", "kvfe_imu_buffer_shutdown",
     "kvfe_imu_buffer_between", "kvfe_imu_buffer_interpolated_upper_border", "kvfe_imu_buffer_interpolated_borders",
-    "kvfe_imu_linear_interpolate", "kvfe_stereo_sync_create", "kvfe_stereo_sync_destroy", "kvfe_stereo_sync_set_mode",
+    "kvfe_imu_linear_interpolate", "kvfe_imu_preintegrate_rotation", "kvfe_keyframe_R_cur_frame",
+    "kvfe_stereo_sync_create", "kvfe_stereo_sync_destroy", "kvfe_stereo_sync_set_mode",
     "kvfe_stereo_sync_fill_left", "kvfe_stereo_sync_fill_right", "kvfe_stereo_sync_fill_imu",
     "kvfe_stereo_sync_do_coarse_imu_camera_temporal_sync", "kvfe_stereo_sync_set_imu_time_shift",
     "kvfe_stereo_sync_shutdown", "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv",

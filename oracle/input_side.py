@@ -141,3 +141,34 @@ class StereoProvider:
             return self.DROP_NO_RIGHT, None
         self.last = t
         return self.PACKET, (t, lf[1], rf[1], ts, vs)
+
+
+def _mul3(a, b):
+    return [a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j] for i in range(3) for j in range(3)]
+
+
+def preintegrate_rotation(stamps, gyro, gyro_bias=(0.0, 0.0, 0.0), deltaRij=None):
+    """ImuFrontend::preintegrateImuMeasurements (src/imu-frontend/ImuFrontend.cpp:158-173), rotation only:
+    deltaRij <- deltaRij . so3::ExpmapFunctor((gyro_i - bias) dt_i).expmap() for i < n - 1, dt = ns / 1e9 (gtsam 4.2
+    on-manifold preintegration, NavState::update).  gyro: n rows of 3.  Returns the 9 row-major entries."""
+    import math
+    R = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0] if deltaRij is None else [float(x) for x in deltaRij]
+    for i in range(len(stamps) - 1):
+        dt = float(stamps[i + 1] - stamps[i]) / 1e9
+        w = [(float(gyro[i][k]) - float(gyro_bias[k])) * dt for k in range(3)]
+        theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2]
+        W = [0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0]
+        if theta2 <= 2.220446049250313e-16:
+            E = list(W)
+        else:
+            theta = math.sqrt(theta2)
+            s, s2 = math.sin(theta), math.sin(theta / 2.0)
+            omc = 2.0 * s2 * s2
+            K = [x / theta for x in W]
+            KK = _mul3(K, K)
+            E = [s * K[k] + omc * KK[k] for k in range(9)]
+        E[0] += 1.0
+        E[4] += 1.0
+        E[8] += 1.0
+        R = _mul3(R, E)
+    return R

@@ -973,3 +973,65 @@ def test_jpeg_reference_frames_equal_committed_fixture():
         for k, n in enumerate((0, 1, 8)):
             img = dp.ReadAndConvertToGrayScale(f"/root/reference/tests/data/ForStereoTracker/{side}_frame{n:04d}.jpg")
             assert np.array_equal(img, z[key][k])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gyro rotation between keyframes -> keyframe_R_cur_frame
+# ---------------------------------------------------------------------------------------------------------------
+def test_preintegrate_rotation_equals_restatement_and_scipy():
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(12)
+    for trial in range(10):
+        n = int(rng.integers(2, 60))
+        t = np.cumsum(rng.integers(1, 9_000_000, n)).astype(np.int64)
+        ag = rng.normal(0, 1, (6, n))
+        if trial == 3:
+            ag[3:, :] = 0.0                                   # the near-zero branch of so3::ExpmapFunctor
+        if trial == 4:
+            ag[3:, :] *= 1e-9
+        bias = rng.normal(0, 0.01, 3) if trial % 2 else np.zeros(3)
+        R0 = Rot.from_rotvec(rng.normal(0, 0.3, 3)).as_matrix() if trial % 3 == 0 else None
+        R = dp.preintegrate_rotation(t, ag, bias, R0)
+        want = ora.preintegrate_rotation(t.tolist(), ag[3:].T.tolist(), bias.tolist(),
+                                         None if R0 is None else R0.reshape(9).tolist())
+        assert R.reshape(9).tolist() == want                  # same IEEE operations in the same order
+        E = np.eye(3) if R0 is None else R0.copy()
+        for i in range(n - 1):
+            E = E @ Rot.from_rotvec((ag[3:, i] - bias) * ((t[i + 1] - t[i]) / 1e9)).as_matrix()
+        assert np.abs(R - E).max() < 1e-13
+    with pytest.raises(KvfeError):                            # "No Imu data found." / "Imu delta is 0!"
+        dp.preintegrate_rotation(np.array([5], np.int64), np.zeros((6, 1)))
+    with pytest.raises(KvfeError):
+        dp.preintegrate_rotation(np.array([5, 5], np.int64), np.zeros((6, 2)))
+    bRc = Rot.from_rotvec([0.1, -1.2, 0.4]).as_matrix()
+    d = Rot.from_rotvec([0.02, 0.01, -0.03]).as_matrix()
+    assert np.abs(dp.keyframe_R_cur_frame(bRc, d) - bRc.T @ d @ bRc).max() < 1e-15
+
+
+@pytest.mark.skipif(not os.path.isdir(MICRO_EUROC), reason="the reference checkout (build container only)")
+def test_micro_euroc_packets_to_keyframe_rotation():
+    """dataset -> provider -> synchroniser -> gyro preintegration: the rotation since frame 10 accumulated packet by
+    packet stays within a milliradian of the fixture's own coarser integration (tests/golden/make_fixtures.py: raw
+    samples, no interpolated borders) over the nine frames the smoke test and the benchmark's single stream replay"""
+    from scipy.spatial.transform import Rotation as Rot
+    z = np.load(os.path.join(GOLDEN, "micro_euroc_f10_18.npz"))
+    prov = dp.EurocDataProvider(MICRO_EUROC, initial_k=9, final_k=19)
+    sync = dp.StereoDataProviderModule(-1)
+    prov.imu_single_callback = sync.fillImuQueue
+    prov.left_frame_callback = lambda k, t, img: sync.fillLeftFrameQueue(t, k)
+    prov.right_frame_callback = lambda k, t, img: sync.fillRightFrameQueue(t, k)
+    prov.spin()
+    R, got = np.eye(3), {}
+    while True:
+        pk = sync.getInputPacket()
+        if pk is None and sync.last_action == abi.SYNC_EMPTY:
+            break
+        if pk is None:
+            continue
+        if pk.left_tag >= 11:                                 # packets 11..18 carry the IMU data since frame 10..17
+            R = dp.preintegrate_rotation(pk.imu_stamps, pk.imu_accgyrs, deltaRij=R)
+            got[pk.left_tag] = R.copy()
+    assert sorted(got) == list(range(11, 19)) and z["timestamps"][0] == prov.timestampAtFrame(10)
+    for k in range(11, 19):
+        err = Rot.from_matrix(z["body_R"][k - 10].T @ got[k]).magnitude()
+        assert err < 1e-3, (k, err)
