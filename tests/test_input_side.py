@@ -1035,3 +1035,16 @@ def test_micro_euroc_packets_to_keyframe_rotation():
     for k in range(11, 19):
         err = Rot.from_matrix(z["body_R"][k - 10].T @ got[k]).magnitude()
         assert err < 1e-3, (k, err)
+
+
+@pytest.mark.skipif(not os.path.isdir(MICRO_EUROC), reason="the reference checkout (build container only)")
+def test_replay_tool_dry_run():
+    """tools/replay_euroc.py --dry-run: dataset -> packets -> rotation -> batch decode, no device"""
+    import subprocess
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "replay_euroc.py")
+    r = subprocess.run([sys.executable, tool, MICRO_EUROC, "--dry-run", "--final-k", "6", "--copies", "3"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert [ln.split()[1] for ln in lines[:-1]] == ["1", "2", "3", "4", "5"]      # frame 0 only sets the previous stamp
+    assert all("imu=11" in ln for ln in lines[:-1]) and "5 pairs x 3 stream(s)" in lines[-1]
