@@ -426,6 +426,21 @@ KVFE_API kvfe_status kvfe_calc_optical_flow_pyr_lk(kvfe_ctx* ctx,
                                                    int32_t n, uint8_t* status,
                                                    float* err);
 
+/* cv::buildOpticalFlowPyramid as cv::calcOpticalFlowPyrLK runs it on both images
+ * (Tracker.cpp:137-146): the cv::pyrDown chain, levels 1..L of `n_images` images of
+ * the context's size (L from klt_max_level and the window, as in OpenCV).
+ * levels_out: per image the levels 1..L densely packed one after the other;
+ * level_sizes_out[2 l], [2 l + 1] = width, height of level l = 0..L (may be NULL);
+ * level0_copy_out (may be NULL): the dense level-0 copy the device-pointer step
+ * keeps for the next frame's tracking (written by the same launch). */
+KVFE_API kvfe_status kvfe_build_optical_flow_pyramid(kvfe_ctx* ctx, const uint8_t* imgs,
+                                                     size_t row_stride, size_t image_stride,
+                                                     int32_t n_images, uint8_t* levels_out,
+                                                     size_t levels_capacity,
+                                                     int32_t* level_sizes_out,
+                                                     int32_t* n_levels_out,
+                                                     uint8_t* level0_copy_out);
+
 /* OpticalFlowPredictor::predictSparseFlow
  * (optical-flow/OpticalFlowPredictor.cpp:27-33,70-126); ref_R_cur row-major. */
 KVFE_API kvfe_status kvfe_predict_sparse_flow(kvfe_ctx* ctx, const float* prev_xy,

@@ -584,16 +584,231 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const unsigned char* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pyr2_kernel: TWO cv::pyrDown levels in one streaming pass, no barrier, no LDS staging of pixels.
+//   wave  = one horizontal strip (T2 rows of level l+2 = 2 T2 rows of level l+1 = 4 T2 source rows + halo) of one stream
+//   lane  = 16 source columns = 8 level-(l+1) columns = 4 level-(l+2) columns: ONE aligned 16-byte load per lane and
+//           source row (a wave reads 1 KB row segments), one 16-byte store of the level-0 copy, one 8-byte store per
+//           level-(l+1) row, one 4-byte store per level-(l+2) row -- every byte is requested once per strip;
+//   rows  = the wave walks down its strip with a five-row register window of horizontal sums; the columns a lane
+//           needs from its neighbours (2 on the left, 1 on the right) come by DPP wave shifts, BORDER_REFLECT_101 at
+//           the image border is a byte permutation of the lane's own dwords (columns) and index arithmetic (rows);
+//   sums  = horizontal 1-4-6-4-1 by two v_dot4_u32_u8 per output, two outputs per register; the vertical pass in packed
+//           16-bit arithmetic (v_pk_add_u16 / v_pk_mad_u16: the full 5x5 sum + 128 is at most 65 408 < 2^16; the
+//           rounding constant rides in as +16 on the odd rows, whose weight is always 4); the second level's horizontal
+//           sums are taken from the registers that hold the first level's row and parked in a per-lane LDS ring (rows of
+//           level l+1 reflect at the image border, so they are addressed by row index), its vertical pass reads five
+//           ring rows.  Integer arithmetic, any order of the 25 taps gives the same sum => bit-exact.
+// Requirements (else the tile kernel above is used): source width % 16 == 0, 16-byte aligned rows, height >= 16.
+// Waves along x only for more than 62 lanes (992 columns): a wave then owns lanes 2..61, the two lanes on either
+// side recompute their neighbours' values.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short pk16_t __attribute__((ext_vector_type(2)));
+constexpr unsigned PW_A = 0x04060401u;   // taps (1,4,6,4) on bytes 0..3
+constexpr unsigned PW_B = 0x00000001u;   // tap 1 on byte 0
+constexpr unsigned PW_C = 0x04010000u;   // taps (1,4) on bytes 2,3
+constexpr unsigned PW_D = 0x00010406u;   // taps (6,4,1) on bytes 0..2
+constexpr unsigned PSEL_LEFT = 0x01020c0cu;    // columns -2, -1 of BORDER_REFLECT_101 = columns 2, 1
+constexpr unsigned PSEL_RIGHT = 0x0c0c0c02u;   // column w = column w - 2
+constexpr unsigned PSEL_ROUND = 0x07050301u;   // (sum + 128) >> 8 of four 16-bit sums = their high bytes
+
+struct PyrH {   // horizontal sums of the 8 outputs of one lane and source row, two per register
+  pk16_t a, b, c, d;
+};
+
+__device__ __forceinline__ unsigned pyr_dot4(unsigned x, unsigned w, unsigned acc) {
+  return __builtin_amdgcn_udot4(x, w, acc, false);
+}
+__device__ __forceinline__ unsigned pyr_shr1(unsigned v, unsigned fill) {   // lane i <- lane i-1, lane 0 <- fill
+  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned pyr_shl1(unsigned v, unsigned fill) {   // lane i <- lane i+1, lane 63 <- fill
+  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ pk16_t pyr_pk(unsigned lo, unsigned hi) { return __builtin_bit_cast(pk16_t, lo | (hi << 16)); }
+
+// eight outputs from the 16 bytes of a lane (+ 2 bytes of the left, 1 byte of the right neighbour)
+__device__ __forceinline__ PyrH pyr_hpass16(const uint4& d, bool last, unsigned bias) {
+  const unsigned pd = pyr_shr1(d.w, __builtin_amdgcn_perm(d.x, d.x, PSEL_LEFT));
+  unsigned nd = pyr_shl1(d.x, 0u);
+  nd = last ? __builtin_amdgcn_perm(d.w, d.w, PSEL_RIGHT) : nd;
+  PyrH h;
+  h.a = pyr_pk(pyr_dot4(pd, PW_C, pyr_dot4(d.x, PW_D, bias)), pyr_dot4(d.x, PW_A, pyr_dot4(d.y, PW_B, bias)));
+  h.b = pyr_pk(pyr_dot4(d.x, PW_C, pyr_dot4(d.y, PW_D, bias)), pyr_dot4(d.y, PW_A, pyr_dot4(d.z, PW_B, bias)));
+  h.c = pyr_pk(pyr_dot4(d.y, PW_C, pyr_dot4(d.z, PW_D, bias)), pyr_dot4(d.z, PW_A, pyr_dot4(d.w, PW_B, bias)));
+  h.d = pyr_pk(pyr_dot4(d.z, PW_C, pyr_dot4(d.w, PW_D, bias)), pyr_dot4(d.w, PW_A, pyr_dot4(nd, PW_B, bias)));
+  return h;
+}
+// four outputs of the second level from the 8 bytes (lo, hi) of a lane's first-level row
+__device__ __forceinline__ uint2 pyr_hpass8(unsigned lo, unsigned hi, bool last, unsigned bias) {
+  const unsigned ph = pyr_shr1(hi, __builtin_amdgcn_perm(lo, lo, PSEL_LEFT));
+  unsigned nl = pyr_shl1(lo, 0u);
+  nl = last ? __builtin_amdgcn_perm(hi, hi, PSEL_RIGHT) : nl;
+  const unsigned g0 = pyr_dot4(ph, PW_C, pyr_dot4(lo, PW_D, bias)), g1 = pyr_dot4(lo, PW_A, pyr_dot4(hi, PW_B, bias));
+  const unsigned g2 = pyr_dot4(lo, PW_C, pyr_dot4(hi, PW_D, bias)), g3 = pyr_dot4(hi, PW_A, pyr_dot4(nl, PW_B, bias));
+  return make_uint2(g0 | (g1 << 16), g2 | (g3 << 16));
+}
+__device__ __forceinline__ pk16_t pyr_vert(pk16_t r0, pk16_t r1, pk16_t r2, pk16_t r3, pk16_t r4) {
+  const pk16_t four = {4, 4}, six = {6, 6};
+  return r2 * six + ((r1 + r3) * four + (r0 + r4));
+}
+// the 8 first-level pixels of a lane from five rows of horizontal sums
+__device__ __forceinline__ void pyr_vert8(const PyrH& r0, const PyrH& r1, const PyrH& r2, const PyrH& r3, const PyrH& r4,
+                                          unsigned& lo, unsigned& hi) {
+  const unsigned ua = __builtin_bit_cast(unsigned, pyr_vert(r0.a, r1.a, r2.a, r3.a, r4.a));
+  const unsigned ub = __builtin_bit_cast(unsigned, pyr_vert(r0.b, r1.b, r2.b, r3.b, r4.b));
+  const unsigned uc = __builtin_bit_cast(unsigned, pyr_vert(r0.c, r1.c, r2.c, r3.c, r4.c));
+  const unsigned ud = __builtin_bit_cast(unsigned, pyr_vert(r0.d, r1.d, r2.d, r3.d, r4.d));
+  lo = __builtin_amdgcn_perm(ub, ua, PSEL_ROUND);
+  hi = __builtin_amdgcn_perm(ud, uc, PSEL_ROUND);
+}
+__device__ __forceinline__ int pyr_reflect(int k, int n) {   // BORDER_REFLECT_101 for -n < k < 2n - 1
+  return k < 0 ? -k : (k >= n ? 2 * n - 2 - k : k);
+}
+
+template <bool COPY, bool TWO>
+__global__ __launch_bounds__(64) void pyr2_kernel(const unsigned char* __restrict__ src, size_t srow, size_t simg, int w0,
+                                                  int h0, unsigned char* __restrict__ dst1, unsigned char* __restrict__ dst2,
+                                                  size_t dimg, unsigned char* __restrict__ copy_dst, size_t cimg, int B,
+                                                  int T2, int NS, int nwx, int xcd_mode) {
+  extern __shared__ uint2 pyr_ring[];   // [2 T2 + 4][64]: second-level horizontal sums of the strip's first-level rows
+  int s, strip, wx;
+  {
+    const int per_stream = NS * nwx;
+    int b = blockIdx.x, rem;
+    if (xcd_mode) {   // workgroup b runs on XCD b & 7 (a speed assumption only): a stream's strips share one L2
+      const int j = b >> 3;
+      s = (b & 7) + 8 * (j / per_stream);
+      rem = j % per_stream;
+      if (s >= B) return;
+    } else {
+      s = b / per_stream;
+      rem = b - s * per_stream;
+    }
+    strip = rem / nwx;
+    wx = rem - strip * nwx;
+  }
+  const int lane = threadIdx.x;
+  const int nl = w0 >> 4;
+  const int gl = 60 * wx + lane;
+  const int glc = min(gl, nl - 1);
+  const bool owner = gl < nl && lane < 62 && (wx == 0 || lane >= 2);
+  const bool last = gl == nl - 1;
+  const int w1 = w0 >> 1, h1 = (h0 + 1) >> 1, w2 = w0 >> 2, h2 = (h1 + 1) >> 1;
+  const int T1 = 2 * T2, Y1 = strip * T1;
+  const int y1_lo = TWO ? max(0, Y1 - 2) : Y1;
+  const int y1_hi = min(h1 - 1, TWO ? Y1 + T1 : Y1 + T1 - 1);
+  const int own0_lo = 2 * Y1, own0_hi = min(h0, 2 * (Y1 + T1));   // source rows whose level-0 copy this strip writes
+  const int own1_hi = min(h1, Y1 + T1);
+  const unsigned char* S = src + (size_t)s * simg + (size_t)glc * 16;
+  unsigned char* C = COPY ? copy_dst + (size_t)s * cimg + (size_t)gl * 16 : nullptr;
+  unsigned char* D1 = dst1 + (size_t)s * dimg + (size_t)gl * 8;
+  auto load = [&](int k) { return *reinterpret_cast<const uint4*>(S + (size_t)pyr_reflect(k, h0) * srow); };
+  auto keep = [&](int k, const uint4& d) {   // level-0 copy of source row k
+    if (COPY && owner && k >= own0_lo && k < own0_hi) *reinterpret_cast<uint4*>(C + (size_t)k * w0) = d;
+  };
+  auto emit1 = [&](int y1, const PyrH& r0, const PyrH& r1, const PyrH& r2, const PyrH& r3, const PyrH& r4) {
+    unsigned lo, hi;
+    pyr_vert8(r0, r1, r2, r3, r4, lo, hi);
+    if (owner && y1 >= Y1 && y1 < own1_hi) *reinterpret_cast<uint2*>(D1 + (size_t)y1 * w1) = make_uint2(lo, hi);
+    if (TWO) pyr_ring[(y1 - y1_lo) * 64 + lane] = pyr_hpass8(lo, hi, last, (y1 & 1) ? 16u : 0u);
+  };
+  const int k0 = 2 * y1_lo - 2;
+  uint4 q0 = load(k0), q1 = load(k0 + 1), q2 = load(k0 + 2);
+  uint4 n0 = load(k0 + 3), n1 = load(k0 + 4), n2 = load(k0 + 5), n3 = load(k0 + 6);
+  PyrH r0 = pyr_hpass16(q0, last, 0u), r1 = pyr_hpass16(q1, last, 16u), r2 = pyr_hpass16(q2, last, 0u);
+  keep(k0, q0);       // (negative for the first strip: not kept)
+  keep(k0 + 1, q1);
+  keep(k0 + 2, q2);
+  for (int y1 = y1_lo; y1 <= y1_hi; y1 += 2) {
+    const int k = 2 * y1;
+    // the four source rows of the NEXT two first-level rows are requested before this pair is computed
+    const uint4 m0 = load(k + 5), m1 = load(k + 6), m2 = load(k + 7), m3 = load(k + 8);
+    const PyrH r3 = pyr_hpass16(n0, last, 16u), r4 = pyr_hpass16(n1, last, 0u);
+    keep(k + 1, n0);
+    keep(k + 2, n1);
+    emit1(y1, r0, r1, r2, r3, r4);
+    const PyrH r5 = pyr_hpass16(n2, last, 16u), r6 = pyr_hpass16(n3, last, 0u);
+    keep(k + 3, n2);
+    keep(k + 4, n3);
+    emit1(y1 + 1, r2, r3, r4, r5, r6);   // (a row past y1_hi is computed from reflected rows and not stored)
+    r0 = r4;
+    r1 = r5;
+    r2 = r6;
+    n0 = m0;
+    n1 = m1;
+    n2 = m2;
+    n3 = m3;
+  }
+  if (TWO) {
+    unsigned char* D2 = dst2 + (size_t)s * dimg + (size_t)gl * 4;
+    const int y2_hi = min(h2, (strip + 1) * T2);
+    for (int y2 = strip * T2; y2 < y2_hi; y2++) {
+      uint2 g[5];
+#pragma unroll
+      for (int d = 0; d < 5; d++) g[d] = pyr_ring[(pyr_reflect(2 * y2 - 2 + d, h1) - y1_lo) * 64 + lane];
+      const unsigned ua = __builtin_bit_cast(unsigned, pyr_vert(__builtin_bit_cast(pk16_t, g[0].x), __builtin_bit_cast(pk16_t, g[1].x),
+                                                                __builtin_bit_cast(pk16_t, g[2].x), __builtin_bit_cast(pk16_t, g[3].x),
+                                                                __builtin_bit_cast(pk16_t, g[4].x)));
+      const unsigned ub = __builtin_bit_cast(unsigned, pyr_vert(__builtin_bit_cast(pk16_t, g[0].y), __builtin_bit_cast(pk16_t, g[1].y),
+                                                                __builtin_bit_cast(pk16_t, g[2].y), __builtin_bit_cast(pk16_t, g[3].y),
+                                                                __builtin_bit_cast(pk16_t, g[4].y)));
+      if (owner) *reinterpret_cast<unsigned*>(D2 + (size_t)y2 * w2) = __builtin_amdgcn_perm(ub, ua, PSEL_ROUND);
+    }
+  }
+}
+
+// can level `l` (and l+1) be produced by pyr2_kernel from level l-1?
+static bool pyr2_ok(const unsigned char* src, size_t srow, size_t simg, int w0, int h0, const unsigned char* d1,
+                    const unsigned char* d2, size_t dimg) {
+  return w0 % 16 == 0 && h0 >= 16 && srow % 16 == 0 && simg % 16 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(d1) % 8 == 0 && reinterpret_cast<uintptr_t>(d2) % 4 == 0 && dimg % 8 == 0;
+}
+
 void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
                     size_t img_stride, unsigned char* pyr, hipStream_t st, unsigned char* level0_copy) {
   if (level0_copy && P.nlevels < 2)   // (klt_max_level 0: no level-1 launch to piggyback on)
     for (int s = 0; s < P.B; s++)
       (void)hipMemcpy2DAsync(level0_copy + (size_t)s * P.W * P.H, (size_t)P.W, img + (size_t)s * img_stride, row_stride,
                              (size_t)P.W, (size_t)P.H, hipMemcpyDeviceToDevice, st);
+  // KVFE_PYR_IMPL: 0 = tile kernel per level, 1 = streaming two-level kernel where the geometry allows (default);
+  // KVFE_PYR_T2: second-level rows per strip (0 = from the batch size)
+  static const int impl = std::getenv("KVFE_PYR_IMPL") ? std::atoi(std::getenv("KVFE_PYR_IMPL")) : 1;
+  static const int t2_env = std::getenv("KVFE_PYR_T2") ? std::atoi(std::getenv("KVFE_PYR_T2")) : 0;
   for (int l = 1; l < P.nlevels; l++) {
     const unsigned char* src = l == 1 ? img : pyr + P.loff[l - 1];
     const size_t srow = l == 1 ? row_stride : (size_t)P.lw[l - 1];
     const size_t simg = l == 1 ? img_stride : (size_t)P.pyr_stride;
+    const bool two = l + 1 < P.nlevels;
+    const bool copy = l == 1 && level0_copy;
+    if (impl == 1 && pyr2_ok(src, srow, simg, P.lw[l - 1], P.lh[l - 1], pyr + P.loff[l], two ? pyr + P.loff[l + 1] : pyr,
+                             (size_t)P.pyr_stride) &&
+        (!copy || (reinterpret_cast<uintptr_t>(level0_copy) % 16 == 0 && ((size_t)P.W * P.H) % 16 == 0))) {
+      const int w0 = P.lw[l - 1], h0 = P.lh[l - 1], h1 = (h0 + 1) / 2, h2 = (h1 + 1) / 2;
+      const int nl = w0 / 16, nwx = nl <= 62 ? 1 : 1 + (nl - 62 + 59) / 60;
+      // strip height: the halo costs (4 T2 + 9) / (4 T2) source rows, so strips are as tall as the chip stays busy with
+      int T2 = t2_env;
+      if (T2 <= 0) {
+        T2 = 16;
+        while (T2 > 2 && (long long)P.B * nwx * ((h2 + T2 - 1) / T2) < 1536) T2 >>= 1;
+      }
+      T2 = std::max(1, std::min(T2, 32));
+      const int NS = two ? (h2 + T2 - 1) / T2 : (h1 + 2 * T2 - 1) / (2 * T2);
+      const int xcd = P.B >= 8 ? 1 : 0;
+      const int nblk = xcd ? 8 * ((P.B + 7) / 8) * NS * nwx : P.B * NS * nwx;
+      const size_t lds = two ? (size_t)(2 * T2 + 4) * 64 * sizeof(uint2) : 0;
+#define KVFE_PYR2(COPY_, TWO_)                                                                                         \
+  hipLaunchKernelGGL((pyr2_kernel<COPY_, TWO_>), dim3(nblk), dim3(64), lds, st, src, srow, simg, w0, h0,                \
+                     pyr + P.loff[l], two ? pyr + P.loff[l + 1] : (unsigned char*)nullptr, (size_t)P.pyr_stride,        \
+                     level0_copy, (size_t)P.W * P.H, P.B, T2, NS, nwx, xcd)
+      if (copy && two) KVFE_PYR2(true, true);
+      else if (copy) KVFE_PYR2(true, false);
+      else if (two) KVFE_PYR2(false, true);
+      else KVFE_PYR2(false, false);
+#undef KVFE_PYR2
+      if (two) l++;
+      continue;
+    }
     dim3 grid((P.lw[l] + PT_W - 1) / PT_W, (P.lh[l] + PT_H - 1) / PT_H, P.B);
     if (l == 1 && level0_copy)
       hipLaunchKernelGGL(pyrdown_kernel<true>, grid, dim3(256), 0, st, src, srow, simg, P.lw[l - 1], P.lh[l - 1],

@@ -1444,6 +1444,64 @@ kvfe_status kvfe_calc_optical_flow_pyr_lk(kvfe_ctx* c, const uint8_t* prev_img,
   return KVFE_OK;
 }
 
+kvfe_status kvfe_build_optical_flow_pyramid(kvfe_ctx* c, const uint8_t* imgs, size_t row_stride, size_t image_stride,
+                                            int32_t n_images, uint8_t* levels_out, size_t levels_capacity,
+                                            int32_t* level_sizes_out, int32_t* n_levels_out, uint8_t* level0_copy_out) {
+  DeviceGuard _dev(c);
+  if (!c || !imgs || !levels_out || n_images < 1) return KVFE_ERR_INVALID_ARG;
+  KParams P = c->P;
+  P.B = n_images;
+  if (row_stride < (size_t)P.W || (n_images > 1 && image_stride < row_stride * (size_t)(P.H - 1) + P.W))
+    return KVFE_ERR_INVALID_ARG;
+  size_t per_image = 0;
+  for (int l = 1; l < P.nlevels; l++) per_image += (size_t)P.lw[l] * P.lh[l];
+  if (levels_capacity < per_image * n_images) return KVFE_ERR_CAPACITY;
+  if (n_levels_out) *n_levels_out = P.nlevels;
+  if (level_sizes_out)
+    for (int l = 0; l < P.nlevels; l++) {
+      level_sizes_out[2 * l] = P.lw[l];
+      level_sizes_out[2 * l + 1] = P.lh[l];
+    }
+  hipStream_t st = c->stream;
+  // component call (tests, inspection): its own scratch, nothing of the front-end state is touched
+  const size_t src_bytes = image_stride * (size_t)(n_images - 1) + row_stride * (size_t)(P.H - 1) + P.W;
+  const size_t N = (size_t)P.W * P.H;
+  unsigned char *dsrc = nullptr, *dpyr = nullptr, *dcopy = nullptr;
+  auto release = [&]() {
+    if (dsrc) hipFree(dsrc);
+    if (dpyr) hipFree(dpyr);
+    if (dcopy) hipFree(dcopy);
+  };
+  kvfe_status rc = KVFE_OK;
+  do {
+    if (hipMalloc(&dsrc, src_bytes) != hipSuccess || hipMalloc(&dpyr, (size_t)P.pyr_stride * n_images) != hipSuccess ||
+        (level0_copy_out && hipMalloc(&dcopy, N * n_images) != hipSuccess)) {
+      c->last_error = "kvfe_build_optical_flow_pyramid: device allocation failed";
+      rc = KVFE_ERR_HIP;
+      break;
+    }
+    if (hipMemcpyAsync(dsrc, imgs, src_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = KVFE_ERR_HIP; break; }
+    launch_pyramid(P, dsrc, row_stride, image_stride, dpyr, st, dcopy);
+    if (hipGetLastError() != hipSuccess) { rc = KVFE_ERR_HIP; break; }
+    for (int s = 0; s < n_images && rc == KVFE_OK; s++) {
+      size_t off = 0;
+      for (int l = 1; l < P.nlevels; l++) {
+        const size_t bytes = (size_t)P.lw[l] * P.lh[l];
+        if (hipMemcpyAsync(levels_out + per_image * s + off, dpyr + (size_t)P.pyr_stride * s + P.loff[l], bytes,
+                           hipMemcpyDeviceToHost, st) != hipSuccess) { rc = KVFE_ERR_HIP; break; }
+        off += bytes;
+      }
+    }
+    if (rc == KVFE_OK && level0_copy_out &&
+        hipMemcpyAsync(level0_copy_out, dcopy, N * n_images, hipMemcpyDeviceToHost, st) != hipSuccess)
+      rc = KVFE_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = KVFE_ERR_HIP;
+  } while (0);
+  release();
+  if (rc == KVFE_ERR_HIP && c->last_error.empty()) c->last_error = "kvfe_build_optical_flow_pyramid: HIP error";
+  return rc;
+}
+
 kvfe_status kvfe_predict_sparse_flow(kvfe_ctx* c, const float* prev_xy, int32_t n,
                                      const double ref_R_cur[9], float* out_xy) {
   DeviceGuard _dev(c);

@@ -193,6 +193,36 @@ class Context:
                   "calc_optical_flow_pyr_lk")
         return q, status, err
 
+    def build_optical_flow_pyramid(self, imgs, with_level0_copy=False):
+        """cv::buildOpticalFlowPyramid (the cv::pyrDown chain of cv::calcOpticalFlowPyrLK, Tracker.cpp:137-146) of a
+        batch of images [n, H, W] (any row / image strides).  Returns (levels, copy): levels[s] = list of the
+        levels 1..L of image s as 2-D arrays; copy = the dense level-0 copy [n, H, W] or None."""
+        a = np.asarray(imgs)
+        if a.ndim == 2:
+            a = a[None]
+        assert a.dtype == np.uint8 and a.ndim == 3 and a.strides[2] == 1
+        n, H, W = a.shape
+        row_stride, img_stride = a.strides[1], (a.strides[0] if n > 1 else a.strides[1] * H)
+        sizes = np.zeros(2 * 16, np.int32)
+        nlev = np.zeros(1, np.int32)
+        cap = n * H * W
+        out = np.zeros(cap, np.uint8)
+        cp = np.zeros((n, H, W), np.uint8) if with_level0_copy else None
+        self._chk(self.lib.kvfe_build_optical_flow_pyramid(self._h, a.ctypes.data, row_stride, img_stride, n, _p(out),
+                                                           cap, _p(sizes), _p(nlev), _p(cp) if cp is not None else None),
+                  "build_optical_flow_pyramid")
+        L = int(nlev[0])
+        per = sum(int(sizes[2 * l]) * int(sizes[2 * l + 1]) for l in range(1, L))
+        levels = []
+        for s in range(n):
+            off, lv = s * per, []
+            for l in range(1, L):
+                w, h = int(sizes[2 * l]), int(sizes[2 * l + 1])
+                lv.append(out[off:off + w * h].reshape(h, w).copy())
+                off += w * h
+            levels.append(lv)
+        return levels, cp
+
     def predict_sparse_flow(self, prev_xy, ref_R_cur) -> np.ndarray:
         p = _pts(prev_xy)
         R = np.ascontiguousarray(ref_R_cur, np.float64).reshape(9)

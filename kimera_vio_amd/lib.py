@@ -64,6 +64,7 @@ def load() -> C.CDLL:
     L.kvfe_feature_detection.argtypes = [vp, vp, sz, vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.kvfe_corner_subpix.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, f64]
     L.kvfe_calc_optical_flow_pyr_lk.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp]
+    L.kvfe_build_optical_flow_pyramid.argtypes = [vp, vp, sz, sz, i32, vp, sz, vp, vp, vp]
     L.kvfe_predict_sparse_flow.argtypes = [vp, vp, i32, vp, vp]
     L.kvfe_get_right_keypoints_rectified.argtypes = [vp, vp, vp, sz, vp, vp, i32, vp, vp, vp]
     L.kvfe_sparse_stereo_reconstruction.argtypes = [vp, vp, vp, sz, vp, i32,
@@ -162,7 +163,7 @@ def load() -> C.CDLL:
                "kvfe_get_rectification", "kvfe_undistort_rectify_image",
                "kvfe_undistort_rectify_keypoints", "kvfe_get_bearing_vectors",
                "kvfe_raw_feature_detection", "kvfe_feature_detection", "kvfe_corner_subpix",
-               "kvfe_calc_optical_flow_pyr_lk", "kvfe_predict_sparse_flow",
+               "kvfe_calc_optical_flow_pyr_lk", "kvfe_build_optical_flow_pyramid", "kvfe_predict_sparse_flow",
                "kvfe_get_right_keypoints_rectified", "kvfe_sparse_stereo_reconstruction",
                "kvfe_outlier_rejection_2d2d_given_rotation",
                "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_equalize_hist",
@@ -176,6 +177,8 @@ def load() -> C.CDLL:
     _lib = L
     return L
 
+
+NEW_R3_SYMBOLS = ["kvfe_build_optical_flow_pyramid"]
 
 NEW_R2_SYMBOLS = [
     "kvfe_check_undistorted_rectified_left_keypoints", "kvfe_distort_unrectify_keypoints",
@@ -196,7 +199,7 @@ INPUT_SIDE_SYMBOLS = [
     "kvfe_stereo_sync_shutdown", "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv",
 ]
 
-EXPORTED_SYMBOLS = NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
+EXPORTED_SYMBOLS = NEW_R3_SYMBOLS + NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
     "kvfe_version", "kvfe_status_string", "kvfe_last_error", "kvfe_default_frontend_params",
     "kvfe_create", "kvfe_destroy", "kvfe_compute_rectification",
     "kvfe_compute_undistort_rectify_maps", "kvfe_get_rectification", "kvfe_undistort_rectify_image",

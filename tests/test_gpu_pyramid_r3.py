@@ -1,0 +1,115 @@
+"""cv::buildOpticalFlowPyramid (the cv::pyrDown chain inside cv::calcOpticalFlowPyrLK, Tracker.cpp:137-146) through
+`kvfe_build_optical_flow_pyramid`, bit-exact against the oracle's pyrDown, level by level.
+
+The streaming two-level kernel (`pyr2_kernel`, k_rectify.hip) has geometry preconditions (source width % 16 == 0,
+16-byte aligned rows) and several code paths -- one or several waves along x, image-border lanes, strips with and
+without reflected rows, the XCD-banded block order for >= 8 streams, the level-0 copy of the device-pointer step --
+so the sizes below are chosen to hit each of them, plus sizes that must take the tile kernel."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from kimera_vio_amd import frontend as F
+from kimera_vio_amd import workloads as WL
+from test_gpu_parity import euroc_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(w, h, maxlevel, win=24):
+    L, R = WL.make_cameras(w, h)
+    p = euroc_params()
+    p.tracker.klt_max_level = maxlevel
+    p.tracker.klt_win_size = win
+    return F.Context(L, R, p)
+
+
+def _oracle_levels(img, nlev):
+    out, cur = [], img
+    for _ in range(nlev):
+        cur = O.pyr_down(cur)
+        out.append(cur)
+    return out
+
+
+def _images(n, h, w, seed, pad=0):
+    rng = np.random.RandomState(seed)
+    a = rng.randint(0, 256, (n, h, w + pad), dtype=np.uint8)
+    a[0, : h // 2] = 255          # saturated block: the 16-bit sums reach their maximum
+    if n > 1:
+        a[1, :, : w // 2] = 0
+    return a[:, :, :w] if pad else a
+
+
+CASES = [
+    # (w, h, klt_max_level, n_images)            path
+    (752, 480, 2, 1),     # EuRoC, one wave per row, strips of 2 rows (few streams)
+    (752, 480, 4, 3),     # 5 levels: two-level launch, then 188 x 120 (% 16 != 0) through the tile kernel
+    (752, 480, 2, 9),     # >= 8 streams: XCD-banded order with a ragged last group
+    (1280, 720, 3, 2),    # two waves along x (80 lanes), 640 x 360 second launch (one wave, single level)
+    (2048, 96, 2, 1),     # three waves along x, few rows
+    (112, 50, 1, 2),      # seven lanes, single level, odd level-1 height
+    (112, 34, 2, 1),      # h1 = 17 (odd), h2 = 9: reflected rows at both ends of both levels
+    (752, 478, 2, 2),     # h0 % 4 == 2
+    (752, 481, 2, 2),     # odd source height
+    (750, 480, 2, 2),     # width % 16 != 0: tile kernel
+    (120, 100, 2, 1),
+]
+
+
+@pytest.mark.parametrize("w,h,maxlevel,n", CASES)
+def test_pyramid_levels_bit_exact(w, h, maxlevel, n):
+    c = _ctx(w, h, maxlevel, win=8)
+    try:
+        imgs = _images(n, h, w, seed=w * 7 + h)
+        levels, copy = c.build_optical_flow_pyramid(imgs, with_level0_copy=True)
+        assert np.array_equal(copy, imgs)
+        for s in range(n):
+            exp = _oracle_levels(imgs[s], len(levels[s]))
+            assert len(levels[s]) >= 1
+            for l, (g, e) in enumerate(zip(levels[s], exp)):
+                assert g.shape == e.shape, (s, l, g.shape, e.shape)
+                bad = np.argwhere(g != e)
+                assert len(bad) == 0, "image %d level %d: %d px differ, first at %s" % (s, l + 1, len(bad), bad[:4])
+    finally:
+        c.close()
+
+
+def test_pyramid_strided_rows():
+    """rows with a pitch: 16-byte aligned (streaming kernel) and unaligned (tile kernel)"""
+    for pad in (16, 5):
+        c = _ctx(752, 480, 2, win=8)
+        try:
+            imgs = _images(2, 480, 752, seed=3 + pad, pad=pad)
+            assert imgs.strides[1] == 752 + pad
+            levels, copy = c.build_optical_flow_pyramid(imgs, with_level0_copy=True)
+            assert np.array_equal(copy, imgs)
+            for s in range(2):
+                for g, e in zip(levels[s], _oracle_levels(np.ascontiguousarray(imgs[s]), 2)):
+                    assert np.array_equal(g, e)
+        finally:
+            c.close()
+
+
+@pytest.mark.parametrize("t2", ["1", "3", "8", "32"])
+def test_pyramid_strip_heights(t2, monkeypatch):
+    """every strip height gives the same levels (KVFE_PYR_T2 is read at the first launch of a process, so the variants
+    run in sub-processes)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gpu_pyramid_r3 as T\n"
+        "for (w, h, ml, n) in [(752, 480, 2, 2), (1280, 722, 3, 1)]:\n"
+        "    c = T._ctx(w, h, ml, win=8)\n"
+        "    imgs = T._images(n, h, w, seed=11)\n"
+        "    levels, copy = c.build_optical_flow_pyramid(imgs, with_level0_copy=True)\n"
+        "    assert np.array_equal(copy, imgs)\n"
+        "    for s in range(n):\n"
+        "        for g, e in zip(levels[s], T._oracle_levels(imgs[s], len(levels[s]))):\n"
+        "            assert np.array_equal(g, e)\n"
+        "print('ok')\n" % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))))
+    env = dict(os.environ, KVFE_PYR_T2=t2)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
