@@ -628,10 +628,9 @@ __device__ __forceinline__ unsigned pyr_shl1(unsigned v, unsigned fill) {   // l
 __device__ __forceinline__ pk16_t pyr_pk(unsigned lo, unsigned hi) { return __builtin_bit_cast(pk16_t, lo | (hi << 16)); }
 
 // eight outputs from the 16 bytes of a lane (+ 2 bytes of the left, 1 byte of the right neighbour)
-__device__ __forceinline__ PyrH pyr_hpass16(const uint4& d, bool last, unsigned bias) {
+__device__ __forceinline__ PyrH pyr_hpass16(const uint4& d, unsigned sel_right, unsigned bias) {
   const unsigned pd = pyr_shr1(d.w, __builtin_amdgcn_perm(d.x, d.x, PSEL_LEFT));
-  unsigned nd = pyr_shl1(d.x, 0u);
-  nd = last ? __builtin_amdgcn_perm(d.w, d.w, PSEL_RIGHT) : nd;
+  const unsigned nd = __builtin_amdgcn_perm(pyr_shl1(d.x, 0u), d.w, sel_right);
   PyrH h;
   h.a = pyr_pk(pyr_dot4(pd, PW_C, pyr_dot4(d.x, PW_D, bias)), pyr_dot4(d.x, PW_A, pyr_dot4(d.y, PW_B, bias)));
   h.b = pyr_pk(pyr_dot4(d.x, PW_C, pyr_dot4(d.y, PW_D, bias)), pyr_dot4(d.y, PW_A, pyr_dot4(d.z, PW_B, bias)));
@@ -640,10 +639,9 @@ __device__ __forceinline__ PyrH pyr_hpass16(const uint4& d, bool last, unsigned 
   return h;
 }
 // four outputs of the second level from the 8 bytes (lo, hi) of a lane's first-level row
-__device__ __forceinline__ uint2 pyr_hpass8(unsigned lo, unsigned hi, bool last, unsigned bias) {
+__device__ __forceinline__ uint2 pyr_hpass8(unsigned lo, unsigned hi, unsigned sel_right, unsigned bias) {
   const unsigned ph = pyr_shr1(hi, __builtin_amdgcn_perm(lo, lo, PSEL_LEFT));
-  unsigned nl = pyr_shl1(lo, 0u);
-  nl = last ? __builtin_amdgcn_perm(hi, hi, PSEL_RIGHT) : nl;
+  const unsigned nl = __builtin_amdgcn_perm(pyr_shl1(lo, 0u), hi, sel_right);
   const unsigned g0 = pyr_dot4(ph, PW_C, pyr_dot4(lo, PW_D, bias)), g1 = pyr_dot4(lo, PW_A, pyr_dot4(hi, PW_B, bias));
   const unsigned g2 = pyr_dot4(lo, PW_C, pyr_dot4(hi, PW_D, bias)), g3 = pyr_dot4(hi, PW_A, pyr_dot4(nl, PW_B, bias));
   return make_uint2(g0 | (g1 << 16), g2 | (g3 << 16));
@@ -666,12 +664,117 @@ __device__ __forceinline__ int pyr_reflect(int k, int n) {   // BORDER_REFLECT_1
   return k < 0 ? -k : (k >= n ? 2 * n - 2 - k : k);
 }
 
-template <bool COPY, bool TWO>
-__global__ __launch_bounds__(64) void pyr2_kernel(const unsigned char* __restrict__ src, size_t srow, size_t simg, int w0,
-                                                  int h0, unsigned char* __restrict__ dst1, unsigned char* __restrict__ dst2,
-                                                  size_t dimg, unsigned char* __restrict__ copy_dst, size_t cimg, int B,
-                                                  int T2, int NS, int nwx, int xcd_mode) {
-  extern __shared__ uint2 pyr_ring[];   // [2 T2 + 4][64]: second-level horizontal sums of the strip's first-level rows
+typedef unsigned pyr_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned pyr_v2u __attribute__((ext_vector_type(2)));
+
+// T2: second-level rows per strip (compile time: the strip is fully unrolled -- ALL its source rows are requested
+// before the first one is used, so a wave waits for memory once; the five-row window rotates by register renaming).
+struct Pyr2Args {
+  const unsigned char* src;
+  unsigned srow;
+  size_t simg;
+  int w0, h0;
+  unsigned char *dst1, *dst2;
+  size_t dimg;
+  unsigned char* copy_dst;
+  size_t cimg;
+};
+
+// One strip.  INTERIOR: no source / first-level row of the strip reflects at the image border and every row it owns
+// exists -- row offsets are then plain multiples and every bounds test folds away; the border strips take the general
+// instantiation (a wave-uniform choice).
+template <int T2, bool COPY, bool TWO, bool INTERIOR>
+__device__ __forceinline__ void pyr2_strip(const Pyr2Args& A, uint2* ring, int s, int strip, int gl, int nl, bool owner) {
+  constexpr int NJ = TWO ? 2 * T2 + 3 : 2 * T2;   // first-level rows a strip computes (TWO: 2 + 1 rows of halo)
+  constexpr int NR = 2 * NJ + 3;                  // source rows it reads
+  constexpr int J0 = TWO ? 2 : 0;                 // first first-level row it owns (stores)
+  constexpr int I0 = TWO ? 6 : 2;                 // first source row whose level-0 copy it stores
+  const int lane = threadIdx.x;
+  const int w0 = A.w0, h0 = A.h0;
+  const int w1 = w0 >> 1, h1 = (h0 + 1) >> 1, w2 = w0 >> 2, h2 = (h1 + 1) >> 1;
+  const int Y1 = strip * 2 * T2;                  // first owned first-level row (even)
+  const int y1b = TWO ? Y1 - 2 : Y1;              // first-level row of j = 0 (may be virtual: -2)
+  const int kb = 2 * y1b - 2;                     // source row of i = 0 (may be virtual)
+  // right image border: column w is column w - 2; every other lane takes its neighbour's first dword (one v_perm_b32
+  // with a per-lane selector instead of a select)
+  const unsigned sel_right = gl == nl - 1 ? PSEL_RIGHT : 0x07060504u;
+  // raw buffers: per-lane byte offset in a VGPR, the row offset in an SGPR (one scalar op per row, no 64-bit math);
+  // lanes that own nothing store at offset 2^32 - 1, which the buffer bounds check drops
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(A.src) + (size_t)s * A.simg, 0,
+                                                                     (int)(A.srow * (unsigned)(h0 - 1) + (unsigned)w0), 0x00027000);
+  const unsigned voff = (unsigned)min(gl, nl - 1) * 16u;
+  pyr_v4u R[NR];
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    const unsigned r = INTERIOR ? (unsigned)(kb + i) : (unsigned)pyr_reflect(kb + i, h0);
+    R[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, r * A.srow, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (keep the requests ahead of the arithmetic)
+  // rows are consumed in request order (vmcnt counts in order): row i is worked on while rows i+1.. are still in flight
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(COPY ? A.copy_dst + (size_t)s * A.cimg : nullptr, 0,
+                                                                     COPY ? h0 * w0 : 0, 0x00027000);
+  const unsigned coff = owner ? (unsigned)gl * 16u : 0xffffffffu;
+  auto keep = [&](int i) {   // level-0 copy of source row kb + i
+    if (COPY && i >= I0 && i < I0 + 4 * T2 && (INTERIOR || kb + i < h0))
+      __builtin_amdgcn_raw_buffer_store_b128(R[i], rc, coff, (unsigned)(kb + i) * (unsigned)w0, 0);
+  };
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(A.dst1 + (size_t)s * A.dimg, 0, h1 * w1, 0x00027000);
+  const unsigned o1 = owner ? (unsigned)gl * 8u : 0xffffffffu;
+  PyrH H[5];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const uint4 d = make_uint4(R[i].x, R[i].y, R[i].z, R[i].w);
+    H[i] = pyr_hpass16(d, sel_right, (i & 1) ? 16u : 0u);
+    keep(i);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    // first-level row y1b + j from source rows 2 j .. 2 j + 4 (window slots rotate: slot of source row i is i % 5)
+#pragma unroll
+    for (int i = 2 * j + 3; i <= 2 * j + 4; i++) {
+      const uint4 d = make_uint4(R[i].x, R[i].y, R[i].z, R[i].w);
+      H[i % 5] = pyr_hpass16(d, sel_right, (i & 1) ? 16u : 0u);
+      keep(i);
+    }
+    unsigned lo, hi;
+    pyr_vert8(H[(2 * j) % 5], H[(2 * j + 1) % 5], H[(2 * j + 2) % 5], H[(2 * j + 3) % 5], H[(2 * j + 4) % 5], lo, hi);
+    if (j >= J0 && j < J0 + 2 * T2 && (INTERIOR || y1b + j < h1)) {
+      const pyr_v2u v = {lo, hi};
+      __builtin_amdgcn_raw_buffer_store_b64(v, r1, o1, (unsigned)(y1b + j) * (unsigned)w1, 0);
+    }
+    if (TWO) ring[j * 64 + lane] = pyr_hpass8(lo, hi, sel_right, (j & 1) ? 16u : 0u);
+  }
+  if (TWO) {
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(A.dst2 + (size_t)s * A.dimg, 0, h2 * w2, 0x00027000);
+    const unsigned o2 = owner ? (unsigned)gl * 4u : 0xffffffffu;
+#pragma unroll
+    for (int t = 0; t < T2; t++) {
+      const int y2 = strip * T2 + t;
+      if (INTERIOR || y2 < h2) {
+        uint2 g[5];
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+          const int slot = INTERIOR ? 2 * t + d : pyr_reflect(2 * y2 - 2 + d, h1) - y1b;
+          g[d] = ring[slot * 64 + lane];
+        }
+        const unsigned ua = __builtin_bit_cast(unsigned, pyr_vert(__builtin_bit_cast(pk16_t, g[0].x), __builtin_bit_cast(pk16_t, g[1].x),
+                                                                  __builtin_bit_cast(pk16_t, g[2].x), __builtin_bit_cast(pk16_t, g[3].x),
+                                                                  __builtin_bit_cast(pk16_t, g[4].x)));
+        const unsigned ub = __builtin_bit_cast(unsigned, pyr_vert(__builtin_bit_cast(pk16_t, g[0].y), __builtin_bit_cast(pk16_t, g[1].y),
+                                                                  __builtin_bit_cast(pk16_t, g[2].y), __builtin_bit_cast(pk16_t, g[3].y),
+                                                                  __builtin_bit_cast(pk16_t, g[4].y)));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(ub, ua, PSEL_ROUND), r2, o2, (unsigned)y2 * (unsigned)w2, 0);
+      }
+    }
+  }
+}
+
+// T2: second-level rows per strip (compile time: the strip is fully unrolled -- ALL its source rows are requested
+// before the first one is used, so a wave waits for memory once; the five-row window rotates by register renaming).
+template <int T2, bool COPY, bool TWO>
+__global__ __launch_bounds__(64) void pyr2_kernel(Pyr2Args A, int B, int NS, int nwx, int xcd_mode) {
+  constexpr int NJ = TWO ? 2 * T2 + 3 : 2 * T2;
+  __shared__ uint2 ring[TWO ? NJ * 64 : 1];       // second-level horizontal sums of the strip's first-level rows
   int s, strip, wx;
   {
     const int per_stream = NS * nwx;
@@ -689,73 +792,15 @@ __global__ __launch_bounds__(64) void pyr2_kernel(const unsigned char* __restric
     wx = rem - strip * nwx;
   }
   const int lane = threadIdx.x;
-  const int nl = w0 >> 4;
+  const int nl = A.w0 >> 4;
   const int gl = 60 * wx + lane;
-  const int glc = min(gl, nl - 1);
   const bool owner = gl < nl && lane < 62 && (wx == 0 || lane >= 2);
-  const bool last = gl == nl - 1;
-  const int w1 = w0 >> 1, h1 = (h0 + 1) >> 1, w2 = w0 >> 2, h2 = (h1 + 1) >> 1;
-  const int T1 = 2 * T2, Y1 = strip * T1;
-  const int y1_lo = TWO ? max(0, Y1 - 2) : Y1;
-  const int y1_hi = min(h1 - 1, TWO ? Y1 + T1 : Y1 + T1 - 1);
-  const int own0_lo = 2 * Y1, own0_hi = min(h0, 2 * (Y1 + T1));   // source rows whose level-0 copy this strip writes
-  const int own1_hi = min(h1, Y1 + T1);
-  const unsigned char* S = src + (size_t)s * simg + (size_t)glc * 16;
-  unsigned char* C = COPY ? copy_dst + (size_t)s * cimg + (size_t)gl * 16 : nullptr;
-  unsigned char* D1 = dst1 + (size_t)s * dimg + (size_t)gl * 8;
-  auto load = [&](int k) { return *reinterpret_cast<const uint4*>(S + (size_t)pyr_reflect(k, h0) * srow); };
-  auto keep = [&](int k, const uint4& d) {   // level-0 copy of source row k
-    if (COPY && owner && k >= own0_lo && k < own0_hi) *reinterpret_cast<uint4*>(C + (size_t)k * w0) = d;
-  };
-  auto emit1 = [&](int y1, const PyrH& r0, const PyrH& r1, const PyrH& r2, const PyrH& r3, const PyrH& r4) {
-    unsigned lo, hi;
-    pyr_vert8(r0, r1, r2, r3, r4, lo, hi);
-    if (owner && y1 >= Y1 && y1 < own1_hi) *reinterpret_cast<uint2*>(D1 + (size_t)y1 * w1) = make_uint2(lo, hi);
-    if (TWO) pyr_ring[(y1 - y1_lo) * 64 + lane] = pyr_hpass8(lo, hi, last, (y1 & 1) ? 16u : 0u);
-  };
-  const int k0 = 2 * y1_lo - 2;
-  uint4 q0 = load(k0), q1 = load(k0 + 1), q2 = load(k0 + 2);
-  uint4 n0 = load(k0 + 3), n1 = load(k0 + 4), n2 = load(k0 + 5), n3 = load(k0 + 6);
-  PyrH r0 = pyr_hpass16(q0, last, 0u), r1 = pyr_hpass16(q1, last, 16u), r2 = pyr_hpass16(q2, last, 0u);
-  keep(k0, q0);       // (negative for the first strip: not kept)
-  keep(k0 + 1, q1);
-  keep(k0 + 2, q2);
-  for (int y1 = y1_lo; y1 <= y1_hi; y1 += 2) {
-    const int k = 2 * y1;
-    // the four source rows of the NEXT two first-level rows are requested before this pair is computed
-    const uint4 m0 = load(k + 5), m1 = load(k + 6), m2 = load(k + 7), m3 = load(k + 8);
-    const PyrH r3 = pyr_hpass16(n0, last, 16u), r4 = pyr_hpass16(n1, last, 0u);
-    keep(k + 1, n0);
-    keep(k + 2, n1);
-    emit1(y1, r0, r1, r2, r3, r4);
-    const PyrH r5 = pyr_hpass16(n2, last, 16u), r6 = pyr_hpass16(n3, last, 0u);
-    keep(k + 3, n2);
-    keep(k + 4, n3);
-    emit1(y1 + 1, r2, r3, r4, r5, r6);   // (a row past y1_hi is computed from reflected rows and not stored)
-    r0 = r4;
-    r1 = r5;
-    r2 = r6;
-    n0 = m0;
-    n1 = m1;
-    n2 = m2;
-    n3 = m3;
-  }
-  if (TWO) {
-    unsigned char* D2 = dst2 + (size_t)s * dimg + (size_t)gl * 4;
-    const int y2_hi = min(h2, (strip + 1) * T2);
-    for (int y2 = strip * T2; y2 < y2_hi; y2++) {
-      uint2 g[5];
-#pragma unroll
-      for (int d = 0; d < 5; d++) g[d] = pyr_ring[(pyr_reflect(2 * y2 - 2 + d, h1) - y1_lo) * 64 + lane];
-      const unsigned ua = __builtin_bit_cast(unsigned, pyr_vert(__builtin_bit_cast(pk16_t, g[0].x), __builtin_bit_cast(pk16_t, g[1].x),
-                                                                __builtin_bit_cast(pk16_t, g[2].x), __builtin_bit_cast(pk16_t, g[3].x),
-                                                                __builtin_bit_cast(pk16_t, g[4].x)));
-      const unsigned ub = __builtin_bit_cast(unsigned, pyr_vert(__builtin_bit_cast(pk16_t, g[0].y), __builtin_bit_cast(pk16_t, g[1].y),
-                                                                __builtin_bit_cast(pk16_t, g[2].y), __builtin_bit_cast(pk16_t, g[3].y),
-                                                                __builtin_bit_cast(pk16_t, g[4].y)));
-      if (owner) *reinterpret_cast<unsigned*>(D2 + (size_t)y2 * w2) = __builtin_amdgcn_perm(ub, ua, PSEL_ROUND);
-    }
-  }
+  const int h1 = (A.h0 + 1) >> 1, h2 = (h1 + 1) >> 1;
+  const int Y1 = strip * 2 * T2, kb = 2 * (TWO ? Y1 - 2 : Y1) - 2;
+  const bool interior = kb >= 0 && kb + 2 * NJ + 3 <= A.h0 && Y1 + 2 * T2 + (TWO ? 1 : 0) <= h1 &&
+                        (!TWO || (strip + 1) * T2 <= h2);
+  if (interior) pyr2_strip<T2, COPY, TWO, true>(A, ring, s, strip, gl, nl, owner);
+  else pyr2_strip<T2, COPY, TWO, false>(A, ring, s, strip, gl, nl, owner);
 }
 
 // can level `l` (and l+1) be produced by pyr2_kernel from level l-1?
@@ -787,24 +832,30 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
       const int w0 = P.lw[l - 1], h0 = P.lh[l - 1], h1 = (h0 + 1) / 2, h2 = (h1 + 1) / 2;
       const int nl = w0 / 16, nwx = nl <= 62 ? 1 : 1 + (nl - 62 + 59) / 60;
       // strip height: the halo costs (4 T2 + 9) / (4 T2) source rows, so strips are as tall as the chip stays busy with
+      // (a strip is one wave; its source rows live in registers: T2 = 8 needs ~220 VGPRs)
       int T2 = t2_env;
-      if (T2 <= 0) {
-        T2 = 16;
+      if (T2 != 2 && T2 != 4 && T2 != 8) {
+        T2 = 8;
         while (T2 > 2 && (long long)P.B * nwx * ((h2 + T2 - 1) / T2) < 1536) T2 >>= 1;
       }
-      T2 = std::max(1, std::min(T2, 32));
       const int NS = two ? (h2 + T2 - 1) / T2 : (h1 + 2 * T2 - 1) / (2 * T2);
       const int xcd = P.B >= 8 ? 1 : 0;
       const int nblk = xcd ? 8 * ((P.B + 7) / 8) * NS * nwx : P.B * NS * nwx;
-      const size_t lds = two ? (size_t)(2 * T2 + 4) * 64 * sizeof(uint2) : 0;
-#define KVFE_PYR2(COPY_, TWO_)                                                                                         \
-  hipLaunchKernelGGL((pyr2_kernel<COPY_, TWO_>), dim3(nblk), dim3(64), lds, st, src, srow, simg, w0, h0,                \
-                     pyr + P.loff[l], two ? pyr + P.loff[l + 1] : (unsigned char*)nullptr, (size_t)P.pyr_stride,        \
-                     level0_copy, (size_t)P.W * P.H, P.B, T2, NS, nwx, xcd)
-      if (copy && two) KVFE_PYR2(true, true);
-      else if (copy) KVFE_PYR2(true, false);
-      else if (two) KVFE_PYR2(false, true);
-      else KVFE_PYR2(false, false);
+      const Pyr2Args pa{src, (unsigned)srow, simg, w0, h0, pyr + P.loff[l], two ? pyr + P.loff[l + 1] : (unsigned char*)nullptr,
+                        (size_t)P.pyr_stride, level0_copy, (size_t)P.W * P.H};
+#define KVFE_PYR2(T2_, COPY_, TWO_)                                                                                    \
+  hipLaunchKernelGGL((pyr2_kernel<T2_, COPY_, TWO_>), dim3(nblk), dim3(64), 0, st, pa, P.B, NS, nwx, xcd)
+#define KVFE_PYR2_T(T2_)                             \
+  do {                                               \
+    if (copy && two) KVFE_PYR2(T2_, true, true);     \
+    else if (copy) KVFE_PYR2(T2_, true, false);      \
+    else if (two) KVFE_PYR2(T2_, false, true);       \
+    else KVFE_PYR2(T2_, false, false);               \
+  } while (0)
+      if (T2 == 8) KVFE_PYR2_T(8);
+      else if (T2 == 4) KVFE_PYR2_T(4);
+      else KVFE_PYR2_T(2);
+#undef KVFE_PYR2_T
 #undef KVFE_PYR2
       if (two) l++;
       continue;
