@@ -18,6 +18,7 @@
 #include <mutex>
 #include "kvfe_dev.hpp"
 
+#include <type_traits>
 #include <utility>
 
 namespace kvfe {
@@ -296,6 +297,278 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
     atomicMax(&maxkey[s], bestkey);
 }
 
+// ---------------------------------------------------------------------------------------------
+// mineig2_kernel: the same pipeline and the same arithmetic, restructured around what bounds it (instruction issue,
+// every category: profiles/r2_v5_lk_analysis.md, tools/ubench/valu_rate.hip):
+//   * the strip's rows are split into a prologue, a STEADY part and an epilogue.  Every stage is live and no row
+//     reflects in the steady part, so its steps carry no range test, no border copy and no row-index arithmetic (the
+//     old step spent ~45 scalar instructions and ~10 branches per row on them); the checked step runs only on the few
+//     rows at either end of a strip and on strips at the top / bottom of the image;
+//   * the source byte of a row comes from a raw buffer load: per-lane column offset in a VGPR, row offset in an SGPR that
+//     advances by one scalar add;
+//   * the row's detection-mask word is read from LDS one step ahead and stays in VGPRs until it is used;
+//   * lane predicates that are wave-wide facts (detection mask, image columns 1..W-2) live as 64-bit scalar masks and
+//     are combined with scalar ANDs; only the two float compares of the local-maximum test are vector instructions.
+// ---------------------------------------------------------------------------------------------
+typedef int me_v4i __attribute__((ext_vector_type(4)));
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(64) void mineig2_kernel(
+    const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
+    const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
+    const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
+    const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
+    const int* __restrict__ flags,
+    unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
+    unsigned int* __restrict__ maxkey, int strip_rows) {
+  const int s = blockIdx.z;
+  if (flags && !(flags[s] & FLAG_DETECT)) return;
+  __shared__ unsigned long long rowmask[ME_ROWS + 1];  // bit l set: lane l's column is masked OUT (+1: read-ahead slot)
+  __shared__ unsigned long long lcand[ME_LCAP];
+  __shared__ int hw_s[MAX_RADIUS + 1];
+
+  const unsigned char* I = img + (size_t)s * img_stride;
+  const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
+  const int lane = threadIdx.x;
+  const int xs = blockIdx.x * ME_COLS, ys = blockIdx.y * strip_rows;
+  const int ye = min(ys + strip_rows, H);
+  const int x0 = xs - ME_HALO;          // column of lane 0
+  const int gx = x0 + lane;
+  const int cxr = reflect101(gx, W);    // source column (BORDER_REFLECT_101)
+  const bool out_col = lane >= ME_HALO && lane < 64 - ME_HALO && gx < W;
+  const bool at_left = gx == 0, at_right = gx == W - 1;
+
+  if (lane <= ME_ROWS) rowmask[lane] = 0ull;
+  if (lane == 0) rowmask[ME_ROWS] = 0ull;
+  for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
+  __syncthreads();
+  // detection mask: rasterise the cv::circle discs that touch this strip into row bit-masks
+  if (use_discs) {
+    const float2* kp = kp_all + (size_t)s * kcap;
+    const int nk = kp_count[s];
+    const long long* lmk = lmk_all + (size_t)s * kcap;
+    for (int i = lane; i < nk; i += 64) {
+      if (lmk[i] == -1) continue;  // only keypoints with a landmark mask (FeatureDetector.cpp:191)
+      const float2 p = kp[i];
+      const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
+      if (cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye)
+        continue;
+      const int r0 = max(cy - radius, ys), r1 = min(cy + radius, ye - 1);
+      for (int gy = r0; gy <= r1; gy++) {
+        const int hw = hw_s[abs(gy - cy)];
+        const int xa = max(cx - hw, x0) - x0, xb = min(cx + hw, x0 + 63) - x0;
+        if (xa > xb) continue;
+        const unsigned long long bits =
+            (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
+        atomicOr(&rowmask[gy - ys], bits);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0));  // (float)scale, blockSize 3, ksize 3
+  const float f0 = 2.0f * f1;
+  // rows: hm rows b0..b1, cov/h rows c0..c1, pixel rows c0-1..c1+1 (reflected outside the image)
+  const int b0 = max(ys - 1, 0), b1 = min(ye, H - 1);
+  const int c0 = max(b0 - 1, 0), c1 = min(b1 + 1, H - 1);
+  const int r_first = c0 - 1, r_last = min(ye + 2, H + 1);
+  const int lm0 = max(ys, 1), lm1 = min(ye - 1, H - 2);
+  // steady steps r: cov row r-1, box row r-2 (inside the strip, not an image border row), local-max row r-3 are all
+  // live and the row requested by the step, r+3, is a plain image row
+  const int rs = max(max(c0 + 1, max(max(b0, ys), 1) + 2), lm0 + 3);
+  const int re = min(min(c1 + 1, min(min(b1, ye - 1), H - 2) + 2), min(lm1 + 3, H - 4));
+
+  float bestv = -__builtin_inff();  // masked maximum of lambda (no pixel has lambda = -inf)
+  int n_loc = 0;                    // wave-uniform
+  auto flush = [&]() {
+    int base = 0;
+    if (lane == 0 && n_loc > 0) base = atomicAdd(&cand_count[s], n_loc);
+    base = __shfl(base, 0);
+    for (int i = lane; i < n_loc; i += 64) {
+      const int pos = base + i;
+      if (pos < ccap) cand_all[(size_t)s * ccap + pos] = lcand[i];
+    }
+    n_loc = 0;
+  };
+
+  // source rows: raw buffer, per-lane column in a VGPR, row offset in an SGPR (an image is < 2 GiB).  Three rows in
+  // flight per lane (one per rotating slot), issued and awaited by hand: vmcnt counts in issue order, so "at most two
+  // outstanding" means this slot's load has landed.
+  const unsigned stride_u = (unsigned)row_stride;
+  const unsigned long long ibase = (unsigned long long)(size_t)I;
+  const me_v4i rsrc = {(int)(unsigned)ibase, (int)(unsigned)((ibase >> 32) & 0xffffu),
+                       (int)(stride_u * (unsigned)(H - 1) + (unsigned)W), 0x00027000};
+  const unsigned voff = (unsigned)cxr;
+  const unsigned char* mcol = HAS_MASK ? M + min(max(gx, 0), W - 1) : nullptr;
+  auto row_of = [&](int r) {  // BORDER_REFLECT_101 for r in [-1, H], clamped for the unused rows beyond
+    int rr = r < 0 ? -r : r;
+    rr = rr >= H ? 2 * H - 2 - rr : rr;
+    return (unsigned)min(max(rr, 0), H - 1);
+  };
+  auto issue_off = [&](unsigned& dst, unsigned soff) {
+    asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  unsigned pq0, pq1, pq2;  // raw bytes: converted at use
+  issue_off(pq0, row_of(r_first) * stride_u);
+  issue_off(pq1, row_of(r_first + 1) * stride_u);
+  issue_off(pq2, row_of(r_first + 2) * stride_u);
+  const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
+  // wave-wide lane facts as scalar masks
+  const unsigned long long out_mask = __ballot(out_col);
+  const unsigned long long colok_mask = __ballot(gx >= 1 && gx < W - 1);
+  unsigned long long in_b_mask = 0ull;   // lanes whose pixel of the last box row passes the detection mask
+  // the detection-mask word of the next box row, read one step ahead; the per-lane zero keeps the value in VGPRs (a
+  // uniform LDS read would be moved to SGPRs -- and waited for -- right where it is issued)
+  unsigned lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  unsigned long long mk_v = 0ull;
+  auto fetch_mask = [&](int b) {   // row b of the strip's mask (clamped: rows outside the strip are never used)
+    const int idx = min(max(b - ys, 0), ME_ROWS);
+    mk_v = rowmask[idx + lane_zero];
+  };
+  unsigned soff_next = 0;   // steady part: row offset of the next request
+
+  // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  CHECK: the stages test their row ranges and
+  // copy border rows (prologue, epilogue, image-border strips); otherwise every stage is live.  Only wave-uniform
+  // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
+  auto step = [&](auto check_tag, int r, MeRow& X, MeRow& Y, MeRow& Z, unsigned& p_next) {
+    constexpr bool CHECK = decltype(check_tag)::value;
+    const unsigned long long in_m_mask = in_b_mask;  // row m = r-3 was the box row of the previous step
+    // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
+    {
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(p_next));
+      const float p = (float)p_next;
+      if (CHECK) {
+        issue_off(p_next, row_of(r + 3) * stride_u);
+      } else {
+        issue_off(p_next, soff_next);
+        soff_next += stride_u;
+      }
+      const float pl = dpp_from_left(p), pr = dpp_from_right(p);
+      X.dh = pr - pl;
+      float t = f1 * pl;
+      t += f0 * p;
+      t += f1 * pr;
+      X.sm = t;
+    }
+    // the mask word of box row r-2 was requested by the previous step; request the next one now
+    const unsigned long long mk_cur_v = mk_v;
+    fetch_mask(r - 1);
+    // ---- cov row c = r-1 -> horizontal float64 sums --------------------------------------------
+    const int c = r - 1;
+    if (!CHECK || (c >= c0 && c <= c1)) {
+      const float dx = (Z.dh + X.dh) * f1 + Y.dh * f0;
+      const float dy = X.sm - Z.sm;
+      const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
+      const float lxx = dpp_from_left(cxx), rxx = dpp_from_right(cxx);
+      const float lxy = dpp_from_left(cxy), rxy = dpp_from_right(cxy);
+      const float lyy = dpp_from_left(cyy), ryy = dpp_from_right(cyy);
+      // BORDER_REFLECT_101 of cv::boxFilter: column -1 is column 1, column W is column W-2
+      float axx = lxx, bxx = rxx, axy = lxy, bxy = rxy, ayy = lyy, byy = ryy;
+      if (edge_strip) {
+        axx = at_left ? rxx : lxx, bxx = at_right ? lxx : rxx;
+        axy = at_left ? rxy : lxy, bxy = at_right ? lxy : rxy;
+        ayy = at_left ? ryy : lyy, byy = at_right ? lyy : ryy;
+      }
+      // cv::boxFilter accumulates 0 + a + b + c in float64; "0 +" is dropped: it is exact for the
+      // non-negative dx*dx / dy*dy sums and can only change the sign of a zero dx*dy sum, which
+      // enters lambda squared.
+      Y.h0 = ((double)axx + (double)cxx) + (double)bxx;
+      Y.h1 = ((double)axy + (double)cxy) + (double)bxy;
+      Y.h2 = ((double)ayy + (double)cyy) + (double)byy;
+    }
+    // ---- box row b = r-2 -> lambda, horizontal max; masked maximum ------------------------------
+    const int b = r - 2;
+    if (!CHECK || (b >= b0 && b <= b1)) {
+      // rows b-1, b, b+1 = slots X, Z, Y; BORDER_REFLECT_101 at the image border: row -1 is row 1
+      // (slot Y), row H is row H-2 (slot X) -- wave-uniform branches taken once per strip
+      if (CHECK && b == 0) {
+        asm volatile("");  // keep the once-per-strip border copies out of the row loop's selects
+        X.h0 = Y.h0;
+        X.h1 = Y.h1;
+        X.h2 = Y.h2;
+      }
+      if (CHECK && b == H - 1) {
+        asm volatile("");
+        Y.h0 = X.h0;
+        Y.h1 = X.h1;
+        Y.h2 = X.h2;
+      }
+      const double s0 = (X.h0 + Z.h0) + Y.h0, s1 = (X.h1 + Z.h1) + Y.h1, s2 = (X.h2 + Z.h2) + Y.h2;
+      const float fa = (float)s0 * 0.5f, fb = (float)s1, fc = (float)s2 * 0.5f;
+      const float lam = (fa + fc) - sqrt_rn_small((fa - fc) * (fa - fc) + fb * fb);
+      Z.lam = lam;
+      Z.hm = fmaxf(fmaxf(dpp_from_left(lam), lam), dpp_from_right(lam));
+      if (!CHECK || (b >= ys && b < ye)) {
+        // the row's bit mask is wave-uniform: it IS the lane predicate
+        const unsigned long long mk = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mk_cur_v >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mk_cur_v);
+        unsigned long long in_mask = out_mask & ~mk;
+        if (HAS_MASK) in_mask &= __ballot(mcol[(unsigned)(b * W)] != 0);
+        in_b_mask = in_mask;
+        bestv = vmaxf(bestv, __builtin_amdgcn_inverse_ballot_w64(in_mask) ? lam : -__builtin_inff());
+      } else if (CHECK) {
+        in_b_mask = 0ull;   // (box rows outside the strip feed only the 3x3 maximum)
+      }
+    }
+    // ---- row m = r-3: 3x3 local maximum (rows m-1, m, m+1 = slots Y, X, Z) ----------------------
+    const int m = r - 3;
+    if (!CHECK || (m >= lm0 && m <= lm1)) {
+      const float v = X.lam;
+      const unsigned long long bal = __ballot((v != 0.0f) & (v == fmaxf(fmaxf(Y.hm, X.hm), Z.hm))) & in_m_mask & colok_mask;
+      if (bal) {
+        if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
+          const int pos = n_loc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          lcand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(m * W + gx);
+        }
+        n_loc += __popcll(bal);
+        if (n_loc > ME_LCAP - 64) {
+          __syncthreads();
+          flush();
+          __syncthreads();
+        }
+      }
+    }
+  };
+  using CK = std::integral_constant<bool, true>;
+  using NC = std::integral_constant<bool, false>;
+
+  MeRow S0, S1, S2;
+  S0 = S1 = S2 = MeRow{0.f, 0.f, 0., 0., 0., 0.f, 0.f};
+  // slots rotate with the row index: slot(r) = (r - r_first) % 3
+  int r = r_first;
+  fetch_mask(r - 2);   // (the first step's "previous" request)
+  // prologue: checked steps up to the first steady row, rounded up to a whole slot rotation
+  const int n_pro = rs > re ? 0x3fffffff : ((rs - r_first + 2) / 3) * 3;
+  for (; r <= r_last && r - r_first < n_pro; r += 3) {
+    step(CK{}, r, S0, S2, S1, pq0);
+    if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
+    if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
+  }
+  if (r + 2 <= re) {
+    // the three requests in flight are rows r, r+1, r+2 (the prologue issued them with the checked addressing)
+    soff_next = (unsigned)(r + 3) * stride_u;
+    for (; r + 2 <= re; r += 3) {
+      step(NC{}, r, S0, S2, S1, pq0);
+      step(NC{}, r + 1, S1, S0, S2, pq1);
+      step(NC{}, r + 2, S2, S1, S0, pq2);
+    }
+  }
+  for (; r <= r_last; r += 3) {
+    step(CK{}, r, S0, S2, S1, pq0);
+    if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
+    if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
+  }
+  __syncthreads();
+  flush();
+  for (int off = 32; off > 0; off >>= 1) bestv = fmaxf(bestv, __shfl_xor(bestv, off));
+  const unsigned bestkey = bestv == -__builtin_inff() ? 0u : fkey(bestv);
+  // masked maximum: one global atomic per wave, skipped when it cannot raise the maximum
+  if (lane == 0 && bestkey &&
+      bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&maxkey[s], bestkey);
+}
+
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
@@ -322,6 +595,21 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     if (cost <= best) best = cost, strip_rows = rws;
   }
   dim3 grid(nx, (P.H + strip_rows - 1) / strip_rows, P.B);
+  // KVFE_MINEIG_IMPL: 1 = round-1/2 kernel (every step checked), 2 = prologue / steady / epilogue kernel (default)
+  static const int impl = std::getenv("KVFE_MINEIG_IMPL") ? std::atoi(std::getenv("KVFE_MINEIG_IMPL")) : 2;
+  if (impl == 2) {
+    if (user_mask)
+      hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
+                         img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
+                         T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                         D.maxkey, strip_rows);
+    else
+      hipLaunchKernelGGL(mineig2_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
+                         img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
+                         T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                         D.maxkey, strip_rows);
+    return;
+  }
   if (user_mask)
     hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                        img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
