@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
 //     are combined with scalar ANDs; only the two float compares of the local-maximum test are vector instructions.
 // ---------------------------------------------------------------------------------------------
 typedef int me_v4i __attribute__((ext_vector_type(4)));
+constexpr int ME2_ROWS = 128;             // most output rows per wave of mineig2_kernel
 
 template <bool HAS_MASK>
 __global__ __launch_bounds__(64) void mineig2_kernel(
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     unsigned int* __restrict__ maxkey, int strip_rows) {
   const int s = blockIdx.z;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
-  __shared__ unsigned long long rowmask[ME_ROWS + 1];  // bit l set: lane l's column is masked OUT (+1: read-ahead slot)
+  __shared__ unsigned long long rowmask[ME2_ROWS + 1];  // bit l set: lane l's column is masked OUT (+1: read-ahead slot)
   __shared__ unsigned long long lcand[ME_LCAP];
   __shared__ int hw_s[MAX_RADIUS + 1];
 
@@ -338,31 +339,49 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   const bool out_col = lane >= ME_HALO && lane < 64 - ME_HALO && gx < W;
   const bool at_left = gx == 0, at_right = gx == W - 1;
 
-  if (lane <= ME_ROWS) rowmask[lane] = 0ull;
-  if (lane == 0) rowmask[ME_ROWS] = 0ull;
   for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
   __syncthreads();
-  // detection mask: rasterise the cv::circle discs that touch this strip into row bit-masks
-  if (use_discs) {
-    const float2* kp = kp_all + (size_t)s * kcap;
-    const int nk = kp_count[s];
-    const long long* lmk = lmk_all + (size_t)s * kcap;
-    for (int i = lane; i < nk; i += 64) {
-      if (lmk[i] == -1) continue;  // only keypoints with a landmark mask (FeatureDetector.cpp:191)
-      const float2 p = kp[i];
-      const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
-      if (cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye)
-        continue;
-      const int r0 = max(cy - radius, ys), r1 = min(cy + radius, ye - 1);
-      for (int gy = r0; gy <= r1; gy++) {
-        const int hw = hw_s[abs(gy - cy)];
-        const int xa = max(cx - hw, x0) - x0, xb = min(cx + hw, x0 + 63) - x0;
-        if (xa > xb) continue;
-        const unsigned long long bits =
-            (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
-        atomicOr(&rowmask[gy - ys], bits);
+  // detection mask: the cv::circle discs that touch this strip, rasterised into row bit-masks.  Lane = row of the strip
+  // (two rows per lane for strips above 64 rows): the keypoints are tested 64 at a time, then every hit is replayed for all
+  // rows at once from scalar registers -- no atomics, no per-row loop (the per-keypoint row loop of the first kernel
+  // was a quarter of its instructions).
+  {
+    unsigned long long mrow0 = 0ull, mrow1 = 0ull;
+    if (use_discs) {
+      const float2* kp = kp_all + (size_t)s * kcap;
+      const int nk = kp_count[s];
+      const long long* lmk = lmk_all + (size_t)s * kcap;
+      const int gy0 = ys + lane, gy1 = ys + 64 + lane;
+      for (int i0 = 0; i0 < nk; i0 += 64) {
+        const int i = i0 + lane;
+        int cx = 0, cy = 0;
+        bool hit = false;
+        if (i < nk && lmk[i] != -1) {  // only keypoints with a landmark mask (FeatureDetector.cpp:191)
+          const float2 p = kp[i];
+          cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
+          hit = !(cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye);
+        }
+        unsigned long long bal = __ballot(hit);
+        while (bal) {
+          const int l = __builtin_ctzll(bal);
+          bal &= bal - 1;
+          const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
+          auto span = [&](int gy) -> unsigned long long {
+            const int dy = abs(gy - ccy);
+            if (dy > radius) return 0ull;
+            const int hw = hw_s[dy];
+            const int xa = max(ccx - hw, x0) - x0, xb = min(ccx + hw, x0 + 63) - x0;
+            if (xa > xb) return 0ull;
+            return (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
+          };
+          mrow0 |= span(gy0);
+          if (strip_rows > 64) mrow1 |= span(gy1);
+        }
       }
     }
+    rowmask[lane] = mrow0;
+    rowmask[64 + lane] = mrow1;   // (rows past the strip: all zero; slot 128 is the read-ahead slot)
+    if (lane == 0) rowmask[ME2_ROWS] = 0ull;
   }
   __syncthreads();
 
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
   unsigned long long mk_v = 0ull;
   auto fetch_mask = [&](int b) {   // row b of the strip's mask (clamped: rows outside the strip are never used)
-    const int idx = min(max(b - ys, 0), ME_ROWS);
+    const int idx = min(max(b - ys, 0), ME2_ROWS);
     mk_v = rowmask[idx + lane_zero];
   };
   unsigned soff_next = 0;   // steady part: row offset of the next request
@@ -506,7 +525,8 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
         unsigned long long in_mask = out_mask & ~mk;
         if (HAS_MASK) in_mask &= __ballot(mcol[(unsigned)(b * W)] != 0);
         in_b_mask = in_mask;
-        bestv = vmaxf(bestv, __builtin_amdgcn_inverse_ballot_w64(in_mask) ? lam : -__builtin_inff());
+        // masked maximum under the mask as EXEC (all 64 lanes are live here): one VALU instruction instead of select + max
+        asm volatile("s_mov_b64 exec, %2\n\tv_max_f32 %0, %0, %1\n\ts_mov_b64 exec, -1" : "+v"(bestv) : "v"(lam), "s"(in_mask));
       } else if (CHECK) {
         in_b_mask = 0ull;   // (box rows outside the strip feed only the 3x3 maximum)
       }
@@ -515,7 +535,12 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     const int m = r - 3;
     if (!CHECK || (m >= lm0 && m <= lm1)) {
       const float v = X.lam;
-      const unsigned long long bal = __ballot((v != 0.0f) & (v == fmaxf(fmaxf(Y.hm, X.hm), Z.hm))) & in_m_mask & colok_mask;
+      // the two float compares write scalar masks directly (the ballot idiom costs a select and a third compare)
+      const float mx3 = fmaxf(fmaxf(Y.hm, X.hm), Z.hm);
+      unsigned long long mne, meq;
+      asm("v_cmp_neq_f32_e64 %0, 0, %1" : "=s"(mne) : "v"(v));
+      asm("v_cmp_eq_f32_e64 %0, %1, %2" : "=s"(meq) : "v"(v), "v"(mx3));
+      const unsigned long long bal = mne & meq & in_m_mask & colok_mask;
       if (bal) {
         if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
           const int pos = n_loc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
@@ -594,10 +619,26 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     const double cost = (fill > 1.0 ? ceil(fill) : fmax(fill, 0.25)) * (min(rws, P.H) + 5);
     if (cost <= best) best = cost, strip_rows = rws;
   }
-  dim3 grid(nx, (P.H + strip_rows - 1) / strip_rows, P.B);
-  // KVFE_MINEIG_IMPL: 1 = round-1/2 kernel (every step checked), 2 = prologue / steady / epilogue kernel (default)
+  // KVFE_MINEIG_IMPL: 1 = round-1/2 kernel (every step checked), 2 = prologue / steady / epilogue kernel (default);
+  // KVFE_MINEIG_ROWS: rows per strip of the latter (16..128)
   static const int impl = std::getenv("KVFE_MINEIG_IMPL") ? std::atoi(std::getenv("KVFE_MINEIG_IMPL")) : 2;
+  static const int rows_env = std::getenv("KVFE_MINEIG_ROWS") ? std::atoi(std::getenv("KVFE_MINEIG_ROWS")) : 0;
   if (impl == 2) {
+    // the kernel is bound by VALU issue: every wave of the launch is resident at once and a SIMD works through its
+    // waves' rows, so the launch lasts (waves per SIMD, rounded UP) x (rows per wave).  Every strip pays 5 rows of
+    // overlap; pick the strip height that minimises the product (64 x 752x480: 6 strips of 80 rows = 4992 waves,
+    // 5 per SIMD x 85 rows = 425 row-times; 4 strips are 4 x 125 = 500, 8 strips 7 x 65 = 455).
+    const int simds = slots / 8;
+    best = 1e30;
+    for (int ns = 1; ns <= (P.H + 15) / 16; ns++) {
+      const int rws = (P.H + ns - 1) / ns;
+      if (rws > ME2_ROWS) continue;
+      const long long waves = (long long)nx * ns * P.B;
+      const double cost = (double)((waves + simds - 1) / simds) * (rws + 5);
+      if (cost < best) best = cost, strip_rows = rws;
+    }
+    if (rows_env >= 16 && rows_env <= ME2_ROWS) strip_rows = rows_env;
+    const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);
     if (user_mask)
       hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                          img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
@@ -610,6 +651,7 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
                          D.maxkey, strip_rows);
     return;
   }
+  const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);
   if (user_mask)
     hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                        img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
