@@ -234,7 +234,12 @@ typedef struct kvfe_config {
   kvfe_frontend_params params;
   int32_t batch;                 /* number of independent stereo streams     */
   int32_t device;                /* HIP device ordinal                       */
-  void* hip_stream;              /* optional hipStream_t owned by the caller */
+  void* hip_stream;              /* optional hipStream_t owned by the caller: every step is then
+                                    stream-ordered on it as a whole (work the caller enqueues on the
+                                    stream after a step call runs after the step, including the part
+                                    the library runs on its internal side stream).  With a
+                                    library-owned stream (NULL) completion is defined by
+                                    kvfe_synchronize / kvfe_frontend_get_output only            */
   int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
   int32_t frontend_type;         /* KVFE_FRONTEND_*: stereo (default), the monocular front-end
                                     (MonoVisionImuFrontend.cpp: `left` only, `right` ignored) or
@@ -872,7 +877,15 @@ typedef struct kvfe_stage_times {
   int32_t reserved0;
   const char* name[KVFE_N_STAGES];
   double ms_total[KVFE_N_STAGES];      /* summed over samples                 */
-  double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch (mean) */
+  double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch with every stream active */
+  /* The keyframe-only stages (detection, rectification, stereo matching, outlier rejection) are launched on
+   * every step but work only for the streams whose flags of that step say so; the flags of every sampled
+   * step are read back.  A stage's time and bytes per launch that DID work:
+   *   ms_active / active_launches   and   alg_bytes_per_stream * active_streams / active_launches          */
+  double ms_active[KVFE_N_STAGES];            /* summed over the sampled launches with >= 1 active stream */
+  double active_streams[KVFE_N_STAGES];       /* active streams summed over those launches               */
+  double alg_bytes_per_stream[KVFE_N_STAGES]; /* algorithmic bytes of one active stream                  */
+  int32_t active_launches[KVFE_N_STAGES];     /* sampled launches with >= 1 active stream                */
 } kvfe_stage_times;
 /* on = 0: off; on = N > 0: every N-th step records a begin/end HIP event pair per stage on the
  * stream the stage runs on (recording every step costs ~10 % at 64 streams: 24 extra stream ops) */

@@ -124,8 +124,9 @@ PNP_KNEIP_P2P, PNP_KNEIP_P3P, PNP_GAO_P3P, PNP_EPNP, PNP_UPNP, PNP_UP3P, PNP_NON
 
 
 def pnp_params_default():
-    """VisionImuTrackerParams.h defaults / params/Euroc: EPNP, 20 inliers, 1 px"""
-    return PnpParams(PNP_EPNP, 20, 1.0, 0, 0)
+    """class defaults of VisionImuTrackerParams.h:55-76 (= kvfe_default_frontend_params): EPNP, 10 inliers, 1 px
+    (the shipped YAMLs set min_pnp_inliers: 20)"""
+    return PnpParams(PNP_EPNP, 10, 1.0, 0, 0)
 
 
 class FrontendParams(C.Structure):
@@ -230,6 +231,10 @@ class StageTimes(C.Structure):
         ("name", C.c_char_p * KVFE_N_STAGES),
         ("ms_total", C.c_double * KVFE_N_STAGES),
         ("alg_bytes", C.c_double * KVFE_N_STAGES),
+        ("ms_active", C.c_double * KVFE_N_STAGES),
+        ("active_streams", C.c_double * KVFE_N_STAGES),
+        ("alg_bytes_per_stream", C.c_double * KVFE_N_STAGES),
+        ("active_launches", C.c_int32 * KVFE_N_STAGES),
     ]
 
 

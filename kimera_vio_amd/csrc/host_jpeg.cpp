@@ -397,9 +397,12 @@ bool decode_block(Reader& R, const Jpeg& J, Comp& c, int bx, int by) {
     if (s > 15) return false;
     diff = extend(R.get(s), s);
   }
-  c.pred += diff;
+  // (crafted streams: keep the DC prediction and the dequantised coefficient inside int without overflow; a
+  // conforming stream never leaves 16 bits here)
+  const long long pred = (long long)c.pred + diff;
+  c.pred = (int)std::max<long long>(-(1LL << 20), std::min<long long>(1LL << 20, pred));
   const uint16_t* q = J.qt[c.tq];
-  coef[0] = c.pred * q[0];
+  coef[0] = (int)std::max<long long>(-(1LL << 30), std::min<long long>(1LL << 30, (long long)c.pred * q[0]));
   for (int k = 1; k < 64;) {
     const int rs = decode_sym(R, HA);
     const int r = rs >> 4, sz = rs & 15;
@@ -476,19 +479,24 @@ kvfe_status decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stride, 
   up[0].resize((size_t)2 * J.comp[1].dw + 8 + (size_t)J.w);
   up[1].resize((size_t)2 * J.comp[2].dw + 8 + (size_t)J.w);
   // jdcolor.c build_ycc_rgb_table
-  static int Cr_r[256], Cb_b[256];
-  static long Cr_g[256], Cb_g[256];
-  static bool tables = false;
-  if (!tables) {
-    for (int i = 0; i < 256; i++) {
-      const long x = i - 128;
-      Cr_r[i] = (int)((91881L * x + 32768L) >> 16);
-      Cb_b[i] = (int)((116130L * x + 32768L) >> 16);
-      Cr_g[i] = -46802L * x;
-      Cb_g[i] = -22554L * x + 32768L;
+  struct YccTables {
+    int Cr_r[256], Cb_b[256];
+    long Cr_g[256], Cb_g[256];
+    YccTables() {
+      for (int i = 0; i < 256; i++) {
+        const long x = i - 128;
+        Cr_r[i] = (int)((91881L * x + 32768L) >> 16);
+        Cb_b[i] = (int)((116130L * x + 32768L) >> 16);
+        Cr_g[i] = -46802L * x;
+        Cb_g[i] = -22554L * x + 32768L;
+      }
     }
-    tables = true;
-  }
+  };
+  static const YccTables ycc;   // (function-local static: initialised once, thread-safe)
+  const int* Cr_r = ycc.Cr_r;
+  const int* Cb_b = ycc.Cb_b;
+  const long* Cr_g = ycc.Cr_g;
+  const long* Cb_g = ycc.Cb_g;
   for (int y = 0; y < J.h; y++) {
     for (int k = 0; k < 2; k++) {
       const Comp& C = J.comp[1 + k];

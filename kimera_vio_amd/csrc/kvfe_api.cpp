@@ -23,6 +23,7 @@ using namespace kvfe;
 namespace {
 
 constexpr int ACAP = 8192;  // accepted-corner capacity (LDS sort capacity of the select kernel)
+constexpr int PROF_FLAG_SAMPLES = 512;  // sampled steps whose stream flags are kept between two profile reads
 constexpr int MIN_GROUP_STREAMS = 8;  // automatic stream groups hold at least this many streams
 
 enum Stage {
@@ -128,6 +129,14 @@ struct kvfe_ctx {
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
   int prof_samples = 0;
+  // per-stage activity of the sampled steps: the keyframe-only stages are launched every step but work only for the
+  // streams whose flags say so (read back per sampled step from the device)
+  double prof_ms_active[ST_COUNT] = {};
+  double prof_active_streams[ST_COUNT] = {};
+  int prof_active_launches[ST_COUNT] = {};
+  int* prof_flags_host = nullptr;     // pinned [PROF_FLAG_SAMPLES][B]
+  std::vector<int> prof_flag_slot;    // per pending sample: its slot in prof_flags_host (-1: none)
+  int prof_flag_next = 0;
   std::string last_error;
   // dense stereo (allocated on first use, re-allocated when the volume geometry changes)
   DenseBuffers dense;
@@ -751,19 +760,44 @@ void prof_end(kvfe_ctx* c, int stage, hipStream_t st) {
   hipEventRecord(c->prof_ev[c->prof_ev.size() - 2 * ST_COUNT + 2 * stage + 1], st);
 }
 
+// which stream flag gates a stage's work (0: every stream, every step)
+int stage_flag(int s) {
+  switch (s) {
+    case ST_MINEIG: case ST_SELECT: case ST_SUBPIX: return FLAG_DETECT;
+    case ST_RECTIFY: case ST_STEREO: case ST_STEREO_NEW: case ST_RANSAC_STEREO: return FLAG_STEREO;
+    case ST_RANSAC_MONO: return FLAG_KEYFRAME;
+    default: return 0;
+  }
+}
+
 void prof_collect(kvfe_ctx* c) {
   if (c->prof_pending.empty()) return;
-  for (int base : c->prof_pending) {
+  for (size_t k = 0; k < c->prof_pending.size(); k++) {
+    const int base = c->prof_pending[k];
+    const int slot = k < c->prof_flag_slot.size() ? c->prof_flag_slot[k] : -1;
     for (int s = 0; s < ST_COUNT; s++) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->prof_ev[base + 2 * s], c->prof_ev[base + 2 * s + 1]) == hipSuccess)
-        c->prof_ms[s] += ms;
+      if (hipEventElapsedTime(&ms, c->prof_ev[base + 2 * s], c->prof_ev[base + 2 * s + 1]) != hipSuccess) continue;
+      c->prof_ms[s] += ms;
+      int active = c->P.B;
+      const int f = stage_flag(s);
+      if (f && slot >= 0 && c->prof_flags_host) {
+        active = 0;
+        for (int i = 0; i < c->P.B; i++) active += (c->prof_flags_host[(size_t)slot * c->P.B + i] & f) ? 1 : 0;
+      }
+      if (active > 0) {
+        c->prof_ms_active[s] += ms;
+        c->prof_active_streams[s] += active;
+        c->prof_active_launches[s]++;
+      }
     }
     c->prof_samples++;
   }
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   c->prof_ev.clear();
   c->prof_pending.clear();
+  c->prof_flag_slot.clear();
+  c->prof_flag_next = 0;
 }
 
 kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char* right,
@@ -789,6 +823,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // gaps around it.  The slot is released by the event recorded after the step's last kernel.
   static const bool copy_inputs = std::getenv("KVFE_COPY_INPUTS") != nullptr;
   if (copy_inputs) {
+    join_tail(c);   // the previous step's finalisation (side stream) reads the single device copy of the inputs
     HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B,
                              hipMemcpyHostToDevice, st));
     b.ss.kf_R_cur = b.kf_R_cur;
@@ -802,12 +837,21 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     b.ss.in_timestamp = reinterpret_cast<const long long*>(d + sizeof(double) * 9 * P.B);
     b.ss.in_force_kf = reinterpret_cast<const int*>(d + (sizeof(double) * 9 + sizeof(long long)) * P.B);
   }
-  struct SlotRelease {  // records the slot's event when do_step returns (all kernels enqueued), on the stream that
-    kvfe_ctx* c;        // runs the step's last kernels (the side stream when the step forks)
-    int slot;
+  struct SlotRelease {  // records the slot's event when do_step returns (all kernels enqueued), after the step's last
+    kvfe_ctx* c;        // kernels on EITHER stream: once the step has forked, the side stream (which waits for the main
+    int slot;           // stream's part before its tail) -- also on an error return between the fork and the tail event
     hipStream_t st;
+    bool side_used = false, tail_recorded = false;
     ~SlotRelease() {
-      hipEventRecord(c->ring_ev[slot], c->tail_pending && c->side ? c->side : st);
+      if (side_used && c->side) {
+        if (!tail_recorded) {   // error path: the side stream has not been made to wait for the main stream yet
+          hipEventRecord(c->ev_main, st);
+          hipStreamWaitEvent(c->side, c->ev_main, 0);
+        }
+        hipEventRecord(c->ring_ev[slot], c->side);
+      } else {
+        hipEventRecord(c->ring_ev[slot], st);
+      }
       c->ring_used[slot] = true;
     }
   } slot_release{c, slot, st};
@@ -846,6 +890,15 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_TRACK_FINALIZE, st);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
   prof_end(c, ST_TRACK_FINALIZE, st);
+  if (c->prof_on) {   // this step's keyframe / detect / stereo flags, for the per-stage activity of the profile
+    int slot = -1;
+    if (c->prof_flags_host && c->prof_flag_next < PROF_FLAG_SAMPLES) {
+      slot = c->prof_flag_next++;
+      HIPCHK(c, hipMemcpyAsync(c->prof_flags_host + (size_t)slot * P.B, b.ss.flags, sizeof(int) * P.B,
+                               hipMemcpyDeviceToHost, st));
+    }
+    c->prof_flag_slot.push_back(slot);
+  }
   if (c->ev_tracked) {
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
     c->ev_tracked_valid = true;
@@ -906,6 +959,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
+    slot_release.side_used = true;
   }
   prof_begin(c, ST_SUBPIX, sd);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, sd);
@@ -939,6 +993,13 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_tail, sd));
     c->tail_pending = true;
+    slot_release.tail_recorded = true;
+    if (!c->own_stream) {
+      // caller-owned stream (kvfe_config.hip_stream): work the caller enqueues on it after this call must be ordered
+      // after the WHOLE step, so the tail is joined here instead of being deferred to the next step
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
+      c->tail_pending = false;
+    }
   }
   HIPCHK(c, hipGetLastError());
 
@@ -2052,6 +2113,9 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   const bool eq = c->cfg.params.stereo.equalize_image != 0;
   unsigned char* dl = b.raw_left[c->img_step % 3];
   unsigned char* dr = b.raw_right2[c->img_step % 2];
+  // equalizeImage: the raw frames are uploaded into the rectified buffers as scratch -- which the previous step's tail
+  // (stereo matching of its new corners, on the side stream) may still be reading
+  if (eq) join_tail(c);
   unsigned char* ul = eq ? b.rect[0] : dl;  // (rectified buffers are free until rectification runs)
   unsigned char* ur = eq ? b.rect[1] : dr;
   if (row_stride == (size_t)P.W && image_stride == N) {  // tightly packed batch: one copy per side
@@ -2567,8 +2631,18 @@ kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
   c->prof_step = 0;
   c->prof_on = false;
   if (on) {
-    for (double& v : c->prof_ms) v = 0;
+    for (int i = 0; i < ST_COUNT; i++) {
+      c->prof_ms[i] = c->prof_ms_active[i] = c->prof_active_streams[i] = 0;
+      c->prof_active_launches[i] = 0;
+    }
     c->prof_samples = 0;
+    if (!c->prof_flags_host && c->children.empty()) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, sizeof(int) * (size_t)PROF_FLAG_SAMPLES * c->P.B, hipHostMallocDefault) == hipSuccess) {
+        c->host_allocs.push_back(h);
+        c->prof_flags_host = reinterpret_cast<int*>(h);
+      }
+    }
   }
   return KVFE_OK;
 }
@@ -2589,6 +2663,10 @@ kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
         out->name[s] = t.name[s];
         out->ms_total[s] += t.ms_total[s];
         out->alg_bytes[s] += t.alg_bytes[s] * t.n_samples;
+        out->ms_active[s] += t.ms_active[s];
+        out->active_streams[s] += t.active_streams[s];
+        out->active_launches[s] += t.active_launches[s];
+        out->alg_bytes_per_stream[s] = t.alg_bytes_per_stream[s];
       }
     }
     for (int s = 0; s < ST_COUNT; s++) out->alg_bytes[s] /= std::max(out->n_samples, 1);
@@ -2604,6 +2682,9 @@ kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
   for (int s = 0; s < ST_COUNT; s++) {
     out->name[s] = kStageNames[s];
     out->ms_total[s] = c->prof_ms[s];
+    out->ms_active[s] = c->prof_ms_active[s];
+    out->active_streams[s] = c->prof_active_streams[s];
+    out->active_launches[s] = c->prof_active_launches[s];
   }
   // algorithmic bytes per launch of the dense kernels (DESIGN.md "roofline accounting")
   double pyr_out = 0;
@@ -2611,6 +2692,7 @@ kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
   out->alg_bytes[ST_PYRAMID] = N + pyr_out * c->P.B;              // read level 0, write levels 1..L
   out->alg_bytes[ST_MINEIG] = N;                                  // read the left image once
   out->alg_bytes[ST_RECTIFY] = 4.0 * N;                           // read L,R raw + write L,R rectified
+  for (int s = 0; s < ST_COUNT; s++) out->alg_bytes_per_stream[s] = out->alg_bytes[s] / c->P.B;
   return KVFE_OK;
 }
 

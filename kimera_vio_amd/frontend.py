@@ -544,7 +544,10 @@ class Context:
         st = abi.StageTimes()
         self._chk(self.lib.kvfe_profile_read(self._h, C.byref(st)), "profile_read")
         return dict(n_samples=st.n_samples, n_groups=st.n_groups,
-                    stages={st.name[i].decode(): dict(ms_total=st.ms_total[i], alg_bytes=st.alg_bytes[i])
+                    stages={st.name[i].decode(): dict(ms_total=st.ms_total[i], alg_bytes=st.alg_bytes[i],
+                                                      ms_active=st.ms_active[i], active_streams=st.active_streams[i],
+                                                      alg_bytes_per_stream=st.alg_bytes_per_stream[i],
+                                                      active_launches=st.active_launches[i])
                             for i in range(st.n_stages)})
 
 

@@ -176,7 +176,9 @@ def load_frontend_params(path: str, use_ransac: int | None = None) -> abi.Fronte
     # implemented, another pnp_algorithm is refused at kvfe_create (KVFE_ERR_UNSUPPORTED).
     int(y["use_2d2d_tracking"]), int(y["use_3d3d_tracking"])
     p.use_pnp_tracking = int(y["use_pnp_tracking"])
-    p.pnp = abi.PnpParams(int(y.get("pnp_algorithm", abi.PNP_EPNP)), int(y.get("min_pnp_inliers", 20)),
+    # (the reference's YamlParser aborts on a missing key; its own detector-test YAMLs, which it never parses as tracker
+    # parameters, lack these four -- they fall back to the class defaults of VisionImuTrackerParams.h:55-76)
+    p.pnp = abi.PnpParams(int(y.get("pnp_algorithm", abi.PNP_EPNP)), int(y.get("min_pnp_inliers", 10)),
                           float(y.get("ransac_threshold_pnp", 1.0)),
                           int(y.get("optimize_2d3d_pose_from_inliers", 0)), 0)
     return p

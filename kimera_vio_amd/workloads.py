@@ -32,6 +32,9 @@ CONFIGS = {
     "c3": dict(batch=64, width=752, height=480, features=600, klt_max_level=2, unique=8, ring=6, source="rig"),
     "c4": dict(batch=1, width=752, height=480, features=300, klt_max_level=2, unique=1, ring=6, source="euroc"),
     "c5": dict(batch=32, width=1280, height=720, features=1000, klt_max_level=3, unique=4, ring=6, source="rig"),
+    # c3 on REAL frames: 64 streams replaying 4 offset windows of MicroEuroc (600 features, every frame a keyframe): the
+    # detection side sees real image statistics (~50 new corners per keyframe instead of ~11 on the rendered plane)
+    "c3e": dict(batch=64, width=752, height=480, features=600, klt_max_level=2, unique=4, ring=6, source="euroc"),
 }
 
 
@@ -163,6 +166,8 @@ def build(config: str, mode: str = "kf", rank: int = 0, use_ransac: int = 1, bat
         seqs = list(sequences) if sequences is not None else [rank]
         if config == "c2":
             seqs = [0]
+        elif sequences is None and U > 1:   # c3e: U windows replicated to B streams
+            seqs = [rank * U + u for u in range(U)]
         U = len(seqs)
         wl = Workload(config, L, R, p, U if sequences is not None else B, U, T, mode, "euroc")
         span = n - T + 1

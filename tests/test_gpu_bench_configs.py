@@ -140,3 +140,22 @@ def test_c4_rank_windows_are_distinct_sequences():
     wl0 = WL.build("c4", mode="nominal", rank=0)
     assert not np.array_equal(wl.lefts[0], wl0.lefts[0])
     _run_workload(wl, 9, [0])
+
+
+def test_c3_at_the_shipped_klt_max_level_4():
+    """bench.py's `klt_max_level_4` leg ("also one run at the shipped value 4"): configs[2] with the
+    five-level pyramid of params/Euroc/FrontendParams.yaml:5 -- two pyr2 launches for levels 1-2, the tile kernel for
+    levels 3-4 (188 x 120 is not a multiple of 16 wide)."""
+    wl = _build("c3", "kf", klt_max_level=4, batch=16)
+    assert wl.params.tracker.klt_max_level == 4
+    kinds = _run_workload(wl, 8, list(range(8)) + [15])
+    assert all(k[2] > 400 for k in kinds[1:]), kinds
+
+
+def test_c3e_real_frames_64_streams():
+    """bench.py's `kf_realistic` leg: 64 streams replaying 4 offset windows of MicroEuroc, 600 features, every frame a
+    keyframe; all unique windows + one replica on 8 steps"""
+    wl = _build("c3e", "kf")
+    assert (wl.batch, wl.unique, wl.source) == (64, 4, "euroc")
+    kinds = _run_workload(wl, 8, [0, 1, 2, 3, 63])
+    assert all(k[1] == 1 for k in kinds) and all(k[3] > 20 for k in kinds[1:]), kinds

@@ -131,8 +131,23 @@ def test_yaml_pnp_settings():
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
     assert p.use_pnp_tracking == 0 and p.pnp.pnp_algorithm == abi.PNP_EPNP
     assert p.pnp.min_pnp_inliers == 20 and p.pnp.ransac_threshold_pnp == 1.0 and p.pnp.optimize_2d3d_pose_from_inliers == 0
+    # the class defaults (VisionImuTrackerParams.h:55-76), also what a YAML without the keys falls back to and what
+    # kvfe_default_frontend_params fills in: one set of numbers everywhere
     d = abi.pnp_params_default()
-    assert (d.pnp_algorithm, d.min_pnp_inliers, d.ransac_threshold_pnp) == (3, 20, 1.0)
+    assert (d.pnp_algorithm, d.min_pnp_inliers, d.ransac_threshold_pnp) == (3, 10, 1.0)
+    import tempfile
+    keys = ("pnp_algorithm", "min_pnp_inliers", "ransac_threshold_pnp", "optimize_2d3d_pose_from_inliers")
+    src = open(os.path.join(G, "params_euroc", "FrontendParams.yaml")).read().splitlines(True)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.writelines(l for l in src if not l.startswith(keys))
+    q = P.load_frontend_params(f.name, use_ransac=0)
+    os.unlink(f.name)
+    assert (q.pnp.pnp_algorithm, q.pnp.min_pnp_inliers, q.pnp.ransac_threshold_pnp,
+            q.pnp.optimize_2d3d_pose_from_inliers) == (3, 10, 1.0, 0)
+    from kimera_vio_amd import lib as L
+    dp = abi.FrontendParams()
+    L.load().kvfe_default_frontend_params(C.byref(dp))
+    assert dp.pnp.min_pnp_inliers == d.min_pnp_inliers and dp.pnp.pnp_algorithm == d.pnp_algorithm
 
 
 def test_cpp_adapter_program_builds_with_plain_gxx():
