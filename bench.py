@@ -308,7 +308,10 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torchrun (also with ONE rank) the process group is RCCL: the barrier and the timing reduction then run the
+    # same collective code on 1 GPU as on 8 (tests/test_gpu_rccl_r3.py runs exactly this at world size 1)
+    under_torchrun = "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or under_torchrun:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     pmc = load_pmc()
@@ -405,9 +408,11 @@ def main():
         result["input_side"] = input_side()
     if solo and "cpu" in args.legs:
         result["cpu_baseline"] = cpu_baseline(wl, args)
+    if dist.is_initialized():
+        result["collective_backend"] = f"{dist.get_backend()} (RCCL), world {dist.get_world_size()}: barrier + timing all_reduce"
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

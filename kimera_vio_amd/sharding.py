@@ -21,14 +21,23 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _collective(dist, world: int) -> bool:
+    """collectives run whenever a process group exists -- also at world size 1 under torchrun, so that the RCCL path
+    (init_process_group("nccl"), barrier, CUDA-tensor all_reduce) is the same code on 1 and on 8 GPUs"""
+    try:
+        return world > 1 or (dist is not None and dist.is_available() and dist.is_initialized())
+    except Exception:
+        return world > 1
+
+
 def barrier(dist, world: int) -> None:
-    if world > 1:
+    if _collective(dist, world):
         dist.barrier()
 
 
 def reduce_timing(dist, world: int, elapsed_s: float, units: int, device=None) -> Tuple[float, int]:
     """Whole-job timing: MAX of the per-rank elapsed time, SUM of the units (stereo pairs) done."""
-    if world == 1:
+    if not _collective(dist, world):
         return elapsed_s, units
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)

@@ -49,6 +49,13 @@ def main():
         Rs.append(R.copy())
     np.savez_compressed(OUT, lefts=lefts, rights=rights, timestamps=ts, body_R=np.stack(Rs))
     print("wrote", OUT, os.path.getsize(OUT) / 1e6, "MB")
+    # the IMU rows around those frames, verbatim (imu0/data.csv: 60 ms before frame 10 .. 15 ms after frame 18): with the
+    # frames above they make a complete EuRoC-layout clip for the end-to-end replay test (tests/test_gpu_replay_r3.py)
+    lo, hi = ts[0] - 60_000_000, ts[-1] + 15_000_000
+    rows_imu = [ln for ln in open(os.path.join(SRC, "imu0", "data.csv"))
+                if ln.startswith("#") or lo <= int(ln.split(",")[0]) <= hi]
+    with open(os.path.join(os.path.dirname(OUT), "micro_euroc_imu_f10_18.csv"), "w") as f:
+        f.writelines(rows_imu)
 
 
 def bgr2gray_opencv(rgb: np.ndarray) -> np.ndarray:

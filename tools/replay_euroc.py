@@ -11,9 +11,8 @@ left / right / IMU synchronisation (kvfe_stereo_sync_*), the gyro rotation since
     python tools/replay_euroc.py /data/V1_01_easy --final-k 400
     python tools/replay_euroc.py /root/reference/tests/data/MicroEurocDataset --dry-run     # no GPU: stops at the step
 
-Status: the host legs (provider, synchroniser, rotation, decode: --dry-run) are covered by tests/test_input_side.py;
-the GPU leg only strings together calls the GPU suite covers one by one (staging slots, step_staged, get_output) and
-was written after round 2's GPU budget was spent -- run it once before relying on it.
+The host legs (provider, synchroniser, rotation, decode: --dry-run) are covered by tests/test_input_side.py; the whole
+chain including the GPU step is driven by tests/test_gpu_replay_r3.py (`replay()` below, every step against the oracle).
 
 The dataset's own cam0 / cam1 sensor.yaml give the calibration; the front-end parameters default to the shipped
 params/Euroc/FrontendParams.yaml (tests/golden/params_euroc).
@@ -69,6 +68,45 @@ def packets(dataset, initial_k, final_k):
             del files[key]
 
 
+def replay(dataset, L, R, ctx, copies=1, threads=0, gyro_bias=(0.0, 0.0, 0.0), initial_k=0, final_k=1 << 30,
+           host=None, read_back=True):
+    """The chain itself, one dict per synchronised stereo pair:
+        {k, ts, imu_n, deltaRij (since the last keyframe, before this step's reset), Rk = keyframe_R_cur_frame,
+         left, right (the decoded frames of this step: staging slot views, valid until the slot is reused),
+         out (kvfe_frontend_get_output of stream 0, when a context is given)}
+    ctx = None: everything but the GPU step (frames are decoded into `host`)."""
+    from kimera_vio_amd import frontend as F
+    B = copies
+    rect_R1 = np.array(ctx.rect.R1 if ctx is not None else F.compute_rectification(L, R).R1).reshape(3, 3)
+    body_R_camLrect = np.array(L.body_pose_cam).reshape(4, 4)[:3, :3] @ rect_R1.T   # getBodyPoseLeftCamRect().rotation()
+    deltaRij = np.eye(3)
+    slot = 0
+    if ctx is None and host is None:
+        host = np.empty((2 * B, L.height, L.width), np.uint8)
+    for k, ts, lf, rf, imu_t, imu_ag in packets(dataset, initial_k, final_k):
+        deltaRij = dp.preintegrate_rotation(imu_t, imu_ag, gyro_bias, deltaRij)
+        Rk = dp.keyframe_R_cur_frame(body_R_camLrect, deltaRij)
+        td = time.perf_counter()
+        if ctx is None:
+            dp.decode_png_gray_batch([lf] * B + [rf] * B, host, threads)
+            left, right = host[:B], host[B:]
+        else:
+            ctx.staging_wait(slot)
+            left, right = ctx.staging_buffers(slot)
+            dp.decode_png_gray_batch([lf] * B, left, threads)
+            dp.decode_png_gray_batch([rf] * B, right, threads)
+        rec = dict(k=k, ts=ts, imu_n=int(imu_t.size), deltaRij=deltaRij.copy(), Rk=Rk, left=left, right=right,
+                   decode_s=time.perf_counter() - td, out=None)
+        if ctx is not None:
+            ctx.step_staged(slot, ctx.make_inputs([ts] * B, [Rk] * B, [0] * B))
+            if read_back:
+                rec["out"] = ctx.get_output(0)                # (a replay reads every frame back; a pipeline need not)
+                if rec["out"]["is_keyframe"]:
+                    deltaRij = np.eye(3)                      # ImuFrontend::resetIntegrationWithCachedBias
+            slot = (slot + 1) % 3
+        yield rec
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("dataset")
@@ -89,40 +127,19 @@ def main():
     if not a.dry_run:
         from kimera_vio_amd import frontend as F
         ctx = F.Context(L, R, p, batch=B)
-        rect_R1 = np.array(ctx.rect.R1).reshape(3, 3)
-    else:
-        from kimera_vio_amd import frontend as F
-        rect_R1 = np.array(F.compute_rectification(L, R).R1).reshape(3, 3)   # host arithmetic, no device
-    body_R_camLrect = np.array(L.body_pose_cam).reshape(4, 4)[:3, :3] @ rect_R1.T   # getBodyPoseLeftCamRect().rotation()
-
-    deltaRij = np.eye(3)
-    slot, n, t_decode, t0 = 0, 0, 0.0, time.perf_counter()
-    host = np.empty((2 * B, L.height, L.width), np.uint8) if ctx is None else None
-    for k, ts, lf, rf, imu_t, imu_ag in packets(a.dataset, a.initial_k, a.final_k):
-        deltaRij = dp.preintegrate_rotation(imu_t, imu_ag, a.gyro_bias, deltaRij)
-        Rk = dp.keyframe_R_cur_frame(body_R_camLrect, deltaRij)
-        td = time.perf_counter()
-        if ctx is None:
-            dp.decode_png_gray_batch([lf] * B + [rf] * B, host, a.threads)
-            left = host[:B]
-        else:
-            ctx.staging_wait(slot)
-            left, right = ctx.staging_buffers(slot)
-            dp.decode_png_gray_batch([lf] * B, left, a.threads)
-            dp.decode_png_gray_batch([rf] * B, right, a.threads)
-        t_decode += time.perf_counter() - td
-        line = f"frame {k} t={ts} imu={imu_t.size} |dR|={np.degrees(np.arccos(np.clip((np.trace(deltaRij) - 1) / 2, -1, 1))):.3f}deg"
-        if ctx is not None:
-            ctx.step_staged(slot, ctx.make_inputs([ts] * B, [Rk] * B, [0] * B))
-            out = ctx.get_output(0)                           # (a replay reads every frame back; a pipeline need not)
-            if out["is_keyframe"]:
-                deltaRij = np.eye(3)                          # ImuFrontend::resetIntegrationWithCachedBias
+    n, t_decode, t0 = 0, 0.0, time.perf_counter()
+    for rec in replay(a.dataset, L, R, ctx, B, a.threads, a.gyro_bias, a.initial_k, a.final_k):
+        dR = rec["deltaRij"]
+        line = (f"frame {rec['k']} t={rec['ts']} imu={rec['imu_n']} "
+                f"|dR|={np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))):.3f}deg")
+        out = rec["out"]
+        if out is not None:
             line += (f" keypoints={out['n_keypoints']} keyframe={int(out['is_keyframe'])} "
                      f"mono={out['tracking_status_mono']} stereo={out['tracking_status_stereo']}")
-            slot = (slot + 1) % 3
         else:
-            line += f" left_mean={left[0].mean():.2f}"
+            line += f" left_mean={rec['left'][0].mean():.2f}"
         print(line)
+        t_decode += rec["decode_s"]
         n += 1
     dt = time.perf_counter() - t0
     print(f"{n} pairs x {B} stream(s) in {dt:.2f} s: {n * B / dt:.1f} pairs/s end to end, decode {1e3 * t_decode / max(n, 1):.2f} ms per "
