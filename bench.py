@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true",
                     help="do not record per-stage HIP events in the timed region (no roofline object)")
-    ap.add_argument("--stage-event-stride", type=int, default=4,
+    ap.add_argument("--stage-event-stride", type=int, default=8,
                     help="every N-th timed step records per-stage HIP events (roofline / stage breakdown)")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-stereo (SGBM) legs")

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void rectify_kernel(
     size_t src_row_stride, size_t src_img_stride, unsigned char* __restrict__ dst0,
     unsigned char* __restrict__ dst1, const float2* __restrict__ map0,
     const float2* __restrict__ map1, int W, int H, int B, const int* __restrict__ flags,
-    int act_flag, int n_tiles, int gz, int mode) {
+    int act_flag, int n_tiles, int gz, int mode, const int* __restrict__ skip) {
+  // stream s is worked on iff (flags == null or flags[s] & act_flag) and not (skip != null and skip[s])
+  auto inactive = [&](int s) { return (flags && !(flags[s] & act_flag)) || (skip && skip[s]); };
   // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (each with its
   // own L2), so linear block id L runs on XCD L & 7.  XCD k owns the k-th horizontal band of the
   // image for ALL streams and both cameras, and walks it tile-major / stream-group-minor: a map
@@ -164,14 +166,14 @@ __global__ __launch_bounds__(256) void rectify_kernel(
 #pragma unroll
       for (int k = 0; k < RECT_SPB; k++) {
         const int s = s_begin + k;
-        if (s >= s_end || (flags && !(flags[s] & act_flag))) continue;
+        if (s >= s_end || inactive(s)) continue;
         const unsigned p0 = blend(u[k], v[k], e0, a0, b0), p1 = blend(u[k], v[k], e1, a1, b1),
                        p2 = blend(u[k], v[k], e2, a2, b2), p3 = blend(u[k], v[k], e3, a3, b3);
         *reinterpret_cast<unsigned*>(dst + (size_t)s * N + i) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
       }
     } else {
       for (int s = s_begin; s < s_end; s++) {
-        if (flags && !(flags[s] & act_flag)) continue;
+        if (inactive(s)) continue;
         const unsigned char* S = src + (size_t)s * src_img_stride;
         const unsigned p0 = remap_apply(S, t0), p1 = remap_apply(S, t1), p2 = remap_apply(S, t2),
                        p3 = remap_apply(S, t3);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void rectify_kernel(
     const float2 m = map[i];
     const RemapTap t = remap_tap(W, H, stride, m.x, m.y);
     for (int s = s_begin; s < s_end; s++) {
-      if (flags && !(flags[s] & act_flag)) continue;
+      if (inactive(s)) continue;
       dst[(size_t)s * N + i] = (unsigned char)remap_apply(src + (size_t)s * src_img_stride, t);
     }
   }
@@ -281,7 +283,8 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1, size_t src_row_stride,
     size_t src_img_stride, unsigned char* __restrict__ dst0, unsigned char* __restrict__ dst1,
     const float2* __restrict__ map0, const float2* __restrict__ map1, int W, int H, int B,
-    const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode) {
+    const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode,
+    const int* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int NBUF = NSUB > 1 ? 2 : 1;   // LDS boxes: SPB streams x NBUF buffers
   constexpr int NR = TH / 8;               // tile rows per lane
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
 #pragma unroll
   for (int k = 0; k < SPB * NSUB; k++) {
     const int s = s_begin + k;
-    if (s < B && (!flags || (flags[s] & act_flag))) act |= 1u << k;
+    if (s < B && (!flags || (flags[s] & act_flag)) && !(skip && skip[s])) act |= 1u << k;
   }
   if (!act) return;
   if (staged) {
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
 
 void launch_rectify(const KParams& P, const Tables& T, const unsigned char* const src[2],
                     size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
-                    const int* flags, int act_flag, hipStream_t st) {
+                    const int* flags, int act_flag, hipStream_t st, const int* skip) {
   const int N = P.W * P.H;
   // KVFE_RECT_IMPL: 0 = per-lane gathers (rectify_kernel), 1 = LDS-staged tiles (default where the source rows are
   // 16-byte aligned); KVFE_RECT_TILE_MODE: 0 = 3-D grid, 1 = XCD-banded; KVFE_RECT_SPB: streams per block (4 | 8)
@@ -486,7 +489,7 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
 #define KVFE_RT_LAUNCH(TH_, SPB_, NSUB_, MINW_)                                                                     \
   hipLaunchKernelGGL((rectify_tile_kernel<TH_, SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],        \
                      src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, \
-                     tiles_x, tiles_y, gz, tmode)
+                     tiles_x, tiles_y, gz, tmode, skip)
 #define KVFE_RT_DISPATCH(TH_, W1_, W2_)                 \
   do {                                                  \
     if (S == 1 && NS == 1) KVFE_RT_LAUNCH(TH_, 1, 1, W1_);      \
@@ -513,11 +516,11 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
   if (vec4)
     hipLaunchKernelGGL(rectify_kernel<true>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
-                       P.H, P.B, flags, act_flag, n_tiles, gz, mode);
+                       P.H, P.B, flags, act_flag, n_tiles, gz, mode, skip);
   else
     hipLaunchKernelGGL(rectify_kernel<false>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
-                       P.H, P.B, flags, act_flag, n_tiles, gz, mode);
+                       P.H, P.B, flags, act_flag, n_tiles, gz, mode, skip);
 }
 
 // ---------------------------------------------------------------------------------------------

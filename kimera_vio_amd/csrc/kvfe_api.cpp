@@ -872,6 +872,26 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   const int pc = c->pyr_cur, pp = pc ^ 1;
   hipStream_t sd = c->side ? c->side : st;
 
+  // KVFE_EARLY_RECTIFY=1 (measured, NOT the default): streams the caller forces to be keyframes are rectified right away
+  // on the side stream -- rectification depends on nothing but the images, and the tracking kernel that opens the step
+  // ends in a tail of a few slow points.  On MI355X it loses: the remap's workgroups take issue slots from the tracking
+  // kernel for longer than the remap takes after it (64 x 752x480, every frame a keyframe: 1.160 ms per step against
+  // 1.097 ms, profiles/r3 notes), so the remap stays behind the tracking.
+  int n_forced = 0;
+  for (int s = 0; s < P.B; s++) n_forced += inputs[s].force_keyframe ? 1 : 0;
+  static const bool early_rect_on = std::getenv("KVFE_EARLY_RECTIFY") != nullptr;
+  const bool early_rect = c->side && !P.mono && n_forced > 0 && early_rect_on;
+  const bool all_early = early_rect && n_forced == P.B;
+  if (early_rect) {
+    HIPCHK(c, hipEventRecord(c->ev_join, st));            // (the images are ready in the main stream's order)
+    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_join, 0));
+    slot_release.side_used = true;
+    if (all_early) prof_begin(c, ST_RECTIFY, sd);
+    const unsigned char* srcs[2] = {left, right};
+    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.in_force_kf, ~0, sd);
+    if (all_early) prof_end(c, ST_RECTIFY, sd);
+    HIPCHK(c, hipEventRecord(c->ev_mono, sd));
+  }
   prof_begin(c, ST_PYRAMID, st);
   launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st, c->own_level0 ? b.lvl0[pc] : nullptr);
   prof_end(c, ST_PYRAMID, st);
@@ -964,10 +984,14 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SUBPIX, sd);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, sd);
   prof_end(c, ST_SUBPIX, sd);
-  prof_begin(c, ST_RECTIFY, st);
-  const unsigned char* srcs[2] = {left, right};
-  launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st);
-  prof_end(c, ST_RECTIFY, st);
+  if (!all_early) {
+    prof_begin(c, ST_RECTIFY, st);
+    const unsigned char* srcs[2] = {left, right};
+    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st,
+                   early_rect ? b.ss.in_force_kf : nullptr);
+    prof_end(c, ST_RECTIFY, st);
+  }
+  if (early_rect) HIPCHK(c, hipStreamWaitEvent(st, c->ev_mono, 0));   // the pairs rectified at the start of the step
   prof_begin(c, ST_STEREO, st);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, st);
   prof_end(c, ST_STEREO, st);

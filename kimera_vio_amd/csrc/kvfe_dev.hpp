@@ -238,10 +238,11 @@ __host__ __device__ inline int reflect101(int p, int len) {
 }
 
 // ---- launchers (each enqueues on `st`; no synchronisation) -----------------------------------
-// K1: cv::remap of `ncam` images per stream.  act_flag: only streams with (flags & act_flag).
+// K1: cv::remap of both images per stream.  act_flag: only streams with (flags & act_flag); skip (optional): streams
+// with skip[s] != 0 are left alone (rectified earlier in the step).
 void launch_rectify(const KParams& P, const Tables& T, const unsigned char* const src[2],
                     size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
-                    const int* flags, int act_flag, hipStream_t st);
+                    const int* flags, int act_flag, hipStream_t st, const int* skip = nullptr);
 // cv::equalizeHist of B images: dst[s] = lut_s(src[s]); hist: [B][256] int scratch (zeroed here)
 void launch_equalize_hist(int W, int H, int B, const unsigned char* src, size_t src_row_stride,
                           size_t src_img_stride, unsigned char* dst, int* hist, hipStream_t st);
