@@ -1868,6 +1868,7 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
       K.kp[o] = c;
       K.lmk[o] = S.lmk_counter[s] + ci;
       K.age[o] = 1;
+      K.cost[o] = 0;   // (a new corner: no tracking history)
       double v[3];
       bearing_vector(T.und_left_R, c.x, c.y, v);
       K.versor[o * 3] = v[0];

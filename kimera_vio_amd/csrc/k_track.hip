@@ -412,13 +412,26 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
                                                     const unsigned char* prev_pyr,
                                                     const unsigned char* cur_img,
                                                     size_t cur_row_stride, size_t cur_img_stride,
-                                                    const unsigned char* cur_pyr, LkScratch lk) {
+                                                    const unsigned char* cur_pyr, LkScratch lk, int use_order) {
   using C = LkSys<WIN>;
   constexpr int NC = C::NC, NQ = C::NQ, NPX = C::NPX, NST = C::NST, WS = C::WS, WP = C::WP,
                 JM = C::JM, JS = C::JS, JSTR = C::JSTR, PSTR = C::PSTR, NT = C::NT, DSTR = C::DSTR,
                 NJ = C::NJ;
-  const int s = blockIdx.y, pt = blockIdx.x;
-  if (pt >= lk.npts[s]) return;
+  // dispatch order (results are independent of it).  use_order: a 1-D grid walks the RANKS of all streams -- rank r =
+  // the r-th slowest point of the previous frame -- so that every stream's slow points start at the beginning of the
+  // launch; the stream index is rotated by the rank so that a stream's points spread over all XCDs (workgroup b runs
+  // on XCD b & 7).  Otherwise (component calls) blockIdx = (point, stream).
+  int s, rank;
+  if (use_order) {
+    rank = blockIdx.x / P.B;
+    s = (blockIdx.x - rank * P.B + rank) % P.B;
+  } else {
+    s = blockIdx.y;
+    rank = blockIdx.x;
+  }
+  if (rank >= lk.npts[s]) return;
+  const int pt = use_order ? lk.order[(size_t)s * P.kcap + rank] : rank;
+  int iters_total = 0;
   const int lane = threadIdx.x;
   const int g = lane >> 4, q = lane & 15;
   const bool active = q < NQ;
@@ -662,6 +675,7 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
     for (int j = 0; j < klt_iters; j++) {
       LKP(5);
       LKP_COUNT(lkp_iters);
+      iters_total++;
       const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
       if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
         if (level == 0) status = 0;
@@ -765,6 +779,7 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
     lk.next_pts[po] = nextOut;
     lk.status[po] = (unsigned char)status;
     lk.err[po] = errOut;
+    lk.iters[po] = (unsigned char)min(iters_total, 255);
 #ifdef KVFE_LK_PROF
     const size_t wid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;   // (dispatch order)
     if (wid < (size_t)LKP_WAVES) {
@@ -1180,13 +1195,19 @@ __global__ __launch_bounds__(64) void lk_kernel_sys2(KParams P, const unsigned c
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st) {
+               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order) {
   if (max_pts <= 0) return;
+  // KVFE_LK_ORDER=1 (measured, NOT the default): dispatch the points by the iterations they took in the previous frame,
+  // slowest first and rank-major over the streams, so that the launch's tail of slow points starts early.  Bit-exact
+  // (158 GPU tests), but the count of the previous frame does not predict this frame's: 0.555 ms against 0.547 ms
+  // per 64-stream launch in table order.
+  static const bool order_on = std::getenv("KVFE_LK_ORDER") != nullptr;
+  const int ord = use_order && order_on ? 1 : 0;
   const dim3 grid(max_pts, P.B), block(64);
 #define KVFE_LK_SYS(WINSZ)                                                                      \
-  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, grid, block, 0, st, P, prev_img, prev_row_stride,    \
+  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, ord ? dim3((unsigned)max_pts * P.B) : grid, block, 0, st, P, prev_img, prev_row_stride,    \
                      prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,        \
-                     cur_pyr, lk)
+                     cur_pyr, lk, ord)
   // KVFE_LK_PTS=2: two points per wave for the reference's window of 24 (lk_kernel_sys2: bit-exact, 18 % fewer VALU
   // instructions, but 0.65 ms against 0.56 ms per 64-stream step -- three waves per SIMD do not hide its LDS latency
   // and the two points' windows collide on LDS banks, profiles/r2_lk2_pmc.md); default: one point per wave
@@ -1390,7 +1411,24 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
   const size_t so = (size_t)s * P.kcap;
   __shared__ int wave_tot[4];
   __shared__ int sh_off;
+  // dispatch order of the tracking launch: eight cost classes (iterations of the previous frame / 8), slowest first;
+  // a counting sort -- class sizes first, then every point takes the next free slot of its class (the order inside a
+  // class is arbitrary and irrelevant: only WHEN a point is tracked depends on it, never the result)
+  __shared__ int cls_cursor[8];
+  if (threadIdx.x < 8) cls_cursor[threadIdx.x] = 0;
   if (threadIdx.x == 0) sh_off = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (KM1.lmk[so + i] != -1) atomicAdd(&cls_cursor[min(7, (int)KM1.cost[so + i] >> 3)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int k = 7; k >= 0; k--) {
+      const int c = cls_cursor[k];
+      cls_cursor[k] = acc;
+      acc += c;
+    }
+  }
   __syncthreads();
   for (int base = 0; base < n; base += 256) {
     const int i = base + threadIdx.x;
@@ -1415,6 +1453,7 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
       lk.prev_pts[so + o] = p;
       lk.next_pts[so + o] = use_h ? predict_point(Hs, p, P.W, P.H) : p;
       lk.src_idx[so + o] = i;
+      lk.order[so + atomicAdd(&cls_cursor[min(7, (int)KM1.cost[so + i] >> 3)], 1)] = o;
     }
     __syncthreads();
     if (threadIdx.x == 0) sh_off = off0 + tot;
@@ -1515,6 +1554,7 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
       K.kp[o] = p;
       K.lmk[o] = KM1.lmk[so + src];
       K.age[o] = KM1.age[so + src];
+      K.cost[o] = lk.iters[so + i];
       double v[3];
       bearing_vector(T.und_left_R, p.x, p.y, v);
       K.versor[o * 3] = v[0];

@@ -253,6 +253,7 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
     TRY(dalloc(c, &b.ft[i].lmk, K));
     TRY(dalloc(c, &b.ft[i].age, K));
     TRY(dalloc(c, &b.ft[i].versor, K * 3));
+    TRY(dalloc(c, &b.ft[i].cost, K));
     TRY(dalloc(c, &b.ft[i].count, B));
     TRY(dalloc(c, &b.ft[i].timestamp, B));
   }
@@ -328,6 +329,8 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
   TRY(dalloc(c, &b.lk.src_idx, K));
+  TRY(dalloc(c, &b.lk.order, K));
+  TRY(dalloc(c, &b.lk.iters, K));
   TRY(reset_tracker_status(c, b));
   // keyframe_R_ref_frame_ = identity
   std::vector<double> eye(B * 9, 0.0);
@@ -905,7 +908,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
   if (c->prev_left)
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, c->pts_bound, st);
+              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, true);
   prof_end(c, ST_TRACK, st);
   prof_begin(c, ST_TRACK_FINALIZE, st);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);

@@ -127,6 +127,7 @@ struct FrameTab {
   long long* lmk;       // [B][kcap]
   int* age;             // [B][kcap]
   double* versor;       // [B][kcap][3]
+  unsigned char* cost;  // [B][kcap] LK iterations the keypoint took when it was last tracked (dispatch order only)
   int* count;           // [B]
   long long* timestamp; // [B]
 };
@@ -223,6 +224,11 @@ struct LkScratch {
   int* npts;              // [B]
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
+  // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
+  // order[s][b] -- the points that took the most iterations in the previous frame first, so that the launch does not
+  // end on a few slow points that started late; iters = iterations of this launch (saturated), carried to frame k
+  int* order;             // [B][kcap]
+  unsigned char* iters;   // [B][kcap]
 };
 
 __host__ __device__ inline int reflect101(int p, int len) {
@@ -254,7 +260,7 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st);
+               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order = false);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
                           const StreamState& S, const LkScratch& lk, hipStream_t st);
