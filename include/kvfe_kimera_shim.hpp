@@ -9,6 +9,11 @@
 //   void StereoMatcher::getDepthFromRectifiedMatches(StatusKeypointsCV&, StatusKeypointsCV&, Depths*) const
 //                                                                                             StereoMatcher.h:85-92
 //   void StereoCamera::undistortRectifyStereoFrame(StereoFrame*) const                        StereoCamera.h:225-233
+//   void StereoMatcher::sparseStereoReconstruction(StereoFrame* stereo_frame)                StereoMatcher.h:49-52
+//   void StereoMatcher::denseStereoReconstruction(const cv::Mat& left_img_rectified,
+//                           const cv::Mat& right_img_rectified, cv::Mat* disparity_img)       StereoMatcher.h:54-66
+//   FrontendOutputPacketBase::UniquePtr StereoVisionImuFrontend::spinOnce(
+//                           FrontendInputPacketBase::UniquePtr&& input)                       VisionImuFrontend.h:63-64
 //
 // It needs <opencv2/core.hpp> (cv::Mat, cv::Point2f, cv::KeyPoint) and <gtsam/geometry/Rot3.h>; the Kimera types
 // (VIO::Frame, VIO::StereoFrame, VIO::FeatureDetectorParams) are template parameters, so this header does not
@@ -19,6 +24,7 @@
 // This container has neither OpenCV nor GTSAM: tests/cpp/shim_check.cpp compiles this header against minimal
 // stand-ins (tests/cpp/stubs/) and runs it; INTEGRATION.md shows the two-line change at each reference call site.
 #pragma once
+#include <cstring>
 #include <optional>
 #include <stdexcept>
 #include <utility>
@@ -239,7 +245,47 @@ class UndistorterRectifier {
 
 class StereoMatcher {
  public:
-  explicit StereoMatcher(Context ctx) : impl_(std::move(ctx)) {}
+  explicit StereoMatcher(Context ctx) : impl_(ctx), camera_(ctx) {}
+  // StereoMatcher.h:49-52, StereoMatcher.cpp:123-175: rectified images, rectified left / right keypoints with their
+  // statuses, depths, distorted right keypoints and 3-D points of `stereo_frame`, from its two images and its left
+  // keypoints (one call into the library: the reference's five steps run fused on the device)
+  template <class VioStereoFrame>
+  void sparseStereoReconstruction(VioStereoFrame* stereo_frame) {
+    const cv::Mat& l = stereo_frame->left_frame_.img_;
+    const cv::Mat& r = stereo_frame->right_frame_.img_;
+    const auto& kps = stereo_frame->left_frame_.keypoints_;
+    if (kps.empty()) throw Error(KVFE_ERR_INVALID_ARG, "Call feature detection on left frame first...");   // CHECK_GT upstream
+    cv::Mat lr, rr;
+    lr.create(l.rows, l.cols, CV_8UC1);
+    rr.create(r.rows, r.cols, CV_8UC1);
+    camera_.undistortRectifyStereoFrame(view(l), view(r), lr.data, rr.data);
+    stereo_frame->setRectifiedImages(lr, rr);
+    KeypointsCV k(kps.size());
+    for (size_t i = 0; i < k.size(); i++) k[i] = KeypointCV{kps[i].x, kps[i].y};
+    const kvfe::StereoMatcher::SparseResult res = impl_.sparseStereoReconstruction(view(l), view(r), k);
+    from_status(res.left_keypoints_rectified, &stereo_frame->left_keypoints_rectified_);
+    from_status(res.right_keypoints_rectified, &stereo_frame->right_keypoints_rectified_);
+    stereo_frame->keypoints_depth_ = res.keypoints_depth;
+    stereo_frame->right_frame_.keypoints_.resize(k.size());
+    stereo_frame->keypoints_3d_.resize(k.size());
+    for (size_t i = 0; i < k.size(); i++) {
+      stereo_frame->right_frame_.keypoints_[i].x = res.right_keypoints[i].x;
+      stereo_frame->right_frame_.keypoints_[i].y = res.right_keypoints[i].y;
+      for (int c = 0; c < 3; c++) stereo_frame->keypoints_3d_[i](c) = res.keypoints_3d[3 * i + c];
+    }
+  }
+  // StereoMatcher.h:54-66, StereoMatcher.cpp:32-121: *disparity_img becomes the CV_16S matrix (4 fractional bits)
+  // cv::StereoSGBM / cv::StereoBM ::compute leaves there, after the optional median blur
+  void denseStereoReconstruction(const cv::Mat& left_img_rectified, const cv::Mat& right_img_rectified,
+                                 cv::Mat* disparity_img) {
+    if (!disparity_img || right_img_rectified.cols != left_img_rectified.cols ||
+        right_img_rectified.rows != left_img_rectified.rows)
+      throw Error(KVFE_ERR_INVALID_ARG, "denseStereoReconstruction: image sizes differ");   // CHECK_EQ upstream
+    disparity_img->create(left_img_rectified.rows, left_img_rectified.cols, CV_16SC1);
+    impl_.denseStereoReconstruction(view(left_img_rectified), view(right_img_rectified),
+                                    reinterpret_cast<int16_t*>(disparity_img->data), disparity_img->step / sizeof(int16_t));
+  }
+  kvfe_dense_stereo_params& denseStereoParams() { return impl_.dense_stereo_params_; }   // DenseStereoParams
   // StereoMatcher.h:85-92
   template <class StatusKps>
   void getDepthFromRectifiedMatches(StatusKps& left_keypoints_rectified, StatusKps& right_keypoints_rectified,
@@ -259,6 +305,7 @@ class StereoMatcher {
 
  private:
   kvfe::StereoMatcher impl_;
+  kvfe::StereoCamera camera_;
 };
 
 class StereoCamera {
@@ -279,6 +326,123 @@ class StereoCamera {
 
  private:
   kvfe::StereoCamera impl_;
+};
+
+// StereoVisionImuFrontend::spinOnce (VisionImuFrontend.h:63-64 -> nominalSpinStereo / bootstrapSpinStereo,
+// StereoVisionImuFrontend.cpp:102-276) on the reference's packet types.  What the library computes is handed to a
+// caller-supplied `build` callable as a SpinResult, from which the call site constructs its StereoFrontendOutput with
+// the reference's own constructor (StereoVisionImuFrontend-definitions.h:30-55): the IMU front-end (pim) and the
+// display image stay where they are upstream, on the host.
+//   Packet:  getStereoFrame() (left_frame_.img_, right_frame_.img_, timestamp_), getImuStamps() (1 x k int64),
+//            getImuAccGyrs() (6 x k double), as StereoImuSyncPacket.h:81-107 / FrontendInputPacketBase.h:37-52
+struct SpinResult {
+  bool is_keyframe = false;
+  int64_t timestamp = 0;
+  // TrackerStatusSummary (Tracker-definitions.h:134-183)
+  int kfTrackingStatus_mono = 0, kfTrackingStatus_stereo = 0, kfTracking_status_pnp = 0;
+  double lkf_T_k_mono[12], lkf_T_k_stereo[12], W_T_k_pnp[12], infoMatStereoTranslation[9];
+  // StereoMeasurements: (LandmarkId, StereoPoint2(uL, uR or NaN, v)) (StereoFrame-definitions.h:24-28)
+  std::vector<int64_t> meas_landmark;
+  std::vector<double> meas_uL_uR_v;   // n x 3
+  // stereoFrame_k_: left frame tables and the stereo arrays of a keyframe
+  Frame left_frame;
+  StatusKeypointsCV left_keypoints_rectified, right_keypoints_rectified;
+  std::vector<double> keypoints_depth, keypoints_3d;   // n, n x 3
+  KeypointsCV right_keypoints;
+  // DebugTrackerInfo (Tracker-definitions.h:78-124)
+  int nrMonoPutatives = 0, nrMonoInliers = 0, monoRansacIters = 0, nrStereoPutatives = 0, nrStereoInliers = 0;
+};
+
+class StereoVisionImuFrontend {
+ public:
+  // body_R_camLrect: rotation of StereoCamera::getBodyPoseLeftCamRect (R_BS . R1^T), row-major
+  StereoVisionImuFrontend(Context ctx, const double body_R_camLrect[9]) : c_(std::move(ctx)) {
+    for (int i = 0; i < 9; i++) {
+      body_R_cam_[i] = body_R_camLrect[i];
+      deltaRij_[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    if (c_.config().batch != 1) throw Error(KVFE_ERR_INVALID_ARG, "the packet interface drives one stream");
+  }
+  // ImuFrontend::updateBias (the back-end's estimate; only the gyro part enters the rotation)
+  void updateImuBias(const double gyro_bias[3]) {
+    for (int i = 0; i < 3; i++) gyro_bias_[i] = gyro_bias[i];
+  }
+  template <class Packet, class Build>
+  auto spinOnce(Packet&& input, Build&& build) -> decltype(build(std::declval<const SpinResult&>())) {
+    const auto& sf = input.getStereoFrame();
+    const auto& stamps = input.getImuStamps();
+    const auto& accgyr = input.getImuAccGyrs();
+    const int k = (int)stamps.cols();
+    // ImuFrontend::preintegrateImuMeasurements, rotation part, since the last keyframe (StereoVisionImuFrontend.cpp:125-150)
+    std::vector<int64_t> t(k);
+    std::vector<double> ag((size_t)6 * k);
+    for (int j = 0; j < k; j++) {
+      t[j] = (int64_t)stamps(0, j);
+      for (int r = 0; r < 6; r++) ag[(size_t)6 * j + r] = accgyr(r, j);
+    }
+    if (initialised_)
+      c_.check(kvfe_imu_preintegrate_rotation(t.data(), ag.data(), k, gyro_bias_, deltaRij_), "preintegrateImuMeasurements");
+    kvfe_frame_input in;
+    std::memset(&in, 0, sizeof(in));
+    in.timestamp_ns = (int64_t)sf.timestamp_;
+    kvfe_keyframe_R_cur_frame(body_R_cam_, deltaRij_, in.keyframe_R_cur_frame);
+    const ImageView l = view(sf.left_frame_.img_), r = view(sf.right_frame_.img_);
+    if (l.step != r.step) throw Error(KVFE_ERR_INVALID_ARG, "left / right images with different strides");
+    c_.check(kvfe_frontend_step_host(c_.get(), l.data, r.data, l.step, l.step * (size_t)l.rows, &in), "spinOnce");
+    initialised_ = true;
+    // StereoFrontendOutput
+    const int cap = c_.config().params.detector.max_features_per_frame + c_.config().params.detector.max_nr_keypoints_before_anms + 64;
+    SpinResult o;
+    std::vector<int64_t> lmk(cap), mlmk(cap);
+    std::vector<int32_t> age(cap);
+    std::vector<float> kp(2 * cap), lr(2 * cap), rr(2 * cap), rxy(2 * cap);
+    std::vector<double> ver(3 * cap), dep(cap), p3(3 * cap), muv(3 * cap);
+    std::vector<uint8_t> ls(cap), rs(cap);
+    kvfe_frame_output f;
+    std::memset(&f, 0, sizeof(f));
+    f.capacity = cap;
+    f.landmarks = lmk.data(); f.landmarks_age = age.data(); f.keypoints = kp.data(); f.versors = ver.data();
+    f.left_rect_xy = lr.data(); f.left_status = ls.data(); f.right_rect_xy = rr.data(); f.right_status = rs.data();
+    f.depth = dep.data(); f.right_xy = rxy.data(); f.keypoints_3d = p3.data();
+    f.meas_landmark = mlmk.data(); f.meas_uL_uR_v = muv.data();
+    c_.check(kvfe_frontend_get_output(c_.get(), 0, &f), "getOutput");
+    o.is_keyframe = f.is_keyframe != 0;
+    o.timestamp = in.timestamp_ns;
+    o.kfTrackingStatus_mono = f.tracking_status_mono;
+    o.kfTrackingStatus_stereo = f.tracking_status_stereo;
+    o.kfTracking_status_pnp = f.tracking_status_pnp;
+    std::memcpy(o.lkf_T_k_mono, f.lkf_T_k_mono, sizeof(o.lkf_T_k_mono));
+    std::memcpy(o.lkf_T_k_stereo, f.lkf_T_k_stereo, sizeof(o.lkf_T_k_stereo));
+    std::memcpy(o.W_T_k_pnp, f.W_T_k_pnp, sizeof(o.W_T_k_pnp));
+    std::memcpy(o.infoMatStereoTranslation, f.info_mat_stereo_translation, sizeof(o.infoMatStereoTranslation));
+    o.nrMonoPutatives = f.nr_mono_putatives; o.nrMonoInliers = f.nr_mono_inliers; o.monoRansacIters = f.mono_ransac_iters;
+    o.nrStereoPutatives = f.nr_stereo_putatives; o.nrStereoInliers = f.nr_stereo_inliers;
+    const int n = f.n_keypoints, m = f.n_measurements;
+    o.meas_landmark.assign(mlmk.begin(), mlmk.begin() + m);
+    o.meas_uL_uR_v.assign(muv.begin(), muv.begin() + 3 * m);
+    o.left_frame.img_ = l;
+    o.left_frame.keypoints_.resize(n);
+    o.left_frame.landmarks_.assign(lmk.begin(), lmk.begin() + n);
+    o.left_frame.landmarks_age_.assign(age.begin(), age.begin() + n);
+    o.left_frame.versors_.assign(ver.begin(), ver.begin() + 3 * n);
+    o.left_keypoints_rectified.resize(n); o.right_keypoints_rectified.resize(n); o.right_keypoints.resize(n);
+    for (int i = 0; i < n; i++) {
+      o.left_frame.keypoints_[i] = KeypointCV{kp[2 * i], kp[2 * i + 1]};
+      o.left_keypoints_rectified[i] = {static_cast<KeypointStatus>(ls[i]), KeypointCV{lr[2 * i], lr[2 * i + 1]}};
+      o.right_keypoints_rectified[i] = {static_cast<KeypointStatus>(rs[i]), KeypointCV{rr[2 * i], rr[2 * i + 1]}};
+      o.right_keypoints[i] = KeypointCV{rxy[2 * i], rxy[2 * i + 1]};
+    }
+    o.keypoints_depth.assign(dep.begin(), dep.begin() + n);
+    o.keypoints_3d.assign(p3.begin(), p3.begin() + 3 * n);
+    if (o.is_keyframe)   // ImuFrontend::resetIntegrationWithCachedBias (StereoVisionImuFrontend.cpp:203)
+      for (int i = 0; i < 9; i++) deltaRij_[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return build(static_cast<const SpinResult&>(o));
+  }
+
+ private:
+  Context c_;
+  double body_R_cam_[9], deltaRij_[9], gyro_bias_[3] = {0, 0, 0};
+  bool initialised_ = false;
 };
 
 }  // namespace shim

@@ -2,8 +2,11 @@
 // and drives the reference-signature methods on Kimera-shaped Frame / StereoFrame structs (same member names and
 // types as include/kimera-vio/frontend/Frame.h:160-186, StereoFrame.h:137-171).  Input / output format as
 // adapter_sequence.cpp; tests/test_gpu_parity.py compares the records with the oracle.
+#include <array>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <cmath>
 #include <unordered_map>
@@ -37,15 +40,53 @@ struct TrackerParams {   // the PnP members of VisionImuTrackerParams.h:72-76
 using BearingVectors = std::vector<gtsam::Vector3>;
 using Landmarks = std::vector<gtsam::Point3>;
 using LandmarksMap = std::unordered_map<LandmarkId, gtsam::Point3>;
-struct StereoFrame {
+using Timestamp = std::int64_t;
+struct StereoFrame {   // StereoFrame.h:137-171
+  Timestamp timestamp_ = 0;
   Frame left_frame_, right_frame_;
-  StatusKeypointsCV left_keypoints_rectified_;
+  StatusKeypointsCV left_keypoints_rectified_, right_keypoints_rectified_;
+  std::vector<double> keypoints_depth_;
   BearingVectors keypoints_3d_;
   cv::Mat left_img_rectified_, right_img_rectified_;
   void setRectifiedImages(const cv::Mat& l, const cv::Mat& r) {
     left_img_rectified_ = l;
     right_img_rectified_ = r;
   }
+};
+// Eigen-shaped stand-ins of ImuStampS (1 x k int64) / ImuAccGyrS (6 x k double): cols(), operator()(row, col)
+struct ImuStampS {
+  std::vector<std::int64_t> v;
+  long cols() const { return (long)v.size(); }
+  std::int64_t operator()(int, int c) const { return v[c]; }
+};
+struct ImuAccGyrS {
+  std::vector<double> v;   // column-major 6 x k
+  long cols() const { return (long)v.size() / 6; }
+  double operator()(int r, int c) const { return v[(size_t)6 * c + r]; }
+};
+struct StereoImuSyncPacket {   // StereoImuSyncPacket.h:81-107 (+ FrontendInputPacketBase.h:37-52)
+  StereoFrame stereo_frame_;
+  ImuStampS imu_stamps_;
+  ImuAccGyrS imu_accgyrs_;
+  const StereoFrame& getStereoFrame() const { return stereo_frame_; }
+  const ImuStampS& getImuStamps() const { return imu_stamps_; }
+  const ImuAccGyrS& getImuAccGyrs() const { return imu_accgyrs_; }
+};
+enum class TrackingStatus { VALID, LOW_DISPARITY, FEW_MATCHES, INVALID, DISABLED };
+struct TrackerStatusSummary {   // Tracker-definitions.h:134-183
+  TrackingStatus kfTrackingStatus_mono_ = TrackingStatus::INVALID, kfTrackingStatus_stereo_ = TrackingStatus::INVALID;
+  gtsam::Pose3 lkf_T_k_mono_, lkf_T_k_stereo_;
+};
+using StereoMeasurement = std::pair<LandmarkId, std::array<double, 3>>;   // StereoPoint2(uL, uR, v)
+using StatusStereoMeasurements = std::pair<TrackerStatusSummary, std::vector<StereoMeasurement>>;
+struct StereoFrontendOutput {   // the constructor arguments of StereoVisionImuFrontend-definitions.h:30-42 this path fills
+  bool is_keyframe_;
+  std::shared_ptr<StatusStereoMeasurements> status_stereo_measurements_;
+  StereoFrame stereo_frame_lkf_;
+  ImuAccGyrS imu_acc_gyrs_;
+  StereoFrontendOutput(bool is_keyframe, std::shared_ptr<StatusStereoMeasurements> m, const StereoFrame& sf,
+                       const ImuAccGyrS& ag)
+      : is_keyframe_(is_keyframe), status_stereo_measurements_(std::move(m)), stereo_frame_lkf_(sf), imu_acc_gyrs_(ag) {}
 };
 }  // namespace VIO
 
@@ -184,6 +225,91 @@ int main(int argc, char** argv) {
     VIO::StatusKeypointsCV right{{VIO::KeypointStatus::VALID, {380.f, 200.f}},
                                  {VIO::KeypointStatus::VALID, {310.f, 100.f}},
                                  {VIO::KeypointStatus::VALID, {5.f, 10.f}}};
+    {   // StereoMatcher::sparseStereoReconstruction(StereoFrame*) (StereoMatcher.h:49-52) on the first frame's corners
+      VIO::StereoFrame s2;
+      s2.left_frame_ = ref;                    // (keypoints / versors of featureDetection above; image = left 0)
+      s2.left_frame_.img_ = cv::Mat(H, W, CV_8UC1, lefts[0].data(), (size_t)W);
+      s2.right_frame_.img_ = cv::Mat(H, W, CV_8UC1, rights[0].data(), (size_t)W);
+      stereo_matcher.sparseStereoReconstruction(&s2);
+      std::vector<float> lrx, rrx, rk;
+      std::vector<uint8_t> lst, rst;
+      std::vector<double> p3;
+      for (size_t i = 0; i < s2.left_keypoints_rectified_.size(); i++) {
+        lst.push_back((uint8_t)s2.left_keypoints_rectified_[i].first);
+        rst.push_back((uint8_t)s2.right_keypoints_rectified_[i].first);
+        lrx.push_back(s2.left_keypoints_rectified_[i].second.x);
+        lrx.push_back(s2.left_keypoints_rectified_[i].second.y);
+        rrx.push_back(s2.right_keypoints_rectified_[i].second.x);
+        rrx.push_back(s2.right_keypoints_rectified_[i].second.y);
+        rk.push_back(s2.right_frame_.keypoints_[i].x);
+        rk.push_back(s2.right_frame_.keypoints_[i].y);
+        for (int c = 0; c < 3; c++) p3.push_back(s2.keypoints_3d_[i](c));
+      }
+      w.put("s_sp_lst", lst.data(), lst.size());
+      w.put("s_sp_rst", rst.data(), rst.size());
+      w.put("s_sp_lr", lrx.data(), lrx.size() * 4);
+      w.put("s_sp_rr", rrx.data(), rrx.size() * 4);
+      w.put("s_sp_rk", rk.data(), rk.size() * 4);
+      w.put("s_sp_dep", s2.keypoints_depth_.data(), s2.keypoints_depth_.size() * 8);
+      w.put("s_sp_p3", p3.data(), p3.size() * 8);
+      w.put("s_sp_lrect", s2.left_img_rectified_.data, N);
+      // StereoMatcher::denseStereoReconstruction(const cv::Mat&, const cv::Mat&, cv::Mat*) (StereoMatcher.h:54-66)
+      cv::Mat disp;
+      stereo_matcher.denseStereoReconstruction(s2.left_img_rectified_, s2.right_img_rectified_, &disp);
+      w.put("s_disp", disp.data, (size_t)disp.rows * disp.step);
+    }
+    {   // StereoVisionImuFrontend::spinOnce(StereoImuSyncPacket&&) -> StereoFrontendOutput on every frame of the input:
+      // IMU samples are synthesised from the input rotations' time stamps (constant rate about z), the rotation the
+      // step receives is what the shim integrates from them
+      kvfe::Context fctx(cfg.left, cfg.right, cfg.params, 1, cfg.device);
+      kvfe::StereoCamera cam(fctx);
+      const kvfe::Pose3 bl = cam.getBodyPoseLeftCamRect(cfg.left);
+      kvfe::shim::StereoVisionImuFrontend frontend(fctx, bl.R);
+      std::vector<int32_t> kf;
+      std::vector<int32_t> nmeas;
+      std::vector<double> Rk, last_meas;
+      std::vector<int64_t> last_lmk;
+      for (int i = 0; i < n_frames; i++) {
+        VIO::StereoImuSyncPacket pk;
+        pk.stereo_frame_.timestamp_ = inputs[i].timestamp_ns;
+        pk.stereo_frame_.left_frame_.img_ = cv::Mat(H, W, CV_8UC1, lefts[i].data(), (size_t)W);
+        pk.stereo_frame_.right_frame_.img_ = cv::Mat(H, W, CV_8UC1, rights[i].data(), (size_t)W);
+        const int64_t t1 = inputs[i].timestamp_ns, t0 = i ? inputs[i - 1].timestamp_ns : t1 - 50000000;
+        for (int j = 0; j <= 10; j++) {
+          pk.imu_stamps_.v.push_back(t0 + (t1 - t0) * j / 10);
+          const double row[6] = {0.1, 9.8, 0.2, 0.01, -0.02, 0.3};   // acc, gyro
+          pk.imu_accgyrs_.v.insert(pk.imu_accgyrs_.v.end(), row, row + 6);
+        }
+        auto out = frontend.spinOnce(std::move(pk), [&](const kvfe::shim::SpinResult& r) {
+          auto m = std::make_shared<VIO::StatusStereoMeasurements>();
+          m->first.kfTrackingStatus_mono_ = static_cast<VIO::TrackingStatus>(r.kfTrackingStatus_mono);
+          m->first.kfTrackingStatus_stereo_ = static_cast<VIO::TrackingStatus>(r.kfTrackingStatus_stereo);
+          for (size_t q = 0; q < r.meas_landmark.size(); q++)
+            m->second.push_back({(VIO::LandmarkId)r.meas_landmark[q],
+                                 {r.meas_uL_uR_v[3 * q], r.meas_uL_uR_v[3 * q + 1], r.meas_uL_uR_v[3 * q + 2]}});
+          VIO::StereoFrame sfo;
+          sfo.timestamp_ = r.timestamp;
+          kvfe::shim::from_frame(r.left_frame, &sfo.left_frame_);
+          kvfe::shim::from_status(r.left_keypoints_rectified, &sfo.left_keypoints_rectified_);
+          kvfe::shim::from_status(r.right_keypoints_rectified, &sfo.right_keypoints_rectified_);
+          sfo.keypoints_depth_ = r.keypoints_depth;
+          return std::make_unique<VIO::StereoFrontendOutput>(r.is_keyframe, m, sfo, VIO::ImuAccGyrS());
+        });
+        kf.push_back(out->is_keyframe_ ? 1 : 0);
+        nmeas.push_back((int32_t)out->status_stereo_measurements_->second.size());
+        if (i == n_frames - 1) {
+          for (const auto& mm : out->status_stereo_measurements_->second) {
+            last_lmk.push_back(mm.first);
+            last_meas.insert(last_meas.end(), mm.second.begin(), mm.second.end());
+          }
+          put_frame(w, "s_fe_last", out->stereo_frame_lkf_.left_frame_);
+        }
+      }
+      w.put("s_fe_kf", kf.data(), kf.size() * 4);
+      w.put("s_fe_nmeas", nmeas.data(), nmeas.size() * 4);
+      w.put("s_fe_lmk", last_lmk.data(), last_lmk.size() * 8);
+      w.put("s_fe_meas", last_meas.data(), last_meas.size() * 8);
+    }
     std::vector<double> depths;
     stereo_matcher.getDepthFromRectifiedMatches(left, right, &depths);            // StereoMatcher.h:85-92
     std::vector<uint8_t> rs;

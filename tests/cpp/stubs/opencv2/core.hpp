@@ -6,6 +6,7 @@
 #include <memory>
 #include <vector>
 #define CV_8UC1 0
+#define CV_16SC1 3
 namespace cv {
 struct Point2f {
   float x = 0, y = 0;
@@ -24,15 +25,18 @@ struct Mat {
   size_t step = 0;
   std::shared_ptr<std::vector<unsigned char>> buf;
   Mat() = default;
-  Mat(int r, int c, int /*type*/, unsigned char* d, size_t s) : data(d), rows(r), cols(c), step(s) {}
-  int type() const { return CV_8UC1; }
+  int type_ = CV_8UC1;
+  Mat(int r, int c, int t, unsigned char* d, size_t s) : data(d), rows(r), cols(c), step(s), type_(t) {}
+  int type() const { return type_; }
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-  void create(int r, int c, int /*type*/) {
-    buf = std::make_shared<std::vector<unsigned char>>((size_t)r * c);
+  void create(int r, int c, int t) {
+    const size_t es = t == CV_16SC1 ? 2 : 1;
+    buf = std::make_shared<std::vector<unsigned char>>((size_t)r * c * es);
     data = buf->data();
     rows = r;
     cols = c;
-    step = (size_t)c;
+    step = (size_t)c * es;
+    type_ = t;
   }
 };
 }  // namespace cv

@@ -3,6 +3,7 @@ UndistorterRectifier / StereoCamera / StereoMatcher / FeatureDetector / Tracker 
 fused now has its own C entry point; each is compared here with the oracle on the same inputs (tolerance 0), the
 frame-level calls also against the fused front-end step itself."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -190,14 +191,15 @@ def test_kimera_shim_reference_signatures(seq, ocam, tmp_path):
     camR = _kf_rotations(seq["body_R"], ocam)
     R01 = camR[0].T @ camR[1]
     H, W = seq["lefts"][0].shape
+    NF = 6      # frames 0, 1 feed the component calls, all of them the packet interface of the front-end
     with open(tmp_path / "in.bin", "wb") as f:
         f.write(bytes(cfg))
-        f.write(np.array([2, W, H], np.int32).tobytes())
-        for i in range(2):
+        f.write(np.array([NF, W, H], np.int32).tobytes())
+        for i in range(NF):
             fi = abi.FrameInput()
             fi.timestamp_ns = int(seq["ts"][i])
             for k in range(9):
-                fi.keyframe_R_cur_frame[k] = float((R01 if i else np.eye(3)).reshape(9)[k])
+                fi.keyframe_R_cur_frame[k] = float((R01 if i == 1 else np.eye(3)).reshape(9)[k])
             f.write(bytes(fi))
             f.write(np.ascontiguousarray(seq["lefts"][i]).tobytes())
             f.write(np.ascontiguousarray(seq["rights"][i]).tobytes())
@@ -234,3 +236,41 @@ def test_kimera_shim_reference_signatures(seq, ocam, tmp_path):
                                                     np.array([0, 0, 0], np.uint8))
     assert np.array_equal(np.frombuffer(one["s_depth"], np.float64), ed)
     assert list(np.frombuffer(one["s_rstat"], np.uint8)) == list(ers) == [abi.KP_VALID, abi.KP_NO_DEPTH, abi.KP_NO_LEFT_RECT]
+    # StereoMatcher::sparseStereoReconstruction(StereoFrame*) on the first frame's corners
+    sp = ocam.sparse_stereo(seq["lefts"][0], seq["rights"][0], e0["keypoints"], p.stereo, want_images=True)
+    assert np.array_equal(np.frombuffer(one["s_sp_lst"], np.uint8), sp["left_status"])
+    assert np.array_equal(np.frombuffer(one["s_sp_rst"], np.uint8), sp["right_status"])
+    assert np.array_equal(np.frombuffer(one["s_sp_lr"], np.float32).reshape(-1, 2), sp["left_rect_xy"])
+    assert np.array_equal(np.frombuffer(one["s_sp_rr"], np.float32).reshape(-1, 2), sp["right_rect_xy"])
+    assert np.array_equal(np.frombuffer(one["s_sp_rk"], np.float32).reshape(-1, 2), sp["right_xy"])
+    assert np.array_equal(np.frombuffer(one["s_sp_dep"], np.float64), sp["depth"])
+    assert np.array_equal(np.frombuffer(one["s_sp_p3"], np.float64).reshape(-1, 3), sp["keypoints_3d"])
+    assert np.array_equal(np.frombuffer(one["s_sp_lrect"], np.uint8).reshape(H, W), sp["left_rect_img"])
+    assert (sp["right_status"] == abi.KP_VALID).sum() > 50
+    # StereoMatcher::denseStereoReconstruction(const cv::Mat&, const cv::Mat&, cv::Mat*): the CV_16S disparity
+    dd = O.dense_stereo_reconstruction(sp["left_rect_img"], sp["right_rect_img"], abi.dense_stereo_params_default())
+    assert np.array_equal(np.frombuffer(one["s_disp"], np.int16).reshape(H, W), dd)
+    # StereoVisionImuFrontend::spinOnce(StereoImuSyncPacket&&) -> StereoFrontendOutput, NF packets: the oracle front-end
+    # fed the rotation its own gyro preintegration gives for the same IMU rows
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import input_side as ora
+    pr = euroc_params(max_features_per_frame=200)
+    fe = O.Frontend(L, R, pr)
+    bRc = np.array(L.body_pose_cam).reshape(4, 4)[:3, :3] @ np.array(ocam.rect.R1).reshape(3, 3).T
+    dR, kfs, nmeas, exp = np.eye(3), [], [], None
+    for i in range(NF):
+        t1 = int(seq["ts"][i])
+        t0 = int(seq["ts"][i - 1]) if i else t1 - 50000000
+        stamps = [t0 + (t1 - t0) * j // 10 for j in range(11)]
+        if i:
+            dR = np.array(ora.preintegrate_rotation(stamps, [[0.01, -0.02, 0.3]] * 11, deltaRij=dR.reshape(9))).reshape(3, 3)
+        exp = fe.process(seq["lefts"][i], seq["rights"][i], t1, bRc.T @ dR @ bRc, False)
+        kfs.append(int(exp["is_keyframe"]))
+        nmeas.append(int(exp["n_measurements"]))
+        if exp["is_keyframe"]:
+            dR = np.eye(3)
+    assert list(np.frombuffer(one["s_fe_kf"], np.int32)) == kfs and sum(kfs) >= 2
+    assert list(np.frombuffer(one["s_fe_nmeas"], np.int32)) == nmeas
+    _frame_eq(frame_of("s_fe_last"), exp)
+    assert np.array_equal(np.frombuffer(one["s_fe_lmk"], np.int64), exp["meas_landmark"])
+    assert np.array_equal(np.frombuffer(one["s_fe_meas"], np.float64).reshape(-1, 3), exp["meas_uL_uR_v"], equal_nan=True)
