@@ -357,6 +357,14 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
 }
+// carry hand-over of a systolic chain fused with the next addition: (value of lane q-1, 0 for the first lane of a DPP row)
+// + b, one v_add_f32_dpp.  Stage 0 of a chain passes 0 as carry: 0 + x is x in IEEE arithmetic (the terms are never -0
+// sums that matter: +0 + -0 = +0 only changes the sign of a zero), exactly the `carry = 0` start of the plain form.
+__device__ __forceinline__ float dpp_shr1_add(float carry_src, float b) {
+  float r;
+  asm("v_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(carry_src), "v"(b));
+  return r;
+}
 __device__ __forceinline__ int dot2_i16(int a, int b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
 }
@@ -580,8 +588,12 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
             dot2_i16(pack_lo16(d00, d01), wq0, dot2_i16(pack_lo16(d10, d11), wq1, 1 << 13)) >> 14;
         const int iyval =
             dot2_i16(pack_hi16(d00, d01), wq0, dot2_i16(pack_hi16(d10, d11), wq1, 1 << 13)) >> 14;
-        rI[k] = active ? sat16(ival) : 0;
-        rgxy[k] = active ? pack_lo16(sat16(ixval), sat16(iyval)) : 0;
+        // no saturation (OpenCV stores these as short without one): 0 <= ival <= 255 * 2^14 >> 9 = 8160 and
+        // |ixval|, |iyval| <= 4080 (a bilinear blend of Scharr sums of at most 16 * 255).  No zeroing of the idle lanes
+        // either (q >= NQ shadow lane 0's pixels): they sit BEHIND lane NQ-1 in the row_shr pipeline of their DPP row,
+        // so nothing they compute reaches a lane that is read -- and a select here is re-issued in every iteration.
+        rI[k] = ival;
+        rgxy[k] = pack_lo16(ixval, iyval);
       }
     LKP(2);
     // A11/A12/A22 chains (SSE lane l = g; order: row, then column chunk)
@@ -595,21 +607,20 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
         pa[k] = v2f{fx * fx, fx * fy};
         pc[k] = fy * fy;
       }
-      float c11 = 0.f, c12 = 0.f, c22 = 0.f;
+      // stage st: carry from lane q-1 (0 into lane 0 of the row) + this lane's terms, in order.  The hand-over is fused
+      // into the stage's first addition (v_add_f32_dpp: the shifted carry IS the left operand), so a stage is
+      // 1 + (NPX - 1) additions per component instead of a move and NPX additions.
       v2f t = {0.f, 0.f};
       float t22 = 0.f;
 #pragma unroll
       for (int st = 0; st < NQ; st++) {
-        t = v2f{c11, c12};
-        t22 = c22;
+        t = v2f{dpp_shr1_add(t.x, pa[0].x), dpp_shr1_add(t.y, pa[0].y)};
+        t22 = dpp_shr1_add(t22, pc[0]);
 #pragma unroll
-        for (int k = 0; k < NPX; k++) {
+        for (int k = 1; k < NPX; k++) {
           t = t + pa[k];
           t22 = t22 + pc[k];
         }
-        c11 = dpp_row_shr1(t.x);
-        c12 = dpp_row_shr1(t.y);
-        c22 = dpp_row_shr1(t22);
       }
       constexpr int L0 = NQ - 1, L1 = 16 + NQ - 1, L2 = 32 + NQ - 1, L3 = 48 + NQ - 1;
       float iA11 = 0.f, iA12 = 0.f, iA22 = 0.f;
@@ -711,15 +722,12 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
           const int m2 = dot2_i16(dd, pack_hi16(rgxy[k0], rgxy[k1]), 0);
           term[r * (NC / 2) + c] = v2f{(float)m1, (float)m2};
         }
-      float cb1 = 0.f, cb2 = 0.f;
       v2f t = {0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < NQ; st++) {
-        t = v2f{cb1, cb2};
+        t = v2f{dpp_shr1_add(t.x, term[0].x), dpp_shr1_add(t.y, term[0].y)};
 #pragma unroll
-        for (int i = 0; i < NST; i++) t = t + term[i];
-        cb1 = dpp_row_shr1(t.x);
-        cb2 = dpp_row_shr1(t.y);
+        for (int i = 1; i < NST; i++) t = t + term[i];
       }
       constexpr int L0 = NQ - 1, L1 = 16 + NQ - 1, L2 = 32 + NQ - 1, L3 = 48 + NQ - 1;
       // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]
