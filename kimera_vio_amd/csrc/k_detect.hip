@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
 //     are combined with scalar ANDs; only the two float compares of the local-maximum test are vector instructions.
 // ---------------------------------------------------------------------------------------------
 typedef int me_v4i __attribute__((ext_vector_type(4)));
-constexpr int ME2_ROWS = 128;             // most output rows per wave of mineig2_kernel
+constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig2_kernel (row-need masks: 128 bits incl. margins)
 
 template <bool HAS_MASK>
 __global__ __launch_bounds__(64) void mineig2_kernel(
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     unsigned int* __restrict__ maxkey, int strip_rows) {
   const int s = blockIdx.z;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
-  __shared__ unsigned long long rowmask[ME2_ROWS + 1];  // bit l set: lane l's column is masked OUT (+1: read-ahead slot)
+  __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
   __shared__ unsigned long long lcand[ME_LCAP];
   __shared__ int hw_s[MAX_RADIUS + 1];
 
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
 
   for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
   __syncthreads();
+  unsigned long long needc0 = ~0ull, needc1 = ~0ull, needb0 = ~0ull, needb1 = ~0ull;   // wave-uniform
   // detection mask: the cv::circle discs that touch this strip, rasterised into row bit-masks.  Lane = row of the strip
   // (two rows per lane for strips above 64 rows): the keypoints are tested 64 at a time, then every hit is replayed for all
   // rows at once from scalar registers -- no atomics, no per-row loop (the per-keypoint row loop of the first kernel
@@ -381,7 +382,23 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     }
     rowmask[lane] = mrow0;
     rowmask[64 + lane] = mrow1;   // (rows past the strip: all zero; slot 128 is the read-ahead slot)
-    if (lane == 0) rowmask[ME2_ROWS] = 0ull;
+    if (lane == 0) rowmask[128] = 0ull;
+    // Rows nobody needs.  lambda matters only at pixels that pass the detection mask (masked maximum, candidates) and at
+    // their 8 neighbours (the 3x3 maximum): U(y) = row y of the strip has an unmasked output pixel; box row b is needed
+    // iff U(b-1) | U(b) | U(b+1), cov row c iff one of the box rows c-1 .. c+1 is.  With a few hundred tracked keypoints
+    // and discs of radius min_distance most of a frame is masked, and whole 58-pixel row segments drop out (cv::
+    // goodFeaturesToTrack computes them and throws them away).  Bit i + 2 of the 128-bit masks = strip row i.
+    const unsigned long long om = __ballot(out_col);
+    const unsigned long long u_lo = __ballot(lane < strip_rows && (om & ~mrow0) != 0ull);
+    const unsigned long long u_hi = __ballot(64 + lane < strip_rows && (om & ~mrow1) != 0ull);
+    // U shifted to bit i + 2 (strip_rows <= 120, so nothing falls off the top)
+    const unsigned long long U0 = u_lo << 2, U1 = (u_hi << 2) | (u_lo >> 62);
+    auto or3 = [](unsigned long long x0, unsigned long long x1, unsigned long long& y0, unsigned long long& y1) {
+      y0 = x0 | (x0 << 1) | (x0 >> 1) | (x1 << 63);
+      y1 = x1 | (x1 << 1) | (x0 >> 63) | (x1 >> 1);
+    };
+    or3(U0, U1, needc0, needc1);
+    or3(needc0, needc1, needb0, needb1);
   }
   __syncthreads();
 
@@ -442,11 +459,16 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
   unsigned long long mk_v = 0ull;
   auto fetch_mask = [&](int b) {   // row b of the strip's mask (clamped: rows outside the strip are never used)
-    const int idx = min(max(b - ys, 0), ME2_ROWS);
+    const int idx = min(max(b - ys, 0), 128);
     mk_v = rowmask[idx + lane_zero];
   };
   unsigned soff_next = 0;   // steady part: row offset of the next request
 
+  auto row_needed = [&](unsigned long long m0, unsigned long long m1, int y) {   // bit (y - ys + 2) of a 128-bit row mask
+    const int pos = y - ys + 2;
+    if (pos < 0 || pos > 127) return false;
+    return (((pos < 64 ? m0 : m1) >> (pos & 63)) & 1ull) != 0ull;
+  };
   // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  CHECK: the stages test their row ranges and
   // copy border rows (prologue, epilogue, image-border strips); otherwise every stage is live.  Only wave-uniform
   // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     fetch_mask(r - 1);
     // ---- cov row c = r-1 -> horizontal float64 sums --------------------------------------------
     const int c = r - 1;
-    if (!CHECK || (c >= c0 && c <= c1)) {
+    if ((!CHECK || (c >= c0 && c <= c1)) && row_needed(needb0, needb1, c)) {
       const float dx = (Z.dh + X.dh) * f1 + Y.dh * f0;
       const float dy = X.sm - Z.sm;
       const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
@@ -498,7 +520,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     }
     // ---- box row b = r-2 -> lambda, horizontal max; masked maximum ------------------------------
     const int b = r - 2;
-    if (!CHECK || (b >= b0 && b <= b1)) {
+    if (!row_needed(needc0, needc1, b)) {
+      in_b_mask = 0ull;   // (no unmasked pixel in rows b-1 .. b+1: lambda of this row is never read)
+    } else if (!CHECK || (b >= b0 && b <= b1)) {
       // rows b-1, b, b+1 = slots X, Z, Y; BORDER_REFLECT_101 at the image border: row -1 is row 1
       // (slot Y), row H is row H-2 (slot X) -- wave-uniform branches taken once per strip
       if (CHECK && b == 0) {
@@ -533,7 +557,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     }
     // ---- row m = r-3: 3x3 local maximum (rows m-1, m, m+1 = slots Y, X, Z) ----------------------
     const int m = r - 3;
-    if (!CHECK || (m >= lm0 && m <= lm1)) {
+    if (in_m_mask != 0ull && (!CHECK || (m >= lm0 && m <= lm1))) {
       const float v = X.lam;
       // the two float compares write scalar masks directly (the ballot idiom costs a select and a third compare)
       const float mx3 = fmaxf(fmaxf(Y.hm, X.hm), Z.hm);
