@@ -1904,11 +1904,24 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
   }
 }
 
-// after the append: counts and the per-stream landmark-id counter
+// after the append: counts and the per-stream landmark-id counter -- and the two pieces of per-stream state the NEXT
+// step's tracking reads (they depend on this step's flags only): keyframe_R_ref_frame_ and the "initialised" flag.
+// They used to be written by step_finalize, at the very end of the step; written here, the next step's predictor and
+// tracking launch depend on the corner refinement only, and this step's tail (stereo matching of the new corners,
+// measurements, lkf <- k) runs next to them instead of in front of them.
 __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.B) return;
-  if (!(S.flags[s] & FLAG_DETECT)) return;
+  const int flags = S.flags[s];
+  if (flags & FLAG_KEYFRAME) {   // keyframe_R_ref_frame_ = identity (StereoVisionImuFrontend.cpp:203,225)
+    for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else if ((flags & FLAG_INIT) && !(flags & FLAG_DETECT)) {
+    // non-keyframe of the normal path: keyframe_R_ref_frame_ = keyframe_R_cur_frame; the "all tracks lost" early
+    // return (StereoVisionImuFrontend.cpp:313-323) leaves it untouched
+    for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = S.kf_R_cur[(size_t)s * 9 + i];
+  }
+  S.flags[s] = flags | FLAG_INIT;
+  if (!(flags & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
   K.count[s] = S.n_tracked[s] + n_new;
   S.lmk_counter[s] += n_new;

@@ -557,18 +557,12 @@ __global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab 
       LKF.timestamp[s] = K.timestamp[s];
       S.n_meas[s] = sh_off;
     }
-    if (tid < 9) S.kf_R_ref[(size_t)s * 9 + tid] = (tid % 4 == 0) ? 1.0 : 0.0;
   } else {
     if (tid == 0) S.n_meas[s] = 0;
-    // non-keyframe of the normal path: keyframe_R_ref_frame_ = keyframe_R_cur_frame; the
-    // "all tracks lost" early return (StereoVisionImuFrontend.cpp:313-323) leaves it untouched.
-    if ((flags & FLAG_INIT) && !(flags & FLAG_DETECT) && tid < 9)
-      S.kf_R_ref[(size_t)s * 9 + tid] = S.kf_R_cur[(size_t)s * 9 + tid];
   }
-  if (tid == 0) {
-    S.frame_count[s] += 1;
-    S.flags[s] = flags | FLAG_INIT;
-  }
+  // (keyframe_R_ref_frame_ and the "initialised" flag are written by detect_commit_kernel, earlier in the step: the next
+  // step's tracking reads them and must not wait for this kernel)
+  if (tid == 0) S.frame_count[s] += 1;
 }
 
 // ---------------------------------------------------------------------------------------------

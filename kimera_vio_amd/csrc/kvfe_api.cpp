@@ -125,6 +125,8 @@ struct kvfe_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
   hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // main-stream part of the fork done / tail of the step (side stream) done
+  hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
+  bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
   bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
@@ -193,6 +195,7 @@ inline void join_tail(kvfe_ctx* c) {
   if (c && c->tail_pending && c->stream) {
     hipStreamWaitEvent(c->stream, c->ev_tail, 0);
     c->tail_pending = false;
+    c->commit_pending = false;   // (the tail follows the commit on the side stream)
   }
   if (c)
     for (kvfe_ctx* ch : c->children) join_tail(ch);
@@ -898,11 +901,13 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_PYRAMID, st);
   launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st, c->own_level0 ? b.lvl0[pc] : nullptr);
   prof_end(c, ST_PYRAMID, st);
-  // the previous step's tail (stereo matching of its new corners + its finalisation, on the side stream) is joined
-  // HERE: this step's pyramid does not depend on it and hides the cross-stream hand-over
-  if (c->tail_pending) {
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
-    c->tail_pending = false;
+  // The previous step's side-stream work is joined in two places.  The predictor and the tracking launch need its
+  // refined new corners and the per-stream state detect_commit wrote (ev_commit) -- joined HERE, behind the pyramid,
+  // which does not depend on it and hides the cross-stream hand-over.  Its tail (stereo matching of the new corners,
+  // measurements, lkf <- k) is only needed by track_finalize: it runs next to this step's tracking launch.
+  if (c->commit_pending) {
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
+    c->commit_pending = false;
   }
   prof_begin(c, ST_TRACK, st);
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
@@ -910,6 +915,10 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
               img_stride, b.pyr[pc], b.lk, c->pts_bound, st, true);
   prof_end(c, ST_TRACK, st);
+  if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
+    c->tail_pending = false;
+  }
   prof_begin(c, ST_TRACK_FINALIZE, st);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
   prof_end(c, ST_TRACK_FINALIZE, st);
@@ -987,6 +996,10 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SUBPIX, sd);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, sd);
   prof_end(c, ST_SUBPIX, sd);
+  if (c->side && c->own_stream) {
+    HIPCHK(c, hipEventRecord(c->ev_commit, sd));
+    c->commit_pending = true;
+  }
   if (!all_early) {
     prof_begin(c, ST_RECTIFY, st);
     const unsigned char* srcs[2] = {left, right};
@@ -1226,7 +1239,8 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_mono, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_commit, hipEventDisableTiming) != hipSuccess)
       s = KVFE_ERR_HIP;
   }
   if (s != KVFE_OK) {
@@ -1325,6 +1339,7 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->ev_mono) hipEventDestroy(c->ev_mono);
   if (c->ev_main) hipEventDestroy(c->ev_main);
   if (c->ev_tail) hipEventDestroy(c->ev_tail);
+  if (c->ev_commit) hipEventDestroy(c->ev_commit);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->dense_allocs) hipFree(p);
   for (int i = 0; i < 2; i++)
