@@ -1821,13 +1821,16 @@ static int rs_n_tiles(int max_matches) {
 
 void launch_stereo_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
                           const StereoTab& ST, const StereoTab& LST, const StreamState& S,
-                          const RansacScratch& RS, int max_matches, hipStream_t st) {
+                          const RansacScratch& RS, int max_matches, hipStream_t st, bool need_arun) {
   hipLaunchKernelGGL(stereo_ransac_prepare_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T,
                      k, lkf, ST, LST, S, RS);
   hipLaunchKernelGGL(stereo_ransac_tile_kernel, dim3(rs_n_tiles(max_matches), P.B), dim3(64), 0, st, P, RS);
   hipLaunchKernelGGL(stereo_ransac_finish_kernel, dim3(P.B), dim3(RS_T), 0, st, P, S, RS);
-  hipLaunchKernelGGL(stereo_arun_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k, lkf, ST, LST,
-                     S, RS);
+  // the 3-point kernel serves the streams the voting does not (no usable gyro rotation, or ransac_use_1point_stereo
+  // off); the caller knows the step's rotations, so a step in which every stream votes does not launch it
+  if (need_arun)
+    hipLaunchKernelGGL(stereo_arun_kernel, dim3(P.B), dim3(RS_T), rs_lds_bytes(P.kcap), st, P, T, k, lkf, ST, LST,
+                       S, RS);
 }
 
 // ---------------------------------------------------------------------------------------------

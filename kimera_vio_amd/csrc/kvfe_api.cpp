@@ -119,7 +119,10 @@ struct kvfe_ctx {
   bool prof_on = false;      // this step records stage events
   int prof_stride = 0;       // 0 = profiling off; N = every N-th step records
   long long prof_step = 0;
-  std::vector<hipEvent_t> prof_ev;  // 2 * ST_COUNT (begin, end) events per recorded step
+  std::vector<hipEvent_t> prof_ev;  // events of the recorded steps; a recorded step owns 2 * ST_COUNT INDICES into it
+  std::vector<int> prof_idx;        // [sample][2 * ST_COUNT] begin / end event of a stage (-1: stage not run)
+  int prof_last_end = -1;           // the event that ended the previous stage of this step ...
+  hipStream_t prof_last_stream = nullptr;   // ... and the stream it was recorded on
   // corner refinement runs on a side stream, concurrently with rectification and the stereo
   // matching of the tracked keypoints (its result is only needed by the newly detected ones)
   hipStream_t side = nullptr;
@@ -757,14 +760,34 @@ kvfe_status upload_image(kvfe_ctx* c, unsigned char* dst, const uint8_t* src, si
   return KVFE_OK;
 }
 
+// A stage that starts on the stream the previous stage just ended on shares that event (back-to-back kernels: the end of
+// one IS the beginning of the next), which nearly halves the timing packets a recorded step puts on the streams.
 void prof_begin(kvfe_ctx* c, int stage, hipStream_t st) {
   if (!c->prof_on) return;
-  hipEventRecord(c->prof_ev[c->prof_ev.size() - 2 * ST_COUNT + 2 * stage], st);
+  int* idx = c->prof_idx.data() + c->prof_idx.size() - 2 * ST_COUNT;
+  if (c->prof_last_end >= 0 && c->prof_last_stream == st) {
+    idx[2 * stage] = c->prof_last_end;
+    return;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  c->prof_ev.push_back(e);
+  idx[2 * stage] = (int)c->prof_ev.size() - 1;
+  hipEventRecord(e, st);
 }
 void prof_end(kvfe_ctx* c, int stage, hipStream_t st) {
   if (!c->prof_on) return;
-  hipEventRecord(c->prof_ev[c->prof_ev.size() - 2 * ST_COUNT + 2 * stage + 1], st);
+  int* idx = c->prof_idx.data() + c->prof_idx.size() - 2 * ST_COUNT;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  c->prof_ev.push_back(e);
+  idx[2 * stage + 1] = (int)c->prof_ev.size() - 1;
+  hipEventRecord(e, st);
+  c->prof_last_end = idx[2 * stage + 1];
+  c->prof_last_stream = st;
 }
+// work that is not part of any stage follows on `st`: the next stage there starts with its own event
+void prof_break(kvfe_ctx* c) { c->prof_last_end = -1; }
 
 // which stream flag gates a stage's work (0: every stream, every step)
 int stage_flag(int s) {
@@ -779,11 +802,12 @@ int stage_flag(int s) {
 void prof_collect(kvfe_ctx* c) {
   if (c->prof_pending.empty()) return;
   for (size_t k = 0; k < c->prof_pending.size(); k++) {
-    const int base = c->prof_pending[k];
+    const int* idx = c->prof_idx.data() + (size_t)c->prof_pending[k] * 2 * ST_COUNT;
     const int slot = k < c->prof_flag_slot.size() ? c->prof_flag_slot[k] : -1;
     for (int s = 0; s < ST_COUNT; s++) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->prof_ev[base + 2 * s], c->prof_ev[base + 2 * s + 1]) != hipSuccess) continue;
+      if (idx[2 * s] < 0 || idx[2 * s + 1] < 0) continue;
+      if (hipEventElapsedTime(&ms, c->prof_ev[idx[2 * s]], c->prof_ev[idx[2 * s + 1]]) != hipSuccess) continue;
       c->prof_ms[s] += ms;
       int active = c->P.B;
       const int f = stage_flag(s);
@@ -801,6 +825,7 @@ void prof_collect(kvfe_ctx* c) {
   }
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   c->prof_ev.clear();
+  c->prof_idx.clear();
   c->prof_pending.clear();
   c->prof_flag_slot.clear();
   c->prof_flag_next = 0;
@@ -864,13 +889,9 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
 
   c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
   if (c->prof_on) {
-    const int base = (int)c->prof_ev.size();
-    for (int i = 0; i < 2 * ST_COUNT; i++) {
-      hipEvent_t e;
-      HIPCHK(c, hipEventCreate(&e));
-      c->prof_ev.push_back(e);
-    }
-    c->prof_pending.push_back(base);
+    c->prof_pending.push_back((int)(c->prof_idx.size() / (2 * ST_COUNT)));
+    c->prof_idx.insert(c->prof_idx.end(), 2 * ST_COUNT, -1);
+    c->prof_last_end = -1;
   }
   const FrameTab& K = b.ft[c->role_k];
   const FrameTab& KM1 = b.ft[c->role_km1];
@@ -908,6 +929,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   if (c->commit_pending) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
     c->commit_pending = false;
+    prof_break(c);   // (the wait is not part of the tracking stage)
   }
   prof_begin(c, ST_TRACK, st);
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
@@ -918,6 +940,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
     c->tail_pending = false;
+    prof_break(c);
   }
   prof_begin(c, ST_TRACK_FINALIZE, st);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
@@ -1013,7 +1036,20 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_end(c, ST_STEREO, st);
   // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387)
   prof_begin(c, ST_RANSAC_STEREO, st);
-  if (P.use_ransac) launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st);
+  if (P.use_ransac) {
+    // (the device's own test, rs_rot_is_identity: a stream without a usable gyro rotation takes the 3-point problem)
+    bool need_arun = !P.ransac_1pt_stereo;
+    for (int s = 0; s < P.B && !need_arun; s++) {
+      bool ident = true;
+      for (int i = 0; i < 9 && ident; i++) {
+        const double a = inputs[s].keyframe_R_cur_frame[i], e = (i % 4 == 0) ? 1.0 : 0.0;
+        if (std::isnan(a) || std::isinf(a)) ident = false;
+        else if (a != e && !(std::fabs(a - e) <= 1e-9)) ident = false;
+      }
+      need_arun = ident;
+    }
+    launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st, need_arun);
+  }
   // outlierRejectionPnP(*stereoFrame_k_) (:389-399): after the stereo rejection, before detection
   if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, st);
   prof_end(c, ST_RANSAC_STEREO, st);

@@ -317,7 +317,7 @@ void launch_mono_ransac(const KParams& P, const Tables& T, const FrameTab& k, co
 // VisionImuFrontend::outlierRejectionStereo on keyframes (1-point voting)
 void launch_stereo_ransac(const KParams& P, const Tables& T, const FrameTab& k, const FrameTab& lkf,
                           const StereoTab& ST, const StereoTab& LST, const StreamState& S,
-                          const RansacScratch& RS, int max_matches, hipStream_t st);
+                          const RansacScratch& RS, int max_matches, hipStream_t st, bool need_arun = true);
 // component API: the two problems on caller-supplied matches (one stream)
 void launch_ransac_2d2d_points(const KParams& P, const Tables& T, const double* f_ref,
                                const double* f_cur, int n, const double* R, const RansacScratch& RS,
