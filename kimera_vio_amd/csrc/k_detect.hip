@@ -321,8 +321,23 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
     const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows) {
-  const int s = blockIdx.z;
+    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int xcd_mode) {
+  // block -> (column strip, row strip, stream).  xcd_mode: a 1-D grid in which workgroup b (it runs on XCD b & 7: a
+  // speed assumption only) takes the strips of the streams s = b & 7 (mod 8), so that the cache lines neighbouring
+  // strips share -- 64-byte row segments out of 128-byte lines, the 3-column and 5-row overlaps -- meet in ONE L2.
+  int s, bx, by;
+  if (xcd_mode) {
+    const int per_stream = nx * ny, j = blockIdx.x >> 3;
+    s = (blockIdx.x & 7) + 8 * (j / per_stream);
+    if (s >= B) return;
+    const int rem = j % per_stream;
+    by = rem / nx;
+    bx = rem - by * nx;
+  } else {
+    s = blockIdx.z;
+    bx = blockIdx.x;
+    by = blockIdx.y;
+  }
   if (flags && !(flags[s] & FLAG_DETECT)) return;
   __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
   __shared__ unsigned long long lcand[ME_LCAP];
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   const unsigned char* I = img + (size_t)s * img_stride;
   const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
   const int lane = threadIdx.x;
-  const int xs = blockIdx.x * ME_COLS, ys = blockIdx.y * strip_rows;
+  const int xs = bx * ME_COLS, ys = by * strip_rows;
   const int ye = min(ys + strip_rows, H);
   const int x0 = xs - ME_HALO;          // column of lane 0
   const int gx = x0 + lane;
@@ -353,30 +368,41 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
       const int nk = kp_count[s];
       const long long* lmk = lmk_all + (size_t)s * kcap;
       const int gy0 = ys + lane, gy1 = ys + 64 + lane;
-      for (int i0 = 0; i0 < nk; i0 += 64) {
-        const int i = i0 + lane;
-        int cx = 0, cy = 0;
-        bool hit = false;
-        if (i < nk && lmk[i] != -1) {  // only keypoints with a landmark mask (FeatureDetector.cpp:191)
-          const float2 p = kp[i];
-          cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
-          hit = !(cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye);
+      // the keypoint list is read in chunks of 8 x 64 entries, all requests of a chunk in flight at once: one memory
+      // round trip per chunk instead of one per 64 keypoints (ten dependent round trips were a third of a wave's life)
+      constexpr int CH = 8;
+      for (int base = 0; base < nk; base += 64 * CH) {
+        float2 pk[CH];
+        long long lk[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const int i = min(base + 64 * j + lane, nk - 1);
+          lk[j] = lmk[i];
+          pk[j] = kp[i];
         }
-        unsigned long long bal = __ballot(hit);
-        while (bal) {
-          const int l = __builtin_ctzll(bal);
-          bal &= bal - 1;
-          const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
-          auto span = [&](int gy) -> unsigned long long {
-            const int dy = abs(gy - ccy);
-            if (dy > radius) return 0ull;
-            const int hw = hw_s[dy];
-            const int xa = max(ccx - hw, x0) - x0, xb = min(ccx + hw, x0 + 63) - x0;
-            if (xa > xb) return 0ull;
-            return (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
-          };
-          mrow0 |= span(gy0);
-          if (strip_rows > 64) mrow1 |= span(gy1);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const int i = base + 64 * j + lane;
+          // only keypoints with a landmark mask (FeatureDetector.cpp:191); cv::Point(Point2f) rounds
+          const int cx = __float2int_rn(pk[j].x), cy = __float2int_rn(pk[j].y);
+          const bool hit = i < nk && lk[j] != -1 &&
+                           !(cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye);
+          unsigned long long bal = __ballot(hit);
+          while (bal) {
+            const int l = __builtin_ctzll(bal);
+            bal &= bal - 1;
+            const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
+            auto span = [&](int gy) -> unsigned long long {
+              const int dy = abs(gy - ccy);
+              if (dy > radius) return 0ull;
+              const int hw = hw_s[dy];
+              const int xa = max(ccx - hw, x0) - x0, xb = min(ccx + hw, x0 + 63) - x0;
+              if (xa > xb) return 0ull;
+              return (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
+            };
+            mrow0 |= span(gy0);
+            if (strip_rows > 64) mrow1 |= span(gy1);
+          }
         }
       }
     }
@@ -662,17 +688,20 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
       if (cost < best) best = cost, strip_rows = rws;
     }
     if (rows_env >= 16 && rows_env <= ME2_ROWS) strip_rows = rows_env;
-    const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);
+    const int ny = (P.H + strip_rows - 1) / strip_rows;
+    static const int xcd_env = std::getenv("KVFE_MINEIG_XCD") ? std::atoi(std::getenv("KVFE_MINEIG_XCD")) : 0;   // (measured: 0.084 vs 0.082 ms plain)
+    const int xcd = (xcd_env && P.B >= 8) ? 1 : 0;
+    const dim3 grid = xcd ? dim3((unsigned)(8 * ((P.B + 7) / 8) * nx * ny)) : dim3((unsigned)nx, (unsigned)ny, (unsigned)P.B);
     if (user_mask)
       hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                          img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
                          T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                         D.maxkey, strip_rows);
+                         D.maxkey, strip_rows, P.B, nx, ny, xcd);
     else
       hipLaunchKernelGGL(mineig2_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
                          img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
                          T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                         D.maxkey, strip_rows);
+                         D.maxkey, strip_rows, P.B, nx, ny, xcd);
     return;
   }
   const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);

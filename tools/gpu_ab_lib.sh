@@ -10,6 +10,6 @@ timeout 900 python -m pytest tests -m gpu -x -q ${TEST_ARGS:-} > gpurun_out/gpu_
 [ $rc -ne 0 ] && { grep -E "Error|FAILED|assert" gpurun_out/gpu_tests.log | head -20; exit 1; }
 run() {
 KVFE_LIB=$L/$1 timeout 300 python bench.py --legs ${LEGS:-none} --steps 30 --warmup 8 --repeats 2 ${BENCH_ARGS:---stage-event-stride 0} | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['repeats']['values'], [(k, d[k]['value']) for k in ('nominal','single_stream','c5','kf_realistic') if k in d])"
+import json,sys; d=json.loads(sys.stdin.read()); st=d.get('stage_ms_per_step_summed_over_groups',{}); print('$1', d['value'], d['ms_per_step'], d['repeats']['values'], [(k, d[k]['value']) for k in ('nominal','single_stream','c5','kf_realistic') if k in d], ' '.join('%s %.3f' % (k[:9], v) for k, v in st.items()))"
 }
 for lib in libkvfe_base.so libkvfe.so libkvfe_base.so libkvfe.so; do [ -f $L/$lib ] && run $lib; done
