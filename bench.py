@@ -152,23 +152,26 @@ def valu_issue(valu, prefix, launch_ms, n_cu, clock_ghz):
 
 
 # kernel behind every dense (image-sized) stage: (rocprof kernel name, launches per step)
-PMC_NAMES = {"pyramid": ("pyr", 1), "mineig_localmax": ("mineig", 1),
-             "rectify": ("rectify_", 1)}
+# third entry: FETCH_SIZE correction.  2 for kernels that read with wide (dwordx4) coalesced loads, the gfx950 correction
+# of MI355X_MICROARCH.md; 1 for mineig2_kernel, whose source reads are byte loads (64 B requests: the counter is exact
+# for those -- with x2 it would claim 3.7 x the image for a kernel whose row / column overlap is 16 %)
+PMC_NAMES = {"pyramid": ("pyr", 1, 2.0), "mineig_localmax": ("mineig", 1, 1.0),
+             "rectify": ("rectify_", 1, 2.0)}
 
 
 def pmc_traffic(pmc_leg, stage):
     """HBM-side bytes per step of the stage's kernel(s) from the committed rocprofv3 PMC passes of the same
     leg alone (tools/rocpd_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes; per launch shape, the
-    shapes of one step added up — the pyramid is one launch per level).  2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads
-    — an upper bound for kernels that also issue narrow loads.  None when no counters are committed for
+    shapes of one step added up).  f x FETCH_SIZE + WRITE_SIZE with f from PMC_NAMES: MI355X_MICROARCH.md's gfx950
+    correction (2) for wide coalesced reads, 1 for byte loads.  None when no counters are committed for
     this leg."""
     if not pmc_leg or stage not in PMC_NAMES:
         return None
-    prefix, launches = PMC_NAMES[stage]
+    prefix, launches, ffac = PMC_NAMES[stage]
     tot, hit = 0.0, False
     for k, v in pmc_leg.items():
         if k.startswith(prefix):
-            tot += (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0
+            tot += (ffac * v["fetch_kb"] + v["write_kb"]) * 1024.0
             hit = True
     if not hit:
         return None
