@@ -12,6 +12,7 @@
 // by wave shuffles returns the first minimum, as cv::minMaxLoc does.
 #include "kvfe_dev.hpp"
 
+#include <cstdlib>
 #include <utility>
 
 namespace kvfe {
@@ -80,6 +81,8 @@ __global__ void stereo_left_kernel(KParams P, Tables T, FrameTab K, StereoTab ST
 // LDS geometry of match_one (dwords), shared by the kernel and the launcher
 struct StereoGeom {
   int tcw, MC, TSW, SSW, P2N;
+  int KS, TPW, SPB;      // MFMA search (ssd_search_mfma): K steps of 64 bytes, template row pitch (dwords), stripe row pitch (bytes)
+  bool mfma_ok;          // its lane maps hold: one stripe dword and one template dword per lane and row
   size_t match_bytes;
 };
 __host__ __device__ inline StereoGeom stereo_geom(const KParams& P) {
@@ -95,8 +98,196 @@ __host__ __device__ inline StereoGeom stereo_geom(const KParams& P) {
   g.SSW = ssw;
   g.P2N = 4 * ndw + 4;
   size_t b = 4 * ((size_t)P.templ_rows * g.TSW + (size_t)P.stripe_rows * g.SSW + (size_t)g.P2N);
+  // MFMA search: template rows [16 zero bytes | template | zeros] of 64 KS + 32 bytes, stripe rows of whole 16-byte
+  // chunks up to the furthest one an A operand reads (offset block NJ - 1, lane group 3, last K step)
+  g.KS = (P.templ_cols + 15 + 63) >> 6;
+  g.TPW = 16 * g.KS + 8;
+  const int nch = NJ + 3 + 4 * (g.KS - 1), nchd = (ndw + 3) >> 2;
+  g.SPB = 16 * (nch > nchd ? nch : nchd);
+  g.mfma_ok = ndw <= 64 && g.TPW <= 64 && rw >= 1;
+  if (g.mfma_ok) {
+    // (one template row of zeros and one stripe row of anything behind the real ones: the phantom row of an odd tr)
+    const size_t bm = 4 * (size_t)(P.templ_rows + 1) * g.TPW + (size_t)(P.stripe_rows + 1) * g.SPB + 4 * (size_t)g.P2N;
+    if (bm > b) b = bm;
+  }
   g.match_bytes = (b + 15) & ~(size_t)15;
   return g;
+}
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// inclusive prefix sum over the wavefront: Hillis-Steele inside the 16-lane DPP rows (row_shr, zero fill), then the
+// row totals with row_bcast:15 / row_bcast:31 -- six DPP additions, no LDS permutes
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// The SSD search of one keypoint on the matrix cores (round 3).  cv::matchTemplate(TM_SQDIFF) over one stripe is, per
+// template row, a correlation c(u) = sum_k T[k] S[u + k]: with u = 16 oh + j it is the matrix product
+//     C[oh][j] = sum_k' A[oh][k'] B[k'][j],   A[oh][k'] = S[16 oh + k'],   B[k'][j] = T[k' - j]  (0 outside the template)
+// -- A's rows are the stripe read at 16-byte steps (one aligned ds_read_b128 per lane: lane (oh, g) holds bytes
+// 16 (oh + g + 4 s) .. +15 of the row for K step s), B's columns the template shifted by j bytes (five dwords of the
+// zero-padded template row funnel-shifted by v_alignbyte) -- and v_mfma_i32_16x16x64_i8 does 16 x 16 x 64 of the
+// products per instruction: tr x KS MFMAs (22 for the shipped 101 x 11 template) replace ~770 v_dot4 wave-instructions.
+// The instruction multiplies SIGNED bytes, so both images are staged as x - 128 (x ^ 0x80): the SSD
+// sum (T - S)^2 = sum T'^2 + sum S'^2 - 2 sum T'S' is the same integer in the shifted domain, the zero padding of the
+// template stays zero, and every sum is exact in int32 (1111 * 128^2 < 2^25).  Stripe bytes beyond the staged ones
+// are never initialised: they only ever meet zero template bytes.
+// LDS bytes: template (tr + 1) x 4 TPW | stripe (sr + 1) x SPB | P2 (prefix of the per-column sums of S'^2 over the tr rows).
+// Returns the wave's candidate keys (ssd << 32 | oy * rw + ox), one per lane.
+// KSC: the number of K steps at compile time (2 for the shipped template; 0 = any, plain loop); SWAP: operands
+// exchanged (KVFE_SSD_IMPL=3, a bring-up switch: it must FAIL the parity tests).
+template <int KSC, bool SWAP>
+__device__ __forceinline__ unsigned long long ssd_search_mfma(const KParams& P, const StereoGeom& G,
+                                                              const unsigned char* __restrict__ L,
+                                                              const unsigned char* __restrict__ R, unsigned char* lds,
+                                                              int lane, int tcx, int tcy, int scx, int scy) {
+  const int W = P.W, tc = P.templ_cols, tr = P.templ_rows, sc = P.stripe_cols, sr = P.stripe_rows;
+  const int KS = G.KS, TPW = G.TPW, SPB = G.SPB, SPW = SPB >> 2, tcw = G.tcw, W4 = W >> 2;
+  unsigned* Xw = reinterpret_cast<unsigned*>(lds);
+  unsigned char* stpb = lds + (size_t)(tr + 1) * TPW * 4;
+  unsigned* stpw = reinterpret_cast<unsigned*>(stpb);
+  unsigned* P2 = stpw + (sr + 1) * SPW;
+  const int sh0 = scx & 3, x_al = scx - sh0;
+  const int ndw = (sh0 + sc + 3) >> 2;
+  int t2 = 0;
+  if (lane < TPW) {   // template dword m = lane - 4 of every row (the four dwords in front of it are the zero pad)
+    const int m = lane - 4, tsh = tcx & 3, tail = tc & 3;
+    const bool ld = m >= 0 && m < tcw;
+    const unsigned* src = reinterpret_cast<const unsigned*>(L + (size_t)tcy * W + (tcx - tsh)) + (ld ? m : 0);
+    const unsigned keep = (m == tcw - 1 && tail) ? (1u << (8 * tail)) - 1u : 0xffffffffu;
+    for (int y = 0; y < tr; y++) {
+      unsigned v = 0;
+      if (ld) v = (__builtin_amdgcn_alignbyte(src[1], src[0], tsh) ^ 0x80808080u) & keep;
+      src += W4;
+      Xw[y * TPW + lane] = v;
+      t2 = __builtin_amdgcn_sdot4((int)v, (int)v, t2, false);
+    }
+    Xw[tr * TPW + lane] = 0u;
+  }
+  if (lane < ndw) {
+    const unsigned* rs = reinterpret_cast<const unsigned*>(R + (size_t)scy * W + x_al) + lane;
+    for (int y = 0; y < sr; y++) {
+      stpw[y * SPW + lane] = rs[0] ^ 0x80808080u;
+      rs += W4;
+    }
+  }
+  __syncthreads();
+  const unsigned t2u = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan((unsigned)t2), 63);
+  const int rw = sc - tc + 1, rh = sr - tr + 1;
+  const int NJ = (sh0 + rw + 15) >> 4;
+  const int j = lane & 15, g = lane >> 4;
+  const int jc = (j + 3) >> 2, bsh = (4 - (j & 3)) & 3;   // B: bytes 64 s + 16 g + 16 - j .. of the padded template row
+  unsigned long long best = ~0ull;
+  for (int oy = 0; oy < rh; oy++) {
+    {  // P2: lane = stripe dword
+      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      if (lane < ndw)
+        for (int y = 0; y < tr; y++) {
+          const int v = (int)stpw[(oy + y) * SPW + lane];
+          const int b0 = __builtin_amdgcn_sbfe(v, 0, 8), b1 = __builtin_amdgcn_sbfe(v, 8, 8),
+                    b2 = __builtin_amdgcn_sbfe(v, 16, 8), b3 = v >> 24;
+          c0 += __mul24(b0, b0);
+          c1 += __mul24(b1, b1);
+          c2 += __mul24(b2, b2);
+          c3 += __mul24(b3, b3);
+        }
+      const unsigned run = (unsigned)(c0 + c1 + c2 + c3);
+      const unsigned inc = wave_incl_scan(run);
+      const unsigned base = inc - run;
+      if (lane < ndw)
+        *reinterpret_cast<uint4*>(P2 + 4 * lane) =
+            make_uint4(base, base + (unsigned)c0, base + (unsigned)(c0 + c1), base + (unsigned)(c0 + c1 + c2));
+      if (lane == 63) P2[4 * ndw] = inc;
+      __syncthreads();
+    }
+    for (int mt = 0; 16 * mt < NJ; mt++) {
+      const int ia = min(16 * mt + j, NJ - 1);   // A: offset block of this lane (unused rows re-read the last one)
+      const unsigned char* arow = stpb + (size_t)oy * SPB + 16 * (ia + g);
+      const unsigned* brow = Xw + (4 * g + 4 - jc);
+      v4i_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      if (KSC > 0) {
+        // two rows per trip, two operand sets: the operands of the next row are requested before the MFMAs of this one
+        // are issued, nothing is copied between trips.  An odd tr runs one phantom row: template row tr is all zeros
+        // and stripe row oy + tr is staged memory of any content.  K step s accumulates into accumulator s & 1.
+        constexpr int KN = KSC > 0 ? KSC : 1;
+        v4i_t a0[KN], a1[KN];
+        unsigned x0[KN][5], x1[KN][5];
+#define KVFE_MM_LOAD(a_, x_)                                              \
+  _Pragma("unroll") for (int s = 0; s < KN; s++) {                        \
+    a_[s] = *reinterpret_cast<const v4i_t*>(arow + 64 * s);               \
+    _Pragma("unroll") for (int w = 0; w < 5; w++) x_[s][w] = brow[16 * s + w]; \
+  }                                                                       \
+  arow += SPB;                                                            \
+  brow += TPW;
+#define KVFE_MM_MULT(a_, x_)                                                                   \
+  _Pragma("unroll") for (int s = 0; s < KN; s++) {                                             \
+    v4i_t B;                                                                                   \
+    B.x = (int)__builtin_amdgcn_alignbyte(x_[s][1], x_[s][0], bsh);                            \
+    B.y = (int)__builtin_amdgcn_alignbyte(x_[s][2], x_[s][1], bsh);                            \
+    B.z = (int)__builtin_amdgcn_alignbyte(x_[s][3], x_[s][2], bsh);                            \
+    B.w = (int)__builtin_amdgcn_alignbyte(x_[s][4], x_[s][3], bsh);                            \
+    if (s & 1)                                                                                 \
+      acc1 = SWAP ? __builtin_amdgcn_mfma_i32_16x16x64_i8(B, a_[s], acc1, 0, 0, 0)             \
+                  : __builtin_amdgcn_mfma_i32_16x16x64_i8(a_[s], B, acc1, 0, 0, 0);            \
+    else                                                                                       \
+      acc0 = SWAP ? __builtin_amdgcn_mfma_i32_16x16x64_i8(B, a_[s], acc0, 0, 0, 0)             \
+                  : __builtin_amdgcn_mfma_i32_16x16x64_i8(a_[s], B, acc0, 0, 0, 0);            \
+  }
+        KVFE_MM_LOAD(a0, x0)
+        for (int y = 0; y < tr; y += 2) {
+          KVFE_MM_LOAD(a1, x1)
+          KVFE_MM_MULT(a0, x0)
+          if (y + 2 < tr) {   // (uniform) the last trip has nothing further to request
+            KVFE_MM_LOAD(a0, x0)
+          }
+          KVFE_MM_MULT(a1, x1)
+        }
+#undef KVFE_MM_LOAD
+#undef KVFE_MM_MULT
+      } else {
+        for (int y = 0; y < tr; y++) {
+          for (int s = 0; s < KS; s++) {
+            const v4i_t A = *reinterpret_cast<const v4i_t*>(arow + 64 * s);
+            const unsigned* bp = brow + 16 * s;
+            const unsigned x0 = bp[0], x1 = bp[1], x2 = bp[2], x3 = bp[3], x4 = bp[4];
+            v4i_t B;
+            B.x = (int)__builtin_amdgcn_alignbyte(x1, x0, bsh);
+            B.y = (int)__builtin_amdgcn_alignbyte(x2, x1, bsh);
+            B.z = (int)__builtin_amdgcn_alignbyte(x3, x2, bsh);
+            B.w = (int)__builtin_amdgcn_alignbyte(x4, x3, bsh);
+            acc0 = SWAP ? __builtin_amdgcn_mfma_i32_16x16x64_i8(B, A, acc0, 0, 0, 0)
+                        : __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc0, 0, 0, 0);
+          }
+          arow += SPB;
+          brow += TPW;
+        }
+      }
+      acc0 += acc1;
+      // D: column (lane & 15) = j, rows 4 (lane >> 4) + r = offset block
+      const int cs[4] = {acc0.x, acc0.y, acc0.z, acc0.w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int oh = 16 * mt + 4 * g + r;
+        const int u = 16 * oh + j;
+        const int ox = u - sh0;
+        if (oh < NJ && ox >= 0 && ox < rw) {
+          const unsigned ss = P2[u + tc] - P2[u];
+          const unsigned ssd = t2u + ss - 2u * (unsigned)cs[r];
+          const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)(oy * rw + ox);
+          best = key < best ? key : best;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return best;
 }
 
 // core of searchRightKeypointEpipolar for one keypoint, executed by one wavefront
@@ -106,7 +297,7 @@ __host__ __device__ inline StereoGeom stereo_geom(const KParams& P) {
 template <bool SUBPIX>
 __device__ void match_one(const KParams& P, const Tables& T, const unsigned char* __restrict__ L,
                           const unsigned char* __restrict__ R, float2 lkp, unsigned char* lds,
-                          int lane, float2* out_kp, int* out_status, double* out_score) {
+                          int lane, float2* out_kp, int* out_status, double* out_score, int impl) {
   const int W = P.W, H = P.H, tc = P.templ_cols, tr = P.templ_rows, sc = P.stripe_cols,
             sr = P.stripe_rows;
   const int rx = (int)roundf(lkp.x), ry = (int)roundf(lkp.y);
@@ -167,6 +358,16 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int x_al = stripe_corner_x - sh0;
   const int ncol = sh0 + sc;                 // staged stripe bytes per row that hold image data
   const int ndw = (ncol + 3) >> 2;
+  const int rw = sc - tc + 1, rh = sr - tr + 1;
+  unsigned long long best = ~0ull;
+  if (impl != 0 && G.mfma_ok && dword_rows && ((size_t)L & 3) == 0) {
+    if (G.KS == 2 && impl == 3)
+      best = ssd_search_mfma<2, true>(P, G, L, R, lds, lane, temp_corner_x, temp_corner_y, stripe_corner_x, stripe_corner_y);
+    else if (G.KS == 2)
+      best = ssd_search_mfma<2, false>(P, G, L, R, lds, lane, temp_corner_x, temp_corner_y, stripe_corner_x, stripe_corner_y);
+    else
+      best = ssd_search_mfma<0, false>(P, G, L, R, lds, lane, temp_corner_x, temp_corner_y, stripe_corner_x, stripe_corner_y);
+  } else {
   {  // zero fill, 16 bytes per store (both areas are whole uint4s and contiguous)
     uint4* z4 = reinterpret_cast<uint4*>(lds);
     const int nz = (tr * TSW + sr * SSW) >> 2;
@@ -217,11 +418,9 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   unsigned t2 = 0;
   for (int e = lane; e < tr * TSW; e += 64) t2 = __builtin_amdgcn_udot4(tplw[e], tplw[e], t2, false);
   for (int off = 32; off > 0; off >>= 1) t2 += (unsigned)__shfl_xor((int)t2, off);
-  const int rw = sc - tc + 1, rh = sr - tr + 1;
   const int NJ = (sh0 + rw + 15) >> 4;        // tasks: (J, r), J < NJ, r < 4
   const int r = lane & 3;
   const int cpl = ((ndw + 63) >> 6);          // stripe dwords per lane for the column sums
-  unsigned long long best = ~0ull;
   for (int oy = 0; oy < rh; oy++) {
     // ---- P2: exclusive prefix of the column sums of squares over rows oy .. oy+tr-1 -----------
     {
@@ -342,6 +541,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
     }
     __syncthreads();
   }
+  }  // dot4 search
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned long long other = __shfl_xor(best, off);
     best = other < best ? other : best;
@@ -367,7 +567,7 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
                                                           const unsigned char* __restrict__ Lr,
                                                           const unsigned char* __restrict__ Rr,
                                                           FrameTab K, StereoTab ST, StreamState S,
-                                                          int act_flag, int mode) {
+                                                          int act_flag, int mode, int impl) {
   const int s = blockIdx.y;
   if (!(S.flags[s] & act_flag)) return;
   int i;
@@ -382,7 +582,7 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
   float2 rkp = make_float2(0.f, 0.f);
   int rstatus = lstatus;
   double score = -1.0;
-  if (lstatus == 0) match_one<SUBPIX>(P, T, L, R, lkp, lds_raw, lane, &rkp, &rstatus, &score);
+  if (lstatus == 0) match_one<SUBPIX>(P, T, L, R, lkp, lds_raw, lane, &rkp, &rstatus, &score, impl);
   if (lane != 0) return;
   // getDepthFromRectifiedMatches (StereoMatcher.cpp:425-483)
   double depth = 0.0;
@@ -423,6 +623,13 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
   ST.kp3d[o * 3 + 2] = z3;
 }
 
+// KVFE_SSD_IMPL: 1 (default) = the SSD search on the matrix cores where its lane maps fit (ssd_search_mfma), 0 = the
+// v_dot4 search everywhere.  Read at every launch (the tests switch it inside one process).
+static int stereo_ssd_impl() {
+  const char* e = std::getenv("KVFE_SSD_IMPL");
+  return e ? std::atoi(e) : 0;   // (0 until the matrix-core search has passed the GPU parity tests)
+}
+
 static size_t stereo_lds_bytes(const KParams& P) {
   size_t b = stereo_geom(P).match_bytes;
   if (P.stereo_subpix) b += subpix_geom(10).bytes;
@@ -437,10 +644,10 @@ void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_
                      ST, S, act_flag, mode);
   if (P.stereo_subpix)
     hipLaunchKernelGGL(stereo_match_kernel<true>, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st,
-                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode);
+                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode, stereo_ssd_impl());
   else
     hipLaunchKernelGGL(stereo_match_kernel<false>, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st,
-                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode);
+                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode, stereo_ssd_impl());
 }
 
 void launch_undistort_left(const KParams& P, const Tables& T, const FrameTab& k, const StereoTab& ST,
@@ -454,7 +661,7 @@ template <bool SUBPIX>
 __global__ __launch_bounds__(64) void stereo_match_only_kernel(
     KParams P, Tables T, const unsigned char* __restrict__ L, const unsigned char* __restrict__ R,
     const float2* __restrict__ lkps, const unsigned char* __restrict__ lstat, int n,
-    float2* rkps, unsigned char* rstat, double* scores) {
+    float2* rkps, unsigned char* rstat, double* scores, int impl) {
   const int i = blockIdx.x;
   if (i >= n) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -462,7 +669,7 @@ __global__ __launch_bounds__(64) void stereo_match_only_kernel(
   int rstatus = lstat[i];
   double score = -1.0;
   if (rstatus == 0)
-    match_one<SUBPIX>(P, T, L, R, lkps[i], lds_raw, threadIdx.x, &rkp, &rstatus, &score);
+    match_one<SUBPIX>(P, T, L, R, lkps[i], lds_raw, threadIdx.x, &rkp, &rstatus, &score, impl);
   if (threadIdx.x == 0) {
     rkps[i] = rkp;
     rstat[i] = (unsigned char)rstatus;
@@ -478,11 +685,11 @@ void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned 
   if (P.stereo_subpix)
     hipLaunchKernelGGL(stereo_match_only_kernel<true>, dim3(n), dim3(64), stereo_lds_bytes(P), st, P,
                        T, left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
-                       right_status, score);
+                       right_status, score, stereo_ssd_impl());
   else
     hipLaunchKernelGGL(stereo_match_only_kernel<false>, dim3(n), dim3(64), stereo_lds_bytes(P), st, P,
                        T, left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
-                       right_status, score);
+                       right_status, score, stereo_ssd_impl());
 }
 
 // ---------------------------------------------------------------------------------------------
