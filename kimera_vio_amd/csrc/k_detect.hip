@@ -1938,22 +1938,40 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
 // They used to be written by step_finalize, at the very end of the step; written here, the next step's predictor and
 // tracking launch depend on the corner refinement only, and this step's tail (stereo matching of the new corners,
 // measurements, lkf <- k) runs next to them instead of in front of them.
-__global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D) {
+// what: bit 0 = the state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the keypoint count: all
+// known once the corners are selected), bit 1 = the landmark-id counter (read by the append of THIS frame's corners, so
+// it moves after them).  The pipelined step runs bit 0 on the main stream right after the selection
+// (launch_detect_state) and bit 1 behind the corner refinement; everything else runs both behind the refinement.
+__global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D, int what) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.B) return;
   const int flags = S.flags[s];
-  if (flags & FLAG_KEYFRAME) {   // keyframe_R_ref_frame_ = identity (StereoVisionImuFrontend.cpp:203,225)
-    for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
-  } else if ((flags & FLAG_INIT) && !(flags & FLAG_DETECT)) {
-    // non-keyframe of the normal path: keyframe_R_ref_frame_ = keyframe_R_cur_frame; the "all tracks lost" early
-    // return (StereoVisionImuFrontend.cpp:313-323) leaves it untouched
-    for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = S.kf_R_cur[(size_t)s * 9 + i];
+  if (what & 1) {
+    if (flags & FLAG_KEYFRAME) {   // keyframe_R_ref_frame_ = identity (StereoVisionImuFrontend.cpp:203,225)
+      for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+    } else if ((flags & FLAG_INIT) && !(flags & FLAG_DETECT)) {
+      // non-keyframe of the normal path: keyframe_R_ref_frame_ = keyframe_R_cur_frame; the "all tracks lost" early
+      // return (StereoVisionImuFrontend.cpp:313-323) leaves it untouched
+      for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = S.kf_R_cur[(size_t)s * 9 + i];
+    }
+    S.flags[s] = flags | FLAG_INIT;
   }
-  S.flags[s] = flags | FLAG_INIT;
   if (!(flags & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
-  K.count[s] = S.n_tracked[s] + n_new;
-  S.lmk_counter[s] += n_new;
+  if (what & 1) K.count[s] = S.n_tracked[s] + n_new;
+  if (what & 2) S.lmk_counter[s] += n_new;
+}
+
+void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 1);
+}
+
+int detect_new_bound(const KParams& P) {
+  int bound = P.max_corners > 0 ? P.max_corners : P.acap;
+  if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
+    bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
+  return min(bound, P.acap);
 }
 
 void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
@@ -1961,10 +1979,7 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
                           const StreamState& S, const DetectScratch& D, int append,
                           hipStream_t st) {
   const size_t lds = subpix_geom(P.subpix_win).bytes;
-  int bound = P.max_corners > 0 ? P.max_corners : P.acap;
-  if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
-    bound = min(bound, P.max_features + P.hbins * P.vbins + P.max_features / 4 + 8);
-  bound = min(bound, P.acap);
+  const int bound = detect_new_bound(P);
   // KVFE_SUBPIX_WAVES=1: one wave per corner (LDS-ring chains); default 2 (DPP broadcast chains, kvfe_subpix.inl), and
   // 4 for a few streams: the patch and term work of an iteration is spread over four SIMDs (5.4 k instead of 6.3 k
   // cycles per iteration as long as the corners are few; with ~1000 corners in flight two waves are faster)
@@ -1982,8 +1997,8 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   else
     hipLaunchKernelGGL((subpix_append_kernel<0, 1>), dim3(bound, P.B), dim3(64), lds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append);
-  if (append)
-    hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D);
+  if (append)   // (append == 2: the state half has been launched by launch_detect_state)
+    hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, append == 2 ? 2 : 3);
 }
 
 template <int WIN, int NW>

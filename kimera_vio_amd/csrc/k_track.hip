@@ -437,7 +437,14 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
     s = blockIdx.y;
     rank = blockIdx.x;
   }
-  if (rank >= lk.npts[s]) return;
+  // part (use_order bits 1-2): 0 = all points of the stream, 1 = the first npts_old (keypoints that were already tracked
+  // in frame k-1), 2 = the rest (frame k-1's new corners): the split launch of the pipelined step
+  const int part = use_order >> 1;
+  use_order &= 1;
+  const int lo = part == 2 ? lk.npts_old[s] : 0;
+  const int hi = part == 1 ? lk.npts_old[s] : lk.npts[s];
+  rank += lo;
+  if (rank >= hi) return;
   const int pt = use_order ? lk.order[(size_t)s * P.kcap + rank] : rank;
   int iters_total = 0;
   const int lane = threadIdx.x;
@@ -1200,26 +1207,33 @@ __global__ __launch_bounds__(64) void lk_kernel_sys2(KParams P, const unsigned c
   }
 }
 
+// the split launch (part 1 | 2) exists for the systolic kernels only
+bool lk_supports_parts(const KParams& P) {
+  static const int lk_pts = std::getenv("KVFE_LK_PTS") ? std::atoi(std::getenv("KVFE_LK_PTS")) : 1;
+  return (P.klt_win == 16 || P.klt_win == 24 || P.klt_win == 32) && lk_pts != 2;
+}
+
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order) {
+               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order, int part) {
   if (max_pts <= 0) return;
   // KVFE_LK_ORDER=1 (measured, NOT the default): dispatch the points by the iterations they took in the previous frame,
   // slowest first and rank-major over the streams, so that the launch's tail of slow points starts early.  Bit-exact
   // (158 GPU tests), but the count of the previous frame does not predict this frame's: 0.555 ms against 0.547 ms
   // per 64-stream launch in table order.
   static const bool order_on = std::getenv("KVFE_LK_ORDER") != nullptr;
-  const int ord = use_order && order_on ? 1 : 0;
+  const int ord = part ? (part << 1) : (use_order && order_on ? 1 : 0);   // (the kernel's use_order argument: bit 0 | part << 1)
   const dim3 grid(max_pts, P.B), block(64);
 #define KVFE_LK_SYS(WINSZ)                                                                      \
-  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, ord ? dim3((unsigned)max_pts * P.B) : grid, block, 0, st, P, prev_img, prev_row_stride,    \
+  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, (ord & 1) ? dim3((unsigned)max_pts * P.B) : grid, block, 0, st, P, prev_img, prev_row_stride,    \
                      prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,        \
                      cur_pyr, lk, ord)
   // KVFE_LK_PTS=2: two points per wave for the reference's window of 24 (lk_kernel_sys2: bit-exact, 18 % fewer VALU
   // instructions, but 0.65 ms against 0.56 ms per 64-stream step -- three waves per SIMD do not hide its LDS latency
   // and the two points' windows collide on LDS banks, profiles/r2_lk2_pmc.md); default: one point per wave
   static const int lk_pts = std::getenv("KVFE_LK_PTS") ? std::atoi(std::getenv("KVFE_LK_PTS")) : 1;
+  if (part && !lk_supports_parts(P)) return;   // (the caller asks lk_supports_parts first)
   switch (P.klt_win) {
     case 16: KVFE_LK_SYS(16); break;
     case 24:
@@ -1386,13 +1400,20 @@ __device__ __forceinline__ float2 predict_point(const float* H, float2 p, int W,
   return p;
 }
 
+// part: 0 = all keypoints of frame k-1; 1 = those that were tracked INTO frame k-1 (table entries below n_tracked: final
+// since its track_finalize / outlier rejections, on the main stream) -> npts_old; 2 = frame k-1's new corners (entries
+// n_tracked .. count - 1, written by its corner refinement on the side stream), appended behind the first part -> npts.
+// 1 + 2 produce exactly the arrays of 0: the gather keeps table order and the new corners are the table's tail.
 __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T, FrameTab KM1,
-                                                            StreamState S, LkScratch lk) {
+                                                            StreamState S, LkScratch lk, int part) {
   const int s = blockIdx.x;
   __shared__ float Hs[9];
   __shared__ int use_h;
   if (!(S.flags[s] & FLAG_INIT)) {
-    if (threadIdx.x == 0) lk.npts[s] = 0;
+    if (threadIdx.x == 0) {
+      if (part != 2) lk.npts_old[s] = 0;
+      if (part != 1) lk.npts[s] = 0;
+    }
     return;
   }
   if (threadIdx.x == 0) {
@@ -1415,7 +1436,10 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
   __syncthreads();
   // Tracker.cpp:103-112: only keypoints with a valid landmark are tracked (geometric outlier
   // rejection leaves landmark -1 entries in a keyframe); src_idx maps point -> index in frame k-1
-  const int n = KM1.count[s];
+  const int n_all = KM1.count[s];
+  const int n_old = min(S.n_tracked[s], n_all);
+  const int i0 = part == 2 ? n_old : 0;
+  const int n = part == 1 ? n_old : n_all;
   const size_t so = (size_t)s * P.kcap;
   __shared__ int wave_tot[4];
   __shared__ int sh_off;
@@ -1424,13 +1448,13 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
   // class is arbitrary and irrelevant: only WHEN a point is tracked depends on it, never the result)
   __shared__ int cls_cursor[8];
   if (threadIdx.x < 8) cls_cursor[threadIdx.x] = 0;
-  if (threadIdx.x == 0) sh_off = 0;
+  if (threadIdx.x == 0) sh_off = part == 2 ? lk.npts_old[s] : 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256)
+  for (int i = i0 + threadIdx.x; i < n; i += 256)
     if (KM1.lmk[so + i] != -1) atomicAdd(&cls_cursor[min(7, (int)KM1.cost[so + i] >> 3)], 1);
   __syncthreads();
   if (threadIdx.x == 0) {
-    int acc = 0;
+    int acc = part == 2 ? lk.npts_old[s] : 0;
     for (int k = 7; k >= 0; k--) {
       const int c = cls_cursor[k];
       cls_cursor[k] = acc;
@@ -1438,7 +1462,7 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
     }
   }
   __syncthreads();
-  for (int base = 0; base < n; base += 256) {
+  for (int base = i0; base < n; base += 256) {
     const int i = base + threadIdx.x;
     const bool valid = i < n && KM1.lmk[so + i] != -1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1467,12 +1491,17 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
     if (threadIdx.x == 0) sh_off = off0 + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) lk.npts[s] = sh_off;
+  if (threadIdx.x == 0) {
+    if (part == 1)
+      lk.npts_old[s] = sh_off;
+    else
+      lk.npts[s] = sh_off;
+  }
 }
 
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st) {
-  hipLaunchKernelGGL(track_prepare_kernel, dim3(P.B), dim3(256), 0, st, P, T, km1, S, lk);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part) {
+  hipLaunchKernelGGL(track_prepare_kernel, dim3(P.B), dim3(256), 0, st, P, T, km1, S, lk, part);
 }
 
 __global__ void predict_flow_kernel(KParams P, Tables T, const double* R, const float2* prev,

@@ -129,7 +129,9 @@ struct kvfe_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
   hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // main-stream part of the fork done / tail of the step (side stream) done
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
+  hipEvent_t ev_prep = nullptr, ev_lknew = nullptr;  // split tracking: first part gathered (main) / second part tracked (side)
   bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
+  bool split_lk = false;                             // KVFE_LK_SPLIT: see do_step
   bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
@@ -334,6 +336,7 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
+  TRY(dalloc(c, &b.lk.npts_old, B));
   TRY(dalloc(c, &b.lk.src_idx, K));
   TRY(dalloc(c, &b.lk.order, K));
   TRY(dalloc(c, &b.lk.iters, K));
@@ -926,18 +929,37 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // refined new corners and the per-stream state detect_commit wrote (ev_commit) -- joined HERE, behind the pyramid,
   // which does not depend on it and hides the cross-stream hand-over.  Its tail (stereo matching of the new corners,
   // measurements, lkf <- k) is only needed by track_finalize: it runs next to this step's tracking launch.
-  if (c->commit_pending) {
+  // KVFE_LK_SPLIT=1: the tracking launch in two parts.  The keypoints frame k-1 had tracked itself are final on the main
+  // stream (track_finalize, outlier rejections) and the state the predictor reads is written there too
+  // (launch_detect_state): their part starts right behind the pyramid.  Frame k-1's NEW corners come out of the corner
+  // refinement on the side stream: they are gathered and tracked THERE, behind the previous step's tail and next to the
+  // first part -- the corner refinement (40 dependent iterations per corner) is off the critical path.
+  const bool split = c->split_lk && c->commit_pending && c->prev_left;
+  if (c->commit_pending && !split) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
-    c->commit_pending = false;
     prof_break(c);   // (the wait is not part of the tracking stage)
   }
+  c->commit_pending = false;
   prof_begin(c, ST_TRACK, st);
-  launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
+  launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st, split ? 1 : 0);
+  if (split) {
+    HIPCHK(c, hipEventRecord(c->ev_prep, st));   // (pyramid of frame k and npts_old)
+    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_prep, 0));
+    launch_track_prepare(P, c->T, KM1, b.ss, b.lk, sd, 2);
+    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride, img_stride,
+              b.pyr[pc], b.lk, std::min(c->pts_bound, detect_new_bound(P)), sd, false, 2);
+    HIPCHK(c, hipEventRecord(c->ev_lknew, sd));
+    slot_release.side_used = true;
+  }
   if (c->prev_left)
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, true);
+              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, !split, split ? 1 : 0);
   prof_end(c, ST_TRACK, st);
-  if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
+  if (split) {   // (recorded behind the previous step's tail on the side stream: joins both)
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_lknew, 0));
+    c->tail_pending = false;
+    prof_break(c);
+  } else if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
     c->tail_pending = false;
     prof_break(c);
@@ -1011,13 +1033,15 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // rectify / stereo chain to the side stream right after track_finalize is 10 % slower -- its
   // workgroups delay the one-block-per-stream kernels of the detection chain; stream priorities
   // do not change that.)
+  const bool state_on_main = c->side && c->own_stream && c->split_lk;
+  if (state_on_main) launch_detect_state(P, K, b.ss, b.ds, st);
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
     slot_release.side_used = true;
   }
   prof_begin(c, ST_SUBPIX, sd);
-  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, sd);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, state_on_main ? 2 : 1, sd);
   prof_end(c, ST_SUBPIX, sd);
   if (c->side && c->own_stream) {
     HIPCHK(c, hipEventRecord(c->ev_commit, sd));
@@ -1276,8 +1300,12 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
         hipEventCreateWithFlags(&c->ev_mono, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_commit, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_commit, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_lknew, hipEventDisableTiming) != hipSuccess)
       s = KVFE_ERR_HIP;
+    const char* sp = std::getenv("KVFE_LK_SPLIT");
+    c->split_lk = (sp ? std::atoi(sp) != 0 : false) && c->own_stream && lk_supports_parts(c->P);
   }
   if (s != KVFE_OK) {
     std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
@@ -1376,6 +1404,8 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->ev_main) hipEventDestroy(c->ev_main);
   if (c->ev_tail) hipEventDestroy(c->ev_tail);
   if (c->ev_commit) hipEventDestroy(c->ev_commit);
+  if (c->ev_prep) hipEventDestroy(c->ev_prep);
+  if (c->ev_lknew) hipEventDestroy(c->ev_lknew);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->dense_allocs) hipFree(p);
   for (int i = 0; i < 2; i++)

@@ -222,6 +222,7 @@ struct LkScratch {
   unsigned char* status;  // [B][kcap]
   float* err;             // [B][kcap]
   int* npts;              // [B]
+  int* npts_old;          // [B] split launch: points gathered from the keypoints frame k-1 had tracked itself
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
   // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
@@ -260,10 +261,11 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order = false);
+               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order = false, int part = 0);
+bool lk_supports_parts(const KParams& P);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part = 0);
 // survivors -> frame k, bearing vectors, keyframe decision (Tracker.cpp:167-189,
 // StereoVisionImuFrontend.cpp:313-347, VisionImuFrontend.cpp:175-232)
 void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
@@ -281,6 +283,11 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
                           hipStream_t st);
+// the per-stream state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the frame's keypoint
+// count): known once the new corners are SELECTED.  launch_subpix_append(append = 2) leaves it to this launch.
+void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D,
+                         hipStream_t st);
+int detect_new_bound(const KParams& P);   // upper bound of the new corners per stream and frame
 // cv::cornerSubPix on arbitrary points (component API)
 void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigned char* img,
                           size_t row_stride, int W, int H, float2* pts, int n, int win,

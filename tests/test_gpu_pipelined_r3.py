@@ -22,30 +22,37 @@ from test_gpu_parity import _euroc_ransac_params, _kf_rotations, euroc_cams, oca
 pytestmark = pytest.mark.gpu
 
 
-def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0):
+def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=None, features=200):
     seq = dict(seq)
     seq["camR"] = _kf_rotations(seq["body_R"], ocam)
     L, R = euroc_cams()
-    p = _euroc_ransac_params(max_features_per_frame=200)
+    p = _euroc_ransac_params(max_features_per_frame=features)
     p.stereo.equalize_image = equalize
     fe = [O.Frontend(L, R, p) for _ in range(B)]
     c = F.Context(L, R, p, batch=B, hip_stream=hip_stream)
     try:
         exp = None
+        lkf = [None] * B   # frame index of each stream's last keyframe (from the oracle: nothing is read back from the GPU)
         for i in range(n):
             idx = [i, 8 - i][:B]
-            # keyframe_R_cur_frame: every frame is a keyframe, so the reference frame is the previous one
-            Rs = [np.eye(3) if i == 0 else seq["camR"][[i - 1, 9 - i][s]].T @ seq["camR"][idx[s]] for s in range(B)]
+            # keyframe_R_cur_frame: rotation from the stream's last keyframe to this frame
+            Rs = [np.eye(3) if lkf[s] is None else seq["camR"][lkf[s]].T @ seq["camR"][idx[s]] for s in range(B)]
             ts = [int(seq["ts"][i])] * B
+            fk = [1] * B if force is None else [int(force[(i + s) % len(force)]) for s in range(B)]
             lefts = np.stack([seq["lefts"][j] for j in idx])
             rights = np.stack([seq["rights"][j] for j in idx])
-            c.step_host(lefts, rights, c.make_inputs(ts, Rs, [1] * B))      # enqueue only
+            c.step_host(lefts, rights, c.make_inputs(ts, Rs, fk))      # enqueue only
             if sync_every and (i + 1) % sync_every == 0:
                 c.synchronize()
-            exp = [fe[s].process(lefts[s], rights[s], ts[s], Rs[s], True) for s in range(B)]
+            exp = [fe[s].process(lefts[s], rights[s], ts[s], Rs[s], bool(fk[s])) for s in range(B)]
+            for s in range(B):
+                if exp[s]["is_keyframe"]:
+                    lkf[s] = idx[s]
         for s in range(B):
             assert_step_equal(c.get_output(s), exp[s], ("last", s))
-            assert exp[s]["is_keyframe"] and exp[s]["n_measurements"] > 50
+            if force is None:
+                assert exp[s]["is_keyframe"] and exp[s]["n_measurements"] > 50
+        return exp
     finally:
         c.close()
 
@@ -78,3 +85,34 @@ def test_pipelined_host_steps_copy_inputs():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KVFE_COPY_INPUTS="1"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.fixture
+def split_tracking_env():
+    old = os.environ.get("KVFE_LK_SPLIT")
+    os.environ["KVFE_LK_SPLIT"] = "1"      # read when a context is created
+    yield
+    if old is None:
+        os.environ.pop("KVFE_LK_SPLIT", None)
+    else:
+        os.environ["KVFE_LK_SPLIT"] = old
+
+
+@pytest.mark.parametrize("force,features,equalize", [
+    (None, 200, 0),                # every frame a keyframe: every step has new corners to track on the side stream
+    (None, 60, 1),                 # few features: most of a frame's keypoints are new corners
+    ([1, 0, 0], 200, 0),           # keyframes and plain frames alternate, the two streams out of phase
+    ([0, 0, 0, 0, 1], 300, 0),     # mostly the front-end's own keyframe decisions
+])
+def test_pipelined_split_tracking_launch(seq, ocam, split_tracking_env, force, features, equalize):
+    """KVFE_LK_SPLIT=1: frame k-1's new corners are gathered and tracked on the side stream behind its corner
+    refinement, the keypoints it had tracked itself on the main stream right behind the pyramid -- same tables, same
+    results, steps enqueued back to back"""
+    exp = _replay(seq, ocam, equalize, force=force, features=features)
+    assert all(e["n_tracked"] > 20 for e in exp)
+
+
+def test_split_tracking_with_synchronised_steps(seq, ocam, split_tracking_env):
+    """the same with the tail joined between steps (get_output / synchronize reset the pending hand-overs)"""
+    _replay(seq, ocam, 0, sync_every=2)
+    _replay(seq, ocam, 0, sync_every=1, force=[1, 0])
