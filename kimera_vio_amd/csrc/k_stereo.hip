@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
 // v_dot4 search everywhere.  Read at every launch (the tests switch it inside one process).
 static int stereo_ssd_impl() {
   const char* e = std::getenv("KVFE_SSD_IMPL");
-  return e ? std::atoi(e) : 0;   // (0 until the matrix-core search has passed the GPU parity tests)
+  return e ? std::atoi(e) : 1;
 }
 
 static size_t stereo_lds_bytes(const KParams& P) {

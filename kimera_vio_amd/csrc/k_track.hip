@@ -429,6 +429,10 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
   // the r-th slowest point of the previous frame -- so that every stream's slow points start at the beginning of the
   // launch; the stream index is rotated by the rank so that a stream's points spread over all XCDs (workgroup b runs
   // on XCD b & 7).  Otherwise (component calls) blockIdx = (point, stream).
+  // part (use_order bits 1-2): 0 = all points of the stream, 1 = the first npts_old (keypoints that were already tracked
+  // in frame k-1), 2 = the rest (frame k-1's new corners): the split launch of the pipelined step
+  const int part = use_order >> 1;
+  use_order &= 1;
   int s, rank;
   if (use_order) {
     rank = blockIdx.x / P.B;
@@ -437,10 +441,6 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
     s = blockIdx.y;
     rank = blockIdx.x;
   }
-  // part (use_order bits 1-2): 0 = all points of the stream, 1 = the first npts_old (keypoints that were already tracked
-  // in frame k-1), 2 = the rest (frame k-1's new corners): the split launch of the pipelined step
-  const int part = use_order >> 1;
-  use_order &= 1;
   const int lo = part == 2 ? lk.npts_old[s] : 0;
   const int hi = part == 1 ? lk.npts_old[s] : lk.npts[s];
   rank += lo;

@@ -1,9 +1,8 @@
 """Round 3: the SSD search of searchRightKeypointEpipolar (StereoMatcher.cpp:196-423) on the matrix cores
 (`ssd_search_mfma`, v_mfma_i32_16x16x64_i8 on the images shifted to signed bytes) against the oracle and against the
 v_dot4 search it replaces (KVFE_SSD_IMPL=0), tolerance 0: right keypoints, statuses and scores.  Template / stripe
-geometries cover both K-step variants (compile-time 2 = the shipped 101-column template, run-time 1 and 3), odd and
-even template heights (the phantom row), stripes higher than the template (several offset rows), template widths
-with and without a partial last dword, and keypoints whose template or stripe is clamped at either image border."""
+geometries cover both K-step variants (compile-time 2 = the shipped 101-column template, run-time 1 and 3), stripes
+higher than the template (several offset rows), template widths with one and three bytes in the last dword, and keypoints whose template or stripe is clamped at either image border."""
 import os
 
 import numpy as np
@@ -54,13 +53,14 @@ def ssd_impl_env():
         os.environ["KVFE_SSD_IMPL"] = old
 
 
-@pytest.mark.parametrize("tc,tr,extra,min_dist", [
-    (101, 11, 0, 0.5),    # shipped (EuRoC): 2 K steps, 101 offsets, odd template height
+@pytest.mark.parametrize("tc,tr,extra,min_dist", [   # (template sizes are odd, extra rows even: the reference's CHECKs)
+    (101, 11, 0, 0.5),    # shipped (EuRoC): 2 K steps, 101 offsets, odd template height (one phantom row)
     (101, 11, 2, 0.5),    # three offset rows
-    (100, 10, 0, 0.5),    # whole last template dword, even height
-    (41, 7, 1, 0.4),      # one K step
+    (103, 11, 0, 0.5),    # three bytes in the last template dword
+    (99, 9, 0, 0.5),      # 2 K steps, 25 template dwords
+    (41, 7, 2, 0.4),      # one K step
     (121, 5, 0, 0.6),     # three K steps
-    (49, 4, 3, 0.3),      # template + 15 = 64: exactly one K step; 160-odd offsets
+    (49, 3, 4, 0.3),      # template + 15 = 64: exactly one K step; 160-odd offsets, five offset rows
 ])
 def test_ssd_search_matrix_cores_vs_oracle_and_dot4(ssd_impl_env, tc, tr, extra, min_dist):
     L, R = _cams()

@@ -6,19 +6,12 @@ timeout 60 python -c "
 import sys; sys.path.insert(0,'tests')
 import test_gpu_pyramid_r3 as T
 c=T._ctx(752,480,2,win=8); print('sanity ok')" || { echo "SANITY FAILED"; exit 1; }
-KVFE_SSD_IMPL=1 KVFE_LK_SPLIT=1 timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/g_tests_both.log 2>&1; rc=$?
-echo "pytest both rc=$rc"; tail -3 gpurun_out/g_tests_both.log
+timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/g_tests_default.log 2>&1; rc=$?
+echo "pytest default (SSD on the matrix cores) rc=$rc"; tail -3 gpurun_out/g_tests_default.log
 SSD=1; SPL=1
-if [ $rc -ne 0 ]; then
-  grep -E "Error|FAILED|assert" gpurun_out/g_tests_both.log | head -12
-  KVFE_SSD_IMPL=1 timeout 300 python -m pytest tests/test_gpu_stereo_mfma_r3.py tests/test_gpu_parity.py -m gpu -q -k "ssd or stereo_match or sparse_stereo" > gpurun_out/g_tests_ssd1.log 2>&1; r1=$?
-  echo "ssd impl 1 rc=$r1"; tail -3 gpurun_out/g_tests_ssd1.log; [ $r1 -ne 0 ] && SSD=0
-  if [ $r1 -ne 0 ]; then
-    KVFE_SSD_IMPL=3 timeout 300 python -m pytest tests/test_gpu_stereo_mfma_r3.py -m gpu -q > gpurun_out/g_tests_ssd3.log 2>&1; echo "ssd impl 3 (operands exchanged) rc=$?"; tail -3 gpurun_out/g_tests_ssd3.log
-  fi
-  KVFE_SSD_IMPL=0 KVFE_LK_SPLIT=1 timeout 400 python -m pytest tests/test_gpu_pipelined_r3.py tests/test_gpu_parity.py tests/test_gpu_bench_configs.py -m gpu -q -k "pipelined or split or sequence or bench or config" > gpurun_out/g_tests_split.log 2>&1; r2=$?
-  echo "split rc=$r2"; tail -3 gpurun_out/g_tests_split.log; [ $r2 -ne 0 ] && { SPL=0; grep -E "Error|FAILED|assert" gpurun_out/g_tests_split.log | head -12; }
-fi
+[ $rc -ne 0 ] && { SSD=0; grep -E "Error|FAILED|assert" gpurun_out/g_tests_default.log | head -12; }
+KVFE_LK_SPLIT=1 timeout 400 python -m pytest tests/test_gpu_pipelined_r3.py tests/test_gpu_parity.py tests/test_gpu_bench_configs.py tests/test_gpu_fuzz_slices.py -m gpu -q -k "pipelined or split or sequence or bench or config or fuzz" > gpurun_out/g_tests_split.log 2>&1; r2=$?
+echo "split rc=$r2"; tail -3 gpurun_out/g_tests_split.log; [ $r2 -ne 0 ] && { SPL=0; grep -E "Error|FAILED|assert" gpurun_out/g_tests_split.log | head -12; }
 run() {  # ssd split legs steps
 KVFE_SSD_IMPL=$1 KVFE_LK_SPLIT=$2 timeout 300 python bench.py --legs $3 --steps $4 --warmup 8 --repeats 2 2> gpurun_out/g_bench.err | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); st=d.get('stage_ms_per_step_summed_over_groups',{}); print('ssd=$1 split=$2', d['value'], d['ms_per_step'], d['repeats']['values'], [(k, d[k]['value']) for k in ('nominal','single_stream','c5','kf_realistic','klt_max_level_4') if k in d], ' '.join('%s %.3f' % (k[:9], v) for k, v in st.items()))"
