@@ -51,7 +51,7 @@ def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=
         for s in range(B):
             assert_step_equal(c.get_output(s), exp[s], ("last", s))
             if force is None:
-                assert exp[s]["is_keyframe"] and exp[s]["n_measurements"] > 50
+                assert exp[s]["is_keyframe"] and exp[s]["n_measurements"] > min(50, features // 2)
         return exp
     finally:
         c.close()
