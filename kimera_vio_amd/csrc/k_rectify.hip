@@ -278,13 +278,75 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+// the block's source box from the lanes' tap extents: x_lo (16-byte aligned), y_lo, 16-byte chunks per row and rows that
+// hold needed bytes; ncx = 0 when the tile has no pixel or its box does not fit the LDS stage
+template <int TH>
+__device__ __forceinline__ void rt_block_box(int mnx, int mxx, int mny, int mxy, int* bounds, int lane, int wave, int W,
+                                             int H, int& x_lo, int& y_lo, int& ncx, int& ph) {
+  mnx = wave_min(mnx);
+  mxx = wave_max(mxx);
+  mny = wave_min(mny);
+  mxy = wave_max(mxy);
+  if (lane == 0) {
+    bounds[wave * 4 + 0] = mnx;
+    bounds[wave * 4 + 1] = mxx;
+    bounds[wave * 4 + 2] = mny;
+    bounds[wave * 4 + 3] = mxy;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    mnx = min(mnx, bounds[w * 4 + 0]);
+    mxx = max(mxx, bounds[w * 4 + 1]);
+    mny = min(mny, bounds[w * 4 + 2]);
+    mxy = max(mxy, bounds[w * 4 + 3]);
+  }
+  x_lo = mnx & ~15;
+  y_lo = mny;
+  ncx = ((min(mxx + 1, W - 1) - x_lo) >> 4) + 1;
+  ph = min(mxy + 1, H - 1) - y_lo + 1;
+  if (!(mxx >= 0 && ncx <= RT_CPR && ph <= rt_rows(TH))) ncx = 0;
+}
+
+// the boxes of all 128 x 16 tiles of one camera (context creation): one block per tile
+__global__ __launch_bounds__(256) void rectify_box_kernel(const float2* __restrict__ map, int W, int H, int tiles_x,
+                                                          int4* __restrict__ box) {
+  __shared__ int bounds[16];
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x = tx * RT_W + (tid & 31) * 4, y0 = ty * 16 + (tid >> 5);
+  int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
+  for (int r = 0; r < 2; r++) {
+    const int y = y0 + 8 * r;
+    if (x < W && y < H)
+      for (int q = 0; q < 4; q++) {
+        const float2 m = map[y * W + x + q];
+        const RTap t = rtap(W, H, m.x, m.y);
+        mnx = min(mnx, t.cx);
+        mxx = max(mxx, t.cx);
+        mny = min(mny, t.cy);
+        mxy = max(mxy, t.cy);
+      }
+  }
+  int x_lo, y_lo, ncx, ph;
+  rt_block_box<16>(mnx, mxx, mny, mxy, bounds, lane, wave, W, H, x_lo, y_lo, ncx, ph);
+  if (tid == 0) box[blockIdx.x] = make_int4(x_lo, y_lo, ncx, ph);
+}
+
+void launch_rectify_boxes(const float2* map, int W, int H, int4* box, hipStream_t st) {
+  const int tiles_x = (W + RT_W - 1) / RT_W, tiles_y = (H + 15) / 16;
+  hipLaunchKernelGGL(rectify_box_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, st, map, W, H, tiles_x, box);
+}
+
+size_t rectify_box_count(int W, int H) { return (size_t)((W + RT_W - 1) / RT_W) * ((H + 15) / 16); }
+
 template <int TH, int SPB, int NSUB, int MINW>
 __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1, size_t src_row_stride,
     size_t src_img_stride, unsigned char* __restrict__ dst0, unsigned char* __restrict__ dst1,
     const float2* __restrict__ map0, const float2* __restrict__ map1, int W, int H, int B,
     const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode,
-    const int* __restrict__ skip) {
+    const int* __restrict__ skip, const int4* __restrict__ box0, const int4* __restrict__ box1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int NBUF = NSUB > 1 ? 2 : 1;   // LDS boxes: SPB streams x NBUF buffers
   constexpr int NR = TH / 8;               // tile rows per lane
@@ -322,6 +384,65 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
   const int lx = tid & 31, ly = tid >> 5;
   const int x = tx * RT_W + lx * 4;
   const int y0 = ty * TH + ly;
+  // stream activity (block-uniform), one bit per stream of the block
+  unsigned act = 0;
+#pragma unroll
+  for (int k = 0; k < SPB * NSUB; k++) {
+    const int s = s_begin + k;
+    if (s < B && (!flags || (flags[s] & act_flag)) && !(skip && skip[s])) act |= 1u << k;
+  }
+  if (!act) return;
+  // The source box of a tile depends on the maps only: for TH = 16 it is tabulated when the context is created
+  // (rectify_box_kernel, the same taps and the same reduction), so the first boxes are requested BEFORE the map tile is
+  // read and the taps are computed -- one memory round trip of the five a block used to make in sequence.
+  const int4* box = cam == 0 ? box0 : box1;
+  const bool tabulated = TH == 16 && box != nullptr;
+  int x_lo = 0, y_lo = 0, ncx = 0, ph = 0;
+  bool staged = false;
+  if (tabulated) {
+    const int4 bx = box[ty * tiles_x + tx];
+    x_lo = bx.x;
+    y_lo = bx.y;
+    ncx = bx.z;
+    ph = bx.w;
+    staged = ncx > 0 && !(mode & 2);   // mode bit 1: force the gather path (tests)
+  }
+  // this lane's (at most NIT) 16-byte chunks of a box: offsets are the same for every stream
+  int goff[NIT];
+  bool gok[NIT];
+  int n = 0;
+  const unsigned char* Sbase = src;
+  auto plan = [&]() {
+    n = ph * RT_CPR;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int c = wave * 64 + it * 256 + lane;
+      const int row = c / RT_CPR, ch = c - row * RT_CPR;
+      gok[it] = c < n && ch < ncx;
+      goff[it] = row * stride + ch * 16;
+    }
+    Sbase = src + (size_t)y_lo * stride + x_lo;
+  };
+  auto issue = [&](int j) {
+    unsigned char* pb = sm + (j & (NBUF - 1)) * (SPB * RT_PATCH);
+#pragma unroll
+    for (int k = 0; k < SPB; k++) {
+      if (!((act >> (j * SPB + k)) & 1u)) continue;
+      const unsigned char* S = Sbase + (size_t)(s_begin + j * SPB + k) * src_img_stride;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        if (wave * 64 + it * 256 < n && gok[it])
+          __builtin_amdgcn_global_load_lds((glb_cu8_t*)(S + goff[it]),
+                                           (lds_u8_t*)(pb + k * RT_PATCH + (wave * 64 + it * 256) * 16), 16, 0, 0);
+      }
+    }
+  };
+  const bool pairs = NSUB > 1 && (mode & 4);
+  if (tabulated && staged) {
+    plan();
+    issue(0);
+    if (pairs) issue(1);
+  }
   // ---- phase A: taps of this lane's NR x 4 pixels ----------------------------------------------------------
   RTap tp[4 * NR];
   int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
@@ -350,74 +471,22 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
       for (int q = 0; q < 4; q++) tp[4 * r + q] = RTap{0, 0, 0u, 0u};
     }
   }
-  mnx = wave_min(mnx);
-  mxx = wave_max(mxx);
-  mny = wave_min(mny);
-  mxy = wave_max(mxy);
-  if (lane == 0) {
-    bounds[wave * 4 + 0] = mnx;
-    bounds[wave * 4 + 1] = mxx;
-    bounds[wave * 4 + 2] = mny;
-    bounds[wave * 4 + 3] = mxy;
+  if (!tabulated) {
+    rt_block_box<TH>(mnx, mxx, mny, mxy, bounds, lane, wave, W, H, x_lo, y_lo, ncx, ph);
+    staged = ncx > 0 && !(mode & 2);
+    if (staged) {
+      plan();
+      issue(0);
+      if (pairs) issue(1);
+    }
   }
-  __syncthreads();
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    mnx = min(mnx, bounds[w * 4 + 0]);
-    mxx = max(mxx, bounds[w * 4 + 1]);
-    mny = min(mny, bounds[w * 4 + 2]);
-    mxy = max(mxy, bounds[w * 4 + 3]);
-  }
-  const int x_lo = mnx & ~15, y_lo = mny;
-  const int ncx = ((min(mxx + 1, W - 1) - x_lo) >> 4) + 1;   // 16-byte chunks per row that hold needed bytes
-  const int ph = min(mxy + 1, H - 1) - y_lo + 1;             // rows that hold needed bytes
-  const bool staged = mxx >= 0 && ncx <= RT_CPR && ph <= RT_ROWS && !(mode & 2);   // mode bit 1: force the gather path (tests)
-  // stream activity (block-uniform), one bit per stream of the block
-  unsigned act = 0;
-#pragma unroll
-  for (int k = 0; k < SPB * NSUB; k++) {
-    const int s = s_begin + k;
-    if (s < B && (!flags || (flags[s] & act_flag)) && !(skip && skip[s])) act |= 1u << k;
-  }
-  if (!act) return;
   if (staged) {
     // ---- phase B: LDS-DMA of the source boxes, phase C: blend; software pipeline over sub-chunks of SPB streams:
     //      the boxes of sub-chunk j+1 are in flight while sub-chunk j is blended (two LDS buffers) ----------------
-    const int n = ph * RT_CPR;
-    // this lane's (at most NIT) 16-byte chunks of a box: offsets are the same for every stream
-    int goff[NIT];
-    bool gok[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int c = wave * 64 + it * 256 + lane;
-      const int row = c / RT_CPR, ch = c - row * RT_CPR;
-      gok[it] = c < n && ch < ncx;
-      goff[it] = row * stride + ch * 16;
-    }
-    const unsigned char* Sbase = src + (size_t)y_lo * stride + x_lo;
-    auto issue = [&](int j) {
-      unsigned char* pb = sm + (j & (NBUF - 1)) * (SPB * RT_PATCH);
-#pragma unroll
-      for (int k = 0; k < SPB; k++) {
-        if (!((act >> (j * SPB + k)) & 1u)) continue;
-        const unsigned char* S = Sbase + (size_t)(s_begin + j * SPB + k) * src_img_stride;
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          if (wave * 64 + it * 256 < n && gok[it])
-            __builtin_amdgcn_global_load_lds((glb_cu8_t*)(S + goff[it]),
-                                             (lds_u8_t*)(pb + k * RT_PATCH + (wave * 64 + it * 256) * 16), 16, 0, 0);
-        }
-      }
-    };
     unsigned ad[4 * NR];
 #pragma unroll
     for (int q = 0; q < 4 * NR; q++) ad[q] = (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
-    issue(0);
-#pragma unroll
-    for (int j = 0; j < NSUB; j++) {
-      if (!(act >> (j * SPB))) break;   // no active stream in this or any later sub-chunk (block-uniform)
-      __syncthreads();   // hipcc drains vmcnt before the barrier: sub-chunk j has landed; everybody is done with j-1
-      if (j + 1 < NSUB) issue(j + 1);
+    auto blend = [&](int j) {
       const unsigned char* pb = sm + (j & (NBUF - 1)) * (SPB * RT_PATCH);
 #pragma unroll
       for (int k = 0; k < SPB; k++) {
@@ -435,6 +504,31 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
           }
           *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
         }
+      }
+    };
+    if (pairs) {
+      // both buffers are requested together and blended together: two memory round trips of 2 SPB boxes per block
+      // instead of four of SPB boxes (the barrier drains ALL outstanding requests, so a pipeline of depth two cannot
+      // keep more than one sub-chunk in flight while it blends)
+#pragma unroll
+      for (int j = 0; j < NSUB; j += 2) {
+        if (!(act >> (j * SPB))) break;
+        if (j > 0) {
+          __syncthreads();   // everybody is done with both buffers
+          issue(j);
+          if (j + 1 < NSUB) issue(j + 1);
+        }
+        __syncthreads();     // (drains vmcnt: both sub-chunks have landed)
+        blend(j);
+        if (j + 1 < NSUB) blend(j + 1);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NSUB; j++) {
+        if (!(act >> (j * SPB))) break;   // no active stream in this or any later sub-chunk (block-uniform)
+        __syncthreads();   // hipcc drains vmcnt before the barrier: sub-chunk j has landed; everybody is done with j-1
+        if (j + 1 < NSUB) issue(j + 1);
+        blend(j);
       }
     }
   } else {
@@ -467,8 +561,10 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
   // KVFE_RECT_IMPL: 0 = per-lane gathers (rectify_kernel), 1 = LDS-staged tiles (default where the source rows are
   // 16-byte aligned); KVFE_RECT_TILE_MODE: 0 = 3-D grid, 1 = XCD-banded; KVFE_RECT_SPB: streams per block (4 | 8)
   static const int impl = std::getenv("KVFE_RECT_IMPL") ? std::atoi(std::getenv("KVFE_RECT_IMPL")) : 1;
+  // KVFE_RECT_PAIRS=1: both LDS buffers requested and blended together (see the kernel)
   static const int tmode = (std::getenv("KVFE_RECT_TILE_MODE") ? std::atoi(std::getenv("KVFE_RECT_TILE_MODE")) & 1 : 0) |
-                           (std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0);
+                           (std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0) |
+                           (std::getenv("KVFE_RECT_PAIRS") && std::atoi(std::getenv("KVFE_RECT_PAIRS")) ? 4 : 0);
   static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 2;
   static const int nsub = std::getenv("KVFE_RECT_NSUB") ? std::atoi(std::getenv("KVFE_RECT_NSUB")) : 4;
   static const int th = std::getenv("KVFE_RECT_TH") ? std::atoi(std::getenv("KVFE_RECT_TH")) : 16;
@@ -486,10 +582,13 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
     dim3 grid(tiles_x * tiles_y, 2, gz);
     if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
     const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * rt_patch(TH) + 64;
+    static const bool box_off = std::getenv("KVFE_RECT_NO_BOX") != nullptr;   // (A/B switch: boxes recomputed per block)
+    const bool use_box = TH == 16 && !box_off && T.rect_box[0] && T.rect_box[1];
 #define KVFE_RT_LAUNCH(TH_, SPB_, NSUB_, MINW_)                                                                     \
   hipLaunchKernelGGL((rectify_tile_kernel<TH_, SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],        \
                      src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, \
-                     tiles_x, tiles_y, gz, tmode, skip)
+                     tiles_x, tiles_y, gz, tmode, skip, use_box ? T.rect_box[0] : nullptr,                               \
+                     use_box ? T.rect_box[1] : nullptr)
 #define KVFE_RT_DISPATCH(TH_, W1_, W2_)                 \
   do {                                                  \
     if (S == 1 && NS == 1) KVFE_RT_LAUNCH(TH_, 1, 1, W1_);      \

@@ -669,6 +669,11 @@ kvfe_status build_tables(kvfe_ctx* c) {
     TRY(dalloc(c, &dm, N, false));
     HIPCHK(c, hipMemcpy(dm, inter.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
     T.map[cam] = dm;
+    int4* dbox;
+    TRY(dalloc(c, &dbox, rectify_box_count(P.W, P.H), false));
+    launch_rectify_boxes(dm, P.W, P.H, dbox, nullptr);
+    HIPCHK(c, hipDeviceSynchronize());
+    T.rect_box[cam] = dbox;
     for (int m = 0; m < 4; m++) {
       const bool useR = m & 1, useP = m & 2;
       c->und[cam][m] = to_dev(make_undistort_ctx(cp, useR ? (cam == 0 ? c->rect.R1 : c->rect.R2) : nullptr,

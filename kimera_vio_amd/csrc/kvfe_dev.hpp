@@ -108,6 +108,7 @@ struct UndistortDev {
 // Constant tables shared by all streams (device pointers).
 struct Tables {
   const float2* map[2];        // [H][W] (map_x, map_y) per camera
+  const int4* rect_box[2];     // per 128 x 16 output tile of a camera: source box (x_lo, y_lo, 16-byte chunks per row, rows)
   const float* subpix_mask;    // (2w+1)^2 Gaussian-ish weights of cv::cornerSubPix
   const float* subpix_mask10;  // same for the hard-coded 10x10 stereo refinement
   const int* circle_hw;        // [radius+1] half widths of cv::circle(FILLED)
@@ -254,6 +255,9 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
 void launch_equalize_hist(int W, int H, int B, const unsigned char* src, size_t src_row_stride,
                           size_t src_img_stride, unsigned char* dst, int* hist, hipStream_t st);
 // K4a: pyramid levels 1..nlevels-1 of `img` into pyr.
+// source boxes of the rectification tiles (context creation; Tables::rect_box)
+void launch_rectify_boxes(const float2* map, int W, int H, int4* box, hipStream_t st);
+size_t rectify_box_count(int W, int H);
 void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
                     size_t img_stride, unsigned char* pyr, hipStream_t st,
                     unsigned char* level0_copy = nullptr);
