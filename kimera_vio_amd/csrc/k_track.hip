@@ -431,7 +431,8 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
   // on XCD b & 7).  Otherwise (component calls) blockIdx = (point, stream).
   // part (use_order bits 1-2): 0 = all points of the stream, 1 = the first npts_old (keypoints that were already tracked
   // in frame k-1), 2 = the rest (frame k-1's new corners): the split launch of the pipelined step
-  const int part = use_order >> 1;
+  const int part = (use_order >> 1) & 3;
+  const bool want_err = !(use_order & 8);   // bit 3: the caller does not read the error output (the front-end step)
   use_order &= 1;
   int s, rank;
   if (use_order) {
@@ -767,6 +768,10 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
         status = 0;
         continue;
       }
+      // (the window test above is part of the tracking result -- calcOpticalFlowPyrLK clears the status there whenever
+      // an error array is passed, and the reference passes one, Tracker.cpp:137-139 -- the error itself is an output
+      // nobody reads in the front-end step: Tracker::featureTracking drops the vector)
+      if (!want_err) continue;
       const float aa = np.x - inx, bb = np.y - iny;
       lk_weights(aa, bb, &iw00, &iw01, &iw10, &iw11);
       wq0 = pack_lo16(iw00, iw01);
@@ -1216,14 +1221,16 @@ bool lk_supports_parts(const KParams& P) {
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order, int part) {
+               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order, int part, bool want_err) {
   if (max_pts <= 0) return;
   // KVFE_LK_ORDER=1 (measured, NOT the default): dispatch the points by the iterations they took in the previous frame,
   // slowest first and rank-major over the streams, so that the launch's tail of slow points starts early.  Bit-exact
   // (158 GPU tests), but the count of the previous frame does not predict this frame's: 0.555 ms against 0.547 ms
   // per 64-stream launch in table order.
   static const bool order_on = std::getenv("KVFE_LK_ORDER") != nullptr;
-  const int ord = part ? (part << 1) : (use_order && order_on ? 1 : 0);   // (the kernel's use_order argument: bit 0 | part << 1)
+  // (the kernel's use_order argument: bit 0 | part << 1 | no error output << 3; KVFE_LK_ERR=1: always computed, A/B switch)
+  static const bool force_err = std::getenv("KVFE_LK_ERR") != nullptr;
+  const int ord = (part ? (part << 1) : (use_order && order_on ? 1 : 0)) | (want_err || force_err ? 0 : 8);
   const dim3 grid(max_pts, P.B), block(64);
 #define KVFE_LK_SYS(WINSZ)                                                                      \
   hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, (ord & 1) ? dim3((unsigned)max_pts * P.B) : grid, block, 0, st, P, prev_img, prev_row_stride,    \

@@ -132,6 +132,8 @@ struct kvfe_ctx {
   hipEvent_t ev_prep = nullptr, ev_lknew = nullptr;  // split tracking: first part gathered (main) / second part tracked (side)
   bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
   bool split_lk = false;                             // KVFE_LK_SPLIT: see do_step
+  bool fork_swap = false;                            // few streams: the corner refinement stays on the main stream (do_step)
+  bool chain_pending = false;                        // fork_swap: the side stream's outlier rejection has not been joined yet
   bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
   std::vector<int> prof_pending;
   double prof_ms[ST_COUNT] = {};
@@ -201,6 +203,7 @@ inline void join_tail(kvfe_ctx* c) {
     hipStreamWaitEvent(c->stream, c->ev_tail, 0);
     c->tail_pending = false;
     c->commit_pending = false;   // (the tail follows the commit on the side stream)
+    c->chain_pending = false;    // (... and the side stream's part of the fork)
   }
   if (c)
     for (kvfe_ctx* ch : c->children) join_tail(ch);
@@ -939,6 +942,11 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // (launch_detect_state): their part starts right behind the pyramid.  Frame k-1's NEW corners come out of the corner
   // refinement on the side stream: they are gathered and tracked THERE, behind the previous step's tail and next to the
   // first part -- the corner refinement (40 dependent iterations per corner) is off the critical path.
+  if (c->chain_pending) {   // fork_swap: the previous step's outlier rejections ran on the side stream (landmarks of frame k-1)
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_main, 0));
+    c->chain_pending = false;
+    prof_break(c);
+  }
   const bool split = c->split_lk && c->commit_pending && c->prev_left;
   if (c->commit_pending && !split) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
@@ -952,13 +960,13 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_prep, 0));
     launch_track_prepare(P, c->T, KM1, b.ss, b.lk, sd, 2);
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride, img_stride,
-              b.pyr[pc], b.lk, std::min(c->pts_bound, detect_new_bound(P)), sd, false, 2);
+              b.pyr[pc], b.lk, std::min(c->pts_bound, detect_new_bound(P)), sd, false, 2, false);
     HIPCHK(c, hipEventRecord(c->ev_lknew, sd));
     slot_release.side_used = true;
   }
   if (c->prev_left)
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, !split, split ? 1 : 0);
+              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, !split, split ? 1 : 0, false);
   prof_end(c, ST_TRACK, st);
   if (split) {   // (recorded behind the previous step's tail on the side stream: joins both)
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_lknew, 0));
@@ -1040,31 +1048,37 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // do not change that.)
   const bool state_on_main = c->side && c->own_stream && c->split_lk;
   if (state_on_main) launch_detect_state(P, K, b.ss, b.ds, st);
+  // fa: the stream of the corner refinement, fb: the stream of the rectify / match / reject chain.  Many streams: the
+  // chain is the throughput-bound side and stays on the main stream, the refinement forks off.  A few streams
+  // (fork_swap): every kernel is a latency, the refinement is on the loop that bounds the step and keeps the main
+  // stream -- no cross-stream hand-over on that loop -- and the chain forks off.
+  const bool swap = c->fork_swap && c->side && !early_rect;
+  hipStream_t fa = swap ? st : sd, fb = swap ? sd : st;
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
     slot_release.side_used = true;
   }
-  prof_begin(c, ST_SUBPIX, sd);
-  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, state_on_main ? 2 : 1, sd);
-  prof_end(c, ST_SUBPIX, sd);
-  if (c->side && c->own_stream) {
-    HIPCHK(c, hipEventRecord(c->ev_commit, sd));
-    c->commit_pending = true;
+  prof_begin(c, ST_SUBPIX, fa);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, state_on_main ? 2 : 1, fa);
+  prof_end(c, ST_SUBPIX, fa);
+  if (c->side && (c->own_stream || swap)) {
+    HIPCHK(c, hipEventRecord(c->ev_commit, fa));
+    c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
   }
   if (!all_early) {
-    prof_begin(c, ST_RECTIFY, st);
+    prof_begin(c, ST_RECTIFY, fb);
     const unsigned char* srcs[2] = {left, right};
-    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, st,
+    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, fb,
                    early_rect ? b.ss.in_force_kf : nullptr);
-    prof_end(c, ST_RECTIFY, st);
+    prof_end(c, ST_RECTIFY, fb);
   }
   if (early_rect) HIPCHK(c, hipStreamWaitEvent(st, c->ev_mono, 0));   // the pairs rectified at the start of the step
-  prof_begin(c, ST_STEREO, st);
-  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, st);
-  prof_end(c, ST_STEREO, st);
+  prof_begin(c, ST_STEREO, fb);
+  launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, fb);
+  prof_end(c, ST_STEREO, fb);
   // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387)
-  prof_begin(c, ST_RANSAC_STEREO, st);
+  prof_begin(c, ST_RANSAC_STEREO, fb);
   if (P.use_ransac) {
     // (the device's own test, rs_rot_is_identity: a stream without a usable gyro rotation takes the 3-point problem)
     bool need_arun = !P.ransac_1pt_stereo;
@@ -1077,17 +1091,23 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
       }
       need_arun = ident;
     }
-    launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, st, need_arun);
+    launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, fb, need_arun);
   }
   // outlierRejectionPnP(*stereoFrame_k_) (:389-399): after the stereo rejection, before detection
-  if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, st);
-  prof_end(c, ST_RANSAC_STEREO, st);
-  // the tail -- stereo matching of the new corners, finalisation -- follows the corner refinement on ITS stream (no
-  // cross-stream hand-over on the critical path); the main stream's part of the fork is awaited there, the tail is
-  // joined by the next step after its pyramid (or by kvfe_synchronize / kvfe_frontend_get_output)
+  if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, fb);
+  prof_end(c, ST_RANSAC_STEREO, fb);
+  // the tail -- stereo matching of the new corners, finalisation -- runs on the side stream behind both parts of the
+  // fork (the part on the main stream is awaited there); it is joined by the next step before its keyframe decision
+  // (or by kvfe_synchronize / kvfe_frontend_get_output)
   if (c->side) {
-    HIPCHK(c, hipEventRecord(c->ev_main, st));
-    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_main, 0));
+    if (swap) {
+      HIPCHK(c, hipEventRecord(c->ev_main, sd));            // the rejections are done: frame k's landmarks are final
+      c->chain_pending = true;
+      HIPCHK(c, hipStreamWaitEvent(sd, c->ev_commit, 0));   // the refined new corners (main stream)
+    } else {
+      HIPCHK(c, hipEventRecord(c->ev_main, st));
+      HIPCHK(c, hipStreamWaitEvent(sd, c->ev_main, 0));
+    }
   }
   prof_begin(c, ST_STEREO_NEW, sd);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, sd);
@@ -1311,6 +1331,10 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
       s = KVFE_ERR_HIP;
     const char* sp = std::getenv("KVFE_LK_SPLIT");
     c->split_lk = (sp ? std::atoi(sp) != 0 : false) && c->own_stream && lk_supports_parts(c->P);
+    // a few streams are latency bound: the loop refinement -> tracking -> keyframe decision -> detection -> refinement
+    // is what a step costs, so it stays on ONE stream and the rectify / match / reject chain takes the side stream
+    const char* fs = std::getenv("KVFE_FORK_SWAP");
+    c->fork_swap = (fs ? std::atoi(fs) != 0 : c->P.B <= 4) && c->own_stream && !c->split_lk && !c->P.mono;
   }
   if (s != KVFE_OK) {
     std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
@@ -2315,6 +2339,9 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
     c->step_done_valid[(n - 1) % 4] = true;
   } else if (dep >= 0 && c->step_done_valid[dep % 4]) {
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->step_done[dep % 4], 0));
+    // fork_swap: rectification (the other reader of a frame's slots) runs on the side stream and is not covered by the
+    // main stream's step_done; the side stream's latest "chain done" event is behind every earlier one
+    if (c->fork_swap && c->chain_pending) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_main, 0));
   }
   unsigned char* ul = eq ? b.eq_in[0] : dl;
   unsigned char* ur = eq ? b.eq_in[1] : dr;

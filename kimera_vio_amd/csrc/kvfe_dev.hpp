@@ -265,7 +265,8 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order = false, int part = 0);
+               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order = false, int part = 0,
+               bool want_err = true);
 bool lk_supports_parts(const KParams& P);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
