@@ -282,12 +282,13 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
             lk_ms = stages["lk_track"]["ms_total"] / ns
             vi = valu_issue(valu_ctx[0], "lk_kernel", lk_ms, valu_ctx[1], valu_ctx[2])
             if vi:   # the largest kernel of the step is sparse (no HBM roofline); its VALU issue floor is reported, but the
-                # launch is bound by the issue of ALL its instructions (profiles/r2_v5_lk_analysis.md)
+                # launch is bound by more than that count (profiles/r3_analysis.md)
                 res["largest_kernel"] = {"kernel": "lk_track", "avg_launch_ms": round(lk_ms, 5),
-                                         "bound": "total instruction issue (one instruction of any category per SIMD "
-                                                  "and 4-cycle slot: SQ_ACTIVE_INST_ANY 89 %, 6.9 k instructions per point "
-                                                  "-> 77-80 points/us at any occupancy) + a 10-13 % tail of non-converging "
-                                                  "points; profiles/r2_v5_lk_analysis.md",
+                                         "bound": "vector instruction issue weighted by instruction class (2.4 cycles for plain "
+                                                  "VOP2 float / integer, 3.7-3.9 for everything else: profiles/r3_ubench_valu_rate.txt) "
+                                                  "-- 4.9 k vector instructions per point, a third of them in the sequential float "
+                                                  "chains OpenCV's summation order dictates -- plus LDS waits (27 % of the wave cycles) "
+                                                  "and a 10-13 % tail of non-converging points; profiles/r3_analysis.md",
                                          "valu_issue": vi}
         res["stream_groups"] = g
     return res
