@@ -1077,8 +1077,15 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_STEREO, fb);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, fb);
   prof_end(c, ST_STEREO, fb);
-  // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387)
-  prof_begin(c, ST_RANSAC_STEREO, fb);
+  // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387).  Its results (right-keypoint
+  // statuses of the outliers, the stereo pose and status; the PnP pose) are read by the tail only -- the landmark removal
+  // that the next step's tracking reads is the mono rejection's -- so it runs at the head of the tail on the side stream,
+  // off the main stream's critical path (-1.2 % step time on four A/B pairs, +7 % on configs[4]; KVFE_RANSAC_TAIL=0
+  // puts it back on the main stream; profiles/r3_analysis.md)
+  static const bool ransac_tail_env = !(std::getenv("KVFE_RANSAC_TAIL") && std::atoi(std::getenv("KVFE_RANSAC_TAIL")) == 0);
+  const bool ransac_tail = ransac_tail_env && c->side && !swap;
+  auto stereo_rejection = [&](hipStream_t rs) -> kvfe_status {
+  prof_begin(c, ST_RANSAC_STEREO, rs);
   if (P.use_ransac) {
     // (the device's own test, rs_rot_is_identity: a stream without a usable gyro rotation takes the 3-point problem)
     bool need_arun = !P.ransac_1pt_stereo;
@@ -1091,11 +1098,14 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
       }
       need_arun = ident;
     }
-    launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, fb, need_arun);
+    launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, rs, need_arun);
   }
   // outlierRejectionPnP(*stereoFrame_k_) (:389-399): after the stereo rejection, before detection
-  if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, fb);
-  prof_end(c, ST_RANSAC_STEREO, fb);
+  if (P.use_pnp && P.use_ransac) launch_pnp_frontend(P, c->T, K, b.st, b.ss, b.rs, rs);
+  prof_end(c, ST_RANSAC_STEREO, rs);
+  return KVFE_OK;
+  };
+  if (!ransac_tail) TRY(stereo_rejection(fb));
   // the tail -- stereo matching of the new corners, finalisation -- runs on the side stream behind both parts of the
   // fork (the part on the main stream is awaited there); it is joined by the next step before its keyframe decision
   // (or by kvfe_synchronize / kvfe_frontend_get_output)
@@ -1109,6 +1119,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
       HIPCHK(c, hipStreamWaitEvent(sd, c->ev_main, 0));
     }
   }
+  if (ransac_tail) TRY(stereo_rejection(sd));
   prof_begin(c, ST_STEREO_NEW, sd);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, sd);
   prof_end(c, ST_STEREO_NEW, sd);
