@@ -1330,10 +1330,11 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     s = KVFE_ERR_HIP;
   static const bool no_side = std::getenv("KVFE_NO_SIDE_STREAM") != nullptr;
   if (s == KVFE_OK && alloc_frontend && !no_side) {
-    // the side stream runs at the device's highest stream priority: the corner refinement on it is the longer side of
-    // the fork and its tail has to fit beside the next tracking launch (+0.5 % on the 64-stream step, +2 % on
-    // kf_realistic, two A/B pairs on one box; KVFE_SIDE_PRIO=0: default priority)
-    static const bool side_prio = !(std::getenv("KVFE_SIDE_PRIO") && std::atoi(std::getenv("KVFE_SIDE_PRIO")) == 0);
+    // KVFE_SIDE_PRIO=1: the side stream at the device's highest stream priority.  Measured: +0.5 ... 0.8 % on the
+    // 64-stream step (the corner refinement on it is the longer side of the fork), but the rectification that runs
+    // beside it on the main stream takes 0.08 instead of 0.06 ms -- the dense kernel pays for the latency-bound one;
+    // not the default
+    static const bool side_prio = std::getenv("KVFE_SIDE_PRIO") && std::atoi(std::getenv("KVFE_SIDE_PRIO")) != 0;
     int prio_least = 0, prio_greatest = 0;
     if (side_prio) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if ((side_prio ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest)
