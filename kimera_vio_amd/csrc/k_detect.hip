@@ -1897,6 +1897,9 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
 // cv::undistortPoints of one pixel (double), shared with k_stereo.hip via kvfe_undistort.inl
 #include "kvfe_undistort.inl"
 
+// KVFE_SUBPIX_STATS=1 (debugging aid): per-corner cycle counts of the refinement launches, printed at exit
+__device__ unsigned long long kvfe_subpix_stats[8];   // corners, sum cycles, max cycles, launches' first/last stamp
+
 template <int WIN, int NW>
 __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Tables T,
                                                            const unsigned char* __restrict__ img,
@@ -1911,12 +1914,22 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
   const int n_new = D.n_new[s];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x;
+  const bool stats = (append & 16) != 0;
+  append &= 15;
   for (int ci = blockIdx.y; ci < n_new; ci += gridDim.y) {
   float2 c = D.newc[(size_t)s * P.acap + ci];
+  const unsigned long long t_begin = stats ? __builtin_readcyclecounter() : 0ull;
   if (P.subpix_enable) {
     __syncthreads();   // (the previous corner's readers of the LDS areas are done)
     c = corner_subpix_wave<WIN, NW>(img + (size_t)s * img_stride, row_stride, P.W, P.H, c, P.subpix_win,
                                P.subpix_iters, P.subpix_eps2, T.subpix_mask, lds_raw, lane);
+  }
+  if (stats && lane == 0) {
+    const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+    atomicAdd(&kvfe_subpix_stats[0], 1ull);
+    atomicAdd(&kvfe_subpix_stats[1], dt);
+    atomicMax(&kvfe_subpix_stats[2], dt);
+    atomicAdd(&kvfe_subpix_stats[3 + (dt < 100000 ? 0 : (dt < 200000 ? 1 : (dt < 400000 ? 2 : 3)))], 1ull);
   }
   if (lane == 0) {
     if (append) {
@@ -1994,20 +2007,36 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   // kernel).  A grid sized to what the device holds at once, every block walking ~10 corners of its stream, was measured:
   // -24 % on kf_realistic (276 corners per stream) -- the iteration counts of the corners differ too much for a static
   // assignment, the dispatcher's dynamic one wins; the blocks without a corner now trail the launch instead of leading it
-  const int slots = bound;
+  // (KVFE_SUBPIX_SLOTS: fewer slots than the bound -- blocks then walk their stream's corners with the stride of the grid)
+  static const int slots_env = std::getenv("KVFE_SUBPIX_SLOTS") ? std::atoi(std::getenv("KVFE_SUBPIX_SLOTS")) : 0;
+  const int slots = slots_env > 0 ? std::min(bound, slots_env) : bound;
   const dim3 grid(P.B, slots);
+  static const bool stats_on = std::getenv("KVFE_SUBPIX_STATS") != nullptr;
+  const int kappend = append | (stats_on ? 16 : 0);   // (bit 4: per-corner cycle statistics)
+  if (stats_on) {
+    static bool reg = false;
+    if (!reg) {
+      reg = true;
+      std::atexit([] {
+        unsigned long long h[8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_subpix_stats), sizeof(h)) == hipSuccess && h[0])
+          std::fprintf(stderr, "KVFE_SUBPIX_STATS corners %llu, cycles per corner: mean %.0f max %llu; < 100 k: %llu, < 200 k: %llu, < 400 k: %llu, more: %llu\n",
+                       h[0], (double)h[1] / (double)h[0], h[2], h[3], h[4], h[5], h[6]);
+      });
+    }
+  }
   if (P.subpix_win == 10 && nw == 4)
     hipLaunchKernelGGL((subpix_append_kernel<10, 4>), grid, dim3(256), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, append);
+                       row_stride, img_stride, k, S, D, kappend);
   else if (P.subpix_win == 10 && nw == 2)
     hipLaunchKernelGGL((subpix_append_kernel<10, 2>), grid, dim3(128), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, append);
+                       row_stride, img_stride, k, S, D, kappend);
   else if (P.subpix_win == 10)
     hipLaunchKernelGGL((subpix_append_kernel<10, 1>), grid, dim3(64), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, append);
+                       row_stride, img_stride, k, S, D, kappend);
   else
     hipLaunchKernelGGL((subpix_append_kernel<0, 1>), grid, dim3(64), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, append);
+                       row_stride, img_stride, k, S, D, kappend);
   if (append)   // (append == 2: the state half has been launched by launch_detect_state)
     hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, append == 2 ? 2 : 3);
 }

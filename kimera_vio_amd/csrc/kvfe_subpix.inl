@@ -143,6 +143,70 @@ static __device__ __forceinline__ void rect_subpix_from_stage(const unsigned cha
   }
 }
 
+// border branch of cv::getRectSubPix (the window leaves the image: rows and columns are replicated with OpenCV's
+// r.x / r.width / r.y / r.height rules, rect_subpix_8u32f above) reading the source from the LDS stage, whose window
+// [sx0, sx0 + rs) x [sy0, sy0 + rs) lies inside the image and holds every row and column the branch can address.
+// New corners are found where new scene content enters the image, i.e. near its border: without this a border
+// corner reads global memory in every one of its up to 40 dependent iterations and bounds the launch.
+template <int MAXP, int NTHR = 64>
+static __device__ __forceinline__ void rect_subpix_border_from_stage(const unsigned char* stage, int rs, int sx0,
+                                                                     int sy0, int W, int H, float ccx, float ccy,
+                                                                     int ipx, int ipy, int n, const int (&eij)[MAXP],
+                                                                     float* dst, int lane) {
+  const float a = ccx - ipx, b = ccy - ipy;
+  const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+  const float b1 = 1.f - b, b2 = b;
+  int rx, rw, ry, rh;
+  if (ipx >= 0)
+    rx = 0;
+  else {
+    rx = -ipx;
+    if (rx > n) rx = n;
+  }
+  if (ipx < W - n)
+    rw = n;
+  else {
+    rw = W - ipx - 1;
+    if (rw < 0) rw = 0;
+  }
+  ry = ipy >= 0 ? 0 : -ipy;
+  if (ipy < H - n)
+    rh = n;
+  else {
+    rh = H - ipy - 1;
+    if (rh < 0) rh = 0;
+  }
+  const int row0 = ipy >= 0 ? ipy : 0;
+  auto col = [&](int jj) {
+    const int c = ipx + jj;
+    return (c < 0 ? 0 : (c > W - 1 ? W - 1 : c)) - sx0;
+  };
+#pragma unroll
+  for (int t = 0; t < MAXP; t++) {
+    const int e = lane + NTHR * t;
+    if (e < n * n) {
+      const int i = eij[t] >> 8, j = eij[t] & 255;
+      int adv = min(i, rh) - min(i, ry);
+      if (adv < 0) adv = 0;
+      int row = row0 + adv;
+      int row2 = (i < ry || i >= rh) ? row : row + 1;
+      row = min(max(row, 0), H - 1);
+      row2 = min(max(row2, 0), H - 1);
+      const unsigned char* S = stage + (row - sy0) * rs;
+      const unsigned char* S2 = stage + (row2 - sy0) * rs;
+      float v;
+      if (j < rx) {
+        v = S[col(rx)] * b1 + S2[col(rx)] * b2;
+      } else if (j >= rw) {
+        v = S[col(rw)] * b1 + S2[col(rw)] * b2;
+      } else {
+        v = S[col(j)] * a11 + S[col(j + 1)] * a12 + S2[col(j)] * a21 + S2[col(j + 1)] * a22;
+      }
+      dst[e] = v;
+    }
+  }
+}
+
 // refines one corner; all 64 lanes of the wave call it with identical arguments.
 // LDS (subpix_geom): terms 5 x ntp float64 | patch (2w+3)^2 float | stage rs^2 bytes.
 // Latency matters here (40 strictly sequential iterations for a corner that does not converge):
@@ -301,28 +365,29 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
       const int ipx = cv_floorf(ccx), ipy = cv_floorf(ccy);
       const bool interior = 0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H;
       bool use_stage = false;
-      if (interior) {
-        // footprint: columns ipx .. ipx+pw, rows ipy .. ipy+pw
-        if (!staged || ipx < sx0 || ipy < sy0 || ipx + pw >= sx0 + rs || ipy + pw >= sy0 + rs) {
+      // footprint inside the image: columns fx0 .. fx1, rows fy0 .. fy1 (interior: ipx .. ipx+pw, ipy .. ipy+pw; a
+      // window that leaves the image addresses the clamped range, see rect_subpix_border_from_stage)
+      const int fx0 = min(max(ipx, 0), W - 1), fx1 = min(max(ipx + pw, 0), W - 1);
+      const int fy0 = min(max(ipy, 0), H - 1), fy1 = min(max(ipy + pw, 0), H - 1);
+      if (W >= rs && H >= rs) {
+        if (!staged || fx0 < sx0 || fy0 < sy0 || fx1 >= sx0 + rs || fy1 >= sy0 + rs) {
           const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
-          if (nx0 >= 0 && ny0 >= 0) {
-            __syncthreads();
-            for (int e = lane; e < rs * rs; e += NTHR) {
-              const int y = e / rs, x = e - y * rs;
-              stage[e] = img[(size_t)(ny0 + y) * step + nx0 + x];
-            }
-            __syncthreads();
-            sx0 = nx0;
-            sy0 = ny0;
-            staged = true;
-          } else {
-            staged = false;
+          __syncthreads();
+          for (int e = lane; e < rs * rs; e += NTHR) {
+            const int y = e / rs, x = e - y * rs;
+            stage[e] = img[(size_t)(ny0 + y) * step + nx0 + x];
           }
+          __syncthreads();
+          sx0 = nx0;
+          sy0 = ny0;
+          staged = true;
         }
-        use_stage = staged && ipx >= sx0 && ipy >= sy0 && ipx + pw < sx0 + rs && ipy + pw < sy0 + rs;
+        use_stage = staged && fx0 >= sx0 && fy0 >= sy0 && fx1 < sx0 + rs && fy1 < sy0 + rs;
       }
-      if (use_stage)
+      if (use_stage && interior)
         rect_subpix_from_stage<MAXP, NTHR>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
+      else if (use_stage)
+        rect_subpix_border_from_stage<MAXP, NTHR>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
       else
         rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane, NTHR);
     }
