@@ -942,7 +942,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // (launch_detect_state): their part starts right behind the pyramid.  Frame k-1's NEW corners come out of the corner
   // refinement on the side stream: they are gathered and tracked THERE, behind the previous step's tail and next to the
   // first part -- the corner refinement (40 dependent iterations per corner) is off the critical path.
-  if (c->chain_pending) {   // fork_swap: the previous step's outlier rejections ran on the side stream (landmarks of frame k-1)
+  if (c->chain_pending) {   // fork_swap: the previous step's rectify / match / reject chain ran on the side stream
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_main, 0));
     c->chain_pending = false;
     prof_break(c);
@@ -1111,7 +1111,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // (or by kvfe_synchronize / kvfe_frontend_get_output)
   if (c->side) {
     if (swap) {
-      HIPCHK(c, hipEventRecord(c->ev_main, sd));            // the rejections are done: frame k's landmarks are final
+      HIPCHK(c, hipEventRecord(c->ev_main, sd));            // the chain (last reader of this frame's image slots) is done
       c->chain_pending = true;
       HIPCHK(c, hipStreamWaitEvent(sd, c->ev_commit, 0));   // the refined new corners (main stream)
     } else {
