@@ -29,6 +29,11 @@ def pytest_sessionstart(session):
     oso = os.path.join(ROOT, "oracle", "liboracle_kvfe.so")
     if not os.path.exists(oso):
         subprocess.run(["make", "-C", os.path.dirname(oso)], check=True, capture_output=True)
+    # GPU session: the first touch of a freshly provisioned box happens in a throw-away process (kimera_vio_amd/_warmup.py)
+    m = session.config.getoption("-m") or ""
+    if "gpu" in m and "not gpu" not in m:
+        from kimera_vio_amd._warmup import warm_up_device
+        warm_up_device()
 
 
 def pytest_collection_modifyitems(config, items):
