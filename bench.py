@@ -313,10 +313,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libkvfe has no CPU fallback")
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
     if local_rank == 0:   # first touch of a freshly provisioned box in a throw-away process (kimera_vio_amd/_warmup.py)
         from kimera_vio_amd._warmup import warm_up_device
         warm_up_device(attempts=2)
+    torch.cuda.set_device(local_rank)
     # under torchrun (also with ONE rank) the process group is RCCL: the barrier and the timing reduction then run the
     # same collective code on 1 GPU as on 8 (tests/test_gpu_rccl_r3.py runs exactly this at world size 1)
     under_torchrun = "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
