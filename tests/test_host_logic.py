@@ -330,3 +330,13 @@ def test_cpp_adapter_rectified_body_poses_and_relative_pose(tmp_path):
     P1 = np.array(rect.P1).reshape(3, 4)
     assert got["stereo_calib"].tolist() == [P1[0, 0], P1[1, 1], P1[0, 1], P1[0, 2], P1[1, 2], rect.baseline]
     assert abs(rect.baseline - 0.110078) < 1e-5                      # tests/testStereoMatcher.cpp:148
+
+
+def test_device_warm_up_is_harmless_without_a_device():
+    """kimera_vio_amd/_warmup.py: the throw-away first touch of a GPU box reports failure (it does not raise, and it
+    does not hide anything: the caller's own kvfe_create still fails loudly) when there is no device"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    from kimera_vio_amd._warmup import warm_up_device
+    assert warm_up_device(attempts=1, timeout_s=120) is False
