@@ -876,6 +876,8 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
                                                        int fixed_need, int prof) {
   const int s = blockIdx.x;
   if (!(S.flags[s] & FLAG_DETECT)) return;
+  const bool use_rounds = (prof & 2) != 0;   // KVFE_SELECT_IMPL=1
+  prof &= 1;
   SEL_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // LDS carve-up: [xy u32 [LDS_SORT_CAP] when the blocked-pixel bitmap fits |] sortkeys [LDS_SORT_CAP] u64 |
@@ -1247,7 +1249,156 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     }
     __syncthreads();
     };
-    greedy(0, NL, 0);
+    // KVFE_SELECT_IMPL=1 (opt-in, round 3: written and checked against the sequential filter on the CPU --
+    // tests/test_select_rounds_algebra.py -- NOT yet measured on a GPU): the same filter by ROUNDS over all threads of the
+    // block instead of one wave walking the ranked list.  The accepted set is the lexicographically-first maximal
+    // independent set of the "closer than minDistance" graph in rank order; a candidate is decided as soon as all its
+    // stronger neighbours are:
+    //   test:    undecided r -- its pixel is blocked (disc of a corner accepted in an earlier round) -> rejected;
+    //            otherwise no candidate q < r within minDistance is undecided or pending -> pending;
+    //   commit:  pending -> accepted, disc marked;
+    // until nothing is undecided.  Inside a test phase a neighbour's state may be read from before or after its own
+    // test: undecided (0) and pending (3) both block, a stale 0 only costs a round.  Neighbours come from a grid of
+    // cells of side minDistance (3 x 3 cells, as the reference's own search); the real frames' 5 553 candidates take
+    // 180 k cycles in the sequential walk (457 cycles per accepted corner).
+    bool did_rounds = false;
+    if (use_rounds && !two_pass && md <= 32 && NL >= 1024 && W < 65536 && H < 65536) {
+      const int gw = (W + md - 1) / md, gh = (H + md - 1) / md, ncell = gw * gh;
+      const size_t bm_bytes = ((size_t)H * rw * 8 + 15) & ~(size_t)15;
+      const size_t need = (size_t)SEL_XY_BYTES + bm_bytes + (size_t)LDS_SORT_CAP * 5 + sizeof(int) * ((size_t)ncell + 2);
+      const long long avail_b = sel_bitmap_lds_bytes(W, H);
+      const size_t avail = (size_t)(avail_b > (long long)SEL_LDS_BITMAP_MIN ? avail_b : (long long)SEL_LDS_BITMAP_MIN);
+      if (need <= avail && ncell < 65536) {
+        did_rounds = true;
+        unsigned char* F = lds_raw + SEL_XY_BYTES + bm_bytes;
+        unsigned char* stt = F;                                                        // [NL] 0 undecided 1 accepted 2 rejected 3 pending
+        unsigned short* cidx = reinterpret_cast<unsigned short*>(F + LDS_SORT_CAP);    // [NL] cell of candidate r
+        unsigned short* items = cidx + LDS_SORT_CAP;                                   // [NL] ranks grouped by cell
+        int* cstart = reinterpret_cast<int*>(items + LDS_SORT_CAP);                    // [ncell + 1]
+        __shared__ int hwt[64];                                                        // half widths of the disc's rows
+        const unsigned mdiv = (unsigned)(((1ull << 21) + (unsigned)md - 1) / (unsigned)md);   // x / md = (x * mdiv) >> 21 for x < 2^16, md <= 32
+        auto div_md = [&](int v) -> int { return (int)(((unsigned long long)(unsigned)v * mdiv) >> 21); };
+        const int md2i = md * md;
+        for (int i = tid; i <= ncell; i += SEL_T) cstart[i] = 0;
+        if (tid < 2 * md - 1) {
+          const int dy = tid - (md - 1);
+          const int t = md2i - dy * dy;  // > 0
+          int h = (int)sqrtf((float)t);
+          while (h * h >= t) h--;
+          while ((h + 1) * (h + 1) < t) h++;
+          hwt[tid] = h;
+        }
+        __syncthreads();
+        for (int r = tid; r < NL; r += SEL_T) {
+          const unsigned c = xy[r];
+          const int ci = div_md((int)(c >> 16)) * gw + div_md((int)(c & 0xffffu));
+          cidx[r] = (unsigned short)ci;
+          stt[r] = 0;
+          atomicAdd(&cstart[ci + 1], 1);   // counts one slot up: the inclusive scan below leaves the cells' first items
+        }
+        __syncthreads();
+        {
+          const int per = (ncell + SEL_T) / SEL_T;   // ceil((ncell + 1) / SEL_T) entries per thread
+          const int b = min(tid * per, ncell + 1), e = min(b + per, ncell + 1);
+          int sum = 0;
+          for (int i = b; i < e; i++) sum += cstart[i];
+          int run = block_exclusive_scan(sum, wave_tot, nullptr);
+          for (int i = b; i < e; i++) {
+            run += cstart[i];
+            cstart[i] = run;
+          }
+        }
+        __syncthreads();
+        // fill: the cursor of a cell is its own start; afterwards cstart[i] is the END of cell i (= the start of i + 1)
+        for (int r = tid; r < NL; r += SEL_T) items[atomicAdd(&cstart[cidx[r]], 1)] = (unsigned short)r;
+        __syncthreads();
+        for (;;) {
+          if (tid == 0) sh_flag = 0;
+          __syncthreads();
+          for (int r = tid; r < NL; r += SEL_T) {
+            if (stt[r] != 0) continue;
+            const unsigned c = xy[r];
+            const int x = (int)(c & 0xffffu), y = (int)(c >> 16);
+            if ((bm[y * rw + (x >> 6)] >> (x & 63)) & 1ull) {
+              stt[r] = 2;
+              continue;
+            }
+            const int ci = cidx[r];
+            const int cy = div_md(y), cx = ci - cy * gw;
+            bool wait = false;
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, gh - 1) && !wait; yy++)
+              for (int xx = max(cx - 1, 0); xx <= min(cx + 1, gw - 1) && !wait; xx++) {
+                const int cell = yy * gw + xx;
+                const int kb = cell ? cstart[cell - 1] : 0, ke = cstart[cell];
+                for (int k = kb; k < ke; k++) {
+                  const int q = items[k];
+                  if (q >= r) continue;
+                  const unsigned char sq = stt[q];
+                  if (sq != 0 && sq != 3) continue;
+                  const unsigned cq = xy[q];
+                  const int dx = x - (int)(cq & 0xffffu), dy = y - (int)(cq >> 16);
+                  if (dx * dx + dy * dy < md2i) {
+                    wait = true;
+                    break;
+                  }
+                }
+              }
+            if (wait)
+              sh_flag = 1;
+            else
+              stt[r] = 3;
+          }
+          __syncthreads();
+          for (int r = tid; r < NL; r += SEL_T) {
+            if (stt[r] != 3) continue;
+            stt[r] = 1;
+            const unsigned c = xy[r];
+            const int x = (int)(c & 0xffffu), y = (int)(c >> 16);
+            for (int row = 0; row < 2 * md - 1; row++) {
+              const int yy = y + row - (md - 1);
+              const int h = hwt[row];
+              if (h < 0 || (unsigned)yy >= (unsigned)H) continue;
+              const int x0 = max(x - h, 0), x1 = min(x + h, W - 1);
+              const int sh = x0 & 63;
+              const unsigned long long span = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 63 ones
+              unsigned long long* pw = &bm[yy * rw + (x0 >> 6)];
+              __hip_atomic_fetch_or(pw, span << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_or(pw + 1, (span >> 1) >> (63 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          __syncthreads();
+          const int more = sh_flag;
+          __syncthreads();   // (everybody has read the flag before the next round resets it)
+          if (!more) break;
+        }
+        // accepted ranks, ascending, to the head of the list (through the cell arrays, which are dead now)
+        {
+          unsigned* tmp = reinterpret_cast<unsigned*>(cidx);   // cidx + items: room for LDS_SORT_CAP entries
+          const int per = (NL + SEL_T - 1) / SEL_T;
+          const int b = min(tid * per, NL), e = min(b + per, NL);
+          int cnt = 0;
+          for (int r = b; r < e; r++) cnt += stt[r] == 1 ? 1 : 0;
+          int total = 0;
+          int pos = block_exclusive_scan(cnt, wave_tot, &total);
+          unsigned keepv[LDS_SORT_CAP / SEL_T];   // (xy[r] is read before the barrier: tmp aliases nothing of xy, but
+          int nk = 0;                             //  the cell arrays it overwrites are read by nobody any more)
+          for (int r = b; r < e; r++)
+            if (stt[r] == 1 && nk < LDS_SORT_CAP / SEL_T) keepv[nk++] = xy[r];
+          __syncthreads();
+          for (int i = 0; i < nk; i++) tmp[pos + i] = keepv[i];
+          __syncthreads();
+          int n_acc = total;
+          if (P.max_corners > 0) n_acc = min(n_acc, P.max_corners);
+          for (int i = tid; i < n_acc; i += SEL_T) xy[i] = tmp[i];
+          if (tid == 0) {
+            sh_cnt = n_acc;
+            sh_flag = (P.max_corners > 0 && total >= P.max_corners) ? 1 : 0;
+          }
+          __syncthreads();
+        }
+      }
+    }
+    if (!did_rounds) greedy(0, NL, 0);
     A = sh_cnt;
     if (two_pass && !sh_flag) {
       // second pass: the keys of the bins from cut_bin on that the bitmap has not blocked yet
@@ -1857,7 +2008,9 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
     }
   }
   static const bool prof = std::getenv("KVFE_SELECT_PROF") != nullptr;
-  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need, prof ? 1 : 0);
+  static const bool rounds = std::getenv("KVFE_SELECT_IMPL") && std::atoi(std::getenv("KVFE_SELECT_IMPL")) == 1;
+  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need,
+                     (prof ? 1 : 0) | (rounds ? 2 : 0));
   if (prof) {
     static double acc[16];
     static long n = 0;
