@@ -274,11 +274,20 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
                     vi = valu_issue(valu_ctx[0], PMC_NAMES[name][0], avg_ms, valu_ctx[1], valu_ctx[2])   # (all launches of the stage)
                     if vi:
                         kernels[-1]["valu_issue"] = vi
-        # the dominant dense kernel = the one that moves the most algorithmic bytes per launch (rectification: 4 N B;
-        # by launch time it trades places with the min-eigenvalue kernel from box to box, both ~0.08 ms in the step)
-        kernels.sort(key=lambda r: (-r["alg_bytes_per_launch"], -r["avg_launch_ms"]))
+        # FIXED RULE (rounds 1, 2 and 4 on; round 3's last commit had switched it): `roofline` = the dense kernel with the
+        # LONGEST launch inside the step; `roofline_dense_weighted` = sum of algorithmic bytes / sum of launch times of
+        # all dense kernels of the step (the time-weighted fraction); `roofline_kernels` lists every one of them
+        kernels.sort(key=lambda r: (-r["avg_launch_ms"], -r["alg_bytes_per_launch"]))
         res["roofline"] = dict(kernels[0]) if kernels else None
         res["roofline_kernels"] = kernels
+        if kernels:
+            tb = sum(k["alg_bytes_per_launch"] for k in kernels)
+            tt = sum(k["avg_launch_ms"] for k in kernels)
+            ach = tb / (tt * 1e-3) / 1e9
+            res["roofline_dense_weighted"] = {
+                "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 5), "alg_bytes": round(tb), "sum_launch_ms": round(tt, 5),
+                "kernels": [k["kernel"] for k in kernels]}
         res["stage_ms_per_step_summed_over_groups"] = {k: round(v["ms_total"] / ns * g, 5) for k, v in stages.items()}
         if pmc_leg is not None and valu_ctx and B == 64 and W == 752 and "lk_track" in stages:
             lk_ms = stages["lk_track"]["ms_total"] / ns
@@ -313,9 +322,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libkvfe has no CPU fallback")
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if local_rank == 0:   # first touch of a freshly provisioned box in a throw-away process (kimera_vio_amd/_warmup.py)
-        from kimera_vio_amd._warmup import warm_up_device
-        warm_up_device(attempts=2)
+    # first touch of a freshly provisioned box in a throw-away process (kimera_vio_amd/_warmup.py): EVERY local rank
+    # warms its own device (on an 8-GPU node each device is touched for the first time by its own rank)
+    from kimera_vio_amd._warmup import warm_up_device
+    warmed = warm_up_device(attempts=2, device=local_rank)
     torch.cuda.set_device(local_rank)
     # under torchrun (also with ONE rank) the process group is RCCL: the barrier and the timing reduction then run the
     # same collective code on 1 GPU as on 8 (tests/test_gpu_rccl_r3.py runs exactly this at world size 1)
@@ -363,8 +373,9 @@ def main():
                    "mode": args.mode, "use_ransac": p.use_ransac, "stream_groups": main_leg.get("stream_groups", 1),
                    "parallelism": f"streams x{world}"},
         "value_is": f"median of {args.repeats} timed regions of exactly {args.steps} steps each",
+        "device_warm_up_ok": bool(warmed),
     }
-    for k in ("repeats", "roofline", "roofline_kernels", "largest_kernel", "end_to_end_traffic",
+    for k in ("repeats", "roofline", "roofline_dense_weighted", "roofline_kernels", "largest_kernel", "end_to_end_traffic",
               "stage_ms_per_step_summed_over_groups", "host_enqueue_ms_per_step", "check"):
         if k in main_leg:
             result[k] = main_leg[k]

@@ -672,7 +672,11 @@ KVFE_API kvfe_status kvfe_synchronize(kvfe_ctx* ctx);
 
 /* StereoFrontendOutput (StereoVisionImuFrontend-definitions.h:25-91) reduced to
  * the arrays the hot path produces.  Caller allocates `capacity` entries per
- * array (NULL arrays are skipped); synchronises the context. */
+ * array (NULL arrays are skipped).
+ * Output side (round 4): the step itself packs every stream's output into one contiguous record and sends the
+ * records of the step to a pinned host ring slot in ONE device-initiated transfer (off the critical path: beside the
+ * next step's tracking launch); kvfe_frontend_get_output waits for that transfer of the LATEST step -- which implies
+ * that every kernel of the step has completed -- and copies out of pinned memory.  No blocking device copies. */
 typedef struct kvfe_frame_output {
   int32_t capacity;
   int32_t n_keypoints;          /* left_frame_.keypoints_.size()             */
@@ -719,6 +723,13 @@ KVFE_API kvfe_status kvfe_frontend_update_map(kvfe_ctx* ctx, int32_t stream, con
 
 KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,
                                               kvfe_frame_output* out);
+/* The same for the step `steps_back` steps before the latest one (0 = kvfe_frontend_get_output; at most
+ * KVFE_OUTPUT_RING - 1): waits for THAT step's record only, so a consumer reads frame k while frame k+1 is being
+ * processed -- how upstream hands StereoFrontendOutput to the back-end queue while the front-end thread goes on
+ * (PipelineModule.h:324-343). */
+#define KVFE_OUTPUT_RING 3
+KVFE_API kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* ctx, int32_t stream, int32_t steps_back,
+                                                 kvfe_frame_output* out);
 
 /* ------------------------------------------------------------------------- */
 /* Input side: what sits between the dataset / sensor and    */

@@ -19,20 +19,27 @@ G = os.path.join(%r, "tests", "golden")
 L = P.load_camera_params(os.path.join(G, "sensorLeft.yaml"))
 R = P.load_camera_params(os.path.join(G, "sensorRight.yaml"))
 p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
-c = F.Context(L, R, p, batch=1)
+c = F.Context(L, R, p, batch=1, device=%d)
 c.close()
 print("warm")
 """
 
 
-def warm_up_device(attempts: int = 3, timeout_s: int = 180) -> bool:
+def warm_up_device(attempts: int = 3, timeout_s: int = 180, device: int = 0) -> bool:
+    """True when a child process created and destroyed a context on `device`.  A failed attempt is reported on stderr
+    (return code and the tail of the child's stderr) -- it is retried, never hidden; the caller's own context creation
+    right afterwards is what fails loudly if the device really is unusable."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = _CODE % (root, root)
-    for _ in range(max(1, attempts)):
+    code = _CODE % (root, root, int(device))
+    for k in range(max(1, attempts)):
         try:
             r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s)
             if r.returncode == 0 and "warm" in r.stdout:
                 return True
-        except Exception:
-            pass
+            print(f"[kvfe warm-up] device {device}, attempt {k + 1}: rc={r.returncode} stderr tail: "
+                  f"{(r.stderr or '')[-400:]!r}", file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            print(f"[kvfe warm-up] device {device}, attempt {k + 1}: no answer within {timeout_s} s", file=sys.stderr)
+        except OSError as e:
+            print(f"[kvfe warm-up] device {device}, attempt {k + 1}: {e}", file=sys.stderr)
     return False

@@ -120,4 +120,82 @@ void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScra
   hipLaunchKernelGGL(mark_lost_tracks_kernel, dim3((max_pts + 255) / 256, P.B), dim3(256), 0, st, P, km1, lk);
 }
 
+// ---- output side (kvfe_dev.hpp "output side") ------------------------------------------------------------------------
+// One block per stream: the header by thread 0, the arrays by coalesced element copies.  `dst` is a device staging
+// buffer (many streams: the record then crosses PCIe on the output stream, beside the next step's tracking launch) or
+// the mapped pinned ring slot itself (a few streams: one launch less on the latency path).
+template <typename T>
+__device__ __forceinline__ void out_copy_arr(unsigned char* rec, size_t off, const T* __restrict__ src, size_t n) {
+  T* d = reinterpret_cast<T*>(rec + off);
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, StereoTab ST, StreamState S,
+                                                       unsigned char* __restrict__ dst, size_t rec_stride) {
+  const int s = blockIdx.x;
+  unsigned char* rec = dst + (size_t)s * rec_stride;
+  const int flags = S.flags[s];
+  const int n = min(K.count[s], P.kcap), m = min(S.n_meas[s], P.kcap);
+  const bool stereo = (flags & FLAG_STEREO) != 0;
+  const OutLayout L = out_layout(n, m, stereo);
+  if (threadIdx.x == 0) {
+    OutHeader* h = reinterpret_cast<OutHeader*>(rec);
+    h->n_keypoints = K.count[s];
+    h->flags = flags;
+    h->n_tracked = S.n_tracked[s];
+    h->n_detected = S.n_detected[s];
+    h->n_meas = S.n_meas[s];
+    h->trk_status[0] = S.trk_status[2 * s];
+    h->trk_status[1] = S.trk_status[2 * s + 1];
+    for (int i = 0; i < 6; i++) h->trk_counts[i] = S.trk_counts[6 * s + i];
+    h->pnp_status = S.pnp_status[s];
+    for (int i = 0; i < 3; i++) h->pnp_counts[i] = S.pnp_counts[3 * s + i];
+    h->frame_count = S.frame_count[s];
+    h->used_bytes = (unsigned long long)L.end;
+  } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 45) {
+    OutHeader* h = reinterpret_cast<OutHeader*>(rec);
+    const int i = threadIdx.x - 64;
+    if (i < 24) h->trk_pose[i] = S.trk_pose[24 * (size_t)s + i];
+    else if (i < 33) h->trk_info[i - 24] = S.trk_info[9 * (size_t)s + i - 24];
+    else h->pnp_pose[i - 33] = S.pnp_pose[12 * (size_t)s + i - 33];
+  }
+  const size_t so = (size_t)s * P.kcap;
+  out_copy_arr(rec, L.lmk, K.lmk + so, (size_t)n);
+  out_copy_arr(rec, L.age, K.age + so, (size_t)n);
+  out_copy_arr(rec, L.kp, K.kp + so, (size_t)n);
+  out_copy_arr(rec, L.versor, K.versor + so * 3, (size_t)n * 3);
+  if (stereo) {
+    out_copy_arr(rec, L.left_rect, ST.left_rect + so, (size_t)n);
+    out_copy_arr(rec, L.left_status, ST.left_status + so, (size_t)n);
+    out_copy_arr(rec, L.right_rect, ST.right_rect + so, (size_t)n);
+    out_copy_arr(rec, L.right_status, ST.right_status + so, (size_t)n);
+    out_copy_arr(rec, L.depth, ST.depth + so, (size_t)n);
+    out_copy_arr(rec, L.right_kp, ST.right_kp + so, (size_t)n);
+    out_copy_arr(rec, L.kp3d, ST.kp3d + so * 3, (size_t)n * 3);
+  }
+  out_copy_arr(rec, L.meas_lmk, S.meas_lmk + so, (size_t)m);
+  out_copy_arr(rec, L.meas, S.meas_uLuRv + so * 3, (size_t)m * 3);
+}
+
+void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, const StreamState& S, unsigned char* dst,
+                     size_t rec_stride, hipStream_t st) {
+  hipLaunchKernelGGL(out_pack_kernel, dim3((unsigned)P.B), dim3(256), 0, st, P, k, ST, S, dst, rec_stride);
+}
+
+// staging -> pinned host ring slot: the used bytes of every record (16-byte words; gaps between the arrays are not
+// initialised and not read), OUT_COPY_PARTS blocks per stream so that enough writes are in flight to fill the link
+constexpr int OUT_COPY_PARTS = 4;
+__global__ __launch_bounds__(256) void out_copy_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                       size_t rec_stride) {
+  const int s = blockIdx.x;
+  const uint4* a = reinterpret_cast<const uint4*>(src + (size_t)s * rec_stride);
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)s * rec_stride);
+  const size_t words = (size_t)(reinterpret_cast<const OutHeader*>(a)->used_bytes >> 4);
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < words; i += 256 * OUT_COPY_PARTS) d[i] = a[i];
+}
+
+void launch_out_copy(int B, const unsigned char* src, unsigned char* dst_host_mapped, size_t rec_stride, hipStream_t st) {
+  hipLaunchKernelGGL(out_copy_kernel, dim3((unsigned)B, OUT_COPY_PARTS), dim3(256), 0, st, src, dst_host_mapped, rec_stride);
+}
+
 }  // namespace kvfe

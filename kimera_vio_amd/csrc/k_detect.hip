@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
     const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int xcd_mode) {
+    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int xcd_mode, int run_skip) {
   // block -> (column strip, row strip, stream).  xcd_mode: a 1-D grid in which workgroup b (it runs on XCD b & 7: a
   // speed assumption only) takes the strips of the streams s = b & 7 (mod 8), so that the cache lines neighbouring
   // strips share -- 64-byte row segments out of 128-byte lines, the 3-column and 5-row overlaps -- meet in ONE L2.
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
   __syncthreads();
   unsigned long long needc0 = ~0ull, needc1 = ~0ull, needb0 = ~0ull, needb1 = ~0ull;   // wave-uniform
+  unsigned long long needp0 = ~0ull, needp1 = ~0ull;   // pixel rows somebody needs: bit q = row ys - 3 + q
   // detection mask: the cv::circle discs that touch this strip, rasterised into row bit-masks.  Lane = row of the strip
   // (two rows per lane for strips above 64 rows): the keypoints are tested 64 at a time, then every hit is replayed for all
   // rows at once from scalar registers -- no atomics, no per-row loop (the per-keypoint row loop of the first kernel
@@ -425,6 +426,10 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     };
     or3(U0, U1, needc0, needc1);
     or3(needc0, needc1, needb0, needb1);
+    // cov row c (bit c - ys + 2 of needb) reads the pixel rows c-1 .. c+1: bits q-2, q-1, q of needb -> bit q of needp
+    // (strip_rows <= 120: the highest cov bit is 123, nothing falls off the top)
+    needp0 = needb0 | (needb0 << 1) | (needb0 << 2);
+    needp1 = needb1 | (needb1 << 1) | (needb1 << 2) | (needb0 >> 63) | (needb0 >> 62);
   }
   __syncthreads();
 
@@ -613,6 +618,52 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // slots rotate with the row index: slot(r) = (r - r_first) % 3
   int r = r_first;
   fetch_mask(r - 2);   // (the first step's "previous" request)
+  if (run_skip) {
+    // RUNS OF NEEDED ROWS (round 4).  With a few hundred tracked keypoints and discs of radius min_distance a frame is
+    // almost entirely masked (the 600-feature benchmark streams: 3 % of the pixels pass the mask, a quarter of a strip's
+    // rows is needed by anybody), so the wave walks only the runs of pixel rows that some unmasked pixel needs -- it
+    // does not even fetch the others -- instead of stepping through every row and gating the stages.  A run restarts the
+    // pipeline: three row requests, the mask word one step ahead; the slots keep their phase (a run starts on a multiple
+    // of three steps from r_first, at most two rows early), and what they hold from before the gap is never read: a
+    // needed cov / box / local-maximum row has all of its source rows inside the same run (needp is needb widened by one
+    // row, needb is needc widened by one, needc the unmasked rows widened by one).
+    auto next_needed = [&](int from) -> int {   // first needed pixel row >= from (wave-uniform); INT_MAX: none
+      int q = from - (ys - 3);
+      q = q < 0 ? 0 : q;
+      if (q < 64) {
+        const unsigned long long m = (needp0 >> q) << q;
+        if (m) return ys - 3 + __builtin_ctzll(m);
+        if (needp1) return ys - 3 + 64 + __builtin_ctzll(needp1);
+        return 0x7fffffff;
+      }
+      if (q >= 128) return 0x7fffffff;
+      const unsigned long long m = (needp1 >> (q - 64)) << (q - 64);
+      return m ? ys - 3 + 64 + __builtin_ctzll(m) : 0x7fffffff;
+    };
+    while (true) {
+      const int rn = next_needed(r);
+      if (rn > r_last) break;
+      if (rn >= r + 3) {
+        r += ((rn - r) / 3) * 3;
+        issue_off(pq0, row_of(r) * stride_u);
+        issue_off(pq1, row_of(r + 1) * stride_u);
+        issue_off(pq2, row_of(r + 2) * stride_u);
+        fetch_mask(r - 2);
+        in_b_mask = 0ull;
+      }
+      if (r >= rs && r + 2 <= re) {
+        soff_next = (unsigned)(r + 3) * stride_u;
+        step(NC{}, r, S0, S2, S1, pq0);
+        step(NC{}, r + 1, S1, S0, S2, pq1);
+        step(NC{}, r + 2, S2, S1, S0, pq2);
+      } else {
+        step(CK{}, r, S0, S2, S1, pq0);
+        if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
+        if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
+      }
+      r += 3;
+    }
+  } else {
   // prologue: checked steps up to the first steady row, rounded up to a whole slot rotation
   const int n_pro = rs > re ? 0x3fffffff : ((rs - r_first + 2) / 3) * 3;
   for (; r <= r_last && r - r_first < n_pro; r += 3) {
@@ -633,6 +684,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     step(CK{}, r, S0, S2, S1, pq0);
     if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
     if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
+  }
   }
   __syncthreads();
   flush();
@@ -691,17 +743,19 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     const int ny = (P.H + strip_rows - 1) / strip_rows;
     static const int xcd_env = std::getenv("KVFE_MINEIG_XCD") ? std::atoi(std::getenv("KVFE_MINEIG_XCD")) : 0;   // (measured: 0.084 vs 0.082 ms plain)
     const int xcd = (xcd_env && P.B >= 8) ? 1 : 0;
+    // KVFE_MINEIG_SKIP=0: step through every row of a strip (round 3) instead of walking the runs of needed rows (A/B)
+    static const int run_skip = std::getenv("KVFE_MINEIG_SKIP") ? std::atoi(std::getenv("KVFE_MINEIG_SKIP")) : 1;
     const dim3 grid = xcd ? dim3((unsigned)(8 * ((P.B + 7) / 8) * nx * ny)) : dim3((unsigned)nx, (unsigned)ny, (unsigned)P.B);
     if (user_mask)
       hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
                          img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
                          T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                         D.maxkey, strip_rows, P.B, nx, ny, xcd);
+                         D.maxkey, strip_rows, P.B, nx, ny, xcd, run_skip);
     else
       hipLaunchKernelGGL(mineig2_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
                          img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
                          T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                         D.maxkey, strip_rows, P.B, nx, ny, xcd);
+                         D.maxkey, strip_rows, P.B, nx, ny, xcd, run_skip);
     return;
   }
   const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);

@@ -361,9 +361,28 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // + b, one v_add_f32_dpp.  Stage 0 of a chain passes 0 as carry: 0 + x is x in IEEE arithmetic (the terms are never -0
 // sums that matter: +0 + -0 = +0 only changes the sign of a zero), exactly the `carry = 0` start of the plain form.
 __device__ __forceinline__ float dpp_shr1_add(float carry_src, float b) {
-  float r;
-  asm("v_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(carry_src), "v"(b));
-  return r;
+  // plain form: hipcc fuses the DPP move + add into one v_add_f32_dpp where it can and inserts the wait states itself
+  return dpp_row_shr1(carry_src) + b;
+}
+// The same hand-over for the two / three carries of a chain stage in ONE asm statement.  gfx9 needs 2 wait states
+// between a VALU write of a VGPR and a DPP read of it, and hipcc cannot see a DPP operand inside inline asm (ADVICE round 3:
+// 99 of 215 sites had 1 wait state).  The leading `s_nop 1` provides them for the first carry whatever instruction the
+// compiler scheduled in front of the statement; it and the first hand-over provide them for the second and third.
+// tools/check_dpp_hazard.py scans the compiled ISA for this hazard (tests/test_host_logic.py runs it).
+__device__ __forceinline__ void dpp_shr1_add3(float& c0, float& c1, float& c2, float b0, float b1, float b2) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(c0), "+v"(c1), "+v"(c2)
+      : "v"(b0), "v"(b1), "v"(b2));
+}
+__device__ __forceinline__ void dpp_shr1_add2(float& c0, float& c1, float b0, float b1) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(c0), "+v"(c1)
+      : "v"(b0), "v"(b1));
 }
 __device__ __forceinline__ int dot2_i16(int a, int b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
@@ -622,8 +641,11 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
       float t22 = 0.f;
 #pragma unroll
       for (int st = 0; st < NQ; st++) {
-        t = v2f{dpp_shr1_add(t.x, pa[0].x), dpp_shr1_add(t.y, pa[0].y)};
-        t22 = dpp_shr1_add(t22, pc[0]);
+        {
+          float cx = t.x, cy = t.y;
+          dpp_shr1_add3(cx, cy, t22, pa[0].x, pa[0].y, pc[0]);
+          t = v2f{cx, cy};
+        }
 #pragma unroll
         for (int k = 1; k < NPX; k++) {
           t = t + pa[k];
@@ -733,7 +755,11 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
       v2f t = {0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < NQ; st++) {
-        t = v2f{dpp_shr1_add(t.x, term[0].x), dpp_shr1_add(t.y, term[0].y)};
+        {
+          float cx = t.x, cy = t.y;
+          dpp_shr1_add2(cx, cy, term[0].x, term[0].y);
+          t = v2f{cx, cy};
+        }
 #pragma unroll
         for (int i = 1; i < NST; i++) t = t + term[i];
       }

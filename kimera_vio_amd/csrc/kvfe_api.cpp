@@ -147,6 +147,17 @@ struct kvfe_ctx {
   std::vector<int> prof_flag_slot;    // per pending sample: its slot in prof_flags_host (-1: none)
   int prof_flag_next = 0;
   std::string last_error;
+  // output side (kvfe_dev.hpp "output side"): OUT_RING pinned host slots of B packed records; with many streams a
+  // device staging buffer per slot + a copy kernel on `out_stream`, with a few (out_direct) the pack kernel writes the
+  // mapped slot itself
+  unsigned char* out_host[OUT_RING] = {};
+  unsigned char* out_host_dev[OUT_RING] = {};   // device address of the mapped slot
+  unsigned char* out_stage[OUT_RING] = {};
+  hipEvent_t ev_packed[OUT_RING] = {}, ev_out[OUT_RING] = {};
+  hipStream_t out_stream = nullptr;
+  size_t out_stride = 0;
+  bool out_direct = false;
+  long long out_steps = 0;   // steps whose record has been enqueued; slot of step i = i % OUT_RING
   // dense stereo (allocated on first use, re-allocated when the volume geometry changes)
   DenseBuffers dense;
   std::vector<void*> dense_allocs;
@@ -842,6 +853,29 @@ void prof_collect(kvfe_ctx* c) {
   c->prof_flag_next = 0;
 }
 
+// The step's output records (kvfe_dev.hpp "output side"), enqueued behind step_finalize on the stream `sd` of the tail
+// and BEFORE the tail's event: the next step's track_finalize (which clears the landmarks of lost tracks in this frame's
+// table) waits for that event, so the records hold the frame as the reference's StereoFrontendOutput would.  Many streams:
+// a device-to-device gather (microseconds) on `sd`, then the PCIe transfer by a copy kernel on the output stream, beside
+// the next step's tracking launch.  A few streams: the gather writes the mapped pinned slot directly.
+kvfe_status enqueue_outputs(kvfe_ctx* c, const FrameTab& K, hipStream_t sd) {
+  const int slot = (int)(c->out_steps % OUT_RING);
+  Buffers& b = c->fe;
+  if (c->out_direct) {
+    launch_out_pack(c->P, K, b.st, b.ss, c->out_host_dev[slot], c->out_stride, sd);
+    HIPCHK(c, hipEventRecord(c->ev_out[slot], sd));
+  } else {
+    if (c->out_steps >= OUT_RING) HIPCHK(c, hipStreamWaitEvent(sd, c->ev_out[slot], 0));   // the slot's last transfer read it
+    launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_stride, sd);
+    HIPCHK(c, hipEventRecord(c->ev_packed[slot], sd));
+    HIPCHK(c, hipStreamWaitEvent(c->out_stream, c->ev_packed[slot], 0));
+    launch_out_copy(c->P.B, c->out_stage[slot], c->out_host_dev[slot], c->out_stride, c->out_stream);
+    HIPCHK(c, hipEventRecord(c->ev_out[slot], c->out_stream));
+  }
+  c->out_steps++;
+  return KVFE_OK;
+}
+
 kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char* right,
                     size_t row_stride, size_t img_stride, const kvfe_frame_input* inputs) {
   const KParams& P = c->P;
@@ -1032,6 +1066,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     prof_begin(c, ST_FINALIZE, st);
     launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, st);
     prof_end(c, ST_FINALIZE, st);
+    TRY(enqueue_outputs(c, K, st));
     HIPCHK(c, hipGetLastError());
     std::swap(c->role_k, c->role_km1);
     c->pyr_cur ^= 1;
@@ -1126,6 +1161,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_FINALIZE, sd);
   launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, sd);
   prof_end(c, ST_FINALIZE, sd);
+  TRY(enqueue_outputs(c, K, sd));
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_tail, sd));
     c->tail_pending = true;
@@ -1325,6 +1361,29 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
         s = KVFE_ERR_HIP;
     }
   }
+  if (s == KVFE_OK && alloc_frontend) {
+    c->out_stride = out_record_stride(c->P.kcap);
+    c->out_direct = c->P.B <= 4;
+    const size_t bytes = c->out_stride * (size_t)c->P.B;
+    for (int i = 0; i < OUT_RING && s == KVFE_OK; i++) {
+      void* h = nullptr;
+      void* d = nullptr;
+      if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) s = KVFE_ERR_HIP;
+      if (s == KVFE_OK) {
+        c->host_allocs.push_back(h);
+        c->out_host[i] = reinterpret_cast<unsigned char*>(h);
+        std::memset(h, 0, std::min<size_t>(bytes, OUT_HDR_BYTES));
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) s = KVFE_ERR_HIP;
+        c->out_host_dev[i] = reinterpret_cast<unsigned char*>(d);
+      }
+      if (s == KVFE_OK && !c->out_direct) s = dalloc(c, &c->out_stage[i], bytes);
+      if (s == KVFE_OK && (hipEventCreateWithFlags(&c->ev_packed[i], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming) != hipSuccess))
+        s = KVFE_ERR_HIP;
+    }
+    if (s == KVFE_OK && !c->out_direct && hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking) != hipSuccess)
+      s = KVFE_ERR_HIP;
+  }
   if (s == KVFE_OK && parent &&
       hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess)
     s = KVFE_ERR_HIP;
@@ -1441,6 +1500,14 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->copy_stream) {
     hipStreamSynchronize(c->copy_stream);
     hipStreamDestroy(c->copy_stream);
+  }
+  if (c->out_stream) {
+    hipStreamSynchronize(c->out_stream);
+    hipStreamDestroy(c->out_stream);
+  }
+  for (int i = 0; i < OUT_RING; i++) {
+    if (c->ev_packed[i]) hipEventDestroy(c->ev_packed[i]);
+    if (c->ev_out[i]) hipEventDestroy(c->ev_out[i]);
   }
   for (int i = 0; i < KVFE_STAGING_SLOTS; i++)
     if (c->stage_copied[i]) hipEventDestroy(c->stage_copied[i]);
@@ -2450,6 +2517,8 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   c->prev_left = nullptr;
   c->img_step = 0;
   c->pyr_cur = 0;
+  if (c->out_stream) HIPCHK(c, hipStreamSynchronize(c->out_stream));
+  c->out_steps = 0;
   c->last_step_staged = false;
   for (int i = 0; i < 4; i++) c->step_done_valid[i] = false;
   c->role_k = 0;
@@ -2458,84 +2527,86 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   return KVFE_OK;
 }
 
-kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {
+// Reads the packed record of stream `s` written by the step `steps_back` steps before the latest one out of its pinned
+// ring slot (kvfe_dev.hpp "output side"): one event wait for THAT step's transfer, then host memcpys.  No device call
+// touches the context's streams, so the step that is running meanwhile is not disturbed.
+kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_back, kvfe_frame_output* out) {
   DeviceGuard _dev(c);
-  join_tail(c);
-  if (!c || !out || s < 0 || s >= c->P.B || out->capacity < 0) return KVFE_ERR_INVALID_ARG;
+  if (!c || !out || s < 0 || s >= c->P.B || out->capacity < 0 || steps_back < 0 || steps_back >= OUT_RING)
+    return KVFE_ERR_INVALID_ARG;
   for (kvfe_ctx* ch : c->children)
     if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
-      const kvfe_status r = kvfe_frontend_get_output(ch, s - ch->s0, out);
+      const kvfe_status r = kvfe_frontend_get_output_at(ch, s - ch->s0, steps_back, out);
       if (r != KVFE_OK) c->last_error = ch->last_error;
       return r;
     }
-  Buffers& b = c->fe;
+  if (c->out_steps <= steps_back) {
+    c->last_error = "kvfe_frontend_get_output: no step has produced that output yet";
+    return KVFE_ERR_INVALID_ARG;
+  }
+  const int slot = (int)((c->out_steps - 1 - steps_back) % OUT_RING);
+  HIPCHK(c, hipEventSynchronize(c->ev_out[slot]));
+  if (c->prof_stride > 0 && steps_back == 0) {   // stage events of the profiled steps: collected once everything is complete
+    join_tail(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+  }
   const KParams& P = c->P;
-  hipStream_t st = c->stream;
-  HIPCHK(c, hipStreamSynchronize(st));
-  prof_collect(c);
-  const FrameTab& K = b.ft[c->role_km1];  // the frame processed last
-  int count = 0, flags = 0, ntr = 0, ndet = 0, nmeas = 0;
-  long long fcount = 0;
-  HIPCHK(c, hipMemcpy(&count, K.count + s, sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(&flags, b.ss.flags + s, sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(&ntr, b.ss.n_tracked + s, sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(&ndet, b.ss.n_detected + s, sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(&nmeas, b.ss.n_meas + s, sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(&fcount, b.ss.frame_count + s, sizeof(long long), hipMemcpyDeviceToHost));
+  const unsigned char* rec = c->out_host[slot] + (size_t)s * c->out_stride;
+  const OutHeader* h = reinterpret_cast<const OutHeader*>(rec);
+  const int count = h->n_keypoints, flags = h->flags, nmeas = h->n_meas;
   out->n_keypoints = count;
   out->is_keyframe = (flags & FLAG_KEYFRAME) ? 1 : 0;
-  out->n_tracked = ntr;
-  out->n_detected = ndet;
+  out->n_tracked = h->n_tracked;
+  out->n_detected = h->n_detected;
   out->n_measurements = nmeas;
-  out->frame_id = fcount - 1;
-  {
-    int stt[2], cnt[6];
-    HIPCHK(c, hipMemcpy(stt, b.ss.trk_status + 2 * (size_t)s, sizeof(stt), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(cnt, b.ss.trk_counts + 6 * (size_t)s, sizeof(cnt), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->lkf_T_k_mono, b.ss.trk_pose + 24 * (size_t)s, sizeof(double) * 12, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->lkf_T_k_stereo, b.ss.trk_pose + 24 * (size_t)s + 12, sizeof(double) * 12, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->info_mat_stereo_translation, b.ss.trk_info + 9 * (size_t)s, sizeof(double) * 9, hipMemcpyDeviceToHost));
-    out->tracking_status_mono = stt[0];
-    out->tracking_status_stereo = stt[1];
-    out->nr_mono_putatives = cnt[0];
-    out->nr_mono_inliers = cnt[1];
-    out->mono_ransac_iters = cnt[2];
-    out->nr_stereo_putatives = cnt[3];
-    out->nr_stereo_inliers = cnt[4];
-    out->reserved0 = 0;
-    int pst = 0, pcnt[3] = {0, 0, 0};
-    HIPCHK(c, hipMemcpy(&pst, b.ss.pnp_status + s, sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(pcnt, b.ss.pnp_counts + 3 * (size_t)s, sizeof(pcnt), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->W_T_k_pnp, b.ss.pnp_pose + 12 * (size_t)s, sizeof(double) * 12, hipMemcpyDeviceToHost));
-    out->tracking_status_pnp = pst;
-    out->nr_pnp_inliers = pcnt[0];
+  out->frame_id = h->frame_count - 1;
+  out->tracking_status_mono = h->trk_status[0];
+  out->tracking_status_stereo = h->trk_status[1];
+  std::memcpy(out->lkf_T_k_mono, h->trk_pose, sizeof(double) * 12);
+  std::memcpy(out->lkf_T_k_stereo, h->trk_pose + 12, sizeof(double) * 12);
+  std::memcpy(out->info_mat_stereo_translation, h->trk_info, sizeof(double) * 9);
+  out->nr_mono_putatives = h->trk_counts[0];
+  out->nr_mono_inliers = h->trk_counts[1];
+  out->mono_ransac_iters = h->trk_counts[2];
+  out->nr_stereo_putatives = h->trk_counts[3];
+  out->nr_stereo_inliers = h->trk_counts[4];
+  out->reserved0 = 0;
+  out->tracking_status_pnp = h->pnp_status;
+  out->nr_pnp_inliers = h->pnp_counts[0];
+  std::memcpy(out->W_T_k_pnp, h->pnp_pose, sizeof(double) * 12);
+  const int np = std::min(count, P.kcap), mp = std::min(nmeas, P.kcap);   // entries the record holds
+  const bool stereo = (flags & FLAG_STEREO) != 0;
+  const OutLayout L = out_layout(np, mp, stereo);
+  const int n = std::min(np, out->capacity);
+  const int m = std::min(mp, out->capacity);
+#define DL(dst, off, bytes) \
+  if (dst && (bytes) > 0) std::memcpy(dst, rec + (off), bytes)
+  DL(out->landmarks, L.lmk, sizeof(long long) * n);
+  DL(out->landmarks_age, L.age, sizeof(int) * n);
+  DL(out->keypoints, L.kp, sizeof(float2) * n);
+  DL(out->versors, L.versor, sizeof(double) * 3 * n);
+  if (stereo) {
+    DL(out->left_rect_xy, L.left_rect, sizeof(float2) * n);
+    DL(out->left_status, L.left_status, (size_t)n);
+    DL(out->right_rect_xy, L.right_rect, sizeof(float2) * n);
+    DL(out->right_status, L.right_status, (size_t)n);
+    DL(out->depth, L.depth, sizeof(double) * n);
+    DL(out->right_xy, L.right_kp, sizeof(float2) * n);
+    DL(out->keypoints_3d, L.kp3d, sizeof(double) * 3 * n);
   }
-  const size_t so = (size_t)s * P.kcap;
-  const int n = std::min(count, out->capacity);
-  const int m = std::min(nmeas, out->capacity);
-#define DL(dst, src, bytes) \
-  if (dst && (bytes) > 0) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost))
-  DL(out->landmarks, K.lmk + so, sizeof(long long) * n);
-  DL(out->landmarks_age, K.age + so, sizeof(int) * n);
-  DL(out->keypoints, K.kp + so, sizeof(float2) * n);
-  DL(out->versors, K.versor + so * 3, sizeof(double) * 3 * n);
-  if (flags & FLAG_STEREO) {
-    DL(out->left_rect_xy, b.st.left_rect + so, sizeof(float2) * n);
-    DL(out->left_status, b.st.left_status + so, (size_t)n);
-    DL(out->right_rect_xy, b.st.right_rect + so, sizeof(float2) * n);
-    DL(out->right_status, b.st.right_status + so, (size_t)n);
-    DL(out->depth, b.st.depth + so, sizeof(double) * n);
-    DL(out->right_xy, b.st.right_kp + so, sizeof(float2) * n);
-    DL(out->keypoints_3d, b.st.kp3d + so * 3, sizeof(double) * 3 * n);
-  }
-  DL(out->meas_landmark, b.ss.meas_lmk + so, sizeof(long long) * m);
-  DL(out->meas_uL_uR_v, b.ss.meas_uLuRv + so * 3, sizeof(double) * 3 * m);
+  DL(out->meas_landmark, L.meas_lmk, sizeof(long long) * m);
+  DL(out->meas_uL_uR_v, L.meas, sizeof(double) * 3 * m);
 #undef DL
   if (flags & FLAG_OVERFLOW) {
     c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
     return KVFE_ERR_CAPACITY;
   }
   return KVFE_OK;
+}
+
+kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {
+  return kvfe_frontend_get_output_at(c, s, 0, out);
 }
 
 // ---- dense stereo --------------------------------------------------------

@@ -378,6 +378,49 @@ void launch_distort_unrectify(const float2* map, int W, const float2* rect_xy, c
 void launch_depth_from_matches(const float2* left_xy, const unsigned char* left_status, const float2* right_xy,
                                unsigned char* right_status, int n, double fx_b, double min_dist, double max_dist,
                                double* depth, hipStream_t st);
+// ---- output side: one packed record per stream and step (StereoFrontendOutput, StereoVisionImuFrontend-definitions.h:25-91) ----
+// step_finalize's successor `out_pack_kernel` gathers everything kvfe_frontend_get_output returns for a stream -- counters,
+// TrackerStatusSummary, the frame / stereo / measurement arrays cut to the entries in use -- into ONE contiguous record
+// (header + 16-byte aligned arrays); the records of a step travel to a pinned host ring slot in one device-initiated
+// transfer, and kvfe_frontend_get_output is a memcpy out of that slot (round 3: ~27 blocking hipMemcpy per stream).
+constexpr int OUT_HDR_BYTES = 512;
+constexpr int OUT_RING = 3;   // steps whose output records are kept (kvfe_frontend_get_output_at: steps_back < OUT_RING)
+struct OutHeader {
+  int n_keypoints, flags, n_tracked, n_detected, n_meas;
+  int trk_status[2], trk_counts[6], pnp_status, pnp_counts[3];
+  long long frame_count;
+  unsigned long long used_bytes;   // header + arrays of this record
+  double trk_pose[24], trk_info[9], pnp_pose[12];
+};
+static_assert(sizeof(OutHeader) <= OUT_HDR_BYTES, "output header grew past its slot");
+struct OutLayout {   // byte offsets inside a record
+  size_t lmk, age, kp, versor, left_rect, left_status, right_rect, right_status, depth, right_kp, kp3d, meas_lmk, meas, end;
+};
+__host__ __device__ inline size_t out_al16(size_t v) { return (v + 15) & ~(size_t)15; }
+__host__ __device__ inline OutLayout out_layout(int n, int m, bool stereo) {
+  OutLayout L;
+  size_t o = OUT_HDR_BYTES;
+  L.lmk = o;          o = out_al16(o + sizeof(long long) * (size_t)n);
+  L.age = o;          o = out_al16(o + sizeof(int) * (size_t)n);
+  L.kp = o;           o = out_al16(o + sizeof(float2) * (size_t)n);
+  L.versor = o;       o = out_al16(o + sizeof(double) * 3 * (size_t)n);
+  const size_t ns = stereo ? (size_t)n : 0;
+  L.left_rect = o;    o = out_al16(o + sizeof(float2) * ns);
+  L.left_status = o;  o = out_al16(o + ns);
+  L.right_rect = o;   o = out_al16(o + sizeof(float2) * ns);
+  L.right_status = o; o = out_al16(o + ns);
+  L.depth = o;        o = out_al16(o + sizeof(double) * ns);
+  L.right_kp = o;     o = out_al16(o + sizeof(float2) * ns);
+  L.kp3d = o;         o = out_al16(o + sizeof(double) * 3 * ns);
+  L.meas_lmk = o;     o = out_al16(o + sizeof(long long) * (size_t)m);
+  L.meas = o;         o = out_al16(o + sizeof(double) * 3 * (size_t)m);
+  L.end = o;
+  return L;
+}
+inline size_t out_record_stride(int kcap) { return (out_layout(kcap, kcap, true).end + 255) & ~(size_t)255; }
+void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, const StreamState& S, unsigned char* dst,
+                     size_t rec_stride, hipStream_t st);
+void launch_out_copy(int B, const unsigned char* src, unsigned char* dst_host_mapped, size_t rec_stride, hipStream_t st);
 void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScratch& lk, int max_pts, hipStream_t st);
 void launch_predict_flow(const KParams& P, const Tables& T, const double* R, const float2* prev,
                          int n, float2* out, hipStream_t st);

@@ -505,7 +505,8 @@ class Context:
     def reset(self):
         self._chk(self.lib.kvfe_frontend_reset(self._h), "frontend_reset")
 
-    def get_output(self, stream: int) -> dict:
+    def get_output(self, stream: int, steps_back: int = 0) -> dict:
+        """kvfe_frontend_get_output_at: the output record of the step `steps_back` steps before the latest one"""
         cap = self.kcap
         arrs = dict(landmarks=np.zeros(cap, np.int64), landmarks_age=np.zeros(cap, np.int32),
                     keypoints=np.zeros((cap, 2), np.float32), versors=np.zeros((cap, 3), np.float64),
@@ -518,7 +519,7 @@ class Context:
         out.capacity = cap
         for k, v in arrs.items():
             setattr(out, k, v.ctypes.data)
-        self._chk(self.lib.kvfe_frontend_get_output(self._h, stream, C.byref(out)), "frontend_get_output")
+        self._chk(self.lib.kvfe_frontend_get_output_at(self._h, stream, steps_back, C.byref(out)), "frontend_get_output")
         n = min(out.n_keypoints, cap)
         m = min(out.n_measurements, cap)
         d = dict(n_keypoints=out.n_keypoints, is_keyframe=out.is_keyframe, n_tracked=out.n_tracked,

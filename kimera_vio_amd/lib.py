@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     L.kvfe_frontend_reset.argtypes = [vp]
     L.kvfe_synchronize.argtypes = [vp]
     L.kvfe_frontend_get_output.argtypes = [vp, i32, C.POINTER(abi.FrameOutput)]
+    L.kvfe_frontend_get_output_at.argtypes = [vp, i32, i32, C.POINTER(abi.FrameOutput)]
     L.kvfe_profile_enable.argtypes = [vp, i32]
     L.kvfe_profile_read.argtypes = [vp, C.POINTER(abi.StageTimes)]
     f32 = C.c_float
@@ -169,7 +170,7 @@ def load() -> C.CDLL:
                "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_equalize_hist",
                "kvfe_frontend_staging_buffer", "kvfe_frontend_staging_wait", "kvfe_frontend_step_staged",
                "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
-               "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
+               "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_frontend_get_output_at", "kvfe_profile_enable",
                "kvfe_profile_read", "kvfe_dense_stereo_reconstruction", "kvfe_dense_profile_read",
                "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume", "kvfe_outlier_rejection_3d3d",
                "kvfe_outlier_rejection_2d2d"):
@@ -179,6 +180,7 @@ def load() -> C.CDLL:
 
 
 NEW_R3_SYMBOLS = ["kvfe_build_optical_flow_pyramid"]
+NEW_R4_SYMBOLS = ["kvfe_frontend_get_output_at"]
 
 NEW_R2_SYMBOLS = [
     "kvfe_check_undistorted_rectified_left_keypoints", "kvfe_distort_unrectify_keypoints",
@@ -199,7 +201,7 @@ INPUT_SIDE_SYMBOLS = [
     "kvfe_stereo_sync_shutdown", "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv",
 ]
 
-EXPORTED_SYMBOLS = NEW_R3_SYMBOLS + NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
+EXPORTED_SYMBOLS = NEW_R4_SYMBOLS + NEW_R3_SYMBOLS + NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
     "kvfe_version", "kvfe_status_string", "kvfe_last_error", "kvfe_default_frontend_params",
     "kvfe_create", "kvfe_destroy", "kvfe_compute_rectification",
     "kvfe_compute_undistort_rectify_maps", "kvfe_get_rectification", "kvfe_undistort_rectify_image",

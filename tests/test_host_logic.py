@@ -340,3 +340,20 @@ def test_device_warm_up_is_harmless_without_a_device():
         pytest.skip("a device is present")
     from kimera_vio_amd._warmup import warm_up_device
     assert warm_up_device(attempts=1, timeout_s=120) is False
+
+
+def test_no_valu_to_dpp_hazard_in_inline_asm():
+    """gfx9 needs 2 wait states between a VALU write of a VGPR and a DPP read of it; hipcc provides them
+    for its own DPP instructions but cannot see inside inline asm.  tools/check_dpp_hazard.py scans the compiled gfx950
+    ISA of the tracking kernels (the only file with hand-written DPP arithmetic on freshly computed carries)."""
+    import importlib.util
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(root, "tools", "check_dpp_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = mod.check_hip(os.path.join(root, "kimera_vio_amd", "csrc", "k_track.hip"))
+    assert n > 100, "the tracking kernels are expected to hold their DPP chains"
+    assert not bad, bad[:5]
