@@ -33,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALL_LEGS = ("nominal", "single_stream", "c5", "klt4", "kf_realistic", "dense", "dense_c5", "pcie", "input", "cpu")
+ALL_LEGS = ("nominal", "single_stream", "c5", "klt4", "kf_realistic", "outputs", "spinonce", "dense", "dense_c5", "pcie",
+            "input", "cpu")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -76,6 +77,9 @@ def parse():
                     help="every N-th timed step records per-stage HIP events (roofline / stage breakdown)")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-stereo (SGBM) legs")
+    ap.add_argument("--copy-level0", action="store_true",
+                    help="kvfe_config.device_frames_persist = 0: the context copies every left frame (no caller pointer "
+                         "outlives a step) instead of tracking from the caller's resident ring")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (tests/test_multi_rank.py, no GPU): become --gpus ranks, build each "
                          "rank's workload shard, barrier + timing reduction over gloo, print the shard map; "
@@ -179,10 +183,14 @@ def pmc_traffic(pmc_leg, stage):
 
 
 valu_ctx = None   # (per-kernel SQ counters, number of CUs, peak engine clock in GHz), set by main()
+# kvfe_config execution options of every front-end leg: the benchmark's frames sit in a device ring that is never
+# rewritten, so the caller's guarantee of `device_frames_persist` holds (--copy-level0 switches it off: the context then
+# keeps its own copy of every left frame, one more image write per pair)
+DEFAULT_CTX_KW = {"device_frames_persist": 1}
 
 
 def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, repeats, groups, stage_stride,
-                     pmc_leg=None):
+                     pmc_leg=None, read_outputs=False, ctx_kw=None):
     """times `repeats` regions of exactly `steps` steps of the workload on this rank's GPU; returns the
     result dict of the leg (rank-reduced: MAX time over ranks, SUM of pairs)."""
     B, W, H = wl.batch, wl.width, wl.height
@@ -190,14 +198,26 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
     d_left = torch.from_numpy(lefts).to(dev)
     d_right = torch.from_numpy(rights).to(dev)
     torch.cuda.synchronize()
-    ctx = F.Context(wl.left, wl.right, wl.params, batch=B, device=dev.index, stream_groups=groups)
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=B, device=dev.index, stream_groups=groups,
+                    **(DEFAULT_CTX_KW if ctx_kw is None else ctx_kw))
     total = warmup + repeats * steps
     plan = [(st[0], wl.batch_inputs(ctx, st)) for st in wl.plan(total)]   # host work outside the timed region
+    # read_outputs: the consumer side inside the timed region -- after enqueuing step i the host copies the complete
+    # output records of step i-1 of ALL streams out of the pinned ring (kvfe_frontend_get_outputs), the last step's after
+    # the loop: every frame's keypoints, stereo arrays and measurements reach caller-owned memory
+    obuf = ctx.output_buffers() if read_outputs else None
+    n_read = [0]
 
     def run(i0, i1):
         for i in range(i0, i1):
             t, inp = plan[i]
             ctx.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), inp)
+            if obuf is not None and i > i0:
+                o = obuf.read(1)
+                n_read[0] += o[0].n_keypoints
+        if obuf is not None:
+            o = obuf.read(0)
+            n_read[0] += o[0].n_keypoints
 
     def barrier():
         sharding.barrier(dist, world)  # RCCL: lock-step only, no data-path collective
@@ -333,6 +353,8 @@ def main():
     if world > 1 or under_torchrun:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    DEFAULT_CTX_KW["device_frames_persist"] = 0 if args.copy_level0 else 1
+    ctx_kw = None
     pmc = load_pmc()
     global valu_ctx
     props = torch.cuda.get_device_properties(dev)
@@ -371,6 +393,7 @@ def main():
                                f"{p.tracker.klt_max_level + 1}-level LK, useRANSAC={p.use_ransac}, mode={args.mode}",
                    "batch_per_gpu": B, "width": W, "height": H, "features": p.detector.max_features_per_frame,
                    "mode": args.mode, "use_ransac": p.use_ransac, "stream_groups": main_leg.get("stream_groups", 1),
+                   "device_frames_persist": DEFAULT_CTX_KW["device_frames_persist"],
                    "parallelism": f"streams x{world}"},
         "value_is": f"median of {args.repeats} timed regions of exactly {args.steps} steps each",
         "device_warm_up_ok": bool(warmed),
@@ -418,6 +441,21 @@ def main():
                            f"{we.ring} MicroEuroc frames, 600 features, 3-level LK, every frame a keyframe -- detection "
                            f"and cornerSubPix at the loss rate of real images (see check.new_corners_per_keyframe_stream0)")
         result["kf_realistic"] = leg
+    if solo and "outputs" in args.legs and args.config == "c3":
+        # the `value` workload with every frame's outputs read by the host inside the timed region
+        leg = run_frontend_leg(torch, F, dist, sharding, wl, dev, 1, args.steps, args.warmup, args.repeats, args.groups,
+                               0, None, read_outputs=True, ctx_kw=ctx_kw)
+        ref = run_frontend_leg(torch, F, dist, sharding, wl, dev, 1, args.steps, args.warmup, args.repeats, args.groups,
+                               0, None, ctx_kw=ctx_kw)
+        leg["workload"] = ("as `value`, plus: the complete kvfe_frame_output of every stream and every step (frame tables, "
+                           "stereo arrays, smart stereo measurements, TrackerStatusSummary) is copied into caller-owned "
+                           "host memory inside the timed region -- step i-1's records while step i runs "
+                           "(kvfe_frontend_get_outputs, steps_back = 1), the last step's at the end")
+        leg["no_readback_value"] = ref["value"]
+        leg["vs_no_readback"] = round(leg["value"] / ref["value"], 4)
+        result["outputs_inclusive"] = leg
+    if solo and "spinonce" in args.legs:
+        result["single_stream_spinonce"] = spinonce_leg(torch, F, dist, sharding, WL, dev, args)
     if solo and "dense" in args.legs:
         result["dense_stereo"] = dense_stereo(F, WL, 752, 480, dev, pmc.get("dense"))
     if solo and "dense_c5" in args.legs:
@@ -463,6 +501,56 @@ def dry_run(args, dist, sharding, WL, rank, world):
                           "scaling": "strong" if args.config == "c4" else "weak", "ranks": gathered}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def spinonce_leg(torch, F, dist, sharding, WL, dev, args):
+    """BASELINE configs[1] through the reference's own call: shim::StereoVisionImuFrontend::spinOnce(StereoImuSyncPacket&&)
+    -> StereoFrontendOutput (include/kvfe_kimera_shim.hpp), one stream, host images, the front-end's own keyframe
+    decisions, EVERY call returning its complete output -- a synchronous call per frame, as Kimera-VIO's front-end thread
+    makes it.  Driven by the plain-g++ host program tests/cpp/shim_check (bench mode).  Beside it the same stream and
+    cadence through kvfe_frontend_step_device with no read-back and no per-frame synchronisation."""
+    import subprocess
+    import tempfile
+    from kimera_vio_amd import _abi as abi
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "shim_check"], check=True, capture_output=True)
+    w2 = WL.build("c2", mode="nominal", use_ransac=args.ransac)
+    z = np.load(os.path.join(WL.GOLDEN, "micro_euroc_f10_18.npz"))
+    body_R = z["body_R"][: w2.ring]
+    cfg = abi.Config()
+    cfg.left, cfg.right, cfg.params, cfg.batch, cfg.device = w2.left, w2.right, w2.params, 1, dev.index or 0
+    n_spin = 600
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(bytes(cfg))
+            f.write(np.array([w2.ring, w2.width, w2.height], np.int32).tobytes())
+            for i in range(w2.ring):
+                fi = abi.FrameInput()
+                fi.timestamp_ns = i * WL.DT_NS
+                if i > 0:   # body-frame gyro rate of the interval i-1 -> i: Log(R_{i-1}^T R_i) / dt
+                    from scipy.spatial.transform import Rotation
+                    w = Rotation.from_matrix(body_R[i - 1].T @ body_R[i]).as_rotvec() / (WL.DT_NS * 1e-9)
+                    for k in range(3):
+                        fi.keyframe_R_cur_frame[k] = float(w[k])
+                f.write(bytes(fi))
+                f.write(np.ascontiguousarray(w2.lefts[i, 0]).tobytes())
+                f.write(np.ascontiguousarray(w2.rights[i, 0]).tobytes())
+        r = subprocess.run([os.path.join(cpp, "shim_check"), fin, fout, "bench", str(n_spin)], capture_output=True,
+                           text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-500:]}
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    ref = run_frontend_leg(torch, F, dist, sharding, w2, dev, 1, 200, 20, args.repeats, 0, 0)
+    return {"value": res["pairs_per_s"], "unit": "stereo-pairs/s", "ms_per_pair": res["ms_per_pair"],
+            "spins": res["spins"], "keyframes": res["keyframes"], "measurements_per_spin": res["measurements_per_spin"],
+            "workload": "BASELINE configs[1] (single EuRoC stream, 300 features, 3-level LK), reference cadence (the front-end's "
+                        "own keyframe decisions), host images, through shim::StereoVisionImuFrontend::spinOnce: every call "
+                        "uploads the pair, runs the step, waits for it and builds the StereoFrontendOutput",
+            "no_readback_value": ref["value"], "no_readback_ms_per_pair": ref["ms_per_step"],
+            "no_readback_workload": "the same stream and cadence, frames resident in HBM, kvfe_frontend_step_device back to "
+                                    "back, no output read and no synchronisation inside the timed region",
+            "vs_no_readback": round(res["pairs_per_s"] / ref["value"], 4)}
 
 
 def input_side():

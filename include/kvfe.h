@@ -253,6 +253,20 @@ typedef struct kvfe_config {
                                     that latency-bound and throughput-bound kernels of
                                     different groups can overlap (always 1 with
                                     hip_stream).  Measured on MI355X: 1 is fastest    */
+  /* ---- execution options (round 4: these were environment variables of the library) ---- */
+  int32_t device_frames_persist; /* kvfe_frontend_step_device only.  1 = the caller guarantees that the LEFT image
+                                    of a step stays valid and unchanged until the NEXT step has completed (frames
+                                    resident in a device ring): tracking then reads frame k-1 from the caller's
+                                    buffer and the context does not keep its own copy (one image write per frame
+                                    less).  0 (default): no caller pointer outlives a step                       */
+  int32_t single_hip_stream;     /* 1 = every kernel of a step on the context's one HIP stream: no internal side
+                                    stream (corner refinement beside rectification / matching) and no output stream.
+                                    For callers that need strict single-stream order and for timing kernels alone  */
+  int32_t copy_inputs;           /* 1 = the per-stream inputs of a step travel by one H2D copy instead of being read
+                                    by the kernels from the mapped pinned ring slot                                */
+  int32_t ssd_impl;              /* sparse stereo SSD search (searchRightKeypointEpipolar): 0 = on the matrix cores
+                                    where the template / stripe geometry fits their lane maps (default), 1 = the
+                                    v_dot4 search for every geometry                                               */
 } kvfe_config;
 
 typedef struct kvfe_ctx kvfe_ctx;
@@ -730,6 +744,13 @@ KVFE_API kvfe_status kvfe_frontend_get_output(kvfe_ctx* ctx, int32_t stream,
 #define KVFE_OUTPUT_RING 3
 KVFE_API kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* ctx, int32_t stream, int32_t steps_back,
                                                  kvfe_frame_output* out);
+/* all `batch` streams in one call: outs[s] as above (capacity and array pointers set by the caller per stream) */
+KVFE_API kvfe_status kvfe_frontend_get_outputs(kvfe_ctx* ctx, int32_t steps_back, kvfe_frame_output* outs);
+/* zero-copy: the scalar fields are filled and the array pointers of `out` are pointed INTO the pinned record
+ * (capacity = entries held; stereo arrays NULL on a frame without stereo data).  Valid until
+ * KVFE_OUTPUT_RING - 1 - steps_back further steps have been enqueued; read-only for the caller. */
+KVFE_API kvfe_status kvfe_frontend_view_output(kvfe_ctx* ctx, int32_t stream, int32_t steps_back,
+                                               kvfe_frame_output* out);
 
 /* ------------------------------------------------------------------------- */
 /* Input side: what sits between the dataset / sensor and    */

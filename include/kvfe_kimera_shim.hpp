@@ -390,22 +390,18 @@ class StereoVisionImuFrontend {
     if (l.step != r.step) throw Error(KVFE_ERR_INVALID_ARG, "left / right images with different strides");
     c_.check(kvfe_frontend_step_host(c_.get(), l.data, r.data, l.step, l.step * (size_t)l.rows, &in), "spinOnce");
     initialised_ = true;
-    // StereoFrontendOutput
-    const int cap = c_.config().params.detector.max_features_per_frame + c_.config().params.detector.max_nr_keypoints_before_anms + 64;
+    // StereoFrontendOutput: read in place from the step's packed record in pinned host memory (kvfe_frontend_view_output:
+    // one event wait for this step's record, no device copy, no intermediate buffers)
     SpinResult o;
-    std::vector<int64_t> lmk(cap), mlmk(cap);
-    std::vector<int32_t> age(cap);
-    std::vector<float> kp(2 * cap), lr(2 * cap), rr(2 * cap), rxy(2 * cap);
-    std::vector<double> ver(3 * cap), dep(cap), p3(3 * cap), muv(3 * cap);
-    std::vector<uint8_t> ls(cap), rs(cap);
     kvfe_frame_output f;
     std::memset(&f, 0, sizeof(f));
-    f.capacity = cap;
-    f.landmarks = lmk.data(); f.landmarks_age = age.data(); f.keypoints = kp.data(); f.versors = ver.data();
-    f.left_rect_xy = lr.data(); f.left_status = ls.data(); f.right_rect_xy = rr.data(); f.right_status = rs.data();
-    f.depth = dep.data(); f.right_xy = rxy.data(); f.keypoints_3d = p3.data();
-    f.meas_landmark = mlmk.data(); f.meas_uL_uR_v = muv.data();
-    c_.check(kvfe_frontend_get_output(c_.get(), 0, &f), "getOutput");
+    c_.check(kvfe_frontend_view_output(c_.get(), 0, 0, &f), "getOutput");
+    const int64_t* lmk = f.landmarks;
+    const int64_t* mlmk = f.meas_landmark;
+    const int32_t* age = f.landmarks_age;
+    const float *kp = f.keypoints, *lr = f.left_rect_xy, *rr = f.right_rect_xy, *rxy = f.right_xy;
+    const double *ver = f.versors, *dep = f.depth, *p3 = f.keypoints_3d, *muv = f.meas_uL_uR_v;
+    const uint8_t *ls = f.left_status, *rs = f.right_status;
     o.is_keyframe = f.is_keyframe != 0;
     o.timestamp = in.timestamp_ns;
     o.kfTrackingStatus_mono = f.tracking_status_mono;
@@ -417,23 +413,33 @@ class StereoVisionImuFrontend {
     std::memcpy(o.infoMatStereoTranslation, f.info_mat_stereo_translation, sizeof(o.infoMatStereoTranslation));
     o.nrMonoPutatives = f.nr_mono_putatives; o.nrMonoInliers = f.nr_mono_inliers; o.monoRansacIters = f.mono_ransac_iters;
     o.nrStereoPutatives = f.nr_stereo_putatives; o.nrStereoInliers = f.nr_stereo_inliers;
-    const int n = f.n_keypoints, m = f.n_measurements;
-    o.meas_landmark.assign(mlmk.begin(), mlmk.begin() + m);
-    o.meas_uL_uR_v.assign(muv.begin(), muv.begin() + 3 * m);
+    const int n = std::min(f.n_keypoints, f.capacity), m = std::min(f.n_measurements, f.capacity);
+    o.meas_landmark.assign(mlmk, mlmk + m);
+    o.meas_uL_uR_v.assign(muv, muv + 3 * m);
     o.left_frame.img_ = l;
     o.left_frame.keypoints_.resize(n);
-    o.left_frame.landmarks_.assign(lmk.begin(), lmk.begin() + n);
-    o.left_frame.landmarks_age_.assign(age.begin(), age.begin() + n);
-    o.left_frame.versors_.assign(ver.begin(), ver.begin() + 3 * n);
+    o.left_frame.landmarks_.assign(lmk, lmk + n);
+    o.left_frame.landmarks_age_.assign(age, age + n);
+    o.left_frame.versors_.assign(ver, ver + 3 * n);
     o.left_keypoints_rectified.resize(n); o.right_keypoints_rectified.resize(n); o.right_keypoints.resize(n);
-    for (int i = 0; i < n; i++) {
-      o.left_frame.keypoints_[i] = KeypointCV{kp[2 * i], kp[2 * i + 1]};
-      o.left_keypoints_rectified[i] = {static_cast<KeypointStatus>(ls[i]), KeypointCV{lr[2 * i], lr[2 * i + 1]}};
-      o.right_keypoints_rectified[i] = {static_cast<KeypointStatus>(rs[i]), KeypointCV{rr[2 * i], rr[2 * i + 1]}};
-      o.right_keypoints[i] = KeypointCV{rxy[2 * i], rxy[2 * i + 1]};
+    for (int i = 0; i < n; i++) o.left_frame.keypoints_[i] = KeypointCV{kp[2 * i], kp[2 * i + 1]};
+    if (ls) {   // a frame with stereo data (every keyframe): the record holds the stereo arrays
+      for (int i = 0; i < n; i++) {
+        o.left_keypoints_rectified[i] = {static_cast<KeypointStatus>(ls[i]), KeypointCV{lr[2 * i], lr[2 * i + 1]}};
+        o.right_keypoints_rectified[i] = {static_cast<KeypointStatus>(rs[i]), KeypointCV{rr[2 * i], rr[2 * i + 1]}};
+        o.right_keypoints[i] = KeypointCV{rxy[2 * i], rxy[2 * i + 1]};
+      }
+      o.keypoints_depth.assign(dep, dep + n);
+      o.keypoints_3d.assign(p3, p3 + 3 * n);
+    } else {    // (what the zero-initialised buffers of the copying read gave: status 0, zero coordinates)
+      for (int i = 0; i < n; i++) {
+        o.left_keypoints_rectified[i] = {static_cast<KeypointStatus>(0), KeypointCV{0.f, 0.f}};
+        o.right_keypoints_rectified[i] = {static_cast<KeypointStatus>(0), KeypointCV{0.f, 0.f}};
+        o.right_keypoints[i] = KeypointCV{0.f, 0.f};
+      }
+      o.keypoints_depth.assign(n, 0.0);
+      o.keypoints_3d.assign(3 * (size_t)n, 0.0);
     }
-    o.keypoints_depth.assign(dep.begin(), dep.begin() + n);
-    o.keypoints_3d.assign(p3.begin(), p3.begin() + 3 * n);
     if (o.is_keyframe)   // ImuFrontend::resetIntegrationWithCachedBias (StereoVisionImuFrontend.cpp:203)
       for (int i = 0; i < 9; i++) deltaRij_[i] = (i % 4 == 0) ? 1.0 : 0.0;
     return build(static_cast<const SpinResult&>(o));

@@ -168,6 +168,8 @@ class Config(C.Structure):
         ("candidate_capacity", C.c_int32), ("frontend_type", C.c_int32), ("landmark_map_capacity", C.c_int32),
         ("depth", DepthParams),
         ("stream_groups", C.c_int32),
+        ("device_frames_persist", C.c_int32), ("single_hip_stream", C.c_int32), ("copy_inputs", C.c_int32),
+        ("ssd_impl", C.c_int32),
     ]
 
 

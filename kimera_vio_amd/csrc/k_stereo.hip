@@ -361,9 +361,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
   const int rw = sc - tc + 1, rh = sr - tr + 1;
   unsigned long long best = ~0ull;
   if (impl != 0 && G.mfma_ok && dword_rows && ((size_t)L & 3) == 0) {
-    if (G.KS == 2 && impl == 3)
-      best = ssd_search_mfma<2, true>(P, G, L, R, lds, lane, temp_corner_x, temp_corner_y, stripe_corner_x, stripe_corner_y);
-    else if (G.KS == 2)
+    if (G.KS == 2)
       best = ssd_search_mfma<2, false>(P, G, L, R, lds, lane, temp_corner_x, temp_corner_y, stripe_corner_x, stripe_corner_y);
     else
       best = ssd_search_mfma<0, false>(P, G, L, R, lds, lane, temp_corner_x, temp_corner_y, stripe_corner_x, stripe_corner_y);
@@ -623,12 +621,9 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
   ST.kp3d[o * 3 + 2] = z3;
 }
 
-// KVFE_SSD_IMPL: 1 (default) = the SSD search on the matrix cores where its lane maps fit (ssd_search_mfma), 0 = the
-// v_dot4 search everywhere.  Read at every launch (the tests switch it inside one process).
-static int stereo_ssd_impl() {
-  const char* e = std::getenv("KVFE_SSD_IMPL");
-  return e ? std::atoi(e) : 1;
-}
+// kvfe_config.ssd_impl: 0 (default) = the SSD search on the matrix cores where its lane maps fit (ssd_search_mfma),
+// 1 = the v_dot4 search everywhere (also the path of the geometries that do not fit)
+static int stereo_ssd_impl(const KParams& P) { return P.ssd_dot4 ? 0 : 1; }
 
 static size_t stereo_lds_bytes(const KParams& P) {
   size_t b = stereo_geom(P).match_bytes;
@@ -644,10 +639,10 @@ void launch_stereo(const KParams& P, const Tables& T, const unsigned char* left_
                      ST, S, act_flag, mode);
   if (P.stereo_subpix)
     hipLaunchKernelGGL(stereo_match_kernel<true>, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st,
-                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode, stereo_ssd_impl());
+                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode, stereo_ssd_impl(P));
   else
     hipLaunchKernelGGL(stereo_match_kernel<false>, dim3(nb, P.B), dim3(64), stereo_lds_bytes(P), st,
-                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode, stereo_ssd_impl());
+                       P, T, left_rect, right_rect, k, ST, S, act_flag, mode, stereo_ssd_impl(P));
 }
 
 void launch_undistort_left(const KParams& P, const Tables& T, const FrameTab& k, const StereoTab& ST,
@@ -685,11 +680,11 @@ void launch_stereo_match_only(const KParams& P, const Tables& T, const unsigned 
   if (P.stereo_subpix)
     hipLaunchKernelGGL(stereo_match_only_kernel<true>, dim3(n), dim3(64), stereo_lds_bytes(P), st, P,
                        T, left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
-                       right_status, score, stereo_ssd_impl());
+                       right_status, score, stereo_ssd_impl(P));
   else
     hipLaunchKernelGGL(stereo_match_only_kernel<false>, dim3(n), dim3(64), stereo_lds_bytes(P), st, P,
                        T, left_rect, right_rect, left_rect_kp, left_status, n, right_rect_kp,
-                       right_status, score, stereo_ssd_impl());
+                       right_status, score, stereo_ssd_impl(P));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -474,6 +474,8 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
   if (!mono && (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height))
     return fail("left/right image sizes differ", KVFE_ERR_INVALID_ARG);
   if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
+  for (int v : {cfg->device_frames_persist, cfg->single_hip_stream, cfg->copy_inputs, cfg->ssd_impl})
+    if (v != 0 && v != 1) return fail("execution options of kvfe_config are 0 or 1", KVFE_ERR_INVALID_ARG);
   if (p.use_ransac) {
     const kvfe_tracker_params& tr = p.tracker;
     if (tr.ransac_randomize)
@@ -630,6 +632,7 @@ kvfe_status fill_params(kvfe_ctx* c) {
     if (w <= P.klt_win || h <= P.klt_win) break;
   }
   P.nlevels = nl;
+  P.ssd_dot4 = cfg.ssd_impl == 1 ? 1 : 0;
   P.klt_maxlevel = nl - 1;
   P.pyr_stride = std::max(off, 64);
   P.acap = ACAP;
@@ -897,7 +900,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // The kernels read this step's inputs straight from the pinned, device-mapped ring slot (a few
   // hundred bytes over PCIe, once per per-stream block): no H2D copy and none of the two launch
   // gaps around it.  The slot is released by the event recorded after the step's last kernel.
-  static const bool copy_inputs = std::getenv("KVFE_COPY_INPUTS") != nullptr;
+  const bool copy_inputs = c->cfg.copy_inputs != 0;
   if (copy_inputs) {
     join_tail(c);   // the previous step's finalisation (side stream) reads the single device copy of the inputs
     HIPCHK(c, hipMemcpyAsync(b.kf_R_cur, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B,
@@ -1363,7 +1366,7 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
   }
   if (s == KVFE_OK && alloc_frontend) {
     c->out_stride = out_record_stride(c->P.kcap);
-    c->out_direct = c->P.B <= 4;
+    c->out_direct = c->P.B <= 4 || cfg->single_hip_stream != 0;
     const size_t bytes = c->out_stride * (size_t)c->P.B;
     for (int i = 0; i < OUT_RING && s == KVFE_OK; i++) {
       void* h = nullptr;
@@ -1387,7 +1390,7 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
   if (s == KVFE_OK && parent &&
       hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess)
     s = KVFE_ERR_HIP;
-  static const bool no_side = std::getenv("KVFE_NO_SIDE_STREAM") != nullptr;
+  const bool no_side = cfg->single_hip_stream != 0;
   if (s == KVFE_OK && alloc_frontend && !no_side) {
     // KVFE_SIDE_PRIO=1: the side stream at the device's highest stream priority.  Measured: +0.5 ... 0.8 % on the
     // 64-stream step (the corner refinement on it is the longer side of the fork), but the rectification that runs
@@ -2290,6 +2293,9 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
     return do_step(c, dl, dr, P.W, N, inputs);
   }
   c->last_step_staged = false;
+  if (c->cfg.device_frames_persist)   // the caller keeps frame k valid until step k+1 has completed: no copy
+    return do_step(c, reinterpret_cast<const unsigned char*>(left_dev), reinterpret_cast<const unsigned char*>(right_dev),
+                   row_stride, image_stride, inputs);
   // the caller's buffers are only read by THIS step: the left image the next step's LK needs is copied into the
   // context (by the first pyramid launch, which reads it anyway)
   {
@@ -2527,19 +2533,10 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   return KVFE_OK;
 }
 
-// Reads the packed record of stream `s` written by the step `steps_back` steps before the latest one out of its pinned
-// ring slot (kvfe_dev.hpp "output side"): one event wait for THAT step's transfer, then host memcpys.  No device call
-// touches the context's streams, so the step that is running meanwhile is not disturbed.
-kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_back, kvfe_frame_output* out) {
-  DeviceGuard _dev(c);
-  if (!c || !out || s < 0 || s >= c->P.B || out->capacity < 0 || steps_back < 0 || steps_back >= OUT_RING)
-    return KVFE_ERR_INVALID_ARG;
-  for (kvfe_ctx* ch : c->children)
-    if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
-      const kvfe_status r = kvfe_frontend_get_output_at(ch, s - ch->s0, steps_back, out);
-      if (r != KVFE_OK) c->last_error = ch->last_error;
-      return r;
-    }
+// The packed record of stream `s` written by the step `steps_back` steps before the latest one, in its pinned ring slot
+// (kvfe_dev.hpp "output side"): one event wait for THAT step's transfer.  No device call touches the context's streams,
+// so the step that is running meanwhile is not disturbed.
+static kvfe_status locate_output(kvfe_ctx* c, int32_t s, int32_t steps_back, const unsigned char** rec_out) {
   if (c->out_steps <= steps_back) {
     c->last_error = "kvfe_frontend_get_output: no step has produced that output yet";
     return KVFE_ERR_INVALID_ARG;
@@ -2551,15 +2548,18 @@ kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_ba
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
   }
-  const KParams& P = c->P;
-  const unsigned char* rec = c->out_host[slot] + (size_t)s * c->out_stride;
+  *rec_out = c->out_host[slot] + (size_t)s * c->out_stride;
+  return KVFE_OK;
+}
+
+// header fields of a record -> kvfe_frame_output; returns the record's layout
+static OutLayout output_header(const KParams& P, const unsigned char* rec, kvfe_frame_output* out, int* n_rec, int* m_rec) {
   const OutHeader* h = reinterpret_cast<const OutHeader*>(rec);
-  const int count = h->n_keypoints, flags = h->flags, nmeas = h->n_meas;
-  out->n_keypoints = count;
-  out->is_keyframe = (flags & FLAG_KEYFRAME) ? 1 : 0;
+  out->n_keypoints = h->n_keypoints;
+  out->is_keyframe = (h->flags & FLAG_KEYFRAME) ? 1 : 0;
   out->n_tracked = h->n_tracked;
   out->n_detected = h->n_detected;
-  out->n_measurements = nmeas;
+  out->n_measurements = h->n_meas;
   out->frame_id = h->frame_count - 1;
   out->tracking_status_mono = h->trk_status[0];
   out->tracking_status_stereo = h->trk_status[1];
@@ -2575,9 +2575,27 @@ kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_ba
   out->tracking_status_pnp = h->pnp_status;
   out->nr_pnp_inliers = h->pnp_counts[0];
   std::memcpy(out->W_T_k_pnp, h->pnp_pose, sizeof(double) * 12);
-  const int np = std::min(count, P.kcap), mp = std::min(nmeas, P.kcap);   // entries the record holds
+  *n_rec = std::min(h->n_keypoints, P.kcap);   // entries the record holds
+  *m_rec = std::min(h->n_meas, P.kcap);
+  return out_layout(*n_rec, *m_rec, (h->flags & FLAG_STEREO) != 0);
+}
+
+kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_back, kvfe_frame_output* out) {
+  DeviceGuard _dev(c);
+  if (!c || !out || s < 0 || s >= c->P.B || out->capacity < 0 || steps_back < 0 || steps_back >= OUT_RING)
+    return KVFE_ERR_INVALID_ARG;
+  for (kvfe_ctx* ch : c->children)
+    if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
+      const kvfe_status r = kvfe_frontend_get_output_at(ch, s - ch->s0, steps_back, out);
+      if (r != KVFE_OK) c->last_error = ch->last_error;
+      return r;
+    }
+  const unsigned char* rec = nullptr;
+  TRY(locate_output(c, s, steps_back, &rec));
+  int np = 0, mp = 0;
+  const OutLayout L = output_header(c->P, rec, out, &np, &mp);
+  const int flags = reinterpret_cast<const OutHeader*>(rec)->flags;
   const bool stereo = (flags & FLAG_STEREO) != 0;
-  const OutLayout L = out_layout(np, mp, stereo);
   const int n = std::min(np, out->capacity);
   const int m = std::min(mp, out->capacity);
 #define DL(dst, off, bytes) \
@@ -2603,6 +2621,57 @@ kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_ba
     return KVFE_ERR_CAPACITY;
   }
   return KVFE_OK;
+}
+
+// Zero-copy variant: the array pointers of `out` are set to the arrays INSIDE the pinned record (stereo arrays NULL on a
+// frame without stereo data); they stay valid until KVFE_OUTPUT_RING - 1 - steps_back further steps have been enqueued.
+kvfe_status kvfe_frontend_view_output(kvfe_ctx* c, int32_t s, int32_t steps_back, kvfe_frame_output* out) {
+  DeviceGuard _dev(c);
+  if (!c || !out || s < 0 || s >= c->P.B || steps_back < 0 || steps_back >= OUT_RING) return KVFE_ERR_INVALID_ARG;
+  for (kvfe_ctx* ch : c->children)
+    if (s >= ch->s0 && s < ch->s0 + ch->P.B) {
+      const kvfe_status r = kvfe_frontend_view_output(ch, s - ch->s0, steps_back, out);
+      if (r != KVFE_OK) c->last_error = ch->last_error;
+      return r;
+    }
+  const unsigned char* rec = nullptr;
+  TRY(locate_output(c, s, steps_back, &rec));
+  int np = 0, mp = 0;
+  const OutLayout L = output_header(c->P, rec, out, &np, &mp);
+  const int flags = reinterpret_cast<const OutHeader*>(rec)->flags;
+  const bool stereo = (flags & FLAG_STEREO) != 0;
+  unsigned char* r = const_cast<unsigned char*>(rec);
+  out->capacity = np;
+  out->landmarks = reinterpret_cast<int64_t*>(r + L.lmk);
+  out->landmarks_age = reinterpret_cast<int32_t*>(r + L.age);
+  out->keypoints = reinterpret_cast<float*>(r + L.kp);
+  out->versors = reinterpret_cast<double*>(r + L.versor);
+  out->left_rect_xy = stereo ? reinterpret_cast<float*>(r + L.left_rect) : nullptr;
+  out->left_status = stereo ? r + L.left_status : nullptr;
+  out->right_rect_xy = stereo ? reinterpret_cast<float*>(r + L.right_rect) : nullptr;
+  out->right_status = stereo ? r + L.right_status : nullptr;
+  out->depth = stereo ? reinterpret_cast<double*>(r + L.depth) : nullptr;
+  out->right_xy = stereo ? reinterpret_cast<float*>(r + L.right_kp) : nullptr;
+  out->keypoints_3d = stereo ? reinterpret_cast<double*>(r + L.kp3d) : nullptr;
+  out->meas_landmark = reinterpret_cast<int64_t*>(r + L.meas_lmk);
+  out->meas_uL_uR_v = reinterpret_cast<double*>(r + L.meas);
+  if (flags & FLAG_OVERFLOW) {
+    c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
+    return KVFE_ERR_CAPACITY;
+  }
+  return KVFE_OK;
+}
+
+// All streams of the context at once: outs[s] as for kvfe_frontend_get_output_at (one call, one event wait).
+kvfe_status kvfe_frontend_get_outputs(kvfe_ctx* c, int32_t steps_back, kvfe_frame_output* outs) {
+  if (!c || !outs) return KVFE_ERR_INVALID_ARG;
+  kvfe_status worst = KVFE_OK;
+  for (int s = 0; s < c->P.B; s++) {
+    const kvfe_status r = kvfe_frontend_get_output_at(c, s, steps_back, outs + s);
+    if (r == KVFE_ERR_CAPACITY) worst = r;
+    else if (r != KVFE_OK) return r;
+  }
+  return worst;
 }
 
 kvfe_status kvfe_frontend_get_output(kvfe_ctx* c, int32_t s, kvfe_frame_output* out) {

@@ -43,7 +43,8 @@ class Context:
     def __init__(self, left: abi.CameraParams, right: abi.CameraParams, params: abi.FrontendParams,
                  batch: int = 1, device: int = 0, hip_stream: int | None = None,
                  candidate_capacity: int = 0, stream_groups: int = 0, frontend_type: int = 0,
-                 depth: "abi.DepthParams | None" = None):
+                 depth: "abi.DepthParams | None" = None, device_frames_persist: int = 0,
+                 single_hip_stream: int = 0, copy_inputs: int = 0, ssd_impl: int = 0):
         self.lib = load()
         cfg = abi.Config()
         cfg.left, cfg.right, cfg.params = left, right, params
@@ -52,6 +53,10 @@ class Context:
         cfg.candidate_capacity = candidate_capacity
         cfg.stream_groups = stream_groups
         cfg.frontend_type = frontend_type
+        cfg.device_frames_persist = device_frames_persist
+        cfg.single_hip_stream = single_hip_stream
+        cfg.copy_inputs = copy_inputs
+        cfg.ssd_impl = ssd_impl
         if depth is not None:   # RgbdVisionImuFrontend: CameraParams::DepthParams of `left`
             cfg.depth = depth
         self.depth_params = depth
@@ -537,6 +542,10 @@ class Context:
             d[k] = v[:m].copy() if k.startswith("meas_") else v[:n].copy()
         return d
 
+    def output_buffers(self) -> "OutputBuffers":
+        """caller-owned output storage for all streams, allocated once (kvfe_frontend_get_outputs fills it)"""
+        return OutputBuffers(self)
+
     def profile_enable(self, on=1):
         """on = N: every N-th step records per-stage HIP events (0 / False: off)."""
         self._chk(self.lib.kvfe_profile_enable(self._h, int(on)), "profile_enable")
@@ -553,6 +562,33 @@ class Context:
 
 
 # reference-shaped aliases ------------------------------------------------------------------------
+class OutputBuffers:
+    """kvfe_frame_output[batch] with their arrays, allocated once: `read(steps_back)` = kvfe_frontend_get_outputs -- one
+    C call copies every stream's record of that step out of the pinned ring slot (a consumer that reads frame k while
+    frame k+1 is being processed passes steps_back = 1)."""
+    FIELDS = (("landmarks", np.int64, 1), ("landmarks_age", np.int32, 1), ("keypoints", np.float32, 2),
+              ("versors", np.float64, 3), ("left_rect_xy", np.float32, 2), ("left_status", np.uint8, 1),
+              ("right_rect_xy", np.float32, 2), ("right_status", np.uint8, 1), ("depth", np.float64, 1),
+              ("right_xy", np.float32, 2), ("keypoints_3d", np.float64, 3), ("meas_landmark", np.int64, 1),
+              ("meas_uL_uR_v", np.float64, 3))
+
+    def __init__(self, ctx: "Context"):
+        self.ctx = ctx
+        B, cap = ctx.batch, ctx.kcap
+        self.structs = (abi.FrameOutput * B)()
+        self.arrays = []
+        for s in range(B):
+            arrs = {k: np.zeros((cap, w) if w > 1 else cap, dt) for k, dt, w in self.FIELDS}
+            self.structs[s].capacity = cap
+            for k, v in arrs.items():
+                setattr(self.structs[s], k, v.ctypes.data)
+            self.arrays.append(arrs)
+
+    def read(self, steps_back: int = 0):
+        self.ctx._chk(self.ctx.lib.kvfe_frontend_get_outputs(self.ctx._h, steps_back, self.structs), "frontend_get_outputs")
+        return self.structs
+
+
 class StereoVisionImuFrontend(Context):
     """Batched StereoVisionImuFrontend::spinOnce for `batch` independent streams."""
 

@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     L.kvfe_synchronize.argtypes = [vp]
     L.kvfe_frontend_get_output.argtypes = [vp, i32, C.POINTER(abi.FrameOutput)]
     L.kvfe_frontend_get_output_at.argtypes = [vp, i32, i32, C.POINTER(abi.FrameOutput)]
+    L.kvfe_frontend_get_outputs.argtypes = [vp, i32, C.POINTER(abi.FrameOutput)]
+    L.kvfe_frontend_view_output.argtypes = [vp, i32, i32, C.POINTER(abi.FrameOutput)]
     L.kvfe_profile_enable.argtypes = [vp, i32]
     L.kvfe_profile_read.argtypes = [vp, C.POINTER(abi.StageTimes)]
     f32 = C.c_float
@@ -170,7 +172,8 @@ def load() -> C.CDLL:
                "kvfe_outlier_rejection_3d3d_given_rotation", "kvfe_equalize_hist",
                "kvfe_frontend_staging_buffer", "kvfe_frontend_staging_wait", "kvfe_frontend_step_staged",
                "kvfe_frontend_step_host", "kvfe_frontend_step_device", "kvfe_frontend_reset",
-               "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_frontend_get_output_at", "kvfe_profile_enable",
+               "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_frontend_get_output_at", "kvfe_frontend_get_outputs", "kvfe_frontend_view_output",
+               "kvfe_profile_enable",
                "kvfe_profile_read", "kvfe_dense_stereo_reconstruction", "kvfe_dense_profile_read",
                "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume", "kvfe_outlier_rejection_3d3d",
                "kvfe_outlier_rejection_2d2d"):
@@ -180,7 +183,7 @@ def load() -> C.CDLL:
 
 
 NEW_R3_SYMBOLS = ["kvfe_build_optical_flow_pyramid"]
-NEW_R4_SYMBOLS = ["kvfe_frontend_get_output_at"]
+NEW_R4_SYMBOLS = ["kvfe_frontend_get_output_at", "kvfe_frontend_get_outputs", "kvfe_frontend_view_output"]
 
 NEW_R2_SYMBOLS = [
     "kvfe_check_undistorted_rectified_left_keypoints", "kvfe_distort_unrectify_keypoints",

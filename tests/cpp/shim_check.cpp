@@ -2,7 +2,10 @@
 // and drives the reference-signature methods on Kimera-shaped Frame / StereoFrame structs (same member names and
 // types as include/kimera-vio/frontend/Frame.h:160-186, StereoFrame.h:137-171).  Input / output format as
 // adapter_sequence.cpp; tests/test_gpu_parity.py compares the records with the oracle.
+#include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -123,7 +126,11 @@ bool read_exact(FILE* f, void* p, size_t n) { return std::fread(p, 1, n, f) == n
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc != 3) return 2;
+  // shim_check in.bin out.bin            the parity records (tests/test_gpu_components_r2.py)
+  // shim_check in.bin out.bin bench N    N timed StereoVisionImuFrontend::spinOnce calls over the input frames walked
+  //                                      ping-pong, every call returning its StereoFrontendOutput (bench.py: single_stream_spinonce)
+  const int bench_n = (argc == 5 && std::string(argv[3]) == "bench") ? std::atoi(argv[4]) : 0;
+  if (argc != 3 && bench_n <= 0) return 2;
   FILE* fi = std::fopen(argv[1], "rb");
   FILE* fo = std::fopen(argv[2], "wb");
   if (!fi || !fo) return 2;
@@ -144,6 +151,65 @@ int main(int argc, char** argv) {
   }
   std::fclose(fi);
   Writer w{fo};
+  if (bench_n > 0) {
+    try {
+      kvfe::Context fctx(cfg.left, cfg.right, cfg.params, 1, cfg.device);
+      kvfe::StereoCamera cam(fctx);
+      const kvfe::Pose3 bl = cam.getBodyPoseLeftCamRect(cfg.left);
+      kvfe::shim::StereoVisionImuFrontend frontend(fctx, bl.R);
+      const int warm = 20;
+      size_t total_meas = 0, keyframes = 0;
+      std::chrono::steady_clock::time_point t_begin;
+      for (int it = 0; it < warm + bench_n; it++) {
+        if (it == warm) t_begin = std::chrono::steady_clock::now();
+        const int period = 2 * (n_frames - 1), j = it % period, i = j < n_frames ? j : period - j;
+        VIO::StereoImuSyncPacket pk;
+        pk.stereo_frame_.timestamp_ = (int64_t)it * 50000000;
+        pk.stereo_frame_.left_frame_.img_ = cv::Mat(H, W, CV_8UC1, lefts[i].data(), (size_t)W);
+        pk.stereo_frame_.right_frame_.img_ = cv::Mat(H, W, CV_8UC1, rights[i].data(), (size_t)W);
+        const int64_t t1 = pk.stereo_frame_.timestamp_, t0 = t1 - 50000000;
+        // bench input: keyframe_R_cur_frame[0..2] of frame i carries the body-frame gyro rate (rad/s) of the interval
+        // i-1 -> i, so that the rotation the shim preintegrates is the one the images show; walking backwards it is
+        // the negative rate of the interval just undone
+        const bool fwd = j < n_frames && j > 0;
+        const double* g = fwd ? inputs[i].keyframe_R_cur_frame : inputs[std::min(i + 1, n_frames - 1)].keyframe_R_cur_frame;
+        const double sgn = it == 0 ? 0.0 : (fwd ? 1.0 : -1.0);
+        for (int q = 0; q <= 10; q++) {
+          pk.imu_stamps_.v.push_back(t0 + (t1 - t0) * q / 10);
+          const double row[6] = {0.1, 9.8, 0.2, sgn * g[0], sgn * g[1], sgn * g[2]};   // acc, gyro
+          pk.imu_accgyrs_.v.insert(pk.imu_accgyrs_.v.end(), row, row + 6);
+        }
+        auto out = frontend.spinOnce(std::move(pk), [&](const kvfe::shim::SpinResult& r) {
+          auto m = std::make_shared<VIO::StatusStereoMeasurements>();
+          m->first.kfTrackingStatus_mono_ = static_cast<VIO::TrackingStatus>(r.kfTrackingStatus_mono);
+          m->first.kfTrackingStatus_stereo_ = static_cast<VIO::TrackingStatus>(r.kfTrackingStatus_stereo);
+          for (size_t q = 0; q < r.meas_landmark.size(); q++)
+            m->second.push_back({(VIO::LandmarkId)r.meas_landmark[q],
+                                 {r.meas_uL_uR_v[3 * q], r.meas_uL_uR_v[3 * q + 1], r.meas_uL_uR_v[3 * q + 2]}});
+          VIO::StereoFrame sfo;
+          sfo.timestamp_ = r.timestamp;
+          kvfe::shim::from_frame(r.left_frame, &sfo.left_frame_);
+          kvfe::shim::from_status(r.left_keypoints_rectified, &sfo.left_keypoints_rectified_);
+          kvfe::shim::from_status(r.right_keypoints_rectified, &sfo.right_keypoints_rectified_);
+          sfo.keypoints_depth_ = r.keypoints_depth;
+          return std::make_unique<VIO::StereoFrontendOutput>(r.is_keyframe, m, sfo, VIO::ImuAccGyrS());
+        });
+        if (it >= warm) {
+          total_meas += out->status_stereo_measurements_->second.size();
+          keyframes += out->is_keyframe_ ? 1 : 0;
+        }
+      }
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+      std::printf("{\"spins\": %d, \"seconds\": %.6f, \"pairs_per_s\": %.2f, \"ms_per_pair\": %.5f, "
+                  "\"keyframes\": %zu, \"measurements_per_spin\": %.1f}\n",
+                  bench_n, sec, bench_n / sec, 1e3 * sec / bench_n, keyframes, (double)total_meas / bench_n);
+    } catch (const kvfe::Error& e) {
+      std::fprintf(stderr, "kvfe::Error %d: %s\n", (int)e.status, e.what());
+      return 1;
+    }
+    std::fclose(fo);
+    return 0;
+  }
   try {
     kvfe::Context ctx(cfg.left, cfg.right, cfg.params, 1, cfg.device);
     kvfe::shim::FeatureDetector feature_detector(ctx);

@@ -36,7 +36,7 @@ def _build(config, mode, **kw):
     return dataclasses.replace(_CACHE[key], mode=mode)
 
 
-def _run_workload(wl, n_steps, check_streams, replicas_equal_at_end=True):
+def _run_workload(wl, n_steps, check_streams, replicas_equal_at_end=True, persist=1):
     """drives the GPU context exactly like bench.py's timed loop and the per-unique-stream oracles in
     lock-step; returns [(step, is_keyframe, n_tracked, n_detected)] of unique stream 0"""
     import torch
@@ -45,7 +45,8 @@ def _run_workload(wl, n_steps, check_streams, replicas_equal_at_end=True):
     d_left = torch.from_numpy(lefts).to(dev)
     d_right = torch.from_numpy(rights).to(dev)
     torch.cuda.synchronize()
-    ctx = F.Context(wl.left, wl.right, wl.params, batch=wl.batch)
+    # bench.py's contexts: kvfe_config.device_frames_persist = 1 (the frames sit in a device ring that is never rewritten)
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=wl.batch, device_frames_persist=persist)
     fes = [O.Frontend(wl.left, wl.right, wl.params) for _ in range(wl.unique)]
     kinds = []
     try:
@@ -85,6 +86,13 @@ def test_c3_headline_64_streams_600_features(mode):
         assert all(k[2] > 400 for k in kinds[1:]), kinds        # the headline really tracks ~600 points
     else:
         assert [k[1] for k in kinds[:9]] == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+
+
+def test_c3_with_the_context_owned_level0_copy():
+    """bench.py --copy-level0 (kvfe_config.device_frames_persist = 0, the default of the C ABI): the pyramid launch also
+    writes the context's own copy of the left frame, and the next step tracks from it"""
+    wl = _build("c3", "kf")
+    _run_workload(wl, 5, [0, 7, 63], persist=0)
 
 
 @pytest.mark.parametrize("mode", ["kf", "nominal"])

@@ -2,7 +2,7 @@
 of its new corners + finalisation) runs on the library's side stream while the next step is already being enqueued, so
 every buffer the next step's entry point touches before do_step must be ordered after that tail:
   * equalize_image = 1 + kvfe_frontend_step_host uploads the raw frames into the rectified buffers as scratch,
-  * KVFE_COPY_INPUTS copies the per-stream inputs into the single device copy the finalisation reads,
+  * kvfe_config.copy_inputs copies the per-stream inputs into the single device copy the finalisation reads,
   * a caller-owned hip_stream must cover the whole step (work enqueued on it afterwards runs after the tail).
 Each case replays MicroEuroc frames with every frame a keyframe (the tail always has work) and compares the LAST
 step's full output with the oracle: any corruption of an earlier keyframe's right keypoints / depths changes the stereo
@@ -22,19 +22,20 @@ from test_gpu_parity import _euroc_ransac_params, _kf_rotations, euroc_cams, oca
 pytestmark = pytest.mark.gpu
 
 
-def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=None, features=200):
+def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=None, features=200, **ctx_kw):
     seq = dict(seq)
     seq["camR"] = _kf_rotations(seq["body_R"], ocam)
     L, R = euroc_cams()
     p = _euroc_ransac_params(max_features_per_frame=features)
     p.stereo.equalize_image = equalize
     fe = [O.Frontend(L, R, p) for _ in range(B)]
-    c = F.Context(L, R, p, batch=B, hip_stream=hip_stream)
+    c = F.Context(L, R, p, batch=B, hip_stream=hip_stream, **ctx_kw)
     try:
-        exp = None
+        exp, hist = None, []
         lkf = [None] * B   # frame index of each stream's last keyframe (from the oracle: nothing is read back from the GPU)
         for i in range(n):
-            idx = [i, 8 - i][:B]
+            pp = lambda j: (j % 16) if (j % 16) < 9 else 16 - (j % 16)   # ping-pong over the 9 frames
+            idx = ([i, 8 - i] + [pp(i + 3 * s) for s in range(2, B)])[:B]
             # keyframe_R_cur_frame: rotation from the stream's last keyframe to this frame
             Rs = [np.eye(3) if lkf[s] is None else seq["camR"][lkf[s]].T @ seq["camR"][idx[s]] for s in range(B)]
             ts = [int(seq["ts"][i])] * B
@@ -45,11 +46,16 @@ def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=
             if sync_every and (i + 1) % sync_every == 0:
                 c.synchronize()
             exp = [fe[s].process(lefts[s], rights[s], ts[s], Rs[s], bool(fk[s])) for s in range(B)]
+            hist.append(exp)
             for s in range(B):
                 if exp[s]["is_keyframe"]:
                     lkf[s] = idx[s]
         for s in range(B):
             assert_step_equal(c.get_output(s), exp[s], ("last", s))
+            # the output ring: the records of the two steps before the last one are still there (kvfe_frontend_get_output_at)
+            for back in (1, 2):
+                if len(hist) > back:
+                    assert_step_equal(c.get_output(s, steps_back=back), hist[-1 - back][s], ("back", back, s))
             if force is None:
                 assert exp[s]["is_keyframe"] and exp[s]["n_measurements"] > min(50, features // 2)
         return exp
@@ -70,21 +76,21 @@ def test_pipelined_host_steps_user_stream(seq, ocam):
     st.synchronize()
 
 
-def test_pipelined_host_steps_copy_inputs():
-    """KVFE_COPY_INPUTS (read when the library is loaded): the same replay in a sub-process"""
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import numpy as np, os\n"
-            "import oracle_lib as O\n"
-            "import test_gpu_pipelined_r3 as T\n"
-            "from test_gpu_parity import G, euroc_cams\n"
-            "z = np.load(os.path.join(G, 'micro_euroc_f10_18.npz'))\n"
-            "seq = dict(lefts=z['lefts'], rights=z['rights'], ts=z['timestamps'], body_R=z['body_R'])\n"
-            "L, R = euroc_cams()\n"
-            "T._replay(seq, O.Camera(L, R), 1)\n"
-            "print('ok')\n" % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KVFE_COPY_INPUTS="1"), capture_output=True,
-                       text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+def test_pipelined_host_steps_copy_inputs(seq, ocam):
+    """kvfe_config.copy_inputs = 1: the per-stream inputs travel by a H2D copy into the single device copy the
+    finalisation reads (the previous step's tail must be joined first)"""
+    _replay(seq, ocam, 1, copy_inputs=1)
+
+
+def test_pipelined_host_steps_single_hip_stream(seq, ocam):
+    """kvfe_config.single_hip_stream = 1: no side stream, no output stream -- every kernel in order on one stream"""
+    _replay(seq, ocam, 0, single_hip_stream=1)
+    _replay(seq, ocam, 1, B=6, single_hip_stream=1)
+
+
+def test_pipelined_host_steps_many_streams_output_stream(seq, ocam):
+    """more than four streams: the output records go through the device staging buffer and the output stream"""
+    _replay(seq, ocam, 0, B=6)
 
 
 @pytest.fixture

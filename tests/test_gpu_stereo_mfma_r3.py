@@ -1,6 +1,6 @@
 """Round 3: the SSD search of searchRightKeypointEpipolar (StereoMatcher.cpp:196-423) on the matrix cores
 (`ssd_search_mfma`, v_mfma_i32_16x16x64_i8 on the images shifted to signed bytes) against the oracle and against the
-v_dot4 search it replaces (KVFE_SSD_IMPL=0), tolerance 0: right keypoints, statuses and scores.  Template / stripe
+v_dot4 search it replaces (kvfe_config.ssd_impl = 1), tolerance 0: right keypoints, statuses and scores.  Template / stripe
 geometries cover both K-step variants (compile-time 2 = the shipped 101-column template, run-time 1 and 3), stripes
 higher than the template (several offset rows), template widths with one and three bytes in the last dword, and keypoints whose template or stripe is clamped at either image border."""
 import os
@@ -43,16 +43,6 @@ def _keypoints(left):
     return np.concatenate([kps, np.array(border + rows, np.float32)]).astype(np.float32)
 
 
-@pytest.fixture
-def ssd_impl_env():
-    old = os.environ.get("KVFE_SSD_IMPL")
-    yield
-    if old is None:
-        os.environ.pop("KVFE_SSD_IMPL", None)
-    else:
-        os.environ["KVFE_SSD_IMPL"] = old
-
-
 @pytest.mark.parametrize("tc,tr,extra,min_dist", [   # (template sizes are odd, extra rows even: the reference's CHECKs)
     (101, 11, 0, 0.5),    # shipped (EuRoC): 2 K steps, 101 offsets, odd template height (one phantom row)
     (101, 11, 2, 0.5),    # three offset rows
@@ -62,7 +52,7 @@ def ssd_impl_env():
     (121, 5, 0, 0.6),     # three K steps
     (49, 3, 4, 0.3),      # template + 15 = 64: exactly one K step; 160-odd offsets, five offset rows
 ])
-def test_ssd_search_matrix_cores_vs_oracle_and_dot4(ssd_impl_env, tc, tr, extra, min_dist):
+def test_ssd_search_matrix_cores_vs_oracle_and_dot4(tc, tr, extra, min_dist):
     L, R = _cams()
     p = _params(tc, tr, extra, min_dist)
     ocam = O.Camera(L, R)
@@ -70,22 +60,19 @@ def test_ssd_search_matrix_cores_vs_oracle_and_dot4(ssd_impl_env, tc, tr, extra,
     kps = _keypoints(left)
     st = np.zeros(len(kps), np.uint8)
     exy, est, esc = ocam.get_right_keypoints_rectified(left, right, kps, st, p.stereo)
-    c = F.Context(L, R, p)
-    try:
-        res = {}
-        for impl in ("1", "0"):
-            os.environ["KVFE_SSD_IMPL"] = impl
-            res[impl] = c.get_right_keypoints_rectified(left, right, kps, st)
-            rxy, rst, sc = res[impl]
+    for impl in (0, 1):   # kvfe_config.ssd_impl: 0 = matrix cores where the geometry fits, 1 = v_dot4 everywhere
+        c = F.Context(L, R, p, ssd_impl=impl)
+        try:
+            rxy, rst, sc = c.get_right_keypoints_rectified(left, right, kps, st)
             assert np.array_equal(rst, est), impl
             assert np.array_equal(rxy, exy), impl
             assert np.array_equal(sc, esc), impl
-        assert (est == 0).sum() > 60
-    finally:
-        c.close()
+        finally:
+            c.close()
+    assert (est == 0).sum() > 60
 
 
-def test_ssd_search_matrix_cores_shifted_image(ssd_impl_env):
+def test_ssd_search_matrix_cores_shifted_image():
     """the reference's own construction (tests/testStereoMatcher.cpp:272-388): the right image is the left one shifted,
     so every interior match is exact (SSD 0) -- with the EuRoC stripe width, which takes the matrix-core path"""
     L, R = _cams()
@@ -94,7 +81,6 @@ def test_ssd_search_matrix_cores_shifted_image(ssd_impl_env):
     left = _gray("left_img_0.png")
     kps, _ = O.good_features_to_track(left, 100, 0.01, 10, 3)
     cols = left.shape[1]
-    os.environ["KVFE_SSD_IMPL"] = "1"
     c = F.Context(L, R, p)
     try:
         for offset in (-20, -5):
