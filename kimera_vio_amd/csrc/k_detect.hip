@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
 typedef int me_v4i __attribute__((ext_vector_type(4)));
 constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig2_kernel (row-need masks: 128 bits incl. margins)
 
-template <bool HAS_MASK>
+template <bool HAS_MASK, bool RUNS>
 __global__ __launch_bounds__(64) void mineig2_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
     const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
@@ -321,7 +321,8 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
     const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int xcd_mode, int run_skip) {
+    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int xcd_mode) {
+  constexpr bool run_skip = RUNS;   // walk the runs of needed rows (round 4) / step through every row (round 3, A/B)
   // block -> (column strip, row strip, stream).  xcd_mode: a 1-D grid in which workgroup b (it runs on XCD b & 7: a
   // speed assumption only) takes the strips of the streams s = b & 7 (mod 8), so that the cache lines neighbouring
   // strips share -- 64-byte row segments out of 128-byte lines, the 3-column and 5-row overlaps -- meet in ONE L2.
@@ -472,13 +473,34 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     rr = rr >= H ? 2 * H - 2 - rr : rr;
     return (unsigned)min(max(rr, 0), H - 1);
   };
-  auto issue_off = [&](unsigned& dst, unsigned soff) {
-    asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  // The destination of a request is an ACCUMULATION register (a0 / a1 / a2, one per rotating slot; gfx950 loads can
+  // target them): hipcc never allocates AGPRs in this kernel, so nothing it generates can touch a register with a request
+  // in flight.  (With a VGPR destination bound to a C++ variable hipcc is free to copy that variable -- a phi move at a
+  // loop header, a tied asm operand -- before the byte has landed: it cannot know that the asm statement's output is
+  // written late.  tools/check_inflight_regs.py checks the ISA.)
+  auto issue_off = [&](auto slot_tag, unsigned soff) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    if constexpr (SLOT == 0) asm volatile("buffer_load_ubyte a0, %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a0", "memory");
+    else if constexpr (SLOT == 1) asm volatile("buffer_load_ubyte a1, %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a1", "memory");
+    else asm volatile("buffer_load_ubyte a2, %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a2", "memory");
   };
-  unsigned pq0, pq1, pq2;  // raw bytes: converted at use
-  issue_off(pq0, row_of(r_first) * stride_u);
-  issue_off(pq1, row_of(r_first + 1) * stride_u);
-  issue_off(pq2, row_of(r_first + 2) * stride_u);
+  // wait for the slot's request (at most two younger ones outstanding: vmcnt counts in issue order) and convert the byte
+  auto take = [&](auto slot_tag) -> float {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    float p;
+    if constexpr (SLOT == 0) asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a0\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a0", "memory");
+    else if constexpr (SLOT == 1) asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a1\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a1", "memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a2\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a2", "memory");
+    return p;
+  };
+  using SL0 = std::integral_constant<int, 0>;
+  using SL1 = std::integral_constant<int, 1>;
+  using SL2 = std::integral_constant<int, 2>;
+  if constexpr (!run_skip) {
+    issue_off(SL0{}, row_of(r_first) * stride_u);
+    issue_off(SL1{}, row_of(r_first + 1) * stride_u);
+    issue_off(SL2{}, row_of(r_first + 2) * stride_u);
+  }
   const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
   // wave-wide lane facts as scalar masks
   const unsigned long long out_mask = __ballot(out_col);
@@ -503,18 +525,22 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  CHECK: the stages test their row ranges and
   // copy border rows (prologue, epilogue, image-border strips); otherwise every stage is live.  Only wave-uniform
   // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
-  auto step = [&](auto check_tag, int r, MeRow& X, MeRow& Y, MeRow& Z, unsigned& p_next) {
+  auto step = [&](auto check_tag, auto slot_tag, int r, MeRow& X, MeRow& Y, MeRow& Z, const bool live = true) {
     constexpr bool CHECK = decltype(check_tag)::value;
     const unsigned long long in_m_mask = in_b_mask;  // row m = r-3 was the box row of the previous step
     // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
     {
-      asm volatile("s_waitcnt vmcnt(2)" : "+v"(p_next));
-      const float p = (float)p_next;
+      const float p = take(slot_tag);
       if (CHECK) {
-        issue_off(p_next, row_of(r + 3) * stride_u);
+        issue_off(slot_tag, row_of(r + 3) * stride_u);
       } else {
-        issue_off(p_next, soff_next);
+        issue_off(slot_tag, soff_next);
         soff_next += stride_u;
+      }
+      if (CHECK && !live) {   // a step that only restarts the request pipeline (the three steps in front of a run)
+        fetch_mask(r - 1);
+        in_b_mask = 0ull;
+        return;
       }
       const float pl = dpp_from_left(p), pr = dpp_from_right(p);
       X.dh = pr - pl;
@@ -618,7 +644,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // slots rotate with the row index: slot(r) = (r - r_first) % 3
   int r = r_first;
   fetch_mask(r - 2);   // (the first step's "previous" request)
-  if (run_skip) {
+  if constexpr (run_skip) {
     // RUNS OF NEEDED ROWS (round 4).  With a few hundred tracked keypoints and discs of radius min_distance a frame is
     // almost entirely masked (the 600-feature benchmark streams: 3 % of the pixels pass the mask, a quarter of a strip's
     // rows is needed by anybody), so the wave walks only the runs of pixel rows that some unmasked pixel needs -- it
@@ -640,52 +666,55 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
       const unsigned long long m = (needp1 >> (q - 64)) << (q - 64);
       return m ? ys - 3 + 64 + __builtin_ctzll(m) : 0x7fffffff;
     };
+    // The request pipeline is (re)started by three steps of the SAME loop body that do nothing but wait for the slot's
+    // previous request and issue the next one (`live` = false): rows t, t+1, t+2 of a run starting at t are requested by
+    // the steps t-3, t-2, t-1.  No separate priming code: the destination registers of the hand-issued loads must be
+    // the same at every site (hipcc does not know that they are written late; a register copy between two sites
+    // would read a byte that has not landed -- tools/check_inflight_regs.py scans the ISA for exactly that).
+    r = r_first - 3;
+    bool live = false;
     while (true) {
-      const int rn = next_needed(r);
-      if (rn > r_last) break;
-      if (rn >= r + 3) {
-        r += ((rn - r) / 3) * 3;
-        issue_off(pq0, row_of(r) * stride_u);
-        issue_off(pq1, row_of(r + 1) * stride_u);
-        issue_off(pq2, row_of(r + 2) * stride_u);
-        fetch_mask(r - 2);
-        in_b_mask = 0ull;
+      if (live) {
+        const int rn = next_needed(r);
+        if (rn > r_last) break;
+        if (rn >= r + 3) {   // a gap: the run that starts at (or up to two rows before) rn is primed from three rows back
+          r += ((rn - r) / 3) * 3 - 3;
+          live = false;
+        }
       }
-      if (r >= rs && r + 2 <= re) {
-        soff_next = (unsigned)(r + 3) * stride_u;
-        step(NC{}, r, S0, S2, S1, pq0);
-        step(NC{}, r + 1, S1, S0, S2, pq1);
-        step(NC{}, r + 2, S2, S1, S0, pq2);
-      } else {
-        step(CK{}, r, S0, S2, S1, pq0);
-        if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
-        if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
-      }
+      // (checked steps only: with the unchecked steady variant in the same loop nest hipcc needs 96 instead of 62
+      // VGPRs, i.e. 4 instead of 7 waves per SIMD; the walk spends most of its steps near run boundaries anyway)
+      step(CK{}, SL0{}, r, S0, S2, S1, live);
+      if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2, live);
+      if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0, live);
       r += 3;
+      live = true;
     }
   } else {
   // prologue: checked steps up to the first steady row, rounded up to a whole slot rotation
   const int n_pro = rs > re ? 0x3fffffff : ((rs - r_first + 2) / 3) * 3;
   for (; r <= r_last && r - r_first < n_pro; r += 3) {
-    step(CK{}, r, S0, S2, S1, pq0);
-    if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
-    if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
+    step(CK{}, SL0{}, r, S0, S2, S1);
+    if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
+    if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
   }
   if (r + 2 <= re) {
     // the three requests in flight are rows r, r+1, r+2 (the prologue issued them with the checked addressing)
     soff_next = (unsigned)(r + 3) * stride_u;
     for (; r + 2 <= re; r += 3) {
-      step(NC{}, r, S0, S2, S1, pq0);
-      step(NC{}, r + 1, S1, S0, S2, pq1);
-      step(NC{}, r + 2, S2, S1, S0, pq2);
+      step(NC{}, SL0{}, r, S0, S2, S1);
+      step(NC{}, SL1{}, r + 1, S1, S0, S2);
+      step(NC{}, SL2{}, r + 2, S2, S1, S0);
     }
   }
   for (; r <= r_last; r += 3) {
-    step(CK{}, r, S0, S2, S1, pq0);
-    if (r + 1 <= r_last) step(CK{}, r + 1, S1, S0, S2, pq1);
-    if (r + 2 <= r_last) step(CK{}, r + 2, S2, S1, S0, pq2);
+    step(CK{}, SL0{}, r, S0, S2, S1);
+    if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
+    if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
   }
   }
+  // the row requests issued beyond the last step are still in flight: they land before their registers are re-used
+  asm volatile("s_waitcnt vmcnt(0)" : : : "a0", "a1", "a2", "memory");
   __syncthreads();
   flush();
   for (int off = 32; off > 0; off >>= 1) bestv = fmaxf(bestv, __shfl_xor(bestv, off));
@@ -746,16 +775,15 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     // KVFE_MINEIG_SKIP=0: step through every row of a strip (round 3) instead of walking the runs of needed rows (A/B)
     static const int run_skip = std::getenv("KVFE_MINEIG_SKIP") ? std::atoi(std::getenv("KVFE_MINEIG_SKIP")) : 1;
     const dim3 grid = xcd ? dim3((unsigned)(8 * ((P.B + 7) / 8) * nx * ny)) : dim3((unsigned)nx, (unsigned)ny, (unsigned)P.B);
-    if (user_mask)
-      hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
-                         img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
-                         T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                         D.maxkey, strip_rows, P.B, nx, ny, xcd, run_skip);
-    else
-      hipLaunchKernelGGL(mineig2_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
-                         img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
-                         T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                         D.maxkey, strip_rows, P.B, nx, ny, xcd, run_skip);
+#define KVFE_ME2(MASK_, RUNS_)                                                                                    \
+  hipLaunchKernelGGL((mineig2_kernel<MASK_, RUNS_>), grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, \
+                     P.W, P.H, P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs,        \
+                     S.flags, D.cand, D.cand_count, D.maxkey, strip_rows, P.B, nx, ny, xcd)
+    if (user_mask && run_skip) KVFE_ME2(true, true);
+    else if (user_mask) KVFE_ME2(true, false);
+    else if (run_skip) KVFE_ME2(false, true);
+    else KVFE_ME2(false, false);
+#undef KVFE_ME2
     return;
   }
   const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);

@@ -6,9 +6,9 @@ timeout 120 python -c "
 import sys; sys.path.insert(0,'tests')
 import test_gpu_pyramid_r3 as T
 c=T._ctx(752,480,2,win=8); print('sanity ok')" || { echo "SANITY FAILED"; exit 1; }
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/a_tests.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/a_tests.log
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/a_tests.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/a_tests.log | cut -c1-220
 echo "== KVFE_SELECT_IMPL=1 on detection + sequences"
-KVFE_SELECT_IMPL=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_configs.py tests/test_gpu_fuzz_slices.py -m gpu -q -x > gpurun_out/a_tests_sel.log 2>&1; echo "pytest(select rounds) rc=$?"; tail -8 gpurun_out/a_tests_sel.log
+KVFE_SELECT_IMPL=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_configs.py tests/test_gpu_fuzz_slices.py -m gpu -q > gpurun_out/a_tests_sel.log 2>&1; echo "pytest(select rounds) rc=$?"; tail -12 gpurun_out/a_tests_sel.log | cut -c1-220
 run() {
 env $1 timeout 300 python bench.py --legs ${2:-none} --steps 30 --warmup 8 --repeats 2 --stage-event-stride 4 2> gpurun_out/a_bench.err | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); st=d.get('stage_ms_per_step_summed_over_groups',{})
