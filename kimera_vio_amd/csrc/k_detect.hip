@@ -958,8 +958,6 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
                                                        int fixed_need, int prof) {
   const int s = blockIdx.x;
   if (!(S.flags[s] & FLAG_DETECT)) return;
-  const bool use_rounds = (prof & 2) != 0;   // KVFE_SELECT_IMPL=1
-  prof &= 1;
   SEL_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // LDS carve-up: [xy u32 [LDS_SORT_CAP] when the blocked-pixel bitmap fits |] sortkeys [LDS_SORT_CAP] u64 |
@@ -1331,156 +1329,12 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     }
     __syncthreads();
     };
-    // KVFE_SELECT_IMPL=1 (opt-in, round 3: written and checked against the sequential filter on the CPU --
-    // tests/test_select_rounds_algebra.py -- NOT yet measured on a GPU): the same filter by ROUNDS over all threads of the
-    // block instead of one wave walking the ranked list.  The accepted set is the lexicographically-first maximal
-    // independent set of the "closer than minDistance" graph in rank order; a candidate is decided as soon as all its
-    // stronger neighbours are:
-    //   test:    undecided r -- its pixel is blocked (disc of a corner accepted in an earlier round) -> rejected;
-    //            otherwise no candidate q < r within minDistance is undecided or pending -> pending;
-    //   commit:  pending -> accepted, disc marked;
-    // until nothing is undecided.  Inside a test phase a neighbour's state may be read from before or after its own
-    // test: undecided (0) and pending (3) both block, a stale 0 only costs a round.  Neighbours come from a grid of
-    // cells of side minDistance (3 x 3 cells, as the reference's own search); the real frames' 5 553 candidates take
-    // 180 k cycles in the sequential walk (457 cycles per accepted corner).
-    bool did_rounds = false;
-    if (use_rounds && !two_pass && md <= 32 && NL >= 1024 && W < 65536 && H < 65536) {
-      const int gw = (W + md - 1) / md, gh = (H + md - 1) / md, ncell = gw * gh;
-      const size_t bm_bytes = ((size_t)H * rw * 8 + 15) & ~(size_t)15;
-      const size_t need = (size_t)SEL_XY_BYTES + bm_bytes + (size_t)LDS_SORT_CAP * 5 + sizeof(int) * ((size_t)ncell + 2);
-      const long long avail_b = sel_bitmap_lds_bytes(W, H);
-      const size_t avail = (size_t)(avail_b > (long long)SEL_LDS_BITMAP_MIN ? avail_b : (long long)SEL_LDS_BITMAP_MIN);
-      if (need <= avail && ncell < 65536) {
-        did_rounds = true;
-        unsigned char* F = lds_raw + SEL_XY_BYTES + bm_bytes;
-        unsigned char* stt = F;                                                        // [NL] 0 undecided 1 accepted 2 rejected 3 pending
-        unsigned short* cidx = reinterpret_cast<unsigned short*>(F + LDS_SORT_CAP);    // [NL] cell of candidate r
-        unsigned short* items = cidx + LDS_SORT_CAP;                                   // [NL] ranks grouped by cell
-        int* cstart = reinterpret_cast<int*>(items + LDS_SORT_CAP);                    // [ncell + 1]
-        __shared__ int hwt[64];                                                        // half widths of the disc's rows
-        const unsigned mdiv = (unsigned)(((1ull << 21) + (unsigned)md - 1) / (unsigned)md);   // x / md = (x * mdiv) >> 21 for x < 2^16, md <= 32
-        auto div_md = [&](int v) -> int { return (int)(((unsigned long long)(unsigned)v * mdiv) >> 21); };
-        const int md2i = md * md;
-        for (int i = tid; i <= ncell; i += SEL_T) cstart[i] = 0;
-        if (tid < 2 * md - 1) {
-          const int dy = tid - (md - 1);
-          const int t = md2i - dy * dy;  // > 0
-          int h = (int)sqrtf((float)t);
-          while (h * h >= t) h--;
-          while ((h + 1) * (h + 1) < t) h++;
-          hwt[tid] = h;
-        }
-        __syncthreads();
-        for (int r = tid; r < NL; r += SEL_T) {
-          const unsigned c = xy[r];
-          const int ci = div_md((int)(c >> 16)) * gw + div_md((int)(c & 0xffffu));
-          cidx[r] = (unsigned short)ci;
-          stt[r] = 0;
-          atomicAdd(&cstart[ci + 1], 1);   // counts one slot up: the inclusive scan below leaves the cells' first items
-        }
-        __syncthreads();
-        {
-          const int per = (ncell + SEL_T) / SEL_T;   // ceil((ncell + 1) / SEL_T) entries per thread
-          const int b = min(tid * per, ncell + 1), e = min(b + per, ncell + 1);
-          int sum = 0;
-          for (int i = b; i < e; i++) sum += cstart[i];
-          int run = block_exclusive_scan(sum, wave_tot, nullptr);
-          for (int i = b; i < e; i++) {
-            run += cstart[i];
-            cstart[i] = run;
-          }
-        }
-        __syncthreads();
-        // fill: the cursor of a cell is its own start; afterwards cstart[i] is the END of cell i (= the start of i + 1)
-        for (int r = tid; r < NL; r += SEL_T) items[atomicAdd(&cstart[cidx[r]], 1)] = (unsigned short)r;
-        __syncthreads();
-        for (;;) {
-          if (tid == 0) sh_flag = 0;
-          __syncthreads();
-          for (int r = tid; r < NL; r += SEL_T) {
-            if (stt[r] != 0) continue;
-            const unsigned c = xy[r];
-            const int x = (int)(c & 0xffffu), y = (int)(c >> 16);
-            if ((bm[y * rw + (x >> 6)] >> (x & 63)) & 1ull) {
-              stt[r] = 2;
-              continue;
-            }
-            const int ci = cidx[r];
-            const int cy = div_md(y), cx = ci - cy * gw;
-            bool wait = false;
-            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, gh - 1) && !wait; yy++)
-              for (int xx = max(cx - 1, 0); xx <= min(cx + 1, gw - 1) && !wait; xx++) {
-                const int cell = yy * gw + xx;
-                const int kb = cell ? cstart[cell - 1] : 0, ke = cstart[cell];
-                for (int k = kb; k < ke; k++) {
-                  const int q = items[k];
-                  if (q >= r) continue;
-                  const unsigned char sq = stt[q];
-                  if (sq != 0 && sq != 3) continue;
-                  const unsigned cq = xy[q];
-                  const int dx = x - (int)(cq & 0xffffu), dy = y - (int)(cq >> 16);
-                  if (dx * dx + dy * dy < md2i) {
-                    wait = true;
-                    break;
-                  }
-                }
-              }
-            if (wait)
-              sh_flag = 1;
-            else
-              stt[r] = 3;
-          }
-          __syncthreads();
-          for (int r = tid; r < NL; r += SEL_T) {
-            if (stt[r] != 3) continue;
-            stt[r] = 1;
-            const unsigned c = xy[r];
-            const int x = (int)(c & 0xffffu), y = (int)(c >> 16);
-            for (int row = 0; row < 2 * md - 1; row++) {
-              const int yy = y + row - (md - 1);
-              const int h = hwt[row];
-              if (h < 0 || (unsigned)yy >= (unsigned)H) continue;
-              const int x0 = max(x - h, 0), x1 = min(x + h, W - 1);
-              const int sh = x0 & 63;
-              const unsigned long long span = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 63 ones
-              unsigned long long* pw = &bm[yy * rw + (x0 >> 6)];
-              __hip_atomic_fetch_or(pw, span << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_or(pw + 1, (span >> 1) >> (63 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
-          __syncthreads();
-          const int more = sh_flag;
-          __syncthreads();   // (everybody has read the flag before the next round resets it)
-          if (!more) break;
-        }
-        // accepted ranks, ascending, to the head of the list (through the cell arrays, which are dead now)
-        {
-          unsigned* tmp = reinterpret_cast<unsigned*>(cidx);   // cidx + items: room for LDS_SORT_CAP entries
-          const int per = (NL + SEL_T - 1) / SEL_T;
-          const int b = min(tid * per, NL), e = min(b + per, NL);
-          int cnt = 0;
-          for (int r = b; r < e; r++) cnt += stt[r] == 1 ? 1 : 0;
-          int total = 0;
-          int pos = block_exclusive_scan(cnt, wave_tot, &total);
-          unsigned keepv[LDS_SORT_CAP / SEL_T];   // (xy[r] is read before the barrier: tmp aliases nothing of xy, but
-          int nk = 0;                             //  the cell arrays it overwrites are read by nobody any more)
-          for (int r = b; r < e; r++)
-            if (stt[r] == 1 && nk < LDS_SORT_CAP / SEL_T) keepv[nk++] = xy[r];
-          __syncthreads();
-          for (int i = 0; i < nk; i++) tmp[pos + i] = keepv[i];
-          __syncthreads();
-          int n_acc = total;
-          if (P.max_corners > 0) n_acc = min(n_acc, P.max_corners);
-          for (int i = tid; i < n_acc; i += SEL_T) xy[i] = tmp[i];
-          if (tid == 0) {
-            sh_cnt = n_acc;
-            sh_flag = (P.max_corners > 0 && total >= P.max_corners) ? 1 : 0;
-          }
-          __syncthreads();
-        }
-      }
-    }
-    if (!did_rounds) greedy(0, NL, 0);
+    // (Round 3 also wrote the filter by ROUNDS over all threads of the block -- the lexicographically-first maximal
+    // independent set of the "closer than minDistance" graph over a cell grid.  Round 4 ran it on the hardware: bit-exact
+    // on every detection / sequence test and 2.2 x SLOWER at 64 streams (select 0.079 against 0.036 ms), 3.4 x on the
+    // single EuRoC stream (1.25 against 0.37 ms per pair: the rounds are long dependency chains in clustered corners, each
+    // a block barrier).  Deleted; tests/test_select_rounds_algebra.py keeps the statement of the algorithm.)
+    greedy(0, NL, 0);
     A = sh_cnt;
     if (two_pass && !sh_flag) {
       // second pass: the keys of the bins from cut_bin on that the bitmap has not blocked yet
@@ -2090,9 +1944,7 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
     }
   }
   static const bool prof = std::getenv("KVFE_SELECT_PROF") != nullptr;
-  static const bool rounds = std::getenv("KVFE_SELECT_IMPL") && std::atoi(std::getenv("KVFE_SELECT_IMPL")) == 1;
-  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need,
-                     (prof ? 1 : 0) | (rounds ? 2 : 0));
+  hipLaunchKernelGGL(select_kernel, dim3(P.B), dim3(SEL_T), lds, st, P, T, k, S, D, fixed_need, prof ? 1 : 0);
   if (prof) {
     static double acc[16];
     static long n = 0;
@@ -2190,6 +2042,237 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cv::cornerSubPix for a GROUP of corners per block (round 4; FeatureDetector.cpp:283-296, kvfe_subpix.inl).
+//
+// Why: a step is bound by the number of instructions its kernels issue (profiles/r4_analysis.md: every kernel of the
+// step runs at ~1 instruction per SIMD and 4 cycles, whatever its category), and the one-corner-per-block kernel above
+// spends 900 of its 1 900 vector instructions per corner and iteration on the five sequential float64 chains: 448
+// v_fmac_f64_dpp per wave with FOUR useful lanes in one wave and ONE in the other.  Here a lane IS a chain:
+//   * block = SPG_G corners of one stream, 256 threads;
+//   * patch phase: 32 threads per corner compute cv::getRectSubPix's 23 x 23 float patch from the corner's u8 stage in
+//     LDS (the same device functions as above: rect_subpix_from_stage / _border_from_stage, 17 entries per thread);
+//   * term phase: waves 1-3 turn patches into the five float64 terms of every window pixel, SPG_KC window pixels of all
+//     corners per chunk, into one of two LDS chunk buffers laid out [pixel][chain][corner];
+//   * chain phase: wave 0, lane = 8 chain + corner (40 lanes), adds its chain's terms in window order -- one
+//     ds_read_b64 + one v_add_f64 per term for ALL corners of the block -- while waves 1-3 produce the next chunk;
+//   * solve: lanes 0..7 of wave 0, one corner each, the 2 x 2 system and the convergence test.
+// Same operations in the same order per corner as corner_subpix_wave_t => bit-identical (tests/test_gpu_subpix_r4.py
+// runs both kernels on the same corners).  ~650 instead of ~1 900 instructions per corner and iteration.
+// Used for many streams; a few streams (latency bound, few corners) keep the four-waves-per-corner kernel, and so do
+// windows other than 10 and images smaller than the 36 x 36 stage.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPG_G = 8;     // corners per block
+constexpr int SPG_T = 256;   // threads per block
+constexpr int SPG_KC = 64;   // window pixels per chunk
+struct SpgGeom {
+  int pw, nt, rs;
+  size_t mask_off, state_off, stage_off, patch_off, terms_off, bytes;
+};
+__host__ __device__ inline SpgGeom spg_geom(int win) {
+  SpgGeom g;
+  const SubpixGeom s = subpix_geom(win);
+  g.pw = s.pw;
+  g.nt = s.nt;
+  g.rs = s.rs;
+  size_t o = 0;
+  g.mask_off = o;   o += sizeof(float) * (size_t)((g.nt + 15) & ~15);
+  g.state_off = o;  o += 16 * sizeof(int) * SPG_G;                                         // [corner][16] ints / floats
+  g.stage_off = o;  o += (size_t)SPG_G * (((size_t)g.rs * g.rs + 15) & ~(size_t)15);
+  g.patch_off = o;  o += (size_t)SPG_G * sizeof(float) * g.pw * g.pw;
+  o = (o + 15) & ~(size_t)15;
+  g.terms_off = o;  o += 2 * sizeof(double) * SPG_KC * 5 * SPG_G;
+  g.bytes = o;
+  return g;
+}
+enum { SPG_CIX = 0, SPG_CIY, SPG_CTX, SPG_CTY, SPG_ACTIVE, SPG_STAGED, SPG_SX0, SPG_SY0, SPG_ITER };
+
+template <int WIN>
+__global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T, const unsigned char* __restrict__ img,
+                                                             size_t row_stride, size_t img_stride, FrameTab K,
+                                                             StreamState S, DetectScratch D, int append) {
+  const int s = blockIdx.x;
+  if (!(S.flags[s] & FLAG_DETECT)) return;
+  const int n_new = D.n_new[s];
+  const int c_first = blockIdx.y * SPG_G;
+  if (c_first >= n_new) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const SpgGeom G = spg_geom(WIN);
+  constexpr int pw = 2 * WIN + 3, ww = 2 * WIN + 1, nt = ww * ww, rs = pw + 1 + 12;
+  constexpr int MAXP = (pw * pw + 31) / 32;
+  constexpr int NCH = (nt + SPG_KC - 1) / SPG_KC;
+  float* mask_s = reinterpret_cast<float*>(lds_raw + G.mask_off);
+  int* state = reinterpret_cast<int*>(lds_raw + G.state_off);
+  float* statef = reinterpret_cast<float*>(lds_raw + G.state_off);
+  const size_t stage_stride = ((size_t)rs * rs + 15) & ~(size_t)15;
+  double* terms = reinterpret_cast<double*>(lds_raw + G.terms_off);
+  __shared__ int sh_active;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cs = tid >> 5, sub = tid & 31;   // corner slot and thread of the slot (patch phase)
+  const unsigned char* I = img + (size_t)s * img_stride;
+  const int W = P.W, H = P.H;
+  const int max_iters = P.subpix_iters;
+  const double eps2 = P.subpix_eps2;
+
+  for (int k = tid; k < nt; k += SPG_T) mask_s[k] = T.subpix_mask[k];
+  if (tid < SPG_G) {
+    const int ci = c_first + tid;
+    const bool on = ci < n_new;
+    const float2 c0 = on ? D.newc[(size_t)s * P.acap + ci] : make_float2(0.f, 0.f);
+    statef[tid * 16 + SPG_CIX] = c0.x;
+    statef[tid * 16 + SPG_CIY] = c0.y;
+    statef[tid * 16 + SPG_CTX] = c0.x;
+    statef[tid * 16 + SPG_CTY] = c0.y;
+    state[tid * 16 + SPG_ACTIVE] = (on && P.subpix_enable) ? 1 : 0;
+    state[tid * 16 + SPG_STAGED] = 0;
+    state[tid * 16 + SPG_SX0] = 0;
+    state[tid * 16 + SPG_SY0] = 0;
+    state[tid * 16 + SPG_ITER] = 0;
+  }
+  if (tid == 0) sh_active = P.subpix_enable ? min(SPG_G, n_new - c_first) : 0;
+  int eij[MAXP];   // patch entries e = sub + 32 t of the (2w+3)^2 window
+#pragma unroll
+  for (int t = 0; t < MAXP; t++) {
+    const int e = sub + 32 * t, i = e / pw;
+    eij[t] = (i << 8) | (e - i * pw);
+  }
+  __syncthreads();
+
+  while (sh_active > 0) {
+    // ---- A: the corner's u8 stage and cv::getRectSubPix patch, 32 threads per corner -------------------------------
+    if (state[cs * 16 + SPG_ACTIVE]) {
+      const float cIx = statef[cs * 16 + SPG_CIX], cIy = statef[cs * 16 + SPG_CIY];
+      unsigned char* stage = lds_raw + G.stage_off + (size_t)cs * stage_stride;
+      float* patch = reinterpret_cast<float*>(lds_raw + G.patch_off) + (size_t)cs * pw * pw;
+      const float ccx = cIx - (pw - 1) * 0.5f, ccy = cIy - (pw - 1) * 0.5f;
+      const int ipx = cv_floorf(ccx), ipy = cv_floorf(ccy);
+      const bool interior = 0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H;
+      const int fx0 = min(max(ipx, 0), W - 1), fx1 = min(max(ipx + pw, 0), W - 1);
+      const int fy0 = min(max(ipy, 0), H - 1), fy1 = min(max(ipy + pw, 0), H - 1);
+      int sx0 = state[cs * 16 + SPG_SX0], sy0 = state[cs * 16 + SPG_SY0];
+      bool staged = state[cs * 16 + SPG_STAGED] != 0;
+      if (!staged || fx0 < sx0 || fy0 < sy0 || fx1 >= sx0 + rs || fy1 >= sy0 + rs) {
+        const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
+        for (int e = sub; e < rs * rs; e += 32) {
+          const int y = e / rs, x = e - y * rs;
+          stage[e] = I[(size_t)(ny0 + y) * row_stride + nx0 + x];
+        }
+        sx0 = nx0;
+        sy0 = ny0;
+        staged = true;
+        if (sub == 0) {
+          state[cs * 16 + SPG_SX0] = nx0;
+          state[cs * 16 + SPG_SY0] = ny0;
+          state[cs * 16 + SPG_STAGED] = 1;
+        }
+      }
+      const bool use_stage = staged && fx0 >= sx0 && fy0 >= sy0 && fx1 < sx0 + rs && fy1 < sy0 + rs;
+      if (use_stage && interior)
+        rect_subpix_from_stage<MAXP, 32>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
+      else if (use_stage)
+        rect_subpix_border_from_stage<MAXP, 32>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
+      else
+        rect_subpix_8u32f(I, row_stride, W, H, cIx, cIy, pw, patch, sub, 32);
+    }
+    __syncthreads();
+    // ---- B: terms (waves 1-3) and chains (wave 0), software pipelined over chunks of SPG_KC window pixels ------------
+    auto produce = [&](int kc, int buf) {
+      const int p = tid - 64;
+      double* tb = terms + (size_t)buf * SPG_KC * 5 * SPG_G;
+#pragma unroll
+      for (int j = 0; j < (SPG_KC * SPG_G + 191) / 192; j++) {
+        const int pi = p + 192 * j;
+        const int c = pi & (SPG_G - 1), kk = pi >> 3, k = kc * SPG_KC + kk;
+        if (pi < SPG_KC * SPG_G && k < nt && state[c * 16 + SPG_ACTIVE]) {
+          const int i = k / ww, jj = k - i * ww;
+          const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off) + (size_t)c * pw * pw + (i + 1) * pw + (jj + 1);
+          const double m = (double)mask_s[k];
+          const double tgx = (double)(sp[1] - sp[-1]);
+          const double tgy = (double)(sp[pw] - sp[-pw]);
+          const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+          const double px = (double)(jj - WIN), py = (double)(i - WIN);
+          double* o = tb + (size_t)kk * 5 * SPG_G + c;
+          o[0] = gxx;
+          o[SPG_G] = gxy;
+          o[2 * SPG_G] = gyy;
+          o[3 * SPG_G] = gxx * px + gxy * py;
+          o[4 * SPG_G] = gxy * px + gyy * py;
+        }
+      }
+    };
+    double acc = 0.0;   // wave 0, lane = 8 chain + corner: the chain's running float64 sum, in window order
+    if (wave > 0) produce(0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < NCH; kc++) {
+      if (wave == 0) {
+        if (lane < 5 * SPG_G) {
+          const double* tb = terms + (size_t)(kc & 1) * SPG_KC * 5 * SPG_G + lane;
+          const int nk = min(SPG_KC, nt - kc * SPG_KC);
+#pragma unroll 8
+          for (int kk = 0; kk < nk; kk++) acc += tb[(size_t)kk * 5 * SPG_G];
+        }
+      } else if (kc + 1 < NCH) {
+        produce(kc + 1, (kc + 1) & 1);
+      }
+      if (kc + 1 < NCH) __syncthreads();
+    }
+    // ---- C: the 2 x 2 system, one lane per corner (wave 0) ------------------------------------------------------
+    if (wave == 0) {
+      const int c = lane & (SPG_G - 1);
+      const double a = __shfl(acc, c), b = __shfl(acc, SPG_G + c), cc = __shfl(acc, 2 * SPG_G + c);
+      const double bb1 = __shfl(acc, 3 * SPG_G + c), bb2 = __shfl(acc, 4 * SPG_G + c);
+      bool still = false;
+      if (lane < SPG_G && state[lane * 16 + SPG_ACTIVE]) {
+        float2 cI = make_float2(statef[lane * 16 + SPG_CIX], statef[lane * 16 + SPG_CIY]);
+        int iter = state[lane * 16 + SPG_ITER];
+        still = true;
+        const double det = a * cc - b * b;
+        if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) {
+          still = false;
+        } else {
+          const double scale = 1.0 / det;
+          float2 cI2;
+          cI2.x = (float)(cI.x + cc * scale * bb1 - b * scale * bb2);
+          cI2.y = (float)(cI.y - b * scale * bb1 + a * scale * bb2);
+          const double err = (double)((cI2.x - cI.x) * (cI2.x - cI.x) + (cI2.y - cI.y) * (cI2.y - cI.y));
+          cI = cI2;
+          if (cI.x < 0 || cI.x >= W || cI.y < 0 || cI.y >= H) still = false;
+          else still = (++iter < max_iters && err > eps2);
+        }
+        statef[lane * 16 + SPG_CIX] = cI.x;
+        statef[lane * 16 + SPG_CIY] = cI.y;
+        state[lane * 16 + SPG_ITER] = iter;
+        state[lane * 16 + SPG_ACTIVE] = still ? 1 : 0;
+      }
+      const unsigned long long bal = __ballot(still);
+      if (lane == 0) sh_active = __popcll(bal);
+    }
+    __syncthreads();
+  }
+  // ---- append (FeatureDetector.cpp:141-160) -----------------------------------------------------------------------
+  if (tid < SPG_G && c_first + tid < n_new) {
+    const int ci = c_first + tid;
+    float2 c = make_float2(statef[tid * 16 + SPG_CIX], statef[tid * 16 + SPG_CIY]);
+    const float2 cT = make_float2(statef[tid * 16 + SPG_CTX], statef[tid * 16 + SPG_CTY]);
+    if (P.subpix_enable && (fabsf(c.x - cT.x) > WIN || fabsf(c.y - cT.y) > WIN)) c = cT;
+    if (append) {
+      const int base = S.n_tracked[s];
+      const size_t o = (size_t)s * P.kcap + base + ci;
+      K.kp[o] = c;
+      K.lmk[o] = S.lmk_counter[s] + ci;
+      K.age[o] = 1;
+      K.cost[o] = 0;   // (a new corner: no tracking history)
+      double v[3];
+      bearing_vector(T.und_left_R, c.x, c.y, v);
+      K.versor[o * 3] = v[0];
+      K.versor[o * 3 + 1] = v[1];
+      K.versor[o * 3 + 2] = v[2];
+    } else {
+      D.newc[(size_t)s * P.acap + ci] = c;
+    }
+  }
+}
+
 // after the append: counts and the per-stream landmark-id counter -- and the two pieces of per-stream state the NEXT
 // step's tracking reads (they depend on this step's flags only): keyframe_R_ref_frame_ and the "initialised" flag.
 // They used to be written by step_finalize, at the very end of the step; written here, the next step's predictor and
@@ -2265,6 +2348,22 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
           std::fprintf(stderr, "KVFE_SUBPIX_STATS corners %llu, cycles per corner: mean %.0f max %llu; < 100 k: %llu, < 200 k: %llu, < 400 k: %llu, more: %llu\n",
                        h[0], (double)h[1] / (double)h[0], h[2], h[3], h[4], h[5], h[6]);
       });
+    }
+  }
+  // many streams: SPG_G corners per block, one lane per float64 chain (subpix_group_kernel); a few streams keep the
+  // four-waves-per-corner kernel (fewer corners than SIMDs: the latency of one iteration is what counts there)
+  static const int group_env = std::getenv("KVFE_SUBPIX_GROUP") ? std::atoi(std::getenv("KVFE_SUBPIX_GROUP")) : -1;   // (A/B)
+  const bool group = (group_env >= 0 ? group_env != 0 : P.B > 4) && P.subpix_win == 10 &&
+                     P.W >= subpix_geom(10).rs && P.H >= subpix_geom(10).rs && !stats_on;
+  if (group) {
+    static const int budget = lds_dynamic_budget(reinterpret_cast<const void*>(subpix_group_kernel<10>));
+    const size_t glds = spg_geom(10).bytes;
+    if ((long long)glds <= budget) {
+      hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, (bound + SPG_G - 1) / SPG_G), dim3(SPG_T), glds, st, P, T, img,
+                         row_stride, img_stride, k, S, D, append);
+      if (append)
+        hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, append == 2 ? 2 : 3);
+      return;
     }
   }
   if (P.subpix_win == 10 && nw == 4)
