@@ -906,7 +906,9 @@ typedef struct kvfe_stage_times {
   int32_t n_stages;
   int32_t n_samples;                   /* launches recorded per stage (all groups)  */
   int32_t n_groups;                    /* stream groups (launches per step)         */
-  int32_t reserved0;
+  int32_t struct_size;                 /* IN: sizeof(kvfe_stage_times) of the caller's header; kvfe_profile_read writes no
+                                          more than that (0 = the layout that ended before ms_active, round 2).  The
+                                          struct grew in round 3; a caller built against the shorter layout is safe     */
   const char* name[KVFE_N_STAGES];
   double ms_total[KVFE_N_STAGES];      /* summed over samples                 */
   double alg_bytes[KVFE_N_STAGES];     /* algorithmic bytes per launch with every stream active */

@@ -229,7 +229,7 @@ class RansacOutput(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [
         ("n_stages", C.c_int32), ("n_samples", C.c_int32),
-        ("n_groups", C.c_int32), ("reserved0", C.c_int32),
+        ("n_groups", C.c_int32), ("struct_size", C.c_int32),
         ("name", C.c_char_p * KVFE_N_STAGES),
         ("ms_total", C.c_double * KVFE_N_STAGES),
         ("alg_bytes", C.c_double * KVFE_N_STAGES),

@@ -85,218 +85,6 @@ struct MeRow {          // per-lane values of one image row at the different pip
   float hm, lam;        // horizontal 3-max of lambda, lambda
 };
 
-template <bool HAS_MASK>
-__global__ __launch_bounds__(64) void mineig_localmax_kernel(
-    const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
-    const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
-    const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
-    const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
-    const int* __restrict__ flags,
-    unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows) {
-  const int s = blockIdx.z;
-  if (flags && !(flags[s] & FLAG_DETECT)) return;
-  __shared__ unsigned long long rowmask[ME_ROWS];  // bit l set: lane l's column is masked OUT
-  __shared__ unsigned long long lcand[ME_LCAP];
-  __shared__ int hw_s[MAX_RADIUS + 1];
-
-  const unsigned char* I = img + (size_t)s * img_stride;
-  const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
-  const int lane = threadIdx.x;
-  const int xs = blockIdx.x * ME_COLS, ys = blockIdx.y * strip_rows;
-  const int ye = min(ys + strip_rows, H);
-  const int x0 = xs - ME_HALO;          // column of lane 0
-  const int gx = x0 + lane;
-  const int cxr = reflect101(gx, W);    // source column (BORDER_REFLECT_101)
-  const bool col_in = gx >= 0 && gx < W;
-  const bool out_col = lane >= ME_HALO && lane < 64 - ME_HALO && gx < W;
-  const bool at_left = gx == 0, at_right = gx == W - 1;
-
-  if (lane < ME_ROWS) rowmask[lane] = 0ull;
-  for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
-  __syncthreads();
-  // detection mask: rasterise the cv::circle discs that touch this strip into row bit-masks
-  if (use_discs) {
-    const float2* kp = kp_all + (size_t)s * kcap;
-    const int nk = kp_count[s];
-    const long long* lmk = lmk_all + (size_t)s * kcap;
-    for (int i = lane; i < nk; i += 64) {
-      if (lmk[i] == -1) continue;  // only keypoints with a landmark mask (FeatureDetector.cpp:191)
-      const float2 p = kp[i];
-      const int cx = __float2int_rn(p.x), cy = __float2int_rn(p.y);  // cv::Point(Point2f)
-      if (cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye)
-        continue;
-      const int r0 = max(cy - radius, ys), r1 = min(cy + radius, ye - 1);
-      for (int gy = r0; gy <= r1; gy++) {
-        const int hw = hw_s[abs(gy - cy)];
-        const int xa = max(cx - hw, x0) - x0, xb = min(cx + hw, x0 + 63) - x0;
-        if (xa > xb) continue;
-        const unsigned long long bits =
-            (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
-        atomicOr(&rowmask[gy - ys], bits);
-      }
-    }
-  }
-  __syncthreads();
-
-  const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0));  // (float)scale, blockSize 3, ksize 3
-  const float f0 = 2.0f * f1;
-  // rows: hm rows b0..b1, cov/h rows c0..c1, pixel rows c0-1..c1+1 (reflected outside the image)
-  const int b0 = max(ys - 1, 0), b1 = min(ye, H - 1);
-  const int c0 = max(b0 - 1, 0), c1 = min(b1 + 1, H - 1);
-  const int r_first = c0 - 1, r_last = min(ye + 2, H + 1);
-  const int lm0 = max(ys, 1), lm1 = min(ye - 1, H - 2);
-
-  float bestv = -__builtin_inff();  // masked maximum of lambda (no pixel has lambda = -inf)
-  int n_loc = 0;                    // wave-uniform
-  auto flush = [&]() {
-    int base = 0;
-    if (lane == 0 && n_loc > 0) base = atomicAdd(&cand_count[s], n_loc);
-    base = __shfl(base, 0);
-    for (int i = lane; i < n_loc; i += 64) {
-      const int pos = base + i;
-      if (pos < ccap) cand_all[(size_t)s * ccap + pos] = lcand[i];
-    }
-    n_loc = 0;
-  };
-
-  // source column of this lane; rows are addressed with 32-bit offsets (an image is < 2 GiB)
-  const unsigned char* colp = I + cxr;
-  const unsigned stride_u = (unsigned)row_stride;
-  const unsigned char* mcol = HAS_MASK ? M + min(max(gx, 0), W - 1) : nullptr;
-  // three source rows in flight per lane (one per rotating slot): a row is a fresh 64-byte line for
-  // every wave, so one row of look-ahead (~one pipeline step) does not cover an HBM miss
-  // The loads are issued and awaited by hand (vmcnt counts in issue order, so "at most two
-  // outstanding" means this slot's load has landed): the compiler's own waits drain the queue at every
-  // branch join of the step and would shorten the look-ahead to one row again.
-  auto row_of = [&](int r) {  // BORDER_REFLECT_101 for r in [-1, H], clamped for the unused row H+1
-    int rr = r < 0 ? -r : r;
-    rr = rr >= H ? 2 * H - 2 - rr : rr;
-    return (unsigned)min(max(rr, 0), H - 1);
-  };
-  auto issue_row = [&](unsigned& dst, int r) {
-    const unsigned char* a = colp + row_of(r) * stride_u;
-    asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(a) : "memory");
-  };
-  unsigned pq0, pq1, pq2;  // raw bytes: converted at use
-  issue_row(pq0, r_first);
-  issue_row(pq1, r_first + 1);
-  issue_row(pq2, r_first + 2);
-  const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
-
-  // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  Only wave-uniform
-  // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
-  bool in_b = false;  // lane's pixel of box row b passes the detection mask (carried to stage m)
-  auto step = [&](int r, MeRow& X, MeRow& Y, MeRow& Z, unsigned& p_next) {
-    const bool in_m = in_b;  // row m = r-3 was the box row of the previous step
-    // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
-    // (unconditional, one load and one use per step with the row index clamped: the compiler can then
-    // wait for exactly this slot's load, vmcnt(2), instead of draining all three at a branch join;
-    // the clamped extra row H+1 is never consumed by a cov row)
-    {
-      asm volatile("s_waitcnt vmcnt(2)" : "+v"(p_next));
-      const float p = (float)p_next;
-      issue_row(p_next, r + 3);
-      const float pl = dpp_from_left(p), pr = dpp_from_right(p);
-      X.dh = pr - pl;
-      float t = f1 * pl;
-      t += f0 * p;
-      t += f1 * pr;
-      X.sm = t;
-    }
-    // ---- cov row c = r-1 -> horizontal float64 sums --------------------------------------------
-    const int c = r - 1;
-    if (c >= c0 && c <= c1) {
-      const float dx = (Z.dh + X.dh) * f1 + Y.dh * f0;
-      const float dy = X.sm - Z.sm;
-      const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
-      const float lxx = dpp_from_left(cxx), rxx = dpp_from_right(cxx);
-      const float lxy = dpp_from_left(cxy), rxy = dpp_from_right(cxy);
-      const float lyy = dpp_from_left(cyy), ryy = dpp_from_right(cyy);
-      // BORDER_REFLECT_101 of cv::boxFilter: column -1 is column 1, column W is column W-2
-      float axx = lxx, bxx = rxx, axy = lxy, bxy = rxy, ayy = lyy, byy = ryy;
-      if (edge_strip) {
-        axx = at_left ? rxx : lxx, bxx = at_right ? lxx : rxx;
-        axy = at_left ? rxy : lxy, bxy = at_right ? lxy : rxy;
-        ayy = at_left ? ryy : lyy, byy = at_right ? lyy : ryy;
-      }
-      // cv::boxFilter accumulates 0 + a + b + c in float64; "0 +" is dropped: it is exact for the
-      // non-negative dx*dx / dy*dy sums and can only change the sign of a zero dx*dy sum, which
-      // enters lambda squared.
-      Y.h0 = ((double)axx + (double)cxx) + (double)bxx;
-      Y.h1 = ((double)axy + (double)cxy) + (double)bxy;
-      Y.h2 = ((double)ayy + (double)cyy) + (double)byy;
-    }
-    // ---- box row b = r-2 -> lambda, horizontal max; masked maximum ------------------------------
-    const int b = r - 2;
-    if (b >= b0 && b <= b1) {
-      // rows b-1, b, b+1 = slots X, Z, Y; BORDER_REFLECT_101 at the image border: row -1 is row 1
-      // (slot Y), row H is row H-2 (slot X) -- wave-uniform branches taken once per strip
-      if (b == 0) {
-        asm volatile("");  // keep the once-per-strip border copies out of the row loop's selects
-        X.h0 = Y.h0;
-        X.h1 = Y.h1;
-        X.h2 = Y.h2;
-      }
-      if (b == H - 1) {
-        asm volatile("");
-        Y.h0 = X.h0;
-        Y.h1 = X.h1;
-        Y.h2 = X.h2;
-      }
-      const double s0 = (X.h0 + Z.h0) + Y.h0, s1 = (X.h1 + Z.h1) + Y.h1, s2 = (X.h2 + Z.h2) + Y.h2;
-      const float fa = (float)s0 * 0.5f, fb = (float)s1, fc = (float)s2 * 0.5f;
-      const float lam = (fa + fc) - sqrt_rn_small((fa - fc) * (fa - fc) + fb * fb);
-      Z.lam = lam;
-      Z.hm = fmaxf(fmaxf(dpp_from_left(lam), lam), dpp_from_right(lam));
-      if (b >= ys && b < ye) {
-        // the row's bit mask is wave-uniform: one LDS read, then it IS the lane predicate
-        bool masked_in = out_col & !__builtin_amdgcn_inverse_ballot_w64(rowmask[b - ys]);
-        if (HAS_MASK) masked_in &= mcol[(unsigned)(b * W)] != 0;
-        in_b = masked_in;
-        bestv = vmaxf(bestv, masked_in ? lam : -__builtin_inff());
-      }
-    }
-    // ---- row m = r-3: 3x3 local maximum (rows m-1, m, m+1 = slots Y, X, Z) ----------------------
-    const int m = r - 3;
-    if (m >= lm0 && m <= lm1) {
-      const float v = X.lam;
-      const bool is_cand = in_m & (gx >= 1) & (gx < W - 1) & (v != 0.0f) &
-                           (v == fmaxf(fmaxf(Y.hm, X.hm), Z.hm));
-      const unsigned long long bal = __ballot(is_cand);
-      if (bal) {
-        if (is_cand) {
-          const int pos = n_loc + __popcll(bal & ((1ull << lane) - 1ull));
-          lcand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(m * W + gx);
-        }
-        n_loc += __popcll(bal);
-        if (n_loc > ME_LCAP - 64) {
-          __syncthreads();
-          flush();
-          __syncthreads();
-        }
-      }
-    }
-  };
-
-  MeRow S0, S1, S2;
-  S0 = S1 = S2 = MeRow{0.f, 0.f, 0., 0., 0., 0.f, 0.f};
-  // slots rotate with the row index: slot(r) = (r - r_first) % 3
-  for (int r = r_first; r <= r_last; r += 3) {
-    step(r, S0, S2, S1, pq0);
-    if (r + 1 <= r_last) step(r + 1, S1, S0, S2, pq1);
-    if (r + 2 <= r_last) step(r + 2, S2, S1, S0, pq2);
-  }
-  __syncthreads();
-  flush();
-  for (int off = 32; off > 0; off >>= 1) bestv = fmaxf(bestv, __shfl_xor(bestv, off));
-  const unsigned bestkey = bestv == -__builtin_inff() ? 0u : fkey(bestv);
-  // masked maximum: one global atomic per wave, skipped when it cannot raise the maximum
-  if (lane == 0 && bestkey &&
-      bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(&maxkey[s], bestkey);
-}
-
 // ---------------------------------------------------------------------------------------------
 // mineig2_kernel: the same pipeline and the same arithmetic, restructured around what bounds it (instruction issue,
 // every category: profiles/r2_v5_lk_analysis.md, tools/ubench/valu_rate.hip):
@@ -313,7 +101,7 @@ __global__ __launch_bounds__(64) void mineig_localmax_kernel(
 typedef int me_v4i __attribute__((ext_vector_type(4)));
 constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig2_kernel (row-need masks: 128 bits incl. margins)
 
-template <bool HAS_MASK, bool RUNS>
+template <bool HAS_MASK>
 __global__ __launch_bounds__(64) void mineig2_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
     const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
@@ -321,24 +109,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
     const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int xcd_mode) {
-  constexpr bool run_skip = RUNS;   // walk the runs of needed rows (round 4) / step through every row (round 3, A/B)
-  // block -> (column strip, row strip, stream).  xcd_mode: a 1-D grid in which workgroup b (it runs on XCD b & 7: a
-  // speed assumption only) takes the strips of the streams s = b & 7 (mod 8), so that the cache lines neighbouring
-  // strips share -- 64-byte row segments out of 128-byte lines, the 3-column and 5-row overlaps -- meet in ONE L2.
-  int s, bx, by;
-  if (xcd_mode) {
-    const int per_stream = nx * ny, j = blockIdx.x >> 3;
-    s = (blockIdx.x & 7) + 8 * (j / per_stream);
-    if (s >= B) return;
-    const int rem = j % per_stream;
-    by = rem / nx;
-    bx = rem - by * nx;
-  } else {
-    s = blockIdx.z;
-    bx = blockIdx.x;
-    by = blockIdx.y;
-  }
+    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int /*unused*/) {
+  // block -> (column strip, row strip, stream).  (An XCD-banded 1-D order was measured in round 3: 0.084 against 0.082 ms.)
+  const int s = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
   __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
   __shared__ unsigned long long lcand[ME_LCAP];
@@ -496,11 +269,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   using SL0 = std::integral_constant<int, 0>;
   using SL1 = std::integral_constant<int, 1>;
   using SL2 = std::integral_constant<int, 2>;
-  if constexpr (!run_skip) {
-    issue_off(SL0{}, row_of(r_first) * stride_u);
-    issue_off(SL1{}, row_of(r_first + 1) * stride_u);
-    issue_off(SL2{}, row_of(r_first + 2) * stride_u);
-  }
+  issue_off(SL0{}, row_of(r_first) * stride_u);
+  issue_off(SL1{}, row_of(r_first + 1) * stride_u);
+  issue_off(SL2{}, row_of(r_first + 2) * stride_u);
   const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
   // wave-wide lane facts as scalar masks
   const unsigned long long out_mask = __ballot(out_col);
@@ -525,7 +296,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // one pipeline step; X = slot of pixel row r, Y = row r-1, Z = row r-2.  CHECK: the stages test their row ranges and
   // copy border rows (prologue, epilogue, image-border strips); otherwise every stage is live.  Only wave-uniform
   // branches: per-lane conditions are predicated, so every DPP sees all 64 lanes.
-  auto step = [&](auto check_tag, auto slot_tag, int r, MeRow& X, MeRow& Y, MeRow& Z, const bool live = true) {
+  auto step = [&](auto check_tag, auto slot_tag, int r, MeRow& X, MeRow& Y, MeRow& Z) {
     constexpr bool CHECK = decltype(check_tag)::value;
     const unsigned long long in_m_mask = in_b_mask;  // row m = r-3 was the box row of the previous step
     // ---- pixel row r -> Sobel partials (row r+1 is already being fetched) ------------------------
@@ -536,11 +307,6 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
       } else {
         issue_off(slot_tag, soff_next);
         soff_next += stride_u;
-      }
-      if (CHECK && !live) {   // a step that only restarts the request pipeline (the three steps in front of a run)
-        fetch_mask(r - 1);
-        in_b_mask = 0ull;
-        return;
       }
       const float pl = dpp_from_left(p), pr = dpp_from_right(p);
       X.dh = pr - pl;
@@ -644,7 +410,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // slots rotate with the row index: slot(r) = (r - r_first) % 3
   int r = r_first;
   fetch_mask(r - 2);   // (the first step's "previous" request)
-  if constexpr (run_skip) {
+  {
     // RUNS OF NEEDED ROWS (round 4).  With a few hundred tracked keypoints and discs of radius min_distance a frame is
     // almost entirely masked (the 600-feature benchmark streams: 3 % of the pixels pass the mask, a quarter of a strip's
     // rows is needed by anybody), so the wave walks only the runs of pixel rows that some unmasked pixel needs -- it
@@ -666,52 +432,45 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
       const unsigned long long m = (needp1 >> (q - 64)) << (q - 64);
       return m ? ys - 3 + 64 + __builtin_ctzll(m) : 0x7fffffff;
     };
-    // The request pipeline is (re)started by three steps of the SAME loop body that do nothing but wait for the slot's
-    // previous request and issue the next one (`live` = false): rows t, t+1, t+2 of a run starting at t are requested by
-    // the steps t-3, t-2, t-1.  No separate priming code: the destination registers of the hand-issued loads must be
-    // the same at every site (hipcc does not know that they are written late; a register copy between two sites
-    // would read a byte that has not landed -- tools/check_inflight_regs.py scans the ISA for exactly that).
-    r = r_first - 3;
-    bool live = false;
-    while (true) {
-      if (live) {
+    // Structure as without the walk (checked prologue / unchecked steady part / checked epilogue: with both step variants
+    // in ONE loop hipcc needs 96 instead of 62 VGPRs); the gaps are skipped inside the steady part, where almost all rows
+    // of a strip lie.  A jump re-issues the three row requests (into the same accumulation registers: whatever is still in
+    // flight for them lands first, requests return in order) and the mask word one step ahead.
+    const int n_pro = rs > re ? 0x3fffffff : ((rs - r_first + 2) / 3) * 3;
+    for (; r <= r_last && r - r_first < n_pro; r += 3) {
+      step(CK{}, SL0{}, r, S0, S2, S1);
+      if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
+      if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
+    }
+    if (r + 2 <= re) {
+      soff_next = (unsigned)(r + 3) * stride_u;
+      while (r + 2 <= re) {
         const int rn = next_needed(r);
-        if (rn > r_last) break;
-        if (rn >= r + 3) {   // a gap: the run that starts at (or up to two rows before) rn is primed from three rows back
-          r += ((rn - r) / 3) * 3 - 3;
-          live = false;
+        if (rn >= r + 3) {
+          if (rn > r_last) {   // nothing needed any more in this strip
+            r = r_last + 1;
+            break;
+          }
+          r += ((rn - r) / 3) * 3;
+          issue_off(SL0{}, row_of(r) * stride_u);
+          issue_off(SL1{}, row_of(r + 1) * stride_u);
+          issue_off(SL2{}, row_of(r + 2) * stride_u);
+          soff_next = (unsigned)(r + 3) * stride_u;
+          fetch_mask(r - 2);
+          in_b_mask = 0ull;
+          continue;
         }
+        step(NC{}, SL0{}, r, S0, S2, S1);
+        step(NC{}, SL1{}, r + 1, S1, S0, S2);
+        step(NC{}, SL2{}, r + 2, S2, S1, S0);
+        r += 3;
       }
-      // (checked steps only: with the unchecked steady variant in the same loop nest hipcc needs 96 instead of 62
-      // VGPRs, i.e. 4 instead of 7 waves per SIMD; the walk spends most of its steps near run boundaries anyway)
-      step(CK{}, SL0{}, r, S0, S2, S1, live);
-      if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2, live);
-      if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0, live);
-      r += 3;
-      live = true;
     }
-  } else {
-  // prologue: checked steps up to the first steady row, rounded up to a whole slot rotation
-  const int n_pro = rs > re ? 0x3fffffff : ((rs - r_first + 2) / 3) * 3;
-  for (; r <= r_last && r - r_first < n_pro; r += 3) {
-    step(CK{}, SL0{}, r, S0, S2, S1);
-    if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
-    if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
-  }
-  if (r + 2 <= re) {
-    // the three requests in flight are rows r, r+1, r+2 (the prologue issued them with the checked addressing)
-    soff_next = (unsigned)(r + 3) * stride_u;
-    for (; r + 2 <= re; r += 3) {
-      step(NC{}, SL0{}, r, S0, S2, S1);
-      step(NC{}, SL1{}, r + 1, S1, S0, S2);
-      step(NC{}, SL2{}, r + 2, S2, S1, S0);
+    for (; r <= r_last; r += 3) {
+      step(CK{}, SL0{}, r, S0, S2, S1);
+      if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
+      if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
     }
-  }
-  for (; r <= r_last; r += 3) {
-    step(CK{}, SL0{}, r, S0, S2, S1);
-    if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
-    if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
-  }
   }
   // the row requests issued beyond the last step are still in flight: they land before their registers are re-used
   asm volatile("s_waitcnt vmcnt(0)" : : : "a0", "a1", "a2", "memory");
@@ -729,74 +488,39 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
   // D.cand_count / D.maxkey are zero here: allocated zeroed, re-zeroed by every select_kernel
-  // Rows per strip: every strip pays 5 pipeline rows of overlap, so strips should be long, but the
-  // launch should also fit the chip's wave slots in ONE round (8 waves per SIMD: 38 VGPRs, 2.5 KB of
-  // LDS) -- 64 streams of 752x480 at 48 rows are 8320 waves for 8192 slots, and the 128 left over run
-  // after everything else.  Few streams want short strips instead (more waves than SIMDs).
-  static int slots = 0;
-  if (!slots) {
+  static int simds = 0;
+  if (!simds) {
     hipDeviceProp_t prop;
     int dev = 0;
-    slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                ? prop.multiProcessorCount * 4 * 8 : 8192;
+    simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                ? prop.multiProcessorCount * 4 : 1024;
   }
+  // Strip height.  Every wave of the launch is resident at once (87 registers: 5 waves per SIMD) and a SIMD works
+  // through its waves' rows, so the launch lasts (waves per SIMD, rounded UP) x (rows per wave); every strip pays 5 rows
+  // of overlap.  The product is smallest for 6 strips of 80 rows at 64 x 752x480 (4992 waves, 5 per SIMD x 85 rows =
+  // 425 row-times; 4 strips: 4 x 125 = 500, 8 strips: 7 x 65 = 455); a few streams get short strips (more waves than
+  // SIMDs).  Measured in round 3 (KVFE_MINEIG_ROWS sweep) and again with the run walk in round 4: 40 / 60 / 80 / 120
+  // rows -> 0.090 / 0.088 / 0.082 / 0.105 ms.
   const int nx = (P.W + ME_COLS - 1) / ME_COLS;
-  int strip_rows = 16;
+  int strip_rows = min(P.H, ME2_ROWS);
   double best = 1e30;
-  for (int rws = 16; rws <= ME_ROWS; rws += 4) {
-    const int ns = (P.H + rws - 1) / rws;
-    const double fill = (double)nx * ns * P.B / slots;
-    // time ~ rounds x rows per wave; below a quarter of the slots a wave runs at its own latency
-    const double cost = (fill > 1.0 ? ceil(fill) : fmax(fill, 0.25)) * (min(rws, P.H) + 5);
-    if (cost <= best) best = cost, strip_rows = rws;
+  for (int ns = 1; ns <= (P.H + 15) / 16; ns++) {
+    const int rws = (P.H + ns - 1) / ns;
+    if (rws > ME2_ROWS) continue;
+    const long long waves = (long long)nx * ns * P.B;
+    const double cost = (double)((waves + simds - 1) / simds) * (rws + 5);
+    if (cost < best) best = cost, strip_rows = rws;
   }
-  // KVFE_MINEIG_IMPL: 1 = round-1/2 kernel (every step checked), 2 = prologue / steady / epilogue kernel (default);
-  // KVFE_MINEIG_ROWS: rows per strip of the latter (16..128)
-  static const int impl = std::getenv("KVFE_MINEIG_IMPL") ? std::atoi(std::getenv("KVFE_MINEIG_IMPL")) : 2;
-  static const int rows_env = std::getenv("KVFE_MINEIG_ROWS") ? std::atoi(std::getenv("KVFE_MINEIG_ROWS")) : 0;
-  if (impl == 2) {
-    // the kernel is bound by VALU issue: every wave of the launch is resident at once and a SIMD works through its
-    // waves' rows, so the launch lasts (waves per SIMD, rounded UP) x (rows per wave).  Every strip pays 5 rows of
-    // overlap; pick the strip height that minimises the product (64 x 752x480: 6 strips of 80 rows = 4992 waves,
-    // 5 per SIMD x 85 rows = 425 row-times; 4 strips are 4 x 125 = 500, 8 strips 7 x 65 = 455).
-    const int simds = slots / 8;
-    best = 1e30;
-    for (int ns = 1; ns <= (P.H + 15) / 16; ns++) {
-      const int rws = (P.H + ns - 1) / ns;
-      if (rws > ME2_ROWS) continue;
-      const long long waves = (long long)nx * ns * P.B;
-      const double cost = (double)((waves + simds - 1) / simds) * (rws + 5);
-      if (cost < best) best = cost, strip_rows = rws;
-    }
-    if (rows_env >= 16 && rows_env <= ME2_ROWS) strip_rows = rows_env;
-    const int ny = (P.H + strip_rows - 1) / strip_rows;
-    static const int xcd_env = std::getenv("KVFE_MINEIG_XCD") ? std::atoi(std::getenv("KVFE_MINEIG_XCD")) : 0;   // (measured: 0.084 vs 0.082 ms plain)
-    const int xcd = (xcd_env && P.B >= 8) ? 1 : 0;
-    // KVFE_MINEIG_SKIP=0: step through every row of a strip (round 3) instead of walking the runs of needed rows (A/B)
-    static const int run_skip = std::getenv("KVFE_MINEIG_SKIP") ? std::atoi(std::getenv("KVFE_MINEIG_SKIP")) : 1;
-    const dim3 grid = xcd ? dim3((unsigned)(8 * ((P.B + 7) / 8) * nx * ny)) : dim3((unsigned)nx, (unsigned)ny, (unsigned)P.B);
-#define KVFE_ME2(MASK_, RUNS_)                                                                                    \
-  hipLaunchKernelGGL((mineig2_kernel<MASK_, RUNS_>), grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, \
-                     P.W, P.H, P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs,        \
-                     S.flags, D.cand, D.cand_count, D.maxkey, strip_rows, P.B, nx, ny, xcd)
-    if (user_mask && run_skip) KVFE_ME2(true, true);
-    else if (user_mask) KVFE_ME2(true, false);
-    else if (run_skip) KVFE_ME2(false, true);
-    else KVFE_ME2(false, false);
-#undef KVFE_ME2
-    return;
-  }
-  const dim3 grid((unsigned)nx, (unsigned)((P.H + strip_rows - 1) / strip_rows), (unsigned)P.B);
+  const int ny = (P.H + strip_rows - 1) / strip_rows;
+  const dim3 grid((unsigned)nx, (unsigned)ny, (unsigned)P.B);
   if (user_mask)
-    hipLaunchKernelGGL(mineig_localmax_kernel<true>, grid, dim3(64), 0, st, img, row_stride,
-                       img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
-                       T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                       D.maxkey, strip_rows);
+    hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
+                       P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand,
+                       D.cand_count, D.maxkey, strip_rows, P.B, nx, ny, 0);
   else
-    hipLaunchKernelGGL(mineig_localmax_kernel<false>, grid, dim3(64), 0, st, img, row_stride,
-                       img_stride, user_mask, P.W, P.H, P.kcap, P.ccap, P.min_distance,
-                       T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
-                       D.maxkey, strip_rows);
+    hipLaunchKernelGGL(mineig2_kernel<false>, grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
+                       P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand,
+                       D.cand_count, D.maxkey, strip_rows, P.B, nx, ny, 0);
 }
 
 // =============================================================================================
@@ -1985,6 +1709,20 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
 #include "kvfe_undistort.inl"
 
 // KVFE_SUBPIX_STATS=1 (debugging aid): per-corner cycle counts of the refinement launches, printed at exit
+// New corners of ALL detecting streams of the launch (every wave computes it for itself: one coalesced read per 64
+// streams and a wave reduction).  The two cornerSubPix kernels share a launch slot: few corners in total -> the chip is
+// not full, an iteration's latency decides -> one corner per block, four float64 chains per wave; many corners -> the
+// number of instructions decides -> SPG_G corners per block, one chain per lane.  Both are bit-identical, so the choice
+// is invisible in the results; it is made on the device because the count is only known there.
+constexpr int SPG_MIN_TOTAL = 3000;
+__device__ __forceinline__ int subpix_total_new(const StreamState& S, const DetectScratch& D, int B) {
+  int v = 0;
+  for (int t = threadIdx.x & 63; t < B; t += 64) v += (S.flags[t] & FLAG_DETECT) ? D.n_new[t] : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
 __device__ unsigned long long kvfe_subpix_stats[8];   // corners, sum cycles, max cycles, launches' first/last stamp
 
 template <int WIN, int NW>
@@ -1999,13 +1737,13 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
   const int s = blockIdx.x;
   if (!(S.flags[s] & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
+  if ((int)blockIdx.y >= n_new) return;
+  if ((append & 128) && subpix_total_new(S, D, P.B) >= SPG_MIN_TOTAL) return;   // (bit 7: the group kernel's launch follows)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x;
   const bool stats = (append & 16) != 0;
-  // bit 5: the waves of this launch issue with raised priority.  The launch is a latency chain (dependent iterations of
-  // dependent float64 additions) that shares its SIMDs with the throughput kernels of the other stream (rectification,
-  // stereo matching); whenever one of its instructions is ready it should win the arbitration
-  if (append & 32) __builtin_amdgcn_s_setprio(3);
+  // (raised wave priority -- s_setprio 3 -- was measured in round 3: +0.6 % on the step, and the rectification beside it
+  // 0.098 -> 0.108 ms: the dense kernel pays for the latency-bound one; removed)
   append &= 15;
   for (int ci = blockIdx.y; ci < n_new; ci += gridDim.y) {
   float2 c = D.newc[(size_t)s * P.acap + ci];
@@ -2029,7 +1767,6 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
       K.kp[o] = c;
       K.lmk[o] = S.lmk_counter[s] + ci;
       K.age[o] = 1;
-      K.cost[o] = 0;   // (a new corner: no tracking history)
       double v[3];
       bearing_vector(T.und_left_R, c.x, c.y, v);
       K.versor[o * 3] = v[0];
@@ -2062,9 +1799,11 @@ __global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Table
 // Used for many streams; a few streams (latency bound, few corners) keep the four-waves-per-corner kernel, and so do
 // windows other than 10 and images smaller than the 36 x 36 stage.
 // ---------------------------------------------------------------------------------------------
+__device__ unsigned long long kvfe_spg_stats[8];   // KVFE_SUBPIX_STATS: iterations, cycles of the phases (wave 0 of every block)
 constexpr int SPG_G = 8;     // corners per block
-constexpr int SPG_T = 256;   // threads per block
-constexpr int SPG_KC = 64;   // window pixels per chunk
+constexpr int SPG_T = 512;   // threads per block: 64 per corner in the patch phase; wave 0 walks the chains, waves 1-7 make the terms
+constexpr int SPG_KC = 56;   // window pixels per chunk: 56 x 8 corners = 448 term sets = ONE per producing thread and chunk,
+                             // and 8 chunks are exactly the 448 zero-padded terms of a chain
 struct SpgGeom {
   int pw, nt, rs;
   size_t mask_off, state_off, stage_off, patch_off, terms_off, bytes;
@@ -2088,7 +1827,7 @@ __host__ __device__ inline SpgGeom spg_geom(int win) {
 enum { SPG_CIX = 0, SPG_CIY, SPG_CTX, SPG_CTY, SPG_ACTIVE, SPG_STAGED, SPG_SX0, SPG_SY0, SPG_ITER };
 
 template <int WIN>
-__global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T, const unsigned char* __restrict__ img,
+__global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Tables T, const unsigned char* __restrict__ img,
                                                              size_t row_stride, size_t img_stride, FrameTab K,
                                                              StreamState S, DetectScratch D, int append) {
   const int s = blockIdx.x;
@@ -2096,11 +1835,14 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
   const int n_new = D.n_new[s];
   const int c_first = blockIdx.y * SPG_G;
   if (c_first >= n_new) return;
+  if (!(append & 64) && subpix_total_new(S, D, P.B) < SPG_MIN_TOTAL) return;   // (bit 6: forced, A/B and tests)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const SpgGeom G = spg_geom(WIN);
   constexpr int pw = 2 * WIN + 3, ww = 2 * WIN + 1, nt = ww * ww, rs = pw + 1 + 12;
-  constexpr int MAXP = (pw * pw + 31) / 32;
+  constexpr int TPC = SPG_T / SPG_G;   // threads per corner in the patch phase
+  constexpr int MAXP = (pw * pw + TPC - 1) / TPC;
   constexpr int NCH = (nt + SPG_KC - 1) / SPG_KC;
+  constexpr int NPROD = SPG_T - 64;    // term-producing threads
   float* mask_s = reinterpret_cast<float*>(lds_raw + G.mask_off);
   int* state = reinterpret_cast<int*>(lds_raw + G.state_off);
   float* statef = reinterpret_cast<float*>(lds_raw + G.state_off);
@@ -2108,7 +1850,7 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
   double* terms = reinterpret_cast<double*>(lds_raw + G.terms_off);
   __shared__ int sh_active;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int cs = tid >> 5, sub = tid & 31;   // corner slot and thread of the slot (patch phase)
+  const int cs = tid / TPC, sub = tid % TPC;   // corner slot and thread of the slot (patch phase)
   const unsigned char* I = img + (size_t)s * img_stride;
   const int W = P.W, H = P.H;
   const int max_iters = P.subpix_iters;
@@ -2133,12 +1875,24 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
   int eij[MAXP];   // patch entries e = sub + 32 t of the (2w+3)^2 window
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
-    const int e = sub + 32 * t, i = e / pw;
+    const int e = sub + TPC * t, i = e / pw;
     eij[t] = (i << 8) | (e - i * pw);
   }
   __syncthreads();
 
+  const bool stats = (append & 16) != 0;
+  append &= 15;
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = stats ? __builtin_readcyclecounter() : 0ull;
+#define SPG_STAMP(i)                                           \
+  do {                                                         \
+    if (stats) {                                               \
+      const unsigned long long t_ = __builtin_readcyclecounter(); \
+      st_acc[i] += t_ - st_t;                                  \
+      st_t = t_;                                               \
+    }                                                          \
+  } while (0)
   while (sh_active > 0) {
+    SPG_STAMP(4);
     // ---- A: the corner's u8 stage and cv::getRectSubPix patch, 32 threads per corner -------------------------------
     if (state[cs * 16 + SPG_ACTIVE]) {
       const float cIx = statef[cs * 16 + SPG_CIX], cIy = statef[cs * 16 + SPG_CIY];
@@ -2153,7 +1907,7 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
       bool staged = state[cs * 16 + SPG_STAGED] != 0;
       if (!staged || fx0 < sx0 || fy0 < sy0 || fx1 >= sx0 + rs || fy1 >= sy0 + rs) {
         const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
-        for (int e = sub; e < rs * rs; e += 32) {
+        for (int e = sub; e < rs * rs; e += TPC) {
           const int y = e / rs, x = e - y * rs;
           stage[e] = I[(size_t)(ny0 + y) * row_stride + nx0 + x];
         }
@@ -2168,54 +1922,80 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
       }
       const bool use_stage = staged && fx0 >= sx0 && fy0 >= sy0 && fx1 < sx0 + rs && fy1 < sy0 + rs;
       if (use_stage && interior)
-        rect_subpix_from_stage<MAXP, 32>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
+        rect_subpix_from_stage<MAXP, TPC>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
       else if (use_stage)
-        rect_subpix_border_from_stage<MAXP, 32>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
+        rect_subpix_border_from_stage<MAXP, TPC>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
       else
-        rect_subpix_8u32f(I, row_stride, W, H, cIx, cIy, pw, patch, sub, 32);
+        rect_subpix_8u32f(I, row_stride, W, H, cIx, cIy, pw, patch, sub, TPC);
     }
+    SPG_STAMP(0);
     __syncthreads();
+    SPG_STAMP(1);
     // ---- B: terms (waves 1-3) and chains (wave 0), software pipelined over chunks of SPG_KC window pixels ------------
     auto produce = [&](int kc, int buf) {
       const int p = tid - 64;
       double* tb = terms + (size_t)buf * SPG_KC * 5 * SPG_G;
 #pragma unroll
-      for (int j = 0; j < (SPG_KC * SPG_G + 191) / 192; j++) {
-        const int pi = p + 192 * j;
+      for (int j = 0; j < (SPG_KC * SPG_G + NPROD - 1) / NPROD; j++) {
+        const int pi = p + NPROD * j;
         const int c = pi & (SPG_G - 1), kk = pi >> 3, k = kc * SPG_KC + kk;
-        if (pi < SPG_KC * SPG_G && k < nt && state[c * 16 + SPG_ACTIVE]) {
-          const int i = k / ww, jj = k - i * ww;
-          const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off) + (size_t)c * pw * pw + (i + 1) * pw + (jj + 1);
-          const double m = (double)mask_s[k];
-          const double tgx = (double)(sp[1] - sp[-1]);
-          const double tgy = (double)(sp[pw] - sp[-pw]);
-          const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-          const double px = (double)(jj - WIN), py = (double)(i - WIN);
+        if (pi < SPG_KC * SPG_G && state[c * 16 + SPG_ACTIVE]) {
           double* o = tb + (size_t)kk * 5 * SPG_G + c;
-          o[0] = gxx;
-          o[SPG_G] = gxy;
-          o[2 * SPG_G] = gyy;
-          o[3 * SPG_G] = gxx * px + gxy * py;
-          o[4 * SPG_G] = gxy * px + gyy * py;
+          if (k < nt) {
+            const int i = k / ww, jj = k - i * ww;
+            const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off) + (size_t)c * pw * pw + (i + 1) * pw + (jj + 1);
+            const double m = (double)mask_s[k];
+            const double tgx = (double)(sp[1] - sp[-1]);
+            const double tgy = (double)(sp[pw] - sp[-pw]);
+            const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+            const double px = (double)(jj - WIN), py = (double)(i - WIN);
+            o[0] = gxx;
+            o[SPG_G] = gxy;
+            o[2 * SPG_G] = gyy;
+            o[3 * SPG_G] = gxx * px + gxy * py;
+            o[4 * SPG_G] = gxy * px + gyy * py;
+          } else {   // the tail of the last chunk: + 0.0 leaves a sum as it is (the one-corner kernel pads the same way)
+            o[0] = 0.0;
+            o[SPG_G] = 0.0;
+            o[2 * SPG_G] = 0.0;
+            o[3 * SPG_G] = 0.0;
+            o[4 * SPG_G] = 0.0;
+          }
         }
       }
     };
     double acc = 0.0;   // wave 0, lane = 8 chain + corner: the chain's running float64 sum, in window order
     if (wave > 0) produce(0, 0);
     __syncthreads();
+    SPG_STAMP(2);
     for (int kc = 0; kc < NCH; kc++) {
       if (wave == 0) {
         if (lane < 5 * SPG_G) {
+          // the chain is a string of dependent additions (~8 cycles each for a lone wave): the reads run SPG_PF terms
+          // ahead of them so that no addition waits for LDS
           const double* tb = terms + (size_t)(kc & 1) * SPG_KC * 5 * SPG_G + lane;
-          const int nk = min(SPG_KC, nt - kc * SPG_KC);
-#pragma unroll 8
-          for (int kk = 0; kk < nk; kk++) acc += tb[(size_t)kk * 5 * SPG_G];
+          constexpr int SPG_PF = 16;
+          double r[SPG_KC];
+#pragma unroll
+          for (int kk = 0; kk < SPG_PF; kk++) r[kk] = tb[(size_t)kk * 5 * SPG_G];
+          __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the reads to ~6 terms ahead of their additions)
+#pragma unroll
+          for (int kk = 0; kk < SPG_KC; kk += 2) {
+            if (kk + SPG_PF < SPG_KC) {
+              r[kk + SPG_PF] = tb[(size_t)(kk + SPG_PF) * 5 * SPG_G];
+              r[kk + SPG_PF + 1] = tb[(size_t)(kk + SPG_PF + 1) * 5 * SPG_G];
+            }
+            acc += r[kk];
+            acc += r[kk + 1];
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       } else if (kc + 1 < NCH) {
         produce(kc + 1, (kc + 1) & 1);
       }
       if (kc + 1 < NCH) __syncthreads();
     }
+    SPG_STAMP(3);
     // ---- C: the 2 x 2 system, one lane per corner (wave 0) ------------------------------------------------------
     if (wave == 0) {
       const int c = lane & (SPG_G - 1);
@@ -2249,6 +2029,11 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
     }
     __syncthreads();
   }
+  if (stats && tid == 0) {
+    for (int i = 0; i < 5; i++) atomicAdd(&kvfe_spg_stats[i], st_acc[i]);
+    atomicAdd(&kvfe_spg_stats[5], 1ull);
+  }
+#undef SPG_STAMP
   // ---- append (FeatureDetector.cpp:141-160) -----------------------------------------------------------------------
   if (tid < SPG_G && c_first + tid < n_new) {
     const int ci = c_first + tid;
@@ -2261,7 +2046,6 @@ __global__ __launch_bounds__(SPG_T) void subpix_group_kernel(KParams P, Tables T
       K.kp[o] = c;
       K.lmk[o] = S.lmk_counter[s] + ci;
       K.age[o] = 1;
-      K.cost[o] = 0;   // (a new corner: no tracking history)
       double v[3];
       bearing_vector(T.und_left_R, c.x, c.y, v);
       K.versor[o * 3] = v[0];
@@ -2302,11 +2086,6 @@ __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, Detec
   if (what & 2) S.lmk_counter[s] += n_new;
 }
 
-void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 1);
-}
-
 int detect_new_bound(const KParams& P) {
   int bound = P.max_corners > 0 ? P.max_corners : P.acap;
   if (P.enable_anms && (P.anms_type == 0 || P.anms_type == 6))
@@ -2320,66 +2099,61 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
                           hipStream_t st) {
   const size_t lds = subpix_geom(P.subpix_win).bytes;
   const int bound = detect_new_bound(P);
-  // KVFE_SUBPIX_WAVES=1: one wave per corner (LDS-ring chains); default 2 (DPP broadcast chains, kvfe_subpix.inl), and
-  // 4 for a few streams: the patch and term work of an iteration is spread over four SIMDs (5.4 k instead of 6.3 k
-  // cycles per iteration as long as the corners are few; with ~1000 corners in flight two waves are faster)
-  static const int nw_env = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 0;
-  const int nw = nw_env ? nw_env : (P.B <= 4 ? 4 : 2);
-  // one block per (stream, corner slot) up to the bound of the new corners; the stream is the fast grid index (see the
-  // kernel).  A grid sized to what the device holds at once, every block walking ~10 corners of its stream, was measured:
-  // -24 % on kf_realistic (276 corners per stream) -- the iteration counts of the corners differ too much for a static
-  // assignment, the dispatcher's dynamic one wins; the blocks without a corner now trail the launch instead of leading it
-  // (KVFE_SUBPIX_SLOTS: fewer slots than the bound -- blocks then walk their stream's corners with the stride of the grid)
-  static const int slots_env = std::getenv("KVFE_SUBPIX_SLOTS") ? std::atoi(std::getenv("KVFE_SUBPIX_SLOTS")) : 0;
-  const int slots = slots_env > 0 ? std::min(bound, slots_env) : bound;
-  const dim3 grid(P.B, slots);
+  // waves per corner of the one-corner-per-block kernel: 2 (DPP broadcast chains, kvfe_subpix.inl), and 4 for a few
+  // streams -- the patch and term work of an iteration spread over four SIMDs (5.4 k instead of 6.3 k cycles per
+  // iteration as long as the corners are few; with ~1000 corners in flight two waves are faster).  One block per
+  // (stream, corner slot) up to the bound of the new corners, the stream is the fast grid index (see the kernel); a
+  // grid sized to what the device holds at once, every block walking ~10 corners, lost 24 % on real frames (round 3:
+  // the corners' iteration counts differ too much for a static assignment).
+  const int nw = P.B <= 4 ? 4 : 2;
+  const dim3 grid(P.B, bound);
   static const bool stats_on = std::getenv("KVFE_SUBPIX_STATS") != nullptr;
-  // KVFE_SUBPIX_PRIO=1: raised wave priority.  Measured: step 1.158 -> 1.151 / 1.155 -> 1.148 ms, and the rectification
-  // that runs beside it 0.098 -> 0.108 ms -- like the stream priority, the dense kernel pays; not the default
-  static const bool wave_prio = std::getenv("KVFE_SUBPIX_PRIO") && std::atoi(std::getenv("KVFE_SUBPIX_PRIO")) != 0;
-  const int kappend = append | (stats_on ? 16 : 0) | (wave_prio ? 32 : 0);   // (bit 4: per-corner cycle statistics)
+  const int kappend = append | (stats_on ? 16 : 0);   // (bit 4: per-corner cycle statistics)
   if (stats_on) {
     static bool reg = false;
     if (!reg) {
       reg = true;
       std::atexit([] {
         unsigned long long h[8];
+        unsigned long long g[8];
+        if (hipMemcpyFromSymbol(g, HIP_SYMBOL(kvfe_spg_stats), sizeof(g)) == hipSuccess && g[5])
+          std::fprintf(stderr, "KVFE_SUBPIX_STATS (group kernel) blocks %llu, cycles per block: patch %.0f | barrier %.0f | first chunk %.0f | chunk loop %.0f | solve + loop %.0f\n",
+                       g[5], (double)g[0] / g[5], (double)g[1] / g[5], (double)g[2] / g[5], (double)g[3] / g[5], (double)g[4] / g[5]);
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_subpix_stats), sizeof(h)) == hipSuccess && h[0])
           std::fprintf(stderr, "KVFE_SUBPIX_STATS corners %llu, cycles per corner: mean %.0f max %llu; < 100 k: %llu, < 200 k: %llu, < 400 k: %llu, more: %llu\n",
                        h[0], (double)h[1] / (double)h[0], h[2], h[3], h[4], h[5], h[6]);
       });
     }
   }
-  // many streams: SPG_G corners per block, one lane per float64 chain (subpix_group_kernel); a few streams keep the
-  // four-waves-per-corner kernel (fewer corners than SIMDs: the latency of one iteration is what counts there)
-  static const int group_env = std::getenv("KVFE_SUBPIX_GROUP") ? std::atoi(std::getenv("KVFE_SUBPIX_GROUP")) : -1;   // (A/B)
-  const bool group = (group_env >= 0 ? group_env != 0 : P.B > 4) && P.subpix_win == 10 &&
-                     P.W >= subpix_geom(10).rs && P.H >= subpix_geom(10).rs && !stats_on;
-  if (group) {
-    static const int budget = lds_dynamic_budget(reinterpret_cast<const void*>(subpix_group_kernel<10>));
-    const size_t glds = spg_geom(10).bytes;
-    if ((long long)glds <= budget) {
-      hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, (bound + SPG_G - 1) / SPG_G), dim3(SPG_T), glds, st, P, T, img,
-                         row_stride, img_stride, k, S, D, append);
-      if (append)
-        hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, append == 2 ? 2 : 3);
-      return;
-    }
-  }
+  // Two kernels share the launch slot when there are many streams (see subpix_total_new): the one-corner-per-block
+  // kernel below works when the launch holds fewer than SPG_MIN_TOTAL new corners, the grouped kernel after it when it
+  // holds more; the other one's blocks return at once.  KVFE_SUBPIX_GROUP = 0 / 1 forces one of them (A/B, tests).
+  static const int group_env = std::getenv("KVFE_SUBPIX_GROUP") ? std::atoi(std::getenv("KVFE_SUBPIX_GROUP")) : -1;
+  const bool group_ok = P.subpix_win == 10 && P.W >= subpix_geom(10).rs && P.H >= subpix_geom(10).rs;
+  const int group_mode = !group_ok ? 0 : (group_env == 0 ? 0 : (group_env == 1 ? 2 : (P.B > 4 ? 1 : 0)));   // 0 never, 1 by count, 2 always
+  int kapp = kappend | (group_mode == 1 ? 128 : 0);
+  if (group_mode != 2) {
   if (P.subpix_win == 10 && nw == 4)
     hipLaunchKernelGGL((subpix_append_kernel<10, 4>), grid, dim3(256), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, kappend);
+                       row_stride, img_stride, k, S, D, kapp);
   else if (P.subpix_win == 10 && nw == 2)
     hipLaunchKernelGGL((subpix_append_kernel<10, 2>), grid, dim3(128), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, kappend);
+                       row_stride, img_stride, k, S, D, kapp);
   else if (P.subpix_win == 10)
     hipLaunchKernelGGL((subpix_append_kernel<10, 1>), grid, dim3(64), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, kappend);
+                       row_stride, img_stride, k, S, D, kapp);
   else
     hipLaunchKernelGGL((subpix_append_kernel<0, 1>), grid, dim3(64), lds, st, P, T, img,
-                       row_stride, img_stride, k, S, D, kappend);
-  if (append)   // (append == 2: the state half has been launched by launch_detect_state)
-    hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, append == 2 ? 2 : 3);
+                       row_stride, img_stride, k, S, D, kapp);
+  }
+  if (group_mode != 0) {
+    static const int budget = lds_dynamic_budget(reinterpret_cast<const void*>(subpix_group_kernel<10>));
+    const size_t glds = spg_geom(10).bytes;
+    if ((long long)glds > budget) std::fprintf(stderr, "kvfe: subpix_group_kernel needs %zu B of LDS, %d available\n", glds, budget);
+    hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, (bound + SPG_G - 1) / SPG_G), dim3(SPG_T), glds, st, P, T, img,
+                       row_stride, img_stride, k, S, D, append | (stats_on ? 16 : 0) | (group_mode == 2 ? 64 : 0));
+  }
+  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 3);
 }
 
 template <int WIN, int NW>
@@ -2401,8 +2175,7 @@ void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigne
                           int max_iters, double eps2, hipStream_t st) {
   if (n <= 0) return;
   const size_t lds = subpix_geom(win).bytes;
-  static const int nw_env = std::getenv("KVFE_SUBPIX_WAVES") ? std::atoi(std::getenv("KVFE_SUBPIX_WAVES")) : 0;
-  const int nw = nw_env ? nw_env : (n <= 256 ? 4 : 2);
+  const int nw = n <= 256 ? 4 : 2;
   if (win == 10 && nw == 4)
     hipLaunchKernelGGL((subpix_points_kernel<10, 4>), dim3(n), dim3(256), lds, st, mask_tab, img, row_stride,
                        W, H, pts, n, win, max_iters, eps2);

@@ -36,17 +36,9 @@ __device__ __forceinline__ void rs_matvec3(const double* R, const double* v, dou
   for (int r = 0; r < 3; r++) o[r] = (R[r * 3] * v[0] + R[r * 3 + 1] * v[1]) + R[r * 3 + 2] * v[2];
 }
 
-// gtsam::Rot3::equals(Rot3(), 1e-9) (fpEqual without the relative test)
-__device__ bool rs_rot_is_identity(const double* R) {
-  for (int i = 0; i < 9; i++) {
-    const double a = R[i], b = (i % 4 == 0) ? 1.0 : 0.0;
-    if (isnan(a)) return false;
-    if (isinf(a)) return false;
-    if (a == b) continue;
-    if (!(fabs(a - b) <= 1e-9)) return false;
-  }
-  return true;
-}
+// gtsam::Rot3::equals(Rot3(), 1e-9): ONE predicate for the device and for the host's "is the 3-point kernel needed at
+// all" test (kvfe_dev.hpp: rot_is_identity)
+__device__ __forceinline__ bool rs_rot_is_identity(const double* R) { return rot_is_identity(R); }
 
 // exclusive scan of one int per thread over the 256-thread block; *total = block sum
 __device__ __forceinline__ int rs_scan(int v, int* wave_tot /*[4]*/, int* total) {

@@ -558,16 +558,12 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
                     size_t src_row_stride, size_t src_img_stride, unsigned char* const dst[2],
                     const int* flags, int act_flag, hipStream_t st, const int* skip) {
   const int N = P.W * P.H;
-  // KVFE_RECT_IMPL: 0 = per-lane gathers (rectify_kernel), 1 = LDS-staged tiles (default where the source rows are
-  // 16-byte aligned); KVFE_RECT_TILE_MODE: 0 = 3-D grid, 1 = XCD-banded; KVFE_RECT_SPB: streams per block (4 | 8)
-  static const int impl = std::getenv("KVFE_RECT_IMPL") ? std::atoi(std::getenv("KVFE_RECT_IMPL")) : 1;
-  // KVFE_RECT_PAIRS=1: both LDS buffers requested and blended together (see the kernel)
-  static const int tmode = (std::getenv("KVFE_RECT_TILE_MODE") ? std::atoi(std::getenv("KVFE_RECT_TILE_MODE")) & 1 : 0) |
-                           (std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0) |
-                           (std::getenv("KVFE_RECT_PAIRS") && std::atoi(std::getenv("KVFE_RECT_PAIRS")) ? 4 : 0);
-  static const int spb = std::getenv("KVFE_RECT_SPB") ? std::atoi(std::getenv("KVFE_RECT_SPB")) : 2;
-  static const int nsub = std::getenv("KVFE_RECT_NSUB") ? std::atoi(std::getenv("KVFE_RECT_NSUB")) : 4;
-  static const int th = std::getenv("KVFE_RECT_TH") ? std::atoi(std::getenv("KVFE_RECT_TH")) : 16;
+  // LDS-staged tiles where the source rows are 16-byte aligned, per-lane gathers (rectify_kernel) otherwise.
+  // KVFE_RECT_FORCE_GATHER (debugging aid, tests/test_gpu_parity.py): every tile takes the gather fallback of the tile
+  // kernel.  Measured and removed in round 4 (profiles/r3_analysis.md section 6): tile height 32, 1 / 4 streams per LDS
+  // buffer, both buffers requested together (-2 %), the XCD-banded block order (-8 % alone, +6 % inside the step).
+  static const int tmode = std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0;
+  const int impl = 1, spb = 2, nsub = 4, th = 16;
   const bool aligned = P.W % 4 == 0 && src_row_stride % 16 == 0 && src_img_stride % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(src[0]) % 16 == 0 && reinterpret_cast<uintptr_t>(src[1]) % 16 == 0;
   if (impl == 1 && aligned) {
@@ -582,8 +578,7 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
     dim3 grid(tiles_x * tiles_y, 2, gz);
     if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
     const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * rt_patch(TH) + 64;
-    static const bool box_off = std::getenv("KVFE_RECT_NO_BOX") != nullptr;   // (A/B switch: boxes recomputed per block)
-    const bool use_box = TH == 16 && !box_off && T.rect_box[0] && T.rect_box[1];
+    const bool use_box = TH == 16 && T.rect_box[0] && T.rect_box[1];
 #define KVFE_RT_LAUNCH(TH_, SPB_, NSUB_, MINW_)                                                                     \
   hipLaunchKernelGGL((rectify_tile_kernel<TH_, SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],        \
                      src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, \
@@ -591,15 +586,11 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
                      use_box ? T.rect_box[1] : nullptr)
 #define KVFE_RT_DISPATCH(TH_, W1_, W2_)                 \
   do {                                                  \
-    if (S == 1 && NS == 1) KVFE_RT_LAUNCH(TH_, 1, 1, W1_);      \
-    else if (S == 1 && NS == 2) KVFE_RT_LAUNCH(TH_, 1, 2, W1_); \
-    else if (S == 1) KVFE_RT_LAUNCH(TH_, 1, 4, W1_);            \
-    else if (NS == 1) KVFE_RT_LAUNCH(TH_, 2, 1, W1_);           \
-    else if (NS == 2) KVFE_RT_LAUNCH(TH_, 2, 2, W2_);           \
-    else KVFE_RT_LAUNCH(TH_, 2, 4, W2_);                        \
+    if (NS == 1) KVFE_RT_LAUNCH(TH_, 2, 1, W1_);        \
+    else if (NS == 2) KVFE_RT_LAUNCH(TH_, 2, 2, W2_);   \
+    else KVFE_RT_LAUNCH(TH_, 2, 4, W2_);                \
   } while (0)
-    if (TH == 16) KVFE_RT_DISPATCH(16, 7, 4);
-    else KVFE_RT_DISPATCH(32, 4, 3);
+    KVFE_RT_DISPATCH(16, 7, 4);
 #undef KVFE_RT_DISPATCH
 #undef KVFE_RT_LAUNCH
     return;
@@ -610,8 +601,8 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
   // 1-D grid: 8 XCDs x (tiles of the largest band) x 2 cameras x stream groups (see the kernel)
   const int band_tiles = (n_tiles + 7) / 8;
   dim3 grid(8 * band_tiles * 2 * gz);
-  static const int mode = std::getenv("KVFE_RECT_MODE") ? std::atoi(std::getenv("KVFE_RECT_MODE")) : 3;
-  if (mode == 3) grid = dim3(n_tiles, 2, gz);
+  const int mode = 3;   // 3-D grid (tile, camera, stream group); the XCD-banded orders of round 1 are kept in the kernel
+  grid = dim3(n_tiles, 2, gz);
   if (vec4)
     hipLaunchKernelGGL(rectify_kernel<true>, grid, dim3(256), 0, st, src[0], src[1],
                        src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W,
@@ -918,10 +909,8 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
     for (int s = 0; s < P.B; s++)
       (void)hipMemcpy2DAsync(level0_copy + (size_t)s * P.W * P.H, (size_t)P.W, img + (size_t)s * img_stride, row_stride,
                              (size_t)P.W, (size_t)P.H, hipMemcpyDeviceToDevice, st);
-  // KVFE_PYR_IMPL: 0 = tile kernel per level, 1 = streaming two-level kernel where the geometry allows (default);
-  // KVFE_PYR_T2: second-level rows per strip (0 = from the batch size)
-  static const int impl = std::getenv("KVFE_PYR_IMPL") ? std::atoi(std::getenv("KVFE_PYR_IMPL")) : 1;
-  static const int t2_env = std::getenv("KVFE_PYR_T2") ? std::atoi(std::getenv("KVFE_PYR_T2")) : 0;
+  // the streaming two-level kernel where the geometry allows, the tile kernel per level otherwise
+  const int impl = 1, t2_env = 0;
   for (int l = 1; l < P.nlevels; l++) {
     const unsigned char* src = l == 1 ? img : pyr + P.loff[l - 1];
     const size_t srow = l == 1 ? row_stride : (size_t)P.lw[l - 1];

@@ -444,28 +444,13 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
   constexpr int NC = C::NC, NQ = C::NQ, NPX = C::NPX, NST = C::NST, WS = C::WS, WP = C::WP,
                 JM = C::JM, JS = C::JS, JSTR = C::JSTR, PSTR = C::PSTR, NT = C::NT, DSTR = C::DSTR,
                 NJ = C::NJ;
-  // dispatch order (results are independent of it).  use_order: a 1-D grid walks the RANKS of all streams -- rank r =
-  // the r-th slowest point of the previous frame -- so that every stream's slow points start at the beginning of the
-  // launch; the stream index is rotated by the rank so that a stream's points spread over all XCDs (workgroup b runs
-  // on XCD b & 7).  Otherwise (component calls) blockIdx = (point, stream).
-  // part (use_order bits 1-2): 0 = all points of the stream, 1 = the first npts_old (keypoints that were already tracked
-  // in frame k-1), 2 = the rest (frame k-1's new corners): the split launch of the pipelined step
-  const int part = (use_order >> 1) & 3;
-  const bool want_err = !(use_order & 8);   // bit 3: the caller does not read the error output (the front-end step)
-  use_order &= 1;
-  int s, rank;
-  if (use_order) {
-    rank = blockIdx.x / P.B;
-    s = (blockIdx.x - rank * P.B + rank) % P.B;
-  } else {
-    s = blockIdx.y;
-    rank = blockIdx.x;
-  }
-  const int lo = part == 2 ? lk.npts_old[s] : 0;
-  const int hi = part == 1 ? lk.npts_old[s] : lk.npts[s];
-  rank += lo;
-  if (rank >= hi) return;
-  const int pt = use_order ? lk.order[(size_t)s * P.kcap + rank] : rank;
+  // blockIdx = (point, stream); flags bit 3: the caller does not read the error output (the front-end step).
+  // (Round 3 measured two more launch forms -- points ordered by the previous frame's iteration count, and the launch
+  // split over two HIP streams; both lost their A/B and were removed in round 4)
+  const bool want_err = !(use_order & 8);
+  const int s = blockIdx.y, rank = blockIdx.x;
+  if (rank >= lk.npts[s]) return;
+  const int pt = rank;
   int iters_total = 0;
   const int lane = threadIdx.x;
   const int g = lane >> 4, q = lane & 15;
@@ -825,7 +810,6 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
     lk.next_pts[po] = nextOut;
     lk.status[po] = (unsigned char)status;
     lk.err[po] = errOut;
-    lk.iters[po] = (unsigned char)min(iters_total, 255);
 #ifdef KVFE_LK_PROF
     const size_t wid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;   // (dispatch order)
     if (wid < (size_t)LKP_WAVES) {
@@ -842,440 +826,19 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Systolic kernel with TWO points per wavefront (WIN = 24).
-//
-// The sequential float chains are the instruction floor of lk_kernel_sys: per level 144 + 144 dependent adds for
-// A11/A12 | A22 and per iteration 72 for (b1, b2), issued by the whole wave whatever the number of lanes that carry
-// pixels (48 of 64 there).  Here a DPP row holds both points: lane = 16 g + 2 q + pt, g = SSE lane class (x & 3),
-// q < 8 owns window rows {3q, 3q+1, 3q+2} and columns {g + 4m} of point pt (18 pixels), and the carry moves with
-// row_shr:2, so that one pass of the chain serves two points and all 64 lanes carry pixels: 8 stages x 9 packed adds
-// per iteration for two points instead of 12 x 6 for one.  Per-point state (position, status, the 2x2 system) lives
-// replicated in the 32 lanes of the point; the two points iterate in lock step and a point that has converged (or
-// left the image, or failed the min-eigenvalue test) just stops updating its state.  The per-level derivative patch
-// is dead once the template registers are filled, so the staged current-level window aliases it: 4.8 KB of LDS per
-// point.  The arithmetic and its order are those of lk_kernel_sys, hence of OpenCV's SSE2 build: bit-identical.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_row_shr2(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-}
-__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-
-struct LkSys2 {
-  static constexpr int WIN = 24;
-  static constexpr int NC = WIN / 4;        // columns per lane
-  static constexpr int NR = 3;              // window rows per lane
-  static constexpr int NQ = 8;              // lanes per point and DPP row
-  static constexpr int NPX = NR * NC;       // pixels per lane
-  static constexpr int NST = NR * NC / 2;   // b-chain terms per lane
-  static constexpr int WS = WIN + 3, WP = WIN + 1, JM = 3, JS = WIN + 1 + 2 * JM;
-  static constexpr int JSTR = ((JS - 1 - 1 + 15) / 16) * 16 + 1;
-  static constexpr int PATCH_B = (WS * WS + 3) & ~3;
-  static constexpr int DXY_W = WP * WP;
-  static constexpr int UNI_W = DXY_W > JS * JSTR ? DXY_W : JS * JSTR;   // dxy and jp share this region
-  static constexpr int PT_BYTES = PATCH_B + 4 * UNI_W;
-};
-
-__global__ __launch_bounds__(64) void lk_kernel_sys2(KParams P, const unsigned char* prev_img,
-                                                     size_t prev_row_stride, size_t prev_img_stride,
-                                                     const unsigned char* prev_pyr, const unsigned char* cur_img,
-                                                     size_t cur_row_stride, size_t cur_img_stride,
-                                                     const unsigned char* cur_pyr, LkScratch lk) {
-  using C = LkSys2;
-  constexpr int WIN = C::WIN, NC = C::NC, NR = C::NR, NQ = C::NQ, NPX = C::NPX, NST = C::NST, WS = C::WS,
-                WP = C::WP, JM = C::JM, JS = C::JS, JSTR = C::JSTR;
-  const int s = blockIdx.y, pair = blockIdx.x;
-  const int npts = lk.npts[s];
-  if (2 * pair >= npts) return;
-  const int lane = threadIdx.x;
-  const int g = lane >> 4, q = (lane & 15) >> 1, pt = lane & 1;
-  const bool exists = 2 * pair + pt < npts;      // the last pair of an odd count has one point
-  const int pidx = exists ? 2 * pair + pt : 2 * pair;
-
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::PT_BYTES];
-  unsigned char* const my_patch = lds + pt * C::PT_BYTES;
-  int* const my_uni = reinterpret_cast<int*>(my_patch + C::PATCH_B);   // dxy (set-up) / jp (iterations)
-
-  const unsigned char* pimg = prev_img + (size_t)s * prev_img_stride;
-  const unsigned char* cimg = cur_img + (size_t)s * cur_img_stride;
-  const unsigned char* ppyr = prev_pyr + (size_t)s * P.pyr_stride;
-  const unsigned char* cpyr = cur_pyr + (size_t)s * P.pyr_stride;
-
-  const size_t po = (size_t)s * P.kcap + pidx;
-  const float2 prevPt0 = lk.prev_pts[po];
-  float2 nextOut = lk.next_pts[po];  // initial flow
-  int status = 1;
-  float errOut = 0.f;
-  const int maxLevel = P.nlevels - 1;
-  const float FLT_SCALE = 1.f / (1 << 20);
-  const float halfWin = (WIN - 1) * 0.5f;
-  const int klt_iters = P.klt_iters;
-  const double klt_eps2 = P.klt_eps2;
-  const int y0w = NR * q, x0w = g;   // window offset of this lane's first pixel
-
-  for (int level = maxLevel; level >= 0; level--) {
-    const LevelImg LI = level_img(P, pimg, prev_row_stride, ppyr, level);
-    const LevelImg LJ = level_img(P, cimg, cur_row_stride, cpyr, level);
-    const float lscale = (float)(1. / (1 << level));
-    float2 prevPt = make_float2(prevPt0.x * lscale, prevPt0.y * lscale);
-    float2 nextPt;
-    if (level == maxLevel)
-      nextPt = make_float2(nextOut.x * lscale, nextOut.y * lscale);
-    else
-      nextPt = make_float2(nextOut.x * 2.f, nextOut.y * 2.f);
-    nextOut = nextPt;
-
-    prevPt.x -= halfWin;
-    prevPt.y -= halfWin;
-    int ipx = (int)floorf(prevPt.x), ipy = (int)floorf(prevPt.y);
-    bool lv = true;   // this point takes part in this level
-    if (ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h) {
-      if (level == 0) {
-        status = 0;
-        errOut = 0.f;
-      }
-      lv = false;
-      ipx = ipy = 0;   // any in-range window: the lanes keep computing, the results are dropped
-    }
-    if (__builtin_amdgcn_readlane((int)lv, 0) == 0 && __builtin_amdgcn_readlane((int)lv, 1) == 0) continue;
-    float a = prevPt.x - ipx, b = prevPt.y - ipy;
-    if (!lv) a = b = 0.f;
-    int iw00, iw01, iw10, iw11;
-    lk_weights(a, b, &iw00, &iw01, &iw10, &iw11);
-    int wq0 = pack_lo16(iw00, iw01), wq1 = pack_lo16(iw10, iw11);
-
-    __syncthreads();  // previous level's readers of patch / dxy / jp are done
-    // stage the (WIN+3)^2 neighbourhoods of the previous level (REFLECT_101 padded image), both points by all lanes
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-      const int pix = lane_i(ipx, p), piy = lane_i(ipy, p);
-      unsigned char* patch = lds + p * C::PT_BYTES;
-      const bool interior = pix - 1 >= 0 && piy - 1 >= 0 && pix - 1 + WS <= LI.w && piy - 1 + WS <= LI.h;
-      if (interior) {
-        const unsigned char* base = LI.p + (size_t)(piy - 1) * LI.stride + (pix - 1);
-        for (int e = lane; e < WS * WS; e += 64) {
-          const int py = e / WS, px = e - py * WS;
-          patch[e] = base[(size_t)py * LI.stride + px];
-        }
-      } else {
-        for (int e = lane; e < WS * WS; e += 64) {
-          const int py = e / WS, px = e - py * WS;
-          patch[e] = (unsigned char)at101(LI, pix - 1 + px, piy - 1 + py);
-        }
-      }
-    }
-    __syncthreads();
-    // Scharr derivative at the (WIN+1)^2 positions; zero outside the image (BORDER_CONSTANT)
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-      const int pix = lane_i(ipx, p), piy = lane_i(ipy, p);
-      const unsigned char* patch = lds + p * C::PT_BYTES;
-      int* dxy = reinterpret_cast<int*>(lds + p * C::PT_BYTES + C::PATCH_B);
-      for (int e = lane; e < WP * WP; e += 64) {
-        const int y = e / WP, x = e - y * WP;
-        const int gx = pix + x, gy = piy + y;
-        int vx = 0, vy = 0;
-        if (gx >= 0 && gx < LI.w && gy >= 0 && gy < LI.h) {
-          const unsigned char* r0 = patch + y * WS + x;  // row gy-1, col gx-1
-          const unsigned char* r1 = r0 + WS;
-          const unsigned char* r2 = r1 + WS;
-          const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
-          const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
-          vx = t0p - t0m;
-          vy = (t1p + t1m) * 3 + t1c * 10;
-        }
-        dxy[e] = pack_lo16(vx, vy);
-      }
-    }
-    __syncthreads();
-    // bilinear template and derivative window of this lane's pixels -> registers
-    int rI[NPX], rgxy[NPX];  // rgxy = (Ix & 0xffff) | (Iy << 16)
-#pragma unroll
-    for (int r = 0; r < NR; r++)
-#pragma unroll
-      for (int m = 0; m < NC; m++) {
-        const int k = r * NC + m;
-        const int y = y0w + r, x = x0w + 4 * m;
-        const unsigned char* s0 = my_patch + (y + 1) * WS + (x + 1);
-        const int p0 = (int)s0[0] | ((int)s0[1] << 16), p1 = (int)s0[WS] | ((int)s0[WS + 1] << 16);
-        const int ival = dot2_i16(p0, wq0, dot2_i16(p1, wq1, 1 << 8)) >> 9;
-        const int* d = my_uni + y * WP + x;
-        const int d00 = d[0], d01 = d[1], d10 = d[WP], d11 = d[WP + 1];
-        const int ixval =
-            dot2_i16(pack_lo16(d00, d01), wq0, dot2_i16(pack_lo16(d10, d11), wq1, 1 << 13)) >> 14;
-        const int iyval =
-            dot2_i16(pack_hi16(d00, d01), wq0, dot2_i16(pack_hi16(d10, d11), wq1, 1 << 13)) >> 14;
-        rI[k] = sat16(ival);
-        rgxy[k] = pack_lo16(sat16(ixval), sat16(iyval));
-      }
-    // A11/A12/A22 chains (SSE lane l = g; order: row, then column chunk), both points at once
-    float A11, A12, A22;
-    {
-      // two passes (A11 | A12 packed, then A22) so that only 36 + 18 product registers are live at a time
-      v2f t = {0.f, 0.f};
-      float t22 = 0.f;
-      {
-        v2f pa[NPX];
-#pragma unroll
-        for (int k = 0; k < NPX; k++) {
-          const float fx = (float)(short)(rgxy[k] & 0xffff), fy = (float)(rgxy[k] >> 16);
-          pa[k] = v2f{fx * fx, fx * fy};
-        }
-        float c11 = 0.f, c12 = 0.f;
-#pragma unroll
-        for (int st = 0; st < NQ; st++) {
-          t = v2f{c11, c12};
-#pragma unroll
-          for (int k = 0; k < NPX; k++) t = t + pa[k];
-          c11 = dpp_row_shr2(t.x);
-          c12 = dpp_row_shr2(t.y);
-        }
-      }
-      asm volatile("" : "+v"(t));   // keep the second pass's products from being hoisted above the first chain
-      {
-        float pc[NPX];
-#pragma unroll
-        for (int k = 0; k < NPX; k++) {
-          const float fy = (float)(rgxy[k] >> 16);
-          pc[k] = fy * fy;
-        }
-        float c22 = 0.f;
-#pragma unroll
-        for (int st = 0; st < NQ; st++) {
-          t22 = c22;
-#pragma unroll
-          for (int k = 0; k < NPX; k++) t22 = t22 + pc[k];
-          c22 = dpp_row_shr2(t22);
-        }
-      }
-      // the last lane of each (row, point) holds that SSE lane's sum: lanes 16 g + 14 + pt
-      float s11[2], s12[2], s22[2];
-#pragma unroll
-      for (int p = 0; p < 2; p++) {
-        float i11 = 0.f, i12 = 0.f, i22 = 0.f;
-        i11 += lane_f(t.x, 14 + p) + lane_f(t.x, 30 + p) + lane_f(t.x, 46 + p) + lane_f(t.x, 62 + p);
-        i12 += lane_f(t.y, 14 + p) + lane_f(t.y, 30 + p) + lane_f(t.y, 46 + p) + lane_f(t.y, 62 + p);
-        i22 += lane_f(t22, 14 + p) + lane_f(t22, 30 + p) + lane_f(t22, 46 + p) + lane_f(t22, 62 + p);
-        s11[p] = i11;
-        s12[p] = i12;
-        s22[p] = i22;
-      }
-      A11 = (pt ? s11[1] : s11[0]) * FLT_SCALE;
-      A12 = (pt ? s12[1] : s12[0]) * FLT_SCALE;
-      A22 = (pt ? s22[1] : s22[0]) * FLT_SCALE;
-    }
-    float D = A11 * A22 - A12 * A12;
-    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
-                         (float)(2 * WIN * WIN);
-    if (lv && (minEig < 1e-4f || D < 1.1920929e-07f)) {
-      if (level == 0) status = 0;
-      lv = false;
-    }
-    D = 1.f / D;
-
-    nextPt.x -= halfWin;
-    nextPt.y -= halfWin;
-    float2 prevDelta = make_float2(0.f, 0.f);
-    int jx0 = 0, jy0 = 0;          // origin of this point's staged current-level window
-    bool jvalid = false;
-    __syncthreads();               // every lane has read dxy: jp may overwrite it
-    // (re)stage the current-level window of point p as (pixel, pixel+1) pairs around (inx, iny): all 64 lanes
-    auto stage_j = [&](int p, int sx, int sy) {
-      int* jp = reinterpret_cast<int*>(lds + p * C::PT_BYTES + C::PATCH_B);
-      const int ox = sx - JM, oy = sy - JM;
-      const bool interior = ox >= 0 && oy >= 0 && ox + JS <= LJ.w && oy + JS <= LJ.h;
-      if (interior) {
-        const unsigned char* base = LJ.p + (size_t)oy * LJ.stride + ox;
-        for (int e = lane; e < JS * (JS - 1); e += 64) {
-          const int yy = e / (JS - 1), xx = e - yy * (JS - 1);
-          const unsigned char* r = base + (size_t)yy * LJ.stride + xx;
-          jp[yy * JSTR + xx] = (int)r[0] | ((int)r[1] << 16);
-        }
-      } else {
-        for (int e = lane; e < JS * (JS - 1); e += 64) {
-          const int yy = e / (JS - 1), xx = e - yy * (JS - 1);
-          jp[yy * JSTR + xx] = at101(LJ, ox + xx, oy + yy) | (at101(LJ, ox + xx + 1, oy + yy) << 16);
-        }
-      }
-    };
-    // makes sure the window (inx .. inx+WIN, iny .. iny+WIN) of every point with `want` set is staged
-    auto ensure_staged = [&](bool want, int inx, int iny) {
-      const bool need = want && (!jvalid || inx < jx0 || iny < jy0 || inx + WIN + 1 > jx0 + JS || iny + WIN + 1 > jy0 + JS);
-      const int n0 = lane_i((int)need, 0), n1 = lane_i((int)need, 1);
-      if (n0 | n1) {
-        __syncthreads();
-        if (n0) stage_j(0, lane_i(inx, 0), lane_i(iny, 0));
-        if (n1) stage_j(1, lane_i(inx, 1), lane_i(iny, 1));
-        __syncthreads();
-        if (need) {
-          jx0 = inx - JM;
-          jy0 = iny - JM;
-          jvalid = true;
-        }
-      }
-    };
-    bool run = lv;                 // this point is still iterating
-    int joff = 0;                  // offset of this lane's first pair in its jp (kept valid when the point stops)
-    for (int j = 0; j < klt_iters; j++) {
-      int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
-      if (run && (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h)) {
-        if (level == 0) status = 0;
-        run = false;
-      }
-      if (lane_i((int)run, 0) == 0 && lane_i((int)run, 1) == 0) break;
-      if (run) {
-        a = nextPt.x - inx;
-        b = nextPt.y - iny;
-        lk_weights(a, b, &iw00, &iw01, &iw10, &iw11);
-        wq0 = pack_lo16(iw00, iw01);
-        wq1 = pack_lo16(iw10, iw11);
-      }
-      ensure_staged(run, inx, iny);
-      if (run) joff = (iny - jy0 + y0w) * JSTR + (inx - jx0 + x0w);
-      const int* jb = my_uni + joff;
-      int diff[NPX];
-#pragma unroll
-      for (int r = 0; r < NR; r++)
-#pragma unroll
-        for (int m = 0; m < NC; m++) {
-          const int k = r * NC + m;
-          const int t = dot2_i16(jb[r * JSTR + 4 * m], wq0,
-                                 dot2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, 1 << 8)) >> 9;
-          diff[k] = t - rI[k];
-        }
-      // chain terms: madd pairs (x, x+4) of one row chunk, converted to float
-      v2f term[NST];
-#pragma unroll
-      for (int r = 0; r < NR; r++)
-#pragma unroll
-        for (int c = 0; c < NC / 2; c++) {
-          const int k0 = r * NC + 2 * c, k1 = k0 + 1;
-          const int dd = pack_lo16(diff[k0], diff[k1]);
-          const int m1 = dot2_i16(dd, pack_lo16(rgxy[k0], rgxy[k1]), 0);
-          const int m2 = dot2_i16(dd, pack_hi16(rgxy[k0], rgxy[k1]), 0);
-          term[r * (NC / 2) + c] = v2f{(float)m1, (float)m2};
-        }
-      float cb1 = 0.f, cb2 = 0.f;
-      v2f t = {0.f, 0.f};
-#pragma unroll
-      for (int st = 0; st < NQ; st++) {
-        t = v2f{cb1, cb2};
-#pragma unroll
-        for (int i = 0; i < NST; i++) t = t + term[i];
-        cb1 = dpp_row_shr2(t.x);
-        cb2 = dpp_row_shr2(t.y);
-      }
-      // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]   (per point)
-      float sb1[2], sb2[2];
-#pragma unroll
-      for (int p = 0; p < 2; p++) {
-        const float bb0 = lane_f(t.x, 14 + p) + lane_f(t.x, 46 + p), bb1 = lane_f(t.y, 14 + p) + lane_f(t.y, 46 + p);
-        const float bb2 = lane_f(t.x, 30 + p) + lane_f(t.x, 62 + p), bb3 = lane_f(t.y, 30 + p) + lane_f(t.y, 62 + p);
-        float ib1 = 0.f, ib2 = 0.f;
-        ib1 += bb0 + bb2;
-        ib2 += bb1 + bb3;
-        sb1[p] = ib1;
-        sb2[p] = ib2;
-      }
-      if (run) {
-        const float b1 = (pt ? sb1[1] : sb1[0]) * FLT_SCALE, b2 = (pt ? sb2[1] : sb2[0]) * FLT_SCALE;
-        const float2 delta =
-            make_float2((float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D));
-        nextPt.x += delta.x;
-        nextPt.y += delta.y;
-        nextOut = make_float2(nextPt.x + halfWin, nextPt.y + halfWin);
-        if ((double)delta.x * (double)delta.x + (double)delta.y * (double)delta.y <= klt_eps2) {
-          run = false;
-        } else if (j > 0 && fabs((double)(delta.x + prevDelta.x)) < 0.01 &&
-                   fabs((double)(delta.y + prevDelta.y)) < 0.01) {
-          nextOut.x -= delta.x * 0.5f;
-          nextOut.y -= delta.y * 0.5f;
-          run = false;
-        }
-        prevDelta = delta;
-      }
-    }
-
-    if (level == 0) {
-      bool want = lv && status;
-      const float2 np = make_float2(nextOut.x - halfWin, nextOut.y - halfWin);
-      int inx = (int)floorf(np.x), iny = (int)floorf(np.y);
-      if (want && (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h)) {
-        status = 0;
-        want = false;
-      }
-      if (lane_i((int)want, 0) | lane_i((int)want, 1)) {
-        if (want) {
-          const float aa = np.x - inx, bb = np.y - iny;
-          lk_weights(aa, bb, &iw00, &iw01, &iw10, &iw11);
-          wq0 = pack_lo16(iw00, iw01);
-          wq1 = pack_lo16(iw10, iw11);
-        }
-        ensure_staged(want, inx, iny);
-        if (want) joff = (iny - jy0 + y0w) * JSTR + (inx - jx0 + x0w);
-        const int* jb = my_uni + joff;
-        // errval is a float sum of integers < 2^24: exact in any order
-        int esum = 0;
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-#pragma unroll
-          for (int m = 0; m < NC; m++) {
-            const int k = r * NC + m;
-            const int t = dot2_i16(jb[r * JSTR + 4 * m], wq0,
-                                   dot2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, 1 << 8)) >> 9;
-            esum += abs(t - rI[k]);
-          }
-        for (int off = 32; off > 1; off >>= 1) esum += __shfl_xor(esum, off);   // over the 32 lanes of the point
-        if (want) errOut = (float)esum * 1.f / (float)(32 * WIN * WIN);
-      }
-    }
-  }
-  if (lane < 2 && exists) {
-    lk.next_pts[po] = nextOut;
-    lk.status[po] = (unsigned char)status;
-    lk.err[po] = errOut;
-  }
-}
-
-// the split launch (part 1 | 2) exists for the systolic kernels only
-bool lk_supports_parts(const KParams& P) {
-  static const int lk_pts = std::getenv("KVFE_LK_PTS") ? std::atoi(std::getenv("KVFE_LK_PTS")) : 1;
-  return (P.klt_win == 16 || P.klt_win == 24 || P.klt_win == 32) && lk_pts != 2;
-}
-
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order, int part, bool want_err) {
+               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err) {
   if (max_pts <= 0) return;
-  // KVFE_LK_ORDER=1 (measured, NOT the default): dispatch the points by the iterations they took in the previous frame,
-  // slowest first and rank-major over the streams, so that the launch's tail of slow points starts early.  Bit-exact
-  // (158 GPU tests), but the count of the previous frame does not predict this frame's: 0.555 ms against 0.547 ms
-  // per 64-stream launch in table order.
-  static const bool order_on = std::getenv("KVFE_LK_ORDER") != nullptr;
-  // (the kernel's use_order argument: bit 0 | part << 1 | no error output << 3; KVFE_LK_ERR=1: always computed, A/B switch)
-  static const bool force_err = std::getenv("KVFE_LK_ERR") != nullptr;
-  const int ord = (part ? (part << 1) : (use_order && order_on ? 1 : 0)) | (want_err || force_err ? 0 : 8);
+  const int flags = want_err ? 0 : 8;   // (bit 3: no error output -- Tracker::featureTracking drops that vector)
   const dim3 grid(max_pts, P.B), block(64);
-#define KVFE_LK_SYS(WINSZ)                                                                      \
-  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, (ord & 1) ? dim3((unsigned)max_pts * P.B) : grid, block, 0, st, P, prev_img, prev_row_stride,    \
-                     prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,        \
-                     cur_pyr, lk, ord)
-  // KVFE_LK_PTS=2: two points per wave for the reference's window of 24 (lk_kernel_sys2: bit-exact, 18 % fewer VALU
-  // instructions, but 0.65 ms against 0.56 ms per 64-stream step -- three waves per SIMD do not hide its LDS latency
-  // and the two points' windows collide on LDS banks, profiles/r2_lk2_pmc.md); default: one point per wave
-  static const int lk_pts = std::getenv("KVFE_LK_PTS") ? std::atoi(std::getenv("KVFE_LK_PTS")) : 1;
-  if (part && !lk_supports_parts(P)) return;   // (the caller asks lk_supports_parts first)
+#define KVFE_LK_SYS(WINSZ)                                                                                          \
+  hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, grid, block, 0, st, P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, \
+                     cur_img, cur_row_stride, cur_img_stride, cur_pyr, lk, flags)
   switch (P.klt_win) {
     case 16: KVFE_LK_SYS(16); break;
-    case 24:
-      if (lk_pts == 2)
-        hipLaunchKernelGGL(lk_kernel_sys2, dim3((max_pts + 1) / 2, P.B), block, 0, st, P, prev_img, prev_row_stride,
-                           prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride, cur_pyr, lk);
-      else
-        KVFE_LK_SYS(24);
-      break;
+    case 24: KVFE_LK_SYS(24); break;
     case 32: KVFE_LK_SYS(32); break;
     default:
       hipLaunchKernelGGL(lk_kernel_generic, grid, block, lk_generic_lds_bytes(P.klt_win), st, P,
@@ -1433,20 +996,13 @@ __device__ __forceinline__ float2 predict_point(const float* H, float2 p, int W,
   return p;
 }
 
-// part: 0 = all keypoints of frame k-1; 1 = those that were tracked INTO frame k-1 (table entries below n_tracked: final
-// since its track_finalize / outlier rejections, on the main stream) -> npts_old; 2 = frame k-1's new corners (entries
-// n_tracked .. count - 1, written by its corner refinement on the side stream), appended behind the first part -> npts.
-// 1 + 2 produce exactly the arrays of 0: the gather keeps table order and the new corners are the table's tail.
 __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T, FrameTab KM1,
-                                                            StreamState S, LkScratch lk, int part) {
+                                                            StreamState S, LkScratch lk) {
   const int s = blockIdx.x;
   __shared__ float Hs[9];
   __shared__ int use_h;
   if (!(S.flags[s] & FLAG_INIT)) {
-    if (threadIdx.x == 0) {
-      if (part != 2) lk.npts_old[s] = 0;
-      if (part != 1) lk.npts[s] = 0;
-    }
+    if (threadIdx.x == 0) lk.npts[s] = 0;
     return;
   }
   if (threadIdx.x == 0) {
@@ -1469,33 +1025,13 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
   __syncthreads();
   // Tracker.cpp:103-112: only keypoints with a valid landmark are tracked (geometric outlier
   // rejection leaves landmark -1 entries in a keyframe); src_idx maps point -> index in frame k-1
-  const int n_all = KM1.count[s];
-  const int n_old = min(S.n_tracked[s], n_all);
-  const int i0 = part == 2 ? n_old : 0;
-  const int n = part == 1 ? n_old : n_all;
+  const int n = KM1.count[s];
   const size_t so = (size_t)s * P.kcap;
   __shared__ int wave_tot[4];
   __shared__ int sh_off;
-  // dispatch order of the tracking launch: eight cost classes (iterations of the previous frame / 8), slowest first;
-  // a counting sort -- class sizes first, then every point takes the next free slot of its class (the order inside a
-  // class is arbitrary and irrelevant: only WHEN a point is tracked depends on it, never the result)
-  __shared__ int cls_cursor[8];
-  if (threadIdx.x < 8) cls_cursor[threadIdx.x] = 0;
-  if (threadIdx.x == 0) sh_off = part == 2 ? lk.npts_old[s] : 0;
+  if (threadIdx.x == 0) sh_off = 0;
   __syncthreads();
-  for (int i = i0 + threadIdx.x; i < n; i += 256)
-    if (KM1.lmk[so + i] != -1) atomicAdd(&cls_cursor[min(7, (int)KM1.cost[so + i] >> 3)], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = part == 2 ? lk.npts_old[s] : 0;
-    for (int k = 7; k >= 0; k--) {
-      const int c = cls_cursor[k];
-      cls_cursor[k] = acc;
-      acc += c;
-    }
-  }
-  __syncthreads();
-  for (int base = i0; base < n; base += 256) {
+  for (int base = 0; base < n; base += 256) {
     const int i = base + threadIdx.x;
     const bool valid = i < n && KM1.lmk[so + i] != -1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1518,23 +1054,17 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
       lk.prev_pts[so + o] = p;
       lk.next_pts[so + o] = use_h ? predict_point(Hs, p, P.W, P.H) : p;
       lk.src_idx[so + o] = i;
-      lk.order[so + atomicAdd(&cls_cursor[min(7, (int)KM1.cost[so + i] >> 3)], 1)] = o;
     }
     __syncthreads();
     if (threadIdx.x == 0) sh_off = off0 + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    if (part == 1)
-      lk.npts_old[s] = sh_off;
-    else
-      lk.npts[s] = sh_off;
-  }
+  if (threadIdx.x == 0) lk.npts[s] = sh_off;
 }
 
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part) {
-  hipLaunchKernelGGL(track_prepare_kernel, dim3(P.B), dim3(256), 0, st, P, T, km1, S, lk, part);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st) {
+  hipLaunchKernelGGL(track_prepare_kernel, dim3(P.B), dim3(256), 0, st, P, T, km1, S, lk);
 }
 
 __global__ void predict_flow_kernel(KParams P, Tables T, const double* R, const float2* prev,
@@ -1624,7 +1154,6 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
       K.kp[o] = p;
       K.lmk[o] = KM1.lmk[so + src];
       K.age[o] = KM1.age[so + src];
-      K.cost[o] = lk.iters[so + i];
       double v[3];
       bearing_vector(T.und_left_R, p.x, p.y, v);
       K.versor[o * 3] = v[0];

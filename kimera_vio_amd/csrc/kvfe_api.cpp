@@ -129,9 +129,7 @@ struct kvfe_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
   hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // main-stream part of the fork done / tail of the step (side stream) done
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
-  hipEvent_t ev_prep = nullptr, ev_lknew = nullptr;  // split tracking: first part gathered (main) / second part tracked (side)
   bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
-  bool split_lk = false;                             // KVFE_LK_SPLIT: see do_step
   bool fork_swap = false;                            // few streams: the corner refinement stays on the main stream (do_step)
   bool chain_pending = false;                        // fork_swap: the side stream's outlier rejection has not been joined yet
   bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
@@ -275,7 +273,6 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
     TRY(dalloc(c, &b.ft[i].lmk, K));
     TRY(dalloc(c, &b.ft[i].age, K));
     TRY(dalloc(c, &b.ft[i].versor, K * 3));
-    TRY(dalloc(c, &b.ft[i].cost, K));
     TRY(dalloc(c, &b.ft[i].count, B));
     TRY(dalloc(c, &b.ft[i].timestamp, B));
   }
@@ -350,10 +347,7 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
-  TRY(dalloc(c, &b.lk.npts_old, B));
   TRY(dalloc(c, &b.lk.src_idx, K));
-  TRY(dalloc(c, &b.lk.order, K));
-  TRY(dalloc(c, &b.lk.iters, K));
   TRY(reset_tracker_status(c, b));
   // keyframe_R_ref_frame_ = identity
   std::vector<double> eye(B * 9, 0.0);
@@ -836,7 +830,11 @@ void prof_collect(kvfe_ctx* c) {
       c->prof_ms[s] += ms;
       int active = c->P.B;
       const int f = stage_flag(s);
-      if (f && slot >= 0 && c->prof_flags_host) {
+      if (f) {
+        // a keyframe-only stage: its activity comes from the step's flag word; a sample without one (more than
+        // PROF_FLAG_SAMPLES sampled steps between two reads) stays out of the activity statistics instead of
+        // counting as "all streams active"
+        if (slot < 0 || !c->prof_flags_host) continue;
         active = 0;
         for (int i = 0; i < c->P.B; i++) active += (c->prof_flags_host[(size_t)slot * c->P.B + i] & f) ? 1 : 0;
       }
@@ -938,6 +936,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
   if (c->prof_on) {
     c->prof_pending.push_back((int)(c->prof_idx.size() / (2 * ST_COUNT)));
+    c->prof_flag_slot.push_back(-1);   // (filled in behind track_finalize: an error return in between keeps the lists aligned)
     c->prof_idx.insert(c->prof_idx.end(), 2 * ST_COUNT, -1);
     c->prof_last_end = -1;
   }
@@ -947,26 +946,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   const int pc = c->pyr_cur, pp = pc ^ 1;
   hipStream_t sd = c->side ? c->side : st;
 
-  // KVFE_EARLY_RECTIFY=1 (measured, NOT the default): streams the caller forces to be keyframes are rectified right away
-  // on the side stream -- rectification depends on nothing but the images, and the tracking kernel that opens the step
-  // ends in a tail of a few slow points.  On MI355X it loses: the remap's workgroups take issue slots from the tracking
-  // kernel for longer than the remap takes after it (64 x 752x480, every frame a keyframe: 1.160 ms per step against
-  // 1.097 ms, profiles/r3 notes), so the remap stays behind the tracking.
-  int n_forced = 0;
-  for (int s = 0; s < P.B; s++) n_forced += inputs[s].force_keyframe ? 1 : 0;
-  static const bool early_rect_on = std::getenv("KVFE_EARLY_RECTIFY") != nullptr;
-  const bool early_rect = c->side && !P.mono && n_forced > 0 && early_rect_on;
-  const bool all_early = early_rect && n_forced == P.B;
-  if (early_rect) {
-    HIPCHK(c, hipEventRecord(c->ev_join, st));            // (the images are ready in the main stream's order)
-    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_join, 0));
-    slot_release.side_used = true;
-    if (all_early) prof_begin(c, ST_RECTIFY, sd);
-    const unsigned char* srcs[2] = {left, right};
-    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.in_force_kf, ~0, sd);
-    if (all_early) prof_end(c, ST_RECTIFY, sd);
-    HIPCHK(c, hipEventRecord(c->ev_mono, sd));
-  }
   prof_begin(c, ST_PYRAMID, st);
   launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st, c->own_level0 ? b.lvl0[pc] : nullptr);
   prof_end(c, ST_PYRAMID, st);
@@ -974,42 +953,23 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // refined new corners and the per-stream state detect_commit wrote (ev_commit) -- joined HERE, behind the pyramid,
   // which does not depend on it and hides the cross-stream hand-over.  Its tail (stereo matching of the new corners,
   // measurements, lkf <- k) is only needed by track_finalize: it runs next to this step's tracking launch.
-  // KVFE_LK_SPLIT=1: the tracking launch in two parts.  The keypoints frame k-1 had tracked itself are final on the main
-  // stream (track_finalize, outlier rejections) and the state the predictor reads is written there too
-  // (launch_detect_state): their part starts right behind the pyramid.  Frame k-1's NEW corners come out of the corner
-  // refinement on the side stream: they are gathered and tracked THERE, behind the previous step's tail and next to the
-  // first part -- the corner refinement (40 dependent iterations per corner) is off the critical path.
   if (c->chain_pending) {   // fork_swap: the previous step's rectify / match / reject chain ran on the side stream
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_main, 0));
     c->chain_pending = false;
     prof_break(c);
   }
-  const bool split = c->split_lk && c->commit_pending && c->prev_left;
-  if (c->commit_pending && !split) {
+  if (c->commit_pending) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
     prof_break(c);   // (the wait is not part of the tracking stage)
   }
   c->commit_pending = false;
   prof_begin(c, ST_TRACK, st);
-  launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st, split ? 1 : 0);
-  if (split) {
-    HIPCHK(c, hipEventRecord(c->ev_prep, st));   // (pyramid of frame k and npts_old)
-    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_prep, 0));
-    launch_track_prepare(P, c->T, KM1, b.ss, b.lk, sd, 2);
-    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride, img_stride,
-              b.pyr[pc], b.lk, std::min(c->pts_bound, detect_new_bound(P)), sd, false, 2, false);
-    HIPCHK(c, hipEventRecord(c->ev_lknew, sd));
-    slot_release.side_used = true;
-  }
+  launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
   if (c->prev_left)
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, !split, split ? 1 : 0, false);
+              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, false);
   prof_end(c, ST_TRACK, st);
-  if (split) {   // (recorded behind the previous step's tail on the side stream: joins both)
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_lknew, 0));
-    c->tail_pending = false;
-    prof_break(c);
-  } else if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
+  if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
     c->tail_pending = false;
     prof_break(c);
@@ -1024,7 +984,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
       HIPCHK(c, hipMemcpyAsync(c->prof_flags_host + (size_t)slot * P.B, b.ss.flags, sizeof(int) * P.B,
                                hipMemcpyDeviceToHost, st));
     }
-    c->prof_flag_slot.push_back(slot);
+    c->prof_flag_slot.back() = slot;
   }
   if (c->ev_tracked) {
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
@@ -1084,13 +1044,11 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // rectify / stereo chain to the side stream right after track_finalize is 10 % slower -- its
   // workgroups delay the one-block-per-stream kernels of the detection chain; stream priorities
   // do not change that.)
-  const bool state_on_main = c->side && c->own_stream && c->split_lk;
-  if (state_on_main) launch_detect_state(P, K, b.ss, b.ds, st);
   // fa: the stream of the corner refinement, fb: the stream of the rectify / match / reject chain.  Many streams: the
   // chain is the throughput-bound side and stays on the main stream, the refinement forks off.  A few streams
   // (fork_swap): every kernel is a latency, the refinement is on the loop that bounds the step and keeps the main
   // stream -- no cross-stream hand-over on that loop -- and the chain forks off.
-  const bool swap = c->fork_swap && c->side && !early_rect;
+  const bool swap = c->fork_swap && c->side;
   hipStream_t fa = swap ? st : sd, fb = swap ? sd : st;
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
@@ -1098,44 +1056,35 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     slot_release.side_used = true;
   }
   prof_begin(c, ST_SUBPIX, fa);
-  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, state_on_main ? 2 : 1, fa);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, fa);
   prof_end(c, ST_SUBPIX, fa);
   if (c->side && (c->own_stream || swap)) {
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
   }
-  if (!all_early) {
-    prof_begin(c, ST_RECTIFY, fb);
+  prof_begin(c, ST_RECTIFY, fb);
+  {
     const unsigned char* srcs[2] = {left, right};
-    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, fb,
-                   early_rect ? b.ss.in_force_kf : nullptr);
-    prof_end(c, ST_RECTIFY, fb);
+    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, fb);
   }
-  if (early_rect) HIPCHK(c, hipStreamWaitEvent(st, c->ev_mono, 0));   // the pairs rectified at the start of the step
+  prof_end(c, ST_RECTIFY, fb);
   prof_begin(c, ST_STEREO, fb);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, fb);
   prof_end(c, ST_STEREO, fb);
   // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387).  Its results (right-keypoint
   // statuses of the outliers, the stereo pose and status; the PnP pose) are read by the tail only -- the landmark removal
   // that the next step's tracking reads is the mono rejection's -- so it runs at the head of the tail on the side stream,
-  // off the main stream's critical path (-1.2 % step time on four A/B pairs, +7 % on configs[4]; KVFE_RANSAC_TAIL=0
-  // puts it back on the main stream; profiles/r3_analysis.md)
-  static const bool ransac_tail_env = !(std::getenv("KVFE_RANSAC_TAIL") && std::atoi(std::getenv("KVFE_RANSAC_TAIL")) == 0);
-  const bool ransac_tail = ransac_tail_env && c->side && !swap;
+  // off the main stream's critical path (round 3: -1.2 % step time on four A/B pairs, +7 % on configs[4]).
+  // NOTE for whoever edits launch_stereo_ransac / launch_pnp_frontend: they run concurrently with the NEXT step's
+  // track_prepare and tracking launch and must therefore not write frame-table fields those read (K.kp, K.lmk, K.count).
+  const bool ransac_tail = c->side && !swap;
   auto stereo_rejection = [&](hipStream_t rs) -> kvfe_status {
   prof_begin(c, ST_RANSAC_STEREO, rs);
   if (P.use_ransac) {
-    // (the device's own test, rs_rot_is_identity: a stream without a usable gyro rotation takes the 3-point problem)
+    // (the device's own predicate, rot_is_identity of kvfe_dev.hpp: a stream without a usable gyro rotation takes the
+    // 3-point problem; the launch of that kernel is skipped when no stream of the batch does)
     bool need_arun = !P.ransac_1pt_stereo;
-    for (int s = 0; s < P.B && !need_arun; s++) {
-      bool ident = true;
-      for (int i = 0; i < 9 && ident; i++) {
-        const double a = inputs[s].keyframe_R_cur_frame[i], e = (i % 4 == 0) ? 1.0 : 0.0;
-        if (std::isnan(a) || std::isinf(a)) ident = false;
-        else if (a != e && !(std::fabs(a - e) <= 1e-9)) ident = false;
-      }
-      need_arun = ident;
-    }
+    for (int s = 0; s < P.B && !need_arun; s++) need_arun = rot_is_identity(inputs[s].keyframe_R_cur_frame);
     launch_stereo_ransac(P, c->T, K, LKF, b.st, b.lst, b.ss, b.rs, c->pts_bound, rs, need_arun);
   }
   // outlierRejectionPnP(*stereoFrame_k_) (:389-399): after the stereo rejection, before detection
@@ -1196,8 +1145,7 @@ kvfe_status step_groups(kvfe_ctx* c, const unsigned char* left, const unsigned c
   for (int g = 0; g < G; g++) {
     kvfe_ctx* ch = c->children[g];
     kvfe_ctx* pred = c->children[(g + G - 1) % G];
-    static const bool no_token = std::getenv("KVFE_NO_TOKEN") != nullptr;
-    if (G > 1 && !no_token && pred->ev_tracked_valid) HIPCHK(c, hipStreamWaitEvent(ch->stream, pred->ev_tracked, 0));
+    if (G > 1 && pred->ev_tracked_valid) HIPCHK(c, hipStreamWaitEvent(ch->stream, pred->ev_tracked, 0));
     const unsigned char* l = left + (size_t)ch->s0 * img_stride;
     const unsigned char* r = right + (size_t)ch->s0 * img_stride;
     // through the child's own entry point, so that whatever the entry point does before do_step (uploads,
@@ -1392,30 +1340,17 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     s = KVFE_ERR_HIP;
   const bool no_side = cfg->single_hip_stream != 0;
   if (s == KVFE_OK && alloc_frontend && !no_side) {
-    // KVFE_SIDE_PRIO=1: the side stream at the device's highest stream priority.  Measured: +0.5 ... 0.8 % on the
-    // 64-stream step (the corner refinement on it is the longer side of the fork), but the rectification that runs
-    // beside it on the main stream takes 0.08 instead of 0.06 ms -- the dense kernel pays for the latency-bound one;
-    // not the default
-    static const bool side_prio = std::getenv("KVFE_SIDE_PRIO") && std::atoi(std::getenv("KVFE_SIDE_PRIO")) != 0;
-    int prio_least = 0, prio_greatest = 0;
-    if (side_prio) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if ((side_prio ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest)
-                   : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_mono, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_commit, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_lknew, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_commit, hipEventDisableTiming) != hipSuccess)
       s = KVFE_ERR_HIP;
-    const char* sp = std::getenv("KVFE_LK_SPLIT");
-    c->split_lk = (sp ? std::atoi(sp) != 0 : false) && c->own_stream && lk_supports_parts(c->P);
     // a few streams are latency bound: the loop refinement -> tracking -> keyframe decision -> detection -> refinement
     // is what a step costs, so it stays on ONE stream and the rectify / match / reject chain takes the side stream
-    const char* fs = std::getenv("KVFE_FORK_SWAP");
-    c->fork_swap = (fs ? std::atoi(fs) != 0 : c->P.B <= 4) && c->own_stream && !c->split_lk && !c->P.mono;
+    c->fork_swap = c->P.B <= 4 && c->own_stream && !c->P.mono;
   }
   if (s != KVFE_OK) {
     std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
@@ -1522,8 +1457,6 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->ev_main) hipEventDestroy(c->ev_main);
   if (c->ev_tail) hipEventDestroy(c->ev_tail);
   if (c->ev_commit) hipEventDestroy(c->ev_commit);
-  if (c->ev_prep) hipEventDestroy(c->ev_prep);
-  if (c->ev_lknew) hipEventDestroy(c->ev_lknew);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->dense_allocs) hipFree(p);
   for (int i = 0; i < 2; i++)
@@ -2839,11 +2772,7 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
         for (int x = 0; x < P.W; x++) disparity[i][(size_t)y * dstride + x] = (int16_t)P.invalid_scaled;
     return KVFE_OK;
   }
-  static const int env_chunk = [] {
-    const char* e = getenv("KVFE_DENSE_BATCH");
-    return e ? std::max(1, atoi(e)) : 8;
-  }();
-  const int chunk = std::min<int>(env_chunk, n_pairs);
+  const int chunk = std::min<int>(8, n_pairs);   // pairs per launch group (three cost volumes of 42 MB per pair)
   TRY(dense_ensure(c, P, chunk));
   DenseBuffers& b = c->dense;
   const size_t px = (size_t)P.W * P.H;
@@ -2946,7 +2875,22 @@ kvfe_status kvfe_profile_enable(kvfe_ctx* c, int32_t on) {
   return KVFE_OK;
 }
 
-kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
+static kvfe_status profile_read_full(kvfe_ctx* c, kvfe_stage_times* out);
+
+kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* user) {
+  if (!c || !user) return KVFE_ERR_INVALID_ARG;
+  // the caller's struct may be shorter than this build's (kvfe_stage_times::struct_size): fill a full one, copy what fits
+  size_t n = user->struct_size > 0 ? (size_t)user->struct_size : offsetof(kvfe_stage_times, ms_active);
+  n = std::min(n, sizeof(kvfe_stage_times));
+  if (n < offsetof(kvfe_stage_times, name)) return KVFE_ERR_INVALID_ARG;
+  kvfe_stage_times full;
+  TRY(profile_read_full(c, &full));
+  full.struct_size = (int32_t)n;
+  std::memcpy(user, &full, n);
+  return KVFE_OK;
+}
+
+static kvfe_status profile_read_full(kvfe_ctx* c, kvfe_stage_times* out) {
   DeviceGuard _dev(c);
   join_tail(c);
   if (!c || !out) return KVFE_ERR_INVALID_ARG;
@@ -2956,7 +2900,7 @@ kvfe_status kvfe_profile_read(kvfe_ctx* c, kvfe_stage_times* out) {
     out->n_groups = (int)c->children.size();
     for (kvfe_ctx* ch : c->children) {
       kvfe_stage_times t;
-      TRY(kvfe_profile_read(ch, &t));
+      TRY(profile_read_full(ch, &t));
       out->n_samples += t.n_samples;
       for (int s = 0; s < ST_COUNT; s++) {
         out->name[s] = t.name[s];

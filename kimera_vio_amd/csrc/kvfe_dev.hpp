@@ -129,7 +129,6 @@ struct FrameTab {
   long long* lmk;       // [B][kcap]
   int* age;             // [B][kcap]
   double* versor;       // [B][kcap][3]
-  unsigned char* cost;  // [B][kcap] LK iterations the keypoint took when it was last tracked (dispatch order only)
   int* count;           // [B]
   long long* timestamp; // [B]
 };
@@ -224,15 +223,27 @@ struct LkScratch {
   unsigned char* status;  // [B][kcap]
   float* err;             // [B][kcap]
   int* npts;              // [B]
-  int* npts_old;          // [B] split launch: points gathered from the keypoints frame k-1 had tracked itself
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
   // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
   // order[s][b] -- the points that took the most iterations in the previous frame first, so that the launch does not
   // end on a few slow points that started late; iters = iterations of this launch (saturated), carried to frame k
-  int* order;             // [B][kcap]
-  unsigned char* iters;   // [B][kcap]
 };
+
+// gtsam::Rot3::equals(Rot3(), 1e-9) (fpEqual without the relative test): "this stream has no usable gyro rotation".
+// Shared by the outlier-rejection kernels and by the host, which skips the 3-point kernel's launch when no stream of the
+// batch needs it (two copies of the test could drift apart).  NaN / Inf compare false.
+__host__ __device__ inline bool rot_is_identity(const double* R) {
+  for (int i = 0; i < 9; i++) {
+    const double a = R[i], b = (i % 4 == 0) ? 1.0 : 0.0;
+    if (a != a) return false;                                   // NaN
+    if (a - a != 0.0) return false;                             // +-Inf
+    if (a == b) continue;
+    const double d = a - b;
+    if (!((d < 0 ? -d : d) <= 1e-9)) return false;
+  }
+  return true;
+}
 
 __host__ __device__ inline int reflect101(int p, int len) {
   if ((unsigned)p < (unsigned)len) return p;
@@ -266,12 +277,10 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool use_order = false, int part = 0,
-               bool want_err = true);
-bool lk_supports_parts(const KParams& P);
+               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part = 0);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st);
 // survivors -> frame k, bearing vectors, keyframe decision (Tracker.cpp:167-189,
 // StereoVisionImuFrontend.cpp:313-347, VisionImuFrontend.cpp:175-232)
 void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
@@ -291,8 +300,6 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
                           hipStream_t st);
 // the per-stream state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the frame's keypoint
 // count): known once the new corners are SELECTED.  launch_subpix_append(append = 2) leaves it to this launch.
-void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D,
-                         hipStream_t st);
 int detect_new_bound(const KParams& P);   // upper bound of the new corners per stream and frame
 // cv::cornerSubPix on arbitrary points (component API)
 void launch_subpix_points(const KParams& P, const float* mask_tab, const unsigned char* img,

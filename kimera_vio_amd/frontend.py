@@ -552,6 +552,7 @@ class Context:
 
     def profile_read(self) -> dict:
         st = abi.StageTimes()
+        st.struct_size = C.sizeof(abi.StageTimes)
         self._chk(self.lib.kvfe_profile_read(self._h, C.byref(st)), "profile_read")
         return dict(n_samples=st.n_samples, n_groups=st.n_groups,
                     stages={st.name[i].decode(): dict(ms_total=st.ms_total[i], alg_bytes=st.alg_bytes[i],

@@ -13,6 +13,7 @@ with the CPU oracle (`StereoVisionImuFrontend::processStereoFrame` restatement,
 
 Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 """
+import os
 import numpy as np
 import pytest
 
@@ -167,3 +168,19 @@ def test_c3e_real_frames_64_streams():
     assert (wl.batch, wl.unique, wl.source) == (64, 4, "euroc")
     kinds = _run_workload(wl, 8, [0, 1, 2, 3, 63])
     assert all(k[1] == 1 for k in kinds) and all(k[3] > 20 for k in kinds[1:]), kinds
+
+
+def test_grouped_corner_subpix_kernel_forced():
+    """round 4: two cornerSubPix kernels share the launch slot -- one corner per block for launches with few new corners,
+    SPG_G corners per block (one lane per float64 chain) for launches with many (>= 3000 over all streams: the real-frame
+    configuration above takes it by itself).  KVFE_SUBPIX_GROUP=1 (read once per process, hence the sub-process) forces the
+    grouped kernel onto the small configurations too: single stream, 64 synthetic streams, the pipelined host steps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_bench_configs.py") + "::test_c2_single_euroc_stream_300_features_3_level_lk",
+                        os.path.join(root, "tests", "test_gpu_bench_configs.py") + "::test_c3_headline_64_streams_600_features",
+                        os.path.join(root, "tests", "test_gpu_pipelined_r3.py") + "::test_pipelined_host_steps_no_sync"],
+                       env=dict(os.environ, KVFE_SUBPIX_GROUP="1"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -22,7 +22,8 @@ from test_gpu_parity import _euroc_ransac_params, _kf_rotations, euroc_cams, oca
 pytestmark = pytest.mark.gpu
 
 
-def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=None, features=200, **ctx_kw):
+def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=None, features=200,
+            identity_streams=(), **ctx_kw):
     seq = dict(seq)
     seq["camR"] = _kf_rotations(seq["body_R"], ocam)
     L, R = euroc_cams()
@@ -37,7 +38,8 @@ def _replay(seq, ocam, equalize, n=8, B=2, hip_stream=None, sync_every=0, force=
             pp = lambda j: (j % 16) if (j % 16) < 9 else 16 - (j % 16)   # ping-pong over the 9 frames
             idx = ([i, 8 - i] + [pp(i + 3 * s) for s in range(2, B)])[:B]
             # keyframe_R_cur_frame: rotation from the stream's last keyframe to this frame
-            Rs = [np.eye(3) if lkf[s] is None else seq["camR"][lkf[s]].T @ seq["camR"][idx[s]] for s in range(B)]
+            Rs = [np.eye(3) if (lkf[s] is None or s in identity_streams) else seq["camR"][lkf[s]].T @ seq["camR"][idx[s]]
+                  for s in range(B)]
             ts = [int(seq["ts"][i])] * B
             fk = [1] * B if force is None else [int(force[(i + s) % len(force)]) for s in range(B)]
             lefts = np.stack([seq["lefts"][j] for j in idx])
@@ -93,32 +95,11 @@ def test_pipelined_host_steps_many_streams_output_stream(seq, ocam):
     _replay(seq, ocam, 0, B=6)
 
 
-@pytest.fixture
-def split_tracking_env():
-    old = os.environ.get("KVFE_LK_SPLIT")
-    os.environ["KVFE_LK_SPLIT"] = "1"      # read when a context is created
-    yield
-    if old is None:
-        os.environ.pop("KVFE_LK_SPLIT", None)
-    else:
-        os.environ["KVFE_LK_SPLIT"] = old
-
-
-@pytest.mark.parametrize("force,features,equalize", [
-    (None, 200, 0),                # every frame a keyframe: every step has new corners to track on the side stream
-    (None, 60, 1),                 # few features: most of a frame's keypoints are new corners
-    ([1, 0, 0], 200, 0),           # keyframes and plain frames alternate, the two streams out of phase
-    ([0, 0, 0, 0, 1], 300, 0),     # mostly the front-end's own keyframe decisions
-])
-def test_pipelined_split_tracking_launch(seq, ocam, split_tracking_env, force, features, equalize):
-    """KVFE_LK_SPLIT=1: frame k-1's new corners are gathered and tracked on the side stream behind its corner
-    refinement, the keypoints it had tracked itself on the main stream right behind the pyramid -- same tables, same
-    results, steps enqueued back to back"""
-    exp = _replay(seq, ocam, equalize, force=force, features=features)
-    assert all(e["n_tracked"] > 20 for e in exp)
-
-
-def test_split_tracking_with_synchronised_steps(seq, ocam, split_tracking_env):
-    """the same with the tail joined between steps (get_output / synchronize reset the pending hand-overs)"""
-    _replay(seq, ocam, 0, sync_every=2)
-    _replay(seq, ocam, 0, sync_every=1, force=[1, 0])
+def test_mixed_identity_and_gyro_rotations_in_one_batch(seq, ocam):
+    """the host skips the launch of the 3-point (Arun) stereo rejection when no stream of the batch needs
+    it, with the SAME predicate the kernels use (rot_is_identity, kvfe_dev.hpp).  Streams 0 and 2 never get a gyro
+    rotation (identity: mono 5-point / stereo 3-point problems apply), streams 1 and 3 do (2-point / 1-point): both
+    kinds in one launch, every stream equal to its oracle."""
+    _replay(seq, ocam, 0, B=4, identity_streams=(0, 2))
+    _replay(seq, ocam, 0, B=2, identity_streams=(0, 1))
+    _replay(seq, ocam, 0, B=2)

@@ -91,25 +91,19 @@ def test_pyramid_strided_rows():
             c.close()
 
 
-@pytest.mark.parametrize("t2", ["1", "3", "8", "32"])
-def test_pyramid_strip_heights(t2, monkeypatch):
-    """every strip height gives the same levels (KVFE_PYR_T2 is read at the first launch of a process, so the variants
-    run in sub-processes)"""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import test_gpu_pyramid_r3 as T\n"
-        "for (w, h, ml, n) in [(752, 480, 2, 2), (1280, 722, 3, 1)]:\n"
-        "    c = T._ctx(w, h, ml, win=8)\n"
-        "    imgs = T._images(n, h, w, seed=11)\n"
-        "    levels, copy = c.build_optical_flow_pyramid(imgs, with_level0_copy=True)\n"
-        "    assert np.array_equal(copy, imgs)\n"
-        "    for s in range(n):\n"
-        "        for g, e in zip(levels[s], T._oracle_levels(imgs[s], len(levels[s]))):\n"
-        "            assert np.array_equal(g, e)\n"
-        "print('ok')\n" % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))))
-    env = dict(os.environ, KVFE_PYR_T2=t2)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+@pytest.mark.parametrize("n", [2, 60, 110])
+def test_pyramid_strip_heights(n):
+    """the strip height of pyr2_kernel follows the number of images of the call (2 / 4 / 8 second-level rows per wave at
+    2 / 60 / 110 images of 752 x 480): every instantiation gives the same levels (the KVFE_PYR_T2 switch that used to
+    select them was removed in round 4)"""
+    w, h = 752, 480
+    c = _ctx(w, h, 2, win=8)
+    try:
+        imgs = _images(n, h, w, seed=11)
+        levels, copy = c.build_optical_flow_pyramid(imgs, with_level0_copy=True)
+        assert np.array_equal(copy, imgs)
+        for s in (0, 1, n // 2, n - 1):
+            for g, e in zip(levels[s], _oracle_levels(imgs[s], len(levels[s]))):
+                assert np.array_equal(g, e)
+    finally:
+        c.close()

@@ -4,7 +4,7 @@ timeout 120 python -c "
 import sys; sys.path.insert(0,'tests')
 import test_gpu_pyramid_r3 as T
 c=T._ctx(752,480,2,win=8); print('sanity ok')" || { echo "SANITY FAILED"; exit 1; }
-timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/c_tests.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/c_tests.log | cut -c1-220
+timeout 900 python -m pytest ${TESTS:-tests} -m gpu -q -x > gpurun_out/c_tests.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/c_tests.log | cut -c1-220
 run() {
 env $1 timeout 300 python bench.py --legs ${2:-none} --steps 30 --warmup 8 --repeats 2 --stage-event-stride 4 2> gpurun_out/c_bench.err | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); st=d.get('stage_ms_per_step_summed_over_groups',{})
@@ -16,5 +16,4 @@ if 'roofline' in d and d['roofline']: print('    roofline', d['roofline']['kerne
 }
 run KVFE_SUBPIX_GROUP=0 kf_realistic
 run KVFE_SUBPIX_GROUP=1 kf_realistic
-run KVFE_SUBPIX_GROUP=0 c5
-run KVFE_SUBPIX_GROUP=1 c5
+[ -n "$SKIP_C5" ] || { run KVFE_SUBPIX_GROUP=0 c5; run KVFE_SUBPIX_GROUP=1 c5; }
