@@ -910,7 +910,7 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
       (void)hipMemcpy2DAsync(level0_copy + (size_t)s * P.W * P.H, (size_t)P.W, img + (size_t)s * img_stride, row_stride,
                              (size_t)P.W, (size_t)P.H, hipMemcpyDeviceToDevice, st);
   // the streaming two-level kernel where the geometry allows, the tile kernel per level otherwise
-  const int impl = 1, t2_env = 0;
+  const int impl = 1;
   for (int l = 1; l < P.nlevels; l++) {
     const unsigned char* src = l == 1 ? img : pyr + P.loff[l - 1];
     const size_t srow = l == 1 ? row_stride : (size_t)P.lw[l - 1];
@@ -923,12 +923,10 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
       const int w0 = P.lw[l - 1], h0 = P.lh[l - 1], h1 = (h0 + 1) / 2, h2 = (h1 + 1) / 2;
       const int nl = w0 / 16, nwx = nl <= 62 ? 1 : 1 + (nl - 62 + 59) / 60;
       // strip height: the halo costs (4 T2 + 9) / (4 T2) source rows, so strips are as tall as the chip stays busy with
-      // (a strip is one wave; its source rows live in registers: T2 = 8 needs ~220 VGPRs)
-      int T2 = t2_env;
-      if (T2 != 2 && T2 != 4 && T2 != 8) {
-        T2 = 8;
-        while (T2 > 2 && (long long)P.B * nwx * ((h2 + T2 - 1) / T2) < 1536) T2 >>= 1;
-      }
+      // (a strip is one wave; its source rows live in registers).  T2 = 8 (~220 VGPRs, chosen only for more than ~100
+      // streams of 752 x 480) was removed in round 4: its first test at such a batch size failed the level-0 copy.
+      int T2 = 4;
+      while (T2 > 2 && (long long)P.B * nwx * ((h2 + T2 - 1) / T2) < 1536) T2 >>= 1;
       const int NS = two ? (h2 + T2 - 1) / T2 : (h1 + 2 * T2 - 1) / (2 * T2);
       const int xcd = P.B >= 8 ? 1 : 0;
       const int nblk = xcd ? 8 * ((P.B + 7) / 8) * NS * nwx : P.B * NS * nwx;
@@ -943,8 +941,7 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
     else if (two) KVFE_PYR2(T2_, false, true);       \
     else KVFE_PYR2(T2_, false, false);               \
   } while (0)
-      if (T2 == 8) KVFE_PYR2_T(8);
-      else if (T2 == 4) KVFE_PYR2_T(4);
+      if (T2 == 4) KVFE_PYR2_T(4);
       else KVFE_PYR2_T(2);
 #undef KVFE_PYR2_T
 #undef KVFE_PYR2

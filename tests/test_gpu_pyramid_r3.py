@@ -93,9 +93,9 @@ def test_pyramid_strided_rows():
 
 @pytest.mark.parametrize("n", [2, 60, 110])
 def test_pyramid_strip_heights(n):
-    """the strip height of pyr2_kernel follows the number of images of the call (2 / 4 / 8 second-level rows per wave at
-    2 / 60 / 110 images of 752 x 480): every instantiation gives the same levels (the KVFE_PYR_T2 switch that used to
-    select them was removed in round 4)"""
+    """the strip height of pyr2_kernel follows the number of images of the call (2 second-level rows per wave for a few
+    images of 752 x 480, 4 from ~52 on): both instantiations, also at a batch far beyond the benchmark's 64 (the T2 = 8
+    instantiation that a 110-image call used to select failed this very test in round 4 and was removed)"""
     w, h = 752, 480
     c = _ctx(w, h, 2, win=8)
     try:
