@@ -186,8 +186,15 @@ typedef struct kvfe_stereo_params {
   double min_point_dist, max_point_dist;
   int32_t equalize_image;                    /* equalizeImage: cv::equalizeHist on both
                                                 input images (UtilsOpenCV.cpp:398-401) */
-  int32_t reserved0;
+  int32_t ssd_tie_policy;                    /* KVFE_SSD_TIE_*: which minimum searchRightKeypointEpipolar takes when
+                                                candidates are (nearly) tied -- an implementation-defined corner of
+                                                cv::matchTemplate + minMaxLoc (StereoMatcher.cpp:388-392), exposed like
+                                                sortidx_policy instead of guessed.  On the reference's EuRoC frames it
+                                                decides 0 of 16 209 matches (profiles/r4_ssd_tie_exposure.md)          */
 } kvfe_stereo_params;
+#define KVFE_SSD_TIE_EXACT 0   /* first minimum, row-major, of the EXACT integer SSDs (default)                        */
+#define KVFE_SSD_TIE_F32 1     /* first minimum of the SSDs rounded to float32 (round to nearest even): the CV_32F
+                                  result matrix of cv::matchTemplate without its DFT rounding noise                    */
 
 /* the PnP members of VIO::TrackerParams (VisionImuTrackerParams.h:72-76), see kvfe_pnp */
 typedef struct kvfe_pnp_params {

@@ -3,6 +3,7 @@ import ctypes as C
 
 KVFE_MAX_BINS = 256
 KVFE_MAX_DIST_COEFFS = 8
+SSD_TIE_EXACT, SSD_TIE_F32 = 0, 1
 KVFE_N_STAGES = 16
 
 # status
@@ -84,7 +85,7 @@ class StereoParams(C.Structure):
         ("templ_cols", C.c_int32), ("templ_rows", C.c_int32),
         ("stripe_extra_rows", C.c_int32), ("subpixel_refinement", C.c_int32),
         ("min_point_dist", C.c_double), ("max_point_dist", C.c_double),
-        ("equalize_image", C.c_int32), ("reserved0", C.c_int32),
+        ("equalize_image", C.c_int32), ("ssd_tie_policy", C.c_int32),
     ]
 
 

@@ -143,6 +143,13 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
 // Returns the wave's candidate keys (ssd << 32 | oy * rw + ox), one per lane.
 // KSC: the number of K steps at compile time (2 for the shipped template; 0 = any, plain loop); SWAP: operands
 // exchanged (KVFE_SSD_IMPL=3, a bring-up switch: it must FAIL the parity tests).
+// kvfe_stereo_params.ssd_tie_policy: the value the minimum is taken over -- the exact integer SSD, or the SSD rounded
+// to float32 (v_cvt_f32_u32 rounds to nearest even; positive floats order like their bit patterns), i.e. what a CV_32F
+// result matrix holds.  The offset in the low word keeps "first minimum in row-major order" in both cases.
+__device__ __forceinline__ unsigned ssd_key(const KParams& P, unsigned ssd) {
+  return P.ssd_f32 ? __float_as_uint((float)ssd) : ssd;
+}
+
 template <int KSC, bool SWAP>
 __device__ __forceinline__ unsigned long long ssd_search_mfma(const KParams& P, const StereoGeom& G,
                                                               const unsigned char* __restrict__ L,
@@ -280,7 +287,7 @@ __device__ __forceinline__ unsigned long long ssd_search_mfma(const KParams& P, 
         if (oh < NJ && ox >= 0 && ox < rw) {
           const unsigned ss = P2[u + tc] - P2[u];
           const unsigned ssd = t2u + ss - 2u * (unsigned)cs[r];
-          const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)(oy * rw + ox);
+          const unsigned long long key = ((unsigned long long)ssd_key(P, ssd) << 32) | (unsigned)(oy * rw + ox);
           best = key < best ? key : best;
         }
       }
@@ -532,7 +539,7 @@ __device__ void match_one(const KParams& P, const Tables& T, const unsigned char
         if (active && ox >= 0 && ox < rw) {
           const unsigned ss = P2[u + tc] - P2[u];
           const unsigned ssd = t2 + ss - 2u * ts[a];
-          const unsigned long long key = ((unsigned long long)ssd << 32) | (unsigned)(oy * rw + ox);
+          const unsigned long long key = ((unsigned long long)ssd_key(P, ssd) << 32) | (unsigned)(oy * rw + ox);
           best = key < best ? key : best;
         }
       }

@@ -468,6 +468,8 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
   if (!mono && (cfg->left.width != cfg->right.width || cfg->left.height != cfg->right.height))
     return fail("left/right image sizes differ", KVFE_ERR_INVALID_ARG);
   if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
+  if (p.stereo.ssd_tie_policy != KVFE_SSD_TIE_EXACT && p.stereo.ssd_tie_policy != KVFE_SSD_TIE_F32)
+    return fail("bad ssd_tie_policy", KVFE_ERR_INVALID_ARG);
   for (int v : {cfg->device_frames_persist, cfg->single_hip_stream, cfg->copy_inputs, cfg->ssd_impl})
     if (v != 0 && v != 1) return fail("execution options of kvfe_config are 0 or 1", KVFE_ERR_INVALID_ARG);
   if (p.use_ransac) {
@@ -627,6 +629,7 @@ kvfe_status fill_params(kvfe_ctx* c) {
   }
   P.nlevels = nl;
   P.ssd_dot4 = cfg.ssd_impl == 1 ? 1 : 0;
+  P.ssd_f32 = p.stereo.ssd_tie_policy == KVFE_SSD_TIE_F32 ? 1 : 0;
   P.klt_maxlevel = nl - 1;
   P.pyr_stride = std::max(off, 64);
   P.acap = ACAP;

@@ -56,6 +56,7 @@ struct KParams {
   double depth_fx_b;                 // intrinsics[0] * virtual_baseline (RgbdFrame.cpp:65)
   // pyramid geometry: level 0 is the raw image, levels 1..nlevels-1 live in the pyramid buffer
   int ssd_dot4;                      // kvfe_config.ssd_impl = 1: v_dot4 SSD search for every geometry
+  int ssd_f32;                       // kvfe_stereo_params.ssd_tie_policy = KVFE_SSD_TIE_F32
   int nlevels;
   int lw[MAX_LEVELS], lh[MAX_LEVELS], loff[MAX_LEVELS];
   int pyr_stride;  // bytes per stream in a pyramid buffer

@@ -614,15 +614,31 @@ static void searchRightKeypointEpipolar(const uint8_t* left_rect, Point2f left_k
   const int rw = stripe_cols - p.templ_cols + 1, rh = stripe_rows - p.templ_rows + 1;
   // normalize(0,1,MINMAX) + minMaxLoc: first minimum in row-major order; the
   // normalised minimum is 0 (also for a flat result).
-  int64_t best = std::numeric_limits<int64_t>::max();
+  // kvfe_stereo_params.ssd_tie_policy: KVFE_SSD_TIE_EXACT compares the exact integers; KVFE_SSD_TIE_F32 compares
+  // them rounded to float32 (the CV_32F result matrix of cv::matchTemplate; int64 -> float converts with round to
+  // nearest even), first minimum in row-major order either way.
   int bx = 0, by = 0;
-  for (int y = 0; y < rh; y++)
-    for (int x = 0; x < rw; x++)
-      if (result[(size_t)y * rw + x] < best) {
-        best = result[(size_t)y * rw + x];
-        bx = x;
-        by = y;
+  if (p.ssd_tie_policy == KVFE_SSD_TIE_F32) {
+    float bestf = std::numeric_limits<float>::infinity();
+    for (int y = 0; y < rh; y++)
+      for (int x = 0; x < rw; x++) {
+        const float v = (float)result[(size_t)y * rw + x];
+        if (v < bestf) {
+          bestf = v;
+          bx = x;
+          by = y;
+        }
       }
+  } else {
+    int64_t best = std::numeric_limits<int64_t>::max();
+    for (int y = 0; y < rh; y++)
+      for (int x = 0; x < rw; x++)
+        if (result[(size_t)y * rw + x] < best) {
+          best = result[(size_t)y * rw + x];
+          bx = x;
+          by = y;
+        }
+  }
   double min_val = 0.0;
   int mx = bx + stripe_corner_x + (p.templ_cols - 1) / 2 + offset_temp;
   int my = by + stripe_corner_y + (p.templ_rows - 1) / 2;

@@ -124,3 +124,34 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert [x["sequences"] for x in d["ranks"]] == [[0, 2, 4, 6], [1, 3, 5, 7]]
     assert d["pairs_sum"] == 8 * 5 and d["elapsed_max"] == 2.0          # SUM of units, MAX of rank times
     assert d["ranks"][0]["first_pixel_sum"] != d["ranks"][1]["first_pixel_sum"]   # different sequences
+
+
+def test_bench_eight_ranks_dry_run_headline_config():
+    """the driver's 8-GPU launch line on BASELINE configs[2] (c3, weak scaling: every rank its
+    own streams) and on configs[3] (c4: one EuRoC sequence per GPU) -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py --gpus 8` with --dry-run: 8 gloo ranks build their shards,
+    meet at the barrier and reduce the timing; no GPU, nothing computed."""
+    import json
+    import socket
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                           "MASTER_PORT")}
+    for config, steps in (("c3", 3), ("c4", 2)):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                            "--gpus", "8", "--config", config, "--steps", str(steps), "--warmup", "1", "--dry-run"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 8 and len(d["ranks"]) == 8 and [x["rank"] for x in d["ranks"]] == list(range(8))
+        assert d["elapsed_max"] == 8.0                       # MAX over the ranks' times (rank r reports 1 + r)
+        if config == "c3":
+            assert d["scaling"] == "weak" and d["pairs_sum"] == sum(x["batch"] for x in d["ranks"]) * steps
+            assert len({x["first_pixel_sum"] for x in d["ranks"]}) == 8   # every rank renders its own streams
+        else:
+            assert d["scaling"] == "strong" and [x["sequences"] for x in d["ranks"]] == [[q] for q in range(8)]
+            assert d["pairs_sum"] == 8 * steps
