@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--copy-level0", action="store_true",
                     help="kvfe_config.device_frames_persist = 0: the context copies every left frame (no caller pointer "
                          "outlives a step) instead of tracking from the caller's resident ring")
+    ap.add_argument("--single-hip-stream", action="store_true",
+                    help="kvfe_config.single_hip_stream = 1: every kernel of a step on one HIP stream (no side / output "
+                         "stream) -- the stage times are then those of the kernels ALONE")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (tests/test_multi_rank.py, no GPU): become --gpus ranks, build each "
                          "rank's workload shard, barrier + timing reduction over gloo, print the shard map; "
@@ -354,6 +357,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     DEFAULT_CTX_KW["device_frames_persist"] = 0 if args.copy_level0 else 1
+    if args.single_hip_stream:
+        DEFAULT_CTX_KW["single_hip_stream"] = 1
     ctx_kw = None
     pmc = load_pmc()
     global valu_ctx

@@ -483,15 +483,21 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
   if (staged) {
     // ---- phase B: LDS-DMA of the source boxes, phase C: blend; software pipeline over sub-chunks of SPB streams:
     //      the boxes of sub-chunk j+1 are in flight while sub-chunk j is blended (two LDS buffers) ----------------
+    // LDS byte address of every pixel's 2 x 2 block in buffer 0, stream 0 -- ABSOLUTE (the base of the dynamic LDS area
+    // added once here: added per read it cost one v_add_u32 per pixel and stream, hipcc does not fold the relocated
+    // base into the address); the buffer / stream offsets of a read are compile-time constants and ride in the
+    // instruction's 16-bit offset field
+    typedef __attribute__((address_space(3))) const unsigned char lds_cu8_t;
+    const unsigned sm_base = (unsigned)(size_t)(lds_u8_t*)sm;
     unsigned ad[4 * NR];
 #pragma unroll
-    for (int q = 0; q < 4 * NR; q++) ad[q] = (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
+    for (int q = 0; q < 4 * NR; q++) ad[q] = sm_base + (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
     auto blend = [&](int j) {
-      const unsigned char* pb = sm + (j & (NBUF - 1)) * (SPB * RT_PATCH);
+      const int pb_off = (j & (NBUF - 1)) * (SPB * RT_PATCH);
 #pragma unroll
       for (int k = 0; k < SPB; k++) {
         if (!((act >> (j * SPB + k)) & 1u)) continue;
-        const unsigned char* pk = pb + k * RT_PATCH;
+        const int pk_off = pb_off + k * RT_PATCH;
         unsigned char* D = dst + (size_t)(s_begin + j * SPB + k) * N;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
           unsigned px[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const unsigned char* a = pk + ad[4 * r + q];
+            lds_cu8_t* a = (lds_cu8_t*)(size_t)ad[4 * r + q] + pk_off;
             px[q] = rblend(a[0], a[1], a[RT_PITCH], a[RT_PITCH + 1], tp[4 * r + q].w0, tp[4 * r + q].w1);
           }
           *reinterpret_cast<unsigned*>(D + (size_t)(y0 + 8 * r) * W + x) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
@@ -570,6 +576,8 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
     const int TH = th == 16 ? 16 : 32;
     const int tiles_x = (P.W + RT_W - 1) / RT_W, tiles_y = (P.H + TH - 1) / TH;
     // streams per block = SPB (streams per LDS buffer) x NSUB (pipelined sub-chunks; taps computed once for all)
+    // (16 streams per block -- taps and map tile shared by twice as many streams -- was measured in round 4: the launch
+    // inside the step 0.060 against 0.068 ms, alone 0.048 against 0.044 ms, the step 1.2035 against 1.195 ms: not kept)
     int S = spb == 1 ? 1 : 2, NS = nsub == 1 ? 1 : (nsub == 2 ? 2 : 4);
     if (P.B <= S) NS = 1;
     else if (P.B <= 2 * S && NS > 2) NS = 2;
