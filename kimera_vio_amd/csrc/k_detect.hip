@@ -1725,8 +1725,12 @@ __device__ __forceinline__ int subpix_total_new(const StreamState& S, const Dete
 
 __device__ unsigned long long kvfe_subpix_stats[8];   // corners, sum cycles, max cycles, launches' first/last stamp
 
+// Launch bound of the two-wave variant (round 4): hipcc's own allocation is 172 VGPRs -- 2 waves per SIMD, four corners
+// per CU, although LDS (21.5 KB per corner) admits seven.  Bounded to 4 waves per SIMD it is 128 VGPRs + 30 spilled
+// to scratch, seven corners per CU: cornerSubPix 0.431 -> 0.377 ms in the 64-stream step, 1.878 -> 1.604 ms on real
+// frames (A/B of two builds on one box, tools/r4/gpu_j.sh); (128, 3) = 168 VGPRs gave 0.402 / 1.626 ms.
 template <int WIN, int NW>
-__global__ __launch_bounds__(64 * NW) void subpix_append_kernel(KParams P, Tables T,
+__global__ __launch_bounds__(64 * NW, NW == 2 ? 4 : 2) void subpix_append_kernel(KParams P, Tables T,
                                                            const unsigned char* __restrict__ img,
                                                            size_t row_stride, size_t img_stride,
                                                            FrameTab K, StreamState S,
