@@ -16,6 +16,7 @@
 //   dense_prefilter   1 thread / pixel
 //   dense_bt_cost     wave = one pixel, lane = disparity
 //   dense_hsum/vsum   sliding window sums along x then y (2 lines read per line written)
+//   dense_cost_fused  MODE_HH: the three kernels above in one (only C(p,d) reaches HBM)
 //   dense_aggregate   one wave per scan-line path (8 directions), lane = disparity; neighbours d-1 / d+1
 //                     through DPP wave shifts, min_k L_r through DPP + readlane; the running path cost
 //                     stays in a register, the 4-path sums are accumulated in place (u16)
@@ -175,6 +176,132 @@ __global__ __launch_bounds__(256) void dense_vsum_kernel(DenseParams P, const sh
   for (int y = y0 + 1; y < ye; y++) {
     s += in[(size_t)min(y + SH2, h1) * rs] - in[(size_t)max(y - SH2 - 1, 0) * rs];
     out[(size_t)y * rs] = (short)value(y, s);
+  }
+}
+
+// ---- C(p,d) in one kernel (MODE_HH) -------------------------------------------------------------------
+// The three kernels above move the cost volume five times (pixel costs written and read, row sums written and read, C
+// written): 0.19 GB of the 1.30 GB a 752x480 pair costs.  Here one wave owns NCOL matchable columns x RC rows of a pair
+// (lane = disparity) and walks its rows top-down: the pixel costs of the NCOL + 2 SW2 columns of a row are evaluated from
+// the 8-byte records into registers, the row sums slide along them, and the column sums slide down through a ring of the
+// last 2 SW2 + 1 row sums in LDS (two columns per dword).  Only C is written.
+// The records of a row reach the wave through three vector loads issued one row ahead (lane l: the left record of window
+// column l, the right records lo + l and lo + 64 + l) and a 1 KB LDS stage: column j then reads the left record at a
+// wave-uniform address (broadcast) and its right record at position 63 + j - lane -- immediate offsets, no address
+// arithmetic beyond the clamp of the window column (hsum's: columns outside [0, width1) repeat the edge column), no
+// global-load latency inside the row.
+// Price: the pixel costs of the halo columns and rows are evaluated by two waves ((NCOL + 2 SW2) / NCOL x
+// (RC + 2 SW2) / RC evaluations per output).  Same integers as the three kernels: every sum is below 2^15
+// (11 x 11 x 189 + P2).  MODE_SGBM keeps the three kernels (its frozen rows need sums of other rows).
+// Measured (8 pairs of 752x480, 64 disparities): 0.35 ms against 0.70 ms for the three kernels; 16 / 12 / 8 columns per
+// wave give 0.356 / 0.346 / 0.35 ms (LDS ring 22.5 / 16.9 / 11.3 KB per wave against 1.6 / 1.8 / 2.3 evaluations per
+// output) -- profiles/r4_analysis.md.
+#ifndef KVFE_CF_NCOL
+#define KVFE_CF_NCOL 12
+#endif
+constexpr int CF_NCOL = KVFE_CF_NCOL;
+template <int SW2>
+__global__ __launch_bounds__(64) void dense_cost_fused_kernel(DenseParams P, const uint2* __restrict__ rec,
+                                                              short* __restrict__ Cv, int RC) {
+  constexpr int NCOL = CF_NCOL, NR = 2 * SW2 + 1, NP = NCOL + 2 * SW2, NK = NCOL / 2;
+  static_assert(NCOL % 2 == 0 && NP <= 64, "two columns per ring dword; one lane per window column");
+  __shared__ unsigned ring[NR * NK * 64];
+  __shared__ uint2 stage_r[128];
+  __shared__ uint2 stage_l[NP];
+  const int lane = threadIdx.x;
+  const int x0 = blockIdx.x * NCOL, y0 = blockIdx.y * RC, pair = blockIdx.z;
+  const int W = P.W, H = P.H, W1 = P.width1, w1 = W1 - 1, D = P.D;
+  const bool act = lane < D;
+  const size_t plane = (size_t)H * W;
+  const uint2* recL = rec + (size_t)(pair * 2) * plane;
+  const uint2* recR = recL + plane;
+  short* out = Cv + (size_t)pair * H * W1 * D + min(lane, D - 1);
+  // image columns this lane fetches every row (clamped into the row: what a clamped right-image address returns
+  // belongs to an idle lane or to a window column nobody reads)
+  const int xl0 = x0 - SW2 + P.minX1;              // image column of window column 0
+  const int lo = xl0 - P.minD - 63;                // right record at stage position 0
+  const int cl = min(max(x0 - SW2 + lane, 0), w1) + P.minX1;   // (clamped like the window column it serves)
+  const int ca = min(max(lo + lane, 0), W - 1), cb = min(max(lo + 64 + lane, 0), W - 1);
+  const uint2* sr = stage_r + (63 - lane);         // + j: the right record of window column j at this lane's disparity
+  // (the left record's address is wave-uniform; hidden from the compiler, which would otherwise move all 26 records
+  // through v_readfirstlane into scalar registers and spill them)
+  int zero_v;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+  const uint2* sl = stage_l + zero_v;
+#pragma unroll
+  for (int i = 0; i < NR * NK; i++) ring[i * 64 + lane] = 0u;
+  unsigned Vp[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++) Vp[k] = 0u;
+  int slot = 0;
+  const int ye = min(y0 + RC, H);
+  // window columns left of column 0 / right of column width1-1 repeat the edge column (hsum's clamp)
+  const int jl = x0 == 0 ? SW2 : 0, jr = min(w1 - x0 + SW2, NP - 1);
+  uint2 nl, na, nb;
+  {
+    const size_t ro = (size_t)min(max(y0 - SW2, 0), H - 1) * W;
+    nl = recL[ro + cl];
+    na = recR[ro + ca];
+    nb = recR[ro + cb];
+  }
+  for (int v = y0 - SW2; v < ye + SW2; v++) {
+    if (lane < NP) stage_l[lane] = nl;
+    stage_r[lane] = na;
+    stage_r[64 + lane] = nb;
+    {   // the next row's records (the last iteration re-reads its own row)
+      const size_t ro = (size_t)min(max(min(v + 1, ye + SW2 - 1), 0), H - 1) * W;
+      nl = recL[ro + cl];
+      na = recR[ro + ca];
+      nb = recR[ro + cb];
+    }
+    int pix[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      const int jc = min(max(j, jl), jr);   // (wave-uniform: hsum's clamp of the window column)
+      const uint2 L = sl[j];
+      const uint2 R = sr[jc];
+      const int u = L.x & 255, u0 = (L.x >> 8) & 255, u1 = (L.x >> 16) & 255;
+      const int q = R.x & 255, q0 = (R.x >> 8) & 255, q1 = (R.x >> 16) & 255;
+      const int c0 = max(max(0, u - q1), q0 - u), c1 = max(max(0, q - u1), u0 - q);
+      const int ur = L.x >> 24, ur0 = L.y & 255, ur1 = (L.y >> 8) & 255;
+      const int qr = R.x >> 24, qr0 = R.y & 255, qr1 = (R.y >> 8) & 255;
+      const int e0 = max(max(0, ur - qr1), qr0 - ur), e1 = max(max(0, qr - ur1), ur0 - qr);
+      pix[j] = min(c0, c1) + (min(e0, e1) >> 2);
+    }
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) s += pix[j];
+    unsigned hp[NK];
+#pragma unroll
+    for (int c = 0; c < NCOL; c++) {
+      if (c > 0) s += pix[c + 2 * SW2] - pix[c - 1];
+      if (c & 1)
+        hp[c >> 1] |= (unsigned)s << 16;
+      else
+        hp[c >> 1] = (unsigned)s;
+    }
+    // column sums: + this row, - the row that leaves the window (the halves never borrow from each other: both stay
+    // true window sums in [0, 2^16))
+    unsigned* rg = ring + (size_t)slot * NK * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      const unsigned old = rg[k * 64];
+      Vp[k] = Vp[k] + hp[k] - old;
+      rg[k * 64] = hp[k];
+    }
+    slot = slot + 1 == NR ? 0 : slot + 1;
+    const int y = v - SW2;
+    if (y >= y0) {
+      // (OpenCV's recurrence leaves C at its initial P2 in column 0 of every row but the first and in the last SW2 rows)
+      const bool rowdead = y > 0 && y + SW2 >= H;
+      short* o = out + ((size_t)y * W1 + x0) * D;
+#pragma unroll
+      for (int c = 0; c < NCOL; c++) {
+        const int val = (int)((Vp[c >> 1] >> ((c & 1) * 16)) & 0xffffu);
+        const bool dead = rowdead || (y > 0 && x0 + c == 0);
+        if (act && x0 + c < W1) o[(size_t)c * D] = (short)(P.P2 + (dead ? 0 : val));
+      }
+    }
   }
 }
 
@@ -715,11 +842,24 @@ size_t dense_volume_elems(const DenseParams& P) { return (size_t)P.H * P.width1 
 void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st) {
   const dim3 blk(256);
   dense_prefilter_kernel<<<dim3((P.W + 255) / 256, P.H, 2 * n), blk, 0, st>>>(P, B.left, B.right, B.rec);
-  dense_bt_cost_kernel<<<dim3((P.width1 + BT_XPB - 1) / BT_XPB, P.H, n), blk, 0, st>>>(P, B.rec, B.vol[0]);
-  dense_hsum_kernel<<<dim3((P.width1 + 4 * HS_CHUNK - 1) / (4 * HS_CHUNK), P.H, n), blk, 0, st>>>(P, B.vol[0],
-                                                                                                 B.vol[1]);
-  dense_vsum_kernel<<<dim3((P.width1 + 3) / 4, (P.H + VS_CHUNK - 1) / VS_CHUNK, n), blk, 0, st>>>(P, B.vol[1],
-                                                                                                 B.vol[2]);
+  if (P.full_dp && P.SW2 >= 1 && P.SW2 <= 5) {
+    // rows per wave: enough waves for the chip when few pairs are in the call, less halo work when many are
+    const int RC = n >= 4 ? 48 : 16;
+    const dim3 g((P.width1 + CF_NCOL - 1) / CF_NCOL, (P.H + RC - 1) / RC, n);
+    switch (P.SW2) {
+      case 1: dense_cost_fused_kernel<1><<<g, dim3(64), 0, st>>>(P, B.rec, B.vol[2], RC); break;
+      case 2: dense_cost_fused_kernel<2><<<g, dim3(64), 0, st>>>(P, B.rec, B.vol[2], RC); break;
+      case 3: dense_cost_fused_kernel<3><<<g, dim3(64), 0, st>>>(P, B.rec, B.vol[2], RC); break;
+      case 4: dense_cost_fused_kernel<4><<<g, dim3(64), 0, st>>>(P, B.rec, B.vol[2], RC); break;
+      default: dense_cost_fused_kernel<5><<<g, dim3(64), 0, st>>>(P, B.rec, B.vol[2], RC); break;
+    }
+  } else {
+    dense_bt_cost_kernel<<<dim3((P.width1 + BT_XPB - 1) / BT_XPB, P.H, n), blk, 0, st>>>(P, B.rec, B.vol[0]);
+    dense_hsum_kernel<<<dim3((P.width1 + 4 * HS_CHUNK - 1) / (4 * HS_CHUNK), P.H, n), blk, 0, st>>>(P, B.vol[0],
+                                                                                                   B.vol[1]);
+    dense_vsum_kernel<<<dim3((P.width1 + 3) / 4, (P.H + VS_CHUNK - 1) / VS_CHUNK, n), blk, 0, st>>>(P, B.vol[1],
+                                                                                                   B.vol[2]);
+  }
   const short* Cv = B.vol[2];
   unsigned short* sA = (unsigned short*)B.vol[0];
   unsigned short* sB = (unsigned short*)B.vol[1];
