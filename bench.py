@@ -660,10 +660,11 @@ def dense_stereo(F, WL, W, H, dev, pmc_leg):
     w1 = W - (dp.min_disparity + D)
     vol = H * w1 * D * 2.0                      # one int16 cost volume
     npx = float(W) * H
-    # algorithmic bytes per pair: pixel records, cost -> row sums -> C (write + read each), eight
-    # path sweeps (C read, one sum write, seven sum read-modify-writes), selection, the small disparity passes
+    # algorithmic bytes per pair: pixel records, C(p,d) written once by the fused cost kernel (round 4;
+    # rounds 1-3 wrote and re-read the pixel costs and the row sums: + 4 volumes), eight path sweeps (C read, one sum
+    # write, seven sum read-modify-writes), selection, the small disparity passes
     agg_bytes = 8 * vol + vol + 7 * 2 * vol
-    alg = (2 * npx + 16 * npx) + (16 * npx + vol) + 2 * vol + 2 * vol + agg_bytes + (vol + 2 * npx) + 24 * npx
+    alg = (2 * npx + 16 * npx) + (16 * npx + vol) + agg_bytes + (vol + 2 * npx) + 24 * npx
     traffic = None
     if pmc_leg:   # HBM-side bytes of the same kernels from the committed rocprofv3 PMC passes
         tb = sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 for k, v in pmc_leg.items()

@@ -387,6 +387,22 @@ __device__ __forceinline__ void dpp_shr1_add2(float& c0, float& c1, float b0, fl
 __device__ __forceinline__ int dot2_i16(int a, int b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
 }
+// c + a1 . b1 + a0 . b0 and (a . b0, a . b1) as three-operand dot products.  hipcc only emits the accumulate-in-place form
+// (v_dot2c), which costs a v_mov per start value -- 36 of the 320 vector instructions of an LK iteration.  The hazards
+// the compiler would otherwise handle are closed inside the block: a dot product feeding the SAME opcode's accumulator
+// needs no wait state, any other reader of a dot product's result needs three (s_nop 2).
+__device__ __forceinline__ int dot2x2_i16(int a1, int b1, int c, int a0, int b0) {
+  int d;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\ts_nop 2"
+      : "=&v"(d)
+      : "v"(a1), "v"(b1), "v"(c), "v"(a0), "v"(b0));
+  return d;
+}
+__device__ __forceinline__ void dot2_pair0_i16(int a, int b0, int b1, int& d0, int& d1) {
+  asm("v_dot2_i32_i16 %0, %2, %3, 0\n\tv_dot2_i32_i16 %1, %2, %4, 0\n\ts_nop 2"
+      : "=&v"(d0), "=&v"(d1)
+      : "v"(a), "v"(b0), "v"(b1));
+}
 __device__ __forceinline__ int pack_lo16(int lo, int hi) {  // (lo & 0xffff) | (hi << 16)
   return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u);
 }
@@ -583,7 +599,10 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
     }
     LKP(1);
     // bilinear template and derivative window of this lane's pixels -> registers
-    int rI[NPX], rgxy[NPX];  // rgxy = (Ix & 0xffff) | (Iy << 16)
+    // rA = 2^8 - (I << 9): the template value folded into the start value of the blend's accumulator -- the blend of the
+    // current frame, its rounding and the subtraction of I are then two dot products and a shift:
+    // ((b + 2^8) >> 9) - I == (b + 2^8 - (I << 9)) >> 9 for every integer b
+    int rA[NPX], rgxy[NPX];  // rgxy = (Ix & 0xffff) | (Iy << 16)
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -596,15 +615,13 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
         const int ival = dot2_i16(p0, wq0, dot2_i16(p1, wq1, 1 << 8)) >> 9;
         const int* d = dxy + y * DSTR + x;
         const int d00 = d[0], d01 = d[1], d10 = d[DSTR], d11 = d[DSTR + 1];
-        const int ixval =
-            dot2_i16(pack_lo16(d00, d01), wq0, dot2_i16(pack_lo16(d10, d11), wq1, 1 << 13)) >> 14;
-        const int iyval =
-            dot2_i16(pack_hi16(d00, d01), wq0, dot2_i16(pack_hi16(d10, d11), wq1, 1 << 13)) >> 14;
+        const int ixval = dot2_i16(pack_lo16(d00, d01), wq0, dot2_i16(pack_lo16(d10, d11), wq1, 1 << 13)) >> 14;
+        const int iyval = dot2_i16(pack_hi16(d00, d01), wq0, dot2_i16(pack_hi16(d10, d11), wq1, 1 << 13)) >> 14;
         // no saturation (OpenCV stores these as short without one): 0 <= ival <= 255 * 2^14 >> 9 = 8160 and
         // |ixval|, |iyval| <= 4080 (a bilinear blend of Scharr sums of at most 16 * 255).  No zeroing of the idle lanes
         // either (q >= NQ shadow lane 0's pixels): they sit BEHIND lane NQ-1 in the row_shr pipeline of their DPP row,
         // so nothing they compute reaches a lane that is read -- and a select here is re-issued in every iteration.
-        rI[k] = ival;
+        rA[k] = (1 << 8) - (ival << 9);
         rgxy[k] = pack_lo16(ixval, iyval);
       }
     LKP(2);
@@ -721,9 +738,7 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
 #pragma unroll
         for (int m = 0; m < NC; m++) {
           const int k = r * NC + m;
-          const int t = dot2_i16(jb[r * JSTR + 4 * m], wq0,
-                                 dot2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, 1 << 8)) >> 9;
-          diff[k] = t - rI[k];
+          diff[k] = dot2x2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, rA[k], jb[r * JSTR + 4 * m], wq0) >> 9;
         }
       // chain terms: madd pairs (x, x+4) of one row chunk, converted to float
       v2f term[NST];
@@ -733,8 +748,8 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
         for (int c = 0; c < NC / 2; c++) {
           const int k0 = r * NC + 2 * c, k1 = k0 + 1;
           const int dd = pack_lo16(diff[k0], diff[k1]);
-          const int m1 = dot2_i16(dd, pack_lo16(rgxy[k0], rgxy[k1]), 0);
-          const int m2 = dot2_i16(dd, pack_hi16(rgxy[k0], rgxy[k1]), 0);
+          int m1, m2;
+          dot2_pair0_i16(dd, pack_lo16(rgxy[k0], rgxy[k1]), pack_hi16(rgxy[k0], rgxy[k1]), m1, m2);
           term[r * (NC / 2) + c] = v2f{(float)m1, (float)m2};
         }
       v2f t = {0.f, 0.f};
@@ -797,9 +812,8 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams
 #pragma unroll
         for (int m = 0; m < NC; m++) {
           const int k = r * NC + m;
-          const int t = dot2_i16(jb[r * JSTR + 4 * m], wq0,
-                                 dot2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, 1 << 8)) >> 9;
-          esum += active ? abs(t - rI[k]) : 0;
+          const int t = dot2x2_i16(jb[(r + 1) * JSTR + 4 * m], wq1, rA[k], jb[r * JSTR + 4 * m], wq0) >> 9;
+          esum += active ? abs(t) : 0;
         }
       for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
       errOut = (float)esum * 1.f / (float)(32 * WIN * WIN);
