@@ -1,4 +1,8 @@
-# round 4, call p (experiment): why does track_finalize start only when the output transfer has ended?
+# round 4, call p (experiment, the KVFE_X_OUT switch it used is not in the tree): in the kernel traces track_finalize starts
+# 6 us after max(end of the tracking launch, end of the output transfer kernel).  Moving the transfer behind the tail's
+# event on the tail's stream (2), binding the wait through a relay stream (3), both (4) change nothing; dropping the
+# wait (5, racy) gains 0.7 %.  The tracking launch itself ends within +-5 us of the transfer's end in most steps: its
+# completion appears to wait for the transfer's PCIe writes (not proven).  Worth <= 1 % of the step: left alone.
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$PWD
 for X in 0 3 4 5 0 3; do
 KVFE_X_OUT=$X timeout 300 python bench.py --legs none --steps 30 --warmup 8 --repeats 3 --stage-event-stride 4 2> gpurun_out/p_bench.err | python -c "
