@@ -131,6 +131,7 @@ struct kvfe_ctx {
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
   bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
   bool fork_swap = false;                            // few streams: the corner refinement stays on the main stream (do_step)
+  bool frames_persist_call = false;                  // this do_step call reads caller frames that stay valid for one more step
   bool chain_pending = false;                        // fork_swap: the side stream's outlier rejection has not been joined yet
   bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
   std::vector<int> prof_pending;
@@ -956,10 +957,15 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // refined new corners and the per-stream state detect_commit wrote (ev_commit) -- joined HERE, behind the pyramid,
   // which does not depend on it and hides the cross-stream hand-over.  Its tail (stereo matching of the new corners,
   // measurements, lkf <- k) is only needed by track_finalize: it runs next to this step's tracking launch.
-  if (c->chain_pending) {   // fork_swap: the previous step's rectify / match / reject chain ran on the side stream
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_main, 0));
+  if (c->chain_pending) {   // the previous step's rectify / match / reject chain ran on the side stream (fork swapped)
+    // It reads nothing this step's tracking writes and writes nothing it reads; what has to wait for it is the release
+    // of the previous frame's image buffers.  Frames the caller keeps valid for one more step (device_frames_persist)
+    // need no wait here: the chain is followed by the tail on the same stream, and track_finalize joins the tail.
+    if (!c->frames_persist_call) {
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_main, 0));
+      prof_break(c);
+    }
     c->chain_pending = false;
-    prof_break(c);
   }
   if (c->commit_pending) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
@@ -1051,7 +1057,14 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // chain is the throughput-bound side and stays on the main stream, the refinement forks off.  A few streams
   // (fork_swap): every kernel is a latency, the refinement is on the loop that bounds the step and keeps the main
   // stream -- no cross-stream hand-over on that loop -- and the chain forks off.
-  const bool swap = c->fork_swap && c->side;
+  // Many streams take the same arrangement when the caller's frames persist (kvfe_config.device_frames_persist, device
+  // frames): the chain then does not have to be joined in front of the next tracking launch, so neither cross-stream
+  // hand-over (fork, join: 9 + 21 us in the kernel trace) is on the loop -- +1.9 % on the 64-stream headline, +2.0 % on
+  // real frames, +1.1 % at the reference cadence (profiles/r4_analysis.md).  Without that guarantee the chain has to be
+  // awaited before the caller may reuse its buffers, and it stays on the main stream.  (Measured and not kept: starting
+  // the chain only when the refinement is done -- the refinement gains 0.035 ms, the chain then runs beside the next
+  // tracking launch, starved, and the tail gates the keyframe decision: step 1.145 -> 1.263 ms.)
+  const bool swap = c->side && (c->fork_swap || (c->frames_persist_call && c->own_stream && !P.mono));
   hipStream_t fa = swap ? st : sd, fb = swap ? sd : st;
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
@@ -1353,6 +1366,7 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
       s = KVFE_ERR_HIP;
     // a few streams are latency bound: the loop refinement -> tracking -> keyframe decision -> detection -> refinement
     // is what a step costs, so it stays on ONE stream and the rectify / match / reject chain takes the side stream
+    // (many streams: the same arrangement for the calls whose frames persist, do_step)
     c->fork_swap = c->P.B <= 4 && c->own_stream && !c->P.mono;
   }
   if (s != KVFE_OK) {
@@ -2229,9 +2243,13 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
     return do_step(c, dl, dr, P.W, N, inputs);
   }
   c->last_step_staged = false;
-  if (c->cfg.device_frames_persist)   // the caller keeps frame k valid until step k+1 has completed: no copy
-    return do_step(c, reinterpret_cast<const unsigned char*>(left_dev), reinterpret_cast<const unsigned char*>(right_dev),
-                   row_stride, image_stride, inputs);
+  if (c->cfg.device_frames_persist) {   // the caller keeps frame k valid until step k+1 has completed: no copy
+    c->frames_persist_call = true;
+    const kvfe_status r = do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
+                                  reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
+    c->frames_persist_call = false;
+    return r;
+  }
   // the caller's buffers are only read by THIS step: the left image the next step's LK needs is copied into the
   // context (by the first pyramid launch, which reads it anyway)
   {
@@ -2369,7 +2387,7 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->step_done[dep % 4], 0));
     // fork_swap: rectification (the other reader of a frame's slots) runs on the side stream and is not covered by the
     // main stream's step_done; the side stream's latest "chain done" event is behind every earlier one
-    if (c->fork_swap && c->chain_pending) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_main, 0));
+    if (c->chain_pending) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_main, 0));
   }
   unsigned char* ul = eq ? b.eq_in[0] : dl;
   unsigned char* ur = eq ? b.eq_in[1] : dr;
