@@ -1,4 +1,5 @@
 # round 4, call q (experiment): the corner refinement on the main stream and the rectify / match / reject chain on the side
+# (result: +1.9 % headline, +2.0 % kf_realistic, +1.1 % nominal, +0.2 % c5; kept as the rule for persisting device frames -- the KVFE_X_SWAP switch is not in the tree)
 # stream for 64 streams too (fork_swap), without the chain join in front of the tracking launch when the frames persist
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$PWD
 KVFE_X_SWAP=1 timeout 600 python -m pytest tests/test_gpu_pipelined_r3.py tests/test_gpu_bench_configs.py -m gpu -q -x -k "not dense" > gpurun_out/q_tests.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/q_tests.log | cut -c1-300
