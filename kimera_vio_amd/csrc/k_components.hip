@@ -122,8 +122,9 @@ void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScra
 
 // ---- output side (kvfe_dev.hpp "output side") ------------------------------------------------------------------------
 // One block per stream: the header by thread 0, the arrays by coalesced element copies.  `dst` is a device staging
-// buffer (many streams: the record then crosses PCIe on the output stream, beside the next step's tracking launch) or
-// the mapped pinned ring slot itself (a few streams: one launch less on the latency path).
+// buffer (many streams: the records then cross PCIe in one DMA transfer on the output stream, beside the next step's
+// tracking launch) or the mapped pinned ring slot itself (a few streams: one launch less on the latency path).
+// `rec_cap` = entries a record has room for (the host side cuts with the same number).
 template <typename T>
 __device__ __forceinline__ void out_copy_arr(unsigned char* rec, size_t off, const T* __restrict__ src, size_t n) {
   T* d = reinterpret_cast<T*>(rec + off);
@@ -131,17 +132,17 @@ __device__ __forceinline__ void out_copy_arr(unsigned char* rec, size_t off, con
 }
 
 __global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, StereoTab ST, StreamState S,
-                                                       unsigned char* __restrict__ dst, size_t rec_stride) {
+                                                       unsigned char* __restrict__ dst, size_t rec_stride, int rec_cap) {
   const int s = blockIdx.x;
   unsigned char* rec = dst + (size_t)s * rec_stride;
   const int flags = S.flags[s];
-  const int n = min(K.count[s], P.kcap), m = min(S.n_meas[s], P.kcap);
+  const int n = min(K.count[s], rec_cap), m = min(S.n_meas[s], rec_cap);
   const bool stereo = (flags & FLAG_STEREO) != 0;
   const OutLayout L = out_layout(n, m, stereo);
   if (threadIdx.x == 0) {
     OutHeader* h = reinterpret_cast<OutHeader*>(rec);
     h->n_keypoints = K.count[s];
-    h->flags = flags;
+    h->flags = flags | (K.count[s] > rec_cap ? FLAG_OVERFLOW : 0);   // (cannot happen while pts_bound holds; loud if it does)
     h->n_tracked = S.n_tracked[s];
     h->n_detected = S.n_detected[s];
     h->n_meas = S.n_meas[s];
@@ -178,24 +179,8 @@ __global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, St
 }
 
 void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, const StreamState& S, unsigned char* dst,
-                     size_t rec_stride, hipStream_t st) {
-  hipLaunchKernelGGL(out_pack_kernel, dim3((unsigned)P.B), dim3(256), 0, st, P, k, ST, S, dst, rec_stride);
-}
-
-// staging -> pinned host ring slot: the used bytes of every record (16-byte words; gaps between the arrays are not
-// initialised and not read), OUT_COPY_PARTS blocks per stream so that enough writes are in flight to fill the link
-constexpr int OUT_COPY_PARTS = 4;
-__global__ __launch_bounds__(256) void out_copy_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
-                                                       size_t rec_stride) {
-  const int s = blockIdx.x;
-  const uint4* a = reinterpret_cast<const uint4*>(src + (size_t)s * rec_stride);
-  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)s * rec_stride);
-  const size_t words = (size_t)(reinterpret_cast<const OutHeader*>(a)->used_bytes >> 4);
-  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < words; i += 256 * OUT_COPY_PARTS) d[i] = a[i];
-}
-
-void launch_out_copy(int B, const unsigned char* src, unsigned char* dst_host_mapped, size_t rec_stride, hipStream_t st) {
-  hipLaunchKernelGGL(out_copy_kernel, dim3((unsigned)B, OUT_COPY_PARTS), dim3(256), 0, st, src, dst_host_mapped, rec_stride);
+                     size_t rec_stride, int rec_cap, hipStream_t st) {
+  hipLaunchKernelGGL(out_pack_kernel, dim3((unsigned)P.B), dim3(256), 0, st, P, k, ST, S, dst, rec_stride, rec_cap);
 }
 
 }  // namespace kvfe

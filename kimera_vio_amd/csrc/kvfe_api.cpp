@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kvfe.h"
@@ -147,14 +148,15 @@ struct kvfe_ctx {
   int prof_flag_next = 0;
   std::string last_error;
   // output side (kvfe_dev.hpp "output side"): OUT_RING pinned host slots of B packed records; with many streams a
-  // device staging buffer per slot + a copy kernel on `out_stream`, with a few (out_direct) the pack kernel writes the
-  // mapped slot itself
+  // device staging buffer per slot + one DMA transfer on `out_stream`, with a few (out_direct) the pack kernel writes
+  // the mapped slot itself
   unsigned char* out_host[OUT_RING] = {};
   unsigned char* out_host_dev[OUT_RING] = {};   // device address of the mapped slot
   unsigned char* out_stage[OUT_RING] = {};
   hipEvent_t ev_packed[OUT_RING] = {}, ev_out[OUT_RING] = {};
   hipStream_t out_stream = nullptr;
   size_t out_stride = 0;
+  int out_cap = 0;           // entries a record has room for: what a frame table can hold (pts_bound), not what it is allocated for
   bool out_direct = false;
   long long out_steps = 0;   // steps whose record has been enqueued; slot of step i = i % OUT_RING
   // dense stereo (allocated on first use, re-allocated when the volume geometry changes)
@@ -861,20 +863,21 @@ void prof_collect(kvfe_ctx* c) {
 // The step's output records (kvfe_dev.hpp "output side"), enqueued behind step_finalize on the stream `sd` of the tail
 // and BEFORE the tail's event: the next step's track_finalize (which clears the landmarks of lost tracks in this frame's
 // table) waits for that event, so the records hold the frame as the reference's StereoFrontendOutput would.  Many streams:
-// a device-to-device gather (microseconds) on `sd`, then the PCIe transfer by a copy kernel on the output stream, beside
+// a device-to-device gather (microseconds) on `sd`, then the PCIe transfer by the DMA engine on the output stream, beside
 // the next step's tracking launch.  A few streams: the gather writes the mapped pinned slot directly.
 kvfe_status enqueue_outputs(kvfe_ctx* c, const FrameTab& K, hipStream_t sd) {
   const int slot = (int)(c->out_steps % OUT_RING);
   Buffers& b = c->fe;
   if (c->out_direct) {
-    launch_out_pack(c->P, K, b.st, b.ss, c->out_host_dev[slot], c->out_stride, sd);
+    launch_out_pack(c->P, K, b.st, b.ss, c->out_host_dev[slot], c->out_stride, c->out_cap, sd);
     HIPCHK(c, hipEventRecord(c->ev_out[slot], sd));
   } else {
     if (c->out_steps >= OUT_RING) HIPCHK(c, hipStreamWaitEvent(sd, c->ev_out[slot], 0));   // the slot's last transfer read it
-    launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_stride, sd);
+    launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_stride, c->out_cap, sd);
     HIPCHK(c, hipEventRecord(c->ev_packed[slot], sd));
     HIPCHK(c, hipStreamWaitEvent(c->out_stream, c->ev_packed[slot], 0));
-    launch_out_copy(c->P.B, c->out_stage[slot], c->out_host_dev[slot], c->out_stride, c->out_stream);
+    HIPCHK(c, hipMemcpyAsync(c->out_host[slot], c->out_stage[slot], c->out_stride * (size_t)c->P.B, hipMemcpyDeviceToHost,
+                             c->out_stream));
     HIPCHK(c, hipEventRecord(c->ev_out[slot], c->out_stream));
   }
   c->out_steps++;
@@ -1329,7 +1332,10 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     }
   }
   if (s == KVFE_OK && alloc_frontend) {
-    c->out_stride = out_record_stride(c->P.kcap);
+    // (a frame table holds at most the tracked entries plus the new corners, each bounded by pts_bound -- the bound the
+    // per-keypoint launches of the step use -- although it is allocated for kcap)
+    c->out_cap = std::min(c->P.kcap, 2 * c->pts_bound);
+    c->out_stride = out_record_stride(c->out_cap);
     c->out_direct = c->P.B <= 4 || cfg->single_hip_stream != 0;
     const size_t bytes = c->out_stride * (size_t)c->P.B;
     for (int i = 0; i < OUT_RING && s == KVFE_OK; i++) {
@@ -2507,7 +2513,7 @@ static kvfe_status locate_output(kvfe_ctx* c, int32_t s, int32_t steps_back, con
 }
 
 // header fields of a record -> kvfe_frame_output; returns the record's layout
-static OutLayout output_header(const KParams& P, const unsigned char* rec, kvfe_frame_output* out, int* n_rec, int* m_rec) {
+static OutLayout output_header(int rec_cap, const unsigned char* rec, kvfe_frame_output* out, int* n_rec, int* m_rec) {
   const OutHeader* h = reinterpret_cast<const OutHeader*>(rec);
   out->n_keypoints = h->n_keypoints;
   out->is_keyframe = (h->flags & FLAG_KEYFRAME) ? 1 : 0;
@@ -2529,10 +2535,12 @@ static OutLayout output_header(const KParams& P, const unsigned char* rec, kvfe_
   out->tracking_status_pnp = h->pnp_status;
   out->nr_pnp_inliers = h->pnp_counts[0];
   std::memcpy(out->W_T_k_pnp, h->pnp_pose, sizeof(double) * 12);
-  *n_rec = std::min(h->n_keypoints, P.kcap);   // entries the record holds
-  *m_rec = std::min(h->n_meas, P.kcap);
+  *n_rec = std::min(h->n_keypoints, rec_cap);   // entries the record holds
+  *m_rec = std::min(h->n_meas, rec_cap);
   return out_layout(*n_rec, *m_rec, (h->flags & FLAG_STEREO) != 0);
 }
+
+static kvfe_status copy_output_record(int rec_cap, const unsigned char* rec, kvfe_frame_output* out);
 
 kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_back, kvfe_frame_output* out) {
   DeviceGuard _dev(c);
@@ -2546,8 +2554,17 @@ kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_ba
     }
   const unsigned char* rec = nullptr;
   TRY(locate_output(c, s, steps_back, &rec));
+  const kvfe_status r = copy_output_record(c->out_cap, rec, out);
+  if (r == KVFE_ERR_CAPACITY)
+    c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
+  return r;
+}
+
+// record in a pinned ring slot -> the caller's kvfe_frame_output (no device call, no context state: safe from any thread)
+static kvfe_status copy_output_record(int rec_cap, const unsigned char* rec, kvfe_frame_output* out) {
+  if (out->capacity < 0) return KVFE_ERR_INVALID_ARG;
   int np = 0, mp = 0;
-  const OutLayout L = output_header(c->P, rec, out, &np, &mp);
+  const OutLayout L = output_header(rec_cap, rec, out, &np, &mp);
   const int flags = reinterpret_cast<const OutHeader*>(rec)->flags;
   const bool stereo = (flags & FLAG_STEREO) != 0;
   const int n = std::min(np, out->capacity);
@@ -2570,11 +2587,7 @@ kvfe_status kvfe_frontend_get_output_at(kvfe_ctx* c, int32_t s, int32_t steps_ba
   DL(out->meas_landmark, L.meas_lmk, sizeof(long long) * m);
   DL(out->meas_uL_uR_v, L.meas, sizeof(double) * 3 * m);
 #undef DL
-  if (flags & FLAG_OVERFLOW) {
-    c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
-    return KVFE_ERR_CAPACITY;
-  }
-  return KVFE_OK;
+  return (flags & FLAG_OVERFLOW) ? KVFE_ERR_CAPACITY : KVFE_OK;
 }
 
 // Zero-copy variant: the array pointers of `out` are set to the arrays INSIDE the pinned record (stereo arrays NULL on a
@@ -2591,7 +2604,7 @@ kvfe_status kvfe_frontend_view_output(kvfe_ctx* c, int32_t s, int32_t steps_back
   const unsigned char* rec = nullptr;
   TRY(locate_output(c, s, steps_back, &rec));
   int np = 0, mp = 0;
-  const OutLayout L = output_header(c->P, rec, out, &np, &mp);
+  const OutLayout L = output_header(c->out_cap, rec, out, &np, &mp);
   const int flags = reinterpret_cast<const OutHeader*>(rec)->flags;
   const bool stereo = (flags & FLAG_STEREO) != 0;
   unsigned char* r = const_cast<unsigned char*>(rec);
@@ -2619,12 +2632,41 @@ kvfe_status kvfe_frontend_view_output(kvfe_ctx* c, int32_t s, int32_t steps_back
 // All streams of the context at once: outs[s] as for kvfe_frontend_get_output_at (one call, one event wait).
 kvfe_status kvfe_frontend_get_outputs(kvfe_ctx* c, int32_t steps_back, kvfe_frame_output* outs) {
   if (!c || !outs) return KVFE_ERR_INVALID_ARG;
-  kvfe_status worst = KVFE_OK;
-  for (int s = 0; s < c->P.B; s++) {
-    const kvfe_status r = kvfe_frontend_get_output_at(c, s, steps_back, outs + s);
+  const int B = c->P.B;
+  // 64 records of ~77 KB are a millisecond of memcpy for one core -- as long as the whole step takes on the device --
+  // so batches of 16 streams and more are copied by up to four threads (the first call waits for the transfer's event
+  // once; the others find it complete)
+  const int nthr = B >= 16 ? std::min(4, B / 8) : 1;
+  if (nthr <= 1 || !c->children.empty()) {
+    kvfe_status worst = KVFE_OK;
+    for (int s = 0; s < B; s++) {
+      const kvfe_status r = kvfe_frontend_get_output_at(c, s, steps_back, outs + s);
+      if (r == KVFE_ERR_CAPACITY) worst = r;
+      else if (r != KVFE_OK) return r;
+    }
+    return worst;
+  }
+  kvfe_status first = kvfe_frontend_get_output_at(c, 0, steps_back, outs);
+  if (first != KVFE_OK && first != KVFE_ERR_CAPACITY) return first;
+  std::vector<kvfe_status> res((size_t)nthr, KVFE_OK);
+  std::vector<std::string> err((size_t)nthr);
+  std::vector<std::thread> pool;
+  const int slot = (int)((c->out_steps - 1 - steps_back) % OUT_RING);
+  const unsigned char* base = c->out_host[slot];
+  for (int t = 0; t < nthr; t++)
+    pool.emplace_back([&, t] {
+      for (int s = 1 + t; s < B; s += nthr) {
+        const kvfe_status r = copy_output_record(c->out_cap, base + (size_t)s * c->out_stride, outs + s);
+        if (r != KVFE_OK) res[(size_t)t] = r;
+      }
+    });
+  for (auto& th : pool) th.join();
+  kvfe_status worst = first;
+  for (kvfe_status r : res)
     if (r == KVFE_ERR_CAPACITY) worst = r;
     else if (r != KVFE_OK) return r;
-  }
+  if (worst == KVFE_ERR_CAPACITY)
+    c->last_error = "a device-side list overflowed its capacity (candidates / corners / keypoints)";
   return worst;
 }
 

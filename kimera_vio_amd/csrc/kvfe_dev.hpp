@@ -390,8 +390,11 @@ void launch_depth_from_matches(const float2* left_xy, const unsigned char* left_
 // ---- output side: one packed record per stream and step (StereoFrontendOutput, StereoVisionImuFrontend-definitions.h:25-91) ----
 // step_finalize's successor `out_pack_kernel` gathers everything kvfe_frontend_get_output returns for a stream -- counters,
 // TrackerStatusSummary, the frame / stereo / measurement arrays cut to the entries in use -- into ONE contiguous record
-// (header + 16-byte aligned arrays); the records of a step travel to a pinned host ring slot in one device-initiated
-// transfer, and kvfe_frontend_get_output is a memcpy out of that slot (round 3: ~27 blocking hipMemcpy per stream).
+// (header + 16-byte aligned arrays); the records of a step travel to a pinned host ring slot in ONE transfer of the DMA
+// engine, and kvfe_frontend_get_output is a memcpy out of that slot (round 3: ~27 blocking hipMemcpy per stream).
+// (The first form of round 4 moved them with a copy KERNEL writing the mapped slot: every kernel of the step that ended
+// while its PCIe writes were in flight completed only when they had drained -- the tracking launch ended with the
+// transfer, 0.09 ms late, in most steps.  The DMA engine does not have that effect: +5.8 % on the 64-stream headline.)
 constexpr int OUT_HDR_BYTES = 512;
 constexpr int OUT_RING = 3;   // steps whose output records are kept (kvfe_frontend_get_output_at: steps_back < OUT_RING)
 struct OutHeader {
@@ -426,10 +429,9 @@ __host__ __device__ inline OutLayout out_layout(int n, int m, bool stereo) {
   L.end = o;
   return L;
 }
-inline size_t out_record_stride(int kcap) { return (out_layout(kcap, kcap, true).end + 255) & ~(size_t)255; }
+inline size_t out_record_stride(int rec_cap) { return (out_layout(rec_cap, rec_cap, true).end + 255) & ~(size_t)255; }
 void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, const StreamState& S, unsigned char* dst,
-                     size_t rec_stride, hipStream_t st);
-void launch_out_copy(int B, const unsigned char* src, unsigned char* dst_host_mapped, size_t rec_stride, hipStream_t st);
+                     size_t rec_stride, int rec_cap, hipStream_t st);
 void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScratch& lk, int max_pts, hipStream_t st);
 void launch_predict_flow(const KParams& P, const Tables& T, const double* R, const float2* prev,
                          int n, float2* out, hipStream_t st);
