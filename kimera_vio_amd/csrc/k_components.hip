@@ -125,6 +125,8 @@ void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScra
 // buffer (many streams: the records then cross PCIe in one DMA transfer on the output stream, beside the next step's
 // tracking launch) or the mapped pinned ring slot itself (a few streams: one launch less on the latency path).
 // `rec_cap` = entries a record has room for (the host side cuts with the same number).
+// The records of a step lie back to back behind a table of their offsets (kvfe_dev.hpp "output side"): a block derives
+// its own offset from the counts of the streams before it (at most 63 triples of ints).
 template <typename T>
 __device__ __forceinline__ void out_copy_arr(unsigned char* rec, size_t off, const T* __restrict__ src, size_t n) {
   T* d = reinterpret_cast<T*>(rec + off);
@@ -132,9 +134,17 @@ __device__ __forceinline__ void out_copy_arr(unsigned char* rec, size_t off, con
 }
 
 __global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, StereoTab ST, StreamState S,
-                                                       unsigned char* __restrict__ dst, size_t rec_stride, int rec_cap) {
+                                                       unsigned char* __restrict__ dst, size_t table_bytes, int rec_cap) {
   const int s = blockIdx.x;
-  unsigned char* rec = dst + (size_t)s * rec_stride;
+  __shared__ unsigned long long sh_off;
+  if (threadIdx.x == 0) sh_off = 0ull;
+  __syncthreads();
+  for (int t = threadIdx.x; t < s; t += blockDim.x)
+    atomicAdd(&sh_off, (unsigned long long)out_record_bytes(min(K.count[t], rec_cap), min(S.n_meas[t], rec_cap),
+                                                            (S.flags[t] & FLAG_STEREO) != 0));
+  __syncthreads();
+  const size_t off = table_bytes + (size_t)sh_off;
+  unsigned char* rec = dst + off;
   const int flags = S.flags[s];
   const int n = min(K.count[s], rec_cap), m = min(S.n_meas[s], rec_cap);
   const bool stereo = (flags & FLAG_STEREO) != 0;
@@ -153,6 +163,9 @@ __global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, St
     for (int i = 0; i < 3; i++) h->pnp_counts[i] = S.pnp_counts[3 * s + i];
     h->frame_count = S.frame_count[s];
     h->used_bytes = (unsigned long long)L.end;
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(dst);
+    tab[s] = (unsigned long long)off;
+    if (s == (int)gridDim.x - 1) tab[gridDim.x] = (unsigned long long)(off + out_record_bytes(n, m, stereo));   // end of the step's data
   } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 45) {
     OutHeader* h = reinterpret_cast<OutHeader*>(rec);
     const int i = threadIdx.x - 64;
@@ -179,8 +192,8 @@ __global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, St
 }
 
 void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, const StreamState& S, unsigned char* dst,
-                     size_t rec_stride, int rec_cap, hipStream_t st) {
-  hipLaunchKernelGGL(out_pack_kernel, dim3((unsigned)P.B), dim3(256), 0, st, P, k, ST, S, dst, rec_stride, rec_cap);
+                     size_t table_bytes, int rec_cap, hipStream_t st) {
+  hipLaunchKernelGGL(out_pack_kernel, dim3((unsigned)P.B), dim3(256), 0, st, P, k, ST, S, dst, table_bytes, rec_cap);
 }
 
 }  // namespace kvfe

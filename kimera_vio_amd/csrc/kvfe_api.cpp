@@ -155,10 +155,14 @@ struct kvfe_ctx {
   unsigned char* out_stage[OUT_RING] = {};
   hipEvent_t ev_packed[OUT_RING] = {}, ev_out[OUT_RING] = {};
   hipStream_t out_stream = nullptr;
-  size_t out_stride = 0;
+  size_t out_tab_bytes = 0, out_slot_size = 0;   // offset table in front of a slot's records / bytes of a slot
+  size_t out_copied[OUT_RING] = {};              // bytes of the slot the step's transfer covers
+  size_t out_guess = 0;                          // bytes the next transfer covers: the last known need + a margin
+  size_t out_guess_forced = 0;                   // KVFE_OUT_TRANSFER_BYTES (debugging aid: exercises the top-up path)
   int out_cap = 0;           // entries a record has room for: what a frame table can hold (pts_bound), not what it is allocated for
   bool out_direct = false;
   long long out_steps = 0;   // steps whose record has been enqueued; slot of step i = i % OUT_RING
+  long long out_topups = 0;  // accesses that had to fetch the rest of a step's records (locate_output)
   // dense stereo (allocated on first use, re-allocated when the volume geometry changes)
   DenseBuffers dense;
   std::vector<void*> dense_allocs;
@@ -869,16 +873,28 @@ kvfe_status enqueue_outputs(kvfe_ctx* c, const FrameTab& K, hipStream_t sd) {
   const int slot = (int)(c->out_steps % OUT_RING);
   Buffers& b = c->fe;
   if (c->out_direct) {
-    launch_out_pack(c->P, K, b.st, b.ss, c->out_host_dev[slot], c->out_stride, c->out_cap, sd);
+    launch_out_pack(c->P, K, b.st, b.ss, c->out_host_dev[slot], c->out_tab_bytes, c->out_cap, sd);
     HIPCHK(c, hipEventRecord(c->ev_out[slot], sd));
+    c->out_copied[slot] = c->out_slot_size;
   } else {
+    // what the newest COMPLETED transfer shows the records need (entry B of its table), plus a quarter and 64 KB
+    for (int back = 1; back < OUT_RING && back <= c->out_steps; back++) {
+      const int ps = (int)((c->out_steps - back) % OUT_RING);
+      if (hipEventQuery(c->ev_out[ps]) != hipSuccess) continue;
+      const size_t need = (size_t)reinterpret_cast<const unsigned long long*>(c->out_host[ps])[c->P.B];
+      if (need >= c->out_tab_bytes && need <= c->out_slot_size)
+        c->out_guess = std::min(c->out_slot_size, (need + need / 4 + 65536 + 255) & ~(size_t)255);
+      break;
+    }
+    const size_t bytes = c->out_guess_forced ? std::min(c->out_slot_size, std::max(c->out_tab_bytes, c->out_guess_forced))
+                                             : c->out_guess;
     if (c->out_steps >= OUT_RING) HIPCHK(c, hipStreamWaitEvent(sd, c->ev_out[slot], 0));   // the slot's last transfer read it
-    launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_stride, c->out_cap, sd);
+    launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_tab_bytes, c->out_cap, sd);
     HIPCHK(c, hipEventRecord(c->ev_packed[slot], sd));
     HIPCHK(c, hipStreamWaitEvent(c->out_stream, c->ev_packed[slot], 0));
-    HIPCHK(c, hipMemcpyAsync(c->out_host[slot], c->out_stage[slot], c->out_stride * (size_t)c->P.B, hipMemcpyDeviceToHost,
-                             c->out_stream));
+    HIPCHK(c, hipMemcpyAsync(c->out_host[slot], c->out_stage[slot], bytes, hipMemcpyDeviceToHost, c->out_stream));
     HIPCHK(c, hipEventRecord(c->ev_out[slot], c->out_stream));
+    c->out_copied[slot] = bytes;
   }
   c->out_steps++;
   return KVFE_OK;
@@ -1335,9 +1351,12 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     // (a frame table holds at most the tracked entries plus the new corners, each bounded by pts_bound -- the bound the
     // per-keypoint launches of the step use -- although it is allocated for kcap)
     c->out_cap = std::min(c->P.kcap, 2 * c->pts_bound);
-    c->out_stride = out_record_stride(c->out_cap);
+    c->out_tab_bytes = out_table_bytes(c->P.B);
+    c->out_slot_size = out_slot_bytes(c->P.B, c->out_cap);
+    c->out_guess = c->out_slot_size;   // (until a transfer has completed)
+    if (const char* e = getenv("KVFE_OUT_TRANSFER_BYTES")) c->out_guess_forced = (size_t)std::max(0ll, atoll(e));
     c->out_direct = c->P.B <= 4 || cfg->single_hip_stream != 0;
-    const size_t bytes = c->out_stride * (size_t)c->P.B;
+    const size_t bytes = c->out_slot_size;
     for (int i = 0; i < OUT_RING && s == KVFE_OK; i++) {
       void* h = nullptr;
       void* d = nullptr;
@@ -2508,7 +2527,21 @@ static kvfe_status locate_output(kvfe_ctx* c, int32_t s, int32_t steps_back, con
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
   }
-  *rec_out = c->out_host[slot] + (size_t)s * c->out_stride;
+  const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(c->out_host[slot]);
+  const size_t end = (size_t)tab[c->P.B];
+  if (end < c->out_tab_bytes || end > c->out_slot_size) {
+    c->last_error = "kvfe_frontend_get_output: the output slot holds no valid record table";
+    return KVFE_ERR_HIP;
+  }
+  if (end > c->out_copied[slot]) {   // the step needed more than its transfer was sized for: fetch the rest now
+    const size_t from = c->out_copied[slot];
+    HIPCHK(c, hipMemcpyAsync(c->out_host[slot] + from, c->out_stage[slot] + from, end - from, hipMemcpyDeviceToHost,
+                             c->out_stream));
+    HIPCHK(c, hipStreamSynchronize(c->out_stream));
+    c->out_copied[slot] = end;
+    c->out_topups++;
+  }
+  *rec_out = c->out_host[slot] + (size_t)tab[s];
   return KVFE_OK;
 }
 
@@ -2653,10 +2686,11 @@ kvfe_status kvfe_frontend_get_outputs(kvfe_ctx* c, int32_t steps_back, kvfe_fram
   std::vector<std::thread> pool;
   const int slot = (int)((c->out_steps - 1 - steps_back) % OUT_RING);
   const unsigned char* base = c->out_host[slot];
+  const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(base);   // (complete: the first call saw to it)
   for (int t = 0; t < nthr; t++)
     pool.emplace_back([&, t] {
       for (int s = 1 + t; s < B; s += nthr) {
-        const kvfe_status r = copy_output_record(c->out_cap, base + (size_t)s * c->out_stride, outs + s);
+        const kvfe_status r = copy_output_record(c->out_cap, base + (size_t)tab[s], outs + s);
         if (r != KVFE_OK) res[(size_t)t] = r;
       }
     });

@@ -429,9 +429,17 @@ __host__ __device__ inline OutLayout out_layout(int n, int m, bool stereo) {
   L.end = o;
   return L;
 }
-inline size_t out_record_stride(int rec_cap) { return (out_layout(rec_cap, rec_cap, true).end + 255) & ~(size_t)255; }
+// A step's slot: [table: B + 1 byte offsets (uint64; entry B = end of the data), 256-byte aligned][records back to back,
+// each 256-byte aligned].  Only the bytes in use cross PCIe: the host enqueues the transfer before it can know their
+// number, so it transfers what the last completed step needed plus a margin, and an access that finds a record beyond
+// that fetches the rest from the staging buffer first (kvfe_api.cpp locate_output).
+__host__ __device__ inline size_t out_record_bytes(int n, int m, bool stereo) {
+  return (out_layout(n, m, stereo).end + 255) & ~(size_t)255;
+}
+inline size_t out_table_bytes(int B) { return (sizeof(unsigned long long) * (size_t)(B + 1) + 255) & ~(size_t)255; }
+inline size_t out_slot_bytes(int B, int rec_cap) { return out_table_bytes(B) + (size_t)B * out_record_bytes(rec_cap, rec_cap, true); }
 void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, const StreamState& S, unsigned char* dst,
-                     size_t rec_stride, int rec_cap, hipStream_t st);
+                     size_t table_bytes, int rec_cap, hipStream_t st);
 void launch_mark_lost_tracks(const KParams& P, const FrameTab& km1, const LkScratch& lk, int max_pts, hipStream_t st);
 void launch_predict_flow(const KParams& P, const Tables& T, const double* R, const float2* prev,
                          int n, float2* out, hipStream_t st);

@@ -68,6 +68,22 @@ def _run_workload(wl, n_steps, check_streams, replicas_equal_at_end=True, persis
                     assert got[k] == ref[wl.unique_of(s)][k], (s, k)
                 for k in ("keypoints", "landmarks", "depth", "meas_uL_uR_v"):
                     assert np.array_equal(got[k], ref[wl.unique_of(s)][k], equal_nan=True), (s, k)
+        # kvfe_frontend_get_outputs (all streams in one call, copied by several threads from 16 streams up) against the
+        # per-stream accessor, for the last step and the one before it
+        bufs = ctx.output_buffers()
+        for back in ((0, 1) if n_steps > 1 else (0,)):
+            for arrs in bufs.arrays:      # (a frame without stereo data leaves the stereo arrays of the caller untouched)
+                for v in arrs.values():
+                    v[...] = 0
+            structs = bufs.read(back)
+            for s in range(wl.batch):
+                one = ctx.get_output(s, steps_back=back)
+                assert structs[s].n_keypoints == one["n_keypoints"] and structs[s].n_measurements == one["n_measurements"]
+                assert structs[s].frame_id == one["frame_id"] and structs[s].is_keyframe == one["is_keyframe"]
+                n, m = one["n_keypoints"], one["n_measurements"]
+                for k, _, _ in bufs.FIELDS:
+                    cnt = m if k.startswith("meas_") else n
+                    assert np.array_equal(bufs.arrays[s][k][:cnt], one[k], equal_nan=True), (back, s, k)
     finally:
         ctx.close()
     return kinds

@@ -95,6 +95,23 @@ def test_pipelined_host_steps_many_streams_output_stream(seq, ocam):
     _replay(seq, ocam, 0, B=6)
 
 
+def test_output_transfer_smaller_than_the_records():
+    """round 4: the step's records lie back to back behind an offset table and travel in one DMA transfer whose size the
+    host has to choose before the device knows the counts (the last completed step's need + a margin).  An access that
+    finds a record beyond the transferred bytes fetches the rest from the staging buffer.  KVFE_OUT_TRANSFER_BYTES (read
+    at kvfe_create, hence the sub-process) forces transfers of 4 KB -- less than one record -- so that every access of the
+    many-stream replay (last step and the two before it, every stream) goes through that path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_pipelined_r3.py") + "::test_pipelined_host_steps_many_streams_output_stream",
+                        os.path.join(root, "tests", "test_gpu_bench_configs.py") + "::test_c3_headline_64_streams_600_features"],
+                       env=dict(os.environ, KVFE_OUT_TRANSFER_BYTES="4096"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_mixed_identity_and_gyro_rotations_in_one_batch(seq, ocam):
     """the host skips the launch of the 3-point (Arun) stereo rejection when no stream of the batch needs
     it, with the SAME predicate the kernels use (rot_is_identity, kvfe_dev.hpp).  Streams 0 and 2 never get a gyro
