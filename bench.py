@@ -33,8 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALL_LEGS = ("nominal", "single_stream", "c5", "klt4", "kf_realistic", "outputs", "spinonce", "dense", "dense_c5", "pcie",
-            "input", "cpu")
+ALL_LEGS = ("nominal", "single_stream", "c5", "klt4", "kf_realistic", "outputs", "spinonce", "alone", "dense", "dense_c5",
+            "pcie", "input", "cpu")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -461,6 +461,18 @@ def main():
         result["outputs_inclusive"] = leg
     if solo and "spinonce" in args.legs:
         result["single_stream_spinonce"] = spinonce_leg(torch, F, dist, sharding, WL, dev, args)
+    if solo and "alone" in args.legs and args.config == "c3":
+        # the same step with every kernel in order on ONE HIP stream (kvfe_config.single_hip_stream): what the three
+        # dense kernels take when nothing runs beside them -- `roofline` above prices them inside the overlapped step
+        leg = run_frontend_leg(torch, F, dist, sharding, wl, dev, 1, 12, 4, 1, 0, 1, pmc.get("c3_" + args.mode),
+                               ctx_kw=dict(DEFAULT_CTX_KW, single_hip_stream=1))
+        result["dense_kernels_alone"] = {
+            "workload": "as `value`, kvfe_config.single_hip_stream = 1 (no side stream, no output stream), HIP events "
+                        "around every stage of 12 steps",
+            "ms_per_step": leg["ms_per_step"],
+            "kernels": [{k: r[k] for k in ("kernel", "avg_launch_ms", "achieved", "frac", "alg_bytes_per_launch") if k in r}
+                        for r in leg.get("roofline_kernels", [])],
+            "weighted": leg.get("roofline_dense_weighted")}
     if solo and "dense" in args.legs:
         result["dense_stereo"] = dense_stereo(F, WL, 752, 480, dev, pmc.get("dense"))
     if solo and "dense_c5" in args.legs:

@@ -8,6 +8,7 @@ import test_gpu_pyramid_r3 as T
 c=T._ctx(752,480,2,win=8); print('sanity ok')" || { echo "SANITY FAILED"; exit 1; }
 timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gpu_tests.log
 tail -4 gpurun_out/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 600 python bench.py $BENCH_ARGS > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
 python - <<'PY'
 import json
@@ -20,6 +21,7 @@ for k in ('nominal','single_stream','c5','klt_max_level_4','kf_realistic','outpu
 print("roofline", d.get('roofline'))
 print("weighted", d.get('roofline_dense_weighted'))
 for k in d.get('roofline_kernels', []): print("   ", k['kernel'], k['frac'], k['avg_launch_ms'], k.get('traffic'))
+print("alone", d.get('dense_kernels_alone'))
 PY
 if [ -n "$PROFILE" ]; then
 cd /tmp
