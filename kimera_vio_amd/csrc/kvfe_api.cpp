@@ -132,6 +132,7 @@ struct kvfe_ctx {
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
   bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
   bool fork_swap = false;                            // few streams: the corner refinement stays on the main stream (do_step)
+  bool serial_call = false;                          // this do_step call keeps every kernel on the main stream (see do_step)
   bool frames_persist_call = false;                  // this do_step call reads caller frames that stay valid for one more step
   bool chain_pending = false;                        // fork_swap: the side stream's outlier rejection has not been joined yet
   bool tail_pending = false;                          // the last step's tail has not been joined into the main stream yet
@@ -940,21 +941,25 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   struct SlotRelease {  // records the slot's event when do_step returns (all kernels enqueued), after the step's last
     kvfe_ctx* c;        // kernels on EITHER stream: once the step has forked, the side stream (which waits for the main
     int slot;           // stream's part before its tail) -- also on an error return between the fork and the tail event
-    hipStream_t st;
+    hipStream_t st, side;
     bool side_used = false, tail_recorded = false;
     ~SlotRelease() {
-      if (side_used && c->side) {
+      if (side_used && side) {
         if (!tail_recorded) {   // error path: the side stream has not been made to wait for the main stream yet
           hipEventRecord(c->ev_main, st);
-          hipStreamWaitEvent(c->side, c->ev_main, 0);
+          hipStreamWaitEvent(side, c->ev_main, 0);
         }
-        hipEventRecord(c->ring_ev[slot], c->side);
+        hipEventRecord(c->ring_ev[slot], side);
       } else {
         hipEventRecord(c->ring_ev[slot], st);
       }
       c->ring_used[slot] = true;
     }
-  } slot_release{c, slot, st};
+  } slot_release{c, slot, st, c->serial_call ? nullptr : c->side};
+  // (serial_call: frames that arrive over PCIe while the step runs -- kvfe_frontend_step_staged / _step_host -- keep every
+  // kernel on the main stream: with a transfer in flight each cross-stream hand-over of the forked step completes late,
+  // kvfe_frontend_step_staged below)
+  hipStream_t const side = c->serial_call ? nullptr : c->side;
 
   c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
   if (c->prof_on) {
@@ -967,7 +972,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   const FrameTab& KM1 = b.ft[c->role_km1];
   const FrameTab& LKF = b.ft[c->role_lkf];
   const int pc = c->pyr_cur, pp = pc ^ 1;
-  hipStream_t sd = c->side ? c->side : st;
+  hipStream_t sd = side ? side : st;
 
   prof_begin(c, ST_PYRAMID, st);
   launch_pyramid(P, left, row_stride, img_stride, b.pyr[pc], st, c->own_level0 ? b.lvl0[pc] : nullptr);
@@ -1083,9 +1088,9 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // awaited before the caller may reuse its buffers, and it stays on the main stream.  (Measured and not kept: starting
   // the chain only when the refinement is done -- the refinement gains 0.035 ms, the chain then runs beside the next
   // tracking launch, starved, and the tail gates the keyframe decision: step 1.145 -> 1.263 ms.)
-  const bool swap = c->side && (c->fork_swap || (c->frames_persist_call && c->own_stream && !P.mono));
+  const bool swap = side && (c->fork_swap || (c->frames_persist_call && c->own_stream && !P.mono));
   hipStream_t fa = swap ? st : sd, fb = swap ? sd : st;
-  if (c->side) {
+  if (side) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
     slot_release.side_used = true;
@@ -1093,7 +1098,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SUBPIX, fa);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, fa);
   prof_end(c, ST_SUBPIX, fa);
-  if (c->side && (c->own_stream || swap)) {
+  if (side && (c->own_stream || swap)) {
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
   }
@@ -1112,7 +1117,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // off the main stream's critical path (round 3: -1.2 % step time on four A/B pairs, +7 % on configs[4]).
   // NOTE for whoever edits launch_stereo_ransac / launch_pnp_frontend: they run concurrently with the NEXT step's
   // track_prepare and tracking launch and must therefore not write frame-table fields those read (K.kp, K.lmk, K.count).
-  const bool ransac_tail = c->side && !swap;
+  const bool ransac_tail = side && !swap;
   auto stereo_rejection = [&](hipStream_t rs) -> kvfe_status {
   prof_begin(c, ST_RANSAC_STEREO, rs);
   if (P.use_ransac) {
@@ -1131,7 +1136,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // the tail -- stereo matching of the new corners, finalisation -- runs on the side stream behind both parts of the
   // fork (the part on the main stream is awaited there); it is joined by the next step before its keyframe decision
   // (or by kvfe_synchronize / kvfe_frontend_get_output)
-  if (c->side) {
+  if (side) {
     if (swap) {
       HIPCHK(c, hipEventRecord(c->ev_main, sd));            // the chain (last reader of this frame's image slots) is done
       c->chain_pending = true;
@@ -1149,7 +1154,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, sd);
   prof_end(c, ST_FINALIZE, sd);
   TRY(enqueue_outputs(c, K, sd));
-  if (c->side) {
+  if (side) {
     HIPCHK(c, hipEventRecord(c->ev_tail, sd));
     c->tail_pending = true;
     slot_release.tail_recorded = true;
@@ -2426,7 +2431,15 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
     launch_equalize_hist(P.W, P.H, P.B, ur, P.W, N, dr, b.eq_hist + 256 * P.B, c->stream);
   }
   c->img_step++;
-  TRY(do_step(c, dl, dr, P.W, N, inputs));
+  {
+    // Every kernel of this step on the main stream (no fork): the next slot's upload is in flight while the step runs, and
+    // with a DMA transfer in flight the cross-stream hand-overs of the forked step complete late (round 4, tools/r4/
+    // staged_probe.py, 64 streams, 30 steps: 3.1 ms per step forked, 2.0 ms in order -- the upload itself is 0.86 ms).
+    c->serial_call = true;
+    const kvfe_status r = do_step(c, dl, dr, P.W, N, inputs);
+    c->serial_call = false;
+    if (r != KVFE_OK) return r;
+  }
   HIPCHK(c, hipEventRecord(c->step_done[n % 4], c->stream));
   c->step_done_valid[n % 4] = true;
   c->last_step_staged = true;
