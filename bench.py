@@ -36,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ALL_LEGS = ("nominal", "single_stream", "c5", "klt4", "kf_realistic", "outputs", "spinonce", "alone", "dense", "dense_c5",
             "pcie", "input", "cpu")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PREWARM = 40                 # untimed steps in front of every leg's warm-up (run_frontend_leg)
 
 
 def parse():
@@ -203,6 +204,11 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
     torch.cuda.synchronize()
     ctx = F.Context(wl.left, wl.right, wl.params, batch=B, device=dev.index, stream_groups=groups,
                     **(DEFAULT_CTX_KW if ctx_kw is None else ctx_kw))
+    # PREWARM untimed steps in front of the W warm-up steps the command line asks for: the first ~30 steps (~35 ms) after
+    # the seconds of host-side set-up run 20 - 35 % slow (round 4, tools/r4/gpu_z.sh: ten regions of 20 steps read
+    # 39 / 65 / 58 / 58 ... k pairs/s after 8 warm-up steps, 59 / 64 / 58 / 58 ... after 60) -- clocks and the PCIe link of
+    # a device that has just been idle, not this library; the timed regions are untouched (exactly K steps each)
+    warmup = warmup + PREWARM
     total = warmup + repeats * steps
     plan = [(st[0], wl.batch_inputs(ctx, st)) for st in wl.plan(total)]   # host work outside the timed region
     # read_outputs: the consumer side inside the timed region -- after enqueuing step i the host copies the complete
@@ -390,7 +396,7 @@ def main():
     result = {
         "metric": f"stereo-pairs/sec front-end (detect+track+match) @{W}x{H}",
         "value": main_leg["value"], "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"],
+        "warmup": args.warmup, "prewarm_steps_untimed": PREWARM, "ms_per_step": main_leg["ms_per_step"],
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/int32+f32",
         "data": f"synthetic ({src})",
         "config": {"workload": f"BASELINE {args.config}: batched {B} {W}x{H} stereo streams per GPU, "
