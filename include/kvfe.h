@@ -261,11 +261,14 @@ typedef struct kvfe_config {
                                     different groups can overlap (always 1 with
                                     hip_stream).  Measured on MI355X: 1 is fastest    */
   /* ---- execution options (round 4: these were environment variables of the library) ---- */
-  int32_t device_frames_persist; /* kvfe_frontend_step_device only.  1 = the caller guarantees that the LEFT image
-                                    of a step stays valid and unchanged until the NEXT step has completed (frames
-                                    resident in a device ring): tracking then reads frame k-1 from the caller's
-                                    buffer and the context does not keep its own copy (one image write per frame
-                                    less).  0 (default): no caller pointer outlives a step                       */
+  int32_t device_frames_persist; /* kvfe_frontend_step_device only.  1 = the caller guarantees that BOTH images of
+                                    a step stay valid and unchanged until the NEXT step has completed (frames
+                                    resident in a device ring of >= 2 entries): tracking then reads frame k-1 from
+                                    the caller's buffer and the context does not keep its own copy (one image write
+                                    per frame less), and the rectification / matching chain of step k -- which
+                                    reads both images -- is joined by step k+1's keyframe decision instead of in
+                                    front of its tracking launch.  0 (default): no caller
+                                    pointer outlives a step                                                       */
   int32_t single_hip_stream;     /* 1 = every kernel of a step on the context's one HIP stream: no internal side
                                     stream (corner refinement beside rectification / matching) and no output stream.
                                     For callers that need strict single-stream order and for timing kernels alone  */
