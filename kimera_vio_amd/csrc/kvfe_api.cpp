@@ -1023,6 +1023,25 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
     c->ev_tracked_valid = true;
   }
+  // Rectification right behind the keyframe decision, on the side stream, when the caller FORCES a keyframe on every
+  // stream (then the host knows that the step rectifies; otherwise the decision is the device's) and the chain is on the
+  // side stream anyway: beside the mono rejection, the min-eigenvalue launch and the selection it runs at the speed it has
+  // alone -- 0.046 ms instead of 0.167 ms beside cornerSubPix, whose blocks leave LDS room for one rectification block
+  // per CU -- and cornerSubPix loses a neighbour (0.423 -> 0.401 ms): step 1.076 -> 1.070 ms, real frames +1.6 %
+  // (tools/r4/gpu_aa.sh).  Without forced keyframes three of four steps would pay the extra hand-over for nothing (-2 %
+  // at the reference cadence), so those keep the rectification at the head of the chain.
+  bool all_forced = side && !P.mono && (c->fork_swap || (c->frames_persist_call && c->own_stream));
+  for (int s = 0; s < P.B && all_forced; s++) all_forced = inputs[s].force_keyframe != 0;
+  const bool rect_early = all_forced;
+  if (rect_early) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
+    prof_begin(c, ST_RECTIFY, sd);
+    const unsigned char* srcs[2] = {left, right};
+    launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, sd);
+    prof_end(c, ST_RECTIFY, sd);
+    slot_release.side_used = true;
+  }
   // keyframes: mono geometric outlier rejection before detection (it frees landmarks, so more
   // corners are extracted, StereoVisionImuFrontend.cpp:349-363,413-417)
   prof_begin(c, ST_RANSAC_MONO, st);
@@ -1102,12 +1121,14 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
   }
+  if (!rect_early) {
   prof_begin(c, ST_RECTIFY, fb);
   {
     const unsigned char* srcs[2] = {left, right};
     launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, fb);
   }
   prof_end(c, ST_RECTIFY, fb);
+  }
   prof_begin(c, ST_STEREO, fb);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, fb);
   prof_end(c, ST_STEREO, fb);
