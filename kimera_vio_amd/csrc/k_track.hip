@@ -446,10 +446,12 @@ __device__ __forceinline__ int perm_b32(int hi, int lo, unsigned sel) {
   return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, sel);
 }
 
-// six waves per SIMD up to the reference's window of 24 (80 VGPRs without spilling, 4.8 KB of LDS per point); a window
-// of 32 keeps 16 pixels per lane in registers and stays at five
+// seven waves per SIMD up to the reference's window of 24 (72 VGPRs, 8 spilled to scratch, 4.8 KB of LDS per point; round 4,
+// tools/r4/gpu_ab.sh: 0.534 -> 0.530 ms against six waves at 80 VGPRs without spills -- the launch hardly notices the
+// seventh wave: it is bound by instruction issue of all categories plus its tail); a window of 32 keeps 16 pixels per
+// lane in registers and stays at five
 template <int WIN>
-__global__ __launch_bounds__(64, (WIN <= 24 ? 6 : 5)) void lk_kernel_sys(KParams P, const unsigned char* prev_img,
+__global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams P, const unsigned char* prev_img,
                                                     size_t prev_row_stride,
                                                     size_t prev_img_stride,
                                                     const unsigned char* prev_pyr,
