@@ -101,6 +101,17 @@ struct MeRow {          // per-lane values of one image row at the different pip
 typedef int me_v4i __attribute__((ext_vector_type(4)));
 constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig2_kernel (row-need masks: 128 bits incl. margins)
 
+// -DKVFE_ME_PROF (debugging aid, tools/r4/gpu_ac.sh): cycle stamps per wave of the last launch.  Round 4, 64 x 752x480 with
+// ~590 keypoints per stream: mean wave 73 k cycles (mask phase 26 k, row loop 43 k with 25 of 85 pixel rows needed,
+// epilogue 4 k), SLOWEST wave 175 k -- a strip with no keypoint near it needs every row, and the launch (one round of
+// waves) lasts as long as that wave.  Strips of 60 / 40 rows: slowest 154 / 155 k, launch 0.083 / 0.092 ms against 0.079 (the
+// mask phase does not shrink with the strip: 23 k).  Two waves per block sharing one mask phase, each walking half the
+// strip (tools/r4/gpu_ad.sh, 109 parity tests green): 0.087 against 0.080 ms, real frames 0.110 against 0.089,
+// 1280x720 0.154 against 0.113 -- not kept.
+#ifdef KVFE_ME_PROF
+constexpr size_t KVFE_ME_PROF_WAVES = 8192;
+__device__ unsigned long long kvfe_me_prof[KVFE_ME_PROF_WAVES * 8];   // per wave: cycles of the mask phase, the row loop, the epilogue; 1; needed pixel rows; rows walked; start; end
+#endif
 template <bool HAS_MASK>
 __global__ __launch_bounds__(64) void mineig2_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
@@ -113,6 +124,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // block -> (column strip, row strip, stream).  (An XCD-banded 1-D order was measured in round 3: 0.084 against 0.082 ms.)
   const int s = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
   if (flags && !(flags[s] & FLAG_DETECT)) return;
+#ifdef KVFE_ME_PROF
+  const unsigned long long me_t0 = __builtin_readcyclecounter();
+#endif
   __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
   __shared__ unsigned long long lcand[ME_LCAP];
   __shared__ int hw_s[MAX_RADIUS + 1];
@@ -206,6 +220,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     needp1 = needb1 | (needb1 << 1) | (needb1 << 2) | (needb0 >> 63) | (needb0 >> 62);
   }
   __syncthreads();
+#ifdef KVFE_ME_PROF
+  const unsigned long long me_t1 = __builtin_readcyclecounter();
+#endif
 
   const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0));  // (float)scale, blockSize 3, ksize 3
   const float f0 = 2.0f * f1;
@@ -474,6 +491,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   }
   // the row requests issued beyond the last step are still in flight: they land before their registers are re-used
   asm volatile("s_waitcnt vmcnt(0)" : : : "a0", "a1", "a2", "memory");
+#ifdef KVFE_ME_PROF
+  const unsigned long long me_t2 = __builtin_readcyclecounter();
+#endif
   __syncthreads();
   flush();
   for (int off = 32; off > 0; off >>= 1) bestv = fmaxf(bestv, __shfl_xor(bestv, off));
@@ -482,12 +502,52 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   if (lane == 0 && bestkey &&
       bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&maxkey[s], bestkey);
+#ifdef KVFE_ME_PROF
+  if (lane == 0) {   // one record per wave of the LAST launch (no atomics: they would be what is measured)
+    const unsigned long long me_t3 = __builtin_readcyclecounter();
+    const size_t w = ((size_t)s * gridDim.y + by) * gridDim.x + bx;
+    if (w < KVFE_ME_PROF_WAVES) {
+      unsigned long long* o = kvfe_me_prof + w * 8;
+      o[0] = me_t1 - me_t0;
+      o[1] = me_t2 - me_t1;
+      o[2] = me_t3 - me_t2;
+      o[3] = 1ull;
+      o[4] = (unsigned long long)(__popcll(needp0) + __popcll(needp1));
+      o[5] = (unsigned long long)(r_last - r_first + 1);
+      o[6] = me_t0;
+      o[7] = me_t3;
+    }
+  }
+#endif
 }
 
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
   // D.cand_count / D.maxkey are zero here: allocated zeroed, re-zeroed by every select_kernel
+#ifdef KVFE_ME_PROF
+  {
+    static bool reg = false;
+    if (!reg) {
+      reg = true;
+      std::atexit([] {
+        static unsigned long long h[KVFE_ME_PROF_WAVES * 8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_me_prof), sizeof(h)) != hipSuccess) return;
+        double a[6] = {0, 0, 0, 0, 0, 0}, longest = 0;
+        for (size_t w = 0; w < KVFE_ME_PROF_WAVES; w++) {
+          const unsigned long long* o = h + w * 8;
+          if (!o[3]) continue;
+          for (int i = 0; i < 6; i++) a[i] += (double)o[i];
+          longest = std::max(longest, (double)(o[7] - o[6]));
+        }
+        if (a[3] > 0)
+          std::fprintf(stderr, "KVFE_ME_PROF last launch: waves %.0f, cycles per wave: mask phase %.0f | row loop %.0f | epilogue %.0f | "
+                       "longest wave %.0f; pixel rows needed %.1f of %.1f walked\n", a[3], a[0] / a[3], a[1] / a[3], a[2] / a[3],
+                       longest, a[4] / a[3], a[5] / a[3]);
+      });
+    }
+  }
+#endif
   static int simds = 0;
   if (!simds) {
     hipDeviceProp_t prop;
@@ -511,6 +571,9 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     const double cost = (double)((waves + simds - 1) / simds) * (rws + 5);
     if (cost < best) best = cost, strip_rows = rws;
   }
+#ifdef KVFE_ME_ROWS_OVERRIDE   // (with KVFE_ME_PROF: strip height of the A/B builds)
+  strip_rows = KVFE_ME_ROWS_OVERRIDE;
+#endif
   const int ny = (P.H + strip_rows - 1) / strip_rows;
   const dim3 grid((unsigned)nx, (unsigned)ny, (unsigned)P.B);
   if (user_mask)
