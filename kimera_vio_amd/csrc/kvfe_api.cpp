@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -956,9 +957,8 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
       c->ring_used[slot] = true;
     }
   } slot_release{c, slot, st, c->serial_call ? nullptr : c->side};
-  // (serial_call: frames that arrive over PCIe while the step runs -- kvfe_frontend_step_staged / _step_host -- keep every
-  // kernel on the main stream: with a transfer in flight each cross-stream hand-over of the forked step completes late,
-  // kvfe_frontend_step_staged below)
+  // (serial_call: frames that arrive over PCIe while the step runs -- kvfe_frontend_step_staged -- keep every kernel on the
+  // main stream: with a transfer in flight each cross-stream hand-over of the forked step completes late, see there)
   hipStream_t const side = c->serial_call ? nullptr : c->side;
 
   c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
@@ -2716,18 +2716,24 @@ kvfe_status kvfe_frontend_get_outputs(kvfe_ctx* c, int32_t steps_back, kvfe_fram
   kvfe_status first = kvfe_frontend_get_output_at(c, 0, steps_back, outs);
   if (first != KVFE_OK && first != KVFE_ERR_CAPACITY) return first;
   std::vector<kvfe_status> res((size_t)nthr, KVFE_OK);
-  std::vector<std::string> err((size_t)nthr);
   std::vector<std::thread> pool;
   const int slot = (int)((c->out_steps - 1 - steps_back) % OUT_RING);
   const unsigned char* base = c->out_host[slot];
   const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(base);   // (complete: the first call saw to it)
-  for (int t = 0; t < nthr; t++)
-    pool.emplace_back([&, t] {
-      for (int s = 1 + t; s < B; s += nthr) {
-        const kvfe_status r = copy_output_record(c->out_cap, base + (size_t)tab[s], outs + s);
-        if (r != KVFE_OK) res[(size_t)t] = r;
-      }
-    });
+  auto work = [&](int t) {
+    for (int s = 1 + t; s < B; s += nthr) {
+      const kvfe_status r = copy_output_record(c->out_cap, base + (size_t)tab[s], outs + s);
+      if (r != KVFE_OK) res[(size_t)t] = r;
+    }
+  };
+  for (int t = 1; t < nthr; t++) {
+    try {
+      pool.emplace_back(work, t);
+    } catch (const std::system_error&) {   // no thread to be had: this one does the share itself
+      work(t);
+    }
+  }
+  work(0);
   for (auto& th : pool) th.join();
   kvfe_status worst = first;
   for (kvfe_status r : res)
