@@ -124,7 +124,9 @@ typedef struct kvfe_camera_params {
 /* VIO::FeatureDetectorParams + SubPixelCornerFinderParams
  * (include/kimera-vio/frontend/feature-detector/FeatureDetectorParams.h:25-106) */
 typedef struct kvfe_detector_params {
-  int32_t feature_detector_type;             /* only KVFE_DET_GFTT           */
+  int32_t feature_detector_type;             /* KVFE_DET_GFTT (all shipped parameter sets) or KVFE_DET_FAST
+                                                (cv::FastFeatureDetector(fast_thresh, true)); ORB / AGAST:
+                                                KVFE_ERR_UNSUPPORTED            */
   int32_t max_features_per_frame;            /* maxFeaturesPerFrame          */
   int32_t enable_subpixel_corner_refinement;
   int32_t subpix_window_size;                /* window_size (half window)    */
@@ -142,8 +144,7 @@ typedef struct kvfe_detector_params {
   int32_t use_harris_detector;
   double k;
   int32_t sortidx_policy;                    /* KVFE_SORTIDX_*               */
-  int32_t fast_thresh;                       /* fast_thresh (FAST / ORB only: parsed and carried, those
-                                                detector types are KVFE_ERR_UNSUPPORTED) */
+  int32_t fast_thresh;                       /* fast_thresh (KVFE_DET_FAST)  */
 } kvfe_detector_params;
 
 /* VIO::TrackerParams (include/kimera-vio/frontend/VisionImuTrackerParams.h:24-85).

@@ -49,6 +49,7 @@ constexpr int ME_HALO = 3;
 constexpr int ME_COLS = 64 - 2 * ME_HALO;  // 58 output columns per wave
 constexpr int ME_ROWS = 64;                // most output rows per wave (rows per strip is a launch parameter)
 constexpr int ME_LCAP = 256;               // LDS candidate buffer (flushed when nearly full); small = 8 waves per SIMD
+constexpr int ME_WAVES_PER_SIMD = 5;       // resident waves of the min-eigenvalue launch (its register count admits 5)
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i <- lane i-1
   return __builtin_bit_cast(
@@ -86,6 +87,155 @@ struct MeRow {          // per-lane values of one image row at the different pip
 };
 
 // ---------------------------------------------------------------------------------------------
+// Detection mask and work list of the min-eigenvalue launch (round 5).
+//
+// Round 4's launch was ONE round of one-wave workgroups, each of which (a) tested all ~590 tracked keypoints of its
+// stream against its own strip to rasterise the cv::circle discs (26 k of a wave's mean 73 k cycles, 4 992 times per
+// launch) and (b) lasted as long as its strip had unmasked rows -- the launch ended with the slowest wave, 175 k cycles.
+// Now one block per stream (mineig_prep_kernel) rasterises the stream's discs ONCE into a bitmap of masked-out pixels
+// in HBM (bit x + 64 of row y, rows of MW 64-bit words: a strip's 64 lane columns are two words and a funnel shift),
+// derives from it the number of pixel rows every (column strip, row strip) item will have to walk -- exactly the
+// row-need masks the wave itself computes -- and writes the stream's items ordered by that cost, heaviest first, items
+// nobody needs dropped, and their summed cost.  The min-eigenvalue launch is a fixed number of waves (what the device
+// holds at once); every wave derives from the 64 stream costs which stream it serves -- streams get waves in proportion
+// to their cost, at least one -- takes its first item by its position among the stream's waves and PULLS the rest off the
+// stream's own atomic counter: the heavy strips start first, and a SIMD that is stuck with several of them simply pulls
+// less of the light rest.  (First form of this round: ONE counter for the launch -- 10 k returning device-scope
+// atomics on one word take 0.11 ms on this chip, 88 per microsecond; tools/r5/gpu_a.sh.)
+// ---------------------------------------------------------------------------------------------
+constexpr int MEP_T = 1024;
+constexpr int ME_COUNTER_STRIDE = 1024;    // unsigned words between two streams' work counters: one memory channel each (returning
+                                           // device-scope atomics on neighbouring words queue behind each other: 88 per microsecond)
+constexpr int ME_ITEM_OVERHEAD_ROWS = 6;   // what an item costs besides its rows (mask words, pipeline fill, flush), in row steps
+// (me_mask_words / me_max_items: kvfe_dev.hpp, the context sizes the scratch with them)
+// the 64 mask bits of lane columns x0 .. x0 + 63 (x0 >= -64) of a bitmap row
+__device__ __forceinline__ unsigned long long me_row_bits(const unsigned long long* row, int x0) {
+  const int p = x0 + 64;
+  const unsigned long long w0 = row[p >> 6], w1 = row[(p >> 6) + 1];
+  const int sh = p & 63;
+  return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+}
+// Rows nobody needs.  lambda matters only at pixels that pass the detection mask (masked maximum, candidates) and at
+// their 8 neighbours (the 3x3 maximum): U(y) = row y of the strip has an unmasked output pixel; box row b is needed
+// iff U(b-1) | U(b) | U(b+1), cov row c iff one of the box rows c-1 .. c+1 is.  With a few hundred tracked keypoints
+// and discs of radius min_distance most of a frame is masked, and whole 58-pixel row segments drop out (cv::
+// goodFeaturesToTrack computes them and throws them away).  Bit i + 2 of the 128-bit masks = strip row i; u_lo / u_hi =
+// U of strip rows 0..63 / 64..127 (strip_rows <= 120, so nothing falls off the top).
+struct MeNeed {
+  unsigned long long c0, c1, b0, b1, p0, p1;
+};
+__device__ __forceinline__ MeNeed me_need_masks(unsigned long long u_lo, unsigned long long u_hi) {
+  const unsigned long long U0 = u_lo << 2, U1 = (u_hi << 2) | (u_lo >> 62);
+  auto or3 = [](unsigned long long x0, unsigned long long x1, unsigned long long& y0, unsigned long long& y1) {
+    y0 = x0 | (x0 << 1) | (x0 >> 1) | (x1 << 63);
+    y1 = x1 | (x1 << 1) | (x0 >> 63) | (x1 >> 1);
+  };
+  MeNeed n;
+  or3(U0, U1, n.c0, n.c1);
+  or3(n.c0, n.c1, n.b0, n.b1);
+  // cov row c (bit c - ys + 2 of needb) reads the pixel rows c-1 .. c+1: bits q-2, q-1, q of needb -> bit q of needp
+  // (bit q = pixel row ys - 3 + q; the highest cov bit is 123, nothing falls off the top)
+  n.p0 = n.b0 | (n.b0 << 1) | (n.b0 << 2);
+  n.p1 = n.b1 | (n.b1 << 1) | (n.b1 << 2) | (n.b0 >> 63) | (n.b0 >> 62);
+  return n;
+}
+
+__global__ __launch_bounds__(MEP_T) void mineig_prep_kernel(
+    int W, int H, int kcap, int radius, const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
+    const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
+    const int* __restrict__ flags, unsigned long long* __restrict__ maskbits, int MW, int band_rows,
+    unsigned* __restrict__ items, int* __restrict__ n_items, int max_items, int nx, int ny, int strip_rows,
+    unsigned* __restrict__ counter, int* __restrict__ cost_total) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) counter[(size_t)s * ME_COUNTER_STRIDE] = 0u;   // the stream's work counter of the launch that follows
+  if (flags && !(flags[s] & FLAG_DETECT)) {
+    if (tid == 0) n_items[s] = 0, cost_total[s] = 0;
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char mep_lds[];
+  __shared__ int hw_s[MAX_RADIUS + 1];
+  __shared__ int n_pos, c_sum;
+  unsigned long long* band = reinterpret_cast<unsigned long long*>(mep_lds);              // [band_rows][MW]
+  int* cxy = reinterpret_cast<int*>(mep_lds + sizeof(unsigned long long) * (size_t)band_rows * MW);   // [kcap] x | y << 16
+  unsigned short* cost_s = reinterpret_cast<unsigned short*>(cxy + kcap);               // [max_items]
+  unsigned long long* MB = maskbits + (size_t)s * H * MW;
+  const int nk = use_discs ? min(kp_count[s], kcap) : 0;
+  const int nr = 2 * radius + 1;
+  for (int i = tid; i <= radius && i <= MAX_RADIUS; i += MEP_T) hw_s[i] = circle_hw[i];
+  // only keypoints with a landmark mask (FeatureDetector.cpp:191); cv::Point(Point2f) rounds.  Centres far outside the
+  // image cannot touch it and are dropped (the packed form holds +-32 K)
+  for (int i = tid; i < nk; i += MEP_T) {
+    const float2 k = kp_all[(size_t)s * kcap + i];
+    const int cx = __float2int_rn(k.x), cy = __float2int_rn(k.y);
+    const bool on = lmk_all[(size_t)s * kcap + i] != -1 && cx + radius >= 0 && cx - radius < W && cy + radius >= 0 &&
+                    cy - radius < H;
+    cxy[i] = on ? ((cx + 16384) & 0xffff) | ((cy + 16384) << 16) : -1;
+  }
+  if (tid == 0) n_pos = 0, c_sum = 0;
+  for (int y0 = 0; y0 < H; y0 += band_rows) {
+    const int y1 = min(y0 + band_rows, H);
+    __syncthreads();
+    for (int i = tid; i < (y1 - y0) * MW; i += MEP_T) band[i] = 0ull;
+    __syncthreads();
+    for (int idx = tid; idx < nk * nr; idx += MEP_T) {
+      const int d = idx / nr, dy = idx - d * nr - radius;
+      const int c = cxy[d];
+      if (c == -1) continue;
+      const int cx = (c & 0xffff) - 16384, cy = (int)((unsigned)c >> 16) - 16384;
+      const int y = cy + dy;
+      if (y < y0 || y >= y1) continue;
+      const int hw = hw_s[abs(dy)];
+      const int pa = max(cx - hw, 0) + 64, pb = min(cx + hw, W - 1) + 64;
+      if (pa > pb) continue;
+      unsigned long long* row = band + (size_t)(y - y0) * MW;
+      for (int w = pa >> 6; w <= (pb >> 6); w++) {
+        const int lo = max(pa - (w << 6), 0), hi = min(pb - (w << 6), 63);
+        const unsigned long long m = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
+        atomicOr(&row[w], m);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < (y1 - y0) * MW; i += MEP_T) MB[(size_t)y0 * MW + i] = band[i];
+  }
+  __syncthreads();   // the block's own writes to MB are visible to all of its threads
+  // cost of every item = pixel rows its wave will walk (the wave's own row-need masks), one wave per item
+  const int n_all = nx * ny;
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int it = wv; it < n_all; it += MEP_T / 64) {
+    const int bx = it % nx, by = it / nx;
+    const int ys = by * strip_rows, ye = min(ys + strip_rows, H);
+    const int x0 = bx * ME_COLS - ME_HALO;
+    const int gx = x0 + lane;
+    const unsigned long long om = __ballot(lane >= ME_HALO && lane < 64 - ME_HALO && gx < W);
+    const int r0 = ys + lane, r1 = ys + 64 + lane;
+    // (one band = the whole bitmap is still in LDS: a global round trip per item would be most of this kernel's time)
+    const unsigned long long* src = band_rows >= H ? band : MB;
+    const unsigned long long m0 = r0 < ye ? me_row_bits(src + (size_t)r0 * MW, x0) : ~0ull;
+    const unsigned long long m1 = r1 < ye ? me_row_bits(src + (size_t)r1 * MW, x0) : ~0ull;
+    const unsigned long long u_lo = __ballot(r0 < ye && (om & ~m0) != 0ull);
+    const unsigned long long u_hi = __ballot(r1 < ye && (om & ~m1) != 0ull);
+    const MeNeed nd = me_need_masks(u_lo, u_hi);
+    if (lane == 0 && it < max_items) cost_s[it] = (unsigned short)(__popcll(nd.p0) + __popcll(nd.p1));
+  }
+  __syncthreads();
+  // heaviest first; an item nobody needs is dropped (its wave would find no row to walk)
+  for (int i = tid; i < min(n_all, max_items); i += MEP_T) {
+    const int ci = cost_s[i];
+    if (ci == 0) continue;
+    int rank = 0;
+    for (int j = 0; j < min(n_all, max_items); j++) {
+      const int cj = cost_s[j];
+      rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
+    }
+    items[(size_t)s * max_items + rank] = (unsigned)i | ((unsigned)ci << 16);
+    atomicAdd(&n_pos, 1);
+    atomicAdd(&c_sum, ci + ME_ITEM_OVERHEAD_ROWS);
+  }
+  __syncthreads();
+  if (tid == 0) n_items[s] = n_pos, cost_total[s] = c_sum;
+}
+
+// ---------------------------------------------------------------------------------------------
 // mineig2_kernel: the same pipeline and the same arithmetic, restructured around what bounds it (instruction issue,
 // every category: profiles/r2_v5_lk_analysis.md, tools/ubench/valu_rate.hip):
 //   * the strip's rows are split into a prologue, a STEADY part and an epilogue.  Every stage is live and no row
@@ -110,30 +260,104 @@ constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig
 // 1280x720 0.154 against 0.113 -- not kept.
 #ifdef KVFE_ME_PROF
 constexpr size_t KVFE_ME_PROF_WAVES = 8192;
-__device__ unsigned long long kvfe_me_prof[KVFE_ME_PROF_WAVES * 8];   // per wave: cycles of the mask phase, the row loop, the epilogue; 1; needed pixel rows; rows walked; start; end
+__device__ unsigned long long kvfe_me_prof[KVFE_ME_PROF_WAVES * 8];   // per wave: cycles of the mask phase, the row loop, the epilogue; items; needed pixel rows; rows walked; start; end
 #endif
-template <bool HAS_MASK>
+template <bool HAS_MASK, bool HARRIS>
 __global__ __launch_bounds__(64) void mineig2_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
-    const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
-    const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
-    const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
-    const int* __restrict__ flags,
+    const unsigned char* __restrict__ user_mask, int W, int H, int ccap,
+    const unsigned long long* __restrict__ maskbits, int MW, const unsigned* __restrict__ items,
+    const int* __restrict__ n_items, int max_items, unsigned* __restrict__ counter, const int* __restrict__ cost_total,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, int /*unused*/) {
-  // block -> (column strip, row strip, stream).  (An XCD-banded 1-D order was measured in round 3: 0.084 against 0.082 ms.)
-  const int s = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (flags && !(flags[s] & FLAG_DETECT)) return;
+    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, float harris_kf, double harris_kd) {
+  __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
+  __shared__ unsigned long long lcand[ME_LCAP];
+  const int lane = threadIdx.x;
+  // ---- which stream does this wave serve?  Stream t gets 1 + floor((G - A) cost_t / T) of the G waves of the launch (A
+  // streams with work, T their summed cost); the few waves left over go round the streams with work once more.  Every
+  // wave derives the same table from the B stream costs (lane = stream, B / 64 rounds) and keeps its own entry.
+  int s = -1, first_rank = -1, share = 0;   // stream; the wave's position among the stream's regular waves; their number
+  {
+    const int G = (int)gridDim.x, w = (int)blockIdx.x;
+    long long T = 0;
+    int A = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      const int c = b0 + lane < B ? cost_total[b0 + lane] : 0;
+      long long v = c;
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+      T += v;
+      A += __popcll(__ballot(c > 0));
+    }
+    if (A == 0) return;      // no stream detects in this step
+    const int spare = max(G - A, 0);
+    int first = 0;           // first wave of the 64 streams under the scan
+    for (int b0 = 0; b0 < B && s < 0; b0 += 64) {
+      const int c = b0 + lane < B ? cost_total[b0 + lane] : 0;
+      const int mine = c > 0 ? 1 + (int)(((long long)spare * c) / T) : 0;
+      int inc = mine;        // inclusive scan over the lanes
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+      }
+      const int lo = first + inc - mine;
+      const unsigned long long hit = __ballot(mine > 0 && w >= lo && w < lo + mine);
+      if (hit) {
+        const int l = __builtin_ctzll(hit);
+        s = b0 + l;
+        first_rank = w - __builtin_amdgcn_readlane(lo, l);
+        share = __builtin_amdgcn_readlane(mine, l);
+      }
+      first += __builtin_amdgcn_readfirstlane(__shfl(inc, 63));
+    }
+    if (s < 0) {             // a left-over wave: one more for the ((w - first) mod A)-th stream with work, pulls only
+      int k = (w - first) % A;
+      for (int b0 = 0; b0 < B && s < 0; b0 += 64) {
+        const int c = b0 + lane < B ? cost_total[b0 + lane] : 0;
+        const unsigned long long act = __ballot(c > 0);
+        const int na = __popcll(act);
+        if (k < na) {
+          unsigned long long m = act;
+          for (int i = 0; i < k; i++) m &= m - 1;
+          const int l = __builtin_ctzll(m);
+          s = b0 + l;
+          share = 1 + (int)(((long long)spare * __builtin_amdgcn_readlane(c, l)) / T);
+        }
+        k -= na;
+      }
+    }
+    if (s < 0) return;       // (cannot happen: k < A)
+    s = __builtin_amdgcn_readfirstlane(s);
+    share = __builtin_amdgcn_readfirstlane(share);
+    first_rank = __builtin_amdgcn_readfirstlane(first_rank);
+  }
+  const int n_mine = n_items[s];
+#ifdef KVFE_ME_PROF
+  unsigned long long me_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long me_start = __builtin_readcyclecounter();
+#endif
+  // Work items, heaviest first: the wave's FIRST item is its position among the stream's regular waves (no atomic: all
+  // waves of the launch start at once), the others come off the stream's counter -- a pulled value c stands for rank
+  // share + c -- and the next one is requested while the current one is worked on (the atomic's round trip is hidden
+  // behind the strip).
+  unsigned* const ctr = counter + (size_t)s * ME_COUNTER_STRIDE;
+  auto pull = [&]() -> int {
+    unsigned v = 0;
+    if (lane == 0) v = atomicAdd(ctr, 1u);
+    return share + (int)v;
+  };
+  int id_next = first_rank >= 0 ? first_rank : pull();
+  for (;;) {
+  const int rank = __builtin_amdgcn_readfirstlane(id_next);
+  if (rank >= n_mine) break;
+  id_next = pull();
+  const unsigned item = items[(size_t)s * max_items + rank] & 0xffffu;
+  const int bx = (int)item % nx, by = (int)item / nx;
 #ifdef KVFE_ME_PROF
   const unsigned long long me_t0 = __builtin_readcyclecounter();
 #endif
-  __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
-  __shared__ unsigned long long lcand[ME_LCAP];
-  __shared__ int hw_s[MAX_RADIUS + 1];
 
   const unsigned char* I = img + (size_t)s * img_stride;
   const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
-  const int lane = threadIdx.x;
   const int xs = bx * ME_COLS, ys = by * strip_rows;
   const int ye = min(ys + strip_rows, H);
   const int x0 = xs - ME_HALO;          // column of lane 0
@@ -142,82 +366,24 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   const bool out_col = lane >= ME_HALO && lane < 64 - ME_HALO && gx < W;
   const bool at_left = gx == 0, at_right = gx == W - 1;
 
-  for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
-  __syncthreads();
-  unsigned long long needc0 = ~0ull, needc1 = ~0ull, needb0 = ~0ull, needb1 = ~0ull;   // wave-uniform
-  unsigned long long needp0 = ~0ull, needp1 = ~0ull;   // pixel rows somebody needs: bit q = row ys - 3 + q
-  // detection mask: the cv::circle discs that touch this strip, rasterised into row bit-masks.  Lane = row of the strip
-  // (two rows per lane for strips above 64 rows): the keypoints are tested 64 at a time, then every hit is replayed for all
-  // rows at once from scalar registers -- no atomics, no per-row loop (the per-keypoint row loop of the first kernel
-  // was a quarter of its instructions).
+  unsigned long long needc0, needc1, needb0, needb1;   // wave-uniform
+  unsigned long long needp0, needp1;   // pixel rows somebody needs: bit q = row ys - 3 + q
+  // detection mask: the strip's 64 lane columns of the stream's bitmap (mineig_prep_kernel), lane = row of the strip (two
+  // rows per lane for strips above 64 rows)
   {
-    unsigned long long mrow0 = 0ull, mrow1 = 0ull;
-    if (use_discs) {
-      const float2* kp = kp_all + (size_t)s * kcap;
-      const int nk = kp_count[s];
-      const long long* lmk = lmk_all + (size_t)s * kcap;
-      const int gy0 = ys + lane, gy1 = ys + 64 + lane;
-      // the keypoint list is read in chunks of 8 x 64 entries, all requests of a chunk in flight at once: one memory
-      // round trip per chunk instead of one per 64 keypoints (ten dependent round trips were a third of a wave's life)
-      constexpr int CH = 8;
-      for (int base = 0; base < nk; base += 64 * CH) {
-        float2 pk[CH];
-        long long lk[CH];
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-          const int i = min(base + 64 * j + lane, nk - 1);
-          lk[j] = lmk[i];
-          pk[j] = kp[i];
-        }
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-          const int i = base + 64 * j + lane;
-          // only keypoints with a landmark mask (FeatureDetector.cpp:191); cv::Point(Point2f) rounds
-          const int cx = __float2int_rn(pk[j].x), cy = __float2int_rn(pk[j].y);
-          const bool hit = i < nk && lk[j] != -1 &&
-                           !(cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye);
-          unsigned long long bal = __ballot(hit);
-          while (bal) {
-            const int l = __builtin_ctzll(bal);
-            bal &= bal - 1;
-            const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
-            auto span = [&](int gy) -> unsigned long long {
-              const int dy = abs(gy - ccy);
-              if (dy > radius) return 0ull;
-              const int hw = hw_s[dy];
-              const int xa = max(ccx - hw, x0) - x0, xb = min(ccx + hw, x0 + 63) - x0;
-              if (xa > xb) return 0ull;
-              return (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
-            };
-            mrow0 |= span(gy0);
-            if (strip_rows > 64) mrow1 |= span(gy1);
-          }
-        }
-      }
-    }
+    const unsigned long long* MB = maskbits + (size_t)s * H * MW;
+    const int gy0 = ys + lane, gy1 = ys + 64 + lane;
+    const unsigned long long mrow0 = gy0 < ye ? me_row_bits(MB + (size_t)gy0 * MW, x0) : 0ull;
+    const unsigned long long mrow1 = gy1 < ye ? me_row_bits(MB + (size_t)gy1 * MW, x0) : 0ull;
+    __syncthreads();   // (the previous item's readers of the LDS arrays are done)
     rowmask[lane] = mrow0;
     rowmask[64 + lane] = mrow1;   // (rows past the strip: all zero; slot 128 is the read-ahead slot)
     if (lane == 0) rowmask[128] = 0ull;
-    // Rows nobody needs.  lambda matters only at pixels that pass the detection mask (masked maximum, candidates) and at
-    // their 8 neighbours (the 3x3 maximum): U(y) = row y of the strip has an unmasked output pixel; box row b is needed
-    // iff U(b-1) | U(b) | U(b+1), cov row c iff one of the box rows c-1 .. c+1 is.  With a few hundred tracked keypoints
-    // and discs of radius min_distance most of a frame is masked, and whole 58-pixel row segments drop out (cv::
-    // goodFeaturesToTrack computes them and throws them away).  Bit i + 2 of the 128-bit masks = strip row i.
     const unsigned long long om = __ballot(out_col);
-    const unsigned long long u_lo = __ballot(lane < strip_rows && (om & ~mrow0) != 0ull);
-    const unsigned long long u_hi = __ballot(64 + lane < strip_rows && (om & ~mrow1) != 0ull);
-    // U shifted to bit i + 2 (strip_rows <= 120, so nothing falls off the top)
-    const unsigned long long U0 = u_lo << 2, U1 = (u_hi << 2) | (u_lo >> 62);
-    auto or3 = [](unsigned long long x0, unsigned long long x1, unsigned long long& y0, unsigned long long& y1) {
-      y0 = x0 | (x0 << 1) | (x0 >> 1) | (x1 << 63);
-      y1 = x1 | (x1 << 1) | (x0 >> 63) | (x1 >> 1);
-    };
-    or3(U0, U1, needc0, needc1);
-    or3(needc0, needc1, needb0, needb1);
-    // cov row c (bit c - ys + 2 of needb) reads the pixel rows c-1 .. c+1: bits q-2, q-1, q of needb -> bit q of needp
-    // (strip_rows <= 120: the highest cov bit is 123, nothing falls off the top)
-    needp0 = needb0 | (needb0 << 1) | (needb0 << 2);
-    needp1 = needb1 | (needb1 << 1) | (needb1 << 2) | (needb0 >> 63) | (needb0 >> 62);
+    const unsigned long long u_lo = __ballot(lane < strip_rows && gy0 < ye && (om & ~mrow0) != 0ull);
+    const unsigned long long u_hi = __ballot(64 + lane < strip_rows && gy1 < ye && (om & ~mrow1) != 0ull);
+    const MeNeed nd = me_need_masks(u_lo, u_hi);
+    needc0 = nd.c0, needc1 = nd.c1, needb0 = nd.b0, needb1 = nd.b1, needp0 = nd.p0, needp1 = nd.p1;
   }
   __syncthreads();
 #ifdef KVFE_ME_PROF
@@ -378,8 +544,22 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
         Y.h2 = X.h2;
       }
       const double s0 = (X.h0 + Z.h0) + Y.h0, s1 = (X.h1 + Z.h1) + Y.h1, s2 = (X.h2 + Z.h2) + Y.h2;
-      const float fa = (float)s0 * 0.5f, fb = (float)s1, fc = (float)s2 * 0.5f;
-      const float lam = (fa + fc) - sqrt_rn_small((fa - fc) * (fa - fc) + fb * fb);
+      float lam;
+      if constexpr (HARRIS) {
+        // cv::cornerHarris (use_harris_corner_detector_, FeatureDetector.cpp:78-79): calcHarris runs 4-wide float lanes
+        // over the image as ONE row of W * H pixels -- a*c - b*b - (float)k*(a+c)*(a+c), every operation in float -- and
+        // the (W * H) % 4 pixels at the very end go through its scalar tail, whose k is a double
+        const float ha = (float)s0, hb = (float)s1, hc = (float)s2;
+        const float ac = ha + hc;
+        lam = (ha * hc - hb * hb) - (harris_kf * ac) * ac;
+        if (CHECK && b == H - 1 && ((W * H) & 3) != 0) {
+          const float ld = (float)((double)(ha * hc - hb * hb) - harris_kd * (double)ac * (double)ac);
+          lam = gx >= W - ((W * H) & 3) ? ld : lam;
+        }
+      } else {
+        const float fa = (float)s0 * 0.5f, fb = (float)s1, fc = (float)s2 * 0.5f;
+        lam = (fa + fc) - sqrt_rn_small((fa - fc) * (fa - fc) + fb * fb);
+      }
       Z.lam = lam;
       Z.hm = fmaxf(fmaxf(dpp_from_left(lam), lam), dpp_from_right(lam));
       if (!CHECK || (b >= ys && b < ye)) {
@@ -503,20 +683,23 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
       bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&maxkey[s], bestkey);
 #ifdef KVFE_ME_PROF
-  if (lane == 0) {   // one record per wave of the LAST launch (no atomics: they would be what is measured)
+  {
     const unsigned long long me_t3 = __builtin_readcyclecounter();
-    const size_t w = ((size_t)s * gridDim.y + by) * gridDim.x + bx;
-    if (w < KVFE_ME_PROF_WAVES) {
-      unsigned long long* o = kvfe_me_prof + w * 8;
-      o[0] = me_t1 - me_t0;
-      o[1] = me_t2 - me_t1;
-      o[2] = me_t3 - me_t2;
-      o[3] = 1ull;
-      o[4] = (unsigned long long)(__popcll(needp0) + __popcll(needp1));
-      o[5] = (unsigned long long)(r_last - r_first + 1);
-      o[6] = me_t0;
-      o[7] = me_t3;
-    }
+    me_acc[0] += me_t1 - me_t0;
+    me_acc[1] += me_t2 - me_t1;
+    me_acc[2] += me_t3 - me_t2;
+    me_acc[3] += 1ull;
+    me_acc[4] += (unsigned long long)(__popcll(needp0) + __popcll(needp1));
+    me_acc[5] += (unsigned long long)(r_last - r_first + 1);
+  }
+#endif
+  }   // next item
+#ifdef KVFE_ME_PROF
+  if (lane == 0 && blockIdx.x < KVFE_ME_PROF_WAVES) {   // one record per wave of the LAST launch
+    unsigned long long* o = kvfe_me_prof + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 6; i++) o[i] = me_acc[i];
+    o[6] = me_start;
+    o[7] = __builtin_readcyclecounter();
   }
 #endif
 }
@@ -525,6 +708,7 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st) {
   // D.cand_count / D.maxkey are zero here: allocated zeroed, re-zeroed by every select_kernel
+  if (P.detector == 0) return launch_fast(P, T, img, row_stride, img_stride, user_mask, k, S, D, use_discs, st);   // FeatureDetectorType::FAST
 #ifdef KVFE_ME_PROF
   {
     static bool reg = false;
@@ -533,17 +717,20 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
       std::atexit([] {
         static unsigned long long h[KVFE_ME_PROF_WAVES * 8];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_me_prof), sizeof(h)) != hipSuccess) return;
-        double a[6] = {0, 0, 0, 0, 0, 0}, longest = 0;
+        double a[6] = {0, 0, 0, 0, 0, 0}, longest = 0, life = 0, waves = 0, idle = 0;
         for (size_t w = 0; w < KVFE_ME_PROF_WAVES; w++) {
           const unsigned long long* o = h + w * 8;
-          if (!o[3]) continue;
+          if (!o[7]) continue;
+          waves += 1;
+          idle += o[3] ? 0 : 1;
           for (int i = 0; i < 6; i++) a[i] += (double)o[i];
+          life += (double)(o[7] - o[6]);
           longest = std::max(longest, (double)(o[7] - o[6]));
         }
         if (a[3] > 0)
-          std::fprintf(stderr, "KVFE_ME_PROF last launch: waves %.0f, cycles per wave: mask phase %.0f | row loop %.0f | epilogue %.0f | "
-                       "longest wave %.0f; pixel rows needed %.1f of %.1f walked\n", a[3], a[0] / a[3], a[1] / a[3], a[2] / a[3],
-                       longest, a[4] / a[3], a[5] / a[3]);
+          std::fprintf(stderr, "KVFE_ME_PROF last launch: waves %.0f (%.0f without an item), items %.0f, cycles per item: mask phase %.0f | "
+                       "row loop %.0f | epilogue %.0f; wave lifetime mean %.0f longest %.0f; pixel rows needed %.1f of %.1f per item\n",
+                       waves, idle, a[3], a[0] / a[3], a[1] / a[3], a[2] / a[3], life / waves, longest, a[4] / a[3], a[5] / a[3]);
       });
     }
   }
@@ -555,35 +742,183 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
                 ? prop.multiProcessorCount * 4 : 1024;
   }
-  // Strip height.  Every wave of the launch is resident at once (87 registers: 5 waves per SIMD) and a SIMD works
-  // through its waves' rows, so the launch lasts (waves per SIMD, rounded UP) x (rows per wave); every strip pays 5 rows
-  // of overlap.  The product is smallest for 6 strips of 80 rows at 64 x 752x480 (4992 waves, 5 per SIMD x 85 rows =
-  // 425 row-times; 4 strips: 4 x 125 = 500, 8 strips: 7 x 65 = 455); a few streams get short strips (more waves than
-  // SIMDs).  Measured in round 3 (KVFE_MINEIG_ROWS sweep) and again with the run walk in round 4: 40 / 60 / 80 / 120
-  // rows -> 0.090 / 0.088 / 0.082 / 0.105 ms.
+  // Strip height.  The launch is a fixed set of resident waves pulling (column strip, row strip) items, heaviest first,
+  // off one counter (see mineig_prep_kernel), so the strips only have to be short enough that a wave's last item is
+  // small against its share of the launch -- each strip pays 6 rows of overlap with its neighbours, though, so not
+  // shorter than that: the shortest height that still leaves every resident wave about two items, between 32 and
+  // ME2_ROWS rows.  (Round 4, one resident wave per 80-row strip and the mask rasterised by every wave: the launch ended
+  // with its slowest wave, 175 k cycles against a mean of 73 k.)
   const int nx = (P.W + ME_COLS - 1) / ME_COLS;
+  const int resident = simds * ME_WAVES_PER_SIMD;
   int strip_rows = min(P.H, ME2_ROWS);
-  double best = 1e30;
-  for (int ns = 1; ns <= (P.H + 15) / 16; ns++) {
+  for (int ns = (P.H + ME2_ROWS - 1) / ME2_ROWS; ns <= (P.H + 31) / 32; ns++) {
     const int rws = (P.H + ns - 1) / ns;
     if (rws > ME2_ROWS) continue;
-    const long long waves = (long long)nx * ns * P.B;
-    const double cost = (double)((waves + simds - 1) / simds) * (rws + 5);
-    if (cost < best) best = cost, strip_rows = rws;
+    strip_rows = rws;
+    if ((long long)nx * ns * P.B >= 2LL * resident) break;
   }
-#ifdef KVFE_ME_ROWS_OVERRIDE   // (with KVFE_ME_PROF: strip height of the A/B builds)
-  strip_rows = KVFE_ME_ROWS_OVERRIDE;
-#endif
+  static const int rows_env = std::getenv("KVFE_ME_ROWS") ? std::atoi(std::getenv("KVFE_ME_ROWS")) : 0;   // A/B aid (round 5)
+  if (rows_env >= 16 && rows_env <= ME2_ROWS) strip_rows = min(P.H, rows_env);
   const int ny = (P.H + strip_rows - 1) / strip_rows;
-  const dim3 grid((unsigned)nx, (unsigned)ny, (unsigned)P.B);
+  const int MW = me_mask_words(P.W);
+  const int max_items = me_max_items(P.W, P.H);
+  // the prep block's LDS: as many bitmap rows as fit beside the packed keypoint centres and the item costs
+  static const int prep_budget = lds_dynamic_budget(reinterpret_cast<const void*>(mineig_prep_kernel));
+  const size_t fixed = sizeof(int) * (size_t)P.kcap + sizeof(unsigned short) * (size_t)max_items + 16;
+  int band_rows = (int)std::min<long long>(P.H, ((long long)prep_budget - (long long)fixed) / ((long long)MW * 8));
+  if (band_rows < 1) {
+    std::fprintf(stderr, "kvfe: mineig_prep_kernel does not fit in LDS (kcap %d, %d x %d)\n", P.kcap, P.W, P.H);
+    return;
+  }
+  const size_t prep_lds = (size_t)band_rows * MW * 8 + fixed;
+  hipLaunchKernelGGL(mineig_prep_kernel, dim3(P.B), dim3(MEP_T), prep_lds, st, P.W, P.H, P.kcap, P.min_distance,
+                     T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.me_maskbits, MW, band_rows, D.me_items,
+                     D.me_n_items, max_items, nx, ny, strip_rows, D.me_counter, D.me_cost);
+  // (at least one wave per stream: a stream's items are only pulled by the waves that serve it)
+  const unsigned grid = (unsigned)std::max<long long>(P.B, std::min<long long>((long long)nx * ny * P.B, resident));
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H, P.ccap,
+                       D.me_maskbits, MW, D.me_items, D.me_n_items, max_items, D.me_counter, D.me_cost, D.cand, D.cand_count,
+                       D.maxkey, strip_rows, P.B, nx, (float)P.harris_k, P.harris_k);
+  };
+  if (P.use_harris) {
+    if (user_mask) go(mineig2_kernel<true, true>);
+    else go(mineig2_kernel<false, true>);
+  } else {
+    if (user_mask) go(mineig2_kernel<true, false>);
+    else go(mineig2_kernel<false, false>);
+  }
+}
+
+// =============================================================================================
+// FeatureDetectorType::FAST (FeatureDetector.cpp:35-40): cv::FastFeatureDetector::create(fast_thresh_, true) ->
+// cv::FAST(TYPE_9_16) with non-maximum suppression + KeyPointsFilter::runByPixelsMask.
+// Integer work, one image read: a block stages a (64 + 8) x (16 + 8) pixel tile in LDS, scores the (64 + 2) x (16 + 2)
+// pixels whose 3 x 3 neighbourhood the tile's output pixels look at (corner test: 9 contiguous pixels of the 16-pixel
+// circle all darker than v - t or all brighter than v + t, as bit tricks on the two 16-bit class masks; score = the
+// largest threshold that keeps the pixel a corner, minus 1 = max over the 16 arcs of the arc's smallest one-sided
+// difference, cornerScore<16>), keeps the strict 3 x 3 maxima under the mask (the stream's disc bitmap of
+// mineig_prep_kernel and the optional user mask) and appends (pixel index, score) to the stream's candidate list.
+// The keypoint ORDER of cv::FAST (raster) is restored by the select kernel's sort.
+// =============================================================================================
+constexpr int FAST_TW = 64, FAST_TH = 16, FAST_T = 256;
+__device__ __forceinline__ int fast_score16(const int (&d)[16]) {
+  int best = -256;
+#pragma unroll
+  for (int a = 0; a < 16; a++) {
+    int mn = 255, mx = -255;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      mn = min(mn, d[(a + j) & 15]);
+      mx = max(mx, d[(a + j) & 15]);
+    }
+    best = max(best, max(mn, -mx));
+  }
+  return best - 1;
+}
+template <bool HAS_MASK>
+__global__ __launch_bounds__(FAST_T) void fast_kernel(const unsigned char* __restrict__ img, size_t row_stride,
+                                                     size_t img_stride, const unsigned char* __restrict__ user_mask,
+                                                     int W, int H, int ccap, int threshold,
+                                                     const unsigned long long* __restrict__ maskbits, int MW,
+                                                     const int* __restrict__ flags,
+                                                     unsigned long long* __restrict__ cand_all,
+                                                     int* __restrict__ cand_count) {
+  const int s = blockIdx.z;
+  if (flags && !(flags[s] & FLAG_DETECT)) return;
+  constexpr int PW = FAST_TW + 8, PH = FAST_TH + 8, SW = FAST_TW + 2, SH = FAST_TH + 2;
+  __shared__ unsigned char px[PH][PW + 4];
+  __shared__ unsigned char sc[SH][SW + 2];
+  __shared__ unsigned long long lc[FAST_TW * FAST_TH];   // (a tile cannot hold more maxima than a quarter of its pixels)
+  __shared__ int n_loc, g_base;
+  const unsigned char* I = img + (size_t)s * img_stride;
+  const int tid = threadIdx.x;
+  const int tx0 = blockIdx.x * FAST_TW, ty0 = blockIdx.y * FAST_TH;
+  if (tid == 0) n_loc = 0;
+  for (int e = tid; e < PH * PW; e += FAST_T) {
+    const int yy = e / PW, xx = e - yy * PW;
+    const int gy = min(max(ty0 - 4 + yy, 0), H - 1), gx = min(max(tx0 - 4 + xx, 0), W - 1);   // (clamped: never scored)
+    px[yy][xx] = I[(size_t)gy * row_stride + gx];
+  }
+  __syncthreads();
+  // circle offsets of cv::FAST's 16-pixel pattern (dx, dy), fast.cpp makeOffsets
+  constexpr int OX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  constexpr int OY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+  const int t = min(max(threshold, 0), 255);
+  for (int e = tid; e < SH * SW; e += FAST_T) {
+    const int yy = e / SW, xx = e - yy * SW;          // score cell (yy, xx) = pixel (ty0 - 1 + yy, tx0 - 1 + xx)
+    const int gy = ty0 - 1 + yy, gx = tx0 - 1 + xx;
+    int score = 0;
+    if (gy >= 3 && gy < H - 3 && gx >= 3 && gx < W - 3) {
+      const int cy = yy + 3, cx = xx + 3;            // in the pixel tile
+      const int v = px[cy][cx];
+      int d[16];
+      unsigned dark = 0, bright = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        d[k] = v - (int)px[cy + OY[k]][cx + OX[k]];
+        dark |= (d[k] > t ? 1u : 0u) << k;
+        bright |= (d[k] < -t ? 1u : 0u) << k;
+      }
+      auto nine = [](unsigned m) {   // 9 contiguous set bits in the cyclic 16-bit mask
+        unsigned x = m | (m << 16);
+        x &= x >> 1;
+        x &= x >> 2;
+        x &= x >> 4;
+        x &= (m | (m << 16)) >> 8;
+        return (x & 0xffffu) != 0;
+      };
+      if (nine(dark) || nine(bright)) score = fast_score16(d);
+    }
+    sc[yy][xx] = (unsigned char)score;
+  }
+  __syncthreads();
+  const unsigned long long* MB = maskbits + (size_t)s * H * MW;
+  for (int e = tid; e < FAST_TH * FAST_TW; e += FAST_T) {
+    const int yy = e / FAST_TW, xx = e - yy * FAST_TW;
+    const int gy = ty0 + yy, gx = tx0 + xx;
+    if (gy >= H || gx >= W) continue;
+    const int v = sc[yy + 1][xx + 1];
+    if (v == 0) continue;   // (a corner's score is at least the threshold: > 0 unless t = 0 and the arc's margin is 1 ... see below)
+    const bool is_max = v > sc[yy][xx] && v > sc[yy][xx + 1] && v > sc[yy][xx + 2] && v > sc[yy + 1][xx] &&
+                        v > sc[yy + 1][xx + 2] && v > sc[yy + 2][xx] && v > sc[yy + 2][xx + 1] && v > sc[yy + 2][xx + 2];
+    if (!is_max) continue;
+    const int p = gx + 64;
+    if ((MB[(size_t)gy * MW + (p >> 6)] >> (p & 63)) & 1ull) continue;                       // inside a tracked keypoint's disc
+    if (HAS_MASK && user_mask[(size_t)s * W * H + (size_t)gy * W + gx] == 0) continue;        // runByPixelsMask
+    const int pos = atomicAdd(&n_loc, 1);
+    lc[pos] = ((unsigned long long)(~(unsigned)(gy * W + gx)) << 32) | (unsigned)v;   // descending key order = raster order
+  }
+  __syncthreads();
+  if (tid == 0 && n_loc > 0) g_base = atomicAdd(&cand_count[s], n_loc);
+  __syncthreads();
+  for (int i = tid; i < n_loc; i += FAST_T) {
+    const int pos = g_base + i;
+    if (pos < ccap) cand_all[(size_t)s * ccap + pos] = lc[i];
+  }
+}
+
+void launch_fast(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride, size_t img_stride,
+                 const unsigned char* user_mask, const FrameTab& k, const StreamState& S, const DetectScratch& D,
+                 int use_discs, hipStream_t st) {
+  // the disc bitmap of the tracked keypoints (the work list it also writes is not used here)
+  const int nx = (P.W + ME_COLS - 1) / ME_COLS;
+  const int strip_rows = min(P.H, ME2_ROWS), ny = (P.H + strip_rows - 1) / strip_rows;
+  const int MW = me_mask_words(P.W), max_items = me_max_items(P.W, P.H);
+  static const int prep_budget = lds_dynamic_budget(reinterpret_cast<const void*>(mineig_prep_kernel));
+  const size_t fixed = sizeof(int) * (size_t)P.kcap + sizeof(unsigned short) * (size_t)max_items + 16;
+  const int band_rows = (int)std::min<long long>(P.H, ((long long)prep_budget - (long long)fixed) / ((long long)MW * 8));
+  if (band_rows < 1) return;
+  hipLaunchKernelGGL(mineig_prep_kernel, dim3(P.B), dim3(MEP_T), (size_t)band_rows * MW * 8 + fixed, st, P.W, P.H, P.kcap,
+                     P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.me_maskbits, MW, band_rows,
+                     D.me_items, D.me_n_items, max_items, nx, ny, strip_rows, D.me_counter, D.me_cost);
+  const dim3 grid((P.W + FAST_TW - 1) / FAST_TW, (P.H + FAST_TH - 1) / FAST_TH, P.B);
   if (user_mask)
-    hipLaunchKernelGGL(mineig2_kernel<true>, grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
-                       P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand,
-                       D.cand_count, D.maxkey, strip_rows, P.B, nx, ny, 0);
+    hipLaunchKernelGGL(fast_kernel<true>, grid, dim3(FAST_T), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H, P.ccap,
+                       P.fast_thresh, D.me_maskbits, MW, S.flags, D.cand, D.cand_count);
   else
-    hipLaunchKernelGGL(mineig2_kernel<false>, grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
-                       P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand,
-                       D.cand_count, D.maxkey, strip_rows, P.B, nx, ny, 0);
+    hipLaunchKernelGGL(fast_kernel<false>, grid, dim3(FAST_T), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H, P.ccap,
+                       P.fast_thresh, D.me_maskbits, MW, S.flags, D.cand, D.cand_count);
 }
 
 // =============================================================================================
@@ -769,6 +1104,10 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     C = P.ccap;
     overflow = 1;
   }
+  // FeatureDetectorType::FAST: the candidates ARE the keypoints (cv::FAST has no quality threshold, no minimum distance
+  // and no maxCorners); they only have to be put back into cv::FAST's raster order, and the (int)response sort of
+  // AdaptiveNonMaximumSuppression::suppressNonMax works on real scores instead of all-equal keys
+  const bool fast_det = P.detector == 0;
   // ---- quality threshold (cv::threshold THRESH_TOZERO with maxVal*qualityLevel) -------------
   const float maxVal = fkey_inv(D.maxkey[s]);
   const float thr = (float)((double)maxVal * P.quality);
@@ -789,7 +1128,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     if (i < C) {
       key = cand[i];
       const float v = __uint_as_float((unsigned)(key >> 32));
-      keep = (v > thr) && (v != 0.0f);
+      keep = fast_det || ((v > thr) && (v != 0.0f));   // (FAST: every candidate is a keypoint, key = ~index << 32 | score)
     }
     const unsigned long long km = __ballot(keep);
     if (km) {
@@ -835,7 +1174,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   // accepted list.  NL = keys of the first pass, cut_bin = first bin of the second.
   int NL = C2, cut_bin = SEL_RADIX_BINS;
   bool two_pass = false;
-  if (bitmap_cfg && C2 > LDS_SORT_CAP) {
+  if (!fast_det && bitmap_cfg && C2 > LDS_SORT_CAP) {
     int* hist = cell_start;
     for (int i = tid; i < SEL_RADIX_BINS; i += SEL_T) hist[i] = 0;
     if (tid == 0) {
@@ -887,7 +1226,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
       __syncthreads();
     }
   }
-  if (bitmap_cfg && C2 > 0 && (C2 <= LDS_SORT_CAP || two_pass)) {
+  if (!fast_det && bitmap_cfg && C2 > 0 && (C2 <= LDS_SORT_CAP || two_pass)) {
     // ---- cv::goodFeaturesToTrack's greedy minimum-distance filter, in its own (sequential) order ----
     // 1. the candidates are RANKED by (value, index) descending: radix-rank sort -- histogram over the top bits of the
     //    value, prefix sum, grouping by bin, then every key counts the larger keys of its own bin (two or three on real
@@ -1181,7 +1520,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     }
     corners_written = true;
     sorted_accepted = true;
-  } else if (md >= 1 && C2 > 0 && C2 <= LDS_SORT_CAP &&
+  } else if (!fast_det && md >= 1 && C2 > 0 && C2 <= LDS_SORT_CAP &&
       ((W + md - 1) / md) * ((H + md - 1) / md) <= GREEDY_CELLS && W < 65536 && H < 65536) {
     // ---- cv::goodFeaturesToTrack's greedy minimum-distance filter, in its own (sequential) order ----
     // 1. all candidates sorted by (value, index) descending in LDS;
@@ -1293,7 +1632,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     if (sh_flag == 2) overflow = 1;
     sorted_accepted = true;
     }
-  } else if (md >= 1 && C2 > 0) {
+  } else if (!fast_det && md >= 1 && C2 > 0) {
     // grid of cells of side >= minDistance (cvRound(minDistance) for an integer distance): the 3x3 block
     // around a candidate holds every corner closer than minDistance.  For a small distance on a large
     // image the side grows until the grid fits the LDS work area (the grid only accelerates the search).
@@ -1445,14 +1784,60 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   __syncthreads();
   SEL_STAMP(3);
   int n_corners = A;
-  if (P.max_corners > 0) n_corners = min(n_corners, P.max_corners);
+  if (P.max_corners > 0 && !fast_det) n_corners = min(n_corners, P.max_corners);
   n_corners = min(n_corners, P.acap);
-  if (A > P.acap && (P.max_corners <= 0 || P.max_corners > P.acap)) overflow = 1;
+  if (A > P.acap && (fast_det || P.max_corners <= 0 || P.max_corners > P.acap)) overflow = 1;
   float2* corners = D.corners + (size_t)s * P.acap;
+  unsigned short* perm_dyn = reinterpret_cast<unsigned short*>(items);   // FAST: cv::sortIdx((int)response, DESCENDING)
+  if (fast_det) {
+    // keypoints in raster order + the permutation cv::sortIdx gives their integer responses: libstdc++'s std::sort of
+    // the indices by `response[a] < response[b]` (restated on one lane, kvfe_stdsort.inl: the comparator `a.r > b.r` on
+    // r = -response orders exactly like it), reversed.  FAST scores tie all the time, so the unstable sort's tie
+    // order is part of the result (binning and the Bailo ANMS variants walk the list in order).
+    constexpr int PER = LDS_SORT_CAP / SEL_T;
+    int sc_reg[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int i = tid + q * SEL_T;
+      sc_reg[q] = 0;
+      if (i < n_corners) {
+        const unsigned long long key = akeys[i];
+        const unsigned idx = ~(unsigned)(key >> 32);
+        const int y = idx / W, x = idx - y * W;
+        corners[i] = make_float2((float)x, (float)y);
+        sc_reg[q] = (int)(key & 0xffu);
+      }
+    }
+    __syncthreads();
+    BrownRI* res = reinterpret_cast<BrownRI*>(skeys);   // [n_corners <= LDS_SORT_CAP]
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int i = tid + q * SEL_T;
+      if (i < n_corners) {
+        res[i].r = -(float)sc_reg[q];
+        res[i].i = i;
+      }
+    }
+    __syncthreads();
+    if (P.sortidx_policy == 0) {
+      if (tid == 0) brown_std_sort(res, n_corners, cell_start);
+      __syncthreads();
+      for (int i = tid; i < n_corners; i += SEL_T) perm_dyn[i] = (unsigned short)res[n_corners - 1 - i].i;
+    } else {   // KVFE_SORTIDX_STABLE: descending response, equal responses in keypoint order
+      for (int i = tid; i < n_corners; i += SEL_T) {
+        const float ri = res[i].r;
+        int rank = 0;
+        for (int j = 0; j < n_corners; j++) rank += (res[j].r < ri || (res[j].r == ri && j < i)) ? 1 : 0;
+        perm_dyn[rank] = (unsigned short)i;
+      }
+    }
+    __syncthreads();
+  } else {
   for (int i = tid; i < n_corners && !corners_written; i += SEL_T) {
     const unsigned idx = (unsigned)akeys[i];
     const int y = idx / W, x = idx - y * W;
     corners[i] = make_float2((float)x, (float)y);
+  }
   }
   __syncthreads();
 
@@ -1522,7 +1907,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     //   RangeTree (4) |dx| <= w and |dy| <= w
     //   SSC (5)       cells of side c = (double)(w / 2) : |dr|, |dc| <= floor(w / c)
     // The sweep that defines the result is replayed once at the end to write the corners out.
-    const unsigned short* perm = T.sortidx + T.sortidx_off[n_corners];
+    const unsigned short* perm = fast_det ? perm_dyn : T.sortidx + T.sortidx_off[n_corners];
     int* pxy = reinterpret_cast<int*>(cell_start);          // [n] x | y << 16 of the permuted keypoints
     int* sel = pxy + n_corners;                              // [n] kept keypoints (pixel or cell coords)
     const int n = n_corners;
@@ -1644,7 +2029,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
     n_new = sh_cnt;
     if (sh_flag == 3) overflow = 1;
   } else {  // Binning on the cv::sortIdx-permuted keypoints
-    const unsigned short* perm = T.sortidx + T.sortidx_off[n_corners];
+    const unsigned short* perm = fast_det ? perm_dyn : T.sortidx + T.sortidx_off[n_corners];
     if (need > n_corners) {
       for (int i = tid; i < n_corners; i += SEL_T) newc[i] = corners[perm[i]];
       n_new = n_corners;

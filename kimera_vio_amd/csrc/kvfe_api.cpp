@@ -351,6 +351,11 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.ds.cell_items, (size_t)P.ccap * B));
   TRY(dalloc(c, &b.ds.state, (size_t)P.ccap * B));
   TRY(dalloc(c, &b.ds.sortbuf, (size_t)sort_cap * B));
+  TRY(dalloc(c, &b.ds.me_maskbits, (size_t)P.H * me_mask_words(P.W) * B));
+  TRY(dalloc(c, &b.ds.me_items, (size_t)me_max_items(P.W, P.H) * B));
+  TRY(dalloc(c, &b.ds.me_n_items, B));
+  TRY(dalloc(c, &b.ds.me_counter, (size_t)B * 1024));   // (k_detect.hip ME_COUNTER_STRIDE: one memory channel per stream)
+  TRY(dalloc(c, &b.ds.me_cost, B));
   TRY(dalloc(c, &b.lk.prev_pts, K));
   TRY(dalloc(c, &b.lk.next_pts, K));
   TRY(dalloc(c, &b.lk.status, K));
@@ -503,9 +508,13 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
       return fail("bad ransac_rng_policy", KVFE_ERR_INVALID_ARG);
   }
   const kvfe_detector_params& d = p.detector;
-  if (d.feature_detector_type != KVFE_DET_GFTT)
-    return fail("only the GFTT detector is implemented", KVFE_ERR_UNSUPPORTED);
-  if (d.use_harris_detector) return fail("Harris response is not implemented", KVFE_ERR_UNSUPPORTED);
+  if (d.feature_detector_type != KVFE_DET_GFTT && d.feature_detector_type != KVFE_DET_FAST)
+    return fail("feature_detector_type: GFTT and FAST are implemented (ORB is not; AGAST is LOG(FATAL) upstream, "
+                "FeatureDetector.cpp:67-70)", KVFE_ERR_UNSUPPORTED);
+  if (d.feature_detector_type == KVFE_DET_FAST && (cfg->left.width < 7 || cfg->left.height < 7))
+    return fail("FAST needs an image of at least 7 x 7 pixels", KVFE_ERR_INVALID_ARG);
+  if (d.use_harris_detector && (long long)cfg->left.width * cfg->left.height < 4)
+    return fail("use_harris_detector needs an image of at least 4 pixels", KVFE_ERR_INVALID_ARG);
   if (d.block_size != 3) return fail("block_size must be 3", KVFE_ERR_UNSUPPORTED);
   if (d.enable_non_max_suppression &&
       (d.non_max_suppression_type < KVFE_ANMS_TOPN || d.non_max_suppression_type > KVFE_ANMS_BINNING))
@@ -554,6 +563,10 @@ kvfe_status fill_params(kvfe_ctx* c) {
   P.hbins = d.nr_horizontal_bins;
   P.vbins = d.nr_vertical_bins;
   P.block_size = d.block_size;
+  P.detector = d.feature_detector_type;
+  P.fast_thresh = d.fast_thresh;
+  P.use_harris = d.use_harris_detector ? 1 : 0;
+  P.harris_k = d.k;
   P.subpix_enable = d.enable_subpixel_corner_refinement;
   P.subpix_win = d.subpix_window_size;
   P.subpix_zero = d.subpix_zero_zone;

@@ -27,7 +27,10 @@ struct KParams {
   // detector (FeatureDetectorParams)
   int max_features, enable_anms, anms_type, min_distance, max_corners, hbins, vbins, block_size;
   int subpix_enable, subpix_win, subpix_zero, subpix_iters, sortidx_policy;
-  double quality, subpix_eps2;
+  int detector;          // FeatureDetectorType (kvfe.h KVFE_DET_*): 0 FAST, 3 GFTT
+  int fast_thresh;       // cv::FastFeatureDetector threshold
+  int use_harris;        // use_harris_corner_detector_: cv::cornerHarris response instead of the minimum eigenvalue
+  double quality, subpix_eps2, harris_k;
   // tracker (TrackerParams)
   int klt_win, klt_iters, klt_maxlevel, max_age, predictor;
   double klt_eps2, disparity_thr;
@@ -215,7 +218,15 @@ struct DetectScratch {
   unsigned char* state;      // [B][ccap]
   unsigned long long* sortbuf;  // [B][ccap rounded to pow2]
   int sort_cap;
+  // detection mask and work list of the min-eigenvalue launch (k_detect.hip mineig_prep_kernel)
+  unsigned long long* me_maskbits;  // [B][H][me_mask_words(W)] bit x + 64 of row y: pixel (x, y) is masked OUT
+  unsigned* me_items;               // [B][me_max_items] item (row strip * nx + column strip) | cost << 16, heaviest first
+  int* me_n_items;                  // [B] items with at least one needed row (0: the stream does not detect)
+  unsigned* me_counter;             // [B][1024] (first word used) next work item of the stream
+  int* me_cost;                     // [B] summed cost of the stream's items (row steps)
 };
+__host__ __device__ inline int me_mask_words(int W) { return ((W + 64 + 63) >> 6) + 1; }   // 64 bits in front, 1 word behind
+inline int me_max_items(int W, int H) { return ((W + 57) / 58) * ((H + 15) / 16); }         // strips of >= 16 rows
 
 // LK scratch (component API and frontend share it)
 struct LkScratch {
@@ -291,6 +302,10 @@ void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
                    const StreamState& S, const DetectScratch& D, int use_discs, hipStream_t st);
+// FeatureDetectorType::FAST: cv::FastFeatureDetector(fast_thresh, nonmaxSuppression = true)::detect into the candidate list
+void launch_fast(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride, size_t img_stride,
+                 const unsigned char* user_mask, const FrameTab& k, const StreamState& S, const DetectScratch& D,
+                 int use_discs, hipStream_t st);
 // K2d + ANMS (per stream): threshold, greedy min-distance, sort, ANMS.
 void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const StreamState& S,
                    const DetectScratch& D, int fixed_need /* <0: from frame */, hipStream_t st);

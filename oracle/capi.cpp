@@ -80,6 +80,38 @@ KVO_API void kvo_corner_min_eigen_val(const uint8_t* img, int w, int h, size_t s
                                       float* eig) {
   ocv::cornerMinEigenVal(img, w, h, stride, block, eig);
 }
+// cv::FAST(TYPE_9_16) / cv::FastFeatureDetector::detect: out = (x, y, response) triples, returns the count
+KVO_API int kvo_fast_detect(const uint8_t* img, int w, int h, size_t stride, const uint8_t* mask, size_t mask_stride,
+                            int threshold, int nonmax, float* out_xyr, int capacity) {
+  std::vector<ocv::FastKeyPoint> k;
+  ocv::fastDetect(img, w, h, stride, mask, mask_stride, threshold, nonmax != 0, k);
+  const int n = std::min((int)k.size(), capacity);
+  for (int i = 0; i < n; i++) {
+    out_xyr[3 * i] = k[i].x;
+    out_xyr[3 * i + 1] = k[i].y;
+    out_xyr[3 * i + 2] = k[i].response;
+  }
+  return (int)k.size();
+}
+KVO_API void kvo_corner_harris(const uint8_t* img, int w, int h, size_t stride, int block, double k, float* dst) {
+  ocv::cornerHarris(img, w, h, stride, block, k, dst);
+}
+KVO_API int kvo_good_features_to_track_harris(const uint8_t* img, int w, int h, size_t stride,
+                                              const uint8_t* mask, size_t mask_stride, int maxCorners,
+                                              double quality, double minDist, int block, double k, float* out_xy,
+                                              float* out_quality, int capacity) {
+  std::vector<Point2f> c;
+  std::vector<float> q;
+  ocv::goodFeaturesToTrack(img, w, h, stride, mask, mask_stride, maxCorners, quality, minDist,
+                           block, c, &q, true, k);
+  int n = std::min((int)c.size(), capacity);
+  for (int i = 0; i < n; i++) {
+    out_xy[2 * i] = c[i].x;
+    out_xy[2 * i + 1] = c[i].y;
+    if (out_quality) out_quality[i] = q[i];
+  }
+  return (int)c.size();
+}
 KVO_API int kvo_good_features_to_track(const uint8_t* img, int w, int h, size_t stride,
                                        const uint8_t* mask, size_t mask_stride, int maxCorners,
                                        double quality, double minDist, int block, float* out_xy,

@@ -370,11 +370,28 @@ static void anmsBinarySearch(const std::vector<Point2f>& kp, int numRetPoints, i
 }
 
 bool suppressNonMax(const std::vector<Point2f>& keyPoints, int numRetPoints, int cols, int rows,
-                    const kvfe_detector_params& p, std::vector<Point2f>& out) {
+                    const kvfe_detector_params& p, std::vector<Point2f>& out, const std::vector<float>* responses) {
   out.clear();
   if (keyPoints.empty()) return true;  // "No keypoints for non-max suppression..."
   std::vector<int> Indx;
-  sortidx_descending_equal_keys((int)keyPoints.size(), p.sortidx_policy, Indx);
+  if (!responses) {   // GFTT keypoints: response 0 (OpenCV 4.2), all keys equal
+    sortidx_descending_equal_keys((int)keyPoints.size(), p.sortidx_policy, Indx);
+  } else {
+    // NonMaximumSuppression.cpp:50-56: responseVector.push_back(keyPoints[i].response) truncates to int;
+    // cv::sortIdx(SORT_DESCENDING) = std::sort(idx, LessThanIdx) -- the REAL std::sort of the host's libstdc++, whose
+    // tie order is part of the reference's result -- followed by a reversal (core/src/matrix_sort.cpp sortIdx_)
+    const int n = (int)keyPoints.size();
+    std::vector<int> key(n);
+    for (int i = 0; i < n; i++) key[i] = (int)(*responses)[i];
+    Indx.resize(n);
+    for (int i = 0; i < n; i++) Indx[i] = i;
+    if (p.sortidx_policy == KVFE_SORTIDX_STABLE) {
+      std::stable_sort(Indx.begin(), Indx.end(), [&](int a, int b) { return key[a] > key[b]; });
+    } else {
+      std::sort(Indx.begin(), Indx.end(), [&](int a, int b) { return key[a] < key[b]; });
+      for (int j = 0; j < n / 2; j++) std::swap(Indx[j], Indx[n - 1 - j]);
+    }
+  }
   std::vector<Point2f> keyPointsSorted(keyPoints.size());
   for (size_t i = 0; i < keyPoints.size(); i++) keyPointsSorted[i] = keyPoints[Indx[i]];
 
@@ -464,12 +481,24 @@ bool featureDetection(const uint8_t* img, int w, int h, size_t stride,
     ocv::circle_filled(mask.data(), w, h, w, ocv::cvRoundf(kp.x), ocv::cvRoundf(kp.y),
                        p.min_distance, 0);
   std::vector<Point2f> keypoints;
-  ocv::goodFeaturesToTrack(img, w, h, stride, mask.data(), w, p.max_nr_keypoints_before_anms,
-                           p.quality_level, (double)p.min_distance, p.block_size, keypoints);
+  std::vector<float> responses;
+  const bool fast = p.feature_detector_type == KVFE_DET_FAST;
+  if (fast) {   // FeatureDetector.cpp:35-40: cv::FastFeatureDetector::create(fast_thresh_, true)->detect(img, keypoints, mask)
+    std::vector<ocv::FastKeyPoint> kps;
+    ocv::fastDetect(img, w, h, stride, mask.data(), w, p.fast_thresh, true, kps);
+    for (const ocv::FastKeyPoint& k : kps) {
+      keypoints.push_back(Point2f{k.x, k.y});
+      responses.push_back(k.response);
+    }
+  } else {
+    ocv::goodFeaturesToTrack(img, w, h, stride, mask.data(), w, p.max_nr_keypoints_before_anms,
+                             p.quality_level, (double)p.min_distance, p.block_size, keypoints, nullptr,
+                             p.use_harris_detector != 0, p.k);
+  }
   if (raw_gftt) *raw_gftt = keypoints;
   std::vector<Point2f> max_keypoints = keypoints;
   if (p.enable_non_max_suppression) {
-    if (!suppressNonMax(keypoints, need_n_corners, w, h, p, max_keypoints)) return false;
+    if (!suppressNonMax(keypoints, need_n_corners, w, h, p, max_keypoints, fast ? &responses : nullptr)) return false;
   }
   new_corners = max_keypoints;
   if (!new_corners.empty() && p.enable_subpixel_corner_refinement) {

@@ -65,8 +65,10 @@ void sortidx_descending_equal_keys(int n, int policy, std::vector<int>& idx);
 // AdaptiveNonMaximumSuppression::suppressNonMax (NonMaximumSuppression.cpp:33-122)
 // for TopN, Binning (the types the shipped YAMLs and the reference tests use), BrownANMS and the
 // radius-search variants Sdc / KdTree / RangeTree / Ssc (anms/anms.cpp).
+// responses: the keypoints' cv::KeyPoint::response (FAST scores); null = all-equal keys (GFTT)
 bool suppressNonMax(const std::vector<Point2f>& keypoints, int numRetPoints, int cols, int rows,
-                    const kvfe_detector_params& p, std::vector<Point2f>& out);
+                    const kvfe_detector_params& p, std::vector<Point2f>& out,
+                    const std::vector<float>* responses = nullptr);
 
 // private FeatureDetector::featureDetection(const Frame&, need) (FeatureDetector.cpp:174-299)
 bool featureDetection(const uint8_t* img, int w, int h, size_t stride,

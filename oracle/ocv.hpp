@@ -117,15 +117,30 @@ void remap_linear_replicate(const uint8_t* src, int sw, int sh, size_t sstride, 
 // cv::cornerMinEigenVal(src u8, dst f32, blockSize, ksize=3, BORDER_DEFAULT).
 void cornerMinEigenVal(const uint8_t* src, int w, int h, size_t stride, int block_size,
                        float* eig);
+// cv::cornerHarris(src u8, dst f32, blockSize, ksize=3, k, BORDER_DEFAULT) (FeatureDetector.cpp:78-79:
+// use_harris_corner_detector_, k_)
+void cornerHarris(const uint8_t* src, int w, int h, size_t stride, int block_size, double k, float* dst);
 
 // cv::goodFeaturesToTrack(img, corners, maxCorners, quality, minDistance, mask,
-// blockSize, gradientSize=3, useHarris=false, k) as reached through
+// blockSize, gradientSize=3, useHarrisDetector, k) as reached through
 // cv::GFTTDetector::detect.  Reference: FeatureDetector.cpp:73-80,170.
 // mask may be null.  Output: integer-valued corners, quality-descending.
 void goodFeaturesToTrack(const uint8_t* img, int w, int h, size_t stride, const uint8_t* mask,
                          size_t mask_stride, int maxCorners, double qualityLevel,
                          double minDistance, int blockSize, std::vector<Point2f>& corners,
-                         std::vector<float>* quality = nullptr);
+                         std::vector<float>* quality = nullptr, bool useHarrisDetector = false,
+                         double harrisK = 0.04);
+
+// cv::FAST(..., TYPE_9_16) and cv::FastFeatureDetector::detect(img, keypoints, mask) (FeatureDetector.cpp:35-40:
+// cv::FastFeatureDetector::create(fast_thresh_, nonmaxSuppression = true)): keypoints in raster order,
+// response = corner score.
+struct FastKeyPoint {
+  float x, y, response;
+};
+void FAST_9_16(const uint8_t* img, int w, int h, size_t stride, int threshold, bool nonmax_suppression,
+               std::vector<FastKeyPoint>& keypoints);
+void fastDetect(const uint8_t* img, int w, int h, size_t stride, const uint8_t* mask, size_t mask_stride,
+                int threshold, bool nonmax, std::vector<FastKeyPoint>& keypoints);
 
 // cv::circle(img, Point(center), radius, color, FILLED, LINE_8, 0) on a u8 image.
 // Reference: FeatureDetector.cpp:196-201.

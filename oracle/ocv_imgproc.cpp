@@ -61,10 +61,16 @@ void remap_linear_replicate(const uint8_t* src, int sw, int sh, size_t sstride, 
 }
 
 // ---------------------------------------------------------------------------
-// cv::cornerMinEigenVal (ksize 3, BORDER_REFLECT_101), float32.
+// cv::cornerMinEigenVal / cv::cornerHarris (ksize 3, BORDER_REFLECT_101), float32: corner.cpp cornerEigenValsVecs
+// with op_type MINEIGENVAL / HARRIS.  Both share Sobel -> (dx*dx, dx*dy, dy*dy) -> unnormalised box filter; they
+// differ in the last line (calcMinEigenVal / calcHarris).
+// calcHarris (corner.cpp): the covariance image is continuous, so OpenCV folds it into ONE row of w*h pixels and runs
+// its 4-wide float lanes over it -- v_a*v_c - v_b*v_b - (float)k*(v_a+v_c)*(v_a+v_c), every operation in float -- and
+// the (w*h) % 4 pixels at the very end of the image go through the scalar tail, whose k is a double:
+// (float)(a*c - b*b - k*(a + c)*(a + c)).  (An AVX build takes 8 lanes first; the tail is the same w*h % 4 pixels.)
 // ---------------------------------------------------------------------------
-void cornerMinEigenVal(const uint8_t* src, int w, int h, size_t stride, int block_size,
-                       float* eig) {
+static void cornerEigenVals(const uint8_t* src, int w, int h, size_t stride, int block_size, bool harris, double k,
+                            float* eig) {
   double scale = (double)(1 << 2) * block_size;  // aperture 3
   scale *= 255.0;
   scale = 1.0 / scale;
@@ -130,9 +136,28 @@ void cornerMinEigenVal(const uint8_t* src, int w, int h, size_t stride, int bloc
         }
         cv3[c] = (float)s;
       }
-      float a = cv3[0] * 0.5f, b = cv3[1], c = cv3[2] * 0.5f;
-      eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
+      if (!harris) {
+        float a = cv3[0] * 0.5f, b = cv3[1], c = cv3[2] * 0.5f;
+        eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
+      } else {
+        const float a = cv3[0], b = cv3[1], c = cv3[2];
+        const size_t j = (size_t)y * w + x, n = (size_t)w * h;
+        if (j < n - n % 4) {
+          const float kf = (float)k;
+          const float ac_bb = a * c - b * b;
+          const float ac = a + c;
+          eig[j] = ac_bb - kf * ac * ac;
+        } else {
+          eig[j] = (float)(a * c - b * b - k * (a + c) * (a + c));
+        }
+      }
     }
+}
+void cornerMinEigenVal(const uint8_t* src, int w, int h, size_t stride, int block_size, float* eig) {
+  cornerEigenVals(src, w, h, stride, block_size, false, 0.0, eig);
+}
+void cornerHarris(const uint8_t* src, int w, int h, size_t stride, int block_size, double k, float* dst) {
+  cornerEigenVals(src, w, h, stride, block_size, true, k, dst);
 }
 
 // ---------------------------------------------------------------------------
@@ -141,11 +166,14 @@ void cornerMinEigenVal(const uint8_t* src, int w, int h, size_t stride, int bloc
 void goodFeaturesToTrack(const uint8_t* img, int w, int h, size_t stride, const uint8_t* mask,
                          size_t mask_stride, int maxCorners, double qualityLevel,
                          double minDistance, int blockSize, std::vector<Point2f>& corners,
-                         std::vector<float>* quality) {
+                         std::vector<float>* quality, bool useHarrisDetector, double harrisK) {
   corners.clear();
   if (quality) quality->clear();
   std::vector<float> eig((size_t)w * h);
-  cornerMinEigenVal(img, w, h, stride, blockSize, eig.data());
+  if (useHarrisDetector)   // featureselect.cpp: cornerHarris(image, eig, blockSize, gradientSize, harrisK)
+    cornerHarris(img, w, h, stride, blockSize, harrisK, eig.data());
+  else
+    cornerMinEigenVal(img, w, h, stride, blockSize, eig.data());
 
   // minMaxLoc(eig, 0, &maxVal, 0, 0, mask)
   double maxVal = 0;
@@ -226,6 +254,150 @@ void goodFeaturesToTrack(const uint8_t* img, int w, int h, size_t stride, const 
       if (maxCorners > 0 && (int)ncorners == maxCorners) break;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// cv::FAST(img, keypoints, threshold, nonmaxSuppression, TYPE_9_16) -- features2d/src/fast.cpp FAST_t<16> and
+// fast_score.cpp cornerScore<16> (the scalar statements; the SIMD paths compute the same integers).
+// A pixel is a corner when 9 contiguous pixels of the 16-pixel Bresenham circle of radius 3 are all darker than
+// v - t or all brighter than v + t; rows 3 .. h-4, columns 3 .. w-4.  Its score is the largest threshold for which it
+// still is one, minus 1 -- max over the 16 arcs of the arc's smallest one-sided difference -- stored as a byte; with
+// non-maximum suppression a corner survives when its score is strictly greater than its 8 neighbours' (0 for
+// non-corners).  Keypoints leave in raster order (row, then column), response = score.
+// ---------------------------------------------------------------------------
+static const int kFastOffsets16[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                                          {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+static int fastCornerScore16(const uint8_t* ptr, const int pixel[25], int threshold) {
+  const int K = 8, N = K * 3 + 1;
+  int k, v = ptr[0];
+  short d[N];
+  for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+  int a0 = threshold;
+  for (k = 0; k < 16; k += 2) {
+    int a = std::min((int)d[k + 1], (int)d[k + 2]);
+    a = std::min(a, (int)d[k + 3]);
+    if (a <= a0) continue;
+    a = std::min(a, (int)d[k + 4]);
+    a = std::min(a, (int)d[k + 5]);
+    a = std::min(a, (int)d[k + 6]);
+    a = std::min(a, (int)d[k + 7]);
+    a = std::min(a, (int)d[k + 8]);
+    a0 = std::max(a0, std::min(a, (int)d[k]));
+    a0 = std::max(a0, std::min(a, (int)d[k + 9]));
+  }
+  int b0 = -a0;
+  for (k = 0; k < 16; k += 2) {
+    int b = std::max((int)d[k + 1], (int)d[k + 2]);
+    b = std::max(b, (int)d[k + 3]);
+    b = std::max(b, (int)d[k + 4]);
+    b = std::max(b, (int)d[k + 5]);
+    if (b >= b0) continue;
+    b = std::max(b, (int)d[k + 6]);
+    b = std::max(b, (int)d[k + 7]);
+    b = std::max(b, (int)d[k + 8]);
+    b0 = std::min(b0, std::max(b, (int)d[k]));
+    b0 = std::min(b0, std::max(b, (int)d[k + 9]));
+  }
+  threshold = -b0 - 1;
+  return threshold;
+}
+
+void FAST_9_16(const uint8_t* img, int w, int h, size_t stride, int threshold, bool nonmax_suppression,
+               std::vector<FastKeyPoint>& keypoints) {
+  const int K = 8, N = 16 + K + 1;
+  int i, j, k, pixel[25];
+  for (k = 0; k < 16; k++) pixel[k] = kFastOffsets16[k][0] + kFastOffsets16[k][1] * (int)stride;
+  for (; k < 25; k++) pixel[k] = pixel[k - 16];
+  keypoints.clear();
+  threshold = std::min(std::max(threshold, 0), 255);
+  uint8_t threshold_tab[512];
+  for (i = -255; i <= 255; i++) threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+  std::vector<uint8_t> bufv((size_t)w * 3, 0);
+  std::vector<int> cpv((size_t)(w + 1) * 3, 0);
+  uint8_t* buf[3] = {bufv.data(), bufv.data() + w, bufv.data() + 2 * w};
+  int* cpbuf[3] = {cpv.data(), cpv.data() + (w + 1), cpv.data() + 2 * (w + 1)};
+  for (i = 3; i < h - 2; i++) {
+    const uint8_t* ptr = img + (size_t)i * stride + 3;
+    uint8_t* curr = buf[(i - 3) % 3];
+    int* cornerpos = cpbuf[(i - 3) % 3] + 1;
+    std::fill(curr, curr + w, (uint8_t)0);
+    int ncorners = 0;
+    if (i < h - 3) {
+      for (j = 3; j < w - 3; j++, ptr++) {
+        int v = ptr[0];
+        const uint8_t* tab = &threshold_tab[0] - v + 255;
+        int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+        if (d == 0) continue;
+        d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+        d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+        d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+        if (d == 0) continue;
+        d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+        d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+        d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+        d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
+        if (d & 1) {
+          int vt = v - threshold, count = 0;
+          for (k = 0; k < N; k++) {
+            int x = ptr[pixel[k]];
+            if (x < vt) {
+              if (++count > K) {
+                cornerpos[ncorners++] = j;
+                if (nonmax_suppression) curr[j] = (uint8_t)fastCornerScore16(ptr, pixel, threshold);
+                break;
+              }
+            } else
+              count = 0;
+          }
+        }
+        if (d & 2) {
+          int vt = v + threshold, count = 0;
+          for (k = 0; k < N; k++) {
+            int x = ptr[pixel[k]];
+            if (x > vt) {
+              if (++count > K) {
+                cornerpos[ncorners++] = j;
+                if (nonmax_suppression) curr[j] = (uint8_t)fastCornerScore16(ptr, pixel, threshold);
+                break;
+              }
+            } else
+              count = 0;
+          }
+        }
+      }
+    }
+    cornerpos[-1] = ncorners;
+    if (i == 3) continue;
+    const uint8_t* prev = buf[(i - 4 + 3) % 3];
+    const uint8_t* pprev = buf[(i - 5 + 3) % 3];
+    cornerpos = cpbuf[(i - 4 + 3) % 3] + 1;
+    ncorners = cornerpos[-1];
+    for (k = 0; k < ncorners; k++) {
+      j = cornerpos[k];
+      int score = prev[j];
+      if (!nonmax_suppression ||
+          (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+           score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1])) {
+        keypoints.push_back(FastKeyPoint{(float)j, (float)(i - 1), (float)score});
+      }
+    }
+  }
+}
+
+// cv::FastFeatureDetector::detect(image, keypoints, mask): FAST + KeyPointsFilter::runByPixelsMask
+void fastDetect(const uint8_t* img, int w, int h, size_t stride, const uint8_t* mask, size_t mask_stride,
+                int threshold, bool nonmax, std::vector<FastKeyPoint>& keypoints) {
+  if (w <= 0 || h <= 0) {
+    keypoints.clear();
+    return;
+  }
+  FAST_9_16(img, w, h, stride, threshold, nonmax, keypoints);
+  if (!mask) return;
+  std::vector<FastKeyPoint> kept;
+  for (const FastKeyPoint& kp : keypoints)   // MaskPredicate: mask.at<uchar>((int)(pt.y + 0.5f), (int)(pt.x + 0.5f)) == 0
+    if (mask[(size_t)(int)(kp.y + 0.5f) * mask_stride + (int)(kp.x + 0.5f)] != 0) kept.push_back(kp);
+  keypoints.swap(kept);
 }
 
 // ---------------------------------------------------------------------------

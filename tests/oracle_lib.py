@@ -63,6 +63,14 @@ def lib() -> C.CDLL:
     L.kvo_corner_min_eigen_val.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                            C.c_void_p]
     L.kvo_good_features_to_track.restype = C.c_int
+    L.kvo_fast_detect.restype = C.c_int
+    L.kvo_fast_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_int]
+    L.kvo_corner_harris.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_void_p]
+    L.kvo_good_features_to_track_harris.restype = C.c_int
+    L.kvo_good_features_to_track_harris.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                                    C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                    C.c_double, C.c_void_p, C.c_void_p, C.c_int]
     L.kvo_good_features_to_track.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                              C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int]
@@ -227,7 +235,8 @@ def dense_stereo_reconstruction(left_rect, right_rect, dp: abi.DenseStereoParams
 
 
 # --------------------------------------------------------------------------- imgproc
-def good_features_to_track(img, max_corners, quality, min_dist, block=3, mask=None):
+def good_features_to_track(img, max_corners, quality, min_dist, block=3, mask=None, harris_k=None):
+    """harris_k: None = minimum eigenvalue (useHarrisDetector = false), a float = cv::cornerHarris with that k"""
     img = _img(img)
     h, w = img.shape
     cap = max(max_corners, 1) if max_corners > 0 else w * h
@@ -235,9 +244,14 @@ def good_features_to_track(img, max_corners, quality, min_dist, block=3, mask=No
     q = np.zeros(cap, np.float32)
     if mask is not None:
         mask = _img(mask)
-    n = lib().kvo_good_features_to_track(_p(img), w, h, w, _p(mask) if mask is not None else None,
-                                         w, max_corners, quality, float(min_dist), block, _p(xy),
-                                         _p(q), cap)
+    if harris_k is not None:
+        n = lib().kvo_good_features_to_track_harris(_p(img), w, h, w, _p(mask) if mask is not None else None,
+                                                    w, max_corners, quality, float(min_dist), block, float(harris_k),
+                                                    _p(xy), _p(q), cap)
+    else:
+        n = lib().kvo_good_features_to_track(_p(img), w, h, w, _p(mask) if mask is not None else None,
+                                             w, max_corners, quality, float(min_dist), block, _p(xy),
+                                             _p(q), cap)
     n = min(n, cap)
     return xy[:n].copy(), q[:n].copy()
 
@@ -256,6 +270,27 @@ def corner_min_eigen_val(img, block=3):
     eig = np.zeros((h, w), np.float32)
     lib().kvo_corner_min_eigen_val(_p(img), w, h, w, block, _p(eig))
     return eig
+
+
+def fast_detect(img, threshold, nonmax=True, mask=None):
+    """cv::FastFeatureDetector::create(threshold, nonmax)->detect(img, kps, mask): (x, y, response) rows, raster order"""
+    img = _img(img)
+    h, w = img.shape
+    cap = w * h // 4 + 16 if nonmax else w * h
+    out = np.zeros((cap, 3), np.float32)
+    if mask is not None:
+        mask = _img(mask)
+    n = lib().kvo_fast_detect(_p(img), w, h, w, _p(mask) if mask is not None else None, w, int(threshold), int(nonmax),
+                              _p(out), cap)
+    return out[:min(n, cap)].copy()
+
+
+def corner_harris(img, k, block=3):
+    img = _img(img)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    lib().kvo_corner_harris(_p(img), w, h, w, block, float(k), _p(out))
+    return out
 
 
 def draw_detection_mask(w, h, xy, radius):

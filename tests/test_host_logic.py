@@ -105,6 +105,13 @@ def test_unsupported_configurations_are_rejected():
         with pytest.raises(L.KvfeError) as e:
             F.Context(Lc, Rc, q)
         assert e.value.status == abi.KVFE_ERR_UNSUPPORTED, field
+    # FeatureDetectorType: GFTT and FAST exist; ORB does not, AGAST is LOG(FATAL) upstream (FeatureDetector.cpp:67-70)
+    for det in (abi.DET_ORB, abi.DET_AGAST, 7):
+        q = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
+        q.detector.feature_detector_type = det
+        with pytest.raises(L.KvfeError) as e:
+            F.Context(Lc, Rc, q)
+        assert e.value.status == abi.KVFE_ERR_UNSUPPORTED, det
     # the 5-point problem is implemented for 2d2d_algorithm: 1 (NISTER, every shipped YAML) only
     q = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=None)
     assert q.tracker.pose_2d2d_algorithm == 1
