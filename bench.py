@@ -33,17 +33,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALL_LEGS = ("persist", "nominal", "single_stream", "c5", "klt4", "kf_realistic", "outputs", "spinonce", "alone", "dense", "dense_c5",
+ALL_LEGS = ("persist", "first_steps", "nominal", "single_stream", "c5", "klt4", "kf_realistic", "outputs", "spinonce", "alone", "dense", "dense_c5",
             "pcie", "input", "cpu")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PREWARM = 40                 # untimed steps in front of every leg's warm-up (run_frontend_leg)
+PREWARM = 0                  # (round 4 ran 40 untimed steps in front of every leg: see run_frontend_leg)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=52,
+                    help="steps per timed region; the default is two periods of the workload's feature-age cycle "
+                         "(maxFeatureAge + 1 = 26 steps, see run_frontend_leg), so every region holds the same work")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c3",
                     help="which BASELINE config `value` is measured on: c3 = configs[2] (headline), c4 = configs[3] "
                          "(8 EuRoC sequences sharded over the GPUs, one stream per sequence, strong scaling), "
@@ -207,11 +209,14 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
     torch.cuda.synchronize()
     ctx = F.Context(wl.left, wl.right, wl.params, batch=B, device=dev.index, stream_groups=groups,
                     **(DEFAULT_CTX_KW if ctx_kw is None else ctx_kw))
-    # PREWARM untimed steps in front of the W warm-up steps the command line asks for: the first ~30 steps (~35 ms) after
-    # the seconds of host-side set-up run 20 - 35 % slow (round 4, tools/r4/gpu_z.sh: ten regions of 20 steps read
-    # 39 / 65 / 58 / 58 ... k pairs/s after 8 warm-up steps, 59 / 64 / 58 / 58 ... after 60).  The transient appeared when
-    # the output records started to travel by the DMA engine and is not removed by exercising that path when the context
-    # is created; its cause is not identified.  The timed regions are untouched (exactly K steps each).
+    # Round 4 saw "the first ~30 steps run 20-35 % slow" and "every fourth 20-step region is 12 % faster" and put 40
+    # untimed steps in front of every leg.  Round 5 (tools/r5/stall_probe.py): neither is a transient of the device or
+    # of the runtime -- it is the workload.  Every feature of a synthetic stream is born at the bootstrap frame, so all of
+    # them reach maxFeatureAge (25, Tracker.cpp:167-180) in the SAME step: every 26th step re-detects ~320 corners per
+    # stream (2.7 ms instead of 1.3, and the two steps after it 1.8 / 1.65 ms); with maxFeatureAge = 1000 all regions of
+    # 10 steps read 57.7 k +- 0.3 k pairs/s, with 13 the slow steps come twice as often.  A region of 20 or 40 steps holds
+    # one or two of these bursts (hence the pattern); the default region is now 52 steps = two periods, PREWARM is gone,
+    # and the rate over a context's first 30 steps (bootstrap frame + the first burst) is its own figure (`first_steps`).
     warmup = warmup + PREWARM
     total = warmup + repeats * steps
     plan = [(st[0], wl.batch_inputs(ctx, st)) for st in wl.plan(total)]   # host work outside the timed region
@@ -513,6 +518,8 @@ def main():
                            "stay valid until the next step has completed: no level-0 copy, the rectify / match chain is "
                            "joined one step later) -- the configuration of round 4's headline")
         result["frames_persist"] = leg
+    if solo and "first_steps" in args.legs:
+        result["first_steps"] = first_steps_leg(torch, F, wl, dev)
     if solo and args.config == "c3" and args.mode == "kf" and "nominal" in args.legs:
         import dataclasses
         # (keyframes fall on every 4th step: a stride of 3 samples keyframe and non-keyframe steps alike)
@@ -582,7 +589,7 @@ def main():
     if solo and "dense_c5" in args.legs:
         result["dense_stereo_c5"] = dense_stereo(F, WL, 1280, 720, dev, pmc.get("dense_c5"))
     if solo and "pcie" in args.legs and args.config == "c3":
-        result["pcie_inclusive"] = pcie_inclusive(F, wl)
+        result["pcie_inclusive"] = pcie_inclusive(F, wl, torch)
     if solo and "input" in args.legs:
         result["input_side"] = input_side()
     if solo and "cpu" in args.legs:
@@ -593,6 +600,25 @@ def main():
         emit(result)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def first_steps_leg(torch, F, wl, dev):
+    """the first 30 steps of a fresh context: the bootstrap frame (600 corners per stream detected and refined), 24 tracked
+    frames, the first maxFeatureAge burst -- what a front-end that has just been started delivers"""
+    lefts, rights = wl.replicated()
+    d_left, d_right = torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev)
+    torch.cuda.synchronize()
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=wl.batch, device=dev.index, **DEFAULT_CTX_KW)
+    plan = [(st[0], wl.batch_inputs(ctx, st)) for st in wl.plan(30)]
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for t, inp in plan:
+        ctx.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), inp)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"value": round(wl.batch * 30 / dt, 2), "unit": "stereo-pairs/s", "ms_per_step": round(1e3 * dt / 30, 4),
+            "workload": "steps 0..29 of a fresh context on the `value` workload (no warm-up): bootstrap frame + first feature-age burst"}
 
 
 def dry_run(args, dist, sharding, WL, rank, world):
@@ -708,19 +734,43 @@ def input_side():
     return res
 
 
-def pcie_inclusive(F, wl):
+def pcie_inclusive(F, wl, torch=None):
     """PCIe-inclusive rates (host buffers handed over at the boundary): reported, never `value`.
-      staged  : the data provider writes into the context's pinned slots, the upload runs on a copy stream and
-                overlaps the previous step (kvfe_frontend_step_staged)
-      pageable: kvfe_frontend_step_host from ordinary host memory, copies on the compute stream"""
+      staged  : the `value` workload with every frame arriving from the host -- the data provider's decoded frames sit in
+                the context's pinned slots (one per frame of the ring), every step uploads its pair of frames on a copy
+                stream beside the previous step (kvfe_frontend_step_staged)
+      cyclic3 : round 4's form of this leg -- three frames in a cycle (the wrap-around loses most tracks: a much heavier
+                step than `value`'s, 1.9 ms where `value` takes 1.1) -- kept as a scalar for continuity
+      pageable: kvfe_frontend_step_host from ordinary host memory, copies on the compute stream
+    Beside them the link's own ceiling: the upload of one step's frames alone (2 x batch x W x H bytes)."""
     B = wl.batch
     lefts, rights = wl.replicated()
+    ring = lefts.shape[0]
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=B)
+    n_h, n_w = 52, 12        # (two maxFeatureAge periods of 26 steps, like `value`'s regions)
+    steps = wl.plan(n_w + n_h)
+    plan = [wl.batch_inputs(ctx, st) for st in steps]
+    res = {"unit": "stereo-pairs/s"}
+    if ring <= 8:            # KVFE_STAGING_SLOTS
+        for sl in range(ring):   # "decoded" frames sit in the pinned slots before the clock starts
+            a, b = ctx.staging_buffers(sl)
+            a[:] = lefts[sl]
+            b[:] = rights[sl]
+        for i in range(n_w):
+            ctx.step_staged(steps[i][0], plan[i])
+        ctx.synchronize()
+        th = time.perf_counter()
+        for i in range(n_w, n_w + n_h):
+            ctx.step_staged(steps[i][0], plan[i])
+        ctx.synchronize()
+        dt = time.perf_counter() - th
+        res["value"] = round(B * n_h / dt, 2)
+        res["ms_per_step"] = round(1e3 * dt / n_h, 4)
+        ctx.reset()
+    # round 4's leg: three frames in a cycle, 30 steps
     hl = np.ascontiguousarray(lefts[:3])
     hr = np.ascontiguousarray(rights[:3])
-    ctx = F.Context(wl.left, wl.right, wl.params, batch=B)
-    plan = [wl.batch_inputs(ctx, st) for st in wl.plan(40)]
-    n_h = 30   # (12 until round 4: too few to reach the steady state of upload || step -- it read 32 k where 30 steps read 21 k)
-    for sl in range(3):  # "decoded" frames sit in the pinned slots before the clock starts
+    for sl in range(3):
         a, b = ctx.staging_buffers(sl)
         a[:] = hl[sl]
         b[:] = hr[sl]
@@ -728,10 +778,10 @@ def pcie_inclusive(F, wl):
         ctx.step_staged(i % 3, plan[i])
     ctx.synchronize()
     th = time.perf_counter()
-    for i in range(3, 3 + n_h):
+    for i in range(3, 33):
         ctx.step_staged(i % 3, plan[i])
     ctx.synchronize()
-    staged = B * n_h / (time.perf_counter() - th)
+    res["cyclic3_value"] = round(B * 30 / (time.perf_counter() - th), 2)
     ctx.reset()
     for i in range(2):
         ctx.step_host(hl[i % 2], hr[i % 2], plan[i])
@@ -740,13 +790,26 @@ def pcie_inclusive(F, wl):
     for i in range(2, 8):
         ctx.step_host(hl[i % 2], hr[i % 2], plan[i])
     ctx.synchronize()
-    pageable = B * 6 / (time.perf_counter() - th)
+    res["pageable_value"] = round(B * 6 / (time.perf_counter() - th), 2)
     ctx.close()
-    return {"value": round(staged, 2), "unit": "stereo-pairs/s",
-            "note": "kvfe_frontend_step_staged: pinned staging slots, H2D upload of every frame inside the "
-                    "timed region on a copy stream overlapping the previous step; 30 steps over a cycle of three "
-                    "frames (the wrap-around loses most tracks: a heavier step than `value`'s)",
-            "pageable_value": round(pageable, 2)}
+    if torch is not None:    # the link alone: one step's frames from pinned memory, 20 times
+        nbytes = 2 * B * wl.width * wl.height
+        h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(20):
+            d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        up = (time.perf_counter() - th) / 20
+        res["link"] = {"bytes_per_step": nbytes, "upload_alone_ms": round(1e3 * up, 4), "GBps": round(nbytes / up / 1e9, 1),
+                       "ceiling_pairs_per_s": round(B / up, 1)}
+    res["note"] = ("value: the `value` workload (same frames, same ping-pong order) through kvfe_frontend_step_staged -- every "
+                   "step's frames uploaded from pinned host slots inside the timed region, %d steps; cyclic3_value: round "
+                   "4's form of the leg (three frames in a cycle, a heavier step); link: the upload of one step's frames "
+                   "alone" % n_h)
+    return res
 
 
 def dense_stereo(F, WL, W, H, dev, pmc_leg):

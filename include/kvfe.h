@@ -685,8 +685,11 @@ KVFE_API kvfe_status kvfe_frontend_step_device(kvfe_ctx* ctx, const void* left_d
  * `batch` left + `batch` right images (tightly packed, width*height bytes each); the data provider
  * decodes straight into a slot and calls kvfe_frontend_step_staged, which uploads the slot on a copy
  * stream (overlapping the previous step's kernels) and enqueues the step.  A slot may be refilled
- * once kvfe_frontend_staging_wait(slot) returns (its upload has completed). */
-#define KVFE_STAGING_SLOTS 3
+ * once kvfe_frontend_staging_wait(slot) returns (its upload has completed).  A slot's pinned memory is allocated
+ * the first time kvfe_frontend_staging_buffer / kvfe_frontend_step_staged names it (2 * batch * width * height bytes);
+ * three slots are what a decoder thread ahead of the front-end needs, eight let a benchmark keep a ring of frames
+ * resident on the host. */
+#define KVFE_STAGING_SLOTS 8
 KVFE_API kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* ctx, int32_t slot, uint8_t** left,
                                                   uint8_t** right);
 KVFE_API kvfe_status kvfe_frontend_staging_wait(kvfe_ctx* ctx, int32_t slot);
@@ -701,7 +704,16 @@ KVFE_API kvfe_status kvfe_synchronize(kvfe_ctx* ctx);
  * Output side (round 4): the step itself packs every stream's output into one contiguous record and sends the
  * records of the step to a pinned host ring slot in ONE device-initiated transfer (off the critical path: beside the
  * next step's tracking launch); kvfe_frontend_get_output waits for that transfer of the LATEST step -- which implies
- * that every kernel of the step has completed -- and copies out of pinned memory.  No blocking device copies. */
+ * that every kernel of the step has completed -- and copies out of pinned memory.  No blocking device copies.
+ * Contract of the accessors (kvfe_frontend_get_output / _at / s, kvfe_frontend_view_output):
+ *   - they do NOT synchronise the context: they wait for the records of the step they name and nothing else (use
+ *     kvfe_synchronize for "everything enqueued has completed"); a record set that outgrew its transfer is completed
+ *     by a copy on a stream of its own, never behind the running step;
+ *   - before the first step, and after kvfe_frontend_reset, there is no record: KVFE_ERR_INVALID_ARG (until round 3
+ *     this returned KVFE_OK with zero counts -- callers that polled before stepping must check the status);
+ *   - they belong to the thread that calls kvfe_frontend_step_*: a context is single-threaded (section "Threading"
+ *     of INTEGRATION.md); a consumer thread reading step k while the producer enqueues step k+1 needs the caller's
+ *     own mutex around both -- the record data it then reads is stable for KVFE_OUTPUT_RING - 1 further steps. */
 typedef struct kvfe_frame_output {
   int32_t capacity;
   int32_t n_keypoints;          /* left_frame_.keypoints_.size()             */

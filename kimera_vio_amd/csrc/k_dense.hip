@@ -245,9 +245,14 @@ __global__ __launch_bounds__(64) void dense_cost_fused_kernel(DenseParams P, con
     nb = recR[ro + cb];
   }
   for (int v = y0 - SW2; v < ye + SW2; v++) {
+    // (the block is ONE wave -- __launch_bounds__(64), checked by the launcher -- so a barrier is a wave barrier and
+    // free; it is what orders the previous row's cross-lane reads of the stage before these writes and the writes
+    // before this row's reads, instead of the in-order LDS pipe and the compiler's caution doing so by accident)
+    __syncthreads();
     if (lane < NP) stage_l[lane] = nl;
     stage_r[lane] = na;
     stage_r[64 + lane] = nb;
+    __syncthreads();
     {   // the next row's records (the last iteration re-reads its own row)
       const size_t ro = (size_t)min(max(min(v + 1, ye + SW2 - 1), 0), H - 1) * W;
       nl = recL[ro + cl];

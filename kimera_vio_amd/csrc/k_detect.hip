@@ -49,6 +49,7 @@ constexpr int ME_HALO = 3;
 constexpr int ME_COLS = 64 - 2 * ME_HALO;  // 58 output columns per wave
 constexpr int ME_ROWS = 64;                // most output rows per wave (rows per strip is a launch parameter)
 constexpr int ME_LCAP = 256;               // LDS candidate buffer (flushed when nearly full); small = 8 waves per SIMD
+constexpr int ME_NSLOT = 6;                // source rows in flight per lane (accumulation registers a0 .. a5)
 constexpr int ME_WAVES_PER_SIMD = 5;       // resident waves of the min-eigenvalue launch (its register count admits 5)
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i <- lane i-1
@@ -87,40 +88,14 @@ struct MeRow {          // per-lane values of one image row at the different pip
 };
 
 // ---------------------------------------------------------------------------------------------
-// Detection mask and work list of the min-eigenvalue launch (round 5).
-//
-// Round 4's launch was ONE round of one-wave workgroups, each of which (a) tested all ~590 tracked keypoints of its
-// stream against its own strip to rasterise the cv::circle discs (26 k of a wave's mean 73 k cycles, 4 992 times per
-// launch) and (b) lasted as long as its strip had unmasked rows -- the launch ended with the slowest wave, 175 k cycles.
-// Now one block per stream (mineig_prep_kernel) rasterises the stream's discs ONCE into a bitmap of masked-out pixels
-// in HBM (bit x + 64 of row y, rows of MW 64-bit words: a strip's 64 lane columns are two words and a funnel shift),
-// derives from it the number of pixel rows every (column strip, row strip) item will have to walk -- exactly the
-// row-need masks the wave itself computes -- and writes the stream's items ordered by that cost, heaviest first, items
-// nobody needs dropped, and their summed cost.  The min-eigenvalue launch is a fixed number of waves (what the device
-// holds at once); every wave derives from the 64 stream costs which stream it serves -- streams get waves in proportion
-// to their cost, at least one -- takes its first item by its position among the stream's waves and PULLS the rest off the
-// stream's own atomic counter: the heavy strips start first, and a SIMD that is stuck with several of them simply pulls
-// less of the light rest.  (First form of this round: ONE counter for the launch -- 10 k returning device-scope
-// atomics on one word take 0.11 ms on this chip, 88 per microsecond; tools/r5/gpu_a.sh.)
+// Rows nobody needs (shared by the kernel below and by its CPU statement in the comments): lambda matters only at
+// pixels that pass the detection mask (masked maximum, candidates) and at their 8 neighbours (the 3x3 maximum):
+// U(y) = row y of the strip has an unmasked output pixel; box row b is needed iff U(b-1) | U(b) | U(b+1), cov row c iff
+// one of the box rows c-1 .. c+1 is.  With a few hundred tracked keypoints and discs of radius min_distance most of a
+// frame is masked, and whole 58-pixel row segments drop out (cv::goodFeaturesToTrack computes them and throws them
+// away).  Bit i + 2 of the 128-bit masks = strip row i; u_lo / u_hi = U of strip rows 0..63 / 64..127 (strip_rows <= 120,
+// so nothing falls off the top).
 // ---------------------------------------------------------------------------------------------
-constexpr int MEP_T = 1024;
-constexpr int ME_COUNTER_STRIDE = 1024;    // unsigned words between two streams' work counters: one memory channel each (returning
-                                           // device-scope atomics on neighbouring words queue behind each other: 88 per microsecond)
-constexpr int ME_ITEM_OVERHEAD_ROWS = 6;   // what an item costs besides its rows (mask words, pipeline fill, flush), in row steps
-// (me_mask_words / me_max_items: kvfe_dev.hpp, the context sizes the scratch with them)
-// the 64 mask bits of lane columns x0 .. x0 + 63 (x0 >= -64) of a bitmap row
-__device__ __forceinline__ unsigned long long me_row_bits(const unsigned long long* row, int x0) {
-  const int p = x0 + 64;
-  const unsigned long long w0 = row[p >> 6], w1 = row[(p >> 6) + 1];
-  const int sh = p & 63;
-  return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-}
-// Rows nobody needs.  lambda matters only at pixels that pass the detection mask (masked maximum, candidates) and at
-// their 8 neighbours (the 3x3 maximum): U(y) = row y of the strip has an unmasked output pixel; box row b is needed
-// iff U(b-1) | U(b) | U(b+1), cov row c iff one of the box rows c-1 .. c+1 is.  With a few hundred tracked keypoints
-// and discs of radius min_distance most of a frame is masked, and whole 58-pixel row segments drop out (cv::
-// goodFeaturesToTrack computes them and throws them away).  Bit i + 2 of the 128-bit masks = strip row i; u_lo / u_hi =
-// U of strip rows 0..63 / 64..127 (strip_rows <= 120, so nothing falls off the top).
 struct MeNeed {
   unsigned long long c0, c1, b0, b1, p0, p1;
 };
@@ -140,30 +115,34 @@ __device__ __forceinline__ MeNeed me_need_masks(unsigned long long u_lo, unsigne
   return n;
 }
 
-__global__ __launch_bounds__(MEP_T) void mineig_prep_kernel(
+// ---------------------------------------------------------------------------------------------
+// Detection mask as a bitmap (round 5): one block per stream rasterises the cv::circle discs of the stream's tracked
+// keypoints (FeatureDetector.cpp:185-203) into bits "pixel masked OUT" in HBM -- bit x + 64 of row y, rows of MW 64-bit
+// words.  Reader: fast_kernel (one bit test per FAST corner).
+// The min-eigenvalue launch does NOT use it.  Two forms of this round did (tools/r5/gpu_a.sh .. gpu_c.sh: the bitmap plus
+// cost-ordered work items pulled by resident waves, first off one atomic counter -- 10 k returning device-scope atomics
+// on one word take 0.11 ms, 88 per microsecond --, then off one counter per stream a memory channel apart): both were
+// bit-exact and both lost to round 4's launch, 0.097 - 0.237 ms against 0.079 -- this extra launch and a wave's
+// dependent round trips (stream costs -> item -> mask words -> rows) cost more than the mask phase they replace, and the
+// launch was bound by the memory latency of its longest strip either way, which the six-deep row requests below address.
+// ---------------------------------------------------------------------------------------------
+constexpr int MEP_T = 1024;
+__global__ __launch_bounds__(MEP_T) void detect_mask_kernel(
     int W, int H, int kcap, int radius, const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
     const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
-    const int* __restrict__ flags, unsigned long long* __restrict__ maskbits, int MW, int band_rows,
-    unsigned* __restrict__ items, int* __restrict__ n_items, int max_items, int nx, int ny, int strip_rows,
-    unsigned* __restrict__ counter, int* __restrict__ cost_total) {
+    const int* __restrict__ flags, unsigned long long* __restrict__ maskbits, int MW, int band_rows) {
   const int s = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) counter[(size_t)s * ME_COUNTER_STRIDE] = 0u;   // the stream's work counter of the launch that follows
-  if (flags && !(flags[s] & FLAG_DETECT)) {
-    if (tid == 0) n_items[s] = 0, cost_total[s] = 0;
-    return;
-  }
+  if (flags && !(flags[s] & FLAG_DETECT)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char mep_lds[];
   __shared__ int hw_s[MAX_RADIUS + 1];
-  __shared__ int n_pos, c_sum;
   unsigned long long* band = reinterpret_cast<unsigned long long*>(mep_lds);              // [band_rows][MW]
   int* cxy = reinterpret_cast<int*>(mep_lds + sizeof(unsigned long long) * (size_t)band_rows * MW);   // [kcap] x | y << 16
-  unsigned short* cost_s = reinterpret_cast<unsigned short*>(cxy + kcap);               // [max_items]
   unsigned long long* MB = maskbits + (size_t)s * H * MW;
   const int nk = use_discs ? min(kp_count[s], kcap) : 0;
   const int nr = 2 * radius + 1;
   for (int i = tid; i <= radius && i <= MAX_RADIUS; i += MEP_T) hw_s[i] = circle_hw[i];
   // only keypoints with a landmark mask (FeatureDetector.cpp:191); cv::Point(Point2f) rounds.  Centres far outside the
-  // image cannot touch it and are dropped (the packed form holds +-32 K)
+  // image cannot touch it and are dropped (the packed form holds +-16 K around the image)
   for (int i = tid; i < nk; i += MEP_T) {
     const float2 k = kp_all[(size_t)s * kcap + i];
     const int cx = __float2int_rn(k.x), cy = __float2int_rn(k.y);
@@ -171,7 +150,6 @@ __global__ __launch_bounds__(MEP_T) void mineig_prep_kernel(
                     cy - radius < H;
     cxy[i] = on ? ((cx + 16384) & 0xffff) | ((cy + 16384) << 16) : -1;
   }
-  if (tid == 0) n_pos = 0, c_sum = 0;
   for (int y0 = 0; y0 < H; y0 += band_rows) {
     const int y1 = min(y0 + band_rows, H);
     __syncthreads();
@@ -197,42 +175,6 @@ __global__ __launch_bounds__(MEP_T) void mineig_prep_kernel(
     __syncthreads();
     for (int i = tid; i < (y1 - y0) * MW; i += MEP_T) MB[(size_t)y0 * MW + i] = band[i];
   }
-  __syncthreads();   // the block's own writes to MB are visible to all of its threads
-  // cost of every item = pixel rows its wave will walk (the wave's own row-need masks), one wave per item
-  const int n_all = nx * ny;
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int it = wv; it < n_all; it += MEP_T / 64) {
-    const int bx = it % nx, by = it / nx;
-    const int ys = by * strip_rows, ye = min(ys + strip_rows, H);
-    const int x0 = bx * ME_COLS - ME_HALO;
-    const int gx = x0 + lane;
-    const unsigned long long om = __ballot(lane >= ME_HALO && lane < 64 - ME_HALO && gx < W);
-    const int r0 = ys + lane, r1 = ys + 64 + lane;
-    // (one band = the whole bitmap is still in LDS: a global round trip per item would be most of this kernel's time)
-    const unsigned long long* src = band_rows >= H ? band : MB;
-    const unsigned long long m0 = r0 < ye ? me_row_bits(src + (size_t)r0 * MW, x0) : ~0ull;
-    const unsigned long long m1 = r1 < ye ? me_row_bits(src + (size_t)r1 * MW, x0) : ~0ull;
-    const unsigned long long u_lo = __ballot(r0 < ye && (om & ~m0) != 0ull);
-    const unsigned long long u_hi = __ballot(r1 < ye && (om & ~m1) != 0ull);
-    const MeNeed nd = me_need_masks(u_lo, u_hi);
-    if (lane == 0 && it < max_items) cost_s[it] = (unsigned short)(__popcll(nd.p0) + __popcll(nd.p1));
-  }
-  __syncthreads();
-  // heaviest first; an item nobody needs is dropped (its wave would find no row to walk)
-  for (int i = tid; i < min(n_all, max_items); i += MEP_T) {
-    const int ci = cost_s[i];
-    if (ci == 0) continue;
-    int rank = 0;
-    for (int j = 0; j < min(n_all, max_items); j++) {
-      const int cj = cost_s[j];
-      rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
-    }
-    items[(size_t)s * max_items + rank] = (unsigned)i | ((unsigned)ci << 16);
-    atomicAdd(&n_pos, 1);
-    atomicAdd(&c_sum, ci + ME_ITEM_OVERHEAD_ROWS);
-  }
-  __syncthreads();
-  if (tid == 0) n_items[s] = n_pos, cost_total[s] = c_sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,96 +204,55 @@ constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig
 constexpr size_t KVFE_ME_PROF_WAVES = 8192;
 __device__ unsigned long long kvfe_me_prof[KVFE_ME_PROF_WAVES * 8];   // per wave: cycles of the mask phase, the row loop, the epilogue; items; needed pixel rows; rows walked; start; end
 #endif
+// Launch shape (round 5): TWO blocks of ME_BLOCK_WAVES waves per compute unit, each wave pulling (column strip, row strip,
+// stream) items off the block's own LDS counter; block b owns the items b, b + G, b + 2 G ... (G blocks).  Rounds 3-4
+// launched one resident wave per item: the waves of neighbouring strips -- whose cost is correlated: a region without a
+// tracked keypoint needs all of its rows in every strip that crosses it -- land on the same SIMD, which then issues for
+// five full strips (5 x 85 rows x ~90 instructions x 4 cycles = 153 k cycles, the launch's longest wave) while the
+// average SIMD has a third of that to do (vector issue 41 % busy over the launch).  With the stride a block's items come
+// from all over the batch, and inside the block whichever wave is free takes the next one.  Waves of a block share
+// nothing but the counter and the disc half widths: their LDS areas are per wave and ordered by wave-level fences.
+constexpr int ME_BLOCK_WAVES = 8;    // two blocks per compute unit (a 1024-thread block would leave hipcc 64 vector registers per
+                                      // lane beside the accumulation half the row requests make it reserve: it spills into the
+                                      // accumulation registers, which the requests in flight own -- tools/check_inflight_regs.py)
+#define KVFE_ME_WAVE_SYNC()                                    \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
 template <bool HAS_MASK, bool HARRIS>
-__global__ __launch_bounds__(64) void mineig2_kernel(
+__global__ __launch_bounds__(64 * ME_BLOCK_WAVES) void mineig2_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
-    const unsigned char* __restrict__ user_mask, int W, int H, int ccap,
-    const unsigned long long* __restrict__ maskbits, int MW, const unsigned* __restrict__ items,
-    const int* __restrict__ n_items, int max_items, unsigned* __restrict__ counter, const int* __restrict__ cost_total,
+    const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
+    const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
+    const long long* __restrict__ lmk_all, const int* __restrict__ kp_count, int use_discs,
+    const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
-    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, float harris_kf, double harris_kd) {
-  __shared__ unsigned long long rowmask[129];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
-  __shared__ unsigned long long lcand[ME_LCAP];
-  const int lane = threadIdx.x;
-  // ---- which stream does this wave serve?  Stream t gets 1 + floor((G - A) cost_t / T) of the G waves of the launch (A
-  // streams with work, T their summed cost); the few waves left over go round the streams with work once more.  Every
-  // wave derives the same table from the B stream costs (lane = stream, B / 64 rounds) and keeps its own entry.
-  int s = -1, first_rank = -1, share = 0;   // stream; the wave's position among the stream's regular waves; their number
-  {
-    const int G = (int)gridDim.x, w = (int)blockIdx.x;
-    long long T = 0;
-    int A = 0;
-    for (int b0 = 0; b0 < B; b0 += 64) {
-      const int c = b0 + lane < B ? cost_total[b0 + lane] : 0;
-      long long v = c;
-      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-      T += v;
-      A += __popcll(__ballot(c > 0));
-    }
-    if (A == 0) return;      // no stream detects in this step
-    const int spare = max(G - A, 0);
-    int first = 0;           // first wave of the 64 streams under the scan
-    for (int b0 = 0; b0 < B && s < 0; b0 += 64) {
-      const int c = b0 + lane < B ? cost_total[b0 + lane] : 0;
-      const int mine = c > 0 ? 1 + (int)(((long long)spare * c) / T) : 0;
-      int inc = mine;        // inclusive scan over the lanes
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-      }
-      const int lo = first + inc - mine;
-      const unsigned long long hit = __ballot(mine > 0 && w >= lo && w < lo + mine);
-      if (hit) {
-        const int l = __builtin_ctzll(hit);
-        s = b0 + l;
-        first_rank = w - __builtin_amdgcn_readlane(lo, l);
-        share = __builtin_amdgcn_readlane(mine, l);
-      }
-      first += __builtin_amdgcn_readfirstlane(__shfl(inc, 63));
-    }
-    if (s < 0) {             // a left-over wave: one more for the ((w - first) mod A)-th stream with work, pulls only
-      int k = (w - first) % A;
-      for (int b0 = 0; b0 < B && s < 0; b0 += 64) {
-        const int c = b0 + lane < B ? cost_total[b0 + lane] : 0;
-        const unsigned long long act = __ballot(c > 0);
-        const int na = __popcll(act);
-        if (k < na) {
-          unsigned long long m = act;
-          for (int i = 0; i < k; i++) m &= m - 1;
-          const int l = __builtin_ctzll(m);
-          s = b0 + l;
-          share = 1 + (int)(((long long)spare * __builtin_amdgcn_readlane(c, l)) / T);
-        }
-        k -= na;
-      }
-    }
-    if (s < 0) return;       // (cannot happen: k < A)
-    s = __builtin_amdgcn_readfirstlane(s);
-    share = __builtin_amdgcn_readfirstlane(share);
-    first_rank = __builtin_amdgcn_readfirstlane(first_rank);
-  }
-  const int n_mine = n_items[s];
+    unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, float harris_kf, double harris_kd) {
+  __shared__ unsigned long long rowmask_all[ME_BLOCK_WAVES][132];  // per wave: [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
+  __shared__ unsigned long long lcand_all[ME_BLOCK_WAVES][ME_LCAP];
+  __shared__ int hw_s[MAX_RADIUS + 1];
+  __shared__ int q_next;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* const rowmask = rowmask_all[wave];
+  unsigned long long* const lcand = lcand_all[wave];
+  for (int i = threadIdx.x; i <= radius && i <= MAX_RADIUS; i += 64 * ME_BLOCK_WAVES) hw_s[i] = circle_hw[i];
+  if (threadIdx.x == 0) q_next = 0;
+  __syncthreads();
+  const long long total = (long long)nx * ny * B;
 #ifdef KVFE_ME_PROF
   unsigned long long me_acc[6] = {0, 0, 0, 0, 0, 0};
   const unsigned long long me_start = __builtin_readcyclecounter();
 #endif
-  // Work items, heaviest first: the wave's FIRST item is its position among the stream's regular waves (no atomic: all
-  // waves of the launch start at once), the others come off the stream's counter -- a pulled value c stands for rank
-  // share + c -- and the next one is requested while the current one is worked on (the atomic's round trip is hidden
-  // behind the strip).
-  unsigned* const ctr = counter + (size_t)s * ME_COUNTER_STRIDE;
-  auto pull = [&]() -> int {
-    unsigned v = 0;
-    if (lane == 0) v = atomicAdd(ctr, 1u);
-    return share + (int)v;
-  };
-  int id_next = first_rank >= 0 ? first_rank : pull();
   for (;;) {
-  const int rank = __builtin_amdgcn_readfirstlane(id_next);
-  if (rank >= n_mine) break;
-  id_next = pull();
-  const unsigned item = items[(size_t)s * max_items + rank] & 0xffffu;
-  const int bx = (int)item % nx, by = (int)item / nx;
+  int qk = 0;
+  if (lane == 0) qk = atomicAdd(&q_next, 1);
+  qk = __builtin_amdgcn_readfirstlane(qk);
+  const long long id = (long long)qk * gridDim.x + blockIdx.x;
+  if (id >= total) break;
+  const int bx = (int)(id % nx), by = (int)((id / nx) % ny), s = (int)(id / ((long long)nx * ny));
+  if (flags && !(flags[s] & FLAG_DETECT)) continue;
 #ifdef KVFE_ME_PROF
   const unsigned long long me_t0 = __builtin_readcyclecounter();
 #endif
@@ -366,26 +267,69 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   const bool out_col = lane >= ME_HALO && lane < 64 - ME_HALO && gx < W;
   const bool at_left = gx == 0, at_right = gx == W - 1;
 
-  unsigned long long needc0, needc1, needb0, needb1;   // wave-uniform
-  unsigned long long needp0, needp1;   // pixel rows somebody needs: bit q = row ys - 3 + q
-  // detection mask: the strip's 64 lane columns of the stream's bitmap (mineig_prep_kernel), lane = row of the strip (two
-  // rows per lane for strips above 64 rows)
+  unsigned long long needc0 = ~0ull, needc1 = ~0ull, needb0 = ~0ull, needb1 = ~0ull;   // wave-uniform
+  unsigned long long needp0 = ~0ull, needp1 = ~0ull;   // pixel rows somebody needs: bit q = row ys - 3 + q
+  // detection mask: the cv::circle discs that touch this strip, rasterised into row bit-masks.  Lane = row of the strip
+  // (two rows per lane for strips above 64 rows): the keypoints are tested 64 at a time, then every hit is replayed for all
+  // rows at once from scalar registers -- no atomics, no per-row loop (the per-keypoint row loop of the first kernel
+  // was a quarter of its instructions).
   {
-    const unsigned long long* MB = maskbits + (size_t)s * H * MW;
-    const int gy0 = ys + lane, gy1 = ys + 64 + lane;
-    const unsigned long long mrow0 = gy0 < ye ? me_row_bits(MB + (size_t)gy0 * MW, x0) : 0ull;
-    const unsigned long long mrow1 = gy1 < ye ? me_row_bits(MB + (size_t)gy1 * MW, x0) : 0ull;
-    __syncthreads();   // (the previous item's readers of the LDS arrays are done)
+    unsigned long long mrow0 = 0ull, mrow1 = 0ull;
+    if (use_discs) {
+      const float2* kp = kp_all + (size_t)s * kcap;
+      const int nk = kp_count[s];
+      const long long* lmk = lmk_all + (size_t)s * kcap;
+      const int gy0 = ys + lane, gy1 = ys + 64 + lane;
+      // the keypoint list is read in chunks of 8 x 64 entries, all requests of a chunk in flight at once: one memory
+      // round trip per chunk instead of one per 64 keypoints (ten dependent round trips were a third of a wave's life)
+      constexpr int CH = 8;
+      for (int base = 0; base < nk; base += 64 * CH) {
+        float2 pk[CH];
+        long long lk[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const int i = min(base + 64 * j + lane, nk - 1);
+          lk[j] = lmk[i];
+          pk[j] = kp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const int i = base + 64 * j + lane;
+          // only keypoints with a landmark mask (FeatureDetector.cpp:191); cv::Point(Point2f) rounds
+          const int cx = __float2int_rn(pk[j].x), cy = __float2int_rn(pk[j].y);
+          const bool hit = i < nk && lk[j] != -1 &&
+                           !(cx + radius < x0 || cx - radius >= x0 + 64 || cy + radius < ys || cy - radius >= ye);
+          unsigned long long bal = __ballot(hit);
+          while (bal) {
+            const int l = __builtin_ctzll(bal);
+            bal &= bal - 1;
+            const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
+            auto span = [&](int gy) -> unsigned long long {
+              const int dy = abs(gy - ccy);
+              if (dy > radius) return 0ull;
+              const int hw = hw_s[dy];
+              const int xa = max(ccx - hw, x0) - x0, xb = min(ccx + hw, x0 + 63) - x0;
+              if (xa > xb) return 0ull;
+              return (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
+            };
+            mrow0 |= span(gy0);
+            if (strip_rows > 64) mrow1 |= span(gy1);
+          }
+        }
+      }
+    }
+    KVFE_ME_WAVE_SYNC();   // (the previous item's readers of the wave's LDS areas are done)
     rowmask[lane] = mrow0;
     rowmask[64 + lane] = mrow1;   // (rows past the strip: all zero; slot 128 is the read-ahead slot)
     if (lane == 0) rowmask[128] = 0ull;
+    // rows nobody needs: me_need_masks above
     const unsigned long long om = __ballot(out_col);
-    const unsigned long long u_lo = __ballot(lane < strip_rows && gy0 < ye && (om & ~mrow0) != 0ull);
-    const unsigned long long u_hi = __ballot(64 + lane < strip_rows && gy1 < ye && (om & ~mrow1) != 0ull);
+    const unsigned long long u_lo = __ballot(lane < strip_rows && (om & ~mrow0) != 0ull);
+    const unsigned long long u_hi = __ballot(64 + lane < strip_rows && (om & ~mrow1) != 0ull);
     const MeNeed nd = me_need_masks(u_lo, u_hi);
     needc0 = nd.c0, needc1 = nd.c1, needb0 = nd.b0, needb1 = nd.b1, needp0 = nd.p0, needp1 = nd.p1;
   }
-  __syncthreads();
+  KVFE_ME_WAVE_SYNC();
 #ifdef KVFE_ME_PROF
   const unsigned long long me_t1 = __builtin_readcyclecounter();
 #endif
@@ -398,9 +342,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   const int r_first = c0 - 1, r_last = min(ye + 2, H + 1);
   const int lm0 = max(ys, 1), lm1 = min(ye - 1, H - 2);
   // steady steps r: cov row r-1, box row r-2 (inside the strip, not an image border row), local-max row r-3 are all
-  // live and the row requested by the step, r+3, is a plain image row
+  // live and the row requested by the step, r + ME_NSLOT, is a plain image row
   const int rs = max(max(c0 + 1, max(max(b0, ys), 1) + 2), lm0 + 3);
-  const int re = min(min(c1 + 1, min(min(b1, ye - 1), H - 2) + 2), min(lm1 + 3, H - 4));
+  const int re = min(min(c1 + 1, min(min(b1, ye - 1), H - 2) + 2), min(lm1 + 3, H - 1 - ME_NSLOT));
 
   float bestv = -__builtin_inff();  // masked maximum of lambda (no pixel has lambda = -inf)
   int n_loc = 0;                    // wave-uniform
@@ -415,9 +359,11 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     n_loc = 0;
   };
 
-  // source rows: raw buffer, per-lane column in a VGPR, row offset in an SGPR (an image is < 2 GiB).  Three rows in
-  // flight per lane (one per rotating slot), issued and awaited by hand: vmcnt counts in issue order, so "at most two
-  // outstanding" means this slot's load has landed.
+  // source rows: raw buffer, per-lane column in a VGPR, row offset in an SGPR (an image is < 2 GiB).  SIX rows in flight
+  // per lane (one per rotating slot), issued and awaited by hand: vmcnt counts in issue order, so "at most five
+  // outstanding" means this slot's load has landed.  (Rounds 3-4 kept three in flight: a wave then advances one row per
+  // third of a memory round trip -- 1.75 k cycles per row measured under load, whatever shares its SIMD -- and the launch
+  // lasts as long as the strip that needs all of its 85 rows, 149 k of its 175 k cycles; tools/r5/gpu_c.sh.)
   const unsigned stride_u = (unsigned)row_stride;
   const unsigned long long ibase = (unsigned long long)(size_t)I;
   const me_v4i rsrc = {(int)(unsigned)ibase, (int)(unsigned)((ibase >> 32) & 0xffffu),
@@ -434,27 +380,59 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
   // in flight.  (With a VGPR destination bound to a C++ variable hipcc is free to copy that variable -- a phi move at a
   // loop header, a tied asm operand -- before the byte has landed: it cannot know that the asm statement's output is
   // written late.  tools/check_inflight_regs.py checks the ISA.)
+#define KVFE_ME_ISSUE(N_) asm volatile("buffer_load_ubyte a" #N_ ", %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a" #N_, "memory")
+#define KVFE_ME_TAKE(N_) asm volatile("s_waitcnt vmcnt(5)\n\tv_accvgpr_read_b32 %0, a" #N_ "\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a" #N_, "memory")
   auto issue_off = [&](auto slot_tag, unsigned soff) {
     constexpr int SLOT = decltype(slot_tag)::value;
-    if constexpr (SLOT == 0) asm volatile("buffer_load_ubyte a0, %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a0", "memory");
-    else if constexpr (SLOT == 1) asm volatile("buffer_load_ubyte a1, %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a1", "memory");
-    else asm volatile("buffer_load_ubyte a2, %0, %1, %2 offen" : : "v"(voff), "s"(rsrc), "s"(soff) : "a2", "memory");
+    static_assert(SLOT >= 0 && SLOT < ME_NSLOT, "slot");
+    if constexpr (SLOT == 0) KVFE_ME_ISSUE(0);
+    else if constexpr (SLOT == 1) KVFE_ME_ISSUE(1);
+    else if constexpr (SLOT == 2) KVFE_ME_ISSUE(2);
+    else if constexpr (SLOT == 3) KVFE_ME_ISSUE(3);
+    else if constexpr (SLOT == 4) KVFE_ME_ISSUE(4);
+    else KVFE_ME_ISSUE(5);
   };
-  // wait for the slot's request (at most two younger ones outstanding: vmcnt counts in issue order) and convert the byte
+  // wait for the slot's request (at most ME_NSLOT - 1 younger ones outstanding: vmcnt counts in issue order) and convert
+  // the byte
   auto take = [&](auto slot_tag) -> float {
     constexpr int SLOT = decltype(slot_tag)::value;
     float p;
-    if constexpr (SLOT == 0) asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a0\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a0", "memory");
-    else if constexpr (SLOT == 1) asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a1\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a1", "memory");
-    else asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a2\n\tv_cvt_f32_ubyte0 %0, %0" : "=v"(p) : : "a2", "memory");
+    if constexpr (SLOT == 0) KVFE_ME_TAKE(0);
+    else if constexpr (SLOT == 1) KVFE_ME_TAKE(1);
+    else if constexpr (SLOT == 2) KVFE_ME_TAKE(2);
+    else if constexpr (SLOT == 3) KVFE_ME_TAKE(3);
+    else if constexpr (SLOT == 4) KVFE_ME_TAKE(4);
+    else KVFE_ME_TAKE(5);
     return p;
   };
+#undef KVFE_ME_ISSUE
+#undef KVFE_ME_TAKE
   using SL0 = std::integral_constant<int, 0>;
   using SL1 = std::integral_constant<int, 1>;
   using SL2 = std::integral_constant<int, 2>;
-  issue_off(SL0{}, row_of(r_first) * stride_u);
-  issue_off(SL1{}, row_of(r_first + 1) * stride_u);
-  issue_off(SL2{}, row_of(r_first + 2) * stride_u);
+  using SL3 = std::integral_constant<int, 3>;
+  using SL4 = std::integral_constant<int, 4>;
+  using SL5 = std::integral_constant<int, 5>;
+  // the six requests of a (re)start at pixel row r, in row order; hi: row r belongs to slot 3 (the slots rotate with the
+  // row index, slot(r) = (r - r_first) % 6, and the walk advances in threes, so a start is on slot 0 or on slot 3)
+  auto issue_six = [&](int r, bool hi) {
+    if (!hi) {
+      issue_off(SL0{}, row_of(r) * stride_u);
+      issue_off(SL1{}, row_of(r + 1) * stride_u);
+      issue_off(SL2{}, row_of(r + 2) * stride_u);
+      issue_off(SL3{}, row_of(r + 3) * stride_u);
+      issue_off(SL4{}, row_of(r + 4) * stride_u);
+      issue_off(SL5{}, row_of(r + 5) * stride_u);
+    } else {
+      issue_off(SL3{}, row_of(r) * stride_u);
+      issue_off(SL4{}, row_of(r + 1) * stride_u);
+      issue_off(SL5{}, row_of(r + 2) * stride_u);
+      issue_off(SL0{}, row_of(r + 3) * stride_u);
+      issue_off(SL1{}, row_of(r + 4) * stride_u);
+      issue_off(SL2{}, row_of(r + 5) * stride_u);
+    }
+  };
+  issue_six(r_first, false);
   const bool edge_strip = x0 <= 0 || x0 + 64 >= W;  // strip contains column 0 or W-1 (wave-uniform)
   // wave-wide lane facts as scalar masks
   const unsigned long long out_mask = __ballot(out_col);
@@ -486,7 +464,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     {
       const float p = take(slot_tag);
       if (CHECK) {
-        issue_off(slot_tag, row_of(r + 3) * stride_u);
+        issue_off(slot_tag, row_of(r + ME_NSLOT) * stride_u);
       } else {
         issue_off(slot_tag, soff_next);
         soff_next += stride_u;
@@ -592,9 +570,9 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
         }
         n_loc += __popcll(bal);
         if (n_loc > ME_LCAP - 64) {
-          __syncthreads();
+          KVFE_ME_WAVE_SYNC();
           flush();
-          __syncthreads();
+          KVFE_ME_WAVE_SYNC();
         }
       }
     }
@@ -604,7 +582,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
 
   MeRow S0, S1, S2;
   S0 = S1 = S2 = MeRow{0.f, 0.f, 0., 0., 0., 0.f, 0.f};
-  // slots rotate with the row index: slot(r) = (r - r_first) % 3
+  // the row registers rotate with the row index in threes (S0, S1, S2), the request slots in sixes: slot(r) = (r - r_first) % 6
   int r = r_first;
   fetch_mask(r - 2);   // (the first step's "previous" request)
   {
@@ -612,7 +590,7 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
     // almost entirely masked (the 600-feature benchmark streams: 3 % of the pixels pass the mask, a quarter of a strip's
     // rows is needed by anybody), so the wave walks only the runs of pixel rows that some unmasked pixel needs -- it
     // does not even fetch the others -- instead of stepping through every row and gating the stages.  A run restarts the
-    // pipeline: three row requests, the mask word one step ahead; the slots keep their phase (a run starts on a multiple
+    // pipeline: six row requests, the mask word one step ahead; the registers keep their phase (a run starts on a multiple
     // of three steps from r_first, at most two rows early), and what they hold from before the gap is never read: a
     // needed cov / box / local-maximum row has all of its source rows inside the same run (needp is needb widened by one
     // row, needb is needc widened by one, needc the unmasked rows widened by one).
@@ -629,18 +607,28 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
       const unsigned long long m = (needp1 >> (q - 64)) << (q - 64);
       return m ? ys - 3 + 64 + __builtin_ctzll(m) : 0x7fffffff;
     };
+    // three rows of the walk; hi = they sit in request slots 3 .. 5 (wave-uniform, alternates every three rows)
+    auto three = [&](auto ck, int r0, bool hi) {
+      constexpr bool CHECK = decltype(ck)::value;
+      if (!hi) {
+        step(ck, SL0{}, r0, S0, S2, S1);
+        if (!CHECK || r0 + 1 <= r_last) step(ck, SL1{}, r0 + 1, S1, S0, S2);
+        if (!CHECK || r0 + 2 <= r_last) step(ck, SL2{}, r0 + 2, S2, S1, S0);
+      } else {
+        step(ck, SL3{}, r0, S0, S2, S1);
+        if (!CHECK || r0 + 1 <= r_last) step(ck, SL4{}, r0 + 1, S1, S0, S2);
+        if (!CHECK || r0 + 2 <= r_last) step(ck, SL5{}, r0 + 2, S2, S1, S0);
+      }
+    };
+    bool hi = false;
     // Structure as without the walk (checked prologue / unchecked steady part / checked epilogue: with both step variants
     // in ONE loop hipcc needs 96 instead of 62 VGPRs); the gaps are skipped inside the steady part, where almost all rows
-    // of a strip lie.  A jump re-issues the three row requests (into the same accumulation registers: whatever is still in
+    // of a strip lie.  A jump re-issues the six row requests (into the same accumulation registers: whatever is still in
     // flight for them lands first, requests return in order) and the mask word one step ahead.
     const int n_pro = rs > re ? 0x3fffffff : ((rs - r_first + 2) / 3) * 3;
-    for (; r <= r_last && r - r_first < n_pro; r += 3) {
-      step(CK{}, SL0{}, r, S0, S2, S1);
-      if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
-      if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
-    }
+    for (; r <= r_last && r - r_first < n_pro; r += 3, hi = !hi) three(CK{}, r, hi);
     if (r + 2 <= re) {
-      soff_next = (unsigned)(r + 3) * stride_u;
+      soff_next = (unsigned)(r + ME_NSLOT) * stride_u;
       while (r + 2 <= re) {
         const int rn = next_needed(r);
         if (rn >= r + 3) {
@@ -648,37 +636,32 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
             r = r_last + 1;
             break;
           }
-          r += ((rn - r) / 3) * 3;
-          issue_off(SL0{}, row_of(r) * stride_u);
-          issue_off(SL1{}, row_of(r + 1) * stride_u);
-          issue_off(SL2{}, row_of(r + 2) * stride_u);
-          soff_next = (unsigned)(r + 3) * stride_u;
+          const int jump = (rn - r) / 3;
+          r += jump * 3;
+          hi = hi != ((jump & 1) != 0);
+          issue_six(r, hi);
+          soff_next = (unsigned)(r + ME_NSLOT) * stride_u;
           fetch_mask(r - 2);
           in_b_mask = 0ull;
           continue;
         }
-        step(NC{}, SL0{}, r, S0, S2, S1);
-        step(NC{}, SL1{}, r + 1, S1, S0, S2);
-        step(NC{}, SL2{}, r + 2, S2, S1, S0);
+        three(NC{}, r, hi);
         r += 3;
+        hi = !hi;
       }
     }
-    for (; r <= r_last; r += 3) {
-      step(CK{}, SL0{}, r, S0, S2, S1);
-      if (r + 1 <= r_last) step(CK{}, SL1{}, r + 1, S1, S0, S2);
-      if (r + 2 <= r_last) step(CK{}, SL2{}, r + 2, S2, S1, S0);
-    }
+    for (; r <= r_last; r += 3, hi = !hi) three(CK{}, r, hi);
   }
   // the row requests issued beyond the last step are still in flight: they land before their registers are re-used
-  asm volatile("s_waitcnt vmcnt(0)" : : : "a0", "a1", "a2", "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : : : "a0", "a1", "a2", "a3", "a4", "a5", "memory");
 #ifdef KVFE_ME_PROF
   const unsigned long long me_t2 = __builtin_readcyclecounter();
 #endif
-  __syncthreads();
+  KVFE_ME_WAVE_SYNC();
   flush();
   for (int off = 32; off > 0; off >>= 1) bestv = fmaxf(bestv, __shfl_xor(bestv, off));
   const unsigned bestkey = bestv == -__builtin_inff() ? 0u : fkey(bestv);
-  // masked maximum: one global atomic per wave, skipped when it cannot raise the maximum
+  // masked maximum: one global atomic per item, skipped when it cannot raise the maximum
   if (lane == 0 && bestkey &&
       bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&maxkey[s], bestkey);
@@ -695,14 +678,18 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
 #endif
   }   // next item
 #ifdef KVFE_ME_PROF
-  if (lane == 0 && blockIdx.x < KVFE_ME_PROF_WAVES) {   // one record per wave of the LAST launch
-    unsigned long long* o = kvfe_me_prof + (size_t)blockIdx.x * 8;
-    for (int i = 0; i < 6; i++) o[i] = me_acc[i];
-    o[6] = me_start;
-    o[7] = __builtin_readcyclecounter();
+  {
+    const size_t w = (size_t)blockIdx.x * ME_BLOCK_WAVES + wave;
+    if (lane == 0 && w < KVFE_ME_PROF_WAVES) {   // one record per wave of the LAST launch
+      unsigned long long* o = kvfe_me_prof + w * 8;
+      for (int i = 0; i < 6; i++) o[i] = me_acc[i];
+      o[6] = me_start;
+      o[7] = __builtin_readcyclecounter();
+    }
   }
 #endif
 }
+#undef KVFE_ME_WAVE_SYNC
 
 void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride,
                    size_t img_stride, const unsigned char* user_mask, const FrameTab& k,
@@ -717,7 +704,7 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
       std::atexit([] {
         static unsigned long long h[KVFE_ME_PROF_WAVES * 8];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_me_prof), sizeof(h)) != hipSuccess) return;
-        double a[6] = {0, 0, 0, 0, 0, 0}, longest = 0, life = 0, waves = 0, idle = 0;
+        double a[6] = {0, 0, 0, 0, 0, 0}, longest = 0, life = 0, waves = 0, idle = 0, first = 1e300, last = 0;
         for (size_t w = 0; w < KVFE_ME_PROF_WAVES; w++) {
           const unsigned long long* o = h + w * 8;
           if (!o[7]) continue;
@@ -726,60 +713,47 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
           for (int i = 0; i < 6; i++) a[i] += (double)o[i];
           life += (double)(o[7] - o[6]);
           longest = std::max(longest, (double)(o[7] - o[6]));
+          first = std::min(first, (double)o[6]);
+          last = std::max(last, (double)o[7]);
         }
         if (a[3] > 0)
           std::fprintf(stderr, "KVFE_ME_PROF last launch: waves %.0f (%.0f without an item), items %.0f, cycles per item: mask phase %.0f | "
-                       "row loop %.0f | epilogue %.0f; wave lifetime mean %.0f longest %.0f; pixel rows needed %.1f of %.1f per item\n",
-                       waves, idle, a[3], a[0] / a[3], a[1] / a[3], a[2] / a[3], life / waves, longest, a[4] / a[3], a[5] / a[3]);
+                       "row loop %.0f | epilogue %.0f; wave lifetime mean %.0f longest %.0f, first start to last end %.0f (100 MHz ticks x 24); pixel rows needed %.1f of %.1f per item\n",
+                       waves, idle, a[3], a[0] / a[3], a[1] / a[3], a[2] / a[3], life / waves, longest, last - first, a[4] / a[3], a[5] / a[3]);
       });
     }
   }
 #endif
-  static int simds = 0;
-  if (!simds) {
+  static int cus = 0;
+  if (!cus) {
     hipDeviceProp_t prop;
     int dev = 0;
-    simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                ? prop.multiProcessorCount * 4 : 1024;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
-  // Strip height.  The launch is a fixed set of resident waves pulling (column strip, row strip) items, heaviest first,
-  // off one counter (see mineig_prep_kernel), so the strips only have to be short enough that a wave's last item is
-  // small against its share of the launch -- each strip pays 6 rows of overlap with its neighbours, though, so not
-  // shorter than that: the shortest height that still leaves every resident wave about two items, between 32 and
-  // ME2_ROWS rows.  (Round 4, one resident wave per 80-row strip and the mask rasterised by every wave: the launch ended
-  // with its slowest wave, 175 k cycles against a mean of 73 k.)
+  // Strip height.  Every item pays 6 rows of overlap with its neighbours and the mask phase (~600 keypoint tests),
+  // so strips are tall; ME2_ROWS bounds them (the row-need masks hold 128 rows).  With one block per compute unit pulling
+  // items, the height no longer has to make the number of waves fit the device: the shortest height above 64 rows whose
+  // item count gives every block at least ME_BLOCK_WAVES items (few streams: fewer, taller does not help either).
   const int nx = (P.W + ME_COLS - 1) / ME_COLS;
-  const int resident = simds * ME_WAVES_PER_SIMD;
   int strip_rows = min(P.H, ME2_ROWS);
-  for (int ns = (P.H + ME2_ROWS - 1) / ME2_ROWS; ns <= (P.H + 31) / 32; ns++) {
+  for (int ns = (P.H + ME2_ROWS - 1) / ME2_ROWS; ns <= (P.H + 63) / 64; ns++) {
     const int rws = (P.H + ns - 1) / ns;
     if (rws > ME2_ROWS) continue;
     strip_rows = rws;
-    if ((long long)nx * ns * P.B >= 2LL * resident) break;
+    if ((long long)nx * ns * P.B >= (long long)cus * 2 * ME_BLOCK_WAVES) break;
   }
+#ifdef KVFE_ME_ROWS_OVERRIDE   // (with KVFE_ME_PROF: strip height of the A/B builds)
+  strip_rows = KVFE_ME_ROWS_OVERRIDE;
+#endif
   static const int rows_env = std::getenv("KVFE_ME_ROWS") ? std::atoi(std::getenv("KVFE_ME_ROWS")) : 0;   // A/B aid (round 5)
   if (rows_env >= 16 && rows_env <= ME2_ROWS) strip_rows = min(P.H, rows_env);
   const int ny = (P.H + strip_rows - 1) / strip_rows;
-  const int MW = me_mask_words(P.W);
-  const int max_items = me_max_items(P.W, P.H);
-  // the prep block's LDS: as many bitmap rows as fit beside the packed keypoint centres and the item costs
-  static const int prep_budget = lds_dynamic_budget(reinterpret_cast<const void*>(mineig_prep_kernel));
-  const size_t fixed = sizeof(int) * (size_t)P.kcap + sizeof(unsigned short) * (size_t)max_items + 16;
-  int band_rows = (int)std::min<long long>(P.H, ((long long)prep_budget - (long long)fixed) / ((long long)MW * 8));
-  if (band_rows < 1) {
-    std::fprintf(stderr, "kvfe: mineig_prep_kernel does not fit in LDS (kcap %d, %d x %d)\n", P.kcap, P.W, P.H);
-    return;
-  }
-  const size_t prep_lds = (size_t)band_rows * MW * 8 + fixed;
-  hipLaunchKernelGGL(mineig_prep_kernel, dim3(P.B), dim3(MEP_T), prep_lds, st, P.W, P.H, P.kcap, P.min_distance,
-                     T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.me_maskbits, MW, band_rows, D.me_items,
-                     D.me_n_items, max_items, nx, ny, strip_rows, D.me_counter, D.me_cost);
-  // (at least one wave per stream: a stream's items are only pulled by the waves that serve it)
-  const unsigned grid = (unsigned)std::max<long long>(P.B, std::min<long long>((long long)nx * ny * P.B, resident));
+  const long long items = (long long)nx * ny * P.B;
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(items, 2LL * cus));
   auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H, P.ccap,
-                       D.me_maskbits, MW, D.me_items, D.me_n_items, max_items, D.me_counter, D.me_cost, D.cand, D.cand_count,
-                       D.maxkey, strip_rows, P.B, nx, (float)P.harris_k, P.harris_k);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * ME_BLOCK_WAVES), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
+                       P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
+                       D.maxkey, strip_rows, P.B, nx, ny, (float)P.harris_k, P.harris_k);
   };
   if (P.use_harris) {
     if (user_mask) go(mineig2_kernel<true, true>);
@@ -798,7 +772,7 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
 // circle all darker than v - t or all brighter than v + t, as bit tricks on the two 16-bit class masks; score = the
 // largest threshold that keeps the pixel a corner, minus 1 = max over the 16 arcs of the arc's smallest one-sided
 // difference, cornerScore<16>), keeps the strict 3 x 3 maxima under the mask (the stream's disc bitmap of
-// mineig_prep_kernel and the optional user mask) and appends (pixel index, score) to the stream's candidate list.
+// detect_mask_kernel and the optional user mask) and appends (pixel index, score) to the stream's candidate list.
 // The keypoint ORDER of cv::FAST (raster) is restored by the select kernel's sort.
 // =============================================================================================
 constexpr int FAST_TW = 64, FAST_TH = 16, FAST_T = 256;
@@ -901,17 +875,17 @@ __global__ __launch_bounds__(FAST_T) void fast_kernel(const unsigned char* __res
 void launch_fast(const KParams& P, const Tables& T, const unsigned char* img, size_t row_stride, size_t img_stride,
                  const unsigned char* user_mask, const FrameTab& k, const StreamState& S, const DetectScratch& D,
                  int use_discs, hipStream_t st) {
-  // the disc bitmap of the tracked keypoints (the work list it also writes is not used here)
-  const int nx = (P.W + ME_COLS - 1) / ME_COLS;
-  const int strip_rows = min(P.H, ME2_ROWS), ny = (P.H + strip_rows - 1) / strip_rows;
-  const int MW = me_mask_words(P.W), max_items = me_max_items(P.W, P.H);
-  static const int prep_budget = lds_dynamic_budget(reinterpret_cast<const void*>(mineig_prep_kernel));
-  const size_t fixed = sizeof(int) * (size_t)P.kcap + sizeof(unsigned short) * (size_t)max_items + 16;
+  // the disc bitmap of the tracked keypoints
+  const int MW = me_mask_words(P.W);
+  static const int prep_budget = lds_dynamic_budget(reinterpret_cast<const void*>(detect_mask_kernel));
+  const size_t fixed = sizeof(int) * (size_t)P.kcap + 16;
   const int band_rows = (int)std::min<long long>(P.H, ((long long)prep_budget - (long long)fixed) / ((long long)MW * 8));
-  if (band_rows < 1) return;
-  hipLaunchKernelGGL(mineig_prep_kernel, dim3(P.B), dim3(MEP_T), (size_t)band_rows * MW * 8 + fixed, st, P.W, P.H, P.kcap,
-                     P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.me_maskbits, MW, band_rows,
-                     D.me_items, D.me_n_items, max_items, nx, ny, strip_rows, D.me_counter, D.me_cost);
+  if (band_rows < 1) {
+    std::fprintf(stderr, "kvfe: detect_mask_kernel does not fit in LDS (kcap %d, %d x %d)\n", P.kcap, P.W, P.H);
+    return;
+  }
+  hipLaunchKernelGGL(detect_mask_kernel, dim3(P.B), dim3(MEP_T), (size_t)band_rows * MW * 8 + fixed, st, P.W, P.H, P.kcap,
+                     P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.me_maskbits, MW, band_rows);
   const dim3 grid((P.W + FAST_TW - 1) / FAST_TW, (P.H + FAST_TH - 1) / FAST_TH, P.B);
   if (user_mask)
     hipLaunchKernelGGL(fast_kernel<true>, grid, dim3(FAST_T), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H, P.ccap,
@@ -2420,6 +2394,13 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     if (wave > 0) produce(0, 0);
     __syncthreads();
     SPG_STAMP(2);
+    // The chain wave is the block's critical path (448 dependent additions per iteration while the seven producer waves
+    // wait for it at the chunk barriers) but shares its SIMD's issue slots with three of them: raised wave priority lets
+    // it issue whenever its next addition is ready (round 4 measured ~25 cycles per term against the 5.6 a dependent
+    // v_add_f64 needs).
+#ifndef KVFE_SPG_NOPRIO
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+#endif
     for (int kc = 0; kc < NCH; kc++) {
       if (wave == 0) {
         if (lane < 5 * SPG_G) {
@@ -2447,6 +2428,9 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       }
       if (kc + 1 < NCH) __syncthreads();
     }
+#ifndef KVFE_SPG_NOPRIO
+    if (wave == 0) __builtin_amdgcn_s_setprio(0);
+#endif
     SPG_STAMP(3);
     // ---- C: the 2 x 2 system, one lane per corner (wave 0) ------------------------------------------------------
     if (wave == 0) {
@@ -2514,10 +2498,13 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
 // They used to be written by step_finalize, at the very end of the step; written here, the next step's predictor and
 // tracking launch depend on the corner refinement only, and this step's tail (stereo matching of the new corners,
 // measurements, lkf <- k) runs next to them instead of in front of them.
-// what: bit 0 = the state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the keypoint count: all
-// known once the corners are selected), bit 1 = the landmark-id counter (read by the append of THIS frame's corners, so
-// it moves after them).  The pipelined step runs bit 0 on the main stream right after the selection
-// (launch_detect_state) and bit 1 behind the corner refinement; everything else runs both behind the refinement.
+// what: bit 0 = the state the next step's tracking of the OLD points reads (keyframe_R_ref_frame_, "initialised": known
+// once the keyframe decision is made), bit 1 = the landmark-id counter (read by the append of THIS frame's corners, so it
+// moves after them), bit 2 = the frame's keypoint count.  The count moves only when the new corners ARE in the table:
+// kernels that walk the table up to the count (the stereo outlier rejection beside the refinement) must not meet entries
+// that still hold an older frame's landmarks.  Round 5: the step runs bit 0 on the main stream right after the selection
+// (launch_detect_state) and bits 1 + 2 behind the corner refinement on its own stream, so that the next step's tracking
+// of the old points does not wait for the refinement (kvfe_api.cpp do_step); every other caller runs all three behind it.
 __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D, int what) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.B) return;
@@ -2534,8 +2521,11 @@ __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, Detec
   }
   if (!(flags & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
-  if (what & 1) K.count[s] = S.n_tracked[s] + n_new;
+  if (what & 4) K.count[s] = S.n_tracked[s] + n_new;
   if (what & 2) S.lmk_counter[s] += n_new;
+}
+void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D, hipStream_t st) {
+  hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 1);
 }
 
 int detect_new_bound(const KParams& P) {
@@ -2548,7 +2538,7 @@ int detect_new_bound(const KParams& P) {
 void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
-                          hipStream_t st) {
+                          hipStream_t st, int commit_what) {
   const size_t lds = subpix_geom(P.subpix_win).bytes;
   const int bound = detect_new_bound(P);
   // waves per corner of the one-corner-per-block kernel: 2 (DPP broadcast chains, kvfe_subpix.inl), and 4 for a few
@@ -2605,7 +2595,7 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
     hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, (bound + SPG_G - 1) / SPG_G), dim3(SPG_T), glds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append | (stats_on ? 16 : 0) | (group_mode == 2 ? 64 : 0));
   }
-  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 3);
+  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, commit_what);
 }
 
 template <int WIN, int NW>

@@ -41,12 +41,13 @@ enum Stage {
   ST_FINALIZE,
   ST_RANSAC_MONO,
   ST_RANSAC_STEREO,
+  ST_TRACK_NEW,     // split tracking (do_step): the previous frame's new corners, behind their refinement
   ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "mineig_localmax",
                                      "gftt_select", "subpix_append", "rectify", "stereo_match",
                                      "stereo_match_new", "step_finalize", "ransac_mono",
-                                     "ransac_stereo"};
+                                     "ransac_stereo", "lk_track_new"};
 
 struct Buffers {  // everything that scales with the number of streams
   unsigned char* lvl0[2] = {nullptr, nullptr};  // [B][H][W] own copy of the left image per pyramid slot (device-pointer steps)
@@ -128,6 +129,9 @@ struct kvfe_ctx {
   // corner refinement runs on a side stream, concurrently with rectification and the stereo
   // matching of the tracked keypoints (its result is only needed by the newly detected ones)
   hipStream_t side = nullptr;
+  hipStream_t sub = nullptr;                         // corner refinement of a step whose tracking is split (do_step)
+  hipEvent_t ev_sel = nullptr;                       // the selection (and the state the next tracking reads) is done
+  bool split_prev = false;                           // the previous step's refinement runs on `sub`: this step tracks the old points first
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
   hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // main-stream part of the fork done / tail of the step (side stream) done
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
@@ -160,6 +164,7 @@ struct kvfe_ctx {
   size_t out_tab_bytes = 0, out_slot_size = 0;   // offset table in front of a slot's records / bytes of a slot
   size_t out_copied[OUT_RING] = {};              // bytes of the slot the step's transfer covers
   size_t out_guess = 0;                          // bytes the next transfer covers: the last known need + a margin
+  hipStream_t topup_stream = nullptr;            // locate_output: the rest of a record set that outgrew its transfer
   size_t out_guess_forced = 0;                   // KVFE_OUT_TRANSFER_BYTES (debugging aid: exercises the top-up path)
   int out_cap = 0;           // entries a record has room for: what a frame table can hold (pts_bound), not what it is allocated for
   bool out_direct = false;
@@ -351,16 +356,16 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.ds.cell_items, (size_t)P.ccap * B));
   TRY(dalloc(c, &b.ds.state, (size_t)P.ccap * B));
   TRY(dalloc(c, &b.ds.sortbuf, (size_t)sort_cap * B));
-  TRY(dalloc(c, &b.ds.me_maskbits, (size_t)P.H * me_mask_words(P.W) * B));
-  TRY(dalloc(c, &b.ds.me_items, (size_t)me_max_items(P.W, P.H) * B));
-  TRY(dalloc(c, &b.ds.me_n_items, B));
-  TRY(dalloc(c, &b.ds.me_counter, (size_t)B * 1024));   // (k_detect.hip ME_COUNTER_STRIDE: one memory channel per stream)
-  TRY(dalloc(c, &b.ds.me_cost, B));
+  if (P.detector == 0)   // FeatureDetectorType::FAST: the detection mask as a bitmap
+    TRY(dalloc(c, &b.ds.me_maskbits, (size_t)P.H * me_mask_words(P.W) * B));
+  else
+    b.ds.me_maskbits = nullptr;
   TRY(dalloc(c, &b.lk.prev_pts, K));
   TRY(dalloc(c, &b.lk.next_pts, K));
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
+  TRY(dalloc(c, &b.lk.nold, B));
   TRY(dalloc(c, &b.lk.src_idx, K));
   TRY(reset_tracker_status(c, b));
   // keyframe_R_ref_frame_ = identity
@@ -1004,6 +1009,26 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     }
     c->chain_pending = false;
   }
+  if (c->split_prev && c->commit_pending && c->prev_left) {
+    // SPLIT TRACKING (round 5).  The previous step's new corners are still being refined (on `sub`), but the points that
+    // frame k-1 already had when its detection ran -- the survivors of its own tracking, ~98 % of the list -- depend on
+    // nothing the refinement writes: their tracking starts now, and the chip works on it while the refinement's ~40
+    // sequential iterations per corner (latency, a few hundred waves) run beside it.  The new corners follow as a second,
+    // small launch behind the refinement.  Same points, same order, same arithmetic as one launch (track_prepare_kernel).
+    prof_begin(c, ST_TRACK, st);
+    launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st, 1);
+    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
+              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, false, 1);
+    prof_end(c, ST_TRACK, st);
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
+    c->commit_pending = false;
+    prof_break(c);
+    prof_begin(c, ST_TRACK_NEW, st);
+    launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st, 2);
+    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
+              img_stride, b.pyr[pc], b.lk, std::min(c->pts_bound, detect_new_bound(P)), st, false, 2);
+    prof_end(c, ST_TRACK_NEW, st);
+  } else {
   if (c->commit_pending) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
     prof_break(c);   // (the wait is not part of the tracking stage)
@@ -1015,6 +1040,8 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
               img_stride, b.pyr[pc], b.lk, c->pts_bound, st, false);
   prof_end(c, ST_TRACK, st);
+  }
+  c->split_prev = false;
   if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
     c->tail_pending = false;
@@ -1127,12 +1154,28 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
     slot_release.side_used = true;
   }
+  // swap + split: the refinement on its own stream `sub`, behind the selection and the state the next tracking reads; the
+  // main stream is free for the next step's tracking of the old points (see the tracking stage above)
+  static const bool split_env = !std::getenv("KVFE_X_SPLIT") || std::atoi(std::getenv("KVFE_X_SPLIT")) != 0;   // A/B aid (round 5)
+  const bool split = swap && c->sub && split_env;
+  if (split) {
+    launch_detect_state(P, K, b.ss, b.ds, st);
+    HIPCHK(c, hipEventRecord(c->ev_sel, st));
+    HIPCHK(c, hipStreamWaitEvent(c->sub, c->ev_sel, 0));
+    prof_begin(c, ST_SUBPIX, c->sub);
+    launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, c->sub, 6);
+    prof_end(c, ST_SUBPIX, c->sub);
+    HIPCHK(c, hipEventRecord(c->ev_commit, c->sub));
+    c->commit_pending = true;
+    c->split_prev = true;
+  } else {
   prof_begin(c, ST_SUBPIX, fa);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, fa);
   prof_end(c, ST_SUBPIX, fa);
   if (side && (c->own_stream || swap)) {
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
+  }
   }
   if (!rect_early) {
   prof_begin(c, ST_RECTIFY, fb);
@@ -1432,6 +1475,10 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     // is what a step costs, so it stays on ONE stream and the rectify / match / reject chain takes the side stream
     // (many streams: the same arrangement for the calls whose frames persist, do_step)
     c->fork_swap = c->P.B <= 4 && c->own_stream && !c->P.mono;
+    if (s == KVFE_OK && c->own_stream && !c->P.mono &&
+        (hipStreamCreateWithFlags(&c->sub, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess))
+      s = KVFE_ERR_HIP;
   }
   if (s != KVFE_OK) {
     std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
@@ -1524,6 +1571,7 @@ void kvfe_destroy(kvfe_ctx* c) {
     hipStreamSynchronize(c->out_stream);
     hipStreamDestroy(c->out_stream);
   }
+  if (c->topup_stream) hipStreamDestroy(c->topup_stream);
   for (int i = 0; i < OUT_RING; i++) {
     if (c->ev_packed[i]) hipEventDestroy(c->ev_packed[i]);
     if (c->ev_out[i]) hipEventDestroy(c->ev_out[i]);
@@ -1538,6 +1586,11 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->ev_main) hipEventDestroy(c->ev_main);
   if (c->ev_tail) hipEventDestroy(c->ev_tail);
   if (c->ev_commit) hipEventDestroy(c->ev_commit);
+  if (c->ev_sel) hipEventDestroy(c->ev_sel);
+  if (c->sub) {
+    hipStreamSynchronize(c->sub);
+    hipStreamDestroy(c->sub);
+  }
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->dense_allocs) hipFree(p);
   for (int i = 0; i < 2; i++)
@@ -2322,10 +2375,19 @@ kvfe_status kvfe_frontend_step_device(kvfe_ctx* c, const void* left_dev, const v
     for (int i = 0; i < 2; i++)
       if (!b.lvl0[i]) TRY(dalloc(c, &b.lvl0[i], bytes, false));
   }
+  // Round 5: with a library-owned stream the step is arranged exactly as with device_frames_persist (corner refinement off
+  // the main stream, rectify / match / reject chain on the side stream, joined by the NEXT step's keyframe decision): the
+  // contract above says the frames of a step are read until the step has COMPLETED -- kvfe_synchronize /
+  // kvfe_frontend_get_output, which wait for both streams -- not until the next step has been enqueued, so nothing has
+  // to be awaited in front of the next tracking launch.  (Round 4 awaited the chain there and therefore kept it on the main
+  // stream.)  What is left of the option is the copy of the left frame: the next step's tracking reads the context's
+  // copy, not the caller's buffer.  A caller-owned stream keeps the stream-ordered arrangement.
   c->own_level0 = true;
+  c->frames_persist_call = c->own_stream;
   const kvfe_status st = do_step(c, reinterpret_cast<const unsigned char*>(left_dev),
                                  reinterpret_cast<const unsigned char*>(right_dev), row_stride, image_stride, inputs);
   c->own_level0 = false;
+  c->frames_persist_call = false;
   return st;
 }
 
@@ -2386,21 +2448,22 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
 }
 
 // ---- staged input -----------------------------------------------------------------
-static kvfe_status ensure_staging(kvfe_ctx* c) {
+static kvfe_status ensure_staging(kvfe_ctx* c, int slot) {
   DeviceGuard _dev(c);
-  if (c->copy_stream) return KVFE_OK;
   const size_t bytes = 2 * (size_t)c->P.W * c->P.H * c->P.B;
-  HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  for (int i = 0; i < KVFE_STAGING_SLOTS; i++) {
+  if (!c->copy_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
+    if (c->cfg.params.stereo.equalize_image)
+      for (int i = 0; i < 2; i++) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));
+  }
+  if (!c->stage_host[slot]) {   // a slot's pinned memory on first use
     void* h = nullptr;
     HIPCHK(c, hipHostMalloc(&h, bytes, hipHostMallocDefault));
     c->host_allocs.push_back(h);
-    c->stage_host[i] = reinterpret_cast<unsigned char*>(h);
-    HIPCHK(c, hipEventCreateWithFlags(&c->stage_copied[i], hipEventDisableTiming));
+    c->stage_host[slot] = reinterpret_cast<unsigned char*>(h);
+    HIPCHK(c, hipEventCreateWithFlags(&c->stage_copied[slot], hipEventDisableTiming));
   }
-  for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
-  if (c->cfg.params.stereo.equalize_image)
-    for (int i = 0; i < 2; i++) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));
   return KVFE_OK;
 }
 
@@ -2409,7 +2472,7 @@ kvfe_status kvfe_frontend_staging_buffer(kvfe_ctx* c, int32_t slot, uint8_t** le
   if (!c || !left || !right || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;  // staged input drives one stream group
   if (c->P.rgbd) return KVFE_ERR_UNSUPPORTED;             // (depth images: use the host / device step)
-  TRY(ensure_staging(c));
+  TRY(ensure_staging(c, slot));
   *left = c->stage_host[slot];
   *right = c->stage_host[slot] + (size_t)c->P.W * c->P.H * c->P.B;
   return KVFE_OK;
@@ -2429,7 +2492,7 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
   DeviceGuard _dev(c);
   if (!c || !inputs || slot < 0 || slot >= KVFE_STAGING_SLOTS) return KVFE_ERR_INVALID_ARG;
   if (!c->children.empty()) return KVFE_ERR_UNSUPPORTED;
-  TRY(ensure_staging(c));
+  TRY(ensure_staging(c, slot));
   Buffers& b = c->fe;
   const KParams& P = c->P;
   const size_t N = (size_t)P.W * P.H, NB = N * P.B;
@@ -2466,10 +2529,12 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
   }
   c->img_step++;
   {
-    // Every kernel of this step on the main stream (no fork): the next slot's upload is in flight while the step runs, and
-    // with a DMA transfer in flight the cross-stream hand-overs of the forked step complete late (round 4, tools/r4/
-    // staged_probe.py, 64 streams, 30 steps: 3.1 ms per step forked, 2.0 ms in order -- the upload itself is 0.86 ms).
-    c->serial_call = true;
+    // Many streams: every kernel of this step on the main stream (no fork) -- the next slot's upload is in flight while the
+    // step runs, and with a DMA transfer in flight the cross-stream hand-overs of the forked step complete late (round 4,
+    // tools/r4/staged_probe.py, 64 streams, 30 steps: 3.1 ms per step forked, 2.0 ms in order; the upload itself is
+    // 0.86 ms).  A few streams (fork_swap: every kernel is a latency, the upload is a few hundred KB) keep the fork that
+    // was tuned for them.
+    c->serial_call = !c->fork_swap;
     const kvfe_status r = do_step(c, dl, dr, P.W, N, inputs);
     c->serial_call = false;
     if (r != KVFE_OK) return r;
@@ -2549,6 +2614,7 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   c->prev_left = nullptr;
   c->img_step = 0;
   c->pyr_cur = 0;
+  c->split_prev = false;
   if (c->out_stream) HIPCHK(c, hipStreamSynchronize(c->out_stream));
   c->out_steps = 0;
   c->last_step_staged = false;
@@ -2581,10 +2647,15 @@ static kvfe_status locate_output(kvfe_ctx* c, int32_t s, int32_t steps_back, con
     return KVFE_ERR_HIP;
   }
   if (end > c->out_copied[slot]) {   // the step needed more than its transfer was sized for: fetch the rest now
+    // On a stream of its own: the output stream already holds the transfers of LATER steps, each waiting for its
+    // step's records, so a top-up enqueued there would wait for the running step.  The slot's records
+    // are complete (ev_out above follows the event of their gather) and its staging buffer is not rewritten before
+    // OUT_RING more steps have been enqueued by this same thread.
     const size_t from = c->out_copied[slot];
+    if (!c->topup_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->topup_stream, hipStreamNonBlocking));
     HIPCHK(c, hipMemcpyAsync(c->out_host[slot] + from, c->out_stage[slot] + from, end - from, hipMemcpyDeviceToHost,
-                             c->out_stream));
-    HIPCHK(c, hipStreamSynchronize(c->out_stream));
+                             c->topup_stream));
+    HIPCHK(c, hipStreamSynchronize(c->topup_stream));
     c->out_copied[slot] = end;
     c->out_topups++;
   }

@@ -218,15 +218,11 @@ struct DetectScratch {
   unsigned char* state;      // [B][ccap]
   unsigned long long* sortbuf;  // [B][ccap rounded to pow2]
   int sort_cap;
-  // detection mask and work list of the min-eigenvalue launch (k_detect.hip mineig_prep_kernel)
-  unsigned long long* me_maskbits;  // [B][H][me_mask_words(W)] bit x + 64 of row y: pixel (x, y) is masked OUT
-  unsigned* me_items;               // [B][me_max_items] item (row strip * nx + column strip) | cost << 16, heaviest first
-  int* me_n_items;                  // [B] items with at least one needed row (0: the stream does not detect)
-  unsigned* me_counter;             // [B][1024] (first word used) next work item of the stream
-  int* me_cost;                     // [B] summed cost of the stream's items (row steps)
+  // detection mask as a bitmap (k_detect.hip detect_mask_kernel; FeatureDetectorType::FAST)
+  unsigned long long* me_maskbits;  // [B][H][me_mask_words(W)] bit x + 64 of row y: pixel (x, y) is masked OUT (null: GFTT)
 };
 __host__ __device__ inline int me_mask_words(int W) { return ((W + 64 + 63) >> 6) + 1; }   // 64 bits in front, 1 word behind
-inline int me_max_items(int W, int H) { return ((W + 57) / 58) * ((H + 15) / 16); }         // strips of >= 16 rows
+
 
 // LK scratch (component API and frontend share it)
 struct LkScratch {
@@ -235,6 +231,7 @@ struct LkScratch {
   unsigned char* status;  // [B][kcap]
   float* err;             // [B][kcap]
   int* npts;              // [B]
+  int* nold;              // [B] how many of them existed before the previous frame's detection (launch_track_prepare part 1)
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
   // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
@@ -289,10 +286,10 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true);
+               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true, int part = 0);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part = 0);
 // survivors -> frame k, bearing vectors, keyframe decision (Tracker.cpp:167-189,
 // StereoVisionImuFrontend.cpp:313-347, VisionImuFrontend.cpp:175-232)
 void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
@@ -313,7 +310,9 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
 void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
-                          hipStream_t st);
+                          hipStream_t st, int commit_what = 7 /* detect_commit_kernel: state | landmark counter | count */);
+// detect_commit_kernel bit 0 alone: what the next step's tracking of the old points reads
+void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D, hipStream_t st);
 // the per-stream state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the frame's keypoint
 // count): known once the new corners are SELECTED.  launch_subpix_append(append = 2) leaves it to this launch.
 int detect_new_bound(const KParams& P);   // upper bound of the new corners per stream and frame

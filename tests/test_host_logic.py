@@ -381,4 +381,4 @@ def test_hand_issued_row_requests_target_accumulation_registers():
     rep = mod.check_hip()
     assert len(rep) >= 2
     for k, (dests, bad) in rep.items():
-        assert dests == ["a0", "a1", "a2"] and not bad, (k, dests, bad[:3])
+        assert dests == ["a0", "a1", "a2", "a3", "a4", "a5"] and not bad, (k, dests, bad[:3])

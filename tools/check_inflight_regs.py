@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """ISA check for the hand-issued row requests of mineig2_kernel (k_detect.hip).
 
-The kernel issues `buffer_load_ubyte` from inline asm and waits for them with a hand-placed `s_waitcnt vmcnt(2)`; hipcc does
+The kernel issues `buffer_load_ubyte` from inline asm and waits for them with a hand-placed `s_waitcnt vmcnt(5)`; hipcc does
 not know that the destination register of such a statement is written LATER, so nothing stops it from copying that register
 (a phi move, a tied asm operand) before the byte has landed -- which is what the first version of round 4's run loop ran
 into.  This script compiles k_detect.hip to gfx950 assembly and checks, for every mineig2_kernel instantiation, that the
-hand-issued loads target accumulation registers (a0 / a1 / a2: the fix -- hipcc allocates no AGPR in this kernel, so
+hand-issued loads target accumulation registers (a0 .. a5: the fix -- hipcc allocates no AGPR in this kernel, so
 nothing it generates can touch a request in flight), that the kernel owns exactly those AGPRs (no AGPR spilling by
 hipcc) and that no compiler-generated instruction names an accumulation register.
 
