@@ -204,25 +204,18 @@ constexpr int ME2_ROWS = 120;             // most output rows per wave of mineig
 constexpr size_t KVFE_ME_PROF_WAVES = 8192;
 __device__ unsigned long long kvfe_me_prof[KVFE_ME_PROF_WAVES * 8];   // per wave: cycles of the mask phase, the row loop, the epilogue; items; needed pixel rows; rows walked; start; end
 #endif
-// Launch shape (round 5): TWO blocks of ME_BLOCK_WAVES waves per compute unit, each wave pulling (column strip, row strip,
-// stream) items off the block's own LDS counter; block b owns the items b, b + G, b + 2 G ... (G blocks).  Rounds 3-4
-// launched one resident wave per item: the waves of neighbouring strips -- whose cost is correlated: a region without a
-// tracked keypoint needs all of its rows in every strip that crosses it -- land on the same SIMD, which then issues for
-// five full strips (5 x 85 rows x ~90 instructions x 4 cycles = 153 k cycles, the launch's longest wave) while the
-// average SIMD has a third of that to do (vector issue 41 % busy over the launch).  With the stride a block's items come
-// from all over the batch, and inside the block whichever wave is free takes the next one.  Waves of a block share
-// nothing but the counter and the disc half widths: their LDS areas are per wave and ordered by wave-level fences.
-constexpr int ME_BLOCK_WAVES = 8;    // two blocks per compute unit (a 1024-thread block would leave hipcc 64 vector registers per
-                                      // lane beside the accumulation half the row requests make it reserve: it spills into the
-                                      // accumulation registers, which the requests in flight own -- tools/check_inflight_regs.py)
-#define KVFE_ME_WAVE_SYNC()                                    \
-  do {                                                         \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
-    __builtin_amdgcn_wave_barrier();                           \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
-  } while (0)
+// Launch shape: one single-wave block per (column strip, row strip, stream) item, every wave of the launch resident at
+// once (rounds 3-5).  Round 5 measured three other shapes, all bit-exact, all slower (tools/r5/gpu_a.sh .. gpu_e.sh,
+// profiles/r5_analysis.md): resident waves pulling cost-ordered items off one global counter (0.20 - 0.24 ms: 10 k
+// returning device-scope atomics on one word take 0.11 ms), off one counter per stream with a per-stream disc bitmap from
+// a prep launch (0.097 - 0.114 ms), and two 8-wave blocks per compute unit pulling items off an LDS counter (0.085 - 0.104
+// ms) -- against 0.079 ms.  The launch ends with its longest item either way (a strip that needs all of its rows: 85
+// rows at ~1.75 k cycles each, the issue rate of a SIMD shared by five waves -- not memory latency: six rows in flight
+// instead of three changed nothing), and shorter strips pay the mask phase (22 k cycles, ~600 keypoint tests) once more
+// per item.
+#define KVFE_ME_WAVE_SYNC() __syncthreads()   /* (a block is one wave) */
 template <bool HAS_MASK, bool HARRIS>
-__global__ __launch_bounds__(64 * ME_BLOCK_WAVES) void mineig2_kernel(
+__global__ __launch_bounds__(64) void mineig2_kernel(
     const unsigned char* __restrict__ img, size_t row_stride, size_t img_stride,
     const unsigned char* __restrict__ user_mask, int W, int H, int kcap, int ccap, int radius,
     const int* __restrict__ circle_hw, const float2* __restrict__ kp_all,
@@ -230,32 +223,18 @@ __global__ __launch_bounds__(64 * ME_BLOCK_WAVES) void mineig2_kernel(
     const int* __restrict__ flags,
     unsigned long long* __restrict__ cand_all, int* __restrict__ cand_count,
     unsigned int* __restrict__ maxkey, int strip_rows, int B, int nx, int ny, float harris_kf, double harris_kd) {
-  __shared__ unsigned long long rowmask_all[ME_BLOCK_WAVES][132];  // per wave: [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
-  __shared__ unsigned long long lcand_all[ME_BLOCK_WAVES][ME_LCAP];
-  __shared__ int hw_s[MAX_RADIUS + 1];
-  __shared__ int q_next;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long* const rowmask = rowmask_all[wave];
-  unsigned long long* const lcand = lcand_all[wave];
-  for (int i = threadIdx.x; i <= radius && i <= MAX_RADIUS; i += 64 * ME_BLOCK_WAVES) hw_s[i] = circle_hw[i];
-  if (threadIdx.x == 0) q_next = 0;
-  __syncthreads();
-  const long long total = (long long)nx * ny * B;
-#ifdef KVFE_ME_PROF
-  unsigned long long me_acc[6] = {0, 0, 0, 0, 0, 0};
-  const unsigned long long me_start = __builtin_readcyclecounter();
-#endif
-  for (;;) {
-  int qk = 0;
-  if (lane == 0) qk = atomicAdd(&q_next, 1);
-  qk = __builtin_amdgcn_readfirstlane(qk);
-  const long long id = (long long)qk * gridDim.x + blockIdx.x;
-  if (id >= total) break;
-  const int bx = (int)(id % nx), by = (int)((id / nx) % ny), s = (int)(id / ((long long)nx * ny));
-  if (flags && !(flags[s] & FLAG_DETECT)) continue;
+  // block -> (column strip, row strip, stream).  (An XCD-banded 1-D order was measured in round 3: 0.084 against 0.082 ms.)
+  const int s = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+  if (flags && !(flags[s] & FLAG_DETECT)) return;
 #ifdef KVFE_ME_PROF
   const unsigned long long me_t0 = __builtin_readcyclecounter();
 #endif
+  __shared__ unsigned long long rowmask[132];  // [row of the strip] bit l set: lane l's column is masked OUT; 128: read-ahead slot
+  __shared__ unsigned long long lcand[ME_LCAP];
+  __shared__ int hw_s[MAX_RADIUS + 1];
+  const int lane = threadIdx.x;
+  for (int i = lane; i <= radius && i <= MAX_RADIUS; i += 64) hw_s[i] = circle_hw[i];
+  __syncthreads();
 
   const unsigned char* I = img + (size_t)s * img_stride;
   const unsigned char* M = HAS_MASK ? user_mask + (size_t)s * W * H : nullptr;
@@ -318,7 +297,6 @@ __global__ __launch_bounds__(64 * ME_BLOCK_WAVES) void mineig2_kernel(
         }
       }
     }
-    KVFE_ME_WAVE_SYNC();   // (the previous item's readers of the wave's LDS areas are done)
     rowmask[lane] = mrow0;
     rowmask[64 + lane] = mrow1;   // (rows past the strip: all zero; slot 128 is the read-ahead slot)
     if (lane == 0) rowmask[128] = 0ull;
@@ -361,9 +339,9 @@ __global__ __launch_bounds__(64 * ME_BLOCK_WAVES) void mineig2_kernel(
 
   // source rows: raw buffer, per-lane column in a VGPR, row offset in an SGPR (an image is < 2 GiB).  SIX rows in flight
   // per lane (one per rotating slot), issued and awaited by hand: vmcnt counts in issue order, so "at most five
-  // outstanding" means this slot's load has landed.  (Rounds 3-4 kept three in flight: a wave then advances one row per
-  // third of a memory round trip -- 1.75 k cycles per row measured under load, whatever shares its SIMD -- and the launch
-  // lasts as long as the strip that needs all of its 85 rows, 149 k of its 175 k cycles; tools/r5/gpu_c.sh.)
+  // outstanding" means this slot's load has landed.  (Rounds 3-4 kept three in flight; six measured the same launch
+  // time, 0.078 against 0.079 ms, tools/r5/gpu_d.sh: a row costs ~1.75 k cycles because five waves share the SIMD's
+  // issue slots, not because its byte is late.)
   const unsigned stride_u = (unsigned)row_stride;
   const unsigned long long ibase = (unsigned long long)(size_t)I;
   const me_v4i rsrc = {(int)(unsigned)ibase, (int)(unsigned)((ibase >> 32) & 0xffffu),
@@ -666,25 +644,19 @@ __global__ __launch_bounds__(64 * ME_BLOCK_WAVES) void mineig2_kernel(
       bestkey > __hip_atomic_load(&maxkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&maxkey[s], bestkey);
 #ifdef KVFE_ME_PROF
-  {
+  if (lane == 0) {   // one record per wave of the LAST launch (no atomics: they would be what is measured)
     const unsigned long long me_t3 = __builtin_readcyclecounter();
-    me_acc[0] += me_t1 - me_t0;
-    me_acc[1] += me_t2 - me_t1;
-    me_acc[2] += me_t3 - me_t2;
-    me_acc[3] += 1ull;
-    me_acc[4] += (unsigned long long)(__popcll(needp0) + __popcll(needp1));
-    me_acc[5] += (unsigned long long)(r_last - r_first + 1);
-  }
-#endif
-  }   // next item
-#ifdef KVFE_ME_PROF
-  {
-    const size_t w = (size_t)blockIdx.x * ME_BLOCK_WAVES + wave;
-    if (lane == 0 && w < KVFE_ME_PROF_WAVES) {   // one record per wave of the LAST launch
+    const size_t w = ((size_t)s * gridDim.y + by) * gridDim.x + bx;
+    if (w < KVFE_ME_PROF_WAVES) {
       unsigned long long* o = kvfe_me_prof + w * 8;
-      for (int i = 0; i < 6; i++) o[i] = me_acc[i];
-      o[6] = me_start;
-      o[7] = __builtin_readcyclecounter();
+      o[0] = me_t1 - me_t0;
+      o[1] = me_t2 - me_t1;
+      o[2] = me_t3 - me_t2;
+      o[3] = 1ull;
+      o[4] = (unsigned long long)(__popcll(needp0) + __popcll(needp1));
+      o[5] = (unsigned long long)(r_last - r_first + 1);
+      o[6] = me_t0;
+      o[7] = me_t3;
     }
   }
 #endif
@@ -724,34 +696,36 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     }
   }
 #endif
-  static int cus = 0;
-  if (!cus) {
+  static int simds = 0;
+  if (!simds) {
     hipDeviceProp_t prop;
     int dev = 0;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                ? prop.multiProcessorCount * 4 : 1024;
   }
-  // Strip height.  Every item pays 6 rows of overlap with its neighbours and the mask phase (~600 keypoint tests),
-  // so strips are tall; ME2_ROWS bounds them (the row-need masks hold 128 rows).  With one block per compute unit pulling
-  // items, the height no longer has to make the number of waves fit the device: the shortest height above 64 rows whose
-  // item count gives every block at least ME_BLOCK_WAVES items (few streams: fewer, taller does not help either).
+  // Strip height.  Every wave of the launch is resident at once (5 waves per SIMD) and a SIMD works through its waves'
+  // rows, so the launch lasts (waves per SIMD, rounded UP) x (rows per wave); every strip pays 5 rows of overlap.  The
+  // product is smallest for 6 strips of 80 rows at 64 x 752x480 (4992 waves, 5 per SIMD x 85 rows = 425 row-times;
+  // 4 strips: 4 x 125 = 500, 8 strips: 7 x 65 = 455); a few streams get short strips (more waves than SIMDs).
+  // Measured in round 3, again with the run walk in round 4 (40 / 60 / 80 / 120 rows -> 0.090 / 0.088 / 0.082 / 0.105 ms)
+  // and in round 5 with six rows in flight (48 / 60 / 80 / 96 / 120 -> 0.092 / 0.101 / 0.078 / 0.079 / 0.087 ms).
   const int nx = (P.W + ME_COLS - 1) / ME_COLS;
   int strip_rows = min(P.H, ME2_ROWS);
-  for (int ns = (P.H + ME2_ROWS - 1) / ME2_ROWS; ns <= (P.H + 63) / 64; ns++) {
+  double best = 1e30;
+  for (int ns = 1; ns <= (P.H + 15) / 16; ns++) {
     const int rws = (P.H + ns - 1) / ns;
     if (rws > ME2_ROWS) continue;
-    strip_rows = rws;
-    if ((long long)nx * ns * P.B >= (long long)cus * 2 * ME_BLOCK_WAVES) break;
+    const long long waves = (long long)nx * ns * P.B;
+    const double cost = (double)((waves + simds - 1) / simds) * (rws + 5);
+    if (cost < best) best = cost, strip_rows = rws;
   }
 #ifdef KVFE_ME_ROWS_OVERRIDE   // (with KVFE_ME_PROF: strip height of the A/B builds)
   strip_rows = KVFE_ME_ROWS_OVERRIDE;
 #endif
-  static const int rows_env = std::getenv("KVFE_ME_ROWS") ? std::atoi(std::getenv("KVFE_ME_ROWS")) : 0;   // A/B aid (round 5)
-  if (rows_env >= 16 && rows_env <= ME2_ROWS) strip_rows = min(P.H, rows_env);
   const int ny = (P.H + strip_rows - 1) / strip_rows;
-  const long long items = (long long)nx * ny * P.B;
-  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(items, 2LL * cus));
+  const dim3 grid((unsigned)nx, (unsigned)ny, (unsigned)P.B);
   auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * ME_BLOCK_WAVES), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
+    hipLaunchKernelGGL(kernel, grid, dim3(64), 0, st, img, row_stride, img_stride, user_mask, P.W, P.H,
                        P.kcap, P.ccap, P.min_distance, T.circle_hw, k.kp, k.lmk, k.count, use_discs, S.flags, D.cand, D.cand_count,
                        D.maxkey, strip_rows, P.B, nx, ny, (float)P.harris_k, P.harris_k);
   };
@@ -2064,6 +2038,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(KParams P, Tables T, Fram
   if (tid == 0) {
     D.n_corners[s] = n_corners;
     D.n_new[s] = n_new;
+    D.sp_next[s] = 0;   // (the refinement's work counter of this stream)
     D.need[s] = need;
     S.n_detected[s] = n_new;
     if (overflow) S.flags[s] |= FLAG_OVERFLOW;
@@ -2250,7 +2225,7 @@ __host__ __device__ inline SpgGeom spg_geom(int win) {
   g.bytes = o;
   return g;
 }
-enum { SPG_CIX = 0, SPG_CIY, SPG_CTX, SPG_CTY, SPG_ACTIVE, SPG_STAGED, SPG_SX0, SPG_SY0, SPG_ITER };
+enum { SPG_CIX = 0, SPG_CIY, SPG_CTX, SPG_CTY, SPG_ACTIVE, SPG_STAGED, SPG_SX0, SPG_SY0, SPG_ITER, SPG_CI };
 
 template <int WIN>
 __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Tables T, const unsigned char* __restrict__ img,
@@ -2283,21 +2258,58 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
   const double eps2 = P.subpix_eps2;
 
   for (int k = tid; k < nt; k += SPG_T) mask_s[k] = T.subpix_mask[k];
-  if (tid < SPG_G) {
-    const int ci = c_first + tid;
-    const bool on = ci < n_new;
-    const float2 c0 = on ? D.newc[(size_t)s * P.acap + ci] : make_float2(0.f, 0.f);
-    statef[tid * 16 + SPG_CIX] = c0.x;
-    statef[tid * 16 + SPG_CIY] = c0.y;
-    statef[tid * 16 + SPG_CTX] = c0.x;
-    statef[tid * 16 + SPG_CTY] = c0.y;
-    state[tid * 16 + SPG_ACTIVE] = (on && P.subpix_enable) ? 1 : 0;
-    state[tid * 16 + SPG_STAGED] = 0;
-    state[tid * 16 + SPG_SX0] = 0;
-    state[tid * 16 + SPG_SY0] = 0;
-    state[tid * 16 + SPG_ITER] = 0;
+  // A finished corner is written out at once and its slot takes the stream's next corner off a counter (round 5).  Until
+  // round 4 a block kept its eight corners to the end, i.e. for as many iterations as its slowest one: corners need 19
+  // iterations on average and 40 % of them more than 20 (KVFE_SUBPIX_STATS), so most of a block's lanes idled most of
+  // the time.  Same arithmetic per corner; which block refines a corner is invisible in the result.
+  const bool do_append = (append & 15) != 0;
+  auto finish = [&](int ci, float2 c, float2 cT) {   // FeatureDetector.cpp:141-160
+    if (P.subpix_enable && (fabsf(c.x - cT.x) > WIN || fabsf(c.y - cT.y) > WIN)) c = cT;
+    if (do_append) {
+      const int base = S.n_tracked[s];
+      const size_t o = (size_t)s * P.kcap + base + ci;
+      K.kp[o] = c;
+      K.lmk[o] = S.lmk_counter[s] + ci;
+      K.age[o] = 1;
+      double v[3];
+      bearing_vector(T.und_left_R, c.x, c.y, v);
+      K.versor[o * 3] = v[0];
+      K.versor[o * 3 + 1] = v[1];
+      K.versor[o * 3 + 2] = v[2];
+    } else {
+      D.newc[(size_t)s * P.acap + ci] = c;
+    }
+  };
+  auto pull = [&](int slot) -> bool {   // the slot's next corner; false: the stream has none left
+    for (;;) {
+      const int ci = atomicAdd(&D.sp_next[s], 1);
+      if (ci >= n_new) {
+        state[slot * 16 + SPG_ACTIVE] = 0;
+        return false;
+      }
+      const float2 c0 = D.newc[(size_t)s * P.acap + ci];
+      if (!P.subpix_enable) {   // nothing to refine: the corner goes out as it is
+        finish(ci, c0, c0);
+        continue;
+      }
+      statef[slot * 16 + SPG_CIX] = c0.x;
+      statef[slot * 16 + SPG_CIY] = c0.y;
+      statef[slot * 16 + SPG_CTX] = c0.x;
+      statef[slot * 16 + SPG_CTY] = c0.y;
+      state[slot * 16 + SPG_ACTIVE] = 1;
+      state[slot * 16 + SPG_STAGED] = 0;
+      state[slot * 16 + SPG_SX0] = 0;
+      state[slot * 16 + SPG_SY0] = 0;
+      state[slot * 16 + SPG_ITER] = 0;
+      state[slot * 16 + SPG_CI] = ci;
+      return true;
+    }
+  };
+  if (wave == 0) {
+    const bool on = lane < SPG_G && pull(lane);
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) sh_active = __popcll(bal);
   }
-  if (tid == 0) sh_active = P.subpix_enable ? min(SPG_G, n_new - c_first) : 0;
   int eij[MAXP];   // patch entries e = sub + 32 t of the (2w+3)^2 window
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
@@ -2394,13 +2406,8 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     if (wave > 0) produce(0, 0);
     __syncthreads();
     SPG_STAMP(2);
-    // The chain wave is the block's critical path (448 dependent additions per iteration while the seven producer waves
-    // wait for it at the chunk barriers) but shares its SIMD's issue slots with three of them: raised wave priority lets
-    // it issue whenever its next addition is ready (round 4 measured ~25 cycles per term against the 5.6 a dependent
-    // v_add_f64 needs).
-#ifndef KVFE_SPG_NOPRIO
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);
-#endif
+    // (raised wave priority -- s_setprio 3 -- for the chain wave, the block's critical path, was measured in round 5:
+    // cornerSubPix on real frames 1.560 ms with and without it, tools/r5/gpu_e.sh)
     for (int kc = 0; kc < NCH; kc++) {
       if (wave == 0) {
         if (lane < 5 * SPG_G) {
@@ -2428,9 +2435,6 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       }
       if (kc + 1 < NCH) __syncthreads();
     }
-#ifndef KVFE_SPG_NOPRIO
-    if (wave == 0) __builtin_amdgcn_s_setprio(0);
-#endif
     SPG_STAMP(3);
     // ---- C: the 2 x 2 system, one lane per corner (wave 0) ------------------------------------------------------
     if (wave == 0) {
@@ -2458,7 +2462,10 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
         statef[lane * 16 + SPG_CIX] = cI.x;
         statef[lane * 16 + SPG_CIY] = cI.y;
         state[lane * 16 + SPG_ITER] = iter;
-        state[lane * 16 + SPG_ACTIVE] = still ? 1 : 0;
+        if (!still) {   // done: out it goes, and the slot takes the stream's next corner
+          finish(state[lane * 16 + SPG_CI], cI, make_float2(statef[lane * 16 + SPG_CTX], statef[lane * 16 + SPG_CTY]));
+          still = pull(lane);
+        }
       }
       const unsigned long long bal = __ballot(still);
       if (lane == 0) sh_active = __popcll(bal);
@@ -2470,27 +2477,6 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     atomicAdd(&kvfe_spg_stats[5], 1ull);
   }
 #undef SPG_STAMP
-  // ---- append (FeatureDetector.cpp:141-160) -----------------------------------------------------------------------
-  if (tid < SPG_G && c_first + tid < n_new) {
-    const int ci = c_first + tid;
-    float2 c = make_float2(statef[tid * 16 + SPG_CIX], statef[tid * 16 + SPG_CIY]);
-    const float2 cT = make_float2(statef[tid * 16 + SPG_CTX], statef[tid * 16 + SPG_CTY]);
-    if (P.subpix_enable && (fabsf(c.x - cT.x) > WIN || fabsf(c.y - cT.y) > WIN)) c = cT;
-    if (append) {
-      const int base = S.n_tracked[s];
-      const size_t o = (size_t)s * P.kcap + base + ci;
-      K.kp[o] = c;
-      K.lmk[o] = S.lmk_counter[s] + ci;
-      K.age[o] = 1;
-      double v[3];
-      bearing_vector(T.und_left_R, c.x, c.y, v);
-      K.versor[o * 3] = v[0];
-      K.versor[o * 3 + 1] = v[1];
-      K.versor[o * 3 + 2] = v[2];
-    } else {
-      D.newc[(size_t)s * P.acap + ci] = c;
-    }
-  }
 }
 
 // after the append: counts and the per-stream landmark-id counter -- and the two pieces of per-stream state the NEXT
@@ -2498,13 +2484,13 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
 // They used to be written by step_finalize, at the very end of the step; written here, the next step's predictor and
 // tracking launch depend on the corner refinement only, and this step's tail (stereo matching of the new corners,
 // measurements, lkf <- k) runs next to them instead of in front of them.
-// what: bit 0 = the state the next step's tracking of the OLD points reads (keyframe_R_ref_frame_, "initialised": known
-// once the keyframe decision is made), bit 1 = the landmark-id counter (read by the append of THIS frame's corners, so it
-// moves after them), bit 2 = the frame's keypoint count.  The count moves only when the new corners ARE in the table:
-// kernels that walk the table up to the count (the stereo outlier rejection beside the refinement) must not meet entries
-// that still hold an older frame's landmarks.  Round 5: the step runs bit 0 on the main stream right after the selection
-// (launch_detect_state) and bits 1 + 2 behind the corner refinement on its own stream, so that the next step's tracking
-// of the old points does not wait for the refinement (kvfe_api.cpp do_step); every other caller runs all three behind it.
+// what: bit 0 = the state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the keypoint count: all
+// known once the corners are selected), bit 1 = the landmark-id counter (read by the append of THIS frame's corners, so
+// it moves after them).  Every caller runs both behind the corner refinement.
+// (Round 5 measured a step whose tracking is split -- the points frame k-1 already had tracked while its new corners are
+// still refined on a third stream, the new corners in a second small launch behind the refinement: bit exact, and 8 %
+// SLOWER, tools/r5/gpu_e.sh, gpu_f.sh.  The window the refinement's latency leaves is not idle: the rectify / match /
+// reject chain fills it, and with the tracking launch on top all three only share the chip.)
 __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D, int what) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.B) return;
@@ -2521,11 +2507,8 @@ __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, Detec
   }
   if (!(flags & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
-  if (what & 4) K.count[s] = S.n_tracked[s] + n_new;
+  if (what & 1) K.count[s] = S.n_tracked[s] + n_new;
   if (what & 2) S.lmk_counter[s] += n_new;
-}
-void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D, hipStream_t st) {
-  hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 1);
 }
 
 int detect_new_bound(const KParams& P) {
@@ -2538,7 +2521,7 @@ int detect_new_bound(const KParams& P) {
 void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
-                          hipStream_t st, int commit_what) {
+                          hipStream_t st) {
   const size_t lds = subpix_geom(P.subpix_win).bytes;
   const int bound = detect_new_bound(P);
   // waves per corner of the one-corner-per-block kernel: 2 (DPP broadcast chains, kvfe_subpix.inl), and 4 for a few
@@ -2592,10 +2575,19 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
     static const int budget = lds_dynamic_budget(reinterpret_cast<const void*>(subpix_group_kernel<10>));
     const size_t glds = spg_geom(10).bytes;
     if ((long long)glds > budget) std::fprintf(stderr, "kvfe: subpix_group_kernel needs %zu B of LDS, %d available\n", glds, budget);
-    hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, (bound + SPG_G - 1) / SPG_G), dim3(SPG_T), glds, st, P, T, img,
+    // blocks per stream: what the device holds at once (two 65 KB blocks per compute unit) shared out over the streams --
+    // every block resident from the start, its eight slots refilled from the stream's counter as corners finish
+    static int cus = 0;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int gy = std::max(1, std::min((bound + SPG_G - 1) / SPG_G, (2 * cus + P.B - 1) / P.B));
+    hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, gy), dim3(SPG_T), glds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append | (stats_on ? 16 : 0) | (group_mode == 2 ? 64 : 0));
   }
-  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, commit_what);
+  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 3);
 }
 
 template <int WIN, int NW>

@@ -69,11 +69,9 @@ __global__ __launch_bounds__(64) void lk_kernel_generic(KParams P, const unsigne
                                                         size_t cur_row_stride,
                                                         size_t cur_img_stride,
                                                         const unsigned char* cur_pyr,
-                                                        LkScratch lk, int part) {
-  const int s = blockIdx.y;
-  const int first = part == 2 ? lk.nold[s] : 0, limit = part == 1 ? lk.nold[s] : lk.npts[s];
-  const int pt = first + (int)blockIdx.x;
-  if (pt >= limit) return;
+                                                        LkScratch lk) {
+  const int s = blockIdx.y, pt = blockIdx.x;
+  if (pt >= lk.npts[s]) return;
   const int lane = threadIdx.x;
   const int win = P.klt_win, w2 = win * win, wp = win + 1, ws = win + 3;
   extern __shared__ unsigned char lds_raw[];
@@ -469,12 +467,8 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams
   // split over two HIP streams; both lost their A/B and were removed in round 4)
   const bool want_err = !(use_order & 8);
   const int s = blockIdx.y, rank = blockIdx.x;
-  // bits 4-5 of the flags: which part of the stream's points this launch tracks (launch_lk): 0 all, 1 the points that
-  // existed before the previous frame's detection [0, nold), 2 the corners that detection appended [nold, npts)
-  const int part = (use_order >> 4) & 3;
-  const int first = part == 2 ? lk.nold[s] : 0, limit = part == 1 ? lk.nold[s] : lk.npts[s];
-  if (first + rank >= limit) return;
-  const int pt = first + rank;
+  if (rank >= lk.npts[s]) return;
+  const int pt = rank;
   int iters_total = 0;
   const int lane = threadIdx.x;
   const int g = lane >> 4, q = lane & 15;
@@ -851,10 +845,9 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err, int part) {
+               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err) {
   if (max_pts <= 0) return;
-  // (bit 3: no error output -- Tracker::featureTracking drops that vector; bits 4-5: the part of the points, see the kernel)
-  const int flags = (want_err ? 0 : 8) | ((part & 3) << 4);
+  const int flags = want_err ? 0 : 8;   // (bit 3: no error output -- Tracker::featureTracking drops that vector)
   const dim3 grid(max_pts, P.B), block(64);
 #define KVFE_LK_SYS(WINSZ)                                                                                          \
   hipLaunchKernelGGL(lk_kernel_sys<WINSZ>, grid, block, 0, st, P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, \
@@ -866,7 +859,7 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
     default:
       hipLaunchKernelGGL(lk_kernel_generic, grid, block, lk_generic_lds_bytes(P.klt_win), st, P,
                          prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
-                         cur_row_stride, cur_img_stride, cur_pyr, lk, part & 3);
+                         cur_row_stride, cur_img_stride, cur_pyr, lk);
   }
 #undef KVFE_LK_SYS
 #ifdef KVFE_LK_PROF
@@ -1019,17 +1012,13 @@ __device__ __forceinline__ float2 predict_point(const float* H, float2 p, int W,
   return p;
 }
 
-// part: 0 = every keypoint of frame k-1; 1 = the entries that were there BEFORE frame k-1's detection (the survivors of
-// its own tracking, [0, n_tracked)); 2 = the corners its detection appended ([n_tracked, count)), appended behind part
-// 1's points.  Parts 1 and 2 together write exactly what part 0 writes (the gather is order preserving); the split lets
-// the tracking of the old points start while the new corners are still being refined (kvfe_api.cpp do_step).
 __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T, FrameTab KM1,
-                                                            StreamState S, LkScratch lk, int part) {
+                                                            StreamState S, LkScratch lk) {
   const int s = blockIdx.x;
   __shared__ float Hs[9];
   __shared__ int use_h;
   if (!(S.flags[s] & FLAG_INIT)) {
-    if (threadIdx.x == 0) lk.npts[s] = 0, lk.nold[s] = 0;
+    if (threadIdx.x == 0) lk.npts[s] = 0;
     return;
   }
   if (threadIdx.x == 0) {
@@ -1052,15 +1041,13 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
   __syncthreads();
   // Tracker.cpp:103-112: only keypoints with a valid landmark are tracked (geometric outlier
   // rejection leaves landmark -1 entries in a keyframe); src_idx maps point -> index in frame k-1
-  const int n_all = KM1.count[s];
-  const int n_before = min(S.n_tracked[s], n_all);   // entries in front of the last detection's corners
-  const int i0 = part == 2 ? n_before : 0, n = part == 1 ? n_before : n_all;
+  const int n = KM1.count[s];
   const size_t so = (size_t)s * P.kcap;
   __shared__ int wave_tot[4];
   __shared__ int sh_off;
-  if (threadIdx.x == 0) sh_off = part == 2 ? lk.nold[s] : 0;
+  if (threadIdx.x == 0) sh_off = 0;
   __syncthreads();
-  for (int base = i0; base < n; base += 256) {
+  for (int base = 0; base < n; base += 256) {
     const int i = base + threadIdx.x;
     const bool valid = i < n && KM1.lmk[so + i] != -1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1088,15 +1075,12 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(KParams P, Tables T,
     if (threadIdx.x == 0) sh_off = off0 + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    lk.npts[s] = sh_off;
-    if (part != 2) lk.nold[s] = sh_off;   // (part 0: everything counts as "old": a part-1 launch would cover it all)
-  }
+  if (threadIdx.x == 0) lk.npts[s] = sh_off;
 }
 
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part) {
-  hipLaunchKernelGGL(track_prepare_kernel, dim3(P.B), dim3(256), 0, st, P, T, km1, S, lk, part);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st) {
+  hipLaunchKernelGGL(track_prepare_kernel, dim3(P.B), dim3(256), 0, st, P, T, km1, S, lk);
 }
 
 __global__ void predict_flow_kernel(KParams P, Tables T, const double* R, const float2* prev,

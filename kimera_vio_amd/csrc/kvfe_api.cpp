@@ -41,13 +41,12 @@ enum Stage {
   ST_FINALIZE,
   ST_RANSAC_MONO,
   ST_RANSAC_STEREO,
-  ST_TRACK_NEW,     // split tracking (do_step): the previous frame's new corners, behind their refinement
   ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "mineig_localmax",
                                      "gftt_select", "subpix_append", "rectify", "stereo_match",
                                      "stereo_match_new", "step_finalize", "ransac_mono",
-                                     "ransac_stereo", "lk_track_new"};
+                                     "ransac_stereo"};
 
 struct Buffers {  // everything that scales with the number of streams
   unsigned char* lvl0[2] = {nullptr, nullptr};  // [B][H][W] own copy of the left image per pyramid slot (device-pointer steps)
@@ -110,11 +109,16 @@ struct kvfe_ctx {
   int pts_bound = 0;
   // pinned input staging ring
   static constexpr int RING = 64;
+  // staged steps: the per-stream inputs travel to a device ring slot by a copy behind the frames' upload (do_step)
+  unsigned char* in_dev = nullptr;                   // [RING][ring_bytes]
+  hipEvent_t in_ev[RING] = {};
+  bool inputs_by_copy_call = false;                  // this do_step call: set by kvfe_frontend_step_staged
+  hipStream_t in_stream = nullptr;                   // (A/B aid, round 5: the inputs' copy on a stream of its own)
   unsigned char* ring_host[RING] = {};
   hipEvent_t ring_ev[RING] = {};
   bool ring_used[RING] = {};
   int ring_pos = 0;
-  size_t ring_bytes = 0;
+  size_t ring_bytes = 0, ring_bytes_dev = 0;
   // device-side tables
   UndistortDev und[2][4];  // [cam][useR + 2*useP]
   std::vector<float> h_map[2][2];  // host copies of the maps [cam][x|y]
@@ -129,9 +133,9 @@ struct kvfe_ctx {
   // corner refinement runs on a side stream, concurrently with rectification and the stereo
   // matching of the tracked keypoints (its result is only needed by the newly detected ones)
   hipStream_t side = nullptr;
-  hipStream_t sub = nullptr;                         // corner refinement of a step whose tracking is split (do_step)
-  hipEvent_t ev_sel = nullptr;                       // the selection (and the state the next tracking reads) is done
-  bool split_prev = false;                           // the previous step's refinement runs on `sub`: this step tracks the old points first
+  hipEvent_t ev_chain[4] = {};                       // "the side stream's rectify / match / reject chain of step i is done", i mod 4
+  long long chain_seq = 0;                           // steps whose chain went to the side stream
+
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mono = nullptr;
   hipEvent_t ev_main = nullptr, ev_tail = nullptr;   // main-stream part of the fork done / tail of the step (side stream) done
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
@@ -352,6 +356,7 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.ds.n_corners, B));
   TRY(dalloc(c, &b.ds.newc, (size_t)P.acap * B));
   TRY(dalloc(c, &b.ds.n_new, B));
+  TRY(dalloc(c, &b.ds.sp_next, B));
   TRY(dalloc(c, &b.ds.need, B));
   TRY(dalloc(c, &b.ds.cell_items, (size_t)P.ccap * B));
   TRY(dalloc(c, &b.ds.state, (size_t)P.ccap * B));
@@ -365,7 +370,6 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
-  TRY(dalloc(c, &b.lk.nold, B));
   TRY(dalloc(c, &b.lk.src_idx, K));
   TRY(reset_tracker_status(c, b));
   // keyframe_R_ref_frame_ = identity
@@ -949,6 +953,23 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     b.ss.kf_R_cur = b.kf_R_cur;
     b.ss.in_timestamp = b.in_ts;
     b.ss.in_force_kf = b.in_force;
+  } else if (c->inputs_by_copy_call && c->in_dev) {
+    // STAGED STEPS: no kernel reads host memory.  A kernel that reads the mapped pinned slot sends its read request up
+    // the PCIe link and waits for the answer to come down it -- behind the 46 MB of frames the NEXT step's upload is
+    // pulling down at that moment.  Round 4 saw the symptom ("with a transfer in flight every cross-stream hand-over of
+    // the forked step completes late": 3.1 ms per staged step instead of 1.9) and serialised the step; the cause was
+    // every small kernel of the step stalling on its few hundred bytes of inputs.  With the inputs copied into a device
+    // ring slot behind the frames' upload: 2.57 -> 1.52 ms per staged step of the headline workload, 24.9 k -> 42.0 k
+    // pairs/s (tools/r5/gpu_f.sh).  Steps fed from device memory keep the mapped slot: nothing big moves down the link
+    // while they run, and the extra copy + event cost them 5 % (same call).
+    unsigned char* d = c->in_dev + (size_t)slot * c->ring_bytes_dev;
+    hipStream_t cs = c->in_stream ? c->in_stream : c->copy_stream;
+    HIPCHK(c, hipMemcpyAsync(d, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B, hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipEventRecord(c->in_ev[slot], cs));
+    HIPCHK(c, hipStreamWaitEvent(st, c->in_ev[slot], 0));
+    b.ss.kf_R_cur = reinterpret_cast<const double*>(d);
+    b.ss.in_timestamp = reinterpret_cast<const long long*>(d + sizeof(double) * 9 * P.B);
+    b.ss.in_force_kf = reinterpret_cast<const int*>(d + (sizeof(double) * 9 + sizeof(long long)) * P.B);
   } else {
     void* dp = nullptr;
     HIPCHK(c, hipHostGetDevicePointer(&dp, hb, 0));
@@ -1009,26 +1030,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     }
     c->chain_pending = false;
   }
-  if (c->split_prev && c->commit_pending && c->prev_left) {
-    // SPLIT TRACKING (round 5).  The previous step's new corners are still being refined (on `sub`), but the points that
-    // frame k-1 already had when its detection ran -- the survivors of its own tracking, ~98 % of the list -- depend on
-    // nothing the refinement writes: their tracking starts now, and the chip works on it while the refinement's ~40
-    // sequential iterations per corner (latency, a few hundred waves) run beside it.  The new corners follow as a second,
-    // small launch behind the refinement.  Same points, same order, same arithmetic as one launch (track_prepare_kernel).
-    prof_begin(c, ST_TRACK, st);
-    launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st, 1);
-    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, false, 1);
-    prof_end(c, ST_TRACK, st);
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
-    c->commit_pending = false;
-    prof_break(c);
-    prof_begin(c, ST_TRACK_NEW, st);
-    launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st, 2);
-    launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, std::min(c->pts_bound, detect_new_bound(P)), st, false, 2);
-    prof_end(c, ST_TRACK_NEW, st);
-  } else {
   if (c->commit_pending) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_commit, 0));
     prof_break(c);   // (the wait is not part of the tracking stage)
@@ -1040,8 +1041,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
               img_stride, b.pyr[pc], b.lk, c->pts_bound, st, false);
   prof_end(c, ST_TRACK, st);
-  }
-  c->split_prev = false;
   if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
     c->tail_pending = false;
@@ -1154,28 +1153,12 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
     slot_release.side_used = true;
   }
-  // swap + split: the refinement on its own stream `sub`, behind the selection and the state the next tracking reads; the
-  // main stream is free for the next step's tracking of the old points (see the tracking stage above)
-  static const bool split_env = !std::getenv("KVFE_X_SPLIT") || std::atoi(std::getenv("KVFE_X_SPLIT")) != 0;   // A/B aid (round 5)
-  const bool split = swap && c->sub && split_env;
-  if (split) {
-    launch_detect_state(P, K, b.ss, b.ds, st);
-    HIPCHK(c, hipEventRecord(c->ev_sel, st));
-    HIPCHK(c, hipStreamWaitEvent(c->sub, c->ev_sel, 0));
-    prof_begin(c, ST_SUBPIX, c->sub);
-    launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, c->sub, 6);
-    prof_end(c, ST_SUBPIX, c->sub);
-    HIPCHK(c, hipEventRecord(c->ev_commit, c->sub));
-    c->commit_pending = true;
-    c->split_prev = true;
-  } else {
   prof_begin(c, ST_SUBPIX, fa);
   launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, fa);
   prof_end(c, ST_SUBPIX, fa);
   if (side && (c->own_stream || swap)) {
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
-  }
   }
   if (!rect_early) {
   prof_begin(c, ST_RECTIFY, fb);
@@ -1216,6 +1199,8 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   if (side) {
     if (swap) {
       HIPCHK(c, hipEventRecord(c->ev_main, sd));            // the chain (last reader of this frame's image slots) is done
+      if (c->ev_chain[0]) HIPCHK(c, hipEventRecord(c->ev_chain[c->chain_seq % 4], sd));
+      c->chain_seq++;
       c->chain_pending = true;
       HIPCHK(c, hipStreamWaitEvent(sd, c->ev_commit, 0));   // the refined new corners (main stream)
     } else {
@@ -1475,10 +1460,6 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     // is what a step costs, so it stays on ONE stream and the rectify / match / reject chain takes the side stream
     // (many streams: the same arrangement for the calls whose frames persist, do_step)
     c->fork_swap = c->P.B <= 4 && c->own_stream && !c->P.mono;
-    if (s == KVFE_OK && c->own_stream && !c->P.mono &&
-        (hipStreamCreateWithFlags(&c->sub, hipStreamNonBlocking) != hipSuccess ||
-         hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess))
-      s = KVFE_ERR_HIP;
   }
   if (s != KVFE_OK) {
     std::fprintf(stderr, "kvfe_create failed: %s\n", c->last_error.c_str());
@@ -1556,8 +1537,14 @@ void kvfe_destroy(kvfe_ctx* c) {
   if (c->side) hipStreamSynchronize(c->side);   // (the last step's tail lives there)
   if (c->stream) hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
-  for (int i = 0; i < kvfe_ctx::RING; i++)
+  for (int i = 0; i < kvfe_ctx::RING; i++) {
     if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
+    if (c->in_ev[i]) hipEventDestroy(c->in_ev[i]);
+  }
+  if (c->in_stream) {
+    hipStreamSynchronize(c->in_stream);
+    hipStreamDestroy(c->in_stream);
+  }
   if (c->ev_tracked) hipEventDestroy(c->ev_tracked);
   if (c->side) {
     hipStreamSynchronize(c->side);
@@ -1578,19 +1565,17 @@ void kvfe_destroy(kvfe_ctx* c) {
   }
   for (int i = 0; i < KVFE_STAGING_SLOTS; i++)
     if (c->stage_copied[i]) hipEventDestroy(c->stage_copied[i]);
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 4; i++) {
     if (c->step_done[i]) hipEventDestroy(c->step_done[i]);
+    if (c->ev_chain[i]) hipEventDestroy(c->ev_chain[i]);
+  }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mono) hipEventDestroy(c->ev_mono);
   if (c->ev_main) hipEventDestroy(c->ev_main);
   if (c->ev_tail) hipEventDestroy(c->ev_tail);
   if (c->ev_commit) hipEventDestroy(c->ev_commit);
-  if (c->ev_sel) hipEventDestroy(c->ev_sel);
-  if (c->sub) {
-    hipStreamSynchronize(c->sub);
-    hipStreamDestroy(c->sub);
-  }
+
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->dense_allocs) hipFree(p);
   for (int i = 0; i < 2; i++)
@@ -2454,6 +2439,15 @@ static kvfe_status ensure_staging(kvfe_ctx* c, int slot) {
   if (!c->copy_stream) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming));
+    static const bool in_ring_env = !std::getenv("KVFE_X_IN_RING") || std::atoi(std::getenv("KVFE_X_IN_RING")) != 0;   // A/B aid (round 5)
+    if (!c->cfg.copy_inputs && in_ring_env) {   // device copies of the input ring slots (do_step)
+      c->ring_bytes_dev = (c->ring_bytes + 255) & ~(size_t)255;
+      TRY(dalloc(c, &c->in_dev, c->ring_bytes_dev * kvfe_ctx::RING));
+      for (int i = 0; i < kvfe_ctx::RING; i++) HIPCHK(c, hipEventCreateWithFlags(&c->in_ev[i], hipEventDisableTiming));
+      if (std::getenv("KVFE_X_IN_STREAM") && std::atoi(std::getenv("KVFE_X_IN_STREAM")) != 0)
+        HIPCHK(c, hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
+    }
     if (c->cfg.params.stereo.equalize_image)
       for (int i = 0; i < 2; i++) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));
   }
@@ -2512,9 +2506,15 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
     c->step_done_valid[(n - 1) % 4] = true;
   } else if (dep >= 0 && c->step_done_valid[dep % 4]) {
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->step_done[dep % 4], 0));
-    // fork_swap: rectification (the other reader of a frame's slots) runs on the side stream and is not covered by the
-    // main stream's step_done; the side stream's latest "chain done" event is behind every earlier one
-    if (c->chain_pending) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_main, 0));
+    // the side stream's chain (the other reader of a frame's slots) is not covered by the main stream's step_done: the
+    // upload of frame n rewrites the right slot of frame n-2 and the left slot of frame n-3 -- the chain of step n-2 is
+    // behind both on the side stream (and behind the refinement of step n-3, which its predecessor's tail awaited)
+    if (c->chain_pending) {
+      if (c->ev_chain[0] && c->chain_seq >= 2 && c->last_step_staged)
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_chain[(c->chain_seq - 2) % 4], 0));
+      else if (!c->ev_chain[0] || !c->last_step_staged)
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_main, 0));
+    }
   }
   unsigned char* ul = eq ? b.eq_in[0] : dl;
   unsigned char* ur = eq ? b.eq_in[1] : dr;
@@ -2535,8 +2535,10 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
     // 0.86 ms).  A few streams (fork_swap: every kernel is a latency, the upload is a few hundred KB) keep the fork that
     // was tuned for them.
     c->serial_call = !c->fork_swap;
+    c->inputs_by_copy_call = true;
     const kvfe_status r = do_step(c, dl, dr, P.W, N, inputs);
     c->serial_call = false;
+    c->inputs_by_copy_call = false;
     if (r != KVFE_OK) return r;
   }
   HIPCHK(c, hipEventRecord(c->step_done[n % 4], c->stream));
@@ -2614,7 +2616,6 @@ kvfe_status kvfe_frontend_reset(kvfe_ctx* c) {
   c->prev_left = nullptr;
   c->img_step = 0;
   c->pyr_cur = 0;
-  c->split_prev = false;
   if (c->out_stream) HIPCHK(c, hipStreamSynchronize(c->out_stream));
   c->out_steps = 0;
   c->last_step_staged = false;

@@ -212,6 +212,7 @@ struct DetectScratch {
   int* n_corners;            // [B]
   float2* newc;              // [B][acap] corners selected by ANMS (pre sub-pixel)
   int* n_new;                // [B]
+  int* sp_next;              // [B] next new corner of the stream a refinement slot takes (subpix_group_kernel; zeroed by select)
   int* need;                 // [B]
   // global-memory work arrays of the per-stream select kernel
   unsigned int* cell_items;  // [B][ccap]
@@ -231,7 +232,6 @@ struct LkScratch {
   unsigned char* status;  // [B][kcap]
   float* err;             // [B][kcap]
   int* npts;              // [B]
-  int* nold;              // [B] how many of them existed before the previous frame's detection (launch_track_prepare part 1)
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
   // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
@@ -286,10 +286,10 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
 void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride,
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
-               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true, int part = 0);
+               const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
-                          const StreamState& S, const LkScratch& lk, hipStream_t st, int part = 0);
+                          const StreamState& S, const LkScratch& lk, hipStream_t st);
 // survivors -> frame k, bearing vectors, keyframe decision (Tracker.cpp:167-189,
 // StereoVisionImuFrontend.cpp:313-347, VisionImuFrontend.cpp:175-232)
 void launch_track_finalize(const KParams& P, const Tables& T, const FrameTab& km1,
@@ -310,9 +310,7 @@ void launch_select(const KParams& P, const Tables& T, const FrameTab& k, const S
 void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char* img,
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
-                          hipStream_t st, int commit_what = 7 /* detect_commit_kernel: state | landmark counter | count */);
-// detect_commit_kernel bit 0 alone: what the next step's tracking of the old points reads
-void launch_detect_state(const KParams& P, const FrameTab& k, const StreamState& S, const DetectScratch& D, hipStream_t st);
+                          hipStream_t st);
 // the per-stream state the next step's tracking reads (keyframe_R_ref_frame_, "initialised", the frame's keypoint
 // count): known once the new corners are SELECTED.  launch_subpix_append(append = 2) leaves it to this launch.
 int detect_new_bound(const KParams& P);   // upper bound of the new corners per stream and frame
