@@ -762,10 +762,12 @@ def pcie_inclusive(F, wl, torch=None):
         th = time.perf_counter()
         for i in range(n_w, n_w + n_h):
             ctx.step_staged(steps[i][0], plan[i])
+        t_enq = time.perf_counter() - th
         ctx.synchronize()
         dt = time.perf_counter() - th
         res["value"] = round(B * n_h / dt, 2)
         res["ms_per_step"] = round(1e3 * dt / n_h, 4)
+        res["host_enqueue_ms_per_step"] = round(1e3 * t_enq / n_h, 4)
         ctx.reset()
     # round 4's leg: three frames in a cycle, 30 steps
     hl = np.ascontiguousarray(lefts[:3])

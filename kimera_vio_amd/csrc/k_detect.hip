@@ -2531,7 +2531,13 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   // grid sized to what the device holds at once, every block walking ~10 corners, lost 24 % on real frames (round 3:
   // the corners' iteration counts differ too much for a static assignment).
   const int nw = P.B <= 4 ? 4 : 2;
-  const dim3 grid(P.B, bound);
+  // (corner slots per stream: a block walks its stream's corners with the stride of the grid, so the grid only has to
+  // hold the corners this kernel is FOR -- fewer than SPG_MIN_TOTAL over the whole launch, otherwise the grouped kernel
+  // works and these blocks return -- instead of one block per possible corner, 50 k mostly empty blocks at 64 streams)
+  static const int group_env = std::getenv("KVFE_SUBPIX_GROUP") ? std::atoi(std::getenv("KVFE_SUBPIX_GROUP")) : -1;
+  const bool group_ok = P.subpix_win == 10 && P.W >= subpix_geom(10).rs && P.H >= subpix_geom(10).rs;
+  const int group_mode = !group_ok ? 0 : (group_env == 0 ? 0 : (group_env == 1 ? 2 : (P.B > 4 ? 1 : 0)));   // 0 never, 1 by count, 2 always
+  const dim3 grid(P.B, group_mode == 1 ? std::min(bound, std::max(64, (SPG_MIN_TOTAL + P.B - 1) / P.B)) : bound);
   static const bool stats_on = std::getenv("KVFE_SUBPIX_STATS") != nullptr;
   const int kappend = append | (stats_on ? 16 : 0);   // (bit 4: per-corner cycle statistics)
   if (stats_on) {
@@ -2553,9 +2559,6 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   // Two kernels share the launch slot when there are many streams (see subpix_total_new): the one-corner-per-block
   // kernel below works when the launch holds fewer than SPG_MIN_TOTAL new corners, the grouped kernel after it when it
   // holds more; the other one's blocks return at once.  KVFE_SUBPIX_GROUP = 0 / 1 forces one of them (A/B, tests).
-  static const int group_env = std::getenv("KVFE_SUBPIX_GROUP") ? std::atoi(std::getenv("KVFE_SUBPIX_GROUP")) : -1;
-  const bool group_ok = P.subpix_win == 10 && P.W >= subpix_geom(10).rs && P.H >= subpix_geom(10).rs;
-  const int group_mode = !group_ok ? 0 : (group_env == 0 ? 0 : (group_env == 1 ? 2 : (P.B > 4 ? 1 : 0)));   // 0 never, 1 by count, 2 always
   int kapp = kappend | (group_mode == 1 ? 128 : 0);
   if (group_mode != 2) {
   if (P.subpix_win == 10 && nw == 4)

@@ -91,6 +91,14 @@ __global__ __launch_bounds__(64) void lk_kernel_generic(KParams P, const unsigne
   const unsigned char* cpyr = cur_pyr + (size_t)s * P.pyr_stride;
 
   const size_t po = (size_t)s * P.kcap + pt;
+  // Tracker.cpp:167-180 drops a point whose landmark is older than maxFeatureAge WHATEVER its tracking result: the
+  // reference tracks it and throws the result away.  The step passes the ages (lk.skip_age), and such a point is
+  // reported lost without being tracked -- nothing reads its position or error.  (All features of a synthetic stream are
+  // born in the bootstrap frame: every 26th step the whole list is in this state.)
+  if (lk.skip_age && lk.skip_age[(size_t)s * P.kcap + lk.src_idx[po]] > P.max_age) {
+    if (threadIdx.x == 0) lk.status[po] = 0;
+    return;
+  }
   const float2 prevPt0 = lk.prev_pts[po];
   float2 nextOut = lk.next_pts[po];  // initial flow
   int status = 1;
@@ -486,6 +494,14 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams
   const unsigned char* cpyr = cur_pyr + (size_t)s * P.pyr_stride;
 
   const size_t po = (size_t)s * P.kcap + pt;
+  // Tracker.cpp:167-180 drops a point whose landmark is older than maxFeatureAge WHATEVER its tracking result: the
+  // reference tracks it and throws the result away.  The step passes the ages (lk.skip_age), and such a point is
+  // reported lost without being tracked -- nothing reads its position or error.  (All features of a synthetic stream are
+  // born in the bootstrap frame: every 26th step the whole list is in this state.)
+  if (lk.skip_age && lk.skip_age[(size_t)s * P.kcap + lk.src_idx[po]] > P.max_age) {
+    if (threadIdx.x == 0) lk.status[po] = 0;
+    return;
+  }
   const float2 prevPt0 = lk.prev_pts[po];
   float2 nextOut = lk.next_pts[po];  // initial flow
   int status = 1;

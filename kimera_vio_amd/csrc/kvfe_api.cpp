@@ -113,7 +113,6 @@ struct kvfe_ctx {
   unsigned char* in_dev = nullptr;                   // [RING][ring_bytes]
   hipEvent_t in_ev[RING] = {};
   bool inputs_by_copy_call = false;                  // this do_step call: set by kvfe_frontend_step_staged
-  hipStream_t in_stream = nullptr;                   // (A/B aid, round 5: the inputs' copy on a stream of its own)
   unsigned char* ring_host[RING] = {};
   hipEvent_t ring_ev[RING] = {};
   bool ring_used[RING] = {};
@@ -370,6 +369,7 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
+  b.lk.skip_age = nullptr;   // (set per launch by the front-end step)
   TRY(dalloc(c, &b.lk.src_idx, K));
   TRY(reset_tracker_status(c, b));
   // keyframe_R_ref_frame_ = identity
@@ -954,18 +954,17 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     b.ss.in_timestamp = b.in_ts;
     b.ss.in_force_kf = b.in_force;
   } else if (c->inputs_by_copy_call && c->in_dev) {
-    // STAGED STEPS: no kernel reads host memory.  A kernel that reads the mapped pinned slot sends its read request up
-    // the PCIe link and waits for the answer to come down it -- behind the 46 MB of frames the NEXT step's upload is
-    // pulling down at that moment.  Round 4 saw the symptom ("with a transfer in flight every cross-stream hand-over of
-    // the forked step completes late": 3.1 ms per staged step instead of 1.9) and serialised the step; the cause was
-    // every small kernel of the step stalling on its few hundred bytes of inputs.  With the inputs copied into a device
-    // ring slot behind the frames' upload: 2.57 -> 1.52 ms per staged step of the headline workload, 24.9 k -> 42.0 k
-    // pairs/s (tools/r5/gpu_f.sh).  Steps fed from device memory keep the mapped slot: nothing big moves down the link
-    // while they run, and the extra copy + event cost them 5 % (same call).
+    // STAGED STEPS of many streams: no kernel reads host memory.  A kernel that reads the mapped pinned slot sends its
+    // read request up the PCIe link and waits for the answer to come down it -- behind the 46 MB of frames the NEXT step's
+    // upload may be pulling down at that moment; the inputs therefore travel by a small copy behind the step's own frames
+    // on the copy stream.  Measured (profiles/r5_analysis.md section 4): on one box of the pool 2.57 -> 1.52 ms per staged
+    // step of the headline workload (24.9 k -> 42.0 k pairs/s) with the copy against the mapped read in the same call; on
+    // two other boxes both forms read 2.3 - 2.5 ms (26 - 28 k) -- there the upload and the step do not overlap whichever
+    // way the inputs travel.  Steps fed from device memory keep the mapped slot (the copy and its event cost them 5 %).
     unsigned char* d = c->in_dev + (size_t)slot * c->ring_bytes_dev;
-    hipStream_t cs = c->in_stream ? c->in_stream : c->copy_stream;
-    HIPCHK(c, hipMemcpyAsync(d, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B, hipMemcpyHostToDevice, cs));
-    HIPCHK(c, hipEventRecord(c->in_ev[slot], cs));
+    HIPCHK(c, hipMemcpyAsync(d, hb, (sizeof(double) * 9 + sizeof(long long) + sizeof(int)) * P.B, hipMemcpyHostToDevice,
+                             c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->in_ev[slot], c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(st, c->in_ev[slot], 0));
     b.ss.kf_R_cur = reinterpret_cast<const double*>(d);
     b.ss.in_timestamp = reinterpret_cast<const long long*>(d + sizeof(double) * 9 * P.B);
@@ -1037,9 +1036,12 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   c->commit_pending = false;
   prof_begin(c, ST_TRACK, st);
   launch_track_prepare(P, c->T, KM1, b.ss, b.lk, st);
-  if (c->prev_left)
+  if (c->prev_left) {
+    LkScratch lkq = b.lk;
+    lkq.skip_age = KM1.age;   // (points past maxFeatureAge are dropped whatever their result: not tracked at all)
     launch_lk(P, c->prev_left, c->prev_row_stride, c->prev_img_stride, b.pyr[pp], left, row_stride,
-              img_stride, b.pyr[pc], b.lk, c->pts_bound, st, false);
+              img_stride, b.pyr[pc], lkq, c->pts_bound, st, false);
+  }
   prof_end(c, ST_TRACK, st);
   if (c->tail_pending) {   // the keyframe decision reads lkf <- k of the previous step's tail and rewrites the stream flags
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tail, 0));
@@ -1541,10 +1543,7 @@ void kvfe_destroy(kvfe_ctx* c) {
     if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     if (c->in_ev[i]) hipEventDestroy(c->in_ev[i]);
   }
-  if (c->in_stream) {
-    hipStreamSynchronize(c->in_stream);
-    hipStreamDestroy(c->in_stream);
-  }
+
   if (c->ev_tracked) hipEventDestroy(c->ev_tracked);
   if (c->side) {
     hipStreamSynchronize(c->side);
@@ -2440,13 +2439,10 @@ static kvfe_status ensure_staging(kvfe_ctx* c, int slot) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming));
-    static const bool in_ring_env = !std::getenv("KVFE_X_IN_RING") || std::atoi(std::getenv("KVFE_X_IN_RING")) != 0;   // A/B aid (round 5)
-    if (!c->cfg.copy_inputs && in_ring_env) {   // device copies of the input ring slots (do_step)
+    if (!c->cfg.copy_inputs && !c->fork_swap) {   // many streams: device copies of the input ring slots (do_step)
       c->ring_bytes_dev = (c->ring_bytes + 255) & ~(size_t)255;
       TRY(dalloc(c, &c->in_dev, c->ring_bytes_dev * kvfe_ctx::RING));
       for (int i = 0; i < kvfe_ctx::RING; i++) HIPCHK(c, hipEventCreateWithFlags(&c->in_ev[i], hipEventDisableTiming));
-      if (std::getenv("KVFE_X_IN_STREAM") && std::atoi(std::getenv("KVFE_X_IN_STREAM")) != 0)
-        HIPCHK(c, hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
     }
     if (c->cfg.params.stereo.equalize_image)
       for (int i = 0; i < 2; i++) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));

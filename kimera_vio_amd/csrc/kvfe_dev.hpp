@@ -232,6 +232,8 @@ struct LkScratch {
   unsigned char* status;  // [B][kcap]
   float* err;             // [B][kcap]
   int* npts;              // [B]
+  const int* skip_age;    // null, or the landmark ages of frame k-1 ([B][kcap], indexed through src_idx): a point older
+                          // than maxFeatureAge is reported lost untracked (the front-end step; Tracker.cpp:167-180)
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
   // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
