@@ -25,6 +25,10 @@
 //   dense_median3/5, speckle filter as connected-component labelling (row runs + union-find)
 #include "kvfe_dev.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
 namespace kvfe {
 
 namespace {
@@ -424,6 +428,267 @@ __global__ __launch_bounds__(256) void dense_aggregate_all_kernel(DenseParams P,
     case 5: dense_aggregate_path<1, -1, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
     case 6: dense_aggregate_path<0, -1, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
     default: dense_aggregate_path<-1, -1, AGG_ATOMIC>(P, Cv, sumB, path, pair); break;
+  }
+}
+
+// ---- two-pass aggregation (MODE_HH, four or more pairs) -------------------------------------------------------
+// computeDisparitySGBM's own order: pass 1 walks the rows top-down and every row left to right with the four paths whose
+// previous pixel lies behind ((x-1,y), (x-1,y-1), (x,y-1), (x+1,y-1)), pass 2 walks them bottom-up and right to left
+// with the other four.  Here a wave is one image row of one pass (lane = disparity): it carries the horizontal path in a
+// register and takes the three paths that come from the row before it out of what that row's wave published, so C is
+// read twice and each partial sum written once per pixel (eight sweeps: C read eight times, S written once and
+// read-modified-written seven times).
+//   * the wave of row r at step i (column x_i) needs, from row r-1: the diagonal path at step i-1, the vertical one at
+//     step i and the other diagonal at step i+1 -- it reads ONE published entry per step (i+1) and keeps the two older
+//     ones in registers; it may run step i as soon as the row before has finished step i+1;
+//   * a block is 16 consecutive rows; entries go from wave to wave through a ring of 8 in LDS (8 bytes per lane: the three
+//     path costs in 15 bits each, their minima in lanes 0-2), guarded by a per-wave step counter both ways;
+//   * from the last row of a block to the first row of the next they go through HBM as relaxed device-scope 64-bit atomics,
+//     each word tagged with the launch's epoch (two spare bits), so the reader needs no fence: it polls the word itself;
+//   * blocks take their (band, pair, pass) from a ticket counter, band-major: a block only ever waits for a block with a
+//     smaller ticket, which is running -- no co-residency assumption, no deadlock whatever the dispatch order;
+//   * every wait is bounded (AGP_TIMEOUT_TICKS); a wait that runs out sets the launch's error word, which every other
+//     wait looks at, and the call returns KVFE_ERR_INTERNAL instead of hanging the device.
+// Same integers as dense_aggregate_path (same step function, same zero predecessors outside the volume).
+constexpr int AGP_ROWS = 16;
+constexpr int AGP_MIN_PAIRS = 4;   // fewer pairs: too few rows in flight, the single-launch atomic sweeps are faster
+constexpr int AGP_RING = 8;
+constexpr int AGP_PF = 4;
+constexpr long long AGP_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wall clock
+
+__device__ __forceinline__ int agp_step(int c, int Lp, int minp, int P1, int P2, bool act, int& minout) {
+  const int delta = minp + P2;
+  const int lm = dpp_wave_shr1(Lp, MAXC), lq = dpp_wave_shl1(Lp, MAXC);
+  const int m = min(min(Lp, delta), min(lm, lq) + P1);
+  const int L = act ? c + m - delta : MAXC;
+  minout = wave_min(L);
+  return L;
+}
+
+struct AgpWait {
+  unsigned* err;      // the launch's error word
+  long long t0 = 0;   // start of the wait in progress (0: none)
+  bool dead = false;
+  unsigned spins = 0;
+  // one more turn of a wait loop; false = give up
+  __device__ __forceinline__ bool again() {
+    if (dead) return false;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 127u) == 0) {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
+      if (now - t0 > AGP_TIMEOUT_TICKS) {
+        dead = true;
+        if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
+      }
+    }
+    return !dead;
+  }
+};
+
+typedef __attribute__((address_space(3))) volatile unsigned long long agp_lds_u64;
+typedef __attribute__((address_space(3))) volatile unsigned agp_lds_u32;
+enum { AGP_IN_ZERO = 0, AGP_IN_LDS = 1, AGP_IN_GLOBAL = 2, AGP_OUT_NONE = 0, AGP_OUT_LDS = 1, AGP_OUT_GLOBAL = 2 };
+
+struct AgpRow {
+  const unsigned* cp;         // C of the row: the dword that holds this lane's disparity (a 16-bit load needs an extension,
+                              // which the compiler places right behind the load -- in the next step, where it turns the
+                              // prefetch into a wait; the half is picked at the use instead, behind an opaque asm)
+  int csh;                    // 0 / 16: which half
+  unsigned short* sp;         // the pass's partial sum of the row
+  unsigned long long* hin;    // entries of the block before (this lane's word of step 0)
+  unsigned long long* hout;   // entries for the block after
+  agp_lds_u64* ring_in;       // ring written by the wave of the row before (this lane's word of slot 0)
+  agp_lds_u64* ring_out;
+  agp_lds_u32 *prog_in, *prog_me, *prog_out;
+  unsigned* err;
+  int W1, D, P1, P2;
+  unsigned etag;
+  bool down, act;
+};
+
+// one row of one pass; IN / OUT: where the row before's entries come from and where this row's go (wave-uniform, so
+// every memory operation of the loop is unconditional and the compiler can count the loads in flight)
+template <int IN, int OUT>
+__device__ __forceinline__ void agp_row(const AgpRow& R) {
+  const int lane = threadIdx.x & 63;
+  const int W1 = R.W1, D = R.D, P1 = R.P1, P2 = R.P2, last = W1 - 1;
+  const bool act = R.act, down = R.down;
+  const int zl = act ? 0 : MAXC;
+  const unsigned etag = R.etag;
+  AgpWait wt;
+  wt.err = R.err;
+  auto xof = [&](int i) { return down ? i : last - i; };
+  unsigned seen_in = 0, seen_out = 0;
+  auto global_entry = [&](unsigned long long v, int j) {   // v = what the prefetch of entry j returned
+    while (__builtin_amdgcn_ballot_w64((((unsigned)v & 0x80008000u) != etag)) != 0ull) {
+      if (!wt.again()) break;
+      v = __hip_atomic_load(R.hin + (size_t)j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wt.t0 = 0;
+    return v;
+  };
+  auto lds_entry = [&](int j) {
+    while (seen_in < (unsigned)j + 1u) {
+      seen_in = __builtin_amdgcn_readfirstlane(*R.prog_in);
+      if (seen_in >= (unsigned)j + 1u) break;
+      if (!wt.again()) break;
+    }
+    wt.t0 = 0;
+    return R.ring_in[(j & (AGP_RING - 1)) * 64];
+  };
+  const unsigned long long zero_entry =
+      (unsigned long long)((unsigned)zl | ((unsigned)zl << 16)) | ((unsigned long long)(unsigned)zl << 32);
+
+  // prefetch: C of the next AGP_PF steps and (first row of a block) the entries of the block before
+  unsigned cbuf[AGP_PF];
+  unsigned long long gbuf[AGP_PF];
+#pragma unroll
+  for (int u = 0; u < AGP_PF; u++) {
+    cbuf[u] = R.cp[(size_t)xof(min(u, last)) * (D >> 1)];
+    gbuf[u] = 0;
+    if (IN == AGP_IN_GLOBAL)   // entry u + 1 is the one step u consumes
+      gbuf[u] = __hip_atomic_load(R.hin + (size_t)min(u + 1, last) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // entry 0: vertical and behind-diagonal predecessors of steps 0 and 1
+  unsigned long long e0 = zero_entry;
+  if (IN == AGP_IN_LDS) e0 = lds_entry(0);
+  if (IN == AGP_IN_GLOBAL) e0 = global_entry(__hip_atomic_load(R.hin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
+  int Lh = zl, mh = 0;                                // horizontal path, carried
+  int h_db1 = (int)((unsigned)e0 & 0x7fffu);          // behind-diagonal of entry i (used at step i + 1)
+  int h_v = (int)(((unsigned)e0 >> 16) & 0x7fffu);    // vertical of entry i (used at step i)
+  int m_db1 = __builtin_amdgcn_readlane((int)((unsigned)(e0 >> 48)), 0);
+  int m_v = __builtin_amdgcn_readlane((int)((unsigned)(e0 >> 48)), 1);
+  int h_db2 = zl, m_db2 = 0;                          // behind-diagonal of entry i - 1: outside at step 0
+
+  // one step; u = i mod AGP_PF selects the prefetch registers (compile-time in the unrolled loops below)
+  auto step = [&](const int u, const int i) {
+    {
+      unsigned craw = cbuf[u];
+      unsigned long long gpre = gbuf[u];
+      cbuf[u] = R.cp[(size_t)xof(min(i + AGP_PF, last)) * (D >> 1)];
+      if (IN == AGP_IN_GLOBAL)
+        gbuf[u] = __hip_atomic_load(R.hin + (size_t)min(i + 1 + AGP_PF, last) * 64, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+      // entry i + 1 of the row before (outside the volume past its last column)
+      unsigned long long e = zero_entry;
+      if (IN == AGP_IN_GLOBAL) asm volatile("" : "+v"(gpre));   // likewise the prefetched entry
+      if (IN != AGP_IN_ZERO && i < last) e = IN == AGP_IN_LDS ? lds_entry(i + 1) : global_entry(gpre, i + 1);
+      const unsigned elo = (unsigned)e, ehi = (unsigned)(e >> 32);
+      asm volatile("" : "+v"(craw));   // first use of the prefetched C: here, not earlier
+      const int c = (int)((craw >> R.csh) & 0xffffu);
+      const int in_da = (int)(ehi & 0x7fffu);
+      const int m_da = __builtin_amdgcn_readlane((int)(ehi >> 16), 2);
+      int n_h, n_db, n_v, n_da;
+      Lh = agp_step(c, Lh, mh, P1, P2, act, n_h);
+      const int Ldb = agp_step(c, h_db2, m_db2, P1, P2, act, n_db);
+      const int Lv = agp_step(c, h_v, m_v, P1, P2, act, n_v);
+      const int Lda = agp_step(c, in_da, m_da, P1, P2, act, n_da);
+      mh = n_h;
+      if (act) R.sp[(size_t)xof(i) * D] = (unsigned short)min(Lh + Ldb + Lv + Lda, 65535);
+      // history: entry i + 1 becomes "entry i" of the next step
+      h_db2 = h_db1;
+      m_db2 = m_db1;
+      h_db1 = (int)(elo & 0x7fffu);
+      m_db1 = __builtin_amdgcn_readlane((int)(ehi >> 16), 0);
+      h_v = (int)((elo >> 16) & 0x7fffu);
+      m_v = __builtin_amdgcn_readlane((int)(ehi >> 16), 1);
+      // publish this row's entry i
+      if (OUT != AGP_OUT_NONE) {
+        const unsigned ex = lane == 0 ? (unsigned)n_db : (lane == 1 ? (unsigned)n_v : (unsigned)n_da);
+        const unsigned olo = (unsigned)Ldb | ((unsigned)Lv << 16) | etag;
+        const unsigned ohi = (unsigned)Lda | (ex << 16);
+        const unsigned long long o = (unsigned long long)olo | ((unsigned long long)ohi << 32);
+        if (OUT == AGP_OUT_LDS) {
+          if (i >= AGP_RING) {   // the slot's previous entry (i - RING) must have been read: reader past step i-RING-1
+            const unsigned need = (unsigned)max(1, i - AGP_RING);
+            while (seen_out < need) {
+              seen_out = __builtin_amdgcn_readfirstlane(*R.prog_out);
+              if (seen_out >= need) break;
+              if (!wt.again()) break;
+            }
+            wt.t0 = 0;
+          }
+          R.ring_out[(i & (AGP_RING - 1)) * 64] = o;
+        } else {
+          __hip_atomic_store(R.hout + (size_t)i * 64, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (lane == 0) *R.prog_me = (unsigned)i + 1u;
+    }
+  };
+  // groups of AGP_PF steps without a condition in between (a conditional update of the prefetch registers costs copies
+  // at the top of the next step, and a copy is a use: the wait for the load moves up to it), then the remainder
+  int i0 = 0;
+  for (; i0 + AGP_PF <= W1; i0 += AGP_PF) {
+#pragma unroll
+    for (int u = 0; u < AGP_PF; u++) step(u, i0 + u);
+  }
+#pragma unroll
+  for (int u = 0; u < AGP_PF; u++)
+    if (i0 + u <= last) step(u, i0 + u);
+}
+
+__global__ __launch_bounds__(AGP_ROWS * 64) void dense_aggregate_pass_kernel(
+    DenseParams P, const short* __restrict__ Cv, unsigned short* __restrict__ sumA, unsigned short* __restrict__ sumB,
+    unsigned long long* __restrict__ hand, unsigned* __restrict__ sync, int n, int cap_pairs, int nbands,
+    unsigned epoch) {
+  __shared__ unsigned long long ring_s[(AGP_ROWS - 1) * AGP_RING * 64];
+  __shared__ unsigned prog_s[AGP_ROWS];
+  __shared__ unsigned ticket_s;
+  // (LDS-qualified pointers: through a generic pointer a volatile access stays a flat one)
+  agp_lds_u64* const ring = (agp_lds_u64*)ring_s;
+  agp_lds_u32* const prog = (agp_lds_u32*)prog_s;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x == 0) ticket_s = atomicAdd(&sync[0], 1u);
+  if (threadIdx.x < AGP_ROWS) prog_s[threadIdx.x] = 0;
+  __syncthreads();
+  const int t = __builtin_amdgcn_readfirstlane((int)ticket_s);
+  const int band = t / (2 * n), rem = t - band * 2 * n;
+  const int pair = rem >> 1;
+  const bool down = (rem & 1) == 0;
+  const int W1 = P.width1, H = P.H, D = P.D;
+  const int r = band * AGP_ROWS + w;   // row in the order of the pass
+  if (band >= nbands || r >= H) return;
+  const int y = down ? r : H - 1 - r;
+  const int in_kind = r == 0 ? AGP_IN_ZERO : (w == 0 ? AGP_IN_GLOBAL : AGP_IN_LDS);
+  const int out_kind = r == H - 1 ? AGP_OUT_NONE : (w == AGP_ROWS - 1 ? AGP_OUT_GLOBAL : AGP_OUT_LDS);
+  // hand-over entries: [pass][pair][boundary][step][lane]
+  const size_t hrow = (size_t)W1 * 64;
+  const size_t hpp = (size_t)(nbands - 1) * hrow;
+  const size_t hbase = ((size_t)(down ? 0 : 1) * cap_pairs + pair) * hpp;
+  const size_t rowbase = (((size_t)pair * H + y) * W1) * D + min(lane, D - 1);
+  AgpRow R;
+  R.cp = reinterpret_cast<const unsigned*>(Cv + (rowbase - min(lane, D - 1))) + (min(lane, D - 1) >> 1);
+  R.csh = (min(lane, D - 1) & 1) * 16;
+  R.sp = (down ? sumA : sumB) + rowbase;
+  R.hin = hand + hbase + (size_t)max(band - 1, 0) * hrow + lane;
+  R.hout = hand + hbase + (size_t)min(band, max(nbands - 2, 0)) * hrow + lane;
+  R.ring_in = ring + (size_t)max(w - 1, 0) * AGP_RING * 64 + lane;
+  R.ring_out = ring + (size_t)min(w, AGP_ROWS - 2) * AGP_RING * 64 + lane;
+  R.prog_in = prog + max(w - 1, 0);
+  R.prog_me = prog + w;
+  R.prog_out = prog + min(w + 1, AGP_ROWS - 1);
+  R.err = sync + 1;
+  R.W1 = W1;
+  R.D = D;
+  R.P1 = P.P1;
+  R.P2 = P.P2;
+  R.etag = ((epoch & 1u) << 15) | ((epoch & 2u) << 30);
+  R.down = down;
+  R.act = lane < D;
+  switch (in_kind * 3 + out_kind) {   // wave-uniform
+    case AGP_IN_ZERO * 3 + AGP_OUT_NONE: agp_row<AGP_IN_ZERO, AGP_OUT_NONE>(R); break;
+    case AGP_IN_ZERO * 3 + AGP_OUT_LDS: agp_row<AGP_IN_ZERO, AGP_OUT_LDS>(R); break;
+    case AGP_IN_ZERO * 3 + AGP_OUT_GLOBAL: agp_row<AGP_IN_ZERO, AGP_OUT_GLOBAL>(R); break;
+    case AGP_IN_LDS * 3 + AGP_OUT_NONE: agp_row<AGP_IN_LDS, AGP_OUT_NONE>(R); break;
+    case AGP_IN_LDS * 3 + AGP_OUT_LDS: agp_row<AGP_IN_LDS, AGP_OUT_LDS>(R); break;
+    case AGP_IN_LDS * 3 + AGP_OUT_GLOBAL: agp_row<AGP_IN_LDS, AGP_OUT_GLOBAL>(R); break;
+    case AGP_IN_GLOBAL * 3 + AGP_OUT_NONE: agp_row<AGP_IN_GLOBAL, AGP_OUT_NONE>(R); break;
+    case AGP_IN_GLOBAL * 3 + AGP_OUT_LDS: agp_row<AGP_IN_GLOBAL, AGP_OUT_LDS>(R); break;
+    default: agp_row<AGP_IN_GLOBAL, AGP_OUT_GLOBAL>(R); break;
   }
 }
 
@@ -844,7 +1109,14 @@ __global__ __launch_bounds__(256) void dense_reproject_kernel(int W, int H, cons
 
 size_t dense_volume_elems(const DenseParams& P) { return (size_t)P.H * P.width1 * P.D; }
 
-void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st) {
+// bytes of the two-pass aggregation's block-to-block entries (0: that path is not used for this call)
+size_t dense_handoff_bytes(const DenseParams& P, int pairs) {
+  if (!P.full_dp || P.bm || pairs < AGP_MIN_PAIRS || P.width1 <= 0) return 0;
+  const size_t nbands = (size_t)(P.H + AGP_ROWS - 1) / AGP_ROWS;
+  return std::max<size_t>(1, nbands - 1) * 2 * pairs * P.width1 * 64 * sizeof(unsigned long long);
+}
+
+void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st) {
   const dim3 blk(256);
   dense_prefilter_kernel<<<dim3((P.W + 255) / 256, P.H, 2 * n), blk, 0, st>>>(P, B.left, B.right, B.rec);
   if (P.full_dp && P.SW2 >= 1 && P.SW2 <= 5) {
@@ -869,7 +1141,23 @@ void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipSt
   unsigned short* sA = (unsigned short*)B.vol[0];
   unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
-  if (n <= 3 && P.full_dp) {
+  static const bool x_eight = getenv("KVFE_X_DENSE8") != nullptr;   // A/B while measuring
+  if (!x_eight && P.full_dp && n >= AGP_MIN_PAIRS && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
+    // computeDisparitySGBM's two passes, one launch: rows of a pass are waves that hand their path costs down
+    const int nbands = (P.H + AGP_ROWS - 1) / AGP_ROWS;
+    const int key[4] = {n, P.width1, P.H, P.D};
+    if (memcmp(key, B.hand_key, sizeof(key)) != 0 || B.hand_epoch == 0) {
+      // entries of another layout could carry this launch's tag: start from a zeroed buffer
+      (void)hipMemsetAsync(B.hand, 0, B.hand_bytes, st);
+      memcpy(B.hand_key, key, sizeof(key));
+      B.hand_epoch = 0;
+    }
+    B.hand_epoch = B.hand_epoch % 3 + 1;
+    (void)hipMemsetAsync(B.agsync, 0, 2 * sizeof(unsigned), st);
+    dense_aggregate_pass_kernel<<<dim3(nbands * 2 * n), dim3(AGP_ROWS * 64), 0, st>>>(
+        P, Cv, sA, sB, B.hand, B.agsync, n, B.cap_pairs, nbands, B.hand_epoch);
+    dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, sB, B.disp[0]);
+  } else if (n <= 3 && P.full_dp) {
     // few pairs: every direction of a pair in one launch, packed atomic adds into two zeroed volumes
     const size_t bytes = sizeof(short) * dense_volume_elems(P) * n;
     (void)hipMemsetAsync(sA, 0, bytes, st);

@@ -2941,7 +2941,9 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   DeviceGuard _dev(c);
   DenseBuffers& b = c->dense;
   const size_t ve = P.width1 > 0 ? dense_volume_elems(P) : 1;
-  if (b.cap_pairs >= pairs && b.vol_elems == ve) return KVFE_OK;
+  const size_t hand_need = dense_handoff_bytes(P, pairs);
+  if (b.cap_pairs >= pairs && b.vol_elems == ve && b.hand_bytes >= dense_handoff_bytes(P, b.cap_pairs))
+    return KVFE_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (void* p : c->dense_allocs) hipFree(p);
   c->dense_allocs.clear();
@@ -2963,6 +2965,11 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   TRY(al((void**)&c->dense_dispf, sizeof(float) * px));
   TRY(al((void**)&c->dense_xyz, sizeof(float) * 3 * px));
   TRY(al((void**)&c->dense_minkey, 16));
+  TRY(al((void**)&b.agsync, 2 * sizeof(unsigned)));
+  if (hand_need) {
+    TRY(al((void**)&b.hand, hand_need));
+    b.hand_bytes = hand_need;
+  }
   b.cap_pairs = pairs;
   b.vol_elems = ve;
   for (int i = 0; i < 2; i++)
@@ -3013,7 +3020,13 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
       HIPCHK(c, hipMemcpy2DAsync(disparity[i0 + i], dstride * sizeof(int16_t), b.disp[0] + px * i,
                                  P.W * sizeof(int16_t), P.W * sizeof(int16_t), P.H, hipMemcpyDeviceToHost,
                                  c->stream));
+    unsigned agg_err = 0;
+    HIPCHK(c, hipMemcpyAsync(&agg_err, b.agsync + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (agg_err) {
+      c->last_error = "dense stereo: a hand-over wait of the two-pass aggregation ran out";
+      return KVFE_ERR_HIP;
+    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->dense_ev[0], c->dense_ev[1]) == hipSuccess) {
       c->dense_ms += ms;

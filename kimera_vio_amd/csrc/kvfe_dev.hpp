@@ -90,13 +90,20 @@ struct DenseBuffers {
   int *label = nullptr, *count = nullptr, *runlen = nullptr;   // [n][H][W]
   int cap_pairs = 0;
   size_t vol_elems = 0;                        // elements per pair in vol[]
+  // two-pass aggregation (MODE_HH, >= 4 pairs): block-to-block hand-over entries and the launch's ticket / error words
+  unsigned long long* hand = nullptr;          // [2 passes][cap_pairs][row bands - 1][width1][64 lanes]
+  size_t hand_bytes = 0;
+  unsigned* agsync = nullptr;                  // [0] ticket counter, [1] error word (a wait ran out)
+  unsigned hand_epoch = 0;                     // tag of the last launch's entries (1..3, 0 = buffer is zero)
+  int hand_key[4] = {};                        // (pairs, width1, H, D) of the last launch: a change zeroes the buffer
 };
+size_t dense_handoff_bytes(const DenseParams& P, int pairs);
 struct ReprojectQ {
   double q[16];
 };
 size_t dense_volume_elems(const DenseParams& P);
 // inputs in B.left / B.right, result in B.disp[0]
-void launch_dense_sgbm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st);
+void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st);
 void launch_dense_bm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st);
 void launch_reproject_to_3d(int W, int H, const float* disp, const ReprojectQ& Q, unsigned* minkey, float* xyz,
                             hipStream_t st);
