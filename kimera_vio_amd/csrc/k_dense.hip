@@ -434,35 +434,61 @@ __global__ __launch_bounds__(256) void dense_aggregate_all_kernel(DenseParams P,
 // ---- two-pass aggregation (MODE_HH, four or more pairs) -------------------------------------------------------
 // computeDisparitySGBM's own order: pass 1 walks the rows top-down and every row left to right with the four paths whose
 // previous pixel lies behind ((x-1,y), (x-1,y-1), (x,y-1), (x+1,y-1)), pass 2 walks them bottom-up and right to left
-// with the other four.  Here a wave is one image row of one pass (lane = disparity): it carries the horizontal path in a
-// register and takes the three paths that come from the row before it out of what that row's wave published, so C is
-// read twice and each partial sum written once per pixel (eight sweeps: C read eight times, S written once and
-// read-modified-written seven times).
-//   * the wave of row r at step i (column x_i) needs, from row r-1: the diagonal path at step i-1, the vertical one at
-//     step i and the other diagonal at step i+1 -- it reads ONE published entry per step (i+1) and keeps the two older
-//     ones in registers; it may run step i as soon as the row before has finished step i+1;
-//   * a block is 16 consecutive rows; entries go from wave to wave through a ring of 8 in LDS (8 bytes per lane: the three
-//     path costs in 15 bits each, their minima in lanes 0-2), guarded by a per-wave step counter both ways;
-//   * from the last row of a block to the first row of the next they go through HBM as relaxed device-scope 64-bit atomics,
-//     each word tagged with the launch's epoch (two spare bits), so the reader needs no fence: it polls the word itself;
+// with the other four.  Here a wave is one image row of one pass and does the four paths of a pixel in ONE set of
+// instructions: DPP row q of the wave (16 lanes) is path q (0 horizontal, 1 the diagonal whose predecessor is behind, 2
+// vertical, 3 the diagonal whose predecessor is ahead), lane g of a row holds disparities 4g .. 4g+3 as two packed
+// 16-bit pairs.  C is read twice and each partial sum written once per pixel (eight sweeps: C read eight times, S written
+// once and read-modified-written seven times), and a pixel of a pass costs ~50 vector instructions (a wave per path
+// with lane = disparity: ~190, which was slower than the eight sweeps -- profiles/r5_analysis.md).
+//   * path q of the row r at step i (column x_i) continues path q of row r-1 at step i-2+q: the row before publishes one
+//     ENTRY per step (its four new cost vectors, 8 bytes per lane, + the three minima), and lane (q, g) reads its 8 bytes
+//     out of entry i-2+q -- one LDS read with per-lane addresses; row 0 of the wave (horizontal) takes its own previous
+//     result instead.  A row may run step i as soon as the row before has finished step i+1;
+//   * the sum of the four paths is formed from the entry the wave has just written (lanes of row 0 read the other three
+//     rows back), one step later so that the LDS latency is not waited for;
+//   * a block is 15 consecutive rows + a loader wave; entries go from wave to wave through a ring of 8 in LDS, guarded
+//     by a per-wave step counter both ways;
+//   * from the last row of a block to the first row of the next they go through HBM as relaxed device-scope atomics, each
+//     word tagged with the launch's epoch (two spare bits: costs are <= 16383), so the reader needs no fence: the next
+//     block's loader wave polls the words themselves (requested AGP_LPF steps ahead; a word that has not arrived is
+//     loaded again) and puts them into the ring its first row reads -- every row wave is the same LDS-fed code, and the
+//     registers of the prefetch are the loader's (a row that prefetches for itself needs 84 and halves the occupancy);
 //   * blocks take their (band, pair, pass) from a ticket counter, band-major: a block only ever waits for a block with a
 //     smaller ticket, which is running -- no co-residency assumption, no deadlock whatever the dispatch order;
 //   * every wait is bounded (AGP_TIMEOUT_TICKS); a wait that runs out sets the launch's error word, which every other
-//     wait looks at, and the call returns KVFE_ERR_INTERNAL instead of hanging the device.
-// Same integers as dense_aggregate_path (same step function, same zero predecessors outside the volume).
-constexpr int AGP_ROWS = 16;
+//     wait looks at, and the call returns an error instead of hanging the device.
+// Same integers as dense_aggregate_path: 16383 stands for SHRT_MAX at d = -1, d = D and in the lanes past D (every cost
+// is <= 16383 -- dense_params() refuses parameters that could exceed it -- so 16383 + P1 is never the minimum, which is
+// all SHRT_MAX does upstream), zero predecessors outside the volume.
+constexpr int AGP_ROWS = 15;    // image rows per block
+constexpr int AGP_WAVES = 16;   // + the loader wave (wave 0)
+constexpr int AGP_LPF = 4;      // steps the loader requests ahead
 constexpr int AGP_MIN_PAIRS = 4;   // fewer pairs: too few rows in flight, the single-launch atomic sweeps are faster
 constexpr int AGP_RING = 8;
 constexpr int AGP_PF = 4;
 constexpr long long AGP_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wall clock
+constexpr unsigned AGP_INF2 = 0x3FFF3FFFu;
+constexpr unsigned AGP_TAGMASK = 0x80008000u;
 
-__device__ __forceinline__ int agp_step(int c, int Lp, int minp, int P1, int P2, bool act, int& minout) {
-  const int delta = minp + P2;
-  const int lm = dpp_wave_shr1(Lp, MAXC), lq = dpp_wave_shl1(Lp, MAXC);
-  const int m = min(min(Lp, delta), min(lm, lq) + P1);
-  const int L = act ? c + m - delta : MAXC;
-  minout = wave_min(L);
-  return L;
+typedef short agp_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short agp_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned agp_pk_min(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned,
+                            __builtin_elementwise_min(__builtin_bit_cast(agp_s2, a), __builtin_bit_cast(agp_s2, b)));
+}
+__device__ __forceinline__ unsigned agp_pk_add(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(agp_u2, a) + __builtin_bit_cast(agp_u2, b));
+}
+__device__ __forceinline__ unsigned agp_pk_sub(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(agp_u2, a) - __builtin_bit_cast(agp_u2, b));
+}
+// minimum over the 16 lanes of a DPP row of a value whose two halves are equal (so the 32-bit order is the 16-bit one)
+__device__ __forceinline__ unsigned agp_row_min(unsigned x) {
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false));   // row_ror:8
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xf, 0xf, false));   // row_ror:4
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x122, 0xf, 0xf, false));   // row_ror:2
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xf, 0xf, false));   // row_ror:1
+  return x;
 }
 
 struct AgpWait {
@@ -470,9 +496,15 @@ struct AgpWait {
   long long t0 = 0;   // start of the wait in progress (0: none)
   bool dead = false;
   unsigned spins = 0;
+#ifdef KVFE_AGP_PROF
+  unsigned turns = 0;   // turns of wait loops since the counter was last read
+#endif
   // one more turn of a wait loop; false = give up
   __device__ __forceinline__ bool again() {
     if (dead) return false;
+#ifdef KVFE_AGP_PROF
+    turns++;
+#endif
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 127u) == 0) {
       const long long now = wall_clock64();
@@ -489,23 +521,24 @@ struct AgpWait {
 
 typedef __attribute__((address_space(3))) volatile unsigned long long agp_lds_u64;
 typedef __attribute__((address_space(3))) volatile unsigned agp_lds_u32;
-enum { AGP_IN_ZERO = 0, AGP_IN_LDS = 1, AGP_IN_GLOBAL = 2, AGP_OUT_NONE = 0, AGP_OUT_LDS = 1, AGP_OUT_GLOBAL = 2 };
+enum { AGP_IN_ZERO = 0, AGP_IN_LDS = 1, AGP_OUT_NONE = 0, AGP_OUT_LDS = 1, AGP_OUT_GLOBAL = 2 };
 
 struct AgpRow {
-  const unsigned* cp;         // C of the row: the dword that holds this lane's disparity (a 16-bit load needs an extension,
-                              // which the compiler places right behind the load -- in the next step, where it turns the
-                              // prefetch into a wait; the half is picked at the use instead, behind an opaque asm)
-  int csh;                    // 0 / 16: which half
-  unsigned short* sp;         // the pass's partial sum of the row
-  unsigned long long* hin;    // entries of the block before (this lane's word of step 0)
-  unsigned long long* hout;   // entries for the block after
-  agp_lds_u64* ring_in;       // ring written by the wave of the row before (this lane's word of slot 0)
-  agp_lds_u64* ring_out;
+  // wave-uniform bases (scalar registers); the lane's part of an address is a 32-bit offset computed in agp_row
+  const char* cp;             // C of the row, column 0
+  char* sp;                   // the pass's partial sum of the row
+  char* hout;                 // entries for the block after: [step][64 lanes] x 8 bytes
+  char* hmin_out;             // their minima: [step][4] words
+  agp_lds_u64* ring_in;       // ring written by the wave of the row before: [slot][64]
+  agp_lds_u32* minring_in;    //   its minima: [slot][4]
+  agp_lds_u64* ring_out;      // this wave's ring (or its two scratch slots when nobody reads it)
+  agp_lds_u32* minring_out;
   agp_lds_u32 *prog_in, *prog_me, *prog_out;
   unsigned* err;
+  int omask;                  // slots of ring_out - 1
   int W1, D, P1, P2;
   unsigned etag;
-  bool down, act;
+  bool down;
 };
 
 // one row of one pass; IN / OUT: where the row before's entries come from and where this row's go (wave-uniform, so
@@ -513,110 +546,135 @@ struct AgpRow {
 template <int IN, int OUT>
 __device__ __forceinline__ void agp_row(const AgpRow& R) {
   const int lane = threadIdx.x & 63;
-  const int W1 = R.W1, D = R.D, P1 = R.P1, P2 = R.P2, last = W1 - 1;
-  const bool act = R.act, down = R.down;
-  const int zl = act ? 0 : MAXC;
+  const int q = lane >> 4, g = lane & 15;
+  const int W1 = R.W1, D = R.D, last = W1 - 1;
+  const bool down = R.down;
+  const unsigned cbytes = (unsigned)D * 2u;                               // bytes of C / S per column
+  const unsigned coff = 8u * (unsigned)min(g, D / 4 - 1);                 // this lane's four disparities in a column
+  const unsigned hoff = 8u * (unsigned)lane, moff = 4u * (unsigned)q;    // this lane's word of an entry / of the minima
+  auto xof = [&](int i) { return down ? i : last - i; };
+  auto c_at = [&](int i) { return *reinterpret_cast<const unsigned long long*>(R.cp + (size_t)xof(i) * cbytes + coff); };
+  const bool actl = 4 * g < D;
+  const bool all_active = D == 64;
+  const unsigned zero2 = actl ? 0u : AGP_INF2;
+  const unsigned P1P1 = (unsigned)R.P1 * 0x10001u, P2P2 = (unsigned)R.P2 * 0x10001u;
   const unsigned etag = R.etag;
+  const bool row0 = q == 0;
   AgpWait wt;
   wt.err = R.err;
-  auto xof = [&](int i) { return down ? i : last - i; };
   unsigned seen_in = 0, seen_out = 0;
-  auto global_entry = [&](unsigned long long v, int j) {   // v = what the prefetch of entry j returned
-    while (__builtin_amdgcn_ballot_w64((((unsigned)v & 0x80008000u) != etag)) != 0ull) {
-      if (!wt.again()) break;
-      v = __hip_atomic_load(R.hin + (size_t)j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    wt.t0 = 0;
-    return v;
-  };
-  auto lds_entry = [&](int j) {
-    while (seen_in < (unsigned)j + 1u) {
-      seen_in = __builtin_amdgcn_readfirstlane(*R.prog_in);
-      if (seen_in >= (unsigned)j + 1u) break;
-      if (!wt.again()) break;
-    }
-    wt.t0 = 0;
-    return R.ring_in[(j & (AGP_RING - 1)) * 64];
-  };
-  const unsigned long long zero_entry =
-      (unsigned long long)((unsigned)zl | ((unsigned)zl << 16)) | ((unsigned long long)(unsigned)zl << 32);
+#ifdef KVFE_AGP_PROF
+  const long long prof_t0 = wall_clock64();
+  unsigned prof_in_turns = 0, prof_out_turns = 0, prof_in_steps = 0, prof_out_steps = 0;
+#endif
 
-  // prefetch: C of the next AGP_PF steps and (first row of a block) the entries of the block before
-  unsigned cbuf[AGP_PF];
-  unsigned long long gbuf[AGP_PF];
+  // prefetch: C of the next AGP_PF steps
+  unsigned long long cbuf[AGP_PF];   // (one 64-bit value each: as two words they are copied at the loop's back edge)
 #pragma unroll
-  for (int u = 0; u < AGP_PF; u++) {
-    cbuf[u] = R.cp[(size_t)xof(min(u, last)) * (D >> 1)];
-    gbuf[u] = 0;
-    if (IN == AGP_IN_GLOBAL)   // entry u + 1 is the one step u consumes
-      gbuf[u] = __hip_atomic_load(R.hin + (size_t)min(u + 1, last) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // entry 0: vertical and behind-diagonal predecessors of steps 0 and 1
-  unsigned long long e0 = zero_entry;
-  if (IN == AGP_IN_LDS) e0 = lds_entry(0);
-  if (IN == AGP_IN_GLOBAL) e0 = global_entry(__hip_atomic_load(R.hin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
-  int Lh = zl, mh = 0;                                // horizontal path, carried
-  int h_db1 = (int)((unsigned)e0 & 0x7fffu);          // behind-diagonal of entry i (used at step i + 1)
-  int h_v = (int)(((unsigned)e0 >> 16) & 0x7fffu);    // vertical of entry i (used at step i)
-  int m_db1 = __builtin_amdgcn_readlane((int)((unsigned)(e0 >> 48)), 0);
-  int m_v = __builtin_amdgcn_readlane((int)((unsigned)(e0 >> 48)), 1);
-  int h_db2 = zl, m_db2 = 0;                          // behind-diagonal of entry i - 1: outside at step 0
+  for (int u = 0; u < AGP_PF; u++) cbuf[u] = c_at(min(u, last));
+  unsigned pA = zero2, pB = zero2, pM = 0;   // this lane's result of the step before (row 0: the horizontal path's input)
+
+  // the sum of the four paths of step j, from the entry this wave wrote at step j (hA, hB: row 0's own part)
+  auto store_sum = [&](int j, unsigned hA, unsigned hB) {
+    if (row0) {
+      const int so = (j & R.omask) * 64 + g;
+      const unsigned long long r1 = R.ring_out[so + 16], r2 = R.ring_out[so + 32], r3 = R.ring_out[so + 48];
+      uint2 sum;
+      sum.x = agp_pk_add(agp_pk_add(hA, (unsigned)r1), agp_pk_add((unsigned)r2, (unsigned)r3));
+      sum.y = agp_pk_add(agp_pk_add(hB, (unsigned)(r1 >> 32)), agp_pk_add((unsigned)(r2 >> 32), (unsigned)(r3 >> 32)));
+      if (actl) *reinterpret_cast<uint2*>(R.sp + (size_t)xof(j) * cbytes + coff) = sum;
+    }
+  };
 
   // one step; u = i mod AGP_PF selects the prefetch registers (compile-time in the unrolled loops below)
   auto step = [&](const int u, const int i) {
-    {
-      unsigned craw = cbuf[u];
-      unsigned long long gpre = gbuf[u];
-      cbuf[u] = R.cp[(size_t)xof(min(i + AGP_PF, last)) * (D >> 1)];
-      if (IN == AGP_IN_GLOBAL)
-        gbuf[u] = __hip_atomic_load(R.hin + (size_t)min(i + 1 + AGP_PF, last) * 64, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT);
-      // entry i + 1 of the row before (outside the volume past its last column)
-      unsigned long long e = zero_entry;
-      if (IN == AGP_IN_GLOBAL) asm volatile("" : "+v"(gpre));   // likewise the prefetched entry
-      if (IN != AGP_IN_ZERO && i < last) e = IN == AGP_IN_LDS ? lds_entry(i + 1) : global_entry(gpre, i + 1);
-      const unsigned elo = (unsigned)e, ehi = (unsigned)(e >> 32);
-      asm volatile("" : "+v"(craw));   // first use of the prefetched C: here, not earlier
-      const int c = (int)((craw >> R.csh) & 0xffffu);
-      const int in_da = (int)(ehi & 0x7fffu);
-      const int m_da = __builtin_amdgcn_readlane((int)(ehi >> 16), 2);
-      int n_h, n_db, n_v, n_da;
-      Lh = agp_step(c, Lh, mh, P1, P2, act, n_h);
-      const int Ldb = agp_step(c, h_db2, m_db2, P1, P2, act, n_db);
-      const int Lv = agp_step(c, h_v, m_v, P1, P2, act, n_v);
-      const int Lda = agp_step(c, in_da, m_da, P1, P2, act, n_da);
-      mh = n_h;
-      if (act) R.sp[(size_t)xof(i) * D] = (unsigned short)min(Lh + Ldb + Lv + Lda, 65535);
-      // history: entry i + 1 becomes "entry i" of the next step
-      h_db2 = h_db1;
-      m_db2 = m_db1;
-      h_db1 = (int)(elo & 0x7fffu);
-      m_db1 = __builtin_amdgcn_readlane((int)(ehi >> 16), 0);
-      h_v = (int)((elo >> 16) & 0x7fffu);
-      m_v = __builtin_amdgcn_readlane((int)(ehi >> 16), 1);
-      // publish this row's entry i
-      if (OUT != AGP_OUT_NONE) {
-        const unsigned ex = lane == 0 ? (unsigned)n_db : (lane == 1 ? (unsigned)n_v : (unsigned)n_da);
-        const unsigned olo = (unsigned)Ldb | ((unsigned)Lv << 16) | etag;
-        const unsigned ohi = (unsigned)Lda | (ex << 16);
-        const unsigned long long o = (unsigned long long)olo | ((unsigned long long)ohi << 32);
-        if (OUT == AGP_OUT_LDS) {
-          if (i >= AGP_RING) {   // the slot's previous entry (i - RING) must have been read: reader past step i-RING-1
-            const unsigned need = (unsigned)max(1, i - AGP_RING);
-            while (seen_out < need) {
-              seen_out = __builtin_amdgcn_readfirstlane(*R.prog_out);
-              if (seen_out >= need) break;
-              if (!wt.again()) break;
-            }
-            wt.t0 = 0;
-          }
-          R.ring_out[(i & (AGP_RING - 1)) * 64] = o;
-        } else {
-          __hip_atomic_store(R.hout + (size_t)i * 64, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    unsigned long long craw = cbuf[u];
+    const int e = i - 2 + q;   // the entry of the row before that this lane's path continues
+    unsigned inA = zero2, inB = zero2, inM = 0;
+    if (IN == AGP_IN_LDS) {
+      const unsigned need = (unsigned)min(i + 2, W1);
+      while (seen_in < need) {
+        seen_in = __builtin_amdgcn_readfirstlane(*R.prog_in);
+        if (seen_in >= need) break;
+        if (!wt.again()) break;
       }
-      if (lane == 0) *R.prog_me = (unsigned)i + 1u;
+      wt.t0 = 0;
+#ifdef KVFE_AGP_PROF
+      prof_in_turns += wt.turns;
+      prof_in_steps += wt.turns ? 1 : 0;
+      wt.turns = 0;
+#endif
+      const int slot = e & (AGP_RING - 1);
+      const unsigned long long v = R.ring_in[slot * 64 + lane];
+      inM = R.minring_in[slot * 4 + q];
+      inA = (unsigned)v;
+      inB = (unsigned)(v >> 32);
     }
+    if (IN != AGP_IN_ZERO && (i == 0 || i == last)) {   // wave-uniform: entries -1 and W1 lie outside the volume
+      const bool inr = e >= 0 && e <= last;
+      inA = inr ? inA : zero2;
+      inB = inr ? inB : zero2;
+      inM = inr ? inM : 0u;
+    }
+    // the sum of the step before (its entry has been in LDS for a step)
+    if (i > 0) store_sum(i - 1, pA, pB);
+    inA = row0 ? pA : inA;
+    inB = row0 ? pB : inB;
+    inM = row0 ? pM : inM;
+    asm volatile("" : "+v"(craw));   // first use of the prefetched C: here, not earlier
+    const unsigned cA = (unsigned)craw, cB = (unsigned)(craw >> 32);
+    // (the next request after the use: issued before it, old and new value are alive together and the registers
+    // rotate through copies at the loop's back edge -- behind a wait for every load)
+    cbuf[u] = c_at(min(i + AGP_PF, last));
+    // L(d) = C(d) + min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1, min Lp + P2) - (min Lp + P2), four disparities at a time
+    const unsigned delta = agp_pk_add(inM, P2P2);
+    const unsigned nbp = (unsigned)__builtin_amdgcn_update_dpp((int)AGP_INF2, (int)inB, 0x111, 0xf, 0xf, false);   // row_shr:1
+    const unsigned nbn = (unsigned)__builtin_amdgcn_update_dpp((int)AGP_INF2, (int)inA, 0x101, 0xf, 0xf, false);   // row_shl:1
+    const unsigned lmA = __builtin_amdgcn_alignbit(inA, nbp, 16);   // (L[4g-1], L[4g])
+    const unsigned lmB = __builtin_amdgcn_alignbit(inB, inA, 16);   // (L[4g+1], L[4g+2])
+    const unsigned lqB = __builtin_amdgcn_alignbit(nbn, inB, 16);   // (L[4g+3], L[4g+4])
+    const unsigned tA = agp_pk_add(agp_pk_min(lmA, lmB), P1P1);
+    const unsigned tB = agp_pk_add(agp_pk_min(lmB, lqB), P1P1);
+    const unsigned mA = agp_pk_min(agp_pk_min(inA, delta), tA);
+    const unsigned mB = agp_pk_min(agp_pk_min(inB, delta), tB);
+    unsigned nA = agp_pk_add(cA, agp_pk_sub(mA, delta));
+    unsigned nB = agp_pk_add(cB, agp_pk_sub(mB, delta));
+    if (!all_active) {
+      nA = actl ? nA : AGP_INF2;
+      nB = actl ? nB : AGP_INF2;
+    }
+    unsigned x = agp_pk_min(nA, nB);
+    x = agp_pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
+    const unsigned nM = agp_row_min(x);
+    // publish this row's entry i (in LDS always: the sum is formed from it)
+    if (OUT == AGP_OUT_LDS && i >= AGP_RING - 1) {   // the slot's previous entry (i - RING) is read last at step i - RING + 1
+      const unsigned need = (unsigned)(i - AGP_RING + 2);
+      while (seen_out < need) {
+        seen_out = __builtin_amdgcn_readfirstlane(*R.prog_out);
+        if (seen_out >= need) break;
+        if (!wt.again()) break;
+      }
+      wt.t0 = 0;
+#ifdef KVFE_AGP_PROF
+      prof_out_turns += wt.turns;
+      prof_out_steps += wt.turns ? 1 : 0;
+      wt.turns = 0;
+#endif
+    }
+    const unsigned long long o = (unsigned long long)nA | ((unsigned long long)nB << 32);
+    R.ring_out[(i & R.omask) * 64 + lane] = o;
+    if (OUT == AGP_OUT_LDS && g == 0) R.minring_out[(i & R.omask) * 4 + q] = nM;
+    if (OUT == AGP_OUT_GLOBAL) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.hout + (size_t)i * 512 + hoff), o | etag,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(R.hmin_out + (size_t)i * 16 + moff), nM | etag, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) *R.prog_me = (unsigned)i + 1u;
+    pA = nA;
+    pB = nB;
+    pM = nM;
   };
   // groups of AGP_PF steps without a condition in between (a conditional update of the prefetch registers costs copies
   // at the top of the next step, and a copy is a use: the wait for the load moves up to it), then the remainder
@@ -628,67 +686,181 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
 #pragma unroll
   for (int u = 0; u < AGP_PF; u++)
     if (i0 + u <= last) step(u, i0 + u);
+  store_sum(last, pA, pB);
+#ifdef KVFE_AGP_PROF
+  if (lane == 0) {
+    const long long t1 = wall_clock64();
+    unsigned* st = R.err + 1;   // sync[2..]
+    const unsigned dur = (unsigned)(t1 - prof_t0);
+    atomicAdd(st + 0, 1u);
+    atomicAdd(st + 1, dur);
+    atomicMax(st + 2, dur);
+    atomicAdd(st + 3, prof_in_turns);
+    atomicAdd(st + 4, prof_out_turns);
+    atomicAdd(st + 5, prof_in_steps);
+    atomicAdd(st + 6, prof_out_steps);
+    atomicMin(st + 7, (unsigned)prof_t0);
+    atomicMax(st + 8, (unsigned)t1);
+    if (IN == AGP_IN_ZERO) {
+      atomicAdd(st + 11, dur);
+      atomicAdd(st + 12, 1u);
+    }
+  }
+#endif
 }
 
-__global__ __launch_bounds__(AGP_ROWS * 64) void dense_aggregate_pass_kernel(
+// the loader wave of a block: the entries the block before wrote to HBM -> the ring the block's first row reads
+__device__ __forceinline__ void agp_loader(const char* hin, const char* hmin_in, agp_lds_u64* ring_out,
+                                           agp_lds_u32* minring_out, agp_lds_u32* prog_me, agp_lds_u32* prog_out,
+                                           unsigned* err, int W1, unsigned etag) {
+  const int lane = threadIdx.x & 63;
+  const int last = W1 - 1;
+  const unsigned hoff = 8u * (unsigned)lane, moff = 4u * (unsigned)(lane & 3);
+  AgpWait wt;
+  wt.err = err;
+  unsigned seen_out = 0;
+  auto h_at = [&](int e) {
+    return __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<char*>(hin) + ((size_t)e * 512u + hoff)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto hm_at = [&](int e) {   // (all lanes load one of the four words: no lane predicate around the request)
+    return __hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<char*>(hmin_in) + ((size_t)e * 16u + moff)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+#ifdef KVFE_AGP_PROF
+  unsigned prof_turns = 0, prof_steps = 0;
+#endif
+  unsigned long long gL[AGP_LPF];
+  unsigned gM[AGP_LPF];
+#pragma unroll
+  for (int u = 0; u < AGP_LPF; u++) {
+    gL[u] = h_at(min(u, last));
+    gM[u] = hm_at(min(u, last));
+  }
+  auto step = [&](const int u, const int j) {
+    unsigned long long gl = gL[u];
+    unsigned gm = gM[u];
+    gL[u] = h_at(min(j + AGP_LPF, last));
+    gM[u] = hm_at(min(j + AGP_LPF, last));
+    asm volatile("" : "+v"(gl), "+v"(gm));   // first use of the requested words: here, not earlier
+    // word 0 of the minima is not written (row 0 of a wave is the horizontal path)
+    while (__builtin_amdgcn_ballot_w64((((unsigned)gl & AGP_TAGMASK) != etag) ||
+                                       ((lane & 3) != 0 && (gm & AGP_TAGMASK) != etag)) != 0ull) {
+      if (!wt.again()) break;
+      gl = h_at(j);
+      gm = hm_at(j);
+    }
+    wt.t0 = 0;
+#ifdef KVFE_AGP_PROF
+    prof_turns += wt.turns;
+    prof_steps += wt.turns ? 1 : 0;
+    wt.turns = 0;
+#endif
+    if (j >= AGP_RING - 1) {   // as in agp_row: entry j - RING is read last at the reader's step j - RING + 1
+      const unsigned need = (unsigned)(j - AGP_RING + 2);
+      while (seen_out < need) {
+        seen_out = __builtin_amdgcn_readfirstlane(*prog_out);
+        if (seen_out >= need) break;
+        if (!wt.again()) break;
+      }
+      wt.t0 = 0;
+    }
+    const int slot = j & (AGP_RING - 1);
+    ring_out[slot * 64 + lane] = gl & ~(unsigned long long)AGP_TAGMASK;
+    if (lane < 4) minring_out[slot * 4 + lane] = gm & ~AGP_TAGMASK;
+    if (lane == 0) *prog_me = (unsigned)j + 1u;
+  };
+  int j0 = 0;
+  for (; j0 + AGP_LPF <= W1; j0 += AGP_LPF) {
+#pragma unroll
+    for (int u = 0; u < AGP_LPF; u++) step(u, j0 + u);
+  }
+#pragma unroll
+  for (int u = 0; u < AGP_LPF; u++)
+    if (j0 + u <= last) step(u, j0 + u);
+#ifdef KVFE_AGP_PROF
+  if (lane == 0) {
+    atomicAdd(err + 1 + 9, prof_turns);
+    atomicAdd(err + 1 + 10, prof_steps);
+  }
+#endif
+}
+
+#ifdef KVFE_AGP_PROF
+// profiling build only: the launch's counters -> the first words of the C volume (read with kvfe_dense_debug_volume)
+__global__ void agp_prof_copy_kernel(const unsigned* sync, unsigned* out) {
+  if (threadIdx.x < 16) out[threadIdx.x] = sync[2 + threadIdx.x];
+}
+#endif
+
+// (eight waves per SIMD = two blocks per CU: 64 registers)
+__global__ __launch_bounds__(AGP_WAVES * 64) void dense_aggregate_pass_kernel(
     DenseParams P, const short* __restrict__ Cv, unsigned short* __restrict__ sumA, unsigned short* __restrict__ sumB,
-    unsigned long long* __restrict__ hand, unsigned* __restrict__ sync, int n, int cap_pairs, int nbands,
-    unsigned epoch) {
-  __shared__ unsigned long long ring_s[(AGP_ROWS - 1) * AGP_RING * 64];
-  __shared__ unsigned prog_s[AGP_ROWS];
+    unsigned long long* __restrict__ hand, unsigned* __restrict__ hand_min, unsigned* __restrict__ sync, int n,
+    int cap_pairs, int nbands, unsigned epoch) {
+  // ring k: written by wave k, read by wave k + 1; wave 15 has two scratch slots behind the rings
+  __shared__ unsigned long long ring_s[((AGP_WAVES - 1) * AGP_RING + 2) * 64];
+  __shared__ unsigned minring_s[(AGP_WAVES - 1) * AGP_RING * 4];
+  __shared__ unsigned prog_s[AGP_WAVES];
   __shared__ unsigned ticket_s;
   // (LDS-qualified pointers: through a generic pointer a volatile access stays a flat one)
   agp_lds_u64* const ring = (agp_lds_u64*)ring_s;
+  agp_lds_u32* const minring = (agp_lds_u32*)minring_s;
   agp_lds_u32* const prog = (agp_lds_u32*)prog_s;
-  const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (threadIdx.x == 0) ticket_s = atomicAdd(&sync[0], 1u);
-  if (threadIdx.x < AGP_ROWS) prog_s[threadIdx.x] = 0;
+  if (threadIdx.x < AGP_WAVES) prog_s[threadIdx.x] = 0;
   __syncthreads();
   const int t = __builtin_amdgcn_readfirstlane((int)ticket_s);
   const int band = t / (2 * n), rem = t - band * 2 * n;
   const int pair = rem >> 1;
   const bool down = (rem & 1) == 0;
   const int W1 = P.width1, H = P.H, D = P.D;
-  const int r = band * AGP_ROWS + w;   // row in the order of the pass
-  if (band >= nbands || r >= H) return;
-  const int y = down ? r : H - 1 - r;
-  const int in_kind = r == 0 ? AGP_IN_ZERO : (w == 0 ? AGP_IN_GLOBAL : AGP_IN_LDS);
-  const int out_kind = r == H - 1 ? AGP_OUT_NONE : (w == AGP_ROWS - 1 ? AGP_OUT_GLOBAL : AGP_OUT_LDS);
-  // hand-over entries: [pass][pair][boundary][step][lane]
-  const size_t hrow = (size_t)W1 * 64;
-  const size_t hpp = (size_t)(nbands - 1) * hrow;
+  if (band >= nbands) return;
+  const unsigned etag = ((epoch & 1u) << 15) | ((epoch & 2u) << 30);
+  // hand-over words: [pass][pair][boundary][step] x 64 lanes (entries) / x 4 (minima)
+  const size_t hpp = (size_t)max(nbands - 1, 1) * W1;
   const size_t hbase = ((size_t)(down ? 0 : 1) * cap_pairs + pair) * hpp;
-  const size_t rowbase = (((size_t)pair * H + y) * W1) * D + min(lane, D - 1);
+  const size_t hin = hbase + (size_t)max(band - 1, 0) * W1, hout = hbase + (size_t)min(band, max(nbands - 2, 0)) * W1;
+  if (w == 0) {
+    if (band > 0)
+      agp_loader(reinterpret_cast<const char*>(hand + hin * 64), reinterpret_cast<const char*>(hand_min + hin * 4), ring,
+                 minring, prog, prog + 1, sync + 1, W1, etag);
+    return;
+  }
+  const int r = band * AGP_ROWS + (w - 1);   // row in the order of the pass
+  if (r >= H) return;
+  const int y = down ? r : H - 1 - r;
+  const int in_kind = r == 0 ? AGP_IN_ZERO : AGP_IN_LDS;
+  const int out_kind = r == H - 1 ? AGP_OUT_NONE : (w == AGP_WAVES - 1 ? AGP_OUT_GLOBAL : AGP_OUT_LDS);
+  const size_t rowbase = (((size_t)pair * H + y) * W1) * D;
   AgpRow R;
-  R.cp = reinterpret_cast<const unsigned*>(Cv + (rowbase - min(lane, D - 1))) + (min(lane, D - 1) >> 1);
-  R.csh = (min(lane, D - 1) & 1) * 16;
-  R.sp = (down ? sumA : sumB) + rowbase;
-  R.hin = hand + hbase + (size_t)max(band - 1, 0) * hrow + lane;
-  R.hout = hand + hbase + (size_t)min(band, max(nbands - 2, 0)) * hrow + lane;
-  R.ring_in = ring + (size_t)max(w - 1, 0) * AGP_RING * 64 + lane;
-  R.ring_out = ring + (size_t)min(w, AGP_ROWS - 2) * AGP_RING * 64 + lane;
-  R.prog_in = prog + max(w - 1, 0);
+  R.cp = reinterpret_cast<const char*>(Cv + rowbase);
+  R.sp = reinterpret_cast<char*>((down ? sumA : sumB) + rowbase);
+  R.hout = reinterpret_cast<char*>(hand + hout * 64);
+  R.hmin_out = reinterpret_cast<char*>(hand_min + hout * 4);
+  R.ring_in = ring + (size_t)(w - 1) * AGP_RING * 64;
+  R.minring_in = minring + (size_t)(w - 1) * AGP_RING * 4;
+  R.ring_out = ring + (size_t)w * AGP_RING * 64;           // wave 15: the two scratch slots behind the rings
+  R.minring_out = minring + (size_t)min(w, AGP_WAVES - 2) * AGP_RING * 4;
+  R.omask = w == AGP_WAVES - 1 ? 1 : AGP_RING - 1;
+  R.prog_in = prog + (w - 1);
   R.prog_me = prog + w;
-  R.prog_out = prog + min(w + 1, AGP_ROWS - 1);
+  R.prog_out = prog + min(w + 1, AGP_WAVES - 1);
   R.err = sync + 1;
   R.W1 = W1;
   R.D = D;
   R.P1 = P.P1;
   R.P2 = P.P2;
-  R.etag = ((epoch & 1u) << 15) | ((epoch & 2u) << 30);
+  R.etag = etag;
   R.down = down;
-  R.act = lane < D;
   switch (in_kind * 3 + out_kind) {   // wave-uniform
     case AGP_IN_ZERO * 3 + AGP_OUT_NONE: agp_row<AGP_IN_ZERO, AGP_OUT_NONE>(R); break;
     case AGP_IN_ZERO * 3 + AGP_OUT_LDS: agp_row<AGP_IN_ZERO, AGP_OUT_LDS>(R); break;
     case AGP_IN_ZERO * 3 + AGP_OUT_GLOBAL: agp_row<AGP_IN_ZERO, AGP_OUT_GLOBAL>(R); break;
     case AGP_IN_LDS * 3 + AGP_OUT_NONE: agp_row<AGP_IN_LDS, AGP_OUT_NONE>(R); break;
     case AGP_IN_LDS * 3 + AGP_OUT_LDS: agp_row<AGP_IN_LDS, AGP_OUT_LDS>(R); break;
-    case AGP_IN_LDS * 3 + AGP_OUT_GLOBAL: agp_row<AGP_IN_LDS, AGP_OUT_GLOBAL>(R); break;
-    case AGP_IN_GLOBAL * 3 + AGP_OUT_NONE: agp_row<AGP_IN_GLOBAL, AGP_OUT_NONE>(R); break;
-    case AGP_IN_GLOBAL * 3 + AGP_OUT_LDS: agp_row<AGP_IN_GLOBAL, AGP_OUT_LDS>(R); break;
-    default: agp_row<AGP_IN_GLOBAL, AGP_OUT_GLOBAL>(R); break;
+    default: agp_row<AGP_IN_LDS, AGP_OUT_GLOBAL>(R); break;
   }
 }
 
@@ -1113,7 +1285,8 @@ size_t dense_volume_elems(const DenseParams& P) { return (size_t)P.H * P.width1 
 size_t dense_handoff_bytes(const DenseParams& P, int pairs) {
   if (!P.full_dp || P.bm || pairs < AGP_MIN_PAIRS || P.width1 <= 0) return 0;
   const size_t nbands = (size_t)(P.H + AGP_ROWS - 1) / AGP_ROWS;
-  return std::max<size_t>(1, nbands - 1) * 2 * pairs * P.width1 * 64 * sizeof(unsigned long long);
+  // per step of a block boundary: the entry (64 lanes x 8 bytes) and the three minima (4 words)
+  return std::max<size_t>(1, nbands - 1) * 2 * pairs * P.width1 * (64 * sizeof(unsigned long long) + 4 * sizeof(unsigned));
 }
 
 void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st) {
@@ -1153,10 +1326,19 @@ void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t
       B.hand_epoch = 0;
     }
     B.hand_epoch = B.hand_epoch % 3 + 1;
-    (void)hipMemsetAsync(B.agsync, 0, 2 * sizeof(unsigned), st);
-    dense_aggregate_pass_kernel<<<dim3(nbands * 2 * n), dim3(AGP_ROWS * 64), 0, st>>>(
-        P, Cv, sA, sB, B.hand, B.agsync, n, B.cap_pairs, nbands, B.hand_epoch);
+    (void)hipMemsetAsync(B.agsync, 0, AGP_SYNC_WORDS * sizeof(unsigned), st);
+#ifdef KVFE_AGP_PROF
+    (void)hipMemsetAsync(B.agsync + 2 + 7, 0xff, sizeof(unsigned), st);   // the minimum of the start times
+#endif
+    // (the minima lie behind the entries of the context's pair capacity)
+    unsigned* hand_min = reinterpret_cast<unsigned*>(
+        B.hand + (size_t)std::max(1, nbands - 1) * 2 * B.cap_pairs * P.width1 * 64);
+    dense_aggregate_pass_kernel<<<dim3(nbands * 2 * n), dim3(AGP_WAVES * 64), 0, st>>>(
+        P, Cv, sA, sB, B.hand, hand_min, B.agsync, n, B.cap_pairs, nbands, B.hand_epoch);
     dense_select_kernel<<<dim3(P.H, n), blk, 0, st>>>(P, sA, sB, B.disp[0]);
+#ifdef KVFE_AGP_PROF
+    agp_prof_copy_kernel<<<1, 64, 0, st>>>(B.agsync, reinterpret_cast<unsigned*>(B.vol[2]));
+#endif
   } else if (n <= 3 && P.full_dp) {
     // few pairs: every direction of a pair in one launch, packed atomic adds into two zeroed volumes
     const size_t bytes = sizeof(short) * dense_volume_elems(P) * n;

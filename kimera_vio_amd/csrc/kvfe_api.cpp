@@ -2965,7 +2965,7 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   TRY(al((void**)&c->dense_dispf, sizeof(float) * px));
   TRY(al((void**)&c->dense_xyz, sizeof(float) * 3 * px));
   TRY(al((void**)&c->dense_minkey, 16));
-  TRY(al((void**)&b.agsync, 2 * sizeof(unsigned)));
+  TRY(al((void**)&b.agsync, AGP_SYNC_WORDS * sizeof(unsigned)));
   if (hand_need) {
     TRY(al((void**)&b.hand, hand_need));
     b.hand_bytes = hand_need;

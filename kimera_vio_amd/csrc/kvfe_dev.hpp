@@ -98,6 +98,7 @@ struct DenseBuffers {
   int hand_key[4] = {};                        // (pairs, width1, H, D) of the last launch: a change zeroes the buffer
 };
 size_t dense_handoff_bytes(const DenseParams& P, int pairs);
+constexpr int AGP_SYNC_WORDS = 2 + 16;   // DenseBuffers::agsync: ticket, error, counters of the profiling build
 struct ReprojectQ {
   double q[16];
 };

@@ -32,12 +32,24 @@ def main():
         ms, cnt = ctx.dense_profile_read()
         vals.append(ms / cnt)
     same = all(np.array_equal(a, b) for a, b in zip(first, disp))
+    prof = None
+    if "agprof" in os.environ.get("KVFE_LIB", ""):
+        prof = ctx.dense_debug_volume(2, (32,)).view(np.uint32).astype(np.int64)
     ctx.close()
     import zlib
     crc = zlib.crc32(b"".join(np.ascontiguousarray(d).tobytes() for d in disp))
     print("dense %dx%d n=%d %s: %.4f ms per pair (median of 7; min %.4f max %.4f)  repeat-identical %s  crc %08x" % (
         W, H, n, "eight sweeps" if os.environ.get("KVFE_X_DENSE8") else "two passes", statistics.median(vals),
         min(vals), max(vals), same, crc))
+    if prof is not None:
+        rows, dur, dmax, tin, tout, sin, sout, t0, t1, lturns, lsteps, zdur, zrows = prof[:13]
+        steps = rows * (W - 65)
+        print("   last launch: %d rows, row duration mean %.1f us max %.1f us, kernel span %.1f us; per step %.0f ns; "
+              "steps that waited for the row before %.1f %% (%.2f turns per step), for the row after %.1f %% (%.2f); "
+              "first rows %.1f us; loader: steps re-polled %d, turns %d" % (
+                  rows, dur / max(rows, 1) / 100.0, dmax / 100.0, ((t1 - t0) & 0xffffffff) / 100.0,
+                  dur * 10.0 / max(steps, 1), 100.0 * sin / max(steps, 1), tin / max(steps, 1),
+                  100.0 * sout / max(steps, 1), tout / max(steps, 1), zdur / max(zrows, 1) / 100.0, lsteps, lturns))
 
 
 if __name__ == "__main__":
