@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace kvfe {
 
@@ -455,8 +456,9 @@ __global__ __launch_bounds__(256) void dense_aggregate_all_kernel(DenseParams P,
 //     registers of the prefetch are the loader's (a row that prefetches for itself needs 84 and halves the occupancy);
 //   * blocks take their (band, pair, pass) from a ticket counter, band-major: a block only ever waits for a block with a
 //     smaller ticket, which is running -- no co-residency assumption, no deadlock whatever the dispatch order;
-//   * every wait is bounded (AGP_TIMEOUT_TICKS); a wait that runs out sets the launch's error word, which every other
-//     wait looks at, and the call returns an error instead of hanging the device.
+//   * every wait is bounded (a budget of AGP_WAIT_TURNS polls per wave); a wave whose budget is used up stops waiting,
+//     finishes with what it reads and sets the launch's error word: the call returns an error instead of hanging the
+//     device.
 // Same integers as dense_aggregate_path: 16383 stands for SHRT_MAX at d = -1, d = D and in the lanes past D (every cost
 // is <= 16383 -- dense_params() refuses parameters that could exceed it -- so 16383 + P1 is never the minimum, which is
 // all SHRT_MAX does upstream), zero predecessors outside the volume.
@@ -465,8 +467,7 @@ constexpr int AGP_WAVES = 16;   // + the loader wave (wave 0)
 constexpr int AGP_LPF = 4;      // steps the loader requests ahead
 constexpr int AGP_MIN_PAIRS = 4;   // fewer pairs: too few rows in flight, the single-launch atomic sweeps are faster
 constexpr int AGP_RING = 8;
-constexpr int AGP_PF = 4;
-constexpr long long AGP_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wall clock
+constexpr int AGP_PF = 6;
 constexpr unsigned AGP_INF2 = 0x3FFF3FFFu;
 constexpr unsigned AGP_TAGMASK = 0x80008000u;
 
@@ -482,50 +483,46 @@ __device__ __forceinline__ unsigned agp_pk_add(unsigned a, unsigned b) {
 __device__ __forceinline__ unsigned agp_pk_sub(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_bit_cast(agp_u2, a) - __builtin_bit_cast(agp_u2, b));
 }
-// minimum over the 16 lanes of a DPP row of a value whose two halves are equal (so the 32-bit order is the 16-bit one)
-__device__ __forceinline__ unsigned agp_row_min(unsigned x) {
-  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false));   // row_ror:8
-  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xf, 0xf, false));   // row_ror:4
-  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x122, 0xf, 0xf, false));   // row_ror:2
-  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xf, 0xf, false));   // row_ror:1
-  return x;
-}
 
-struct AgpWait {
-  unsigned* err;      // the launch's error word
-  long long t0 = 0;   // start of the wait in progress (0: none)
-  bool dead = false;
-  unsigned spins = 0;
-#ifdef KVFE_AGP_PROF
-  unsigned turns = 0;   // turns of wait loops since the counter was last read
-#endif
-  // one more turn of a wait loop; false = give up
-  __device__ __forceinline__ bool again() {
-    if (dead) return false;
-#ifdef KVFE_AGP_PROF
-    turns++;
-#endif
-    __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 127u) == 0) {
-      const long long now = wall_clock64();
-      if (t0 == 0) t0 = now;
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
-      if (now - t0 > AGP_TIMEOUT_TICKS) {
-        dead = true;
-        if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-      }
-    }
-    return !dead;
-  }
-};
+// A wait is a loop over "read the counter, sleep"; every wave has a budget of turns for all its waits together
+// (AGP_WAIT_TURNS of >= 64 cycles each: some tenths of a second, far beyond a launch); when it is used up the wave stops
+// waiting, finishes its row with whatever it reads, and sets the launch's error word.
+constexpr unsigned AGP_WAIT_TURNS = 1u << 22;
 
 typedef __attribute__((address_space(3))) volatile unsigned long long agp_lds_u64;
 typedef __attribute__((address_space(3))) volatile unsigned agp_lds_u32;
 enum { AGP_IN_ZERO = 0, AGP_IN_LDS = 1, AGP_OUT_NONE = 0, AGP_OUT_LDS = 1, AGP_OUT_GLOBAL = 2 };
 
+// wait until the step counter *p has reached `need`; returns the counter (wave-uniform)
+__device__ __forceinline__ unsigned agp_wait(agp_lds_u32* p, unsigned need, unsigned& budget) {
+  unsigned seen = __builtin_amdgcn_readfirstlane(*p);
+  while (seen < need && budget != 0) {
+    __builtin_amdgcn_s_sleep(1);
+    budget--;
+    seen = __builtin_amdgcn_readfirstlane(*p);
+  }
+  return seen;
+}
+
+// minimum over the 16 lanes of a DPP row of a value whose two halves are equal (so the 32-bit order is the 16-bit one);
+// (written out: the compiler keeps v_mov_b32_dpp + v_min_u32 apart, three instructions per rotation instead of one; a DPP
+// operand written by the instruction before needs two wait states)
+__device__ __forceinline__ unsigned agp_row_min(unsigned x) {
+  asm("s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(x));
+  return x;
+}
+
 struct AgpRow {
   // wave-uniform bases (scalar registers); the lane's part of an address is a 32-bit offset computed in agp_row
-  const char* cp;             // C of the row, column 0
+  const char* cp;             // C of the row, column 0 (the volume has a guard band: requests run AGP_PF columns past a row)
   char* sp;                   // the pass's partial sum of the row
   char* hout;                 // entries for the block after: [step][64 lanes] x 8 bytes
   char* hmin_out;             // their minima: [step][4] words
@@ -535,7 +532,6 @@ struct AgpRow {
   agp_lds_u32* minring_out;
   agp_lds_u32 *prog_in, *prog_me, *prog_out;
   unsigned* err;
-  int omask;                  // slots of ring_out - 1
   int W1, D, P1, P2;
   unsigned etag;
   bool down;
@@ -545,91 +541,122 @@ struct AgpRow {
 // every memory operation of the loop is unconditional and the compiler can count the loads in flight)
 template <int IN, int OUT>
 __device__ __forceinline__ void agp_row(const AgpRow& R) {
+  constexpr int OM = OUT == AGP_OUT_LDS ? AGP_RING - 1 : 1;   // slots of its own ring the wave uses, - 1
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, g = lane & 15;
   const int W1 = R.W1, D = R.D, last = W1 - 1;
   const bool down = R.down;
-  const unsigned cbytes = (unsigned)D * 2u;                               // bytes of C / S per column
+  const int cstep = down ? D * 2 : -D * 2;                                // bytes of C / S from a step's column to the next
   const unsigned coff = 8u * (unsigned)min(g, D / 4 - 1);                 // this lane's four disparities in a column
   const unsigned hoff = 8u * (unsigned)lane, moff = 4u * (unsigned)q;    // this lane's word of an entry / of the minima
-  auto xof = [&](int i) { return down ? i : last - i; };
-  auto c_at = [&](int i) { return *reinterpret_cast<const unsigned long long*>(R.cp + (size_t)xof(i) * cbytes + coff); };
   const bool actl = 4 * g < D;
   const bool all_active = D == 64;
   const unsigned zero2 = actl ? 0u : AGP_INF2;
   const unsigned P1P1 = (unsigned)R.P1 * 0x10001u, P2P2 = (unsigned)R.P2 * 0x10001u;
   const unsigned etag = R.etag;
   const bool row0 = q == 0;
-  AgpWait wt;
-  wt.err = R.err;
+  const bool sum_lane = row0 && actl;
+  const bool min_lane = g == 0;
+  const int qm2 = q - 2;
+  unsigned budget = AGP_WAIT_TURNS;
   unsigned seen_in = 0, seen_out = 0;
 #ifdef KVFE_AGP_PROF
   const long long prof_t0 = wall_clock64();
   unsigned prof_in_turns = 0, prof_out_turns = 0, prof_in_steps = 0, prof_out_steps = 0;
 #endif
+  // uniform running pointers: the column of the step, of the step whose C is requested, of the step whose sum is stored
+  const char* cnext = R.cp + (long)(down ? 0 : last) * (D * 2);
+  char* sprev = R.sp + (long)(down ? 0 : last) * (D * 2);
+  char* hptr = R.hout;
+  char* hmptr = R.hmin_out;
 
-  // prefetch: C of the next AGP_PF steps
-  unsigned long long cbuf[AGP_PF];   // (one 64-bit value each: as two words they are copied at the loop's back edge)
+  // requests: C of the next AGP_PF steps (one 64-bit value each: as two words they are copied at the loop's back edge)
+  unsigned long long cbuf[AGP_PF];
 #pragma unroll
-  for (int u = 0; u < AGP_PF; u++) cbuf[u] = c_at(min(u, last));
+  for (int u = 0; u < AGP_PF; u++) {
+    cbuf[u] = *reinterpret_cast<const unsigned long long*>(cnext + coff);
+    cnext += cstep;
+  }
   unsigned pA = zero2, pB = zero2, pM = 0;   // this lane's result of the step before (row 0: the horizontal path's input)
+  // the neighbour lanes' values; lanes 0 / 15 of a row keep 16383 for good (DPP leaves lanes without a source alone)
+  unsigned nbp = AGP_INF2, nbn = AGP_INF2;
 
-  // the sum of the four paths of step j, from the entry this wave wrote at step j (hA, hB: row 0's own part)
-  auto store_sum = [&](int j, unsigned hA, unsigned hB) {
-    if (row0) {
-      const int so = (j & R.omask) * 64 + g;
-      const unsigned long long r1 = R.ring_out[so + 16], r2 = R.ring_out[so + 32], r3 = R.ring_out[so + 48];
-      uint2 sum;
-      sum.x = agp_pk_add(agp_pk_add(hA, (unsigned)r1), agp_pk_add((unsigned)r2, (unsigned)r3));
-      sum.y = agp_pk_add(agp_pk_add(hB, (unsigned)(r1 >> 32)), agp_pk_add((unsigned)(r2 >> 32), (unsigned)(r3 >> 32)));
-      if (actl) *reinterpret_cast<uint2*>(R.sp + (size_t)xof(j) * cbytes + coff) = sum;
-    }
+  // the sum of the four paths of step j, from the entry this wave wrote at step j: every lane reads rows 1 - 3 of the
+  // entry (no lane mask around the LDS reads, so that they are requested together with the step's other reads and
+  // waited for once), row 0 adds its own part (hA, hB) and stores
+  auto sum_read = [&](int j, unsigned long long& r1, unsigned long long& r2, unsigned long long& r3) {
+    const int so = (j & OM) * 64 + g;
+    r1 = R.ring_out[so + 16];
+    r2 = R.ring_out[so + 32];
+    r3 = R.ring_out[so + 48];
+  };
+  auto sum_store = [&](unsigned hA, unsigned hB, unsigned long long r1, unsigned long long r2, unsigned long long r3) {
+    uint2 sum;
+    sum.x = agp_pk_add(agp_pk_add(hA, (unsigned)r1), agp_pk_add((unsigned)r2, (unsigned)r3));
+    sum.y = agp_pk_add(agp_pk_add(hB, (unsigned)(r1 >> 32)), agp_pk_add((unsigned)(r2 >> 32), (unsigned)(r3 >> 32)));
+    if (sum_lane) *reinterpret_cast<uint2*>(sprev + coff) = sum;
+    sprev += cstep;
   };
 
-  // one step; u = i mod AGP_PF selects the prefetch registers (compile-time in the unrolled loops below)
-  auto step = [&](const int u, const int i) {
+  // one step; u = i mod AGP_PF selects the request register (compile-time in the unrolled groups below); EDGE: the step
+  // may be the first or the last of the row (entries -1 and W1 lie outside the volume)
+  auto step = [&](auto edge_tag, const int u, const int i) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
     unsigned long long craw = cbuf[u];
-    const int e = i - 2 + q;   // the entry of the row before that this lane's path continues
     unsigned inA = zero2, inB = zero2, inM = 0;
+    unsigned long long r1 = 0, r2 = 0, r3 = 0;
     if (IN == AGP_IN_LDS) {
-      const unsigned need = (unsigned)min(i + 2, W1);
-      while (seen_in < need) {
-        seen_in = __builtin_amdgcn_readfirstlane(*R.prog_in);
-        if (seen_in >= need) break;
-        if (!wt.again()) break;
-      }
-      wt.t0 = 0;
-#ifdef KVFE_AGP_PROF
-      prof_in_turns += wt.turns;
-      prof_in_steps += wt.turns ? 1 : 0;
-      wt.turns = 0;
-#endif
-      const int slot = e & (AGP_RING - 1);
-      const unsigned long long v = R.ring_in[slot * 64 + lane];
+      // the row before's step counter, the entry and the minima requested together: LDS serves a wave's requests in
+      // order, so an entry read behind a counter that is high enough is valid -- one wait instead of two
+      const unsigned need = EDGE ? (unsigned)min(i + 2, W1) : (unsigned)(i + 2);
+      const int slot = (i + qm2) & (AGP_RING - 1);   // entry i - 2 + q: the one this lane's path continues
+      const unsigned pr = *R.prog_in;
+      unsigned long long v = R.ring_in[slot * 64 + lane];
       inM = R.minring_in[slot * 4 + q];
+      if (!EDGE || i > 0) sum_read(i - 1, r1, r2, r3);
+      if (seen_in < need) {
+        seen_in = __builtin_amdgcn_readfirstlane(pr);
+        if (seen_in < need) {
+#ifdef KVFE_AGP_PROF
+          const unsigned b0 = budget;
+#endif
+          seen_in = agp_wait(R.prog_in, need, budget);
+          v = R.ring_in[slot * 64 + lane];
+          inM = R.minring_in[slot * 4 + q];
+#ifdef KVFE_AGP_PROF
+          prof_in_turns += b0 - budget;
+          prof_in_steps += b0 != budget ? 1 : 0;
+#endif
+        }
+      }
       inA = (unsigned)v;
       inB = (unsigned)(v >> 32);
+      if (EDGE && (i == 0 || i == last)) {   // wave-uniform
+        const int e = i + qm2;
+        const bool inr = e >= 0 && e <= last;
+        inA = inr ? inA : zero2;
+        inB = inr ? inB : zero2;
+        inM = inr ? inM : 0u;
+      }
+    } else if (!EDGE || i > 0) {
+      sum_read(i - 1, r1, r2, r3);
     }
-    if (IN != AGP_IN_ZERO && (i == 0 || i == last)) {   // wave-uniform: entries -1 and W1 lie outside the volume
-      const bool inr = e >= 0 && e <= last;
-      inA = inr ? inA : zero2;
-      inB = inr ? inB : zero2;
-      inM = inr ? inM : 0u;
-    }
-    // the sum of the step before (its entry has been in LDS for a step)
-    if (i > 0) store_sum(i - 1, pA, pB);
-    inA = row0 ? pA : inA;
-    inB = row0 ? pB : inB;
-    inM = row0 ? pM : inM;
-    asm volatile("" : "+v"(craw));   // first use of the prefetched C: here, not earlier
+    asm volatile("" : "+v"(craw));   // first use of the requested C: here, not earlier
     const unsigned cA = (unsigned)craw, cB = (unsigned)(craw >> 32);
     // (the next request after the use: issued before it, old and new value are alive together and the registers
     // rotate through copies at the loop's back edge -- behind a wait for every load)
-    cbuf[u] = c_at(min(i + AGP_PF, last));
+    cbuf[u] = *reinterpret_cast<const unsigned long long*>(cnext + coff);
+    cnext += cstep;
+    // the sum of the step before (its entry has been in LDS for a step).  Behind the wait for C: the compiler cannot count
+    // a store under a lane mask, so it keeps only AGP_PF - 1 operations in flight at that wait, stores included
+    if (!EDGE || i > 0) sum_store(pA, pB, r1, r2, r3);
+    inA = row0 ? pA : inA;
+    inB = row0 ? pB : inB;
+    inM = row0 ? pM : inM;
     // L(d) = C(d) + min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1, min Lp + P2) - (min Lp + P2), four disparities at a time
     const unsigned delta = agp_pk_add(inM, P2P2);
-    const unsigned nbp = (unsigned)__builtin_amdgcn_update_dpp((int)AGP_INF2, (int)inB, 0x111, 0xf, 0xf, false);   // row_shr:1
-    const unsigned nbn = (unsigned)__builtin_amdgcn_update_dpp((int)AGP_INF2, (int)inA, 0x101, 0xf, 0xf, false);   // row_shl:1
+    nbp = (unsigned)__builtin_amdgcn_update_dpp((int)nbp, (int)inB, 0x111, 0xf, 0xf, false);   // row_shr:1
+    nbn = (unsigned)__builtin_amdgcn_update_dpp((int)nbn, (int)inA, 0x101, 0xf, 0xf, false);   // row_shl:1
     const unsigned lmA = __builtin_amdgcn_alignbit(inA, nbp, 16);   // (L[4g-1], L[4g])
     const unsigned lmB = __builtin_amdgcn_alignbit(inB, inA, 16);   // (L[4g+1], L[4g+2])
     const unsigned lqB = __builtin_amdgcn_alignbit(nbn, inB, 16);   // (L[4g+3], L[4g+4])
@@ -647,46 +674,61 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     x = agp_pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
     const unsigned nM = agp_row_min(x);
     // publish this row's entry i (in LDS always: the sum is formed from it)
-    if (OUT == AGP_OUT_LDS && i >= AGP_RING - 1) {   // the slot's previous entry (i - RING) is read last at step i - RING + 1
+    if (OUT == AGP_OUT_LDS && (EDGE ? i >= AGP_RING - 1 : true)) {
+      // the slot's previous entry (i - RING) is read last at the reader's step i - RING + 1
       const unsigned need = (unsigned)(i - AGP_RING + 2);
-      while (seen_out < need) {
-        seen_out = __builtin_amdgcn_readfirstlane(*R.prog_out);
-        if (seen_out >= need) break;
-        if (!wt.again()) break;
-      }
-      wt.t0 = 0;
+      if ((EDGE || i >= AGP_RING - 1) && seen_out < need && (int)need > 0) {
 #ifdef KVFE_AGP_PROF
-      prof_out_turns += wt.turns;
-      prof_out_steps += wt.turns ? 1 : 0;
-      wt.turns = 0;
+        const unsigned b0 = budget;
 #endif
+        seen_out = agp_wait(R.prog_out, need, budget);
+#ifdef KVFE_AGP_PROF
+        prof_out_turns += b0 - budget;
+        prof_out_steps += b0 != budget ? 1 : 0;
+#endif
+      }
     }
     const unsigned long long o = (unsigned long long)nA | ((unsigned long long)nB << 32);
-    R.ring_out[(i & R.omask) * 64 + lane] = o;
-    if (OUT == AGP_OUT_LDS && g == 0) R.minring_out[(i & R.omask) * 4 + q] = nM;
+    R.ring_out[(i & OM) * 64 + lane] = o;
+    if (OUT == AGP_OUT_LDS && min_lane) R.minring_out[(i & OM) * 4 + q] = nM;
     if (OUT == AGP_OUT_GLOBAL) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(R.hout + (size_t)i * 512 + hoff), o | etag,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned*>(R.hmin_out + (size_t)i * 16 + moff), nM | etag, __ATOMIC_RELAXED,
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(hptr + hoff), o | etag, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (min_lane)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(hmptr + moff), nM | etag, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+      hptr += 512;
+      hmptr += 16;
     }
     if (lane == 0) *R.prog_me = (unsigned)i + 1u;
     pA = nA;
     pB = nB;
     pM = nM;
   };
-  // groups of AGP_PF steps without a condition in between (a conditional update of the prefetch registers costs copies
-  // at the top of the next step, and a copy is a use: the wait for the load moves up to it), then the remainder
-  int i0 = 0;
-  for (; i0 + AGP_PF <= W1; i0 += AGP_PF) {
+  // groups of AGP_PF steps without a condition in between (a conditional update of the request registers costs copies
+  // at the top of the next step, and a copy is a use: the wait for the load moves up to it).  The first group and the
+  // last one or two carry the tests for the row's ends; the groups in between do not.
+  auto edge_group = [&](int i0) {
 #pragma unroll
-    for (int u = 0; u < AGP_PF; u++) step(u, i0 + u);
+    for (int u = 0; u < AGP_PF; u++)
+      if (i0 + u <= last) step(std::true_type{}, u, i0 + u);
+  };
+  // (the first group without the test for the row's end -- the launch needs W1 > AGP_PF: with conditional requests in
+  // front of the loop the compiler no longer knows how many are in flight at its top and waits for all of them)
+  int i0 = AGP_PF;
+#pragma unroll
+  for (int u = 0; u < AGP_PF; u++) step(std::true_type{}, u, u);
+  for (; i0 + AGP_PF <= last; i0 += AGP_PF) {   // every step of the group has 0 < i < last
+#pragma unroll
+    for (int u = 0; u < AGP_PF; u++) step(std::false_type{}, u, i0 + u);
   }
-#pragma unroll
-  for (int u = 0; u < AGP_PF; u++)
-    if (i0 + u <= last) step(u, i0 + u);
-  store_sum(last, pA, pB);
+  for (; i0 <= last; i0 += AGP_PF) edge_group(i0);
+  {
+    unsigned long long r1, r2, r3;
+    sum_read(last, r1, r2, r3);
+    sum_store(pA, pB, r1, r2, r3);
+  }
+  if (budget == 0 && lane == 0) atomicOr(R.err, 1u);
 #ifdef KVFE_AGP_PROF
   if (lane == 0) {
     const long long t1 = wall_clock64();
@@ -716,8 +758,7 @@ __device__ __forceinline__ void agp_loader(const char* hin, const char* hmin_in,
   const int lane = threadIdx.x & 63;
   const int last = W1 - 1;
   const unsigned hoff = 8u * (unsigned)lane, moff = 4u * (unsigned)(lane & 3);
-  AgpWait wt;
-  wt.err = err;
+  unsigned budget = AGP_WAIT_TURNS;
   unsigned seen_out = 0;
   auto h_at = [&](int e) {
     return __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<char*>(hin) + ((size_t)e * 512u + hoff)),
@@ -740,30 +781,28 @@ __device__ __forceinline__ void agp_loader(const char* hin, const char* hmin_in,
   auto step = [&](const int u, const int j) {
     unsigned long long gl = gL[u];
     unsigned gm = gM[u];
+    asm volatile("" : "+v"(gl), "+v"(gm));   // first use of the requested words: here, not earlier
     gL[u] = h_at(min(j + AGP_LPF, last));
     gM[u] = hm_at(min(j + AGP_LPF, last));
-    asm volatile("" : "+v"(gl), "+v"(gm));   // first use of the requested words: here, not earlier
-    // word 0 of the minima is not written (row 0 of a wave is the horizontal path)
+    // word 0 of the minima is not read by anyone (row 0 of a wave is the horizontal path)
+#ifdef KVFE_AGP_PROF
+    const unsigned b0 = budget;
+#endif
     while (__builtin_amdgcn_ballot_w64((((unsigned)gl & AGP_TAGMASK) != etag) ||
-                                       ((lane & 3) != 0 && (gm & AGP_TAGMASK) != etag)) != 0ull) {
-      if (!wt.again()) break;
+                                       ((lane & 3) != 0 && (gm & AGP_TAGMASK) != etag)) != 0ull &&
+           budget != 0) {
+      __builtin_amdgcn_s_sleep(1);
+      budget--;
       gl = h_at(j);
       gm = hm_at(j);
     }
-    wt.t0 = 0;
 #ifdef KVFE_AGP_PROF
-    prof_turns += wt.turns;
-    prof_steps += wt.turns ? 1 : 0;
-    wt.turns = 0;
+    prof_turns += b0 - budget;
+    prof_steps += b0 != budget ? 1 : 0;
 #endif
     if (j >= AGP_RING - 1) {   // as in agp_row: entry j - RING is read last at the reader's step j - RING + 1
       const unsigned need = (unsigned)(j - AGP_RING + 2);
-      while (seen_out < need) {
-        seen_out = __builtin_amdgcn_readfirstlane(*prog_out);
-        if (seen_out >= need) break;
-        if (!wt.again()) break;
-      }
-      wt.t0 = 0;
+      if (seen_out < need) seen_out = agp_wait(prog_out, need, budget);
     }
     const int slot = j & (AGP_RING - 1);
     ring_out[slot * 64 + lane] = gl & ~(unsigned long long)AGP_TAGMASK;
@@ -778,6 +817,7 @@ __device__ __forceinline__ void agp_loader(const char* hin, const char* hmin_in,
 #pragma unroll
   for (int u = 0; u < AGP_LPF; u++)
     if (j0 + u <= last) step(u, j0 + u);
+  if (budget == 0 && lane == 0) atomicOr(err, 1u);
 #ifdef KVFE_AGP_PROF
   if (lane == 0) {
     atomicAdd(err + 1 + 9, prof_turns);
@@ -843,7 +883,6 @@ __global__ __launch_bounds__(AGP_WAVES * 64) void dense_aggregate_pass_kernel(
   R.minring_in = minring + (size_t)(w - 1) * AGP_RING * 4;
   R.ring_out = ring + (size_t)w * AGP_RING * 64;           // wave 15: the two scratch slots behind the rings
   R.minring_out = minring + (size_t)min(w, AGP_WAVES - 2) * AGP_RING * 4;
-  R.omask = w == AGP_WAVES - 1 ? 1 : AGP_RING - 1;
   R.prog_in = prog + (w - 1);
   R.prog_me = prog + w;
   R.prog_out = prog + min(w + 1, AGP_WAVES - 1);
@@ -1283,7 +1322,7 @@ size_t dense_volume_elems(const DenseParams& P) { return (size_t)P.H * P.width1 
 
 // bytes of the two-pass aggregation's block-to-block entries (0: that path is not used for this call)
 size_t dense_handoff_bytes(const DenseParams& P, int pairs) {
-  if (!P.full_dp || P.bm || pairs < AGP_MIN_PAIRS || P.width1 <= 0) return 0;
+  if (!P.full_dp || P.bm || pairs < AGP_MIN_PAIRS || P.width1 <= AGP_PF) return 0;
   const size_t nbands = (size_t)(P.H + AGP_ROWS - 1) / AGP_ROWS;
   // per step of a block boundary: the entry (64 lanes x 8 bytes) and the three minima (4 words)
   return std::max<size_t>(1, nbands - 1) * 2 * pairs * P.width1 * (64 * sizeof(unsigned long long) + 4 * sizeof(unsigned));
@@ -1315,7 +1354,7 @@ void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t
   unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
   static const bool x_eight = getenv("KVFE_X_DENSE8") != nullptr;   // A/B while measuring
-  if (!x_eight && P.full_dp && n >= AGP_MIN_PAIRS && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
+  if (!x_eight && P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
     // computeDisparitySGBM's two passes, one launch: rows of a pass are waves that hand their path costs down
     const int nbands = (P.H + AGP_ROWS - 1) / AGP_ROWS;
     const int key[4] = {n, P.width1, P.H, P.D};

@@ -2957,7 +2957,12 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   TRY(al((void**)&b.left, px * pairs));
   TRY(al((void**)&b.right, px * pairs));
   TRY(al((void**)&b.rec, sizeof(uint2) * px * 2 * pairs));
-  for (int i = 0; i < 3; i++) TRY(al((void**)&b.vol[i], sizeof(short) * ve * pairs));
+  // (a guard band either side: the two-pass aggregation requests C a few columns past the ends of a row)
+  constexpr size_t kVolGuard = 1024;   // elements
+  for (int i = 0; i < 3; i++) {
+    TRY(al((void**)&b.vol[i], sizeof(short) * (ve * pairs + 2 * kVolGuard)));
+    b.vol[i] += kVolGuard;
+  }
   for (int i = 0; i < 2; i++) TRY(al((void**)&b.disp[i], sizeof(short) * px * pairs));
   TRY(al((void**)&b.label, sizeof(int) * px * pairs));
   TRY(al((void**)&b.count, sizeof(int) * px * pairs));
