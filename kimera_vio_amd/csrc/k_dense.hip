@@ -26,6 +26,7 @@
 #include "kvfe_dev.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -484,23 +485,42 @@ __device__ __forceinline__ unsigned agp_pk_sub(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_bit_cast(agp_u2, a) - __builtin_bit_cast(agp_u2, b));
 }
 
-// A wait is a loop over "read the counter, sleep"; every wave has a budget of turns for all its waits together
-// (AGP_WAIT_TURNS of >= 64 cycles each: some tenths of a second, far beyond a launch); when it is used up the wave stops
-// waiting, finishes its row with whatever it reads, and sets the launch's error word.
-constexpr unsigned AGP_WAIT_TURNS = 1u << 22;
+// A wait is a loop over "read the counter, sleep"; every wave has a budget for all its waits together (AGP_WAIT_TURNS
+// loops of up to 64 turns: seconds, far beyond a launch); when it is used up the wave stops waiting, finishes its row
+// with whatever it reads, and sets the launch's error word.
+constexpr unsigned AGP_WAIT_TURNS = 1u << 18;   // x 64 turns of >= 512 cycles
 
 typedef __attribute__((address_space(3))) volatile unsigned long long agp_lds_u64;
 typedef __attribute__((address_space(3))) volatile unsigned agp_lds_u32;
 enum { AGP_IN_ZERO = 0, AGP_IN_LDS = 1, AGP_OUT_NONE = 0, AGP_OUT_LDS = 1, AGP_OUT_GLOBAL = 2 };
 
-// wait until the step counter *p has reached `need`; returns the counter (wave-uniform)
-__device__ __forceinline__ unsigned agp_wait(agp_lds_u32* p, unsigned need, unsigned& budget) {
-  unsigned seen = __builtin_amdgcn_readfirstlane(*p);
-  while (seen < need && budget != 0) {
-    __builtin_amdgcn_s_sleep(1);
-    budget--;
+// wait until the step counter *p has reached `need`; returns the counter (wave-uniform).  Three loops of a few
+// instructions each, the sleep growing with the time already waited: a row that follows its neighbour step by step
+// waits a turn or two, but the rows of a pass start one after the other, and the ones that have not started yet would
+// otherwise spend the launch polling every 64 cycles on the SIMDs the running rows need (profiles/r5_analysis.md: 60 %
+// of the kernel's scalar instructions).
+template <int SLEEP>
+__device__ __forceinline__ unsigned agp_wait_loop(agp_lds_u32* p, unsigned need, unsigned seen, unsigned turns,
+                                                  unsigned& budget) {
+  while (seen < need && turns != 0) {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    turns--;
     seen = __builtin_amdgcn_readfirstlane(*p);
   }
+  budget -= budget != 0 ? 1u : 0u;   // (per loop, not per turn: the budget is a bound, not a clock)
+  return seen;
+}
+__device__ __forceinline__ unsigned agp_wait(agp_lds_u32* p, unsigned need, unsigned& budget) {
+#ifdef KVFE_AGP_FREERUN   // measurement only (wrong results): nobody waits, every row runs at its own speed
+  return need;
+#endif
+  unsigned seen = __builtin_amdgcn_readfirstlane(*p);
+  if (seen >= need || budget == 0) return seen;
+  seen = agp_wait_loop<1>(p, need, seen, 8, budget);
+  if (seen >= need) return seen;
+  seen = agp_wait_loop<3>(p, need, seen, 16, budget);
+  while (seen < need && budget > 3) seen = agp_wait_loop<8>(p, need, seen, 64, budget);
+  if (seen < need) budget = 0;
   return seen;
 }
 
@@ -539,7 +559,7 @@ struct AgpRow {
 
 // one row of one pass; IN / OUT: where the row before's entries come from and where this row's go (wave-uniform, so
 // every memory operation of the loop is unconditional and the compiler can count the loads in flight)
-template <int IN, int OUT>
+template <int IN, int OUT, bool FULL>
 __device__ __forceinline__ void agp_row(const AgpRow& R) {
   constexpr int OM = OUT == AGP_OUT_LDS ? AGP_RING - 1 : 1;   // slots of its own ring the wave uses, - 1
   const int lane = threadIdx.x & 63;
@@ -550,7 +570,7 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
   const unsigned coff = 8u * (unsigned)min(g, D / 4 - 1);                 // this lane's four disparities in a column
   const unsigned hoff = 8u * (unsigned)lane, moff = 4u * (unsigned)q;    // this lane's word of an entry / of the minima
   const bool actl = 4 * g < D;
-  const bool all_active = D == 64;
+  constexpr bool all_active = FULL;   // D == 64: no lane of a row lies past the last disparity
   const unsigned zero2 = actl ? 0u : AGP_INF2;
   const unsigned P1P1 = (unsigned)R.P1 * 0x10001u, P2P2 = (unsigned)R.P2 * 0x10001u;
   const unsigned etag = R.etag;
@@ -560,13 +580,19 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
   const int qm2 = q - 2;
   unsigned budget = AGP_WAIT_TURNS;
   unsigned seen_in = 0, seen_out = 0;
+  const unsigned progaddr = (unsigned)(size_t)R.prog_me;   // LDS byte address of this wave's step counter
+  unsigned progv = 0;                                      // its value
 #ifdef KVFE_AGP_PROF
   const long long prof_t0 = wall_clock64();
   unsigned prof_in_turns = 0, prof_out_turns = 0, prof_in_steps = 0, prof_out_steps = 0;
 #endif
-  // uniform running pointers: the column of the step, of the step whose C is requested, of the step whose sum is stored
-  const char* cnext = R.cp + (long)(down ? 0 : last) * (D * 2);
-  char* sprev = R.sp + (long)(down ? 0 : last) * (D * 2);
+  // C and the sum through buffer descriptors of the row: lane offset in a register, column offset in a scalar that runs
+  // with the steps -- no vector instruction per address (a request a few columns past the row's end in the bottom-up
+  // pass has a negative = huge offset: out of range, returns 0, never used)
+  const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(R.cp), 0, 0x7fffffff, 0x00027000);
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(R.sp, 0, 0x7fffffff, 0x00027000);
+  int cnext = (down ? 0 : last) * (D * 2);   // byte offset of the column whose C is requested next
+  int sprev = cnext;                         // ... of the column whose sum is stored next
   char* hptr = R.hout;
   char* hmptr = R.hmin_out;
 
@@ -574,7 +600,7 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
   unsigned long long cbuf[AGP_PF];
 #pragma unroll
   for (int u = 0; u < AGP_PF; u++) {
-    cbuf[u] = *reinterpret_cast<const unsigned long long*>(cnext + coff);
+    cbuf[u] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(crsrc, coff, cnext, 0));
     cnext += cstep;
   }
   unsigned pA = zero2, pB = zero2, pM = 0;   // this lane's result of the step before (row 0: the horizontal path's input)
@@ -594,7 +620,8 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     uint2 sum;
     sum.x = agp_pk_add(agp_pk_add(hA, (unsigned)r1), agp_pk_add((unsigned)r2, (unsigned)r3));
     sum.y = agp_pk_add(agp_pk_add(hB, (unsigned)(r1 >> 32)), agp_pk_add((unsigned)(r2 >> 32), (unsigned)(r3 >> 32)));
-    if (sum_lane) *reinterpret_cast<uint2*>(sprev + coff) = sum;
+    typedef unsigned agp_v2u __attribute__((ext_vector_type(2)));
+    if (sum_lane) __builtin_amdgcn_raw_buffer_store_b64(agp_v2u{sum.x, sum.y}, srsrc, coff, sprev, 0);
     sprev += cstep;
   };
 
@@ -645,7 +672,7 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     const unsigned cA = (unsigned)craw, cB = (unsigned)(craw >> 32);
     // (the next request after the use: issued before it, old and new value are alive together and the registers
     // rotate through copies at the loop's back edge -- behind a wait for every load)
-    cbuf[u] = *reinterpret_cast<const unsigned long long*>(cnext + coff);
+    cbuf[u] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(crsrc, coff, cnext, 0));
     cnext += cstep;
     // the sum of the step before (its entry has been in LDS for a step).  Behind the wait for C: the compiler cannot count
     // a store under a lane mask, so it keeps only AGP_PF - 1 operations in flight at that wait, stores included
@@ -674,14 +701,15 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     x = agp_pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
     const unsigned nM = agp_row_min(x);
     // publish this row's entry i (in LDS always: the sum is formed from it)
-    if (OUT == AGP_OUT_LDS && (EDGE ? i >= AGP_RING - 1 : true)) {
-      // the slot's previous entry (i - RING) is read last at the reader's step i - RING + 1
-      const unsigned need = (unsigned)(i - AGP_RING + 2);
-      if ((EDGE || i >= AGP_RING - 1) && seen_out < need && (int)need > 0) {
+    if (OUT == AGP_OUT_LDS) {
+      // the slot's previous entry (i - RING) is read last at the reader's step i - RING + 1 (signed: nothing to wait for
+      // during the first RING - 2 steps)
+      const int need = i - AGP_RING + 2;
+      if ((int)seen_out < need) {
 #ifdef KVFE_AGP_PROF
         const unsigned b0 = budget;
 #endif
-        seen_out = agp_wait(R.prog_out, need, budget);
+        seen_out = agp_wait(R.prog_out, (unsigned)need, budget);
 #ifdef KVFE_AGP_PROF
         prof_out_turns += b0 - budget;
         prof_out_steps += b0 != budget ? 1 : 0;
@@ -690,7 +718,14 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     }
     const unsigned long long o = (unsigned long long)nA | ((unsigned long long)nB << 32);
     R.ring_out[(i & OM) * 64 + lane] = o;
-    if (OUT == AGP_OUT_LDS && min_lane) R.minring_out[(i & OM) * 4 + q] = nM;
+    if (OUT == AGP_OUT_LDS) {
+      // lane 0 of every row writes the row's minimum (the lane mask set and reset by hand: every lane is active here, and
+      // the compiler's version is a saved mask, a branch around the store and a restore)
+      const unsigned maddr = (unsigned)(size_t)(R.minring_out + (i & OM) * 4) + moff;
+      asm volatile("s_mov_b64 exec, %2\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(maddr), "v"(nM),
+                   "s"(0x0001000100010001ull)
+                   : "memory");
+    }
     if (OUT == AGP_OUT_GLOBAL) {
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(hptr + hoff), o | etag, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -700,7 +735,10 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
       hptr += 512;
       hmptr += 16;
     }
-    if (lane == 0) *R.prog_me = (unsigned)i + 1u;
+    progv += 1u;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(progaddr),
+                 "v"(progv)
+                 : "memory");
     pA = nA;
     pB = nB;
     pM = nM;
@@ -728,7 +766,9 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     sum_read(last, r1, r2, r3);
     sum_store(pA, pB, r1, r2, r3);
   }
+#ifndef KVFE_AGP_FREERUN
   if (budget == 0 && lane == 0) atomicOr(R.err, 1u);
+#endif
 #ifdef KVFE_AGP_PROF
   if (lane == 0) {
     const long long t1 = wall_clock64();
@@ -788,6 +828,9 @@ __device__ __forceinline__ void agp_loader(const char* hin, const char* hmin_in,
 #ifdef KVFE_AGP_PROF
     const unsigned b0 = budget;
 #endif
+#ifdef KVFE_AGP_FREERUN
+    budget = 0;
+#endif
     while (__builtin_amdgcn_ballot_w64((((unsigned)gl & AGP_TAGMASK) != etag) ||
                                        ((lane & 3) != 0 && (gm & AGP_TAGMASK) != etag)) != 0ull &&
            budget != 0) {
@@ -817,7 +860,9 @@ __device__ __forceinline__ void agp_loader(const char* hin, const char* hmin_in,
 #pragma unroll
   for (int u = 0; u < AGP_LPF; u++)
     if (j0 + u <= last) step(u, j0 + u);
+#ifndef KVFE_AGP_FREERUN
   if (budget == 0 && lane == 0) atomicOr(err, 1u);
+#endif
 #ifdef KVFE_AGP_PROF
   if (lane == 0) {
     atomicAdd(err + 1 + 9, prof_turns);
@@ -893,14 +938,24 @@ __global__ __launch_bounds__(AGP_WAVES * 64) void dense_aggregate_pass_kernel(
   R.P2 = P.P2;
   R.etag = etag;
   R.down = down;
+  const bool full = D == 64;
+#define AGP_CASE(I, O)                               \
+  case I * 3 + O:                                    \
+    if (full) agp_row<I, O, true>(R);                \
+    else agp_row<I, O, false>(R);                    \
+    break;
   switch (in_kind * 3 + out_kind) {   // wave-uniform
-    case AGP_IN_ZERO * 3 + AGP_OUT_NONE: agp_row<AGP_IN_ZERO, AGP_OUT_NONE>(R); break;
-    case AGP_IN_ZERO * 3 + AGP_OUT_LDS: agp_row<AGP_IN_ZERO, AGP_OUT_LDS>(R); break;
-    case AGP_IN_ZERO * 3 + AGP_OUT_GLOBAL: agp_row<AGP_IN_ZERO, AGP_OUT_GLOBAL>(R); break;
-    case AGP_IN_LDS * 3 + AGP_OUT_NONE: agp_row<AGP_IN_LDS, AGP_OUT_NONE>(R); break;
-    case AGP_IN_LDS * 3 + AGP_OUT_LDS: agp_row<AGP_IN_LDS, AGP_OUT_LDS>(R); break;
-    default: agp_row<AGP_IN_LDS, AGP_OUT_GLOBAL>(R); break;
+    AGP_CASE(AGP_IN_ZERO, AGP_OUT_NONE)
+    AGP_CASE(AGP_IN_ZERO, AGP_OUT_LDS)
+    AGP_CASE(AGP_IN_ZERO, AGP_OUT_GLOBAL)
+    AGP_CASE(AGP_IN_LDS, AGP_OUT_NONE)
+    AGP_CASE(AGP_IN_LDS, AGP_OUT_LDS)
+    default:
+      if (full) agp_row<AGP_IN_LDS, AGP_OUT_GLOBAL, true>(R);
+      else agp_row<AGP_IN_LDS, AGP_OUT_GLOBAL, false>(R);
+      break;
   }
+#undef AGP_CASE
 }
 
 // ---- disparity selection (computeDisparitySGBM, pass == npasses block) ---------------------------------
@@ -1353,8 +1408,7 @@ void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t
   unsigned short* sA = (unsigned short*)B.vol[0];
   unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
-  static const bool x_eight = getenv("KVFE_X_DENSE8") != nullptr;   // A/B while measuring
-  if (!x_eight && P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
+  if (P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
     // computeDisparitySGBM's two passes, one launch: rows of a pass are waves that hand their path costs down
     const int nbands = (P.H + AGP_ROWS - 1) / AGP_ROWS;
     const int key[4] = {n, P.width1, P.H, P.D};

@@ -33,7 +33,7 @@ def main():
         vals.append(ms / cnt)
     same = all(np.array_equal(a, b) for a, b in zip(first, disp))
     prof = None
-    if "agprof" in os.environ.get("KVFE_LIB", ""):
+    if "agprof" in os.environ.get("KVFE_LIB", "") or "agfree" in os.environ.get("KVFE_LIB", ""):
         prof = ctx.dense_debug_volume(2, (32,)).view(np.uint32).astype(np.int64)
     ctx.close()
     import zlib
