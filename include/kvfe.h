@@ -407,8 +407,9 @@ KVFE_API kvfe_status kvfe_dense_profile_read(kvfe_ctx* ctx, double* kernel_ms, i
 
 /* test hook: cost volumes [H][width1][D] int16 of the first pair of the last
  * kvfe_dense_stereo_reconstruction call: which = 2: C(p,d) of computeDisparitySGBM (with its +P2
- * bias); 0: the sum of the eight path costs (uint16, saturated at 65535; S of OpenCV is
- * min(32767, sum)). */
+ * bias); 0 and 1: the partial sums of the path costs (uint16): MODE_SGBM and StereoBM keep everything
+ * in volume 0; MODE_HH adds four directions into each (pass 1 / pass 2 of computeDisparitySGBM), and
+ * S of OpenCV is min(32767, volume 0 + volume 1). */
 KVFE_API kvfe_status kvfe_dense_debug_volume(kvfe_ctx* ctx, int32_t which, int16_t* out,
                                              size_t elems);
 

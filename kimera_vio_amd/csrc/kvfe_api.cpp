@@ -2971,6 +2971,7 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   TRY(al((void**)&c->dense_xyz, sizeof(float) * 3 * px));
   TRY(al((void**)&c->dense_minkey, 16));
   TRY(al((void**)&b.agsync, AGP_SYNC_WORDS * sizeof(unsigned)));
+  HIPCHK(c, hipMemset(b.agsync, 0, AGP_SYNC_WORDS * sizeof(unsigned)));   // (the error word is read after every call)
   if (hand_need) {
     TRY(al((void**)&b.hand, hand_need));
     b.hand_bytes = hand_need;
@@ -3042,7 +3043,7 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
 }
 
 // debug / test hook: the cost volumes of the FIRST pair of the last kvfe_dense_stereo_reconstruction
-// call, [H][width1][D] int16: which = 0 sum of the eight path costs (u16, saturated at 65535), 2 = C(p,d)
+// call, [H][width1][D] int16: which = 0 / 1 partial sums of the path costs (u16; MODE_HH: four directions each), 2 = C(p,d)
 kvfe_status kvfe_dense_debug_volume(kvfe_ctx* c, int32_t which, int16_t* out, size_t elems) {
   DeviceGuard _dev(c);
   if (!c || !out || which < 0 || which > 2 || !c->dense.vol[which] || elems > c->dense.vol_elems)
