@@ -468,7 +468,10 @@ constexpr int AGP_WAVES = 16;   // + the loader wave (wave 0)
 constexpr int AGP_LPF = 4;      // steps the loader requests ahead
 constexpr int AGP_MIN_PAIRS = 4;   // fewer pairs: too few rows in flight, the single-launch atomic sweeps are faster
 constexpr int AGP_RING = 8;
-constexpr int AGP_PF = 6;
+constexpr int AGP_PF = 6;      // requests of C in flight per row
+constexpr int AGP_PF_G = 6;  // ... in the last row of a block: its device-scope stores of the entries complete late and sit
+                               // in the same in-order counter as the requests (with 6, these rows -- and through the rings the
+                               // whole block -- ran at the stores' latency / 2.75 steps)
 constexpr unsigned AGP_INF2 = 0x3FFF3FFFu;
 constexpr unsigned AGP_TAGMASK = 0x80008000u;
 
@@ -510,6 +513,38 @@ __device__ __forceinline__ unsigned agp_wait_loop(agp_lds_u32* p, unsigned need,
   budget -= budget != 0 ? 1u : 0u;   // (per loop, not per turn: the budget is a bound, not a clock)
   return seen;
 }
+// the same for a row's input: every turn reads the counter AND the lane's words of the entry behind it (LDS serves a
+// wave's requests in order: words read behind a counter that is high enough are valid), so that the turn that sees the
+// counter arrive has the entry already -- no second round trip after the wait
+template <int SLEEP>
+__device__ __forceinline__ unsigned agp_wait_in_loop(agp_lds_u32* p, agp_lds_u64* pe, agp_lds_u32* pm, unsigned need,
+                                                     unsigned seen, unsigned turns, unsigned& budget,
+                                                     unsigned long long& v, unsigned& m) {
+  while (seen < need && turns != 0) {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    turns--;
+    const unsigned pr = *p;
+    v = *pe;
+    m = *pm;
+    seen = __builtin_amdgcn_readfirstlane(pr);
+  }
+  budget -= budget != 0 ? 1u : 0u;
+  return seen;
+}
+__device__ __forceinline__ unsigned agp_wait_in(agp_lds_u32* p, agp_lds_u64* pe, agp_lds_u32* pm, unsigned need,
+                                                unsigned seen, unsigned& budget, unsigned long long& v, unsigned& m) {
+#ifdef KVFE_AGP_FREERUN
+  return need;
+#endif
+  if (budget == 0) return seen;
+  seen = agp_wait_in_loop<1>(p, pe, pm, need, seen, 8, budget, v, m);
+  if (seen >= need) return seen;
+  seen = agp_wait_in_loop<3>(p, pe, pm, need, seen, 16, budget, v, m);
+  while (seen < need && budget > 3) seen = agp_wait_in_loop<8>(p, pe, pm, need, seen, 64, budget, v, m);
+  if (seen < need) budget = 0;
+  return seen;
+}
+
 __device__ __forceinline__ unsigned agp_wait(agp_lds_u32* p, unsigned need, unsigned& budget) {
 #ifdef KVFE_AGP_FREERUN   // measurement only (wrong results): nobody waits, every row runs at its own speed
   return need;
@@ -562,6 +597,7 @@ struct AgpRow {
 template <int IN, int OUT, bool FULL>
 __device__ __forceinline__ void agp_row(const AgpRow& R) {
   constexpr int OM = OUT == AGP_OUT_LDS ? AGP_RING - 1 : 1;   // slots of its own ring the wave uses, - 1
+  constexpr int PF = OUT == AGP_OUT_GLOBAL ? AGP_PF_G : AGP_PF;
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, g = lane & 15;
   const int W1 = R.W1, D = R.D, last = W1 - 1;
@@ -596,10 +632,10 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
   char* hptr = R.hout;
   char* hmptr = R.hmin_out;
 
-  // requests: C of the next AGP_PF steps (one 64-bit value each: as two words they are copied at the loop's back edge)
-  unsigned long long cbuf[AGP_PF];
+  // requests: C of the next PF steps (one 64-bit value each: as two words they are copied at the loop's back edge)
+  unsigned long long cbuf[PF];
 #pragma unroll
-  for (int u = 0; u < AGP_PF; u++) {
+  for (int u = 0; u < PF; u++) {
     cbuf[u] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(crsrc, coff, cnext, 0));
     cnext += cstep;
   }
@@ -625,7 +661,7 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     sprev += cstep;
   };
 
-  // one step; u = i mod AGP_PF selects the request register (compile-time in the unrolled groups below); EDGE: the step
+  // one step; u = i mod PF selects the request register (compile-time in the unrolled groups below); EDGE: the step
   // may be the first or the last of the row (entries -1 and W1 lie outside the volume)
   auto step = [&](auto edge_tag, const int u, const int i) {
     constexpr bool EDGE = decltype(edge_tag)::value;
@@ -647,9 +683,8 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
 #ifdef KVFE_AGP_PROF
           const unsigned b0 = budget;
 #endif
-          seen_in = agp_wait(R.prog_in, need, budget);
-          v = R.ring_in[slot * 64 + lane];
-          inM = R.minring_in[slot * 4 + q];
+          seen_in = agp_wait_in(R.prog_in, R.ring_in + (slot * 64 + lane), R.minring_in + (slot * 4 + q), need, seen_in,
+                                budget, v, inM);
 #ifdef KVFE_AGP_PROF
           prof_in_turns += b0 - budget;
           prof_in_steps += b0 != budget ? 1 : 0;
@@ -675,7 +710,7 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     cbuf[u] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(crsrc, coff, cnext, 0));
     cnext += cstep;
     // the sum of the step before (its entry has been in LDS for a step).  Behind the wait for C: the compiler cannot count
-    // a store under a lane mask, so it keeps only AGP_PF - 1 operations in flight at that wait, stores included
+    // a store under a lane mask, so it keeps only PF - 1 operations in flight at that wait, stores included
     if (!EDGE || i > 0) sum_store(pA, pB, r1, r2, r3);
     inA = row0 ? pA : inA;
     inB = row0 ? pB : inB;
@@ -743,24 +778,24 @@ __device__ __forceinline__ void agp_row(const AgpRow& R) {
     pB = nB;
     pM = nM;
   };
-  // groups of AGP_PF steps without a condition in between (a conditional update of the request registers costs copies
+  // groups of PF steps without a condition in between (a conditional update of the request registers costs copies
   // at the top of the next step, and a copy is a use: the wait for the load moves up to it).  The first group and the
   // last one or two carry the tests for the row's ends; the groups in between do not.
   auto edge_group = [&](int i0) {
 #pragma unroll
-    for (int u = 0; u < AGP_PF; u++)
+    for (int u = 0; u < PF; u++)
       if (i0 + u <= last) step(std::true_type{}, u, i0 + u);
   };
-  // (the first group without the test for the row's end -- the launch needs W1 > AGP_PF: with conditional requests in
+  // (the first group without the test for the row's end -- the launch needs W1 > PF: with conditional requests in
   // front of the loop the compiler no longer knows how many are in flight at its top and waits for all of them)
-  int i0 = AGP_PF;
+  int i0 = PF;
 #pragma unroll
-  for (int u = 0; u < AGP_PF; u++) step(std::true_type{}, u, u);
-  for (; i0 + AGP_PF <= last; i0 += AGP_PF) {   // every step of the group has 0 < i < last
+  for (int u = 0; u < PF; u++) step(std::true_type{}, u, u);
+  for (; i0 + PF <= last; i0 += PF) {   // every step of the group has 0 < i < last
 #pragma unroll
-    for (int u = 0; u < AGP_PF; u++) step(std::false_type{}, u, i0 + u);
+    for (int u = 0; u < PF; u++) step(std::false_type{}, u, i0 + u);
   }
-  for (; i0 <= last; i0 += AGP_PF) edge_group(i0);
+  for (; i0 <= last; i0 += PF) edge_group(i0);
   {
     unsigned long long r1, r2, r3;
     sum_read(last, r1, r2, r3);
@@ -1377,7 +1412,7 @@ size_t dense_volume_elems(const DenseParams& P) { return (size_t)P.H * P.width1 
 
 // bytes of the two-pass aggregation's block-to-block entries (0: that path is not used for this call)
 size_t dense_handoff_bytes(const DenseParams& P, int pairs) {
-  if (!P.full_dp || P.bm || pairs < AGP_MIN_PAIRS || P.width1 <= AGP_PF) return 0;
+  if (!P.full_dp || P.bm || pairs < AGP_MIN_PAIRS || P.width1 <= AGP_PF_G) return 0;
   const size_t nbands = (size_t)(P.H + AGP_ROWS - 1) / AGP_ROWS;
   // per step of a block boundary: the entry (64 lanes x 8 bytes) and the three minima (4 words)
   return std::max<size_t>(1, nbands - 1) * 2 * pairs * P.width1 * (64 * sizeof(unsigned long long) + 4 * sizeof(unsigned));
@@ -1408,7 +1443,7 @@ void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t
   unsigned short* sA = (unsigned short*)B.vol[0];
   unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
-  if (P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
+  if (P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF_G && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
     // computeDisparitySGBM's two passes, one launch: rows of a pass are waves that hand their path costs down
     const int nbands = (P.H + AGP_ROWS - 1) / AGP_ROWS;
     const int key[4] = {n, P.width1, P.H, P.D};
