@@ -2432,11 +2432,21 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
 }
 
 // ---- staged input -----------------------------------------------------------------
+// A HIP stream is not a hardware queue: the runtime multiplexes a process's streams of one priority onto
+// GPU_MAX_HW_QUEUES (default 4) queues, and two streams that share a queue run in order.  A context has five streams
+// (main, side, output, upload, top-up) and a process may hold several contexts: when the upload stream lands on the queue
+// of a compute stream, the frames' transfer and the step simply add up (2.3 ms instead of 1.4, profiles/r5_analysis.md
+// section 4).  Queues are pooled per priority, so the upload stream asks for the other pool.
+static hipError_t create_stream_in_other_pool(hipStream_t* s) {
+  int lo = 0, hi = 0;   // (numerically: greatest priority <= least)
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
 static kvfe_status ensure_staging(kvfe_ctx* c, int slot) {
   DeviceGuard _dev(c);
   const size_t bytes = 2 * (size_t)c->P.W * c->P.H * c->P.B;
   if (!c->copy_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(c, create_stream_in_other_pool(&c->copy_stream));
     for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming));
     if (!c->cfg.copy_inputs && !c->fork_swap) {   // many streams: device copies of the input ring slots (do_step)
