@@ -267,12 +267,15 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
         long long lk[CH];
 #pragma unroll
         for (int j = 0; j < CH; j++) {
-          const int i = min(base + 64 * j + lane, nk - 1);
-          lk[j] = lmk[i];
-          pk[j] = kp[i];
+          if (base + 64 * j < nk) {   // (wave-uniform: the groups past the end of the list are neither read nor tested)
+            const int i = min(base + 64 * j + lane, nk - 1);
+            lk[j] = lmk[i];
+            pk[j] = kp[i];
+          }
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
+          if (base + 64 * j >= nk) break;
           const int i = base + 64 * j + lane;
           // only keypoints with a landmark mask (FeatureDetector.cpp:191); cv::Point(Point2f) rounds
           const int cx = __float2int_rn(pk[j].x), cy = __float2int_rn(pk[j].y);
@@ -289,10 +292,11 @@ __global__ __launch_bounds__(64) void mineig2_kernel(
               const int hw = hw_s[dy];
               const int xa = max(ccx - hw, x0) - x0, xb = min(ccx + hw, x0 + 63) - x0;
               if (xa > xb) return 0ull;
-              return (xb - xa == 63) ? ~0ull : (((1ull << (xb - xa + 1)) - 1ull) << xa);
+              return (~0ull >> (63 - (xb - xa))) << xa;   // bits xa .. xb (0 <= xa <= xb <= 63)
             };
-            mrow0 |= span(gy0);
-            if (strip_rows > 64) mrow1 |= span(gy1);
+            // (a disc of a strip above 64 rows touches its rows 0..63, its rows 64.., or both: wave-uniform tests)
+            if (ccy - radius <= ys + 63) mrow0 |= span(gy0);
+            if (strip_rows > 64 && ccy + radius >= ys + 64) mrow1 |= span(gy1);
           }
         }
       }
@@ -2167,12 +2171,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 4 : 2) void subpix_append_kernel
       const size_t o = (size_t)s * P.kcap + base + ci;
       K.kp[o] = c;
       K.lmk[o] = S.lmk_counter[s] + ci;
-      K.age[o] = 1;
-      double v[3];
-      bearing_vector(T.und_left_R, c.x, c.y, v);
-      K.versor[o * 3] = v[0];
-      K.versor[o * 3 + 1] = v[1];
-      K.versor[o * 3 + 2] = v[2];
+      K.age[o] = 1;   // (the bearing vector: detect_commit_kernel, all corners of the stream side by side)
     } else {
       D.newc[(size_t)s * P.acap + ci] = c;
     }
@@ -2262,25 +2261,43 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
   // round 4 a block kept its eight corners to the end, i.e. for as many iterations as its slowest one: corners need 19
   // iterations on average and 40 % of them more than 20 (KVFE_SUBPIX_STATS), so most of a block's lanes idled most of
   // the time.  Same arithmetic per corner; which block refines a corner is invisible in the result.
+  //
+  // A refill is on the critical path of the WHOLE block (the other seven corners wait at the next barrier), and one
+  // happens every ~2.4 iterations.  Its first form cost ~10 dependent memory round trips and ~400 dependent float64
+  // instructions each time: the counter, the corner's coordinates, the per-stream append offsets, the bearing vector of
+  // the finished corner, six round trips of the byte-wise stage load.  Now:
+  //   * the block keeps one corner ON DECK -- index and coordinates requested one / two iterations before a slot needs
+  //     them (wave 0; the barriers of the loop wait for LDS only, so the requests stay in flight across them);
+  //   * the append offsets are read once, the bearing vectors are left to detect_commit_kernel (all of a stream's corners
+  //     side by side instead of one lane at a time in here);
+  //   * the stage comes in one round trip (subpix_load_stage).
   const bool do_append = (append & 15) != 0;
+  const int app_base = S.n_tracked[s];
+  const long long app_lmk0 = S.lmk_counter[s];
   auto finish = [&](int ci, float2 c, float2 cT) {   // FeatureDetector.cpp:141-160
     if (P.subpix_enable && (fabsf(c.x - cT.x) > WIN || fabsf(c.y - cT.y) > WIN)) c = cT;
     if (do_append) {
-      const int base = S.n_tracked[s];
-      const size_t o = (size_t)s * P.kcap + base + ci;
+      const size_t o = (size_t)s * P.kcap + app_base + ci;
       K.kp[o] = c;
-      K.lmk[o] = S.lmk_counter[s] + ci;
+      K.lmk[o] = app_lmk0 + ci;
       K.age[o] = 1;
-      double v[3];
-      bearing_vector(T.und_left_R, c.x, c.y, v);
-      K.versor[o * 3] = v[0];
-      K.versor[o * 3 + 1] = v[1];
-      K.versor[o * 3 + 2] = v[2];
     } else {
       D.newc[(size_t)s * P.acap + ci] = c;
     }
   };
-  auto pull = [&](int slot) -> bool {   // the slot's next corner; false: the stream has none left
+  auto take = [&](int slot, int ci, float2 c0) {   // corner ci moves into the slot
+    statef[slot * 16 + SPG_CIX] = c0.x;
+    statef[slot * 16 + SPG_CIY] = c0.y;
+    statef[slot * 16 + SPG_CTX] = c0.x;
+    statef[slot * 16 + SPG_CTY] = c0.y;
+    state[slot * 16 + SPG_ACTIVE] = 1;
+    state[slot * 16 + SPG_STAGED] = 0;
+    state[slot * 16 + SPG_SX0] = 0;
+    state[slot * 16 + SPG_SY0] = 0;
+    state[slot * 16 + SPG_ITER] = 0;
+    state[slot * 16 + SPG_CI] = ci;
+  };
+  auto pull = [&](int slot) -> bool {   // the slot's next corner, waited for; false: the stream has none left
     for (;;) {
       const int ci = atomicAdd(&D.sp_next[s], 1);
       if (ci >= n_new) {
@@ -2292,23 +2309,31 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
         finish(ci, c0, c0);
         continue;
       }
-      statef[slot * 16 + SPG_CIX] = c0.x;
-      statef[slot * 16 + SPG_CIY] = c0.y;
-      statef[slot * 16 + SPG_CTX] = c0.x;
-      statef[slot * 16 + SPG_CTY] = c0.y;
-      state[slot * 16 + SPG_ACTIVE] = 1;
-      state[slot * 16 + SPG_STAGED] = 0;
-      state[slot * 16 + SPG_SX0] = 0;
-      state[slot * 16 + SPG_SY0] = 0;
-      state[slot * 16 + SPG_ITER] = 0;
-      state[slot * 16 + SPG_CI] = ci;
+      take(slot, ci, c0);
       return true;
     }
   };
+  // the corner on deck (wave 0, the same values in every lane): 0 none, 1 index requested (deck_raw of lane 0; at the end
+  // of phase C), 2 index known and coordinates requested (in the middle of the next chunk loop), 3 the stream has no
+  // corner left
+  int deck_state = 0, deck_raw = 0, deck_ci = 0;
+  float2 deck_c = make_float2(0.f, 0.f);
+  // (the counter's address through an opaque VGPR: with an address it can prove uniform hipcc rewrites the atomic as
+  // "first active lane adds for all, v_readfirstlane, per-lane prefix" -- and the v_readfirstlane waits for the answer on
+  // the spot, which is exactly what the deck is there to avoid)
+  typedef __attribute__((address_space(1))) int glb_int_t;   // (global, not generic: a flat atomic would count as LDS traffic too)
+  glb_int_t* deck_ctr = (glb_int_t*)&D.sp_next[s];
+  asm volatile("" : "+v"(deck_ctr));
   if (wave == 0) {
     const bool on = lane < SPG_G && pull(lane);
     const unsigned long long bal = __ballot(on);
     if (lane == 0) sh_active = __popcll(bal);
+    if (__popcll(bal) == SPG_G) {
+      if (lane == 0) deck_raw = __hip_atomic_fetch_add(deck_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      deck_state = 1;
+    } else {
+      deck_state = 3;   // (a slot found the counter past the end)
+    }
   }
   int eij[MAXP];   // patch entries e = sub + 32 t of the (2w+3)^2 window
 #pragma unroll
@@ -2316,6 +2341,9 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     const int e = sub + TPC * t, i = e / pw;
     eij[t] = (i << 8) | (e - i * pw);
   }
+  static_assert(SPG_KC * SPG_G == NPROD, "one term set per producing thread and chunk");
+  static_assert(TPC == 64, "a slot's patch threads are one wave (its stage is written and read without a barrier)");
+  const int prod_c = (tid - 64) & (SPG_G - 1), prod_kk = (tid - 64) >> 3;   // producing thread: corner slot, window pixel of the chunk
   __syncthreads();
 
   const bool stats = (append & 16) != 0;
@@ -2331,7 +2359,7 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
   } while (0)
   while (sh_active > 0) {
     SPG_STAMP(4);
-    // ---- A: the corner's u8 stage and cv::getRectSubPix patch, 32 threads per corner -------------------------------
+    // ---- A: the corner's u8 stage and cv::getRectSubPix patch, 64 threads (one wave) per corner ---------------------
     if (state[cs * 16 + SPG_ACTIVE]) {
       const float cIx = statef[cs * 16 + SPG_CIX], cIy = statef[cs * 16 + SPG_CIY];
       unsigned char* stage = lds_raw + G.stage_off + (size_t)cs * stage_stride;
@@ -2345,10 +2373,7 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       bool staged = state[cs * 16 + SPG_STAGED] != 0;
       if (!staged || fx0 < sx0 || fy0 < sy0 || fx1 >= sx0 + rs || fy1 >= sy0 + rs) {
         const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
-        for (int e = sub; e < rs * rs; e += TPC) {
-          const int y = e / rs, x = e - y * rs;
-          stage[e] = I[(size_t)(ny0 + y) * row_stride + nx0 + x];
-        }
+        subpix_load_stage<rs, TPC>(I + (size_t)ny0 * row_stride + nx0, row_stride, stage, sub);
         sx0 = nx0;
         sy0 = ny0;
         staged = true;
@@ -2367,49 +2392,55 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
         rect_subpix_8u32f(I, row_stride, W, H, cIx, cIy, pw, patch, sub, TPC);
     }
     SPG_STAMP(0);
-    __syncthreads();
+    lds_block_sync();
     SPG_STAMP(1);
-    // ---- B: terms (waves 1-3) and chains (wave 0), software pipelined over chunks of SPG_KC window pixels ------------
+    // ---- B: terms (waves 1-7) and chains (wave 0), software pipelined over chunks of SPG_KC window pixels ------------
+    // (whether the thread's corner slot is in use is read once per iteration: the slots change hands in phase C only)
+    const bool prod_on = wave > 0 && state[prod_c * 16 + SPG_ACTIVE] != 0;
     auto produce = [&](int kc, int buf) {
-      const int p = tid - 64;
-      double* tb = terms + (size_t)buf * SPG_KC * 5 * SPG_G;
-#pragma unroll
-      for (int j = 0; j < (SPG_KC * SPG_G + NPROD - 1) / NPROD; j++) {
-        const int pi = p + NPROD * j;
-        const int c = pi & (SPG_G - 1), kk = pi >> 3, k = kc * SPG_KC + kk;
-        if (pi < SPG_KC * SPG_G && state[c * 16 + SPG_ACTIVE]) {
-          double* o = tb + (size_t)kk * 5 * SPG_G + c;
-          if (k < nt) {
-            const int i = k / ww, jj = k - i * ww;
-            const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off) + (size_t)c * pw * pw + (i + 1) * pw + (jj + 1);
-            const double m = (double)mask_s[k];
-            const double tgx = (double)(sp[1] - sp[-1]);
-            const double tgy = (double)(sp[pw] - sp[-pw]);
-            const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-            const double px = (double)(jj - WIN), py = (double)(i - WIN);
-            o[0] = gxx;
-            o[SPG_G] = gxy;
-            o[2 * SPG_G] = gyy;
-            o[3 * SPG_G] = gxx * px + gxy * py;
-            o[4 * SPG_G] = gxy * px + gyy * py;
-          } else {   // the tail of the last chunk: + 0.0 leaves a sum as it is (the one-corner kernel pads the same way)
-            o[0] = 0.0;
-            o[SPG_G] = 0.0;
-            o[2 * SPG_G] = 0.0;
-            o[3 * SPG_G] = 0.0;
-            o[4 * SPG_G] = 0.0;
-          }
-        }
+      if (!prod_on) return;
+      const int k = kc * SPG_KC + prod_kk;
+      double* o = terms + (size_t)buf * SPG_KC * 5 * SPG_G + (size_t)prod_kk * 5 * SPG_G + prod_c;
+      if (k < nt) {
+        const int i = k / ww, jj = k - i * ww;
+        const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off) + (size_t)prod_c * pw * pw + (i + 1) * pw + (jj + 1);
+        const double m = (double)mask_s[k];
+        const double tgx = (double)(sp[1] - sp[-1]);
+        const double tgy = (double)(sp[pw] - sp[-pw]);
+        const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+        const double px = (double)(jj - WIN), py = (double)(i - WIN);
+        o[0] = gxx;
+        o[SPG_G] = gxy;
+        o[2 * SPG_G] = gyy;
+        o[3 * SPG_G] = gxx * px + gxy * py;
+        o[4 * SPG_G] = gxy * px + gyy * py;
+      } else {   // the tail of the last chunk: + 0.0 leaves a sum as it is (the one-corner kernel pads the same way)
+        o[0] = 0.0;
+        o[SPG_G] = 0.0;
+        o[2 * SPG_G] = 0.0;
+        o[3 * SPG_G] = 0.0;
+        o[4 * SPG_G] = 0.0;
       }
     };
     double acc = 0.0;   // wave 0, lane = 8 chain + corner: the chain's running float64 sum, in window order
-    if (wave > 0) produce(0, 0);
-    __syncthreads();
+    produce(0, 0);
+    lds_block_sync();
     SPG_STAMP(2);
     // (raised wave priority -- s_setprio 3 -- for the chain wave, the block's critical path, was measured in round 5:
     // cornerSubPix on real frames 1.560 ms with and without it, tools/r5/gpu_e.sh)
     for (int kc = 0; kc < NCH; kc++) {
       if (wave == 0) {
+        if (kc == NCH / 2 && deck_state == 1) {
+          // the index asked for at the end of the last phase C has long arrived: ask for the coordinates now, half an
+          // iteration before phase C can want them
+          deck_ci = __builtin_amdgcn_readfirstlane(deck_raw);
+          if (deck_ci >= n_new) {
+            deck_state = 3;
+          } else {
+            deck_c = D.newc[(size_t)s * P.acap + deck_ci];
+            deck_state = 2;
+          }
+        }
         if (lane < 5 * SPG_G) {
           // the chain is a string of dependent additions (~8 cycles each for a lone wave): the reads run SPG_PF terms
           // ahead of them so that no addition waits for LDS
@@ -2433,15 +2464,15 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       } else if (kc + 1 < NCH) {
         produce(kc + 1, (kc + 1) & 1);
       }
-      if (kc + 1 < NCH) __syncthreads();
+      if (kc + 1 < NCH) lds_block_sync();
     }
     SPG_STAMP(3);
-    // ---- C: the 2 x 2 system, one lane per corner (wave 0) ------------------------------------------------------
+    // ---- C: the 2 x 2 system, one lane per corner (wave 0); finished corners out, their slots refilled -------------
     if (wave == 0) {
       const int c = lane & (SPG_G - 1);
       const double a = __shfl(acc, c), b = __shfl(acc, SPG_G + c), cc = __shfl(acc, 2 * SPG_G + c);
       const double bb1 = __shfl(acc, 3 * SPG_G + c), bb2 = __shfl(acc, 4 * SPG_G + c);
-      bool still = false;
+      bool still = false, need = false;
       if (lane < SPG_G && state[lane * 16 + SPG_ACTIVE]) {
         float2 cI = make_float2(statef[lane * 16 + SPG_CIX], statef[lane * 16 + SPG_CIY]);
         int iter = state[lane * 16 + SPG_ITER];
@@ -2462,15 +2493,41 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
         statef[lane * 16 + SPG_CIX] = cI.x;
         statef[lane * 16 + SPG_CIY] = cI.y;
         state[lane * 16 + SPG_ITER] = iter;
-        if (!still) {   // done: out it goes, and the slot takes the stream's next corner
+        if (!still) {   // done: out it goes, and the slot wants the stream's next corner
           finish(state[lane * 16 + SPG_CI], cI, make_float2(statef[lane * 16 + SPG_CTX], statef[lane * 16 + SPG_CTY]));
-          still = pull(lane);
+          need = true;
         }
+      }
+      const unsigned long long need_m = __ballot(need);
+      if (need_m != 0ull) {
+        // the first slot that wants a corner takes the one on deck; a second one in the same iteration (rare) asks the
+        // counter itself and waits.  A corner on deck is never left behind: the loop ends when the last slot finds the
+        // stream empty, and a slot that finds a corner on deck stays active.
+        const int first = __builtin_ctzll(need_m);
+        const bool exhausted = deck_state == 3;
+        if (lane == first) {
+          if (deck_state == 2) {
+            take(lane, deck_ci, deck_c);
+            still = true;
+          } else if (exhausted) {
+            state[lane * 16 + SPG_ACTIVE] = 0;
+          } else {
+            still = pull(lane);
+          }
+        } else if (need) {
+          if (exhausted) state[lane * 16 + SPG_ACTIVE] = 0;
+          else still = pull(lane);
+        }
+        if (deck_state == 2) deck_state = 0;
+      }
+      if (deck_state == 0) {   // the next corner on deck: ask for its index now, for its coordinates next time round
+        if (lane == 0) deck_raw = __hip_atomic_fetch_add(deck_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        deck_state = 1;
       }
       const unsigned long long bal = __ballot(still);
       if (lane == 0) sh_active = __popcll(bal);
     }
-    __syncthreads();
+    lds_block_sync();
   }
   if (stats && tid == 0) {
     for (int i = 0; i < 5; i++) atomicAdd(&kvfe_spg_stats[i], st_acc[i]);
@@ -2491,11 +2548,15 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
 // still refined on a third stream, the new corners in a second small launch behind the refinement: bit exact, and 8 %
 // SLOWER, tools/r5/gpu_e.sh, gpu_f.sh.  The window the refinement's latency leaves is not idle: the rectify / match /
 // reject chain fills it, and with the tracking launch on top all three only share the chip.)
-__global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, DetectScratch D, int what) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= P.B) return;
+// bit 2 = the bearing vectors of the appended corners (UndistorterRectifier::GetBearingVector, FeatureDetector.cpp:149-150):
+// a block per stream, a thread per corner.  Until round 5 the refinement kernels computed them, one lane at a time at the
+// end of a corner -- ~400 dependent float64 instructions that, in the grouped kernel, the whole block waited for.
+constexpr int DC_T = 128;
+__global__ __launch_bounds__(DC_T) void detect_commit_kernel(KParams P, Tables T, FrameTab K, StreamState S, DetectScratch D,
+                                                           int what) {
+  const int s = blockIdx.x;
   const int flags = S.flags[s];
-  if (what & 1) {
+  if (threadIdx.x == 0 && (what & 1)) {
     if (flags & FLAG_KEYFRAME) {   // keyframe_R_ref_frame_ = identity (StereoVisionImuFrontend.cpp:203,225)
       for (int i = 0; i < 9; i++) S.kf_R_ref[(size_t)s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
     } else if ((flags & FLAG_INIT) && !(flags & FLAG_DETECT)) {
@@ -2507,8 +2568,22 @@ __global__ void detect_commit_kernel(KParams P, FrameTab K, StreamState S, Detec
   }
   if (!(flags & FLAG_DETECT)) return;
   const int n_new = D.n_new[s];
-  if (what & 1) K.count[s] = S.n_tracked[s] + n_new;
-  if (what & 2) S.lmk_counter[s] += n_new;
+  const int base = S.n_tracked[s];
+  if (what & 4) {
+    for (int ci = threadIdx.x; ci < n_new; ci += DC_T) {
+      const size_t o = (size_t)s * P.kcap + base + ci;
+      const float2 c = K.kp[o];
+      double v[3];
+      bearing_vector(T.und_left_R, c.x, c.y, v);
+      K.versor[o * 3] = v[0];
+      K.versor[o * 3 + 1] = v[1];
+      K.versor[o * 3 + 2] = v[2];
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (what & 1) K.count[s] = base + n_new;
+    if (what & 2) S.lmk_counter[s] += n_new;
+  }
 }
 
 int detect_new_bound(const KParams& P) {
@@ -2590,7 +2665,7 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
     hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, gy), dim3(SPG_T), glds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append | (stats_on ? 16 : 0) | (group_mode == 2 ? 64 : 0));
   }
-  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, st, P, k, S, D, 3);
+  if (append) hipLaunchKernelGGL(detect_commit_kernel, dim3(P.B), dim3(DC_T), 0, st, P, T, k, S, D, 7);
 }
 
 template <int WIN, int NW>

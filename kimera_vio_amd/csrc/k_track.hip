@@ -1123,9 +1123,12 @@ void launch_predict_flow(const KParams& P, const Tables& T, const double* R, con
 // ---------------------------------------------------------------------------------------------
 // survivors -> frame k; keyframe decision
 // ---------------------------------------------------------------------------------------------
-constexpr int TF_T = 256;
+// 1024 threads per stream (round 5; 256 until then): a stream's ~600 points are ONE pass of each loop below instead of
+// three or four, and every pass is a chain of dependent memory round trips, a block scan and -- in the first loop -- the
+// ~400 dependent float64 instructions of a bearing vector.
+constexpr int TF_T = 1024;
 
-__device__ __forceinline__ int block_scan256(int v, int* wave_tot, int* total) {
+__device__ __forceinline__ int block_scan_tf(int v, int* wave_tot, int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int inc = v;
   for (int off = 1; off < 64; off <<= 1) {
@@ -1135,6 +1138,7 @@ __device__ __forceinline__ int block_scan256(int v, int* wave_tot, int* total) {
   if (lane == 63) wave_tot[wv] = inc;
   __syncthreads();
   int base = 0, tot = 0;
+#pragma unroll
   for (int i = 0; i < TF_T / 64; i++) {
     const int t = wave_tot[i];
     if (i < wv) base += t;
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
     const int src = i < n ? lk.src_idx[so + i] : 0;
     if (i < n) keep = lk.status[so + i] && !(KM1.age[so + src] > P.max_age);
     int tot;
-    const int pos = block_scan256(keep ? 1 : 0, wave_tot, &tot);
+    const int pos = block_scan_tf(keep ? 1 : 0, wave_tot, &tot);
     const int off = sh_cnt;
     if (keep) {
       const size_t o = so + off + pos;
@@ -1223,7 +1227,7 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
     long long id = -1;
     if (j < nl_all) id = LKF.lmk[so + j];
     int tot;
-    const int pos = block_scan256(id != -1 ? 1 : 0, wave_tot, &tot);
+    const int pos = block_scan_tf(id != -1 ? 1 : 0, wave_tot, &tot);
     const int off = sh_cnt;
     if (id != -1) {
       lkf_ids[off + pos] = id;

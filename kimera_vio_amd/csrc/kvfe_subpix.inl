@@ -112,6 +112,38 @@ __host__ __device__ inline SubpixGeom subpix_geom(int win) {
   return g;
 }
 
+// The rs x rs byte neighbourhood of a corner, image -> LDS stage (row stride rs), by NTHR threads (`t` = index of the
+// thread among them).  rs % 4 == 0 (the reference's half size 10: rs = 36): rows are whole dwords, read as dwords at
+// byte addresses with EVERY request of the thread in flight before the first LDS write -- ONE memory round trip.  (Until
+// round 5 this was a byte loop; hipcc turned it into groups of four loads with a wait behind each: six dependent round
+// trips per stage, and in the grouped kernel the seven other corners of the block wait at the barrier behind them.)
+typedef int kvfe_int_u __attribute__((aligned(1)));   // dword at any byte address
+template <int RS, int NTHR>
+static __device__ __forceinline__ void subpix_load_stage(const unsigned char* __restrict__ src, size_t step,
+                                                         unsigned char* stage, int t) {
+  static_assert(RS % 4 == 0, "rows of whole dwords");
+  constexpr int ND = RS / 4, NTASK = RS * ND, NPT = (NTASK + NTHR - 1) / NTHR;
+  int v[NPT];
+#pragma unroll
+  for (int k = 0; k < NPT; k++) {
+    const int d = t + NTHR * k;
+    const int y = d / ND, xd = d - y * ND;
+    v[k] = 0;
+    if (d < NTASK) v[k] = *reinterpret_cast<const kvfe_int_u*>(src + (size_t)y * step + 4 * xd);
+  }
+#pragma unroll
+  for (int k = 0; k < NPT; k++) {
+    const int d = t + NTHR * k;
+    if (d < NTASK) reinterpret_cast<int*>(stage)[d] = v[k];   // (y * RS + 4 * xd) / 4 == d
+  }
+}
+
+// Block barrier of kernels whose waves talk through LDS only: waits for this wave's LDS traffic, not for its global
+// memory requests (__syncthreads() drains vmcnt as well, which would end every prefetch at the next barrier).
+static __device__ __forceinline__ void lds_block_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // interior branch of cv::getRectSubPix reading the source from the LDS stage (row stride rs);
 // eij[t] = (i << 8) | j of this lane's patch entries e = lane + 64 t (fixed per corner)
 template <int MAXP, int NTHR = 64>
@@ -373,9 +405,13 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
         if (!staged || fx0 < sx0 || fy0 < sy0 || fx1 >= sx0 + rs || fy1 >= sy0 + rs) {
           const int nx0 = min(max(ipx - 6, 0), W - rs), ny0 = min(max(ipy - 6, 0), H - rs);
           __syncthreads();
-          for (int e = lane; e < rs * rs; e += NTHR) {
-            const int y = e / rs, x = e - y * rs;
-            stage[e] = img[(size_t)(ny0 + y) * step + nx0 + x];
+          if constexpr (WIN > 0 && (2 * WIN + 16) % 4 == 0) {
+            subpix_load_stage<2 * WIN + 16, NTHR>(img + (size_t)ny0 * step + nx0, step, stage, lane);
+          } else {
+            for (int e = lane; e < rs * rs; e += NTHR) {
+              const int y = e / rs, x = e - y * rs;
+              stage[e] = img[(size_t)(ny0 + y) * step + nx0 + x];
+            }
           }
           __syncthreads();
           sx0 = nx0;
