@@ -226,34 +226,49 @@ struct RTap {
   unsigned w0, w1;     // w00 | w01 << 16, w10 | w11 << 16 (after folding; each <= 32768)
 };
 
-__device__ __forceinline__ RTap rtap(int W, int H, float mx, float my) {
+// the two halves of a tap: where the 2 x 2 block sits and which of its columns / rows fold onto each other (rtap_parts),
+// and the four 15-bit weights that follow from the 5-bit fractions and the folds (rtap_weights).  The packed tap table of
+// the tile kernel stores the first half per pixel and recomputes the second -- through these same functions.
+__device__ __forceinline__ void rtap_parts(int W, int H, float mx, float my, int& cx, int& cy, int& ax, int& ay,
+                                           bool& foldx, bool& foldy) {
   const int sxf = __float2int_rn(mx * 32.0f);
   const int syf = __float2int_rn(my * 32.0f);
-  const int ax = sxf & 31, ay = syf & 31;
+  ax = sxf & 31;
+  ay = syf & 31;
   int sx = sxf >> 5, sy = syf >> 5;
   sx = max(-32768, min(32767, sx));  // saturate_cast<short>
   sy = max(-32768, min(32767, sy));
+  const int sx0 = clipi(sx, W), sx1 = clipi(sx + 1, W), sy0 = clipi(sy, H), sy1 = clipi(sy + 1, H);
+  cx = sx0;
+  cy = sy0;
+  foldx = sx1 == sx0;  // both columns clamp onto the same source column
+  foldy = sy1 == sy0;
+}
+__device__ __forceinline__ void rtap_weights(int ax, int ay, bool foldx, bool foldy, unsigned& w0, unsigned& w1) {
   int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
   if ((ax | ay) == 0) {  // table entry (0,0) after saturation and fix-up: {32767,0,0,1}
     w00 = 32767;
     w11 = 1;
   }
-  const int sx0 = clipi(sx, W), sx1 = clipi(sx + 1, W), sy0 = clipi(sy, H), sy1 = clipi(sy + 1, H);
-  if (sx1 == sx0) {  // both columns clamp onto the same source column
+  if (foldx) {
     w00 += w01;
     w10 += w11;
     w01 = w11 = 0;
   }
-  if (sy1 == sy0) {
+  if (foldy) {
     w00 += w10;
     w01 += w11;
     w10 = w11 = 0;
   }
+  w0 = (unsigned)w00 | ((unsigned)w01 << 16);
+  w1 = (unsigned)w10 | ((unsigned)w11 << 16);
+}
+__device__ __forceinline__ RTap rtap(int W, int H, float mx, float my) {
+  int ax, ay;
+  bool foldx, foldy;
   RTap t;
-  t.cx = sx0;
-  t.cy = sy0;
-  t.w0 = (unsigned)w00 | ((unsigned)w01 << 16);
-  t.w1 = (unsigned)w10 | ((unsigned)w11 << 16);
+  rtap_parts(W, H, mx, my, t.cx, t.cy, ax, ay, foldx, foldy);
+  rtap_weights(ax, ay, foldx, foldy, t.w0, t.w1);
   return t;
 }
 
@@ -340,13 +355,51 @@ void launch_rectify_boxes(const float2* map, int W, int H, int4* box, hipStream_
 
 size_t rectify_box_count(int W, int H) { return (size_t)((W + RT_W - 1) / RT_W) * ((H + 15) / 16); }
 
+// Packed taps of the staged tiles (context creation, behind the boxes): per output pixel ONE dword instead of the 8-byte
+// map entry --
+//   bits 0..13  byte offset of the 2 x 2 block inside the tile's staged source box ((cy - y_lo) * RT_PITCH + cx - x_lo),
+//   bits 14..18 / 19..23  the 5-bit fractions ax / ay,   bit 24 / 25  columns / rows fold (BORDER_REPLICATE)
+// -- everything rtap() derives from the map entry that does not depend on the frame.  The tile kernel reads 8 KB instead
+// of 16 KB of map per tile and stream group (the map was a quarter of the launch's fetched bytes) and skips the float
+// conversions and clamps of phase A.  Tiles whose box does not fit the LDS stage keep the float map (gather path).
+constexpr unsigned RT_TAP_FOLDX = 1u << 24, RT_TAP_FOLDY = 1u << 25;
+static_assert(rt_patch(16) <= (1 << 14), "box offsets fit 14 bits");
+__global__ __launch_bounds__(256) void rectify_pack_kernel(const float2* __restrict__ map, int W, int H, int tiles_x,
+                                                           const int4* __restrict__ box, unsigned* __restrict__ tap) {
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tid = threadIdx.x;
+  const int x = tx * RT_W + (tid & 31) * 4, y0 = ty * 16 + (tid >> 5);
+  const int4 bx = box[blockIdx.x];
+  for (int r = 0; r < 2; r++) {
+    const int y = y0 + 8 * r;
+    if (x < W && y < H)
+      for (int q = 0; q < 4 && x + q < W; q++) {
+        const float2 m = map[y * W + x + q];
+        int cx, cy, ax, ay;
+        bool fx, fy;
+        rtap_parts(W, H, m.x, m.y, cx, cy, ax, ay, fx, fy);
+        unsigned t = 0;
+        if (bx.z > 0)
+          t = (unsigned)((cy - bx.y) * RT_PITCH + (cx - bx.x)) | ((unsigned)ax << 14) | ((unsigned)ay << 19) |
+              (fx ? RT_TAP_FOLDX : 0u) | (fy ? RT_TAP_FOLDY : 0u);
+        tap[y * W + x + q] = t;
+      }
+  }
+}
+
+void launch_rectify_taps(const float2* map, int W, int H, const int4* box, unsigned* tap, hipStream_t st) {
+  const int tiles_x = (W + RT_W - 1) / RT_W, tiles_y = (H + 15) / 16;
+  hipLaunchKernelGGL(rectify_pack_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, st, map, W, H, tiles_x, box, tap);
+}
+
 template <int TH, int SPB, int NSUB, int MINW>
 __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const unsigned char* __restrict__ src0, const unsigned char* __restrict__ src1, size_t src_row_stride,
     size_t src_img_stride, unsigned char* __restrict__ dst0, unsigned char* __restrict__ dst1,
     const float2* __restrict__ map0, const float2* __restrict__ map1, int W, int H, int B,
     const int* __restrict__ flags, int act_flag, int tiles_x, int tiles_y, int gz, int mode,
-    const int* __restrict__ skip, const int4* __restrict__ box0, const int4* __restrict__ box1) {
+    const int* __restrict__ skip, const int4* __restrict__ box0, const int4* __restrict__ box1,
+    const unsigned* __restrict__ tap0, const unsigned* __restrict__ tap1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int NBUF = NSUB > 1 ? 2 : 1;   // LDS boxes: SPB streams x NBUF buffers
   constexpr int NR = TH / 8;               // tile rows per lane
@@ -447,6 +500,29 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
   RTap tp[4 * NR];
   int mnx = 1 << 30, mxx = -1, mny = 1 << 30, mxy = -1;
   bool okr[NR];
+  // packed taps (tabulated boxes only: see rectify_pack_kernel): cx holds the byte offset inside the staged box
+  const unsigned* tap = cam == 0 ? tap0 : tap1;
+  const bool packed = tabulated && staged && tap != nullptr;
+  if (packed) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const int y = y0 + 8 * r;
+      okr[r] = x < W && y < H;
+      uint4 t4 = make_uint4(0u, 0u, 0u, 0u);
+      if (okr[r]) t4 = *reinterpret_cast<const uint4*>(tap + (size_t)y * W + x);
+      const unsigned tq[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        RTap t;
+        t.cx = (int)(tq[q] & 0x3fffu);
+        t.cy = 0;
+        rtap_weights((int)((tq[q] >> 14) & 31u), (int)((tq[q] >> 19) & 31u), (tq[q] & RT_TAP_FOLDX) != 0u,
+                     (tq[q] & RT_TAP_FOLDY) != 0u, t.w0, t.w1);
+        if (!okr[r]) t = RTap{0, 0, 0u, 0u};
+        tp[4 * r + q] = t;
+      }
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int y = y0 + 8 * r;
@@ -471,6 +547,7 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
       for (int q = 0; q < 4; q++) tp[4 * r + q] = RTap{0, 0, 0u, 0u};
     }
   }
+  }
   if (!tabulated) {
     rt_block_box<TH>(mnx, mxx, mny, mxy, bounds, lane, wave, W, H, x_lo, y_lo, ncx, ph);
     staged = ncx > 0 && !(mode & 2);
@@ -491,7 +568,8 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     const unsigned sm_base = (unsigned)(size_t)(lds_u8_t*)sm;
     unsigned ad[4 * NR];
 #pragma unroll
-    for (int q = 0; q < 4 * NR; q++) ad[q] = sm_base + (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo));
+    for (int q = 0; q < 4 * NR; q++)
+      ad[q] = sm_base + (packed ? (unsigned)tp[q].cx : (unsigned)((tp[q].cy - y_lo) * RT_PITCH + (tp[q].cx - x_lo)));
     auto blend = [&](int j) {
       const int pb_off = (j & (NBUF - 1)) * (SPB * RT_PATCH);
 #pragma unroll
@@ -587,11 +665,15 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
     if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
     const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * rt_patch(TH) + 64;
     const bool use_box = TH == 16 && T.rect_box[0] && T.rect_box[1];
+    // KVFE_RECT_FLOAT_MAP (debugging aid, A/B): the tiles read the float map although the packed taps exist
+    static const bool float_map = std::getenv("KVFE_RECT_FLOAT_MAP") != nullptr;
+    const bool use_tap = use_box && T.rect_tap[0] && T.rect_tap[1] && P.W % 4 == 0 && !float_map;
 #define KVFE_RT_LAUNCH(TH_, SPB_, NSUB_, MINW_)                                                                     \
   hipLaunchKernelGGL((rectify_tile_kernel<TH_, SPB_, NSUB_, MINW_>), grid, dim3(256), lds, st, src[0], src[1],        \
                      src_row_stride, src_img_stride, dst[0], dst[1], T.map[0], T.map[1], P.W, P.H, P.B, flags, act_flag, \
                      tiles_x, tiles_y, gz, tmode, skip, use_box ? T.rect_box[0] : nullptr,                               \
-                     use_box ? T.rect_box[1] : nullptr)
+                     use_box ? T.rect_box[1] : nullptr, use_tap ? T.rect_tap[0] : nullptr,                               \
+                     use_tap ? T.rect_tap[1] : nullptr)
 #define KVFE_RT_DISPATCH(TH_, W1_, W2_)                 \
   do {                                                  \
     if (NS == 1) KVFE_RT_LAUNCH(TH_, 2, 1, W1_);        \

@@ -717,8 +717,12 @@ kvfe_status build_tables(kvfe_ctx* c) {
     int4* dbox;
     TRY(dalloc(c, &dbox, rectify_box_count(P.W, P.H), false));
     launch_rectify_boxes(dm, P.W, P.H, dbox, nullptr);
+    unsigned* dtap;
+    TRY(dalloc(c, &dtap, N, false));
+    launch_rectify_taps(dm, P.W, P.H, dbox, dtap, nullptr);
     HIPCHK(c, hipDeviceSynchronize());
     T.rect_box[cam] = dbox;
+    T.rect_tap[cam] = dtap;
     for (int m = 0; m < 4; m++) {
       const bool useR = m & 1, useP = m & 2;
       c->und[cam][m] = to_dev(make_undistort_ctx(cp, useR ? (cam == 0 ? c->rect.R1 : c->rect.R2) : nullptr,

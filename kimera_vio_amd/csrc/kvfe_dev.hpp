@@ -122,6 +122,7 @@ struct UndistortDev {
 struct Tables {
   const float2* map[2];        // [H][W] (map_x, map_y) per camera
   const int4* rect_box[2];     // per 128 x 16 output tile of a camera: source box (x_lo, y_lo, 16-byte chunks per row, rows)
+  const unsigned* rect_tap[2]; // [H][W] packed taps of the tiles whose box fits the LDS stage (k_rectify.hip rectify_pack_kernel)
   const float* subpix_mask;    // (2w+1)^2 Gaussian-ish weights of cv::cornerSubPix
   const float* subpix_mask10;  // same for the hard-coded 10x10 stereo refinement
   const int* circle_hw;        // [radius+1] half widths of cv::circle(FILLED)
@@ -289,6 +290,8 @@ void launch_equalize_hist(int W, int H, int B, const unsigned char* src, size_t 
 // source boxes of the rectification tiles (context creation; Tables::rect_box)
 void launch_rectify_boxes(const float2* map, int W, int H, int4* box, hipStream_t st);
 size_t rectify_box_count(int W, int H);
+// packed taps of the staged tiles (context creation, behind the boxes; Tables::rect_tap)
+void launch_rectify_taps(const float2* map, int W, int H, const int4* box, unsigned* tap, hipStream_t st);
 void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_stride,
                     size_t img_stride, unsigned char* pyr, hipStream_t st,
                     unsigned char* level0_copy = nullptr);

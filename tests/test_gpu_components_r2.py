@@ -274,3 +274,17 @@ def test_kimera_shim_reference_signatures(seq, ocam, tmp_path):
     _frame_eq(frame_of("s_fe_last"), exp)
     assert np.array_equal(np.frombuffer(one["s_fe_lmk"], np.int64), exp["meas_landmark"])
     assert np.array_equal(np.frombuffer(one["s_fe_meas"], np.float64).reshape(-1, 3), exp["meas_uL_uR_v"], equal_nan=True)
+
+
+def test_rectify_tiles_on_the_float_map_forced():
+    """round 5: the tile kernel reads one packed dword per output pixel (rectify_pack_kernel, built with the context) for
+    the tiles whose source box fits its LDS stage; KVFE_RECT_FLOAT_MAP=1 (read once per process, hence the sub-process)
+    keeps those tiles on the 8-byte float map -- the path every round before took -- and must give the same images."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    me = os.path.join(root, "tests", "test_gpu_components_r2.py")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        me + "::test_undistort_rectify_stereo_frame"],
+                       env=dict(os.environ, KVFE_RECT_FLOAT_MAP="1"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
