@@ -2597,10 +2597,10 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
                           size_t row_stride, size_t img_stride, const FrameTab& k,
                           const StreamState& S, const DetectScratch& D, int append,
                           hipStream_t st) {
-  // KVFE_SUBPIX_LDS_PAD (debugging aid, tools/r5/gpu_z.sh): extra LDS bytes per block of the one-corner kernel, i.e. fewer
-  // corners per compute unit -- does the dispatcher pack a launch's few hundred latency-bound blocks onto few units?
-  static const size_t lds_pad = std::getenv("KVFE_SUBPIX_LDS_PAD") ? (size_t)std::atoi(std::getenv("KVFE_SUBPIX_LDS_PAD")) : 0;
-  const size_t lds = subpix_geom(P.subpix_win).bytes + lds_pad;
+  // (Fewer corners per compute unit -- extra LDS per block as a probe, tools/r5/gpu_z.sh -- make a corner faster, mean 183 k ->
+  // 154 k cycles and slowest 586 k -> 401 k at two per unit, and the launch slower, 0.27 -> 0.42 ms per step on average: the
+  // steps behind a feature-age burst bring thousands of corners and need the slots.)
+  const size_t lds = subpix_geom(P.subpix_win).bytes;
   const int bound = detect_new_bound(P);
   // waves per corner of the one-corner-per-block kernel: 2 (DPP broadcast chains, kvfe_subpix.inl), and 4 for a few
   // streams -- the patch and term work of an iteration spread over four SIMDs (5.4 k instead of 6.3 k cycles per
