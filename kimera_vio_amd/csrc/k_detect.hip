@@ -2215,7 +2215,7 @@ __host__ __device__ inline SpgGeom spg_geom(int win) {
   g.nt = s.nt;
   g.rs = s.rs;
   size_t o = 0;
-  g.mask_off = o;   o += sizeof(float) * (size_t)((g.nt + 15) & ~15);
+  g.mask_off = o;   o += sizeof(uint2) * (size_t)SPG_KC * ((g.nt + SPG_KC - 1) / SPG_KC);   // [window pixel, zero padded] {mask weight, packed patch offset and window coordinates}
   g.state_off = o;  o += 16 * sizeof(int) * SPG_G;                                         // [corner][16] ints / floats
   g.stage_off = o;  o += (size_t)SPG_G * (((size_t)g.rs * g.rs + 15) & ~(size_t)15);
   g.patch_off = o;  o += (size_t)SPG_G * sizeof(float) * g.pw * g.pw;
@@ -2243,7 +2243,11 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
   constexpr int MAXP = (pw * pw + TPC - 1) / TPC;
   constexpr int NCH = (nt + SPG_KC - 1) / SPG_KC;
   constexpr int NPROD = SPG_T - 64;    // term-producing threads
-  float* mask_s = reinterpret_cast<float*>(lds_raw + G.mask_off);
+  // per window pixel k (zero padded to whole chunks): .x = the mask weight's bits (0 in the padding: such a term set is
+  // +-0, and adding +-0 leaves a float64 sum that started at +0 as it is), .y = byte offset of the pixel in a corner's
+  // patch | (j - WIN) << 16 | (i - WIN) << 24 -- everything a producing thread needs about its pixel in ONE ds_read_b64
+  // (it used to divide k by the window width in every chunk)
+  uint2* ktab = reinterpret_cast<uint2*>(lds_raw + G.mask_off);
   int* state = reinterpret_cast<int*>(lds_raw + G.state_off);
   float* statef = reinterpret_cast<float*>(lds_raw + G.state_off);
   const size_t stage_stride = ((size_t)rs * rs + 15) & ~(size_t)15;
@@ -2256,7 +2260,12 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
   const int max_iters = P.subpix_iters;
   const double eps2 = P.subpix_eps2;
 
-  for (int k = tid; k < nt; k += SPG_T) mask_s[k] = T.subpix_mask[k];
+  for (int k = tid; k < NCH * SPG_KC; k += SPG_T) {
+    const int kq = min(k, nt - 1), i = kq / ww, jj = kq - i * ww;   // (padding: the last pixel's addresses, weight 0)
+    const unsigned off = (unsigned)(((i + 1) * pw + (jj + 1)) * (int)sizeof(float));
+    ktab[k] = make_uint2(k < nt ? __float_as_uint(T.subpix_mask[k]) : 0u,
+                         off | ((unsigned)((jj - WIN) & 0xff) << 16) | ((unsigned)((i - WIN) & 0xff) << 24));
+  }
   // A finished corner is written out at once and its slot takes the stream's next corner off a counter (round 5).  Until
   // round 4 a block kept its eight corners to the end, i.e. for as many iterations as its slowest one: corners need 19
   // iterations on average and 40 % of them more than 20 (KVFE_SUBPIX_STATS), so most of a block's lanes idled most of
@@ -2385,7 +2394,7 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       }
       const bool use_stage = staged && fx0 >= sx0 && fy0 >= sy0 && fx1 < sx0 + rs && fy1 < sy0 + rs;
       if (use_stage && interior)
-        rect_subpix_from_stage<MAXP, TPC>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
+        rect_subpix_from_stage_w64<MAXP>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
       else if (use_stage)
         rect_subpix_border_from_stage<MAXP, TPC>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, sub);
       else
@@ -2399,28 +2408,19 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     const bool prod_on = wave > 0 && state[prod_c * 16 + SPG_ACTIVE] != 0;
     auto produce = [&](int kc, int buf) {
       if (!prod_on) return;
-      const int k = kc * SPG_KC + prod_kk;
+      const uint2 e = ktab[kc * SPG_KC + prod_kk];
       double* o = terms + (size_t)buf * SPG_KC * 5 * SPG_G + (size_t)prod_kk * 5 * SPG_G + prod_c;
-      if (k < nt) {
-        const int i = k / ww, jj = k - i * ww;
-        const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off) + (size_t)prod_c * pw * pw + (i + 1) * pw + (jj + 1);
-        const double m = (double)mask_s[k];
-        const double tgx = (double)(sp[1] - sp[-1]);
-        const double tgy = (double)(sp[pw] - sp[-pw]);
-        const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-        const double px = (double)(jj - WIN), py = (double)(i - WIN);
-        o[0] = gxx;
-        o[SPG_G] = gxy;
-        o[2 * SPG_G] = gyy;
-        o[3 * SPG_G] = gxx * px + gxy * py;
-        o[4 * SPG_G] = gxy * px + gyy * py;
-      } else {   // the tail of the last chunk: + 0.0 leaves a sum as it is (the one-corner kernel pads the same way)
-        o[0] = 0.0;
-        o[SPG_G] = 0.0;
-        o[2 * SPG_G] = 0.0;
-        o[3 * SPG_G] = 0.0;
-        o[4 * SPG_G] = 0.0;
-      }
+      const float* sp = reinterpret_cast<const float*>(lds_raw + G.patch_off + (size_t)prod_c * pw * pw * sizeof(float) + (e.y & 0xffffu));
+      const double m = (double)__uint_as_float(e.x);
+      const double tgx = (double)(sp[1] - sp[-1]);
+      const double tgy = (double)(sp[pw] - sp[-pw]);
+      const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+      const double px = (double)((int)(e.y << 8) >> 24), py = (double)((int)e.y >> 24);
+      o[0] = gxx;
+      o[SPG_G] = gxy;
+      o[2 * SPG_G] = gyy;
+      o[3 * SPG_G] = gxx * px + gxy * py;
+      o[4 * SPG_G] = gxy * px + gyy * py;
     };
     double acc = 0.0;   // wave 0, lane = 8 chain + corner: the chain's running float64 sum, in window order
     produce(0, 0);

@@ -175,6 +175,47 @@ static __device__ __forceinline__ void rect_subpix_from_stage(const unsigned cha
   }
 }
 
+// The same branch for ONE wave per patch (lane = entry e = lane + 64 t, row-major): cv::getRectSubPix walks a row as
+//   prev = (1-a) * (b1*R[0] + b2*R[rs]);  for j: t = a12*R[j+1] + a22*R[j+1+rs]; dst[j] = prev + t; prev = (float)(t * s)
+// so entry (i, j)'s `prev` is entry (i, j-1)'s `t` scaled -- the value the lane to the left has just computed.  Every
+// lane computes its own t (two bytes of the stage) and takes its neighbour's through a DPP wave shift (lane 0: lane 63
+// of the previous batch); the 23 row heads (j = 0) are written by the first lanes on their own: two stage bytes and ~17
+// instructions per entry instead of four bytes and ~30.  Same operations on the same operands in the same order as
+// rect_subpix_from_stage => the same bits.
+template <int MAXP>
+static __device__ __forceinline__ void rect_subpix_from_stage_w64(const unsigned char* stage, int rs, int dx0, int dy0,
+                                                                  float ccx, float ccy, int ipx, int ipy, int n,
+                                                                  const int (&eij)[MAXP], float* dst, int lane) {
+  float a = ccx - ipx;
+  const float b = ccy - ipy;
+  a = fmaxf(a, 0.0001f);
+  const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+  const double sc = (1. - a) / a;
+  const unsigned char* S = stage + dy0 * rs + dx0;
+  if (lane < n) {   // entry (lane, 0)
+    const unsigned char* R = S + lane * rs;
+    const float r0 = (float)R[0], r1 = (float)R[rs];
+    const float first = (1 - a) * (b1 * r0 + b2 * r1);
+    const float t0 = a12 * R[1] + a22 * R[1 + rs];
+    dst[lane * n] = first + t0;
+  }
+  float tt_last = 0.f;   // t of the previous batch
+#pragma unroll
+  for (int t = 0; t < MAXP; t++) {
+    const int e = lane + 64 * t;
+    // (entries past the patch -- the last batch's upper lanes -- compute on the last row's bytes and store nothing)
+    const int i = min(eij[t] >> 8, n - 1), j = eij[t] & 255;
+    const unsigned char* R = S + i * rs;
+    const float tt = a12 * R[j + 1] + a22 * R[j + 1 + rs];
+    float tp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tt), 0x138, 0xf, 0xf, true));   // wave_shr:1
+    const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt_last), 63));
+    tp = lane == 0 ? t63 : tp;
+    const float prev = (float)(tp * sc);
+    if (e < n * n && j != 0) dst[e] = prev + tt;
+    tt_last = tt;
+  }
+}
+
 // border branch of cv::getRectSubPix (the window leaves the image: rows and columns are replicated with OpenCV's
 // r.x / r.width / r.y / r.height rules, rect_subpix_8u32f above) reading the source from the LDS stage, whose window
 // [sx0, sx0 + rs) x [sy0, sy0 + rs) lies inside the image and holds every row and column the branch can address.
