@@ -2350,6 +2350,9 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     const int e = sub + TPC * t, i = e / pw;
     eij[t] = (i << 8) | (e - i * pw);
   }
+#if defined(KVFE_SPG_DIAG) && KVFE_SPG_DIAG == 2
+  for (int k = tid; k < 2 * SPG_KC * 5 * SPG_G; k += SPG_T) terms[k] = 0.0;   // (nobody produces: every sum is 0, every corner stays where it is)
+#endif
   static_assert(SPG_KC * SPG_G == NPROD, "one term set per producing thread and chunk");
   static_assert(TPC == 64, "a slot's patch threads are one wave (its stage is written and read without a barrier)");
   const int prod_c = (tid - 64) & (SPG_G - 1), prod_kk = (tid - 64) >> 3;   // producing thread: corner slot, window pixel of the chunk
@@ -2366,7 +2369,9 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       st_t = t_;                                               \
     }                                                          \
   } while (0)
+  unsigned long long st_iters = 0;
   while (sh_active > 0) {
+    st_iters++;
     SPG_STAMP(4);
     // ---- A: the corner's u8 stage and cv::getRectSubPix patch, 64 threads (one wave) per corner ---------------------
     if (state[cs * 16 + SPG_ACTIVE]) {
@@ -2406,7 +2411,12 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
     // ---- B: terms (waves 1-7) and chains (wave 0), software pipelined over chunks of SPG_KC window pixels ------------
     // (whether the thread's corner slot is in use is read once per iteration: the slots change hands in phase C only)
     const bool prod_on = wave > 0 && state[prod_c * 16 + SPG_ACTIVE] != 0;
+    // -DKVFE_SPG_DIAG=1 / 2 (profiling aid, never in the product build, WRONG results): the chain wave adds nothing / the
+    // producers produce nothing -- what the chunk loop costs when only the other side works (tools/r5/gpu_ab.sh)
     auto produce = [&](int kc, int buf) {
+#if defined(KVFE_SPG_DIAG) && KVFE_SPG_DIAG == 2
+      return;
+#endif
       if (!prod_on) return;
       const uint2 e = ktab[kc * SPG_KC + prod_kk];
       double* o = terms + (size_t)buf * SPG_KC * 5 * SPG_G + (size_t)prod_kk * 5 * SPG_G + prod_c;
@@ -2441,7 +2451,11 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
             deck_state = 2;
           }
         }
+#if defined(KVFE_SPG_DIAG) && KVFE_SPG_DIAG == 1
+        if (false) {
+#else
         if (lane < 5 * SPG_G) {
+#endif
           // the chain is a string of dependent additions (~8 cycles each for a lone wave): the reads run SPG_PF terms
           // ahead of them so that no addition waits for LDS
           const double* tb = terms + (size_t)(kc & 1) * SPG_KC * 5 * SPG_G + lane;
@@ -2532,6 +2546,7 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
   if (stats && tid == 0) {
     for (int i = 0; i < 5; i++) atomicAdd(&kvfe_spg_stats[i], st_acc[i]);
     atomicAdd(&kvfe_spg_stats[5], 1ull);
+    atomicAdd(&kvfe_spg_stats[6], st_iters);
   }
 #undef SPG_STAMP
 }
@@ -2626,8 +2641,9 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
         unsigned long long h[8];
         unsigned long long g[8];
         if (hipMemcpyFromSymbol(g, HIP_SYMBOL(kvfe_spg_stats), sizeof(g)) == hipSuccess && g[5])
-          std::fprintf(stderr, "KVFE_SUBPIX_STATS (group kernel) blocks %llu, cycles per block: patch %.0f | barrier %.0f | first chunk %.0f | chunk loop %.0f | solve + loop %.0f\n",
-                       g[5], (double)g[0] / g[5], (double)g[1] / g[5], (double)g[2] / g[5], (double)g[3] / g[5], (double)g[4] / g[5]);
+          std::fprintf(stderr, "KVFE_SUBPIX_STATS (group kernel) blocks %llu, cycles per block: patch %.0f | barrier %.0f | first chunk %.0f | chunk loop %.0f | solve + loop %.0f | iterations per block %.1f, chunk loop per iteration %.0f\n",
+                       g[5], (double)g[0] / g[5], (double)g[1] / g[5], (double)g[2] / g[5], (double)g[3] / g[5], (double)g[4] / g[5],
+                       (double)g[6] / g[5], g[6] ? (double)g[3] / g[6] : 0.0);
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kvfe_subpix_stats), sizeof(h)) == hipSuccess && h[0])
           std::fprintf(stderr, "KVFE_SUBPIX_STATS corners %llu, cycles per corner: mean %.0f max %llu; < 100 k: %llu, < 200 k: %llu, < 400 k: %llu, more: %llu\n",
                        h[0], (double)h[1] / (double)h[0], h[2], h[3], h[4], h[5], h[6]);
