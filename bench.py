@@ -731,6 +731,16 @@ def input_side():
     except ImportError:
         res["pil_1_thread"] = None
     res["stereo_pairs_per_s_all_threads"] = round(res["decode_all_threads"] / 2.0, 1)
+    # one step of the headline configuration: the 64 stereo pairs of 64 streams = 128 files in one call
+    files2 = files * 2
+    out2 = np.empty((len(files2), 480, 752), np.uint8)
+    DP.decode_png_gray_batch(files2, out2, 0)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 1.0:
+        DP.decode_png_gray_batch(files2, out2, 0)
+        n += len(files2)
+    res["decode_all_threads_128_files_per_call"] = round(n / (time.perf_counter() - t0), 1)
+    res["stereo_pairs_per_s_all_threads_128_files_per_call"] = round(res["decode_all_threads_128_files_per_call"] / 2.0, 1)
     return res
 
 

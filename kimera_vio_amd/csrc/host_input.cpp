@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -425,6 +426,16 @@ namespace {
 // is created on first use, grows to the largest thread count asked for (at most the hardware concurrency), lives for
 // the rest of the process (its threads are detached: nothing to join at exit) and serves one batch at a time -- a
 // second caller that finds it busy decodes on threads of its own.
+//
+// Round 5: a batch is handed over through ONE atomic word, and a worker that has just finished a batch spins on it for
+// ~0.5 ms before it goes to sleep.  The first pool woke its workers through one mutex and condition variable: 63 threads
+// taking the same lock one after the other (and idle cores coming out of their sleep states) cost ~3.7 ms per call of 64
+// files on the 256-thread host of the GPU box -- three times the decode itself (bench.py input_side: 13.0 k frames/s on
+// all threads against 0.83 k on one).  A decoder that feeds a running front-end calls again within that window, so its
+// workers are awake when the next step's files arrive.
+//   state_ = generation << 32 | OPEN | number of registered helpers.  A helper registers by compare-and-swap while the
+//   batch is open and fewer than want_ have; the caller closes the batch (clears OPEN) when the files are handed out and
+//   waits for exactly the helpers that registered: a late worker can neither touch the caller's stack nor be waited for.
 // ------------------------------------------------------------------------------------------------
 class DecodePool {
  public:
@@ -453,24 +464,40 @@ class DecodePool {
       std::lock_guard<std::mutex> lk(mu_);
       grow(threads - 1);
       helpers = std::min<int>(threads - 1, (int)started_);
-      job_ = body;
-      job_ctx_ = &ctx;
-      want_ = helpers;
-      taken_ = 0;
-      done_ = 0;
-      gen_++;
     }
-    if (helpers > 0) cv_job_.notify_all();
+    job_ = body;
+    job_ctx_ = &ctx;
+    want_.store(helpers, std::memory_order_relaxed);
+    done_.store(0);
+    const uint64_t gen = ((state_.load() >> 32) + 1) & 0xffffffffull;
+    state_.store(gen << 32 | (helpers > 0 ? kOpen : 0));   // (seq_cst: ordered against the sleepers_ read below)
+    if (helpers > 0 && sleepers_.load() > 0) {
+      { std::lock_guard<std::mutex> lk(mu_); }   // a worker between its predicate test and its wait holds mu_
+      cv_job_.notify_all();
+    }
     body(&ctx);
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [&] { return done_ == taken_ && (taken_ == want_ || ctx.next.load() >= n); });
-    want_ = taken_;   // helpers that have not woken up yet find nothing to take
+    // every file is handed out: close the batch, then wait for the helpers that got in
+    uint64_t s = state_.load();
+    while (!state_.compare_exchange_weak(s, s & ~kOpen)) {
+    }
+    const int registered = (int)(s & kCount);
+    for (int spins = 0; done_.load(std::memory_order_acquire) != registered; spins++) {
+      if (spins < 20000) cpu_relax();
+      else std::this_thread::yield();
+    }
     job_ = nullptr;
-    // (a helper that takes the job after this point cannot exist: taking happens under mu_ and checks want_)
     return true;
   }
 
  private:
+  static constexpr uint64_t kOpen = 1ull << 31, kCount = kOpen - 1;
+  static void cpu_relax() noexcept {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
   void grow(int helpers) {   // mu_ held
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 1;
@@ -485,33 +512,46 @@ class DecodePool {
     }
   }
   void worker() {
-    unsigned long long seen = 0;
+    uint64_t seen = state_.load() >> 32;   // (a worker started for batch g + 1 sees generation g here)
     for (;;) {
-      void (*job)(void*) noexcept = nullptr;
-      void* ctx = nullptr;
-      {
+      // the next batch: spin for a while (a running decoder comes back within a step), then sleep
+      uint64_t s;
+      auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
+      for (int spins = 0;;) {
+        s = state_.load();
+        if ((s >> 32) != seen) break;
+        if ((++spins & 63) != 0 || std::chrono::steady_clock::now() < spin_until) {   // (the clock every 64th look)
+          cpu_relax();
+          continue;
+        }
         std::unique_lock<std::mutex> lk(mu_);
-        cv_job_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (!job_ || taken_ >= want_) continue;
-        taken_++;
-        job = job_;
-        ctx = job_ctx_;
+        sleepers_.fetch_add(1);
+        cv_job_.wait(lk, [&] { return (state_.load() >> 32) != seen; });
+        sleepers_.fetch_sub(1);
+        spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
       }
-      job(ctx);
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        done_++;
+      seen = s >> 32;
+      bool in = false;
+      while ((s & kOpen) && (s >> 32) == seen && (int)(s & kCount) < want_.load(std::memory_order_relaxed)) {
+        if (state_.compare_exchange_weak(s, s + 1)) {
+          in = true;
+          break;
+        }
       }
-      cv_done_.notify_all();
+      if (!in) continue;   // (closed, full, or already the next batch: the loop above looks at it again)
+      job_(job_ctx_);
+      done_.fetch_add(1, std::memory_order_release);
     }
   }
+  static constexpr int kSpinUs = 500;   // a worker spins this long for the next batch: the gap between two steps' batches of a running decoder
   std::mutex run_mu_, mu_;
-  std::condition_variable cv_job_, cv_done_;
+  std::condition_variable cv_job_;
+  std::atomic<uint64_t> state_{0};
+  std::atomic<int> done_{0}, sleepers_{0};
+  // written by run() before it publishes the batch in state_, read by a worker after it has registered
   void (*job_)(void*) noexcept = nullptr;
   void* job_ctx_ = nullptr;
-  int want_ = 0, taken_ = 0, done_ = 0;
-  unsigned long long gen_ = 0;
+  std::atomic<int> want_{0};   // (atomic: a late worker may look at it while the next batch is being set up; its registration then fails)
   size_t started_ = 0;
 };
 

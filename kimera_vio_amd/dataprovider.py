@@ -72,11 +72,15 @@ def decode_png_gray_batch(files: list[bytes], out: np.ndarray, threads: int = 0)
     if out.ndim != 3 or out.shape[0] != n or out.dtype != np.uint8 or out.strides[2] != 1:
         raise ValueError("output must be (n, height, width) uint8 with unit column stride")
     h, w = out.shape[1], out.shape[2]
-    bufs = (C.c_void_p * n)(*[C.cast(C.c_char_p(f), C.c_void_p) for f in files])
-    sizes = (C.c_size_t * n)(*[len(f) for f in files])
-    dsts = (C.c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+    # (pointer tables without a Python-level loop over ctypes objects: at 128 files per call that loop was ~0.4 ms,
+    # a third of a frame's decode time, spent with every worker thread idle)
+    bufs = (C.c_char_p * n)(*files)
+    sizes = np.fromiter(map(len, files), np.uint64, n)
+    dsts = out.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(out.strides[0])
     status = (C.c_int32 * n)()
-    st = load().kvfe_png_decode_gray_batch(bufs, sizes, dsts, out.strides[1], w, h, n, threads, status)
+    st = load().kvfe_png_decode_gray_batch(C.cast(bufs, C.POINTER(C.c_void_p)), sizes.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                           dsts.ctypes.data_as(C.POINTER(C.c_void_p)), out.strides[1], w, h, n, threads,
+                                           status)
     if st != 0:
         bad = [i for i in range(n) if status[i] != 0]
         raise KvfeError(st, "kvfe_png_decode_gray_batch", f"files {bad}")
