@@ -15,6 +15,9 @@
 // the pinned staging slots of kvfe_frontend_staging_buffer.  The PNG container is decoded with zlib's inflate (the
 // only codec library in the image); everything around it (chunks, CRCs, filters, Adam7, sample expansion) is here.
 #include <zlib.h>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -23,6 +26,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -428,7 +432,7 @@ namespace {
 // second caller that finds it busy decodes on threads of its own.
 //
 // Round 5: a batch is handed over through ONE atomic word, and a worker that has just finished a batch spins on it for
-// ~0.5 ms before it goes to sleep.  The first pool woke its workers through one mutex and condition variable: 63 threads
+// 50 us before it goes to sleep.  The first pool woke its workers through one mutex and condition variable: 63 threads
 // taking the same lock one after the other (and idle cores coming out of their sleep states) cost ~3.7 ms per call of 64
 // files on the 256-thread host of the GPU box -- three times the decode itself (bench.py input_side: 13.0 k frames/s on
 // all threads against 0.83 k on one).  A decoder that feeds a running front-end calls again within that window, so its
@@ -543,7 +547,8 @@ class DecodePool {
       done_.fetch_add(1, std::memory_order_release);
     }
   }
-  static constexpr int kSpinUs = 500;   // a worker spins this long for the next batch: the gap between two steps' batches of a running decoder
+  static constexpr int kSpinUs = 50;   // a worker spins this long for the next batch (a decoder that calls again at once finds it awake;
+                                         // longer spins only burn the CPU quota of a container: 0.5 ms cost 12 % at 64 threads, tools/r5/gpu_ad.sh)
   std::mutex run_mu_, mu_;
   std::condition_variable cv_job_;
   std::atomic<uint64_t> state_{0};
@@ -554,6 +559,48 @@ class DecodePool {
   std::atomic<int> want_{0};   // (atomic: a late worker may look at it while the next batch is being set up; its registration then fails)
   size_t started_ = 0;
 };
+
+// The processors this process can actually use: the hardware threads, cut down to its affinity mask and to its cgroup's
+// CPU quota (a container on a 256-thread host is typically allowed a dozen: bench.py's input_side leg read the same
+// 12 - 13 k frames/s from 16 threads as from 256 -- and 64 spinning or waking threads only eat that quota).  The default
+// thread count of kvfe_png_decode_gray_batch (threads <= 0).
+unsigned effective_cpus() {
+  static const unsigned n = [] {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+#if defined(__linux__)
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      const int c = CPU_COUNT(&set);
+      if (c > 0) hw = std::min<unsigned>(hw, (unsigned)c);
+    }
+    auto read_ll = [](const char* path, long long* a, long long* b) -> int {   // "a b" or "max b" or "a"
+      FILE* f = std::fopen(path, "r");
+      if (!f) return 0;
+      char buf[64] = {0};
+      const size_t got = std::fread(buf, 1, sizeof(buf) - 1, f);
+      std::fclose(f);
+      if (got == 0) return 0;
+      if (!std::strncmp(buf, "max", 3)) return -1;
+      char* end = nullptr;
+      *a = std::strtoll(buf, &end, 10);
+      if (end == buf) return 0;
+      if (b) *b = std::strtoll(end, nullptr, 10);
+      return 1;
+    };
+    long long quota = 0, period = 0;
+    if (read_ll("/sys/fs/cgroup/cpu.max", &quota, &period) == 1 && quota > 0 && period > 0) {   // cgroup v2
+      hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    } else if (read_ll("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, nullptr) == 1 && quota > 0 &&
+               read_ll("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, nullptr) == 1 && period > 0) {   // cgroup v1
+      hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    }
+#endif
+    return hw;
+  }();
+  return n;
+}
 
 }  // namespace
 
@@ -591,8 +638,7 @@ kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t*
                                        kvfe_status* status) {
   if (n < 0 || (n > 0 && (!data || !sizes || !dst))) return KVFE_ERR_INVALID_ARG;
   if (n == 0) return KVFE_OK;
-  unsigned hw = std::thread::hardware_concurrency();
-  if (hw == 0) hw = 1;
+  const unsigned hw = effective_cpus();
   int nt = threads > 0 ? threads : (int)std::min<unsigned>(hw, (unsigned)n);
   nt = std::max(1, std::min(nt, n));
   try {
