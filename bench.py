@@ -386,6 +386,8 @@ def compact_line(result):
         ac = cb.get("all_cores") or {}
         if "value" in ac:
             c2["all_cores_value"], c2["all_cores"] = ac["value"], ac.get("cores")
+            if "usable_cpus" in ac:   # (processes started vs processors the container's CPU quota lets them use)
+                c2["all_cores_usable_cpus"] = ac["usable_cpus"]
         line["cpu_baseline"] = c2
     legs = {}
     for k in LEG_SCALARS:
@@ -700,6 +702,31 @@ def spinonce_leg(torch, F, dist, sharding, WL, dev, args):
             "vs_no_readback": round(res["pairs_per_s"] / ref["value"], 4)}
 
 
+def usable_cpus():
+    """processors this process may use: hardware threads cut down to the affinity mask and the cgroup CPU quota (the GPU
+    boxes of the pool: 256 hardware threads, cpu.max = 16 -- tools/r5/gpu_ad.sh)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, -(-int(q) // int(per))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, -(-q // per)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def input_side():
     """SURVEY 8 f3, host side: PNG -> grey decode rate of the data provider (kvfe_png_decode_gray_batch into one
     buffer per frame, the role of the pinned staging slots) on the committed 752x480 EuRoC frames, one host thread and
@@ -714,7 +741,7 @@ def input_side():
     out = np.empty((len(files), 480, 752), np.uint8)
     DP.decode_png_gray_batch(files[:2], out[:2], 1)
     res = {"workload": "64 PNG files per call (32 x tests/golden/{left,right}_img_0.png, 752x480 8-bit grey, "
-                       "362 kB each)", "unit": "frames/s", "host_cores": os.cpu_count()}
+                       "362 kB each)", "unit": "frames/s", "host_cores": os.cpu_count(), "usable_cpus": usable_cpus()}
     for key, threads in (("decode_1_thread", 1), ("decode_all_threads", 0)):
         t0, n = time.perf_counter(), 0
         while time.perf_counter() - t0 < 1.0:
@@ -916,7 +943,8 @@ def cpu_baseline(wl, args):
     out = {"value": round(n / secs, 3), "unit": "stereo-pairs/s", "cores": 1, "kind": "port",
            "sample": f"{n} consecutive stereo pairs of one {wl.width}x{wl.height} stream of the `value` workload, "
                      f"{p.detector.max_features_per_frame} features, mode={wl.mode}, {secs:.1f} s on one host core "
-                     f"(scalar OpenCV-faithful restatement, no SIMD/IPP; host has {os.cpu_count()} cores)"}
+                     f"(scalar OpenCV-faithful restatement, no SIMD/IPP; host has {os.cpu_count()} hardware threads, "
+                     f"{usable_cpus()} usable under the container's CPU quota)"}
     # independent streams on the host's cores (one single-threaded front-end per core, the
     # many-sequence mode on the CPU), bounded to a few seconds; best of 3
     try:
@@ -933,6 +961,7 @@ def cpu_baseline(wl, args):
                 pool.map(_cpu_worker_run, range(C_))
                 walls.append(time.perf_counter() - t0)
         out["all_cores"] = {"value": round(C_ * m / min(walls), 2), "unit": "stereo-pairs/s", "cores": C_,
+                            "usable_cpus": usable_cpus(),
                             "sample": f"{C_} processes x {m} pairs of the same stream, best of 3 "
                                       f"({min(walls):.1f} s wall; all: {[round(w, 1) for w in walls]})"}
     except Exception as e:  # the single-core figure above is the contract; this one is informative

@@ -128,6 +128,25 @@ def test_png_every_filter_type_and_split_idat():
         assert np.array_equal(np.asarray(PIL.open(io.BytesIO(data))), img)   # the encoder above is sound
 
 
+def test_png_runs_of_average_and_paeth_rows():
+    """round 5: runs of Average / Paeth rows of 8-bit grey are undone four (or two) rows at a time as a wavefront
+    (host_input.cpp unfilter_wave): every run length 1..9 between rows of the other types, both orders of the two types
+    inside a run, widths from below the wavefront's minimum to a full EuRoC row, against PIL"""
+    rng = np.random.default_rng(17)
+    for w in (1, 3, 7, 8, 9, 31, 752):
+        seq = []
+        for run in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+            seq += [int(t) for t in rng.integers(3, 5, run)] + [int(rng.integers(0, 3))]
+        seq += [4] * 11 + [3] * 5 + [4, 3] * 6        # long runs, the image's last rows inside one
+        h = len(seq)
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        img[h // 3: h // 2] = (np.arange(w) * 3 % 256).astype(np.uint8)   # smooth rows: the predictors matter
+        rows = [img[y].tobytes() for y in range(h)]
+        data = make_png(rows, w, 8, 0, tuple(seq), idat_split=2)
+        assert np.array_equal(np.asarray(PIL.open(io.BytesIO(data))), img)   # the encoder above is sound
+        assert np.array_equal(dp.decode_png_gray(data), img), w
+
+
 @pytest.mark.parametrize("interlace", [False, True])
 def test_png_colour_types_and_depths(interlace):
     rng = np.random.default_rng(11)
