@@ -793,7 +793,8 @@ KVFE_API kvfe_status kvfe_png_info(const uint8_t* data, size_t size, int32_t* wi
                                    int32_t* channels);
 KVFE_API kvfe_status kvfe_png_decode_gray(const uint8_t* data, size_t size, uint8_t* dst, size_t dst_stride,
                                           int32_t width, int32_t height);
-/* n files by `threads` host threads (<= 0: one per file, at most the hardware concurrency) straight into the
+/* n files by `threads` host threads (<= 0: one per file, at most the processors this process may use -- hardware
+ * threads cut down to its affinity mask and its cgroup CPU quota) straight into the
  * caller's buffers -- typically the pinned staging slot of kvfe_frontend_staging_buffer.  status[i] per file
  * (may be NULL); returns the first failure. */
 KVFE_API kvfe_status kvfe_png_decode_gray_batch(const uint8_t* const* data, const size_t* sizes,
