@@ -394,6 +394,9 @@ def compact_line(result):
         v = result.get(k)
         if isinstance(v, dict) and "value" in v:
             legs[k] = v["value"]
+    ins = result.get("input_side")
+    if isinstance(ins, dict) and "stereo_pairs_per_s_all_threads" in ins:   # host side: PNG decode on the usable CPUs
+        legs["input_side_host_decode"] = ins["stereo_pairs_per_s_all_threads"]
     if legs:
         line["legs_pairs_per_s"] = legs
     for k in ("value_is", "device_warm_up_ok", "collective_backend", "detail"):

@@ -36,7 +36,7 @@ def synthetic_result(blow=1):
            "collective_backend": "nccl (RCCL), world 1: barrier + timing all_reduce"}
     for k in bench.LEG_SCALARS:
         res[k] = dict(leg)
-    res["input_side"] = {"decode_all_threads": 12000.0}
+    res["input_side"] = {"decode_all_threads": 12000.0, "stereo_pairs_per_s_all_threads": 6000.0, "usable_cpus": 16}
     return res
 
 
@@ -58,7 +58,7 @@ def test_bench_line_is_small_and_round_trips(blow):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["all_cores_value"] == 540.0
-    assert set(d["legs_pairs_per_s"]) == set(bench.LEG_SCALARS)
+    assert set(d["legs_pairs_per_s"]) == set(bench.LEG_SCALARS) | {"input_side_host_decode"}
     assert all(isinstance(v, float) for v in d["legs_pairs_per_s"].values())
     assert "workload" in d["config"] and "model" not in d["config"]
 
