@@ -396,7 +396,8 @@ def compact_line(result):
             legs[k] = v["value"]
     ins = result.get("input_side")
     if isinstance(ins, dict) and "stereo_pairs_per_s_all_threads" in ins:   # host side: PNG decode on the usable CPUs
-        legs["input_side_host_decode"] = ins["stereo_pairs_per_s_all_threads"]
+        legs["input_side_host_decode"] = max(ins["stereo_pairs_per_s_all_threads"],
+                                             ins.get("stereo_pairs_per_s_all_threads_128_files_per_call", 0.0))   # (64 / 128 files per call)
     if legs:
         line["legs_pairs_per_s"] = legs
     for k in ("value_is", "device_warm_up_ok", "collective_backend", "detail"):
