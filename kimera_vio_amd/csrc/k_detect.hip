@@ -2186,16 +2186,18 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 4 : 2) void subpix_append_kernel
 // step runs at ~1 instruction per SIMD and 4 cycles, whatever its category), and the one-corner-per-block kernel above
 // spends 900 of its 1 900 vector instructions per corner and iteration on the five sequential float64 chains: 448
 // v_fmac_f64_dpp per wave with FOUR useful lanes in one wave and ONE in the other.  Here a lane IS a chain:
-//   * block = SPG_G corners of one stream, 256 threads;
-//   * patch phase: 32 threads per corner compute cv::getRectSubPix's 23 x 23 float patch from the corner's u8 stage in
-//     LDS (the same device functions as above: rect_subpix_from_stage / _border_from_stage, 17 entries per thread);
-//   * term phase: waves 1-3 turn patches into the five float64 terms of every window pixel, SPG_KC window pixels of all
-//     corners per chunk, into one of two LDS chunk buffers laid out [pixel][chain][corner];
+//   * block = SPG_G corner SLOTS of one stream, 512 threads; a slot whose corner is done takes the stream's next one;
+//   * patch phase: one wave per slot computes cv::getRectSubPix's 23 x 23 float patch from the corner's u8 stage in LDS
+//     (rect_subpix_from_stage_w64 / rect_subpix_border_from_stage, 9 entries per lane);
+//   * term phase: waves 1-7 turn patches into the five float64 terms of every window pixel, SPG_KC window pixels of all
+//     corners per chunk (one term set per thread), into one of two LDS chunk buffers laid out [pixel][chain][corner];
 //   * chain phase: wave 0, lane = 8 chain + corner (40 lanes), adds its chain's terms in window order -- one
-//     ds_read_b64 + one v_add_f64 per term for ALL corners of the block -- while waves 1-3 produce the next chunk;
-//   * solve: lanes 0..7 of wave 0, one corner each, the 2 x 2 system and the convergence test.
-// Same operations in the same order per corner as corner_subpix_wave_t => bit-identical (tests/test_gpu_subpix_r4.py
-// runs both kernels on the same corners).  ~650 instead of ~1 900 instructions per corner and iteration.
+//     ds_read_b64 + one v_add_f64 per term for ALL corners of the block -- while waves 1-7 produce the next chunk;
+//   * solve: lanes 0..7 of wave 0, one corner each, the 2 x 2 system, the convergence test and the refill.
+// Same operations in the same order per corner as corner_subpix_wave_t => bit-identical
+// (tests/test_gpu_bench_configs.py::test_grouped_corner_subpix_kernel_forced runs the small configurations through this
+// kernel, ::test_c3e_real_frames_64_streams takes it by itself).  ~600 instead of ~1 900 instructions per corner and
+// iteration.  What an iteration costs and what bounds it: profiles/r5_analysis.md sections 10 and 12.
 // Used for many streams; a few streams (latency bound, few corners) keep the four-waves-per-corner kernel, and so do
 // windows other than 10 and images smaller than the 36 x 36 stage.
 // ---------------------------------------------------------------------------------------------
@@ -2344,7 +2346,7 @@ __global__ __launch_bounds__(SPG_T, 4) void subpix_group_kernel(KParams P, Table
       deck_state = 3;   // (a slot found the counter past the end)
     }
   }
-  int eij[MAXP];   // patch entries e = sub + 32 t of the (2w+3)^2 window
+  int eij[MAXP];   // patch entries e = sub + 64 t of the (2w+3)^2 window
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
     const int e = sub + TPC * t, i = e / pw;
