@@ -112,6 +112,93 @@ def test_c3_with_the_context_owned_level0_copy():
     _run_workload(wl, 5, [0, 7, 63], persist=0)
 
 
+_BURST = {}
+
+
+def _burst_expectation(wl, n_steps):
+    """the oracle over all unique streams of the headline workload for `n_steps` steps (shared by the two burst tests:
+    ~6 s of CPU): [step][unique stream] -> oracle record"""
+    key = (wl.name, wl.mode, n_steps)
+    if key not in _BURST:
+        fes = [O.Frontend(wl.left, wl.right, wl.params) for _ in range(wl.unique)]
+        out = []
+        for (t, ts, Rs, force) in wl.plan(n_steps):
+            out.append([fes[u].process(wl.lefts[t, u], wl.rights[t, u], ts, Rs[u], bool(force))
+                        for u in range(wl.unique)])
+        _BURST[key] = out
+    return _BURST[key]
+
+
+def _assert_burst_shape(wl, exp):
+    """Tracker.cpp:167-180: every feature of a synthetic stream is born in frame 0, so at step maxFeatureAge + 1 (the
+    first step where age > maxFeatureAge) the whole list passes the age limit at once, only the corners detected
+    after frame 0 survive the tracker and the detector refills the frame"""
+    age = wl.params.tracker.max_feature_track_age
+    assert age == 25, age
+    for u in range(wl.unique):
+        before, burst = exp[age][u], exp[age + 1][u]
+        assert before["n_tracked"] > 400, (u, before["n_tracked"])
+        # the survivors of the burst step are the few corners detected after frame 0, everything else expired
+        assert burst["n_tracked"] < 0.5 * before["n_tracked"], (u, burst["n_tracked"], before["n_tracked"])
+        assert burst["n_detected"] > 250, (u, burst["n_detected"])
+
+
+def test_c3_headline_through_a_feature_age_burst():
+    """the headline's timed loop (bench.py `value`: c3, device_frames_persist = 0,
+    kvfe_frontend_step_device) runs through the step where every feature of a stream passes maxFeatureAge at once
+    (step 26, the 27th: lk.skip_age skips the whole list, ~440 corners per stream re-detected, the grouped cornerSubPix kernel
+    chosen by count, two heavy steps behind it).  30 steps, all 8 unique streams + replica 63 against the oracle on
+    every step, tolerance 0 (Tracker.cpp:167-180, StereoVisionImuFrontend.cpp:283-481)."""
+    import torch
+    wl = _build("c3", "kf")
+    n_steps = 30
+    exp = _burst_expectation(wl, n_steps)
+    _assert_burst_shape(wl, exp)
+    dev = torch.device("cuda", 0)
+    lefts, rights = wl.replicated()
+    d_left = torch.from_numpy(lefts).to(dev)
+    d_right = torch.from_numpy(rights).to(dev)
+    torch.cuda.synchronize()
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=wl.batch, device_frames_persist=0)
+    try:
+        for i, step in enumerate(wl.plan(n_steps)):
+            t = step[0]
+            ctx.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), wl.batch_inputs(ctx, step))
+            for s in list(range(8)) + [63]:
+                assert_step_equal(ctx.get_output(s), exp[i][wl.unique_of(s)], ("c3 burst", "step", i, "stream", s))
+    finally:
+        ctx.close()
+
+
+def test_c3_headline_burst_through_the_staged_input_path():
+    """the same 30 steps through kvfe_frontend_step_staged at batch 64 (bench.py's `pcie_inclusive` leg: the frames of
+    the ring sit in the context's pinned slots, every step uploads its pair on the copy stream behind the previous
+    step's kernels and is only enqueued); outputs read back one step late like a pipelined caller does"""
+    wl = _build("c3", "kf")
+    n_steps = 30
+    exp = _burst_expectation(wl, n_steps)
+    lefts, rights = wl.replicated()
+    ctx = F.Context(wl.left, wl.right, wl.params, batch=wl.batch)
+    check = list(range(8)) + [63]
+    try:
+        for sl in range(wl.ring):
+            a, b = ctx.staging_buffers(sl)
+            a[:] = lefts[sl]
+            b[:] = rights[sl]
+        plan = wl.plan(n_steps)
+        for i, step in enumerate(plan):
+            ctx.step_staged(step[0], wl.batch_inputs(ctx, step))         # enqueue only
+            if i > 0:                                                    # the previous step's record, one step back
+                for s in check:
+                    assert_step_equal(ctx.get_output(s, steps_back=1), exp[i - 1][wl.unique_of(s)],
+                                      ("c3 burst staged", "step", i - 1, "stream", s))
+        for s in check:
+            assert_step_equal(ctx.get_output(s), exp[n_steps - 1][wl.unique_of(s)],
+                              ("c3 burst staged", "step", n_steps - 1, "stream", s))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("mode", ["kf", "nominal"])
 def test_c2_single_euroc_stream_300_features_3_level_lk(mode):
     """BASELINE configs[1] as stated: EuRoC frames (MicroEuroc 10..18), 300 features, klt_max_level 2, shipped
