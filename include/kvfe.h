@@ -278,6 +278,11 @@ typedef struct kvfe_config {
   int32_t ssd_impl;              /* sparse stereo SSD search (searchRightKeypointEpipolar): 0 = on the matrix cores
                                     where the template / stripe geometry fits their lane maps (default), 1 = the
                                     v_dot4 search for every geometry                                               */
+  int32_t lk_impl;               /* pyramidal Lucas-Kanade launch of the front-end step (Tracker::featureTracking):
+                                    0 = eight points per wavefront, one float chain per lane (k_lk8.hip; windows of 16
+                                    and 24 pixels, default), 1 = one wavefront per point (k_track.hip lk_kernel_sys)
+                                    for every window.  Results are bit-identical; the component call kvfe_lk_track,
+                                    which returns the error array, always takes the second                         */
 } kvfe_config;
 
 typedef struct kvfe_ctx kvfe_ctx;

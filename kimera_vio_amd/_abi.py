@@ -170,7 +170,7 @@ class Config(C.Structure):
         ("depth", DepthParams),
         ("stream_groups", C.c_int32),
         ("device_frames_persist", C.c_int32), ("single_hip_stream", C.c_int32), ("copy_inputs", C.c_int32),
-        ("ssd_impl", C.c_int32),
+        ("ssd_impl", C.c_int32), ("lk_impl", C.c_int32),
     ]
 
 

@@ -493,7 +493,7 @@ kvfe_status validate(const kvfe_config* cfg, std::string* why) {
   if (cfg->left.width < 16 || cfg->left.height < 16) return fail("image too small", KVFE_ERR_INVALID_ARG);
   if (p.stereo.ssd_tie_policy != KVFE_SSD_TIE_EXACT && p.stereo.ssd_tie_policy != KVFE_SSD_TIE_F32)
     return fail("bad ssd_tie_policy", KVFE_ERR_INVALID_ARG);
-  for (int v : {cfg->device_frames_persist, cfg->single_hip_stream, cfg->copy_inputs, cfg->ssd_impl})
+  for (int v : {cfg->device_frames_persist, cfg->single_hip_stream, cfg->copy_inputs, cfg->ssd_impl, cfg->lk_impl})
     if (v != 0 && v != 1) return fail("execution options of kvfe_config are 0 or 1", KVFE_ERR_INVALID_ARG);
   if (p.use_ransac) {
     const kvfe_tracker_params& tr = p.tracker;
@@ -660,6 +660,7 @@ kvfe_status fill_params(kvfe_ctx* c) {
   }
   P.nlevels = nl;
   P.ssd_dot4 = cfg.ssd_impl == 1 ? 1 : 0;
+  P.lk_one = cfg.lk_impl == 1 ? 1 : 0;
   P.ssd_f32 = p.stereo.ssd_tie_policy == KVFE_SSD_TIE_F32 ? 1 : 0;
   P.klt_maxlevel = nl - 1;
   P.pyr_stride = std::max(off, 64);

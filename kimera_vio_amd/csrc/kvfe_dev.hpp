@@ -60,6 +60,7 @@ struct KParams {
   // pyramid geometry: level 0 is the raw image, levels 1..nlevels-1 live in the pyramid buffer
   int ssd_dot4;                      // kvfe_config.ssd_impl = 1: v_dot4 SSD search for every geometry
   int ssd_f32;                       // kvfe_stereo_params.ssd_tie_policy = KVFE_SSD_TIE_F32
+  int lk_one;                        // kvfe_config.lk_impl = 1: one wavefront per tracked point for every window
   int nlevels;
   int lw[MAX_LEVELS], lh[MAX_LEVELS], loff[MAX_LEVELS];
   int pyr_stride;  // bytes per stream in a pyramid buffer
@@ -300,6 +301,10 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
                const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true);
+// k_lk8.hip: eight points per wavefront (no error output); false when the window size is not covered
+bool launch_lk8(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride, size_t prev_img_stride,
+                const unsigned char* prev_pyr, const unsigned char* cur_img, size_t cur_row_stride,
+                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
                           const StreamState& S, const LkScratch& lk, hipStream_t st);

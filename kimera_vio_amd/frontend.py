@@ -44,7 +44,7 @@ class Context:
                  batch: int = 1, device: int = 0, hip_stream: int | None = None,
                  candidate_capacity: int = 0, stream_groups: int = 0, frontend_type: int = 0,
                  depth: "abi.DepthParams | None" = None, device_frames_persist: int = 0,
-                 single_hip_stream: int = 0, copy_inputs: int = 0, ssd_impl: int = 0):
+                 single_hip_stream: int = 0, copy_inputs: int = 0, ssd_impl: int = 0, lk_impl: int = 0):
         self.lib = load()
         cfg = abi.Config()
         cfg.left, cfg.right, cfg.params = left, right, params
@@ -57,6 +57,7 @@ class Context:
         cfg.single_hip_stream = single_hip_stream
         cfg.copy_inputs = copy_inputs
         cfg.ssd_impl = ssd_impl
+        cfg.lk_impl = lk_impl
         if depth is not None:   # RgbdVisionImuFrontend: CameraParams::DepthParams of `left`
             cfg.depth = depth
         self.depth_params = depth
