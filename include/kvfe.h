@@ -279,9 +279,9 @@ typedef struct kvfe_config {
                                     where the template / stripe geometry fits their lane maps (default), 1 = the
                                     v_dot4 search for every geometry                                               */
   int32_t lk_impl;               /* pyramidal Lucas-Kanade launch of the front-end step (Tracker::featureTracking):
-                                    0 = eight points per wavefront, one float chain per lane (k_lk8.hip; windows of 16
-                                    and 24 pixels, default), 1 = one wavefront per point (k_track.hip lk_kernel_sys)
-                                    for every window.  Results are bit-identical; the component call kvfe_lk_track,
+                                    0 = four points per wavefront, a quad of lanes per SSE lane class (k_lk4.hip; the
+                                    24-pixel window, pyramid levels of at least 32 x 32; default), 1 = one wavefront
+                                    per point (k_track.hip lk_kernel_sys) for every window.  Results are bit-identical; the component call kvfe_lk_track,
                                     which returns the error array, always takes the second                         */
 } kvfe_config;
 

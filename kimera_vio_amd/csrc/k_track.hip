@@ -771,16 +771,17 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
                const LkScratch& lk, int max_pts, hipStream_t st, bool want_err) {
   if (max_pts <= 0) return;
-  // the front-end step (no error output): eight points per wavefront unless kvfe_config.lk_impl = 1 / KVFE_LK_IMPL=1
-  // (the A/B switch of tools/ and bench.py) asks for the one-point kernel
+  // the front-end step (no error output): four points per wavefront (k_lk4.hip) unless kvfe_config.lk_impl = 1 /
+  // KVFE_LK_IMPL=1 (the A/B switch of tools/ and bench.py) asks for the one-point kernel; KVFE_LK_IMPL=8: the eight-point
+  // kernel of k_lk8.hip (slower: kept for the record of profiles/r6_analysis.md)
   static const int env_impl = [] { const char* e = std::getenv("KVFE_LK_IMPL"); return e ? std::atoi(e) : -1; }();
-  const bool one = env_impl >= 0 ? env_impl == 1 : true /* WIP: lk8 not yet the default */ || P.lk_one != 0;
+  const bool one = env_impl >= 0 ? env_impl == 1 : P.lk_one != 0;
   static const int env_cap = [] { const char* e = std::getenv("KVFE_LK8_CAP"); return e ? std::atoi(e) : 0; }();
-  const int iter_cap = env_cap > 0 ? env_cap : 5;
+  const int iter_cap = env_cap > 0 ? env_cap : 30;
   if (!want_err && !one && P.klt_win == 24) {
-    // the eight-point waves hand points that are still iterating after iter_cap iterations of a level to one-point waves
-    (void)hipMemsetAsync(lk.defer_cnt, 0, sizeof(int) * P.B, st);
-    if (launch_lk8(P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,
+    // (the multi-point waves can hand points that are still iterating after iter_cap iterations of a level to one-point waves)
+    if (iter_cap < P.klt_iters) (void)hipMemsetAsync(lk.defer_cnt, 0, sizeof(int) * P.B, st);
+    if ((env_impl == 8 ? launch_lk8 : launch_lk4)(P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,
                    cur_pyr, lk, max_pts, st, iter_cap)) {
       if (iter_cap < P.klt_iters)
         hipLaunchKernelGGL(lk_kernel_sys<24>, dim3(lk.defer_cap, P.B), dim3(64), 0, st, P, prev_img, prev_row_stride,

@@ -312,6 +312,11 @@ bool launch_lk8(const KParams& P, const unsigned char* prev_img, size_t prev_row
                 const unsigned char* prev_pyr, const unsigned char* cur_img, size_t cur_row_stride,
                 size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st,
                 int iter_cap);
+// k_lk4.hip: four points per wavefront (no error output); false when the window size / pyramid is not covered
+bool launch_lk4(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride, size_t prev_img_stride,
+                const unsigned char* prev_pyr, const unsigned char* cur_img, size_t cur_row_stride,
+                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st,
+                int iter_cap);
 constexpr int LK_DEFER_CAP = 128;   // deferred points per stream and launch (a point that finds the list full stays)
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
