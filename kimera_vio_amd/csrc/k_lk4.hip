@@ -43,9 +43,11 @@ namespace kvfe {
 #include "kvfe_lk.inl"
 
 // BORDER_REFLECT_101 index for -len < p < 2 len - 1 (one fold), branch-free so that the loads of a pass stay in flight
-// together: min(|p|, 2 len - 2 - |p|).  launch_lk4 refuses pyramids whose smallest level is narrower than LK4_MIN_DIM
-// (a window plus its staging margin could fold twice).
-constexpr int LK4_MIN_DIM = 32;
+// together: min(|p|, 2 len - 2 - |p|).  The indices this kernel forms lie in [-(WIN + 3), len + WIN + 4] (a window may start
+// WIN pixels outside the image, calcOpticalFlowPyrLK's own bound, plus the staging margin of 3 and the fifth byte of the
+// last column group): one fold covers them from len = WIN + 6 = 30 on.  launch_lk4 refuses pyramids with a smaller level
+// (the shipped five-level pyramid of 752 x 480 ends at 47 x 30).
+constexpr int LK4_MIN_DIM = 30;
 __device__ __forceinline__ int refl1(int p, int len) {
   const int q = max(p, -p);
   return min(q, 2 * len - 2 - q);
@@ -222,8 +224,7 @@ template <int WIN>
 __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned char* prev_img, size_t prev_row_stride,
                                                     size_t prev_img_stride, const unsigned char* prev_pyr,
                                                     const unsigned char* cur_img, size_t cur_row_stride,
-                                                    size_t cur_img_stride, const unsigned char* cur_pyr, LkScratch lk,
-                                                    int iter_cap) {
+                                                    size_t cur_img_stride, const unsigned char* cur_pyr, LkScratch lk) {
   using C = Lk4<WIN>;
   constexpr int NC = C::NC, NCH = C::NCH, NG = C::NG, WS = C::WS, WP = C::WP, NT = C::NT, PSTR = C::PSTR,
                 DSTR = C::DSTR, HROWS = C::HROWS, PROWS = C::PROWS, JM = C::JM, JS = C::JS, JW = C::JW, NJ = C::NJ,
@@ -269,7 +270,6 @@ __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned ch
   LK4P_DECL;
   for (int level = maxLevel; level >= 0; level--) {
     LK4P(6);
-    const float2 entryOut = nextOut;   // (the state a deferred point restarts this level from)
     const LevelImg LI = level_img(P, pimg, prev_row_stride, ppyr, level);
     const LevelImg LJ = level_img(P, cimg, cur_row_stride, cpyr, level);
     const float lscale = (float)(1. / (1 << level));
@@ -455,7 +455,6 @@ __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned ch
     int jx0 = 0, jy0 = 0;
     bool jvalid = false;
     bool active = lvl;
-    bool may_defer = true;
     int jboff = 2 * q * JSTRB + 2 * g;   // (a point that never staged a window reads its region's garbage: never used)
     LK4P(3);
     for (int j = 0; j < klt_iters; j++) {
@@ -572,23 +571,6 @@ __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned ch
           active = false;
         }
         prevDelta = delta;
-        // still iterating after iter_cap iterations of this level: the other points of the wave would wait for this one in
-        // lock step -- hand it to a one-point wave (lk_kernel_sys, deferred pass), which redoes the level from its start
-        if (active && may_defer && j + 1 >= iter_cap && j + 1 < klt_iters) {
-          int di = 0;
-          if (l16 == 0) di = atomicAdd(&lk.defer_cnt[s], 1);
-          di = __shfl(di, pbase);
-          if (di < lk.defer_cap) {
-            if (l16 == 0) {
-              lk.defer_pt[(size_t)s * lk.defer_cap + di] = pt | (level << 24);
-              lk.next_pts[po] = entryOut;
-            }
-            valid = false;
-            active = false;
-          } else {
-            may_defer = false;   // (list full: the point stays)
-          }
-        }
       }
     }
 
@@ -618,8 +600,7 @@ __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned ch
 
 bool launch_lk4(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride, size_t prev_img_stride,
                 const unsigned char* prev_pyr, const unsigned char* cur_img, size_t cur_row_stride,
-                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st,
-                int iter_cap) {
+                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st) {
   if (P.klt_win != 24) return false;
   for (int l = 0; l < P.nlevels; l++)
     if (P.lw[l] < LK4_MIN_DIM || P.lh[l] < LK4_MIN_DIM) return false;   // (refl1: one fold)
@@ -642,7 +623,7 @@ bool launch_lk4(const KParams& P, const unsigned char* prev_img, size_t prev_row
   }
 #endif
   hipLaunchKernelGGL(lk4_kernel<24>, grid, block, 0, st, P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
-                     cur_row_stride, cur_img_stride, cur_pyr, lk, iter_cap);
+                     cur_row_stride, cur_img_stride, cur_pyr, lk);
   return true;
 }
 

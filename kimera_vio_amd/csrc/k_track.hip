@@ -373,18 +373,8 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams
   // split over two HIP streams; both lost their A/B and were removed in round 4)
   const bool want_err = !(use_order & 8);
   const int s = blockIdx.y, rank = blockIdx.x;
-  // flags bit 4: the deferred pass behind k_lk8.hip -- wave `rank` finishes point defer_pt[s][rank] from the start of the
-  // level it was deferred at (next_pts holds the flow estimate on entry to that level)
-  const bool deferred = (use_order & 16) != 0;
-  int pt = rank, start_level = P.nlevels - 1;
-  if (deferred) {
-    if (rank >= min(lk.defer_cnt[s], lk.defer_cap)) return;
-    const int e = lk.defer_pt[(size_t)s * lk.defer_cap + rank];
-    pt = e & 0xffffff;
-    start_level = e >> 24;
-  } else if (rank >= lk.npts[s]) {
-    return;
-  }
+  if (rank >= lk.npts[s]) return;
+  const int pt = rank;
   int iters_total = 0;
   const int lane = threadIdx.x;
   const int g = lane >> 4, q = lane & 15;
@@ -406,7 +396,7 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams
   // reference tracks it and throws the result away.  The step passes the ages (lk.skip_age), and such a point is
   // reported lost without being tracked -- nothing reads its position or error.  (All features of a synthetic stream are
   // born in the bootstrap frame: every 26th step the whole list is in this state.)
-  if (!deferred && lk.skip_age && lk.skip_age[(size_t)s * P.kcap + lk.src_idx[po]] > P.max_age) {
+  if (lk.skip_age && lk.skip_age[(size_t)s * P.kcap + lk.src_idx[po]] > P.max_age) {
     if (threadIdx.x == 0) lk.status[po] = 0;
     return;
   }
@@ -423,7 +413,7 @@ __global__ __launch_bounds__(64, (WIN <= 24 ? 7 : 5)) void lk_kernel_sys(KParams
   const int y0w = 2 * qa, x0w = g;
   LKP_DECL;
 
-  for (int level = start_level; level >= 0; level--) {
+  for (int level = maxLevel; level >= 0; level--) {
     LKP(7);
     const LevelImg LI = level_img(P, pimg, prev_row_stride, ppyr, level);
     const LevelImg LJ = level_img(P, cimg, cur_row_stride, cpyr, level);
@@ -772,23 +762,13 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                const LkScratch& lk, int max_pts, hipStream_t st, bool want_err) {
   if (max_pts <= 0) return;
   // the front-end step (no error output): four points per wavefront (k_lk4.hip) unless kvfe_config.lk_impl = 1 /
-  // KVFE_LK_IMPL=1 (the A/B switch of tools/ and bench.py) asks for the one-point kernel; KVFE_LK_IMPL=8: the eight-point
-  // kernel of k_lk8.hip (slower: kept for the record of profiles/r6_analysis.md)
+  // KVFE_LK_IMPL=1 (the A/B switch of tools/ and bench.py) asks for the one-point kernel
   static const int env_impl = [] { const char* e = std::getenv("KVFE_LK_IMPL"); return e ? std::atoi(e) : -1; }();
   const bool one = env_impl >= 0 ? env_impl == 1 : P.lk_one != 0;
-  static const int env_cap = [] { const char* e = std::getenv("KVFE_LK8_CAP"); return e ? std::atoi(e) : 0; }();
-  const int iter_cap = env_cap > 0 ? env_cap : 30;
-  if (!want_err && !one && P.klt_win == 24) {
-    // (the multi-point waves can hand points that are still iterating after iter_cap iterations of a level to one-point waves)
-    if (iter_cap < P.klt_iters) (void)hipMemsetAsync(lk.defer_cnt, 0, sizeof(int) * P.B, st);
-    if ((env_impl == 8 ? launch_lk8 : launch_lk4)(P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,
-                   cur_pyr, lk, max_pts, st, iter_cap)) {
-      if (iter_cap < P.klt_iters)
-        hipLaunchKernelGGL(lk_kernel_sys<24>, dim3(lk.defer_cap, P.B), dim3(64), 0, st, P, prev_img, prev_row_stride,
-                           prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride, cur_pyr, lk, 8 | 16);
-      return;
-    }
-  }
+  if (!want_err && !one &&
+      launch_lk4(P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img, cur_row_stride, cur_img_stride,
+                 cur_pyr, lk, max_pts, st))
+    return;
   const int flags = want_err ? 0 : 8;   // (bit 3: no error output -- Tracker::featureTracking drops that vector)
   const dim3 grid(max_pts, P.B), block(64);
 #define KVFE_LK_SYS(WINSZ)                                                                                          \

@@ -369,9 +369,6 @@ kvfe_status alloc_buffers(kvfe_ctx* c, Buffers& b, const KParams& P) {
   TRY(dalloc(c, &b.lk.status, K));
   TRY(dalloc(c, &b.lk.err, K));
   TRY(dalloc(c, &b.lk.npts, B));
-  TRY(dalloc(c, &b.lk.defer_cnt, B));
-  TRY(dalloc(c, &b.lk.defer_pt, (size_t)B * LK_DEFER_CAP));
-  b.lk.defer_cap = LK_DEFER_CAP;
   b.lk.skip_age = nullptr;   // (set per launch by the front-end step)
   TRY(dalloc(c, &b.lk.src_idx, K));
   TRY(reset_tracker_status(c, b));

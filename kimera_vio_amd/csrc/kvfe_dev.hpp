@@ -246,12 +246,6 @@ struct LkScratch {
                           // than maxFeatureAge is reported lost untracked (the front-end step; Tracker.cpp:167-180)
   int* src_idx;           // [B][kcap] index of point i in frame k-1 (keypoints with landmark -1 are
                           //           not tracked, Tracker.cpp:103-112)
-  // k_lk8.hip: a point that is still iterating after `cap` iterations of a level leaves the eight-point wave (which would
-  // wait for it in lock step) and is finished by a one-point wave of lk_kernel_sys from the START of that level:
-  // defer_pt[s][i] = point | level << 24, next_pts[point] = the flow estimate on entry to that level
-  int* defer_cnt;         // [B]
-  int* defer_pt;          // [B][defer_cap]
-  int defer_cap;
   // dispatch order of the tracking launch (results do not depend on it): workgroup b of stream s tracks point
   // order[s][b] -- the points that took the most iterations in the previous frame first, so that the launch does not
   // end on a few slow points that started late; iters = iterations of this launch (saturated), carried to frame k
@@ -307,17 +301,10 @@ void launch_lk(const KParams& P, const unsigned char* prev_img, size_t prev_row_
                size_t prev_img_stride, const unsigned char* prev_pyr, const unsigned char* cur_img,
                size_t cur_row_stride, size_t cur_img_stride, const unsigned char* cur_pyr,
                const LkScratch& lk, int max_pts, hipStream_t st, bool want_err = true);
-// k_lk8.hip: eight points per wavefront (no error output); false when the window size is not covered
-bool launch_lk8(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride, size_t prev_img_stride,
-                const unsigned char* prev_pyr, const unsigned char* cur_img, size_t cur_row_stride,
-                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st,
-                int iter_cap);
 // k_lk4.hip: four points per wavefront (no error output); false when the window size / pyramid is not covered
 bool launch_lk4(const KParams& P, const unsigned char* prev_img, size_t prev_row_stride, size_t prev_img_stride,
                 const unsigned char* prev_pyr, const unsigned char* cur_img, size_t cur_row_stride,
-                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st,
-                int iter_cap);
-constexpr int LK_DEFER_CAP = 128;   // deferred points per stream and launch (a point that finds the list full stays)
+                size_t cur_img_stride, const unsigned char* cur_pyr, const LkScratch& lk, int max_pts, hipStream_t st);
 // predictor + gather of the reference keypoints (Tracker.cpp:103-129)
 void launch_track_prepare(const KParams& P, const Tables& T, const FrameTab& km1,
                           const StreamState& S, const LkScratch& lk, hipStream_t st);

@@ -112,6 +112,37 @@ def test_c3_with_the_context_owned_level0_copy():
     _run_workload(wl, 5, [0, 7, 63], persist=0)
 
 
+def test_lk_launch_forms_agree_on_the_headline_batch():
+    """round 6: kvfe_config.lk_impl -- 0 = four points per wavefront (k_lk4.hip, the default), 1 = one wavefront per point
+    (lk_kernel_sys).  Both are compared with the oracle elsewhere; here the whole 64-stream batch, every field of every
+    stream, on 8 steps of the headline workload and of its five-level (klt_max_level 4: a 47 x 30 top level, every
+    window of it on a border) variant."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for kw in (dict(), dict(klt_max_level=4, batch=16)):
+        wl = _build("c3", "kf", **kw)
+        lefts, rights = wl.replicated()
+        d_left = torch.from_numpy(lefts).to(dev)
+        d_right = torch.from_numpy(rights).to(dev)
+        torch.cuda.synchronize()
+        ctxs = [F.Context(wl.left, wl.right, wl.params, batch=wl.batch, device_frames_persist=1, lk_impl=i) for i in (0, 1)]
+        try:
+            for i, step in enumerate(wl.plan(8)):
+                t = step[0]
+                for c in ctxs:
+                    c.step_device(d_left[t].data_ptr(), d_right[t].data_ptr(), wl.batch_inputs(c, step))
+                for s in range(wl.batch):
+                    a, b = ctxs[0].get_output(s), ctxs[1].get_output(s)
+                    for k in ("n_keypoints", "n_tracked", "n_detected", "is_keyframe", "tracking_status_mono",
+                              "tracking_status_stereo", "n_measurements"):
+                        assert a[k] == b[k], (kw, i, s, k, a[k], b[k])
+                    for k in ("keypoints", "landmarks", "landmarks_age", "versors", "depth", "meas_uL_uR_v"):
+                        assert np.array_equal(a[k], b[k], equal_nan=True), (kw, i, s, k)
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 _BURST = {}
 
 

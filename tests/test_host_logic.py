@@ -364,6 +364,11 @@ def test_no_valu_to_dpp_hazard_in_inline_asm():
     n, bad = mod.check_hip(os.path.join(root, "kimera_vio_amd", "csrc", "k_track.hip"))
     assert n > 100, "the tracking kernels are expected to hold their DPP chains"
     assert not bad, bad[:5]
+    # round 6: the four-points-per-wave kernel adds its chain terms with quad-broadcast DPP additions right behind
+    # hand-scheduled blocks (v_dot2 / v_cvt in inline asm, ending in their own s_nop)
+    n, bad = mod.check_hip(os.path.join(root, "kimera_vio_amd", "csrc", "k_lk4.hip"))
+    assert n > 400
+    assert not bad, bad[:5]
     # round 5: the row minimum of the dense two-pass aggregation is four hand-written v_min_u32_dpp with their own s_nop
     n, bad = mod.check_hip(os.path.join(root, "kimera_vio_amd", "csrc", "k_dense.hip"))
     assert n > 100
