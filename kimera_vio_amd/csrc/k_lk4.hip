@@ -205,19 +205,43 @@ __device__ __forceinline__ void lk4_blend_row6(const int (&Ea)[6], const int (&E
         "v"(Eb[3]), "v"(Eb[4]), "v"(Eb[5]), "v"(wq0), "v"(wq1), "s"(c0), "n"(SH));
 }
 
-// acc += term of owner O, in all four lanes of the quad (one v_add_f32_dpp)
-template <int O>
-__device__ __forceinline__ void chain_add6(float& acc, const float (&t)[6]) {
-#pragma unroll
-  for (int k = 0; k < 6; k++) acc = acc + quad_bcast_f<O>(t[k]);
+// The chains.  `v_add_f32_dpp acc, term, acc quad_perm:[o,o,o,o]` adds owner o's term in all four lanes of the quad.  Written
+// as asm because hipcc pads EVERY VALU write -> DPP-instruction read with two wait states, also when the freshly written
+// register is the plain operand (the accumulator, src1) and not the permuted one (src0): one s_nop per addition of a
+// two-chain interleave.  The hardware hazard is on the DPP source only (it is read ahead of the operand forwarding); the
+// terms were written at least two instructions earlier (the producing blocks end in s_nop 1).
+#define LK4_QP(o) "quad_perm:[" #o "," #o "," #o "," #o "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define LK4_ADD2(o, a, b) "v_add_f32_dpp %0, %" #a ", %0 " LK4_QP(o) "v_add_f32_dpp %1, %" #b ", %1 " LK4_QP(o)
+#define LK4_OWNER2(o) LK4_ADD2(o, 2, 8) LK4_ADD2(o, 3, 9) LK4_ADD2(o, 4, 10) LK4_ADD2(o, 5, 11) LK4_ADD2(o, 6, 12) LK4_ADD2(o, 7, 13)
+#define LK4_ADD1(o, a) "v_add_f32_dpp %0, %" #a ", %0 " LK4_QP(o)
+#define LK4_OWNER1(o, b) LK4_ADD1(o, b##1) LK4_ADD1(o, b##2) LK4_ADD1(o, b##3) LK4_ADD1(o, b##4) LK4_ADD1(o, b##5) LK4_ADD1(o, b##6)
+// two independent chains, interleaved: the six terms ta / tb of every owner in owner (= row) order
+__device__ __forceinline__ void chain_owners_x2(float& a, const float (&ta)[6], float& b, const float (&tb)[6]) {
+  asm(LK4_OWNER2(0) LK4_OWNER2(1) LK4_OWNER2(2) LK4_OWNER2(3) "s_nop 0"
+      : "+v"(a), "+v"(b)
+      : "v"(ta[0]), "v"(ta[1]), "v"(ta[2]), "v"(ta[3]), "v"(ta[4]), "v"(ta[5]), "v"(tb[0]), "v"(tb[1]), "v"(tb[2]),
+        "v"(tb[3]), "v"(tb[4]), "v"(tb[5]));
 }
-template <int O>
-__device__ __forceinline__ void chain_add6x2(float& a, const float (&ta)[6], float& b, const float (&tb)[6]) {
-#pragma unroll
-  for (int k = 0; k < 6; k++) {   // (two independent chains, interleaved)
-    a = a + quad_bcast_f<O>(ta[k]);
-    b = b + quad_bcast_f<O>(tb[k]);
-  }
+// two rows per owner (the A chains of a level: twelve terms of every owner), two chains
+__device__ __forceinline__ void chain_owner_rows_x2(float& a, const float (&ta)[2][6], float& b, const float (&tb)[2][6]) {
+#define LK4_O2R(o) LK4_ADD2(o, 2, 14) LK4_ADD2(o, 3, 15) LK4_ADD2(o, 4, 16) LK4_ADD2(o, 5, 17) LK4_ADD2(o, 6, 18) LK4_ADD2(o, 7, 19) \
+                   LK4_ADD2(o, 8, 20) LK4_ADD2(o, 9, 21) LK4_ADD2(o, 10, 22) LK4_ADD2(o, 11, 23) LK4_ADD2(o, 12, 24) LK4_ADD2(o, 13, 25)
+  asm(LK4_O2R(0) LK4_O2R(1) LK4_O2R(2) LK4_O2R(3) "s_nop 0"
+      : "+v"(a), "+v"(b)
+      : "v"(ta[0][0]), "v"(ta[0][1]), "v"(ta[0][2]), "v"(ta[0][3]), "v"(ta[0][4]), "v"(ta[0][5]), "v"(ta[1][0]), "v"(ta[1][1]),
+        "v"(ta[1][2]), "v"(ta[1][3]), "v"(ta[1][4]), "v"(ta[1][5]), "v"(tb[0][0]), "v"(tb[0][1]), "v"(tb[0][2]), "v"(tb[0][3]),
+        "v"(tb[0][4]), "v"(tb[0][5]), "v"(tb[1][0]), "v"(tb[1][1]), "v"(tb[1][2]), "v"(tb[1][3]), "v"(tb[1][4]), "v"(tb[1][5]));
+#undef LK4_O2R
+}
+// ... and one chain
+__device__ __forceinline__ void chain_owner_rows(float& a, const float (&ta)[2][6]) {
+#define LK4_O1R(o) LK4_ADD1(o, 1) LK4_ADD1(o, 2) LK4_ADD1(o, 3) LK4_ADD1(o, 4) LK4_ADD1(o, 5) LK4_ADD1(o, 6) \
+                   LK4_ADD1(o, 7) LK4_ADD1(o, 8) LK4_ADD1(o, 9) LK4_ADD1(o, 10) LK4_ADD1(o, 11) LK4_ADD1(o, 12)
+  asm(LK4_O1R(0) LK4_O1R(1) LK4_O1R(2) LK4_O1R(3) "s_nop 0"
+      : "+v"(a)
+      : "v"(ta[0][0]), "v"(ta[0][1]), "v"(ta[0][2]), "v"(ta[0][3]), "v"(ta[0][4]), "v"(ta[0][5]), "v"(ta[1][0]), "v"(ta[1][1]),
+        "v"(ta[1][2]), "v"(ta[1][3]), "v"(ta[1][4]), "v"(ta[1][5]));
+#undef LK4_O1R
 }
 
 template <int WIN>
@@ -412,15 +436,11 @@ __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned ch
           GY[j][r][cc] = pack_lo16(vy[2 * cc], vy[2 * cc + 1]);
         }
       }
-      // rows 8j + 2o + {0, 1} come from owner o: row order = owner order
-      chain_add6<0>(a11, pxx[0]); chain_add6<0>(a11, pxx[1]);
-      chain_add6<1>(a11, pxx[0]); chain_add6<1>(a11, pxx[1]);
-      chain_add6<2>(a11, pxx[0]); chain_add6<2>(a11, pxx[1]);
-      chain_add6<3>(a11, pxx[0]); chain_add6<3>(a11, pxx[1]);
-      chain_add6x2<0>(a12, pxy[0], a22, pyy[0]); chain_add6x2<0>(a12, pxy[1], a22, pyy[1]);
-      chain_add6x2<1>(a12, pxy[0], a22, pyy[0]); chain_add6x2<1>(a12, pxy[1], a22, pyy[1]);
-      chain_add6x2<2>(a12, pxy[0], a22, pyy[0]); chain_add6x2<2>(a12, pxy[1], a22, pyy[1]);
-      chain_add6x2<3>(a12, pxy[0], a22, pyy[0]); chain_add6x2<3>(a12, pxy[1], a22, pyy[1]);
+      // rows 8j + 2o + {0, 1} come from owner o: row order = owner order.  (The products are plain VALU results of the
+      // compiler's own instructions: two wait states before the first DPP read.)
+      asm volatile("s_nop 1");
+      chain_owner_rows_x2(a11, pxx, a12, pxy);
+      chain_owner_rows(a22, pyy);
     }
     LK4P(2);
 
@@ -545,10 +565,7 @@ __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned ch
         float tx[6], ty[6];
         lk4_terms12(dd, reinterpret_cast<const int(&)[6]>(GX[jg][0][0]), reinterpret_cast<const int(&)[6]>(GY[jg][0][0]),
                     tx, ty);
-        chain_add6x2<0>(b1c, tx, b2c, ty);
-        chain_add6x2<1>(b1c, tx, b2c, ty);
-        chain_add6x2<2>(b1c, tx, b2c, ty);
-        chain_add6x2<3>(b1c, tx, b2c, ty);
+        chain_owners_x2(b1c, tx, b2c, ty);
       }
       // bbuf = qb0 + qb1 ; ib1 += bbuf[0] + bbuf[2] ; ib2 += bbuf[1] + bbuf[3]: classes (0, 2) and (1, 3) first -- the
       // row rotated by two quads, then by one (float addition is commutative: every lane ends with the same two sums)
