@@ -955,6 +955,11 @@ typedef struct kvfe_stage_times {
  * stream the stage runs on (recording every step costs ~10 % at 64 streams: 24 extra stream ops) */
 KVFE_API kvfe_status kvfe_profile_enable(kvfe_ctx* ctx, int32_t on);
 KVFE_API kvfe_status kvfe_profile_read(kvfe_ctx* ctx, kvfe_stage_times* out);
+/* what a plain streaming copy (one 16-byte load + one 16-byte store per lane and trip) reaches on the current device, in
+ * this process: `iters` copies of `bytes` bytes between two freshly allocated buffers, HIP events around them.
+ * *read_plus_write_GBps = 2 * bytes * iters / time.  bench.py prints it beside the roofline fractions (which stay
+ * quoted against the guide's 8 TB/s) so that a slow box can be told from a regression.  No reference counterpart.      */
+KVFE_API kvfe_status kvfe_hbm_copy_probe(size_t bytes, int32_t iters, double* read_plus_write_GBps, double* ms_per_copy);
 
 #ifdef __cplusplus
 }

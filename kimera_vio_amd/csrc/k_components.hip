@@ -196,4 +196,61 @@ void launch_out_pack(const KParams& P, const FrameTab& k, const StereoTab& ST, c
   hipLaunchKernelGGL(out_pack_kernel, dim3((unsigned)P.B), dim3(256), 0, st, P, k, ST, S, dst, table_bytes, rec_cap);
 }
 
+// ---------------------------------------------------------------------------------------------
+// kvfe_hbm_copy_probe (measurement hook, bench.py): what a plain streaming copy reaches on THIS device in THIS process.
+// The dense kernels' roofline fractions are quoted against the guide's 8 TB/s; boxes of this pool differ by up to 2 x on
+// the same binary, and this number beside them tells a slow box from a regression.  One 16-byte load and one 16-byte
+// store per lane and trip, grid-stride, 2048 workgroups of 256 (8 per compute unit).
+// ---------------------------------------------------------------------------------------------
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const probe_f4* __restrict__ src, probe_f4* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {   // four independent requests in flight per lane
+    const probe_f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const probe_f4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i);
+    __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride);
+    __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  }
+  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 }  // namespace kvfe
+
+extern "C" KVFE_API kvfe_status kvfe_hbm_copy_probe(size_t bytes, int32_t iters, double* read_plus_write_GBps,
+                                                    double* ms_per_copy) {
+  if (bytes < 16 || iters < 1 || !read_plus_write_GBps) return KVFE_ERR_INVALID_ARG;
+  const size_t n = bytes / 16;
+  kvfe::probe_f4 *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = nullptr;
+  kvfe_status rc = KVFE_ERR_HIP;
+  float ms = 0.f;
+  if (hipMalloc(&src, n * 16) != hipSuccess || hipMalloc(&dst, n * 16) != hipSuccess) goto out;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) goto out;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) goto out;
+  if (hipMemsetAsync(src, 0x5a, n * 16, st) != hipSuccess || hipMemsetAsync(dst, 0, n * 16, st) != hipSuccess) goto out;
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL(kvfe::hbm_copy_kernel, dim3(2048), dim3(256), 0, st, src, dst, n);
+  if (hipEventRecord(e0, st) != hipSuccess) goto out;
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kvfe::hbm_copy_kernel, dim3(2048), dim3(256), 0, st, src, dst, n);
+  if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) goto out;
+  if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) goto out;
+  {
+    unsigned char probe[16];
+    if (hipMemcpy(probe, reinterpret_cast<unsigned char*>(dst) + (n - 1) * 16, 16, hipMemcpyDeviceToHost) != hipSuccess) goto out;
+    for (unsigned char b : probe)
+      if (b != 0x5a) goto out;   // (the copy really ran)
+  }
+  *read_plus_write_GBps = 2.0 * (double)(n * 16) * iters / ((double)ms * 1e6);
+  if (ms_per_copy) *ms_per_copy = (double)ms / iters;
+  rc = KVFE_OK;
+out:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  return rc;
+}

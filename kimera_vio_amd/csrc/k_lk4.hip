@@ -248,21 +248,34 @@ template <int WIN>
 __global__ __launch_bounds__(64, 3) void lk4_kernel(KParams P, const unsigned char* prev_img, size_t prev_row_stride,
                                                     size_t prev_img_stride, const unsigned char* prev_pyr,
                                                     const unsigned char* cur_img, size_t cur_row_stride,
-                                                    size_t cur_img_stride, const unsigned char* cur_pyr, LkScratch lk) {
+                                                    size_t cur_img_stride, const unsigned char* cur_pyr, LkScratch lk,
+                                                    int order) {
   using C = Lk4<WIN>;
   constexpr int NC = C::NC, NCH = C::NCH, NG = C::NG, WS = C::WS, WP = C::WP, NT = C::NT, PSTR = C::PSTR,
                 DSTR = C::DSTR, HROWS = C::HROWS, PROWS = C::PROWS, JM = C::JM, JS = C::JS, JW = C::JW, NJ = C::NJ,
                 JSTRB = C::JSTRB, JH = C::JH;
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * C::RB];
 
-  const int s = blockIdx.y;
+  // Dispatch order (results do not depend on it).  The launch ends on the few waves that hold a point running all 30
+  // iterations on every level (~0.11 ms for such a wave alone), so those should start EARLY.  They sit at the END of a
+  // stream's list -- the youngest landmarks: corners the detector appended last, which have not yet survived a track -- so
+  // a stream's blocks are taken in reverse (order & 1), and consecutive workgroups take the same block of consecutive
+  // streams (order & 2) so that every stream's last blocks are among the first dispatched: 0.325 -> 0.262 ms at 64 x 600
+  // points (tools/r6/gpu_lk4_order.sh; KVFE_LK4_ORDER=0..3 is the A/B switch, 3 the default)
+  int bx = blockIdx.x, s = blockIdx.y;
+  if (order & 2) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    s = lin % gridDim.y;
+    bx = lin / gridDim.y;
+  }
   const int npts = lk.npts[s];
-  if ((int)blockIdx.x * 4 >= npts) return;
+  if (order & 1) bx = (npts + 3) / 4 - 1 - bx;
+  if (bx < 0 || bx * 4 >= npts) return;
   const int lane = threadIdx.x;
   const int slot = lane >> 4, l16 = lane & 15, g = l16 >> 2, q = l16 & 3;
   const int tcol = l16 & 7, half = l16 >> 3;   // set-up role: column group, half of the rows
   const int pbase = lane & ~15;
-  const int pt = blockIdx.x * 4 + slot;
+  const int pt = bx * 4 + slot;
   bool valid = pt < npts;
   const size_t po = (size_t)s * P.kcap + (valid ? pt : 0);
   // Tracker.cpp:167-180 drops a point whose landmark is older than maxFeatureAge whatever its tracking result; the step
@@ -622,6 +635,7 @@ bool launch_lk4(const KParams& P, const unsigned char* prev_img, size_t prev_row
   for (int l = 0; l < P.nlevels; l++)
     if (P.lw[l] < LK4_MIN_DIM || P.lh[l] < LK4_MIN_DIM) return false;   // (refl1: one fold)
   const dim3 grid((max_pts + 3) / 4, P.B), block(64);
+  static const int order = [] { const char* e = std::getenv("KVFE_LK4_ORDER"); return e ? std::atoi(e) : 3; }();
 #ifdef KVFE_LK4_PROF
   {
     static bool reg = false;
@@ -640,7 +654,7 @@ bool launch_lk4(const KParams& P, const unsigned char* prev_img, size_t prev_row
   }
 #endif
   hipLaunchKernelGGL(lk4_kernel<24>, grid, block, 0, st, P, prev_img, prev_row_stride, prev_img_stride, prev_pyr, cur_img,
-                     cur_row_stride, cur_img_stride, cur_pyr, lk);
+                     cur_row_stride, cur_img_stride, cur_pyr, lk, order);
   return true;
 }
 

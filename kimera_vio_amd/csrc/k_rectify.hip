@@ -1017,6 +1017,8 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
       // streams of 752 x 480) was removed in round 4: its first test at such a batch size failed the level-0 copy.
       int T2 = 4;
       while (T2 > 2 && (long long)P.B * nwx * ((h2 + T2 - 1) / T2) < 1536) T2 >>= 1;
+      static const int t2_env = [] { const char* e = std::getenv("KVFE_PYR2_T2"); return e ? std::atoi(e) : 0; }();
+      if (t2_env == 1 || t2_env == 2 || t2_env == 4) T2 = t2_env;
       const int NS = two ? (h2 + T2 - 1) / T2 : (h1 + 2 * T2 - 1) / (2 * T2);
       const int xcd = P.B >= 8 ? 1 : 0;
       const int nblk = xcd ? 8 * ((P.B + 7) / 8) * NS * nwx : P.B * NS * nwx;
@@ -1032,7 +1034,8 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
     else KVFE_PYR2(T2_, false, false);               \
   } while (0)
       if (T2 == 4) KVFE_PYR2_T(4);
-      else KVFE_PYR2_T(2);
+      else if (T2 == 2) KVFE_PYR2_T(2);
+      else KVFE_PYR2_T(1);
 #undef KVFE_PYR2_T
 #undef KVFE_PYR2
       if (two) l++;

@@ -563,6 +563,17 @@ class Context:
                             for i in range(st.n_stages)})
 
 
+def hbm_copy_probe(nbytes=1 << 30, iters=10) -> dict:
+    """kvfe_hbm_copy_probe on the current device: read + write GB/s of a plain 16-byte-per-lane streaming copy of
+    `nbytes` bytes (measurement hook: tells a slow box from a regression; no reference counterpart)"""
+    L = load()
+    g, ms = C.c_double(0.0), C.c_double(0.0)
+    st = L.kvfe_hbm_copy_probe(int(nbytes), int(iters), C.byref(g), C.byref(ms))
+    if st != 0:
+        raise KvfeError(st, "hbm_copy_probe", L.kvfe_status_string(st).decode())
+    return dict(read_plus_write_GBps=g.value, ms_per_copy=ms.value, bytes=int(nbytes), iters=int(iters))
+
+
 # reference-shaped aliases ------------------------------------------------------------------------
 class OutputBuffers:
     """kvfe_frame_output[batch] with their arrays, allocated once: `read(steps_back)` = kvfe_frontend_get_outputs -- one

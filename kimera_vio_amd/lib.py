@@ -98,6 +98,8 @@ def load() -> C.CDLL:
     L.kvfe_frontend_view_output.argtypes = [vp, i32, i32, C.POINTER(abi.FrameOutput)]
     L.kvfe_profile_enable.argtypes = [vp, i32]
     L.kvfe_profile_read.argtypes = [vp, C.POINTER(abi.StageTimes)]
+    L.kvfe_hbm_copy_probe.argtypes = [C.c_size_t, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.kvfe_hbm_copy_probe.restype = C.c_int32
     f32 = C.c_float
     L.kvfe_check_undistorted_rectified_left_keypoints.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp]
     L.kvfe_distort_unrectify_keypoints.argtypes = [vp, i32, vp, vp, i32, vp]
@@ -182,6 +184,7 @@ def load() -> C.CDLL:
     return L
 
 
+NEW_R6_SYMBOLS = ["kvfe_hbm_copy_probe"]
 NEW_R3_SYMBOLS = ["kvfe_build_optical_flow_pyramid"]
 NEW_R4_SYMBOLS = ["kvfe_frontend_get_output_at", "kvfe_frontend_get_outputs", "kvfe_frontend_view_output"]
 
@@ -204,7 +207,7 @@ INPUT_SIDE_SYMBOLS = [
     "kvfe_stereo_sync_shutdown", "kvfe_stereo_sync_next", "kvfe_euroc_parse_camera_csv", "kvfe_euroc_parse_imu_csv",
 ]
 
-EXPORTED_SYMBOLS = NEW_R4_SYMBOLS + NEW_R3_SYMBOLS + NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
+EXPORTED_SYMBOLS = NEW_R6_SYMBOLS + NEW_R4_SYMBOLS + NEW_R3_SYMBOLS + NEW_R2_SYMBOLS + INPUT_SIDE_SYMBOLS + [
     "kvfe_version", "kvfe_status_string", "kvfe_last_error", "kvfe_default_frontend_params",
     "kvfe_create", "kvfe_destroy", "kvfe_compute_rectification",
     "kvfe_compute_undistort_rectify_maps", "kvfe_get_rectification", "kvfe_undistort_rectify_image",

@@ -18,7 +18,7 @@ def synthetic_result(blow=1):
            "repeats": {"values": [1.0] * 30 * blow}, "roofline_kernels": [{"kernel": "k", "frac": 0.1}] * 10 * blow}
     rf = {"kernel": "mineig_localmax", "bound": "hbm", "achieved": 295.23, "peak": 8000.0, "unit": "GB/s", "frac": 0.0369,
           "traffic": 20925850, "traffic_source": "committed profiles/pmc_traffic_latest.json " + "x" * 200 * blow,
-          "alg_bytes_per_launch": 23101440, "avg_launch_ms": 0.07825, "launches_sampled": 15,
+          "alg_bytes_per_launch": 23101440, "avg_launch_ms": 0.07825, "launches_sampled": 15, "frac_of_copy": 0.0601,
           "valu_issue": {"note": "n" * 500 * blow}}
     res = {"metric": "stereo-pairs/sec front-end (detect+track+match) @752x480", "value": 58000.12, "unit": "stereo-pairs/s",
            "n_gpus": 1, "steps": 40, "warmup": 8, "prewarm_steps_untimed": 0, "ms_per_step": 1.1, "higher_is_better": True,
@@ -27,6 +27,7 @@ def synthetic_result(blow=1):
                       "features": 600, "mode": "kf", "use_ransac": 1, "stream_groups": 1, "device_frames_persist": 0,
                       "parallelism": "streams x1"},
            "value_is": "median of 3 timed regions of exactly 40 steps each", "device_warm_up_ok": True,
+           "hbm_copy_GBps": 4912.3, "hbm_copy_probe": {"what": "p" * 300 * blow},
            "roofline": rf, "roofline_kernels": [dict(rf, kernel=k) for k in ("mineig_localmax", "rectify", "pyramid")],
            "roofline_dense_weighted": {"bound": "hbm", "achieved": 1100.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1375,
                                        "alg_bytes": 145800000, "sum_launch_ms": 0.13, "kernels": ["a", "b", "c"]},
@@ -58,6 +59,10 @@ def test_bench_line_is_small_and_round_trips(blow):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["all_cores_value"] == 540.0
+    # round 6: the copy rate of the box beside the fractions, the real-frame leg beside `value`
+    assert d["hbm_copy_GBps"] == 4912.3 and d["roofline"]["frac_of_copy"] == 0.0601
+    assert d["roofline_kernels_frac_of_copy"] == {k: 0.0601 for k in ("mineig_localmax", "rectify", "pyramid")}
+    assert d["kf_realistic_value"] == 12345.67 and d["kf_realistic_ms_per_step"] == 1.234
     assert set(d["legs_pairs_per_s"]) == set(bench.LEG_SCALARS) | {"input_side_host_decode"}
     assert all(isinstance(v, float) for v in d["legs_pairs_per_s"].values())
     assert "workload" in d["config"] and "model" not in d["config"]
