@@ -1012,11 +1012,13 @@ void launch_pyramid(const KParams& P, const unsigned char* img, size_t row_strid
         (!copy || (reinterpret_cast<uintptr_t>(level0_copy) % 16 == 0 && ((size_t)P.W * P.H) % 16 == 0))) {
       const int w0 = P.lw[l - 1], h0 = P.lh[l - 1], h1 = (h0 + 1) / 2, h2 = (h1 + 1) / 2;
       const int nl = w0 / 16, nwx = nl <= 62 ? 1 : 1 + (nl - 62 + 59) / 60;
-      // strip height: the halo costs (4 T2 + 9) / (4 T2) source rows, so strips are as tall as the chip stays busy with
-      // (a strip is one wave; its source rows live in registers).  T2 = 8 (~220 VGPRs, chosen only for more than ~100
-      // streams of 752 x 480) was removed in round 4: its first test at such a batch size failed the level-0 copy.
-      int T2 = 4;
-      while (T2 > 2 && (long long)P.B * nwx * ((h2 + T2 - 1) / T2) < 1536) T2 >>= 1;
+      // strip height: the halo costs (4 T2 + 9) / (4 T2) source rows (re-read from the XCD's L2, not from HBM: a stream's
+      // strips run on one XCD), against waves in flight: a strip is one wave and its source rows live in registers.
+      // Round 6 (tools/r6/gpu_pyr2_t2.sh, 64 x 752x480, same call, copy probe 4.4 - 4.7 TB/s): T2 = 4 (1 920 waves) 16.9 /
+      // 16.6 us alone, T2 = 2 (3 840 waves, ~110 VGPRs) 16.0 / 15.8, T2 = 1 (7 680 waves) 17.6 / 17.4 -- 53 MB of real traffic
+      // at 3.3 TB/s = 0.72 of what the plain copy kernel reaches on that box.  T2 = 2 everywhere; KVFE_PYR2_T2 is the A/B
+      // switch.  (T2 = 8 was removed in round 4: its first test at more than 100 streams failed the level-0 copy.)
+      int T2 = 2;
       static const int t2_env = [] { const char* e = std::getenv("KVFE_PYR2_T2"); return e ? std::atoi(e) : 0; }();
       if (t2_env == 1 || t2_env == 2 || t2_env == 4) T2 = t2_env;
       const int NS = two ? (h2 + T2 - 1) / T2 : (h1 + 2 * T2 - 1) / (2 * T2);

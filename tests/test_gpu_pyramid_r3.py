@@ -93,9 +93,10 @@ def test_pyramid_strided_rows():
 
 @pytest.mark.parametrize("n", [2, 60, 110])
 def test_pyramid_strip_heights(n):
-    """the strip height of pyr2_kernel follows the number of images of the call (2 second-level rows per wave for a few
-    images of 752 x 480, 4 from ~52 on): both instantiations, also at a batch far beyond the benchmark's 64 (the T2 = 8
-    instantiation that a 110-image call used to select failed this very test in round 4 and was removed)"""
+    """pyr2_kernel at a few, at the benchmark's and at far more images per call.  (Until round 5 the strip height followed the
+    number of images: 2 second-level rows per wave for a few 752 x 480 images, 4 from ~52 on, 8 beyond 100 -- the T2 = 8
+    instantiation failed this very test in round 4 and was removed.  Round 6: 2 rows per wave everywhere; the 1- and 4-row
+    instantiations stay behind KVFE_PYR2_T2 and tools/r6/gpu_pyr2_t2.sh runs this file under each.)"""
     w, h = 752, 480
     c = _ctx(w, h, 2, win=8)
     try:
