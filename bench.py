@@ -332,15 +332,17 @@ def run_frontend_leg(torch, F, dist, sharding, wl, dev, world, steps, warmup, re
         res["stage_ms_per_step_summed_over_groups"] = {k: round(v["ms_total"] / ns * g, 5) for k, v in stages.items()}
         if pmc_leg is not None and valu_ctx and B == 64 and W == 752 and "lk_track" in stages:
             lk_ms = stages["lk_track"]["ms_total"] / ns
-            vi = valu_issue(valu_ctx[0], "lk_kernel", lk_ms, valu_ctx[1], valu_ctx[2])
+            # (lk4_kernel from round 6 on; lk_kernel_sys with counters committed before it)
+            vi = (valu_issue(valu_ctx[0], "lk4_kernel", lk_ms, valu_ctx[1], valu_ctx[2]) or
+                  valu_issue(valu_ctx[0], "lk_kernel", lk_ms, valu_ctx[1], valu_ctx[2]))
             if vi:   # the largest kernel of the step is sparse (no HBM roofline); its VALU issue floor is reported, but the
-                # launch is bound by more than that count (profiles/r3_analysis.md)
+                # launch is bound by more than that count (profiles/r6_analysis.md)
                 res["largest_kernel"] = {"kernel": "lk_track", "avg_launch_ms": round(lk_ms, 5),
                                          "bound": "vector instruction issue weighted by instruction class (2.4 cycles for plain "
-                                                  "VOP2 float / integer, 3.7-3.9 for everything else: profiles/r3_ubench_valu_rate.txt) "
-                                                  "-- 4.9 k vector instructions per point, a third of them in the sequential float "
-                                                  "chains OpenCV's summation order dictates -- plus LDS waits (27 % of the wave cycles) "
-                                                  "and a 10-13 % tail of non-converging points; profiles/r3_analysis.md",
+                                                  "VOP2 float / integer, 3.7-3.9 for everything else: profiles/r3_ubench_valu_rate.txt); "
+                                                  "four points per wavefront, the sequential float chains OpenCV's summation order "
+                                                  "dictates in every lane of a quad (k_lk4.hip); the launch ends on the waves whose "
+                                                  "points run all 30 iterations on every level; profiles/r6_analysis.md",
                                          "valu_issue": vi}
         res["stream_groups"] = g
     return res
