@@ -269,7 +269,12 @@ typedef struct kvfe_config {
                                     per frame less), and the rectification / matching chain of step k -- which
                                     reads both images -- is joined by step k+1's keyframe decision instead of in
                                     front of its tracking launch.  0 (default): no caller
-                                    pointer outlives a step                                                       */
+                                    pointer is read after the step it was passed to has COMPLETED -- not "after the
+                                    call returned": the call only enqueues, and from round 5 on the step's
+                                    rectification / matching chain (which reads both images) runs on the side
+                                    stream beside the NEXT steps' tracking.  A caller that rewrites one buffer pair
+                                    must wait for the step (kvfe_synchronize, kvfe_frontend_get_output*) first;
+                                    rewriting it after merely enqueueing the next step is a race               */
   int32_t single_hip_stream;     /* 1 = every kernel of a step on the context's one HIP stream: no internal side
                                     stream (corner refinement beside rectification / matching) and no output stream.
                                     For callers that need strict single-stream order and for timing kernels alone  */

@@ -611,7 +611,13 @@ namespace {
 class DecodePool {
  public:
   static DecodePool& get() {
-    static DecodePool* p = new DecodePool();   // never destroyed: the workers may outlive static destruction
+    // never destroyed (the detached workers may outlive static destruction); at exit they are told to stop, so none of
+    // them is still spinning or decoding while the process tears its statics down
+    static DecodePool* p = [] {
+      DecodePool* q = new DecodePool();
+      std::atexit([] { DecodePool::get().shutdown(); });
+      return q;
+    }();
     return *p;
   }
   // runs fn(i) for i in [0, n) on `threads` threads in total (the caller is one of them); false = pool busy
@@ -652,12 +658,23 @@ class DecodePool {
     while (!state_.compare_exchange_weak(s, s & ~kOpen)) {
     }
     const int registered = (int)(s & kCount);
-    for (int spins = 0; done_.load(std::memory_order_acquire) != registered; spins++) {
-      if (spins < 20000) cpu_relax();
-      else std::this_thread::yield();
+    // a bounded spin (a helper is at most one file behind), then a blocking wait: under a cgroup CPU quota a descheduled
+    // helper must not have the caller burn the very quota it is waiting to be given
+    for (int spins = 0; done_.load(std::memory_order_acquire) != registered && spins < 20000; spins++) cpu_relax();
+    if (done_.load(std::memory_order_acquire) != registered) {
+      std::unique_lock<std::mutex> lk(mu_);
+      caller_waits_.store(true);
+      while (done_.load(std::memory_order_acquire) != registered)
+        cv_done_.wait_for(lk, std::chrono::milliseconds(2));   // (the timeout covers a notify that raced the flag)
+      caller_waits_.store(false);
     }
     job_ = nullptr;
     return true;
+  }
+  void shutdown() {
+    stop_.store(true);
+    { std::lock_guard<std::mutex> lk(mu_); }
+    cv_job_.notify_all();
   }
 
  private:
@@ -689,6 +706,7 @@ class DecodePool {
       uint64_t s;
       auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
       for (int spins = 0;;) {
+        if (stop_.load(std::memory_order_relaxed)) return;
         s = state_.load();
         if ((s >> 32) != seen) break;
         if ((++spins & 63) != 0 || std::chrono::steady_clock::now() < spin_until) {   // (the clock every 64th look)
@@ -697,7 +715,7 @@ class DecodePool {
         }
         std::unique_lock<std::mutex> lk(mu_);
         sleepers_.fetch_add(1);
-        cv_job_.wait(lk, [&] { return (state_.load() >> 32) != seen; });
+        cv_job_.wait(lk, [&] { return (state_.load() >> 32) != seen || stop_.load(); });
         sleepers_.fetch_sub(1);
         spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
       }
@@ -712,12 +730,17 @@ class DecodePool {
       if (!in) continue;   // (closed, full, or already the next batch: the loop above looks at it again)
       job_(job_ctx_);
       done_.fetch_add(1, std::memory_order_release);
+      if (caller_waits_.load()) {
+        { std::lock_guard<std::mutex> lk(mu_); }
+        cv_done_.notify_one();
+      }
     }
   }
   static constexpr int kSpinUs = 50;   // a worker spins this long for the next batch (a decoder that calls again at once finds it awake;
                                          // longer spins only burn the CPU quota of a container: 0.5 ms cost 12 % at 64 threads, tools/r5/gpu_ad.sh)
   std::mutex run_mu_, mu_;
-  std::condition_variable cv_job_;
+  std::condition_variable cv_job_, cv_done_;
+  std::atomic<bool> stop_{false}, caller_waits_{false};
   std::atomic<uint64_t> state_{0};
   std::atomic<int> done_{0}, sleepers_{0};
   // written by run() before it publishes the batch in state_, read by a worker after it has registered

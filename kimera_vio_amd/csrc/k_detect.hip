@@ -700,13 +700,7 @@ void launch_mineig(const KParams& P, const Tables& T, const unsigned char* img, 
     }
   }
 #endif
-  static int simds = 0;
-  if (!simds) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                ? prop.multiProcessorCount * 4 : 1024;
-  }
+  const int simds = 4 * (P.n_cu > 0 ? P.n_cu : 256);   // (of the context's device, KParams)
   // Strip height.  Every wave of the launch is resident at once (5 waves per SIMD) and a SIMD works through its waves'
   // rows, so the launch lasts (waves per SIMD, rounded UP) x (rows per wave); every strip pays 5 rows of overlap.  The
   // product is smallest for 6 strips of 80 rows at 64 x 752x480 (4992 waves, 5 per SIMD x 85 rows = 425 row-times;
@@ -2625,7 +2619,8 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   // (stream, corner slot) up to the bound of the new corners, the stream is the fast grid index (see the kernel); a
   // grid sized to what the device holds at once, every block walking ~10 corners, lost 24 % on real frames (round 3:
   // the corners' iteration counts differ too much for a static assignment).
-  const int nw = P.B <= 4 ? 4 : 2;
+  static const int nw_env = [] { const char* e = std::getenv("KVFE_SUBPIX_NW"); return e ? std::atoi(e) : 0; }();   // (A/B switch)
+  const int nw = (nw_env == 2 || nw_env == 4) ? nw_env : (P.B <= 4 ? 4 : 2);
   // (corner slots per stream: a block walks its stream's corners with the stride of the grid, so the grid only has to
   // hold the corners this kernel is FOR -- fewer than SPG_MIN_TOTAL over the whole launch, otherwise the grouped kernel
   // works and these blocks return -- instead of one block per possible corner, 50 k mostly empty blocks at 64 streams)
@@ -2676,12 +2671,7 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
     if ((long long)glds > budget) std::fprintf(stderr, "kvfe: subpix_group_kernel needs %zu B of LDS, %d available\n", glds, budget);
     // blocks per stream: what the device holds at once (two 65 KB blocks per compute unit) shared out over the streams --
     // every block resident from the start, its eight slots refilled from the stream's counter as corners finish
-    static int cus = 0;
-    if (!cus) {
-      hipDeviceProp_t prop;
-      int dev = 0;
-      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = P.n_cu > 0 ? P.n_cu : 256;   // (of the context's device, KParams)
     const int gy = std::max(1, std::min((bound + SPG_G - 1) / SPG_G, (2 * cus + P.B - 1) / P.B));
     hipLaunchKernelGGL((subpix_group_kernel<10>), dim3(P.B, gy), dim3(SPG_T), glds, st, P, T, img,
                        row_stride, img_stride, k, S, D, append | (stats_on ? 16 : 0) | (group_mode == 2 ? 64 : 0));

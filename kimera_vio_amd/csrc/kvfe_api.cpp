@@ -110,7 +110,9 @@ struct kvfe_ctx {
   // pinned input staging ring
   static constexpr int RING = 64;
   // staged steps: the per-stream inputs travel to a device ring slot by a copy behind the frames' upload (do_step)
-  unsigned char* in_dev = nullptr;                   // [RING][ring_bytes]
+  unsigned char* in_dev = nullptr;                   // [RING][ring_bytes]; set when ALL staging resources exist
+  unsigned char* in_dev_staging = nullptr;           // (its allocation)
+  bool staging_ready = false;                        // ensure_staging completed: copy stream, step_done / ev_chain events, input ring
   hipEvent_t in_ev[RING] = {};
   bool inputs_by_copy_call = false;                  // this do_step call: set by kvfe_frontend_step_staged
   unsigned char* ring_host[RING] = {};
@@ -659,6 +661,10 @@ kvfe_status fill_params(kvfe_ctx* c) {
     if (w <= P.klt_win || h <= P.klt_win) break;
   }
   P.nlevels = nl;
+  {   // compute units of THIS context's device (a process may hold contexts on several devices)
+    int ncu = 0;
+    P.n_cu = (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg.device) == hipSuccess && ncu > 0) ? ncu : 256;
+  }
   P.ssd_dot4 = cfg.ssd_impl == 1 ? 1 : 0;
   P.lk_one = cfg.lk_impl == 1 ? 1 : 0;
   P.ssd_f32 = p.stereo.ssd_tie_policy == KVFE_SSD_TIE_F32 ? 1 : 0;
@@ -1206,7 +1212,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   if (side) {
     if (swap) {
       HIPCHK(c, hipEventRecord(c->ev_main, sd));            // the chain (last reader of this frame's image slots) is done
-      if (c->ev_chain[0]) HIPCHK(c, hipEventRecord(c->ev_chain[c->chain_seq % 4], sd));
+      if (c->staging_ready) HIPCHK(c, hipEventRecord(c->ev_chain[c->chain_seq % 4], sd));
       c->chain_seq++;
       c->chain_pending = true;
       HIPCHK(c, hipStreamWaitEvent(sd, c->ev_commit, 0));   // the refined new corners (main stream)
@@ -2450,17 +2456,27 @@ static hipError_t create_stream_in_other_pool(hipStream_t* s) {
 static kvfe_status ensure_staging(kvfe_ctx* c, int slot) {
   DeviceGuard _dev(c);
   const size_t bytes = 2 * (size_t)c->P.W * c->P.H * c->P.B;
-  if (!c->copy_stream) {
-    HIPCHK(c, create_stream_in_other_pool(&c->copy_stream));
-    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
-    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming));
+  if (!c->staging_ready) {
+    // one-time resources; a call that fails half way (say, no memory for the input ring) leaves what it created in place
+    // and the next call creates only what is missing -- nothing reads them before staging_ready is set
+    if (!c->copy_stream) HIPCHK(c, create_stream_in_other_pool(&c->copy_stream));
+    for (int i = 0; i < 4; i++)
+      if (!c->step_done[i]) HIPCHK(c, hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
+    for (int i = 0; i < 4; i++)
+      if (!c->ev_chain[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming));
     if (!c->cfg.copy_inputs && !c->fork_swap) {   // many streams: device copies of the input ring slots (do_step)
-      c->ring_bytes_dev = (c->ring_bytes + 255) & ~(size_t)255;
-      TRY(dalloc(c, &c->in_dev, c->ring_bytes_dev * kvfe_ctx::RING));
-      for (int i = 0; i < kvfe_ctx::RING; i++) HIPCHK(c, hipEventCreateWithFlags(&c->in_ev[i], hipEventDisableTiming));
+      for (int i = 0; i < kvfe_ctx::RING; i++)
+        if (!c->in_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->in_ev[i], hipEventDisableTiming));
+      if (!c->in_dev_staging) {
+        c->ring_bytes_dev = (c->ring_bytes + 255) & ~(size_t)255;
+        TRY(dalloc(c, &c->in_dev_staging, c->ring_bytes_dev * kvfe_ctx::RING));
+      }
     }
     if (c->cfg.params.stereo.equalize_image)
-      for (int i = 0; i < 2; i++) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));
+      for (int i = 0; i < 2; i++)
+        if (!c->fe.eq_in[i]) TRY(dalloc(c, &c->fe.eq_in[i], (size_t)c->P.W * c->P.H * c->P.B, false));
+    c->in_dev = c->in_dev_staging;   // (do_step takes the copy path once this is set: everything it needs exists)
+    c->staging_ready = true;
   }
   if (!c->stage_host[slot]) {   // a slot's pinned memory on first use
     void* h = nullptr;
@@ -2521,9 +2537,9 @@ kvfe_status kvfe_frontend_step_staged(kvfe_ctx* c, int32_t slot, const kvfe_fram
     // upload of frame n rewrites the right slot of frame n-2 and the left slot of frame n-3 -- the chain of step n-2 is
     // behind both on the side stream (and behind the refinement of step n-3, which its predecessor's tail awaited)
     if (c->chain_pending) {
-      if (c->ev_chain[0] && c->chain_seq >= 2 && c->last_step_staged)
+      if (c->staging_ready && c->chain_seq >= 2 && c->last_step_staged)
         HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_chain[(c->chain_seq - 2) % 4], 0));
-      else if (!c->ev_chain[0] || !c->last_step_staged)
+      else if (!c->staging_ready || !c->last_step_staged)
         HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_main, 0));
     }
   }

@@ -21,6 +21,7 @@ constexpr int MAX_RADIUS = 127;
 
 struct KParams {
   int W, H, B;
+  int n_cu;  // compute units of the context's device (launch shapes; filled at context creation)
   int kcap;  // keypoint capacity per stream
   int ccap;  // candidate capacity per stream
   int acap;  // accepted-corner capacity per stream (<= 8192)
