@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -22,6 +24,9 @@
 
 using namespace kvfe;
 
+namespace kvfe {
+int warm_dma_engines(int device_ordinal, void* dev_buf, void* host_buf, size_t bytes);   // host_dma_warm.cpp
+}
 namespace {
 
 constexpr int ACAP = 8192;  // accepted-corner capacity (LDS sort capacity of the select kernel)
@@ -41,12 +46,15 @@ enum Stage {
   ST_FINALIZE,
   ST_RANSAC_MONO,
   ST_RANSAC_STEREO,
+  ST_OUT_PACK,       // round 6: the step's output records gathered on the tail's stream ...
+  ST_OUT_TRANSFER,   // ... and their transfer to the pinned ring slot on the output stream (many streams)
   ST_COUNT
 };
+static_assert(ST_COUNT <= KVFE_N_STAGES, "kvfe_stage_times holds KVFE_N_STAGES stages");
 const char* kStageNames[ST_COUNT] = {"pyramid",  "lk_track", "track_finalize", "mineig_localmax",
                                      "gftt_select", "subpix_append", "rectify", "stereo_match",
                                      "stereo_match_new", "step_finalize", "ransac_mono",
-                                     "ransac_stereo"};
+                                     "ransac_stereo", "out_pack", "out_transfer"};
 
 struct Buffers {  // everything that scales with the number of streams
   unsigned char* lvl0[2] = {nullptr, nullptr};  // [B][H][W] own copy of the left image per pyramid slot (device-pointer steps)
@@ -865,9 +873,27 @@ int stage_flag(int s) {
 
 void prof_collect(kvfe_ctx* c) {
   if (c->prof_pending.empty()) return;
+  // KVFE_PROF_TIMELINE=N (debugging aid): begin / end of every stage of the first N sampled steps of a read, in
+  // microseconds from the FIRST sampled step's first event -- the un-profiled counterpart of a rocprofv3 kernel timeline
+  // (under rocprofv3 the output transfer runs as a blit kernel and delays the kernels that end beside it)
+  static const int timeline = [] { const char* e = std::getenv("KVFE_PROF_TIMELINE"); return e ? std::atoi(e) : 0; }();
   for (size_t k = 0; k < c->prof_pending.size(); k++) {
     const int* idx = c->prof_idx.data() + (size_t)c->prof_pending[k] * 2 * ST_COUNT;
     const int slot = k < c->prof_flag_slot.size() ? c->prof_flag_slot[k] : -1;
+    if ((int)k < timeline) {
+      const int* idx0 = c->prof_idx.data() + (size_t)c->prof_pending[0] * 2 * ST_COUNT;
+      int base = -1;
+      for (int s = 0; s < ST_COUNT && base < 0; s++) base = idx0[2 * s];
+      std::fprintf(stderr, "KVFE_PROF_TIMELINE sample %zu:", k);
+      for (int s = 0; s < ST_COUNT && base >= 0; s++) {
+        float b0 = 0.f, b1 = 0.f;
+        if (idx[2 * s] < 0 || idx[2 * s + 1] < 0) continue;
+        if (hipEventElapsedTime(&b0, c->prof_ev[base], c->prof_ev[idx[2 * s]]) != hipSuccess ||
+            hipEventElapsedTime(&b1, c->prof_ev[base], c->prof_ev[idx[2 * s + 1]]) != hipSuccess) continue;
+        std::fprintf(stderr, " %s %.0f-%.0f", kStageNames[s], 1e3 * b0, 1e3 * b1);
+      }
+      std::fprintf(stderr, "\n");
+    }
     for (int s = 0; s < ST_COUNT; s++) {
       float ms = 0.f;
       if (idx[2 * s] < 0 || idx[2 * s + 1] < 0) continue;
@@ -904,11 +930,45 @@ void prof_collect(kvfe_ctx* c) {
 // table) waits for that event, so the records hold the frame as the reference's StereoFrontendOutput would.  Many streams:
 // a device-to-device gather (microseconds) on `sd`, then the PCIe transfer by the DMA engine on the output stream, beside
 // the next step's tracking launch.  A few streams: the gather writes the mapped pinned slot directly.
+// KVFE_HOST_PROF=1 (debugging aid): host time spent inside the calls below, per context, printed by kvfe_destroy
+struct HostProf {
+  double ms[8] = {};
+  long long n[8] = {};
+};
+static const bool kHostProf = std::getenv("KVFE_HOST_PROF") != nullptr;
+static HostProf g_hostprof;
+static std::vector<float> g_hostprof_calls;
+struct HostTimer {
+  int i;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimer(int idx) : i(idx) { if (kHostProf) t0 = std::chrono::steady_clock::now(); }
+  ~HostTimer() {
+    if (!kHostProf) return;
+    g_hostprof.ms[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g_hostprof.n[i]++;
+  }
+};
+static void hostprof_print_and_reset(const char* what) {
+  if (!kHostProf || !g_hostprof.n[0]) return;
+  static const char* names[8] = {"do_step", "enqueue_outputs", "out memcpyAsync", "out_pack launch", "lk launch", "ring wait", "", ""};
+  std::fprintf(stderr, "KVFE_HOST_PROF %s:", what);
+  for (int i = 0; i < 6; i++)
+    if (g_hostprof.n[i]) std::fprintf(stderr, " %s %.4f ms x %lld;", names[i], g_hostprof.ms[i] / g_hostprof.n[i], g_hostprof.n[i]);
+  std::fprintf(stderr, "\nKVFE_HOST_PROF out memcpyAsync per call (us):");
+  for (float v : g_hostprof_calls) std::fprintf(stderr, " %.0f", 1e3 * v);
+  std::fprintf(stderr, "\n");
+  g_hostprof_calls.clear();
+  g_hostprof = HostProf();
+}
+
 kvfe_status enqueue_outputs(kvfe_ctx* c, const FrameTab& K, hipStream_t sd) {
+  HostTimer _t(1);
   const int slot = (int)(c->out_steps % OUT_RING);
   Buffers& b = c->fe;
   if (c->out_direct) {
+    prof_begin(c, ST_OUT_PACK, sd);
     launch_out_pack(c->P, K, b.st, b.ss, c->out_host_dev[slot], c->out_tab_bytes, c->out_cap, sd);
+    prof_end(c, ST_OUT_PACK, sd);
     HIPCHK(c, hipEventRecord(c->ev_out[slot], sd));
     c->out_copied[slot] = c->out_slot_size;
   } else {
@@ -924,10 +984,23 @@ kvfe_status enqueue_outputs(kvfe_ctx* c, const FrameTab& K, hipStream_t sd) {
     const size_t bytes = c->out_guess_forced ? std::min(c->out_slot_size, std::max(c->out_tab_bytes, c->out_guess_forced))
                                              : c->out_guess;
     if (c->out_steps >= OUT_RING) HIPCHK(c, hipStreamWaitEvent(sd, c->ev_out[slot], 0));   // the slot's last transfer read it
-    launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_tab_bytes, c->out_cap, sd);
+    prof_begin(c, ST_OUT_PACK, sd);
+    {
+      HostTimer _t3(3);
+      launch_out_pack(c->P, K, b.st, b.ss, c->out_stage[slot], c->out_tab_bytes, c->out_cap, sd);
+    }
+    prof_end(c, ST_OUT_PACK, sd);
     HIPCHK(c, hipEventRecord(c->ev_packed[slot], sd));
     HIPCHK(c, hipStreamWaitEvent(c->out_stream, c->ev_packed[slot], 0));
-    HIPCHK(c, hipMemcpyAsync(c->out_host[slot], c->out_stage[slot], bytes, hipMemcpyDeviceToHost, c->out_stream));
+    prof_begin(c, ST_OUT_TRANSFER, c->out_stream);
+    {
+      HostTimer _t2(2);
+      const auto t0_ = std::chrono::steady_clock::now();
+      HIPCHK(c, hipMemcpyAsync(c->out_host[slot], c->out_stage[slot], bytes, hipMemcpyDeviceToHost, c->out_stream));
+      if (kHostProf) g_hostprof_calls.push_back((float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
+    }
+    prof_end(c, ST_OUT_TRANSFER, c->out_stream);
+    prof_break(c);
     HIPCHK(c, hipEventRecord(c->ev_out[slot], c->out_stream));
     c->out_copied[slot] = bytes;
   }
@@ -937,13 +1010,17 @@ kvfe_status enqueue_outputs(kvfe_ctx* c, const FrameTab& K, hipStream_t sd) {
 
 kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char* right,
                     size_t row_stride, size_t img_stride, const kvfe_frame_input* inputs) {
+  HostTimer _t0(0);
   const KParams& P = c->P;
   Buffers& b = c->fe;
   hipStream_t st = c->stream;
   // ---- per-stream inputs through the pinned ring ------------------------------------------------
   const int slot = c->ring_pos;
   c->ring_pos = (c->ring_pos + 1) % kvfe_ctx::RING;
-  if (c->ring_used[slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+  if (c->ring_used[slot]) {
+    HostTimer _t5(5);
+    HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+  }
   unsigned char* hb = c->ring_host[slot];
   double* hR = reinterpret_cast<double*>(hb);
   long long* hts = reinterpret_cast<long long*>(hb + sizeof(double) * 9 * P.B);
@@ -1455,6 +1532,9 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     }
     if (s == KVFE_OK && !c->out_direct && hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking) != hipSuccess)
       s = KVFE_ERR_HIP;
+    // every SDMA engine's queue is created here instead of inside a hipMemcpyAsync of the step loop (host_dma_warm.cpp)
+    if (s == KVFE_OK && !c->out_direct && hipStreamSynchronize(c->stream) == hipSuccess)   // (the stage buffers' zero fill)
+      (void)warm_dma_engines(cfg->device, c->out_stage[0], c->out_host[0], std::min<size_t>(bytes, (size_t)65536));
   }
   if (s == KVFE_OK && parent &&
       hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess)
@@ -1543,6 +1623,7 @@ kvfe_status kvfe_create(const kvfe_config* cfg, kvfe_ctx** out) {
 }
 
 void kvfe_destroy(kvfe_ctx* c) {
+  if (c && c->children.empty()) hostprof_print_and_reset("context destroyed");
   DeviceGuard _dev(c);
   if (!c) return;
   for (kvfe_ctx* ch : c->children) kvfe_destroy(ch);
