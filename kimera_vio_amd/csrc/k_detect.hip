@@ -2142,7 +2142,8 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 4 : 2) void subpix_append_kernel
   const int lane = threadIdx.x;
   const bool stats = (append & 16) != 0;
   // (raised wave priority -- s_setprio 3 -- was measured in round 3: +0.6 % on the step, and the rectification beside it
-  // 0.098 -> 0.108 ms: the dense kernel pays for the latency-bound one; removed)
+  // 0.098 -> 0.108 ms: the dense kernel pays for the latency-bound one; removed.  Round 6, with the matching kernels beside it
+  // instead of the rectification: 82.3 / 81.8 k with against 82.4 / 82.8 k without, tools/r6/gpu_ab_env.sh)
   append &= 15;
   for (int ci = blockIdx.y; ci < n_new; ci += gridDim.y) {
   float2 c = D.newc[(size_t)s * P.acap + ci];
@@ -2611,6 +2612,12 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   // (Fewer corners per compute unit -- extra LDS per block as a probe, tools/r5/gpu_z.sh -- make a corner faster, mean 183 k ->
   // 154 k cycles and slowest 586 k -> 401 k at two per unit, and the launch slower, 0.27 -> 0.42 ms per step on average: the
   // steps behind a feature-age burst bring thousands of corners and need the slots.)
+  // append bit 9 (do_step, a few streams, synchronous call): the host has read this step's flags and no stream of the batch
+  // detects -- the refinement launches would find nothing to do; detect_commit_kernel still has its per-step state to write
+  if (append & 512) {
+    if (append & 15) hipLaunchKernelGGL(detect_commit_kernel, dim3(P.B), dim3(DC_T), 0, st, P, T, k, S, D, 7);
+    return;
+  }
   const size_t lds = subpix_geom(P.subpix_win).bytes;
   const int bound = detect_new_bound(P);
   // waves per corner of the one-corner-per-block kernel: 2 (DPP broadcast chains, kvfe_subpix.inl), and 4 for a few

@@ -1055,6 +1055,12 @@ __device__ __forceinline__ int block_scan_tf(int v, int* wave_tot, int* total) {
   return base + inc - v;
 }
 
+// see StreamState::host_flags
+__device__ __forceinline__ void publish_flags(const StreamState& S, int s, int f) {
+  if (!S.host_flags) return;
+  __hip_atomic_store(&S.host_flags[s], f | (S.host_seq << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables T, FrameTab KM1,
                                                               FrameTab LKF, FrameTab K,
                                                               StreamState S, LkScratch lk) {
@@ -1074,7 +1080,9 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
       K.timestamp[s] = ts;
       S.n_tracked[s] = 0;
       S.n_detected[s] = 0;
-      S.flags[s] = (S.flags[s] & FLAG_OVERFLOW) | FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO | FLAG_FIRST;
+      const int f0 = (S.flags[s] & FLAG_OVERFLOW) | FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO | FLAG_FIRST;
+      S.flags[s] = f0;
+      publish_flags(S, s, f0);
     }
     return;
   }
@@ -1115,7 +1123,9 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
       K.timestamp[s] = ts;
       S.n_tracked[s] = 0;
       S.n_detected[s] = 0;
-      S.flags[s] = (S.flags[s] & (FLAG_OVERFLOW | FLAG_INIT)) | FLAG_DETECT;
+      const int f0 = (S.flags[s] & (FLAG_OVERFLOW | FLAG_INIT)) | FLAG_DETECT;
+      S.flags[s] = f0;
+      publish_flags(S, s, f0);
     }
     return;
   }
@@ -1243,6 +1253,7 @@ __global__ __launch_bounds__(TF_T) void track_finalize_kernel(KParams P, Tables 
     int f = S.flags[s] & (FLAG_OVERFLOW | FLAG_INIT);
     if (kf) f |= FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO;
     S.flags[s] = f;
+    publish_flags(S, s, f);
   }
 }
 

@@ -76,7 +76,7 @@ struct Buffers {  // everything that scales with the number of streams
   StereoTab st;
   StereoTab lst;  // stereo tables of the last keyframe (geometric outlier rejection reads them)
   RansacScratch rs;
-  StreamState ss;
+  StreamState ss = {};
   DetectScratch ds;
   LkScratch lk;
   double* kf_R_cur = nullptr;
@@ -150,6 +150,14 @@ struct kvfe_ctx {
   hipEvent_t ev_commit = nullptr;                    // this step's new corners are in the frame table (side stream)
   bool commit_pending = false;                       // the next step's tracking has not been ordered after ev_commit yet
   bool fork_swap = false;                            // few streams: the corner refinement stays on the main stream (do_step)
+  // Round 6, a few streams through kvfe_frontend_step_host (the synchronous single-robot use, shim::spinOnce): the host
+  // reads the step's flags behind the keyframe decision and does not launch the keyframe-only kernels of a step in which
+  // no stream is a keyframe -- at the reference cadence four steps of five, each ~95 us of a dozen kernels that return at
+  // their first flag test
+  int* quiet_flags_host = nullptr;                   // [B] pinned + mapped: track_finalize publishes flags | seq << 8 (StreamState)
+  int* quiet_flags_dev = nullptr;                    // (its device address)
+  int quiet_seq = 0;
+  bool quiet_check_call = false;
   bool serial_call = false;                          // this do_step call keeps every kernel on the main stream (see do_step)
   bool frames_persist_call = false;                  // this do_step call reads caller frames that stay valid for one more step
   bool chain_pending = false;                        // fork_swap: the side stream's outlier rejection has not been joined yet
@@ -950,9 +958,9 @@ struct HostTimer {
 };
 static void hostprof_print_and_reset(const char* what) {
   if (!kHostProf || !g_hostprof.n[0]) return;
-  static const char* names[8] = {"do_step", "enqueue_outputs", "out memcpyAsync", "out_pack launch", "lk launch", "ring wait", "", ""};
+  static const char* names[8] = {"do_step", "enqueue_outputs", "out memcpyAsync", "out_pack launch", "flag poll", "ring wait", "host upload calls", "output event wait"};
   std::fprintf(stderr, "KVFE_HOST_PROF %s:", what);
-  for (int i = 0; i < 6; i++)
+  for (int i = 0; i < 8; i++)
     if (g_hostprof.n[i]) std::fprintf(stderr, " %s %.4f ms x %lld;", names[i], g_hostprof.ms[i] / g_hostprof.n[i], g_hostprof.n[i]);
   std::fprintf(stderr, "\nKVFE_HOST_PROF out memcpyAsync per call (us):");
   for (float v : g_hostprof_calls) std::fprintf(stderr, " %.0f", 1e3 * v);
@@ -1085,7 +1093,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   } slot_release{c, slot, st, c->serial_call ? nullptr : c->side};
   // (serial_call: frames that arrive over PCIe while the step runs -- kvfe_frontend_step_staged -- keep every kernel on the
   // main stream: with a transfer in flight each cross-stream hand-over of the forked step completes late, see there)
-  hipStream_t const side = c->serial_call ? nullptr : c->side;
+  hipStream_t side = c->serial_call ? nullptr : c->side;   // (a quiet step -- below -- keeps everything on the main stream)
 
   c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
   if (c->prof_on) {
@@ -1136,9 +1144,29 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     c->tail_pending = false;
     prof_break(c);
   }
+  static const bool quiet_env = [] { const char* e = std::getenv("KVFE_QUIET_STEPS"); return !e || std::atoi(e) != 0; }();   // (A/B switch)
+  const bool quiet_check = quiet_env && c->quiet_check_call && P.B <= 4 && !P.mono && !P.rgbd && !P.use_pnp && c->own_stream;
+  if (quiet_check) {
+    if (!c->quiet_flags_host) {
+      void* h = nullptr;
+      void* d = nullptr;
+      HIPCHK(c, hipHostMalloc(&h, sizeof(int) * (size_t)P.B, hipHostMallocMapped | hipHostMallocCoherent));
+      c->host_allocs.push_back(h);
+      std::memset(h, 0, sizeof(int) * (size_t)P.B);
+      HIPCHK(c, hipHostGetDevicePointer(&d, h, 0));
+      c->quiet_flags_host = reinterpret_cast<int*>(h);
+      c->quiet_flags_dev = reinterpret_cast<int*>(d);
+    }
+    c->quiet_seq = c->quiet_seq % 0x7fffff + 1;
+    b.ss.host_flags = c->quiet_flags_dev;
+    b.ss.host_seq = c->quiet_seq;
+  } else {
+    b.ss.host_flags = nullptr;
+  }
   prof_begin(c, ST_TRACK_FINALIZE, st);
   launch_track_finalize(P, c->T, KM1, LKF, K, b.ss, b.lk, st);
   prof_end(c, ST_TRACK_FINALIZE, st);
+  b.ss.host_flags = nullptr;   // (only track_finalize publishes)
   if (c->prof_on) {   // this step's keyframe / detect / stereo flags, for the per-stage activity of the profile
     int slot = -1;
     if (c->prof_flags_host && c->prof_flag_next < PROF_FLAG_SAMPLES) {
@@ -1152,6 +1180,37 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
     c->ev_tracked_valid = true;
   }
+  // quiet step (see quiet_check_call): every kernel skipped below returns at its first test of a flag that is off
+  // (FLAG_KEYFRAME / FLAG_DETECT / FLAG_STEREO), writes nothing before it, and is not the mono / RGB-D / PnP variant whose
+  // kernels do write before the test
+  bool quiet = false;
+  if (quiet_check) {
+    // the flag words carry this step's tag once track_finalize has written them; the poll is bounded (2 s), after that
+    // the stream is awaited and the device copy of the flags read
+    quiet = true;
+    HostTimer _t4(4);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+    for (int s = 0; s < P.B && quiet; s++) {
+      volatile int* w = c->quiet_flags_host + s;
+      int v = *w;
+      for (unsigned spins = 0; (v >> 8) != c->quiet_seq; v = *w) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() > t_end) {
+          HIPCHK(c, hipStreamSynchronize(st));
+          HIPCHK(c, hipMemcpy(&v, b.ss.flags + s, sizeof(int), hipMemcpyDeviceToHost));
+          v |= c->quiet_seq << 8;
+          break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      if (v & (FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO | FLAG_FIRST)) quiet = false;
+    }
+    if (quiet) {   // nothing forks: the tail follows on the main stream
+      side = nullptr;
+      sd = st;
+    }
+  }
   // Rectification right behind the keyframe decision, on the side stream, when the caller FORCES a keyframe on every
   // stream (then the host knows that the step rectifies; otherwise the decision is the device's) and the chain is on the
   // side stream anyway: beside the mono rejection, the min-eigenvalue launch and the selection it runs at the speed it has
@@ -1161,7 +1220,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // at the reference cadence), so those keep the rectification at the head of the chain.
   bool all_forced = side && !P.mono && (c->fork_swap || (c->frames_persist_call && c->own_stream));
   for (int s = 0; s < P.B && all_forced; s++) all_forced = inputs[s].force_keyframe != 0;
-  const bool rect_early = all_forced;
+  const bool rect_early = all_forced && !quiet;
   if (rect_early) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
@@ -1173,6 +1232,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   }
   // keyframes: mono geometric outlier rejection before detection (it frees landmarks, so more
   // corners are extracted, StereoVisionImuFrontend.cpp:349-363,413-417)
+  if (!quiet) {
   prof_begin(c, ST_RANSAC_MONO, st);
   launch_mono_ransac(P, c->T, K, LKF, b.ss, b.rs, st);
   prof_end(c, ST_RANSAC_MONO, st);
@@ -1184,6 +1244,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SELECT, st);
   launch_select(P, c->T, K, b.ss, b.ds, -1, st);
   prof_end(c, ST_SELECT, st);
+  }
   if (P.mono) {
     // MonoVisionImuFrontend::processFrame (:288-318): refine + append the new corners, undistort all
     // keypoints (Camera::undistortKeypoints), measurements
@@ -1244,13 +1305,13 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     slot_release.side_used = true;
   }
   prof_begin(c, ST_SUBPIX, fa);
-  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, fa);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, quiet ? (1 | 512) : 1, fa);
   prof_end(c, ST_SUBPIX, fa);
   if (side && (c->own_stream || swap)) {
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
   }
-  if (!rect_early) {
+  if (!rect_early && !quiet) {
   prof_begin(c, ST_RECTIFY, fb);
   {
     const unsigned char* srcs[2] = {left, right};
@@ -1258,9 +1319,11 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   }
   prof_end(c, ST_RECTIFY, fb);
   }
+  if (!quiet) {
   prof_begin(c, ST_STEREO, fb);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, fb);
   prof_end(c, ST_STEREO, fb);
+  }
   // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387).  Its results (right-keypoint
   // statuses of the outliers, the stereo pose and status; the PnP pose) are read by the tail only -- the landmark removal
   // that the next step's tracking reads is the mono rejection's -- so it runs at the head of the tail on the side stream,
@@ -1269,6 +1332,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // track_prepare and tracking launch and must therefore not write frame-table fields those read (K.kp, K.lmk, K.count).
   const bool ransac_tail = side && !swap;
   auto stereo_rejection = [&](hipStream_t rs) -> kvfe_status {
+  if (quiet) return KVFE_OK;
   prof_begin(c, ST_RANSAC_STEREO, rs);
   if (P.use_ransac) {
     // (the device's own predicate, rot_is_identity of kvfe_dev.hpp: a stream without a usable gyro rotation takes the
@@ -1299,9 +1363,11 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     }
   }
   if (ransac_tail) TRY(stereo_rejection(sd));
+  if (!quiet) {
   prof_begin(c, ST_STEREO_NEW, sd);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, sd);
   prof_end(c, ST_STEREO_NEW, sd);
+  }
   prof_begin(c, ST_FINALIZE, sd);
   launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, sd);
   prof_end(c, ST_FINALIZE, sd);
@@ -1533,8 +1599,9 @@ static kvfe_status create_one(const kvfe_config* cfg, kvfe_ctx* parent, int s0, 
     if (s == KVFE_OK && !c->out_direct && hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking) != hipSuccess)
       s = KVFE_ERR_HIP;
     // every SDMA engine's queue is created here instead of inside a hipMemcpyAsync of the step loop (host_dma_warm.cpp)
-    if (s == KVFE_OK && !c->out_direct && hipStreamSynchronize(c->stream) == hipSuccess)   // (the stage buffers' zero fill)
-      (void)warm_dma_engines(cfg->device, c->out_stage[0], c->out_host[0], std::min<size_t>(bytes, (size_t)65536));
+    // (also for a few streams, whose records need no transfer: their frames come up the link through the same engines)
+    if (s == KVFE_OK && hipStreamSynchronize(c->stream) == hipSuccess)   // (the buffers' zero fill)
+      (void)warm_dma_engines(cfg->device, c->fe.raw_left[0], c->out_host[0], std::min<size_t>(bytes, (size_t)65536));
   }
   if (s == KVFE_OK && parent &&
       hipEventCreateWithFlags(&c->ev_tracked, hipEventDisableTiming) != hipSuccess)
@@ -2504,6 +2571,7 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   unsigned char* ul = eq ? b.rect[0] : dl;  // (rectified buffers are free until rectification runs)
   unsigned char* ur = eq ? b.rect[1] : dr;
   if (row_stride == (size_t)P.W && image_stride == N) {  // tightly packed batch: one copy per side
+    HostTimer _t6(6);
     HIPCHK(c, hipMemcpyAsync(ul, left, N * P.B, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(ur, right, N * P.B, hipMemcpyHostToDevice, c->stream));
   } else {
@@ -2520,7 +2588,10 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   }
   c->img_step++;
   c->last_step_staged = false;
-  return do_step(c, dl, dr, P.W, N, inputs);
+  c->quiet_check_call = true;
+  const kvfe_status r = do_step(c, dl, dr, P.W, N, inputs);
+  c->quiet_check_call = false;
+  return r;
 }
 
 // ---- staged input -----------------------------------------------------------------
@@ -2743,7 +2814,10 @@ static kvfe_status locate_output(kvfe_ctx* c, int32_t s, int32_t steps_back, con
     return KVFE_ERR_INVALID_ARG;
   }
   const int slot = (int)((c->out_steps - 1 - steps_back) % OUT_RING);
-  HIPCHK(c, hipEventSynchronize(c->ev_out[slot]));
+  {
+    HostTimer _t7(7);
+    HIPCHK(c, hipEventSynchronize(c->ev_out[slot]));
+  }
   if (c->prof_stride > 0 && steps_back == 0) {   // stage events of the profiled steps: collected once everything is complete
     join_tail(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));

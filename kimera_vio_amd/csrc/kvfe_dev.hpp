@@ -186,6 +186,11 @@ struct StreamState {
   long long* map_ids;     // [B][map_cap] ascending
   double* map_xyz;        // [B][map_cap][3]
   int* map_n;             // [B]
+  // a few streams, synchronous call (do_step, "quiet step"): track_finalize also publishes a stream's flags of this step
+  // to a word the host polls -- flags | host_seq << 8, system scope -- so that the host learns the keyframe decision
+  // without a copy and a stream synchronisation (null: not published)
+  int* host_flags;        // [B] mapped pinned host memory
+  int host_seq;           // this step's tag (1 .. 2^23)
 };
 
 // VIO::TrackingStatus
