@@ -136,6 +136,7 @@ __device__ __forceinline__ void out_copy_arr(unsigned char* rec, size_t off, con
 __global__ __launch_bounds__(256) void out_pack_kernel(KParams P, FrameTab K, StereoTab ST, StreamState S,
                                                        unsigned char* __restrict__ dst, size_t table_bytes, int rec_cap) {
   const int s = blockIdx.x;
+  if (P.quiet_gate && !kvfe_all_quiet(S.flags, P.B)) return;
   __shared__ unsigned long long sh_off;
   if (threadIdx.x == 0) sh_off = 0ull;
   __syncthreads();

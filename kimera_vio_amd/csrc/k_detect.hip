@@ -2567,6 +2567,7 @@ constexpr int DC_T = 128;
 __global__ __launch_bounds__(DC_T) void detect_commit_kernel(KParams P, Tables T, FrameTab K, StreamState S, DetectScratch D,
                                                            int what) {
   const int s = blockIdx.x;
+  if (P.quiet_gate && !kvfe_all_quiet(S.flags, P.B)) return;
   const int flags = S.flags[s];
   if (threadIdx.x == 0 && (what & 1)) {
     if (flags & FLAG_KEYFRAME) {   // keyframe_R_ref_frame_ = identity (StereoVisionImuFrontend.cpp:203,225)

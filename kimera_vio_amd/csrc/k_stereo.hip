@@ -701,6 +701,7 @@ __global__ __launch_bounds__(256) void step_finalize_kernel(KParams P, FrameTab 
                                                             StereoTab ST, StereoTab LST,
                                                             StreamState S) {
   const int s = blockIdx.x, tid = threadIdx.x;
+  if (P.quiet_gate && !kvfe_all_quiet(S.flags, P.B)) return;
   const size_t so = (size_t)s * P.kcap;
   const int flags = S.flags[s];
   const int n = K.count[s];

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -158,6 +159,11 @@ struct kvfe_ctx {
   int* quiet_flags_dev = nullptr;                    // (its device address)
   int quiet_seq = 0;
   bool quiet_check_call = false;
+  // kvfe_frontend_step_host, a few streams: the RIGHT image comes up on its own stream -- the pyramid and the tracking
+  // launch only read the left one, and nothing reads the right one before the rectification of a keyframe
+  hipStream_t up2_stream = nullptr;
+  hipEvent_t ev_up2 = nullptr;
+  bool right_pending = false;                        // this do_step call: the right image's upload ends with ev_up2
   bool serial_call = false;                          // this do_step call keeps every kernel on the main stream (see do_step)
   bool frames_persist_call = false;                  // this do_step call reads caller frames that stay valid for one more step
   bool chain_pending = false;                        // fork_swap: the side stream's outlier rejection has not been joined yet
@@ -1093,7 +1099,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   } slot_release{c, slot, st, c->serial_call ? nullptr : c->side};
   // (serial_call: frames that arrive over PCIe while the step runs -- kvfe_frontend_step_staged -- keep every kernel on the
   // main stream: with a transfer in flight each cross-stream hand-over of the forked step completes late, see there)
-  hipStream_t side = c->serial_call ? nullptr : c->side;   // (a quiet step -- below -- keeps everything on the main stream)
+  hipStream_t const side = c->serial_call ? nullptr : c->side;
 
   c->prof_on = c->prof_stride > 0 && (c->prof_step++ % c->prof_stride) == 0;
   if (c->prof_on) {
@@ -1145,7 +1151,7 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     prof_break(c);
   }
   static const bool quiet_env = [] { const char* e = std::getenv("KVFE_QUIET_STEPS"); return !e || std::atoi(e) != 0; }();   // (A/B switch)
-  const bool quiet_check = quiet_env && c->quiet_check_call && P.B <= 4 && !P.mono && !P.rgbd && !P.use_pnp && c->own_stream;
+  const bool quiet_check = quiet_env && c->quiet_check_call && P.B <= 4 && c->out_direct && side && !P.mono && !P.rgbd && !P.use_pnp && c->own_stream;
   if (quiet_check) {
     if (!c->quiet_flags_host) {
       void* h = nullptr;
@@ -1180,35 +1186,64 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     HIPCHK(c, hipEventRecord(c->ev_tracked, st));
     c->ev_tracked_valid = true;
   }
-  // quiet step (see quiet_check_call): every kernel skipped below returns at its first test of a flag that is off
-  // (FLAG_KEYFRAME / FLAG_DETECT / FLAG_STEREO), writes nothing before it, and is not the mono / RGB-D / PnP variant whose
-  // kernels do write before the test
-  bool quiet = false;
+  // QUIET STEP (see quiet_check_call).  What a step in which no stream is a keyframe still has to do behind the keyframe
+  // decision is detect_commit (per-step state), step_finalize and the output record; every other kernel of the chain
+  // returns at its first test of a flag that is off.  Those three are launched SPECULATIVELY right behind track_finalize,
+  // gated on the device (KParams::quiet_gate: they return unless no stream of the batch is a keyframe), while the host
+  // polls the flags track_finalize publishes: a quiet step is then complete without a host round trip in the middle of
+  // it, and a keyframe step goes on as always (three kernels that returned at once: ~20 us on one step of five).
   if (quiet_check) {
+    KParams Pq = P;
+    Pq.quiet_gate = 1;
+    const int oslot = (int)(c->out_steps % OUT_RING);
+    prof_begin(c, ST_SUBPIX, st);
+    launch_subpix_append(Pq, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1 | 512, st);   // (detect_commit only)
+    prof_end(c, ST_SUBPIX, st);
+    prof_begin(c, ST_FINALIZE, st);
+    launch_step_finalize(Pq, K, LKF, b.st, b.lst, b.ss, st);
+    prof_end(c, ST_FINALIZE, st);
+    if (c->right_pending) {   // the record of a step is not complete before its frames have left the caller's memory
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_up2, 0));
+      prof_break(c);
+    }
+    prof_begin(c, ST_OUT_PACK, st);
+    launch_out_pack(Pq, K, b.st, b.ss, c->out_host_dev[oslot], c->out_tab_bytes, c->out_cap, st);   // (out_direct: B <= 4)
+    prof_end(c, ST_OUT_PACK, st);
+    HIPCHK(c, hipEventRecord(c->ev_out[oslot], st));   // (a keyframe step records it again behind its own record)
+    prof_break(c);
     // the flag words carry this step's tag once track_finalize has written them; the poll is bounded (2 s), after that
     // the stream is awaited and the device copy of the flags read
-    quiet = true;
-    HostTimer _t4(4);
-    const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(2);
-    for (int s = 0; s < P.B && quiet; s++) {
-      volatile int* w = c->quiet_flags_host + s;
-      int v = *w;
-      for (unsigned spins = 0; (v >> 8) != c->quiet_seq; v = *w) {
-        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() > t_end) {
-          HIPCHK(c, hipStreamSynchronize(st));
-          HIPCHK(c, hipMemcpy(&v, b.ss.flags + s, sizeof(int), hipMemcpyDeviceToHost));
-          v |= c->quiet_seq << 8;
-          break;
-        }
+    bool quiet = true;
+    {
+      HostTimer _t4(4);
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+      for (int s = 0; s < P.B && quiet; s++) {
+        volatile int* w = c->quiet_flags_host + s;
+        int v = *w;
+        for (unsigned spins = 0; (v >> 8) != c->quiet_seq; v = *w) {
+          if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() > t_end) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipMemcpy(&v, b.ss.flags + s, sizeof(int), hipMemcpyDeviceToHost));
+            v |= c->quiet_seq << 8;
+            break;
+          }
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+          __builtin_ia32_pause();
 #endif
+        }
+        if (v & (FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO | FLAG_FIRST)) quiet = false;
       }
-      if (v & (FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO | FLAG_FIRST)) quiet = false;
     }
-    if (quiet) {   // nothing forks: the tail follows on the main stream
-      side = nullptr;
-      sd = st;
+    if (quiet) {   // the step is enqueued: what enqueue_outputs and the end of do_step keep track of
+      c->out_copied[oslot] = c->out_slot_size;
+      c->out_steps++;
+      HIPCHK(c, hipGetLastError());
+      std::swap(c->role_k, c->role_km1);
+      c->pyr_cur ^= 1;
+      c->prev_left = c->own_level0 ? b.lvl0[pc] : left;
+      c->prev_row_stride = c->own_level0 ? (size_t)P.W : row_stride;
+      c->prev_img_stride = c->own_level0 ? (size_t)P.W * P.H : img_stride;
+      return KVFE_OK;
     }
   }
   // Rectification right behind the keyframe decision, on the side stream, when the caller FORCES a keyframe on every
@@ -1220,10 +1255,11 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // at the reference cadence), so those keep the rectification at the head of the chain.
   bool all_forced = side && !P.mono && (c->fork_swap || (c->frames_persist_call && c->own_stream));
   for (int s = 0; s < P.B && all_forced; s++) all_forced = inputs[s].force_keyframe != 0;
-  const bool rect_early = all_forced && !quiet;
+  const bool rect_early = all_forced;
   if (rect_early) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
+    if (c->right_pending) HIPCHK(c, hipStreamWaitEvent(sd, c->ev_up2, 0));
     prof_begin(c, ST_RECTIFY, sd);
     const unsigned char* srcs[2] = {left, right};
     launch_rectify(P, c->T, srcs, row_stride, img_stride, b.rect, b.ss.flags, FLAG_STEREO, sd);
@@ -1232,7 +1268,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   }
   // keyframes: mono geometric outlier rejection before detection (it frees landmarks, so more
   // corners are extracted, StereoVisionImuFrontend.cpp:349-363,413-417)
-  if (!quiet) {
   prof_begin(c, ST_RANSAC_MONO, st);
   launch_mono_ransac(P, c->T, K, LKF, b.ss, b.rs, st);
   prof_end(c, ST_RANSAC_MONO, st);
@@ -1244,7 +1279,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   prof_begin(c, ST_SELECT, st);
   launch_select(P, c->T, K, b.ss, b.ds, -1, st);
   prof_end(c, ST_SELECT, st);
-  }
   if (P.mono) {
     // MonoVisionImuFrontend::processFrame (:288-318): refine + append the new corners, undistort all
     // keypoints (Camera::undistortKeypoints), measurements
@@ -1305,13 +1339,17 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     slot_release.side_used = true;
   }
   prof_begin(c, ST_SUBPIX, fa);
-  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, quiet ? (1 | 512) : 1, fa);
+  launch_subpix_append(P, c->T, left, row_stride, img_stride, K, b.ss, b.ds, 1, fa);
   prof_end(c, ST_SUBPIX, fa);
   if (side && (c->own_stream || swap)) {
     HIPCHK(c, hipEventRecord(c->ev_commit, fa));
     c->commit_pending = !swap;   // (swap: the next step's tracking follows the commit in stream order)
   }
-  if (!rect_early && !quiet) {
+  if (!rect_early) {
+  if (c->right_pending) {
+    HIPCHK(c, hipStreamWaitEvent(fb, c->ev_up2, 0));
+    prof_break(c);
+  }
   prof_begin(c, ST_RECTIFY, fb);
   {
     const unsigned char* srcs[2] = {left, right};
@@ -1319,11 +1357,9 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   }
   prof_end(c, ST_RECTIFY, fb);
   }
-  if (!quiet) {
   prof_begin(c, ST_STEREO, fb);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 1, fb);
   prof_end(c, ST_STEREO, fb);
-  }
   // stereo geometric outlier rejection on the matches of the tracked keypoints (:364-387).  Its results (right-keypoint
   // statuses of the outliers, the stereo pose and status; the PnP pose) are read by the tail only -- the landmark removal
   // that the next step's tracking reads is the mono rejection's -- so it runs at the head of the tail on the side stream,
@@ -1332,7 +1368,6 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
   // track_prepare and tracking launch and must therefore not write frame-table fields those read (K.kp, K.lmk, K.count).
   const bool ransac_tail = side && !swap;
   auto stereo_rejection = [&](hipStream_t rs) -> kvfe_status {
-  if (quiet) return KVFE_OK;
   prof_begin(c, ST_RANSAC_STEREO, rs);
   if (P.use_ransac) {
     // (the device's own predicate, rot_is_identity of kvfe_dev.hpp: a stream without a usable gyro rotation takes the
@@ -1363,14 +1398,13 @@ kvfe_status do_step(kvfe_ctx* c, const unsigned char* left, const unsigned char*
     }
   }
   if (ransac_tail) TRY(stereo_rejection(sd));
-  if (!quiet) {
   prof_begin(c, ST_STEREO_NEW, sd);
   launch_stereo(P, c->T, b.rect[0], b.rect[1], K, b.st, b.ss, FLAG_STEREO, c->pts_bound, 2, sd);
   prof_end(c, ST_STEREO_NEW, sd);
-  }
   prof_begin(c, ST_FINALIZE, sd);
   launch_step_finalize(P, K, LKF, b.st, b.lst, b.ss, sd);
   prof_end(c, ST_FINALIZE, sd);
+  if (c->right_pending) HIPCHK(c, hipStreamWaitEvent(sd, c->ev_up2, 0));   // (complete = the frames have left the caller's memory)
   TRY(enqueue_outputs(c, K, sd));
   if (side) {
     HIPCHK(c, hipEventRecord(c->ev_tail, sd));
@@ -1712,6 +1746,11 @@ void kvfe_destroy(kvfe_ctx* c) {
     hipStreamSynchronize(c->copy_stream);
     hipStreamDestroy(c->copy_stream);
   }
+  if (c->up2_stream) {
+    hipStreamSynchronize(c->up2_stream);
+    hipStreamDestroy(c->up2_stream);
+  }
+  if (c->ev_up2) hipEventDestroy(c->ev_up2);
   if (c->out_stream) {
     hipStreamSynchronize(c->out_stream);
     hipStreamDestroy(c->out_stream);
@@ -2570,10 +2609,32 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   if (eq) join_tail(c);
   unsigned char* ul = eq ? b.rect[0] : dl;  // (rectified buffers are free until rectification runs)
   unsigned char* ur = eq ? b.rect[1] : dr;
+  // a few streams: the right image on its own stream (see up2_stream).  Its target slot was last read by the
+  // rectification of the frame two steps back, and everything of a step is behind its ring event.
+  static const bool up2_env = [] { const char* e = std::getenv("KVFE_RIGHT_UPLOAD_STREAM"); return !e || std::atoi(e) != 0; }();   // (A/B switch)
+  hipStream_t rstream = c->stream;
+  if (up2_env && P.B <= 4 && !eq && !P.mono && c->own_stream && c->side) {
+    if (!c->up2_stream) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->up2_stream, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_up2, hipEventDisableTiming));
+    }
+    for (int back = 1; back <= 2; back++) {
+      const int ps = (c->ring_pos + kvfe_ctx::RING - back) % kvfe_ctx::RING;
+      if (c->ring_used[ps]) HIPCHK(c, hipStreamWaitEvent(c->up2_stream, c->ring_ev[ps], 0));
+    }
+    rstream = c->up2_stream;
+  }
   if (row_stride == (size_t)P.W && image_stride == N) {  // tightly packed batch: one copy per side
     HostTimer _t6(6);
     HIPCHK(c, hipMemcpyAsync(ul, left, N * P.B, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ur, right, N * P.B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ur, right, N * P.B, hipMemcpyHostToDevice, rstream));
+  } else if (rstream != c->stream) {
+    for (int s = 0; s < P.B; s++)
+      HIPCHK(c, hipMemcpy2DAsync(ul + s * N, P.W, left + s * image_stride, row_stride, P.W, P.H,
+                                 hipMemcpyHostToDevice, c->stream));
+    for (int s = 0; s < P.B; s++)
+      HIPCHK(c, hipMemcpy2DAsync(ur + s * N, P.W, right + s * image_stride, row_stride, P.W, P.H,
+                                 hipMemcpyHostToDevice, rstream));
   } else {
     for (int s = 0; s < P.B; s++) {
       HIPCHK(c, hipMemcpy2DAsync(ul + s * N, P.W, left + s * image_stride, row_stride, P.W, P.H,
@@ -2588,9 +2649,14 @@ kvfe_status kvfe_frontend_step_host(kvfe_ctx* c, const uint8_t* left, const uint
   }
   c->img_step++;
   c->last_step_staged = false;
+  if (rstream != c->stream) {
+    HIPCHK(c, hipEventRecord(c->ev_up2, rstream));
+    c->right_pending = true;
+  }
   c->quiet_check_call = true;
   const kvfe_status r = do_step(c, dl, dr, P.W, N, inputs);
   c->quiet_check_call = false;
+  c->right_pending = false;
   return r;
 }
 

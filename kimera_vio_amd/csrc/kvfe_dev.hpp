@@ -22,6 +22,8 @@ constexpr int MAX_RADIUS = 127;
 struct KParams {
   int W, H, B;
   int n_cu;  // compute units of the context's device (launch shapes; filled at context creation)
+  int quiet_gate;  // 1: detect_commit / step_finalize / out_pack return unless NO stream of the batch is a keyframe (the
+                   // speculative tail of a quiet step, do_step; a few streams)
   int kcap;  // keypoint capacity per stream
   int ccap;  // candidate capacity per stream
   int acap;  // accepted-corner capacity per stream (<= 8192)
@@ -218,6 +220,13 @@ enum : int {
   FLAG_OVERFLOW = 16,
   FLAG_FIRST = 32,  // processFirstStereoFrame: no stereo measurements are produced
 };
+// KParams::quiet_gate: no stream of the batch is a keyframe, detects or matches in this step (a few streams)
+__device__ __forceinline__ bool kvfe_all_quiet(const int* flags, int B) {
+  for (int t = 0; t < B; t++)
+    if (flags[t] & (FLAG_KEYFRAME | FLAG_DETECT | FLAG_STEREO | FLAG_FIRST)) return false;
+  return true;
+}
+
 
 // detection scratch
 struct DetectScratch {
