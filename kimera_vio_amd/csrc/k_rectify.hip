@@ -412,6 +412,22 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
     ty = blockIdx.x / tiles_x;
     cam = blockIdx.y;
     s_begin = blockIdx.z * (SPB * NSUB);
+  } else if (mode & 8) {
+    // 1-D grid, an XCD per STREAM GROUP (round 6).  Workgroups are dealt round-robin to the 8 XCDs (block L runs on XCD
+    // L & 7, a speed assumption only): XCD k takes the stream groups k, k + 8, .. and walks a group's tiles in raster order,
+    // camera by camera, so the source rows two neighbouring tiles share (a 128 x 16 tile stages ~24 rows of ~160 bytes:
+    // 1.9 x its own pixels) are fetched by ONE L2 and are still there when the neighbour asks.  Every XCD does the same
+    // amount of work whatever the image height (the banded order below gives 3 or 4 of 30 tile rows to an XCD).
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int per = tiles_x * tiles_y * 2;
+    const int g = xcd + 8 * (j / per);
+    if (g >= gz) return;
+    const int t = j % per;
+    cam = t / (tiles_x * tiles_y);
+    const int tt = t - cam * (tiles_x * tiles_y);
+    ty = tt / tiles_x;
+    tx = tt - ty * tiles_x;
+    s_begin = g * (SPB * NSUB);
   } else {
     // XCD-banded 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (block L runs on XCD L & 7, a speed
     // assumption only): XCD k owns the k-th band of tile rows of both cameras for ALL streams and walks it
@@ -583,6 +599,9 @@ __global__ __launch_bounds__(256, MINW) void rectify_tile_kernel(
           unsigned px[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
+            // (round 6: the two pixels of a row in ONE 16-bit read at the byte address -- hipcc emits ds_read_u16 for an
+            // align-1 load on gfx950 -- and a byte permute into the dot product's lanes: bit-exact, and the launch takes
+            // 0.174 ms instead of 0.042: a 16-bit LDS read at an odd address is replayed; tools/r6/gpu_rect_xcd.sh)
             lds_cu8_t* a = (lds_cu8_t*)(size_t)ad[4 * r + q] + pk_off;
             px[q] = rblend(a[0], a[1], a[RT_PITCH], a[RT_PITCH + 1], tp[4 * r + q].w0, tp[4 * r + q].w1);
           }
@@ -645,8 +664,12 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
   // LDS-staged tiles where the source rows are 16-byte aligned, per-lane gathers (rectify_kernel) otherwise.
   // KVFE_RECT_FORCE_GATHER (debugging aid, tests/test_gpu_parity.py): every tile takes the gather fallback of the tile
   // kernel.  Measured and removed in round 4 (profiles/r3_analysis.md section 6): tile height 32, 1 / 4 streams per LDS
-  // buffer, both buffers requested together (-2 %), the XCD-banded block order (-8 % alone, +6 % inside the step).
-  static const int tmode = std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0;
+  // buffer, both buffers requested together (-2 %), the XCD-banded block order (-8 % alone, +6 % inside the step: 3 or 4 of
+  // the 30 tile rows per XCD).
+  static const int fmode = std::getenv("KVFE_RECT_FORCE_GATHER") ? 2 : 0;
+  // KVFE_RECT_XCD (A/B switch): 0 = 3-D grid (tile, camera, stream group), 1 = XCD-banded, 2 = an XCD per stream group
+  static const int xcd_env = [] { const char* e = std::getenv("KVFE_RECT_XCD"); return e ? std::atoi(e) : -1; }();
+  int tmode = fmode;
   const int impl = 1, spb = 2, nsub = 4, th = 16;
   const bool aligned = P.W % 4 == 0 && src_row_stride % 16 == 0 && src_img_stride % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(src[0]) % 16 == 0 && reinterpret_cast<uintptr_t>(src[1]) % 16 == 0;
@@ -662,7 +685,15 @@ void launch_rectify(const KParams& P, const Tables& T, const unsigned char* cons
     const int per_block = S * NS;
     const int gz = (P.B + per_block - 1) / per_block;
     dim3 grid(tiles_x * tiles_y, 2, gz);
-    if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
+    // Round 6 (tools/r6/gpu_rect_xcd.sh, gpu_rect_pmc.sh; 64 x 752x480, same call): 3-D grid 0.0421 / 0.0425 ms alone,
+    // FETCH_SIZE 62.4 MB (x 2: 124.8) + WRITE_SIZE 50.9 MB = 1.90 x the algorithmic bytes; XCD-banded 0.0398 / 0.0394; an
+    // XCD per stream group 0.0393 / 0.0392 ms, 32.8 MB (x 2: 65.6) + 45.3 MB = 1.20 x -- a third less traffic buys 7 %:
+    // the launch is bound by its LDS gather and instruction issue, not by HBM.
+    const int xcd_mode = xcd_env >= 0 ? xcd_env : 2;
+    if (xcd_mode == 1) tmode |= 1;
+    if (xcd_mode == 2 && gz % 8 == 0) tmode |= 1 | 8;   // (fewer groups than XCDs: the 3-D grid)
+    if (tmode & 8) grid = dim3(8 * tiles_x * tiles_y * 2 * (gz / 8));
+    else if (tmode & 1) grid = dim3(8 * ((tiles_y + 7) / 8) * tiles_x * 2 * gz);
     const size_t lds = (size_t)S * (NS > 1 ? 2 : 1) * rt_patch(TH) + 64;
     const bool use_box = TH == 16 && T.rect_box[0] && T.rect_box[1];
     // KVFE_RECT_FLOAT_MAP (debugging aid, A/B): the tiles read the float map although the packed taps exist
