@@ -1,4 +1,4 @@
-# one GPU call of round 6 on the final build (tools/r5/gpu_round.sh): sanity, parity tests, the full bench line, then (PROFILE=1) the rocprofv3
+# one GPU call of round 6 on the final build (successor of tools/history/r5/gpu_round.sh): sanity, parity tests, the full bench line, then (PROFILE=1) the rocprofv3
 # passes -- kernel traces (c3 / c5 / c2), FETCH_SIZE / WRITE_SIZE per leg (each leg alone), SQ counters of the c3 leg.
 # Every leg has its own short timeout (a wedged box must not eat the budget).
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$PWD

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r6/save_profiles.sh <tag>: summarise the rocprofv3 databases of the last tools/gpu_r3_round.sh PROFILE=1 run
+# tools/r6/save_profiles.sh <tag>: summarise the rocprofv3 databases of the last tools/r6/gpu_round.sh PROFILE=1 run
 # (gpurun_out/, scratch) into profiles/<tag>_*.{md,json,log} (tracked).
 set -e
 T=$1
@@ -8,7 +8,7 @@ cp gpurun_out/gpu_tests.log profiles/${T}_gpu_tests.log
 for L in "" _c5 _c2 _e; do
   db=$(find gpurun_out/prof_kt$L -name "*.db" 2>/dev/null | head -1)
   if [ -n "$db" ]; then
-  { echo "# rocprofv3 --kernel-trace --stats, bench.py leg ${L:-_c3} alone (see tools/gpu_r3_round.sh for the command)"; echo;
+  { echo "# rocprofv3 --kernel-trace --stats, bench.py leg ${L:-_c3} alone (see tools/r6/gpu_round.sh for the command)"; echo;
     python tools/rocpd_stats.py $db; } > profiles/${T}_rocprof_kernel_stats${L}.md
   fi
 done
