@@ -945,7 +945,12 @@ def dense_stereo(F, WL, W, H, dev, pmc_leg):
                                  "two-pass minimum of cv::StereoSGBM MODE_HH (~6 cost-volume transfers), which `achieved` "
                                  "and `frac` are priced against; design_traffic_* = what this implementation's two "
                                  "aggregation passes move (rounds 1-4: eight sweeps); traffic = PMC bytes per pair of the "
-                                 "dense_* / speckle_* kernels"},
+                                 "dense_* / speckle_* kernels, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 rule, the "
+                                 "one rule used for every kernel of this file and of profiles/r6_analysis.md)"},
+            "parity": "unpinned -- HIP == oracle bit for bit (tests/test_gpu_dense_twopass.py, tests/test_gpu_parity.py), but "
+                      "the oracle's SGBM / BM restate OpenCV 4.2's published algorithm and are pinned on an independent numpy "
+                      "statement only: the reference's own test of this method is a stub (tests/testStereoMatcher.cpp:131) "
+                      "and OpenCV is not in this image",
             "valid_fraction_pair0": round(valid, 3)}
 
 

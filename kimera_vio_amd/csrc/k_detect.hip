@@ -2627,8 +2627,9 @@ void launch_subpix_append(const KParams& P, const Tables& T, const unsigned char
   // (stream, corner slot) up to the bound of the new corners, the stream is the fast grid index (see the kernel); a
   // grid sized to what the device holds at once, every block walking ~10 corners, lost 24 % on real frames (round 3:
   // the corners' iteration counts differ too much for a static assignment).
-  static const int nw_env = [] { const char* e = std::getenv("KVFE_SUBPIX_NW"); return e ? std::atoi(e) : 0; }();   // (A/B switch)
-  const int nw = (nw_env == 2 || nw_env == 4) ? nw_env : (P.B <= 4 ? 4 : 2);
+  // (Round 6, four waves per corner at 64 streams: 0.45 against 0.40 ms over a feature-age period, and the quiet steps alone --
+  // ~640 corners in the launch -- 225 - 270 against 180 - 190 us: tools/r6/gpu_subpix_nw.sh, profiles/r6_analysis.md section 8.)
+  const int nw = P.B <= 4 ? 4 : 2;
   // (corner slots per stream: a block walks its stream's corners with the stride of the grid, so the grid only has to
   // hold the corners this kernel is FOR -- fewer than SPG_MIN_TOTAL over the whole launch, otherwise the grouped kernel
   // works and these blocks return -- instead of one block per possible corner, 50 k mostly empty blocks at 64 streams)

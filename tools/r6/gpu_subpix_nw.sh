@@ -1,4 +1,5 @@
-# round 6: waves per corner of the one-corner cornerSubPix kernel at 64 streams (KVFE_SUBPIX_NW = 2 | 4)
+# round 6: waves per corner of the one-corner cornerSubPix kernel at 64 streams (KVFE_SUBPIX_NW = 2 | 4: the switch was removed with the
+# variant's loss -- 0.45 against 0.40 ms; a record, not a runnable A/B)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for V in ${VS:-2 4 2 4}; do
 export KVFE_SUBPIX_NW=$V
