@@ -613,6 +613,7 @@ def main():
             "workload": "as `value`, kvfe_config.single_hip_stream = 1 (no side stream, no output stream), HIP events "
                         "around every stage of 12 steps",
             "ms_per_step": leg["ms_per_step"],
+            "stage_ms_per_step": leg.get("stage_ms_per_step_summed_over_groups"),
             "kernels": [{k: r[k] for k in ("kernel", "avg_launch_ms", "achieved", "frac", "alg_bytes_per_launch") if k in r}
                         for r in leg.get("roofline_kernels", [])],
             "weighted": leg.get("roofline_dense_weighted")}
