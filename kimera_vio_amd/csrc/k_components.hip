@@ -51,22 +51,25 @@ void launch_check_undistorted_rectified(const float2* map, int W, int H, const f
                      distorted, undistorted, n, pixel_tol, out_xy, out_status);
 }
 
-__global__ void distort_unrectify_kernel(const float2* __restrict__ map, int W, const float2* __restrict__ rect_xy,
+__global__ void distort_unrectify_kernel(const float2* __restrict__ map, int W, int H, const float2* __restrict__ rect_xy,
                                          const unsigned char* __restrict__ status, int n, float2* __restrict__ out_xy) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float2 o = make_float2(0.f, 0.f);
   if (status[i] == KVFE_KP_VALID) {
+    // a VALID keypoint outside the image: upstream's map_x_.at<float>() is an unchecked read (undefined); here the map
+    // entry of the nearest pixel (k_stereo.hip stereo_match_kernel, oracle/kimera.cpp)
     const float2 px = rect_xy[i];
-    o = map[(size_t)(int)roundf(px.y) * W + (int)roundf(px.x)];
+    const int ry = min(max((int)roundf(px.y), 0), H - 1), rx = min(max((int)roundf(px.x), 0), W - 1);
+    o = map[(size_t)ry * W + rx];
   }
   out_xy[i] = o;
 }
 
-void launch_distort_unrectify(const float2* map, int W, const float2* rect_xy, const unsigned char* status, int n,
+void launch_distort_unrectify(const float2* map, int W, int H, const float2* rect_xy, const unsigned char* status, int n,
                               float2* out_xy, hipStream_t st) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(distort_unrectify_kernel, dim3((n + 255) / 256), dim3(256), 0, st, map, W, rect_xy, status, n,
+  hipLaunchKernelGGL(distort_unrectify_kernel, dim3((n + 255) / 256), dim3(256), 0, st, map, W, H, rect_xy, status, n,
                      out_xy);
 }
 

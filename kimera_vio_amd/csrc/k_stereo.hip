@@ -611,7 +611,11 @@ __global__ __launch_bounds__(64) void stereo_match_kernel(KParams P, Tables T,
   // distortUnrectifyKeypoints (UndistorterRectifier.cpp:213-228)
   float2 rraw = make_float2(0.f, 0.f);
   if (rstatus == 0) {
-    const int yy = (int)roundf(rkp.y), xx = (int)roundf(rkp.x);
+    // (cornerSubPix may leave a match up to its half window OUTSIDE the image -- a stripe at the image edge -- and upstream's
+    // map_x_.at<float>(round(y), round(x)) is an unchecked read there (cv::Mat::at asserts in debug builds only): undefined
+    // upstream, defined here and in the oracle as the map entry of the nearest pixel.  Found by tools/fuzz_components.py
+    // (seed 63, configuration 66: a memory access fault when the map happened to end a mapping).)
+    const int yy = min(max((int)roundf(rkp.y), 0), P.H - 1), xx = min(max((int)roundf(rkp.x), 0), P.W - 1);
     rraw = T.map[1][(size_t)yy * P.W + xx];
   }
   ST.right_kp[o] = rraw;
@@ -834,7 +838,7 @@ __global__ void rgbd_fill_kernel(KParams P, Tables T, const void* __restrict__ d
         dep = (double)d;
         const double v2 = K.versor[o * 3 + 2];
         for (int c = 0; c < 3; c++) p3[c] = K.versor[o * 3 + c] * (double)d / v2;
-        const int ry = (int)roundf(rr.y), rx = (int)roundf(rr.x);
+        const int ry = min(max((int)roundf(rr.y), 0), P.H - 1), rx = min(max((int)roundf(rr.x), 0), P.W - 1);   // (see stereo_match_kernel)
         rk = T.map[0][(size_t)ry * P.W + rx];
       }
     }

@@ -2171,7 +2171,7 @@ kvfe_status kvfe_distort_unrectify_keypoints(kvfe_ctx* c, int32_t cam, const flo
   hipStream_t st = c->stream;
   HIPCHK(c, hipMemcpyAsync(b.st.right_rect, rect_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(b.st.right_status, status, (size_t)n, hipMemcpyHostToDevice, st));
-  launch_distort_unrectify(c->T.map[cam], P.W, b.st.right_rect, b.st.right_status, n, b.st.right_kp, st);
+  launch_distort_unrectify(c->T.map[cam], P.W, P.H, b.st.right_rect, b.st.right_status, n, b.st.right_kp, st);
   HIPCHK(c, hipMemcpyAsync(out_xy, b.st.right_kp, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   return KVFE_OK;

@@ -427,7 +427,7 @@ void launch_undistort_points(const UndistortDev& U, const float2* in, int n, flo
 void launch_check_undistorted_rectified(const float2* map, int W, int H, const float2* distorted,
                                         const float2* undistorted, int n, float pixel_tol, float2* out_xy,
                                         unsigned char* out_status, hipStream_t st);
-void launch_distort_unrectify(const float2* map, int W, const float2* rect_xy, const unsigned char* status, int n,
+void launch_distort_unrectify(const float2* map, int W, int H, const float2* rect_xy, const unsigned char* status, int n,
                               float2* out_xy, hipStream_t st);
 void launch_depth_from_matches(const float2* left_xy, const unsigned char* left_status, const float2* right_xy,
                                unsigned char* right_status, int n, double fx_b, double min_dist, double max_dist,

@@ -210,7 +210,9 @@ void StereoCamera::distortUnrectifyKeypoints(int cam, const std::vector<StatusKe
   out.reserve(rectk.size());
   for (const StatusKeypoint& sk : rectk) {
     if (sk.status == KVFE_KP_VALID) {
-      int ry = (int)std::round(sk.kp.y), rx = (int)std::round(sk.kp.x);
+      // (upstream: map_x_.at<float>(round(y), round(x)), unchecked in release builds -- a VALID keypoint that cornerSubPix
+      // left outside the image reads out of bounds there; defined here, as on the device, as the nearest pixel's entry)
+      int ry = std::min(std::max((int)std::round(sk.kp.y), 0), h - 1), rx = std::min(std::max((int)std::round(sk.kp.x), 0), w - 1);
       out.push_back({map_x[cam][(size_t)ry * w + rx], map_y[cam][(size_t)ry * w + rx]});
     } else {
       out.push_back({0.0f, 0.0f});
@@ -1149,7 +1151,7 @@ void Frontend::fillStereoFrame(StereoFrame& sf, const void* depth, size_t stride
   for (size_t i = 0; i < n; ++i) {
     if (sf.right_kp_rect[i].status != KVFE_KP_VALID) continue;
     const Point2f px = sf.right_kp_rect[i].kp;
-    const int ry = (int)std::round(px.y), rx = (int)std::round(px.x);
+    const int ry = std::min(std::max((int)std::round(px.y), 0), cam.h - 1), rx = std::min(std::max((int)std::round(px.x), 0), cam.w - 1);
     sf.right_kp[i] = Point2f{cam.map_x[0][(size_t)ry * w + rx], cam.map_y[0][(size_t)ry * w + rx]};
   }
 }

@@ -1,7 +1,8 @@
 """Randomised GPU-vs-oracle comparison of the component calls (not part of the test suite): rectification,
 LK (random points incl. the image border and outside, random window / levels / images), sub-pixel refinement,
 epipolar stereo search, flow predictor, undistortion, on random image sizes incl. small ones.
-Usage: python tools/fuzz_components.py [n_configs] [seed]"""
+Usage: python tools/fuzz_components.py [n_configs] [seed] [only]     (only = k: configuration k alone, with the random
+draws of the ones before it replayed -- to reproduce a finding of a long run)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,11 +13,17 @@ from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workl
 G = os.path.join(ROOT, "tests", "golden")
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 bad = 0
+
+
+TRACE = os.environ.get("FUZZ_TRACE") is not None
 
 
 def check(name, a, b, desc):
     global bad
+    if TRACE:
+        print("   checked", name, flush=True)
     if not np.array_equal(a, b, equal_nan=True):
         bad += 1
         n = np.count_nonzero(a != b) if getattr(a, "shape", None) == getattr(b, "shape", None) else "shape"
@@ -45,6 +52,13 @@ for ci in range(n_cfg):
                 ssub=p.stereo.subpixel_refinement)
     if p.stereo.templ_cols >= w:
         continue
+    if ONLY >= 0 and ci != ONLY:   # the draws of a configuration that is skipped (same order as below)
+        n = 200
+        rng.randint(0, 1000); rng.randint(0, 256, (h, w)); rng.uniform(-6, w + 6, n); rng.uniform(-6, h + 6, n)
+        rng.uniform(0, w - 1, n); rng.uniform(0, h - 1, n); rng.normal(0, 2.0, (n, 2))
+        rng.normal(size=3); rng.uniform(0, 3); rng.uniform(-2, w + 2, n); rng.uniform(-2, h + 2, n); rng.randint(0, 10, n)
+        continue
+    print(ci, "start", desc, flush=True)
     try:
         c = F.Context(L, R, p)
     except F.KvfeError as e:
