@@ -482,6 +482,16 @@ KVFE_API kvfe_status kvfe_build_optical_flow_pyramid(kvfe_ctx* ctx, const uint8_
                                                      int32_t* n_levels_out,
                                                      uint8_t* level0_copy_out);
 
+/* test hook: the front-end's OWN pyramid of the frame of the last step (steps_back 0) or of the one
+ * before (steps_back 1) -- what the next tracking launch reads as its previous frame -- after awaiting
+ * the context.  levels_out: per stream the levels 1..L packed as kvfe_build_optical_flow_pyramid packs
+ * them; level0_copy_out: [batch][H][W], the context-owned level-0 copy of device-pointer steps with
+ * device_frames_persist 0 (KVFE_ERR_UNSUPPORTED on other paths).  Either may be NULL.  One stream
+ * group only.  (tools/r6/pyr_probe.py: the pyramid launch checked in place, step by step.) */
+KVFE_API kvfe_status kvfe_frontend_debug_pyramid(kvfe_ctx* ctx, int32_t steps_back,
+                                                 uint8_t* level0_copy_out, uint8_t* levels_out,
+                                                 size_t levels_capacity);
+
 /* OpticalFlowPredictor::predictSparseFlow
  * (optical-flow/OpticalFlowPredictor.cpp:27-33,70-126); ref_R_cur row-major. */
 KVFE_API kvfe_status kvfe_predict_sparse_flow(kvfe_ctx* ctx, const float* prev_xy,

@@ -927,10 +927,19 @@ __device__ __forceinline__ void pyr2_strip(const Pyr2Args& A, uint2* ring, int s
   // rows are consumed in request order (vmcnt counts in order): row i is worked on while rows i+1.. are still in flight
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(COPY ? A.copy_dst + (size_t)s * A.cimg : nullptr, 0,
                                                                      COPY ? h0 * w0 : 0, 0x00027000);
-  const unsigned coff = owner ? (unsigned)gl * 16u : 0xffffffffu;
+  // The 16-byte store takes its row offset in the VECTOR offset, the scalar offset is the constant 0 -- NOT the row offset
+  // in an SGPR as the loads and the narrower stores do.  gfx950 reads the data registers of a store of more than 64 bits
+  // after the instruction has issued: a VALU write of one of them in the very next issue slot changes what lanes 12 - 15
+  // of every row of 16 store (measured, round 6: tools/fuzz_batched.py 120 2 79 -- the first dword of the copy's 16 bytes
+  // replaced by the next row's v_perm_b32 result when a wave runs alone on its SIMD, one run in three; tools/r6/
+  // gpu_pyr_probe.sh reads the copy back).  The compiler pads that hazard with an s_nop only for a store WITHOUT an SGPR
+  // offset (its rule: "a buffer store that uses an SGPR offset needs no wait state") -- so this store has none.
+  // tests/test_isa_hazards.py scans the compiled code of every kernel for the pattern.  (Lanes that own nothing: offset
+  // 2^31 + row offset, which the bounds check drops -- an image is smaller than 2^31 bytes.)
+  const unsigned coff = owner ? (unsigned)gl * 16u : 0x80000000u;
   auto keep = [&](int i) {   // level-0 copy of source row kb + i
     if (COPY && i >= I0 && i < I0 + 4 * T2 && (INTERIOR || kb + i < h0))
-      __builtin_amdgcn_raw_buffer_store_b128(R[i], rc, coff, (unsigned)(kb + i) * (unsigned)w0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(R[i], rc, coff + (unsigned)(kb + i) * (unsigned)w0, 0, 0);
   };
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(A.dst1 + (size_t)s * A.dimg, 0, h1 * w1, 0x00027000);
   const unsigned o1 = owner ? (unsigned)gl * 8u : 0xffffffffu;

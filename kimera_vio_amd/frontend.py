@@ -229,6 +229,32 @@ class Context:
             levels.append(lv)
         return levels, cp
 
+    def debug_pyramid(self, steps_back=0, with_level0_copy=True):
+        """test hook (kvfe_frontend_debug_pyramid): the front-end's own pyramid of the last step's frame (or the one
+        before): (levels, copy) as build_optical_flow_pyramid returns them, for every stream of the batch."""
+        sizes = np.zeros(2 * 16, np.int32)
+        nlev = np.zeros(1, np.int32)
+        H, W, n = self.h, self.w, self.batch
+        probe = np.zeros((1, H, W), np.uint8)
+        tmp = np.zeros(H * W, np.uint8)
+        self._chk(self.lib.kvfe_build_optical_flow_pyramid(self._h, probe.ctypes.data, W, H * W, 1, _p(tmp), tmp.size,
+                                                           _p(sizes), _p(nlev), None), "build_optical_flow_pyramid")
+        L = int(nlev[0])
+        per = sum(int(sizes[2 * l]) * int(sizes[2 * l + 1]) for l in range(1, L))
+        out = np.zeros(max(1, n * per), np.uint8)
+        cp = np.zeros((n, H, W), np.uint8) if with_level0_copy else None
+        self._chk(self.lib.kvfe_frontend_debug_pyramid(self._h, steps_back, _p(cp) if cp is not None else None, _p(out),
+                                                       out.size), "debug_pyramid")
+        levels = []
+        for s in range(n):
+            off, lv = s * per, []
+            for l in range(1, L):
+                w, h = int(sizes[2 * l]), int(sizes[2 * l + 1])
+                lv.append(out[off:off + w * h].reshape(h, w).copy())
+                off += w * h
+            levels.append(lv)
+        return levels, cp
+
     def predict_sparse_flow(self, prev_xy, ref_R_cur) -> np.ndarray:
         p = _pts(prev_xy)
         R = np.ascontiguousarray(ref_R_cur, np.float64).reshape(9)

@@ -85,6 +85,7 @@ def load() -> C.CDLL:
     L.kvfe_dense_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.kvfe_backproject_disparity_to_3d.argtypes = [vp, vp, sz, vp]
     L.kvfe_dense_debug_volume.argtypes = [vp, i32, vp, sz]
+    L.kvfe_frontend_debug_pyramid.argtypes = [vp, i32, vp, vp, sz]
     L.kvfe_frontend_staging_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.kvfe_frontend_staging_wait.argtypes = [vp, i32]
     L.kvfe_frontend_step_staged.argtypes = [vp, i32, vp]
@@ -177,7 +178,8 @@ def load() -> C.CDLL:
                "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_frontend_get_output_at", "kvfe_frontend_get_outputs", "kvfe_frontend_view_output",
                "kvfe_profile_enable",
                "kvfe_profile_read", "kvfe_dense_stereo_reconstruction", "kvfe_dense_profile_read",
-               "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume", "kvfe_outlier_rejection_3d3d",
+               "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume", "kvfe_frontend_debug_pyramid",
+               "kvfe_outlier_rejection_3d3d",
                "kvfe_outlier_rejection_2d2d"):
         getattr(L, fn).restype = C.c_int32
     _lib = L
@@ -221,5 +223,6 @@ EXPORTED_SYMBOLS = NEW_R6_SYMBOLS + NEW_R4_SYMBOLS + NEW_R3_SYMBOLS + NEW_R2_SYM
     "kvfe_frontend_reset", "kvfe_synchronize", "kvfe_frontend_get_output", "kvfe_profile_enable",
     "kvfe_profile_read", "kvfe_dense_stereo_params_default", "kvfe_dense_stereo_reconstruction",
     "kvfe_dense_profile_read", "kvfe_backproject_disparity_to_3d", "kvfe_dense_debug_volume",
+    "kvfe_frontend_debug_pyramid",
     "kvfe_outlier_rejection_3d3d", "kvfe_outlier_rejection_2d2d",
 ]

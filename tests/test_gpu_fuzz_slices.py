@@ -53,3 +53,14 @@ def test_fuzz_ransac_slice():
     out = _run("fuzz_ransac.py", 12, 41)
     m = re.search(r"mismatching checks: (\d+)", out)
     assert m and int(m.group(1)) == 0, out[-4000:]
+
+
+def test_fuzz_batched_slice():
+    """round 6: batches of 5 - 24 streams with different sequences and cadences through every entry point (host, device
+    with device_frames_persist 0 / 1, staged), random sizes / windows (24 = the four-points-per-wave tracking kernel) /
+    pyramid depths / ANMS types: 8 configurations, every stream compared on every step"""
+    out = _run("fuzz_batched.py", 8, 51, timeout=900)
+    m = re.search(r"configs failed: (\d+) of (\d+)", out)
+    assert m and int(m.group(2)) == 8, out[-2000:]
+    assert int(m.group(1)) == 0, out[-4000:]
+    assert out.count(" ok ") >= 6, out[-4000:]

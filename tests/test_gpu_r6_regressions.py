@@ -7,7 +7,18 @@
    in front of the rectification map on the device: a GPU memory access fault when the map happened to begin a mapping
    (it took 66 configurations of allocation history to get there).  The library and the oracle now define the case as
    "the map entry of the nearest pixel"; this test holds the case itself (asserted on the oracle's output, so that it
-   keeps testing what it says) and compares every output of StereoMatcher::sparseStereoReconstruction."""
+   keeps testing what it says) and compares every output of StereoMatcher::sparseStereoReconstruction.
+
+2. tools/fuzz_batched.py, seed 2, configuration 79 (12 streams of 752 x 480, klt_max_level 1, device-pointer steps with
+   device_frames_persist 0): one run in three, a tracked keypoint of streams 8 - 11 differed from the oracle.  The
+   context's own pyramid read back in place (kvfe_frontend_debug_pyramid) showed the level-0 copy with the first dword of
+   some 16-byte groups replaced -- columns 192 - 255, 448 - 511, 704 - 751 of one row = lanes 12 - 15 of every row of 16
+   lanes -- by [0, 0, c, b]: the v_perm_b32 that follows the copy's buffer_store_dwordx4 in pyr2_kernel and overwrites
+   the store's first data register.  gfx950 reads the data of a store of more than 64 bits after issue; hipcc pads that
+   hazard except for a store with an SGPR offset; a wave that issues back to back (the second group of 8 streams had
+   only 4: its waves ran alone on their SIMDs) hits it.  The store now carries its row offset in the vector offset
+   (k_rectify.hip, pyr2_strip), tools/check_store_data_hazard.py scans the compiled code of every kernel file
+   (tests/test_host_logic.py), and the second test below repeats the launch that showed it."""
 import os
 
 import numpy as np
@@ -57,5 +68,81 @@ def test_right_keypoint_refined_out_of_the_image_is_looked_up_at_the_nearest_pix
                 if k in e and k in g:
                     assert np.array_equal(g[k], e[k], equal_nan=True), (seed, k)
         assert found >= 1, "no VALID right keypoint outside the image in any of the scenes: the case is gone"
+    finally:
+        ctx.close()
+
+
+def test_level0_copy_of_the_pyramid_launch_with_a_half_empty_stream_group():
+    """finding 2: the launch itself (pyr2_kernel with the level-0 copy, 12 images = one full group of 8 streams and one
+    with 4, whose waves run alone on their SIMDs), 150 times; the copy and every level against the oracle's cv::pyrDown.
+    The build with the hazard failed one launch in ~20 (tools/r6/gpu_pyr_probe.sh: 15 corrupted copies in 280 steps)."""
+    w, h = 752, 480
+    L, R = workloads.make_cameras(w, h)
+    for max_level in (1, 3):     # one-level launch (COPY, no second level) and the two-level launch of the shipped pyramid
+        p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
+        p.tracker.klt_max_level = max_level
+        ctx = F.Context(L, R, p)
+        try:
+            rng = np.random.RandomState(5 + max_level)
+            imgs = rng.randint(0, 256, (12, h, w)).astype(np.uint8)
+            exp = []
+            for s in range(12):
+                lv, src = [], imgs[s]
+                for _ in range(max_level):
+                    src = O.pyr_down(src)
+                    lv.append(src)
+                exp.append(lv)
+            for it in range(150):
+                levels, cp = ctx.build_optical_flow_pyramid(imgs, with_level0_copy=True)
+                if not np.array_equal(cp, imgs):
+                    s_, ys, xs = np.nonzero(cp != imgs)
+                    raise AssertionError("launch %d, klt_max_level %d: level-0 copy differs at %d bytes, stream %d row %d "
+                                         "columns %s" % (it, max_level, len(ys), s_[0], ys[0], xs[:16].tolist()))
+                for s in range(12):
+                    assert len(levels[s]) == max_level
+                    for l in range(max_level):
+                        assert np.array_equal(levels[s][l], exp[s][l]), (it, max_level, s, l)
+        finally:
+            ctx.close()
+
+
+def test_level0_copy_read_back_in_place_over_front_end_steps():
+    """finding 2 where it was found: 12 streams of 752 x 480, klt_max_level 1, device-pointer steps with
+    device_frames_persist 0; after every step the context's own level-0 copy and pyramid are read back
+    (kvfe_frontend_debug_pyramid) and compared with the frame and with the oracle's cv::pyrDown.  (The component call of
+    the test above runs the same launch but did not show the hazard on the build that had it: whether a wave issues the
+    store and the next instruction back to back depends on what else the chip is doing.)"""
+    import torch
+    w, h, B = 752, 480, 12
+    L, R = workloads.make_cameras(w, h)
+    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
+    p.detector.max_features_per_frame = 60
+    p.tracker.klt_max_level = 1
+    p.tracker.klt_max_iter = 10
+    p.tracker.max_feature_track_age = 4
+    ctx = F.Context(L, R, p, batch=B, device_frames_persist=0)
+    try:
+        R1 = np.array(ctx.rect.R1).reshape(3, 3)
+        streams = [synth.RigStream(L, R, seed=100 + s, rect_R1=R1) for s in range(B)]
+        keep, frames, down = [], [], []
+        for i in range(7):
+            fr = [streams[s].frame(i) for s in range(B)]
+            frames.append((np.ascontiguousarray(np.stack([f[0] for f in fr])), np.ascontiguousarray(np.stack([f[1] for f in fr]))))
+            down.append([O.pyr_down(f[0]) for f in fr])
+        for run in range(8):
+            ctx.reset()
+            for i in range(7):
+                lefts, rights = frames[i]
+                dl, dr = torch.from_numpy(lefts).cuda(), torch.from_numpy(rights).cuda()
+                torch.cuda.synchronize()
+                keep = keep[-2:] + [(dl, dr)]
+                ctx.step_device(dl.data_ptr(), dr.data_ptr(), ctx.make_inputs([i * 70_000_000] * B))
+                levels, cp = ctx.debug_pyramid(0, True)
+                if not np.array_equal(cp, lefts):
+                    s_, ys, xs = np.nonzero(cp != lefts)
+                    raise AssertionError("run %d step %d: level-0 copy differs at %d bytes, stream %d row %d columns %s"
+                                         % (run, i, len(ys), s_[0], ys[0], xs[:16].tolist()))
+                for s in range(B):
+                    assert len(levels[s]) == 1 and np.array_equal(levels[s][0], down[i][s]), (run, i, s)
     finally:
         ctx.close()
