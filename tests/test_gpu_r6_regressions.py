@@ -75,7 +75,8 @@ def test_right_keypoint_refined_out_of_the_image_is_looked_up_at_the_nearest_pix
 def test_level0_copy_of_the_pyramid_launch_with_a_half_empty_stream_group():
     """finding 2: the launch itself (pyr2_kernel with the level-0 copy, 12 images = one full group of 8 streams and one
     with 4, whose waves run alone on their SIMDs), 150 times; the copy and every level against the oracle's cv::pyrDown.
-    The build with the hazard failed one launch in ~20 (tools/r6/gpu_pyr_probe.sh: 15 corrupted copies in 280 steps)."""
+    (In the front-end the build with the hazard failed one launch in ~20 -- tools/r6/gpu_pyr_probe.sh: 15 corrupted copies
+    in 280 steps; this component call did not reproduce it on that build.  Kept as the plain check of the launch.)"""
     w, h = 752, 480
     L, R = workloads.make_cameras(w, h)
     for max_level in (1, 3):     # one-level launch (COPY, no second level) and the two-level launch of the shipped pyramid
@@ -106,43 +107,21 @@ def test_level0_copy_of_the_pyramid_launch_with_a_half_empty_stream_group():
             ctx.close()
 
 
-def test_level0_copy_read_back_in_place_over_front_end_steps():
-    """finding 2 where it was found: 12 streams of 752 x 480, klt_max_level 1, device-pointer steps with
-    device_frames_persist 0; after every step the context's own level-0 copy and pyramid are read back
-    (kvfe_frontend_debug_pyramid) and compared with the frame and with the oracle's cv::pyrDown.  (The component call of
-    the test above runs the same launch but did not show the hazard on the build that had it: whether a wave issues the
-    store and the next instruction back to back depends on what else the chip is doing.)"""
-    import torch
-    w, h, B = 752, 480, 12
-    L, R = workloads.make_cameras(w, h)
-    p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
-    p.detector.max_features_per_frame = 60
-    p.tracker.klt_max_level = 1
-    p.tracker.klt_max_iter = 10
-    p.tracker.max_feature_track_age = 4
-    ctx = F.Context(L, R, p, batch=B, device_frames_persist=0)
-    try:
-        R1 = np.array(ctx.rect.R1).reshape(3, 3)
-        streams = [synth.RigStream(L, R, seed=100 + s, rect_R1=R1) for s in range(B)]
-        keep, frames, down = [], [], []
-        for i in range(7):
-            fr = [streams[s].frame(i) for s in range(B)]
-            frames.append((np.ascontiguousarray(np.stack([f[0] for f in fr])), np.ascontiguousarray(np.stack([f[1] for f in fr]))))
-            down.append([O.pyr_down(f[0]) for f in fr])
-        for run in range(8):
-            ctx.reset()
-            for i in range(7):
-                lefts, rights = frames[i]
-                dl, dr = torch.from_numpy(lefts).cuda(), torch.from_numpy(rights).cuda()
-                torch.cuda.synchronize()
-                keep = keep[-2:] + [(dl, dr)]
-                ctx.step_device(dl.data_ptr(), dr.data_ptr(), ctx.make_inputs([i * 70_000_000] * B))
-                levels, cp = ctx.debug_pyramid(0, True)
-                if not np.array_equal(cp, lefts):
-                    s_, ys, xs = np.nonzero(cp != lefts)
-                    raise AssertionError("run %d step %d: level-0 copy differs at %d bytes, stream %d row %d columns %s"
-                                         % (run, i, len(ys), s_[0], ys[0], xs[:16].tolist()))
-                for s in range(B):
-                    assert len(levels[s]) == 1 and np.array_equal(levels[s][0], down[i][s]), (run, i, s)
-    finally:
-        ctx.close()
+def test_level0_copy_read_back_in_place_in_the_configuration_that_found_it():
+    """finding 2 where it was found: tools/fuzz_batched.py seed 2, configuration 79, eight times in one process, with the
+    context's own level-0 copy and pyramid read back after every step (FUZZ_PYR_PROBE: kvfe_frontend_debug_pyramid
+    against the frame and the oracle's cv::pyrDown) besides the comparison of every output with the oracle.  The build with
+    the hazard failed 10 - 11 of 30 / 10 of 40 such repeats (tools/r6/gpu_fb79.sh, gpu_pyr_probe.sh); neither the
+    component call above nor a re-staging of the same steps with other scenes reproduced it there (tools/r6/
+    gpu_store_hazard.sh) -- what makes a wave issue the store and the next instruction back to back is not understood
+    beyond "it ran alone on its SIMD", which is why the static scan (tests/test_host_logic.py) is the check that counts."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_PYR_PROBE="1", FUZZ_REPEAT="8")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_batched.py"), "120", "2", "79"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    m = re.search(r"configs failed: (\d+) of", out)
+    assert m and int(m.group(1)) == 0 and "PYRAMID" not in out and "MISMATCH" not in out, out[-3000:]

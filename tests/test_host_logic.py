@@ -377,7 +377,7 @@ def test_no_valu_to_dpp_hazard_in_inline_asm():
 
 def test_no_valu_write_of_the_data_of_a_wide_store_in_the_next_issue_slot():
     """round 6 (tools/fuzz_batched.py 120 2 79): gfx950 reads the data registers of a VMEM store of more than 64 bits
-    after the store has issued; a VALU write of one of them in the next issue slot changes what lanes 12 - 15 of every row
+    after the store has issued; a VALU write of one of them within two wait states changes what lanes 12 - 15 of every row
     of 16 store.  hipcc pads the pair except behind a buffer store with an SGPR offset -- pyr2_kernel's level-0 copy was
     that form, and a wave that ran alone on its SIMD stored the following v_perm_b32's result.  tools/
     check_store_data_hazard.py scans the compiled gfx950 code of every kernel file for the pair."""
@@ -401,13 +401,15 @@ def test_no_valu_write_of_the_data_of_a_wide_store_in_the_next_issue_slot():
     import tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as t:
         t.write("k:\n\tbuffer_store_dwordx4 v[12:15], v45, s[8:11], s3 offen\n\tv_perm_b32 v12, v8, v8, s7\n"
-                "\tbuffer_store_dwordx4 v[8:11], v45, s[8:11], 0 offen\n\ts_nop 0\n\tv_pk_add_u16 v8, v16, v20\n"
-                "\tglobal_store_dwordx4 v[0:1], v[4:7], off\n\tv_mov_b32_e32 v5, 0\n")
+                "\tbuffer_store_dwordx4 v[8:11], v45, s[8:11], 0 offen\n\ts_nop 1\n\tv_pk_add_u16 v8, v16, v20\n"
+                "\tglobal_store_dwordx4 v[0:1], v[4:7], off\n\ts_add_i32 s3, s3, s6\n\tv_mov_b32_e32 v5, 0\n"
+                "\tbuffer_store_dwordx4 v[20:23], v45, s[8:11], 0 offen\n\ts_add_i32 s3, s3, s6\n\ts_nop 0\n\tv_mov_b32_e32 v20, 0\n")
     try:
         n, bad = mod.check_asm(t.name)
     finally:
         os.unlink(t.name)
-    assert n == 3 and len(bad) == 2 and "v_perm_b32" in bad[0][2] and "v_mov_b32" in bad[1][2], (n, bad)
+    # (two wait states: the instruction behind the store and the one behind that; an s_nop N counts N + 1)
+    assert n == 4 and len(bad) == 2 and "v_perm_b32" in bad[0][2] and "v_mov_b32_e32 v5" in bad[1][2], (n, bad)
 
 
 def test_hand_issued_row_requests_target_accumulation_registers():

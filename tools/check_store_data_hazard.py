@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA check for the "VMEM store of more than 64 bits -> VALU write of its data registers" hazard (1 wait state).
+"""ISA check for the "VMEM store of more than 64 bits -> VALU write of its data registers" hazard (2 wait states on gfx950).
 
 A store of three or four dwords reads its data VGPRs after it has issued; a VALU instruction in the very next issue slot
 that writes one of them changes what part of the wave stores.  hipcc pads the pair with an s_nop -- except for a buffer
@@ -8,9 +8,9 @@ the first dword of pyr2_kernel's 16-byte level-0 copy replaced by the following 
 every row of 16, one run in three, when a wave issues back to back (profiles/r6_analysis.md, tools/r6/gpu_pyr_probe.sh).
 
 This script compiles the .hip files of csrc/ to gfx950 assembly and reports every buffer / global / flat / scratch store
-of more than 64 bits that is followed, with no other instruction in between, by a VALU write of one of its data
-registers.  A label between the two counts as "in between" only if it is not a fall-through position -- to stay
-conservative, labels are looked through.
+of more than 64 bits that is followed within fewer than two wait states (an instruction = 1, s_nop N = N + 1; hipcc's own
+count for the forms it pads on gfx940 and later) by a VALU write of one of its data registers.  Local labels are looked
+through (conservative).
 
     python tools/check_store_data_hazard.py [file.hip ...]       (default: every k_*.hip of kimera_vio_amd/csrc)
 
@@ -59,30 +59,35 @@ def valu_written(mn, rest):
     return set(range(int(m.group(2)), int(m.group(3)) + 1))
 
 
+WAIT_STATES = 2   # gfx940 and later (hipcc's own rule for the forms it pads: "VALUWaitStates = hasGFX940Insts() ? 2 : 1")
+
+
 def check_asm(path):
-    """returns (number of wide stores, [(kernel, store, next instruction)])"""
+    """returns (number of wide stores, [(kernel, store, the instruction that writes its data)])"""
     bad, n = [], 0
     kernel = "?"
-    pending = None   # (store text, data registers) of a wide store that was the previous instruction
+    pending = []   # [store text, data registers, wait states seen since] of the wide stores still inside their window
     for ln in open(path):
         s = ln.split(";")[0].strip()
         if not s or s.startswith("."):
-            if s.endswith(":"):
-                continue          # a local label: look through it
-            continue
+            continue              # (a local label is looked through: conservative)
         if s.endswith(":"):
             kernel = s[:-1]
-            pending = None
+            pending = []
             continue
         parts = s.split(None, 1)
         mn, rest = parts[0], (parts[1] if len(parts) > 1 else "")
-        if pending:
-            if valu_written(mn, rest) & pending[1]:
-                bad.append((kernel, pending[0], s))
-            pending = None
+        w = valu_written(mn, rest)
+        for pnd in pending:
+            if w & pnd[1]:
+                bad.append((kernel, pnd[0], s))
+        states = (int(rest.strip() or 0) + 1) if mn == "s_nop" else 1
+        for pnd in pending:
+            pnd[2] += states
+        pending = [pnd for pnd in pending if pnd[2] < WAIT_STATES]
         if WIDE_STORE.match(mn):
             n += 1
-            pending = (s, store_data_regs(mn, rest))
+            pending.append([s, store_data_regs(mn, rest), 0])
     return n, bad
 
 
