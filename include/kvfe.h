@@ -400,7 +400,16 @@ KVFE_API void kvfe_dense_stereo_params_default(kvfe_dense_stereo_params* p);
  * = the context's rectification ROIs, StereoMatcher.cpp:81-86).  KVFE_ERR_UNSUPPORTED:
  * num_disparities > 64, SGBM with min_disparity < 0, BM's normalized-response prefilter or
  * disp_12_max_diff >= 0, cost ranges that
- * leave 16 bits (sad_window_size^2 * 125 + 2 * p2 > 16383). */
+ * leave 16 bits (sad_window_size^2 * 125 + 2 * p2 > 16383).
+ * Device memory (allocated at the first call, kept until the context is destroyed, sized by the largest
+ * group of pairs a call has launched -- at most 8): three cost volumes of H x width1 x D int16 per pair
+ * (42 MB per 752 x 480 pair at 64 disparities) and, for MODE_HH with four or more pairs in a launch, the
+ * hand-over buffer of the two-pass aggregation, (row bands - 1) x 2 x pairs x width1 x 528 bytes (180 MB
+ * for 8 such pairs); the latter is zeroed whenever the number of pairs in a launch changes (its entries
+ * carry a 2-bit launch tag), so a call with 12 pairs (groups of 8 and 4) pays ~50 us per group for it.
+ * The waves of that launch wait for each other with BOUNDED polls; if one runs out (a preempted or
+ * debugged process) the group is repeated on the eight independent direction sweeps -- same result,
+ * ~2.5 x the time -- and kvfe_last_error says so while the call returns KVFE_OK. */
 KVFE_API kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* ctx,
                                                       const kvfe_dense_stereo_params* params,
                                                       int32_t n_pairs,

@@ -1418,7 +1418,7 @@ size_t dense_handoff_bytes(const DenseParams& P, int pairs) {
   return std::max<size_t>(1, nbands - 1) * 2 * pairs * P.width1 * (64 * sizeof(unsigned long long) + 4 * sizeof(unsigned));
 }
 
-void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st) {
+void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st, bool two_pass_allowed) {
   const dim3 blk(256);
   dense_prefilter_kernel<<<dim3((P.W + 255) / 256, P.H, 2 * n), blk, 0, st>>>(P, B.left, B.right, B.rec);
   if (P.full_dp && P.SW2 >= 1 && P.SW2 <= 5) {
@@ -1443,7 +1443,8 @@ void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t
   unsigned short* sA = (unsigned short*)B.vol[0];
   unsigned short* sB = (unsigned short*)B.vol[1];
   const int nh = (P.H + 3) / 4, nw = (P.width1 + 3) / 4, nd = (P.width1 + P.H - 1 + 3) / 4;
-  if (P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF_G && B.hand && B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
+  if (two_pass_allowed && P.full_dp && n >= AGP_MIN_PAIRS && P.width1 > AGP_PF_G && B.hand &&
+      B.hand_bytes >= dense_handoff_bytes(P, B.cap_pairs)) {
     // computeDisparitySGBM's two passes, one launch: rows of a pass are waves that hand their path costs down
     const int nbands = (P.H + AGP_ROWS - 1) / AGP_ROWS;
     const int key[4] = {n, P.width1, P.H, P.D};
@@ -1467,7 +1468,7 @@ void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t
 #ifdef KVFE_AGP_PROF
     agp_prof_copy_kernel<<<1, 64, 0, st>>>(B.agsync, reinterpret_cast<unsigned*>(B.vol[2]));
 #endif
-  } else if (n <= 3 && P.full_dp) {
+  } else if (n <= 3 && P.full_dp && two_pass_allowed) {
     // few pairs: every direction of a pair in one launch, packed atomic adds into two zeroed volumes
     const size_t bytes = sizeof(short) * dense_volume_elems(P) * n;
     (void)hipMemsetAsync(sA, 0, bytes, st);

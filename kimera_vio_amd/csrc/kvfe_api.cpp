@@ -207,6 +207,7 @@ struct kvfe_ctx {
   hipEvent_t dense_ev[2] = {};
   double dense_ms = 0;            // kernel time of kvfe_dense_stereo_reconstruction calls (HIP events)
   long long dense_pairs = 0;
+  long long dense_fallbacks = 0;  // chunks repeated on the direction sweeps after a two-pass hand-over wait ran out
   // stream groups: a context with batch >= 2*MIN_GROUP_STREAMS splits its streams into `groups`
   // child contexts (own HIP stream, own buffers, shared constant tables).  The children free-run;
   // the only coupling is the token below that staggers their phases so that the latency-bound
@@ -3378,24 +3379,36 @@ kvfe_status kvfe_dense_stereo_reconstruction(kvfe_ctx* c, const kvfe_dense_stere
       HIPCHK(c, hipMemcpy2DAsync(b.right + px * i, P.W, right_rect[i0 + i], stride, P.W, P.H,
                                  hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipEventRecord(c->dense_ev[0], c->stream));
-    if (P.bm)
-      launch_dense_bm(P, b, n, c->stream);
-    else
-      launch_dense_sgbm(P, b, n, c->stream);
-    HIPCHK(c, hipEventRecord(c->dense_ev[1], c->stream));
-    HIPCHK(c, hipGetLastError());
+    // The two-pass launch's waves wait for each other with BOUNDED polls (a preempted or debugged process must not hang the
+    // chip); a wait that ran out sets an error word and the launch's result is garbage.  The chunk is then repeated on the
+    // eight independent sweeps, which wait for nothing -- same result, 0.69 instead of 0.27 ms per pair --
+    // and the context counts it (kvfe_last_error names it, the call succeeds).  KVFE_DENSE_FORCE_FALLBACK=1 takes that path
+    // on every chunk (tests/test_gpu_dense_twopass.py).
+    static const bool force_fallback = [] { const char* e = std::getenv("KVFE_DENSE_FORCE_FALLBACK"); return e && std::atoi(e) != 0; }();
+    for (int attempt = 0; attempt < 2; attempt++) {
+      HIPCHK(c, hipEventRecord(c->dense_ev[0], c->stream));
+      if (P.bm)
+        launch_dense_bm(P, b, n, c->stream);
+      else
+        launch_dense_sgbm(P, b, n, c->stream, attempt == 0);
+      HIPCHK(c, hipEventRecord(c->dense_ev[1], c->stream));
+      HIPCHK(c, hipGetLastError());
+      unsigned agg_err = 0;
+      if (attempt == 0 && !P.bm) {
+        HIPCHK(c, hipMemcpyAsync(&agg_err, b.agsync + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (force_fallback) agg_err = 1;
+      }
+      if (!agg_err) break;
+      c->dense_fallbacks++;
+      c->last_error = "dense stereo: a hand-over wait of the two-pass aggregation ran out; the chunk was repeated on the direction sweeps";
+      HIPCHK(c, hipMemsetAsync(b.agsync + 1, 0, sizeof(unsigned), c->stream));
+    }
     for (int i = 0; i < n; i++)
       HIPCHK(c, hipMemcpy2DAsync(disparity[i0 + i], dstride * sizeof(int16_t), b.disp[0] + px * i,
                                  P.W * sizeof(int16_t), P.W * sizeof(int16_t), P.H, hipMemcpyDeviceToHost,
                                  c->stream));
-    unsigned agg_err = 0;
-    HIPCHK(c, hipMemcpyAsync(&agg_err, b.agsync + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (agg_err) {
-      c->last_error = "dense stereo: a hand-over wait of the two-pass aggregation ran out";
-      return KVFE_ERR_HIP;
-    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->dense_ev[0], c->dense_ev[1]) == hipSuccess) {
       c->dense_ms += ms;

@@ -108,7 +108,9 @@ struct ReprojectQ {
 };
 size_t dense_volume_elems(const DenseParams& P);
 // inputs in B.left / B.right, result in B.disp[0]
-void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st);
+// two_pass_allowed = false: the eight direction sweeps whatever the number of pairs (the path a chunk is repeated on when a
+// bounded hand-over wait of the two-pass launch ran out)
+void launch_dense_sgbm(const DenseParams& P, DenseBuffers& B, int n, hipStream_t st, bool two_pass_allowed = true);
 void launch_dense_bm(const DenseParams& P, const DenseBuffers& B, int n, hipStream_t st);
 void launch_reproject_to_3d(int W, int H, const float* disp, const ReprojectQ& Q, unsigned* minkey, float* xyz,
                             hipStream_t st);

@@ -103,3 +103,40 @@ def test_other_image_sizes(w, h):
         _check(c, pairs[:4], dp, roi)
     finally:
         c.close()
+
+
+def test_a_chunk_whose_hand_over_wait_ran_out_is_repeated_on_the_direction_sweeps():
+    """the two-pass launch's waves wait for each other with bounded polls; when one runs out (preemption, a
+    debugger) the call used to fail with KVFE_ERR_HIP.  The chunk is now repeated on the eight independent sweeps.
+    KVFE_DENSE_FORCE_FALLBACK=1 treats every chunk's first attempt as timed out (a child process: the switch is read
+    once): 5 pairs in one call still equal the oracle, and equal the two-pass result of this process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import oracle_lib as O\n"
+        "from kimera_vio_amd import _abi as abi, frontend as F\n"
+        "from test_gpu_parity import euroc_cams, euroc_params\n"
+        "z = np.load(os.path.join(%r, 'tests', 'golden', 'micro_euroc_f10_18.npz'))\n"
+        "L, R = euroc_cams(); oc = O.Camera(L, R)\n"
+        "pairs = [(oc.rectify_image(0, z['lefts'][i]), oc.rectify_image(1, z['rights'][i])) for i in range(5)]\n"
+        "dp = abi.dense_stereo_params_default()\n"
+        "c = F.Context(L, R, euroc_params())\n"
+        "got = c.dense_stereo_reconstruction([p[0] for p in pairs], [p[1] for p in pairs], dp)\n"
+        "bad = sum(int(not np.array_equal(g, O.dense_stereo_reconstruction(l, r, dp))) for g, (l, r) in zip(got, pairs))\n"
+        "np.save(sys.argv[1], np.stack(got)); c.close(); print('pairs differing from the oracle:', bad)\n" % (root, root, root))
+    import tempfile
+    outs = []
+    for force in ("1", "0"):
+        with tempfile.NamedTemporaryFile(suffix=".npy", delete=False) as t:
+            pass
+        try:
+            r = subprocess.run([sys.executable, "-c", code, t.name], env=dict(os.environ, KVFE_DENSE_FORCE_FALLBACK=force),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "pairs differing from the oracle: 0" in r.stdout, (force, r.stdout[-800:], r.stderr[-1500:])
+            outs.append(np.load(t.name))
+        finally:
+            os.unlink(t.name)
+    assert np.array_equal(outs[0], outs[1])

@@ -53,6 +53,20 @@ def run(n_cfg, seed, only=-1, verbose=True):
                     lvl=t.klt_max_level, it=t.klt_max_iter, age=t.max_feature_track_age, ransac=p.use_ransac,
                     one=t.ransac_use_1point_stereo, two=t.ransac_use_2point_mono, kf_ns=p.min_intra_keyframe_time_ns,
                     ssub=p.stereo.subpixel_refinement, force_p=force_p)
+        groups = 0
+        if seed >= 100:   # extensions of the second campaign, drawn from their own generator: the configurations of the
+            r2 = np.random.RandomState(seed * 1000 + ci)   # seeds below 100 (a regression test replays one) stay what they were
+            if r2.randint(0, 4) == 0:
+                B = int(r2.choice([3, 4, 32, 40]))          # few streams in the batched call (fork_swap) / more than three groups of 8
+            if r2.randint(0, 5) == 0:
+                t.klt_max_level = 0                         # no pyramid launch: the level-0 copy is a 2-D memcpy
+            if r2.randint(0, 6) == 0:
+                p.stereo.equalize_image = 1                 # context-owned equalised slots in front of every entry point
+            if r2.randint(0, 5) == 0 and entry in (0, 1, 2) and B >= 6:
+                groups = int(r2.choice([2, 3]))             # kvfe_config.stream_groups: child contexts on their own streams
+            if r2.randint(0, 12) == 0 and B <= 8:
+                w, h = 1280, 720                            # two waves along x in the pyramid launch
+            desc.update(B=B, lvl=t.klt_max_level, eq=p.stereo.equalize_image, groups=groups, w=w, h=h)
         seeds = [int(rng.randint(0, 1000)) for _ in range(B)]
         starts = [int(rng.randint(0, 3)) for _ in range(B)]
         forces = rng.randint(0, force_p, (n_steps, B)) == 0
@@ -62,7 +76,8 @@ def run(n_cfg, seed, only=-1, verbose=True):
         R1 = np.array(F.compute_rectification(L, R).R1).reshape(3, 3)
         streams = [synth.RigStream(L, R, seed=sd, rect_R1=R1) for sd in seeds]
         try:
-            c = F.Context(L, R, p, batch=B, **({"device_frames_persist": entry - 1} if entry in (1, 2) else {}))
+            c = F.Context(L, R, p, batch=B, stream_groups=groups,
+                          **({"device_frames_persist": entry - 1} if entry in (1, 2) else {}))
         except F.KvfeError as e:
             if verbose:
                 print(ci, "create refused", e, desc, flush=True)
@@ -94,7 +109,7 @@ def run(n_cfg, seed, only=-1, verbose=True):
                     a[:] = lefts
                     b[:] = rights
                     c.step_staged(i % 3, inp)
-                if PYR_PROBE and entry == 1:   # the context's own pyramid of this frame, checked in place
+                if PYR_PROBE and entry == 1 and not groups and t.klt_max_level > 0:   # the context's own pyramid of this frame, checked in place
                     lv, cp = c.debug_pyramid(0, True)
                     for s in range(B):
                         exp_l, src = [], lefts[s]
