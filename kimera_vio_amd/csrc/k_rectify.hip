@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void rectify_box_kernel(const float2* __restri
   for (int r = 0; r < 2; r++) {
     const int y = y0 + 8 * r;
     if (x < W && y < H)
-      for (int q = 0; q < 4; q++) {
-        const float2 m = map[y * W + x + q];
+      for (int q = 0; q < 4 && x + q < W; q++) {   // (a width that is no multiple of 4: the last lane's columns end at W --
+        const float2 m = map[y * W + x + q];        // round 6, KVFE_GUARD_ALLOC=1: the last row read 16 bytes past the map)
         const RTap t = rtap(W, H, m.x, m.y);
         mnx = min(mnx, t.cx);
         mxx = max(mxx, t.cx);

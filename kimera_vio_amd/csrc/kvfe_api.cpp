@@ -280,6 +280,12 @@ int guard_mode() {
 }
 hipError_t dev_malloc(void** out, size_t bytes) {
   const int mode = guard_mode();
+  if (mode == 3) {   // plain allocations filled with a poison byte (KVFE_POISON, default 0xff): a read of memory no kernel of the
+    hipError_t e3 = hipMalloc(out, bytes);   // call has written shows up as a result that depends on it
+    if (e3 != hipSuccess) return e3;
+    static const int poison = [] { const char* e = std::getenv("KVFE_POISON"); return e ? (int)std::strtol(e, nullptr, 0) : 0xff; }();
+    return hipMemset(*out, poison, bytes);
+  }
   if (mode != 1 && mode != 2) return hipMalloc(out, bytes);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -312,6 +318,10 @@ hipError_t dev_malloc(void** out, size_t bytes) {
     return e;
   }
   void* user = mode == 1 ? static_cast<char*>(r.mapped) + (mapped - need) : r.mapped;
+  static const bool log_allocs = std::getenv("KVFE_GUARD_ALLOC_LOG") != nullptr;   // (which buffer a fault address belongs to)
+  if (log_allocs)
+    std::fprintf(stderr, "KVFE_GUARD_ALLOC: %zu bytes at %p .. %p, mapping %p .. %p\n", bytes, user,
+                 static_cast<void*>(static_cast<char*>(user) + bytes), r.mapped, static_cast<void*>(static_cast<char*>(r.mapped) + mapped));
   {
     std::lock_guard<std::mutex> lk(g_guard_mu);
     g_guard[user] = r;
@@ -337,9 +347,16 @@ void dev_free(void* p) {
     return;
   }
   (void)hipDeviceSynchronize();   // (hipFree's implicit synchronisation)
+  if (std::getenv("KVFE_GUARD_ALLOC_LOG")) std::fprintf(stderr, "KVFE_GUARD_ALLOC: free %p (mapping %p)\n", p, r.mapped);
   (void)hipMemUnmap(r.mapped, r.mapped_bytes);
   (void)hipMemRelease(r.handle);
-  (void)hipMemAddressFree(r.base, r.reserve);
+  // The address range stays reserved (KVFE_GUARD_VA_REUSE=1 frees it): a later reservation that landed on a range this
+  // process had unmapped before saw rows of a freshly written buffer hold another buffer's values (tools/r6/
+  // guard_dense_probe.py: the labels of cv::filterSpeckles after seven calls that re-allocate the dense buffers) -- a stale
+  // translation, not a kernel of the library: plain allocations filled with 0xff / 0xa5 / 0 (KVFE_GUARD_ALLOC=3) run the
+  // same sequence to the same results.  A used-once address also keeps a dangling pointer of the library faulting.
+  static const bool va_reuse = [] { const char* e = std::getenv("KVFE_GUARD_VA_REUSE"); return e && std::atoi(e) != 0; }();
+  if (va_reuse) (void)hipMemAddressFree(r.base, r.reserve);
 }
 
 template <typename T>

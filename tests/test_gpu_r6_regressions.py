@@ -18,7 +18,15 @@
    hazard except for a store with an SGPR offset; a wave that issues back to back (the second group of 8 streams had
    only 4: its waves ran alone on their SIMDs) hits it.  The store now carries its row offset in the vector offset
    (k_rectify.hip, pyr2_strip), tools/check_store_data_hazard.py scans the compiled code of every kernel file
-   (tests/test_host_logic.py), and the second test below repeats the launch that showed it."""
+   (tests/test_host_logic.py), and the second test below repeats the launch that showed it.
+
+3. tools/r6/gpu_guard.sh (the GPU suite with every device buffer of the library between unmapped guard ranges,
+   KVFE_GUARD_ALLOC = 1 / 2 -- the pool has no GPU AddressSanitizer): kvfe_create for a 130 x 16 image faulted --
+   rectify_box_kernel (context creation) read its four columns per lane without the test against the width the pack
+   kernel beside it has, 16 bytes past the rectification map in the last row when the width is no multiple of 4.  (The
+   boxes are only used for widths that are; with plain allocations the read landed in a neighbour.)  The last test runs
+   context creation at such sizes, and the dense sequence that showed the allocator's own artefact
+   (profiles/r6_analysis.md section 15), under the guard allocator in child processes."""
 import os
 
 import numpy as np
@@ -125,3 +133,21 @@ def test_level0_copy_read_back_in_place_in_the_configuration_that_found_it():
     out = r.stdout + r.stderr
     m = re.search(r"configs failed: (\d+) of", out)
     assert m and int(m.group(1)) == 0 and "PYRAMID" not in out and "MISMATCH" not in out, out[-3000:]
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_context_creation_and_a_dense_sequence_under_guard_allocations(mode):
+    """finding 3: KVFE_GUARD_ALLOC = 1 (buffers end where their mapping ends) / 2 (begin where it begins) in child processes
+    (the switch is read once per process): context creation for widths that are no multiple of 4 and tiny heights, then
+    eight dense calls with changing pair counts -- an out-of-bounds access of 16 bytes or more kills the child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KVFE_GUARD_ALLOC=mode)
+    for w, h in ((130, 16), (323, 241), (750, 480)):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "r6", "guard_create_probe.py"), str(w), str(h)], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "done" in r.stdout, (mode, w, h, r.stdout[-500:], r.stderr[-1500:])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "r6", "guard_dense_probe.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "done" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
