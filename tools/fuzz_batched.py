@@ -11,6 +11,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+# FUZZ_ODD_SIZES=1: widths / heights that are no multiples of 4 / 8 / 16 (the same number of random draws, so every other
+# parameter of a configuration stays what it is without the switch) -- for runs under KVFE_GUARD_ALLOC, where an access
+# past a row's or an image's end faults
+ODD = int(os.environ.get("FUZZ_ODD_SIZES", "0"))
+ODD_W, ODD_H = [250, 321, 377, 481, 642, 750], [193, 241, 290, 363, 479]
 import oracle_lib as O
 from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
@@ -29,8 +34,8 @@ def run(n_cfg, seed, only=-1, verbose=True):
     rng = np.random.RandomState(seed)
     bad = 0
     for ci in range(n_cfg):
-        w = int(rng.choice([256, 320, 376, 480, 752]))
-        h = int(rng.choice([192, 240, 288, 480]))
+        w = int(rng.choice(ODD_W if ODD else [256, 320, 376, 480, 752]))
+        h = int(rng.choice(ODD_H if ODD else [192, 240, 288, 480]))
         B = int(rng.choice([5, 6, 8, 9, 12, 16, 17, 24]))
         entry = int(rng.choice([0, 1, 2, 3]))        # host | device persist 0 | device persist 1 | staged
         n_steps = int(rng.choice([5, 7, 9]))

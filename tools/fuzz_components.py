@@ -7,6 +7,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+# FUZZ_ODD_SIZES=1: widths / heights that are no multiples of 4 / 8 / 16 (the same number of random draws, so every other
+# parameter of a configuration stays what it is without the switch) -- for runs under KVFE_GUARD_ALLOC, where an access
+# past a row's or an image's end faults
+ODD = int(os.environ.get("FUZZ_ODD_SIZES", "0"))
+ODD_W, ODD_H = [98, 130, 163, 250, 321, 377, 751], [81, 97, 121, 193, 241, 363]
 import oracle_lib as O
 from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
@@ -33,8 +38,8 @@ def check(name, a, b, desc):
 
 
 for ci in range(n_cfg):
-    w = int(rng.choice([96, 160, 256, 320, 377, 480, 752]))
-    h = int(rng.choice([80, 120, 192, 241, 360, 480]))
+    w = int(rng.choice(ODD_W if ODD else [96, 160, 256, 320, 377, 480, 752]))
+    h = int(rng.choice(ODD_H if ODD else [80, 120, 192, 241, 360, 480]))
     L, R = workloads.make_cameras(w, h)
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=0)
     p.tracker.klt_win_size = int(rng.choice([9, 15, 16, 21, 24, 32]))

@@ -5,6 +5,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+# FUZZ_ODD_SIZES=1: widths / heights that are no multiples of 4 / 8 / 16 (the same number of random draws, so every other
+# parameter of a configuration stays what it is without the switch) -- for runs under KVFE_GUARD_ALLOC, where an access
+# past a row's or an image's end faults
+ODD = int(os.environ.get("FUZZ_ODD_SIZES", "0"))
+ODD_W, ODD_H = [250, 321, 377, 481, 642, 750], [193, 241, 290, 363, 479]
 import oracle_lib as O
 from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
@@ -14,8 +19,8 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ORACLE_ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # config index: print the oracle's outputs, no GPU
 bad = 0
 for ci in range(n_cfg):
-    w = int(rng.choice([256, 320, 376, 480, 640, 752]))
-    h = int(rng.choice([192, 240, 288, 360, 480]))
+    w = int(rng.choice(ODD_W if ODD else [256, 320, 376, 480, 640, 752]))
+    h = int(rng.choice(ODD_H if ODD else [192, 240, 288, 360, 480]))
     L, R = workloads.make_cameras(w, h)
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=int(rng.randint(0, 2)))
     d, t, s = p.detector, p.tracker, p.stereo

@@ -5,6 +5,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+# FUZZ_ODD_SIZES=1: widths / heights that are no multiples of 4 / 8 / 16 (the same number of random draws, so every other
+# parameter of a configuration stays what it is without the switch) -- for runs under KVFE_GUARD_ALLOC, where an access
+# past a row's or an image's end faults
+ODD = int(os.environ.get("FUZZ_ODD_SIZES", "0"))
+ODD_W, ODD_H = [321, 377, 481, 750], [241, 290, 479]
 import oracle_lib as O
 from kimera_vio_amd import _abi as abi, frontend as F, params as P, synth, workloads
 
@@ -30,8 +35,8 @@ def depth_image(h, w, t, f32, seed):
 bad = 0
 for ci in range(n_cfg):
     kind = int(rng.choice([0, 1, 2]))   # stereo / mono / rgbd
-    w = int(rng.choice([320, 376, 480, 752]))
-    h = int(rng.choice([240, 288, 480]))
+    w = int(rng.choice(ODD_W if ODD else [320, 376, 480, 752]))
+    h = int(rng.choice(ODD_H if ODD else [240, 288, 480]))
     B = int(rng.choice([1, 2, 3]))
     L, R = workloads.make_cameras(w, h)
     p = P.load_frontend_params(os.path.join(G, "params_euroc", "FrontendParams.yaml"), use_ransac=int(rng.randint(0, 2)))
