@@ -248,7 +248,16 @@ typedef struct kvfe_config {
                                     the library runs on its internal side stream).  With a
                                     library-owned stream (NULL) completion is defined by
                                     kvfe_synchronize / kvfe_frontend_get_output only            */
-  int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0=default */
+  int32_t candidate_capacity;    /* per-stream GFTT candidate cap, 0 = default: max(W * H / 4, 4096).
+                                    Capacities of the detection stage (a step that exceeds one sets
+                                    KVFE_ERR_CAPACITY on that stream's output -- never a silently shorter
+                                    list): candidates above the quality level <= candidate_capacity; corners
+                                    the minimum-distance filter accepts <= 8192 when
+                                    max_nr_keypoints_before_anms is <= 0 or larger than that (cv::
+                                    goodFeaturesToTrack stops at maxCorners; the shipped 2000 never gets
+                                    there); keypoints into the tree / range / SSC non-maximum suppression
+                                    <= 4096; kvfe_create refuses max_features_per_frame +
+                                    max_nr_keypoints_before_anms + 64 > 4877 keypoints per frame          */
   int32_t frontend_type;         /* KVFE_FRONTEND_*: stereo (default), the monocular front-end
                                     (MonoVisionImuFrontend.cpp: `left` only, `right` ignored) or
                                     the RGBD front-end (RgbdVisionImuFrontend.cpp: `left` is the

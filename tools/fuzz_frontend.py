@@ -81,6 +81,11 @@ for ci in range(n_cfg):
             try:
                 got = c.get_output(0)
             except F.KvfeError as e:
+                # kvfe.h, kvfe_config.candidate_capacity: the minimum-distance filter holds 8192 accepted corners, the tree /
+                # range / SSC suppression 4096 keypoints -- reachable only with max_nr_keypoints_before_anms beyond that
+                if e.status == -5 and d.max_nr_keypoints_before_anms > 4096:
+                    print(ci, "frame", i, "refused by a documented capacity:", e)
+                    break
                 ok = False
                 print(ci, "frame", i, "DEVICE ERROR", e, "oracle:", {k: exp[k] for k in ("n_keypoints", "n_tracked", "n_detected")})
                 break
