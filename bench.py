@@ -405,6 +405,9 @@ def compact_line(result):
         v = result.get(k)
         if isinstance(v, dict) and "value" in v:
             legs[k] = v["value"]
+    d1 = (result.get("dense_stereo") or {}).get("one_pair_per_call") if isinstance(result.get("dense_stereo"), dict) else None
+    if isinstance(d1, dict) and "value" in d1:   # (the single pair upstream calls the method with)
+        legs["dense_stereo_1pair"] = d1["value"]
     ins = result.get("input_side")
     if isinstance(ins, dict) and "stereo_pairs_per_s_all_threads" in ins:   # host side: PNG decode on the usable CPUs
         legs["input_side_host_decode"] = max(ins["stereo_pairs_per_s_all_threads"],
@@ -904,6 +907,16 @@ def dense_stereo(F, WL, W, H, dev, pmc_leg):
         disp = ctx.dense_stereo_reconstruction(lefts, rights, dp)
         ms, cnt = ctx.dense_profile_read()
         vals.append(ms / cnt)
+    # what upstream calls the method with: ONE pair per call (StereoMatcher.cpp:32-121) -- the eight direction sweeps, not the
+    # two-pass launch (its critical path is W + 2H dependent steps whatever the tiling: profiles/r6_analysis.md section 13)
+    one = []
+    if W == 752:
+        ctx.dense_stereo_reconstruction(lefts[:1], rights[:1], dp)
+        ctx.dense_profile_read()
+        for _ in range(5):
+            ctx.dense_stereo_reconstruction(lefts[:1], rights[:1], dp)
+            ms1, cnt1 = ctx.dense_profile_read()
+            one.append(ms1 / cnt1)
     ctx.close()
     ms_pair = statistics.median(vals)
     D = dp.num_disparities
@@ -936,6 +949,8 @@ def dense_stereo(F, WL, W, H, dev, pmc_leg):
                         f"{n} rectified pairs per call",
             "value": round(1e3 / ms_pair, 2), "unit": "stereo-pairs/s", "ms_per_pair": round(ms_pair, 4),
             "ms_per_pair_min": round(min(vals), 4),
+            **({"one_pair_per_call": {"value": round(1e3 / statistics.median(one), 2), "unit": "stereo-pairs/s",
+                                      "ms_per_pair": round(statistics.median(one), 4)}} if one else {}),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "alg_bytes_per_pair": round(alg_min),
