@@ -377,16 +377,19 @@ __device__ __forceinline__ void dense_aggregate_path(const DenseParams& P, const
     cbuf[i] = cp[(long)min(i, last) * step];
     if (!FIRST) sbuf[i] = sp[(long)min(i, last) * step];
   }
+  // element offsets of the pixel requested PF steps ahead and of the pixel stored, advanced by `step` (round 6: two 64-bit
+  // products per step were a third of the scalar instructions of a step, and a step's instructions are what bounds the
+  // few-pairs launch -- profiles/r6_analysis.md section 17)
+  long tn = (long)min(PF, last) * step, ts = 0;
   for (int t0 = 0; t0 < len; t0 += PF) {
 #pragma unroll
     for (int i = 0; i < PF; i++) {
-      const int t = min(t0 + i, last);   // the tail repeats the last pixel (same value stored again)
-      const bool live = t0 + i <= last;
+      const bool live = t0 + i <= last;  // the tail repeats the last pixel (nothing is stored for it)
       const int c = cbuf[i];
       const int sprev = FIRST ? 0 : sbuf[i];
-      const long tn = (long)min(t0 + i + PF, last) * step;
       cbuf[i] = cp[tn];
       if (!FIRST) sbuf[i] = sp[tn];
+      if (t0 + i + PF < last) tn += step;
       const int delta = minp + P2;
       const int lm = dpp_wave_shr1(Lp, MAXC), lq = dpp_wave_shl1(Lp, MAXC);
       const int m = min(min(Lp, delta), min(lm, lq) + P1);
@@ -398,10 +401,11 @@ __device__ __forceinline__ void dense_aggregate_path(const DenseParams& P, const
           // even lanes add (L_d | L_{d+1} << 16): four sweeps share a volume, 4 * 16383 < 65536, so no carry
           const int hi = dpp_wave_shl1(act ? L : 0, 0);
           if (act && !(lane & 1))
-            atomicAdd(reinterpret_cast<unsigned*>(sp + (long)t * step), (unsigned)L | ((unsigned)hi << 16));
+            atomicAdd(reinterpret_cast<unsigned*>(sp + ts), (unsigned)L | ((unsigned)hi << 16));
         } else if (act) {
-          sp[(long)t * step] = (unsigned short)min(sprev + L, 65535);
+          sp[ts] = (unsigned short)min(sprev + L, 65535);
         }
+        ts += step;
       }
     }
   }
