@@ -47,10 +47,20 @@ __device__ __forceinline__ int dpp_wave_shl1(int v, int fill) {   // lane i <- l
 }
 // minimum over the 64 lanes, returned uniformly
 __device__ __forceinline__ int wave_min(int v) {
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+  // the minimum of every row of 16 lanes, written out (round 6): from the builtins the compiler makes v_mov_b32 +
+  // v_mov_b32_dpp + v_min_i32 and a wait per rotation -- 16 issue slots of the ~70 of a sweep step, and the few-pairs launch
+  // is bound by the instructions of its steps (profiles/r6_analysis.md section 17).  A DPP operand written by the
+  // instruction before needs two wait states (tools/check_dpp_hazard.py scans this file).
+  asm("s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"   // (the v_readlane_b32 behind the statement reads what the last instruction wrote: one wait state, which
+      : "+v"(v));   //  the compiler pads between its own instructions and cannot see here)
   const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
   const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
   return min(min(a, b), min(c, d));
