@@ -1329,6 +1329,20 @@ __device__ __forceinline__ int cc_find(const int* L, int i) {
   while ((p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != i) i = p;
   return i;
 }
+// find with path halving, for the launches BEHIND the merge (no union runs beside them): an entry is only ever replaced by
+// an ancestor of its own tree, so every concurrent reader still reaches the same root, and the trees -- as deep as a
+// component is tall, one link per image row -- flatten while the launch walks them (round 6: the count and apply launches
+// of a single 752 x 480 pair took 43 + 23 us of dependent loads)
+__device__ __forceinline__ int cc_find_halving(int* L, int i) {
+  for (;;) {
+    const int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == i) return i;
+    const int g = __hip_atomic_load(&L[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g == p) return p;
+    __hip_atomic_store(&L[i], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    i = g;
+  }
+}
 __device__ void cc_union(int* L, int a, int b) {
   for (;;) {
     a = cc_find(L, a);
@@ -1364,7 +1378,7 @@ __global__ __launch_bounds__(256) void speckle_merge_kernel(int W, int H, int ne
   cc_union(L, i, i + W);
 }
 // Step 3: component sizes, one atomic per horizontal run
-__global__ __launch_bounds__(256) void speckle_count_kernel(int W, int H, const int* __restrict__ label,
+__global__ __launch_bounds__(256) void speckle_count_kernel(int W, int H, int* __restrict__ label,
                                                             const int* __restrict__ runlen, int* __restrict__ count) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
@@ -1372,17 +1386,17 @@ __global__ __launch_bounds__(256) void speckle_count_kernel(int W, int H, const 
   const int i = y * W + x;
   const int n = runlen[img + i];
   if (n == 0) return;
-  atomicAdd(&count[img + cc_find(label + img, i)], n);
+  atomicAdd(&count[img + cc_find_halving(label + img, i)], n);
 }
 __global__ __launch_bounds__(256) void speckle_apply_kernel(int W, int H, int newVal, int maxSize,
-                                                            const int* __restrict__ label, const int* __restrict__ count,
+                                                            int* __restrict__ label, const int* __restrict__ count,
                                                             short* __restrict__ disp) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
   const size_t img = (size_t)blockIdx.z * W * H;
   const size_t i = img + (size_t)y * W + x;
   const int r = label[i];
-  if (r >= 0 && count[img + cc_find(label + img, r)] <= maxSize) disp[i] = (short)newVal;
+  if (r >= 0 && count[img + cc_find_halving(label + img, r)] <= maxSize) disp[i] = (short)newVal;
 }
 
 // cv::reprojectImageTo3D(CV_32F -> CV_32FC3, handleMissingValues = true)
