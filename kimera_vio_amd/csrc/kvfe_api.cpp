@@ -284,7 +284,8 @@ hipError_t dev_malloc(void** out, size_t bytes) {
     hipError_t e3 = hipMalloc(out, bytes);   // call has written shows up as a result that depends on it
     if (e3 != hipSuccess) return e3;
     static const int poison = [] { const char* e = std::getenv("KVFE_POISON"); return e ? (int)std::strtol(e, nullptr, 0) : 0xff; }();
-    return hipMemset(*out, poison, bytes);
+    if ((e3 = hipMemset(*out, poison, bytes)) != hipSuccess) return e3;
+    return hipDeviceSynchronize();   // (the fill runs on the null stream; the library's streams are non-blocking and do not wait for it)
   }
   if (mode != 1 && mode != 2) return hipMalloc(out, bytes);
   int dev = 0;
@@ -3352,7 +3353,9 @@ static kvfe_status dense_ensure(kvfe_ctx* c, const DenseParams& P, int pairs) {
   TRY(al((void**)&c->dense_xyz, sizeof(float) * 3 * px));
   TRY(al((void**)&c->dense_minkey, 16));
   TRY(al((void**)&b.agsync, AGP_SYNC_WORDS * sizeof(unsigned)));
-  HIPCHK(c, hipMemset(b.agsync, 0, AGP_SYNC_WORDS * sizeof(unsigned)));   // (the error word is read after every call)
+  // (the error word is read after every call.  On the context's stream: the streams of the library are non-blocking, a fill
+  // on the null stream is not ordered in front of their work -- found with poisoned allocations, KVFE_GUARD_ALLOC=3)
+  HIPCHK(c, hipMemsetAsync(b.agsync, 0, AGP_SYNC_WORDS * sizeof(unsigned), c->stream));
   if (hand_need) {
     TRY(al((void**)&b.hand, hand_need));
     b.hand_bytes = hand_need;
