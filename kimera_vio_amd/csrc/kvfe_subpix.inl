@@ -182,31 +182,49 @@ static __device__ __forceinline__ void rect_subpix_from_stage(const unsigned cha
 // of the previous batch); the 23 row heads (j = 0) are written by the first lanes on their own: two stage bytes and ~17
 // instructions per entry instead of four bytes and ~30.  Same operations on the same operands in the same order as
 // rect_subpix_from_stage => the same bits.
+// Round 6: a patch shared by TWO waves (the one-corner kernel, NW = 2): wave w takes the entries e_base + lane + 64 t with
+// e_base = 320 w (eij is built for that mapping), the second wave starts from the t of entry e_base - 1 -- which every lane
+// computes for itself (two uniform byte reads) -- and `heads` says which wave writes the 23 row heads.
 template <int MAXP>
 static __device__ __forceinline__ void rect_subpix_from_stage_w64(const unsigned char* stage, int rs, int dx0, int dy0,
                                                                   float ccx, float ccy, int ipx, int ipy, int n,
-                                                                  const int (&eij)[MAXP], float* dst, int lane) {
+                                                                  const int (&eij)[MAXP], float* dst, int lane,
+                                                                  int e_base = 0, bool heads = true) {
   float a = ccx - ipx;
   const float b = ccy - ipy;
   a = fmaxf(a, 0.0001f);
   const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
   const double sc = (1. - a) / a;
   const unsigned char* S = stage + dy0 * rs + dx0;
-  if (lane < n) {   // entry (lane, 0)
+  if (heads && lane < n) {   // entry (lane, 0)
     const unsigned char* R = S + lane * rs;
     const float r0 = (float)R[0], r1 = (float)R[rs];
     const float first = (1 - a) * (b1 * r0 + b2 * r1);
     const float t0 = a12 * R[1] + a22 * R[1 + rs];
     dst[lane * n] = first + t0;
   }
-  float tt_last = 0.f;   // t of the previous batch
+  float tt_last = 0.f;   // t of the previous batch (its lane 63 feeds lane 0)
+  if (e_base > 0) {
+    const int ip = (e_base - 1) / n, jp = (e_base - 1) - ip * n;
+    const unsigned char* R = S + min(ip, n - 1) * rs;
+    tt_last = a12 * R[jp + 1] + a22 * R[jp + 1 + rs];
+  }
+  // every byte of the thread first, then the arithmetic (round 6): `dst` and the stage are both LDS and may alias as far as
+  // the compiler knows, so a batch's reads stayed behind the store of the batch before -- a read latency per batch
+  unsigned char ra[MAXP], rb[MAXP];
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
-    const int e = lane + 64 * t;
     // (entries past the patch -- the last batch's upper lanes -- compute on the last row's bytes and store nothing)
     const int i = min(eij[t] >> 8, n - 1), j = eij[t] & 255;
     const unsigned char* R = S + i * rs;
-    const float tt = a12 * R[j + 1] + a22 * R[j + 1 + rs];
+    ra[t] = R[j + 1];
+    rb[t] = R[j + 1 + rs];
+  }
+#pragma unroll
+  for (int t = 0; t < MAXP; t++) {
+    const int e = e_base + lane + 64 * t;
+    const int j = eij[t] & 255;
+    const float tt = a12 * ra[t] + a22 * rb[t];
     float tp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tt), 0x138, 0xf, 0xf, true));   // wave_shr:1
     const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt_last), 63));
     tp = lane == 0 ? t63 : tp;
@@ -414,10 +432,17 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
       pij[t] = (i << 8) | j;
     }
   }
-  int eij[MAXP];            // patch entries e = lane + 64 t of the (2w+3)^2 window
+  // patch entries of this thread in the (2w+3)^2 window: e = pe0 + PES t.  One or four waves: thread index + NTHR t.  Two
+  // waves (round 6): wave w owns the CONTIGUOUS entries 320 w + lane + 64 t, so that an entry's left neighbour is the lane
+  // before it and the interior branch can take the neighbour's product through a DPP shift (rect_subpix_from_stage_w64:
+  // two stage bytes and ~17 instructions per entry instead of four and ~30)
+  constexpr bool SPLIT2 = NW == 2;
+  constexpr int PES = SPLIT2 ? 64 : NTHR;
+  const int pe0 = SPLIT2 ? (lane & 63) + 320 * (lane >> 6) : lane;
+  int eij[MAXP];
 #pragma unroll
   for (int t = 0; t < MAXP; t++) {
-    const int e = lane + NTHR * t;
+    const int e = pe0 + PES * t;
     const int i = e / pw;
     eij[t] = (i << 8) | (e - i * pw);
   }
@@ -461,24 +486,40 @@ static __device__ float2 corner_subpix_wave_t(const unsigned char* __restrict__ 
         }
         use_stage = staged && fx0 >= sx0 && fy0 >= sy0 && fx1 < sx0 + rs && fy1 < sy0 + rs;
       }
-      if (use_stage && interior)
-        rect_subpix_from_stage<MAXP, NTHR>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
-      else if (use_stage)
-        rect_subpix_border_from_stage<MAXP, NTHR>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
+      if (use_stage && interior) {
+        if constexpr (SPLIT2)
+          rect_subpix_from_stage_w64<MAXP>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane & 63,
+                                           320 * (lane >> 6), (lane >> 6) == 1);
+        else
+          rect_subpix_from_stage<MAXP, NTHR>(stage, rs, ipx - sx0, ipy - sy0, ccx, ccy, ipx, ipy, pw, eij, patch, lane);
+      } else if (use_stage) {   // (the functions index entries as `lane + NTHR t`: here pe0 + PES t)
+        rect_subpix_border_from_stage<MAXP, PES>(stage, rs, sx0, sy0, W, H, ccx, ccy, ipx, ipy, pw, eij, patch, pe0);
+      }
       else
         rect_subpix_8u32f(img, step, W, H, cI.x, cI.y, pw, patch, lane, NTHR);
     }
     __syncthreads();
     KVFE_SP_T(0);
+    // (the patch values of all slots first: `terms` and `patch` are both LDS, and as far as the compiler knows a slot's reads
+    // must stay behind the stores of the slot before -- round 6)
+    float pxr[MAXT], pxl[MAXT], pyd[MAXT], pyu[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+      const int i = pij[t] >> 8, j = pij[t] & 255;   // (slots past the window hold (0, 0): a valid address, unused)
+      const float* sp = patch + (i + 1) * pw + (j + 1);
+      pxr[t] = sp[1];
+      pxl[t] = sp[-1];
+      pyd[t] = sp[pw];
+      pyu[t] = sp[-pw];
+    }
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
       const int k = lane + NTHR * t;
       if (k < nt) {
         const int i = pij[t] >> 8, j = pij[t] & 255;
-        const float* sp = patch + (i + 1) * pw + (j + 1);
         const double m = (double)mk[t];
-        const double tgx = (double)(sp[1] - sp[-1]);
-        const double tgy = (double)(sp[pw] - sp[-pw]);
+        const double tgx = (double)(pxr[t] - pxl[t]);
+        const double tgy = (double)(pyd[t] - pyu[t]);
         const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
         const double px = (double)(j - win), py = (double)(i - win);
         terms[k] = gxx;
